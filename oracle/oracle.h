@@ -1,0 +1,153 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see gl64.h).  CPU restatement, in plain C, of the
+ * reference's GKR/sumcheck hot path.  PARITY STATUS:
+ *   - tower-witness functions are pinned against the reference's literal known-answer
+ *     tests (ceno_zkvm/src/scheme/utils.rs:934-1194) — tests/golden/tower_witness.json;
+ *   - eq / MLE-evaluate / selector / succinct evaluators are pinned against the
+ *     reference's identity tests (gkr_iop/src/utils.rs:332-441, selector.rs:396-435);
+ *   - sumcheck round messages, final evaluations and tower proofs are pinned by the
+ *     restated verifiers (scheme/verifier.rs:1282-1353,1372-1709) — values are unique
+ *     field elements given identical inputs and challenges;
+ *   - PARITY UNPINNED: Fiat–Shamir bytes (Poseidon2-Goldilocks constants, label
+ *     encoding), Basefold commitment root, W of the extension (gl64.h) — SURVEY.md §8c.
+ *
+ * Field elements cross this API as canonical little-endian uint64 words; an extension
+ * element is two consecutive words [c0, c1].
+ */
+#ifndef CENO_ORACLE_H
+#define CENO_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- transcript abstraction (reference: EXT `transcript::Transcript`, call sites
+ * ceno_zkvm/src/scheme/cpu/mod.rs:375-381,534; script restated in
+ * ceno_recursion_v2/src/tower/mod.rs:1541-1646) ---- */
+typedef struct orc_transcript {
+    void (*append_label)(void* self, const uint8_t* bytes, size_t n);
+    void (*append_ext)(void* self, const uint64_t* e2);
+    void (*sample_ext)(void* self, uint64_t* out2);
+    void* self;
+} orc_transcript;
+
+/* deterministic, data-dependent stand-in for BasicTranscript (NOT Poseidon2) */
+typedef struct orc_stub_state { uint64_t s; } orc_stub_state;
+void orc_stub_init(orc_stub_state* st, uint64_t seed);
+void orc_stub_bind(orc_transcript* t, orc_stub_state* st);
+void orc_stub_append_label(orc_stub_state* st, const uint8_t* bytes, size_t n);
+void orc_stub_append_ext(orc_stub_state* st, const uint64_t* e2);
+void orc_stub_sample_ext(orc_stub_state* st, uint64_t* out2);
+
+/* ---- field helpers exported for Python cross-checks ---- */
+uint64_t orc_gl_mul(uint64_t a, uint64_t b);
+uint64_t orc_gl_inv(uint64_t a);
+void orc_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* out);
+void orc_e2_inv(const uint64_t* a, uint64_t* out);
+void orc_fill_splitmix(uint64_t* out, size_t n_words, uint64_t seed, uint64_t word_offset);
+
+/* ---- MLE primitives (a3, EXT multilinear_extensions; LSB-first: gkr_iop/src/utils.rs:215-232) ---- */
+void orc_build_eq_x_r_vec(const uint64_t* point, int n, uint64_t* out /* 2*2^n words */);
+void orc_eq_eval(const uint64_t* a, const uint64_t* b, int n, uint64_t* out2);
+void orc_mle_evaluate(const uint64_t* evals, int is_ext, int num_vars, const uint64_t* point, uint64_t* out2);
+/* out[j] = f[2j] + r (f[2j+1] - f[2j]); out has 2^(num_vars-1) ext elements */
+void orc_mle_fix_variable(const uint64_t* evals, int is_ext, int num_vars, const uint64_t* r2, uint64_t* out);
+void orc_extrapolate_uni_poly(const uint64_t* p0, const uint64_t* evals_1_to_d, int d, const uint64_t* x, uint64_t* out2);
+
+/* ---- succinct evaluators (gkr_iop/src/utils.rs:166-307) ---- */
+void orc_eq_eval_less_or_equal_than(uint64_t max_idx, const uint64_t* a, int na, const uint64_t* b, int nb, uint64_t* out2);
+void orc_eval_wellform_address_vec(uint64_t offset, uint64_t scaled, const uint64_t* r, int n, int descending, uint64_t* out2);
+void orc_eval_stacked_wellform_address_vec(const uint64_t* r, int n, uint64_t* out2);
+void orc_eval_stacked_constant_vec(const uint64_t* r, int n, uint64_t* out2);
+
+/* ---- selectors (a4, gkr_iop/src/selector.rs:131-363) ---- */
+enum { ORC_SEL_WHOLE = 0, ORC_SEL_PREFIX = 1, ORC_SEL_ORDERED_SPARSE = 2, ORC_SEL_QUARK_LT = 3 };
+int orc_selector_compute(int kind, const uint64_t* out_point, int num_vars, size_t offset, size_t num_instances,
+                         const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, uint64_t* out);
+int orc_selector_evaluate(int kind, const uint64_t* out_point, const uint64_t* in_point, int num_vars, size_t offset,
+                          size_t num_instances, const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars,
+                          uint64_t* out2);
+
+/* ---- generic sumcheck (a1; message format SURVEY.md §3.4) ---- */
+typedef struct orc_mle {
+    const uint64_t* data; /* 2^num_vars base words or 2*2^num_vars ext words */
+    int is_ext;
+    int num_vars;
+} orc_mle;
+
+/* Run the n-round prover for  sum_x sum_t c_t prod_{j in S_t} f_j(x).
+ * Challenges come from `tr` exactly as IOPProverState::prove drives a transcript
+ * (append n, d as le-bytes labels; per round append d evals, label "Internal round",
+ * sample) — ceno_recursion_v2/src/main/mod.rs:3503-3529.
+ * out_msgs: n*d ext; out_challenges: n ext; out_final_evals: num_mles ext (pure
+ * evaluations f_j(r_0..r_{nv_j-1}), no front-load tail factor). Returns 0 on success. */
+int orc_sumcheck_prove(const orc_mle* mles, int num_mles, const uint64_t* term_coeffs, const uint32_t* term_offsets,
+                       const uint32_t* term_mle_idx, int num_terms, int max_num_vars, int max_degree,
+                       orc_transcript* tr, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals);
+
+/* IOPVerifierState::verify semantics (scheme/verifier.rs:1286-1295; main/mod.rs:3508-3529):
+ * returns the expected evaluation and the point; transcript driven identically. */
+int orc_sumcheck_verify(const uint64_t* claimed_sum, const uint64_t* msgs, int num_vars, int degree, orc_transcript* tr,
+                        uint64_t* out_point, uint64_t* out_expected2);
+
+/* expected evaluation of the batched polynomial at the end (front-load rule,
+ * scheme/verifier.rs:180-238 restated in ceno_recursion_v2/src/main/mod.rs:3414-3447) */
+void orc_sumcheck_expected_from_evals(const int* mle_num_vars, int num_mles, const uint64_t* term_coeffs,
+                                      const uint32_t* term_offsets, const uint32_t* term_mle_idx, int num_terms,
+                                      int max_num_vars, const uint64_t* point, const uint64_t* final_evals,
+                                      uint64_t* out2);
+
+/* recover_sumcheck_claim_from_final (scheme/cpu/mod.rs:1393-1413) */
+void orc_recover_claim_from_final(const uint64_t* final_claim, const uint64_t* msgs, const uint64_t* challenges, int n,
+                                  int d, uint64_t* out2);
+
+/* multi-threaded (OpenMP) fused fold+accumulate for a single product of `k` ext MLEs
+ * with externally supplied per-round challenges: the cpu_baseline leg of bench.py.
+ * tables are consumed (folded in place). */
+int orc_sumcheck_dense_mt(uint64_t** tables, int k, int num_vars, const uint64_t* challenges, int threads,
+                          uint64_t* out_msgs, uint64_t* out_final_evals);
+
+/* ---- element-wise witness inference (a5, EXT wit_infer_by_monomial_expr;
+ * gkr_iop/src/cpu/mod.rs:119-176) ---- */
+int orc_wit_infer(const orc_mle* mles, int num_mles, const uint64_t* term_coeffs, const uint32_t* term_offsets,
+                  const uint32_t* term_mle_idx, int num_terms, int num_vars, uint64_t* out /* 2*2^num_vars */);
+
+/* ---- tower witness (a6-a8, ceno_zkvm/src/scheme/utils.rs:402-659) ---- */
+size_t orc_interleave_out_len(int num_mles, size_t num_instances, int num_limbs);
+int orc_interleaving_mles_to_mles(const orc_mle* mles, int num_mles, size_t num_instances, int num_limbs,
+                                  const uint64_t* default2, uint64_t** out_limbs /* num_limbs buffers */);
+/* layers: for layer l in 0..num_vars-1 two buffers of 2^l ext each; layers[2*l+s] */
+int orc_infer_tower_product_witness(int num_vars, const uint64_t* last0, const uint64_t* last1, uint64_t** layers);
+/* layers[4*l + {p1,p2,q1,q2}], l in 0..num_vars (num_vars+1 layers); p may be NULL */
+int orc_infer_tower_logup_witness(int num_vars, const uint64_t* p0, const uint64_t* p1, const uint64_t* q0,
+                                  const uint64_t* q1, uint64_t** layers);
+
+/* ---- tower prover/verifier (a10; scheme/cpu/mod.rs:346-554, scheme/verifier.rs:1372-1709) ---- */
+typedef struct orc_tower_spec {
+    int num_vars;            /* number of witness layers (layer l has limbs of 2^l ext) */
+    uint64_t** layers;       /* prod: 2 per layer; logup: 4 per layer */
+} orc_tower_spec;
+
+typedef struct orc_tower_proof {
+    int num_rounds;          /* max_num_vars - 1 */
+    uint64_t* msgs;          /* per round r (1-based layer r): r*3 ext, concatenated */
+    uint64_t* prod_evals;    /* [spec][round][2] ext; zero when inactive */
+    uint64_t* logup_evals;   /* [spec][round][4] ext */
+    uint64_t* point;         /* final rt: max_num_vars ext */
+} orc_tower_proof;
+
+size_t orc_tower_msgs_words(int max_num_vars);
+int orc_tower_prove(const orc_tower_spec* prod, int n_prod, const orc_tower_spec* logup, int n_logup,
+                    orc_transcript* tr, orc_tower_proof* out);
+/* returns 0 if the proof verifies; out_point (max_nv ext), and the final claims */
+int orc_tower_verify(const uint64_t* prod_out_evals /* n_prod*2 ext */, const uint64_t* logup_out_evals /* n_logup*4 */,
+                     const int* num_variables, int n_prod, int n_logup, const orc_tower_proof* proof,
+                     orc_transcript* tr, uint64_t* out_point, uint64_t* out_prod_claims /* n_prod ext */,
+                     uint64_t* out_logup_p_claims, uint64_t* out_logup_q_claims);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

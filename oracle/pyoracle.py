@@ -1,0 +1,450 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/libceno_oracle.so (the plain-C CPU restatement) plus a tiny
+pure-Python big-int model of Goldilocks / GoldilocksExt2 used to cross-check the C code on
+small cases.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; nothing in ceno_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+W = 7
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libceno_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "oracle.h", "gl64.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libceno_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+# ---------------------------------------------------------------------------------------------
+# pure-python field model (independent of the C code)
+# ---------------------------------------------------------------------------------------------
+def e2_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def e2_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def e2_mul(a, b):
+    return ((a[0] * b[0] + W * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def e2_inv(a):
+    n = (a[0] * a[0] - W * a[1] * a[1]) % P
+    ni = pow(n, P - 2, P)
+    return (a[0] * ni % P, (-a[1]) * ni % P)
+
+
+def splitmix64_at(seed: int, i: int) -> int:
+    M = (1 << 64) - 1
+    z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    return z ^ (z >> 31)
+
+
+def splitmix_gl(seed: int, i: int) -> int:
+    z = splitmix64_at(seed, i)
+    return z - P if z >= P else z
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes plumbing
+# ---------------------------------------------------------------------------------------------
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+class OrcMle(C.Structure):
+    _fields_ = [("data", u64p), ("is_ext", C.c_int), ("num_vars", C.c_int)]
+
+
+class OrcStubState(C.Structure):
+    _fields_ = [("s", C.c_uint64)]
+
+
+class OrcTranscript(C.Structure):
+    _fields_ = [
+        ("append_label", C.c_void_p),
+        ("append_ext", C.c_void_p),
+        ("sample_ext", C.c_void_p),
+        ("self", C.c_void_p),
+    ]
+
+
+class OrcTowerSpec(C.Structure):
+    _fields_ = [("num_vars", C.c_int), ("layers", C.POINTER(u64p))]
+
+
+class OrcTowerProof(C.Structure):
+    _fields_ = [
+        ("num_rounds", C.c_int),
+        ("msgs", u64p),
+        ("prod_evals", u64p),
+        ("logup_evals", u64p),
+        ("point", u64p),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_gl_mul.restype = C.c_uint64
+        _lib.orc_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.orc_gl_inv.restype = C.c_uint64
+        _lib.orc_gl_inv.argtypes = [C.c_uint64]
+        _lib.orc_interleave_out_len.restype = C.c_size_t
+        _lib.orc_interleave_out_len.argtypes = [C.c_int, C.c_size_t, C.c_int]
+        _lib.orc_tower_msgs_words.restype = C.c_size_t
+        _lib.orc_tower_msgs_words.argtypes = [C.c_int]
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def ext(vals) -> np.ndarray:
+    """list of (c0,c1) / ints -> uint64 array of shape (n,2)"""
+    out = np.zeros((len(vals), 2), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        if isinstance(v, (tuple, list, np.ndarray)):
+            out[i, 0], out[i, 1] = int(v[0]) % P, int(v[1]) % P
+        else:
+            out[i, 0] = int(v) % P
+    return out
+
+
+def fill_splitmix(n_words: int, seed: int, word_offset: int = 0) -> np.ndarray:
+    out = np.empty(n_words, dtype=np.uint64)
+    lib().orc_fill_splitmix(_p(out), C.c_size_t(n_words), C.c_uint64(seed), C.c_uint64(word_offset))
+    return out
+
+
+def rand_ext(n: int, seed: int) -> np.ndarray:
+    return fill_splitmix(2 * n, seed).reshape(n, 2)
+
+
+def rand_base(n: int, seed: int) -> np.ndarray:
+    return fill_splitmix(n, seed)
+
+
+class StubTranscript:
+    def __init__(self, seed: int = 0xF5):
+        self.state = OrcStubState()
+        lib().orc_stub_init(C.byref(self.state), C.c_uint64(seed))
+        self.tr = OrcTranscript()
+        lib().orc_stub_bind(C.byref(self.tr), C.byref(self.state))
+
+    def ptr(self):
+        return C.byref(self.tr)
+
+    def append_label(self, b: bytes):
+        buf = (C.c_uint8 * len(b)).from_buffer_copy(b) if b else (C.c_uint8 * 1)()
+        lib().orc_stub_append_label(C.byref(self.state), buf, C.c_size_t(len(b)))
+
+    def append_ext(self, e):
+        a = ext([e]).reshape(2)
+        lib().orc_stub_append_ext(C.byref(self.state), _p(a))
+
+    def sample_ext(self) -> Tuple[int, int]:
+        o = np.zeros(2, dtype=np.uint64)
+        lib().orc_stub_sample_ext(C.byref(self.state), _p(o))
+        return int(o[0]), int(o[1])
+
+
+def build_eq(point: np.ndarray) -> np.ndarray:
+    n = point.shape[0]
+    out = np.zeros((1 << n, 2), dtype=np.uint64)
+    lib().orc_build_eq_x_r_vec(_p(np.ascontiguousarray(point)), n, _p(out))
+    return out
+
+
+def eq_eval(a: np.ndarray, b: np.ndarray) -> Tuple[int, int]:
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_eq_eval(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), a.shape[0], _p(o))
+    return int(o[0]), int(o[1])
+
+
+def mle_evaluate(evals: np.ndarray, point: np.ndarray) -> Tuple[int, int]:
+    is_ext = int(evals.ndim == 2)
+    nv = int(evals.shape[0]).bit_length() - 1
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_mle_evaluate(_p(np.ascontiguousarray(evals)), is_ext, nv, _p(np.ascontiguousarray(point)), _p(o))
+    return int(o[0]), int(o[1])
+
+
+def mle_fix_variable(evals: np.ndarray, r) -> np.ndarray:
+    is_ext = int(evals.ndim == 2)
+    nv = int(evals.shape[0]).bit_length() - 1
+    out = np.zeros((1 << (nv - 1), 2), dtype=np.uint64)
+    lib().orc_mle_fix_variable(_p(np.ascontiguousarray(evals)), is_ext, nv, _p(ext([r]).reshape(2)), _p(out))
+    return out
+
+
+def extrapolate_uni_poly(p0, evals: np.ndarray, x) -> Tuple[int, int]:
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_extrapolate_uni_poly(_p(ext([p0]).reshape(2)), _p(np.ascontiguousarray(evals)), evals.shape[0],
+                                   _p(ext([x]).reshape(2)), _p(o))
+    return int(o[0]), int(o[1])
+
+
+def _mk_mles(mles: Sequence[np.ndarray]):
+    arr = (OrcMle * len(mles))()
+    keep = []
+    for i, m in enumerate(mles):
+        m = np.ascontiguousarray(m)
+        keep.append(m)
+        arr[i].data = _p(m)
+        arr[i].is_ext = int(m.ndim == 2)
+        arr[i].num_vars = int(m.shape[0]).bit_length() - 1
+    return arr, keep
+
+
+def _csr(terms: Sequence[Sequence[int]]):
+    off = np.zeros(len(terms) + 1, dtype=np.uint32)
+    idx: List[int] = []
+    for t, s in enumerate(terms):
+        idx.extend(s)
+        off[t + 1] = len(idx)
+    return off, np.array(idx if idx else [0], dtype=np.uint32)
+
+
+def sumcheck_prove(mles: Sequence[np.ndarray], coeffs: np.ndarray, terms: Sequence[Sequence[int]], max_nv: int,
+                   max_degree: int, tr: StubTranscript):
+    arr, keep = _mk_mles(mles)
+    off, idx = _csr(terms)
+    msgs = np.zeros((max_nv, max_degree, 2), dtype=np.uint64)
+    chal = np.zeros((max_nv, 2), dtype=np.uint64)
+    fin = np.zeros((len(mles), 2), dtype=np.uint64)
+    rc = lib().orc_sumcheck_prove(arr, len(mles), _p(np.ascontiguousarray(coeffs)), _p32(off), _p32(idx), len(terms),
+                                  max_nv, max_degree, tr.ptr(), _p(msgs), _p(chal), _p(fin))
+    if rc != 0:
+        raise ValueError(f"orc_sumcheck_prove rc={rc}")
+    return msgs, chal, fin
+
+
+def sumcheck_verify(claimed_sum, msgs: np.ndarray, tr: StubTranscript):
+    n, d = msgs.shape[0], msgs.shape[1]
+    point = np.zeros((n, 2), dtype=np.uint64)
+    exp = np.zeros(2, dtype=np.uint64)
+    lib().orc_sumcheck_verify(_p(ext([claimed_sum]).reshape(2)), _p(np.ascontiguousarray(msgs)), n, d, tr.ptr(),
+                              _p(point), _p(exp))
+    return point, (int(exp[0]), int(exp[1]))
+
+
+def sumcheck_expected_from_evals(mle_num_vars: Sequence[int], coeffs, terms, max_nv, point, final_evals):
+    off, idx = _csr(terms)
+    nv = (C.c_int * len(mle_num_vars))(*mle_num_vars)
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_sumcheck_expected_from_evals(nv, len(mle_num_vars), _p(np.ascontiguousarray(coeffs)), _p32(off),
+                                           _p32(idx), len(terms), max_nv, _p(np.ascontiguousarray(point)),
+                                           _p(np.ascontiguousarray(final_evals)), _p(o))
+    return int(o[0]), int(o[1])
+
+
+def recover_claim_from_final(final_claim, msgs, challenges):
+    n, d = msgs.shape[0], msgs.shape[1]
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_recover_claim_from_final(_p(ext([final_claim]).reshape(2)), _p(np.ascontiguousarray(msgs)),
+                                       _p(np.ascontiguousarray(challenges)), n, d, _p(o))
+    return int(o[0]), int(o[1])
+
+
+def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, threads: int = 0):
+    """tables: k ext arrays (2^n,2). Inputs are not modified."""
+    k = len(tables)
+    n = int(tables[0].shape[0]).bit_length() - 1
+    bufs = [np.ascontiguousarray(t) for t in tables]
+    ping = [np.empty((max(1, 1 << (n - 1)), 2), dtype=np.uint64) for _ in range(k)]
+    pong = [np.empty((max(1, 1 << max(n - 2, 0)), 2), dtype=np.uint64) for _ in range(k)]
+    ptrs = (u64p * (3 * k))(*[_p(b) for b in bufs + ping + pong])
+    msgs = np.zeros((n, k, 2), dtype=np.uint64)
+    fin = np.zeros((k, 2), dtype=np.uint64)
+    rc = lib().orc_sumcheck_dense_mt(ptrs, k, n, _p(np.ascontiguousarray(challenges)), threads, _p(msgs), _p(fin))
+    if rc != 0:
+        raise ValueError(f"orc_sumcheck_dense_mt rc={rc}")
+    return msgs, fin
+
+
+def wit_infer(mles: Sequence[np.ndarray], coeffs: np.ndarray, terms, num_vars: int) -> np.ndarray:
+    arr, keep = _mk_mles(mles)
+    off, idx = _csr(terms)
+    out = np.zeros((1 << num_vars, 2), dtype=np.uint64)
+    rc = lib().orc_wit_infer(arr, len(mles), _p(np.ascontiguousarray(coeffs)), _p32(off), _p32(idx), len(terms),
+                             num_vars, _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_wit_infer rc={rc}")
+    return out
+
+
+SEL_WHOLE, SEL_PREFIX, SEL_ORDERED_SPARSE, SEL_QUARK_LT = 0, 1, 2, 3
+
+
+def selector_compute(kind, out_point, offset=0, num_instances=0, sparse_indices=(), sparse_num_vars=0):
+    n = out_point.shape[0]
+    out = np.zeros((1 << n, 2), dtype=np.uint64)
+    si = np.array(list(sparse_indices) or [0], dtype=np.uint32)
+    rc = lib().orc_selector_compute(kind, _p(np.ascontiguousarray(out_point)), n, C.c_size_t(offset),
+                                    C.c_size_t(num_instances), _p32(si), len(sparse_indices), sparse_num_vars, _p(out))
+    if rc != 0:
+        raise ValueError(f"orc_selector_compute rc={rc}")
+    return out
+
+
+def selector_evaluate(kind, out_point, in_point, offset=0, num_instances=0, sparse_indices=(), sparse_num_vars=0):
+    n = out_point.shape[0]
+    o = np.zeros(2, dtype=np.uint64)
+    si = np.array(list(sparse_indices) or [0], dtype=np.uint32)
+    rc = lib().orc_selector_evaluate(kind, _p(np.ascontiguousarray(out_point)), _p(np.ascontiguousarray(in_point)), n,
+                                     C.c_size_t(offset), C.c_size_t(num_instances), _p32(si), len(sparse_indices),
+                                     sparse_num_vars, _p(o))
+    if rc != 0:
+        raise ValueError(f"orc_selector_evaluate rc={rc}")
+    return int(o[0]), int(o[1])
+
+
+def eq_eval_less_or_equal_than(max_idx: int, a: np.ndarray, b: np.ndarray):
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_eq_eval_less_or_equal_than(C.c_uint64(max_idx), _p(np.ascontiguousarray(a)), a.shape[0],
+                                         _p(np.ascontiguousarray(b)), b.shape[0], _p(o))
+    return int(o[0]), int(o[1])
+
+
+def eval_wellform_address_vec(offset, scaled, r, descending=False):
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_eval_wellform_address_vec(C.c_uint64(offset), C.c_uint64(scaled), _p(np.ascontiguousarray(r)),
+                                        r.shape[0], int(descending), _p(o))
+    return int(o[0]), int(o[1])
+
+
+def eval_stacked_wellform_address_vec(r):
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_eval_stacked_wellform_address_vec(_p(np.ascontiguousarray(r)), r.shape[0], _p(o))
+    return int(o[0]), int(o[1])
+
+
+def eval_stacked_constant_vec(r):
+    o = np.zeros(2, dtype=np.uint64)
+    lib().orc_eval_stacked_constant_vec(_p(np.ascontiguousarray(r)), r.shape[0], _p(o))
+    return int(o[0]), int(o[1])
+
+
+# ---- tower witness -----------------------------------------------------------------------
+def interleaving_mles_to_mles(mles: Sequence[np.ndarray], num_instances: int, num_limbs: int, default) -> List[np.ndarray]:
+    arr, keep = _mk_mles(mles)
+    out_len = lib().orc_interleave_out_len(len(mles), C.c_size_t(num_instances), num_limbs)
+    outs = [np.zeros((out_len, 2), dtype=np.uint64) for _ in range(num_limbs)]
+    ptrs = (u64p * num_limbs)(*[_p(o) for o in outs])
+    rc = lib().orc_interleaving_mles_to_mles(arr, len(mles), C.c_size_t(num_instances), num_limbs,
+                                             _p(ext([default]).reshape(2)), ptrs)
+    if rc != 0:
+        raise ValueError(f"orc_interleaving_mles_to_mles rc={rc}")
+    return outs
+
+
+def infer_tower_product_witness(num_vars: int, last_layer: Sequence[np.ndarray]) -> List[List[np.ndarray]]:
+    layers = [[np.zeros((1 << l, 2), dtype=np.uint64) for _ in range(2)] for l in range(num_vars)]
+    flat = [a for lay in layers for a in lay]
+    ptrs = (u64p * len(flat))(*[_p(a) for a in flat])
+    rc = lib().orc_infer_tower_product_witness(num_vars, _p(np.ascontiguousarray(last_layer[0])),
+                                               _p(np.ascontiguousarray(last_layer[1])), ptrs)
+    if rc != 0:
+        raise ValueError(f"orc_infer_tower_product_witness rc={rc}")
+    return layers
+
+
+def infer_tower_logup_witness(p: Optional[Sequence[np.ndarray]], q: Sequence[np.ndarray]) -> List[List[np.ndarray]]:
+    nv = int(q[0].shape[0]).bit_length() - 1
+    layers = [[np.zeros((1 << l, 2), dtype=np.uint64) for _ in range(4)] for l in range(nv + 1)]
+    flat = [a for lay in layers for a in lay]
+    ptrs = (u64p * len(flat))(*[_p(a) for a in flat])
+    p0 = _p(np.ascontiguousarray(p[0])) if p is not None else None
+    p1 = _p(np.ascontiguousarray(p[1])) if p is not None else None
+    rc = lib().orc_infer_tower_logup_witness(nv, p0, p1, _p(np.ascontiguousarray(q[0])),
+                                             _p(np.ascontiguousarray(q[1])), ptrs)
+    if rc != 0:
+        raise ValueError(f"orc_infer_tower_logup_witness rc={rc}")
+    return layers
+
+
+class TowerProof:
+    def __init__(self, max_nv: int, n_prod: int, n_logup: int):
+        self.max_nv, self.n_prod, self.n_logup = max_nv, n_prod, n_logup
+        R = max_nv - 1
+        self.msgs = np.zeros(max(1, lib().orc_tower_msgs_words(max_nv)), dtype=np.uint64)
+        self.prod_evals = np.zeros((max(1, n_prod), max(1, R), 2, 2), dtype=np.uint64)
+        self.logup_evals = np.zeros((max(1, n_logup), max(1, R), 4, 2), dtype=np.uint64)
+        self.point = np.zeros((max_nv + 1, 2), dtype=np.uint64)
+        self.c = OrcTowerProof(R, _p(self.msgs), _p(self.prod_evals), _p(self.logup_evals), _p(self.point))
+
+    def round_msgs(self, rnd: int) -> np.ndarray:
+        """messages of tower round `rnd` (1-based): array (rnd, 3, 2)"""
+        off = sum(r * 3 * 2 for r in range(1, rnd))
+        return self.msgs[off: off + rnd * 6].reshape(rnd, 3, 2)
+
+
+def _mk_specs(specs: Sequence[List[List[np.ndarray]]]):
+    arr = (OrcTowerSpec * max(1, len(specs)))()
+    keep = []
+    for i, layers in enumerate(specs):
+        flat = [np.ascontiguousarray(a) for lay in layers for a in lay]
+        ptrs = (u64p * len(flat))(*[_p(a) for a in flat])
+        keep.append((flat, ptrs))
+        arr[i].num_vars = len(layers)
+        arr[i].layers = ptrs
+    return arr, keep
+
+
+def tower_prove(prod_specs, logup_specs, tr: StubTranscript) -> TowerProof:
+    max_nv = max([len(s) for s in prod_specs] + [len(s) for s in logup_specs])
+    proof = TowerProof(max_nv, len(prod_specs), len(logup_specs))
+    pa, k1 = _mk_specs(prod_specs)
+    la, k2 = _mk_specs(logup_specs)
+    rc = lib().orc_tower_prove(pa, len(prod_specs), la, len(logup_specs), tr.ptr(), C.byref(proof.c))
+    if rc != 0:
+        raise ValueError(f"orc_tower_prove rc={rc}")
+    return proof
+
+
+def tower_verify(prod_out_evals: np.ndarray, logup_out_evals: np.ndarray, num_variables: Sequence[int],
+                 proof: TowerProof, tr: StubTranscript):
+    n_prod, n_logup = proof.n_prod, proof.n_logup
+    max_nv = max(num_variables)
+    pt = np.zeros((max_nv + 1, 2), dtype=np.uint64)
+    pc = np.zeros((max(1, n_prod), 2), dtype=np.uint64)
+    lp = np.zeros((max(1, n_logup), 2), dtype=np.uint64)
+    lq = np.zeros((max(1, n_logup), 2), dtype=np.uint64)
+    nv = (C.c_int * len(num_variables))(*num_variables)
+    po = np.ascontiguousarray(prod_out_evals) if n_prod else np.zeros((1, 2), dtype=np.uint64)
+    lo = np.ascontiguousarray(logup_out_evals) if n_logup else np.zeros((1, 2), dtype=np.uint64)
+    rc = lib().orc_tower_verify(_p(po), _p(lo), nv, n_prod, n_logup, C.byref(proof.c), tr.ptr(), _p(pt), _p(pc),
+                                _p(lp), _p(lq))
+    return rc, pt[:max_nv], pc, lp, lq
