@@ -1,0 +1,133 @@
+"""ctypes loader for libceno_hip.so (the C ABI declared in include/ceno_hip.h).
+
+The product path has no CPU fallback: if the HIP extension is missing the import of the
+library fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libceno_hip.so")
+PROVER_LIB_PATH = os.path.join(HERE, "libceno_prover.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+vpp = C.POINTER(C.c_void_p)
+
+
+class SumcheckPlan(C.Structure):
+    _fields_ = [
+        ("num_mles", C.c_int),
+        ("num_terms", C.c_int),
+        ("term_coeffs", u64p),
+        ("term_offsets", u32p),
+        ("term_mle_idx", u32p),
+        ("num_groups", C.c_int),
+        ("group_term_offsets", u32p),
+        ("group_term_idx", u32p),
+        ("common_offsets", u32p),
+        ("common_mle_idx", u32p),
+        ("max_num_vars", C.c_int),
+        ("max_degree", C.c_int),
+    ]
+
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libceno_hip.so; raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m ceno_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the prover kernels."
+        )
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    sz = C.c_size_t
+    i = C.c_int
+    sig = {
+        "ceno_hip_init": (i, [i, sz, vpp]),
+        "ceno_hip_destroy": (None, [vp]),
+        "ceno_hip_last_error": (C.c_char_p, [vp]),
+        "ceno_hip_version": (C.c_char_p, []),
+        "ceno_hip_stream_create": (i, [vp, vpp]),
+        "ceno_hip_stream_destroy": (i, [vp, vp]),
+        "ceno_hip_stream_sync": (i, [vp, vp]),
+        "ceno_hip_mem_info": (i, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+        "ceno_hip_mem_trim": (i, [vp]),
+        "ceno_hip_mle_alloc": (i, [vp, i, i, vpp]),
+        "ceno_hip_mle_upload": (i, [vp, u64p, i, i, vp, vpp]),
+        "ceno_hip_mle_wrap": (i, [vp, vp, i, i, vpp]),
+        "ceno_hip_mle_view_chunk": (i, [vp, vp, i, sz, vpp]),
+        "ceno_hip_mle_download": (i, [vp, vp, u64p, vp]),
+        "ceno_hip_mle_free": (i, [vp, vp]),
+        "ceno_hip_mle_num_vars": (i, [vp]),
+        "ceno_hip_mle_is_ext": (i, [vp]),
+        "ceno_hip_mle_device_ptr": (vp, [vp]),
+        "ceno_hip_mle_fill_splitmix": (i, [vp, vp, C.c_uint64, C.c_uint64, vp]),
+        "ceno_hip_mle_evaluate": (i, [vp, vp, u64p, u64p, vp]),
+        "ceno_hip_mle_fix_variables": (i, [vp, vp, u64p, i, vp, vpp]),
+        "ceno_hip_eq_build": (i, [vp, u64p, i, u64p, vp, vpp]),
+        "ceno_hip_selector_build": (i, [vp, i, u64p, i, sz, sz, u32p, i, i, vp, vpp]),
+        "ceno_hip_wit_infer": (i, [vp, vpp, i, u64p, u32p, u32p, i, u32p, i, i, vp, vpp]),
+        "ceno_hip_sumcheck_begin": (i, [vp, vpp, C.POINTER(SumcheckPlan), vp, vpp]),
+        "ceno_hip_sumcheck_round": (i, [vp, vp, u64p, u64p]),
+        "ceno_hip_sumcheck_round_dev": (i, [vp, vp, u64p, vp]),
+        "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),
+        "ceno_hip_sumcheck_rounds_done": (i, [vp]),
+        "ceno_hip_sumcheck_free": (i, [vp, vp]),
+        "ceno_hip_tower_build_prod": (i, [vp, vpp, i, sz, u64p, vp, vpp]),
+        "ceno_hip_tower_build_logup": (i, [vp, vpp, vpp, i, sz, u64p, vp, vpp]),
+        "ceno_hip_tower_from_last_layer": (i, [vp, vpp, i, vp, vpp]),
+        "ceno_hip_tower_num_vars": (i, [vp]),
+        "ceno_hip_tower_num_limbs": (i, [vp]),
+        "ceno_hip_tower_layer": (i, [vp, vp, i, i, vpp]),
+        "ceno_hip_tower_out_evals": (i, [vp, vp, u64p, vp]),
+        "ceno_hip_tower_free": (i, [vp, vp]),
+        "ceno_hip_tower_layer_sumcheck_begin": (i, [vp, vpp, i, vpp, i, i, u64p, u64p, vp, vpp]),
+        "ceno_hip_ntt_batch": (i, [vp, vp, i, i, i, vp]),
+        "ceno_hip_rs_encode": (i, [vp, vp, i, i, i, vp, vp]),
+        "ceno_hip_transpose": (i, [vp, vp, sz, sz, vp, vp]),
+        "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),
+        "ceno_hip_poseidon2_permute": (i, [vp, vp, sz, vp]),
+        "ceno_hip_merkle_commit": (i, [vp, vp, i, i, vp, vpp]),
+        "ceno_hip_merkle_root": (i, [vp, vp, u64p, vp]),
+        "ceno_hip_merkle_open": (i, [vp, vp, sz, u64p, vp]),
+        "ceno_hip_merkle_free": (i, [vp, vp]),
+        "ceno_hip_prof_reset": (i, [vp]),
+        "ceno_hip_prof_enable": (i, [vp, i]),
+        "ceno_hip_prof_get": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    }
+    missing = []
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    L._ceno_missing = missing
+    L._ceno_sig = sig
+    _lib = L
+    return L
+
+
+def declared_symbols():
+    """every function name include/ceno_hip.h declares (parsed from the header)"""
+    import re
+
+    hdr = os.path.join(os.path.dirname(HERE), "include", "ceno_hip.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ceno_hip_[a-z0-9_]+)\s*\(", txt)))

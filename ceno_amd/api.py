@@ -1,0 +1,287 @@
+"""Thin Python handles over the C ABI (include/ceno_hip.h).
+
+These classes are plumbing for tests, bench.py and the torch.distributed driver: every compute call
+goes through libceno_hip.so.  Field elements are numpy uint64; an extension element is a pair
+[c0, c1]; an ext table has shape (2^nv, 2), a base table shape (2^nv,).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import SumcheckPlan, u32p, u64p
+
+P = 0xFFFFFFFF00000001
+
+
+class CenoHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ceno_hip error {code}: {msg}")
+        self.code = code
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _p32(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u32p)
+
+
+def _ext1(e) -> np.ndarray:
+    a = np.zeros(2, dtype=np.uint64)
+    a[0], a[1] = int(e[0]), int(e[1])
+    return a
+
+
+class Device:
+    """ceno_hip_ctx: one per process/GPU (reference: process-global CUDA_HAL, gkr_iop/src/gpu/mod.rs:53-66)."""
+
+    def __init__(self, device: int = 0, pool_bytes: int = 0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.ceno_hip_init(device, pool_bytes, C.byref(h))
+        if rc != 0:
+            raise CenoHipError(rc, (self.L.ceno_hip_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise CenoHipError(rc, (self.L.ceno_hip_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ceno_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- streams / memory ----
+    def stream_create(self) -> C.c_void_p:
+        s = C.c_void_p()
+        self.check(self.L.ceno_hip_stream_create(self.h, C.byref(s)))
+        return s
+
+    def stream_destroy(self, s):
+        self.check(self.L.ceno_hip_stream_destroy(self.h, s))
+
+    def sync(self, stream=None):
+        self.check(self.L.ceno_hip_stream_sync(self.h, stream))
+
+    def mem_info(self):
+        f, t, u, c = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.check(self.L.ceno_hip_mem_info(self.h, C.byref(f), C.byref(t), C.byref(u), C.byref(c)))
+        return {"free": f.value, "total": t.value, "pool_used": u.value, "pool_cached": c.value}
+
+    def mem_trim(self):
+        self.check(self.L.ceno_hip_mem_trim(self.h))
+
+    # ---- MLEs ----
+    def alloc(self, num_vars: int, is_ext: bool) -> "Mle":
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_mle_alloc(self.h, num_vars, int(is_ext), C.byref(h)))
+        return Mle(self, h)
+
+    def upload(self, table: np.ndarray, stream=None) -> "Mle":
+        table = np.ascontiguousarray(table, dtype=np.uint64)
+        is_ext = table.ndim == 2
+        n = table.shape[0]
+        assert n & (n - 1) == 0 and n >= 1
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_mle_upload(self.h, _p(table), n.bit_length() - 1, int(is_ext), stream, C.byref(h)))
+        return Mle(self, h)
+
+    def wrap(self, device_ptr: int, num_vars: int, is_ext: bool) -> "Mle":
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_mle_wrap(self.h, C.c_void_p(device_ptr), num_vars, int(is_ext), C.byref(h)))
+        return Mle(self, h)
+
+    def synthetic(self, num_vars: int, is_ext: bool, seed: int, word_offset: int = 0, stream=None) -> "Mle":
+        m = self.alloc(num_vars, is_ext)
+        self.check(self.L.ceno_hip_mle_fill_splitmix(self.h, m.h, C.c_uint64(seed), C.c_uint64(word_offset), stream))
+        return m
+
+    def eq_build(self, point: np.ndarray, scalar=None, stream=None) -> "Mle":
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        h = C.c_void_p()
+        sc = _p(_ext1(scalar)) if scalar is not None else None
+        pp = _p(point) if point.shape[0] else None
+        self.check(self.L.ceno_hip_eq_build(self.h, pp, point.shape[0], sc, stream, C.byref(h)))
+        return Mle(self, h)
+
+    def selector_build(self, kind: int, point: np.ndarray, offset=0, num_instances=0, sparse_indices=(),
+                       sparse_num_vars=0, stream=None) -> "Mle":
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        si = np.array(list(sparse_indices) or [0], dtype=np.uint32)
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_selector_build(self.h, kind, _p(point) if point.shape[0] else None, point.shape[0],
+                                                  offset, num_instances, _p32(si), len(sparse_indices), sparse_num_vars,
+                                                  stream, C.byref(h)))
+        return Mle(self, h)
+
+    def wit_infer(self, mles: Sequence["Mle"], coeffs: np.ndarray, terms: Sequence[Sequence[int]],
+                  out_terms: Sequence[Sequence[int]], num_vars: int, stream=None) -> List["Mle"]:
+        """out o = sum over term ids in out_terms[o]; terms must be listed so that each output owns a
+        contiguous range (the CSR the C ABI takes)."""
+        order = [t for o in out_terms for t in o]
+        assert order == list(range(len(terms))), "terms must be grouped contiguously per output"
+        toff, tidx = _csr(terms)
+        ooff = np.zeros(len(out_terms) + 1, dtype=np.uint32)
+        for o, ts in enumerate(out_terms):
+            ooff[o + 1] = ooff[o] + len(ts)
+        arr = (C.c_void_p * len(mles))(*[m.h for m in mles])
+        outs = (C.c_void_p * len(out_terms))()
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        self.check(self.L.ceno_hip_wit_infer(self.h, arr, len(mles), _p(coeffs), _p32(toff), _p32(tidx), len(terms),
+                                             _p32(ooff), len(out_terms), num_vars, stream, outs))
+        return [Mle(self, C.c_void_p(o)) for o in outs]
+
+    # ---- profiling hooks ----
+    def prof_enable(self, on: bool = True):
+        self.check(self.L.ceno_hip_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self.check(self.L.ceno_hip_prof_reset(self.h))
+
+    def prof_get(self):
+        ms, n, b = C.c_double(), C.c_uint64(), C.c_double()
+        self.check(self.L.ceno_hip_prof_get(self.h, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
+
+
+def _csr(terms: Sequence[Sequence[int]]):
+    off = np.zeros(len(terms) + 1, dtype=np.uint32)
+    idx: List[int] = []
+    for t, s in enumerate(terms):
+        idx.extend(s)
+        off[t + 1] = len(idx)
+    return off, np.array(idx if idx else [0], dtype=np.uint32)
+
+
+class Mle:
+    """device multilinear polynomial (reference: MultilinearExtensionGpu, gkr_iop/src/gpu/mod.rs:157-370)"""
+
+    def __init__(self, dev: Device, h, borrowed: bool = False):
+        self.dev, self.h, self.borrowed = dev, h, borrowed
+
+    @property
+    def num_vars(self) -> int:
+        return self.dev.L.ceno_hip_mle_num_vars(self.h)
+
+    @property
+    def is_ext(self) -> bool:
+        return bool(self.dev.L.ceno_hip_mle_is_ext(self.h))
+
+    @property
+    def device_ptr(self) -> int:
+        return self.dev.L.ceno_hip_mle_device_ptr(self.h) or 0
+
+    def download(self, stream=None) -> np.ndarray:
+        n = 1 << self.num_vars
+        out = np.empty((n, 2) if self.is_ext else (n,), dtype=np.uint64)
+        self.dev.check(self.dev.L.ceno_hip_mle_download(self.dev.h, self.h, _p(out), stream))
+        return out
+
+    def evaluate(self, point: np.ndarray, stream=None) -> Tuple[int, int]:
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        assert point.shape[0] == self.num_vars
+        o = np.zeros(2, dtype=np.uint64)
+        self.dev.check(self.dev.L.ceno_hip_mle_evaluate(self.dev.h, self.h, _p(point) if point.shape[0] else None, _p(o), stream))
+        return int(o[0]), int(o[1])
+
+    def fix_variables(self, point: np.ndarray, stream=None) -> "Mle":
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        h = C.c_void_p()
+        self.dev.check(self.dev.L.ceno_hip_mle_fix_variables(self.dev.h, self.h, _p(point) if point.shape[0] else None,
+                                                             point.shape[0], stream, C.byref(h)))
+        return Mle(self.dev, h)
+
+    def view_chunk(self, sub_vars: int, chunk: int) -> "Mle":
+        h = C.c_void_p()
+        self.dev.check(self.dev.L.ceno_hip_mle_view_chunk(self.dev.h, self.h, sub_vars, chunk, C.byref(h)))
+        m = Mle(self.dev, h)
+        m._parent = self  # keep the parent alive (gkr_iop/src/gpu/mod.rs:244-253)
+        return m
+
+    def free(self):
+        if self.h and not self.borrowed and self.dev.h:
+            self.dev.L.ceno_hip_mle_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Sumcheck:
+    """round-granular generic sumcheck (reference: prove_generic_sumcheck_gpu, layer/gpu/mod.rs:259-271)"""
+
+    def __init__(self, dev: Device, mles: Sequence[Mle], coeffs: np.ndarray, terms: Sequence[Sequence[int]],
+                 max_num_vars: int, max_degree: int, groups: Optional[Sequence[Tuple[Sequence[int], Sequence[int]]]] = None,
+                 stream=None, _handle=None):
+        self.dev = dev
+        self.mles = list(mles)  # keep inputs alive
+        self.n, self.d = max_num_vars, max_degree
+        if _handle is not None:
+            self.h = _handle
+            return
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 2)
+        assert coeffs.shape[0] == len(terms)
+        toff, tidx = _csr(terms)
+        plan = SumcheckPlan()
+        plan.num_mles, plan.num_terms = len(mles), len(terms)
+        plan.term_coeffs, plan.term_offsets, plan.term_mle_idx = _p(coeffs), _p32(toff), _p32(tidx)
+        keep = [coeffs, toff, tidx]
+        if groups:
+            goff, gidx = _csr([g[1] for g in groups])
+            coff, cidx = _csr([g[0] for g in groups])
+            plan.num_groups = len(groups)
+            plan.group_term_offsets, plan.group_term_idx = _p32(goff), _p32(gidx)
+            plan.common_offsets, plan.common_mle_idx = _p32(coff), _p32(cidx)
+            keep += [goff, gidx, coff, cidx]
+        else:
+            plan.num_groups = 0
+        plan.max_num_vars, plan.max_degree = max_num_vars, max_degree
+        arr = (C.c_void_p * len(mles))(*[m.h for m in mles])
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_sumcheck_begin(dev.h, arr, C.byref(plan), stream, C.byref(h)))
+        self.h = h
+
+    def round(self, challenge=None) -> np.ndarray:
+        out = np.zeros((self.d, 2), dtype=np.uint64)
+        ch = _p(_ext1(challenge)) if challenge is not None else None
+        self.dev.check(self.dev.L.ceno_hip_sumcheck_round(self.dev.h, self.h, ch, _p(out)))
+        return out
+
+    def round_dev(self, challenge, dev_out_ptr: int):
+        ch = _p(_ext1(challenge)) if challenge is not None else None
+        self.dev.check(self.dev.L.ceno_hip_sumcheck_round_dev(self.dev.h, self.h, ch, C.c_void_p(dev_out_ptr)))
+
+    def finish(self, last_challenge) -> np.ndarray:
+        out = np.zeros((len(self.mles), 2), dtype=np.uint64)
+        ch = _p(_ext1(last_challenge)) if last_challenge is not None else None
+        self.dev.check(self.dev.L.ceno_hip_sumcheck_finish(self.dev.h, self.h, ch, _p(out)))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            self.dev.L.ceno_hip_sumcheck_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,84 @@
+"""Builds libceno_hip.so (HIP kernels + C ABI) and libceno_prover.so (C++ host layer) in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU; objects are cached under ceno_amd/_build and only
+stale translation units are recompiled.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+OBJ = os.path.join(HERE, "_build")
+LIB_HIP = os.path.join(HERE, "libceno_hip.so")
+LIB_PROVER = os.path.join(HERE, "libceno_prover.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include")]
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        glob.glob(os.path.join(ROOT, "include", "*.h"))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+            for out in ex.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out)
+    if force or jobs or _stale(LIB_HIP, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_HIP] + objs)
+    return LIB_HIP
+
+
+def build_prover(force: bool = False) -> str:
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
+    if not srcs:
+        return ""
+    hdrs = glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    if force or _stale(LIB_PROVER, srcs + hdrs + [LIB_HIP]):
+        cxx = shutil.which("g++") or "g++"
+        _run([cxx] + CXX_FLAGS + ["-shared", "-o", LIB_PROVER] + srcs +
+             ["-L", HERE, "-lceno_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    return LIB_PROVER
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    build_hip(force, verbose)
+    build_prover(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", LIB_HIP, LIB_PROVER if os.path.exists(LIB_PROVER) else "")

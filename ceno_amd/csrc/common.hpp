@@ -1,0 +1,92 @@
+// Internal definitions shared by the translation units of libceno_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ceno_hip.h"
+#include "gl64.cuh"
+
+using gl::E2;
+
+struct PoseidonParams;  // poseidon2.hip
+
+struct ceno_hip_ctx {
+    int device = 0;
+    hipStream_t default_stream = nullptr;
+    int num_cus = 256;
+    // ---- pool (size-bucketed caching allocator over hipMalloc) ----
+    std::mutex mu;
+    size_t pool_limit = 0;  // 0 = unlimited
+    size_t pool_used = 0;   // bytes handed out
+    size_t pool_cached = 0; // bytes parked in free lists
+    std::unordered_map<size_t, std::vector<void*>> free_lists;
+    std::unordered_map<void*, size_t> live;  // ptr -> bucket size
+    // ---- errors ----
+    std::string err;
+    // ---- profiling of the dominant kernel (bench.py roofline) ----
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_event_pool;
+    uint64_t prof_launches = 0;
+    double prof_bytes = 0.0;
+    // ---- poseidon2 parameters (device) ----
+    PoseidonParams* poseidon_dev = nullptr;
+};
+
+struct ceno_hip_mle {
+    uint64_t* d = nullptr;
+    int num_vars = 0;
+    int is_ext = 0;
+    bool owned = false;  // backed by the ctx pool
+    size_t len() const { return (size_t)1 << num_vars; }
+    size_t bytes() const { return len() * (is_ext ? 16 : 8); }
+};
+
+int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
+int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
+void ctx_free(ceno_hip_ctx* ctx, void* p);
+inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) { return s ? (hipStream_t)s : ctx->default_stream; }
+
+// profiling hooks (ctx.hip)
+void prof_begin(ceno_hip_ctx* ctx, hipStream_t st);
+void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes);
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return ctx_fail((ctx), CENO_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                                        \
+    } while (0)
+
+#define CHECK_ARG(ctx, cond, ...)                                        \
+    do {                                                                 \
+        if (!(cond)) return ctx_fail((ctx), CENO_HIP_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// launch helper: grid for a grid-stride kernel over `work` items
+inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
+    size_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (unsigned)g;
+}
+
+// ---- kernels exported across translation units ----
+// fold: out[j] = in[2j] + r (in[2j+1] - in[2j]) for j < half ; `in` base or ext, `out` ext
+int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* out, size_t half, E2 r, hipStream_t st);
+int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st);

@@ -1,0 +1,302 @@
+// Context, memory pool, streams and MLE handles of libceno_hip.so.
+// Reference counterpart: the process-global `CUDA_HAL` with its memory pool and stream binding
+// (gkr_iop/src/gpu/mod.rs:53-154) and the alloc/copy entry points catalogued in SURVEY.md §2.2.
+#include "common.hpp"
+
+static thread_local std::string g_init_err;
+
+int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->err = buf;
+    } else {
+        g_init_err = buf;
+    }
+    return code;
+}
+
+static size_t bucket_size(size_t bytes) {
+    if (bytes < 256) return 256;
+    if (bytes <= ((size_t)1 << 20)) {
+        size_t p = 256;
+        while (p < bytes) p <<= 1;
+        return p;
+    }
+    const size_t MB = (size_t)1 << 20;
+    return (bytes + MB - 1) / MB * MB;
+}
+
+int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
+    size_t b = bucket_size(bytes);
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        auto it = ctx->free_lists.find(b);
+        if (it != ctx->free_lists.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            ctx->pool_cached -= b;
+            ctx->pool_used += b;
+            ctx->live[p] = b;
+            *out = p;
+            return 0;
+        }
+        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
+            // try to make room by dropping cached blocks
+            for (auto& kv : ctx->free_lists) {
+                for (void* p : kv.second) {
+                    (void)hipFree(p);
+                    ctx->pool_cached -= kv.first;
+                }
+                kv.second.clear();
+            }
+            if (ctx->pool_used + b > ctx->pool_limit) {
+                ctx->err = "pool capacity exceeded";
+                return CENO_HIP_ERR_OOM;
+            }
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        ceno_hip_mem_trim(ctx);
+        e = hipMalloc(&p, b);
+        if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->pool_used += b;
+    ctx->live[p] = b;
+    *out = p;
+    return 0;
+}
+
+void ctx_free(ceno_hip_ctx* ctx, void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->live.find(p);
+    if (it == ctx->live.end()) return;
+    size_t b = it->second;
+    ctx->live.erase(it);
+    ctx->pool_used -= b;
+    ctx->pool_cached += b;
+    ctx->free_lists[b].push_back(p);
+}
+
+extern "C" {
+
+const char* ceno_hip_version(void) { return "ceno_hip 0.1 (gfx950)"; }
+
+int ceno_hip_init(int device, size_t pool_bytes, ceno_hip_ctx** out) {
+    if (!out) return ctx_fail(nullptr, CENO_HIP_ERR_INVALID, "out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return ctx_fail(nullptr, CENO_HIP_ERR_HIP, "no HIP device available (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return ctx_fail(nullptr, CENO_HIP_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return ctx_fail(nullptr, CENO_HIP_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    auto* ctx = new ceno_hip_ctx();
+    ctx->device = device;
+    ctx->pool_limit = pool_bytes;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    e = hipStreamCreateWithFlags(&ctx->default_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return ctx_fail(nullptr, CENO_HIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return 0;
+}
+
+void ceno_hip_destroy(ceno_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : ctx->free_lists)
+        for (void* p : kv.second) (void)hipFree(p);
+    for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->prof_event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
+    if (ctx->default_stream) (void)hipStreamDestroy(ctx->default_stream);
+    delete ctx;
+}
+
+const char* ceno_hip_last_error(ceno_hip_ctx* ctx) {
+    if (!ctx) return g_init_err.c_str();
+    return ctx->err.c_str();
+}
+
+int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out) {
+    CHECK_ARG(ctx, out, "out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (ceno_hip_stream)s;
+    return 0;
+}
+int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    if (s) HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));
+    return 0;
+}
+int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx_stream(ctx, s)));
+    return 0;
+}
+
+int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached) {
+    size_t f = 0, t = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (pool_used) *pool_used = ctx->pool_used;
+    if (pool_cached) *pool_cached = ctx->pool_cached;
+    return 0;
+}
+
+int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (auto& kv : ctx->free_lists) {
+        for (void* p : kv.second) {
+            (void)hipFree(p);
+            ctx->pool_cached -= kv.first;
+        }
+        kv.second.clear();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLE handles
+// ------------------------------------------------------------------------------------------------
+int ceno_hip_mle_alloc(ceno_hip_ctx* ctx, int num_vars, int is_ext, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, out && num_vars >= 0 && num_vars < 40, "bad num_vars %d", num_vars);
+    auto* m = new ceno_hip_mle();
+    m->num_vars = num_vars;
+    m->is_ext = is_ext ? 1 : 0;
+    m->owned = true;
+    void* p = nullptr;
+    int rc = ctx_alloc(ctx, m->bytes(), &p);
+    if (rc) {
+        delete m;
+        return rc;
+    }
+    m->d = (uint64_t*)p;
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_mle_upload(ceno_hip_ctx* ctx, const uint64_t* host, int num_vars, int is_ext, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, host, "host is NULL");
+    ceno_hip_mle* m = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, num_vars, is_ext, &m));
+    hipStream_t st = ctx_stream(ctx, s);
+    hipError_t e = hipMemcpyAsync(m->d, host, m->bytes(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // host buffer is only borrowed for the call
+    if (e != hipSuccess) {
+        ceno_hip_mle_free(ctx, m);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "upload: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_mle_wrap(ceno_hip_ctx* ctx, uint64_t* device_ptr, int num_vars, int is_ext, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, out && device_ptr && num_vars >= 0 && num_vars < 40, "bad wrap arguments");
+    CHECK_ARG(ctx, ((uintptr_t)device_ptr & 15) == 0, "device pointer must be 16-byte aligned");
+    auto* m = new ceno_hip_mle();
+    m->d = device_ptr;
+    m->num_vars = num_vars;
+    m->is_ext = is_ext ? 1 : 0;
+    m->owned = false;
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_mle_view_chunk(ceno_hip_ctx* ctx, ceno_hip_mle* parent, int sub_vars, size_t chunk, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, parent && out, "NULL argument");
+    CHECK_ARG(ctx, sub_vars >= 0 && sub_vars <= parent->num_vars, "sub_vars %d out of range", sub_vars);
+    CHECK_ARG(ctx, chunk < ((size_t)1 << (parent->num_vars - sub_vars)), "chunk out of range");
+    auto* m = new ceno_hip_mle();
+    m->num_vars = sub_vars;
+    m->is_ext = parent->is_ext;
+    m->owned = false;
+    m->d = parent->d + chunk * ((size_t)1 << sub_vars) * (parent->is_ext ? 2 : 1);
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_mle_download(ceno_hip_ctx* ctx, const ceno_hip_mle* m, uint64_t* host, ceno_hip_stream s) {
+    CHECK_ARG(ctx, m && host, "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    HIP_TRY(ctx, hipMemcpyAsync(host, m->d, m->bytes(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+int ceno_hip_mle_free(ceno_hip_ctx* ctx, ceno_hip_mle* m) {
+    if (!m) return 0;
+    if (m->owned) ctx_free(ctx, m->d);
+    delete m;
+    return 0;
+}
+int ceno_hip_mle_num_vars(const ceno_hip_mle* m) { return m ? m->num_vars : -1; }
+int ceno_hip_mle_is_ext(const ceno_hip_mle* m) { return m ? m->is_ext : -1; }
+uint64_t* ceno_hip_mle_device_ptr(const ceno_hip_mle* m) { return m ? m->d : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// profiling hooks: HIP events on the stream the kernel is launched on
+// ------------------------------------------------------------------------------------------------
+int ceno_hip_prof_enable(ceno_hip_ctx* ctx, int on) {
+    ctx->prof_on = on != 0;
+    return 0;
+}
+int ceno_hip_prof_reset(ceno_hip_ctx* ctx) {
+    for (auto& ev : ctx->prof_events) ctx->prof_event_pool.push_back(ev);
+    ctx->prof_events.clear();
+    ctx->prof_launches = 0;
+    ctx->prof_bytes = 0.0;
+    return 0;
+}
+int ceno_hip_prof_get(ceno_hip_ctx* ctx, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes) {
+    double tot = 0.0;
+    for (auto& ev : ctx->prof_events) {
+        HIP_TRY(ctx, hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+    }
+    if (kernel_ms) *kernel_ms = tot;
+    if (launches) *launches = ctx->prof_launches;
+    if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes;
+    return 0;
+}
+
+}  // extern "C"
+
+void prof_begin(ceno_hip_ctx* ctx, hipStream_t st) {
+    if (!ctx->prof_on) return;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!ctx->prof_event_pool.empty()) {
+        ev = ctx->prof_event_pool.back();
+        ctx->prof_event_pool.pop_back();
+    } else {
+        (void)hipEventCreate(&ev.first);
+        (void)hipEventCreate(&ev.second);
+    }
+    (void)hipEventRecord(ev.first, st);
+    ctx->prof_events.push_back(ev);
+}
+void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes) {
+    if (!ctx->prof_on) return;
+    (void)hipEventRecord(ctx->prof_events.back().second, st);
+    ctx->prof_launches += 1;
+    ctx->prof_bytes += algorithmic_bytes;
+}

@@ -1,0 +1,338 @@
+// MLE kernels: synthetic fill, fold (fix_variable), eq / selector tables, evaluate.
+// Reference semantics: EXT multilinear_extensions `build_eq_x_r_vec`, `MultilinearExtension::
+// {evaluate, fix_variables}` (call sites gkr_iop/src/selector.rs:140-194, layer/cpu/mod.rs:266);
+// selectors gkr_iop/src/selector.rs:131-245; LSB-first variable order gkr_iop/src/utils.rs:215-232.
+// All kernels are HBM-streaming: 16 B per lane coalesced loads/stores, grid-stride.
+#include "common.hpp"
+#include "reduce.cuh"
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr unsigned MAXB = 2048;  // 256 CUs x 8 blocks
+
+struct PointArg {
+    E2 r[40];
+};
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_fill_splitmix(uint64_t* out, size_t n_words, uint64_t seed, uint64_t off) {
+    size_t stride = (size_t)gridDim.x * NT;
+    // two words per thread-iteration -> 16 B stores
+    for (size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 2; i < n_words; i += stride * 2) {
+        uint64_t a = splitmix_gl(seed, off + i);
+        if (i + 1 < n_words) {
+            uint64_t b = splitmix_gl(seed, off + i + 1);
+            *reinterpret_cast<ulonglong2*>(out + i) = make_ulonglong2(a, b);
+        } else {
+            out[i] = a;
+        }
+    }
+}
+
+// out[j] = in[2j] + r (in[2j+1] - in[2j])
+template <bool IN_EXT>
+__global__ void __launch_bounds__(NT) k_fold(const uint64_t* __restrict__ in, E2* __restrict__ out, size_t half, E2 r) {
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {
+        E2 lo, hi;
+        if (IN_EXT) {
+            const E2* p = reinterpret_cast<const E2*>(in) + 2 * j;
+            lo = p[0];
+            hi = p[1];
+            out[j] = lo + r * (hi - lo);
+        } else {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(in + 2 * j);
+            uint64_t d = sub(v.y, v.x);
+            E2 t = e2_mul_base(r, d);
+            out[j] = E2{add(t.c0, v.x), t.c1};
+        }
+    }
+}
+
+int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* out, size_t half, E2 r, hipStream_t st) {
+    unsigned g = grid_for(half, NT, MAXB);
+    if (in_is_ext)
+        hipLaunchKernelGGL(k_fold<true>, dim3(g), dim3(NT), 0, st, in, reinterpret_cast<E2*>(out), half, r);
+    else
+        hipLaunchKernelGGL(k_fold<false>, dim3(g), dim3(NT), 0, st, in, reinterpret_cast<E2*>(out), half, r);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// eq(x, r) = prod_k (x_k r_k + (1-x_k)(1-r_k)) built as an outer product of two half tables:
+// eq[i] = lo[i & (2^a - 1)] * hi[i >> a]; both halves are produced by direct products
+// (<= 20 mults per entry of a table that is at most 2^20 entries), the full table costs one ext
+// mult and one 16 B store per entry -> write-bandwidth bound.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_eq_half(E2* out, int first_var, int n_vars, PointArg pt, E2 scalar) {
+    size_t len = (size_t)1 << n_vars;
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+        E2 acc = scalar;
+        for (int k = 0; k < n_vars; k++) {
+            E2 r = pt.r[first_var + k];
+            E2 f = ((i >> k) & 1) ? r : (e2_one() - r);
+            acc = acc * f;
+        }
+        out[i] = acc;
+    }
+}
+
+struct SelArg {
+    int kind;
+    int num_vars;
+    uint64_t start, end;       // PREFIX: keep [start,end);  ORDERED_SPARSE/QUARK: end = num_instances
+    int sparse_num_vars;
+    uint64_t sparse_mask[4];   // up to 2^8 positions per chunk
+    uint32_t quark_seq[40];
+};
+
+__device__ __forceinline__ bool sel_keep(const SelArg& sa, size_t x) {
+    switch (sa.kind) {
+    case CENO_HIP_SEL_WHOLE: return true;
+    case CENO_HIP_SEL_PREFIX: return x >= sa.start && x < sa.end;
+    case CENO_HIP_SEL_ORDERED_SPARSE: {
+        size_t chunk = x >> sa.sparse_num_vars;
+        if (chunk >= sa.end) return false;
+        unsigned pos = (unsigned)(x & (((size_t)1 << sa.sparse_num_vars) - 1));
+        return (sa.sparse_mask[pos >> 6] >> (pos & 63)) & 1;
+    }
+    case CENO_HIP_SEL_QUARK_LT: {
+        // region i = indices whose top i bits are 1 and next bit is 0 (selector.rs:217-238)
+        int nv = sa.num_vars;
+        int i = 0;
+        while (i < nv && ((x >> (nv - 1 - i)) & 1)) i++;
+        if (i >= nv) return false;  // last hypercube entry is zeroed
+        size_t len = (size_t)1 << (nv - 1 - i);
+        size_t pos = x & (len - 1);
+        return pos < sa.quark_seq[i];
+    }
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(NT) k_eq_outer(E2* __restrict__ out, const E2* __restrict__ lo, const E2* __restrict__ hi, int a,
+                                                 size_t len, SelArg sa) {
+    size_t stride = (size_t)gridDim.x * NT;
+    size_t mask = ((size_t)1 << a) - 1;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+        E2 v = e2_zero();
+        if (sel_keep(sa, i)) v = lo[i & mask] * hi[i >> a];
+        out[i] = v;
+    }
+}
+
+static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 scalar, const SelArg& sa, uint64_t* dev_out, hipStream_t st) {
+    CHECK_ARG(ctx, n >= 0 && n <= 40, "eq: num_vars %d out of range", n);
+    PointArg pt;
+    for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
+    int a = (n + 1) / 2, b = n - a;
+    void* tmp = nullptr;
+    TRY(ctx_alloc(ctx, (((size_t)1 << a) + ((size_t)1 << b)) * sizeof(E2), &tmp));
+    E2* lo = (E2*)tmp;
+    E2* hi = lo + ((size_t)1 << a);
+    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << a, NT, MAXB)), dim3(NT), 0, st, lo, 0, a, pt, e2_one());
+    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << b, NT, MAXB)), dim3(NT), 0, st, hi, a, b, pt, scalar);
+    size_t len = (size_t)1 << n;
+    hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, (E2*)dev_out, lo, hi, a, len, sa);
+    hipError_t e = hipGetLastError();
+    // the scratch halves are read by the queued kernel: return them to the pool only after it ran
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    ctx_free(ctx, tmp);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "eq build: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st) {
+    SelArg sa{};
+    sa.kind = CENO_HIP_SEL_WHOLE;
+    sa.num_vars = n;
+    return eq_build_impl(ctx, host_point, n, scalar, sa, dev_out, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// evaluate: sum_i f[i] * lo[i & mask] * hi[i >> a]   (one read-only pass over the table)
+// ------------------------------------------------------------------------------------------------
+template <bool IN_EXT>
+__global__ void __launch_bounds__(NT) k_eval_dot(const uint64_t* __restrict__ f, const E2* __restrict__ lo, const E2* __restrict__ hi,
+                                                 int a, size_t len, E2* __restrict__ partials) {
+    __shared__ E2 smem[NT / 64];
+    size_t stride = (size_t)gridDim.x * NT;
+    size_t mask = ((size_t)1 << a) - 1;
+    E2 acc[1] = {e2_zero()};
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+        E2 w = lo[i & mask] * hi[i >> a];
+        if (IN_EXT) acc[0] = acc[0] + reinterpret_cast<const E2*>(f)[i] * w;
+        else acc[0] = acc[0] + e2_mul_base(w, f[i]);
+    }
+    red::block_sum<1, NT>(acc, smem);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+__global__ void __launch_bounds__(NT) k_sum_partials(const E2* __restrict__ partials, int n, E2* out) {
+    __shared__ E2 smem[NT / 64];
+    E2 acc[1] = {e2_zero()};
+    for (int i = threadIdx.x; i < n; i += NT) acc[0] = acc[0] + partials[i];
+    red::block_sum<1, NT>(acc, smem);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+extern "C" {
+
+int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed, uint64_t word_offset, ceno_hip_stream s) {
+    CHECK_ARG(ctx, m, "NULL mle");
+    size_t n_words = m->len() * (m->is_ext ? 2 : 1);
+    hipStream_t st = ctx_stream(ctx, s);
+    hipLaunchKernelGGL(k_fill_splitmix, dim3(grid_for((n_words + 1) / 2, NT, MAXB)), dim3(NT), 0, st, m->d, n_words, seed, word_offset);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, const uint64_t* scalar2, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, out && (point || num_vars == 0), "NULL argument");
+    ceno_hip_mle* m = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, num_vars, 1, &m));
+    E2 sc = scalar2 ? E2{scalar2[0], scalar2[1]} : e2_one();
+    int rc = launch_eq_build(ctx, point, num_vars, sc, m->d, ctx_stream(ctx, s));
+    if (rc) {
+        ceno_hip_mle_free(ctx, m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_selector_build(ceno_hip_ctx* ctx, int kind, const uint64_t* point, int num_vars, size_t offset, size_t num_instances,
+                            const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, out && (point || num_vars == 0), "NULL argument");
+    CHECK_ARG(ctx, num_vars >= 0 && num_vars <= 40, "num_vars out of range");
+    SelArg sa{};
+    sa.kind = kind;
+    sa.num_vars = num_vars;
+    size_t len = (size_t)1 << num_vars;
+    switch (kind) {
+    case CENO_HIP_SEL_WHOLE: break;
+    case CENO_HIP_SEL_PREFIX:
+        // selector.rs:144-150: end <= 2^num_vars
+        CHECK_ARG(ctx, offset + num_instances <= len, "prefix selector: offset %zu + num_instances %zu > 2^%d", offset, num_instances, num_vars);
+        sa.start = offset;
+        sa.end = offset + num_instances;
+        break;
+    case CENO_HIP_SEL_ORDERED_SPARSE: {
+        CHECK_ARG(ctx, sparse_num_vars >= 0 && sparse_num_vars <= 8 && sparse_num_vars <= num_vars, "sparse_num_vars %d unsupported", sparse_num_vars);
+        CHECK_ARG(ctx, offset == 0, "ordered-sparse selector requires offset 0 (layer/gpu/utils.rs:145)");
+        sa.end = num_instances;
+        sa.sparse_num_vars = sparse_num_vars;
+        // indices are assumed ascending (selector.rs:50-52): anything out of order is skipped by the reference's merge walk
+        uint32_t prev = 0;
+        bool first = true;
+        for (int i = 0; i < n_sparse; i++) {
+            uint32_t ix = sparse_indices[i];
+            if (ix >= (1u << sparse_num_vars)) break;
+            if (!first && ix <= prev) break;
+            sa.sparse_mask[ix >> 6] |= (uint64_t)1 << (ix & 63);
+            prev = ix;
+            first = false;
+        }
+        break;
+    }
+    case CENO_HIP_SEL_QUARK_LT: {
+        CHECK_ARG(ctx, offset == 0, "quark selector requires offset 0 (selector.rs:192)");
+        size_t n_inst = num_instances;
+        for (int i = 0; i < num_vars; i++) {
+            sa.quark_seq[i] = (uint32_t)(n_inst / 2);
+            n_inst = (n_inst + 1) / 2;
+        }
+        break;
+    }
+    default: return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "unknown selector kind %d", kind);
+    }
+    ceno_hip_mle* m = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, num_vars, 1, &m));
+    int rc = eq_build_impl(ctx, point, num_vars, e2_one(), sa, m->d, ctx_stream(ctx, s));
+    if (rc) {
+        ceno_hip_mle_free(ctx, m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, uint64_t* out2, ceno_hip_stream s) {
+    CHECK_ARG(ctx, m && out2 && (point || m->num_vars == 0), "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    int n = m->num_vars;
+    PointArg pt;
+    for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
+    int a = (n + 1) / 2, b = n - a;
+    size_t len = m->len();
+    unsigned g = grid_for(len, NT, MAXB);
+    void* tmp = nullptr;
+    TRY(ctx_alloc(ctx, (((size_t)1 << a) + ((size_t)1 << b) + g + 1) * sizeof(E2), &tmp));
+    E2* lo = (E2*)tmp;
+    E2* hi = lo + ((size_t)1 << a);
+    E2* partials = hi + ((size_t)1 << b);
+    E2* res = partials + g;
+    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << a, NT, MAXB)), dim3(NT), 0, st, lo, 0, a, pt, e2_one());
+    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << b, NT, MAXB)), dim3(NT), 0, st, hi, a, b, pt, e2_one());
+    if (m->is_ext)
+        hipLaunchKernelGGL(k_eval_dot<true>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials);
+    else
+        hipLaunchKernelGGL(k_eval_dot<false>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(NT), 0, st, partials, (int)g, res);
+    hipError_t e = hipGetLastError();
+    E2 h{};
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, res, sizeof(E2), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    ctx_free(ctx, tmp);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "evaluate: %s", hipGetErrorString(e));
+    out2[0] = h.c0;
+    out2[1] = h.c1;
+    return 0;
+}
+
+int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, int n_fix, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, m && out && (point || n_fix == 0), "NULL argument");
+    CHECK_ARG(ctx, n_fix >= 0 && n_fix <= m->num_vars, "n_fix %d out of range", n_fix);
+    hipStream_t st = ctx_stream(ctx, s);
+    ceno_hip_mle* res = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, m->num_vars - n_fix, 1, &res));
+    if (n_fix == 0) {
+        // ext copy (base inputs are widened)
+        if (m->is_ext) {
+            HIP_TRY(ctx, hipMemcpyAsync(res->d, m->d, m->bytes(), hipMemcpyDeviceToDevice, st));
+        } else {
+            ceno_hip_mle_free(ctx, res);
+            return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "fix_variables with n_fix = 0 on a base table");
+        }
+        *out = res;
+        return 0;
+    }
+    // ping-pong: scratch A holds 2^(nv-1) elements, scratch B 2^(nv-2); the last fold lands in res
+    void* scratch = nullptr;
+    size_t half = m->len() / 2;
+    if (n_fix > 1) TRY(ctx_alloc(ctx, (half + half / 2 + 1) * sizeof(E2), &scratch));
+    uint64_t* bufA = (uint64_t*)scratch;
+    uint64_t* bufB = reinterpret_cast<uint64_t*>(reinterpret_cast<E2*>(scratch) + half);
+    const uint64_t* cur = m->d;
+    int cur_ext = m->is_ext;
+    int rc = 0;
+    for (int k = 0; k < n_fix && rc == 0; k++) {
+        uint64_t* dst = (k == n_fix - 1) ? res->d : ((k & 1) ? bufB : bufA);
+        rc = launch_fold(ctx, cur, cur_ext, dst, half, E2{point[2 * k], point[2 * k + 1]}, st);
+        cur = dst;
+        cur_ext = 1;
+        half >>= 1;
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    ctx_free(ctx, scratch);
+    if (rc || e != hipSuccess) {
+        ceno_hip_mle_free(ctx, res);
+        return rc ? rc : ctx_fail(ctx, CENO_HIP_ERR_HIP, "fix_variables: %s", hipGetErrorString(e));
+    }
+    *out = res;
+    return 0;
+}
+
+}  // extern "C"

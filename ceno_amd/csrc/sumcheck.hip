@@ -1,0 +1,814 @@
+// Sumcheck prover rounds on gfx950.
+//
+// Reference operator: `prove_generic_sumcheck_gpu(mles, mle_size_info, term_coefficients,
+// mle_indices_per_term, max_num_var, max_degree, Option<&CommonTermPlan>, &mut transcript, stream)`
+// (call sites gkr_iop/src/gkr/layer/gpu/mod.rs:259-271, ceno_zkvm/src/scheme/gpu/mod.rs:891-902,
+// 2968-2982), i.e. EXT `IOPProverState::prove` (gkr_iop/src/gkr/layer/cpu/mod.rs:217-227).
+// Semantics: round i binds variable i (LSB first), the message is p(1..d),
+// MLEs with fewer variables are front-loaded (scheme/verifier.rs:233-237).
+//
+// Schedule.  Round 0 is one read-only pass.  Round i>0 is ONE fused pass per size class: read the
+// table of round i-1, fold it with r_{i-1} in registers, write the half-size table and accumulate the
+// message of round i on the folded values.  Every table is therefore read once and written once (half
+// size) per round: HBM-streaming, 16 B per lane, no reuse -> HBM-roofline bound; no MFMA.
+//   * dense class  (one product term of K<=4 tables): register-resident fused kernel `k_dense`.
+//   * generic class (CSR term plan with optional common-factor groups): batched fold kernel + plan-
+//     driven accumulate kernel (`k_fold_batch`, `k_accum`), factor re-reads served by L1/L2.
+// Per-block partial sums (wave64 shuffle -> LDS) go to a partials buffer; `k_reduce_msg` adds them,
+// applies class coefficients and the host-computed scalar (front-loaded) contributions, and writes the
+// d extension elements of the message to pinned host memory (or a caller device buffer).
+#include "common.hpp"
+#include "reduce.cuh"
+
+#include <algorithm>
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr int MAXD = 8;
+static constexpr int MAXK = 4;
+static constexpr unsigned MAXB = 2048;
+static constexpr int MAX_CLASSES = 40;
+
+// ------------------------------------------------------------------------------------------------
+// dense fused kernel
+// ------------------------------------------------------------------------------------------------
+template <int K>
+struct TabPtrs {
+    const uint64_t* in[K];
+    uint64_t* out[K];
+};
+
+__device__ __forceinline__ E2 ld_e2(const uint64_t* p) { return *reinterpret_cast<const E2*>(p); }
+__device__ __forceinline__ void st_e2(uint64_t* p, E2 v) { *reinterpret_cast<E2*>(p) = v; }
+
+// MODE 0: accumulate only, ext input      MODE 1: accumulate only, base input
+// MODE 2: fold + accumulate, ext input    MODE 3: fold + accumulate, base input (output ext)
+template <int K, int MODE>
+__global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, E2* __restrict__ partials) {
+    __shared__ E2 smem[(NT / 64) * K];
+    E2 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
+        if (MODE == 1) {
+            // all-base first round: the product of base values stays in the base field
+            uint64_t pr[K];
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tp.in[m] + 2 * p);
+                uint64_t delta = sub(v.y, v.x), x = v.y;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+                    pr[t] = (m == 0) ? x : mul(pr[t], x);
+                    x = add(x, delta);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < K; t++) acc[t].c0 = add(acc[t].c0, pr[t]);
+        } else {
+            E2 pr[K];
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                E2 lo, hi;
+                if (MODE == 0) {
+                    lo = ld_e2(tp.in[m] + 4 * p);
+                    hi = ld_e2(tp.in[m] + 4 * p + 2);
+                } else if (MODE == 2) {
+                    const uint64_t* q = tp.in[m] + 8 * p;
+                    E2 a0 = ld_e2(q), a1 = ld_e2(q + 2), a2 = ld_e2(q + 4), a3 = ld_e2(q + 6);
+                    lo = a0 + r * (a1 - a0);
+                    hi = a2 + r * (a3 - a2);
+                    st_e2(tp.out[m] + 4 * p, lo);
+                    st_e2(tp.out[m] + 4 * p + 2, hi);
+                } else {
+                    const uint64_t* q = tp.in[m] + 4 * p;
+                    ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(q);
+                    ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(q + 2);
+                    E2 t0 = e2_mul_base(r, sub(v0.y, v0.x));
+                    E2 t1 = e2_mul_base(r, sub(v1.y, v1.x));
+                    lo = E2{add(t0.c0, v0.x), t0.c1};
+                    hi = E2{add(t1.c0, v1.x), t1.c1};
+                    st_e2(tp.out[m] + 4 * p, lo);
+                    st_e2(tp.out[m] + 4 * p + 2, hi);
+                }
+                E2 delta = hi - lo, x = hi;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+                    pr[t] = (m == 0) ? x : pr[t] * x;
+                    x = x + delta;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
+        }
+    }
+    red::block_sum<K, NT>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < K; t++) partials[(size_t)blockIdx.x * K + t] = acc[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic path
+// ------------------------------------------------------------------------------------------------
+struct MleSlot {
+    const uint64_t* in;  // table of the previous round
+    uint64_t* out;       // table of this round (ext), written by the fold
+    int in_ext;
+    int pad;
+};
+
+// fold every MLE of a class: blockIdx.y = MLE
+__global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ slots, size_t half, E2 r) {
+    const MleSlot sl = slots[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * NT;
+    E2* out = reinterpret_cast<E2*>(sl.out);
+    if (sl.in_ext) {
+        const E2* in = reinterpret_cast<const E2*>(sl.in);
+        for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {
+            E2 lo = in[2 * j], hi = in[2 * j + 1];
+            out[j] = lo + r * (hi - lo);
+        }
+    } else {
+        for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * j);
+            E2 t = e2_mul_base(r, sub(v.y, v.x));
+            out[j] = E2{add(t.c0, v.x), t.c1};
+        }
+    }
+}
+
+struct DevPlan {
+    const MleSlot* slots;
+    int use_out;                    // 1: read slot.out (ext), 0: read slot.in (round 0)
+    int n_groups;
+    const uint32_t* group_term_off; // n_groups + 1 -> range in group_terms
+    const uint32_t* group_terms;    // term ids
+    const uint32_t* common_off;     // n_groups + 1 -> range in common_idx
+    const uint32_t* common_idx;     // local mle ids
+    const E2* coeffs;               // per term
+    const uint32_t* term_off;       // per term -> range in term_idx
+    const uint32_t* term_idx;       // local mle ids
+};
+
+__device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t p, E2& lo, E2& hi) {
+    if (use_out) {
+        const E2* q = reinterpret_cast<const E2*>(sl.out) + 2 * p;
+        lo = q[0];
+        hi = q[1];
+    } else if (sl.in_ext) {
+        const E2* q = reinterpret_cast<const E2*>(sl.in) + 2 * p;
+        lo = q[0];
+        hi = q[1];
+    } else {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
+        lo = E2{v.x, 0};
+        hi = E2{v.y, 0};
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, E2* __restrict__ partials) {
+    __shared__ E2 smem[(NT / 64) * D];
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
+        for (int g = 0; g < pl.n_groups; g++) {
+            E2 inner[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) inner[t] = e2_zero();
+            for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                const uint32_t term = pl.group_terms[ti];
+                const E2 c = pl.coeffs[term];
+                E2 pr[D];
+#pragma unroll
+                for (int t = 0; t < D; t++) pr[t] = c;
+                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                    E2 lo, hi;
+                    load_pair(pl.slots[pl.term_idx[k]], pl.use_out, p, lo, hi);
+                    E2 delta = hi - lo, x = hi;
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        pr[t] = pr[t] * x;
+                        x = x + delta;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
+            }
+            const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+            if (ce > cb) {
+                E2 cm[D];
+                for (uint32_t k = cb; k < ce; k++) {
+                    E2 lo, hi;
+                    load_pair(pl.slots[pl.common_idx[k]], pl.use_out, p, lo, hi);
+                    E2 delta = hi - lo, x = hi;
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        cm[t] = (k == cb) ? x : cm[t] * x;
+                        x = x + delta;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) acc[t] = acc[t] + cm[t] * inner[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+            }
+        }
+    }
+    red::block_sum<D, NT>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int t = 0; t < D; t++) partials[(size_t)blockIdx.x * D + t] = acc[t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// message reduction: sum partials of every class (class c: `cnt[c]` blocks x stride[c] values at off[c];
+// the first d values of each block row are used), scale by the class coefficient, add host scalars.
+// ------------------------------------------------------------------------------------------------
+struct ReduceArgs {
+    int n_classes;
+    int d;
+    uint32_t off[MAX_CLASSES];
+    uint32_t cnt[MAX_CLASSES];
+    uint32_t stride[MAX_CLASSES];
+    E2 coeff[MAX_CLASSES];
+    E2 scalars[MAXD];
+};
+
+__global__ void __launch_bounds__(NT) k_reduce_msg(const E2* __restrict__ partials, ReduceArgs ra, E2* __restrict__ out) {
+    __shared__ E2 smem[(NT / 64) * MAXD];
+    E2 tot[MAXD];
+#pragma unroll
+    for (int t = 0; t < MAXD; t++) tot[t] = e2_zero();
+    for (int c = 0; c < ra.n_classes; c++) {
+        E2 acc[MAXD];
+#pragma unroll
+        for (int t = 0; t < MAXD; t++) acc[t] = e2_zero();
+        const E2* base = partials + ra.off[c];
+        const uint32_t st = ra.stride[c];
+        for (uint32_t b = threadIdx.x; b < ra.cnt[c]; b += NT) {
+#pragma unroll
+            for (int t = 0; t < MAXD; t++)
+                if (t < ra.d && t < (int)st) acc[t] = acc[t] + base[(size_t)b * st + t];
+        }
+        const E2 cf = ra.coeff[c];
+        const bool unit = (cf.c0 == 1 && cf.c1 == 0);
+#pragma unroll
+        for (int t = 0; t < MAXD; t++)
+            if (t < ra.d) tot[t] = tot[t] + (unit ? acc[t] : acc[t] * cf);
+    }
+    red::block_sum<MAXD, NT>(tot, smem);
+    if (threadIdx.x == 0) {
+        for (int t = 0; t < ra.d; t++) out[t] = tot[t] + ra.scalars[t];
+    }
+}
+
+// gather element 0 of every listed table into out[i] (final evaluations)
+struct GatherArgs {
+    const MleSlot* slots;
+};
+__global__ void k_gather_first(const MleSlot* __restrict__ slots, int n, E2* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = *reinterpret_cast<const E2*>(slots[i].out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side state
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct ScMle {
+    const uint64_t* cur = nullptr;
+    int cur_ext = 0;
+    int nv = 0;
+    uint64_t* buf[2] = {nullptr, nullptr};  // ping (2^(nv-1) ext), pong (2^(nv-2) ext)
+    int which = 0;
+    bool done = false;  // reduced to a single value
+    E2 eval = e2_zero();
+    E2 tail = e2_one();
+    int cls = -1, local = -1;
+};
+
+struct ScTerm {
+    E2 coeff;
+    std::vector<int> idx;   // residual factors (what the plan lists for the term)
+    std::vector<int> full;  // residual + common factors of its group
+    int nv;
+};
+
+struct ScClass {
+    int nv = 0;
+    std::vector<int> mles;    // global ids
+    std::vector<int> terms;   // global term ids
+    bool dense = false;       // single term, no groups, K == d <= MAXK, all same element kind
+    // device plan (generic)
+    MleSlot* d_slots = nullptr;
+    uint32_t *d_group_term_off = nullptr, *d_group_terms = nullptr, *d_common_off = nullptr, *d_common_idx = nullptr;
+    uint32_t *d_term_off = nullptr, *d_term_idx = nullptr;
+    E2* d_coeffs = nullptr;
+    int n_groups = 0;
+    uint32_t part_off = 0;    // offset (E2 units) into partials
+};
+
+}  // namespace
+
+struct ceno_hip_sumcheck {
+    ceno_hip_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;
+    int n = 0, d = 0;
+    int round = 0;  // next message to produce
+    bool finished = false;
+    std::vector<ScMle> mles;
+    std::vector<ScTerm> terms;
+    std::vector<ScClass> classes;  // sorted by nv descending
+    E2* d_partials = nullptr;
+    E2* d_msg = nullptr;           // d ext (device)
+    E2* d_evals = nullptr;         // gather scratch (device), num_mles
+    E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
+    MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
+    size_t slots_per_round = 0;
+    std::vector<void*> dev_allocs; // everything from ctx_alloc, freed on free()
+    bool owns_tower_eq = false;
+    ceno_hip_mle* extra_owned = nullptr;  // eq table built by tower_layer_sumcheck_begin
+};
+
+template <typename T>
+static int upload_vec(ceno_hip_sumcheck* sc, const std::vector<T>& v, T** out) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    TRY(ctx_alloc(sc->ctx, bytes, &p));
+    sc->dev_allocs.push_back(p);
+    if (!v.empty()) HIP_TRY(sc->ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, sc->st));
+    *out = (T*)p;
+    return 0;
+}
+
+static void sc_release(ceno_hip_sumcheck* sc) {
+    if (!sc) return;
+    (void)hipStreamSynchronize(sc->st);
+    for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
+    if (sc->h_pinned) (void)hipHostFree(sc->h_pinned);
+    if (sc->h_slots) (void)hipHostFree(sc->h_slots);
+    if (sc->extra_owned) ceno_hip_mle_free(sc->ctx, sc->extra_owned);
+    delete sc;
+}
+
+template <int K>
+static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, E2* partials, unsigned grid, hipStream_t st) {
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k_dense<K, 0>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
+    case 1: hipLaunchKernelGGL((k_dense<K, 1>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
+    case 2: hipLaunchKernelGGL((k_dense<K, 2>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
+    default: hipLaunchKernelGGL((k_dense<K, 3>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
+    }
+}
+
+template <int K>
+static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pairs, E2 r, unsigned grid) {
+    TabPtrs<K> tp;
+    const ScTerm& term = sc->terms[cl.terms[0]];
+    for (int m = 0; m < K; m++) {
+        ScMle& M = sc->mles[term.idx[m]];
+        tp.in[m] = M.cur;
+        tp.out[m] = M.buf[M.which];
+    }
+    launch_dense_k<K>(mode, tp, pairs, r, sc->d_partials + cl.part_off, grid, sc->st);
+}
+
+template <int D>
+static void launch_accum_d(const DevPlan& pl, size_t pairs, E2* partials, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, partials);
+}
+static void launch_accum(int d, const DevPlan& pl, size_t pairs, E2* partials, unsigned grid, hipStream_t st) {
+    switch (d) {
+    case 1: launch_accum_d<1>(pl, pairs, partials, grid, st); break;
+    case 2: launch_accum_d<2>(pl, pairs, partials, grid, st); break;
+    case 3: launch_accum_d<3>(pl, pairs, partials, grid, st); break;
+    case 4: launch_accum_d<4>(pl, pairs, partials, grid, st); break;
+    case 5: launch_accum_d<5>(pl, pairs, partials, grid, st); break;
+    case 6: launch_accum_d<6>(pl, pairs, partials, grid, st); break;
+    case 7: launch_accum_d<7>(pl, pairs, partials, grid, st); break;
+    default: launch_accum_d<8>(pl, pairs, partials, grid, st); break;
+    }
+}
+
+// grid for `pairs` work items: enough blocks to fill 256 CUs x 8, at least 1
+static unsigned sc_grid(size_t pairs) { return grid_for(pairs, NT, MAXB); }
+
+static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st,
+                    ceno_hip_sumcheck** out) {
+    CHECK_ARG(ctx, mles && plan && out, "NULL argument");
+    const int n = plan->max_num_vars, d = plan->max_degree;
+    CHECK_ARG(ctx, n >= 0 && n < 40, "max_num_vars %d out of range", n);
+    CHECK_ARG(ctx, d >= 1 && d <= MAXD, "max_degree %d unsupported (1..%d)", d, MAXD);
+    CHECK_ARG(ctx, plan->num_mles >= 1 && plan->num_terms >= 1, "empty plan");
+    auto* sc = new ceno_hip_sumcheck();
+    sc->ctx = ctx;
+    sc->st = st;
+    sc->n = n;
+    sc->d = d;
+    sc->mles.resize(plan->num_mles);
+    for (int j = 0; j < plan->num_mles; j++) {
+        if (!mles[j]) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "mle %d is NULL", j); }
+        if (mles[j]->num_vars > n) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "mle %d has %d vars > max_num_vars %d", j, mles[j]->num_vars, n); }
+        sc->mles[j].cur = mles[j]->d;
+        sc->mles[j].cur_ext = mles[j]->is_ext;
+        sc->mles[j].nv = mles[j]->num_vars;
+    }
+    sc->terms.resize(plan->num_terms);
+    for (int t = 0; t < plan->num_terms; t++) {
+        uint32_t b = plan->term_offsets[t], e = plan->term_offsets[t + 1];
+        ScTerm& T = sc->terms[t];
+        T.coeff = E2{plan->term_coeffs[2 * t], plan->term_coeffs[2 * t + 1]};
+        // all factors of a term share num_vars (layer/gpu/utils.rs:54-63); empty products are not sumcheck terms
+        if (e <= b) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d has an empty product", t); }
+        for (uint32_t k = b; k < e; k++) {
+            uint32_t j = plan->term_mle_idx[k];
+            if ((int)j >= plan->num_mles) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d references mle %u", t, j); }
+            T.idx.push_back((int)j);
+        }
+        T.nv = sc->mles[T.idx[0]].nv;
+        for (int j : T.idx)
+            if (sc->mles[j].nv != T.nv) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d mixes MLEs of %d and %d variables", t, T.nv, sc->mles[j].nv); }
+    }
+    // degree check including common factors
+    std::vector<int> term_group(plan->num_terms, -1);
+    for (int g = 0; g < plan->num_groups; g++) {
+        int ncommon = (int)(plan->common_offsets[g + 1] - plan->common_offsets[g]);
+        for (uint32_t k = plan->group_term_offsets[g]; k < plan->group_term_offsets[g + 1]; k++) {
+            uint32_t t = plan->group_term_idx[k];
+            if ((int)t >= plan->num_terms || term_group[t] != -1) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "bad common-term plan (term %u)", t); }
+            term_group[t] = g;
+            if ((int)sc->terms[t].idx.size() + ncommon > d) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %u exceeds max_degree %d", t, d); }
+            for (uint32_t c = plan->common_offsets[g]; c < plan->common_offsets[g + 1]; c++) {
+                uint32_t j = plan->common_mle_idx[c];
+                if ((int)j >= plan->num_mles || sc->mles[j].nv != sc->terms[t].nv) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "group %d common factor / term size mismatch", g); }
+                sc->terms[t].full.push_back((int)j);
+            }
+        }
+    }
+    for (int t = 0; t < plan->num_terms; t++) sc->terms[t].full.insert(sc->terms[t].full.end(), sc->terms[t].idx.begin(), sc->terms[t].idx.end());
+    for (int t = 0; t < plan->num_terms; t++)
+        if (term_group[t] < 0 && (int)sc->terms[t].idx.size() > d) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d exceeds max_degree %d", t, d); }
+
+    // ---- size classes (descending nv); every MLE belongs to the class of its nv ----
+    std::vector<int> nvs;
+    for (auto& M : sc->mles) nvs.push_back(M.nv);
+    std::sort(nvs.begin(), nvs.end(), std::greater<int>());
+    nvs.erase(std::unique(nvs.begin(), nvs.end()), nvs.end());
+    if ((int)nvs.size() > MAX_CLASSES) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "too many distinct sizes"); }
+    sc->classes.resize(nvs.size());
+    for (size_t c = 0; c < nvs.size(); c++) sc->classes[c].nv = nvs[c];
+    auto class_of = [&](int nv) { return (int)(std::find(nvs.begin(), nvs.end(), nv) - nvs.begin()); };
+    for (int j = 0; j < plan->num_mles; j++) {
+        ScClass& cl = sc->classes[class_of(sc->mles[j].nv)];
+        sc->mles[j].cls = (int)(&cl - sc->classes.data());
+        sc->mles[j].local = (int)cl.mles.size();
+        cl.mles.push_back(j);
+    }
+    for (int t = 0; t < plan->num_terms; t++) sc->classes[class_of(sc->terms[t].nv)].terms.push_back(t);
+
+    // ---- working buffers per MLE ----
+    for (auto& M : sc->mles) {
+        if (M.nv >= 1) {
+            void* p = nullptr;
+            int rc = ctx_alloc(ctx, ((size_t)1 << (M.nv - 1)) * sizeof(E2), &p);
+            if (rc) { sc_release(sc); return rc; }
+            sc->dev_allocs.push_back(p);
+            M.buf[0] = (uint64_t*)p;
+        }
+        if (M.nv >= 2) {
+            void* p = nullptr;
+            int rc = ctx_alloc(ctx, ((size_t)1 << (M.nv - 2)) * sizeof(E2), &p);
+            if (rc) { sc_release(sc); return rc; }
+            sc->dev_allocs.push_back(p);
+            M.buf[1] = (uint64_t*)p;
+        }
+    }
+
+    // ---- per-class plans ----
+    uint32_t part_off = 0;
+    size_t total_slots = 0;
+    for (auto& cl : sc->classes) {
+        total_slots += cl.mles.size();
+        cl.part_off = part_off;
+        part_off += MAXB * MAXD;
+        // dense: exactly one term, not grouped, K == d <= MAXK, distinct MLEs, every MLE of the class used, one element kind
+        cl.dense = false;
+        if (cl.terms.size() == 1 && term_group[cl.terms[0]] < 0) {
+            const ScTerm& T = sc->terms[cl.terms[0]];
+            bool ok = (int)T.idx.size() == d && d <= MAXK && T.idx.size() == cl.mles.size();
+            std::vector<int> s = T.idx;
+            std::sort(s.begin(), s.end());
+            ok = ok && std::unique(s.begin(), s.end()) == s.end();
+            for (int j : T.idx) ok = ok && sc->mles[j].cur_ext == sc->mles[T.idx[0]].cur_ext;
+            cl.dense = ok;
+        }
+        if (cl.dense || cl.terms.empty()) {
+            // terms-less classes still need slots to fold their MLEs
+        }
+        // generic device plan with class-local MLE ids
+        std::vector<uint32_t> g_term_off{0}, g_terms, c_off{0}, c_idx, t_off{0}, t_idx;
+        std::vector<E2> coeffs;
+        std::map<int, int> local_term;  // global term -> class-local term id
+        for (int t : cl.terms) {
+            local_term[t] = (int)coeffs.size();
+            coeffs.push_back(sc->terms[t].coeff);
+            for (int j : sc->terms[t].idx) t_idx.push_back((uint32_t)sc->mles[j].local);
+            t_off.push_back((uint32_t)t_idx.size());
+        }
+        // groups of this class first, then every ungrouped term as its own group without common factors
+        for (int g = 0; g < plan->num_groups; g++) {
+            uint32_t b = plan->group_term_offsets[g], e = plan->group_term_offsets[g + 1];
+            if (e <= b || sc->terms[plan->group_term_idx[b]].nv != cl.nv) continue;
+            for (uint32_t k = b; k < e; k++) g_terms.push_back((uint32_t)local_term[(int)plan->group_term_idx[k]]);
+            g_term_off.push_back((uint32_t)g_terms.size());
+            for (uint32_t c = plan->common_offsets[g]; c < plan->common_offsets[g + 1]; c++) c_idx.push_back((uint32_t)sc->mles[plan->common_mle_idx[c]].local);
+            c_off.push_back((uint32_t)c_idx.size());
+        }
+        bool any_free = false;
+        for (int t : cl.terms)
+            if (term_group[t] < 0) { g_terms.push_back((uint32_t)local_term[t]); any_free = true; }
+        if (any_free) {
+            g_term_off.push_back((uint32_t)g_terms.size());
+            c_off.push_back((uint32_t)c_idx.size());
+        }
+        cl.n_groups = (int)g_term_off.size() - 1;
+        int rc = 0;
+        rc = rc ? rc : upload_vec(sc, g_term_off, &cl.d_group_term_off);
+        rc = rc ? rc : upload_vec(sc, g_terms, &cl.d_group_terms);
+        rc = rc ? rc : upload_vec(sc, c_off, &cl.d_common_off);
+        rc = rc ? rc : upload_vec(sc, c_idx, &cl.d_common_idx);
+        rc = rc ? rc : upload_vec(sc, t_off, &cl.d_term_off);
+        rc = rc ? rc : upload_vec(sc, t_idx, &cl.d_term_idx);
+        rc = rc ? rc : upload_vec(sc, coeffs, &cl.d_coeffs);
+        if (!rc) {
+            void* p = nullptr;
+            rc = ctx_alloc(ctx, std::max<size_t>(cl.mles.size(), 1) * sizeof(MleSlot) * (size_t)(n + 2), &p);
+            if (!rc) { sc->dev_allocs.push_back(p); cl.d_slots = (MleSlot*)p; }
+        }
+        if (rc) { sc_release(sc); return rc; }
+    }
+    sc->slots_per_round = total_slots;
+    {
+        void* p = nullptr;
+        int rc = ctx_alloc(ctx, (size_t)part_off * sizeof(E2), &p);
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_partials = (E2*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_msg = (E2*)p; rc = ctx_alloc(ctx, (size_t)plan->num_mles * sizeof(E2), &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; }
+        if (rc) { sc_release(sc); return rc; }
+    }
+    hipError_t e = hipHostMalloc((void**)&sc->h_pinned, (MAXD + (size_t)plan->num_mles) * sizeof(E2), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_slots, std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2), hipHostMallocDefault);
+    if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+
+    // zero-variable MLEs are already scalars: fetch their values
+    for (auto& M : sc->mles) {
+        if (M.nv == 0) {
+            uint64_t h[2] = {0, 0};
+            e = hipMemcpyAsync(h, M.cur, M.cur_ext ? 16 : 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "begin: %s", hipGetErrorString(e)); }
+            M.eval = E2{h[0], M.cur_ext ? h[1] : 0};
+            M.done = true;
+        }
+    }
+    e = hipStreamSynchronize(st);  // plan uploads borrowed host vectors
+    if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "begin: %s", hipGetErrorString(e)); }
+    *out = sc;
+    return 0;
+}
+
+// write this round's slot table of class `cl` (device copy queued on the stream); returns device ptr
+static int sc_push_slots(ceno_hip_sumcheck* sc, ScClass& cl, int slot_round, size_t& h_cursor, const MleSlot** d_out) {
+    MleSlot* h = sc->h_slots + (size_t)slot_round * sc->slots_per_round + h_cursor;
+    for (size_t k = 0; k < cl.mles.size(); k++) {
+        ScMle& M = sc->mles[cl.mles[k]];
+        h[k].in = M.cur;
+        h[k].out = M.buf[M.which];
+        h[k].in_ext = M.cur_ext;
+        h[k].pad = 0;
+    }
+    MleSlot* d = cl.d_slots + (size_t)slot_round * std::max<size_t>(cl.mles.size(), 1);
+    HIP_TRY(sc->ctx, hipMemcpyAsync(d, h, cl.mles.size() * sizeof(MleSlot), hipMemcpyHostToDevice, sc->st));
+    h_cursor += cl.mles.size();
+    *d_out = d;
+    return 0;
+}
+
+static void sc_advance(ceno_hip_sumcheck* sc, ScClass& cl) {
+    for (int j : cl.mles) {
+        ScMle& M = sc->mles[j];
+        M.cur = M.buf[M.which];
+        M.cur_ext = 1;
+        M.which ^= 1;
+    }
+}
+
+// one round; out goes to host (h_out != NULL, synchronises) or to device memory d_out
+static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* h_out, uint64_t* d_out) {
+    ceno_hip_ctx* ctx = sc->ctx;
+    if (sc->finished || sc->round >= sc->n) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: all %d rounds already produced", sc->n);
+    const int i = sc->round;
+    if (i > 0 && !challenge2) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "sumcheck round %d needs the challenge of round %d", i, i - 1);
+    if (i == 0 && challenge2) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "sumcheck round 0 takes no challenge");
+    const E2 r = i > 0 ? E2{challenge2[0], challenge2[1]} : e2_zero();
+    const int d = sc->d;
+    ReduceArgs ra{};
+    ra.d = d;
+    size_t h_cursor = 0;
+    std::vector<ScClass*> became_scalar;
+    for (auto& cl : sc->classes) {
+        double bytes = 0.0;
+        if (cl.nv < i) {
+            for (int j : cl.mles) sc->mles[j].tail = sc->mles[j].tail * r;  // exhausted earlier
+            continue;
+        }
+        if (cl.nv == i) {
+            if (i == 0) continue;  // zero-variable class: already scalars
+            // last real variable of this class: fold 2 -> 1
+            const MleSlot* d_slots = nullptr;
+            TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
+            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r);
+            hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
+                               sc->d_evals);
+            became_scalar.push_back(&cl);
+            continue;
+        }
+        // live class
+        const size_t pairs = (size_t)1 << (cl.nv - i - 1);
+        const unsigned grid = sc_grid(pairs);
+        const int c = ra.n_classes++;
+        ra.off[c] = cl.part_off;
+        ra.cnt[c] = grid;
+        ra.coeff[c] = e2_one();
+        const size_t esz_in = 16;
+        if (cl.dense) {
+            const ScTerm& T = sc->terms[cl.terms[0]];
+            const int K = (int)T.idx.size();
+            const bool base_in = !sc->mles[T.idx[0]].cur_ext;
+            const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
+            ra.stride[c] = (uint32_t)K;
+            ra.coeff[c] = T.coeff;
+            prof_begin(ctx, sc->st);
+            switch (K) {
+            case 1: launch_dense<1>(sc, cl, mode, pairs, r, grid); break;
+            case 2: launch_dense<2>(sc, cl, mode, pairs, r, grid); break;
+            case 3: launch_dense<3>(sc, cl, mode, pairs, r, grid); break;
+            default: launch_dense<4>(sc, cl, mode, pairs, r, grid); break;
+            }
+            const double in_el = base_in ? 8.0 : (double)esz_in;
+            if (i == 0) bytes += (double)K * 2.0 * pairs * in_el;
+            else bytes += (double)K * (4.0 * pairs * in_el + 2.0 * pairs * 16.0);
+            prof_end(ctx, sc->st, bytes);
+            if (i > 0) sc_advance(sc, cl);
+        } else {
+            const MleSlot* d_slots = nullptr;
+            TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
+            prof_begin(ctx, sc->st);
+            if (i > 0) {
+                hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots,
+                                   2 * pairs, r);
+            }
+            ra.stride[c] = (uint32_t)d;
+            if (!cl.terms.empty()) {
+                DevPlan pl;
+                pl.slots = d_slots;
+                pl.use_out = i > 0 ? 1 : 0;
+                pl.n_groups = cl.n_groups;
+                pl.group_term_off = cl.d_group_term_off;
+                pl.group_terms = cl.d_group_terms;
+                pl.common_off = cl.d_common_off;
+                pl.common_idx = cl.d_common_idx;
+                pl.coeffs = cl.d_coeffs;
+                pl.term_off = cl.d_term_off;
+                pl.term_idx = cl.d_term_idx;
+                launch_accum(d, pl, pairs, sc->d_partials + cl.part_off, grid, sc->st);
+            } else {
+                ra.n_classes--;  // nothing to accumulate for a class no term references
+            }
+            for (int j : cl.mles) {
+                const double in_el = sc->mles[j].cur_ext ? 16.0 : 8.0;
+                if (i == 0) bytes += 2.0 * pairs * in_el;
+                else bytes += 4.0 * pairs * in_el + 2.0 * pairs * 16.0;
+            }
+            prof_end(ctx, sc->st, bytes);
+            if (i > 0) sc_advance(sc, cl);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // classes that just became scalars: fetch their evaluations (needed for this round's message)
+    if (!became_scalar.empty()) {
+        E2* h_ev = sc->h_pinned + MAXD;
+        for (ScClass* cl : became_scalar)
+            HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl->mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        for (ScClass* cl : became_scalar) {
+            // at most one class reaches its last variable per round; evaluations are in class-local order
+            for (size_t k = 0; k < cl->mles.size(); k++) {
+                ScMle& M = sc->mles[cl->mles[k]];
+                M.eval = h_ev[k];
+                M.done = true;
+                M.cur = M.buf[M.which];
+                M.cur_ext = 1;
+            }
+        }
+    }
+    // scalar (front-loaded) contributions: c_t * prod_j (eval_j * tail_j * t)   (scheme/verifier.rs:233-237)
+    for (auto& cl : sc->classes) {
+        if (cl.nv > i) continue;
+        for (int t : cl.terms) {
+            const ScTerm& T = sc->terms[t];
+            for (int x = 0; x < d; x++) {
+                E2 pr = T.coeff;
+                const uint64_t tt = (uint64_t)(x + 1);
+                for (int j : T.full) pr = pr * e2_mul_base(sc->mles[j].eval * sc->mles[j].tail, tt);
+                ra.scalars[x] = ra.scalars[x] + pr;
+            }
+        }
+    }
+    // common-factor groups whose class is exhausted are covered above because group membership only
+    // affects how live classes are evaluated: a grouped term's full product = common * residual.
+    E2* target = d_out ? reinterpret_cast<E2*>(d_out) : sc->d_msg;
+    hipLaunchKernelGGL(k_reduce_msg, dim3(1), dim3(NT), 0, sc->st, sc->d_partials, ra, target);
+    HIP_TRY(ctx, hipGetLastError());
+    if (h_out) {
+        HIP_TRY(ctx, hipMemcpyAsync(sc->h_pinned, sc->d_msg, (size_t)d * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        memcpy(h_out, sc->h_pinned, (size_t)d * sizeof(E2));
+    }
+    sc->round++;
+    return 0;
+}
+
+extern "C" {
+
+int ceno_hip_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, ceno_hip_stream s,
+                            ceno_hip_sumcheck** out) {
+    return sc_build(ctx, mles, plan, ctx_stream(ctx, s), out);
+}
+
+int ceno_hip_sumcheck_round(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* out_evals) {
+    CHECK_ARG(ctx, sc && out_evals, "NULL argument");
+    return sc_round(sc, challenge2, out_evals, nullptr);
+}
+
+int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* dev_out_evals) {
+    CHECK_ARG(ctx, sc && dev_out_evals, "NULL argument");
+    return sc_round(sc, challenge2, nullptr, dev_out_evals);
+}
+
+int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals) {
+    CHECK_ARG(ctx, sc && final_evals, "NULL argument");
+    if (sc->finished) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck already finished");
+    if (sc->round != sc->n) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck finish after %d of %d rounds", sc->round, sc->n);
+    if (sc->n > 0) {
+        CHECK_ARG(ctx, last_challenge2, "last challenge is NULL");
+        const E2 r{last_challenge2[0], last_challenge2[1]};
+        size_t h_cursor = 0;
+        for (auto& cl : sc->classes) {
+            if (cl.nv != sc->n) continue;
+            const MleSlot* d_slots = nullptr;
+            TRY(sc_push_slots(sc, cl, sc->n + 1, h_cursor, &d_slots));
+            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r);
+            hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
+                               sc->d_evals);
+            HIP_TRY(ctx, hipGetLastError());
+            E2* h_ev = sc->h_pinned + MAXD;
+            HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl.mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+            HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+            for (size_t k = 0; k < cl.mles.size(); k++) {
+                ScMle& M = sc->mles[cl.mles[k]];
+                M.eval = h_ev[k];
+                M.done = true;
+            }
+        }
+    }
+    for (size_t j = 0; j < sc->mles.size(); j++) {
+        final_evals[2 * j] = sc->mles[j].eval.c0;
+        final_evals[2 * j + 1] = sc->mles[j].eval.c1;
+    }
+    sc->finished = true;
+    return 0;
+}
+
+int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc) { return sc ? sc->round : -1; }
+
+int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc) {
+    (void)ctx;
+    sc_release(sc);
+    return 0;
+}
+
+}  // extern "C"
+
+// used by tower.hip: attach an MLE whose lifetime is tied to the sumcheck handle
+void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m) { sc->extra_owned = m; }

@@ -1,0 +1,383 @@
+// Tower (grand-product / LogUp) witness construction on gfx950.
+//
+// Reference semantics: `interleaving_mles_to_mles` (ceno_zkvm/src/scheme/utils.rs:402-462),
+// `infer_tower_product_witness` (:588-659), `infer_tower_logup_witness` (:488-582, tower_mle_4 :464-479);
+// GPU call sites `build_prod_tower_from_virtual_ext_batch` / `build_logup_tower_from_virtual_ext_batch`
+// and `GpuProverSpec::get_output_evals` (ceno_zkvm/src/scheme/gpu/mod.rs:2365-2402,379-410).
+// Layer l of a tower holds 2 (product) or 4 (p1,p2,q1,q2) limbs of 2^l extension elements; limb s of
+// layer l is computed from the s-th half of the limbs of layer l+1.  All kernels are element-wise
+// streams: 48 B of traffic per product -> HBM bound.
+#include "common.hpp"
+
+#include <algorithm>
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr unsigned MAXB = 2048;
+static constexpr int MAX_REC = 64;
+
+struct ceno_hip_tower {
+    int num_vars = 0;   // number of layers
+    int n_limbs = 2;    // 2 = product, 4 = logup
+    std::vector<E2*> layers;  // layers[l] -> n_limbs * 2^l elements, limb-major
+};
+
+struct RecArg {
+    const uint64_t* ptr[MAX_REC];
+    uint32_t cnt0[MAX_REC];  // rows available for limb 0
+    uint32_t cnt1[MAX_REC];  // rows available for limb 1
+    uint8_t is_ext[MAX_REC];
+    int k;
+    int log_s;              // per-instance slot count = 2^log_s
+    uint64_t start1;        // first source row of limb 1 (= per_fanin_len)
+    E2 dflt;
+    int ones;               // 1: no records, fill both limbs with `dflt`
+};
+
+// out[limb][i * S + j] = rec_j[start_limb + i]  (or default)
+__global__ void __launch_bounds__(NT) k_interleave(RecArg ra, E2* __restrict__ out0, E2* __restrict__ out1, size_t out_len) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    const size_t smask = ((size_t)1 << ra.log_s) - 1;
+    for (size_t o = (size_t)blockIdx.x * NT + threadIdx.x; o < 2 * out_len; o += stride) {
+        const int limb = o >= out_len;
+        const size_t x = limb ? o - out_len : o;
+        const size_t i = x >> ra.log_s;
+        const int j = (int)(x & smask);
+        E2 v = ra.dflt;
+        if (!ra.ones && j < ra.k) {
+            const uint32_t cnt = limb ? ra.cnt1[j] : ra.cnt0[j];
+            if (i < cnt) {
+                const size_t src = (limb ? ra.start1 : 0) + i;
+                if (ra.is_ext[j]) v = reinterpret_cast<const E2*>(ra.ptr[j])[src];
+                else v = E2{ra.ptr[j][src], 0};
+            }
+        }
+        (limb ? out1 : out0)[x] = v;
+    }
+}
+
+// product layer: out[s*half + j] = a[s*half + j] * b[s*half + j], a/b = limbs of the layer below (len 2*half)
+__global__ void __launch_bounds__(NT) k_prod_layer(const E2* __restrict__ below, E2* __restrict__ out, size_t len_below) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    const E2* a = below;
+    const E2* b = below + len_below;
+    // out limbs are contiguous: out[0..half) = limb 0, out[half..2*half) = limb 1 ; index x = s*half + j
+    for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len_below; x += stride) out[x] = a[x] * b[x];
+}
+
+// logup layer: (p, q) <- (q1 p2 + q2 p1, q1 q2); `below` = [p1|p2|q1|q2] each len_below; out = [p1|p2|q1|q2] each len_below/2
+__global__ void __launch_bounds__(NT) k_logup_layer(const E2* __restrict__ below, E2* __restrict__ out, size_t len_below) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    const E2* p1 = below;
+    const E2* p2 = below + len_below;
+    const E2* q1 = below + 2 * len_below;
+    const E2* q2 = below + 3 * len_below;
+    // out p limbs: indices [0, len_below) cover p1|p2 (index x = s*half + j) ; q limbs follow
+    for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len_below; x += stride) {
+        E2 a = q1[x], b = q2[x];
+        out[x] = a * p2[x] + b * p1[x];
+        out[len_below + x] = a * b;
+    }
+}
+
+static int ceil_log2_sz(size_t x) {
+    int l = 0;
+    while (((size_t)1 << l) < x) l++;
+    return l;
+}
+static size_t next_pow2_instance_padding(size_t n) {  // ceno_zkvm/src/scheme/hal.rs:127-128
+    size_t p = 1;
+    while (p < n) p <<= 1;
+    return p < 2 ? 2 : p;
+}
+
+static void tower_release(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
+    if (!t) return;
+    for (E2* p : t->layers) ctx_free(ctx, p);
+    delete t;
+}
+
+static int tower_alloc(ceno_hip_ctx* ctx, int num_vars, int n_limbs, ceno_hip_tower** out) {
+    auto* t = new ceno_hip_tower();
+    t->num_vars = num_vars;
+    t->n_limbs = n_limbs;
+    t->layers.assign(num_vars, nullptr);
+    for (int l = 0; l < num_vars; l++) {
+        void* p = nullptr;
+        int rc = ctx_alloc(ctx, ((size_t)n_limbs << l) * sizeof(E2), &p);
+        if (rc) {
+            tower_release(ctx, t);
+            return rc;
+        }
+        t->layers[l] = (E2*)p;
+    }
+    *out = t;
+    return 0;
+}
+
+static int tower_build_upper(ceno_hip_ctx* ctx, ceno_hip_tower* t, hipStream_t st) {
+    for (int l = t->num_vars - 2; l >= 0; l--) {
+        size_t len_below = (size_t)1 << (l + 1);
+        unsigned g = grid_for(len_below, NT, MAXB);
+        if (t->n_limbs == 2) hipLaunchKernelGGL(k_prod_layer, dim3(g), dim3(NT), 0, st, t->layers[l + 1], t->layers[l], len_below);
+        else hipLaunchKernelGGL(k_logup_layer, dim3(g), dim3(NT), 0, st, t->layers[l + 1], t->layers[l], len_below);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+// fill RecArg following interleaving_mles_to_mles (utils.rs:410-457) for num_limbs = 2
+static int make_rec_arg(ceno_hip_ctx* ctx, ceno_hip_mle* const* recs, int k, size_t num_instances, E2 dflt, RecArg& ra, size_t& out_len) {
+    CHECK_ARG(ctx, k >= 1 && k <= MAX_REC, "tower: %d records unsupported (1..%d)", k, MAX_REC);
+    const size_t np2 = next_pow2_instance_padding(num_instances);
+    for (int j = 0; j < k; j++) {
+        CHECK_ARG(ctx, recs[j], "tower: record %d is NULL", j);
+        CHECK_ARG(ctx, recs[j]->len() <= np2, "tower: record %d longer than padded instance count", j);
+    }
+    const int log2_num_instances = ceil_log2_sz(np2);
+    const size_t mle0_len = recs[0]->len();
+    const size_t per_fanin_len = std::max<size_t>(mle0_len / 2, 1);
+    const int log_s = ceil_log2_sz((size_t)k);
+    out_len = (size_t)1 << (log_s + std::max(log2_num_instances - 1, 0));
+    const size_t n_chunks = out_len >> log_s;
+    ra.k = k;
+    ra.log_s = log_s;
+    ra.start1 = per_fanin_len;
+    ra.dflt = dflt;
+    ra.ones = 0;
+    for (int limb = 0; limb < 2; limb++) {
+        const size_t start = per_fanin_len * (size_t)limb;
+        for (int j = 0; j < k; j++) {
+            size_t cnt = 0;
+            if (start < num_instances) {
+                const size_t valid = std::min(per_fanin_len, num_instances - start);
+                // Ext arm slices start..start+valid, Base arm start..start+per_fanin_len; `.get(range)` is
+                // empty when the range exceeds the vector (utils.rs:436-455)
+                cnt = recs[j]->is_ext ? valid : per_fanin_len;
+                if (start + cnt > recs[j]->len()) cnt = 0;
+                cnt = std::min(cnt, n_chunks);
+            }
+            (limb ? ra.cnt1 : ra.cnt0)[j] = (uint32_t)cnt;
+        }
+    }
+    for (int j = 0; j < k; j++) {
+        ra.ptr[j] = recs[j]->d;
+        ra.is_ext[j] = (uint8_t)recs[j]->is_ext;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int ceno_hip_tower_build_prod(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, int k, size_t num_instances, const uint64_t* default2,
+                              ceno_hip_stream s, ceno_hip_tower** out) {
+    CHECK_ARG(ctx, records && default2 && out, "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    RecArg ra{};
+    size_t out_len = 0;
+    TRY(make_rec_arg(ctx, records, k, num_instances, E2{default2[0], default2[1]}, ra, out_len));
+    const int num_vars = ceil_log2_sz(out_len) + 1;
+    ceno_hip_tower* t = nullptr;
+    TRY(tower_alloc(ctx, num_vars, 2, &t));
+    E2* last = t->layers[num_vars - 1];
+    hipLaunchKernelGGL(k_interleave, dim3(grid_for(2 * out_len, NT, MAXB)), dim3(NT), 0, st, ra, last, last + out_len, out_len);
+    int rc = tower_build_upper(ctx, t, st);
+    if (rc) {
+        tower_release(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+int ceno_hip_tower_build_logup(ceno_hip_ctx* ctx, ceno_hip_mle* const* p_records, ceno_hip_mle* const* q_records, int k,
+                               size_t num_instances, const uint64_t* default2, ceno_hip_stream s, ceno_hip_tower** out) {
+    CHECK_ARG(ctx, q_records && default2 && out, "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    RecArg rq{};
+    size_t out_len = 0;
+    const E2 dflt{default2[0], default2[1]};
+    TRY(make_rec_arg(ctx, q_records, k, num_instances, dflt, rq, out_len));
+    const int num_vars = ceil_log2_sz(out_len) + 1;
+    ceno_hip_tower* t = nullptr;
+    TRY(tower_alloc(ctx, num_vars, 4, &t));
+    E2* last = t->layers[num_vars - 1];
+    unsigned g = grid_for(2 * out_len, NT, MAXB);
+    if (p_records) {
+        RecArg rp{};
+        size_t pl = 0;
+        int rc = make_rec_arg(ctx, p_records, k, num_instances, dflt, rp, pl);
+        if (rc || pl != out_len) {
+            tower_release(ctx, t);
+            return rc ? rc : ctx_fail(ctx, CENO_HIP_ERR_INVALID, "logup numerator / denominator shapes differ");
+        }
+        hipLaunchKernelGGL(k_interleave, dim3(g), dim3(NT), 0, st, rp, last, last + out_len, out_len);
+    } else {
+        // numerators absent: the input layer's p limbs are all ONE (utils.rs:558-579)
+        RecArg rp{};
+        rp.ones = 1;
+        rp.dflt = e2_one();
+        rp.log_s = 0;
+        hipLaunchKernelGGL(k_interleave, dim3(g), dim3(NT), 0, st, rp, last, last + out_len, out_len);
+    }
+    hipLaunchKernelGGL(k_interleave, dim3(g), dim3(NT), 0, st, rq, last + 2 * out_len, last + 3 * out_len, out_len);
+    int rc = tower_build_upper(ctx, t, st);
+    if (rc) {
+        tower_release(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+int ceno_hip_tower_from_last_layer(ceno_hip_ctx* ctx, ceno_hip_mle* const* limbs, int n_limbs, ceno_hip_stream s, ceno_hip_tower** out) {
+    CHECK_ARG(ctx, limbs && out && (n_limbs == 2 || n_limbs == 4), "tower: n_limbs must be 2 or 4");
+    hipStream_t st = ctx_stream(ctx, s);
+    // logup with absent numerators: limbs[0], limbs[1] may be NULL
+    const ceno_hip_mle* ref = limbs[n_limbs - 1];
+    CHECK_ARG(ctx, ref, "tower: last limb is NULL");
+    for (int i = 0; i < n_limbs; i++) {
+        if (!limbs[i]) {
+            CHECK_ARG(ctx, n_limbs == 4 && i < 2, "tower: limb %d is NULL", i);
+            continue;
+        }
+        CHECK_ARG(ctx, limbs[i]->is_ext && limbs[i]->num_vars == ref->num_vars, "tower: limbs must be ext tables of one size");
+    }
+    const int num_vars = ref->num_vars + 1;
+    ceno_hip_tower* t = nullptr;
+    TRY(tower_alloc(ctx, num_vars, n_limbs, &t));
+    const size_t len = ref->len();
+    E2* last = t->layers[num_vars - 1];
+    for (int i = 0; i < n_limbs; i++) {
+        if (limbs[i]) {
+            hipError_t e = hipMemcpyAsync(last + (size_t)i * len, limbs[i]->d, len * sizeof(E2), hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) {
+                tower_release(ctx, t);
+                return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower copy: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    if (n_limbs == 4 && (!limbs[0] || !limbs[1])) {
+        RecArg rp{};
+        rp.ones = 1;
+        rp.dflt = e2_one();
+        hipLaunchKernelGGL(k_interleave, dim3(grid_for(2 * len, NT, MAXB)), dim3(NT), 0, st, rp, last, last + len, len);
+    }
+    int rc = tower_build_upper(ctx, t, st);
+    if (rc) {
+        tower_release(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+int ceno_hip_tower_num_vars(const ceno_hip_tower* t) { return t ? t->num_vars : -1; }
+int ceno_hip_tower_num_limbs(const ceno_hip_tower* t) { return t ? t->n_limbs : -1; }
+
+int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int limb, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, t && out, "NULL argument");
+    CHECK_ARG(ctx, layer >= 0 && layer < t->num_vars && limb >= 0 && limb < t->n_limbs, "tower layer/limb out of range");
+    return ceno_hip_mle_wrap(ctx, reinterpret_cast<uint64_t*>(t->layers[layer] + ((size_t)limb << layer)), layer, 1, out);
+}
+
+int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out, ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && out, "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    HIP_TRY(ctx, hipMemcpyAsync(out, t->layers[0], (size_t)t->n_limbs * sizeof(E2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
+    tower_release(ctx, t);
+    return 0;
+}
+
+// defined in sumcheck.hip
+}  // extern "C"
+
+void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m);
+
+extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup,
+                                                   int n_logup, int layer, const uint64_t* out_rt, const uint64_t* alpha_pows,
+                                                   ceno_hip_stream s, ceno_hip_sumcheck** out) {
+    CHECK_ARG(ctx, out && out_rt && alpha_pows && layer >= 1, "tower layer sumcheck: bad arguments");
+    CHECK_ARG(ctx, (n_prod == 0 || prod) && (n_logup == 0 || logup), "NULL tower list");
+    // sum_x eq(x, out_rt) * [ sum_i alpha_i a_i b_i + sum_k (alpha_n (p1 q2 + p2 q1) + alpha_d q1 q2) ]
+    // -> one common-factor group (eq) over all residual terms  (scheme/cpu/mod.rs:417-494)
+    ceno_hip_mle* eq = nullptr;
+    TRY(ceno_hip_eq_build(ctx, out_rt, layer, nullptr, s, &eq));
+    std::vector<ceno_hip_mle*> mles{eq};
+    std::vector<ceno_hip_mle*> views;
+    std::vector<uint64_t> coeffs;
+    std::vector<uint32_t> toff{0}, tidx, gterms;
+    auto cleanup = [&]() {
+        for (auto* v : views) ceno_hip_mle_free(ctx, v);
+    };
+    auto add_term = [&](const uint64_t* c, std::initializer_list<uint32_t> f) {
+        coeffs.push_back(c[0]);
+        coeffs.push_back(c[1]);
+        for (uint32_t x : f) tidx.push_back(x);
+        gterms.push_back((uint32_t)toff.size() - 1);
+        toff.push_back((uint32_t)tidx.size());
+    };
+    int rc = 0;
+    for (int i = 0; i < n_prod && !rc; i++) {
+        if (!prod[i] || prod[i]->n_limbs != 2) { rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "prod tower %d invalid", i); break; }
+        if (prod[i]->num_vars <= layer) continue;  // spec has no layer `layer`
+        uint32_t base = (uint32_t)mles.size();
+        for (int l = 0; l < 2 && !rc; l++) {
+            ceno_hip_mle* v = nullptr;
+            rc = ceno_hip_tower_layer(ctx, prod[i], layer, l, &v);
+            if (!rc) { views.push_back(v); mles.push_back(v); }
+        }
+        if (!rc) add_term(alpha_pows + 2 * i, {base, base + 1});
+    }
+    for (int i = 0; i < n_logup && !rc; i++) {
+        if (!logup[i] || logup[i]->n_limbs != 4) { rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "logup tower %d invalid", i); break; }
+        if (logup[i]->num_vars <= layer) continue;
+        uint32_t base = (uint32_t)mles.size();
+        for (int l = 0; l < 4 && !rc; l++) {
+            ceno_hip_mle* v = nullptr;
+            rc = ceno_hip_tower_layer(ctx, logup[i], layer, l, &v);
+            if (!rc) { views.push_back(v); mles.push_back(v); }
+        }
+        if (rc) break;
+        const uint64_t* an = alpha_pows + 2 * (n_prod + 2 * i);
+        const uint64_t* ad = alpha_pows + 2 * (n_prod + 2 * i + 1);
+        uint32_t p1 = base, p2 = base + 1, q1 = base + 2, q2 = base + 3;
+        add_term(an, {p1, q2});
+        add_term(an, {p2, q1});
+        add_term(ad, {q1, q2});
+    }
+    if (!rc && toff.size() == 1) rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "no tower has layer %d", layer);
+    if (rc) {
+        cleanup();
+        ceno_hip_mle_free(ctx, eq);
+        return rc;
+    }
+    std::vector<uint32_t> goff{0, (uint32_t)gterms.size()}, coff{0, 1}, cidx{0};
+    ceno_hip_sumcheck_plan plan{};
+    plan.num_mles = (int)mles.size();
+    plan.num_terms = (int)toff.size() - 1;
+    plan.term_coeffs = coeffs.data();
+    plan.term_offsets = toff.data();
+    plan.term_mle_idx = tidx.data();
+    plan.num_groups = 1;
+    plan.group_term_offsets = goff.data();
+    plan.group_term_idx = gterms.data();
+    plan.common_offsets = coff.data();
+    plan.common_mle_idx = cidx.data();
+    plan.max_num_vars = layer;
+    plan.max_degree = 3;
+    rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, out);
+    cleanup();  // views are borrowed wrappers; the sumcheck copied the pointers
+    if (rc) {
+        ceno_hip_mle_free(ctx, eq);
+        return rc;
+    }
+    sumcheck_adopt_mle(*out, eq);  // eq lives as long as the sumcheck
+    return 0;
+}

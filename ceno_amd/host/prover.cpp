@@ -1,0 +1,220 @@
+// Host layer above the device C ABI: the reference's prover control flow for the hot path,
+// restated in C++ (the reference is Rust; see include/ceno_prover.h).
+//
+//   ceno_prover_sumcheck_prove       IOPProverState::prove (EXT sumcheck); transcript script per
+//                                    ceno_recursion_v2/src/main/mod.rs:3503-3529
+//   ceno_prover_tower_create_proof   CpuTowerProver::create_proof, ceno_zkvm/src/scheme/cpu/mod.rs:346-554
+//   ceno_prover_prove_tower_relation TowerProver::prove_tower_relation, scheme/cpu/mod.rs:765-797
+#include "../../include/ceno_prover.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../csrc/gl64.cuh"
+#include "transcript.hpp"
+
+using gl::E2;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+static int fail_from_ctx(ceno_hip_ctx* ctx, int code) {
+    const char* m = ceno_hip_last_error(ctx);
+    g_err = m ? m : "";
+    return code;
+}
+
+extern "C" const char* ceno_prover_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// transcript helpers (same call shapes as the reference's Transcript trait)
+// ------------------------------------------------------------------------------------------------
+static void tr_label(ceno_transcript* t, const char* s) { t->append_label(t->self, (const uint8_t*)s, strlen(s)); }
+static void tr_usize(ceno_transcript* t, uint64_t v) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));  // usize::to_le_bytes
+    t->append_label(t->self, b, 8);
+}
+static void tr_ext(ceno_transcript* t, const uint64_t* e) { t->append_ext(t->self, e); }
+static E2 tr_sample(ceno_transcript* t) {
+    uint64_t o[2];
+    t->sample_ext(t->self, o);
+    return E2{o[0], o[1]};
+}
+// get_challenge_pows(size, transcript): label b"combine subset evals", one sample, [1, a, a^2, ...]
+static void tr_challenge_pows(ceno_transcript* t, int n, std::vector<uint64_t>& out) {
+    tr_label(t, "combine subset evals");
+    E2 a = tr_sample(t), acc = gl::e2_one();
+    out.resize((size_t)2 * (n > 0 ? n : 0));
+    for (int i = 0; i < n; i++) {
+        out[2 * i] = acc.c0;
+        out[2 * i + 1] = acc.c1;
+        acc = acc * a;
+    }
+}
+
+extern "C" {
+
+void ceno_transcript_append_label(ceno_transcript* t, const uint8_t* bytes, size_t n) { t->append_label(t->self, bytes, n); }
+void ceno_transcript_append_ext(ceno_transcript* t, const uint64_t* e2) { t->append_ext(t->self, e2); }
+void ceno_transcript_sample_ext(ceno_transcript* t, uint64_t* out2) { t->sample_ext(t->self, out2); }
+void ceno_transcript_free(ceno_transcript* t) {
+    if (!t) return;
+    if (t->destroy) t->destroy(t->self);
+    delete t;
+}
+
+int ceno_prover_sumcheck_run(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, int d, int num_mles, ceno_transcript* tr,
+                             uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
+    (void)num_mles;
+    if (!ctx || !sc || !tr || !out_msgs || !out_challenges || !out_final_evals) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
+    tr_usize(tr, (uint64_t)n);
+    tr_usize(tr, (uint64_t)d);
+    uint64_t ch[2] = {0, 0};
+    for (int round = 0; round < n; round++) {
+        uint64_t* msg = out_msgs + (size_t)2 * d * round;
+        int rc = ceno_hip_sumcheck_round(ctx, sc, round == 0 ? nullptr : ch, msg);
+        if (rc) return fail_from_ctx(ctx, rc);
+        for (int t = 0; t < d; t++) tr_ext(tr, msg + 2 * t);
+        tr_label(tr, "Internal round");
+        E2 r = tr_sample(tr);
+        ch[0] = r.c0;
+        ch[1] = r.c1;
+        out_challenges[2 * round] = r.c0;
+        out_challenges[2 * round + 1] = r.c1;
+    }
+    int rc = ceno_hip_sumcheck_finish(ctx, sc, n > 0 ? ch : nullptr, out_final_evals);
+    if (rc) return fail_from_ctx(ctx, rc);
+    return 0;
+}
+
+int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, ceno_transcript* tr,
+                               ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
+    if (!ctx || !plan) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
+    ceno_hip_sumcheck* sc = nullptr;
+    int rc = ceno_hip_sumcheck_begin(ctx, mles, plan, s, &sc);
+    if (rc) return fail_from_ctx(ctx, rc);
+    rc = ceno_prover_sumcheck_run(ctx, sc, plan->max_num_vars, plan->max_degree, plan->num_mles, tr, out_msgs, out_challenges,
+                                  out_final_evals);
+    ceno_hip_sumcheck_free(ctx, sc);
+    return rc;
+}
+
+size_t ceno_tower_msgs_words(int max_nv) {
+    size_t tot = 0;
+    for (int r = 1; r < max_nv; r++) tot += (size_t)r * 3 * 2;
+    return tot;
+}
+
+int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                   ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out) {
+    if (!ctx || !tr || !out) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
+    int max_nv = 0;
+    for (int i = 0; i < n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(prod[i]));
+    for (int i = 0; i < n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(logup[i]));
+    if (max_nv < 1) return fail(CENO_HIP_ERR_INVALID, "tower: no specs");
+    const int n_alpha = n_prod + 2 * n_logup;
+    std::vector<uint64_t> alpha;
+    tr_challenge_pows(tr, n_alpha, alpha);          // cpu/mod.rs:375-380
+    tr_label(tr, "product_sum");                    // cpu/mod.rs:381  (sample_and_append_vec, log2(fanin) = 1)
+    std::vector<uint64_t> out_rt(2 * (size_t)(max_nv + 1));
+    {
+        E2 r0 = tr_sample(tr);
+        out_rt[0] = r0.c0;
+        out_rt[1] = r0.c1;
+    }
+    const int R = max_nv - 1;
+    out->num_rounds = R;
+    size_t msg_off = 0;
+    std::vector<uint64_t> chal, fin;
+    for (int round = 1; round <= R; round++) {      // cpu/mod.rs:409: skip(1) for the output layer
+        ceno_hip_sumcheck* sc = nullptr;
+        int rc = ceno_hip_tower_layer_sumcheck_begin(ctx, prod, n_prod, logup, n_logup, round, out_rt.data(), alpha.data(), s, &sc);
+        if (rc) return fail_from_ctx(ctx, rc);
+        // MLE order of the handle: [eq, active prod (a,b)..., active logup (p1,p2,q1,q2)...]
+        int n_mles = 1;
+        for (int i = 0; i < n_prod; i++) if (ceno_hip_tower_num_vars(prod[i]) > round) n_mles += 2;
+        for (int i = 0; i < n_logup; i++) if (ceno_hip_tower_num_vars(logup[i]) > round) n_mles += 4;
+        chal.assign((size_t)2 * round, 0);
+        fin.assign((size_t)2 * n_mles, 0);
+        rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + msg_off, chal.data(), fin.data());
+        ceno_hip_sumcheck_free(ctx, sc);
+        if (rc) return rc;
+        msg_off += (size_t)round * 3 * 2;
+        // evaluations are bound into the transcript before r_merge is sampled (cpu/mod.rs:498-531)
+        int cursor = 1;
+        for (int i = 0; i < n_prod; i++) {
+            uint64_t* dst = out->prod_evals + 2 * ((size_t)(i * R + (round - 1)) * 2);
+            if (ceno_hip_tower_num_vars(prod[i]) <= round) { memset(dst, 0, 32); continue; }
+            for (int k = 0; k < 2; k++) {
+                memcpy(dst + 2 * k, fin.data() + 2 * (cursor + k), 16);
+                tr_ext(tr, dst + 2 * k);
+            }
+            cursor += 2;
+        }
+        for (int i = 0; i < n_logup; i++) {
+            uint64_t* dst = out->logup_evals + 2 * ((size_t)(i * R + (round - 1)) * 4);
+            if (ceno_hip_tower_num_vars(logup[i]) <= round) { memset(dst, 0, 64); continue; }
+            for (int k = 0; k < 4; k++) {
+                memcpy(dst + 2 * k, fin.data() + 2 * (cursor + k), 16);
+                tr_ext(tr, dst + 2 * k);
+            }
+            cursor += 4;
+        }
+        tr_label(tr, "merge");                       // cpu/mod.rs:534
+        E2 r_merge = tr_sample(tr);
+        memcpy(out_rt.data(), chal.data(), (size_t)16 * round);   // rt' = challenges || r_merge (cpu/mod.rs:535)
+        out_rt[2 * round] = r_merge.c0;
+        out_rt[2 * round + 1] = r_merge.c1;
+        tr_challenge_pows(tr, n_alpha, alpha);       // cpu/mod.rs:538-541
+    }
+    memcpy(out->point, out_rt.data(), (size_t)16 * max_nv);
+    return 0;
+}
+
+int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                     ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_evals, ceno_tower_proof* out) {
+    if (!ctx || !tr || !out || !out_evals) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
+    // bind read/write/lookup out-evals into the transcript first (cpu/mod.rs:783-786)
+    uint64_t* cur = out_evals;
+    for (int i = 0; i < n_prod; i++) {
+        int rc = ceno_hip_tower_out_evals(ctx, prod[i], cur, s);
+        if (rc) return fail_from_ctx(ctx, rc);
+        cur += 4;
+    }
+    for (int i = 0; i < n_logup; i++) {
+        int rc = ceno_hip_tower_out_evals(ctx, logup[i], cur, s);
+        if (rc) return fail_from_ctx(ctx, rc);
+        cur += 8;
+    }
+    for (uint64_t* e = out_evals; e < cur; e += 2) tr_ext(tr, e);
+    return ceno_prover_tower_create_proof(ctx, prod, n_prod, logup, n_logup, tr, s, out);
+}
+
+// ---- host-side field arithmetic exposed for CPU tests of the shared gl64.cuh code ----
+uint64_t ceno_prover_test_gl_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
+uint64_t ceno_prover_test_gl_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
+uint64_t ceno_prover_test_gl_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }
+uint64_t ceno_prover_test_gl_mul_small(uint64_t a, uint32_t c) { return gl::mul_small(a, c); }
+void ceno_prover_test_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* o) {
+    E2 r = E2{a[0], a[1]} * E2{b[0], b[1]};
+    o[0] = r.c0;
+    o[1] = r.c1;
+}
+void ceno_prover_test_e2_inv(const uint64_t* a, uint64_t* o) {
+    E2 r = gl::e2_inv(E2{a[0], a[1]});
+    o[0] = r.c0;
+    o[1] = r.c1;
+}
+
+}  // extern "C"

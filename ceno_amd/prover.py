@@ -1,0 +1,236 @@
+"""Python binding of the C++ host layer (libceno_prover.so, include/ceno_prover.h).
+
+Names follow the reference: `sumcheck_prove` = IOPProverState::prove, `tower_create_proof` =
+CpuTowerProver::create_proof, `prove_tower_relation` = TowerProver::prove_tower_relation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import SumcheckPlan, u32p, u64p
+from .api import CenoHipError, Device, Mle, Sumcheck, _csr, _ext1, _p, _p32
+
+_plib = None
+
+
+class TowerProofC(C.Structure):
+    _fields_ = [("num_rounds", C.c_int), ("msgs", u64p), ("prod_evals", u64p), ("logup_evals", u64p), ("point", u64p)]
+
+
+def plib():
+    global _plib
+    if _plib is not None:
+        return _plib
+    _lib.lib()  # libceno_hip.so first (RTLD_GLOBAL)
+    if not os.path.exists(_lib.PROVER_LIB_PATH):
+        raise _lib.HipLibraryMissing(f"{_lib.PROVER_LIB_PATH} not found: run `python -m ceno_amd.build`")
+    L = C.CDLL(_lib.PROVER_LIB_PATH)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    vpp = C.POINTER(C.c_void_p)
+    L.ceno_transcript_stub_new.restype = vp
+    L.ceno_transcript_stub_new.argtypes = [C.c_uint64]
+    L.ceno_transcript_free.restype = None
+    L.ceno_transcript_free.argtypes = [vp]
+    L.ceno_transcript_append_label.restype = None
+    L.ceno_transcript_append_label.argtypes = [vp, C.c_char_p, sz]
+    L.ceno_transcript_append_ext.restype = None
+    L.ceno_transcript_append_ext.argtypes = [vp, u64p]
+    L.ceno_transcript_sample_ext.restype = None
+    L.ceno_transcript_sample_ext.argtypes = [vp, u64p]
+    L.ceno_prover_sumcheck_prove.restype = i
+    L.ceno_prover_sumcheck_prove.argtypes = [vp, vpp, C.POINTER(SumcheckPlan), vp, vp, u64p, u64p, u64p]
+    L.ceno_prover_sumcheck_run.restype = i
+    L.ceno_prover_sumcheck_run.argtypes = [vp, vp, i, i, i, vp, u64p, u64p, u64p]
+    L.ceno_tower_msgs_words.restype = sz
+    L.ceno_tower_msgs_words.argtypes = [i]
+    L.ceno_prover_tower_create_proof.restype = i
+    L.ceno_prover_tower_create_proof.argtypes = [vp, vpp, i, vpp, i, vp, vp, C.POINTER(TowerProofC)]
+    L.ceno_prover_prove_tower_relation.restype = i
+    L.ceno_prover_prove_tower_relation.argtypes = [vp, vpp, i, vpp, i, vp, vp, u64p, C.POINTER(TowerProofC)]
+    L.ceno_prover_last_error.restype = C.c_char_p
+    L.ceno_prover_last_error.argtypes = []
+    for name in ("ceno_transcript_poseidon2_new",):
+        if hasattr(L, name):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [C.c_char_p, sz]
+    L.ceno_prover_test_gl_mul.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_add.restype = C.c_uint64
+    L.ceno_prover_test_gl_add.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_sub.restype = C.c_uint64
+    L.ceno_prover_test_gl_sub.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_mul_small.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul_small.argtypes = [C.c_uint64, C.c_uint32]
+    L.ceno_prover_test_e2_mul.restype = None
+    L.ceno_prover_test_e2_mul.argtypes = [u64p, u64p, u64p]
+    L.ceno_prover_test_e2_inv.restype = None
+    L.ceno_prover_test_e2_inv.argtypes = [u64p, u64p]
+    _plib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise CenoHipError(rc, (plib().ceno_prover_last_error() or b"").decode())
+
+
+class Transcript:
+    """handle on a ceno_transcript (reference: transcript::Transcript<E>)"""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def stub(cls, seed: int = 0xF5) -> "Transcript":
+        return cls(plib().ceno_transcript_stub_new(C.c_uint64(seed)))
+
+    @classmethod
+    def poseidon2(cls, label: bytes = b"riscv") -> "Transcript":
+        return cls(plib().ceno_transcript_poseidon2_new(label, len(label)))
+
+    def append_label(self, b: bytes):
+        plib().ceno_transcript_append_label(self.h, b, len(b))
+
+    def append_ext(self, e):
+        plib().ceno_transcript_append_ext(self.h, _p(_ext1(e)))
+
+    def sample_ext(self) -> Tuple[int, int]:
+        o = np.zeros(2, dtype=np.uint64)
+        plib().ceno_transcript_sample_ext(self.h, _p(o))
+        return int(o[0]), int(o[1])
+
+    def __del__(self):
+        try:
+            if self.h:
+                plib().ceno_transcript_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def make_plan(n_mles: int, coeffs: np.ndarray, terms, max_num_vars: int, max_degree: int, groups=None):
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 2)
+    toff, tidx = _csr(terms)
+    plan = SumcheckPlan()
+    plan.num_mles, plan.num_terms = n_mles, len(terms)
+    plan.term_coeffs, plan.term_offsets, plan.term_mle_idx = _p(coeffs), _p32(toff), _p32(tidx)
+    keep = [coeffs, toff, tidx]
+    if groups:
+        goff, gidx = _csr([g[1] for g in groups])
+        coff, cidx = _csr([g[0] for g in groups])
+        plan.num_groups = len(groups)
+        plan.group_term_offsets, plan.group_term_idx = _p32(goff), _p32(gidx)
+        plan.common_offsets, plan.common_mle_idx = _p32(coff), _p32(cidx)
+        keep += [goff, gidx, coff, cidx]
+    plan.max_num_vars, plan.max_degree = max_num_vars, max_degree
+    return plan, keep
+
+
+def sumcheck_prove(dev: Device, mles: Sequence[Mle], coeffs: np.ndarray, terms, max_num_vars: int, max_degree: int,
+                   tr: Transcript, groups=None, stream=None):
+    """IOPProverState::prove — returns (msgs (n,d,2), challenges (n,2), final_evals (k,2))"""
+    plan, keep = make_plan(len(mles), coeffs, terms, max_num_vars, max_degree, groups)
+    arr = (C.c_void_p * len(mles))(*[m.h for m in mles])
+    msgs = np.zeros((max_num_vars, max_degree, 2), dtype=np.uint64)
+    chal = np.zeros((max(max_num_vars, 1), 2), dtype=np.uint64)
+    fin = np.zeros((len(mles), 2), dtype=np.uint64)
+    _check(plib().ceno_prover_sumcheck_prove(dev.h, arr, C.byref(plan), tr.h, stream,
+                                             _p(msgs) if max_num_vars else None, _p(chal), _p(fin)))
+    return msgs, chal[:max_num_vars], fin
+
+
+class Tower:
+    """built tower witness (reference: TowerProverSpec / GpuProverSpec)"""
+
+    def __init__(self, dev: Device, h):
+        self.dev, self.h = dev, h
+
+    @classmethod
+    def build_prod(cls, dev: Device, records: Sequence[Mle], num_instances: int, default=(1, 0), stream=None):
+        arr = (C.c_void_p * len(records))(*[m.h for m in records])
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_tower_build_prod(dev.h, arr, len(records), num_instances, _p(_ext1(default)), stream, C.byref(h)))
+        return cls(dev, h)
+
+    @classmethod
+    def build_logup(cls, dev: Device, p_records: Optional[Sequence[Mle]], q_records: Sequence[Mle], num_instances: int,
+                    default, stream=None):
+        q = (C.c_void_p * len(q_records))(*[m.h for m in q_records])
+        p = (C.c_void_p * len(p_records))(*[m.h for m in p_records]) if p_records is not None else None
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_tower_build_logup(dev.h, p, q, len(q_records), num_instances, _p(_ext1(default)), stream, C.byref(h)))
+        return cls(dev, h)
+
+    @classmethod
+    def from_last_layer(cls, dev: Device, limbs: Sequence[Optional[Mle]], stream=None):
+        arr = (C.c_void_p * len(limbs))(*[(m.h if m is not None else None) for m in limbs])
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_tower_from_last_layer(dev.h, arr, len(limbs), stream, C.byref(h)))
+        return cls(dev, h)
+
+    @property
+    def num_vars(self) -> int:
+        return self.dev.L.ceno_hip_tower_num_vars(self.h)
+
+    @property
+    def num_limbs(self) -> int:
+        return self.dev.L.ceno_hip_tower_num_limbs(self.h)
+
+    def layer(self, layer: int, limb: int) -> np.ndarray:
+        h = C.c_void_p()
+        self.dev.check(self.dev.L.ceno_hip_tower_layer(self.dev.h, self.h, layer, limb, C.byref(h)))
+        m = Mle(self.dev, h)
+        out = m.download()
+        m.free()
+        return out
+
+    def out_evals(self, stream=None) -> np.ndarray:
+        out = np.zeros((self.num_limbs, 2), dtype=np.uint64)
+        self.dev.check(self.dev.L.ceno_hip_tower_out_evals(self.dev.h, self.h, _p(out), stream))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            self.dev.L.ceno_hip_tower_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class TowerProof:
+    def __init__(self, max_nv: int, n_prod: int, n_logup: int):
+        self.max_nv, self.n_prod, self.n_logup = max_nv, n_prod, n_logup
+        R = max_nv - 1
+        self.msgs = np.zeros(max(1, plib().ceno_tower_msgs_words(max_nv)), dtype=np.uint64)
+        self.prod_evals = np.zeros((max(1, n_prod), max(1, R), 2, 2), dtype=np.uint64)
+        self.logup_evals = np.zeros((max(1, n_logup), max(1, R), 4, 2), dtype=np.uint64)
+        self.point = np.zeros((max_nv + 1, 2), dtype=np.uint64)
+        self.c = TowerProofC(R, _p(self.msgs), _p(self.prod_evals), _p(self.logup_evals), _p(self.point))
+
+
+def tower_create_proof(dev: Device, prod: Sequence[Tower], logup: Sequence[Tower], tr: Transcript, stream=None) -> TowerProof:
+    max_nv = max([t.num_vars for t in prod] + [t.num_vars for t in logup])
+    proof = TowerProof(max_nv, len(prod), len(logup))
+    pa = (C.c_void_p * max(1, len(prod)))(*[t.h for t in prod])
+    la = (C.c_void_p * max(1, len(logup)))(*[t.h for t in logup])
+    _check(plib().ceno_prover_tower_create_proof(dev.h, pa, len(prod), la, len(logup), tr.h, stream, C.byref(proof.c)))
+    return proof
+
+
+def prove_tower_relation(dev: Device, prod: Sequence[Tower], logup: Sequence[Tower], tr: Transcript, stream=None):
+    max_nv = max([t.num_vars for t in prod] + [t.num_vars for t in logup])
+    proof = TowerProof(max_nv, len(prod), len(logup))
+    pa = (C.c_void_p * max(1, len(prod)))(*[t.h for t in prod])
+    la = (C.c_void_p * max(1, len(logup)))(*[t.h for t in logup])
+    out_evals = np.zeros((2 * len(prod) + 4 * len(logup), 2), dtype=np.uint64)
+    _check(plib().ceno_prover_prove_tower_relation(dev.h, pa, len(prod), la, len(logup), tr.h, stream, _p(out_evals), C.byref(proof.c)))
+    return out_evals, proof

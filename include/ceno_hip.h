@@ -1,0 +1,227 @@
+/*
+ * ceno_hip.h — C ABI of libceno_hip.so, the MI355X (gfx950) device back end for Ceno's
+ * GKR / sumcheck prover core.
+ *
+ * This is the drop-in boundary: the entry points below are what a Rust `HipBackend/HipProver`
+ * implementing `gkr_iop::hal::ProverBackend` + `ceno_zkvm::scheme::hal::ProverDevice`
+ * (reference gkr_iop/src/hal.rs:11-68, ceno_zkvm/src/scheme/hal.rs:19-35) binds over FFI, exactly
+ * where the reference's GPU arm calls the external `ceno_gpu` HAL (catalogue: SURVEY.md §2.2).
+ * INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *  - Field elements are canonical little-endian uint64 (< p = 2^64-2^32+1).  An extension element
+ *    (GoldilocksExt2 = F_p[X]/(X^2-7)) is two consecutive words [c0, c1].
+ *  - Multilinear polynomials are dense evaluation tables; index bit k <-> variable k (LSB first,
+ *    reference gkr_iop/src/utils.rs:215-232).
+ *  - Every function returns 0 on success or a negative ceno_hip_status; the message is available
+ *    from ceno_hip_last_error().  Nothing throws or aborts across the boundary
+ *    (reference: Result<_, HalError>, ceno_zkvm/src/scheme/gpu/mod.rs:348-352).
+ *  - Every call that touches the device takes an explicit stream (reference: thread-bound streams,
+ *    gkr_iop/src/gpu/mod.rs:87-154).  `NULL` selects the context's default stream.  The library is
+ *    re-entrant across streams; host buffers passed in are only borrowed for the call.
+ *  - Handles are opaque; device memory is owned by the library pool unless wrapped from outside.
+ *  - The Fiat–Shamir transcript stays with the caller: sumcheck is exposed round by round
+ *    (the reference passes `&mut BasicTranscript` into the HAL, gkr_iop/src/gkr/layer/gpu/mod.rs:252-270;
+ *    a C ABI cannot take a Rust generic, so control is inverted).
+ */
+#ifndef CENO_HIP_H
+#define CENO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ceno_hip_ctx ceno_hip_ctx;
+typedef struct ceno_hip_mle ceno_hip_mle;             /* device MLE; cf. MultilinearExtensionGpu, gkr_iop/src/gpu/mod.rs:157-370 */
+typedef struct ceno_hip_sumcheck ceno_hip_sumcheck;   /* in-flight sumcheck; cf. prove_generic_sumcheck_gpu */
+typedef struct ceno_hip_tower ceno_hip_tower;         /* built tower witness; cf. GpuProverSpec */
+typedef struct ceno_hip_merkle ceno_hip_merkle;       /* committed Merkle tree; cf. basefold PcsData */
+typedef void* ceno_hip_stream;                        /* hipStream_t */
+
+typedef enum ceno_hip_status {
+    CENO_HIP_OK = 0,
+    CENO_HIP_ERR_INVALID = -1,     /* bad argument / plan */
+    CENO_HIP_ERR_HIP = -2,         /* HIP runtime error */
+    CENO_HIP_ERR_OOM = -3,         /* pool capacity exceeded / allocation failed */
+    CENO_HIP_ERR_STATE = -4,       /* call out of order (e.g. round after finish) */
+    CENO_HIP_ERR_UNSUPPORTED = -5
+} ceno_hip_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * context, streams, memory  (reference: CUDA_HAL lazy global + pool, gkr_iop/src/gpu/mod.rs:53-66;
+ * get_cuda_mem_info / mem_pool booking, ceno_zkvm/src/scheme/gpu/mod.rs:226-267)
+ * ---------------------------------------------------------------------------------------------- */
+int ceno_hip_init(int device, size_t pool_bytes /* 0 = unlimited */, ceno_hip_ctx** out);
+void ceno_hip_destroy(ceno_hip_ctx* ctx);
+const char* ceno_hip_last_error(ceno_hip_ctx* ctx);   /* ctx may be NULL: last init error */
+const char* ceno_hip_version(void);
+int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out);
+int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s);
+int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
+/* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
+int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);
+int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334) */
+
+/* ------------------------------------------------------------------------------------------------
+ * MLE handles  (alloc_elems_on_device / alloc_ext_elems_from_host / Buffer::to_cpu_vec)
+ * ---------------------------------------------------------------------------------------------- */
+int ceno_hip_mle_alloc(ceno_hip_ctx* ctx, int num_vars, int is_ext, ceno_hip_mle** out);
+int ceno_hip_mle_upload(ceno_hip_ctx* ctx, const uint64_t* host, int num_vars, int is_ext, ceno_hip_stream s, ceno_hip_mle** out);
+/* borrow device memory owned by the caller (e.g. a torch tensor); never freed by the library */
+int ceno_hip_mle_wrap(ceno_hip_ctx* ctx, uint64_t* device_ptr, int num_vars, int is_ext, ceno_hip_mle** out);
+/* borrowed view of the contiguous chunk [chunk*2^sub_vars, (chunk+1)*2^sub_vars) of a parent (as_view_chunk, gkr_iop/src/gpu/mod.rs:244-253) */
+int ceno_hip_mle_view_chunk(ceno_hip_ctx* ctx, ceno_hip_mle* parent, int sub_vars, size_t chunk, ceno_hip_mle** out);
+int ceno_hip_mle_download(ceno_hip_ctx* ctx, const ceno_hip_mle* m, uint64_t* host, ceno_hip_stream s);  /* synchronises s */
+int ceno_hip_mle_free(ceno_hip_ctx* ctx, ceno_hip_mle* m);
+int ceno_hip_mle_num_vars(const ceno_hip_mle* m);
+int ceno_hip_mle_is_ext(const ceno_hip_mle* m);
+uint64_t* ceno_hip_mle_device_ptr(const ceno_hip_mle* m);
+/* word i of the table = SplitMix64(seed, word_offset + i) reduced mod p (BASELINE.md synthetic inputs) */
+int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed, uint64_t word_offset, ceno_hip_stream s);
+
+/* MultilinearExtension::evaluate(point) — out2 = f(point), point has num_vars ext elements */
+int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, uint64_t* out2, ceno_hip_stream s);
+/* fix_variables (low variables first): out has num_vars - n_fix variables, always ext */
+int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, int n_fix, ceno_hip_stream s, ceno_hip_mle** out);
+
+/* ------------------------------------------------------------------------------------------------
+ * eq tables and selectors  (build_mle_as_ceno / ordered_sparse_selector_gpu,
+ * gkr_iop/src/gkr/layer/gpu/utils.rs:121-190; semantics gkr_iop/src/selector.rs:131-245)
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum ceno_hip_selector_kind {
+    CENO_HIP_SEL_WHOLE = 0,
+    CENO_HIP_SEL_PREFIX = 1,          /* rows [offset, offset+num_instances) keep eq, others 0 */
+    CENO_HIP_SEL_ORDERED_SPARSE = 2,  /* within each 2^sparse_num_vars chunk keep `sparse_indices`; chunks >= num_instances are 0 */
+    CENO_HIP_SEL_QUARK_LT = 3         /* QuarkBinaryTreeLessThan */
+} ceno_hip_selector_kind;
+
+/* out[x] = scalar * eq(x, point); scalar2 may be NULL (= 1).  The scalar carries eq over the
+ * high (sharded-away) variables when the hypercube is split across GPUs. */
+int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, const uint64_t* scalar2, ceno_hip_stream s, ceno_hip_mle** out);
+int ceno_hip_selector_build(ceno_hip_ctx* ctx, int kind, const uint64_t* point, int num_vars, size_t offset, size_t num_instances,
+                            const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, ceno_hip_stream s, ceno_hip_mle** out);
+
+/* ------------------------------------------------------------------------------------------------
+ * element-wise witness inference  (wit_infer_by_monomial_expr, gkr_iop/src/gpu/mod.rs:599-609)
+ *   outs[o][x] = sum_{t in terms of o} coeff_t * prod_{j in S_t} mles[j][x]
+ * terms are CSR: output o owns terms [out_term_offsets[o], out_term_offsets[o+1]); term t owns
+ * factors term_mle_idx[term_offsets[t] .. term_offsets[t+1]).  Outputs are ext tables.
+ * ---------------------------------------------------------------------------------------------- */
+int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mles, const uint64_t* term_coeffs,
+                       const uint32_t* term_offsets, const uint32_t* term_mle_idx, int num_terms,
+                       const uint32_t* out_term_offsets, int num_outs, int num_vars, ceno_hip_stream s, ceno_hip_mle** outs);
+
+/* ------------------------------------------------------------------------------------------------
+ * generic sumcheck  (prove_generic_sumcheck_gpu / _v2, gkr_iop/src/gkr/layer/gpu/mod.rs:259-271,
+ * ceno_zkvm/src/scheme/gpu/mod.rs:891-902,2968-2982)
+ *
+ * Claim: sum_{x in {0,1}^n} sum_t c_t prod_{j in S_t} f_j(x), n = max_num_vars, degree d = max_degree.
+ * Round i binds variable i; the round message is exactly d extension elements p(1..d).
+ * An MLE with n' < n variables is front-loaded: f(x_0..x_{n'-1}) * x_{n'} ... x_{n-1}
+ * (scheme/verifier.rs:233-237); all factors of one term must have the same num_vars.
+ * Optional common-factor plan (CommonTermPlan, layer/gpu/utils.rs:69-119): group g multiplies the
+ * sum of its terms by prod of common_mle_idx[common_offsets[g]..common_offsets[g+1]); terms listed in
+ * a group are given by group_term_idx[group_term_offsets[g]..]; terms not in any group stand alone.
+ *
+ * Inputs are never modified (the first fold writes into library-owned half-size buffers).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ceno_hip_sumcheck_plan {
+    int num_mles;
+    int num_terms;
+    const uint64_t* term_coeffs;        /* 2 * num_terms words */
+    const uint32_t* term_offsets;       /* num_terms + 1 */
+    const uint32_t* term_mle_idx;       /* term_offsets[num_terms] */
+    int num_groups;                     /* 0 = no common-factor plan */
+    const uint32_t* group_term_offsets; /* num_groups + 1 */
+    const uint32_t* group_term_idx;
+    const uint32_t* common_offsets;     /* num_groups + 1 */
+    const uint32_t* common_mle_idx;
+    int max_num_vars;
+    int max_degree;
+} ceno_hip_sumcheck_plan;
+
+int ceno_hip_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan,
+                            ceno_hip_stream s, ceno_hip_sumcheck** out);
+/* Produce the message of the next round.  `challenge2` is the challenge of the PREVIOUS round
+ * (NULL for round 0): the tables are folded with it and the new message accumulated in one pass.
+ * out_evals receives max_degree ext elements (host memory). Synchronises the stream. */
+int ceno_hip_sumcheck_round(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* out_evals);
+/* same, but the (partial) message is left in device memory `dev_out_evals` (max_degree ext) and the
+ * call does not synchronise — for hypercube shards whose partials are combined by a collective. */
+int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* dev_out_evals);
+/* bind the last variable; final_evals receives num_mles ext elements: f_j(r_0..r_{nv_j - 1})
+ * (get_mle_flatten_final_evaluations, gkr_iop/src/gkr/layer/cpu/mod.rs:229-230) */
+int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals);
+int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc);
+int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc);
+
+/* ------------------------------------------------------------------------------------------------
+ * tower witness  (build_prod_tower_from_virtual_ext_batch / build_logup_tower_from_virtual_ext_batch,
+ * GpuProverSpec::get_output_evals — ceno_zkvm/src/scheme/gpu/mod.rs:2365-2402,379-410; CPU semantics
+ * ceno_zkvm/src/scheme/utils.rs:402-659)
+ * ---------------------------------------------------------------------------------------------- */
+/* interleave `k` record MLEs into 2 limbs (default-padded) and build all product layers.
+ * Resulting tower has num_vars = row_vars' + ceil_log2(next_pow2(k)) layers, layer l = 2 limbs of 2^l. */
+int ceno_hip_tower_build_prod(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, int k, size_t num_instances,
+                              const uint64_t* default2, ceno_hip_stream s, ceno_hip_tower** out);
+/* LogUp tower over denominators q (records) and optional numerators p (NULL = all ones):
+ * layer l = 4 limbs p1,p2,q1,q2 of 2^l */
+int ceno_hip_tower_build_logup(ceno_hip_ctx* ctx, ceno_hip_mle* const* p_records, ceno_hip_mle* const* q_records, int k,
+                               size_t num_instances, const uint64_t* default2, ceno_hip_stream s, ceno_hip_tower** out);
+/* build directly from already interleaved last-layer limbs (infer_tower_product_witness / _logup_witness) */
+int ceno_hip_tower_from_last_layer(ceno_hip_ctx* ctx, ceno_hip_mle* const* limbs, int n_limbs /* 2 = prod; 4 = logup p1,p2,q1,q2; */,
+                                   ceno_hip_stream s, ceno_hip_tower** out);
+int ceno_hip_tower_num_vars(const ceno_hip_tower* t);   /* number of layers */
+int ceno_hip_tower_num_limbs(const ceno_hip_tower* t);  /* 2 or 4 */
+/* borrowed handle of limb `limb` of layer `layer` (valid while the tower lives) */
+int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int limb, ceno_hip_mle** out);
+int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out /* n_limbs ext */, ceno_hip_stream s);
+int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t);
+
+/* One tower layer sumcheck (the body of CpuTowerProver::create_proof's round loop,
+ * ceno_zkvm/src/scheme/cpu/mod.rs:409-494):  sum_x eq(x, out_rt) * [ sum_i alpha_i a_i(x) b_i(x)
+ *   + sum_k ( alpha_n,k (p1 q2 + p2 q1) + alpha_d,k q1 q2 ) ]  over layer `layer` of every tower that has it.
+ * alpha_pows has n_prod + 2*n_logup ext elements in the reference's order.  Returns a sumcheck handle
+ * whose MLE order is [eq, prod0.a, prod0.b, ..., logup0.p1, p2, q1, q2, ...] restricted to active towers. */
+int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                        int layer, const uint64_t* out_rt /* `layer` ext */, const uint64_t* alpha_pows,
+                                        ceno_hip_stream s, ceno_hip_sumcheck** out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Basefold commit path  (cuda_hal.basefold.batch_commit, ceno_zkvm/src/scheme/gpu/mod.rs:1642-1646;
+ * protocol shape restated in ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7720-8002).  PARITY UNPINNED:
+ * Poseidon2-Goldilocks round constants and the RS/leaf layout live in EXT crates.
+ * ---------------------------------------------------------------------------------------------- */
+/* in-place radix-2 NTT of `n_cols` columns of length 2^log_n stored column-major (col stride 2^log_n):
+ * natural-order input -> bit-reversed-order output (inverse: bit-reversed in -> natural out, scaled by 1/N) */
+int ceno_hip_ntt_batch(ceno_hip_ctx* ctx, uint64_t* dev_cols, int log_n, int n_cols, int inverse, ceno_hip_stream s);
+/* Reed–Solomon encode: each column of 2^log_n evaluations-as-coefficients is zero-extended by 2^log_blowup and transformed. */
+int ceno_hip_rs_encode(ceno_hip_ctx* ctx, const uint64_t* dev_cols, int log_n, int n_cols, int log_blowup, uint64_t* dev_codewords, ceno_hip_stream s);
+/* row-major (rows x width) -> column-major (matrix_transpose, ceno_zkvm/src/scheme/gpu/mod.rs:84,963-968) */
+int ceno_hip_transpose(ceno_hip_ctx* ctx, const uint64_t* dev_row_major, size_t rows, size_t width, uint64_t* dev_col_major, ceno_hip_stream s);
+/* Poseidon2 (width 8, rate 4, x^7) parameter table; NULL restores the built-in placeholder constants */
+int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external_rc /* 8 rounds x 8 */, const uint64_t* internal_rc /* 22 */,
+                                     const uint64_t* internal_diag /* 8 */);
+int ceno_hip_poseidon2_permute(ceno_hip_ctx* ctx, uint64_t* dev_states /* n x 8 */, size_t n, ceno_hip_stream s);
+/* leaves = sponge hash of each row of a column-major matrix (rows = 2^log_rows); tree = 2-to-1 compression */
+int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int log_rows, int width, ceno_hip_stream s, ceno_hip_merkle** out);
+int ceno_hip_merkle_root(ceno_hip_ctx* ctx, ceno_hip_merkle* t, uint64_t* root4, ceno_hip_stream s);
+/* authentication path of leaf `index`: log_rows sibling digests (4 words each), bottom-up */
+int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, uint64_t* path /* log_rows*4 */, ceno_hip_stream s);
+int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
+
+/* ------------------------------------------------------------------------------------------------
+ * diagnostics used by bench.py (HIP-event timing of the dominant kernel on the launch stream)
+ * ---------------------------------------------------------------------------------------------- */
+/* accumulated device time (ms) and launch count of the fused sumcheck round kernel since the last reset */
+int ceno_hip_prof_reset(ceno_hip_ctx* ctx);
+int ceno_hip_prof_enable(ceno_hip_ctx* ctx, int on);
+int ceno_hip_prof_get(ceno_hip_ctx* ctx, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Integer / field work: equality is exact (canonical uint64 limbs); no tolerance anywhere.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ceno_amd import Device
+
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def prover():
+    from ceno_amd import prover as pv
+
+    pv.plib()
+    return pv
+
+
+def tup(a):
+    return int(a[0]), int(a[1])
+
+
+# ------------------------------------------------------------------------------------------
+# MLE primitives
+# ------------------------------------------------------------------------------------------
+def test_upload_download_roundtrip_and_views(dev):
+    t = po.rand_ext(64, 1)
+    m = dev.upload(t)
+    assert np.array_equal(m.download(), t)
+    b = po.rand_base(32, 2)
+    mb = dev.upload(b)
+    assert np.array_equal(mb.download(), b) and not mb.is_ext and mb.num_vars == 5
+    v = m.view_chunk(4, 3)
+    assert np.array_equal(v.download(), t[48:64])
+
+
+def test_synthetic_fill_matches_oracle_generator(dev):
+    for nv, is_ext, seed, off in [(0, True, 7, 0), (5, True, 0xCE10, 0), (7, False, 0xCE11, 13), (12, True, 3, 1 << 20)]:
+        m = dev.synthetic(nv, is_ext, seed, off)
+        n_words = (1 << nv) * (2 if is_ext else 1)
+        exp = po.fill_splitmix(n_words, seed, off)
+        assert np.array_equal(m.download().reshape(-1), exp)
+
+
+@pytest.mark.parametrize("nv", [0, 1, 2, 5, 9, 14])
+def test_eq_build(dev, nv):
+    pt = po.rand_ext(nv, 40 + nv) if nv else np.zeros((0, 2), dtype=np.uint64)
+    got = dev.eq_build(pt).download()
+    assert np.array_equal(got, po.build_eq(pt))
+    sc = (123456789, 987654321)
+    got = dev.eq_build(pt, scalar=sc).download()
+    exp = po.build_eq(pt)
+    for i in (0, (1 << nv) - 1, (1 << nv) // 3):
+        assert tup(got[i]) == po.e2_mul(tup(exp[i]), sc)
+
+
+def test_selectors(dev):
+    from ceno_amd.api import Device  # noqa: F401
+
+    nv = 7
+    pt = po.rand_ext(nv, 77)
+    for off, n in [(0, 128), (0, 77), (5, 100), (127, 1), (0, 0)]:
+        got = dev.selector_build(po.SEL_PREFIX, pt, off, n).download()
+        assert np.array_equal(got, po.selector_compute(po.SEL_PREFIX, pt, off, n))
+    for n in (1, 7, 16):
+        idx = [0, 3, 4, 7]
+        got = dev.selector_build(po.SEL_ORDERED_SPARSE, pt, 0, n, idx, 3).download()
+        assert np.array_equal(got, po.selector_compute(po.SEL_ORDERED_SPARSE, pt, 0, n, idx, 3))
+    for n in (1, 2, 5, 64, 100, 128):
+        got = dev.selector_build(po.SEL_QUARK_LT, pt, 0, n).download()
+        assert np.array_equal(got, po.selector_compute(po.SEL_QUARK_LT, pt, 0, n))
+    assert np.array_equal(dev.selector_build(po.SEL_WHOLE, pt).download(), po.build_eq(pt))
+    from ceno_amd import CenoHipError
+
+    with pytest.raises(CenoHipError):
+        dev.selector_build(po.SEL_PREFIX, pt, 100, 100)  # end > 2^nv (selector.rs:144-150)
+
+
+@pytest.mark.parametrize("nv,is_ext", [(0, True), (1, True), (6, True), (6, False), (13, True), (13, False)])
+def test_evaluate_and_fix_variables(dev, nv, is_ext):
+    t = po.rand_ext(1 << nv, 5) if is_ext else po.rand_base(1 << nv, 5)
+    pt = po.rand_ext(nv, 6) if nv else np.zeros((0, 2), dtype=np.uint64)
+    m = dev.upload(t)
+    assert m.evaluate(pt) == po.mle_evaluate(t, pt)
+    for k in range(1, min(nv, 4) + 1):
+        got = m.fix_variables(pt[:k]).download()
+        exp = t
+        for j in range(k):
+            exp = po.mle_fix_variable(exp, tup(pt[j]))
+        assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------------------------------
+# sumcheck: every round message, every challenge, every final evaluation
+# ------------------------------------------------------------------------------------------
+def _run_both(dev, prover, tables, coeffs, terms, nv, d, groups=None, seed=1):
+    mles = [dev.upload(t) for t in tables]
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, coeffs, terms, nv, d, prover.Transcript.stub(seed), groups=groups)
+    # oracle: groups expanded to full terms
+    full_terms = [list(t) for t in terms]
+    if groups:
+        for common, members in groups:
+            for t in members:
+                full_terms[t] = list(common) + full_terms[t]
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, coeffs, full_terms, nv, d, po.StubTranscript(seed))
+    assert np.array_equal(msgs, omsgs)
+    assert np.array_equal(chal, ochal)
+    assert np.array_equal(fin, ofin)
+    return msgs, chal, fin
+
+
+@pytest.mark.parametrize("nv", [1, 2, 3, 8, 12, 16])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_sumcheck_dense_ext(dev, prover, nv, k):
+    tables = [po.rand_ext(1 << nv, 10 * k + j) for j in range(k)]
+    _run_both(dev, prover, tables, po.rand_ext(1, 99), [list(range(k))], nv, k)
+
+
+@pytest.mark.parametrize("nv", [1, 4, 11])
+@pytest.mark.parametrize("k", [2, 3])
+def test_sumcheck_dense_base_start(dev, prover, nv, k):
+    tables = [po.rand_base(1 << nv, 50 + j) for j in range(k)]
+    _run_both(dev, prover, tables, po.ext([1]), [list(range(k))], nv, k)
+
+
+def test_sumcheck_generic_terms_and_degrees(dev, prover):
+    nv = 9
+    tables = [po.rand_ext(1 << nv, 1), po.rand_base(1 << nv, 2), po.rand_ext(1 << nv, 3), po.rand_base(1 << nv, 4),
+              po.rand_ext(1 << nv, 5)]
+    terms = [[0, 1, 2], [1, 3], [4], [0, 0, 4, 4], [2, 3, 4, 1, 0]]
+    coeffs = po.rand_ext(len(terms), 6)
+    _run_both(dev, prover, tables, coeffs, terms, nv, 5)
+    # max_degree larger than every term
+    _run_both(dev, prover, tables, coeffs[:3], terms[:3], nv, 4)
+
+
+def test_sumcheck_mixed_sizes_frontload(dev, prover):
+    big = [po.rand_base(1 << 10, 1), po.rand_ext(1 << 10, 2), po.rand_ext(1 << 10, 3)]
+    mid = [po.rand_ext(1 << 6, 4), po.rand_base(1 << 6, 5)]
+    small = [po.rand_ext(4, 6)]
+    tiny = [po.rand_ext(1, 7)]  # zero variables
+    tables = big + mid + small + tiny
+    terms = [[0, 1, 2], [1, 2], [3, 4], [3, 3, 4], [5], [5, 5], [6, 6]]
+    coeffs = po.rand_ext(len(terms), 8)
+    msgs, chal, fin = _run_both(dev, prover, tables, coeffs, terms, 10, 3)
+    # restated verifier accepts, final check uses the front-load rule
+    claim = (0, 0)
+    for c, t in zip(coeffs, terms):
+        nvt = int(tables[t[0]].shape[0]).bit_length() - 1
+        s = (0, 0)
+        for x in range(1 << nvt):
+            v = (1, 0)
+            for j in t:
+                e = tables[j][x]
+                v = po.e2_mul(v, tup(e) if tables[j].ndim == 2 else (int(e), 0))
+            s = po.e2_add(s, v)
+        claim = po.e2_add(claim, po.e2_mul(tup(c), s))
+    point, expected = po.sumcheck_verify(claim, msgs, po.StubTranscript(1))
+    nvs = [10, 10, 10, 6, 6, 2, 0]
+    assert po.sumcheck_expected_from_evals(nvs, coeffs, terms, 10, chal, fin) == expected
+
+
+def test_sumcheck_common_factor_groups(dev, prover):
+    nv = 8
+    tables = [po.rand_ext(1 << nv, 20 + j) for j in range(7)]
+    # eq-like common factor 0 over terms 0..2, common factors (1,2) over term 3, term 4 ungrouped
+    terms = [[3, 4], [5], [4, 6], [6], [1, 5, 6]]
+    groups = [([0], [0, 1, 2]), ([1, 2], [3])]
+    coeffs = po.rand_ext(len(terms), 30)
+    _run_both(dev, prover, tables, coeffs, terms, nv, 3, groups=groups)
+
+
+def test_sumcheck_error_behaviour(dev, prover):
+    from ceno_amd import CenoHipError, Sumcheck
+
+    a, b = dev.upload(po.rand_ext(4, 1)), dev.upload(po.rand_ext(8, 2))
+    with pytest.raises(CenoHipError):
+        Sumcheck(dev, [a, b], po.ext([1]), [[0, 1]], 3, 2)  # mixed sizes inside one term
+    with pytest.raises(CenoHipError):
+        Sumcheck(dev, [a], po.ext([1]), [[]], 2, 2)  # empty product
+    with pytest.raises(CenoHipError):
+        Sumcheck(dev, [a], po.ext([1]), [[0, 0, 0]], 2, 2)  # degree > max_degree
+    with pytest.raises(CenoHipError):
+        Sumcheck(dev, [b], po.ext([1]), [[0]], 2, 2)  # mle larger than max_num_vars
+    sc = Sumcheck(dev, [a], po.ext([1]), [[0]], 2, 1)
+    with pytest.raises(CenoHipError):
+        sc.round((1, 2))  # round 0 takes no challenge
+    sc.round()
+    with pytest.raises(CenoHipError):
+        sc.round()  # round 1 needs a challenge
+    sc.round((3, 4))
+    with pytest.raises(CenoHipError):
+        sc.round((5, 6))  # all rounds done
+    fin = sc.finish((5, 6))
+    assert tup(fin[0]) == po.mle_evaluate(a.download(), po.ext([(3, 4), (5, 6)]))
+    with pytest.raises(CenoHipError):
+        sc.finish((5, 6))
+
+
+def test_sumcheck_inputs_are_not_modified(dev, prover):
+    t = [po.rand_ext(1 << 10, j) for j in range(3)]
+    mles = [dev.upload(x) for x in t]
+    prover.sumcheck_prove(dev, mles, po.ext([1]), [[0, 1, 2]], 10, 3, prover.Transcript.stub(3))
+    for m, x in zip(mles, t):
+        assert np.array_equal(m.download(), x)
+
+
+# ------------------------------------------------------------------------------------------
+# full-size property checks (BASELINE config #2 size: 3 x 2^22 ext)
+# ------------------------------------------------------------------------------------------
+def test_sumcheck_nv22_properties(dev, prover):
+    nv, k = 22, 3
+    mles = [dev.synthetic(nv, True, 0xCE10 + j) for j in range(k)]
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, po.ext([1]), [[0, 1, 2]], nv, k, prover.Transcript.stub(0xF5))
+    # (1) final evaluations equal independent MLE evaluations at the challenge point (device evaluate kernel
+    #     shares no code with the sumcheck kernels)
+    for j in range(k):
+        assert mles[j].evaluate(chal) == tup(fin[j])
+    # (2) the transcript of messages satisfies the restated verifier and the final product check
+    expected = (1, 0)
+    for j in range(k):
+        expected = po.e2_mul(expected, tup(fin[j]))
+    claim = po.recover_claim_from_final(expected, msgs, chal)
+    point, exp2 = po.sumcheck_verify(claim, msgs, po.StubTranscript(0xF5))
+    assert np.array_equal(point, chal) and exp2 == expected
+    # (3) folding 8 variables on the device then finishing with the oracle reproduces messages 8..21
+    folded = [m.fix_variables(chal[:8]).download() for m in mles]
+    omsgs, _ = po.sumcheck_dense_mt(folded, chal[8:], threads=4)
+    assert np.array_equal(omsgs, msgs[8:])
+
+
+# ------------------------------------------------------------------------------------------
+# tower
+# ------------------------------------------------------------------------------------------
+def test_tower_build_matches_oracle(dev, prover):
+    for k, rows in [(4, 8), (3, 8), (1, 4), (5, 16), (2, 2)]:
+        recs = [po.rand_ext(rows, 100 + j) for j in range(k)]
+        limbs = po.interleaving_mles_to_mles(recs, rows, 2, (1, 0))
+        nv = int(limbs[0].shape[0]).bit_length()  # limb vars + 1
+        layers = po.infer_tower_product_witness(nv, limbs)
+        t = prover.Tower.build_prod(dev, [dev.upload(r) for r in recs], rows, (1, 0))
+        assert t.num_vars == nv and t.num_limbs == 2
+        for l in range(nv):
+            for s in range(2):
+                assert np.array_equal(t.layer(l, s), layers[l][s])
+        assert np.array_equal(t.out_evals(), np.stack([layers[0][0][0], layers[0][1][0]]))
+
+
+def test_tower_interleave_golden_vectors(dev, prover):
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tower_witness.json")))
+    for case in gold["interleaving_mles_to_mles"]:
+        recs = [dev.upload(po.ext(m)) for m in case["mles"]]
+        t = prover.Tower.build_prod(dev, recs, case["num_instances"], (case["default"], 0))
+        last = t.num_vars - 1
+        for s in range(2):
+            got = t.layer(last, s)
+            assert [int(x[0]) for x in got] == case["expected"][s] and all(int(x[1]) == 0 for x in got)
+    case = gold["infer_tower_logup_witness"][0]
+    q = [dev.upload(po.ext(x)) for x in case["q"]]
+    t = prover.Tower.from_last_layer(dev, [None, None, q[0], q[1]])
+    assert t.num_vars == case["num_layers"]
+    for l, exp_layer in enumerate(case["layers"]):
+        for s in range(4):
+            got = t.layer(l, s)
+            assert [int(x[0]) for x in got] == exp_layer[s]
+
+
+def test_tower_logup_build_matches_oracle(dev, prover):
+    k, rows = 3, 16
+    alpha = (777, 888)
+    qs = [po.rand_ext(rows, 200 + j) for j in range(k)]
+    ps = [po.rand_ext(rows, 300 + j) for j in range(k)]
+    for with_p in (True, False):
+        ql = po.interleaving_mles_to_mles(qs, rows, 2, alpha)
+        pl = po.interleaving_mles_to_mles(ps, rows, 2, alpha) if with_p else None
+        layers = po.infer_tower_logup_witness(pl, ql)
+        t = prover.Tower.build_logup(dev, [dev.upload(p) for p in ps] if with_p else None, [dev.upload(q) for q in qs], rows, alpha)
+        assert t.num_vars == len(layers) and t.num_limbs == 4
+        for l in range(len(layers)):
+            for s in range(4):
+                assert np.array_equal(t.layer(l, s), layers[l][s])
+
+
+@pytest.mark.parametrize("leaf_log", [1, 2, 5, 9])
+def test_tower_proof_matches_oracle_and_verifies(dev, prover, leaf_log):
+    nv = leaf_log + 1
+    last = [po.rand_ext(1 << leaf_log, 1000 + leaf_log), po.rand_ext(1 << leaf_log, 2000 + leaf_log)]
+    spec = po.infer_tower_product_witness(nv, last)
+    oproof = po.tower_prove([spec], [], po.StubTranscript(5))
+    t = prover.Tower.from_last_layer(dev, [dev.upload(x) for x in last])
+    proof = prover.tower_create_proof(dev, [t], [], prover.Transcript.stub(5))
+    assert np.array_equal(proof.msgs, oproof.msgs)
+    assert np.array_equal(proof.prod_evals, oproof.prod_evals)
+    assert np.array_equal(proof.point[:nv], oproof.point[:nv])
+
+
+def test_tower_relation_mixed_specs(dev, prover):
+    # read tower (6 layers), write tower (4 layers), two lookup towers (with and without numerators)
+    def prod_last(nv, seed):
+        return [po.rand_ext(1 << (nv - 1), seed), po.rand_ext(1 << (nv - 1), seed + 1)]
+
+    pl = [prod_last(6, 1), prod_last(4, 3), prod_last(2, 5)]
+    ql = [(prod_last(5, 7), prod_last(5, 9)), (None, prod_last(6, 11))]
+    specs_p = [po.infer_tower_product_witness(len(l[0]).bit_length(), l) for l in pl]
+    specs_l = [po.infer_tower_logup_witness(p, q) for p, q in ql]
+    towers_p = [prover.Tower.from_last_layer(dev, [dev.upload(x) for x in l]) for l in pl]
+    towers_l = [prover.Tower.from_last_layer(dev, [dev.upload(p[0]) if p else None, dev.upload(p[1]) if p else None,
+                                                   dev.upload(q[0]), dev.upload(q[1])]) for p, q in ql]
+    out_evals, proof = prover.prove_tower_relation(dev, towers_p, towers_l, prover.Transcript.stub(8))
+    # oracle: same script (append out evals, then create_proof)
+    tr = po.StubTranscript(8)
+    po_ev = np.stack([np.stack([s[0][0][0], s[0][1][0]]) for s in specs_p])
+    lo_ev = np.stack([np.stack([s[0][k][0] for k in range(4)]) for s in specs_l])
+    for e in list(po_ev.reshape(-1, 2)) + list(lo_ev.reshape(-1, 2)):
+        tr.append_ext(tup(e))
+    oproof = po.tower_prove(specs_p, specs_l, tr)
+    assert np.array_equal(out_evals, np.concatenate([po_ev.reshape(-1, 2), lo_ev.reshape(-1, 2)]))
+    assert np.array_equal(proof.msgs, oproof.msgs)
+    assert np.array_equal(proof.prod_evals, oproof.prod_evals)
+    assert np.array_equal(proof.logup_evals, oproof.logup_evals)
+    assert np.array_equal(proof.point[:6], oproof.point[:6])
+    # and the restated verifier accepts the GPU proof
+    vt = po.StubTranscript(8)
+    for e in list(po_ev.reshape(-1, 2)) + list(lo_ev.reshape(-1, 2)):
+        vt.append_ext(tup(e))
+    oproof.msgs[:] = proof.msgs
+    rc, pt, pc, lp, lq = po.tower_verify(po_ev, lo_ev, [6, 4, 2, 5, 6], oproof, vt)
+    assert rc == 0
