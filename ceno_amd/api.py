@@ -285,3 +285,58 @@ class Sumcheck:
             self.free()
         except Exception:
             pass
+
+
+# ---- Basefold commit path over raw device memory (torch tensors or Mle.device_ptr) -----------------
+def ntt_batch(dev: Device, dev_ptr: int, log_n: int, n_cols: int, inverse: bool = False, stream=None):
+    dev.check(dev.L.ceno_hip_ntt_batch(dev.h, C.c_void_p(dev_ptr), log_n, n_cols, int(inverse), stream))
+
+
+def rs_encode(dev: Device, src_ptr: int, log_n: int, n_cols: int, log_blowup: int, dst_ptr: int, stream=None):
+    dev.check(dev.L.ceno_hip_rs_encode(dev.h, C.c_void_p(src_ptr), log_n, n_cols, log_blowup, C.c_void_p(dst_ptr), stream))
+
+
+def transpose(dev: Device, src_ptr: int, rows: int, width: int, dst_ptr: int, stream=None):
+    dev.check(dev.L.ceno_hip_transpose(dev.h, C.c_void_p(src_ptr), rows, width, C.c_void_p(dst_ptr), stream))
+
+
+def poseidon2_permute(dev: Device, states_ptr: int, n: int, stream=None):
+    dev.check(dev.L.ceno_hip_poseidon2_permute(dev.h, C.c_void_p(states_ptr), n, stream))
+
+
+def poseidon2_set_constants(dev: Device, ext_rc=None, int_rc=None, int_diag=None):
+    def p(a):
+        return _p(np.ascontiguousarray(a, dtype=np.uint64)) if a is not None else None
+
+    dev.check(dev.L.ceno_hip_poseidon2_set_constants(dev.h, p(ext_rc), p(int_rc), p(int_diag)))
+
+
+class Merkle:
+    """Poseidon2 Merkle tree over the rows of a column-major matrix (reference: basefold PcsData)"""
+
+    def __init__(self, dev: Device, col_major_ptr: int, log_rows: int, width: int, stream=None):
+        self.dev, self.log_rows = dev, log_rows
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_merkle_commit(dev.h, C.c_void_p(col_major_ptr), log_rows, width, stream, C.byref(h)))
+        self.h = h
+
+    def root(self, stream=None) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        self.dev.check(self.dev.L.ceno_hip_merkle_root(self.dev.h, self.h, _p(out), stream))
+        return out
+
+    def open(self, index: int, stream=None) -> np.ndarray:
+        out = np.zeros((max(self.log_rows, 1), 4), dtype=np.uint64)
+        self.dev.check(self.dev.L.ceno_hip_merkle_open(self.dev.h, self.h, index, _p(out), stream))
+        return out[: self.log_rows]
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            self.dev.L.ceno_hip_merkle_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

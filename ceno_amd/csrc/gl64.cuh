@@ -22,43 +22,119 @@ constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
 constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
 constexpr uint64_t W = 7;                // X^2 = W
 
+// ---- 32-bit add/sub with carry: clang lowers the builtins to v_add_co/v_addc_co chains (carry kept
+// in VCC / an SGPR pair, no compare+select), g++ gets portable equivalents for the host build ----
+#if defined(__clang__)
+GL_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) { return __builtin_addc(a, b, cin, &cout); }
+GL_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) { return __builtin_subc(a, b, bin, &bout); }
+#else
+GL_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
+    uint64_t s = (uint64_t)a + b + cin;
+    cout = (uint32_t)(s >> 32);
+    return (uint32_t)s;
+}
+GL_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
+    uint64_t d = (uint64_t)a - b - bin;
+    bout = (uint32_t)(d >> 63);
+    return (uint32_t)d;
+}
+#endif
+GL_HD uint64_t join(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
-    uint64_t s = a + b;
-    uint64_t t = s + EPS;  // s - p (mod 2^64)
-    return (s < a || s >= P) ? t : s;
+    // s = a + b (65 bit); u = s - p = s + EPS (mod 2^64); take u when s >= p
+    uint32_t c, c2;
+    const uint32_t s0 = addc32((uint32_t)a, (uint32_t)b, 0u, c);
+    const uint32_t s1 = addc32((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, c);
+    const uint32_t u0 = addc32(s0, 0xFFFFFFFFu, 0u, c2);
+    const uint32_t u1 = addc32(s1, 0u, c2, c2);
+    const bool take = (c | c2) != 0;  // overflowed 2^64, or s + EPS overflowed <=> s >= p
+    return take ? join(u0, u1) : join(s0, s1);
 }
 GL_HD uint64_t sub(uint64_t a, uint64_t b) {
-    uint64_t d = a - b;
-    return (a < b) ? d - EPS : d;  // + p (mod 2^64)
+    uint32_t bw, b2;
+    uint32_t d0 = subc32((uint32_t)a, (uint32_t)b, 0u, bw);
+    uint32_t d1 = subc32((uint32_t)(a >> 32), (uint32_t)(b >> 32), bw, bw);
+    const uint32_t m = 0u - bw;  // borrow: add p = subtract EPS
+    d0 = subc32(d0, m, 0u, b2);
+    d1 = subc32(d1, 0u, b2, b2);
+    return join(d0, d1);
 }
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
 GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
 
-GL_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
-#else
-    return (uint64_t)(((unsigned __int128)a * b) >> 64);
-#endif
+// ---- 64x64 -> 128 product as four 32-bit limbs, from four 32x32+64 multiply-adds (v_mad_u64_u32) ----
+struct L4 {
+    uint32_t w0, w1, w2, w3;
+};
+GL_HD L4 mul_wide(uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    const uint64_t p00 = (uint64_t)a0 * b0;
+    const uint64_t t = (uint64_t)a0 * b1 + (p00 >> 32);              // <= (2^32-1)^2 + 2^32-1 < 2^64
+    const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;              // same bound
+    const uint64_t hi = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);   // <= 2^64 - 1
+    return L4{(uint32_t)p00, (uint32_t)t2, (uint32_t)hi, (uint32_t)(hi >> 32)};
 }
 
-// reduce hi*2^64 + lo (any 128-bit value) to canonical form
+// Reduce  (w1:w0) + w2*2^64 + w3*2^96 + c*2^128  (c in {0,1}) to canonical form with
+// 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p):   x = (w1:w0) + w2*(2^32-1) - (c:w3).
+GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
+    uint32_t bw, b2, cy, c2;
+    uint32_t r0 = subc32(w0, w3, 0u, bw);
+    uint32_t r1 = subc32(w1, c, bw, bw);
+    const uint32_t m = 0u - bw;      // wrapped by 2^64 = EPS (mod p): subtract EPS; r >= 2^64 - 2^33 so no second wrap
+    r0 = subc32(r0, m, 0u, b2);
+    r1 = subc32(r1, 0u, b2, b2);
+    // w2 * (2^32 - 1) without a multiply: low word = -w2, high word = w2 - (w2 != 0)
+    const uint32_t t1l = subc32(0u, w2, 0u, b2);
+    const uint32_t t1h = subc32(w2, 0u, b2, b2);
+    r0 = addc32(r0, t1l, 0u, cy);
+    r1 = addc32(r1, t1h, cy, cy);
+    const uint32_t m2 = 0u - cy;     // wrapped again: add EPS; cannot wrap a third time (t1 <= 2^64 - 2^33 + 1)
+    r0 = addc32(r0, m2, 0u, c2);
+    r1 = addc32(r1, 0u, c2, c2);
+    // canonical: r + EPS overflows <=> r >= p
+    const uint32_t u0 = addc32(r0, 0xFFFFFFFFu, 0u, cy);
+    const uint32_t u1 = addc32(r1, 0u, cy, cy);
+    return cy ? join(u0, u1) : join(r0, r1);
+}
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
+    return reduce_limbs((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0u);
+}
+GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+    const L4 p = mul_wide(a, b);
+    return reduce_limbs(p.w0, p.w1, p.w2, p.w3, 0u);
+}
+// a*b + c*d with a single reduction (129-bit sum)
+GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    const L4 p = mul_wide(a, b), q = mul_wide(c, d);
+    uint32_t cy;
+    const uint32_t s0 = addc32(p.w0, q.w0, 0u, cy);
+    const uint32_t s1 = addc32(p.w1, q.w1, cy, cy);
+    const uint32_t s2 = addc32(p.w2, q.w2, cy, cy);
+    const uint32_t s3 = addc32(p.w3, q.w3, cy, cy);
+    return reduce_limbs(s0, s1, s2, s3, cy);
+}
+GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+// small-constant multiply (c < 2^32): the product has 96 bits
+GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
+    const uint64_t p0 = (uint64_t)(uint32_t)a * c;
+    const uint64_t p1 = (uint64_t)(uint32_t)(a >> 32) * c + (p0 >> 32);
+    return reduce_limbs((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32), 0u, 0u);
+}
+// reference forms kept for cross-checks (tests/test_host_cpu.py)
+GL_HD uint64_t mul_ref(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t lo = a * b, hi = __umul64hi(a, b);
+#else
+    unsigned __int128 w = (unsigned __int128)a * b;
+    uint64_t lo = (uint64_t)w, hi = (uint64_t)(w >> 64);
+#endif
     uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
     uint64_t t0 = lo - hi_hi;
     if (lo < hi_hi) t0 -= EPS;
-    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * EPS
+    uint64_t t1 = (hi_lo << 32) - hi_lo;
     uint64_t r = t0 + t1;
-    if (r < t1) r += EPS;
-    return r >= P ? r - P : r;
-}
-GL_HD uint64_t mul(uint64_t a, uint64_t b) { return reduce128(a * b, mulhi64(a, b)); }
-GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
-// small-constant multiply (c < 2^32): product fits 96 bits
-GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
-    uint64_t lo = a * (uint64_t)c, hi = mulhi64(a, (uint64_t)c);  // hi < 2^32
-    uint64_t t1 = (hi << 32) - hi;
-    uint64_t r = lo + t1;
     if (r < t1) r += EPS;
     return r >= P ? r - P : r;
 }
@@ -87,13 +163,24 @@ GL_HD E2 operator-(E2 a, E2 b) { return E2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 GL_HD E2 e2_neg(E2 a) { return E2{neg(a.c0), neg(a.c1)}; }
 GL_HD E2 e2_dbl(E2 a) { return E2{dbl(a.c0), dbl(a.c1)}; }
 
-// (a0 + a1 X)(b0 + b1 X) = (a0 b0 + 7 a1 b1) + ((a0+a1)(b0+b1) - a0 b0 - a1 b1) X   [Karatsuba, 3 mults]
+// (a0 + a1 X)(b0 + b1 X) = (a0 b0 + (7 a1) b1) + (a0 b1 + a1 b0) X
+// schoolbook with lazy reduction: four 128-bit products, two 129-bit sums, two reductions.
 GL_HD E2 operator*(E2 a, E2 b) {
-    uint64_t m0 = mul(a.c0, b.c0);
-    uint64_t m1 = mul(a.c1, b.c1);
-    // (a0+a1) and (b0+b1) may exceed 64 bits: reduce first (canonical add)
-    uint64_t m2 = mul(add(a.c0, a.c1), add(b.c0, b.c1));
-    uint64_t w = mul_small(m1, (uint32_t)W);
+    const uint64_t a1w = mul_small(a.c1, (uint32_t)W);
+    return E2{mul_add2(a.c0, b.c0, a1w, b.c1), mul_add2(a.c0, b.c1, a.c1, b.c0)};
+}
+// multiply by a fixed element whose W*c1 is precomputed (sumcheck challenge r)
+struct E2Pre {
+    uint64_t c0, c1, c1w;
+};
+GL_HD E2Pre e2_pre(E2 r) { return E2Pre{r.c0, r.c1, mul_small(r.c1, (uint32_t)W)}; }
+GL_HD E2 e2_mul_pre(E2Pre r, E2 b) { return E2{mul_add2(r.c0, b.c0, r.c1w, b.c1), mul_add2(r.c0, b.c1, r.c1, b.c0)}; }
+// Karatsuba form with three full multiplications, kept as an independent cross-check
+GL_HD E2 e2_mul_ref(E2 a, E2 b) {
+    uint64_t m0 = mul_ref(a.c0, b.c0);
+    uint64_t m1 = mul_ref(a.c1, b.c1);
+    uint64_t m2 = mul_ref(add(a.c0, a.c1), add(b.c0, b.c1));
+    uint64_t w = mul_ref(m1, W);
     return E2{add(m0, w), sub(sub(m2, m0), m1)};
 }
 GL_HD E2 e2_mul_base(E2 a, uint64_t b) { return E2{mul(a.c0, b), mul(a.c1, b)}; }

@@ -34,13 +34,14 @@ __global__ void __launch_bounds__(NT) k_fill_splitmix(uint64_t* out, size_t n_wo
 template <bool IN_EXT>
 __global__ void __launch_bounds__(NT) k_fold(const uint64_t* __restrict__ in, E2* __restrict__ out, size_t half, E2 r) {
     size_t stride = (size_t)gridDim.x * NT;
+    const E2Pre rp = e2_pre(r);
     for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {
         E2 lo, hi;
         if (IN_EXT) {
             const E2* p = reinterpret_cast<const E2*>(in) + 2 * j;
             lo = p[0];
             hi = p[1];
-            out[j] = lo + r * (hi - lo);
+            out[j] = lo + e2_mul_pre(rp, hi - lo);
         } else {
             ulonglong2 v = *reinterpret_cast<const ulonglong2*>(in + 2 * j);
             uint64_t d = sub(v.y, v.x);

@@ -1,0 +1,231 @@
+// Radix-2 NTT over Goldilocks and Reed–Solomon encoding of trace columns (Basefold commit path).
+//
+// Reference: the RS encoding inside EXT `mpcs::Basefold::batch_commit` (call sites
+// ceno_zkvm/src/scheme/cpu/mod.rs:559-584, gpu/mod.rs:1642-1646); bit-reversed codeword order as in
+// `encode_small_final_message` (ceno_recursion_v2/src/pcs/mod.rs:7739-7743).  PARITY UNPINNED: rate,
+// evaluation domain and layout live in the EXT crate.  The two-adic generator is the published
+// p3-goldilocks one: 7^((p-1)/2^32) = 1753635133440165772 (order 2^32).
+//
+// Forward = decimation in frequency (natural order in, bit-reversed out), in place, per column:
+//   passes over HBM of `R` = 4 stages each held in registers (16 strided elements per lane, coalesced
+//   along the contiguous index), then ONE pass that finishes the last <= 11 stages of every 2048-element
+//   block in LDS.  log N = 21 -> 3 HBM passes + 1 LDS pass (vs 21 for stage-per-launch).
+// Inverse = the mirrored decimation in time with inverse twiddles and the 1/N scale fused in the last pass.
+// Twiddles w^i (i < N/2) are tabulated once per size in HBM (8 MB at N = 2^21) and stay L2-resident.
+#include "common.hpp"
+
+#include <map>
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr int LOCAL_LOG = 11;  // 2048 elements = 16 KB of LDS per block
+static constexpr uint64_t TWO_ADIC_GEN_2_32 = 1753635133440165772ULL;
+
+static std::mutex g_tw_mu;
+static std::map<std::pair<ceno_hip_ctx*, int>, uint64_t*> g_tw_fwd, g_tw_inv;
+
+__global__ void __launch_bounds__(NT) k_twiddles(uint64_t* tw, size_t half, uint64_t w) {
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < half; i += stride) tw[i] = gl::pow(w, i);
+}
+
+static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t st, const uint64_t** out) {
+    std::lock_guard<std::mutex> g(g_tw_mu);
+    auto& cache = inverse ? g_tw_inv : g_tw_fwd;
+    auto key = std::make_pair(ctx, log_n);
+    auto it = cache.find(key);
+    if (it != cache.end()) {
+        *out = it->second;
+        return 0;
+    }
+    uint64_t w = gl::pow(TWO_ADIC_GEN_2_32, (uint64_t)1 << (32 - log_n));  // primitive 2^log_n-th root
+    if (inverse) w = gl::inv(w);
+    size_t half = log_n ? (size_t)1 << (log_n - 1) : 1;
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, half * 8));
+    hipLaunchKernelGGL(k_twiddles, dim3(grid_for(half, NT, 2048)), dim3(NT), 0, st, (uint64_t*)p, half, w);
+    HIP_TRY(ctx, hipGetLastError());
+    cache[key] = (uint64_t*)p;
+    *out = (uint64_t*)p;
+    return 0;
+}
+
+// R register-resident stages starting at global stage `s` (forward DIF) — or ending at stage s (inverse DIT).
+// Block of size M = N >> s splits into L = M >> R interleaved sub-sequences; a lane owns indices
+// blk*M + k*L + l, k < 2^R.
+template <int R, bool INVERSE>
+__global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data, int log_n, int s, const uint64_t* __restrict__ tw,
+                                                    uint64_t scale) {
+    constexpr int E = 1 << R;
+    const size_t n = (size_t)1 << log_n;
+    uint64_t* col = data + (size_t)blockIdx.y * n;
+    const int log_m = log_n - s;
+    const int log_l = log_m - R;
+    const size_t L = (size_t)1 << log_l;
+    const size_t items = n >> R;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t it = (size_t)blockIdx.x * NT + threadIdx.x; it < items; it += stride) {
+        const size_t blk = it >> log_l, l = it & (L - 1);
+        uint64_t* base = col + (blk << log_m) + l;
+        uint64_t v[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) v[k] = base[(size_t)k << log_l];
+        if (!INVERSE) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                // global stage s+q: sub-block of 2^(R-q) lanes-elements, partner distance 2^(R-q-1)
+                const int hb = 1 << (R - q - 1);
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    if ((k & hb) == 0) {
+                        const int kk = k & (2 * hb - 1);  // position inside the sub-block (lower half)
+                        const size_t pos = ((size_t)kk << log_l) + l;
+                        const uint64_t w = tw[pos << (s + q)];
+                        const uint64_t a = v[k], b = v[k + hb];
+                        v[k] = add(a, b);
+                        v[k + hb] = mul(sub(a, b), w);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = R - 1; q >= 0; q--) {
+                const int hb = 1 << (R - q - 1);
+#pragma unroll
+                for (int k = 0; k < E; k++) {
+                    if ((k & hb) == 0) {
+                        const int kk = k & (2 * hb - 1);
+                        const size_t pos = ((size_t)kk << log_l) + l;
+                        const uint64_t w = tw[pos << (s + q)];
+                        const uint64_t a = v[k], b = mul(v[k + hb], w);
+                        v[k] = add(a, b);
+                        v[k + hb] = sub(a, b);
+                    }
+                }
+            }
+            if (scale != 1) {
+#pragma unroll
+                for (int k = 0; k < E; k++) v[k] = mul(v[k], scale);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; k++) base[(size_t)k << log_l] = v[k];
+    }
+}
+
+// last (forward) / first (inverse) `lb` stages of every contiguous 2^lb block, in LDS
+template <bool INVERSE>
+__global__ void __launch_bounds__(NT) k_ntt_local(uint64_t* __restrict__ data, int log_n, int lb, const uint64_t* __restrict__ tw, uint64_t scale) {
+    __shared__ uint64_t sm[1 << LOCAL_LOG];
+    const size_t n = (size_t)1 << log_n;
+    const size_t bsz = (size_t)1 << lb;
+    const size_t n_blocks = n >> lb;
+    uint64_t* col = data + (size_t)blockIdx.y * n;
+    const int s0 = log_n - lb;  // first global stage handled here
+    for (size_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        uint64_t* base = col + blk * bsz;
+        for (size_t i = threadIdx.x; i < bsz; i += NT) sm[i] = base[i];
+        __syncthreads();
+        if (!INVERSE) {
+            for (int q = 0; q < lb; q++) {
+                const int log_half = lb - q - 1;
+                const size_t half = (size_t)1 << log_half;
+                for (size_t b = threadIdx.x; b < bsz / 2; b += NT) {
+                    const size_t j = b & (half - 1), grp = b >> log_half;
+                    const size_t i0 = (grp << (log_half + 1)) + j, i1 = i0 + half;
+                    const uint64_t w = tw[j << (s0 + q)];
+                    const uint64_t a = sm[i0], c = sm[i1];
+                    sm[i0] = add(a, c);
+                    sm[i1] = mul(sub(a, c), w);
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int q = lb - 1; q >= 0; q--) {
+                const int log_half = lb - q - 1;
+                const size_t half = (size_t)1 << log_half;
+                for (size_t b = threadIdx.x; b < bsz / 2; b += NT) {
+                    const size_t j = b & (half - 1), grp = b >> log_half;
+                    const size_t i0 = (grp << (log_half + 1)) + j, i1 = i0 + half;
+                    const uint64_t w = tw[j << (s0 + q)];
+                    const uint64_t a = sm[i0], c = mul(sm[i1], w);
+                    sm[i0] = add(a, c);
+                    sm[i1] = sub(a, c);
+                }
+                __syncthreads();
+            }
+        }
+        for (size_t i = threadIdx.x; i < bsz; i += NT) base[i] = (INVERSE && scale != 1) ? mul(sm[i], scale) : sm[i];
+        __syncthreads();
+    }
+}
+
+template <bool INV>
+static void launch_strided(int R, uint64_t* d, int log_n, int s, const uint64_t* tw, uint64_t scale, int n_cols, hipStream_t st) {
+    size_t items = ((size_t)1 << log_n) >> R;
+    dim3 grid(grid_for(items, NT, 2048), (unsigned)n_cols);
+    switch (R) {
+    case 1: hipLaunchKernelGGL((k_ntt_strided<1, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
+    case 2: hipLaunchKernelGGL((k_ntt_strided<2, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
+    case 3: hipLaunchKernelGGL((k_ntt_strided<3, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
+    default: hipLaunchKernelGGL((k_ntt_strided<4, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
+    }
+}
+
+static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool inverse, hipStream_t st) {
+    CHECK_ARG(ctx, d && log_n >= 0 && log_n <= 32 && n_cols >= 1 && n_cols <= 65535, "bad ntt arguments (log_n %d, cols %d)", log_n, n_cols);
+    if (log_n == 0) return 0;
+    const uint64_t* tw = nullptr;
+    TRY(get_twiddles(ctx, log_n, inverse, st, &tw));
+    const int lb = log_n < LOCAL_LOG ? log_n : LOCAL_LOG;
+    const int n_strided = log_n - lb;  // stages done by strided passes
+    const size_t n_blocks = ((size_t)1 << log_n) >> lb;
+    dim3 lgrid((unsigned)(n_blocks < 1024 ? n_blocks : 1024), (unsigned)n_cols);
+    if (!inverse) {
+        int s = 0;
+        while (s < n_strided) {
+            int R = n_strided - s >= 4 ? 4 : n_strided - s;
+            launch_strided<false>(R, d, log_n, s, tw, 1, n_cols, st);
+            s += R;
+        }
+        hipLaunchKernelGGL(k_ntt_local<false>, lgrid, dim3(NT), 0, st, d, log_n, lb, tw, (uint64_t)1);
+    } else {
+        const uint64_t n_inv = gl::inv(((uint64_t)1 << log_n) % gl::P);
+        // mirrored order: local stages first, then strided groups from the innermost outwards
+        hipLaunchKernelGGL(k_ntt_local<true>, lgrid, dim3(NT), 0, st, d, log_n, lb, tw, n_strided == 0 ? n_inv : (uint64_t)1);
+        int s = n_strided;
+        while (s > 0) {
+            int R = s >= 4 ? 4 : s;
+            s -= R;
+            launch_strided<true>(R, d, log_n, s, tw, s == 0 ? n_inv : (uint64_t)1, n_cols, st);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+__global__ void __launch_bounds__(NT) k_pad_copy(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t n_in, size_t n_out) {
+    const uint64_t* src = in + (size_t)blockIdx.y * n_in;
+    uint64_t* dst = out + (size_t)blockIdx.y * n_out;
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n_out; i += stride) dst[i] = i < n_in ? src[i] : 0;
+}
+
+extern "C" {
+
+int ceno_hip_ntt_batch(ceno_hip_ctx* ctx, uint64_t* dev_cols, int log_n, int n_cols, int inverse, ceno_hip_stream s) {
+    return ntt_impl(ctx, dev_cols, log_n, n_cols, inverse != 0, ctx_stream(ctx, s));
+}
+
+int ceno_hip_rs_encode(ceno_hip_ctx* ctx, const uint64_t* dev_cols, int log_n, int n_cols, int log_blowup, uint64_t* dev_codewords, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_cols && dev_codewords && log_blowup >= 0 && log_n >= 0 && log_n + log_blowup <= 32, "bad rs_encode arguments");
+    CHECK_ARG(ctx, n_cols >= 1 && n_cols <= 65535, "bad column count");
+    hipStream_t st = ctx_stream(ctx, s);
+    size_t n_in = (size_t)1 << log_n, n_out = (size_t)1 << (log_n + log_blowup);
+    hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(n_out, NT, 2048), (unsigned)n_cols), dim3(NT), 0, st, dev_cols, dev_codewords, n_in, n_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return ntt_impl(ctx, dev_codewords, log_n + log_blowup, n_cols, false, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// Poseidon2 permutation over Goldilocks, width 8 (rate 4 / capacity 4), S-box x^7,
+// 8 external (4 + 4) and 22 internal rounds — the shape of p3-poseidon2 0.4.3 for Goldilocks that the
+// reference's EXT `poseidon` / `transcript` / `mpcs` crates instantiate (reference Cargo.lock:4111-4375).
+//
+// PARITY UNPINNED (SURVEY.md §8c(i),(ii)): the round constants are not present anywhere under
+// /root/reference.  The defaults below are PLACEHOLDERS derived from SplitMix64("poseidon2-goldilocks-8")
+// — structurally valid, not the HorizenLabs constants — and can be replaced at run time through
+// ceno_hip_poseidon2_set_constants() once goldens from the real BasicTranscript are available.
+// The internal diagonal is the published MATRIX_DIAG_8_GOLDILOCKS.
+#pragma once
+#include "gl64.cuh"
+
+namespace p2 {
+
+constexpr int WIDTH = 8;
+constexpr int RATE = 4;
+constexpr int ROUNDS_F = 8;
+constexpr int ROUNDS_P = 22;
+
+struct Params {
+    uint64_t ext_rc[ROUNDS_F][WIDTH];
+    uint64_t int_rc[ROUNDS_P];
+    uint64_t int_diag[WIDTH];
+};
+
+inline void default_params(Params& p) {
+    const uint64_t seed = 0x706f736569646f6eULL;  // "poseidon"
+    uint64_t i = 0;
+    for (int r = 0; r < ROUNDS_F; r++)
+        for (int k = 0; k < WIDTH; k++) p.ext_rc[r][k] = gl::splitmix_gl(seed, i++);
+    for (int r = 0; r < ROUNDS_P; r++) p.int_rc[r] = gl::splitmix_gl(seed, i++);
+    const uint64_t diag[WIDTH] = {0xa98811a1fed4e3a5ULL, 0x1cc48b54f377e2a0ULL, 0xe40cd4f6c5609a26ULL, 0x11de79ebca97a4a3ULL,
+                                  0x9177c73d8b7e929cULL, 0x2a6fe8085797e791ULL, 0x3de6e93329f8d5adULL, 0x3f7af9125da962feULL};
+    for (int k = 0; k < WIDTH; k++) p.int_diag[k] = diag[k];
+}
+
+GL_HD uint64_t sbox7(uint64_t x) {
+    uint64_t x2 = gl::mul(x, x);
+    uint64_t x3 = gl::mul(x2, x);
+    uint64_t x4 = gl::mul(x2, x2);
+    return gl::mul(x4, x3);
+}
+
+// [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]]
+GL_HD void mat4(uint64_t* x) {
+    using gl::add;
+    uint64_t t01 = add(x[0], x[1]), t23 = add(x[2], x[3]);
+    uint64_t t0123 = add(t01, t23);
+    uint64_t t01123 = add(t0123, x[1]), t01233 = add(t0123, x[3]);
+    uint64_t n3 = add(t01233, gl::dbl(x[0]));
+    uint64_t n1 = add(t01123, gl::dbl(x[2]));
+    uint64_t n0 = add(t01123, t01);
+    uint64_t n2 = add(t01233, t23);
+    x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3;
+}
+
+GL_HD void external_linear(uint64_t* s) {
+    mat4(s);
+    mat4(s + 4);
+    uint64_t sums[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) sums[i] = gl::add(s[i], s[i + 4]);
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::add(s[i], sums[i & 3]);
+}
+
+GL_HD void internal_linear(uint64_t* s, const Params& p) {
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) sum = gl::add(sum, s[i]);
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::add(gl::mul(s[i], p.int_diag[i]), sum);
+}
+
+GL_HD void permute(uint64_t* s, const Params& p) {
+    external_linear(s);
+    for (int r = 0; r < ROUNDS_F / 2; r++) {
+#pragma unroll
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add(s[i], p.ext_rc[r][i]));
+        external_linear(s);
+    }
+    for (int r = 0; r < ROUNDS_P; r++) {
+        s[0] = sbox7(gl::add(s[0], p.int_rc[r]));
+        internal_linear(s, p);
+    }
+    for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
+#pragma unroll
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7(gl::add(s[i], p.ext_rc[r][i]));
+        external_linear(s);
+    }
+}
+
+}  // namespace p2

@@ -1,0 +1,189 @@
+// Poseidon2 permutation, row sponge and Merkle tree on gfx950 (Basefold commit path).
+//
+// Reference: `cuda_hal.basefold.batch_commit` (ceno_zkvm/src/scheme/gpu/mod.rs:1642-1646) — per trace
+// matrix: hash every codeword ROW with a Poseidon2 sponge, build the 2-to-1 compression tree, root =
+// commitment (shape restated in ceno_recursion_v2/src/pcs/mod.rs:1111-1316).
+// Sponge = overwrite-mode padding-free sponge (rate 4, width 8, 4-word digest); compression =
+// truncated permutation of left || right.  PARITY UNPINNED — constants, see poseidon2.cuh.
+//
+// One lane runs one permutation with the 8-word state in registers (16 VGPRs); the matrix is column-
+// major so the lanes of a wave read consecutive rows of a column: 8 B per lane coalesced.  The kernel
+// is ALU bound (118 S-boxes x 4 mults + linear layers per permutation); reported separately from the
+// HBM roofline.
+#include "common.hpp"
+#include "poseidon2.cuh"
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr unsigned MAXB = 4096;
+
+struct PoseidonParams {
+    p2::Params p;
+};
+
+struct ceno_hip_merkle {
+    int log_rows = 0;
+    std::vector<uint64_t*> levels;  // levels[0] = 2^log_rows leaf digests (4 words each) ... levels[log_rows] = root
+};
+
+static int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
+    if (!ctx->poseidon_dev) {
+        PoseidonParams h;
+        p2::default_params(h.p);
+        void* d = nullptr;
+        HIP_TRY(ctx, hipMalloc(&d, sizeof(PoseidonParams)));
+        HIP_TRY(ctx, hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
+        ctx->poseidon_dev = (PoseidonParams*)d;
+    }
+    *out = &ctx->poseidon_dev->p;
+    return 0;
+}
+
+__global__ void __launch_bounds__(NT) k_permute(uint64_t* states, size_t n, const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        uint64_t s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = states[i * 8 + k];
+        p2::permute(s, sp);
+#pragma unroll
+        for (int k = 0; k < 8; k++) states[i * 8 + k] = s[k];
+    }
+}
+
+// leaf digests: sponge over row `r` of a column-major matrix (col stride = rows)
+__global__ void __launch_bounds__(NT) k_leaf_hash(const uint64_t* __restrict__ m, size_t rows, int width, uint64_t* __restrict__ digests,
+                                                  const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        uint64_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < width; c += p2::RATE) {
+#pragma unroll
+            for (int k = 0; k < p2::RATE; k++)
+                if (c + k < width) s[k] = m[(size_t)(c + k) * rows + r];  // overwrite mode; a short last chunk keeps the old tail
+            p2::permute(s, sp);
+        }
+        *reinterpret_cast<ulonglong2*>(digests + 4 * r) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(digests + 4 * r + 2) = make_ulonglong2(s[2], s[3]);
+    }
+}
+
+// parent[i] = perm(child[2i] || child[2i+1])[0..4)
+__global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ child, size_t n_parent, uint64_t* __restrict__ parent,
+                                                 const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n_parent; i += stride) {
+        uint64_t s[8];
+        const ulonglong2* c = reinterpret_cast<const ulonglong2*>(child + 8 * i);
+        ulonglong2 a = c[0], b = c[1], d = c[2], e = c[3];
+        s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = d.x; s[5] = d.y; s[6] = e.x; s[7] = e.y;
+        p2::permute(s, sp);
+        *reinterpret_cast<ulonglong2*>(parent + 4 * i) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(parent + 4 * i + 2) = make_ulonglong2(s[2], s[3]);
+    }
+}
+
+static void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
+    if (!t) return;
+    for (auto* p : t->levels) ctx_free(ctx, p);
+    delete t;
+}
+
+extern "C" {
+
+int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external_rc, const uint64_t* internal_rc, const uint64_t* internal_diag) {
+    const p2::Params* dummy;
+    TRY(get_params(ctx, &dummy));
+    PoseidonParams h;
+    p2::default_params(h.p);
+    if (external_rc) memcpy(h.p.ext_rc, external_rc, sizeof(h.p.ext_rc));
+    if (internal_rc) memcpy(h.p.int_rc, internal_rc, sizeof(h.p.int_rc));
+    if (internal_diag) memcpy(h.p.int_diag, internal_diag, sizeof(h.p.int_diag));
+    for (size_t i = 0; i < sizeof(h) / 8; i++)
+        CHECK_ARG(ctx, reinterpret_cast<uint64_t*>(&h)[i] < gl::P, "poseidon2 constant %zu is not canonical", i);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(ctx->poseidon_dev, &h, sizeof(h), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ceno_hip_poseidon2_permute(ceno_hip_ctx* ctx, uint64_t* dev_states, size_t n, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_states, "NULL argument");
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    hipStream_t st = ctx_stream(ctx, s);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_permute, dim3(grid_for(n, NT, MAXB)), dim3(NT), 0, st, dev_states, n, pp);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int log_rows, int width, ceno_hip_stream s, ceno_hip_merkle** out) {
+    CHECK_ARG(ctx, dev_col_major && out && log_rows >= 0 && log_rows < 40 && width >= 1, "bad merkle arguments");
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    hipStream_t st = ctx_stream(ctx, s);
+    auto* t = new ceno_hip_merkle();
+    t->log_rows = log_rows;
+    t->levels.assign(log_rows + 1, nullptr);
+    for (int l = 0; l <= log_rows; l++) {
+        void* p = nullptr;
+        int rc = ctx_alloc(ctx, ((size_t)1 << (log_rows - l)) * 32, &p);
+        if (rc) {
+            merkle_release(ctx, t);
+            return rc;
+        }
+        t->levels[l] = (uint64_t*)p;
+    }
+    size_t rows = (size_t)1 << log_rows;
+    hipLaunchKernelGGL(k_leaf_hash, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, dev_col_major, rows, width, t->levels[0], pp);
+    for (int l = 1; l <= log_rows; l++) {
+        size_t np = (size_t)1 << (log_rows - l);
+        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        merkle_release(ctx, t);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "merkle commit: %s", hipGetErrorString(e));
+    }
+    *out = t;
+    return 0;
+}
+
+int ceno_hip_merkle_root(ceno_hip_ctx* ctx, ceno_hip_merkle* t, uint64_t* root4, ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && root4, "NULL argument");
+    hipStream_t st = ctx_stream(ctx, s);
+    HIP_TRY(ctx, hipMemcpyAsync(root4, t->levels[t->log_rows], 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, uint64_t* path, ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && path, "NULL argument");
+    CHECK_ARG(ctx, index < ((size_t)1 << t->log_rows), "leaf index out of range");
+    hipStream_t st = ctx_stream(ctx, s);
+    size_t idx = index;
+    for (int l = 0; l < t->log_rows; l++) {
+        HIP_TRY(ctx, hipMemcpyAsync(path + 4 * l, t->levels[l] + 4 * (idx ^ 1), 32, hipMemcpyDeviceToHost, st));
+        idx >>= 1;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
+    if (t) (void)hipStreamSynchronize(ctx->default_stream);
+    merkle_release(ctx, t);
+    return 0;
+}
+
+}  // extern "C"

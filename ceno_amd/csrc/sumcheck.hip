@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
 #pragma unroll
     for (int t = 0; t < K; t++) acc[t] = e2_zero();
     const size_t stride = (size_t)gridDim.x * NT;
+    const E2Pre rp = e2_pre(r);
     for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
         if (MODE == 1) {
             // all-base first round: the product of base values stays in the base field
@@ -78,8 +79,8 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
                 } else if (MODE == 2) {
                     const uint64_t* q = tp.in[m] + 8 * p;
                     E2 a0 = ld_e2(q), a1 = ld_e2(q + 2), a2 = ld_e2(q + 4), a3 = ld_e2(q + 6);
-                    lo = a0 + r * (a1 - a0);
-                    hi = a2 + r * (a3 - a2);
+                    lo = a0 + e2_mul_pre(rp, a1 - a0);
+                    hi = a2 + e2_mul_pre(rp, a3 - a2);
                     st_e2(tp.out[m] + 4 * p, lo);
                     st_e2(tp.out[m] + 4 * p + 2, hi);
                 } else {
@@ -126,11 +127,12 @@ __global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ s
     const MleSlot sl = slots[blockIdx.y];
     const size_t stride = (size_t)gridDim.x * NT;
     E2* out = reinterpret_cast<E2*>(sl.out);
+    const E2Pre rp = e2_pre(r);
     if (sl.in_ext) {
         const E2* in = reinterpret_cast<const E2*>(sl.in);
         for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {
             E2 lo = in[2 * j], hi = in[2 * j + 1];
-            out[j] = lo + r * (hi - lo);
+            out[j] = lo + e2_mul_pre(rp, hi - lo);
         }
     } else {
         for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < half; j += stride) {

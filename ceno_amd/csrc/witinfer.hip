@@ -1,0 +1,152 @@
+// Element-wise record inference and trace transpose.
+//
+// wit_infer: reference `wit_infer_by_monomial_expr` (EXT; CPU caller gkr_iop/src/cpu/mod.rs:119-176,
+// GPU call site gkr_iop/src/gpu/mod.rs:599-609): out[o][x] = sum_t c_t prod_j f_j[x] with base-field
+// witness columns in and extension-field record columns out (RLC with alpha, beta).
+// Traffic: 8 B per input column + 16 B per output column per row -> HBM bound; column re-reads across
+// outputs of the same row tile are served by L1/L2.
+// transpose: reference `common::transpose::matrix_transpose` (ceno_zkvm/src/scheme/gpu/mod.rs:84,963-968):
+// row-major RowMajorMatrix values[row*width+col] -> column-major device layout.
+#include "common.hpp"
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr unsigned MAXB = 2048;
+
+struct WiSlot {
+    const uint64_t* ptr;
+    int is_ext;
+    int pad;
+};
+
+struct WiPlan {
+    const WiSlot* mles;
+    const E2* coeffs;
+    const uint32_t* term_off;
+    const uint32_t* term_idx;
+    const uint32_t* out_term_off;
+    E2* const* outs;
+    int num_outs;
+};
+
+__global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len; x += stride) {
+        for (int o = 0; o < pl.num_outs; o++) {
+            E2 acc = e2_zero();
+            for (uint32_t t = pl.out_term_off[o]; t < pl.out_term_off[o + 1]; t++) {
+                E2 v = pl.coeffs[t];
+                for (uint32_t k = pl.term_off[t]; k < pl.term_off[t + 1]; k++) {
+                    const WiSlot sl = pl.mles[pl.term_idx[k]];
+                    if (sl.is_ext) v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
+                    else v = e2_mul_base(v, sl.ptr[x]);
+                }
+                acc = acc + v;
+            }
+            pl.outs[o][x] = acc;
+        }
+    }
+}
+
+// 32x32 tile transpose of 64-bit words through LDS (+1 padding: conflict-free column reads)
+__global__ void __launch_bounds__(256) k_transpose(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t rows, size_t width) {
+    __shared__ uint64_t tile[32][33];
+    const size_t col0 = (size_t)blockIdx.x * 32, row0 = (size_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        size_t row = row0 + r, col = col0 + tx;
+        if (row < rows && col < width) tile[r][tx] = in[row * width + col];
+    }
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8) {
+        size_t col = col0 + c, row = row0 + tx;
+        if (row < rows && col < width) out[col * rows + row] = tile[tx][c];
+    }
+}
+
+template <typename T>
+static int up(ceno_hip_ctx* ctx, const T* h, size_t n, hipStream_t st, std::vector<void*>& allocs, T** out) {
+    void* p = nullptr;
+    TRY(ctx_alloc(ctx, (n ? n : 1) * sizeof(T), &p));
+    allocs.push_back(p);
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, st));
+    *out = (T*)p;
+    return 0;
+}
+
+extern "C" {
+
+int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mles, const uint64_t* term_coeffs,
+                       const uint32_t* term_offsets, const uint32_t* term_mle_idx, int num_terms, const uint32_t* out_term_offsets,
+                       int num_outs, int num_vars, ceno_hip_stream s, ceno_hip_mle** outs) {
+    CHECK_ARG(ctx, mles && term_coeffs && term_offsets && term_mle_idx && out_term_offsets && outs, "NULL argument");
+    CHECK_ARG(ctx, num_mles >= 1 && num_terms >= 0 && num_outs >= 1, "empty wit_infer plan");
+    CHECK_ARG(ctx, out_term_offsets[0] == 0 && (int)out_term_offsets[num_outs] == num_terms, "out_term_offsets must cover all terms");
+    for (int j = 0; j < num_mles; j++) CHECK_ARG(ctx, mles[j] && mles[j]->num_vars == num_vars, "mle %d must have %d variables", j, num_vars);
+    for (uint32_t k = 0; k < term_offsets[num_terms]; k++) CHECK_ARG(ctx, (int)term_mle_idx[k] < num_mles, "term factor %u out of range", term_mle_idx[k]);
+    hipStream_t st = ctx_stream(ctx, s);
+    std::vector<void*> allocs;
+    std::vector<ceno_hip_mle*> res(num_outs, nullptr);
+    int rc = 0;
+    for (int o = 0; o < num_outs && !rc; o++) rc = ceno_hip_mle_alloc(ctx, num_vars, 1, &res[o]);
+    std::vector<WiSlot> slots(num_mles);
+    for (int j = 0; j < num_mles; j++) slots[j] = WiSlot{mles[j]->d, mles[j]->is_ext, 0};
+    std::vector<E2> coeffs(num_terms);
+    for (int t = 0; t < num_terms; t++) coeffs[t] = E2{term_coeffs[2 * t], term_coeffs[2 * t + 1]};
+    std::vector<E2*> optr(num_outs);
+    for (int o = 0; o < num_outs && !rc; o++) optr[o] = reinterpret_cast<E2*>(res[o]->d);
+    WiPlan pl{};
+    WiSlot* d_slots = nullptr;
+    E2* d_coeffs = nullptr;
+    uint32_t *d_toff = nullptr, *d_tidx = nullptr, *d_ooff = nullptr;
+    E2** d_outs = nullptr;
+    rc = rc ? rc : up(ctx, slots.data(), slots.size(), st, allocs, &d_slots);
+    rc = rc ? rc : up(ctx, coeffs.data(), coeffs.size(), st, allocs, &d_coeffs);
+    rc = rc ? rc : up(ctx, term_offsets, (size_t)num_terms + 1, st, allocs, &d_toff);
+    rc = rc ? rc : up(ctx, term_mle_idx, (size_t)term_offsets[num_terms], st, allocs, &d_tidx);
+    rc = rc ? rc : up(ctx, out_term_offsets, (size_t)num_outs + 1, st, allocs, &d_ooff);
+    rc = rc ? rc : up(ctx, optr.data(), optr.size(), st, allocs, &d_outs);
+    if (!rc) {
+        pl.mles = d_slots;
+        pl.coeffs = d_coeffs;
+        pl.term_off = d_toff;
+        pl.term_idx = d_tidx;
+        pl.out_term_off = d_ooff;
+        pl.outs = d_outs;
+        pl.num_outs = num_outs;
+        size_t len = (size_t)1 << num_vars;
+        hipLaunchKernelGGL(k_wit_infer, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, pl, len);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // plan buffers and borrowed host arrays
+        if (e != hipSuccess) rc = ctx_fail(ctx, CENO_HIP_ERR_HIP, "wit_infer: %s", hipGetErrorString(e));
+    }
+    for (void* p : allocs) ctx_free(ctx, p);
+    if (rc) {
+        for (auto* m : res) ceno_hip_mle_free(ctx, m);
+        return rc;
+    }
+    for (int o = 0; o < num_outs; o++) outs[o] = res[o];
+    return 0;
+}
+
+int ceno_hip_transpose(ceno_hip_ctx* ctx, const uint64_t* dev_row_major, size_t rows, size_t width, uint64_t* dev_col_major, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_row_major && dev_col_major && rows > 0 && width > 0, "bad transpose arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    dim3 grid((unsigned)((width + 31) / 32), (unsigned)((rows + 31) / 32));
+    CHECK_ARG(ctx, grid.y <= 65535u * 1024u, "too many rows");
+    // grid.y is limited to 65535 on some runtimes: split rows into slabs
+    const size_t slab_rows = (size_t)65535 * 32;
+    for (size_t r0 = 0; r0 < rows; r0 += slab_rows) {
+        size_t nr = rows - r0 < slab_rows ? rows - r0 : slab_rows;
+        dim3 g((unsigned)((width + 31) / 32), (unsigned)((nr + 31) / 32));
+        // a slab of the row-major input starts at r0*width; in the column-major output every column is offset by r0
+        // -> launch with adjusted base pointers and the FULL row count as column stride
+        hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, st, dev_row_major + r0 * width, dev_col_major + r0, nr == rows ? rows : rows, width);
+        if (nr != rows) return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "transpose: more than %zu rows", slab_rows);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -211,6 +211,18 @@ void ceno_prover_test_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* o) 
     o[0] = r.c0;
     o[1] = r.c1;
 }
+uint64_t ceno_prover_test_gl_mul_ref(uint64_t a, uint64_t b) { return gl::mul_ref(a, b); }
+uint64_t ceno_prover_test_gl_mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return gl::mul_add2(a, b, c, d); }
+void ceno_prover_test_e2_mul_ref(const uint64_t* a, const uint64_t* b, uint64_t* o) {
+    E2 r = gl::e2_mul_ref(E2{a[0], a[1]}, E2{b[0], b[1]});
+    o[0] = r.c0;
+    o[1] = r.c1;
+}
+void ceno_prover_test_e2_mul_pre(const uint64_t* a, const uint64_t* b, uint64_t* o) {
+    E2 r = gl::e2_mul_pre(gl::e2_pre(E2{a[0], a[1]}), E2{b[0], b[1]});
+    o[0] = r.c0;
+    o[1] = r.c1;
+}
 void ceno_prover_test_e2_inv(const uint64_t* a, uint64_t* o) {
     E2 r = gl::e2_inv(E2{a[0], a[1]});
     o[0] = r.c0;

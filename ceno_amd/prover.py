@@ -68,6 +68,14 @@ def plib():
     L.ceno_prover_test_gl_mul_small.argtypes = [C.c_uint64, C.c_uint32]
     L.ceno_prover_test_e2_mul.restype = None
     L.ceno_prover_test_e2_mul.argtypes = [u64p, u64p, u64p]
+    L.ceno_prover_test_gl_mul_ref.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul_ref.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_mul_add2.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul_add2.argtypes = [C.c_uint64] * 4
+    L.ceno_prover_test_e2_mul_ref.restype = None
+    L.ceno_prover_test_e2_mul_ref.argtypes = [u64p, u64p, u64p]
+    L.ceno_prover_test_e2_mul_pre.restype = None
+    L.ceno_prover_test_e2_mul_pre.argtypes = [u64p, u64p, u64p]
     L.ceno_prover_test_e2_inv.restype = None
     L.ceno_prover_test_e2_inv.argtypes = [u64p, u64p]
     _plib = L

@@ -147,6 +147,13 @@ int orc_tower_verify(const uint64_t* prod_out_evals /* n_prod*2 ext */, const ui
                      orc_transcript* tr, uint64_t* out_point, uint64_t* out_prod_claims /* n_prod ext */,
                      uint64_t* out_logup_p_claims, uint64_t* out_logup_q_claims);
 
+/* ---- Basefold commit path (a14) — PARITY UNPINNED, see commit.c ---- */
+uint64_t orc_two_adic_generator(int bits);
+void orc_dft_bitrev(const uint64_t* in, int log_n, int inverse, uint64_t* out);
+void orc_poseidon2_permute(uint64_t* state8, const uint64_t* params138);
+void orc_poseidon2_default_params(uint64_t* params138);
+void orc_merkle_commit(const uint64_t* col_major, int log_rows, int width, const uint64_t* params138, uint64_t* out_levels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ _LIB_PATH = os.path.join(_HERE, "libceno_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "oracle.h", "gl64.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "commit.c", "oracle.h", "gl64.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -118,6 +118,8 @@ def lib():
         _lib.orc_interleave_out_len.argtypes = [C.c_int, C.c_size_t, C.c_int]
         _lib.orc_tower_msgs_words.restype = C.c_size_t
         _lib.orc_tower_msgs_words.argtypes = [C.c_int]
+        _lib.orc_two_adic_generator.restype = C.c_uint64
+        _lib.orc_two_adic_generator.argtypes = [C.c_int]
     return _lib
 
 
@@ -448,3 +450,39 @@ def tower_verify(prod_out_evals: np.ndarray, logup_out_evals: np.ndarray, num_va
     rc = lib().orc_tower_verify(_p(po), _p(lo), nv, n_prod, n_logup, C.byref(proof.c), tr.ptr(), _p(pt), _p(pc),
                                 _p(lp), _p(lq))
     return rc, pt[:max_nv], pc, lp, lq
+
+
+# ---- commit path (PARITY UNPINNED) ---------------------------------------------------------
+def dft_bitrev(col: np.ndarray, inverse: bool = False) -> np.ndarray:
+    col = np.ascontiguousarray(col, dtype=np.uint64)
+    log_n = int(col.shape[0]).bit_length() - 1
+    out = np.zeros_like(col)
+    lib().orc_dft_bitrev(_p(col), log_n, int(inverse), _p(out))
+    return out
+
+
+def poseidon2_default_params() -> np.ndarray:
+    p = np.zeros(138, dtype=np.uint64)
+    lib().orc_poseidon2_default_params(_p(p))
+    return p
+
+
+def poseidon2_permute(state: np.ndarray, params: Optional[np.ndarray] = None) -> np.ndarray:
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    s = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    lib().orc_poseidon2_permute(_p(s), _p(params))
+    return s
+
+
+def merkle_commit(col_major: np.ndarray, log_rows: int, width: int, params: Optional[np.ndarray] = None) -> List[np.ndarray]:
+    """returns the tree levels, leaves first; each (n, 4)"""
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    m = np.ascontiguousarray(col_major, dtype=np.uint64)
+    out = np.zeros(4 * ((2 << log_rows) - 1), dtype=np.uint64)
+    lib().orc_merkle_commit(_p(m), log_rows, width, _p(params), _p(out))
+    levels, off = [], 0
+    for l in range(log_rows + 1):
+        n = 1 << (log_rows - l)
+        levels.append(out[off: off + 4 * n].reshape(n, 4))
+        off += 4 * n
+    return levels

@@ -1,0 +1,166 @@
+"""GPU parity for the rows either side of the sumcheck: witness inference (a5), trace transpose, and the
+Basefold commit path (a14: RS encode = NTT, Poseidon2 row hash, Merkle tree).  Bit-exact vs the oracle.
+The commit path is PARITY UNPINNED against the reference (EXT constants); it is pinned against the
+oracle's independent O(N^2) DFT and its own Poseidon2 restatement."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ceno_amd import Device
+
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def _dev_tensor(a: np.ndarray):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to("cuda:0")
+
+
+def _to_np(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_wit_infer_matches_oracle(dev):
+    nv = 10
+    cols = [po.rand_base(1 << nv, 10 + j) for j in range(6)] + [po.rand_ext(1 << nv, 99)]
+    mles = [dev.upload(c) for c in cols]
+    # records: r = alpha + beta*w0 + w1*w2 ; w = const + w3 ; lk = w4*w5*ext6 + w0
+    terms = [[0], [1, 2], [3], [3, 3], [4, 5, 6], [0]]
+    out_terms = [[0, 1], [2, 3], [4, 5]]
+    coeffs = po.rand_ext(len(terms), 5)
+    outs = dev.wit_infer(mles, coeffs, terms, out_terms, nv)
+    for o, ts in enumerate(out_terms):
+        exp = po.wit_infer(cols, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], nv)
+        assert np.array_equal(outs[o].download(), exp)
+
+
+@pytest.mark.parametrize("rows,width", [(8, 3), (64, 22), (1000, 33), (4096, 1)])
+def test_transpose(dev, rows, width):
+    from ceno_amd import api
+
+    m = po.rand_base(rows * width, rows + width).reshape(rows, width)
+    src = _dev_tensor(m)
+    import torch
+
+    dst = torch.empty(rows * width, dtype=torch.int64, device="cuda:0")
+    api.transpose(dev, src.data_ptr(), rows, width, dst.data_ptr())
+    dev.sync()
+    assert np.array_equal(_to_np(dst).reshape(width, rows), m.T)
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 11, 12, 13])
+def test_ntt_forward_inverse_vs_dft(dev, log_n):
+    from ceno_amd import api
+
+    n_cols = 3
+    cols = np.stack([po.rand_base(1 << log_n, 7 * log_n + c) for c in range(n_cols)])
+    d = _dev_tensor(cols)
+    api.ntt_batch(dev, d.data_ptr(), log_n, n_cols, inverse=False)
+    dev.sync()
+    got = _to_np(d).reshape(n_cols, -1)
+    if log_n <= 11:
+        for c in range(n_cols):
+            assert np.array_equal(got[c], po.dft_bitrev(cols[c]))
+    api.ntt_batch(dev, d.data_ptr(), log_n, n_cols, inverse=True)
+    dev.sync()
+    assert np.array_equal(_to_np(d).reshape(n_cols, -1), cols)
+
+
+def test_ntt_large_roundtrip_and_linearity(dev):
+    from ceno_amd import api
+
+    log_n, n_cols = 20, 4
+    a = np.stack([po.rand_base(1 << log_n, 100 + c) for c in range(n_cols)])
+    da = _dev_tensor(a)
+    api.ntt_batch(dev, da.data_ptr(), log_n, n_cols)
+    dev.sync()
+    fa = _to_np(da).reshape(n_cols, -1).copy()
+    # linearity: NTT(col0 + col1) = NTT(col0) + NTT(col1)
+    s = ((a[0].astype(object) + a[1].astype(object)) % P).astype(np.uint64)
+    ds = _dev_tensor(s[None])
+    api.ntt_batch(dev, ds.data_ptr(), log_n, 1)
+    dev.sync()
+    exp = ((fa[0].astype(object) + fa[1].astype(object)) % P).astype(np.uint64)
+    assert np.array_equal(_to_np(ds), exp)
+    # value at bit-reversed index 0 is the plain sum; index bitrev(1) = N/2 is f(w)
+    assert int(fa[2][0]) == int(sum(int(x) for x in a[2]) % P)
+    api.ntt_batch(dev, da.data_ptr(), log_n, n_cols, inverse=True)
+    dev.sync()
+    assert np.array_equal(_to_np(da).reshape(n_cols, -1), a)
+
+
+def test_rs_encode_is_low_degree_extension(dev):
+    from ceno_amd import api
+    import torch
+
+    log_n, blow, n_cols = 8, 1, 2
+    cols = np.stack([po.rand_base(1 << log_n, 40 + c) for c in range(n_cols)])
+    src = _dev_tensor(cols)
+    dst = torch.empty(n_cols << (log_n + blow), dtype=torch.int64, device="cuda:0")
+    api.rs_encode(dev, src.data_ptr(), log_n, n_cols, blow, dst.data_ptr())
+    dev.sync()
+    got = _to_np(dst).reshape(n_cols, -1)
+    for c in range(n_cols):
+        padded = np.concatenate([cols[c], np.zeros(cols[c].shape[0] * ((1 << blow) - 1), dtype=np.uint64)])
+        assert np.array_equal(got[c], po.dft_bitrev(padded))
+
+
+def test_poseidon2_permutation_and_merkle(dev):
+    from ceno_amd import api
+
+    states = po.rand_base(8 * 100, 3).reshape(100, 8)
+    d = _dev_tensor(states)
+    api.poseidon2_permute(dev, d.data_ptr(), 100)
+    dev.sync()
+    got = _to_np(d).reshape(100, 8)
+    for i in (0, 1, 57, 99):
+        assert np.array_equal(got[i], po.poseidon2_permute(states[i]))
+    # zero state must not stay zero and different inputs must differ
+    assert not np.array_equal(po.poseidon2_permute(np.zeros(8, dtype=np.uint64)), np.zeros(8, dtype=np.uint64))
+    for log_rows, width in [(0, 1), (3, 4), (6, 22), (5, 9)]:
+        rows = 1 << log_rows
+        m = po.rand_base(rows * width, 11 * width + log_rows).reshape(width, rows)  # column-major
+        dm = _dev_tensor(m)
+        t = api.Merkle(dev, dm.data_ptr(), log_rows, width)
+        levels = po.merkle_commit(m, log_rows, width)
+        assert np.array_equal(t.root(), levels[-1][0])
+        for idx in {0, rows - 1, rows // 3}:
+            path = t.open(idx)
+            i = idx
+            for l in range(log_rows):
+                assert np.array_equal(path[l], levels[l][i ^ 1])
+                i >>= 1
+        t.free()
+
+
+def test_poseidon2_set_constants_changes_and_restores(dev):
+    from ceno_amd import CenoHipError, api
+
+    s = po.rand_base(8, 5).reshape(1, 8)
+    params = po.poseidon2_default_params()
+    params2 = params.copy()
+    params2[0] = (int(params2[0]) + 1) % P
+    api.poseidon2_set_constants(dev, params2[:64], params2[64:86], params2[86:])
+    d = _dev_tensor(s)
+    api.poseidon2_permute(dev, d.data_ptr(), 1)
+    dev.sync()
+    assert np.array_equal(_to_np(d), po.poseidon2_permute(s[0], params2))
+    with pytest.raises(CenoHipError):
+        bad = params[:64].copy()
+        bad[3] = np.uint64(P)
+        api.poseidon2_set_constants(dev, bad, None, None)
+    api.poseidon2_set_constants(dev, None, None, None)
+    d = _dev_tensor(s)
+    api.poseidon2_permute(dev, d.data_ptr(), 1)
+    dev.sync()
+    assert np.array_equal(_to_np(d), po.poseidon2_permute(s[0]))

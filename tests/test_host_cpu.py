@@ -56,6 +56,9 @@ def test_device_field_source_on_host_matches_bigint(built):
     for a in vals:
         for b in vals[:24]:
             assert L.ceno_prover_test_gl_mul(a, b) == a * b % P
+            assert L.ceno_prover_test_gl_mul_ref(a, b) == a * b % P
+            assert L.ceno_prover_test_gl_mul_add2(a, b, b, a) == 2 * a * b % P
+            assert L.ceno_prover_test_gl_mul_add2(a, b, P - 1, P - 1) == (a * b + 1) % P
             assert L.ceno_prover_test_gl_add(a, b) == (a + b) % P
             assert L.ceno_prover_test_gl_sub(a, b) == (a - b) % P
         for c in (0, 1, 7, 0xFFFFFFFF):
@@ -65,6 +68,10 @@ def test_device_field_source_on_host_matches_bigint(built):
         a = (rng.choice(vals), rng.choice(vals))
         b = (rng.choice(vals), rng.choice(vals))
         L.ceno_prover_test_e2_mul(po._p(po.ext([a]).reshape(2)), po._p(po.ext([b]).reshape(2)), po._p(o))
+        assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
+        L.ceno_prover_test_e2_mul_ref(po._p(po.ext([a]).reshape(2)), po._p(po.ext([b]).reshape(2)), po._p(o))
+        assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
+        L.ceno_prover_test_e2_mul_pre(po._p(po.ext([a]).reshape(2)), po._p(po.ext([b]).reshape(2)), po._p(o))
         assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
         if a != (0, 0):
             L.ceno_prover_test_e2_inv(po._p(po.ext([a]).reshape(2)), po._p(o))

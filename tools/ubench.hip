@@ -51,6 +51,12 @@ __global__ void __launch_bounds__(256) k_alu(E2* out, int iters, E2 seed) {
         if (MODE == 0) { a = a * b; b = b * a; c = c * d; d = d * c; }            // ext mults (Karatsuba)
         else if (MODE == 1) { a.c0 = mul(a.c0, b.c0); b.c0 = mul(b.c0, a.c0); c.c0 = mul(c.c0, d.c0); d.c0 = mul(d.c0, c.c0); }  // base mults
         else if (MODE == 2) { a = a + b; b = b - a; c = c + d; d = d - c; }          // ext adds
+        else if (MODE == 3) { a = e2_mul_ref(a, b); b = e2_mul_ref(b, a); c = e2_mul_ref(c, d); d = e2_mul_ref(d, c); }  // old Karatsuba
+        else if (MODE == 4) { a.c0 = mul_ref(a.c0, b.c0); b.c0 = mul_ref(b.c0, a.c0); c.c0 = mul_ref(c.c0, d.c0); d.c0 = mul_ref(d.c0, c.c0); }
+        else if (MODE == 5) {  // raw 32x32+64 multiply-add chain
+            a.c0 = (uint64_t)(uint32_t)a.c0 * (uint32_t)b.c0 + a.c1; b.c0 = (uint64_t)(uint32_t)b.c0 * (uint32_t)a.c0 + b.c1;
+            c.c0 = (uint64_t)(uint32_t)c.c0 * (uint32_t)d.c0 + c.c1; d.c0 = (uint64_t)(uint32_t)d.c0 * (uint32_t)c.c0 + d.c1;
+        }
     }
     if ((a.c0 ^ b.c0 ^ c.c0 ^ d.c0) == 0x1234567) out[0] = a + b + c + d;
 }
@@ -73,14 +79,18 @@ int main() {
                gb / t0 * 1e3, gb / t1 * 1e3, gb / t2 * 1e3, gb / t3 * 1e3, gb * 1.5 / t4 * 1e3);
     }
     int iters = 2000;
-    for (int mode = 0; mode < 3; mode++) {
+    const char* names[] = {"ext mul (lazy schoolbook)", "base mul (limb)", "ext add/sub", "ext mul (old karatsuba)", "base mul (old)", "mad_u64_u32 chain"};
+    for (int mode = 0; mode < 6; mode++) {
         float t = time([&] {
             if (mode == 0) hipLaunchKernelGGL(k_alu<0>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
             if (mode == 1) hipLaunchKernelGGL(k_alu<1>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
             if (mode == 2) hipLaunchKernelGGL(k_alu<2>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
+            if (mode == 3) hipLaunchKernelGGL(k_alu<3>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
+            if (mode == 4) hipLaunchKernelGGL(k_alu<4>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
+            if (mode == 5) hipLaunchKernelGGL(k_alu<5>, dim3(2048), dim3(256), 0, 0, outp, iters, E2{3, 5});
         });
         double ops = 2048.0 * 256 * iters * 4;
-        printf("alu mode %d (%s): %.3e ops/s\n", mode, mode == 0 ? "ext mul" : mode == 1 ? "base mul" : "ext add/sub", ops / (t * 1e-3));
+        printf("alu mode %d (%s): %.3e ops/s\n", mode, names[mode], ops / (t * 1e-3));
     }
     return 0;
 }
