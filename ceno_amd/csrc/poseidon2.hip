@@ -112,7 +112,13 @@ int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external
     for (size_t i = 0; i < sizeof(h) / 8; i++)
         CHECK_ARG(ctx, reinterpret_cast<uint64_t*>(&h)[i] < gl::P, "poseidon2 constant %zu is not canonical", i);
     HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(ctx->poseidon_dev, &h, sizeof(h), hipMemcpyHostToDevice));
+    // kernels read the table through the scalar cache: publish the new table at a FRESH address instead
+    // of overwriting the old one in place (no stale K$/L2 lines can exist for it)
+    void* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, sizeof(PoseidonParams)));
+    HIP_TRY(ctx, hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
+    (void)hipFree(ctx->poseidon_dev);
+    ctx->poseidon_dev = (PoseidonParams*)d;
     return 0;
 }
 

@@ -14,9 +14,10 @@
 //   * dense class  (one product term of K<=4 tables): register-resident fused kernel `k_dense`.
 //   * generic class (CSR term plan with optional common-factor groups): batched fold kernel + plan-
 //     driven accumulate kernel (`k_fold_batch`, `k_accum`), factor re-reads served by L1/L2.
-// Per-block partial sums (wave64 shuffle -> LDS) go to a partials buffer; `k_reduce_msg` adds them,
-// applies class coefficients and the host-computed scalar (front-loaded) contributions, and writes the
-// d extension elements of the message to pinned host memory (or a caller device buffer).
+// Per-block partial sums (wave64 shuffle -> LDS) are combined inside the same launch by the last block to
+// arrive (`epilogue`), which applies class coefficients and the host-computed front-load scalars and
+// writes the d extension elements of the message straight into pinned host memory + a sequence flag the
+// host spins on (or into a caller device buffer): one launch and no D2H copy per round.
 #include "common.hpp"
 #include "reduce.cuh"
 
@@ -29,6 +30,91 @@ static constexpr int MAXD = 8;
 static constexpr int MAXK = 4;
 static constexpr unsigned MAXB = 2048;
 static constexpr int MAX_CLASSES = 40;
+
+// ------------------------------------------------------------------------------------------------
+// In-kernel message reduction ("last block done").  Every block publishes its D partial sums, the last
+// block to arrive adds all of them, applies the class coefficient, chains the running total of the
+// round (several size classes = several launches on one stream) and — for the last class of the round —
+// adds the host-computed front-load scalars and writes the message either to device memory or straight
+// into pinned host memory followed by a sequence flag the host spins on (no D2H copy, no second launch).
+// Cross-workgroup visibility follows the agent-scope release/acquire recipe (per-XCD L2s are not
+// coherent): write-through (sc1) partial stores, drained (vmcnt(0)) before the agent-scope counter add;
+// acquire fence + agent-scope (sc1) loads in the last block.  No release fence: it would flush the L2.
+// ------------------------------------------------------------------------------------------------
+struct Epilogue {
+    uint64_t* partials;            // gridDim.x * D * 2 words
+    unsigned* counter;             // arrival counter, zero when the kernel starts; reset by the last block
+    E2* round_acc;                 // running total of this round's message (device, MAXD)
+    uint64_t* out_msg;             // destination of the finished message (device or host-mapped), d * 2 words
+    unsigned long long* flag;      // host-mapped sequence flag (nullptr: none)
+    unsigned long long seq;
+    E2 coeff;                      // class coefficient
+    E2 scalars[MAXD];              // front-loaded terms, added once by the last class
+    int first_class;               // 1: start the running total, 0: add to it
+    int last_class;                // 1: finish the message
+    int d;                         // message length (>= the D the kernel accumulates)
+};
+
+__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int D>
+__device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* smem) {
+    __shared__ int s_is_last;
+    red::block_sum<D, NT>(acc, smem);
+    if (threadIdx.x == 0) {
+        uint64_t* row = ep.partials + (size_t)blockIdx.x * D * 2;
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            st_agent(row + 2 * t, acc[t].c0);
+            st_agent(row + 2 * t + 1, acc[t].c1);
+        }
+        // the partials were stored write-through (sc1): draining this wave's stores is enough, and a
+        // release fence here would write back the whole XCD L2 (GBs of freshly folded table data) per block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(ep.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_is_last = (prev == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_is_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    E2 tot[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) tot[t] = e2_zero();
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += NT) {
+        const uint64_t* row = ep.partials + (size_t)b * D * 2;
+#pragma unroll
+        for (int t = 0; t < D; t++) tot[t] = tot[t] + E2{ld_agent(row + 2 * t), ld_agent(row + 2 * t + 1)};
+    }
+    __syncthreads();  // smem is reused
+    red::block_sum<D, NT>(tot, smem);
+    if (threadIdx.x == 0) {
+        const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
+        for (int t = 0; t < ep.d; t++) {
+            E2 v = e2_zero();
+            if (t < D) v = unit ? tot[t < D ? t : 0] : tot[t < D ? t : 0] * ep.coeff;
+            if (!ep.first_class) v = v + ep.round_acc[t];
+            if (ep.last_class) {
+                v = v + ep.scalars[t];
+                if (ep.flag) {
+                    __hip_atomic_store(ep.out_msg + 2 * t, v.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(ep.out_msg + 2 * t + 1, v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    ep.out_msg[2 * t] = v.c0;
+                    ep.out_msg[2 * t + 1] = v.c1;
+                }
+            } else {
+                ep.round_acc[t] = v;
+            }
+        }
+        __hip_atomic_store(ep.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ep.last_class && ep.flag) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: message before flag
+            __hip_atomic_store(ep.flag, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // dense fused kernel
@@ -45,7 +131,7 @@ __device__ __forceinline__ void st_e2(uint64_t* p, E2 v) { *reinterpret_cast<E2*
 // MODE 0: accumulate only, ext input      MODE 1: accumulate only, base input
 // MODE 2: fold + accumulate, ext input    MODE 3: fold + accumulate, base input (output ext)
 template <int K, int MODE>
-__global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, E2* __restrict__ partials) {
+__global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * K];
     E2 acc[K];
 #pragma unroll
@@ -105,11 +191,7 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
             for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
         }
     }
-    red::block_sum<K, NT>(acc, smem);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int t = 0; t < K; t++) partials[(size_t)blockIdx.x * K + t] = acc[t];
-    }
+    epilogue<K>(acc, ep, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -173,7 +255,7 @@ __device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t
 }
 
 template <int D>
-__global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, E2* __restrict__ partials) {
+__global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * D];
     E2 acc[D];
 #pragma unroll
@@ -224,53 +306,7 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, E2* __re
             }
         }
     }
-    red::block_sum<D, NT>(acc, smem);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int t = 0; t < D; t++) partials[(size_t)blockIdx.x * D + t] = acc[t];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// message reduction: sum partials of every class (class c: `cnt[c]` blocks x stride[c] values at off[c];
-// the first d values of each block row are used), scale by the class coefficient, add host scalars.
-// ------------------------------------------------------------------------------------------------
-struct ReduceArgs {
-    int n_classes;
-    int d;
-    uint32_t off[MAX_CLASSES];
-    uint32_t cnt[MAX_CLASSES];
-    uint32_t stride[MAX_CLASSES];
-    E2 coeff[MAX_CLASSES];
-    E2 scalars[MAXD];
-};
-
-__global__ void __launch_bounds__(NT) k_reduce_msg(const E2* __restrict__ partials, ReduceArgs ra, E2* __restrict__ out) {
-    __shared__ E2 smem[(NT / 64) * MAXD];
-    E2 tot[MAXD];
-#pragma unroll
-    for (int t = 0; t < MAXD; t++) tot[t] = e2_zero();
-    for (int c = 0; c < ra.n_classes; c++) {
-        E2 acc[MAXD];
-#pragma unroll
-        for (int t = 0; t < MAXD; t++) acc[t] = e2_zero();
-        const E2* base = partials + ra.off[c];
-        const uint32_t st = ra.stride[c];
-        for (uint32_t b = threadIdx.x; b < ra.cnt[c]; b += NT) {
-#pragma unroll
-            for (int t = 0; t < MAXD; t++)
-                if (t < ra.d && t < (int)st) acc[t] = acc[t] + base[(size_t)b * st + t];
-        }
-        const E2 cf = ra.coeff[c];
-        const bool unit = (cf.c0 == 1 && cf.c1 == 0);
-#pragma unroll
-        for (int t = 0; t < MAXD; t++)
-            if (t < ra.d) tot[t] = tot[t] + (unit ? acc[t] : acc[t] * cf);
-    }
-    red::block_sum<MAXD, NT>(tot, smem);
-    if (threadIdx.x == 0) {
-        for (int t = 0; t < ra.d; t++) out[t] = tot[t] + ra.scalars[t];
-    }
+    epilogue<D>(acc, ep, smem);
 }
 
 // gather element 0 of every listed table into out[i] (final evaluations)
@@ -333,6 +369,12 @@ struct ceno_hip_sumcheck {
     std::vector<ScClass> classes;  // sorted by nv descending
     E2* d_partials = nullptr;
     E2* d_msg = nullptr;           // d ext (device)
+    unsigned* d_counter = nullptr; // arrival counter of the in-kernel reduction
+    E2* d_round_acc = nullptr;     // running message total across the classes of one round
+    uint64_t* d_hmsg = nullptr;    // device view of h_pinned (message lands directly in host memory)
+    unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
+    unsigned long long* d_hflag = nullptr;
+    unsigned long long seq = 0;
     E2* d_evals = nullptr;         // gather scratch (device), num_mles
     E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
     MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
@@ -358,23 +400,24 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     (void)hipStreamSynchronize(sc->st);
     for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
     if (sc->h_pinned) (void)hipHostFree(sc->h_pinned);
+    if (sc->h_flag) (void)hipHostFree(sc->h_flag);
     if (sc->h_slots) (void)hipHostFree(sc->h_slots);
     if (sc->extra_owned) ceno_hip_mle_free(sc->ctx, sc->extra_owned);
     delete sc;
 }
 
 template <int K>
-static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, E2* partials, unsigned grid, hipStream_t st) {
+static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
     switch (mode) {
-    case 0: hipLaunchKernelGGL((k_dense<K, 0>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
-    case 1: hipLaunchKernelGGL((k_dense<K, 1>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
-    case 2: hipLaunchKernelGGL((k_dense<K, 2>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
-    default: hipLaunchKernelGGL((k_dense<K, 3>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, partials); break;
+    case 0: hipLaunchKernelGGL((k_dense<K, 0>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
+    case 1: hipLaunchKernelGGL((k_dense<K, 1>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
+    case 2: hipLaunchKernelGGL((k_dense<K, 2>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
+    default: hipLaunchKernelGGL((k_dense<K, 3>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
     }
 }
 
 template <int K>
-static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pairs, E2 r, unsigned grid) {
+static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pairs, E2 r, unsigned grid, const Epilogue& ep) {
     TabPtrs<K> tp;
     const ScTerm& term = sc->terms[cl.terms[0]];
     for (int m = 0; m < K; m++) {
@@ -382,23 +425,23 @@ static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pa
         tp.in[m] = M.cur;
         tp.out[m] = M.buf[M.which];
     }
-    launch_dense_k<K>(mode, tp, pairs, r, sc->d_partials + cl.part_off, grid, sc->st);
+    launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
 }
 
 template <int D>
-static void launch_accum_d(const DevPlan& pl, size_t pairs, E2* partials, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, partials);
+static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
 }
-static void launch_accum(int d, const DevPlan& pl, size_t pairs, E2* partials, unsigned grid, hipStream_t st) {
+static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
     switch (d) {
-    case 1: launch_accum_d<1>(pl, pairs, partials, grid, st); break;
-    case 2: launch_accum_d<2>(pl, pairs, partials, grid, st); break;
-    case 3: launch_accum_d<3>(pl, pairs, partials, grid, st); break;
-    case 4: launch_accum_d<4>(pl, pairs, partials, grid, st); break;
-    case 5: launch_accum_d<5>(pl, pairs, partials, grid, st); break;
-    case 6: launch_accum_d<6>(pl, pairs, partials, grid, st); break;
-    case 7: launch_accum_d<7>(pl, pairs, partials, grid, st); break;
-    default: launch_accum_d<8>(pl, pairs, partials, grid, st); break;
+    case 1: launch_accum_d<1>(pl, pairs, ep, grid, st); break;
+    case 2: launch_accum_d<2>(pl, pairs, ep, grid, st); break;
+    case 3: launch_accum_d<3>(pl, pairs, ep, grid, st); break;
+    case 4: launch_accum_d<4>(pl, pairs, ep, grid, st); break;
+    case 5: launch_accum_d<5>(pl, pairs, ep, grid, st); break;
+    case 6: launch_accum_d<6>(pl, pairs, ep, grid, st); break;
+    case 7: launch_accum_d<7>(pl, pairs, ep, grid, st); break;
+    default: launch_accum_d<8>(pl, pairs, ep, grid, st); break;
     }
 }
 
@@ -565,10 +608,16 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         int rc = ctx_alloc(ctx, (size_t)part_off * sizeof(E2), &p);
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_partials = (E2*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_msg = (E2*)p; rc = ctx_alloc(ctx, (size_t)plan->num_mles * sizeof(E2), &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; rc = ctx_alloc(ctx, 256, &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_counter = (unsigned*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_round_acc = (E2*)p; }
         if (rc) { sc_release(sc); return rc; }
+        if (hipMemsetAsync(sc->d_counter, 0, 256, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
     }
     hipError_t e = hipHostMalloc((void**)&sc->h_pinned, (MAXD + (size_t)plan->num_mles) * sizeof(E2), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_flag, 64, hipHostMallocDefault);
+    if (e == hipSuccess) { *sc->h_flag = 0; e = hipHostGetDevicePointer((void**)&sc->d_hflag, sc->h_flag, 0); }
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&sc->d_hmsg, sc->h_pinned, 0);
     if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_slots, std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2), hipHostMallocDefault);
     if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
 
@@ -615,7 +664,24 @@ static void sc_advance(ceno_hip_sumcheck* sc, ScClass& cl) {
     }
 }
 
-// one round; out goes to host (h_out != NULL, synchronises) or to device memory d_out
+// wait until the kernel has published sequence number `seq` in pinned host memory
+static int sc_wait_flag(ceno_hip_sumcheck* sc, unsigned long long seq) {
+    volatile unsigned long long* f = sc->h_flag;
+    unsigned long long spins = 0;
+    while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFFF) == 0) {
+            // every ~1M polls make sure the stream is still alive (a faulted kernel never writes the flag)
+            hipError_t q = hipStreamQuery(sc->st);
+            if (q != hipSuccess && q != hipErrorNotReady)
+                return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round kernel failed: %s", hipGetErrorString(q));
+            if (q == hipSuccess && __atomic_load_n(f, __ATOMIC_ACQUIRE) != seq)
+                return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round finished without publishing its message");
+        }
+    }
+    return 0;
+}
+
+// one round; out goes to host (h_out != NULL, waits for the message) or to device memory d_out
 static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* h_out, uint64_t* d_out) {
     ceno_hip_ctx* ctx = sc->ctx;
     if (sc->finished || sc->round >= sc->n) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: all %d rounds already produced", sc->n);
@@ -624,63 +690,103 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     if (i == 0 && challenge2) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "sumcheck round 0 takes no challenge");
     const E2 r = i > 0 ? E2{challenge2[0], challenge2[1]} : e2_zero();
     const int d = sc->d;
-    ReduceArgs ra{};
-    ra.d = d;
     size_t h_cursor = 0;
-    std::vector<ScClass*> became_scalar;
+
+    // ---- 1. classes that are (or just become) scalars: update tails / bind their last variable ----
+    ScClass* became_scalar = nullptr;
     for (auto& cl : sc->classes) {
-        double bytes = 0.0;
         if (cl.nv < i) {
             for (int j : cl.mles) sc->mles[j].tail = sc->mles[j].tail * r;  // exhausted earlier
-            continue;
-        }
-        if (cl.nv == i) {
-            if (i == 0) continue;  // zero-variable class: already scalars
-            // last real variable of this class: fold 2 -> 1
+        } else if (cl.nv == i && i > 0) {
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
             hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r);
             hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
                                sc->d_evals);
-            became_scalar.push_back(&cl);
-            continue;
+            became_scalar = &cl;  // at most one class reaches its last variable per round
         }
-        // live class
+    }
+    if (became_scalar) {
+        ScClass* cl = became_scalar;
+        E2* h_ev = sc->h_pinned + MAXD;
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl->mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        for (size_t k = 0; k < cl->mles.size(); k++) {  // evaluations are in class-local order
+            ScMle& M = sc->mles[cl->mles[k]];
+            M.eval = h_ev[k];
+            M.done = true;
+            M.cur = M.buf[M.which];
+            M.cur_ext = 1;
+        }
+    }
+    // ---- 2. front-loaded contributions: c_t * prod_j (eval_j * tail_j * t)   (scheme/verifier.rs:233-237) ----
+    E2 scalars[MAXD];
+    for (int x = 0; x < MAXD; x++) scalars[x] = e2_zero();
+    for (auto& cl : sc->classes) {
+        if (cl.nv > i) continue;
+        for (int t : cl.terms) {
+            const ScTerm& T = sc->terms[t];
+            for (int x = 0; x < d; x++) {
+                E2 pr = T.coeff;
+                const uint64_t tt = (uint64_t)(x + 1);
+                for (int j : T.full) pr = pr * e2_mul_base(sc->mles[j].eval * sc->mles[j].tail, tt);
+                scalars[x] = scalars[x] + pr;
+            }
+        }
+    }
+    // ---- 3. live classes: one fused launch each; the last one finishes the message ----
+    std::vector<ScClass*> live;
+    for (auto& cl : sc->classes)
+        if (cl.nv > i) live.push_back(&cl);
+    ScClass* last_acc = nullptr;
+    for (ScClass* cl : live)
+        if (!cl->terms.empty()) last_acc = cl;
+    const unsigned long long seq = ++sc->seq;
+    bool first = true;
+    for (ScClass* clp : live) {
+        ScClass& cl = *clp;
+        double bytes = 0.0;
         const size_t pairs = (size_t)1 << (cl.nv - i - 1);
         const unsigned grid = sc_grid(pairs);
-        const int c = ra.n_classes++;
-        ra.off[c] = cl.part_off;
-        ra.cnt[c] = grid;
-        ra.coeff[c] = e2_one();
-        const size_t esz_in = 16;
+        Epilogue ep{};
+        ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
+        ep.counter = sc->d_counter;
+        ep.round_acc = sc->d_round_acc;
+        ep.out_msg = d_out ? d_out : sc->d_hmsg;
+        ep.flag = d_out ? nullptr : sc->d_hflag;
+        ep.seq = seq;
+        ep.coeff = e2_one();
+        ep.first_class = first ? 1 : 0;
+        ep.last_class = (clp == last_acc) ? 1 : 0;
+        ep.d = d;
+        if (ep.last_class)
+            for (int x = 0; x < MAXD; x++) ep.scalars[x] = scalars[x];
         if (cl.dense) {
             const ScTerm& T = sc->terms[cl.terms[0]];
             const int K = (int)T.idx.size();
             const bool base_in = !sc->mles[T.idx[0]].cur_ext;
             const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
-            ra.stride[c] = (uint32_t)K;
-            ra.coeff[c] = T.coeff;
+            ep.coeff = T.coeff;
             prof_begin(ctx, sc->st);
             switch (K) {
-            case 1: launch_dense<1>(sc, cl, mode, pairs, r, grid); break;
-            case 2: launch_dense<2>(sc, cl, mode, pairs, r, grid); break;
-            case 3: launch_dense<3>(sc, cl, mode, pairs, r, grid); break;
-            default: launch_dense<4>(sc, cl, mode, pairs, r, grid); break;
+            case 1: launch_dense<1>(sc, cl, mode, pairs, r, grid, ep); break;
+            case 2: launch_dense<2>(sc, cl, mode, pairs, r, grid, ep); break;
+            case 3: launch_dense<3>(sc, cl, mode, pairs, r, grid, ep); break;
+            default: launch_dense<4>(sc, cl, mode, pairs, r, grid, ep); break;
             }
-            const double in_el = base_in ? 8.0 : (double)esz_in;
+            const double in_el = base_in ? 8.0 : 16.0;
             if (i == 0) bytes += (double)K * 2.0 * pairs * in_el;
             else bytes += (double)K * (4.0 * pairs * in_el + 2.0 * pairs * 16.0);
             prof_end(ctx, sc->st, bytes);
-            if (i > 0) sc_advance(sc, cl);
+            first = false;
         } else {
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
             prof_begin(ctx, sc->st);
-            if (i > 0) {
+            if (i > 0)
                 hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots,
                                    2 * pairs, r);
-            }
-            ra.stride[c] = (uint32_t)d;
             if (!cl.terms.empty()) {
                 DevPlan pl;
                 pl.slots = d_slots;
@@ -693,9 +799,8 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 pl.coeffs = cl.d_coeffs;
                 pl.term_off = cl.d_term_off;
                 pl.term_idx = cl.d_term_idx;
-                launch_accum(d, pl, pairs, sc->d_partials + cl.part_off, grid, sc->st);
-            } else {
-                ra.n_classes--;  // nothing to accumulate for a class no term references
+                launch_accum(d, pl, pairs, ep, grid, sc->st);
+                first = false;
             }
             for (int j : cl.mles) {
                 const double in_el = sc->mles[j].cur_ext ? 16.0 : 8.0;
@@ -703,48 +808,21 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 else bytes += 4.0 * pairs * in_el + 2.0 * pairs * 16.0;
             }
             prof_end(ctx, sc->st, bytes);
-            if (i > 0) sc_advance(sc, cl);
         }
+        if (i > 0) sc_advance(sc, cl);
     }
     HIP_TRY(ctx, hipGetLastError());
-    // classes that just became scalars: fetch their evaluations (needed for this round's message)
-    if (!became_scalar.empty()) {
-        E2* h_ev = sc->h_pinned + MAXD;
-        for (ScClass* cl : became_scalar)
-            HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl->mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
-        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
-        for (ScClass* cl : became_scalar) {
-            // at most one class reaches its last variable per round; evaluations are in class-local order
-            for (size_t k = 0; k < cl->mles.size(); k++) {
-                ScMle& M = sc->mles[cl->mles[k]];
-                M.eval = h_ev[k];
-                M.done = true;
-                M.cur = M.buf[M.which];
-                M.cur_ext = 1;
-            }
+    if (!last_acc) {
+        // no term is live in this round: the message consists of the front-loaded scalars only
+        if (d_out) {
+            memcpy(sc->h_pinned, scalars, (size_t)d * sizeof(E2));
+            HIP_TRY(ctx, hipMemcpyAsync(d_out, sc->h_pinned, (size_t)d * sizeof(E2), hipMemcpyHostToDevice, sc->st));
+            HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        } else {
+            memcpy(h_out, scalars, (size_t)d * sizeof(E2));
         }
-    }
-    // scalar (front-loaded) contributions: c_t * prod_j (eval_j * tail_j * t)   (scheme/verifier.rs:233-237)
-    for (auto& cl : sc->classes) {
-        if (cl.nv > i) continue;
-        for (int t : cl.terms) {
-            const ScTerm& T = sc->terms[t];
-            for (int x = 0; x < d; x++) {
-                E2 pr = T.coeff;
-                const uint64_t tt = (uint64_t)(x + 1);
-                for (int j : T.full) pr = pr * e2_mul_base(sc->mles[j].eval * sc->mles[j].tail, tt);
-                ra.scalars[x] = ra.scalars[x] + pr;
-            }
-        }
-    }
-    // common-factor groups whose class is exhausted are covered above because group membership only
-    // affects how live classes are evaluated: a grouped term's full product = common * residual.
-    E2* target = d_out ? reinterpret_cast<E2*>(d_out) : sc->d_msg;
-    hipLaunchKernelGGL(k_reduce_msg, dim3(1), dim3(NT), 0, sc->st, sc->d_partials, ra, target);
-    HIP_TRY(ctx, hipGetLastError());
-    if (h_out) {
-        HIP_TRY(ctx, hipMemcpyAsync(sc->h_pinned, sc->d_msg, (size_t)d * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
-        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+    } else if (h_out) {
+        TRY(sc_wait_flag(sc, seq));
         memcpy(h_out, sc->h_pinned, (size_t)d * sizeof(E2));
     }
     sc->round++;
