@@ -31,42 +31,17 @@ TR_SEED = 0xF5
 
 
 def cpu_baseline(nv: int = 24):
-    """the oracle's OpenMP fused sumcheck (a port, not the Rust/rayon reference binary) on host cores"""
+    """the oracle's OpenMP fused sumcheck (a port, not the Rust/rayon reference binary) on the host cores,
+    in a child process with a clean OpenMP environment"""
     import subprocess
-    import tempfile
 
-    from oracle import pyoracle as po
-
-    # try a -march=native build on this box; fall back to the shipped portable build
-    try:
-        tmp = tempfile.mkdtemp(prefix="ceno_orc_")
-        so = os.path.join(tmp, "libceno_oracle_native.so")
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", so,
-                               os.path.join(ROOT, "oracle", "oracle.c"), os.path.join(ROOT, "oracle", "tower.c")],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        po._LIB_PATH = so
-        po._lib = None
-    except Exception:
-        pass
-    cores = os.cpu_count() or 1
-    tables = [po.rand_ext(1 << nv, SEED0 + j) for j in range(K)]
-    chal = po.rand_ext(nv, TR_SEED)
-    t0 = time.perf_counter()
-    po.sumcheck_dense_mt(tables, chal, threads=cores)
-    dt = time.perf_counter() - t0
-    mults = K * K * ((1 << nv) - 1)
-    t1 = time.perf_counter()
-    small = [t[: 1 << 20] for t in tables]
-    po.sumcheck_dense_mt(small, chal[:20], threads=1)
-    dt1 = time.perf_counter() - t1
-    return {
-        "value": mults / dt,
-        "unit": "ext-mults/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"one sumcheck, {K} ext MLEs x nv={nv} (same generator), OpenMP x{cores}, {dt:.2f} s; "
-                  f"1-thread nv=20: {K * K * ((1 << 20) - 1) / dt1:.3e} ext-mults/s",
-    }
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_", "MKL_"))}
+    env["OMP_PROC_BIND"] = "false"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), str(nv)], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr[-300:])
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -184,6 +159,7 @@ def main():
             "traffic": None,
             "launches": int(launches),
             "avg_launch_ms": kernel_ms / launches if launches else None,
+            "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
             "schedule_bytes_per_step": sched_bytes / args.steps if args.steps else None,
             "schedule_gbps": (sched_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
         },
@@ -195,7 +171,21 @@ def main():
             except Exception as e:  # the baseline leg must not take the bench line down
                 res["cpu_baseline"] = {"value": None, "unit": "ext-mults/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
-        # traffic from a committed PMC run, if present (profiles/), else null
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (profiles/, tools/pmc_summary.py); null when no matching profile is committed
+        try:
+            if world == 1 and n_local == 26:
+                import glob
+
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sumcheck_nv26_pmc_traffic.json")))
+                if cands:
+                    pm = json.load(open(cands[-1]))
+                    res["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                    res["roofline"]["traffic_per_sumcheck"] = pm["hbm_bytes_per_sumcheck"]
+                    res["roofline"]["traffic_source"] = os.path.relpath(cands[-1], ROOT)
+        except Exception:
+            pass
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

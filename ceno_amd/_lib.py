@@ -85,6 +85,7 @@ def lib():
         "ceno_hip_sumcheck_round_dev": (i, [vp, vp, u64p, vp]),
         "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),
         "ceno_hip_sumcheck_rounds_done": (i, [vp]),
+        "ceno_hip_sumcheck_set_pipelined": (i, [vp, vp, i]),
         "ceno_hip_sumcheck_free": (i, [vp, vp]),
         "ceno_hip_tower_build_prod": (i, [vp, vpp, i, sz, u64p, vp, vpp]),
         "ceno_hip_tower_build_logup": (i, [vp, vpp, vpp, i, sz, u64p, vp, vpp]),

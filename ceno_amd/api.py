@@ -259,6 +259,9 @@ class Sumcheck:
         dev.check(dev.L.ceno_hip_sumcheck_begin(dev.h, arr, C.byref(plan), stream, C.byref(h)))
         self.h = h
 
+    def set_pipelined(self, on: bool = True):
+        self.dev.check(self.dev.L.ceno_hip_sumcheck_set_pipelined(self.dev.h, self.h, int(on)))
+
     def round(self, challenge=None) -> np.ndarray:
         out = np.zeros((self.d, 2), dtype=np.uint64)
         ch = _p(_ext1(challenge)) if challenge is not None else None

@@ -29,6 +29,9 @@ struct ceno_hip_ctx {
     size_t pool_cached = 0; // bytes parked in free lists
     std::unordered_map<size_t, std::vector<void*>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
+    // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
+    std::unordered_map<size_t, std::vector<void*>> pinned_free;
+    std::unordered_map<void*, size_t> pinned_live;
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----
@@ -53,6 +56,9 @@ struct ceno_hip_mle {
 int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
 void ctx_free(ceno_hip_ctx* ctx, void* p);
+// pinned, device-mapped host memory from a per-context cache; *dev_view is the device address of *host
+int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view);
+void ctx_pinned_free(ceno_hip_ctx* ctx, void* host);
 inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) { return s ? (hipStream_t)s : ctx->default_stream; }
 
 // profiling hooks (ctx.hip)

@@ -87,6 +87,46 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
     ctx->free_lists[b].push_back(p);
 }
 
+int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view) {
+    size_t b = 4096;
+    while (b < bytes) b <<= 1;
+    void* h = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        auto it = ctx->pinned_free.find(b);
+        if (it != ctx->pinned_free.end() && !it->second.empty()) {
+            h = it->second.back();
+            it->second.pop_back();
+        }
+    }
+    if (!h) {
+        hipError_t e = hipHostMalloc(&h, b, hipHostMallocDefault);
+        if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipHostMalloc(%zu): %s", b, hipGetErrorString(e));
+    }
+    void* d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+    }
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->pinned_live[h] = b;
+    }
+    *host = h;
+    *dev_view = d;
+    return 0;
+}
+
+void ctx_pinned_free(ceno_hip_ctx* ctx, void* host) {
+    if (!host) return;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    auto it = ctx->pinned_live.find(host);
+    if (it == ctx->pinned_live.end()) return;
+    ctx->pinned_free[it->second].push_back(host);
+    ctx->pinned_live.erase(it);
+}
+
 extern "C" {
 
 const char* ceno_hip_version(void) { return "ceno_hip 0.1 (gfx950)"; }
@@ -121,6 +161,9 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     for (auto& kv : ctx->free_lists)
         for (void* p : kv.second) (void)hipFree(p);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
+    for (auto& kv : ctx->pinned_free)
+        for (void* p : kv.second) (void)hipHostFree(p);
+    for (auto& kv : ctx->pinned_live) (void)hipHostFree(kv.first);
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->prof_event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);

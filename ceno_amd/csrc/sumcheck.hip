@@ -22,13 +22,16 @@
 #include "reduce.cuh"
 
 #include <algorithm>
+#include <ctime>
 
 using namespace gl;
 
 static constexpr int NT = 256;
 static constexpr int MAXD = 8;
 static constexpr int MAXK = 4;
-static constexpr unsigned MAXB = 2048;
+// 4 workgroups per CU: every workgroup of a launch is resident at once (1024 <= 256 CUs x 6 at 75 VGPRs);
+// measured on MI355X: 1024/1280/1536 are within 1 %, 2048 (a second dispatch wave) is 3-6 % slower
+static constexpr unsigned MAXB = 1024;
 static constexpr int MAX_CLASSES = 40;
 
 // ------------------------------------------------------------------------------------------------
@@ -53,15 +56,126 @@ struct Epilogue {
     int first_class;               // 1: start the running total, 0: add to it
     int last_class;                // 1: finish the message
     int d;                         // message length (>= the D the kernel accumulates)
+    // pipelined mode: the kernel was enqueued before its challenge existed and fetches it itself
+    const struct Mailbox* mailbox; // host-mapped, written by the host
+    struct Bcast* bcast;           // device memory, challenge relay between workgroups
+    unsigned long long wait_seq;   // 0: challenge is the kernel argument; else it was relayed as round `wait_seq`
+    unsigned long long next_seq;   // != 0: after publishing, fetch challenge `next_seq` from the host for the next launch
 };
+
+// host -> device mailbox in pinned memory (one cache line)
+struct Mailbox {
+    unsigned long long chal_seq;   // round whose challenge is valid (written last, release)
+    unsigned long long chal[2];
+    unsigned long long abort;      // non-zero: every waiting kernel exits without touching memory
+};
+// device-side relay: the first workgroup to arrive polls the host mailbox, the others poll this
+struct Bcast {
+    unsigned ticket;               // (unused)
+    unsigned ready_seq;            // round whose challenge has been relayed (ABORT_SEQ: give up)
+    unsigned long long chal[2];
+    unsigned long long dbg[64][4]; // wall-clock stamps per round: start, before publish, after flag, after poll
+};
+static constexpr unsigned ABORT_SEQ = 0xFFFFFFFFu;
 
 __device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// thread 0 of the finishing block: class coefficient, running round total, front-load scalars, publish
+// Pipelined launches.  The finishing workgroup of round i — alone on the chip at that point — publishes
+// the message, then polls the host mailbox for challenge i (bounded: ~4 s of wall clock or the host's
+// `abort`) and relays it through device memory; the already queued kernel of round i+1 picks it up with a
+// single load at its start.  Exactly one lane ever polls PCIe, nothing spins inside the big kernels.
+__device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
+    const Mailbox* mb = ep.mailbox;
+    Bcast* bc = ep.bcast;
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    bool ok = true;
+    unsigned spins = 0;
+    for (;;) {
+        // relaxed polls: an acquire per poll would invalidate the (large) L2 every iteration
+        if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ep.next_seq) break;
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > 400000000ull) {
+                ok = false;
+                break;
+            }
+        }
+    }
+    if (ok) {
+        // the host stores chal[] before chal_seq (release); these loads are issued only after the seq load
+        // has returned (control dependency + waitcnt) and bypass the caches, so they see the new words
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c0 = __hip_atomic_load(&mb->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long c1 = __hip_atomic_load(&mb->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&bc->chal[0], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&bc->chal[1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(&bc->ready_seq, ok ? (unsigned)ep.next_seq : ABORT_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// start of a pipelined round kernel: the challenge was relayed by the previous launch (kernel boundary
+// = visibility); anything else means the pipeline was aborted
+__device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r) {
+    // ONE lane per workgroup reads the relay words, LDS broadcast to the rest
+    __shared__ unsigned long long s_c[2];
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        // plain (cacheable) loads: the words were written by the PREVIOUS launch, the kernel boundary makes
+        // them visible; cache-bypassing (sc1) loads of one line from 2048 workgroups serialise at ~90 per us
+        const volatile Bcast* bc = ep.bcast;
+        s_ok = bc->ready_seq == (unsigned)ep.wait_seq;
+        s_c[0] = bc->chal[0];
+        s_c[1] = bc->chal[1];
+    }
+    __syncthreads();
+    r = E2{s_c[0], s_c[1]};
+    return s_ok != 0;
+}
+
+template <int D>
+__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep) {
+    const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
+    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][1] = wall_clock64();
+    for (int t = 0; t < ep.d; t++) {
+        E2 v = e2_zero();
+        if (t < D) v = unit ? tot[t < D ? t : 0] : tot[t < D ? t : 0] * ep.coeff;
+        if (!ep.first_class) v = v + ep.round_acc[t];
+        if (ep.last_class) {
+            v = v + ep.scalars[t];
+            if (ep.flag) {
+                __hip_atomic_store(ep.out_msg + 2 * t, v.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(ep.out_msg + 2 * t + 1, v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                ep.out_msg[2 * t] = v.c0;
+                ep.out_msg[2 * t + 1] = v.c1;
+            }
+        } else {
+            ep.round_acc[t] = v;
+        }
+    }
+    if (ep.last_class && ep.flag) {
+        // message before flag: the message words went out as write-through system-scope stores; drain them
+        // (vmcnt) and only then store the flag.  A system-scope release FENCE would write back every dirty
+        // line of the L2 (the freshly folded tables) — tens of microseconds per round.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(ep.flag, ep.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][2] = wall_clock64();
+    if (ep.next_seq != 0) fetch_next_challenge(ep);
+    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][3] = wall_clock64();
+}
 
 template <int D>
 __device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* smem) {
     __shared__ int s_is_last;
     red::block_sum<D, NT>(acc, smem);
+    if (gridDim.x == 1) {  // latency-critical tail rounds: nothing to exchange between workgroups
+        if (threadIdx.x == 0) {
+            finish_message<D>(acc, ep);
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         uint64_t* row = ep.partials + (size_t)blockIdx.x * D * 2;
 #pragma unroll
@@ -90,29 +204,8 @@ __device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* s
     __syncthreads();  // smem is reused
     red::block_sum<D, NT>(tot, smem);
     if (threadIdx.x == 0) {
-        const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
-        for (int t = 0; t < ep.d; t++) {
-            E2 v = e2_zero();
-            if (t < D) v = unit ? tot[t < D ? t : 0] : tot[t < D ? t : 0] * ep.coeff;
-            if (!ep.first_class) v = v + ep.round_acc[t];
-            if (ep.last_class) {
-                v = v + ep.scalars[t];
-                if (ep.flag) {
-                    __hip_atomic_store(ep.out_msg + 2 * t, v.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(ep.out_msg + 2 * t + 1, v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                } else {
-                    ep.out_msg[2 * t] = v.c0;
-                    ep.out_msg[2 * t + 1] = v.c1;
-                }
-            } else {
-                ep.round_acc[t] = v;
-            }
-        }
         __hip_atomic_store(ep.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ep.last_class && ep.flag) {
-            __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: message before flag
-            __hip_atomic_store(ep.flag, ep.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        finish_message<D>(tot, ep);
     }
 }
 
@@ -137,6 +230,10 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
 #pragma unroll
     for (int t = 0; t < K; t++) acc[t] = e2_zero();
     const size_t stride = (size_t)gridDim.x * NT;
+    if (ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r)) return;  // pipeline aborted / timed out: leave everything untouched
+    }
     const E2Pre rp = e2_pre(r);
     for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
         if (MODE == 1) {
@@ -375,6 +472,12 @@ struct ceno_hip_sumcheck {
     unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
     unsigned long long* d_hflag = nullptr;
     unsigned long long seq = 0;
+    void* h_block = nullptr;       // one pinned allocation carved into flag | mailbox | message+evals | slot staging
+    Mailbox* h_mailbox = nullptr;  // host -> device challenges (pipelined mode)
+    Mailbox* d_mailbox = nullptr;
+    Bcast* d_bcast = nullptr;      // device relay
+    bool allow_pipeline = false;   // caller promised to drive the rounds back to back (ceno_hip_sumcheck_set_pipelined)
+    bool pipelined = false;        // all round kernels were enqueued up front; challenges travel through the mailbox
     E2* d_evals = nullptr;         // gather scratch (device), num_mles
     E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
     MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
@@ -397,11 +500,20 @@ static int upload_vec(ceno_hip_sumcheck* sc, const std::vector<T>& v, T** out) {
 
 static void sc_release(ceno_hip_sumcheck* sc) {
     if (!sc) return;
+    if (sc->pipelined && sc->round < sc->n && sc->h_mailbox)
+        __atomic_store_n(&sc->h_mailbox->abort, 1ull, __ATOMIC_RELEASE);  // queued kernels exit at their wait
     (void)hipStreamSynchronize(sc->st);
+    if (sc->pipelined && getenv("CENO_HIP_DEBUG") && sc->d_bcast) {
+        static Bcast hb;
+        if (hipMemcpy(&hb, sc->d_bcast, sizeof(Bcast), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int i = 1; i <= sc->n && i < 64; i++)
+                fprintf(stderr, "[ceno_hip] dev round %d: start->publish %.1f us, publish %.1f us, poll %.1f us, prev poll end -> start %.1f us\n", i - 1,
+                        (hb.dbg[i][1] - hb.dbg[i][0]) / 100.0, (hb.dbg[i][2] - hb.dbg[i][1]) / 100.0, (hb.dbg[i][3] - hb.dbg[i][2]) / 100.0,
+                        i > 1 ? (hb.dbg[i][0] - hb.dbg[i - 1][3]) / 100.0 : 0.0);
+        }
+    }
     for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
-    if (sc->h_pinned) (void)hipHostFree(sc->h_pinned);
-    if (sc->h_flag) (void)hipHostFree(sc->h_flag);
-    if (sc->h_slots) (void)hipHostFree(sc->h_slots);
+    ctx_pinned_free(sc->ctx, sc->h_block);
     if (sc->extra_owned) ceno_hip_mle_free(sc->ctx, sc->extra_owned);
     delete sc;
 }
@@ -446,7 +558,10 @@ static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue&
 }
 
 // grid for `pairs` work items: enough blocks to fill 256 CUs x 8, at least 1
-static unsigned sc_grid(size_t pairs) { return grid_for(pairs, NT, MAXB); }
+static unsigned sc_grid(size_t pairs) {
+    static const unsigned cap = getenv("CENO_HIP_MAXB") ? (unsigned)atoi(getenv("CENO_HIP_MAXB")) : MAXB;
+    return grid_for(pairs, NT, cap);
+}
 
 static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st,
                     ceno_hip_sumcheck** out) {
@@ -608,18 +723,31 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         int rc = ctx_alloc(ctx, (size_t)part_off * sizeof(E2), &p);
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_partials = (E2*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_msg = (E2*)p; rc = ctx_alloc(ctx, (size_t)plan->num_mles * sizeof(E2), &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; rc = ctx_alloc(ctx, 256, &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_counter = (unsigned*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; rc = ctx_alloc(ctx, 4096, &p); }
+        if (!rc) { sc->dev_allocs.push_back(p); sc->d_counter = (unsigned*)p; sc->d_bcast = (Bcast*)((char*)p + 64); rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_round_acc = (E2*)p; }
         if (rc) { sc_release(sc); return rc; }
-        if (hipMemsetAsync(sc->d_counter, 0, 256, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
+        if (hipMemsetAsync(sc->d_counter, 0, 4096, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
     }
-    hipError_t e = hipHostMalloc((void**)&sc->h_pinned, (MAXD + (size_t)plan->num_mles) * sizeof(E2), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_flag, 64, hipHostMallocDefault);
-    if (e == hipSuccess) { *sc->h_flag = 0; e = hipHostGetDevicePointer((void**)&sc->d_hflag, sc->h_flag, 0); }
-    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&sc->d_hmsg, sc->h_pinned, 0);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&sc->h_slots, std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2), hipHostMallocDefault);
-    if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    hipError_t e = hipSuccess;
+    {
+        // pinned block: [flag 64 B][mailbox 64 B][message MAXD + evals num_mles (E2)][slot staging]
+        const size_t msg_bytes = (MAXD + (size_t)plan->num_mles) * sizeof(E2);
+        const size_t slot_bytes = std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2);
+        void *hb = nullptr, *db = nullptr;
+        int rc = ctx_pinned_alloc(ctx, 128 + msg_bytes + slot_bytes, &hb, &db);
+        if (rc) { sc_release(sc); return rc; }
+        sc->h_block = hb;
+        sc->h_flag = (unsigned long long*)hb;
+        sc->d_hflag = (unsigned long long*)db;
+        sc->h_mailbox = (Mailbox*)((char*)hb + 64);
+        sc->d_mailbox = (Mailbox*)((char*)db + 64);
+        sc->h_pinned = (E2*)((char*)hb + 128);
+        sc->d_hmsg = (uint64_t*)((char*)db + 128);
+        sc->h_slots = (MleSlot*)((char*)hb + 128 + msg_bytes);
+        *sc->h_flag = 0;
+        memset(sc->h_mailbox, 0, sizeof(Mailbox));
+    }
 
     // zero-variable MLEs are already scalars: fetch their values
     for (auto& M : sc->mles) {
@@ -681,6 +809,75 @@ static int sc_wait_flag(ceno_hip_sumcheck* sc, unsigned long long seq) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined rounds (single dense class covering all n variables, host-side transcript):
+// every round kernel is enqueued when round 0 is requested; the finishing workgroup of kernel i-1 fetches
+// challenge i-1 from the host mailbox and relays it, kernel i starts at the kernel boundary and reads it,
+// so neither the launch latency nor a stream synchronisation sits between a message and the next pass —
+// the host only moves 16-byte challenges and d*16-byte messages through pinned memory.
+// ------------------------------------------------------------------------------------------------
+static bool sc_pipeline_eligible(const ceno_hip_sumcheck* sc) {
+    if (!sc->allow_pipeline) return false;
+    static const bool disabled = getenv("CENO_HIP_NO_PIPELINE") != nullptr;  // A/B switch for measurements
+    if (disabled) return false;
+    if (sc->ctx->prof_on) return false;  // per-launch timing wants the kernels free of mailbox waits
+    if (sc->classes.size() != 1) return false;
+    const ScClass& cl = sc->classes[0];
+    return cl.dense && cl.nv == sc->n && sc->n >= 2;
+}
+
+template <int K>
+static void pipe_launch(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pairs, unsigned grid, const Epilogue& ep) {
+    launch_dense<K>(sc, cl, mode, pairs, e2_zero(), grid, ep);
+}
+
+static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
+    ceno_hip_ctx* ctx = sc->ctx;
+    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    timespec ts0, ts1;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &ts0);
+    ScClass& cl = sc->classes[0];
+    const ScTerm& T = sc->terms[cl.terms[0]];
+    const int K = (int)T.idx.size();
+    for (int i = 0; i < sc->n; i++) {
+        const size_t pairs = (size_t)1 << (cl.nv - i - 1);
+        const unsigned grid = sc_grid(pairs);
+        Epilogue ep{};
+        ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
+        ep.counter = sc->d_counter;
+        ep.round_acc = sc->d_round_acc;
+        ep.out_msg = sc->d_hmsg;
+        ep.flag = sc->d_hflag;
+        ep.seq = (unsigned long long)(i + 1);
+        ep.coeff = T.coeff;
+        ep.first_class = 1;
+        ep.last_class = 1;
+        ep.d = sc->d;
+        ep.mailbox = sc->d_mailbox;
+        ep.bcast = sc->d_bcast;
+        ep.wait_seq = (unsigned long long)i;                         // round 0 takes no challenge
+        ep.next_seq = (i + 1 < sc->n) ? (unsigned long long)(i + 1) : 0;  // fetch challenge i for round i+1
+        const bool base_in = !sc->mles[T.idx[0]].cur_ext;
+        const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
+        switch (K) {
+        case 1: pipe_launch<1>(sc, cl, mode, pairs, grid, ep); break;
+        case 2: pipe_launch<2>(sc, cl, mode, pairs, grid, ep); break;
+        case 3: pipe_launch<3>(sc, cl, mode, pairs, grid, ep); break;
+        default: pipe_launch<4>(sc, cl, mode, pairs, grid, ep); break;
+        }
+        if (i > 0) sc_advance(sc, cl);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (dbg) {
+        clock_gettime(CLOCK_MONOTONIC, &ts1);
+        fprintf(stderr, "[ceno_hip] enqueued %d pipelined rounds in %.1f us\n", sc->n,
+                (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3);
+    }
+    sc->pipelined = true;
+    sc->seq = (unsigned long long)sc->n;
+    return 0;
+}
+
 // one round; out goes to host (h_out != NULL, waits for the message) or to device memory d_out
 static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* h_out, uint64_t* d_out) {
     ceno_hip_ctx* ctx = sc->ctx;
@@ -691,6 +888,32 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     const E2 r = i > 0 ? E2{challenge2[0], challenge2[1]} : e2_zero();
     const int d = sc->d;
     size_t h_cursor = 0;
+
+    // ---- 0. pipelined fast path ----
+    if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc));
+    if (sc->pipelined) {
+        if (d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: device-output rounds cannot follow host-output rounds");
+        if (i > 0) {
+            sc->h_mailbox->chal[0] = r.c0;
+            sc->h_mailbox->chal[1] = r.c1;
+            __atomic_store_n(&sc->h_mailbox->chal_seq, (unsigned long long)i, __ATOMIC_RELEASE);
+        }
+        static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+        timespec ta, tb;
+        if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
+        TRY(sc_wait_flag(sc, (unsigned long long)(i + 1)));
+        if (dbg) {
+            clock_gettime(CLOCK_MONOTONIC, &tb);
+            static timespec last_ret = {0, 0};
+            fprintf(stderr, "[ceno_hip] round %d: host away %.1f us, waited %.1f us\n", i,
+                    (ta.tv_sec - last_ret.tv_sec) * 1e6 + (ta.tv_nsec - last_ret.tv_nsec) / 1e3,
+                    (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) / 1e3);
+            last_ret = tb;
+        }
+        memcpy(h_out, sc->h_pinned, (size_t)d * sizeof(E2));
+        sc->round++;
+        return 0;
+    }
 
     // ---- 1. classes that are (or just become) scalars: update tails / bind their last variable ----
     ScClass* became_scalar = nullptr;
@@ -881,6 +1104,13 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
 }
 
 int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc) { return sc ? sc->round : -1; }
+
+int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on) {
+    CHECK_ARG(ctx, sc, "NULL argument");
+    if (sc->round != 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: pipelining must be chosen before round 0");
+    sc->allow_pipeline = on != 0;
+    return 0;
+}
 
 int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc) {
     (void)ctx;

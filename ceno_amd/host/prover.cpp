@@ -104,6 +104,7 @@ int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
     ceno_hip_sumcheck* sc = nullptr;
     int rc = ceno_hip_sumcheck_begin(ctx, mles, plan, s, &sc);
     if (rc) return fail_from_ctx(ctx, rc);
+    ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // this loop drives the rounds back to back
     rc = ceno_prover_sumcheck_run(ctx, sc, plan->max_num_vars, plan->max_degree, plan->num_mles, tr, out_msgs, out_challenges,
                                   out_final_evals);
     ceno_hip_sumcheck_free(ctx, sc);

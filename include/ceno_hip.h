@@ -156,6 +156,12 @@ int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const 
  * (get_mle_flatten_final_evaluations, gkr_iop/src/gkr/layer/cpu/mod.rs:229-230) */
 int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals);
 int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc);
+/* Opt in (before round 0) to pipelined rounds: all round kernels are enqueued at round 0 and pick their
+ * challenges up from a pinned-memory mailbox, which removes the launch latency from every round.  The
+ * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after ~4 s without
+ * its challenge and the next call then fails with CENO_HIP_ERR_HIP).  Only taken for plans the library can
+ * pipeline (one dense product over tables of max_num_vars variables); otherwise a no-op. */
+int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on);
 int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,0 +1,63 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  cpu_baseline leg of bench.py, run as a child process so that the
+OpenMP runtime is not shared with (or pinned by) the torch process: times the oracle's fused OpenMP
+sumcheck (a port of the algorithm — the Rust/rayon reference cannot be built in this image) on the host
+cores of the box and prints one JSON object."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    nv = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    K, SEED0, TR_SEED = 3, 0xCE10, 0xF5
+    from oracle import pyoracle as po
+
+    try:  # -march=native build for this box; fall back to the shipped portable build
+        tmp = tempfile.mkdtemp(prefix="ceno_orc_")
+        so = os.path.join(tmp, "libceno_oracle_native.so")
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "tower.c", "commit.c")]
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", so] + srcs,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        po._LIB_PATH = so
+        po._lib = None
+    except Exception:
+        pass
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    tables = [po.rand_ext(1 << nv, SEED0 + j) for j in range(K)]
+    chal = po.rand_ext(nv, TR_SEED)
+    ws = po.dense_mt_workspace(K, nv)
+    best = None
+    for threads in sorted({cores, max(1, cores // 2), min(cores, 64), min(cores, 16)}, reverse=True):
+        po.sumcheck_dense_mt([t[: 1 << 16] for t in tables], chal[:16], threads=threads)  # spin up the team
+        t0 = time.perf_counter()
+        po.sumcheck_dense_mt(tables, chal, threads=threads, workspace=ws)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (threads, dt)
+    mults = K * K * ((1 << nv) - 1)
+    small = [t[: 1 << 20].copy() for t in tables]
+    ws1 = po.dense_mt_workspace(K, 20)
+    t1 = time.perf_counter()
+    po.sumcheck_dense_mt(small, chal[:20], threads=1, workspace=ws1)
+    dt1 = time.perf_counter() - t1
+    print(json.dumps({
+        "value": mults / best[1],
+        "unit": "ext-mults/s",
+        "cores": best[0],
+        "kind": "port",
+        "sample": f"one sumcheck, {K} ext MLEs x nv={nv} (same generator as the GPU run), OpenMP x{best[0]} of {cores} "
+                  f"available cores, {best[1]:.2f} s; 1 thread at nv=20: {K * K * ((1 << 20) - 1) / dt1:.3e} ext-mults/s",
+    }))
+
+
+if __name__ == "__main__":
+    main()

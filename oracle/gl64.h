@@ -40,7 +40,22 @@ static inline uint64_t gl_add(uint64_t a, uint64_t b) {
 }
 static inline uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
 static inline uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
-static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % GL_P); }
+/* definition by division — kept as the cross-check of the fast form below (tests/test_oracle_field.py) */
+static inline uint64_t gl_mul_div(uint64_t a, uint64_t b) { return (uint64_t)(((u128)a * b) % GL_P); }
+/* x = hi*2^64 + lo = lo + hi_lo*(2^32-1) - hi_hi  (2^64 = 2^32-1, 2^96 = -1 mod p), all in u128/i128 */
+static inline uint64_t gl_mul(uint64_t a, uint64_t b) {
+    u128 x = (u128)a * b;
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hi_lo = hi & 0xFFFFFFFFULL, hi_hi = hi >> 32;
+    /* lo + hi_lo*EPS < 2^64 + 2^64 ; subtract hi_hi after adding p to stay non-negative */
+    u128 t = (u128)lo + (u128)hi_lo * 0xFFFFFFFFULL + GL_P - hi_hi;  /* < 3 * 2^64 */
+    uint64_t tl = (uint64_t)t, th = (uint64_t)(t >> 64);               /* th in {0,1,2} */
+    u128 r = (u128)tl + (u128)th * 0xFFFFFFFFULL;                     /* 2^64 = EPS */
+    if (r >> 64) r = (uint64_t)r + (u128)0xFFFFFFFFULL;
+    uint64_t v = (uint64_t)r;
+    if (r >> 64) v += 0xFFFFFFFFULL; /* cannot happen twice; kept for safety */
+    return v >= GL_P ? v - GL_P : v;
+}
 static inline uint64_t gl_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; }

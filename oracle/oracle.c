@@ -70,6 +70,7 @@ __attribute__((unused)) static void tr_challenge_pows(orc_transcript* t, int n, 
  * exported field helpers
  * ---------------------------------------------------------------------------------------- */
 uint64_t orc_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a, b); }
+uint64_t orc_gl_mul_div(uint64_t a, uint64_t b) { return gl_mul_div(a, b); }
 uint64_t orc_gl_inv(uint64_t a) { return gl_inv(a); }
 void orc_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* out) { st2(out, e2_mul(ld2(a), ld2(b))); }
 void orc_e2_inv(const uint64_t* a, uint64_t* out) { st2(out, e2_inv(ld2(a))); }

@@ -43,6 +43,7 @@ void orc_stub_sample_ext(orc_stub_state* st, uint64_t* out2);
 
 /* ---- field helpers exported for Python cross-checks ---- */
 uint64_t orc_gl_mul(uint64_t a, uint64_t b);
+uint64_t orc_gl_mul_div(uint64_t a, uint64_t b); /* by division: cross-check */
 uint64_t orc_gl_inv(uint64_t a);
 void orc_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* out);
 void orc_e2_inv(const uint64_t* a, uint64_t* out);

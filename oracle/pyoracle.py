@@ -112,6 +112,8 @@ def lib():
         _lib = C.CDLL(_LIB_PATH)
         _lib.orc_gl_mul.restype = C.c_uint64
         _lib.orc_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.orc_gl_mul_div.restype = C.c_uint64
+        _lib.orc_gl_mul_div.argtypes = [C.c_uint64, C.c_uint64]
         _lib.orc_gl_inv.restype = C.c_uint64
         _lib.orc_gl_inv.argtypes = [C.c_uint64]
         _lib.orc_interleave_out_len.restype = C.c_size_t
@@ -280,13 +282,19 @@ def recover_claim_from_final(final_claim, msgs, challenges):
     return int(o[0]), int(o[1])
 
 
-def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, threads: int = 0):
+def dense_mt_workspace(k: int, n: int):
+    """ping/pong buffers of sumcheck_dense_mt, touched (zero-filled) so that timing excludes page faults"""
+    ping = [np.zeros((max(1, 1 << (n - 1)), 2), dtype=np.uint64) for _ in range(k)]
+    pong = [np.zeros((max(1, 1 << max(n - 2, 0)), 2), dtype=np.uint64) for _ in range(k)]
+    return ping, pong
+
+
+def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, threads: int = 0, workspace=None):
     """tables: k ext arrays (2^n,2). Inputs are not modified."""
     k = len(tables)
     n = int(tables[0].shape[0]).bit_length() - 1
     bufs = [np.ascontiguousarray(t) for t in tables]
-    ping = [np.empty((max(1, 1 << (n - 1)), 2), dtype=np.uint64) for _ in range(k)]
-    pong = [np.empty((max(1, 1 << max(n - 2, 0)), 2), dtype=np.uint64) for _ in range(k)]
+    ping, pong = workspace if workspace is not None else dense_mt_workspace(k, n)
     ptrs = (u64p * (3 * k))(*[_p(b) for b in bufs + ping + pong])
     msgs = np.zeros((n, k, 2), dtype=np.uint64)
     fin = np.zeros((k, 2), dtype=np.uint64)

@@ -210,6 +210,32 @@ def test_sumcheck_error_behaviour(dev, prover):
         sc.finish((5, 6))
 
 
+def test_sumcheck_abandoned_midway_does_not_hang(dev, prover):
+    # pipelined mode has every round kernel queued behind a host mailbox: freeing the handle early must
+    # release them (abort flag) instead of leaving kernels spinning
+    import time
+
+    from ceno_amd import Sumcheck
+
+    mles = [dev.synthetic(14, True, 70 + j) for j in range(3)]
+    for rounds_before_free in (1, 3):
+        sc = Sumcheck(dev, mles, po.ext([1]), [[0, 1, 2]], 14, 3)
+        sc.set_pipelined(True)
+        ch = None
+        for _ in range(rounds_before_free):
+            sc.round(ch)
+            ch = (5, 6)
+        t0 = time.time()
+        sc.free()
+        dev.sync()
+        assert time.time() - t0 < 2.0
+    # the device is still healthy and a fresh sumcheck on the same tables is still bit-exact
+    tables = [m.download() for m in mles]
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, po.ext([1]), [[0, 1, 2]], 14, 3, prover.Transcript.stub(4))
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, po.ext([1]), [[0, 1, 2]], 14, 3, po.StubTranscript(4))
+    assert np.array_equal(msgs, omsgs) and np.array_equal(fin, ofin)
+
+
 def test_sumcheck_inputs_are_not_modified(dev, prover):
     t = [po.rand_ext(1 << 10, j) for j in range(3)]
     mles = [dev.upload(x) for x in t]

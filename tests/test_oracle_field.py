@@ -16,6 +16,7 @@ def test_gl_mul_inv_vs_bigint():
     for a in vals:
         for b in vals[:20]:
             assert lib.orc_gl_mul(a, b) == a * b % P
+            assert lib.orc_gl_mul_div(a, b) == a * b % P
         if a:
             assert lib.orc_gl_inv(a) * a % P == 1
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of `bench.py` into the files kept under profiles/.
+
+usage: tools/pmc_summary.py <trace_dir> <pmc_fetch_dir> <pmc_write_dir> <sumchecks_in_pmc_run> <out_prefix>
+ - kernel stats: copied verbatim (rocprofv3 --kernel-trace --stats)
+ - traffic: FETCH_SIZE / WRITE_SIZE (KB) of the k_dense launches; FETCH_SIZE is doubled (gfx950: the counter
+   reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md §HBM)
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+
+def counter_sum(d, name):
+    fn = glob.glob(d + "/*counter_collection.csv")[0]
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(fn)):
+        if r["Counter_Name"] == name and "k_dense" in r["Kernel_Name"]:
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot, n
+
+
+def main():
+    trace, fdir, wdir, n_sc, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    shutil.copy(glob.glob(trace + "/*kernel_stats.csv")[0], out + "_kernel_stats.csv")
+    f, nf = counter_sum(fdir, "FETCH_SIZE")
+    w, nw = counter_sum(wdir, "WRITE_SIZE")
+    fetch_b = f * 1024 * 2  # gfx950 correction
+    write_b = w * 1024
+    res = {
+        "kernel": "k_dense<3,*>",
+        "sumchecks_profiled": n_sc,
+        "launches": nf,
+        "fetch_size_kb_raw": f,
+        "write_size_kb_raw": w,
+        "fetch_bytes_corrected": fetch_b,
+        "write_bytes": write_b,
+        "hbm_bytes_per_sumcheck": (fetch_b + write_b) / n_sc,
+        "hbm_bytes_per_launch": (fetch_b + write_b) / max(nf, 1),
+        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (wide coalesced reads are tallied at half size on gfx950); "
+                "WRITE_SIZE checked against k_fill_splitmix (exact)",
+    }
+    json.dump(res, open(out + "_pmc_traffic.json", "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,23 @@ __global__ void __launch_bounds__(256) k_fold_like(const E2* __restrict__ in, E2
     }
 }
 
+// fold-like variants: V=0 plain, 1 nontemporal stores, 2 nontemporal loads+stores, 3 nontemporal loads only
+template <int V>
+__global__ void __launch_bounds__(256) k_fold_nt(const E2* __restrict__ in, E2* __restrict__ outp, size_t pairs) {
+    size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+    const u2* vin = reinterpret_cast<const u2*>(in);
+    u2* vout = reinterpret_cast<u2*>(outp);
+    for (size_t p = tid; p < pairs; p += nthreads) {
+        u2 a, b, c, d;
+        if (V == 2 || V == 3) { a = __builtin_nontemporal_load(vin + 4 * p); b = __builtin_nontemporal_load(vin + 4 * p + 1); c = __builtin_nontemporal_load(vin + 4 * p + 2); d = __builtin_nontemporal_load(vin + 4 * p + 3); }
+        else { a = vin[4 * p]; b = vin[4 * p + 1]; c = vin[4 * p + 2]; d = vin[4 * p + 3]; }
+        u2 x = a ^ b, y = c ^ d;
+        if (V == 1 || V == 2) { __builtin_nontemporal_store(x, vout + 2 * p); __builtin_nontemporal_store(y, vout + 2 * p + 1); }
+        else { vout[2 * p] = x; vout[2 * p + 1] = y; }
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_alu(E2* out, int iters, E2 seed) {
     E2 a = E2{seed.c0 + threadIdx.x, seed.c1 + blockIdx.x}, b = E2{seed.c1 ^ threadIdx.x, seed.c0};
@@ -77,6 +94,14 @@ int main() {
         double gb = n * 16.0 / 1e9;
         printf("blocks=%5d  read16B/lane %.0f GB/s | 32B/lane %.0f | 64B/lane %.0f | 4x1KB rows %.0f | fold-like(r+w) %.0f GB/s\n", blocks,
                gb / t0 * 1e3, gb / t1 * 1e3, gb / t2 * 1e3, gb / t3 * 1e3, gb * 1.5 / t4 * 1e3);
+    }
+    for (int blocks : {1024, 1536, 2048}) {
+        float f0 = time([&] { hipLaunchKernelGGL(k_fold_nt<0>, dim3(blocks), dim3(256), 0, 0, in, outp, n / 4); });
+        float f1 = time([&] { hipLaunchKernelGGL(k_fold_nt<1>, dim3(blocks), dim3(256), 0, 0, in, outp, n / 4); });
+        float f2 = time([&] { hipLaunchKernelGGL(k_fold_nt<2>, dim3(blocks), dim3(256), 0, 0, in, outp, n / 4); });
+        float f3 = time([&] { hipLaunchKernelGGL(k_fold_nt<3>, dim3(blocks), dim3(256), 0, 0, in, outp, n / 4); });
+        double gb = n * 16.0 * 1.5 / 1e9;
+        printf("fold-like blocks=%d: plain %.0f | nt-store %.0f | nt-load+store %.0f | nt-load %.0f GB/s\n", blocks, gb / f0 * 1e3, gb / f1 * 1e3, gb / f2 * 1e3, gb / f3 * 1e3);
     }
     int iters = 2000;
     const char* names[] = {"ext mul (lazy schoolbook)", "base mul (limb)", "ext add/sub", "ext mul (old karatsuba)", "base mul (old)", "mad_u64_u32 chain"};
