@@ -91,12 +91,45 @@ def main():
         torch.cuda.synchronize()
         dev.sync()
 
-    def step():
-        tr = prover.Transcript.stub(TR_SEED)
-        if world == 1:
-            return prover.sumcheck_prove(dev, mles, np.array([[1, 0]], dtype=np.uint64), [list(range(K))], n_total, K, tr)
+    ONE = np.array([[1, 0]], dtype=np.uint64)
+    TERMS = [list(range(K))]
+    collective = "none"
+    comm = stream = None
+
+    def step_torch():
+        # per-round all-gather issued from Python through torch.distributed (RCCL underneath)
         eng = cdist.HipShardEngine(dev, mles)
-        return cdist.sharded_sumcheck_prove(eng, n_total, K, tr, dist=dist, world=world, rank=rank)
+        return cdist.sharded_sumcheck_prove(eng, n_total, K, prover.Transcript.stub(TR_SEED), dist=dist, world=world, rank=rank)
+
+    def step_native():
+        # the same protocol driven from C++ with ncclAllGather on the kernels' HIP stream (host/dist.cpp)
+        return prover.dist_sumcheck_prove(dev, comm, mles, ONE, TERMS, n_total, K, prover.Transcript.stub(TR_SEED), stream)
+
+    if world > 1:
+        collective = "torch.distributed all_gather (python loop)"
+        step_fn = step_torch
+        try:
+            stream = dev.stream_create()
+            comm = prover.RcclComm(world, rank, dist)
+            a, b = step_native(), step_torch()
+            same = all(np.array_equal(x, y) for x, y in zip(a, b))
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                step_fn = step_native
+                collective = "ncclAllGather from the C++ host loop (checked against the torch.distributed path)"
+        except Exception as e:  # keep the tested path if the native one is unavailable
+            print(f"bench.py: native RCCL path unavailable on rank {rank}: {e}", file=sys.stderr)
+            ok = torch.tensor([0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            try:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            except Exception:
+                pass
+
+    def step():
+        if world == 1:
+            return prover.sumcheck_prove(dev, mles, ONE, TERMS, n_total, K, prover.Transcript.stub(TR_SEED))
+        return step_fn()
 
     for _ in range(args.warmup):
         step()
@@ -148,6 +181,7 @@ def main():
                         f"degree {K}, stub Fiat-Shamir transcript on host, inputs resident in HBM",
             "global_num_vars": n_total,
             "sharding": "none" if world == 1 else f"top-{log_w}-bits over {world} GPUs, all-gather of partials per round",
+            "collective": collective,
         },
         "roofline": {
             "bound": "hbm",

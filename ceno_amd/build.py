@@ -23,7 +23,8 @@ LIB_PROVER = os.path.join(HERE, "libceno_prover.so")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")]
-CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include")]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+             "-D__HIP_PLATFORM_AMD__"]
 
 
 def _stale(target: str, deps) -> bool:
@@ -70,7 +71,8 @@ def build_prover(force: bool = False) -> str:
     if force or _stale(LIB_PROVER, srcs + hdrs + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"
         _run([cxx] + CXX_FLAGS + ["-shared", "-o", LIB_PROVER] + srcs +
-             ["-L", HERE, "-lceno_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+             ["-L", HERE, "-lceno_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib",
+              "-lpthread", "-ldl"])
     return LIB_PROVER
 
 

@@ -123,6 +123,11 @@ def _gather(dist, local, world: int, degree: int, device_tensor: bool) -> np.nda
         dist.all_gather_into_tensor(out, local)
         return out.cpu().numpy().view(np.uint64).reshape(world, degree, 2)
     t = torch.from_numpy(np.ascontiguousarray(local).view(np.int64).reshape(-1))
+    if dist.get_backend() == "nccl":  # RCCL moves device memory only
+        t = t.cuda()
+        out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().view(np.uint64).reshape(world, degree, 2)
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return np.stack([o.numpy().view(np.uint64).reshape(degree, 2) for o in outs])

@@ -1,0 +1,257 @@
+// Hypercube-sharded sumcheck across the GPUs of one node, driven from C++ with RCCL.
+//
+// the reference has no intra-sumcheck distribution ("Distributed Sumcheck — TODO",
+// docs/src/optimizations.md:3-5) — this is new design.  LSB-first binding pairs adjacent indices, so
+// splitting every table by its TOP log2(world) index bits keeps every fold local for the first
+// n_local = n - log2(world) rounds.  One process per GPU (launched by torch.distributed, which also
+// carries the ncclUniqueId bootstrap); per local round each rank's kernel leaves d partial evaluations in
+// device memory, ONE ncclAllGather of world*d extension elements runs on the same HIP stream, the host adds
+// them mod p (RCCL has no mod-p reduction; ncclSum on uint64 would wrap mod 2^64) and the replicated
+// transcript produces the challenge.  After the local rounds one more all-gather of the per-rank final
+// values builds world-sized tables and the last log2(world) rounds run replicated on every rank.
+// The collectives are latency bound (48*world bytes); xGMI bandwidth never matters on this path.
+//
+// RCCL is resolved with dlopen at first use so that libceno_prover.so loads on machines without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ceno_prover.h"
+#include "../csrc/gl64.cuh"
+
+using gl::E2;
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::string g_dist_err;
+
+int load_rccl() {
+    if (g_rccl.h) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) {
+        g_dist_err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?");
+        return CENO_HIP_ERR_UNSUPPORTED;
+    }
+    *(void**)&g_rccl.GetUniqueId = dlsym(g_rccl.h, "ncclGetUniqueId");
+    *(void**)&g_rccl.CommInitRank = dlsym(g_rccl.h, "ncclCommInitRank");
+    *(void**)&g_rccl.AllGather = dlsym(g_rccl.h, "ncclAllGather");
+    *(void**)&g_rccl.CommDestroy = dlsym(g_rccl.h, "ncclCommDestroy");
+    *(void**)&g_rccl.GetErrorString = dlsym(g_rccl.h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        g_dist_err = "RCCL symbols missing";
+        return CENO_HIP_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
+int nccl_fail(ncclResult_t r, const char* what) {
+    g_dist_err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+    return CENO_HIP_ERR_HIP;
+}
+
+void tr_usize(ceno_transcript* t, uint64_t v) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
+    t->append_label(t->self, b, 8);
+}
+E2 absorb_round(ceno_transcript* tr, const uint64_t* msg, int d) {
+    for (int t = 0; t < d; t++) tr->append_ext(tr->self, msg + 2 * t);
+    static const char lbl[] = "Internal round";
+    tr->append_label(tr->self, (const uint8_t*)lbl, sizeof(lbl) - 1);
+    uint64_t o[2];
+    tr->sample_ext(tr->self, o);
+    return E2{o[0], o[1]};
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ceno_dist_last_error(void) { return g_dist_err.c_str(); }
+
+struct ceno_dist_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    uint64_t* d_send = nullptr;  // device staging: up to 64 ext per rank
+    uint64_t* d_recv = nullptr;
+    uint64_t* h_recv = nullptr;  // pinned
+};
+
+int ceno_dist_unique_id(uint8_t* out128) {
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    memcpy(out128, &id, 128);
+    return 0;
+}
+
+int ceno_dist_comm_init(int world, int rank, const uint8_t* id128, ceno_dist_comm** out) {
+    int rc = load_rccl();
+    if (rc) return rc;
+    auto* c = new ceno_dist_comm();
+    c->world = world;
+    c->rank = rank;
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return nccl_fail(r, "ncclCommInitRank");
+    }
+    const size_t per_rank = 64 * 2;  // words
+    if (hipMalloc((void**)&c->d_send, per_rank * 8) != hipSuccess || hipMalloc((void**)&c->d_recv, per_rank * 8 * world) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_recv, per_rank * 8 * world, hipHostMallocDefault) != hipSuccess) {
+        g_dist_err = "allocation of collective staging failed";
+        return CENO_HIP_ERR_OOM;
+    }
+    *out = c;
+    return 0;
+}
+
+void ceno_dist_comm_destroy(ceno_dist_comm* c) {
+    if (!c) return;
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    (void)hipFree(c->d_send);
+    (void)hipFree(c->d_recv);
+    (void)hipHostFree(c->h_recv);
+    delete c;
+}
+
+// all-gather `n_ext` extension elements per rank from device buffer c->d_send; result (world x n_ext) in c->h_recv
+static int gather_ext(ceno_dist_comm* c, int n_ext, hipStream_t st) {
+    if (n_ext > 64) {
+        g_dist_err = "gather_ext: more than 64 elements per rank";
+        return CENO_HIP_ERR_INVALID;
+    }
+    ncclResult_t r = g_rccl.AllGather(c->d_send, c->d_recv, (size_t)n_ext * 2, ncclUint64, c->comm, st);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclAllGather");
+    if (hipMemcpyAsync(c->h_recv, c->d_recv, (size_t)n_ext * 16 * c->world, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        g_dist_err = "gather_ext: copy/sync failed";
+        return CENO_HIP_ERR_HIP;
+    }
+    return 0;
+}
+
+/* Sumcheck of the plan's terms over a 2^n_total hypercube whose tables are sharded by their top
+ * log2(world) index bits: `mles` are this rank's shards (n_total - log2(world) variables each).
+ * Same transcript script as IOPProverState::prove, so the proof equals the single-device proof of the
+ * unsharded tables.  Outputs (identical on every rank): msgs n_total*d ext, challenges n_total ext,
+ * final_evals num_mles ext.  `s` must be an explicit stream created by ceno_hip_stream_create. */
+int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
+                             int n_total, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
+                             uint64_t* out_final_evals) {
+    if (!ctx || !c || !plan_local || !tr || !s) {
+        g_dist_err = "NULL argument (an explicit stream is required)";
+        return CENO_HIP_ERR_INVALID;
+    }
+    const int world = c->world;
+    int log_w = 0;
+    while ((1 << log_w) < world) log_w++;
+    const int n_local = plan_local->max_num_vars, d = plan_local->max_degree, k = plan_local->num_mles;
+    if ((1 << log_w) != world || n_local + log_w != n_total || k > 64 || d > 8) {
+        g_dist_err = "bad sharding geometry";
+        return CENO_HIP_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)s;
+    tr_usize(tr, (uint64_t)n_total);
+    tr_usize(tr, (uint64_t)d);
+    ceno_hip_sumcheck* sc = nullptr;
+    int rc = ceno_hip_sumcheck_begin(ctx, mles, plan_local, s, &sc);
+    if (rc) {
+        g_dist_err = ceno_hip_last_error(ctx);
+        return rc;
+    }
+    uint64_t ch[2] = {0, 0};
+    std::vector<uint64_t> msg(2 * (size_t)d);
+    for (int r = 0; r < n_local; r++) {
+        rc = ceno_hip_sumcheck_round_dev(ctx, sc, r == 0 ? nullptr : ch, c->d_send);
+        if (!rc) rc = gather_ext(c, d, st);
+        if (rc) {
+            if (g_dist_err.empty()) g_dist_err = ceno_hip_last_error(ctx);
+            ceno_hip_sumcheck_free(ctx, sc);
+            return rc;
+        }
+        for (int t = 0; t < d; t++) {
+            E2 acc = gl::e2_zero();
+            for (int g = 0; g < world; g++) acc = acc + E2{c->h_recv[2 * ((size_t)g * d + t)], c->h_recv[2 * ((size_t)g * d + t) + 1]};
+            msg[2 * t] = acc.c0;
+            msg[2 * t + 1] = acc.c1;
+        }
+        memcpy(out_msgs + (size_t)2 * d * r, msg.data(), (size_t)16 * d);
+        E2 rr = absorb_round(tr, msg.data(), d);
+        ch[0] = rr.c0;
+        ch[1] = rr.c1;
+        out_challenges[2 * r] = rr.c0;
+        out_challenges[2 * r + 1] = rr.c1;
+    }
+    std::vector<uint64_t> fin_local(2 * (size_t)k);
+    rc = ceno_hip_sumcheck_finish(ctx, sc, n_local > 0 ? ch : nullptr, fin_local.data());
+    ceno_hip_sumcheck_free(ctx, sc);
+    if (rc) {
+        g_dist_err = ceno_hip_last_error(ctx);
+        return rc;
+    }
+    if (world == 1) {
+        memcpy(out_final_evals, fin_local.data(), (size_t)16 * k);
+        return 0;
+    }
+    // one value per table per rank -> world-sized tables (index = rank = the top bits), replicated tail
+    if (hipMemcpyAsync(c->d_send, fin_local.data(), (size_t)16 * k, hipMemcpyHostToDevice, st) != hipSuccess) return CENO_HIP_ERR_HIP;
+    rc = gather_ext(c, k, st);
+    if (rc) return rc;
+    std::vector<ceno_hip_mle*> tail(k, nullptr);
+    std::vector<uint64_t> tab(2 * (size_t)world);
+    for (int j = 0; j < k && !rc; j++) {
+        for (int g = 0; g < world; g++) {
+            tab[2 * g] = c->h_recv[2 * ((size_t)g * k + j)];
+            tab[2 * g + 1] = c->h_recv[2 * ((size_t)g * k + j) + 1];
+        }
+        rc = ceno_hip_mle_upload(ctx, tab.data(), log_w, 1, s, &tail[j]);
+    }
+    if (!rc) {
+        ceno_hip_sumcheck_plan tp = *plan_local;
+        tp.max_num_vars = log_w;
+        ceno_hip_sumcheck* ts = nullptr;
+        rc = ceno_hip_sumcheck_begin(ctx, tail.data(), &tp, s, &ts);
+        for (int r = 0; r < log_w && !rc; r++) {
+            rc = ceno_hip_sumcheck_round(ctx, ts, (n_local + r) == 0 ? nullptr : (r == 0 ? nullptr : ch), msg.data());
+            if (rc) break;
+            memcpy(out_msgs + (size_t)2 * d * (n_local + r), msg.data(), (size_t)16 * d);
+            E2 rr = absorb_round(tr, msg.data(), d);
+            ch[0] = rr.c0;
+            ch[1] = rr.c1;
+            out_challenges[2 * (n_local + r)] = rr.c0;
+            out_challenges[2 * (n_local + r) + 1] = rr.c1;
+        }
+        if (!rc) rc = ceno_hip_sumcheck_finish(ctx, ts, ch, out_final_evals);
+        if (ts) ceno_hip_sumcheck_free(ctx, ts);
+    }
+    for (auto* m : tail)
+        if (m) ceno_hip_mle_free(ctx, m);
+    if (rc) g_dist_err = ceno_hip_last_error(ctx);
+    return rc;
+}
+
+}  // extern "C"

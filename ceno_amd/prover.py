@@ -54,6 +54,16 @@ def plib():
     L.ceno_prover_prove_tower_relation.argtypes = [vp, vpp, i, vpp, i, vp, vp, u64p, C.POINTER(TowerProofC)]
     L.ceno_prover_last_error.restype = C.c_char_p
     L.ceno_prover_last_error.argtypes = []
+    L.ceno_dist_unique_id.restype = i
+    L.ceno_dist_unique_id.argtypes = [C.c_char_p]
+    L.ceno_dist_comm_init.restype = i
+    L.ceno_dist_comm_init.argtypes = [i, i, C.c_char_p, vpp]
+    L.ceno_dist_comm_destroy.restype = None
+    L.ceno_dist_comm_destroy.argtypes = [vp]
+    L.ceno_dist_sumcheck_prove.restype = i
+    L.ceno_dist_sumcheck_prove.argtypes = [vp, vp, vpp, C.POINTER(SumcheckPlan), i, vp, vp, u64p, u64p, u64p]
+    L.ceno_dist_last_error.restype = C.c_char_p
+    L.ceno_dist_last_error.argtypes = []
     for name in ("ceno_transcript_poseidon2_new",):
         if hasattr(L, name):
             getattr(L, name).restype = vp
@@ -242,3 +252,51 @@ def prove_tower_relation(dev: Device, prod: Sequence[Tower], logup: Sequence[Tow
     out_evals = np.zeros((2 * len(prod) + 4 * len(logup), 2), dtype=np.uint64)
     _check(plib().ceno_prover_prove_tower_relation(dev.h, pa, len(prod), la, len(logup), tr.h, stream, _p(out_evals), C.byref(proof.c)))
     return out_evals, proof
+
+
+class RcclComm:
+    """RCCL communicator for the C++ sharded prover (ceno_amd/host/dist.cpp).  `dist` is an initialised
+    torch.distributed module (or None for world 1): it only carries the 128-byte unique id."""
+
+    def __init__(self, world: int, rank: int, dist=None):
+        L = plib()
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = L.ceno_dist_unique_id(idbuf)
+            if rc != 0:
+                raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+        if world > 1:
+            obj = [bytes(idbuf.raw)]
+            dist.broadcast_object_list(obj, src=0)
+            idbuf = C.create_string_buffer(obj[0], 128)
+        h = C.c_void_p()
+        rc = L.ceno_dist_comm_init(world, rank, idbuf, C.byref(h))
+        if rc != 0:
+            raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+        self.h, self.world, self.rank = h, world, rank
+
+    def close(self):
+        if getattr(self, "h", None):
+            plib().ceno_dist_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dist_sumcheck_prove(dev: Device, comm: RcclComm, mles: Sequence[Mle], coeffs: np.ndarray, terms, n_total: int,
+                        max_degree: int, tr: Transcript, stream):
+    """sharded IOPProverState::prove — `mles` are this rank's shards; returns the global proof"""
+    n_local = n_total - (comm.world.bit_length() - 1)
+    plan, keep = make_plan(len(mles), coeffs, terms, n_local, max_degree)
+    arr = (C.c_void_p * len(mles))(*[m.h for m in mles])
+    msgs = np.zeros((n_total, max_degree, 2), dtype=np.uint64)
+    chal = np.zeros((max(n_total, 1), 2), dtype=np.uint64)
+    fin = np.zeros((len(mles), 2), dtype=np.uint64)
+    rc = plib().ceno_dist_sumcheck_prove(dev.h, comm.h, arr, C.byref(plan), n_total, tr.h, stream, _p(msgs), _p(chal), _p(fin))
+    if rc != 0:
+        raise CenoHipError(rc, (plib().ceno_dist_last_error() or b"").decode())
+    return msgs, chal[:n_total], fin

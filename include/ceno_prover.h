@@ -77,6 +77,18 @@ int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
 
 const char* ceno_prover_last_error(void);
 
+/* ---- hypercube-sharded sumcheck over the GPUs of one node (ceno_amd/host/dist.cpp) ----
+ * One process per GPU; the 128-byte RCCL unique id is created on rank 0 and distributed by the launcher
+ * (torch.distributed broadcast).  See DESIGN.md section 6. */
+typedef struct ceno_dist_comm ceno_dist_comm;
+int ceno_dist_unique_id(uint8_t* out128);
+int ceno_dist_comm_init(int world, int rank, const uint8_t* id128, ceno_dist_comm** out);
+void ceno_dist_comm_destroy(ceno_dist_comm* c);
+int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
+                             int n_total, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
+                             uint64_t* out_final_evals);
+const char* ceno_dist_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

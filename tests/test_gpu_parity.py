@@ -368,3 +368,25 @@ def test_tower_relation_mixed_specs(dev, prover):
     oproof.msgs[:] = proof.msgs
     rc, pt, pc, lp, lq = po.tower_verify(po_ev, lo_ev, [6, 4, 2, 5, 6], oproof, vt)
     assert rc == 0
+
+
+# ------------------------------------------------------------------------------------------
+# sharded driver, C++ / RCCL path at world size 1 (the >1 logic is covered under gloo in test_dist_cpu.py)
+# ------------------------------------------------------------------------------------------
+def test_native_dist_path_world1_matches_oracle(dev, prover):
+    nv, k = 12, 3
+    tables = [po.rand_ext(1 << nv, 0xCE10 + j) for j in range(k)]
+    mles = [dev.upload(t) for t in tables]
+    comm = prover.RcclComm(1, 0, None)
+    stream = dev.stream_create()
+    msgs, chal, fin = prover.dist_sumcheck_prove(dev, comm, mles, po.ext([1]), [list(range(k))], nv, k, prover.Transcript.stub(0xF5), stream)
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, po.ext([1]), [list(range(k))], nv, k, po.StubTranscript(0xF5))
+    assert np.array_equal(msgs, omsgs) and np.array_equal(chal, ochal) and np.array_equal(fin, ofin)
+    # the python/torch engine gives the same proof (this is what bench.py cross-checks at N > 1)
+    from ceno_amd import dist as cdist
+
+    eng = cdist.HipShardEngine(dev, mles)
+    m2, c2, f2 = cdist.sharded_sumcheck_prove(eng, nv, k, prover.Transcript.stub(0xF5), dist=None, world=1, rank=0)
+    assert np.array_equal(m2, omsgs) and np.array_equal(f2, ofin)
+    comm.close()
+    dev.stream_destroy(stream)
