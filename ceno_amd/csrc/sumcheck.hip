@@ -116,21 +116,19 @@ __device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
 
 // start of a pipelined round kernel: the challenge was relayed by the previous launch (kernel boundary
 // = visibility); anything else means the pipeline was aborted
-__device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r) {
+__device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r, unsigned long long* s_c /* 3 words of LDS */) {
     // ONE lane per workgroup reads the relay words, LDS broadcast to the rest
-    __shared__ unsigned long long s_c[2];
-    __shared__ int s_ok;
     if (threadIdx.x == 0) {
         // plain (cacheable) loads: the words were written by the PREVIOUS launch, the kernel boundary makes
         // them visible; cache-bypassing (sc1) loads of one line from 2048 workgroups serialise at ~90 per us
         const volatile Bcast* bc = ep.bcast;
-        s_ok = bc->ready_seq == (unsigned)ep.wait_seq;
+        s_c[2] = bc->ready_seq == (unsigned)ep.wait_seq;
         s_c[0] = bc->chal[0];
         s_c[1] = bc->chal[1];
     }
     __syncthreads();
     r = E2{s_c[0], s_c[1]};
-    return s_ok != 0;
+    return s_c[2] != 0;
 }
 
 template <int D>
@@ -166,10 +164,10 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
     if (ep.bcast) ep.bcast->dbg[ep.seq & 63][3] = wall_clock64();
 }
 
-template <int D>
-__device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* smem) {
-    __shared__ int s_is_last;
-    red::block_sum<D, NT>(acc, smem);
+template <int D, int TNT>
+__device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* smem, int* s_flag) {
+    int& s_is_last = *s_flag;
+    red::block_sum<D, TNT>(acc, smem);
     if (gridDim.x == 1) {  // latency-critical tail rounds: nothing to exchange between workgroups
         if (threadIdx.x == 0) {
             finish_message<D>(acc, ep);
@@ -196,13 +194,13 @@ __device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* s
     E2 tot[D];
 #pragma unroll
     for (int t = 0; t < D; t++) tot[t] = e2_zero();
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += NT) {
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += TNT) {
         const uint64_t* row = ep.partials + (size_t)b * D * 2;
 #pragma unroll
         for (int t = 0; t < D; t++) tot[t] = tot[t] + E2{ld_agent(row + 2 * t), ld_agent(row + 2 * t + 1)};
     }
     __syncthreads();  // smem is reused
-    red::block_sum<D, NT>(tot, smem);
+    red::block_sum<D, TNT>(tot, smem);
     if (threadIdx.x == 0) {
         __hip_atomic_store(ep.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         finish_message<D>(tot, ep);
@@ -231,8 +229,10 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
     for (int t = 0; t < K; t++) acc[t] = e2_zero();
     const size_t stride = (size_t)gridDim.x * NT;
     if (ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
+    __shared__ unsigned long long s_chal[3];
+    __shared__ int s_flag;
     if (ep.wait_seq != 0) {
-        if (!read_challenge(ep, r)) return;  // pipeline aborted / timed out: leave everything untouched
+        if (!read_challenge(ep, r, s_chal)) return;  // pipeline aborted / timed out: leave everything untouched
     }
     const E2Pre rp = e2_pre(r);
     for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
             for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
         }
     }
-    epilogue<K>(acc, ep, smem);
+    epilogue<K, NT>(acc, ep, smem, &s_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,7 +403,109 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
             }
         }
     }
-    epilogue<D>(acc, ep, smem);
+    __shared__ int s_flag;
+    epilogue<D, NT>(acc, ep, smem, &s_flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused generic round: fold every MLE of the class with r_{i-1}, write the half-size tables, stage the
+// folded (f(1), delta) of this lane's pair in LDS — lane-private columns, no barrier — and evaluate the CSR
+// term plan from LDS.  One launch per round for any single-class plan whose staging fits in LDS
+// (n_mles * TNT * 32 B); all LDS is dynamic so the 16-byte alignment of the b128 accesses is guaranteed.
+// ------------------------------------------------------------------------------------------------
+template <int D, int TNT>
+__global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pairs, E2 r, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    E2* stage = reinterpret_cast<E2*>(dyn);                               // [n_mles][2][TNT]
+    E2* smem = stage + (size_t)n_mles * 2 * TNT;                          // [(TNT/64) * D]
+    unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (TNT / 64) * D);  // 3 words + flag
+    int* s_flag = reinterpret_cast<int*>(s_chal + 4);
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) return;
+    }
+    const E2Pre rp = e2_pre(r);
+    const bool fold = pl.use_out != 0;
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * TNT;
+    const int tid = threadIdx.x;
+    for (size_t p = (size_t)blockIdx.x * TNT + tid; p < pairs; p += stride) {
+        for (int m = 0; m < n_mles; m++) {
+            const MleSlot sl = pl.slots[m];
+            E2 lo, hi;
+            if (fold) {
+                if (sl.in_ext) {
+                    const uint64_t* q = sl.in + 8 * p;
+                    const E2 a0 = ld_e2(q), a1 = ld_e2(q + 2), a2 = ld_e2(q + 4), a3 = ld_e2(q + 6);
+                    lo = a0 + e2_mul_pre(rp, a1 - a0);
+                    hi = a2 + e2_mul_pre(rp, a3 - a2);
+                } else {
+                    const uint64_t* q = sl.in + 4 * p;
+                    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(q);
+                    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(q + 2);
+                    const E2 t0 = e2_mul_base(r, sub(v0.y, v0.x)), t1 = e2_mul_base(r, sub(v1.y, v1.x));
+                    lo = E2{add(t0.c0, v0.x), t0.c1};
+                    hi = E2{add(t1.c0, v1.x), t1.c1};
+                }
+                st_e2(sl.out + 4 * p, lo);
+                st_e2(sl.out + 4 * p + 2, hi);
+            } else if (sl.in_ext) {
+                lo = ld_e2(sl.in + 4 * p);
+                hi = ld_e2(sl.in + 4 * p + 2);
+            } else {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
+                lo = E2{v.x, 0};
+                hi = E2{v.y, 0};
+            }
+            stage[(size_t)(2 * m) * TNT + tid] = hi;           // f(1)
+            stage[(size_t)(2 * m + 1) * TNT + tid] = hi - lo;  // delta
+        }
+        for (int g = 0; g < pl.n_groups; g++) {
+            E2 inner[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) inner[t] = e2_zero();
+            for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                const uint32_t term = pl.group_terms[ti];
+                const E2 c = pl.coeffs[term];
+                E2 pr[D];
+#pragma unroll
+                for (int t = 0; t < D; t++) pr[t] = c;
+                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                    const uint32_t m = pl.term_idx[k];
+                    E2 x = stage[(size_t)(2 * m) * TNT + tid];
+                    const E2 delta = stage[(size_t)(2 * m + 1) * TNT + tid];
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        pr[t] = pr[t] * x;
+                        x = x + delta;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
+            }
+            const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+            if (ce > cb) {
+                E2 cm[D];
+                for (uint32_t k = cb; k < ce; k++) {
+                    const uint32_t m = pl.common_idx[k];
+                    E2 x = stage[(size_t)(2 * m) * TNT + tid];
+                    const E2 delta = stage[(size_t)(2 * m + 1) * TNT + tid];
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        cm[t] = (k == cb) ? x : cm[t] * x;
+                        x = x + delta;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) acc[t] = acc[t] + cm[t] * inner[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+            }
+        }
+    }
+    epilogue<D, TNT>(acc, ep, smem, s_flag);
 }
 
 // gather element 0 of every listed table into out[i] (final evaluations)
@@ -554,6 +656,42 @@ static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue&
     case 6: launch_accum_d<6>(pl, pairs, ep, grid, st); break;
     case 7: launch_accum_d<7>(pl, pairs, ep, grid, st); break;
     default: launch_accum_d<8>(pl, pairs, ep, grid, st); break;
+    }
+}
+
+// fused generic kernel: threads per block chosen so that the LDS staging (n_mles * TNT * 32 B) stays <= 60 KB
+// The staging costs 32 B of LDS per MLE per in-flight pair, which caps occupancy (160 KB / CU), so the fused
+// kernel is used where a round is latency bound (one launch instead of two); large rounds keep the
+// two-kernel path whose factor re-reads are served by L2 (measured on the 2^20-row chip flow).
+static constexpr size_t FUSED_MAX_PAIRS = (size_t)1 << 14;
+static int fused_tnt(size_t n_mles, size_t pairs) {
+    if (pairs > FUSED_MAX_PAIRS) return 0;
+    if (n_mles <= 7) return 256;
+    if (n_mles <= 15) return 128;
+    if (n_mles <= 30) return 64;
+    return 0;  // does not fit: two-kernel path
+}
+template <int D, int TNT>
+static void launch_fused_dt(const DevPlan& pl, int n_mles, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    const size_t lds = ((size_t)n_mles * 2 * TNT + (TNT / 64) * D) * sizeof(E2) + 64;
+    hipLaunchKernelGGL((k_fused<D, TNT>), dim3(grid), dim3(TNT), lds, st, pl, n_mles, pairs, r, ep);
+}
+template <int D>
+static void launch_fused_d(int tnt, const DevPlan& pl, int n_mles, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    if (tnt == 256) launch_fused_dt<D, 256>(pl, n_mles, pairs, r, ep, grid, st);
+    else if (tnt == 128) launch_fused_dt<D, 128>(pl, n_mles, pairs, r, ep, grid, st);
+    else launch_fused_dt<D, 64>(pl, n_mles, pairs, r, ep, grid, st);
+}
+static void launch_fused(int d, int tnt, const DevPlan& pl, int n_mles, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    switch (d) {
+    case 1: launch_fused_d<1>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 2: launch_fused_d<2>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 3: launch_fused_d<3>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 4: launch_fused_d<4>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 5: launch_fused_d<5>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 6: launch_fused_d<6>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    case 7: launch_fused_d<7>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
+    default: launch_fused_d<8>(tnt, pl, n_mles, pairs, r, ep, grid, st); break;
     }
 }
 
@@ -1007,7 +1145,8 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
             prof_begin(ctx, sc->st);
-            if (i > 0)
+            const int tnt = cl.terms.empty() ? 0 : fused_tnt(cl.mles.size(), pairs);
+            if (i > 0 && tnt == 0)
                 hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots,
                                    2 * pairs, r);
             if (!cl.terms.empty()) {
@@ -1022,7 +1161,8 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 pl.coeffs = cl.d_coeffs;
                 pl.term_off = cl.d_term_off;
                 pl.term_idx = cl.d_term_idx;
-                launch_accum(d, pl, pairs, ep, grid, sc->st);
+                if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
+                else launch_accum(d, pl, pairs, ep, grid, sc->st);
                 first = false;
             }
             for (int j : cl.mles) {

@@ -10,6 +10,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -138,10 +140,18 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
     out->num_rounds = R;
     size_t msg_off = 0;
     std::vector<uint64_t> chal, fin;
+    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
     for (int round = 1; round <= R; round++) {      // cpu/mod.rs:409: skip(1) for the output layer
         ceno_hip_sumcheck* sc = nullptr;
+        const double t_a = dbg ? now_us() : 0;
         int rc = ceno_hip_tower_layer_sumcheck_begin(ctx, prod, n_prod, logup, n_logup, round, out_rt.data(), alpha.data(), s, &sc);
         if (rc) return fail_from_ctx(ctx, rc);
+        const double t_b = dbg ? now_us() : 0;
         // MLE order of the handle: [eq, active prod (a,b)..., active logup (p1,p2,q1,q2)...]
         int n_mles = 1;
         for (int i = 0; i < n_prod; i++) if (ceno_hip_tower_num_vars(prod[i]) > round) n_mles += 2;
@@ -149,7 +159,9 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         chal.assign((size_t)2 * round, 0);
         fin.assign((size_t)2 * n_mles, 0);
         rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + msg_off, chal.data(), fin.data());
+        const double t_c = dbg ? now_us() : 0;
         ceno_hip_sumcheck_free(ctx, sc);
+        if (dbg) fprintf(stderr, "[ceno_prover] tower layer %d: begin %.0f us, rounds %.0f us, free %.0f us\n", round, t_b - t_a, t_c - t_b, now_us() - t_c);
         if (rc) return rc;
         msg_off += (size_t)round * 3 * 2;
         // evaluations are bound into the transcript before r_merge is sampled (cpu/mod.rs:498-531)

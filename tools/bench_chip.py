@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""S-chip(2^20 rows, width 22) — BASELINE.json config #3 shape (benches/riscv_add.rs:74-150 analogue):
+commit (transpose + RS encode + Poseidon2 Merkle) -> record inference -> tower build -> tower proof ->
+main zerocheck sumcheck, all on one MI355X with the stub transcript.  Prints per-phase wall times.
+Synthetic ADD-shaped plan: 4 read + 4 write records, 8 lookups, 22 base witness columns.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-rows", type=int, default=20)
+    ap.add_argument("--width", type=int, default=22)
+    ap.add_argument("--log-blowup", type=int, default=1)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+
+    from ceno_amd import Device, api, prover
+
+    dev = Device(0)
+    n, w = args.log_rows, args.width
+    rows = 1 << n
+    P = api.P
+
+    def sync():
+        torch.cuda.synchronize()
+        dev.sync()
+
+    def timed(f):
+        sync()
+        t0 = time.perf_counter()
+        r = f()
+        sync()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    res = {"log_rows": n, "width": w}
+    # ---- witness: row-major base matrix on the device (RowMajorMatrix::rand) ----
+    big = dev.synthetic((rows * w - 1).bit_length(), False, 0xADD)
+    row_major_ptr = big.device_ptr
+    col_major = torch.empty(rows * w, dtype=torch.int64, device="cuda:0")
+    codeword = torch.empty((rows << args.log_blowup) * w, dtype=torch.int64, device="cuda:0")
+    best = {}
+    for _ in range(args.reps):
+        _, t = timed(lambda: api.transpose(dev, row_major_ptr, rows, w, col_major.data_ptr()))
+        best["transpose_ms"] = min(best.get("transpose_ms", 1e9), t)
+        _, t = timed(lambda: api.rs_encode(dev, col_major.data_ptr(), n, w, args.log_blowup, codeword.data_ptr()))
+        best["rs_encode_ms"] = min(best.get("rs_encode_ms", 1e9), t)
+        mt, t = timed(lambda: api.Merkle(dev, codeword.data_ptr(), n + args.log_blowup, w))
+        best["merkle_ms"] = min(best.get("merkle_ms", 1e9), t)
+        root = mt.root()
+        mt.free()
+    res.update(best)
+    res["commit_ms"] = best["transpose_ms"] + best["rs_encode_ms"] + best["merkle_ms"]
+    # ---- witness columns as MLE views ----
+    cols = [dev.wrap(col_major.data_ptr() + 8 * rows * j, n, False) for j in range(w)]
+    alpha, beta = (0x1234567, 0x89abcde), (0x13579b, 0x2468ac)
+    # records: r_k = alpha + beta*w_{2k} + beta^2*w_{2k+1}  (RLC of two columns), 4 reads, 4 writes, 8 lookups
+    b2 = ((beta[0] * beta[0] + 7 * beta[1] * beta[1]) % P, (2 * beta[0] * beta[1]) % P)
+    n_rec = 16
+    terms, coeffs, out_terms = [], [], []
+    for k in range(n_rec):
+        base = len(terms)
+        terms += [[(2 * k) % w], [(2 * k + 1) % w], [(3 * k + 5) % w, (k + 7) % w]]
+        coeffs += [beta, b2, alpha]
+        out_terms.append([base, base + 1, base + 2])
+    coeffs = np.array(coeffs, dtype=np.uint64)
+    recs, t = None, 1e9
+    for _ in range(args.reps):
+        r_, t_ = timed(lambda: dev.wit_infer(cols, coeffs, terms, out_terms, n))
+        if recs is not None:
+            for m in recs:
+                m.free()
+        recs, t = r_, min(t, t_)
+    res["wit_infer_ms"] = t
+    reads, writes, lks = recs[:4], recs[4:8], recs[8:16]
+    tb, tp = 1e9, 1e9
+    for _ in range(args.reps):
+        def build():
+            return ([prover.Tower.build_prod(dev, reads, rows, (1, 0)), prover.Tower.build_prod(dev, writes, rows, (1, 0))],
+                    [prover.Tower.build_logup(dev, None, lks, rows, alpha)])
+        (pt, lt), t_ = timed(build)
+        tb = min(tb, t_)
+        (_, proof), t_ = timed(lambda: prover.prove_tower_relation(dev, pt, lt, prover.Transcript.stub(1)))
+        tp = min(tp, t_)
+        res["tower_num_vars"] = [x.num_vars for x in pt + lt]
+        for x in pt + lt:
+            x.free()
+    res["tower_build_ms"], res["tower_prove_ms"] = tb, tp
+    # ---- main zerocheck-style sumcheck: sel * sum of degree<=3 terms over the witness columns ----
+    pt_ = np.array([[(i * 7919 + 13) % P, (i * 104729 + 17) % P] for i in range(n)], dtype=np.uint64)
+    sel = dev.selector_build(1, pt_, 0, rows - 3)
+    mles = cols + [sel]
+    s_idx = len(cols)
+    mterms = [[j, (j + 1) % w] for j in range(w)] + [[j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 2)]
+    mcoeffs = np.array([[(3 + 5 * i) % P, (11 * i + 1) % P] for i in range(len(mterms))], dtype=np.uint64)
+    groups = [([s_idx], list(range(len(mterms))))]
+    tm = 1e9
+    for _ in range(args.reps):
+        _, t_ = timed(lambda: prover.sumcheck_prove(dev, mles, mcoeffs, mterms, n, 4, prover.Transcript.stub(2), groups=groups))
+        tm = min(tm, t_)
+    res["main_sumcheck_ms"] = tm
+    res["total_ms"] = res["commit_ms"] + res["wit_infer_ms"] + tb + tp + tm
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
