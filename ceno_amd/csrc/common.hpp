@@ -95,4 +95,4 @@ inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
 // ---- kernels exported across translation units ----
 // fold: out[j] = in[2j] + r (in[2j+1] - in[2j]) for j < half ; `in` base or ext, `out` ext
 int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* out, size_t half, E2 r, hipStream_t st);
-int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st);
+int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, void** keep_tmp);

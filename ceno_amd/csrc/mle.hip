@@ -125,7 +125,10 @@ __global__ void __launch_bounds__(NT) k_eq_outer(E2* __restrict__ out, const E2*
     }
 }
 
-static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 scalar, const SelArg& sa, uint64_t* dev_out, hipStream_t st) {
+// `keep_tmp` != nullptr: the scratch halves are returned to the caller (who frees them once the stream has
+// passed this point) and the call does not synchronise; otherwise the call synchronises and frees them.
+static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 scalar, const SelArg& sa, uint64_t* dev_out, hipStream_t st,
+                         void** keep_tmp = nullptr) {
     CHECK_ARG(ctx, n >= 0 && n <= 40, "eq: num_vars %d out of range", n);
     PointArg pt;
     for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
@@ -139,6 +142,10 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
     size_t len = (size_t)1 << n;
     hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, (E2*)dev_out, lo, hi, a, len, sa);
     hipError_t e = hipGetLastError();
+    if (keep_tmp && e == hipSuccess) {
+        *keep_tmp = tmp;
+        return 0;
+    }
     // the scratch halves are read by the queued kernel: return them to the pool only after it ran
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     ctx_free(ctx, tmp);
@@ -146,11 +153,11 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
     return 0;
 }
 
-int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st) {
+int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, void** keep_tmp) {
     SelArg sa{};
     sa.kind = CENO_HIP_SEL_WHOLE;
     sa.num_vars = n;
-    return eq_build_impl(ctx, host_point, n, scalar, sa, dev_out, st);
+    return eq_build_impl(ctx, host_point, n, scalar, sa, dev_out, st, keep_tmp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +202,7 @@ int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, co
     ceno_hip_mle* m = nullptr;
     TRY(ceno_hip_mle_alloc(ctx, num_vars, 1, &m));
     E2 sc = scalar2 ? E2{scalar2[0], scalar2[1]} : e2_one();
-    int rc = launch_eq_build(ctx, point, num_vars, sc, m->d, ctx_stream(ctx, s));
+    int rc = launch_eq_build(ctx, point, num_vars, sc, m->d, ctx_stream(ctx, s), nullptr);
     if (rc) {
         ceno_hip_mle_free(ctx, m);
         return rc;

@@ -302,7 +302,20 @@ struct MleSlot {
 };
 
 // fold every MLE of a class: blockIdx.y = MLE
-__global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ slots, size_t half, E2 r) {
+__global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ slots, size_t half, E2 r, const Bcast* bcast,
+                                                    unsigned long long wait_seq) {
+    if (wait_seq != 0) {  // pipelined: the challenge was relayed by the previous launch
+        __shared__ unsigned long long s_c[3];
+        if (threadIdx.x == 0) {
+            const volatile Bcast* bc = bcast;
+            s_c[2] = bc->ready_seq == (unsigned)wait_seq;
+            s_c[0] = bc->chal[0];
+            s_c[1] = bc->chal[1];
+        }
+        __syncthreads();
+        if (s_c[2] == 0) return;
+        r = E2{s_c[0], s_c[1]};
+    }
     const MleSlot sl = slots[blockIdx.y];
     const size_t stride = (size_t)gridDim.x * NT;
     E2* out = reinterpret_cast<E2*>(sl.out);
@@ -354,6 +367,11 @@ __device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t
 template <int D>
 __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * D];
+    if (ep.wait_seq != 0) {  // pipelined: do nothing (and publish nothing) if the fold before us was aborted
+        __shared__ unsigned long long s_c[3];
+        E2 unused;
+        if (!read_challenge(ep, unused, s_c)) return;
+    }
     E2 acc[D];
 #pragma unroll
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
@@ -792,9 +810,18 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
     }
 
-    // ---- per-class plans ----
+    // ---- per-class plans: every array goes into ONE blob, uploaded with a single copy from pinned memory ----
     uint32_t part_off = 0;
     size_t total_slots = 0;
+    std::vector<char> blob;
+    auto append = [&blob](const void* data, size_t bytes) {
+        size_t off = (blob.size() + 15) & ~(size_t)15;
+        blob.resize(off + std::max<size_t>(bytes, 16));
+        if (bytes) memcpy(blob.data() + off, data, bytes);
+        return off;
+    };
+    struct PlanOff { size_t gto, gt, co, ci, to, ti, cf; };
+    std::vector<PlanOff> plan_offs;
     for (auto& cl : sc->classes) {
         total_slots += cl.mles.size();
         cl.part_off = part_off;
@@ -841,13 +868,10 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
         cl.n_groups = (int)g_term_off.size() - 1;
         int rc = 0;
-        rc = rc ? rc : upload_vec(sc, g_term_off, &cl.d_group_term_off);
-        rc = rc ? rc : upload_vec(sc, g_terms, &cl.d_group_terms);
-        rc = rc ? rc : upload_vec(sc, c_off, &cl.d_common_off);
-        rc = rc ? rc : upload_vec(sc, c_idx, &cl.d_common_idx);
-        rc = rc ? rc : upload_vec(sc, t_off, &cl.d_term_off);
-        rc = rc ? rc : upload_vec(sc, t_idx, &cl.d_term_idx);
-        rc = rc ? rc : upload_vec(sc, coeffs, &cl.d_coeffs);
+        plan_offs.push_back(PlanOff{append(g_term_off.data(), g_term_off.size() * 4), append(g_terms.data(), g_terms.size() * 4),
+                                    append(c_off.data(), c_off.size() * 4), append(c_idx.data(), c_idx.size() * 4),
+                                    append(t_off.data(), t_off.size() * 4), append(t_idx.data(), t_idx.size() * 4),
+                                    append(coeffs.data(), coeffs.size() * sizeof(E2))});
         if (!rc) {
             void* p = nullptr;
             rc = ctx_alloc(ctx, std::max<size_t>(cl.mles.size(), 1) * sizeof(MleSlot) * (size_t)(n + 2), &p);
@@ -873,7 +897,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         const size_t msg_bytes = (MAXD + (size_t)plan->num_mles) * sizeof(E2);
         const size_t slot_bytes = std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2);
         void *hb = nullptr, *db = nullptr;
-        int rc = ctx_pinned_alloc(ctx, 128 + msg_bytes + slot_bytes, &hb, &db);
+        int rc = ctx_pinned_alloc(ctx, 128 + msg_bytes + slot_bytes + blob.size() + 16, &hb, &db);
         if (rc) { sc_release(sc); return rc; }
         sc->h_block = hb;
         sc->h_flag = (unsigned long long*)hb;
@@ -885,6 +909,26 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         sc->h_slots = (MleSlot*)((char*)hb + 128 + msg_bytes);
         *sc->h_flag = 0;
         memset(sc->h_mailbox, 0, sizeof(Mailbox));
+        // plan blob: pinned staging -> one device allocation, one copy (the pinned block outlives the copy)
+        char* h_blob = (char*)hb + ((128 + msg_bytes + slot_bytes + 15) & ~(size_t)15);
+        memcpy(h_blob, blob.data(), blob.size());
+        void* d_blob = nullptr;
+        rc = ctx_alloc(ctx, std::max<size_t>(blob.size(), 16), &d_blob);
+        if (rc) { sc_release(sc); return rc; }
+        sc->dev_allocs.push_back(d_blob);
+        if (hipMemcpyAsync(d_blob, h_blob, blob.size(), hipMemcpyHostToDevice, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+        for (size_t c = 0; c < sc->classes.size(); c++) {
+            ScClass& cl = sc->classes[c];
+            const PlanOff& po = plan_offs[c];
+            char* base = (char*)d_blob;
+            cl.d_group_term_off = (uint32_t*)(base + po.gto);
+            cl.d_group_terms = (uint32_t*)(base + po.gt);
+            cl.d_common_off = (uint32_t*)(base + po.co);
+            cl.d_common_idx = (uint32_t*)(base + po.ci);
+            cl.d_term_off = (uint32_t*)(base + po.to);
+            cl.d_term_idx = (uint32_t*)(base + po.ti);
+            cl.d_coeffs = (E2*)(base + po.cf);
+        }
     }
 
     // zero-variable MLEs are already scalars: fetch their values
@@ -898,8 +942,6 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
             M.done = true;
         }
     }
-    e = hipStreamSynchronize(st);  // plan uploads borrowed host vectors
-    if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "begin: %s", hipGetErrorString(e)); }
     *out = sc;
     return 0;
 }
@@ -961,7 +1003,7 @@ static bool sc_pipeline_eligible(const ceno_hip_sumcheck* sc) {
     if (sc->ctx->prof_on) return false;  // per-launch timing wants the kernels free of mailbox waits
     if (sc->classes.size() != 1) return false;
     const ScClass& cl = sc->classes[0];
-    return cl.dense && cl.nv == sc->n && sc->n >= 2;
+    return cl.nv == sc->n && sc->n >= 2 && !cl.terms.empty();
 }
 
 template <int K>
@@ -969,41 +1011,88 @@ static void pipe_launch(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pai
     launch_dense<K>(sc, cl, mode, pairs, e2_zero(), grid, ep);
 }
 
+static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
+    Epilogue ep{};
+    ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
+    ep.counter = sc->d_counter;
+    ep.round_acc = sc->d_round_acc;
+    ep.out_msg = sc->d_hmsg;
+    ep.flag = sc->d_hflag;
+    ep.seq = (unsigned long long)(i + 1);
+    ep.coeff = e2_one();
+    ep.first_class = 1;
+    ep.last_class = 1;
+    ep.d = sc->d;
+    ep.mailbox = sc->d_mailbox;
+    ep.bcast = sc->d_bcast;
+    ep.wait_seq = (unsigned long long)i;                              // round 0 takes no challenge
+    ep.next_seq = (i + 1 < sc->n) ? (unsigned long long)(i + 1) : 0;  // fetch challenge i for round i+1
+    return ep;
+}
+
 static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
     ceno_hip_ctx* ctx = sc->ctx;
+    ScClass& cl = sc->classes[0];
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     timespec ts0, ts1;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &ts0);
-    ScClass& cl = sc->classes[0];
-    const ScTerm& T = sc->terms[cl.terms[0]];
-    const int K = (int)T.idx.size();
-    for (int i = 0; i < sc->n; i++) {
-        const size_t pairs = (size_t)1 << (cl.nv - i - 1);
-        const unsigned grid = sc_grid(pairs);
-        Epilogue ep{};
-        ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
-        ep.counter = sc->d_counter;
-        ep.round_acc = sc->d_round_acc;
-        ep.out_msg = sc->d_hmsg;
-        ep.flag = sc->d_hflag;
-        ep.seq = (unsigned long long)(i + 1);
-        ep.coeff = T.coeff;
-        ep.first_class = 1;
-        ep.last_class = 1;
-        ep.d = sc->d;
-        ep.mailbox = sc->d_mailbox;
-        ep.bcast = sc->d_bcast;
-        ep.wait_seq = (unsigned long long)i;                         // round 0 takes no challenge
-        ep.next_seq = (i + 1 < sc->n) ? (unsigned long long)(i + 1) : 0;  // fetch challenge i for round i+1
-        const bool base_in = !sc->mles[T.idx[0]].cur_ext;
-        const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
-        switch (K) {
-        case 1: pipe_launch<1>(sc, cl, mode, pairs, grid, ep); break;
-        case 2: pipe_launch<2>(sc, cl, mode, pairs, grid, ep); break;
-        case 3: pipe_launch<3>(sc, cl, mode, pairs, grid, ep); break;
-        default: pipe_launch<4>(sc, cl, mode, pairs, grid, ep); break;
+    if (cl.dense) {
+        const ScTerm& T = sc->terms[cl.terms[0]];
+        const int K = (int)T.idx.size();
+        for (int i = 0; i < sc->n; i++) {
+            const size_t pairs = (size_t)1 << (cl.nv - i - 1);
+            const unsigned grid = sc_grid(pairs);
+            Epilogue ep = pipe_epilogue(sc, cl, i);
+            ep.coeff = T.coeff;
+            const bool base_in = !sc->mles[T.idx[0]].cur_ext;
+            const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
+            switch (K) {
+            case 1: pipe_launch<1>(sc, cl, mode, pairs, grid, ep); break;
+            case 2: pipe_launch<2>(sc, cl, mode, pairs, grid, ep); break;
+            case 3: pipe_launch<3>(sc, cl, mode, pairs, grid, ep); break;
+            default: pipe_launch<4>(sc, cl, mode, pairs, grid, ep); break;
+            }
+            if (i > 0) sc_advance(sc, cl);
         }
-        if (i > 0) sc_advance(sc, cl);
+    } else {
+        // slot tables of every round are deterministic: stage them all, one upload
+        const size_t k = cl.mles.size();
+        for (int i = 0; i < sc->n; i++) {
+            MleSlot* h = sc->h_slots + (size_t)i * sc->slots_per_round;
+            for (size_t m = 0; m < k; m++) {
+                ScMle& M = sc->mles[cl.mles[m]];
+                h[m].in = M.cur;
+                h[m].out = M.buf[M.which];
+                h[m].in_ext = M.cur_ext;
+                h[m].pad = 0;
+            }
+            if (i > 0) sc_advance(sc, cl);
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(cl.d_slots, sc->h_slots, (size_t)sc->n * k * sizeof(MleSlot), hipMemcpyHostToDevice, sc->st));
+        for (int i = 0; i < sc->n; i++) {
+            const size_t pairs = (size_t)1 << (cl.nv - i - 1);
+            Epilogue ep = pipe_epilogue(sc, cl, i);
+            DevPlan pl;
+            pl.slots = cl.d_slots + (size_t)i * k;
+            pl.use_out = i > 0 ? 1 : 0;
+            pl.n_groups = cl.n_groups;
+            pl.group_term_off = cl.d_group_term_off;
+            pl.group_terms = cl.d_group_terms;
+            pl.common_off = cl.d_common_off;
+            pl.common_idx = cl.d_common_idx;
+            pl.coeffs = cl.d_coeffs;
+            pl.term_off = cl.d_term_off;
+            pl.term_idx = cl.d_term_idx;
+            const int tnt = fused_tnt(k, pairs);
+            if (tnt) {
+                launch_fused(sc->d, tnt, pl, (int)k, pairs, e2_zero(), ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
+            } else {
+                if (i > 0)
+                    hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)k), dim3(NT), 0, sc->st, pl.slots, 2 * pairs,
+                                       e2_zero(), (const Bcast*)sc->d_bcast, (unsigned long long)i);
+                launch_accum(sc->d, pl, pairs, ep, sc_grid(pairs), sc->st);
+            }
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     if (dbg) {
@@ -1061,7 +1150,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         } else if (cl.nv == i && i > 0) {
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
-            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r);
+            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r, (const Bcast*)nullptr, 0ull);
             hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
                                sc->d_evals);
             became_scalar = &cl;  // at most one class reaches its last variable per round
@@ -1148,7 +1237,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             const int tnt = cl.terms.empty() ? 0 : fused_tnt(cl.mles.size(), pairs);
             if (i > 0 && tnt == 0)
                 hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots,
-                                   2 * pairs, r);
+                                   2 * pairs, r, (const Bcast*)nullptr, 0ull);
             if (!cl.terms.empty()) {
                 DevPlan pl;
                 pl.slots = d_slots;
@@ -1221,7 +1310,7 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
             if (cl.nv != sc->n) continue;
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, sc->n + 1, h_cursor, &d_slots));
-            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r);
+            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r, (const Bcast*)nullptr, 0ull);
             hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
                                sc->d_evals);
             HIP_TRY(ctx, hipGetLastError());
@@ -1262,3 +1351,4 @@ int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc) {
 
 // used by tower.hip: attach an MLE whose lifetime is tied to the sumcheck handle
 void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m) { sc->extra_owned = m; }
+void sumcheck_adopt_alloc(ceno_hip_sumcheck* sc, void* p) { if (p) sc->dev_allocs.push_back(p); }

@@ -299,6 +299,7 @@ int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
 }  // extern "C"
 
 void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m);
+void sumcheck_adopt_alloc(ceno_hip_sumcheck* sc, void* p);
 
 extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup,
                                                    int n_logup, int layer, const uint64_t* out_rt, const uint64_t* alpha_pows,
@@ -308,7 +309,15 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     // sum_x eq(x, out_rt) * [ sum_i alpha_i a_i b_i + sum_k (alpha_n (p1 q2 + p2 q1) + alpha_d q1 q2) ]
     // -> one common-factor group (eq) over all residual terms  (scheme/cpu/mod.rs:417-494)
     ceno_hip_mle* eq = nullptr;
-    TRY(ceno_hip_eq_build(ctx, out_rt, layer, nullptr, s, &eq));
+    void* eq_tmp = nullptr;  // scratch of the eq build; lives (like eq) until the sumcheck handle is freed
+    TRY(ceno_hip_mle_alloc(ctx, layer, 1, &eq));
+    {
+        int erc = launch_eq_build(ctx, out_rt, layer, gl::e2_one(), eq->d, ctx_stream(ctx, s), &eq_tmp);
+        if (erc) {
+            ceno_hip_mle_free(ctx, eq);
+            return erc;
+        }
+    }
     std::vector<ceno_hip_mle*> mles{eq};
     std::vector<ceno_hip_mle*> views;
     std::vector<uint64_t> coeffs;
@@ -355,6 +364,8 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     if (!rc && toff.size() == 1) rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "no tower has layer %d", layer);
     if (rc) {
         cleanup();
+        (void)hipStreamSynchronize(ctx_stream(ctx, s));
+        ctx_free(ctx, eq_tmp);
         ceno_hip_mle_free(ctx, eq);
         return rc;
     }
@@ -375,9 +386,12 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, out);
     cleanup();  // views are borrowed wrappers; the sumcheck copied the pointers
     if (rc) {
+        (void)hipStreamSynchronize(ctx_stream(ctx, s));
+        ctx_free(ctx, eq_tmp);
         ceno_hip_mle_free(ctx, eq);
         return rc;
     }
-    sumcheck_adopt_mle(*out, eq);  // eq lives as long as the sumcheck
+    sumcheck_adopt_mle(*out, eq);      // eq lives as long as the sumcheck
+    sumcheck_adopt_alloc(*out, eq_tmp);
     return 0;
 }

@@ -158,6 +158,7 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         for (int i = 0; i < n_logup; i++) if (ceno_hip_tower_num_vars(logup[i]) > round) n_mles += 4;
         chal.assign((size_t)2 * round, 0);
         fin.assign((size_t)2 * n_mles, 0);
+        ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // the loop below drives the rounds back to back
         rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + msg_off, chal.data(), fin.data());
         const double t_c = dbg ? now_us() : 0;
         ceno_hip_sumcheck_free(ctx, sc);
