@@ -79,6 +79,8 @@ def lib():
         "ceno_hip_mle_fix_variables": (i, [vp, vp, u64p, i, vp, vpp]),
         "ceno_hip_eq_build": (i, [vp, u64p, i, u64p, vp, vpp]),
         "ceno_hip_selector_build": (i, [vp, i, u64p, i, sz, sz, u32p, i, i, vp, vpp]),
+        "ceno_hip_rotation_next_base_mle": (i, [vp, vp, i, vp, vpp]),
+        "ceno_hip_rotation_selector_build": (i, [vp, u64p, i, i, i, vp, vpp]),
         "ceno_hip_wit_infer": (i, [vp, vpp, i, u64p, u32p, u32p, i, u32p, i, i, vp, vpp]),
         "ceno_hip_sumcheck_begin": (i, [vp, vpp, C.POINTER(SumcheckPlan), vp, vpp]),
         "ceno_hip_sumcheck_round": (i, [vp, vp, u64p, u64p]),

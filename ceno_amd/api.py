@@ -129,6 +129,18 @@ class Device:
                                                   stream, C.byref(h)))
         return Mle(self, h)
 
+    def rotation_next_base_mle(self, m: "Mle", cyclic_group_log2: int, stream=None) -> "Mle":
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_rotation_next_base_mle(self.h, m.h, cyclic_group_log2, stream, C.byref(h)))
+        return Mle(self, h)
+
+    def rotation_selector_build(self, point: np.ndarray, cyclic_subgroup_size: int, cyclic_group_log2: int, stream=None) -> "Mle":
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        h = C.c_void_p()
+        self.check(self.L.ceno_hip_rotation_selector_build(self.h, _p(point), point.shape[0], cyclic_subgroup_size,
+                                                           cyclic_group_log2, stream, C.byref(h)))
+        return Mle(self, h)
+
     def wit_infer(self, mles: Sequence["Mle"], coeffs: np.ndarray, terms: Sequence[Sequence[int]],
                   out_terms: Sequence[Sequence[int]], num_vars: int, stream=None) -> List["Mle"]:
         """out o = sum over term ids in out_terms[o]; terms must be listed so that each output owns a

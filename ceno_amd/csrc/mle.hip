@@ -186,7 +186,77 @@ __global__ void __launch_bounds__(NT) k_sum_partials(const E2* __restrict__ part
     if (threadIdx.x == 0) out[0] = acc[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// rotation (keccak-style chips): cyclic sequence x^i in GF(2)[X]/(X^5+X^2+1) resp. /(X^6+X+1)
+// (gkr_iop/src/gkr/booleanhypercube.rs:10-113)
+// ------------------------------------------------------------------------------------------------
+struct RotArg {
+    uint8_t next[64];  // next[x^i] = x^(i+1), next[0] = 0
+};
+static int cyclic_table(int log2, uint32_t* out) {
+    uint32_t modulus = log2 == 5 ? 0x25u : log2 == 6 ? 0x43u : 0u;
+    if (!modulus) return -1;
+    uint32_t cur = 1;
+    for (int i = 0; i < (1 << log2); i++) {
+        out[i] = cur;
+        cur <<= 1;
+        if (cur & (1u << log2)) cur ^= modulus;
+    }
+    return 0;
+}
+__global__ void __launch_bounds__(NT) k_rotate_base(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t len, int log2, RotArg ra) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    const size_t mask = ((size_t)1 << log2) - 1;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) out[i] = in[(i & ~mask) | ra.next[i & mask]];
+}
+
 extern "C" {
+
+int ceno_hip_rotation_next_base_mle(ceno_hip_ctx* ctx, const ceno_hip_mle* in, int cyclic_group_log2, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, in && out, "NULL argument");
+    CHECK_ARG(ctx, !in->is_ext, "rotation source must be a base-field table (layer/gpu/utils.rs:250-254)");
+    CHECK_ARG(ctx, in->num_vars >= cyclic_group_log2, "table smaller than one cyclic group");
+    uint32_t r[64];
+    CHECK_ARG(ctx, cyclic_table(cyclic_group_log2, r) == 0, "cyclic group log2 must be 5 or 6");
+    RotArg ra{};
+    const int g = 1 << cyclic_group_log2;
+    for (int i = 0; i < g; i++) ra.next[i] = (uint8_t)i;   // positions outside the cycle (only 0) keep their value
+    for (int i = 0; i + 1 < g; i++) ra.next[r[i]] = (uint8_t)r[i + 1];  // utils.rs:45-49
+    ceno_hip_mle* m = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, in->num_vars, 0, &m));
+    hipLaunchKernelGGL(k_rotate_base, dim3(grid_for(in->len(), NT, MAXB)), dim3(NT), 0, ctx_stream(ctx, s), in->d, m->d, in->len(), cyclic_group_log2, ra);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ceno_hip_mle_free(ctx, m);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "rotation: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return 0;
+}
+
+int ceno_hip_rotation_selector_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, int cyclic_subgroup_size, int cyclic_group_log2,
+                                     ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, out && point, "NULL argument");
+    uint32_t r[64];
+    CHECK_ARG(ctx, cyclic_table(cyclic_group_log2, r) == 0, "cyclic group log2 must be 5 or 6");
+    CHECK_ARG(ctx, cyclic_subgroup_size >= 0 && cyclic_subgroup_size <= (1 << cyclic_group_log2), "cyclic subgroup larger than the group");
+    CHECK_ARG(ctx, num_vars >= cyclic_group_log2 && num_vars <= 40, "num_vars out of range");
+    SelArg sa{};
+    sa.kind = CENO_HIP_SEL_ORDERED_SPARSE;
+    sa.num_vars = num_vars;
+    sa.sparse_num_vars = cyclic_group_log2;
+    sa.end = (uint64_t)1 << (num_vars - cyclic_group_log2);  // every chunk is active (utils.rs:66-74)
+    for (int i = 0; i < cyclic_subgroup_size; i++) sa.sparse_mask[r[i] >> 6] |= (uint64_t)1 << (r[i] & 63);
+    ceno_hip_mle* m = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, num_vars, 1, &m));
+    int rc = eq_build_impl(ctx, point, num_vars, e2_one(), sa, m->d, ctx_stream(ctx, s));
+    if (rc) {
+        ceno_hip_mle_free(ctx, m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
 
 int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed, uint64_t word_offset, ceno_hip_stream s) {
     CHECK_ARG(ctx, m, "NULL mle");

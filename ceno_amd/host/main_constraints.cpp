@@ -1,0 +1,157 @@
+// Batched main-constraint sumcheck — host control flow of
+// `BatchedMainConstraintProver::prove_batched_main_constraints` (ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390),
+// written against the device C ABI.  See include/ceno_prover.h for the job encoding.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ceno_prover.h"
+#include "../csrc/gl64.cuh"
+
+using gl::E2;
+
+extern "C" const char* ceno_prover_last_error(void);
+int prover_set_error(int code, const char* msg);  // prover.cpp
+
+namespace {
+
+// extrapolate_uni_poly: degree-d polynomial through (0, p0), (i, ev[i-1]) evaluated at x
+E2 extrapolate(E2 p0, const std::vector<E2>& ev, E2 x) {
+    const int d = (int)ev.size();
+    E2 acc = gl::e2_zero();
+    for (int i = 0; i <= d; i++) {
+        E2 yi = i == 0 ? p0 : ev[i - 1];
+        E2 num = gl::e2_one();
+        uint64_t den = 1;
+        for (int j = 0; j <= d; j++) {
+            if (j == i) continue;
+            num = num * (x - E2{(uint64_t)j, 0});
+            uint64_t dij = i > j ? (uint64_t)(i - j) : gl::neg((uint64_t)(j - i));
+            den = gl::mul(den, dij);
+        }
+        acc = acc + yi * gl::e2_mul_base(num, gl::inv(den));
+    }
+    return acc;
+}
+
+}  // namespace
+
+extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_main_job* jobs, int n_jobs, const uint64_t* gc4,
+                                                          ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
+                                                          uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree) {
+    if (!ctx || !jobs || n_jobs < 1 || !gc4 || !tr) return prover_set_error(CENO_HIP_ERR_INVALID, "bad arguments");
+    int max_nv = 0, max_deg = 0, total_exprs = 0;
+    for (int c = 0; c < n_jobs; c++) {
+        max_nv = std::max(max_nv, jobs[c].num_vars);       // cpu/mod.rs:1091-1099
+        max_deg = std::max(max_deg, jobs[c].max_degree);
+        total_exprs += jobs[c].n_exprs;
+    }
+    // ---- selector eq tables per chip (cpu/mod.rs:1200-1234): first selector per structural id wins ----
+    std::vector<std::vector<ceno_hip_mle*>> sel_by_id(n_jobs);
+    std::vector<ceno_hip_mle*> owned;
+    auto cleanup = [&]() { for (auto* m : owned) ceno_hip_mle_free(ctx, m); };
+    for (int c = 0; c < n_jobs; c++) {
+        const ceno_main_job& J = jobs[c];
+        sel_by_id[c].assign(J.n_structural, nullptr);
+        for (int k = 0; k < J.n_selectors; k++) {
+            const int id = J.sel_structural_id[k];
+            if (id < 0 || id >= J.n_structural) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "selector wit id out of range"); }
+            if (sel_by_id[c][id]) continue;
+            ceno_hip_mle* m = nullptr;
+            int rc = ceno_hip_selector_build(ctx, J.sel_kind[k], J.sel_points[k], J.num_vars, J.sel_offset[k], J.sel_num_instances[k],
+                                             J.sel_sparse_indices ? J.sel_sparse_indices[k] : nullptr, J.sel_n_sparse ? J.sel_n_sparse[k] : 0,
+                                             J.sel_sparse_num_vars ? J.sel_sparse_num_vars[k] : 0, s, &m);
+            if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+            owned.push_back(m);
+            sel_by_id[c][id] = m;
+        }
+    }
+    // ---- alpha powers (cpu/mod.rs:1254) ----
+    static const char lbl[] = "combine subset evals";
+    tr->append_label(tr->self, (const uint8_t*)lbl, sizeof(lbl) - 1);
+    uint64_t a2[2];
+    tr->sample_ext(tr->self, a2);
+    std::vector<E2> alpha_pows(total_exprs);
+    {
+        E2 a{a2[0], a2[1]}, acc = gl::e2_one();
+        for (int i = 0; i < total_exprs; i++) { alpha_pows[i] = acc; acc = acc * a; }
+    }
+    // ---- global MLE list and monomial terms (cpu/mod.rs:1255-1329) ----
+    std::vector<ceno_hip_mle*> mles;
+    std::vector<int> mle_start(n_jobs), mle_nv;
+    std::vector<uint64_t> coeffs;
+    std::vector<uint32_t> toff{0}, tidx;
+    int alpha_start = 0;
+    for (int c = 0; c < n_jobs; c++) {
+        const ceno_main_job& J = jobs[c];
+        mle_start[c] = (int)mles.size();
+        const int n_m = J.n_witin + J.n_fixed + J.n_structural;
+        for (int j = 0; j < n_m; j++) {
+            ceno_hip_mle* m = J.mles[j];
+            if (j >= J.n_witin + J.n_fixed && sel_by_id[c][j - J.n_witin - J.n_fixed]) m = sel_by_id[c][j - J.n_witin - J.n_fixed];
+            if (!m) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "structural witness without selector is NULL"); }
+            mles.push_back(m);
+            mle_nv.push_back(ceno_hip_mle_num_vars(m));
+        }
+        std::vector<E2> ch{E2{gc4[0], gc4[1]}, E2{gc4[2], gc4[3]}};
+        for (int i = 0; i < J.n_exprs; i++) ch.push_back(alpha_pows[alpha_start + i]);
+        for (int t = 0; t < J.n_terms; t++) {
+            E2 scalar = gl::e2_zero();
+            for (uint32_t m = J.scalar_offsets[t]; m < J.scalar_offsets[t + 1]; m++) {
+                E2 v{J.mono_coeffs[2 * m], J.mono_coeffs[2 * m + 1]};
+                for (uint32_t k = J.mono_chal_offsets[m]; k < J.mono_chal_offsets[m + 1]; k++) {
+                    if (J.mono_chal_idx[k] >= ch.size()) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "challenge id out of range"); }
+                    v = v * ch[J.mono_chal_idx[k]];
+                }
+                scalar = scalar + v;
+            }
+            if (scalar.c0 == 0 && scalar.c1 == 0) continue;  // cpu/mod.rs:1308-1314
+            coeffs.push_back(scalar.c0);
+            coeffs.push_back(scalar.c1);
+            for (uint32_t k = J.term_offsets[t]; k < J.term_offsets[t + 1]; k++) tidx.push_back((uint32_t)(mle_start[c] + (int)J.term_mle_idx[k]));
+            toff.push_back((uint32_t)tidx.size());
+        }
+        alpha_start += J.n_exprs;
+    }
+    const int n_terms = (int)toff.size() - 1;
+    if (n_terms == 0) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "all term scalars are zero"); }
+    ceno_hip_sumcheck_plan plan{};
+    plan.num_mles = (int)mles.size();
+    plan.num_terms = n_terms;
+    plan.term_coeffs = coeffs.data();
+    plan.term_offsets = toff.data();
+    plan.term_mle_idx = tidx.data();
+    plan.max_num_vars = max_nv;
+    plan.max_degree = max_deg;
+    std::vector<uint64_t> evals(2 * mles.size());
+    int rc = ceno_prover_sumcheck_prove(ctx, mles.data(), &plan, tr, s, out_msgs, out_global_rt, evals.data());   // cpu/mod.rs:1332-1337
+    if (rc) { cleanup(); return rc; }
+    // ---- final claim by the front-load rule and the claimed sum recovered backwards (cpu/mod.rs:1338-1360,1393-1413) ----
+    E2 final_claim = gl::e2_zero();
+    for (int t = 0; t < n_terms; t++) {
+        E2 v{coeffs[2 * t], coeffs[2 * t + 1]};
+        for (uint32_t k = toff[t]; k < toff[t + 1]; k++) {
+            const int j = (int)tidx[k];
+            v = v * E2{evals[2 * j], evals[2 * j + 1]};
+            for (int i = mle_nv[j]; i < max_nv; i++) v = v * E2{out_global_rt[2 * i], out_global_rt[2 * i + 1]};
+        }
+        final_claim = final_claim + v;
+    }
+    E2 expected = final_claim;
+    for (int round = max_nv - 1; round >= 0; round--) {
+        std::vector<E2> ev(max_deg), zeros(max_deg, gl::e2_zero());
+        for (int t = 0; t < max_deg; t++) ev[t] = E2{out_msgs[2 * ((size_t)round * max_deg + t)], out_msgs[2 * ((size_t)round * max_deg + t) + 1]};
+        const E2 r{out_global_rt[2 * round], out_global_rt[2 * round + 1]};
+        const E2 hidden = extrapolate(gl::e2_one(), zeros, r);
+        const E2 without = extrapolate(gl::e2_neg(ev[0]), ev, r);
+        expected = (expected - without) * gl::e2_inv(hidden);
+    }
+    out_claimed_sum[0] = expected.c0;
+    out_claimed_sum[1] = expected.c1;
+    for (size_t j = 0; j < mles.size(); j++) tr->append_ext(tr->self, evals.data() + 2 * j);                      // cpu/mod.rs:1361
+    memcpy(out_evals, evals.data(), evals.size() * 8);
+    if (out_num_vars) *out_num_vars = max_nv;
+    if (out_degree) *out_degree = max_deg;
+    cleanup();
+    return 0;
+}

@@ -37,6 +37,10 @@ static int fail_from_ctx(ceno_hip_ctx* ctx, int code) {
 }
 
 extern "C" const char* ceno_prover_last_error(void) { return g_err.c_str(); }
+int prover_set_error(int code, const char* msg) {
+    g_err = msg ? msg : "";
+    return code;
+}
 
 // ------------------------------------------------------------------------------------------------
 // transcript helpers (same call shapes as the reference's Transcript trait)
@@ -213,6 +217,86 @@ int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
     }
     for (uint64_t* e = out_evals; e < cur; e += 2) tr_ext(tr, e);
     return ceno_prover_tower_create_proof(ctx, prod, n_prod, logup, n_logup, tr, s, out);
+}
+
+// BooleanHypercube::get_rotation_points (gkr_iop/src/gkr/booleanhypercube.rs:117-168)
+static void rotation_points(const uint64_t* point, int n, int log2, uint64_t* left, uint64_t* right) {
+    auto get = [&](int i) { return E2{point[2 * i], point[2 * i + 1]}; };
+    auto put = [](uint64_t* dst, int i, E2 v) { dst[2 * i] = v.c0; dst[2 * i + 1] = v.c1; };
+    put(left, 0, gl::e2_zero());
+    put(right, 0, gl::e2_one());
+    for (int i = 1; i < n; i++) {
+        E2 v = (i <= log2 - 1) ? get(i - 1) : get(i);
+        put(left, i, v);
+        put(right, i, v);
+    }
+    if (log2 == 5 && n > 2) put(right, 2, gl::e2_one() - get(1));  // (1, r0, 1-r1, r2, r3, r5, ...)
+    if (log2 == 6 && n > 1) put(right, 1, gl::e2_one() - get(0));  // (1, 1-r0, r1, ..., r4, r6, ...)
+}
+
+int ceno_prover_prove_rotation(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, const int* source_idx, const int* target_idx, int n_pairs,
+                               int cyclic_subgroup_size, int cyclic_group_log2, const uint64_t* rt, int n, ceno_transcript* tr,
+                               ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin, uint64_t* out_left,
+                               uint64_t* out_right) {
+    if (!ctx || !wit || !source_idx || !target_idx || !rt || !tr || n_pairs < 1) return fail(CENO_HIP_ERR_INVALID, "bad rotation arguments");
+    if (cyclic_group_log2 != 5 && cyclic_group_log2 != 6) return fail(CENO_HIP_ERR_INVALID, "cyclic group log2 must be 5 or 6");
+    std::vector<ceno_hip_mle*> rotated(n_pairs, nullptr);
+    ceno_hip_mle* sel = nullptr;
+    auto cleanup = [&]() {
+        for (auto* m : rotated) if (m) ceno_hip_mle_free(ctx, m);
+        if (sel) ceno_hip_mle_free(ctx, sel);
+    };
+    int rc = ceno_hip_rotation_selector_build(ctx, rt, n, cyclic_subgroup_size, cyclic_group_log2, s, &sel);   // cpu/mod.rs:266-283
+    for (int j = 0; j < n_pairs && !rc; j++) rc = ceno_hip_rotation_next_base_mle(ctx, wit[source_idx[j]], cyclic_group_log2, s, &rotated[j]);
+    if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    std::vector<uint64_t> alpha;
+    tr_challenge_pows(tr, n_pairs, alpha);                                                                     // cpu/mod.rs:288-292
+    // mles [rot_0, tgt_0, rot_1, tgt_1, ..., selector]; sel * sum_j alpha^j (rot_j - tgt_j)
+    std::vector<ceno_hip_mle*> mles;
+    std::vector<uint64_t> coeffs;
+    std::vector<uint32_t> toff{0}, tidx, gterms;
+    for (int j = 0; j < n_pairs; j++) {
+        mles.push_back(rotated[j]);
+        mles.push_back(wit[target_idx[j]]);
+        E2 a{alpha[2 * j], alpha[2 * j + 1]}, na = gl::e2_neg(a);
+        coeffs.insert(coeffs.end(), {a.c0, a.c1, na.c0, na.c1});
+        tidx.push_back(2 * j);     toff.push_back((uint32_t)tidx.size()); gterms.push_back(2 * j);
+        tidx.push_back(2 * j + 1); toff.push_back((uint32_t)tidx.size()); gterms.push_back(2 * j + 1);
+    }
+    mles.push_back(sel);
+    std::vector<uint32_t> goff{0, (uint32_t)gterms.size()}, coff{0, 1}, cidx{(uint32_t)(2 * n_pairs)};
+    ceno_hip_sumcheck_plan plan{};
+    plan.num_mles = (int)mles.size();
+    plan.num_terms = 2 * n_pairs;
+    plan.term_coeffs = coeffs.data();
+    plan.term_offsets = toff.data();
+    plan.term_mle_idx = tidx.data();
+    plan.num_groups = 1;
+    plan.group_term_offsets = goff.data();
+    plan.group_term_idx = gterms.data();
+    plan.common_offsets = coff.data();
+    plan.common_mle_idx = cidx.data();
+    plan.max_num_vars = n;
+    plan.max_degree = 2;
+    std::vector<uint64_t> fin(2 * mles.size());
+    rc = ceno_prover_sumcheck_prove(ctx, mles.data(), &plan, tr, s, out_msgs, out_origin, fin.data());
+    if (rc) { cleanup(); return rc; }
+    rotation_points(out_origin, n, cyclic_group_log2, out_left, out_right);                                   // cpu/mod.rs:341-342
+    const int kk = cyclic_group_log2 - 1;
+    const E2 rk{out_origin[2 * kk], out_origin[2 * kk + 1]};
+    const E2 rk_inv = gl::e2_inv(rk);
+    for (int j = 0; j < n_pairs; j++) {
+        uint64_t le[2];
+        rc = ceno_hip_mle_evaluate(ctx, wit[source_idx[j]], out_left, le, s);                                 // cpu/mod.rs:350-355
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+        const E2 left{le[0], le[1]}, rot{fin[4 * j], fin[4 * j + 1]}, target{fin[4 * j + 2], fin[4 * j + 3]};
+        const E2 right = (rot - (gl::e2_one() - rk) * left) * rk_inv;                                          // booleanhypercube.rs:170-186
+        uint64_t* e = out_evals + 6 * j;
+        e[0] = left.c0; e[1] = left.c1; e[2] = right.c0; e[3] = right.c1; e[4] = target.c0; e[5] = target.c1;
+    }
+    for (int j = 0; j < 3 * n_pairs; j++) tr_ext(tr, out_evals + 2 * j);                                       // cpu/mod.rs:377
+    cleanup();
+    return 0;
 }
 
 // ---- host-side field arithmetic exposed for CPU tests of the shared gl64.cuh code ----

@@ -105,6 +105,18 @@ int ceno_hip_selector_build(ceno_hip_ctx* ctx, int kind, const uint64_t* point, 
                             const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, ceno_hip_stream s, ceno_hip_mle** out);
 
 /* ------------------------------------------------------------------------------------------------
+ * rotation argument of the keccak-style chips  (rotation_next_base_mle_gpu / rotation_selector_gpu,
+ * gkr_iop/src/gkr/layer/gpu/utils.rs:231-336; semantics gkr_iop/src/utils.rs:19-76,
+ * cyclic tables gkr_iop/src/gkr/booleanhypercube.rs:10-113)
+ * ---------------------------------------------------------------------------------------------- */
+/* out[c*G + x^i] = in[c*G + x^(i+1)] within every chunk of G = 2^cyclic_group_log2 (5 or 6) entries, position 0 fixed;
+ * `in` is a base-field table, `out` a new base-field table */
+int ceno_hip_rotation_next_base_mle(ceno_hip_ctx* ctx, const ceno_hip_mle* in, int cyclic_group_log2, ceno_hip_stream s, ceno_hip_mle** out);
+/* eq(x, point) kept on the first `cyclic_subgroup_size` elements x^i of every chunk, zero elsewhere */
+int ceno_hip_rotation_selector_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, int cyclic_subgroup_size,
+                                     int cyclic_group_log2, ceno_hip_stream s, ceno_hip_mle** out);
+
+/* ------------------------------------------------------------------------------------------------
  * element-wise witness inference  (wit_infer_by_monomial_expr, gkr_iop/src/gpu/mod.rs:599-609)
  *   outs[o][x] = sum_{t in terms of o} coeff_t * prod_{j in S_t} mles[j][x]
  * terms are CSR: output o owns terms [out_term_offsets[o], out_term_offsets[o+1]); term t owns

@@ -75,6 +75,57 @@ int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
                                      int n_logup, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_evals,
                                      ceno_tower_proof* out);
 
+/* prove_rotation (gkr_iop/src/gkr/layer/cpu/mod.rs:249-389; GPU arm layer/gpu/mod.rs:305-462): for pairs
+ * (source_j, target_j) of base-field witness tables prove  0 = sum_b sel(b) sum_j alpha^j (rotated(source_j)(b) - target_j(b))
+ * with sel = eq(., rt) on the cyclic subgroup.  Transcript: get_challenge_pows(n_pairs), the degree-2 sumcheck,
+ * then the 3*n_pairs evaluations [left, right, target] are appended.
+ * out_msgs: n*2 ext; out_evals: 3*n_pairs ext; out_origin/left/right: n ext each. */
+int ceno_prover_prove_rotation(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, const int* source_idx, const int* target_idx, int n_pairs,
+                               int cyclic_subgroup_size, int cyclic_group_log2, const uint64_t* rt, int num_vars, ceno_transcript* tr,
+                               ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin, uint64_t* out_left,
+                               uint64_t* out_right);
+
+/* ---- batched main-constraint sumcheck (a12/a13) ----
+ * BatchedMainConstraintProver::prove_batched_main_constraints (ceno_zkvm/src/scheme/hal.rs:37-52, CPU body
+ * scheme/cpu/mod.rs:1052-1390): ONE sumcheck over the first GKR layer of every chip.  Per chip the caller
+ * passes its MLEs (witness ++ fixed ++ structural), the selector groups (built here as eq tables at the
+ * given out-points and substituted for their structural witness id, first occurrence wins), and the layer's
+ * monomial terms.  The scalar of a term is a polynomial in the "main sumcheck challenges"
+ *   [global_challenges[0], global_challenges[1], alpha_pows[alpha_start .. alpha_start + n_exprs)]
+ * encoded as monomials: scalar_t = sum_m mono_coeffs[m] * prod_k challenges[mono_chal_idx[k]].
+ * A job list of length 1 is the per-layer ZerocheckLayerProver::prove (gkr_iop/src/gkr/layer/cpu/mod.rs:102-238). */
+typedef struct ceno_main_job {
+    int circuit_idx;
+    int num_vars;                          /* log2_num_instances + rotation_vars */
+    int n_witin, n_fixed, n_structural;
+    ceno_hip_mle* const* mles;             /* n_witin + n_fixed + n_structural handles (a replaced structural slot may be NULL) */
+    int n_selectors;
+    const int* sel_kind;                   /* ceno_hip_selector_kind */
+    const size_t* sel_offset;
+    const size_t* sel_num_instances;
+    const int* sel_structural_id;          /* structural witness id the selector stands for */
+    const uint32_t* const* sel_sparse_indices;
+    const int* sel_n_sparse;
+    const int* sel_sparse_num_vars;
+    const uint64_t* const* sel_points;     /* num_vars ext each */
+    int n_exprs;                           /* number of alpha powers this chip consumes (layer.exprs.len()) */
+    int max_degree;                        /* first_layer.max_expr_degree + 1 */
+    int n_terms;
+    const uint32_t* term_offsets;          /* n_terms + 1 */
+    const uint32_t* term_mle_idx;          /* chip-local MLE ids */
+    const uint32_t* scalar_offsets;        /* n_terms + 1 -> monomial range */
+    const uint64_t* mono_coeffs;           /* 2 words per monomial */
+    const uint32_t* mono_chal_offsets;     /* n_monomials + 1 */
+    const uint32_t* mono_chal_idx;         /* ids into the chip's main-sumcheck challenge list */
+} ceno_main_job;
+
+/* outputs: claimed_sum (1 ext), msgs (max_num_vars * max_degree ext), global_rt (max_num_vars ext),
+ * evals (sum of per-chip MLE counts, ext; chip order, witness ++ fixed ++ structural).
+ * *out_num_vars / *out_degree receive max_num_variables / max_degree of the batched sumcheck. */
+int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_main_job* jobs, int n_jobs, const uint64_t* global_challenges4,
+                                               ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
+                                               uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree);
+
 const char* ceno_prover_last_error(void);
 
 /* ---- hypercube-sharded sumcheck over the GPUs of one node (ceno_amd/host/dist.cpp) ----

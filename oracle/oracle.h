@@ -148,6 +148,15 @@ int orc_tower_verify(const uint64_t* prod_out_evals /* n_prod*2 ext */, const ui
                      orc_transcript* tr, uint64_t* out_point, uint64_t* out_prod_claims /* n_prod ext */,
                      uint64_t* out_logup_p_claims, uint64_t* out_logup_q_claims);
 
+/* ---- rotation argument (a11; gkr_iop/src/utils.rs:19-102, gkr/booleanhypercube.rs, layer/cpu/mod.rs:249-389) ---- */
+int orc_cyclic_table(int log2, uint32_t* out);
+int orc_rotation_next_base_mle(const uint64_t* in, int num_vars, int log2, uint64_t* out);
+int orc_rotation_selector(const uint64_t* eq, int num_vars, int subgroup_size, int log2, uint64_t* out);
+int orc_rotation_points(const uint64_t* point, int n, int log2, uint64_t* left, uint64_t* right);
+int orc_prove_rotation(const orc_mle* wit, int n_wit, const int* src, const int* tgt, int n_pairs, int subgroup_size, int log2,
+                       const uint64_t* rt, int n, orc_transcript* tr, uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin,
+                       uint64_t* out_left, uint64_t* out_right);
+
 /* ---- Basefold commit path (a14) — PARITY UNPINNED, see commit.c ---- */
 uint64_t orc_two_adic_generator(int bits);
 void orc_dft_bitrev(const uint64_t* in, int log_n, int inverse, uint64_t* out);

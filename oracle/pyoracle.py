@@ -21,7 +21,7 @@ _LIB_PATH = os.path.join(_HERE, "libceno_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "commit.c", "oracle.h", "gl64.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "commit.c", "rotation.c", "oracle.h", "gl64.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -494,3 +494,47 @@ def merkle_commit(col_major: np.ndarray, log_rows: int, width: int, params: Opti
         levels.append(out[off: off + 4 * n].reshape(n, 4))
         off += 4 * n
     return levels
+
+
+# ---- rotation (a11) -------------------------------------------------------------------------
+def cyclic_table(log2: int) -> np.ndarray:
+    out = np.zeros(1 << log2, dtype=np.uint32)
+    assert lib().orc_cyclic_table(log2, _p32(out)) == 0
+    return out
+
+
+def rotation_next_base_mle(table: np.ndarray, log2: int) -> np.ndarray:
+    t = np.ascontiguousarray(table, dtype=np.uint64)
+    out = np.zeros_like(t)
+    assert lib().orc_rotation_next_base_mle(_p(t), int(t.shape[0]).bit_length() - 1, log2, _p(out)) == 0
+    return out
+
+
+def rotation_selector(eq: np.ndarray, subgroup_size: int, log2: int) -> np.ndarray:
+    e = np.ascontiguousarray(eq)
+    out = np.zeros_like(e)
+    assert lib().orc_rotation_selector(_p(e), int(e.shape[0]).bit_length() - 1, subgroup_size, log2, _p(out)) == 0
+    return out
+
+
+def rotation_points(point: np.ndarray, log2: int):
+    p = np.ascontiguousarray(point)
+    l, r = np.zeros_like(p), np.zeros_like(p)
+    assert lib().orc_rotation_points(_p(p), p.shape[0], log2, _p(l), _p(r)) == 0
+    return l, r
+
+
+def prove_rotation(wit: Sequence[np.ndarray], pairs: Sequence[Tuple[int, int]], subgroup_size: int, log2: int, rt: np.ndarray,
+                   tr: StubTranscript):
+    arr, keep = _mk_mles(wit)
+    n = rt.shape[0]
+    src = (C.c_int * len(pairs))(*[p[0] for p in pairs])
+    tgt = (C.c_int * len(pairs))(*[p[1] for p in pairs])
+    msgs = np.zeros((n, 2, 2), dtype=np.uint64)
+    evals = np.zeros((3 * len(pairs), 2), dtype=np.uint64)
+    origin, left, right = (np.zeros((n, 2), dtype=np.uint64) for _ in range(3))
+    rc = lib().orc_prove_rotation(arr, len(wit), src, tgt, len(pairs), subgroup_size, log2, _p(np.ascontiguousarray(rt)), n,
+                                  tr.ptr(), _p(msgs), _p(evals), _p(origin), _p(left), _p(right))
+    if rc != 0:
+        raise ValueError(f"orc_prove_rotation rc={rc}")
+    return msgs, evals, origin, left, right

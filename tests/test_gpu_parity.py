@@ -390,3 +390,98 @@ def test_native_dist_path_world1_matches_oracle(dev, prover):
     assert np.array_equal(m2, omsgs) and np.array_equal(f2, ofin)
     comm.close()
     dev.stream_destroy(stream)
+
+
+# ------------------------------------------------------------------------------------------
+# rotation argument (a11)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log2,sub", [(5, 23), (5, 32), (6, 24), (6, 1)])
+def test_rotation_kernels_and_proof(dev, prover, log2, sub):
+    nv = log2 + 4
+    src = po.rand_base(1 << nv, 5 + log2)
+    other = po.rand_base(1 << nv, 6 + log2)
+    d_src, d_other = dev.upload(src), dev.upload(other)
+    rot = dev.rotation_next_base_mle(d_src, log2)
+    assert np.array_equal(rot.download(), po.rotation_next_base_mle(src, log2))
+    rt = po.rand_ext(nv, 7)
+    sel = dev.rotation_selector_build(rt, sub, log2)
+    assert np.array_equal(sel.download(), po.rotation_selector(po.build_eq(rt), sub, log2))
+    tgt = po.rotation_next_base_mle(src, log2)
+    wit = [src, tgt, other]
+    d_wit = [d_src, dev.upload(tgt), d_other]
+    pairs = [(0, 1), (2, 0)]  # the second pair does not satisfy the relation: the proof is still a function of the inputs
+    got = prover.prove_rotation(dev, d_wit, pairs, sub, log2, rt, prover.Transcript.stub(3))
+    exp = po.prove_rotation(wit, pairs, sub, log2, rt, po.StubTranscript(3))
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    from ceno_amd import CenoHipError
+
+    with pytest.raises(CenoHipError):
+        dev.rotation_next_base_mle(dev.upload(po.rand_ext(64, 1)), 5)  # ext source is rejected like the reference
+
+
+# ------------------------------------------------------------------------------------------
+# batched main-constraint sumcheck (a12): three synthetic chips of different sizes in ONE sumcheck
+# ------------------------------------------------------------------------------------------
+def test_batched_main_constraints_matches_oracle(dev, prover):
+    gch = [(11, 22), (33, 44)]
+    chips = []
+    rng_seed = 500
+    for c, (nv, n_w, n_f) in enumerate([(10, 5, 1), (7, 3, 0), (5, 2, 1)]):
+        wit = [po.rand_base(1 << nv, rng_seed + 10 * c + j) for j in range(n_w)]
+        fixed = [po.rand_base(1 << nv, rng_seed + 10 * c + 7 + j) for j in range(n_f)]
+        point = po.rand_ext(nv, 900 + c)
+        n_inst = (1 << nv) - 3 - c
+        # one structural witness = the Prefix selector of the chip
+        sel = (po.SEL_PREFIX, 0, n_inst, 0, (), 0, point)
+        s_id = n_w + n_f
+        n_exprs = 2
+        # sel * (alpha_0 * w0*w1 + alpha_1 * (w1 - beta*w2 ...)): a few monomial terms with polynomial scalars
+        terms = [[s_id, 0, 1], [s_id, 1], [s_id, min(2, n_w - 1), 0, 0][: 3 + (nv > 6)]]
+        scalars = [[((1, 0), [2])], [((5, 0), [3, 0]), ((7, 1), [1, 1])], [((2, 3), [3]), ((P - 1, 0), [2, 0, 1])]]
+        chips.append(dict(nv=nv, wit=wit, fixed=fixed, sel=sel, n_exprs=n_exprs, terms=terms, scalars=scalars,
+                          max_degree=max(len(t) for t in terms)))
+    jobs = []
+    for ch in chips:
+        mles = [dev.upload(t) for t in ch["wit"] + ch["fixed"]] + [None]
+        jobs.append(dict(num_vars=ch["nv"], mles=mles, n_witin=len(ch["wit"]), n_fixed=len(ch["fixed"]), n_structural=1,
+                         selectors=[ch["sel"]], n_exprs=ch["n_exprs"], max_degree=ch["max_degree"], terms=ch["terms"],
+                         scalars=ch["scalars"]))
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(77))
+    # ---- expected, assembled from oracle pieces exactly as scheme/cpu/mod.rs:1052-1390 does ----
+    tr = po.StubTranscript(77)
+    tr.append_label(b"combine subset evals")
+    alpha = tr.sample_ext()
+    total_exprs = sum(ch["n_exprs"] for ch in chips)
+    pows = [(1, 0)]
+    for _ in range(total_exprs - 1):
+        pows.append(po.e2_mul(pows[-1], alpha))
+    tables, coeffs, terms, nvs = [], [], [], []
+    a0 = 0
+    for ch in chips:
+        start = len(tables)
+        sel_tab = po.selector_compute(ch["sel"][0], ch["sel"][6], ch["sel"][1], ch["sel"][2])
+        tables += ch["wit"] + ch["fixed"] + [sel_tab]
+        nvs += [ch["nv"]] * (len(ch["wit"]) + len(ch["fixed"]) + 1)
+        chal = gch + pows[a0: a0 + ch["n_exprs"]]
+        for t, monos in zip(ch["terms"], ch["scalars"]):
+            sc = (0, 0)
+            for coeff, ids in monos:
+                v = coeff
+                for i in ids:
+                    v = po.e2_mul(v, chal[i])
+                sc = po.e2_add(sc, v)
+            coeffs.append(sc)
+            terms.append([start + j for j in t])
+        a0 += ch["n_exprs"]
+    max_nv, max_deg = 10, max(ch["max_degree"] for ch in chips)
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, po.ext(coeffs), terms, max_nv, max_deg, tr)
+    assert np.array_equal(msgs, omsgs) and np.array_equal(rt, ochal) and np.array_equal(evals, ofin)
+    final_claim = po.sumcheck_expected_from_evals(nvs, po.ext(coeffs), terms, max_nv, ochal, ofin)
+    assert claimed == po.recover_claim_from_final(final_claim, omsgs, ochal)
+    # and the restated verifier accepts: claimed sum -> expected evaluation == front-load evaluation
+    vt = po.StubTranscript(77)
+    vt.append_label(b"combine subset evals")
+    vt.sample_ext()
+    _, expected = po.sumcheck_verify(claimed, msgs, vt)
+    assert expected == final_claim

@@ -349,3 +349,54 @@ def test_wit_infer_matches_definition():
                 v = po.e2_mul(v, (int(e[0]), int(e[1])) if mles[j].ndim == 2 else (int(e), 0))
             acc = po.e2_add(acc, v)
         assert tuple(map(int, out[x])) == acc
+
+
+# ------------------------------------------------------------------------------------------
+# rotation (a11): cyclic tables and the identity of test_rotation_next_base_mle_eval (gkr_iop/src/utils.rs:332-353)
+# ------------------------------------------------------------------------------------------
+def test_cyclic_tables_match_reference_prefix_and_are_cyclic():
+    t5, t6 = po.cyclic_table(5), po.cyclic_table(6)
+    # first entries as listed in gkr_iop/src/gkr/booleanhypercube.rs:10-31 and the wrap-around entry
+    assert list(t5[:20]) == [1, 2, 4, 8, 16, 5, 10, 20, 13, 26, 17, 7, 14, 28, 29, 31, 27, 19, 3, 6]
+    assert t5[31] == 1 and len(set(t5[:31].tolist())) == 31
+    assert t6[63] == 1 and len(set(t6[:63].tolist())) == 63
+    assert list(t6[37:48]) == [44, 27, 54, 47, 29, 58, 55, 45, 25, 50, 39]  # booleanhypercube.rs:86-96
+
+
+@pytest.mark.parametrize("log2", [5, 6])
+def test_rotation_next_base_mle_eval_identity(log2):
+    nv = log2 + 2
+    poly = np.arange(1 << nv, dtype=np.uint64)
+    rotated = po.rotation_next_base_mle(poly, log2)
+    point = po.rand_ext(nv, 9 + log2)
+    left, right = po.rotation_points(point, log2)
+    rot_eval = po.mle_evaluate(rotated, point)
+    le, re = po.mle_evaluate(poly, left), po.mle_evaluate(poly, right)
+    rk = tuple(map(int, point[log2 - 1]))
+    exp = po.e2_add(po.e2_mul(po.e2_sub((1, 0), rk), le), po.e2_mul(rk, re))
+    assert rot_eval == exp
+
+
+def test_prove_rotation_messages_verify():
+    log2, nv = 5, 8
+    # a witness where target = rotated(source) on the selected subgroup makes the claimed sum zero
+    src = po.rand_base(1 << nv, 5)
+    tgt = po.rotation_next_base_mle(src, log2)
+    rt = po.rand_ext(nv, 6)
+    msgs, evals, origin, left, right = po.prove_rotation([src, tgt], [(0, 1)], 23, log2, rt, po.StubTranscript(3))
+    # verifier side: claimed sum 0, degree 2
+    tr = po.StubTranscript(3)
+    tr.append_label(b"combine subset evals")
+    tr.sample_ext()
+    point, expected = po.sumcheck_verify((0, 0), msgs, tr)
+    assert np.array_equal(point, origin)
+    # left/right evals are evaluations of the source at the rotation points, target at the origin
+    assert tuple(map(int, evals[0])) == po.mle_evaluate(src, left)
+    assert tuple(map(int, evals[1])) == po.mle_evaluate(src, right)
+    assert tuple(map(int, evals[2])) == po.mle_evaluate(tgt, origin)
+    # expected evaluation = sel(origin) * (rotated(origin) - target(origin)) with rotated(origin) from left/right
+    eq = po.build_eq(rt)
+    sel = po.rotation_selector(eq, 23, log2)
+    rk = tuple(map(int, origin[log2 - 1]))
+    rot = po.e2_add(po.e2_mul(po.e2_sub((1, 0), rk), tuple(map(int, evals[0]))), po.e2_mul(rk, tuple(map(int, evals[1]))))
+    assert po.e2_mul(po.mle_evaluate(sel, origin), po.e2_sub(rot, tuple(map(int, evals[2])))) == expected
