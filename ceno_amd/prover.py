@@ -391,3 +391,66 @@ def prove_batched_main_constraints(dev: Device, jobs: Sequence[dict], global_cha
     _check(L.ceno_prover_prove_batched_main_constraints(dev.h, arr, len(jobs), _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
                                                         _p(evals), C.byref(nv_o), C.byref(d_o)))
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
+
+
+class PcsData:
+    """committed traces (reference: PCS::CommitmentWithWitness returned by commit_traces)"""
+
+    def __init__(self, dev: Device, matrices: Sequence[np.ndarray], log_blowup: int, stream):
+        L = plib()
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.ceno_prover_commit_traces.restype = i
+        L.ceno_prover_commit_traces.argtypes = [vp, C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
+        L.ceno_pcs_data_num_vars.restype = i
+        L.ceno_pcs_data_num_vars.argtypes = [vp, i]
+        L.ceno_pcs_data_root.restype = i
+        L.ceno_pcs_data_root.argtypes = [vp, vp, i, u64p, vp]
+        L.ceno_pcs_data_witness_mle.restype = i
+        L.ceno_pcs_data_witness_mle.argtypes = [vp, vp, i, sz, C.POINTER(vp)]
+        L.ceno_pcs_data_open_row.restype = i
+        L.ceno_pcs_data_open_row.argtypes = [vp, vp, i, sz, u64p, u64p, vp]
+        L.ceno_pcs_data_free.restype = None
+        L.ceno_pcs_data_free.argtypes = [vp, vp]
+        self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
+        mats = [np.ascontiguousarray(m, dtype=np.uint64) for m in matrices]
+        self.shapes = [m.shape for m in mats]
+        ptrs = (u64p * len(mats))(*[_p(m) for m in mats])
+        rows = (sz * len(mats))(*[m.shape[0] for m in mats])
+        widths = (sz * len(mats))(*[m.shape[1] for m in mats])
+        h = vp()
+        _check(L.ceno_prover_commit_traces(dev.h, ptrs, rows, widths, len(mats), log_blowup, stream, C.byref(h)))
+        self.h = h
+
+    def num_vars(self, matrix: int) -> int:
+        return plib().ceno_pcs_data_num_vars(self.h, matrix)
+
+    def root(self, matrix: int) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint64)
+        _check(plib().ceno_pcs_data_root(self.dev.h, self.h, matrix, _p(out), self.stream))
+        return out
+
+    def witness_mle(self, matrix: int, col: int) -> Mle:
+        h = C.c_void_p()
+        _check(plib().ceno_pcs_data_witness_mle(self.dev.h, self.h, matrix, col, C.byref(h)))
+        m = Mle(self.dev, h)
+        m._parent = self
+        return m
+
+    def open_row(self, matrix: int, index: int):
+        width = self.shapes[matrix][1]
+        depth = self.num_vars(matrix) + self.log_blowup
+        row = np.zeros(width, dtype=np.uint64)
+        path = np.zeros((max(depth, 1), 4), dtype=np.uint64)
+        _check(plib().ceno_pcs_data_open_row(self.dev.h, self.h, matrix, index, _p(row), _p(path), self.stream))
+        return row, path[:depth]
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            plib().ceno_pcs_data_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -126,6 +126,25 @@ int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_mai
                                                ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
                                                uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree);
 
+/* ---- trace commitment (a14) ----
+ * TraceCommitter::commit_traces (ceno_zkvm/src/scheme/hal.rs:137-156, CPU scheme/cpu/mod.rs:559-584, GPU
+ * scheme/gpu/mod.rs:1519-1660): per row-major trace matrix — pad the rows to next_pow2_instance_padding
+ * (>= 2, zero rows), move it to the device, transpose to column-major, RS-encode every column (blow-up
+ * 2^log_blowup), hash the codeword rows and build the Merkle tree.  The witness MLEs handed to the sumchecks
+ * are borrowed views of the column-major trace (nothing is copied or re-uploaded).
+ * PARITY UNPINNED (EXT mpcs): one tree per matrix instead of p3's mixed-height MMCS, placeholder Poseidon2
+ * constants, rate / layout assumptions — see DESIGN.md section 5. */
+typedef struct ceno_pcs_data ceno_pcs_data;
+int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
+                              int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
+int ceno_pcs_data_num_vars(const ceno_pcs_data* d, int matrix);
+int ceno_pcs_data_root(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, uint64_t* root4, ceno_hip_stream s);
+/* borrowed base-field MLE view of column `col` of matrix `matrix` (valid while `d` lives; free the handle with ceno_hip_mle_free) */
+int ceno_pcs_data_witness_mle(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, size_t col, ceno_hip_mle** out);
+/* Merkle path of codeword row `index` and the row itself (`width` base elements) */
+int ceno_pcs_data_open_row(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, size_t index, uint64_t* row_out, uint64_t* path_out, ceno_hip_stream s);
+void ceno_pcs_data_free(ceno_hip_ctx* ctx, ceno_pcs_data* d);
+
 const char* ceno_prover_last_error(void);
 
 /* ---- hypercube-sharded sumcheck over the GPUs of one node (ceno_amd/host/dist.cpp) ----

@@ -164,3 +164,38 @@ def test_poseidon2_set_constants_changes_and_restores(dev):
     api.poseidon2_permute(dev, d.data_ptr(), 1)
     dev.sync()
     assert np.array_equal(_to_np(d).reshape(-1), po.poseidon2_permute(s[0]))
+
+
+def test_commit_traces_matches_oracle_composition(dev):
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    blow = 1
+    mats = [po.rand_base(5 * 3, 1).reshape(5, 3), po.rand_base(64 * 22, 2).reshape(64, 22), po.rand_base(1 * 4, 3).reshape(1, 4)]
+    pcs = prover.PcsData(dev, mats, blow, stream)
+    params = po.poseidon2_default_params()
+    for i, m in enumerate(mats):
+        rows = 2
+        while rows < m.shape[0]:
+            rows *= 2
+        padded = np.zeros((rows, m.shape[1]), dtype=np.uint64)
+        padded[: m.shape[0]] = m
+        assert pcs.num_vars(i) == rows.bit_length() - 1
+        # witness MLE views are the (padded) columns
+        for c in (0, m.shape[1] - 1):
+            assert np.array_equal(pcs.witness_mle(i, c).download(), padded[:, c])
+        # codeword = DFT of the zero-extended column, bit-reversed order; leaves hash codeword rows
+        cw = np.stack([po.dft_bitrev(np.concatenate([padded[:, c], np.zeros(rows * ((1 << blow) - 1), dtype=np.uint64)]))
+                       for c in range(m.shape[1])])
+        log_cw = (rows << blow).bit_length() - 1
+        levels = po.merkle_commit(cw, log_cw, m.shape[1], params)
+        assert np.array_equal(pcs.root(i), levels[-1][0])
+        for idx in {0, (rows << blow) - 1, (rows << blow) // 3}:
+            row, path = pcs.open_row(i, idx)
+            assert np.array_equal(row, cw[:, idx])
+            j = idx
+            for l in range(log_cw):
+                assert np.array_equal(path[l], levels[l][j ^ 1])
+                j >>= 1
+    pcs.free()
+    dev.stream_destroy(stream)
