@@ -88,6 +88,7 @@ def lib():
         "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),
         "ceno_hip_sumcheck_rounds_done": (i, [vp]),
         "ceno_hip_sumcheck_set_pipelined": (i, [vp, vp, i]),
+        "ceno_hip_sumcheck_table": (i, [vp, vp, i, C.POINTER(u64p), C.POINTER(i), C.POINTER(i)]),
         "ceno_hip_sumcheck_free": (i, [vp, vp]),
         "ceno_hip_tower_build_prod": (i, [vp, vpp, i, sz, u64p, vp, vpp]),
         "ceno_hip_tower_build_logup": (i, [vp, vpp, vpp, i, sz, u64p, vp, vpp]),

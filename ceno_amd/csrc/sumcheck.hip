@@ -1334,6 +1334,20 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
 
 int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc) { return sc ? sc->round : -1; }
 
+int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t** device_ptr, int* is_ext, int* num_vars) {
+    CHECK_ARG(ctx, sc && device_ptr && is_ext && num_vars, "NULL argument");
+    CHECK_ARG(ctx, mle_index >= 0 && mle_index < (int)sc->mles.size(), "mle index out of range");
+    if (sc->pipelined) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "tables of a pipelined sumcheck are not observable between rounds");
+    const ScMle& M = sc->mles[mle_index];
+    // after r rounds the live table is the one round r-1 was computed on: nv - (r - 1) variables (r >= 1), nv before round 0
+    const int folds = sc->round > 0 ? sc->round - 1 : 0;
+    if (M.nv < folds) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "table %d is already a scalar", mle_index);
+    *device_ptr = const_cast<uint64_t*>(M.cur);
+    *is_ext = M.cur_ext;
+    *num_vars = M.nv - folds;
+    return 0;
+}
+
 int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on) {
     CHECK_ARG(ctx, sc, "NULL argument");
     if (sc->round != 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: pipelining must be chosen before round 0");

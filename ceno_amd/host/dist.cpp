@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -185,7 +186,14 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
     }
     uint64_t ch[2] = {0, 0};
     std::vector<uint64_t> msg(2 * (size_t)d);
-    for (int r = 0; r < n_local; r++) {
+    // Once a shard is down to 2^TAIL_VARS elements per table the per-round collective costs more than the
+    // round itself: gather the small shards onto every rank ONCE and let each rank finish all remaining
+    // rounds locally (replicated, pipelined, no further collectives).
+    const int TAIL_VARS = 12;
+    const bool force_gather = getenv("CENO_DIST_FORCE_GATHER") != nullptr;  // exercises the gather path at world size 1 (tests)
+    int r = 0;
+    for (; r < n_local; r++) {
+        if ((world > 1 || force_gather) && r >= 1 && n_local - (r - 1) <= TAIL_VARS) break;  // live tables have n_local-(r-1) variables
         rc = ceno_hip_sumcheck_round_dev(ctx, sc, r == 0 ? nullptr : ch, c->d_send);
         if (!rc) rc = gather_ext(c, d, st);
         if (rc) {
@@ -205,6 +213,58 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
         ch[1] = rr.c1;
         out_challenges[2 * r] = rr.c0;
         out_challenges[2 * r + 1] = rr.c1;
+    }
+    if (r < n_local) {
+        // ---- early gather: tables T_{r-1} (m variables per shard), messages 0..r-1 sent, challenge r-1 in `ch` ----
+        const int m = n_local - (r - 1), nv2 = m + log_w;
+        std::vector<ceno_hip_mle*> full(k, nullptr);
+        auto drop = [&]() {
+            for (auto* x : full) if (x) ceno_hip_mle_free(ctx, x);
+        };
+        for (int j = 0; j < k && !rc; j++) {
+            uint64_t* src = nullptr;
+            int is_ext = 0, nvj = 0;
+            rc = ceno_hip_sumcheck_table(ctx, sc, j, &src, &is_ext, &nvj);
+            if (!rc && nvj != m) { g_dist_err = "sharded tables of unequal size"; rc = CENO_HIP_ERR_INVALID; }
+            if (!rc) rc = ceno_hip_mle_alloc(ctx, nv2, is_ext, &full[j]);
+            if (!rc) {
+                ncclResult_t nr = g_rccl.AllGather(src, ceno_hip_mle_device_ptr(full[j]), ((size_t)1 << m) * (is_ext ? 2 : 1), ncclUint64, c->comm, st);
+                if (nr != ncclSuccess) rc = nccl_fail(nr, "ncclAllGather(tables)");
+            }
+        }
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = CENO_HIP_ERR_HIP;
+        ceno_hip_sumcheck_free(ctx, sc);
+        if (rc) {
+            if (g_dist_err.empty()) g_dist_err = ceno_hip_last_error(ctx);
+            drop();
+            return rc;
+        }
+        ceno_hip_sumcheck_plan p2 = *plan_local;
+        p2.max_num_vars = nv2;
+        ceno_hip_sumcheck* s2 = nullptr;
+        rc = ceno_hip_sumcheck_begin(ctx, full.data(), &p2, s, &s2);
+        if (!rc) ceno_hip_sumcheck_set_pipelined(ctx, s2, 1);
+        // its round 0 recomputes message r-1 from the gathered tables: a free consistency check of the gather
+        if (!rc) rc = ceno_hip_sumcheck_round(ctx, s2, nullptr, msg.data());
+        if (!rc && memcmp(msg.data(), out_msgs + (size_t)2 * d * (r - 1), (size_t)16 * d) != 0) {
+            g_dist_err = "gathered tables do not reproduce the last sharded message";
+            rc = CENO_HIP_ERR_STATE;
+        }
+        for (int g = r; g < n_total && !rc; g++) {
+            rc = ceno_hip_sumcheck_round(ctx, s2, ch, msg.data());
+            if (rc) break;
+            memcpy(out_msgs + (size_t)2 * d * g, msg.data(), (size_t)16 * d);
+            E2 rr = absorb_round(tr, msg.data(), d);
+            ch[0] = rr.c0;
+            ch[1] = rr.c1;
+            out_challenges[2 * g] = rr.c0;
+            out_challenges[2 * g + 1] = rr.c1;
+        }
+        if (!rc) rc = ceno_hip_sumcheck_finish(ctx, s2, ch, out_final_evals);
+        if (s2) ceno_hip_sumcheck_free(ctx, s2);
+        drop();
+        if (rc && g_dist_err.empty()) g_dist_err = ceno_hip_last_error(ctx);
+        return rc;
     }
     std::vector<uint64_t> fin_local(2 * (size_t)k);
     rc = ceno_hip_sumcheck_finish(ctx, sc, n_local > 0 ? ch : nullptr, fin_local.data());

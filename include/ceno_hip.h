@@ -168,6 +168,10 @@ int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const 
  * (get_mle_flatten_final_evaluations, gkr_iop/src/gkr/layer/cpu/mod.rs:229-230) */
 int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals);
 int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc);
+/* Device pointer, element kind and current number of variables of table `mle_index` as the next round will
+ * read it (i.e. not yet folded with the challenge that call is going to receive).  Valid until the next
+ * round/finish call; used by the sharded driver to gather small shards onto every rank. */
+int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t** device_ptr, int* is_ext, int* num_vars);
 /* Opt in (before round 0) to pipelined rounds: all round kernels are enqueued at round 0 and pick their
  * challenges up from a pinned-memory mailbox, which removes the launch latency from every round.  The
  * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after ~4 s without

@@ -388,6 +388,20 @@ def test_native_dist_path_world1_matches_oracle(dev, prover):
     eng = cdist.HipShardEngine(dev, mles)
     m2, c2, f2 = cdist.sharded_sumcheck_prove(eng, nv, k, prover.Transcript.stub(0xF5), dist=None, world=1, rank=0)
     assert np.array_equal(m2, omsgs) and np.array_equal(f2, ofin)
+    # the early-gather branch (taken at world > 1 once shards are small) run at world size 1
+    import os
+
+    for nv2, seed in ((15, 3), (9, 4)):
+        t2 = [po.rand_ext(1 << nv2, 40 + j) for j in range(k)]
+        m2_ = [dev.upload(t) for t in t2]
+        os.environ["CENO_DIST_FORCE_GATHER"] = "1"
+        try:
+            got = prover.dist_sumcheck_prove(dev, comm, m2_, po.ext([1]), [list(range(k))], nv2, k, prover.Transcript.stub(seed), stream)
+        finally:
+            del os.environ["CENO_DIST_FORCE_GATHER"]
+        exp = po.sumcheck_prove(t2, po.ext([1]), [list(range(k))], nv2, k, po.StubTranscript(seed))
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
     comm.close()
     dev.stream_destroy(stream)
 
@@ -485,3 +499,38 @@ def test_batched_main_constraints_matches_oracle(dev, prover):
     vt.sample_ext()
     _, expected = po.sumcheck_verify(claimed, msgs, vt)
     assert expected == final_claim
+
+
+# ------------------------------------------------------------------------------------------
+# limits and ragged plans
+# ------------------------------------------------------------------------------------------
+def test_sumcheck_limits_degree8_many_mles_and_unused_tables(dev, prover):
+    from ceno_amd import CenoHipError, Sumcheck
+
+    nv = 7
+    tables = [po.rand_ext(1 << nv, 300 + j) if j % 3 else po.rand_base(1 << nv, 300 + j) for j in range(40)]
+    # 60 terms of ragged degree 1..8 over 40 tables (two-kernel generic path: LDS staging does not fit),
+    # table 39 is referenced by no term (it must still be folded and evaluated)
+    terms = [[(7 * t + 3 * k) % 39 for k in range(1 + t % 8)] for t in range(60)]
+    coeffs = po.rand_ext(len(terms), 11)
+    _run_both(dev, prover, tables, coeffs, terms, nv, 8)
+    # a plan that fits the fused LDS-staged kernel (<= 7 tables), degree 8
+    _run_both(dev, prover, tables[:6], coeffs[:5], [[0, 1, 2, 3, 4, 5, 0, 1], [2], [3, 3], [4, 5, 1], [0, 0, 0, 0, 0]], nv, 8)
+    with pytest.raises(CenoHipError):
+        Sumcheck(dev, [dev.upload(tables[1])], po.ext([1]), [[0] * 9], nv, 9)  # degree 9 is outside the supported range
+
+
+def test_sumcheck_dense_k4_base_and_single_variable(dev, prover):
+    tables = [po.rand_base(1 << 9, 400 + j) for j in range(4)]
+    _run_both(dev, prover, tables, po.rand_ext(1, 5), [[0, 1, 2, 3]], 9, 4)
+    one = [po.rand_ext(2, 410 + j) for j in range(2)]
+    _run_both(dev, prover, one, po.ext([3]), [[0, 1]], 1, 2)
+
+
+def test_large_eq_and_evaluate_consistency(dev):
+    # 2^24-entry eq table (256 MB): eq(r, r') evaluated through the table equals the closed form
+    nv = 24
+    r, rp = po.rand_ext(nv, 1), po.rand_ext(nv, 2)
+    eq = dev.eq_build(r)
+    assert eq.evaluate(rp) == po.eq_eval(r, rp)
+    eq.free()
