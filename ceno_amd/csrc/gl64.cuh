@@ -183,6 +183,39 @@ GL_HD E2 e2_mul_ref(E2 a, E2 b) {
     uint64_t w = mul_ref(m1, W);
     return E2{add(m0, w), sub(sub(m2, m0), m1)};
 }
+// ---- unreduced accumulation of ext products (sumcheck inner loops) ----
+// Sum_i a_i * b_i over many i without reducing each product: the four 128-bit partial products of an
+// ext multiply are added limb-wise into 160-bit accumulators (room for 2^32 products) and reduced once.
+//   c0 = S(a0 b0) + W * S(a1 b1),   c1 = S(a0 b1) + S(a1 b0)
+struct Acc5 {
+    uint32_t w0, w1, w2, w3, w4;
+};
+GL_HD void acc5_add(Acc5& a, const L4& p) {
+    uint32_t cy;
+    a.w0 = addc32(a.w0, p.w0, 0u, cy);
+    a.w1 = addc32(a.w1, p.w1, cy, cy);
+    a.w2 = addc32(a.w2, p.w2, cy, cy);
+    a.w3 = addc32(a.w3, p.w3, cy, cy);
+    a.w4 = addc32(a.w4, 0u, cy, cy);
+}
+// w4 * 2^128 = -(w4 << 32) (mod p), and (w4 << 32) <= p - 1 is canonical
+GL_HD uint64_t acc5_reduce(const Acc5& a) {
+    return sub(reduce_limbs(a.w0, a.w1, a.w2, a.w3, 0u), (uint64_t)a.w4 << 32);
+}
+struct E2Acc {
+    Acc5 s00, s11, s01;
+};
+GL_HD E2Acc e2acc_zero() { return E2Acc{Acc5{0, 0, 0, 0, 0}, Acc5{0, 0, 0, 0, 0}, Acc5{0, 0, 0, 0, 0}}; }
+GL_HD void e2acc_mac(E2Acc& acc, E2 a, E2 b) {
+    acc5_add(acc.s00, mul_wide(a.c0, b.c0));
+    acc5_add(acc.s11, mul_wide(a.c1, b.c1));
+    acc5_add(acc.s01, mul_wide(a.c0, b.c1));
+    acc5_add(acc.s01, mul_wide(a.c1, b.c0));
+}
+GL_HD E2 e2acc_reduce(const E2Acc& acc) {
+    return E2{add(acc5_reduce(acc.s00), mul_small(acc5_reduce(acc.s11), (uint32_t)W)), acc5_reduce(acc.s01)};
+}
+
 GL_HD E2 e2_mul_base(E2 a, uint64_t b) { return E2{mul(a.c0, b), mul(a.c1, b)}; }
 GL_HD E2 e2_sqr(E2 a) {
     uint64_t m0 = mul(a.c0, a.c0), m1 = mul(a.c1, a.c1), m2 = mul(a.c0, a.c1);

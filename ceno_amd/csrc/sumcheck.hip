@@ -225,8 +225,12 @@ template <int K, int MODE>
 __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * K];
     E2 acc[K];
+    E2Acc wacc[K];
 #pragma unroll
-    for (int t = 0; t < K; t++) acc[t] = e2_zero();
+    for (int t = 0; t < K; t++) {
+        acc[t] = e2_zero();
+        wacc[t] = e2acc_zero();
+    }
     const size_t stride = (size_t)gridDim.x * NT;
     if (ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
     __shared__ unsigned long long s_chal[3];
@@ -277,16 +281,23 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
                     st_e2(tp.out[m] + 4 * p, lo);
                     st_e2(tp.out[m] + 4 * p + 2, hi);
                 }
-                E2 delta = hi - lo, x = hi;
+                // evaluation points 1..K: x_t = hi + (t-1)(hi - lo), stepped by subtracting (lo - hi)
+                // (a modular subtract is two instructions shorter than a modular add)
+                E2 nd = lo - hi, x = hi;
 #pragma unroll
                 for (int t = 0; t < K; t++) {
-                    pr[t] = (m == 0) ? x : pr[t] * x;
-                    x = x + delta;
+                    if (m == 0) pr[t] = x;
+                    else if (m < K - 1) pr[t] = pr[t] * x;
+                    else e2acc_mac(wacc[t], pr[t], x);  // last factor: accumulate the product unreduced
+                    if (t + 1 < K) x = x - nd;
                 }
             }
-#pragma unroll
-            for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
+            if (K == 1) acc[0] = acc[0] + pr[0];
         }
+    }
+    if (MODE != 1 && K > 1) {
+#pragma unroll
+        for (int t = 0; t < K; t++) acc[t] = e2acc_reduce(wacc[t]);
     }
     epilogue<K, NT>(acc, ep, smem, &s_flag);
 }
