@@ -221,9 +221,13 @@ __device__ __forceinline__ void st_e2(uint64_t* p, E2 v) { *reinterpret_cast<E2*
 
 // MODE 0: accumulate only, ext input      MODE 1: accumulate only, base input
 // MODE 2: fold + accumulate, ext input    MODE 3: fold + accumulate, base input (output ext)
-template <int K, int MODE>
+template <int K, int MODE, bool WIDE_>
 __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * K];
+    // Unreduced accumulation costs 9 more registers per evaluation point (one resident wave fewer) but
+    // ~15-25% fewer VALU instructions; measured on MI355X it wins in the read-only round (ALU-bound) and,
+    // by a smaller margin, in the folding rounds (CENO_HIP_DENSE_WIDE selects, profiles/r01 notes).
+    constexpr bool WIDE = WIDE_ && (MODE == 0 || MODE == 2) && K > 1;
     E2 acc[K];
     E2Acc wacc[K];
 #pragma unroll
@@ -287,15 +291,18 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
 #pragma unroll
                 for (int t = 0; t < K; t++) {
                     if (m == 0) pr[t] = x;
-                    else if (m < K - 1) pr[t] = pr[t] * x;
+                    else if (m < K - 1 || !WIDE) pr[t] = pr[t] * x;
                     else e2acc_mac(wacc[t], pr[t], x);  // last factor: accumulate the product unreduced
                     if (t + 1 < K) x = x - nd;
                 }
             }
-            if (K == 1) acc[0] = acc[0] + pr[0];
+            if (!WIDE) {
+#pragma unroll
+                for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
+            }
         }
     }
-    if (MODE != 1 && K > 1) {
+    if (WIDE) {
 #pragma unroll
         for (int t = 0; t < K; t++) acc[t] = e2acc_reduce(wacc[t]);
     }
@@ -649,13 +656,28 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     delete sc;
 }
 
+static int dense_wide_mode() {  // tuning switch: 0 = never, 1 = read-only round only, 2 = every ext round
+    static int m = [] {
+        const char* e = getenv("CENO_HIP_DENSE_WIDE");
+        return e ? atoi(e) : 2;
+    }();
+    return m;
+}
+
 template <int K>
 static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    const int wm = dense_wide_mode();
     switch (mode) {
-    case 0: hipLaunchKernelGGL((k_dense<K, 0>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
-    case 1: hipLaunchKernelGGL((k_dense<K, 1>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
-    case 2: hipLaunchKernelGGL((k_dense<K, 2>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
-    default: hipLaunchKernelGGL((k_dense<K, 3>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
+    case 0:
+        if (wm >= 1) hipLaunchKernelGGL((k_dense<K, 0, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        else hipLaunchKernelGGL((k_dense<K, 0, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        break;
+    case 1: hipLaunchKernelGGL((k_dense<K, 1, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
+    case 2:
+        if (wm >= 2) hipLaunchKernelGGL((k_dense<K, 2, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        else hipLaunchKernelGGL((k_dense<K, 2, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        break;
+    default: hipLaunchKernelGGL((k_dense<K, 3, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
     }
 }
 
