@@ -76,13 +76,15 @@ GL_HD L4 mul_wide(uint64_t a, uint64_t b) {
     return L4{(uint32_t)p00, (uint32_t)t2, (uint32_t)hi, (uint32_t)(hi >> 32)};
 }
 
-// Reduce  (w1:w0) + w2*2^64 + w3*2^96 + c*2^128  (c in {0,1}) to canonical form with
+// Reduce  (w1:w0) + w2*2^64 + w3*2^96 + c*2^128  (c < 16) to canonical form with
 // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p):   x = (w1:w0) + w2*(2^32-1) - (c:w3).
-GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
+// Same value modulo p as reduce_limbs but only guaranteed to lie in [0, 2^64): enough for anything that
+// is next fed to mul_wide (whose inputs are plain 64-bit integers) and four instructions shorter.
+GL_HD uint64_t reduce_limbs_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
     uint32_t bw, b2, cy, c2;
     uint32_t r0 = subc32(w0, w3, 0u, bw);
     uint32_t r1 = subc32(w1, c, bw, bw);
-    const uint32_t m = 0u - bw;      // wrapped by 2^64 = EPS (mod p): subtract EPS; r >= 2^64 - 2^33 so no second wrap
+    const uint32_t m = 0u - bw;      // wrapped by 2^64 = EPS (mod p): subtract EPS; r >= 2^64 - 2^36 so no second wrap (c < 16)
     r0 = subc32(r0, m, 0u, b2);
     r1 = subc32(r1, 0u, b2, b2);
     // w2 * (2^32 - 1) without a multiply: low word = -w2, high word = w2 - (w2 != 0)
@@ -93,10 +95,16 @@ GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, 
     const uint32_t m2 = 0u - cy;     // wrapped again: add EPS; cannot wrap a third time (t1 <= 2^64 - 2^33 + 1)
     r0 = addc32(r0, m2, 0u, c2);
     r1 = addc32(r1, 0u, c2, c2);
-    // canonical: r + EPS overflows <=> r >= p
-    const uint32_t u0 = addc32(r0, 0xFFFFFFFFu, 0u, cy);
-    const uint32_t u1 = addc32(r1, 0u, cy, cy);
-    return cy ? join(u0, u1) : join(r0, r1);
+    return join(r0, r1);
+}
+GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
+    uint32_t cy;
+    const uint32_t u0 = addc32((uint32_t)r, 0xFFFFFFFFu, 0u, cy);
+    const uint32_t u1 = addc32((uint32_t)(r >> 32), 0u, cy, cy);
+    return cy ? join(u0, u1) : r;
+}
+GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
+    return canon(reduce_limbs_nc(w0, w1, w2, w3, c));
 }
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
     return reduce_limbs((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0u);
@@ -169,12 +177,47 @@ GL_HD E2 operator*(E2 a, E2 b) {
     const uint64_t a1w = mul_small(a.c1, (uint32_t)W);
     return E2{mul_add2(a.c0, b.c0, a1w, b.c1), mul_add2(a.c0, b.c1, a.c1, b.c0)};
 }
+// Products whose result is only used as a multiplicand again: components in [0, 2^64), not canonical.
+GL_HD uint64_t mul_add2_nc(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    const L4 p = mul_wide(a, b), q = mul_wide(c, d);
+    uint32_t cy;
+    const uint32_t s0 = addc32(p.w0, q.w0, 0u, cy);
+    const uint32_t s1 = addc32(p.w1, q.w1, cy, cy);
+    const uint32_t s2 = addc32(p.w2, q.w2, cy, cy);
+    const uint32_t s3 = addc32(p.w3, q.w3, cy, cy);
+    return reduce_limbs_nc(s0, s1, s2, s3, cy);
+}
+GL_HD E2 e2_mul_nc(E2 a, E2 b) {
+    const uint64_t p0 = (uint64_t)(uint32_t)a.c1 * (uint32_t)W;
+    const uint64_t p1 = (uint64_t)(uint32_t)(a.c1 >> 32) * (uint32_t)W + (p0 >> 32);
+    const uint64_t a1w = reduce_limbs_nc((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32), 0u, 0u);
+    return E2{mul_add2_nc(a.c0, b.c0, a1w, b.c1), mul_add2_nc(a.c0, b.c1, a.c1, b.c0)};
+}
+// a*b + c*d + e with a single reduction (e < 2^64)
+GL_HD uint64_t mul_add2_plus(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) {
+    const L4 p = mul_wide(a, b), q = mul_wide(c, d);
+    uint32_t cy, c2, top;
+    uint32_t s0 = addc32(p.w0, q.w0, 0u, cy);
+    uint32_t s1 = addc32(p.w1, q.w1, cy, cy);
+    uint32_t s2 = addc32(p.w2, q.w2, cy, cy);
+    uint32_t s3 = addc32(p.w3, q.w3, cy, cy);
+    s0 = addc32(s0, (uint32_t)e, 0u, c2);
+    s1 = addc32(s1, (uint32_t)(e >> 32), c2, c2);
+    s2 = addc32(s2, 0u, c2, c2);
+    s3 = addc32(s3, 0u, c2, c2);
+    top = cy + c2;
+    return reduce_limbs(s0, s1, s2, s3, top);
+}
 // multiply by a fixed element whose W*c1 is precomputed (sumcheck challenge r)
 struct E2Pre {
     uint64_t c0, c1, c1w;
 };
 GL_HD E2Pre e2_pre(E2 r) { return E2Pre{r.c0, r.c1, mul_small(r.c1, (uint32_t)W)}; }
 GL_HD E2 e2_mul_pre(E2Pre r, E2 b) { return E2{mul_add2(r.c0, b.c0, r.c1w, b.c1), mul_add2(r.c0, b.c1, r.c1, b.c0)}; }
+// a + r * b for the fixed element r (the MLE fold lo + r (hi - lo)), canonical result
+GL_HD E2 e2_fma_pre(E2Pre r, E2 b, E2 a) {
+    return E2{mul_add2_plus(r.c0, b.c0, r.c1w, b.c1, a.c0), mul_add2_plus(r.c0, b.c1, r.c1, b.c0, a.c1)};
+}
 // Karatsuba form with three full multiplications, kept as an independent cross-check
 GL_HD E2 e2_mul_ref(E2 a, E2 b) {
     uint64_t m0 = mul_ref(a.c0, b.c0);

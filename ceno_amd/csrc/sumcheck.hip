@@ -224,9 +224,10 @@ __device__ __forceinline__ void st_e2(uint64_t* p, E2 v) { *reinterpret_cast<E2*
 template <int K, int MODE, bool WIDE_>
 __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * K];
-    // Unreduced accumulation costs 9 more registers per evaluation point (one resident wave fewer) but
-    // ~15-25% fewer VALU instructions; measured on MI355X it wins in the read-only round (ALU-bound) and,
-    // by a smaller margin, in the folding rounds (CENO_HIP_DENSE_WIDE selects, profiles/r01 notes).
+    // Unreduced accumulation costs 9 more registers per evaluation point but ~15% fewer VALU instructions.
+    // Measured on MI355X: a clear win in the read-only round (ALU-bound, 750 -> 600 us at nv=26); in the
+    // folding rounds (HBM-bound) it is within run-to-run noise of the reduced form, which keeps 81 VGPRs and
+    // two more resident waves, so the default (CENO_HIP_DENSE_WIDE=1) uses it in the read-only round only.
     constexpr bool WIDE = WIDE_ && (MODE == 0 || MODE == 2) && K > 1;
     E2 acc[K];
     E2Acc wacc[K];
@@ -291,7 +292,8 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
 #pragma unroll
                 for (int t = 0; t < K; t++) {
                     if (m == 0) pr[t] = x;
-                    else if (m < K - 1 || !WIDE) pr[t] = pr[t] * x;
+                    else if (m < K - 1) pr[t] = e2_mul_nc(pr[t], x);  // only multiplied again: skip canonicalisation
+                    else if (!WIDE) pr[t] = pr[t] * x;
                     else e2acc_mac(wacc[t], pr[t], x);  // last factor: accumulate the product unreduced
                     if (t + 1 < K) x = x - nd;
                 }
@@ -659,7 +661,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
 static int dense_wide_mode() {  // tuning switch: 0 = never, 1 = read-only round only, 2 = every ext round
     static int m = [] {
         const char* e = getenv("CENO_HIP_DENSE_WIDE");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;
     }();
     return m;
 }

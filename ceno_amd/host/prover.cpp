@@ -321,6 +321,27 @@ void ceno_prover_test_e2_mul_pre(const uint64_t* a, const uint64_t* b, uint64_t*
     o[0] = r.c0;
     o[1] = r.c1;
 }
+// non-canonical product (any 64-bit inputs) brought to canonical form for comparison
+void ceno_prover_test_e2_mul_nc(const uint64_t* a, const uint64_t* b, uint64_t* o) {
+    E2 r = gl::e2_mul_nc(E2{a[0], a[1]}, E2{b[0], b[1]});
+    o[0] = gl::canon(r.c0);
+    o[1] = gl::canon(r.c1);
+}
+// acc + r * b, the fold form
+void ceno_prover_test_e2_fma_pre(const uint64_t* r, const uint64_t* b, const uint64_t* a, uint64_t* o) {
+    E2 v = gl::e2_fma_pre(gl::e2_pre(E2{r[0], r[1]}), E2{b[0], b[1]}, E2{a[0], a[1]});
+    o[0] = v.c0;
+    o[1] = v.c1;
+}
+// sum_i a_i * b_i through the unreduced 160-bit accumulators; `reps` repeats the list to push the top limb
+void ceno_prover_test_e2_acc(const uint64_t* a, const uint64_t* b, int n, int reps, uint64_t* o) {
+    gl::E2Acc acc = gl::e2acc_zero();
+    for (int k = 0; k < reps; k++)
+        for (int i = 0; i < n; i++) gl::e2acc_mac(acc, E2{a[2 * i], a[2 * i + 1]}, E2{b[2 * i], b[2 * i + 1]});
+    E2 v = gl::e2acc_reduce(acc);
+    o[0] = v.c0;
+    o[1] = v.c1;
+}
 void ceno_prover_test_e2_inv(const uint64_t* a, uint64_t* o) {
     E2 r = gl::e2_inv(E2{a[0], a[1]});
     o[0] = r.c0;

@@ -88,6 +88,12 @@ def plib():
     L.ceno_prover_test_e2_mul_ref.argtypes = [u64p, u64p, u64p]
     L.ceno_prover_test_e2_mul_pre.restype = None
     L.ceno_prover_test_e2_mul_pre.argtypes = [u64p, u64p, u64p]
+    L.ceno_prover_test_e2_mul_nc.restype = None
+    L.ceno_prover_test_e2_mul_nc.argtypes = [u64p, u64p, u64p]
+    L.ceno_prover_test_e2_fma_pre.restype = None
+    L.ceno_prover_test_e2_fma_pre.argtypes = [u64p, u64p, u64p, u64p]
+    L.ceno_prover_test_e2_acc.restype = None
+    L.ceno_prover_test_e2_acc.argtypes = [u64p, u64p, C.c_int, C.c_int, u64p]
     L.ceno_prover_test_e2_inv.restype = None
     L.ceno_prover_test_e2_inv.argtypes = [u64p, u64p]
     _plib = L

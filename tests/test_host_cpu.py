@@ -73,9 +73,36 @@ def test_device_field_source_on_host_matches_bigint(built):
         assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
         L.ceno_prover_test_e2_mul_pre(po._p(po.ext([a]).reshape(2)), po._p(po.ext([b]).reshape(2)), po._p(o))
         assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
+        # non-canonical operands (any 64-bit pattern) are legal inputs of the unreduced forms
+        an = (a[0] + (P if a[0] < (1 << 64) - P and rng.random() < 0.5 else 0), a[1])
+        L.ceno_prover_test_e2_mul_nc(po._p(np.array(an, dtype=np.uint64)), po._p(po.ext([b]).reshape(2)), po._p(o))
+        assert (int(o[0]), int(o[1])) == po.e2_mul(a, b)
+        c = (rng.choice(vals), rng.choice(vals))
+        L.ceno_prover_test_e2_fma_pre(po._p(po.ext([a]).reshape(2)), po._p(po.ext([b]).reshape(2)), po._p(po.ext([c]).reshape(2)), po._p(o))
+        assert (int(o[0]), int(o[1])) == po.e2_add(po.e2_mul(a, b), c)
         if a != (0, 0):
             L.ceno_prover_test_e2_inv(po._p(po.ext([a]).reshape(2)), po._p(o))
             assert po.e2_mul((int(o[0]), int(o[1])), a) == (1, 0)
+
+
+def test_unreduced_ext_accumulator_matches_bigint(built):
+    """gl::E2Acc (ceno_amd/csrc/gl64.cuh): sums of ext products kept in 160-bit limbs, reduced once"""
+    _, prover = built
+    L = prover.plib()
+    rng = random.Random(5)
+    o = np.zeros(2, dtype=np.uint64)
+    worst = [(P - 1, P - 1)] * 16  # maximal products: the top limb must absorb the carries
+    for n, reps, gen in ((16, 4096, lambda: worst), (37, 1, None), (1, 1, None), (64, 300, None)):
+        a = gen() if gen else [(rng.randrange(1 << 64), rng.randrange(1 << 64)) for _ in range(n)]  # non-canonical allowed
+        b = gen() if gen else [(rng.randrange(P), rng.randrange(P)) for _ in range(n)]
+        A = np.array(a, dtype=np.uint64).reshape(-1)
+        B = np.array(b, dtype=np.uint64).reshape(-1)
+        L.ceno_prover_test_e2_acc(po._p(A), po._p(B), n, reps, po._p(o))
+        want = (0, 0)
+        for x, y in zip(a, b):
+            want = po.e2_add(want, po.e2_mul((x[0] % P, x[1] % P), y))
+        want = po.e2_mul(want, (reps % P, 0))
+        assert (int(o[0]), int(o[1])) == want
 
 
 def test_stub_transcript_equals_oracle_stub(built):
