@@ -108,6 +108,11 @@ def lib():
         "ceno_hip_merkle_root": (i, [vp, vp, u64p, vp]),
         "ceno_hip_merkle_open": (i, [vp, vp, sz, u64p, vp]),
         "ceno_hip_merkle_free": (i, [vp, vp]),
+        "ceno_hip_batch_columns": (i, [vp, vp, sz, i, u64p, vp, i, vp]),
+        "ceno_hip_basefold_fold_commit": (i, [vp, vp, i, u64p, vp, vp, vp, C.POINTER(vp)]),
+        "ceno_hip_gather": (i, [vp, vp, sz, i, i, vp, sz, i, i, vp, vp]),
+        "ceno_hip_merkle_open_batch": (i, [vp, vp, vp, sz, i, vp, vp]),
+        "ceno_hip_pow_grind": (i, [vp, u64p, i, u64p, vp]),
         "ceno_hip_prof_reset": (i, [vp]),
         "ceno_hip_prof_enable": (i, [vp, i]),
         "ceno_hip_prof_get": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

@@ -1,0 +1,270 @@
+// Basefold batch-open kernels for gfx950.
+//
+// Reference: `OpeningProver::open` -> `PCS::batch_open` (ceno_zkvm/src/scheme/hal.rs:284-294, cpu/mod.rs:1418-1457;
+// the implementation is the EXT crate mpcs).  Protocol shape restated in-tree by the recursion verifier:
+// ceno_recursion_v2/src/pcs/mod.rs:1111-1316 (transcript, degree-2 rounds), :7494-7720 (query phase),
+// :7765-7781 (fold: lo=(a+b)/2, hi=(a-b) g^-bitrev(i)/2, lo + r(hi-lo)).  PARITY UNPINNED.
+//
+//   k_batch_cols    acc[i] (+)= sum_c coeff_c * col_c[i]      batch codewords / trace columns with the ext
+//                   batch coefficients: reads every column once (8 B/row/col), 160-bit unreduced accumulators
+//   k_fold_commit   one pass over the running codeword per commit round: hash every pair (the Merkle leaf of
+//                   this round), fold it with the round challenge, add the codeword that joins at the next height
+//   k_gather        query answers: rows / siblings / authentication paths gathered on device, one D2H copy
+//   k_pow_grind     proof-of-work search, one Poseidon2 permutation per candidate
+#include "merkle.hpp"
+
+using namespace gl;
+
+static constexpr int NT = 256;
+static constexpr unsigned MAXB = 2048;
+static constexpr uint64_t TWO_ADIC_GEN_2_32 = 1753635133440165772ULL;
+static constexpr uint64_t INV2 = 0x7FFFFFFF80000001ULL;  // (p + 1) / 2
+
+// ---- fold coefficients: T[j] = g_H^(-bitrev_{H-1}(j)) / 2.  The table of a smaller height is a prefix. ----
+static std::mutex g_ft_mu;
+static std::map<std::pair<ceno_hip_ctx*, int>, uint64_t*> g_fold_tw;
+
+__global__ void __launch_bounds__(NT) k_fold_twiddles(uint64_t* t, size_t n, int bits, uint64_t g_inv) {
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < n; j += stride) {
+        const unsigned e = bits ? (__brev((unsigned)j) >> (32 - bits)) : 0u;
+        t[j] = mul(gl::pow(g_inv, e), INV2);
+    }
+}
+
+static int get_fold_twiddles(ceno_hip_ctx* ctx, int log_h, hipStream_t st, const uint64_t** out) {
+    std::lock_guard<std::mutex> g(g_ft_mu);
+    for (auto& kv : g_fold_tw)
+        if (kv.first.first == ctx && kv.first.second >= log_h) {  // any taller table serves as a prefix
+            *out = kv.second;
+            return 0;
+        }
+    const uint64_t gh = gl::pow(TWO_ADIC_GEN_2_32, (uint64_t)1 << (32 - log_h));
+    const size_t n = (size_t)1 << (log_h - 1);
+    void* p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, n * 8));
+    hipLaunchKernelGGL(k_fold_twiddles, dim3(grid_for(n, NT, MAXB)), dim3(NT), 0, st, (uint64_t*)p, n, log_h - 1, gl::inv(gh));
+    HIP_TRY(ctx, hipGetLastError());
+    g_fold_tw[std::make_pair(ctx, log_h)] = (uint64_t*)p;
+    *out = (uint64_t*)p;
+    return 0;
+}
+
+// ---- batching ----
+static constexpr int COEFF_CHUNK = 512;
+
+__global__ void __launch_bounds__(NT) k_batch_cols(const uint64_t* __restrict__ cols, size_t len, int n_cols, const E2* __restrict__ coeffs,
+                                                   E2* __restrict__ acc, int accumulate) {
+    __shared__ E2 sc[COEFF_CHUNK];
+    const size_t stride = (size_t)gridDim.x * NT;
+    // all lanes walk the chunk loop together (the LDS refill is block-wide), rows beyond `len` just idle
+    const size_t rounds = (len + stride - 1) / stride;
+    for (size_t it = 0; it < rounds; it++) {
+        const size_t i = it * stride + (size_t)blockIdx.x * NT + threadIdx.x;
+        Acc5 a0{0, 0, 0, 0, 0}, a1{0, 0, 0, 0, 0};
+        for (int c0 = 0; c0 < n_cols; c0 += COEFF_CHUNK) {
+            const int nc = min(COEFF_CHUNK, n_cols - c0);
+            __syncthreads();
+            for (int k = threadIdx.x; k < nc; k += NT) sc[k] = coeffs[c0 + k];
+            __syncthreads();
+            if (i < len) {
+                for (int k = 0; k < nc; k++) {
+                    const uint64_t v = cols[(size_t)(c0 + k) * len + i];
+                    acc5_add(a0, mul_wide(sc[k].c0, v));
+                    acc5_add(a1, mul_wide(sc[k].c1, v));
+                }
+            }
+        }
+        if (i < len) {
+            E2 r{acc5_reduce(a0), acc5_reduce(a1)};
+            if (accumulate) r = r + acc[i];
+            acc[i] = r;
+        }
+    }
+}
+
+// ---- commit-phase round ----
+__global__ void __launch_bounds__(NT) k_fold_commit(const E2* __restrict__ cw, size_t n_pairs, E2 c, const E2* __restrict__ addend,
+                                                    const uint64_t* __restrict__ tw, E2* __restrict__ out, uint64_t* __restrict__ digests,
+                                                    const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    const E2Pre cp = e2_pre(c);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < n_pairs; j += stride) {
+        const E2 a = cw[2 * j], b = cw[2 * j + 1];
+        uint64_t s[8] = {a.c0, a.c1, b.c0, b.c1, 0, 0, 0, 0};
+        p2::permute(s, sp);
+        *reinterpret_cast<ulonglong2*>(digests + 4 * j) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(digests + 4 * j + 2) = make_ulonglong2(s[2], s[3]);
+        const E2 lo = e2_mul_base(a + b, INV2);
+        const E2 hi = e2_mul_base(a - b, tw[j]);
+        E2 v = lo + e2_mul_pre(cp, hi - lo);
+        if (addend) v = v + addend[j];
+        out[j] = v;
+    }
+}
+
+// ---- gathers for the query phase ----
+// out[(q * n_cols + c) * elem_words + e] = src[c * col_stride + idx[q] * elem_words + e]
+__global__ void __launch_bounds__(NT) k_gather(const uint64_t* __restrict__ src, size_t col_stride, int n_cols, int elem_words,
+                                               const uint64_t* __restrict__ idx, size_t n_q, int shift, int flip, uint64_t* __restrict__ out) {
+    const size_t per_q = (size_t)n_cols * elem_words, total = n_q * per_q;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
+        const size_t q = t / per_q, rem = t % per_q, c = rem / elem_words, e = rem % elem_words;
+        const size_t i = (idx[q] >> shift) ^ (size_t)flip;
+        out[t] = src[c * col_stride + i * elem_words + e];
+    }
+}
+// authentication paths: out[(q * depth + l) * 4 + k] = levels[l][((idx[q] >> shift) >> l) ^ 1][k]
+__global__ void __launch_bounds__(NT) k_gather_paths(uint64_t* const* __restrict__ levels, int depth, const uint64_t* __restrict__ idx, size_t n_q,
+                                                     int shift, uint64_t* __restrict__ out) {
+    const size_t total = n_q * (size_t)depth * 4;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
+        const size_t q = t / ((size_t)depth * 4), rem = t % ((size_t)depth * 4);
+        const int l = (int)(rem / 4), k = (int)(rem % 4);
+        const size_t node = ((idx[q] >> shift) >> l) ^ 1;
+        out[t] = levels[l][4 * node + k];
+    }
+}
+
+// ---- proof of work: least w >= base with permute(seed0, seed1, w, 0...)[0] = 0 mod 2^bits ----
+__global__ void __launch_bounds__(NT) k_pow_grind(uint64_t seed0, uint64_t seed1, uint64_t base, uint64_t count, uint64_t mask,
+                                                  const p2::Params* __restrict__ pp, unsigned long long* __restrict__ best) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (uint64_t t = (uint64_t)blockIdx.x * NT + threadIdx.x; t < count; t += stride) {
+        const uint64_t w = base + t;
+        uint64_t s[8] = {seed0, seed1, w, 0, 0, 0, 0, 0};
+        p2::permute(s, sp);
+        if ((s[0] & mask) == 0) atomicMin(best, (unsigned long long)w);
+    }
+}
+
+extern "C" {
+
+int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t len, int n_cols, const uint64_t* coeffs_ext, uint64_t* dev_acc_ext,
+                           int accumulate, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_cols && coeffs_ext && dev_acc_ext && len >= 1 && n_cols >= 1, "bad batch_columns arguments");
+    for (int i = 0; i < 2 * n_cols; i++) CHECK_ARG(ctx, coeffs_ext[i] < gl::P, "batch coefficient word %d is not canonical", i);
+    hipStream_t st = ctx_stream(ctx, s);
+    void* d_coeff = nullptr;
+    TRY(ctx_alloc(ctx, (size_t)n_cols * 16, &d_coeff));
+    hipError_t e = hipMemcpyAsync(d_coeff, coeffs_ext, (size_t)n_cols * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_batch_cols, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, dev_cols, len, n_cols, (const E2*)d_coeff, (E2*)dev_acc_ext,
+                           accumulate);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the coefficient buffer goes back to the pool
+    ctx_free(ctx, d_coeff);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "batch_columns: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
+                                  const uint64_t* dev_addend_ext, uint64_t* dev_out_ext, ceno_hip_stream s, ceno_hip_merkle** out_tree) {
+    CHECK_ARG(ctx, dev_codeword_ext && challenge2 && dev_out_ext && out_tree && log_h >= 1 && log_h <= 32, "bad fold_commit arguments");
+    CHECK_ARG(ctx, challenge2[0] < gl::P && challenge2[1] < gl::P, "challenge is not canonical");
+    hipStream_t st = ctx_stream(ctx, s);
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    const uint64_t* tw = nullptr;
+    TRY(get_fold_twiddles(ctx, log_h, st, &tw));
+    ceno_hip_merkle* t = nullptr;
+    TRY(merkle_alloc(ctx, log_h - 1, &t));
+    const size_t n_pairs = (size_t)1 << (log_h - 1);
+    hipLaunchKernelGGL(k_fold_commit, dim3(grid_for(n_pairs, NT, MAXB)), dim3(NT), 0, st, (const E2*)dev_codeword_ext, n_pairs,
+                       E2{challenge2[0], challenge2[1]}, (const E2*)dev_addend_ext, tw, (E2*)dev_out_ext, t->levels[0], pp);
+    int rc = merkle_build_upper(ctx, t, st);
+    if (rc) {
+        merkle_release(ctx, t);
+        return rc;
+    }
+    *out_tree = t;
+    return 0;
+}
+
+int ceno_hip_gather(ceno_hip_ctx* ctx, const uint64_t* dev_src, size_t col_stride_words, int n_cols, int elem_words, const uint64_t* dev_indices,
+                    size_t n, int shift, int flip_low_bit, uint64_t* dev_out, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_src && dev_indices && dev_out && n_cols >= 1 && elem_words >= 1 && shift >= 0 && shift < 64, "bad gather arguments");
+    if (n == 0) return 0;
+    hipStream_t st = ctx_stream(ctx, s);
+    hipLaunchKernelGGL(k_gather, dim3(grid_for(n * n_cols * elem_words, NT, MAXB)), dim3(NT), 0, st, dev_src, col_stride_words, n_cols, elem_words,
+                       dev_indices, n, shift, flip_low_bit ? 1 : 0, dev_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
+                               ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && dev_indices && dev_out && shift >= 0 && shift < 64, "bad merkle_open_batch arguments");
+    if (n == 0 || t->log_rows == 0) return 0;
+    CHECK_ARG(ctx, t->log_rows <= 62, "tree too tall");
+    hipStream_t st = ctx_stream(ctx, s);
+    if (!t->all_ptrs) {
+        void* p = nullptr;
+        TRY(ctx_alloc(ctx, 64 * sizeof(uint64_t*), &p));
+        uint64_t* h[64] = {nullptr};
+        for (int l = 0; l <= t->log_rows; l++) h[l] = t->levels[l];
+        hipError_t e = hipMemcpyAsync(p, h, sizeof(h), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) {
+            ctx_free(ctx, p);
+            return ctx_fail(ctx, CENO_HIP_ERR_HIP, "merkle_open_batch: %s", hipGetErrorString(e));
+        }
+        t->all_ptrs = (uint64_t**)p;
+    }
+    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, t->all_ptrs, t->log_rows, dev_indices, n, shift,
+                       dev_out);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint64_t* out_witness, ceno_hip_stream s) {
+    CHECK_ARG(ctx, seed2 && out_witness && bits >= 0 && bits <= 40, "bad pow_grind arguments");
+    if (bits == 0) {
+        *out_witness = 0;
+        return 0;
+    }
+    hipStream_t st = ctx_stream(ctx, s);
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    void* d = nullptr;
+    TRY(ctx_alloc(ctx, 8, &d));
+    const uint64_t mask = ((uint64_t)1 << bits) - 1;
+    // expected 2^bits candidates: search windows of 4 * 2^bits until one holds a witness (the least one wins)
+    const uint64_t window = (uint64_t)4 << (bits < 16 ? 16 : bits);
+    int rc = 0;
+    for (uint64_t base = 0;; base += window) {
+        unsigned long long best = ~0ull;
+        hipError_t e = hipMemcpyAsync(d, &best, 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_pow_grind, dim3(grid_for(window, NT, MAXB)), dim3(NT), 0, st, seed2[0], seed2[1], base, window, mask, pp,
+                               (unsigned long long*)d);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&best, d, 8, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            rc = ctx_fail(ctx, CENO_HIP_ERR_HIP, "pow_grind: %s", hipGetErrorString(e));
+            break;
+        }
+        if (best != ~0ull) {
+            *out_witness = best;
+            break;
+        }
+        if (base > ((uint64_t)1 << 60)) {
+            rc = ctx_fail(ctx, CENO_HIP_ERR_STATE, "pow_grind: no witness found");
+            break;
+        }
+    }
+    ctx_free(ctx, d);
+    return rc;
+}
+
+}  // extern "C"

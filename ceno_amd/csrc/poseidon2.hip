@@ -18,16 +18,9 @@ using namespace gl;
 static constexpr int NT = 256;
 static constexpr unsigned MAXB = 4096;
 
-struct PoseidonParams {
-    p2::Params p;
-};
+#include "merkle.hpp"
 
-struct ceno_hip_merkle {
-    int log_rows = 0;
-    std::vector<uint64_t*> levels;  // levels[0] = 2^log_rows leaf digests (4 words each) ... levels[log_rows] = root
-};
-
-static int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
+int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
     if (!ctx->poseidon_dev) {
         PoseidonParams h;
         p2::default_params(h.p);
@@ -93,10 +86,84 @@ __global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ ch
     }
 }
 
-static void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
+void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
+    if (t->top_ptrs) ctx_free(ctx, t->top_ptrs);
+    if (t->all_ptrs) ctx_free(ctx, t->all_ptrs);
     for (auto* p : t->levels) ctx_free(ctx, p);
     delete t;
+}
+
+// levels 1..log_rows over leaf digests already in levels[0]
+int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
+    auto* t = new ceno_hip_merkle();
+    t->log_rows = log_rows;
+    t->levels.assign(log_rows + 1, nullptr);
+    for (int l = 0; l <= log_rows; l++) {
+        void* p = nullptr;
+        int rc = ctx_alloc(ctx, ((size_t)1 << (log_rows - l)) * 32, &p);
+        if (rc) {
+            merkle_release(ctx, t);
+            return rc;
+        }
+        t->levels[l] = (uint64_t*)p;
+    }
+    *out = t;
+    return 0;
+}
+
+// the last <= 9 levels (<= 512 nodes in) in one workgroup: a tree top is a chain of tiny dependent launches otherwise
+__global__ void __launch_bounds__(NT) k_compress_top(const uint64_t* __restrict__ child, int levels, uint64_t* const* __restrict__ outs,
+                                                     const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    __shared__ uint64_t buf[2][4 * 512];
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    int n = 1 << levels;  // child digests
+    for (int i = threadIdx.x; i < 4 * n; i += NT) buf[0][i] = child[i];
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < levels; l++) {
+        const int np = n >> 1;
+        for (int i = threadIdx.x; i < np; i += NT) {
+            uint64_t s[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) s[k] = buf[cur][8 * i + k];
+            p2::permute(s, sp);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                buf[cur ^ 1][4 * i + k] = s[k];
+                outs[l][4 * i + k] = s[k];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+        n = np;
+    }
+}
+
+int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    const int log_rows = t->log_rows;
+    int l = 1;
+    for (; l <= log_rows && (log_rows - l + 1) > 9; l++) {
+        size_t np = (size_t)1 << (log_rows - l);
+        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+    }
+    if (l <= log_rows) {  // levels l..log_rows: child level l-1 has 2^(log_rows-l+1) <= 512 digests
+        const int rem = log_rows - l + 1;
+        if (!t->top_ptrs) {
+            void* p = nullptr;
+            TRY(ctx_alloc(ctx, 16 * sizeof(uint64_t*), &p));
+            t->top_ptrs = (uint64_t**)p;
+        }
+        uint64_t* h[16] = {nullptr};
+        for (int i = 0; i < rem; i++) h[i] = t->levels[l + i];
+        HIP_TRY(ctx, hipMemcpyAsync(t->top_ptrs, h, sizeof(h), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(NT), 0, st, t->levels[l - 1], rem, t->top_ptrs, pp);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 extern "C" {
@@ -138,28 +205,14 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
     const p2::Params* pp;
     TRY(get_params(ctx, &pp));
     hipStream_t st = ctx_stream(ctx, s);
-    auto* t = new ceno_hip_merkle();
-    t->log_rows = log_rows;
-    t->levels.assign(log_rows + 1, nullptr);
-    for (int l = 0; l <= log_rows; l++) {
-        void* p = nullptr;
-        int rc = ctx_alloc(ctx, ((size_t)1 << (log_rows - l)) * 32, &p);
-        if (rc) {
-            merkle_release(ctx, t);
-            return rc;
-        }
-        t->levels[l] = (uint64_t*)p;
-    }
+    ceno_hip_merkle* t = nullptr;
+    TRY(merkle_alloc(ctx, log_rows, &t));
     size_t rows = (size_t)1 << log_rows;
     hipLaunchKernelGGL(k_leaf_hash, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, dev_col_major, rows, width, t->levels[0], pp);
-    for (int l = 1; l <= log_rows; l++) {
-        size_t np = (size_t)1 << (log_rows - l);
-        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
+    int rc = merkle_build_upper(ctx, t, st);
+    if (rc) {
         merkle_release(ctx, t);
-        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "merkle commit: %s", hipGetErrorString(e));
+        return rc;
     }
     *out = t;
     return 0;

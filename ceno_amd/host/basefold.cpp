@@ -1,0 +1,314 @@
+// Basefold batch open — host control flow of `OpeningProver::open` -> `PCS::batch_open`
+// (ceno_zkvm/src/scheme/hal.rs:284-294, CPU scheme/cpu/mod.rs:1418-1457) over the device C ABI.
+//
+// The implementation the reference calls is in the EXT crate mpcs; the protocol is taken from the in-tree verifier
+// replay ceno_recursion_v2/src/pcs/mod.rs:1111-1316 (transcript script, initial/final claims), :7494-7720 (queries),
+// :7765-7781 (fold).  PARITY UNPINNED (include/ceno_prover.h); oracle/basefold.c is the CPU restatement of the same
+// script plus the verifier, and the parity tests compare complete proofs word for word.
+//
+// Per opening group (one committed trace matrix with its point): F_m = sum_col coeff * column (ext table) and
+// E_m = eq(point_m, .).  The degree-2 sumcheck of sum_m 2^(n - nv_m) <E_m, F_m> runs over n = max nv rounds; a
+// matrix with fewer variables contributes a constant until round n - nv_m and is live afterwards (it meets the LAST
+// nv_m challenges).  In lock step the running codeword (ext, bit-reversed order) is Merkle-committed pair-wise and
+// folded once per round by ONE fused kernel, and the batched codeword of the next height is added as it joins.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <map>
+#include <vector>
+
+#include "../csrc/gl64.cuh"
+#include "pcs_data.hpp"
+
+using gl::E2;
+
+int prover_set_error(int code, const char* msg);  // prover.cpp
+
+namespace {
+
+void tr_label(ceno_transcript* t, const char* s) { t->append_label(t->self, (const uint8_t*)s, strlen(s)); }
+void tr_ext(ceno_transcript* t, E2 e) {
+    uint64_t w[2] = {e.c0, e.c1};
+    t->append_ext(t->self, w);
+}
+E2 tr_sample(ceno_transcript* t) {
+    uint64_t o[2];
+    t->sample_ext(t->self, o);
+    return E2{o[0], o[1]};
+}
+
+size_t query_words(const ceno_pcs_data* d, int n) {
+    size_t w = 1;
+    for (auto& M : d->mats) w += M.width + 4 * (size_t)(M.log_rows + d->log_blowup);
+    for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + d->log_blowup - r - 1);
+    return w;
+}
+int max_nv(const ceno_pcs_data* d) {
+    int n = 0;
+    for (auto& M : d->mats) n = std::max(n, M.log_rows);
+    return n;
+}
+
+struct Group {  // matrices with the same number of variables share one sumcheck handle
+    std::vector<int> mats;
+    ceno_hip_sumcheck* sc = nullptr;
+    bool started = false;
+};
+
+}  // namespace
+
+extern "C" {
+
+size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries) {
+    if (!d || n_queries < 0) return 0;
+    const int n = max_nv(d);
+    return 8 * (size_t)n + 2 * d->mats.size() + 1 + (size_t)n_queries * query_words(d, n);
+}
+
+int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_t* const* points, const uint64_t* const* evals, int n_queries,
+                              int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
+    if (!ctx || !d || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 || pow_bits > 40 || d->mats.empty())
+        return prover_set_error(CENO_HIP_ERR_INVALID, "bad basefold_open arguments");
+    if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "basefold_open needs an explicit stream (ceno_hip_stream_create)");
+    hipStream_t st = (hipStream_t)s;
+    const int n_mats = (int)d->mats.size(), rate_log = d->log_blowup, n = max_nv(d), H = n + rate_log;
+    size_t total_cols = 0;
+    for (auto& M : d->mats) total_cols += M.width;
+
+    // everything allocated here is released by `cleanup`
+    std::vector<ceno_hip_mle*> owned;
+    std::vector<ceno_hip_merkle*> trees;
+    std::map<int, Group> groups;  // key: nv
+    void* d_scratch = nullptr;
+    auto cleanup = [&]() {
+        for (auto& g : groups)
+            if (g.second.sc) ceno_hip_sumcheck_free(ctx, g.second.sc);
+        for (auto* t : trees) ceno_hip_merkle_free(ctx, t);
+        for (auto* m : owned) ceno_hip_mle_free(ctx, m);
+        if (d_scratch) (void)hipFree(d_scratch);
+    };
+    auto fail = [&](int rc) {
+        std::string msg = ceno_hip_last_error(ctx);
+        cleanup();
+        return prover_set_error(rc, msg.c_str());
+    };
+    auto alloc_ext = [&](int nv, ceno_hip_mle** out) {
+        int rc = ceno_hip_mle_alloc(ctx, nv, 1, out);
+        if (!rc) owned.push_back(*out);
+        return rc;
+    };
+
+    // ---- batch coefficients (pcs/mod.rs:1130-1131) ----
+    tr_label(tr, "batch coeffs");
+    const E2 alpha = tr_sample(tr);
+    std::vector<uint64_t> coeff(2 * total_cols);
+    {
+        E2 c = gl::e2_one();
+        for (size_t i = 0; i < total_cols; i++) {
+            coeff[2 * i] = c.c0;
+            coeff[2 * i + 1] = c.c1;
+            c = c * alpha;
+        }
+    }
+    // ---- batched codeword per height, F_m / E_m per matrix, S_m = sum coeff * eval ----
+    std::vector<ceno_hip_mle*> B(H + 1, nullptr), F(n_mats, nullptr), Eq(n_mats, nullptr);
+    std::vector<E2> S(n_mats);
+    {
+        size_t ci = 0;
+        for (int m = 0; m < n_mats; m++) {
+            auto& M = d->mats[m];
+            const int h = M.log_rows + rate_log;
+            int rc = 0, fresh = 0;
+            if (!B[h]) {
+                rc = alloc_ext(h, &B[h]);
+                fresh = 1;
+            }
+            if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(M.codeword), M.rows << rate_log, (int)M.width, coeff.data() + 2 * ci,
+                                                 ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
+            if (!rc) rc = alloc_ext(M.log_rows, &F[m]);
+            if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(M.trace), M.rows, (int)M.width, coeff.data() + 2 * ci,
+                                                 ceno_hip_mle_device_ptr(F[m]), 0, s);
+            if (!rc) {
+                rc = ceno_hip_eq_build(ctx, points[m], M.log_rows, nullptr, s, &Eq[m]);
+                if (!rc) owned.push_back(Eq[m]);
+            }
+            if (rc) return fail(rc);
+            E2 acc = gl::e2_zero();
+            for (size_t c = 0; c < M.width; c++, ci++)
+                acc = acc + E2{coeff[2 * ci], coeff[2 * ci + 1]} * E2{evals[m][2 * c], evals[m][2 * c + 1]};
+            S[m] = acc;
+            groups[M.log_rows].mats.push_back(m);
+        }
+    }
+    uint64_t* msgs = out_proof;
+    uint64_t* commits = out_proof + 4 * (size_t)n;
+    uint64_t* finalm = out_proof + 8 * (size_t)n;
+    uint64_t* powp = finalm + 2 * (size_t)n_mats;
+    uint64_t* qbase = powp + 1;
+
+    // ---- commit phase ----
+    std::vector<ceno_hip_mle*> C(n + 1, nullptr);
+    C[0] = B[H];
+    std::vector<uint64_t> ch(2 * (size_t)std::max(n, 1));
+    for (int r = 0; r < n; r++) {
+        const int h = H - r;
+        E2 p1 = gl::e2_zero(), p2 = gl::e2_zero();
+        for (auto& kv : groups) {
+            Group& g = kv.second;
+            const int s_m = n - kv.first;
+            if (s_m > r) {  // joins later: constant in this variable
+                const uint64_t scale = gl::pow(2, (uint64_t)(s_m - r - 1));
+                for (int m : g.mats) {
+                    E2 c = gl::e2_mul_base(S[m], scale);
+                    p1 = p1 + c;
+                    p2 = p2 + c;
+                }
+                continue;
+            }
+            int rc = 0;
+            if (!g.started) {  // becomes live now: terms E_m * F_m over kv.first variables
+                std::vector<ceno_hip_mle*> mles;
+                std::vector<uint64_t> tc;
+                std::vector<uint32_t> toff{0}, tidx;
+                for (int m : g.mats) {
+                    tidx.push_back((uint32_t)mles.size());
+                    mles.push_back(Eq[m]);
+                    tidx.push_back((uint32_t)mles.size());
+                    mles.push_back(F[m]);
+                    toff.push_back((uint32_t)tidx.size());
+                    tc.push_back(1);
+                    tc.push_back(0);
+                }
+                ceno_hip_sumcheck_plan plan{};
+                plan.num_mles = (int)mles.size();
+                plan.num_terms = (int)g.mats.size();
+                plan.term_coeffs = tc.data();
+                plan.term_offsets = toff.data();
+                plan.term_mle_idx = tidx.data();
+                plan.max_num_vars = kv.first;
+                plan.max_degree = 2;
+                rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, &g.sc);
+                g.started = true;
+            }
+            uint64_t ev[4];
+            if (!rc) rc = ceno_hip_sumcheck_round(ctx, g.sc, (r - s_m) == 0 ? nullptr : &ch[2 * (r - 1)], ev);
+            if (rc) return fail(rc);
+            p1 = p1 + E2{ev[0], ev[1]};
+            p2 = p2 + E2{ev[2], ev[3]};
+        }
+        msgs[4 * r] = p1.c0; msgs[4 * r + 1] = p1.c1; msgs[4 * r + 2] = p2.c0; msgs[4 * r + 3] = p2.c1;
+        tr_ext(tr, p1);
+        tr_ext(tr, p2);
+        tr_label(tr, "commit round");
+        const E2 c = tr_sample(tr);
+        ch[2 * r] = c.c0;
+        ch[2 * r + 1] = c.c1;
+        // commit the running codeword and fold it in one pass; the codeword of the next height joins
+        ceno_hip_merkle* tree = nullptr;
+        int rc = alloc_ext(h - 1, &C[r + 1]);
+        if (!rc) rc = ceno_hip_basefold_fold_commit(ctx, ceno_hip_mle_device_ptr(C[r]), h, &ch[2 * r], B[h - 1] ? ceno_hip_mle_device_ptr(B[h - 1]) : nullptr,
+                                                    ceno_hip_mle_device_ptr(C[r + 1]), s, &tree);
+        if (!rc) {
+            trees.push_back(tree);
+            rc = ceno_hip_merkle_root(ctx, tree, commits + 4 * r, s);
+        }
+        if (rc) return fail(rc);
+        tr->append_ext(tr->self, commits + 4 * r);
+        tr->append_ext(tr->self, commits + 4 * r + 2);
+    }
+    // ---- final message: F_m at the challenges, one row per opening point ----
+    E2 total = gl::e2_zero();
+    for (auto& kv : groups) {
+        Group& g = kv.second;
+        std::vector<uint64_t> fin(4 * g.mats.size());
+        int rc = ceno_hip_sumcheck_finish(ctx, g.sc, n ? &ch[2 * (n - 1)] : nullptr, fin.data());
+        if (rc) return fail(rc);
+        for (size_t i = 0; i < g.mats.size(); i++) {
+            finalm[2 * g.mats[i]] = fin[4 * i + 2];
+            finalm[2 * g.mats[i] + 1] = fin[4 * i + 3];
+        }
+    }
+    for (int m = 0; m < n_mats; m++) {
+        const E2 v{finalm[2 * m], finalm[2 * m + 1]};
+        total = total + v;
+        tr_ext(tr, v);
+    }
+    {   // the fully folded codeword must be the constant codeword of the message
+        std::vector<uint64_t> last(2 * ((size_t)1 << rate_log));
+        int rc = ceno_hip_mle_download(ctx, C[n], last.data(), s);
+        if (rc) return fail(rc);
+        for (size_t i = 0; i < ((size_t)1 << rate_log); i++)
+            if (last[2 * i] != total.c0 || last[2 * i + 1] != total.c1) {
+                cleanup();
+                return prover_set_error(CENO_HIP_ERR_STATE, "basefold_open: folded codeword is not the encoding of the final message");
+            }
+    }
+    // ---- proof of work ----
+    *powp = 0;
+    if (pow_bits > 0) {
+        const E2 seed = tr_sample(tr);
+        const uint64_t sw[2] = {seed.c0, seed.c1};
+        int rc = ceno_hip_pow_grind(ctx, sw, pow_bits, powp, s);
+        if (rc) return fail(rc);
+        tr_ext(tr, E2{*powp, 0});
+    }
+    // ---- queries ----
+    tr_label(tr, "query indices");
+    if (n_queries == 0) {
+        cleanup();
+        return 0;
+    }
+    const size_t qw = query_words(d, n), Q = (size_t)n_queries;
+    std::vector<uint64_t> qidx(Q);
+    for (size_t q = 0; q < Q; q++) qidx[q] = tr_sample(tr).c0 & (((uint64_t)1 << H) - 1);
+    // device scratch: [indices Q][piece-major answers]; host buffer mirrors the answers
+    const size_t ans_words = Q * (qw - 1);
+    if (hipMalloc(&d_scratch, (Q + ans_words) * 8) != hipSuccess) {
+        cleanup();
+        return prover_set_error(CENO_HIP_ERR_OOM, "basefold_open: query scratch allocation failed");
+    }
+    uint64_t* d_idx = (uint64_t*)d_scratch;
+    uint64_t* d_ans = d_idx + Q;
+    if (hipMemcpyAsync(d_idx, qidx.data(), Q * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+    struct Piece { size_t off, per_q; };
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    int rc = 0;
+    for (int m = 0; m < n_mats && !rc; m++) {
+        auto& M = d->mats[m];
+        const int hm = M.log_rows + rate_log, shift = H - hm;
+        rc = ceno_hip_gather(ctx, ceno_hip_mle_device_ptr(M.codeword), M.rows << rate_log, (int)M.width, 1, d_idx, Q, shift, 0, d_ans + off, s);
+        pieces.push_back({off, M.width});
+        off += Q * M.width;
+        if (!rc) rc = ceno_hip_merkle_open_batch(ctx, M.tree, d_idx, Q, shift, d_ans + off, s);
+        pieces.push_back({off, 4 * (size_t)hm});
+        off += Q * 4 * (size_t)hm;
+    }
+    for (int r = 0; r < n && !rc; r++) {
+        const int h = H - r;
+        rc = ceno_hip_gather(ctx, ceno_hip_mle_device_ptr(C[r]), 0, 1, 2, d_idx, Q, r, 1, d_ans + off, s);
+        pieces.push_back({off, 2});
+        off += Q * 2;
+        if (!rc) rc = ceno_hip_merkle_open_batch(ctx, trees[r], d_idx, Q, r + 1, d_ans + off, s);
+        pieces.push_back({off, 4 * (size_t)(h - 1)});
+        off += Q * 4 * (size_t)(h - 1);
+    }
+    if (rc) return fail(rc);
+    std::vector<uint64_t> ans(ans_words);
+    if (hipMemcpyAsync(ans.data(), d_ans, ans_words * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(CENO_HIP_ERR_HIP);
+    for (size_t q = 0; q < Q; q++) {
+        uint64_t* out = qbase + q * qw;
+        *out++ = qidx[q];
+        for (auto& p : pieces) {
+            memcpy(out, ans.data() + p.off + q * p.per_q, p.per_q * 8);
+            out += p.per_q;
+        }
+    }
+    cleanup();
+    return 0;
+}
+
+}  // extern "C"

@@ -9,17 +9,7 @@
 
 int prover_set_error(int code, const char* msg);  // prover.cpp
 
-struct ceno_pcs_data {
-    struct Mat {
-        size_t rows = 0, width = 0;  // padded rows
-        int log_rows = 0;
-        ceno_hip_mle* trace = nullptr;     // column-major trace, raw buffer (base words)
-        ceno_hip_mle* codeword = nullptr;  // column-major codewords
-        ceno_hip_merkle* tree = nullptr;
-    };
-    std::vector<Mat> mats;
-    int log_blowup = 0;
-};
+#include "pcs_data.hpp"
 
 static int ceil_log2_sz(size_t x) {
     int l = 0;

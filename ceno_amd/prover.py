@@ -417,6 +417,10 @@ class PcsData:
         L.ceno_pcs_data_open_row.argtypes = [vp, vp, i, sz, u64p, u64p, vp]
         L.ceno_pcs_data_free.restype = None
         L.ceno_pcs_data_free.argtypes = [vp, vp]
+        L.ceno_prover_basefold_proof_words.restype = sz
+        L.ceno_prover_basefold_proof_words.argtypes = [vp, i]
+        L.ceno_prover_basefold_open.restype = i
+        L.ceno_prover_basefold_open.argtypes = [vp, vp, C.POINTER(u64p), C.POINTER(u64p), i, i, vp, vp, u64p]
         self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
         mats = [np.ascontiguousarray(m, dtype=np.uint64) for m in matrices]
         self.shapes = [m.shape for m in mats]
@@ -449,6 +453,21 @@ class PcsData:
         path = np.zeros((max(depth, 1), 4), dtype=np.uint64)
         _check(plib().ceno_pcs_data_open_row(self.dev.h, self.h, matrix, index, _p(row), _p(path), self.stream))
         return row, path[:depth]
+
+    def basefold_open(self, points: Sequence[np.ndarray], evals: Sequence[np.ndarray], n_queries: int, pow_bits: int,
+                      transcript: "Transcript") -> np.ndarray:
+        """OpeningProver::open (ceno_zkvm/src/scheme/hal.rs:284-294): every matrix at its own point.
+        Returns the flat proof (layout: include/ceno_prover.h)."""
+        L = plib()
+        n = len(self.shapes)
+        pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
+        evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
+        assert len(pts) == n and len(evs) == n
+        proof = np.zeros(int(L.ceno_prover_basefold_proof_words(self.h, n_queries)), dtype=np.uint64)
+        pp = (u64p * n)(*[_p(x) for x in pts])
+        ep = (u64p * n)(*[_p(x) for x in evs])
+        _check(L.ceno_prover_basefold_open(self.dev.h, self.h, pp, ep, n_queries, pow_bits, transcript.h, self.stream, _p(proof)))
+        return proof
 
     def free(self):
         if getattr(self, "h", None) and self.dev.h:

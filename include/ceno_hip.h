@@ -236,6 +236,29 @@ int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, ui
 int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
 
 /* ------------------------------------------------------------------------------------------------
+ * Basefold batch open  (OpeningProver::open -> PCS::batch_open, ceno_zkvm/src/scheme/hal.rs:284-294,
+ * cpu/mod.rs:1418-1457; protocol restated in ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781).
+ * PARITY UNPINNED like the commit path.  The round loop lives in the host layer (ceno_prover_basefold_open).
+ * ---------------------------------------------------------------------------------------------- */
+/* acc[i] (+)= sum_c coeff_c * col_c[i]: `n_cols` base columns of length `len` (column-major, stride len), ext
+ * coefficients from the host, ext accumulator of length `len` on the device.  Synchronises the stream. */
+int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t len, int n_cols, const uint64_t* coeffs_ext,
+                           uint64_t* dev_acc_ext, int accumulate, ceno_hip_stream s);
+/* One commit-phase round over the running ext codeword of length 2^log_h (bit-reversed order, pairs adjacent):
+ * tree over the 2^(log_h-1) pair leaves (returned), and out[j] = fold(cw[2j], cw[2j+1]; challenge) (+ addend[j]). */
+int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
+                                  const uint64_t* dev_addend_ext /* may be NULL */, uint64_t* dev_out_ext, ceno_hip_stream s,
+                                  ceno_hip_merkle** out_tree);
+/* dev_out[(q*n_cols + c)*elem_words + e] = dev_src[c*col_stride_words + i_q*elem_words + e], i_q = (idx[q] >> shift) ^ flip */
+int ceno_hip_gather(ceno_hip_ctx* ctx, const uint64_t* dev_src, size_t col_stride_words, int n_cols, int elem_words,
+                    const uint64_t* dev_indices, size_t n, int shift, int flip_low_bit, uint64_t* dev_out, ceno_hip_stream s);
+/* authentication paths of leaves (idx[q] >> shift): dev_out[q][level][4], log_rows levels, bottom-up */
+int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift,
+                               uint64_t* dev_out, ceno_hip_stream s);
+/* least w with poseidon2(seed.c0, seed.c1, w, 0, 0, 0, 0, 0)[0] = 0 mod 2^bits (synchronises) */
+int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint64_t* out_witness, ceno_hip_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * diagnostics used by bench.py (HIP-event timing of the dominant kernel on the launch stream)
  * ---------------------------------------------------------------------------------------------- */
 /* accumulated device time (ms) and launch count of the fused sumcheck round kernel since the last reset */

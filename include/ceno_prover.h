@@ -145,6 +145,21 @@ int ceno_pcs_data_witness_mle(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, s
 int ceno_pcs_data_open_row(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, size_t index, uint64_t* row_out, uint64_t* path_out, ceno_hip_stream s);
 void ceno_pcs_data_free(ceno_hip_ctx* ctx, ceno_pcs_data* d);
 
+/* ---- Basefold batch open (a15) ----
+ * OpeningProver::open -> PCS::batch_open (ceno_zkvm/src/scheme/hal.rs:284-294, CPU scheme/cpu/mod.rs:1418-1457);
+ * protocol as replayed by the in-tree verifier ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781
+ * (basecode_msg_size_log = 0).  Every committed matrix is opened at its own point (`points[m]`: num_vars ext) with
+ * the claimed column evaluations `evals[m]` (width ext).  PARITY UNPINNED (EXT mpcs), see commit_traces above;
+ * additionally: digests are observed as two ext elements, query indices are the low bits of a sampled ext's c0,
+ * and the proof of work is seed-based.
+ * Flat proof (ceno_prover_basefold_proof_words words), n = max num_vars, H = n + log_blowup:
+ *   [sumcheck messages n x (p(1), p(2)) ext][commit-round roots n x 4][final message: one ext per matrix][pow witness]
+ *   then per query: [index] per matrix [opened codeword row: width][path 4 x (num_vars + log_blowup)]
+ *                   per round r [sibling ext][path 4 x (H - r - 1)]                                         */
+size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries);
+int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_t* const* points, const uint64_t* const* evals,
+                              int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof);
+
 const char* ceno_prover_last_error(void);
 
 /* ---- hypercube-sharded sumcheck over the GPUs of one node (ceno_amd/host/dist.cpp) ----

@@ -164,6 +164,22 @@ void orc_poseidon2_permute(uint64_t* state8, const uint64_t* params138);
 void orc_poseidon2_default_params(uint64_t* params138);
 void orc_merkle_commit(const uint64_t* col_major, int log_rows, int width, const uint64_t* params138, uint64_t* out_levels);
 
+
+/* ---- Basefold batch open + verifier (a15) — PARITY UNPINNED, see basefold.c ----
+ * proof layout (words): [sumcheck msgs 4n][commit roots 4n][final message 2*n_mats][pow witness 1] then per query
+ *   [index 1] per matrix [opened row width_m][path 4*(nv_m+rate_log)] per round r [sibling 2][path 4*(n+rate_log-r-1)] */
+void orc_fft_bitrev(uint64_t* a, int log_n);
+size_t orc_basefold_query_words(int n_mats, const int* nv, const int* width, int rate_log);
+size_t orc_basefold_proof_words(int n_mats, const int* nv, const int* width, int rate_log, int n_queries);
+int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_t* const* traces /* column-major base */,
+                      const uint64_t* const* points, const uint64_t* const* evals /* width ext per matrix */, int rate_log,
+                      int n_queries, int pow_bits, const uint64_t* params138, orc_transcript* tr, uint64_t* proof);
+void orc_basefold_commit_roots(int n_mats, const int* nv, const int* width, const uint64_t* const* traces, int rate_log,
+                               const uint64_t* params138, uint64_t* roots /* 4 per matrix */);
+int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint64_t* roots, const uint64_t* const* points,
+                        const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits, const uint64_t* params138,
+                        orc_transcript* tr, const uint64_t* proof);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,6 +496,68 @@ def merkle_commit(col_major: np.ndarray, log_rows: int, width: int, params: Opti
     return levels
 
 
+# ---- Basefold open / verify (a15) --------------------------------------------------------------
+def fft_bitrev(col: np.ndarray) -> np.ndarray:
+    a = np.array(col, dtype=np.uint64).copy()
+    lib().orc_fft_bitrev(_p(a), int(a.shape[0]).bit_length() - 1)
+    return a
+
+
+def _bf_args(traces, points, evals):
+    """traces: list of (rows, width) row-major base matrices -> column-major buffers + C pointer arrays"""
+    n = len(traces)
+    nv = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
+    width = (C.c_int * n)(*[int(t.shape[1]) for t in traces])
+    cols = [np.ascontiguousarray(np.asarray(t, dtype=np.uint64).T) for t in traces]
+    pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
+    evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
+    PP = C.POINTER(C.c_uint64)
+    arr = lambda xs: (PP * n)(*[x.ctypes.data_as(PP) for x in xs])
+    return n, nv, width, arr(cols), arr(pts), arr(evs), (cols, pts, evs)
+
+
+def basefold_proof_words(traces, rate_log: int, n_queries: int) -> int:
+    n = len(traces)
+    nv = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
+    width = (C.c_int * n)(*[int(t.shape[1]) for t in traces])
+    f = lib().orc_basefold_proof_words
+    f.restype = C.c_size_t
+    return int(f(n, nv, width, rate_log, n_queries))
+
+
+def basefold_open(traces, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, params=None) -> np.ndarray:
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    n, nv, width, tp, pp, ep, keep = _bf_args(traces, points, evals)
+    proof = np.zeros(basefold_proof_words(traces, rate_log, n_queries), dtype=np.uint64)
+    rc = lib().orc_basefold_open(n, nv, width, tp, pp, ep, rate_log, n_queries, pow_bits, _p(params), transcript.ptr(), _p(proof))
+    assert rc == 0, f"orc_basefold_open rc={rc}"
+    return proof
+
+
+def basefold_commit_roots(traces, rate_log: int, params=None) -> np.ndarray:
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    n, nv, width, tp, _, _, keep = _bf_args(traces, [np.zeros((1, 2))] * len(traces), [np.zeros((1, 2))] * len(traces))
+    roots = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_basefold_commit_roots(n, nv, width, tp, rate_log, _p(params), _p(roots))
+    return roots
+
+
+def basefold_verify(shapes, roots, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, proof, params=None) -> int:
+    """shapes: list of (num_vars, width). returns 0 when accepted"""
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    n = len(shapes)
+    nv = (C.c_int * n)(*[s[0] for s in shapes])
+    width = (C.c_int * n)(*[s[1] for s in shapes])
+    pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
+    evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
+    PP = C.POINTER(C.c_uint64)
+    arr = lambda xs: (PP * n)(*[x.ctypes.data_as(PP) for x in xs])
+    r = np.ascontiguousarray(roots, dtype=np.uint64)
+    pr = np.ascontiguousarray(proof, dtype=np.uint64)
+    return int(lib().orc_basefold_verify(n, nv, width, _p(r), arr(pts), arr(evs), rate_log, n_queries, pow_bits, _p(params),
+                                         transcript.ptr(), _p(pr)))
+
+
 # ---- rotation (a11) -------------------------------------------------------------------------
 def cyclic_table(log2: int) -> np.ndarray:
     out = np.zeros(1 << log2, dtype=np.uint32)

@@ -1,0 +1,115 @@
+"""GPU parity for the Basefold batch open: the HIP path must emit, word for word, the proof the
+oracle's restated prover emits under the same transcript, and the oracle's restated verifier
+(ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781) must accept it.  PARITY UNPINNED vs the reference (EXT mpcs)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ceno_amd import Device
+
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def make_case(seed, shapes):
+    traces = [po.rand_base((1 << nv) * w, seed + 7 * i).reshape(1 << nv, w) for i, (nv, w) in enumerate(shapes)]
+    points = [po.rand_ext(nv, seed + 100 + i) for i, (nv, _) in enumerate(shapes)]
+    evals = [np.array([po.mle_evaluate(t[:, c].copy(), p) for c in range(t.shape[1])], dtype=np.uint64) for t, p in zip(traces, points)]
+    return traces, points, evals
+
+
+@pytest.mark.parametrize("shapes,rate_log,nq,pow_bits", [
+    ([(5, 3)], 1, 5, 4),
+    ([(6, 4), (6, 2)], 1, 7, 0),
+    ([(8, 3), (4, 5), (8, 1), (1, 2), (3, 7)], 1, 9, 8),
+    ([(1, 1)], 1, 3, 2),
+    ([(7, 6), (5, 2)], 2, 4, 5),
+])
+def test_open_matches_oracle_word_for_word_and_verifies(dev, shapes, rate_log, nq, pow_bits):
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    traces, points, evals = make_case(3, shapes)
+    pcs = prover.PcsData(dev, traces, rate_log, stream)
+    proof = pcs.basefold_open(points, evals, nq, pow_bits, prover.Transcript.stub(0xBF))
+    expect = po.basefold_open(traces, points, evals, rate_log, nq, pow_bits, po.StubTranscript(0xBF))
+    assert proof.shape == expect.shape
+    bad = np.nonzero(proof != expect)[0]
+    assert bad.size == 0, f"first mismatch at word {bad[:5]} of {proof.size}"
+    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+    assert np.array_equal(roots, po.basefold_commit_roots(traces, rate_log))
+    assert po.basefold_verify(shapes, roots, points, evals, rate_log, nq, pow_bits, po.StubTranscript(0xBF), proof) == 0
+    pcs.free()
+    dev.stream_destroy(stream)
+
+
+def test_open_at_chip_size_verifies(dev):
+    """ADD-chip shaped commitment (2^16 x 22 here) plus two smaller tables; too big for the oracle prover's
+    quadratic pieces to be pleasant, so only the verifier (linear in the proof) is run."""
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    shapes = [(16, 22), (12, 9), (16, 3)]
+    rng = np.random.default_rng(9)
+    traces = [(rng.integers(0, 1 << 62, size=(1 << nv, w), dtype=np.uint64)) % np.uint64(P) for nv, w in shapes]
+    points = [po.rand_ext(nv, 500 + i) for i, (nv, _) in enumerate(shapes)]
+    pcs = prover.PcsData(dev, traces, 1, stream)
+    evals = []
+    for i, (nv, w) in enumerate(shapes):
+        ev = np.zeros((w, 2), dtype=np.uint64)
+        for c in range(w):
+            ev[c] = pcs.witness_mle(i, c).evaluate(points[i])
+        evals.append(ev)
+    tr = prover.Transcript.poseidon2(b"open")
+    proof = pcs.basefold_open(points, evals, 20, 10, tr)
+    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+
+    class P2(object):  # the oracle verifier driven by the host library's Poseidon2 transcript through its C table
+        def __init__(self):
+            self.t = prover.Transcript.poseidon2(b"open")
+
+        def ptr(self):
+            return self.t.h
+
+    assert po.basefold_verify(shapes, roots, points, evals, 1, 20, 10, P2(), proof) == 0
+    tampered = proof.copy()
+    tampered[4 * 16 + 2] ^= np.uint64(1)  # a commit-round root
+    assert po.basefold_verify(shapes, roots, points, evals, 1, 20, 10, P2(), tampered) != 0
+    pcs.free()
+    dev.stream_destroy(stream)
+
+
+def test_batch_columns_and_fold_commit_primitives(dev):
+    """kernel-level parity: column batching with unreduced accumulators, and one fused fold+commit round"""
+    import ctypes as C
+    import torch
+
+    from ceno_amd import _lib
+
+    L = _lib.lib()
+    n, width = 1 << 9, 37
+    cols = po.rand_base(n * width, 4).reshape(width, n)
+    cols[0, :4] = P - 1
+    coeffs = po.rand_ext(width, 8)
+    coeffs[0] = (P - 1, P - 1)
+    d_cols = torch.from_numpy(cols.view(np.int64)).to("cuda:0")
+    d_acc = torch.zeros(2 * n, dtype=torch.int64, device="cuda:0")
+    c = np.ascontiguousarray(coeffs)
+    for accumulate in (0, 1):
+        rc = L.ceno_hip_batch_columns(dev.h, d_cols.data_ptr(), n, width, c.ctypes.data_as(C.POINTER(C.c_uint64)), d_acc.data_ptr(), accumulate, None)
+        assert rc == 0
+    got = d_acc.cpu().numpy().view(np.uint64).reshape(n, 2)
+    for i in (0, 1, 3, 17, n - 1):
+        want = (0, 0)
+        for k in range(width):
+            want = po.e2_add(want, po.e2_mul((int(coeffs[k, 0]), int(coeffs[k, 1])), (int(cols[k, i]), 0)))
+        want = po.e2_add(want, want)
+        assert (int(got[i, 0]), int(got[i, 1])) == want
