@@ -90,4 +90,43 @@ GL_HD void permute(uint64_t* s, const Params& p) {
     }
 }
 
+#if defined(__HIPCC__)
+// ---- one permutation spread over 8 adjacent lanes (lane g = threadIdx & 7 holds state word g) ----
+// A tree level with few nodes is bound by the LATENCY of one permutation (a ~14k-instruction dependent chain on
+// one lane, ~45 us); spreading the state over 8 lanes shortens the chain ~5x at ~2x the total work.  Used for
+// Merkle levels too small to fill the chip.  Linear layers via cross-lane shuffles:
+//   mat4 row i = sum(chunk) + x_i + 2 x_{(i+1)&3};  external: 2 t_i + t_{i^4};  internal: diag_g x_g + sum(all 8).
+__device__ __forceinline__ uint64_t lanes8_external(uint64_t x, int lane) {
+    using gl::add;
+    const uint64_t s1 = add(x, __shfl_xor((unsigned long long)x, 1));
+    const uint64_t s = add(s1, __shfl_xor((unsigned long long)s1, 2));
+    const uint64_t nb = __shfl((unsigned long long)x, (lane & ~3) | ((lane + 1) & 3));
+    const uint64_t t = add(add(s, x), gl::dbl(nb));
+    const uint64_t o = __shfl_xor((unsigned long long)t, 4);
+    return add(gl::dbl(t), o);
+}
+__device__ __forceinline__ uint64_t permute_lanes8(uint64_t x, const Params& p) {
+    const int lane = threadIdx.x & 63, g = lane & 7;
+    x = lanes8_external(x, lane);
+    for (int r = 0; r < ROUNDS_F / 2; r++) {
+        x = sbox7(gl::add(x, p.ext_rc[r][g]));
+        x = lanes8_external(x, lane);
+    }
+    const uint64_t dg = p.int_diag[g];
+    for (int r = 0; r < ROUNDS_P; r++) {
+        const uint64_t y = sbox7(gl::add(x, p.int_rc[r]));
+        x = g == 0 ? y : x;
+        uint64_t sum = gl::add(x, __shfl_xor((unsigned long long)x, 1));
+        sum = gl::add(sum, __shfl_xor((unsigned long long)sum, 2));
+        sum = gl::add(sum, __shfl_xor((unsigned long long)sum, 4));
+        x = gl::add(gl::mul(x, dg), sum);
+    }
+    for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
+        x = sbox7(gl::add(x, p.ext_rc[r][g]));
+        x = lanes8_external(x, lane);
+    }
+    return x;
+}
+#endif
+
 }  // namespace p2

@@ -112,27 +112,40 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
     return 0;
 }
 
-// the last <= 9 levels (<= 512 nodes in) in one workgroup: a tree top is a chain of tiny dependent launches otherwise
-__global__ void __launch_bounds__(NT) k_compress_top(const uint64_t* __restrict__ child, int levels, uint64_t* const* __restrict__ outs,
-                                                     const p2::Params* __restrict__ pp) {
+// 8 lanes per node: levels too small to fill the chip (latency-bound, see permute_lanes8)
+__global__ void __launch_bounds__(NT) k_compress8(const uint64_t* __restrict__ child, size_t n_parent, uint64_t* __restrict__ parent,
+                                                  const p2::Params* __restrict__ pp) {
     __shared__ p2::Params sp;
-    __shared__ uint64_t buf[2][4 * 512];
     for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    const size_t t = (size_t)blockIdx.x * NT + threadIdx.x, i = t >> 3;
+    const int g = threadIdx.x & 7;
+    const bool live = i < n_parent;  // whole 8-lane groups are live or idle together
+    uint64_t x = live ? child[8 * i + g] : 0;
+    x = p2::permute_lanes8(x, sp);
+    if (live && g < 4) parent[4 * i + g] = x;
+}
+
+// the last <= 8 levels (<= 256 digests in) in one workgroup of 1024 lanes = 128 nodes per pass
+static constexpr int TOP_NT = 1024, TOP_LEVELS = 8;
+__global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restrict__ child, int levels, uint64_t* const* __restrict__ outs,
+                                                         const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    __shared__ uint64_t buf[2][4 << TOP_LEVELS];
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += TOP_NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
     int n = 1 << levels;  // child digests
-    for (int i = threadIdx.x; i < 4 * n; i += NT) buf[0][i] = child[i];
+    for (int i = threadIdx.x; i < 4 * n; i += TOP_NT) buf[0][i] = child[i];
     __syncthreads();
     int cur = 0;
+    const int g = threadIdx.x & 7, slot = threadIdx.x >> 3;
     for (int l = 0; l < levels; l++) {
         const int np = n >> 1;
-        for (int i = threadIdx.x; i < np; i += NT) {
-            uint64_t s[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) s[k] = buf[cur][8 * i + k];
-            p2::permute(s, sp);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                buf[cur ^ 1][4 * i + k] = s[k];
-                outs[l][4 * i + k] = s[k];
+        if (slot < np) {  // np <= 128 = one pass; a wave is entirely inside or outside (8 nodes per wave)
+            uint64_t x = buf[cur][8 * slot + g];
+            x = p2::permute_lanes8(x, sp);
+            if (g < 4) {
+                buf[cur ^ 1][4 * slot + g] = x;
+                outs[l][4 * slot + g] = x;
             }
         }
         __syncthreads();
@@ -146,11 +159,14 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     TRY(get_params(ctx, &pp));
     const int log_rows = t->log_rows;
     int l = 1;
-    for (; l <= log_rows && (log_rows - l + 1) > 9; l++) {
+    for (; l <= log_rows && (log_rows - l + 1) > TOP_LEVELS; l++) {
         size_t np = (size_t)1 << (log_rows - l);
-        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+        if (np > ((size_t)1 << 14))
+            hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+        else
+            hipLaunchKernelGGL(k_compress8, dim3((unsigned)((np * 8 + NT - 1) / NT)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
     }
-    if (l <= log_rows) {  // levels l..log_rows: child level l-1 has 2^(log_rows-l+1) <= 512 digests
+    if (l <= log_rows) {  // levels l..log_rows: child level l-1 has 2^(log_rows-l+1) <= 256 digests
         const int rem = log_rows - l + 1;
         if (!t->top_ptrs) {
             void* p = nullptr;
@@ -160,7 +176,7 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
         uint64_t* h[16] = {nullptr};
         for (int i = 0; i < rem; i++) h[i] = t->levels[l + i];
         HIP_TRY(ctx, hipMemcpyAsync(t->top_ptrs, h, sizeof(h), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(NT), 0, st, t->levels[l - 1], rem, t->top_ptrs, pp);
+        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(TOP_NT), 0, st, t->levels[l - 1], rem, t->top_ptrs, pp);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

@@ -14,6 +14,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <map>
@@ -100,6 +103,15 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         return rc;
     };
 
+    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(st);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ceno_prover] basefold_open %-16s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     // ---- batch coefficients (pcs/mod.rs:1130-1131) ----
     tr_label(tr, "batch coeffs");
     const E2 alpha = tr_sample(tr);
@@ -142,6 +154,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
             groups[M.log_rows].mats.push_back(m);
         }
     }
+    lap("batching");
     uint64_t* msgs = out_proof;
     uint64_t* commits = out_proof + 4 * (size_t)n;
     uint64_t* finalm = out_proof + 8 * (size_t)n;
@@ -218,6 +231,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         tr->append_ext(tr->self, commits + 4 * r);
         tr->append_ext(tr->self, commits + 4 * r + 2);
     }
+    lap("commit phase");
     // ---- final message: F_m at the challenges, one row per opening point ----
     E2 total = gl::e2_zero();
     for (auto& kv : groups) {
@@ -245,6 +259,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
                 return prover_set_error(CENO_HIP_ERR_STATE, "basefold_open: folded codeword is not the encoding of the final message");
             }
     }
+    lap("final message");
     // ---- proof of work ----
     *powp = 0;
     if (pow_bits > 0) {
@@ -254,6 +269,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         if (rc) return fail(rc);
         tr_ext(tr, E2{*powp, 0});
     }
+    lap("proof of work");
     // ---- queries ----
     tr_label(tr, "query indices");
     if (n_queries == 0) {
@@ -299,6 +315,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     std::vector<uint64_t> ans(ans_words);
     if (hipMemcpyAsync(ans.data(), d_ans, ans_words * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return fail(CENO_HIP_ERR_HIP);
+    lap("query gathers");
     for (size_t q = 0; q < Q; q++) {
         uint64_t* out = qbase + q * qw;
         *out++ = qidx[q];
