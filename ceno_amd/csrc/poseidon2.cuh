@@ -93,37 +93,47 @@ GL_HD void permute(uint64_t* s, const Params& p) {
 #if defined(__HIPCC__)
 // ---- one permutation spread over 8 adjacent lanes (lane g = threadIdx & 7 holds state word g) ----
 // A tree level with few nodes is bound by the LATENCY of one permutation (a ~14k-instruction dependent chain on
-// one lane, ~45 us); spreading the state over 8 lanes shortens the chain ~5x at ~2x the total work.  Used for
-// Merkle levels too small to fill the chip.  Linear layers via cross-lane shuffles:
+// one lane, ~45 us); spreading the state over 8 lanes shortens the chain several times at ~2x the total work.
+// Used for Merkle levels too small to fill the chip.  Linear layers via cross-lane permutes:
 //   mat4 row i = sum(chunk) + x_i + 2 x_{(i+1)&3};  external: 2 t_i + t_{i^4};  internal: diag_g x_g + sum(all 8).
-__device__ __forceinline__ uint64_t lanes8_external(uint64_t x, int lane) {
+// DPP lane permutes (VALU, a few cycles) instead of ds_bpermute shuffles (~100 cycles each, dependent):
+// quad_perm [1,0,3,2] = lane^1, [2,3,0,1] = lane^2, [1,2,3,0] = next lane of the quad,
+// row_half_mirror (j -> 7-j) followed by quad_perm [3,2,1,0] (j -> j^3 inside the quad) = lane^4.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t lanes8_external(uint64_t x) {
     using gl::add;
-    const uint64_t s1 = add(x, __shfl_xor((unsigned long long)x, 1));
-    const uint64_t s = add(s1, __shfl_xor((unsigned long long)s1, 2));
-    const uint64_t nb = __shfl((unsigned long long)x, (lane & ~3) | ((lane + 1) & 3));
+    const uint64_t s1 = add(x, dpp64<0xB1>(x));
+    const uint64_t s = add(s1, dpp64<0x4E>(s1));
+    const uint64_t nb = dpp64<0x39>(x);
     const uint64_t t = add(add(s, x), gl::dbl(nb));
-    const uint64_t o = __shfl_xor((unsigned long long)t, 4);
+    const uint64_t o = dpp64<0x1B>(dpp64<0x141>(t));
     return add(gl::dbl(t), o);
 }
 __device__ __forceinline__ uint64_t permute_lanes8(uint64_t x, const Params& p) {
-    const int lane = threadIdx.x & 63, g = lane & 7;
-    x = lanes8_external(x, lane);
+    const int g = threadIdx.x & 7;
+    x = lanes8_external(x);
     for (int r = 0; r < ROUNDS_F / 2; r++) {
         x = sbox7(gl::add(x, p.ext_rc[r][g]));
-        x = lanes8_external(x, lane);
+        x = lanes8_external(x);
     }
     const uint64_t dg = p.int_diag[g];
     for (int r = 0; r < ROUNDS_P; r++) {
         const uint64_t y = sbox7(gl::add(x, p.int_rc[r]));
         x = g == 0 ? y : x;
-        uint64_t sum = gl::add(x, __shfl_xor((unsigned long long)x, 1));
-        sum = gl::add(sum, __shfl_xor((unsigned long long)sum, 2));
-        sum = gl::add(sum, __shfl_xor((unsigned long long)sum, 4));
+        uint64_t sum = gl::add(x, dpp64<0xB1>(x));
+        sum = gl::add(sum, dpp64<0x4E>(sum));
+        sum = gl::add(sum, dpp64<0x141>(sum));  // every lane of a quad holds the quad sum: the mirror lane is in the other quad
         x = gl::add(gl::mul(x, dg), sum);
     }
     for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
         x = sbox7(gl::add(x, p.ext_rc[r][g]));
-        x = lanes8_external(x, lane);
+        x = lanes8_external(x);
     }
     return x;
 }
