@@ -170,3 +170,168 @@ def sharded_sumcheck_prove(engine: ShardEngine, n_total: int, degree: int, trans
     tables = [np.ascontiguousarray(allv[:, j, :]) for j in range(k)]
     fin = engine.tail(tables, degree, transcript, msgs, chal, n_local)
     return msgs, chal, fin
+
+
+# ==================================================================================================
+# Mixed-size (front-loaded) batched sumcheck across ranks — SURVEY.md §8(e), BASELINE config #4
+# ==================================================================================================
+"""
+`prove_batched_main_constraints` batches chips of different sizes in ONE sumcheck (front-load rule,
+ceno_zkvm/src/scheme/verifier.rs:180-238): an MLE with n' < n variables is f(x_0..x_{n'-1}) * prod_{i>=n'} x_i.
+The round polynomial is a plain sum over the indices of each size class, so every class can be split over
+the ranks along the TOP bits of ITS OWN hypercube, independently of the other classes:
+
+  * sharded class (n' - log2(world) local variables per rank): rounds 0..n'-log2(world)-1 are local folds and
+    partial messages; then ONE all-gather of the k per-rank values turns the class into `world`-element
+    tables, replicated on every rank, which continue as a replicated class;
+  * replicated class (small chips: every rank holds the whole table and runs the same rounds): its message
+    is added ONCE after the cross-rank sum.  Its engine is begun with `max_num_vars` = the rounds that are
+    left, so the engine itself applies the front-load scalars once the class runs out of variables.
+
+Per round: every live sharded class leaves d partial evaluations, ONE all-gather of (#live classes * d) ext
+per rank, modular sum on the host, replicated transcript.  Nothing else crosses ranks.
+"""
+
+
+class BatchedEngine:
+    """one size class on one rank (product: HipBatchedEngine over the C ABI; tests: the CPU oracle)"""
+
+    def round(self, challenge) -> np.ndarray:  # (d, 2) host
+        raise NotImplementedError
+
+    def finish(self, last_challenge) -> np.ndarray:  # (k, 2) pure evaluations
+        raise NotImplementedError
+
+    def free(self):
+        pass
+
+
+class HipBatchedEngine(BatchedEngine):
+    def __init__(self, dev, mles, coeffs, terms, max_num_vars, degree, stream=None):
+        from .api import Sumcheck
+
+        self.sc = Sumcheck(dev, mles, coeffs, terms, max_num_vars, degree, stream=stream)
+
+    def round(self, challenge):
+        return self.sc.round(challenge)
+
+    def finish(self, last_challenge):
+        return self.sc.finish(last_challenge)
+
+    def free(self):
+        self.sc.free()
+
+
+def hip_engine_factory(dev, stream=None):
+    """factory(tables_or_mles, coeffs, terms, max_num_vars, degree): numpy tables are uploaded, Mle handles borrowed"""
+
+    def make(tables, coeffs, terms, max_num_vars, degree):
+        mles = [t if hasattr(t, "h") else dev.upload(np.ascontiguousarray(t)) for t in tables]
+        return HipBatchedEngine(dev, mles, coeffs, terms, max_num_vars, degree, stream)
+
+    return make
+
+
+def _gather_rows(dist, local: np.ndarray, world: int) -> np.ndarray:
+    """all-gather a small (m, 2) uint64 array -> (world, m, 2)"""
+    import torch
+
+    flat = np.ascontiguousarray(local, dtype=np.uint64).reshape(-1)
+    if world == 1 or dist is None:
+        return flat.reshape(1, -1, 2)
+    t = torch.from_numpy(flat.view(np.int64).copy())
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+        out = torch.empty(world * t.numel(), dtype=torch.int64, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().view(np.uint64).reshape(world, -1, 2)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return np.stack([o.numpy().view(np.uint64).reshape(-1, 2) for o in outs])
+
+
+def _sum_mod(rows: np.ndarray) -> np.ndarray:
+    """(a, m, 2) -> (m, 2) modular sum over axis 0"""
+    a, m, _ = rows.shape
+    out = np.zeros((m, 2), dtype=np.uint64)
+    for j in range(m):
+        out[j, 0] = sum(int(rows[g, j, 0]) for g in range(a)) % P
+        out[j, 1] = sum(int(rows[g, j, 1]) for g in range(a)) % P
+    return out
+
+
+def sharded_batched_sumcheck_prove(factory, classes, n_total: int, degree: int, transcript, dist=None, world: int = 1,
+                                   rank: int = 0):
+    """classes: list of dicts
+         {"tables": [k local tables or Mle handles], "num_vars": GLOBAL number of variables of the class,
+          "sharded": bool, "coeffs": (T, 2) uint64, "terms": [[class-local MLE ids]]}
+       A sharded class holds, on rank g, indices [g * 2^(nv - log2 world), ...) of each of its tables; a replicated
+       class holds the whole tables on every rank.  All factors of a term belong to one class (reference rule,
+       gkr_iop/src/gkr/layer/gpu/utils.rs:54-63).
+       Returns (msgs (n_total, d, 2), challenges (n_total, 2), [final evals (k_c, 2) per class]) — identical on
+       every rank and equal to the single-prover proof of the unsharded plan."""
+    assert world & (world - 1) == 0
+    log_w = world.bit_length() - 1
+    transcript.append_label(int(n_total).to_bytes(8, "little"))
+    transcript.append_label(int(degree).to_bytes(8, "little"))
+    msgs = np.zeros((n_total, degree, 2), dtype=np.uint64)
+    chal = np.zeros((n_total, 2), dtype=np.uint64)
+    finals = [None] * len(classes)
+    # segment = [class id, engine, kind, first round, last sharded round (exclusive)]
+    segs = []
+    pending_tail = {}  # class id -> local values (k, 2) of a sharded class that has no local variable at all
+    for ci, c in enumerate(classes):
+        nv = int(c["num_vars"])
+        assert 0 < nv <= n_total or (nv == 0 and not c["sharded"])
+        if c["sharded"] and world > 1:
+            nv_local = nv - log_w
+            assert nv_local >= 0, "a sharded class needs at least log2(world) variables"
+            if nv_local == 0:
+                vals = np.stack([np.asarray(t.download() if hasattr(t, "download") else t, dtype=np.uint64).reshape(-1, 2)[0]
+                                 for t in c["tables"]])
+                pending_tail[ci] = vals
+            else:
+                segs.append({"ci": ci, "eng": factory(c["tables"], c["coeffs"], c["terms"], nv_local, degree), "sharded": True,
+                             "start": 0, "end": nv_local})
+        else:
+            segs.append({"ci": ci, "eng": factory(c["tables"], c["coeffs"], c["terms"], n_total, degree), "sharded": False,
+                         "start": 0, "end": n_total})
+
+    def start_tail(ci, local_vals, first_round):
+        """per-rank values of a sharded class -> world-sized replicated tables from round `first_round` on"""
+        allv = _gather_rows(dist, local_vals, world)  # (world, k, 2)
+        k = allv.shape[1]
+        tables = [np.ascontiguousarray(allv[:, j, :]) for j in range(k)]
+        c = classes[ci]
+        if first_round == n_total:  # nothing left to bind (cannot happen for world > 1)
+            finals[ci] = allv[0]
+            return
+        segs.append({"ci": ci, "eng": factory(tables, c["coeffs"], c["terms"], n_total - first_round, degree), "sharded": False,
+                     "start": first_round, "end": n_total})
+
+    for ci, vals in sorted(pending_tail.items()):
+        start_tail(ci, vals, 0)
+    ch = None
+    for i in range(n_total):
+        live_sh = [s for s in segs if s["sharded"] and s["start"] <= i < s["end"]]
+        live_rp = [s for s in segs if not s["sharded"] and s["start"] <= i < s["end"]]
+        msg = np.zeros((degree, 2), dtype=np.uint64)
+        if live_sh:
+            parts = np.concatenate([s["eng"].round(None if i == s["start"] else ch) for s in live_sh])  # (#live * d, 2)
+            msg = _sum_mod(_gather_rows(dist, parts, world).reshape(world * len(live_sh), degree, 2))
+        for s in live_rp:
+            m = s["eng"].round(None if i == s["start"] else ch)
+            msg = _sum_mod(np.stack([msg, m]))
+        ch = _absorb_round(transcript, msg)
+        msgs[i] = msg
+        chal[i] = ch
+        for s in live_sh:
+            if s["end"] == i + 1:  # last local variable bound: one value per table per rank
+                fin_local = s["eng"].finish(ch)
+                s["eng"].free()
+                start_tail(s["ci"], fin_local, i + 1)
+    for s in segs:
+        if not s["sharded"]:
+            finals[s["ci"]] = s["eng"].finish(ch)
+            s["eng"].free()
+    return msgs, chal, finals

@@ -52,9 +52,80 @@ class OracleShardEngine(cdist.ShardEngine):
         return np.stack([t[0] for t in tabs])
 
 
+class OracleBatchedEngine(cdist.BatchedEngine):
+    """round-granular stand-in for the device engine: the message of engine round j is the FIRST message of a
+    fresh oracle sumcheck over the tables folded so far (exhausted tables carry their front-load tail product)"""
+
+    def __init__(self, tables, coeffs, terms, max_num_vars, degree):
+        self.tabs = [np.ascontiguousarray(np.asarray(t, dtype=np.uint64).reshape(-1, 2)) for t in tables]
+        self.pure = [None] * len(self.tabs)
+        self.coeffs, self.terms, self.left, self.deg = np.asarray(coeffs, dtype=np.uint64), terms, max_num_vars, degree
+
+    def _bind(self, ch):
+        for j, t in enumerate(self.tabs):
+            if t.shape[0] > 1:
+                self.tabs[j] = po.mle_fix_variable(t, ch)
+                if self.tabs[j].shape[0] == 1:
+                    self.pure[j] = self.tabs[j][0].copy()
+            else:
+                if self.pure[j] is None:
+                    self.pure[j] = t[0].copy()
+                self.tabs[j] = np.array([po.e2_mul((int(t[0, 0]), int(t[0, 1])), (int(ch[0]), int(ch[1])))], dtype=np.uint64)
+        self.left -= 1
+
+    def round(self, challenge):
+        if challenge is not None:
+            self._bind(challenge)
+        msgs, _, _ = po.sumcheck_prove(self.tabs, self.coeffs, self.terms, self.left, self.deg, po.StubTranscript(1))
+        return msgs[0]
+
+    def finish(self, last_challenge):
+        if last_challenge is not None:
+            self._bind(last_challenge)
+        return np.stack([self.pure[j] if self.pure[j] is not None else t[0] for j, t in enumerate(self.tabs)])
+
+
+def batched_case(n_total):
+    """global description of a mixed-size plan: (num_vars, k tables, terms) per class; tables from SplitMix streams"""
+    spec = [(n_total, 3, [[0, 1, 2], [0, 1]]), (n_total - 2, 2, [[0, 1], [1]]), (2, 2, [[0, 1, 1]]), (n_total - 1, 1, [[0]])]
+    classes = []
+    for ci, (nv, k, terms) in enumerate(spec):
+        tabs = [po.fill_splitmix(2 << nv, 0xBA7C + 16 * ci + j, 0).reshape(-1, 2) for j in range(k)]
+        coeffs = po.fill_splitmix(2 * len(terms), 0xC0EF + ci, 0).reshape(-1, 2)
+        classes.append({"num_vars": nv, "tables": tabs, "terms": terms, "coeffs": coeffs})
+    return classes
+
+
+def main_batched(out_dir, n_total):
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    log_w = world.bit_length() - 1
+    classes = []
+    for c in batched_case(n_total):
+        sharded = c["num_vars"] >= log_w + 1 and c["num_vars"] != 2  # the 2-variable class stays replicated
+        if c["num_vars"] == n_total - 1:
+            sharded = True
+        if sharded:
+            m = 1 << (c["num_vars"] - log_w)
+            tabs = [t[rank * m:(rank + 1) * m] for t in c["tables"]]
+        else:
+            tabs = c["tables"]
+        classes.append(dict(c, tables=tabs, sharded=sharded))
+    factory = lambda tables, coeffs, terms, max_nv, degree: OracleBatchedEngine(tables, coeffs, terms, max_nv, degree)
+    msgs, chal, fins = cdist.sharded_batched_sumcheck_prove(factory, classes, n_total, 3, prover.Transcript.stub(0xF5), dist=dist,
+                                                          world=world, rank=rank)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=msgs, chal=chal, fin=np.concatenate(fins))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     import torch.distributed as dist
 
+    if len(sys.argv) > 3 and sys.argv[3] == "batched":
+        return main_batched(sys.argv[1], int(sys.argv[2]))
     out_dir = sys.argv[1]
     n_local = int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

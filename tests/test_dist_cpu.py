@@ -44,3 +44,32 @@ def test_sharded_sumcheck_matches_unsharded(world, n_local):
         assert np.array_equal(res[r]["msgs"], omsgs)
         assert np.array_equal(res[r]["chal"], ochal)
         assert np.array_equal(res[r]["fin"], ofin)
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 6), (4, 5)])
+def test_sharded_batched_mixed_size_sumcheck_matches_unsharded(world, n_total):
+    """front-loaded classes of different sizes, sharded along their own top bits or replicated"""
+    from ceno_amd import build
+    from tests.dist_worker import batched_case
+
+    build.build_all()
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29650 + world * 7 + n_total), WORLD_SIZE=str(world))
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n_total), "batched"], env=e))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
+    tables, coeffs, terms, off = [], [], [], 0
+    for c in batched_case(n_total):
+        tables += c["tables"]
+        coeffs.append(c["coeffs"])
+        terms += [[off + j for j in t] for t in c["terms"]]
+        off += len(c["tables"])
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, np.concatenate(coeffs), terms, n_total, 3, po.StubTranscript(0xF5))
+    for r in range(world):
+        assert np.array_equal(res[r]["msgs"], omsgs)
+        assert np.array_equal(res[r]["chal"], ochal)
+        assert np.array_equal(res[r]["fin"], ofin)

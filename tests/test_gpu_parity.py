@@ -534,3 +534,74 @@ def test_large_eq_and_evaluate_consistency(dev):
     eq = dev.eq_build(r)
     assert eq.evaluate(rp) == po.eq_eval(r, rp)
     eq.free()
+
+
+def test_sharded_batched_sumcheck_hip_engine_virtual_ranks(dev):
+    """SURVEY §8(e) mixed-size sharding with the REAL device engine: `world` virtual ranks = threads of this process,
+    each with its own stream and sumcheck handles, exchanging partials through an in-process all-gather.  The
+    result must equal the single-prover proof of the unsharded plan (oracle)."""
+    import threading
+
+    from ceno_amd import dist as cdist
+    from ceno_amd import prover
+    from tests.dist_worker import batched_case
+
+    world, n_total = 4, 9
+    log_w = 2
+
+    class ThreadDist:
+        def __init__(self, world):
+            self.world, self.slots, self.bar = world, [None] * world, threading.Barrier(world)
+
+        def for_rank(self, rank):
+            outer = self
+
+            class D:
+                def get_backend(self):
+                    return "threads"
+
+                def all_gather(self, outs, t):
+                    outer.slots[rank] = t.clone()
+                    outer.bar.wait()
+                    for g in range(outer.world):
+                        outs[g].copy_(outer.slots[g])
+                    outer.bar.wait()
+
+            return D()
+
+    td = ThreadDist(world)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            stream = dev.stream_create()
+            classes = []
+            for c in batched_case(n_total):
+                sharded = c["num_vars"] != 2
+                m = 1 << (c["num_vars"] - log_w) if sharded else None
+                tabs = [t[rank * m:(rank + 1) * m] for t in c["tables"]] if sharded else c["tables"]
+                classes.append(dict(c, tables=tabs, sharded=sharded))
+            results[rank] = cdist.sharded_batched_sumcheck_prove(cdist.hip_engine_factory(dev, stream), classes, n_total, 3,
+                                                                 prover.Transcript.stub(0xF5), dist=td.for_rank(rank), world=world, rank=rank)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+            td.bar.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    tables, coeffs, terms, off = [], [], [], 0
+    for c in batched_case(n_total):
+        tables += c["tables"]
+        coeffs.append(c["coeffs"])
+        terms += [[off + j for j in t] for t in c["terms"]]
+        off += len(c["tables"])
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, np.concatenate(coeffs), terms, n_total, 3, po.StubTranscript(0xF5))
+    for r in range(world):
+        msgs, chal, fins = results[r]
+        assert np.array_equal(msgs, omsgs)
+        assert np.array_equal(chal, ochal)
+        assert np.array_equal(np.concatenate(fins), ofin)
