@@ -335,3 +335,64 @@ def sharded_batched_sumcheck_prove(factory, classes, n_total: int, degree: int, 
             finals[s["ci"]] = s["eng"].finish(ch)
             s["eng"].free()
     return msgs, chal, finals
+
+
+# ==================================================================================================
+# Trace commitment across ranks — SURVEY.md §8(e) "Commit path"
+# ==================================================================================================
+def sharded_commit(dev, local_columns: np.ndarray, log_rows: int, log_blowup: int, dist=None, world: int = 1, rank: int = 0,
+                   stream=None):
+    """Column-parallel RS encoding + row-sharded Merkle leaves.
+
+    `local_columns`: this rank's columns of the (padded) trace, shape (w_local, 2^log_rows) — columns are
+    independent, so every rank encodes its own (NTT, no exchange).  A Merkle leaf hashes one codeword ROW across ALL
+    columns and the sponge is sequential along the row, so the codeword is re-sharded by rows with ONE all-to-all
+    (the only step of the whole path whose cost is xGMI bandwidth: (world-1)/world of the codeword bytes leave each
+    rank); rank g then owns rows [g R/world, (g+1) R/world) = the sub-tree under node g of level log2(world) from the
+    top.  The `world` sub-tree roots are all-gathered and the top levels finished on every rank.
+    Returns {"root", "subtree" (api.Merkle over the local rows), "subtree_roots" (world, 4), "codeword_rows" (tensor:
+    (w_total, R/world) column-major int64 view of the local rows), "widths"}.  Equal to the single-device commitment."""
+    import torch
+
+    from . import api
+
+    assert world & (world - 1) == 0
+    log_w = world.bit_length() - 1
+    cols = np.ascontiguousarray(local_columns, dtype=np.uint64)
+    w_local, rows = cols.shape
+    assert rows == 1 << log_rows and log_rows + log_blowup >= log_w
+    R = rows << log_blowup
+    device = f"cuda:{dev.device}"
+    d_cols = torch.from_numpy(cols.view(np.int64)).to(device)
+    d_cw = torch.empty(w_local * R, dtype=torch.int64, device=device)
+    api.rs_encode(dev, d_cols.data_ptr(), log_rows, w_local, log_blowup, d_cw.data_ptr(), stream)
+    dev.sync(stream)
+    if world == 1:
+        widths = [w_local]
+        recv = d_cw
+    else:
+        wt = torch.tensor([w_local], dtype=torch.int64, device=device)
+        wl = [torch.empty_like(wt) for _ in range(world)]
+        dist.all_gather(wl, wt)
+        widths = [int(x.item()) for x in wl]
+        rl = R // world
+        # destination h gets rows [h*rl, (h+1)*rl) of each of my columns, column-major
+        send = d_cw.view(w_local, world, rl).permute(1, 0, 2).contiguous()
+        outs = [torch.empty(widths[g] * rl, dtype=torch.int64, device=device) for g in range(world)]
+        dist.all_to_all(outs, [send[h].reshape(-1) for h in range(world)])
+        recv = torch.cat(outs)  # source ranks in order = global column order
+    w_total = sum(widths)
+    rl = R // world
+    sub = api.Merkle(dev, recv.data_ptr(), log_rows + log_blowup - log_w, w_total, stream)
+    sub_root = sub.root(stream)
+    if world == 1:
+        return {"root": sub_root, "subtree": sub, "subtree_roots": sub_root.reshape(1, 4), "codeword_rows": recv, "widths": widths}
+    roots = _gather_rows(dist, sub_root.reshape(2, 2), world).reshape(world, 4)
+    level = torch.from_numpy(roots.view(np.int64).copy()).to(device)
+    while level.shape[0] > 1:  # top log2(world) levels: node = permute(left || right)[0..4)
+        st = level.reshape(-1, 8).contiguous()
+        api.poseidon2_permute(dev, st.data_ptr(), st.shape[0], stream)
+        dev.sync(stream)
+        level = st[:, :4].contiguous()
+    root = level.cpu().numpy().view(np.uint64).reshape(4)
+    return {"root": root, "subtree": sub, "subtree_roots": roots, "codeword_rows": recv, "widths": widths}
