@@ -28,6 +28,9 @@ def main():
     shutil.copy(glob.glob(trace + "/*kernel_stats.csv")[0], out + "_kernel_stats.csv")
     f, nf = counter_sum(fdir, "FETCH_SIZE")
     w, nw = counter_sum(wdir, "WRITE_SIZE")
+    if n_sc == 0:  # one k_dense launch per round: nv = 26 rounds per sumcheck
+        n_sc = nf // 26
+        assert nf == 26 * n_sc and nw == nf, (nf, nw)
     fetch_b = f * 1024 * 2  # gfx950 correction
     write_b = w * 1024
     res = {
