@@ -30,7 +30,7 @@ SEED0 = 0xCE10
 TR_SEED = 0xF5
 
 
-def cpu_baseline(nv: int = 24):
+def cpu_baseline(nv: int = 25):
     """the oracle's OpenMP fused sumcheck (a port, not the Rust/rayon reference binary) on the host cores,
     in a child process with a clean OpenMP environment"""
     import subprocess

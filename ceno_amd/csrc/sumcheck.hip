@@ -546,6 +546,104 @@ __global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pa
     epilogue<D, TNT>(acc, ep, smem, s_flag);
 }
 
+// ------------------------------------------------------------------------------------------------
+// term-parallel generic round for small / mid-size rounds.  k_fused gives one pair to one lane, which then walks the
+// whole plan serially: for a 33-term degree-4 layer that is ~400 dependent ext multiplies = 120 us per round however
+// small the round is.  Here a workgroup owns a tile of 2^tp_log pairs: phase 1 spreads the folds (MLE x pair) over the
+// lanes and stages (f(1), delta) in LDS, phase 2 spreads (term x pair) over the lanes; a term of a group with common
+// factors multiplies them in itself (the sum over terms is linear).  Rounds become 10-20 us.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int tp_log, size_t pairs, E2 r, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int TP = 1 << tp_log;
+    E2* stage = reinterpret_cast<E2*>(dyn);                               // [n_mles][2][TP]
+    E2* smem = stage + ((size_t)n_mles * 2 << tp_log);                    // [(NT/64) * D]
+    unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // 3 words + flag
+    int* s_flag = reinterpret_cast<int*>(s_chal + 4);
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) return;
+    }
+    const E2Pre rp = e2_pre(r);
+    const bool fold = pl.use_out != 0;
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const size_t n_tiles = (pairs + TP - 1) >> tp_log;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t p0 = tile << tp_log;
+        for (int idx = threadIdx.x; idx < (n_mles << tp_log); idx += NT) {
+            const int m = idx >> tp_log, q = idx & (TP - 1);
+            const size_t p = p0 + q;
+            if (p >= pairs) continue;
+            const MleSlot sl = pl.slots[m];
+            E2 lo, hi;
+            if (fold) {
+                if (sl.in_ext) {
+                    const uint64_t* qq = sl.in + 8 * p;
+                    const E2 a0 = ld_e2(qq), a1 = ld_e2(qq + 2), a2 = ld_e2(qq + 4), a3 = ld_e2(qq + 6);
+                    lo = a0 + e2_mul_pre(rp, a1 - a0);
+                    hi = a2 + e2_mul_pre(rp, a3 - a2);
+                } else {
+                    const uint64_t* qq = sl.in + 4 * p;
+                    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(qq);
+                    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(qq + 2);
+                    const E2 t0 = e2_mul_base(r, sub(v0.y, v0.x)), t1 = e2_mul_base(r, sub(v1.y, v1.x));
+                    lo = E2{add(t0.c0, v0.x), t0.c1};
+                    hi = E2{add(t1.c0, v1.x), t1.c1};
+                }
+                st_e2(sl.out + 4 * p, lo);
+                st_e2(sl.out + 4 * p + 2, hi);
+            } else if (sl.in_ext) {
+                lo = ld_e2(sl.in + 4 * p);
+                hi = ld_e2(sl.in + 4 * p + 2);
+            } else {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
+                lo = E2{v.x, 0};
+                hi = E2{v.y, 0};
+            }
+            stage[((size_t)(2 * m) << tp_log) + q] = hi;           // f(1)
+            stage[((size_t)(2 * m + 1) << tp_log) + q] = hi - lo;  // delta
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < (n_flat << tp_log); idx += NT) {
+            const int ti = idx >> tp_log, q = idx & (TP - 1);
+            if (p0 + q >= pairs) continue;
+            int g = 0;
+            while ((int)pl.group_term_off[g + 1] <= ti) g++;
+            const uint32_t term = pl.group_terms[ti];
+            const E2 c = pl.coeffs[term];
+            E2 pr[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) pr[t] = c;
+            for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                const uint32_t m = pl.term_idx[k];
+                E2 x = stage[((size_t)(2 * m) << tp_log) + q];
+                const E2 delta = stage[((size_t)(2 * m + 1) << tp_log) + q];
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    pr[t] = pr[t] * x;
+                    x = x + delta;
+                }
+            }
+            for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
+                const uint32_t m = pl.common_idx[k];
+                E2 x = stage[((size_t)(2 * m) << tp_log) + q];
+                const E2 delta = stage[((size_t)(2 * m + 1) << tp_log) + q];
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    pr[t] = pr[t] * x;
+                    x = x + delta;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
+        }
+        __syncthreads();  // the stage is reused by the next tile
+    }
+    epilogue<D, NT>(acc, ep, smem, s_flag);
+}
+
 // gather element 0 of every listed table into out[i] (final evaluations)
 struct GatherArgs {
     const MleSlot* slots;
@@ -590,6 +688,7 @@ struct ScClass {
     uint32_t *d_term_off = nullptr, *d_term_idx = nullptr;
     E2* d_coeffs = nullptr;
     int n_groups = 0;
+    int n_flat = 0;           // entries of group_terms
     uint32_t part_off = 0;    // offset (E2 units) into partials
 };
 
@@ -748,6 +847,42 @@ static void launch_fused(int d, int tnt, const DevPlan& pl, int n_mles, size_t p
     }
 }
 
+// tile geometry of k_tile: enough (term x pair) / (MLE x pair) items to occupy the 256 lanes of a workgroup
+static int tile_log(size_t n_flat, size_t n_mles, size_t pairs) {
+    const size_t per_pair = std::max<size_t>(1, std::min(n_flat, 2 * n_mles));
+    int l = 0;
+    while (l < 6 && ((size_t)per_pair << l) < 256) l++;
+    while (l > 0 && ((size_t)1 << l) > pairs) l--;
+    while (l > 0 && ((n_mles * 2) << l) * sizeof(E2) > 48 * 1024) l--;
+    return l;
+}
+static bool tile_eligible(size_t n_mles, size_t pairs) {
+    static int v = [] {
+        const char* e = getenv("CENO_HIP_TILE");  // 0 restores the one-lane-per-pair kernel (A/B measurements)
+        return e ? atoi(e) : 1;
+    }();
+    return v != 0 && pairs <= FUSED_MAX_PAIRS && n_mles <= 1024;
+}
+template <int D>
+static void launch_tile_d(const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
+    const int l = tile_log((size_t)n_flat, (size_t)n_mles, pairs);
+    const size_t lds = (((size_t)n_mles * 2 << l) + (NT / 64) * D) * sizeof(E2) + 64;
+    const size_t tiles = (pairs + ((size_t)1 << l) - 1) >> l;
+    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)std::min<size_t>(tiles, MAXB)), dim3(NT), lds, st, pl, n_mles, n_flat, l, pairs, r, ep);
+}
+static void launch_tile(int d, const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
+    switch (d) {
+    case 1: launch_tile_d<1>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 2: launch_tile_d<2>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 3: launch_tile_d<3>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 4: launch_tile_d<4>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 5: launch_tile_d<5>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 6: launch_tile_d<6>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    case 7: launch_tile_d<7>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    default: launch_tile_d<8>(pl, n_mles, n_flat, pairs, r, ep, st); break;
+    }
+}
+
 // grid for `pairs` work items: enough blocks to fill 256 CUs x 8, at least 1
 static unsigned sc_grid(size_t pairs) {
     static const unsigned cap = getenv("CENO_HIP_MAXB") ? (unsigned)atoi(getenv("CENO_HIP_MAXB")) : MAXB;
@@ -902,6 +1037,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
             c_off.push_back((uint32_t)c_idx.size());
         }
         cl.n_groups = (int)g_term_off.size() - 1;
+        cl.n_flat = (int)g_terms.size();
         int rc = 0;
         plan_offs.push_back(PlanOff{append(g_term_off.data(), g_term_off.size() * 4), append(g_terms.data(), g_terms.size() * 4),
                                     append(c_off.data(), c_off.size() * 4), append(c_idx.data(), c_idx.size() * 4),
@@ -1119,7 +1255,9 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
             pl.term_off = cl.d_term_off;
             pl.term_idx = cl.d_term_idx;
             const int tnt = fused_tnt(k, pairs);
-            if (tnt) {
+            if (tile_eligible(k, pairs)) {
+                launch_tile(sc->d, pl, (int)k, cl.n_flat, pairs, e2_zero(), ep, sc->st);
+            } else if (tnt) {
                 launch_fused(sc->d, tnt, pl, (int)k, pairs, e2_zero(), ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
             } else {
                 if (i > 0)
@@ -1269,8 +1407,9 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
             prof_begin(ctx, sc->st);
-            const int tnt = cl.terms.empty() ? 0 : fused_tnt(cl.mles.size(), pairs);
-            if (i > 0 && tnt == 0)
+            const bool tile = !cl.terms.empty() && tile_eligible(cl.mles.size(), pairs);
+            const int tnt = cl.terms.empty() || tile ? 0 : fused_tnt(cl.mles.size(), pairs);
+            if (i > 0 && tnt == 0 && !tile)
                 hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots,
                                    2 * pairs, r, (const Bcast*)nullptr, 0ull);
             if (!cl.terms.empty()) {
@@ -1285,7 +1424,8 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 pl.coeffs = cl.d_coeffs;
                 pl.term_off = cl.d_term_off;
                 pl.term_idx = cl.d_term_idx;
-                if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
+                if (tile) launch_tile(d, pl, (int)cl.mles.size(), cl.n_flat, pairs, r, ep, sc->st);
+                else if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
                 else launch_accum(d, pl, pairs, ep, grid, sc->st);
                 first = false;
             }
