@@ -384,6 +384,35 @@ __device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t
     }
 }
 
+// evaluations at points 1..D of one factor's pair, multiplied into the running products of a term / a group:
+// base-field tables (round 0 reads the witness columns as they are) stay in the base field — one 64-bit multiply per
+// point instead of an extension multiply — and are folded into the extension product once per term.
+template <int D>
+__device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_t p, E2 (&pe)[D], bool& has_e, uint64_t (&pb)[D], bool& has_b) {
+    if (!use_out && !sl.in_ext) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
+        const uint64_t delta = sub(v.y, v.x);
+        uint64_t x = v.y;
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pb[t] = has_b ? mul(pb[t], x) : x;
+            x = add(x, delta);
+        }
+        has_b = true;
+    } else {
+        E2 lo, hi;
+        load_pair(sl, use_out, p, lo, hi);
+        const E2 delta = hi - lo;
+        E2 x = hi;
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pe[t] = has_e ? pe[t] * x : x;
+            x = x + delta;
+        }
+        has_e = true;
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * D];
@@ -405,17 +434,15 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                 const uint32_t term = pl.group_terms[ti];
                 const E2 c = pl.coeffs[term];
                 E2 pr[D];
+                uint64_t pb[D];
 #pragma unroll
                 for (int t = 0; t < D; t++) pr[t] = c;
-                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
-                    E2 lo, hi;
-                    load_pair(pl.slots[pl.term_idx[k]], pl.use_out, p, lo, hi);
-                    E2 delta = hi - lo, x = hi;
+                bool has_e = true, has_b = false;  // the coefficient seeds the extension product
+                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
+                    mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
+                if (has_b) {
 #pragma unroll
-                    for (int t = 0; t < D; t++) {
-                        pr[t] = pr[t] * x;
-                        x = x + delta;
-                    }
+                    for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
@@ -423,18 +450,16 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
             const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
             if (ce > cb) {
                 E2 cm[D];
-                for (uint32_t k = cb; k < ce; k++) {
-                    E2 lo, hi;
-                    load_pair(pl.slots[pl.common_idx[k]], pl.use_out, p, lo, hi);
-                    E2 delta = hi - lo, x = hi;
+                uint64_t cmb[D];
+                bool has_e = false, has_b = false;
+                for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
 #pragma unroll
-                    for (int t = 0; t < D; t++) {
-                        cm[t] = (k == cb) ? x : cm[t] * x;
-                        x = x + delta;
-                    }
+                for (int t = 0; t < D; t++) {
+                    E2 v = inner[t];
+                    if (has_e) v = cm[t] * v;
+                    if (has_b) v = e2_mul_base(v, cmb[t]);
+                    acc[t] = acc[t] + v;
                 }
-#pragma unroll
-                for (int t = 0; t < D; t++) acc[t] = acc[t] + cm[t] * inner[t];
             } else {
 #pragma unroll
                 for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
@@ -549,16 +574,15 @@ __global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pa
 // ------------------------------------------------------------------------------------------------
 // term-parallel generic round for small / mid-size rounds.  k_fused gives one pair to one lane, which then walks the
 // whole plan serially: for a 33-term degree-4 layer that is ~400 dependent ext multiplies = 120 us per round however
-// small the round is.  Here a workgroup owns a tile of 2^tp_log pairs: phase 1 spreads the folds (MLE x pair) over the
+// small the round is.  Here a workgroup owns a tile of TP pairs: phase 1 spreads the folds (MLE x pair) over the
 // lanes and stages (f(1), delta) in LDS, phase 2 spreads (term x pair) over the lanes; a term of a group with common
 // factors multiplies them in itself (the sum over terms is linear).  Rounds become 10-20 us.
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int tp_log, size_t pairs, E2 r, Epilogue ep) {
+__global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int TP, size_t pairs, E2 r, Epilogue ep) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    const int TP = 1 << tp_log;
     E2* stage = reinterpret_cast<E2*>(dyn);                               // [n_mles][2][TP]
-    E2* smem = stage + ((size_t)n_mles * 2 << tp_log);                    // [(NT/64) * D]
+    E2* smem = stage + (size_t)n_mles * 2 * TP;                    // [(NT/64) * D]
     unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // 3 words + flag
     int* s_flag = reinterpret_cast<int*>(s_chal + 4);
     if (ep.wait_seq != 0) {
@@ -569,11 +593,11 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
     E2 acc[D];
 #pragma unroll
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
-    const size_t n_tiles = (pairs + TP - 1) >> tp_log;
+    const size_t n_tiles = (pairs + TP - 1) / TP;
     for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const size_t p0 = tile << tp_log;
-        for (int idx = threadIdx.x; idx < (n_mles << tp_log); idx += NT) {
-            const int m = idx >> tp_log, q = idx & (TP - 1);
+        const size_t p0 = tile * TP;
+        for (int idx = threadIdx.x; idx < n_mles * TP; idx += NT) {
+            const int m = idx / TP, q = idx - m * TP;
             const size_t p = p0 + q;
             if (p >= pairs) continue;
             const MleSlot sl = pl.slots[m];
@@ -602,12 +626,12 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
                 lo = E2{v.x, 0};
                 hi = E2{v.y, 0};
             }
-            stage[((size_t)(2 * m) << tp_log) + q] = hi;           // f(1)
-            stage[((size_t)(2 * m + 1) << tp_log) + q] = hi - lo;  // delta
+            stage[(size_t)(2 * m) * TP + q] = hi;           // f(1)
+            stage[(size_t)(2 * m + 1) * TP + q] = hi - lo;  // delta
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < (n_flat << tp_log); idx += NT) {
-            const int ti = idx >> tp_log, q = idx & (TP - 1);
+        for (int idx = threadIdx.x; idx < n_flat * TP; idx += NT) {
+            const int ti = idx / TP, q = idx - ti * TP;
             if (p0 + q >= pairs) continue;
             int g = 0;
             while ((int)pl.group_term_off[g + 1] <= ti) g++;
@@ -618,8 +642,8 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
             for (int t = 0; t < D; t++) pr[t] = c;
             for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
                 const uint32_t m = pl.term_idx[k];
-                E2 x = stage[((size_t)(2 * m) << tp_log) + q];
-                const E2 delta = stage[((size_t)(2 * m + 1) << tp_log) + q];
+                E2 x = stage[(size_t)(2 * m) * TP + q];
+                const E2 delta = stage[(size_t)(2 * m + 1) * TP + q];
 #pragma unroll
                 for (int t = 0; t < D; t++) {
                     pr[t] = pr[t] * x;
@@ -628,8 +652,8 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
             }
             for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
                 const uint32_t m = pl.common_idx[k];
-                E2 x = stage[((size_t)(2 * m) << tp_log) + q];
-                const E2 delta = stage[((size_t)(2 * m + 1) << tp_log) + q];
+                E2 x = stage[(size_t)(2 * m) * TP + q];
+                const E2 delta = stage[(size_t)(2 * m + 1) * TP + q];
 #pragma unroll
                 for (int t = 0; t < D; t++) {
                     pr[t] = pr[t] * x;
@@ -716,7 +740,8 @@ struct ceno_hip_sumcheck {
     Mailbox* d_mailbox = nullptr;
     Bcast* d_bcast = nullptr;      // device relay
     bool allow_pipeline = false;   // caller promised to drive the rounds back to back (ceno_hip_sumcheck_set_pipelined)
-    bool pipelined = false;        // all round kernels were enqueued up front; challenges travel through the mailbox
+    bool pipelined = false;        // round kernels are enqueued ahead of their challenges, which travel through the mailbox
+    int enq = 0;                   // pipelined: rounds [0, enq) are in the stream
     E2* d_evals = nullptr;         // gather scratch (device), num_mles
     E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
     MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
@@ -847,28 +872,32 @@ static void launch_fused(int d, int tnt, const DevPlan& pl, int n_mles, size_t p
     }
 }
 
-// tile geometry of k_tile: enough (term x pair) / (MLE x pair) items to occupy the 256 lanes of a workgroup
-static int tile_log(size_t n_flat, size_t n_mles, size_t pairs) {
-    const size_t per_pair = std::max<size_t>(1, std::min(n_flat, 2 * n_mles));
-    int l = 0;
-    while (l < 6 && ((size_t)per_pair << l) < 256) l++;
-    while (l > 0 && ((size_t)1 << l) > pairs) l--;
-    while (l > 0 && ((n_mles * 2) << l) * sizeof(E2) > 48 * 1024) l--;
-    return l;
+// tile geometry of k_tile: as many pairs per workgroup as keep the (term x pair) items within ONE pass of the 256 lanes
+// (a second, nearly empty pass would double the evaluation time), bounded by the LDS stage
+static int tile_pairs(size_t n_flat, size_t n_mles, size_t pairs) {
+    size_t tp = std::max<size_t>(1, NT / std::max<size_t>(1, n_flat));
+    tp = std::min<size_t>(tp, 64);
+    tp = std::min(tp, pairs);
+    while (tp > 1 && n_mles * 2 * tp * sizeof(E2) > 48 * 1024) tp--;
+    return (int)tp;
 }
 static bool tile_eligible(size_t n_mles, size_t pairs) {
     static int v = [] {
         const char* e = getenv("CENO_HIP_TILE");  // 0 restores the one-lane-per-pair kernel (A/B measurements)
         return e ? atoi(e) : 1;
     }();
-    return v != 0 && pairs <= FUSED_MAX_PAIRS && n_mles <= 1024;
+    static size_t max_pairs = [] {
+        const char* e = getenv("CENO_HIP_TILE_MAX_LOG");
+        return (size_t)1 << (e ? atoi(e) : 16);
+    }();
+    return v != 0 && pairs <= max_pairs && n_mles <= 1024;
 }
 template <int D>
 static void launch_tile_d(const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
-    const int l = tile_log((size_t)n_flat, (size_t)n_mles, pairs);
-    const size_t lds = (((size_t)n_mles * 2 << l) + (NT / 64) * D) * sizeof(E2) + 64;
-    const size_t tiles = (pairs + ((size_t)1 << l) - 1) >> l;
-    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)std::min<size_t>(tiles, MAXB)), dim3(NT), lds, st, pl, n_mles, n_flat, l, pairs, r, ep);
+    const int tp = tile_pairs((size_t)n_flat, (size_t)n_mles, pairs);
+    const size_t lds = ((size_t)n_mles * 2 * tp + (NT / 64) * D) * sizeof(E2) + 64;
+    const size_t tiles = (pairs + tp - 1) / tp;
+    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)std::min<size_t>(tiles, MAXB)), dim3(NT), lds, st, pl, n_mles, n_flat, tp, pairs, r, ep);
 }
 static void launch_tile(int d, const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
     switch (d) {
@@ -1201,16 +1230,23 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
     return ep;
 }
 
-static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
+// Rounds are enqueued a few ahead of the one being answered instead of all at once: launching ~2n kernels costs
+// 100-300 us of host time, and a round-0 kernel shorter than that would sit in its challenge poll until the host
+// got around to reading its message (measured: 20 us per tiny round instead of 12, 800 us for a 160 us round 0).
+static constexpr int PIPE_LOOKAHEAD = 3;
+static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     ceno_hip_ctx* ctx = sc->ctx;
     ScClass& cl = sc->classes[0];
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     timespec ts0, ts1;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &ts0);
+    upto = std::min(upto, sc->n);
+    const int from = sc->enq;
+    if (from >= upto) return 0;
     if (cl.dense) {
         const ScTerm& T = sc->terms[cl.terms[0]];
         const int K = (int)T.idx.size();
-        for (int i = 0; i < sc->n; i++) {
+        for (int i = from; i < upto; i++) {
             const size_t pairs = (size_t)1 << (cl.nv - i - 1);
             const unsigned grid = sc_grid(pairs);
             Epilogue ep = pipe_epilogue(sc, cl, i);
@@ -1228,7 +1264,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
     } else {
         // slot tables of every round are deterministic: stage them all, one upload
         const size_t k = cl.mles.size();
-        for (int i = 0; i < sc->n; i++) {
+        for (int i = 0; i < sc->n && from == 0; i++) {
             MleSlot* h = sc->h_slots + (size_t)i * sc->slots_per_round;
             for (size_t m = 0; m < k; m++) {
                 ScMle& M = sc->mles[cl.mles[m]];
@@ -1239,8 +1275,9 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
             }
             if (i > 0) sc_advance(sc, cl);
         }
-        HIP_TRY(ctx, hipMemcpyAsync(cl.d_slots, sc->h_slots, (size_t)sc->n * k * sizeof(MleSlot), hipMemcpyHostToDevice, sc->st));
-        for (int i = 0; i < sc->n; i++) {
+        if (from == 0)
+            HIP_TRY(ctx, hipMemcpyAsync(cl.d_slots, sc->h_slots, (size_t)sc->n * k * sizeof(MleSlot), hipMemcpyHostToDevice, sc->st));
+        for (int i = from; i < upto; i++) {
             const size_t pairs = (size_t)1 << (cl.nv - i - 1);
             Epilogue ep = pipe_epilogue(sc, cl, i);
             DevPlan pl;
@@ -1270,9 +1307,10 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc) {
     HIP_TRY(ctx, hipGetLastError());
     if (dbg) {
         clock_gettime(CLOCK_MONOTONIC, &ts1);
-        fprintf(stderr, "[ceno_hip] enqueued %d pipelined rounds in %.1f us\n", sc->n,
+        fprintf(stderr, "[ceno_hip] enqueued pipelined rounds %d..%d in %.1f us\n", from, upto - 1,
                 (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3);
     }
+    sc->enq = upto;
     sc->pipelined = true;
     sc->seq = (unsigned long long)sc->n;
     return 0;
@@ -1290,13 +1328,14 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     size_t h_cursor = 0;
 
     // ---- 0. pipelined fast path ----
-    if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc));
+    if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc, 1 + PIPE_LOOKAHEAD));
     if (sc->pipelined) {
         if (d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: device-output rounds cannot follow host-output rounds");
         if (i > 0) {
             sc->h_mailbox->chal[0] = r.c0;
             sc->h_mailbox->chal[1] = r.c1;
             __atomic_store_n(&sc->h_mailbox->chal_seq, (unsigned long long)i, __ATOMIC_RELEASE);
+            TRY(sc_pipeline_enqueue(sc, i + 1 + PIPE_LOOKAHEAD));  // the device is busy with round i meanwhile
         }
         static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
         timespec ta, tb;
