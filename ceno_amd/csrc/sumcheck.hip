@@ -1233,7 +1233,13 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
 // Rounds are enqueued a few ahead of the one being answered instead of all at once: launching ~2n kernels costs
 // 100-300 us of host time, and a round-0 kernel shorter than that would sit in its challenge poll until the host
 // got around to reading its message (measured: 20 us per tiny round instead of 12, 800 us for a 160 us round 0).
-static constexpr int PIPE_LOOKAHEAD = 3;
+static int pipe_lookahead() {
+    static int v = [] {
+        const char* e = getenv("CENO_HIP_PIPE_LOOKAHEAD");  // large value = enqueue everything at round 0 (A/B measurements)
+        return e ? atoi(e) : 3;
+    }();
+    return v;
+}
 static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     ceno_hip_ctx* ctx = sc->ctx;
     ScClass& cl = sc->classes[0];
@@ -1328,14 +1334,14 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     size_t h_cursor = 0;
 
     // ---- 0. pipelined fast path ----
-    if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc, 1 + PIPE_LOOKAHEAD));
+    if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc, 1 + pipe_lookahead()));
     if (sc->pipelined) {
         if (d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: device-output rounds cannot follow host-output rounds");
         if (i > 0) {
             sc->h_mailbox->chal[0] = r.c0;
             sc->h_mailbox->chal[1] = r.c1;
             __atomic_store_n(&sc->h_mailbox->chal_seq, (unsigned long long)i, __ATOMIC_RELEASE);
-            TRY(sc_pipeline_enqueue(sc, i + 1 + PIPE_LOOKAHEAD));  // the device is busy with round i meanwhile
+            TRY(sc_pipeline_enqueue(sc, i + 1 + pipe_lookahead()));  // the device is busy with round i meanwhile
         }
         static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
         timespec ta, tb;
