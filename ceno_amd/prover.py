@@ -96,6 +96,8 @@ def plib():
     L.ceno_prover_test_e2_acc.argtypes = [u64p, u64p, C.c_int, C.c_int, u64p]
     L.ceno_prover_test_e2_inv.restype = None
     L.ceno_prover_test_e2_inv.argtypes = [u64p, u64p]
+    L.ceno_vp_builder_max_degree.restype = C.c_int
+    L.ceno_vp_builder_max_degree.argtypes = [C.c_void_p]
     _plib = L
     return L
 
@@ -168,6 +170,67 @@ def sumcheck_prove(dev: Device, mles: Sequence[Mle], coeffs: np.ndarray, terms, 
     _check(plib().ceno_prover_sumcheck_prove(dev.h, arr, C.byref(plan), tr.h, stream,
                                              _p(msgs) if max_num_vars else None, _p(chal), _p(fin)))
     return msgs, chal[:max_num_vars], fin
+
+
+class VirtualPolynomialsBuilder:
+    """host-side plan builder (reference: multilinear_extensions::virtual_polys::VirtualPolynomialsBuilder)"""
+
+    def __init__(self, dev: Device, max_num_vars: int):
+        L = plib()
+        vp, i = C.c_void_p, C.c_int
+        L.ceno_vp_builder_new.restype = vp
+        L.ceno_vp_builder_new.argtypes = [i]
+        L.ceno_vp_builder_free.restype = None
+        L.ceno_vp_builder_free.argtypes = [vp, vp]
+        L.ceno_vp_builder_lift.restype = i
+        L.ceno_vp_builder_lift.argtypes = [vp, vp, i]
+        L.ceno_vp_builder_add_term.restype = i
+        L.ceno_vp_builder_add_term.argtypes = [vp, u64p, C.POINTER(i), i]
+        L.ceno_vp_builder_num_mles.restype = i
+        L.ceno_vp_builder_num_mles.argtypes = [vp]
+        L.ceno_vp_builder_prove.restype = i
+        L.ceno_vp_builder_prove.argtypes = [vp, vp, i, vp, vp, u64p, u64p, u64p]
+        self.dev, self.n = dev, max_num_vars
+        self.h = C.c_void_p(L.ceno_vp_builder_new(max_num_vars))
+        self._keep = []
+
+    def lift(self, mle: Mle, owned: bool = False) -> int:
+        r = plib().ceno_vp_builder_lift(self.h, mle.h, int(owned))
+        if r < 0:
+            _check(r)
+        if owned:
+            mle.h = None  # the builder frees it
+        else:
+            self._keep.append(mle)
+        return r
+
+    def add_term(self, scalar, product: Sequence[int]) -> int:
+        arr = (C.c_int * len(product))(*product)
+        r = plib().ceno_vp_builder_add_term(self.h, _p(_ext1(scalar)), arr, len(product))
+        if r < 0:
+            _check(r)
+        return r
+
+    def prove(self, transcript: "Transcript", max_degree: int = 0, stream=None):
+        L = plib()
+        k = L.ceno_vp_builder_num_mles(self.h)
+        d = max_degree if max_degree > 0 else L.ceno_vp_builder_max_degree(self.h)
+        msgs = np.zeros((self.n, d, 2), dtype=np.uint64)
+        chal = np.zeros((self.n, 2), dtype=np.uint64)
+        fin = np.zeros((k, 2), dtype=np.uint64)
+        _check(L.ceno_vp_builder_prove(self.dev.h, self.h, max_degree, transcript.h, stream, _p(msgs), _p(chal), _p(fin)))
+        return msgs, chal, fin
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            plib().ceno_vp_builder_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Tower:

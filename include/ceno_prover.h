@@ -49,6 +49,20 @@ void ceno_transcript_sample_ext(ceno_transcript* t, uint64_t* out2);
 int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan,
                                ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
                                uint64_t* out_final_evals);
+/* VirtualPolynomialsBuilder (EXT multilinear_extensions; call sites gkr_iop/src/gkr/layer/cpu/mod.rs:80-88,213-226,
+ * ceno_zkvm/src/scheme/cpu/mod.rs:98,135-137,413-418,1255-1334): register MLEs — `lift` returns the expression id,
+ * the same id for the same handle; take_ownership != 0 is the reference's `Either::Right` (owned, freed with the builder),
+ * 0 is `Either::Left` (borrowed) — add monomial terms `Term{scalar, product}`, then prove
+ * (`to_virtual_polys_with_monomial_terms` + `IOPProverState::prove`).  max_degree <= 0 means the largest product. */
+typedef struct ceno_vp_builder ceno_vp_builder;
+ceno_vp_builder* ceno_vp_builder_new(int max_num_vars);
+void ceno_vp_builder_free(ceno_hip_ctx* ctx, ceno_vp_builder* b);
+int ceno_vp_builder_lift(ceno_vp_builder* b, ceno_hip_mle* mle, int take_ownership);                 /* >= 0: id, < 0: error */
+int ceno_vp_builder_add_term(ceno_vp_builder* b, const uint64_t* scalar2, const int* product, int n);  /* >= 0: term id */
+int ceno_vp_builder_num_mles(const ceno_vp_builder* b);
+int ceno_vp_builder_max_degree(const ceno_vp_builder* b);
+int ceno_vp_builder_prove(ceno_hip_ctx* ctx, ceno_vp_builder* b, int max_degree, ceno_transcript* tr, ceno_hip_stream s,
+                          uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals);
 /* same loop over an already begun sumcheck handle (consumes rounds 0..n-1 and finishes) */
 int ceno_prover_sumcheck_run(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int num_vars, int degree, int num_mles,
                              ceno_transcript* tr, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals);

@@ -605,3 +605,28 @@ def test_sharded_batched_sumcheck_hip_engine_virtual_ranks(dev):
         assert np.array_equal(msgs, omsgs)
         assert np.array_equal(chal, ochal)
         assert np.array_equal(np.concatenate(fins), ofin)
+
+
+def test_virtual_polynomials_builder_matches_oracle(dev):
+    """VirtualPolynomialsBuilder mirror: lift (dedup, borrowed / owned), monomial terms, prove"""
+    from ceno_amd import prover
+    from ceno_amd.api import CenoHipError
+
+    nv = 9
+    tabs = [po.rand_ext(1 << nv, 31), po.rand_base(1 << nv, 32), po.rand_ext(1 << (nv - 3), 33), po.rand_ext(1 << (nv - 3), 34)]
+    b = prover.VirtualPolynomialsBuilder(dev, nv)
+    m0, m1 = dev.upload(tabs[0]), dev.upload(tabs[1])
+    i0 = b.lift(m0)
+    i1 = b.lift(m1)
+    assert b.lift(m0) == i0  # the same MLE lifts to the same expression
+    i2 = b.lift(dev.upload(tabs[2]), owned=True)
+    i3 = b.lift(dev.upload(tabs[3]), owned=True)
+    terms = [((3, 1), [i0, i1, i0]), ((5, 0), [i2, i3]), ((7, 9), [i1])]
+    for sc, prod in terms:
+        b.add_term(sc, prod)
+    with pytest.raises(CenoHipError):
+        b.add_term((1, 0), [i0, i2])  # factors of different sizes in one term
+    msgs, chal, fin = b.prove(prover.Transcript.stub(0xF5))
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext([t[0] for t in terms]), [t[1] for t in terms], nv, 3, po.StubTranscript(0xF5))
+    assert np.array_equal(msgs, omsgs) and np.array_equal(chal, ochal) and np.array_equal(fin, ofin)
+    b.free()

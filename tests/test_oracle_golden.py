@@ -115,6 +115,20 @@ def test_eval_wellform_address_vec():
         assert po.eval_wellform_address_vec(7, 3, R5[:n], descending=True) == po.mle_evaluate(v2, R5[:n])
 
 
+def test_eval_inner_and_outer_repeated_incremental_vec():  # utils.rs:398-441, definitions utils.rs:310-327
+    """eval_inner_repeated_incremental_vec(k, r) = wellform(r[k:]), eval_outer_...(k, r) = wellform(r[:k]); the
+    reference checks them against the explicit tables [each value repeated 2^k times] / [0..2^k repeated]."""
+    r = po.ext([123, 456, 789, 3210, 9876])  # the reference's own point
+    for n in range(1, 6):
+        for k in range(n + 1):
+            inner = E([i for i in range(1 << (n - k)) for _ in range(1 << k)])
+            outer = E([j for _ in range(1 << (n - k)) for j in range(1 << k)])
+            want_in, want_out = po.mle_evaluate(inner, r[:n]), po.mle_evaluate(outer, r[:n])
+            got_in = po.eval_wellform_address_vec(0, 1, r[k:n]) if k < n else (0, 0)
+            got_out = po.eval_wellform_address_vec(0, 1, r[:k]) if k > 0 else (0, 0)
+            assert got_in == want_in and got_out == want_out, (n, k)
+
+
 def test_eval_stacked_wellform_address_vec():  # utils.rs:355-374
     for n in range(5):
         v = [0] + [j for i in range(n + 1) for j in range(1 << i)]
