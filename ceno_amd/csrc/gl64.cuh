@@ -123,6 +123,21 @@ GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
     const uint32_t s3 = addc32(p.w3, q.w3, cy, cy);
     return reduce_limbs(s0, s1, s2, s3, cy);
 }
+// product that is only multiplied again (any 64-bit inputs, result in [0, 2^64) not canonical)
+GL_HD uint64_t mul_nc(uint64_t a, uint64_t b) {
+    const L4 p = mul_wide(a, b);
+    return reduce_limbs_nc(p.w0, p.w1, p.w2, p.w3, 0u);
+}
+// a*b + c with one reduction (c < 2^64: the sum stays below 2^128), canonical result
+GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
+    const L4 p = mul_wide(a, b);
+    uint32_t cy;
+    const uint32_t s0 = addc32(p.w0, (uint32_t)c, 0u, cy);
+    const uint32_t s1 = addc32(p.w1, (uint32_t)(c >> 32), cy, cy);
+    const uint32_t s2 = addc32(p.w2, 0u, cy, cy);
+    const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
+    return reduce_limbs(s0, s1, s2, s3, 0u);
+}
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 // small-constant multiply (c < 2^32): the product has 96 bits
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {

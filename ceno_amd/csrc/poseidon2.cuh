@@ -35,9 +35,10 @@ inline void default_params(Params& p) {
 }
 
 GL_HD uint64_t sbox7(uint64_t x) {
-    uint64_t x2 = gl::mul(x, x);
-    uint64_t x3 = gl::mul(x2, x);
-    uint64_t x4 = gl::mul(x2, x2);
+    // the three inner products are only multiplied again: they skip canonicalisation (gl::mul_nc)
+    uint64_t x2 = gl::mul_nc(x, x);
+    uint64_t x3 = gl::mul_nc(x2, x);
+    uint64_t x4 = gl::mul_nc(x2, x2);
     return gl::mul(x4, x3);
 }
 
@@ -69,7 +70,7 @@ GL_HD void internal_linear(uint64_t* s, const Params& p) {
 #pragma unroll
     for (int i = 0; i < WIDTH; i++) sum = gl::add(sum, s[i]);
 #pragma unroll
-    for (int i = 0; i < WIDTH; i++) s[i] = gl::add(gl::mul(s[i], p.int_diag[i]), sum);
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::mul_add(s[i], p.int_diag[i], sum);
 }
 
 GL_HD void permute(uint64_t* s, const Params& p) {
@@ -129,7 +130,7 @@ __device__ __forceinline__ uint64_t permute_lanes8(uint64_t x, const Params& p) 
         uint64_t sum = gl::add(x, dpp64<0xB1>(x));
         sum = gl::add(sum, dpp64<0x4E>(sum));
         sum = gl::add(sum, dpp64<0x141>(sum));  // every lane of a quad holds the quad sum: the mirror lane is in the other quad
-        x = gl::add(gl::mul(x, dg), sum);
+        x = gl::mul_add(x, dg, sum);
     }
     for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
         x = sbox7(gl::add(x, p.ext_rc[r][g]));

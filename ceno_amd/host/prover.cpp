@@ -310,6 +310,8 @@ void ceno_prover_test_e2_mul(const uint64_t* a, const uint64_t* b, uint64_t* o) 
     o[1] = r.c1;
 }
 uint64_t ceno_prover_test_gl_mul_ref(uint64_t a, uint64_t b) { return gl::mul_ref(a, b); }
+uint64_t ceno_prover_test_gl_mul_nc(uint64_t a, uint64_t b) { return gl::canon(gl::mul_nc(a, b)); }
+uint64_t ceno_prover_test_gl_mul_add(uint64_t a, uint64_t b, uint64_t c) { return gl::mul_add(a, b, c); }
 uint64_t ceno_prover_test_gl_mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return gl::mul_add2(a, b, c, d); }
 void ceno_prover_test_e2_mul_ref(const uint64_t* a, const uint64_t* b, uint64_t* o) {
     E2 r = gl::e2_mul_ref(E2{a[0], a[1]}, E2{b[0], b[1]});

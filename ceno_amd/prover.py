@@ -82,6 +82,10 @@ def plib():
     L.ceno_prover_test_e2_mul.argtypes = [u64p, u64p, u64p]
     L.ceno_prover_test_gl_mul_ref.restype = C.c_uint64
     L.ceno_prover_test_gl_mul_ref.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_mul_nc.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul_nc.argtypes = [C.c_uint64, C.c_uint64]
+    L.ceno_prover_test_gl_mul_add.restype = C.c_uint64
+    L.ceno_prover_test_gl_mul_add.argtypes = [C.c_uint64] * 3
     L.ceno_prover_test_gl_mul_add2.restype = C.c_uint64
     L.ceno_prover_test_gl_mul_add2.argtypes = [C.c_uint64] * 4
     L.ceno_prover_test_e2_mul_ref.restype = None

@@ -59,6 +59,9 @@ def test_device_field_source_on_host_matches_bigint(built):
             assert L.ceno_prover_test_gl_mul_ref(a, b) == a * b % P
             assert L.ceno_prover_test_gl_mul_add2(a, b, b, a) == 2 * a * b % P
             assert L.ceno_prover_test_gl_mul_add2(a, b, P - 1, P - 1) == (a * b + 1) % P
+            assert L.ceno_prover_test_gl_mul_nc(a, b) == a * b % P
+            assert L.ceno_prover_test_gl_mul_nc(a + (P if a < (1 << 64) - P else 0), b) == a * b % P  # non-canonical operand
+            assert L.ceno_prover_test_gl_mul_add(a, b, P - 1 - (a % 3)) == (a * b + P - 1 - (a % 3)) % P
             assert L.ceno_prover_test_gl_add(a, b) == (a + b) % P
             assert L.ceno_prover_test_gl_sub(a, b) == (a - b) % P
         for c in (0, 1, 7, 0xFFFFFFFF):
