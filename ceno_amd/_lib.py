@@ -110,6 +110,8 @@ def lib():
         "ceno_hip_merkle_free": (i, [vp, vp]),
         "ceno_hip_batch_columns": (i, [vp, vp, sz, i, u64p, vp, i, vp]),
         "ceno_hip_basefold_fold_commit": (i, [vp, vp, i, u64p, vp, vp, vp, C.POINTER(vp)]),
+        "ceno_hip_basefold_commit_codeword": (i, [vp, vp, i, vp, C.POINTER(vp)]),
+        "ceno_hip_basefold_fold": (i, [vp, vp, i, u64p, vp, vp, vp]),
         "ceno_hip_gather": (i, [vp, vp, sz, i, i, vp, sz, i, i, vp, vp]),
         "ceno_hip_merkle_open_batch": (i, [vp, vp, vp, sz, i, vp, vp]),
         "ceno_hip_pow_grind": (i, [vp, u64p, i, u64p, vp]),

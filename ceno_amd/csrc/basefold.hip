@@ -106,6 +106,79 @@ __global__ void __launch_bounds__(NT) k_fold_commit(const E2* __restrict__ cw, s
     }
 }
 
+// ---- one-round-ahead variant: fold the running codeword and hash the pairs of the RESULT ----
+// The tree of the codeword a round commits to depends only on the PREVIOUS challenge, so it can be built while
+// the current round's sumcheck message and transcript work are still in flight (host: two alternating streams).
+__device__ __forceinline__ E2 fold_one(E2 a, E2 b, const E2Pre& cp, uint64_t tw) {
+    const E2 lo = e2_mul_base(a + b, INV2);
+    const E2 hi = e2_mul_base(a - b, tw);
+    return lo + e2_mul_pre(cp, hi - lo);
+}
+// out[j] = fold(cw[2j], cw[2j+1]) (+ addend[j]); lane i produces out[2i], out[2i+1] and, when digests != NULL, their leaf
+__global__ void __launch_bounds__(NT) k_fold_hash(const E2* __restrict__ cw, size_t n_out, E2 c, const E2* __restrict__ addend,
+                                                  const uint64_t* __restrict__ tw, E2* __restrict__ out, uint64_t* __restrict__ digests,
+                                                  const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    if (digests) {
+        for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+        __syncthreads();
+    }
+    const E2Pre cp = e2_pre(c);
+    const size_t stride = (size_t)gridDim.x * NT;
+    if (n_out == 1) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            E2 v = fold_one(cw[0], cw[1], cp, tw[0]);
+            if (addend) v = v + addend[0];
+            out[0] = v;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n_out / 2; i += stride) {
+        E2 v0 = fold_one(cw[4 * i], cw[4 * i + 1], cp, tw[2 * i]);
+        E2 v1 = fold_one(cw[4 * i + 2], cw[4 * i + 3], cp, tw[2 * i + 1]);
+        if (addend) {
+            v0 = v0 + addend[2 * i];
+            v1 = v1 + addend[2 * i + 1];
+        }
+        out[2 * i] = v0;
+        out[2 * i + 1] = v1;
+        if (digests) {
+            uint64_t s[8] = {v0.c0, v0.c1, v1.c0, v1.c1, 0, 0, 0, 0};
+            p2::permute(s, sp);
+            *reinterpret_cast<ulonglong2*>(digests + 4 * i) = make_ulonglong2(s[0], s[1]);
+            *reinterpret_cast<ulonglong2*>(digests + 4 * i + 2) = make_ulonglong2(s[2], s[3]);
+        }
+    }
+}
+// leaf digests of the adjacent pairs of an ext codeword, 8 lanes per leaf (latency-bound sizes)
+__global__ void __launch_bounds__(NT) k_hash_pairs8(const uint64_t* __restrict__ cw_words, size_t n_leaf, uint64_t* __restrict__ digests,
+                                                    const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    const size_t t = (size_t)blockIdx.x * NT + threadIdx.x, i = t >> 3;
+    const int g = threadIdx.x & 7;
+    const bool live = i < n_leaf;
+    uint64_t x = (live && g < 4) ? cw_words[4 * i + g] : 0;  // [a.c0, a.c1, b.c0, b.c1, 0, 0, 0, 0]
+    x = p2::permute_lanes8(x, sp);
+    if (live && g < 4) digests[4 * i + g] = x;
+}
+// leaf digests, one lane per leaf (throughput-bound sizes)
+__global__ void __launch_bounds__(NT) k_hash_pairs(const E2* __restrict__ cw, size_t n_leaf, uint64_t* __restrict__ digests,
+                                                   const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t j = (size_t)blockIdx.x * NT + threadIdx.x; j < n_leaf; j += stride) {
+        const E2 a = cw[2 * j], b = cw[2 * j + 1];
+        uint64_t s[8] = {a.c0, a.c1, b.c0, b.c1, 0, 0, 0, 0};
+        p2::permute(s, sp);
+        *reinterpret_cast<ulonglong2*>(digests + 4 * j) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(digests + 4 * j + 2) = make_ulonglong2(s[2], s[3]);
+    }
+}
+
 // ---- gathers for the query phase ----
 // out[(q * n_cols + c) * elem_words + e] = src[c * col_stride + idx[q] * elem_words + e]
 __global__ void __launch_bounds__(NT) k_gather(const uint64_t* __restrict__ src, size_t col_stride, int n_cols, int elem_words,
@@ -187,6 +260,44 @@ int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codewor
         return rc;
     }
     *out_tree = t;
+    return 0;
+}
+
+static constexpr size_t LANES8_MAX_LEAVES = (size_t)1 << 14;
+
+int ceno_hip_basefold_commit_codeword(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, ceno_hip_stream s, ceno_hip_merkle** out_tree) {
+    CHECK_ARG(ctx, dev_codeword_ext && out_tree && log_h >= 1 && log_h <= 32, "bad commit_codeword arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    ceno_hip_merkle* t = nullptr;
+    TRY(merkle_alloc(ctx, log_h - 1, &t));
+    const size_t n_leaf = (size_t)1 << (log_h - 1);
+    if (n_leaf <= LANES8_MAX_LEAVES)
+        hipLaunchKernelGGL(k_hash_pairs8, dim3((unsigned)((n_leaf * 8 + NT - 1) / NT)), dim3(NT), 0, st, dev_codeword_ext, n_leaf, t->levels[0], pp);
+    else
+        hipLaunchKernelGGL(k_hash_pairs, dim3(grid_for(n_leaf, NT, MAXB)), dim3(NT), 0, st, (const E2*)dev_codeword_ext, n_leaf, t->levels[0], pp);
+    int rc = merkle_build_upper(ctx, t, st);
+    if (rc) {
+        merkle_release(ctx, t);
+        return rc;
+    }
+    *out_tree = t;
+    return 0;
+}
+
+int ceno_hip_basefold_fold(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
+                           const uint64_t* dev_addend_ext, uint64_t* dev_out_ext, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_codeword_ext && challenge2 && dev_out_ext && log_h >= 1 && log_h <= 32, "bad basefold_fold arguments");
+    CHECK_ARG(ctx, challenge2[0] < gl::P && challenge2[1] < gl::P, "challenge is not canonical");
+    hipStream_t st = ctx_stream(ctx, s);
+    const uint64_t* tw = nullptr;
+    TRY(get_fold_twiddles(ctx, log_h, st, &tw));
+    const size_t n_out = (size_t)1 << (log_h - 1);
+    hipLaunchKernelGGL(k_fold_hash, dim3(grid_for(std::max<size_t>(n_out / 2, 1), NT, MAXB)), dim3(NT), 0, st, (const E2*)dev_codeword_ext, n_out,
+                       E2{challenge2[0], challenge2[1]}, (const E2*)dev_addend_ext, tw, (E2*)dev_out_ext, (uint64_t*)nullptr,
+                       (const p2::Params*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 

@@ -128,7 +128,10 @@ __global__ void __launch_bounds__(NT) k_compress8(const uint64_t* __restrict__ c
 
 // the last <= 8 levels (<= 256 digests in) in one workgroup of 1024 lanes = 128 nodes per pass
 static constexpr int TOP_NT = 1024, TOP_LEVELS = 8;
-__global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restrict__ child, int levels, uint64_t* const* __restrict__ outs,
+struct TopPtrs {
+    uint64_t* p[TOP_LEVELS];  // by value in the kernel arguments: no host-to-device copy (a pageable one would block the host on the stream)
+};
+__global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restrict__ child, int levels, TopPtrs outs,
                                                          const p2::Params* __restrict__ pp) {
     __shared__ p2::Params sp;
     __shared__ uint64_t buf[2][4 << TOP_LEVELS];
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
             x = p2::permute_lanes8(x, sp);
             if (g < 4) {
                 buf[cur ^ 1][4 * slot + g] = x;
-                outs[l][4 * slot + g] = x;
+                outs.p[l][4 * slot + g] = x;
             }
         }
         __syncthreads();
@@ -168,15 +171,9 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     }
     if (l <= log_rows) {  // levels l..log_rows: child level l-1 has 2^(log_rows-l+1) <= 256 digests
         const int rem = log_rows - l + 1;
-        if (!t->top_ptrs) {
-            void* p = nullptr;
-            TRY(ctx_alloc(ctx, 16 * sizeof(uint64_t*), &p));
-            t->top_ptrs = (uint64_t**)p;
-        }
-        uint64_t* h[16] = {nullptr};
-        for (int i = 0; i < rem; i++) h[i] = t->levels[l + i];
-        HIP_TRY(ctx, hipMemcpyAsync(t->top_ptrs, h, sizeof(h), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(TOP_NT), 0, st, t->levels[l - 1], rem, t->top_ptrs, pp);
+        TopPtrs tp{};
+        for (int i = 0; i < rem; i++) tp.p[i] = t->levels[l + i];
+        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(TOP_NT), 0, st, t->levels[l - 1], rem, tp, pp);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;

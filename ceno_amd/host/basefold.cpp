@@ -85,10 +85,20 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     std::vector<ceno_hip_merkle*> trees;
     std::map<int, Group> groups;  // key: nv
     void* d_scratch = nullptr;
+    ceno_hip_stream sx[2] = {nullptr, nullptr};  // tree building runs one round ahead on two alternating streams
+    hipEvent_t ev[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
+        for (int i = 0; i < 2; i++) {
+            if (sx[i]) {
+                (void)hipStreamSynchronize((hipStream_t)sx[i]);
+                (void)hipStreamDestroy((hipStream_t)sx[i]);
+            }
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
         for (auto& g : groups)
             if (g.second.sc) ceno_hip_sumcheck_free(ctx, g.second.sc);
-        for (auto* t : trees) ceno_hip_merkle_free(ctx, t);
+        for (auto* t : trees)
+            if (t) ceno_hip_merkle_free(ctx, t);
         for (auto* m : owned) ceno_hip_mle_free(ctx, m);
         if (d_scratch) (void)hipFree(d_scratch);
     };
@@ -162,9 +172,33 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     uint64_t* qbase = powp + 1;
 
     // ---- commit phase ----
+    // Round r commits to the running codeword C[r], which depends only on challenge r-1: its tree is built as soon as
+    // C[r] exists — on the stream that folded it — while round r's sumcheck message and the transcript work run on `s`.
+    // Two alternating streams let the (latency-bound) trees of consecutive rounds overlap.
     std::vector<ceno_hip_mle*> C(n + 1, nullptr);
     C[0] = B[H];
     std::vector<uint64_t> ch(2 * (size_t)std::max(n, 1));
+    trees.assign(n, nullptr);
+    {
+        // HIP spreads streams over a few hardware queues round-robin, and two streams that land on the same queue run
+        // their kernels back to back (seen in the kernel trace: both tree streams on queue 4).  Streams of different
+        // PRIORITY get queues of their own, so the two tree streams take the highest and the lowest level and leave the
+        // caller's (normal) stream alone.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio[2] = {greatest, least};
+        for (int i = 0; i < 2; i++) {
+            hipStream_t hs = nullptr;
+            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, prio[i]) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+            sx[i] = (ceno_hip_stream)hs;
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+        }
+    }
+    if (n > 0) {
+        int rc = ceno_hip_basefold_commit_codeword(ctx, ceno_hip_mle_device_ptr(C[0]), H, sx[0], &trees[0]);
+        if (rc) return fail(rc);
+    }
+    auto t_round = std::chrono::steady_clock::now();
     for (int r = 0; r < n; r++) {
         const int h = H - r;
         E2 p1 = gl::e2_zero(), p2 = gl::e2_zero();
@@ -218,18 +252,25 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         const E2 c = tr_sample(tr);
         ch[2 * r] = c.c0;
         ch[2 * r + 1] = c.c1;
-        // commit the running codeword and fold it in one pass; the codeword of the next height joins
-        ceno_hip_merkle* tree = nullptr;
+        // fold with c_r (the codeword of the next height joins) and start the NEXT round's tree right away
+        ceno_hip_stream fs = sx[(r + 1) & 1];  // C[r] was produced on sx[r & 1] (event ev[r & 1]); C[0] by the batching on `s` (synchronised)
         int rc = alloc_ext(h - 1, &C[r + 1]);
-        if (!rc) rc = ceno_hip_basefold_fold_commit(ctx, ceno_hip_mle_device_ptr(C[r]), h, &ch[2 * r], B[h - 1] ? ceno_hip_mle_device_ptr(B[h - 1]) : nullptr,
-                                                    ceno_hip_mle_device_ptr(C[r + 1]), s, &tree);
-        if (!rc) {
-            trees.push_back(tree);
-            rc = ceno_hip_merkle_root(ctx, tree, commits + 4 * r, s);
-        }
+        if (!rc && r > 0 && hipStreamWaitEvent((hipStream_t)fs, ev[r & 1], 0) != hipSuccess) rc = CENO_HIP_ERR_HIP;
+        if (!rc) rc = ceno_hip_basefold_fold(ctx, ceno_hip_mle_device_ptr(C[r]), h, &ch[2 * r], B[h - 1] ? ceno_hip_mle_device_ptr(B[h - 1]) : nullptr,
+                                             ceno_hip_mle_device_ptr(C[r + 1]), fs);
+        if (!rc && hipEventRecord(ev[(r + 1) & 1], (hipStream_t)fs) != hipSuccess) rc = CENO_HIP_ERR_HIP;
+        if (!rc && r + 1 < n) rc = ceno_hip_basefold_commit_codeword(ctx, ceno_hip_mle_device_ptr(C[r + 1]), h - 1, fs, &trees[r + 1]);
+        // the root of THIS round's tree (built one round ago on the other stream) is observed after the challenge
+        if (!rc) rc = ceno_hip_merkle_root(ctx, trees[r], commits + 4 * r, sx[r & 1]);
         if (rc) return fail(rc);
         tr->append_ext(tr->self, commits + 4 * r);
         tr->append_ext(tr->self, commits + 4 * r + 2);
+        if (dbg) {
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[ceno_prover] basefold_open round %2d (height %2d): %7.1f us since the previous round\n", r, h,
+                    std::chrono::duration<double, std::micro>(now - t_round).count());
+            t_round = now;
+        }
     }
     lap("commit phase");
     // ---- final message: F_m at the challenges, one row per opening point ----
@@ -251,7 +292,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     }
     {   // the fully folded codeword must be the constant codeword of the message
         std::vector<uint64_t> last(2 * ((size_t)1 << rate_log));
-        int rc = ceno_hip_mle_download(ctx, C[n], last.data(), s);
+        int rc = ceno_hip_mle_download(ctx, C[n], last.data(), n > 0 ? sx[n & 1] : s);  // the stream of the last fold
         if (rc) return fail(rc);
         for (size_t i = 0; i < ((size_t)1 << rate_log); i++)
             if (last[2 * i] != total.c0 || last[2 * i + 1] != total.c1) {

@@ -249,6 +249,14 @@ int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t l
 int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
                                   const uint64_t* dev_addend_ext /* may be NULL */, uint64_t* dev_out_ext, ceno_hip_stream s,
                                   ceno_hip_merkle** out_tree);
+/* One-round-ahead form of the same round: the tree a round commits to depends only on the PREVIOUS challenge, so the
+ * host folds (ceno_hip_basefold_fold: out[j] = fold(cw[2j], cw[2j+1]; challenge) (+ addend[j])) and at once commits the
+ * result (ceno_hip_basefold_commit_codeword: tree over its pair leaves) on a second stream while the next round's
+ * sumcheck message is computed. */
+int ceno_hip_basefold_fold(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
+                           const uint64_t* dev_addend_ext /* may be NULL */, uint64_t* dev_out_ext, ceno_hip_stream s);
+int ceno_hip_basefold_commit_codeword(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, ceno_hip_stream s,
+                                      ceno_hip_merkle** out_tree);
 /* dev_out[(q*n_cols + c)*elem_words + e] = dev_src[c*col_stride_words + i_q*elem_words + e], i_q = (idx[q] >> shift) ^ flip */
 int ceno_hip_gather(ceno_hip_ctx* ctx, const uint64_t* dev_src, size_t col_stride_words, int n_cols, int elem_words,
                     const uint64_t* dev_indices, size_t n, int shift, int flip_low_bit, uint64_t* dev_out, ceno_hip_stream s);
