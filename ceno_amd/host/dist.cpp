@@ -42,8 +42,11 @@ std::string g_dist_err;
 
 int load_rccl() {
     if (g_rccl.h) return 0;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // CENO_RCCL_PATH first: the launcher points it at the RCCL the process already uses (torch bundles its own copy;
+    // two different RCCL builds in one process would each run their own bootstrap and transport setup)
+    const char* names[] = {getenv("CENO_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+        if (!n || !*n) continue;
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.h) break;
     }

@@ -334,6 +334,15 @@ class RcclComm:
     torch.distributed module (or None for world 1): it only carries the 128-byte unique id."""
 
     def __init__(self, world: int, rank: int, dist=None):
+        if "CENO_RCCL_PATH" not in os.environ:  # share the RCCL build torch.distributed already loaded
+            try:
+                import torch
+
+                cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                if os.path.exists(cand):
+                    os.environ["CENO_RCCL_PATH"] = cand
+            except Exception:
+                pass
         L = plib()
         idbuf = C.create_string_buffer(128)
         if rank == 0:
