@@ -13,7 +13,10 @@
 //
 // RCCL is resolved with dlopen at first use so that libceno_prover.so loads on machines without it.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime_api.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
 #include <cstdio>
@@ -91,12 +94,32 @@ extern "C" {
 
 const char* ceno_dist_last_error(void) { return g_dist_err.c_str(); }
 
+// Host shared-memory exchange between the ranks of one node.  The round messages are already in host memory (the
+// transcript lives there), so the per-round "collective" of 16*d bytes per rank is cheapest as a store into a
+// shared segment plus a spin on the peers' sequence words (~1-2 us) — an RCCL all-gather of the same 48 bytes costs
+// a kernel launch on every rank plus a device-to-host copy (tens of us).  RCCL keeps the bulk transfers.
+struct ShmRank {
+    volatile uint64_t seq;             // last exchange this rank has published
+    uint64_t pad[7];                   // one cache line per flag
+    uint64_t slot[2][2 * 64];          // payload of exchanges seq (parity indexed), up to 64 ext
+};
+struct ShmSeg {
+    uint64_t magic;
+    uint64_t world;
+    uint64_t pad[6];
+    ShmRank ranks[1];                  // `world` entries
+};
+
 struct ceno_dist_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     uint64_t* d_send = nullptr;  // device staging: up to 64 ext per rank
     uint64_t* d_recv = nullptr;
-    uint64_t* h_recv = nullptr;  // pinned
+    uint64_t* h_recv = nullptr;  // pinned (RCCL path) or plain host memory (shm-only communicator)
+    ShmSeg* shm = nullptr;
+    size_t shm_bytes = 0;
+    uint64_t shm_seq = 0;        // exchanges done so far (identical on every rank)
+    bool h_recv_plain = false;
 };
 
 int ceno_dist_unique_id(uint8_t* out128) {
@@ -136,10 +159,117 @@ int ceno_dist_comm_init(int world, int rank, const uint8_t* id128, ceno_dist_com
 void ceno_dist_comm_destroy(ceno_dist_comm* c) {
     if (!c) return;
     if (c->comm) g_rccl.CommDestroy(c->comm);
-    (void)hipFree(c->d_send);
-    (void)hipFree(c->d_recv);
-    (void)hipHostFree(c->h_recv);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->h_recv_plain) free(c->h_recv);
+    else if (c->h_recv) (void)hipHostFree(c->h_recv);
+    if (c->shm) munmap((void*)c->shm, c->shm_bytes);
     delete c;
+}
+
+static size_t shm_size(int world) { return sizeof(ShmSeg) + sizeof(ShmRank) * (size_t)(world > 0 ? world - 1 : 0); }
+static const uint64_t SHM_MAGIC = 0x43454e4f53484d31ULL;  // "CENOSHM1"
+
+/* Attach the host shared-memory exchange to a communicator (`c` may come from ceno_dist_comm_init, or be created
+ * here without RCCL when *c is NULL).  Rank 0 passes create != 0 and must attach BEFORE the name is given to the
+ * other ranks; it may shm_unlink the name once every rank has attached (ceno_dist_shm_unlink). */
+int ceno_dist_comm_attach_shm(ceno_dist_comm** pc, int world, int rank, const char* name, int create) {
+    if (!pc || !name || world < 1 || world > 64 || rank < 0 || rank >= world) {
+        g_dist_err = "attach_shm: bad arguments";
+        return CENO_HIP_ERR_INVALID;
+    }
+    ceno_dist_comm* c = *pc;
+    if (c && (c->world != world || c->rank != rank)) {
+        g_dist_err = "attach_shm: geometry differs from the communicator's";
+        return CENO_HIP_ERR_INVALID;
+    }
+    const size_t bytes = shm_size(world);
+    int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) {
+        g_dist_err = std::string("shm_open(") + name + ") failed";
+        return CENO_HIP_ERR_STATE;
+    }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) {
+        close(fd);
+        g_dist_err = "ftruncate on the shared segment failed";
+        return CENO_HIP_ERR_STATE;
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        g_dist_err = "mmap of the shared segment failed";
+        return CENO_HIP_ERR_STATE;
+    }
+    ShmSeg* seg = (ShmSeg*)m;
+    if (create) {
+        memset(m, 0, bytes);
+        seg->world = (uint64_t)world;
+        __atomic_store_n(&seg->magic, SHM_MAGIC, __ATOMIC_RELEASE);
+    } else if (__atomic_load_n(&seg->magic, __ATOMIC_ACQUIRE) != SHM_MAGIC || seg->world != (uint64_t)world) {
+        munmap(m, bytes);
+        g_dist_err = "shared segment is not initialised for this world size";
+        return CENO_HIP_ERR_STATE;
+    }
+    if (!c) {
+        c = new ceno_dist_comm();
+        c->world = world;
+        c->rank = rank;
+        c->h_recv = (uint64_t*)calloc((size_t)64 * 2 * world, 8);
+        c->h_recv_plain = true;
+        *pc = c;
+    }
+    c->shm = seg;
+    c->shm_bytes = bytes;
+    c->shm_seq = 0;
+    return 0;
+}
+int ceno_dist_shm_unlink(const char* name) { return name && shm_unlink(name) == 0 ? 0 : CENO_HIP_ERR_STATE; }
+
+// all-gather `n_ext` extension elements per rank through the shared segment; result (world x n_ext) in c->h_recv
+static int shm_gather_ext(ceno_dist_comm* c, const uint64_t* mine, int n_ext) {
+    if (n_ext > 64) {
+        g_dist_err = "shm_gather_ext: more than 64 elements per rank";
+        return CENO_HIP_ERR_INVALID;
+    }
+    const uint64_t seq = ++c->shm_seq;
+    ShmRank& me = c->shm->ranks[c->rank];
+    memcpy((void*)me.slot[seq & 1], mine, (size_t)n_ext * 16);
+    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    for (int g = 0; g < c->world; g++) {
+        ShmRank& r = c->shm->ranks[g];
+        uint64_t spins = 0;
+        while (__atomic_load_n(&r.seq, __ATOMIC_ACQUIRE) < seq) {
+            if (++spins > ((uint64_t)1 << 34)) {  // a peer died: minutes of spinning
+                g_dist_err = "shm_gather_ext: peer never published its message";
+                return CENO_HIP_ERR_STATE;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        memcpy(c->h_recv + (size_t)g * n_ext * 2, (const void*)r.slot[seq & 1], (size_t)n_ext * 16);
+    }
+    return 0;
+}
+
+/* self-test of the exchange (CPU tests, no GPU involved): `iters` gathers of varying size; every rank checks every
+ * payload word.  Returns 0 when all match. */
+int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters) {
+    if (!c || !c->shm) return CENO_HIP_ERR_INVALID;
+    uint64_t buf[128];
+    for (int it = 0; it < iters; it++) {
+        const int n = 1 + (it * 7) % 64;
+        for (int k = 0; k < 2 * n; k++) buf[k] = gl::splitmix64_at(1000 + (uint64_t)c->rank, (uint64_t)it * 131 + k);
+        int rc = shm_gather_ext(c, buf, n);
+        if (rc) return rc;
+        for (int g = 0; g < c->world; g++)
+            for (int k = 0; k < 2 * n; k++)
+                if (c->h_recv[(size_t)g * n * 2 + k] != gl::splitmix64_at(1000 + (uint64_t)g, (uint64_t)it * 131 + k)) {
+                    g_dist_err = "shm selftest: payload mismatch";
+                    return CENO_HIP_ERR_STATE;
+                }
+    }
+    return 0;
 }
 
 // all-gather `n_ext` extension elements per rank from device buffer c->d_send; result (world x n_ext) in c->h_recv
@@ -156,6 +286,107 @@ static int gather_ext(ceno_dist_comm* c, int n_ext, hipStream_t st) {
         return CENO_HIP_ERR_HIP;
     }
     return 0;
+}
+
+// replicated last rounds on world-sized tables built from the per-rank final values (index = rank = the top bits)
+static int dist_tail(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumcheck_plan* plan_local, int n_local, int log_w, int d, int k,
+                     ceno_transcript* tr, ceno_hip_stream s, uint64_t* ch, uint64_t* out_msgs, uint64_t* out_challenges,
+                     uint64_t* out_final_evals) {
+    const int world = c->world;
+    std::vector<ceno_hip_mle*> tail(k, nullptr);
+    std::vector<uint64_t> tab(2 * (size_t)world), msg(2 * (size_t)d);
+    int rc = 0;
+    for (int j = 0; j < k && !rc; j++) {
+        for (int g = 0; g < world; g++) {
+            tab[2 * g] = c->h_recv[2 * ((size_t)g * k + j)];
+            tab[2 * g + 1] = c->h_recv[2 * ((size_t)g * k + j) + 1];
+        }
+        rc = ceno_hip_mle_upload(ctx, tab.data(), log_w, 1, s, &tail[j]);
+    }
+    if (!rc) {
+        ceno_hip_sumcheck_plan tp = *plan_local;
+        tp.max_num_vars = log_w;
+        ceno_hip_sumcheck* ts = nullptr;
+        rc = ceno_hip_sumcheck_begin(ctx, tail.data(), &tp, s, &ts);
+        if (!rc) ceno_hip_sumcheck_set_pipelined(ctx, ts, 1);
+        for (int r = 0; r < log_w && !rc; r++) {
+            rc = ceno_hip_sumcheck_round(ctx, ts, r == 0 ? nullptr : ch, msg.data());
+            if (rc) break;
+            memcpy(out_msgs + (size_t)2 * d * (n_local + r), msg.data(), (size_t)16 * d);
+            E2 rr = absorb_round(tr, msg.data(), d);
+            ch[0] = rr.c0;
+            ch[1] = rr.c1;
+            out_challenges[2 * (n_local + r)] = rr.c0;
+            out_challenges[2 * (n_local + r) + 1] = rr.c1;
+        }
+        if (!rc) rc = ceno_hip_sumcheck_finish(ctx, ts, ch, out_final_evals);
+        if (ts) ceno_hip_sumcheck_free(ctx, ts);
+    }
+    for (auto* m : tail)
+        if (m) ceno_hip_mle_free(ctx, m);
+    if (rc) g_dist_err = ceno_hip_last_error(ctx);
+    return rc;
+}
+
+// Sharded rounds with the host shared-memory exchange: every rank runs the ordinary PIPELINED single-device round
+// loop over its shard (message to pinned host memory, challenge through the mailbox) and the only addition per round
+// is the ~1-2 us exchange of d ext partials between the host processes.  No device collective on the round path.
+static int dist_prove_shm(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
+                          int n_total, int n_local, int log_w, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs,
+                          uint64_t* out_challenges, uint64_t* out_final_evals) {
+    const int world = c->world, d = plan_local->max_degree, k = plan_local->num_mles;
+    if (n_local < 1) {
+        g_dist_err = "shared-memory exchange needs at least one local variable per shard";
+        return CENO_HIP_ERR_INVALID;
+    }
+    ceno_hip_sumcheck* sc = nullptr;
+    int rc = ceno_hip_sumcheck_begin(ctx, mles, plan_local, s, &sc);
+    if (rc) {
+        g_dist_err = ceno_hip_last_error(ctx);
+        return rc;
+    }
+    ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);
+    uint64_t ch[2] = {0, 0};
+    std::vector<uint64_t> part(2 * (size_t)d), msg(2 * (size_t)d);
+    for (int r = 0; r < n_local && !rc; r++) {
+        rc = ceno_hip_sumcheck_round(ctx, sc, r == 0 ? nullptr : ch, part.data());
+        if (rc) {
+            g_dist_err = ceno_hip_last_error(ctx);
+            break;
+        }
+        rc = shm_gather_ext(c, part.data(), d);
+        if (rc) break;
+        for (int t = 0; t < d; t++) {
+            E2 acc = gl::e2_zero();
+            for (int g = 0; g < world; g++) acc = acc + E2{c->h_recv[2 * ((size_t)g * d + t)], c->h_recv[2 * ((size_t)g * d + t) + 1]};
+            msg[2 * t] = acc.c0;
+            msg[2 * t + 1] = acc.c1;
+        }
+        memcpy(out_msgs + (size_t)2 * d * r, msg.data(), (size_t)16 * d);
+        E2 rr = absorb_round(tr, msg.data(), d);
+        ch[0] = rr.c0;
+        ch[1] = rr.c1;
+        out_challenges[2 * r] = rr.c0;
+        out_challenges[2 * r + 1] = rr.c1;
+    }
+    std::vector<uint64_t> fin_local(2 * (size_t)k);
+    if (!rc) {
+        rc = ceno_hip_sumcheck_finish(ctx, sc, ch, fin_local.data());
+        if (rc) g_dist_err = ceno_hip_last_error(ctx);
+    }
+    ceno_hip_sumcheck_free(ctx, sc);
+    if (rc) return rc;
+    if (world == 1) {
+        memcpy(out_final_evals, fin_local.data(), (size_t)16 * k);
+        return 0;
+    }
+    if (k > 64) {
+        g_dist_err = "more than 64 MLEs in a sharded sumcheck";
+        return CENO_HIP_ERR_INVALID;
+    }
+    rc = shm_gather_ext(c, fin_local.data(), k);
+    if (rc) return rc;
+    return dist_tail(ctx, c, plan_local, n_local, log_w, d, k, tr, s, ch, out_msgs, out_challenges, out_final_evals);
 }
 
 /* Sumcheck of the plan's terms over a 2^n_total hypercube whose tables are sharded by their top
@@ -181,6 +412,12 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
     hipStream_t st = (hipStream_t)s;
     tr_usize(tr, (uint64_t)n_total);
     tr_usize(tr, (uint64_t)d);
+    if (c->shm && (!c->comm || !getenv("CENO_DIST_EXCHANGE_RCCL")))
+        return dist_prove_shm(ctx, c, mles, plan_local, n_total, n_local, log_w, tr, s, out_msgs, out_challenges, out_final_evals);
+    if (!c->comm) {
+        g_dist_err = "communicator has neither RCCL nor the shared-memory exchange";
+        return CENO_HIP_ERR_STATE;
+    }
     ceno_hip_sumcheck* sc = nullptr;
     int rc = ceno_hip_sumcheck_begin(ctx, mles, plan_local, s, &sc);
     if (rc) {

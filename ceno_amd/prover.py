@@ -371,7 +371,57 @@ class RcclComm:
             pass
 
 
-def dist_sumcheck_prove(dev: Device, comm: RcclComm, mles: Sequence[Mle], coeffs: np.ndarray, terms, n_total: int,
+class ShmComm:
+    """Communicator whose per-round exchange goes through a host shared-memory segment (one node; see
+    include/ceno_prover.h ceno_dist_comm_attach_shm).  `dist` only carries the segment name and two barriers."""
+
+    def __init__(self, world: int, rank: int, dist=None, name: Optional[str] = None):
+        L = plib()
+        L.ceno_dist_comm_attach_shm.restype = C.c_int
+        L.ceno_dist_comm_attach_shm.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.ceno_dist_shm_unlink.restype = C.c_int
+        L.ceno_dist_shm_unlink.argtypes = [C.c_char_p]
+        L.ceno_dist_shm_selftest.restype = C.c_int
+        L.ceno_dist_shm_selftest.argtypes = [C.c_void_p, C.c_int]
+        if name is None:
+            name = f"/ceno_dist_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little'):08x}" if rank == 0 else None
+        h = C.c_void_p()
+
+        def attach(create):
+            rc = L.ceno_dist_comm_attach_shm(C.byref(h), world, rank, name.encode(), int(create))
+            if rc != 0:
+                raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+
+        if rank == 0:
+            attach(True)  # the segment exists and is initialised before anybody learns its name
+        if world > 1 and dist is not None:
+            obj = [name]
+            dist.broadcast_object_list(obj, src=0)
+            name = obj[0]
+        if rank != 0:
+            attach(False)
+        if world > 1 and dist is not None:
+            dist.barrier()
+        if rank == 0:
+            L.ceno_dist_shm_unlink(name.encode())  # mappings stay valid; nothing is left behind in /dev/shm
+        self.h, self.world, self.rank, self.name = h, world, rank, name
+
+    def selftest(self, iters: int = 1000) -> int:
+        return plib().ceno_dist_shm_selftest(self.h, iters)
+
+    def close(self):
+        if getattr(self, "h", None):
+            plib().ceno_dist_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dist_sumcheck_prove(dev: Device, comm, mles: Sequence[Mle], coeffs: np.ndarray, terms, n_total: int,
                         max_degree: int, tr: Transcript, stream):
     """sharded IOPProverState::prove — `mles` are this rank's shards; returns the global proof"""
     n_local = n_total - (comm.world.bit_length() - 1)

@@ -186,6 +186,14 @@ void ceno_dist_comm_destroy(ceno_dist_comm* c);
 int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
                              int n_total, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
                              uint64_t* out_final_evals);
+/* Host shared-memory exchange for the ranks of ONE node: the d partial evaluations of a round are already in host
+ * memory (the transcript is there), so they are exchanged through a POSIX shared segment (~1-2 us) instead of a device
+ * collective; with it attached ceno_dist_sumcheck_prove runs every rank's shard as an ordinary pipelined sumcheck.
+ * *c == NULL creates a communicator without RCCL.  Rank 0 creates the segment (create != 0) before the other ranks
+ * attach, and may unlink the name once all have (the mappings stay valid). */
+int ceno_dist_comm_attach_shm(ceno_dist_comm** c, int world, int rank, const char* name, int create);
+int ceno_dist_shm_unlink(const char* name);
+int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters);
 const char* ceno_dist_last_error(void);
 
 #ifdef __cplusplus

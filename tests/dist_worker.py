@@ -121,11 +121,53 @@ def main_batched(out_dir, n_total):
     dist.destroy_process_group()
 
 
+def main_shm(out_dir, iters):
+    """host shared-memory exchange of the C++ sharded driver (ceno_amd/host/dist.cpp), no GPU involved"""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    comm = prover.ShmComm(world, rank, dist)
+    rc = comm.selftest(iters)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(str(rc))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def main_shm_gpu(out_dir, n_local):
+    """the C++ sharded driver with the shared-memory exchange, `world` PROCESSES sharing GPU 0 (no RCCL on this path,
+    so several ranks may use the same device): real HIP engine, real cross-process exchange"""
+    import torch.distributed as dist
+
+    from ceno_amd import Device
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dev = Device(0)
+    k = 3
+    tables = [po.fill_splitmix(2 << n_local, 0xCE10 + j, rank * 2 * (1 << n_local)).reshape(-1, 2) for j in range(k)]
+    mles = [dev.upload(t) for t in tables]
+    comm = prover.ShmComm(world, rank, dist)
+    stream = dev.stream_create()
+    n_total = n_local + world.bit_length() - 1
+    msgs, chal, fin = prover.dist_sumcheck_prove(dev, comm, mles, po.ext([1]), [list(range(k))], n_total, k, prover.Transcript.stub(0xF5), stream)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=msgs, chal=chal, fin=fin)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 def main():
     import torch.distributed as dist
 
     if len(sys.argv) > 3 and sys.argv[3] == "batched":
         return main_batched(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "shm":
+        return main_shm(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":
+        return main_shm_gpu(sys.argv[1], int(sys.argv[2]))
     out_dir = sys.argv[1]
     n_local = int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

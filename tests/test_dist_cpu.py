@@ -73,3 +73,23 @@ def test_sharded_batched_mixed_size_sumcheck_matches_unsharded(world, n_total):
         assert np.array_equal(res[r]["msgs"], omsgs)
         assert np.array_equal(res[r]["chal"], ochal)
         assert np.array_equal(res[r]["fin"], ofin)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_shared_memory_exchange_between_processes(world):
+    """the per-round exchange of the C++ sharded driver: 20000 back-to-back gathers of varying size between `world`
+    processes, every payload word checked on every rank (two-slot sequence protocol, ceno_amd/host/dist.cpp)"""
+    from ceno_amd import build
+
+    build.build_all()
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + world), WORLD_SIZE=str(world))
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "20000", "shm"], env=e))
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+        for r in range(world):
+            assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "0"
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("ceno_dist_")]
