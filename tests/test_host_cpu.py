@@ -4,6 +4,7 @@
    the host inside libceno_prover.so) matches the oracle / big-int model bit for bit;
  - the product's stub transcript equals the oracle's stub transcript.
 """
+import os
 import random
 
 import numpy as np
@@ -34,6 +35,22 @@ def test_c_abi_exports_every_declared_symbol(built):
     assert L._ceno_missing == []
     assert set(L._ceno_sig) == set(declared), sorted(set(L._ceno_sig) ^ set(declared))
     assert b"gfx950" in L.ceno_hip_version()
+
+
+def test_prover_library_exports_every_symbol_of_its_header(built):
+    """include/ceno_prover.h (host layer: transcript, round loops, tower, rotation, main constraints, commit, open,
+    sharded driver) against libceno_prover.so"""
+    import re
+
+    _, prover = built
+    L = prover.plib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "ceno_prover.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ceno_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) > 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert missing == [], f"declared in include/ceno_prover.h but not exported: {missing}"
 
 
 def test_init_without_gpu_fails_loudly(built):
