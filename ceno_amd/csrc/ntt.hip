@@ -7,9 +7,10 @@
 // p3-goldilocks one: 7^((p-1)/2^32) = 1753635133440165772 (order 2^32).
 //
 // Forward = decimation in frequency (natural order in, bit-reversed out), in place, per column:
-//   passes over HBM of `R` = 4 stages each held in registers (16 strided elements per lane, coalesced
+//   passes over HBM of `R` <= 5 stages each held in registers (up to 32 strided elements per lane, coalesced
 //   along the contiguous index), then ONE pass that finishes the last <= 11 stages of every 2048-element
-//   block in LDS.  log N = 21 -> 3 HBM passes + 1 LDS pass (vs 21 for stage-per-launch).
+//   block in LDS.  log N = 21 -> 2 HBM passes (5 + 5 stages) + 1 LDS pass (vs 21 for stage-per-launch); an RS encoding
+//   reads the un-extended column in its first pass, so the zero extension costs no traffic.
 // Inverse = the mirrored decimation in time with inverse twiddles and the 1/N scale fused in the last pass.
 // Twiddles w^i (i < N/2) are tabulated once per size in HBM (8 MB at N = 2^21) and stay L2-resident.
 #include "common.hpp"
@@ -56,10 +57,13 @@ static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t 
 // blk*M + k*L + l, k < 2^R.
 template <int R, bool INVERSE>
 __global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data, int log_n, int s, const uint64_t* __restrict__ tw,
-                                                    uint64_t scale) {
+                                                    uint64_t scale, const uint64_t* __restrict__ src, size_t src_len) {
+    // src != NULL: out-of-place first pass of an RS encoding — the column is read from `src` (src_len elements per
+    // column, zero beyond: the zero extension is never materialised) and the result is written to `data`
     constexpr int E = 1 << R;
     const size_t n = (size_t)1 << log_n;
     uint64_t* col = data + (size_t)blockIdx.y * n;
+    const uint64_t* scol = src ? src + (size_t)blockIdx.y * src_len : nullptr;
     const int log_m = log_n - s;
     const int log_l = log_m - R;
     const size_t L = (size_t)1 << log_l;
@@ -69,8 +73,17 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data,
         const size_t blk = it >> log_l, l = it & (L - 1);
         uint64_t* base = col + (blk << log_m) + l;
         uint64_t v[E];
+        if (scol) {
+            const size_t g0 = (blk << log_m) + l;
 #pragma unroll
-        for (int k = 0; k < E; k++) v[k] = base[(size_t)k << log_l];
+            for (int k = 0; k < E; k++) {
+                const size_t gi = g0 + ((size_t)k << log_l);
+                v[k] = gi < src_len ? scol[gi] : 0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; k++) v[k] = base[(size_t)k << log_l];
+        }
         if (!INVERSE) {
 #pragma unroll
             for (int q = 0; q < R; q++) {
@@ -161,19 +174,36 @@ __global__ void __launch_bounds__(NT) k_ntt_local(uint64_t* __restrict__ data, i
     }
 }
 
+__global__ void __launch_bounds__(NT) k_pad_copy(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t n_in, size_t n_out) {
+    const uint64_t* src = in + (size_t)blockIdx.y * n_in;
+    uint64_t* dst = out + (size_t)blockIdx.y * n_out;
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n_out; i += stride) dst[i] = i < n_in ? src[i] : 0;
+}
+
 template <bool INV>
-static void launch_strided(int R, uint64_t* d, int log_n, int s, const uint64_t* tw, uint64_t scale, int n_cols, hipStream_t st) {
+static void launch_strided(int R, uint64_t* d, int log_n, int s, const uint64_t* tw, uint64_t scale, int n_cols, hipStream_t st,
+                           const uint64_t* src = nullptr, size_t src_len = 0) {
     size_t items = ((size_t)1 << log_n) >> R;
     dim3 grid(grid_for(items, NT, 2048), (unsigned)n_cols);
     switch (R) {
-    case 1: hipLaunchKernelGGL((k_ntt_strided<1, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
-    case 2: hipLaunchKernelGGL((k_ntt_strided<2, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
-    case 3: hipLaunchKernelGGL((k_ntt_strided<3, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
-    default: hipLaunchKernelGGL((k_ntt_strided<4, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale); break;
+    case 1: hipLaunchKernelGGL((k_ntt_strided<1, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale, src, src_len); break;
+    case 2: hipLaunchKernelGGL((k_ntt_strided<2, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale, src, src_len); break;
+    case 3: hipLaunchKernelGGL((k_ntt_strided<3, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale, src, src_len); break;
+    case 4: hipLaunchKernelGGL((k_ntt_strided<4, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale, src, src_len); break;
+    default: hipLaunchKernelGGL((k_ntt_strided<5, INV>), grid, dim3(NT), 0, st, d, log_n, s, tw, scale, src, src_len); break;
     }
 }
 
-static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool inverse, hipStream_t st) {
+// split `total` register-resident stages into the fewest passes of at most 5 stages, as evenly as possible
+// (10 -> 5 + 5, not 4 + 4 + 2: every pass costs a full read + write of the data)
+static int next_pass(int remaining) {
+    const int passes = (remaining + 4) / 5;
+    return (remaining + passes - 1) / passes;
+}
+
+static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool inverse, hipStream_t st, const uint64_t* src = nullptr,
+                    size_t src_len = 0) {
     CHECK_ARG(ctx, d && log_n >= 0 && log_n <= 32 && n_cols >= 1 && n_cols <= 65535, "bad ntt arguments (log_n %d, cols %d)", log_n, n_cols);
     if (log_n == 0) return 0;
     const uint64_t* tw = nullptr;
@@ -184,9 +214,14 @@ static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool 
     dim3 lgrid((unsigned)(n_blocks < 1024 ? n_blocks : 1024), (unsigned)n_cols);
     if (!inverse) {
         int s = 0;
+        if (src && n_strided == 0) {  // small transforms: no strided pass to fold the zero extension into
+            hipLaunchKernelGGL(k_pad_copy, dim3(grid_for((size_t)1 << log_n, NT, 2048), (unsigned)n_cols), dim3(NT), 0, st, src, d, src_len,
+                               (size_t)1 << log_n);
+            src = nullptr;
+        }
         while (s < n_strided) {
-            int R = n_strided - s >= 4 ? 4 : n_strided - s;
-            launch_strided<false>(R, d, log_n, s, tw, 1, n_cols, st);
+            const int R = next_pass(n_strided - s);
+            launch_strided<false>(R, d, log_n, s, tw, 1, n_cols, st, s == 0 ? src : nullptr, src_len);
             s += R;
         }
         hipLaunchKernelGGL(k_ntt_local<false>, lgrid, dim3(NT), 0, st, d, log_n, lb, tw, (uint64_t)1);
@@ -196,7 +231,7 @@ static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool 
         hipLaunchKernelGGL(k_ntt_local<true>, lgrid, dim3(NT), 0, st, d, log_n, lb, tw, n_strided == 0 ? n_inv : (uint64_t)1);
         int s = n_strided;
         while (s > 0) {
-            int R = s >= 4 ? 4 : s;
+            const int R = next_pass(s);
             s -= R;
             launch_strided<true>(R, d, log_n, s, tw, s == 0 ? n_inv : (uint64_t)1, n_cols, st);
         }
@@ -205,12 +240,6 @@ static int ntt_impl(ceno_hip_ctx* ctx, uint64_t* d, int log_n, int n_cols, bool 
     return 0;
 }
 
-__global__ void __launch_bounds__(NT) k_pad_copy(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t n_in, size_t n_out) {
-    const uint64_t* src = in + (size_t)blockIdx.y * n_in;
-    uint64_t* dst = out + (size_t)blockIdx.y * n_out;
-    size_t stride = (size_t)gridDim.x * NT;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n_out; i += stride) dst[i] = i < n_in ? src[i] : 0;
-}
 
 extern "C" {
 
@@ -222,10 +251,8 @@ int ceno_hip_rs_encode(ceno_hip_ctx* ctx, const uint64_t* dev_cols, int log_n, i
     CHECK_ARG(ctx, dev_cols && dev_codewords && log_blowup >= 0 && log_n >= 0 && log_n + log_blowup <= 32, "bad rs_encode arguments");
     CHECK_ARG(ctx, n_cols >= 1 && n_cols <= 65535, "bad column count");
     hipStream_t st = ctx_stream(ctx, s);
-    size_t n_in = (size_t)1 << log_n, n_out = (size_t)1 << (log_n + log_blowup);
-    hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(n_out, NT, 2048), (unsigned)n_cols), dim3(NT), 0, st, dev_cols, dev_codewords, n_in, n_out);
-    HIP_TRY(ctx, hipGetLastError());
-    return ntt_impl(ctx, dev_codewords, log_n + log_blowup, n_cols, false, st);
+    // the zero extension is folded into the first pass (read `dev_cols`, write `dev_codewords`)
+    return ntt_impl(ctx, dev_codewords, log_n + log_blowup, n_cols, false, st, dev_cols, (size_t)1 << log_n);
 }
 
 }  // extern "C"
