@@ -72,6 +72,11 @@ class Device:
         self.check(self.L.ceno_hip_stream_create(self.h, C.byref(s)))
         return s
 
+    def stream_create_lane(self, lane: int) -> C.c_void_p:
+        s = C.c_void_p()
+        self.check(self.L.ceno_hip_stream_create_lane(self.h, lane, C.byref(s)))
+        return s
+
     def stream_destroy(self, s):
         self.check(self.L.ceno_hip_stream_destroy(self.h, s))
 

@@ -184,6 +184,21 @@ int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out) {
     *out = (ceno_hip_stream)s;
     return 0;
 }
+int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out) {
+    // Lanes (reference: thread-bound streams of the chip scheduler, gkr_iop/src/gpu/mod.rs:87-154,
+    // ceno_zkvm/src/scheme/scheduler.rs:73-85) must land on DIFFERENT hardware queues to overlap: streams that share a
+    // queue run back to back and pay a cross-stream barrier per kernel.  HIP gives each priority level queues of its
+    // own, so consecutive lanes rotate through the levels (highest, normal, lowest, highest, ...).
+    CHECK_ARG(ctx, out && lane >= 0, "bad lane");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int least = 0, greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int levels[3] = {greatest, (least + greatest) / 2, least};
+    hipStream_t s;
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, levels[lane % 3]));
+    *out = (ceno_hip_stream)s;
+    return 0;
+}
 int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     if (s) HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));
     return 0;

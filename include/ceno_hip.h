@@ -59,6 +59,9 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx);
 const char* ceno_hip_last_error(ceno_hip_ctx* ctx);   /* ctx may be NULL: last init error */
 const char* ceno_hip_version(void);
 int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out);
+/* stream for proving lane `lane` (concurrent chip proving, ceno_zkvm/src/scheme/scheduler.rs:73-85): consecutive lanes
+ * get different stream priorities so that they land on different hardware queues and really overlap */
+int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out);
 int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s);
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
