@@ -268,6 +268,32 @@ def test_sumcheck_nv22_properties(dev, prover):
     assert np.array_equal(omsgs, msgs[8:])
 
 
+def test_sumcheck_nv26_bench_workload_verifies(dev, prover):
+    """the bench.py workload itself (3 ext MLEs x 2^26, the size the metric is quoted on), checked through
+    size-independent properties: (1) the claimed sum comes from an independent kernel path (pointwise product by
+    wit_infer, then sum = 2^n * MLE(1/2, ..., 1/2) by the evaluate kernel), (2) the restated verifier accepts the 26
+    messages for that claim and lands on the product of the final evaluations, (3) the final evaluations equal
+    independent MLE evaluations, (4) the last 12 rounds replay bit for bit on the oracle from device-folded tables."""
+    nv, k = 26, 3
+    mles = [dev.synthetic(nv, True, 0xCE10 + j) for j in range(k)]
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, po.ext([1]), [[0, 1, 2]], nv, k, prover.Transcript.stub(0xF5))
+    prod = dev.wit_infer(mles, po.ext([1]), [[0, 1, 2]], [[0]], nv)[0]
+    half = np.tile(np.array([[(P + 1) // 2, 0]], dtype=np.uint64), (nv, 1))
+    s_half = prod.evaluate(half)
+    claim = po.e2_mul(s_half, (pow(2, nv, P), 0))
+    prod.free()
+    point, expected = po.sumcheck_verify(claim, msgs, po.StubTranscript(0xF5))
+    assert np.array_equal(point, chal)
+    want = (1, 0)
+    for j in range(k):
+        assert mles[j].evaluate(chal) == tup(fin[j])
+        want = po.e2_mul(want, tup(fin[j]))
+    assert expected == want
+    folded = [m.fix_variables(chal[:14]).download() for m in mles]
+    omsgs, _ = po.sumcheck_dense_mt(folded, chal[14:], threads=4)
+    assert np.array_equal(omsgs, msgs[14:])
+
+
 # ------------------------------------------------------------------------------------------
 # tower
 # ------------------------------------------------------------------------------------------
