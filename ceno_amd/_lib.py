@@ -66,6 +66,9 @@ def lib():
         "ceno_hip_stream_sync": (i, [vp, vp]),
         "ceno_hip_mem_info": (i, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "ceno_hip_mem_trim": (i, [vp]),
+        "ceno_hip_mem_book": (i, [vp, sz]),
+        "ceno_hip_mem_unbook": (i, [vp, sz]),
+        "ceno_hip_mem_booked": (sz, [vp]),
         "ceno_hip_mle_alloc": (i, [vp, i, i, vpp]),
         "ceno_hip_mle_upload": (i, [vp, u64p, i, i, vp, vpp]),
         "ceno_hip_mle_wrap": (i, [vp, vp, i, i, vpp]),

@@ -27,6 +27,8 @@ struct ceno_hip_ctx {
     size_t pool_limit = 0;  // 0 = unlimited
     size_t pool_used = 0;   // bytes handed out
     size_t pool_cached = 0; // bytes parked in free lists
+    size_t pool_booked = 0; // bytes promised to scheduled-but-not-yet-running tasks (ceno_hip_mem_book)
+    size_t pool_capacity = 0;  // booking capacity: pool_limit, or the device memory size when unlimited
     std::unordered_map<size_t, std::vector<void*>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----

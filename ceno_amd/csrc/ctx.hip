@@ -219,6 +219,33 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
     return 0;
 }
 
+// ---- VRAM booking for a chip scheduler (reference: mem_pool try_book_capacity / unbook_capacity / get_booked_total /
+// reset_booking / init_booking_baseline, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,438,622-652): a task books its
+// ESTIMATED footprint before it is handed to a lane and unbooks it when done; booking fails — nothing is allocated —
+// when live allocations + bookings would exceed the capacity, which is how the scheduler back-fills smaller tasks.
+int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->pool_capacity == 0) {
+        size_t f = 0, t = 0;
+        ctx->pool_capacity = ctx->pool_limit ? ctx->pool_limit : (hipMemGetInfo(&f, &t) == hipSuccess ? t : 0);
+    }
+    if (ctx->pool_capacity && ctx->pool_used + ctx->pool_booked + bytes > ctx->pool_capacity) {
+        ctx->err = "booking refused: live allocations plus bookings would exceed the capacity";
+        return CENO_HIP_ERR_OOM;
+    }
+    ctx->pool_booked += bytes;
+    return 0;
+}
+int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->pool_booked = bytes > ctx->pool_booked ? 0 : ctx->pool_booked - bytes;
+    return 0;
+}
+size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    return ctx->pool_booked;
+}
+
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->mu);
     for (auto& kv : ctx->free_lists) {

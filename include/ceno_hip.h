@@ -67,6 +67,12 @@ int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334) */
+/* booking of estimated task footprints by a chip scheduler (mem_pool try_book_capacity / unbook_capacity /
+ * get_booked_total, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,622-652): refused (CENO_HIP_ERR_OOM, nothing is
+ * allocated) when live allocations + bookings + bytes would exceed pool_bytes (or the device memory when unlimited) */
+int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes);
+int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes);
+size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * MLE handles  (alloc_elems_on_device / alloc_ext_elems_from_host / Buffer::to_cpu_vec)

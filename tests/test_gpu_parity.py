@@ -656,3 +656,25 @@ def test_virtual_polynomials_builder_matches_oracle(dev):
     omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext([t[0] for t in terms]), [t[1] for t in terms], nv, 3, po.StubTranscript(0xF5))
     assert np.array_equal(msgs, omsgs) and np.array_equal(chal, ochal) and np.array_equal(fin, ofin)
     b.free()
+
+
+def test_memory_booking_for_a_scheduler():
+    """mem_pool booking (ceno_zkvm/src/scheme/scheduler.rs:622-652): bookings count against the pool capacity together
+    with live allocations; a refused booking allocates nothing and leaves the total unchanged"""
+    from ceno_amd import Device
+    from ceno_amd.api import CenoHipError
+
+    d = Device(0, pool_bytes=1 << 26)  # 64 MiB pool
+    L = d.L
+    assert L.ceno_hip_mem_booked(d.h) == 0
+    assert L.ceno_hip_mem_book(d.h, 40 << 20) == 0
+    m = d.alloc(20, True)  # 16 MiB live
+    assert L.ceno_hip_mem_book(d.h, 16 << 20) != 0  # 40 + 16 + 16 > 64
+    assert L.ceno_hip_mem_booked(d.h) == 40 << 20
+    assert L.ceno_hip_mem_book(d.h, 8 << 20) == 0
+    m.free()
+    assert L.ceno_hip_mem_unbook(d.h, 40 << 20) == 0
+    assert L.ceno_hip_mem_booked(d.h) == 8 << 20
+    assert L.ceno_hip_mem_unbook(d.h, 1 << 40) == 0  # over-unbooking clamps at zero
+    assert L.ceno_hip_mem_booked(d.h) == 0
+    d.close()
