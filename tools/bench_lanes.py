@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--log-rows", type=int, default=18)
     ap.add_argument("--chips", type=int, default=8)
     ap.add_argument("--lanes", type=str, default="1,2,4,8")
+    ap.add_argument("--stream-step", type=int, default=1, help="use every k-th of the created streams (queue-mapping experiments)")
     args = ap.parse_args()
     import torch
     from ceno_amd import Device, api, prover
@@ -55,7 +56,9 @@ def main():
     res = {"log_rows": n, "chips": args.chips}
     base_ms = None
     for lanes in [int(x) for x in args.lanes.split(",")]:
-        streams = [dev.stream_create_lane(i) if os.environ.get("CENO_LANE_PRIORITIES", "1") != "0" else dev.stream_create() for i in range(lanes)]
+        pool_ = [dev.stream_create_lane(i) if os.environ.get("CENO_LANE_PRIORITIES", "1") != "0" else dev.stream_create()
+                 for i in range(lanes * args.stream_step)]
+        streams = pool_[::args.stream_step]
         for rep in range(2):
             todo = list(range(args.chips))
             lock = threading.Lock()
