@@ -8,8 +8,8 @@
 //
 // Forward = decimation in frequency (natural order in, bit-reversed out), in place, per column:
 //   passes over HBM of `R` <= 5 stages each held in registers (up to 32 strided elements per lane, coalesced
-//   along the contiguous index), then ONE pass that finishes the last <= 11 stages of every 2048-element
-//   block in LDS.  log N = 21 -> 2 HBM passes (5 + 5 stages) + 1 LDS pass (vs 21 for stage-per-launch); an RS encoding
+//   along the contiguous index), then ONE pass that finishes the last <= 12 stages of every 4096-element
+//   block in LDS (groups of 4 stages in registers between barriers).  log N = 21 -> 2 HBM passes (5 + 5 stages) + 1 LDS pass (vs 21 for stage-per-launch); an RS encoding
 //   reads the un-extended column in its first pass, so the zero extension costs no traffic.
 // Inverse = the mirrored decimation in time with inverse twiddles and the 1/N scale fused in the last pass.
 // Twiddles w^i (i < N/2) are tabulated once per size in HBM (8 MB at N = 2^21) and stay L2-resident.
@@ -20,7 +20,7 @@
 using namespace gl;
 
 static constexpr int NT = 256;
-static constexpr int LOCAL_LOG = 11;  // 2048 elements = 16 KB of LDS per block
+static constexpr int LOCAL_LOG = 12;  // 4096 elements = 34 KB of LDS per block (with padding)
 static constexpr uint64_t TWO_ADIC_GEN_2_32 = 1753635133440165772ULL;
 
 static std::mutex g_tw_mu;
@@ -55,6 +55,47 @@ static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t 
 // R register-resident stages starting at global stage `s` (forward DIF) — or ending at stage s (inverse DIT).
 // Block of size M = N >> s splits into L = M >> R interleaved sub-sequences; a lane owns indices
 // blk*M + k*L + l, k < 2^R.
+// R register-resident radix-2 stages on the 2^R values a lane holds: value k sits at distance k << log_l inside a
+// sub-block of 2^(R + log_l) elements whose low index is l; `s` is the global stage of the first (forward) / last
+// (inverse) of the R stages.  Shared by the strided HBM passes and the LDS pass.
+template <int R, bool INVERSE>
+__device__ __forceinline__ void radix_stages(uint64_t (&v)[1 << R], int log_l, size_t l, int s, const uint64_t* __restrict__ tw) {
+    constexpr int E = 1 << R;
+    if (!INVERSE) {
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int hb = 1 << (R - q - 1);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                if ((k & hb) == 0) {
+                    const int kk = k & (2 * hb - 1);  // position inside the sub-block (lower half)
+                    const size_t pos = ((size_t)kk << log_l) + l;
+                    const uint64_t w = tw[pos << (s + q)];
+                    const uint64_t a = v[k], b = v[k + hb];
+                    v[k] = add(a, b);
+                    v[k + hb] = mul(sub(a, b), w);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = R - 1; q >= 0; q--) {
+            const int hb = 1 << (R - q - 1);
+#pragma unroll
+            for (int k = 0; k < E; k++) {
+                if ((k & hb) == 0) {
+                    const int kk = k & (2 * hb - 1);
+                    const size_t pos = ((size_t)kk << log_l) + l;
+                    const uint64_t w = tw[pos << (s + q)];
+                    const uint64_t a = v[k], b = mul(v[k + hb], w);
+                    v[k] = add(a, b);
+                    v[k + hb] = sub(a, b);
+                }
+            }
+        }
+    }
+}
+
 template <int R, bool INVERSE>
 __global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data, int log_n, int s, const uint64_t* __restrict__ tw,
                                                     uint64_t scale, const uint64_t* __restrict__ src, size_t src_len) {
@@ -84,39 +125,8 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data,
 #pragma unroll
             for (int k = 0; k < E; k++) v[k] = base[(size_t)k << log_l];
         }
-        if (!INVERSE) {
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                // global stage s+q: sub-block of 2^(R-q) lanes-elements, partner distance 2^(R-q-1)
-                const int hb = 1 << (R - q - 1);
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    if ((k & hb) == 0) {
-                        const int kk = k & (2 * hb - 1);  // position inside the sub-block (lower half)
-                        const size_t pos = ((size_t)kk << log_l) + l;
-                        const uint64_t w = tw[pos << (s + q)];
-                        const uint64_t a = v[k], b = v[k + hb];
-                        v[k] = add(a, b);
-                        v[k + hb] = mul(sub(a, b), w);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = R - 1; q >= 0; q--) {
-                const int hb = 1 << (R - q - 1);
-#pragma unroll
-                for (int k = 0; k < E; k++) {
-                    if ((k & hb) == 0) {
-                        const int kk = k & (2 * hb - 1);
-                        const size_t pos = ((size_t)kk << log_l) + l;
-                        const uint64_t w = tw[pos << (s + q)];
-                        const uint64_t a = v[k], b = mul(v[k + hb], w);
-                        v[k] = add(a, b);
-                        v[k + hb] = sub(a, b);
-                    }
-                }
-            }
+        radix_stages<R, INVERSE>(v, log_l, l, s, tw);
+        if (INVERSE) {
             if (scale != 1) {
 #pragma unroll
                 for (int k = 0; k < E; k++) v[k] = mul(v[k], scale);
@@ -127,10 +137,42 @@ __global__ void __launch_bounds__(NT) k_ntt_strided(uint64_t* __restrict__ data,
     }
 }
 
-// last (forward) / first (inverse) `lb` stages of every contiguous 2^lb block, in LDS
+// last (forward) / first (inverse) `lb` stages of every contiguous 2^lb block, in LDS: groups of up to 4 stages run in
+// registers (16 values per lane) between barriers — 3 LDS round trips for 12 stages instead of 12.  The LDS image is
+// padded by one word every 16 so that the last group, whose lanes own 16 CONSECUTIVE elements (stride 128 B), does not
+// pile every lane onto one bank.
+__device__ __forceinline__ size_t lds_pad(size_t i) { return i + (i >> 4); }
+
+template <int R, bool INVERSE>
+__device__ __forceinline__ void local_group(uint64_t* sm, int lb, int sl, int s0, const uint64_t* __restrict__ tw) {
+    constexpr int E = 1 << R;
+    const int log_m = lb - sl, log_l = log_m - R;
+    const size_t L = (size_t)1 << log_l, items = ((size_t)1 << lb) >> R;
+    for (size_t it = threadIdx.x; it < items; it += NT) {
+        const size_t blk = it >> log_l, l = it & (L - 1);
+        const size_t b0 = (blk << log_m) + l;
+        uint64_t v[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) v[k] = sm[lds_pad(b0 + ((size_t)k << log_l))];
+        radix_stages<R, INVERSE>(v, log_l, l, s0 + sl, tw);
+#pragma unroll
+        for (int k = 0; k < E; k++) sm[lds_pad(b0 + ((size_t)k << log_l))] = v[k];
+    }
+    __syncthreads();
+}
+template <bool INVERSE>
+__device__ __forceinline__ void local_group_r(int R, uint64_t* sm, int lb, int sl, int s0, const uint64_t* __restrict__ tw) {
+    switch (R) {
+    case 1: local_group<1, INVERSE>(sm, lb, sl, s0, tw); break;
+    case 2: local_group<2, INVERSE>(sm, lb, sl, s0, tw); break;
+    case 3: local_group<3, INVERSE>(sm, lb, sl, s0, tw); break;
+    default: local_group<4, INVERSE>(sm, lb, sl, s0, tw); break;
+    }
+}
+
 template <bool INVERSE>
 __global__ void __launch_bounds__(NT) k_ntt_local(uint64_t* __restrict__ data, int log_n, int lb, const uint64_t* __restrict__ tw, uint64_t scale) {
-    __shared__ uint64_t sm[1 << LOCAL_LOG];
+    __shared__ uint64_t sm[(1 << LOCAL_LOG) + (1 << (LOCAL_LOG - 4)) + 1];
     const size_t n = (size_t)1 << log_n;
     const size_t bsz = (size_t)1 << lb;
     const size_t n_blocks = n >> lb;
@@ -138,38 +180,22 @@ __global__ void __launch_bounds__(NT) k_ntt_local(uint64_t* __restrict__ data, i
     const int s0 = log_n - lb;  // first global stage handled here
     for (size_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         uint64_t* base = col + blk * bsz;
-        for (size_t i = threadIdx.x; i < bsz; i += NT) sm[i] = base[i];
+        for (size_t i = threadIdx.x; i < bsz; i += NT) sm[lds_pad(i)] = base[i];
         __syncthreads();
         if (!INVERSE) {
-            for (int q = 0; q < lb; q++) {
-                const int log_half = lb - q - 1;
-                const size_t half = (size_t)1 << log_half;
-                for (size_t b = threadIdx.x; b < bsz / 2; b += NT) {
-                    const size_t j = b & (half - 1), grp = b >> log_half;
-                    const size_t i0 = (grp << (log_half + 1)) + j, i1 = i0 + half;
-                    const uint64_t w = tw[j << (s0 + q)];
-                    const uint64_t a = sm[i0], c = sm[i1];
-                    sm[i0] = add(a, c);
-                    sm[i1] = mul(sub(a, c), w);
-                }
-                __syncthreads();
+            for (int sl = 0; sl < lb;) {
+                const int R = lb - sl >= 4 ? 4 : lb - sl;
+                local_group_r<false>(R, sm, lb, sl, s0, tw);
+                sl += R;
             }
-        } else {
-            for (int q = lb - 1; q >= 0; q--) {
-                const int log_half = lb - q - 1;
-                const size_t half = (size_t)1 << log_half;
-                for (size_t b = threadIdx.x; b < bsz / 2; b += NT) {
-                    const size_t j = b & (half - 1), grp = b >> log_half;
-                    const size_t i0 = (grp << (log_half + 1)) + j, i1 = i0 + half;
-                    const uint64_t w = tw[j << (s0 + q)];
-                    const uint64_t a = sm[i0], c = mul(sm[i1], w);
-                    sm[i0] = add(a, c);
-                    sm[i1] = sub(a, c);
-                }
-                __syncthreads();
+        } else {  // mirrored: innermost stages first
+            for (int hi = lb; hi > 0;) {
+                const int R = hi >= 4 ? 4 : hi;
+                hi -= R;
+                local_group_r<true>(R, sm, lb, hi, s0, tw);
             }
         }
-        for (size_t i = threadIdx.x; i < bsz; i += NT) base[i] = (INVERSE && scale != 1) ? mul(sm[i], scale) : sm[i];
+        for (size_t i = threadIdx.x; i < bsz; i += NT) base[i] = (INVERSE && scale != 1) ? mul(sm[lds_pad(i)], scale) : sm[lds_pad(i)];
         __syncthreads();
     }
 }

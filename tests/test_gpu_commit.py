@@ -58,7 +58,7 @@ def test_transpose(dev, rows, width):
     assert np.array_equal(_to_np(dst).reshape(width, rows), m.T)
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 11, 12, 13])
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 11, 12, 13, 16, 17])
 def test_ntt_forward_inverse_vs_dft(dev, log_n):
     from ceno_amd import api
 
@@ -68,9 +68,8 @@ def test_ntt_forward_inverse_vs_dft(dev, log_n):
     api.ntt_batch(dev, d.data_ptr(), log_n, n_cols, inverse=False)
     dev.sync()
     got = _to_np(d).reshape(n_cols, -1)
-    if log_n <= 11:
-        for c in range(n_cols):
-            assert np.array_equal(got[c], po.dft_bitrev(cols[c]))
+    for c in range(n_cols):  # O(N^2) transform by definition for small sizes, the oracle's radix-2 restatement beyond
+        assert np.array_equal(got[c], po.dft_bitrev(cols[c]) if log_n <= 11 else po.fft_bitrev(cols[c]))
     api.ntt_batch(dev, d.data_ptr(), log_n, n_cols, inverse=True)
     dev.sync()
     assert np.array_equal(_to_np(d).reshape(n_cols, -1), cols)
