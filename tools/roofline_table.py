@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table: times each streaming primitive at chip-flow sizes on one MI355X and
+prints achieved GB/s against the ALGORITHMIC bytes of SURVEY.md §8(d) (wall time over several back-to-back calls,
+so launch overhead is included; peak 8000 GB/s)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from ceno_amd import Device, api, prover
+
+dev = Device(0)
+P = api.P
+rows_log, w = 20, 22
+rows = 1 << rows_log
+
+
+def timed(f, reps=5):
+    f()
+    dev.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    dev.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+out = []
+
+
+def row(name, secs, alg_bytes, note=""):
+    out.append({"kernel": name, "ms": round(secs * 1e3, 4), "algorithmic_MB": round(alg_bytes / 1e6, 1),
+                "GBps": round(alg_bytes / secs / 1e9, 1), "frac_of_8TBps": round(alg_bytes / secs / 8e12, 3), "note": note})
+
+
+pt24 = np.array([[(i * 7919 + 13) % P, (i * 104729 + 17) % P] for i in range(24)], dtype=np.uint64)
+# eq build: 16 * 2^n written
+t = timed(lambda: dev.eq_build(pt24).free())
+row("eq_build nv=24", t, 16 * (1 << 24))
+# evaluate: s * 2^n read
+f_ext = dev.synthetic(24, True, 1)
+f_base = dev.synthetic(24, False, 2)
+row("mle_evaluate ext nv=24", timed(lambda: f_ext.evaluate(pt24)), 16 * (1 << 24))
+row("mle_evaluate base nv=24", timed(lambda: f_base.evaluate(pt24)), 8 * (1 << 24))
+# fix one variable: 2s read + 16/2 written per input pair
+row("fix_variable ext nv=24", timed(lambda: f_ext.fix_variables(pt24[:1]).free()), (16 + 8) * (1 << 24))
+# wit_infer: (8 * in_cols + 16 * out_cols) * rows
+cols = [dev.synthetic(rows_log, False, 10 + j) for j in range(w)]
+alpha, beta = (0x1234567, 0x89abcde), (0x13579b, 0x2468ac)
+b2 = ((beta[0] * beta[0] + 7 * beta[1] * beta[1]) % P, (2 * beta[0] * beta[1]) % P)
+terms, coeffs, out_terms = [], [], []
+for k in range(16):
+    base = len(terms)
+    terms += [[(2 * k) % w], [(2 * k + 1) % w], [(3 * k + 5) % w, (k + 7) % w]]
+    coeffs += [beta, b2, alpha]
+    out_terms.append([base, base + 1, base + 2])
+coeffs = np.array(coeffs, dtype=np.uint64)
+recs = dev.wit_infer(cols, coeffs, terms, out_terms, rows_log)
+
+
+def wi():
+    for m in dev.wit_infer(cols, coeffs, terms, out_terms, rows_log):
+        m.free()
+
+
+row("wit_infer 22 base -> 16 ext, 2^20 rows", timed(wi), (8 * w + 16 * 16) * rows)
+# tower build (product): 48 * 2^n per tower of n variables
+row("tower_build_prod 4 records x 2^20 (nv=22)", timed(lambda: prover.Tower.build_prod(dev, recs[:4], rows, (1, 0)).free()), 48 * (1 << 22),
+    "plus the interleave read of 4 x 16 MB")
+row("tower_build_logup 8 records x 2^20 (nv=23)", timed(lambda: prover.Tower.build_logup(dev, None, recs[8:16], rows, alpha).free()),
+    2 * 48 * (1 << 23), "4 limbs per layer")
+# transpose
+rm = dev.synthetic((rows * w - 1).bit_length(), False, 0xADD)
+cm = torch.empty(rows * w, dtype=torch.int64, device="cuda:0")
+row("transpose 2^20 x 22", timed(lambda: api.transpose(dev, rm.device_ptr, rows, w, cm.data_ptr())), 16 * rows * w)
+# RS encode (blow-up 2): SURVEY target <= 48 N per column, N = codeword length
+cw = torch.empty((rows << 1) * w, dtype=torch.int64, device="cuda:0")
+row("rs_encode 22 x 2^20 -> 2^21", timed(lambda: api.rs_encode(dev, cm.data_ptr(), rows_log, w, 1, cw.data_ptr())), 48 * (rows << 1) * w,
+    "3 passes move 44 N per column")
+# Merkle: 8 w N leaf read + 64 N tree
+row("merkle_commit 2^21 x 22", timed(lambda: api.Merkle(dev, cw.data_ptr(), rows_log + 1, w).free(), reps=3), (8 * w + 64) * (rows << 1),
+    "integer-ALU bound: 6 + 1 Poseidon2 permutations per row")
+print(json.dumps(out, indent=1))
