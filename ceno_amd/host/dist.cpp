@@ -389,6 +389,204 @@ static int dist_prove_shm(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* co
     return dist_tail(ctx, c, plan_local, n_local, log_w, d, k, tr, s, ch, out_msgs, out_challenges, out_final_evals);
 }
 
+}  // extern "C"
+
+/* Mixed-size (front-loaded) batched sumcheck across ranks — SURVEY.md section 8(e), the C++ counterpart of
+ * ceno_amd/dist.py::sharded_batched_sumcheck_prove (same protocol):
+ *   sharded class    : every rank holds slice `rank` of each table (num_vars - log2(world) local variables); its local
+ *                      rounds produce partial messages; when the local variables run out the per-rank values are
+ *                      exchanged once and the class continues as world-sized replicated tables;
+ *   replicated class : every rank holds the whole tables and runs the same rounds; counted once.
+ * The engine of a replicated class is begun with max_num_vars = the rounds left, so it applies the front-load scalars
+ * itself.  Exchanges go through the host shared-memory segment (ceno_dist_comm_attach_shm). */
+namespace {
+struct Seg {
+    int cls = -1;
+    ceno_hip_sumcheck* sc = nullptr;
+    bool sharded = false;
+    int start = 0, end = 0;                 // global rounds [start, end)
+    std::vector<ceno_hip_mle*> owned;       // tail tables uploaded here
+};
+}  // namespace
+
+extern "C" int ceno_dist_batched_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_dist_class* classes, int n_classes, int n_total,
+                                                int max_degree, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs,
+                                                uint64_t* out_challenges, uint64_t* out_final_evals) {
+    if (!ctx || !c || !classes || !tr || !s || n_classes < 1 || n_total < 1 || max_degree < 1 || max_degree > 8) {
+        g_dist_err = "batched: bad arguments (an explicit stream is required)";
+        return CENO_HIP_ERR_INVALID;
+    }
+    if (!c->shm) {
+        g_dist_err = "batched: the communicator needs the shared-memory exchange (ceno_dist_comm_attach_shm)";
+        return CENO_HIP_ERR_STATE;
+    }
+    const int world = c->world, d = max_degree;
+    int log_w = 0;
+    while ((1 << log_w) < world) log_w++;
+    if ((1 << log_w) != world) {
+        g_dist_err = "batched: world size must be a power of two";
+        return CENO_HIP_ERR_INVALID;
+    }
+    std::vector<size_t> fin_off(n_classes + 1, 0);
+    for (int i = 0; i < n_classes; i++) fin_off[i + 1] = fin_off[i] + (size_t)classes[i].num_mles;
+    std::vector<Seg> segs;
+    int rc = 0;
+    auto cleanup = [&]() {
+        for (auto& g : segs) {
+            if (g.sc) ceno_hip_sumcheck_free(ctx, g.sc);
+            for (auto* m : g.owned) ceno_hip_mle_free(ctx, m);
+        }
+    };
+    auto hip_fail = [&](int code) {
+        g_dist_err = ceno_hip_last_error(ctx);
+        cleanup();
+        return code;
+    };
+    auto begin_seg = [&](int ci, ceno_hip_mle* const* mles, int max_nv, bool sharded, int start, int end, std::vector<ceno_hip_mle*> owned) {
+        const ceno_dist_class& K = classes[ci];
+        ceno_hip_sumcheck_plan plan;
+        memset(&plan, 0, sizeof(plan));
+        plan.num_mles = K.num_mles;
+        plan.num_terms = K.num_terms;
+        plan.term_coeffs = K.term_coeffs;
+        plan.term_offsets = K.term_offsets;
+        plan.term_mle_idx = K.term_mle_idx;
+        plan.max_num_vars = max_nv;
+        plan.max_degree = d;
+        Seg g;
+        g.cls = ci;
+        g.sharded = sharded;
+        g.start = start;
+        g.end = end;
+        g.owned = std::move(owned);
+        int r = ceno_hip_sumcheck_begin(ctx, mles, &plan, s, &g.sc);
+        segs.push_back(std::move(g));
+        return r;
+    };
+    // per-rank values of a class (k ext) -> world-sized replicated tables that join at round `first`
+    auto start_tail = [&](int ci, const uint64_t* local_vals, int first) -> int {
+        const int k = classes[ci].num_mles;
+        if (k > 64) {
+            g_dist_err = "batched: more than 64 MLEs in a sharded class";
+            return CENO_HIP_ERR_INVALID;
+        }
+        int r = shm_gather_ext(c, local_vals, k);
+        if (r) return r;
+        std::vector<ceno_hip_mle*> tabs(k, nullptr);
+        std::vector<uint64_t> tab(2 * (size_t)world);
+        for (int j = 0; j < k && !r; j++) {
+            for (int g = 0; g < world; g++) {
+                tab[2 * g] = c->h_recv[2 * ((size_t)g * k + j)];
+                tab[2 * g + 1] = c->h_recv[2 * ((size_t)g * k + j) + 1];
+            }
+            r = ceno_hip_mle_upload(ctx, tab.data(), log_w, 1, s, &tabs[j]);
+        }
+        if (r) {
+            for (auto* m : tabs)
+                if (m) ceno_hip_mle_free(ctx, m);
+            g_dist_err = ceno_hip_last_error(ctx);
+            return r;
+        }
+        std::vector<ceno_hip_mle*> keep = tabs;
+        r = begin_seg(ci, tabs.data(), n_total - first, false, first, n_total, std::move(keep));
+        if (r) g_dist_err = ceno_hip_last_error(ctx);
+        return r;
+    };
+
+    tr_usize(tr, (uint64_t)n_total);
+    tr_usize(tr, (uint64_t)d);
+    for (int ci = 0; ci < n_classes && !rc; ci++) {
+        const ceno_dist_class& K = classes[ci];
+        if (K.num_vars < 1 || K.num_vars > n_total || K.num_mles < 1 || K.num_terms < 1) {
+            g_dist_err = "batched: bad class";
+            cleanup();
+            return CENO_HIP_ERR_INVALID;
+        }
+        if (K.sharded && world > 1) {
+            const int nvl = K.num_vars - log_w;
+            if (nvl < 1) {
+                g_dist_err = "batched: a sharded class needs more than log2(world) variables (pass it replicated)";
+                cleanup();
+                return CENO_HIP_ERR_INVALID;
+            }
+            rc = begin_seg(ci, K.mles, nvl, true, 0, nvl, {});
+        } else {
+            rc = begin_seg(ci, K.mles, n_total, false, 0, n_total, {});
+        }
+    }
+    if (rc) return hip_fail(rc);
+    uint64_t ch[2] = {0, 0};
+    std::vector<uint64_t> part, msg(2 * (size_t)d), tmp(2 * (size_t)d);
+    for (int i = 0; i < n_total; i++) {
+        std::vector<int> live_sh, live_rp;
+        for (int g = 0; g < (int)segs.size(); g++)
+            if (segs[g].start <= i && i < segs[g].end) (segs[g].sharded ? live_sh : live_rp).push_back(g);
+        for (int t = 0; t < 2 * d; t++) msg[t] = 0;
+        auto add_into_msg = [&](const uint64_t* m) {
+            for (int t = 0; t < d; t++) {
+                E2 a = E2{msg[2 * t], msg[2 * t + 1]} + E2{m[2 * t], m[2 * t + 1]};
+                msg[2 * t] = a.c0;
+                msg[2 * t + 1] = a.c1;
+            }
+        };
+        if (!live_sh.empty()) {
+            if ((int)live_sh.size() * d > 64) {
+                g_dist_err = "batched: more than 64 partial evaluations per rank in one round";
+                cleanup();
+                return CENO_HIP_ERR_INVALID;
+            }
+            part.assign(2 * (size_t)d * live_sh.size(), 0);
+            for (size_t q = 0; q < live_sh.size(); q++) {
+                Seg& g = segs[live_sh[q]];
+                rc = ceno_hip_sumcheck_round(ctx, g.sc, i == g.start ? nullptr : ch, part.data() + 2 * (size_t)d * q);
+                if (rc) return hip_fail(rc);
+            }
+            rc = shm_gather_ext(c, part.data(), d * (int)live_sh.size());
+            if (rc) {
+                cleanup();
+                return rc;
+            }
+            for (int g = 0; g < world; g++)
+                for (size_t q = 0; q < live_sh.size(); q++) add_into_msg(c->h_recv + 2 * ((size_t)g * live_sh.size() + q) * d);
+        }
+        for (int gi : live_rp) {
+            Seg& g = segs[gi];
+            rc = ceno_hip_sumcheck_round(ctx, g.sc, i == g.start ? nullptr : ch, tmp.data());
+            if (rc) return hip_fail(rc);
+            add_into_msg(tmp.data());
+        }
+        memcpy(out_msgs + (size_t)2 * d * i, msg.data(), (size_t)16 * d);
+        E2 rr = absorb_round(tr, msg.data(), d);
+        ch[0] = rr.c0;
+        ch[1] = rr.c1;
+        out_challenges[2 * i] = rr.c0;
+        out_challenges[2 * i + 1] = rr.c1;
+        for (int gi : live_sh) {
+            if (segs[gi].end != i + 1) continue;  // last local variable bound: one value per table per rank
+            std::vector<uint64_t> fin(2 * (size_t)classes[segs[gi].cls].num_mles);
+            rc = ceno_hip_sumcheck_finish(ctx, segs[gi].sc, ch, fin.data());
+            if (rc) return hip_fail(rc);
+            ceno_hip_sumcheck_free(ctx, segs[gi].sc);
+            segs[gi].sc = nullptr;
+            const int ci = segs[gi].cls;
+            rc = start_tail(ci, fin.data(), i + 1);  // may reallocate `segs`
+            if (rc) {
+                cleanup();
+                return rc;
+            }
+        }
+    }
+    for (auto& g : segs) {
+        if (g.sharded || !g.sc) continue;
+        rc = ceno_hip_sumcheck_finish(ctx, g.sc, ch, out_final_evals + 2 * fin_off[g.cls]);
+        if (rc) return hip_fail(rc);
+    }
+    cleanup();
+    return 0;
+}
+
+extern "C" {
+
 /* Sumcheck of the plan's terms over a 2^n_total hypercube whose tables are sharded by their top
  * log2(world) index bits: `mles` are this rank's shards (n_total - log2(world) variables each).
  * Same transcript script as IOPProverState::prove, so the proof equals the single-device proof of the

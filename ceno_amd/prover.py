@@ -421,6 +421,41 @@ class ShmComm:
             pass
 
 
+class DistClassC(C.Structure):
+    _fields_ = [("num_vars", C.c_int), ("sharded", C.c_int), ("num_mles", C.c_int), ("mles", C.POINTER(C.c_void_p)),
+                ("num_terms", C.c_int), ("term_coeffs", u64p), ("term_offsets", u32p), ("term_mle_idx", u32p)]
+
+
+def dist_batched_sumcheck_prove(dev: Device, comm, classes: Sequence[dict], n_total: int, max_degree: int, tr: Transcript, stream):
+    """mixed-size batched sumcheck across ranks (C++ driver, shared-memory exchange).  classes: dicts with num_vars
+    (global), sharded, mles (Mle handles of this rank), coeffs (T,2), terms [[class-local ids]].
+    Returns (msgs, challenges, [final evals per class])."""
+    L = plib()
+    L.ceno_dist_batched_sumcheck_prove.restype = C.c_int
+    arr = (DistClassC * len(classes))()
+    keep = []
+    for i, c in enumerate(classes):
+        mh = (C.c_void_p * len(c["mles"]))(*[m.h for m in c["mles"]])
+        coeffs = np.ascontiguousarray(c["coeffs"], dtype=np.uint64).reshape(-1, 2)
+        toff, tidx = _csr(c["terms"])
+        K = arr[i]
+        K.num_vars, K.sharded, K.num_mles, K.mles = int(c["num_vars"]), int(bool(c["sharded"])), len(c["mles"]), mh
+        K.num_terms, K.term_coeffs, K.term_offsets, K.term_mle_idx = len(c["terms"]), _p(coeffs), _p32(toff), _p32(tidx)
+        keep += [mh, coeffs, toff, tidx]
+    total = sum(len(c["mles"]) for c in classes)
+    msgs = np.zeros((n_total, max_degree, 2), dtype=np.uint64)
+    chal = np.zeros((n_total, 2), dtype=np.uint64)
+    fin = np.zeros((total, 2), dtype=np.uint64)
+    rc = L.ceno_dist_batched_sumcheck_prove(dev.h, comm.h, arr, len(classes), n_total, max_degree, tr.h, stream, _p(msgs), _p(chal), _p(fin))
+    if rc != 0:
+        raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+    out, off = [], 0
+    for c in classes:
+        out.append(fin[off: off + len(c["mles"])])
+        off += len(c["mles"])
+    return msgs, chal, out
+
+
 def dist_sumcheck_prove(dev: Device, comm, mles: Sequence[Mle], coeffs: np.ndarray, terms, n_total: int,
                         max_degree: int, tr: Transcript, stream):
     """sharded IOPProverState::prove — `mles` are this rank's shards; returns the global proof"""

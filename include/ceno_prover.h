@@ -194,6 +194,22 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
 int ceno_dist_comm_attach_shm(ceno_dist_comm** c, int world, int rank, const char* name, int create);
 int ceno_dist_shm_unlink(const char* name);
 int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters);
+/* Mixed-size (front-loaded) batched sumcheck across ranks (BASELINE config #4): every size class is
+ * split along the top bits of ITS OWN hypercube or replicated; needs the shared-memory exchange.  Term MLE ids are
+ * class-local.  out_final_evals: concatenated per class (num_mles ext each), identical on every rank. */
+typedef struct ceno_dist_class {
+    int num_vars;                  /* GLOBAL number of variables of the class */
+    int sharded;                   /* 1: `mles` are slice `rank` (num_vars - log2(world) variables); 0: whole tables on every rank */
+    int num_mles;
+    ceno_hip_mle* const* mles;
+    int num_terms;
+    const uint64_t* term_coeffs;   /* 2 * num_terms words */
+    const uint32_t* term_offsets;  /* num_terms + 1 */
+    const uint32_t* term_mle_idx;
+} ceno_dist_class;
+int ceno_dist_batched_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_dist_class* classes, int n_classes, int n_total,
+                                     int max_degree, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs,
+                                     uint64_t* out_challenges, uint64_t* out_final_evals);
 const char* ceno_dist_last_error(void);
 
 #ifdef __cplusplus

@@ -159,6 +159,34 @@ def main_shm_gpu(out_dir, n_local):
     dist.destroy_process_group()
 
 
+def main_shm_gpu_batched(out_dir, n_total):
+    """C++ mixed-size batched sharded driver, `world` processes sharing GPU 0"""
+    import torch.distributed as dist
+
+    from ceno_amd import Device
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    log_w = world.bit_length() - 1
+    dev = Device(0)
+    classes = []
+    for c in batched_case(n_total):
+        sharded = c["num_vars"] > log_w and c["num_vars"] != 2
+        tabs = c["tables"]
+        if sharded:
+            m = 1 << (c["num_vars"] - log_w)
+            tabs = [t[rank * m:(rank + 1) * m] for t in tabs]
+        classes.append(dict(num_vars=c["num_vars"], sharded=sharded, mles=[dev.upload(np.ascontiguousarray(t)) for t in tabs],
+                            coeffs=c["coeffs"], terms=c["terms"]))
+    comm = prover.ShmComm(world, rank, dist)
+    stream = dev.stream_create()
+    msgs, chal, fins = prover.dist_batched_sumcheck_prove(dev, comm, classes, n_total, 3, prover.Transcript.stub(0xF5), stream)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=msgs, chal=chal, fin=np.concatenate(fins))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 def main():
     import torch.distributed as dist
 
@@ -168,6 +196,8 @@ def main():
         return main_shm(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":
         return main_shm_gpu(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_batched":
+        return main_shm_gpu_batched(sys.argv[1], int(sys.argv[2]))
     out_dir = sys.argv[1]
     n_local = int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
