@@ -22,6 +22,8 @@ def main():
     import torch
     from ceno_amd import Device, api, prover
 
+    if os.environ.get("CENO_SWITCH_INTERVAL"):
+        sys.setswitchinterval(float(os.environ["CENO_SWITCH_INTERVAL"]))
     dev = Device(0)
     P = api.P
     n, w = args.log_rows, 22
