@@ -1177,6 +1177,9 @@ static int sc_wait_flag(ceno_hip_sumcheck* sc, unsigned long long seq) {
     volatile unsigned long long* f = sc->h_flag;
     unsigned long long spins = 0;
     while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();  // several lanes may be spinning on their flags at once
+#endif
         if ((++spins & 0xFFFFF) == 0) {
             // every ~1M polls make sure the stream is still alive (a faulted kernel never writes the flag)
             hipError_t q = hipStreamQuery(sc->st);

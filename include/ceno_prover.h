@@ -174,6 +174,19 @@ size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries);
 int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_t* const* points, const uint64_t* const* evals,
                               int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof);
 
+/* ---- concurrent chip proving on lanes (scheduler.rs:231-336, memory booking :342-347,:622-652) ----
+ * One worker thread per lane, each with its own stream (ceno_hip_stream_create_lane); tasks are taken largest-estimate
+ * first, booked against the pool before they start (greedy back-fill with smaller tasks when the largest does not fit)
+ * and unbooked when done.  `fn` runs the C ABI calls of one chip proof on the given stream and returns 0 or an error.
+ * out_status / out_lane (n_tasks each, may be NULL) receive every task's return code and the lane that ran it. */
+typedef int (*ceno_lane_task_fn)(void* arg, int lane, ceno_hip_stream stream);
+typedef struct ceno_lane_task {
+    ceno_lane_task_fn fn;
+    void* arg;
+    size_t estimated_bytes;
+} ceno_lane_task;
+int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane);
+
 const char* ceno_prover_last_error(void);
 
 /* ---- hypercube-sharded sumcheck over the GPUs of one node (ceno_amd/host/dist.cpp) ----

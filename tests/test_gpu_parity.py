@@ -678,3 +678,46 @@ def test_memory_booking_for_a_scheduler():
     assert L.ceno_hip_mem_unbook(d.h, 1 << 40) == 0  # over-unbooking clamps at zero
     assert L.ceno_hip_mem_booked(d.h) == 0
     d.close()
+
+
+def test_lane_scheduler_runs_every_task_once_with_booking(dev, prover):
+    """ceno_prover_lanes_run (scheduler.rs:231-336 + booking :622-652): every task runs exactly once on some lane's
+    stream, results are bit-exact whatever the interleaving, and estimates are booked / unbooked around each task"""
+    import ctypes as C
+
+    L = prover.plib()
+    TASK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+
+    class LaneTask(C.Structure):
+        _fields_ = [("fn", TASK), ("arg", C.c_void_p), ("estimated_bytes", C.c_size_t)]
+
+    L.ceno_prover_lanes_run.restype = C.c_int
+    L.ceno_prover_lanes_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(LaneTask), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    n_tasks, nv, k = 7, 11, 3
+    tables = [[po.rand_ext(1 << nv, 300 + 10 * t + j) for j in range(k)] for t in range(n_tasks)]
+    mles = [[dev.upload(x) for x in tabs] for tabs in tables]
+    results, seen_booked = [None] * n_tasks, []
+
+    def body(arg, lane, stream):
+        t = int(arg or 0)
+        try:
+            seen_booked.append(int(dev.L.ceno_hip_mem_booked(dev.h)))
+            results[t] = prover.sumcheck_prove(dev, mles[t], po.ext([1]), [list(range(k))], nv, k, prover.Transcript.stub(50 + t),
+                                               stream=C.c_void_p(stream))
+            return 0
+        except Exception:  # noqa: BLE001
+            return -1
+
+    cb = TASK(body)
+    arr = (LaneTask * n_tasks)()
+    for t in range(n_tasks):
+        arr[t].fn, arr[t].arg, arr[t].estimated_bytes = cb, C.c_void_p(t) if t else None, (t + 1) << 20
+    status = (C.c_int * n_tasks)(*([-99] * n_tasks))
+    lanes = (C.c_int * n_tasks)(*([-1] * n_tasks))
+    assert L.ceno_prover_lanes_run(dev.h, 3, arr, n_tasks, status, lanes) == 0
+    assert list(status) == [0] * n_tasks and all(0 <= x < 3 for x in lanes)
+    assert min(seen_booked) >= 1 << 20 and dev.L.ceno_hip_mem_booked(dev.h) == 0
+    for t in range(n_tasks):
+        exp = po.sumcheck_prove(tables[t], po.ext([1]), [list(range(k))], nv, k, po.StubTranscript(50 + t))
+        for g, e in zip(results[t], exp):
+            assert np.array_equal(g, e)
