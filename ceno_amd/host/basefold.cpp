@@ -102,8 +102,8 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         for (auto* m : owned) ceno_hip_mle_free(ctx, m);
         if (d_scratch) (void)hipFree(d_scratch);
     };
-    auto fail = [&](int rc) {
-        std::string msg = ceno_hip_last_error(ctx);
+    auto fail = [&](int rc, const char* what = nullptr) {
+        std::string msg = what ? std::string("basefold_open: ") + what : std::string(ceno_hip_last_error(ctx));
         cleanup();
         return prover_set_error(rc, msg.c_str());
     };
@@ -189,9 +189,9 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         const int prio[2] = {greatest, least};
         for (int i = 0; i < 2; i++) {
             hipStream_t hs = nullptr;
-            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, prio[i]) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, prio[i]) != hipSuccess) return fail(CENO_HIP_ERR_HIP, "hipStreamCreateWithPriority failed");
             sx[i] = (ceno_hip_stream)hs;
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return fail(CENO_HIP_ERR_HIP, "hipEventCreate failed");
         }
     }
     if (n > 0) {
@@ -328,7 +328,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     }
     uint64_t* d_idx = (uint64_t*)d_scratch;
     uint64_t* d_ans = d_idx + Q;
-    if (hipMemcpyAsync(d_idx, qidx.data(), Q * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(CENO_HIP_ERR_HIP);
+    if (hipMemcpyAsync(d_idx, qidx.data(), Q * 8, hipMemcpyHostToDevice, st) != hipSuccess) return fail(CENO_HIP_ERR_HIP, "upload of the query indices failed");
     struct Piece { size_t off, per_q; };
     std::vector<Piece> pieces;
     size_t off = 0;
@@ -355,7 +355,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     if (rc) return fail(rc);
     std::vector<uint64_t> ans(ans_words);
     if (hipMemcpyAsync(ans.data(), d_ans, ans_words * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return fail(CENO_HIP_ERR_HIP);
+        return fail(CENO_HIP_ERR_HIP, "download of the query answers failed");
     lap("query gathers");
     for (size_t q = 0; q < Q; q++) {
         uint64_t* out = qbase + q * qw;

@@ -41,7 +41,7 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
-std::string g_dist_err;
+thread_local std::string g_dist_err;
 
 int load_rccl() {
     if (g_rccl.h) return 0;
