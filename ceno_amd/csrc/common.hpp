@@ -34,6 +34,11 @@ struct ceno_hip_ctx {
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
     std::unordered_map<void*, size_t> pinned_live;
+    // ---- challenge mailboxes in host-writable device memory (large-BAR boxes): the device polls HBM, the host posts one
+    // PCIe write per challenge; vram_state: 0 = not probed, 1 = available, -1 = unavailable (mailboxes stay in pinned memory)
+    int vram_state = 0;
+    char* vram_arena = nullptr;
+    std::vector<int> vram_free_slots;
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----
@@ -59,6 +64,9 @@ int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
 void ctx_free(ceno_hip_ctx* ctx, void* p);
 // pinned, device-mapped host memory from a per-context cache; *dev_view is the device address of *host
+// 64-byte slot of fine-grained device memory the host can write through the BAR (nullptr when unavailable)
+void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx);
+void ctx_vram_slot_free(ceno_hip_ctx* ctx, void* slot);
 int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view);
 void ctx_pinned_free(ceno_hip_ctx* ctx, void* host);
 inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) { return s ? (hipStream_t)s : ctx->default_stream; }

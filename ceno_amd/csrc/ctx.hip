@@ -87,6 +87,33 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
     ctx->free_lists[b].push_back(p);
 }
 
+static constexpr int VRAM_SLOTS = 1024;
+void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->vram_state == 0) {
+        ctx->vram_state = -1;
+        const char* env = getenv("CENO_HIP_VRAM_MAILBOX");  // 0 keeps the mailboxes in pinned host memory (A/B measurements)
+        int large_bar = 0;
+        if ((!env || atoi(env) != 0) && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) == hipSuccess && large_bar) {
+            void* p = nullptr;
+            if (hipExtMallocWithFlags(&p, (size_t)VRAM_SLOTS * 64, hipDeviceMallocFinegrained) == hipSuccess && p) {
+                ctx->vram_arena = (char*)p;
+                for (int i = VRAM_SLOTS - 1; i >= 0; i--) ctx->vram_free_slots.push_back(i);
+                ctx->vram_state = 1;
+            }
+        }
+    }
+    if (ctx->vram_state != 1 || ctx->vram_free_slots.empty()) return nullptr;
+    const int i = ctx->vram_free_slots.back();
+    ctx->vram_free_slots.pop_back();
+    return ctx->vram_arena + (size_t)i * 64;
+}
+void ctx_vram_slot_free(ceno_hip_ctx* ctx, void* slot) {
+    if (!slot) return;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->vram_free_slots.push_back((int)(((char*)slot - ctx->vram_arena) / 64));
+}
+
 int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view) {
     size_t b = 4096;
     while (b < bytes) b <<= 1;
@@ -167,6 +194,7 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->prof_event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
+    if (ctx->vram_arena) (void)hipFree(ctx->vram_arena);
     if (ctx->default_stream) (void)hipStreamDestroy(ctx->default_stream);
     delete ctx;
 }
