@@ -288,10 +288,69 @@ static int gather_ext(ceno_dist_comm* c, int n_ext, hipStream_t st) {
     return 0;
 }
 
-// replicated last rounds on world-sized tables built from the per-rank final values (index = rank = the top bits)
-static int dist_tail(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumcheck_plan* plan_local, int n_local, int log_w, int d, int k,
-                     ceno_transcript* tr, ceno_hip_stream s, uint64_t* ch, uint64_t* out_msgs, uint64_t* out_challenges,
-                     uint64_t* out_final_evals) {
+// Replicated last log2(world) rounds on world-sized tables built from the per-rank final values (index = rank = the top
+// bits).  The tables hold `world` <= 64 elements each: every rank evaluates these rounds directly on the host (a few
+// hundred field multiplications) instead of paying a device sumcheck set-up for them; CENO_DIST_GPU_TAIL=1 keeps the
+// device path for comparison.  Terms of a common-factor group list only their residual factors (include/ceno_hip.h),
+// so the group's common factors are multiplied back in here.
+static int dist_tail_host(ceno_dist_comm* c, const ceno_hip_sumcheck_plan* plan, int n_local, int log_w, int d, int k, ceno_transcript* tr,
+                          uint64_t* ch, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
+    const int world = c->world;
+    std::vector<std::vector<E2>> tab(k, std::vector<E2>(world));
+    for (int j = 0; j < k; j++)
+        for (int g = 0; g < world; g++) tab[j][g] = E2{c->h_recv[2 * ((size_t)g * k + j)], c->h_recv[2 * ((size_t)g * k + j) + 1]};
+    // full factor list per term: residual factors + the common factors of its group
+    std::vector<std::vector<uint32_t>> factors(plan->num_terms);
+    for (int t = 0; t < plan->num_terms; t++)
+        for (uint32_t q = plan->term_offsets[t]; q < plan->term_offsets[t + 1]; q++) factors[t].push_back(plan->term_mle_idx[q]);
+    for (int g = 0; g < plan->num_groups; g++)
+        for (uint32_t q = plan->group_term_offsets[g]; q < plan->group_term_offsets[g + 1]; q++)
+            for (uint32_t cc = plan->common_offsets[g]; cc < plan->common_offsets[g + 1]; cc++)
+                factors[plan->group_term_idx[q]].push_back(plan->common_mle_idx[cc]);
+    std::vector<uint64_t> msg(2 * (size_t)d);
+    size_t len = (size_t)world;
+    for (int r = 0; r < log_w; r++) {
+        const size_t pairs = len / 2;
+        std::vector<E2> acc(d, gl::e2_zero());
+        for (int t = 0; t < plan->num_terms; t++) {
+            const E2 coeff{plan->term_coeffs[2 * t], plan->term_coeffs[2 * t + 1]};
+            for (size_t p = 0; p < pairs; p++) {
+                std::vector<E2> pr(d, coeff);
+                for (uint32_t j : factors[t]) {
+                    const E2 lo = tab[j][2 * p], hi = tab[j][2 * p + 1], delta = hi - lo;
+                    E2 x = hi;
+                    for (int e = 0; e < d; e++) {
+                        pr[e] = pr[e] * x;
+                        x = x + delta;
+                    }
+                }
+                for (int e = 0; e < d; e++) acc[e] = acc[e] + pr[e];
+            }
+        }
+        for (int e = 0; e < d; e++) {
+            msg[2 * e] = acc[e].c0;
+            msg[2 * e + 1] = acc[e].c1;
+        }
+        memcpy(out_msgs + (size_t)2 * d * (n_local + r), msg.data(), (size_t)16 * d);
+        const E2 rr = absorb_round(tr, msg.data(), d);
+        ch[0] = rr.c0;
+        ch[1] = rr.c1;
+        out_challenges[2 * (n_local + r)] = rr.c0;
+        out_challenges[2 * (n_local + r) + 1] = rr.c1;
+        for (int j = 0; j < k; j++)
+            for (size_t p = 0; p < pairs; p++) tab[j][p] = tab[j][2 * p] + rr * (tab[j][2 * p + 1] - tab[j][2 * p]);
+        len = pairs;
+    }
+    for (int j = 0; j < k; j++) {
+        out_final_evals[2 * j] = tab[j][0].c0;
+        out_final_evals[2 * j + 1] = tab[j][0].c1;
+    }
+    return 0;
+}
+
+static int dist_tail_device(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumcheck_plan* plan_local, int n_local, int log_w, int d, int k,
+                            ceno_transcript* tr, ceno_hip_stream s, uint64_t* ch, uint64_t* out_msgs, uint64_t* out_challenges,
+                            uint64_t* out_final_evals) {
     const int world = c->world;
     std::vector<ceno_hip_mle*> tail(k, nullptr);
     std::vector<uint64_t> tab(2 * (size_t)world), msg(2 * (size_t)d);
@@ -326,6 +385,14 @@ static int dist_tail(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumche
         if (m) ceno_hip_mle_free(ctx, m);
     if (rc) g_dist_err = ceno_hip_last_error(ctx);
     return rc;
+}
+
+static int dist_tail(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumcheck_plan* plan_local, int n_local, int log_w, int d, int k,
+                     ceno_transcript* tr, ceno_hip_stream s, uint64_t* ch, uint64_t* out_msgs, uint64_t* out_challenges,
+                     uint64_t* out_final_evals) {
+    if (getenv("CENO_DIST_GPU_TAIL"))
+        return dist_tail_device(ctx, c, plan_local, n_local, log_w, d, k, tr, s, ch, out_msgs, out_challenges, out_final_evals);
+    return dist_tail_host(c, plan_local, n_local, log_w, d, k, tr, ch, out_msgs, out_challenges, out_final_evals);
 }
 
 // Sharded rounds with the host shared-memory exchange: every rank runs the ordinary PIPELINED single-device round
