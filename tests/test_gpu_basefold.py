@@ -113,3 +113,39 @@ def test_batch_columns_and_fold_commit_primitives(dev):
             want = po.e2_add(want, po.e2_mul((int(coeffs[k, 0]), int(coeffs[k, 1])), (int(cols[k, i]), 0)))
         want = po.e2_add(want, want)
         assert (int(got[i, 0]), int(got[i, 1])) == want
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_open_random_shapes_differential(dev, seed):
+    """seeded random commitments (1-5 matrices, 1-9 variables, 1-9 columns, blow-up 2 or 4, ragged row counts that are
+    zero padded) opened at random points: proof equal to the oracle's word for word, verifier accepts"""
+    import random
+
+    from ceno_amd import prover
+
+    rng = random.Random(77 + seed)
+    rate_log = rng.choice([1, 1, 2])
+    shapes, traces = [], []
+    for i in range(rng.randint(1, 5)):
+        nv, w = rng.randint(1, 9), rng.randint(1, 9)
+        n_inst = rng.randint(max(1, (1 << nv) // 2 + 1), 1 << nv) if nv > 1 else rng.choice([1, 2])
+        t = po.rand_base(n_inst * w, 1000 * seed + i).reshape(n_inst, w)
+        traces.append(t)
+        shapes.append((nv, w))
+    padded = []
+    for t, (nv, w) in zip(traces, shapes):
+        p = np.zeros((1 << nv, w), dtype=np.uint64)
+        p[: t.shape[0]] = t
+        padded.append(p)
+    points = [po.rand_ext(nv, 31 * seed + i) for i, (nv, _) in enumerate(shapes)]
+    evals = [np.array([po.mle_evaluate(p[:, c].copy(), pt) for c in range(p.shape[1])], dtype=np.uint64) for p, pt in zip(padded, points)]
+    nq, pow_bits = rng.randint(1, 12), rng.choice([0, 3, 6])
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, traces, rate_log, stream)
+    proof = pcs.basefold_open(points, evals, nq, pow_bits, prover.Transcript.stub(seed))
+    expect = po.basefold_open(padded, points, evals, rate_log, nq, pow_bits, po.StubTranscript(seed))
+    assert np.array_equal(proof, expect)
+    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+    assert po.basefold_verify(shapes, roots, points, evals, rate_log, nq, pow_bits, po.StubTranscript(seed), proof) == 0
+    pcs.free()
+    dev.stream_destroy(stream)

@@ -721,3 +721,48 @@ def test_lane_scheduler_runs_every_task_once_with_booking(dev, prover):
         exp = po.sumcheck_prove(tables[t], po.ext([1]), [list(range(k))], nv, k, po.StubTranscript(50 + t))
         for g, e in zip(results[t], exp):
             assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sumcheck_random_plans_differential(dev, prover, seed):
+    """seeded random plans against the oracle: 1-3 size classes (front-loading), base / ext tables, 1-9 terms of degree
+    1-5, optional common-factor groups, sizes on both sides of the tile / two-kernel / dense thresholds, pipelined and
+    round-by-round drivers"""
+    import random
+
+    from ceno_amd import Sumcheck
+
+    rng = random.Random(1000 + seed)
+    max_nv = rng.choice([3, 6, 9, 12, 15, 17, 18])
+    n_classes = rng.choice([1, 1, 2, 3])
+    sizes = sorted({max_nv} | {rng.randint(1, max_nv) for _ in range(n_classes - 1)}, reverse=True)
+    tables, cls_of = [], []
+    for ci, nv in enumerate(sizes):
+        for j in range(rng.randint(1, 4)):
+            is_ext = rng.random() < 0.6
+            tables.append(po.rand_ext(1 << nv, 97 * seed + len(tables)) if is_ext else po.rand_base(1 << nv, 97 * seed + len(tables)))
+            cls_of.append(ci)
+    d = rng.randint(2, 5)
+    terms = []
+    for _ in range(rng.randint(1, 9)):
+        ci = rng.randrange(len(sizes))
+        members = [j for j, c in enumerate(cls_of) if c == ci]
+        terms.append([rng.choice(members) for _ in range(rng.randint(1, d))])
+    groups = None
+    if rng.random() < 0.4:  # a common factor in front of all terms of the largest class that leave room for it
+        big = [j for j, c in enumerate(cls_of) if c == 0]
+        members = [t for t, fac in enumerate(terms) if cls_of[fac[0]] == 0 and len(fac) < d]
+        if members:
+            groups = [([rng.choice(big)], members)]
+    coeffs = po.rand_ext(len(terms), 5000 + seed)
+    msgs, chal, fin = _run_both(dev, prover, tables, coeffs, terms, max_nv, d, groups=groups, seed=seed + 7)
+    # the same plan driven round by round without pipelining must give the same transcript
+    mles = [dev.upload(t) for t in tables]
+    sc = Sumcheck(dev, mles, coeffs, terms, max_nv, d, groups=groups)
+    ch = None
+    for i in range(max_nv):
+        m = sc.round(ch)
+        assert np.array_equal(m, msgs[i]), i
+        ch = tup(chal[i])
+    assert np.array_equal(sc.finish(ch), fin)
+    sc.free()
