@@ -766,3 +766,52 @@ def test_sumcheck_random_plans_differential(dev, prover, seed):
         ch = tup(chal[i])
     assert np.array_equal(sc.finish(ch), fin)
     sc.free()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tower_random_specs_differential(dev, prover, seed):
+    """seeded random tower batches (0-3 product specs, 0-2 LogUp specs with or without numerators, heights 2-13 so that
+    layers cross the tile / two-kernel thresholds): out-evals, every message, every per-round evaluation and the point
+    equal the oracle's; the restated TowerVerify accepts"""
+    import random
+
+    rng = random.Random(400 + seed)
+
+    def last(nv, s):
+        return [po.rand_ext(1 << (nv - 1), s), po.rand_ext(1 << (nv - 1), s + 1)]
+
+    n_p, n_l = rng.randint(0, 3), rng.randint(0, 2)
+    if n_p + n_l == 0:
+        n_p = 1
+    hp = [rng.randint(2, 13) for _ in range(n_p)]
+    hl = [rng.randint(2, 13) for _ in range(n_l)]
+    pl = [last(h, 10 * i + seed) for i, h in enumerate(hp)]
+    ql = [((last(h, 500 + 10 * i + seed) if rng.random() < 0.5 else None), last(h, 700 + 10 * i + seed)) for i, h in enumerate(hl)]
+    specs_p = [po.infer_tower_product_witness(h, l) for h, l in zip(hp, pl)]
+    specs_l = [po.infer_tower_logup_witness(p, q) for p, q in ql]
+    towers_p = [prover.Tower.from_last_layer(dev, [dev.upload(x) for x in l]) for l in pl]
+    towers_l = [prover.Tower.from_last_layer(dev, [dev.upload(p[0]) if p else None, dev.upload(p[1]) if p else None,
+                                                   dev.upload(q[0]), dev.upload(q[1])]) for p, q in ql]
+    out_evals, proof = prover.prove_tower_relation(dev, towers_p, towers_l, prover.Transcript.stub(seed))
+    tr = po.StubTranscript(seed)
+    po_ev = np.stack([np.stack([s[0][0][0], s[0][1][0]]) for s in specs_p]) if n_p else np.zeros((0, 2, 2), dtype=np.uint64)
+    lo_ev = np.stack([np.stack([s[0][k][0] for k in range(4)]) for s in specs_l]) if n_l else np.zeros((0, 4, 2), dtype=np.uint64)
+    flat = list(po_ev.reshape(-1, 2)) + list(lo_ev.reshape(-1, 2))
+    for e in flat:
+        tr.append_ext(tup(e))
+    oproof = po.tower_prove(specs_p, specs_l, tr)
+    max_h = max(hp + hl)
+    assert np.array_equal(out_evals, np.array(flat, dtype=np.uint64).reshape(-1, 2))
+    assert np.array_equal(proof.msgs, oproof.msgs)
+    if n_p:
+        assert np.array_equal(proof.prod_evals, oproof.prod_evals)
+    if n_l:
+        assert np.array_equal(proof.logup_evals, oproof.logup_evals)
+    assert np.array_equal(proof.point[:max_h], oproof.point[:max_h])
+    vt = po.StubTranscript(seed)
+    for e in flat:
+        vt.append_ext(tup(e))
+    rc, *_ = po.tower_verify(po_ev, lo_ev, hp + hl, oproof, vt)
+    assert rc == 0
+    for t in towers_p + towers_l:
+        t.free()
