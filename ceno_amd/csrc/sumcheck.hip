@@ -86,28 +86,29 @@ __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_a
 // the message, then polls the host mailbox for challenge i (bounded: ~4 s of wall clock or the host's
 // `abort`) and relays it through device memory; the already queued kernel of round i+1 picks it up with a
 // single load at its start.  Exactly one lane ever polls PCIe, nothing spins inside the big kernels.
-__device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
-    const Mailbox* mb = ep.mailbox;
-    Bcast* bc = ep.bcast;
+// one lane polls the host's mailbox for challenge `want_seq` (bounded: ~4 s of wall clock or the host's `abort`)
+__device__ __forceinline__ bool poll_challenge(const Mailbox* mb, unsigned long long want_seq, unsigned long long& c0, unsigned long long& c1) {
     const unsigned long long t0 = wall_clock64();  // 100 MHz
-    bool ok = true;
     unsigned spins = 0;
     for (;;) {
         // relaxed polls: an acquire per poll would invalidate the (large) L2 every iteration
-        if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ep.next_seq) break;
+        if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want_seq) break;
         if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > 400000000ull) {
-                ok = false;
-                break;
-            }
+            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > 400000000ull) return false;
         }
     }
+    // the host stores chal[] before chal_seq (release); these loads are issued only after the seq load
+    // has returned (control dependency + waitcnt) and bypass the caches, so they see the new words
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c0 = __hip_atomic_load(&mb->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    c1 = __hip_atomic_load(&mb->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+}
+__device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
+    Bcast* bc = ep.bcast;
+    unsigned long long c0 = 0, c1 = 0;
+    const bool ok = poll_challenge(ep.mailbox, ep.next_seq, c0, c1);
     if (ok) {
-        // the host stores chal[] before chal_seq (release); these loads are issued only after the seq load
-        // has returned (control dependency + waitcnt) and bypass the caches, so they see the new words
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long c0 = __hip_atomic_load(&mb->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned long long c1 = __hip_atomic_load(&mb->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&bc->chal[0], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&bc->chal[1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -668,6 +669,121 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
     epilogue<D, NT>(acc, ep, smem, s_flag);
 }
 
+// ------------------------------------------------------------------------------------------------
+// persistent tail: ALL remaining rounds of a pipelined single-class sumcheck in ONE launch once the tables fit in LDS.
+// A small round is ~3 us of work wrapped in ~10 us of kernel boundary, relay and cold loads; here the workgroup keeps
+// the tables in LDS, publishes each message, polls the mailbox for the challenge itself and folds in place
+// (ping-pong), so a round costs the publish + the host round trip + the arithmetic.  The tables of the last round
+// go back to the buffer ceno_hip_sumcheck_finish expects.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
+                                             E2 r, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    E2* bufA = reinterpret_cast<E2*>(dyn);                 // [n_mles][2 * pairs0]
+    E2* bufB = bufA + (size_t)n_mles * 2 * pairs0;         // [n_mles][pairs0]
+    E2* smem = bufB + (size_t)n_mles * pairs0;             // [(NT/64) * D]
+    unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // c0, c1, ok
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) return;
+    }
+    const int sa = 2 * pairs0, sb = pairs0;  // per-MLE strides of the two LDS images
+    {   // stage the tables of round i0 (folded with r_{i0-1} unless i0 == 0)
+        const E2Pre rp = e2_pre(r);
+        const bool fold = pl.use_out != 0;
+        for (int idx = threadIdx.x; idx < n_mles * sa; idx += NT) {
+            const int m = idx / sa, j = idx - m * sa;
+            const MleSlot sl = pl.slots[m];
+            E2 v;
+            if (fold) {
+                if (sl.in_ext) {
+                    const E2 a = ld_e2(sl.in + 4 * (size_t)j), b = ld_e2(sl.in + 4 * (size_t)j + 2);
+                    v = a + e2_mul_pre(rp, b - a);
+                } else {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * (size_t)j);
+                    const E2 t = e2_mul_base(r, sub(w.y, w.x));
+                    v = E2{add(t.c0, w.x), t.c1};
+                }
+            } else {
+                v = sl.in_ext ? ld_e2(sl.in + 2 * (size_t)j) : E2{sl.in[j], 0};
+            }
+            bufA[idx] = v;
+        }
+    }
+    __syncthreads();
+    E2 *cur = bufA, *nxt = bufB;
+    int sc_ = sa, sn = sb, pairs = pairs0;
+    for (int i = i0; i < n; i++) {
+        E2 acc[D];
+#pragma unroll
+        for (int t = 0; t < D; t++) acc[t] = e2_zero();
+        for (int idx = threadIdx.x; idx < n_flat * pairs; idx += NT) {
+            const int ti = idx / pairs, p = idx - ti * pairs;
+            int g = 0;
+            while ((int)pl.group_term_off[g + 1] <= ti) g++;
+            const uint32_t term = pl.group_terms[ti];
+            const E2 c = pl.coeffs[term];
+            E2 pr[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) pr[t] = c;
+            for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                const E2* q = cur + (size_t)pl.term_idx[k] * sc_ + 2 * p;
+                const E2 lo = q[0], hi = q[1], delta = hi - lo;
+                E2 x = hi;
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    pr[t] = pr[t] * x;
+                    x = x + delta;
+                }
+            }
+            for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
+                const E2* q = cur + (size_t)pl.common_idx[k] * sc_ + 2 * p;
+                const E2 lo = q[0], hi = q[1], delta = hi - lo;
+                E2 x = hi;
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    pr[t] = pr[t] * x;
+                    x = x + delta;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
+        }
+        red::block_sum<D, NT>(acc, smem);
+        if (threadIdx.x == 0) {
+            Epilogue e = ep;
+            e.seq = (unsigned long long)(i + 1);
+            e.next_seq = 0;  // the challenge is fetched right here, not relayed to another launch
+            finish_message<D>(acc, e);
+            if (i + 1 < n) {
+                unsigned long long c0 = 0, c1 = 0;
+                const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1);
+                s_chal[0] = c0;
+                s_chal[1] = c1;
+                s_chal[2] = ok ? 1ull : 0ull;
+            }
+        }
+        if (i + 1 == n) break;
+        __syncthreads();
+        if (s_chal[2] == 0) return;  // aborted / timed out: leave everything as it is
+        const E2Pre rp = e2_pre(E2{s_chal[0], s_chal[1]});
+        for (int idx = threadIdx.x; idx < n_mles * pairs; idx += NT) {
+            const int m = idx / pairs, j = idx - m * pairs;
+            const E2 lo = cur[(size_t)m * sc_ + 2 * j], hi = cur[(size_t)m * sc_ + 2 * j + 1];
+            nxt[(size_t)m * sn + j] = lo + e2_mul_pre(rp, hi - lo);
+        }
+        __syncthreads();
+        E2* tp_ = cur; cur = nxt; nxt = tp_;
+        const int ts_ = sc_; sc_ = sn; sn = ts_;
+        pairs >>= 1;
+    }
+    // the two elements per table that the last round was computed on: ceno_hip_sumcheck_finish folds them
+    for (int idx = threadIdx.x; idx < n_mles * 2; idx += NT) {
+        const int m = idx >> 1, j = idx & 1;
+        st_e2(last_slots[m].out + 2 * j, cur[(size_t)m * sc_ + j]);
+    }
+}
+
 // gather element 0 of every listed table into out[i] (final evaluations)
 struct GatherArgs {
     const MleSlot* slots;
@@ -902,6 +1018,38 @@ static int tile_pairs(size_t n_flat, size_t n_mles, size_t pairs) {
     while (tp > 1 && n_mles * 2 * tp * sizeof(E2) > 48 * 1024) tp--;
     return (int)tp;
 }
+// persistent tail eligibility: tables of the round (2 * pairs per MLE) plus the ping-pong half must fit in LDS
+static size_t tail_max_pairs() {
+    static size_t v = [] {
+        const char* e = getenv("CENO_HIP_TAIL_PAIRS");  // 0 disables the persistent tail (A/B measurements)
+        return (size_t)(e ? atoi(e) : 128);
+    }();
+    return v;
+}
+static size_t tail_lds_bytes(size_t n_mles, size_t pairs, int d) { return (n_mles * 3 * pairs + (size_t)(NT / 64) * d) * sizeof(E2) + 64; }
+static bool tail_eligible(size_t n_mles, size_t pairs, int d) {
+    return pairs >= 1 && pairs <= tail_max_pairs() && tail_lds_bytes(n_mles, pairs, d) <= 60 * 1024;
+}
+template <int D>
+static void launch_tail_d(const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
+                          hipStream_t st) {
+    hipLaunchKernelGGL((k_tail<D>), dim3(1), dim3(NT), tail_lds_bytes((size_t)n_mles, pairs, D), st, pl, last_slots, n_mles, n_flat, (int)pairs, i0, n,
+                       e2_zero(), ep);
+}
+static void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
+                        hipStream_t st) {
+    switch (d) {
+    case 1: launch_tail_d<1>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 2: launch_tail_d<2>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 3: launch_tail_d<3>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 4: launch_tail_d<4>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 5: launch_tail_d<5>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    }
+}
+
 static bool tile_eligible(size_t n_mles, size_t pairs) {
     static int v = [] {
         const char* e = getenv("CENO_HIP_TILE");  // 0 restores the one-lane-per-pair kernel (A/B measurements)
@@ -1326,6 +1474,11 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             pl.term_off = cl.d_term_off;
             pl.term_idx = cl.d_term_idx;
             const int tnt = fused_tnt(k, pairs);
+            if (tail_eligible(k, pairs, sc->d)) {  // this launch produces rounds i .. n-1
+                launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, sc->n, ep, sc->st);
+                upto = sc->n;
+                break;
+            }
             if (tile_eligible(k, pairs)) {
                 launch_tile(sc->d, pl, (int)k, cl.n_flat, pairs, e2_zero(), ep, sc->st);
             } else if (tnt) {
