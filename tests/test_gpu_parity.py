@@ -815,3 +815,45 @@ def test_tower_random_specs_differential(dev, prover, seed):
     assert rc == 0
     for t in towers_p + towers_l:
         t.free()
+
+
+def test_no_device_memory_leaks_over_repeated_proofs(prover):
+    """every handle returns its device memory to the pool: after warm-up, repeating sumcheck / tower / commit+open
+    leaves pool_used where it was and does not grow the cached total"""
+    from ceno_amd import Device
+
+    d = Device(0)
+    stream = d.stream_create()
+
+    def one_pass(seed):
+        tabs = [po.rand_ext(1 << 9, seed + j) for j in range(3)] + [po.rand_base(1 << 6, seed + 9)]
+        mles = [d.upload(t) for t in tabs]
+        prover.sumcheck_prove(d, mles, po.rand_ext(3, seed), [[0, 1, 2], [0, 1], [3, 3]], 9, 3, prover.Transcript.stub(seed))
+        recs = [d.upload(po.rand_ext(1 << 5, seed + 20 + j)) for j in range(3)]
+        t = prover.Tower.build_prod(d, recs, 1 << 5, (1, 0))
+        lt = prover.Tower.build_logup(d, None, recs, 1 << 5, (5, 6))
+        prover.prove_tower_relation(d, [t], [lt], prover.Transcript.stub(seed))
+        t.free()
+        lt.free()
+        m = po.rand_base(40 * 5, seed + 40).reshape(40, 5)
+        pcs = prover.PcsData(d, [m], 1, stream)
+        pt = po.rand_ext(pcs.num_vars(0), seed + 41)
+        ev = np.array([pcs.witness_mle(0, c).evaluate(pt) for c in range(5)], dtype=np.uint64)
+        pcs.basefold_open([pt], [ev], 4, 3, prover.Transcript.stub(seed))
+        pcs.free()
+        for x in mles + recs:
+            x.free()
+
+    for s in range(3):
+        one_pass(s)  # warm-up: pool buckets, twiddle tables, mailboxes
+    d.sync()
+    mi = d.mem_info()
+    used0, cached0 = mi["pool_used"], mi["pool_cached"]
+    for s in range(10):
+        one_pass(100 + s)
+    d.sync()
+    mi = d.mem_info()
+    used1, cached1 = mi["pool_used"], mi["pool_cached"]
+    assert used1 == used0, (used0, used1)
+    assert cached1 <= cached0 + (1 << 20), (cached0, cached1)
+    d.close()
