@@ -73,6 +73,7 @@ def lib():
         "ceno_hip_mle_upload": (i, [vp, u64p, i, i, vp, vpp]),
         "ceno_hip_mle_wrap": (i, [vp, vp, i, i, vpp]),
         "ceno_hip_mle_view_chunk": (i, [vp, vp, i, sz, vpp]),
+        "ceno_hip_mle_filter_even_odd": (i, [vp, vp, i, vp, vpp]),
         "ceno_hip_mle_download": (i, [vp, vp, u64p, vp]),
         "ceno_hip_mle_free": (i, [vp, vp]),
         "ceno_hip_mle_num_vars": (i, [vp]),
@@ -91,6 +92,7 @@ def lib():
         "ceno_hip_sumcheck_round_dev": (i, [vp, vp, u64p, vp]),
         "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),
         "ceno_hip_sumcheck_rounds_done": (i, [vp]),
+        "ceno_hip_sumcheck_estimate_memory": (sz, [i, i, C.POINTER(i), i, i]),
         "ceno_hip_sumcheck_set_pipelined": (i, [vp, vp, i]),
         "ceno_hip_sumcheck_table": (i, [vp, vp, i, C.POINTER(u64p), C.POINTER(i), C.POINTER(i)]),
         "ceno_hip_sumcheck_free": (i, [vp, vp]),

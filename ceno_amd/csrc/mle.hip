@@ -210,6 +210,14 @@ __global__ void __launch_bounds__(NT) k_rotate_base(const uint64_t* __restrict__
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) out[i] = in[(i & ~mask) | ra.next[i & mask]];
 }
 
+__global__ void __launch_bounds__(NT) k_take_stride2(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t n, int elem_words, int odd) {
+    const size_t total = n * elem_words, stride = (size_t)gridDim.x * NT;
+    for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
+        const size_t i = t / elem_words, w = t % elem_words;
+        out[t] = in[(2 * i + odd) * elem_words + w];
+    }
+}
+
 extern "C" {
 
 int ceno_hip_rotation_next_base_mle(ceno_hip_ctx* ctx, const ceno_hip_mle* in, int cyclic_group_log2, ceno_hip_stream s, ceno_hip_mle** out) {
@@ -410,6 +418,26 @@ int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const u
         return rc ? rc : ctx_fail(ctx, CENO_HIP_ERR_HIP, "fix_variables: %s", hipGetErrorString(e));
     }
     *out = res;
+    return 0;
+}
+
+
+// out[i] = in[2 i + odd]  (filter_mle_even_odd_batch, ceno_zkvm/src/scheme/gpu/util.rs:186-266)
+int ceno_hip_mle_filter_even_odd(ceno_hip_ctx* ctx, const ceno_hip_mle* m, int odd, ceno_hip_stream s, ceno_hip_mle** out) {
+    CHECK_ARG(ctx, m && out, "NULL argument");
+    CHECK_ARG(ctx, m->num_vars >= 1, "polynomial must have at least one variable");
+    hipStream_t st = ctx_stream(ctx, s);
+    ceno_hip_mle* o = nullptr;
+    TRY(ceno_hip_mle_alloc(ctx, m->num_vars - 1, m->is_ext, &o));
+    const size_t n = o->len();
+    const int ew = m->is_ext ? 2 : 1;
+    hipLaunchKernelGGL(k_take_stride2, dim3(grid_for(n * ew, NT, 2048)), dim3(NT), 0, st, m->d, o->d, n, ew, odd ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ceno_hip_mle_free(ctx, o);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "filter_even_odd: %s", hipGetErrorString(e));
+    }
+    *out = o;
     return 0;
 }
 

@@ -1765,6 +1765,32 @@ int ceno_hip_sumcheck_free(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc) {
     return 0;
 }
 
+
+// estimate_sumcheck_memory (EXT ceno_gpu; call sites ceno_zkvm/src/scheme/gpu/memory.rs:413-433,768,1114): device bytes a
+// sumcheck over MLEs with the given numbers of variables allocates ON TOP of its (borrowed) inputs — what a scheduler
+// books before it starts the task.  Mirrors sc_build: per MLE a ping (half size) and a pong (quarter size) ext buffer,
+// the per-workgroup partials, message / evaluation / counter blocks and the plan blob; every block rounded up to the
+// pool's bucket size.
+size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const int* mle_num_vars, int num_mles, int num_terms) {
+    auto bucket = [](size_t b) {
+        size_t r = 256;
+        while (r < b) r <<= 1;
+        return r;
+    };
+    (void)max_num_vars;
+    size_t total = 0;
+    for (int j = 0; j < num_mles; j++) {
+        const int nv = mle_num_vars ? mle_num_vars[j] : max_num_vars;
+        if (nv >= 1) total += bucket(((size_t)1 << (nv - 1)) * sizeof(E2));
+        if (nv >= 2) total += bucket(((size_t)1 << (nv - 2)) * sizeof(E2));
+    }
+    total += bucket((size_t)MAXB * MAXD * sizeof(E2) * 4);                       // partials (per size class, a few classes)
+    total += 3 * bucket(MAXD * sizeof(E2)) + bucket((size_t)std::max(num_mles, 1) * sizeof(E2)) + bucket(4096);
+    total += bucket((size_t)std::max(num_terms, 1) * (sizeof(E2) + 8 * (size_t)std::max(max_degree, 1)) + (size_t)num_mles * 64);  // plan blob
+    total += bucket((size_t)std::max(num_mles, 1) * sizeof(MleSlot) * (size_t)(std::max(max_num_vars, 0) + 2));               // slot tables
+    return total;
+}
+
 }  // extern "C"
 
 // used by tower.hip: attach an MLE whose lifetime is tied to the sumcheck handle

@@ -83,6 +83,9 @@ int ceno_hip_mle_upload(ceno_hip_ctx* ctx, const uint64_t* host, int num_vars, i
 int ceno_hip_mle_wrap(ceno_hip_ctx* ctx, uint64_t* device_ptr, int num_vars, int is_ext, ceno_hip_mle** out);
 /* borrowed view of the contiguous chunk [chunk*2^sub_vars, (chunk+1)*2^sub_vars) of a parent (as_view_chunk, gkr_iop/src/gpu/mod.rs:244-253) */
 int ceno_hip_mle_view_chunk(ceno_hip_ctx* ctx, ceno_hip_mle* parent, int sub_vars, size_t chunk, ceno_hip_mle** out);
+/* new MLE with one variable less holding the even (odd = 0) or odd (odd = 1) entries of `m`
+ * (filter_mle_even_odd_batch, ceno_zkvm/src/scheme/gpu/util.rs:186-266) */
+int ceno_hip_mle_filter_even_odd(ceno_hip_ctx* ctx, const ceno_hip_mle* m, int odd, ceno_hip_stream s, ceno_hip_mle** out);
 int ceno_hip_mle_download(ceno_hip_ctx* ctx, const ceno_hip_mle* m, uint64_t* host, ceno_hip_stream s);  /* synchronises s */
 int ceno_hip_mle_free(ceno_hip_ctx* ctx, ceno_hip_mle* m);
 int ceno_hip_mle_num_vars(const ceno_hip_mle* m);
@@ -177,6 +180,9 @@ int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const 
  * (get_mle_flatten_final_evaluations, gkr_iop/src/gkr/layer/cpu/mod.rs:229-230) */
 int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals);
 int ceno_hip_sumcheck_rounds_done(const ceno_hip_sumcheck* sc);
+/* device bytes a sumcheck allocates on top of its inputs (estimate_sumcheck_memory, ceno_zkvm/src/scheme/gpu/memory.rs:413-433):
+ * what a scheduler books (ceno_hip_mem_book) before starting the task.  mle_num_vars == NULL: all MLEs have max_num_vars. */
+size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const int* mle_num_vars, int num_mles, int num_terms);
 /* Device pointer, element kind and current number of variables of table `mle_index` as the next round will
  * read it (i.e. not yet folded with the challenge that call is going to receive).  Valid until the next
  * round/finish call; used by the sharded driver to gather small shards onto every rank. */

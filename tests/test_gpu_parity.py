@@ -857,3 +857,35 @@ def test_no_device_memory_leaks_over_repeated_proofs(prover):
     assert used1 == used0, (used0, used1)
     assert cached1 <= cached0 + (1 << 20), (cached0, cached1)
     d.close()
+
+
+def test_filter_even_odd_and_memory_estimate(dev, prover):
+    """filter_mle_even_odd_batch (scheme/gpu/util.rs:186-266) and estimate_sumcheck_memory (scheme/gpu/memory.rs:413-433):
+    the estimate must cover what a sumcheck really takes from the pool"""
+    import ctypes as C
+
+    from ceno_amd.api import Mle
+
+    for tab in (po.rand_base(1 << 9, 5), po.rand_ext(1 << 6, 6)):
+        m = dev.upload(tab)
+        for odd in (0, 1):
+            h = C.c_void_p()
+            dev.check(dev.L.ceno_hip_mle_filter_even_odd(dev.h, m.h, odd, None, C.byref(h)))
+            out = Mle(dev, h)
+            assert np.array_equal(out.download(), tab[odd::2])
+            out.free()
+    nv, k = 16, 5
+    mles = [dev.synthetic(nv, j % 2 == 0, 40 + j) for j in range(k)]
+    terms = [[0, 1, 2], [3, 4], [0, 4]]
+    dev.sync()
+    before = dev.mem_info()["pool_used"]
+    from ceno_amd import Sumcheck
+
+    sc = Sumcheck(dev, mles, po.rand_ext(3, 1), terms, nv, 3)
+    sc.round(None)
+    sc.round((3, 4))
+    used = dev.mem_info()["pool_used"] - before
+    nvs = (C.c_int * k)(*([nv] * k))
+    est = dev.L.ceno_hip_sumcheck_estimate_memory(nv, 3, nvs, k, len(terms))
+    assert 0 < used <= est <= 4 * used + (1 << 22), (used, est)
+    sc.free()
