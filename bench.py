@@ -178,7 +178,7 @@ def main():
     achieved = alg_bytes_per_step * args.steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     peak = 8000.0
     res = {
-        "metric": "Goldilocks-ext mults/sec in sumcheck nv=26",
+        "metric": f"Goldilocks-ext mults/sec in sumcheck nv={n_local}",  # BASELINE.json metric at the default --nv 26
         "value": value,
         "unit": "ext-mults/s",
         "n_gpus": world,
