@@ -1,17 +1,19 @@
-// Hypercube-sharded sumcheck across the GPUs of one node, driven from C++ with RCCL.
+// Hypercube-sharded sumcheck across the GPUs of one node, driven from C++.
 //
 // the reference has no intra-sumcheck distribution ("Distributed Sumcheck — TODO",
 // docs/src/optimizations.md:3-5) — this is new design.  LSB-first binding pairs adjacent indices, so
 // splitting every table by its TOP log2(world) index bits keeps every fold local for the first
-// n_local = n - log2(world) rounds.  One process per GPU (launched by torch.distributed, which also
-// carries the ncclUniqueId bootstrap); per local round each rank's kernel leaves d partial evaluations in
-// device memory, ONE ncclAllGather of world*d extension elements runs on the same HIP stream, the host adds
-// them mod p (RCCL has no mod-p reduction; ncclSum on uint64 would wrap mod 2^64) and the replicated
-// transcript produces the challenge.  After the local rounds one more all-gather of the per-rank final
-// values builds world-sized tables and the last log2(world) rounds run replicated on every rank.
-// The collectives are latency bound (48*world bytes); xGMI bandwidth never matters on this path.
-//
-// RCCL is resolved with dlopen at first use so that libceno_prover.so loads on machines without it.
+// n_local = n - log2(world) rounds.  One process per GPU (launched by torch.distributed, which also carries
+// the bootstrap of the communicator).  Per local round every rank produces d partial evaluations, the ranks
+// exchange them, each host adds them mod p (no collective library has a mod-p reduction; ncclSum on uint64 would
+// wrap mod 2^64) and the replicated transcript produces the challenge.  Two transports for that exchange:
+//   * host shared memory (ceno_dist_comm_attach_shm, the default of bench.py): the partials are in host memory
+//     anyway, a POSIX segment plus sequence words costs ~1-2 us; every rank runs its shard as an ordinary pipelined
+//     sumcheck, the k final values are exchanged the same way and the last log2(world) rounds run on the host;
+//   * RCCL (ceno_dist_comm_init): ONE ncclAllGather of world*d extension elements per round on the kernels' HIP
+//     stream, and once a shard is down to 2^12 elements per table the shards themselves are all-gathered and every
+//     rank finishes replicated.  RCCL is resolved with dlopen so that libceno_prover.so loads on machines without it.
+// The mixed-size batched variant (ceno_dist_batched_sumcheck_prove) shards every size class along its own top bits.
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
