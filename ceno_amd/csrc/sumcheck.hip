@@ -471,6 +471,78 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
     epilogue<D, NT>(acc, ep, smem, &s_flag);
 }
 
+// First round of a main-constraint sumcheck: every term is a product of BASE-field witness columns times an extension
+// coefficient, under extension common factors (selectors).  Specialised accumulate:
+//   * the product of a term's columns stays in the base field, first factor peeled (no multiply by one);
+//   * c_t * P_t(X) is NOT formed: its two 128-bit partial products go straight into unreduced 160-bit accumulators per
+//     evaluation point, reduced once per group and pair before the selector multiplies in — the coefficient scaling was
+//     half of all multiplications in this round (PMC: 15.7k VALU instructions per pair on the ADD-shaped plan).
+template <int D>
+__global__ void __launch_bounds__(NT) k_accum_base0(DevPlan pl, size_t pairs, Epilogue ep) {
+    __shared__ E2 smem[(NT / 64) * D];
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
+        for (int g = 0; g < pl.n_groups; g++) {
+            Acc5 w0[D], w1[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) w0[t] = w1[t] = Acc5{0, 0, 0, 0, 0};
+            for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                const uint32_t term = pl.group_terms[ti];
+                const E2 c = pl.coeffs[term];
+                uint64_t pb[D];
+                const uint32_t kb = pl.term_off[term], ke = pl.term_off[term + 1];
+                {   // first column of the term
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(pl.slots[pl.term_idx[kb]].in + 2 * p);
+                    const uint64_t nd = sub(v.x, v.y);
+                    uint64_t x = v.y;
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        pb[t] = x;
+                        if (t + 1 < D) x = sub(x, nd);
+                    }
+                }
+                for (uint32_t k = kb + 1; k < ke; k++) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(pl.slots[pl.term_idx[k]].in + 2 * p);
+                    const uint64_t nd = sub(v.x, v.y);
+                    uint64_t x = v.y;
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        pb[t] = mul_nc(pb[t], x);  // only multiplied again: any 64-bit value will do
+                        if (t + 1 < D) x = sub(x, nd);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    acc5_add(w0[t], mul_wide(c.c0, pb[t]));
+                    acc5_add(w1[t], mul_wide(c.c1, pb[t]));
+                }
+            }
+            E2 inner[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) inner[t] = E2{acc5_reduce(w0[t]), acc5_reduce(w1[t])};
+            const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+            for (uint32_t k = cb; k < ce; k++) {  // extension (or base) common factors: selectors
+                E2 lo, hi;
+                load_pair(pl.slots[pl.common_idx[k]], 0, p, lo, hi);
+                const E2 nd = lo - hi;
+                E2 x = hi;
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    inner[t] = inner[t] * x;
+                    if (t + 1 < D) x = x - nd;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+        }
+    }
+    __shared__ int s_flag;
+    epilogue<D, NT>(acc, ep, smem, &s_flag);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused generic round: fold every MLE of the class with r_{i-1}, write the half-size tables, stage the
 // folded (f(1), delta) of this lane's pair in LDS — lane-private columns, no barrier — and evaluate the CSR
@@ -829,6 +901,7 @@ struct ScClass {
     E2* d_coeffs = nullptr;
     int n_groups = 0;
     int n_flat = 0;           // entries of group_terms
+    bool terms_all_base = false;  // every factor of every term is a base-field input table (round 0 may use k_accum_base0)
     uint32_t part_off = 0;    // offset (E2 units) into partials
 };
 
@@ -957,19 +1030,23 @@ static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pa
 }
 
 template <int D>
-static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0) {
+    if (base0) hipLaunchKernelGGL((k_accum_base0<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+    else hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
 }
-static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
+// base0: round 0 of a class whose every term is a product of base-field tables (k_accum_base0)
+static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0 = false) {
+    static const bool no_base0 = getenv("CENO_HIP_NO_BASE0") != nullptr;  // A/B switch
+    if (no_base0) base0 = false;
     switch (d) {
-    case 1: launch_accum_d<1>(pl, pairs, ep, grid, st); break;
-    case 2: launch_accum_d<2>(pl, pairs, ep, grid, st); break;
-    case 3: launch_accum_d<3>(pl, pairs, ep, grid, st); break;
-    case 4: launch_accum_d<4>(pl, pairs, ep, grid, st); break;
-    case 5: launch_accum_d<5>(pl, pairs, ep, grid, st); break;
-    case 6: launch_accum_d<6>(pl, pairs, ep, grid, st); break;
-    case 7: launch_accum_d<7>(pl, pairs, ep, grid, st); break;
-    default: launch_accum_d<8>(pl, pairs, ep, grid, st); break;
+    case 1: launch_accum_d<1>(pl, pairs, ep, grid, st, base0); break;
+    case 2: launch_accum_d<2>(pl, pairs, ep, grid, st, base0); break;
+    case 3: launch_accum_d<3>(pl, pairs, ep, grid, st, base0); break;
+    case 4: launch_accum_d<4>(pl, pairs, ep, grid, st, base0); break;
+    case 5: launch_accum_d<5>(pl, pairs, ep, grid, st, base0); break;
+    case 6: launch_accum_d<6>(pl, pairs, ep, grid, st, base0); break;
+    case 7: launch_accum_d<7>(pl, pairs, ep, grid, st, base0); break;
+    default: launch_accum_d<8>(pl, pairs, ep, grid, st, base0); break;
     }
 }
 
@@ -1236,6 +1313,12 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
         cl.n_groups = (int)g_term_off.size() - 1;
         cl.n_flat = (int)g_terms.size();
+        cl.terms_all_base = !cl.terms.empty();
+        for (int t : cl.terms) {
+            if (sc->terms[t].idx.empty()) cl.terms_all_base = false;  // coefficient x common factors only
+            for (int j : sc->terms[t].idx)
+                if (sc->mles[j].cur_ext) cl.terms_all_base = false;
+        }
         int rc = 0;
         plan_offs.push_back(PlanOff{append(g_term_off.data(), g_term_off.size() * 4), append(g_terms.data(), g_terms.size() * 4),
                                     append(c_off.data(), c_off.size() * 4), append(c_idx.data(), c_idx.size() * 4),
@@ -1487,7 +1570,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 if (i > 0)
                     hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)k), dim3(NT), 0, sc->st, pl.slots, 2 * pairs,
                                        e2_zero(), (const Bcast*)sc->d_bcast, (unsigned long long)i);
-                launch_accum(sc->d, pl, pairs, ep, sc_grid(pairs), sc->st);
+                launch_accum(sc->d, pl, pairs, ep, sc_grid(pairs), sc->st, i == 0 && cl.terms_all_base);
             }
         }
     }
@@ -1655,7 +1738,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 pl.term_idx = cl.d_term_idx;
                 if (tile) launch_tile(d, pl, (int)cl.mles.size(), cl.n_flat, pairs, r, ep, sc->st);
                 else if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
-                else launch_accum(d, pl, pairs, ep, grid, sc->st);
+                else launch_accum(d, pl, pairs, ep, grid, sc->st, i == 0 && cl.terms_all_base);
                 first = false;
             }
             for (int j : cl.mles) {

@@ -1,7 +1,9 @@
 // Batched main-constraint sumcheck — host control flow of
 // `BatchedMainConstraintProver::prove_batched_main_constraints` (ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390),
 // written against the device C ABI.  See include/ceno_prover.h for the job encoding.
+#include <algorithm>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -115,12 +117,49 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     }
     const int n_terms = (int)toff.size() - 1;
     if (n_terms == 0) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "all term scalars are zero"); }
+    // ---- common-factor plan (the role of CommonTermPlan in the reference's GPU arm, scheme/gpu/mod.rs:2811-2962, built
+    // there from shared witness prefixes, gkr_iop/src/gkr/layer/zerocheck_layer.rs:389-513).  Any factoring gives the same
+    // messages; here terms are grouped by their EXTENSION-field factors — the selectors (eq tables) that every constraint of
+    // an expression group carries — so that a group is  selector(s) x sum_t c_t prod(base witness columns):  the selector is
+    // multiplied in once per group instead of once per term, and the first round keeps the column products in the base
+    // field (k_accum_base0). ----
+    std::vector<uint32_t> r_toff{0}, r_tidx;                  // residual factor lists handed to the engine
+    std::vector<uint32_t> g_toff{0}, g_tidx, g_coff{0}, g_cidx;
+    {
+        std::map<std::vector<uint32_t>, std::vector<int>> by_ext;  // (ext factor list incl. the chip's MLE base) -> terms
+        std::vector<std::vector<uint32_t>> base_part(n_terms);
+        for (int t = 0; t < n_terms; t++) {
+            std::vector<uint32_t> ext_part;
+            for (uint32_t k = toff[t]; k < toff[t + 1]; k++) (ceno_hip_mle_is_ext(mles[tidx[k]]) ? ext_part : base_part[t]).push_back(tidx[k]);
+            if (ext_part.empty() || base_part[t].empty()) {
+                base_part[t].assign(tidx.begin() + toff[t], tidx.begin() + toff[t + 1]);  // ungrouped: full product
+            } else {
+                std::sort(ext_part.begin(), ext_part.end());
+                by_ext[ext_part].push_back(t);
+            }
+        }
+        for (int t = 0; t < n_terms; t++) {
+            r_tidx.insert(r_tidx.end(), base_part[t].begin(), base_part[t].end());
+            r_toff.push_back((uint32_t)r_tidx.size());
+        }
+        for (auto& kv : by_ext) {
+            for (int t : kv.second) g_tidx.push_back((uint32_t)t);
+            g_toff.push_back((uint32_t)g_tidx.size());
+            g_cidx.insert(g_cidx.end(), kv.first.begin(), kv.first.end());
+            g_coff.push_back((uint32_t)g_cidx.size());
+        }
+    }
     ceno_hip_sumcheck_plan plan{};
     plan.num_mles = (int)mles.size();
     plan.num_terms = n_terms;
     plan.term_coeffs = coeffs.data();
-    plan.term_offsets = toff.data();
-    plan.term_mle_idx = tidx.data();
+    plan.term_offsets = r_toff.data();
+    plan.term_mle_idx = r_tidx.data();
+    plan.num_groups = (int)g_toff.size() - 1;
+    plan.group_term_offsets = g_toff.data();
+    plan.group_term_idx = g_tidx.data();
+    plan.common_offsets = g_coff.data();
+    plan.common_mle_idx = g_cidx.data();
     plan.max_num_vars = max_nv;
     plan.max_degree = max_deg;
     std::vector<uint64_t> evals(2 * mles.size());
