@@ -394,10 +394,18 @@ __device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_
         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
         const uint64_t delta = sub(v.y, v.x);
         uint64_t x = v.y;
+        if (has_b) {
 #pragma unroll
-        for (int t = 0; t < D; t++) {
-            pb[t] = has_b ? mul(pb[t], x) : x;
-            x = add(x, delta);
+            for (int t = 0; t < D; t++) {
+                pb[t] = mul_nc(pb[t], x);  // only multiplied again
+                x = add(x, delta);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < D; t++) {
+                pb[t] = x;
+                x = add(x, delta);
+            }
         }
         has_b = true;
     } else {
@@ -405,16 +413,24 @@ __device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_
         load_pair(sl, use_out, p, lo, hi);
         const E2 delta = hi - lo;
         E2 x = hi;
+        if (has_e) {
 #pragma unroll
-        for (int t = 0; t < D; t++) {
-            pe[t] = has_e ? pe[t] * x : x;
-            x = x + delta;
+            for (int t = 0; t < D; t++) {
+                pe[t] = e2_mul_nc(pe[t], x);  // only multiplied again
+                x = x + delta;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < D; t++) {
+                pe[t] = x;
+                x = x + delta;
+            }
         }
         has_e = true;
     }
 }
 
-template <int D>
+template <int D, bool LAZY>
 __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue ep) {
     __shared__ E2 smem[(NT / 64) * D];
     if (ep.wait_seq != 0) {  // pipelined: do nothing (and publish nothing) if the fold before us was aborted
@@ -427,43 +443,99 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
-        for (int g = 0; g < pl.n_groups; g++) {
-            E2 inner[D];
+        if constexpr (LAZY) {
+            for (int g = 0; g < pl.n_groups; g++) {
+                // sum_t c_t * P_t(X): the factors of a term are multiplied first (one multiply fewer than seeding the product
+                // with the coefficient), then c_t * P_t goes UNREDUCED into 160-bit accumulators, reduced once per group
+                E2Acc wacc[D];
 #pragma unroll
-            for (int t = 0; t < D; t++) inner[t] = e2_zero();
-            for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
-                const uint32_t term = pl.group_terms[ti];
-                const E2 c = pl.coeffs[term];
-                E2 pr[D];
-                uint64_t pb[D];
+                for (int t = 0; t < D; t++) wacc[t] = e2acc_zero();
+                for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                    const uint32_t term = pl.group_terms[ti];
+                    const E2 c = pl.coeffs[term];
+                    E2 pr[D];
+                    uint64_t pb[D];
+                    bool has_e = false, has_b = false;
+                    for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
+                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
+                    if (has_e) {
+                        if (has_b) {
 #pragma unroll
-                for (int t = 0; t < D; t++) pr[t] = c;
-                bool has_e = true, has_b = false;  // the coefficient seeds the extension product
-                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
-                    mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
-                if (has_b) {
+                            for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
+                        }
 #pragma unroll
-                    for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
+                        for (int t = 0; t < D; t++) e2acc_mac(wacc[t], c, pr[t]);
+                    } else if (has_b) {
+#pragma unroll
+                        for (int t = 0; t < D; t++) {
+                            acc5_add(wacc[t].s00, mul_wide(c.c0, pb[t]));
+                            acc5_add(wacc[t].s01, mul_wide(c.c1, pb[t]));
+                        }
+                    } else {  // coefficient times the group's common factors only
+#pragma unroll
+                        for (int t = 0; t < D; t++) e2acc_mac(wacc[t], c, e2_one());
+                    }
                 }
+                E2 inner[D];
 #pragma unroll
-                for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
+                for (int t = 0; t < D; t++) inner[t] = e2acc_reduce(wacc[t]);
+                const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+                if (ce > cb) {
+                    E2 cm[D];
+                    uint64_t cmb[D];
+                    bool has_e = false, has_b = false;
+                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
+#pragma unroll
+                    for (int t = 0; t < D; t++) {
+                        E2 v = inner[t];
+                        if (has_e) v = cm[t] * v;
+                        if (has_b) v = e2_mul_base(v, cmb[t]);
+                        acc[t] = acc[t] + v;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+                }
             }
-            const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
-            if (ce > cb) {
-                E2 cm[D];
-                uint64_t cmb[D];
-                bool has_e = false, has_b = false;
-                for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
+        } else {
+            for (int g = 0; g < pl.n_groups; g++) {
+                E2 inner[D];
 #pragma unroll
-                for (int t = 0; t < D; t++) {
-                    E2 v = inner[t];
-                    if (has_e) v = cm[t] * v;
-                    if (has_b) v = e2_mul_base(v, cmb[t]);
-                    acc[t] = acc[t] + v;
+                for (int t = 0; t < D; t++) inner[t] = e2_zero();
+                for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                    const uint32_t term = pl.group_terms[ti];
+                    const E2 c = pl.coeffs[term];
+                    E2 pr[D];
+                    uint64_t pb[D];
+#pragma unroll
+                    for (int t = 0; t < D; t++) pr[t] = c;
+                    bool has_e = true, has_b = false;  // the coefficient seeds the extension product
+                    for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
+                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
+                    if (has_b) {
+#pragma unroll
+                        for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
                 }
-            } else {
+                const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+                if (ce > cb) {
+                    E2 cm[D];
+                    uint64_t cmb[D];
+                    bool has_e = false, has_b = false;
+                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
 #pragma unroll
-                for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+                    for (int t = 0; t < D; t++) {
+                        E2 v = inner[t];
+                        if (has_e) v = cm[t] * v;
+                        if (has_b) v = e2_mul_base(v, cmb[t]);
+                        acc[t] = acc[t] + v;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
+                }
             }
         }
     }
@@ -1029,10 +1101,18 @@ static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pa
     launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
 }
 
+static bool accum_lazy() {
+    static bool v = [] {
+        const char* e = getenv("CENO_HIP_ACCUM_LAZY");  // 1: unreduced coefficient products (60 more VGPRs; measured +-1 %, off by default)
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
 template <int D>
 static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0) {
     if (base0) hipLaunchKernelGGL((k_accum_base0<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
-    else hipLaunchKernelGGL((k_accum<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+    else if (accum_lazy()) hipLaunchKernelGGL((k_accum<D, true>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+    else hipLaunchKernelGGL((k_accum<D, false>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
 }
 // base0: round 0 of a class whose every term is a product of base-field tables (k_accum_base0)
 static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0 = false) {
