@@ -889,3 +889,39 @@ def test_filter_even_odd_and_memory_estimate(dev, prover):
     est = dev.L.ceno_hip_sumcheck_estimate_memory(nv, 3, nvs, k, len(terms))
     assert 0 < used <= est <= 4 * used + (1 << 22), (used, est)
     sc.free()
+
+
+def test_batched_main_constraints_grouping_variety(dev, prover):
+    """the host groups terms by their extension-field factors: two selectors per chip (two groups), a term under both
+    selectors, a term without any selector (ungrouped) and a term made of selectors only — the transcript must equal the
+    oracle's single flat plan whatever the factoring"""
+    gch = [(3, 4), (5, 6)]
+    nv, n_w = 8, 4
+    wit = [po.rand_base(1 << nv, 900 + j) for j in range(n_w)]
+    p1, p2 = po.rand_ext(nv, 1), po.rand_ext(nv, 2)
+    sels = [(po.SEL_PREFIX, 0, (1 << nv) - 9, 0, (), 0, p1), (po.SEL_PREFIX, 5, 100, 1, (), 0, p2)]
+    s1, s2 = n_w, n_w + 1
+    terms = [[s1, 0, 1], [s1, 2], [s2, 1, 3], [s2, 0, 0, 2], [s1, s2, 3], [0, 1, 2], [s1, s2], [s2, 3]]
+    scalars = [[((2 + t, t), [2 + (t % 2)])] for t in range(len(terms))]
+    mles = [dev.upload(t) for t in wit] + [None, None]
+    job = dict(num_vars=nv, mles=mles, n_witin=n_w, n_fixed=0, n_structural=2, selectors=sels, n_exprs=2, max_degree=4, terms=terms,
+               scalars=scalars)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, [job], gch, prover.Transcript.stub(9))
+    tr = po.StubTranscript(9)
+    tr.append_label(b"combine subset evals")
+    alpha = tr.sample_ext()
+    chal = gch + [(1, 0), alpha]
+    tables = wit + [po.selector_compute(s[0], s[6], s[1], s[2]) for s in sels]
+    coeffs = []
+    for monos in scalars:
+        sc = (0, 0)
+        for coeff, ids in monos:
+            v = coeff
+            for i in ids:
+                v = po.e2_mul(v, chal[i])
+            sc = po.e2_add(sc, v)
+        coeffs.append(sc)
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, po.ext(coeffs), terms, nv, 4, tr)
+    assert np.array_equal(msgs, omsgs) and np.array_equal(rt, ochal) and np.array_equal(evals, ofin)
+    final_claim = po.sumcheck_expected_from_evals([nv] * len(tables), po.ext(coeffs), terms, nv, ochal, ofin)
+    assert claimed == po.recover_claim_from_final(final_claim, omsgs, ochal)
