@@ -392,18 +392,36 @@ class ShmComm:
             if rc != 0:
                 raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
 
+        # every rank must leave this constructor the same way (all succeed or all raise): a rank that failed alone would
+        # leave the others waiting in the next collective
+        err = None
         if rank == 0:
-            attach(True)  # the segment exists and is initialised before anybody learns its name
+            try:
+                attach(True)  # the segment exists and is initialised before anybody learns its name
+            except Exception as e:  # noqa: BLE001
+                err, name = e, None
         if world > 1 and dist is not None:
             obj = [name]
             dist.broadcast_object_list(obj, src=0)
             name = obj[0]
+        if name is None:
+            raise err if err is not None else RuntimeError("rank 0 could not create the shared-memory segment")
         if rank != 0:
-            attach(False)
+            try:
+                attach(False)
+            except Exception as e:  # noqa: BLE001
+                err = e
         if world > 1 and dist is not None:
-            dist.barrier()
+            oks = [None] * world
+            dist.all_gather_object(oks, err is None)
+        else:
+            oks = [err is None]
         if rank == 0:
             L.ceno_dist_shm_unlink(name.encode())  # mappings stay valid; nothing is left behind in /dev/shm
+        if not all(oks):
+            if h:
+                L.ceno_dist_comm_destroy(h)
+            raise err if err is not None else RuntimeError("another rank could not attach the shared-memory segment")
         self.h, self.world, self.rank, self.name = h, world, rank, name
 
     def selftest(self, iters: int = 1000) -> int:
