@@ -139,6 +139,58 @@ GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
     return reduce_limbs(s0, s1, s2, s3, 0u);
 }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+// ---- lazy sums for hash linear layers: a few 64-bit values added without reduction ----
+// a (any 64-bit value) + b (canonical): same residue, result in [0, 2^64) — one wrap at most since a + b - 2^64 <= p - 2
+GL_HD uint64_t add_nc(uint64_t a, uint64_t b) {
+    uint32_t c, c2;
+    uint32_t s0 = addc32((uint32_t)a, (uint32_t)b, 0u, c);
+    uint32_t s1 = addc32((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, c);
+    const uint32_t m = 0u - c;
+    s0 = addc32(s0, m, 0u, c2);
+    s1 = addc32(s1, 0u, c2, c2);
+    return join(s0, s1);
+}
+// 96-bit plain integer sum of up to 2^32 arbitrary 64-bit values
+struct S96 {
+    uint32_t w0, w1, w2;
+};
+GL_HD S96 s96(uint64_t a) { return S96{(uint32_t)a, (uint32_t)(a >> 32), 0u}; }
+GL_HD S96 operator+(S96 a, uint64_t b) {
+    uint32_t c;
+    S96 r;
+    r.w0 = addc32(a.w0, (uint32_t)b, 0u, c);
+    r.w1 = addc32(a.w1, (uint32_t)(b >> 32), c, c);
+    r.w2 = addc32(a.w2, 0u, c, c);  // stays in the carry chain (v_addc_co), no carry -> integer round trip
+    return r;
+}
+GL_HD S96 operator+(S96 a, S96 b) {
+    uint32_t c;
+    S96 r;
+    r.w0 = addc32(a.w0, b.w0, 0u, c);
+    r.w1 = addc32(a.w1, b.w1, c, c);
+    r.w2 = addc32(a.w2, b.w2, c, c);
+    return r;
+}
+GL_HD S96 s96_sum(uint64_t a, uint64_t b) {
+    uint32_t c;
+    S96 r;
+    r.w0 = addc32((uint32_t)a, (uint32_t)b, 0u, c);
+    r.w1 = addc32((uint32_t)(a >> 32), (uint32_t)(b >> 32), c, c);
+    r.w2 = addc32(0u, 0u, c, c);
+    return r;
+}
+// residue of a 96-bit sum in [0, 2^64) (w2 * 2^64 = w2 * (2^32 - 1))
+GL_HD uint64_t s96_reduce_nc(S96 a) { return reduce_limbs_nc(a.w0, a.w1, a.w2, 0u, 0u); }
+// a*b + s for a < 2^64, b canonical, s < 2^67: the sum stays below 2^128; result in [0, 2^64)
+GL_HD uint64_t mul_add_s96_nc(uint64_t a, uint64_t b, S96 s) {
+    const L4 p = mul_wide(a, b);
+    uint32_t cy;
+    const uint32_t s0 = addc32(p.w0, s.w0, 0u, cy);
+    const uint32_t s1 = addc32(p.w1, s.w1, cy, cy);
+    const uint32_t s2 = addc32(p.w2, s.w2, cy, cy);
+    const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
+    return reduce_limbs_nc(s0, s1, s2, s3, 0u);
+}
 // small-constant multiply (c < 2^32): the product has 96 bits
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
     const uint64_t p0 = (uint64_t)(uint32_t)a * c;

@@ -73,7 +73,67 @@ GL_HD void internal_linear(uint64_t* s, const Params& p) {
     for (int i = 0; i < WIDTH; i++) s[i] = gl::mul_add(s[i], p.int_diag[i], sum);
 }
 
+// The permutation proper keeps its state NON-CANONICAL (any 64-bit representative of the residue) from the first
+// linear layer to the last: every value is next either multiplied (mul_wide takes plain 64-bit integers) or summed,
+// and the sums of the linear layers are formed as plain 96-bit integers (3 instructions per addition instead of the
+// 8 of a modular one) and reduced once per output word.  One canonicalisation per word at the very end.
+GL_HD uint64_t sbox7_nc(uint64_t x) {
+    uint64_t x2 = gl::mul_nc(x, x);
+    uint64_t x3 = gl::mul_nc(x2, x);
+    uint64_t x4 = gl::mul_nc(x2, x2);
+    return gl::mul_nc(x4, x3);
+}
+// rows [2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]: coefficients sum to 7, so every output is < 7 * 2^64
+GL_HD void mat4_lazy(const uint64_t* x, gl::S96* n) {
+    using gl::S96;
+    const S96 t01 = gl::s96_sum(x[0], x[1]), t23 = gl::s96_sum(x[2], x[3]);
+    const S96 t0123 = t01 + t23;
+    const S96 t01123 = t0123 + x[1], t01233 = t0123 + x[3];
+    n[3] = t01233 + x[0] + x[0];
+    n[1] = t01123 + x[2] + x[2];
+    n[0] = t01123 + t01;
+    n[2] = t01233 + t23;
+}
+GL_HD void external_linear_nc(uint64_t* s) {
+    gl::S96 n[WIDTH];
+    mat4_lazy(s, n);
+    mat4_lazy(s + 4, n + 4);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const gl::S96 sum = n[i] + n[i + 4];            // < 14 * 2^64
+        s[i] = gl::s96_reduce_nc(n[i] + sum);           // < 21 * 2^64
+        s[i + 4] = gl::s96_reduce_nc(n[i + 4] + sum);
+    }
+}
+GL_HD void internal_linear_nc(uint64_t* s, const Params& p) {
+    gl::S96 sum = gl::s96_sum(s[0], s[1]);
+#pragma unroll
+    for (int i = 2; i < WIDTH; i++) sum = sum + s[i];   // < 8 * 2^64
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::mul_add_s96_nc(s[i], p.int_diag[i], sum);
+}
+
 GL_HD void permute(uint64_t* s, const Params& p) {
+    external_linear_nc(s);
+    for (int r = 0; r < ROUNDS_F / 2; r++) {
+#pragma unroll
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7_nc(gl::add_nc(s[i], p.ext_rc[r][i]));
+        external_linear_nc(s);
+    }
+    for (int r = 0; r < ROUNDS_P; r++) {
+        s[0] = sbox7_nc(gl::add_nc(s[0], p.int_rc[r]));
+        internal_linear_nc(s, p);
+    }
+    for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
+#pragma unroll
+        for (int i = 0; i < WIDTH; i++) s[i] = sbox7_nc(gl::add_nc(s[i], p.ext_rc[r][i]));
+        external_linear_nc(s);
+    }
+#pragma unroll
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::canon(s[i]);
+}
+// the same permutation with every intermediate canonical (the straightforward form; tests compare the two)
+GL_HD void permute_canonical(uint64_t* s, const Params& p) {
     external_linear(s);
     for (int r = 0; r < ROUNDS_F / 2; r++) {
 #pragma unroll

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(NT) k_permute(uint64_t* states, size_t n, cons
 }
 
 // leaf digests: sponge over row `r` of a column-major matrix (col stride = rows)
+template <bool CANON>
 __global__ void __launch_bounds__(NT) k_leaf_hash(const uint64_t* __restrict__ m, size_t rows, int width, uint64_t* __restrict__ digests,
                                                   const p2::Params* __restrict__ pp) {
     __shared__ p2::Params sp;
@@ -61,7 +62,8 @@ __global__ void __launch_bounds__(NT) k_leaf_hash(const uint64_t* __restrict__ m
 #pragma unroll
             for (int k = 0; k < p2::RATE; k++)
                 if (c + k < width) s[k] = m[(size_t)(c + k) * rows + r];  // overwrite mode; a short last chunk keeps the old tail
-            p2::permute(s, sp);
+            if (CANON) p2::permute_canonical(s, sp);
+            else p2::permute(s, sp);
         }
         *reinterpret_cast<ulonglong2*>(digests + 4 * r) = make_ulonglong2(s[0], s[1]);
         *reinterpret_cast<ulonglong2*>(digests + 4 * r + 2) = make_ulonglong2(s[2], s[3]);
@@ -221,7 +223,10 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
     ceno_hip_merkle* t = nullptr;
     TRY(merkle_alloc(ctx, log_rows, &t));
     size_t rows = (size_t)1 << log_rows;
-    hipLaunchKernelGGL(k_leaf_hash, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, dev_col_major, rows, width, t->levels[0], pp);
+    // CENO_HIP_P2_CANONICAL=1: the straightforward all-canonical permutation (A/B timing and cross-check of the lazy form)
+    static const bool canon = [] { const char* e = getenv("CENO_HIP_P2_CANONICAL"); return e && atoi(e) != 0; }();
+    if (canon) hipLaunchKernelGGL(k_leaf_hash<true>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, dev_col_major, rows, width, t->levels[0], pp);
+    else hipLaunchKernelGGL(k_leaf_hash<false>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, dev_col_major, rows, width, t->levels[0], pp);
     int rc = merkle_build_upper(ctx, t, st);
     if (rc) {
         merkle_release(ctx, t);

@@ -149,8 +149,10 @@ def test_poseidon2_host_source_matches_oracle_and_transcript_is_deterministic(bu
     L.ceno_prover_test_poseidon2_permute.restype = None
     L.ceno_prover_test_poseidon2_permute.argtypes = [po.u64p]
     rng = random.Random(3)
-    for _ in range(20):
-        st = np.array([rng.randrange(P) for _ in range(8)], dtype=np.uint64)
+    # the shipped permutation keeps its state non-canonical with lazily reduced linear layers: stress the carry paths
+    edge = [[P - 1] * 8, [0] * 8, [P - 1, 0] * 4, [0xFFFFFFFF00000000] * 8, [0xFFFFFFFF] * 8, [P - 1, 1, P - 2, 2, 1 << 63, (1 << 63) - 1, 1 << 32, P - (1 << 32)]]
+    for k in range(80 + len(edge)):
+        st = np.array(edge[k] if k < len(edge) else [rng.randrange(P) for _ in range(8)], dtype=np.uint64)
         exp = po.poseidon2_permute(st)
         got = st.copy()
         L.ceno_prover_test_poseidon2_permute(po._p(got))
