@@ -108,6 +108,8 @@ def lib():
         "ceno_hip_ntt_batch": (i, [vp, vp, i, i, i, vp]),
         "ceno_hip_rs_encode": (i, [vp, vp, i, i, i, vp, vp]),
         "ceno_hip_transpose": (i, [vp, vp, sz, sz, vp, vp]),
+        "ceno_hip_witgen_add": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
+        "ceno_hip_witgen_sub": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),
         "ceno_hip_poseidon2_permute": (i, [vp, vp, sz, vp]),
         "ceno_hip_merkle_commit": (i, [vp, vp, i, i, vp, vpp]),

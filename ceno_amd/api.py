@@ -320,6 +320,26 @@ def transpose(dev: Device, src_ptr: int, rows: int, width: int, dst_ptr: int, st
     dev.check(dev.L.ceno_hip_transpose(dev.h, C.c_void_p(src_ptr), rows, width, C.c_void_p(dst_ptr), stream))
 
 
+class ArithColumnMap(C.Structure):
+    """ceno_hip_add_column_map / ceno_hip_sub_column_map (identical layout: 22 column ids + num_cols)"""
+    _fields_ = [("cols", C.c_uint32 * 22), ("num_cols", C.c_uint32)]
+
+
+def witgen_arith(dev: Device, cols, is_sub: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int,
+                 rows_padded: int, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0,
+                 lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_add / witgen_sub (ceno_zkvm/src/instructions/gpu/dispatch.rs:509-571): `cols` = the 22 column ids in
+    AddColumnMap / SubColumnMap field order followed by num_cols; all pointers are device pointers"""
+    m = ArithColumnMap()
+    for k in range(22):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[22])
+    f = dev.L.ceno_hip_witgen_sub if is_sub else dev.L.ceno_hip_witgen_add
+    dev.check(f(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
+                fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
+                stream))
+
+
 def poseidon2_permute(dev: Device, states_ptr: int, n: int, stream=None):
     dev.check(dev.L.ceno_hip_poseidon2_permute(dev.h, C.c_void_p(states_ptr), n, stream))
 

@@ -1,0 +1,173 @@
+// On-device witness generation for the R-type arithmetic chips ADD / SUB.
+//
+// One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
+// CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
+// 112-145, 223-257, 337-400; AssertLt diff limbs gkr_iop/src/gadgets/is_lt.rs:243-287), scatter them into the
+// column-major matrix through the caller's column map, and count the lookups of the row.
+// HBM-bound integer work: 136 B read + 8 * num_cols B written per row; consecutive lanes write consecutive rows of a
+// column (coalesced), the 136-byte records are fetched with 8-byte loads that the L2 merges.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr unsigned MAXB = 4096;
+constexpr uint64_t SUBCYCLES_PER_INSN = 4;  // ceno_emul/src/tracer.rs:574-578
+constexpr uint64_t SUBCYCLE_RS1 = 0, SUBCYCLE_RS2 = 1, SUBCYCLE_RD = 2;
+constexpr int MAX_TS_BITS = 29;  // gkr_iop/src/circuit_builder/ram.rs:13
+
+// byte offsets inside ceno_emul::StepRecord (#[repr(C)], tracer.rs:33-60; Instruction rv32im.rs:115-128; MemOp tracer.rs:634-644)
+constexpr int OFF_CYCLE = 0, OFF_PC_BEFORE = 8;
+constexpr int OFF_RS1 = 48, OFF_RS2 = 64, OFF_RD = 80;  // ReadOp {addr u32, value u32, previous_cycle u64}; WriteOp {addr, before, after, pad, previous_cycle}
+
+struct Map {  // common layout of ceno_hip_add_column_map / ceno_hip_sub_column_map
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t a[2], b[2], carries[2];
+    uint32_t num_cols;
+};
+static_assert(sizeof(Map) == sizeof(ceno_hip_add_column_map) && sizeof(Map) == sizeof(ceno_hip_sub_column_map), "column map layout");
+
+// ShardContext::aligned_prev_ts (ceno_zkvm/src/e2e.rs:435-441)
+__device__ __forceinline__ uint64_t aligned_prev_ts(uint64_t prev_cycle, uint64_t offset) {
+    uint64_t ts = prev_cycle > offset ? prev_cycle - offset : 0;
+    return ts < SUBCYCLES_PER_INSN ? 0 : ts;
+}
+// cal_lt_diff (gkr_iop/src/gadgets/is_lt.rs:277-287): lhs - rhs, plus 2^max_bits when lhs < rhs
+__device__ __forceinline__ uint64_t lt_diff(uint64_t lhs, uint64_t rhs) { return (lhs < rhs ? (1ull << MAX_TS_BITS) : 0ull) + lhs - rhs; }
+
+// counter += 1 per lane; lanes of a wave that hit the slot of the first active lane are merged into one atomic
+// (timestamp-difference limbs are nearly constant across a chip, so most of a wave lands on one slot)
+__device__ __forceinline__ void lk_count(uint32_t* table, uint32_t slot) {
+    if (!table) return;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(slot);
+    const uint64_t same = __ballot(slot == first);
+    if (slot == first) {
+        if ((int)__lane_id() == __ffsll((long long)same) - 1) atomicAdd(table + slot, (uint32_t)__popcll(same));
+    } else {
+        atomicAdd(table + slot, 1u);
+    }
+}
+
+template <bool SUB>
+__global__ void __launch_bounds__(NT) k_witgen_arith(Map m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                     uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w,
+                                                     size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        if (r >= n) {  // padding rows: every mapped column is zero
+            const uint32_t* cols = &m.pc;
+#pragma unroll
+            for (int c = 0; c < 22; c++) w[(size_t)cols[c] * rows + r] = 0;
+            continue;
+        }
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
+        const uint64_t cycle = q[OFF_CYCLE / 8];
+        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
+        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
+        const uint64_t rs2_av = q[OFF_RS2 / 8], rs2_prev = q[OFF_RS2 / 8 + 1];
+        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
+        const uint32_t rs1_addr = (uint32_t)rs1_av, rs1_val = (uint32_t)(rs1_av >> 32);  // rs1_val: ADD operand (unused by SUB)
+        const uint32_t rs2_addr = (uint32_t)rs2_av, rs2_val = (uint32_t)(rs2_av >> 32);
+        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
+        const uint64_t ts = cycle - offset;
+        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
+        put(m.pc, pc);
+        put(m.ts, ts);
+        // register index = (word address * 4) >> 8 as u8 (ceno_emul/src/platform.rs:120-128, tracer.rs:656-658)
+        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), p2 = aligned_prev_ts(rs2_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
+        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), d2 = lt_diff(p2, ts + SUBCYCLE_RS2), dd = lt_diff(pd, ts + SUBCYCLE_RD);
+        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
+        put(m.rs1_prev_ts, p1);
+        put(m.rs1_lt_diff[0], d1 & 0xffff);
+        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
+        put(m.rs2_id, ((rs2_addr << 2) >> 8) & 0xff);
+        put(m.rs2_prev_ts, p2);
+        put(m.rs2_lt_diff[0], d2 & 0xffff);
+        put(m.rs2_lt_diff[1], (d2 >> 16) & 0xffff);
+        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
+        put(m.rd_prev_ts, pd);
+        put(m.rd_prev_val[0], rd_before & 0xffff);
+        put(m.rd_prev_val[1], rd_before >> 16);
+        put(m.rd_lt_diff[0], dd & 0xffff);
+        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
+        // ADD: rs1 + rs2 = rd (limbs of rs1, rs2; carries of the sum).  SUB: rs2 + rd = rs1 (limbs of rs2, rd; carries of that sum)
+        const uint32_t x = SUB ? rs2_val : rs1_val, y = SUB ? rd_after : rs2_val;
+        put(m.a[0], x & 0xffff);
+        put(m.a[1], x >> 16);
+        put(m.b[0], y & 0xffff);
+        put(m.b[1], y >> 16);
+        const uint32_t s0 = (x & 0xffff) + (y & 0xffff);
+        const uint32_t s1 = (x >> 16) + (y >> 16) + (s0 >> 16);
+        put(m.carries[0], s0 >> 16);  // Value::add with_overflow (ceno_zkvm/src/uint.rs:762-785)
+        put(m.carries[1], s1 >> 16);
+        // lookups: fetch, per register access u16(diff limb 0) + 13-bit range(diff limb 1), u16 limbs of the sum
+        // (SUB: also of rd, Value::new uint.rs:684-688)
+        if (lk_fetch) {
+            const uint32_t slot = (pc - fetch_base) >> 2;
+            if (slot < fetch_slots) lk_count(lk_fetch, slot);
+        }
+        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
+        lk_count(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
+        lk_count(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
+        lk_count(lk_dyn, U16 + (uint32_t)(d2 & 0xffff));
+        lk_count(lk_dyn, R13 + (uint32_t)((d2 >> 16) & 0xffff));
+        lk_count(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
+        lk_count(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
+        lk_count(lk_dyn, U16 + (s0 & 0xffff));  // limbs of the addition's result, range-checked inside Value::add
+        lk_count(lk_dyn, U16 + (s1 & 0xffff));
+        if (SUB) {
+            lk_count(lk_dyn, U16 + (rd_after & 0xffff));
+            lk_count(lk_dyn, U16 + (rd_after >> 16));
+        }
+    }
+}
+
+int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
+    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
+    CHECK_ARG(ctx, map->num_cols >= 22, "witgen: the arithmetic chips have 22 mapped columns");
+    const uint32_t* cols = &map->pc;
+    uint64_t seen[4] = {0, 0, 0, 0};
+    for (int c = 0; c < 22; c++) {
+        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
+        if (cols[c] < 256) {
+            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
+            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+        }
+    }
+    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
+    hipStream_t st = ctx_stream(ctx, s);
+    // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written, padding included
+    if (sub) hipLaunchKernelGGL(k_witgen_arith<true>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
+    else hipLaunchKernelGGL(k_witgen_arith<false>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ceno_hip_witgen_add(ceno_hip_ctx* ctx, const ceno_hip_add_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                        uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                        uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_arith(ctx, reinterpret_cast<const Map*>(map), false, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_sub(ceno_hip_ctx* ctx, const ceno_hip_sub_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                        uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                        uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_arith(ctx, reinterpret_cast<const Map*>(map), true, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+}  // extern "C"

@@ -282,6 +282,50 @@ int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint
 int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint64_t* out_witness, ceno_hip_stream s);
 
 /* ------------------------------------------------------------------------------------------------
+ * on-device witness generation for the R-type arithmetic chips
+ *   reference: hal.witgen.witgen_add / witgen_sub as called from ceno_zkvm/src/instructions/gpu/dispatch.rs:509-571
+ *   (column maps: instructions/gpu/chips/add.rs:15-47, chips/sub.rs:15-46; CPU assignment being reproduced:
+ *   instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,112-145,223-257,337-400,
+ *   gkr_iop/src/gadgets/is_lt.rs:243-287).
+ * Input: the shard's StepRecord array as the emulator lays it out (#[repr(C)], 136 bytes per step,
+ * ceno_emul/src/tracer.rs:33-60) already on the device, and the indices of the steps that belong to this chip.
+ * Output: the witness matrix COLUMN-major, `num_cols` columns of `rows_padded` base-field words (rows >= n are zero =
+ * InstancePaddingStrategy::Default), and the lookup multiplicities this chip contributes:
+ *   dev_lk_dynamic[(1 << bits) + v]  (LookupTable::Dynamic, gkr_iop/src/utils/lk_multiplicity.rs:181-198; 2^17 counters)
+ *   dev_lk_fetch[(pc - fetch_base_pc) / 4]  (LookupTable::Instruction, dispatch.rs:438-443)
+ * Counters are ADDED to (atomics), so one pair of tables serves all chips of a shard; either pointer may be NULL.
+ * The shard RAM records of the reference's kernels (F-3) are not produced here.
+ * ---------------------------------------------------------------------------------------------- */
+#define CENO_HIP_STEP_RECORD_BYTES 136
+#define CENO_HIP_LK_DYNAMIC_SLOTS (1u << 17)
+/* same fields, same order as ceno_gpu's AddColumnMap (chips/add.rs:29-46): every entry is a column id < num_cols */
+typedef struct ceno_hip_add_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], rd_carries[2];
+    uint32_t num_cols;
+} ceno_hip_add_column_map;
+/* SubColumnMap (chips/sub.rs:28-45): SUB proves rs1 = rs2 + rd, the carries are those of rs2 + rd */
+typedef struct ceno_hip_sub_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs2_limbs[2], rd_limbs[2], carries[2];
+    uint32_t num_cols;
+} ceno_hip_sub_column_map;
+int ceno_hip_witgen_add(ceno_hip_ctx* ctx, const ceno_hip_add_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                        uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                        uint32_t* dev_lk_fetch, ceno_hip_stream s);
+int ceno_hip_witgen_sub(ceno_hip_ctx* ctx, const ceno_hip_sub_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                        uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                        uint32_t* dev_lk_fetch, ceno_hip_stream s);
+
+/* ------------------------------------------------------------------------------------------------
  * diagnostics used by bench.py (HIP-event timing of the dominant kernel on the launch stream)
  * ---------------------------------------------------------------------------------------------- */
 /* accumulated device time (ms) and launch count of the fused sumcheck round kernel since the last reset */

@@ -180,6 +180,13 @@ int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint6
                         const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits, const uint64_t* params138,
                         orc_transcript* tr, const uint64_t* proof);
 
+/* ---- witness assignment of the ADD / SUB chips (witgen.c; reference arith.rs:101-142 and the files cited there) ---- */
+size_t orc_step_record_bytes(void);
+void orc_step_record_r(void* out, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rs2, uint8_t rd, uint32_t rs1_val,
+                       uint32_t rs2_val, uint32_t rd_before, uint32_t rd_after, uint64_t prev_cycle);
+int orc_witgen_arith(const uint32_t* cols, int is_sub, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                     uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+
 #ifdef __cplusplus
 }
 #endif

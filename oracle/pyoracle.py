@@ -21,7 +21,9 @@ _LIB_PATH = os.path.join(_HERE, "libceno_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("oracle.c", "tower.c", "commit.c", "rotation.c", "oracle.h", "gl64.h", "Makefile")]
+    import glob
+
+    srcs = glob.glob(os.path.join(_HERE, "*.c")) + glob.glob(os.path.join(_HERE, "*.h")) + [os.path.join(_HERE, "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     )
@@ -600,3 +602,43 @@ def prove_rotation(wit: Sequence[np.ndarray], pairs: Sequence[Tuple[int, int]], 
     if rc != 0:
         raise ValueError(f"orc_prove_rotation rc={rc}")
     return msgs, evals, origin, left, right
+
+
+# ---- witness assignment of the ADD / SUB chips (witgen.c) ----
+INSN_ADD, INSN_SUB = 1, 2  # ceno_emul InsnKind discriminants (rv32im.rs:166-172)
+ARITH_COLMAP_FIELDS = 23   # 22 column ids in AddColumnMap / SubColumnMap order + num_cols
+
+
+def step_records_r(cycles, pcs, kind, rs1, rs2, rd, rs1_vals, rs2_vals, rd_before, rd_after, prev_cycles) -> np.ndarray:
+    """StepRecord::new_r_instruction for every entry -> (n, 136) uint8 array laid out as the emulator's #[repr(C)] struct"""
+    n = len(cycles)
+    nb = lib().orc_step_record_bytes()
+    out = np.zeros((n, nb), dtype=np.uint8)
+    L = lib()
+    L.orc_step_record_r.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint32, C.c_uint64]
+    L.orc_step_record_r.restype = None
+    for i in range(n):
+        L.orc_step_record_r(out[i].ctypes.data, int(cycles[i]), int(pcs[i]), kind, rs1, rs2, rd, int(rs1_vals[i]), int(rs2_vals[i]),
+                            int(rd_before[i]), int(rd_after[i]), int(prev_cycles[i]))
+    return out
+
+
+def witgen_arith(cols, is_sub: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the chip's instances: (row-major n x num_cols matrix, dynamic-table counts (2^17), fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (ARITH_COLMAP_FIELDS,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_arith.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    L.orc_witgen_arith.restype = C.c_int
+    rc = L.orc_witgen_arith(cols.ctypes.data, int(is_sub), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc,
+                            fetch_num_slots, out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_arith rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]

@@ -1,0 +1,137 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's witness assignment for the R-type
+ * arithmetic chips ADD / SUB, one instance at a time, in the order the reference's CPU path does it:
+ *   ArithInstruction::assign_instance        ceno_zkvm/src/instructions/riscv/arith.rs:101-142
+ *   RInstructionConfig::assign_instance      ceno_zkvm/src/instructions/riscv/r_insn.rs:67-86
+ *   StateInOut / ReadRS1 / ReadRS2 / WriteRD ceno_zkvm/src/instructions/riscv/insn_base.rs:61-77,112-145,223-257,337-400
+ *   InnerLtConfig::assign_instance_field     gkr_iop/src/gadgets/is_lt.rs:243-274 (cal_lt_diff :277-287)
+ *   Value::add / Value::new                  ceno_zkvm/src/uint.rs:684-688,762-785
+ *   LkMultiplicity keys                      gkr_iop/src/utils/lk_multiplicity.rs:181-198,264-266
+ *   ShardContext::aligned_prev_ts            ceno_zkvm/src/e2e.rs:435-451
+ * The StepRecord layout is the emulator's #[repr(C)] struct (ceno_emul/src/tracer.rs:33-60, 136 bytes).
+ * PARITY: the reference's own test of this path (chips/add.rs:119-188) compares its GPU kernel with this CPU
+ * assignment at run time and holds no literal vectors, so this restatement is pinned only by construction
+ * ("parity unpinned" beyond the cited code); the step generator of that test is reproduced in tests/.
+ */
+#include <string.h>
+#include "oracle.h"
+
+typedef struct {
+    uint32_t addr, value;
+    uint64_t previous_cycle;
+} orc_read_op;
+typedef struct {
+    uint32_t addr, before, after, pad_;
+    uint64_t previous_cycle;
+} orc_write_op;
+typedef struct {
+    uint64_t cycle;
+    uint32_t pc_before, pc_after;
+    uint32_t heap_before, heap_after, hint_before, hint_after;
+    uint8_t kind, rs1_idx, rs2_idx, rd_idx;
+    int32_t imm;
+    uint32_t raw;
+    uint8_t has_rs1, has_rs2, has_rd, has_memory_op;
+    orc_read_op rs1, rs2;
+    orc_write_op rd, memory_op;
+    uint32_t syscall_index;
+    uint8_t future_access_mask, padding_[3];
+} orc_step_record;
+_Static_assert(sizeof(orc_step_record) == 136, "StepRecord is 136 bytes");
+
+size_t orc_step_record_bytes(void) { return sizeof(orc_step_record); }
+
+/* StepRecord::new_r_instruction (ceno_emul/src/tracer.rs:1164-1186,1355-1407): the shape the reference's tests build */
+void orc_step_record_r(void* out, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rs2, uint8_t rd, uint32_t rs1_val,
+                       uint32_t rs2_val, uint32_t rd_before, uint32_t rd_after, uint64_t prev_cycle) {
+    orc_step_record r;
+    memset(&r, 0, sizeof(r));
+    r.cycle = cycle;
+    r.pc_before = pc;
+    r.pc_after = pc + 4;
+    r.kind = kind; r.rs1_idx = rs1; r.rs2_idx = rs2; r.rd_idx = rd;
+    r.has_rs1 = r.has_rs2 = r.has_rd = 1;
+    /* Platform::register_vma(idx) = idx << 8 as a byte address; WordAddr = byte address / 4 (platform.rs:120-123, addr.rs:61-65) */
+    r.rs1.addr = ((uint32_t)rs1 << 8) / 4; r.rs1.value = rs1_val; r.rs1.previous_cycle = prev_cycle;
+    r.rs2.addr = ((uint32_t)rs2 << 8) / 4; r.rs2.value = rs2_val; r.rs2.previous_cycle = prev_cycle;
+    r.rd.addr = ((uint32_t)rd << 8) / 4; r.rd.before = rd_before; r.rd.after = rd_after; r.rd.previous_cycle = prev_cycle;
+    r.syscall_index = 0xFFFFFFFFu;
+    memcpy(out, &r, sizeof(r));
+}
+
+static uint64_t aligned_prev_ts(uint64_t prev_cycle, uint64_t offset) {
+    uint64_t ts = prev_cycle > offset ? prev_cycle - offset : 0; /* saturating_sub */
+    if (ts < 4) ts = 0;                                          /* FullTracer::SUBCYCLES_PER_INSN */
+    return ts;
+}
+static void lk_dyn(uint32_t* t, uint64_t v, unsigned bits) {
+    if (t) t[((uint64_t)1 << bits) + v] += 1;
+}
+/* AssertLtConfig::assign_instance with max_bits = 29: one u16 limb, one 13-bit limb */
+static void assign_lt(uint64_t* row, const uint32_t diff_cols[2], uint32_t* lkd, uint64_t lhs, uint64_t rhs) {
+    const uint64_t diff = (lhs < rhs ? ((uint64_t)1 << 29) : 0) + lhs - rhs;
+    row[diff_cols[0]] = diff & 0xffff;
+    lk_dyn(lkd, diff & 0xffff, 16);
+    row[diff_cols[1]] = (diff >> 16) & 0xffff;
+    lk_dyn(lkd, (diff >> 16) & 0xffff, 13);
+}
+static uint8_t register_index(uint32_t waddr) { return (uint8_t)((waddr * 4u) >> 8); }
+
+/* cols[23]: the column map in AddColumnMap / SubColumnMap field order (num_cols last).  out: ROW-major n x num_cols
+ * (as cpu_assign_instances produces it); lk_dynamic: 2^17 counters or NULL; lk_fetch: slots or NULL. */
+int orc_witgen_arith(const uint32_t* cols, int is_sub, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                     uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[22];
+    for (int c = 0; c < 22; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rs2 || !st->has_rd) return -2; /* step.rs1().expect(..) */
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        /* rs1 */
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        /* rs2 */
+        p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rs2.addr);
+        row[cols[7]] = p;
+        assign_lt(row, cols + 8, lk_dynamic, p, ts + 1);
+        /* rd */
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[10]] = register_index(st->rd.addr);
+        row[cols[11]] = p;
+        row[cols[12]] = st->rd.before & 0xffff;
+        row[cols[13]] = st->rd.before >> 16;
+        assign_lt(row, cols + 14, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        /* the addition: ADD rs1 + rs2, SUB rs2 + rd_written; limb-wise with carries, each result limb range-checked */
+        uint32_t x, y;
+        if (!is_sub) {
+            x = st->rs1.value; y = st->rs2.value;
+        } else {
+            x = st->rs2.value; y = st->rd.after;
+            lk_dyn(lk_dynamic, y & 0xffff, 16); /* Value::new(rd.after, lkm) */
+            lk_dyn(lk_dynamic, y >> 16, 16);
+        }
+        row[cols[16]] = x & 0xffff; row[cols[17]] = x >> 16;
+        row[cols[18]] = y & 0xffff; row[cols[19]] = y >> 16;
+        uint32_t carry = 0;
+        for (int l = 0; l < 2; l++) {
+            const uint32_t a = (x >> (16 * l)) & 0xffff, b = (y >> (16 * l)) & 0xffff;
+            const uint32_t s = a + b + carry;
+            carry = s >> 16;
+            lk_dyn(lk_dynamic, s & 0xffff, 16);
+            row[cols[20 + l]] = carry;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,84 @@
+"""CPU: the oracle's ADD / SUB witness assignment (oracle/witgen.c) against an independent pure-Python model on the
+reference test's step data, plus the circuit identities the columns must satisfy.  PARITY UNPINNED beyond the cited
+reference code: the reference holds no literal vectors for this path (it compares GPU with CPU at run time)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import witgen_cases as wc
+
+
+def _records(d, kind):
+    return po.step_records_r(d["cycles"], d["pcs"], kind, 2, 3, 4, d["rs1_vals"], d["rs2_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+
+
+def test_step_record_layout_is_the_emulators_repr_c():
+    assert po.lib().orc_step_record_bytes() == 136
+    d = wc.reference_test_steps(3)
+    r = _records(d, po.INSN_ADD)
+    dt = np.dtype([("cycle", "<u8"), ("pc", "<u4", 2), ("heap", "<u4", 2), ("hint", "<u4", 2), ("insn", "u1", 4), ("imm", "<i4"), ("raw", "<u4"),
+                   ("has", "u1", 4), ("rs1", [("addr", "<u4"), ("value", "<u4"), ("prev", "<u8")]),
+                   ("rs2", [("addr", "<u4"), ("value", "<u4"), ("prev", "<u8")]),
+                   ("rd", [("addr", "<u4"), ("before", "<u4"), ("after", "<u4"), ("pad", "<u4"), ("prev", "<u8")]),
+                   ("mem", [("addr", "<u4"), ("before", "<u4"), ("after", "<u4"), ("pad", "<u4"), ("prev", "<u8")]),
+                   ("syscall", "<u4"), ("mask", "u1"), ("pad", "u1", 3)])
+    assert dt.itemsize == 136
+    v = r.view(dt).reshape(-1)
+    assert list(v["cycle"]) == [4, 8, 12] and list(v["pc"][:, 0]) == [0x1000, 0x1004, 0x1008] and list(v["pc"][:, 1]) == [0x1004, 0x1008, 0x100C]
+    assert list(v["insn"][0]) == [po.INSN_ADD, 2, 3, 4] and list(v["has"][0]) == [1, 1, 1, 0]
+    assert v["rs1"]["addr"][0] == (2 << 8) // 4 and v["rd"]["addr"][0] == (4 << 8) // 4 and v["syscall"][0] == 0xFFFFFFFF
+    assert v["rs2"]["value"][1] == 1 and v["rd"]["after"][1] == 1
+
+
+@pytest.mark.parametrize("sub", [False, True])
+@pytest.mark.parametrize("offset,prev", [(0, 0), (0, 5), (400, 100), (400, 402), (400, 900)])
+def test_oracle_matches_python_model(sub, offset, prev):
+    n = 300
+    d = wc.reference_test_steps(n, sub)
+    d["cycles"] = d["cycles"] + offset + 1000
+    d["prev_cycles"][:] = prev
+    d["prev_cycles"][::7] = 0
+    recs = _records(d, po.INSN_SUB if sub else po.INSN_ADD)
+    rng = np.random.default_rng(5)
+    cols = list(rng.permutation(30)[:22]) + [30]
+    idx = rng.permutation(n)[:250]
+    base_pc, slots = 0x1000, n
+    got, lkd, lkf = po.witgen_arith(cols, sub, recs, idx, offset, base_pc, slots)
+    exp_dyn, exp_fetch = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
+    for r, i in enumerate(idx):
+        row, lk = wc.model_row(cols, sub, int(d["cycles"][i]), int(d["pcs"][i]), 2, 3, 4, int(d["rs1_vals"][i]), int(d["rs2_vals"][i]),
+                               int(d["rd_before"][i]), int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
+        for c, v in row.items():
+            assert int(got[r, c]) == v, (r, c)
+        unmapped = [c for c in range(30) if c not in row]
+        assert not got[r, unmapped].any()
+        for t, k in lk:
+            if t == "dyn":
+                exp_dyn[k] += 1
+            else:
+                exp_fetch[(k - base_pc) // 4] += 1
+    assert np.array_equal(lkd, exp_dyn) and np.array_equal(lkf, exp_fetch)
+    assert int(lkd.sum()) == len(idx) * (10 if sub else 8) and int(lkf.sum()) == len(idx)
+
+
+def test_columns_satisfy_the_chip_constraints():
+    """rs1 + rs2 = rd with the witnessed carries (UIntLimbs::add), and prev_ts - ts = diff - 2^29 (InnerLtConfig)"""
+    n = 1024
+    d = wc.reference_test_steps(n)
+    recs = _records(d, po.INSN_ADD)
+    m, _, _ = po.witgen_arith(wc.NATURAL_COLS, False, recs, np.arange(n), 0, 0x1000, n)
+    m = m.astype(np.int64)
+    rd = d["rd_after"].astype(np.int64)
+    assert np.array_equal(m[:, 16] + m[:, 18], (rd & 0xFFFF) + (m[:, 20] << 16))
+    assert np.array_equal(m[:, 17] + m[:, 19] + m[:, 20], (rd >> 16) + (m[:, 21] << 16))
+    for base, diff0, sub_cycle in ((3, 4, 0), (7, 8, 1), (11, 14, 2)):
+        assert np.array_equal(m[:, base] - (m[:, 1] + sub_cycle), m[:, diff0] + (m[:, diff0 + 1] << 16) - (1 << 29))
+    assert np.all(m[:, 2] == 2) and np.all(m[:, 6] == 3) and np.all(m[:, 10] == 4)
+
+
+def test_bad_column_map_is_rejected():
+    d = wc.reference_test_steps(4)
+    recs = _records(d, po.INSN_ADD)
+    cols = list(range(22)) + [21]
+    with pytest.raises(ValueError):
+        po.witgen_arith(cols, False, recs, np.arange(4))

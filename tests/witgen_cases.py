@@ -1,0 +1,67 @@
+"""Shared inputs for the ADD / SUB witness-generation tests.
+
+`reference_test_steps` reproduces the INPUT DATA of the reference's own test of this path
+(make_test_steps, ceno_zkvm/src/instructions/gpu/chips/add.rs:62-100): the eight edge-case operand pairs, then
+((i % 1000) + 1, (i % 500) + 3); rd_before = i % 200; cycle = 4 + 4 i; pc = 0x1000 + 4 i; registers x2, x3 -> x4;
+previous cycle 0.  `model_row` is an independent pure-Python statement of the assignment, written from the circuit's
+constraints rather than from the C restatement."""
+import numpy as np
+
+EDGE_CASES = [(0, 0), (0, 1), (1, 0), (0xFFFFFFFF, 1), (0xFFFFFFFF, 0xFFFFFFFF), (0x80000000, 0x80000000), (0x7FFFFFFF, 1),
+              (0xFFFF0000, 0x0000FFFF)]
+# column ids in AddColumnMap order for a circuit that creates its witnesses in this order (illustrative; the real ids come
+# from the Rust circuit builder through extract_add_column_map and are passed in by the caller)
+NATURAL_COLS = list(range(22)) + [22]
+
+
+def reference_test_steps(n, sub=False):
+    i = np.arange(n, dtype=np.uint64)
+    a = (i % 1000 + 1).astype(np.uint64)
+    b = (i % 500 + 3).astype(np.uint64)
+    for k, (x, y) in enumerate(EDGE_CASES[:n]):
+        a[k], b[k] = x, y
+    rd_before = i % 200
+    if sub:
+        rd_after = (a - b) & np.uint64(0xFFFFFFFF)
+    else:
+        rd_after = (a + b) & np.uint64(0xFFFFFFFF)
+    return dict(cycles=4 + 4 * i, pcs=0x1000 + 4 * i, rs1_vals=a, rs2_vals=b, rd_before=rd_before, rd_after=rd_after,
+                prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def model_row(cols, sub, cycle, pc, rs1, rs2, rd, v1, v2, rd_before, rd_after, prev, offset):
+    """one row as {column id: value} plus the list of (table, key) lookups, from first principles"""
+    row, lk = {}, []
+    ts = cycle - offset
+    row[cols[0]], row[cols[1]] = pc, ts
+    lk.append(("fetch", pc))
+
+    def access(base, reg, sub_cycle, extra=()):
+        p = max(prev - offset, 0)
+        p = 0 if p < 4 else p
+        rhs = ts + sub_cycle
+        diff = p - rhs + ((1 << 29) if p < rhs else 0)
+        assert 0 <= diff < (1 << 29)
+        row[cols[base]], row[cols[base + 1]] = reg, p
+        k = base + 2
+        for e in extra:
+            row[cols[k]] = e
+            k += 1
+        row[cols[k]], row[cols[k + 1]] = diff & 0xFFFF, diff >> 16
+        lk.append(("dyn", (1 << 16) + (diff & 0xFFFF)))
+        lk.append(("dyn", (1 << 13) + (diff >> 16)))
+
+    access(2, rs1, 0)
+    access(6, rs2, 1)
+    access(10, rd, 2, extra=(rd_before & 0xFFFF, rd_before >> 16))
+    x, y = (v2, rd_after) if sub else (v1, v2)
+    if sub:
+        lk += [("dyn", (1 << 16) + (rd_after & 0xFFFF)), ("dyn", (1 << 16) + (rd_after >> 16))]
+    row[cols[16]], row[cols[17]], row[cols[18]], row[cols[19]] = x & 0xFFFF, x >> 16, y & 0xFFFF, y >> 16
+    s = x + y
+    c0 = ((x & 0xFFFF) + (y & 0xFFFF)) >> 16
+    c1 = s >> 32
+    row[cols[20]], row[cols[21]] = c0, c1
+    res = s & 0xFFFFFFFF
+    lk += [("dyn", (1 << 16) + (res & 0xFFFF)), ("dyn", (1 << 16) + (res >> 16))]
+    return row, lk

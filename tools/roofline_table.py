@@ -80,4 +80,30 @@ row("rs_encode 22 x 2^20 -> 2^21", timed(lambda: api.rs_encode(dev, cm.data_ptr(
 # Merkle: 8 w N leaf read + 64 N tree
 row("merkle_commit 2^21 x 22", timed(lambda: api.Merkle(dev, cw.data_ptr(), rows_log + 1, w).free(), reps=3), (8 * w + 64) * (rows << 1),
     "integer-ALU bound: 6 + 1 Poseidon2 permutations per row")
+# on-device witness generation of the ADD chip: 136 B step record read + 22 x 8 B written per instance (+ 9 lookup counts)
+n_w = rows
+rng = np.random.default_rng(3)
+rec = np.zeros((n_w, 17), dtype=np.uint64)
+v1, v2 = rng.integers(0, 1 << 32, n_w, dtype=np.uint64), rng.integers(0, 1 << 32, n_w, dtype=np.uint64)
+pcs = np.uint64(0x2000) + np.uint64(4) * (np.arange(n_w, dtype=np.uint64) % np.uint64(4096))
+rec[:, 0] = 4 + 4 * np.arange(n_w, dtype=np.uint64)
+rec[:, 1] = pcs | ((pcs + np.uint64(4)) << np.uint64(32))
+rec[:, 4] = np.uint64(1 | (2 << 8) | (3 << 16) | (4 << 24))
+rec[:, 5] = np.uint64(0x00010101) << np.uint64(32)
+rec[:, 6] = np.uint64((2 << 8) // 4) | (v1 << np.uint64(32))
+rec[:, 8] = np.uint64((3 << 8) // 4) | (v2 << np.uint64(32))
+rec[:, 10] = np.uint64((4 << 8) // 4)
+rec[:, 11] = (v1 + v2) & np.uint64(0xFFFFFFFF)
+d_rec = torch.from_numpy(rec.view(np.int64)).to("cuda:0")
+d_idx = torch.arange(n_w, dtype=torch.int32, device="cuda:0")
+d_w = torch.empty(22 * n_w, dtype=torch.int64, device="cuda:0")
+d_lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+d_lkf = torch.zeros(4096, dtype=torch.int32, device="cuda:0")
+wcols = list(range(22)) + [22]
+row("witgen_add 2^20 instances (22 columns + lookup counts)",
+    timed(lambda: api.witgen_arith(dev, wcols, False, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w.data_ptr(), n_w, 0, 0x2000, 4096,
+                                   d_lkd.data_ptr(), d_lkf.data_ptr())), (136 + 4 + 8 * 22) * n_w)
+row("witgen_add 2^20 instances, witness only",
+    timed(lambda: api.witgen_arith(dev, wcols, False, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w.data_ptr(), n_w, 0, 0x2000, 4096)),
+    (136 + 4 + 8 * 22) * n_w)
 print(json.dumps(out, indent=1))
