@@ -167,36 +167,45 @@ __device__ __forceinline__ uint64_t dpp64(uint64_t v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
     return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
+template <int CTRL>
+__device__ __forceinline__ gl::S96 dpp96(gl::S96 v) {
+    gl::S96 r;
+    r.w0 = (uint32_t)__builtin_amdgcn_update_dpp((int)v.w0, (int)v.w0, CTRL, 0xF, 0xF, false);
+    r.w1 = (uint32_t)__builtin_amdgcn_update_dpp((int)v.w1, (int)v.w1, CTRL, 0xF, 0xF, false);
+    r.w2 = (uint32_t)__builtin_amdgcn_update_dpp((int)v.w2, (int)v.w2, CTRL, 0xF, 0xF, false);
+    return r;
+}
+// state words are any 64-bit representatives; the layer's sums are plain 96-bit integers (coefficients add up to 21)
 __device__ __forceinline__ uint64_t lanes8_external(uint64_t x) {
-    using gl::add;
-    const uint64_t s1 = add(x, dpp64<0xB1>(x));
-    const uint64_t s = add(s1, dpp64<0x4E>(s1));
+    using gl::S96;
+    const S96 s1 = gl::s96_sum(x, dpp64<0xB1>(x));
+    const S96 s = s1 + dpp96<0x4E>(s1);
     const uint64_t nb = dpp64<0x39>(x);
-    const uint64_t t = add(add(s, x), gl::dbl(nb));
-    const uint64_t o = dpp64<0x1B>(dpp64<0x141>(t));
-    return add(gl::dbl(t), o);
+    const S96 t = s + x + nb + nb;
+    const S96 o = dpp96<0x1B>(dpp96<0x141>(t));
+    return gl::s96_reduce_nc(t + t + o);
 }
 __device__ __forceinline__ uint64_t permute_lanes8(uint64_t x, const Params& p) {
     const int g = threadIdx.x & 7;
     x = lanes8_external(x);
     for (int r = 0; r < ROUNDS_F / 2; r++) {
-        x = sbox7(gl::add(x, p.ext_rc[r][g]));
+        x = sbox7_nc(gl::add_nc(x, p.ext_rc[r][g]));
         x = lanes8_external(x);
     }
     const uint64_t dg = p.int_diag[g];
     for (int r = 0; r < ROUNDS_P; r++) {
-        const uint64_t y = sbox7(gl::add(x, p.int_rc[r]));
+        const uint64_t y = sbox7_nc(gl::add_nc(x, p.int_rc[r]));
         x = g == 0 ? y : x;
-        uint64_t sum = gl::add(x, dpp64<0xB1>(x));
-        sum = gl::add(sum, dpp64<0x4E>(sum));
-        sum = gl::add(sum, dpp64<0x141>(sum));  // every lane of a quad holds the quad sum: the mirror lane is in the other quad
-        x = gl::mul_add(x, dg, sum);
+        gl::S96 sum = gl::s96_sum(x, dpp64<0xB1>(x));
+        sum = sum + dpp96<0x4E>(sum);
+        sum = sum + dpp96<0x141>(sum);  // every lane of a quad holds the quad sum: the mirror lane is in the other quad
+        x = gl::mul_add_s96_nc(x, dg, sum);
     }
     for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
-        x = sbox7(gl::add(x, p.ext_rc[r][g]));
+        x = sbox7_nc(gl::add_nc(x, p.ext_rc[r][g]));
         x = lanes8_external(x);
     }
-    return x;
+    return gl::canon(x);
 }
 #endif
 
