@@ -10,7 +10,6 @@ struct PoseidonParams {
 struct ceno_hip_merkle {
     int log_rows = 0;
     std::vector<uint64_t*> levels;   // levels[0] = 2^log_rows leaf digests (4 words each) ... levels[log_rows] = root
-    uint64_t** top_ptrs = nullptr;   // device array of level pointers for the fused tree-top kernel
     uint64_t** all_ptrs = nullptr;   // device array of all level pointers (batched path gathers)
 };
 
