@@ -22,7 +22,7 @@ LIB_PROVER = os.path.join(HERE, "libceno_prover.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-             "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")]
+             "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include")] + os.environ.get("CENO_HIP_EXTRA_FLAGS", "").split()
 CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
              "-D__HIP_PLATFORM_AMD__"]
 

@@ -41,6 +41,27 @@ GL_HD uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
 #endif
 GL_HD uint64_t join(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
+// Two formulations of the conditional corrections (identical results): GL_ARITH64 = 1 writes them with 64-bit overflow
+// builtins (the compiler picks v_lshl_add_u64 / v_cmp_*_u64 / v_cndmask: fewer VALU instructions and fewer VCC hazards;
+// measured on MI355X with tools/ubench_red.hip: 2.15e12 vs 1.75e12 modular multiplications per second), GL_ARITH64 = 0
+// keeps the explicit 32-bit carry chains.
+#ifndef GL_ARITH64
+#define GL_ARITH64 1
+#endif
+#if GL_ARITH64
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+    // s = a + b (65 bit); u = s - p = s + EPS (mod 2^64); take u when s >= p
+    uint64_t s, u;
+    const bool c = __builtin_add_overflow(a, b, &s);
+    const bool c2 = __builtin_add_overflow(s, EPS, &u);
+    return (c | c2) ? u : s;
+}
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t d;
+    const bool bw = __builtin_sub_overflow(a, b, &d);
+    return d - (bw ? EPS : 0);  // borrow: add p = subtract EPS
+}
+#else
 GL_HD uint64_t add(uint64_t a, uint64_t b) {
     // s = a + b (65 bit); u = s - p = s + EPS (mod 2^64); take u when s >= p
     uint32_t c, c2;
@@ -60,6 +81,7 @@ GL_HD uint64_t sub(uint64_t a, uint64_t b) {
     d1 = subc32(d1, 0u, b2, b2);
     return join(d0, d1);
 }
+#endif
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
 GL_HD uint64_t dbl(uint64_t a) { return add(a, a); }
 
@@ -80,6 +102,70 @@ GL_HD L4 mul_wide(uint64_t a, uint64_t b) {
 // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 (mod p):   x = (w1:w0) + w2*(2^32-1) - (c:w3).
 // Same value modulo p as reduce_limbs but only guaranteed to lie in [0, 2^64): enough for anything that
 // is next fed to mul_wide (whose inputs are plain 64-bit integers) and four instructions shorter.
+#ifndef GL_REDUCE_ASM
+#define GL_REDUCE_ASM 1
+#endif
+#if GL_REDUCE_ASM && defined(__HIP_DEVICE_COMPILE__)
+// Device form, 9 VALU instructions: t = w2 * (2^32 - 1) + (w1:w0) in ONE v_mad_u64_u32 (its 64-bit addend is free and the
+// carry lands in an SGPR pair), t -= (c:w3) with borrow, then + (carry - borrow) * EPS.  Bounds as in the portable form
+// below: after a carry t < 2^64 - 2^33, after a borrow t >= 2^64 - 2^36, and both together cancel.  The compiler does not
+// fold the addition into the multiply-add nor reuse the carry flags (it re-derives them with 64-bit compares), hence the
+// assembly; s_nop = the two wait states gfx950 wants between a VALU write of VCC / an SGPR and a VALU read of it as
+// carry or mask.  tools/ubench_red.hip: 2.35e12 modular multiplications per second against 2.10e12 (builtins), 1.89e12 (limbs).
+GL_HD uint64_t reduce_limbs_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
+    uint64_t t = join(w0, w1), cy;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %0\n\ts_nop 1" : "+v"(t), "=s"(cy) : "v"(w2));
+    uint32_t r0 = (uint32_t)t, r1 = (uint32_t)(t >> 32), a, b;
+    asm("v_sub_co_u32 %0, vcc, %0, %5\n\t"
+        "v_cndmask_b32 %2, 0, -1, %4\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32 %1, vcc, %1, %6, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %3, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %3\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(r0), "+v"(r1), "=&v"(a), "=&v"(b)
+        : "s"(cy), "v"(w3), "v"(c)
+        : "vcc");
+    return join(r0, r1);
+}
+// 96-bit input (w2 * 2^64 + (w1:w0)): nothing to subtract, 4 instructions
+#define GL_HAVE_REDUCE96 1
+GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) {
+    uint64_t t = join(w0, w1), cy;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %0\n\ts_nop 1" : "+v"(t), "=s"(cy) : "v"(w2));
+    uint32_t r0 = (uint32_t)t, r1 = (uint32_t)(t >> 32), a;
+    asm("v_cndmask_b32 %2, 0, -1, %3\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(r0), "+v"(r1), "=&v"(a)
+        : "s"(cy)
+        : "vcc");
+    return join(r0, r1);
+}
+GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
+    uint64_t u;
+    return __builtin_add_overflow(r, EPS, &u) ? u : r;
+}
+#elif GL_ARITH64
+GL_HD uint64_t reduce_limbs_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
+    uint64_t t0, r;
+    const bool bw = __builtin_sub_overflow(join(w0, w1), join(w3, c), &t0);
+    t0 -= bw ? EPS : 0;              // wrapped by 2^64 = EPS (mod p); t0 >= 2^64 - 2^36 then, so no second wrap (c < 16)
+    const uint64_t t1 = ((uint64_t)w2 << 32) - w2;  // w2 * (2^32 - 1) <= 2^64 - 2^33 + 1
+    const bool cy = __builtin_add_overflow(t0, t1, &r);
+    return r + (cy ? EPS : 0);       // wrapped again: add EPS; cannot wrap a third time
+}
+GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
+    uint64_t u;
+    return __builtin_add_overflow(r, EPS, &u) ? u : r;
+}
+#else
 GL_HD uint64_t reduce_limbs_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
     uint32_t bw, b2, cy, c2;
     uint32_t r0 = subc32(w0, w3, 0u, bw);
@@ -103,6 +189,10 @@ GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
     const uint32_t u1 = addc32((uint32_t)(r >> 32), 0u, cy, cy);
     return cy ? join(u0, u1) : r;
 }
+#endif
+#ifndef GL_HAVE_REDUCE96
+GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) { return reduce_limbs_nc(w0, w1, w2, 0u, 0u); }
+#endif
 GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
     return canon(reduce_limbs_nc(w0, w1, w2, w3, c));
 }
@@ -141,6 +231,13 @@ GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 // ---- lazy sums for hash linear layers: a few 64-bit values added without reduction ----
 // a (any 64-bit value) + b (canonical): same residue, result in [0, 2^64) — one wrap at most since a + b - 2^64 <= p - 2
+#if GL_ARITH64
+GL_HD uint64_t add_nc(uint64_t a, uint64_t b) {
+    uint64_t s;
+    const bool c = __builtin_add_overflow(a, b, &s);
+    return s + (c ? EPS : 0);
+}
+#else
 GL_HD uint64_t add_nc(uint64_t a, uint64_t b) {
     uint32_t c, c2;
     uint32_t s0 = addc32((uint32_t)a, (uint32_t)b, 0u, c);
@@ -150,6 +247,7 @@ GL_HD uint64_t add_nc(uint64_t a, uint64_t b) {
     s1 = addc32(s1, 0u, c2, c2);
     return join(s0, s1);
 }
+#endif
 // 96-bit plain integer sum of up to 2^32 arbitrary 64-bit values
 struct S96 {
     uint32_t w0, w1, w2;
@@ -180,7 +278,7 @@ GL_HD S96 s96_sum(uint64_t a, uint64_t b) {
     return r;
 }
 // residue of a 96-bit sum in [0, 2^64) (w2 * 2^64 = w2 * (2^32 - 1))
-GL_HD uint64_t s96_reduce_nc(S96 a) { return reduce_limbs_nc(a.w0, a.w1, a.w2, 0u, 0u); }
+GL_HD uint64_t s96_reduce_nc(S96 a) { return reduce96_nc(a.w0, a.w1, a.w2); }
 // a*b + s for a < 2^64, b canonical, s < 2^67: the sum stays below 2^128; result in [0, 2^64)
 GL_HD uint64_t mul_add_s96_nc(uint64_t a, uint64_t b, S96 s) {
     const L4 p = mul_wide(a, b);
@@ -195,7 +293,7 @@ GL_HD uint64_t mul_add_s96_nc(uint64_t a, uint64_t b, S96 s) {
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
     const uint64_t p0 = (uint64_t)(uint32_t)a * c;
     const uint64_t p1 = (uint64_t)(uint32_t)(a >> 32) * c + (p0 >> 32);
-    return reduce_limbs((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32), 0u, 0u);
+    return canon(reduce96_nc((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32)));
 }
 // reference forms kept for cross-checks (tests/test_host_cpu.py)
 GL_HD uint64_t mul_ref(uint64_t a, uint64_t b) {
@@ -257,7 +355,7 @@ GL_HD uint64_t mul_add2_nc(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
 GL_HD E2 e2_mul_nc(E2 a, E2 b) {
     const uint64_t p0 = (uint64_t)(uint32_t)a.c1 * (uint32_t)W;
     const uint64_t p1 = (uint64_t)(uint32_t)(a.c1 >> 32) * (uint32_t)W + (p0 >> 32);
-    const uint64_t a1w = reduce_limbs_nc((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32), 0u, 0u);
+    const uint64_t a1w = reduce96_nc((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32));
     return E2{mul_add2_nc(a.c0, b.c0, a1w, b.c1), mul_add2_nc(a.c0, b.c1, a.c1, b.c0)};
 }
 // a*b + c*d + e with a single reduction (e < 2^64)
