@@ -385,12 +385,38 @@ __device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t
     }
 }
 
+// pr[t] *= f(t) for the factor f(X) = x + (X - 1) * delta at the points 1..D.  `pr` starts as the term's coefficient c; from
+// 3 points on the FIRST factor takes c along as c*f(X) = c*x + (X - 1) * c*delta — two multiplications instead of D.
+template <int D>
+__device__ __forceinline__ void mul_points(E2 (&pr)[D], bool& seeded, const E2& c, E2 x, E2 delta) {
+    if (D >= 3 && !seeded) {
+        x = c * x;
+        delta = c * delta;
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pr[t] = x;
+            x = x + delta;
+        }
+        seeded = true;
+    } else {
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pr[t] = pr[t] * x;
+            x = x + delta;
+        }
+    }
+}
+
 // evaluations at points 1..D of one factor's pair, multiplied into the running products of a term / a group:
 // base-field tables (round 0 reads the witness columns as they are) stay in the base field — one 64-bit multiply per
 // point instead of an extension multiply — and are folded into the extension product once per term.
-template <int D>
-__device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_t p, E2 (&pe)[D], bool& has_e, uint64_t (&pb)[D], bool& has_b) {
-    if (!use_out && !sl.in_ext) {
+// `seed` (optional): the term's coefficient, folded into the FIRST extension factor as c*f(X) = c*hi + (X-1) * c*delta —
+// two multiplications instead of one per evaluation point (used when D >= 3).
+// ALLEXT: every table read is an extension table (all rounds after the first): the base-field arm is compiled out.
+template <int D, bool ALLEXT = false>
+__device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_t p, E2 (&pe)[D], bool& has_e, uint64_t (&pb)[D], bool& has_b,
+                                           const E2* seed = nullptr) {
+    if (!ALLEXT && !use_out && !sl.in_ext) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
         const uint64_t delta = sub(v.y, v.x);
         uint64_t x = v.y;
@@ -410,9 +436,19 @@ __device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_
         has_b = true;
     } else {
         E2 lo, hi;
-        load_pair(sl, use_out, p, lo, hi);
-        const E2 delta = hi - lo;
+        if (ALLEXT) {
+            const E2* q = reinterpret_cast<const E2*>(sl.out) + 2 * p;
+            lo = q[0];
+            hi = q[1];
+        } else {
+            load_pair(sl, use_out, p, lo, hi);
+        }
+        E2 delta = hi - lo;
         E2 x = hi;
+        if (seed && !has_e) {
+            x = *seed * x;
+            delta = *seed * delta;
+        }
         if (has_e) {
 #pragma unroll
             for (int t = 0; t < D; t++) {
@@ -507,11 +543,15 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                     const E2 c = pl.coeffs[term];
                     E2 pr[D];
                     uint64_t pb[D];
+                    // the coefficient seeds the extension product: as the initial value (one multiply per point with the
+                    // first factor) or, from 3 evaluation points on, folded into the first extension factor (two multiplies)
+                    constexpr bool FOLD_SEED = D >= 3;
 #pragma unroll
                     for (int t = 0; t < D; t++) pr[t] = c;
-                    bool has_e = true, has_b = false;  // the coefficient seeds the extension product
+                    bool has_e = !FOLD_SEED, has_b = false;
                     for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
-                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
+                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b, FOLD_SEED ? &c : nullptr);
+                    // no extension factor at all: pr still holds the coefficient
                     if (has_b) {
 #pragma unroll
                         for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
@@ -537,6 +577,59 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                     for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
                 }
             }
+        }
+    }
+    __shared__ int s_flag;
+    epilogue<D, NT>(acc, ep, smem, &s_flag);
+}
+
+// Rounds after the first read the folded tables, which are all extension tables: same plan walk as k_accum without the
+// base-field arm and its registers (the generic kernel keeps base products, flags and both load forms alive).
+template <int D>
+__global__ void __launch_bounds__(NT) k_accum_ext(DevPlan pl, size_t pairs, Epilogue ep) {
+    __shared__ E2 smem[(NT / 64) * D];
+    if (ep.wait_seq != 0) {
+        __shared__ unsigned long long s_c[3];
+        E2 unused;
+        if (!read_challenge(ep, unused, s_c)) return;
+    }
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t p = (size_t)blockIdx.x * NT + threadIdx.x; p < pairs; p += stride) {
+        for (int g = 0; g < pl.n_groups; g++) {
+            E2 inner[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) inner[t] = e2_zero();
+            for (uint32_t ti = pl.group_term_off[g]; ti < pl.group_term_off[g + 1]; ti++) {
+                const uint32_t term = pl.group_terms[ti];
+                const E2 c = pl.coeffs[term];
+                E2 pr[D];
+#pragma unroll
+                for (int t = 0; t < D; t++) pr[t] = c;
+                bool seeded = false;
+                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                    const E2* q = reinterpret_cast<const E2*>(pl.slots[pl.term_idx[k]].out) + 2 * p;
+                    const E2 lo = q[0], hi = q[1];
+                    mul_points<D>(pr, seeded, c, hi, hi - lo);
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
+            }
+            const uint32_t cb = pl.common_off[g], ce = pl.common_off[g + 1];
+            for (uint32_t k = cb; k < ce; k++) {
+                const E2* q = reinterpret_cast<const E2*>(pl.slots[pl.common_idx[k]].out) + 2 * p;
+                const E2 lo = q[0], hi = q[1], delta = hi - lo;
+                E2 x = hi;
+#pragma unroll
+                for (int t = 0; t < D; t++) {
+                    inner[t] = inner[t] * x;
+                    x = x + delta;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < D; t++) acc[t] = acc[t] + inner[t];
         }
     }
     __shared__ int s_flag;
@@ -679,15 +772,10 @@ __global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pa
                 E2 pr[D];
 #pragma unroll
                 for (int t = 0; t < D; t++) pr[t] = c;
+                bool seeded = false;
                 for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
                     const uint32_t m = pl.term_idx[k];
-                    E2 x = stage[(size_t)(2 * m) * TNT + tid];
-                    const E2 delta = stage[(size_t)(2 * m + 1) * TNT + tid];
-#pragma unroll
-                    for (int t = 0; t < D; t++) {
-                        pr[t] = pr[t] * x;
-                        x = x + delta;
-                    }
+                    mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TNT + tid], stage[(size_t)(2 * m + 1) * TNT + tid]);
                 }
 #pragma unroll
                 for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
@@ -785,25 +873,14 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
             E2 pr[D];
 #pragma unroll
             for (int t = 0; t < D; t++) pr[t] = c;
+            bool seeded = false;
             for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
                 const uint32_t m = pl.term_idx[k];
-                E2 x = stage[(size_t)(2 * m) * TP + q];
-                const E2 delta = stage[(size_t)(2 * m + 1) * TP + q];
-#pragma unroll
-                for (int t = 0; t < D; t++) {
-                    pr[t] = pr[t] * x;
-                    x = x + delta;
-                }
+                mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
             }
             for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
                 const uint32_t m = pl.common_idx[k];
-                E2 x = stage[(size_t)(2 * m) * TP + q];
-                const E2 delta = stage[(size_t)(2 * m + 1) * TP + q];
-#pragma unroll
-                for (int t = 0; t < D; t++) {
-                    pr[t] = pr[t] * x;
-                    x = x + delta;
-                }
+                mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
             }
 #pragma unroll
             for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
@@ -870,25 +947,14 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
             E2 pr[D];
 #pragma unroll
             for (int t = 0; t < D; t++) pr[t] = c;
+            bool seeded = false;
             for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
                 const E2* q = cur + (size_t)pl.term_idx[k] * sc_ + 2 * p;
-                const E2 lo = q[0], hi = q[1], delta = hi - lo;
-                E2 x = hi;
-#pragma unroll
-                for (int t = 0; t < D; t++) {
-                    pr[t] = pr[t] * x;
-                    x = x + delta;
-                }
+                mul_points<D>(pr, seeded, c, q[1], q[1] - q[0]);
             }
             for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
                 const E2* q = cur + (size_t)pl.common_idx[k] * sc_ + 2 * p;
-                const E2 lo = q[0], hi = q[1], delta = hi - lo;
-                E2 x = hi;
-#pragma unroll
-                for (int t = 0; t < D; t++) {
-                    pr[t] = pr[t] * x;
-                    x = x + delta;
-                }
+                mul_points<D>(pr, seeded, c, q[1], q[1] - q[0]);
             }
 #pragma unroll
             for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
@@ -1108,10 +1174,18 @@ static bool accum_lazy() {
     }();
     return v;
 }
+static bool accum_ext() {
+    static bool v = [] {
+        const char* e = getenv("CENO_HIP_ACCUM_EXT");  // 0: the generic accumulate kernel in every round (A/B measurements)
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
 template <int D>
 static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0) {
     if (base0) hipLaunchKernelGGL((k_accum_base0<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
     else if (accum_lazy()) hipLaunchKernelGGL((k_accum<D, true>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+    else if (pl.use_out && accum_ext()) hipLaunchKernelGGL((k_accum_ext<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
     else hipLaunchKernelGGL((k_accum<D, false>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
 }
 // base0: round 0 of a class whose every term is a product of base-field tables (k_accum_base0)
