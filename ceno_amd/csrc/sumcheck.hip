@@ -609,10 +609,25 @@ __global__ void __launch_bounds__(NT) k_accum_ext(DevPlan pl, size_t pairs, Epil
 #pragma unroll
                 for (int t = 0; t < D; t++) pr[t] = c;
                 bool seeded = false;
-                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                // the pair of factor k+1 is requested before factor k is multiplied in (one L2 round trip hidden per factor)
+                uint32_t k = pl.term_off[term];
+                const uint32_t ke = pl.term_off[term + 1];
+                E2 lo = e2_zero(), hi = e2_zero();
+                if (k < ke) {
                     const E2* q = reinterpret_cast<const E2*>(pl.slots[pl.term_idx[k]].out) + 2 * p;
-                    const E2 lo = q[0], hi = q[1];
+                    lo = q[0];
+                    hi = q[1];
+                }
+                for (; k < ke; k++) {
+                    E2 nlo = lo, nhi = hi;
+                    if (k + 1 < ke) {
+                        const E2* q = reinterpret_cast<const E2*>(pl.slots[pl.term_idx[k + 1]].out) + 2 * p;
+                        nlo = q[0];
+                        nhi = q[1];
+                    }
                     mul_points<D>(pr, seeded, c, hi, hi - lo);
+                    lo = nlo;
+                    hi = nhi;
                 }
 #pragma unroll
                 for (int t = 0; t < D; t++) inner[t] = inner[t] + pr[t];
