@@ -113,20 +113,6 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
     return 0;
 }
 
-// 8 lanes per node: levels too small to fill the chip (latency-bound, see permute_lanes8)
-__global__ void __launch_bounds__(NT) k_compress8(const uint64_t* __restrict__ child, size_t n_parent, uint64_t* __restrict__ parent,
-                                                  const p2::Params* __restrict__ pp) {
-    __shared__ p2::Params sp;
-    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
-    __syncthreads();
-    const size_t t = (size_t)blockIdx.x * NT + threadIdx.x, i = t >> 3;
-    const int g = threadIdx.x & 7;
-    const bool live = i < n_parent;  // whole 8-lane groups are live or idle together
-    uint64_t x = live ? child[8 * i + g] : 0;
-    x = p2::permute_lanes8(x, sp);
-    if (live && g < 4) parent[4 * i + g] = x;
-}
-
 // the last <= 8 levels (<= 256 digests in) in one workgroup of 1024 lanes = 128 nodes per pass
 static constexpr int TOP_NT = 1024, TOP_LEVELS = 8;
 struct TopPtrs {
@@ -137,7 +123,9 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
     __shared__ p2::Params sp;
     __shared__ uint64_t buf[2][4 << TOP_LEVELS];
     for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += TOP_NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
-    int n = 1 << levels;  // child digests
+    int n = 1 << levels;  // child digests of this workgroup's subtree
+    const size_t b = blockIdx.x;
+    child += 4 * (b << levels);
     for (int i = threadIdx.x; i < 4 * n; i += TOP_NT) buf[0][i] = child[i];
     __syncthreads();
     int cur = 0;
@@ -149,7 +137,7 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
             x = p2::permute_lanes8(x, sp);
             if (g < 4) {
                 buf[cur ^ 1][4 * slot + g] = x;
-                outs.p[l][4 * slot + g] = x;
+                outs.p[l][4 * ((b << (levels - 1 - l)) + slot) + g] = x;
             }
         }
         __syncthreads();
@@ -163,18 +151,22 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     TRY(get_params(ctx, &pp));
     const int log_rows = t->log_rows;
     int l = 1;
-    for (; l <= log_rows && (log_rows - l + 1) > TOP_LEVELS; l++) {
+    // levels with more than 2^14 nodes: one lane per node (throughput bound)
+    for (; l <= log_rows && ((size_t)1 << (log_rows - l)) > ((size_t)1 << 14); l++) {
         size_t np = (size_t)1 << (log_rows - l);
-        if (np > ((size_t)1 << 14))
-            hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
-        else
-            hipLaunchKernelGGL(k_compress8, dim3((unsigned)((np * 8 + NT - 1) / NT)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
     }
-    if (l <= log_rows) {  // levels l..log_rows: child level l-1 has 2^(log_rows-l+1) <= 256 digests
-        const int rem = log_rows - l + 1;
+    // the rest is a chain of dependent permutations (one per level): 8 lanes per permutation, and every launch takes up to
+    // TOP_LEVELS levels at once — each workgroup reduces its own 2^TOP_LEVELS-digest subtree in LDS — so 15 small levels
+    // cost two kernel boundaries instead of eight
+    int rem = log_rows - l + 1;  // the child level l-1 holds 2^rem digests
+    while (rem > 0) {
+        const int lv = rem > TOP_LEVELS ? TOP_LEVELS : rem;
         TopPtrs tp{};
-        for (int i = 0; i < rem; i++) tp.p[i] = t->levels[l + i];
-        hipLaunchKernelGGL(k_compress_top, dim3(1), dim3(TOP_NT), 0, st, t->levels[l - 1], rem, tp, pp);
+        for (int i = 0; i < lv; i++) tp.p[i] = t->levels[l + i];
+        hipLaunchKernelGGL(k_compress_top, dim3(1u << (rem - lv)), dim3(TOP_NT), 0, st, t->levels[l - 1], lv, tp, pp);
+        l += lv;
+        rem -= lv;
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
