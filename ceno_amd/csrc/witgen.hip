@@ -39,22 +39,47 @@ __device__ __forceinline__ uint64_t aligned_prev_ts(uint64_t prev_cycle, uint64_
 __device__ __forceinline__ uint64_t lt_diff(uint64_t lhs, uint64_t rhs) { return (lhs < rhs ? (1ull << MAX_TS_BITS) : 0ull) + lhs - rhs; }
 
 // counter += 1 per lane; lanes of a wave that hit the slot of the first active lane are merged into one atomic
-// (timestamp-difference limbs are nearly constant across a chip, so most of a wave lands on one slot)
+// (timestamp-difference limbs are nearly constant across a chip, so most of a wave lands on one slot).
+// XCD_LOCAL: `table` is this XCD's private copy, so the add only has to be atomic inside the XCD's L2 (workgroup-scope
+// read-modify-write, no sc1: it never leaves the L2); a device-scope atomic is executed on the fabric side of the L2 at
+// ~15 G/s chip-wide, which is what bounds this kernel (5 distinct-slot counts per instance).
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void lk_add(uint32_t* p, uint32_t v) {
+    if (XCD_LOCAL) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(p, v);
+}
+template <bool XCD_LOCAL>
 __device__ __forceinline__ void lk_count(uint32_t* table, uint32_t slot) {
     if (!table) return;
     const uint32_t first = __builtin_amdgcn_readfirstlane(slot);
     const uint64_t same = __ballot(slot == first);
     if (slot == first) {
-        if ((int)__lane_id() == __ffsll((long long)same) - 1) atomicAdd(table + slot, (uint32_t)__popcll(same));
+        if ((int)__lane_id() == __ffsll((long long)same) - 1) lk_add<XCD_LOCAL>(table + slot, (uint32_t)__popcll(same));
     } else {
-        atomicAdd(table + slot, 1u);
+        lk_add<XCD_LOCAL>(table + slot, 1u);
     }
 }
+// dst[i] += sum over the 8 per-XCD copies (device-scope atomics: other chips of the shard may be adding to dst concurrently)
+__global__ void __launch_bounds__(NT) k_lk_merge(const uint32_t* __restrict__ copies, size_t slots, uint32_t* dst) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= slots) return;
+    uint32_t s = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) s += copies[(size_t)x * slots + i];
+    if (s) atomicAdd(dst + i, s);
+}
 
-template <bool SUB>
+// XCD_LOCAL: lk_dyn / lk_fetch point at 8 consecutive copies of the tables, one per XCD (HW_REG_XCC_ID picks this wave's)
+template <bool SUB, bool XCD_LOCAL>
 __global__ void __launch_bounds__(NT) k_witgen_arith(Map m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
                                                      uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w,
                                                      size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    if (XCD_LOCAL) {
+        // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits): simm16 = id | offset << 6 | (size - 1) << 11
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
+        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
+    }
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
         if (r >= n) {  // padding rows: every mapped column is zero
@@ -107,20 +132,20 @@ __global__ void __launch_bounds__(NT) k_witgen_arith(Map m, const unsigned char*
         // (SUB: also of rd, Value::new uint.rs:684-688)
         if (lk_fetch) {
             const uint32_t slot = (pc - fetch_base) >> 2;
-            if (slot < fetch_slots) lk_count(lk_fetch, slot);
+            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
         }
         constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
-        lk_count(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
-        lk_count(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
-        lk_count(lk_dyn, U16 + (uint32_t)(d2 & 0xffff));
-        lk_count(lk_dyn, R13 + (uint32_t)((d2 >> 16) & 0xffff));
-        lk_count(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
-        lk_count(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
-        lk_count(lk_dyn, U16 + (s0 & 0xffff));  // limbs of the addition's result, range-checked inside Value::add
-        lk_count(lk_dyn, U16 + (s1 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d2 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d2 >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (s0 & 0xffff));  // limbs of the addition's result, range-checked inside Value::add
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (s1 & 0xffff));
         if (SUB) {
-            lk_count(lk_dyn, U16 + (rd_after & 0xffff));
-            lk_count(lk_dyn, U16 + (rd_after >> 16));
+            lk_count<XCD_LOCAL>(lk_dyn, U16 + (rd_after & 0xffff));
+            lk_count<XCD_LOCAL>(lk_dyn, U16 + (rd_after >> 16));
         }
     }
 }
@@ -142,8 +167,32 @@ int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, 
     CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
     hipStream_t st = ctx_stream(ctx, s);
     // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written, padding included
-    if (sub) hipLaunchKernelGGL(k_witgen_arith<true>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
-    else hipLaunchKernelGGL(k_witgen_arith<false>, dim3(grid_for(rows, NT, MAXB)), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    if (xcd_local && (lk_dyn || lk_fetch) && n > 0) {
+        // per-XCD copies of both tables, zeroed, counted into with L2-local atomics, then merged into the caller's tables
+        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0;
+        void* scratch = nullptr;
+        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), &scratch));
+        uint32_t* c_dyn = (uint32_t*)scratch;
+        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
+        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            if (sub) hipLaunchKernelGGL((k_witgen_arith<true, true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
+            else hipLaunchKernelGGL((k_witgen_arith<false, true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
+            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
+            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
+            e = hipGetLastError();
+        }
+        // the scratch goes back to the pool only after the stream has consumed it
+        const hipError_t e2 = hipStreamSynchronize(st);
+        ctx_free(ctx, scratch);
+        HIP_TRY(ctx, e);
+        HIP_TRY(ctx, e2);
+        return 0;
+    }
+    if (sub) hipLaunchKernelGGL((k_witgen_arith<true, false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
+    else hipLaunchKernelGGL((k_witgen_arith<false, false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

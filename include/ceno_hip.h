@@ -294,6 +294,7 @@ int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint6
  *   dev_lk_dynamic[(1 << bits) + v]  (LookupTable::Dynamic, gkr_iop/src/utils/lk_multiplicity.rs:181-198; 2^17 counters)
  *   dev_lk_fetch[(pc - fetch_base_pc) / 4]  (LookupTable::Instruction, dispatch.rs:438-443)
  * Counters are ADDED to (atomics), so one pair of tables serves all chips of a shard; either pointer may be NULL.
+ * With lookup tables the call synchronises the stream (it counts into per-XCD scratch copies and merges them).
  * The shard RAM records of the reference's kernels (F-3) are not produced here.
  * ---------------------------------------------------------------------------------------------- */
 #define CENO_HIP_STEP_RECORD_BYTES 136
