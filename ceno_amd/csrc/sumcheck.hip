@@ -912,6 +912,13 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
 // (ping-pong), so a round costs the publish + the host round trip + the arithmetic.  The tables of the last round
 // go back to the buffer ceno_hip_sumcheck_finish expects.
 // ------------------------------------------------------------------------------------------------
+struct alignas(16) TailTerm {
+    E2 c;
+    uint32_t nf;
+    uint16_t idx[8];
+    uint32_t pad[3];
+};
+static_assert(sizeof(TailTerm) == 48, "TailTerm layout");
 template <int D>
 __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
                                              E2 r, Epilogue ep) {
@@ -920,6 +927,22 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
     E2* bufB = bufA + (size_t)n_mles * 2 * pairs0;         // [n_mles][pairs0]
     E2* smem = bufB + (size_t)n_mles * pairs0;             // [(NT/64) * D]
     unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // c0, c1, ok
+    // the plan, flattened once into LDS: every round walks it again, and from global memory that walk is a chain of 4-5
+    // dependent loads (group -> term -> offsets -> indices) on the critical path of a ~10 us round.  A flat term carries its
+    // own factors followed by its group's common factors (their total is <= D, checked at begin).
+    TailTerm* ft = reinterpret_cast<TailTerm*>(s_chal + 4);
+    for (int ti = threadIdx.x; ti < n_flat; ti += NT) {
+        int g = 0;
+        while ((int)pl.group_term_off[g + 1] <= ti) g++;
+        const uint32_t term = pl.group_terms[ti];
+        TailTerm t;
+        t.c = pl.coeffs[term];
+        uint32_t nf = 0;
+        for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.term_idx[k];
+        for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.common_idx[k];
+        t.nf = nf;
+        ft[ti] = t;
+    }
     if (ep.wait_seq != 0) {
         if (!read_challenge(ep, r, s_chal)) return;
     }
@@ -955,20 +978,14 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         for (int t = 0; t < D; t++) acc[t] = e2_zero();
         for (int idx = threadIdx.x; idx < n_flat * pairs; idx += NT) {
             const int ti = idx / pairs, p = idx - ti * pairs;
-            int g = 0;
-            while ((int)pl.group_term_off[g + 1] <= ti) g++;
-            const uint32_t term = pl.group_terms[ti];
-            const E2 c = pl.coeffs[term];
+            const TailTerm& tt = ft[ti];
+            const E2 c = tt.c;
             E2 pr[D];
 #pragma unroll
             for (int t = 0; t < D; t++) pr[t] = c;
             bool seeded = false;
-            for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
-                const E2* q = cur + (size_t)pl.term_idx[k] * sc_ + 2 * p;
-                mul_points<D>(pr, seeded, c, q[1], q[1] - q[0]);
-            }
-            for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
-                const E2* q = cur + (size_t)pl.common_idx[k] * sc_ + 2 * p;
+            for (uint32_t k = 0; k < tt.nf; k++) {
+                const E2* q = cur + (size_t)tt.idx[k] * sc_ + 2 * p;
                 mul_points<D>(pr, seeded, c, q[1], q[1] - q[0]);
             }
 #pragma unroll
@@ -1272,14 +1289,16 @@ static size_t tail_max_pairs() {
     }();
     return v;
 }
-static size_t tail_lds_bytes(size_t n_mles, size_t pairs, int d) { return (n_mles * 3 * pairs + (size_t)(NT / 64) * d) * sizeof(E2) + 64; }
-static bool tail_eligible(size_t n_mles, size_t pairs, int d) {
-    return pairs >= 1 && pairs <= tail_max_pairs() && tail_lds_bytes(n_mles, pairs, d) <= 60 * 1024;
+static size_t tail_lds_bytes(size_t n_mles, size_t pairs, int d, size_t n_flat) {
+    return (n_mles * 3 * pairs + (size_t)(NT / 64) * d) * sizeof(E2) + 64 + n_flat * 48;
+}
+static bool tail_eligible(size_t n_mles, size_t pairs, int d, size_t n_flat) {
+    return pairs >= 1 && pairs <= tail_max_pairs() && n_mles < 65536 && tail_lds_bytes(n_mles, pairs, d, n_flat) <= 60 * 1024;
 }
 template <int D>
 static void launch_tail_d(const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
                           hipStream_t st) {
-    hipLaunchKernelGGL((k_tail<D>), dim3(1), dim3(NT), tail_lds_bytes((size_t)n_mles, pairs, D), st, pl, last_slots, n_mles, n_flat, (int)pairs, i0, n,
+    hipLaunchKernelGGL((k_tail<D>), dim3(1), dim3(NT), tail_lds_bytes((size_t)n_mles, pairs, D, (size_t)n_flat), st, pl, last_slots, n_mles, n_flat, (int)pairs, i0, n,
                        e2_zero(), ep);
 }
 static void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
@@ -1726,7 +1745,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             pl.term_off = cl.d_term_off;
             pl.term_idx = cl.d_term_idx;
             const int tnt = fused_tnt(k, pairs);
-            if (tail_eligible(k, pairs, sc->d)) {  // this launch produces rounds i .. n-1
+            if (tail_eligible(k, pairs, sc->d, (size_t)cl.n_flat)) {  // this launch produces rounds i .. n-1
                 launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, sc->n, ep, sc->st);
                 upto = sc->n;
                 break;
