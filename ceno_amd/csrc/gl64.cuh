@@ -133,6 +133,28 @@ GL_HD uint64_t reduce_limbs_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w
         : "vcc");
     return join(r0, r1);
 }
+// 128-bit input (no fifth limb): the borrow step subtracts with an inline zero
+GL_HD uint64_t reduce128_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    uint64_t t = join(w0, w1), cy;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %0\n\ts_nop 1" : "+v"(t), "=s"(cy) : "v"(w2));
+    uint32_t r0 = (uint32_t)t, r1 = (uint32_t)(t >> 32), a, b;
+    asm("v_sub_co_u32 %0, vcc, %0, %5\n\t"
+        "v_cndmask_b32 %2, 0, -1, %4\n\t"
+        "s_nop 0\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %3, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_sub_co_u32 %0, vcc, %0, %3\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(r0), "+v"(r1), "=&v"(a), "=&v"(b)
+        : "s"(cy), "v"(w3)
+        : "vcc");
+    return join(r0, r1);
+}
 // 96-bit input (w2 * 2^64 + (w1:w0)): nothing to subtract, 4 instructions
 #define GL_HAVE_REDUCE96 1
 GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) {
@@ -192,16 +214,17 @@ GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
 #endif
 #ifndef GL_HAVE_REDUCE96
 GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) { return reduce_limbs_nc(w0, w1, w2, 0u, 0u); }
+GL_HD uint64_t reduce128_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return reduce_limbs_nc(w0, w1, w2, w3, 0u); }
 #endif
 GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
     return canon(reduce_limbs_nc(w0, w1, w2, w3, c));
 }
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
-    return reduce_limbs((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0u);
+    return canon(reduce128_nc((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
 }
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
     const L4 p = mul_wide(a, b);
-    return reduce_limbs(p.w0, p.w1, p.w2, p.w3, 0u);
+    return canon(reduce128_nc(p.w0, p.w1, p.w2, p.w3));
 }
 // a*b + c*d with a single reduction (129-bit sum)
 GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
@@ -216,7 +239,7 @@ GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
 // product that is only multiplied again (any 64-bit inputs, result in [0, 2^64) not canonical)
 GL_HD uint64_t mul_nc(uint64_t a, uint64_t b) {
     const L4 p = mul_wide(a, b);
-    return reduce_limbs_nc(p.w0, p.w1, p.w2, p.w3, 0u);
+    return reduce128_nc(p.w0, p.w1, p.w2, p.w3);
 }
 // a*b + c with one reduction (c < 2^64: the sum stays below 2^128), canonical result
 GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
@@ -226,7 +249,7 @@ GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
     const uint32_t s1 = addc32(p.w1, (uint32_t)(c >> 32), cy, cy);
     const uint32_t s2 = addc32(p.w2, 0u, cy, cy);
     const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
-    return reduce_limbs(s0, s1, s2, s3, 0u);
+    return canon(reduce128_nc(s0, s1, s2, s3));
 }
 GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 // ---- lazy sums for hash linear layers: a few 64-bit values added without reduction ----
@@ -287,7 +310,7 @@ GL_HD uint64_t mul_add_s96_nc(uint64_t a, uint64_t b, S96 s) {
     const uint32_t s1 = addc32(p.w1, s.w1, cy, cy);
     const uint32_t s2 = addc32(p.w2, s.w2, cy, cy);
     const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
-    return reduce_limbs_nc(s0, s1, s2, s3, 0u);
+    return reduce128_nc(s0, s1, s2, s3);
 }
 // small-constant multiply (c < 2^32): the product has 96 bits
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
@@ -408,7 +431,7 @@ GL_HD void acc5_add(Acc5& a, const L4& p) {
 }
 // w4 * 2^128 = -(w4 << 32) (mod p), and (w4 << 32) <= p - 1 is canonical
 GL_HD uint64_t acc5_reduce(const Acc5& a) {
-    return sub(reduce_limbs(a.w0, a.w1, a.w2, a.w3, 0u), (uint64_t)a.w4 << 32);
+    return sub(canon(reduce128_nc(a.w0, a.w1, a.w2, a.w3)), (uint64_t)a.w4 << 32);
 }
 struct E2Acc {
     Acc5 s00, s11, s01;
