@@ -61,6 +61,8 @@ struct Epilogue {
     struct Bcast* bcast;           // device memory, challenge relay between workgroups
     unsigned long long wait_seq;   // 0: challenge is the kernel argument; else it was relayed as round `wait_seq`
     unsigned long long next_seq;   // != 0: after publishing, fetch challenge `next_seq` from the host for the next launch
+    int dbg;                       // 1: record wall-clock stamps per round in bcast->dbg (CENO_HIP_DEBUG); each stamp costs a
+                                   // realtime read and a store on the round's critical path
 };
 
 // host -> device mailbox in pinned memory (one cache line)
@@ -135,16 +137,19 @@ __device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r, unsign
 template <int D>
 __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep) {
     const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
-    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][1] = wall_clock64();
-    for (int t = 0; t < ep.d; t++) {
-        E2 v = e2_zero();
-        if (t < D) v = unit ? tot[t < D ? t : 0] : tot[t < D ? t : 0] * ep.coeff;
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][1] = wall_clock64();
+    // one lane runs this on the critical path of every round: the D accumulated points are handled with STATIC indices (a
+    // run-time index into the register array goes through scratch memory) and their independent loads / multiplies overlap;
+    // points beyond D (a class of lower degree than the message) only carry the running total and the scalars
+    auto emit = [&](int t, E2 v) {
         if (!ep.first_class) v = v + ep.round_acc[t];
         if (ep.last_class) {
             v = v + ep.scalars[t];
             if (ep.flag) {
-                __hip_atomic_store(ep.out_msg + 2 * t, v.c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(ep.out_msg + 2 * t + 1, v.c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // ONE 16-byte write-through system-scope store per point (each such store is its own fabric transaction)
+                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ep.out_msg + 2 * t), "v"(w) : "memory");
             } else {
                 ep.out_msg[2 * t] = v.c0;
                 ep.out_msg[2 * t + 1] = v.c1;
@@ -152,7 +157,11 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
         } else {
             ep.round_acc[t] = v;
         }
-    }
+    };
+#pragma unroll
+    for (int t = 0; t < D; t++)
+        if (t < ep.d) emit(t, unit ? tot[t] : tot[t] * ep.coeff);
+    for (int t = D; t < ep.d; t++) emit(t, e2_zero());
     if (ep.last_class && ep.flag) {
         // message before flag: the message words went out as write-through system-scope stores; drain them
         // (vmcnt) and only then store the flag.  A system-scope release FENCE would write back every dirty
@@ -160,9 +169,9 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(ep.flag, ep.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][2] = wall_clock64();
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][2] = wall_clock64();
     if (ep.next_seq != 0) fetch_next_challenge(ep);
-    if (ep.bcast) ep.bcast->dbg[ep.seq & 63][3] = wall_clock64();
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][3] = wall_clock64();
 }
 
 template <int D, int TNT>
@@ -238,7 +247,7 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
         wacc[t] = e2acc_zero();
     }
     const size_t stride = (size_t)gridDim.x * NT;
-    if (ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
+    if (ep.dbg && ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
     __shared__ unsigned long long s_chal[3];
     __shared__ int s_flag;
     if (ep.wait_seq != 0) {
@@ -1672,6 +1681,8 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
     ep.d = sc->d;
     ep.mailbox = sc->d_mailbox;
     ep.bcast = sc->d_bcast;
+    static const int dbg_on = getenv("CENO_HIP_DEBUG") != nullptr;
+    ep.dbg = dbg_on;
     ep.wait_seq = (unsigned long long)i;                              // round 0 takes no challenge
     ep.next_seq = (i + 1 < sc->n) ? (unsigned long long)(i + 1) : 0;  // fetch challenge i for round i+1
     return ep;
