@@ -982,6 +982,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
     E2 *cur = bufA, *nxt = bufB;
     int sc_ = sa, sn = sb, pairs = pairs0;
     for (int i = i0; i < n; i++) {
+        if (ep.dbg && ep.bcast && threadIdx.x == 0) ep.bcast->dbg[(i + 1) & 63][0] = wall_clock64();
         E2 acc[D];
 #pragma unroll
         for (int t = 0; t < D; t++) acc[t] = e2_zero();
