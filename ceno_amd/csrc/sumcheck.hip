@@ -134,10 +134,13 @@ __device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r, unsign
     return s_c[2] != 0;
 }
 
+// `seq` / `next_seq` are passed apart from `ep` so that the persistent tail kernel can publish round after round from the
+// kernel-argument copy of the epilogue: a modified local copy of the struct would live in scratch memory (its arrays are
+// indexed at run time) and every field read on this single-lane critical path would become a scratch load.
 template <int D>
-__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep) {
+__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep, unsigned long long seq, unsigned long long next_seq) {
     const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][1] = wall_clock64();
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][1] = wall_clock64();
     // one lane runs this on the critical path of every round: the D accumulated points are handled with STATIC indices (a
     // run-time index into the register array goes through scratch memory) and their independent loads / multiplies overlap;
     // points beyond D (a class of lower degree than the message) only carry the running total and the scalars
@@ -167,11 +170,15 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
         // (vmcnt) and only then store the flag.  A system-scope release FENCE would write back every dirty
         // line of the L2 (the freshly folded tables) — tens of microseconds per round.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(ep.flag, ep.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ep.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][2] = wall_clock64();
-    if (ep.next_seq != 0) fetch_next_challenge(ep);
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[ep.seq & 63][3] = wall_clock64();
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][2] = wall_clock64();
+    if (next_seq != 0) fetch_next_challenge(ep);
+    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][3] = wall_clock64();
+}
+template <int D>
+__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep) {
+    finish_message<D>(tot, ep, ep.seq, ep.next_seq);
 }
 
 template <int D, int TNT>
@@ -944,13 +951,12 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         int g = 0;
         while ((int)pl.group_term_off[g + 1] <= ti) g++;
         const uint32_t term = pl.group_terms[ti];
-        TailTerm t;
+        TailTerm& t = ft[ti];  // filled in place: a local struct indexed at run time would sit in scratch memory
         t.c = pl.coeffs[term];
         uint32_t nf = 0;
         for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.term_idx[k];
         for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.common_idx[k];
         t.nf = nf;
-        ft[ti] = t;
     }
     if (ep.wait_seq != 0) {
         if (!read_challenge(ep, r, s_chal)) return;
@@ -1003,10 +1009,8 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         }
         red::block_sum<D, NT>(acc, smem);
         if (threadIdx.x == 0) {
-            Epilogue e = ep;
-            e.seq = (unsigned long long)(i + 1);
-            e.next_seq = 0;  // the challenge is fetched right here, not relayed to another launch
-            finish_message<D>(acc, e);
+            // next_seq = 0: the challenge is fetched right here, not relayed to another launch
+            finish_message<D>(acc, ep, (unsigned long long)(i + 1), 0ull);
             if (i + 1 < n) {
                 unsigned long long c0 = 0, c1 = 0;
                 const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1);
