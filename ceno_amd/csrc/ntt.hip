@@ -58,19 +58,33 @@ static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t 
 // R register-resident radix-2 stages on the 2^R values a lane holds: value k sits at distance k << log_l inside a
 // sub-block of 2^(R + log_l) elements whose low index is l; `s` is the global stage of the first (forward) / last
 // (inverse) of the R stages.  Shared by the strided HBM passes and the LDS pass.
+// Twiddles.  The butterfly of stage q at in-block position kk needs tw[((kk << log_l) + l) << (s + q)]; read as such, the
+// loads of the later stages stride 2^(s+q) elements between adjacent lanes — one cache line per lane, 15 (R = 4) or 31
+// (R = 5) such loads per item — and the passes were bound by the address coalescer, not by HBM or the ALU (PMC: 69 % of
+// the wave cycles of the first RS-encode pass were issue stalls at 10 % VALU activity).  tw[] holds plain powers, so
+//     tw[((kk << log_l) + l) << (s + q)] = B_q * Z[kk << q],   B_q = tw[l << s]^(2^q),   Z[j] = tw[j << (log_l + s)]:
+// ONE per-lane load (B_0), R - 1 squarings, and 2^(R-1) constants that are uniform over the wave (scalar loads); a
+// butterfly whose kk is not zero pays one more multiplication.
 template <int R, bool INVERSE>
 __device__ __forceinline__ void radix_stages(uint64_t (&v)[1 << R], int log_l, size_t l, int s, const uint64_t* __restrict__ tw) {
     constexpr int E = 1 << R;
+    uint64_t B[R];
+    B[0] = tw[l << s];
+#pragma unroll
+    for (int q = 1; q < R; q++) B[q] = mul(B[q - 1], B[q - 1]);
+    uint64_t Z[E / 2];
+#pragma unroll
+    for (int j = 0; j < E / 2; j++) Z[j] = tw[(size_t)j << (log_l + s)];
     if (!INVERSE) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
             const int hb = 1 << (R - q - 1);
 #pragma unroll
-            for (int k = 0; k < E; k++) {
-                if ((k & hb) == 0) {
-                    const int kk = k & (2 * hb - 1);  // position inside the sub-block (lower half)
-                    const size_t pos = ((size_t)kk << log_l) + l;
-                    const uint64_t w = tw[pos << (s + q)];
+            for (int kk = 0; kk < hb; kk++) {  // position inside the sub-block (lower half); shared by 2^q sub-blocks
+                const uint64_t w = kk == 0 ? B[q] : mul(B[q], Z[kk << q]);
+#pragma unroll
+                for (int m = 0; m < (1 << q); m++) {
+                    const int k = kk + m * 2 * hb;
                     const uint64_t a = v[k], b = v[k + hb];
                     v[k] = add(a, b);
                     v[k + hb] = mul(sub(a, b), w);
@@ -82,11 +96,11 @@ __device__ __forceinline__ void radix_stages(uint64_t (&v)[1 << R], int log_l, s
         for (int q = R - 1; q >= 0; q--) {
             const int hb = 1 << (R - q - 1);
 #pragma unroll
-            for (int k = 0; k < E; k++) {
-                if ((k & hb) == 0) {
-                    const int kk = k & (2 * hb - 1);
-                    const size_t pos = ((size_t)kk << log_l) + l;
-                    const uint64_t w = tw[pos << (s + q)];
+            for (int kk = 0; kk < hb; kk++) {
+                const uint64_t w = kk == 0 ? B[q] : mul(B[q], Z[kk << q]);
+#pragma unroll
+                for (int m = 0; m < (1 << q); m++) {
+                    const int k = kk + m * 2 * hb;
                     const uint64_t a = v[k], b = mul(v[k + hb], w);
                     v[k] = add(a, b);
                     v[k + hb] = sub(a, b);
