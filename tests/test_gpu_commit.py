@@ -30,8 +30,8 @@ def _to_np(t):
     return t.cpu().numpy().view(np.uint64)
 
 
-def test_wit_infer_matches_oracle(dev):
-    nv = 10
+@pytest.mark.parametrize("nv", [1, 10, 14])
+def test_wit_infer_matches_oracle(dev, nv):
     cols = [po.rand_base(1 << nv, 10 + j) for j in range(6)] + [po.rand_ext(1 << nv, 99)]
     mles = [dev.upload(c) for c in cols]
     # records: r = alpha + beta*w0 + w1*w2 ; w = const + w3 ; lk = w4*w5*ext6 + w0
