@@ -835,6 +835,26 @@ __global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pa
     epilogue<D, TNT>(acc, ep, smem, s_flag);
 }
 
+// a plan term flattened for the term-parallel kernels: coefficient, then its own factors followed by its group's common
+// factors (their total is <= D <= 8, checked at begin)
+struct alignas(16) TailTerm {
+    E2 c;
+    uint32_t nf;
+    uint16_t idx[8];
+    uint32_t pad[3];
+};
+static_assert(sizeof(TailTerm) == 48, "TailTerm layout");
+__device__ __forceinline__ void flatten_term(const DevPlan& pl, int ti, TailTerm& t) {
+    int g = 0;
+    while ((int)pl.group_term_off[g + 1] <= ti) g++;
+    const uint32_t term = pl.group_terms[ti];
+    t.c = pl.coeffs[term];
+    uint32_t nf = 0;
+    for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.term_idx[k];
+    for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.common_idx[k];
+    t.nf = nf;
+}
+
 // ------------------------------------------------------------------------------------------------
 // term-parallel generic round for small / mid-size rounds.  k_fused gives one pair to one lane, which then walks the
 // whole plan serially: for a 33-term degree-4 layer that is ~400 dependent ext multiplies = 120 us per round however
@@ -843,12 +863,18 @@ __global__ void __launch_bounds__(TNT) k_fused(DevPlan pl, int n_mles, size_t pa
 // factors multiplies them in itself (the sum over terms is linear).  Rounds become 10-20 us.
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int TP, size_t pairs, E2 r, Epilogue ep) {
+__global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int TP, size_t pairs, E2 r, Epilogue ep, int flat_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     E2* stage = reinterpret_cast<E2*>(dyn);                               // [n_mles][2][TP]
     E2* smem = stage + (size_t)n_mles * 2 * TP;                    // [(NT/64) * D]
     unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // 3 words + flag
     int* s_flag = reinterpret_cast<int*>(s_chal + 4);
+    // the flattened plan in LDS (when it fits): its walk in global memory is a chain of dependent loads that phase 2 would
+    // otherwise start only after phase 1; issued here it overlaps the challenge relay, the cold table loads and the folds
+    TailTerm* ft = reinterpret_cast<TailTerm*>(s_chal + 6);
+    if (flat_in_lds)
+        for (int ti = threadIdx.x; ti < n_flat; ti += NT) flatten_term(pl, ti, ft[ti]);
+    if (ep.dbg && ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
     if (ep.wait_seq != 0) {
         if (!read_challenge(ep, r, s_chal)) return;
     }
@@ -897,21 +923,32 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
         for (int idx = threadIdx.x; idx < n_flat * TP; idx += NT) {
             const int ti = idx / TP, q = idx - ti * TP;
             if (p0 + q >= pairs) continue;
-            int g = 0;
-            while ((int)pl.group_term_off[g + 1] <= ti) g++;
-            const uint32_t term = pl.group_terms[ti];
-            const E2 c = pl.coeffs[term];
             E2 pr[D];
-#pragma unroll
-            for (int t = 0; t < D; t++) pr[t] = c;
             bool seeded = false;
-            for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
-                const uint32_t m = pl.term_idx[k];
-                mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
-            }
-            for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
-                const uint32_t m = pl.common_idx[k];
-                mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
+            if (flat_in_lds) {
+                const TailTerm& tt = ft[ti];
+                const E2 c = tt.c;
+#pragma unroll
+                for (int t = 0; t < D; t++) pr[t] = c;
+                for (uint32_t k = 0; k < tt.nf; k++) {
+                    const uint32_t m = tt.idx[k];
+                    mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
+                }
+            } else {
+                int g = 0;
+                while ((int)pl.group_term_off[g + 1] <= ti) g++;
+                const uint32_t term = pl.group_terms[ti];
+                const E2 c = pl.coeffs[term];
+#pragma unroll
+                for (int t = 0; t < D; t++) pr[t] = c;
+                for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++) {
+                    const uint32_t m = pl.term_idx[k];
+                    mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
+                }
+                for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1]; k++) {
+                    const uint32_t m = pl.common_idx[k];
+                    mul_points<D>(pr, seeded, c, stage[(size_t)(2 * m) * TP + q], stage[(size_t)(2 * m + 1) * TP + q]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
@@ -928,13 +965,6 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
 // (ping-pong), so a round costs the publish + the host round trip + the arithmetic.  The tables of the last round
 // go back to the buffer ceno_hip_sumcheck_finish expects.
 // ------------------------------------------------------------------------------------------------
-struct alignas(16) TailTerm {
-    E2 c;
-    uint32_t nf;
-    uint16_t idx[8];
-    uint32_t pad[3];
-};
-static_assert(sizeof(TailTerm) == 48, "TailTerm layout");
 template <int D>
 __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
                                              E2 r, Epilogue ep) {
@@ -947,17 +977,8 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
     // dependent loads (group -> term -> offsets -> indices) on the critical path of a ~10 us round.  A flat term carries its
     // own factors followed by its group's common factors (their total is <= D, checked at begin).
     TailTerm* ft = reinterpret_cast<TailTerm*>(s_chal + 4);
-    for (int ti = threadIdx.x; ti < n_flat; ti += NT) {
-        int g = 0;
-        while ((int)pl.group_term_off[g + 1] <= ti) g++;
-        const uint32_t term = pl.group_terms[ti];
-        TailTerm& t = ft[ti];  // filled in place: a local struct indexed at run time would sit in scratch memory
-        t.c = pl.coeffs[term];
-        uint32_t nf = 0;
-        for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.term_idx[k];
-        for (uint32_t k = pl.common_off[g]; k < pl.common_off[g + 1] && nf < 8; k++) t.idx[nf++] = (uint16_t)pl.common_idx[k];
-        t.nf = nf;
-    }
+    // filled in place: a local struct indexed at run time would sit in scratch memory
+    for (int ti = threadIdx.x; ti < n_flat; ti += NT) flatten_term(pl, ti, ft[ti]);
     if (ep.wait_seq != 0) {
         if (!read_challenge(ep, r, s_chal)) return;
     }
@@ -1343,9 +1364,11 @@ static bool tile_eligible(size_t n_mles, size_t pairs) {
 template <int D>
 static void launch_tile_d(const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
     const int tp = tile_pairs((size_t)n_flat, (size_t)n_mles, pairs);
-    const size_t lds = ((size_t)n_mles * 2 * tp + (NT / 64) * D) * sizeof(E2) + 64;
+    size_t lds = ((size_t)n_mles * 2 * tp + (NT / 64) * D) * sizeof(E2) + 64;
+    const int flat_in_lds = n_mles < 65536 && lds + (size_t)n_flat * 48 <= 60 * 1024;
+    if (flat_in_lds) lds += (size_t)n_flat * 48;
     const size_t tiles = (pairs + tp - 1) / tp;
-    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)std::min<size_t>(tiles, MAXB)), dim3(NT), lds, st, pl, n_mles, n_flat, tp, pairs, r, ep);
+    hipLaunchKernelGGL((k_tile<D>), dim3((unsigned)std::min<size_t>(tiles, MAXB)), dim3(NT), lds, st, pl, n_mles, n_flat, tp, pairs, r, ep, flat_in_lds);
 }
 static void launch_tile(int d, const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st) {
     switch (d) {
