@@ -1070,6 +1070,23 @@ __global__ void k_gather_first(const MleSlot* __restrict__ slots, int n, E2* __r
     if (i < n) out[i] = *reinterpret_cast<const E2*>(slots[i].out);
 }
 
+// last fold of a sumcheck: table i has two elements left, its evaluation is lo + r (hi - lo).  One launch writes all of
+// them straight into pinned host memory (no separate fold, gather and device-to-host blit on the way to the caller).
+__global__ void k_finish_evals(const MleSlot* __restrict__ slots, int n, E2 r, E2* __restrict__ out_host) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MleSlot sl = slots[i];
+    E2 lo, hi;
+    if (sl.in_ext) {
+        lo = ld_e2(sl.in);
+        hi = ld_e2(sl.in + 2);
+    } else {
+        lo = E2{sl.in[0], 0};
+        hi = E2{sl.in[1], 0};
+    }
+    out_host[i] = lo + r * (hi - lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side state
 // ------------------------------------------------------------------------------------------------
@@ -2022,14 +2039,22 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
         size_t h_cursor = 0;
         for (auto& cl : sc->classes) {
             if (cl.nv != sc->n) continue;
-            const MleSlot* d_slots = nullptr;
-            TRY(sc_push_slots(sc, cl, sc->n + 1, h_cursor, &d_slots));
-            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r, (const Bcast*)nullptr, 0ull);
-            hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
-                               sc->d_evals);
-            HIP_TRY(ctx, hipGetLastError());
+            // the slot table is read by the kernel from the pinned block itself (device view of the same words): no
+            // host-to-device blit in front of a kernel that reads a few hundred bytes once
+            MleSlot* h = sc->h_slots + (size_t)(sc->n + 1) * sc->slots_per_round + h_cursor;
+            for (size_t k = 0; k < cl.mles.size(); k++) {
+                ScMle& M = sc->mles[cl.mles[k]];
+                h[k].in = M.cur;
+                h[k].out = M.buf[M.which];
+                h[k].in_ext = M.cur_ext;
+                h[k].pad = 0;
+            }
+            h_cursor += cl.mles.size();
+            const MleSlot* d_slots = reinterpret_cast<const MleSlot*>(reinterpret_cast<char*>(sc->d_hflag) + (reinterpret_cast<char*>(h) - reinterpret_cast<char*>(sc->h_block)));
             E2* h_ev = sc->h_pinned + MAXD;
-            HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl.mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+            E2* d_ev = reinterpret_cast<E2*>(sc->d_hmsg) + MAXD;  // device view of the same pinned words
+            hipLaunchKernelGGL(k_finish_evals, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(), r, d_ev);
+            HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipStreamSynchronize(sc->st));
             for (size_t k = 0; k < cl.mles.size(); k++) {
                 ScMle& M = sc->mles[cl.mles[k]];
