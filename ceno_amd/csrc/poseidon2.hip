@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ ch
 void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
     if (t->all_ptrs) ctx_free(ctx, t->all_ptrs);
+    if (t->h_root) ctx_pinned_free(ctx, t->h_root);
     for (auto* p : t->levels) ctx_free(ctx, p);
     delete t;
 }
@@ -109,6 +110,11 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
         }
         t->levels[l] = (uint64_t*)p;
     }
+    void *h = nullptr, *d = nullptr;
+    if (ctx_pinned_alloc(ctx, 64, &h, &d) == 0) {  // optional: without it the root is fetched with a copy
+        t->h_root = (uint64_t*)h;
+        t->d_root_view = (uint64_t*)d;
+    }
     *out = t;
     return 0;
 }
@@ -117,6 +123,7 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
 static constexpr int TOP_NT = 1024, TOP_LEVELS = 8;
 struct TopPtrs {
     uint64_t* p[TOP_LEVELS];  // by value in the kernel arguments: no host-to-device copy (a pageable one would block the host on the stream)
+    uint64_t* root_host;      // != NULL in the launch that produces the root: it is also written to pinned host memory
 };
 __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restrict__ child, int levels, TopPtrs outs,
                                                          const p2::Params* __restrict__ pp) {
@@ -138,6 +145,7 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
             if (g < 4) {
                 buf[cur ^ 1][4 * slot + g] = x;
                 outs.p[l][4 * ((b << (levels - 1 - l)) + slot) + g] = x;
+                if (outs.root_host && l == levels - 1) outs.root_host[g] = x;  // one node, one workgroup
             }
         }
         __syncthreads();
@@ -164,6 +172,10 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
         const int lv = rem > TOP_LEVELS ? TOP_LEVELS : rem;
         TopPtrs tp{};
         for (int i = 0; i < lv; i++) tp.p[i] = t->levels[l + i];
+        if (rem == lv && t->d_root_view) {  // this launch ends at the root
+            tp.root_host = t->d_root_view;
+            t->root_on_host = true;
+        }
         hipLaunchKernelGGL(k_compress_top, dim3(1u << (rem - lv)), dim3(TOP_NT), 0, st, t->levels[l - 1], lv, tp, pp);
         l += lv;
         rem -= lv;
@@ -230,6 +242,11 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
 int ceno_hip_merkle_root(ceno_hip_ctx* ctx, ceno_hip_merkle* t, uint64_t* root4, ceno_hip_stream s) {
     CHECK_ARG(ctx, t && root4, "NULL argument");
     hipStream_t st = ctx_stream(ctx, s);
+    if (t->root_on_host) {  // the tree-top kernel wrote it to pinned memory: wait for the stream, no copy engine round trip
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        memcpy(root4, t->h_root, 32);
+        return 0;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(root4, t->levels[t->log_rows], 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return 0;
