@@ -1070,6 +1070,14 @@ __global__ void k_gather_first(const MleSlot* __restrict__ slots, int n, E2* __r
     if (i < n) out[i] = *reinterpret_cast<const E2*>(slots[i].out);
 }
 
+// start of a sumcheck: zero the arrival counter / relay block and pull the (small) plan blob out of the pinned block in ONE
+// launch — the runtime's fill and copy kernels cost ~9 and ~4 us of stream time each, in front of every tower layer
+__global__ void __launch_bounds__(256) k_setup(uint64_t* __restrict__ zero, size_t zero_words, uint64_t* __restrict__ dst,
+                                               const uint64_t* __restrict__ src_host_view, size_t words) {
+    for (size_t i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0;
+    for (size_t i = threadIdx.x; i < words; i += 256) dst[i] = src_host_view[i];
+}
+
 // last fold of a sumcheck: table i has two elements left, its evaluation is lo + r (hi - lo).  One launch writes all of
 // them straight into pinned host memory (no separate fold, gather and device-to-host blit on the way to the caller).
 __global__ void k_finish_evals(const MleSlot* __restrict__ slots, int n, E2 r, E2* __restrict__ out_host) {
@@ -1583,7 +1591,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_counter = (unsigned*)p; sc->d_bcast = (Bcast*)((char*)p + 64); rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
         if (!rc) { sc->dev_allocs.push_back(p); sc->d_round_acc = (E2*)p; }
         if (rc) { sc_release(sc); return rc; }
-        if (hipMemsetAsync(sc->d_counter, 0, 4096, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
+        // zeroed together with the plan upload below (k_setup), or by a memset when the plan takes the copy path
     }
     hipError_t e = hipSuccess;
     {
@@ -1614,7 +1622,15 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         rc = ctx_alloc(ctx, std::max<size_t>(blob.size(), 16), &d_blob);
         if (rc) { sc_release(sc); return rc; }
         sc->dev_allocs.push_back(d_blob);
-        if (hipMemcpyAsync(d_blob, h_blob, blob.size(), hipMemcpyHostToDevice, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+        if (blob.size() <= 16 * 1024 && blob.size() % 8 == 0) {
+            const uint64_t* d_view = reinterpret_cast<const uint64_t*>((char*)db + (h_blob - (char*)hb));
+            hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, reinterpret_cast<uint64_t*>(sc->d_counter), (size_t)4096 / 8, (uint64_t*)d_blob, d_view,
+                               blob.size() / 8);
+            if (hipGetLastError() != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+        } else {
+            if (hipMemsetAsync(sc->d_counter, 0, 4096, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
+            if (hipMemcpyAsync(d_blob, h_blob, blob.size(), hipMemcpyHostToDevice, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+        }
         for (size_t c = 0; c < sc->classes.size(); c++) {
             ScClass& cl = sc->classes[c];
             const PlanOff& po = plan_offs[c];
@@ -1784,8 +1800,16 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             }
             if (i > 0) sc_advance(sc, cl);
         }
-        if (from == 0)
-            HIP_TRY(ctx, hipMemcpyAsync(cl.d_slots, sc->h_slots, (size_t)sc->n * k * sizeof(MleSlot), hipMemcpyHostToDevice, sc->st));
+        if (from == 0) {
+            const size_t bytes = (size_t)sc->n * k * sizeof(MleSlot);
+            if (bytes <= 16 * 1024) {  // small: one tiny kernel reads the pinned block instead of a copy-engine blit
+                const uint64_t* d_view = reinterpret_cast<const uint64_t*>(reinterpret_cast<char*>(sc->d_hflag) +
+                                                                           (reinterpret_cast<char*>(sc->h_slots) - reinterpret_cast<char*>(sc->h_block)));
+                hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, sc->st, (uint64_t*)nullptr, (size_t)0, reinterpret_cast<uint64_t*>(cl.d_slots), d_view, bytes / 8);
+            } else {
+                HIP_TRY(ctx, hipMemcpyAsync(cl.d_slots, sc->h_slots, bytes, hipMemcpyHostToDevice, sc->st));
+            }
+        }
         for (int i = from; i < upto; i++) {
             const size_t pairs = (size_t)1 << (cl.nv - i - 1);
             Epilogue ep = pipe_epilogue(sc, cl, i);
