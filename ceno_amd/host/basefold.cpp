@@ -100,7 +100,6 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         for (auto* t : trees)
             if (t) ceno_hip_merkle_free(ctx, t);
         for (auto* m : owned) ceno_hip_mle_free(ctx, m);
-        if (d_scratch) (void)hipFree(d_scratch);
     };
     auto fail = [&](int rc, const char* what = nullptr) {
         std::string msg = what ? std::string("basefold_open: ") + what : std::string(ceno_hip_last_error(ctx));
@@ -322,9 +321,16 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     for (size_t q = 0; q < Q; q++) qidx[q] = tr_sample(tr).c0 & (((uint64_t)1 << H) - 1);
     // device scratch: [indices Q][piece-major answers]; host buffer mirrors the answers
     const size_t ans_words = Q * (qw - 1);
-    if (hipMalloc(&d_scratch, (Q + ans_words) * 8) != hipSuccess) {
-        cleanup();
-        return prover_set_error(CENO_HIP_ERR_OOM, "basefold_open: query scratch allocation failed");
+    {   // scratch from the library's pool (a base-field table of enough words): hipMalloc / hipFree cost ~0.1 ms per open
+        int snv = 0;
+        while (((size_t)1 << snv) < Q + ans_words) snv++;
+        ceno_hip_mle* scratch = nullptr;
+        if (ceno_hip_mle_alloc(ctx, snv, 0, &scratch) != 0) {
+            cleanup();
+            return prover_set_error(CENO_HIP_ERR_OOM, "basefold_open: query scratch allocation failed");
+        }
+        owned.push_back(scratch);
+        d_scratch = ceno_hip_mle_device_ptr(scratch);
     }
     uint64_t* d_idx = (uint64_t*)d_scratch;
     uint64_t* d_ans = d_idx + Q;
