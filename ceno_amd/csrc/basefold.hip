@@ -192,15 +192,18 @@ __global__ void __launch_bounds__(NT) k_gather(const uint64_t* __restrict__ src,
     }
 }
 // authentication paths: out[(q * depth + l) * 4 + k] = levels[l][((idx[q] >> shift) >> l) ^ 1][k]
-__global__ void __launch_bounds__(NT) k_gather_paths(uint64_t* const* __restrict__ levels, int depth, const uint64_t* __restrict__ idx, size_t n_q,
-                                                     int shift, uint64_t* __restrict__ out) {
+struct LevelPtrs {
+    const uint64_t* p[63];  // by value in the kernel arguments: no pointer table to upload per tree
+};
+__global__ void __launch_bounds__(NT) k_gather_paths(LevelPtrs lv, int depth, const uint64_t* __restrict__ idx, size_t n_q, int shift,
+                                                     uint64_t* __restrict__ out) {
     const size_t total = n_q * (size_t)depth * 4;
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
         const size_t q = t / ((size_t)depth * 4), rem = t % ((size_t)depth * 4);
         const int l = (int)(rem / 4), k = (int)(rem % 4);
         const size_t node = ((idx[q] >> shift) >> l) ^ 1;
-        out[t] = levels[l][4 * node + k];
+        out[t] = lv.p[l][4 * node + k];
     }
 }
 
@@ -318,20 +321,9 @@ int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint
     if (n == 0 || t->log_rows == 0) return 0;
     CHECK_ARG(ctx, t->log_rows <= 62, "tree too tall");
     hipStream_t st = ctx_stream(ctx, s);
-    if (!t->all_ptrs) {
-        void* p = nullptr;
-        TRY(ctx_alloc(ctx, 64 * sizeof(uint64_t*), &p));
-        uint64_t* h[64] = {nullptr};
-        for (int l = 0; l <= t->log_rows; l++) h[l] = t->levels[l];
-        hipError_t e = hipMemcpyAsync(p, h, sizeof(h), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) {
-            ctx_free(ctx, p);
-            return ctx_fail(ctx, CENO_HIP_ERR_HIP, "merkle_open_batch: %s", hipGetErrorString(e));
-        }
-        t->all_ptrs = (uint64_t**)p;
-    }
-    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, t->all_ptrs, t->log_rows, dev_indices, n, shift,
-                       dev_out);
+    LevelPtrs lv{};
+    for (int l = 0; l < t->log_rows; l++) lv.p[l] = t->levels[l];
+    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, lv, t->log_rows, dev_indices, n, shift, dev_out);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -10,7 +10,6 @@ struct PoseidonParams {
 struct ceno_hip_merkle {
     int log_rows = 0;
     std::vector<uint64_t*> levels;   // levels[0] = 2^log_rows leaf digests (4 words each) ... levels[log_rows] = root
-    uint64_t** all_ptrs = nullptr;   // device array of all level pointers (batched path gathers)
     uint64_t* h_root = nullptr;      // pinned host copy of the root, written by the kernel that computes it (no D2H blit)
     uint64_t* d_root_view = nullptr; // device view of h_root
     bool root_on_host = false;       // the tree-top kernel has been told to write h_root

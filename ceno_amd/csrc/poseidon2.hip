@@ -90,7 +90,6 @@ __global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ ch
 
 void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
-    if (t->all_ptrs) ctx_free(ctx, t->all_ptrs);
     if (t->h_root) ctx_pinned_free(ctx, t->h_root);
     for (auto* p : t->levels) ctx_free(ctx, p);
     delete t;
