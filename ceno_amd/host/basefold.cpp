@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <map>
 #include <vector>
@@ -62,6 +63,46 @@ struct Group {  // matrices with the same number of variables share one sumcheck
 
 }  // namespace
 
+// Pairs of tree streams (highest / lowest priority, see below) are kept between opens: creating and destroying two
+// streams costs a few hundred microseconds per call, more than a commit round.  A pair is taken out of the pool for the
+// duration of an open, so concurrent opens never share one.
+namespace {
+struct TreeStreams {
+    hipStream_t s[2];
+    int device;
+};
+std::mutex g_ts_mu;
+std::vector<TreeStreams> g_ts_pool;
+bool tree_streams_acquire(TreeStreams* out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(g_ts_mu);
+        for (size_t i = 0; i < g_ts_pool.size(); i++)
+            if (g_ts_pool[i].device == dev) {
+                *out = g_ts_pool[i];
+                g_ts_pool.erase(g_ts_pool.begin() + (long)i);
+                return true;
+            }
+    }
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int prio[2] = {greatest, least};
+    out->device = dev;
+    out->s[0] = out->s[1] = nullptr;
+    for (int i = 0; i < 2; i++)
+        if (hipStreamCreateWithPriority(&out->s[i], hipStreamNonBlocking, prio[i]) != hipSuccess) {
+            if (out->s[0]) (void)hipStreamDestroy(out->s[0]);
+            return false;
+        }
+    return true;
+}
+void tree_streams_release(const TreeStreams& ts) {
+    std::lock_guard<std::mutex> g(g_ts_mu);
+    g_ts_pool.push_back(ts);
+}
+}  // namespace
+
 extern "C" {
 
 size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries) {
@@ -87,14 +128,14 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     void* d_scratch = nullptr;
     ceno_hip_stream sx[2] = {nullptr, nullptr};  // tree building runs one round ahead on two alternating streams
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int ts_device = 0;
     auto cleanup = [&]() {
         for (int i = 0; i < 2; i++) {
-            if (sx[i]) {
-                (void)hipStreamSynchronize((hipStream_t)sx[i]);
-                (void)hipStreamDestroy((hipStream_t)sx[i]);
-            }
+            if (sx[i]) (void)hipStreamSynchronize((hipStream_t)sx[i]);
             if (ev[i]) (void)hipEventDestroy(ev[i]);
         }
+        if (sx[0]) tree_streams_release(TreeStreams{{(hipStream_t)sx[0], (hipStream_t)sx[1]}, ts_device});
+        sx[0] = sx[1] = nullptr;
         for (auto& g : groups)
             if (g.second.sc) ceno_hip_sumcheck_free(ctx, g.second.sc);
         for (auto* t : trees)
@@ -183,13 +224,11 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         // their kernels back to back (seen in the kernel trace: both tree streams on queue 4).  Streams of different
         // PRIORITY get queues of their own, so the two tree streams take the highest and the lowest level and leave the
         // caller's (normal) stream alone.
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const int prio[2] = {greatest, least};
+        TreeStreams ts;
+        if (!tree_streams_acquire(&ts)) return fail(CENO_HIP_ERR_HIP, "hipStreamCreateWithPriority failed");
+        ts_device = ts.device;
         for (int i = 0; i < 2; i++) {
-            hipStream_t hs = nullptr;
-            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, prio[i]) != hipSuccess) return fail(CENO_HIP_ERR_HIP, "hipStreamCreateWithPriority failed");
-            sx[i] = (ceno_hip_stream)hs;
+            sx[i] = (ceno_hip_stream)ts.s[i];
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return fail(CENO_HIP_ERR_HIP, "hipEventCreate failed");
         }
     }
