@@ -60,6 +60,8 @@ def lib():
         "ceno_hip_destroy": (None, [vp]),
         "ceno_hip_last_error": (C.c_char_p, [vp]),
         "ceno_hip_version": (C.c_char_p, []),
+        "ceno_hip_make_current": (i, [vp]),
+        "ceno_hip_device": (i, [vp]),
         "ceno_hip_stream_create": (i, [vp, vpp]),
         "ceno_hip_stream_create_lane": (i, [vp, i, vpp]),
         "ceno_hip_stream_destroy": (i, [vp, vp]),
@@ -111,6 +113,7 @@ def lib():
         "ceno_hip_witgen_add": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_sub": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),
+        "ceno_hip_poseidon2_is_pinned": (i, [vp]),
         "ceno_hip_poseidon2_permute": (i, [vp, vp, sz, vp]),
         "ceno_hip_merkle_commit": (i, [vp, vp, i, i, vp, vpp]),
         "ceno_hip_merkle_root": (i, [vp, vp, u64p, vp]),

@@ -41,8 +41,22 @@ def _run(cmd):
     return r.stdout
 
 
+def _flags_changed() -> bool:
+    """objects are only reusable when they were compiled with the same flags (tools/ab_*.sh rebuild with CENO_HIP_EXTRA_FLAGS):
+    the flag string is part of the cache key, so a variant build never masquerades as the shipped one"""
+    stamp = os.path.join(OBJ, "flags.txt")
+    cur = " ".join(os.environ.get("CENO_HIP_EXTRA_FLAGS", "").split())  # (the fixed flags hold checkout-dependent paths)
+    old = open(stamp).read() if os.path.exists(stamp) else ""
+    if old != cur:
+        with open(stamp, "w") as f:
+            f.write(cur)
+        return True
+    return False
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed()
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h"))

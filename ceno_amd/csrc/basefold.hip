@@ -21,8 +21,6 @@ static constexpr uint64_t TWO_ADIC_GEN_2_32 = 1753635133440165772ULL;
 static constexpr uint64_t INV2 = 0x7FFFFFFF80000001ULL;  // (p + 1) / 2
 
 // ---- fold coefficients: T[j] = g_H^(-bitrev_{H-1}(j)) / 2.  The table of a smaller height is a prefix. ----
-static std::mutex g_ft_mu;
-static std::map<std::pair<ceno_hip_ctx*, int>, uint64_t*> g_fold_tw;
 
 __global__ void __launch_bounds__(NT) k_fold_twiddles(uint64_t* t, size_t n, int bits, uint64_t g_inv) {
     size_t stride = (size_t)gridDim.x * NT;
@@ -33,19 +31,19 @@ __global__ void __launch_bounds__(NT) k_fold_twiddles(uint64_t* t, size_t n, int
 }
 
 static int get_fold_twiddles(ceno_hip_ctx* ctx, int log_h, hipStream_t st, const uint64_t** out) {
-    std::lock_guard<std::mutex> g(g_ft_mu);
-    for (auto& kv : g_fold_tw)
-        if (kv.first.first == ctx && kv.first.second >= log_h) {  // any taller table serves as a prefix
+    std::lock_guard<std::mutex> g(ctx->tw_mu);
+    for (auto& kv : ctx->fold_twiddles)
+        if (kv.first >= log_h) {  // any taller table serves as a prefix
             *out = kv.second;
             return 0;
         }
     const uint64_t gh = gl::pow(TWO_ADIC_GEN_2_32, (uint64_t)1 << (32 - log_h));
     const size_t n = (size_t)1 << (log_h - 1);
     void* p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, n * 8));
+    TRY(ctx_alloc(ctx, n * 8, &p));  // pool block: booked, released with the context
     hipLaunchKernelGGL(k_fold_twiddles, dim3(grid_for(n, NT, MAXB)), dim3(NT), 0, st, (uint64_t*)p, n, log_h - 1, gl::inv(gh));
     HIP_TRY(ctx, hipGetLastError());
-    g_fold_tw[std::make_pair(ctx, log_h)] = (uint64_t*)p;
+    ctx->fold_twiddles[log_h] = (uint64_t*)p;
     *out = (uint64_t*)p;
     return 0;
 }

@@ -47,8 +47,13 @@ struct ceno_hip_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_event_pool;
     uint64_t prof_launches = 0;
     double prof_bytes = 0.0;
+    // ---- NTT twiddle tables by (log_n, inverse): pool blocks (booked like every other allocation, freed with the context) ----
+    std::mutex tw_mu;
+    std::map<std::pair<int, int>, uint64_t*> twiddles;
+    std::map<int, uint64_t*> fold_twiddles;  // Basefold fold coefficients by codeword height (a taller table serves as a prefix)
     // ---- poseidon2 parameters (device) ----
     PoseidonParams* poseidon_dev = nullptr;
+    bool poseidon_pinned = false;  // true once ceno_hip_poseidon2_set_constants supplied a complete external table
 };
 
 struct ceno_hip_mle {
@@ -69,7 +74,14 @@ void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx);
 void ctx_vram_slot_free(ceno_hip_ctx* ctx, void* slot);
 int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view);
 void ctx_pinned_free(ceno_hip_ctx* ctx, void* host);
-inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) { return s ? (hipStream_t)s : ctx->default_stream; }
+// make ctx->device the calling thread's current device (reference: `ensure_context`, gkr_iop/src/gpu/mod.rs:91-92): a fresh
+// thread starts on device 0, and allocations / stream creation / launches follow the CURRENT device, not the context's
+void ctx_make_current(ceno_hip_ctx* ctx);
+// every entry point that touches the device resolves its stream through here, which also makes the device current
+inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    ctx_make_current(ctx);
+    return s ? (hipStream_t)s : ctx->default_stream;
+}
 
 // profiling hooks (ctx.hip)
 void prof_begin(ceno_hip_ctx* ctx, hipStream_t st);

@@ -20,6 +20,12 @@ int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+void ctx_make_current(ceno_hip_ctx* ctx) {
+    // hipGetDevice is a thread-local read; other users of the runtime in this process (torch) may have switched the device
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) (void)hipSetDevice(ctx->device);
+}
+
 static size_t bucket_size(size_t bytes) {
     if (bytes < 256) return 256;
     if (bytes <= ((size_t)1 << 20)) {
@@ -61,6 +67,7 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
         }
     }
     void* p = nullptr;
+    ctx_make_current(ctx);
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
         // drop the cache and retry once
@@ -89,6 +96,7 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
 
 static constexpr int VRAM_SLOTS = 1024;
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx) {
+    ctx_make_current(ctx);
     std::lock_guard<std::mutex> g(ctx->mu);
     if (ctx->vram_state == 0) {
         ctx->vram_state = -1;
@@ -126,6 +134,7 @@ int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_vi
             it->second.pop_back();
         }
     }
+    ctx_make_current(ctx);
     if (!h) {
         hipError_t e = hipHostMalloc(&h, b, hipHostMallocDefault);
         if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipHostMalloc(%zu): %s", b, hipGetErrorString(e));
@@ -204,6 +213,13 @@ const char* ceno_hip_last_error(ceno_hip_ctx* ctx) {
     return ctx->err.c_str();
 }
 
+int ceno_hip_make_current(ceno_hip_ctx* ctx) {
+    CHECK_ARG(ctx, ctx, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return 0;
+}
+int ceno_hip_device(const ceno_hip_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out) {
     CHECK_ARG(ctx, out, "out is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -238,6 +254,7 @@ int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s) {
 
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached) {
     size_t f = 0, t = 0;
+    ctx_make_current(ctx);
     HIP_TRY(ctx, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;

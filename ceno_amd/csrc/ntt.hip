@@ -23,8 +23,6 @@ static constexpr int NT = 256;
 static constexpr int LOCAL_LOG = 12;  // 4096 elements = 34 KB of LDS per block (with padding)
 static constexpr uint64_t TWO_ADIC_GEN_2_32 = 1753635133440165772ULL;
 
-static std::mutex g_tw_mu;
-static std::map<std::pair<ceno_hip_ctx*, int>, uint64_t*> g_tw_fwd, g_tw_inv;
 
 __global__ void __launch_bounds__(NT) k_twiddles(uint64_t* tw, size_t half, uint64_t w) {
     size_t stride = (size_t)gridDim.x * NT;
@@ -32,9 +30,9 @@ __global__ void __launch_bounds__(NT) k_twiddles(uint64_t* tw, size_t half, uint
 }
 
 static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t st, const uint64_t** out) {
-    std::lock_guard<std::mutex> g(g_tw_mu);
-    auto& cache = inverse ? g_tw_inv : g_tw_fwd;
-    auto key = std::make_pair(ctx, log_n);
+    std::lock_guard<std::mutex> g(ctx->tw_mu);
+    auto& cache = ctx->twiddles;
+    auto key = std::make_pair(log_n, inverse ? 1 : 0);
     auto it = cache.find(key);
     if (it != cache.end()) {
         *out = it->second;
@@ -44,7 +42,7 @@ static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t 
     if (inverse) w = gl::inv(w);
     size_t half = log_n ? (size_t)1 << (log_n - 1) : 1;
     void* p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, half * 8));
+    TRY(ctx_alloc(ctx, half * 8, &p));  // from the pool: counted by mem_info / booking, released by ceno_hip_destroy
     hipLaunchKernelGGL(k_twiddles, dim3(grid_for(half, NT, 2048)), dim3(NT), 0, st, (uint64_t*)p, half, w);
     HIP_TRY(ctx, hipGetLastError());
     cache[key] = (uint64_t*)p;

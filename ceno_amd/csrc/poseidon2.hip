@@ -20,7 +20,27 @@ static constexpr unsigned MAXB = 4096;
 
 #include "merkle.hpp"
 
+// The built-in round constants are PLACEHOLDERS (poseidon2.cuh): roots, challenges and proofs made with them are
+// self-consistent but can never verify against the reference.  Until a complete table has been supplied through
+// ceno_hip_poseidon2_set_constants every first use says so on stderr, and CENO_HIP_REQUIRE_PINNED_POSEIDON2=1 turns the
+// commit / open / transcript entry points into errors instead (what a production caller should set).
+static int placeholder_gate(ceno_hip_ctx* ctx) {
+    if (ctx->poseidon_pinned) return 0;
+    static const bool strict = [] { const char* e = getenv("CENO_HIP_REQUIRE_PINNED_POSEIDON2"); return e && atoi(e) != 0; }();
+    if (strict)
+        return ctx_fail(ctx, CENO_HIP_ERR_STATE, "Poseidon2 constants are placeholders: call ceno_hip_poseidon2_set_constants with the reference's "
+                        "table first (CENO_HIP_REQUIRE_PINNED_POSEIDON2 is set)");
+    static bool warned = false;
+    if (!warned && !getenv("CENO_HIP_QUIET_PLACEHOLDER")) {
+        warned = true;
+        fprintf(stderr, "[ceno_hip] WARNING: Poseidon2 placeholder round constants in use - Merkle roots, proofs of work and openings are NOT "
+                        "interoperable with the reference (PARITY UNPINNED); load the real table with ceno_hip_poseidon2_set_constants\n");
+    }
+    return 0;
+}
+
 int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
+    TRY(placeholder_gate(ctx));
     if (!ctx->poseidon_dev) {
         PoseidonParams h;
         p2::default_params(h.p);
@@ -185,9 +205,10 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
 
 extern "C" {
 
+int ceno_hip_poseidon2_is_pinned(const ceno_hip_ctx* ctx) { return ctx && ctx->poseidon_pinned ? 1 : 0; }
+
 int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external_rc, const uint64_t* internal_rc, const uint64_t* internal_diag) {
-    const p2::Params* dummy;
-    TRY(get_params(ctx, &dummy));
+    ctx_make_current(ctx);
     PoseidonParams h;
     p2::default_params(h.p);
     if (external_rc) memcpy(h.p.ext_rc, external_rc, sizeof(h.p.ext_rc));
@@ -201,8 +222,9 @@ int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external
     void* d = nullptr;
     HIP_TRY(ctx, hipMalloc(&d, sizeof(PoseidonParams)));
     HIP_TRY(ctx, hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
-    (void)hipFree(ctx->poseidon_dev);
+    if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
     ctx->poseidon_dev = (PoseidonParams*)d;
+    ctx->poseidon_pinned = external_rc && internal_rc && internal_diag;  // NULLs restore (parts of) the placeholder table
     return 0;
 }
 

@@ -63,6 +63,7 @@ struct Epilogue {
     unsigned long long next_seq;   // != 0: after publishing, fetch challenge `next_seq` from the host for the next launch
     int dbg;                       // 1: record wall-clock stamps per round in bcast->dbg (CENO_HIP_DEBUG); each stamp costs a
                                    // realtime read and a store on the round's critical path
+    unsigned long long poll_ticks; // pipelined: how long (100 MHz ticks) a queued round waits for its challenge before it gives up
 };
 
 // host -> device mailbox in pinned memory (one cache line)
@@ -85,18 +86,19 @@ __device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_a
 
 // thread 0 of the finishing block: class coefficient, running round total, front-load scalars, publish
 // Pipelined launches.  The finishing workgroup of round i — alone on the chip at that point — publishes
-// the message, then polls the host mailbox for challenge i (bounded: ~4 s of wall clock or the host's
+// the message, then polls the host mailbox for challenge i (bounded: CENO_HIP_PIPE_TIMEOUT_S, 60 s by default, or the host's
 // `abort`) and relays it through device memory; the already queued kernel of round i+1 picks it up with a
 // single load at its start.  Exactly one lane ever polls PCIe, nothing spins inside the big kernels.
-// one lane polls the host's mailbox for challenge `want_seq` (bounded: ~4 s of wall clock or the host's `abort`)
-__device__ __forceinline__ bool poll_challenge(const Mailbox* mb, unsigned long long want_seq, unsigned long long& c0, unsigned long long& c1) {
+// one lane polls the host's mailbox for challenge `want_seq` (bounded: ep.poll_ticks or the host's `abort`)
+__device__ __forceinline__ bool poll_challenge(const Mailbox* mb, unsigned long long want_seq, unsigned long long& c0, unsigned long long& c1,
+                                               unsigned long long poll_ticks) {
     const unsigned long long t0 = wall_clock64();  // 100 MHz
     unsigned spins = 0;
     for (;;) {
         // relaxed polls: an acquire per poll would invalidate the (large) L2 every iteration
         if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want_seq) break;
         if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > 400000000ull) return false;
+            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > poll_ticks) return false;
         }
     }
     // the host stores chal[] before chal_seq (release); these loads are issued only after the seq load
@@ -109,7 +111,7 @@ __device__ __forceinline__ bool poll_challenge(const Mailbox* mb, unsigned long 
 __device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
     Bcast* bc = ep.bcast;
     unsigned long long c0 = 0, c1 = 0;
-    const bool ok = poll_challenge(ep.mailbox, ep.next_seq, c0, c1);
+    const bool ok = poll_challenge(ep.mailbox, ep.next_seq, c0, c1, ep.poll_ticks);
     if (ok) {
         __hip_atomic_store(&bc->chal[0], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&bc->chal[1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1034,7 +1036,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
             finish_message<D>(acc, ep, (unsigned long long)(i + 1), 0ull);
             if (i + 1 < n) {
                 unsigned long long c0 = 0, c1 = 0;
-                const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1);
+                const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
                 s_chal[0] = c0;
                 s_chal[1] = c1;
                 s_chal[2] = ok ? 1ull : 0ull;
@@ -1744,6 +1746,16 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
     ep.bcast = sc->d_bcast;
     static const int dbg_on = getenv("CENO_HIP_DEBUG") != nullptr;
     ep.dbg = dbg_on;
+    // A queued round gives up when its challenge does not arrive in time (the host died, or forgot the handle); a live host
+    // aborts the pipeline explicitly (sc_release), so the limit only has to outlast the slowest legitimate gap between two
+    // rounds — ranks of a sharded run wait for each other here (first-use initialisation, a descheduled peer): 60 s by
+    // default, CENO_HIP_PIPE_TIMEOUT_S to change it.
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
+        const double sec = e && atof(e) > 0 ? atof(e) : 60.0;
+        return (unsigned long long)(sec * 1e8);
+    }();
+    ep.poll_ticks = ticks;
     ep.wait_seq = (unsigned long long)i;                              // round 0 takes no challenge
     ep.next_seq = (i + 1 < sc->n) ? (unsigned long long)(i + 1) : 0;  // fetch challenge i for round i+1
     return ep;

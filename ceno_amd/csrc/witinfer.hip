@@ -50,9 +50,12 @@ __global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len) {
 }
 
 // 32x32 tile transpose of 64-bit words through LDS (+1 padding: conflict-free column reads)
-__global__ void __launch_bounds__(256) k_transpose(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t rows, size_t width) {
+// 1-D grid of tiles, column tiles fastest (consecutive workgroups read consecutive segments of the same rows): the grid's
+// y dimension is limited to 65535, which 2^21 rows / 32 exceeds (the reference's add_op_21 bench, benches/riscv_add.rs:74-150)
+__global__ void __launch_bounds__(256) k_transpose(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, size_t rows, size_t width,
+                                                   unsigned col_tiles) {
     __shared__ uint64_t tile[32][33];
-    const size_t col0 = (size_t)blockIdx.x * 32, row0 = (size_t)blockIdx.y * 32;
+    const size_t col0 = (size_t)(blockIdx.x % col_tiles) * 32, row0 = (size_t)(blockIdx.x / col_tiles) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         size_t row = row0 + r, col = col0 + tx;
@@ -133,18 +136,9 @@ int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mle
 int ceno_hip_transpose(ceno_hip_ctx* ctx, const uint64_t* dev_row_major, size_t rows, size_t width, uint64_t* dev_col_major, ceno_hip_stream s) {
     CHECK_ARG(ctx, dev_row_major && dev_col_major && rows > 0 && width > 0, "bad transpose arguments");
     hipStream_t st = ctx_stream(ctx, s);
-    dim3 grid((unsigned)((width + 31) / 32), (unsigned)((rows + 31) / 32));
-    CHECK_ARG(ctx, grid.y <= 65535u * 1024u, "too many rows");
-    // grid.y is limited to 65535 on some runtimes: split rows into slabs
-    const size_t slab_rows = (size_t)65535 * 32;
-    for (size_t r0 = 0; r0 < rows; r0 += slab_rows) {
-        size_t nr = rows - r0 < slab_rows ? rows - r0 : slab_rows;
-        dim3 g((unsigned)((width + 31) / 32), (unsigned)((nr + 31) / 32));
-        // a slab of the row-major input starts at r0*width; in the column-major output every column is offset by r0
-        // -> launch with adjusted base pointers and the FULL row count as column stride
-        hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, st, dev_row_major + r0 * width, dev_col_major + r0, nr == rows ? rows : rows, width);
-        if (nr != rows) return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "transpose: more than %zu rows", slab_rows);
-    }
+    const size_t col_tiles = (width + 31) / 32, row_tiles = (rows + 31) / 32;
+    CHECK_ARG(ctx, col_tiles <= 0xFFFFFFFFull && col_tiles * row_tiles <= 0x7FFFFFFFull, "transpose: %zu x %zu is too large", rows, width);
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)(col_tiles * row_tiles)), dim3(256), 0, st, dev_row_major, dev_col_major, rows, width, (unsigned)col_tiles);
     HIP_TRY(ctx, hipGetLastError());
     return 0;
 }

@@ -73,9 +73,10 @@ struct TreeStreams {
 };
 std::mutex g_ts_mu;
 std::vector<TreeStreams> g_ts_pool;
-bool tree_streams_acquire(TreeStreams* out) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+bool tree_streams_acquire(ceno_hip_ctx* ctx, TreeStreams* out) {
+    // keyed on the CONTEXT's device (a lane worker thread starts with device 0 current), which is made current first
+    if (ceno_hip_make_current(ctx) != 0) return false;
+    const int dev = ceno_hip_device(ctx);
     {
         std::lock_guard<std::mutex> g(g_ts_mu);
         for (size_t i = 0; i < g_ts_pool.size(); i++)
@@ -225,7 +226,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         // PRIORITY get queues of their own, so the two tree streams take the highest and the lowest level and leave the
         // caller's (normal) stream alone.
         TreeStreams ts;
-        if (!tree_streams_acquire(&ts)) return fail(CENO_HIP_ERR_HIP, "hipStreamCreateWithPriority failed");
+        if (!tree_streams_acquire(ctx, &ts)) return fail(CENO_HIP_ERR_HIP, "hipStreamCreateWithPriority failed");
         ts_device = ts.device;
         for (int i = 0; i < 2; i++) {
             sx[i] = (ceno_hip_stream)ts.s[i];

@@ -38,6 +38,8 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
     }
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     auto worker = [&](int lane) {
+        // a fresh thread starts with device 0 current; allocations, stream creation and launches follow the current device
+        (void)ceno_hip_make_current(ctx);
         if (dbg) {
             cpu_set_t set;
             CPU_ZERO(&set);

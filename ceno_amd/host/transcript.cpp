@@ -64,6 +64,10 @@ extern "C" ceno_transcript* ceno_transcript_stub_new(uint64_t seed) {
 // by analogy with the 4-byte packing the in-tree BabyBear restatement uses
 // (ceno_recursion_v2/src/utils.rs:44-67).
 // ------------------------------------------------------------------------------------------------
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../csrc/poseidon2.cuh"
@@ -116,9 +120,51 @@ void dx_destroy(void* self) { delete (Duplex*)self; }
 
 }  // namespace
 
+// process-wide parameter table of the host challenger (mirrors ceno_hip_poseidon2_set_constants on the device side)
+namespace {
+std::mutex g_params_mu;
+p2::Params g_params;
+bool g_params_set = false, g_params_pinned = false;
+const p2::Params& host_params(bool warn) {
+    std::lock_guard<std::mutex> g(g_params_mu);
+    if (!g_params_set) {
+        p2::default_params(g_params);
+        g_params_set = true;
+    }
+    static bool warned = false;
+    if (warn && !g_params_pinned && !warned && !getenv("CENO_HIP_QUIET_PLACEHOLDER")) {
+        warned = true;
+        fprintf(stderr, "[ceno_prover] WARNING: Poseidon2 transcript runs on placeholder round constants - challenges are NOT those of the "
+                        "reference's BasicTranscript (PARITY UNPINNED); load the real table with ceno_transcript_poseidon2_set_constants\n");
+    }
+    return g_params;
+}
+}  // namespace
+
+extern "C" int ceno_transcript_poseidon2_set_constants(const uint64_t* external_rc, const uint64_t* internal_rc, const uint64_t* internal_diag) {
+    p2::Params p;
+    p2::default_params(p);
+    if (external_rc) memcpy(p.ext_rc, external_rc, sizeof(p.ext_rc));
+    if (internal_rc) memcpy(p.int_rc, internal_rc, sizeof(p.int_rc));
+    if (internal_diag) memcpy(p.int_diag, internal_diag, sizeof(p.int_diag));
+    for (size_t i = 0; i < sizeof(p) / 8; i++)
+        if (reinterpret_cast<const uint64_t*>(&p)[i] >= gl::P) return CENO_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> g(g_params_mu);
+    g_params = p;
+    g_params_set = true;
+    g_params_pinned = external_rc && internal_rc && internal_diag;
+    return 0;
+}
+extern "C" int ceno_transcript_poseidon2_is_pinned(void) {
+    std::lock_guard<std::mutex> g(g_params_mu);
+    return g_params_pinned ? 1 : 0;
+}
+
 extern "C" ceno_transcript* ceno_transcript_poseidon2_new(const uint8_t* label, size_t n) {
+    static const bool strict = [] { const char* e = getenv("CENO_HIP_REQUIRE_PINNED_POSEIDON2"); return e && atoi(e) != 0; }();
+    if (strict && !ceno_transcript_poseidon2_is_pinned()) return nullptr;  // production callers: no placeholder challenges
     auto* d = new Duplex();
-    p2::default_params(d->params);
+    d->params = host_params(true);
     auto* t = new ceno_transcript();
     t->self = d;
     t->append_label = dx_label;
@@ -131,7 +177,5 @@ extern "C" ceno_transcript* ceno_transcript_poseidon2_new(const uint8_t* label, 
 
 // host permutation for tests of the shared poseidon2.cuh source
 extern "C" void ceno_prover_test_poseidon2_permute(uint64_t* state8) {
-    p2::Params p;
-    p2::default_params(p);
-    p2::permute(state8, p);
+    p2::permute(state8, host_params(false));
 }

@@ -58,6 +58,10 @@ int ceno_hip_init(int device, size_t pool_bytes /* 0 = unlimited */, ceno_hip_ct
 void ceno_hip_destroy(ceno_hip_ctx* ctx);
 const char* ceno_hip_last_error(ceno_hip_ctx* ctx);   /* ctx may be NULL: last init error */
 const char* ceno_hip_version(void);
+/* make the context's device current for the calling thread (ensure_context, gkr_iop/src/gpu/mod.rs:91-92).  Every entry
+ * point that takes a stream does this itself; worker threads that call the HIP runtime directly call it once. */
+int ceno_hip_make_current(ceno_hip_ctx* ctx);
+int ceno_hip_device(const ceno_hip_ctx* ctx);
 int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out);
 /* stream for proving lane `lane` (concurrent chip proving, ceno_zkvm/src/scheme/scheduler.rs:73-85): consecutive lanes
  * get different stream priorities so that they land on different hardware queues and really overlap */
@@ -189,7 +193,7 @@ size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const
 int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t** device_ptr, int* is_ext, int* num_vars);
 /* Opt in (before round 0) to pipelined rounds: all round kernels are enqueued at round 0 and pick their
  * challenges up from a pinned-memory mailbox, which removes the launch latency from every round.  The
- * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after ~4 s without
+ * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after CENO_HIP_PIPE_TIMEOUT_S (60 s) without
  * its challenge and the next call then fails with CENO_HIP_ERR_HIP).  Only taken for plans the library can
  * pipeline (one dense product over tables of max_num_vars variables); otherwise a no-op. */
 int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on);
@@ -239,9 +243,15 @@ int ceno_hip_ntt_batch(ceno_hip_ctx* ctx, uint64_t* dev_cols, int log_n, int n_c
 int ceno_hip_rs_encode(ceno_hip_ctx* ctx, const uint64_t* dev_cols, int log_n, int n_cols, int log_blowup, uint64_t* dev_codewords, ceno_hip_stream s);
 /* row-major (rows x width) -> column-major (matrix_transpose, ceno_zkvm/src/scheme/gpu/mod.rs:84,963-968) */
 int ceno_hip_transpose(ceno_hip_ctx* ctx, const uint64_t* dev_row_major, size_t rows, size_t width, uint64_t* dev_col_major, ceno_hip_stream s);
-/* Poseidon2 (width 8, rate 4, x^7) parameter table; NULL restores the built-in placeholder constants */
+/* Poseidon2 (width 8, rate 4, x^7) parameter table; NULL restores the built-in placeholder constants.
+ * NON-INTEROPERABLE UNTIL PINNED: the built-in round constants are placeholders (the reference's live in an EXT crate), so
+ * every root / proof-of-work / opening computed before a complete table (all three arrays) has been supplied is
+ * self-consistent only.  First use of the placeholders prints a warning on stderr; with
+ * CENO_HIP_REQUIRE_PINNED_POSEIDON2=1 in the environment the commit / open entry points fail with CENO_HIP_ERR_STATE instead.
+ * tools/goldens/ dumps the table (and known-answer vectors) from the reference where cargo is available. */
 int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external_rc /* 8 rounds x 8 */, const uint64_t* internal_rc /* 22 */,
                                      const uint64_t* internal_diag /* 8 */);
+int ceno_hip_poseidon2_is_pinned(const ceno_hip_ctx* ctx);   /* 1 once a complete table has been supplied */
 int ceno_hip_poseidon2_permute(ceno_hip_ctx* ctx, uint64_t* dev_states /* n x 8 */, size_t n, ceno_hip_stream s);
 /* leaves = sponge hash of each row of a column-major matrix (rows = 2^log_rows); tree = 2-to-1 compression */
 int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int log_rows, int width, ceno_hip_stream s, ceno_hip_merkle** out);

@@ -37,6 +37,13 @@ ceno_transcript* ceno_transcript_stub_new(uint64_t seed);
 /* Poseidon2-Goldilocks duplex challenger (width 8, rate 4) run on the host.  PARITY UNPINNED:
  * constants / label encoding of the reference's BasicTranscript live in EXT crates. */
 ceno_transcript* ceno_transcript_poseidon2_new(const uint8_t* label, size_t n);
+/* parameter table of the host challenger (process-wide; same layout as ceno_hip_poseidon2_set_constants, NULL = placeholder part).
+ * NON-INTEROPERABLE UNTIL PINNED: with the built-in placeholder constants the challenges are not the reference's; first use
+ * warns on stderr, and with CENO_HIP_REQUIRE_PINNED_POSEIDON2=1 ceno_transcript_poseidon2_new returns NULL until a complete
+ * table has been supplied. */
+int ceno_transcript_poseidon2_set_constants(const uint64_t* external_rc /* 8 x 8 */, const uint64_t* internal_rc /* 22 */,
+                                            const uint64_t* internal_diag /* 8 */);
+int ceno_transcript_poseidon2_is_pinned(void);
 void ceno_transcript_free(ceno_transcript* t);
 /* convenience for bindings that cannot call through the function-pointer table */
 void ceno_transcript_append_label(ceno_transcript* t, const uint8_t* bytes, size_t n);

@@ -58,6 +58,22 @@ def test_transpose(dev, rows, width):
     assert np.array_equal(_to_np(dst).reshape(width, rows), m.T)
 
 
+@pytest.mark.parametrize("rows,width", [(1 << 21, 22), ((1 << 21) + 37, 3), (1 << 22, 40)])
+def test_transpose_large_row_counts(dev, rows, width):
+    """>= 2^21 rows (the reference's add_op_21 bench, benches/riscv_add.rs:74-150): more than 65535 row tiles, which the
+    grid's y dimension cannot hold.  Checked on the device against torch's own transpose of the same words."""
+    import torch
+
+    from ceno_amd import api
+
+    g = torch.Generator(device="cuda:0").manual_seed(rows + width)
+    src = torch.randint(0, 1 << 62, (rows * width,), dtype=torch.int64, device="cuda:0", generator=g)
+    dst = torch.full((rows * width,), -1, dtype=torch.int64, device="cuda:0")
+    api.transpose(dev, src.data_ptr(), rows, width, dst.data_ptr())
+    dev.sync()
+    assert torch.equal(dst.view(width, rows), src.view(rows, width).t())
+
+
 @pytest.mark.parametrize("log_n", [1, 2, 5, 9, 11, 12, 13, 16, 17])
 def test_ntt_forward_inverse_vs_dft(dev, log_n):
     from ceno_amd import api

@@ -2,7 +2,7 @@
 # SQ counters of the Merkle leaf hash (is it VALU-issue bound?): one --pmc pass, no trace domains
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 o=gpurun_out/pmc_merkle; rm -rf $o
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $o -- python3 tools/exp_merkle.py > $o.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $o -- python3 tools/bench_merkle.py > $o.log 2>&1
 f=$(ls $o/*/*counter_collection.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, json, collections
