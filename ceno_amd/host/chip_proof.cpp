@@ -1,0 +1,223 @@
+// Per-chip proof flow of the zkVM prover, written against the device C ABI.
+//
+//   ceno_prover_build_tower_witness   CpuProver::build_tower_witness        ceno_zkvm/src/scheme/cpu/mod.rs:608-757
+//                                     (GPU arm: build_tower_witness_gpu      ceno_zkvm/src/scheme/gpu/mod.rs:2136-2407)
+//   ceno_prover_create_chip_proof     ZKVMProver::create_chip_proof          ceno_zkvm/src/scheme/prover.rs:717-833
+//                                     = build_main_witness (tower stage)     ceno_zkvm/src/scheme/utils.rs:667-771
+//                                       -> prove_tower_relation              ceno_zkvm/src/scheme/cpu/mod.rs:765-797
+//                                       -> prove_rotation (keccak-style)     gkr_iop/src/gkr/layer/cpu/mod.rs:249-389
+//                                     harness shape: ceno_zkvm/benches/riscv_add.rs:86-141
+// The ECC quark step (prover.rs:766, shard-RAM chips only) is out of scope: BabyBear-only in the reference.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ceno_prover.h"
+
+int prover_set_error(int code, const char* msg);  // prover.cpp
+
+namespace {
+
+int ceil_log2(size_t x) {
+    int l = 0;
+    while (((size_t)1 << l) < x) l++;
+    return l;
+}
+size_t next_pow2(size_t x) { return (size_t)1 << ceil_log2(x ? x : 1); }
+
+int fail_ctx(ceno_hip_ctx* ctx, int rc) { return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+
+}  // namespace
+
+extern "C" {
+
+void ceno_tower_witness_free(ceno_hip_ctx* ctx, ceno_tower_witness* w) {
+    if (!w) return;
+    for (int i = 0; i < 2; i++) {
+        if (w->prod[i]) ceno_hip_tower_free(ctx, w->prod[i]);
+        w->prod[i] = nullptr;
+    }
+    if (w->logup[0]) ceno_hip_tower_free(ctx, w->logup[0]);
+    w->logup[0] = nullptr;
+    w->n_prod = w->n_logup = 0;
+}
+
+int ceno_prover_build_tower_witness(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, int num_reads, int num_writes, int num_lk_tables, int num_lk,
+                                    int log2_num_instances, int rotation_vars, const uint64_t* challenges4, ceno_hip_stream s,
+                                    ceno_tower_witness* out) {
+    if (!ctx || !out || !challenges4 || num_reads < 0 || num_writes < 0 || num_lk_tables < 0 || num_lk < 0)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "build_tower_witness: bad arguments");
+    memset(out, 0, sizeof(*out));
+    // record slicing (cpu/mod.rs:626-644): [reads | writes | lk numerators (table circuits only) | lk denominators]
+    const int n_lk_num = num_lk_tables;
+    const int n_lk_den = num_lk_tables > 0 ? num_lk_tables : num_lk;
+    const int total = num_reads + num_writes + n_lk_num + n_lk_den;
+    if (total > 0 && !records) return prover_set_error(CENO_HIP_ERR_INVALID, "build_tower_witness: records is NULL");
+    const int active_row_vars = log2_num_instances + rotation_vars;          // cpu/mod.rs:645
+    const size_t active_rows = (size_t)1 << active_row_vars;                 // cpu/mod.rs:646
+    for (int i = 0; i < total; i++)
+        if (!records[i] || ceno_hip_mle_num_vars(records[i]) != active_row_vars)
+            return prover_set_error(CENO_HIP_ERR_INVALID, "build_tower_witness: every record needs log2_num_instances + rotation_vars variables");
+    auto group_num_vars = [&](int num_ops) { return active_row_vars + ceil_log2(next_pow2((size_t)num_ops)); };  // cpu/mod.rs:647-648
+    ceno_hip_mle* const* r_set = records;
+    ceno_hip_mle* const* w_set = records + num_reads;
+    ceno_hip_mle* const* lk_n = records + num_reads + num_writes;
+    ceno_hip_mle* const* lk_d = lk_n + n_lk_num;
+    const uint64_t one[2] = {1, 0};
+    const uint64_t* alpha = challenges4;  // challenges[0]: default of the lookup limbs (cpu/mod.rs:658-661)
+    int rc = 0;
+    // interleaving_mles_to_mles(.., active_rows, NUM_FANIN, default) + infer_tower_product_witness / _logup_witness
+    // (cpu/mod.rs:652-677): one device call per tower
+    if (num_reads > 0) {
+        rc = ceno_hip_tower_build_prod(ctx, r_set, num_reads, active_rows, one, s, &out->prod[out->n_prod]);
+        if (!rc && ceno_hip_tower_num_vars(out->prod[out->n_prod]) != group_num_vars(num_reads)) rc = CENO_HIP_ERR_STATE;
+        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->prod[out->n_prod], out->r_out_evals, s);
+        if (!rc) { out->has_r = 1; out->n_prod++; }
+    }
+    if (!rc && num_writes > 0) {
+        rc = ceno_hip_tower_build_prod(ctx, w_set, num_writes, active_rows, one, s, &out->prod[out->n_prod]);
+        if (!rc && ceno_hip_tower_num_vars(out->prod[out->n_prod]) != group_num_vars(num_writes)) rc = CENO_HIP_ERR_STATE;
+        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->prod[out->n_prod], out->w_out_evals, s);
+        if (!rc) { out->has_w = 1; out->n_prod++; }
+    }
+    if (!rc && n_lk_den > 0) {
+        rc = ceno_hip_tower_build_logup(ctx, n_lk_num > 0 ? lk_n : nullptr, lk_d, n_lk_den, active_rows, alpha, s, &out->logup[0]);
+        if (!rc && ceno_hip_tower_num_vars(out->logup[0]) != group_num_vars(n_lk_den)) rc = CENO_HIP_ERR_STATE;
+        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->logup[0], out->lk_out_evals, s);
+        if (!rc) { out->has_lk = 1; out->n_logup = 1; }
+    }
+    if (rc) {
+        std::string msg = rc == CENO_HIP_ERR_STATE ? "build_tower_witness: tower height differs from group_num_vars" : ceno_hip_last_error(ctx);
+        ceno_tower_witness_free(ctx, out);
+        return prover_set_error(rc, msg.c_str());
+    }
+    return 0;
+}
+
+void ceno_chip_proof_free(ceno_chip_proof* p) {
+    if (!p) return;
+    free(p->tower.msgs);
+    free(p->tower.prod_evals);
+    free(p->tower.logup_evals);
+    free(p->tower.point);
+    free(p->rt_main);
+    free(p->rotation_msgs);
+    free(p->rotation_evals);
+    free(p->rotation_points);
+    memset(p, 0, sizeof(*p));
+}
+
+int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                                  ceno_hip_stream s, ceno_chip_proof* out) {
+    if (!ctx || !task || !challenges4 || !tr || !out) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: NULL argument");
+    memset(out, 0, sizeof(*out));
+    const int n_mles = task->n_witin + task->n_fixed + task->n_structural;
+    const int num_var_with_rotation = task->log2_num_instances + task->rotation_vars;   // prover.rs:728-729
+    const int n_lk_num = task->num_lk_tables, n_lk_den = task->num_lk_tables > 0 ? task->num_lk_tables : task->num_lk;
+    const int n_records = task->num_reads + task->num_writes + n_lk_num + n_lk_den;
+    if (n_records < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a circuit needs at least one read / write / lookup");  // utils.rs:701-710
+    if (n_mles < 1 || !task->mles || !task->record_out_term_offsets || !task->record_term_offsets)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: bad task");
+    for (int j = 0; j < n_mles; j++)
+        if (task->mles[j] && ceno_hip_mle_num_vars(task->mles[j]) != num_var_with_rotation)                      // utils.rs:713-723
+            return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: witness sizes differ from log2_num_instances + rotation_vars");
+    out->num_instances = task->num_instances;
+    // ---- build_main_witness, tower stage (prover.rs:735-745): only the tower-facing records are materialised ----
+    std::vector<ceno_hip_mle*> records(n_records, nullptr);
+    auto free_records = [&]() {
+        for (auto*& m : records) {
+            if (m) ceno_hip_mle_free(ctx, m);
+            m = nullptr;
+        }
+    };
+    // structural witnesses may be absent at this stage ("they are `eq`, and will be filled later", utils.rs:690-695): the
+    // record expressions never read them, so the inference runs on the tables that exist
+    std::vector<ceno_hip_mle*> present;
+    std::vector<uint32_t> remap(n_mles, UINT32_MAX), ridx;
+    for (int j = 0; j < n_mles; j++)
+        if (task->mles[j]) {
+            remap[j] = (uint32_t)present.size();
+            present.push_back(task->mles[j]);
+        }
+    const uint32_t n_factors = task->record_term_offsets[task->n_record_terms];
+    ridx.reserve(n_factors);
+    for (uint32_t k = 0; k < n_factors; k++) {
+        const uint32_t j = task->record_term_mle_idx[k];
+        if ((int)j >= n_mles || remap[j] == UINT32_MAX) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a record expression reads an absent table");
+        ridx.push_back(remap[j]);
+    }
+    int rc = ceno_hip_wit_infer(ctx, present.data(), (int)present.size(), task->record_coeffs, task->record_term_offsets, ridx.data(),
+                                task->n_record_terms, task->record_out_term_offsets, n_records, num_var_with_rotation, s, records.data());
+    if (rc) return fail_ctx(ctx, rc);
+    // ---- prove_tower_relation (prover.rs:747-755 -> cpu/mod.rs:765-797) ----
+    ceno_tower_witness tw;
+    rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk,
+                                         task->log2_num_instances, task->rotation_vars, challenges4, s, &tw);
+    free_records();  // prover.rs:756 drop(records): the towers own their interleaved copies
+    if (rc) return rc;
+    int max_nv = 0;
+    for (int i = 0; i < tw.n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.prod[i]));
+    for (int i = 0; i < tw.n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.logup[i]));
+    const int R = max_nv - 1;
+    out->tower_num_vars = max_nv;
+    out->n_prod = tw.n_prod;
+    out->n_logup = tw.n_logup;
+    out->tower.msgs = (uint64_t*)calloc(std::max<size_t>(1, ceno_tower_msgs_words(max_nv)), 8);
+    out->tower.prod_evals = (uint64_t*)calloc((size_t)std::max(1, tw.n_prod) * std::max(1, R) * 4, 8);
+    out->tower.logup_evals = (uint64_t*)calloc((size_t)std::max(1, tw.n_logup) * std::max(1, R) * 8, 8);
+    out->tower.point = (uint64_t*)calloc((size_t)2 * (max_nv + 1), 8);
+    out->rt_main = (uint64_t*)calloc((size_t)2 * std::max(1, num_var_with_rotation), 8);
+    if (!out->tower.msgs || !out->tower.prod_evals || !out->tower.logup_evals || !out->tower.point || !out->rt_main) {
+        ceno_tower_witness_free(ctx, &tw);
+        ceno_chip_proof_free(out);
+        return prover_set_error(CENO_HIP_ERR_OOM, "create_chip_proof: out of host memory");
+    }
+    // out-evals were computed by build_tower_witness; prove_tower_relation binds them into the transcript (r, w, lk) and
+    // runs the tower prover
+    std::vector<uint64_t> out_evals((size_t)2 * (2 * tw.n_prod + 4 * tw.n_logup));
+    rc = ceno_prover_prove_tower_relation(ctx, tw.prod, tw.n_prod, tw.logup, tw.n_logup, tr, s, out_evals.data(), &out->tower);
+    ceno_tower_witness_free(ctx, &tw);
+    if (rc) {
+        ceno_chip_proof_free(out);
+        return rc;
+    }
+    out->n_r_out = tw.has_r ? 2 : 0;
+    out->n_w_out = tw.has_w ? 2 : 0;
+    out->n_lk_out = tw.has_lk ? 4 : 0;
+    memcpy(out->r_out_evals, tw.r_out_evals, sizeof(out->r_out_evals));
+    memcpy(out->w_out_evals, tw.w_out_evals, sizeof(out->w_out_evals));
+    memcpy(out->lk_out_evals, tw.lk_out_evals, sizeof(out->lk_out_evals));
+    // rt_main = the LAST num_var_with_rotation coordinates of the tower point (prover.rs:758-764): the record selector
+    // occupies the low variables of the interleaved layout (utils.rs:402-462)
+    if (max_nv < num_var_with_rotation) {
+        ceno_chip_proof_free(out);
+        return prover_set_error(CENO_HIP_ERR_STATE, "tower challenge point is shorter than the main point");
+    }
+    out->num_var_with_rotation = num_var_with_rotation;
+    memcpy(out->rt_main, out->tower.point + (size_t)2 * (max_nv - num_var_with_rotation), (size_t)16 * num_var_with_rotation);
+    // ---- prove_rotation (prover.rs:771-776): keccak-style chips only ----
+    if (task->n_rotation_pairs > 0) {
+        const int n = num_var_with_rotation, np = task->n_rotation_pairs;
+        out->n_rotation_pairs = np;
+        out->rotation_msgs = (uint64_t*)calloc((size_t)n * 2 * 2, 8);
+        out->rotation_evals = (uint64_t*)calloc((size_t)3 * np * 2, 8);
+        out->rotation_points = (uint64_t*)calloc((size_t)3 * n * 2, 8);  // origin | left | right
+        if (!out->rotation_msgs || !out->rotation_evals || !out->rotation_points) {
+            ceno_chip_proof_free(out);
+            return prover_set_error(CENO_HIP_ERR_OOM, "create_chip_proof: out of host memory");
+        }
+        rc = ceno_prover_prove_rotation(ctx, task->mles, task->rotation_source_idx, task->rotation_target_idx, np, task->cyclic_subgroup_size,
+                                        task->cyclic_group_log2, out->rt_main, n, tr, s, out->rotation_msgs, out->rotation_evals,
+                                        out->rotation_points, out->rotation_points + (size_t)2 * n, out->rotation_points + (size_t)4 * n);
+        if (rc) {
+            ceno_chip_proof_free(out);
+            return rc;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

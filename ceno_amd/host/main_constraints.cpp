@@ -97,6 +97,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         }
         std::vector<E2> ch{E2{gc4[0], gc4[1]}, E2{gc4[2], gc4[3]}};
         for (int i = 0; i < J.n_exprs; i++) ch.push_back(alpha_pows[alpha_start + i]);
+        for (int i = 0; i < J.n_pi && J.pi; i++) ch.push_back(E2{J.pi[2 * i], J.pi[2 * i + 1]});  // Instance atoms (cpu/mod.rs:1241-1247,1297-1304)
         for (int t = 0; t < J.n_terms; t++) {
             E2 scalar = gl::e2_zero();
             for (uint32_t m = J.scalar_offsets[t]; m < J.scalar_offsets[t + 1]; m++) {

@@ -513,14 +513,15 @@ class MainJobC(C.Structure):
         ("sel_sparse_indices", C.POINTER(u32p)), ("sel_n_sparse", C.POINTER(C.c_int)), ("sel_sparse_num_vars", C.POINTER(C.c_int)),
         ("sel_points", C.POINTER(u64p)), ("n_exprs", C.c_int), ("max_degree", C.c_int), ("n_terms", C.c_int),
         ("term_offsets", u32p), ("term_mle_idx", u32p), ("scalar_offsets", u32p), ("mono_coeffs", u64p),
-        ("mono_chal_offsets", u32p), ("mono_chal_idx", u32p),
+        ("mono_chal_offsets", u32p), ("mono_chal_idx", u32p), ("n_pi", C.c_int), ("pi", u64p),
     ]
 
 
 def prove_batched_main_constraints(dev: Device, jobs: Sequence[dict], global_challenges, tr: Transcript, stream=None):
     """jobs: dicts with keys num_vars, mles (witness++fixed++structural, None allowed for replaced structural slots),
     n_witin, n_fixed, n_structural, selectors [(kind, offset, num_instances, structural_id, sparse_indices, sparse_num_vars, point)],
-    n_exprs, max_degree, terms [[mle ids]], scalars [[(coeff_ext, [challenge ids])...] per term].
+    n_exprs, max_degree, terms [[mle ids]], scalars [[(coeff_ext, [challenge ids])...] per term], optional pi [(c0, c1)...]
+    (public-instance values: challenge ids >= 2 + n_exprs select them).
     Returns (claimed_sum, msgs (n,d,2), global_rt (n,2), evals (total_mles,2))."""
     L = plib()
     L.ceno_prover_prove_batched_main_constraints.restype = C.c_int
@@ -565,6 +566,9 @@ def prove_batched_main_constraints(dev: Device, jobs: Sequence[dict], global_cha
         J.n_exprs, J.max_degree, J.n_terms = j["n_exprs"], j["max_degree"], len(j["terms"])
         J.term_offsets, J.term_mle_idx, J.scalar_offsets = _p32(toff), _p32(tidx), _p32(soff)
         J.mono_coeffs, J.mono_chal_offsets, J.mono_chal_idx = _p(mono_c), _p32(mono_off), _p32(mono_idx)
+        pi = np.ascontiguousarray(j.get("pi", []), dtype=np.uint64).reshape(-1, 2)
+        J.n_pi, J.pi = pi.shape[0], (_p(pi) if pi.shape[0] else None)
+        keep.append(pi)
         keep += [mh, kinds, offs, nins, sids, sp_arrays, spp, nsp, snv, pts, ptp, toff, tidx, soff, mono_c, mono_off, mono_idx]
     gc = np.array([[int(global_challenges[0][0]), int(global_challenges[0][1])],
                    [int(global_challenges[1][0]), int(global_challenges[1][1])]], dtype=np.uint64)
@@ -576,6 +580,118 @@ def prove_batched_main_constraints(dev: Device, jobs: Sequence[dict], global_cha
     _check(L.ceno_prover_prove_batched_main_constraints(dev.h, arr, len(jobs), _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
                                                         _p(evals), C.byref(nv_o), C.byref(d_o)))
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
+
+
+class TowerWitnessC(C.Structure):
+    _fields_ = [("prod", C.c_void_p * 2), ("n_prod", C.c_int), ("logup", C.c_void_p * 1), ("n_logup", C.c_int),
+                ("has_r", C.c_int), ("has_w", C.c_int), ("has_lk", C.c_int),
+                ("r_out_evals", C.c_uint64 * 4), ("w_out_evals", C.c_uint64 * 4), ("lk_out_evals", C.c_uint64 * 8)]
+
+
+def build_tower_witness(dev: Device, records: Sequence[Mle], num_reads: int, num_writes: int, num_lk_tables: int, num_lk: int,
+                        log2_num_instances: int, rotation_vars: int, challenges, stream=None):
+    """CpuProver::build_tower_witness (scheme/cpu/mod.rs:608-757) -> (out_evals dict, prod towers, logup towers)"""
+    L = plib()
+    L.ceno_prover_build_tower_witness.restype = C.c_int
+    L.ceno_prover_build_tower_witness.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  u64p, C.c_void_p, C.POINTER(TowerWitnessC)]
+    arr = (C.c_void_p * max(1, len(records)))(*[m.h for m in records])
+    ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
+    tw = TowerWitnessC()
+    _check(L.ceno_prover_build_tower_witness(dev.h, arr, num_reads, num_writes, num_lk_tables, num_lk, log2_num_instances, rotation_vars,
+                                             _p(ch), stream, C.byref(tw)))
+    evals = {"r": np.array(tw.r_out_evals, dtype=np.uint64).reshape(2, 2) if tw.has_r else None,
+             "w": np.array(tw.w_out_evals, dtype=np.uint64).reshape(2, 2) if tw.has_w else None,
+             "lk": np.array(tw.lk_out_evals, dtype=np.uint64).reshape(4, 2) if tw.has_lk else None}
+    prod = [Tower(dev, C.c_void_p(tw.prod[i])) for i in range(tw.n_prod)]
+    logup = [Tower(dev, C.c_void_p(tw.logup[i])) for i in range(tw.n_logup)]
+    return evals, prod, logup
+
+
+class ChipTaskC(C.Structure):
+    _fields_ = [("circuit_idx", C.c_int), ("num_instances", C.c_size_t), ("log2_num_instances", C.c_int), ("rotation_vars", C.c_int),
+                ("n_witin", C.c_int), ("n_fixed", C.c_int), ("n_structural", C.c_int), ("mles", C.POINTER(C.c_void_p)),
+                ("num_reads", C.c_int), ("num_writes", C.c_int), ("num_lk_tables", C.c_int), ("num_lk", C.c_int),
+                ("n_record_terms", C.c_int), ("record_coeffs", u64p), ("record_term_offsets", u32p), ("record_term_mle_idx", u32p),
+                ("record_out_term_offsets", u32p), ("n_rotation_pairs", C.c_int), ("rotation_source_idx", C.POINTER(C.c_int)),
+                ("rotation_target_idx", C.POINTER(C.c_int)), ("cyclic_subgroup_size", C.c_int), ("cyclic_group_log2", C.c_int)]
+
+
+class ChipProofC(C.Structure):
+    _fields_ = [("num_instances", C.c_size_t), ("n_r_out", C.c_int), ("n_w_out", C.c_int), ("n_lk_out", C.c_int),
+                ("r_out_evals", C.c_uint64 * 4), ("w_out_evals", C.c_uint64 * 4), ("lk_out_evals", C.c_uint64 * 8),
+                ("tower_num_vars", C.c_int), ("n_prod", C.c_int), ("n_logup", C.c_int), ("tower", TowerProofC),
+                ("num_var_with_rotation", C.c_int), ("rt_main", u64p), ("n_rotation_pairs", C.c_int), ("rotation_msgs", u64p),
+                ("rotation_evals", u64p), ("rotation_points", u64p)]
+
+
+class ChipProof:
+    """ZKVMChipProof (ceno_zkvm/src/scheme.rs:59-76) copied out of the C structure"""
+
+    def __init__(self, c: ChipProofC):
+        def arr(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+
+        nv, R = c.tower_num_vars, c.tower_num_vars - 1
+        self.num_instances = c.num_instances
+        self.r_out_evals = np.array(c.r_out_evals, dtype=np.uint64).reshape(2, 2)[: c.n_r_out]
+        self.w_out_evals = np.array(c.w_out_evals, dtype=np.uint64).reshape(2, 2)[: c.n_w_out]
+        self.lk_out_evals = np.array(c.lk_out_evals, dtype=np.uint64).reshape(4, 2)[: c.n_lk_out]
+        self.tower_num_vars, self.n_prod, self.n_logup = nv, c.n_prod, c.n_logup
+        self.tower_msgs = arr(c.tower.msgs, int(plib().ceno_tower_msgs_words(nv)))
+        self.tower_prod_evals = arr(c.tower.prod_evals, c.n_prod * R * 4).reshape(c.n_prod, R, 2, 2)
+        self.tower_logup_evals = arr(c.tower.logup_evals, c.n_logup * R * 8).reshape(c.n_logup, R, 4, 2)
+        self.tower_point = arr(c.tower.point, 2 * nv).reshape(nv, 2)
+        n = c.num_var_with_rotation
+        self.rt_main = arr(c.rt_main, 2 * n).reshape(n, 2)
+        self.n_rotation_pairs = c.n_rotation_pairs
+        if c.n_rotation_pairs:
+            self.rotation_msgs = arr(c.rotation_msgs, n * 4).reshape(n, 2, 2)
+            self.rotation_evals = arr(c.rotation_evals, 6 * c.n_rotation_pairs).reshape(-1, 2)
+            self.rotation_points = arr(c.rotation_points, 6 * n).reshape(3, n, 2)
+
+    def tower_round_msgs(self, rnd: int) -> np.ndarray:
+        off = sum(r * 6 for r in range(1, rnd))
+        return self.tower_msgs[off: off + rnd * 6].reshape(rnd, 3, 2)
+
+
+def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, stream=None) -> ChipProof:
+    """ZKVMProver::create_chip_proof (scheme/prover.rs:717-833).  task: mles (witness ++ fixed ++ structural), n_witin, n_fixed,
+    n_structural, num_instances, log2_num_instances, rotation_vars (0), num_reads, num_writes, num_lk_tables, num_lk,
+    record_coeffs (T,2), record_terms [[mle ids]], record_out_terms [[term ids]] (consecutive), optional rotation
+    dict(pairs, cyclic_subgroup_size, cyclic_group_log2)."""
+    L = plib()
+    L.ceno_prover_create_chip_proof.restype = C.c_int
+    L.ceno_prover_create_chip_proof.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), u64p, C.c_void_p, C.c_void_p, C.POINTER(ChipProofC)]
+    L.ceno_chip_proof_free.restype = None
+    L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
+    T = ChipTaskC()
+    mh = (C.c_void_p * len(task["mles"]))(*[(m.h if m is not None else None) for m in task["mles"]])
+    coeffs = np.ascontiguousarray(task["record_coeffs"], dtype=np.uint64).reshape(-1, 2)
+    toff, tidx = _csr(task["record_terms"])
+    ooff = np.zeros(len(task["record_out_terms"]) + 1, dtype=np.uint32)
+    for o, ts in enumerate(task["record_out_terms"]):
+        assert list(ts) == list(range(int(ooff[o]), int(ooff[o]) + len(ts))), "record terms must be listed output by output"
+        ooff[o + 1] = ooff[o] + len(ts)
+    T.circuit_idx, T.num_instances = task.get("circuit_idx", 0), task["num_instances"]
+    T.log2_num_instances, T.rotation_vars = task["log2_num_instances"], task.get("rotation_vars", 0)
+    T.n_witin, T.n_fixed, T.n_structural, T.mles = task["n_witin"], task["n_fixed"], task["n_structural"], mh
+    T.num_reads, T.num_writes, T.num_lk_tables, T.num_lk = task["num_reads"], task["num_writes"], task["num_lk_tables"], task["num_lk"]
+    T.n_record_terms, T.record_coeffs, T.record_term_offsets, T.record_term_mle_idx = len(task["record_terms"]), _p(coeffs), _p32(toff), _p32(tidx)
+    T.record_out_term_offsets = _p32(ooff)
+    rot = task.get("rotation")
+    if rot:
+        src = (C.c_int * len(rot["pairs"]))(*[p[0] for p in rot["pairs"]])
+        tgt = (C.c_int * len(rot["pairs"]))(*[p[1] for p in rot["pairs"]])
+        T.n_rotation_pairs, T.rotation_source_idx, T.rotation_target_idx = len(rot["pairs"]), src, tgt
+        T.cyclic_subgroup_size, T.cyclic_group_log2 = rot["cyclic_subgroup_size"], rot["cyclic_group_log2"]
+    ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
+    out = ChipProofC()
+    _check(L.ceno_prover_create_chip_proof(dev.h, C.byref(T), _p(ch), tr.h, stream, C.byref(out)))
+    try:
+        return ChipProof(out)
+    finally:
+        L.ceno_chip_proof_free(C.byref(out))
 
 
 class PcsData:

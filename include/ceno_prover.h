@@ -96,6 +96,75 @@ int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
                                      int n_logup, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_evals,
                                      ceno_tower_proof* out);
 
+/* ---- per-chip proof flow (a9 + create_chip_proof) ----
+ * build_tower_witness (ceno_zkvm/src/scheme/cpu/mod.rs:608-757; GPU arm scheme/gpu/mod.rs:2136-2407): slice the record MLEs
+ * [reads | writes | lookup numerators | lookup denominators] (numerators exist for table circuits only: num_lk_tables =
+ * cs.lk_table_expressions.len(), then the denominators are the table expressions too; otherwise num_lk = cs.lk_expressions.len()
+ * denominators and all-one numerators), interleave every group over ALL 2^(log2_num_instances + rotation_vars) rows with
+ * default ONE (read / write sets) or challenges[0] (lookup limbs), and build the product / LogUp towers of
+ * group_num_vars = row_vars + ceil_log2(next_pow2(group size)) layers.  Out-evals = layer 0 of every tower. */
+typedef struct ceno_tower_witness {
+    ceno_hip_tower* prod[2];       /* read set, write set (an absent set is skipped) */
+    int n_prod;
+    ceno_hip_tower* logup[1];
+    int n_logup;
+    int has_r, has_w, has_lk;
+    uint64_t r_out_evals[4];       /* 2 ext */
+    uint64_t w_out_evals[4];       /* 2 ext */
+    uint64_t lk_out_evals[8];      /* 4 ext: p1, p2, q1, q2 */
+} ceno_tower_witness;
+int ceno_prover_build_tower_witness(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, int num_reads, int num_writes, int num_lk_tables,
+                                    int num_lk, int log2_num_instances, int rotation_vars, const uint64_t* challenges4, ceno_hip_stream s,
+                                    ceno_tower_witness* out);
+void ceno_tower_witness_free(ceno_hip_ctx* ctx, ceno_tower_witness* w);
+
+/* ZKVMProver::create_chip_proof (ceno_zkvm/src/scheme/prover.rs:717-833; harness benches/riscv_add.rs:86-141):
+ * build_main_witness at the tower stage (record MLEs by wit_infer over witness ++ fixed ++ structural, scheme/utils.rs:667-771),
+ * prove_tower_relation (out-evals into the transcript, tower proof), rt_main = the last num_var_with_rotation coordinates of
+ * the tower point, prove_rotation for chips with a rotation argument.  The main constraints are NOT proved here: the caller
+ * collects one ceno_main_job per chip with selector points = rt_main and calls ceno_prover_prove_batched_main_constraints
+ * (prover.rs:818-826, 577-586).  ECC quark (shard-RAM chips) is out of scope. */
+typedef struct ceno_chip_task {
+    int circuit_idx;
+    size_t num_instances;          /* input.num_instances */
+    int log2_num_instances;        /* of the padded instance count */
+    int rotation_vars;             /* 0 without rotation */
+    int n_witin, n_fixed, n_structural;
+    ceno_hip_mle* const* mles;     /* witness ++ fixed ++ structural; every table has log2_num_instances + rotation_vars variables */
+    /* record expressions in monomial form, coefficients already evaluated at the two global challenges
+     * (wit_infer_by_monomial_expr, gkr_iop/src/cpu/mod.rs:119-176); outputs in the order reads, writes, lk numerators, lk denominators */
+    int num_reads, num_writes, num_lk_tables, num_lk;
+    int n_record_terms;
+    const uint64_t* record_coeffs;            /* 2 words per term */
+    const uint32_t* record_term_offsets;      /* n_record_terms + 1 */
+    const uint32_t* record_term_mle_idx;
+    const uint32_t* record_out_term_offsets;  /* n_records + 1 */
+    /* rotation argument (n_rotation_pairs = 0: none); indices into `mles` */
+    int n_rotation_pairs;
+    const int* rotation_source_idx;
+    const int* rotation_target_idx;
+    int cyclic_subgroup_size;
+    int cyclic_group_log2;
+} ceno_chip_task;
+/* ZKVMChipProof (ceno_zkvm/src/scheme.rs:59-76) flattened; buffers are allocated by create_chip_proof, released by
+ * ceno_chip_proof_free.  tower: layout of ceno_tower_proof for max_num_vars = tower_num_vars. */
+typedef struct ceno_chip_proof {
+    size_t num_instances;
+    int n_r_out, n_w_out, n_lk_out;           /* 0 or 2, 0 or 2, 0 or 4 */
+    uint64_t r_out_evals[4], w_out_evals[4], lk_out_evals[8];
+    int tower_num_vars, n_prod, n_logup;
+    ceno_tower_proof tower;
+    int num_var_with_rotation;
+    uint64_t* rt_main;                        /* num_var_with_rotation ext: MainConstraintJob.rt_tower */
+    int n_rotation_pairs;
+    uint64_t* rotation_msgs;                  /* num_var_with_rotation x 2 ext */
+    uint64_t* rotation_evals;                 /* 3 x n_rotation_pairs ext: [left, right, target] per pair */
+    uint64_t* rotation_points;                /* origin | left | right, num_var_with_rotation ext each */
+} ceno_chip_proof;
+int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                                  ceno_hip_stream s, ceno_chip_proof* out);
+void ceno_chip_proof_free(ceno_chip_proof* p);
+
 /* prove_rotation (gkr_iop/src/gkr/layer/cpu/mod.rs:249-389; GPU arm layer/gpu/mod.rs:305-462): for pairs
  * (source_j, target_j) of base-field witness tables prove  0 = sum_b sel(b) sum_j alpha^j (rotated(source_j)(b) - target_j(b))
  * with sel = eq(., rt) on the cyclic subgroup.  Transcript: get_challenge_pows(n_pairs), the degree-2 sumcheck,
@@ -138,6 +207,10 @@ typedef struct ceno_main_job {
     const uint64_t* mono_coeffs;           /* 2 words per monomial */
     const uint32_t* mono_chal_offsets;     /* n_monomials + 1 */
     const uint32_t* mono_chal_idx;         /* ids into the chip's main-sumcheck challenge list */
+    /* public-instance values the scalar expressions may reference (eval_by_expr_with_instance(.., &chip.pi, ..),
+     * scheme/cpu/mod.rs:1241-1247,1297-1304): atoms with id >= 2 + n_exprs select pi[id - 2 - n_exprs] */
+    int n_pi;
+    const uint64_t* pi;                    /* n_pi ext (base-field instances embedded) */
 } ceno_main_job;
 
 /* outputs: claimed_sum (1 ext), msgs (max_num_vars * max_degree ext), global_rt (max_num_vars ext),

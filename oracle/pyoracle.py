@@ -186,6 +186,28 @@ class StubTranscript:
         return int(o[0]), int(o[1])
 
 
+class ReplayTranscript:
+    """transcript that ignores what is appended and hands out a fixed list of challenges: replays the tail of a proof on the
+    oracle from tables folded up to some round (tests at sizes the oracle cannot run from round 0)"""
+
+    def __init__(self, challenges):
+        self.q = [(int(c[0]), int(c[1])) for c in challenges]
+        self.pos = 0
+        LBL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+        EXT = C.CFUNCTYPE(None, C.c_void_p, u64p)
+
+        def sample(_self, out):
+            c = self.q[self.pos]
+            self.pos += 1
+            out[0], out[1] = c
+
+        self._cb = (LBL(lambda *_: None), EXT(lambda *_: None), EXT(sample))
+        self.tr = OrcTranscript(C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), C.cast(self._cb[2], C.c_void_p), None)
+
+    def ptr(self):
+        return C.byref(self.tr)
+
+
 def build_eq(point: np.ndarray) -> np.ndarray:
     n = point.shape[0]
     out = np.zeros((1 << n, 2), dtype=np.uint64)

@@ -69,6 +69,7 @@ def test_transpose_large_row_counts(dev, rows, width):
     g = torch.Generator(device="cuda:0").manual_seed(rows + width)
     src = torch.randint(0, 1 << 62, (rows * width,), dtype=torch.int64, device="cuda:0", generator=g)
     dst = torch.full((rows * width,), -1, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()  # the library launches on its own stream, not torch's
     api.transpose(dev, src.data_ptr(), rows, width, dst.data_ptr())
     dev.sync()
     assert torch.equal(dst.view(width, rows), src.view(rows, width).t())

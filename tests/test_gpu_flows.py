@@ -1,0 +1,376 @@
+"""GPU parity for the per-chip proof flow and the BASELINE.json configs at FULL size.
+
+* create_chip_proof / build_tower_witness (ceno_zkvm/src/scheme/prover.rs:717-833, scheme/cpu/mod.rs:608-797) against the
+  oracle, bit for bit, on small chips of every record shape (table circuits with numerators, a missing write set,
+  non-power-of-two group sizes, a rotation argument).
+* config #3 (benches/riscv_add.rs:86-141 shape): ADD-shaped chip, 2^20 rows x 22 columns, commit -> record inference ->
+  three towers -> tower proof -> batched main constraints (one job) -> Basefold open, every proof object checked by the
+  oracle's restated verifiers, the main sumcheck's last 12 rounds replayed on the oracle.
+* config #4 shape on one GPU (scheme/cpu/mod.rs:1052-1390): 24 chips of 14..24 variables in ONE batched main sumcheck.
+The commit / open path is PARITY UNPINNED against the reference (placeholder Poseidon2 constants).
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ceno_amd import Device
+
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def prover():
+    from ceno_amd import prover as p
+
+    return p
+
+
+def tup(a):
+    return int(a[0]), int(a[1])
+
+
+def e2_pow(a, k):
+    r = (1, 0)
+    for _ in range(k):
+        r = po.e2_mul(r, a)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# synthetic ADD-shaped circuit (SURVEY.md section 8d "S-chip"): records are RLCs of witness columns with the two global
+# challenges, the main constraints are selector x (degree-2 and degree-3 products of columns)
+# ------------------------------------------------------------------------------------------------------------------
+def record_plan(w, n_records, alpha, beta):
+    b2 = po.e2_mul(beta, beta)
+    terms, coeffs, out_terms = [], [], []
+    for k in range(n_records):
+        base = len(terms)
+        terms += [[(2 * k) % w], [(2 * k + 1) % w], [(3 * k + 5) % w, (k + 7) % w]]
+        coeffs += [beta, b2, alpha]
+        out_terms.append([base, base + 1, base + 2])
+    return po.ext(coeffs), terms, out_terms
+
+
+def main_plan(w, s_id):
+    terms = [[s_id, j, (j + 1) % w] for j in range(w)] + [[s_id, j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 2)]
+    # scalar_t = (3 + 5t, 11t + 1) * challenge[2 + t % 2]  (an alpha power), every third one also times the global beta
+    scalars = [[(((3 + 5 * t) % P, (11 * t + 1) % P), [2 + (t % 2)] + ([1] if t % 3 == 0 else []))] for t in range(len(terms))]
+    return terms, scalars
+
+
+def oracle_scalars(scalars, chal):
+    out = []
+    for monos in scalars:
+        sc = (0, 0)
+        for coeff, ids in monos:
+            v = coeff
+            for i in ids:
+                v = po.e2_mul(v, chal[i])
+            sc = po.e2_add(sc, v)
+        out.append(sc)
+    return out
+
+
+@pytest.mark.parametrize("shape", [(4, 4, 0, 8), (3, 0, 2, 0), (0, 1, 0, 1), (5, 2, 0, 3), (1, 1, 1, 0)])
+def test_create_chip_proof_matches_oracle(dev, prover, shape):
+    """every field of the chip proof equals the oracle's restatement of create_chip_proof"""
+    num_reads, num_writes, num_lk_tables, num_lk = shape
+    log2_n, w = 6, 9
+    rows = 1 << log2_n
+    n_lk_den = num_lk_tables if num_lk_tables else num_lk
+    n_rec = num_reads + num_writes + num_lk_tables + n_lk_den
+    alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+    cols = [po.rand_base(rows, 700 + j) for j in range(w)]
+    coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+    mles = [dev.upload(c) for c in cols]
+    task = dict(mles=mles, n_witin=w, n_fixed=0, n_structural=0, num_instances=rows - 5, log2_num_instances=log2_n,
+                num_reads=num_reads, num_writes=num_writes, num_lk_tables=num_lk_tables, num_lk=num_lk, record_coeffs=coeffs,
+                record_terms=terms, record_out_terms=out_terms)
+    proof = prover.create_chip_proof(dev, task, [alpha, beta], prover.Transcript.stub(21))
+    # ---- oracle: wit_infer -> interleave -> towers -> out-evals into the transcript -> tower proof ----
+    recs = [po.wit_infer(cols, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], log2_n) for ts in out_terms]
+    r_set, w_set = recs[:num_reads], recs[num_reads: num_reads + num_writes]
+    lk_n = recs[num_reads + num_writes: num_reads + num_writes + num_lk_tables]
+    lk_d = recs[num_reads + num_writes + num_lk_tables:]
+    prod_specs, logup_specs, out_evals = [], [], []
+    for group in (r_set, w_set):
+        if group:
+            limbs = po.interleaving_mles_to_mles(group, rows, 2, (1, 0))
+            nv = int(limbs[0].shape[0]).bit_length()
+            assert nv == log2_n + (max(1, len(group)) - 1).bit_length()  # group_num_vars (cpu/mod.rs:647-648)
+            layers = po.infer_tower_product_witness(nv, limbs)
+            prod_specs.append(layers)
+            out_evals += [layers[0][0][0], layers[0][1][0]]
+    if lk_d:
+        ql = po.interleaving_mles_to_mles(lk_d, rows, 2, alpha)
+        pl = po.interleaving_mles_to_mles(lk_n, rows, 2, alpha) if lk_n else None
+        layers = po.infer_tower_logup_witness(pl, ql)
+        logup_specs.append(layers)
+        out_evals += [layers[0][k][0] for k in range(4)]
+    tr = po.StubTranscript(21)
+    for e in out_evals:
+        tr.append_ext(tup(e))
+    oproof = po.tower_prove(prod_specs, logup_specs, tr)
+    assert np.array_equal(proof.tower_msgs, oproof.msgs)
+    assert np.array_equal(proof.tower_point, oproof.point[: proof.tower_num_vars])
+    if prod_specs:
+        assert np.array_equal(proof.tower_prod_evals, oproof.prod_evals)
+    if logup_specs:
+        assert np.array_equal(proof.tower_logup_evals, oproof.logup_evals)
+    got_out = [x for x in proof.r_out_evals] + [x for x in proof.w_out_evals] + [x for x in proof.lk_out_evals]
+    assert len(got_out) == len(out_evals) and all(tup(a) == tup(b) for a, b in zip(got_out, out_evals))
+    assert proof.rt_main.shape[0] == log2_n and np.array_equal(proof.rt_main, proof.tower_point[-log2_n:])
+    # build_tower_witness on its own gives the same towers
+    d_recs = [dev.upload(r) for r in recs]
+    ev, pt, lt = prover.build_tower_witness(dev, d_recs, num_reads, num_writes, num_lk_tables, num_lk, log2_n, 0, [alpha, beta])
+    assert [t.num_vars for t in pt] == [len(s) for s in prod_specs] and [t.num_vars for t in lt] == [len(s) for s in logup_specs]
+    for t, spec in zip(pt + lt, prod_specs + logup_specs):
+        last = t.num_vars - 1
+        for limb in range(t.num_limbs):
+            assert np.array_equal(t.layer(last, limb), spec[last][limb])
+
+
+def test_create_chip_proof_with_rotation_matches_oracle(dev, prover):
+    """a keccak-style chip: 2^2 instances x 2^5 rotation rows; the rotation argument runs at rt_main after the tower"""
+    log2_n, rot_vars, w = 2, 5, 4
+    nv = log2_n + rot_vars
+    alpha, beta = (5, 6), (7, 8)
+    src = po.rand_base(1 << nv, 31)
+    cols = [src, po.rotation_next_base_mle(src, 5), po.rand_base(1 << nv, 32), po.rand_base(1 << nv, 33)]
+    coeffs, terms, out_terms = record_plan(w, 3, alpha, beta)
+    task = dict(mles=[dev.upload(c) for c in cols], n_witin=w, n_fixed=0, n_structural=0, num_instances=3, log2_num_instances=log2_n,
+                rotation_vars=rot_vars, num_reads=1, num_writes=1, num_lk_tables=0, num_lk=1, record_coeffs=coeffs, record_terms=terms,
+                record_out_terms=out_terms, rotation=dict(pairs=[(0, 1), (2, 3)], cyclic_subgroup_size=23, cyclic_group_log2=5))
+    proof = prover.create_chip_proof(dev, task, [alpha, beta], prover.Transcript.stub(8))
+    recs = [po.wit_infer(cols, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], nv) for ts in out_terms]
+    specs, out_evals = [], []
+    for r in recs[:2]:
+        limbs = po.interleaving_mles_to_mles([r], 1 << nv, 2, (1, 0))
+        layers = po.infer_tower_product_witness(nv, limbs)
+        specs.append(layers)
+        out_evals += [layers[0][0][0], layers[0][1][0]]
+    ll = po.infer_tower_logup_witness(None, po.interleaving_mles_to_mles(recs[2:], 1 << nv, 2, alpha))
+    out_evals += [ll[0][k][0] for k in range(4)]
+    tr = po.StubTranscript(8)
+    for e in out_evals:
+        tr.append_ext(tup(e))
+    oproof = po.tower_prove(specs, [ll], tr)
+    assert np.array_equal(proof.tower_msgs, oproof.msgs)
+    rt_main = oproof.point[:nv][-nv:]
+    exp = po.prove_rotation(cols, [(0, 1), (2, 3)], 23, 5, np.ascontiguousarray(rt_main), tr)
+    assert np.array_equal(proof.rotation_msgs, exp[0]) and np.array_equal(proof.rotation_evals, exp[1])
+    assert np.array_equal(proof.rotation_points, np.stack(exp[2:5]))
+
+
+def test_main_constraints_public_instance_atoms(dev, prover):
+    """scalar expressions may reference public-instance values (eval_by_expr_with_instance(.., &chip.pi, ..),
+    scheme/cpu/mod.rs:1297-1304): atoms >= 2 + n_exprs select pi"""
+    nv, w = 7, 3
+    gch = [(3, 4), (5, 6)]
+    pi = [(1000, 0), (77, 88)]
+    wit = [po.rand_base(1 << nv, 40 + j) for j in range(w)]
+    point = po.rand_ext(nv, 9)
+    sel = (po.SEL_PREFIX, 0, (1 << nv) - 3, 0, (), 0, point)
+    terms = [[w, 0, 1], [w, 2], [w, 1, 2, 0]]
+    scalars = [[((1, 0), [2, 4])], [((2, 0), [3, 5]), ((7, 0), [4, 4, 0])], [((1, 1), [5])]]
+    job = dict(num_vars=nv, mles=[dev.upload(t) for t in wit] + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2,
+               max_degree=4, terms=terms, scalars=scalars, pi=pi)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, [job], gch, prover.Transcript.stub(4))
+    tr = po.StubTranscript(4)
+    tr.append_label(b"combine subset evals")
+    a = tr.sample_ext()
+    chal = gch + [(1, 0), a] + pi
+    coeffs = po.ext(oracle_scalars(scalars, chal))
+    tables = wit + [po.selector_compute(sel[0], sel[6], sel[1], sel[2])]
+    omsgs, ochal, ofin = po.sumcheck_prove(tables, coeffs, terms, nv, 4, tr)
+    assert np.array_equal(msgs, omsgs) and np.array_equal(rt, ochal) and np.array_equal(evals, ofin)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config #3 at full size
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("log_rows", [12, 20])
+def test_config3_add_chip_full_flow(dev, prover, log_rows):
+    """commit -> 2 challenges -> create_chip_proof -> batched main constraints (1 job) -> open, at 2^20 rows x 22 columns
+    (2^12: the same flow at a size where the tower proof is also compared with the oracle's prover bit for bit)"""
+    w, n_rec, log_blowup, n_queries, pow_bits = 22, 16, 1, 100, 16
+    rows = 1 << log_rows
+    num_instances = rows - 3
+    host = (np.random.default_rng(log_rows).integers(0, 1 << 62, size=(rows, w), dtype=np.uint64)) % np.uint64(P)
+    host[num_instances:] = 0  # InstancePaddingStrategy::Default
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, [host], log_blowup, stream)
+    root = pcs.root(0)
+    tr = prover.Transcript.stub(0xADD)
+    tr.append_ext((int(root[0]), int(root[1])))
+    tr.append_ext((int(root[2]), int(root[3])))
+    alpha, beta = tr.sample_ext(), tr.sample_ext()      # prover.rs:528-531
+    cols = [pcs.witness_mle(0, c) for c in range(w)]
+    coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+    task = dict(mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, num_instances=num_instances, log2_num_instances=log_rows,
+                num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+    proof = prover.create_chip_proof(dev, task, [alpha, beta], tr, stream)
+    assert proof.tower_num_vars == log_rows + 3 and (proof.n_prod, proof.n_logup) == (2, 1)
+    # ---- the restated TowerVerify accepts (scheme/verifier.rs:1372-1709) ----
+    vt = po.StubTranscript(0xADD)
+    vt.append_ext((int(root[0]), int(root[1])))
+    vt.append_ext((int(root[2]), int(root[3])))
+    assert vt.sample_ext() == alpha and vt.sample_ext() == beta
+    for e in list(proof.r_out_evals) + list(proof.w_out_evals) + list(proof.lk_out_evals):
+        vt.append_ext(tup(e))
+    op = po.TowerProof(proof.tower_num_vars, 2, 1)
+    op.msgs[:] = proof.tower_msgs
+    op.prod_evals[:] = proof.tower_prod_evals
+    op.logup_evals[:] = proof.tower_logup_evals
+    rc, vpoint, pclaims, lp, lq = po.tower_verify(np.concatenate([proof.r_out_evals, proof.w_out_evals]), proof.lk_out_evals,
+                                                  [log_rows + 2, log_rows + 2, log_rows + 3], op, vt)
+    assert rc == 0 and np.array_equal(vpoint, proof.tower_point)
+    # the verifier's leaf claim of the TALLEST tower (the LogUp one: its point is the final tower point) is an evaluation of the
+    # interleaved lookup records: check it through an independent path — record inference, MLE evaluation of every record at
+    # the row part of the point, the record index as eq-weights of the 3 low variables (interleaving, utils.rs:402-462)
+    recs = dev.wit_infer(cols, coeffs, terms, out_terms, log_rows)
+    eq_low = po.build_eq(np.ascontiguousarray(proof.tower_point[:3]))
+    claim = (0, 0)
+    for j in range(8):
+        claim = po.e2_add(claim, po.e2_mul(tup(eq_low[j]), recs[8 + j].evaluate(proof.tower_point[3: 3 + log_rows])))
+    assert claim == tup(lq[0]) and tup(lp[0]) == (1, 0)
+    if log_rows <= 12:   # and the prover's messages equal the oracle prover's, bit for bit
+        h_recs = [r.download() for r in recs]
+        specs = [po.infer_tower_product_witness(log_rows + 2, po.interleaving_mles_to_mles(h_recs[4 * g: 4 * g + 4], rows, 2, (1, 0)))
+                 for g in range(2)]
+        ll = po.infer_tower_logup_witness(None, po.interleaving_mles_to_mles(h_recs[8:], rows, 2, alpha))
+        t2 = po.StubTranscript(0xADD)
+        t2.append_ext((int(root[0]), int(root[1])))
+        t2.append_ext((int(root[2]), int(root[3])))
+        t2.sample_ext(), t2.sample_ext()
+        for e in list(proof.r_out_evals) + list(proof.w_out_evals) + list(proof.lk_out_evals):
+            t2.append_ext(tup(e))
+        assert np.array_equal(po.tower_prove(specs, [ll], t2).msgs, proof.tower_msgs)
+    for r in recs:
+        r.free()
+    # ---- batched main constraints with this one job (prover.rs:577-586) ----
+    mterms, mscalars = main_plan(w, w)
+    sel = (po.SEL_PREFIX, 0, num_instances, 0, (), 0, proof.rt_main)
+    job = dict(num_vars=log_rows, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4,
+               terms=mterms, scalars=mscalars)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, [job], [alpha, beta], tr, stream)
+    # verifier side: alpha powers, sumcheck_verify, final evaluations recomputed independently
+    vt.append_label(b"combine subset evals")
+    a = vt.sample_ext()
+    mcoeffs = po.ext(oracle_scalars(mscalars, [alpha, beta, (1, 0), a]))
+    vpoint, expected = po.sumcheck_verify(claimed, msgs, vt)
+    assert np.array_equal(vpoint, rt)
+    for c in range(w):
+        assert cols[c].evaluate(rt) == tup(evals[c])                       # k_eval_dot: an independent kernel path
+    assert po.selector_evaluate(po.SEL_PREFIX, proof.rt_main, rt, 0, num_instances) == tup(evals[w])   # succinct evaluator (selector.rs:247-363)
+    final_claim = po.sumcheck_expected_from_evals([log_rows] * (w + 1), mcoeffs, mterms, log_rows, rt, evals)
+    assert expected == final_claim and claimed == po.recover_claim_from_final(final_claim, msgs, rt)
+    # the last rounds replay on the oracle from independently folded tables (fix_variables: k_fold)
+    keep = min(12, log_rows)
+    cut = log_rows - keep
+    sel_tab = dev.selector_build(po.SEL_PREFIX, proof.rt_main, 0, num_instances)
+    folded = [m.fix_variables(rt[:cut]).download() if cut else m.download() for m in cols + [sel_tab]]
+    if cut == 0:
+        folded = [np.stack([f, np.zeros_like(f)], axis=1) if f.ndim == 1 else f for f in folded]
+    omsgs, _, ofin = po.sumcheck_prove(folded, mcoeffs, mterms, keep, 4, po.ReplayTranscript(rt[cut:]))
+    assert np.array_equal(omsgs, msgs[cut:]) and np.array_equal(ofin, evals)
+    for e in evals:
+        vt.append_ext(tup(e))
+    # ---- Basefold open at the main point (prover.rs:588-599); the oracle's verifier accepts ----
+    oproof = pcs.basefold_open([rt], [evals[:w]], n_queries, pow_bits, tr)
+    state = vt.state.s
+    assert po.basefold_verify([(log_rows, w)], root.reshape(1, 4), [rt], [evals[:w]], log_blowup, n_queries, pow_bits, vt, oproof) == 0
+    bad = oproof.copy()
+    bad[len(bad) // 2] ^= 1   # somewhere inside the query answers
+    vt.state.s = state
+    assert po.basefold_verify([(log_rows, w)], root.reshape(1, 4), [rt], [evals[:w]], log_blowup, n_queries, pow_bits, vt, bad) != 0
+    pcs.free()
+    dev.stream_destroy(stream)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config #4 shape on one GPU: S-batched, 24 chips, max_nv = 24
+# ------------------------------------------------------------------------------------------------------------------
+def batched_jobs(dev, max_nv, w):
+    sizes = [max_nv, max_nv - 2, max_nv - 2] + [max_nv - 4] * 5 + [max_nv - 6] * 8 + [max_nv - 10] * 8
+    jobs, chips = [], []
+    for c, nv in enumerate(sizes):
+        cols = [dev.synthetic(nv, False, 1000 + 50 * c + j) for j in range(w)]
+        point = np.array([[(i * 7919 + 13 + c) % P, (i * 104729 + 17) % P] for i in range(nv)], dtype=np.uint64)
+        n_inst = max(1, (1 << nv) - 5 - c)
+        sel = (po.SEL_PREFIX, 0, n_inst, 0, (), 0, point)
+        terms = [[w, j, (j + 1) % w] for j in range(w)] + [[w, j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 3)]
+        scalars = [[((3 + t, 1), [2 + (t % 2)])] for t in range(len(terms))]
+        jobs.append(dict(num_vars=nv, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4,
+                         terms=terms, scalars=scalars))
+        chips.append(dict(nv=nv, cols=cols, point=point, n_inst=n_inst, terms=terms, scalars=scalars))
+    return jobs, chips
+
+
+@pytest.mark.parametrize("max_nv", [13, 24])
+def test_config4_batched_main_sumcheck_full_size(dev, prover, max_nv):
+    """prove_batched_main_constraints over 24 chips of mixed sizes (front-load rule, scheme/verifier.rs:180-238) at max_nv = 24
+    (424 M table elements; 13: the same plan small enough for the oracle's prover to produce every message)"""
+    w = 12
+    gch = [(11, 22), (33, 44)]
+    jobs, chips = batched_jobs(dev, max_nv, w)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+    vt = po.StubTranscript(5)
+    vt.append_label(b"combine subset evals")
+    a = vt.sample_ext()
+    pows = [e2_pow(a, i) for i in range(2 * len(chips))]
+    coeffs, terms, nvs = [], [], []
+    for c, ch in enumerate(chips):
+        start = len(nvs)
+        nvs += [ch["nv"]] * (w + 1)
+        coeffs += oracle_scalars(ch["scalars"], gch + pows[2 * c: 2 * c + 2])
+        terms += [[start + j for j in t] for t in ch["terms"]]
+    coeffs = po.ext(coeffs)
+    vpoint, expected = po.sumcheck_verify(claimed, msgs, vt)
+    assert np.array_equal(vpoint, rt)
+    # final evaluations through independent paths: evaluate kernel for the witness columns, succinct evaluator for selectors
+    off = 0
+    for ch in chips:
+        nv = ch["nv"]
+        for j in (0, w // 2, w - 1):
+            assert ch["cols"][j].evaluate(rt[:nv]) == tup(evals[off + j])
+        assert po.selector_evaluate(po.SEL_PREFIX, ch["point"], rt[:nv], 0, ch["n_inst"]) == tup(evals[off + w])
+        off += w + 1
+    final_claim = po.sumcheck_expected_from_evals(nvs, coeffs, terms, max_nv, rt, evals)
+    assert expected == final_claim and claimed == po.recover_claim_from_final(final_claim, msgs, rt)
+    # replay on the oracle: every table folded (k_fold path) with the first `cut` challenges; the replay starts at round `cut`
+    keep = min(12, max_nv)
+    cut = max_nv - keep
+    tables = []
+    for ch in chips:
+        nv = ch["nv"]
+        sel_tab = dev.selector_build(po.SEL_PREFIX, ch["point"], 0, ch["n_inst"])
+        for m in ch["cols"] + [sel_tab]:
+            k = min(cut, nv)
+            t = m.fix_variables(rt[:k]).download() if k else m.download()
+            if t.ndim == 1:
+                t = np.stack([t, np.zeros_like(t)], axis=1)
+            tables.append(np.ascontiguousarray(t))
+        sel_tab.free()
+    if all(ch["nv"] > cut for ch in chips):
+        omsgs, _, ofin = po.sumcheck_prove(tables, coeffs, terms, keep, 4, po.ReplayTranscript(rt[cut:]))
+        assert np.array_equal(omsgs, msgs[cut:]) and np.array_equal(ofin, evals)
+    if max_nv <= 13:  # the oracle's prover from round 0
+        full = []
+        for ch in chips:
+            sel_tab = po.selector_compute(po.SEL_PREFIX, ch["point"], 0, ch["n_inst"])
+            full += [m.download() for m in ch["cols"]] + [sel_tab]
+        t2 = po.StubTranscript(5)
+        t2.append_label(b"combine subset evals")
+        t2.sample_ext()
+        omsgs, ochal, ofin = po.sumcheck_prove(full, coeffs, terms, max_nv, 4, t2)
+        assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals)
