@@ -30,7 +30,7 @@ SEED0 = 0xCE10
 TR_SEED = 0xF5
 
 
-def cpu_baseline(nv: int = 25):
+def cpu_baseline(nv: int = 26):
     """the oracle's OpenMP fused sumcheck (a port, not the Rust/rayon reference binary) on the host cores,
     in a child process with a clean OpenMP environment"""
     import subprocess
@@ -44,6 +44,65 @@ def cpu_baseline(nv: int = 25):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
+def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int = 3):
+    """BASELINE.json configs #2, #3 and #4 at their own sizes (best of `reps`, wall clock around synchronous host entries,
+    inputs resident in HBM), each with its algorithmic bytes against the 8 TB/s HBM peak"""
+    from ceno_amd import synthetic
+
+    def roof(alg_bytes, ms, note=None):
+        gbps = alg_bytes / (ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "algorithmic_bytes": alg_bytes}
+        if note:
+            r["note"] = note
+        return r
+
+    def best_of(f):
+        best = None
+        for _ in range(reps):
+            dev.sync()
+            t0 = time.perf_counter()
+            f()
+            dev.sync()
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        return best
+
+    out = {"transcript": transcript_name}
+    # config #2: single sumcheck instance, 3 ext MLEs x nv=22
+    m22 = [dev.synthetic(22, True, SEED0 + j) for j in range(K)]
+    one = np.array([[1, 0]], dtype=np.uint64)
+    ms = best_of(lambda: prover.sumcheck_prove(dev, m22, one, [list(range(K))], 22, K, new_transcript()))
+    out["nv22"] = {"workload": "config #2: single sumcheck instance, 3 ext MLEs x nv=22", "ms": ms,
+                   "ext_mults_per_s": K * K * ((1 << 22) - 1) / (ms * 1e-3), "roofline": roof(3 * K * 16 * (1 << 22), ms)}
+    for m in m22:
+        m.free()
+    # config #4 shape on one GPU: batched main-constraint sumcheck, 24 chips, max_nv = 24
+    jobs, elems = synthetic.batched_jobs(dev, 24, 12)
+    ms = best_of(lambda: prover.prove_batched_main_constraints(dev, jobs, [(11, 22), (33, 44)], new_transcript()))
+    out["batched_main"] = {"workload": "config #4 shape: prove_batched_main_constraints, 24 chips of 14..24 variables, 12 base columns + "
+                                       "selector, 16 terms of degree <= 4 each", "ms": ms, "table_elements": elems,
+                           "roofline": roof(synthetic.batched_algorithmic_bytes(24, 12), ms, "integer-ALU bound: DESIGN.md section 3")}
+    for j in jobs:
+        for m in j["mles"]:
+            if m is not None:
+                m.free()
+    # config #3: ADD-shaped chip, 2^20 rows x 22 columns, commit -> chip proof -> main constraints -> open
+    flow = synthetic.ChipFlow(dev, prover, 20, 22)
+    best = None
+    for _ in range(reps):
+        r = flow.run(new_transcript)
+        if best is None or r["total_ms"] < best["total_ms"]:
+            best = r
+    ab = flow.algorithmic_bytes()
+    flow.close()
+    best["workload"] = "config #3: ADD-shaped chip, 2^20 rows x 22 base columns, blow-up 2, 100 queries, 16-bit proof of work"
+    best["roofline"] = roof(sum(ab.values()), best["total_ms"], "commit is integer-ALU bound (Poseidon2): DESIGN.md section 3")
+    best["roofline_by_phase"] = {k: roof(v, best[f"{k}_ms"]) for k, v in ab.items()}
+    out["chip_flow"] = best
+    out["chip_flow_ms"], out["batched_main_ms"], out["nv22_ms"] = best["total_ms"], out["batched_main"]["ms"], out["nv22"]["ms"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +110,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nv", type=int, default=26, help="variables per GPU shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config #2 / #3 / #4 shaped measurements reported under `extra`")
+    ap.add_argument("--transcript", choices=["poseidon2", "stub"], default="poseidon2",
+                    help="Fiat-Shamir transcript of the timed steps (the other one is timed too and reported beside it)")
     args = ap.parse_args()
 
     import torch
@@ -98,17 +160,21 @@ def main():
 
     ONE = np.array([[1, 0]], dtype=np.uint64)
     TERMS = [list(range(K))]
+    # Fiat-Shamir on the host between every two rounds: the Poseidon2 duplex challenger (what the reference's BasicTranscript
+    # is; 2 permutations per round on the critical path) by default, the SplitMix stub for comparison
+    factories = {"poseidon2": lambda: prover.Transcript.poseidon2(b"riscv"), "stub": lambda: prover.Transcript.stub(TR_SEED)}
+    new_transcript = factories[args.transcript]
     collective = "none"
     comm = stream = None
 
     def step_torch():
         # per-round all-gather issued from Python through torch.distributed (RCCL underneath)
         eng = cdist.HipShardEngine(dev, mles)
-        return cdist.sharded_sumcheck_prove(eng, n_total, K, prover.Transcript.stub(TR_SEED), dist=dist, world=world, rank=rank)
+        return cdist.sharded_sumcheck_prove(eng, n_total, K, new_transcript(), dist=dist, world=world, rank=rank)
 
     def step_native():
         # the same protocol driven from C++ with ncclAllGather on the kernels' HIP stream (host/dist.cpp)
-        return prover.dist_sumcheck_prove(dev, comm, mles, ONE, TERMS, n_total, K, prover.Transcript.stub(TR_SEED), stream)
+        return prover.dist_sumcheck_prove(dev, comm, mles, ONE, TERMS, n_total, K, new_transcript(), stream)
 
     if world > 1:
         # Three drivers of the same protocol, fastest first; each candidate must reproduce the torch.distributed path's
@@ -146,7 +212,7 @@ def main():
 
     def step():
         if world == 1:
-            return prover.sumcheck_prove(dev, mles, ONE, TERMS, n_total, K, prover.Transcript.stub(TR_SEED))
+            return prover.sumcheck_prove(dev, mles, ONE, TERMS, n_total, K, new_transcript())
         return step_fn()
 
     for _ in range(args.warmup):
@@ -168,6 +234,17 @@ def main():
     barrier()
     kernel_ms, launches, prof_bytes = dev.prof_get()
     dev.prof_enable(False)
+    # the same steps with the other transcript (untimed for `value`; reported as ms_per_step_<name>)
+    other = "stub" if args.transcript == "poseidon2" else "poseidon2"
+    new_transcript = factories[other]
+    step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt_other = time.perf_counter() - t1
+    new_transcript = factories[args.transcript]
 
     # max over ranks
     if dist is not None:
@@ -189,6 +266,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        f"ms_per_step_{args.transcript}": dt / args.steps * 1e3,
+        f"ms_per_step_{other}": dt_other / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -196,7 +275,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"single sumcheck instance, {K} MLEs x nv={n_local} per GPU, Goldilocks-ext2 (16 B/elem), "
-                        f"degree {K}, stub Fiat-Shamir transcript on host, inputs resident in HBM",
+                        f"degree {K}, {args.transcript} Fiat-Shamir transcript on host, inputs resident in HBM",
             "global_num_vars": n_total,
             "sharding": "none" if world == 1 else f"top-{log_w}-bits over {world} GPUs, all-gather of partials per round",
             "collective": collective,
@@ -238,6 +317,11 @@ def main():
                     res["roofline"]["traffic_source"] = os.path.relpath(cands[-1], ROOT)
         except Exception:
             pass
+        if world == 1 and not args.no_extra:
+            try:
+                res["extra"] = extra_measurements(dev, prover, factories[args.transcript], args.transcript)
+            except Exception as e:  # the extras must not take the headline down
+                res["extra"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -29,8 +29,20 @@ void ceno_pcs_data_free(ceno_hip_ctx* ctx, ceno_pcs_data* d) {
     delete d;
 }
 
+static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
+                       int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out, bool on_device);
+
 int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
                               int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out) {
+    return commit_impl(ctx, host_row_major, num_instances, widths, n_matrices, log_blowup, s, out, false);
+}
+int ceno_prover_commit_traces_dev(ceno_hip_ctx* ctx, const uint64_t* const* dev_row_major, const size_t* num_instances, const size_t* widths,
+                                  int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out) {
+    return commit_impl(ctx, dev_row_major, num_instances, widths, n_matrices, log_blowup, s, out, true);
+}
+
+static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
+                       int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out, bool on_device) {
     if (!ctx || !host_row_major || !num_instances || !widths || !out || n_matrices < 1 || log_blowup < 0)
         return prover_set_error(CENO_HIP_ERR_INVALID, "bad commit_traces arguments");
     if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces needs an explicit stream (ceno_hip_stream_create)");
@@ -46,8 +58,10 @@ int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row
         M.width = widths[i];
         M.log_rows = ceil_log2_sz(rows);
         const size_t words = rows * M.width, cw_words = words << log_blowup;
+        // a device-resident matrix that already has all `rows` rows is transposed straight out of the caller's buffer
+        const bool direct = on_device && num_instances[i] == rows;
         ceno_hip_mle* staging = nullptr;
-        int rc = ceno_hip_mle_alloc(ctx, ceil_log2_sz(words), 0, &staging);
+        int rc = direct ? 0 : ceno_hip_mle_alloc(ctx, ceil_log2_sz(words), 0, &staging);
         if (!rc) rc = ceno_hip_mle_alloc(ctx, ceil_log2_sz(words), 0, &M.trace);
         if (!rc) rc = ceno_hip_mle_alloc(ctx, ceil_log2_sz(cw_words), 0, &M.codeword);
         if (rc) {
@@ -55,20 +69,25 @@ int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row
             ceno_pcs_data_free(ctx, d);
             return prover_set_error(rc, ceno_hip_last_error(ctx));
         }
-        uint64_t* d_stage = ceno_hip_mle_device_ptr(staging);
+        const uint64_t* d_stage = direct ? host_row_major[i] : ceno_hip_mle_device_ptr(staging);
         hipStream_t st = (hipStream_t)s;
-        hipError_t e = hipMemsetAsync(d_stage, 0, words * 8, st);  // zero rows beyond num_instances (InstancePaddingStrategy::Default)
-        if (e == hipSuccess) e = hipMemcpyAsync(d_stage, host_row_major[i], num_instances[i] * M.width * 8, hipMemcpyHostToDevice, st);
+        hipError_t e = hipSuccess;
+        if (!direct) {
+            uint64_t* dst = ceno_hip_mle_device_ptr(staging);
+            const size_t used = num_instances[i] * M.width;
+            if (used < words) e = hipMemsetAsync(dst + used, 0, (words - used) * 8, st);  // rows beyond num_instances are zero (InstancePaddingStrategy::Default)
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, host_row_major[i], used * 8, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
+        }
         if (e != hipSuccess) {
-            ceno_hip_mle_free(ctx, staging);
+            if (staging) ceno_hip_mle_free(ctx, staging);
             ceno_pcs_data_free(ctx, d);
             return prover_set_error(CENO_HIP_ERR_HIP, hipGetErrorString(e));
         }
         rc = ceno_hip_transpose(ctx, d_stage, rows, M.width, ceno_hip_mle_device_ptr(M.trace), s);
         if (!rc) rc = ceno_hip_rs_encode(ctx, ceno_hip_mle_device_ptr(M.trace), M.log_rows, (int)M.width, log_blowup, ceno_hip_mle_device_ptr(M.codeword), s);
         if (!rc) rc = ceno_hip_merkle_commit(ctx, ceno_hip_mle_device_ptr(M.codeword), M.log_rows + log_blowup, (int)M.width, s, &M.tree);
-        if (!rc) rc = ceno_hip_stream_sync(ctx, s);  // the host matrix and the staging buffer are only borrowed
-        ceno_hip_mle_free(ctx, staging);
+        if (!rc) rc = ceno_hip_stream_sync(ctx, s);  // the caller's matrix and the staging buffer are only borrowed
+        if (staging) ceno_hip_mle_free(ctx, staging);
         if (rc) {
             ceno_pcs_data_free(ctx, d);
             return prover_set_error(rc, ceno_hip_last_error(ctx));

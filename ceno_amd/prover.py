@@ -697,7 +697,9 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
 class PcsData:
     """committed traces (reference: PCS::CommitmentWithWitness returned by commit_traces)"""
 
-    def __init__(self, dev: Device, matrices: Sequence[np.ndarray], log_blowup: int, stream):
+    def __init__(self, dev: Device, matrices: Sequence[np.ndarray], log_blowup: int, stream, device_ptrs=None):
+        """matrices: host row-major (rows, width) arrays; or device_ptrs = [(device pointer, rows, width)] for device-resident
+        row-major matrices (ceno_prover_commit_traces_dev)"""
         L = plib()
         vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
         L.ceno_prover_commit_traces.restype = i
@@ -716,7 +718,19 @@ class PcsData:
         L.ceno_prover_basefold_proof_words.argtypes = [vp, i]
         L.ceno_prover_basefold_open.restype = i
         L.ceno_prover_basefold_open.argtypes = [vp, vp, C.POINTER(u64p), C.POINTER(u64p), i, i, vp, vp, u64p]
+        L.ceno_prover_commit_traces_dev.restype = i
+        L.ceno_prover_commit_traces_dev.argtypes = [vp, C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
         self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
+        if device_ptrs is not None:
+            n = len(device_ptrs)
+            self.shapes = [(int(r), int(w)) for _, r, w in device_ptrs]
+            ptrs = (u64p * n)(*[C.cast(C.c_void_p(int(p_)), u64p) for p_, _, _ in device_ptrs])
+            rows = (sz * n)(*[r for _, r, _ in device_ptrs])
+            widths = (sz * n)(*[w for _, _, w in device_ptrs])
+            h = vp()
+            _check(L.ceno_prover_commit_traces_dev(dev.h, ptrs, rows, widths, n, log_blowup, stream, C.byref(h)))
+            self.h = h
+            return
         mats = [np.ascontiguousarray(m, dtype=np.uint64) for m in matrices]
         self.shapes = [m.shape for m in mats]
         ptrs = (u64p * len(mats))(*[_p(m) for m in mats])

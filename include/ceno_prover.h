@@ -231,6 +231,10 @@ int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_mai
 typedef struct ceno_pcs_data ceno_pcs_data;
 int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
                               int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
+/* same with the row-major matrices already in device memory (the reference's device-backed RowMajorMatrix: witness generated
+ * on the GPU, `has_device_backing()` / `device_backing_layout()`, scheme/gpu/mod.rs:1556-1582): no PCIe transfer */
+int ceno_prover_commit_traces_dev(ceno_hip_ctx* ctx, const uint64_t* const* dev_row_major, const size_t* num_instances, const size_t* widths,
+                                  int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
 int ceno_pcs_data_num_vars(const ceno_pcs_data* d, int matrix);
 int ceno_pcs_data_root(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, uint64_t* root4, ceno_hip_stream s);
 /* borrowed base-field MLE view of column `col` of matrix `matrix` (valid while `d` lives; free the handle with ceno_hip_mle_free) */

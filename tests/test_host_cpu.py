@@ -148,6 +148,8 @@ def test_poseidon2_host_source_matches_oracle_and_transcript_is_deterministic(bu
     L = prover.plib()
     L.ceno_prover_test_poseidon2_permute.restype = None
     L.ceno_prover_test_poseidon2_permute.argtypes = [po.u64p]
+    L.ceno_prover_test_poseidon2_permute_fast.restype = None
+    L.ceno_prover_test_poseidon2_permute_fast.argtypes = [po.u64p]
     rng = random.Random(3)
     # the shipped permutation keeps its state non-canonical with lazily reduced linear layers: stress the carry paths
     edge = [[P - 1] * 8, [0] * 8, [P - 1, 0] * 4, [0xFFFFFFFF00000000] * 8, [0xFFFFFFFF] * 8, [P - 1, 1, P - 2, 2, 1 << 63, (1 << 63) - 1, 1 << 32, P - (1 << 32)]]
@@ -157,6 +159,9 @@ def test_poseidon2_host_source_matches_oracle_and_transcript_is_deterministic(bu
         got = st.copy()
         L.ceno_prover_test_poseidon2_permute(po._p(got))
         assert np.array_equal(got, exp)
+        fast = st.copy()  # the host-only 128-bit form the transcript runs on (host/transcript.cpp p2host)
+        L.ceno_prover_test_poseidon2_permute_fast(po._p(fast))
+        assert np.array_equal(fast, exp)
     # duplex challenger: same script -> same challenges; one changed element -> different challenges
     def run(x):
         t = prover.Transcript.poseidon2(b"riscv")
