@@ -61,6 +61,7 @@ struct ceno_hip_mle {
     int num_vars = 0;
     int is_ext = 0;
     bool owned = false;  // backed by the ctx pool
+    void* aux = nullptr; // pool block that must outlive the kernels that built this table (eq half tables); freed with the handle
     size_t len() const { return (size_t)1 << num_vars; }
     size_t bytes() const { return len() * (is_ext ? 16 : 8); }
 };

@@ -374,6 +374,7 @@ int ceno_hip_mle_download(ceno_hip_ctx* ctx, const ceno_hip_mle* m, uint64_t* ho
 int ceno_hip_mle_free(ceno_hip_ctx* ctx, ceno_hip_mle* m) {
     if (!m) return 0;
     if (m->owned) ctx_free(ctx, m->d);
+    if (m->aux) ctx_free(ctx, m->aux);
     delete m;
     return 0;
 }

@@ -18,213 +18,13 @@
 // arrive (`epilogue`), which applies class coefficients and the host-computed front-load scalars and
 // writes the d extension elements of the message straight into pinned host memory + a sequence flag the
 // host spins on (or into a caller device buffer): one launch and no D2H copy per round.
-#include "common.hpp"
-#include "reduce.cuh"
+#include "sumcheck_dev.cuh"
+#include "sumcheck_gen.hpp"
 
 #include <algorithm>
+#include <functional>
+#include <numeric>
 #include <ctime>
-
-using namespace gl;
-
-static constexpr int NT = 256;
-static constexpr int MAXD = 8;
-static constexpr int MAXK = 4;
-// 4 workgroups per CU: every workgroup of a launch is resident at once (1024 <= 256 CUs x 6 at 75 VGPRs);
-// measured on MI355X: 1024/1280/1536 are within 1 %, 2048 (a second dispatch wave) is 3-6 % slower
-static constexpr unsigned MAXB = 1024;
-static constexpr int MAX_CLASSES = 40;
-
-// ------------------------------------------------------------------------------------------------
-// In-kernel message reduction ("last block done").  Every block publishes its D partial sums, the last
-// block to arrive adds all of them, applies the class coefficient, chains the running total of the
-// round (several size classes = several launches on one stream) and — for the last class of the round —
-// adds the host-computed front-load scalars and writes the message either to device memory or straight
-// into pinned host memory followed by a sequence flag the host spins on (no D2H copy, no second launch).
-// Cross-workgroup visibility follows the agent-scope release/acquire recipe (per-XCD L2s are not
-// coherent): write-through (sc1) partial stores, drained (vmcnt(0)) before the agent-scope counter add;
-// acquire fence + agent-scope (sc1) loads in the last block.  No release fence: it would flush the L2.
-// ------------------------------------------------------------------------------------------------
-struct Epilogue {
-    uint64_t* partials;            // gridDim.x * D * 2 words
-    unsigned* counter;             // arrival counter, zero when the kernel starts; reset by the last block
-    E2* round_acc;                 // running total of this round's message (device, MAXD)
-    uint64_t* out_msg;             // destination of the finished message (device or host-mapped), d * 2 words
-    unsigned long long* flag;      // host-mapped sequence flag (nullptr: none)
-    unsigned long long seq;
-    E2 coeff;                      // class coefficient
-    E2 scalars[MAXD];              // front-loaded terms, added once by the last class
-    int first_class;               // 1: start the running total, 0: add to it
-    int last_class;                // 1: finish the message
-    int d;                         // message length (>= the D the kernel accumulates)
-    // pipelined mode: the kernel was enqueued before its challenge existed and fetches it itself
-    const struct Mailbox* mailbox; // host-mapped, written by the host
-    struct Bcast* bcast;           // device memory, challenge relay between workgroups
-    unsigned long long wait_seq;   // 0: challenge is the kernel argument; else it was relayed as round `wait_seq`
-    unsigned long long next_seq;   // != 0: after publishing, fetch challenge `next_seq` from the host for the next launch
-    int dbg;                       // 1: record wall-clock stamps per round in bcast->dbg (CENO_HIP_DEBUG); each stamp costs a
-                                   // realtime read and a store on the round's critical path
-    unsigned long long poll_ticks; // pipelined: how long (100 MHz ticks) a queued round waits for its challenge before it gives up
-};
-
-// host -> device mailbox in pinned memory (one cache line)
-struct Mailbox {
-    unsigned long long chal_seq;   // round whose challenge is valid (written last, release)
-    unsigned long long chal[2];
-    unsigned long long abort;      // non-zero: every waiting kernel exits without touching memory
-};
-// device-side relay: the first workgroup to arrive polls the host mailbox, the others poll this
-struct Bcast {
-    unsigned ticket;               // (unused)
-    unsigned ready_seq;            // round whose challenge has been relayed (ABORT_SEQ: give up)
-    unsigned long long chal[2];
-    unsigned long long dbg[64][4]; // wall-clock stamps per round: start, before publish, after flag, after poll
-};
-static constexpr unsigned ABORT_SEQ = 0xFFFFFFFFu;
-
-__device__ __forceinline__ void st_agent(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t ld_agent(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// thread 0 of the finishing block: class coefficient, running round total, front-load scalars, publish
-// Pipelined launches.  The finishing workgroup of round i — alone on the chip at that point — publishes
-// the message, then polls the host mailbox for challenge i (bounded: CENO_HIP_PIPE_TIMEOUT_S, 60 s by default, or the host's
-// `abort`) and relays it through device memory; the already queued kernel of round i+1 picks it up with a
-// single load at its start.  Exactly one lane ever polls PCIe, nothing spins inside the big kernels.
-// one lane polls the host's mailbox for challenge `want_seq` (bounded: ep.poll_ticks or the host's `abort`)
-__device__ __forceinline__ bool poll_challenge(const Mailbox* mb, unsigned long long want_seq, unsigned long long& c0, unsigned long long& c1,
-                                               unsigned long long poll_ticks) {
-    const unsigned long long t0 = wall_clock64();  // 100 MHz
-    unsigned spins = 0;
-    for (;;) {
-        // relaxed polls: an acquire per poll would invalidate the (large) L2 every iteration
-        if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want_seq) break;
-        if ((++spins & 63u) == 0) {
-            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > poll_ticks) return false;
-        }
-    }
-    // the host stores chal[] before chal_seq (release); these loads are issued only after the seq load
-    // has returned (control dependency + waitcnt) and bypass the caches, so they see the new words
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    c0 = __hip_atomic_load(&mb->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    c1 = __hip_atomic_load(&mb->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return true;
-}
-__device__ __forceinline__ void fetch_next_challenge(const Epilogue& ep) {
-    Bcast* bc = ep.bcast;
-    unsigned long long c0 = 0, c1 = 0;
-    const bool ok = poll_challenge(ep.mailbox, ep.next_seq, c0, c1, ep.poll_ticks);
-    if (ok) {
-        __hip_atomic_store(&bc->chal[0], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&bc->chal[1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __hip_atomic_store(&bc->ready_seq, ok ? (unsigned)ep.next_seq : ABORT_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// start of a pipelined round kernel: the challenge was relayed by the previous launch (kernel boundary
-// = visibility); anything else means the pipeline was aborted
-__device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r, unsigned long long* s_c /* 3 words of LDS */) {
-    // ONE lane per workgroup reads the relay words, LDS broadcast to the rest
-    if (threadIdx.x == 0) {
-        // plain (cacheable) loads: the words were written by the PREVIOUS launch, the kernel boundary makes
-        // them visible; cache-bypassing (sc1) loads of one line from 2048 workgroups serialise at ~90 per us
-        const volatile Bcast* bc = ep.bcast;
-        s_c[2] = bc->ready_seq == (unsigned)ep.wait_seq;
-        s_c[0] = bc->chal[0];
-        s_c[1] = bc->chal[1];
-    }
-    __syncthreads();
-    r = E2{s_c[0], s_c[1]};
-    return s_c[2] != 0;
-}
-
-// `seq` / `next_seq` are passed apart from `ep` so that the persistent tail kernel can publish round after round from the
-// kernel-argument copy of the epilogue: a modified local copy of the struct would live in scratch memory (its arrays are
-// indexed at run time) and every field read on this single-lane critical path would become a scratch load.
-template <int D>
-__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep, unsigned long long seq, unsigned long long next_seq) {
-    const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][1] = wall_clock64();
-    // one lane runs this on the critical path of every round: the D accumulated points are handled with STATIC indices (a
-    // run-time index into the register array goes through scratch memory) and their independent loads / multiplies overlap;
-    // points beyond D (a class of lower degree than the message) only carry the running total and the scalars
-    auto emit = [&](int t, E2 v) {
-        if (!ep.first_class) v = v + ep.round_acc[t];
-        if (ep.last_class) {
-            v = v + ep.scalars[t];
-            if (ep.flag) {
-                // ONE 16-byte write-through system-scope store per point (each such store is its own fabric transaction)
-                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-                const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ep.out_msg + 2 * t), "v"(w) : "memory");
-            } else {
-                ep.out_msg[2 * t] = v.c0;
-                ep.out_msg[2 * t + 1] = v.c1;
-            }
-        } else {
-            ep.round_acc[t] = v;
-        }
-    };
-#pragma unroll
-    for (int t = 0; t < D; t++)
-        if (t < ep.d) emit(t, unit ? tot[t] : tot[t] * ep.coeff);
-    for (int t = D; t < ep.d; t++) emit(t, e2_zero());
-    if (ep.last_class && ep.flag) {
-        // message before flag: the message words went out as write-through system-scope stores; drain them
-        // (vmcnt) and only then store the flag.  A system-scope release FENCE would write back every dirty
-        // line of the L2 (the freshly folded tables) — tens of microseconds per round.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(ep.flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][2] = wall_clock64();
-    if (next_seq != 0) fetch_next_challenge(ep);
-    if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][3] = wall_clock64();
-}
-template <int D>
-__device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep) {
-    finish_message<D>(tot, ep, ep.seq, ep.next_seq);
-}
-
-template <int D, int TNT>
-__device__ __forceinline__ void epilogue(E2 (&acc)[D], const Epilogue& ep, E2* smem, int* s_flag) {
-    int& s_is_last = *s_flag;
-    red::block_sum<D, TNT>(acc, smem);
-    if (gridDim.x == 1) {  // latency-critical tail rounds: nothing to exchange between workgroups
-        if (threadIdx.x == 0) {
-            finish_message<D>(acc, ep);
-        }
-        return;
-    }
-    if (threadIdx.x == 0) {
-        uint64_t* row = ep.partials + (size_t)blockIdx.x * D * 2;
-#pragma unroll
-        for (int t = 0; t < D; t++) {
-            st_agent(row + 2 * t, acc[t].c0);
-            st_agent(row + 2 * t + 1, acc[t].c1);
-        }
-        // the partials were stored write-through (sc1): draining this wave's stores is enough, and a
-        // release fence here would write back the whole XCD L2 (GBs of freshly folded table data) per block
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(ep.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_is_last = (prev == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_is_last) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    E2 tot[D];
-#pragma unroll
-    for (int t = 0; t < D; t++) tot[t] = e2_zero();
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += TNT) {
-        const uint64_t* row = ep.partials + (size_t)b * D * 2;
-#pragma unroll
-        for (int t = 0; t < D; t++) tot[t] = tot[t] + E2{ld_agent(row + 2 * t), ld_agent(row + 2 * t + 1)};
-    }
-    __syncthreads();  // smem is reused
-    red::block_sum<D, TNT>(tot, smem);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(ep.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        finish_message<D>(tot, ep);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // dense fused kernel
@@ -234,9 +34,6 @@ struct TabPtrs {
     const uint64_t* in[K];
     uint64_t* out[K];
 };
-
-__device__ __forceinline__ E2 ld_e2(const uint64_t* p) { return *reinterpret_cast<const E2*>(p); }
-__device__ __forceinline__ void st_e2(uint64_t* p, E2 v) { *reinterpret_cast<E2*>(p) = v; }
 
 // MODE 0: accumulate only, ext input      MODE 1: accumulate only, base input
 // MODE 2: fold + accumulate, ext input    MODE 3: fold + accumulate, base input (output ext)
@@ -333,13 +130,6 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
 // ------------------------------------------------------------------------------------------------
 // generic path
 // ------------------------------------------------------------------------------------------------
-struct MleSlot {
-    const uint64_t* in;  // table of the previous round
-    uint64_t* out;       // table of this round (ext), written by the fold
-    int in_ext;
-    int pad;
-};
-
 // fold every MLE of a class: blockIdx.y = MLE
 __global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ slots, size_t half, E2 r, const Bcast* bcast,
                                                     unsigned long long wait_seq) {
@@ -1135,6 +925,29 @@ struct ScClass {
     int n_flat = 0;           // entries of group_terms
     bool terms_all_base = false;  // every factor of every term is a base-field input table (round 0 may use k_accum_base0)
     uint32_t part_off = 0;    // offset (E2 units) into partials
+    // host copies of the class plan (class-local MLE ids), from which the LDS-blocked kernel's component tables are built
+    std::vector<uint32_t> h_gto, h_gt, h_co, h_ci, h_to, h_ti;
+    std::vector<E2> h_coeffs;
+    bool gen = false;         // rounds of this class run in the merged k_gen launch (sumcheck_gen.hip)
+};
+
+// one connected component of a class's plan (a chip of a batched main sumcheck: its columns, selectors and terms)
+struct GenCompHost {
+    int cls = 0;
+    std::vector<int> mles;                 // class-local MLE ids in component order
+    int n_groups = 0, n_terms = 0;
+    int tp_log = 8, wt_log = 0;
+    bool base0_ok = false;
+    size_t units[2] = {0, 0};              // stage rows: [0] all-extension layout, [1] first-round layout (base rows are one unit)
+    size_t off_terms[2] = {0, 0}, off_groups[2] = {0, 0}, off_unit[2] = {0, 0};  // offsets into the gen blob
+    size_t slot_off = 0;                   // first slot of the component inside a round's slot row
+};
+struct GenRound {
+    size_t off_comps = 0;
+    int n_comps = 0;
+    unsigned total_tiles = 0;
+    size_t stage_bytes = 0;
+    bool base0 = false, has_terms = false;
 };
 
 }  // namespace
@@ -1171,6 +984,12 @@ struct ceno_hip_sumcheck {
     std::vector<void*> dev_allocs; // everything from ctx_alloc, freed on free()
     bool owns_tower_eq = false;
     ceno_hip_mle* extra_owned = nullptr;  // eq table built by tower_layer_sumcheck_begin
+    // LDS-blocked generic rounds (sumcheck_gen.hip): component tables and the slot schedule of every round, one device blob
+    bool gen_on = false;
+    std::vector<GenCompHost> gen_comps;
+    std::vector<GenRound> gen_rounds;
+    char* d_gen = nullptr;
+    void* h_gen = nullptr;                // pinned staging of the blob (alive until the handle is freed)
 };
 
 template <typename T>
@@ -1219,6 +1038,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     }
     for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
     ctx_pinned_free(sc->ctx, sc->h_block);
+    ctx_pinned_free(sc->ctx, sc->h_gen);
     ctx_vram_slot_free(sc->ctx, sc->vram_slot);
     if (sc->extra_owned) ceno_hip_mle_free(sc->ctx, sc->extra_owned);
     delete sc;
@@ -1416,6 +1236,273 @@ static unsigned sc_grid(size_t pairs) {
     return grid_for(pairs, NT, cap);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-blocked generic rounds (sumcheck_gen.hip): split every generic class into the connected components of its plan, lay
+// the terms / groups out per component, and precompute the slot tables and component lists of ALL rounds (buffer
+// ping-pong is deterministic), so that a round is one launch and no copy.  Built only for sumchecks large enough to pay
+// for the table upload; anything that does not fit (a component whose staged rows exceed the LDS budget) keeps the
+// two-kernel path.
+// ------------------------------------------------------------------------------------------------
+// (read per call, not cached: the test-suite switches them between sumchecks)
+static int gen_min_log() {
+    const char* e = getenv("CENO_HIP_GEN_MIN_LOG");  // smallest class (variables) that gets component tables
+    return e ? atoi(e) : 13;
+}
+static size_t gen_stage_budget(int d) {
+    const char* e = getenv("CENO_HIP_GEN_STAGE_KB");  // LDS the staged rows of one tile may take
+    const int kb = e ? atoi(e) : 48;
+    // the whole block (fixed part + stage + exchange of 4 KB per evaluation point) stays within 64 KB
+    const size_t cap = 63 * 1024 - gen_lds_bytes(d, 0);
+    return std::min((size_t)std::max(kb, 1) * 1024, cap);
+}
+static size_t gen_pipe_min_pairs() {
+    // pipelined single-class sumchecks (tower layers, a single chip's main sumcheck): rounds with at least 2^this pairs use
+    // k_gen.  Off by default: these plans have few terms per column (memory-bound), where the two-kernel path's streaming
+    // fold + L2-served accumulate measured faster than tiles separated by barriers (tower proof 6.1 vs 7.3 ms at 2^20 rows).
+    const char* e = getenv("CENO_HIP_GEN_PIPE_MIN_LOG");
+    return (size_t)1 << std::min(e ? atoi(e) : 62, 62);
+}
+static size_t gen_stage_bytes(size_t units, int tp_log) { return units * (((size_t)1 << tp_log) + GEN_PAD) * sizeof(E2); }
+
+static int sc_build_gen(ceno_hip_sumcheck* sc) {
+    ceno_hip_ctx* ctx = sc->ctx;
+    if (sc->n < gen_min_log()) return 0;
+    bool any = false;
+    for (auto& cl : sc->classes) any = any || (!cl.dense && cl.nv >= gen_min_log());
+    if (!any) return 0;
+    std::vector<char> blob;
+    auto append = [&blob](const void* data, size_t bytes) {
+        const size_t off = (blob.size() + 15) & ~(size_t)15;
+        blob.resize(off + std::max<size_t>(bytes, 16));
+        if (bytes && data) memcpy(blob.data() + off, data, bytes);
+        return off;
+    };
+    std::vector<GenCompHost> comps;
+    for (size_t ci = 0; ci < sc->classes.size(); ci++) {
+        ScClass& cl = sc->classes[ci];
+        if (cl.dense || cl.nv < gen_min_log()) continue;
+        const int km = (int)cl.mles.size();
+        // ---- connected components over class-local MLE ids (a group ties its common factors and its terms' factors) ----
+        std::vector<int> uf(km);
+        std::iota(uf.begin(), uf.end(), 0);
+        std::function<int(int)> find = [&](int x) { return uf[x] == x ? x : uf[x] = find(uf[x]); };
+        std::vector<char> used(km, 0);
+        const int ng = cl.n_groups;
+        bool ok = true;
+        for (int g = 0; g < ng && ok; g++) {
+            int anchor = -1;
+            auto touch = [&](uint32_t m) {
+                used[m] = 1;
+                if (anchor < 0) anchor = (int)m;
+                else uf[find((int)m)] = find(anchor);
+            };
+            const bool free_group = cl.h_co[g + 1] == cl.h_co[g];
+            for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++) touch(cl.h_ci[k]);
+            if (cl.h_co[g + 1] - cl.h_co[g] > 8) ok = false;
+            for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
+                const uint32_t t = cl.h_gt[ti];
+                if (free_group) anchor = -1;  // ungrouped terms share nothing: every term may be its own component
+                if (cl.h_to[t + 1] - cl.h_to[t] > 8) ok = false;
+                for (uint32_t k = cl.h_to[t]; k < cl.h_to[t + 1]; k++) touch(cl.h_ti[k]);
+            }
+        }
+        if (!ok) continue;  // a term / group too wide for the flat records: two-kernel path
+        std::map<int, int> comp_of_root;
+        std::vector<GenCompHost> mine;
+        for (int m = 0; m < km; m++) {
+            if (!used[m]) continue;
+            const int r = find(m);
+            auto it = comp_of_root.find(r);
+            if (it == comp_of_root.end()) {
+                it = comp_of_root.emplace(r, (int)mine.size()).first;
+                mine.emplace_back();
+                mine.back().cls = (int)ci;
+            }
+            mine[it->second].mles.push_back(m);
+        }
+        GenCompHost fold_only;  // tables no term reads: folded only
+        fold_only.cls = (int)ci;
+        for (int m = 0; m < km; m++)
+            if (!used[m]) fold_only.mles.push_back(m);
+        // ---- per component: units, terms, groups in both layouts ----
+        for (auto& C : mine) {
+            std::map<int, int> pos;  // class-local id -> component-local id
+            for (size_t k = 0; k < C.mles.size(); k++) pos[C.mles[k]] = (int)k;
+            std::vector<uint16_t> unit[2];
+            std::vector<char> is_base(C.mles.size());
+            size_t u0 = 0, u1 = 0;
+            for (size_t k = 0; k < C.mles.size(); k++) {
+                is_base[k] = !sc->mles[cl.mles[C.mles[k]]].cur_ext;
+                unit[0].push_back((uint16_t)u0);
+                unit[1].push_back((uint16_t)u1);
+                u0 += 2;
+                u1 += is_base[k] ? 1 : 2;
+            }
+            C.units[0] = u0;
+            C.units[1] = u1;
+            std::vector<GenTerm> terms[2];
+            std::vector<GenGroup> groups[2];
+            C.base0_ok = true;
+            size_t max_terms = 0;
+            for (int g = 0; g < ng; g++) {
+                const bool free_group = cl.h_co[g + 1] == cl.h_co[g];
+                // terms of this group that live in this component (a common-factor group lies in one component entirely; the
+                // ungrouped terms of the class are spread over theirs)
+                std::vector<uint32_t> ts;
+                for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
+                    const uint32_t t = cl.h_gt[ti];
+                    const uint32_t probe = cl.h_to[t + 1] > cl.h_to[t] ? cl.h_ti[cl.h_to[t]] : (free_group ? UINT32_MAX : cl.h_ci[cl.h_co[g]]);
+                    if (probe != UINT32_MAX && pos.count((int)probe)) ts.push_back(t);
+                }
+                if (ts.empty()) continue;
+                // widest terms first: the round-robin split over the waves stays balanced
+                std::stable_sort(ts.begin(), ts.end(), [&](uint32_t a, uint32_t b) { return cl.h_to[a + 1] - cl.h_to[a] > cl.h_to[b + 1] - cl.h_to[b]; });
+                max_terms = std::max(max_terms, ts.size());
+                for (int lay = 0; lay < 2; lay++) {
+                    GenGroup G{};
+                    G.term_begin = (uint32_t)terms[lay].size();
+                    for (uint32_t t : ts) {
+                        GenTerm T{};
+                        T.c = cl.h_coeffs[t];
+                        T.nf = cl.h_to[t + 1] - cl.h_to[t];
+                        for (uint32_t k = 0; k < T.nf; k++) {
+                            const int cm = pos[(int)cl.h_ti[cl.h_to[t] + k]];
+                            T.idx8 |= (uint64_t)(unit[lay][cm] & 0xff) << (8 * k);
+                            if (lay == 1 && !is_base[cm]) C.base0_ok = false;  // an extension factor inside a term: no base-field product
+                        }
+                        if (lay == 1 && T.nf == 0) C.base0_ok = false;
+                        terms[lay].push_back(T);
+                    }
+                    G.term_end = (uint32_t)terms[lay].size();
+                    G.n_common = cl.h_co[g + 1] - cl.h_co[g];
+                    for (uint32_t k = 0; k < G.n_common; k++) {
+                        const int cm = pos[(int)cl.h_ci[cl.h_co[g] + k]];
+                        G.common8 |= (uint64_t)(unit[lay][cm] & 0xff) << (8 * k);
+                        if (lay == 1 && is_base[cm]) G.base_mask |= 1u << k;
+                    }
+                    groups[lay].push_back(G);
+                }
+            }
+            C.n_groups = (int)groups[0].size();
+            C.n_terms = (int)terms[0].size();
+            // geometry: waves sharing a group's terms, pairs per tile, shrunk until the staged rows fit the LDS budget
+            C.wt_log = max_terms >= 4 ? 2 : (max_terms >= 2 ? 1 : 0);
+            C.tp_log = 8 - C.wt_log;
+            while (C.tp_log > 4 && gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d)) C.tp_log--;
+            if (gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d) || C.units[0] > GEN_MAX_UNITS) { ok = false; break; }
+            C.wt_log = std::min(2, 8 - C.tp_log);
+            for (int lay = 0; lay < 2; lay++) {
+                C.off_terms[lay] = append(terms[lay].data(), terms[lay].size() * sizeof(GenTerm));
+                C.off_groups[lay] = append(groups[lay].data(), groups[lay].size() * sizeof(GenGroup));
+                C.off_unit[lay] = append(unit[lay].data(), unit[lay].size() * sizeof(uint16_t));
+            }
+        }
+        if (!ok) continue;
+        if (!fold_only.mles.empty()) {
+            std::vector<uint16_t> zeros(fold_only.mles.size(), 0);
+            fold_only.off_unit[0] = fold_only.off_unit[1] = append(zeros.data(), zeros.size() * sizeof(uint16_t));
+            fold_only.base0_ok = true;
+            mine.push_back(fold_only);
+        }
+        cl.gen = true;
+        comps.insert(comps.end(), mine.begin(), mine.end());
+    }
+    if (comps.empty()) return 0;
+    // ---- slot schedule of every round (simulation of the buffer ping-pong of sc_round / sc_advance) ----
+    size_t slots_per_round = 0;
+    for (auto& C : comps) {
+        C.slot_off = slots_per_round;
+        slots_per_round += C.mles.size();
+    }
+    const int n = sc->n;
+    const size_t off_slots = append(nullptr, (size_t)n * slots_per_round * sizeof(MleSlot));
+    {
+        std::vector<ScMle> sim = sc->mles;
+        for (int i = 0; i < n; i++) {
+            MleSlot* row = reinterpret_cast<MleSlot*>(blob.data() + off_slots) + (size_t)i * slots_per_round;
+            for (auto& C : comps) {
+                const ScClass& cl = sc->classes[C.cls];
+                if (cl.nv <= i) continue;
+                for (size_t k = 0; k < C.mles.size(); k++) {
+                    const ScMle& M = sim[cl.mles[C.mles[k]]];
+                    row[C.slot_off + k] = MleSlot{M.cur, M.buf[M.which], M.cur_ext, 0};
+                }
+            }
+            if (i > 0)
+                for (auto& cl : sc->classes)
+                    if (cl.nv > i)
+                        for (int j : cl.mles) {
+                            ScMle& M = sim[j];
+                            M.cur = M.buf[M.which];
+                            M.cur_ext = 1;
+                            M.which ^= 1;
+                        }
+        }
+    }
+    // ---- component lists per round ----
+    sc->gen_rounds.assign(n, GenRound{});
+    std::vector<size_t> comp_fix;  // offsets of GenComp records whose pointers still hold blob offsets
+    for (int i = 0; i < n; i++) {
+        GenRound& R = sc->gen_rounds[i];
+        std::vector<GenComp> list;
+        bool base0 = i == 0;
+        for (auto& C : comps)
+            if (sc->classes[C.cls].nv > i && C.n_groups > 0 && !C.base0_ok) base0 = false;
+        unsigned tiles = 0;
+        for (auto& C : comps) {
+            const ScClass& cl = sc->classes[C.cls];
+            if (cl.nv <= i) continue;
+            const int lay = base0 ? 1 : 0;
+            GenComp G{};
+            G.slots = reinterpret_cast<const MleSlot*>(off_slots + ((size_t)i * slots_per_round + C.slot_off) * sizeof(MleSlot));
+            G.terms = reinterpret_cast<const GenTerm*>(C.off_terms[lay]);
+            G.groups = reinterpret_cast<const GenGroup*>(C.off_groups[lay]);
+            G.unit = reinterpret_cast<const uint16_t*>(C.off_unit[lay]);
+            G.pairs = 1ull << (cl.nv - i - 1);
+            G.n_mles = (uint32_t)C.mles.size();
+            G.n_groups = (uint32_t)C.n_groups;
+            G.tp_log = (uint32_t)C.tp_log;
+            G.wt_log = (uint32_t)C.wt_log;
+            G.fold = i > 0 ? 1u : 0u;
+            G.tile_begin = tiles;
+            G.n_tiles = (uint32_t)((G.pairs + ((1ull << C.tp_log) - 1)) >> C.tp_log);
+            if (i == 0 && C.n_groups == 0) continue;  // nothing to fold and nothing to evaluate in the first round
+            tiles += G.n_tiles;
+            if (C.n_groups > 0) {
+                R.has_terms = true;
+                R.stage_bytes = std::max(R.stage_bytes, gen_stage_bytes(C.units[lay], C.tp_log));
+            }
+            list.push_back(G);
+        }
+        R.base0 = base0;
+        R.n_comps = (int)list.size();
+        R.total_tiles = tiles;
+        R.off_comps = append(list.data(), list.size() * sizeof(GenComp));
+        for (size_t k = 0; k < list.size(); k++) comp_fix.push_back(R.off_comps + k * sizeof(GenComp));
+    }
+    // ---- one device allocation, pointers fixed up, one copy from pinned staging ----
+    void* d = nullptr;
+    TRY(ctx_alloc(ctx, blob.size(), &d));
+    sc->dev_allocs.push_back(d);
+    sc->d_gen = (char*)d;
+    for (size_t off : comp_fix) {
+        GenComp* G = reinterpret_cast<GenComp*>(blob.data() + off);
+        G->slots = reinterpret_cast<const MleSlot*>(sc->d_gen + reinterpret_cast<size_t>(G->slots));
+        G->terms = reinterpret_cast<const GenTerm*>(sc->d_gen + reinterpret_cast<size_t>(G->terms));
+        G->groups = reinterpret_cast<const GenGroup*>(sc->d_gen + reinterpret_cast<size_t>(G->groups));
+        G->unit = reinterpret_cast<const uint16_t*>(sc->d_gen + reinterpret_cast<size_t>(G->unit));
+    }
+    void *hb = nullptr, *db = nullptr;
+    TRY(ctx_pinned_alloc(ctx, blob.size(), &hb, &db));
+    sc->h_gen = hb;
+    memcpy(hb, blob.data(), blob.size());
+    HIP_TRY(ctx, hipMemcpyAsync(d, hb, blob.size(), hipMemcpyHostToDevice, sc->st));
+    sc->gen_comps = std::move(comps);
+    sc->gen_on = true;
+    return 0;
+}
+
 static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st,
                     ceno_hip_sumcheck** out) {
     CHECK_ARG(ctx, mles && plan && out, "NULL argument");
@@ -1572,6 +1659,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
                 if (sc->mles[j].cur_ext) cl.terms_all_base = false;
         }
         int rc = 0;
+        cl.h_gto = g_term_off; cl.h_gt = g_terms; cl.h_co = c_off; cl.h_ci = c_idx; cl.h_to = t_off; cl.h_ti = t_idx; cl.h_coeffs = coeffs;
         plan_offs.push_back(PlanOff{append(g_term_off.data(), g_term_off.size() * 4), append(g_terms.data(), g_terms.size() * 4),
                                     append(c_off.data(), c_off.size() * 4), append(c_idx.data(), c_idx.size() * 4),
                                     append(t_off.data(), t_off.size() * 4), append(t_idx.data(), t_idx.size() * 4),
@@ -1656,6 +1744,13 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
             if (e != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "begin: %s", hipGetErrorString(e)); }
             M.eval = E2{h[0], M.cur_ext ? h[1] : 0};
             M.done = true;
+        }
+    }
+    {
+        static const bool no_gen = getenv("CENO_HIP_NO_GEN") != nullptr;  // A/B switch: two-kernel generic path everywhere
+        if (!no_gen) {
+            int rc = sc_build_gen(sc);
+            if (rc) { sc_release(sc); return rc; }
         }
     }
     *out = sc;
@@ -1842,7 +1937,11 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 upto = sc->n;
                 break;
             }
-            if (tile_eligible(k, pairs)) {
+            if (sc->gen_on && cl.gen && sc->gen_rounds[i].n_comps > 0 && pairs >= gen_pipe_min_pairs()) {
+                const GenRound& R = sc->gen_rounds[i];
+                launch_gen(sc->d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, e2_zero(), ep,
+                           std::min<unsigned>(R.total_tiles, MAXB), R.stage_bytes, sc->st);
+            } else if (tile_eligible(k, pairs)) {
                 launch_tile(sc->d, pl, (int)k, cl.n_flat, pairs, e2_zero(), ep, sc->st);
             } else if (tnt) {
                 launch_fused(sc->d, tnt, pl, (int)k, pairs, e2_zero(), ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
@@ -1950,34 +2049,78 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             }
         }
     }
-    // ---- 3. live classes: one fused launch each; the last one finishes the message ----
+    // ---- 3. live classes: dense classes launch their fused kernel, all classes with component tables share ONE k_gen
+    // launch, the rest take the two-kernel path; the last launch that accumulates finishes the message ----
     std::vector<ScClass*> live;
     for (auto& cl : sc->classes)
         if (cl.nv > i) live.push_back(&cl);
-    ScClass* last_acc = nullptr;
+    enum { U_DENSE, U_GEN, U_LEGACY };
+    struct Unit {
+        int kind;
+        ScClass* cl;
+        bool accumulates;
+    };
+    std::vector<Unit> units;
+    bool gen_added = false;
+    // first round of base-field columns: the per-class base-field kernel (k_accum_base0) executes fewer instructions than the
+    // blocked kernel's first-round form (no staging, one reduction per pair): taken when EVERY class of the merged launch
+    // qualifies (the component list of a round is all or nothing); CENO_HIP_GEN_ROUND0=1 keeps k_gen
+    static const bool gen_round0 = getenv("CENO_HIP_GEN_ROUND0") != nullptr && atoi(getenv("CENO_HIP_GEN_ROUND0")) != 0;
+    bool legacy_round0 = i == 0 && !gen_round0 && sc->gen_on;
     for (ScClass* cl : live)
-        if (!cl->terms.empty()) last_acc = cl;
+        if (cl->gen && !cl->dense && !cl->terms_all_base) legacy_round0 = false;
+    for (ScClass* cl : live) {
+        if (cl->dense) units.push_back(Unit{U_DENSE, cl, true});
+        else if (cl->gen && sc->gen_on && !legacy_round0) {
+            if (!gen_added && sc->gen_rounds[i].n_comps > 0) units.push_back(Unit{U_GEN, nullptr, sc->gen_rounds[i].has_terms});
+            gen_added = true;
+        } else units.push_back(Unit{U_LEGACY, cl, !cl->terms.empty()});
+    }
+    int last_acc = -1, first_acc = -1;
+    for (size_t u = 0; u < units.size(); u++)
+        if (units[u].accumulates) {
+            if (first_acc < 0) first_acc = (int)u;
+            last_acc = (int)u;
+        }
     const unsigned long long seq = ++sc->seq;
-    bool first = true;
-    for (ScClass* clp : live) {
-        ScClass& cl = *clp;
-        double bytes = 0.0;
-        const size_t pairs = (size_t)1 << (cl.nv - i - 1);
-        const unsigned grid = sc_grid(pairs);
+    for (size_t u = 0; u < units.size(); u++) {
+        const Unit& U = units[u];
         Epilogue ep{};
-        ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
         ep.counter = sc->d_counter;
         ep.round_acc = sc->d_round_acc;
         ep.out_msg = d_out ? d_out : sc->d_hmsg;
         ep.flag = d_out ? nullptr : sc->d_hflag;
         ep.seq = seq;
         ep.coeff = e2_one();
-        ep.first_class = first ? 1 : 0;
-        ep.last_class = (clp == last_acc) ? 1 : 0;
-        ep.d = d;
+        ep.first_class = ((int)u == first_acc) ? 1 : 0;
+        ep.last_class = ((int)u == last_acc) ? 1 : 0;
+        ep.d = U.accumulates ? d : 0;
         if (ep.last_class)
             for (int x = 0; x < MAXD; x++) ep.scalars[x] = scalars[x];
-        if (cl.dense) {
+        double bytes = 0.0;
+        if (U.kind == U_GEN) {
+            const GenRound& R = sc->gen_rounds[i];
+            ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);  // the merged launch uses the first class's partial rows
+            prof_begin(ctx, sc->st);
+            launch_gen(d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, r, ep,
+                       std::min<unsigned>(R.total_tiles, MAXB), R.stage_bytes, sc->st);
+            for (ScClass* cl : live) {
+                if (!(cl->gen && !cl->dense)) continue;
+                const size_t pairs = (size_t)1 << (cl->nv - i - 1);
+                for (int j : cl->mles) {
+                    const double in_el = sc->mles[j].cur_ext ? 16.0 : 8.0;
+                    if (i == 0) bytes += 2.0 * pairs * in_el;
+                    else bytes += 4.0 * pairs * in_el + 2.0 * pairs * 16.0;
+                }
+            }
+            prof_end(ctx, sc->st, bytes);
+            continue;
+        }
+        ScClass& cl = *U.cl;
+        const size_t pairs = (size_t)1 << (cl.nv - i - 1);
+        const unsigned grid = sc_grid(pairs);
+        ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials + cl.part_off);
+        if (U.kind == U_DENSE) {
             const ScTerm& T = sc->terms[cl.terms[0]];
             const int K = (int)T.idx.size();
             const bool base_in = !sc->mles[T.idx[0]].cur_ext;
@@ -1994,7 +2137,6 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             if (i == 0) bytes += (double)K * 2.0 * pairs * in_el;
             else bytes += (double)K * (4.0 * pairs * in_el + 2.0 * pairs * 16.0);
             prof_end(ctx, sc->st, bytes);
-            first = false;
         } else {
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
@@ -2019,7 +2161,6 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 if (tile) launch_tile(d, pl, (int)cl.mles.size(), cl.n_flat, pairs, r, ep, sc->st);
                 else if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
                 else launch_accum(d, pl, pairs, ep, grid, sc->st, i == 0 && cl.terms_all_base);
-                first = false;
             }
             for (int j : cl.mles) {
                 const double in_el = sc->mles[j].cur_ext ? 16.0 : 8.0;
@@ -2028,10 +2169,11 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             }
             prof_end(ctx, sc->st, bytes);
         }
-        if (i > 0) sc_advance(sc, cl);
     }
+    if (i > 0)
+        for (ScClass* cl : live) sc_advance(sc, *cl);
     HIP_TRY(ctx, hipGetLastError());
-    if (!last_acc) {
+    if (last_acc < 0) {
         // no term is live in this round: the message consists of the front-loaded scalars only
         if (d_out) {
             memcpy(sc->h_pinned, scalars, (size_t)d * sizeof(E2));

@@ -2,7 +2,10 @@
 // `BatchedMainConstraintProver::prove_batched_main_constraints` (ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390),
 // written against the device C ABI.  See include/ceno_prover.h for the job encoding.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <vector>
@@ -42,6 +45,13 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
                                                           ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
                                                           uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree) {
     if (!ctx || !jobs || n_jobs < 1 || !gc4 || !tr) return prover_set_error(CENO_HIP_ERR_INVALID, "bad arguments");
+    static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
+    const double t_start = dbg ? now_us() : 0;
     int max_nv = 0, max_deg = 0, total_exprs = 0;
     for (int c = 0; c < n_jobs; c++) {
         max_nv = std::max(max_nv, jobs[c].num_vars);       // cpu/mod.rs:1091-1099
@@ -68,6 +78,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             sel_by_id[c][id] = m;
         }
     }
+    const double t_sel = dbg ? (ceno_hip_stream_sync(ctx, s), now_us()) : 0;
     // ---- alpha powers (cpu/mod.rs:1254) ----
     static const char lbl[] = "combine subset evals";
     tr->append_label(tr->self, (const uint8_t*)lbl, sizeof(lbl) - 1);
@@ -164,7 +175,9 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     plan.max_num_vars = max_nv;
     plan.max_degree = max_deg;
     std::vector<uint64_t> evals(2 * mles.size());
+    const double t_plan = dbg ? now_us() : 0;
     int rc = ceno_prover_sumcheck_prove(ctx, mles.data(), &plan, tr, s, out_msgs, out_global_rt, evals.data());   // cpu/mod.rs:1332-1337
+    if (dbg) fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan %.0f us, sumcheck %.0f us\n", t_sel - t_start, t_plan - t_sel, now_us() - t_plan);
     if (rc) { cleanup(); return rc; }
     // ---- final claim by the front-load rule and the claimed sum recovered backwards (cpu/mod.rs:1338-1360,1393-1413) ----
     E2 final_claim = gl::e2_zero();

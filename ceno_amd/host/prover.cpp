@@ -108,12 +108,23 @@ int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
                                ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
     if (!ctx || !plan) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
     ceno_hip_sumcheck* sc = nullptr;
+    static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
+    const double t0 = dbg ? now_us() : 0;
     int rc = ceno_hip_sumcheck_begin(ctx, mles, plan, s, &sc);
     if (rc) return fail_from_ctx(ctx, rc);
+    const double t1 = dbg ? now_us() : 0;
     ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // this loop drives the rounds back to back
     rc = ceno_prover_sumcheck_run(ctx, sc, plan->max_num_vars, plan->max_degree, plan->num_mles, tr, out_msgs, out_challenges,
                                   out_final_evals);
+    const double t2 = dbg ? now_us() : 0;
     ceno_hip_sumcheck_free(ctx, sc);
+    if (dbg) fprintf(stderr, "[ceno_prover] sumcheck_prove (%d mles, %d terms, n=%d): begin %.0f us, rounds %.0f us, free %.0f us\n", plan->num_mles,
+                     plan->num_terms, plan->max_num_vars, t1 - t0, t2 - t1, now_us() - t2);
     return rc;
 }
 

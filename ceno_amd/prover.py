@@ -517,67 +517,75 @@ class MainJobC(C.Structure):
     ]
 
 
-def prove_batched_main_constraints(dev: Device, jobs: Sequence[dict], global_challenges, tr: Transcript, stream=None):
+class MainJobs:
+    """the C view (ceno_main_job array) of a list of job dicts, marshalled once"""
+
+    def __init__(self, jobs: Sequence[dict]):
+        self.arr = (MainJobC * len(jobs))()
+        self.keep = [jobs]  # the job dicts own the device tables the handles point to
+        self.n = len(jobs)
+        self.total_mles = 0
+        self.max_nv = max(j["num_vars"] for j in jobs)
+        self.max_deg = max(j["max_degree"] for j in jobs)
+        keep = self.keep
+        for c, j in enumerate(jobs):
+            J = self.arr[c]
+            J.circuit_idx, J.num_vars = j.get("circuit_idx", c), j["num_vars"]
+            J.n_witin, J.n_fixed, J.n_structural = j["n_witin"], j["n_fixed"], j["n_structural"]
+            mh = (C.c_void_p * len(j["mles"]))(*[(m.h if m is not None else None) for m in j["mles"]])
+            self.total_mles += len(j["mles"])
+            sels = j["selectors"]
+            ns = len(sels)
+            kinds = (C.c_int * max(ns, 1))(*[s[0] for s in sels])
+            offs = (C.c_size_t * max(ns, 1))(*[s[1] for s in sels])
+            nins = (C.c_size_t * max(ns, 1))(*[s[2] for s in sels])
+            sids = (C.c_int * max(ns, 1))(*[s[3] for s in sels])
+            sp_arrays = [np.array(list(s[4]) or [0], dtype=np.uint32) for s in sels]
+            spp = (u32p * max(ns, 1))(*[_p32(a) for a in sp_arrays])
+            nsp = (C.c_int * max(ns, 1))(*[len(s[4]) for s in sels])
+            snv = (C.c_int * max(ns, 1))(*[s[5] for s in sels])
+            pts = [np.ascontiguousarray(s[6], dtype=np.uint64) for s in sels]
+            ptp = (u64p * max(ns, 1))(*[_p(p) for p in pts])
+            toff, tidx = _csr(j["terms"])
+            soff = np.zeros(len(j["terms"]) + 1, dtype=np.uint32)
+            mono_c, mono_off, mono_idx = [], [0], []
+            for t, monos in enumerate(j["scalars"]):
+                for coeff, ids in monos:
+                    mono_c.append([int(coeff[0]), int(coeff[1])])
+                    mono_idx.extend(ids)
+                    mono_off.append(len(mono_idx))
+                soff[t + 1] = len(mono_c)
+            mono_c = np.array(mono_c if mono_c else [[0, 0]], dtype=np.uint64)
+            mono_off = np.array(mono_off, dtype=np.uint32)
+            mono_idx = np.array(mono_idx if mono_idx else [0], dtype=np.uint32)
+            J.mles, J.n_selectors = mh, ns
+            J.sel_kind, J.sel_offset, J.sel_num_instances, J.sel_structural_id = kinds, offs, nins, sids
+            J.sel_sparse_indices, J.sel_n_sparse, J.sel_sparse_num_vars, J.sel_points = spp, nsp, snv, ptp
+            J.n_exprs, J.max_degree, J.n_terms = j["n_exprs"], j["max_degree"], len(j["terms"])
+            J.term_offsets, J.term_mle_idx, J.scalar_offsets = _p32(toff), _p32(tidx), _p32(soff)
+            J.mono_coeffs, J.mono_chal_offsets, J.mono_chal_idx = _p(mono_c), _p32(mono_off), _p32(mono_idx)
+            pi = np.ascontiguousarray(j.get("pi", []), dtype=np.uint64).reshape(-1, 2)
+            J.n_pi, J.pi = pi.shape[0], (_p(pi) if pi.shape[0] else None)
+            keep += [pi, mh, kinds, offs, nins, sids, sp_arrays, spp, nsp, snv, pts, ptp, toff, tidx, soff, mono_c, mono_off, mono_idx]
+
+
+def prove_batched_main_constraints(dev: Device, jobs, global_challenges, tr: Transcript, stream=None):
     """jobs: dicts with keys num_vars, mles (witness++fixed++structural, None allowed for replaced structural slots),
     n_witin, n_fixed, n_structural, selectors [(kind, offset, num_instances, structural_id, sparse_indices, sparse_num_vars, point)],
     n_exprs, max_degree, terms [[mle ids]], scalars [[(coeff_ext, [challenge ids])...] per term], optional pi [(c0, c1)...]
-    (public-instance values: challenge ids >= 2 + n_exprs select them).
+    (public-instance values: challenge ids >= 2 + n_exprs select them) — or a MainJobs built from such a list once.
     Returns (claimed_sum, msgs (n,d,2), global_rt (n,2), evals (total_mles,2))."""
     L = plib()
     L.ceno_prover_prove_batched_main_constraints.restype = C.c_int
-    arr = (MainJobC * len(jobs))()
-    keep = []
-    total_mles = 0
-    max_nv = max(j["num_vars"] for j in jobs)
-    max_deg = max(j["max_degree"] for j in jobs)
-    for c, j in enumerate(jobs):
-        J = arr[c]
-        J.circuit_idx, J.num_vars = j.get("circuit_idx", c), j["num_vars"]
-        J.n_witin, J.n_fixed, J.n_structural = j["n_witin"], j["n_fixed"], j["n_structural"]
-        mh = (C.c_void_p * len(j["mles"]))(*[(m.h if m is not None else None) for m in j["mles"]])
-        total_mles += len(j["mles"])
-        sels = j["selectors"]
-        ns = len(sels)
-        kinds = (C.c_int * max(ns, 1))(*[s[0] for s in sels])
-        offs = (C.c_size_t * max(ns, 1))(*[s[1] for s in sels])
-        nins = (C.c_size_t * max(ns, 1))(*[s[2] for s in sels])
-        sids = (C.c_int * max(ns, 1))(*[s[3] for s in sels])
-        sp_arrays = [np.array(list(s[4]) or [0], dtype=np.uint32) for s in sels]
-        spp = (u32p * max(ns, 1))(*[_p32(a) for a in sp_arrays])
-        nsp = (C.c_int * max(ns, 1))(*[len(s[4]) for s in sels])
-        snv = (C.c_int * max(ns, 1))(*[s[5] for s in sels])
-        pts = [np.ascontiguousarray(s[6], dtype=np.uint64) for s in sels]
-        ptp = (u64p * max(ns, 1))(*[_p(p) for p in pts])
-        toff, tidx = _csr(j["terms"])
-        soff = np.zeros(len(j["terms"]) + 1, dtype=np.uint32)
-        mono_c, mono_off, mono_idx = [], [0], []
-        for t, monos in enumerate(j["scalars"]):
-            for coeff, ids in monos:
-                mono_c.append([int(coeff[0]), int(coeff[1])])
-                mono_idx.extend(ids)
-                mono_off.append(len(mono_idx))
-            soff[t + 1] = len(mono_c)
-        mono_c = np.array(mono_c if mono_c else [[0, 0]], dtype=np.uint64)
-        mono_off = np.array(mono_off, dtype=np.uint32)
-        mono_idx = np.array(mono_idx if mono_idx else [0], dtype=np.uint32)
-        J.mles, J.n_selectors = mh, ns
-        J.sel_kind, J.sel_offset, J.sel_num_instances, J.sel_structural_id = kinds, offs, nins, sids
-        J.sel_sparse_indices, J.sel_n_sparse, J.sel_sparse_num_vars, J.sel_points = spp, nsp, snv, ptp
-        J.n_exprs, J.max_degree, J.n_terms = j["n_exprs"], j["max_degree"], len(j["terms"])
-        J.term_offsets, J.term_mle_idx, J.scalar_offsets = _p32(toff), _p32(tidx), _p32(soff)
-        J.mono_coeffs, J.mono_chal_offsets, J.mono_chal_idx = _p(mono_c), _p32(mono_off), _p32(mono_idx)
-        pi = np.ascontiguousarray(j.get("pi", []), dtype=np.uint64).reshape(-1, 2)
-        J.n_pi, J.pi = pi.shape[0], (_p(pi) if pi.shape[0] else None)
-        keep.append(pi)
-        keep += [mh, kinds, offs, nins, sids, sp_arrays, spp, nsp, snv, pts, ptp, toff, tidx, soff, mono_c, mono_off, mono_idx]
+    mj = jobs if isinstance(jobs, MainJobs) else MainJobs(jobs)
     gc = np.array([[int(global_challenges[0][0]), int(global_challenges[0][1])],
                    [int(global_challenges[1][0]), int(global_challenges[1][1])]], dtype=np.uint64)
     claimed = np.zeros(2, dtype=np.uint64)
-    msgs = np.zeros((max_nv, max_deg, 2), dtype=np.uint64)
-    rt = np.zeros((max_nv, 2), dtype=np.uint64)
-    evals = np.zeros((total_mles, 2), dtype=np.uint64)
+    msgs = np.zeros((mj.max_nv, mj.max_deg, 2), dtype=np.uint64)
+    rt = np.zeros((mj.max_nv, 2), dtype=np.uint64)
+    evals = np.zeros((mj.total_mles, 2), dtype=np.uint64)
     nv_o, d_o = C.c_int(), C.c_int()
-    _check(L.ceno_prover_prove_batched_main_constraints(dev.h, arr, len(jobs), _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
+    _check(L.ceno_prover_prove_batched_main_constraints(dev.h, mj.arr, mj.n, _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
                                                         _p(evals), C.byref(nv_o), C.byref(d_o)))
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
 

@@ -768,6 +768,71 @@ def test_sumcheck_random_plans_differential(dev, prover, seed):
     sc.free()
 
 
+@pytest.mark.parametrize("seed", range(28))
+def test_sumcheck_random_plans_lds_blocked_kernel(dev, prover, seed, monkeypatch):
+    """the LDS-blocked generic kernel (k_gen, csrc/sumcheck_gen.hip) forced onto small plans: 1-3 size classes, several
+    chips (connected components) per class with their own selectors, first rounds over base-field columns (the base-field
+    phase 2) or extension tables, terms without a group, groups with two common factors, tables no term reads (fold-only
+    components), small LDS budgets (tiles of 16 .. 256 pairs, 1 / 2 / 4 waves sharing a group's terms); pipelined host loop
+    and round-by-round driver against the oracle"""
+    import random
+
+    from ceno_amd import Sumcheck
+
+    rng = random.Random(4242 + seed)
+    monkeypatch.setenv("CENO_HIP_GEN_MIN_LOG", "1")
+    monkeypatch.setenv("CENO_HIP_GEN_PIPE_MIN_LOG", "0")
+    monkeypatch.setenv("CENO_HIP_GEN_STAGE_KB", str(rng.choice([2, 6, 16, 48])))
+    max_nv = rng.choice([4, 7, 9, 11, 13, 15])
+    n_classes = rng.choice([1, 1, 2, 3])
+    sizes = sorted({max_nv} | {rng.randint(2, max_nv) for _ in range(n_classes - 1)}, reverse=True)
+    d = rng.randint(2, 5)
+    all_base = rng.random() < 0.5   # witness columns in the base field: round 0 runs the base-field phase 2
+    tables, nvs, terms, groups = [], [], [], []
+    for nv in sizes:
+        for chip in range(rng.randint(1, 3)):
+            first = len(tables)
+            n_cols = rng.randint(1, 6)
+            for j in range(n_cols):
+                is_ext = (not all_base) and rng.random() < 0.5
+                tables.append(po.rand_ext(1 << nv, 31 * seed + len(tables)) if is_ext else po.rand_base(1 << nv, 31 * seed + len(tables)))
+                nvs.append(nv)
+            cols = list(range(first, first + n_cols))
+            n_sel = rng.choice([0, 1, 1, 2])
+            sels = []
+            for _ in range(n_sel):
+                sels.append(len(tables))
+                tables.append(po.rand_ext(1 << nv, 31 * seed + len(tables)))
+                nvs.append(nv)
+            if rng.random() < 0.3:   # a table nothing reads
+                tables.append(po.rand_base(1 << nv, 31 * seed + len(tables)))
+                nvs.append(nv)
+            for gi in range(max(1, n_sel)):
+                common = sels[: gi + 1] if (n_sel and rng.random() < 0.3) else (sels[gi: gi + 1] if n_sel else [])
+                members = []
+                for _ in range(rng.randint(1, 7)):
+                    room = d - len(common)
+                    if room < 1:
+                        break
+                    members.append(len(terms))
+                    terms.append([rng.choice(cols) for _ in range(rng.randint(1, room))])
+                if common and members:
+                    groups.append((common, members))
+    if not terms:
+        terms.append([0])
+    coeffs = po.rand_ext(len(terms), 7000 + seed)
+    msgs, chal, fin = _run_both(dev, prover, tables, coeffs, terms, max_nv, d, groups=groups or None, seed=seed + 3)
+    mles = [dev.upload(t) for t in tables]
+    sc = Sumcheck(dev, mles, coeffs, terms, max_nv, d, groups=groups or None)
+    ch = None
+    for i in range(max_nv):
+        m = sc.round(ch)
+        assert np.array_equal(m, msgs[i]), i
+        ch = tup(chal[i])
+    assert np.array_equal(sc.finish(ch), fin)
+    sc.free()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_tower_random_specs_differential(dev, prover, seed):
     """seeded random tower batches (0-3 product specs, 0-2 LogUp specs with or without numerators, heights 2-13 so that
