@@ -132,6 +132,13 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
     CHECK_ARG(ctx, n >= 0 && n <= 40, "eq: num_vars %d out of range", n);
     PointArg pt;
     for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
+    if (n <= 12 && sa.kind == CENO_HIP_SEL_WHOLE) {
+        // small unmasked tables (tower layers): the direct-product kernel writes the whole table — one launch instead of three
+        hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << n, NT, MAXB)), dim3(NT), 0, st, (E2*)dev_out, 0, n, pt, scalar);
+        HIP_TRY(ctx, hipGetLastError());
+        if (keep_tmp) *keep_tmp = nullptr;
+        return 0;
+    }
     int a = (n + 1) / 2, b = n - a;
     void* tmp = nullptr;
     TRY(ctx_alloc(ctx, (((size_t)1 << a) + ((size_t)1 << b)) * sizeof(E2), &tmp));

@@ -1026,7 +1026,9 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         __atomic_store_n(&sc->h_mailbox->abort, 1ull, __ATOMIC_RELEASE);  // queued kernels exit at their wait
         host_store_fence();
     }
-    (void)hipStreamSynchronize(sc->st);
+    // a finished sumcheck has nothing in flight (finish synchronised the stream after its last kernel): no second wait —
+    // it was ~20 us per tower layer
+    if (!sc->finished) (void)hipStreamSynchronize(sc->st);
     if (sc->pipelined && getenv("CENO_HIP_DEBUG") && sc->d_bcast) {
         static Bcast hb;
         if (hipMemcpy(&hb, sc->d_bcast, sizeof(Bcast), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1268,6 +1270,9 @@ static size_t gen_stage_bytes(size_t units, int tp_log) { return units * (((size
 static int sc_build_gen(ceno_hip_sumcheck* sc) {
     ceno_hip_ctx* ctx = sc->ctx;
     if (sc->n < gen_min_log()) return 0;
+    // a single class covering all variables runs pipelined (tower layers, one chip's main sumcheck), where k_gen is off unless
+    // CENO_HIP_GEN_PIPE_MIN_LOG asks for it: do not build tables nobody reads
+    if (sc->classes.size() == 1 && sc->classes[0].nv == sc->n && !getenv("CENO_HIP_GEN_PIPE_MIN_LOG")) return 0;
     bool any = false;
     for (auto& cl : sc->classes) any = any || (!cl.dense && cl.nv >= gen_min_log());
     if (!any) return 0;
