@@ -1,0 +1,81 @@
+//! Basefold commit and batch open over the device.
+//! Reference: `cuda_hal.basefold.{batch_commit, get_pure_commitment, get_trace, batch_open}`
+//! (`ceno_zkvm/src/scheme/gpu/mod.rs:1642-1646,1717-1720,3401-3402`); traits `TraceCommitter::commit_traces`
+//! (`scheme/hal.rs:137-156`) and `OpeningProver::open` (`:284-294`).  PARITY UNPINNED against the reference's `mpcs` crate
+//! (Poseidon2 constants, mixed-height MMCS, query derivation): see DESIGN.md section 5.
+use std::{ptr, sync::Arc};
+
+use ceno_hip_sys as sys;
+
+use crate::{error::Result, hal::HipHal, hal::HipStream, mle::HipMle, ExtWords};
+
+/// committed traces: column-major trace, codewords and Merkle tree per matrix (`PcsData`)
+pub struct HipPcsData {
+    hal: Arc<HipHal>,
+    raw: *mut sys::ceno_pcs_data,
+    pub widths: Vec<usize>,
+}
+unsafe impl Send for HipPcsData {}
+unsafe impl Sync for HipPcsData {}
+
+impl HipPcsData {
+    /// `commit_traces`: row-major host matrices (`RowMajorMatrix::values`, `num_instances` rows each), padded to
+    /// `next_pow2_instance_padding`, transposed, RS-encoded (blow-up `2^log_blowup`), row-hashed, Merkle-committed
+    pub fn commit(hal: &Arc<HipHal>, matrices: &[(&[u64], usize, usize)], log_blowup: usize, stream: &HipStream) -> Result<Self> {
+        let ptrs: Vec<*const u64> = matrices.iter().map(|m| m.0.as_ptr()).collect();
+        let rows: Vec<usize> = matrices.iter().map(|m| m.1).collect();
+        let widths: Vec<usize> = matrices.iter().map(|m| m.2).collect();
+        let mut d = ptr::null_mut();
+        hal.check_prover(unsafe {
+            sys::ceno_prover_commit_traces(hal.ctx, ptrs.as_ptr(), rows.as_ptr(), widths.as_ptr(), matrices.len() as i32, log_blowup as i32, stream.raw(), &mut d)
+        })?;
+        Ok(Self { hal: hal.clone(), raw: d, widths })
+    }
+    /// same with device-resident row-major matrices (witness generated on the GPU: `device_backing_layout`)
+    ///
+    /// # Safety
+    /// every pointer must reference `rows * width` device words that stay valid for the call.
+    pub unsafe fn commit_device(hal: &Arc<HipHal>, matrices: &[(*const u64, usize, usize)], log_blowup: usize, stream: &HipStream) -> Result<Self> {
+        let ptrs: Vec<*const u64> = matrices.iter().map(|m| m.0).collect();
+        let rows: Vec<usize> = matrices.iter().map(|m| m.1).collect();
+        let widths: Vec<usize> = matrices.iter().map(|m| m.2).collect();
+        let mut d = ptr::null_mut();
+        hal.check_prover(sys::ceno_prover_commit_traces_dev(hal.ctx, ptrs.as_ptr(), rows.as_ptr(), widths.as_ptr(), matrices.len() as i32,
+                                                            log_blowup as i32, stream.raw(), &mut d))?;
+        Ok(Self { hal: hal.clone(), raw: d, widths })
+    }
+    pub fn num_vars(&self, matrix: usize) -> usize {
+        unsafe { sys::ceno_pcs_data_num_vars(self.raw, matrix as i32) as usize }
+    }
+    /// `get_pure_commitment`: the Merkle root of matrix `matrix` (4 base-field words)
+    pub fn root(&self, matrix: usize, stream: &HipStream) -> Result<[u64; 4]> {
+        let mut r = [0u64; 4];
+        self.hal.check_prover(unsafe { sys::ceno_pcs_data_root(self.hal.ctx, self.raw, matrix as i32, r.as_mut_ptr(), stream.raw()) })?;
+        Ok(r)
+    }
+    /// `get_arc_mle_witness_from_commitment`: borrowed base-field view of one column (nothing is copied)
+    pub fn witness_mle(self: &Arc<Self>, matrix: usize, col: usize) -> Result<HipMle> {
+        let mut m = ptr::null_mut();
+        self.hal.check_prover(unsafe { sys::ceno_pcs_data_witness_mle(self.hal.ctx, self.raw, matrix as i32, col, &mut m) })?;
+        Ok(HipMle::from_raw(&self.hal, m))
+    }
+    /// `PCS::batch_open`: every matrix at its own point with the claimed column evaluations; flat proof words (layout:
+    /// `include/ceno_prover.h`)
+    pub fn batch_open(&self, points: &[Vec<ExtWords>], evals: &[Vec<ExtWords>], n_queries: usize, pow_bits: usize,
+                      transcript: *mut sys::ceno_transcript, stream: &HipStream) -> Result<Vec<u64>> {
+        let pp: Vec<*const u64> = points.iter().map(|p| p.as_ptr() as *const u64).collect();
+        let ep: Vec<*const u64> = evals.iter().map(|e| e.as_ptr() as *const u64).collect();
+        let words = unsafe { sys::ceno_prover_basefold_proof_words(self.raw, n_queries as i32) };
+        let mut proof = vec![0u64; words];
+        self.hal.check_prover(unsafe {
+            sys::ceno_prover_basefold_open(self.hal.ctx, self.raw, pp.as_ptr(), ep.as_ptr(), n_queries as i32, pow_bits as i32, transcript, stream.raw(),
+                                           proof.as_mut_ptr())
+        })?;
+        Ok(proof)
+    }
+}
+impl Drop for HipPcsData {
+    fn drop(&mut self) {
+        unsafe { sys::ceno_pcs_data_free(self.hal.ctx, self.raw) };
+    }
+}

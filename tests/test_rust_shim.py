@@ -1,0 +1,162 @@
+"""The Rust side of the boundary (rust/) cannot be compiled in this image (no rustc): check it mechanically instead.
+
+* every prototype of include/ceno_hip.h and include/ceno_prover.h has exactly one `extern "C"` declaration in
+  rust/ceno_hip-sys/src/lib.rs with the same arity and the same width class for every argument and the result
+  (pointer / 32-bit / 64-bit / usize / f64), and the Rust file declares nothing the headers do not;
+* every non-opaque C struct has a `#[repr(C)]` Rust struct with the same fields in the same order and widths;
+* enum constants and #defines agree;
+* the generated file is up to date with the headers (tools/gen_rust_sys.py);
+* the safe crate and the in-tree arms only call FFI items that exist, the ten ProverDevice traits plus the gkr_iop traits
+  all have an `impl .. for HipProver` / `HipBackend`, and the patch names the cfg arm of create_backend / create_prover.
+The Rust parser below is independent of the generator (tools/cabi.py is only used for the C side)."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import cabi  # noqa: E402
+
+SYS_RS = os.path.join(ROOT, "rust", "ceno_hip-sys", "src", "lib.rs")
+
+
+def rust_width(t: str) -> str:
+    t = t.strip()
+    if t.startswith("*") or t.startswith("Option<unsafe extern") or t in ("ceno_hip_stream", "ceno_lane_task_fn"):
+        return "ptr"
+    m = re.match(r"^\[(.+);\s*(\d+)\]$", t)
+    if m:
+        return "[%s;%s]" % (rust_width(m.group(1)), m.group(2))
+    return {"c_int": "i32", "c_uint": "u32", "u32": "u32", "u64": "u64", "usize": "usize", "f64": "f64", "u8": "u8", "u16": "u16",
+            "c_char": "i8", "i32": "i32"}.get(t, "struct:" + t)
+
+
+def split_top(s: str):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "(<[":
+            depth += 1
+        if ch in ")>]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out]
+
+
+def parse_rust(path=SYS_RS):
+    text = open(path).read()
+    text = re.sub(r"//[^\n]*", "", text)
+    fns = {}
+    for block in re.finditer(r'extern\s+"C"\s*\{(.*?)\n\}', text, flags=re.S):
+        for m in re.finditer(r"pub fn (\w+)\((.*?)\)\s*(?:->\s*([^;]+))?;", block.group(1), flags=re.S):
+            args = [a.split(":", 1)[1].strip() for a in split_top(m.group(2))]
+            assert m.group(1) not in fns, f"{m.group(1)} declared twice"
+            fns[m.group(1)] = (args, (m.group(3) or "()").strip())
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:#\[derive\([^)]*\)\]\s*)?pub struct (\w+)\s*\{(.*?)\n\}", text, flags=re.S):
+        fields = []
+        for f in split_top(m.group(2)):
+            f = f.strip()
+            if not f or f.startswith("_private"):
+                continue
+            name, ty = f.replace("pub ", "", 1).split(":", 1)
+            fields.append((name.strip(), ty.strip()))
+        structs[m.group(1)] = fields
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+): \w+ = (-?\d+);", text)}
+    return fns, structs, consts
+
+
+def c_width(t: cabi.CType) -> str:
+    w = t.width_class(typedef_ptrs=("ceno_hip_stream", "ceno_lane_task_fn"))
+    if t.array is not None and not t.is_ptr:
+        return "[%s;%d]" % (w, t.array)
+    if t.array is not None:
+        return "[ptr;%d]" % t.array
+    return w
+
+
+def test_generated_bindings_are_up_to_date():
+    before = open(SYS_RS).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py")], stdout=subprocess.DEVNULL)
+    assert open(SYS_RS).read() == before, "rust/ceno_hip-sys/src/lib.rs is stale: run python tools/gen_rust_sys.py"
+
+
+def test_every_prototype_agrees_in_name_arity_and_width():
+    protos, *_ = cabi.parse_headers()
+    fns, _, _ = parse_rust()
+    assert len(protos) >= 115
+    assert set(fns) == set(protos), sorted(set(fns) ^ set(protos))
+    for name, p in protos.items():
+        args, ret = fns[name]
+        assert len(args) == len(p.args), f"{name}: arity {len(args)} != {len(p.args)}"
+        for i, ((an, ct), rt) in enumerate(zip(p.args, args)):
+            assert rust_width(rt) == c_width(ct), f"{name} arg {i} ({an}): rust {rt} vs C {ct}"
+            if ct.ptr_const:  # constness of the outermost pointee
+                assert rt.startswith("*const" if ct.ptr_const[-1] else "*mut"), f"{name} arg {i}: pointer constness"
+        c_ret = "void" if (p.ret.base == "void" and not p.ret.is_ptr) else c_width(p.ret)
+        assert (ret == "()" and c_ret == "void") or rust_width(ret) == c_ret, f"{name}: return {ret} vs {p.ret}"
+
+
+def test_structs_enums_and_defines_agree():
+    _, structs, enums, defines, _, _ = cabi.parse_headers()
+    _, rstructs, consts = parse_rust()
+    for name, s in structs.items():
+        assert name in rstructs, f"struct {name} missing on the Rust side"
+        if s.opaque:
+            assert rstructs[name] == [], f"{name} must stay opaque"
+            continue
+        rf = rstructs[name]
+        assert len(rf) == len(s.fields), f"{name}: {len(rf)} fields vs {len(s.fields)}"
+        for (cn, ct), (rn, rt) in zip(s.fields, rf):
+            assert rn.rstrip("_") == cn, f"{name}: field order {rn} vs {cn}"
+            cw = "ptr" if (ct.fn is not None or ct.base == "ceno_lane_task_fn") else c_width(ct)
+            assert rust_width(rt) == cw or (cw.startswith("struct:") and rt == cw[7:]), f"{name}.{cn}: rust {rt} vs C {ct}"
+    for vals in enums.values():
+        for k, v in vals:
+            assert consts[k] == v
+    for k, v in defines.items():
+        assert consts[k] == v
+
+
+def _ffi_uses(path):
+    text = re.sub(r"//[^\n]*", "", open(path).read())
+    return set(re.findall(r"\bsys::(ceno_\w+)\s*[({]", text)) | set(re.findall(r"\bsys::(ceno_\w+)\b", text))
+
+
+def test_safe_crate_and_arms_reference_only_existing_items_and_cover_every_trait():
+    fns, rstructs, consts = parse_rust()
+    known = set(fns) | set(rstructs) | {"ceno_hip_stream", "ceno_lane_task_fn", "ceno_hip_status", "ceno_hip_selector_kind"} | set(consts)
+    src_dir = os.path.join(ROOT, "rust", "ceno_hip", "src")
+    used = set()
+    for f in os.listdir(src_dir):
+        used |= _ffi_uses(os.path.join(src_dir, f))
+    arms = [os.path.join(ROOT, "rust", "patches", p) for p in
+            ("gkr_iop/src/hip/mod.rs", "gkr_iop/src/gkr/layer/hip/mod.rs", "ceno_zkvm/src/scheme/hip/mod.rs")]
+    for a in arms:
+        used |= _ffi_uses(a)
+    unknown = sorted(u for u in used if u not in known and not u.startswith("CENO_"))
+    assert unknown == [], f"FFI items used but not declared: {unknown}"
+    # sumcheck, tower, commit, open, chip proof and lanes are all reachable from the safe crate
+    for must in ("ceno_hip_sumcheck_begin", "ceno_hip_sumcheck_round", "ceno_hip_sumcheck_finish", "ceno_hip_tower_layer_sumcheck_begin",
+                 "ceno_prover_commit_traces", "ceno_prover_basefold_open", "ceno_prover_create_chip_proof", "ceno_prover_lanes_run",
+                 "ceno_hip_selector_build", "ceno_hip_wit_infer", "ceno_hip_mle_free", "ceno_hip_mem_book"):
+        assert must in used, must
+    zk = open(arms[2]).read()
+    for trait in ("TraceCommitter", "TowerProver", "MainSumcheckProver", "BatchedMainConstraintProver", "OpeningProver", "DeviceTransporter",
+                  "EccQuarkProver", "RotationProver", "ChipInputPreparer", "ProverDevice"):  # ceno_zkvm/src/scheme/hal.rs:19-35
+        assert re.search(r"impl<[^{]*>\s*%s<PB<E, PCS>>\s*for\s*HipProver<PB<E, PCS>>" % trait, zk), trait
+    gk = open(arms[0]).read() + open(arms[1]).read()
+    for trait in ("ProverBackend for HipBackend", "ProverDevice<HipBackend<E, PCS>> for HipProver", "ProtocolWitnessGeneratorProver<HipBackend<E, PCS>> for HipProver",
+                  "LinearLayerProver<HipBackend<E, PCS>> for HipProver", "SumcheckLayerProver<HipBackend<E, PCS>> for HipProver",
+                  "ZerocheckLayerProver<HipBackend<E, PCS>> for HipProver", "MultilinearPolynomial<E> for MultilinearExtensionHip"):
+        assert re.sub(r"\s+", " ", trait) in re.sub(r"\s+", " ", gk), trait
+    assert "impl Drop for HipMle" in open(os.path.join(src_dir, "mle.rs")).read()
+    patch = open(os.path.join(ROOT, "rust", "patches", "0001-hip-backend.patch")).read()
+    for needle in ('#[cfg(feature = "hip")]', "pub fn create_backend", "pub fn create_prover", "gkr_iop::hip::HipBackend", "e2e.rs"):
+        assert needle in patch, needle
