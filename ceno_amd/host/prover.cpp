@@ -74,6 +74,13 @@ extern "C" {
 void ceno_transcript_append_label(ceno_transcript* t, const uint8_t* bytes, size_t n) { t->append_label(t->self, bytes, n); }
 void ceno_transcript_append_ext(ceno_transcript* t, const uint64_t* e2) { t->append_ext(t->self, e2); }
 void ceno_transcript_sample_ext(ceno_transcript* t, uint64_t* out2) { t->sample_ext(t->self, out2); }
+void ceno_transcript_append_base(ceno_transcript* t, uint64_t v) {
+    if (t->append_base) t->append_base(t->self, v);
+    else {  // a transcript without the entry: a base element is the extension element (v, 0)?  No — it is ONE observed element.
+        const uint8_t* b = reinterpret_cast<const uint8_t*>(&v);
+        t->append_label(t->self, b, 8);  // 8 little-endian bytes pack into exactly one field element
+    }
+}
 void ceno_transcript_free(ceno_transcript* t) {
     if (!t) return;
     if (t->destroy) t->destroy(t->self);

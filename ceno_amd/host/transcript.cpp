@@ -43,6 +43,11 @@ void stub_sample(void* self, uint64_t* o) {
     o[1] = st->s >= gl::P ? st->s - gl::P : st->s;
 }
 void stub_destroy(void* self) { delete (Stub*)self; }
+void stub_base(void* self, uint64_t v) {
+    auto* st = (Stub*)self;
+    st->absorb(0x4241534500000000ULL);  // "BASE"
+    st->absorb(v);
+}
 
 }  // namespace
 
@@ -53,6 +58,7 @@ extern "C" ceno_transcript* ceno_transcript_stub_new(uint64_t seed) {
     t->append_ext = stub_ext;
     t->sample_ext = stub_sample;
     t->destroy = stub_destroy;
+    t->append_base = stub_base;
     return t;
 }
 
@@ -182,6 +188,7 @@ void dx_sample(void* self, uint64_t* o) {
     o[1] = d->sample();
 }
 void dx_destroy(void* self) { delete (Duplex*)self; }
+void dx_base(void* self, uint64_t v) { ((Duplex*)self)->observe(v % gl::P); }
 
 }  // namespace
 
@@ -236,8 +243,21 @@ extern "C" ceno_transcript* ceno_transcript_poseidon2_new(const uint8_t* label, 
     t->append_ext = dx_ext;
     t->sample_ext = dx_sample;
     t->destroy = dx_destroy;
+    t->append_base = dx_base;
     if (label && n) dx_label(d, label, n);  // BasicTranscript::new(label) absorbs the label
     return t;
+}
+
+// label packing as the host challenger does it (tests/test_ref_goldens.py compares it with the reference's bytes_to_field_elements)
+extern "C" int ceno_prover_test_label_to_field(const uint8_t* bytes, size_t n, uint64_t* out, int max_out) {
+    int k = 0;
+    for (size_t i = 0; i < n; i += 8) {
+        uint64_t w = 0;
+        for (size_t j = 0; j < 8 && i + j < n; j++) w |= (uint64_t)bytes[i + j] << (8 * j);
+        if (k < max_out) out[k] = w % gl::P;
+        k++;
+    }
+    return k;
 }
 
 // host permutation for tests of the shared poseidon2.cuh source

@@ -42,6 +42,8 @@ def plib():
     L.ceno_transcript_append_ext.argtypes = [vp, u64p]
     L.ceno_transcript_sample_ext.restype = None
     L.ceno_transcript_sample_ext.argtypes = [vp, u64p]
+    L.ceno_transcript_append_base.restype = None
+    L.ceno_transcript_append_base.argtypes = [vp, C.c_uint64]
     L.ceno_prover_sumcheck_prove.restype = i
     L.ceno_prover_sumcheck_prove.argtypes = [vp, vpp, C.POINTER(SumcheckPlan), vp, vp, u64p, u64p, u64p]
     L.ceno_prover_sumcheck_run.restype = i
@@ -135,6 +137,9 @@ class Transcript:
         o = np.zeros(2, dtype=np.uint64)
         plib().ceno_transcript_sample_ext(self.h, _p(o))
         return int(o[0]), int(o[1])
+
+    def append_base(self, v: int):
+        plib().ceno_transcript_append_base(self.h, C.c_uint64(int(v)))
 
     def __del__(self):
         try:

@@ -29,6 +29,7 @@ typedef struct ceno_transcript {
     void (*sample_ext)(void* self, uint64_t* out2);
     void* self;
     void (*destroy)(void* self);
+    void (*append_base)(void* self, uint64_t v);   /* `append_field_element` (instance counts, circuit ids: prover.rs:682-689) */
 } ceno_transcript;
 
 /* deterministic data-dependent stand-in (SplitMix64 chaining) — identical to the oracle's stub so
@@ -48,6 +49,7 @@ void ceno_transcript_free(ceno_transcript* t);
 /* convenience for bindings that cannot call through the function-pointer table */
 void ceno_transcript_append_label(ceno_transcript* t, const uint8_t* bytes, size_t n);
 void ceno_transcript_append_ext(ceno_transcript* t, const uint64_t* e2);
+void ceno_transcript_append_base(ceno_transcript* t, uint64_t v);
 void ceno_transcript_sample_ext(ceno_transcript* t, uint64_t* out2);
 
 /* IOPProverState::prove: appends n and d (usize le-bytes), then per round the d evaluations and

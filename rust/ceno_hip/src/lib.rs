@@ -33,6 +33,8 @@ pub trait FsTranscript {
     fn append_bytes(&mut self, bytes: &[u8]);
     /// `Transcript::append_field_element_ext(e)`
     fn append_ext(&mut self, e: ExtWords);
+    /// `Transcript::append_field_element(b)` (one base-field element)
+    fn append_base(&mut self, b: u64);
     /// `Transcript::read_challenge().elements`
     fn sample(&mut self) -> ExtWords;
     /// `Transcript::sample_and_append_challenge(label).elements` = `append_message(label)` then `read_challenge()`

@@ -34,8 +34,12 @@ impl<'a, T: FsTranscript> CTranscript<'a, T> {
             *o = r[0];
             *o.add(1) = r[1];
         }
+        unsafe extern "C" fn base<T: FsTranscript>(s: *mut c_void, v: u64) {
+            (*(s as *mut T)).append_base(v);
+        }
         Self {
-            table: sys::ceno_transcript { append_label: Some(label::<T>), append_ext: Some(ext::<T>), sample_ext: Some(sample::<T>), self_: t as *mut T as *mut c_void, destroy: None },
+            table: sys::ceno_transcript { append_label: Some(label::<T>), append_ext: Some(ext::<T>), sample_ext: Some(sample::<T>), self_: t as *mut T as *mut c_void,
+                                          destroy: None, append_base: Some(base::<T>) },
             _borrow: PhantomData,
         }
     }

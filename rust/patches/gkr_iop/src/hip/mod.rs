@@ -66,6 +66,9 @@ impl<'a, E: ExtensionField, T: Transcript<E>> FsTranscript for TranscriptAdapter
     fn append_ext(&mut self, e: ExtWords) {
         self.0.append_field_element_ext(&words_ext::<E>(&e));
     }
+    fn append_base(&mut self, b: u64) {
+        self.0.append_field_element(&E::BaseField::from_canonical_u64(b));
+    }
     fn sample(&mut self) -> ExtWords {
         ext_words(&self.0.read_challenge().elements)
     }
