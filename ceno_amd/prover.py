@@ -595,6 +595,107 @@ def prove_batched_main_constraints(dev: Device, jobs, global_challenges, tr: Tra
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
 
 
+class EvalExprC(C.Structure):
+    _fields_ = [("kind", C.c_int), ("idx", C.c_int), ("c0", C.c_uint64 * 2), ("c1", C.c_uint64 * 2)]
+
+
+class GkrLayerC(C.Structure):
+    _fields_ = [("type", C.c_int), ("num_vars", C.c_int), ("n_witin", C.c_int), ("n_fixed", C.c_int), ("n_structural", C.c_int),
+                ("mles", C.POINTER(C.c_void_p)), ("n_groups", C.c_int), ("group_sel_kind", C.POINTER(C.c_int)),
+                ("group_sel_structural_id", C.POINTER(C.c_int)), ("group_sel_offset", C.POINTER(C.c_size_t)),
+                ("group_sel_num_instances", C.POINTER(C.c_size_t)), ("group_sel_sparse_indices", C.POINTER(u32p)),
+                ("group_sel_n_sparse", C.POINTER(C.c_int)), ("group_sel_sparse_num_vars", C.POINTER(C.c_int)), ("group_expr_offsets", u32p),
+                ("out_exprs", C.POINTER(EvalExprC)), ("n_exprs", C.c_int), ("max_degree", C.c_int), ("n_terms", C.c_int),
+                ("term_offsets", u32p), ("term_mle_idx", u32p), ("scalar_offsets", u32p), ("mono_coeffs", u64p),
+                ("mono_chal_offsets", u32p), ("mono_chal_idx", u32p), ("n_in_evals", C.c_int), ("in_eval_pos", C.POINTER(C.c_int))]
+
+
+LAYER_ZEROCHECK, LAYER_LINEAR, LAYER_SUMCHECK = 0, 1, 2
+
+
+def gkr_prove(dev: Device, layers: Sequence[dict], max_num_vars: int, claims: Sequence, pub_io, challenges, tr: Transcript, stream=None):
+    """GKRCircuit::prove (gkr_iop/src/gkr.rs:72-115).  layers (output side first): dicts with type, num_vars, mles (witin ++ fixed ++
+    structural, None for selector slots), n_witin, n_fixed, n_structural, groups [(selector | None, [exprs])] with selector =
+    (kind, structural_id, offset, num_instances, sparse_indices, sparse_num_vars) and expr = ("zero",) | ("single", idx) |
+    ("linear", idx, c0, c1), n_exprs, max_degree, terms, scalars (as in prove_batched_main_constraints), in_eval_pos.
+    claims: [(point (k,2) or None, eval)] per evaluation slot.
+    Returns ([(msgs, evals, point)] per layer, final claims [(point, eval)])."""
+    L = plib()
+    L.ceno_prover_gkr_prove.restype = C.c_int
+    arr = (GkrLayerC * len(layers))()
+    keep, outs = [], []
+    for li, ly in enumerate(layers):
+        G = arr[li]
+        n_m = len(ly["mles"])
+        mh = (C.c_void_p * n_m)(*[(m.h if m is not None else None) for m in ly["mles"]])
+        groups = ly["groups"]
+        ng = len(groups)
+        kinds = (C.c_int * ng)(*[(g[0][0] if g[0] is not None else -1) for g in groups])
+        sids = (C.c_int * ng)(*[(g[0][1] if g[0] is not None else 0) for g in groups])
+        offs = (C.c_size_t * ng)(*[(g[0][2] if g[0] is not None else 0) for g in groups])
+        nins = (C.c_size_t * ng)(*[(g[0][3] if g[0] is not None else 0) for g in groups])
+        sp_arrays = [np.array(list(g[0][4]) or [0], dtype=np.uint32) if g[0] is not None else np.zeros(1, dtype=np.uint32) for g in groups]
+        spp = (u32p * ng)(*[_p32(a) for a in sp_arrays])
+        nsp = (C.c_int * ng)(*[(len(g[0][4]) if g[0] is not None else 0) for g in groups])
+        snv = (C.c_int * ng)(*[(g[0][5] if g[0] is not None else 0) for g in groups])
+        eoff = np.zeros(ng + 1, dtype=np.uint32)
+        flat = []
+        for gi, g in enumerate(groups):
+            flat += list(g[1])
+            eoff[gi + 1] = len(flat)
+        exprs = (EvalExprC * max(1, len(flat)))()
+        for k, e in enumerate(flat):
+            exprs[k].kind = {"zero": 0, "single": 1, "linear": 2}[e[0]]
+            exprs[k].idx = e[1] if len(e) > 1 else 0
+            if e[0] == "linear":
+                exprs[k].c0[0], exprs[k].c0[1] = int(e[2][0]), int(e[2][1])
+                exprs[k].c1[0], exprs[k].c1[1] = int(e[3][0]), int(e[3][1])
+        terms = ly.get("terms", [])
+        toff, tidx = _csr(terms)
+        soff = np.zeros(len(terms) + 1, dtype=np.uint32)
+        mono_c, mono_off, mono_idx = [], [0], []
+        for t, monos in enumerate(ly.get("scalars", [])):
+            for coeff, ids in monos:
+                mono_c.append([int(coeff[0]), int(coeff[1])])
+                mono_idx.extend(ids)
+                mono_off.append(len(mono_idx))
+            soff[t + 1] = len(mono_c)
+        mono_c = np.array(mono_c if mono_c else [[0, 0]], dtype=np.uint64)
+        mono_off = np.array(mono_off, dtype=np.uint32)
+        mono_idx = np.array(mono_idx if mono_idx else [0], dtype=np.uint32)
+        inpos = (C.c_int * max(1, len(ly["in_eval_pos"])))(*ly["in_eval_pos"])
+        G.type, G.num_vars = ly["type"], ly["num_vars"]
+        G.n_witin, G.n_fixed, G.n_structural, G.mles = ly["n_witin"], ly["n_fixed"], ly["n_structural"], mh
+        G.n_groups, G.group_sel_kind, G.group_sel_structural_id, G.group_sel_offset, G.group_sel_num_instances = ng, kinds, sids, offs, nins
+        G.group_sel_sparse_indices, G.group_sel_n_sparse, G.group_sel_sparse_num_vars = spp, nsp, snv
+        G.group_expr_offsets, G.out_exprs = _p32(eoff), exprs
+        G.n_exprs, G.max_degree, G.n_terms = ly.get("n_exprs", 0), ly.get("max_degree", 1), len(terms)
+        G.term_offsets, G.term_mle_idx, G.scalar_offsets = _p32(toff), _p32(tidx), _p32(soff)
+        G.mono_coeffs, G.mono_chal_offsets, G.mono_chal_idx = _p(mono_c), _p32(mono_off), _p32(mono_idx)
+        G.n_in_evals, G.in_eval_pos = len(ly["in_eval_pos"]), inpos
+        keep += [mh, kinds, sids, offs, nins, sp_arrays, spp, nsp, snv, eoff, exprs, toff, tidx, soff, mono_c, mono_off, mono_idx, inpos]
+        nv, d = ly["num_vars"], ly.get("max_degree", 1)
+        outs.append((np.zeros((max(nv, 1), d, 2), dtype=np.uint64), np.zeros((n_m, 2), dtype=np.uint64), np.zeros((max(nv, 1), 2), dtype=np.uint64)))
+    n_ev = len(claims)
+    pts = [np.ascontiguousarray(c[0], dtype=np.uint64).reshape(-1, 2) if c[0] is not None else np.zeros((0, 2), dtype=np.uint64) for c in claims]
+    cp = (u64p * n_ev)(*[(_p(p) if p.shape[0] else None) for p in pts])
+    cl = (C.c_int * n_ev)(*[p.shape[0] for p in pts])
+    ce = np.array([[int(c[1][0]), int(c[1][1])] for c in claims], dtype=np.uint64)
+    pio = np.ascontiguousarray(pub_io, dtype=np.uint64).reshape(-1, 2)
+    gc = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
+    om = (u64p * len(layers))(*[_p(o[0]) for o in outs])
+    oe = (u64p * len(layers))(*[_p(o[1]) for o in outs])
+    op = (u64p * len(layers))(*[_p(o[2]) for o in outs])
+    ocp = np.zeros((n_ev, max(max_num_vars, 1), 2), dtype=np.uint64)
+    ocl = (C.c_int * n_ev)()
+    oce = np.zeros((n_ev, 2), dtype=np.uint64)
+    _check(L.ceno_prover_gkr_prove(dev.h, arr, len(layers), max_num_vars, n_ev, cp, cl, _p(ce), _p(pio) if pio.shape[0] else None, pio.shape[0], _p(gc),
+                                   tr.h, stream, om, oe, op, _p(ocp), ocl, _p(oce)))
+    res = [(o[0][: ly["num_vars"]], o[1], o[2][: ly["num_vars"]]) for o, ly in zip(outs, layers)]
+    final = [(ocp[i, : ocl[i]].copy() if ocl[i] else None, (int(oce[i, 0]), int(oce[i, 1]))) for i in range(n_ev)]
+    return res, final
+
+
 class TowerWitnessC(C.Structure):
     _fields_ = [("prod", C.c_void_p * 2), ("n_prod", C.c_int), ("logup", C.c_void_p * 1), ("n_logup", C.c_int),
                 ("has_r", C.c_int), ("has_w", C.c_int), ("has_lk", C.c_int),

@@ -222,6 +222,67 @@ int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_mai
                                                ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
                                                uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree);
 
+/* ---- multi-layer GKR circuit (a13) ----
+ * GKRCircuit::prove (gkr_iop/src/gkr.rs:72-115): the running claims (`PointAndEval` per evaluation slot) start from the
+ * circuit's out-evaluations; every layer, output side first, (1) reads its claims: per out-evaluation group the claimed values
+ * and the group's point (Layer::extract_claim_and_point, gkr/layer.rs:289-313), (2) is proved by its layer prover
+ * (gkr/layer.rs:198-243): ZEROCHECK = ZerocheckLayerProver::prove (gkr/layer/cpu/mod.rs:102-238: alpha powers, selector eq
+ * tables at the group points, one sumcheck, final evaluations appended), LINEAR = LinearLayerProver::prove
+ * (gkr/layer/cpu/mod.rs:47-66: no sumcheck, the witness evaluations at the out point), SUMCHECK = SumcheckLayerProver::prove
+ * (gkr/layer/cpu/mod.rs:72-96: plain sumcheck of the layer expression), (3) writes its final evaluations back into the
+ * claims at `in_eval_pos` with the layer's point (Layer::update_claims, gkr/layer.rs:315-322).
+ * The keccak-style harness proves the rotation argument FIRST and feeds its left / right / target evaluations in as
+ * out-evaluations (ceno_zkvm/src/precompiles/lookup_keccakf.rs:1338-1397); ceno_prover_prove_rotation is that step. */
+typedef enum ceno_layer_type { CENO_LAYER_ZEROCHECK = 0, CENO_LAYER_LINEAR = 1, CENO_LAYER_SUMCHECK = 2 } ceno_layer_type;
+/* EvalExpression (gkr_iop/src/evaluation.rs:17-93) with its coefficient expressions already evaluated at the challenges:
+ * ZERO (claim 0 at the point of slot 0), SINGLE (claims[idx]), LINEAR (claims[idx] * c0 + c1).  Partition is not supported. */
+typedef enum ceno_eval_kind { CENO_EVAL_ZERO = 0, CENO_EVAL_SINGLE = 1, CENO_EVAL_LINEAR = 2 } ceno_eval_kind;
+typedef struct ceno_eval_expr {
+    int kind;
+    int idx;
+    uint64_t c0[2], c1[2];
+} ceno_eval_expr;
+typedef struct ceno_gkr_layer {
+    int type;                              /* ceno_layer_type */
+    int num_vars;                          /* variables of the layer's tables */
+    int n_witin, n_fixed, n_structural;
+    ceno_hip_mle* const* mles;             /* witin ++ fixed ++ structural (a selector's structural slot may be NULL) */
+    /* out-evaluation groups (layer.out_sel_and_eval_exprs): selector + the claims it gates */
+    int n_groups;
+    const int* group_sel_kind;             /* ceno_hip_selector_kind, or -1 = SelectorType::None */
+    const int* group_sel_structural_id;
+    const size_t* group_sel_offset;
+    const size_t* group_sel_num_instances;
+    const uint32_t* const* group_sel_sparse_indices;
+    const int* group_sel_n_sparse;
+    const int* group_sel_sparse_num_vars;
+    const uint32_t* group_expr_offsets;    /* n_groups + 1 -> out_exprs */
+    const ceno_eval_expr* out_exprs;
+    /* main sumcheck expression in monomial form, scalars as in ceno_main_job (challenge list: the two global challenges,
+     * then alpha powers [ZEROCHECK only, n_exprs of them], then pub_io) */
+    int n_exprs;
+    int max_degree;
+    int n_terms;
+    const uint32_t* term_offsets;
+    const uint32_t* term_mle_idx;
+    const uint32_t* scalar_offsets;
+    const uint64_t* mono_coeffs;
+    const uint32_t* mono_chal_offsets;
+    const uint32_t* mono_chal_idx;
+    /* claim slots that receive this layer's final evaluations, in MLE order (layer.in_eval_expr) */
+    int n_in_evals;
+    const int* in_eval_pos;
+} ceno_gkr_layer;
+/* claims: n_evaluations slots; claim_points[i] has claim_point_len[i] ext elements (0 = slot not set yet), claim_evals 2 words
+ * per slot.  Outputs per layer l: msgs at out_msgs[l] (num_vars * max_degree ext; nothing for LINEAR), the evaluations of all
+ * the layer's MLEs at out_evals[l], the layer's point at out_points[l] (num_vars ext); out_claim_* receive the final claims
+ * (points padded to max_num_vars ext per slot, lengths in out_claim_point_len). */
+int ceno_prover_gkr_prove(ceno_hip_ctx* ctx, const ceno_gkr_layer* layers, int n_layers, int max_num_vars, int n_evaluations,
+                          const uint64_t* const* claim_points, const int* claim_point_len, const uint64_t* claim_evals,
+                          const uint64_t* pub_io, int n_pub_io, const uint64_t* challenges4, ceno_transcript* tr, ceno_hip_stream s,
+                          uint64_t* const* out_msgs, uint64_t* const* out_evals, uint64_t* const* out_points,
+                          uint64_t* out_claim_points, int* out_claim_point_len, uint64_t* out_claim_evals);
+
 /* ---- trace commitment (a14) ----
  * TraceCommitter::commit_traces (ceno_zkvm/src/scheme/hal.rs:137-156, CPU scheme/cpu/mod.rs:559-584, GPU
  * scheme/gpu/mod.rs:1519-1660): per row-major trace matrix — pad the rows to next_pow2_instance_padding

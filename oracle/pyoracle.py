@@ -664,3 +664,76 @@ def witgen_arith(cols, is_sub: bool, records: np.ndarray, indices, shard_offset:
     if rc != 0:
         raise ValueError(f"orc_witgen_arith rc={rc}")
     return out, lkd, lkf[:fetch_num_slots]
+
+
+# ---- multi-layer GKR (control flow restated; arithmetic by the functions above) -----------------------------------
+LAYER_ZEROCHECK, LAYER_LINEAR, LAYER_SUMCHECK = 0, 1, 2
+
+
+def _scalars(scalars, chal):
+    out = []
+    for monos in scalars:
+        sc = (0, 0)
+        for coeff, ids in monos:
+            v = (int(coeff[0]), int(coeff[1]))
+            for i in ids:
+                v = e2_mul(v, chal[i])
+            sc = e2_add(sc, v)
+        out.append(sc)
+    return out
+
+
+def gkr_prove(layers, claims, pub_io, challenges, tr):
+    """GKRCircuit::prove (gkr_iop/src/gkr.rs:72-115) with Layer::prove / extract_claim_and_point / update_claims
+    (gkr/layer.rs:198-243,289-322) and the three layer provers of gkr/layer/cpu/mod.rs (linear :47-66, sumcheck :72-96,
+    zerocheck :102-238).  Same layer dictionaries as ceno_amd.prover.gkr_prove, with numpy tables instead of handles
+    (None for a selector's structural slot).  Returns ([(msgs, evals, point)], final claims)."""
+    claims = [(None if c[0] is None else np.ascontiguousarray(c[0], dtype=np.uint64).reshape(-1, 2), (int(c[1][0]), int(c[1][1]))) for c in claims]
+    gch = [(int(c[0]), int(c[1])) for c in challenges]
+    pio = [(int(c[0]), int(c[1])) for c in pub_io]
+
+    def ev(e):
+        if e[0] == "zero":
+            return claims[0][0], (0, 0)
+        if e[0] == "single":
+            return claims[e[1]]
+        pt, v = claims[e[1]]
+        return pt, e2_add(e2_mul(v, (int(e[2][0]), int(e[2][1]))), (int(e[3][0]), int(e[3][1])))
+
+    out = []
+    for ly in layers:
+        nv, tabs = ly["num_vars"], list(ly["mles"])
+        gpts = [ev(g[1][0])[0] if g[1] else None for g in ly["groups"]]
+        if ly["type"] == LAYER_LINEAR:
+            point = gpts[0]
+            evals = np.array([mle_evaluate(t, point) for t in tabs], dtype=np.uint64)
+            for e in evals:
+                tr.append_ext((int(e[0]), int(e[1])))
+            msgs = np.zeros((0, 1, 2), dtype=np.uint64)
+        else:
+            if ly["type"] == LAYER_ZEROCHECK:
+                tr.append_label(b"combine subset evals")
+                a = tr.sample_ext()
+                pows, acc = [], (1, 0)
+                for _ in range(ly["n_exprs"]):
+                    pows.append(acc)
+                    acc = e2_mul(acc, a)
+                chal = gch + pows + pio
+                base = ly["n_witin"] + ly["n_fixed"]
+                seen = set()
+                for g, pt in zip(ly["groups"], gpts):
+                    if g[0] is None or g[0][1] in seen:
+                        continue
+                    seen.add(g[0][1])
+                    tabs[base + g[0][1]] = selector_compute(g[0][0], pt, g[0][2], g[0][3], g[0][4], g[0][5])
+            else:
+                chal = gch + pio
+            coeffs = _scalars(ly["scalars"], chal)
+            keep = [i for i, c in enumerate(coeffs) if c != (0, 0)]
+            msgs, point, evals = sumcheck_prove(tabs, ext([coeffs[i] for i in keep]), [ly["terms"][i] for i in keep], nv, ly["max_degree"], tr)
+            for e in evals:
+                tr.append_ext((int(e[0]), int(e[1])))
+        out.append((msgs, evals, point))
+        for k, pos in enumerate(ly["in_eval_pos"][: len(tabs)]):
+            claims[pos] = (np.array(point, dtype=np.uint64), (int(evals[k][0]), int(evals[k][1])))
+    return out, claims

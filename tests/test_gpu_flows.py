@@ -374,3 +374,66 @@ def test_config4_batched_main_sumcheck_full_size(dev, prover, max_nv):
         t2.sample_ext()
         omsgs, ochal, ofin = po.sumcheck_prove(full, coeffs, terms, max_nv, 4, t2)
         assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-layer GKR circuit (a13): rotation argument first, then zerocheck -> linear -> sumcheck layers
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gkr_prove_multi_layer_with_rotation_first_matches_oracle(dev, prover, seed):
+    """the order of the keccak-style harness (precompiles/lookup_keccakf.rs:1338-1397): prove_rotation at the out point, its
+    left / right / target evaluations become out-evaluations of the first layer, then GKRCircuit::prove walks the layers
+    (gkr.rs:72-115): a zerocheck layer with four selector groups (Prefix, Whole, OrderedSparse, a second Prefix at three
+    different points), a linear layer, a plain sumcheck layer; claims flow through Single / Linear / Zero expressions"""
+    import random
+
+    rng = random.Random(77 + seed)
+    log2_n, rot = 2, 5
+    nv = log2_n + rot
+    gch = [(rng.randrange(P), rng.randrange(P)) for _ in range(2)]
+    pub_io = [(rng.randrange(P), 0), (rng.randrange(P), rng.randrange(P))]
+    src = po.rand_base(1 << nv, 900 + seed)
+    w = [src, po.rotation_next_base_mle(src, 5), po.rand_base(1 << nv, 910 + seed), po.rand_ext(1 << nv, 920 + seed)]
+    v = [po.rand_base(1 << nv, 930 + seed), po.rand_ext(1 << nv, 931 + seed)]
+    u = [po.rand_ext(1 << nv, 940 + seed + j) for j in range(3)]
+    rt = po.rand_ext(nv, 950 + seed)
+    d_w = [dev.upload(t) for t in w]
+    # ---- rotation first ----
+    pairs = [(0, 1), (2, 0)]
+    tr_g, tr_o = prover.Transcript.stub(31 + seed), po.StubTranscript(31 + seed)
+    got_rot = prover.prove_rotation(dev, d_w, pairs, 23, 5, rt, tr_g)
+    exp_rot = po.prove_rotation(w, pairs, 23, 5, rt, tr_o)
+    for a, b in zip(got_rot, exp_rot):
+        assert np.array_equal(a, b)
+    _, rev, origin, left, right = exp_rot
+    # ---- claims: slot 0 = the tower-style claim at rt, 1..3 = rotation evaluations at their points ----
+    n_ev = 12
+    claims = [(rt, (rng.randrange(P), rng.randrange(P))), (left, tup(rev[0])), (right, tup(rev[1])), (origin, tup(rev[2]))] + [(None, (0, 0))] * (n_ev - 4)
+    sel = lambda kind, sid, off, n, sparse=(), snv=0: (kind, sid, off, n, tuple(sparse), snv)
+    s0, s1, s2, s3 = 4, 5, 6, 7  # structural slots of the four selectors inside layer 0's table list
+    layer0 = dict(type=po.LAYER_ZEROCHECK, num_vars=nv, n_witin=4, n_fixed=0, n_structural=4,
+                  groups=[(sel(po.SEL_PREFIX, 0, 0, (1 << nv) - 9), [("single", 0), ("linear", 0, (3, 1), (5, 0)), ("zero",)]),
+                          (sel(po.SEL_WHOLE, 1, 0, 1 << nv), [("single", 1)]),
+                          (sel(po.SEL_ORDERED_SPARSE, 2, 0, 3, (0, 2, 5, 17), 5), [("single", 2)]),
+                          (sel(po.SEL_PREFIX, 3, 4, 40), [("single", 3)])],
+                  n_exprs=4, max_degree=4,
+                  terms=[[s0, 0, 1], [s0, 2], [s1, 1, 3], [s2, 0, 0, 2], [s3, 3], [s3, 1, 2]],
+                  scalars=[[((1, 0), [2])], [((2, 0), [3, 0]), ((7, 1), [6])], [((1, 1), [4])], [((5, 0), [5, 7])], [((1, 0), [2, 1])], [((9, 9), [3])]],
+                  in_eval_pos=[4, 5, 6, 7])
+    layer1 = dict(type=po.LAYER_LINEAR, num_vars=nv, n_witin=2, n_fixed=0, n_structural=0, groups=[(None, [("single", 5)])], in_eval_pos=[8, 9])
+    layer2 = dict(type=po.LAYER_SUMCHECK, num_vars=nv, n_witin=3, n_fixed=0, n_structural=0, groups=[(None, [("linear", 9, (2, 0), (1, 1))])], max_degree=3,
+                  terms=[[0, 1, 2], [1], [2, 2]], scalars=[[((1, 0), [])], [((4, 0), [0, 2])], [((1, 2), [1])]], in_eval_pos=[10, 11])
+    o_layers = [dict(layer0, mles=w + [None] * 4), dict(layer1, mles=v), dict(layer2, mles=u)]
+    g_layers = [dict(layer0, mles=d_w + [None] * 4), dict(layer1, mles=[dev.upload(t) for t in v]), dict(layer2, mles=[dev.upload(t) for t in u])]
+    got, got_claims = prover.gkr_prove(dev, g_layers, nv, claims, pub_io, gch, tr_g)
+    exp, exp_claims = po.gkr_prove(o_layers, claims, pub_io, gch, tr_o)
+    for li, ((gm, ge, gp), (em, ee, ep)) in enumerate(zip(got, exp)):
+        if o_layers[li]["type"] != po.LAYER_LINEAR:
+            assert np.array_equal(gm, em), f"layer {li} messages"
+        assert np.array_equal(ge, np.asarray(ee, dtype=np.uint64).reshape(-1, 2)), f"layer {li} evaluations"
+        assert np.array_equal(gp, np.asarray(ep, dtype=np.uint64).reshape(-1, 2)), f"layer {li} point"
+    for (gpnt, gev), (epnt, eev) in zip(got_claims, exp_claims):
+        assert gev == eev and ((gpnt is None and epnt is None) or np.array_equal(gpnt, epnt))
+    assert tr_g.sample_ext() == tr_o.sample_ext()  # both transcripts absorbed exactly the same stream
+    # a linear layer's evaluations are the tables at the layer point (independent path: the evaluate kernel)
+    assert tup(got[1][1][1]) == po.mle_evaluate(v[1], got[0][2])
