@@ -167,6 +167,7 @@ def main():
     new_transcript = factories[args.transcript]
     collective = "none"
     comm = stream = None
+    comms, collective_ms = {}, {}
 
     def step_torch():
         # per-round all-gather issued from Python through torch.distributed (RCCL underneath)
@@ -192,7 +193,10 @@ def main():
         except Exception as e:  # without it a candidate is accepted when it runs on every rank (its proof is replicated by construction)
             print(f"bench.py: torch.distributed reference path failed on rank {rank}: {e}", file=sys.stderr)
             reference = None
+        # every exchange that works on all ranks and reproduces the reference proof is kept: each is timed below and reported
+        # under `collective_ms`; the fastest one carries `value`
         order = [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
+        comms = {}
         for kind in order:
             ok = 1
             try:
@@ -205,11 +209,34 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                step_fn = step_native
-                collective = ("host shared-memory exchange of the d partial evaluations per round from the C++ host loop"
-                              if kind == "shm" else "ncclAllGather from the C++ host loop") + (" (checked against the torch.distributed path)" if reference is not None else " (unchecked: reference path failed)")
-                break
+                comms[kind] = comm
             comm = None
+        names = {"shm": "host shared-memory exchange of the d partial evaluations per round from the C++ host loop",
+                 "rccl": "ncclAllGather of the d partial evaluations per round on the kernels' stream from the C++ host loop (RCCL over xGMI)"}
+        collective_ms = {}
+
+        def time_steps(fn, n):
+            for _ in range(min(2, args.warmup + 1)):
+                fn()
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            d_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+            return float(d_.item()) / n * 1e3
+
+        for kind, c in comms.items():
+            comm = c
+            collective_ms[kind] = time_steps(step_native, max(2, args.steps // 2))
+        if not comms:
+            collective_ms["torch"] = time_steps(step_torch, max(2, args.steps // 2))
+        else:
+            best = min(comms, key=lambda k_: collective_ms[k_])
+            comm = comms[best]
+            step_fn = step_native
+            collective = names[best] + (" (checked against the torch.distributed path)" if reference is not None else " (unchecked: reference path failed)")
 
     def step():
         if world == 1:
@@ -281,6 +308,7 @@ def main():
             "sharding": "none" if world == 1 else f"top-{log_w}-bits over {world} GPUs, all-gather of partials per round",
             "collective": collective,
         },
+        **({"collective_ms": collective_ms, "exchanges_validated": sorted(comms)} if world > 1 else {}),
         "roofline": {
             "bound": "hbm",
             "kernel": "k_dense<3,*> (fused fold + round-polynomial accumulate)",

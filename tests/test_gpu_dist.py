@@ -62,3 +62,29 @@ def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
         assert np.array_equal(res[r]["msgs"], omsgs)
         assert np.array_equal(res[r]["chal"], ochal)
         assert np.array_equal(res[r]["fin"], ofin)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_py_multi_rank_launch_end_to_end(world):
+    """`bench.py --gpus N` exactly as the driver launches it (python -m torch.distributed.run, one rank per GPU), on a 1-GPU box:
+    CENO_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 with a gloo process group, so the whole N > 1 flow runs — reference
+    path through torch.distributed, the C++ driver with the shared-memory exchange validated against it, timing of every
+    validated exchange, max over ranks, ONE JSON line from rank 0.  (RCCL cannot place two ranks on one device: it is reported
+    as unavailable here and validated on the multi-GPU node.)"""
+    import json
+
+    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--nv", "12"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["config"]["global_num_vars"] == 12 + world.bit_length() - 1
+    assert "shm" in r["exchanges_validated"] and r["collective_ms"]["shm"] > 0
+    assert "shared-memory exchange" in r["config"]["collective"] and "checked against the torch.distributed path" in r["config"]["collective"]
+    assert r["value"] > 0 and abs(r["value"] - 9 * ((1 << r["config"]["global_num_vars"]) - 1) / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
