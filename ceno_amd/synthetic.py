@@ -125,3 +125,128 @@ class ChipFlow:
     def close(self):
         self.trace.free()
         self.dev.stream_destroy(self.stream)
+
+
+class ShardFlow:
+    """BASELINE.json metric M2 shape ("e2e prover sec for 2^20 cycles") on synthetic data: one shard whose 2^20 cycles are spread
+    over eight ADD-shaped opcode chips of 2^19 .. 2^13 rows (22 base columns, 4 + 4 + 8 records, 33 main-constraint terms each),
+    proved the way ZKVMProver::create_proof does it (ceno_zkvm/src/scheme/prover.rs:319-611): commit every trace, bind the
+    commitment and draw the two record challenges, one chip proof per circuit on a forked transcript (tower relation), merge one
+    sample per fork, ONE batched main-constraint sumcheck over all chips, ONE Basefold opening of all traces.  Witness
+    generation and the emulator are upstream of the path and not part of the time."""
+
+    LOG_ROWS = (19, 18, 17, 16, 15, 14, 13, 13)
+
+    def __init__(self, dev, prover, w: int = 22, log_blowup: int = 1, n_queries: int = 100, pow_bits: int = 16, log_rows=None):
+        self.dev, self.prover, self.w = dev, prover, w
+        self.log_blowup, self.n_queries, self.pow_bits = log_blowup, n_queries, pow_bits
+        if log_rows is not None:
+            self.LOG_ROWS = tuple(log_rows)   # (tests run the same flow on a small shard)
+        else:
+            assert sum(1 << r for r in self.LOG_ROWS) == 1 << 20
+        self.traces = [dev.synthetic(((1 << r) * w - 1).bit_length(), False, 0x5A0 + i) for i, r in enumerate(self.LOG_ROWS)]
+        self.stream = dev.stream_create()
+
+    def run(self, transcript_factory, fork_factory, lanes: int = 1) -> dict:
+        """lanes > 1: the chip proofs run concurrently, one host thread and one HIP stream per lane, largest chip first (the
+        reference's chip scheduler, ceno_zkvm/src/scheme/scheduler.rs:231-336: forks make the chip transcripts independent,
+        results are merged in task order)"""
+        dev, prover, w = self.dev, self.prover, self.w
+
+        def timed(f):
+            dev.sync()
+            t0 = time.perf_counter()
+            r = f()
+            dev.sync()
+            return r, (time.perf_counter() - t0) * 1e3
+
+        res = {}
+        ptrs = [(t.device_ptr, 1 << r, w) for t, r in zip(self.traces, self.LOG_ROWS)]
+        pcs, res["commit_ms"] = timed(lambda: prover.PcsData(dev, None, self.log_blowup, self.stream, device_ptrs=ptrs))
+        tr = transcript_factory()
+        for m in range(len(ptrs)):
+            root = pcs.root(m)
+            tr.append_ext((int(root[0]), int(root[1])))
+            tr.append_ext((int(root[2]), int(root[3])))
+        alpha, beta = tr.sample_ext(), tr.sample_ext()              # prover.rs:528-531
+        coeffs, terms, out_terms = record_plan(w, 16, alpha, beta)
+        mterms, mscalars = main_plan(w, w)
+        chips, jobs = [], []
+
+        def one_chip(i, stream):
+            r = self.LOG_ROWS[i]
+            cols = [pcs.witness_mle(i, c) for c in range(w)]
+            fork = fork_factory()                                     # prover.rs:556-558, 682-689
+            fork.append_ext(alpha)
+            fork.append_ext(beta)
+            for v in (i, i, (1 << r) - 3, 0):
+                fork.append_base(v)
+            task = dict(circuit_idx=i, mles=cols, n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3, log2_num_instances=r,
+                        num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+            proof = prover.create_chip_proof(dev, task, [alpha, beta], fork, stream)
+            return cols, proof, fork.sample_ext()
+
+        def chip_proofs():
+            n = len(self.LOG_ROWS)
+            if lanes <= 1:
+                chips.extend(one_chip(i, self.stream) for i in range(n))
+            else:
+                import queue
+                import threading
+
+                todo = queue.Queue()
+                for i in sorted(range(n), key=lambda i: -self.LOG_ROWS[i]):   # largest estimate first
+                    todo.put(i)
+                done = [None] * n
+                import os
+
+                plain = os.environ.get("CENO_LANE_PLAIN") == "1"   # A/B: same-priority streams instead of the rotating priorities
+                streams = [dev.stream_create() if plain else dev.stream_create_lane(l) for l in range(lanes)]
+
+                def worker(l):
+                    while True:
+                        try:
+                            i = todo.get_nowait()
+                        except queue.Empty:
+                            return
+                        done[i] = one_chip(i, streams[l])
+
+                ths = [threading.Thread(target=worker, args=(l,)) for l in range(lanes)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+                for st in streams:
+                    dev.stream_destroy(st)
+                chips.extend(done)                                    # results in task order (scheduler.rs:303-304)
+            for _, _, s in chips:                                     # one sample per fork back into the main transcript (prover.rs:567-570)
+                tr.append_ext(s)
+
+        _, res["chip_proofs_ms"] = timed(chip_proofs)
+        for i, r in enumerate(self.LOG_ROWS):
+            cols, proof, _ = chips[i]
+            sel = (1, 0, (1 << r) - 3, 0, (), 0, proof.rt_main)
+            jobs.append(dict(circuit_idx=i, num_vars=r, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2,
+                             max_degree=4, terms=mterms, scalars=mscalars))
+        mj = prover.MainJobs(jobs)
+        (claimed, msgs, rt, evals), res["batched_main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, mj, [alpha, beta], tr, self.stream))
+        points = [rt[:r] for r in self.LOG_ROWS]
+        ev = [evals[i * (w + 1): i * (w + 1) + w] for i in range(len(self.LOG_ROWS))]
+        oproof, res["open_ms"] = timed(lambda: pcs.basefold_open(points, ev, self.n_queries, self.pow_bits, tr))
+        res["total_ms"] = res["commit_ms"] + res["chip_proofs_ms"] + res["batched_main_ms"] + res["open_ms"]
+        res["e2e_prover_sec_for_2p20_cycles"] = res["total_ms"] / 1e3
+        res["open_proof_bytes"] = int(oproof.size * 8)
+        # everything a verifier needs (tests/test_gpu_flows.py replays the whole transcript with the oracle's verifiers)
+        self.artifacts = dict(roots=[pcs.root(m) for m in range(len(ptrs))], alpha=alpha, beta=beta, chip_proofs=[c[1] for c in chips],
+                              fork_samples=[c[2] for c in chips], claimed=claimed, msgs=msgs, rt=rt, evals=evals, points=points, open_evals=ev,
+                              open_proof=oproof, mterms=mterms, mscalars=mscalars)
+        for cols, _, _ in chips:
+            for m in cols:
+                m.free()
+        pcs.free()
+        return res
+
+    def close(self):
+        for t in self.traces:
+            t.free()
+        self.dev.stream_destroy(self.stream)

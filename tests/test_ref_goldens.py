@@ -49,22 +49,9 @@ def plib():
 
 
 def _constants(g):
-    """(external 8x8, internal 22, diag 8) as uint64 arrays from whatever shape the dump produced; diag may be absent (the
-    published MATRIX_DIAG_8_GOLDILOCKS is built in)"""
-    rc = g["poseidon2"]["round_constants"]
-    if isinstance(rc, dict):
-        ext = np.array(rc["external"], dtype=np.uint64).reshape(8, 8)
-        internal = np.array(rc["internal"], dtype=np.uint64).reshape(22)
-        diag = np.array(rc["diag"], dtype=np.uint64).reshape(8) if rc.get("diag") is not None else None
-        return ext, internal, diag
-    flat = np.array(rc, dtype=np.uint64).reshape(-1)
-    if flat.size == 8 * 8 + 22:          # external initial (4 x 8), internal (22), external terminal (4 x 8)
-        ext = np.concatenate([flat[:32], flat[32 + 22:]]).reshape(8, 8)
-        return ext, flat[32: 32 + 22].copy(), None
-    if flat.size == 30 * 8:              # one row of 8 per round, internal rounds use word 0 (shard_ram.rs:227 layout)
-        rows = flat.reshape(30, 8)
-        return np.concatenate([rows[:4], rows[26:]]), rows[4:26, 0].copy(), None
-    raise AssertionError(f"unrecognised round-constant table of {flat.size} words")
+    from ceno_amd import goldens
+
+    return goldens.parse_constants(g)
 
 
 def _oracle_params(ext, internal, diag):
