@@ -29,8 +29,13 @@ struct ceno_hip_ctx {
     size_t pool_cached = 0; // bytes parked in free lists
     size_t pool_booked = 0; // bytes promised to scheduled-but-not-yet-running tasks (ceno_hip_mem_book)
     size_t pool_capacity = 0;  // booking capacity: pool_limit, or the device memory size when unlimited
-    std::unordered_map<size_t, std::vector<void*>> free_lists;
+    // a cached block remembers the stream its last user was working on (the freeing thread's current stream): handing it to a
+    // DIFFERENT stream first orders that stream behind the old one (ctx_alloc), so a block freed with kernels still queued is
+    // never overwritten early by another lane
+    std::unordered_map<size_t, std::vector<std::pair<void*, hipStream_t>>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
+    std::vector<hipStream_t> streams;        // streams created through the C ABI that are still alive
+    hipEvent_t order_event = nullptr;        // scratch event of the cross-stream ordering above (used under `mu`)
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
     std::unordered_map<void*, size_t> pinned_live;
@@ -79,9 +84,10 @@ void ctx_pinned_free(ceno_hip_ctx* ctx, void* host);
 // thread starts on device 0, and allocations / stream creation / launches follow the CURRENT device, not the context's
 void ctx_make_current(ceno_hip_ctx* ctx);
 // every entry point that touches the device resolves its stream through here, which also makes the device current
+extern thread_local hipStream_t ceno_tls_stream;  // the stream the calling thread resolved last (ctx.hip)
 inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     ctx_make_current(ctx);
-    return s ? (hipStream_t)s : ctx->default_stream;
+    return ceno_tls_stream = (s ? (hipStream_t)s : ctx->default_stream);
 }
 
 // profiling hooks (ctx.hip)

@@ -37,25 +37,45 @@ static size_t bucket_size(size_t bytes) {
     return (bytes + MB - 1) / MB * MB;
 }
 
+thread_local hipStream_t ceno_tls_stream = nullptr;
+
+static bool stream_alive(ceno_hip_ctx* ctx, hipStream_t s) {
+    if (s == ctx->default_stream) return true;
+    for (hipStream_t t : ctx->streams)
+        if (t == s) return true;
+    return false;
+}
+
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     size_t b = bucket_size(bytes);
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
         if (it != ctx->free_lists.end() && !it->second.empty()) {
-            void* p = it->second.back();
+            void* p = it->second.back().first;
+            const hipStream_t last = it->second.back().second;
             it->second.pop_back();
             ctx->pool_cached -= b;
             ctx->pool_used += b;
             ctx->live[p] = b;
             *out = p;
+            // the block was last used on another stream that may still have work queued on it: order the new user behind it.
+            // A destroyed stream was synchronised on the way out (ceno_hip_stream_destroy); streams the library did not
+            // create are the caller's to synchronise before freeing (include/ceno_hip.h, "Memory").
+            const hipStream_t cur = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
+            if (last && last != cur && stream_alive(ctx, last)) {
+                if (!ctx->order_event && hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming) != hipSuccess) ctx->order_event = nullptr;
+                if (!ctx->order_event || hipEventRecord(ctx->order_event, last) != hipSuccess ||
+                    hipStreamWaitEvent(cur, ctx->order_event, 0) != hipSuccess)
+                    (void)hipStreamSynchronize(last);
+            }
             return 0;
         }
         if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
             // try to make room by dropping cached blocks
             for (auto& kv : ctx->free_lists) {
-                for (void* p : kv.second) {
-                    (void)hipFree(p);
+                for (auto& p : kv.second) {
+                    (void)hipFree(p.first);
                     ctx->pool_cached -= kv.first;
                 }
                 kv.second.clear();
@@ -91,7 +111,7 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
     ctx->live.erase(it);
     ctx->pool_used -= b;
     ctx->pool_cached += b;
-    ctx->free_lists[b].push_back(p);
+    ctx->free_lists[b].push_back({p, ceno_tls_stream ? ceno_tls_stream : ctx->default_stream});
 }
 
 static constexpr int VRAM_SLOTS = 1024;
@@ -195,7 +215,8 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : ctx->free_lists)
-        for (void* p : kv.second) (void)hipFree(p);
+        for (auto& p : kv.second) (void)hipFree(p.first);
+    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     for (auto& kv : ctx->pinned_free)
         for (void* p : kv.second) (void)hipHostFree(p);
@@ -225,6 +246,10 @@ int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->streams.push_back(s);
+    }
     *out = (ceno_hip_stream)s;
     return 0;
 }
@@ -240,11 +265,33 @@ int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* ou
     const int levels[3] = {greatest, (least + greatest) / 2, least};
     hipStream_t s;
     HIP_TRY(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, levels[lane % 3]));
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        ctx->streams.push_back(s);
+    }
     *out = (ceno_hip_stream)s;
     return 0;
 }
+int ceno_hip_stream_adopt(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx && s, "bad stream");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!stream_alive(ctx, (hipStream_t)s)) ctx->streams.push_back((hipStream_t)s);
+    return 0;
+}
 int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
-    if (s) HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));
+    if (!s) return 0;
+    // blocks freed while this stream still had work queued carry its tag in the pool: drain it before the tag goes stale
+    (void)hipStreamSynchronize((hipStream_t)s);
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (size_t i = 0; i < ctx->streams.size(); i++)
+            if (ctx->streams[i] == (hipStream_t)s) {
+                ctx->streams.erase(ctx->streams.begin() + i);
+                break;
+            }
+    }
+    if (ceno_tls_stream == (hipStream_t)s) ceno_tls_stream = nullptr;
+    HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));
     return 0;
 }
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s) {
@@ -294,8 +341,8 @@ size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->mu);
     for (auto& kv : ctx->free_lists) {
-        for (void* p : kv.second) {
-            (void)hipFree(p);
+        for (auto& p : kv.second) {
+            (void)hipFree(p.first);
             ctx->pool_cached -= kv.first;
         }
         kv.second.clear();

@@ -83,6 +83,7 @@ bool tree_streams_acquire(ceno_hip_ctx* ctx, TreeStreams* out) {
             if (g_ts_pool[i].device == dev) {
                 *out = g_ts_pool[i];
                 g_ts_pool.erase(g_ts_pool.begin() + (long)i);
+                for (int k = 0; k < 2; k++) (void)ceno_hip_stream_adopt(ctx, (ceno_hip_stream)out->s[k]);
                 return true;
             }
     }
@@ -96,6 +97,7 @@ bool tree_streams_acquire(ceno_hip_ctx* ctx, TreeStreams* out) {
             if (out->s[0]) (void)hipStreamDestroy(out->s[0]);
             return false;
         }
+    for (int k = 0; k < 2; k++) (void)ceno_hip_stream_adopt(ctx, (ceno_hip_stream)out->s[k]);  // pool blocks freed on them are ordered
     return true;
 }
 void tree_streams_release(const TreeStreams& ts) {

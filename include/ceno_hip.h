@@ -20,6 +20,11 @@
  *    gkr_iop/src/gpu/mod.rs:87-154).  `NULL` selects the context's default stream.  The library is
  *    re-entrant across streams; host buffers passed in are only borrowed for the call.
  *  - Handles are opaque; device memory is owned by the library pool unless wrapped from outside.
+ *  - Memory: freeing a handle does not wait for the device.  A freed block remembers the stream the freeing thread used last
+ *    (one lane = one thread = one stream); the pool orders a different stream behind that one (event + wait) before it hands
+ *    the block out again, so a lane may free tables whose kernels are still queued.  Streams NOT created through
+ *    ceno_hip_stream_create / _create_lane (a caller's own HIP stream passed as ceno_hip_stream) are outside that
+ *    bookkeeping: synchronise them before freeing handles that were used on them from another thread.
  *  - The Fiat–Shamir transcript stays with the caller: sumcheck is exposed round by round
  *    (the reference passes `&mut BasicTranscript` into the HAL, gkr_iop/src/gkr/layer/gpu/mod.rs:252-270;
  *    a C ABI cannot take a Rust generic, so control is inverted).
@@ -67,6 +72,9 @@ int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out);
  * get different stream priorities so that they land on different hardware queues and really overlap */
 int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out);
 int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s);
+/* registers a HIP stream the caller created itself with the pool's cross-stream ordering (see "Memory" above); the stream must
+ * stay alive until ceno_hip_stream_destroy (which also forgets it) or the context is destroyed */
+int ceno_hip_stream_adopt(ceno_hip_ctx* ctx, ceno_hip_stream s);
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);

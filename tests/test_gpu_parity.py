@@ -680,6 +680,37 @@ def test_memory_booking_for_a_scheduler():
     d.close()
 
 
+def test_pool_orders_a_reused_block_behind_the_stream_that_used_it_last():
+    """A handle may be freed while kernels that read it are still queued; when the pool hands the block to ANOTHER stream it
+    first orders that stream behind the old one (include/ceno_hip.h "Memory"; reference: the CUDA pool's stream-ordered
+    frees behind `get_thread_stream`, gkr_iop/src/gpu/mod.rs:87-154)"""
+    from ceno_amd import Device
+
+    d = Device(0)
+    s1, s2 = d.stream_create(), d.stream_create()
+    nv = 23
+    r = po.rand_ext(1, 99)
+    for trial in range(3):
+        # a queue of work on s1, then the fold that reads `a`; `a` is freed at once and its block re-filled through s2
+        filler = [d.synthetic(nv, True, 1000 + k, stream=s1) for k in range(6)]
+        a = d.synthetic(nv, True, 7 + trial, stream=s1)
+        folded = a.fix_variables(r, stream=s1)
+        ptr = a.device_ptr
+        a.free()
+        b = d.synthetic(nv, True, 5000 + trial, stream=s2)
+        assert b.device_ptr == ptr, "the pool did not reuse the freed block (test premise)"
+        d.sync(s1)
+        d.sync(s2)
+        want = d.synthetic(nv, True, 7 + trial, stream=s1).fix_variables(r, stream=s1)
+        d.sync(s1)
+        assert np.array_equal(folded.download(s1), want.download(s1)), "the re-filled block was overwritten before its reader ran"
+        for m in filler + [b, folded, want]:
+            m.free()
+    d.stream_destroy(s1)
+    d.stream_destroy(s2)
+    d.close()
+
+
 def test_lane_scheduler_runs_every_task_once_with_booking(dev, prover):
     """ceno_prover_lanes_run (scheduler.rs:231-336 + booking :622-652): every task runs exactly once on some lane's
     stream, results are bit-exact whatever the interleaving, and estimates are booked / unbooked around each task"""
