@@ -29,13 +29,12 @@ struct ceno_hip_ctx {
     size_t pool_cached = 0; // bytes parked in free lists
     size_t pool_booked = 0; // bytes promised to scheduled-but-not-yet-running tasks (ceno_hip_mem_book)
     size_t pool_capacity = 0;  // booking capacity: pool_limit, or the device memory size when unlimited
-    // a cached block remembers the stream its last user was working on (the freeing thread's current stream): handing it to a
-    // DIFFERENT stream first orders that stream behind the old one (ctx_alloc), so a block freed with kernels still queued is
-    // never overwritten early by another lane
+    // a cached block remembers the stream its last user was working on (the freeing thread's current stream): it is handed to
+    // a DIFFERENT stream only once that stream has drained (ctx_alloc), so a block freed with kernels still queued is never
+    // overwritten early by another lane
     std::unordered_map<size_t, std::vector<std::pair<void*, hipStream_t>>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
     std::vector<hipStream_t> streams;        // streams created through the C ABI that are still alive
-    hipEvent_t order_event = nullptr;        // scratch event of the cross-stream ordering above (used under `mu`)
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
     std::unordered_map<void*, size_t> pinned_live;

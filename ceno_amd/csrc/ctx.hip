@@ -52,24 +52,29 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
         if (it != ctx->free_lists.end() && !it->second.empty()) {
-            void* p = it->second.back().first;
-            const hipStream_t last = it->second.back().second;
-            it->second.pop_back();
-            ctx->pool_cached -= b;
-            ctx->pool_used += b;
-            ctx->live[p] = b;
-            *out = p;
-            // the block was last used on another stream that may still have work queued on it: order the new user behind it.
-            // A destroyed stream was synchronised on the way out (ceno_hip_stream_destroy); streams the library did not
-            // create are the caller's to synchronise before freeing (include/ceno_hip.h, "Memory").
+            // A cached block was last used on the stream in its tag, which may still have that work queued.  Same stream:
+            // stream order protects it.  Another stream: take the block only if the old stream has drained (hipStreamQuery);
+            // NEVER wait for it — a pipelined sumcheck keeps kernels queued that wait for the host, and a stream ordered behind
+            // them would stall until the host answers, which it may be unable to do while it waits for THIS stream.  A
+            // destroyed stream was synchronised on the way out (ceno_hip_stream_destroy); streams the library does not know
+            // are the caller's to synchronise before freeing (include/ceno_hip.h, "Memory").
             const hipStream_t cur = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
-            if (last && last != cur && stream_alive(ctx, last)) {
-                if (!ctx->order_event && hipEventCreateWithFlags(&ctx->order_event, hipEventDisableTiming) != hipSuccess) ctx->order_event = nullptr;
-                if (!ctx->order_event || hipEventRecord(ctx->order_event, last) != hipSuccess ||
-                    hipStreamWaitEvent(cur, ctx->order_event, 0) != hipSuccess)
-                    (void)hipStreamSynchronize(last);
+            auto& fl = it->second;
+            int pick = -1, probes = 0;
+            for (int k = (int)fl.size() - 1; k >= 0 && pick < 0; k--) {
+                const hipStream_t last = fl[k].second;
+                if (!last || last == cur || !stream_alive(ctx, last)) pick = k;
+                else if (probes++ < 4 && hipStreamQuery(last) == hipSuccess) pick = k;
             }
-            return 0;
+            if (pick >= 0) {
+                void* p = fl[pick].first;
+                fl.erase(fl.begin() + pick);
+                ctx->pool_cached -= b;
+                ctx->pool_used += b;
+                ctx->live[p] = b;
+                *out = p;
+                return 0;
+            }
         }
         if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
             // try to make room by dropping cached blocks
@@ -216,7 +221,6 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& kv : ctx->free_lists)
         for (auto& p : kv.second) (void)hipFree(p.first);
-    if (ctx->order_event) (void)hipEventDestroy(ctx->order_event);
     for (auto& kv : ctx->live) (void)hipFree(kv.first);
     for (auto& kv : ctx->pinned_free)
         for (void* p : kv.second) (void)hipHostFree(p);

@@ -155,6 +155,39 @@ GL_HD uint64_t reduce128_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) 
         : "vcc");
     return join(r0, r1);
 }
+// The same reduction in 8 VALU instructions: carry (SGPR pair) and borrow (VCC) are combined on the SCALAR unit into "carry
+// only" / "borrow only" masks (both together cancel), turned into ONE 64-bit correction D in {+EPS, 0, -EPS} = (a - b : b) with
+// a = -[carry only], b = -[borrow only], and added with a single add / add-with-carry pair.  Measured on one box
+// (tools/ab_arith.sh, AB_FLAGS=-DGL_REDUCE_MERGED=0): the Poseidon2 leaf hash gains 6 % (Merkle commit 4.34 -> 4.07 ms), the
+// sumcheck kernels LOSE 2 % (two more scalar instructions per reduction compete with their address and loop arithmetic, and
+// tools/ubench_red.hip's bare multiply chains lose 9 %), so only the hash (mul_ncm, mul_add_s96_ncm) uses this form.
+#ifndef GL_REDUCE_MERGED
+#define GL_REDUCE_MERGED 1
+#endif
+#if GL_REDUCE_MERGED
+GL_HD uint64_t reduce128_ncm(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    uint64_t t = join(w0, w1), cy, ma, mb;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %0" : "+v"(t), "=s"(cy) : "v"(w2));
+    uint32_t r0 = (uint32_t)t, r1 = (uint32_t)(t >> 32), a, b;
+    asm("v_sub_co_u32 %0, vcc, %0, %7\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "s_andn2_b64 %4, %6, vcc\n\t"
+        "s_andn2_b64 %5, vcc, %6\n\t"
+        "v_cndmask_b32 %2, 0, -1, %4\n\t"
+        "v_cndmask_b32 %3, 0, -1, %5\n\t"
+        "v_sub_u32 %2, %2, %3\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, vcc, %1, %3, vcc"
+        : "+v"(r0), "+v"(r1), "=&v"(a), "=&v"(b), "=&s"(ma), "=&s"(mb)
+        : "s"(cy), "v"(w3)
+        : "vcc", "scc");
+    return join(r0, r1);
+}
+#else
+GL_HD uint64_t reduce128_ncm(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return reduce128_nc(w0, w1, w2, w3); }
+#endif
 // 96-bit input (w2 * 2^64 + (w1:w0)): nothing to subtract, 4 instructions
 #define GL_HAVE_REDUCE96 1
 GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) {
@@ -215,6 +248,7 @@ GL_HD uint64_t canon(uint64_t r) {  // r + EPS overflows <=> r >= p
 #ifndef GL_HAVE_REDUCE96
 GL_HD uint64_t reduce96_nc(uint32_t w0, uint32_t w1, uint32_t w2) { return reduce_limbs_nc(w0, w1, w2, 0u, 0u); }
 GL_HD uint64_t reduce128_nc(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return reduce_limbs_nc(w0, w1, w2, w3, 0u); }
+GL_HD uint64_t reduce128_ncm(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) { return reduce_limbs_nc(w0, w1, w2, w3, 0u); }
 #endif
 GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t c) {
     return canon(reduce_limbs_nc(w0, w1, w2, w3, c));
@@ -240,6 +274,11 @@ GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
 GL_HD uint64_t mul_nc(uint64_t a, uint64_t b) {
     const L4 p = mul_wide(a, b);
     return reduce128_nc(p.w0, p.w1, p.w2, p.w3);
+}
+// the same product through the 8-instruction reduction (hash kernels, see reduce128_ncm)
+GL_HD uint64_t mul_ncm(uint64_t a, uint64_t b) {
+    const L4 p = mul_wide(a, b);
+    return reduce128_ncm(p.w0, p.w1, p.w2, p.w3);
 }
 // a*b + c with one reduction (c < 2^64: the sum stays below 2^128), canonical result
 GL_HD uint64_t mul_add(uint64_t a, uint64_t b, uint64_t c) {
@@ -311,6 +350,15 @@ GL_HD uint64_t mul_add_s96_nc(uint64_t a, uint64_t b, S96 s) {
     const uint32_t s2 = addc32(p.w2, s.w2, cy, cy);
     const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
     return reduce128_nc(s0, s1, s2, s3);
+}
+GL_HD uint64_t mul_add_s96_ncm(uint64_t a, uint64_t b, S96 s) {
+    const L4 p = mul_wide(a, b);
+    uint32_t cy;
+    const uint32_t s0 = addc32(p.w0, s.w0, 0u, cy);
+    const uint32_t s1 = addc32(p.w1, s.w1, cy, cy);
+    const uint32_t s2 = addc32(p.w2, s.w2, cy, cy);
+    const uint32_t s3 = addc32(p.w3, 0u, cy, cy);
+    return reduce128_ncm(s0, s1, s2, s3);
 }
 // small-constant multiply (c < 2^32): the product has 96 bits
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {

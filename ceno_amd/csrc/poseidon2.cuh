@@ -78,10 +78,10 @@ GL_HD void internal_linear(uint64_t* s, const Params& p) {
 // and the sums of the linear layers are formed as plain 96-bit integers (3 instructions per addition instead of the
 // 8 of a modular one) and reduced once per output word.  One canonicalisation per word at the very end.
 GL_HD uint64_t sbox7_nc(uint64_t x) {
-    uint64_t x2 = gl::mul_nc(x, x);
-    uint64_t x3 = gl::mul_nc(x2, x);
-    uint64_t x4 = gl::mul_nc(x2, x2);
-    return gl::mul_nc(x4, x3);
+    uint64_t x2 = gl::mul_ncm(x, x);
+    uint64_t x3 = gl::mul_ncm(x2, x);
+    uint64_t x4 = gl::mul_ncm(x2, x2);
+    return gl::mul_ncm(x4, x3);
 }
 // rows [2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]: coefficients sum to 7, so every output is < 7 * 2^64
 GL_HD void mat4_lazy(const uint64_t* x, gl::S96* n) {
@@ -110,7 +110,7 @@ GL_HD void internal_linear_nc(uint64_t* s, const Params& p) {
 #pragma unroll
     for (int i = 2; i < WIDTH; i++) sum = sum + s[i];   // < 8 * 2^64
 #pragma unroll
-    for (int i = 0; i < WIDTH; i++) s[i] = gl::mul_add_s96_nc(s[i], p.int_diag[i], sum);
+    for (int i = 0; i < WIDTH; i++) s[i] = gl::mul_add_s96_ncm(s[i], p.int_diag[i], sum);
 }
 
 GL_HD void permute(uint64_t* s, const Params& p) {
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint64_t permute_lanes8(uint64_t x, const Params& p) 
         gl::S96 sum = gl::s96_sum(x, dpp64<0xB1>(x));
         sum = sum + dpp96<0x4E>(sum);
         sum = sum + dpp96<0x141>(sum);  // every lane of a quad holds the quad sum: the mirror lane is in the other quad
-        x = gl::mul_add_s96_nc(x, dg, sum);
+        x = gl::mul_add_s96_ncm(x, dg, sum);
     }
     for (int r = ROUNDS_F / 2; r < ROUNDS_F; r++) {
         x = sbox7_nc(gl::add_nc(x, p.ext_rc[r][g]));

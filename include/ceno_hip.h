@@ -21,8 +21,8 @@
  *    re-entrant across streams; host buffers passed in are only borrowed for the call.
  *  - Handles are opaque; device memory is owned by the library pool unless wrapped from outside.
  *  - Memory: freeing a handle does not wait for the device.  A freed block remembers the stream the freeing thread used last
- *    (one lane = one thread = one stream); the pool orders a different stream behind that one (event + wait) before it hands
- *    the block out again, so a lane may free tables whose kernels are still queued.  Streams NOT created through
+ *    (one lane = one thread = one stream); the pool hands the block to a different stream only after that stream has drained
+ *    (it never waits: it takes another block or allocates), so a lane may free tables whose kernels are still queued.  Streams NOT created through
  *    ceno_hip_stream_create / _create_lane (a caller's own HIP stream passed as ceno_hip_stream) are outside that
  *    bookkeeping: synchronise them before freeing handles that were used on them from another thread.
  *  - The Fiat–Shamir transcript stays with the caller: sumcheck is exposed round by round
@@ -351,6 +351,14 @@ int ceno_hip_witgen_sub(ceno_hip_ctx* ctx, const ceno_hip_sub_column_map* map, c
 int ceno_hip_prof_reset(ceno_hip_ctx* ctx);
 int ceno_hip_prof_enable(ceno_hip_ctx* ctx, int on);
 int ceno_hip_prof_get(ceno_hip_ctx* ctx, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * self-test hook of the device field arithmetic (test infrastructure; no reference counterpart): runs the reduction
+ * (which = 0: n records of five 32-bit limbs w0..w3, c -> canon(reduce128), reduce_limbs), the base-field operations
+ * (which = 1: n pairs of arbitrary 64-bit words -> mul, mul_nc, add, sub, add_nc, mul_add) or the extension multiply and its
+ * unreduced accumulator (which = 2: n pairs of ext -> a*b, a*b + b*a + a*a) on host-supplied inputs.
+ * ------------------------------------------------------------------------------------------------ */
+int ceno_hip_selftest_field(ceno_hip_ctx* ctx, int which, const void* host_in, size_t n, uint64_t* host_out);
 
 #ifdef __cplusplus
 }

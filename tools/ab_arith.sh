@@ -7,7 +7,7 @@ trap 'env -u CENO_HIP_EXTRA_FLAGS python -m ceno_amd.build --force > gpurun_out/
 run() {
   echo "== $1"
   python tools/bench_merkle.py | cut -c1-40
-  python bench.py --steps 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench ms', r['ms_per_step'], 'frac', r['roofline']['frac'])"
+  python bench.py --steps 10 --no-cpu-baseline --no-extra 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench ms', r['ms_per_step'], 'frac', r['roofline']['frac'])"
   python tools/bench_batched.py 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('batched ms', r['batched_main_sumcheck_ms'])"
   python tools/bench_chip.py 2>/dev/null | tail -1 | python -c "import json,sys; r=json.loads(sys.stdin.read()); print({k: round(v,3) for k,v in r.items() if k.endswith('_ms')})"
 }
