@@ -396,3 +396,35 @@ def sharded_commit(dev, local_columns: np.ndarray, log_rows: int, log_blowup: in
         level = st[:, :4].contiguous()
     root = level.cpu().numpy().view(np.uint64).reshape(4)
     return {"root": root, "subtree": sub, "subtree_roots": roots, "codeword_rows": recv, "widths": widths}
+
+
+def sharded_commit_native(dev, comm_handle, d_cols_ptr: int, widths, log_rows: int, log_blowup: int, rank: int, stream):
+    """The same commitment through the C++ driver `ceno_dist_commit_traces` (ceno_amd/host/dist.cpp): encode, ONE
+    all-to-all of unequal blocks (RCCL grouped send/recv, or device copies inside a local group), local sub-tree, top levels.
+    `comm_handle`: a ceno_dist_comm* (prover.RcclComm(...).h, or a local-group communicator).  Returns
+    {"root", "subtree" (ceno_hip_merkle*), "subtree_roots", "codeword_rows" (int64 tensor, (w_total, R/world) column-major)}."""
+    import ctypes as C
+
+    import torch
+
+    from . import prover
+    from .api import CenoHipError
+
+    L = prover.plib()
+    world = len(widths)
+    L.ceno_dist_commit_traces.restype = C.c_int
+    L.ceno_dist_commit_traces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    R = 1 << (log_rows + log_blowup)
+    w_total = int(sum(widths))
+    rows = torch.empty(w_total * (R // world), dtype=torch.int64, device=f"cuda:{dev.device}")
+    roots = np.zeros((world, 4), dtype=np.uint64)
+    root = np.zeros(4, dtype=np.uint64)
+    sub = C.c_void_p()
+    wa = (C.c_int * world)(*[int(w) for w in widths])
+    u64p = C.POINTER(C.c_uint64)
+    rc = L.ceno_dist_commit_traces(dev.h, comm_handle, C.c_void_p(d_cols_ptr), wa, log_rows, log_blowup, stream, C.c_void_p(rows.data_ptr()),
+                                   C.byref(sub), roots.ctypes.data_as(u64p), root.ctypes.data_as(u64p))
+    if rc != 0:
+        raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+    return {"root": root, "subtree": sub, "subtree_roots": roots, "codeword_rows": rows, "rank": rank}

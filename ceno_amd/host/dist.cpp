@@ -22,8 +22,11 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +44,11 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // point-to-point (the row re-sharding of the commitment is an all-to-all of unequal blocks)
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
 };
 Rccl g_rccl;
 thread_local std::string g_dist_err;
@@ -64,6 +72,10 @@ int load_rccl() {
     *(void**)&g_rccl.AllGather = dlsym(g_rccl.h, "ncclAllGather");
     *(void**)&g_rccl.CommDestroy = dlsym(g_rccl.h, "ncclCommDestroy");
     *(void**)&g_rccl.GetErrorString = dlsym(g_rccl.h, "ncclGetErrorString");
+    *(void**)&g_rccl.Send = dlsym(g_rccl.h, "ncclSend");
+    *(void**)&g_rccl.Recv = dlsym(g_rccl.h, "ncclRecv");
+    *(void**)&g_rccl.GroupStart = dlsym(g_rccl.h, "ncclGroupStart");
+    *(void**)&g_rccl.GroupEnd = dlsym(g_rccl.h, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         g_dist_err = "RCCL symbols missing";
         return CENO_HIP_ERR_UNSUPPORTED;
@@ -112,6 +124,36 @@ struct ShmSeg {
     ShmRank ranks[1];                  // `world` entries
 };
 
+// In-process group: `world` virtual ranks = threads of ONE process on one device, each with its own stream.  The bulk
+// exchange is a device-to-device copy out of the peers' published send buffers between two barriers; small payloads go
+// through host memory.  It exists so that the multi-rank commit path runs — bit for bit — on a single-GPU box (tests), and
+// serves a single-process deployment; across processes the transports are RCCL (bulk) and the shared segment (messages).
+struct ceno_dist_local_group {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    std::vector<const uint64_t*> send_base;       // per rank: packed send buffer (device)
+    std::vector<std::vector<size_t>> send_off;    // per rank, per destination: offset in words
+    std::vector<uint64_t> small;                  // per rank: up to 128 words
+    bool barrier() {
+        std::unique_lock<std::mutex> g(mu);
+        if (broken) return false;
+        const uint64_t my = gen;
+        if (++arrived == world) {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(g, std::chrono::seconds(120), [&] { return gen != my || broken; })) broken = true;  // a peer died
+        if (broken) cv.notify_all();
+        return !broken;
+    }
+};
+
 struct ceno_dist_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
@@ -122,6 +164,7 @@ struct ceno_dist_comm {
     size_t shm_bytes = 0;
     uint64_t shm_seq = 0;        // exchanges done so far (identical on every rank)
     bool h_recv_plain = false;
+    struct ceno_dist_local_group* local = nullptr;  // in-process group of virtual ranks (threads sharing one device)
 };
 
 int ceno_dist_unique_id(uint8_t* out128) {
@@ -819,6 +862,254 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
         if (m) ceno_hip_mle_free(ctx, m);
     if (rc) g_dist_err = ceno_hip_last_error(ctx);
     return rc;
+}
+
+}  // extern "C"
+
+// ==================================================================================================================
+// Trace commitment across ranks (SURVEY.md §8(e) "Commit path"; reference single-device flow: commit_traces,
+// ceno_zkvm/src/scheme/gpu/mod.rs:927-1020).  Columns are independent, so every rank RS-encodes ITS columns (no exchange);
+// a Merkle leaf hashes one codeword row across ALL columns, so the codeword is re-sharded by rows with ONE all-to-all — the
+// only step of the whole proving path whose cost is xGMI bandwidth ((world-1)/world of the codeword leaves each rank; with
+// point-to-point links every pair of ranks exchanges its block directly, RCCL grouped send/recv) — after which rank g owns
+// rows [g R/world, (g+1) R/world) = the sub-tree under node g of level log2(world).  The sub-tree roots are gathered and
+// the top log2(world) levels are hashed on every rank.  Equal to the single-device commitment bit for bit.
+// ==================================================================================================================
+namespace {
+
+int dist_fail(int code, const std::string& msg) {
+    g_dist_err = msg;
+    return code;
+}
+
+// all-to-all of unequal blocks of 64-bit words.  send block for destination g: send + soff[g], scnt[g] words;
+// block from source g lands at recv + roff[g], rcnt[g] words.  The own block is copied on the device.
+int exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const size_t* soff, const size_t* scnt, uint64_t* recv, const size_t* roff,
+                    const size_t* rcnt, hipStream_t st) {
+    const int W = c->world, me = c->rank;
+    if (scnt[me] != rcnt[me]) return dist_fail(CENO_HIP_ERR_INVALID, "exchange_blocks: own block size mismatch");
+    if (c->local) {
+        ceno_dist_local_group* G = c->local;
+        if (hipStreamSynchronize(st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: sync before publish failed");
+        {
+            std::lock_guard<std::mutex> g(G->mu);
+            G->send_base[me] = send;
+            G->send_off[me].assign(soff, soff + W);
+        }
+        if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: a peer of the local group is gone");
+        for (int g = 0; g < W; g++) {
+            const uint64_t* src;
+            {
+                std::lock_guard<std::mutex> lk(G->mu);
+                src = G->send_base[g] + G->send_off[g][me];
+            }
+            if (rcnt[g] && hipMemcpyAsync(recv + roff[g], src, rcnt[g] * 8, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: device copy failed");
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: sync failed");
+        if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: a peer of the local group is gone");  // send buffers may be reused now
+        return 0;
+    }
+    if (!c->comm) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: the communicator has no bulk transport (RCCL or local group)");
+    if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+        return dist_fail(CENO_HIP_ERR_UNSUPPORTED, "this RCCL has no ncclSend / ncclRecv");
+    const bool self_p2p = getenv("CENO_DIST_SELF_P2P") && atoi(getenv("CENO_DIST_SELF_P2P")) != 0;  // tests: own block through RCCL too
+    if (!self_p2p && scnt[me] &&
+        hipMemcpyAsync(recv + roff[me], send + soff[me], scnt[me] * 8, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: device copy failed");
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+    for (int k = 0; k < W && r == ncclSuccess; k++) {
+        // pairwise order (me + k, me - k): every link of the fully connected xGMI mesh carries one block per direction
+        const int to = (me + k) % W, from = (me - k + W) % W;
+        if (k == 0 && !self_p2p) continue;
+        if (scnt[to]) r = g_rccl.Send(send + soff[to], scnt[to], ncclUint64, to, c->comm, st);
+        if (r == ncclSuccess && rcnt[from]) r = g_rccl.Recv(recv + roff[from], rcnt[from], ncclUint64, from, c->comm, st);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return nccl_fail(r, "ncclSend/ncclRecv");
+    if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
+    return 0;
+}
+
+// every rank contributes 4 words, everyone gets world x 4 (host)
+int gather_digests(ceno_dist_comm* c, const uint64_t* mine4, uint64_t* out, hipStream_t st) {
+    const int W = c->world;
+    if (c->local) {
+        ceno_dist_local_group* G = c->local;
+        {
+            std::lock_guard<std::mutex> g(G->mu);
+            memcpy(&G->small[(size_t)c->rank * 128], mine4, 32);
+        }
+        if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "gather_digests: a peer of the local group is gone");
+        {
+            std::lock_guard<std::mutex> g(G->mu);
+            for (int r = 0; r < W; r++) memcpy(out + 4 * r, &G->small[(size_t)r * 128], 32);
+        }
+        if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "gather_digests: a peer of the local group is gone");
+        return 0;
+    }
+    if (c->shm) {
+        if (int rc = shm_gather_ext(c, mine4, 2)) return rc;
+        memcpy(out, c->h_recv, (size_t)W * 32);
+        return 0;
+    }
+    if (!c->comm) return dist_fail(CENO_HIP_ERR_STATE, "gather_digests: communicator without a transport");
+    if (hipMemcpyAsync(c->d_send, mine4, 32, hipMemcpyHostToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "gather_digests: upload failed");
+    if (int rc = gather_ext(c, 2, st)) return rc;
+    memcpy(out, c->h_recv, (size_t)W * 32);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+ceno_dist_local_group* ceno_dist_local_group_create(int world) {
+    if (world < 1 || (world & (world - 1)) != 0) return nullptr;
+    auto* G = new ceno_dist_local_group();
+    G->world = world;
+    G->send_base.assign((size_t)world, nullptr);
+    G->send_off.assign((size_t)world, std::vector<size_t>((size_t)world, 0));
+    G->small.assign((size_t)world * 128, 0);
+    return G;
+}
+void ceno_dist_local_group_destroy(ceno_dist_local_group* g) { delete g; }
+int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_comm** out) {
+    if (!group || !out || rank < 0 || rank >= group->world) return dist_fail(CENO_HIP_ERR_INVALID, "comm_init_local: bad arguments");
+    auto* c = new ceno_dist_comm();
+    c->world = group->world;
+    c->rank = rank;
+    c->local = group;
+    *out = c;
+    return 0;
+}
+
+int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t* local_cols_dev, const int* widths, int log_rows, int log_blowup,
+                            ceno_hip_stream s, uint64_t* out_rows_dev, ceno_hip_merkle** out_subtree, uint64_t* out_subtree_roots,
+                            uint64_t* out_root) {
+    if (!ctx || !c || !widths || !s || !out_rows_dev || !out_subtree || !out_root)
+        return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: NULL argument (an explicit stream is required)");
+    const int W = c->world, me = c->rank;
+    int log_w = 0;
+    while ((1 << log_w) < W) log_w++;
+    if ((1 << log_w) != W) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: world must be a power of two");
+    if (log_rows < 0 || log_blowup < 0 || log_rows + log_blowup < log_w || log_rows + log_blowup > 40)
+        return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad log_rows / log_blowup");
+    size_t w_total = 0;
+    for (int g = 0; g < W; g++) {
+        if (widths[g] < 0) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: negative width");
+        w_total += (size_t)widths[g];
+    }
+    const size_t w_local = (size_t)widths[me];
+    if (w_total == 0 || w_total > (1u << 20)) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad total width");
+    if (w_local && !local_cols_dev) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: local_cols_dev is NULL");
+    const size_t R = (size_t)1 << (log_rows + log_blowup), rl = R >> log_w;
+    hipStream_t st = (hipStream_t)s;
+    auto fail_hip = [&](int rc) {
+        g_dist_err = ceno_hip_last_error(ctx);
+        return rc;
+    };
+
+    // 1. encode my columns; 2. pack: block for destination h = rows [h rl, (h+1) rl) of each of my columns (one strided copy
+    // per destination, the rows of one column are contiguous)
+    uint64_t *d_cw = nullptr, *d_pack = nullptr;
+    std::vector<ceno_hip_mle*> scratch;  // pool blocks through the C ABI (the host layer has no other access to the pool)
+    auto pool_words = [&](size_t words, uint64_t** out) -> int {
+        int nv = 0;
+        while (((size_t)1 << nv) < words) nv++;
+        ceno_hip_mle* m = nullptr;
+        int rc = ceno_hip_mle_alloc(ctx, nv, 0, &m);
+        if (rc) return rc;
+        scratch.push_back(m);
+        *out = ceno_hip_mle_device_ptr(m);
+        return 0;
+    };
+    auto release = [&]() {
+        for (auto* m : scratch) ceno_hip_mle_free(ctx, m);
+        scratch.clear();
+    };
+    int rc = 0;
+    // a one-rank communicator normally skips the exchange; CENO_DIST_SELF_P2P=1 (tests) sends the own block through RCCL
+    const bool exchange = W > 1 || (c->comm && getenv("CENO_DIST_SELF_P2P") && atoi(getenv("CENO_DIST_SELF_P2P")) != 0);
+    if (w_local) {
+        if ((rc = pool_words(w_local * R, &d_cw)) || (exchange && (rc = pool_words(w_local * R, &d_pack)))) {
+            release();
+            return fail_hip(rc);
+        }
+        if ((rc = ceno_hip_rs_encode(ctx, local_cols_dev, log_rows, (int)w_local, log_blowup, d_cw, s))) {
+            release();
+            return fail_hip(rc);
+        }
+    }
+    std::vector<size_t> soff((size_t)W), scnt((size_t)W), roff((size_t)W), rcnt((size_t)W);
+    size_t col0 = 0;
+    for (int g = 0; g < W; g++) {
+        soff[g] = (size_t)g * w_local * rl;
+        scnt[g] = w_local * rl;
+        roff[g] = col0 * rl;  // source ranks in order = global column order
+        rcnt[g] = (size_t)widths[g] * rl;
+        col0 += (size_t)widths[g];
+    }
+    if (!exchange) {
+        if (hipMemcpyAsync(out_rows_dev, d_cw, w_local * R * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            release();
+            return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: copy failed");
+        }
+    } else {
+        if (w_local)
+            for (int h = 0; h < W; h++)
+                if (hipMemcpy2DAsync(d_pack + soff[h], rl * 8, d_cw + (size_t)h * rl, R * 8, rl * 8, w_local, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                    release();
+                    return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: pack failed");
+                }
+        if ((rc = exchange_blocks(c, d_pack, soff.data(), scnt.data(), out_rows_dev, roff.data(), rcnt.data(), st))) {
+            (void)hipStreamSynchronize(st);
+            release();
+            return rc;
+        }
+    }
+    // 3. sub-tree over my rows; 4. gather the sub-tree roots, hash the top levels (node = permute(left || right)[0..4))
+    ceno_hip_merkle* sub = nullptr;
+    if ((rc = ceno_hip_merkle_commit(ctx, out_rows_dev, log_rows + log_blowup - log_w, (int)w_total, s, &sub))) {
+        (void)hipStreamSynchronize(st);
+        release();
+        return fail_hip(rc);
+    }
+    uint64_t mine[4];
+    if ((rc = ceno_hip_merkle_root(ctx, sub, mine, s))) {  // synchronises: encode, pack and exchange are complete behind it
+        ceno_hip_merkle_free(ctx, sub);
+        release();
+        return fail_hip(rc);
+    }
+    release();
+    std::vector<uint64_t> level((size_t)W * 4);
+    if ((rc = gather_digests(c, mine, level.data(), st))) {
+        ceno_hip_merkle_free(ctx, sub);
+        return rc;
+    }
+    if (out_subtree_roots) memcpy(out_subtree_roots, level.data(), (size_t)W * 32);
+    if (W > 1) {
+        uint64_t* d_states = nullptr;
+        if ((rc = pool_words((size_t)W * 4, &d_states))) {
+            ceno_hip_merkle_free(ctx, sub);
+            return fail_hip(rc);
+        }
+        for (size_t n = (size_t)W; n > 1; n >>= 1) {  // n digests = n/2 states of 8 words
+            if (hipMemcpyAsync(d_states, level.data(), n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+                ceno_hip_poseidon2_permute(ctx, d_states, n / 2, s) != 0 ||
+                hipMemcpyAsync(level.data(), d_states, n * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                release();
+                ceno_hip_merkle_free(ctx, sub);
+                return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: top levels failed");
+            }
+            for (size_t j = 0; j < n / 2; j++) memmove(&level[4 * j], &level[8 * j], 32);
+        }
+        release();
+    }
+    memcpy(out_root, level.data(), 32);
+    *out_subtree = sub;
+    return 0;
 }
 
 }  // extern "C"

@@ -370,6 +370,25 @@ typedef struct ceno_dist_class {
 int ceno_dist_batched_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_dist_class* classes, int n_classes, int n_total,
                                      int max_degree, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs,
                                      uint64_t* out_challenges, uint64_t* out_final_evals);
+/* Trace commitment across ranks (SURVEY section 8e "Commit path"; single-device reference flow: commit_traces,
+ * ceno_zkvm/src/scheme/gpu/mod.rs:927-1020).  Rank g holds widths[g] columns of the padded trace, column-major on the
+ * device (column stride 2^log_rows); `widths` has `world` entries and is identical on every rank.  Every rank RS-encodes
+ * its columns, ONE all-to-all of unequal blocks (RCCL grouped send/recv over the point-to-point xGMI links; device copies
+ * inside a local group) re-shards the codeword by rows, rank g hashes the sub-tree over rows [g R/world, (g+1) R/world),
+ * R = 2^(log_rows+log_blowup), the sub-tree roots are gathered (shared segment when attached, else RCCL) and the top
+ * log2(world) levels are hashed on every rank.  out_rows_dev: (sum widths) x R/world words, column-major = this rank's
+ * codeword rows (caller-allocated, kept for the openings); *out_subtree: Merkle tree over them (ceno_hip_merkle_free);
+ * out_subtree_roots: world x 4 words or NULL; out_root: 4 words = the single-device commitment root, bit for bit. */
+int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t* local_cols_dev, const int* widths, int log_rows,
+                            int log_blowup, ceno_hip_stream s, uint64_t* out_rows_dev, ceno_hip_merkle** out_subtree,
+                            uint64_t* out_subtree_roots, uint64_t* out_root);
+/* In-process group of `world` virtual ranks (threads of one process sharing a device, one stream each): the transport the
+ * single-GPU tests run the multi-rank commit path on, and a single-process deployment's.  Create the group once, one
+ * communicator per rank (ceno_dist_comm_destroy), destroy the group last. */
+typedef struct ceno_dist_local_group ceno_dist_local_group;
+ceno_dist_local_group* ceno_dist_local_group_create(int world);
+void ceno_dist_local_group_destroy(ceno_dist_local_group* g);
+int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_comm** out);
 const char* ceno_dist_last_error(void);
 
 #ifdef __cplusplus

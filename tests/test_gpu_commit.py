@@ -285,3 +285,99 @@ def test_sharded_commit_virtual_ranks_equals_single_device(dev):
         local = res[r]["codeword_rows"].cpu().numpy().view(np.uint64).reshape(sum(width_split), R // world)
         assert np.array_equal(local[:, 5], row)
     pcs.free()
+
+
+@pytest.mark.parametrize("world,width_split", [(4, [3, 1, 4, 2]), (2, [5, 0]), (8, [1, 2, 1, 3, 1, 1, 2, 1])])
+def test_native_sharded_commit_local_group_equals_single_device(dev, world, width_split):
+    """ceno_dist_commit_traces (C++ driver of the SURVEY section 8e commit path) with `world` virtual ranks = threads of this
+    process, each on its own stream, exchanging through the in-process group: root, sub-tree roots and the local codeword
+    rows equal the single-device commitment; ragged and EMPTY column shares"""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    from ceno_amd import dist as cdist
+    from ceno_amd import prover
+
+    L = prover.plib()
+    L.ceno_dist_local_group_create.restype = C.c_void_p
+    L.ceno_dist_local_group_create.argtypes = [C.c_int]
+    L.ceno_dist_local_group_destroy.argtypes = [C.c_void_p]
+    L.ceno_dist_comm_init_local.restype = C.c_int
+    L.ceno_dist_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    log_rows, blow = 9, 1
+    rows = 1 << log_rows
+    wt = sum(width_split)
+    full = po.rand_base(rows * wt, 91).reshape(rows, wt)
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, [full], blow, stream)
+    want = pcs.root(0)
+    group = L.ceno_dist_local_group_create(world)
+    assert group
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            comm = C.c_void_p()
+            assert L.ceno_dist_comm_init_local(group, rank, C.byref(comm)) == 0
+            c0 = sum(width_split[:rank])
+            cols = np.ascontiguousarray(full[:, c0:c0 + width_split[rank]].T)
+            d_cols = torch.from_numpy(cols.view(np.int64).copy()).to("cuda:0") if cols.size else torch.empty(1, dtype=torch.int64, device="cuda:0")
+            torch.cuda.synchronize()
+            s = dev.stream_create()
+            res[rank] = cdist.sharded_commit_native(dev, comm, d_cols.data_ptr(), width_split, log_rows, blow, rank, s)
+            dev.sync(s)
+            L.ceno_dist_comm_destroy(comm)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=200)
+    assert not errors, errors
+    R = rows << blow
+    for r in range(world):
+        assert np.array_equal(res[r]["root"], want), r
+        assert np.array_equal(res[r]["subtree_roots"], res[0]["subtree_roots"])
+        idx = r * (R // world) + 3
+        row, _ = pcs.open_row(0, idx)
+        local = res[r]["codeword_rows"].cpu().numpy().view(np.uint64).reshape(wt, R // world)
+        assert np.array_equal(local[:, 3], row)
+        dev.check(dev.L.ceno_hip_merkle_free(dev.h, res[r]["subtree"]))
+    L.ceno_dist_local_group_destroy(group)
+    pcs.free()
+    dev.stream_destroy(stream)
+
+
+def test_native_sharded_commit_world1_through_rccl_self_exchange(dev, monkeypatch):
+    """the RCCL arm of the same driver on a one-rank communicator: symbols resolve, and with CENO_DIST_SELF_P2P=1 the own block
+    really goes through ncclSend / ncclRecv inside a group (the call sequence the multi-GPU run uses)"""
+    import ctypes as C
+
+    import torch
+
+    from ceno_amd import dist as cdist
+    from ceno_amd import prover
+
+    log_rows, blow, w = 10, 1, 6
+    full = po.rand_base((1 << log_rows) * w, 92).reshape(1 << log_rows, w)
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, [full], blow, stream)
+    want = pcs.root(0)
+    comm = prover.RcclComm(1, 0, None)
+    d_cols = torch.from_numpy(np.ascontiguousarray(full.T).view(np.int64).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    for self_p2p in ("0", "1"):
+        monkeypatch.setenv("CENO_DIST_SELF_P2P", self_p2p)
+        out = cdist.sharded_commit_native(dev, comm.h, d_cols.data_ptr(), [w], log_rows, blow, 0, stream)
+        assert np.array_equal(out["root"], want), self_p2p
+        row, _ = pcs.open_row(0, 77)
+        local = out["codeword_rows"].cpu().numpy().view(np.uint64).reshape(w, -1)
+        assert np.array_equal(local[:, 77], row)
+        dev.check(dev.L.ceno_hip_merkle_free(dev.h, out["subtree"]))
+    comm.close()
+    pcs.free()
+    dev.stream_destroy(stream)
