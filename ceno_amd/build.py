@@ -58,7 +58,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     force = force or _flags_changed()
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + \
         glob.glob(os.path.join(ROOT, "include", "*.h"))
     jobs = []
     objs = []
@@ -81,7 +81,7 @@ def build_prover(force: bool = False) -> str:
     srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
     if not srcs:
         return ""
-    hdrs = glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    hdrs = glob.glob(os.path.join(HOST, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
     if force or _stale(LIB_PROVER, srcs + hdrs + [LIB_HIP]):
         cxx = shutil.which("g++") or "g++"
         _run([cxx] + CXX_FLAGS + ["-shared", "-o", LIB_PROVER] + srcs +

@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/ceno_hip.h"
-#include "gl64.cuh"
+#include "gl64.hpp"
 
 using gl::E2;
 

@@ -1,7 +1,7 @@
 // Merkle tree handle and helpers shared by poseidon2.hip (trace commitment) and basefold.hip (commit phase).
 #pragma once
 #include "common.hpp"
-#include "poseidon2.cuh"
+#include "poseidon2.hpp"
 
 struct PoseidonParams {
     p2::Params p;

@@ -4,7 +4,7 @@
 // selectors gkr_iop/src/selector.rs:131-245; LSB-first variable order gkr_iop/src/utils.rs:215-232.
 // All kernels are HBM-streaming: 16 B per lane coalesced loads/stores, grid-stride.
 #include "common.hpp"
-#include "reduce.cuh"
+#include "reduce.hpp"
 
 using namespace gl;
 

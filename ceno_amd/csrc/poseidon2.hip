@@ -4,14 +4,14 @@
 // matrix: hash every codeword ROW with a Poseidon2 sponge, build the 2-to-1 compression tree, root =
 // commitment (shape restated in ceno_recursion_v2/src/pcs/mod.rs:1111-1316).
 // Sponge = overwrite-mode padding-free sponge (rate 4, width 8, 4-word digest); compression =
-// truncated permutation of left || right.  PARITY UNPINNED — constants, see poseidon2.cuh.
+// truncated permutation of left || right.  PARITY UNPINNED — constants, see poseidon2.hpp.
 //
 // One lane runs one permutation with the 8-word state in registers (16 VGPRs); the matrix is column-
 // major so the lanes of a wave read consecutive rows of a column: 8 B per lane coalesced.  The kernel
 // is ALU bound (118 S-boxes x 4 mults + linear layers per permutation); reported separately from the
 // HBM roofline.
 #include "common.hpp"
-#include "poseidon2.cuh"
+#include "poseidon2.hpp"
 
 using namespace gl;
 
@@ -20,7 +20,7 @@ static constexpr unsigned MAXB = 4096;
 
 #include "merkle.hpp"
 
-// The built-in round constants are PLACEHOLDERS (poseidon2.cuh): roots, challenges and proofs made with them are
+// The built-in round constants are PLACEHOLDERS (poseidon2.hpp): roots, challenges and proofs made with them are
 // self-consistent but can never verify against the reference.  Until a complete table has been supplied through
 // ceno_hip_poseidon2_set_constants every first use says so on stderr, and CENO_HIP_REQUIRE_PINNED_POSEIDON2=1 turns the
 // commit / open / transcript entry points into errors instead (what a production caller should set).

@@ -8,7 +8,7 @@
 // ceno_hip_poseidon2_set_constants() once goldens from the real BasicTranscript are available.
 // The internal diagonal is the published MATRIX_DIAG_8_GOLDILOCKS.
 #pragma once
-#include "gl64.cuh"
+#include "gl64.hpp"
 
 namespace p2 {
 

@@ -5,7 +5,7 @@
 // the four row totals are combined through v_readlane.  (ds_bpermute-based __shfl_down cost ~5 us for
 // three extension accumulators in the latency-critical tail rounds.)
 #pragma once
-#include "gl64.cuh"
+#include "gl64.hpp"
 
 namespace red {
 

@@ -18,7 +18,7 @@
 // arrive (`epilogue`), which applies class coefficients and the host-computed front-load scalars and
 // writes the d extension elements of the message straight into pinned host memory + a sequence flag the
 // host spins on (or into a caller device buffer): one launch and no D2H copy per round.
-#include "sumcheck_dev.cuh"
+#include "sumcheck_dev.hpp"
 #include "sumcheck_gen.hpp"
 
 #include <algorithm>

@@ -2,7 +2,7 @@
 // message reduction ("last block done"), the pipelined challenge relay, slot tables.
 #pragma once
 #include "common.hpp"
-#include "reduce.cuh"
+#include "reduce.hpp"
 
 using namespace gl;
 

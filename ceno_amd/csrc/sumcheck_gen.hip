@@ -18,7 +18,7 @@
 //     one kernel per round instead of two per class.
 // Round 0 of a main-constraint sumcheck (base-field witness columns under extension-field selectors) has its own phase 2:
 // column products stay in the base field and c_t * P_t goes unreduced into 160-bit accumulators (as k_accum_base0).
-#include "sumcheck_dev.cuh"
+#include "sumcheck_dev.hpp"
 #include "sumcheck_gen.hpp"
 
 static constexpr unsigned GEN_FIXED = 640;  // bytes in front of the stage: block-sum scratch (4 x MAXD E2), challenge words, flag

@@ -1,6 +1,6 @@
 // Plan tables of the LDS-blocked generic round kernel (sumcheck_gen.hip), built by the host side in sumcheck.hip.
 #pragma once
-#include "sumcheck_dev.cuh"
+#include "sumcheck_dev.hpp"
 
 static constexpr unsigned GEN_PAD = 2;            // row padding of the stage, in 16-byte units (rows start on different banks)
 static constexpr unsigned GEN_MAX_UNITS = 256;   // stage rows are addressed by one byte

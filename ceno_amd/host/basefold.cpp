@@ -23,7 +23,7 @@
 #include <map>
 #include <vector>
 
-#include "../csrc/gl64.cuh"
+#include "../csrc/gl64.hpp"
 #include "pcs_data.hpp"
 
 using gl::E2;

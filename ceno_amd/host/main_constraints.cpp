@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/ceno_prover.h"
-#include "../csrc/gl64.cuh"
+#include "../csrc/gl64.hpp"
 
 using gl::E2;
 

@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "../csrc/gl64.cuh"
+#include "../csrc/gl64.hpp"
 #include "transcript.hpp"
 
 using gl::E2;
@@ -317,7 +317,7 @@ int ceno_prover_prove_rotation(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, cons
     return 0;
 }
 
-// ---- host-side field arithmetic exposed for CPU tests of the shared gl64.cuh code ----
+// ---- host-side field arithmetic exposed for CPU tests of the shared gl64.hpp code ----
 uint64_t ceno_prover_test_gl_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t ceno_prover_test_gl_add(uint64_t a, uint64_t b) { return gl::add(a, b); }
 uint64_t ceno_prover_test_gl_sub(uint64_t a, uint64_t b) { return gl::sub(a, b); }

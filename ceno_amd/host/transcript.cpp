@@ -5,7 +5,7 @@
 //  - poseidon2: duplex challenger over Goldilocks (poseidon2_host.cpp); PARITY UNPINNED.
 #include "transcript.hpp"
 
-#include "../csrc/gl64.cuh"
+#include "../csrc/gl64.hpp"
 
 namespace {
 
@@ -65,7 +65,7 @@ extern "C" ceno_transcript* ceno_transcript_stub_new(uint64_t seed) {
 // ------------------------------------------------------------------------------------------------
 // Poseidon2 duplex challenger over Goldilocks (width 8, rate 4) — the shape of p3-challenger's
 // DuplexChallenger that the reference's EXT `transcript::BasicTranscript` wraps.  PARITY UNPINNED
-// (SURVEY.md §8c(i)): round constants are placeholders (csrc/poseidon2.cuh) and the byte -> field packing
+// (SURVEY.md §8c(i)): round constants are placeholders (csrc/poseidon2.hpp) and the byte -> field packing
 // of labels (`bytes_to_field_elements`, EXT ff_ext) is ASSUMED to be 8 little-endian bytes per element,
 // by analogy with the 4-byte packing the in-tree BabyBear restatement uses
 // (ceno_recursion_v2/src/utils.rs:44-67).
@@ -76,10 +76,10 @@ extern "C" ceno_transcript* ceno_transcript_stub_new(uint64_t seed) {
 #include <mutex>
 #include <vector>
 
-#include "../csrc/poseidon2.cuh"
+#include "../csrc/poseidon2.hpp"
 
 // Host-only form of the same permutation: the challenger sits on the critical path of every sumcheck round (two
-// permutations between a message and its challenge), and the shared source (csrc/poseidon2.cuh) is written for the GPU's
+// permutations between a message and its challenge), and the shared source (csrc/poseidon2.hpp) is written for the GPU's
 // 32-bit multiplier.  Here products and the sums of the linear layers are plain 128-bit integers, reduced once per word
 // with 2^64 = 2^32 - 1, 2^96 = -1 (mod p); bit-identical to p2::permute (tests/test_host_cpu.py), ~3x faster on x86-64.
 namespace p2host {
@@ -260,7 +260,7 @@ extern "C" int ceno_prover_test_label_to_field(const uint8_t* bytes, size_t n, u
     return k;
 }
 
-// host permutation for tests of the shared poseidon2.cuh source
+// host permutation for tests of the shared poseidon2.hpp source
 extern "C" void ceno_prover_test_poseidon2_permute(uint64_t* state8) {
     p2::permute(state8, host_params(false));
 }

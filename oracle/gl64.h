@@ -16,7 +16,7 @@
  * so none of them exercises W).
  *
  * This file deliberately uses unsigned __int128 so that it shares no code with the
- * 32-bit-limb device implementation in ceno_amd/csrc/gl64.cuh.
+ * 32-bit-limb device implementation in ceno_amd/csrc/gl64.hpp.
  */
 #ifndef CENO_ORACLE_GL64_H
 #define CENO_ORACLE_GL64_H

@@ -1,6 +1,6 @@
 """CPU-side checks of the product's host code (no GPU needed):
  - the C ABI library loads and exports every symbol include/ceno_hip.h declares;
- - the field arithmetic shared between device kernels and the host layer (csrc/gl64.cuh, compiled for
+ - the field arithmetic shared between device kernels and the host layer (csrc/gl64.hpp, compiled for
    the host inside libceno_prover.so) matches the oracle / big-int model bit for bit;
  - the product's stub transcript equals the oracle's stub transcript.
 """
@@ -106,7 +106,7 @@ def test_device_field_source_on_host_matches_bigint(built):
 
 
 def test_unreduced_ext_accumulator_matches_bigint(built):
-    """gl::E2Acc (ceno_amd/csrc/gl64.cuh): sums of ext products kept in 160-bit limbs, reduced once"""
+    """gl::E2Acc (ceno_amd/csrc/gl64.hpp): sums of ext products kept in 160-bit limbs, reduced once"""
     _, prover = built
     L = prover.plib()
     rng = random.Random(5)

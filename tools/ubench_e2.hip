@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-#include "../ceno_amd/csrc/gl64.cuh"
+#include "../ceno_amd/csrc/gl64.hpp"
 using namespace gl;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
