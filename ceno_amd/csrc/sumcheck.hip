@@ -884,7 +884,11 @@ __global__ void k_finish_evals(const MleSlot* __restrict__ slots, int n, E2 r, E
         lo = E2{sl.in[0], 0};
         hi = E2{sl.in[1], 0};
     }
-    out_host[i] = lo + r * (hi - lo);
+    // one 16-byte write-through system-scope store: the host watches these words (ceno_hip_sumcheck_finish)
+    const E2 v = lo + r * (hi - lo);
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host + i), "v"(w) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1709,6 +1713,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         sc->d_hmsg = (uint64_t*)((char*)db + 128);
         sc->h_slots = (MleSlot*)((char*)hb + 128 + msg_bytes);
         *sc->h_flag = 0;
+        for (size_t k = 0; k < 2 * (MAXD + (size_t)plan->num_mles); k++) reinterpret_cast<uint64_t*>(sc->h_pinned)[k] = MSG_INVALID;
         mailbox_clear(sc->h_mailbox);
         // plan blob: pinned staging -> one device allocation, one copy (the pinned block outlives the copy)
         char* h_blob = (char*)hb + ((128 + msg_bytes + slot_bytes + 15) & ~(size_t)15);
@@ -1788,22 +1793,39 @@ static void sc_advance(ceno_hip_sumcheck* sc, ScClass& cl) {
     }
 }
 
-// wait until the kernel has published sequence number `seq` in pinned host memory
-static int sc_wait_flag(ceno_hip_sumcheck* sc, unsigned long long seq) {
-    volatile unsigned long long* f = sc->h_flag;
+// wait until `n_words` pinned words (pre-filled with MSG_INVALID) have all been written by the device
+static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_words) {
     unsigned long long spins = 0;
-    while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != seq) {
+    for (;;) {
+        int k = 0;
+        while (k < n_words && __atomic_load_n(&words[k], __ATOMIC_ACQUIRE) != MSG_INVALID) k++;
+        if (k == n_words) return 0;
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-        __builtin_ia32_pause();  // several lanes may be spinning on their flags at once
+        __builtin_ia32_pause();  // several lanes may be spinning at once
 #endif
         if ((++spins & 0xFFFFF) == 0) {
-            // every ~1M polls make sure the stream is still alive (a faulted kernel never writes the flag)
+            // every ~1M polls make sure the stream is still alive (a faulted kernel never writes its message)
             hipError_t q = hipStreamQuery(sc->st);
             if (q != hipSuccess && q != hipErrorNotReady)
                 return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round kernel failed: %s", hipGetErrorString(q));
-            if (q == hipSuccess && __atomic_load_n(f, __ATOMIC_ACQUIRE) != seq)
+            if (q == hipSuccess) {
+                k = 0;
+                while (k < n_words && __atomic_load_n(&words[k], __ATOMIC_ACQUIRE) != MSG_INVALID) k++;
+                if (k == n_words) return 0;
                 return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round finished without publishing its message");
+            }
         }
+    }
+}
+// take the round message out of the pinned block and arm the words for the next one (the reset is ordered before whatever
+// releases the next kernel: the mailbox post fences, a launch rings a doorbell)
+static int sc_take_message(ceno_hip_sumcheck* sc, uint64_t* h_out) {
+    uint64_t* w = reinterpret_cast<uint64_t*>(sc->h_pinned);
+    const int n_words = 2 * sc->d;
+    TRY(sc_wait_words(sc, w, n_words));
+    for (int k = 0; k < n_words; k++) {
+        h_out[k] = w[k];
+        __atomic_store_n(&w[k], MSG_INVALID, __ATOMIC_RELAXED);
     }
     return 0;
 }
@@ -1997,7 +2019,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
         timespec ta, tb;
         if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
-        TRY(sc_wait_flag(sc, (unsigned long long)(i + 1)));
+        TRY(sc_take_message(sc, h_out));
         if (dbg) {
             clock_gettime(CLOCK_MONOTONIC, &tb);
             static timespec last_ret = {0, 0};
@@ -2006,7 +2028,6 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                     (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) / 1e3);
             last_ret = tb;
         }
-        memcpy(h_out, sc->h_pinned, (size_t)d * sizeof(E2));
         sc->round++;
         return 0;
     }
@@ -2188,8 +2209,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             memcpy(h_out, scalars, (size_t)d * sizeof(E2));
         }
     } else if (h_out) {
-        TRY(sc_wait_flag(sc, seq));
-        memcpy(h_out, sc->h_pinned, (size_t)d * sizeof(E2));
+        TRY(sc_take_message(sc, h_out));
     }
     sc->round++;
     return 0;
@@ -2236,9 +2256,13 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
             const MleSlot* d_slots = reinterpret_cast<const MleSlot*>(reinterpret_cast<char*>(sc->d_hflag) + (reinterpret_cast<char*>(h) - reinterpret_cast<char*>(sc->h_block)));
             E2* h_ev = sc->h_pinned + MAXD;
             E2* d_ev = reinterpret_cast<E2*>(sc->d_hmsg) + MAXD;  // device view of the same pinned words
+            for (size_t k = 0; k < 2 * cl.mles.size(); k++) reinterpret_cast<uint64_t*>(h_ev)[k] = MSG_INVALID;  // arm (several classes share the words)
             hipLaunchKernelGGL(k_finish_evals, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(), r, d_ev);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+            // the evaluation words were armed with MSG_INVALID at begin: watching them costs the kernel's own time, a stream
+            // synchronisation ~10 us more (completion signal + runtime).  Everything queued before this kernel has completed
+            // when its stores are visible, and they are its last instructions.
+            TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(h_ev), 2 * (int)cl.mles.size()));
             for (size_t k = 0; k < cl.mles.size(); k++) {
                 ScMle& M = sc->mles[cl.mles[k]];
                 M.eval = h_ev[k];

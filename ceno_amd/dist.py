@@ -381,6 +381,7 @@ def sharded_commit(dev, local_columns: np.ndarray, log_rows: int, log_blowup: in
         outs = [torch.empty(widths[g] * rl, dtype=torch.int64, device=device) for g in range(world)]
         dist.all_to_all(outs, [send[h].reshape(-1) for h in range(world)])
         recv = torch.cat(outs)  # source ranks in order = global column order
+        torch.cuda.current_stream().synchronize()  # torch's stream produced `recv`; the library reads it on ITS stream
     w_total = sum(widths)
     rl = R // world
     sub = api.Merkle(dev, recv.data_ptr(), log_rows + log_blowup - log_w, w_total, stream)
@@ -391,6 +392,7 @@ def sharded_commit(dev, local_columns: np.ndarray, log_rows: int, log_blowup: in
     level = torch.from_numpy(roots.view(np.int64).copy()).to(device)
     while level.shape[0] > 1:  # top log2(world) levels: node = permute(left || right)[0..4)
         st = level.reshape(-1, 8).contiguous()
+        torch.cuda.current_stream().synchronize()
         api.poseidon2_permute(dev, st.data_ptr(), st.shape[0], stream)
         dev.sync(stream)
         level = st[:, :4].contiguous()
