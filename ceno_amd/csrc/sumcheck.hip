@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
-                                             E2 r, Epilogue ep) {
+                                             E2 r, Epilogue ep, E2* __restrict__ out_evals) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     E2* bufA = reinterpret_cast<E2*>(dyn);                 // [n_mles][2 * pairs0]
     E2* bufB = bufA + (size_t)n_mles * 2 * pairs0;         // [n_mles][pairs0]
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         if (threadIdx.x == 0) {
             // next_seq = 0: the challenge is fetched right here, not relayed to another launch
             finish_message<D>(acc, ep, (unsigned long long)(i + 1), 0ull);
-            if (i + 1 < n) {
+            if (i + 1 < n || out_evals) {  // after the last message: the challenge the final evaluations are taken at
                 unsigned long long c0 = 0, c1 = 0;
                 const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
                 s_chal[0] = c0;
@@ -846,7 +846,23 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         const int ts_ = sc_; sc_ = sn; sn = ts_;
         pairs >>= 1;
     }
-    // the two elements per table that the last round was computed on: ceno_hip_sumcheck_finish folds them
+    // the final evaluations f_m(r_0..r_{n-1}) = lo + r_{n-1} (hi - lo), straight into the pinned words the host watches: no
+    // separate launch (and kernel boundary) for them at the end of every sumcheck
+    if (out_evals) {
+        __syncthreads();
+        if (s_chal[2] != 0) {
+            const E2Pre rp = e2_pre(E2{s_chal[0], s_chal[1]});
+            for (int m = threadIdx.x; m < n_mles; m += NT) {
+                const E2 lo = cur[(size_t)m * sc_], hi = cur[(size_t)m * sc_ + 1];
+                const E2 v = lo + e2_mul_pre(rp, hi - lo);
+                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_evals + m), "v"(w) : "memory");
+            }
+        }
+    }
+    // the two elements per table that the last round was computed on (ceno_hip_sumcheck_finish folds them when the
+    // evaluations were not produced above)
     for (int idx = threadIdx.x; idx < n_mles * 2; idx += NT) {
         const int m = idx >> 1, j = idx & 1;
         st_e2(last_slots[m].out + 2 * j, cur[(size_t)m * sc_ + j]);
@@ -970,6 +986,7 @@ struct ceno_hip_sumcheck {
     unsigned* d_counter = nullptr; // arrival counter of the in-kernel reduction
     E2* d_round_acc = nullptr;     // running message total across the classes of one round
     uint64_t* d_hmsg = nullptr;    // device view of h_pinned (message lands directly in host memory)
+    bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
     unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
     unsigned long long* d_hflag = nullptr;
     unsigned long long seq = 0;
@@ -1026,7 +1043,7 @@ static inline void mailbox_clear(Mailbox* m) {
 
 static void sc_release(ceno_hip_sumcheck* sc) {
     if (!sc) return;
-    if (sc->pipelined && sc->round < sc->n && sc->h_mailbox) {
+    if (sc->pipelined && !sc->finished && sc->h_mailbox) {  // also after the last round: the tail may be waiting for the final challenge
         __atomic_store_n(&sc->h_mailbox->abort, 1ull, __ATOMIC_RELEASE);  // queued kernels exit at their wait
         host_store_fence();
     }
@@ -1185,21 +1202,21 @@ static bool tail_eligible(size_t n_mles, size_t pairs, int d, size_t n_flat) {
 }
 template <int D>
 static void launch_tail_d(const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
-                          hipStream_t st) {
+                          E2* out_evals, hipStream_t st) {
     hipLaunchKernelGGL((k_tail<D>), dim3(1), dim3(NT), tail_lds_bytes((size_t)n_mles, pairs, D, (size_t)n_flat), st, pl, last_slots, n_mles, n_flat, (int)pairs, i0, n,
-                       e2_zero(), ep);
+                       e2_zero(), ep, out_evals);
 }
 static void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
-                        hipStream_t st) {
+                        E2* out_evals, hipStream_t st) {
     switch (d) {
-    case 1: launch_tail_d<1>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 2: launch_tail_d<2>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 3: launch_tail_d<3>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 4: launch_tail_d<4>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 5: launch_tail_d<5>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
-    default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, st); break;
+    case 1: launch_tail_d<1>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 2: launch_tail_d<2>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 3: launch_tail_d<3>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 4: launch_tail_d<4>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 5: launch_tail_d<5>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
     }
 }
 
@@ -1960,7 +1977,10 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             pl.term_idx = cl.d_term_idx;
             const int tnt = fused_tnt(k, pairs);
             if (tail_eligible(k, pairs, sc->d, (size_t)cl.n_flat)) {  // this launch produces rounds i .. n-1
-                launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, sc->n, ep, sc->st);
+                static const bool tail_evals = !(getenv("CENO_HIP_TAIL_EVALS") && atoi(getenv("CENO_HIP_TAIL_EVALS")) == 0);  // A/B switch
+                sc->tail_evals = tail_evals;
+                launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, sc->n, ep,
+                            tail_evals ? reinterpret_cast<E2*>(sc->d_hmsg) + MAXD : nullptr, sc->st);
                 upto = sc->n;
                 break;
             }
@@ -2240,6 +2260,23 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
         CHECK_ARG(ctx, last_challenge2, "last challenge is NULL");
         const E2 r{last_challenge2[0], last_challenge2[1]};
         size_t h_cursor = 0;
+        if (sc->pipelined && sc->tail_evals) {
+            // the persistent tail kernel is waiting for this challenge and writes the evaluations itself
+            ScClass& cl = sc->classes[0];
+            volatile Mailbox* mb = sc->h_mailbox;
+            mb->chal[0] = r.c0;
+            mb->chal[1] = r.c1;
+            host_store_fence();
+            __atomic_store_n(&sc->h_mailbox->chal_seq, (unsigned long long)sc->n, __ATOMIC_RELEASE);
+            host_store_fence();
+            E2* h_ev = sc->h_pinned + MAXD;
+            TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(h_ev), 2 * (int)cl.mles.size()));
+            for (size_t k = 0; k < cl.mles.size(); k++) {
+                ScMle& M = sc->mles[cl.mles[k]];
+                M.eval = h_ev[k];
+                M.done = true;
+            }
+        } else
         for (auto& cl : sc->classes) {
             if (cl.nv != sc->n) continue;
             // the slot table is read by the kernel from the pinned block itself (device view of the same words): no

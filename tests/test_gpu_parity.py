@@ -229,6 +229,19 @@ def test_sumcheck_abandoned_midway_does_not_hang(dev, prover):
         sc.free()
         dev.sync()
         assert time.time() - t0 < 2.0
+    # a generic plan small enough to run inside the persistent tail kernel, abandoned after ALL its rounds but before finish:
+    # the kernel is then waiting for the challenge it takes the final evaluations at, and the free must release it
+    small = [dev.synthetic(6, True, 90 + j) for j in range(3)]
+    sc = Sumcheck(dev, small, po.ext([1, 2]), [[0, 1], [1, 2]], 6, 2)
+    sc.set_pipelined(True)
+    ch = None
+    for _ in range(6):
+        sc.round(ch)
+        ch = (7, 8)
+    t0 = time.time()
+    sc.free()
+    dev.sync()
+    assert time.time() - t0 < 2.0
     # the device is still healthy and a fresh sumcheck on the same tables is still bit-exact
     tables = [m.download() for m in mles]
     msgs, chal, fin = prover.sumcheck_prove(dev, mles, po.ext([1]), [[0, 1, 2]], 14, 3, prover.Transcript.stub(4))
