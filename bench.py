@@ -103,12 +103,15 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     # metric M2 shape: one synthetic shard of 2^20 cycles through the whole create_proof flow
     shard = synthetic.ShardFlow(dev, prover)
     fork = (lambda: prover.Transcript.poseidon2(b"fork")) if transcript_name == "poseidon2" else (lambda: prover.Transcript.stub(0xF0))
-    bs = None
-    for _ in range(reps):
-        r = shard.run(new_transcript, fork)
-        if bs is None or r["total_ms"] < bs["total_ms"]:
-            bs = r
+    bs, by_lanes = None, {}
+    for lanes in (1, 4):  # chip proofs serially, then four at a time (one host thread + one HIP stream per lane: the chip scheduler)
+        for _ in range(reps):
+            r = shard.run(new_transcript, fork, lanes=lanes)
+            by_lanes[lanes] = min(by_lanes.get(lanes, 1e30), r["total_ms"])
+            if bs is None or r["total_ms"] < bs["total_ms"]:
+                bs = dict(r, chip_proof_lanes=lanes)
     shard.close()
+    bs["total_ms_by_chip_proof_lanes"] = by_lanes
     bs["workload"] = ("metric M2 shape: synthetic shard, 2^20 cycles over 8 ADD-shaped chips of 2^19..2^13 rows x 22 columns: commit all traces, "
                       "8 chip proofs (tower relation) on forked transcripts, one batched main sumcheck, one Basefold opening; witness generation "
                       "and the emulator are upstream and excluded")

@@ -60,12 +60,15 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
             // are the caller's to synchronise before freeing (include/ceno_hip.h, "Memory").
             const hipStream_t cur = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
             auto& fl = it->second;
-            int pick = -1, probes = 0;
+            int pick = -1;
+            // first choice: a block this stream (or nobody alive) used last — no runtime call; concurrent lanes mostly recycle
+            // their own blocks, and a hipStreamQuery per candidate under the pool mutex would serialise them
             for (int k = (int)fl.size() - 1; k >= 0 && pick < 0; k--) {
                 const hipStream_t last = fl[k].second;
                 if (!last || last == cur || !stream_alive(ctx, last)) pick = k;
-                else if (probes++ < 4 && hipStreamQuery(last) == hipSuccess) pick = k;
             }
+            for (int k = (int)fl.size() - 1, probes = 0; k >= 0 && pick < 0 && probes < 2; k--, probes++)
+                if (hipStreamQuery(fl[k].second) == hipSuccess) pick = k;
             if (pick >= 0) {
                 void* p = fl[pick].first;
                 fl.erase(fl.begin() + pick);

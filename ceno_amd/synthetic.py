@@ -146,6 +146,7 @@ class ShardFlow:
             assert sum(1 << r for r in self.LOG_ROWS) == 1 << 20
         self.traces = [dev.synthetic(((1 << r) * w - 1).bit_length(), False, 0x5A0 + i) for i, r in enumerate(self.LOG_ROWS)]
         self.stream = dev.stream_create()
+        self.lane_streams = []
 
     def run(self, transcript_factory, fork_factory, lanes: int = 1) -> dict:
         """lanes > 1: the chip proofs run concurrently, one host thread and one HIP stream per lane, largest chip first (the
@@ -201,7 +202,11 @@ class ShardFlow:
                 import os
 
                 plain = os.environ.get("CENO_LANE_PLAIN") == "1"   # A/B: same-priority streams instead of the rotating priorities
-                streams = [dev.stream_create() if plain else dev.stream_create_lane(l) for l in range(lanes)]
+                # lane streams live as long as the flow: creating a HIP stream costs ~4 ms and destroying one ~2 ms
+                while len(self.lane_streams) < lanes:
+                    l = len(self.lane_streams)
+                    self.lane_streams.append(dev.stream_create() if plain else dev.stream_create_lane(l))
+                streams = self.lane_streams[:lanes]
 
                 def worker(l):
                     while True:
@@ -216,8 +221,6 @@ class ShardFlow:
                     t.start()
                 for t in ths:
                     t.join()
-                for st in streams:
-                    dev.stream_destroy(st)
                 chips.extend(done)                                    # results in task order (scheduler.rs:303-304)
             for _, _, s in chips:                                     # one sample per fork back into the main transcript (prover.rs:567-570)
                 tr.append_ext(s)
@@ -249,4 +252,7 @@ class ShardFlow:
     def close(self):
         for t in self.traces:
             t.free()
+        for st in self.lane_streams:
+            self.dev.stream_destroy(st)
+        self.lane_streams = []
         self.dev.stream_destroy(self.stream)

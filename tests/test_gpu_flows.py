@@ -442,8 +442,11 @@ def test_gkr_prove_multi_layer_with_rotation_first_matches_oracle(dev, prover, s
 # ------------------------------------------------------------------------------------------------------------------
 # whole create_proof flow on a small synthetic shard (the shape of BASELINE config #5 / metric M2), verified end to end
 # ------------------------------------------------------------------------------------------------------------------
-def test_shard_flow_end_to_end_verifies(dev, prover):
-    """commit -> challenges -> per-chip proofs on forked transcripts -> merged fork samples -> batched main sumcheck -> one
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_shard_flow_end_to_end_verifies(dev, prover, lanes):
+    """(lanes > 1: the chip proofs run concurrently on their own host threads and HIP streams, the reference's chip scheduler;
+    forked transcripts make the result independent of the interleaving)
+    commit -> challenges -> per-chip proofs on forked transcripts -> merged fork samples -> batched main sumcheck -> one
     opening of all traces (ceno_zkvm/src/scheme/prover.rs:319-611), replayed by a verifier assembled from the oracle's restated
     TowerVerify / sumcheck verifier / Basefold verifier on ONE transcript: any deviation in what the prover binds, or in
     which order, makes a later challenge differ and the verification fail"""
@@ -452,7 +455,7 @@ def test_shard_flow_end_to_end_verifies(dev, prover):
     log_rows = (9, 8, 7, 6, 6)
     w = 22
     flow = synthetic.ShardFlow(dev, prover, w=w, n_queries=20, pow_bits=8, log_rows=log_rows)
-    res = flow.run(lambda: prover.Transcript.stub(0x5A), lambda: prover.Transcript.stub(0xF0))
+    res = flow.run(lambda: prover.Transcript.stub(0x5A), lambda: prover.Transcript.stub(0xF0), lanes=lanes)
     a = flow.artifacts
     assert res["total_ms"] > 0
     vt = po.StubTranscript(0x5A)
