@@ -66,6 +66,7 @@ def lib():
         "ceno_hip_stream_create_lane": (i, [vp, i, vpp]),
         "ceno_hip_stream_destroy": (i, [vp, vp]),
         "ceno_hip_stream_adopt": (i, [vp, vp]),
+        "ceno_hip_stream_bind": (i, [vp, vp]),
         "ceno_hip_selftest_field": (i, [vp, i, vp, C.c_size_t, u64p]),
         "ceno_hip_stream_sync": (i, [vp, vp]),
         "ceno_hip_mem_info": (i, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),

@@ -279,6 +279,11 @@ int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* ou
     *out = (ceno_hip_stream)s;
     return 0;
 }
+int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "ctx is NULL");
+    (void)ctx_stream(ctx, s);
+    return 0;
+}
 int ceno_hip_stream_adopt(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     CHECK_ARG(ctx, ctx && s, "bad stream");
     std::lock_guard<std::mutex> g(ctx->mu);

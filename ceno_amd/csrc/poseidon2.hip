@@ -287,7 +287,7 @@ int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, ui
 }
 
 int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
-    if (t) (void)hipStreamSynchronize(ctx->default_stream);
+    // no wait: the pool hands a freed block to another stream only once the stream that used it last has drained (ctx_alloc)
     merkle_release(ctx, t);
     return 0;
 }

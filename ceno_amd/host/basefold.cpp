@@ -106,6 +106,18 @@ void tree_streams_release(const TreeStreams& ts) {
 }
 }  // namespace
 
+// the same pooled pair serves commit_traces as its helper streams (pcs_data.hpp): another stream object per context would
+// shift the runtime's stream -> hardware-queue mapping and put the opening's two tree streams on one queue
+bool ceno_aux_streams_acquire(ceno_hip_ctx* ctx, hipStream_t out[2], int* device) {
+    TreeStreams ts;
+    if (!tree_streams_acquire(ctx, &ts)) return false;
+    out[0] = ts.s[0];
+    out[1] = ts.s[1];
+    *device = ts.device;
+    return true;
+}
+void ceno_aux_streams_release(hipStream_t s[2], int device) { tree_streams_release(TreeStreams{{s[0], s[1]}, device}); }
+
 extern "C" {
 
 size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries) {

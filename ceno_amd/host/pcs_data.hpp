@@ -1,5 +1,7 @@
 // PcsData of the trace commitment, shared by commit.cpp (commit_traces) and basefold.cpp (batch open).
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include <vector>
 
 #include "../../include/ceno_prover.h"
@@ -15,3 +17,7 @@ struct ceno_pcs_data {
     std::vector<Mat> mats;
     int log_blowup = 0;
 };
+
+// pooled pair of auxiliary streams per device (highest / lowest priority; basefold.cpp): acquire, use, release
+bool ceno_aux_streams_acquire(ceno_hip_ctx* ctx, hipStream_t out[2], int* device);
+void ceno_aux_streams_release(hipStream_t s[2], int device);

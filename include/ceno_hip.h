@@ -75,6 +75,9 @@ int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* registers a HIP stream the caller created itself with the pool's cross-stream ordering (see "Memory" above); the stream must
  * stay alive until ceno_hip_stream_destroy (which also forgets it) or the context is destroyed */
 int ceno_hip_stream_adopt(ceno_hip_ctx* ctx, ceno_hip_stream s);
+/* the calling thread's following allocations and frees belong to work on stream `s` (NULL: the default stream).  Every entry
+ * point that takes a stream does this implicitly; a thread that drives SEVERAL streams calls it before allocating for one. */
+int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s);
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);
