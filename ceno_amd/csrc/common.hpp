@@ -43,6 +43,8 @@ struct ceno_hip_ctx {
     int vram_state = 0;
     char* vram_arena = nullptr;
     std::vector<int> vram_free_slots;
+    // ---- persistent multi-workgroup kernels (k_mid) wait for each other and must ALL be resident: workgroups in flight ----
+    int mid_wgs_in_flight = 0;  // guarded by `mu`; budget MID_WG_BUDGET (sumcheck.hip)
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----

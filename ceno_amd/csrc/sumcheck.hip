@@ -22,6 +22,7 @@
 #include "sumcheck_gen.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <numeric>
 #include <ctime>
@@ -869,6 +870,226 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// persistent MID rounds: the rounds between the streaming kernels and the single-workgroup tail, in ONE launch of W
+// workgroups and without a kernel boundary.  LSB-first folding pairs neighbours, so workgroup b keeps ITS slice of every
+// table (elements [b 2S0, (b+1) 2S0) of round i0) in LDS for good and folds it in place — no table data ever crosses
+// workgroups.  Per round the workgroups only send their D partial sums to workgroup 0 (armed rows, see below), which
+// adds them and publishes the message; the challenge is read from the mailbox by every workgroup itself when the mailbox
+// lives in device memory (large-BAR boxes), otherwise workgroup 0 fetches it across PCIe and passes it on through one
+// 64-byte line PER WORKGROUP (pollers of a shared line serialise at ~90 loads per us).  The launch ends with the
+// last round too large for the single-workgroup tail: the slices go back to memory and the tail kernel, already queued, takes
+// over (its rounds cost ~9.5 us against ~15 us here, so nothing that fits the tail is kept).
+// Relay words carry a per-sumcheck nonce, so the lines need no clearing.  All W workgroups must be resident at once
+// (they wait for each other): W <= 64 with <= 64 KB of LDS each leaves room for eight such launches on 256 CUs.
+// ------------------------------------------------------------------------------------------------
+struct alignas(64) MidRelay {
+    unsigned long long seq;   // (nonce << 8) | round + 1, or (nonce << 8) | 0xFF: give up
+    unsigned long long pad;
+    unsigned long long chal[2];
+    unsigned long long pad2[4];
+};
+template <int D>
+__global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restrict__ out_slots, int n_mles, int n_flat, int S0, int i0, int i1, E2 r,
+                                            Epilogue ep, MidRelay* __restrict__ relay, unsigned long long nonce, int direct_poll) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int stride = 2 * S0;
+    E2* tab = reinterpret_cast<E2*>(dyn);                  // [n_mles][2 * S0], folded in place
+    E2* smem = tab + (size_t)n_mles * stride;              // [(NT/64) * D]
+    unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // c0, c1, ok, last
+    TailTerm* ft = reinterpret_cast<TailTerm*>(s_chal + 4);
+    const int W = gridDim.x, b = blockIdx.x;
+    for (int ti = threadIdx.x; ti < n_flat; ti += NT) flatten_term(pl, ti, ft[ti]);
+    if (ep.dbg && ep.bcast && b == 0 && threadIdx.x == 0) ep.bcast->dbg[(i0 + 1) & 63][0] = wall_clock64();
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) return;
+    }
+    {   // stage this workgroup's slice of the tables of round i0 (folded with r_{i0-1} unless i0 == 0)
+        const E2Pre rp = e2_pre(r);
+        const bool fold = pl.use_out != 0;
+        for (int idx = threadIdx.x; idx < n_mles * stride; idx += NT) {
+            const int m = idx / stride, j = idx - m * stride;
+            const size_t g = (size_t)b * stride + j;
+            const MleSlot sl = pl.slots[m];
+            E2 v;
+            if (fold) {
+                if (sl.in_ext) {
+                    const E2 a = ld_e2(sl.in + 4 * g), c = ld_e2(sl.in + 4 * g + 2);
+                    v = a + e2_mul_pre(rp, c - a);
+                } else {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * g);
+                    const E2 t = e2_mul_base(r, sub(w.y, w.x));
+                    v = E2{add(t.c0, w.x), t.c1};
+                }
+            } else {
+                v = sl.in_ext ? ld_e2(sl.in + 2 * g) : E2{sl.in[g], 0};
+            }
+            tab[idx] = v;
+        }
+    }
+    __syncthreads();
+    int pairs = S0;
+    for (int i = i0; i <= i1; i++) {
+        E2 acc[D];
+#pragma unroll
+        for (int t = 0; t < D; t++) acc[t] = e2_zero();
+        for (int idx = threadIdx.x; idx < n_flat * pairs; idx += NT) {
+            const int ti = idx / pairs, p = idx - ti * pairs;
+            const TailTerm& tt = ft[ti];
+            const E2 c = tt.c;
+            E2 pr[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) pr[t] = c;
+            bool seeded = false;
+            for (uint32_t k = 0; k < tt.nf; k++) {
+                const E2* q = tab + (size_t)tt.idx[k] * stride + 2 * p;
+                mul_points<D>(pr, seeded, c, q[1], q[1] - q[0]);
+            }
+#pragma unroll
+            for (int t = 0; t < D; t++) acc[t] = acc[t] + pr[t];
+        }
+        red::block_sum<D, NT>(acc, smem);
+        // Exchange of the partial sums without a counter: every workgroup fires its D partial sums at its row (write-through,
+        // no wait) and workgroup 0 watches the rows — they were armed with MSG_INVALID, which no canonical element equals —
+        // one lane per row, adds them, re-arms the rows and publishes.  (An arrival counter costs the writer a store drain and
+        // an atomic round trip and the last arriver an acquire + reload: three trips through memory instead of one.)
+        if (threadIdx.x == 0) {
+            uint64_t* row = ep.partials + (size_t)b * D * 2;
+#pragma unroll
+            for (int t = 0; t < D; t++) {
+                typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+                const u4 w = {(unsigned)acc[t].c0, (unsigned)(acc[t].c0 >> 32), (unsigned)acc[t].c1, (unsigned)(acc[t].c1 >> 32)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(row + 2 * t), "v"(w) : "memory");
+            }
+        }
+        if (i == i1) {  // the tables this round was computed on go back to memory for the tail kernel: `pairs` pairs per workgroup
+            const int ne = 2 * pairs;
+            for (int idx = threadIdx.x; idx < n_mles * ne; idx += NT) {
+                const int m = idx / ne, j = idx - m * ne;
+                st_e2(out_slots[m].out + 2 * ((size_t)b * ne + j), tab[(size_t)m * stride + j]);
+            }
+        }
+        if (b == 0) {
+            if (threadIdx.x == 0) s_chal[3] = 1;
+            __syncthreads();  // smem is reused
+            E2 tot[D];
+#pragma unroll
+            for (int t = 0; t < D; t++) tot[t] = e2_zero();
+            bool got = true;
+            for (int bb = threadIdx.x; bb < W; bb += NT) {
+                uint64_t* row = ep.partials + (size_t)bb * D * 2;
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                uint64_t w[2 * D];
+                for (;;) {
+                    bool all = true;
+#pragma unroll
+                    for (int k = 0; k < 2 * D; k++) {
+                        w[k] = ld_agent(row + k);
+                        all = all && w[k] != MSG_INVALID;
+                    }
+                    if (all) break;
+                    if ((++spins & 63u) == 0 && wall_clock64() - t0 > ep.poll_ticks) { got = false; break; }
+                }
+                if (!got) {
+                    s_chal[3] = 0;  // a workgroup never delivered (it was never resident, or the device is going down)
+                    break;
+                }
+#pragma unroll
+                for (int t = 0; t < D; t++) tot[t] = tot[t] + E2{w[2 * t], w[2 * t + 1]};
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) st_agent(row + k, MSG_INVALID);  // re-arm: drained before the message goes out
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s_chal[3] == 0) return;  // nothing is published: the host sees the stream drain without a message
+            red::block_sum<D, NT>(tot, smem);
+            if (threadIdx.x == 0) {
+                finish_message<D>(tot, ep, (unsigned long long)(i + 1), 0ull);
+                if (i == i1 || !direct_poll) {
+                    unsigned long long c0 = 0, c1 = 0;
+                    const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
+                    s_chal[0] = c0;
+                    s_chal[1] = c1;
+                    s_chal[2] = ok ? 1ull : 0ull;
+                    if (i == i1) {  // the next round belongs to the tail kernel: relay the way every launch does (read_challenge)
+                        Bcast* bc = ep.bcast;
+                        if (ok) {
+                            __hip_atomic_store(&bc->chal[0], c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&bc->chal[1], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        __hip_atomic_store(&bc->ready_seq, ok ? (unsigned)(i + 1) : ABORT_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (i == i1) return;
+            if (!direct_poll) {  // mailbox across PCIe: one poller, the challenge travels on through one line per workgroup
+                __syncthreads();
+                for (int t = threadIdx.x; t < W; t += NT) {
+                    if (t == 0) continue;
+                    MidRelay* line = relay + t;
+                    __hip_atomic_store(&line->chal[0], s_chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&line->chal[1], s_chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&line->seq, (nonce << 8) | (s_chal[2] ? (unsigned long long)(i + 1) : 0xFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else if (i == i1) {
+            return;
+        }
+        if (direct_poll) {
+            // the mailbox lives in device memory the host writes through the BAR: every workgroup watches it itself
+            if (threadIdx.x == 0) {
+                unsigned long long c0 = 0, c1 = 0;
+                const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
+                s_chal[0] = c0;
+                s_chal[1] = c1;
+                s_chal[2] = ok ? 1ull : 0ull;
+            }
+        } else if (b != 0) {
+            if (threadIdx.x == 0) {
+                const MidRelay* line = relay + b;
+                const unsigned long long want = (nonce << 8) | (unsigned long long)(i + 1), dead = (nonce << 8) | 0xFFull;
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                bool ok = false;
+                for (;;) {
+                    const unsigned long long v = __hip_atomic_load(&line->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == want) { ok = true; break; }
+                    if (v == dead) break;
+                    if ((++spins & 63u) == 0 && wall_clock64() - t0 > 2 * ep.poll_ticks) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_chal[0] = ok ? __hip_atomic_load(&line->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                s_chal[1] = ok ? __hip_atomic_load(&line->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                s_chal[2] = ok ? 1ull : 0ull;
+            }
+        }
+        __syncthreads();
+        if (s_chal[2] == 0) return;  // aborted / timed out
+        // fold in place: item j of a table reads elements 2j, 2j+1 and writes element j; a pass reads everything it needs
+        // before the barrier, and later passes only touch higher indices
+        const E2Pre rp = e2_pre(E2{s_chal[0], s_chal[1]});
+        const int items = n_mles * pairs;
+        for (int base = 0; base < items; base += NT) {
+            const int idx = base + threadIdx.x;
+            E2 v = e2_zero();
+            int m = 0, j = 0;
+            if (idx < items) {
+                m = idx / pairs;
+                j = idx - m * pairs;
+                const E2 lo = tab[(size_t)m * stride + 2 * j], hi = tab[(size_t)m * stride + 2 * j + 1];
+                v = lo + e2_mul_pre(rp, hi - lo);
+            }
+            __syncthreads();
+            if (idx < items) tab[(size_t)m * stride + j] = v;
+        }
+        __syncthreads();
+        pairs >>= 1;
+    }
+}
+
 // gather element 0 of every listed table into out[i] (final evaluations)
 struct GatherArgs {
     const MleSlot* slots;
@@ -986,6 +1207,7 @@ struct ceno_hip_sumcheck {
     unsigned* d_counter = nullptr; // arrival counter of the in-kernel reduction
     E2* d_round_acc = nullptr;     // running message total across the classes of one round
     uint64_t* d_hmsg = nullptr;    // device view of h_pinned (message lands directly in host memory)
+    int mid_reserved = 0;                   // workgroups of a k_mid launch booked against the context's residency budget
     bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
     unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
     unsigned long long* d_hflag = nullptr;
@@ -1058,6 +1280,11 @@ static void sc_release(ceno_hip_sumcheck* sc) {
                         (hb.dbg[i][1] - hb.dbg[i][0]) / 100.0, (hb.dbg[i][2] - hb.dbg[i][1]) / 100.0, (hb.dbg[i][3] - hb.dbg[i][2]) / 100.0,
                         i > 1 ? (hb.dbg[i][0] - hb.dbg[i - 1][3]) / 100.0 : 0.0);
         }
+    }
+    if (sc->mid_reserved) {
+        std::lock_guard<std::mutex> g(sc->ctx->mu);
+        sc->ctx->mid_wgs_in_flight -= sc->mid_reserved;
+        sc->mid_reserved = 0;
     }
     for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
     ctx_pinned_free(sc->ctx, sc->h_block);
@@ -1217,6 +1444,60 @@ static void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int
     case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
     case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
     default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    }
+}
+
+// persistent mid rounds (k_mid): W workgroups of S0 pairs each; S0 = the largest power of two <= 128 whose slice fits
+static size_t mid_lds_bytes(size_t n_mles, size_t s0, int d, size_t n_flat) {
+    return (n_mles * 2 * s0 + (size_t)(NT / 64) * d) * sizeof(E2) + 64 + n_flat * 48;
+}
+static int mid_max_w() {
+    static int v = [] {
+        const char* e = getenv("CENO_HIP_MID_W");  // 0 disables the persistent mid rounds (A/B measurements)
+        int w = e ? atoi(e) : 256;
+        while (w & (w - 1)) w &= w - 1;
+        return std::min(w, 256);
+    }();
+    return v;
+}
+// geometry for a round of `pairs` pairs, or W = 0 when the round is not (yet) one for k_mid: as many workgroups as allowed
+// (CENO_HIP_MID_W, default 256, and what the context's residency budget still has), slices of at most CENO_HIP_MID_S0 (default 128) pairs that fit the LDS
+static void mid_geometry(size_t n_mles, size_t pairs, int d, size_t n_flat, int w_cap, int* W, int* S0) {
+    *W = 0;
+    *S0 = 0;
+    w_cap = std::min(w_cap, mid_max_w());
+    while (w_cap & (w_cap - 1)) w_cap &= w_cap - 1;
+    if (w_cap < 4 || n_mles >= 65536) return;
+    static const size_t s0_cap = [] {
+        const char* e = getenv("CENO_HIP_MID_S0");
+        size_t v = e ? (size_t)atoi(e) : 128;
+        while (v & (v - 1)) v &= v - 1;
+        return std::max<size_t>(v, 2);
+    }();
+    size_t s0 = s0_cap;
+    while (s0 >= 2 && mid_lds_bytes(n_mles, s0, d, n_flat) > 60 * 1024) s0 >>= 1;
+    if (s0 < 2 || pairs > (size_t)w_cap * s0 || pairs < 8) return;
+    const size_t w = std::min<size_t>((size_t)w_cap, pairs / 2);  // at least two pairs per workgroup in the first round
+    *W = (int)w;
+    *S0 = (int)(pairs / w);
+}
+template <int D>
+static void launch_mid_d(const DevPlan& pl, const MleSlot* out_slots, int n_mles, int n_flat, int W, int S0, int i0, int i1, const Epilogue& ep,
+                         MidRelay* relay, unsigned long long nonce, int direct_poll, hipStream_t st) {
+    hipLaunchKernelGGL((k_mid<D>), dim3((unsigned)W), dim3(NT), mid_lds_bytes((size_t)n_mles, (size_t)S0, D, (size_t)n_flat), st, pl, out_slots, n_mles, n_flat,
+                       S0, i0, i1, e2_zero(), ep, relay, nonce, direct_poll);
+}
+static void launch_mid(int d, const DevPlan& pl, const MleSlot* out_slots, int n_mles, int n_flat, int W, int S0, int i0, int i1, const Epilogue& ep,
+                       MidRelay* relay, unsigned long long nonce, int direct_poll, hipStream_t st) {
+    switch (d) {
+    case 1: launch_mid_d<1>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 2: launch_mid_d<2>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 3: launch_mid_d<3>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 4: launch_mid_d<4>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 5: launch_mid_d<5>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 6: launch_mid_d<6>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    case 7: launch_mid_d<7>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
+    default: launch_mid_d<8>(pl, out_slots, n_mles, n_flat, W, S0, i0, i1, ep, relay, nonce, direct_poll, st); break;
     }
 }
 
@@ -1983,6 +2264,41 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                             tail_evals ? reinterpret_cast<E2*>(sc->d_hmsg) + MAXD : nullptr, sc->st);
                 upto = sc->n;
                 break;
+            }
+            {
+                // Residency budget: the workgroups of a k_mid launch wait for each other, so all of them must fit on the chip
+                // next to every other such launch in flight (lanes): 256 CUs x 2 workgroups of <= 60 KB LDS, minus headroom.
+                static constexpr int MID_WG_BUDGET = 448;
+                int W = 0, S0 = 0, w_free = 0;
+                {
+                    std::lock_guard<std::mutex> g(ctx->mu);
+                    w_free = MID_WG_BUDGET - ctx->mid_wgs_in_flight;
+                }
+                mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, sc->mid_reserved ? 0 : w_free, &W, &S0);
+                // rounds i .. i1 in one launch of W resident workgroups, i1 = the last round too large for the tail kernel
+                int i1 = i;
+                while (i1 + 1 < sc->n && !tail_eligible(k, pairs >> (i1 + 1 - i), sc->d, (size_t)cl.n_flat)) i1++;
+                if (W >= 4 && i1 > i && i1 + 1 < sc->n && (pairs >> (i1 - i)) >= (size_t)W) {
+                    {
+                        std::lock_guard<std::mutex> g(ctx->mu);
+                        if (ctx->mid_wgs_in_flight + W > MID_WG_BUDGET) W = 0;  // another lane took it meanwhile
+                        else ctx->mid_wgs_in_flight += W;
+                    }
+                    if (W == 0) goto no_mid;
+                    sc->mid_reserved = W;
+                    static std::atomic<unsigned long long> nonce_src{0};
+                    const unsigned long long nonce = (++nonce_src) & ((1ull << 56) - 1);
+                    MidRelay* relay = reinterpret_cast<MidRelay*>(reinterpret_cast<char*>(ep.partials) + 65536);
+                    // the partial-sum rows start out armed (every byte 0xFF = MSG_INVALID); queued ahead of the launch, off the critical path
+                    HIP_TRY(ctx, hipMemsetAsync(ep.partials, 0xFF, (size_t)W * MAXD * sizeof(E2), sc->st));
+                    static const bool relay_only = getenv("CENO_HIP_MID_RELAY") && atoi(getenv("CENO_HIP_MID_RELAY")) != 0;  // A/B switch
+                    launch_mid(sc->d, pl, cl.d_slots + (size_t)i1 * k, (int)k, cl.n_flat, W, S0, i, i1, ep, relay, nonce,
+                               sc->vram_slot != nullptr && !relay_only, sc->st);
+                    i = i1;          // the loop continues with round i1 + 1: the persistent tail
+                    upto = sc->n;
+                    continue;
+                }
+            no_mid:;
             }
             if (sc->gen_on && cl.gen && sc->gen_rounds[i].n_comps > 0 && pairs >= gen_pipe_min_pairs()) {
                 const GenRound& R = sc->gen_rounds[i];
