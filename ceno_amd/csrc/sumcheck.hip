@@ -930,6 +930,7 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
     __syncthreads();
     int pairs = S0;
     for (int i = i0; i <= i1; i++) {
+        if (ep.dbg && ep.bcast && b == 0 && threadIdx.x == 0 && i > i0) ep.bcast->dbg[(i + 1) & 63][0] = wall_clock64();
         E2 acc[D];
 #pragma unroll
         for (int t = 0; t < D; t++) acc[t] = e2_zero();
@@ -953,8 +954,11 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
         // no wait) and workgroup 0 watches the rows — they were armed with MSG_INVALID, which no canonical element equals —
         // one lane per row, adds them, re-arms the rows and publishes.  (An arrival counter costs the writer a store drain and
         // an atomic round trip and the last arriver an acquire + reload: three trips through memory instead of one.)
+        // two sets of rows, used alternately: a set is re-armed right AFTER its message has gone out (stores in flight, nobody
+        // waits) and is next written two rounds later, behind a drain that by then costs nothing
+        uint64_t* const rows = ep.partials + (size_t)(i & 1) * W * D * 2;
         if (threadIdx.x == 0) {
-            uint64_t* row = ep.partials + (size_t)b * D * 2;
+            uint64_t* row = rows + (size_t)b * D * 2;
 #pragma unroll
             for (int t = 0; t < D; t++) {
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -977,7 +981,7 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
             for (int t = 0; t < D; t++) tot[t] = e2_zero();
             bool got = true;
             for (int bb = threadIdx.x; bb < W; bb += NT) {
-                uint64_t* row = ep.partials + (size_t)bb * D * 2;
+                uint64_t* row = rows + (size_t)bb * D * 2;
                 const unsigned long long t0 = wall_clock64();
                 unsigned spins = 0;
                 uint64_t w[2 * D];
@@ -997,15 +1001,18 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
                 }
 #pragma unroll
                 for (int t = 0; t < D; t++) tot[t] = tot[t] + E2{w[2 * t], w[2 * t + 1]};
-#pragma unroll
-                for (int k = 0; k < 2 * D; k++) st_agent(row + k, MSG_INVALID);  // re-arm: drained before the message goes out
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-arming stores of the previous round (other set): long done
             __syncthreads();
             if (s_chal[3] == 0) return;  // nothing is published: the host sees the stream drain without a message
             red::block_sum<D, NT>(tot, smem);
+            if (threadIdx.x == 0) finish_message<D>(tot, ep, (unsigned long long)(i + 1), 0ull);
+            for (int bb = threadIdx.x; bb < W; bb += NT) {  // re-arm this round's set behind the message
+                uint64_t* row = rows + (size_t)bb * D * 2;
+#pragma unroll
+                for (int k = 0; k < 2 * D; k++) st_agent(row + k, MSG_INVALID);
+            }
             if (threadIdx.x == 0) {
-                finish_message<D>(tot, ep, (unsigned long long)(i + 1), 0ull);
                 if (i == i1 || !direct_poll) {
                     unsigned long long c0 = 0, c1 = 0;
                     const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
@@ -2290,7 +2297,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                     const unsigned long long nonce = (++nonce_src) & ((1ull << 56) - 1);
                     MidRelay* relay = reinterpret_cast<MidRelay*>(reinterpret_cast<char*>(ep.partials) + 65536);
                     // the partial-sum rows start out armed (every byte 0xFF = MSG_INVALID); queued ahead of the launch, off the critical path
-                    HIP_TRY(ctx, hipMemsetAsync(ep.partials, 0xFF, (size_t)W * MAXD * sizeof(E2), sc->st));
+                    HIP_TRY(ctx, hipMemsetAsync(ep.partials, 0xFF, (size_t)2 * W * MAXD * sizeof(E2), sc->st));  // both sets
                     static const bool relay_only = getenv("CENO_HIP_MID_RELAY") && atoi(getenv("CENO_HIP_MID_RELAY")) != 0;  // A/B switch
                     launch_mid(sc->d, pl, cl.d_slots + (size_t)i1 * k, (int)k, cl.n_flat, W, S0, i, i1, ep, relay, nonce,
                                sc->vram_slot != nullptr && !relay_only, sc->st);
