@@ -1214,6 +1214,7 @@ struct ceno_hip_sumcheck {
     unsigned* d_counter = nullptr; // arrival counter of the in-kernel reduction
     E2* d_round_acc = nullptr;     // running message total across the classes of one round
     uint64_t* d_hmsg = nullptr;    // device view of h_pinned (message lands directly in host memory)
+    bool slots_preloaded = false;           // the slot rows of every round went to the device with the plan blob (single generic class)
     int mid_reserved = 0;                   // workgroups of a k_mid launch booked against the context's residency budget
     bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
     unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
@@ -1997,6 +1998,33 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         if (rc) { sc_release(sc); return rc; }
         // zeroed together with the plan upload below (k_setup), or by a memset when the plan takes the copy path
     }
+    // A single generic class over all n variables is what the pipelined driver runs: its slot table of every round is
+    // deterministic (ping-pong), so it travels inside the plan blob — one set-up kernel, not a second one at round 0
+    size_t off_pre_slots = (size_t)-1;
+    if (sc->classes.size() == 1 && !sc->classes[0].dense && sc->classes[0].nv == n && n >= 1 && !sc->classes[0].terms.empty()) {
+        const ScClass& cl = sc->classes[0];
+        const size_t k = cl.mles.size();
+        std::vector<MleSlot> rows((size_t)(n + 2) * k);
+        std::vector<const uint64_t*> cur(k);
+        std::vector<int> cur_ext(k), which(k);
+        for (size_t m = 0; m < k; m++) {
+            const ScMle& M = sc->mles[cl.mles[m]];
+            cur[m] = M.cur;
+            cur_ext[m] = M.cur_ext;
+            which[m] = M.which;
+        }
+        for (int i = 0; i < n; i++)
+            for (size_t m = 0; m < k; m++) {
+                const ScMle& M = sc->mles[cl.mles[m]];
+                rows[(size_t)i * k + m] = MleSlot{cur[m], M.buf[which[m]], cur_ext[m], 0};
+                if (i > 0) {  // the same walk as sc_advance
+                    cur[m] = M.buf[which[m]];
+                    cur_ext[m] = 1;
+                    which[m] ^= 1;
+                }
+            }
+        off_pre_slots = append(rows.data(), rows.size() * sizeof(MleSlot));
+    }
     hipError_t e = hipSuccess;
     {
         // pinned block: [flag 64 B][mailbox 64 B][message MAXD + evals num_mles (E2)][slot staging]
@@ -2047,6 +2075,10 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
             cl.d_term_off = (uint32_t*)(base + po.to);
             cl.d_term_idx = (uint32_t*)(base + po.ti);
             cl.d_coeffs = (E2*)(base + po.cf);
+        }
+        if (off_pre_slots != (size_t)-1) {
+            sc->classes[0].d_slots = reinterpret_cast<MleSlot*>((char*)d_blob + off_pre_slots);
+            sc->slots_preloaded = true;
         }
     }
 
@@ -2239,7 +2271,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             }
             if (i > 0) sc_advance(sc, cl);
         }
-        if (from == 0) {
+        if (from == 0 && !sc->slots_preloaded) {
             const size_t bytes = (size_t)sc->n * k * sizeof(MleSlot);
             if (bytes <= 16 * 1024) {  // small: one tiny kernel reads the pinned block instead of a copy-engine blit
                 const uint64_t* d_view = reinterpret_cast<const uint64_t*>(reinterpret_cast<char*>(sc->d_hflag) +
