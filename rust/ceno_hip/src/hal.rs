@@ -129,7 +129,11 @@ thread_local! {
 
 /// Bind a stream to the current thread for all GPU work issued from it; also makes the device current for the thread.
 pub fn bind_thread_stream(stream: Arc<HipStream>) -> ThreadStreamGuard {
-    get_hip_hal().expect("Failed to get HIP HAL").ensure_context().expect("hipSetDevice");
+    let hal = get_hip_hal().expect("Failed to get HIP HAL");
+    hal.ensure_context().expect("hipSetDevice");
+    // the pool tags freed blocks with the thread's stream and hands them to another lane only once that stream has drained
+    // (include/ceno_hip.h "Memory"): tell the library which stream this thread works on before it allocates anything
+    unsafe { sys::ceno_hip_stream_bind(hal.ctx, stream.raw()) };
     THREAD_STREAM.with(|c| *c.borrow_mut() = Some(stream));
     ThreadStreamGuard
 }

@@ -79,3 +79,40 @@ impl Drop for HipPcsData {
         unsafe { sys::ceno_pcs_data_free(self.hal.ctx, self.raw) };
     }
 }
+
+/// One rank's share of a commitment that spans the GPUs of a node (`ceno_dist_commit_traces`): this rank
+/// RS-encodes its `widths[rank]` columns, ONE grouped `ncclSend` / `ncclRecv` all-to-all re-shards the codeword by rows, the
+/// rank hashes the sub-tree over its rows and every rank finishes the top `log2(world)` levels from the gathered roots.
+/// `comm` comes from `ceno_dist_comm_init` (RCCL) — the launcher distributes the 128-byte unique id.
+pub struct ShardedCommitment {
+    hal: Arc<HipHal>,
+    pub root: [u64; 4],
+    pub subtree_roots: Vec<[u64; 4]>,
+    /// (sum of widths) x R / world codeword words, column-major: this rank's rows, kept for the openings
+    pub rows: HipMle,
+    subtree: *mut sys::ceno_hip_merkle,
+}
+unsafe impl Send for ShardedCommitment {}
+impl ShardedCommitment {
+    /// # Safety
+    /// `local_cols_dev` must hold `widths[rank]` columns of `2^log_rows` base words each, column-major, on the device.
+    pub unsafe fn commit(hal: &Arc<HipHal>, comm: *mut sys::ceno_dist_comm, world: usize, local_cols_dev: *const u64, widths: &[i32],
+                         log_rows: usize, log_blowup: usize, stream: &HipStream) -> Result<Self> {
+        assert_eq!(widths.len(), world);
+        let w_total: usize = widths.iter().map(|&w| w as usize).sum();
+        let local_words = (w_total << (log_rows + log_blowup)) / world;
+        let rows = HipMle::alloc(hal, (usize::BITS - (local_words.max(2) - 1).leading_zeros()) as usize, false)?;
+        let mut roots = vec![0u64; 4 * world];
+        let mut root = [0u64; 4];
+        let mut subtree = ptr::null_mut();
+        hal.check_prover(sys::ceno_dist_commit_traces(hal.ctx, comm, local_cols_dev, widths.as_ptr(), log_rows as i32, log_blowup as i32,
+                                                      stream.raw(), rows.device_ptr(), &mut subtree, roots.as_mut_ptr(), root.as_mut_ptr()))?;
+        let subtree_roots = roots.chunks(4).map(|c| [c[0], c[1], c[2], c[3]]).collect();
+        Ok(Self { hal: hal.clone(), root, subtree_roots, rows, subtree })
+    }
+}
+impl Drop for ShardedCommitment {
+    fn drop(&mut self) {
+        unsafe { sys::ceno_hip_merkle_free(self.hal.ctx, self.subtree) };
+    }
+}
