@@ -1459,14 +1459,12 @@ static void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int
 static size_t mid_lds_bytes(size_t n_mles, size_t s0, int d, size_t n_flat) {
     return (n_mles * 2 * s0 + (size_t)(NT / 64) * d) * sizeof(E2) + 64 + n_flat * 48;
 }
+// (read per call, not cached: the test-suite switches them between sumchecks)
 static int mid_max_w() {
-    static int v = [] {
-        const char* e = getenv("CENO_HIP_MID_W");  // 0 disables the persistent mid rounds (A/B measurements)
-        int w = e ? atoi(e) : 256;
-        while (w & (w - 1)) w &= w - 1;
-        return std::min(w, 256);
-    }();
-    return v;
+    const char* e = getenv("CENO_HIP_MID_W");  // 0 disables the persistent mid rounds (A/B measurements)
+    int w = e ? atoi(e) : 256;
+    while (w & (w - 1)) w &= w - 1;
+    return std::min(w, 256);
 }
 // geometry for a round of `pairs` pairs, or W = 0 when the round is not (yet) one for k_mid: as many workgroups as allowed
 // (CENO_HIP_MID_W, default 256, and what the context's residency budget still has), slices of at most CENO_HIP_MID_S0 (default 128) pairs that fit the LDS
@@ -1476,13 +1474,11 @@ static void mid_geometry(size_t n_mles, size_t pairs, int d, size_t n_flat, int 
     w_cap = std::min(w_cap, mid_max_w());
     while (w_cap & (w_cap - 1)) w_cap &= w_cap - 1;
     if (w_cap < 4 || n_mles >= 65536) return;
-    static const size_t s0_cap = [] {
-        const char* e = getenv("CENO_HIP_MID_S0");
-        size_t v = e ? (size_t)atoi(e) : 128;
-        while (v & (v - 1)) v &= v - 1;
-        return std::max<size_t>(v, 2);
-    }();
-    size_t s0 = s0_cap;
+    size_t s0 = 128;
+    if (const char* e = getenv("CENO_HIP_MID_S0")) {
+        s0 = (size_t)std::max(atoi(e), 2);
+        while (s0 & (s0 - 1)) s0 &= s0 - 1;
+    }
     while (s0 >= 2 && mid_lds_bytes(n_mles, s0, d, n_flat) > 60 * 1024) s0 >>= 1;
     if (s0 < 2 || pairs > (size_t)w_cap * s0 || pairs < 8) return;
     const size_t w = std::min<size_t>((size_t)w_cap, pairs / 2);  // at least two pairs per workgroup in the first round
@@ -2330,7 +2326,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                     MidRelay* relay = reinterpret_cast<MidRelay*>(reinterpret_cast<char*>(ep.partials) + 65536);
                     // the partial-sum rows start out armed (every byte 0xFF = MSG_INVALID); queued ahead of the launch, off the critical path
                     HIP_TRY(ctx, hipMemsetAsync(ep.partials, 0xFF, (size_t)2 * W * MAXD * sizeof(E2), sc->st));  // both sets
-                    static const bool relay_only = getenv("CENO_HIP_MID_RELAY") && atoi(getenv("CENO_HIP_MID_RELAY")) != 0;  // A/B switch
+                    const bool relay_only = getenv("CENO_HIP_MID_RELAY") && atoi(getenv("CENO_HIP_MID_RELAY")) != 0;  // A/B switch
                     launch_mid(sc->d, pl, cl.d_slots + (size_t)i1 * k, (int)k, cl.n_flat, W, S0, i, i1, ep, relay, nonce,
                                sc->vram_slot != nullptr && !relay_only, sc->st);
                     i = i1;          // the loop continues with round i1 + 1: the persistent tail

@@ -878,6 +878,27 @@ def test_sumcheck_random_plans_lds_blocked_kernel(dev, prover, seed, monkeypatch
     sc.free()
 
 
+@pytest.mark.parametrize("w,s0,relay", [(256, 128, 0), (64, 32, 0), (16, 8, 0), (4, 2, 0), (256, 128, 1), (8, 64, 1)])
+@pytest.mark.parametrize("nv,n_mles,terms", [(13, 4, [[0, 1, 2], [1, 2, 3]]), (15, 6, [[0, 1], [2, 3, 4, 5], [1, 5]]), (10, 3, [[0, 1, 2]])])
+def test_sumcheck_persistent_mid_rounds_geometries(dev, prover, monkeypatch, w, s0, relay, nv, n_mles, terms):
+    """k_mid (rounds between the streaming kernels and the single-workgroup tail in one launch of resident workgroups): every
+    geometry — many small slices, few large ones, the relay path used when the mailbox is in host memory — gives the oracle's
+    proof bit for bit; base-field inputs start the ladder in round 0 (nv = 10: the whole sumcheck is k_mid + k_tail)"""
+    monkeypatch.setenv("CENO_HIP_MID_W", str(w))
+    monkeypatch.setenv("CENO_HIP_MID_S0", str(s0))
+    monkeypatch.setenv("CENO_HIP_MID_RELAY", str(relay))
+    is_ext = nv != 10
+    tabs = [po.rand_ext(1 << nv, 500 + j) if is_ext else po.rand_base(1 << nv, 500 + j) for j in range(n_mles)]
+    mles = [dev.upload(t) for t in tabs]
+    coeffs = po.ext([(3 + 2 * i, 7 * i + 1) for i in range(len(terms))])
+    deg = max(len(t) for t in terms)
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, coeffs, terms, nv, deg, prover.Transcript.stub(0xA1))
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, coeffs, terms, nv, deg, po.StubTranscript(0xA1))
+    assert np.array_equal(msgs, omsgs) and np.array_equal(chal, ochal) and np.array_equal(fin, ofin)
+    for m in mles:
+        m.free()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_tower_random_specs_differential(dev, prover, seed):
     """seeded random tower batches (0-3 product specs, 0-2 LogUp specs with or without numerators, heights 2-13 so that
