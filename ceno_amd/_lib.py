@@ -105,9 +105,11 @@ def lib():
         "ceno_hip_tower_build_logup": (i, [vp, vpp, vpp, i, sz, u64p, vp, vpp]),
         "ceno_hip_tower_from_last_layer": (i, [vp, vpp, i, vp, vpp]),
         "ceno_hip_tower_num_vars": (i, [vp]),
-        "ceno_hip_tower_num_limbs": (i, [vp]),
         "ceno_hip_tower_layer": (i, [vp, vp, i, i, vpp]),
         "ceno_hip_tower_out_evals": (i, [vp, vp, u64p, vp]),
+        "ceno_hip_tower_download_top": (i, [vp, vp, i, u64p, vp]),
+        "ceno_hip_tower_top_layers": (i, [vp]),
+        "ceno_hip_tower_num_limbs": (i, [vp]),
         "ceno_hip_tower_free": (i, [vp, vp]),
         "ceno_hip_tower_layer_sumcheck_begin": (i, [vp, vpp, i, vpp, i, i, u64p, u64p, vp, vpp]),
         "ceno_hip_ntt_batch": (i, [vp, vp, i, i, i, vp]),

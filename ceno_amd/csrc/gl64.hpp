@@ -256,12 +256,33 @@ GL_HD uint64_t reduce_limbs(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, 
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) {
     return canon(reduce128_nc((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)));
 }
+// Host code (the C++ prover layer: transcripts, host-side rounds, small tower layers) multiplies through the native
+// 64 x 64 -> 128 product instead of the device's four 32-bit multiply-adds: ~3x fewer instructions, identical results.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+#define GL_HOST_INT128 1
+inline uint64_t host_red128(unsigned __int128 x) {  // canonical residue of a 128-bit value: 2^64 = 2^32 - 1, 2^96 = -1
+    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t t0, r;
+    if (__builtin_sub_overflow(lo, hi >> 32, &t0)) t0 -= EPS;
+    if (__builtin_add_overflow(t0, (hi & EPS) * EPS, &r)) r += EPS;
+    return canon(r);
+}
+#endif
 GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+#ifdef GL_HOST_INT128
+    return host_red128((unsigned __int128)a * b);
+#else
     const L4 p = mul_wide(a, b);
     return canon(reduce128_nc(p.w0, p.w1, p.w2, p.w3));
+#endif
 }
 // a*b + c*d with a single reduction (129-bit sum)
 GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+#ifdef GL_HOST_INT128
+    const unsigned __int128 p = (unsigned __int128)a * b, q = (unsigned __int128)c * d, s = p + q;
+    const uint64_t r = host_red128(s);
+    return s < p ? sub(r, (uint64_t)1 << 32) : r;  // the carry out of bit 128: 2^128 = -2^32 (mod p)
+#else
     const L4 p = mul_wide(a, b), q = mul_wide(c, d);
     uint32_t cy;
     const uint32_t s0 = addc32(p.w0, q.w0, 0u, cy);
@@ -269,6 +290,7 @@ GL_HD uint64_t mul_add2(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
     const uint32_t s2 = addc32(p.w2, q.w2, cy, cy);
     const uint32_t s3 = addc32(p.w3, q.w3, cy, cy);
     return reduce_limbs(s0, s1, s2, s3, cy);
+#endif
 }
 // product that is only multiplied again (any 64-bit inputs, result in [0, 2^64) not canonical)
 GL_HD uint64_t mul_nc(uint64_t a, uint64_t b) {
@@ -362,9 +384,13 @@ GL_HD uint64_t mul_add_s96_ncm(uint64_t a, uint64_t b, S96 s) {
 }
 // small-constant multiply (c < 2^32): the product has 96 bits
 GL_HD uint64_t mul_small(uint64_t a, uint32_t c) {
+#ifdef GL_HOST_INT128
+    return host_red128((unsigned __int128)a * c);
+#else
     const uint64_t p0 = (uint64_t)(uint32_t)a * c;
     const uint64_t p1 = (uint64_t)(uint32_t)(a >> 32) * c + (p0 >> 32);
     return canon(reduce96_nc((uint32_t)p0, (uint32_t)p1, (uint32_t)(p1 >> 32)));
+#endif
 }
 // reference forms kept for cross-checks (tests/test_host_cpu.py)
 GL_HD uint64_t mul_ref(uint64_t a, uint64_t b) {

@@ -21,7 +21,11 @@ struct ceno_hip_tower {
     int num_vars = 0;   // number of layers
     int n_limbs = 2;    // 2 = product, 4 = logup
     std::vector<E2*> layers;  // layers[l] -> n_limbs * 2^l elements, limb-major
+    // layers 0 .. top_layers-1 live back to back in ONE block (layer l at element offset n_limbs * (2^l - 1)): the host proves
+    // the small layers itself from a single copy of that block (ceno_hip_tower_download_top)
+    int top_layers = 0;
 };
+static constexpr int TOWER_TOP_LAYERS = 11;  // layers of up to 2^10 entries per limb
 
 struct RecArg {
     const uint64_t* ptr[MAX_REC];
@@ -94,7 +98,8 @@ static size_t next_pow2_instance_padding(size_t n) {  // ceno_zkvm/src/scheme/ha
 
 static void tower_release(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
     if (!t) return;
-    for (E2* p : t->layers) ctx_free(ctx, p);
+    for (size_t l = 0; l < t->layers.size(); l++)
+        if (l == 0 || (int)l >= t->top_layers) ctx_free(ctx, t->layers[l]);  // layers 1 .. top_layers-1 point into layer 0's block
     delete t;
 }
 
@@ -103,7 +108,18 @@ static int tower_alloc(ceno_hip_ctx* ctx, int num_vars, int n_limbs, ceno_hip_to
     t->num_vars = num_vars;
     t->n_limbs = n_limbs;
     t->layers.assign(num_vars, nullptr);
-    for (int l = 0; l < num_vars; l++) {
+    const int top = std::min(num_vars, TOWER_TOP_LAYERS);
+    {
+        void* p = nullptr;
+        int rc = ctx_alloc(ctx, (size_t)n_limbs * (((size_t)1 << top) - 1) * sizeof(E2), &p);
+        if (rc) {
+            delete t;
+            return rc;
+        }
+        for (int l = 0; l < top; l++) t->layers[l] = (E2*)p + (size_t)n_limbs * (((size_t)1 << l) - 1);
+        t->top_layers = top;
+    }
+    for (int l = top; l < num_vars; l++) {
         void* p = nullptr;
         int rc = ctx_alloc(ctx, ((size_t)n_limbs << l) * sizeof(E2), &p);
         if (rc) {
@@ -289,6 +305,16 @@ int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return 0;
 }
+
+int ceno_hip_tower_download_top(ceno_hip_ctx* ctx, ceno_hip_tower* t, int n_layers, uint64_t* host_out, ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && host_out, "NULL argument");
+    CHECK_ARG(ctx, n_layers >= 1 && n_layers <= t->top_layers, "tower: %d top layers requested, %d are contiguous", n_layers, t->top_layers);
+    hipStream_t st = ctx_stream(ctx, s);
+    HIP_TRY(ctx, hipMemcpyAsync(host_out, t->layers[0], (size_t)t->n_limbs * (((size_t)1 << n_layers) - 1) * sizeof(E2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+int ceno_hip_tower_top_layers(const ceno_hip_tower* t) { return t ? t->top_layers : 0; }
 
 int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
     tower_release(ctx, t);

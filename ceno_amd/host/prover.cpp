@@ -141,6 +141,90 @@ size_t ceno_tower_msgs_words(int max_nv) {
     return tot;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small tower layers are proved ON THE HOST.  A layer of 2^l entries per limb is l sumcheck rounds of a few hundred to a few
+// thousand field multiplications each; on the device it costs ~45 us of per-layer set-up (eq table, plan, launches) plus
+// ~9 us of latency per round whatever its size.  The top layers of every tower arrive with one copy each
+// (ceno_hip_tower_download_top) and the layer sumcheck of scheme/cpu/mod.rs:417-494 runs right here:
+//   sum_x eq(x, rt) * [ sum_i alpha_i a_i b_i + sum_k (alpha_n (p1 q2 + p2 q1) + alpha_d q1 q2) ],  messages at X = 1, 2, 3.
+// Field arithmetic is exact, so the messages, challenges and evaluations equal the device path's bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct HostTowerTop {
+    std::vector<uint64_t> words;  // ceno_hip_tower_download_top layout
+    int n_limbs = 0, n_layers = 0;
+    const E2* limb(int layer, int b) const {
+        return reinterpret_cast<const E2*>(words.data()) + (size_t)n_limbs * (((size_t)1 << layer) - 1) + ((size_t)b << layer);
+    }
+};
+int tower_host_layers() {
+    const char* e = getenv("CENO_TOWER_HOST_LAYERS");  // layers 1 .. this are proved on the host (0: none)
+    return e ? atoi(e) : 8;
+}
+// one layer sumcheck on the host; tabs[0] = eq, then per active product spec (a, b), per active logup spec (p1, p2, q1, q2)
+void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active, const std::vector<E2>& alpha_prod,
+                      const std::vector<E2>& alpha_num, const std::vector<E2>& alpha_den, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal,
+                      uint64_t* fin) {
+    tr_usize(tr, (uint64_t)n);
+    tr_usize(tr, 3);
+    size_t len = (size_t)1 << n;
+    for (int round = 0; round < n; round++) {
+        const size_t pairs = len / 2;
+        E2 acc[3] = {gl::e2_zero(), gl::e2_zero(), gl::e2_zero()};
+        for (size_t p = 0; p < pairs; p++) {
+            E2 inner[3] = {gl::e2_zero(), gl::e2_zero(), gl::e2_zero()};
+            size_t t = 1;
+            for (int i = 0; i < n_prod_active; i++, t += 2) {
+                const E2 a1 = tabs[t][2 * p + 1], da = a1 - tabs[t][2 * p];
+                const E2 b1 = tabs[t + 1][2 * p + 1], db = b1 - tabs[t + 1][2 * p];
+                E2 ca = alpha_prod[i] * a1;
+                const E2 cda = alpha_prod[i] * da;  // the coefficient rides on the first factor
+                E2 b = b1;
+                for (int e = 0; e < 3; e++) {
+                    inner[e] = inner[e] + ca * b;
+                    ca = ca + cda;
+                    b = b + db;
+                }
+            }
+            for (int k = 0; k < n_logup_active; k++, t += 4) {
+                E2 p1 = tabs[t][2 * p + 1], p2 = tabs[t + 1][2 * p + 1], q1 = tabs[t + 2][2 * p + 1], q2 = tabs[t + 3][2 * p + 1];
+                const E2 dp1 = p1 - tabs[t][2 * p], dp2 = p2 - tabs[t + 1][2 * p], dq1 = q1 - tabs[t + 2][2 * p], dq2 = q2 - tabs[t + 3][2 * p];
+                for (int e = 0; e < 3; e++) {
+                    inner[e] = inner[e] + alpha_num[k] * (p1 * q2 + p2 * q1) + alpha_den[k] * (q1 * q2);
+                    p1 = p1 + dp1;
+                    p2 = p2 + dp2;
+                    q1 = q1 + dq1;
+                    q2 = q2 + dq2;
+                }
+            }
+            E2 ev = tabs[0][2 * p + 1];
+            const E2 de = ev - tabs[0][2 * p];
+            for (int e = 0; e < 3; e++) {
+                acc[e] = acc[e] + ev * inner[e];
+                ev = ev + de;
+            }
+        }
+        uint64_t* msg = msgs + (size_t)6 * round;
+        for (int e = 0; e < 3; e++) {
+            msg[2 * e] = acc[e].c0;
+            msg[2 * e + 1] = acc[e].c1;
+            tr_ext(tr, msg + 2 * e);
+        }
+        tr_label(tr, "Internal round");
+        const E2 r = tr_sample(tr);
+        chal[2 * round] = r.c0;
+        chal[2 * round + 1] = r.c1;
+        for (auto& T : tabs)
+            for (size_t p = 0; p < pairs; p++) T[p] = T[2 * p] + r * (T[2 * p + 1] - T[2 * p]);
+        len = pairs;
+    }
+    for (size_t t = 0; t < tabs.size(); t++) {
+        fin[2 * t] = tabs[t][0].c0;
+        fin[2 * t + 1] = tabs[t][0].c1;
+    }
+}
+}  // namespace
+
 int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
                                    ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out) {
     if (!ctx || !tr || !out) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
@@ -168,7 +252,65 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         clock_gettime(CLOCK_MONOTONIC, &ts);
         return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
     };
+    // the small layers of every tower, one copy per tower
+    const int host_layers = std::min(tower_host_layers(), R);
+    std::vector<HostTowerTop> top_prod((size_t)n_prod), top_logup((size_t)n_logup);
+    if (host_layers >= 1) {
+        auto fetch = [&](ceno_hip_tower* t, HostTowerTop& h) -> int {
+            // layers 0 .. min(host_layers, num_vars - 1) of this tower (layer `round` exists when num_vars > round)
+            h.n_limbs = ceno_hip_tower_num_limbs(t);
+            h.n_layers = std::min(std::min(host_layers + 1, ceno_hip_tower_num_vars(t)), ceno_hip_tower_top_layers(t));
+            if (h.n_layers < 1) return 0;
+            h.words.resize((size_t)2 * h.n_limbs * (((size_t)1 << h.n_layers) - 1));
+            return ceno_hip_tower_download_top(ctx, t, h.n_layers, h.words.data(), s);
+        };
+        for (int i = 0; i < n_prod; i++)
+            if (int rc = fetch(prod[i], top_prod[i])) return fail_from_ctx(ctx, rc);
+        for (int i = 0; i < n_logup; i++)
+            if (int rc = fetch(logup[i], top_logup[i])) return fail_from_ctx(ctx, rc);
+    }
     for (int round = 1; round <= R; round++) {      // cpu/mod.rs:409: skip(1) for the output layer
+        bool on_host = round <= host_layers;
+        for (int i = 0; i < n_prod && on_host; i++)
+            if (ceno_hip_tower_num_vars(prod[i]) > round && top_prod[i].n_layers <= round) on_host = false;
+        for (int i = 0; i < n_logup && on_host; i++)
+            if (ceno_hip_tower_num_vars(logup[i]) > round && top_logup[i].n_layers <= round) on_host = false;
+        if (on_host) {
+            std::vector<std::vector<E2>> tabs;
+            std::vector<E2> a_prod, a_num, a_den;
+            const size_t len = (size_t)1 << round;
+            {   // eq(x, out_rt): variable j of x is bit j of the index (LSB first)
+                std::vector<E2> eq(len);
+                eq[0] = gl::e2_one();
+                for (int j = 0; j < round; j++) {
+                    const E2 rj{out_rt[2 * j], out_rt[2 * j + 1]};
+                    for (size_t x = 0; x < ((size_t)1 << j); x++) {
+                        const E2 hi = eq[x] * rj;
+                        eq[x + ((size_t)1 << j)] = hi;
+                        eq[x] = eq[x] - hi;
+                    }
+                }
+                tabs.push_back(std::move(eq));
+            }
+            int np_act = 0, nl_act = 0;
+            for (int i = 0; i < n_prod; i++) {
+                if (ceno_hip_tower_num_vars(prod[i]) <= round) continue;
+                for (int b = 0; b < 2; b++) tabs.emplace_back(top_prod[i].limb(round, b), top_prod[i].limb(round, b) + len);
+                a_prod.push_back(E2{alpha[2 * i], alpha[2 * i + 1]});
+                np_act++;
+            }
+            for (int i = 0; i < n_logup; i++) {
+                if (ceno_hip_tower_num_vars(logup[i]) <= round) continue;
+                for (int b = 0; b < 4; b++) tabs.emplace_back(top_logup[i].limb(round, b), top_logup[i].limb(round, b) + len);
+                a_num.push_back(E2{alpha[2 * (n_prod + 2 * i)], alpha[2 * (n_prod + 2 * i) + 1]});
+                a_den.push_back(E2{alpha[2 * (n_prod + 2 * i + 1)], alpha[2 * (n_prod + 2 * i + 1) + 1]});
+                nl_act++;
+            }
+            if (np_act + nl_act == 0) return fail(CENO_HIP_ERR_INVALID, "tower: no spec has this layer");
+            chal.assign((size_t)2 * round, 0);
+            fin.assign((size_t)2 * tabs.size(), 0);
+            host_tower_layer(round, tabs, np_act, nl_act, a_prod, a_num, a_den, tr, out->msgs + msg_off, chal.data(), fin.data());
+        } else {
         ceno_hip_sumcheck* sc = nullptr;
         const double t_a = dbg ? now_us() : 0;
         int rc = ceno_hip_tower_layer_sumcheck_begin(ctx, prod, n_prod, logup, n_logup, round, out_rt.data(), alpha.data(), s, &sc);
@@ -186,6 +328,7 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         ceno_hip_sumcheck_free(ctx, sc);
         if (dbg) fprintf(stderr, "[ceno_prover] tower layer %d: begin %.0f us, rounds %.0f us, free %.0f us\n", round, t_b - t_a, t_c - t_b, now_us() - t_c);
         if (rc) return rc;
+        }
         msg_off += (size_t)round * 3 * 2;
         // evaluations are bound into the transcript before r_merge is sampled (cpu/mod.rs:498-531)
         int cursor = 1;

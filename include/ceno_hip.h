@@ -231,6 +231,11 @@ int ceno_hip_tower_num_limbs(const ceno_hip_tower* t);  /* 2 or 4 */
 /* borrowed handle of limb `limb` of layer `layer` (valid while the tower lives) */
 int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int limb, ceno_hip_mle** out);
 int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out /* n_limbs ext */, ceno_hip_stream s);
+/* The top layers of a tower (layer l has n_limbs * 2^l elements) are stored back to back so that a host-side prover of the small
+ * layers needs ONE copy: layers 0 .. n_layers-1 into host_out, layer l limb b at element offset n_limbs * (2^l - 1) + b * 2^l
+ * (n_limbs * (2^n_layers - 1) extension elements in all; n_layers <= ceno_hip_tower_top_layers).  Synchronises. */
+int ceno_hip_tower_download_top(ceno_hip_ctx* ctx, ceno_hip_tower* t, int n_layers, uint64_t* host_out, ceno_hip_stream s);
+int ceno_hip_tower_top_layers(const ceno_hip_tower* t);  /* how many layers are contiguous (min(num_vars, 11)) */
 int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t);
 
 /* One tower layer sumcheck (the body of CpuTowerProver::create_proof's round loop,
