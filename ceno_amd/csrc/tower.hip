@@ -132,12 +132,39 @@ static int tower_alloc(ceno_hip_ctx* ctx, int num_vars, int n_limbs, ceno_hip_to
     return 0;
 }
 
+// the contiguous top of a tower in ONE launch: layers from-1 .. 0 out of layer `from` (<= 2^10 entries per limb), one workgroup,
+// a barrier between layers — eleven launches of a few microseconds each were mostly kernel boundary
+template <int LIMBS>
+__global__ void __launch_bounds__(1024) k_tower_top(E2* __restrict__ block, int from) {
+    for (int l = from - 1; l >= 0; l--) {
+        const E2* below = block + (size_t)LIMBS * (((size_t)1 << (l + 1)) - 1);
+        E2* out = block + (size_t)LIMBS * (((size_t)1 << l) - 1);
+        const size_t len_below = (size_t)1 << (l + 1);
+        for (size_t x = threadIdx.x; x < len_below; x += 1024) {
+            if (LIMBS == 2) {
+                out[x] = below[x] * below[len_below + x];
+            } else {
+                const E2 a = below[2 * len_below + x], b = below[3 * len_below + x];
+                out[x] = a * below[len_below + x] + b * below[x];
+                out[len_below + x] = a * b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int tower_build_upper(ceno_hip_ctx* ctx, ceno_hip_tower* t, hipStream_t st) {
-    for (int l = t->num_vars - 2; l >= 0; l--) {
+    static const bool fuse = !(getenv("CENO_HIP_TOWER_TOP_FUSED") && atoi(getenv("CENO_HIP_TOWER_TOP_FUSED")) == 0);  // A/B switch
+    const int from = fuse ? std::min(t->num_vars - 1, t->top_layers - 1) : 0;  // layers below `from` come from the fused kernel
+    for (int l = t->num_vars - 2; l >= from; l--) {
         size_t len_below = (size_t)1 << (l + 1);
         unsigned g = grid_for(len_below, NT, MAXB);
         if (t->n_limbs == 2) hipLaunchKernelGGL(k_prod_layer, dim3(g), dim3(NT), 0, st, t->layers[l + 1], t->layers[l], len_below);
         else hipLaunchKernelGGL(k_logup_layer, dim3(g), dim3(NT), 0, st, t->layers[l + 1], t->layers[l], len_below);
+    }
+    if (from >= 1) {
+        if (t->n_limbs == 2) hipLaunchKernelGGL(k_tower_top<2>, dim3(1), dim3(1024), 0, st, t->layers[0], from);
+        else hipLaunchKernelGGL(k_tower_top<4>, dim3(1), dim3(1024), 0, st, t->layers[0], from);
     }
     HIP_TRY(ctx, hipGetLastError());
     return 0;
