@@ -30,7 +30,51 @@ struct WiPlan {
     int num_outs;
 };
 
-__global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len) {
+// The plan (slots, coefficients, CSR offsets) is pulled into LDS once per workgroup: every lane walks the same records, and
+// from global memory that walk is a chain of four dependent loads per factor.  Base-field factors of a term are multiplied
+// together first (one 64-bit product each) and meet the extension-field coefficient once at the end.
+__global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len, int num_mles, int num_terms, int num_factors) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    WiSlot* s_slots = reinterpret_cast<WiSlot*>(dyn);
+    E2* s_coeffs = reinterpret_cast<E2*>(s_slots + num_mles);
+    E2** s_outs = reinterpret_cast<E2**>(s_coeffs + num_terms);
+    uint32_t* s_toff = reinterpret_cast<uint32_t*>(s_outs + pl.num_outs);
+    uint32_t* s_tidx = s_toff + num_terms + 1;
+    uint32_t* s_ooff = s_tidx + num_factors;
+    for (int i = threadIdx.x; i < num_mles; i += NT) s_slots[i] = pl.mles[i];
+    for (int i = threadIdx.x; i < num_terms; i += NT) s_coeffs[i] = pl.coeffs[i];
+    for (int i = threadIdx.x; i < pl.num_outs; i += NT) s_outs[i] = pl.outs[i];
+    for (int i = threadIdx.x; i <= num_terms; i += NT) s_toff[i] = pl.term_off[i];
+    for (int i = threadIdx.x; i < num_factors; i += NT) s_tidx[i] = pl.term_idx[i];
+    for (int i = threadIdx.x; i <= pl.num_outs; i += NT) s_ooff[i] = pl.out_term_off[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len; x += stride) {
+        for (int o = 0; o < pl.num_outs; o++) {
+            E2 acc = e2_zero();
+            for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
+                E2 v = s_coeffs[t];
+                uint64_t pb = 1;
+                bool any_base = false;
+                for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
+                    const WiSlot sl = s_slots[s_tidx[k]];
+                    if (sl.is_ext) {
+                        v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
+                    } else {
+                        const uint64_t f = sl.ptr[x];
+                        pb = any_base ? mul(pb, f) : f;
+                        any_base = true;
+                    }
+                }
+                if (any_base) v = e2_mul_base(v, pb);
+                acc = acc + v;
+            }
+            s_outs[o][x] = acc;
+        }
+    }
+}
+// plans too large for the LDS stage (thousands of terms) walk the records in global memory
+__global__ void __launch_bounds__(NT) k_wit_infer_big(WiPlan pl, size_t len) {
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len; x += stride) {
         for (int o = 0; o < pl.num_outs; o++) {
@@ -47,6 +91,10 @@ __global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len) {
             pl.outs[o][x] = acc;
         }
     }
+}
+static size_t wit_infer_lds(int num_mles, int num_terms, int num_factors, int num_outs) {
+    return (size_t)num_mles * sizeof(WiSlot) + (size_t)num_terms * sizeof(E2) + (size_t)num_outs * sizeof(E2*) +
+           ((size_t)num_terms + 1 + (size_t)num_factors + (size_t)num_outs + 1) * 4 + 16;
 }
 
 // 32x32 tile transpose of 64-bit words through LDS (+1 padding: conflict-free column reads)
@@ -93,35 +141,38 @@ int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mle
     std::vector<ceno_hip_mle*> res(num_outs, nullptr);
     int rc = 0;
     for (int o = 0; o < num_outs && !rc; o++) rc = ceno_hip_mle_alloc(ctx, num_vars, 1, &res[o]);
-    std::vector<WiSlot> slots(num_mles);
-    for (int j = 0; j < num_mles; j++) slots[j] = WiSlot{mles[j]->d, mles[j]->is_ext, 0};
-    std::vector<E2> coeffs(num_terms);
-    for (int t = 0; t < num_terms; t++) coeffs[t] = E2{term_coeffs[2 * t], term_coeffs[2 * t + 1]};
-    std::vector<E2*> optr(num_outs);
-    for (int o = 0; o < num_outs && !rc; o++) optr[o] = reinterpret_cast<E2*>(res[o]->d);
-    WiPlan pl{};
-    WiSlot* d_slots = nullptr;
-    E2* d_coeffs = nullptr;
-    uint32_t *d_toff = nullptr, *d_tidx = nullptr, *d_ooff = nullptr;
-    E2** d_outs = nullptr;
-    rc = rc ? rc : up(ctx, slots.data(), slots.size(), st, allocs, &d_slots);
-    rc = rc ? rc : up(ctx, coeffs.data(), coeffs.size(), st, allocs, &d_coeffs);
-    rc = rc ? rc : up(ctx, term_offsets, (size_t)num_terms + 1, st, allocs, &d_toff);
-    rc = rc ? rc : up(ctx, term_mle_idx, (size_t)term_offsets[num_terms], st, allocs, &d_tidx);
-    rc = rc ? rc : up(ctx, out_term_offsets, (size_t)num_outs + 1, st, allocs, &d_ooff);
-    rc = rc ? rc : up(ctx, optr.data(), optr.size(), st, allocs, &d_outs);
+    // the whole plan travels as ONE blob in one copy (six small uploads cost ~10 us each in front of a ~100 us kernel);
+    // the source is pageable, so the runtime has captured it when hipMemcpyAsync returns
+    const size_t n_fac = term_offsets[num_terms];
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_slots = 0, o_coeffs = al(o_slots + (size_t)num_mles * sizeof(WiSlot)), o_outs = al(o_coeffs + (size_t)num_terms * sizeof(E2)),
+                 o_toff = al(o_outs + (size_t)num_outs * sizeof(E2*)), o_tidx = al(o_toff + ((size_t)num_terms + 1) * 4),
+                 o_ooff = al(o_tidx + n_fac * 4), total = al(o_ooff + ((size_t)num_outs + 1) * 4);
+    std::vector<char> blob(total, 0);
+    for (int j = 0; j < num_mles; j++) reinterpret_cast<WiSlot*>(blob.data() + o_slots)[j] = WiSlot{mles[j]->d, mles[j]->is_ext, 0};
+    for (int t = 0; t < num_terms; t++) reinterpret_cast<E2*>(blob.data() + o_coeffs)[t] = E2{term_coeffs[2 * t], term_coeffs[2 * t + 1]};
+    for (int o = 0; o < num_outs && !rc; o++) reinterpret_cast<E2**>(blob.data() + o_outs)[o] = reinterpret_cast<E2*>(res[o]->d);
+    memcpy(blob.data() + o_toff, term_offsets, ((size_t)num_terms + 1) * 4);
+    if (n_fac) memcpy(blob.data() + o_tidx, term_mle_idx, n_fac * 4);
+    memcpy(blob.data() + o_ooff, out_term_offsets, ((size_t)num_outs + 1) * 4);
+    char* d_blob = nullptr;
+    rc = rc ? rc : up(ctx, blob.data(), blob.size(), st, allocs, &d_blob);
+    const size_t lds = wit_infer_lds(num_mles, num_terms, (int)n_fac, num_outs);
     if (!rc) {
-        pl.mles = d_slots;
-        pl.coeffs = d_coeffs;
-        pl.term_off = d_toff;
-        pl.term_idx = d_tidx;
-        pl.out_term_off = d_ooff;
-        pl.outs = d_outs;
+        WiPlan pl{};
+        pl.mles = reinterpret_cast<const WiSlot*>(d_blob + o_slots);
+        pl.coeffs = reinterpret_cast<const E2*>(d_blob + o_coeffs);
+        pl.term_off = reinterpret_cast<const uint32_t*>(d_blob + o_toff);
+        pl.term_idx = reinterpret_cast<const uint32_t*>(d_blob + o_tidx);
+        pl.out_term_off = reinterpret_cast<const uint32_t*>(d_blob + o_ooff);
+        pl.outs = reinterpret_cast<E2* const*>(d_blob + o_outs);
         pl.num_outs = num_outs;
         size_t len = (size_t)1 << num_vars;
-        hipLaunchKernelGGL(k_wit_infer, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, pl, len);
+        if (lds <= 60 * 1024) hipLaunchKernelGGL(k_wit_infer, dim3(grid_for(len, NT, MAXB)), dim3(NT), lds, st, pl, len, num_mles, num_terms, (int)n_fac);
+        else hipLaunchKernelGGL(k_wit_infer_big, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, pl, len);
+        // no wait: the outputs are ordered on `st` like every other result, and the plan blob returns to the pool tagged with
+        // this stream (another stream gets it only after this one has drained)
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);  // plan buffers and borrowed host arrays
         if (e != hipSuccess) rc = ctx_fail(ctx, CENO_HIP_ERR_HIP, "wit_infer: %s", hipGetErrorString(e));
     }
     for (void* p : allocs) ctx_free(ctx, p);
