@@ -43,6 +43,7 @@ static int get_fold_twiddles(ceno_hip_ctx* ctx, int log_h, hipStream_t st, const
     TRY(ctx_alloc(ctx, n * 8, &p));  // pool block: booked, released with the context
     hipLaunchKernelGGL(k_fold_twiddles, dim3(grid_for(n, NT, MAXB)), dim3(NT), 0, st, (uint64_t*)p, n, log_h - 1, gl::inv(gh));
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // shared by every stream from now on: complete before the cache shows it (once per height)
     ctx->fold_twiddles[log_h] = (uint64_t*)p;
     *out = (uint64_t*)p;
     return 0;

@@ -45,6 +45,9 @@ static int get_twiddles(ceno_hip_ctx* ctx, int log_n, bool inverse, hipStream_t 
     TRY(ctx_alloc(ctx, half * 8, &p));  // from the pool: counted by mem_info / booking, released by ceno_hip_destroy
     hipLaunchKernelGGL(k_twiddles, dim3(grid_for(half, NT, 2048)), dim3(NT), 0, st, (uint64_t*)p, half, w);
     HIP_TRY(ctx, hipGetLastError());
+    // the table is shared by every stream of the context from now on: it must be complete before the cache shows it (a
+    // second stream — the commit's helper, another lane — would otherwise transform with a half-written table).  Once per size.
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     cache[key] = (uint64_t*)p;
     *out = (uint64_t*)p;
     return 0;

@@ -41,6 +41,7 @@ static int placeholder_gate(ceno_hip_ctx* ctx) {
 
 int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
     TRY(placeholder_gate(ctx));
+    std::lock_guard<std::mutex> g(ctx->tw_mu);  // lanes may arrive here together on first use
     if (!ctx->poseidon_dev) {
         PoseidonParams h;
         p2::default_params(h.p);

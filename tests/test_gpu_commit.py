@@ -381,3 +381,28 @@ def test_native_sharded_commit_world1_through_rccl_self_exchange(dev, monkeypatc
     comm.close()
     pcs.free()
     dev.stream_destroy(stream)
+
+
+def test_commit_of_several_matrices_on_a_fresh_context_equals_one_by_one():
+    """commit_traces queues its matrices on two alternating streams.  On a FRESH context the first transform of a size also
+    builds that size's twiddle table, which the other stream then shares: two matrices of one size (the last two chips of a
+    shard) must still give the roots of committing each alone (regression: the table used to be visible before it was complete)"""
+    from ceno_amd import Device, prover
+
+    shapes = [(1 << 12, 5), (1 << 11, 3), (1 << 9, 4), (1 << 9, 4), (1 << 7, 2), (1 << 7, 6)]
+    mats = [po.rand_base(r * w, 300 + i).reshape(r, w) for i, (r, w) in enumerate(shapes)]
+    d1 = Device(0)
+    s1 = d1.stream_create()
+    together = prover.PcsData(d1, mats, 1, s1)
+    roots = [together.root(m).copy() for m in range(len(mats))]
+    together.free()
+    d1.stream_destroy(s1)
+    d1.close()
+    d2 = Device(0)
+    s2 = d2.stream_create()
+    for m, mat in enumerate(mats):
+        alone = prover.PcsData(d2, [mat], 1, s2)
+        assert np.array_equal(alone.root(0), roots[m]), m
+        alone.free()
+    d2.stream_destroy(s2)
+    d2.close()
