@@ -216,3 +216,55 @@ struct MleSlot {
     int pad;
 };
 
+// ---- the generic CSR plan as the round kernels see it, and the per-factor helpers they share ----
+struct DevPlan {
+    const MleSlot* slots;
+    int use_out;                    // 1: read slot.out (ext), 0: read slot.in (round 0)
+    int n_groups;
+    const uint32_t* group_term_off; // n_groups + 1 -> range in group_terms
+    const uint32_t* group_terms;    // term ids
+    const uint32_t* common_off;     // n_groups + 1 -> range in common_idx
+    const uint32_t* common_idx;     // local mle ids
+    const E2* coeffs;               // per term
+    const uint32_t* term_off;       // per term -> range in term_idx
+    const uint32_t* term_idx;       // local mle ids
+};
+
+__device__ __forceinline__ void load_pair(const MleSlot& sl, int use_out, size_t p, E2& lo, E2& hi) {
+    if (use_out) {
+        const E2* q = reinterpret_cast<const E2*>(sl.out) + 2 * p;
+        lo = q[0];
+        hi = q[1];
+    } else if (sl.in_ext) {
+        const E2* q = reinterpret_cast<const E2*>(sl.in) + 2 * p;
+        lo = q[0];
+        hi = q[1];
+    } else {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
+        lo = E2{v.x, 0};
+        hi = E2{v.y, 0};
+    }
+}
+
+// pr[t] *= f(t) for the factor f(X) = x + (X - 1) * delta at the points 1..D.  `pr` starts as the term's coefficient c; from
+// 3 points on the FIRST factor takes c along as c*f(X) = c*x + (X - 1) * c*delta — two multiplications instead of D.
+template <int D>
+__device__ __forceinline__ void mul_points(E2 (&pr)[D], bool& seeded, const E2& c, E2 x, E2 delta) {
+    if (D >= 3 && !seeded) {
+        x = c * x;
+        delta = c * delta;
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pr[t] = x;
+            x = x + delta;
+        }
+        seeded = true;
+    } else {
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            pr[t] = pr[t] * x;
+            x = x + delta;
+        }
+    }
+}
+

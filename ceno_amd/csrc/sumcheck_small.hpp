@@ -1,0 +1,23 @@
+// The latency ladder of a pipelined generic sumcheck (sumcheck_small.hip): term-parallel tiles (k_tile), persistent mid rounds
+// over resident workgroups (k_mid) and the persistent single-workgroup tail (k_tail).  sumcheck.hip decides which rounds go
+// where with the eligibility / geometry helpers below and launches through these entry points.
+#pragma once
+#include "sumcheck_dev.hpp"
+
+// one 64-byte relay line per workgroup of a k_mid launch (used when the mailbox lives in host memory)
+struct alignas(64) MidRelay {
+    unsigned long long seq;   // (nonce << 8) | round + 1, or (nonce << 8) | 0xFF: give up
+    unsigned long long pad;
+    unsigned long long chal[2];
+    unsigned long long pad2[4];
+};
+
+int tile_pairs(size_t n_flat, size_t n_mles, size_t pairs);
+bool tile_eligible(size_t n_mles, size_t pairs);
+bool tail_eligible(size_t n_mles, size_t pairs, int d, size_t n_flat);
+void mid_geometry(size_t n_mles, size_t pairs, int d, size_t n_flat, int w_cap, int* W, int* S0);
+void launch_tile(int d, const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st);
+void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
+                 E2* out_evals, hipStream_t st);
+void launch_mid(int d, const DevPlan& pl, const MleSlot* out_slots, int n_mles, int n_flat, int W, int S0, int i0, int i1, const Epilogue& ep,
+                MidRelay* relay, unsigned long long nonce, int direct_poll, hipStream_t st);
