@@ -139,8 +139,11 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
     return 0;
 }
 
-// the last <= 8 levels (<= 256 digests in) in one workgroup of 1024 lanes = 128 nodes per pass
-static constexpr int TOP_NT = 1024, TOP_LEVELS = 8;
+// up to 6 levels (<= 64 digests in) per workgroup of 256 lanes = 32 nodes per pass, one wave per SIMD: every level costs the
+// latency of one 8-lane permutation, measured ~12.5 us (rocprofv3 kernel trace of the opening: 13 / 25 / 48 / 75 us for
+// 1 / 2 / 4 / 6 levels).  A tree of h small levels is therefore h x 12.5 us however it is tiled (1024 lanes over 8 levels
+// measured the same per level); the opening hides half of it by building the tree of round r+1 while round r is answered.
+static constexpr int TOP_NT = 256, TOP_LEVELS = 6;
 struct TopPtrs {
     uint64_t* p[TOP_LEVELS];  // by value in the kernel arguments: no host-to-device copy (a pageable one would block the host on the stream)
     uint64_t* root_host;      // != NULL in the launch that produces the root: it is also written to pinned host memory
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
     const int g = threadIdx.x & 7, slot = threadIdx.x >> 3;
     for (int l = 0; l < levels; l++) {
         const int np = n >> 1;
-        if (slot < np) {  // np <= 128 = one pass; a wave is entirely inside or outside (8 nodes per wave)
+        if (slot < np) {  // np <= 32 = one pass; a wave is entirely inside or outside (8 nodes per wave)
             uint64_t x = buf[cur][8 * slot + g];
             x = p2::permute_lanes8(x, sp);
             if (g < 4) {
@@ -186,7 +189,7 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     }
     // the rest is a chain of dependent permutations (one per level): 8 lanes per permutation, and every launch takes up to
     // TOP_LEVELS levels at once — each workgroup reduces its own 2^TOP_LEVELS-digest subtree in LDS — so 15 small levels
-    // cost two kernel boundaries instead of eight
+    // cost three kernel boundaries instead of fifteen
     int rem = log_rows - l + 1;  // the child level l-1 holds 2^rem digests
     while (rem > 0) {
         const int lv = rem > TOP_LEVELS ? TOP_LEVELS : rem;
