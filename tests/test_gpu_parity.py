@@ -375,6 +375,26 @@ def test_tower_proof_matches_oracle_and_verifies(dev, prover, leaf_log):
     assert np.array_equal(proof.point[:nv], oproof.point[:nv])
 
 
+@pytest.mark.parametrize("host_layers", [0, 3, 8, 10])
+def test_tower_proof_is_the_same_wherever_the_small_layers_are_proved(dev, prover, monkeypatch, host_layers):
+    """layers 1..CENO_TOWER_HOST_LAYERS of a tower proof run on the host from one copy of each tower's top block
+    (ceno_hip_tower_download_top), the rest on the device: product and LogUp specs of different heights, every split point,
+    bit-identical to the oracle's CpuTowerProver::create_proof (scheme/cpu/mod.rs:366-541)"""
+    monkeypatch.setenv("CENO_TOWER_HOST_LAYERS", str(host_layers))
+    lasts = [[po.rand_ext(1 << 11, 31), po.rand_ext(1 << 11, 32)], [po.rand_ext(1 << 6, 33), po.rand_ext(1 << 6, 34)]]
+    lk = [po.rand_ext(1 << 9, 40 + j) for j in range(4)]
+    pspecs = [po.infer_tower_product_witness(12, lasts[0]), po.infer_tower_product_witness(7, lasts[1])]
+    lspec = po.infer_tower_logup_witness(lk[:2], lk[2:])
+    oproof = po.tower_prove(pspecs, [lspec], po.StubTranscript(9))
+    pt = [prover.Tower.from_last_layer(dev, [dev.upload(x) for x in l]) for l in lasts]
+    lt = prover.Tower.from_last_layer(dev, [dev.upload(x) for x in lk])
+    proof = prover.tower_create_proof(dev, pt, [lt], prover.Transcript.stub(9))
+    assert np.array_equal(proof.msgs, oproof.msgs)
+    assert np.array_equal(proof.prod_evals, oproof.prod_evals)
+    assert np.array_equal(proof.logup_evals, oproof.logup_evals)
+    assert np.array_equal(proof.point[:12], oproof.point[:12])
+
+
 def test_tower_relation_mixed_specs(dev, prover):
     # read tower (6 layers), write tower (4 layers), two lookup towers (with and without numerators)
     def prod_last(nv, seed):
