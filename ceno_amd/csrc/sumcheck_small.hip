@@ -6,6 +6,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef CENO_SMALL_SETPRIO
+#define CENO_SMALL_SETPRIO 1
+#endif
+
 // a plan term flattened for the term-parallel kernels: coefficient, then its own factors followed by its group's common
 // factors (their total is <= D <= 8, checked at begin)
 struct alignas(16) TailTerm {
@@ -36,6 +40,7 @@ __device__ __forceinline__ void flatten_term(const DevPlan& pl, int ti, TailTerm
 template <int D>
 __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat, int TP, size_t pairs, E2 r, Epilogue ep, int flat_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
+    if (CENO_SMALL_SETPRIO) __builtin_amdgcn_s_setprio(3);  // latency chain: win issue arbitration against bulk kernels of other lanes
     E2* stage = reinterpret_cast<E2*>(dyn);                               // [n_mles][2][TP]
     E2* smem = stage + (size_t)n_mles * 2 * TP;                    // [(NT/64) * D]
     unsigned long long* s_chal = reinterpret_cast<unsigned long long*>(smem + (NT / 64) * D);  // 3 words + flag
@@ -140,6 +145,7 @@ template <int D>
 __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
                                              E2 r, Epilogue ep, E2* __restrict__ out_evals) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
+    if (CENO_SMALL_SETPRIO) __builtin_amdgcn_s_setprio(3);  // latency chain: win issue arbitration against bulk kernels of other lanes
     E2* bufA = reinterpret_cast<E2*>(dyn);                 // [n_mles][2 * pairs0]
     E2* bufB = bufA + (size_t)n_mles * 2 * pairs0;         // [n_mles][pairs0]
     E2* smem = bufB + (size_t)n_mles * pairs0;             // [(NT/64) * D]
@@ -265,6 +271,7 @@ template <int D>
 __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restrict__ out_slots, int n_mles, int n_flat, int S0, int i0, int i1, E2 r,
                                             Epilogue ep, MidRelay* __restrict__ relay, unsigned long long nonce, int direct_poll) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
+    if (CENO_SMALL_SETPRIO) __builtin_amdgcn_s_setprio(3);  // latency chain: win issue arbitration against bulk kernels of other lanes
     const int stride = 2 * S0;
     E2* tab = reinterpret_cast<E2*>(dyn);                  // [n_mles][2 * S0], folded in place
     E2* smem = tab + (size_t)n_mles * stride;              // [(NT/64) * D]
