@@ -375,6 +375,27 @@ def test_tower_proof_matches_oracle_and_verifies(dev, prover, leaf_log):
     assert np.array_equal(proof.point[:nv], oproof.point[:nv])
 
 
+def test_tower_top_block_layout(dev, prover):
+    """ceno_hip_tower_download_top: layers 0..n-1 in one copy, layer l limb b at element offset n_limbs (2^l - 1) + b 2^l —
+    equal to the per-layer views (ceno_hip_tower_layer), for product and LogUp towers, shorter and taller than the block"""
+    import ctypes as C
+
+    for n_limbs, leaf_log in ((2, 13), (4, 12), (2, 4)):
+        last = [po.rand_ext(1 << leaf_log, 700 + 10 * n_limbs + j) for j in range(n_limbs)]
+        t = prover.Tower.from_last_layer(dev, [dev.upload(x) for x in last])
+        top = dev.L.ceno_hip_tower_top_layers(t.h)
+        assert top == min(t.num_vars, 11) and t.num_limbs == n_limbs
+        for n_layers in sorted({1, min(3, top), top}):
+            buf = np.zeros((n_limbs * ((1 << n_layers) - 1), 2), dtype=np.uint64)
+            dev.check(dev.L.ceno_hip_tower_download_top(dev.h, t.h, n_layers, buf.ctypes.data_as(C.POINTER(C.c_uint64)), None))
+            for l in range(n_layers):
+                for b in range(n_limbs):
+                    off = n_limbs * ((1 << l) - 1) + (b << l)
+                    assert np.array_equal(buf[off: off + (1 << l)], t.layer(l, b)), (n_limbs, leaf_log, l, b)
+        assert dev.L.ceno_hip_tower_download_top(dev.h, t.h, top + 1, buf.ctypes.data_as(C.POINTER(C.c_uint64)), None) != 0
+        t.free()
+
+
 @pytest.mark.parametrize("host_layers", [0, 3, 8, 10])
 def test_tower_proof_is_the_same_wherever_the_small_layers_are_proved(dev, prover, monkeypatch, host_layers):
     """layers 1..CENO_TOWER_HOST_LAYERS of a tower proof run on the host from one copy of each tower's top block
