@@ -1668,13 +1668,15 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 // rounds i .. i1 in one launch of W resident workgroups, i1 = the last round too large for the tail kernel
                 int i1 = i;
                 while (i1 + 1 < sc->n && !tail_eligible(k, pairs >> (i1 + 1 - i), sc->d, (size_t)cl.n_flat)) i1++;
+                bool booked = false;
                 if (W >= 4 && i1 > i && i1 + 1 < sc->n && (pairs >> (i1 - i)) >= (size_t)W) {
-                    {
-                        std::lock_guard<std::mutex> g(ctx->mu);
-                        if (ctx->mid_wgs_in_flight + W > MID_WG_BUDGET) W = 0;  // another lane took it meanwhile
-                        else ctx->mid_wgs_in_flight += W;
+                    std::lock_guard<std::mutex> g(ctx->mu);
+                    if (ctx->mid_wgs_in_flight + W <= MID_WG_BUDGET) {  // (another lane may have taken it meanwhile)
+                        ctx->mid_wgs_in_flight += W;
+                        booked = true;
                     }
-                    if (W == 0) goto no_mid;
+                }
+                if (booked) {
                     sc->mid_reserved = W;
                     static std::atomic<unsigned long long> nonce_src{0};
                     const unsigned long long nonce = (++nonce_src) & ((1ull << 56) - 1);
@@ -1688,7 +1690,6 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                     upto = sc->n;
                     continue;
                 }
-            no_mid:;
             }
             if (sc->gen_on && cl.gen && sc->gen_rounds[i].n_comps > 0 && pairs >= gen_pipe_min_pairs()) {
                 const GenRound& R = sc->gen_rounds[i];
