@@ -590,9 +590,11 @@ __global__ void k_gather_first(const MleSlot* __restrict__ slots, int n, E2* __r
 // start of a sumcheck: zero the arrival counter / relay block and pull the (small) plan blob out of the pinned block in ONE
 // launch — the runtime's fill and copy kernels cost ~9 and ~4 us of stream time each, in front of every tower layer
 __global__ void __launch_bounds__(256) k_setup(uint64_t* __restrict__ zero, size_t zero_words, uint64_t* __restrict__ dst,
-                                               const uint64_t* __restrict__ src_host_view, size_t words) {
+                                               const uint64_t* __restrict__ src_host_view, size_t words, uint64_t* __restrict__ ones = nullptr,
+                                               size_t ones_words = 0) {
     for (size_t i = threadIdx.x; i < zero_words; i += 256) zero[i] = 0;
     for (size_t i = threadIdx.x; i < words; i += 256) dst[i] = src_host_view[i];
+    for (size_t i = threadIdx.x; i < ones_words; i += 256) ones[i] = MSG_INVALID;  // the armed partial-sum rows of k_mid
 }
 
 // last fold of a sumcheck: table i has two elements left, its evaluation is lo + r (hi - lo).  One launch writes all of
@@ -695,6 +697,7 @@ struct ceno_hip_sumcheck {
     unsigned* d_counter = nullptr; // arrival counter of the in-kernel reduction
     E2* d_round_acc = nullptr;     // running message total across the classes of one round
     uint64_t* d_hmsg = nullptr;    // device view of h_pinned (message lands directly in host memory)
+    uint64_t* d_mid_rows = nullptr;         // two sets of armed partial-sum rows + relay lines of the persistent mid-round kernel
     bool slots_preloaded = false;           // the slot rows of every round went to the device with the plan blob (single generic class)
     int mid_reserved = 0;                   // workgroups of a k_mid launch booked against the context's residency budget
     bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
@@ -1406,12 +1409,23 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         rc = ctx_alloc(ctx, std::max<size_t>(blob.size(), 16), &d_blob);
         if (rc) { sc_release(sc); return rc; }
         sc->dev_allocs.push_back(d_blob);
+        // rows of the persistent mid-round kernel (2 sets x 256 workgroups x MAXD ext, then 256 relay lines): armed HERE, by the
+        // set-up kernel — a fill queued right in front of k_mid sat on the critical path of its first round (~9 us)
+        static constexpr size_t MID_ROWS_BYTES = (size_t)2 * 256 * MAXD * sizeof(E2), MID_BLOCK_BYTES = MID_ROWS_BYTES + 256 * 64;
+        if (off_pre_slots != (size_t)-1 && n >= 9) {
+            void* p = nullptr;
+            rc = ctx_alloc(ctx, MID_BLOCK_BYTES, &p);
+            if (rc) { sc_release(sc); return rc; }
+            sc->dev_allocs.push_back(p);
+            sc->d_mid_rows = (uint64_t*)p;
+        }
         if (blob.size() <= 16 * 1024 && blob.size() % 8 == 0) {
             const uint64_t* d_view = reinterpret_cast<const uint64_t*>((char*)db + (h_blob - (char*)hb));
             hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, reinterpret_cast<uint64_t*>(sc->d_counter), (size_t)4096 / 8, (uint64_t*)d_blob, d_view,
-                               blob.size() / 8);
+                               blob.size() / 8, sc->d_mid_rows, sc->d_mid_rows ? MID_ROWS_BYTES / 8 : (size_t)0);
             if (hipGetLastError() != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
         } else {
+            if (sc->d_mid_rows && hipMemsetAsync(sc->d_mid_rows, 0xFF, MID_ROWS_BYTES, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
             if (hipMemsetAsync(sc->d_counter, 0, 4096, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
             if (hipMemcpyAsync(d_blob, h_blob, blob.size(), hipMemcpyHostToDevice, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
         }
@@ -1664,7 +1678,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                     std::lock_guard<std::mutex> g(ctx->mu);
                     w_free = MID_WG_BUDGET - ctx->mid_wgs_in_flight;
                 }
-                mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, sc->mid_reserved ? 0 : w_free, &W, &S0);
+                mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, (sc->mid_reserved || !sc->d_mid_rows) ? 0 : w_free, &W, &S0);
                 // rounds i .. i1 in one launch of W resident workgroups, i1 = the last round too large for the tail kernel
                 int i1 = i;
                 while (i1 + 1 < sc->n && !tail_eligible(k, pairs >> (i1 + 1 - i), sc->d, (size_t)cl.n_flat)) i1++;
@@ -1680,11 +1694,12 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                     sc->mid_reserved = W;
                     static std::atomic<unsigned long long> nonce_src{0};
                     const unsigned long long nonce = (++nonce_src) & ((1ull << 56) - 1);
-                    MidRelay* relay = reinterpret_cast<MidRelay*>(reinterpret_cast<char*>(ep.partials) + 65536);
-                    // the partial-sum rows start out armed (every byte 0xFF = MSG_INVALID); queued ahead of the launch, off the critical path
-                    HIP_TRY(ctx, hipMemsetAsync(ep.partials, 0xFF, (size_t)2 * W * MAXD * sizeof(E2), sc->st));  // both sets
+                    // armed rows (every word MSG_INVALID since the set-up kernel; the reducer re-arms what it reads) + relay lines
+                    Epilogue epm = ep;
+                    epm.partials = sc->d_mid_rows;
+                    MidRelay* relay = reinterpret_cast<MidRelay*>(reinterpret_cast<char*>(sc->d_mid_rows) + (size_t)2 * 256 * MAXD * sizeof(E2));
                     const bool relay_only = getenv("CENO_HIP_MID_RELAY") && atoi(getenv("CENO_HIP_MID_RELAY")) != 0;  // A/B switch
-                    launch_mid(sc->d, pl, cl.d_slots + (size_t)i1 * k, (int)k, cl.n_flat, W, S0, i, i1, ep, relay, nonce,
+                    launch_mid(sc->d, pl, cl.d_slots + (size_t)i1 * k, (int)k, cl.n_flat, W, S0, i, i1, epm, relay, nonce,
                                sc->vram_slot != nullptr && !relay_only, sc->st);
                     i = i1;          // the loop continues with round i1 + 1: the persistent tail
                     upto = sc->n;
