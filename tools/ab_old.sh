@@ -1,5 +1,6 @@
 #!/bin/bash
 # same-box A/B of bench.py headline between the working tree and the build of an older revision kept under _old/
+# (prepare with: git worktree add -f _old <rev> && (cd _old && python -m ceno_amd.build); remove the worktree afterwards)
 cd $GRAFT_REPO_ROOT
 for i in 1 2; do
 for d in . _old . _old; do
