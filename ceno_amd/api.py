@@ -112,6 +112,7 @@ class Device:
         return Mle(self, h)
 
     def synthetic(self, num_vars: int, is_ext: bool, seed: int, word_offset: int = 0, stream=None) -> "Mle":
+        self.check(self.L.ceno_hip_stream_bind(self.h, stream))  # the block is for work on `stream` (pool tags)
         m = self.alloc(num_vars, is_ext)
         self.check(self.L.ceno_hip_mle_fill_splitmix(self.h, m.h, C.c_uint64(seed), C.c_uint64(word_offset), stream))
         return m

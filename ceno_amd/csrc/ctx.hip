@@ -384,6 +384,7 @@ int ceno_hip_mle_alloc(ceno_hip_ctx* ctx, int num_vars, int is_ext, ceno_hip_mle
 
 int ceno_hip_mle_upload(ceno_hip_ctx* ctx, const uint64_t* host, int num_vars, int is_ext, ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, host, "host is NULL");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     ceno_hip_mle* m = nullptr;
     TRY(ceno_hip_mle_alloc(ctx, num_vars, is_ext, &m));
     hipStream_t st = ctx_stream(ctx, s);

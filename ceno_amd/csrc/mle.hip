@@ -231,6 +231,7 @@ int ceno_hip_rotation_next_base_mle(ceno_hip_ctx* ctx, const ceno_hip_mle* in, i
     CHECK_ARG(ctx, in && out, "NULL argument");
     CHECK_ARG(ctx, !in->is_ext, "rotation source must be a base-field table (layer/gpu/utils.rs:250-254)");
     CHECK_ARG(ctx, in->num_vars >= cyclic_group_log2, "table smaller than one cyclic group");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     uint32_t r[64];
     CHECK_ARG(ctx, cyclic_table(cyclic_group_log2, r) == 0, "cyclic group log2 must be 5 or 6");
     RotArg ra{};
@@ -252,6 +253,7 @@ int ceno_hip_rotation_next_base_mle(ceno_hip_ctx* ctx, const ceno_hip_mle* in, i
 int ceno_hip_rotation_selector_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, int cyclic_subgroup_size, int cyclic_group_log2,
                                      ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, out && point, "NULL argument");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     uint32_t r[64];
     CHECK_ARG(ctx, cyclic_table(cyclic_group_log2, r) == 0, "cyclic group log2 must be 5 or 6");
     CHECK_ARG(ctx, cyclic_subgroup_size >= 0 && cyclic_subgroup_size <= (1 << cyclic_group_log2), "cyclic subgroup larger than the group");
@@ -284,6 +286,7 @@ int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed
 
 int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, const uint64_t* scalar2, ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, out && (point || num_vars == 0), "NULL argument");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     ceno_hip_mle* m = nullptr;
     TRY(ceno_hip_mle_alloc(ctx, num_vars, 1, &m));
     E2 sc = scalar2 ? E2{scalar2[0], scalar2[1]} : e2_one();
@@ -300,6 +303,7 @@ int ceno_hip_selector_build(ceno_hip_ctx* ctx, int kind, const uint64_t* point, 
                             const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, out && (point || num_vars == 0), "NULL argument");
     CHECK_ARG(ctx, num_vars >= 0 && num_vars <= 40, "num_vars out of range");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     SelArg sa{};
     sa.kind = kind;
     sa.num_vars = num_vars;
@@ -420,7 +424,9 @@ int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const u
         cur_ext = 1;
         half >>= 1;
     }
-    hipError_t e = hipStreamSynchronize(st);
+    // no wait: the result is ordered on `st` like every other table, and the scratch returns to the pool tagged with this stream
+    // (another stream gets it only once this one has drained)
+    hipError_t e = hipGetLastError();
     ctx_free(ctx, scratch);
     if (rc || e != hipSuccess) {
         ceno_hip_mle_free(ctx, res);

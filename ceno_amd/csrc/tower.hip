@@ -359,6 +359,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
                                                    ceno_hip_stream s, ceno_hip_sumcheck** out) {
     CHECK_ARG(ctx, out && out_rt && alpha_pows && layer >= 1, "tower layer sumcheck: bad arguments");
     CHECK_ARG(ctx, (n_prod == 0 || prod) && (n_logup == 0 || logup), "NULL tower list");
+    (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     // sum_x eq(x, out_rt) * [ sum_i alpha_i a_i b_i + sum_k (alpha_n (p1 q2 + p2 q1) + alpha_d q1 q2) ]
     // -> one common-factor group (eq) over all residual terms  (scheme/cpu/mod.rs:417-494)
     ceno_hip_mle* eq = nullptr;

@@ -131,6 +131,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     if (!ctx || !d || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 || pow_bits > 40 || d->mats.empty())
         return prover_set_error(CENO_HIP_ERR_INVALID, "bad basefold_open arguments");
     if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "basefold_open needs an explicit stream (ceno_hip_stream_create)");
+    (void)ceno_hip_stream_bind(ctx, s);  // this thread drives three streams: say which one every allocation is for (pool tags)
     hipStream_t st = (hipStream_t)s;
     const int n_mats = (int)d->mats.size(), rate_log = d->log_blowup, n = max_nv(d), H = n + rate_log;
     size_t total_cols = 0;
@@ -307,6 +308,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         ch[2 * r + 1] = c.c1;
         // fold with c_r (the codeword of the next height joins) and start the NEXT round's tree right away
         ceno_hip_stream fs = sx[(r + 1) & 1];  // C[r] was produced on sx[r & 1] (event ev[r & 1]); C[0] by the batching on `s` (synchronised)
+        (void)ceno_hip_stream_bind(ctx, fs);  // C[r + 1] is produced and consumed on `fs`
         int rc = alloc_ext(h - 1, &C[r + 1]);
         if (!rc && r > 0 && hipStreamWaitEvent((hipStream_t)fs, ev[r & 1], 0) != hipSuccess) rc = CENO_HIP_ERR_HIP;
         if (!rc) rc = ceno_hip_basefold_fold(ctx, ceno_hip_mle_device_ptr(C[r]), h, &ch[2 * r], B[h - 1] ? ceno_hip_mle_device_ptr(B[h - 1]) : nullptr,
@@ -379,6 +381,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         int snv = 0;
         while (((size_t)1 << snv) < Q + ans_words) snv++;
         ceno_hip_mle* scratch = nullptr;
+        (void)ceno_hip_stream_bind(ctx, s);
         if (ceno_hip_mle_alloc(ctx, snv, 0, &scratch) != 0) {
             cleanup();
             return prover_set_error(CENO_HIP_ERR_OOM, "basefold_open: query scratch allocation failed");

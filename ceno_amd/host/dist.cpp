@@ -776,6 +776,7 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
             int is_ext = 0, nvj = 0;
             rc = ceno_hip_sumcheck_table(ctx, sc, j, &src, &is_ext, &nvj);
             if (!rc && nvj != m) { g_dist_err = "sharded tables of unequal size"; rc = CENO_HIP_ERR_INVALID; }
+            if (!rc) rc = ceno_hip_stream_bind(ctx, s);
             if (!rc) rc = ceno_hip_mle_alloc(ctx, nv2, is_ext, &full[j]);
             if (!rc) {
                 ncclResult_t nr = g_rccl.AllGather(src, ceno_hip_mle_device_ptr(full[j]), ((size_t)1 << m) * (is_ext ? 2 : 1), ncclUint64, c->comm, st);
@@ -1006,6 +1007,7 @@ int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t
     if (w_local && !local_cols_dev) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: local_cols_dev is NULL");
     const size_t R = (size_t)1 << (log_rows + log_blowup), rl = R >> log_w;
     hipStream_t st = (hipStream_t)s;
+    (void)ceno_hip_stream_bind(ctx, s);  // every allocation below is for work on `s`
     auto fail_hip = [&](int rc) {
         g_dist_err = ceno_hip_last_error(ctx);
         return rc;

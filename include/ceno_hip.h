@@ -92,6 +92,7 @@ size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx);
 /* ------------------------------------------------------------------------------------------------
  * MLE handles  (alloc_elems_on_device / alloc_ext_elems_from_host / Buffer::to_cpu_vec)
  * ---------------------------------------------------------------------------------------------- */
+/* (takes its block for the stream the calling thread is bound to: the last call that took a stream, or ceno_hip_stream_bind) */
 int ceno_hip_mle_alloc(ceno_hip_ctx* ctx, int num_vars, int is_ext, ceno_hip_mle** out);
 int ceno_hip_mle_upload(ceno_hip_ctx* ctx, const uint64_t* host, int num_vars, int is_ext, ceno_hip_stream s, ceno_hip_mle** out);
 /* borrow device memory owned by the caller (e.g. a torch tensor); never freed by the library */
