@@ -183,3 +183,25 @@ def test_poseidon2_host_source_matches_oracle_and_transcript_is_deterministic(bu
     state[0], state[1] = 11, 22
     state = po.poseidon2_permute(state)
     assert got == (int(state[3]), int(state[2]))
+
+
+def test_entry_points_resolve_their_stream_before_they_allocate():
+    """The pool tags a block with the stream the calling thread resolved last (ctx_stream) and hands it to another stream only
+    once that one has drained.  An entry point that allocates BEFORE it resolves its own stream argument would take blocks
+    under the previous call's tag (a real bug once: the pool-ordering GPU test).  Static check over the C-ABI sources."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for f in sorted(glob.glob(os.path.join(root, "ceno_amd", "csrc", "*.hip"))):
+        s = open(f).read()
+        for m in re.finditer(r'\n(?:extern "C" )?int (ceno_hip_\w+)\(([^)]*)\)\s*\{', s):
+            if "ceno_hip_stream" not in m.group(2):
+                continue
+            body = s[m.end(): s.find("\n}\n", m.end())]
+            allocs = [body.find(x) for x in ("ctx_alloc(", "ceno_hip_mle_alloc(", "merkle_alloc(", "tower_alloc(") if body.find(x) >= 0]
+            st = body.find("ctx_stream(")
+            if allocs and (st < 0 or min(allocs) < st):
+                offenders.append((os.path.basename(f), m.group(1)))
+    assert offenders == [], offenders
