@@ -185,6 +185,63 @@ __global__ void __launch_bounds__(NT) k_eval_dot(const uint64_t* __restrict__ f,
     red::block_sum<1, NT>(acc, smem);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
 }
+// both half tables of an evaluation in ONE launch (lo over the first a variables, hi over the remaining b); also clears the
+// arrival counter of the reduction that follows on the same stream
+__global__ void __launch_bounds__(NT) k_eq_halves(E2* __restrict__ lo, int a, E2* __restrict__ hi, int b, PointArg pt, unsigned* __restrict__ counter) {
+    const size_t na = (size_t)1 << a, total = na + ((size_t)1 << b);
+    const size_t stride = (size_t)gridDim.x * NT;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+        const bool second = i >= na;
+        const size_t x = second ? i - na : i;
+        const int first_var = second ? a : 0, n_vars = second ? b : a;
+        E2 acc = e2_one();
+        for (int k = 0; k < n_vars; k++) {
+            const E2 r = pt.r[first_var + k];
+            acc = acc * (((x >> k) & 1) ? r : (e2_one() - r));
+        }
+        (second ? hi : lo)[x] = acc;
+    }
+}
+// sum f[i] lo[i & mask] hi[i >> a] in one read-only pass; the last workgroup to arrive adds the per-workgroup partials and
+// writes the evaluation straight into pinned host words the caller watches (no second launch, no copy, no stream wait)
+template <bool IN_EXT>
+__global__ void __launch_bounds__(NT) k_eval_dot_host(const uint64_t* __restrict__ f, const E2* __restrict__ lo, const E2* __restrict__ hi, int a, size_t len,
+                                                      uint64_t* __restrict__ partials, unsigned* __restrict__ counter, E2* __restrict__ out_host) {
+    __shared__ E2 smem[NT / 64];
+    __shared__ int s_last;
+    const size_t stride = (size_t)gridDim.x * NT;
+    const size_t mask = ((size_t)1 << a) - 1;
+    E2 acc[1] = {e2_zero()};
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+        const E2 w = lo[i & mask] * hi[i >> a];
+        if (IN_EXT) acc[0] = acc[0] + reinterpret_cast<const E2*>(f)[i] * w;
+        else acc[0] = acc[0] + e2_mul_base(w, f[i]);
+    }
+    red::block_sum<1, NT>(acc, smem);
+    if (threadIdx.x == 0) {
+        // write-through partial, drained before the agent-scope arrival count (per-XCD L2s are not coherent)
+        __hip_atomic_store(partials + 2 * blockIdx.x, acc[0].c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(partials + 2 * blockIdx.x + 1, acc[0].c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    E2 tot[1] = {e2_zero()};
+    for (unsigned bb = threadIdx.x; bb < gridDim.x; bb += NT)
+        tot[0] = tot[0] + E2{__hip_atomic_load(partials + 2 * bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                             __hip_atomic_load(partials + 2 * bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+    __syncthreads();
+    red::block_sum<1, NT>(tot, smem);
+    if (threadIdx.x == 0) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 w = {(unsigned)tot[0].c0, (unsigned)(tot[0].c0 >> 32), (unsigned)tot[0].c1, (unsigned)(tot[0].c1 >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host), "v"(w) : "memory");
+    }
+}
 __global__ void __launch_bounds__(NT) k_sum_partials(const E2* __restrict__ partials, int n, E2* out) {
     __shared__ E2 smem[NT / 64];
     E2 acc[1] = {e2_zero()};
@@ -367,27 +424,45 @@ int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64
     int a = (n + 1) / 2, b = n - a;
     size_t len = m->len();
     unsigned g = grid_for(len, NT, MAXB);
+    // two launches and no copy: half tables (+ counter reset), then the dot product whose last workgroup writes the value
+    // into pinned words armed with a non-canonical pattern — the caller's thread watches them instead of waiting for the stream
     void* tmp = nullptr;
     TRY(ctx_alloc(ctx, (((size_t)1 << a) + ((size_t)1 << b) + g + 1) * sizeof(E2), &tmp));
     E2* lo = (E2*)tmp;
     E2* hi = lo + ((size_t)1 << a);
-    E2* partials = hi + ((size_t)1 << b);
-    E2* res = partials + g;
-    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << a, NT, MAXB)), dim3(NT), 0, st, lo, 0, a, pt, e2_one());
-    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << b, NT, MAXB)), dim3(NT), 0, st, hi, a, b, pt, e2_one());
+    uint64_t* partials = reinterpret_cast<uint64_t*>(hi + ((size_t)1 << b));
+    unsigned* counter = reinterpret_cast<unsigned*>(partials + 2 * (size_t)g);
+    void *h_res = nullptr, *d_res = nullptr;
+    int rc = ctx_pinned_alloc(ctx, 64, &h_res, &d_res);
+    if (rc) {
+        ctx_free(ctx, tmp);
+        return rc;
+    }
+    volatile uint64_t* hw = (volatile uint64_t*)h_res;
+    hw[0] = hw[1] = ~0ull;
+    const size_t total = ((size_t)1 << a) + ((size_t)1 << b);
+    hipLaunchKernelGGL(k_eq_halves, dim3(grid_for(total, NT, MAXB)), dim3(NT), 0, st, lo, a, hi, b, pt, counter);
     if (m->is_ext)
-        hipLaunchKernelGGL(k_eval_dot<true>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials);
+        hipLaunchKernelGGL(k_eval_dot_host<true>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials, counter, (E2*)d_res);
     else
-        hipLaunchKernelGGL(k_eval_dot<false>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(NT), 0, st, partials, (int)g, res);
+        hipLaunchKernelGGL(k_eval_dot_host<false>, dim3(g), dim3(NT), 0, st, m->d, lo, hi, a, len, partials, counter, (E2*)d_res);
     hipError_t e = hipGetLastError();
-    E2 h{};
-    if (e == hipSuccess) e = hipMemcpyAsync(&h, res, sizeof(E2), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    ctx_free(ctx, tmp);
+    unsigned long long spins = 0;
+    while (e == hipSuccess && (__atomic_load_n(&hw[0], __ATOMIC_ACQUIRE) == ~0ull || __atomic_load_n(&hw[1], __ATOMIC_ACQUIRE) == ~0ull)) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();
+#endif
+        if ((++spins & 0xFFFFF) == 0) {  // a faulted kernel never writes: make sure the stream is still alive
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipSuccess && q != hipErrorNotReady) e = q;
+            else if (q == hipSuccess && (hw[0] == ~0ull || hw[1] == ~0ull)) e = hipErrorUnknown;
+        }
+    }
+    out2[0] = hw[0];
+    out2[1] = hw[1];
+    ctx_pinned_free(ctx, h_res);
+    ctx_free(ctx, tmp);  // tagged with this stream; the last kernel has written its result, nothing of it is still queued
     if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "evaluate: %s", hipGetErrorString(e));
-    out2[0] = h.c0;
-    out2[1] = h.c1;
     return 0;
 }
 
