@@ -170,21 +170,6 @@ int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 sca
 // ------------------------------------------------------------------------------------------------
 // evaluate: sum_i f[i] * lo[i & mask] * hi[i >> a]   (one read-only pass over the table)
 // ------------------------------------------------------------------------------------------------
-template <bool IN_EXT>
-__global__ void __launch_bounds__(NT) k_eval_dot(const uint64_t* __restrict__ f, const E2* __restrict__ lo, const E2* __restrict__ hi,
-                                                 int a, size_t len, E2* __restrict__ partials) {
-    __shared__ E2 smem[NT / 64];
-    size_t stride = (size_t)gridDim.x * NT;
-    size_t mask = ((size_t)1 << a) - 1;
-    E2 acc[1] = {e2_zero()};
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
-        E2 w = lo[i & mask] * hi[i >> a];
-        if (IN_EXT) acc[0] = acc[0] + reinterpret_cast<const E2*>(f)[i] * w;
-        else acc[0] = acc[0] + e2_mul_base(w, f[i]);
-    }
-    red::block_sum<1, NT>(acc, smem);
-    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
-}
 // both half tables of an evaluation in ONE launch (lo over the first a variables, hi over the remaining b); also clears the
 // arrival counter of the reduction that follows on the same stream
 __global__ void __launch_bounds__(NT) k_eq_halves(E2* __restrict__ lo, int a, E2* __restrict__ hi, int b, PointArg pt, unsigned* __restrict__ counter) {
@@ -241,13 +226,6 @@ __global__ void __launch_bounds__(NT) k_eval_dot_host(const uint64_t* __restrict
         const u4 w = {(unsigned)tot[0].c0, (unsigned)(tot[0].c0 >> 32), (unsigned)tot[0].c1, (unsigned)(tot[0].c1 >> 32)};
         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host), "v"(w) : "memory");
     }
-}
-__global__ void __launch_bounds__(NT) k_sum_partials(const E2* __restrict__ partials, int n, E2* out) {
-    __shared__ E2 smem[NT / 64];
-    E2 acc[1] = {e2_zero()};
-    for (int i = threadIdx.x; i < n; i += NT) acc[0] = acc[0] + partials[i];
-    red::block_sum<1, NT>(acc, smem);
-    if (threadIdx.x == 0) out[0] = acc[0];
 }
 
 // ------------------------------------------------------------------------------------------------
