@@ -3,6 +3,8 @@
 // (gkr_iop/src/gpu/mod.rs:53-154) and the alloc/copy entry points catalogued in SURVEY.md §2.2.
 #include "common.hpp"
 
+#include <algorithm>
+
 static thread_local std::string g_init_err;
 
 int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...) {
@@ -67,8 +69,25 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                 const hipStream_t last = fl[k].second;
                 if (!last || last == cur || !stream_alive(ctx, last)) pick = k;
             }
-            for (int k = (int)fl.size() - 1, probes = 0; k >= 0 && pick < 0 && probes < 2; k--, probes++)
-                if (hipStreamQuery(fl[k].second) == hipSuccess) pick = k;
+            // second choice: any block whose stream has drained — one query per DISTINCT stream (a handful), not per block, so
+            // that blocks tagged with a lane that no longer asks for this size do not pile up behind busy ones
+            if (pick < 0) {
+                hipStream_t seen[16];
+                bool idle[16];
+                int n_seen = 0;
+                for (int k = (int)fl.size() - 1; k >= 0 && pick < 0; k--) {
+                    const hipStream_t last = fl[k].second;
+                    int j = 0;
+                    while (j < n_seen && seen[j] != last) j++;
+                    if (j == n_seen) {
+                        if (n_seen == 16) break;
+                        seen[n_seen] = last;
+                        idle[n_seen] = hipStreamQuery(last) == hipSuccess;
+                        n_seen++;
+                    }
+                    if (idle[j]) pick = k;
+                }
+            }
             if (pick >= 0) {
                 void* p = fl[pick].first;
                 fl.erase(fl.begin() + pick);
@@ -96,6 +115,26 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     }
     void* p = nullptr;
     ctx_make_current(ctx);
+    {   // soft cap on the cache: blocks parked without a tag (their stream had drained) go back to the driver once the cache is
+        // several times what is in use — a backstop against slow growth under many lanes, far below any real footprint
+        std::lock_guard<std::mutex> g(ctx->mu);
+        const size_t floor_ = (size_t)2 << 30;
+        if (ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_)) {
+            for (auto& kv : ctx->free_lists) {
+                auto& fl = kv.second;
+                for (size_t k = 0; k < fl.size();) {
+                    if (fl[k].second == nullptr) {
+                        (void)hipFree(fl[k].first);
+                        ctx->pool_cached -= kv.first;
+                        fl[k] = fl.back();
+                        fl.pop_back();
+                    } else {
+                        k++;
+                    }
+                }
+            }
+        }
+    }
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
         // drop the cache and retry once
@@ -119,7 +158,13 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
     ctx->live.erase(it);
     ctx->pool_used -= b;
     ctx->pool_cached += b;
-    ctx->free_lists[b].push_back({p, ceno_tls_stream ? ceno_tls_stream : ctx->default_stream});
+    // Tag = the stream this thread worked on last.  A LARGE block is worth one runtime call: if that stream has already
+    // drained, the block is free for everybody (no tag) — otherwise blocks freed after a synchronisation by a thread that
+    // alternates between streams (commit_traces, the opening) could only ever go back to the stream of the tag, and every run
+    // would allocate the other stream's share afresh (measured: +230 MB of cache per shard flow).
+    hipStream_t tag = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
+    if (b >= ((size_t)64 << 10) && stream_alive(ctx, tag) && hipStreamQuery(tag) == hipSuccess) tag = nullptr;
+    ctx->free_lists[b].push_back({p, tag});
 }
 
 static constexpr int VRAM_SLOTS = 1024;

@@ -515,3 +515,23 @@ def _stub_absorb(t, word):
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
     t.state.s = z ^ (z >> 31)
+
+
+def test_pool_cache_does_not_grow_over_repeated_flows_with_lanes(prover):
+    """The pool hands a block to another stream only once the stream that used it last has drained; blocks freed after a
+    synchronisation must become free for everybody, or a flow that alternates streams (two-stream commit, lanes) allocates a
+    share of its footprint afresh on every run (regression: +230 MB of cache per shard flow)"""
+    from ceno_amd import Device, synthetic
+
+    d = Device(0)
+    flow = synthetic.ShardFlow(d, prover, w=22, n_queries=10, pow_bits=4, log_rows=(14, 13, 12, 11, 11))
+    tr, fk = (lambda: prover.Transcript.stub(0x5A)), (lambda: prover.Transcript.stub(0xF0))
+    for it in range(6):
+        flow.run(tr, fk, lanes=(1, 3)[it % 2])
+    base = d.mem_info()["pool_cached"]
+    for it in range(16):
+        flow.run(tr, fk, lanes=(1, 3)[it % 2])
+    grown = d.mem_info()["pool_cached"] - base
+    flow.close()
+    d.close()
+    assert grown <= base // 4 + (8 << 20), (base, grown)
