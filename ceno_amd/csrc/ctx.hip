@@ -283,7 +283,13 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
 
 const char* ceno_hip_last_error(ceno_hip_ctx* ctx) {
     if (!ctx) return g_init_err.c_str();
-    return ctx->err.c_str();
+    // a copy per calling thread: another lane may be writing its own failure into ctx->err right now
+    thread_local std::string mine;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        mine = ctx->err;
+    }
+    return mine.c_str();
 }
 
 int ceno_hip_make_current(ceno_hip_ctx* ctx) {
