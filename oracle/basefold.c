@@ -13,12 +13,14 @@
  *                                               sibling + Merkle path per commit round, final constant codeword
  *   ceno_recursion_v2/src/pcs/mod.rs:7765-7781  fold: lo=(a+b)/2, hi=(a-b) g^-bitrev(i) /2, lo + r (hi - lo)
  * with basecode_msg_size_log = 0 (the only shape that verifier supports, pcs/mod.rs:8330-8338).
- * Deviations forced by what is absent in-tree (all inside "unpinned" territory):
- *   - field/hash instances are this repo's Goldilocks ones (commit.c): Poseidon2 width 8, one tree per trace matrix
- *     (p3's mixed-height MMCS is an EXT crate);
- *   - digests are observed as two extension elements; query indices are the low bits of c0 of a sampled ext;
- *   - proof of work: seed = sample, witness = least w with permute(seed.c0, seed.c1, w, 0..)[0] = 0 mod 2^bits,
- *     then observed (p3's grinding challenger needs a transcript fork the C transcript interface does not have).
+ *   ceno_recursion_v2/src/pcs/mod.rs:8125-8155  proof of work: check_witness = observe(witness), sample_bits(bits) == 0
+ *   ceno_recursion_v2/src/pcs/mod.rs:1253-1266  query index = sample_bits(max_num_var + rate_log), ONE base sample each
+ *   ceno_recursion_v2/src/pcs/mod.rs:7547-7565  one input opening per COMMITMENT (`rounds`): reduced_index = query >>
+ *                                               (log2_max_codeword_size - commit.log2_max_codeword_size), opened rows of
+ *                                               all its matrices + one MMCS path (commit.c: orc_mmcs_*)
+ * Unpinned remainder: the Goldilocks field/hash instances (commit.c: Poseidon2 width 8 constants) and
+ * the byte packing of labels.  A digest is observed as its four base elements (written here as two ext appends: the same
+ * absorb sequence).  p3's grinding takes ANY valid witness (`find_any`, parallel); this restatement takes the least.
  */
 #include "oracle.h"
 #include "gl64.h"
@@ -65,19 +67,34 @@ static void rs_encode_col(const uint64_t* col, int nv, int rate_log, uint64_t* o
     orc_fft_bitrev(out, nv + rate_log);
 }
 
-size_t orc_basefold_query_words(int n_mats, const int* nv, const int* width, int rate_log) {
+static int total_mats(int n_commits, const int* commit_sizes) {
+    int t = 0;
+    for (int c = 0; c < n_commits; c++) t += commit_sizes[c];
+    return t;
+}
+size_t orc_basefold_query_words(int n_commits, const int* commit_sizes, const int* nv, const int* width, int rate_log) {
+    const int n_mats = total_mats(n_commits, commit_sizes);
     int n = 0;
     for (int m = 0; m < n_mats; m++) if (nv[m] > n) n = nv[m];
     size_t w = 1;
-    for (int m = 0; m < n_mats; m++) w += (size_t)width[m] + 4 * (size_t)(nv[m] + rate_log);
+    for (int c = 0, m0 = 0; c < n_commits; m0 += commit_sizes[c], c++) {
+        int hc = 0;
+        for (int m = m0; m < m0 + commit_sizes[c]; m++) {
+            w += (size_t)width[m];
+            if (nv[m] > hc) hc = nv[m];
+        }
+        w += 4 * (size_t)(hc + rate_log);
+    }
     for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + rate_log - r - 1);
     return w;
 }
 /* [msgs 4n][commits 4n][final 2*n_mats][pow 1][n_queries * query_words] */
-size_t orc_basefold_proof_words(int n_mats, const int* nv, const int* width, int rate_log, int n_queries) {
+size_t orc_basefold_proof_words(int n_commits, const int* commit_sizes, const int* nv, const int* width, int rate_log, int n_queries) {
+    const int n_mats = total_mats(n_commits, commit_sizes);
     int n = 0;
     for (int m = 0; m < n_mats; m++) if (nv[m] > n) n = nv[m];
-    return 8 * (size_t)n + 2 * (size_t)n_mats + 1 + (size_t)n_queries * orc_basefold_query_words(n_mats, nv, width, rate_log);
+    return 8 * (size_t)n + 2 * (size_t)n_mats + 1 +
+           (size_t)n_queries * orc_basefold_query_words(n_commits, commit_sizes, nv, width, rate_log);
 }
 
 static void hash_pair(ext2 a, ext2 b, const uint64_t* params, uint64_t* digest4) {
@@ -140,17 +157,13 @@ static ext2 fold_pair(ext2 a, ext2 b, ext2 r, uint64_t coeff) {
     return e2_add(lo, e2_mul(r, e2_sub(hi, lo)));
 }
 
-static uint64_t pow_hash(ext2 seed, uint64_t w, const uint64_t* params) {
-    uint64_t s[8] = {seed.c[0], seed.c[1], w, 0, 0, 0, 0, 0};
-    orc_poseidon2_permute(s, params);
-    return s[0];
-}
-
-int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_t* const* traces, const uint64_t* const* points,
-                      const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits, const uint64_t* params,
-                      orc_transcript* tr, uint64_t* proof) {
+int orc_basefold_open(int n_commits, const int* commit_sizes, const int* nv, const int* width, const uint64_t* const* traces,
+                      const uint64_t* const* points, const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits,
+                      const uint64_t* params, orc_transcript* tr, uint64_t* proof) {
     int n = 0, total_cols = 0;
-    if (n_mats < 1 || n_mats > 4096) return -1;
+    const int n_mats = total_mats(n_commits, commit_sizes);
+    if (n_commits < 1 || n_mats < 1 || n_mats > 4096) return -1;
+    if (!tr->append_base || !tr->sample_base || !tr->fork) return -1;
     for (int m = 0; m < n_mats; m++) {
         if (nv[m] < 1 || width[m] < 1) return -1;
         if (nv[m] > n) n = nv[m];
@@ -158,15 +171,20 @@ int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_
     }
     const int H = n + rate_log;
     int rc = 0;
-    /* input codewords + trees (what commit_traces produced) */
+    /* input codewords + ONE mixed-height tree per commitment (what commit_traces produced) */
     uint64_t** cw = calloc(n_mats, sizeof(*cw));
-    uint64_t** in_tree = calloc(n_mats, sizeof(*in_tree));
+    uint64_t** in_tree = calloc(n_commits, sizeof(*in_tree));
+    int* log_h = calloc(n_mats, sizeof(int));
     for (int m = 0; m < n_mats; m++) {
         size_t rows = (size_t)1 << nv[m], N = rows << rate_log;
         cw[m] = malloc(N * width[m] * 8);
         for (int c = 0; c < width[m]; c++) rs_encode_col(traces[m] + (size_t)c * rows, nv[m], rate_log, cw[m] + (size_t)c * N);
-        in_tree[m] = malloc(4 * (2 * N - 1) * 8);
-        orc_merkle_commit(cw[m], nv[m] + rate_log, width[m], params, in_tree[m]);
+        log_h[m] = nv[m] + rate_log;
+    }
+    for (int c = 0, m0 = 0; c < n_commits; m0 += commit_sizes[c], c++) {
+        const int hc = orc_mmcs_log_max(commit_sizes[c], log_h + m0);
+        in_tree[c] = malloc(4 * (((size_t)2 << hc) - 1) * 8);
+        orc_mmcs_commit(commit_sizes[c], log_h + m0, width + m0, (const uint64_t* const*)cw + m0, params, in_tree[c]);
     }
     /* batch coefficients */
     tr_label(tr, "batch coeffs");
@@ -205,7 +223,7 @@ int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_
     uint64_t* finalm = proof + 8 * (size_t)n;
     uint64_t* powp = finalm + 2 * (size_t)n_mats;
     uint64_t* qbase = powp + 1;
-    const size_t qwords = orc_basefold_query_words(n_mats, nv, width, rate_log);
+    const size_t qwords = orc_basefold_query_words(n_commits, commit_sizes, nv, width, rate_log);
 
     /* commit phase */
     ext2** C = calloc(n + 1, sizeof(*C));          /* running codeword before the fold of round r */
@@ -272,29 +290,23 @@ int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_
     }
     for (size_t i = 0; i < ((size_t)1 << rate_log); i++)
         if (!e2_eq(C[n][i], total)) rc = -2; /* the final codeword must be the constant codeword of the message */
-    /* proof of work */
+    /* proof of work (pcs/mod.rs:1248-1251, 8125-8155) */
     *powp = 0;
-    if (pow_bits > 0) {
-        ext2 seed = tr_sample(tr);
-        uint64_t w = 0, mask = ((uint64_t)1 << pow_bits) - 1;
-        while (pow_hash(seed, w, params) & mask) w++;
-        *powp = w;
-        ext2 we = {{w, 0}};
-        tr_ext(tr, we);
-    }
-    /* queries */
+    if (pow_bits > 0) *powp = orc_tr_grind(tr, pow_bits);
+    /* queries (pcs/mod.rs:1252-1266) */
     tr_label(tr, "query indices");
     for (int q = 0; q < n_queries; q++) {
         uint64_t* out = qbase + (size_t)q * qwords;
-        ext2 s = tr_sample(tr);
-        size_t query = (size_t)(s.c[0] & (((uint64_t)1 << H) - 1));
+        size_t query = (size_t)orc_tr_sample_bits(tr, H);
         *out++ = query;
-        for (int m = 0; m < n_mats; m++) {
-            int hm = nv[m] + rate_log;
-            size_t N = (size_t)1 << hm, idx = query >> (H - hm);
-            for (int c = 0; c < width[m]; c++) *out++ = cw[m][(size_t)c * N + idx];
-            tree_path(in_tree[m], N, hm, idx, out);
-            out += 4 * hm;
+        for (int c = 0, m0 = 0; c < n_commits; m0 += commit_sizes[c], c++) {
+            const int hc = orc_mmcs_log_max(commit_sizes[c], log_h + m0);
+            size_t wsum = 0;
+            for (int m = m0; m < m0 + commit_sizes[c]; m++) wsum += (size_t)width[m];
+            /* reduced_index = query >> bits_reduced (pcs/mod.rs:7553-7554) */
+            orc_mmcs_open(commit_sizes[c], log_h + m0, width + m0, (const uint64_t* const*)cw + m0, in_tree[c], query >> (H - hc), out,
+                          out + wsum);
+            out += wsum + 4 * (size_t)hc;
         }
         size_t idx = query;
         for (int r = 0; r < n; r++) {
@@ -306,7 +318,9 @@ int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_
             idx >>= 1;
         }
     }
-    for (int m = 0; m < n_mats; m++) { free(cw[m]); free(in_tree[m]); free(F[m]); free(E[m]); }
+    for (int m = 0; m < n_mats; m++) { free(cw[m]); free(F[m]); free(E[m]); }
+    for (int c = 0; c < n_commits; c++) free(in_tree[c]);
+    free(log_h);
     for (int h = 0; h <= H; h++) free(B[h]);
     for (int r = 0; r <= n; r++) free(C[r]);
     for (int r = 0; r < n; r++) free(ctree[r]);
@@ -314,26 +328,36 @@ int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_
     return rc;
 }
 
-/* input commitment roots, as commit_traces publishes them */
-void orc_basefold_commit_roots(int n_mats, const int* nv, const int* width, const uint64_t* const* traces, int rate_log,
-                               const uint64_t* params, uint64_t* roots) {
-    for (int m = 0; m < n_mats; m++) {
-        size_t rows = (size_t)1 << nv[m], N = rows << rate_log;
-        uint64_t* cw = malloc(N * width[m] * 8);
-        for (int c = 0; c < width[m]; c++) rs_encode_col(traces[m] + (size_t)c * rows, nv[m], rate_log, cw + (size_t)c * N);
-        uint64_t* t = malloc(4 * (2 * N - 1) * 8);
-        orc_merkle_commit(cw, nv[m] + rate_log, width[m], params, t);
-        memcpy(roots + 4 * m, t + 4 * (2 * N - 2), 32);
-        free(cw);
-        free(t);
+/* input commitment roots, as commit_traces publishes them: ONE root per commitment (cpu/mod.rs:559-584) */
+void orc_basefold_commit_roots(int n_commits, const int* commit_sizes, const int* nv, const int* width, const uint64_t* const* traces,
+                               int rate_log, const uint64_t* params, uint64_t* roots) {
+    for (int c = 0, m0 = 0; c < n_commits; m0 += commit_sizes[c], c++) {
+        const int k = commit_sizes[c];
+        uint64_t** cw = calloc(k, sizeof(*cw));
+        int* log_h = calloc(k, sizeof(int));
+        for (int i = 0; i < k; i++) {
+            const int m = m0 + i;
+            size_t rows = (size_t)1 << nv[m], N = rows << rate_log;
+            cw[i] = malloc(N * width[m] * 8);
+            for (int col = 0; col < width[m]; col++) rs_encode_col(traces[m] + (size_t)col * rows, nv[m], rate_log, cw[i] + (size_t)col * N);
+            log_h[i] = nv[m] + rate_log;
+        }
+        const int hc = orc_mmcs_log_max(k, log_h);
+        uint64_t* t = malloc(4 * (((size_t)2 << hc) - 1) * 8);
+        orc_mmcs_commit(k, log_h, width + m0, (const uint64_t* const*)cw, params, t);
+        memcpy(roots + 4 * c, t + 4 * (((size_t)2 << hc) - 2), 32);
+        for (int i = 0; i < k; i++) free(cw[i]);
+        free(cw); free(log_h); free(t);
     }
 }
 
 /* returns 0 when the proof is accepted, a positive code naming the failed check otherwise */
-int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint64_t* roots, const uint64_t* const* points,
-                        const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits, const uint64_t* params,
-                        orc_transcript* tr, const uint64_t* proof) {
+int orc_basefold_verify(int n_commits, const int* commit_sizes, const int* nv, const int* width, const uint64_t* roots,
+                        const uint64_t* const* points, const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits,
+                        const uint64_t* params, orc_transcript* tr, const uint64_t* proof) {
     int n = 0, total_cols = 0;
+    const int n_mats = total_mats(n_commits, commit_sizes);
+    if (!tr->append_base || !tr->sample_base) return -1;
     for (int m = 0; m < n_mats; m++) {
         if (nv[m] > n) n = nv[m];
         total_cols += width[m];
@@ -344,8 +368,10 @@ int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint6
     const uint64_t* finalm = proof + 8 * (size_t)n;
     const uint64_t* powp = finalm + 2 * (size_t)n_mats;
     const uint64_t* qbase = powp + 1;
-    const size_t qwords = orc_basefold_query_words(n_mats, nv, width, rate_log);
+    const size_t qwords = orc_basefold_query_words(n_commits, commit_sizes, nv, width, rate_log);
     int rc = 0;
+    int* log_h = malloc(sizeof(int) * (size_t)n_mats);
+    for (int m = 0; m < n_mats; m++) log_h[m] = nv[m] + rate_log;
 
     tr_label(tr, "batch coeffs");
     ext2 alpha = tr_sample(tr);
@@ -385,39 +411,34 @@ int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint6
     }
     if (!e2_eq(expect, claim)) rc = 1;
     if (!rc && pow_bits > 0) {
-        ext2 seed = tr_sample(tr);
-        if (pow_hash(seed, *powp, params) & (((uint64_t)1 << pow_bits) - 1)) rc = 2;
-        ext2 we = {{*powp, 0}};
-        tr_ext(tr, we);
+        if (*powp >= GL_P || !orc_tr_check_witness(tr, pow_bits, *powp)) rc = 2; /* pcs/mod.rs:1248-1251 */
     }
     tr_label(tr, "query indices");
     ext2* reduced = malloc(sizeof(ext2) * (H + 1));
     char* has = malloc(H + 1);
     for (int q = 0; q < n_queries && !rc; q++) {
         const uint64_t* in = qbase + (size_t)q * qwords;
-        ext2 s = tr_sample(tr);
-        size_t query = (size_t)(s.c[0] & (((uint64_t)1 << H) - 1));
+        size_t query = (size_t)orc_tr_sample_bits(tr, H);
         if (*in++ != query) { rc = 3; break; }
         memset(has, 0, H + 1);
         int ci = 0;
-        for (int m = 0; m < n_mats && !rc; m++) {
-            int hm = nv[m] + rate_log;
-            size_t idx = query >> (H - hm);
-            /* leaf = sponge over the opened row (commit.c orc_merkle_commit) */
-            uint64_t st[8] = {0};
-            for (int c = 0; c < width[m]; c += 4) {
-                for (int k = 0; k < 4 && c + k < width[m]; k++) st[k] = in[c + k];
-                orc_poseidon2_permute(st, params);
+        for (int c = 0, m0 = 0; c < n_commits && !rc; m0 += commit_sizes[c], c++) {
+            const int hc = orc_mmcs_log_max(commit_sizes[c], log_h + m0);
+            size_t wsum = 0;
+            for (int m = m0; m < m0 + commit_sizes[c]; m++) wsum += (size_t)width[m];
+            /* one MMCS opening per commitment at reduced_index (pcs/mod.rs:7553-7566) */
+            if (orc_mmcs_verify(commit_sizes[c], log_h + m0, width + m0, roots + 4 * c, query >> (H - hc), in, in + wsum, params)) rc = 4;
+            /* reduce the opened values per height with the batch coefficients (pcs/mod.rs:7567-7612) */
+            for (int m = m0; m < m0 + commit_sizes[c]; m++) {
+                const int hm = log_h[m];
+                if (!has[hm]) { reduced[hm] = e2_zero(); has[hm] = 1; }
+                for (int k = 0; k < width[m]; k++, ci++) {
+                    if (in[k] >= GL_P) rc = rc ? rc : 5;
+                    reduced[hm] = e2_add(reduced[hm], e2_scale(coeff[ci], in[k]));
+                }
+                in += width[m];
             }
-            uint64_t root[4];
-            path_root(st, idx, in + width[m], hm, params, root);
-            if (memcmp(root, roots + 4 * m, 32) != 0) rc = 4;
-            if (!has[hm]) { reduced[hm] = e2_zero(); has[hm] = 1; }
-            for (int c = 0; c < width[m]; c++, ci++) {
-                if (in[c] >= GL_P) rc = 5;
-                reduced[hm] = e2_add(reduced[hm], e2_scale(coeff[ci], in[c]));
-            }
-            in += width[m] + 4 * hm;
+            in += 4 * (size_t)hc;
         }
         size_t idx = query;
         ext2 folded = e2_zero();
@@ -440,6 +461,6 @@ int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint6
         /* a matrix may not have height rate_log (nv >= 1), so nothing joins after the last fold */
         if (!rc && !e2_eq(folded, total)) rc = 8; /* constant final codeword = sum of the message rows */
     }
-    free(coeff); free(chal); free(reduced); free(has);
+    free(coeff); free(chal); free(reduced); free(has); free(log_h);
     return rc;
 }

@@ -115,3 +115,132 @@ void orc_merkle_commit(const uint64_t* m, int log_rows, int width, const uint64_
         n /= 2;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Mixed-height Merkle commitment: ONE root for matrices of several power-of-two heights.  The reference commits all
+ * trace matrices of a `commit_traces` call under one `PCS::Commitment` (ceno_zkvm/src/scheme/cpu/mod.rs:559-584,
+ * PCS::batch_commit) and opens several `num_vars` under one commitment (ceno_recursion_v2/src/pcs/mod.rs:1123-1135,
+ * 7547-7565: reduced_index = query >> bits_reduced; :7783-7802 one opening proof per commitment).  The tree itself is
+ * p3-merkle-tree 0.4.3 (EXT) `MerkleTree::new` / `MerkleTreeMmcs::{open_batch, verify_batch}`, whose published
+ * algorithm this restates:
+ *   - matrices sorted by height, tallest first, STABLE (equal heights keep the caller's order);
+ *   - first digest layer: row i of ALL tallest matrices, concatenated in that order, through the padding-free sponge;
+ *   - each next layer has half the nodes: next[i] = compress(prev[2i], prev[2i+1]); when matrices of exactly that
+ *     height exist ("inject"): next[i] = compress( compress(prev[2i], prev[2i+1]), sponge(row i of those matrices) );
+ *   - opening at `index` (a row of the tallest height): matrix m shows row index >> (log_max - log_rows[m]); the proof
+ *     is the sibling at every layer, digest_layers[l][(index >> l) ^ 1], l = 0 .. log_max - 1;
+ *   - verify: sponge of the tallest rows, then per sibling compress in index order and, where shorter matrices join,
+ *     compress with the sponge of their opened rows.
+ * Heights here are powers of two (codewords), so p3's padding rules for odd layers never apply.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static void sponge_rows(int n_mats, const int* log_rows, const int* width, const uint64_t* const* col_major, const int* order,
+                        int log_h, size_t row, const uint64_t* params, uint64_t* digest4) {
+    uint64_t s[8] = {0};
+    int k = 0;
+    for (int oi = 0; oi < n_mats; oi++) {
+        int m = order[oi];
+        if (log_rows[m] != log_h) continue;
+        size_t rows = (size_t)1 << log_h;
+        for (int c = 0; c < width[m]; c++) {
+            s[k++] = col_major[m][(size_t)c * rows + row];
+            if (k == 4) { orc_poseidon2_permute(s, params); k = 0; }
+        }
+    }
+    if (k) orc_poseidon2_permute(s, params);
+    memcpy(digest4, s, 32);
+}
+static void mmcs_order(int n_mats, const int* log_rows, int* order) {
+    for (int i = 0; i < n_mats; i++) order[i] = i;
+    for (int i = 1; i < n_mats; i++) { /* stable insertion sort, tallest first */
+        int v = order[i], j = i;
+        while (j > 0 && log_rows[order[j - 1]] < log_rows[v]) { order[j] = order[j - 1]; j--; }
+        order[j] = v;
+    }
+}
+int orc_mmcs_log_max(int n_mats, const int* log_rows) {
+    int h = 0;
+    for (int m = 0; m < n_mats; m++) if (log_rows[m] > h) h = log_rows[m];
+    return h;
+}
+/* out_levels: layer 0 (2^log_max digests) ... root; 4 * (2^(log_max+1) - 1) words */
+void orc_mmcs_commit(int n_mats, const int* log_rows, const int* width, const uint64_t* const* col_major, const uint64_t* params,
+                     uint64_t* out_levels) {
+    int* order = malloc(sizeof(int) * (size_t)n_mats);
+    mmcs_order(n_mats, log_rows, order);
+    const int H = orc_mmcs_log_max(n_mats, log_rows);
+    size_t n = (size_t)1 << H;
+    for (size_t r = 0; r < n; r++) sponge_rows(n_mats, log_rows, width, col_major, order, H, r, params, out_levels + 4 * r);
+    uint64_t* child = out_levels;
+    for (int h = H - 1; h >= 0; h--) {
+        uint64_t* parent = child + 4 * n;
+        n /= 2;
+        int inject = 0;
+        for (int m = 0; m < n_mats; m++) if (log_rows[m] == h) inject = 1;
+        for (size_t i = 0; i < n; i++) {
+            uint64_t s[8];
+            memcpy(s, child + 8 * i, 64);
+            orc_poseidon2_permute(s, params);
+            if (inject) {
+                sponge_rows(n_mats, log_rows, width, col_major, order, h, i, params, s + 4);
+                orc_poseidon2_permute(s, params);
+            }
+            memcpy(parent + 4 * i, s, 32);
+        }
+        child = parent;
+    }
+    free(order);
+}
+/* rows_out: the opened row of every matrix in the CALLER's order (sum of widths words); path_out: 4 * log_max words */
+void orc_mmcs_open(int n_mats, const int* log_rows, const int* width, const uint64_t* const* col_major, const uint64_t* levels,
+                   size_t index, uint64_t* rows_out, uint64_t* path_out) {
+    const int H = orc_mmcs_log_max(n_mats, log_rows);
+    for (int m = 0; m < n_mats; m++) {
+        size_t rows = (size_t)1 << log_rows[m], r = index >> (H - log_rows[m]);
+        for (int c = 0; c < width[m]; c++) *rows_out++ = col_major[m][(size_t)c * rows + r];
+    }
+    const uint64_t* lv = levels;
+    size_t n = (size_t)1 << H, idx = index;
+    for (int l = 0; l < H; l++) {
+        memcpy(path_out + 4 * l, lv + 4 * (idx ^ 1), 32);
+        lv += 4 * n;
+        n /= 2;
+        idx >>= 1;
+    }
+}
+/* 0 when the opened rows and the path lead to `root4` */
+int orc_mmcs_verify(int n_mats, const int* log_rows, const int* width, const uint64_t* root4, size_t index, const uint64_t* rows,
+                    const uint64_t* path, const uint64_t* params) {
+    int* order = malloc(sizeof(int) * (size_t)n_mats);
+    mmcs_order(n_mats, log_rows, order);
+    const int H = orc_mmcs_log_max(n_mats, log_rows);
+    /* one-row "matrices" so that sponge_rows can be reused: column c of matrix m = rows[off_m + c] */
+    const uint64_t** one = malloc(sizeof(*one) * (size_t)n_mats);
+    int* zero_log = malloc(sizeof(int) * (size_t)n_mats);
+    {
+        size_t off = 0;
+        for (int m = 0; m < n_mats; m++) { one[m] = rows + off; off += (size_t)width[m]; zero_log[m] = 0; }
+    }
+    uint64_t cur[8];
+    {   /* sponge over the tallest rows: select them by giving every other matrix a non-matching height */
+        for (int m = 0; m < n_mats; m++) zero_log[m] = (log_rows[m] == H) ? 0 : -1;
+        sponge_rows(n_mats, zero_log, width, one, order, 0, 0, params, cur);
+    }
+    size_t idx = index;
+    for (int l = 0; l < H; l++) {
+        uint64_t s[8];
+        if (idx & 1) { memcpy(s, path + 4 * l, 32); memcpy(s + 4, cur, 32); }
+        else { memcpy(s, cur, 32); memcpy(s + 4, path + 4 * l, 32); }
+        orc_poseidon2_permute(s, params);
+        idx >>= 1;
+        const int h = H - 1 - l;
+        int inject = 0;
+        for (int m = 0; m < n_mats; m++) { zero_log[m] = (log_rows[m] == h) ? 0 : -1; inject |= (log_rows[m] == h); }
+        if (inject) {
+            sponge_rows(n_mats, zero_log, width, one, order, 0, 0, params, s + 4);
+            orc_poseidon2_permute(s, params);
+        }
+        memcpy(cur, s, 32);
+    }
+    free(order); free(one); free(zero_log);
+    return memcmp(cur, root4, 32) != 0;
+}

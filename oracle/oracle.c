@@ -42,11 +42,27 @@ void orc_stub_sample_ext(orc_stub_state* st, uint64_t* out2) {
     st->s = mix64(st->s); out2[0] = gl_reduce(st->s);
     st->s = mix64(st->s); out2[1] = gl_reduce(st->s);
 }
+void orc_stub_append_base(orc_stub_state* st, uint64_t v) {
+    stub_absorb(st, 0x4241534500000000ULL); /* "BASE" */
+    stub_absorb(st, v);
+}
+uint64_t orc_stub_sample_base(orc_stub_state* st) {
+    st->s = mix64(st->s);
+    return gl_reduce(st->s);
+}
 static void stub_al(void* s, const uint8_t* b, size_t n) { orc_stub_append_label((orc_stub_state*)s, b, n); }
 static void stub_ae(void* s, const uint64_t* e) { orc_stub_append_ext((orc_stub_state*)s, e); }
 static void stub_se(void* s, uint64_t* o) { orc_stub_sample_ext((orc_stub_state*)s, o); }
+static void stub_ab(void* s, uint64_t v) { orc_stub_append_base((orc_stub_state*)s, v); }
+static uint64_t stub_sb(void* s) { return orc_stub_sample_base((orc_stub_state*)s); }
+static void* stub_fork(void* s) {
+    orc_stub_state* c = malloc(sizeof(*c));
+    *c = *(orc_stub_state*)s;
+    return c;
+}
 void orc_stub_bind(orc_transcript* t, orc_stub_state* st) {
     t->append_label = stub_al; t->append_ext = stub_ae; t->sample_ext = stub_se; t->self = st;
+    t->append_base = stub_ab; t->sample_base = stub_sb; t->fork = stub_fork; t->fork_free = free;
 }
 
 static void tr_label(orc_transcript* t, const char* s) { t->append_label(t->self, (const uint8_t*)s, strlen(s)); }

@@ -31,7 +31,24 @@ typedef struct orc_transcript {
     void (*append_ext)(void* self, const uint64_t* e2);
     void (*sample_ext)(void* self, uint64_t* out2);
     void* self;
+    void (*reserved)(void* self);     /* keeps the table layout-compatible with the host library's ceno_transcript (its `destroy`), so that
+                                       * tests can drive the oracle's verifiers with the product's transcript objects */
+    /* base-field side of the challenger, needed by the PCS (p3-challenger 0.4.3 `CanObserve<F>` / `CanSample<F>` /
+     * `CanSampleBits` / `GrindingChallenger`; in-tree use: ceno_recursion_v2/src/pcs/mod.rs:8125-8204).  NULL in
+     * transcripts that only serve sumchecks (the PCS entry points then fail). */
+    void (*append_base)(void* self, uint64_t v);
+    uint64_t (*sample_base)(void* self);
+    void* (*fork)(void* self);        /* heap copy of the challenger state (`self.clone()`) */
+    void (*fork_free)(void* forked);
 } orc_transcript;
+
+/* sample_bits (p3-challenger DuplexChallenger::sample_bits; pcs/mod.rs:8164-8204): the low `bits` bits of ONE base sample */
+uint64_t orc_tr_sample_bits(orc_transcript* t, int bits);
+/* check_witness (pcs/mod.rs:8125-8155): observe the witness, then sample_bits(bits) == 0.  Advances the transcript. */
+int orc_tr_check_witness(orc_transcript* t, int bits, uint64_t witness);
+/* grind (p3-challenger `GrindingChallenger::grind`): a witness that check_witness accepts on a CLONE of the challenger, then
+ * check_witness on the challenger itself.  p3 takes any such witness (`find_any`); this restatement takes the least. */
+uint64_t orc_tr_grind(orc_transcript* t, int bits);
 
 /* deterministic, data-dependent stand-in for BasicTranscript (NOT Poseidon2) */
 typedef struct orc_stub_state { uint64_t s; } orc_stub_state;
@@ -39,7 +56,24 @@ void orc_stub_init(orc_stub_state* st, uint64_t seed);
 void orc_stub_bind(orc_transcript* t, orc_stub_state* st);
 void orc_stub_append_label(orc_stub_state* st, const uint8_t* bytes, size_t n);
 void orc_stub_append_ext(orc_stub_state* st, const uint64_t* e2);
+void orc_stub_append_base(orc_stub_state* st, uint64_t v);
 void orc_stub_sample_ext(orc_stub_state* st, uint64_t* out2);
+uint64_t orc_stub_sample_base(orc_stub_state* st);
+
+/* Poseidon2 duplex challenger over Goldilocks, width 8 / rate 4 (transcript.c): the shape of p3-challenger 0.4.3
+ * `DuplexChallenger<F, Perm, 8, 4>` that the reference's EXT `transcript::BasicTranscript` wraps.  PARITY UNPINNED
+ * (round constants, label packing): SURVEY.md section 8c(i). */
+typedef struct orc_duplex_state {
+    uint64_t state[8];
+    uint64_t in[4];
+    int n_in;
+    int n_out;             /* the output buffer is state[0 .. n_out) (samples pop from the back) */
+    uint64_t params[138];
+} orc_duplex_state;
+void orc_duplex_init(orc_duplex_state* st, const uint64_t* params138, const uint8_t* label, size_t n);
+void orc_duplex_bind(orc_transcript* t, orc_duplex_state* st);
+void orc_duplex_observe(orc_duplex_state* st, uint64_t v);
+uint64_t orc_duplex_sample(orc_duplex_state* st);
 
 /* ---- field helpers exported for Python cross-checks ---- */
 uint64_t orc_gl_mul(uint64_t a, uint64_t b);
@@ -165,20 +199,33 @@ void orc_poseidon2_default_params(uint64_t* params138);
 void orc_merkle_commit(const uint64_t* col_major, int log_rows, int width, const uint64_t* params138, uint64_t* out_levels);
 
 
-/* ---- Basefold batch open + verifier (a15) — PARITY UNPINNED, see basefold.c ----
+/* mixed-height Merkle commitment (p3 MerkleTreeMmcs), commit.c */
+int orc_mmcs_log_max(int n_mats, const int* log_rows);
+void orc_mmcs_commit(int n_mats, const int* log_rows, const int* width, const uint64_t* const* col_major, const uint64_t* params138,
+                     uint64_t* out_levels /* 4 * (2^(log_max+1) - 1) */);
+void orc_mmcs_open(int n_mats, const int* log_rows, const int* width, const uint64_t* const* col_major, const uint64_t* levels,
+                   size_t index, uint64_t* rows_out /* sum of widths */, uint64_t* path_out /* 4 * log_max */);
+int orc_mmcs_verify(int n_mats, const int* log_rows, const int* width, const uint64_t* root4, size_t index, const uint64_t* rows,
+                    const uint64_t* path, const uint64_t* params138);
+
+/* ---- Basefold batch open + verifier (a15), see basefold.c ----
+ * `n_commits` commitments ("rounds" of PCS::batch_open: witness, fixed), commitment c holds commit_sizes[c] consecutive matrices
+ * of the flat arrays nv / width / traces / points / evals.
  * proof layout (words): [sumcheck msgs 4n][commit roots 4n][final message 2*n_mats][pow witness 1] then per query
- *   [index 1] per matrix [opened row width_m][path 4*(nv_m+rate_log)] per round r [sibling 2][path 4*(n+rate_log-r-1)] */
+ *   [index 1] per commitment [opened rows of its matrices: sum width_m][MMCS path 4*(max nv_m + rate_log)]
+ *   per round r [sibling 2][path 4*(n+rate_log-r-1)] */
 void orc_fft_bitrev(uint64_t* a, int log_n);
-size_t orc_basefold_query_words(int n_mats, const int* nv, const int* width, int rate_log);
-size_t orc_basefold_proof_words(int n_mats, const int* nv, const int* width, int rate_log, int n_queries);
-int orc_basefold_open(int n_mats, const int* nv, const int* width, const uint64_t* const* traces /* column-major base */,
-                      const uint64_t* const* points, const uint64_t* const* evals /* width ext per matrix */, int rate_log,
-                      int n_queries, int pow_bits, const uint64_t* params138, orc_transcript* tr, uint64_t* proof);
-void orc_basefold_commit_roots(int n_mats, const int* nv, const int* width, const uint64_t* const* traces, int rate_log,
-                               const uint64_t* params138, uint64_t* roots /* 4 per matrix */);
-int orc_basefold_verify(int n_mats, const int* nv, const int* width, const uint64_t* roots, const uint64_t* const* points,
-                        const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits, const uint64_t* params138,
-                        orc_transcript* tr, const uint64_t* proof);
+size_t orc_basefold_query_words(int n_commits, const int* commit_sizes, const int* nv, const int* width, int rate_log);
+size_t orc_basefold_proof_words(int n_commits, const int* commit_sizes, const int* nv, const int* width, int rate_log, int n_queries);
+int orc_basefold_open(int n_commits, const int* commit_sizes, const int* nv, const int* width,
+                      const uint64_t* const* traces /* column-major base */, const uint64_t* const* points,
+                      const uint64_t* const* evals /* width ext per matrix */, int rate_log, int n_queries, int pow_bits,
+                      const uint64_t* params138, orc_transcript* tr, uint64_t* proof);
+void orc_basefold_commit_roots(int n_commits, const int* commit_sizes, const int* nv, const int* width, const uint64_t* const* traces,
+                               int rate_log, const uint64_t* params138, uint64_t* roots /* 4 per commitment */);
+int orc_basefold_verify(int n_commits, const int* commit_sizes, const int* nv, const int* width, const uint64_t* roots,
+                        const uint64_t* const* points, const uint64_t* const* evals, int rate_log, int n_queries, int pow_bits,
+                        const uint64_t* params138, orc_transcript* tr, const uint64_t* proof);
 
 /* ---- witness assignment of the ADD / SUB chips (witgen.c; reference arith.rs:101-142 and the files cited there) ---- */
 size_t orc_step_record_bytes(void);

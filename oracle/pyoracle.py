@@ -87,7 +87,16 @@ class OrcTranscript(C.Structure):
         ("append_ext", C.c_void_p),
         ("sample_ext", C.c_void_p),
         ("self", C.c_void_p),
+        ("reserved", C.c_void_p),
+        ("append_base", C.c_void_p),
+        ("sample_base", C.c_void_p),
+        ("fork", C.c_void_p),
+        ("fork_free", C.c_void_p),
     ]
+
+
+class OrcDuplexState(C.Structure):
+    _fields_ = [("state", C.c_uint64 * 8), ("inp", C.c_uint64 * 4), ("n_in", C.c_int), ("n_out", C.c_int), ("params", C.c_uint64 * 138)]
 
 
 class OrcTowerSpec(C.Structure):
@@ -124,6 +133,13 @@ def lib():
         _lib.orc_tower_msgs_words.argtypes = [C.c_int]
         _lib.orc_two_adic_generator.restype = C.c_uint64
         _lib.orc_two_adic_generator.argtypes = [C.c_int]
+        _lib.orc_stub_sample_base.restype = C.c_uint64
+        _lib.orc_tr_sample_bits.restype = C.c_uint64
+        _lib.orc_tr_sample_bits.argtypes = [C.c_void_p, C.c_int]
+        _lib.orc_tr_check_witness.restype = C.c_int
+        _lib.orc_tr_check_witness.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        _lib.orc_tr_grind.restype = C.c_uint64
+        _lib.orc_tr_grind.argtypes = [C.c_void_p, C.c_int]
     return _lib
 
 
@@ -184,6 +200,72 @@ class StubTranscript:
         o = np.zeros(2, dtype=np.uint64)
         lib().orc_stub_sample_ext(C.byref(self.state), _p(o))
         return int(o[0]), int(o[1])
+
+    def append_base(self, v: int):
+        lib().orc_stub_append_base(C.byref(self.state), C.c_uint64(v))
+
+    def sample_base(self) -> int:
+        return int(lib().orc_stub_sample_base(C.byref(self.state)))
+
+    def sample_bits(self, bits: int) -> int:
+        return int(lib().orc_tr_sample_bits(self.ptr(), bits))
+
+    def check_witness(self, bits: int, w: int) -> bool:
+        return bool(lib().orc_tr_check_witness(self.ptr(), bits, C.c_uint64(w)))
+
+    def grind(self, bits: int) -> int:
+        return int(lib().orc_tr_grind(self.ptr(), bits))
+
+
+class DuplexTranscript(StubTranscript):
+    """the oracle's own Poseidon2 duplex challenger (oracle/transcript.c): p3 DuplexChallenger<_, _, 8, 4> rules"""
+
+    def __init__(self, label: bytes = b"", params=None):
+        self.params = poseidon2_default_params() if params is None else np.ascontiguousarray(params, dtype=np.uint64)
+        self.state = OrcDuplexState()
+        buf = (C.c_uint8 * max(1, len(label))).from_buffer_copy(label or b"\0")
+        lib().orc_duplex_init(C.byref(self.state), _p(self.params), buf, C.c_size_t(len(label)))
+        self.tr = OrcTranscript()
+        lib().orc_duplex_bind(C.byref(self.tr), C.byref(self.state))
+
+    def _call(self, name, *args):
+        f = C.cast(getattr(self.tr, name), {
+            "append_label": C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t),
+            "append_ext": C.CFUNCTYPE(None, C.c_void_p, u64p),
+            "sample_ext": C.CFUNCTYPE(None, C.c_void_p, u64p),
+            "append_base": C.CFUNCTYPE(None, C.c_void_p, C.c_uint64),
+            "sample_base": C.CFUNCTYPE(C.c_uint64, C.c_void_p),
+        }[name])
+        return f(self.tr.self, *args)
+
+    def append_label(self, b: bytes):
+        buf = (C.c_uint8 * max(1, len(b))).from_buffer_copy(b or b"\0")
+        self._call("append_label", buf, len(b))
+
+    def append_ext(self, e):
+        a = ext([e]).reshape(2)
+        self._call("append_ext", _p(a))
+
+    def sample_ext(self) -> Tuple[int, int]:
+        o = np.zeros(2, dtype=np.uint64)
+        self._call("sample_ext", _p(o))
+        return int(o[0]), int(o[1])
+
+    def append_base(self, v: int):
+        self._call("append_base", C.c_uint64(v))
+
+    def sample_base(self) -> int:
+        return int(self._call("sample_base"))
+
+    def export_state(self) -> np.ndarray:
+        """[state 8][n_in][in 4][n_out][0, 0]: the layout of the host library's ceno_transcript export"""
+        o = np.zeros(16, dtype=np.uint64)
+        o[:8] = np.frombuffer(bytes(self.state.state), dtype=np.uint64)
+        o[8] = self.state.n_in
+        o[9:13] = np.frombuffer(bytes(self.state.inp), dtype=np.uint64)
+        o[9 + self.state.n_in:13] = 0
+        o[13] = self.state.n_out
+        return o
 
 
 class ReplayTranscript:
@@ -527,59 +609,108 @@ def fft_bitrev(col: np.ndarray) -> np.ndarray:
     return a
 
 
-def _bf_args(traces, points, evals):
-    """traces: list of (rows, width) row-major base matrices -> column-major buffers + C pointer arrays"""
-    n = len(traces)
-    nv = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
-    width = (C.c_int * n)(*[int(t.shape[1]) for t in traces])
+def _bf_shapes(shapes, commit_sizes):
+    n = len(shapes)
+    sizes = [n] if commit_sizes is None else [int(x) for x in commit_sizes]
+    assert sum(sizes) == n and all(x > 0 for x in sizes)
+    return n, (C.c_int * len(sizes))(*sizes), (C.c_int * n)(*[int(s[0]) for s in shapes]), (C.c_int * n)(*[int(s[1]) for s in shapes]), len(sizes)
+
+
+def _pp(xs):
+    PP = C.POINTER(C.c_uint64)
+    return (PP * len(xs))(*[x.ctypes.data_as(PP) for x in xs])
+
+
+def _bf_args(traces, points, evals, commit_sizes=None):
+    """traces: list of (rows, width) row-major base matrices -> column-major buffers + C pointer arrays.  commit_sizes: how many
+    consecutive matrices each commitment holds (default: all of them in ONE commitment, as commit_traces does)"""
+    shapes = [(int(t.shape[0]).bit_length() - 1, int(t.shape[1])) for t in traces]
+    n, sizes, nv, width, nc = _bf_shapes(shapes, commit_sizes)
     cols = [np.ascontiguousarray(np.asarray(t, dtype=np.uint64).T) for t in traces]
     pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
     evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
-    PP = C.POINTER(C.c_uint64)
-    arr = lambda xs: (PP * n)(*[x.ctypes.data_as(PP) for x in xs])
-    return n, nv, width, arr(cols), arr(pts), arr(evs), (cols, pts, evs)
+    return nc, sizes, nv, width, _pp(cols), _pp(pts), _pp(evs), (cols, pts, evs)
 
 
-def basefold_proof_words(traces, rate_log: int, n_queries: int) -> int:
-    n = len(traces)
-    nv = (C.c_int * n)(*[int(t.shape[0]).bit_length() - 1 for t in traces])
-    width = (C.c_int * n)(*[int(t.shape[1]) for t in traces])
+def basefold_proof_words(traces, rate_log: int, n_queries: int, commit_sizes=None) -> int:
+    shapes = [(int(t.shape[0]).bit_length() - 1, int(t.shape[1])) for t in traces]
+    n, sizes, nv, width, nc = _bf_shapes(shapes, commit_sizes)
     f = lib().orc_basefold_proof_words
     f.restype = C.c_size_t
-    return int(f(n, nv, width, rate_log, n_queries))
+    return int(f(nc, sizes, nv, width, rate_log, n_queries))
 
 
-def basefold_open(traces, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, params=None) -> np.ndarray:
+def basefold_open(traces, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, params=None, commit_sizes=None) -> np.ndarray:
     params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
-    n, nv, width, tp, pp, ep, keep = _bf_args(traces, points, evals)
-    proof = np.zeros(basefold_proof_words(traces, rate_log, n_queries), dtype=np.uint64)
-    rc = lib().orc_basefold_open(n, nv, width, tp, pp, ep, rate_log, n_queries, pow_bits, _p(params), transcript.ptr(), _p(proof))
+    nc, sizes, nv, width, tp, pp, ep, keep = _bf_args(traces, points, evals, commit_sizes)
+    proof = np.zeros(basefold_proof_words(traces, rate_log, n_queries, commit_sizes), dtype=np.uint64)
+    rc = lib().orc_basefold_open(nc, sizes, nv, width, tp, pp, ep, rate_log, n_queries, pow_bits, _p(params), transcript.ptr(), _p(proof))
     assert rc == 0, f"orc_basefold_open rc={rc}"
     return proof
 
 
-def basefold_commit_roots(traces, rate_log: int, params=None) -> np.ndarray:
+def basefold_commit_roots(traces, rate_log: int, params=None, commit_sizes=None) -> np.ndarray:
+    """(n_commits, 4): ONE root per commitment"""
     params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
-    n, nv, width, tp, _, _, keep = _bf_args(traces, [np.zeros((1, 2))] * len(traces), [np.zeros((1, 2))] * len(traces))
-    roots = np.zeros((n, 4), dtype=np.uint64)
-    lib().orc_basefold_commit_roots(n, nv, width, tp, rate_log, _p(params), _p(roots))
+    nc, sizes, nv, width, tp, _, _, keep = _bf_args(traces, [np.zeros((1, 2))] * len(traces), [np.zeros((1, 2))] * len(traces), commit_sizes)
+    roots = np.zeros((nc, 4), dtype=np.uint64)
+    lib().orc_basefold_commit_roots(nc, sizes, nv, width, tp, rate_log, _p(params), _p(roots))
     return roots
 
 
-def basefold_verify(shapes, roots, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, proof, params=None) -> int:
+def basefold_verify(shapes, roots, points, evals, rate_log: int, n_queries: int, pow_bits: int, transcript, proof, params=None,
+                    commit_sizes=None) -> int:
     """shapes: list of (num_vars, width). returns 0 when accepted"""
     params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
-    n = len(shapes)
-    nv = (C.c_int * n)(*[s[0] for s in shapes])
-    width = (C.c_int * n)(*[s[1] for s in shapes])
+    n, sizes, nv, width, nc = _bf_shapes(shapes, commit_sizes)
     pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
     evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
-    PP = C.POINTER(C.c_uint64)
-    arr = lambda xs: (PP * n)(*[x.ctypes.data_as(PP) for x in xs])
-    r = np.ascontiguousarray(roots, dtype=np.uint64)
+    r = np.ascontiguousarray(roots, dtype=np.uint64).reshape(nc, 4)
     pr = np.ascontiguousarray(proof, dtype=np.uint64)
-    return int(lib().orc_basefold_verify(n, nv, width, _p(r), arr(pts), arr(evs), rate_log, n_queries, pow_bits, _p(params),
+    return int(lib().orc_basefold_verify(nc, sizes, nv, width, _p(r), _pp(pts), _pp(evs), rate_log, n_queries, pow_bits, _p(params),
                                          transcript.ptr(), _p(pr)))
+
+
+# ---- mixed-height Merkle commitment (p3 MerkleTreeMmcs) ------------------------------------------------------
+def mmcs_commit(mats_col_major: Sequence[np.ndarray], params=None) -> List[np.ndarray]:
+    """mats_col_major: (width, rows) arrays, rows a power of two.  returns the digest layers, tallest first; each (n, 4)"""
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    ms = [np.ascontiguousarray(m, dtype=np.uint64) for m in mats_col_major]
+    n = len(ms)
+    lr = (C.c_int * n)(*[int(m.shape[1]).bit_length() - 1 for m in ms])
+    w = (C.c_int * n)(*[int(m.shape[0]) for m in ms])
+    H = max(lr)
+    out = np.zeros(4 * ((2 << H) - 1), dtype=np.uint64)
+    lib().orc_mmcs_commit(n, lr, w, _pp(ms), _p(params), _p(out))
+    levels, off = [], 0
+    for l in range(H + 1):
+        k = 1 << (H - l)
+        levels.append(out[off: off + 4 * k].reshape(k, 4))
+        off += 4 * k
+    return levels
+
+
+def mmcs_open(mats_col_major, levels, index: int):
+    ms = [np.ascontiguousarray(m, dtype=np.uint64) for m in mats_col_major]
+    n = len(ms)
+    lr = (C.c_int * n)(*[int(m.shape[1]).bit_length() - 1 for m in ms])
+    w = (C.c_int * n)(*[int(m.shape[0]) for m in ms])
+    H = max(lr)
+    flat = np.ascontiguousarray(np.concatenate([l.reshape(-1) for l in levels]))
+    rows = np.zeros(sum(int(m.shape[0]) for m in ms), dtype=np.uint64)
+    path = np.zeros((H, 4), dtype=np.uint64)
+    lib().orc_mmcs_open(n, lr, w, _pp(ms), _p(flat), C.c_size_t(index), _p(rows), _p(path))
+    return rows, path
+
+
+def mmcs_verify(shapes, root, index: int, rows, path, params=None) -> int:
+    """shapes: list of (log_rows, width); 0 when accepted"""
+    params = poseidon2_default_params() if params is None else np.ascontiguousarray(params)
+    n = len(shapes)
+    lr = (C.c_int * n)(*[int(s[0]) for s in shapes])
+    w = (C.c_int * n)(*[int(s[1]) for s in shapes])
+    return int(lib().orc_mmcs_verify(n, lr, w, _p(np.ascontiguousarray(root, dtype=np.uint64)), C.c_size_t(index),
+                                     _p(np.ascontiguousarray(rows, dtype=np.uint64)), _p(np.ascontiguousarray(path, dtype=np.uint64)), _p(params)))
 
 
 # ---- rotation (a11) -------------------------------------------------------------------------
