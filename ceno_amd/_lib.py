@@ -130,7 +130,10 @@ def lib():
         "ceno_hip_basefold_fold": (i, [vp, vp, i, u64p, vp, vp, vp]),
         "ceno_hip_gather": (i, [vp, vp, sz, i, i, vp, sz, i, i, vp, vp]),
         "ceno_hip_merkle_open_batch": (i, [vp, vp, vp, sz, i, vp, vp]),
-        "ceno_hip_pow_grind": (i, [vp, u64p, i, u64p, vp]),
+        "ceno_hip_pow_grind_duplex": (i, [vp, u64p, i, u64p, vp]),
+        "ceno_hip_mmcs_commit": (i, [vp, C.POINTER(vp), C.POINTER(i), C.POINTER(i), i, vp, vpp]),
+        "ceno_hip_mmcs_opening_words": (sz, [vp]),
+        "ceno_hip_mmcs_open_batch": (i, [vp, vp, vp, sz, i, vp, sz, vp]),
         "ceno_hip_prof_reset": (i, [vp]),
         "ceno_hip_prof_enable": (i, [vp, i]),
         "ceno_hip_prof_get": (i, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

@@ -195,19 +195,36 @@ struct LevelPtrs {
     const uint64_t* p[63];  // by value in the kernel arguments: no pointer table to upload per tree
 };
 __global__ void __launch_bounds__(NT) k_gather_paths(LevelPtrs lv, int depth, const uint64_t* __restrict__ idx, size_t n_q, int shift,
-                                                     uint64_t* __restrict__ out) {
+                                                     uint64_t* __restrict__ out, size_t out_stride) {
     const size_t total = n_q * (size_t)depth * 4;
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
         const size_t q = t / ((size_t)depth * 4), rem = t % ((size_t)depth * 4);
         const int l = (int)(rem / 4), k = (int)(rem % 4);
         const size_t node = ((idx[q] >> shift) >> l) ^ 1;
-        out[t] = lv.p[l][4 * node + k];
+        out[q * out_stride + rem] = lv.p[l][4 * node + k];
     }
 }
+int merkle_gather_paths(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
+                        size_t out_stride_words, hipStream_t st) {
+    CHECK_ARG(ctx, t->log_rows <= 62, "tree too tall");
+    LevelPtrs lv{};
+    for (int l = 0; l < t->log_rows; l++) lv.p[l] = t->levels[l];
+    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, lv, t->log_rows, dev_indices, n, shift, dev_out,
+                       out_stride_words);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
 
-// ---- proof of work: least w >= base with permute(seed0, seed1, w, 0...)[0] = 0 mod 2^bits ----
-__global__ void __launch_bounds__(NT) k_pow_grind(uint64_t seed0, uint64_t seed1, uint64_t base, uint64_t count, uint64_t mask,
+// ---- proof of work (p3-challenger GrindingChallenger::grind / check_witness, ceno_recursion_v2/src/pcs/mod.rs:8125-8155):
+// a clone of the duplex challenger observes the candidate and samples ONE base element; the candidate is a witness when the
+// low `bits` bits of that sample are zero.  Whatever the number of pending inputs (< RATE) this is exactly one permutation:
+// the pending inputs and then the candidate overwrite state[0 .. pos], permute, and the sample is the BACK of the fresh
+// output buffer = state[RATE - 1].  The state arrives with the pending inputs already written; least witness >= base wins.
+struct DuplexState {
+    uint64_t s[8];
+};
+__global__ void __launch_bounds__(NT) k_pow_grind(DuplexState st0, int pos, uint64_t base, uint64_t count, uint64_t mask,
                                                   const p2::Params* __restrict__ pp, unsigned long long* __restrict__ best) {
     __shared__ p2::Params sp;
     for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
@@ -215,9 +232,11 @@ __global__ void __launch_bounds__(NT) k_pow_grind(uint64_t seed0, uint64_t seed1
     const size_t stride = (size_t)gridDim.x * NT;
     for (uint64_t t = (uint64_t)blockIdx.x * NT + threadIdx.x; t < count; t += stride) {
         const uint64_t w = base + t;
-        uint64_t s[8] = {seed0, seed1, w, 0, 0, 0, 0, 0};
+        uint64_t s[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = (k == pos) ? w : st0.s[k];
         p2::permute(s, sp);
-        if ((s[0] & mask) == 0) atomicMin(best, (unsigned long long)w);
+        if ((s[p2::RATE - 1] & mask) == 0) atomicMin(best, (unsigned long long)w);
     }
 }
 
@@ -318,17 +337,18 @@ int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint
                                ceno_hip_stream s) {
     CHECK_ARG(ctx, t && dev_indices && dev_out && shift >= 0 && shift < 64, "bad merkle_open_batch arguments");
     if (n == 0 || t->log_rows == 0) return 0;
-    CHECK_ARG(ctx, t->log_rows <= 62, "tree too tall");
     hipStream_t st = ctx_stream(ctx, s);
-    LevelPtrs lv{};
-    for (int l = 0; l < t->log_rows; l++) lv.p[l] = t->levels[l];
-    hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, lv, t->log_rows, dev_indices, n, shift, dev_out);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
+    return merkle_gather_paths(ctx, t, dev_indices, n, shift, dev_out, 4 * (size_t)t->log_rows, st);
 }
 
-int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint64_t* out_witness, ceno_hip_stream s) {
-    CHECK_ARG(ctx, seed2 && out_witness && bits >= 0 && bits <= 40, "bad pow_grind arguments");
+int ceno_hip_pow_grind_duplex(ceno_hip_ctx* ctx, const uint64_t* state16, int bits, uint64_t* out_witness, ceno_hip_stream s) {
+    CHECK_ARG(ctx, state16 && out_witness && bits >= 0 && bits <= 40, "bad pow_grind arguments");
+    const int pos = (int)state16[8];
+    CHECK_ARG(ctx, state16[8] < (uint64_t)p2::RATE && state16[13] <= (uint64_t)p2::RATE, "bad duplex state (pending inputs %llu, outputs %llu)",
+              (unsigned long long)state16[8], (unsigned long long)state16[13]);
+    DuplexState st0;
+    for (int k = 0; k < 8; k++) st0.s[k] = (k < pos) ? state16[9 + k] : state16[k];  // pending inputs overwrite the front of the state
+    for (int k = 0; k < 8; k++) CHECK_ARG(ctx, st0.s[k] < gl::P, "duplex state word %d is not canonical", k);
     if (bits == 0) {
         *out_witness = 0;
         return 0;
@@ -346,7 +366,7 @@ int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint6
         unsigned long long best = ~0ull;
         hipError_t e = hipMemcpyAsync(d, &best, 8, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_pow_grind, dim3(grid_for(window, NT, MAXB)), dim3(NT), 0, st, seed2[0], seed2[1], base, window, mask, pp,
+            hipLaunchKernelGGL(k_pow_grind, dim3(grid_for(window, NT, MAXB)), dim3(NT), 0, st, st0, pos, base, window, mask, pp,
                                (unsigned long long*)d);
             e = hipGetLastError();
         }

@@ -13,9 +13,32 @@ struct ceno_hip_merkle {
     uint64_t* h_root = nullptr;      // pinned host copy of the root, written by the kernel that computes it (no D2H blit)
     uint64_t* d_root_view = nullptr; // device view of h_root
     bool root_on_host = false;       // the tree-top kernel has been told to write h_root
+    // mixed-height commitment (ceno_hip_mmcs_commit): the matrices in the CALLER's order (borrowed) and their device table
+    struct Mat {
+        const uint64_t* p;
+        int log_rows, width;
+    };
+    std::vector<Mat> mats;
+    size_t total_width = 0;
+    void* d_table = nullptr;         // MmcsMat[n] in device memory (row gathers of the openings)
+    void* h_table = nullptr;         // its pinned source
+    size_t mat_table_off = 0;        // byte offset of the MmcsMat[n] table inside d_table
+};
+
+// device-side description of one committed matrix (openings) / of one input segment of the leaf hashing
+struct MmcsMat {
+    const uint64_t* p;   // column-major, column stride = 2^log_rows
+    uint32_t log_rows, width;
+    uint32_t out_off;    // word offset of this matrix's row inside one opening
+    uint32_t pad;
 };
 
 int get_params(ceno_hip_ctx* ctx, const p2::Params** out);
 int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out);
-int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st);  // levels 1.. from the leaf digests in levels[0]
+// levels 1.. from the leaf digests in levels[0]; inject[l] (may be NULL / absent) = digests of the rows of the matrices whose
+// height equals level l's node count: parent = compress(compress(left, right), inject[l][i])  (p3 MerkleTreeMmcs)
+int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, const uint64_t* const* inject = nullptr);
 void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
+// authentication paths of leaves (idx[q] >> shift): out[q * out_stride + 4 * level + k] (basefold.hip)
+int merkle_gather_paths(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
+                        size_t out_stride_words, hipStream_t st);

@@ -10,6 +10,8 @@
 // major so the lanes of a wave read consecutive rows of a column: 8 B per lane coalesced.  The kernel
 // is ALU bound (118 S-boxes x 4 mults + linear layers per permutation); reported separately from the
 // HBM roofline.
+#include <algorithm>
+
 #include "common.hpp"
 #include "poseidon2.hpp"
 
@@ -91,9 +93,9 @@ __global__ void __launch_bounds__(NT) k_leaf_hash(const uint64_t* __restrict__ m
     }
 }
 
-// parent[i] = perm(child[2i] || child[2i+1])[0..4)
+// parent[i] = perm(child[2i] || child[2i+1])[0..4); with `inj`: parent[i] = perm(that || inj[i])[0..4) (matrices of this height join)
 __global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ child, size_t n_parent, uint64_t* __restrict__ parent,
-                                                 const p2::Params* __restrict__ pp) {
+                                                 const uint64_t* __restrict__ inj, const p2::Params* __restrict__ pp) {
     __shared__ p2::Params sp;
     for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
     __syncthreads();
@@ -104,14 +106,83 @@ __global__ void __launch_bounds__(NT) k_compress(const uint64_t* __restrict__ ch
         ulonglong2 a = c[0], b = c[1], d = c[2], e = c[3];
         s[0] = a.x; s[1] = a.y; s[2] = b.x; s[3] = b.y; s[4] = d.x; s[5] = d.y; s[6] = e.x; s[7] = e.y;
         p2::permute(s, sp);
+        if (inj) {  // uniform
+            const ulonglong2* q = reinterpret_cast<const ulonglong2*>(inj + 4 * i);
+            const ulonglong2 u = q[0], v = q[1];
+            s[4] = u.x; s[5] = u.y; s[6] = v.x; s[7] = v.y;
+            p2::permute(s, sp);
+        }
         *reinterpret_cast<ulonglong2*>(parent + 4 * i) = make_ulonglong2(s[0], s[1]);
         *reinterpret_cast<ulonglong2*>(parent + 4 * i + 2) = make_ulonglong2(s[2], s[3]);
+    }
+}
+
+// ---- mixed-height commitment: row digests of EVERY height class in one launch -------------------------------------------
+// A class = the matrices of one height, in commitment order; its row r is the concatenation of their rows r, hashed by the
+// overwrite-mode sponge (p3 `hash_iter_slices` over the rows of the equal-height matrices).  Workgroups [block0, block0 +
+// nblocks) belong to a class, so the many small classes of a shard's commitment run beside the tall ones instead of one
+// latency-bound launch each.  The tables are read through the scalar cache (wave-uniform).
+struct MmcsClass {
+    uint64_t* out;          // 2^log_rows digests: levels[0] for the tallest class, the inject buffer otherwise
+    uint32_t log_rows;
+    uint32_t seg0, nseg;    // segments [seg0, seg0 + nseg) of the segment table
+    uint32_t block0, nblocks;
+    uint32_t total_w;
+};
+template <bool CANON>
+__global__ void __launch_bounds__(NT) k_leaf_hash_classes(const MmcsClass* __restrict__ cls, int n_cls, const MmcsMat* __restrict__ segs,
+                                                          const p2::Params* __restrict__ pp) {
+    __shared__ p2::Params sp;
+    for (int i = threadIdx.x; i < (int)(sizeof(p2::Params) / 8); i += NT) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(pp)[i];
+    __syncthreads();
+    int ci = 0;
+    while (ci + 1 < n_cls && blockIdx.x >= cls[ci + 1].block0) ci++;
+    const MmcsClass c = cls[ci];
+    const size_t rows = (size_t)1 << c.log_rows, stride = (size_t)c.nblocks * NT;
+    for (size_t r = (size_t)(blockIdx.x - c.block0) * NT + threadIdx.x; r < rows; r += stride) {
+        uint64_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t seg = c.seg0, col = 0;
+        const uint64_t* base = segs[seg].p;
+        uint32_t w = segs[seg].width;
+        for (uint32_t done = 0; done < c.total_w; done += p2::RATE) {
+#pragma unroll
+            for (int k = 0; k < p2::RATE; k++)
+                if (done + k < c.total_w) {  // overwrite mode; a short last chunk keeps the old tail
+                    s[k] = base[(size_t)col * rows + r];
+                    if (++col == w && done + k + 1 < c.total_w) {
+                        seg++;
+                        col = 0;
+                        base = segs[seg].p;
+                        w = segs[seg].width;
+                    }
+                }
+            if (CANON) p2::permute_canonical(s, sp);
+            else p2::permute(s, sp);
+        }
+        *reinterpret_cast<ulonglong2*>(c.out + 4 * r) = make_ulonglong2(s[0], s[1]);
+        *reinterpret_cast<ulonglong2*>(c.out + 4 * r + 2) = make_ulonglong2(s[2], s[3]);
+    }
+}
+
+// openings of a mixed-height commitment: out[q] = [row (idx_q >> (H - log_rows_m)) of every matrix m, caller's order][path]
+__global__ void __launch_bounds__(NT) k_mmcs_gather_rows(const MmcsMat* __restrict__ mats, int n_mats, int log_max, const uint64_t* __restrict__ idx,
+                                                         size_t n_q, int shift, size_t q_stride, uint64_t* __restrict__ out) {
+    // one workgroup column per matrix (blockIdx.y), lanes over (query, column)
+    const MmcsMat m = mats[blockIdx.y];
+    const size_t total = n_q * m.width, rows = (size_t)1 << m.log_rows;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
+        const size_t q = t / m.width, c = t % m.width;
+        const size_t r = (idx[q] >> shift) >> (log_max - (int)m.log_rows);
+        out[q * q_stride + m.out_off + c] = m.p[c * rows + r];
     }
 }
 
 void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
     if (t->h_root) ctx_pinned_free(ctx, t->h_root);
+    if (t->h_table) ctx_pinned_free(ctx, t->h_table);
+    if (t->d_table) ctx_free(ctx, t->d_table);
     for (auto* p : t->levels) ctx_free(ctx, p);
     delete t;
 }
@@ -146,6 +217,7 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
 static constexpr int TOP_NT = 256, TOP_LEVELS = 6;
 struct TopPtrs {
     uint64_t* p[TOP_LEVELS];  // by value in the kernel arguments: no host-to-device copy (a pageable one would block the host on the stream)
+    const uint64_t* inj[TOP_LEVELS];  // digests that join at that level (mixed-height commitment), or NULL
     uint64_t* root_host;      // != NULL in the launch that produces the root: it is also written to pinned host memory
 };
 __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restrict__ child, int levels, TopPtrs outs,
@@ -165,6 +237,11 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
         if (slot < np) {  // np <= 32 = one pass; a wave is entirely inside or outside (8 nodes per wave)
             uint64_t x = buf[cur][8 * slot + g];
             x = p2::permute_lanes8(x, sp);
+            if (outs.inj[l]) {  // uniform: lanes 0..3 keep the compressed pair, lanes 4..7 take the joining digest
+                const size_t node = (b << (levels - 1 - l)) + slot;
+                if (g >= 4) x = outs.inj[l][4 * node + (g - 4)];
+                x = p2::permute_lanes8(x, sp);
+            }
             if (g < 4) {
                 buf[cur ^ 1][4 * slot + g] = x;
                 outs.p[l][4 * ((b << (levels - 1 - l)) + slot) + g] = x;
@@ -177,7 +254,7 @@ __global__ void __launch_bounds__(TOP_NT) k_compress_top(const uint64_t* __restr
     }
 }
 
-int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
+int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, const uint64_t* const* inject) {
     const p2::Params* pp;
     TRY(get_params(ctx, &pp));
     const int log_rows = t->log_rows;
@@ -185,7 +262,8 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     // levels with more than 2^14 nodes: one lane per node (throughput bound)
     for (; l <= log_rows && ((size_t)1 << (log_rows - l)) > ((size_t)1 << 14); l++) {
         size_t np = (size_t)1 << (log_rows - l);
-        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l], pp);
+        hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l],
+                           inject ? inject[l] : (const uint64_t*)nullptr, pp);
     }
     // the rest is a chain of dependent permutations (one per level): 8 lanes per permutation, and every launch takes up to
     // TOP_LEVELS levels at once — each workgroup reduces its own 2^TOP_LEVELS-digest subtree in LDS — so 15 small levels
@@ -194,7 +272,10 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st) {
     while (rem > 0) {
         const int lv = rem > TOP_LEVELS ? TOP_LEVELS : rem;
         TopPtrs tp{};
-        for (int i = 0; i < lv; i++) tp.p[i] = t->levels[l + i];
+        for (int i = 0; i < lv; i++) {
+            tp.p[i] = t->levels[l + i];
+            tp.inj[i] = inject ? inject[l + i] : nullptr;
+        }
         if (rem == lv && t->d_root_view) {  // this launch ends at the root
             tp.root_host = t->d_root_view;
             t->root_on_host = true;
@@ -261,6 +342,121 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
         return rc;
     }
     *out = t;
+    return 0;
+}
+
+int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major, const int* log_rows, const int* widths, int n_mats,
+                         ceno_hip_stream s, ceno_hip_merkle** out) {
+    CHECK_ARG(ctx, dev_col_major && log_rows && widths && out && n_mats >= 1 && n_mats <= 65535, "bad mmcs_commit arguments");
+    int H = 0;
+    size_t total_w = 0;
+    for (int m = 0; m < n_mats; m++) {
+        CHECK_ARG(ctx, dev_col_major[m] && log_rows[m] >= 0 && log_rows[m] < 40 && widths[m] >= 1, "bad matrix %d", m);
+        H = std::max(H, log_rows[m]);
+        total_w += (size_t)widths[m];
+    }
+    const p2::Params* pp;
+    TRY(get_params(ctx, &pp));
+    hipStream_t st = ctx_stream(ctx, s);
+    ceno_hip_merkle* t = nullptr;
+    TRY(merkle_alloc(ctx, H, &t));
+    t->total_width = total_w;
+    for (int m = 0; m < n_mats; m++) t->mats.push_back({dev_col_major[m], log_rows[m], widths[m]});
+    // tallest first, STABLE: equal heights keep the caller's order (p3 MerkleTree::new sorts by Reverse(height))
+    std::vector<int> order(n_mats);
+    for (int i = 0; i < n_mats; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_rows[a] > log_rows[b]; });
+    // classes and their segments (adjacent matrices that are contiguous in memory merge into one segment)
+    std::vector<MmcsClass> cls;
+    std::vector<MmcsMat> segs;
+    std::vector<void*> inj_bufs;                        // released below (stream-ordered pool)
+    std::vector<const uint64_t*> inject(H + 1, nullptr);  // by LEVEL: level l has 2^(H - l) nodes
+    int rc = 0;
+    unsigned nblocks_total = 0;
+    for (int i = 0; i < n_mats && !rc;) {
+        const int h = log_rows[order[i]];
+        MmcsClass c{};
+        c.log_rows = (uint32_t)h;
+        c.seg0 = (uint32_t)segs.size();
+        if (h == H) c.out = t->levels[0];
+        else {
+            void* p = nullptr;
+            rc = ctx_alloc(ctx, ((size_t)1 << h) * 32, &p);
+            if (rc) break;
+            inj_bufs.push_back(p);
+            c.out = (uint64_t*)p;
+            inject[H - h] = (const uint64_t*)p;
+        }
+        for (; i < n_mats && log_rows[order[i]] == h; i++) {
+            const int m = order[i];
+            const size_t rows = (size_t)1 << h;
+            if (segs.size() > c.seg0 && segs.back().p + (size_t)segs.back().width * rows == dev_col_major[m]) segs.back().width += (uint32_t)widths[m];
+            else segs.push_back(MmcsMat{dev_col_major[m], (uint32_t)h, (uint32_t)widths[m], 0, 0});
+            c.total_w += (uint32_t)widths[m];
+        }
+        c.nseg = (uint32_t)segs.size() - c.seg0;
+        c.block0 = nblocks_total;
+        c.nblocks = grid_for((size_t)1 << h, NT, MAXB);
+        nblocks_total += c.nblocks;
+        cls.push_back(c);
+    }
+    // tables: [classes][segments][matrices in the caller's order (openings)] in one pinned block -> one async copy
+    const size_t b_cls = cls.size() * sizeof(MmcsClass), b_seg = segs.size() * sizeof(MmcsMat), b_mat = (size_t)n_mats * sizeof(MmcsMat);
+    const size_t off_seg = (b_cls + 15) & ~(size_t)15, off_mat = off_seg + b_seg, bytes = off_mat + b_mat;
+    void *h_tab = nullptr, *h_view = nullptr, *d_tab = nullptr;
+    if (!rc) rc = ctx_pinned_alloc(ctx, bytes, &h_tab, &h_view);
+    if (!rc) {
+        t->h_table = h_tab;
+        rc = ctx_alloc(ctx, bytes, &d_tab);
+    }
+    if (!rc) {
+        t->d_table = d_tab;
+        t->mat_table_off = off_mat;
+        memcpy(h_tab, cls.data(), b_cls);
+        memcpy((char*)h_tab + off_seg, segs.data(), b_seg);
+        auto* hm = reinterpret_cast<MmcsMat*>((char*)h_tab + off_mat);
+        uint32_t off = 0;
+        for (int m = 0; m < n_mats; m++) {
+            hm[m] = MmcsMat{dev_col_major[m], (uint32_t)log_rows[m], (uint32_t)widths[m], off, 0};
+            off += (uint32_t)widths[m];
+        }
+        if (hipMemcpyAsync(d_tab, h_tab, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = ctx_fail(ctx, CENO_HIP_ERR_HIP, "mmcs_commit: table upload failed");
+    }
+    if (!rc) {
+        const auto* d_cls = reinterpret_cast<const MmcsClass*>(d_tab);
+        const auto* d_seg = reinterpret_cast<const MmcsMat*>((char*)d_tab + off_seg);
+        static const bool canon = [] { const char* e = getenv("CENO_HIP_P2_CANONICAL"); return e && atoi(e) != 0; }();
+        if (canon) hipLaunchKernelGGL(k_leaf_hash_classes<true>, dim3(nblocks_total), dim3(NT), 0, st, d_cls, (int)cls.size(), d_seg, pp);
+        else hipLaunchKernelGGL(k_leaf_hash_classes<false>, dim3(nblocks_total), dim3(NT), 0, st, d_cls, (int)cls.size(), d_seg, pp);
+        rc = merkle_build_upper(ctx, t, st, inject.data());
+    }
+    for (void* p : inj_bufs) ctx_free(ctx, p);  // tagged with this stream: reused behind the kernels just queued
+    if (rc) {
+        merkle_release(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+size_t ceno_hip_mmcs_opening_words(const ceno_hip_merkle* t) { return t ? t->total_width + 4 * (size_t)t->log_rows : 0; }
+
+int ceno_hip_mmcs_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
+                             size_t out_stride_words, ceno_hip_stream s) {
+    CHECK_ARG(ctx, t && dev_indices && dev_out && shift >= 0 && shift < 64, "bad mmcs_open_batch arguments");
+    CHECK_ARG(ctx, t->d_table && !t->mats.empty(), "the tree is not a mixed-height commitment (ceno_hip_mmcs_commit)");
+    const size_t per_q = t->total_width + 4 * (size_t)t->log_rows;
+    CHECK_ARG(ctx, out_stride_words >= per_q, "output stride %zu is smaller than one opening (%zu words)", out_stride_words, per_q);
+    if (n == 0) return 0;
+    hipStream_t st = ctx_stream(ctx, s);
+    // the matrix table sits behind the class and segment tables of the commit
+    const MmcsMat* d_mats = reinterpret_cast<const MmcsMat*>((char*)t->d_table + t->mat_table_off);
+    size_t widest = 1;
+    for (auto& m : t->mats) widest = std::max(widest, (size_t)m.width);
+    hipLaunchKernelGGL(k_mmcs_gather_rows, dim3(grid_for(n * widest, NT, 64), (unsigned)t->mats.size()), dim3(NT), 0, st, d_mats, (int)t->mats.size(),
+                       t->log_rows, dev_indices, n, shift, out_stride_words, dev_out);
+    HIP_TRY(ctx, hipGetLastError());
+    if (t->log_rows > 0) TRY(merkle_gather_paths(ctx, t, dev_indices, n, shift, dev_out + t->total_width, out_stride_words, st));
     return 0;
 }
 

@@ -3,8 +3,10 @@
 //
 // The implementation the reference calls is in the EXT crate mpcs; the protocol is taken from the in-tree verifier
 // replay ceno_recursion_v2/src/pcs/mod.rs:1111-1316 (transcript script, initial/final claims), :7494-7720 (queries),
-// :7765-7781 (fold).  PARITY UNPINNED (include/ceno_prover.h); oracle/basefold.c is the CPU restatement of the same
-// script plus the verifier, and the parity tests compare complete proofs word for word.
+// :7765-7781 (fold), :8125-8204 (proof of work = check_witness, sample_bits), :1252-1266 (query indices), :7547-7565 (one input
+// opening per commitment at query >> bits_reduced).  PARITY UNPINNED (include/ceno_prover.h: constants, label packing);
+// oracle/basefold.c is the CPU restatement of the same script plus the verifier, and the parity tests compare complete proofs
+// word for word.
 //
 // Per opening group (one committed trace matrix with its point): F_m = sum_col coeff * column (ext table) and
 // E_m = eq(point_m, .).  The degree-2 sumcheck of sum_m 2^(n - nv_m) <E_m, F_m> runs over n = max nv rounds; a
@@ -43,16 +45,23 @@ E2 tr_sample(ceno_transcript* t) {
     return E2{o[0], o[1]};
 }
 
-size_t query_words(const ceno_pcs_data* d, int n) {
+int max_nv(ceno_pcs_data* const* commits, int n_commits) {
+    int n = 0;
+    for (int c = 0; c < n_commits; c++) n = std::max(n, commits[c]->max_log_rows());
+    return n;
+}
+size_t query_words(ceno_pcs_data* const* commits, int n_commits, int n) {
     size_t w = 1;
-    for (auto& M : d->mats) w += M.width + 4 * (size_t)(M.log_rows + d->log_blowup);
-    for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + d->log_blowup - r - 1);
+    const int rate_log = commits[0]->log_blowup;
+    for (int c = 0; c < n_commits; c++) w += ceno_hip_mmcs_opening_words(commits[c]->tree);
+    for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + rate_log - r - 1);
     return w;
 }
-int max_nv(const ceno_pcs_data* d) {
-    int n = 0;
-    for (auto& M : d->mats) n = std::max(n, M.log_rows);
-    return n;
+bool commits_ok(ceno_pcs_data* const* commits, int n_commits) {
+    if (!commits || n_commits < 1) return false;
+    for (int c = 0; c < n_commits; c++)
+        if (!commits[c] || !commits[c]->tree || commits[c]->mats.empty() || commits[c]->log_blowup != commits[0]->log_blowup) return false;
+    return true;
 }
 
 struct Group {  // matrices with the same number of variables share one sumcheck handle
@@ -120,22 +129,39 @@ void ceno_aux_streams_release(hipStream_t s[2], int device) { tree_streams_relea
 
 extern "C" {
 
-size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries) {
-    if (!d || n_queries < 0) return 0;
-    const int n = max_nv(d);
-    return 8 * (size_t)n + 2 * d->mats.size() + 1 + (size_t)n_queries * query_words(d, n);
+size_t ceno_prover_basefold_proof_words(ceno_pcs_data* const* commits, int n_commits, int n_queries) {
+    if (!commits_ok(commits, n_commits) || n_queries < 0) return 0;
+    const int n = max_nv(commits, n_commits);
+    size_t n_mats = 0;
+    for (int c = 0; c < n_commits; c++) n_mats += commits[c]->mats.size();
+    return 8 * (size_t)n + 2 * n_mats + 1 + (size_t)n_queries * query_words(commits, n_commits, n);
 }
 
-int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_t* const* points, const uint64_t* const* evals, int n_queries,
-                              int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
-    if (!ctx || !d || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 || pow_bits > 40 || d->mats.empty())
+int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points,
+                              const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s,
+                              uint64_t* out_proof) {
+    if (!ctx || !commits_ok(commits, n_commits) || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 || pow_bits > 40)
         return prover_set_error(CENO_HIP_ERR_INVALID, "bad basefold_open arguments");
     if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "basefold_open needs an explicit stream (ceno_hip_stream_create)");
+    if (!tr->sample_bits || !tr->append_base)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "basefold_open: the transcript lacks the base-field operations (append_base / sample_bits)");
     (void)ceno_hip_stream_bind(ctx, s);  // this thread drives three streams: say which one every allocation is for (pool tags)
     hipStream_t st = (hipStream_t)s;
-    const int n_mats = (int)d->mats.size(), rate_log = d->log_blowup, n = max_nv(d), H = n + rate_log;
+    const int rate_log = commits[0]->log_blowup, n = max_nv(commits, n_commits), H = n + rate_log;
+    // the matrices of all commitments in opening order (batch coefficients, final message)
+    struct Flat {
+        ceno_pcs_data* d;
+        int m;
+        size_t coeff0;  // index of its first batch coefficient
+    };
+    std::vector<Flat> flat;
     size_t total_cols = 0;
-    for (auto& M : d->mats) total_cols += M.width;
+    for (int c = 0; c < n_commits; c++)
+        for (int m = 0; m < (int)commits[c]->mats.size(); m++) {
+            flat.push_back({commits[c], m, total_cols});
+            total_cols += commits[c]->mats[m].width;
+        }
+    const int n_mats = (int)flat.size();
 
     // everything allocated here is released by `cleanup`
     std::vector<ceno_hip_mle*> owned;
@@ -194,19 +220,36 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     std::vector<ceno_hip_mle*> B(H + 1, nullptr), F(n_mats, nullptr), Eq(n_mats, nullptr);
     std::vector<E2> S(n_mats);
     {
-        size_t ci = 0;
-        for (int m = 0; m < n_mats; m++) {
-            auto& M = d->mats[m];
-            const int h = M.log_rows + rate_log;
-            int rc = 0, fresh = 0;
-            if (!B[h]) {
-                rc = alloc_ext(h, &B[h]);
-                fresh = 1;
+        // codewords: one pass per height CLASS of every commitment (its matrices are stored back to back, so the class is one
+        // wide column-major matrix); the class's coefficients are gathered from the flat order
+        size_t m0 = 0;
+        for (int c = 0; c < n_commits; c++) {
+            ceno_pcs_data* d = commits[c];
+            for (size_t k = 0; k < d->classes.size(); k++) {
+                auto& K = d->classes[k];
+                std::vector<uint64_t> cc(2 * K.width);
+                for (size_t m = 0; m < d->mats.size(); m++) {
+                    auto& M = d->mats[m];
+                    if (M.cls != (int)k) continue;
+                    memcpy(cc.data() + 2 * M.col0, coeff.data() + 2 * flat[m0 + m].coeff0, 16 * M.width);
+                }
+                const int h = K.log_rows + rate_log;
+                int rc = 0, fresh = 0;
+                if (!B[h]) {
+                    rc = alloc_ext(h, &B[h]);
+                    fresh = 1;
+                }
+                if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(K.codeword), (size_t)1 << h, (int)K.width, cc.data(),
+                                                     ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
+                if (rc) return fail(rc);
             }
-            if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(M.codeword), M.rows << rate_log, (int)M.width, coeff.data() + 2 * ci,
-                                                 ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
-            if (!rc) rc = alloc_ext(M.log_rows, &F[m]);
-            if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(M.trace), M.rows, (int)M.width, coeff.data() + 2 * ci,
+            m0 += d->mats.size();
+        }
+        for (int m = 0; m < n_mats; m++) {
+            auto& M = flat[m].d->mats[flat[m].m];
+            const size_t ci = flat[m].coeff0;
+            int rc = alloc_ext(M.log_rows, &F[m]);
+            if (!rc) rc = ceno_hip_batch_columns(ctx, flat[m].d->trace_ptr(flat[m].m), M.rows, (int)M.width, coeff.data() + 2 * ci,
                                                  ceno_hip_mle_device_ptr(F[m]), 0, s);
             if (!rc) {
                 rc = ceno_hip_eq_build(ctx, points[m], M.log_rows, nullptr, s, &Eq[m]);
@@ -214,15 +257,15 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
             }
             if (rc) return fail(rc);
             E2 acc = gl::e2_zero();
-            for (size_t c = 0; c < M.width; c++, ci++)
-                acc = acc + E2{coeff[2 * ci], coeff[2 * ci + 1]} * E2{evals[m][2 * c], evals[m][2 * c + 1]};
+            for (size_t c = 0; c < M.width; c++)
+                acc = acc + E2{coeff[2 * (ci + c)], coeff[2 * (ci + c) + 1]} * E2{evals[m][2 * c], evals[m][2 * c + 1]};
             S[m] = acc;
             groups[M.log_rows].mats.push_back(m);
         }
     }
     lap("batching");
     uint64_t* msgs = out_proof;
-    uint64_t* commits = out_proof + 4 * (size_t)n;
+    uint64_t* round_roots = out_proof + 4 * (size_t)n;
     uint64_t* finalm = out_proof + 8 * (size_t)n;
     uint64_t* powp = finalm + 2 * (size_t)n_mats;
     uint64_t* qbase = powp + 1;
@@ -316,10 +359,10 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         if (!rc && hipEventRecord(ev[(r + 1) & 1], (hipStream_t)fs) != hipSuccess) rc = CENO_HIP_ERR_HIP;
         if (!rc && r + 1 < n) rc = ceno_hip_basefold_commit_codeword(ctx, ceno_hip_mle_device_ptr(C[r + 1]), h - 1, fs, &trees[r + 1]);
         // the root of THIS round's tree (built one round ago on the other stream) is observed after the challenge
-        if (!rc) rc = ceno_hip_merkle_root(ctx, trees[r], commits + 4 * r, sx[r & 1]);
+        if (!rc) rc = ceno_hip_merkle_root(ctx, trees[r], round_roots + 4 * r, sx[r & 1]);
         if (rc) return fail(rc);
-        tr->append_ext(tr->self, commits + 4 * r);
-        tr->append_ext(tr->self, commits + 4 * r + 2);
+        tr->append_ext(tr->self, round_roots + 4 * r);
+        tr->append_ext(tr->self, round_roots + 4 * r + 2);
         if (dbg) {
             auto now = std::chrono::steady_clock::now();
             fprintf(stderr, "[ceno_prover] basefold_open round %2d (height %2d): %7.1f us since the previous round\n", r, h,
@@ -356,14 +399,14 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
             }
     }
     lap("final message");
-    // ---- proof of work ----
+    // ---- proof of work: p3 grinding — a witness that check_witness accepts (pcs/mod.rs:1248-1251, 8125-8155) ----
     *powp = 0;
     if (pow_bits > 0) {
-        const E2 seed = tr_sample(tr);
-        const uint64_t sw[2] = {seed.c0, seed.c1};
-        int rc = ceno_hip_pow_grind(ctx, sw, pow_bits, powp, s);
-        if (rc) return fail(rc);
-        tr_ext(tr, E2{*powp, 0});
+        int rc = ceno_prover_transcript_grind(ctx, tr, pow_bits, s, powp);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
     }
     lap("proof of work");
     // ---- queries ----
@@ -372,9 +415,9 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
         cleanup();
         return 0;
     }
-    const size_t qw = query_words(d, n), Q = (size_t)n_queries;
+    const size_t qw = query_words(commits, n_commits, n), Q = (size_t)n_queries;
     std::vector<uint64_t> qidx(Q);
-    for (size_t q = 0; q < Q; q++) qidx[q] = tr_sample(tr).c0 & (((uint64_t)1 << H) - 1);
+    for (size_t q = 0; q < Q; q++) qidx[q] = ceno_transcript_sample_bits(tr, H);  // ONE base sample per query (pcs/mod.rs:1252-1266)
     // device scratch: [indices Q][piece-major answers]; host buffer mirrors the answers
     const size_t ans_words = Q * (qw - 1);
     {   // scratch from the library's pool (a base-field table of enough words): hipMalloc / hipFree cost ~0.1 ms per open
@@ -396,15 +439,13 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_
     std::vector<Piece> pieces;
     size_t off = 0;
     int rc = 0;
-    for (int m = 0; m < n_mats && !rc; m++) {
-        auto& M = d->mats[m];
-        const int hm = M.log_rows + rate_log, shift = H - hm;
-        rc = ceno_hip_gather(ctx, ceno_hip_mle_device_ptr(M.codeword), M.rows << rate_log, (int)M.width, 1, d_idx, Q, shift, 0, d_ans + off, s);
-        pieces.push_back({off, M.width});
-        off += Q * M.width;
-        if (!rc) rc = ceno_hip_merkle_open_batch(ctx, M.tree, d_idx, Q, shift, d_ans + off, s);
-        pieces.push_back({off, 4 * (size_t)hm});
-        off += Q * 4 * (size_t)hm;
+    for (int c = 0; c < n_commits && !rc; c++) {  // one MMCS opening per commitment at reduced_index = query >> bits_reduced
+        ceno_pcs_data* d = commits[c];
+        const int hc = d->max_log_rows() + rate_log;
+        const size_t per_q = ceno_hip_mmcs_opening_words(d->tree);
+        rc = ceno_hip_mmcs_open_batch(ctx, d->tree, d_idx, Q, H - hc, d_ans + off, per_q, s);
+        pieces.push_back({off, per_q});
+        off += Q * per_q;
     }
     for (int r = 0; r < n && !rc; r++) {
         const int h = H - r;

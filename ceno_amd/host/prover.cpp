@@ -86,6 +86,56 @@ void ceno_transcript_free(ceno_transcript* t) {
     if (t->destroy) t->destroy(t->self);
     delete t;
 }
+// sample_bits: low bits of the canonical value of ONE base sample (ceno_recursion_v2/src/pcs/mod.rs:8164-8204)
+uint64_t ceno_transcript_sample_bits(ceno_transcript* t, int bits) { return t->sample_bits(t->self, bits); }
+// check_witness: observe(witness); sample_bits(bits) == 0 (pcs/mod.rs:8125-8155)
+int ceno_transcript_check_witness(ceno_transcript* t, int bits, uint64_t witness) {
+    ceno_transcript_append_base(t, witness);
+    return ceno_transcript_sample_bits(t, bits) == 0 ? 1 : 0;
+}
+ceno_transcript* ceno_transcript_clone(const ceno_transcript* t) {
+    if (!t || !t->fork || !t->fork_free) return nullptr;
+    auto* c = new ceno_transcript(*t);
+    c->self = t->fork(t->self);
+    c->destroy = t->fork_free;
+    if (!c->self) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+int ceno_transcript_export_state(ceno_transcript* t, uint64_t* out16) { return (t && t->export_state) ? t->export_state(t->self, out16) : 0; }
+int ceno_transcript_import_state(ceno_transcript* t, const uint64_t* in16) {
+    return (t && t->import_state) ? t->import_state(t->self, in16) : CENO_HIP_ERR_INVALID;
+}
+
+int ceno_prover_transcript_grind(ceno_hip_ctx* ctx, ceno_transcript* t, int bits, ceno_hip_stream s, uint64_t* out_witness) {
+    if (!t || !out_witness || bits < 0 || bits > 40) return fail(CENO_HIP_ERR_INVALID, "bad transcript_grind arguments");
+    if (!t->sample_bits || !t->append_base) return fail(CENO_HIP_ERR_INVALID, "transcript_grind: the transcript has no base-field operations (sample_bits / append_base)");
+    uint64_t st16[16];
+    uint64_t w = 0;
+    if (bits > 0 && ceno_transcript_export_state(t, st16) == CENO_TRANSCRIPT_DUPLEX8) {
+        if (!ctx) return fail(CENO_HIP_ERR_INVALID, "transcript_grind: NULL context");
+        int rc = ceno_hip_pow_grind_duplex(ctx, st16, bits, &w, s);  // one permutation per candidate, on the device
+        if (rc) return fail_from_ctx(ctx, rc);
+    } else if (bits > 0 && t->grind) {  // the transcript's own GrindingChallenger::grind: it also runs check_witness on itself
+        *out_witness = t->grind(t->self, bits);
+        return 0;
+    } else if (bits > 0) {
+        if (!t->fork || !t->fork_free) return fail(CENO_HIP_ERR_INVALID, "transcript_grind: the transcript can neither export its state, grind, nor fork");
+        for (;; w++) {
+            ceno_transcript c = *t;
+            c.self = t->fork(t->self);
+            const int ok = ceno_transcript_check_witness(&c, bits, w);
+            t->fork_free(c.self);
+            if (ok) break;
+            if (w > ((uint64_t)1 << 44)) return fail(CENO_HIP_ERR_STATE, "transcript_grind: no witness found");
+        }
+    }
+    if (!ceno_transcript_check_witness(t, bits, w)) return fail(CENO_HIP_ERR_STATE, "transcript_grind: the witness found does not pass check_witness");
+    *out_witness = w;
+    return 0;
+}
 
 int ceno_prover_sumcheck_run(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, int d, int num_mles, ceno_transcript* tr,
                              uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {

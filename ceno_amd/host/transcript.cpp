@@ -5,6 +5,8 @@
 //  - poseidon2: duplex challenger over Goldilocks (poseidon2_host.cpp); PARITY UNPINNED.
 #include "transcript.hpp"
 
+#include <cstring>
+
 #include "../csrc/gl64.hpp"
 
 namespace {
@@ -48,6 +50,13 @@ void stub_base(void* self, uint64_t v) {
     st->absorb(0x4241534500000000ULL);  // "BASE"
     st->absorb(v);
 }
+uint64_t stub_sample_bits(void* self, int bits) {
+    auto* st = (Stub*)self;
+    st->s = mix64(st->s);
+    const uint64_t v = st->s >= gl::P ? st->s - gl::P : st->s;
+    return bits >= 64 ? v : v & (((uint64_t)1 << bits) - 1);
+}
+void* stub_fork(void* self) { return new Stub(*(Stub*)self); }
 
 }  // namespace
 
@@ -59,6 +68,12 @@ extern "C" ceno_transcript* ceno_transcript_stub_new(uint64_t seed) {
     t->sample_ext = stub_sample;
     t->destroy = stub_destroy;
     t->append_base = stub_base;
+    t->sample_bits = stub_sample_bits;
+    t->fork = stub_fork;
+    t->fork_free = stub_destroy;
+    t->export_state = nullptr;  // not a duplex sponge: grinding runs through fork / append_base / sample_bits
+    t->import_state = nullptr;
+    t->grind = nullptr;
     return t;
 }
 
@@ -189,6 +204,32 @@ void dx_sample(void* self, uint64_t* o) {
 }
 void dx_destroy(void* self) { delete (Duplex*)self; }
 void dx_base(void* self, uint64_t v) { ((Duplex*)self)->observe(v % gl::P); }
+uint64_t dx_sample_bits(void* self, int bits) {
+    const uint64_t v = ((Duplex*)self)->sample();  // canonical
+    return bits >= 64 ? v : v & (((uint64_t)1 << bits) - 1);
+}
+void* dx_fork(void* self) { return new Duplex(*(Duplex*)self); }
+// [sponge state 8][n pending inputs][pending inputs 4][n outputs left][0][0] (include/ceno_prover.h)
+int dx_export(void* self, uint64_t* o) {
+    auto* d = (Duplex*)self;
+    memset(o, 0, 16 * 8);
+    memcpy(o, d->state, 64);
+    o[8] = d->in.size();
+    for (size_t i = 0; i < d->in.size(); i++) o[9 + i] = d->in[i];
+    o[13] = d->out.size();
+    return CENO_TRANSCRIPT_DUPLEX8;
+}
+int dx_import(void* self, const uint64_t* in16) {
+    auto* d = (Duplex*)self;
+    if (in16[8] >= (uint64_t)p2::RATE || in16[13] > (uint64_t)p2::RATE) return CENO_HIP_ERR_INVALID;
+    for (int i = 0; i < 13; i++)
+        if (i != 8 && in16[i] >= gl::P) return CENO_HIP_ERR_INVALID;
+    if (in16[8] != 0 && in16[13] != 0) return CENO_HIP_ERR_INVALID;  // observing clears the output buffer
+    memcpy(d->state, in16, 64);
+    d->in.assign(in16 + 9, in16 + 9 + in16[8]);
+    d->out.assign(d->state, d->state + in16[13]);  // the output buffer is always a prefix of the state
+    return 0;
+}
 
 }  // namespace
 
@@ -244,6 +285,12 @@ extern "C" ceno_transcript* ceno_transcript_poseidon2_new(const uint8_t* label, 
     t->sample_ext = dx_sample;
     t->destroy = dx_destroy;
     t->append_base = dx_base;
+    t->sample_bits = dx_sample_bits;
+    t->fork = dx_fork;
+    t->fork_free = dx_destroy;
+    t->export_state = dx_export;
+    t->import_state = dx_import;
+    t->grind = nullptr;  // the device search (ceno_prover_transcript_grind) serves this challenger
     if (label && n) dx_label(d, label, n);  // BasicTranscript::new(label) absorbs the label
     return t;
 }

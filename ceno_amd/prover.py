@@ -44,6 +44,18 @@ def plib():
     L.ceno_transcript_sample_ext.argtypes = [vp, u64p]
     L.ceno_transcript_append_base.restype = None
     L.ceno_transcript_append_base.argtypes = [vp, C.c_uint64]
+    L.ceno_transcript_sample_bits.restype = C.c_uint64
+    L.ceno_transcript_sample_bits.argtypes = [vp, i]
+    L.ceno_transcript_check_witness.restype = i
+    L.ceno_transcript_check_witness.argtypes = [vp, i, C.c_uint64]
+    L.ceno_transcript_clone.restype = vp
+    L.ceno_transcript_clone.argtypes = [vp]
+    L.ceno_transcript_export_state.restype = i
+    L.ceno_transcript_export_state.argtypes = [vp, u64p]
+    L.ceno_transcript_import_state.restype = i
+    L.ceno_transcript_import_state.argtypes = [vp, u64p]
+    L.ceno_prover_transcript_grind.restype = i
+    L.ceno_prover_transcript_grind.argtypes = [vp, vp, i, vp, u64p]
     L.ceno_prover_sumcheck_prove.restype = i
     L.ceno_prover_sumcheck_prove.argtypes = [vp, vpp, C.POINTER(SumcheckPlan), vp, vp, u64p, u64p, u64p]
     L.ceno_prover_sumcheck_run.restype = i
@@ -140,6 +152,36 @@ class Transcript:
 
     def append_base(self, v: int):
         plib().ceno_transcript_append_base(self.h, C.c_uint64(int(v)))
+
+    def sample_bits(self, bits: int) -> int:
+        return int(plib().ceno_transcript_sample_bits(self.h, bits))
+
+    def sample_base(self) -> int:
+        return self.sample_bits(64)
+
+    def check_witness(self, bits: int, w: int) -> bool:
+        return bool(plib().ceno_transcript_check_witness(self.h, bits, C.c_uint64(int(w))))
+
+    def clone(self) -> "Transcript":
+        h = plib().ceno_transcript_clone(self.h)
+        if not h:
+            raise RuntimeError("this transcript cannot fork")
+        return Transcript(h)
+
+    def export_state(self):
+        """(kind, 16 words): kind 1 = Poseidon2 duplex [state 8][n_in][in 4][n_out][0][0], 0 = not exportable"""
+        o = np.zeros(16, dtype=np.uint64)
+        return int(plib().ceno_transcript_export_state(self.h, _p(o))), o
+
+    def import_state(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        _check(plib().ceno_transcript_import_state(self.h, _p(w)))
+
+    def grind(self, dev, bits: int, stream=None) -> int:
+        """GrindingChallenger::grind: least witness accepted by check_witness on a clone; the transcript then observes it"""
+        o = np.zeros(1, dtype=np.uint64)
+        _check(plib().ceno_prover_transcript_grind(dev.h if dev is not None else None, self.h, bits, stream, _p(o)))
+        return int(o[0])
 
     def __del__(self):
         try:
@@ -821,17 +863,19 @@ class PcsData:
         L.ceno_pcs_data_num_vars.restype = i
         L.ceno_pcs_data_num_vars.argtypes = [vp, i]
         L.ceno_pcs_data_root.restype = i
-        L.ceno_pcs_data_root.argtypes = [vp, vp, i, u64p, vp]
+        L.ceno_pcs_data_root.argtypes = [vp, vp, u64p, vp]
         L.ceno_pcs_data_witness_mle.restype = i
         L.ceno_pcs_data_witness_mle.argtypes = [vp, vp, i, sz, C.POINTER(vp)]
-        L.ceno_pcs_data_open_row.restype = i
-        L.ceno_pcs_data_open_row.argtypes = [vp, vp, i, sz, u64p, u64p, vp]
+        L.ceno_pcs_data_opening_words.restype = sz
+        L.ceno_pcs_data_opening_words.argtypes = [vp]
+        L.ceno_pcs_data_open.restype = i
+        L.ceno_pcs_data_open.argtypes = [vp, vp, sz, u64p, vp]
         L.ceno_pcs_data_free.restype = None
         L.ceno_pcs_data_free.argtypes = [vp, vp]
         L.ceno_prover_basefold_proof_words.restype = sz
-        L.ceno_prover_basefold_proof_words.argtypes = [vp, i]
+        L.ceno_prover_basefold_proof_words.argtypes = [C.POINTER(vp), i, i]
         L.ceno_prover_basefold_open.restype = i
-        L.ceno_prover_basefold_open.argtypes = [vp, vp, C.POINTER(u64p), C.POINTER(u64p), i, i, vp, vp, u64p]
+        L.ceno_prover_basefold_open.argtypes = [vp, C.POINTER(vp), i, C.POINTER(u64p), C.POINTER(u64p), i, i, vp, vp, u64p]
         L.ceno_prover_commit_traces_dev.restype = i
         L.ceno_prover_commit_traces_dev.argtypes = [vp, C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
         self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
@@ -857,9 +901,10 @@ class PcsData:
     def num_vars(self, matrix: int) -> int:
         return plib().ceno_pcs_data_num_vars(self.h, matrix)
 
-    def root(self, matrix: int) -> np.ndarray:
+    def root(self) -> np.ndarray:
+        """PCS::get_pure_commitment: ONE root for all the matrices of the commitment"""
         out = np.zeros(4, dtype=np.uint64)
-        _check(plib().ceno_pcs_data_root(self.dev.h, self.h, matrix, _p(out), self.stream))
+        _check(plib().ceno_pcs_data_root(self.dev.h, self.h, _p(out), self.stream))
         return out
 
     def witness_mle(self, matrix: int, col: int) -> Mle:
@@ -869,27 +914,40 @@ class PcsData:
         m._parent = self
         return m
 
+    def open(self, index: int):
+        """MerkleTreeMmcs::open_batch at row `index` of the tallest codeword: (rows of every matrix, path (H, 4))"""
+        words = int(plib().ceno_pcs_data_opening_words(self.h))
+        out = np.zeros(words, dtype=np.uint64)
+        _check(plib().ceno_pcs_data_open(self.dev.h, self.h, index, _p(out), self.stream))
+        wsum = sum(int(w) for _, w in self.shapes)
+        rows, off = [], 0
+        for _, w in self.shapes:
+            rows.append(out[off: off + w].copy())
+            off += w
+        return rows, out[wsum:].reshape(-1, 4).copy()
+
     def open_row(self, matrix: int, index: int):
-        width = self.shapes[matrix][1]
-        depth = self.num_vars(matrix) + self.log_blowup
-        row = np.zeros(width, dtype=np.uint64)
-        path = np.zeros((max(depth, 1), 4), dtype=np.uint64)
-        _check(plib().ceno_pcs_data_open_row(self.dev.h, self.h, matrix, index, _p(row), _p(path), self.stream))
-        return row, path[:depth]
+        """row `index` of matrix `matrix`'s codeword + the commitment's path of the corresponding tallest-height row"""
+        nmax = max(self.num_vars(m) for m in range(len(self.shapes)))
+        rows, path = self.open(index << (nmax - self.num_vars(matrix)))
+        return rows[matrix], path
 
     def basefold_open(self, points: Sequence[np.ndarray], evals: Sequence[np.ndarray], n_queries: int, pow_bits: int,
-                      transcript: "Transcript") -> np.ndarray:
-        """OpeningProver::open (ceno_zkvm/src/scheme/hal.rs:284-294): every matrix at its own point.
+                      transcript: "Transcript", more_commits: Sequence["PcsData"] = ()) -> np.ndarray:
+        """OpeningProver::open (ceno_zkvm/src/scheme/hal.rs:284-294): every matrix at its own point; `more_commits` are further
+        commitments opened in the same proof (the fixed commitment), their points / evals follow this one's.
         Returns the flat proof (layout: include/ceno_prover.h)."""
         L = plib()
-        n = len(self.shapes)
+        commits = [self] + list(more_commits)
+        n = sum(len(c.shapes) for c in commits)
         pts = [np.ascontiguousarray(p, dtype=np.uint64) for p in points]
         evs = [np.ascontiguousarray(e, dtype=np.uint64) for e in evals]
         assert len(pts) == n and len(evs) == n
-        proof = np.zeros(int(L.ceno_prover_basefold_proof_words(self.h, n_queries)), dtype=np.uint64)
+        ch = (C.c_void_p * len(commits))(*[c.h for c in commits])
+        proof = np.zeros(int(L.ceno_prover_basefold_proof_words(ch, len(commits), n_queries)), dtype=np.uint64)
         pp = (u64p * n)(*[_p(x) for x in pts])
         ep = (u64p * n)(*[_p(x) for x in evs])
-        _check(L.ceno_prover_basefold_open(self.dev.h, self.h, pp, ep, n_queries, pow_bits, transcript.h, self.stream, _p(proof)))
+        _check(L.ceno_prover_basefold_open(self.dev.h, ch, len(commits), pp, ep, n_queries, pow_bits, transcript.h, self.stream, _p(proof)))
         return proof
 
     def free(self):

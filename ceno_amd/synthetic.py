@@ -99,7 +99,7 @@ class ChipFlow:
         res = {}
         pcs, res["commit_ms"] = timed(lambda: prover.PcsData(dev, None, self.log_blowup, self.stream, device_ptrs=[(self.trace.device_ptr, rows, w)]))
         tr = transcript_factory()
-        root = pcs.root(0)
+        root = pcs.root()
         tr.append_ext((int(root[0]), int(root[1])))
         tr.append_ext((int(root[2]), int(root[3])))
         alpha, beta = tr.sample_ext(), tr.sample_ext()
@@ -165,10 +165,9 @@ class ShardFlow:
         ptrs = [(t.device_ptr, 1 << r, w) for t, r in zip(self.traces, self.LOG_ROWS)]
         pcs, res["commit_ms"] = timed(lambda: prover.PcsData(dev, None, self.log_blowup, self.stream, device_ptrs=ptrs))
         tr = transcript_factory()
-        for m in range(len(ptrs)):
-            root = pcs.root(m)
-            tr.append_ext((int(root[0]), int(root[1])))
-            tr.append_ext((int(root[2]), int(root[3])))
+        root = pcs.root()                                           # ONE commitment for all traces (PCS::write_commitment, prover.rs)
+        tr.append_ext((int(root[0]), int(root[1])))
+        tr.append_ext((int(root[2]), int(root[3])))
         alpha, beta = tr.sample_ext(), tr.sample_ext()              # prover.rs:528-531
         coeffs, terms, out_terms = record_plan(w, 16, alpha, beta)
         mterms, mscalars = main_plan(w, w)
@@ -234,7 +233,7 @@ class ShardFlow:
         mj = prover.MainJobs(jobs)
         (claimed, msgs, rt, evals), res["batched_main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, mj, [alpha, beta], tr, self.stream))
         # (kept for tools/dbg_shard_digest.py: what the opening is asked to prove, available even when the opening fails)
-        self.pre_open = dict(roots=[pcs.root(m) for m in range(len(ptrs))], alpha=alpha, chip_proofs=[c[1] for c in chips], msgs=msgs, rt=rt, evals=evals)
+        self.pre_open = dict(roots=[pcs.root()], alpha=alpha, chip_proofs=[c[1] for c in chips], msgs=msgs, rt=rt, evals=evals)
         points = [rt[:r] for r in self.LOG_ROWS]
         ev = [evals[i * (w + 1): i * (w + 1) + w] for i in range(len(self.LOG_ROWS))]
         oproof, res["open_ms"] = timed(lambda: pcs.basefold_open(points, ev, self.n_queries, self.pow_bits, tr))
@@ -242,7 +241,7 @@ class ShardFlow:
         res["e2e_prover_sec_for_2p20_cycles"] = res["total_ms"] / 1e3
         res["open_proof_bytes"] = int(oproof.size * 8)
         # everything a verifier needs (tests/test_gpu_flows.py replays the whole transcript with the oracle's verifiers)
-        self.artifacts = dict(roots=[pcs.root(m) for m in range(len(ptrs))], alpha=alpha, beta=beta, chip_proofs=[c[1] for c in chips],
+        self.artifacts = dict(roots=[pcs.root()], alpha=alpha, beta=beta, chip_proofs=[c[1] for c in chips],
                               fork_samples=[c[2] for c in chips], claimed=claimed, msgs=msgs, rt=rt, evals=evals, points=points, open_evals=ev,
                               open_proof=oproof, mterms=mterms, mscalars=mscalars)
         for cols, _, _ in chips:

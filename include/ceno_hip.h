@@ -272,6 +272,22 @@ int ceno_hip_poseidon2_is_pinned(const ceno_hip_ctx* ctx);   /* 1 once a complet
 int ceno_hip_poseidon2_permute(ceno_hip_ctx* ctx, uint64_t* dev_states /* n x 8 */, size_t n, ceno_hip_stream s);
 /* leaves = sponge hash of each row of a column-major matrix (rows = 2^log_rows); tree = 2-to-1 compression */
 int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int log_rows, int width, ceno_hip_stream s, ceno_hip_merkle** out);
+/* ONE commitment over matrices of several power-of-two heights — what PCS::batch_commit returns for all the traces of a
+ * commit_traces call (ceno_zkvm/src/scheme/cpu/mod.rs:559-584; several num_vars opened under one commitment:
+ * ceno_recursion_v2/src/pcs/mod.rs:1123-1135,7547-7565).  The tree is p3's MerkleTreeMmcs (EXT p3-merkle-tree 0.4.3): matrices
+ * sorted tallest first (stable); leaf i = sponge over row i of ALL tallest matrices concatenated; every next level has half
+ * the nodes, node i = compress(left, right), and where matrices of exactly that height exist
+ * node i = compress(compress(left, right), sponge(row i of those matrices)).  log_rows[m] = log2 of matrix m's height,
+ * dev_col_major[m] its columns (stride 2^log_rows[m]); the matrices are BORROWED for as long as the tree is opened.
+ * The tree has max(log_rows) levels below the root; ceno_hip_merkle_root / _open / _open_batch / _free apply. */
+int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major, const int* log_rows, const int* widths, int n_mats,
+                         ceno_hip_stream s, ceno_hip_merkle** out);
+/* MerkleTreeMmcs::open_batch for many indices at once: for query q, index i_q = dev_indices[q] >> shift (a row of the tallest
+ * height), dev_out[q * out_stride_words ..] = [row (i_q >> (log_max - log_rows[m])) of every matrix m in the caller's order]
+ * [authentication path: 4 x log_max words, bottom-up].  ceno_hip_mmcs_opening_words = sum of widths + 4 log_max. */
+size_t ceno_hip_mmcs_opening_words(const ceno_hip_merkle* t);
+int ceno_hip_mmcs_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
+                             size_t out_stride_words, ceno_hip_stream s);
 int ceno_hip_merkle_root(ceno_hip_ctx* ctx, ceno_hip_merkle* t, uint64_t* root4, ceno_hip_stream s);
 /* authentication path of leaf `index`: log_rows sibling digests (4 words each), bottom-up */
 int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, uint64_t* path /* log_rows*4 */, ceno_hip_stream s);
@@ -305,8 +321,12 @@ int ceno_hip_gather(ceno_hip_ctx* ctx, const uint64_t* dev_src, size_t col_strid
 /* authentication paths of leaves (idx[q] >> shift): dev_out[q][level][4], log_rows levels, bottom-up */
 int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift,
                                uint64_t* dev_out, ceno_hip_stream s);
-/* least w with poseidon2(seed.c0, seed.c1, w, 0, 0, 0, 0, 0)[0] = 0 mod 2^bits (synchronises) */
-int ceno_hip_pow_grind(ceno_hip_ctx* ctx, const uint64_t* seed2, int bits, uint64_t* out_witness, ceno_hip_stream s);
+/* Proof-of-work search of p3's grinding challenger (GrindingChallenger::grind; the verifier side is check_witness,
+ * ceno_recursion_v2/src/pcs/mod.rs:8125-8155): the least w for which a CLONE of the Poseidon2 duplex challenger (width 8, rate 4)
+ * that observes w samples a base element whose low `bits` bits are zero.  state16 = the challenger state as exported by
+ * ceno_transcript.export_state (include/ceno_prover.h): [sponge state 8][n pending inputs][pending inputs 4][n outputs left][0][0].
+ * One permutation per candidate.  Synchronises. */
+int ceno_hip_pow_grind_duplex(ceno_hip_ctx* ctx, const uint64_t* state16, int bits, uint64_t* out_witness, ceno_hip_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * on-device witness generation for the R-type arithmetic chips

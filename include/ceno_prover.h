@@ -22,7 +22,10 @@ extern "C" {
 #endif
 
 /* Transcript as seen by the prover loops: append a byte label (`append_message`), append an
- * extension element (`append_field_element_ext`), squeeze an extension challenge. */
+ * extension element (`append_field_element_ext`), squeeze an extension challenge; and, for the PCS, the base-field side
+ * of the challenger (p3-challenger `CanObserve<F>` / `CanSample<F>`; in-tree use ceno_recursion_v2/src/pcs/mod.rs:8125-8204):
+ * observe one base element, sample bits of ONE base element, clone the challenger (grinding checks candidates on clones), and
+ * export the duplex state so that the proof-of-work search can run on the device. */
 typedef struct ceno_transcript {
     void (*append_label)(void* self, const uint8_t* bytes, size_t n);
     void (*append_ext)(void* self, const uint64_t* e2);
@@ -30,7 +33,25 @@ typedef struct ceno_transcript {
     void* self;
     void (*destroy)(void* self);
     void (*append_base)(void* self, uint64_t v);   /* `append_field_element` (instance counts, circuit ids: prover.rs:682-689) */
+    /* `CanSampleBits::sample_bits(bits)`: the low `bits` bits of the canonical value of ONE base-field sample (p3 DuplexChallenger;
+     * pcs/mod.rs:8164-8204; a supertrait of the reference's `Transcript`, ceno_recursion_v2/src/tower/tower.rs:89-93).  bits >= 64
+     * returns the whole sample (the library's own challengers only) */
+    uint64_t (*sample_bits)(void* self, int bits);
+    void* (*fork)(void* self);                     /* `challenger.clone()`: a new `self` with the same state, released by fork_free */
+    void (*fork_free)(void* forked);
+    /* Poseidon2 duplex state as 16 words: [sponge state 8][n pending inputs][pending inputs 4, zero padded][n outputs left]
+     * [0][0]; the output buffer is state[0 .. n_out) and samples pop from its back (p3-challenger DuplexChallenger: the pub
+     * fields sponge_state / input_buffer / output_buffer).  Returns CENO_TRANSCRIPT_DUPLEX8 (1), or 0 when the transcript
+     * is of another kind (the proof-of-work search then runs through fork / append_base / sample_bits on the host).
+     * May be NULL (same meaning as returning 0). */
+    int (*export_state)(void* self, uint64_t* out16);
+    int (*import_state)(void* self, const uint64_t* in16);   /* 0 = ok; may be NULL */
+    /* the transcript's OWN `GrindingChallenger::grind(bits)` (a supertrait of the reference's `Transcript`, tower.rs:95-101): finds a
+     * witness, observes it, samples the bits; returns the witness.  May be NULL.  Used when the state cannot be exported to the
+     * device search (a Rust transcript whose challenger is private). */
+    uint64_t (*grind)(void* self, int bits);
 } ceno_transcript;
+#define CENO_TRANSCRIPT_DUPLEX8 1
 
 /* deterministic data-dependent stand-in (SplitMix64 chaining) — identical to the oracle's stub so
  * that parity tests compare complete proofs; NOT the reference's Poseidon2 transcript. */
@@ -51,6 +72,20 @@ void ceno_transcript_append_label(ceno_transcript* t, const uint8_t* bytes, size
 void ceno_transcript_append_ext(ceno_transcript* t, const uint64_t* e2);
 void ceno_transcript_append_base(ceno_transcript* t, uint64_t v);
 void ceno_transcript_sample_ext(ceno_transcript* t, uint64_t* out2);
+/* sample_bits (pcs/mod.rs:8164-8204): the low `bits` bits of the canonical value of ONE base sample */
+uint64_t ceno_transcript_sample_bits(ceno_transcript* t, int bits);
+/* check_witness (pcs/mod.rs:8125-8155): observe `witness`, then sample_bits(bits) == 0.  Advances the transcript.  1 = accepted */
+int ceno_transcript_check_witness(ceno_transcript* t, int bits, uint64_t witness);
+/* a complete copy (table + state) of a transcript that implements fork; release with ceno_transcript_free.  NULL when it cannot fork */
+ceno_transcript* ceno_transcript_clone(const ceno_transcript* t);
+int ceno_transcript_export_state(ceno_transcript* t, uint64_t* out16);          /* CENO_TRANSCRIPT_DUPLEX8 or 0 */
+int ceno_transcript_import_state(ceno_transcript* t, const uint64_t* in16);     /* 0 = ok */
+/* `GrindingChallenger::grind` (p3-challenger; the prover side of check_witness): a witness w for which a clone of the
+ * transcript passes check_witness(bits, w) — the LEAST one, found on the device, when the transcript exports a Poseidon2
+ * duplex state (one permutation per candidate: ceno_hip_pow_grind_duplex); else the transcript's own `grind` when the table
+ * has one; else the least one through fork / append_base / sample_bits on the host.  Then check_witness on `t` itself.
+ * p3 accepts any valid witness (`find_any`). */
+int ceno_prover_transcript_grind(ceno_hip_ctx* ctx, ceno_transcript* t, int bits, ceno_hip_stream s, uint64_t* out_witness);
 
 /* IOPProverState::prove: appends n and d (usize le-bytes), then per round the d evaluations and
  * the label "Internal round", samples the challenge.  out_msgs: n*d ext, out_challenges: n ext,
@@ -289,37 +324,47 @@ int ceno_prover_gkr_prove(ceno_hip_ctx* ctx, const ceno_gkr_layer* layers, int n
  * (>= 2, zero rows), move it to the device, transpose to column-major, RS-encode every column (blow-up
  * 2^log_blowup), hash the codeword rows and build the Merkle tree.  The witness MLEs handed to the sumchecks
  * are borrowed views of the column-major trace (nothing is copied or re-uploaded).
- * PARITY UNPINNED (EXT mpcs): one tree per matrix instead of p3's mixed-height MMCS, placeholder Poseidon2
- * constants, rate / layout assumptions — see DESIGN.md section 5. */
+ * ONE commitment for all the matrices of the call (PCS::batch_commit -> one PCS::Commitment): a mixed-height Merkle tree
+ * (ceno_hip_mmcs_commit = p3 MerkleTreeMmcs).  PARITY UNPINNED (EXT mpcs / p3): placeholder Poseidon2 constants, rate /
+ * layout assumptions — see DESIGN.md section 5. */
 typedef struct ceno_pcs_data ceno_pcs_data;
 int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
                               int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
 /* same with the row-major matrices already in device memory (the reference's device-backed RowMajorMatrix: witness generated
- * on the GPU, `has_device_backing()` / `device_backing_layout()`, scheme/gpu/mod.rs:1556-1582): no PCIe transfer */
+ * on the GPU, `has_device_backing()` / `device_backing_layout()`, scheme/gpu/mod.rs:1556-1582): no PCIe transfer.  All the work
+ * is queued on `s`, behind whatever the caller queued there to produce the matrices. */
 int ceno_prover_commit_traces_dev(ceno_hip_ctx* ctx, const uint64_t* const* dev_row_major, const size_t* num_instances, const size_t* widths,
                                   int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
+int ceno_pcs_data_num_matrices(const ceno_pcs_data* d);
 int ceno_pcs_data_num_vars(const ceno_pcs_data* d, int matrix);
-int ceno_pcs_data_root(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, uint64_t* root4, ceno_hip_stream s);
+int ceno_pcs_data_width(const ceno_pcs_data* d, int matrix);
+/* PCS::get_pure_commitment: the root of the commitment (4 words) */
+int ceno_pcs_data_root(ceno_hip_ctx* ctx, ceno_pcs_data* d, uint64_t* root4, ceno_hip_stream s);
 /* borrowed base-field MLE view of column `col` of matrix `matrix` (valid while `d` lives; free the handle with ceno_hip_mle_free) */
 int ceno_pcs_data_witness_mle(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, size_t col, ceno_hip_mle** out);
-/* Merkle path of codeword row `index` and the row itself (`width` base elements) */
-int ceno_pcs_data_open_row(ceno_hip_ctx* ctx, ceno_pcs_data* d, int matrix, size_t index, uint64_t* row_out, uint64_t* path_out, ceno_hip_stream s);
+/* MerkleTreeMmcs::open_batch at `index` (a row of the tallest codeword): out = [row index >> (H - h_m) of every matrix's codeword, in
+ * order (sum of widths words)][path 4 x H words], H = max num_vars + log_blowup; ceno_pcs_data_opening_words words in all */
+size_t ceno_pcs_data_opening_words(const ceno_pcs_data* d);
+int ceno_pcs_data_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, size_t index, uint64_t* out, ceno_hip_stream s);
 void ceno_pcs_data_free(ceno_hip_ctx* ctx, ceno_pcs_data* d);
 
 /* ---- Basefold batch open (a15) ----
  * OpeningProver::open -> PCS::batch_open (ceno_zkvm/src/scheme/hal.rs:284-294, CPU scheme/cpu/mod.rs:1418-1457);
  * protocol as replayed by the in-tree verifier ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781
- * (basecode_msg_size_log = 0).  Every committed matrix is opened at its own point (`points[m]`: num_vars ext) with
- * the claimed column evaluations `evals[m]` (width ext).  PARITY UNPINNED (EXT mpcs), see commit_traces above;
- * additionally: digests are observed as two ext elements, query indices are the low bits of a sampled ext's c0,
- * and the proof of work is seed-based.
- * Flat proof (ceno_prover_basefold_proof_words words), n = max num_vars, H = n + log_blowup:
+ * (basecode_msg_size_log = 0).  `commits` are the `rounds` of batch_open (witness commitment, then the fixed one when present);
+ * every committed matrix is opened at its own point (`points[m]`: num_vars ext) with the claimed column evaluations
+ * `evals[m]` (width ext), m running over the matrices of commits[0], then commits[1], ...  Proof of work = p3 grinding
+ * (check_witness, pcs/mod.rs:8125-8155), query indices = sample_bits(max num_vars + log_blowup) of one base sample each
+ * (pcs/mod.rs:1252-1266), one input opening per commitment at query >> bits_reduced (pcs/mod.rs:7547-7565).
+ * PARITY UNPINNED (EXT mpcs): Poseidon2 constants, label packing — DESIGN.md section 5.
+ * Flat proof (ceno_prover_basefold_proof_words words), n = max num_vars over all commitments, H = n + log_blowup:
  *   [sumcheck messages n x (p(1), p(2)) ext][commit-round roots n x 4][final message: one ext per matrix][pow witness]
- *   then per query: [index] per matrix [opened codeword row: width][path 4 x (num_vars + log_blowup)]
+ *   then per query: [index] per commitment c [opened codeword rows of its matrices: sum of widths][MMCS path 4 x H_c]
  *                   per round r [sibling ext][path 4 x (H - r - 1)]                                         */
-size_t ceno_prover_basefold_proof_words(const ceno_pcs_data* d, int n_queries);
-int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* d, const uint64_t* const* points, const uint64_t* const* evals,
-                              int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof);
+size_t ceno_prover_basefold_proof_words(ceno_pcs_data* const* commits, int n_commits, int n_queries);
+int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points,
+                              const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s,
+                              uint64_t* out_proof);
 
 /* ---- concurrent chip proving on lanes (scheduler.rs:231-336, memory booking :342-347,:622-652) ----
  * One worker thread per lane, each with its own stream (ceno_hip_stream_create_lane); tasks are taken largest-estimate

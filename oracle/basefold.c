@@ -163,7 +163,7 @@ int orc_basefold_open(int n_commits, const int* commit_sizes, const int* nv, con
     int n = 0, total_cols = 0;
     const int n_mats = total_mats(n_commits, commit_sizes);
     if (n_commits < 1 || n_mats < 1 || n_mats > 4096) return -1;
-    if (!tr->append_base || !tr->sample_base || !tr->fork) return -1;
+    if (!tr->append_base || !tr->sample_bits || !tr->fork) return -1;
     for (int m = 0; m < n_mats; m++) {
         if (nv[m] < 1 || width[m] < 1) return -1;
         if (nv[m] > n) n = nv[m];
@@ -357,7 +357,7 @@ int orc_basefold_verify(int n_commits, const int* commit_sizes, const int* nv, c
                         const uint64_t* params, orc_transcript* tr, const uint64_t* proof) {
     int n = 0, total_cols = 0;
     const int n_mats = total_mats(n_commits, commit_sizes);
-    if (!tr->append_base || !tr->sample_base) return -1;
+    if (!tr->append_base || !tr->sample_bits) return -1;
     for (int m = 0; m < n_mats; m++) {
         if (nv[m] > n) n = nv[m];
         total_cols += width[m];

@@ -46,15 +46,16 @@ void orc_stub_append_base(orc_stub_state* st, uint64_t v) {
     stub_absorb(st, 0x4241534500000000ULL); /* "BASE" */
     stub_absorb(st, v);
 }
-uint64_t orc_stub_sample_base(orc_stub_state* st) {
+uint64_t orc_stub_sample_bits(orc_stub_state* st, int bits) {
     st->s = mix64(st->s);
-    return gl_reduce(st->s);
+    const uint64_t v = gl_reduce(st->s);
+    return bits >= 64 ? v : v & (((uint64_t)1 << bits) - 1);
 }
 static void stub_al(void* s, const uint8_t* b, size_t n) { orc_stub_append_label((orc_stub_state*)s, b, n); }
 static void stub_ae(void* s, const uint64_t* e) { orc_stub_append_ext((orc_stub_state*)s, e); }
 static void stub_se(void* s, uint64_t* o) { orc_stub_sample_ext((orc_stub_state*)s, o); }
 static void stub_ab(void* s, uint64_t v) { orc_stub_append_base((orc_stub_state*)s, v); }
-static uint64_t stub_sb(void* s) { return orc_stub_sample_base((orc_stub_state*)s); }
+static uint64_t stub_sb(void* s, int bits) { return orc_stub_sample_bits((orc_stub_state*)s, bits); }
 static void* stub_fork(void* s) {
     orc_stub_state* c = malloc(sizeof(*c));
     *c = *(orc_stub_state*)s;
@@ -62,7 +63,7 @@ static void* stub_fork(void* s) {
 }
 void orc_stub_bind(orc_transcript* t, orc_stub_state* st) {
     t->append_label = stub_al; t->append_ext = stub_ae; t->sample_ext = stub_se; t->self = st;
-    t->append_base = stub_ab; t->sample_base = stub_sb; t->fork = stub_fork; t->fork_free = free;
+    t->append_base = stub_ab; t->sample_bits = stub_sb; t->fork = stub_fork; t->fork_free = free;
 }
 
 static void tr_label(orc_transcript* t, const char* s) { t->append_label(t->self, (const uint8_t*)s, strlen(s)); }

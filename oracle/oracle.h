@@ -37,12 +37,14 @@ typedef struct orc_transcript {
      * `CanSampleBits` / `GrindingChallenger`; in-tree use: ceno_recursion_v2/src/pcs/mod.rs:8125-8204).  NULL in
      * transcripts that only serve sumchecks (the PCS entry points then fail). */
     void (*append_base)(void* self, uint64_t v);
-    uint64_t (*sample_base)(void* self);
+    /* `CanSampleBits::sample_bits` (p3-challenger 0.4.3 DuplexChallenger; in-tree ceno_recursion_v2/src/pcs/mod.rs:8164-8204 and the
+     * supertraits of `Transcript`, ceno_recursion_v2/src/tower/tower.rs:85-101): the low `bits` bits of the canonical value of ONE
+     * base-field sample */
+    uint64_t (*sample_bits)(void* self, int bits);
     void* (*fork)(void* self);        /* heap copy of the challenger state (`self.clone()`) */
     void (*fork_free)(void* forked);
 } orc_transcript;
 
-/* sample_bits (p3-challenger DuplexChallenger::sample_bits; pcs/mod.rs:8164-8204): the low `bits` bits of ONE base sample */
 uint64_t orc_tr_sample_bits(orc_transcript* t, int bits);
 /* check_witness (pcs/mod.rs:8125-8155): observe the witness, then sample_bits(bits) == 0.  Advances the transcript. */
 int orc_tr_check_witness(orc_transcript* t, int bits, uint64_t witness);
@@ -58,7 +60,7 @@ void orc_stub_append_label(orc_stub_state* st, const uint8_t* bytes, size_t n);
 void orc_stub_append_ext(orc_stub_state* st, const uint64_t* e2);
 void orc_stub_append_base(orc_stub_state* st, uint64_t v);
 void orc_stub_sample_ext(orc_stub_state* st, uint64_t* out2);
-uint64_t orc_stub_sample_base(orc_stub_state* st);
+uint64_t orc_stub_sample_bits(orc_stub_state* st, int bits);
 
 /* Poseidon2 duplex challenger over Goldilocks, width 8 / rate 4 (transcript.c): the shape of p3-challenger 0.4.3
  * `DuplexChallenger<F, Perm, 8, 4>` that the reference's EXT `transcript::BasicTranscript` wraps.  PARITY UNPINNED

@@ -89,7 +89,7 @@ class OrcTranscript(C.Structure):
         ("self", C.c_void_p),
         ("reserved", C.c_void_p),
         ("append_base", C.c_void_p),
-        ("sample_base", C.c_void_p),
+        ("sample_bits", C.c_void_p),
         ("fork", C.c_void_p),
         ("fork_free", C.c_void_p),
     ]
@@ -133,7 +133,6 @@ def lib():
         _lib.orc_tower_msgs_words.argtypes = [C.c_int]
         _lib.orc_two_adic_generator.restype = C.c_uint64
         _lib.orc_two_adic_generator.argtypes = [C.c_int]
-        _lib.orc_stub_sample_base.restype = C.c_uint64
         _lib.orc_tr_sample_bits.restype = C.c_uint64
         _lib.orc_tr_sample_bits.argtypes = [C.c_void_p, C.c_int]
         _lib.orc_tr_check_witness.restype = C.c_int
@@ -204,11 +203,11 @@ class StubTranscript:
     def append_base(self, v: int):
         lib().orc_stub_append_base(C.byref(self.state), C.c_uint64(v))
 
-    def sample_base(self) -> int:
-        return int(lib().orc_stub_sample_base(C.byref(self.state)))
-
     def sample_bits(self, bits: int) -> int:
         return int(lib().orc_tr_sample_bits(self.ptr(), bits))
+
+    def sample_base(self) -> int:
+        return self.sample_bits(64)
 
     def check_witness(self, bits: int, w: int) -> bool:
         return bool(lib().orc_tr_check_witness(self.ptr(), bits, C.c_uint64(w)))
@@ -234,7 +233,6 @@ class DuplexTranscript(StubTranscript):
             "append_ext": C.CFUNCTYPE(None, C.c_void_p, u64p),
             "sample_ext": C.CFUNCTYPE(None, C.c_void_p, u64p),
             "append_base": C.CFUNCTYPE(None, C.c_void_p, C.c_uint64),
-            "sample_base": C.CFUNCTYPE(C.c_uint64, C.c_void_p),
         }[name])
         return f(self.tr.self, *args)
 
@@ -253,9 +251,6 @@ class DuplexTranscript(StubTranscript):
 
     def append_base(self, v: int):
         self._call("append_base", C.c_uint64(v))
-
-    def sample_base(self) -> int:
-        return int(self._call("sample_base"))
 
     def export_state(self) -> np.ndarray:
         """[state 8][n_in][in 4][n_out][0, 0]: the layout of the host library's ceno_transcript export"""

@@ -20,10 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-uint64_t orc_tr_sample_bits(orc_transcript* t, int bits) {
-    uint64_t v = t->sample_base(t->self); /* canonical */
-    return v & (((uint64_t)1 << bits) - 1);
-}
+uint64_t orc_tr_sample_bits(orc_transcript* t, int bits) { return t->sample_bits(t->self, bits); }
 int orc_tr_check_witness(orc_transcript* t, int bits, uint64_t witness) {
     t->append_base(t->self, witness);
     return orc_tr_sample_bits(t, bits) == 0;
@@ -74,7 +71,10 @@ static void dx_sample_ext(void* s, uint64_t* o) {
     o[1] = orc_duplex_sample((orc_duplex_state*)s);
 }
 static void dx_base(void* s, uint64_t v) { orc_duplex_observe((orc_duplex_state*)s, gl_reduce(v)); }
-static uint64_t dx_sample_base(void* s) { return orc_duplex_sample((orc_duplex_state*)s); }
+static uint64_t dx_sample_bits(void* s, int bits) {
+    const uint64_t v = orc_duplex_sample((orc_duplex_state*)s); /* canonical */
+    return bits >= 64 ? v : v & (((uint64_t)1 << bits) - 1);
+}
 static void* dx_fork(void* s) {
     orc_duplex_state* c = malloc(sizeof(*c));
     memcpy(c, s, sizeof(*c));
@@ -87,5 +87,5 @@ void orc_duplex_init(orc_duplex_state* d, const uint64_t* params138, const uint8
 }
 void orc_duplex_bind(orc_transcript* t, orc_duplex_state* d) {
     t->append_label = dx_label; t->append_ext = dx_ext; t->sample_ext = dx_sample_ext; t->self = d;
-    t->append_base = dx_base; t->sample_base = dx_sample_base; t->fork = dx_fork; t->fork_free = free;
+    t->append_base = dx_base; t->sample_bits = dx_sample_bits; t->fork = dx_fork; t->fork_free = free;
 }

@@ -45,4 +45,15 @@ pub trait FsTranscript {
     /// `get_challenge_pows(n, transcript)`: label `b"combine subset evals"`, one sample, `[1, a, a^2, ..]` — the powers are
     /// formed by the caller's field type, so the adapter returns them ready-made
     fn challenge_pows(&mut self, n: usize) -> Vec<ExtWords>;
+    /// `CanSampleBits::sample_bits(bits)` (a supertrait of `Transcript`): low bits of ONE base-field sample — the query indices
+    /// and the proof-of-work check of the PCS (`ceno_recursion_v2/src/pcs/mod.rs:8125-8204,1252-1266`)
+    fn sample_bits(&mut self, bits: usize) -> usize;
+    /// `GrindingChallenger::grind(bits)` (a supertrait of `Transcript`): the transcript's own proof-of-work search; the witness
+    /// has been observed and the bits sampled when it returns
+    fn grind(&mut self, bits: usize) -> u64;
+    /// Poseidon2 duplex state `[sponge 8][n_in][in 4][n_out][0][0]` for the device-side search (`ceno_hip_pow_grind_duplex`);
+    /// `None` when the challenger's fields are not reachable — the library then calls [`FsTranscript::grind`]
+    fn export_duplex_state(&self) -> Option<[u64; 16]> {
+        None
+    }
 }

@@ -1,15 +1,16 @@
 //! Basefold commit and batch open over the device.
 //! Reference: `cuda_hal.basefold.{batch_commit, get_pure_commitment, get_trace, batch_open}`
 //! (`ceno_zkvm/src/scheme/gpu/mod.rs:1642-1646,1717-1720,3401-3402`); traits `TraceCommitter::commit_traces`
-//! (`scheme/hal.rs:137-156`) and `OpeningProver::open` (`:284-294`).  PARITY UNPINNED against the reference's `mpcs` crate
-//! (Poseidon2 constants, mixed-height MMCS, query derivation): see DESIGN.md section 5.
+//! (`scheme/hal.rs:137-156`) and `OpeningProver::open` (`:284-294`).  One commitment per `commit_traces` (mixed-height MMCS), p3
+//! grinding and one-base-sample query indices as the in-tree verifier replays them (`ceno_recursion_v2/src/pcs/mod.rs`);
+//! PARITY UNPINNED against the reference's `mpcs` crate for the Poseidon2 constants and label packing: DESIGN.md section 5.
 use std::{ptr, sync::Arc};
 
 use ceno_hip_sys as sys;
 
 use crate::{error::Result, hal::HipHal, hal::HipStream, mle::HipMle, ExtWords};
 
-/// committed traces: column-major trace, codewords and Merkle tree per matrix (`PcsData`)
+/// committed traces: column-major traces and codewords per height class, ONE mixed-height Merkle tree (`PcsData`)
 pub struct HipPcsData {
     hal: Arc<HipHal>,
     raw: *mut sys::ceno_pcs_data,
@@ -47,11 +48,14 @@ impl HipPcsData {
     pub fn num_vars(&self, matrix: usize) -> usize {
         unsafe { sys::ceno_pcs_data_num_vars(self.raw, matrix as i32) as usize }
     }
-    /// `get_pure_commitment`: the Merkle root of matrix `matrix` (4 base-field words)
-    pub fn root(&self, matrix: usize, stream: &HipStream) -> Result<[u64; 4]> {
+    /// `get_pure_commitment`: THE root of the commitment (4 base-field words) — one for all matrices
+    pub fn root(&self, stream: &HipStream) -> Result<[u64; 4]> {
         let mut r = [0u64; 4];
-        self.hal.check_prover(unsafe { sys::ceno_pcs_data_root(self.hal.ctx, self.raw, matrix as i32, r.as_mut_ptr(), stream.raw()) })?;
+        self.hal.check_prover(unsafe { sys::ceno_pcs_data_root(self.hal.ctx, self.raw, r.as_mut_ptr(), stream.raw()) })?;
         Ok(r)
+    }
+    pub(crate) fn raw(&self) -> *mut sys::ceno_pcs_data {
+        self.raw
     }
     /// `get_arc_mle_witness_from_commitment`: borrowed base-field view of one column (nothing is copied)
     pub fn witness_mle(self: &Arc<Self>, matrix: usize, col: usize) -> Result<HipMle> {
@@ -59,17 +63,19 @@ impl HipPcsData {
         self.hal.check_prover(unsafe { sys::ceno_pcs_data_witness_mle(self.hal.ctx, self.raw, matrix as i32, col, &mut m) })?;
         Ok(HipMle::from_raw(&self.hal, m))
     }
-    /// `PCS::batch_open`: every matrix at its own point with the claimed column evaluations; flat proof words (layout:
+    /// `PCS::batch_open(rounds)`: `self` is the witness commitment, `fixed` the optional fixed one (`cpu/mod.rs:1418-1457`); every
+    /// matrix at its own point with the claimed column evaluations, witness matrices first; flat proof words (layout:
     /// `include/ceno_prover.h`)
-    pub fn batch_open(&self, points: &[Vec<ExtWords>], evals: &[Vec<ExtWords>], n_queries: usize, pow_bits: usize,
+    pub fn batch_open(&self, fixed: Option<&HipPcsData>, points: &[Vec<ExtWords>], evals: &[Vec<ExtWords>], n_queries: usize, pow_bits: usize,
                       transcript: *mut sys::ceno_transcript, stream: &HipStream) -> Result<Vec<u64>> {
         let pp: Vec<*const u64> = points.iter().map(|p| p.as_ptr() as *const u64).collect();
         let ep: Vec<*const u64> = evals.iter().map(|e| e.as_ptr() as *const u64).collect();
-        let words = unsafe { sys::ceno_prover_basefold_proof_words(self.raw, n_queries as i32) };
+        let commits: Vec<*mut sys::ceno_pcs_data> = std::iter::once(self.raw).chain(fixed.map(|f| f.raw())).collect();
+        let words = unsafe { sys::ceno_prover_basefold_proof_words(commits.as_ptr(), commits.len() as i32, n_queries as i32) };
         let mut proof = vec![0u64; words];
         self.hal.check_prover(unsafe {
-            sys::ceno_prover_basefold_open(self.hal.ctx, self.raw, pp.as_ptr(), ep.as_ptr(), n_queries as i32, pow_bits as i32, transcript, stream.raw(),
-                                           proof.as_mut_ptr())
+            sys::ceno_prover_basefold_open(self.hal.ctx, commits.as_ptr(), commits.len() as i32, pp.as_ptr(), ep.as_ptr(), n_queries as i32,
+                                           pow_bits as i32, transcript, stream.raw(), proof.as_mut_ptr())
         })?;
         Ok(proof)
     }

@@ -3,7 +3,7 @@
 //!   `create_chip_proof`                 <-> `ZKVMProver::create_chip_proof`        `ceno_zkvm/src/scheme/prover.rs:717-833`
 //!   `prove_batched_main_constraints`    <-> `BatchedMainConstraintProver`           `ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390`
 //!   `lanes_run`                         <-> `ChipScheduler::execute`                `ceno_zkvm/src/scheme/scheduler.rs:231-336`
-use std::{ffi::c_void, marker::PhantomData, ptr, slice, sync::Arc};
+use std::{ffi::c_void, marker::PhantomData, os::raw::c_int, ptr, slice, sync::Arc};
 
 use ceno_hip_sys as sys;
 
@@ -37,9 +37,26 @@ impl<'a, T: FsTranscript> CTranscript<'a, T> {
         unsafe extern "C" fn base<T: FsTranscript>(s: *mut c_void, v: u64) {
             (*(s as *mut T)).append_base(v);
         }
+        unsafe extern "C" fn bits<T: FsTranscript>(s: *mut c_void, bits: c_int) -> u64 {
+            (*(s as *mut T)).sample_bits(bits as usize) as u64
+        }
+        unsafe extern "C" fn grind<T: FsTranscript>(s: *mut c_void, bits: c_int) -> u64 {
+            (*(s as *mut T)).grind(bits as usize)
+        }
+        unsafe extern "C" fn export<T: FsTranscript>(s: *mut c_void, out16: *mut u64) -> c_int {
+            match (*(s as *mut T)).export_duplex_state() {
+                Some(w) => {
+                    ptr::copy_nonoverlapping(w.as_ptr(), out16, 16);
+                    sys::CENO_TRANSCRIPT_DUPLEX8 as c_int
+                }
+                None => 0,
+            }
+        }
         Self {
+            // no fork / import: a borrowed Rust transcript is neither cloned nor overwritten from the C side
             table: sys::ceno_transcript { append_label: Some(label::<T>), append_ext: Some(ext::<T>), sample_ext: Some(sample::<T>), self_: t as *mut T as *mut c_void,
-                                          destroy: None, append_base: Some(base::<T>) },
+                                          destroy: None, append_base: Some(base::<T>), sample_bits: Some(bits::<T>), fork: None, fork_free: None,
+                                          export_state: Some(export::<T>), import_state: None, grind: Some(grind::<T>) },
             _borrow: PhantomData,
         }
     }

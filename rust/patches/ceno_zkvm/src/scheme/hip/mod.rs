@@ -49,8 +49,8 @@ pub trait HipPcsBridge<E: ExtensionField>: PolynomialCommitmentScheme<E> {
     const LOG_BLOWUP: usize;
     const NUM_QUERIES: usize;
     const POW_BITS: usize;
-    /// one Merkle root (4 base-field words) per committed matrix, with its (num_vars, width)
-    fn commitment_from_roots(roots: &[[u64; 4]], shapes: &[(usize, usize)]) -> Self::Commitment;
+    /// THE Merkle root (4 base-field words) of the mixed-height commitment over all matrices, with their (num_vars, width)
+    fn commitment_from_root(root: [u64; 4], shapes: &[(usize, usize)]) -> Self::Commitment;
     /// flat proof words, layout documented at `ceno_prover_basefold_proof_words` in `include/ceno_prover.h`
     fn proof_from_words(words: Vec<u64>, shapes: &[(usize, usize)]) -> Self::Proof;
 }
@@ -76,10 +76,10 @@ impl<E: ExtensionField, PCS: HipPcsBridge<E> + 'static> TraceCommitter<PB<E, PCS
         let mats: Vec<(&[u64], usize, usize)> = words.iter().zip(traces.values()).map(|(w, t)| (w.as_slice(), t.num_instances(), t.width())).collect();
         let pcs = Arc::new(HipPcsData::commit(&hal, &mats, PCS::LOG_BLOWUP, &stream).expect("commit_traces"));
         let shapes = (0..mats.len()).map(|m| (pcs.num_vars(m), mats[m].2)).collect_vec();
-        let roots = (0..mats.len()).map(|m| pcs.root(m, &stream).expect("root")).collect_vec();
+        let root = pcs.root(&stream).expect("root");
         // witness MLEs = borrowed views of the column-major device trace: nothing is copied or re-uploaded
         let mles = (0..mats.len()).flat_map(|m| (0..mats[m].2).map(move |c| (m, c))).map(|(m, c)| Arc::new(MultilinearExtensionHip::from_hip(pcs.witness_mle(m, c).expect("witness view")))).collect_vec();
-        (mles, pcs, PCS::commitment_from_roots(&roots, &shapes))
+        (mles, pcs, PCS::commitment_from_root(root, &shapes))
     }
 
     fn extract_witness_mles<'a, 'b>(&self, witness_mles: &'b mut Vec<Mle<E>>, _pcs_data: &'b Arc<HipPcsData>) -> Box<dyn Iterator<Item = Mle<E>> + 'b> {
@@ -362,14 +362,22 @@ impl<E: ExtensionField, PCS: HipPcsBridge<E> + 'static> OpeningProver<PB<E, PCS>
             transcript: &mut (impl Transcript<E> + 'static)) -> PCS::Proof {
         let hal = get_hip_hal().expect("HIP HAL");
         let stream = get_thread_stream().unwrap_or_else(|| Arc::new(hal.create_stream().expect("stream")));
-        assert!(fixed_data.is_none(), "fixed traces are opened by a second batch_open call: commit them into the same HipPcsData for now");
-        // one (point, column evaluations) per committed matrix, in commit order (cpu/mod.rs:1426-1440)
-        let (pts, evs): (Vec<Vec<ExtWords>>, Vec<Vec<ExtWords>>) = evals.iter_mut().zip(&points)
+        // rounds = [(witness commitment, openings), (fixed commitment, openings)] (cpu/mod.rs:1426-1455): one (point, column
+        // evaluations) per committed matrix, witness matrices first, then the fixed ones of the chips that have fixed columns
+        let (mut pts, mut evs): (Vec<Vec<ExtWords>>, Vec<Vec<ExtWords>>) = evals.iter_mut().zip(&points)
             .filter_map(|(e, p)| { let w = e.remove(0); (!w.is_empty()).then(|| (exts_words(p), exts_words(&w))) }).unzip();
-        let shapes = (0..pts.len()).map(|m| (witness_data.num_vars(m), witness_data.widths[m])).collect_vec();
+        let mut shapes = (0..pts.len()).map(|m| (witness_data.num_vars(m), witness_data.widths[m])).collect_vec();
+        let fixed = fixed_data.as_ref().map(|f| f.as_ref().as_ref());
+        if let Some(fd) = fixed {
+            let (fp, fe): (Vec<Vec<ExtWords>>, Vec<Vec<ExtWords>>) = evals.iter_mut().zip(&points)
+                .filter_map(|(e, p)| (!e.is_empty() && !e[0].is_empty()).then(|| (exts_words(p), exts_words(&e.remove(0))))).unzip();
+            shapes.extend((0..fp.len()).map(|m| (fd.num_vars(m), fd.widths[m])));
+            pts.extend(fp);
+            evs.extend(fe);
+        }
         let mut adapter = TranscriptAdapter::new(transcript);
         let mut ctr = CTranscript::new(&mut adapter);
-        let words = witness_data.batch_open(&pts, &evs, PCS::NUM_QUERIES, PCS::POW_BITS, ctr.raw(), &stream).expect("batch_open");
+        let words = witness_data.batch_open(fixed, &pts, &evs, PCS::NUM_QUERIES, PCS::POW_BITS, ctr.raw(), &stream).expect("batch_open");
         PCS::proof_from_words(words, &shapes)
     }
 }

@@ -75,6 +75,13 @@ impl<'a, E: ExtensionField, T: Transcript<E>> FsTranscript for TranscriptAdapter
     fn challenge_pows(&mut self, n: usize) -> Vec<ExtWords> {
         exts_words(&sumcheck::util::get_challenge_pows::<E>(n, self.0))
     }
+    // `Transcript<E>: CanObserve<F> + CanSampleBits<usize> + GrindingChallenger` (ceno_recursion_v2/src/tower/tower.rs:85-101)
+    fn sample_bits(&mut self, bits: usize) -> usize {
+        p3::challenger::CanSampleBits::sample_bits(self.0, bits)
+    }
+    fn grind(&mut self, bits: usize) -> u64 {
+        p3::challenger::GrindingChallenger::grind(self.0, bits).as_canonical_u64()
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """GPU parity for the Basefold batch open: the HIP path must emit, word for word, the proof the
-oracle's restated prover emits under the same transcript, and the oracle's restated verifier
-(ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781) must accept it.  PARITY UNPINNED vs the reference (EXT mpcs)."""
+oracle's restated prover emits under the same transcript — stub and Poseidon2 duplex — and the oracle's restated verifier
+(ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781,8125-8204) must accept it.  One mixed-height commitment per
+commit_traces, p3 grinding, one-base-sample query indices.  PARITY UNPINNED vs the reference: constants, label packing."""
 import numpy as np
 import pytest
 
@@ -44,11 +45,66 @@ def test_open_matches_oracle_word_for_word_and_verifies(dev, shapes, rate_log, n
     assert proof.shape == expect.shape
     bad = np.nonzero(proof != expect)[0]
     assert bad.size == 0, f"first mismatch at word {bad[:5]} of {proof.size}"
-    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+    roots = pcs.root().reshape(1, 4)   # ONE commitment for all matrices
     assert np.array_equal(roots, po.basefold_commit_roots(traces, rate_log))
     assert po.basefold_verify(shapes, roots, points, evals, rate_log, nq, pow_bits, po.StubTranscript(0xBF), proof) == 0
     pcs.free()
     dev.stream_destroy(stream)
+
+
+@pytest.mark.parametrize("shapes_w,shapes_f,nq,pow_bits", [
+    ([(6, 3), (4, 2), (6, 1)], [(5, 4), (3, 2)], 6, 5),
+    ([(3, 2)], [(7, 3), (7, 1), (2, 5)], 5, 0),
+])
+def test_open_of_witness_and_fixed_commitments_poseidon2_transcript(dev, shapes_w, shapes_f, nq, pow_bits):
+    """PCS::batch_open over TWO commitments (`rounds` = witness, fixed: cpu/mod.rs:1418-1457) under the Poseidon2 duplex
+    transcript: the product's host challenger + device grinding against the oracle's own challenger, word for word"""
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    shapes = shapes_w + shapes_f
+    traces, points, evals = make_case(11, shapes)
+    pw = prover.PcsData(dev, traces[:len(shapes_w)], 1, stream)
+    pf = prover.PcsData(dev, traces[len(shapes_w):], 1, stream)
+    sizes = [len(shapes_w), len(shapes_f)]
+    proof = pw.basefold_open(points, evals, nq, pow_bits, prover.Transcript.poseidon2(b"open"), more_commits=[pf])
+    expect = po.basefold_open(traces, points, evals, 1, nq, pow_bits, po.DuplexTranscript(b"open"), commit_sizes=sizes)
+    assert proof.shape == expect.shape
+    bad = np.nonzero(proof != expect)[0]
+    assert bad.size == 0, f"first mismatch at word {bad[:5]} of {proof.size}"
+    roots = np.stack([pw.root(), pf.root()])
+    assert np.array_equal(roots, po.basefold_commit_roots(traces, 1, commit_sizes=sizes))
+    assert po.basefold_verify(shapes, roots, points, evals, 1, nq, pow_bits, po.DuplexTranscript(b"open"), proof, commit_sizes=sizes) == 0
+    pw.free()
+    pf.free()
+    dev.stream_destroy(stream)
+
+
+def test_transcript_base_operations_and_grinding_match_the_oracle(dev):
+    """sample_base / sample_bits / check_witness / clone / export-import of the host challenger against the oracle's duplex
+    challenger; the device proof-of-work search finds the oracle's (least) witness for every number of pending inputs"""
+    from ceno_amd import prover
+
+    for n_pre in range(6):
+        t, o = prover.Transcript.poseidon2(b"pow"), po.DuplexTranscript(b"pow")
+        for k in range(n_pre):
+            t.append_base(1000 + k)
+            o.append_base(1000 + k)
+        if n_pre == 5:  # outputs left in the buffer: grinding must clear them
+            assert t.sample_base() == o.sample_base()
+        kind, st = t.export_state()
+        assert kind == 1 and np.array_equal(st, o.export_state())
+        c = t.clone()
+        w = t.grind(dev, 9)
+        assert w == o.grind(9)
+        assert c.check_witness(9, w) and c.sample_ext() == t.sample_ext() == o.sample_ext()
+        assert t.sample_bits(20) == o.sample_bits(20)
+        t2 = prover.Transcript.poseidon2(b"")
+        t2.import_state(t.export_state()[1])
+        assert t2.sample_base() == t.sample_base() == o.sample_base()
+    t, o = prover.Transcript.stub(4), po.StubTranscript(4)   # no exportable state: the host searches through clones
+    assert t.export_state()[0] == 0
+    assert t.grind(dev, 7) == o.grind(7) and t.sample_base() == o.sample_base()
 
 
 def test_open_at_chip_size_verifies(dev):
@@ -70,7 +126,7 @@ def test_open_at_chip_size_verifies(dev):
         evals.append(ev)
     tr = prover.Transcript.poseidon2(b"open")
     proof = pcs.basefold_open(points, evals, 20, 10, tr)
-    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+    roots = pcs.root().reshape(1, 4)
 
     class P2(object):  # the oracle verifier driven by the host library's Poseidon2 transcript through its C table
         def __init__(self):
@@ -145,7 +201,7 @@ def test_open_random_shapes_differential(dev, seed):
     proof = pcs.basefold_open(points, evals, nq, pow_bits, prover.Transcript.stub(seed))
     expect = po.basefold_open(padded, points, evals, rate_log, nq, pow_bits, po.StubTranscript(seed))
     assert np.array_equal(proof, expect)
-    roots = np.stack([pcs.root(i) for i in range(len(shapes))])
+    roots = pcs.root().reshape(1, 4)
     assert po.basefold_verify(shapes, roots, points, evals, rate_log, nq, pow_bits, po.StubTranscript(seed), proof) == 0
     pcs.free()
     dev.stream_destroy(stream)

@@ -182,39 +182,83 @@ def test_poseidon2_set_constants_changes_and_restores(dev):
     assert np.array_equal(_to_np(d).reshape(-1), po.poseidon2_permute(s[0]))
 
 
-def test_commit_traces_matches_oracle_composition(dev):
-    from ceno_amd import prover
-
-    stream = dev.stream_create()
-    blow = 1
-    mats = [po.rand_base(5 * 3, 1).reshape(5, 3), po.rand_base(64 * 22, 2).reshape(64, 22), po.rand_base(1 * 4, 3).reshape(1, 4)]
-    pcs = prover.PcsData(dev, mats, blow, stream)
-    params = po.poseidon2_default_params()
-    for i, m in enumerate(mats):
+def _codewords(mats, blow):
+    """oracle-side codewords of padded traces: (width, rows << blow) column-major, bit-reversed DFT of the zero-extended column"""
+    out, padded_all = [], []
+    for m in mats:
         rows = 2
         while rows < m.shape[0]:
             rows *= 2
         padded = np.zeros((rows, m.shape[1]), dtype=np.uint64)
         padded[: m.shape[0]] = m
-        assert pcs.num_vars(i) == rows.bit_length() - 1
-        # witness MLE views are the (padded) columns
-        for c in (0, m.shape[1] - 1):
-            assert np.array_equal(pcs.witness_mle(i, c).download(), padded[:, c])
-        # codeword = DFT of the zero-extended column, bit-reversed order; leaves hash codeword rows
-        cw = np.stack([po.dft_bitrev(np.concatenate([padded[:, c], np.zeros(rows * ((1 << blow) - 1), dtype=np.uint64)]))
-                       for c in range(m.shape[1])])
-        log_cw = (rows << blow).bit_length() - 1
-        levels = po.merkle_commit(cw, log_cw, m.shape[1], params)
-        assert np.array_equal(pcs.root(i), levels[-1][0])
-        for idx in {0, (rows << blow) - 1, (rows << blow) // 3}:
-            row, path = pcs.open_row(i, idx)
-            assert np.array_equal(row, cw[:, idx])
-            j = idx
-            for l in range(log_cw):
-                assert np.array_equal(path[l], levels[l][j ^ 1])
-                j >>= 1
+        padded_all.append(padded)
+        out.append(np.stack([po.fft_bitrev(np.concatenate([padded[:, c], np.zeros(rows * ((1 << blow) - 1), dtype=np.uint64)]))
+                             for c in range(m.shape[1])]))
+    return out, padded_all
+
+
+@pytest.mark.parametrize("blow", [1, 2])
+def test_commit_traces_matches_oracle_composition(dev, blow):
+    """ONE commitment for all matrices (scheme/cpu/mod.rs:559-584): root, every tree level's opened siblings and the opened rows
+    equal the oracle's mixed-height MMCS over the oracle's codewords; equal heights, a 2-row matrix, ragged instance counts"""
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    mats = [po.rand_base(5 * 3, 1).reshape(5, 3), po.rand_base(64 * 22, 2).reshape(64, 22), po.rand_base(1 * 4, 3).reshape(1, 4),
+            po.rand_base(8 * 2, 4).reshape(8, 2), po.rand_base(33 * 5, 5).reshape(33, 5), po.rand_base(16 * 1, 6).reshape(16, 1)]
+    pcs = prover.PcsData(dev, mats, blow, stream)
+    cws, padded = _codewords(mats, blow)
+    for i, m in enumerate(mats):
+        assert pcs.num_vars(i) == padded[i].shape[0].bit_length() - 1
+        for c in (0, m.shape[1] - 1):  # witness MLE views are the (padded) columns
+            assert np.array_equal(pcs.witness_mle(i, c).download(), padded[i][:, c])
+    levels = po.mmcs_commit(cws)
+    H = len(levels) - 1
+    assert np.array_equal(pcs.root(), levels[-1][0])
+    shapes = [(cw.shape[1].bit_length() - 1, cw.shape[0]) for cw in cws]
+    for idx in sorted({0, (1 << H) - 1, (1 << H) // 3, 5, 64}):
+        rows, path = pcs.open(idx)
+        want_rows, want_path = po.mmcs_open(cws, levels, idx)
+        assert np.array_equal(np.concatenate(rows), want_rows) and np.array_equal(path, want_path)
+        assert po.mmcs_verify(shapes, levels[-1][0], idx, np.concatenate(rows), path) == 0
     pcs.free()
     dev.stream_destroy(stream)
+
+
+def test_mmcs_commit_scattered_matrices_and_tall_injection(dev):
+    """ceno_hip_mmcs_commit on matrices that are NOT stored back to back (one segment each), with matrices joining at levels
+    above AND below the 2^14-node switch between the lane-per-node and the 8-lanes-per-node kernels; all levels vs the oracle"""
+    import ctypes as C
+
+    import torch
+
+    shapes = [(16, 2), (10, 3), (16, 1), (15, 2), (3, 5), (15, 1), (0, 2), (12, 7)]
+    mats = [po.rand_base((1 << lr) * w, 40 + i).reshape(w, 1 << lr) for i, (lr, w) in enumerate(shapes)]
+    d_mats = [torch.from_numpy(m.view(np.int64)).to("cuda:0") for m in mats]
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in d_mats])
+    lr = (C.c_int * n)(*[s_[0] for s_ in shapes])
+    ws = (C.c_int * n)(*[s_[1] for s_ in shapes])
+    h = C.c_void_p()
+    dev.check(dev.L.ceno_hip_mmcs_commit(dev.h, ptrs, lr, ws, n, None, C.byref(h)))
+    levels = po.mmcs_commit(mats)
+    root = np.zeros(4, dtype=np.uint64)
+    dev.check(dev.L.ceno_hip_merkle_root(dev.h, h, root.ctypes.data_as(C.POINTER(C.c_uint64)), None))
+    assert np.array_equal(root, levels[-1][0])
+    words = int(dev.L.ceno_hip_mmcs_opening_words(h))
+    assert words == sum(w for _, w in shapes) + 4 * 16
+    idx = np.array([0, 1, 65535, 40000, 12345, 32768], dtype=np.uint64)
+    d_idx = torch.from_numpy(idx.view(np.int64)).to("cuda:0")
+    d_out = torch.zeros(len(idx) * (words + 3), dtype=torch.int64, device="cuda:0")
+    dev.check(dev.L.ceno_hip_mmcs_open_batch(dev.h, h, d_idx.data_ptr(), len(idx), 0, d_out.data_ptr(), words + 3, None))
+    dev.sync()
+    got = d_out.cpu().numpy().view(np.uint64).reshape(len(idx), words + 3)
+    for q, i in enumerate(idx):
+        rows, path = po.mmcs_open(mats, levels, int(i))
+        assert np.array_equal(got[q, : len(rows)], rows), q
+        assert np.array_equal(got[q, len(rows): words].reshape(-1, 4), path), q   # every level's sibling = the whole tree is right
+        assert po.mmcs_verify(shapes, root, int(i), rows, path) == 0
+    dev.check(dev.L.ceno_hip_merkle_free(dev.h, h))
 
 
 def test_sharded_commit_virtual_ranks_equals_single_device(dev):
@@ -233,7 +277,7 @@ def test_sharded_commit_virtual_ranks_equals_single_device(dev):
     full = po.rand_base(rows * sum(width_split), 77).reshape(rows, sum(width_split))
     stream = dev.stream_create()
     pcs = prover.PcsData(dev, [full], blow, stream)
-    want = pcs.root(0)
+    want = pcs.root()
     slots = {"g": [None] * world, "a2a": [None] * world}
     bar = threading.Barrier(world)
 
@@ -312,7 +356,7 @@ def test_native_sharded_commit_local_group_equals_single_device(dev, world, widt
     full = po.rand_base(rows * wt, 91).reshape(rows, wt)
     stream = dev.stream_create()
     pcs = prover.PcsData(dev, [full], blow, stream)
-    want = pcs.root(0)
+    want = pcs.root()
     group = L.ceno_dist_local_group_create(world)
     assert group
     res, errors = [None] * world, []
@@ -366,7 +410,7 @@ def test_native_sharded_commit_world1_through_rccl_self_exchange(dev, monkeypatc
     full = po.rand_base((1 << log_rows) * w, 92).reshape(1 << log_rows, w)
     stream = dev.stream_create()
     pcs = prover.PcsData(dev, [full], blow, stream)
-    want = pcs.root(0)
+    want = pcs.root()
     comm = prover.RcclComm(1, 0, None)
     d_cols = torch.from_numpy(np.ascontiguousarray(full.T).view(np.int64).copy()).to("cuda:0")
     torch.cuda.synchronize()
@@ -383,26 +427,25 @@ def test_native_sharded_commit_world1_through_rccl_self_exchange(dev, monkeypatc
     dev.stream_destroy(stream)
 
 
-def test_commit_of_several_matrices_on_a_fresh_context_equals_one_by_one():
-    """commit_traces queues its matrices on two alternating streams.  On a FRESH context the first transform of a size also
-    builds that size's twiddle table, which the other stream then shares: two matrices of one size (the last two chips of a
-    shard) must still give the roots of committing each alone (regression: the table used to be visible before it was complete)"""
+def test_commit_of_several_matrices_on_a_fresh_context_equals_a_warm_one():
+    """On a FRESH context the first transform of a size also builds that size's twiddle table (a per-context cache): the
+    commitment of a shard's traces, two of them of one size, must not depend on whether the caches are warm (regression: a table
+    used to be visible before it was complete) and must equal the oracle's mixed-height commitment"""
     from ceno_amd import Device, prover
 
     shapes = [(1 << 12, 5), (1 << 11, 3), (1 << 9, 4), (1 << 9, 4), (1 << 7, 2), (1 << 7, 6)]
     mats = [po.rand_base(r * w, 300 + i).reshape(r, w) for i, (r, w) in enumerate(shapes)]
-    d1 = Device(0)
-    s1 = d1.stream_create()
-    together = prover.PcsData(d1, mats, 1, s1)
-    roots = [together.root(m).copy() for m in range(len(mats))]
-    together.free()
-    d1.stream_destroy(s1)
-    d1.close()
-    d2 = Device(0)
-    s2 = d2.stream_create()
-    for m, mat in enumerate(mats):
-        alone = prover.PcsData(d2, [mat], 1, s2)
-        assert np.array_equal(alone.root(0), roots[m]), m
-        alone.free()
-    d2.stream_destroy(s2)
-    d2.close()
+    roots = []
+    for warm in (False, True):
+        d1 = Device(0)
+        s1 = d1.stream_create()
+        for _ in range(2 if warm else 1):
+            together = prover.PcsData(d1, mats, 1, s1)
+            root = together.root().copy()
+            together.free()
+        roots.append(root)
+        d1.stream_destroy(s1)
+        d1.close()
+    assert np.array_equal(roots[0], roots[1])
+    cws, _ = _codewords(mats, 1)
+    assert np.array_equal(roots[0], po.mmcs_commit(cws)[-1][0])

@@ -209,7 +209,7 @@ def test_config3_add_chip_full_flow(dev, prover, log_rows):
     host[num_instances:] = 0  # InstancePaddingStrategy::Default
     stream = dev.stream_create()
     pcs = prover.PcsData(dev, [host], log_blowup, stream)
-    root = pcs.root(0)
+    root = pcs.root()
     tr = prover.Transcript.stub(0xADD)
     tr.append_ext((int(root[0]), int(root[1])))
     tr.append_ext((int(root[2]), int(root[3])))

@@ -34,6 +34,7 @@ def rust_width(t: str) -> str:
 
 def split_top(s: str):
     out, depth, cur = [], 0, ""
+    s = s.replace("->", "\u2192")  # the arrow of a fn-pointer return type is not a closing bracket
     for ch in s:
         if ch in "(<[":
             depth += 1
@@ -46,7 +47,7 @@ def split_top(s: str):
             cur += ch
     if cur.strip():
         out.append(cur)
-    return [x.strip() for x in out]
+    return [x.strip().replace("\u2192", "->") for x in out]
 
 
 def parse_rust(path=SYS_RS):
