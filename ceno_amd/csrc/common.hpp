@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -44,7 +45,10 @@ struct ceno_hip_ctx {
     char* vram_arena = nullptr;
     std::vector<int> vram_free_slots;
     // ---- persistent multi-workgroup kernels (k_mid) wait for each other and must ALL be resident: workgroups in flight ----
-    int mid_wgs_in_flight = 0;  // guarded by `mu`; budget MID_WG_BUDGET (sumcheck.hip)
+    // Booked in units of 1/64 of a compute unit: a launch of W workgroups at an occupancy of `nb` workgroups per CU (what
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor reports for its dynamic LDS) costs ceil(64 W / nb); the chip offers
+    // 64 * num_cus minus headroom.  An atomic of its own: round enqueues never contend with the pool mutex.
+    std::atomic<int> mid_wgs_in_flight{0};
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----
@@ -74,7 +78,8 @@ struct ceno_hip_mle {
 
 int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
-void ctx_free(ceno_hip_ctx* ctx, void* p);
+void ctx_free(ceno_hip_ctx* ctx, void* p);                         // tag = the stream the calling thread resolved last
+void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner);   // tag = the stream that used the block
 // pinned, device-mapped host memory from a per-context cache; *dev_view is the device address of *host
 // 64-byte slot of fine-grained device memory the host can write through the BAR (nullptr when unavailable)
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx);
@@ -85,9 +90,15 @@ void ctx_pinned_free(ceno_hip_ctx* ctx, void* host);
 // thread starts on device 0, and allocations / stream creation / launches follow the CURRENT device, not the context's
 void ctx_make_current(ceno_hip_ctx* ctx);
 // every entry point that touches the device resolves its stream through here, which also makes the device current
-extern thread_local hipStream_t ceno_tls_stream;  // the stream the calling thread resolved last (ctx.hip)
+extern thread_local hipStream_t ceno_tls_stream;   // the stream the calling thread resolved last (ctx.hip)
+extern thread_local hipStream_t ceno_tls_adopted;  // the last caller-made stream this thread registered with the context
+void ctx_adopt_stream(ceno_hip_ctx* ctx, hipStream_t s);
 inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     ctx_make_current(ctx);
+    if (s && (hipStream_t)s != ceno_tls_adopted) {  // streams the library did not create are adopted on first use
+        ctx_adopt_stream(ctx, (hipStream_t)s);
+        ceno_tls_adopted = (hipStream_t)s;
+    }
     return ceno_tls_stream = (s ? (hipStream_t)s : ctx->default_stream);
 }
 

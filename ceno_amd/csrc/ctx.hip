@@ -40,6 +40,7 @@ static size_t bucket_size(size_t bytes) {
 }
 
 thread_local hipStream_t ceno_tls_stream = nullptr;
+thread_local hipStream_t ceno_tls_adopted = nullptr;
 
 static bool stream_alive(ceno_hip_ctx* ctx, hipStream_t s) {
     if (s == ctx->default_stream) return true;
@@ -47,9 +48,33 @@ static bool stream_alive(ceno_hip_ctx* ctx, hipStream_t s) {
         if (t == s) return true;
     return false;
 }
+// a stream the library did not create (a torch stream, a Rust-side stream) becomes known the first time a thread resolves it:
+// blocks freed while it still has work queued then wait for it to drain like those of the library's own streams
+void ctx_adopt_stream(ceno_hip_ctx* ctx, hipStream_t s) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!stream_alive(ctx, s)) ctx->streams.push_back(s);
+}
+// has everything queued on `s` finished?  A handle the runtime no longer knows (destroyed behind the library's back) has
+// nothing queued either; the sticky error of that query is cleared.
+static bool stream_drained(hipStream_t s) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return true;
+    if (e == hipErrorNotReady) return false;
+    (void)hipGetLastError();
+    return true;
+}
 
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     size_t b = bucket_size(bytes);
+    // hipFree waits for every stream of the device, and a lane's queued round kernels wait for a host that may be waiting
+    // for this mutex: blocks that go back to the driver are only COLLECTED under the mutex and released after it is dropped
+    std::vector<void*> victims;
+    struct Release {
+        std::vector<void*>& v;
+        ~Release() {
+            for (void* p : v) (void)hipFree(p);
+        }
+    } release{victims};
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
@@ -82,7 +107,7 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                     if (j == n_seen) {
                         if (n_seen == 16) break;
                         seen[n_seen] = last;
-                        idle[n_seen] = hipStreamQuery(last) == hipSuccess;
+                        idle[n_seen] = stream_drained(last);
                         n_seen++;
                     }
                     if (idle[j]) pick = k;
@@ -102,7 +127,7 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
             // try to make room by dropping cached blocks
             for (auto& kv : ctx->free_lists) {
                 for (auto& p : kv.second) {
-                    (void)hipFree(p.first);
+                    victims.push_back(p.first);
                     ctx->pool_cached -= kv.first;
                 }
                 kv.second.clear();
@@ -124,7 +149,7 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                 auto& fl = kv.second;
                 for (size_t k = 0; k < fl.size();) {
                     if (fl[k].second == nullptr) {
-                        (void)hipFree(fl[k].first);
+                        victims.push_back(fl[k].first);
                         ctx->pool_cached -= kv.first;
                         fl[k] = fl.back();
                         fl.pop_back();
@@ -135,6 +160,8 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
             }
         }
     }
+    for (void* v : victims) (void)hipFree(v);  // outside the mutex (see above)
+    victims.clear();
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
         // drop the cache and retry once
@@ -149,8 +176,13 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     return 0;
 }
 
-void ctx_free(ceno_hip_ctx* ctx, void* p) {
+void ctx_free(ceno_hip_ctx* ctx, void* p) { ctx_free_on(ctx, p, ceno_tls_stream ? ceno_tls_stream : ctx->default_stream); }
+
+// `owner` = the stream that used the block last (an object that carries its own stream frees with it, whatever stream the
+// calling thread happened to resolve last)
+void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner) {
     if (!p) return;
+    if (!owner) owner = ctx->default_stream;
     std::lock_guard<std::mutex> g(ctx->mu);
     auto it = ctx->live.find(p);
     if (it == ctx->live.end()) return;
@@ -162,8 +194,8 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) {
     // drained, the block is free for everybody (no tag) — otherwise blocks freed after a synchronisation by a thread that
     // alternates between streams (commit_traces, the opening) could only ever go back to the stream of the tag, and every run
     // would allocate the other stream's share afresh (measured: +230 MB of cache per shard flow).
-    hipStream_t tag = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
-    if (b >= ((size_t)64 << 10) && stream_alive(ctx, tag) && hipStreamQuery(tag) == hipSuccess) tag = nullptr;
+    hipStream_t tag = owner;
+    if (b >= ((size_t)64 << 10) && stream_alive(ctx, tag) && stream_drained(tag)) tag = nullptr;
     ctx->free_lists[b].push_back({p, tag});
 }
 
@@ -354,6 +386,7 @@ int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
             }
     }
     if (ceno_tls_stream == (hipStream_t)s) ceno_tls_stream = nullptr;
+    if (ceno_tls_adopted == (hipStream_t)s) ceno_tls_adopted = nullptr;
     HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));
     return 0;
 }
@@ -402,14 +435,18 @@ size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
 }
 
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
-    std::lock_guard<std::mutex> g(ctx->mu);
-    for (auto& kv : ctx->free_lists) {
-        for (auto& p : kv.second) {
-            (void)hipFree(p.first);
-            ctx->pool_cached -= kv.first;
+    std::vector<void*> victims;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        for (auto& kv : ctx->free_lists) {
+            for (auto& p : kv.second) {
+                victims.push_back(p.first);
+                ctx->pool_cached -= kv.first;
+            }
+            kv.second.clear();
         }
-        kv.second.clear();
     }
+    for (void* p : victims) (void)hipFree(p);  // hipFree waits for the device: never under the pool mutex
     return 0;
 }
 

@@ -761,8 +761,9 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         __atomic_store_n(&sc->h_mailbox->abort, 1ull, __ATOMIC_RELEASE);  // queued kernels exit at their wait
         host_store_fence();
     }
-    // a finished sumcheck has nothing in flight (finish synchronised the stream after its last kernel): no second wait —
-    // it was ~20 us per tower layer
+    // a finished sumcheck may still have its last kernel's trailing stores in flight (finish takes the evaluations from armed
+    // pinned words and does not synchronise): no wait here either — it was ~20 us per tower layer — the buffers go back to the
+    // pool tagged with THIS sumcheck's stream (ctx_free_on below), so another stream gets them only once it has drained
     if (!sc->finished) (void)hipStreamSynchronize(sc->st);
     if (sc->pipelined && getenv("CENO_HIP_DEBUG") && sc->d_bcast) {
         static Bcast hb;
@@ -774,11 +775,10 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         }
     }
     if (sc->mid_reserved) {
-        std::lock_guard<std::mutex> g(sc->ctx->mu);
-        sc->ctx->mid_wgs_in_flight -= sc->mid_reserved;
+        sc->ctx->mid_wgs_in_flight.fetch_sub(sc->mid_reserved);
         sc->mid_reserved = 0;
     }
-    for (void* p : sc->dev_allocs) ctx_free(sc->ctx, p);
+    for (void* p : sc->dev_allocs) ctx_free_on(sc->ctx, p, sc->st);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
     ctx_vram_slot_free(sc->ctx, sc->vram_slot);
@@ -1671,27 +1671,32 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             }
             {
                 // Residency budget: the workgroups of a k_mid launch wait for each other, so all of them must fit on the chip
-                // next to every other such launch in flight (lanes): 256 CUs x 2 workgroups of <= 60 KB LDS, minus headroom.
-                static constexpr int MID_WG_BUDGET = 448;
-                int W = 0, S0 = 0, w_free = 0;
-                {
-                    std::lock_guard<std::mutex> g(ctx->mu);
-                    w_free = MID_WG_BUDGET - ctx->mid_wgs_in_flight;
+                // next to every other such launch in flight (lanes).  Capacity and cost come from the runtime's occupancy for
+                // the launch's own dynamic LDS and the device's CU count (units of 1/64 CU, 1/8 of the chip kept as headroom
+                // for everything else that is resident); a launch that does not fit falls back to the per-round kernels.
+                const int capacity = ctx->num_cus * 64 - ctx->num_cus * 8;
+                int W = 0, S0 = 0, cost = 0;
+                if (!sc->mid_reserved && sc->d_mid_rows) {
+                    mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, 1 << 30, &W, &S0);  // slice size first: it fixes the LDS
+                    int nb = W ? mid_blocks_per_cu(sc->d, k, (size_t)S0, (size_t)cl.n_flat) : 0;
+                    if (nb > 0) {
+                        const int free_units = capacity - ctx->mid_wgs_in_flight.load();
+                        mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, (int)std::min<long long>((long long)free_units * nb / 64, 1 << 20), &W, &S0);
+                        nb = W ? mid_blocks_per_cu(sc->d, k, (size_t)S0, (size_t)cl.n_flat) : 0;  // fewer workgroups = larger slices
+                    }
+                    if (nb > 0) cost = (W * 64 + nb - 1) / nb;
+                    else W = 0;
                 }
-                mid_geometry(k, pairs, sc->d, (size_t)cl.n_flat, (sc->mid_reserved || !sc->d_mid_rows) ? 0 : w_free, &W, &S0);
                 // rounds i .. i1 in one launch of W resident workgroups, i1 = the last round too large for the tail kernel
                 int i1 = i;
                 while (i1 + 1 < sc->n && !tail_eligible(k, pairs >> (i1 + 1 - i), sc->d, (size_t)cl.n_flat)) i1++;
                 bool booked = false;
                 if (W >= 4 && i1 > i && i1 + 1 < sc->n && (pairs >> (i1 - i)) >= (size_t)W) {
-                    std::lock_guard<std::mutex> g(ctx->mu);
-                    if (ctx->mid_wgs_in_flight + W <= MID_WG_BUDGET) {  // (another lane may have taken it meanwhile)
-                        ctx->mid_wgs_in_flight += W;
-                        booked = true;
-                    }
+                    int cur = ctx->mid_wgs_in_flight.load();
+                    while (cur + cost <= capacity && !booked) booked = ctx->mid_wgs_in_flight.compare_exchange_weak(cur, cur + cost);
                 }
                 if (booked) {
-                    sc->mid_reserved = W;
+                    sc->mid_reserved = cost;
                     static std::atomic<unsigned long long> nonce_src{0};
                     const unsigned long long nonce = (++nonce_src) & ((1ull << 56) - 1);
                     // armed rows (every word MSG_INVALID since the set-up kernel; the reducer re-arms what it reads) + relay lines

@@ -1,6 +1,9 @@
 // Small and mid-size rounds of a pipelined generic sumcheck: see sumcheck_small.hpp.  Reference semantics: the rounds of
 // IOPProverState::prove (EXT sumcheck crate; call sites gkr_iop/src/gkr/layer/cpu/mod.rs:80-96, ceno_zkvm/src/scheme/cpu/mod.rs:409-494)
 // on tables that fit in LDS or nearly so, where a round is a latency chain and not a bandwidth problem.
+#include <map>
+#include <mutex>
+
 #include "sumcheck_small.hpp"
 
 #include <algorithm>
@@ -265,7 +268,8 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
 // last round too large for the single-workgroup tail: the slices go back to memory and the tail kernel, already queued, takes
 // over (its rounds cost ~9.5 us against ~15 us here, so nothing that fits the tail is kept).
 // Relay words carry a per-sumcheck nonce, so the lines need no clearing.  All W workgroups must be resident at once
-// (they wait for each other): W <= 64 with <= 64 KB of LDS each leaves room for eight such launches on 256 CUs.
+// (they wait for each other): the host books every launch against a residency budget computed from the runtime's occupancy
+// for the launch's own dynamic LDS and the device's CU count (sumcheck.hip, mid_blocks_per_cu), W <= 256.
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restrict__ out_slots, int n_mles, int n_flat, int S0, int i0, int i1, E2 r,
@@ -549,6 +553,42 @@ void mid_geometry(size_t n_mles, size_t pairs, int d, size_t n_flat, int w_cap, 
     const size_t w = std::min<size_t>((size_t)w_cap, pairs / 2);  // at least two pairs per workgroup in the first round
     *W = (int)w;
     *S0 = (int)(pairs / w);
+}
+template <int D>
+static int mid_occupancy_d(size_t lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mid<D>, NT, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return nb;
+}
+int mid_blocks_per_cu(int d, size_t n_mles, size_t S0, size_t n_flat) {
+    const size_t lds = mid_lds_bytes(n_mles, S0, std::min(std::max(d, 1), 8), n_flat);
+    // cached by (degree, LDS rounded up to 2 KB): the query costs a few microseconds and sits in front of every tower layer
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, int> cache;
+    const std::pair<int, size_t> key{std::min(std::max(d, 1), 8), (lds + 2047) / 2048};
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    const size_t q = key.second * 2048;
+    int nb = 0;
+    switch (key.first) {
+    case 1: nb = mid_occupancy_d<1>(q); break;
+    case 2: nb = mid_occupancy_d<2>(q); break;
+    case 3: nb = mid_occupancy_d<3>(q); break;
+    case 4: nb = mid_occupancy_d<4>(q); break;
+    case 5: nb = mid_occupancy_d<5>(q); break;
+    case 6: nb = mid_occupancy_d<6>(q); break;
+    case 7: nb = mid_occupancy_d<7>(q); break;
+    default: nb = mid_occupancy_d<8>(q); break;
+    }
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = nb;
+    return nb;
 }
 template <int D>
 static void launch_mid_d(const DevPlan& pl, const MleSlot* out_slots, int n_mles, int n_flat, int W, int S0, int i0, int i1, const Epilogue& ep,

@@ -16,6 +16,8 @@ int tile_pairs(size_t n_flat, size_t n_mles, size_t pairs);
 bool tile_eligible(size_t n_mles, size_t pairs);
 bool tail_eligible(size_t n_mles, size_t pairs, int d, size_t n_flat);
 void mid_geometry(size_t n_mles, size_t pairs, int d, size_t n_flat, int w_cap, int* W, int* S0);
+// resident k_mid<d> workgroups per compute unit at the dynamic LDS of slices of S0 pairs (runtime occupancy query, cached); 0 = none fit
+int mid_blocks_per_cu(int d, size_t n_mles, size_t S0, size_t n_flat);
 void launch_tile(int d, const DevPlan& pl, int n_mles, int n_flat, size_t pairs, E2 r, const Epilogue& ep, hipStream_t st);
 void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
                  E2* out_evals, hipStream_t st);

@@ -141,6 +141,11 @@ pub struct ThreadStreamGuard;
 impl Drop for ThreadStreamGuard {
     fn drop(&mut self) {
         THREAD_STREAM.with(|c| *c.borrow_mut() = None);
+        // the C side keeps the last bound stream per thread as the tag of freed blocks: point it back at the context's default
+        // stream, or a later free on this thread would be tagged with a stream that may since have been destroyed elsewhere
+        if let Ok(hal) = get_hip_hal() {
+            unsafe { sys::ceno_hip_stream_bind(hal.ctx, ptr::null_mut()) };
+        }
     }
 }
 /// the thread's stream, or `None` = the context's default stream (a null `ceno_hip_stream`)

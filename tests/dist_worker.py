@@ -136,15 +136,51 @@ def main_shm(out_dir, iters):
     dist.destroy_process_group()
 
 
+class FileRendezvous:
+    """the three collectives ShmComm needs from a launcher (segment name broadcast, two barriers), through files of the test's
+    temporary directory: the GPU workers of tests/test_gpu_dist.py then start without importing torch (dozens of processes)"""
+
+    def __init__(self, directory, rank, world):
+        self.d, self.rank, self.world, self.seq = directory, rank, world, 0
+
+    def all_gather_object(self, out, obj):
+        import pickle
+        import time
+
+        self.seq += 1
+        mine = os.path.join(self.d, f"rv{self.seq}_{self.rank}.pkl")
+        with open(mine + ".tmp", "wb") as f:
+            pickle.dump(obj, f)
+        os.rename(mine + ".tmp", mine)  # atomic: a reader never sees a partial file
+        t0 = time.time()
+        for r in range(self.world):
+            path = os.path.join(self.d, f"rv{self.seq}_{r}.pkl")
+            while not os.path.exists(path):
+                if time.time() - t0 > 300:
+                    raise TimeoutError(f"rank {r} did not reach rendezvous {self.seq}")
+                time.sleep(0.002)
+            with open(path, "rb") as f:
+                out[r] = pickle.load(f)
+
+    def broadcast_object_list(self, objs, src=0):
+        got = [None] * self.world
+        self.all_gather_object(got, list(objs))
+        objs[:] = got[src]
+
+    def barrier(self):
+        self.all_gather_object([None] * self.world, 0)
+
+    def destroy_process_group(self):
+        pass
+
+
 def main_shm_gpu(out_dir, n_local):
     """the C++ sharded driver with the shared-memory exchange, `world` PROCESSES sharing GPU 0 (no RCCL on this path,
     so several ranks may use the same device): real HIP engine, real cross-process exchange"""
-    import torch.distributed as dist
-
     from ceno_amd import Device
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dist = FileRendezvous(out_dir, rank, world)
     dev = Device(0)
     k = 3
     tables = [po.fill_splitmix(2 << n_local, 0xCE10 + j, rank * 2 * (1 << n_local)).reshape(-1, 2) for j in range(k)]
@@ -161,12 +197,10 @@ def main_shm_gpu(out_dir, n_local):
 
 def main_shm_gpu_batched(out_dir, n_total):
     """C++ mixed-size batched sharded driver, `world` processes sharing GPU 0"""
-    import torch.distributed as dist
-
     from ceno_amd import Device
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dist = FileRendezvous(out_dir, rank, world)
     log_w = world.bit_length() - 1
     dev = Device(0)
     classes = []
@@ -188,16 +222,16 @@ def main_shm_gpu_batched(out_dir, n_total):
 
 
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":
+        return main_shm_gpu(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_batched":
+        return main_shm_gpu_batched(sys.argv[1], int(sys.argv[2]))
     import torch.distributed as dist
 
     if len(sys.argv) > 3 and sys.argv[3] == "batched":
         return main_batched(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm":
         return main_shm(sys.argv[1], int(sys.argv[2]))
-    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":
-        return main_shm_gpu(sys.argv[1], int(sys.argv[2]))
-    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_batched":
-        return main_shm_gpu_batched(sys.argv[1], int(sys.argv[2]))
     out_dir = sys.argv[1]
     n_local = int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])

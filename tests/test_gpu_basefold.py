@@ -171,7 +171,7 @@ def test_batch_columns_and_fold_commit_primitives(dev):
         assert (int(got[i, 0]), int(got[i, 1])) == want
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", [s_ if s_ < 6 else pytest.param(s_, marks=pytest.mark.slow) for s_ in range(10)])
 def test_open_random_shapes_differential(dev, seed):
     """seeded random commitments (1-5 matrices, 1-9 variables, 1-9 columns, blow-up 2 or 4, ragged row counts that are
     zero padded) opened at random points: proof equal to the oracle's word for word, verifier accepts"""

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,n_local", [(2, 9), (4, 7), (8, 5)])
+@pytest.mark.parametrize("world,n_local", [(2, 9), (4, 7), pytest.param(8, 5, marks=pytest.mark.slow)])
 def test_cpp_sharded_driver_shared_memory_exchange(world, n_local):
     with tempfile.TemporaryDirectory() as tmp:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + world), WORLD_SIZE=str(world))
@@ -36,7 +36,7 @@ def test_cpp_sharded_driver_shared_memory_exchange(world, n_local):
         assert np.array_equal(res[r]["fin"], ofin)
 
 
-@pytest.mark.parametrize("world,n_total", [(1, 7), (2, 8), (4, 9)])
+@pytest.mark.parametrize("world,n_total", [pytest.param(1, 7, marks=pytest.mark.slow), (2, 8), (4, 9)])
 def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
     """SURVEY section 8(e) mixed-size batches through the C++ driver (ceno_dist_batched_sumcheck_prove): classes sharded
     along their own top bits or replicated, `world` processes on one GPU, against the single-prover oracle proof"""
@@ -64,7 +64,7 @@ def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
         assert np.array_equal(res[r]["fin"], ofin)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.slow)])
 def test_bench_py_multi_rank_launch_end_to_end(world):
     """`bench.py --gpus N` exactly as the driver launches it (python -m torch.distributed.run, one rank per GPU), on a 1-GPU box:
     CENO_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 with a gloo process group, so the whole N > 1 flow runs — reference

@@ -809,7 +809,7 @@ def test_lane_scheduler_runs_every_task_once_with_booking(dev, prover):
             assert np.array_equal(g, e)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", [s_ if s_ < 12 else pytest.param(s_, marks=pytest.mark.slow) for s_ in range(24)])
 def test_sumcheck_random_plans_differential(dev, prover, seed):
     """seeded random plans against the oracle: 1-3 size classes (front-loading), base / ext tables, 1-9 terms of degree
     1-5, optional common-factor groups, sizes on both sides of the tile / two-kernel / dense thresholds, pipelined and
@@ -854,7 +854,7 @@ def test_sumcheck_random_plans_differential(dev, prover, seed):
     sc.free()
 
 
-@pytest.mark.parametrize("seed", range(28))
+@pytest.mark.parametrize("seed", [s_ if s_ < 14 else pytest.param(s_, marks=pytest.mark.slow) for s_ in range(28)])
 def test_sumcheck_random_plans_lds_blocked_kernel(dev, prover, seed, monkeypatch):
     """the LDS-blocked generic kernel (k_gen, csrc/sumcheck_gen.hip) forced onto small plans: 1-3 size classes, several
     chips (connected components) per class with their own selectors, first rounds over base-field columns (the base-field
