@@ -7,8 +7,10 @@ torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
 A "step" = one complete sumcheck of prod_{k<3} f_k over synthetic GoldilocksExt2 tables already
 resident in HBM: begin, n rounds (each: fused fold+accumulate pass, message to the host transcript,
 challenge back), finish.  N=1 workload: BASELINE.json config "sumcheck, 3 MLEs, Goldilocks-ext2" at the
-size the metric is quoted on, nv=26 (3 x 2^26 x 16 B = 3.2 GB).  N>1: weak scaling — every rank keeps a
-2^26 shard of a 2^(26+log2 N) hypercube (top-bit sharding, one all-gather of partials per round).
+size the metric is quoted on, nv=26 (3 x 2^26 x 16 B = 3.2 GB).  N>1: STRONG scaling is the headline — the nv=26
+hypercube split over the N ranks by its top log2 N bits (BASELINE's metric is quoted at nv=26; config #4 is "nv=26 sharded
+over 8") — and the weak-scaling run (a 2^26 shard per rank of a 2^(26+log2 N) hypercube) is timed beside it and reported under
+`weak_scaling`; one exchange of the d partial evaluations per round.
 
 Algorithmic work: ext mults = d^2 (2^n - 1), d = 3; bytes = 3*d*16*2^n.
 """
@@ -76,17 +78,19 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
                    "ext_mults_per_s": K * K * ((1 << 22) - 1) / (ms * 1e-3), "roofline": roof(3 * K * 16 * (1 << 22), ms)}
     for m in m22:
         m.free()
-    # config #4 shape on one GPU: batched main-constraint sumcheck, 24 chips, max_nv = 24
-    jobs, elems = synthetic.batched_jobs(dev, 24, 12)
-    mj = prover.MainJobs(jobs)  # the C view of the job list, marshalled once (a Rust caller hands the structs over directly)
-    ms = best_of(lambda: prover.prove_batched_main_constraints(dev, mj, [(11, 22), (33, 44)], new_transcript()))
-    out["batched_main"] = {"workload": "config #4 shape: prove_batched_main_constraints, 24 chips of 14..24 variables, 12 base columns + "
-                                       "selector, 16 terms of degree <= 4 each", "ms": ms, "table_elements": elems,
-                           "roofline": roof(synthetic.batched_algorithmic_bytes(24, 12), ms, "integer-ALU bound: DESIGN.md section 3")}
-    for j in jobs:
-        for m in j["mles"]:
-            if m is not None:
-                m.free()
+    # config #4 on one GPU: batched main-constraint sumcheck over 24 chips, at the config's stated size (max_nv = 26) and at 24
+    for max_nv, key in ((26, "batched_main_nv26"), (24, "batched_main")):
+        jobs, elems = synthetic.batched_jobs(dev, max_nv, 12)
+        mj = prover.MainJobs(jobs)  # the C view of the job list, marshalled once (a Rust caller hands the structs over directly)
+        ms = best_of(lambda: prover.prove_batched_main_constraints(dev, mj, [(11, 22), (33, 44)], new_transcript()))
+        out[key] = {"workload": f"config #4{' shape' if max_nv != 26 else ''}: prove_batched_main_constraints, 24 chips of {max_nv - 10}..{max_nv} "
+                                "variables, 12 base columns + selector, 16 terms of degree <= 4 each", "ms": ms, "table_elements": elems,
+                    "roofline": roof(synthetic.batched_algorithmic_bytes(max_nv, 12), ms, "integer-ALU bound: DESIGN.md section 3")}
+        for j in jobs:
+            for m in j["mles"]:
+                if m is not None:
+                    m.free()
+        del mj, jobs
     # config #3: ADD-shaped chip, 2^20 rows x 22 columns, commit -> chip proof -> main constraints -> open
     flow = synthetic.ChipFlow(dev, prover, 20, 22)
     best = None
@@ -117,6 +121,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
                       "and the emulator are upstream and excluded")
     out["shard_e2e"] = bs
     out["chip_flow_ms"], out["batched_main_ms"], out["nv22_ms"] = best["total_ms"], out["batched_main"]["ms"], out["nv22"]["ms"]
+    out["batched_main_nv26_ms"] = out["batched_main_nv26"]["ms"]
     out["shard_e2e_sec"] = bs["e2e_prover_sec_for_2p20_cycles"]
     return out
 
@@ -126,7 +131,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nv", type=int, default=26, help="variables per GPU shard")
+    ap.add_argument("--nv", type=int, default=26, help="variables of the hypercube the metric is quoted on (strong scaling: of the WHOLE "
+                                                       "hypercube, split over the ranks; weak scaling: of every rank's shard)")
+    ap.add_argument("--scaling", choices=["strong", "weak", "both"], default="both",
+                    help="N > 1: strong = the nv-variable hypercube split over the ranks (BASELINE's metric is quoted at nv=26: the headline), "
+                         "weak = an nv-variable shard per rank; both (default) times both and reports the strong one as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the config #2 / #3 / #4 shaped measurements reported under `extra`")
     ap.add_argument("--transcript", choices=["poseidon2", "stub"], default="poseidon2",
@@ -165,12 +174,8 @@ def main():
     dev = Device(local_rank)
     from ceno_amd import goldens
     poseidon2_pinned = goldens.install(dev)  # reference constants when tests/golden/ref_goldens.json exists (README "Closing parity")
-    n_local = args.nv
     log_w = world.bit_length() - 1
-    n_total = n_local + log_w
-    # shard `rank` of table j: words [rank * 2 * 2^n_local, ...) of the SplitMix stream seeded SEED0 + j
-    mles = [dev.synthetic(n_local, True, SEED0 + j, word_offset=rank * 2 * (1 << n_local)) for j in range(K)]
-    dev.sync()
+    tdev = (f"cuda:{local_rank}" if dist is not None and dist.get_backend() == "nccl" else "cpu")
 
     def barrier():
         if dist is not None:
@@ -178,172 +183,205 @@ def main():
         torch.cuda.synchronize()
         dev.sync()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     ONE = np.array([[1, 0]], dtype=np.uint64)
     TERMS = [list(range(K))]
     # Fiat-Shamir on the host between every two rounds: the Poseidon2 duplex challenger (what the reference's BasicTranscript
     # is; 2 permutations per round on the critical path) by default, the SplitMix stub for comparison
     factories = {"poseidon2": lambda: prover.Transcript.poseidon2(b"riscv"), "stub": lambda: prover.Transcript.stub(TR_SEED)}
-    new_transcript = factories[args.transcript]
-    collective = "none"
-    comm = stream = None
-    comms, collective_ms = {}, {}
-
-    def step_torch():
-        # per-round all-gather issued from Python through torch.distributed (RCCL underneath)
-        eng = cdist.HipShardEngine(dev, mles)
-        return cdist.sharded_sumcheck_prove(eng, n_total, K, new_transcript(), dist=dist, world=world, rank=rank)
-
-    def step_native():
-        # the same protocol driven from C++ with ncclAllGather on the kernels' HIP stream (host/dist.cpp)
-        return prover.dist_sumcheck_prove(dev, comm, mles, ONE, TERMS, n_total, K, new_transcript(), stream)
-
-    if world > 1:
-        # Three drivers of the same protocol, fastest first; each candidate must reproduce the torch.distributed path's
-        # proof on every rank before it is used for the timed steps:
-        #   shm  : C++ loop, per-round partials exchanged through host shared memory (the messages are in host memory
-        #          anyway for the transcript) — no device collective on the round path
-        #   rccl : C++ loop, ncclAllGather on the kernels' HIP stream + early gather of small shards
-        #   torch: Python loop over torch.distributed all_gather (RCCL underneath)
-        collective = "torch.distributed all_gather (python loop)"
-        step_fn = step_torch
-        stream = dev.stream_create()
-        try:
-            reference = step_torch()
-        except Exception as e:  # without it a candidate is accepted when it runs on every rank (its proof is replicated by construction)
-            print(f"bench.py: torch.distributed reference path failed on rank {rank}: {e}", file=sys.stderr)
-            reference = None
-        # every exchange that works on all ranks and reproduces the reference proof is kept: each is timed below and reported
-        # under `collective_ms`; the fastest one carries `value`
-        order = [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
-        comms = {}
-        for kind in order:
-            ok = 1
-            try:
-                comm = prover.ShmComm(world, rank, dist) if kind == "shm" else prover.RcclComm(world, rank, dist)
-                got = step_native()
-                ok = 1 if reference is None or all(np.array_equal(x, y) for x, y in zip(got, reference)) else 0
-            except Exception as e:  # keep looking
-                print(f"bench.py: {kind} exchange unavailable on rank {rank}: {e}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                comms[kind] = comm
-            comm = None
-        names = {"shm": "host shared-memory exchange of the d partial evaluations per round from the C++ host loop",
-                 "rccl": "ncclAllGather of the d partial evaluations per round on the kernels' stream from the C++ host loop (RCCL over xGMI)"}
-        collective_ms = {}
-
-        def time_steps(fn, n):
-            for _ in range(min(2, args.warmup + 1)):
-                fn()
-            barrier()
-            t_ = time.perf_counter()
-            for _ in range(n):
-                fn()
-            barrier()
-            d_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(d_, op=dist.ReduceOp.MAX)
-            return float(d_.item()) / n * 1e3
-
-        for kind, c in comms.items():
-            comm = c
-            collective_ms[kind] = time_steps(step_native, max(2, args.steps // 2))
-        if not comms:
-            collective_ms["torch"] = time_steps(step_torch, max(2, args.steps // 2))
-        else:
-            best = min(comms, key=lambda k_: collective_ms[k_])
-            comm = comms[best]
-            step_fn = step_native
-            collective = names[best] + (" (checked against the torch.distributed path)" if reference is not None else " (unchecked: reference path failed)")
-
-    def step():
-        if world == 1:
-            return prover.sumcheck_prove(dev, mles, ONE, TERMS, n_total, K, new_transcript())
-        return step_fn()
-
-    for _ in range(args.warmup):
-        step()
-    # timed region: exactly `steps` steps, no profiling hooks active
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    # second, untimed pass of the same steps with HIP events around every launch of the dominant kernel
-    # (events recorded on the library's launch stream) -> roofline numbers
-    dev.prof_enable(True)
-    dev.prof_reset()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    kernel_ms, launches, prof_bytes = dev.prof_get()
-    dev.prof_enable(False)
-    # the same steps with the other transcript (untimed for `value`; reported as ms_per_step_<name>)
     other = "stub" if args.transcript == "poseidon2" else "poseidon2"
-    new_transcript = factories[other]
-    step()
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
+    names = {"shm": "host shared-memory exchange of the d partial evaluations per round from the C++ host loop",
+             "rccl": "ncclAllGather of the d partial evaluations per round on the kernels' stream from the C++ host loop (RCCL over xGMI)",
+             "torch": "torch.distributed all_gather (python loop)"}
+    stream = dev.stream_create() if world > 1 else None
+    comms = {}        # exchange kind -> communicator, created once and shared by the strong and the weak run
+    comm_info = {}    # e.g. the rank count RCCL itself reports
+
+    def measure(n_local: int) -> dict:
+        """all the timings of one hypercube size: every rank holds shard `rank` (2^n_local elements per table) of a
+        2^(n_local + log2 world) hypercube"""
+        n_total = n_local + log_w
+        # shard `rank` of table j: words [rank * 2 * 2^n_local, ...) of the SplitMix stream seeded SEED0 + j
+        mles = [dev.synthetic(n_local, True, SEED0 + j, word_offset=rank * 2 * (1 << n_local)) for j in range(K)]
+        dev.sync()
+        tr = {"new": factories[args.transcript]}
+        cur = {"comm": None}
+
+        def step_torch():  # per-round all-gather issued from Python through torch.distributed (RCCL underneath)
+            eng = cdist.HipShardEngine(dev, mles)
+            return cdist.sharded_sumcheck_prove(eng, n_total, K, tr["new"](), dist=dist, world=world, rank=rank)
+
+        def step_native():  # the same protocol driven from C++ (host/dist.cpp) over the communicator in `cur`
+            return prover.dist_sumcheck_prove(dev, cur["comm"], mles, ONE, TERMS, n_total, K, tr["new"](), stream)
+
+        def step_single():
+            return prover.sumcheck_prove(dev, mles, ONE, TERMS, n_total, K, tr["new"]())
+
+        out = {"n_local": n_local, "n_total": n_total, "collective": "none", "collective_ms": {}, "validated": []}
+        step = step_single
+        if world > 1:
+            # Three drivers of the same protocol; each candidate must reproduce the torch.distributed path's proof on every rank
+            # before it is timed:
+            #   shm  : C++ loop, per-round partials exchanged through host shared memory (the messages are in host memory
+            #          anyway for the transcript) — no device collective on the round path
+            #   rccl : C++ loop, ncclAllGather on the kernels' HIP stream + early gather of small shards
+            #   torch: Python loop over torch.distributed all_gather (RCCL underneath)
+            try:
+                reference = step_torch()
+            except Exception as e:  # without it a candidate is accepted when it runs on every rank (its proof is replicated by construction)
+                print(f"bench.py: torch.distributed reference path failed on rank {rank}: {e}", file=sys.stderr)
+                reference = None
+            order = [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
+            ok_kinds = []
+            for kind in order:
+                ok = 1
+                try:
+                    if kind not in comms:
+                        comms[kind] = prover.ShmComm(world, rank, dist) if kind == "shm" else prover.RcclComm(world, rank, dist)
+                        if kind == "rccl":
+                            comm_info["rccl_ranks"] = comms[kind].nranks()
+                    cur["comm"] = comms[kind]
+                    got = step_native()
+                    ok = 1 if reference is None or all(np.array_equal(x, y) for x, y in zip(got, reference)) else 0
+                except Exception as e:  # keep looking
+                    print(f"bench.py: {kind} exchange unavailable on rank {rank}: {e}", file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    ok_kinds.append(kind)
+
+            def time_steps(fn, n):
+                for _ in range(min(2, args.warmup + 1)):
+                    fn()
+                barrier()
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                barrier()
+                return max_over_ranks(time.perf_counter() - t_) / n * 1e3
+
+            for kind in ok_kinds:
+                cur["comm"] = comms[kind]
+                out["collective_ms"][kind] = time_steps(step_native, max(2, args.steps // 2))
+            out["validated"] = sorted(ok_kinds)
+            # north_star names the RCCL collective: when it validates it carries the headline and the shared-memory exchange (an
+            # optimisation of the same protocol: the partials are in host memory anyway) is reported beside it; CENO_BENCH_HEADLINE
+            # = fastest picks whichever exchange measured fastest instead
+            pick = None
+            if ok_kinds:
+                fastest = min(ok_kinds, key=lambda k_: out["collective_ms"][k_])
+                pick = "rccl" if ("rccl" in ok_kinds and os.environ.get("CENO_BENCH_HEADLINE", "rccl") != "fastest") else fastest
+                out["fastest_exchange"] = fastest
+            if pick is None:
+                out["collective_ms"]["torch"] = time_steps(step_torch, max(2, args.steps // 2))
+                step, out["collective"] = step_torch, names["torch"]
+            else:
+                cur["comm"] = comms[pick]
+                step = step_native
+                out["collective"] = names[pick] + (" (checked against the torch.distributed path)" if reference is not None
+                                                   else " (unchecked: reference path failed)")
+            out["headline_exchange"] = pick or "torch"
+
+        for _ in range(args.warmup):
+            step()
+        # timed region: exactly `steps` steps, no profiling hooks active
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        out["dt"] = max_over_ranks(time.perf_counter() - t0)
+        # second, untimed pass of the same steps with HIP events around every launch of the dominant kernel
+        # (events recorded on the library's launch stream) -> roofline numbers
+        dev.prof_enable(True)
+        dev.prof_reset()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        out["kernel_ms"], out["launches"], out["prof_bytes"] = dev.prof_get()
+        dev.prof_enable(False)
+        # the same steps with the other transcript (untimed for `value`; reported as ms_per_step_<name>)
+        tr["new"] = factories[other]
         step()
-    barrier()
-    dt_other = time.perf_counter() - t1
-    new_transcript = factories[args.transcript]
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        out["dt_other"] = time.perf_counter() - t1
+        for m in mles:
+            m.free()
+        return out
 
-    # max over ranks
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def line(m: dict, scaling: str) -> dict:
+        n_local, n_total = m["n_local"], m["n_total"]
+        dt, kernel_ms, launches = m["dt"], m["kernel_ms"], m["launches"]
+        value = K * K * ((1 << n_total) - 1) * args.steps / dt
+        alg_bytes_per_step = 3 * K * 16 * (1 << n_local)          # SURVEY §8d: 3*d*s*2^n per sumcheck (per GPU)
+        achieved = alg_bytes_per_step * args.steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        peak = 8000.0
+        return {
+            "metric": f"Goldilocks-ext mults/sec in sumcheck nv={n_total if scaling == 'strong' else n_local}",  # BASELINE.json metric at the default --nv 26
+            "value": value,
+            "unit": "ext-mults/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            f"ms_per_step_{args.transcript}": dt / args.steps * 1e3,
+            f"ms_per_step_{other}": m["dt_other"] / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": scaling,
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "poseidon2_constants": "reference" if poseidon2_pinned else "placeholder (PARITY UNPINNED)",
+            "config": {
+                "workload": (f"single sumcheck instance, {K} MLEs x nv={n_total}, Goldilocks-ext2 (16 B/elem), degree {K}, " +
+                             (f"hypercube split over {world} GPUs (nv={n_local} per GPU), " if world > 1 else "") +
+                             f"{args.transcript} Fiat-Shamir transcript on host, inputs resident in HBM"),
+                "global_num_vars": n_total,
+                "num_vars_per_gpu": n_local,
+                "sharding": "none" if world == 1 else f"top-{log_w}-bits over {world} GPUs, all-gather of partials per round",
+                "collective": m["collective"],
+            },
+            **({"collective_ms": m["collective_ms"], "exchanges_validated": m["validated"], "headline_exchange": m.get("headline_exchange"),
+                "fastest_exchange": m.get("fastest_exchange"), **comm_info} if world > 1 else {}),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_dense<3,*> (fused fold + round-polynomial accumulate)",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "GB/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "launches": int(launches),
+                "avg_launch_ms": kernel_ms / launches if launches else None,
+                "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
+                "schedule_bytes_per_step": m["prof_bytes"] / args.steps if args.steps else None,
+                "schedule_gbps": (m["prof_bytes"] / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
+            },
+        }
 
-    mults_per_step = K * K * ((1 << n_total) - 1)
-    value = mults_per_step * args.steps / dt
-    alg_bytes_per_step = 3 * K * 16 * (1 << n_local)          # 3*d*s*2^n per sumcheck (per GPU)
-    sched_bytes = prof_bytes                                     # bytes the fused schedule itself must move
-    achieved = alg_bytes_per_step * args.steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    peak = 8000.0
-    res = {
-        "metric": f"Goldilocks-ext mults/sec in sumcheck nv={n_local}",  # BASELINE.json metric at the default --nv 26
-        "value": value,
-        "unit": "ext-mults/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        f"ms_per_step_{args.transcript}": dt / args.steps * 1e3,
-        f"ms_per_step_{other}": dt_other / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "poseidon2_constants": "reference" if poseidon2_pinned else "placeholder (PARITY UNPINNED)",
-        "config": {
-            "workload": f"single sumcheck instance, {K} MLEs x nv={n_local} per GPU, Goldilocks-ext2 (16 B/elem), "
-                        f"degree {K}, {args.transcript} Fiat-Shamir transcript on host, inputs resident in HBM",
-            "global_num_vars": n_total,
-            "sharding": "none" if world == 1 else f"top-{log_w}-bits over {world} GPUs, all-gather of partials per round",
-            "collective": collective,
-        },
-        **({"collective_ms": collective_ms, "exchanges_validated": sorted(comms)} if world > 1 else {}),
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_dense<3,*> (fused fold + round-polynomial accumulate)",
-            "achieved": achieved,
-            "peak": peak,
-            "unit": "GB/s",
-            "frac": achieved / peak,
-            "traffic": None,
-            "launches": int(launches),
-            "avg_launch_ms": kernel_ms / launches if launches else None,
-            "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
-            "schedule_bytes_per_step": sched_bytes / args.steps if args.steps else None,
-            "schedule_gbps": (sched_bytes / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
-        },
-    }
+    if world == 1:
+        res = line(measure(args.nv), "weak")  # one GPU: strong and weak coincide; `weak` is what the single-GPU line has always said
+    else:
+        strong = weak = None
+        if args.scaling in ("strong", "both") and args.nv - log_w >= 1:
+            strong = line(measure(args.nv - log_w), "strong")
+        if args.scaling in ("weak", "both") or strong is None:
+            weak = line(measure(args.nv), "weak")
+        res = strong if strong is not None else weak
+        if strong is not None and weak is not None:
+            res["weak_scaling"] = {k: weak[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "collective_ms", "roofline")}
+    n_local = res["config"]["num_vars_per_gpu"]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -374,9 +412,12 @@ def main():
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
+        for c in comms.values():
+            try:
+                c.close()
+            except Exception:
+                pass
         dist.destroy_process_group()
-    for m in mles:
-        m.free()
     dev.close()
 
 

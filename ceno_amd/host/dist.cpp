@@ -49,6 +49,8 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 thread_local std::string g_dist_err;
@@ -76,6 +78,8 @@ int load_rccl() {
     *(void**)&g_rccl.Recv = dlsym(g_rccl.h, "ncclRecv");
     *(void**)&g_rccl.GroupStart = dlsym(g_rccl.h, "ncclGroupStart");
     *(void**)&g_rccl.GroupEnd = dlsym(g_rccl.h, "ncclGroupEnd");
+    *(void**)&g_rccl.CommCount = dlsym(g_rccl.h, "ncclCommCount");
+    *(void**)&g_rccl.CommUserRank = dlsym(g_rccl.h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         g_dist_err = "RCCL symbols missing";
         return CENO_HIP_ERR_UNSUPPORTED;
@@ -199,6 +203,25 @@ int ceno_dist_comm_init(int world, int rank, const uint8_t* id128, ceno_dist_com
     }
     *out = c;
     return 0;
+}
+
+// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): > 0 = number of ranks of the RCCL communicator,
+// 0 = the communicator has no RCCL part (shared-memory or in-process exchange only), < 0 = error
+int ceno_dist_comm_rccl_ranks(ceno_dist_comm* c, int* out_user_rank) {
+    if (!c) return CENO_HIP_ERR_INVALID;
+    if (!c->comm) return 0;
+    if (!g_rccl.CommCount) {
+        g_dist_err = "ncclCommCount is not available in the loaded RCCL";
+        return CENO_HIP_ERR_UNSUPPORTED;
+    }
+    int n = 0, r = -1;
+    ncclResult_t e = g_rccl.CommCount(c->comm, &n);
+    if (e != ncclSuccess) return nccl_fail(e, "ncclCommCount");
+    if (out_user_rank) {
+        if (g_rccl.CommUserRank && g_rccl.CommUserRank(c->comm, &r) != ncclSuccess) r = -1;
+        *out_user_rank = r;
+    }
+    return n;
 }
 
 void ceno_dist_comm_destroy(ceno_dist_comm* c) {

@@ -406,6 +406,17 @@ class RcclComm:
             raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
         self.h, self.world, self.rank = h, world, rank
 
+    def nranks(self) -> int:
+        """the rank count RCCL itself reports for this communicator (ncclCommCount)"""
+        L = plib()
+        L.ceno_dist_comm_rccl_ranks.restype = C.c_int
+        L.ceno_dist_comm_rccl_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        r = C.c_int(-1)
+        n = L.ceno_dist_comm_rccl_ranks(self.h, C.byref(r))
+        if n < 0:
+            raise CenoHipError(n, (L.ceno_dist_last_error() or b"").decode())
+        return int(n)
+
     def close(self):
         if getattr(self, "h", None):
             plib().ceno_dist_comm_destroy(self.h)

@@ -388,6 +388,9 @@ typedef struct ceno_dist_comm ceno_dist_comm;
 int ceno_dist_unique_id(uint8_t* out128);
 int ceno_dist_comm_init(int world, int rank, const uint8_t* id128, ceno_dist_comm** out);
 void ceno_dist_comm_destroy(ceno_dist_comm* c);
+/* what RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank): > 0 = ranks of the RCCL communicator, 0 = no RCCL
+ * part (shared-memory / in-process exchange only), < 0 = error.  bench.py prints it so that a multi-GPU line says which transport ran. */
+int ceno_dist_comm_rccl_ranks(ceno_dist_comm* c, int* out_user_rank);
 int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
                              int n_total, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
                              uint64_t* out_final_evals);

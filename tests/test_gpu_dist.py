@@ -83,8 +83,14 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak"
-    assert r["config"]["global_num_vars"] == 12 + world.bit_length() - 1
-    assert "shm" in r["exchanges_validated"] and r["collective_ms"]["shm"] > 0
+    # the headline is STRONG scaling (the nv-variable hypercube split over the ranks), the weak-scaling run is reported beside it
+    log_w = world.bit_length() - 1
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "strong"
+    assert r["config"]["global_num_vars"] == 12 and r["config"]["num_vars_per_gpu"] == 12 - log_w
+    assert r["metric"].endswith("nv=12")
+    w = r["weak_scaling"]
+    assert w["scaling"] == "weak" and w["config"]["global_num_vars"] == 12 + log_w and w["config"]["num_vars_per_gpu"] == 12
+    assert w["value"] > 0 and abs(w["value"] - 9 * ((1 << (12 + log_w)) - 1) / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
+    assert "shm" in r["exchanges_validated"] and r["collective_ms"]["shm"] > 0 and r["headline_exchange"] == "shm"  # (no RCCL with two ranks on one device)
     assert "shared-memory exchange" in r["config"]["collective"] and "checked against the torch.distributed path" in r["config"]["collective"]
     assert r["value"] > 0 and abs(r["value"] - 9 * ((1 << r["config"]["global_num_vars"]) - 1) / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6

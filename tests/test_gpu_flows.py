@@ -316,10 +316,11 @@ def batched_jobs(dev, max_nv, w):
     return jobs, chips
 
 
-@pytest.mark.parametrize("max_nv", [13, 24])
+@pytest.mark.parametrize("max_nv", [13, 24, 26])
 def test_config4_batched_main_sumcheck_full_size(dev, prover, max_nv):
-    """prove_batched_main_constraints over 24 chips of mixed sizes (front-load rule, scheme/verifier.rs:180-238) at max_nv = 24
-    (424 M table elements; 13: the same plan small enough for the oracle's prover to produce every message)"""
+    """prove_batched_main_constraints over 24 chips of mixed sizes (front-load rule, scheme/verifier.rs:180-238) at max_nv = 26 —
+    BASELINE config #4's stated size, 1.7 G table elements = 13.6 GB of base columns on one GPU — and 24 (424 M elements);
+    13: the same plan small enough for the oracle's prover to produce every message"""
     w = 12
     gch = [(11, 22), (33, 44)]
     jobs, chips = batched_jobs(dev, max_nv, w)
