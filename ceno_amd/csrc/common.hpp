@@ -49,6 +49,10 @@ struct ceno_hip_ctx {
     // hipOccupancyMaxActiveBlocksPerMultiprocessor reports for its dynamic LDS) costs ceil(64 W / nb); the chip offers
     // 64 * num_cus minus headroom.  An atomic of its own: round enqueues never contend with the pool mutex.
     std::atomic<int> mid_wgs_in_flight{0};
+    // live pipelined sumchecks (any lane): their queued round kernels wait for a HOST, and hipFree waits for every stream of the
+    // device, so the pool's soft-cap trim (ctx_alloc) only runs while this is zero — two lanes each inside hipFree, each with
+    // kernels that need the other's... host would otherwise wait for each other until the kernels' poll timeout
+    std::atomic<int> pipelined_live{0};
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----

@@ -141,10 +141,14 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     void* p = nullptr;
     ctx_make_current(ctx);
     {   // soft cap on the cache: blocks parked without a tag (their stream had drained) go back to the driver once the cache is
-        // several times what is in use — a backstop against slow growth under many lanes, far below any real footprint
+        // several times what is in use — a backstop against slow growth under many lanes, far below any real footprint.
+        // hipFree waits for EVERY stream of the device: it is only called while no pipelined sumcheck is alive anywhere (queued
+        // round kernels wait for their host thread; a host thread inside hipFree with such kernels pending, and a second one
+        // likewise, would wait for each other until the kernels give up — seen as "round finished without publishing its
+        // message" after a 13 GB batch had left the cache over the cap in front of a four-lane shard flow)
         std::lock_guard<std::mutex> g(ctx->mu);
         const size_t floor_ = (size_t)2 << 30;
-        if (ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_)) {
+        if (ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_) && ctx->pipelined_live.load() == 0) {
             for (auto& kv : ctx->free_lists) {
                 auto& fl = kv.second;
                 for (size_t k = 0; k < fl.size();) {

@@ -778,6 +778,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         sc->ctx->mid_wgs_in_flight.fetch_sub(sc->mid_reserved);
         sc->mid_reserved = 0;
     }
+    if (sc->pipelined) sc->ctx->pipelined_live.fetch_sub(1);
     for (void* p : sc->dev_allocs) ctx_free_on(sc->ctx, p, sc->st);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
@@ -1735,6 +1736,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     }
     sc->enq = upto;
     sc->pipelined = true;
+    sc->ctx->pipelined_live.fetch_add(1);  // the pool returns nothing to the driver while round kernels may be waiting for a host (ctx_alloc)
     sc->seq = (unsigned long long)sc->n;
     return 0;
 }

@@ -22,9 +22,11 @@
  *  - Handles are opaque; device memory is owned by the library pool unless wrapped from outside.
  *  - Memory: freeing a handle does not wait for the device.  A freed block remembers the stream the freeing thread used last
  *    (one lane = one thread = one stream); the pool hands the block to a different stream only after that stream has drained
- *    (it never waits: it takes another block or allocates), so a lane may free tables whose kernels are still queued.  Streams NOT created through
- *    ceno_hip_stream_create / _create_lane (a caller's own HIP stream passed as ceno_hip_stream) are outside that
- *    bookkeeping: synchronise them before freeing handles that were used on them from another thread.
+ *    (it never waits: it takes another block or allocates), so a lane may free tables whose kernels are still queued.  A caller's own
+ *    HIP stream passed as ceno_hip_stream is registered with that bookkeeping the first time a thread uses it (ceno_hip_stream_adopt
+ *    does it explicitly); handles own the stream they were begun on and free their blocks with it.  Blocks go back to the DRIVER
+ *    (hipFree waits for every stream of the device) only from ceno_hip_mem_trim, from the pool_bytes cap, or while no pipelined
+ *    sumcheck is alive on any lane: call ceno_hip_mem_trim between phases, not while lanes are proving.
  *  - The Fiat–Shamir transcript stays with the caller: sumcheck is exposed round by round
  *    (the reference passes `&mut BasicTranscript` into the HAL, gkr_iop/src/gkr/layer/gpu/mod.rs:252-270;
  *    a C ABI cannot take a Rust generic, so control is inverted).
@@ -81,7 +83,7 @@ int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s);
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);
-int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334) */
+int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device: not while lanes are proving */
 /* booking of estimated task footprints by a chip scheduler (mem_pool try_book_capacity / unbook_capacity /
  * get_booked_total, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,622-652): refused (CENO_HIP_ERR_OOM, nothing is
  * allocated) when live allocations + bookings + bytes would exceed pool_bytes (or the device memory when unlimited) */

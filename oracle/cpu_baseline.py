@@ -21,7 +21,9 @@ def main():
     try:  # -march=native build for this box; fall back to the shipped portable build
         tmp = tempfile.mkdtemp(prefix="ceno_orc_")
         so = os.path.join(tmp, "libceno_oracle_native.so")
-        srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "tower.c", "commit.c")]
+        import glob
+
+        srcs = sorted(glob.glob(os.path.join(ROOT, "oracle", "*.c")))  # every restatement file: pyoracle binds symbols of all of them
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", so] + srcs,
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         po._LIB_PATH = so

@@ -536,3 +536,27 @@ def test_pool_cache_does_not_grow_over_repeated_flows_with_lanes(prover):
     flow.close()
     d.close()
     assert grown <= base // 4 + (8 << 20), (base, grown)
+
+
+def test_cache_over_the_soft_cap_does_not_stall_lanes(prover):
+    """A phase that leaves many GB in the pool's cache (the 13 GB batch of config #4) followed by concurrent chip proofs: the
+    pool's soft cap must not call hipFree — which waits for every stream of the device — while round kernels of the lanes are
+    waiting for their host threads (regression: two lanes inside hipFree waited for each other's kernels until those gave up
+    after their 60 s poll timeout: 'sumcheck round finished without publishing its message')"""
+    import time
+
+    from ceno_amd import Device, synthetic
+
+    d = Device(0)
+    big = [d.synthetic(27, False, 900 + i) for i in range(10)]   # 10 x 1 GiB ...
+    d.sync()
+    for m in big:
+        m.free()                                                 # ... parked in the cache, untagged (the stream is idle)
+    assert d.mem_info()["pool_cached"] >= 10 << 30
+    flow = synthetic.ShardFlow(d, prover, w=22, n_queries=10, pow_bits=4, log_rows=(16, 15, 14, 13, 13, 12))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        flow.run(lambda: prover.Transcript.poseidon2(b"riscv"), lambda: prover.Transcript.poseidon2(b"fork"), lanes=4)
+    assert time.perf_counter() - t0 < 30
+    flow.close()
+    d.close()
