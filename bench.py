@@ -108,7 +108,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     shard = synthetic.ShardFlow(dev, prover)
     fork = (lambda: prover.Transcript.poseidon2(b"fork")) if transcript_name == "poseidon2" else (lambda: prover.Transcript.stub(0xF0))
     bs, by_lanes = None, {}
-    for lanes in (1, 4):  # chip proofs serially, then four at a time (one host thread + one HIP stream per lane: the chip scheduler)
+    for lanes in (1, 4, 8):  # chip proofs serially, then on 4 and 8 lanes of the C++ scheduler (ceno_prover_create_chip_proofs: context-owned lane streams)
         for _ in range(reps):
             r = shard.run(new_transcript, fork, lanes=lanes)
             by_lanes[lanes] = min(by_lanes.get(lanes, 1e30), r["total_ms"])

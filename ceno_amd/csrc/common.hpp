@@ -36,6 +36,7 @@ struct ceno_hip_ctx {
     std::unordered_map<size_t, std::vector<std::pair<void*, hipStream_t>>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
     std::vector<hipStream_t> streams;        // streams created through the C ABI that are still alive
+    std::vector<hipStream_t> lane_streams;   // the context's own lane streams (ceno_hip_lane_stream): created once, reused by every scheduler run
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
     std::unordered_map<void*, size_t> pinned_live;

@@ -313,6 +313,8 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     for (auto& ev : ctx->prof_event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
     if (ctx->vram_arena) (void)hipFree(ctx->vram_arena);
+    for (hipStream_t ls : ctx->lane_streams)
+        if (ls) (void)hipStreamDestroy(ls);
     if (ctx->default_stream) (void)hipStreamDestroy(ctx->default_stream);
     delete ctx;
 }
@@ -364,6 +366,36 @@ int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* ou
         ctx->streams.push_back(s);
     }
     *out = (ceno_hip_stream)s;
+    return 0;
+}
+int ceno_hip_lane_stream(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out) {
+    // Streams are long-lived objects: hipStreamCreateWithPriority costs ~4 ms and hipStreamDestroy ~2 ms (rocprofv3 --hip-trace),
+    // the size of a whole chip proof.  The lanes of the chip scheduler therefore belong to the CONTEXT: created on first use,
+    // handed out again on every later run, destroyed with the context.
+    CHECK_ARG(ctx, out && lane >= 0 && lane < 64, "bad lane");
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (lane < (int)ctx->lane_streams.size() && ctx->lane_streams[lane]) {
+            *out = (ceno_hip_stream)ctx->lane_streams[lane];
+            return 0;
+        }
+    }
+    ceno_hip_stream s = nullptr;
+    TRY(ceno_hip_stream_create_lane(ctx, lane, &s));
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if ((int)ctx->lane_streams.size() <= lane) ctx->lane_streams.resize(lane + 1, nullptr);
+    if (ctx->lane_streams[lane]) {  // another thread was faster: keep its stream (ours is dropped from the bookkeeping below)
+        hipStream_t mine = (hipStream_t)s;
+        for (size_t i = 0; i < ctx->streams.size(); i++)
+            if (ctx->streams[i] == mine) {
+                ctx->streams.erase(ctx->streams.begin() + i);
+                break;
+            }
+        (void)hipStreamDestroy(mine);
+    } else {
+        ctx->lane_streams[lane] = (hipStream_t)s;
+    }
+    *out = (ceno_hip_stream)ctx->lane_streams[lane];
     return 0;
 }
 int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s) {

@@ -3,6 +3,8 @@
 // {evaluate, fix_variables}` (call sites gkr_iop/src/selector.rs:140-194, layer/cpu/mod.rs:266);
 // selectors gkr_iop/src/selector.rs:131-245; LSB-first variable order gkr_iop/src/utils.rs:215-232.
 // All kernels are HBM-streaming: 16 B per lane coalesced loads/stores, grid-stride.
+#include <algorithm>
+
 #include "common.hpp"
 #include "reduce.hpp"
 
@@ -62,25 +64,8 @@ int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// eq(x, r) = prod_k (x_k r_k + (1-x_k)(1-r_k)) built as an outer product of two half tables:
-// eq[i] = lo[i & (2^a - 1)] * hi[i >> a]; both halves are produced by direct products
-// (<= 20 mults per entry of a table that is at most 2^20 entries), the full table costs one ext
-// mult and one 16 B store per entry -> write-bandwidth bound.
+// eq(x, r) = prod_k (x_k r_k + (1-x_k)(1-r_k)), LSB-first (k_eq_fused below), optionally masked by a selector
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NT) k_eq_half(E2* out, int first_var, int n_vars, PointArg pt, E2 scalar) {
-    size_t len = (size_t)1 << n_vars;
-    size_t stride = (size_t)gridDim.x * NT;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
-        E2 acc = scalar;
-        for (int k = 0; k < n_vars; k++) {
-            E2 r = pt.r[first_var + k];
-            E2 f = ((i >> k) & 1) ? r : (e2_one() - r);
-            acc = acc * f;
-        }
-        out[i] = acc;
-    }
-}
-
 struct SelArg {
     int kind;
     int num_vars;
@@ -114,49 +99,53 @@ __device__ __forceinline__ bool sel_keep(const SelArg& sa, size_t x) {
     return false;
 }
 
-__global__ void __launch_bounds__(NT) k_eq_outer(E2* __restrict__ out, const E2* __restrict__ lo, const E2* __restrict__ hi, int a,
-                                                 size_t len, SelArg sa) {
-    size_t stride = (size_t)gridDim.x * NT;
-    size_t mask = ((size_t)1 << a) - 1;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
-        E2 v = e2_zero();
-        if (sel_keep(sa, i)) v = lo[i & mask] * hi[i >> a];
-        out[i] = v;
+// The whole table in ONE launch (it used to be three: two half tables + their outer product, with a scratch allocation in
+// between — per tower layer, i.e. ~60 times per chip proof).  Every workgroup builds eq over the LOW min(n, 11) variables in LDS by
+// the doubling construction (one multiplication per entry: new[j] = old[j] (1 - r_k), new[j + 2^k] = old[j] r_k), then serves
+// tiles of 2^11 consecutive outputs: out[tile * 2^11 + j] = P(tile) * low[j], P = scalar * prod over the high variables of the
+// tile index's bits.  Two multiplications and one 16-byte store per entry; the selector masks apply on the way out.
+static constexpr int EQ_LB = 11;
+__global__ void __launch_bounds__(NT) k_eq_fused(E2* __restrict__ out, int n, PointArg pt, E2 scalar, SelArg sa) {
+    __shared__ E2 tab[1 << EQ_LB];
+    const int lb = n < EQ_LB ? n : EQ_LB;
+    if (threadIdx.x == 0) tab[0] = e2_one();
+    __syncthreads();
+    for (int k = 0; k < lb; k++) {
+        const int half = 1 << k;
+        const E2 r = pt.r[k];
+        for (int j = threadIdx.x; j < half; j += NT) {
+            const E2 v = tab[j], hi = v * r;
+            tab[j + half] = hi;
+            tab[j] = v - hi;
+        }
+        __syncthreads();
+    }
+    const size_t tiles = (size_t)1 << (n - lb), tile_len = (size_t)1 << lb;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        E2 p = scalar;
+        for (int k = lb; k < n; k++) {  // uniform over the workgroup
+            const E2 r = pt.r[k];
+            p = p * (((t >> (k - lb)) & 1) ? r : (e2_one() - r));
+        }
+        const size_t base = t << lb;
+        for (size_t j = threadIdx.x; j < tile_len; j += NT) {
+            E2 v = e2_zero();
+            if (sel_keep(sa, base + j)) v = p * tab[j];
+            out[base + j] = v;
+        }
     }
 }
 
-// `keep_tmp` != nullptr: the scratch halves are returned to the caller (who frees them once the stream has
-// passed this point) and the call does not synchronise; otherwise the call synchronises and frees them.
+// (`keep_tmp`: scratch the caller must free once the stream has passed this point — none since the single-launch form)
 static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 scalar, const SelArg& sa, uint64_t* dev_out, hipStream_t st,
                          void** keep_tmp = nullptr) {
     CHECK_ARG(ctx, n >= 0 && n <= 40, "eq: num_vars %d out of range", n);
     PointArg pt;
     for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
-    if (n <= 12 && sa.kind == CENO_HIP_SEL_WHOLE) {
-        // small unmasked tables (tower layers): the direct-product kernel writes the whole table — one launch instead of three
-        hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << n, NT, MAXB)), dim3(NT), 0, st, (E2*)dev_out, 0, n, pt, scalar);
-        HIP_TRY(ctx, hipGetLastError());
-        if (keep_tmp) *keep_tmp = nullptr;
-        return 0;
-    }
-    int a = (n + 1) / 2, b = n - a;
-    void* tmp = nullptr;
-    TRY(ctx_alloc(ctx, (((size_t)1 << a) + ((size_t)1 << b)) * sizeof(E2), &tmp));
-    E2* lo = (E2*)tmp;
-    E2* hi = lo + ((size_t)1 << a);
-    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << a, NT, MAXB)), dim3(NT), 0, st, lo, 0, a, pt, e2_one());
-    hipLaunchKernelGGL(k_eq_half, dim3(grid_for((size_t)1 << b, NT, MAXB)), dim3(NT), 0, st, hi, a, b, pt, scalar);
-    size_t len = (size_t)1 << n;
-    hipLaunchKernelGGL(k_eq_outer, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, (E2*)dev_out, lo, hi, a, len, sa);
-    hipError_t e = hipGetLastError();
-    if (keep_tmp && e == hipSuccess) {
-        *keep_tmp = tmp;
-        return 0;
-    }
-    // the scratch halves are read by the queued kernel: return them to the pool only after it ran
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    ctx_free(ctx, tmp);
-    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "eq build: %s", hipGetErrorString(e));
+    if (keep_tmp) *keep_tmp = nullptr;
+    const size_t tiles = (size_t)1 << (n > EQ_LB ? n - EQ_LB : 0);
+    hipLaunchKernelGGL(k_eq_fused, dim3((unsigned)std::min<size_t>(tiles, 1024)), dim3(NT), 0, st, (E2*)dev_out, n, pt, scalar, sa);
+    HIP_TRY(ctx, hipGetLastError());
     return 0;
 }
 

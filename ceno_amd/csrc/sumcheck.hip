@@ -129,6 +129,90 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
     epilogue<K, NT>(acc, ep, smem, &s_flag);
 }
 
+// Software-pipelined form of the extension-field modes (MODE 0 / 2).  The plain kernel leaves the placement of the loads to the
+// compiler, which issues a table's four loads and waits for them at once in two of the three table steps: the six waves of a SIMD
+// start together, do identical work and stay in lock step, so the SIMD idles through every such wait (round 1 of the nv=26
+// sumcheck: 4.96 TB/s against a 5.79 TB/s ceiling of the same access pattern without arithmetic, tools/ubench_bw.hip, with
+// ~0.68 ms of VALU issue time under 0.83 ms of memory time).  Here the loads of the NEXT (table, pair) step are issued before the
+// arithmetic of the current one — across the back edge of the pair loop too — and scheduling barriers keep them there; the cost
+// is one more 64-byte buffer per lane.
+template <int K, int MODE, bool WIDE_>
+__global__ void __launch_bounds__(NT) k_dense_pf(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
+    static_assert(MODE == 0 || MODE == 2, "extension-field modes only");
+    __shared__ E2 smem[(NT / 64) * K];
+    constexpr bool WIDE = WIDE_ && K > 1;
+    constexpr int NL = MODE == 2 ? 4 : 2;  // extension elements per lane, table and step
+    E2 acc[K];
+    E2Acc wacc[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) {
+        acc[t] = e2_zero();
+        wacc[t] = e2acc_zero();
+    }
+    const size_t stride = (size_t)gridDim.x * NT;
+    if (ep.dbg && ep.bcast && blockIdx.x == 0 && threadIdx.x == 0) ep.bcast->dbg[ep.seq & 63][0] = wall_clock64();
+    __shared__ unsigned long long s_chal[3];
+    __shared__ int s_flag;
+    size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
+    E2 nxt[NL];
+    // the first loads do not depend on the challenge: they are in flight while a pipelined launch waits for it
+    if (p < pairs) {
+#pragma unroll
+        for (int k = 0; k < NL; k++) nxt[k] = ld_e2(tp.in[0] + 2 * NL * p + 2 * k);
+    }
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) return;  // pipeline aborted / timed out: leave everything untouched
+    }
+    const E2Pre rp = e2_pre(r);
+    for (; p < pairs; p += stride) {
+        E2 pr[K];
+#pragma unroll
+        for (int m = 0; m < K; m++) {
+            E2 cur[NL];
+#pragma unroll
+            for (int k = 0; k < NL; k++) cur[k] = nxt[k];
+            if (m + 1 < K) {
+#pragma unroll
+                for (int k = 0; k < NL; k++) nxt[k] = ld_e2(tp.in[m + 1] + 2 * NL * p + 2 * k);
+            } else {  // the next pair's first table (the last iteration re-reads its own: an L2 hit, and no branch around the loads)
+                const size_t pn = p + stride < pairs ? p + stride : p;
+#pragma unroll
+                for (int k = 0; k < NL; k++) nxt[k] = ld_e2(tp.in[0] + 2 * NL * pn + 2 * k);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            E2 lo, hi;
+            if (MODE == 0) {
+                lo = cur[0];
+                hi = cur[1];
+            } else {
+                lo = cur[0] + e2_mul_pre(rp, cur[1] - cur[0]);
+                hi = cur[2] + e2_mul_pre(rp, cur[3] - cur[2]);
+                st_e2(tp.out[m] + 4 * p, lo);
+                st_e2(tp.out[m] + 4 * p + 2, hi);
+            }
+            E2 nd = lo - hi, x = hi;
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+                if (m == 0) pr[t] = x;
+                else if (m < K - 1) pr[t] = e2_mul_nc(pr[t], x);
+                else if (!WIDE) pr[t] = pr[t] * x;
+                else e2acc_mac(wacc[t], pr[t], x);
+                if (t + 1 < K) x = x - nd;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!WIDE) {
+#pragma unroll
+            for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
+        }
+    }
+    if (WIDE) {
+#pragma unroll
+        for (int t = 0; t < K; t++) acc[t] = e2acc_reduce(wacc[t]);
+    }
+    epilogue<K, NT>(acc, ep, smem, &s_flag);
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic path
 // ------------------------------------------------------------------------------------------------
@@ -795,17 +879,31 @@ static int dense_wide_mode() {  // tuning switch: 0 = never, 1 = read-only round
     return m;
 }
 
+static int dense_pf_mode() {  // tuning switch (bit 0: read-only round, bit 1: folding rounds): software-pipelined loads
+    static int m = [] {
+        const char* e = getenv("CENO_HIP_DENSE_PF");
+        return e ? atoi(e) : 3;
+    }();
+    return m;
+}
+
 template <int K>
 static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
-    const int wm = dense_wide_mode();
+    const int wm = dense_wide_mode(), pf = dense_pf_mode();
     switch (mode) {
     case 0:
-        if (wm >= 1) hipLaunchKernelGGL((k_dense<K, 0, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        if (pf & 1) {
+            if (wm >= 1) hipLaunchKernelGGL((k_dense_pf<K, 0, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+            else hipLaunchKernelGGL((k_dense_pf<K, 0, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        } else if (wm >= 1) hipLaunchKernelGGL((k_dense<K, 0, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
         else hipLaunchKernelGGL((k_dense<K, 0, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
         break;
     case 1: hipLaunchKernelGGL((k_dense<K, 1, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
     case 2:
-        if (wm >= 2) hipLaunchKernelGGL((k_dense<K, 2, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        if (pf & 2) {
+            if (wm >= 2) hipLaunchKernelGGL((k_dense_pf<K, 2, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+            else hipLaunchKernelGGL((k_dense_pf<K, 2, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
+        } else if (wm >= 2) hipLaunchKernelGGL((k_dense<K, 2, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
         else hipLaunchKernelGGL((k_dense<K, 2, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
         break;
     default: hipLaunchKernelGGL((k_dense<K, 3, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;

@@ -28,13 +28,11 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
     std::mutex mu;
     std::condition_variable cv;
     int in_flight = 0, remaining = n_tasks, first_err = 0;
+    // the lanes' streams belong to the context (created once, ~4 ms each; never per run)
     std::vector<ceno_hip_stream> streams(n_lanes, nullptr);
     for (int l = 0; l < n_lanes; l++) {
-        int rc = ceno_hip_stream_create_lane(ctx, l, &streams[l]);
-        if (rc) {
-            for (int k = 0; k < l; k++) ceno_hip_stream_destroy(ctx, streams[k]);
-            return prover_set_error(rc, ceno_hip_last_error(ctx));
-        }
+        int rc = ceno_hip_lane_stream(ctx, l, &streams[l]);
+        if (rc) return prover_set_error(rc, ceno_hip_last_error(ctx));
     }
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     auto worker = [&](int lane) {
@@ -92,6 +90,44 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
     std::vector<std::thread> th;
     for (int l = 0; l < n_lanes; l++) th.emplace_back(worker, l);
     for (auto& t : th) t.join();
-    for (auto st : streams) ceno_hip_stream_destroy(ctx, st);
     return first_err ? prover_set_error(first_err, "lanes_run: a task failed (see the per-task status)") : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The chip-proof phase of ZKVMProver::create_proof on the scheduler (ceno_zkvm/src/scheme/prover.rs:556-570: one forked
+// transcript per chip, `ChipScheduler::execute` scheduler.rs:231-336, results in task order :303-304): every task is one
+// ceno_prover_create_chip_proof on the lane that picked it.  The booking estimate of a task is what its proof allocates on top
+// of its (borrowed) tables: records + three towers + sumcheck work buffers, all extension-field tables of its row count.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ChipJob {
+    ceno_hip_ctx* ctx;
+    const ceno_chip_task* task;
+    const uint64_t* challenges4;
+    ceno_transcript* tr;
+    ceno_chip_proof* out;
+};
+int chip_job_fn(void* arg, int lane, ceno_hip_stream stream) {
+    (void)lane;
+    auto* j = (ChipJob*)arg;
+    return ceno_prover_create_chip_proof(j->ctx, j->task, j->challenges4, j->tr, stream, j->out);
+}
+}  // namespace
+
+extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4,
+                                              ceno_transcript* const* transcripts, int n_lanes, ceno_chip_proof* out_proofs, int* out_status) {
+    if (!ctx || !tasks || !challenges4 || !transcripts || !out_proofs || n_tasks < 0 || n_lanes < 1)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proofs: bad arguments");
+    std::vector<ChipJob> jobs(n_tasks);
+    std::vector<ceno_lane_task> lt(n_tasks);
+    for (int i = 0; i < n_tasks; i++) {
+        if (!transcripts[i]) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proofs: NULL transcript");
+        jobs[i] = ChipJob{ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i]};
+        const ceno_chip_task& t = tasks[i];
+        const size_t rows = (size_t)1 << (t.log2_num_instances + t.rotation_vars);
+        const size_t n_rec = (size_t)t.num_reads + t.num_writes + (t.num_lk_tables > 0 ? 2 * (size_t)t.num_lk_tables : (size_t)t.num_lk);
+        // records (16 B x rows each), towers ~ 2 x the interleaved records, sumcheck ping-pong ~ 0.75 x the tower's last layer
+        lt[i] = ceno_lane_task{chip_job_fn, &jobs[i], (size_t)(16.0 * (double)rows * (double)(n_rec ? n_rec : 1) * 4.0)};
+    }
+    return ceno_prover_lanes_run(ctx, std::min(n_lanes, std::max(n_tasks, 1)), lt.data(), n_tasks, out_status, nullptr);
 }

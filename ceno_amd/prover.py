@@ -822,16 +822,8 @@ class ChipProof:
         return self.tower_msgs[off: off + rnd * 6].reshape(rnd, 3, 2)
 
 
-def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, stream=None) -> ChipProof:
-    """ZKVMProver::create_chip_proof (scheme/prover.rs:717-833).  task: mles (witness ++ fixed ++ structural), n_witin, n_fixed,
-    n_structural, num_instances, log2_num_instances, rotation_vars (0), num_reads, num_writes, num_lk_tables, num_lk,
-    record_coeffs (T,2), record_terms [[mle ids]], record_out_terms [[term ids]] (consecutive), optional rotation
-    dict(pairs, cyclic_subgroup_size, cyclic_group_log2)."""
-    L = plib()
-    L.ceno_prover_create_chip_proof.restype = C.c_int
-    L.ceno_prover_create_chip_proof.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), u64p, C.c_void_p, C.c_void_p, C.POINTER(ChipProofC)]
-    L.ceno_chip_proof_free.restype = None
-    L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
+def _marshal_chip_task(task: dict):
+    """dict -> (ChipTaskC, objects that must stay alive while it is used)"""
     T = ChipTaskC()
     mh = (C.c_void_p * len(task["mles"]))(*[(m.h if m is not None else None) for m in task["mles"]])
     coeffs = np.ascontiguousarray(task["record_coeffs"], dtype=np.uint64).reshape(-1, 2)
@@ -846,12 +838,28 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
     T.num_reads, T.num_writes, T.num_lk_tables, T.num_lk = task["num_reads"], task["num_writes"], task["num_lk_tables"], task["num_lk"]
     T.n_record_terms, T.record_coeffs, T.record_term_offsets, T.record_term_mle_idx = len(task["record_terms"]), _p(coeffs), _p32(toff), _p32(tidx)
     T.record_out_term_offsets = _p32(ooff)
+    keep = [mh, coeffs, toff, tidx, ooff]
     rot = task.get("rotation")
     if rot:
         src = (C.c_int * len(rot["pairs"]))(*[p[0] for p in rot["pairs"]])
         tgt = (C.c_int * len(rot["pairs"]))(*[p[1] for p in rot["pairs"]])
         T.n_rotation_pairs, T.rotation_source_idx, T.rotation_target_idx = len(rot["pairs"]), src, tgt
         T.cyclic_subgroup_size, T.cyclic_group_log2 = rot["cyclic_subgroup_size"], rot["cyclic_group_log2"]
+        keep += [src, tgt]
+    return T, keep
+
+
+def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, stream=None) -> ChipProof:
+    """ZKVMProver::create_chip_proof (scheme/prover.rs:717-833).  task: mles (witness ++ fixed ++ structural), n_witin, n_fixed,
+    n_structural, num_instances, log2_num_instances, rotation_vars (0), num_reads, num_writes, num_lk_tables, num_lk,
+    record_coeffs (T,2), record_terms [[mle ids]], record_out_terms [[term ids]] (consecutive), optional rotation
+    dict(pairs, cyclic_subgroup_size, cyclic_group_log2)."""
+    L = plib()
+    L.ceno_prover_create_chip_proof.restype = C.c_int
+    L.ceno_prover_create_chip_proof.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), u64p, C.c_void_p, C.c_void_p, C.POINTER(ChipProofC)]
+    L.ceno_chip_proof_free.restype = None
+    L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
+    T, keep = _marshal_chip_task(task)
     ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
     out = ChipProofC()
     _check(L.ceno_prover_create_chip_proof(dev.h, C.byref(T), _p(ch), tr.h, stream, C.byref(out)))
@@ -859,6 +867,44 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
         return ChipProof(out)
     finally:
         L.ceno_chip_proof_free(C.byref(out))
+
+
+class ChipTasks:
+    """the C view of a list of chip tasks, marshalled once (a Rust caller hands the structs over directly)"""
+
+    def __init__(self, tasks: Sequence[dict]):
+        self.n = len(tasks)
+        self.arr = (ChipTaskC * self.n)()
+        self.keep = []
+        for i, t in enumerate(tasks):
+            T, keep = _marshal_chip_task(t)
+            self.arr[i] = T
+            self.keep.append(keep)
+
+
+def create_chip_proofs(dev: Device, tasks, challenges, transcripts: Sequence[Transcript], lanes: int) -> List[ChipProof]:
+    """the chip-proof phase of create_proof on the C++ scheduler (ceno_prover_create_chip_proofs; prover.rs:556-570,
+    scheduler.rs:231-336): one forked transcript per task, `lanes` concurrent lanes on the context's own lane streams, results in
+    task order"""
+    L = plib()
+    L.ceno_prover_create_chip_proofs.restype = C.c_int
+    L.ceno_prover_create_chip_proofs.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), C.c_int, u64p, C.POINTER(C.c_void_p), C.c_int,
+                                                 C.POINTER(ChipProofC), C.POINTER(C.c_int)]
+    L.ceno_chip_proof_free.restype = None
+    L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
+    ct = tasks if isinstance(tasks, ChipTasks) else ChipTasks(tasks)
+    assert len(transcripts) == ct.n
+    ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
+    trs = (C.c_void_p * ct.n)(*[t.h for t in transcripts])
+    outs = (ChipProofC * ct.n)()
+    status = (C.c_int * ct.n)()
+    rc = L.ceno_prover_create_chip_proofs(dev.h, ct.arr, ct.n, _p(ch), trs, lanes, outs, status)
+    try:
+        _check(rc)
+        return [ChipProof(outs[i]) for i in range(ct.n)]
+    finally:
+        for i in range(ct.n):
+            L.ceno_chip_proof_free(C.byref(outs[i]))
 
 
 class PcsData:

@@ -146,12 +146,11 @@ class ShardFlow:
             assert sum(1 << r for r in self.LOG_ROWS) == 1 << 20
         self.traces = [dev.synthetic(((1 << r) * w - 1).bit_length(), False, 0x5A0 + i) for i, r in enumerate(self.LOG_ROWS)]
         self.stream = dev.stream_create()
-        self.lane_streams = []
 
     def run(self, transcript_factory, fork_factory, lanes: int = 1) -> dict:
-        """lanes > 1: the chip proofs run concurrently, one host thread and one HIP stream per lane, largest chip first (the
-        reference's chip scheduler, ceno_zkvm/src/scheme/scheduler.rs:231-336: forks make the chip transcripts independent,
-        results are merged in task order)"""
+        """the chip proofs run on `lanes` concurrent lanes of the product's C++ scheduler (ceno_prover_create_chip_proofs: one worker
+        thread and one context-owned HIP stream per lane, largest chip first; the reference's chip scheduler,
+        ceno_zkvm/src/scheme/scheduler.rs:231-336: forks make the chip transcripts independent, results are merged in task order)"""
         dev, prover, w = self.dev, self.prover, self.w
 
         def timed(f):
@@ -173,54 +172,27 @@ class ShardFlow:
         mterms, mscalars = main_plan(w, w)
         chips, jobs = [], []
 
-        def one_chip(i, stream):
-            r = self.LOG_ROWS[i]
-            cols = [pcs.witness_mle(i, c) for c in range(w)]
-            fork = fork_factory()                                     # prover.rs:556-558, 682-689
-            fork.append_ext(alpha)
-            fork.append_ext(beta)
-            for v in (i, i, (1 << r) - 3, 0):
-                fork.append_base(v)
-            task = dict(circuit_idx=i, mles=cols, n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3, log2_num_instances=r,
-                        num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
-            proof = prover.create_chip_proof(dev, task, [alpha, beta], fork, stream)
-            return cols, proof, fork.sample_ext()
+        n_chips = len(self.LOG_ROWS)
+        cols_all = [[pcs.witness_mle(i, c) for c in range(w)] for i in range(n_chips)]
+        tasks = prover.ChipTasks([dict(circuit_idx=i, mles=cols_all[i], n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3,
+                                       log2_num_instances=r, num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs,
+                                       record_terms=terms, record_out_terms=out_terms) for i, r in enumerate(self.LOG_ROWS)])
 
         def chip_proofs():
-            n = len(self.LOG_ROWS)
-            if lanes <= 1:
-                chips.extend(one_chip(i, self.stream) for i in range(n))
-            else:
-                import queue
-                import threading
-
-                todo = queue.Queue()
-                for i in sorted(range(n), key=lambda i: -self.LOG_ROWS[i]):   # largest estimate first
-                    todo.put(i)
-                done = [None] * n
-                import os
-
-                plain = os.environ.get("CENO_LANE_PLAIN") == "1"   # A/B: same-priority streams instead of the rotating priorities
-                # lane streams live as long as the flow: creating a HIP stream costs ~4 ms and destroying one ~2 ms
-                while len(self.lane_streams) < lanes:
-                    l = len(self.lane_streams)
-                    self.lane_streams.append(dev.stream_create() if plain else dev.stream_create_lane(l))
-                streams = self.lane_streams[:lanes]
-
-                def worker(l):
-                    while True:
-                        try:
-                            i = todo.get_nowait()
-                        except queue.Empty:
-                            return
-                        done[i] = one_chip(i, streams[l])
-
-                ths = [threading.Thread(target=worker, args=(l,)) for l in range(lanes)]
-                for t in ths:
-                    t.start()
-                for t in ths:
-                    t.join()
-                chips.extend(done)                                    # results in task order (scheduler.rs:303-304)
+            # forks make the chip transcripts independent (prover.rs:556-558, 682-689); the proofs run on the product's own
+            # scheduler — ceno_prover_create_chip_proofs: C++ worker threads on the context's lane streams, largest chip first,
+            # booked against the pool (scheduler.rs:231-336) — and come back in task order (scheduler.rs:303-304)
+            forks = []
+            for i, r in enumerate(self.LOG_ROWS):
+                fork = fork_factory()
+                fork.append_ext(alpha)
+                fork.append_ext(beta)
+                for v in (i, i, (1 << r) - 3, 0):
+                    fork.append_base(v)
+                forks.append(fork)
+            proofs = prover.create_chip_proofs(dev, tasks, [alpha, beta], forks, max(1, lanes))
+            for i in range(n_chips):
+                chips.append((cols_all[i], proofs[i], forks[i].sample_ext()))
             for _, _, s in chips:                                     # one sample per fork back into the main transcript (prover.rs:567-570)
                 tr.append_ext(s)
 
@@ -253,7 +225,4 @@ class ShardFlow:
     def close(self):
         for t in self.traces:
             t.free()
-        for st in self.lane_streams:
-            self.dev.stream_destroy(st)
-        self.lane_streams = []
         self.dev.stream_destroy(self.stream)

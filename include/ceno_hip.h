@@ -73,6 +73,11 @@ int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out);
 /* stream for proving lane `lane` (concurrent chip proving, ceno_zkvm/src/scheme/scheduler.rs:73-85): consecutive lanes
  * get different stream priorities so that they land on different hardware queues and really overlap */
 int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out);
+/* the CONTEXT's stream of lane `lane` (0..63): created on first use (priorities rotate as in ceno_hip_stream_create_lane), reused by
+ * every later call, destroyed with the context — creating a HIP stream costs ~4 ms and destroying one ~2 ms, so the chip scheduler
+ * (ceno_prover_lanes_run; reference: the thread-bound streams of scheduler.rs:73-85,231-336) never does either per run.  Do NOT pass
+ * it to ceno_hip_stream_destroy. */
+int ceno_hip_lane_stream(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out);
 int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* registers a HIP stream the caller created itself with the pool's cross-stream ordering (see "Memory" above); the stream must
  * stay alive until ceno_hip_stream_destroy (which also forgets it) or the context is destroyed */

@@ -367,7 +367,7 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
                               uint64_t* out_proof);
 
 /* ---- concurrent chip proving on lanes (scheduler.rs:231-336, memory booking :342-347,:622-652) ----
- * One worker thread per lane, each with its own stream (ceno_hip_stream_create_lane); tasks are taken largest-estimate
+ * One worker thread per lane, each with the context's stream of that lane (ceno_hip_lane_stream: created once, never per run); tasks are taken largest-estimate
  * first, booked against the pool before they start (greedy back-fill with smaller tasks when the largest does not fit)
  * and unbooked when done.  `fn` runs the C ABI calls of one chip proof on the given stream and returns 0 or an error.
  * out_status / out_lane (n_tasks each, may be NULL) receive every task's return code and the lane that ran it. */
@@ -378,6 +378,12 @@ typedef struct ceno_lane_task {
     size_t estimated_bytes;
 } ceno_lane_task;
 int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane);
+/* The chip-proof phase of create_proof on the scheduler (prover.rs:556-570, scheduler.rs:231-336): task i = one
+ * ceno_prover_create_chip_proof with its OWN transcript (the caller forks the parent transcript per chip and merges one sample of
+ * each fork back afterwards, prover.rs:567-570), run on whichever of the context's lanes picks it, largest estimate first, booked
+ * against the pool.  out_proofs[i] are released with ceno_chip_proof_free; out_status (may be NULL) receives every task's code. */
+int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4,
+                                   ceno_transcript* const* transcripts, int n_lanes, ceno_chip_proof* out_proofs, int* out_status);
 
 const char* ceno_prover_last_error(void);
 
