@@ -256,9 +256,14 @@ __global__ void __launch_bounds__(NT) k_fold_batch(const MleSlot* __restrict__ s
 // `seed` (optional): the term's coefficient, folded into the FIRST extension factor as c*f(X) = c*hi + (X-1) * c*delta —
 // two multiplications instead of one per evaluation point (used when D >= 3).
 // ALLEXT: every table read is an extension table (all rounds after the first): the base-field arm is compiled out.
+// `flags`: bit 0 = a base-field product is running in pb, bit 1 = an extension-field product is running in pe.  ONE word by
+// reference: two separate bool references ended up in an 8-byte scratch frame (the compiler selected between their addresses:
+// `scratch_store_byte off, v1, s4`, 13-14 scratch instructions per instantiation of k_accum).
+static constexpr unsigned MF_BASE = 1u, MF_EXT = 2u;
 template <int D, bool ALLEXT = false>
-__device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_t p, E2 (&pe)[D], bool& has_e, uint64_t (&pb)[D], bool& has_b,
+__device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_t p, E2 (&pe)[D], uint64_t (&pb)[D], unsigned& flags,
                                            const E2* seed = nullptr) {
+    const bool has_b = flags & MF_BASE, has_e = flags & MF_EXT;
     if (!ALLEXT && !use_out && !sl.in_ext) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(sl.in + 2 * p);
         const uint64_t delta = sub(v.y, v.x);
@@ -276,7 +281,7 @@ __device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_
                 x = add(x, delta);
             }
         }
-        has_b = true;
+        flags |= MF_BASE;
     } else {
         E2 lo, hi;
         if (ALLEXT) {
@@ -305,7 +310,7 @@ __device__ __forceinline__ void mul_factor(const MleSlot& sl, int use_out, size_
                 x = x + delta;
             }
         }
-        has_e = true;
+        flags |= MF_EXT;
     }
 }
 
@@ -334,9 +339,10 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                     const E2 c = pl.coeffs[term];
                     E2 pr[D];
                     uint64_t pb[D];
-                    bool has_e = false, has_b = false;
+                    unsigned fl = 0;
                     for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
-                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b);
+                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, pb, fl);
+                    const bool has_e = fl & MF_EXT, has_b = fl & MF_BASE;
                     if (has_e) {
                         if (has_b) {
 #pragma unroll
@@ -362,8 +368,9 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                 if (ce > cb) {
                     E2 cm[D];
                     uint64_t cmb[D];
-                    bool has_e = false, has_b = false;
-                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
+                    unsigned fl = 0;
+                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, cmb, fl);
+                    const bool has_e = fl & MF_EXT, has_b = fl & MF_BASE;
 #pragma unroll
                     for (int t = 0; t < D; t++) {
                         E2 v = inner[t];
@@ -391,11 +398,11 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                     constexpr bool FOLD_SEED = D >= 3;
 #pragma unroll
                     for (int t = 0; t < D; t++) pr[t] = c;
-                    bool has_e = !FOLD_SEED, has_b = false;
+                    unsigned fl = FOLD_SEED ? 0u : MF_EXT;
                     for (uint32_t k = pl.term_off[term]; k < pl.term_off[term + 1]; k++)
-                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, has_e, pb, has_b, FOLD_SEED ? &c : nullptr);
+                        mul_factor<D>(pl.slots[pl.term_idx[k]], pl.use_out, p, pr, pb, fl, FOLD_SEED ? &c : nullptr);
                     // no extension factor at all: pr still holds the coefficient
-                    if (has_b) {
+                    if (fl & MF_BASE) {
 #pragma unroll
                         for (int t = 0; t < D; t++) pr[t] = e2_mul_base(pr[t], pb[t]);
                     }
@@ -406,8 +413,9 @@ __global__ void __launch_bounds__(NT) k_accum(DevPlan pl, size_t pairs, Epilogue
                 if (ce > cb) {
                     E2 cm[D];
                     uint64_t cmb[D];
-                    bool has_e = false, has_b = false;
-                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, has_e, cmb, has_b);
+                    unsigned fl = 0;
+                    for (uint32_t k = cb; k < ce; k++) mul_factor<D>(pl.slots[pl.common_idx[k]], pl.use_out, p, cm, cmb, fl);
+                    const bool has_e = fl & MF_EXT, has_b = fl & MF_BASE;
 #pragma unroll
                     for (int t = 0; t < D; t++) {
                         E2 v = inner[t];
@@ -879,10 +887,12 @@ static int dense_wide_mode() {  // tuning switch: 0 = never, 1 = read-only round
     return m;
 }
 
-static int dense_pf_mode() {  // tuning switch (bit 0: read-only round, bit 1: folding rounds): software-pipelined loads
+static int dense_pf_mode() {  // tuning switch (bit 0: read-only round, bit 1: folding rounds): software-pipelined loads.  Measured
+    // neutral on MI355X (profiles/r03_dense_kernel_ab.json: 2.88 vs 2.89 ms per nv=26 sumcheck on one box), so the default stays
+    // with the compiler-scheduled form
     static int m = [] {
         const char* e = getenv("CENO_HIP_DENSE_PF");
-        return e ? atoi(e) : 3;
+        return e ? atoi(e) : 0;
     }();
     return m;
 }

@@ -121,7 +121,9 @@ __device__ __forceinline__ bool read_challenge(const Epilogue& ep, E2& r, unsign
 // `seq` / `next_seq` are passed apart from `ep` so that the persistent tail kernel can publish round after round from the
 // kernel-argument copy of the epilogue: a modified local copy of the struct would live in scratch memory (its arrays are
 // indexed at run time) and every field read on this single-lane critical path would become a scratch load.
-template <int D>
+// SCALARS = false: the caller is a persistent single-class kernel (k_mid, k_tail): no front-load scalars exist there, and not
+// reading them keeps 32 SGPRs of kernel arguments out of the persistent loop (those kernels spilled 60-280 SGPRs into VGPR lanes).
+template <int D, bool SCALARS = true>
 __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogue& ep, unsigned long long seq, unsigned long long next_seq) {
     const bool unit = (ep.coeff.c0 == 1 && ep.coeff.c1 == 0);
     if (ep.dbg && ep.bcast) ep.bcast->dbg[seq & 63][1] = wall_clock64();
@@ -131,7 +133,7 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
     auto emit = [&](int t, E2 v) {
         if (!ep.first_class) v = v + ep.round_acc[t];
         if (ep.last_class) {
-            v = v + ep.scalars[t];
+            if (SCALARS) v = v + ep.scalars[t];
             if (ep.flag) {
                 // ONE 16-byte write-through system-scope store per point (each such store is its own fabric transaction)
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         red::block_sum<D, NT>(acc, smem);
         if (threadIdx.x == 0) {
             // next_seq = 0: the challenge is fetched right here, not relayed to another launch
-            finish_message<D>(acc, ep, (unsigned long long)(i + 1), 0ull);
+            finish_message<D, false>(acc, ep, (unsigned long long)(i + 1), 0ull);
             if (i + 1 < n || out_evals) {  // after the last message: the challenge the final evaluations are taken at
                 unsigned long long c0 = 0, c1 = 0;
                 const bool ok = poll_challenge(ep.mailbox, (unsigned long long)(i + 1), c0, c1, ep.poll_ticks);
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
             __syncthreads();
             if (s_chal[3] == 0) return;  // nothing is published: the host sees the stream drain without a message
             red::block_sum<D, NT>(tot, smem);
-            if (threadIdx.x == 0) finish_message<D>(tot, ep, (unsigned long long)(i + 1), 0ull);
+            if (threadIdx.x == 0) finish_message<D, false>(tot, ep, (unsigned long long)(i + 1), 0ull);
             for (int bb = threadIdx.x; bb < W; bb += NT) {  // re-arm this round's set behind the message
                 uint64_t* row = rows + (size_t)bb * D * 2;
 #pragma unroll

@@ -204,7 +204,7 @@ class ShardFlow:
                              max_degree=4, terms=mterms, scalars=mscalars))
         mj = prover.MainJobs(jobs)
         (claimed, msgs, rt, evals), res["batched_main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, mj, [alpha, beta], tr, self.stream))
-        # (kept for tools/dbg_shard_digest.py: what the opening is asked to prove, available even when the opening fails)
+        # (kept for tools/dev/dbg_shard_digest.py: what the opening is asked to prove, available even when the opening fails)
         self.pre_open = dict(roots=[pcs.root()], alpha=alpha, chip_proofs=[c[1] for c in chips], msgs=msgs, rt=rt, evals=evals)
         points = [rt[:r] for r in self.LOG_ROWS]
         ev = [evals[i * (w + 1): i * (w + 1) + w] for i in range(len(self.LOG_ROWS))]

@@ -1,4 +1,4 @@
-"""one tower proof (chip-flow shape, 2^LOG rows) for kernel-trace timelines: python tools/dbg_tower_only.py [log_rows]"""
+"""one tower proof (chip-flow shape, 2^LOG rows) for kernel-trace timelines: python tools/dev/dbg_tower_only.py [log_rows]"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from ceno_amd import Device, prover, synthetic
