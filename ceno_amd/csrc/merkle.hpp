@@ -9,6 +9,7 @@ struct PoseidonParams {
 
 struct ceno_hip_merkle {
     int log_rows = 0;
+    hipStream_t st = nullptr;        // the stream the tree was built on: its blocks go back to the pool tagged with it (merkle_release)
     std::vector<uint64_t*> levels;   // levels[0] = 2^log_rows leaf digests (4 words each) ... levels[log_rows] = root
     uint64_t* h_root = nullptr;      // pinned host copy of the root, written by the kernel that computes it (no D2H blit)
     uint64_t* d_root_view = nullptr; // device view of h_root
@@ -34,7 +35,7 @@ struct MmcsMat {
 };
 
 int get_params(ceno_hip_ctx* ctx, const p2::Params** out);
-int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out);
+int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out);  // owner stream = the stream the calling thread resolved last
 // levels 1.. from the leaf digests in levels[0]; inject[l] (may be NULL / absent) = digests of the rows of the matrices whose
 // height equals level l's node count: parent = compress(compress(left, right), inject[l][i])  (p3 MerkleTreeMmcs)
 int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, const uint64_t* const* inject = nullptr);

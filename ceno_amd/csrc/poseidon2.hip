@@ -182,8 +182,10 @@ void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
     if (t->h_root) ctx_pinned_free(ctx, t->h_root);
     if (t->h_table) ctx_pinned_free(ctx, t->h_table);
-    if (t->d_table) ctx_free(ctx, t->d_table);
-    for (auto* p : t->levels) ctx_free(ctx, p);
+    if (t->d_table) ctx_free_on(ctx, t->d_table, t->st);
+    // freed with the OWNER's stream, whatever stream the calling thread resolved last (a thread that drives several streams:
+    // the opening, commit helpers) — another stream gets these blocks only once the owner has drained
+    for (auto* p : t->levels) ctx_free_on(ctx, p, t->st);
     delete t;
 }
 
@@ -191,6 +193,7 @@ void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
 int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
     auto* t = new ceno_hip_merkle();
     t->log_rows = log_rows;
+    t->st = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;  // every caller resolves its stream before it allocates
     t->levels.assign(log_rows + 1, nullptr);
     for (int l = 0; l <= log_rows; l++) {
         void* p = nullptr;

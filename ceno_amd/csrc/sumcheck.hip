@@ -932,6 +932,19 @@ static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pa
     launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
 }
 
+// the same launch with the tables of one staged slot row (pipelined rounds: the ping-pong walk of every round is staged once)
+template <int K>
+static void launch_dense_row(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pairs, E2 r, unsigned grid, const Epilogue& ep, const MleSlot* row) {
+    TabPtrs<K> tp;
+    const ScTerm& term = sc->terms[cl.terms[0]];
+    for (int m = 0; m < K; m++) {
+        const MleSlot& sl = row[sc->mles[term.idx[m]].local];
+        tp.in[m] = sl.in;
+        tp.out[m] = sl.out;
+    }
+    launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
+}
+
 static bool accum_lazy() {
     static bool v = [] {
         const char* e = getenv("CENO_HIP_ACCUM_LAZY");  // 1: unreduced coefficient products (60 more VGPRs; measured +-1 %, off by default)
@@ -1464,7 +1477,9 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     // A single generic class over all n variables is what the pipelined driver runs: its slot table of every round is
     // deterministic (ping-pong), so it travels inside the plan blob — one set-up kernel, not a second one at round 0
     size_t off_pre_slots = (size_t)-1;
-    if (sc->classes.size() == 1 && !sc->classes[0].dense && sc->classes[0].nv == n && n >= 1 && !sc->classes[0].terms.empty()) {
+    // (a dense class too: its LARGE rounds run the register-resident fused kernel, its small rounds join the same latency
+    // ladder — k_mid / k_tail — as every other pipelined sumcheck: sc_pipeline_enqueue)
+    if (sc->classes.size() == 1 && sc->classes[0].nv == n && n >= 1 && !sc->classes[0].terms.empty()) {
         const ScClass& cl = sc->classes[0];
         const size_t k = cl.mles.size();
         std::vector<MleSlot> rows((size_t)(n + 2) * k);
@@ -1713,25 +1728,15 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     upto = std::min(upto, sc->n);
     const int from = sc->enq;
     if (from >= upto) return 0;
-    if (cl.dense) {
-        const ScTerm& T = sc->terms[cl.terms[0]];
-        const int K = (int)T.idx.size();
-        for (int i = from; i < upto; i++) {
-            const size_t pairs = (size_t)1 << (cl.nv - i - 1);
-            const unsigned grid = sc_grid(pairs);
-            Epilogue ep = pipe_epilogue(sc, cl, i);
-            ep.coeff = T.coeff;
-            const bool base_in = !sc->mles[T.idx[0]].cur_ext;
-            const int mode = (i == 0 ? 0 : 2) + (base_in ? 1 : 0);
-            switch (K) {
-            case 1: pipe_launch<1>(sc, cl, mode, pairs, grid, ep); break;
-            case 2: pipe_launch<2>(sc, cl, mode, pairs, grid, ep); break;
-            case 3: pipe_launch<3>(sc, cl, mode, pairs, grid, ep); break;
-            default: pipe_launch<4>(sc, cl, mode, pairs, grid, ep); break;
-            }
-            if (i > 0) sc_advance(sc, cl);
-        }
-    } else {
+    // A dense class (one product of K <= 4 tables) runs its LARGE rounds on the register-resident fused kernel and hands over to
+    // the latency ladder below (k_mid / k_tail: persistent kernels, no kernel boundary and no cross-workgroup counter per round)
+    // once a round has at most 2^15 pairs: the last ~15 rounds of every dense sumcheck cost ~9-13 us instead of ~15 us each
+    // (CENO_HIP_DENSE_LADDER=0 keeps one k_dense launch per round: A/B measurements).
+    static const size_t dense_small_pairs = [] {
+        const char* e = getenv("CENO_HIP_DENSE_LADDER");
+        return (e && atoi(e) == 0) ? (size_t)0 : (size_t)1 << 15;
+    }();
+    {
         // slot tables of every round are deterministic: stage them all, one upload
         const size_t k = cl.mles.size();
         for (int i = 0; i < sc->n && from == 0; i++) {
@@ -1758,6 +1763,20 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
         for (int i = from; i < upto; i++) {
             const size_t pairs = (size_t)1 << (cl.nv - i - 1);
             Epilogue ep = pipe_epilogue(sc, cl, i);
+            if (cl.dense && pairs > dense_small_pairs) {
+                const ScTerm& T = sc->terms[cl.terms[0]];
+                const MleSlot* row = sc->h_slots + (size_t)i * sc->slots_per_round;
+                ep.coeff = T.coeff;
+                const int mode = (i == 0 ? 0 : 2) + (row[0].in_ext ? 0 : 1);
+                const unsigned grid = sc_grid(pairs);
+                switch ((int)T.idx.size()) {
+                case 1: launch_dense_row<1>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
+                case 2: launch_dense_row<2>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
+                case 3: launch_dense_row<3>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
+                default: launch_dense_row<4>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
+                }
+                continue;
+            }
             DevPlan pl;
             pl.slots = cl.d_slots + (size_t)i * k;
             pl.use_out = i > 0 ? 1 : 0;
