@@ -348,14 +348,16 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
     return 0;
 }
 
-int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major, const int* log_rows, const int* widths, int n_mats,
-                         ceno_hip_stream s, ceno_hip_merkle** out) {
-    CHECK_ARG(ctx, dev_col_major && log_rows && widths && out && n_mats >= 1 && n_mats <= 65535, "bad mmcs_commit arguments");
-    int H = 0;
+// `leaf_digests` != NULL: the tree's layer 0 is GIVEN (2^log_leaves digests, e.g. the sub-tree roots of the ranks of a sharded
+// commitment) and every matrix is shorter than it: they are injected at their levels above, exactly as in the full tree.
+static int mmcs_commit_impl(ceno_hip_ctx* ctx, const uint64_t* leaf_digests, int log_leaves, const uint64_t* const* dev_col_major, const int* log_rows,
+                            const int* widths, int n_mats, ceno_hip_stream s, ceno_hip_merkle** out) {
+    int H = leaf_digests ? log_leaves : 0;
     size_t total_w = 0;
     for (int m = 0; m < n_mats; m++) {
         CHECK_ARG(ctx, dev_col_major[m] && log_rows[m] >= 0 && log_rows[m] < 40 && widths[m] >= 1, "bad matrix %d", m);
-        H = std::max(H, log_rows[m]);
+        if (leaf_digests) CHECK_ARG(ctx, log_rows[m] < log_leaves, "matrix %d is not shorter than the given digest layer", m);
+        else H = std::max(H, log_rows[m]);
         total_w += (size_t)widths[m];
     }
     const p2::Params* pp;
@@ -364,6 +366,10 @@ int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major
     ceno_hip_merkle* t = nullptr;
     TRY(merkle_alloc(ctx, H, &t));
     t->total_width = total_w;
+    if (leaf_digests && hipMemcpyAsync(t->levels[0], leaf_digests, ((size_t)32) << H, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        merkle_release(ctx, t);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "mmcs_commit: copy of the digest layer failed");
+    }
     for (int m = 0; m < n_mats; m++) t->mats.push_back({dev_col_major[m], log_rows[m], widths[m]});
     // tallest first, STABLE: equal heights keep the caller's order (p3 MerkleTree::new sorts by Reverse(height))
     std::vector<int> order(n_mats);
@@ -381,7 +387,7 @@ int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major
         MmcsClass c{};
         c.log_rows = (uint32_t)h;
         c.seg0 = (uint32_t)segs.size();
-        if (h == H) c.out = t->levels[0];
+        if (h == H && !leaf_digests) c.out = t->levels[0];
         else {
             void* p = nullptr;
             rc = ctx_alloc(ctx, ((size_t)1 << h) * 32, &p);
@@ -429,7 +435,8 @@ int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major
         const auto* d_cls = reinterpret_cast<const MmcsClass*>(d_tab);
         const auto* d_seg = reinterpret_cast<const MmcsMat*>((char*)d_tab + off_seg);
         static const bool canon = [] { const char* e = getenv("CENO_HIP_P2_CANONICAL"); return e && atoi(e) != 0; }();
-        if (canon) hipLaunchKernelGGL(k_leaf_hash_classes<true>, dim3(nblocks_total), dim3(NT), 0, st, d_cls, (int)cls.size(), d_seg, pp);
+        if (cls.empty()) {
+        } else if (canon) hipLaunchKernelGGL(k_leaf_hash_classes<true>, dim3(nblocks_total), dim3(NT), 0, st, d_cls, (int)cls.size(), d_seg, pp);
         else hipLaunchKernelGGL(k_leaf_hash_classes<false>, dim3(nblocks_total), dim3(NT), 0, st, d_cls, (int)cls.size(), d_seg, pp);
         rc = merkle_build_upper(ctx, t, st, inject.data());
     }
@@ -440,6 +447,19 @@ int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major
     }
     *out = t;
     return 0;
+}
+
+int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major, const int* log_rows, const int* widths, int n_mats,
+                         ceno_hip_stream s, ceno_hip_merkle** out) {
+    CHECK_ARG(ctx, dev_col_major && log_rows && widths && out && n_mats >= 1 && n_mats <= 65535, "bad mmcs_commit arguments");
+    return mmcs_commit_impl(ctx, nullptr, 0, dev_col_major, log_rows, widths, n_mats, s, out);
+}
+
+int ceno_hip_mmcs_commit_over(ceno_hip_ctx* ctx, const uint64_t* dev_leaf_digests, int log_leaves, const uint64_t* const* dev_col_major,
+                              const int* log_rows, const int* widths, int n_mats, ceno_hip_stream s, ceno_hip_merkle** out) {
+    CHECK_ARG(ctx, dev_leaf_digests && out && log_leaves >= 0 && log_leaves < 40 && n_mats >= 0 && n_mats <= 65535, "bad mmcs_commit_over arguments");
+    CHECK_ARG(ctx, n_mats == 0 || (dev_col_major && log_rows && widths), "bad mmcs_commit_over arguments");
+    return mmcs_commit_impl(ctx, dev_leaf_digests, log_leaves, dev_col_major, log_rows, widths, n_mats, s, out);
 }
 
 size_t ceno_hip_mmcs_opening_words(const ceno_hip_merkle* t) { return t ? t->total_width + 4 * (size_t)t->log_rows : 0; }

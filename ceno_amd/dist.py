@@ -430,3 +430,43 @@ def sharded_commit_native(dev, comm_handle, d_cols_ptr: int, widths, log_rows: i
     if rc != 0:
         raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
     return {"root": root, "subtree": sub, "subtree_roots": roots, "codeword_rows": rows, "rank": rank}
+
+
+def sharded_commit_mmcs_native(dev, comm_handle, d_cols_ptrs, widths, log_rows, log_blowup: int, rank: int, stream):
+    """Several matrices of several heights under ONE root across ranks (`ceno_dist_commit_traces_mmcs`, ceno_amd/host/dist.cpp): the
+    multi-rank form of commit_traces, equal to the single-device mixed-height commitment bit for bit.  widths[m][g] = columns of matrix
+    m on rank g; d_cols_ptrs[m] = this rank's columns of matrix m (device pointer, column-major).  Returns {"root", "subtree", "top"
+    (ceno_hip_merkle* or None), "subtree_roots", "codeword_rows": per matrix an int64 tensor ((total width) x rows of this rank)}."""
+    import ctypes as C
+
+    import torch
+
+    from . import prover
+    from .api import CenoHipError
+
+    L = prover.plib()
+    n = len(log_rows)
+    world = len(widths[0])
+    log_w = world.bit_length() - 1
+    L.ceno_dist_commit_traces_mmcs.restype = C.c_int
+    L.ceno_dist_commit_traces_mmcs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_int,
+                                               C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_uint64)]
+    outs = []
+    for m in range(n):
+        R = 1 << (log_rows[m] + log_blowup)
+        rl = R if log_rows[m] + log_blowup < log_w else R // world
+        outs.append(torch.empty(max(1, int(sum(widths[m])) * rl), dtype=torch.int64, device=f"cuda:{dev.device}"))
+    roots = np.zeros((world, 4), dtype=np.uint64)
+    root = np.zeros(4, dtype=np.uint64)
+    sub, top = C.c_void_p(), C.c_void_p()
+    lr = (C.c_int * n)(*[int(x) for x in log_rows])
+    wa = (C.c_int * (n * world))(*[int(w) for row in widths for w in row])
+    cp = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_cols_ptrs])
+    op = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in outs])
+    u64p = C.POINTER(C.c_uint64)
+    rc = L.ceno_dist_commit_traces_mmcs(dev.h, comm_handle, n, lr, wa, cp, log_blowup, stream, op, C.byref(sub), C.byref(top),
+                                        roots.ctypes.data_as(u64p), root.ctypes.data_as(u64p))
+    if rc != 0:
+        raise CenoHipError(rc, (L.ceno_dist_last_error() or b"").decode())
+    return {"root": root, "subtree": sub, "top": top if top else None, "subtree_roots": roots, "codeword_rows": outs, "rank": rank}

@@ -1009,94 +1009,127 @@ int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_
     return 0;
 }
 
-int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t* local_cols_dev, const int* widths, int log_rows, int log_blowup,
-                            ceno_hip_stream s, uint64_t* out_rows_dev, ceno_hip_merkle** out_subtree, uint64_t* out_subtree_roots,
-                            uint64_t* out_root) {
-    if (!ctx || !c || !widths || !s || !out_rows_dev || !out_subtree || !out_root)
+// The multi-rank form of commit_traces: SEVERAL matrices of several heights under ONE root that equals the single-device
+// mixed-height commitment (ceno_hip_mmcs_commit) bit for bit.  Rank g holds widths[m * world + g] columns of every matrix m.
+//   1. every rank RS-encodes its columns of every matrix (no exchange);
+//   2. per matrix one all-to-all of unequal blocks re-shards the codeword by rows (rank g gets rows [g R_m / W, (g+1) R_m / W) of
+//      ALL columns); a matrix with fewer codeword rows than ranks is gathered whole on every rank instead;
+//   3. rank g's sub-tree = the mixed-height tree over its row shards: it is the sub-tree under node g of the level with W nodes
+//      of the global tree, injected classes included (a class with exactly W rows joins at the sub-tree's root);
+//   4. the W sub-tree roots are gathered and the top log2 W levels are built on every rank over that digest layer, with the
+//      classes shorter than W joining there (ceno_hip_mmcs_commit_over).
+int ceno_dist_commit_traces_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, const int* log_rows, const int* widths,
+                                 const uint64_t* const* local_cols_dev, int log_blowup, ceno_hip_stream s, uint64_t* const* out_rows_dev,
+                                 ceno_hip_merkle** out_subtree, ceno_hip_merkle** out_top, uint64_t* out_subtree_roots, uint64_t* out_root) {
+    if (!ctx || !c || !log_rows || !widths || !local_cols_dev || !s || !out_rows_dev || !out_subtree || !out_root || n_mats < 1)
         return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: NULL argument (an explicit stream is required)");
     const int W = c->world, me = c->rank;
     int log_w = 0;
     while ((1 << log_w) < W) log_w++;
     if ((1 << log_w) != W) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: world must be a power of two");
-    if (log_rows < 0 || log_blowup < 0 || log_rows + log_blowup < log_w || log_rows + log_blowup > 40)
-        return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad log_rows / log_blowup");
-    size_t w_total = 0;
-    for (int g = 0; g < W; g++) {
-        if (widths[g] < 0) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: negative width");
-        w_total += (size_t)widths[g];
+    if (log_blowup < 0) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad log_blowup");
+    int log_max = 0;
+    std::vector<size_t> w_total((size_t)n_mats, 0);
+    for (int m = 0; m < n_mats; m++) {
+        if (log_rows[m] < 0 || log_rows[m] + log_blowup > 40) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad log_rows");
+        log_max = std::max(log_max, log_rows[m] + log_blowup);
+        for (int g = 0; g < W; g++) {
+            if (widths[(size_t)m * W + g] < 0) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: negative width");
+            w_total[m] += (size_t)widths[(size_t)m * W + g];
+        }
+        if (w_total[m] == 0 || w_total[m] > (1u << 20)) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad total width");
+        if (widths[(size_t)m * W + me] && !local_cols_dev[m]) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: local_cols_dev is NULL");
+        if (!out_rows_dev[m]) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: out_rows_dev is NULL");
     }
-    const size_t w_local = (size_t)widths[me];
-    if (w_total == 0 || w_total > (1u << 20)) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad total width");
-    if (w_local && !local_cols_dev) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: local_cols_dev is NULL");
-    const size_t R = (size_t)1 << (log_rows + log_blowup), rl = R >> log_w;
+    if (log_max < log_w) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: the tallest codeword has fewer rows than there are ranks");
     hipStream_t st = (hipStream_t)s;
     (void)ceno_hip_stream_bind(ctx, s);  // every allocation below is for work on `s`
     auto fail_hip = [&](int rc) {
         g_dist_err = ceno_hip_last_error(ctx);
         return rc;
     };
-
-    // 1. encode my columns; 2. pack: block for destination h = rows [h rl, (h+1) rl) of each of my columns (one strided copy
-    // per destination, the rows of one column are contiguous)
-    uint64_t *d_cw = nullptr, *d_pack = nullptr;
     std::vector<ceno_hip_mle*> scratch;  // pool blocks through the C ABI (the host layer has no other access to the pool)
     auto pool_words = [&](size_t words, uint64_t** out) -> int {
         int nv = 0;
         while (((size_t)1 << nv) < words) nv++;
-        ceno_hip_mle* m = nullptr;
-        int rc = ceno_hip_mle_alloc(ctx, nv, 0, &m);
+        ceno_hip_mle* mm = nullptr;
+        int rc = ceno_hip_mle_alloc(ctx, nv, 0, &mm);
         if (rc) return rc;
-        scratch.push_back(m);
-        *out = ceno_hip_mle_device_ptr(m);
+        scratch.push_back(mm);
+        *out = ceno_hip_mle_device_ptr(mm);
         return 0;
     };
     auto release = [&]() {
-        for (auto* m : scratch) ceno_hip_mle_free(ctx, m);
+        for (auto* mm : scratch) ceno_hip_mle_free(ctx, mm);
         scratch.clear();
     };
     int rc = 0;
     // a one-rank communicator normally skips the exchange; CENO_DIST_SELF_P2P=1 (tests) sends the own block through RCCL
     const bool exchange = W > 1 || (c->comm && getenv("CENO_DIST_SELF_P2P") && atoi(getenv("CENO_DIST_SELF_P2P")) != 0);
-    if (w_local) {
-        if ((rc = pool_words(w_local * R, &d_cw)) || (exchange && (rc = pool_words(w_local * R, &d_pack)))) {
-            release();
-            return fail_hip(rc);
+    for (int m = 0; m < n_mats; m++) {
+        const size_t w_local = (size_t)widths[(size_t)m * W + me];
+        const int lr = log_rows[m] + log_blowup;
+        const size_t R = (size_t)1 << lr;
+        const bool tiny = lr < log_w;                 // fewer rows than ranks: every rank gets the whole codeword
+        const size_t rl = tiny ? R : (R >> log_w);    // rows this rank ends up with
+        uint64_t *d_cw = nullptr, *d_pack = nullptr;
+        if (w_local) {
+            if ((rc = pool_words(w_local * R, &d_cw)) || (exchange && !tiny && (rc = pool_words(w_local * R, &d_pack)))) {
+                release();
+                return fail_hip(rc);
+            }
+            if ((rc = ceno_hip_rs_encode(ctx, local_cols_dev[m], log_rows[m], (int)w_local, log_blowup, d_cw, s))) {
+                release();
+                return fail_hip(rc);
+            }
         }
-        if ((rc = ceno_hip_rs_encode(ctx, local_cols_dev, log_rows, (int)w_local, log_blowup, d_cw, s))) {
-            release();
-            return fail_hip(rc);
+        std::vector<size_t> soff((size_t)W), scnt((size_t)W), roff((size_t)W), rcnt((size_t)W);
+        size_t col0 = 0;
+        for (int g = 0; g < W; g++) {
+            soff[g] = tiny ? 0 : (size_t)g * w_local * rl;  // tiny: the same block (all my columns, all rows) goes to everybody
+            scnt[g] = w_local * rl;
+            roff[g] = col0 * rl;  // source ranks in order = global column order
+            rcnt[g] = (size_t)widths[(size_t)m * W + g] * rl;
+            col0 += (size_t)widths[(size_t)m * W + g];
+        }
+        if (!exchange) {
+            if (w_local && hipMemcpyAsync(out_rows_dev[m], d_cw, w_local * R * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                release();
+                return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: copy failed");
+            }
+        } else {
+            // pack: block for destination h = rows [h rl, (h+1) rl) of each of my columns (one strided copy per destination, the
+            // rows of one column are contiguous); a tiny matrix needs no packing
+            if (w_local && !tiny)
+                for (int h = 0; h < W; h++)
+                    if (hipMemcpy2DAsync(d_pack + soff[h], rl * 8, d_cw + (size_t)h * rl, R * 8, rl * 8, w_local, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                        release();
+                        return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: pack failed");
+                    }
+            if ((rc = exchange_blocks(c, tiny ? d_cw : d_pack, soff.data(), scnt.data(), out_rows_dev[m], roff.data(), rcnt.data(), st))) {
+                (void)hipStreamSynchronize(st);
+                release();
+                return rc;
+            }
         }
     }
-    std::vector<size_t> soff((size_t)W), scnt((size_t)W), roff((size_t)W), rcnt((size_t)W);
-    size_t col0 = 0;
-    for (int g = 0; g < W; g++) {
-        soff[g] = (size_t)g * w_local * rl;
-        scnt[g] = w_local * rl;
-        roff[g] = col0 * rl;  // source ranks in order = global column order
-        rcnt[g] = (size_t)widths[g] * rl;
-        col0 += (size_t)widths[g];
-    }
-    if (!exchange) {
-        if (hipMemcpyAsync(out_rows_dev, d_cw, w_local * R * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            release();
-            return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: copy failed");
-        }
-    } else {
-        if (w_local)
-            for (int h = 0; h < W; h++)
-                if (hipMemcpy2DAsync(d_pack + soff[h], rl * 8, d_cw + (size_t)h * rl, R * 8, rl * 8, w_local, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                    release();
-                    return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: pack failed");
-                }
-        if ((rc = exchange_blocks(c, d_pack, soff.data(), scnt.data(), out_rows_dev, roff.data(), rcnt.data(), st))) {
-            (void)hipStreamSynchronize(st);
-            release();
-            return rc;
+    // 3. sub-tree over my row shards of every matrix with at least one row per rank
+    std::vector<const uint64_t*> sp, tp;
+    std::vector<int> slr, sw, tlr, tw;
+    for (int m = 0; m < n_mats; m++) {
+        const int lr = log_rows[m] + log_blowup;
+        if (lr >= log_w) {
+            sp.push_back(out_rows_dev[m]);
+            slr.push_back(lr - log_w);
+            sw.push_back((int)w_total[m]);
+        } else {
+            tp.push_back(out_rows_dev[m]);
+            tlr.push_back(lr);
+            tw.push_back((int)w_total[m]);
         }
     }
-    // 3. sub-tree over my rows; 4. gather the sub-tree roots, hash the top levels (node = permute(left || right)[0..4))
     ceno_hip_merkle* sub = nullptr;
-    if ((rc = ceno_hip_merkle_commit(ctx, out_rows_dev, log_rows + log_blowup - log_w, (int)w_total, s, &sub))) {
+    if ((rc = ceno_hip_mmcs_commit(ctx, sp.data(), slr.data(), sw.data(), (int)sp.size(), s, &sub))) {
         (void)hipStreamSynchronize(st);
         release();
         return fail_hip(rc);
@@ -1108,33 +1141,48 @@ int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t
         return fail_hip(rc);
     }
     release();
+    // 4. gather the sub-tree roots; the top log2 W levels (with the classes shorter than W) on every rank
     std::vector<uint64_t> level((size_t)W * 4);
     if ((rc = gather_digests(c, mine, level.data(), st))) {
         ceno_hip_merkle_free(ctx, sub);
         return rc;
     }
     if (out_subtree_roots) memcpy(out_subtree_roots, level.data(), (size_t)W * 32);
-    if (W > 1) {
-        uint64_t* d_states = nullptr;
-        if ((rc = pool_words((size_t)W * 4, &d_states))) {
+    ceno_hip_merkle* top = nullptr;
+    if (W > 1 || !tp.empty()) {
+        uint64_t* d_level = nullptr;
+        if ((rc = pool_words((size_t)W * 4, &d_level))) {
             ceno_hip_merkle_free(ctx, sub);
             return fail_hip(rc);
         }
-        for (size_t n = (size_t)W; n > 1; n >>= 1) {  // n digests = n/2 states of 8 words
-            if (hipMemcpyAsync(d_states, level.data(), n * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
-                ceno_hip_poseidon2_permute(ctx, d_states, n / 2, s) != 0 ||
-                hipMemcpyAsync(level.data(), d_states, n * 32, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                release();
-                ceno_hip_merkle_free(ctx, sub);
-                return dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: top levels failed");
-            }
-            for (size_t j = 0; j < n / 2; j++) memmove(&level[4 * j], &level[8 * j], 32);
-        }
+        if (hipMemcpyAsync(d_level, level.data(), (size_t)W * 32, hipMemcpyHostToDevice, st) != hipSuccess) rc = dist_fail(CENO_HIP_ERR_HIP, "dist_commit_traces: upload of the sub-tree roots failed");
+        if (!rc && (rc = ceno_hip_mmcs_commit_over(ctx, d_level, log_w, tp.data(), tlr.data(), tw.data(), (int)tp.size(), s, &top))) rc = fail_hip(rc);
+        if (!rc && (rc = ceno_hip_merkle_root(ctx, top, out_root, s))) rc = fail_hip(rc);
         release();
+        if (rc) {
+            if (top) ceno_hip_merkle_free(ctx, top);
+            ceno_hip_merkle_free(ctx, sub);
+            return rc;
+        }
+    } else {
+        memcpy(out_root, mine, 32);
     }
-    memcpy(out_root, level.data(), 32);
+    if (out_top) *out_top = top;
+    else if (top) ceno_hip_merkle_free(ctx, top);
     *out_subtree = sub;
     return 0;
+}
+
+// one matrix: the round-1/2 entry point
+int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t* local_cols_dev, const int* widths, int log_rows, int log_blowup,
+                            ceno_hip_stream s, uint64_t* out_rows_dev, ceno_hip_merkle** out_subtree, uint64_t* out_subtree_roots,
+                            uint64_t* out_root) {
+    if (!c || !widths) return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: NULL argument (an explicit stream is required)");
+    if (log_rows + log_blowup < 0 || (1 << std::min(log_rows + log_blowup, 30)) < c->world)
+        return dist_fail(CENO_HIP_ERR_INVALID, "dist_commit_traces: bad log_rows / log_blowup");
+    const uint64_t* cols[1] = {local_cols_dev};
+    uint64_t* outs[1] = {out_rows_dev};
+    return ceno_dist_commit_traces_mmcs(ctx, c, 1, &log_rows, widths, cols, log_blowup, s, outs, out_subtree, nullptr, out_subtree_roots, out_root);
 }
 
 }  // extern "C"

@@ -289,6 +289,12 @@ int ceno_hip_merkle_commit(ceno_hip_ctx* ctx, const uint64_t* dev_col_major, int
  * The tree has max(log_rows) levels below the root; ceno_hip_merkle_root / _open / _open_batch / _free apply. */
 int ceno_hip_mmcs_commit(ceno_hip_ctx* ctx, const uint64_t* const* dev_col_major, const int* log_rows, const int* widths, int n_mats,
                          ceno_hip_stream s, ceno_hip_merkle** out);
+/* The same tree over a GIVEN bottom layer of 2^log_leaves digests (4 words each, device memory) instead of hashed rows: every
+ * matrix (n_mats may be 0) is shorter than that layer and joins at its level above.  This is the top of a commitment whose rows are
+ * sharded over the GPUs of a node: the layer = the ranks' sub-tree roots, the matrices = the classes with fewer rows than ranks
+ * (ceno_dist_commit_traces_mmcs). */
+int ceno_hip_mmcs_commit_over(ceno_hip_ctx* ctx, const uint64_t* dev_leaf_digests, int log_leaves, const uint64_t* const* dev_col_major,
+                              const int* log_rows, const int* widths, int n_mats, ceno_hip_stream s, ceno_hip_merkle** out);
 /* MerkleTreeMmcs::open_batch for many indices at once: for query q, index i_q = dev_indices[q] >> shift (a row of the tallest
  * height), dev_out[q * out_stride_words ..] = [row (i_q >> (log_max - log_rows[m])) of every matrix m in the caller's order]
  * [authentication path: 4 x log_max words, bottom-up].  ceno_hip_mmcs_opening_words = sum of widths + 4 log_max. */

@@ -436,6 +436,16 @@ int ceno_dist_batched_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, const
 int ceno_dist_commit_traces(ceno_hip_ctx* ctx, ceno_dist_comm* c, const uint64_t* local_cols_dev, const int* widths, int log_rows,
                             int log_blowup, ceno_hip_stream s, uint64_t* out_rows_dev, ceno_hip_merkle** out_subtree,
                             uint64_t* out_subtree_roots, uint64_t* out_root);
+/* The same for SEVERAL matrices of several heights under ONE root = the multi-rank form of ceno_prover_commit_traces: the result
+ * equals the single-device mixed-height commitment (ceno_hip_mmcs_commit) bit for bit.  Rank g holds widths[m * world + g] columns
+ * of matrix m (2^log_rows[m] rows; local_cols_dev[m] column-major).  Per matrix one all-to-all re-shards the codeword by rows —
+ * out_rows_dev[m]: (all columns of matrix m) x (R_m / world) words, column-major, or the WHOLE codeword when it has fewer rows than
+ * there are ranks; rank g's sub-tree (*out_subtree) is the mixed-height tree over its shards = the sub-tree under node g of the
+ * global tree's level with `world` nodes; the top log2(world) levels (*out_top, may be NULL; NULL is returned for world 1 without
+ * short matrices) are built on every rank over the gathered sub-tree roots, the matrices shorter than `world` joining there. */
+int ceno_dist_commit_traces_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, const int* log_rows, const int* widths,
+                                 const uint64_t* const* local_cols_dev, int log_blowup, ceno_hip_stream s, uint64_t* const* out_rows_dev,
+                                 ceno_hip_merkle** out_subtree, ceno_hip_merkle** out_top, uint64_t* out_subtree_roots, uint64_t* out_root);
 /* In-process group of `world` virtual ranks (threads of one process sharing a device, one stream each): the transport the
  * single-GPU tests run the multi-rank commit path on, and a single-process deployment's.  Create the group once, one
  * communicator per rank (ceno_dist_comm_destroy), destroy the group last. */

@@ -117,6 +117,56 @@ impl ShardedCommitment {
         Ok(Self { hal: hal.clone(), root, subtree_roots, rows, subtree })
     }
 }
+/// The multi-rank form of `commit_traces`: SEVERAL matrices of several heights under ONE root across the GPUs of a node
+/// (`ceno_dist_commit_traces_mmcs`); the root equals the single-device mixed-height commitment bit for bit.
+pub struct ShardedMmcsCommitment {
+    hal: Arc<HipHal>,
+    pub root: [u64; 4],
+    pub subtree_roots: Vec<[u64; 4]>,
+    /// per matrix: this rank's codeword rows (all columns), column-major; the whole codeword for matrices shorter than the world
+    pub rows: Vec<HipMle>,
+    subtree: *mut sys::ceno_hip_merkle,
+    top: *mut sys::ceno_hip_merkle,
+}
+unsafe impl Send for ShardedMmcsCommitment {}
+impl ShardedMmcsCommitment {
+    /// `widths[m * world + g]` = columns of matrix `m` on rank `g`; `local_cols_dev[m]` = this rank's columns of matrix `m`.
+    ///
+    /// # Safety
+    /// every `local_cols_dev[m]` must hold `widths[m * world + rank]` columns of `2^log_rows[m]` base words, column-major, on the device.
+    pub unsafe fn commit(hal: &Arc<HipHal>, comm: *mut sys::ceno_dist_comm, world: usize, log_rows: &[i32], widths: &[i32],
+                         local_cols_dev: &[*const u64], log_blowup: usize, stream: &HipStream) -> Result<Self> {
+        let n = log_rows.len();
+        assert_eq!(widths.len(), n * world);
+        let log_w = world.trailing_zeros() as usize;
+        let mut rows = Vec::with_capacity(n);
+        for m in 0..n {
+            let w_total: usize = widths[m * world..(m + 1) * world].iter().map(|&w| w as usize).sum();
+            let lr = log_rows[m] as usize + log_blowup;
+            let local_words = if lr < log_w { w_total << lr } else { (w_total << lr) / world };
+            rows.push(HipMle::alloc(hal, (usize::BITS - (local_words.max(2) - 1).leading_zeros()) as usize, false)?);
+        }
+        let outs: Vec<*mut u64> = rows.iter().map(|r| r.device_ptr()).collect();
+        let mut roots = vec![0u64; 4 * world];
+        let mut root = [0u64; 4];
+        let (mut subtree, mut top) = (ptr::null_mut(), ptr::null_mut());
+        hal.check_prover(sys::ceno_dist_commit_traces_mmcs(hal.ctx, comm, n as i32, log_rows.as_ptr(), widths.as_ptr(), local_cols_dev.as_ptr(),
+                                                           log_blowup as i32, stream.raw(), outs.as_ptr(), &mut subtree, &mut top,
+                                                           roots.as_mut_ptr(), root.as_mut_ptr()))?;
+        let subtree_roots = roots.chunks(4).map(|c| [c[0], c[1], c[2], c[3]]).collect();
+        Ok(Self { hal: hal.clone(), root, subtree_roots, rows, subtree, top })
+    }
+}
+impl Drop for ShardedMmcsCommitment {
+    fn drop(&mut self) {
+        unsafe {
+            sys::ceno_hip_merkle_free(self.hal.ctx, self.subtree);
+            if !self.top.is_null() {
+                sys::ceno_hip_merkle_free(self.hal.ctx, self.top);
+            }
+        }
+    }
+}
 impl Drop for ShardedCommitment {
     fn drop(&mut self) {
         unsafe { sys::ceno_hip_merkle_free(self.hal.ctx, self.subtree) };

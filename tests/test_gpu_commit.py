@@ -396,6 +396,103 @@ def test_native_sharded_commit_local_group_equals_single_device(dev, world, widt
     dev.stream_destroy(stream)
 
 
+@pytest.mark.parametrize("world,shapes", [
+    (4, [(7, [2, 1, 0, 3]), (5, [1, 1, 1, 1]), (7, [0, 2, 2, 0]), (1, [1, 0, 2, 0]), (0, [1, 1, 0, 0])]),
+    (8, [(6, [1, 2, 0, 1, 1, 0, 2, 1]), (2, [1, 0, 0, 1, 0, 0, 0, 1]), (1, [0, 0, 3, 0, 0, 0, 0, 0]), (4, [1, 1, 1, 1, 1, 1, 1, 1])]),
+    (2, [(3, [2, 3]), (8, [4, 1])]),
+])
+def test_native_sharded_mixed_height_commit_equals_single_device(dev, world, shapes):
+    """ceno_dist_commit_traces_mmcs: several trace matrices of several heights, every matrix column-sharded over `world` virtual
+    ranks (ragged, some ranks without columns), under ONE root — equal to the single-device commit_traces root (mixed-height MMCS)
+    bit for bit.  Includes matrices whose codeword has exactly `world` rows (joins at the sub-tree roots) and fewer rows than
+    ranks (gathered whole on every rank, joins in the replicated top levels); shapes = [(log2 trace rows, columns per rank)]"""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    from ceno_amd import dist as cdist
+    from ceno_amd import prover
+
+    L = prover.plib()
+    L.ceno_dist_local_group_create.restype = C.c_void_p
+    L.ceno_dist_local_group_create.argtypes = [C.c_int]
+    L.ceno_dist_local_group_destroy.argtypes = [C.c_void_p]
+    L.ceno_dist_comm_init_local.restype = C.c_int
+    L.ceno_dist_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    blow = 1
+    log_w = world.bit_length() - 1
+    # log2 rows >= 1 for real traces (next_pow2_instance_padding >= 2); a 1-row "trace" (log 0) only reaches the C entry point directly
+    fulls = [po.rand_base((1 << lr) * sum(ws), 500 + i).reshape(1 << lr, sum(ws)) for i, (lr, ws) in enumerate(shapes)]
+    stream = dev.stream_create()
+    # single-device reference: the same matrices through the MMCS primitive (commit_traces pads 1-row traces to 2, so the oracle /
+    # primitive level is used here: RS-encode on the device, then ceno_hip_mmcs_commit)
+    cws = []
+    for (lr, ws), full in zip(shapes, fulls):
+        w = sum(ws)
+        d_cols = torch.from_numpy(np.ascontiguousarray(full.T).view(np.int64).copy()).to("cuda:0")
+        d_cw = torch.empty(w << (lr + blow), dtype=torch.int64, device="cuda:0")
+        dev.check(dev.L.ceno_hip_rs_encode(dev.h, d_cols.data_ptr(), lr, w, blow, d_cw.data_ptr(), stream))
+        cws.append(d_cw)
+    dev.sync(stream)
+    n = len(shapes)
+    h = C.c_void_p()
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in cws])
+    lra = (C.c_int * n)(*[lr + blow for lr, _ in shapes])
+    wsa = (C.c_int * n)(*[sum(ws) for _, ws in shapes])
+    dev.check(dev.L.ceno_hip_mmcs_commit(dev.h, ptrs, lra, wsa, n, stream, C.byref(h)))
+    want = np.zeros(4, dtype=np.uint64)
+    dev.check(dev.L.ceno_hip_merkle_root(dev.h, h, want.ctypes.data_as(C.POINTER(C.c_uint64)), stream))
+    host_cws = [t.cpu().numpy().view(np.uint64).reshape(sum(ws), 1 << (lr + blow)) for t, (lr, ws) in zip(cws, shapes)]
+    assert np.array_equal(want, po.mmcs_commit(host_cws)[-1][0])   # and the oracle agrees with the single-device tree
+    group = L.ceno_dist_local_group_create(world)
+    assert group
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            comm = C.c_void_p()
+            assert L.ceno_dist_comm_init_local(group, rank, C.byref(comm)) == 0
+            keep, ptrs_r = [], []
+            for (lr, ws), full in zip(shapes, fulls):
+                c0 = sum(ws[:rank])
+                cols = np.ascontiguousarray(full[:, c0:c0 + ws[rank]].T)
+                t = torch.from_numpy(cols.view(np.int64).copy()).to("cuda:0") if cols.size else torch.empty(1, dtype=torch.int64, device="cuda:0")
+                keep.append(t)
+                ptrs_r.append(t.data_ptr())
+            torch.cuda.synchronize()
+            s_ = dev.stream_create()
+            res[rank] = cdist.sharded_commit_mmcs_native(dev, comm, ptrs_r, [ws for _, ws in shapes], [lr for lr, _ in shapes], blow, rank, s_)
+            dev.sync(s_)
+            L.ceno_dist_comm_destroy(comm)
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=200)
+    assert not errors, errors
+    for r in range(world):
+        assert np.array_equal(res[r]["root"], want), r
+        assert np.array_equal(res[r]["subtree_roots"], res[0]["subtree_roots"])
+        for m, ((lr, ws), cw) in enumerate(zip(shapes, host_cws)):   # rank r's rows of every matrix = its slice of the codeword
+            R = 1 << (lr + blow)
+            local = res[r]["codeword_rows"][m].cpu().numpy().view(np.uint64)
+            if lr + blow < log_w:
+                assert np.array_equal(local.reshape(sum(ws), R), cw)
+            else:
+                rl = R // world
+                assert np.array_equal(local.reshape(sum(ws), rl), cw[:, r * rl:(r + 1) * rl]), (r, m)
+        dev.check(dev.L.ceno_hip_merkle_free(dev.h, res[r]["subtree"]))
+        if res[r]["top"]:
+            dev.check(dev.L.ceno_hip_merkle_free(dev.h, res[r]["top"]))
+    dev.check(dev.L.ceno_hip_merkle_free(dev.h, h))
+    L.ceno_dist_local_group_destroy(group)
+    dev.stream_destroy(stream)
+
+
 def test_native_sharded_commit_world1_through_rccl_self_exchange(dev, monkeypatch):
     """the RCCL arm of the same driver on a one-rank communicator: symbols resolve, and with CENO_DIST_SELF_P2P=1 the own block
     really goes through ncclSend / ncclRecv inside a group (the call sequence the multi-GPU run uses)"""
