@@ -364,6 +364,11 @@ def main():
                 "traffic": None,
                 "launches": int(launches),
                 "avg_launch_ms": kernel_ms / launches if launches else None,
+                # (to compare with `rocprofv3 --kernel-trace --stats` of this command — profiles/r*_sumcheck_nv26_kernel_stats.csv: sum the
+                # TotalDurationNs of the k_dense rows and divide by the calls of the read-only round-0 instantiation k_dense<3, 0, *> =
+                # the number of sumchecks; the timed steps are pipelined and hand rounds of <= 2^15 pairs to k_mid / k_tail, whose
+                # durations include the waits for the host, so the per-LAUNCH averages of the two runs are not the same population)
+                "kernel_ms_per_sumcheck": kernel_ms / args.steps if args.steps else None,
                 "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
                 "schedule_bytes_per_step": m["prof_bytes"] / args.steps if args.steps else None,
                 "schedule_gbps": (m["prof_bytes"] / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
@@ -399,7 +404,9 @@ def main():
                 cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sumcheck_nv26_pmc_traffic.json")))
                 if cands:
                     pm = json.load(open(cands[-1]))
-                    res["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                    # per launch of the timed pass above (one round kernel per round; the PMC run itself is pipelined and hands its
+                    # small rounds to the persistent ladder, so its own launch count is not the divisor)
+                    res["roofline"]["traffic"] = pm["hbm_bytes_per_sumcheck"] * args.steps / max(int(res["roofline"]["launches"]), 1)
                     res["roofline"]["traffic_per_sumcheck"] = pm["hbm_bytes_per_sumcheck"]
                     res["roofline"]["traffic_source"] = os.path.relpath(cands[-1], ROOT)
         except Exception:

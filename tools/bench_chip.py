@@ -146,7 +146,7 @@ def main():
         evals[c] = pcs.witness_mle(0, c).evaluate(pt_)
     to = 1e9
     for _ in range(args.reps):
-        proof, t_ = timed(lambda: pcs.basefold_open([pt_], [evals], 100, 16, prover.Transcript.stub(3)))
+        proof, t_ = timed(lambda: pcs.basefold_open([pt_], [evals], 100, 16, prover.Transcript.poseidon2(b"open")))
         to = min(to, t_)
     res["open_ms"] = to
     res["open_proof_bytes"] = int(proof.size * 8)

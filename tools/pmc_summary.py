@@ -14,27 +14,36 @@ import sys
 
 
 def counter_sum(d, name):
-    fn = glob.glob(d + "/*counter_collection.csv")[0]
-    tot, n = 0.0, 0
-    for r in csv.DictReader(open(fn)):
-        if r["Counter_Name"] == name and "k_dense" in r["Kernel_Name"]:
-            tot += float(r["Counter_Value"])
-            n += 1
-    return tot, n
+    """(sum over the dense kernel's launches, their number, number of read-only round-0 launches = sumchecks, sum over the small
+    rounds' persistent kernels).  Since round 3 a pipelined dense sumcheck hands its rounds of <= 2^15 pairs to k_mid / k_tail."""
+    tot, n, n0, small = 0.0, 0, 0, 0.0
+    for fn in glob.glob(d + "/*counter_collection.csv"):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != name:
+                continue
+            k = r["Kernel_Name"]
+            if "k_dense" in k:
+                tot += float(r["Counter_Value"])
+                n += 1
+                if "k_dense<3, 0" in k or "k_dense_pf<3, 0" in k:
+                    n0 += 1
+            elif "k_mid" in k or "k_tail" in k:
+                small += float(r["Counter_Value"])
+    return tot, n, n0, small
 
 
 def main():
     trace, fdir, wdir, n_sc, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     shutil.copy(glob.glob(trace + "/*kernel_stats.csv")[0], out + "_kernel_stats.csv")
-    f, nf = counter_sum(fdir, "FETCH_SIZE")
-    w, nw = counter_sum(wdir, "WRITE_SIZE")
-    if n_sc == 0:  # one k_dense launch per round: nv = 26 rounds per sumcheck
-        n_sc = nf // 26
-        assert nf == 26 * n_sc and nw == nf, (nf, nw)
-    fetch_b = f * 1024 * 2  # gfx950 correction
-    write_b = w * 1024
+    f, nf, nf0, fs = counter_sum(fdir, "FETCH_SIZE")
+    w, nw, nw0, ws = counter_sum(wdir, "WRITE_SIZE")
+    if n_sc == 0:  # one read-only round-0 launch per sumcheck
+        n_sc = nf0
+        assert n_sc > 0 and nw0 == nf0 and nw == nf, (nf, nw, nf0, nw0)
+    fetch_b = (f + fs) * 1024 * 2  # gfx950 correction
+    write_b = (w + ws) * 1024
     res = {
-        "kernel": "k_dense<3,*>",
+        "kernel": "k_dense<3,*> (+ k_mid / k_tail for the rounds of <= 2^15 pairs: < 0.1 % of the bytes)",
         "sumchecks_profiled": n_sc,
         "launches": nf,
         "fetch_size_kb_raw": f,
