@@ -470,6 +470,13 @@ size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
     return ctx->pool_booked;
 }
 
+int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight) {
+    CHECK_ARG(ctx, ctx, "ctx is NULL");
+    if (pipelined_live) *pipelined_live = ctx->pipelined_live.load();
+    if (mid_units_in_flight) *mid_units_in_flight = ctx->mid_wgs_in_flight.load();
+    return 0;
+}
+
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
     std::vector<void*> victims;
     {

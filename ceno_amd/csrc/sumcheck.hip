@@ -1862,8 +1862,8 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3);
     }
     sc->enq = upto;
+    if (!sc->pipelined) sc->ctx->pipelined_live.fetch_add(1);  // (once per handle) the pool returns nothing to the driver while round kernels may be waiting for a host (ctx_alloc)
     sc->pipelined = true;
-    sc->ctx->pipelined_live.fetch_add(1);  // the pool returns nothing to the driver while round kernels may be waiting for a host (ctx_alloc)
     sc->seq = (unsigned long long)sc->n;
     return 0;
 }

@@ -88,6 +88,9 @@ int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s);
 int ceno_hip_stream_sync(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* free/total = device memory; pool_used = bytes held by live handles; pool_cached = bytes parked in the pool */
 int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes, size_t* pool_used, size_t* pool_cached);
+/* bookkeeping that must return to zero when no sumcheck handle is alive (tests): live pipelined sumchecks (the pool's soft-cap
+ * trim waits for zero) and the residency budget booked by persistent mid-round kernels (units of 1/64 compute unit) */
+int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight);
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device: not while lanes are proving */
 /* booking of estimated task footprints by a chip scheduler (mem_pool try_book_capacity / unbook_capacity /
  * get_booked_total, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,622-652): refused (CENO_HIP_ERR_OOM, nothing is

@@ -559,4 +559,13 @@ def test_cache_over_the_soft_cap_does_not_stall_lanes(prover):
         flow.run(lambda: prover.Transcript.poseidon2(b"riscv"), lambda: prover.Transcript.poseidon2(b"fork"), lanes=4)
     assert time.perf_counter() - t0 < 30
     flow.close()
+    # every handle is gone: the bookkeeping the trim and the k_mid budget depend on is back at zero (a counter that leaks upwards
+    # would silently switch the trim off for good)
+    import ctypes as C
+
+    live, mid = C.c_int(-1), C.c_int(-1)
+    d.check(d.L.ceno_hip_debug_state(d.h, C.byref(live), C.byref(mid)))
+    assert (live.value, mid.value) == (0, 0)
+    # ... and the parked 10 GB did go back to the driver in the moments when no pipelined sumcheck was alive
+    assert d.mem_info()["pool_cached"] < (9 << 30)
     d.close()
