@@ -143,6 +143,39 @@ def test_open_at_chip_size_verifies(dev):
     dev.stream_destroy(stream)
 
 
+def test_open_of_witness_and_fixed_commitments_at_chip_size_verifies(dev):
+    """`rounds` = (witness commitment: an ADD-shaped trace and two smaller tables, fixed commitment: one table) at 2^16 rows under the
+    Poseidon2 duplex transcript, 16-bit proof of work found on the device: the ORACLE's own challenger and verifier (nothing of the
+    product) accept the proof and reject tampering in every region"""
+    from ceno_amd import prover
+
+    stream = dev.stream_create()
+    shapes_w, shapes_f = [(16, 22), (12, 9), (16, 3)], [(14, 4), (9, 2)]
+    shapes = shapes_w + shapes_f
+    rng = np.random.default_rng(10)
+    traces = [(rng.integers(0, 1 << 62, size=(1 << nv, w), dtype=np.uint64)) % np.uint64(P) for nv, w in shapes]
+    points = [po.rand_ext(nv, 600 + i) for i, (nv, _) in enumerate(shapes)]
+    pw = prover.PcsData(dev, traces[:3], 1, stream)
+    pf = prover.PcsData(dev, traces[3:], 1, stream)
+    evals = []
+    for i, (nv, w) in enumerate(shapes):
+        pcs, m = (pw, i) if i < 3 else (pf, i - 3)
+        evals.append(np.array([pcs.witness_mle(m, c).evaluate(points[i]) for c in range(w)], dtype=np.uint64))
+    nq, pow_bits, sizes = 30, 16, [3, 2]
+    proof = pw.basefold_open(points, evals, nq, pow_bits, prover.Transcript.poseidon2(b"open"), more_commits=[pf])
+    roots = np.stack([pw.root(), pf.root()])
+    assert po.basefold_verify(shapes, roots, points, evals, 1, nq, pow_bits, po.DuplexTranscript(b"open"), proof, commit_sizes=sizes) == 0
+    n = 16
+    for pos in (1, 4 * n + 2, 8 * n + 3, 8 * n + 2 * len(shapes), 8 * n + 2 * len(shapes) + 5, len(proof) - 3):
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % P
+        assert po.basefold_verify(shapes, roots, points, evals, 1, nq, pow_bits, po.DuplexTranscript(b"open"), bad, commit_sizes=sizes) != 0, pos
+    assert po.basefold_verify(shapes, roots[::-1].copy(), points, evals, 1, nq, pow_bits, po.DuplexTranscript(b"open"), proof, commit_sizes=sizes) != 0
+    pw.free()
+    pf.free()
+    dev.stream_destroy(stream)
+
+
 def test_batch_columns_and_fold_commit_primitives(dev):
     """kernel-level parity: column batching with unreduced accumulators, and one fused fold+commit round"""
     import ctypes as C
