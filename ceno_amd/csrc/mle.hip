@@ -241,10 +241,38 @@ __global__ void __launch_bounds__(NT) k_eval_dot_host(const uint64_t* __restrict
     const size_t stride = (size_t)gridDim.x * NT;
     const size_t mask = ((size_t)1 << a) - 1;
     E2 acc[1] = {e2_zero()};
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
-        const E2 w = lo[i & mask] * hi[i >> a];
-        if (IN_EXT) acc[0] = acc[0] + reinterpret_cast<const E2*>(f)[i] * w;
-        else acc[0] = acc[0] + e2_mul_base(w, f[i]);
+    if (a >= 8) {
+        // Row form: a workgroup owns whole rows of 2^a consecutive entries (one hi index each).  Inside a row every entry costs ONE
+        // unreduced multiply-accumulate with lo (four wide products into 160-bit accumulators; two for a base-field table), the
+        // row's sum is reduced once and multiplied by hi[row] once per lane — the element-wise form below spends two full
+        // extension multiplications per entry and was VALU-bound at a quarter of the HBM roofline.
+        const size_t row_len = (size_t)1 << a, rows = len >> a;
+        for (size_t h = blockIdx.x; h < rows; h += gridDim.x) {
+            E2 row;
+            if (IN_EXT) {
+                E2Acc w = e2acc_zero();
+                const E2* fr = reinterpret_cast<const E2*>(f) + (h << a);
+                for (size_t j = threadIdx.x; j < row_len; j += NT) e2acc_mac(w, fr[j], lo[j]);
+                row = e2acc_reduce(w);
+            } else {
+                Acc5 w0{0, 0, 0, 0, 0}, w1{0, 0, 0, 0, 0};
+                const uint64_t* fr = f + (h << a);
+                for (size_t j = threadIdx.x; j < row_len; j += NT) {
+                    const E2 l = lo[j];
+                    const uint64_t v = fr[j];
+                    acc5_add(w0, mul_wide(l.c0, v));
+                    acc5_add(w1, mul_wide(l.c1, v));
+                }
+                row = E2{acc5_reduce(w0), acc5_reduce(w1)};
+            }
+            acc[0] = acc[0] + row * hi[h];
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+            const E2 w = lo[i & mask] * hi[i >> a];
+            if (IN_EXT) acc[0] = acc[0] + reinterpret_cast<const E2*>(f)[i] * w;
+            else acc[0] = acc[0] + e2_mul_base(w, f[i]);
+        }
     }
     red::block_sum<1, NT>(acc, smem);
     if (threadIdx.x == 0) {
