@@ -8,6 +8,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,9 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
         if (rc) return prover_set_error(rc, ceno_hip_last_error(ctx));
     }
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    const bool trace = getenv("CENO_LANES_TRACE") != nullptr;  // one line per task: lane, estimate, start and end (ms since the run began)
+    const auto t_run = std::chrono::steady_clock::now();
+    auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
     auto worker = [&](int lane) {
         // a fresh thread starts with device 0 current; allocations, stream creation and launches follow the current device
         (void)ceno_hip_make_current(ctx);
@@ -74,8 +78,12 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
                 remaining--;
                 in_flight++;
             }
+            const double t_begin = trace ? ms_now() : 0.0;
             const int rc = tasks[pick].fn(tasks[pick].arg, lane, streams[lane]);
             (void)ceno_hip_stream_sync(ctx, streams[lane]);
+            if (trace)
+                fprintf(stderr, "[ceno_prover] lanes trace: task %d (%.1f MB booked) lane %d  %.3f -> %.3f ms\n", pick, (double)tasks[pick].estimated_bytes / 1e6,
+                        lane, t_begin, ms_now());
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (booked) ceno_hip_mem_unbook(ctx, booked);
