@@ -129,6 +129,7 @@ def lib():
         "ceno_hip_basefold_commit_codeword": (i, [vp, vp, i, vp, C.POINTER(vp)]),
         "ceno_hip_basefold_fold": (i, [vp, vp, i, u64p, vp, vp, vp]),
         "ceno_hip_gather": (i, [vp, vp, sz, i, i, vp, sz, i, i, vp, vp]),
+        "ceno_hip_basefold_query_rounds": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, vp, sz, vp, vp]),
         "ceno_hip_merkle_open_batch": (i, [vp, vp, vp, sz, i, vp, vp]),
         "ceno_hip_pow_grind_duplex": (i, [vp, u64p, i, u64p, vp]),
         "ceno_hip_lane_stream": (i, [vp, i, vpp]),

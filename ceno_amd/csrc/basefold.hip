@@ -205,9 +205,39 @@ __global__ void __launch_bounds__(NT) k_gather_paths(LevelPtrs lv, int depth, co
         out[q * out_stride + rem] = lv.p[l][4 * node + k];
     }
 }
+// one commit round of the query phase: round r answers query q with the sibling of its codeword entry (idx >> r) and the path of
+// the leaf (idx >> (r + 1)) in that round's tree
+struct QRound {
+    static constexpr int MAXL = 40;
+    const uint64_t* cw;      // the round's running codeword (ext elements)
+    uint64_t sib_off;        // word offsets inside the output: [n_q x 2 sibling][n_q x 4 depth path]
+    uint64_t path_off;
+    int depth, shift;
+    const uint64_t* levels[MAXL];
+};
+__global__ void __launch_bounds__(NT) k_query_rounds(const QRound* __restrict__ rounds, const uint64_t* __restrict__ idx, size_t n_q,
+                                                     uint64_t* __restrict__ out) {
+    const QRound& R = rounds[blockIdx.y];  // wave-uniform: read through the scalar cache
+    const size_t per_q = 2 + 4 * (size_t)R.depth, total = n_q * per_q;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t t = (size_t)blockIdx.x * NT + threadIdx.x; t < total; t += stride) {
+        const size_t q = t / per_q;
+        int rem = (int)(t % per_q);
+        const uint64_t pos = idx[q] >> R.shift;
+        if (rem < 2) {
+            out[R.sib_off + 2 * q + rem] = R.cw[2 * (pos ^ 1) + rem];
+        } else {
+            rem -= 2;
+            const int l = rem >> 2, k = rem & 3;
+            const uint64_t node = ((pos >> 1) >> l) ^ 1;
+            out[R.path_off + q * 4 * (size_t)R.depth + rem] = R.levels[l][4 * node + k];
+        }
+    }
+}
 int merkle_gather_paths(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift, uint64_t* dev_out,
                         size_t out_stride_words, hipStream_t st) {
     CHECK_ARG(ctx, t->log_rows <= 62, "tree too tall");
+    TRY(merkle_ensure_top(ctx, t));  // the host half of the tree, if nobody has asked for the root yet
     LevelPtrs lv{};
     for (int l = 0; l < t->log_rows; l++) lv.p[l] = t->levels[l];
     hipLaunchKernelGGL(k_gather_paths, dim3(grid_for(n * t->log_rows * 4, NT, MAXB)), dim3(NT), 0, st, lv, t->log_rows, dev_indices, n, shift, dev_out,
@@ -339,6 +369,47 @@ int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint
     if (n == 0 || t->log_rows == 0) return 0;
     hipStream_t st = ctx_stream(ctx, s);
     return merkle_gather_paths(ctx, t, dev_indices, n, shift, dev_out, 4 * (size_t)t->log_rows, st);
+}
+
+// every commit round of the query phase in ONE launch (a gather of the sibling values and one of the Merkle paths per round were
+// 2 x 20 dependent launches of ~2 us of work each: ~0.3 ms of launch gaps in an opening of 2^20 rows)
+int ceno_hip_basefold_query_rounds(ceno_hip_ctx* ctx, const uint64_t* const* dev_codewords_ext, ceno_hip_merkle* const* trees, int n_rounds,
+                                   const uint64_t* dev_indices, size_t n_q, uint64_t* dev_out, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_codewords_ext && trees && dev_indices && dev_out && n_rounds >= 0 && n_rounds < 64, "bad query_rounds arguments");
+    if (n_rounds == 0 || n_q == 0) return 0;
+    hipStream_t st = ctx_stream(ctx, s);
+    void *h = nullptr, *d = nullptr;
+    TRY(ctx_pinned_alloc(ctx, (size_t)n_rounds * sizeof(QRound), &h, &d));
+    QRound* tab = (QRound*)h;
+    size_t off = 0, widest = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        ceno_hip_merkle* t = trees[r];
+        if (!t || !dev_codewords_ext[r] || t->log_rows > QRound::MAXL) {
+            ctx_pinned_free(ctx, h);
+            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "query_rounds: bad round %d", r);
+        }
+        int rc = merkle_ensure_top(ctx, t);  // the host half of the tree, if nobody has asked for the root yet
+        if (rc) {
+            ctx_pinned_free(ctx, h);
+            return rc;
+        }
+        QRound& R = tab[r];
+        R.cw = dev_codewords_ext[r];
+        R.depth = t->log_rows;
+        R.shift = r;
+        R.sib_off = off;
+        off += n_q * 2;
+        R.path_off = off;
+        off += n_q * 4 * (size_t)t->log_rows;
+        for (int l = 0; l < t->log_rows; l++) R.levels[l] = t->levels[l];
+        widest = std::max(widest, n_q * (2 + 4 * (size_t)t->log_rows));
+    }
+    hipLaunchKernelGGL(k_query_rounds, dim3(grid_for(widest, NT, 64), (unsigned)n_rounds), dim3(NT), 0, st, (const QRound*)d, dev_indices, n_q, dev_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the table is read through its host mapping: it goes back to the pool once the kernel is done
+    ctx_pinned_free(ctx, h);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "query_rounds: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int ceno_hip_pow_grind_duplex(ceno_hip_ctx* ctx, const uint64_t* state16, int bits, uint64_t* out_witness, ceno_hip_stream s) {

@@ -18,6 +18,8 @@
 using gl::E2;
 
 struct PoseidonParams;  // poseidon2.hip
+struct ceno_hip_ctx;
+void merkle_drop_host_params(ceno_hip_ctx* ctx);  // poseidon2.hip: frees the host copy of the Poseidon2 table
 
 struct ceno_hip_ctx {
     int device = 0;
@@ -68,6 +70,7 @@ struct ceno_hip_ctx {
     std::map<int, uint64_t*> fold_twiddles;  // Basefold fold coefficients by codeword height (a taller table serves as a prefix)
     // ---- poseidon2 parameters (device) ----
     PoseidonParams* poseidon_dev = nullptr;
+    PoseidonParams* poseidon_host = nullptr;  // the same table for the host half of a Merkle tree top (merkle_finish_host)
     bool poseidon_pinned = false;  // true once ceno_hip_poseidon2_set_constants supplied a complete external table
 };
 

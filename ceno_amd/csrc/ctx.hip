@@ -312,6 +312,7 @@ void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     for (auto& ev : ctx->prof_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->prof_event_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
+    merkle_drop_host_params(ctx);
     if (ctx->vram_arena) (void)hipFree(ctx->vram_arena);
     for (hipStream_t ls : ctx->lane_streams)
         if (ls) (void)hipStreamDestroy(ls);

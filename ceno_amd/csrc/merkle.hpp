@@ -14,6 +14,14 @@ struct ceno_hip_merkle {
     uint64_t* h_root = nullptr;      // pinned host copy of the root, written by the kernel that computes it (no D2H blit)
     uint64_t* d_root_view = nullptr; // device view of h_root
     bool root_on_host = false;       // the tree-top kernel has been told to write h_root
+    // Host-finished top: levels[host_from .. log_rows] live in ONE pinned block (`levels` holds their device views, `h_levels` the
+    // host pointers).  The device builds the tree up to level host_from — whose kernel therefore writes its digests straight into
+    // host memory — and the HOST computes the levels above it (merkle_finish_host): a level of few nodes costs the device the
+    // latency of one permutation (~11.5 us on eight lanes) whatever its size, the host 0.7 us per node.
+    int host_from = -1;              // -1: the whole tree is built on the device
+    std::vector<uint64_t*> h_levels; // [log_rows + 1], NULL below host_from
+    void* h_top = nullptr;           // the pinned block
+    bool host_top_pending = false;   // levels above host_from are not computed yet (needs the owner stream drained first)
     // mixed-height commitment (ceno_hip_mmcs_commit): the matrices in the CALLER's order (borrowed) and their device table
     struct Mat {
         const uint64_t* p;
@@ -35,7 +43,12 @@ struct MmcsMat {
 };
 
 int get_params(ceno_hip_ctx* ctx, const p2::Params** out);
-int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out);  // owner stream = the stream the calling thread resolved last
+// owner stream = the stream the calling thread resolved last.  `max_host_levels` caps the number of top levels left to the host
+// (0 = none; a mixed-height tree passes the distance between the root and its highest injection level: injections stay on the device)
+int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out, int max_host_levels = 64);
+// computes the host half of the tree if it is still pending (drains the owner stream first); called by every reader of the upper levels
+int merkle_ensure_top(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
+void merkle_drop_host_params(ceno_hip_ctx* ctx);
 // levels 1.. from the leaf digests in levels[0]; inject[l] (may be NULL / absent) = digests of the rows of the matrices whose
 // height equals level l's node count: parent = compress(compress(left, right), inject[l][i])  (p3 MerkleTreeMmcs)
 int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, const uint64_t* const* inject = nullptr);

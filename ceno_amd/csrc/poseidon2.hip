@@ -21,6 +21,7 @@ static constexpr int NT = 256;
 static constexpr unsigned MAXB = 4096;
 
 #include "merkle.hpp"
+#include "poseidon2_host.hpp"
 
 // The built-in round constants are PLACEHOLDERS (poseidon2.hpp): roots, challenges and proofs made with them are
 // self-consistent but can never verify against the reference.  Until a complete table has been supplied through
@@ -51,9 +52,15 @@ int get_params(ceno_hip_ctx* ctx, const p2::Params** out) {
         HIP_TRY(ctx, hipMalloc(&d, sizeof(PoseidonParams)));
         HIP_TRY(ctx, hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
         ctx->poseidon_dev = (PoseidonParams*)d;
+        if (!ctx->poseidon_host) ctx->poseidon_host = new PoseidonParams();
+        *ctx->poseidon_host = h;
     }
     *out = &ctx->poseidon_dev->p;
     return 0;
+}
+void merkle_drop_host_params(ceno_hip_ctx* ctx) {
+    delete ctx->poseidon_host;
+    ctx->poseidon_host = nullptr;
 }
 
 __global__ void __launch_bounds__(NT) k_permute(uint64_t* states, size_t n, const p2::Params* __restrict__ pp) {
@@ -180,22 +187,51 @@ __global__ void __launch_bounds__(NT) k_mmcs_gather_rows(const MmcsMat* __restri
 
 void merkle_release(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
     if (!t) return;
-    if (t->h_root) ctx_pinned_free(ctx, t->h_root);
+    if (t->h_top) ctx_pinned_free(ctx, t->h_top);       // holds the root too (h_root points into it)
+    else if (t->h_root) ctx_pinned_free(ctx, t->h_root);
     if (t->h_table) ctx_pinned_free(ctx, t->h_table);
     if (t->d_table) ctx_free_on(ctx, t->d_table, t->st);
     // freed with the OWNER's stream, whatever stream the calling thread resolved last (a thread that drives several streams:
     // the opening, commit helpers) — another stream gets these blocks only once the owner has drained
-    for (auto* p : t->levels) ctx_free_on(ctx, p, t->st);
+    for (int l = 0; l < (int)t->levels.size(); l++)
+        if (t->host_from < 0 || l < t->host_from) ctx_free_on(ctx, t->levels[l], t->st);
     delete t;
 }
 
+// number of top levels a tree leaves to the host (CENO_HIP_HOST_TOP, 0 = build everything on the device)
+static int host_top_levels() {
+    static const int v = [] {
+        const char* e = getenv("CENO_HIP_HOST_TOP");
+        const int x = e ? atoi(e) : 6;
+        return x < 0 ? 0 : (x > 10 ? 10 : x);
+    }();
+    return v;
+}
+
 // levels 1..log_rows over leaf digests already in levels[0]
-int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
+int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out, int max_host_levels) {
     auto* t = new ceno_hip_merkle();
     t->log_rows = log_rows;
     t->st = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;  // every caller resolves its stream before it allocates
     t->levels.assign(log_rows + 1, nullptr);
+    t->h_levels.assign(log_rows + 1, nullptr);
+    const int host_lv = std::min(std::min(host_top_levels(), max_host_levels), log_rows);
+    if (host_lv > 0) {  // optional: without the pinned block the device builds the whole tree
+        void *h = nullptr, *d = nullptr;
+        if (ctx_pinned_alloc(ctx, (size_t)64 << host_lv, &h, &d) == 0) {
+            t->h_top = h;
+            t->host_from = log_rows - host_lv;
+            size_t off = 0;
+            for (int l = t->host_from; l <= log_rows; l++) {
+                t->h_levels[l] = (uint64_t*)((char*)h + off);
+                t->levels[l] = (uint64_t*)((char*)d + off);
+                off += ((size_t)1 << (log_rows - l)) * 32;
+            }
+            t->h_root = t->h_levels[log_rows];
+        }
+    }
     for (int l = 0; l <= log_rows; l++) {
+        if (t->host_from >= 0 && l >= t->host_from) break;
         void* p = nullptr;
         int rc = ctx_alloc(ctx, ((size_t)1 << (log_rows - l)) * 32, &p);
         if (rc) {
@@ -205,11 +241,35 @@ int merkle_alloc(ceno_hip_ctx* ctx, int log_rows, ceno_hip_merkle** out) {
         t->levels[l] = (uint64_t*)p;
     }
     void *h = nullptr, *d = nullptr;
-    if (ctx_pinned_alloc(ctx, 64, &h, &d) == 0) {  // optional: without it the root is fetched with a copy
+    if (t->host_from < 0 && ctx_pinned_alloc(ctx, 64, &h, &d) == 0) {  // optional: without it the root is fetched with a copy
         t->h_root = (uint64_t*)h;
         t->d_root_view = (uint64_t*)d;
     }
     *out = t;
+    return 0;
+}
+
+// the host half of a tree: levels host_from + 1 .. log_rows from the digests the device wrote into the pinned level host_from
+static void merkle_finish_host(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
+    const p2::Params& hp = ctx->poseidon_host->p;
+    for (int l = t->host_from + 1; l <= t->log_rows; l++) {
+        const uint64_t* child = t->h_levels[l - 1];
+        uint64_t* parent = t->h_levels[l];
+        const size_t np = (size_t)1 << (t->log_rows - l);
+        for (size_t i = 0; i < np; i++) {
+            uint64_t s[8];
+            memcpy(s, child + 8 * i, 64);
+            p2host::permute(s, hp);
+            memcpy(parent + 4 * i, s, 32);
+        }
+    }
+    t->host_top_pending = false;
+    t->root_on_host = true;
+}
+int merkle_ensure_top(ceno_hip_ctx* ctx, ceno_hip_merkle* t) {
+    if (!t->host_top_pending) return 0;
+    HIP_TRY(ctx, hipStreamSynchronize(t->st));
+    merkle_finish_host(ctx, t);
     return 0;
 }
 
@@ -261,9 +321,16 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, co
     const p2::Params* pp;
     TRY(get_params(ctx, &pp));
     const int log_rows = t->log_rows;
+    // the device stops at level host_from when the host finishes the tree (its digests land in pinned memory: merkle_alloc)
+    const int top = t->host_from >= 0 ? t->host_from : log_rows;
+    if (t->host_from >= 0) {
+        for (int lv = t->host_from + 1; inject && lv <= log_rows; lv++)
+            if (inject[lv]) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "merkle: an injection level above the host split (merkle_alloc max_host_levels)");
+        t->host_top_pending = true;
+    }
     int l = 1;
     // levels with more than 2^14 nodes: one lane per node (throughput bound)
-    for (; l <= log_rows && ((size_t)1 << (log_rows - l)) > ((size_t)1 << 14); l++) {
+    for (; l <= top && ((size_t)1 << (log_rows - l)) > ((size_t)1 << 14); l++) {
         size_t np = (size_t)1 << (log_rows - l);
         hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l],
                            inject ? inject[l] : (const uint64_t*)nullptr, pp);
@@ -271,7 +338,7 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, co
     // the rest is a chain of dependent permutations (one per level): 8 lanes per permutation, and every launch takes up to
     // TOP_LEVELS levels at once — each workgroup reduces its own 2^TOP_LEVELS-digest subtree in LDS — so 15 small levels
     // cost three kernel boundaries instead of fifteen
-    int rem = log_rows - l + 1;  // the child level l-1 holds 2^rem digests
+    int rem = top - l + 1;  // levels left to the device; the child level l-1 holds 2^(log_rows - l + 1) digests
     while (rem > 0) {
         const int lv = rem > TOP_LEVELS ? TOP_LEVELS : rem;
         TopPtrs tp{};
@@ -279,11 +346,11 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, co
             tp.p[i] = t->levels[l + i];
             tp.inj[i] = inject ? inject[l + i] : nullptr;
         }
-        if (rem == lv && t->d_root_view) {  // this launch ends at the root
+        if (rem == lv && top == log_rows && t->d_root_view) {  // this launch ends at the root
             tp.root_host = t->d_root_view;
             t->root_on_host = true;
         }
-        hipLaunchKernelGGL(k_compress_top, dim3(1u << (rem - lv)), dim3(TOP_NT), 0, st, t->levels[l - 1], lv, tp, pp);
+        hipLaunchKernelGGL(k_compress_top, dim3(1u << (log_rows - l + 1 - lv)), dim3(TOP_NT), 0, st, t->levels[l - 1], lv, tp, pp);
         l += lv;
         rem -= lv;
     }
@@ -312,6 +379,11 @@ int ceno_hip_poseidon2_set_constants(ceno_hip_ctx* ctx, const uint64_t* external
     HIP_TRY(ctx, hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice));
     if (ctx->poseidon_dev) (void)hipFree(ctx->poseidon_dev);
     ctx->poseidon_dev = (PoseidonParams*)d;
+    {
+        std::lock_guard<std::mutex> g(ctx->tw_mu);
+        if (!ctx->poseidon_host) ctx->poseidon_host = new PoseidonParams();
+        *ctx->poseidon_host = h;
+    }
     ctx->poseidon_pinned = external_rc && internal_rc && internal_diag;  // NULLs restore (parts of) the placeholder table
     return 0;
 }
@@ -364,7 +436,12 @@ static int mmcs_commit_impl(ceno_hip_ctx* ctx, const uint64_t* leaf_digests, int
     TRY(get_params(ctx, &pp));
     hipStream_t st = ctx_stream(ctx, s);
     ceno_hip_merkle* t = nullptr;
-    TRY(merkle_alloc(ctx, H, &t));
+    // the host may finish the levels strictly above the highest injection level (the row digests of the short matrices stay on the
+    // device); a tree over a GIVEN digest layer (the few sub-tree roots of a sharded commitment) is built on the device as before
+    int max_host = leaf_digests ? 0 : 64;
+    for (int m = 0; m < n_mats; m++)
+        if (log_rows[m] < H) max_host = std::min(max_host, log_rows[m]);  // injected at level H - log_rows[m]: log_rows[m] levels above it
+    TRY(merkle_alloc(ctx, H, &t, max_host));
     t->total_width = total_w;
     if (leaf_digests && hipMemcpyAsync(t->levels[0], leaf_digests, ((size_t)32) << H, hipMemcpyDeviceToDevice, st) != hipSuccess) {
         merkle_release(ctx, t);
@@ -486,6 +563,13 @@ int ceno_hip_mmcs_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64
 int ceno_hip_merkle_root(ceno_hip_ctx* ctx, ceno_hip_merkle* t, uint64_t* root4, ceno_hip_stream s) {
     CHECK_ARG(ctx, t && root4, "NULL argument");
     hipStream_t st = ctx_stream(ctx, s);
+    if (t->host_top_pending) {  // the device half sits in pinned memory once the stream has drained: the host finishes the tree
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (st != t->st) HIP_TRY(ctx, hipStreamSynchronize(t->st));
+        merkle_finish_host(ctx, t);
+        memcpy(root4, t->h_root, 32);
+        return 0;
+    }
     if (t->root_on_host) {  // the tree-top kernel wrote it to pinned memory: wait for the stream, no copy engine round trip
         HIP_TRY(ctx, hipStreamSynchronize(st));
         memcpy(root4, t->h_root, 32);
@@ -500,9 +584,15 @@ int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, ui
     CHECK_ARG(ctx, t && path, "NULL argument");
     CHECK_ARG(ctx, index < ((size_t)1 << t->log_rows), "leaf index out of range");
     hipStream_t st = ctx_stream(ctx, s);
+    TRY(merkle_ensure_top(ctx, t));
     size_t idx = index;
     for (int l = 0; l < t->log_rows; l++) {
-        HIP_TRY(ctx, hipMemcpyAsync(path + 4 * l, t->levels[l] + 4 * (idx ^ 1), 32, hipMemcpyDeviceToHost, st));
+        if (t->h_levels[l]) {  // a host-resident level (after a drain of the stream: the device half may still be in flight)
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            memcpy(path + 4 * l, t->h_levels[l] + 4 * (idx ^ 1), 32);
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(path + 4 * l, t->levels[l] + 4 * (idx ^ 1), 32, hipMemcpyDeviceToHost, st));
+        }
         idx >>= 1;
     }
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -447,14 +447,17 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
         pieces.push_back({off, per_q});
         off += Q * per_q;
     }
-    for (int r = 0; r < n && !rc; r++) {
-        const int h = H - r;
-        rc = ceno_hip_gather(ctx, ceno_hip_mle_device_ptr(C[r]), 0, 1, 2, d_idx, Q, r, 1, d_ans + off, s);
-        pieces.push_back({off, 2});
-        off += Q * 2;
-        if (!rc) rc = ceno_hip_merkle_open_batch(ctx, trees[r], d_idx, Q, r + 1, d_ans + off, s);
-        pieces.push_back({off, 4 * (size_t)(h - 1)});
-        off += Q * 4 * (size_t)(h - 1);
+    if (!rc && n > 0) {  // every commit round in one launch: [sibling 2][path 4 (h - 1)] per round
+        std::vector<const uint64_t*> cws(n);
+        for (int r = 0; r < n; r++) cws[r] = ceno_hip_mle_device_ptr(C[r]);
+        rc = ceno_hip_basefold_query_rounds(ctx, cws.data(), trees.data(), n, d_idx, Q, d_ans + off, s);
+        for (int r = 0; r < n; r++) {
+            const int h = H - r;
+            pieces.push_back({off, 2});
+            off += Q * 2;
+            pieces.push_back({off, 4 * (size_t)(h - 1)});
+            off += Q * 4 * (size_t)(h - 1);
+        }
     }
     if (rc) return fail(rc);
     std::vector<uint64_t> ans(ans_words);

@@ -337,6 +337,12 @@ int ceno_hip_gather(ceno_hip_ctx* ctx, const uint64_t* dev_src, size_t col_strid
 /* authentication paths of leaves (idx[q] >> shift): dev_out[q][level][4], log_rows levels, bottom-up */
 int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint64_t* dev_indices, size_t n, int shift,
                                uint64_t* dev_out, ceno_hip_stream s);
+/* the commit-round part of ALL queries in one launch: for round r = 0 .. n_rounds-1 (codeword r, tree r) and query q the sibling
+ * value of codeword entry (idx_q >> r) and the authentication path of leaf (idx_q >> (r + 1)); dev_out = per round
+ * [n_q x 2 words sibling][n_q x 4 * depth_r words path, bottom-up], rounds back to back (the layout of n_rounds pairs of
+ * ceno_hip_gather + ceno_hip_merkle_open_batch).  Query phase of ceno_recursion_v2/src/pcs/mod.rs:7611-7690.  Synchronises. */
+int ceno_hip_basefold_query_rounds(ceno_hip_ctx* ctx, const uint64_t* const* dev_codewords_ext, ceno_hip_merkle* const* trees, int n_rounds,
+                                   const uint64_t* dev_indices, size_t n_q, uint64_t* dev_out, ceno_hip_stream s);
 /* Proof-of-work search of p3's grinding challenger (GrindingChallenger::grind; the verifier side is check_witness,
  * ceno_recursion_v2/src/pcs/mod.rs:8125-8155): the least w for which a CLONE of the Poseidon2 duplex challenger (width 8, rate 4)
  * that observes w samples a base element whose low `bits` bits are zero.  state16 = the challenger state as exported by
