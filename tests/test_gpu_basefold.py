@@ -238,3 +238,56 @@ def test_open_random_shapes_differential(dev, seed):
     assert po.basefold_verify(shapes, roots, points, evals, rate_log, nq, pow_bits, po.StubTranscript(seed), proof) == 0
     pcs.free()
     dev.stream_destroy(stream)
+
+
+_HOST_TOP_SCRIPT = r"""
+import sys, zlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import pyoracle as po
+from ceno_amd import Device, prover
+dev = Device(0)
+stream = dev.stream_create()
+out = []
+for shapes, nq in (([(9, 3), (4, 5), (9, 1), (1, 2), (3, 7)], 9), ([(12, 2)], 6), ([(2, 3), (1, 1)], 4)):
+    traces = [po.rand_base((1 << nv) * w, 3 + 7 * i).reshape(1 << nv, w) for i, (nv, w) in enumerate(shapes)]
+    points = [po.rand_ext(nv, 103 + i) for i, (nv, _) in enumerate(shapes)]
+    evals = [np.array([po.mle_evaluate(t[:, c].copy(), p) for c in range(t.shape[1])], dtype=np.uint64) for t, p in zip(traces, points)]
+    pcs = prover.PcsData(dev, traces, 1, stream)
+    proof = pcs.basefold_open(points, evals, nq, 3, prover.Transcript.stub(0xBF))
+    rows, path = pcs.open(5 % (1 << max(nv for nv, _ in shapes)))
+    out.append("%08x %08x %08x" % (zlib.crc32(pcs.root().tobytes()), zlib.crc32(proof.tobytes()), zlib.crc32(path.tobytes() + b"".join(r.tobytes() for r in rows))))
+    pcs.free()
+print("RESULT " + " | ".join(out))
+"""
+
+
+@pytest.mark.parametrize("levels", ["0", "3", "9"])
+def test_host_finished_tree_tops_change_nothing(dev, levels):
+    """CENO_HIP_HOST_TOP = how many top levels of every Merkle tree the HOST computes (default 5).  Roots, Basefold proofs and row
+    openings must be identical for every split: all on the device (0), a split inside the tree (3), and a host half taller than
+    most trees (9: whole trees above their leaf digests on the host; mixed heights keep their injections on the device).  The
+    default split is what every other test of this file compares with the oracle."""
+    import os, subprocess, sys, zlib
+    from ceno_amd import prover
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CENO_HIP_HOST_TOP=levels)
+    r = subprocess.run([sys.executable, "-c", _HOST_TOP_SCRIPT, root_dir], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]
+    # the same cases in THIS process (default split)
+    stream = dev.stream_create()
+    want = []
+    for shapes, nq in (([(9, 3), (4, 5), (9, 1), (1, 2), (3, 7)], 9), ([(12, 2)], 6), ([(2, 3), (1, 1)], 4)):
+        traces, points, evals = make_case(3, shapes)
+        pcs = prover.PcsData(dev, traces, 1, stream)
+        proof = pcs.basefold_open(points, evals, nq, 3, prover.Transcript.stub(0xBF))
+        expect = po.basefold_open(traces, points, evals, 1, nq, 3, po.StubTranscript(0xBF))
+        assert np.array_equal(proof, expect)
+        rows, path = pcs.open(5 % (1 << max(nv for nv, _ in shapes)))
+        want.append("%08x %08x %08x" % (zlib.crc32(pcs.root().tobytes()), zlib.crc32(proof.tobytes()),
+                                        zlib.crc32(path.tobytes() + b"".join(r.tobytes() for r in rows))))
+        pcs.free()
+    dev.stream_destroy(stream)
+    assert got == " | ".join(want)
