@@ -793,6 +793,12 @@ struct ceno_hip_sumcheck {
     bool slots_preloaded = false;           // the slot rows of every round went to the device with the plan blob (single generic class)
     int mid_reserved = 0;                   // workgroups of a k_mid launch booked against the context's residency budget
     bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
+    // host-finished tail: rounds [host_from, n) are computed by the HOST on the tables the tail kernel exported with its last message
+    int host_from = -1;
+    void* h_tail_block = nullptr;           // pinned: n_mles x host_len0 E2, armed with MSG_INVALID
+    int host_len0 = 0;                      // entries per exported table
+    int host_len = 0;                       // entries per table in `host_tab` now (0 = not taken over yet)
+    std::vector<E2> host_tab;               // [class-local mle][host_len0]
     unsigned long long* h_flag = nullptr;   // pinned sequence flag written by the kernel, polled by the host
     unsigned long long* d_hflag = nullptr;
     unsigned long long seq = 0;
@@ -857,6 +863,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     // pinned words and does not synchronise): no wait here either — it was ~20 us per tower layer — the buffers go back to the
     // pool tagged with THIS sumcheck's stream (ctx_free_on below), so another stream gets them only once it has drained
     if (!sc->finished) (void)hipStreamSynchronize(sc->st);
+    if (sc->h_tail_block) ctx_pinned_free(sc->ctx, sc->h_tail_block);  // (a finished sumcheck has read every word the tail kernel exported)
     if (sc->pipelined && getenv("CENO_HIP_DEBUG") && sc->d_bcast) {
         static Bcast hb;
         if (hipMemcpy(&hb, sc->d_bcast, sizeof(Bcast), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1712,6 +1719,67 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
 // Rounds are enqueued a few ahead of the one being answered instead of all at once: launching ~2n kernels costs
 // 100-300 us of host time, and a round-0 kernel shorter than that would sit in its challenge poll until the host
 // got around to reading its message (measured: 20 us per tiny round instead of 12, 800 us for a 160 us round 0).
+// rounds at the end of a pipelined sumcheck that the HOST computes (CENO_HIP_HOST_TAIL, 0 = the device runs every round)
+static int host_tail_rounds() {
+    const char* e = getenv("CENO_HIP_HOST_TAIL");  // (read per call: the test-suite switches it between sumchecks)
+    const int v = e ? atoi(e) : 6;
+    return v < 0 ? 0 : (v > 12 ? 12 : v);
+}
+// One host round of a host-finished tail: fold the tables with the challenge of round i - 1, then the message of round i,
+// p(1) .. p(d) of sum_pairs sum_terms c_T prod_{j in T} f_j(X).  Field arithmetic is exact, so the order of the sums is free and the
+// words equal what the device's kernels would have published.
+static void host_fold(ceno_hip_sumcheck* sc, E2 r) {
+    const size_t k = sc->classes[0].mles.size();
+    const int half = sc->host_len / 2;
+    for (size_t m = 0; m < k; m++) {
+        E2* t = sc->host_tab.data() + m * (size_t)sc->host_len0;
+        for (int j = 0; j < half; j++) {
+            const E2 lo = t[2 * j], hi = t[2 * j + 1];
+            t[j] = lo + r * (hi - lo);
+        }
+    }
+    sc->host_len = half;
+}
+static int host_take_over(ceno_hip_sumcheck* sc) {
+    if (sc->host_len) return 0;
+    const size_t k = sc->classes[0].mles.size(), words = k * (size_t)sc->host_len0 * 2;
+    TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(sc->h_tail_block), (int)words));
+    sc->host_tab.resize(k * (size_t)sc->host_len0);
+    memcpy(sc->host_tab.data(), sc->h_tail_block, words * 8);
+    sc->host_len = sc->host_len0;
+    return 0;
+}
+static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out) {
+    TRY(host_take_over(sc));
+    host_fold(sc, r);
+    const ScClass& cl = sc->classes[0];
+    const int d = sc->d, pairs = sc->host_len / 2;
+    E2 acc[MAXD];
+    for (int t = 0; t < d; t++) acc[t] = e2_zero();
+    for (int ti : cl.terms) {
+        const ScTerm& T = sc->terms[ti];
+        for (int p = 0; p < pairs; p++) {
+            E2 pr[MAXD];
+            for (int t = 0; t < d; t++) pr[t] = T.coeff;
+            for (int j : T.full) {
+                const E2* q = sc->host_tab.data() + (size_t)sc->mles[j].local * sc->host_len0 + 2 * p;
+                E2 x = q[1];
+                const E2 delta = q[1] - q[0];
+                for (int t = 0; t < d; t++) {
+                    pr[t] = pr[t] * x;
+                    x = x + delta;
+                }
+            }
+            for (int t = 0; t < d; t++) acc[t] = acc[t] + pr[t];
+        }
+    }
+    for (int t = 0; t < d; t++) {
+        h_out[2 * t] = acc[t].c0;
+        h_out[2 * t + 1] = acc[t].c1;
+    }
+    return 0;
+}
+
 static int pipe_lookahead() {
     static int v = [] {
         const char* e = getenv("CENO_HIP_PIPE_LOOKAHEAD");  // large value = enqueue everything at round 0 (A/B measurements)
@@ -1791,9 +1859,28 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             const int tnt = fused_tnt(k, pairs);
             if (tail_eligible(k, pairs, sc->d, (size_t)cl.n_flat)) {  // this launch produces rounds i .. n-1
                 static const bool tail_evals = !(getenv("CENO_HIP_TAIL_EVALS") && atoi(getenv("CENO_HIP_TAIL_EVALS")) == 0);  // A/B switch
-                sc->tail_evals = tail_evals;
-                launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, sc->n, ep,
-                            tail_evals ? reinterpret_cast<E2*>(sc->d_hmsg) + MAXD : nullptr, sc->st);
+                // The last rounds belong to the host (sc_host_round): the device stops after round n_stop - 1 and ships its tables.
+                int n_stop = sc->n;
+                E2* export_view = nullptr;
+                const int ht = host_tail_rounds();
+                if (ht > 0 && std::max(i + 1, sc->n - ht) < sc->n) {
+                    n_stop = std::max(i + 1, sc->n - ht);
+                    const int len0 = 2 << (sc->n - n_stop);  // round n_stop - 1 has 2^(n - n_stop) pairs
+                    void *hb = nullptr, *dv = nullptr;
+                    if (ctx_pinned_alloc(ctx, k * (size_t)len0 * sizeof(E2), &hb, &dv) == 0) {
+                        uint64_t* w = reinterpret_cast<uint64_t*>(hb);
+                        for (size_t x = 0; x < k * (size_t)len0 * 2; x++) w[x] = MSG_INVALID;
+                        sc->h_tail_block = hb;
+                        sc->host_from = n_stop;
+                        sc->host_len0 = len0;
+                        export_view = reinterpret_cast<E2*>(dv);
+                    } else {
+                        n_stop = sc->n;  // no pinned memory: the device finishes the sumcheck as before
+                    }
+                }
+                sc->tail_evals = tail_evals && !export_view;
+                launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, n_stop, ep,
+                            sc->tail_evals ? reinterpret_cast<E2*>(sc->d_hmsg) + MAXD : nullptr, export_view, sc->st);
                 upto = sc->n;
                 break;
             }
@@ -1883,6 +1970,11 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     if (i == 0 && h_out && !d_out && sc_pipeline_eligible(sc)) TRY(sc_pipeline_enqueue(sc, 1 + pipe_lookahead()));
     if (sc->pipelined) {
         if (d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: device-output rounds cannot follow host-output rounds");
+        if (sc->host_from >= 0 && i >= sc->host_from) {  // the device has shipped its tables and left: this round is the host's
+            TRY(sc_host_round(sc, r, h_out));
+            sc->round++;
+            return 0;
+        }
         if (i > 0) {
             volatile Mailbox* mb = sc->h_mailbox;
             mb->chal[0] = r.c0;
@@ -2116,7 +2208,17 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
         CHECK_ARG(ctx, last_challenge2, "last challenge is NULL");
         const E2 r{last_challenge2[0], last_challenge2[1]};
         size_t h_cursor = 0;
-        if (sc->pipelined && sc->tail_evals) {
+        if (sc->pipelined && sc->host_from >= 0) {
+            // host-finished tail: the last fold happens here
+            ScClass& cl = sc->classes[0];
+            TRY(host_take_over(sc));
+            host_fold(sc, r);
+            for (size_t k = 0; k < cl.mles.size(); k++) {
+                ScMle& M = sc->mles[cl.mles[k]];
+                M.eval = sc->host_tab[k * (size_t)sc->host_len0];
+                M.done = true;
+            }
+        } else if (sc->pipelined && sc->tail_evals) {
             // the persistent tail kernel is waiting for this challenge and writes the evaluations itself
             ScClass& cl = sc->classes[0];
             volatile Mailbox* mb = sc->h_mailbox;

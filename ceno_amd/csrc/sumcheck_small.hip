@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(NT) k_tile(DevPlan pl, int n_mles, int n_flat,
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restrict__ last_slots, int n_mles, int n_flat, int pairs0, int i0, int n,
-                                             E2 r, Epilogue ep, E2* __restrict__ out_evals) {
+                                             E2 r, Epilogue ep, E2* __restrict__ out_evals, E2* __restrict__ export_host) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     if (CENO_SMALL_SETPRIO) __builtin_amdgcn_s_setprio(3);  // latency chain: win issue arbitration against bulk kernels of other lanes
     E2* bufA = reinterpret_cast<E2*>(dyn);                 // [n_mles][2 * pairs0]
@@ -233,6 +233,21 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
         E2* tp_ = cur; cur = nxt; nxt = tp_;
         const int ts_ = sc_; sc_ = sn; sn = ts_;
         pairs >>= 1;
+    }
+    // Host-finished tail (`n` is then the first round the HOST computes): the tables round n-1 was computed on — still unfolded,
+    // 2 * pairs entries each — go to pinned host memory right behind the message and the kernel is done.  The host folds with the
+    // challenge it samples next and runs the remaining rounds itself: a round of <= 64 pairs is a few microseconds of host arithmetic
+    // against ~10 us of PCIe round trip per round here.  (The words were armed with MSG_INVALID: the host waits for all of them.)
+    if (export_host) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const int len = 2 * pairs;
+        for (int idx = threadIdx.x; idx < n_mles * len; idx += NT) {
+            const int m = idx / len, j = idx - m * len;
+            const E2 v = cur[(size_t)m * sc_ + j];
+            const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(export_host + idx), "v"(w) : "memory");
+        }
+        return;
     }
     // the final evaluations f_m(r_0..r_{n-1}) = lo + r_{n-1} (hi - lo), straight into the pinned words the host watches: no
     // separate launch (and kernel boundary) for them at the end of every sumcheck
@@ -506,21 +521,21 @@ bool tail_eligible(size_t n_mles, size_t pairs, int d, size_t n_flat) {
 }
 template <int D>
 static void launch_tail_d(const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
-                          E2* out_evals, hipStream_t st) {
+                          E2* out_evals, E2* export_host, hipStream_t st) {
     hipLaunchKernelGGL((k_tail<D>), dim3(1), dim3(NT), tail_lds_bytes((size_t)n_mles, pairs, D, (size_t)n_flat), st, pl, last_slots, n_mles, n_flat, (int)pairs, i0, n,
-                       e2_zero(), ep, out_evals);
+                       e2_zero(), ep, out_evals, export_host);
 }
 void launch_tail(int d, const DevPlan& pl, const MleSlot* last_slots, int n_mles, int n_flat, size_t pairs, int i0, int n, const Epilogue& ep,
-                        E2* out_evals, hipStream_t st) {
+                        E2* out_evals, E2* export_host, hipStream_t st) {
     switch (d) {
-    case 1: launch_tail_d<1>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 2: launch_tail_d<2>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 3: launch_tail_d<3>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 4: launch_tail_d<4>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 5: launch_tail_d<5>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
-    default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, st); break;
+    case 1: launch_tail_d<1>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 2: launch_tail_d<2>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 3: launch_tail_d<3>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 4: launch_tail_d<4>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 5: launch_tail_d<5>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 6: launch_tail_d<6>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    case 7: launch_tail_d<7>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
+    default: launch_tail_d<8>(pl, last_slots, n_mles, n_flat, pairs, i0, n, ep, out_evals, export_host, st); break;
     }
 }
 
