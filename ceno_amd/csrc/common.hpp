@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -20,6 +21,10 @@ using gl::E2;
 struct PoseidonParams;  // poseidon2.hip
 struct ceno_hip_ctx;
 void merkle_drop_host_params(ceno_hip_ctx* ctx);  // poseidon2.hip: frees the host copy of the Poseidon2 table
+void ctx_pipelined_begin(ceno_hip_ctx* ctx);  // ctx.hip: counts a pipelined sumcheck in (waits for a trim in progress)
+void ctx_pipelined_end(ceno_hip_ctx* ctx);
+bool ctx_trim_begin(ceno_hip_ctx* ctx);       // false: pipelined sumchecks are alive (or another trim runs) — nothing may be hipFree'd now
+void ctx_trim_end(ceno_hip_ctx* ctx);
 
 struct ceno_hip_ctx {
     int device = 0;
@@ -56,6 +61,13 @@ struct ceno_hip_ctx {
     // device, so the pool's soft-cap trim (ctx_alloc) only runs while this is zero — two lanes each inside hipFree, each with
     // kernels that need the other's... host would otherwise wait for each other until the kernels' poll timeout
     std::atomic<int> pipelined_live{0};
+    // ... and the other half of that rule: a trim that has STARTED keeps new pipelined sumchecks from starting until it is done
+    // (a lane that begins proving while another sits in hipFree has its round kernels waited for by that hipFree, and its own next
+    // hipMalloc queues behind the same hipFree inside the runtime: host and kernel then wait for each other until the kernel's
+    // poll timeout — seen at the start of a four-lane shard right after a 13 GB batch).  ctx_pipelined_begin / ctx_trim_begin.
+    std::mutex gate_mu;
+    std::condition_variable gate_cv;
+    bool trimming = false;
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----

@@ -4,6 +4,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <functional>
 
 static thread_local std::string g_init_err;
 
@@ -64,17 +65,40 @@ static bool stream_drained(hipStream_t s) {
     return true;
 }
 
+void ctx_pipelined_begin(ceno_hip_ctx* ctx) {
+    std::unique_lock<std::mutex> lk(ctx->gate_mu);
+    ctx->gate_cv.wait(lk, [&] { return !ctx->trimming; });
+    ctx->pipelined_live.fetch_add(1);
+}
+void ctx_pipelined_end(ceno_hip_ctx* ctx) { ctx->pipelined_live.fetch_sub(1); }
+bool ctx_trim_begin(ceno_hip_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->gate_mu);
+    if (ctx->trimming || ctx->pipelined_live.load() > 0) return false;
+    ctx->trimming = true;
+    return true;
+}
+void ctx_trim_end(ceno_hip_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> g(ctx->gate_mu);
+        ctx->trimming = false;
+    }
+    ctx->gate_cv.notify_all();
+}
+
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     size_t b = bucket_size(bytes);
     // hipFree waits for every stream of the device, and a lane's queued round kernels wait for a host that may be waiting
     // for this mutex: blocks that go back to the driver are only COLLECTED under the mutex and released after it is dropped
     std::vector<void*> victims;
     struct Release {
+        ceno_hip_ctx* ctx;
         std::vector<void*>& v;
+        bool gate = false;  // this call holds the trim gate
         ~Release() {
             for (void* p : v) (void)hipFree(p);
+            if (gate) ctx_trim_end(ctx);
         }
-    } release{victims};
+    } release{ctx, victims};
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
@@ -123,8 +147,8 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                 return 0;
             }
         }
-        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
-            // try to make room by dropping cached blocks
+        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit && (release.gate = ctx_trim_begin(ctx))) {
+            // try to make room by dropping cached blocks (only while no pipelined sumcheck is alive: gate)
             for (auto& kv : ctx->free_lists) {
                 for (auto& p : kv.second) {
                     victims.push_back(p.first);
@@ -132,10 +156,10 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                 }
                 kv.second.clear();
             }
-            if (ctx->pool_used + b > ctx->pool_limit) {
-                ctx->err = "pool capacity exceeded";
-                return CENO_HIP_ERR_OOM;
-            }
+        }
+        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
+            ctx->err = "pool capacity exceeded";
+            return CENO_HIP_ERR_OOM;
         }
     }
     void* p = nullptr;
@@ -146,15 +170,49 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
         // round kernels wait for their host thread; a host thread inside hipFree with such kernels pending, and a second one
         // likewise, would wait for each other until the kernels give up — seen as "round finished without publishing its
         // message" after a 13 GB batch had left the cache over the cap in front of a four-lane shard flow)
-        std::lock_guard<std::mutex> g(ctx->mu);
         const size_t floor_ = (size_t)2 << 30;
-        if (ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_) && ctx->pipelined_live.load() == 0) {
-            for (auto& kv : ctx->free_lists) {
-                auto& fl = kv.second;
-                for (size_t k = 0; k < fl.size();) {
-                    if (fl[k].second == nullptr) {
+        bool over = false;
+        {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            over = ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_);
+        }
+        if (over && !release.gate) release.gate = ctx_trim_begin(ctx);  // (gate before pool mutex, everywhere)
+        std::lock_guard<std::mutex> g(ctx->mu);
+        if (over && release.gate) {
+            // LARGEST blocks first, only blocks of >= 1 MB, only until the cache is back under HALF the cap: what puts a cache over
+            // a cap of >= 8 GB are the tables of a big batch, not the working set of the flows that follow it — returning every
+            // idle block made those flows re-allocate theirs from the driver on every use (measured after a 13.6 GB batch: 800-2000
+            // hipMalloc and ~1000-2000 hipFree'd blocks per flow, chip proofs 2x slower, for as long as the big blocks — still tagged
+            // with their stream — kept the cache over the cap).  A block counts as idle when it carries no tag or its stream has
+            // drained or is gone (one query per distinct stream).
+            const size_t target = 2 * std::max(ctx->pool_used + b, floor_);
+            hipStream_t seen[16];
+            bool idle[16];
+            int n_seen = 0;
+            std::vector<size_t> keys;
+            for (auto& kv : ctx->free_lists)
+                if (kv.first >= ((size_t)1 << 20) && !kv.second.empty()) keys.push_back(kv.first);
+            std::sort(keys.begin(), keys.end(), std::greater<size_t>());
+            for (size_t key : keys) {
+                if (ctx->pool_cached <= target) break;
+                auto it = ctx->free_lists.find(key);
+                auto& fl = it->second;
+                for (size_t k = 0; k < fl.size() && ctx->pool_cached > target;) {
+                    const hipStream_t tag = fl[k].second;
+                    bool free_now = tag == nullptr || !stream_alive(ctx, tag);
+                    if (!free_now) {
+                        int j = 0;
+                        while (j < n_seen && seen[j] != tag) j++;
+                        if (j == n_seen && n_seen < 16) {
+                            seen[n_seen] = tag;
+                            idle[n_seen] = stream_drained(tag);
+                            n_seen++;
+                        }
+                        free_now = j < n_seen && idle[j];
+                    }
+                    if (free_now) {
                         victims.push_back(fl[k].first);
-                        ctx->pool_cached -= kv.first;
+                        ctx->pool_cached -= it->first;
                         fl[k] = fl.back();
                         fl.pop_back();
                     } else {
@@ -164,8 +222,15 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
             }
         }
     }
+    static const bool pool_trace = getenv("CENO_HIP_POOL_TRACE") != nullptr;  // one line per driver call (debugging cache behaviour)
+    if (pool_trace && !victims.empty()) fprintf(stderr, "[ceno_hip] pool: hipFree of %zu cached blocks (cached %zu MB, used %zu MB)\n", victims.size(), ctx->pool_cached >> 20, ctx->pool_used >> 20);
     for (void* v : victims) (void)hipFree(v);  // outside the mutex (see above)
     victims.clear();
+    if (pool_trace) fprintf(stderr, "[ceno_hip] pool: hipMalloc %zu KB (cached %zu MB, used %zu MB)\n", b >> 10, ctx->pool_cached >> 20, ctx->pool_used >> 20);
+    if (release.gate) {
+        ctx_trim_end(ctx);
+        release.gate = false;
+    }
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
         // drop the cache and retry once
@@ -480,6 +545,11 @@ int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_
 
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
     std::vector<void*> victims;
+    if (!ctx_trim_begin(ctx)) return 0;  // lanes are proving: nothing can go back to the driver now (hipFree would wait for their round kernels)
+    struct End {
+        ceno_hip_ctx* c;
+        ~End() { ctx_trim_end(c); }
+    } end{ctx};
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         for (auto& kv : ctx->free_lists) {

@@ -795,7 +795,9 @@ struct ceno_hip_sumcheck {
     bool tail_evals = false;                // the persistent tail kernel also produces the final evaluations (finish posts the last challenge)
     // host-finished tail: rounds [host_from, n) are computed by the HOST on the tables the tail kernel exported with its last message
     int host_from = -1;
-    void* h_tail_block = nullptr;           // pinned: n_mles x host_len0 E2, armed with MSG_INVALID
+    int host_ht = 0;                        // host rounds this plan is worth (host_tail_rounds at begin)
+    E2* h_tail = nullptr;                   // inside the pinned block: n_mles x (2 << host_ht) E2, armed with MSG_INVALID
+    E2* d_tail_view = nullptr;
     int host_len0 = 0;                      // entries per exported table
     int host_len = 0;                       // entries per table in `host_tab` now (0 = not taken over yet)
     std::vector<E2> host_tab;               // [class-local mle][host_len0]
@@ -809,6 +811,7 @@ struct ceno_hip_sumcheck {
     Bcast* d_bcast = nullptr;      // device relay
     bool allow_pipeline = false;   // caller promised to drive the rounds back to back (ceno_hip_sumcheck_set_pipelined)
     bool pipelined = false;        // round kernels are enqueued ahead of their challenges, which travel through the mailbox
+    bool live_counted = false;     // counted in ctx->pipelined_live (ctx_pipelined_begin / _end)
     int enq = 0;                   // pipelined: rounds [0, enq) are in the stream
     E2* d_evals = nullptr;         // gather scratch (device), num_mles
     E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
@@ -824,6 +827,8 @@ struct ceno_hip_sumcheck {
     char* d_gen = nullptr;
     void* h_gen = nullptr;                // pinned staging of the blob (alive until the handle is freed)
 };
+
+static int host_tail_rounds(const ceno_hip_sumcheck* sc);  // below, next to the host rounds
 
 template <typename T>
 static int upload_vec(ceno_hip_sumcheck* sc, const std::vector<T>& v, T** out) {
@@ -863,7 +868,6 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     // pinned words and does not synchronise): no wait here either — it was ~20 us per tower layer — the buffers go back to the
     // pool tagged with THIS sumcheck's stream (ctx_free_on below), so another stream gets them only once it has drained
     if (!sc->finished) (void)hipStreamSynchronize(sc->st);
-    if (sc->h_tail_block) ctx_pinned_free(sc->ctx, sc->h_tail_block);  // (a finished sumcheck has read every word the tail kernel exported)
     if (sc->pipelined && getenv("CENO_HIP_DEBUG") && sc->d_bcast) {
         static Bcast hb;
         if (hipMemcpy(&hb, sc->d_bcast, sizeof(Bcast), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -877,7 +881,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         sc->ctx->mid_wgs_in_flight.fetch_sub(sc->mid_reserved);
         sc->mid_reserved = 0;
     }
-    if (sc->pipelined) sc->ctx->pipelined_live.fetch_sub(1);
+    if (sc->live_counted) ctx_pipelined_end(sc->ctx);
     for (void* p : sc->dev_allocs) ctx_free_on(sc->ctx, p, sc->st);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
@@ -1515,9 +1519,22 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         // pinned block: [flag 64 B][mailbox 64 B][message MAXD + evals num_mles (E2)][slot staging]
         const size_t msg_bytes = (MAXD + (size_t)plan->num_mles) * sizeof(E2);
         const size_t slot_bytes = std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2);
+        // ... [plan blob][tables of a host-finished tail]: reserved HERE — a pinned allocation at enqueue time may call into the
+        // driver (hipHostMalloc) while this sumcheck's own persistent round kernels wait for this very host thread
+        size_t tail_bytes = 0;
+        if (sc->classes.size() == 1 && sc->classes[0].nv == n && n >= 2 && !sc->classes[0].terms.empty()) {
+            sc->host_ht = host_tail_rounds(sc);
+            if (sc->host_ht > 0) tail_bytes = sc->classes[0].mles.size() * ((size_t)2 << sc->host_ht) * sizeof(E2);
+        }
+        const size_t tail_off = (128 + msg_bytes + slot_bytes + blob.size() + 16 + 15) & ~(size_t)15;
         void *hb = nullptr, *db = nullptr;
-        int rc = ctx_pinned_alloc(ctx, 128 + msg_bytes + slot_bytes + blob.size() + 16, &hb, &db);
+        int rc = ctx_pinned_alloc(ctx, tail_off + tail_bytes, &hb, &db);
         if (rc) { sc_release(sc); return rc; }
+        if (tail_bytes) {
+            sc->h_tail = reinterpret_cast<E2*>((char*)hb + tail_off);
+            sc->d_tail_view = reinterpret_cast<E2*>((char*)db + tail_off);
+            for (size_t x = 0; x < tail_bytes / 8; x++) reinterpret_cast<uint64_t*>(sc->h_tail)[x] = MSG_INVALID;
+        }
         sc->h_block = hb;
         sc->h_flag = (unsigned long long*)hb;
         sc->d_hflag = (unsigned long long*)db;
@@ -1627,7 +1644,7 @@ static void sc_advance(ceno_hip_sumcheck* sc, ScClass& cl) {
 }
 
 // wait until `n_words` pinned words (pre-filled with MSG_INVALID) have all been written by the device
-static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_words) {
+static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_words, const char* what = "its message") {
     unsigned long long spins = 0;
     for (;;) {
         int k = 0;
@@ -1645,7 +1662,8 @@ static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_wor
                 k = 0;
                 while (k < n_words && __atomic_load_n(&words[k], __ATOMIC_ACQUIRE) != MSG_INVALID) k++;
                 if (k == n_words) return 0;
-                return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round finished without publishing its message");
+                return ctx_fail(sc->ctx, CENO_HIP_ERR_HIP, "sumcheck round finished without publishing %s (round %d of %d, %d of %d words, host rounds from %d)",
+                                what, sc->round, sc->n, k, n_words, sc->host_from);
             }
         }
     }
@@ -1719,11 +1737,24 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
 // Rounds are enqueued a few ahead of the one being answered instead of all at once: launching ~2n kernels costs
 // 100-300 us of host time, and a round-0 kernel shorter than that would sit in its challenge poll until the host
 // got around to reading its message (measured: 20 us per tiny round instead of 12, 800 us for a 160 us round 0).
-// rounds at the end of a pipelined sumcheck that the HOST computes (CENO_HIP_HOST_TAIL, 0 = the device runs every round)
-static int host_tail_rounds() {
+// Rounds at the end of a pipelined sumcheck that the HOST computes.  A device round of the persistent tail costs ~9.6 us whatever
+// its size (publish, PCIe, challenger, poll); a host round costs its arithmetic: pairs x sum_T |T| x d extension multiplications of
+// ~7 ns (measured: 0.31 us per pair for a tower layer's 5 terms of degree 3, 2.5 us per pair for a chip's 33 constraint terms of
+// degree 4).  The host takes over at the first round it computes faster than the device would: 32 pairs for a tower layer, 4 for
+// the chip's main sumcheck, 128 for a plain product of three tables.  CENO_HIP_HOST_TAIL caps the number of host rounds (0 = the
+// device runs every round), CENO_HIP_HOST_TAIL_NS is the per-round budget.
+static int host_tail_rounds(const ceno_hip_sumcheck* sc) {
     const char* e = getenv("CENO_HIP_HOST_TAIL");  // (read per call: the test-suite switches it between sumchecks)
-    const int v = e ? atoi(e) : 6;
-    return v < 0 ? 0 : (v > 12 ? 12 : v);
+    int cap = e ? atoi(e) : 8;
+    cap = cap < 0 ? 0 : (cap > 12 ? 12 : cap);
+    const char* b = getenv("CENO_HIP_HOST_TAIL_NS");
+    const double budget = b && atof(b) > 0 ? atof(b) : 10500.0;
+    size_t mults = 0;
+    for (int ti : sc->classes[0].terms) mults += sc->terms[ti].full.size();
+    const double per_pair = 7.0 * (double)sc->d * (double)std::max<size_t>(mults, 1);
+    int ht = 1;  // the last round (one pair) is always cheaper on the host
+    while (ht < cap && (double)((size_t)1 << ht) * per_pair <= budget) ht++;  // first host round of `ht` rounds: 2^(ht-1) pairs
+    return std::min(ht, cap);
 }
 // One host round of a host-finished tail: fold the tables with the challenge of round i - 1, then the message of round i,
 // p(1) .. p(d) of sum_pairs sum_terms c_T prod_{j in T} f_j(X).  Field arithmetic is exact, so the order of the sums is free and the
@@ -1743,14 +1774,18 @@ static void host_fold(ceno_hip_sumcheck* sc, E2 r) {
 static int host_take_over(ceno_hip_sumcheck* sc) {
     if (sc->host_len) return 0;
     const size_t k = sc->classes[0].mles.size(), words = k * (size_t)sc->host_len0 * 2;
-    TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(sc->h_tail_block), (int)words));
+    TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(sc->h_tail), (int)words, "the tables of the host-finished tail"));
     sc->host_tab.resize(k * (size_t)sc->host_len0);
-    memcpy(sc->host_tab.data(), sc->h_tail_block, words * 8);
+    memcpy(sc->host_tab.data(), sc->h_tail, words * 8);
     sc->host_len = sc->host_len0;
     return 0;
 }
 static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out) {
+    static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    timespec ta, tb, tc;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
     TRY(host_take_over(sc));
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &tb);
     host_fold(sc, r);
     const ScClass& cl = sc->classes[0];
     const int d = sc->d, pairs = sc->host_len / 2;
@@ -1777,6 +1812,11 @@ static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out) {
         h_out[2 * t] = acc[t].c0;
         h_out[2 * t + 1] = acc[t].c1;
     }
+    if (dbg) {
+        clock_gettime(CLOCK_MONOTONIC, &tc);
+        fprintf(stderr, "[ceno_hip] host round %d: %d pairs, %zu terms, waited %.1f us for the tables, fold + message %.1f us\n", sc->round, pairs,
+                cl.terms.size(), (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) / 1e3, (tc.tv_sec - tb.tv_sec) * 1e6 + (tc.tv_nsec - tb.tv_nsec) / 1e3);
+    }
     return 0;
 }
 
@@ -1796,6 +1836,10 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     upto = std::min(upto, sc->n);
     const int from = sc->enq;
     if (from >= upto) return 0;
+    if (!sc->live_counted) {  // (once per handle, BEFORE the first kernel that waits for this host is queued) the pool returns nothing
+        ctx_pipelined_begin(ctx);  // to the driver while such kernels exist, and none is queued while a trim is under way (common.hpp)
+        sc->live_counted = true;
+    }
     // A dense class (one product of K <= 4 tables) runs its LARGE rounds on the register-resident fused kernel and hands over to
     // the latency ladder below (k_mid / k_tail: persistent kernels, no kernel boundary and no cross-workgroup counter per round)
     // once a round has at most 2^15 pairs: the last ~15 rounds of every dense sumcheck cost ~9-13 us instead of ~15 us each
@@ -1862,21 +1906,12 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 // The last rounds belong to the host (sc_host_round): the device stops after round n_stop - 1 and ships its tables.
                 int n_stop = sc->n;
                 E2* export_view = nullptr;
-                const int ht = host_tail_rounds();
+                const int ht = sc->h_tail ? sc->host_ht : 0;
                 if (ht > 0 && std::max(i + 1, sc->n - ht) < sc->n) {
                     n_stop = std::max(i + 1, sc->n - ht);
-                    const int len0 = 2 << (sc->n - n_stop);  // round n_stop - 1 has 2^(n - n_stop) pairs
-                    void *hb = nullptr, *dv = nullptr;
-                    if (ctx_pinned_alloc(ctx, k * (size_t)len0 * sizeof(E2), &hb, &dv) == 0) {
-                        uint64_t* w = reinterpret_cast<uint64_t*>(hb);
-                        for (size_t x = 0; x < k * (size_t)len0 * 2; x++) w[x] = MSG_INVALID;
-                        sc->h_tail_block = hb;
-                        sc->host_from = n_stop;
-                        sc->host_len0 = len0;
-                        export_view = reinterpret_cast<E2*>(dv);
-                    } else {
-                        n_stop = sc->n;  // no pinned memory: the device finishes the sumcheck as before
-                    }
+                    sc->host_from = n_stop;
+                    sc->host_len0 = 2 << (sc->n - n_stop);  // round n_stop - 1 has 2^(n - n_stop) <= 2^ht pairs
+                    export_view = sc->d_tail_view;
                 }
                 sc->tail_evals = tail_evals && !export_view;
                 launch_tail(sc->d, pl, cl.d_slots + (size_t)(sc->n - 1) * k, (int)k, cl.n_flat, pairs, i, n_stop, ep,
@@ -1949,7 +1984,6 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) / 1e3);
     }
     sc->enq = upto;
-    if (!sc->pipelined) sc->ctx->pipelined_live.fetch_add(1);  // (once per handle) the pool returns nothing to the driver while round kernels may be waiting for a host (ctx_alloc)
     sc->pipelined = true;
     sc->seq = (unsigned long long)sc->n;
     return 0;
