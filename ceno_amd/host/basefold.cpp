@@ -334,6 +334,13 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
                 plan.max_num_vars = kv.first;
                 plan.max_degree = 2;
                 rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, &g.sc);
+                // rounds queued ahead of their challenges (persistent small-round kernels, host-finished tail): between two rounds
+                // this loop only waits for a tree root, and a round kernel that waits a little longer for its challenge costs nothing.
+                // Only when ONE height group exists: the queued kernels of a pipelined sumcheck wait for this thread, and a second
+                // group's kernels behind them on the same stream would never produce the message this thread waits for.
+                // CENO_BASEFOLD_PIPELINE=0: one launch + synchronisation per round (A/B measurements)
+                static const bool pipe = !(getenv("CENO_BASEFOLD_PIPELINE") && atoi(getenv("CENO_BASEFOLD_PIPELINE")) == 0);
+                if (!rc && pipe && groups.size() == 1) (void)ceno_hip_sumcheck_set_pipelined(ctx, g.sc, 1);
                 g.started = true;
             }
             uint64_t ev[4];

@@ -22,6 +22,15 @@ int prover_set_error(int code, const char* msg);  // prover.cpp
 
 extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane) {
     if (!ctx || !tasks || n_lanes < 1 || n_lanes > 64 || n_tasks < 0) return prover_set_error(CENO_HIP_ERR_INVALID, "lanes_run: bad arguments");
+    {
+        // The command processor dispatches FOUR queues concurrently; further streams are time-multiplexed onto them, and a lane whose
+        // stream shares a queue with another lane's persistent round kernel waits behind it (tools/ubench_lanes.hip,
+        // profiles/r03_lane_launch_latency.json: launch + wait 116 us for 16 launches on 4 streams, 219 us on 8; eight chip-proof
+        // lanes measured 10-20 % slower than four).  More lanes than that are therefore run as four; CENO_HIP_MAX_LANES overrides.
+        const char* e = getenv("CENO_HIP_MAX_LANES");
+        const int cap = e && atoi(e) > 0 ? atoi(e) : 4;
+        n_lanes = std::min(n_lanes, cap);
+    }
     std::vector<int> order(n_tasks);
     for (int i = 0; i < n_tasks; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tasks[a].estimated_bytes > tasks[b].estimated_bytes; });

@@ -370,7 +370,8 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
  * One worker thread per lane, each with the context's stream of that lane (ceno_hip_lane_stream: created once, never per run); tasks are taken largest-estimate
  * first, booked against the pool before they start (greedy back-fill with smaller tasks when the largest does not fit)
  * and unbooked when done.  `fn` runs the C ABI calls of one chip proof on the given stream and returns 0 or an error.
- * out_status / out_lane (n_tasks each, may be NULL) receive every task's return code and the lane that ran it. */
+ * out_status / out_lane (n_tasks each, may be NULL) receive every task's return code and the lane that ran it.
+ * More than four lanes run as four (the device dispatches four queues concurrently; CENO_HIP_MAX_LANES overrides). */
 typedef int (*ceno_lane_task_fn)(void* arg, int lane, ceno_hip_stream stream);
 typedef struct ceno_lane_task {
     ceno_lane_task_fn fn;
