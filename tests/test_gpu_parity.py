@@ -940,6 +940,38 @@ def test_sumcheck_persistent_mid_rounds_geometries(dev, prover, monkeypatch, w, 
         m.free()
 
 
+@pytest.mark.parametrize("cap,budget_ns", [("0", None), ("1", None), ("3", None), ("12", "1e9"), ("12", "1"), (None, None)])
+@pytest.mark.parametrize("nv,n_mles,terms,is_ext", [
+    (13, 4, [[0, 1, 2], [1, 2, 3]], True),                      # k_mid + k_tail + host
+    (9, 3, [[0, 1, 2]], False),                                 # base-field inputs, the tail kernel is the first kernel
+    (4, 2, [[0, 1]], True),                                     # fewer rounds than the host would take: the device keeps round 0
+    (2, 3, [[0, 1, 2], [2]], True),
+    (11, 9, [[0, 1, 2], [3, 4], [5, 6, 7, 8], [0, 8], [2, 4, 6], [1], [3, 5, 7]], True),  # an expensive plan: few host rounds
+])
+def test_sumcheck_host_finished_tail_every_split(dev, prover, monkeypatch, cap, budget_ns, nv, n_mles, terms, is_ext):
+    """The last rounds of a pipelined sumcheck are computed by the HOST on tables the tail kernel ships with its last message
+    (CENO_HIP_HOST_TAIL caps the rounds, CENO_HIP_HOST_TAIL_NS is the per-round budget the plan's cost is held against).  Every
+    split — none, one round, a few, as many as the tables allow (budget 1e9), the default — gives the oracle's messages, challenges
+    and final evaluations word for word."""
+    if cap is None:
+        monkeypatch.delenv("CENO_HIP_HOST_TAIL", raising=False)
+    else:
+        monkeypatch.setenv("CENO_HIP_HOST_TAIL", cap)
+    if budget_ns is None:
+        monkeypatch.delenv("CENO_HIP_HOST_TAIL_NS", raising=False)
+    else:
+        monkeypatch.setenv("CENO_HIP_HOST_TAIL_NS", budget_ns)
+    tabs = [po.rand_ext(1 << nv, 900 + j) if is_ext else po.rand_base(1 << nv, 900 + j) for j in range(n_mles)]
+    mles = [dev.upload(t) for t in tabs]
+    coeffs = po.ext([(5 + 3 * i, 11 * i + 2) for i in range(len(terms))])
+    deg = max(len(t) for t in terms)
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, coeffs, terms, nv, deg, prover.Transcript.stub(0xA7))
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, coeffs, terms, nv, deg, po.StubTranscript(0xA7))
+    assert np.array_equal(msgs, omsgs) and np.array_equal(chal, ochal) and np.array_equal(fin, ofin)
+    for m in mles:
+        m.free()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_tower_random_specs_differential(dev, prover, seed):
     """seeded random tower batches (0-3 product specs, 0-2 LogUp specs with or without numerators, heights 2-13 so that
