@@ -2042,9 +2042,13 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         } else if (cl.nv == i && i > 0) {
             const MleSlot* d_slots = nullptr;
             TRY(sc_push_slots(sc, cl, i, h_cursor, &d_slots));
-            hipLaunchKernelGGL(k_fold_batch, dim3(1, (unsigned)cl.mles.size()), dim3(NT), 0, sc->st, d_slots, (size_t)1, r, (const Bcast*)nullptr, 0ull);
-            hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(),
-                               sc->d_evals);
+            // one launch folds the last variable of every table of the class and writes the values straight into the armed pinned
+            // words the host watches (as ceno_hip_sumcheck_finish does): a fold, a gather, a device-to-host copy and a stream
+            // synchronisation cost ~45 us on each of the rounds in which a class of a mixed-size batch retires
+            E2* h_ev = sc->h_pinned + MAXD;
+            for (size_t k = 0; k < 2 * cl.mles.size(); k++) reinterpret_cast<uint64_t*>(h_ev)[k] = MSG_INVALID;
+            hipLaunchKernelGGL(k_finish_evals, dim3((unsigned)((cl.mles.size() + 63) / 64)), dim3(64), 0, sc->st, d_slots, (int)cl.mles.size(), r,
+                               reinterpret_cast<E2*>(sc->d_hmsg) + MAXD);
             became_scalar = &cl;  // at most one class reaches its last variable per round
         }
     }
@@ -2052,8 +2056,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         ScClass* cl = became_scalar;
         E2* h_ev = sc->h_pinned + MAXD;
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(h_ev, sc->d_evals, cl->mles.size() * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
-        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(h_ev), 2 * (int)cl->mles.size(), "the evaluations of a class that reached its last variable"));
         for (size_t k = 0; k < cl->mles.size(); k++) {  // evaluations are in class-local order
             ScMle& M = sc->mles[cl->mles[k]];
             M.eval = h_ev[k];

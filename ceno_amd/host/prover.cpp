@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <cstdlib>
 #include <ctime>
@@ -144,9 +145,14 @@ int ceno_prover_sumcheck_run(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, in
     tr_usize(tr, (uint64_t)n);
     tr_usize(tr, (uint64_t)d);
     uint64_t ch[2] = {0, 0};
+    static const bool trace_rounds = getenv("CENO_PROVER_ROUND_TRACE") != nullptr;  // wall time of every round of every sumcheck driven here
     for (int round = 0; round < n; round++) {
         uint64_t* msg = out_msgs + (size_t)2 * d * round;
+        const auto t_round = std::chrono::steady_clock::now();
         int rc = ceno_hip_sumcheck_round(ctx, sc, round == 0 ? nullptr : ch, msg);
+        if (trace_rounds)
+            fprintf(stderr, "[ceno_prover] sumcheck of %d variables, round %d: %.1f us\n", n, round,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_round).count());
         if (rc) return fail_from_ctx(ctx, rc);
         for (int t = 0; t < d; t++) tr_ext(tr, msg + 2 * t);
         tr_label(tr, "Internal round");

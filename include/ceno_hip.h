@@ -25,8 +25,11 @@
  *    (it never waits: it takes another block or allocates), so a lane may free tables whose kernels are still queued.  A caller's own
  *    HIP stream passed as ceno_hip_stream is registered with that bookkeeping the first time a thread uses it (ceno_hip_stream_adopt
  *    does it explicitly); handles own the stream they were begun on and free their blocks with it.  Blocks go back to the DRIVER
- *    (hipFree waits for every stream of the device) only from ceno_hip_mem_trim, from the pool_bytes cap, or while no pipelined
- *    sumcheck is alive on any lane: call ceno_hip_mem_trim between phases, not while lanes are proving.
+ *    (hipFree waits for every kernel on the device) only while no pipelined sumcheck is alive on any lane — from
+ *    ceno_hip_mem_trim, from the pool_bytes cap, or when the cache is several times the memory in use (largest idle blocks first) —
+ *    and no pipelined sumcheck starts while such a trim is under way: call ceno_hip_mem_trim between phases.
+ *  - The latency-bound ends of the work are finished by the calling HOST thread: the last rounds of a pipelined sumcheck
+ *    (CENO_HIP_HOST_TAIL) and the top levels of every Merkle tree (CENO_HIP_HOST_TOP).  Results are bit-identical for every split.
  *  - The Fiat–Shamir transcript stays with the caller: sumcheck is exposed round by round
  *    (the reference passes `&mut BasicTranscript` into the HAL, gkr_iop/src/gkr/layer/gpu/mod.rs:252-270;
  *    a C ABI cannot take a Rust generic, so control is inverted).
@@ -91,7 +94,7 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
 /* bookkeeping that must return to zero when no sumcheck handle is alive (tests): live pipelined sumchecks (the pool's soft-cap
  * trim waits for zero) and the residency budget booked by persistent mid-round kernels (units of 1/64 compute unit) */
 int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight);
-int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device: not while lanes are proving */
+int ceno_hip_mem_trim(ceno_hip_ctx* ctx);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device; a no-op while pipelined sumchecks are alive on any lane */
 /* booking of estimated task footprints by a chip scheduler (mem_pool try_book_capacity / unbook_capacity /
  * get_booked_total, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,622-652): refused (CENO_HIP_ERR_OOM, nothing is
  * allocated) when live allocations + bookings + bytes would exceed pool_bytes (or the device memory when unlimited) */
