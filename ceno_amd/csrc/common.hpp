@@ -100,6 +100,7 @@ int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
 void ctx_free(ceno_hip_ctx* ctx, void* p);                         // tag = the stream the calling thread resolved last
 void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner);   // tag = the stream that used the block
+void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner);  // the same for all blocks of one handle
 // pinned, device-mapped host memory from a per-context cache; *dev_view is the device address of *host
 // 64-byte slot of fine-grained device memory the host can write through the BAR (nullptr when unavailable)
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx);

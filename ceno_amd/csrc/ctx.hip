@@ -268,6 +268,29 @@ void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner) {
     ctx->free_lists[b].push_back({p, tag});
 }
 
+// all blocks of one handle: one lock, one stream query (a sumcheck handle frees ~a dozen blocks, and the query alone is 1-2 us)
+void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner) {
+    if (!owner) owner = ctx->default_stream;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    int drained = -1;  // not asked yet
+    for (size_t i = 0; i < n; i++) {
+        void* p = ptrs[i];
+        if (!p) continue;
+        auto it = ctx->live.find(p);
+        if (it == ctx->live.end()) continue;
+        const size_t b = it->second;
+        ctx->live.erase(it);
+        ctx->pool_used -= b;
+        ctx->pool_cached += b;
+        hipStream_t tag = owner;
+        if (b >= ((size_t)64 << 10)) {  // (see ctx_free_on)
+            if (drained < 0) drained = stream_alive(ctx, owner) && stream_drained(owner) ? 1 : 0;
+            if (drained) tag = nullptr;
+        }
+        ctx->free_lists[b].push_back({p, tag});
+    }
+}
+
 static constexpr int VRAM_SLOTS = 1024;
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx) {
     ctx_make_current(ctx);

@@ -134,7 +134,15 @@ __global__ void __launch_bounds__(NT) k_eq_outer(E2* __restrict__ out, const E2*
 // the doubling construction (one multiplication per entry: new[j] = old[j] (1 - r_k), new[j + 2^k] = old[j] r_k), then serves
 // tiles of 2^11 consecutive outputs: out[tile * 2^11 + j] = P(tile) * low[j], P = scalar * prod over the high variables of the
 // tile index's bits.  Two multiplications and one 16-byte store per entry; the selector masks apply on the way out.
-static constexpr int EQ_LB = 11, EQ_FUSED_MAX = 16;
+static constexpr int EQ_LB = 11;
+// largest table built by the one-launch form (CENO_HIP_EQ_FUSED_MAX overrides: A/B measurements)
+static int eq_fused_max() {
+    static const int v = [] {
+        const char* e = getenv("CENO_HIP_EQ_FUSED_MAX");
+        return e ? atoi(e) : 16;
+    }();
+    return v;
+}
 __global__ void __launch_bounds__(NT) k_eq_fused(E2* __restrict__ out, int n, PointArg pt, E2 scalar, SelArg sa) {
     __shared__ E2 tab[1 << EQ_LB];
     const int lb = n < EQ_LB ? n : EQ_LB;
@@ -174,7 +182,7 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
     PointArg pt;
     for (int k = 0; k < n; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
     if (keep_tmp) *keep_tmp = nullptr;
-    if (n <= EQ_FUSED_MAX) {
+    if (n <= eq_fused_max()) {
         // latency-bound sizes: per block the LDS table costs as much as a tile's worth of products, which only pays when the
         // alternative is two more launches (at nv = 24 the fused form measured 0.143 ms against 0.080 ms for the outer product)
         const size_t tiles = (size_t)1 << (n > EQ_LB ? n - EQ_LB : 0);

@@ -882,7 +882,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         sc->mid_reserved = 0;
     }
     if (sc->live_counted) ctx_pipelined_end(sc->ctx);
-    for (void* p : sc->dev_allocs) ctx_free_on(sc->ctx, p, sc->st);
+    ctx_free_many_on(sc->ctx, sc->dev_allocs.data(), sc->dev_allocs.size(), sc->st);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
     ctx_vram_slot_free(sc->ctx, sc->vram_slot);

@@ -302,7 +302,7 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
     out->num_rounds = R;
     size_t msg_off = 0;
     std::vector<uint64_t> chal, fin;
-    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
+    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr || getenv("CENO_PROVER_LAYER_TRACE") != nullptr;
     auto now_us = []() {
         timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
