@@ -1,4 +1,4 @@
-// On-device witness generation for the R-type arithmetic chips ADD / SUB.
+// On-device witness generation for the R-type chips ADD / SUB and AND / OR / XOR.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -150,6 +150,139 @@ __global__ void __launch_bounds__(NT) k_witgen_arith(Map m, const unsigned char*
     }
 }
 
+// ---- R-type logic chips AND / OR / XOR (LogicInstruction, ceno_zkvm/src/instructions/riscv/logic/logic_circuit.rs:30-160): the same
+// R-instruction base (state, rs1, rs2, rd: r_insn.rs:67-86) and then the three registers as 4 BYTES each (UInt8, split_to_u8);
+// lookups: fetch, the six timestamp-difference limbs, and one entry of the op's 2^16-entry table per byte pair, key a | b << 8
+// (UInt8::logic_assign uint/logic.rs:26-32, OpsTable::pack gkr_iop/src/tables/mod.rs:29-31).  28 mapped columns.
+struct LogicMap {  // ceno_hip_logic_r_column_map = ceno_gpu's LogicRColumnMap (chips/logic_r.rs:25-42)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_bytes[4], rs2_bytes[4], rd_bytes[4];
+    uint32_t num_cols;
+};
+static_assert(sizeof(LogicMap) == sizeof(ceno_hip_logic_r_column_map), "column map layout");
+constexpr int LOGIC_COLS = 28;
+constexpr size_t LOGIC_SLOTS = (size_t)1 << 16;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_logic(LogicMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                     uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w,
+                                                     size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic) {
+    if (XCD_LOCAL) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
+        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
+        if (lk_logic) lk_logic += (size_t)xcc * LOGIC_SLOTS;
+    }
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        if (r >= n) {
+            const uint32_t* cols = &m.pc;
+#pragma unroll
+            for (int c = 0; c < LOGIC_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            continue;
+        }
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
+        const uint64_t cycle = q[OFF_CYCLE / 8];
+        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
+        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
+        const uint64_t rs2_av = q[OFF_RS2 / 8], rs2_prev = q[OFF_RS2 / 8 + 1];
+        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
+        const uint32_t rs1_addr = (uint32_t)rs1_av, rs1_val = (uint32_t)(rs1_av >> 32);
+        const uint32_t rs2_addr = (uint32_t)rs2_av, rs2_val = (uint32_t)(rs2_av >> 32);
+        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
+        const uint64_t ts = cycle - offset;
+        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
+        put(m.pc, pc);
+        put(m.ts, ts);
+        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), p2 = aligned_prev_ts(rs2_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
+        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), d2 = lt_diff(p2, ts + SUBCYCLE_RS2), dd = lt_diff(pd, ts + SUBCYCLE_RD);
+        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
+        put(m.rs1_prev_ts, p1);
+        put(m.rs1_lt_diff[0], d1 & 0xffff);
+        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
+        put(m.rs2_id, ((rs2_addr << 2) >> 8) & 0xff);
+        put(m.rs2_prev_ts, p2);
+        put(m.rs2_lt_diff[0], d2 & 0xffff);
+        put(m.rs2_lt_diff[1], (d2 >> 16) & 0xffff);
+        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
+        put(m.rd_prev_ts, pd);
+        put(m.rd_prev_val[0], rd_before & 0xffff);
+        put(m.rd_prev_val[1], rd_before >> 16);
+        put(m.rd_lt_diff[0], dd & 0xffff);
+        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            put(m.rs1_bytes[b], (rs1_val >> (8 * b)) & 0xff);
+            put(m.rs2_bytes[b], (rs2_val >> (8 * b)) & 0xff);
+            put(m.rd_bytes[b], (rd_after >> (8 * b)) & 0xff);
+        }
+        if (lk_fetch) {
+            const uint32_t slot = (pc - fetch_base) >> 2;
+            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
+        }
+        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d2 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d2 >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
+#pragma unroll
+        for (int b = 0; b < 4; b++) lk_count<XCD_LOCAL>(lk_logic, ((rs1_val >> (8 * b)) & 0xff) | (((rs2_val >> (8 * b)) & 0xff) << 8));
+    }
+}
+
+int witgen_logic(ceno_hip_ctx* ctx, const LogicMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic,
+                 ceno_hip_stream s) {
+    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
+    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
+    CHECK_ARG(ctx, map->num_cols >= (uint32_t)LOGIC_COLS, "witgen: the logic chips have 28 mapped columns");
+    const uint32_t* cols = &map->pc;
+    uint64_t seen[4] = {0, 0, 0, 0};
+    for (int c = 0; c < LOGIC_COLS; c++) {
+        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
+        if (cols[c] < 256) {
+            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
+            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+        }
+    }
+    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    if (xcd_local && (lk_dyn || lk_fetch || lk_logic) && n > 0) {
+        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0,
+                     l_slots = lk_logic ? LOGIC_SLOTS : 0;
+        void* scratch = nullptr;
+        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), &scratch));
+        uint32_t* c_dyn = (uint32_t*)scratch;
+        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
+        uint32_t* c_logic = c_fetch + 8 * f_slots;
+        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_witgen_logic<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
+                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr, lk_logic ? c_logic : nullptr);
+            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
+            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
+            if (lk_logic) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((l_slots + NT - 1) / NT)), dim3(NT), 0, st, c_logic, l_slots, lk_logic);
+            e = hipGetLastError();
+        }
+        const hipError_t e2 = hipStreamSynchronize(st);
+        ctx_free(ctx, scratch);
+        HIP_TRY(ctx, e);
+        HIP_TRY(ctx, e2);
+        return 0;
+    }
+    hipLaunchKernelGGL((k_witgen_logic<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
+                       lk_dyn, lk_fetch, lk_logic);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
                  uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
@@ -217,6 +350,17 @@ int ceno_hip_witgen_sub(ceno_hip_ctx* ctx, const ceno_hip_sub_column_map* map, c
     CHECK_ARG(ctx, ctx, "NULL context");
     return witgen_arith(ctx, reinterpret_cast<const Map*>(map), true, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                         fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_logic_r(ceno_hip_ctx* ctx, const ceno_hip_logic_r_column_map* map, int logic_kind, const void* dev_step_records,
+                            size_t num_records, const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                            uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                            uint32_t* dev_lk_fetch, uint32_t* dev_lk_logic, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    // the witness does not depend on the operation (rd comes from the step record); the kind only names the table dev_lk_logic counts
+    CHECK_ARG(ctx, logic_kind >= 0 && logic_kind <= 2, "witgen_logic_r: kind %d is not AND (0) / OR (1) / XOR (2)", logic_kind);
+    return witgen_logic(ctx, reinterpret_cast<const LogicMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_logic, s);
 }
 
 }  // extern "C"

@@ -792,6 +792,31 @@ def witgen_arith(cols, is_sub: bool, records: np.ndarray, indices, shard_offset:
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_XOR, INSN_OR, INSN_AND = 3, 4, 5  # InsnKind discriminants (rv32im.rs:168-175)
+LOGIC_COLMAP_FIELDS = 29                # 28 column ids in LogicRColumnMap order + num_cols
+
+
+def witgen_logic_r(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of an AND / OR / XOR chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts, the op's 2^16 table counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (LOGIC_COLMAP_FIELDS,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[28])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    lkl = np.zeros(1 << 16, dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_logic_r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.orc_witgen_logic_r.restype = C.c_int
+    rc = L.orc_witgen_logic_r(cols.ctypes.data, recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                              out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data, lkl.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_logic_r rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots], lkl
+
+
 # ---- multi-layer GKR (control flow restated; arithmetic by the functions above) -----------------------------------
 LAYER_ZEROCHECK, LAYER_LINEAR, LAYER_SUMCHECK = 0, 1, 2
 

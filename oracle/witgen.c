@@ -1,6 +1,6 @@
 /*
  * ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference's witness assignment for the R-type
- * arithmetic chips ADD / SUB, one instance at a time, in the order the reference's CPU path does it:
+ * chips ADD / SUB (and, at the end of the file, AND / OR / XOR), one instance at a time, in the order the reference's CPU path does it:
  *   ArithInstruction::assign_instance        ceno_zkvm/src/instructions/riscv/arith.rs:101-142
  *   RInstructionConfig::assign_instance      ceno_zkvm/src/instructions/riscv/r_insn.rs:67-86
  *   StateInOut / ReadRS1 / ReadRS2 / WriteRD ceno_zkvm/src/instructions/riscv/insn_base.rs:61-77,112-145,223-257,337-400
@@ -131,6 +131,54 @@ int orc_witgen_arith(const uint32_t* cols, int is_sub, const void* records, cons
             carry = s >> 16;
             lk_dyn(lk_dynamic, s & 0xffff, 16);
             row[cols[20 + l]] = carry;
+        }
+    }
+    return 0;
+}
+
+/* LogicInstruction::assign_instance (ceno_zkvm/src/instructions/riscv/logic/logic_circuit.rs:66-79,137-159): UInt8::logic_assign
+ * counts one entry of the operation's table per byte pair (uint/logic.rs:26-32, key a | b << 8: gkr_iop/src/tables/mod.rs:29-31),
+ * then the R-instruction base (r_insn.rs:67-86) and the bytes of rs1, rs2 and rd.value.after (split_to_u8).
+ * cols[29]: LogicRColumnMap field order (chips/logic_r.rs:25-42), num_cols last.  lk_logic: 2^16 counters of the op's table or NULL. */
+int orc_witgen_logic_r(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                       uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_logic) {
+    const uint32_t num_cols = cols[28];
+    for (int c = 0; c < 28; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rs2 || !st->has_rd) return -2;
+        for (int b = 0; b < 4; b++) {
+            const uint32_t x = (st->rs1.value >> (8 * b)) & 0xff, y = (st->rs2.value >> (8 * b)) & 0xff;
+            if (lk_logic) lk_logic[x | (y << 8)] += 1;
+        }
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rs2.addr);
+        row[cols[7]] = p;
+        assign_lt(row, cols + 8, lk_dynamic, p, ts + 1);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[10]] = register_index(st->rd.addr);
+        row[cols[11]] = p;
+        row[cols[12]] = st->rd.before & 0xffff;
+        row[cols[13]] = st->rd.before >> 16;
+        assign_lt(row, cols + 14, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        for (int b = 0; b < 4; b++) {
+            row[cols[16 + b]] = (st->rs1.value >> (8 * b)) & 0xff;
+            row[cols[20 + b]] = (st->rs2.value >> (8 * b)) & 0xff;
+            row[cols[24 + b]] = (st->rd.after >> (8 * b)) & 0xff;
         }
     }
     return 0;

@@ -130,3 +130,79 @@ def test_bad_arguments_fail_loudly(dev):
         _run(dev, list(range(22)) + [21], False, recs, np.arange(8), 8, 0, 0x1000, 8)
     with pytest.raises(CenoHipError):
         _run(dev, wc.NATURAL_COLS, False, recs, np.arange(8), 4, 0, 0x1000, 8)
+
+
+def _run_logic(dev, cols, kind, recs, idx, rows, offset, base_pc, slots, lk=True):
+    import torch
+
+    from ceno_amd import api
+
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(np.asarray(idx, dtype=np.uint32).view(np.int32))
+    num_cols = int(cols[28])
+    w = torch.full((num_cols * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(max(slots, 1), dtype=torch.int32, device="cuda:0")
+    lkl = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+    api.witgen_logic_r(dev, cols, kind, d_recs.data_ptr(), recs.shape[0], d_idx.data_ptr(), len(idx), w.data_ptr(), rows, offset, base_pc, slots,
+                       lkd.data_ptr() if lk else 0, lkf.data_ptr() if lk else 0, lkl.data_ptr() if lk else 0)
+    dev.sync()
+    return (w.cpu().numpy().view(np.uint64).reshape(num_cols, rows), lkd.cpu().numpy().view(np.uint32), lkf.cpu().numpy().view(np.uint32)[:slots],
+            lkl.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1000, 1024), (1, 2)])
+def test_logic_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
+    """AND / OR / XOR on the reference test's step data (chips/logic_r.rs:85-118,140-170): GPU column-major witness == CPU row-major
+    witness, the dynamic-range, fetch and operation-table multiplicities equal"""
+    d = wc.reference_logic_steps(n, kind)
+    recs = po.step_records_r(d["cycles"], d["pcs"], (po.INSN_AND, po.INSN_OR, po.INSN_XOR)[kind], 2, 3, 4, d["rs1_vals"], d["rs2_vals"],
+                             d["rd_before"], d["rd_after"], d["prev_cycles"])
+    idx = np.arange(n)
+    got, lkd, lkf, lkl = _run_logic(dev, wc.LOGIC_NATURAL_COLS, kind, recs, idx, rows, 0, 0x1000, n)
+    exp, elkd, elkf, elkl = po.witgen_logic_r(wc.LOGIC_NATURAL_COLS, recs, idx, 0, 0x1000, n)
+    assert np.array_equal(got[:, :n], exp.T)
+    assert not got[:, n:].any()
+    assert np.array_equal(lkd, elkd) and np.array_equal(lkf, elkf) and np.array_equal(lkl, elkl)
+
+
+def test_logic_permuted_columns_subset_of_steps_and_shard_offset(dev):
+    rng = np.random.default_rng(11)
+    n_steps = 5000
+    d = wc.reference_logic_steps(n_steps, 2)
+    d["rs1_vals"] = rng.integers(0, 1 << 32, n_steps, dtype=np.uint64)
+    d["rs2_vals"] = rng.integers(0, 1 << 32, n_steps, dtype=np.uint64)
+    d["rd_before"] = rng.integers(0, 1 << 32, n_steps, dtype=np.uint64)
+    d["rd_after"] = d["rs1_vals"] ^ d["rs2_vals"]
+    offset = 1 << 20
+    d["cycles"] = d["cycles"] + offset
+    d["prev_cycles"] = rng.integers(0, 1 << 21, n_steps, dtype=np.uint64)
+    d["prev_cycles"][::5] = 0
+    recs = po.step_records_r(d["cycles"], d["pcs"], po.INSN_XOR, 7, 31, 0, d["rs1_vals"], d["rs2_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    cols = list(rng.permutation(40)[:28]) + [40]
+    idx = rng.permutation(n_steps)[:3000]
+    got, lkd, lkf, lkl = _run_logic(dev, cols, 2, recs, idx, 4096, offset, 0x1000, n_steps)
+    exp, elkd, elkf, elkl = po.witgen_logic_r(cols, recs, idx, offset, 0x1000, n_steps)
+    mapped = sorted(cols[:28])
+    assert np.array_equal(got[mapped, :3000], exp.T[mapped]) and not got[mapped, 3000:].any()
+    unmapped = [c for c in range(40) if c not in mapped]
+    assert np.all(got[unmapped] == np.uint64(0xFFFFFFFFFFFFFFFF))  # columns outside the map are the caller's: left untouched
+    assert np.array_equal(lkd, elkd) and np.array_equal(lkf, elkf) and np.array_equal(lkl, elkl)
+    got2, _, _, _ = _run_logic(dev, cols, 2, recs, idx, 4096, offset, 0x1000, n_steps, lk=False)
+    assert np.array_equal(got2, got)
+
+
+def test_logic_bad_arguments_fail_loudly(dev):
+    from ceno_amd import CenoHipError
+
+    d = wc.reference_logic_steps(8)
+    recs = po.step_records_r(d["cycles"], d["pcs"], po.INSN_AND, 2, 3, 4, d["rs1_vals"], d["rs2_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    dup = list(range(28)) + [28]
+    dup[20] = dup[3]
+    with pytest.raises(CenoHipError):
+        _run_logic(dev, dup, 0, recs, np.arange(8), 8, 0, 0x1000, 8)
+    with pytest.raises(CenoHipError):
+        _run_logic(dev, list(range(28)) + [27], 0, recs, np.arange(8), 8, 0, 0x1000, 8)
+    with pytest.raises(CenoHipError):
+        _run_logic(dev, wc.LOGIC_NATURAL_COLS, 3, recs, np.arange(8), 8, 0, 0x1000, 8)

@@ -82,3 +82,53 @@ def test_bad_column_map_is_rejected():
     cols = list(range(22)) + [21]
     with pytest.raises(ValueError):
         po.witgen_arith(cols, False, recs, np.arange(4))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("offset,prev", [(0, 0), (400, 402), (400, 900)])
+def test_logic_oracle_matches_python_model(kind, offset, prev):
+    """AND / OR / XOR (logic_circuit.rs:66-160): 28 columns, four byte-pair lookups into the operation's table per instance"""
+    n = 300
+    d = wc.reference_logic_steps(n, kind)
+    d["cycles"] = d["cycles"] + offset + 1000
+    d["prev_cycles"][:] = prev
+    d["prev_cycles"][::7] = 0
+    recs = _records(d, (po.INSN_AND, po.INSN_OR, po.INSN_XOR)[kind])
+    rng = np.random.default_rng(6)
+    cols = list(rng.permutation(34)[:28]) + [34]
+    idx = rng.permutation(n)[:250]
+    base_pc, slots = 0x1000, n
+    got, lkd, lkf, lkl = po.witgen_logic_r(cols, recs, idx, offset, base_pc, slots)
+    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
+    for r, i in enumerate(idx):
+        row, lk = wc.model_logic_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 3, 4, int(d["rs1_vals"][i]), int(d["rs2_vals"][i]),
+                                     int(d["rd_before"][i]), int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
+        assert len(row) == 28
+        for c, v in row.items():
+            assert int(got[r, c]) == v, (r, c)
+        assert not got[r, [c for c in range(34) if c not in row]].any()
+        for t, k in lk:
+            if t == "dyn":
+                exp_dyn[k] += 1
+            elif t == "logic":
+                exp_logic[k] += 1
+            else:
+                exp_fetch[(k - base_pc) // 4] += 1
+    assert np.array_equal(lkd, exp_dyn) and np.array_equal(lkf, exp_fetch) and np.array_equal(lkl, exp_logic)
+    assert int(lkd.sum()) == 6 * len(idx) and int(lkl.sum()) == 4 * len(idx)
+
+
+def test_logic_columns_satisfy_the_chip_constraints():
+    """the byte columns recompose the registers and (rs1 byte, rs2 byte, rd byte) is a row of the operation's table"""
+    n = 1024
+    for kind in (0, 1, 2):
+        d = wc.reference_logic_steps(n, kind)
+        recs = _records(d, (po.INSN_AND, po.INSN_OR, po.INSN_XOR)[kind])
+        m, _, _, lkl = po.witgen_logic_r(wc.LOGIC_NATURAL_COLS, recs, np.arange(n), 0, 0x1000, n)
+        m = m.astype(np.int64)
+        for base, reg in ((16, d["rs1_vals"]), (20, d["rs2_vals"]), (24, d["rd_after"])):
+            assert np.array_equal(sum(m[:, base + b] << (8 * b) for b in range(4)), reg.astype(np.int64))
+        for b in range(4):
+            assert np.array_equal(wc.LOGIC_OPS[kind](m[:, 16 + b], m[:, 20 + b]), m[:, 24 + b])
+        keys = np.concatenate([m[:, 16 + b] | (m[:, 20 + b] << 8) for b in range(4)])
+        assert np.array_equal(np.bincount(keys, minlength=1 << 16).astype(np.uint32), lkl)

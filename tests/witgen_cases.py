@@ -65,3 +65,34 @@ def model_row(cols, sub, cycle, pc, rs1, rs2, rd, v1, v2, rd_before, rd_after, p
     res = s & 0xFFFFFFFF
     lk += [("dyn", (1 << 16) + (res & 0xFFFF)), ("dyn", (1 << 16) + (res >> 16))]
     return row, lk
+
+
+# ---- AND / OR / XOR (chips/logic_r.rs:85-118): eight edge cases, then (0xDEAD0000 | i, 0x00FFFF00 | i << 8) ----
+LOGIC_EDGE_CASES = [(0, 0), (0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0), (0, 0xFFFFFFFF), (0xAAAAAAAA, 0x55555555), (0xFFFF0000, 0x0000FFFF),
+                    (0xDEADBEEF, 0xFFFFFFFF), (0x12345678, 0)]
+LOGIC_NATURAL_COLS = list(range(28)) + [28]
+LOGIC_OPS = {0: lambda a, b: a & b, 1: lambda a, b: a | b, 2: lambda a, b: a ^ b}
+
+
+def reference_logic_steps(n, kind=0):
+    i = np.arange(n, dtype=np.uint64)
+    a = (np.uint64(0xDEAD0000) | i) & np.uint64(0xFFFFFFFF)
+    b = (np.uint64(0x00FFFF00) | (i << np.uint64(8))) & np.uint64(0xFFFFFFFF)
+    for k, (x, y) in enumerate(LOGIC_EDGE_CASES[:n]):
+        a[k], b[k] = x, y
+    return dict(cycles=4 + 4 * i, pcs=0x1000 + 4 * i, rs1_vals=a, rs2_vals=b, rd_before=i % 200, rd_after=LOGIC_OPS[kind](a, b),
+                prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def model_logic_row(cols, cycle, pc, rs1, rs2, rd, v1, v2, rd_before, rd_after, prev, offset):
+    """one row of a logic chip as {column id: value} plus its (table, key) lookups, from the circuit's constraints: the R-instruction
+    base of model_row and the byte decompositions; the table key of byte pair (a, b) is a | b << 8"""
+    base, lk = model_row(list(cols[:16]) + [10 ** 6 + k for k in range(6)] + [cols[28]], False, cycle, pc, rs1, rs2, rd, 0, 0, rd_before, rd_after, prev, offset)
+    row = {c: v for c, v in base.items() if c in set(cols[:16])}
+    lk = [x for x in lk[:7]]  # fetch + the six timestamp-difference limbs (the arithmetic chips' own lookups follow them)
+    for b in range(4):
+        row[cols[16 + b]] = (v1 >> (8 * b)) & 0xFF
+        row[cols[20 + b]] = (v2 >> (8 * b)) & 0xFF
+        row[cols[24 + b]] = (rd_after >> (8 * b)) & 0xFF
+        lk.append(("logic", ((v1 >> (8 * b)) & 0xFF) | (((v2 >> (8 * b)) & 0xFF) << 8)))
+    return row, lk
