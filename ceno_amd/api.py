@@ -341,6 +341,23 @@ def witgen_arith(dev: Device, cols, is_sub: bool, records_ptr: int, num_records:
                 stream))
 
 
+class AddiColumnMap(C.Structure):
+    """ceno_hip_addi_column_map: 18 column ids + num_cols"""
+    _fields_ = [("cols", C.c_uint32 * 18), ("num_cols", C.c_uint32)]
+
+
+def witgen_addi(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_addi (GpuWitgenKind::Addi): `cols` = the 18 column ids in AddiColumnMap field order followed by num_cols"""
+    m = AddiColumnMap()
+    for k in range(18):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[18])
+    dev.check(dev.L.ceno_hip_witgen_addi(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
+                                         fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
+                                         C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 class LogicRColumnMap(C.Structure):
     """ceno_hip_logic_r_column_map: 28 column ids + num_cols"""
     _fields_ = [("cols", C.c_uint32 * 28), ("num_cols", C.c_uint32)]

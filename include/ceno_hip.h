@@ -354,7 +354,7 @@ int ceno_hip_basefold_query_rounds(ceno_hip_ctx* ctx, const uint64_t* const* dev
 int ceno_hip_pow_grind_duplex(ceno_hip_ctx* ctx, const uint64_t* state16, int bits, uint64_t* out_witness, ceno_hip_stream s);
 
 /* ------------------------------------------------------------------------------------------------
- * on-device witness generation for the R-type chips: ADD / SUB, then AND / OR / XOR
+ * on-device witness generation: the R-type chips ADD / SUB, then ADDI and AND / OR / XOR
  *   reference: hal.witgen.witgen_add / witgen_sub as called from ceno_zkvm/src/instructions/gpu/dispatch.rs:509-571
  *   (column maps: instructions/gpu/chips/add.rs:15-47, chips/sub.rs:15-46; CPU assignment being reproduced:
  *   instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,112-145,223-257,337-400,
@@ -398,6 +398,20 @@ int ceno_hip_witgen_sub(ceno_hip_ctx* ctx, const ceno_hip_sub_column_map* map, c
                         uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
                         uint32_t* dev_lk_fetch, ceno_hip_stream s);
 
+/* I-type ADDI: hal.witgen.witgen_addi (dispatch.rs GpuWitgenKind::Addi; column map chips/addi.rs:12-43; CPU assignment
+ * arith_imm/arith_imm_circuit_v2.rs:85-117 + i_insn.rs:66-82): rs1 + sign_extend(imm) = rd with the witnessed carries; `imm` = the low
+ * 16 bits of the instruction's immediate (StepRecord.insn.imm), `imm_sign` = 1 when it is negative.  18 mapped columns. */
+typedef struct ceno_hip_addi_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, rd_carries[2];
+    uint32_t num_cols;
+} ceno_hip_addi_column_map;
+int ceno_hip_witgen_addi(ceno_hip_ctx* ctx, const ceno_hip_addi_column_map* map, const void* dev_step_records, size_t num_records,
+                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                         uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
+                         uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* R-type logic chips AND / OR / XOR: hal.witgen.witgen_logic_r (dispatch.rs:574-611; column map chips/logic_r.rs:12-43; CPU
  * assignment logic_circuit.rs:66-160: the R-instruction base as above, the three registers as four bytes each).  logic_kind =
  * 0 AND, 1 OR, 2 XOR as in GpuWitgenKind::LogicR.  dev_lk_logic (may be NULL): the 2^16 counters of THAT operation's table

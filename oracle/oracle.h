@@ -238,6 +238,11 @@ int orc_witgen_arith(const uint32_t* cols, int is_sub, const void* records, cons
 /* AND / OR / XOR (logic_circuit.rs:66-160): cols[29] in LogicRColumnMap order; lk_logic = the 2^16 counters of the op's table */
 int orc_witgen_logic_r(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                        uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_logic);
+/* ADDI (arith_imm_circuit_v2.rs:85-117): cols[19] in AddiColumnMap order; orc_step_record_i = StepRecord::new_i_instruction */
+void orc_step_record_i(void* out, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rd, int32_t imm, uint32_t rs1_val,
+                       uint32_t rd_before, uint32_t rd_after, uint64_t prev_cycle);
+int orc_witgen_addi(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
 
 #ifdef __cplusplus
 }

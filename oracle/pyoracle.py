@@ -792,6 +792,43 @@ def witgen_arith(cols, is_sub: bool, records: np.ndarray, indices, shard_offset:
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_ADDI = 11  # InsnKind::ADDI
+ADDI_COLMAP_FIELDS = 19  # 18 column ids in AddiColumnMap order + num_cols
+
+
+def step_records_i(cycles, pcs, kind, rs1, rd, imms, rs1_vals, rd_before, rd_after, prev_cycles) -> np.ndarray:
+    """StepRecord::new_i_instruction for every entry -> (n, 136) uint8 array"""
+    n = len(cycles)
+    out = np.zeros((n, lib().orc_step_record_bytes()), dtype=np.uint8)
+    L = lib()
+    L.orc_step_record_i.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_uint64]
+    L.orc_step_record_i.restype = None
+    for i in range(n):
+        L.orc_step_record_i(out[i].ctypes.data, int(cycles[i]), int(pcs[i]), kind, rs1, rd, int(imms[i]), int(rs1_vals[i]), int(rd_before[i]),
+                            int(rd_after[i]), int(prev_cycles[i]))
+    return out
+
+
+def witgen_addi(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the ADDI chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (ADDI_COLMAP_FIELDS,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[18])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_addi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_witgen_addi.restype = C.c_int
+    rc = L.orc_witgen_addi(cols.ctypes.data, recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                           out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_addi rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_XOR, INSN_OR, INSN_AND = 3, 4, 5  # InsnKind discriminants (rv32im.rs:168-175)
 LOGIC_COLMAP_FIELDS = 29                # 28 column ids in LogicRColumnMap order + num_cols
 

@@ -183,3 +183,69 @@ int orc_witgen_logic_r(const uint32_t* cols, const void* records, const uint32_t
     }
     return 0;
 }
+
+/* StepRecord::new_i_instruction (ceno_emul/src/tracer.rs:1210-1230): rs1 read, rd written, no rs2; the immediate travels in insn.imm */
+void orc_step_record_i(void* out, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rd, int32_t imm, uint32_t rs1_val,
+                       uint32_t rd_before, uint32_t rd_after, uint64_t prev_cycle) {
+    orc_step_record r;
+    memset(&r, 0, sizeof(r));
+    r.cycle = cycle;
+    r.pc_before = pc;
+    r.pc_after = pc + 4;
+    r.kind = kind; r.rs1_idx = rs1; r.rs2_idx = 0; r.rd_idx = rd;
+    r.imm = imm;
+    r.has_rs1 = r.has_rd = 1;
+    r.rs1.addr = ((uint32_t)rs1 << 8) / 4; r.rs1.value = rs1_val; r.rs1.previous_cycle = prev_cycle;
+    r.rd.addr = ((uint32_t)rd << 8) / 4; r.rd.before = rd_before; r.rd.after = rd_after; r.rd.previous_cycle = prev_cycle;
+    r.syscall_index = 0xFFFFFFFFu;
+    memcpy(out, &r, sizeof(r));
+}
+
+/* AddiInstruction::assign_instance (arith_imm/arith_imm_circuit_v2.rs:85-117): imm = insn.imm as i16 as u16, imm_sign = its sign,
+ * rs1 + [imm, sign ? 0xffff : 0] with overflow (every result limb range-checked: uint.rs:762-785), then the I-instruction base
+ * (i_insn.rs:66-82: state, rs1, rd, fetch).  cols[19]: AddiColumnMap field order (chips/addi.rs:27-42), num_cols last. */
+int orc_witgen_addi(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[18];
+    for (int c = 0; c < 18; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint32_t x = st->rs1.value;
+        const uint16_t imm = (uint16_t)(int16_t)st->imm;
+        const int negative = (int16_t)st->imm < 0;
+        row[cols[14]] = imm;
+        row[cols[15]] = negative ? 1 : 0;
+        const uint32_t ext[2] = {imm, negative ? 0xffffu : 0u};
+        row[cols[12]] = x & 0xffff;
+        row[cols[13]] = x >> 16;
+        uint32_t carry = 0;
+        for (int l = 0; l < 2; l++) {
+            const uint32_t s = ((x >> (16 * l)) & 0xffff) + ext[l] + carry;
+            carry = s >> 16;
+            lk_dyn(lk_dynamic, s & 0xffff, 16);
+            row[cols[16 + l]] = carry;
+        }
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rd.addr);
+        row[cols[7]] = p;
+        row[cols[8]] = st->rd.before & 0xffff;
+        row[cols[9]] = st->rd.before >> 16;
+        assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+    }
+    return 0;
+}

@@ -206,3 +206,56 @@ def test_logic_bad_arguments_fail_loudly(dev):
         _run_logic(dev, list(range(28)) + [27], 0, recs, np.arange(8), 8, 0, 0x1000, 8)
     with pytest.raises(CenoHipError):
         _run_logic(dev, wc.LOGIC_NATURAL_COLS, 3, recs, np.arange(8), 8, 0, 0x1000, 8)
+
+
+def _run_addi(dev, cols, recs, idx, rows, offset, base_pc, slots, lk=True):
+    import torch
+
+    from ceno_amd import api
+
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(np.asarray(idx, dtype=np.uint32).view(np.int32))
+    num_cols = int(cols[18])
+    w = torch.full((num_cols * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(max(slots, 1), dtype=torch.int32, device="cuda:0")
+    api.witgen_addi(dev, cols, d_recs.data_ptr(), recs.shape[0], d_idx.data_ptr(), len(idx), w.data_ptr(), rows, offset, base_pc, slots,
+                    lkd.data_ptr() if lk else 0, lkf.data_ptr() if lk else 0)
+    dev.sync()
+    return w.cpu().numpy().view(np.uint64).reshape(num_cols, rows), lkd.cpu().numpy().view(np.uint32), lkf.cpu().numpy().view(np.uint32)[:slots]
+
+
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1000, 1024), (1, 2), (2100, 4096)])
+def test_addi_witness_and_lookups_match_cpu_assignment(dev, n, rows):
+    """ADDI on the reference test's step data (chips/addi.rs:80-97,115-146): positive and negative immediates"""
+    d = wc.reference_addi_steps(n)
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_ADDI, 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    idx = np.arange(n)
+    got, lkd, lkf = _run_addi(dev, wc.ADDI_NATURAL_COLS, recs, idx, rows, 0, 0x1000, n)
+    exp, elkd, elkf = po.witgen_addi(wc.ADDI_NATURAL_COLS, recs, idx, 0, 0x1000, n)
+    assert np.array_equal(got[:, :n], exp.T) and not got[:, n:].any()
+    assert np.array_equal(lkd, elkd) and np.array_equal(lkf, elkf)
+
+
+def test_addi_permuted_columns_random_operands_and_shard_offset(dev):
+    rng = np.random.default_rng(12)
+    n_steps = 5000
+    d = wc.reference_addi_steps(n_steps)
+    d["rs1_vals"] = rng.integers(0, 1 << 32, n_steps, dtype=np.uint64)
+    d["imms"] = rng.integers(-2048, 2048, n_steps, dtype=np.int64)
+    d["rd_before"] = rng.integers(0, 1 << 32, n_steps, dtype=np.uint64)
+    d["rd_after"] = ((d["rs1_vals"].astype(np.int64) + d["imms"]) & 0xFFFFFFFF).astype(np.uint64)
+    offset = 1 << 20
+    d["cycles"] = d["cycles"] + offset
+    d["prev_cycles"] = rng.integers(0, 1 << 21, n_steps, dtype=np.uint64)
+    d["prev_cycles"][::5] = 0
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_ADDI, 9, 17, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    cols = list(rng.permutation(30)[:18]) + [30]
+    idx = rng.permutation(n_steps)[:3000]
+    got, lkd, lkf = _run_addi(dev, cols, recs, idx, 4096, offset, 0x1000, n_steps)
+    exp, elkd, elkf = po.witgen_addi(cols, recs, idx, offset, 0x1000, n_steps)
+    mapped = sorted(cols[:18])
+    assert np.array_equal(got[mapped, :3000], exp.T[mapped]) and not got[mapped, 3000:].any()
+    assert np.array_equal(lkd, elkd) and np.array_equal(lkf, elkf)
+    with pytest.raises(Exception):
+        _run_addi(dev, list(range(18)) + [17], recs, idx, 4096, offset, 0x1000, n_steps)

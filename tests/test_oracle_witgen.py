@@ -132,3 +132,43 @@ def test_logic_columns_satisfy_the_chip_constraints():
             assert np.array_equal(wc.LOGIC_OPS[kind](m[:, 16 + b], m[:, 20 + b]), m[:, 24 + b])
         keys = np.concatenate([m[:, 16 + b] | (m[:, 20 + b] << 8) for b in range(4)])
         assert np.array_equal(np.bincount(keys, minlength=1 << 16).astype(np.uint32), lkl)
+
+
+@pytest.mark.parametrize("offset,prev", [(0, 0), (400, 402), (400, 900)])
+def test_addi_oracle_matches_python_model(offset, prev):
+    """ADDI (arith_imm_circuit_v2.rs:85-117): 18 columns; negative immediates, carries out of both limbs"""
+    n = 2100
+    d = wc.reference_addi_steps(n)
+    d["rs1_vals"][:6] = [0, 0xFFFFFFFF, 0xFFFF, 0x10000, 0x7FFFFFFF, 0x80000000]
+    d["imms"][:6] = [-1, 1, 1, -1, 2047, -2048]
+    d["rd_after"] = ((d["rs1_vals"].astype(np.int64) + d["imms"]) & 0xFFFFFFFF).astype(np.uint64)
+    d["cycles"] = d["cycles"] + offset + 1000
+    d["prev_cycles"][:] = prev
+    d["prev_cycles"][::7] = 0
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_ADDI, 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(8)
+    cols = list(rng.permutation(25)[:18]) + [25]
+    idx = np.concatenate([np.arange(6), 6 + rng.permutation(n - 6)[:400]])
+    base_pc, slots = 0x1000, n
+    got, lkd, lkf = po.witgen_addi(cols, recs, idx, offset, base_pc, slots)
+    exp_dyn, exp_fetch = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
+    for r, i in enumerate(idx):
+        row, lk = wc.model_addi_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 4, int(d["rs1_vals"][i]), int(d["imms"][i]), int(d["rd_before"][i]),
+                                    int(d["prev_cycles"][i]), offset)
+        assert len(row) == 18
+        for c, v in row.items():
+            assert int(got[r, c]) == v, (r, c)
+        assert not got[r, [c for c in range(25) if c not in row]].any()
+        for t, k in lk:
+            if t == "dyn":
+                exp_dyn[k] += 1
+            else:
+                exp_fetch[(k - base_pc) // 4] += 1
+    assert np.array_equal(lkd, exp_dyn) and np.array_equal(lkf, exp_fetch)
+    # the witnessed carries prove rs1 + sign_extend(imm) = rd
+    m = got.astype(np.int64)
+    c = {k: cols[k] for k in range(18)}
+    rd = d["rd_after"][idx].astype(np.int64)
+    ext_hi = m[:, c[15]] * 0xFFFF
+    assert np.array_equal(m[:, c[12]] + m[:, c[14]], (rd & 0xFFFF) + (m[:, c[16]] << 16))
+    assert np.array_equal(m[:, c[13]] + ext_hi + m[:, c[16]], (rd >> 16) + (m[:, c[17]] << 16))

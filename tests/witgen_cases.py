@@ -96,3 +96,50 @@ def model_logic_row(cols, cycle, pc, rs1, rs2, rd, v1, v2, rd_before, rd_after, 
         row[cols[24 + b]] = (rd_after >> (8 * b)) & 0xFF
         lk.append(("logic", ((v1 >> (8 * b)) & 0xFF) | (((v2 >> (8 * b)) & 0xFF) << 8)))
     return row, lk
+
+
+# ---- ADDI (chips/addi.rs:80-97): rs1 = 137 i + 1, imm = i % 2048 - 1024, rd_before = i % 200 ----
+ADDI_NATURAL_COLS = list(range(18)) + [18]
+
+
+def reference_addi_steps(n):
+    i = np.arange(n, dtype=np.int64)
+    rs1 = ((i * 137 + 1) & 0xFFFFFFFF).astype(np.uint64)
+    imm = (i % 2048 - 1024).astype(np.int64)
+    rd_after = ((rs1.astype(np.int64) + imm) & 0xFFFFFFFF).astype(np.uint64)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=rs1, imms=imm, rd_before=(i % 200).astype(np.uint64),
+                rd_after=rd_after, prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def model_addi_row(cols, cycle, pc, rs1, rd, v1, imm, rd_before, prev, offset):
+    """one ADDI row as {column id: value} plus its lookups, from the constraints: rs1 + sign_extend(imm16) = rd with limb carries"""
+    row, lk = {}, [("fetch", pc)]
+    ts = cycle - offset
+    row[cols[0]], row[cols[1]] = pc, ts
+
+    def access(base, reg, sub_cycle, extra=()):
+        p = max(prev - offset, 0)
+        p = 0 if p < 4 else p
+        rhs = ts + sub_cycle
+        diff = p - rhs + ((1 << 29) if p < rhs else 0)
+        row[cols[base]], row[cols[base + 1]] = reg, p
+        k = base + 2
+        for e in extra:
+            row[cols[k]] = e
+            k += 1
+        row[cols[k]], row[cols[k + 1]] = diff & 0xFFFF, diff >> 16
+        lk.append(("dyn", (1 << 16) + (diff & 0xFFFF)))
+        lk.append(("dyn", (1 << 13) + (diff >> 16)))
+
+    access(2, rs1, 0)
+    access(6, rd, 2, extra=(rd_before & 0xFFFF, rd_before >> 16))
+    imm16 = imm & 0xFFFF
+    neg = 1 if imm16 & 0x8000 else 0
+    ext = (0xFFFF0000 if neg else 0) | imm16
+    row[cols[12]], row[cols[13]], row[cols[14]], row[cols[15]] = v1 & 0xFFFF, v1 >> 16, imm16, neg
+    c0 = ((v1 & 0xFFFF) + imm16) >> 16
+    c1 = (v1 + ext) >> 32
+    row[cols[16]], row[cols[17]] = c0, c1
+    res = (v1 + ext) & 0xFFFFFFFF
+    lk += [("dyn", (1 << 16) + (res & 0xFFFF)), ("dyn", (1 << 16) + (res >> 16))]
+    return row, lk
