@@ -106,4 +106,17 @@ row("witgen_add 2^20 instances (22 columns + lookup counts)",
 row("witgen_add 2^20 instances, witness only",
     timed(lambda: api.witgen_arith(dev, wcols, False, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w.data_ptr(), n_w, 0, 0x2000, 4096)),
     (136 + 4 + 8 * 22) * n_w)
+d_w28 = torch.empty(28 * n_w, dtype=torch.int64, device="cuda:0")
+d_lkl = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+lcols = list(range(28)) + [28]
+row("witgen_logic_r (XOR) 2^20 instances (28 columns + lookup counts: 6 range, fetch, 4 byte-table)",
+    timed(lambda: api.witgen_logic_r(dev, lcols, 2, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w28.data_ptr(), n_w, 0, 0x2000, 4096,
+                                     d_lkd.data_ptr(), d_lkf.data_ptr(), d_lkl.data_ptr())), (136 + 4 + 8 * 28) * n_w)
+row("witgen_logic_r 2^20 instances, witness only",
+    timed(lambda: api.witgen_logic_r(dev, lcols, 2, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w28.data_ptr(), n_w, 0, 0x2000, 4096)),
+    (136 + 4 + 8 * 28) * n_w)
+acols = list(range(18)) + [18]
+row("witgen_addi 2^20 instances (18 columns + lookup counts)",
+    timed(lambda: api.witgen_addi(dev, acols, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w.data_ptr(), n_w, 0, 0x2000, 4096,
+                                  d_lkd.data_ptr(), d_lkf.data_ptr())), (136 + 4 + 8 * 18) * n_w)
 print(json.dumps(out, indent=1))
