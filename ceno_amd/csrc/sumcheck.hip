@@ -710,6 +710,19 @@ __global__ void k_finish_evals(const MleSlot* __restrict__ slots, int n, E2 r, E
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host + i), "v"(w) : "memory");
 }
 
+// tables of a class as extension elements into pinned host memory (armed with MSG_INVALID): the host takes the sumcheck over from here
+__global__ void __launch_bounds__(NT) k_export_tables(const MleSlot* __restrict__ slots, int n_mles, int len, E2* __restrict__ out_host) {
+    const int total = n_mles * len;
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < total; idx += gridDim.x * NT) {
+        const int m = idx / len, j = idx - m * len;
+        const MleSlot sl = slots[m];
+        const E2 v = sl.in_ext ? ld_e2(sl.in + 2 * (size_t)j) : E2{sl.in[j], 0};
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host + idx), "v"(w) : "memory");
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side state
 // ------------------------------------------------------------------------------------------------
@@ -1780,13 +1793,13 @@ static int host_take_over(ceno_hip_sumcheck* sc) {
     sc->host_len = sc->host_len0;
     return 0;
 }
-static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out) {
+static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out, bool fold = true) {
     static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     timespec ta, tb, tc;
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
     TRY(host_take_over(sc));
     if (dbg) clock_gettime(CLOCK_MONOTONIC, &tb);
-    host_fold(sc, r);
+    if (fold) host_fold(sc, r);
     const ScClass& cl = sc->classes[0];
     const int d = sc->d, pairs = sc->host_len / 2;
     E2 acc[MAXD];
@@ -2034,6 +2047,29 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         return 0;
     }
 
+    // ---- 0b. a single-class sumcheck driven round by round (no persistent kernels): once the remaining rounds are worth more on
+    // the host than a launch and a wait each (host_tail_rounds), the live tables are shipped to pinned memory ONCE and every
+    // further round — and the final evaluations — is the host's.  (The opening's height groups: ~18 us per device round.) ----
+    if (sc->host_from < 0 && h_out && !d_out && sc->h_tail && sc->classes.size() == 1 && sc->classes[0].nv == sc->n && i >= sc->n - sc->host_ht) {
+        ScClass& cl = sc->classes[0];
+        const MleSlot* d_slots = nullptr;
+        size_t cur = 0;
+        TRY(sc_push_slots(sc, cl, i, cur, &d_slots));
+        const int len = 1 << (i == 0 ? sc->n : sc->n - i + 1);  // the tables message i - 1 was computed on (round 0: the inputs)
+        const int total = (int)cl.mles.size() * len;
+        hipLaunchKernelGGL(k_export_tables, dim3((unsigned)std::min((total + NT - 1) / NT, 64)), dim3(NT), 0, sc->st, d_slots, (int)cl.mles.size(), len,
+                           sc->d_tail_view);
+        HIP_TRY(ctx, hipGetLastError());
+        sc->host_from = i;
+        sc->host_len0 = len;
+        sc->host_len = 0;
+    }
+    if (sc->host_from >= 0) {
+        if (d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: the host has taken this sumcheck over; device-output rounds cannot follow");
+        TRY(sc_host_round(sc, r, h_out, i > 0));
+        sc->round++;
+        return 0;
+    }
     // ---- 1. classes that are (or just become) scalars: update tails / bind their last variable ----
     ScClass* became_scalar = nullptr;
     for (auto& cl : sc->classes) {
@@ -2245,7 +2281,7 @@ int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uin
         CHECK_ARG(ctx, last_challenge2, "last challenge is NULL");
         const E2 r{last_challenge2[0], last_challenge2[1]};
         size_t h_cursor = 0;
-        if (sc->pipelined && sc->host_from >= 0) {
+        if (sc->host_from >= 0) {
             // host-finished tail: the last fold happens here
             ScClass& cl = sc->classes[0];
             TRY(host_take_over(sc));
@@ -2316,6 +2352,7 @@ int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_in
     CHECK_ARG(ctx, sc && device_ptr && is_ext && num_vars, "NULL argument");
     CHECK_ARG(ctx, mle_index >= 0 && mle_index < (int)sc->mles.size(), "mle index out of range");
     if (sc->pipelined) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "tables of a pipelined sumcheck are not observable between rounds");
+    if (sc->host_from >= 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "the host has taken this sumcheck over: its tables are no longer on the device");
     const ScMle& M = sc->mles[mle_index];
     // after r rounds the live table is the one round r-1 was computed on: nv - (r - 1) variables (r >= 1), nv before round 0
     const int folds = sc->round > 0 ? sc->round - 1 : 0;
