@@ -243,6 +243,9 @@ void orc_step_record_i(void* out, uint64_t cycle, uint32_t pc, uint8_t kind, uin
                        uint32_t rd_before, uint32_t rd_after, uint64_t prev_cycle);
 int orc_witgen_addi(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                     uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* ANDI / ORI / XORI (logic_imm_circuit_v2.rs:105-130,195-224): cols[25] in LogicIColumnMap order */
+int orc_witgen_logic_i(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                       uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_logic);
 
 #ifdef __cplusplus
 }

@@ -249,3 +249,55 @@ int orc_witgen_addi(const uint32_t* cols, const void* records, const uint32_t* i
     }
     return 0;
 }
+
+/* LogicInstruction (imm) ::assign_instance (logic_imm/logic_imm_circuit_v2.rs:105-130) and LogicConfig::assign_instance (:195-224):
+ * imm_lo = imm_internal(insn).0 as u32 & 0xffff, imm_hi = (imm_signed_internal(insn).0 as u32 >> 16) & 0xffff with
+ * imm_internal = imm as i16 as i64 and imm_signed_internal = (imm >> 16) as i16 as i64 for ANDI / ORI / XORI (tables/program.rs:115,140-143);
+ * logic_assign over the two bytes of (rs1_lo, imm_lo) and of (rs1_hi, imm_hi); then the I-instruction base and the byte columns.
+ * cols[25]: LogicIColumnMap field order (chips/logic_i.rs:26-41), num_cols last. */
+int orc_witgen_logic_i(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                       uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_logic) {
+    const uint32_t num_cols = cols[24];
+    for (int c = 0; c < 24; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint32_t rs1_lo = st->rs1.value & 0xffff, rs1_hi = (st->rs1.value >> 16) & 0xffff;
+        const uint32_t imm_internal = (uint32_t)(int64_t)(int16_t)st->imm;          /* imm as i16 as i64, then as u32 */
+        const uint32_t imm_signed = (uint32_t)(int64_t)(int16_t)(st->imm >> 16);    /* (imm >> LIMB_BITS) as i16 as i64, then as u32 */
+        const uint32_t imm_lo = imm_internal & 0xffff, imm_hi = (imm_signed >> 16) & 0xffff;
+        for (int b = 0; b < 2; b++)
+            if (lk_logic) lk_logic[((rs1_lo >> (8 * b)) & 0xff) | (((imm_lo >> (8 * b)) & 0xff) << 8)] += 1;
+        for (int b = 0; b < 2; b++)
+            if (lk_logic) lk_logic[((rs1_hi >> (8 * b)) & 0xff) | (((imm_hi >> (8 * b)) & 0xff) << 8)] += 1;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rd.addr);
+        row[cols[7]] = p;
+        row[cols[8]] = st->rd.before & 0xffff;
+        row[cols[9]] = st->rd.before >> 16;
+        assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        for (int b = 0; b < 4; b++) {
+            row[cols[12 + b]] = (st->rs1.value >> (8 * b)) & 0xff;
+            row[cols[16 + b]] = (st->rd.after >> (8 * b)) & 0xff;
+        }
+        row[cols[20]] = imm_internal & 0xff;          /* split_to_u8(imm_internal as u32)[..2] */
+        row[cols[21]] = (imm_internal >> 8) & 0xff;
+        row[cols[22]] = (imm_signed >> 16) & 0xff;    /* split_to_u8(imm_signed_internal as u32)[2..] */
+        row[cols[23]] = imm_signed >> 24;
+    }
+    return 0;
+}

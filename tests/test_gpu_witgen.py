@@ -259,3 +259,36 @@ def test_addi_permuted_columns_random_operands_and_shard_offset(dev):
     assert np.array_equal(lkd, elkd) and np.array_equal(lkf, elkf)
     with pytest.raises(Exception):
         _run_addi(dev, list(range(18)) + [17], recs, idx, 4096, offset, 0x1000, n_steps)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (600, 1024)])
+def test_logic_i_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
+    """ANDI / ORI / XORI on the reference test's step data (chips/logic_i.rs:79-100) plus sign-extended negative immediates"""
+    import torch
+
+    from ceno_amd import api
+
+    d = wc.reference_logic_i_steps(n, kind)
+    d["imms"][n // 2:] = -(d["imms"][n // 2:] % 2048) - 1
+    d["rd_after"] = wc.LOGIC_OPS[kind](d["rs1_vals"], d["imms"].astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    recs = po.step_records_i(d["cycles"], d["pcs"], (po.INSN_ANDI, po.INSN_ORI, po.INSN_XORI)[kind], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"],
+                             d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(13)
+    cols = list(rng.permutation(30)[:24]) + [30]
+    idx = np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full((30 * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    lkl = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+    api.witgen_logic_i(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr(),
+                       lkl.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(30, rows)
+    exp, elkd, elkf, elkl = po.witgen_logic_i(cols, recs, idx, 0, 0x1000, n)
+    mapped = sorted(cols[:24])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+    assert np.array_equal(lkl.cpu().numpy().view(np.uint32), elkl)

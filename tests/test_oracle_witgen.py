@@ -172,3 +172,42 @@ def test_addi_oracle_matches_python_model(offset, prev):
     ext_hi = m[:, c[15]] * 0xFFFF
     assert np.array_equal(m[:, c[12]] + m[:, c[14]], (rd & 0xFFFF) + (m[:, c[16]] << 16))
     assert np.array_equal(m[:, c[13]] + ext_hi + m[:, c[16]], (rd >> 16) + (m[:, c[17]] << 16))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("offset,prev", [(0, 0), (400, 900)])
+def test_logic_i_oracle_matches_python_model(kind, offset, prev):
+    """ANDI / ORI / XORI (logic_imm_circuit_v2.rs:105-130,195-224): 24 columns; raw 12-bit immediates as in the reference's test and
+    sign-extended negative ones as the decoder produces them"""
+    n = 600
+    d = wc.reference_logic_i_steps(n, kind)
+    d["imms"][300:] = -(d["imms"][300:] % 2048) - 1      # negative immediates: high half 0xffff
+    d["rd_after"] = wc.LOGIC_OPS[kind](d["rs1_vals"], d["imms"].astype(np.uint64) & np.uint64(0xFFFFFFFF))
+    d["cycles"] = d["cycles"] + offset + 1000
+    d["prev_cycles"][:] = prev
+    recs = po.step_records_i(d["cycles"], d["pcs"], (po.INSN_ANDI, po.INSN_ORI, po.INSN_XORI)[kind], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"],
+                             d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(10)
+    cols = list(rng.permutation(31)[:24]) + [31]
+    idx = rng.permutation(n)[:500]
+    base_pc, slots = 0x1000, n
+    got, lkd, lkf, lkl = po.witgen_logic_i(cols, recs, idx, offset, base_pc, slots)
+    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
+    for r, i in enumerate(idx):
+        row, lk = wc.model_logic_i_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 4, int(d["rs1_vals"][i]), int(d["imms"][i]), int(d["rd_before"][i]),
+                                       int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
+        assert len(row) == 24
+        for c, v in row.items():
+            assert int(got[r, c]) == v, (r, c)
+        for t, k in lk:
+            if t == "dyn":
+                exp_dyn[k] += 1
+            elif t == "logic":
+                exp_logic[k] += 1
+            else:
+                exp_fetch[(k - base_pc) // 4] += 1
+    assert np.array_equal(lkd, exp_dyn) and np.array_equal(lkf, exp_fetch) and np.array_equal(lkl, exp_logic)
+    # (rs1 byte, imm byte, rd byte) is a row of the operation's table
+    m = got.astype(np.int64)
+    for b in range(4):
+        assert np.array_equal(wc.LOGIC_OPS[kind](m[:, cols[12 + b]], m[:, cols[20 + b]]), m[:, cols[16 + b]])

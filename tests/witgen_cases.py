@@ -143,3 +143,34 @@ def model_addi_row(cols, cycle, pc, rs1, rd, v1, imm, rd_before, prev, offset):
     res = (v1 + ext) & 0xFFFFFFFF
     lk += [("dyn", (1 << 16) + (res & 0xFFFF)), ("dyn", (1 << 16) + (res >> 16))]
     return row, lk
+
+
+# ---- ANDI / ORI / XORI (chips/logic_i.rs:79-100): edge cases, then (i * 0x01010101 ^ 0xabed5eff, i % 4096) ----
+LOGIC_I_EDGE_CASES = [(0, 0), (0xFFFFFFFF, 0xFFF), (0xFFFFFFFF, 0), (0, 0xFFF), (0xAAAAAAAA, 0x555), (0xFFFF0000, 0xFFF), (0x12345678, 0), (0xDEADBEEF, 0xABC)]
+LOGIC_I_NATURAL_COLS = list(range(24)) + [24]
+
+
+def reference_logic_i_steps(n, kind=0):
+    i = np.arange(n, dtype=np.uint64)
+    a = ((i * np.uint64(0x01010101)) & np.uint64(0xFFFFFFFF)) ^ np.uint64(0xABED5EFF)
+    imm = (i % 4096).astype(np.int64)
+    for k, (x, y) in enumerate(LOGIC_I_EDGE_CASES[:n]):
+        a[k], imm[k] = x, y
+    return dict(cycles=4 + 4 * i, pcs=0x1000 + 4 * i, rs1_vals=a, imms=imm, rd_before=i % 200,
+                rd_after=LOGIC_OPS[kind](a, imm.astype(np.uint64) & np.uint64(0xFFFFFFFF)), prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def model_logic_i_row(cols, cycle, pc, rs1, rd, v1, imm, rd_before, rd_after, prev, offset):
+    """one ANDI / ORI / XORI row: the I-instruction base of model_addi_row, byte columns, and the immediate as the circuit sees it: low
+    half as is, high half 0xffff exactly when the (sign-extended, 32-bit) immediate is negative"""
+    base, lk = model_addi_row(list(cols[:12]) + [10 ** 6 + k for k in range(6)] + [cols[24]], cycle, pc, rs1, rd, 0, 0, rd_before, prev, offset)
+    row = {c: v for c, v in base.items() if c < 10 ** 6}
+    lk = lk[:5]  # fetch + four timestamp-difference limbs
+    imm32 = imm & 0xFFFFFFFF
+    eff = (imm32 & 0xFFFF) | (0xFFFF0000 if imm32 >> 31 else 0)
+    for b in range(4):
+        row[cols[12 + b]] = (v1 >> (8 * b)) & 0xFF
+        row[cols[16 + b]] = (rd_after >> (8 * b)) & 0xFF
+        row[cols[20 + b]] = (eff >> (8 * b)) & 0xFF
+        lk.append(("logic", ((v1 >> (8 * b)) & 0xFF) | (((eff >> (8 * b)) & 0xFF) << 8)))
+    return row, lk
