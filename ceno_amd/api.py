@@ -358,6 +358,23 @@ def witgen_addi(dev: Device, cols, records_ptr: int, num_records: int, indices_p
                                          C.c_void_p(lk_fetch_ptr or None), stream))
 
 
+class LuiColumnMap(C.Structure):
+    """ceno_hip_lui_column_map: 16 column ids + num_cols"""
+    _fields_ = [("cols", C.c_uint32 * 16), ("num_cols", C.c_uint32)]
+
+
+def witgen_lui(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_lui (GpuWitgenKind::Lui): `cols` = the 16 column ids in LuiColumnMap field order followed by num_cols"""
+    m = LuiColumnMap()
+    for k in range(16):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[16])
+    dev.check(dev.L.ceno_hip_witgen_lui(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
+                                        fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
+                                        C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 class LogicIColumnMap(C.Structure):
     """ceno_hip_logic_i_column_map: 24 column ids + num_cols"""
     _fields_ = [("cols", C.c_uint32 * 24), ("num_cols", C.c_uint32)]

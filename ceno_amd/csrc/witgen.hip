@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI (I-type).
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI (I-type base).
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -537,6 +537,123 @@ int witgen_logic_i(ceno_hip_ctx* ctx, const LogicIMap* map, const void* recs, si
     return 0;
 }
 
+// ---- LUI (LuiInstruction, ceno_zkvm/src/instructions/riscv/lui.rs:100-120): the I-instruction base (rs1 is read as decoded: x0), bytes 1..3 of
+// rd (byte 0 is zero by construction), each range-checked as a byte of the dynamic table (assert_ux::<8>), and imm = insn.imm as u32 >> 12
+// (InsnRecord::imm_internal, U type: tables/program.rs:126-129).  16 mapped columns.
+struct LuiMap {  // ceno_hip_lui_column_map = ceno_gpu's LuiColumnMap (chips/lui.rs:29-41)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[3], imm;
+    uint32_t num_cols;
+};
+static_assert(sizeof(LuiMap) == sizeof(ceno_hip_lui_column_map), "column map layout");
+constexpr int LUI_COLS = 16;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_lui(LuiMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                   uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                   uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    if (XCD_LOCAL) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
+        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
+    }
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        if (r >= n) {
+            const uint32_t* cols = &m.pc;
+#pragma unroll
+            for (int c = 0; c < LUI_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            continue;
+        }
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
+        const uint64_t cycle = q[OFF_CYCLE / 8];
+        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
+        const uint32_t imm32 = (uint32_t)(q[OFF_IMM / 8] >> 32);
+        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
+        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
+        const uint32_t rs1_addr = (uint32_t)rs1_av;
+        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
+        const uint64_t ts = cycle - offset;
+        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
+        put(m.pc, pc);
+        put(m.ts, ts);
+        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
+        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), dd = lt_diff(pd, ts + SUBCYCLE_RD);
+        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
+        put(m.rs1_prev_ts, p1);
+        put(m.rs1_lt_diff[0], d1 & 0xffff);
+        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
+        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
+        put(m.rd_prev_ts, pd);
+        put(m.rd_prev_val[0], rd_before & 0xffff);
+        put(m.rd_prev_val[1], rd_before >> 16);
+        put(m.rd_lt_diff[0], dd & 0xffff);
+        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
+        put(m.imm, imm32 >> 12);
+        if (lk_fetch) {
+            const uint32_t slot = (pc - fetch_base) >> 2;
+            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
+        }
+        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16), U8 = 1u << 8;
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
+#pragma unroll
+        for (int b = 1; b < 4; b++) {
+            const uint32_t v = (rd_after >> (8 * b)) & 0xff;
+            put(m.rd_bytes[b - 1], v);
+            lk_count<XCD_LOCAL>(lk_dyn, U8 + v);
+        }
+    }
+}
+
+int witgen_lui(ceno_hip_ctx* ctx, const LuiMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+               uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
+    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
+    CHECK_ARG(ctx, map->num_cols >= (uint32_t)LUI_COLS, "witgen: the LUI chip has 16 mapped columns");
+    const uint32_t* cols = &map->pc;
+    uint64_t seen[4] = {0, 0, 0, 0};
+    for (int c = 0; c < LUI_COLS; c++) {
+        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
+        if (cols[c] < 256) {
+            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
+            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+        }
+    }
+    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    if (xcd_local && (lk_dyn || lk_fetch) && n > 0) {
+        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0;
+        void* scratch = nullptr;
+        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), &scratch));
+        uint32_t* c_dyn = (uint32_t*)scratch;
+        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
+        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((k_witgen_lui<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
+                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
+            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
+            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
+            e = hipGetLastError();
+        }
+        const hipError_t e2 = hipStreamSynchronize(st);
+        ctx_free(ctx, scratch);
+        HIP_TRY(ctx, e);
+        HIP_TRY(ctx, e2);
+        return 0;
+    }
+    hipLaunchKernelGGL((k_witgen_lui<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
+                       lk_dyn, lk_fetch);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
+
 int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
                  uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
@@ -613,6 +730,14 @@ int ceno_hip_witgen_addi(ceno_hip_ctx* ctx, const ceno_hip_addi_column_map* map,
     CHECK_ARG(ctx, ctx, "NULL context");
     return witgen_addi(ctx, reinterpret_cast<const AddiMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_lui(ctx, reinterpret_cast<const LuiMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                      fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_logic_i(ceno_hip_ctx* ctx, const ceno_hip_logic_i_column_map* map, int logic_kind, const void* dev_step_records,

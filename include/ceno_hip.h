@@ -412,6 +412,18 @@ int ceno_hip_witgen_addi(ceno_hip_ctx* ctx, const ceno_hip_addi_column_map* map,
                          const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
                          uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
                          uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
+ * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
+typedef struct ceno_hip_lui_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[3], imm;
+    uint32_t num_cols;
+} ceno_hip_lui_column_map;
+int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* I-type logic chips ANDI / ORI / XORI: hal.witgen.witgen_logic_i (dispatch.rs:612-650; column map chips/logic_i.rs:10-42; CPU assignment
  * logic_imm/logic_imm_circuit_v2.rs:105-130,195-224).  logic_kind = 0 ANDI, 1 ORI, 2 XORI (GpuWitgenKind::LogicI); dev_lk_logic as for
  * the R-type chips, key rs1_byte | imm_byte << 8 with the immediate's high half = its sign spread over 16 bits.  24 mapped columns. */

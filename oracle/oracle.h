@@ -246,6 +246,9 @@ int orc_witgen_addi(const uint32_t* cols, const void* records, const uint32_t* i
 /* ANDI / ORI / XORI (logic_imm_circuit_v2.rs:105-130,195-224): cols[25] in LogicIColumnMap order */
 int orc_witgen_logic_i(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                        uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_logic);
+/* LUI (riscv/lui.rs:100-120): cols[17] in LuiColumnMap order */
+int orc_witgen_lui(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
 
 #ifdef __cplusplus
 }

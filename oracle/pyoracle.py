@@ -829,6 +829,29 @@ def witgen_addi(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_LUI = 42  # InsnKind::LUI (u16limb_circuit feature: after LHU = 41)
+LUI_COLMAP_FIELDS = 17
+
+
+def witgen_lui(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the LUI chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (LUI_COLMAP_FIELDS,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[16])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_lui.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_witgen_lui.restype = C.c_int
+    rc = L.orc_witgen_lui(cols.ctypes.data, recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                          out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_lui rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_XORI, INSN_ORI, INSN_ANDI = 12, 13, 14  # InsnKind discriminants
 LOGIC_I_COLMAP_FIELDS = 25                   # 24 column ids in LogicIColumnMap order + num_cols
 

@@ -301,3 +301,43 @@ int orc_witgen_logic_i(const uint32_t* cols, const void* records, const uint32_t
     }
     return 0;
 }
+
+/* LuiInstruction::assign_instance (riscv/lui.rs:100-120): the I-instruction base, then bytes 1..3 of rd.value.after — each
+ * assert_ux::<8> (LookupTable::Dynamic key 2^8 + v) — and imm = imm_internal(insn).0 = insn.imm as u32 >> 12 (U type).
+ * cols[17]: LuiColumnMap field order (chips/lui.rs:29-41), num_cols last. */
+int orc_witgen_lui(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[16];
+    for (int c = 0; c < 16; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rd.addr);
+        row[cols[7]] = p;
+        row[cols[8]] = st->rd.before & 0xffff;
+        row[cols[9]] = st->rd.before >> 16;
+        assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        for (int b = 1; b < 4; b++) {
+            const uint32_t v = (st->rd.after >> (8 * b)) & 0xff;
+            lk_dyn(lk_dynamic, v, 8);
+            row[cols[12 + (b - 1)]] = v;
+        }
+        row[cols[15]] = (uint32_t)st->imm >> 12;
+    }
+    return 0;
+}

@@ -292,3 +292,30 @@ def test_logic_i_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
     assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
     assert np.array_equal(lkl.cpu().numpy().view(np.uint32), elkl)
+
+
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (500, 512)])
+def test_lui_witness_and_lookups_match_cpu_assignment(dev, n, rows):
+    """LUI on step data shaped like the reference's test (chips/lui.rs:79-97), immediates over the whole 20-bit range"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _lui_steps
+
+    d = _lui_steps(n)
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_LUI, 0, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(15)
+    cols = list(rng.permutation(22)[:16]) + [22]
+    idx = np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full((22 * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_lui(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(22, rows)
+    exp, elkd, elkf = po.witgen_lui(cols, recs, idx, 0, 0x1000, n)
+    mapped = sorted(cols[:16])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)

@@ -211,3 +211,39 @@ def test_logic_i_oracle_matches_python_model(kind, offset, prev):
     m = got.astype(np.int64)
     for b in range(4):
         assert np.array_equal(wc.LOGIC_OPS[kind](m[:, cols[12 + b]], m[:, cols[20 + b]]), m[:, cols[16 + b]])
+
+
+def _lui_steps(n):
+    """chips/lui.rs:79-97: imm = (i % 2^20) << 12, rd = imm, rs1 = x0 reading 0"""
+    i = np.arange(n, dtype=np.int64)
+    imm = ((i * 4099 + 7) % (1 << 20)) << 12          # spread over the 20-bit range, bit 31 set for half of them
+    edge = [0, 1 << 12, 0xFFFFF << 12, 0x80000 << 12]
+    imm[:min(n, 4)] = edge[:min(n, 4)]
+    imm_i32 = ((imm + (1 << 31)) % (1 << 32)) - (1 << 31)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), imms=imm_i32, rs1_vals=np.zeros(n, dtype=np.uint64),
+                rd_before=(i % 200).astype(np.uint64), rd_after=imm.astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def test_lui_oracle_rows_and_lookups():
+    """LUI (riscv/lui.rs:100-120): rd bytes 1..3 recompose imm << 4 (the circuit's own constraint), each a byte lookup of the dynamic table"""
+    n = 500
+    d = _lui_steps(n)
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_LUI, 0, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(14)
+    cols = list(rng.permutation(20)[:16]) + [20]
+    idx = np.arange(n)
+    got, lkd, lkf = po.witgen_lui(cols, recs, idx, 0, 0x1000, n)
+    m = got.astype(np.int64)
+    imm20 = (d["rd_after"] >> np.uint64(12)).astype(np.int64)
+    assert np.array_equal(m[:, cols[15]], imm20)
+    assert np.array_equal(m[:, cols[12]] + (m[:, cols[13]] << 8) + (m[:, cols[14]] << 16), imm20 << 4)   # require_equal in construct_circuit
+    assert np.all(m[:, cols[2]] == 0) and np.all(m[:, cols[6]] == 4) and np.array_equal(m[:, cols[0]], d["pcs"].astype(np.int64))
+    for base, diff0, sub_cycle in ((3, 4, 0), (7, 10, 2)):
+        assert np.array_equal(m[:, cols[base]] - (m[:, cols[1]] + sub_cycle), m[:, cols[diff0]] + (m[:, cols[diff0 + 1]] << 16) - (1 << 29))
+    exp = np.zeros(1 << 17, dtype=np.int64)
+    for b in (12, 13, 14):
+        np.add.at(exp, (1 << 8) + m[:, cols[b]], 1)
+    for d0 in (4, 10):
+        np.add.at(exp, (1 << 16) + m[:, cols[d0]], 1)
+        np.add.at(exp, (1 << 13) + m[:, cols[d0 + 1]], 1)
+    assert np.array_equal(lkd.astype(np.int64), exp) and np.all(lkf == 1)
