@@ -150,6 +150,130 @@ __global__ void __launch_bounds__(NT) k_witgen_arith(Map m, const unsigned char*
     }
 }
 
+// ---- pieces every chip shares (the new chips below are written with them; k_witgen_arith above keeps its hand-scheduled body) ----
+struct Row {  // one instance's row of the column-major witness
+    uint64_t* w;
+    size_t rows, r;
+    __device__ __forceinline__ void put(uint32_t col, uint64_t v) const { w[(size_t)col * rows + r] = v; }
+};
+struct Step {  // the fields of a StepRecord the chips read
+    uint64_t cycle, rs1_prev, rs2_prev, rd_prev;
+    uint32_t pc, imm, rs1_addr, rs1_val, rs2_addr, rs2_val, rd_addr, rd_before, rd_after;
+};
+__device__ __forceinline__ Step load_step(const unsigned char* recs, uint32_t index) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)index * CENO_HIP_STEP_RECORD_BYTES);
+    Step s;
+    s.cycle = q[OFF_CYCLE / 8];
+    s.pc = (uint32_t)q[OFF_PC_BEFORE / 8];
+    s.imm = (uint32_t)(q[4] >> 32);  // Instruction { kind u8, rs1 u8, rs2 u8, rd u8, imm i32, raw u32 } at byte 32: imm = bytes 36..39 (rv32im.rs:115-128)
+    const uint64_t rs1_av = q[OFF_RS1 / 8], rs2_av = q[OFF_RS2 / 8], rd_ab = q[OFF_RD / 8];
+    s.rs1_prev = q[OFF_RS1 / 8 + 1];
+    s.rs2_prev = q[OFF_RS2 / 8 + 1];
+    s.rd_prev = q[OFF_RD / 8 + 2];
+    s.rs1_addr = (uint32_t)rs1_av;
+    s.rs1_val = (uint32_t)(rs1_av >> 32);
+    s.rs2_addr = (uint32_t)rs2_av;
+    s.rs2_val = (uint32_t)(rs2_av >> 32);
+    s.rd_addr = (uint32_t)rd_ab;
+    s.rd_before = (uint32_t)(rd_ab >> 32);
+    s.rd_after = (uint32_t)q[OFF_RD / 8 + 1];
+    return s;
+}
+// this wave's copy of a per-XCD table (s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits))
+template <bool XCD_LOCAL>
+__device__ __forceinline__ uint32_t* xcd_copy(uint32_t* table, size_t slots) {
+    if (!XCD_LOCAL || !table) return table;
+    return table + (size_t)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u) * slots;
+}
+// ReadRS1 / ReadRS2 (insn_base.rs:112-145,223-257): register id, aligned previous timestamp, AssertLt(prev_ts < ts + sub_cycle) limbs
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void emit_read(const Row& o, uint32_t id_col, uint32_t prev_col, const uint32_t (&diff_cols)[2], uint32_t addr,
+                                          uint64_t prev_cycle, uint64_t offset, uint64_t ts_sub, uint32_t* lk_dyn) {
+    const uint64_t p = aligned_prev_ts(prev_cycle, offset), d = lt_diff(p, ts_sub);
+    o.put(id_col, ((addr << 2) >> 8) & 0xff);  // register index = (word address * 4) >> 8 as u8 (platform.rs:120-128, tracer.rs:656-658)
+    o.put(prev_col, p);
+    o.put(diff_cols[0], d & 0xffff);
+    o.put(diff_cols[1], (d >> 16) & 0xffff);
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(d & 0xffff));
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << (MAX_TS_BITS - 16)) + (uint32_t)((d >> 16) & 0xffff));
+}
+// WriteRD (insn_base.rs:337-400): as a read, plus the previous value as two u16 limbs
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void emit_write(const Row& o, uint32_t id_col, uint32_t prev_col, const uint32_t (&prev_val_cols)[2],
+                                           const uint32_t (&diff_cols)[2], uint32_t addr, uint32_t before, uint64_t prev_cycle, uint64_t offset,
+                                           uint64_t ts_sub, uint32_t* lk_dyn) {
+    o.put(prev_val_cols[0], before & 0xffff);
+    o.put(prev_val_cols[1], before >> 16);
+    emit_read<XCD_LOCAL>(o, id_col, prev_col, diff_cols, addr, prev_cycle, offset, ts_sub, lk_dyn);
+}
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void emit_fetch(uint32_t* lk_fetch, uint32_t pc, uint32_t fetch_base, uint32_t fetch_slots) {
+    if (!lk_fetch) return;
+    const uint32_t slot = (pc - fetch_base) >> 2;
+    if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
+}
+template <int N_COLS>
+__device__ __forceinline__ void zero_row(const Row& o, const uint32_t* cols) {  // padding rows: every mapped column is zero
+#pragma unroll
+    for (int c = 0; c < N_COLS; c++) o.put(cols[c], 0);
+}
+
+// ---- host side shared by every chip --------------------------------------------------------------------------------------------
+int witgen_check(ceno_hip_ctx* ctx, const uint32_t* cols, int n_cols, uint32_t num_cols, const void* recs, size_t num_records, const uint32_t* idx,
+                 size_t n, const uint64_t* w, size_t rows, const uint32_t* lk_fetch, uint32_t fetch_slots) {
+    CHECK_ARG(ctx, cols && w && rows > 0 && n <= rows, "bad witgen arguments");
+    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
+    CHECK_ARG(ctx, num_cols >= (uint32_t)n_cols, "witgen: this chip has %d mapped columns", n_cols);
+    uint64_t seen[4] = {0, 0, 0, 0};
+    for (int c = 0; c < n_cols; c++) {
+        CHECK_ARG(ctx, cols[c] < num_cols, "witgen: column id out of range");
+        if (cols[c] < 256) {
+            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
+            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+        }
+    }
+    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
+    return 0;
+}
+// The lookup counts go through per-XCD copies of the tables (zeroed scratch, L2-local atomics, one merge per table) unless
+// CENO_HIP_WITGEN_XCD=0; `launch(xcd_local, t0, t1, t2)` starts the chip's kernel on the tables it is given.  With tables the call
+// synchronises the stream (the scratch goes back to the pool only after the stream has consumed it).
+struct LkTab {
+    uint32_t* user;
+    size_t slots;
+};
+template <class Launch>
+int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[3], Launch&& launch) {
+    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    const bool any = tabs[0].user || tabs[1].user || tabs[2].user;
+    if (!(xcd_local && any && n > 0)) {
+        launch(false, tabs[0].user, tabs[1].user, tabs[2].user);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    }
+    size_t slots[3], total = 0;
+    for (int t = 0; t < 3; t++) total += slots[t] = tabs[t].user ? tabs[t].slots : 0;
+    void* scratch = nullptr;
+    TRY(ctx_alloc(ctx, 8 * total * sizeof(uint32_t), &scratch));
+    uint32_t* copy[3];
+    copy[0] = (uint32_t*)scratch;
+    copy[1] = copy[0] + 8 * slots[0];
+    copy[2] = copy[1] + 8 * slots[1];
+    hipError_t e = hipMemsetAsync(scratch, 0, 8 * total * sizeof(uint32_t), st);
+    if (e == hipSuccess) {
+        launch(true, tabs[0].user ? copy[0] : nullptr, tabs[1].user ? copy[1] : nullptr, tabs[2].user ? copy[2] : nullptr);
+        for (int t = 0; t < 3; t++)
+            if (tabs[t].user) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((slots[t] + NT - 1) / NT)), dim3(NT), 0, st, copy[t], slots[t], tabs[t].user);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    ctx_free(ctx, scratch);
+    HIP_TRY(ctx, e);
+    HIP_TRY(ctx, e2);
+    return 0;
+}
+constexpr size_t LOGIC_SLOTS = (size_t)1 << 16;
+
 // ---- R-type logic chips AND / OR / XOR (LogicInstruction, ceno_zkvm/src/instructions/riscv/logic/logic_circuit.rs:30-160): the same
 // R-instruction base (state, rs1, rs2, rd: r_insn.rs:67-86) and then the three registers as 4 BYTES each (UInt8, split_to_u8);
 // lookups: fetch, the six timestamp-difference limbs, and one entry of the op's 2^16-entry table per byte pair, key a | b << 8
@@ -164,130 +288,44 @@ struct LogicMap {  // ceno_hip_logic_r_column_map = ceno_gpu's LogicRColumnMap (
 };
 static_assert(sizeof(LogicMap) == sizeof(ceno_hip_logic_r_column_map), "column map layout");
 constexpr int LOGIC_COLS = 28;
-constexpr size_t LOGIC_SLOTS = (size_t)1 << 16;
 
 template <bool XCD_LOCAL>
 __global__ void __launch_bounds__(NT) k_witgen_logic(LogicMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
                                                      uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w,
                                                      size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic) {
-    if (XCD_LOCAL) {
-        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
-        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
-        if (lk_logic) lk_logic += (size_t)xcc * LOGIC_SLOTS;
-    }
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    lk_logic = xcd_copy<XCD_LOCAL>(lk_logic, LOGIC_SLOTS);
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
         if (r >= n) {
-            const uint32_t* cols = &m.pc;
-#pragma unroll
-            for (int c = 0; c < LOGIC_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            zero_row<LOGIC_COLS>(o, &m.pc);
             continue;
         }
-        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
-        const uint64_t cycle = q[OFF_CYCLE / 8];
-        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
-        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
-        const uint64_t rs2_av = q[OFF_RS2 / 8], rs2_prev = q[OFF_RS2 / 8 + 1];
-        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
-        const uint32_t rs1_addr = (uint32_t)rs1_av, rs1_val = (uint32_t)(rs1_av >> 32);
-        const uint32_t rs2_addr = (uint32_t)rs2_av, rs2_val = (uint32_t)(rs2_av >> 32);
-        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
-        const uint64_t ts = cycle - offset;
-        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
-        put(m.pc, pc);
-        put(m.ts, ts);
-        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), p2 = aligned_prev_ts(rs2_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
-        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), d2 = lt_diff(p2, ts + SUBCYCLE_RS2), dd = lt_diff(pd, ts + SUBCYCLE_RD);
-        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
-        put(m.rs1_prev_ts, p1);
-        put(m.rs1_lt_diff[0], d1 & 0xffff);
-        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
-        put(m.rs2_id, ((rs2_addr << 2) >> 8) & 0xff);
-        put(m.rs2_prev_ts, p2);
-        put(m.rs2_lt_diff[0], d2 & 0xffff);
-        put(m.rs2_lt_diff[1], (d2 >> 16) & 0xffff);
-        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
-        put(m.rd_prev_ts, pd);
-        put(m.rd_prev_val[0], rd_before & 0xffff);
-        put(m.rd_prev_val[1], rd_before >> 16);
-        put(m.rd_lt_diff[0], dd & 0xffff);
-        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            put(m.rs1_bytes[b], (rs1_val >> (8 * b)) & 0xff);
-            put(m.rs2_bytes[b], (rs2_val >> (8 * b)) & 0xff);
-            put(m.rd_bytes[b], (rd_after >> (8 * b)) & 0xff);
-        }
-        if (lk_fetch) {
-            const uint32_t slot = (pc - fetch_base) >> 2;
-            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
-        }
-        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d2 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d2 >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
-#pragma unroll
-        for (int b = 0; b < 4; b++) lk_count<XCD_LOCAL>(lk_logic, ((rs1_val >> (8 * b)) & 0xff) | (((rs2_val >> (8 * b)) & 0xff) << 8));
-    }
-}
-
-int witgen_logic(ceno_hip_ctx* ctx, const LogicMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
-                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic,
-                 ceno_hip_stream s) {
-    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
-    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
-    CHECK_ARG(ctx, map->num_cols >= (uint32_t)LOGIC_COLS, "witgen: the logic chips have 28 mapped columns");
-    const uint32_t* cols = &map->pc;
-    uint64_t seen[4] = {0, 0, 0, 0};
-    for (int c = 0; c < LOGIC_COLS; c++) {
-        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
-        if (cols[c] < 256) {
-            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
-            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+            const uint32_t x = (st.rs1_val >> (8 * b)) & 0xff, y = (st.rs2_val >> (8 * b)) & 0xff;
+            o.put(m.rs1_bytes[b], x);
+            o.put(m.rs2_bytes[b], y);
+            o.put(m.rd_bytes[b], (st.rd_after >> (8 * b)) & 0xff);
+            lk_count<XCD_LOCAL>(lk_logic, x | (y << 8));
         }
     }
-    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
-    hipStream_t st = ctx_stream(ctx, s);
-    const unsigned grid = grid_for(rows, NT, MAXB);
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    if (xcd_local && (lk_dyn || lk_fetch || lk_logic) && n > 0) {
-        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0,
-                     l_slots = lk_logic ? LOGIC_SLOTS : 0;
-        void* scratch = nullptr;
-        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), &scratch));
-        uint32_t* c_dyn = (uint32_t*)scratch;
-        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
-        uint32_t* c_logic = c_fetch + 8 * f_slots;
-        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_witgen_logic<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
-                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr, lk_logic ? c_logic : nullptr);
-            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
-            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
-            if (lk_logic) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((l_slots + NT - 1) / NT)), dim3(NT), 0, st, c_logic, l_slots, lk_logic);
-            e = hipGetLastError();
-        }
-        const hipError_t e2 = hipStreamSynchronize(st);
-        ctx_free(ctx, scratch);
-        HIP_TRY(ctx, e);
-        HIP_TRY(ctx, e2);
-        return 0;
-    }
-    hipLaunchKernelGGL((k_witgen_logic<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
-                       lk_dyn, lk_fetch, lk_logic);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
 }
 
 // ---- I-type ADDI (AddiInstruction, ceno_zkvm/src/instructions/riscv/arith_imm/arith_imm_circuit_v2.rs:85-117): the I-instruction base
 // (state, rs1, rd: i_insn.rs:66-82; no rs2), rs1 as two u16 limbs, the low 16 bits of the immediate, its sign, and the carries of
 // rs1 + sign_extend(imm) (imm_sign_extend utils.rs:139-148; Value::add with overflow uint.rs:762-785: both result limbs are
 // range-checked).  18 mapped columns; lookups: fetch, four timestamp-difference limbs, two u16 result limbs.
-constexpr int OFF_IMM = 36;  // Instruction { kind u8, rs1 u8, rs2 u8, rd u8, imm i32, raw u32 } at byte 32 (rv32im.rs:115-128)
 struct AddiMap {  // ceno_hip_addi_column_map = ceno_gpu's AddiColumnMap (chips/addi.rs:27-42)
     uint32_t pc, ts;
     uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
@@ -302,110 +340,35 @@ template <bool XCD_LOCAL>
 __global__ void __launch_bounds__(NT) k_witgen_addi(AddiMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
                                                     uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
                                                     uint32_t* lk_dyn, uint32_t* lk_fetch) {
-    if (XCD_LOCAL) {
-        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
-        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
-    }
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
         if (r >= n) {
-            const uint32_t* cols = &m.pc;
-#pragma unroll
-            for (int c = 0; c < ADDI_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            zero_row<ADDI_COLS>(o, &m.pc);
             continue;
         }
-        const unsigned char* rec = recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES;
-        const uint64_t* q = reinterpret_cast<const uint64_t*>(rec);
-        const uint64_t cycle = q[OFF_CYCLE / 8];
-        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
-        const uint32_t imm32 = (uint32_t)(q[OFF_IMM / 8] >> 32);  // bytes 36..39
-        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
-        const uint64_t rd_ab = q[OFF_RD / 8], rd_prev = q[OFF_RD / 8 + 2];
-        const uint32_t rs1_addr = (uint32_t)rs1_av, rs1_val = (uint32_t)(rs1_av >> 32);
-        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32);
-        const uint64_t ts = cycle - offset;
-        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
-        put(m.pc, pc);
-        put(m.ts, ts);
-        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
-        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), dd = lt_diff(pd, ts + SUBCYCLE_RD);
-        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
-        put(m.rs1_prev_ts, p1);
-        put(m.rs1_lt_diff[0], d1 & 0xffff);
-        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
-        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
-        put(m.rd_prev_ts, pd);
-        put(m.rd_prev_val[0], rd_before & 0xffff);
-        put(m.rd_prev_val[1], rd_before >> 16);
-        put(m.rd_lt_diff[0], dd & 0xffff);
-        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
-        // imm as i16 as u16; sign extension to the second limb
-        const uint32_t imm16 = imm32 & 0xffff, neg = (imm16 >> 15) & 1u, ext = neg ? 0xffffu : 0u;
-        put(m.rs1_limbs[0], rs1_val & 0xffff);
-        put(m.rs1_limbs[1], rs1_val >> 16);
-        put(m.imm, imm16);
-        put(m.imm_sign, neg);
-        const uint32_t s0 = (rs1_val & 0xffff) + imm16;
-        const uint32_t s1 = (rs1_val >> 16) + ext + (s0 >> 16);
-        put(m.rd_carries[0], s0 >> 16);
-        put(m.rd_carries[1], s1 >> 16);
-        if (lk_fetch) {
-            const uint32_t slot = (pc - fetch_base) >> 2;
-            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
-        }
-        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (s0 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (s1 & 0xffff));
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        // imm as i16 as u16; sign extension into the second limb
+        const uint32_t imm16 = st.imm & 0xffff, neg = (imm16 >> 15) & 1u, ext = neg ? 0xffffu : 0u;
+        o.put(m.rs1_limbs[0], st.rs1_val & 0xffff);
+        o.put(m.rs1_limbs[1], st.rs1_val >> 16);
+        o.put(m.imm, imm16);
+        o.put(m.imm_sign, neg);
+        const uint32_t s0 = (st.rs1_val & 0xffff) + imm16;
+        const uint32_t s1 = (st.rs1_val >> 16) + ext + (s0 >> 16);
+        o.put(m.rd_carries[0], s0 >> 16);
+        o.put(m.rd_carries[1], s1 >> 16);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (s0 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (s1 & 0xffff));
     }
-}
-
-int witgen_addi(ceno_hip_ctx* ctx, const AddiMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
-                uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
-    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
-    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
-    CHECK_ARG(ctx, map->num_cols >= (uint32_t)ADDI_COLS, "witgen: the ADDI chip has 18 mapped columns");
-    const uint32_t* cols = &map->pc;
-    uint64_t seen[4] = {0, 0, 0, 0};
-    for (int c = 0; c < ADDI_COLS; c++) {
-        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
-        if (cols[c] < 256) {
-            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
-            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
-        }
-    }
-    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
-    hipStream_t st = ctx_stream(ctx, s);
-    const unsigned grid = grid_for(rows, NT, MAXB);
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    if (xcd_local && (lk_dyn || lk_fetch) && n > 0) {
-        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0;
-        void* scratch = nullptr;
-        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), &scratch));
-        uint32_t* c_dyn = (uint32_t*)scratch;
-        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
-        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_witgen_addi<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
-                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
-            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
-            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
-            e = hipGetLastError();
-        }
-        const hipError_t e2 = hipStreamSynchronize(st);
-        ctx_free(ctx, scratch);
-        HIP_TRY(ctx, e);
-        HIP_TRY(ctx, e2);
-        return 0;
-    }
-    hipLaunchKernelGGL((k_witgen_addi<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
-                       lk_dyn, lk_fetch);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
 }
 
 // ---- I-type logic chips ANDI / ORI / XORI (logic_imm/logic_imm_circuit_v2.rs:105-130,195-224): the I-instruction base, rs1 and rd as four
@@ -426,115 +389,37 @@ template <bool XCD_LOCAL>
 __global__ void __launch_bounds__(NT) k_witgen_logic_i(LogicIMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
                                                        uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w,
                                                        size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic) {
-    if (XCD_LOCAL) {
-        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
-        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
-        if (lk_logic) lk_logic += (size_t)xcc * LOGIC_SLOTS;
-    }
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    lk_logic = xcd_copy<XCD_LOCAL>(lk_logic, LOGIC_SLOTS);
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
         if (r >= n) {
-            const uint32_t* cols = &m.pc;
-#pragma unroll
-            for (int c = 0; c < LOGIC_I_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            zero_row<LOGIC_I_COLS>(o, &m.pc);
             continue;
         }
-        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
-        const uint64_t cycle = q[OFF_CYCLE / 8];
-        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
-        const uint32_t imm32 = (uint32_t)(q[OFF_IMM / 8] >> 32);
-        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
-        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
-        const uint32_t rs1_addr = (uint32_t)rs1_av, rs1_val = (uint32_t)(rs1_av >> 32);
-        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
-        const uint64_t ts = cycle - offset;
-        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
-        put(m.pc, pc);
-        put(m.ts, ts);
-        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
-        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), dd = lt_diff(pd, ts + SUBCYCLE_RD);
-        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
-        put(m.rs1_prev_ts, p1);
-        put(m.rs1_lt_diff[0], d1 & 0xffff);
-        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
-        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
-        put(m.rd_prev_ts, pd);
-        put(m.rd_prev_val[0], rd_before & 0xffff);
-        put(m.rd_prev_val[1], rd_before >> 16);
-        put(m.rd_lt_diff[0], dd & 0xffff);
-        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
         // the immediate as the circuit sees it: low half as is, high half = the sign (bit 31) spread over 16 bits
-        const uint32_t imm_eff = (imm32 & 0xffffu) | ((imm32 >> 31) ? 0xffff0000u : 0u);
+        const uint32_t imm_eff = (st.imm & 0xffffu) | ((st.imm >> 31) ? 0xffff0000u : 0u);
+        o.put(m.imm_lo_bytes[0], imm_eff & 0xff);
+        o.put(m.imm_lo_bytes[1], (imm_eff >> 8) & 0xff);
+        o.put(m.imm_hi_bytes[0], (imm_eff >> 16) & 0xff);
+        o.put(m.imm_hi_bytes[1], imm_eff >> 24);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            put(m.rs1_bytes[b], (rs1_val >> (8 * b)) & 0xff);
-            put(m.rd_bytes[b], (rd_after >> (8 * b)) & 0xff);
-        }
-        put(m.imm_lo_bytes[0], imm_eff & 0xff);
-        put(m.imm_lo_bytes[1], (imm_eff >> 8) & 0xff);
-        put(m.imm_hi_bytes[0], (imm_eff >> 16) & 0xff);
-        put(m.imm_hi_bytes[1], imm_eff >> 24);
-        if (lk_fetch) {
-            const uint32_t slot = (pc - fetch_base) >> 2;
-            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
-        }
-        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16);
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
-#pragma unroll
-        for (int b = 0; b < 4; b++) lk_count<XCD_LOCAL>(lk_logic, ((rs1_val >> (8 * b)) & 0xff) | (((imm_eff >> (8 * b)) & 0xff) << 8));
-    }
-}
-
-int witgen_logic_i(ceno_hip_ctx* ctx, const LogicIMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
-                   uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic,
-                   ceno_hip_stream s) {
-    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
-    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
-    CHECK_ARG(ctx, map->num_cols >= (uint32_t)LOGIC_I_COLS, "witgen: the immediate logic chips have 24 mapped columns");
-    const uint32_t* cols = &map->pc;
-    uint64_t seen[4] = {0, 0, 0, 0};
-    for (int c = 0; c < LOGIC_I_COLS; c++) {
-        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
-        if (cols[c] < 256) {
-            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
-            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
+            const uint32_t x = (st.rs1_val >> (8 * b)) & 0xff;
+            o.put(m.rs1_bytes[b], x);
+            o.put(m.rd_bytes[b], (st.rd_after >> (8 * b)) & 0xff);
+            lk_count<XCD_LOCAL>(lk_logic, x | (((imm_eff >> (8 * b)) & 0xff) << 8));
         }
     }
-    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
-    hipStream_t st = ctx_stream(ctx, s);
-    const unsigned grid = grid_for(rows, NT, MAXB);
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    if (xcd_local && (lk_dyn || lk_fetch || lk_logic) && n > 0) {
-        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0,
-                     l_slots = lk_logic ? LOGIC_SLOTS : 0;
-        void* scratch = nullptr;
-        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), &scratch));
-        uint32_t* c_dyn = (uint32_t*)scratch;
-        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
-        uint32_t* c_logic = c_fetch + 8 * f_slots;
-        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots + l_slots) * sizeof(uint32_t), st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_witgen_logic_i<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
-                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr, lk_logic ? c_logic : nullptr);
-            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
-            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
-            if (lk_logic) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((l_slots + NT - 1) / NT)), dim3(NT), 0, st, c_logic, l_slots, lk_logic);
-            e = hipGetLastError();
-        }
-        const hipError_t e2 = hipStreamSynchronize(st);
-        ctx_free(ctx, scratch);
-        HIP_TRY(ctx, e);
-        HIP_TRY(ctx, e2);
-        return 0;
-    }
-    hipLaunchKernelGGL((k_witgen_logic_i<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
-                       lk_dyn, lk_fetch, lk_logic);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
 }
 
 // ---- LUI (LuiInstruction, ceno_zkvm/src/instructions/riscv/lui.rs:100-120): the I-instruction base (rs1 is read as decoded: x0), bytes 1..3 of
@@ -554,152 +439,102 @@ template <bool XCD_LOCAL>
 __global__ void __launch_bounds__(NT) k_witgen_lui(LuiMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
                                                    uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
                                                    uint32_t* lk_dyn, uint32_t* lk_fetch) {
-    if (XCD_LOCAL) {
-        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-        if (lk_dyn) lk_dyn += (size_t)xcc * CENO_HIP_LK_DYNAMIC_SLOTS;
-        if (lk_fetch) lk_fetch += (size_t)xcc * fetch_slots;
-    }
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
         if (r >= n) {
-            const uint32_t* cols = &m.pc;
-#pragma unroll
-            for (int c = 0; c < LUI_COLS; c++) w[(size_t)cols[c] * rows + r] = 0;
+            zero_row<LUI_COLS>(o, &m.pc);
             continue;
         }
-        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
-        const uint64_t cycle = q[OFF_CYCLE / 8];
-        const uint32_t pc = (uint32_t)q[OFF_PC_BEFORE / 8];
-        const uint32_t imm32 = (uint32_t)(q[OFF_IMM / 8] >> 32);
-        const uint64_t rs1_av = q[OFF_RS1 / 8], rs1_prev = q[OFF_RS1 / 8 + 1];
-        const uint64_t rd_ab = q[OFF_RD / 8], rd_after_w = q[OFF_RD / 8 + 1], rd_prev = q[OFF_RD / 8 + 2];
-        const uint32_t rs1_addr = (uint32_t)rs1_av;
-        const uint32_t rd_addr = (uint32_t)rd_ab, rd_before = (uint32_t)(rd_ab >> 32), rd_after = (uint32_t)rd_after_w;
-        const uint64_t ts = cycle - offset;
-        auto put = [&](uint32_t col, uint64_t v) { w[(size_t)col * rows + r] = v; };
-        put(m.pc, pc);
-        put(m.ts, ts);
-        const uint64_t p1 = aligned_prev_ts(rs1_prev, offset), pd = aligned_prev_ts(rd_prev, offset);
-        const uint64_t d1 = lt_diff(p1, ts + SUBCYCLE_RS1), dd = lt_diff(pd, ts + SUBCYCLE_RD);
-        put(m.rs1_id, ((rs1_addr << 2) >> 8) & 0xff);
-        put(m.rs1_prev_ts, p1);
-        put(m.rs1_lt_diff[0], d1 & 0xffff);
-        put(m.rs1_lt_diff[1], (d1 >> 16) & 0xffff);
-        put(m.rd_id, ((rd_addr << 2) >> 8) & 0xff);
-        put(m.rd_prev_ts, pd);
-        put(m.rd_prev_val[0], rd_before & 0xffff);
-        put(m.rd_prev_val[1], rd_before >> 16);
-        put(m.rd_lt_diff[0], dd & 0xffff);
-        put(m.rd_lt_diff[1], (dd >> 16) & 0xffff);
-        put(m.imm, imm32 >> 12);
-        if (lk_fetch) {
-            const uint32_t slot = (pc - fetch_base) >> 2;
-            if (slot < fetch_slots) lk_count<XCD_LOCAL>(lk_fetch, slot);
-        }
-        constexpr uint32_t U16 = 1u << 16, R13 = 1u << (MAX_TS_BITS - 16), U8 = 1u << 8;
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(d1 & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((d1 >> 16) & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (uint32_t)(dd & 0xffff));
-        lk_count<XCD_LOCAL>(lk_dyn, R13 + (uint32_t)((dd >> 16) & 0xffff));
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        o.put(m.imm, st.imm >> 12);
 #pragma unroll
         for (int b = 1; b < 4; b++) {
-            const uint32_t v = (rd_after >> (8 * b)) & 0xff;
-            put(m.rd_bytes[b - 1], v);
-            lk_count<XCD_LOCAL>(lk_dyn, U8 + v);
+            const uint32_t v = (st.rd_after >> (8 * b)) & 0xff;
+            o.put(m.rd_bytes[b - 1], v);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + v);
         }
     }
+}
+
+// one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
+#define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
+    [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2) {                                                             \
+        (void)t2;                                                                                                         \
+        if (xcd) hipLaunchKernelGGL((KERNEL<true>), dim3(grid), dim3(NT), 0, st, __VA_ARGS__);                            \
+        else hipLaunchKernelGGL((KERNEL<false>), dim3(grid), dim3(NT), 0, st, __VA_ARGS__);                               \
+    }
+
+int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, 22, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);  // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*) {
+        if (sub && xcd) hipLaunchKernelGGL((k_witgen_arith<true, true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else if (sub) hipLaunchKernelGGL((k_witgen_arith<true, false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else if (xcd) hipLaunchKernelGGL((k_witgen_arith<false, true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else hipLaunchKernelGGL((k_witgen_arith<false, false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+    });
+}
+
+int witgen_logic(ceno_hip_ctx* ctx, const LogicMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic,
+                 ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, LOGIC_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
+}
+
+int witgen_logic_i(ceno_hip_ctx* ctx, const LogicIMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                   uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_logic,
+                   ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, LOGIC_I_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic_i, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
+}
+
+int witgen_addi(ceno_hip_ctx* ctx, const AddiMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, ADDI_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_addi, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 
 int witgen_lui(ceno_hip_ctx* ctx, const LuiMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
                uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
-    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
-    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
-    CHECK_ARG(ctx, map->num_cols >= (uint32_t)LUI_COLS, "witgen: the LUI chip has 16 mapped columns");
-    const uint32_t* cols = &map->pc;
-    uint64_t seen[4] = {0, 0, 0, 0};
-    for (int c = 0; c < LUI_COLS; c++) {
-        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
-        if (cols[c] < 256) {
-            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
-            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
-        }
-    }
-    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, LUI_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    if (xcd_local && (lk_dyn || lk_fetch) && n > 0) {
-        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0;
-        void* scratch = nullptr;
-        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), &scratch));
-        uint32_t* c_dyn = (uint32_t*)scratch;
-        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
-        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), st);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL((k_witgen_lui<true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w,
-                               rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
-            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
-            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
-            e = hipGetLastError();
-        }
-        const hipError_t e2 = hipStreamSynchronize(st);
-        ctx_free(ctx, scratch);
-        HIP_TRY(ctx, e);
-        HIP_TRY(ctx, e2);
-        return 0;
-    }
-    hipLaunchKernelGGL((k_witgen_lui<false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows,
-                       lk_dyn, lk_fetch);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_lui, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
-
-int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
-                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
-    CHECK_ARG(ctx, map && w && rows > 0 && n <= rows, "bad witgen arguments");
-    CHECK_ARG(ctx, n == 0 || (recs && idx && num_records > 0), "witgen: records / indices missing");
-    CHECK_ARG(ctx, map->num_cols >= 22, "witgen: the arithmetic chips have 22 mapped columns");
-    const uint32_t* cols = &map->pc;
-    uint64_t seen[4] = {0, 0, 0, 0};
-    for (int c = 0; c < 22; c++) {
-        CHECK_ARG(ctx, cols[c] < map->num_cols, "witgen: column id out of range");
-        if (cols[c] < 256) {
-            CHECK_ARG(ctx, !(seen[cols[c] >> 6] >> (cols[c] & 63) & 1), "witgen: duplicate column id");
-            seen[cols[c] >> 6] |= 1ull << (cols[c] & 63);
-        }
-    }
-    CHECK_ARG(ctx, lk_fetch == nullptr || fetch_slots > 0, "witgen: fetch table without slots");
-    hipStream_t st = ctx_stream(ctx, s);
-    // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written, padding included
-    const unsigned grid = grid_for(rows, NT, MAXB);
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    if (xcd_local && (lk_dyn || lk_fetch) && n > 0) {
-        // per-XCD copies of both tables, zeroed, counted into with L2-local atomics, then merged into the caller's tables
-        const size_t dyn_slots = lk_dyn ? (size_t)CENO_HIP_LK_DYNAMIC_SLOTS : 0, f_slots = lk_fetch ? (size_t)fetch_slots : 0;
-        void* scratch = nullptr;
-        TRY(ctx_alloc(ctx, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), &scratch));
-        uint32_t* c_dyn = (uint32_t*)scratch;
-        uint32_t* c_fetch = c_dyn + 8 * dyn_slots;
-        hipError_t e = hipMemsetAsync(scratch, 0, 8 * (dyn_slots + f_slots) * sizeof(uint32_t), st);
-        if (e == hipSuccess) {
-            if (sub) hipLaunchKernelGGL((k_witgen_arith<true, true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
-            else hipLaunchKernelGGL((k_witgen_arith<false, true>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn ? c_dyn : nullptr, lk_fetch ? c_fetch : nullptr);
-            if (lk_dyn) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((dyn_slots + NT - 1) / NT)), dim3(NT), 0, st, c_dyn, dyn_slots, lk_dyn);
-            if (lk_fetch) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((f_slots + NT - 1) / NT)), dim3(NT), 0, st, c_fetch, f_slots, lk_fetch);
-            e = hipGetLastError();
-        }
-        // the scratch goes back to the pool only after the stream has consumed it
-        const hipError_t e2 = hipStreamSynchronize(st);
-        ctx_free(ctx, scratch);
-        HIP_TRY(ctx, e);
-        HIP_TRY(ctx, e2);
-        return 0;
-    }
-    if (sub) hipLaunchKernelGGL((k_witgen_arith<true, false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
-    else hipLaunchKernelGGL((k_witgen_arith<false, false>), dim3(grid), dim3(NT), 0, st, *map, (const unsigned char*)recs, idx, n, offset, fetch_base, fetch_slots, w, rows, lk_dyn, lk_fetch);
-    HIP_TRY(ctx, hipGetLastError());
-    return 0;
-}
+#undef WITGEN_LAUNCH
 
 }  // namespace
 
