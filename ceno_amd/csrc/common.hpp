@@ -158,3 +158,24 @@ inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
 // fold: out[j] = in[2j] + r (in[2j+1] - in[2j]) for j < half ; `in` base or ext, `out` ext
 int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* out, size_t half, E2 r, hipStream_t st);
 int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, void** keep_tmp);
+// The set-up work of a sumcheck handle (zero its counter block, pull the plan blob out of the pinned block, arm the rows of the
+// persistent mid-round kernel) as data: a tower layer hands it to the kernel that builds its eq table, which then does both — one
+// dependent launch (~7 us of stream time) less in front of every layer.  dst == NULL: nothing deferred.
+struct SetupJob {
+    uint64_t* zero = nullptr;
+    size_t zero_words = 0;
+    uint64_t* dst = nullptr;
+    const uint64_t* src_host_view = nullptr;
+    size_t words = 0;
+    uint64_t* ones = nullptr;
+    size_t ones_words = 0;
+};
+// eq table of n <= the one-launch limit variables AND the set-up job in one launch; returns 1 (and launches nothing) when n is too large
+int launch_eq_build_with_setup(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, const SetupJob& job);
+// ceno_hip_sumcheck_begin whose set-up launch is handed back in *job instead of being queued (sumcheck.hip)
+struct ceno_hip_sumcheck;
+struct ceno_hip_sumcheck_plan;
+struct ceno_hip_mle;
+int sumcheck_begin_deferred(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st, ceno_hip_sumcheck** out,
+                            SetupJob* job);
+void launch_setup_job(const SetupJob& job, hipStream_t st);  // the stand-alone set-up kernel (sumcheck.hip)

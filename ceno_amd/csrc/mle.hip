@@ -143,8 +143,15 @@ static int eq_fused_max() {
     }();
     return v;
 }
-__global__ void __launch_bounds__(NT) k_eq_fused(E2* __restrict__ out, int n, PointArg pt, E2 scalar, SelArg sa) {
+__global__ void __launch_bounds__(NT) k_eq_fused(E2* __restrict__ out, int n, PointArg pt, E2 scalar, SelArg sa, SetupJob job) {
     __shared__ E2 tab[1 << EQ_LB];
+    const unsigned eq_blocks = job.dst ? gridDim.x - 1 : gridDim.x;
+    if (blockIdx.x == eq_blocks) {  // (only with a job) the extra workgroup does the sumcheck handle's set-up work: k_setup's three loops
+        for (size_t i = threadIdx.x; i < job.zero_words; i += NT) job.zero[i] = 0;
+        for (size_t i = threadIdx.x; i < job.words; i += NT) job.dst[i] = job.src_host_view[i];
+        for (size_t i = threadIdx.x; i < job.ones_words; i += NT) job.ones[i] = ~0ull;  // MSG_INVALID
+        return;
+    }
     const int lb = n < EQ_LB ? n : EQ_LB;
     if (threadIdx.x == 0) tab[0] = e2_one();
     __syncthreads();
@@ -159,7 +166,7 @@ __global__ void __launch_bounds__(NT) k_eq_fused(E2* __restrict__ out, int n, Po
         __syncthreads();
     }
     const size_t tiles = (size_t)1 << (n - lb), tile_len = (size_t)1 << lb;
-    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (size_t t = blockIdx.x; t < tiles; t += eq_blocks) {
         E2 p = scalar;
         for (int k = lb; k < n; k++) {  // uniform over the workgroup
             const E2 r = pt.r[k];
@@ -186,7 +193,7 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
         // latency-bound sizes: per block the LDS table costs as much as a tile's worth of products, which only pays when the
         // alternative is two more launches (at nv = 24 the fused form measured 0.143 ms against 0.080 ms for the outer product)
         const size_t tiles = (size_t)1 << (n > EQ_LB ? n - EQ_LB : 0);
-        hipLaunchKernelGGL(k_eq_fused, dim3((unsigned)std::min<size_t>(tiles, 1024)), dim3(NT), 0, st, (E2*)dev_out, n, pt, scalar, sa);
+        hipLaunchKernelGGL(k_eq_fused, dim3((unsigned)std::min<size_t>(tiles, 1024)), dim3(NT), 0, st, (E2*)dev_out, n, pt, scalar, sa, SetupJob{});
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
@@ -211,6 +218,18 @@ static int eq_build_impl(ceno_hip_ctx* ctx, const uint64_t* point, int n, E2 sca
     return 0;
 }
 
+int launch_eq_build_with_setup(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, const SetupJob& job) {
+    if (n < 0 || n > eq_fused_max() || !job.dst) return 1;
+    SelArg sa{};
+    sa.kind = CENO_HIP_SEL_WHOLE;
+    sa.num_vars = n;
+    PointArg pt;
+    for (int k = 0; k < n; k++) pt.r[k] = E2{host_point[2 * k], host_point[2 * k + 1]};
+    const size_t tiles = (size_t)1 << (n > EQ_LB ? n - EQ_LB : 0);
+    hipLaunchKernelGGL(k_eq_fused, dim3((unsigned)std::min<size_t>(tiles, 1024) + 1), dim3(NT), 0, st, (E2*)dev_out, n, pt, scalar, sa, job);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+}
 int launch_eq_build(ceno_hip_ctx* ctx, const uint64_t* host_point, int n, E2 scalar, uint64_t* dev_out, hipStream_t st, void** keep_tmp) {
     SelArg sa{};
     sa.kind = CENO_HIP_SEL_WHOLE;

@@ -1319,7 +1319,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
 }
 
 static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st,
-                    ceno_hip_sumcheck** out) {
+                    ceno_hip_sumcheck** out, SetupJob* defer_setup = nullptr) {
     CHECK_ARG(ctx, mles && plan && out, "NULL argument");
     const int n = plan->max_num_vars, d = plan->max_degree;
     CHECK_ARG(ctx, n >= 0 && n < 40, "max_num_vars %d out of range", n);
@@ -1582,9 +1582,20 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
         if (blob.size() <= 16 * 1024 && blob.size() % 8 == 0) {
             const uint64_t* d_view = reinterpret_cast<const uint64_t*>((char*)db + (h_blob - (char*)hb));
-            hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, reinterpret_cast<uint64_t*>(sc->d_counter), (size_t)4096 / 8, (uint64_t*)d_blob, d_view,
-                               blob.size() / 8, sc->d_mid_rows, sc->d_mid_rows ? MID_ROWS_BYTES / 8 : (size_t)0);
-            if (hipGetLastError() != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+            SetupJob job;
+            job.zero = reinterpret_cast<uint64_t*>(sc->d_counter);
+            job.zero_words = (size_t)4096 / 8;
+            job.dst = (uint64_t*)d_blob;
+            job.src_host_view = d_view;
+            job.words = blob.size() / 8;
+            job.ones = sc->d_mid_rows;
+            job.ones_words = sc->d_mid_rows ? MID_ROWS_BYTES / 8 : (size_t)0;
+            if (defer_setup) {
+                *defer_setup = job;  // the caller queues it with a kernel of its own (a tower layer: its eq table)
+            } else {
+                launch_setup_job(job, st);
+                if (hipGetLastError() != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
+            }
         } else {
             if (sc->d_mid_rows && hipMemsetAsync(sc->d_mid_rows, 0xFF, MID_ROWS_BYTES, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
             if (hipMemsetAsync(sc->d_counter, 0, 4096, st) != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "memset failed"); }
@@ -2254,6 +2265,15 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     }
     sc->round++;
     return 0;
+}
+
+void launch_setup_job(const SetupJob& job, hipStream_t st) {
+    hipLaunchKernelGGL(k_setup, dim3(1), dim3(256), 0, st, job.zero, job.zero_words, job.dst, job.src_host_view, job.words, job.ones, job.ones_words);
+}
+int sumcheck_begin_deferred(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st, ceno_hip_sumcheck** out,
+                            SetupJob* job) {
+    *job = SetupJob{};
+    return sc_build(ctx, mles, plan, st, out, job);
 }
 
 extern "C" {

@@ -365,13 +365,8 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     ceno_hip_mle* eq = nullptr;
     void* eq_tmp = nullptr;  // scratch of the eq build; lives (like eq) until the sumcheck handle is freed
     TRY(ceno_hip_mle_alloc(ctx, layer, 1, &eq));
-    {
-        int erc = launch_eq_build(ctx, out_rt, layer, gl::e2_one(), eq->d, ctx_stream(ctx, s), &eq_tmp);
-        if (erc) {
-            ceno_hip_mle_free(ctx, eq);
-            return erc;
-        }
-    }
+    // The eq table is built AFTER the handle below exists: a small table's kernel then also does the handle's set-up work
+    // (launch_eq_build_with_setup), one dependent launch instead of two in front of every layer.  CENO_HIP_TOWER_EQ_SETUP=0 keeps them apart.
     std::vector<ceno_hip_mle*> mles{eq};
     std::vector<ceno_hip_mle*> views;
     std::vector<uint64_t> coeffs;
@@ -437,8 +432,24 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     plan.common_mle_idx = cidx.data();
     plan.max_num_vars = layer;
     plan.max_degree = 3;
-    rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, out);
+    static const bool fuse = !(getenv("CENO_HIP_TOWER_EQ_SETUP") && atoi(getenv("CENO_HIP_TOWER_EQ_SETUP")) == 0);
+    SetupJob job;
+    hipStream_t st = ctx_stream(ctx, s);
+    rc = fuse ? sumcheck_begin_deferred(ctx, mles.data(), &plan, st, out, &job) : ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, out);
     cleanup();  // views are borrowed wrappers; the sumcheck copied the pointers
+    if (!rc) {
+        int fused = 1;
+        if (job.dst) fused = launch_eq_build_with_setup(ctx, out_rt, layer, gl::e2_one(), eq->d, st, job);
+        if (fused < 0 || fused > 1) rc = fused;
+        else if (fused == 1) {  // a large table (or nothing deferred): the two kernels separately
+            if (job.dst) launch_setup_job(job, st);
+            rc = launch_eq_build(ctx, out_rt, layer, gl::e2_one(), eq->d, st, &eq_tmp);
+        }
+        if (rc) {
+            ceno_hip_sumcheck_free(ctx, *out);
+            *out = nullptr;
+        }
+    }
     if (rc) {
         (void)hipStreamSynchronize(ctx_stream(ctx, s));
         ctx_free(ctx, eq_tmp);
