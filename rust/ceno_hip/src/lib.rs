@@ -17,6 +17,7 @@ pub mod pcs;
 pub mod prover;
 pub mod sumcheck;
 pub mod tower;
+pub mod witgen;
 
 pub use ceno_hip_sys as sys;
 pub use error::{HipError, Result};

@@ -1,0 +1,109 @@
+//! On-device witness generation (`hal.witgen.*` of the reference's CUDA HAL as called from
+//! `ceno_zkvm/src/instructions/gpu/dispatch.rs:509-650`): one call per chip kind turns the shard's `StepRecord`s — already on the
+//! device, in the emulator's `#[repr(C)]` layout (`ceno_emul/src/tracer.rs:33-60`, 136 bytes) — into the chip's COLUMN-major
+//! witness matrix and adds the chip's lookup multiplicities to the shard's tables.
+//!
+//! The column maps are the `#[repr(C)]` structs of `ceno_hip_sys`, field for field those of `ceno_gpu::common::witgen::types`
+//! (`AddColumnMap` `chips/add.rs:29-46`, `SubColumnMap` `chips/sub.rs:28-45`, `LogicRColumnMap` `chips/logic_r.rs:25-42`,
+//! `AddiColumnMap` `chips/addi.rs:27-42`, `LogicIColumnMap` `chips/logic_i.rs:26-41`, `LuiColumnMap` `chips/lui.rs:29-41`): the
+//! dispatch arm builds them with the reference's own `extract_*_column_map` helpers and passes them through.
+use std::sync::Arc;
+
+use ceno_hip_sys as sys;
+
+use crate::{
+    error::Result,
+    hal::{raw_stream, HipHal, HipStream},
+};
+
+/// Device pointers of the lookup-multiplicity tables one shard accumulates into (`LkMultiplicity`, one counter per key); a null
+/// pointer skips that table.  `logic` is the 2^16-entry table of the operation being generated (`LookupTable::And` / `Or` / `Xor`).
+#[derive(Clone, Copy)]
+pub struct LkTables {
+    /// `LookupTable::Dynamic`: 2^17 counters, key `(1 << bits) + value`
+    pub dynamic: *mut u32,
+    /// `LookupTable::Instruction`: one counter per program slot, key `(pc - fetch_base_pc) / 4`
+    pub fetch: *mut u32,
+    pub fetch_base_pc: u32,
+    pub fetch_num_slots: u32,
+    pub logic: *mut u32,
+}
+
+/// The step records of a shard on the device and the steps that belong to one chip.
+pub struct ChipSteps<'a> {
+    /// `num_records` x 136 bytes
+    pub dev_records: *const u8,
+    pub num_records: usize,
+    /// device array of `n` indices into the records
+    pub dev_indices: *const u32,
+    pub n: usize,
+    /// `ShardContext::current_shard_offset_cycle()`
+    pub shard_offset_cycle: u64,
+    pub stream: Option<&'a HipStream>,
+}
+
+/// `AND` / `OR` / `XOR` (and `ANDI` / `ORI` / `XORI`): the payload of `GpuWitgenKind::LogicR` / `LogicI`
+#[derive(Clone, Copy, PartialEq, Eq)]
+#[repr(i32)]
+pub enum LogicKind {
+    And = 0,
+    Or = 1,
+    Xor = 2,
+}
+
+pub struct Witgen {
+    hal: Arc<HipHal>,
+}
+
+impl Witgen {
+    pub fn new(hal: &Arc<HipHal>) -> Self {
+        Self { hal: hal.clone() }
+    }
+
+    /// `witgen_add`: `dev_witness` = `map.num_cols` columns of `rows_padded` words; rows `>= steps.n` are zeroed
+    pub fn add(&self, map: &sys::ceno_hip_add_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_add(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                     lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_sub`
+    pub fn sub(&self, map: &sys::ceno_hip_sub_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_sub(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                     lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_logic_r`
+    pub fn logic_r(&self, map: &sys::ceno_hip_logic_r_column_map, kind: LogicKind, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                   lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_logic_r(self.hal.ctx, map, kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                         steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                         lk.logic, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_addi`
+    pub fn addi(&self, map: &sys::ceno_hip_addi_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_addi(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                      lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_logic_i`
+    pub fn logic_i(&self, map: &sys::ceno_hip_logic_i_column_map, kind: LogicKind, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                   lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_logic_i(self.hal.ctx, map, kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                         steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                         lk.logic, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_lui`
+    pub fn lui(&self, map: &sys::ceno_hip_lui_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_lui(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                     lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+}
