@@ -78,6 +78,37 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
                    "ext_mults_per_s": K * K * ((1 << 22) - 1) / (ms * 1e-3), "roofline": roof(3 * K * 16 * (1 << 22), ms)}
     for m in m22:
         m.free()
+    # independent nv = 26 sumchecks IN FLIGHT (one host thread + stream each, as the chip scheduler runs chip proofs): the small rounds of
+    # one instance overlap the streaming rounds of another.  Reported beside the headline, which stays one instance at a time.
+    import threading
+    flight = {}
+    for n_inst in (1, 2, 3):
+        insts = [[dev.synthetic(26, True, SEED0 + 100 * (t + 1) + j) for j in range(K)] for t in range(n_inst)]
+        streams = [dev.stream_create() for _ in range(n_inst)]
+        per = 4
+
+        def work(t):
+            for _ in range(per):
+                prover.sumcheck_prove(dev, insts[t], one, [list(range(K))], 26, K, new_transcript(), stream=streams[t])
+
+        work(0)  # warm-up (buffers, streams)
+        dev.sync()
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(n_inst)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dev.sync()
+        dt = time.perf_counter() - t0
+        flight[str(n_inst)] = {"ms_per_sumcheck": dt / (per * n_inst) * 1e3, "ext_mults_per_s": K * K * ((1 << 26) - 1) * per * n_inst / dt}
+        for row in insts:
+            for m in row:
+                m.free()
+        for st_ in streams:
+            dev.stream_destroy(st_)
+    out["nv26_instances_in_flight"] = dict(flight, workload="independent nv=26 sumchecks (3 ext MLEs each) proved concurrently, one host thread and stream "
+                                                               "per instance; aggregate throughput")
     # config #4 on one GPU: batched main-constraint sumcheck over 24 chips, at the config's stated size (max_nv = 26) and at 24
     for max_nv, key in ((26, "batched_main_nv26"), (24, "batched_main")):
         jobs, elems = synthetic.batched_jobs(dev, max_nv, 12)
