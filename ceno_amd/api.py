@@ -358,6 +358,36 @@ def witgen_addi(dev: Device, cols, records_ptr: int, num_records: int, indices_p
                                          C.c_void_p(lk_fetch_ptr or None), stream))
 
 
+def _witgen_4tab(dev: Device, fn, n_cols: int, cols, records_ptr, num_records, indices_ptr, n, witness_ptr, rows_padded, shard_offset, fetch_base_pc,
+                 fetch_num_slots, lk_dynamic_ptr, lk_fetch_ptr, lk_double_u8_ptr, lk_xor_ptr, stream):
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * n_cols), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(n_cols):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[n_cols])
+    dev.check(fn(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
+                 C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
+                 C.c_void_p(lk_double_u8_ptr or None), C.c_void_p(lk_xor_ptr or None), stream))
+
+
+def witgen_jal(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0,
+               lk_double_u8_ptr: int = 0, lk_xor_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_jal (GpuWitgenKind::Jal): `cols` = the 13 column ids in JalColumnMap field order followed by num_cols"""
+    _witgen_4tab(dev, dev.L.ceno_hip_witgen_jal, 13, cols, records_ptr, num_records, indices_ptr, n, witness_ptr, rows_padded, shard_offset, fetch_base_pc,
+                 fetch_num_slots, lk_dynamic_ptr, lk_fetch_ptr, lk_double_u8_ptr, lk_xor_ptr, stream)
+
+
+def witgen_auipc(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+                 shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0,
+                 lk_double_u8_ptr: int = 0, lk_xor_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_auipc (GpuWitgenKind::Auipc): `cols` = the 21 column ids in AuipcColumnMap field order followed by num_cols"""
+    _witgen_4tab(dev, dev.L.ceno_hip_witgen_auipc, 21, cols, records_ptr, num_records, indices_ptr, n, witness_ptr, rows_padded, shard_offset,
+                 fetch_base_pc, fetch_num_slots, lk_dynamic_ptr, lk_fetch_ptr, lk_double_u8_ptr, lk_xor_ptr, stream)
+
+
 class LuiColumnMap(C.Structure):
     """ceno_hip_lui_column_map: 16 column ids + num_cols"""
     _fields_ = [("cols", C.c_uint32 * 16), ("num_cols", C.c_uint32)]

@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI (I-type base).
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -236,33 +236,32 @@ int witgen_check(ceno_hip_ctx* ctx, const uint32_t* cols, int n_cols, uint32_t n
     return 0;
 }
 // The lookup counts go through per-XCD copies of the tables (zeroed scratch, L2-local atomics, one merge per table) unless
-// CENO_HIP_WITGEN_XCD=0; `launch(xcd_local, t0, t1, t2)` starts the chip's kernel on the tables it is given.  With tables the call
+// CENO_HIP_WITGEN_XCD=0; `launch(xcd_local, t0, t1, t2, t3)` starts the chip's kernel on the tables it is given.  With tables the call
 // synchronises the stream (the scratch goes back to the pool only after the stream has consumed it).
 struct LkTab {
     uint32_t* user;
     size_t slots;
 };
 template <class Launch>
-int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[3], Launch&& launch) {
+int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[4], Launch&& launch) {
     static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
-    const bool any = tabs[0].user || tabs[1].user || tabs[2].user;
+    const bool any = tabs[0].user || tabs[1].user || tabs[2].user || tabs[3].user;
     if (!(xcd_local && any && n > 0)) {
-        launch(false, tabs[0].user, tabs[1].user, tabs[2].user);
+        launch(false, tabs[0].user, tabs[1].user, tabs[2].user, tabs[3].user);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     }
-    size_t slots[3], total = 0;
-    for (int t = 0; t < 3; t++) total += slots[t] = tabs[t].user ? tabs[t].slots : 0;
+    size_t slots[4], total = 0;
+    for (int t = 0; t < 4; t++) total += slots[t] = tabs[t].user ? tabs[t].slots : 0;
     void* scratch = nullptr;
     TRY(ctx_alloc(ctx, 8 * total * sizeof(uint32_t), &scratch));
-    uint32_t* copy[3];
+    uint32_t* copy[4];
     copy[0] = (uint32_t*)scratch;
-    copy[1] = copy[0] + 8 * slots[0];
-    copy[2] = copy[1] + 8 * slots[1];
+    for (int t = 1; t < 4; t++) copy[t] = copy[t - 1] + 8 * slots[t - 1];
     hipError_t e = hipMemsetAsync(scratch, 0, 8 * total * sizeof(uint32_t), st);
     if (e == hipSuccess) {
-        launch(true, tabs[0].user ? copy[0] : nullptr, tabs[1].user ? copy[1] : nullptr, tabs[2].user ? copy[2] : nullptr);
-        for (int t = 0; t < 3; t++)
+        launch(true, tabs[0].user ? copy[0] : nullptr, tabs[1].user ? copy[1] : nullptr, tabs[2].user ? copy[2] : nullptr, tabs[3].user ? copy[3] : nullptr);
+        for (int t = 0; t < 4; t++)
             if (tabs[t].user) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((slots[t] + NT - 1) / NT)), dim3(NT), 0, st, copy[t], slots[t], tabs[t].user);
         e = hipGetLastError();
     }
@@ -465,10 +464,118 @@ __global__ void __launch_bounds__(NT) k_witgen_lui(LuiMap m, const unsigned char
     }
 }
 
+// ---- JAL (JalInstruction, ceno_zkvm/src/instructions/riscv/jump/jal_v2.rs:99-127; J-instruction base j_insn.rs:58-73: state with next_pc,
+// rd write, fetch): rd = pc + 4 as four bytes, range-checked pairwise in the double-byte table (key a << 8 | b), the top byte also XORed
+// with 0xC0 in the XOR table (PC_BITS = 30: the two bits above the program counter's range must be clear).  13 mapped columns.
+constexpr uint32_t PC_MSB_MASK = 0xC0;  // sum of 2^x for x in PC_BITS - 24 .. 8 (riscv/constants.rs:29, jal_v2.rs:120-124)
+struct JalMap {  // ceno_hip_jal_column_map = ceno_gpu's JalColumnMap (chips/jal.rs:21-31)
+    uint32_t pc, next_pc, ts;
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[4];
+    uint32_t num_cols;
+};
+static_assert(sizeof(JalMap) == sizeof(ceno_hip_jal_column_map), "column map layout");
+constexpr int JAL_COLS = 13;
+constexpr int OFF_PC_AFTER = 12;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_jal(JalMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                   uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                   uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    lk_du8 = xcd_copy<XCD_LOCAL>(lk_du8, LOGIC_SLOTS);
+    lk_xor = xcd_copy<XCD_LOCAL>(lk_xor, LOGIC_SLOTS);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<JAL_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint32_t pc_after = *reinterpret_cast<const uint32_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES + OFF_PC_AFTER);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.next_pc, pc_after);
+        o.put(m.ts, ts);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t b0 = st.rd_after & 0xff, b1 = (st.rd_after >> 8) & 0xff, b2 = (st.rd_after >> 16) & 0xff, b3 = st.rd_after >> 24;
+        o.put(m.rd_bytes[0], b0);
+        o.put(m.rd_bytes[1], b1);
+        o.put(m.rd_bytes[2], b2);
+        o.put(m.rd_bytes[3], b3);
+        lk_count<XCD_LOCAL>(lk_du8, (b0 << 8) + b1);  // assert_double_u8 (lk_multiplicity.rs:200-203)
+        lk_count<XCD_LOCAL>(lk_du8, (b2 << 8) + b3);
+        lk_count<XCD_LOCAL>(lk_xor, b3 | (PC_MSB_MASK << 8));
+    }
+}
+
+// ---- AUIPC (AuipcInstruction, ceno_zkvm/src/instructions/riscv/auipc.rs:149-187): the I-instruction base (rs1 = x0 as decoded), rd as four
+// bytes (double-byte table), the middle bytes 1, 2 of pc and the three bytes of imm = insn.imm as u32 >> 8 (imm_internal, AUIPC:
+// tables/program.rs:119-124) each as a byte of the dynamic table, and pc's top byte XORed with 0xC0.  21 mapped columns.
+struct AuipcMap {  // ceno_hip_auipc_column_map = ceno_gpu's AuipcColumnMap (chips/auipc.rs:28-44)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[4], pc_limbs[2], imm_limbs[3];
+    uint32_t num_cols;
+};
+static_assert(sizeof(AuipcMap) == sizeof(ceno_hip_auipc_column_map), "column map layout");
+constexpr int AUIPC_COLS = 21;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_auipc(AuipcMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                     uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                     uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    lk_du8 = xcd_copy<XCD_LOCAL>(lk_du8, LOGIC_SLOTS);
+    lk_xor = xcd_copy<XCD_LOCAL>(lk_xor, LOGIC_SLOTS);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<AUIPC_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t b0 = st.rd_after & 0xff, b1 = (st.rd_after >> 8) & 0xff, b2 = (st.rd_after >> 16) & 0xff, b3 = st.rd_after >> 24;
+        o.put(m.rd_bytes[0], b0);
+        o.put(m.rd_bytes[1], b1);
+        o.put(m.rd_bytes[2], b2);
+        o.put(m.rd_bytes[3], b3);
+        lk_count<XCD_LOCAL>(lk_du8, (b0 << 8) + b1);
+        lk_count<XCD_LOCAL>(lk_du8, (b2 << 8) + b3);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {  // pc bytes 1, 2
+            const uint32_t v = (st.pc >> (8 * (k + 1))) & 0xff;
+            o.put(m.pc_limbs[k], v);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + v);
+        }
+        const uint32_t imm = st.imm >> 8;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t v = (imm >> (8 * k)) & 0xff;
+            o.put(m.imm_limbs[k], v);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + v);
+        }
+        lk_count<XCD_LOCAL>(lk_xor, (st.pc >> 24) | (PC_MSB_MASK << 8));
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
-    [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2) {                                                             \
+    [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
         (void)t2;                                                                                                         \
+        (void)t3;                                                                                                         \
         if (xcd) hipLaunchKernelGGL((KERNEL<true>), dim3(grid), dim3(NT), 0, st, __VA_ARGS__);                            \
         else hipLaunchKernelGGL((KERNEL<false>), dim3(grid), dim3(NT), 0, st, __VA_ARGS__);                               \
     }
@@ -480,8 +587,8 @@ int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);  // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
-    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*) {
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
         if (sub && xcd) hipLaunchKernelGGL((k_witgen_arith<true, true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else if (sub) hipLaunchKernelGGL((k_witgen_arith<true, false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else if (xcd) hipLaunchKernelGGL((k_witgen_arith<false, true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
@@ -497,7 +604,7 @@ int witgen_logic(ceno_hip_ctx* ctx, const LogicMap* map, const void* recs, size_
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
 }
 
@@ -509,7 +616,7 @@ int witgen_logic_i(ceno_hip_ctx* ctx, const LogicIMap* map, const void* recs, si
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic_i, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
 }
 
@@ -520,7 +627,7 @@ int witgen_addi(ceno_hip_ctx* ctx, const AddiMap* map, const void* recs, size_t 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_addi, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 
@@ -531,8 +638,37 @@ int witgen_lui(ceno_hip_ctx* ctx, const LuiMap* map, const void* recs, size_t nu
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[3] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_lui, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
+}
+int witgen_jal(ceno_hip_ctx* ctx, const JalMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+               uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor,
+               ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, JAL_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
+        if (xcd) hipLaunchKernelGGL((k_witgen_jal<true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+        else hipLaunchKernelGGL((k_witgen_jal<false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+    });
+}
+
+int witgen_auipc(ceno_hip_ctx* ctx, const AuipcMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8,
+                 uint32_t* lk_xor, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, AUIPC_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
+        if (xcd) hipLaunchKernelGGL((k_witgen_auipc<true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+        else hipLaunchKernelGGL((k_witgen_auipc<false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+    });
 }
 #undef WITGEN_LAUNCH
 
@@ -565,6 +701,24 @@ int ceno_hip_witgen_addi(ceno_hip_ctx* ctx, const ceno_hip_addi_column_map* map,
     CHECK_ARG(ctx, ctx, "NULL context");
     return witgen_addi(ctx, reinterpret_cast<const AddiMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_jal(ceno_hip_ctx* ctx, const ceno_hip_jal_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, uint32_t* dev_lk_double_u8,
+                        uint32_t* dev_lk_xor, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_jal(ctx, reinterpret_cast<const JalMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                      fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_double_u8, dev_lk_xor, s);
+}
+
+int ceno_hip_witgen_auipc(ceno_hip_ctx* ctx, const ceno_hip_auipc_column_map* map, const void* dev_step_records, size_t num_records,
+                          const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                          uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                          uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_auipc(ctx, reinterpret_cast<const AuipcMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                        fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_double_u8, dev_lk_xor, s);
 }
 
 int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,

@@ -412,6 +412,32 @@ int ceno_hip_witgen_addi(ceno_hip_ctx* ctx, const ceno_hip_addi_column_map* map,
                          const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
                          uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
                          uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* JAL: hal.witgen.witgen_jal (GpuWitgenKind::Jal; column map chips/jal.rs:10-32; CPU assignment riscv/jump/jal_v2.rs:99-127 + j_insn.rs:58-73):
+ * state with next_pc, rd = pc + 4 as four bytes.  dev_lk_double_u8: the 2^16 counters of LookupTable::DoubleU8, key a << 8 | b
+ * (lk_multiplicity.rs:200-203); dev_lk_xor: those of LookupTable::Xor, key a | b << 8 (the top byte of rd against 0xC0).  13 mapped columns.
+ * AUIPC: hal.witgen.witgen_auipc (GpuWitgenKind::Auipc; chips/auipc.rs:10-45; riscv/auipc.rs:149-187): the I-instruction base, rd as four
+ * bytes, bytes 1, 2 of pc, the three bytes of insn.imm as u32 >> 8, the top byte of pc against 0xC0.  21 mapped columns. */
+typedef struct ceno_hip_jal_column_map {
+    uint32_t pc, next_pc, ts;
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[4];
+    uint32_t num_cols;
+} ceno_hip_jal_column_map;
+typedef struct ceno_hip_auipc_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rd_bytes[4], pc_limbs[2], imm_limbs[3];
+    uint32_t num_cols;
+} ceno_hip_auipc_column_map;
+int ceno_hip_witgen_jal(ceno_hip_ctx* ctx, const ceno_hip_jal_column_map* map, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, uint32_t* dev_lk_double_u8,
+                        uint32_t* dev_lk_xor, ceno_hip_stream s);
+int ceno_hip_witgen_auipc(ceno_hip_ctx* ctx, const ceno_hip_auipc_column_map* map, const void* dev_step_records, size_t num_records,
+                          const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                          uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                          uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s);
 /* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
  * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
 typedef struct ceno_hip_lui_column_map {

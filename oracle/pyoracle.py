@@ -829,6 +829,52 @@ def witgen_addi(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_JAL, INSN_AUIPC = 26, 43  # InsnKind::JAL; AUIPC follows LUI (u16limb_circuit feature)
+
+
+def step_records_j(cycles, pcs, pcs_after, kind, rd, imms, rd_before, rd_after, prev_cycles) -> np.ndarray:
+    """StepRecord::new_j_instruction for every entry -> (n, 136) uint8 array"""
+    n = len(cycles)
+    out = np.zeros((n, lib().orc_step_record_bytes()), dtype=np.uint8)
+    L = lib()
+    L.orc_step_record_j.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.orc_step_record_j.restype = None
+    for i in range(n):
+        L.orc_step_record_j(out[i].ctypes.data, int(cycles[i]), int(pcs[i]), int(pcs_after[i]), kind, rd, int(imms[i]), int(rd_before[i]), int(rd_after[i]),
+                            int(prev_cycles[i]))
+    return out
+
+
+def _witgen_4tab(fn, n_cols, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots):
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (n_cols + 1,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[n_cols])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    lk2 = np.zeros(1 << 16, dtype=np.uint32)
+    lkx = np.zeros(1 << 16, dtype=np.uint32)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p]
+    fn.restype = C.c_int
+    rc = fn(cols.ctypes.data, recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots, out.ctypes.data,
+            lkd.ctypes.data, lkf.ctypes.data, lk2.ctypes.data, lkx.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"witgen rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots], lk2, lkx
+
+
+def witgen_jal(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_num_slots=0):
+    """CPU assignment of the JAL chip: (matrix, dynamic counts, fetch counts, double-u8 counts, xor counts)"""
+    return _witgen_4tab(lib().orc_witgen_jal, 13, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
+
+
+def witgen_auipc(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_num_slots=0):
+    """CPU assignment of the AUIPC chip: (matrix, dynamic counts, fetch counts, double-u8 counts, xor counts)"""
+    return _witgen_4tab(lib().orc_witgen_auipc, 21, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
+
+
 INSN_LUI = 42  # InsnKind::LUI (u16limb_circuit feature: after LHU = 41)
 LUI_COLMAP_FIELDS = 17
 

@@ -341,3 +341,105 @@ int orc_witgen_lui(const uint32_t* cols, const void* records, const uint32_t* in
     }
     return 0;
 }
+
+/* StepRecord::new_j_instruction (ceno_emul/src/tracer.rs:1285-1304): only rd is written; pc changes to the jump target */
+void orc_step_record_j(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rd, int32_t imm, uint32_t rd_before,
+                       uint32_t rd_after, uint64_t prev_cycle) {
+    orc_step_record r;
+    memset(&r, 0, sizeof(r));
+    r.cycle = cycle;
+    r.pc_before = pc;
+    r.pc_after = pc_after;
+    r.kind = kind; r.rd_idx = rd;
+    r.imm = imm;
+    r.has_rd = 1;
+    r.rd.addr = ((uint32_t)rd << 8) / 4; r.rd.before = rd_before; r.rd.after = rd_after; r.rd.previous_cycle = prev_cycle;
+    r.syscall_index = 0xFFFFFFFFu;
+    memcpy(out, &r, sizeof(r));
+}
+
+#define ORC_PC_MSB_MASK 0xC0u /* sum of 2^x, x = PC_BITS - 24 .. 7 with PC_BITS = 30 (riscv/constants.rs:29; jal_v2.rs:120-124, auipc.rs:180-184) */
+
+/* JalInstruction::assign_instance (riscv/jump/jal_v2.rs:99-127) over JInstructionConfig (j_insn.rs:58-73: pc, next_pc, ts, rd, fetch):
+ * rd.value.after as four bytes, assert_double_u8 per pair (key a << 8 | b, lk_multiplicity.rs:200-203), logic_u8::<XorTable>(byte 3, 0xC0).
+ * cols[14]: JalColumnMap field order (chips/jal.rs:21-31), num_cols last. */
+int orc_witgen_jal(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_double_u8, uint32_t* lk_xor) {
+    const uint32_t num_cols = cols[13];
+    for (int c = 0; c < 13; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = st->pc_after;
+        row[cols[2]] = ts;
+        const uint64_t p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[3]] = register_index(st->rd.addr);
+        row[cols[4]] = p;
+        row[cols[5]] = st->rd.before & 0xffff;
+        row[cols[6]] = st->rd.before >> 16;
+        assign_lt(row, cols + 7, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        uint32_t b[4];
+        for (int k = 0; k < 4; k++) row[cols[9 + k]] = b[k] = (st->rd.after >> (8 * k)) & 0xff;
+        if (lk_double_u8) { lk_double_u8[(b[0] << 8) + b[1]] += 1; lk_double_u8[(b[2] << 8) + b[3]] += 1; }
+        if (lk_xor) lk_xor[b[3] | (ORC_PC_MSB_MASK << 8)] += 1;
+    }
+    return 0;
+}
+
+/* AuipcInstruction::assign_instance (riscv/auipc.rs:149-187): the I-instruction base, rd bytes (double_u8 pairs), pc bytes 1 and 2 and the
+ * three bytes of imm_internal = insn.imm as u32 >> 8 (tables/program.rs:119-124), each assert_ux::<8>, and logic_u8::<XorTable>(pc byte 3, 0xC0).
+ * cols[22]: AuipcColumnMap field order (chips/auipc.rs:28-44), num_cols last. */
+int orc_witgen_auipc(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                     uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_double_u8, uint32_t* lk_xor) {
+    const uint32_t num_cols = cols[21];
+    for (int c = 0; c < 21; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rd.addr);
+        row[cols[7]] = p;
+        row[cols[8]] = st->rd.before & 0xffff;
+        row[cols[9]] = st->rd.before >> 16;
+        assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        uint32_t b[4];
+        for (int k = 0; k < 4; k++) row[cols[12 + k]] = b[k] = (st->rd.after >> (8 * k)) & 0xff;
+        if (lk_double_u8) { lk_double_u8[(b[0] << 8) + b[1]] += 1; lk_double_u8[(b[2] << 8) + b[3]] += 1; }
+        for (int k = 0; k < 2; k++) {
+            const uint32_t v = (st->pc_before >> (8 * (k + 1))) & 0xff;
+            lk_dyn(lk_dynamic, v, 8);
+            row[cols[16 + k]] = v;
+        }
+        const uint32_t imm = (uint32_t)st->imm >> 8;
+        for (int k = 0; k < 3; k++) {
+            const uint32_t v = (imm >> (8 * k)) & 0xff;
+            lk_dyn(lk_dynamic, v, 8);
+            row[cols[18 + k]] = v;
+        }
+        if (lk_xor) lk_xor[(st->pc_before >> 24) | (ORC_PC_MSB_MASK << 8)] += 1;
+    }
+    return 0;
+}

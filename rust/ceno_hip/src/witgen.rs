@@ -5,7 +5,8 @@
 //!
 //! The column maps are the `#[repr(C)]` structs of `ceno_hip_sys`, field for field those of `ceno_gpu::common::witgen::types`
 //! (`AddColumnMap` `chips/add.rs:29-46`, `SubColumnMap` `chips/sub.rs:28-45`, `LogicRColumnMap` `chips/logic_r.rs:25-42`,
-//! `AddiColumnMap` `chips/addi.rs:27-42`, `LogicIColumnMap` `chips/logic_i.rs:26-41`, `LuiColumnMap` `chips/lui.rs:29-41`): the
+//! `AddiColumnMap` `chips/addi.rs:27-42`, `LogicIColumnMap` `chips/logic_i.rs:26-41`, `LuiColumnMap` `chips/lui.rs:29-41`,
+//! `AuipcColumnMap` `chips/auipc.rs:28-44`, `JalColumnMap` `chips/jal.rs:21-31`): the
 //! dispatch arm builds them with the reference's own `extract_*_column_map` helpers and passes them through.
 use std::sync::Arc;
 
@@ -27,6 +28,10 @@ pub struct LkTables {
     pub fetch_base_pc: u32,
     pub fetch_num_slots: u32,
     pub logic: *mut u32,
+    /// `LookupTable::DoubleU8`: 2^16 counters, key `a << 8 | b` (AUIPC, JAL)
+    pub double_u8: *mut u32,
+    /// `LookupTable::Xor`: 2^16 counters, key `a | b << 8` (the program-counter range check of AUIPC and JAL)
+    pub xor: *mut u32,
 }
 
 /// The step records of a shard on the device and the steps that belong to one chip.
@@ -97,6 +102,22 @@ impl Witgen {
             sys::ceno_hip_witgen_logic_i(self.hal.ctx, map, kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
                                          steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
                                          lk.logic, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_auipc`
+    pub fn auipc(&self, map: &sys::ceno_hip_auipc_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_auipc(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                       lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, lk.double_u8, lk.xor,
+                                       raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_jal`
+    pub fn jal(&self, map: &sys::ceno_hip_jal_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_jal(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                     lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, lk.double_u8, lk.xor,
+                                     raw_stream(steps.stream))
         })
     }
     /// `witgen_lui`

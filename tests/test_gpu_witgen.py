@@ -319,3 +319,39 @@ def test_lui_witness_and_lookups_match_cpu_assignment(dev, n, rows):
     mapped = sorted(cols[:16])
     assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
     assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+@pytest.mark.parametrize("chip", ["jal", "auipc"])
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (400, 512)])
+def test_jal_and_auipc_witness_and_lookups_match_cpu_assignment(dev, chip, n, rows):
+    """JAL (13 columns) and AUIPC (21 columns): dynamic-range, fetch, double-byte and XOR table multiplicities"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _auipc_steps, _jal_steps
+
+    rng = np.random.default_rng(18)
+    if chip == "jal":
+        d = _jal_steps(n)
+        recs = po.step_records_j(d["cycles"], d["pcs"], d["pcs_after"], po.INSN_JAL, 4, d["imms"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+        ncol, fn_gpu, fn_cpu = 13, api.witgen_jal, po.witgen_jal
+    else:
+        d = _auipc_steps(n)
+        recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_AUIPC, 0, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+        ncol, fn_gpu, fn_cpu = 21, api.witgen_auipc, po.witgen_auipc
+    total = ncol + 5
+    cols = list(rng.permutation(total)[:ncol]) + [total]
+    idx = np.arange(n)
+    slots = 1 << 12
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full((total * rows,), -1, dtype=torch.int64, device="cuda:0")
+    tabs = [torch.zeros(sz, dtype=torch.int32, device="cuda:0") for sz in (1 << 17, slots, 1 << 16, 1 << 16)]
+    fn_gpu(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, slots, *[t.data_ptr() for t in tabs])
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(total, rows)
+    exp, *etabs = fn_cpu(cols, recs, idx, 0, 0x1000, slots)
+    mapped = sorted(cols[:ncol])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    for t, e in zip(tabs, etabs):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), e)

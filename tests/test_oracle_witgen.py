@@ -247,3 +247,69 @@ def test_lui_oracle_rows_and_lookups():
         np.add.at(exp, (1 << 16) + m[:, cols[d0]], 1)
         np.add.at(exp, (1 << 13) + m[:, cols[d0 + 1]], 1)
     assert np.array_equal(lkd.astype(np.int64), exp) and np.all(lkf == 1)
+
+
+def _jal_steps(n):
+    """chips/jal.rs:66-86: pc = 0x1000 + 4 i, a jump offset, rd = pc + 4"""
+    i = np.arange(n, dtype=np.int64)
+    pc = 0x1000 + 4 * i
+    pc[: min(n, 3)] = [0x3FFFFFF8, 0x00FFFFFC, 0x1000][: min(n, 3)]       # top byte 0x3f (the XOR check's edge), a carry into byte 3
+    off = ((i * 52) % 4096) - 2048
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=pc.astype(np.uint64), pcs_after=((pc + off) & 0xFFFFFFFF).astype(np.uint64), imms=off,
+                rd_before=(i % 200).astype(np.uint64), rd_after=((pc + 4) & 0xFFFFFFFF).astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def _auipc_steps(n):
+    """chips/auipc.rs:81-99: imm = (i % 2^20) << 12, rd = pc + imm"""
+    i = np.arange(n, dtype=np.int64)
+    pc = 0x1000 + 4 * i
+    pc[: min(n, 2)] = [0x3FABCDE0, 0x00010000][: min(n, 2)]
+    imm = ((i * 4099 + 7) % (1 << 20)) << 12
+    imm_i32 = ((imm + (1 << 31)) % (1 << 32)) - (1 << 31)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=pc.astype(np.uint64), imms=imm_i32, rs1_vals=np.zeros(n, dtype=np.uint64),
+                rd_before=(i % 200).astype(np.uint64), rd_after=((pc + imm) & 0xFFFFFFFF).astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def test_jal_oracle_rows_and_lookups():
+    n = 400
+    d = _jal_steps(n)
+    recs = po.step_records_j(d["cycles"], d["pcs"], d["pcs_after"], po.INSN_JAL, 4, d["imms"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(16)
+    cols = list(rng.permutation(17)[:13]) + [17]
+    got, lkd, lkf, lk2, lkx = po.witgen_jal(cols, recs, np.arange(n), 0, 0x1000, 1 << 20)
+    m = got.astype(np.int64)
+    assert np.array_equal(m[:, cols[0]], d["pcs"].astype(np.int64)) and np.array_equal(m[:, cols[1]], d["pcs_after"].astype(np.int64))
+    assert np.array_equal(sum(m[:, cols[9 + b]] << (8 * b) for b in range(4)), d["pcs"].astype(np.int64) + 4)       # rd = pc + 4
+    assert np.array_equal(m[:, cols[4]] - (m[:, cols[2]] + 2), m[:, cols[7]] + (m[:, cols[8]] << 16) - (1 << 29))
+    e2, ex = np.zeros(1 << 16, dtype=np.int64), np.zeros(1 << 16, dtype=np.int64)
+    np.add.at(e2, (m[:, cols[9]] << 8) + m[:, cols[10]], 1)
+    np.add.at(e2, (m[:, cols[11]] << 8) + m[:, cols[12]], 1)
+    np.add.at(ex, m[:, cols[12]] | (0xC0 << 8), 1)
+    assert np.array_equal(lk2.astype(np.int64), e2) and np.array_equal(lkx.astype(np.int64), ex)
+    assert int(lkd.sum()) == 2 * n and int(lkf.sum()) == n - 2    # two program counters lie outside the fetch table's slots
+
+
+def test_auipc_oracle_rows_and_lookups():
+    n = 400
+    d = _auipc_steps(n)
+    recs = po.step_records_i(d["cycles"], d["pcs"], po.INSN_AUIPC, 0, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(17)
+    cols = list(rng.permutation(26)[:21]) + [26]
+    got, lkd, lkf, lk2, lkx = po.witgen_auipc(cols, recs, np.arange(n), 0, 0x1000, 1 << 20)
+    m = got.astype(np.int64)
+    pc = d["pcs"].astype(np.int64)
+    imm24 = (d["imms"].astype(np.int64) & 0xFFFFFFFF) >> 8
+    assert np.array_equal(sum(m[:, cols[12 + b]] << (8 * b) for b in range(4)), d["rd_after"].astype(np.int64))
+    assert np.array_equal(m[:, cols[16]], (pc >> 8) & 0xFF) and np.array_equal(m[:, cols[17]], (pc >> 16) & 0xFF)
+    assert np.array_equal(sum(m[:, cols[18 + b]] << (8 * b) for b in range(3)), imm24)
+    # the circuit's identity: rd = pc + (imm24 << 8) mod 2^32
+    assert np.array_equal(d["rd_after"].astype(np.int64), (pc + (imm24 << 8)) & 0xFFFFFFFF)
+    ed = np.zeros(1 << 17, dtype=np.int64)
+    for c in (16, 17, 18, 19, 20):
+        np.add.at(ed, (1 << 8) + m[:, cols[c]], 1)
+    for d0 in (4, 10):
+        np.add.at(ed, (1 << 16) + m[:, cols[d0]], 1)
+        np.add.at(ed, (1 << 13) + m[:, cols[d0 + 1]], 1)
+    ex = np.zeros(1 << 16, dtype=np.int64)
+    np.add.at(ex, (pc >> 24) | (0xC0 << 8), 1)
+    assert np.array_equal(lkd.astype(np.int64), ed) and np.array_equal(lkx.astype(np.int64), ex) and int(lk2.sum()) == 2 * n
