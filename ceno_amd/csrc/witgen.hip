@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -571,6 +571,70 @@ __global__ void __launch_bounds__(NT) k_witgen_auipc(AuipcMap m, const unsigned 
     }
 }
 
+// ---- SLT / SLTU (SetLessThanInstruction, ceno_zkvm/src/instructions/riscv/slt/slt_circuit_v2.rs:86-119): the R-instruction base, rs1 and rs2 as
+// u16 limbs, and the UIntLimbsLT comparison (gadgets/signed_limbs.rs:150-236): cmp_lt, the most significant limbs as FIELD elements of
+// their signed value (limb - 2^16 when negative in a signed comparison), a one-hot marker of the most significant differing limb and
+// the (positive) difference there; u16 range lookups of diff - 1 (or 0 when equal) and of the two shifted top limbs.  26 mapped columns.
+constexpr uint64_t GOLDILOCKS_P = 0xFFFFFFFF00000001ULL;
+struct SltMap {  // ceno_hip_slt_column_map = ceno_gpu's SltColumnMap (chips/slt.rs:33-55)
+    uint32_t rs1_limbs[2], rs2_limbs[2], cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t num_cols;
+};
+static_assert(sizeof(SltMap) == sizeof(ceno_hip_slt_column_map), "column map layout");
+constexpr int SLT_COLS = 26;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_slt(SltMap m, int is_signed, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                   uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                   uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<SLT_COLS>(o, &m.rs1_limbs[0]);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t a0 = st.rs1_val & 0xffff, a1 = st.rs1_val >> 16, b0 = st.rs2_val & 0xffff, b1 = st.rs2_val >> 16;
+        o.put(m.rs1_limbs[0], a0);
+        o.put(m.rs1_limbs[1], a1);
+        o.put(m.rs2_limbs[0], b0);
+        o.put(m.rs2_limbs[1], b1);
+        // run_cmp (signed_limbs.rs:226-236): most significant differing limb; the sign bits flip the outcome
+        const bool a_neg = is_signed && (a1 >> 15), b_neg = is_signed && (b1 >> 15);
+        const int diff_idx = a1 != b1 ? 1 : (a0 != b0 ? 0 : 2);
+        const bool lt = diff_idx == 2 ? false : (((diff_idx == 1 ? a1 < b1 : a0 < b0) ? 1 : 0) ^ (a_neg ? 1 : 0) ^ (b_neg ? 1 : 0)) != 0;
+        o.put(m.cmp_lt, lt ? 1 : 0);
+        o.put(m.diff_marker[0], diff_idx == 0);
+        o.put(m.diff_marker[1], diff_idx == 1);
+        // top limbs as signed values; in the field a negative one is p - (2^16 - limb)
+        const int64_t sa = a_neg ? (int64_t)a1 - 65536 : (int64_t)a1, sb = b_neg ? (int64_t)b1 - 65536 : (int64_t)b1;
+        o.put(m.a_msb_f, sa < 0 ? GOLDILOCKS_P - (uint64_t)(-sa) : (uint64_t)sa);
+        o.put(m.b_msb_f, sb < 0 ? GOLDILOCKS_P - (uint64_t)(-sb) : (uint64_t)sb);
+        uint32_t diff_val = 0;
+        if (diff_idx == 1) diff_val = (uint32_t)(lt ? sb - sa : sa - sb) & 0xffff;
+        else if (diff_idx == 0) diff_val = (lt ? b0 - a0 : a0 - b0) & 0xffff;
+        o.put(m.diff_val, diff_val);
+        constexpr uint32_t U16 = 1u << 16;
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (diff_idx == 2 ? 0u : ((diff_val - 1) & 0xffff)));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (a_neg ? a1 - 0x8000u : a1 + ((uint32_t)(is_signed != 0) << 15)));
+        lk_count<XCD_LOCAL>(lk_dyn, U16 + (b_neg ? b1 - 0x8000u : b1 + ((uint32_t)(is_signed != 0) << 15)));
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -670,6 +734,16 @@ int witgen_auipc(ceno_hip_ctx* ctx, const AuipcMap* map, const void* recs, size_
         else hipLaunchKernelGGL((k_witgen_auipc<false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
     });
 }
+int witgen_slt(ceno_hip_ctx* ctx, const SltMap* map, int is_signed, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+               uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->rs1_limbs[0], SLT_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slt, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
+}
 #undef WITGEN_LAUNCH
 
 }  // namespace
@@ -719,6 +793,15 @@ int ceno_hip_witgen_auipc(ceno_hip_ctx* ctx, const ceno_hip_auipc_column_map* ma
     CHECK_ARG(ctx, ctx, "NULL context");
     return witgen_auipc(ctx, reinterpret_cast<const AuipcMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
                         fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_double_u8, dev_lk_xor, s);
+}
+
+int ceno_hip_witgen_slt(ceno_hip_ctx* ctx, const ceno_hip_slt_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, is_signed == 0 || is_signed == 1, "witgen_slt: is_signed is 1 (SLT) or 0 (SLTU)");
+    return witgen_slt(ctx, reinterpret_cast<const SltMap*>(map), is_signed, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                      fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,

@@ -438,6 +438,20 @@ int ceno_hip_witgen_auipc(ceno_hip_ctx* ctx, const ceno_hip_auipc_column_map* ma
                           const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                           uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
                           uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s);
+/* SLT / SLTU: hal.witgen.witgen_slt (GpuWitgenKind::Slt(is_signed): 1 = SLT, 0 = SLTU; column map chips/slt.rs:12-56; CPU assignment
+ * riscv/slt/slt_circuit_v2.rs:86-119 + gadgets/signed_limbs.rs:150-236).  a_msb_f / b_msb_f are FIELD elements: a top limb that is
+ * negative in a signed comparison is stored as p - (2^16 - limb) (Goldilocks p).  26 mapped columns, the comparison's ten first. */
+typedef struct ceno_hip_slt_column_map {
+    uint32_t rs1_limbs[2], rs2_limbs[2], cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t num_cols;
+} ceno_hip_slt_column_map;
+int ceno_hip_witgen_slt(ceno_hip_ctx* ctx, const ceno_hip_slt_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
  * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
 typedef struct ceno_hip_lui_column_map {

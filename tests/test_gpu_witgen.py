@@ -355,3 +355,33 @@ def test_jal_and_auipc_witness_and_lookups_match_cpu_assignment(dev, chip, n, ro
     assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
     for t, e in zip(tabs, etabs):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), e)
+
+
+@pytest.mark.parametrize("signed", [True, False])
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (700, 1024)])
+def test_slt_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
+    """SLT / SLTU on the reference test's step data (chips/slt.rs:94-118) plus sign / equality / limb-boundary edge cases; the negative top
+    limbs are Goldilocks field elements p - (2^16 - limb)"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _slt_steps
+
+    d = _slt_steps(n, signed)
+    recs = po.step_records_r(d["cycles"], d["pcs"], po.INSN_SLT if signed else po.INSN_SLTU, 2, 3, 4, d["rs1_vals"], d["rs2_vals"], d["rd_before"],
+                             d["rd_after"], d["prev_cycles"])
+    rng = np.random.default_rng(20)
+    cols = list(rng.permutation(30)[:26]) + [30]
+    idx = np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full((30 * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_slt(dev, cols, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(30, rows)
+    exp, elkd, elkf = po.witgen_slt(cols, signed, recs, idx, 0, 0x1000, n)
+    mapped = sorted(cols[:26])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)

@@ -313,3 +313,66 @@ def test_auipc_oracle_rows_and_lookups():
     ex = np.zeros(1 << 16, dtype=np.int64)
     np.add.at(ex, (pc >> 24) | (0xC0 << 8), 1)
     assert np.array_equal(lkd.astype(np.int64), ed) and np.array_equal(lkx.astype(np.int64), ex) and int(lk2.sum()) == 2 * n
+
+
+P_GL = (1 << 64) - (1 << 32) + 1
+
+
+def _slt_steps(n, signed):
+    """chips/slt.rs:94-118: rs1 = 137 i - 500, rs2 = 89 i - 300 (mixing signs), plus edge cases"""
+    i = np.arange(n, dtype=np.int64)
+    a = (i * 137 - 500) & 0xFFFFFFFF
+    b = (i * 89 - 300) & 0xFFFFFFFF
+    edge = [(0, 0), (5, 5), (0x80000000, 0x7FFFFFFF), (0x7FFFFFFF, 0x80000000), (0xFFFFFFFF, 0), (0, 0xFFFFFFFF), (0x00010000, 0x0000FFFF),
+            (0x8000FFFF, 0x80000000), (0xFFFF0000, 0xFFFF0001), (0x12340000, 0x12340000)]
+    for k, (x, y) in enumerate(edge[:n]):
+        a[k], b[k] = x, y
+    if signed:
+        sa, sb = np.where(a >> 31, a - (1 << 32), a), np.where(b >> 31, b - (1 << 32), b)
+        lt = (sa < sb).astype(np.uint64)
+    else:
+        lt = (a < b).astype(np.uint64)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=a.astype(np.uint64), rs2_vals=b.astype(np.uint64),
+                rd_before=(i % 200).astype(np.uint64), rd_after=lt, prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("signed", [True, False])
+def test_slt_oracle_satisfies_the_comparison_gadget(signed):
+    """SLT / SLTU (slt_circuit_v2.rs:86-119): the columns satisfy the UIntLimbsLT constraints as the circuit states them
+    (signed_limbs.rs: the marker selects the most significant differing limb, diff_val is the positive difference there, cmp_lt = rd)"""
+    n = 700
+    d = _slt_steps(n, signed)
+    recs = _records(d, po.INSN_SLT if signed else po.INSN_SLTU)
+    rng = np.random.default_rng(19)
+    cols = list(rng.permutation(32)[:26]) + [32]
+    got, lkd, lkf = po.witgen_slt(cols, signed, recs, np.arange(n), 0, 0x1000, n)
+    g = [[int(v) for v in row] for row in got]
+    exp = np.zeros(1 << 17, dtype=np.int64)
+    for r in range(n):
+        row = g[r]
+        a = [row[cols[0]], row[cols[1]]]
+        b = [row[cols[2]], row[cols[3]]]
+        assert a[0] | (a[1] << 16) == int(d["rs1_vals"][r]) and b[0] | (b[1] << 16) == int(d["rs2_vals"][r])
+        lt, am, bm, mk, dv = row[cols[4]], row[cols[5]], row[cols[6]], [row[cols[7]], row[cols[8]]], row[cols[9]]
+        assert lt == int(d["rd_after"][r])                                       # rd_written = is_lt
+        # the top limbs as field elements of the signed values
+        sa = a[1] - 65536 if (signed and a[1] >> 15) else a[1]
+        sb = b[1] - 65536 if (signed and b[1] >> 15) else b[1]
+        assert am == sa % P_GL and bm == sb % P_GL
+        # marker: one-hot on the most significant differing limb (or all zero when equal), diff positive in the direction cmp_lt says
+        vals_a, vals_b = [a[0], sa], [b[0], sb]
+        if a == b:
+            assert mk == [0, 0] and dv == 0 and lt == 0
+            exp[(1 << 16) + 0] += 1
+        else:
+            k = 1 if a[1] != b[1] else 0
+            assert mk == [int(k == 0), int(k == 1)]
+            diff = (vals_b[k] - vals_a[k]) if lt else (vals_a[k] - vals_b[k])
+            assert 0 < diff < (1 << 16) and dv == diff
+            exp[(1 << 16) + diff - 1] += 1
+        for limb, neg in ((a[1], signed and a[1] >> 15), (b[1], signed and b[1] >> 15)):
+            exp[(1 << 16) + (limb - 0x8000 if neg else limb + (0x8000 if signed else 0))] += 1
+        for d0 in (14, 18, 24):
+            exp[(1 << 16) + row[cols[d0]]] += 1
+            exp[(1 << 13) + row[cols[d0 + 1]]] += 1
+    assert np.array_equal(lkd.astype(np.int64), exp) and np.all(lkf == 1)
