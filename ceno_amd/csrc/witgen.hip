@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -576,6 +576,31 @@ __global__ void __launch_bounds__(NT) k_witgen_auipc(AuipcMap m, const unsigned 
 // their signed value (limb - 2^16 when negative in a signed comparison), a one-hot marker of the most significant differing limb and
 // the (positive) difference there; u16 range lookups of diff - 1 (or 0 when equal) and of the two shifted top limbs.  26 mapped columns.
 constexpr uint64_t GOLDILOCKS_P = 0xFFFFFFFF00000001ULL;
+// UIntLimbsLT::assign (gadgets/signed_limbs.rs:150-222) over run_cmp (:226-236) for two 32-bit values as u16 limbs (a0, a1), (b0, b1)
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void emit_uint_lt(const Row& o, uint32_t cmp_lt_col, uint32_t a_msb_col, uint32_t b_msb_col, const uint32_t (&marker_cols)[2],
+                                             uint32_t diff_val_col, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, bool is_signed, uint32_t* lk_dyn) {
+    // most significant differing limb; the sign bits flip the outcome
+    const bool a_neg = is_signed && (a1 >> 15), b_neg = is_signed && (b1 >> 15);
+    const int diff_idx = a1 != b1 ? 1 : (a0 != b0 ? 0 : 2);
+    const bool lt = diff_idx == 2 ? false : (((diff_idx == 1 ? a1 < b1 : a0 < b0) ? 1 : 0) ^ (a_neg ? 1 : 0) ^ (b_neg ? 1 : 0)) != 0;
+    o.put(cmp_lt_col, lt ? 1 : 0);
+    o.put(marker_cols[0], diff_idx == 0);
+    o.put(marker_cols[1], diff_idx == 1);
+    // top limbs as signed values; in the field a negative one is p - (2^16 - limb)
+    const int64_t sa = a_neg ? (int64_t)a1 - 65536 : (int64_t)a1, sb = b_neg ? (int64_t)b1 - 65536 : (int64_t)b1;
+    o.put(a_msb_col, sa < 0 ? GOLDILOCKS_P - (uint64_t)(-sa) : (uint64_t)sa);
+    o.put(b_msb_col, sb < 0 ? GOLDILOCKS_P - (uint64_t)(-sb) : (uint64_t)sb);
+    uint32_t diff_val = 0;
+    if (diff_idx == 1) diff_val = (uint32_t)(lt ? sb - sa : sa - sb) & 0xffff;
+    else if (diff_idx == 0) diff_val = (lt ? b0 - a0 : a0 - b0) & 0xffff;
+    o.put(diff_val_col, diff_val);
+    constexpr uint32_t U16 = 1u << 16;
+    lk_count<XCD_LOCAL>(lk_dyn, U16 + (diff_idx == 2 ? 0u : ((diff_val - 1) & 0xffff)));
+    lk_count<XCD_LOCAL>(lk_dyn, U16 + (a_neg ? a1 - 0x8000u : a1 + ((uint32_t)is_signed << 15)));
+    lk_count<XCD_LOCAL>(lk_dyn, U16 + (b_neg ? b1 - 0x8000u : b1 + ((uint32_t)is_signed << 15)));
+}
+
 struct SltMap {  // ceno_hip_slt_column_map = ceno_gpu's SltColumnMap (chips/slt.rs:33-55)
     uint32_t rs1_limbs[2], rs2_limbs[2], cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
     uint32_t pc, ts;
@@ -613,25 +638,49 @@ __global__ void __launch_bounds__(NT) k_witgen_slt(SltMap m, int is_signed, cons
         o.put(m.rs1_limbs[1], a1);
         o.put(m.rs2_limbs[0], b0);
         o.put(m.rs2_limbs[1], b1);
-        // run_cmp (signed_limbs.rs:226-236): most significant differing limb; the sign bits flip the outcome
-        const bool a_neg = is_signed && (a1 >> 15), b_neg = is_signed && (b1 >> 15);
-        const int diff_idx = a1 != b1 ? 1 : (a0 != b0 ? 0 : 2);
-        const bool lt = diff_idx == 2 ? false : (((diff_idx == 1 ? a1 < b1 : a0 < b0) ? 1 : 0) ^ (a_neg ? 1 : 0) ^ (b_neg ? 1 : 0)) != 0;
-        o.put(m.cmp_lt, lt ? 1 : 0);
-        o.put(m.diff_marker[0], diff_idx == 0);
-        o.put(m.diff_marker[1], diff_idx == 1);
-        // top limbs as signed values; in the field a negative one is p - (2^16 - limb)
-        const int64_t sa = a_neg ? (int64_t)a1 - 65536 : (int64_t)a1, sb = b_neg ? (int64_t)b1 - 65536 : (int64_t)b1;
-        o.put(m.a_msb_f, sa < 0 ? GOLDILOCKS_P - (uint64_t)(-sa) : (uint64_t)sa);
-        o.put(m.b_msb_f, sb < 0 ? GOLDILOCKS_P - (uint64_t)(-sb) : (uint64_t)sb);
-        uint32_t diff_val = 0;
-        if (diff_idx == 1) diff_val = (uint32_t)(lt ? sb - sa : sa - sb) & 0xffff;
-        else if (diff_idx == 0) diff_val = (lt ? b0 - a0 : a0 - b0) & 0xffff;
-        o.put(m.diff_val, diff_val);
-        constexpr uint32_t U16 = 1u << 16;
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (diff_idx == 2 ? 0u : ((diff_val - 1) & 0xffff)));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (a_neg ? a1 - 0x8000u : a1 + ((uint32_t)(is_signed != 0) << 15)));
-        lk_count<XCD_LOCAL>(lk_dyn, U16 + (b_neg ? b1 - 0x8000u : b1 + ((uint32_t)(is_signed != 0) << 15)));
+        emit_uint_lt<XCD_LOCAL>(o, m.cmp_lt, m.a_msb_f, m.b_msb_f, m.diff_marker, m.diff_val, a0, a1, b0, b1, is_signed != 0, lk_dyn);
+    }
+}
+
+// ---- SLTI / SLTIU (riscv/slti/slti_circuit_v2.rs:104-140): the I-instruction base, rs1 as u16 limbs, imm (low 16 bits) and its sign, and the
+// same comparison of rs1 with the sign-extended immediate [imm, sign ? 0xffff : 0].  22 mapped columns.
+struct SltiMap {  // ceno_hip_slti_column_map = ceno_gpu's SltiColumnMap (chips/slti.rs:32-51)
+    uint32_t rs1_limbs[2], imm, imm_sign, cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t num_cols;
+};
+static_assert(sizeof(SltiMap) == sizeof(ceno_hip_slti_column_map), "column map layout");
+constexpr int SLTI_COLS = 22;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_slti(SltiMap m, int is_signed, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                    uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                    uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<SLTI_COLS>(o, &m.rs1_limbs[0]);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t imm16 = st.imm & 0xffff, neg = (imm16 >> 15) & 1u;
+        o.put(m.rs1_limbs[0], st.rs1_val & 0xffff);
+        o.put(m.rs1_limbs[1], st.rs1_val >> 16);
+        o.put(m.imm, imm16);
+        o.put(m.imm_sign, neg);
+        emit_uint_lt<XCD_LOCAL>(o, m.cmp_lt, m.a_msb_f, m.b_msb_f, m.diff_marker, m.diff_val, st.rs1_val & 0xffff, st.rs1_val >> 16, imm16, neg ? 0xffffu : 0u,
+                                is_signed != 0, lk_dyn);
     }
 }
 
@@ -744,6 +793,16 @@ int witgen_slt(ceno_hip_ctx* ctx, const SltMap* map, int is_signed, const void* 
     const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slt, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
+int witgen_slti(ceno_hip_ctx* ctx, const SltiMap* map, int is_signed, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->rs1_limbs[0], SLTI_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slti, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
+}
 #undef WITGEN_LAUNCH
 
 }  // namespace
@@ -802,6 +861,15 @@ int ceno_hip_witgen_slt(ceno_hip_ctx* ctx, const ceno_hip_slt_column_map* map, i
     CHECK_ARG(ctx, is_signed == 0 || is_signed == 1, "witgen_slt: is_signed is 1 (SLT) or 0 (SLTU)");
     return witgen_slt(ctx, reinterpret_cast<const SltMap*>(map), is_signed, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                       fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_slti(ceno_hip_ctx* ctx, const ceno_hip_slti_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, is_signed == 0 || is_signed == 1, "witgen_slti: is_signed is 1 (SLTI) or 0 (SLTIU)");
+    return witgen_slti(ctx, reinterpret_cast<const SltiMap*>(map), is_signed, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                       fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,

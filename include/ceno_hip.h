@@ -452,6 +452,18 @@ typedef struct ceno_hip_slt_column_map {
 int ceno_hip_witgen_slt(ceno_hip_ctx* ctx, const ceno_hip_slt_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* SLTI / SLTIU: hal.witgen.witgen_slti (GpuWitgenKind::Slti(is_signed); chips/slti.rs:10-52; riscv/slti/slti_circuit_v2.rs:104-140): rs1 against
+ * the sign-extended immediate, same comparison gadget.  22 mapped columns. */
+typedef struct ceno_hip_slti_column_map {
+    uint32_t rs1_limbs[2], imm, imm_sign, cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t num_cols;
+} ceno_hip_slti_column_map;
+int ceno_hip_witgen_slti(ceno_hip_ctx* ctx, const ceno_hip_slti_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
  * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
 typedef struct ceno_hip_lui_column_map {

@@ -875,6 +875,29 @@ def witgen_auipc(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_
     return _witgen_4tab(lib().orc_witgen_auipc, 21, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
 
 
+INSN_SLTI, INSN_SLTIU = 18, 19
+
+
+def witgen_slti(cols, is_signed: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the SLTI / SLTIU chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (23,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_slti.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    L.orc_witgen_slti.restype = C.c_int
+    rc = L.orc_witgen_slti(cols.ctypes.data, int(is_signed), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                           out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_slti rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_SLT, INSN_SLTU = 9, 10
 
 

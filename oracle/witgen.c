@@ -444,12 +444,42 @@ int orc_witgen_auipc(const uint32_t* cols, const void* records, const uint32_t* 
     return 0;
 }
 
+/* UIntLimbsLT::assign (gadgets/signed_limbs.rs:150-222) over run_cmp (:226-236).  lt_cols: cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val */
+static void assign_uint_lt(uint64_t* row, const uint32_t* lt_cols, uint32_t* lk_dynamic, const uint16_t a[2], const uint16_t b[2], int is_signed) {
+    const uint64_t P = 0xFFFFFFFF00000001ULL;
+    const int is_a_neg = (a[1] >> 15) == 1 && is_signed, is_b_neg = (b[1] >> 15) == 1 && is_signed;
+    int cmp_lt = 0, diff_idx = 2;
+    for (int k = 1; k >= 0; k--)
+        if (a[k] != b[k]) { cmp_lt = (a[k] < b[k]) ^ is_a_neg ^ is_b_neg; diff_idx = k; break; }
+    row[lt_cols[3]] = diff_idx == 0;
+    row[lt_cols[4]] = diff_idx == 1;
+    row[lt_cols[0]] = (uint64_t)cmp_lt;
+    uint64_t a_msb_f, b_msb_f;
+    uint16_t a_range, b_range;
+    if (is_a_neg) { a_msb_f = P - (uint64_t)((1u << 16) - a[1]); a_range = (uint16_t)(a[1] - (1u << 15)); }
+    else { a_msb_f = a[1]; a_range = (uint16_t)(a[1] + ((uint16_t)(is_signed != 0) << 15)); }
+    if (is_b_neg) { b_msb_f = P - (uint64_t)((1u << 16) - b[1]); b_range = (uint16_t)(b[1] - (1u << 15)); }
+    else { b_msb_f = b[1]; b_range = (uint16_t)(b[1] + ((uint16_t)(is_signed != 0) << 15)); }
+    row[lt_cols[1]] = a_msb_f;
+    row[lt_cols[2]] = b_msb_f;
+    uint16_t diff_val;
+    if (diff_idx == 2) diff_val = 0;
+    else if (diff_idx == 1) { /* field subtraction, canonical, then `as u16` */
+        const uint64_t x = cmp_lt ? b_msb_f : a_msb_f, y = cmp_lt ? a_msb_f : b_msb_f;
+        const uint64_t d = x >= y ? x - y : x + (P - y);
+        diff_val = (uint16_t)d;
+    } else diff_val = (uint16_t)(cmp_lt ? b[0] - a[0] : a[0] - b[0]);
+    row[lt_cols[5]] = diff_val;
+    lk_dyn(lk_dynamic, diff_idx != 2 ? (uint16_t)(diff_val - 1) : 0, 16);
+    lk_dyn(lk_dynamic, a_range, 16);
+    lk_dyn(lk_dynamic, b_range, 16);
+}
+
 /* SetLessThanInstruction::assign_instance (riscv/slt/slt_circuit_v2.rs:86-119): the R-instruction base, the u16 limbs of rs1 and rs2, then
  * UIntLimbsLT::assign (gadgets/signed_limbs.rs:150-222) over run_cmp (:226-236).  Field elements are Goldilocks-canonical words.
  * cols[27]: SltColumnMap field order (chips/slt.rs:33-55), num_cols last. */
 int orc_witgen_slt(const uint32_t* cols, int is_signed, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
                    uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
-    const uint64_t P = 0xFFFFFFFF00000001ULL;
     const uint32_t num_cols = cols[26];
     for (int c = 0; c < 26; c++)
         if (cols[c] >= num_cols) return -1;
@@ -481,34 +511,47 @@ int orc_witgen_slt(const uint32_t* cols, int is_signed, const void* records, con
         }
         const uint16_t a[2] = {(uint16_t)st->rs1.value, (uint16_t)(st->rs1.value >> 16)}, b[2] = {(uint16_t)st->rs2.value, (uint16_t)(st->rs2.value >> 16)};
         row[cols[0]] = a[0]; row[cols[1]] = a[1]; row[cols[2]] = b[0]; row[cols[3]] = b[1];
-        /* run_cmp */
-        const int is_a_neg = (a[1] >> 15) == 1 && is_signed, is_b_neg = (b[1] >> 15) == 1 && is_signed;
-        int cmp_lt = 0, diff_idx = 2;
-        for (int k = 1; k >= 0; k--)
-            if (a[k] != b[k]) { cmp_lt = (a[k] < b[k]) ^ is_a_neg ^ is_b_neg; diff_idx = k; break; }
-        row[cols[7]] = diff_idx == 0;
-        row[cols[8]] = diff_idx == 1;
-        row[cols[4]] = (uint64_t)cmp_lt;
-        uint64_t a_msb_f, b_msb_f;
-        uint16_t a_range, b_range;
-        if (is_a_neg) { a_msb_f = P - (uint64_t)((1u << 16) - a[1]); a_range = (uint16_t)(a[1] - (1u << 15)); }
-        else { a_msb_f = a[1]; a_range = (uint16_t)(a[1] + ((uint16_t)(is_signed != 0) << 15)); }
-        if (is_b_neg) { b_msb_f = P - (uint64_t)((1u << 16) - b[1]); b_range = (uint16_t)(b[1] - (1u << 15)); }
-        else { b_msb_f = b[1]; b_range = (uint16_t)(b[1] + ((uint16_t)(is_signed != 0) << 15)); }
-        row[cols[5]] = a_msb_f;
-        row[cols[6]] = b_msb_f;
-        uint16_t diff_val;
-        if (diff_idx == 2) diff_val = 0;
-        else if (diff_idx == 1) {
-            /* field subtraction, canonical, then `as u16` */
-            const uint64_t x = cmp_lt ? b_msb_f : a_msb_f, y = cmp_lt ? a_msb_f : b_msb_f;
-            const uint64_t d = x >= y ? x - y : x + (P - y);
-            diff_val = (uint16_t)d;
-        } else diff_val = (uint16_t)(cmp_lt ? b[0] - a[0] : a[0] - b[0]);
-        row[cols[9]] = diff_val;
-        lk_dyn(lk_dynamic, diff_idx != 2 ? (uint16_t)(diff_val - 1) : 0, 16);
-        lk_dyn(lk_dynamic, a_range, 16);
-        lk_dyn(lk_dynamic, b_range, 16);
+        assign_uint_lt(row, cols + 4, lk_dynamic, a, b, is_signed);
+    }
+    return 0;
+}
+
+/* SetLessThanImmInstruction::assign_instance (riscv/slti/slti_circuit_v2.rs:104-140): the I-instruction base, rs1 limbs, imm = insn.imm as i16
+ * as u16 and its sign, then UIntLimbsLT::assign(rs1, imm_sign_extend(true, imm), is SLTI).  cols[23]: SltiColumnMap order (chips/slti.rs:32-51). */
+int orc_witgen_slti(const uint32_t* cols, int is_signed, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                    uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[22];
+    for (int c = 0; c < 22; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[10]] = st->pc_before;
+        row[cols[11]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[12]] = register_index(st->rs1.addr);
+        row[cols[13]] = p;
+        assign_lt(row, cols + 14, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[16]] = register_index(st->rd.addr);
+        row[cols[17]] = p;
+        row[cols[18]] = st->rd.before & 0xffff;
+        row[cols[19]] = st->rd.before >> 16;
+        assign_lt(row, cols + 20, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint16_t a[2] = {(uint16_t)st->rs1.value, (uint16_t)(st->rs1.value >> 16)};
+        const uint16_t imm = (uint16_t)(int16_t)st->imm;
+        const uint16_t b[2] = {imm, (int16_t)st->imm < 0 ? 0xffff : 0};
+        row[cols[0]] = a[0]; row[cols[1]] = a[1];
+        row[cols[2]] = imm;
+        row[cols[3]] = b[1] > 0;
+        assign_uint_lt(row, cols + 4, lk_dynamic, a, b, is_signed);
     }
     return 0;
 }

@@ -129,6 +129,15 @@ impl Witgen {
                                      raw_stream(steps.stream))
         })
     }
+    /// `witgen_slti`: `is_signed` = the payload of `GpuWitgenKind::Slti` (true: SLTI, false: SLTIU)
+    pub fn slti(&self, map: &sys::ceno_hip_slti_column_map, is_signed: bool, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_slti(self.hal.ctx, map, is_signed as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                      steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                      raw_stream(steps.stream))
+        })
+    }
     /// `witgen_lui`
     pub fn lui(&self, map: &sys::ceno_hip_lui_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
         self.hal.check(unsafe {

@@ -376,3 +376,39 @@ def test_slt_oracle_satisfies_the_comparison_gadget(signed):
             exp[(1 << 16) + row[cols[d0]]] += 1
             exp[(1 << 13) + row[cols[d0 + 1]]] += 1
     assert np.array_equal(lkd.astype(np.int64), exp) and np.all(lkf == 1)
+
+
+def _slti_steps(n, signed):
+    i = np.arange(n, dtype=np.int64)
+    a = (i * 137 - 500) & 0xFFFFFFFF
+    imm = (i * 29) % 4096 - 2048
+    edge = [(0, 0), (5, 5), (0xFFFFFFFF, -1), (0x7FFFFFFF, -1), (0x80000000, 2047), (0, -2048), (0xFFFFF800, -2048), (0x0000FFFF, -1), (0xFFFF0000, 0)]
+    for k, (x, y) in enumerate(edge[:n]):
+        a[k], imm[k] = x, y
+    b = imm & 0xFFFFFFFF                                  # the sign-extended immediate as a 32-bit word
+    if signed:
+        lt = (np.where(a >> 31, a - (1 << 32), a) < imm).astype(np.uint64)
+    else:
+        lt = (a < b).astype(np.uint64)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=a.astype(np.uint64), imms=imm,
+                rd_before=(i % 200).astype(np.uint64), rd_after=lt, prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("signed", [True, False])
+def test_slti_oracle_agrees_with_slt_on_the_extended_immediate(signed):
+    """SLTI / SLTIU: the comparison columns are those SLT / SLTU produces for (rs1, sign_extend(imm)) — the gadget is shared — and cmp_lt = rd"""
+    n = 600
+    d = _slti_steps(n, signed)
+    recs_i = po.step_records_i(d["cycles"], d["pcs"], po.INSN_SLTI if signed else po.INSN_SLTIU, 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"],
+                               d["prev_cycles"])
+    cols_i = list(range(22)) + [22]
+    got, lkd, lkf = po.witgen_slti(cols_i, signed, recs_i, np.arange(n), 0, 0x1000, n)
+    ext = (d["imms"] & 0xFFFFFFFF).astype(np.uint64)
+    recs_r = po.step_records_r(d["cycles"], d["pcs"], po.INSN_SLT if signed else po.INSN_SLTU, 2, 3, 4, d["rs1_vals"], ext, d["rd_before"], d["rd_after"],
+                               d["prev_cycles"])
+    ref, _, _ = po.witgen_slt(list(range(26)) + [26], signed, recs_r, np.arange(n), 0, 0x1000, n)
+    assert np.array_equal(got[:, 4:10], ref[:, 4:10])                      # cmp_lt, a_msb_f, b_msb_f, diff_marker, diff_val
+    assert np.array_equal(got[:, 0:2], ref[:, 0:2])                        # rs1 limbs
+    assert np.array_equal(got[:, 4], d["rd_after"])
+    assert np.array_equal(got[:, 2], (d["imms"] & 0xFFFF).astype(np.uint64)) and np.array_equal(got[:, 3], (d["imms"] < 0).astype(np.uint64))
+    assert int(lkd.sum()) == 7 * n and np.all(lkf == 1)
