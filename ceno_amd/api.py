@@ -418,6 +418,24 @@ def witgen_slti(dev: Device, cols, is_signed: bool, records_ptr: int, num_record
                                          C.c_void_p(lk_fetch_ptr or None), stream))
 
 
+def witgen_branch(dev: Device, cols, is_eq: bool, flag: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int,
+                  rows_padded: int, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0,
+                  stream=None):
+    """hal.witgen.witgen_branch_cmp (is_eq False; flag = is_signed, 22 column ids) / witgen_branch_eq (is_eq True; flag = is_beq, 19 column ids)"""
+    nc = 19 if is_eq else 22
+
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(nc):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[nc])
+    fn = dev.L.ceno_hip_witgen_branch_eq if is_eq else dev.L.ceno_hip_witgen_branch_cmp
+    dev.check(fn(dev.h, C.byref(m), int(flag), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
+                 fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 class LuiColumnMap(C.Structure):
     """ceno_hip_lui_column_map: 16 column ids + num_cols"""
     _fields_ = [("cols", C.c_uint32 * 16), ("num_cols", C.c_uint32)]

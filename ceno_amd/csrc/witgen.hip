@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU and the six branches.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -684,6 +684,82 @@ __global__ void __launch_bounds__(NT) k_witgen_slti(SltiMap m, int is_signed, co
     }
 }
 
+// ---- branches (BranchCircuit, ceno_zkvm/src/instructions/riscv/branch/branch_circuit_v2.rs:143-209 over BInstructionConfig b_insn.rs:92-116: state
+// with next_pc, rs1, rs2, the immediate as a FIELD element of its signed value, fetch): BLT / BGE / BLTU / BGEU carry the UIntLimbsLT
+// comparison of rs1 and rs2 (22 mapped columns); BEQ / BNE carry the taken bit and, at the first differing limb, the field inverse of
+// the limb difference (19 mapped columns; gl::inv — one exponentiation per instance).
+__device__ __forceinline__ uint64_t signed_to_field(uint32_t imm32) {  // i64_to_base(insn.imm as i64)
+    const int32_t v = (int32_t)imm32;
+    return v < 0 ? GOLDILOCKS_P - (uint64_t)(-(int64_t)v) : (uint64_t)v;
+}
+struct BranchCmpMap {  // ceno_hip_branch_cmp_column_map = ceno_gpu's BranchCmpColumnMap (chips/branch_cmp.rs:35-54)
+    uint32_t rs1_limbs[2], rs2_limbs[2], cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t imm;
+    uint32_t num_cols;
+};
+static_assert(sizeof(BranchCmpMap) == sizeof(ceno_hip_branch_cmp_column_map), "column map layout");
+constexpr int BRANCH_CMP_COLS = 22;
+struct BranchEqMap {  // ceno_hip_branch_eq_column_map = ceno_gpu's BranchEqColumnMap (chips/branch_eq.rs:27-43)
+    uint32_t rs1_limbs[2], rs2_limbs[2], branch_taken, diff_inv_marker[2];
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t imm;
+    uint32_t num_cols;
+};
+static_assert(sizeof(BranchEqMap) == sizeof(ceno_hip_branch_eq_column_map), "column map layout");
+constexpr int BRANCH_EQ_COLS = 19;
+
+// MODE 0: comparison branches (flag = is_signed), MODE 1: equality branches (flag = is_beq)
+template <bool XCD_LOCAL, int MODE, class MapT>
+__global__ void __launch_bounds__(NT) k_witgen_branch(MapT m, int flag, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                      uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                      uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<(MODE == 0 ? BRANCH_CMP_COLS : BRANCH_EQ_COLS)>(o, &m.rs1_limbs[0]);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint32_t pc_after = *reinterpret_cast<const uint32_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES + OFF_PC_AFTER);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.next_pc, pc_after);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+        o.put(m.imm, signed_to_field(st.imm));
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t a0 = st.rs1_val & 0xffff, a1 = st.rs1_val >> 16, b0 = st.rs2_val & 0xffff, b1 = st.rs2_val >> 16;
+        o.put(m.rs1_limbs[0], a0);
+        o.put(m.rs1_limbs[1], a1);
+        o.put(m.rs2_limbs[0], b0);
+        o.put(m.rs2_limbs[1], b1);
+        if constexpr (MODE == 0) {
+            emit_uint_lt<XCD_LOCAL>(o, m.cmp_lt, m.a_msb_f, m.b_msb_f, m.diff_marker, m.diff_val, a0, a1, b0, b1, flag != 0, lk_dyn);
+        } else {
+            // run_eq (branch_circuit_v2.rs:164-182): the FIRST differing limb from the least significant one; inverse of the field difference
+            const int diff_idx = a0 != b0 ? 0 : (a1 != b1 ? 1 : -1);
+            const bool taken = diff_idx < 0 ? flag != 0 : flag == 0;
+            uint64_t inv = 0;
+            if (diff_idx >= 0) {
+                const uint32_t x = diff_idx == 0 ? a0 : a1, y = diff_idx == 0 ? b0 : b1;
+                inv = gl::inv(x > y ? (uint64_t)(x - y) : GOLDILOCKS_P - (uint64_t)(y - x));
+            }
+            o.put(m.branch_taken, taken ? 1 : 0);
+            o.put(m.diff_inv_marker[0], diff_idx == 0 ? inv : 0);
+            o.put(m.diff_inv_marker[1], diff_idx == 1 ? inv : 0);
+        }
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -803,6 +879,20 @@ int witgen_slti(ceno_hip_ctx* ctx, const SltiMap* map, int is_signed, const void
     const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slti, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
+template <int MODE, class MapT>
+int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                  uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->rs1_limbs[0], n_cols, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+        if (xcd) hipLaunchKernelGGL((k_witgen_branch<true, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+    });
+}
 #undef WITGEN_LAUNCH
 
 }  // namespace
@@ -870,6 +960,24 @@ int ceno_hip_witgen_slti(ceno_hip_ctx* ctx, const ceno_hip_slti_column_map* map,
     CHECK_ARG(ctx, is_signed == 0 || is_signed == 1, "witgen_slti: is_signed is 1 (SLTI) or 0 (SLTIU)");
     return witgen_slti(ctx, reinterpret_cast<const SltiMap*>(map), is_signed, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                        fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_branch_cmp(ceno_hip_ctx* ctx, const ceno_hip_branch_cmp_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                               const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                               uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, is_signed == 0 || is_signed == 1, "witgen_branch_cmp: is_signed is 1 (BLT / BGE) or 0 (BLTU / BGEU)");
+    return witgen_branch<0>(ctx, reinterpret_cast<const BranchCmpMap*>(map), BRANCH_CMP_COLS, is_signed, dev_step_records, num_records, dev_step_indices, n,
+                            shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column_map* map, int is_beq, const void* dev_step_records, size_t num_records,
+                              const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                              uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, is_beq == 0 || is_beq == 1, "witgen_branch_eq: is_beq is 1 (BEQ) or 0 (BNE)");
+    return witgen_branch<1>(ctx, reinterpret_cast<const BranchEqMap*>(map), BRANCH_EQ_COLS, is_beq, dev_step_records, num_records, dev_step_indices, n,
+                            shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,

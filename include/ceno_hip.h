@@ -464,6 +464,32 @@ typedef struct ceno_hip_slti_column_map {
 int ceno_hip_witgen_slti(ceno_hip_ctx* ctx, const ceno_hip_slti_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
                          const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                          uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* Branches: hal.witgen.witgen_branch_cmp (GpuWitgenKind::BranchCmp(is_signed): BLT / BGE = 1, BLTU / BGEU = 0; chips/branch_cmp.rs:12-55) and
+ * witgen_branch_eq (GpuWitgenKind::BranchEq(is_beq): BEQ = 1, BNE = 0; chips/branch_eq.rs:12-44); CPU assignment
+ * riscv/branch/branch_circuit_v2.rs:143-209 + b_insn.rs:92-116.  `imm` is the branch offset as a field element (negative: p - |imm|);
+ * diff_inv_marker holds the field inverse of (rs1_limb - rs2_limb) at the first differing limb.  22 / 19 mapped columns. */
+typedef struct ceno_hip_branch_cmp_column_map {
+    uint32_t rs1_limbs[2], rs2_limbs[2], cmp_lt, a_msb_f, b_msb_f, diff_marker[2], diff_val;
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t imm;
+    uint32_t num_cols;
+} ceno_hip_branch_cmp_column_map;
+typedef struct ceno_hip_branch_eq_column_map {
+    uint32_t rs1_limbs[2], rs2_limbs[2], branch_taken, diff_inv_marker[2];
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t imm;
+    uint32_t num_cols;
+} ceno_hip_branch_eq_column_map;
+int ceno_hip_witgen_branch_cmp(ceno_hip_ctx* ctx, const ceno_hip_branch_cmp_column_map* map, int is_signed, const void* dev_step_records, size_t num_records,
+                               const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                               uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column_map* map, int is_beq, const void* dev_step_records, size_t num_records,
+                              const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                              uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
  * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
 typedef struct ceno_hip_lui_column_map {

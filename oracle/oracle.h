@@ -255,6 +255,11 @@ int orc_witgen_slt(const uint32_t* cols, int is_signed, const void* records, con
 /* SLTI / SLTIU (slti_circuit_v2.rs:104-140): cols[23] in SltiColumnMap order */
 int orc_witgen_slti(const uint32_t* cols, int is_signed, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
                     uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* branches (branch_circuit_v2.rs:143-209): is_eq = 0 -> cols[23] BranchCmpColumnMap order, flag = is_signed; is_eq = 1 -> cols[20] BranchEqColumnMap, flag = is_beq */
+void orc_step_record_b(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rs1, uint8_t rs2, int32_t imm, uint32_t rs1_val,
+                       uint32_t rs2_val, uint64_t prev_cycle);
+int orc_witgen_branch(const uint32_t* cols, int is_eq, int flag, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                      uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
 /* JAL (jal_v2.rs:99-127) and AUIPC (auipc.rs:149-187): cols[14] / cols[22] in JalColumnMap / AuipcColumnMap order; double_u8 key a << 8 | b */
 void orc_step_record_j(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rd, int32_t imm, uint32_t rd_before,
                        uint32_t rd_after, uint64_t prev_cycle);

@@ -875,6 +875,44 @@ def witgen_auipc(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_
     return _witgen_4tab(lib().orc_witgen_auipc, 21, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
 
 
+INSN_BEQ, INSN_BNE, INSN_BLT, INSN_BGE, INSN_BLTU, INSN_BGEU = 20, 21, 22, 23, 24, 25
+
+
+def step_records_b(cycles, pcs, pcs_after, kind, rs1, rs2, imms, rs1_vals, rs2_vals, prev_cycles) -> np.ndarray:
+    """B-type step records (rs1, rs2 read; no rd) -> (n, 136) uint8 array"""
+    n = len(cycles)
+    out = np.zeros((n, lib().orc_step_record_bytes()), dtype=np.uint8)
+    L = lib()
+    L.orc_step_record_b.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int32, C.c_uint32, C.c_uint32,
+                                    C.c_uint64]
+    L.orc_step_record_b.restype = None
+    for i in range(n):
+        L.orc_step_record_b(out[i].ctypes.data, int(cycles[i]), int(pcs[i]), int(pcs_after[i]), kind, rs1, rs2, int(imms[i]), int(rs1_vals[i]),
+                            int(rs2_vals[i]), int(prev_cycles[i]))
+    return out
+
+
+def witgen_branch(cols, is_eq: bool, flag: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of a branch chip (is_eq: BEQ / BNE with flag = is_beq, else BLT / BGE / BLTU / BGEU with flag = is_signed)"""
+    nc = 19 if is_eq else 22
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (nc + 1,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_branch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    L.orc_witgen_branch.restype = C.c_int
+    rc = L.orc_witgen_branch(cols.ctypes.data, int(is_eq), int(flag), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc,
+                             fetch_num_slots, out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_branch rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_SLTI, INSN_SLTIU = 18, 19
 
 

@@ -555,3 +555,80 @@ int orc_witgen_slti(const uint32_t* cols, int is_signed, const void* records, co
     }
     return 0;
 }
+
+/* StepRecord::new_b_instruction (ceno_emul/src/tracer.rs): rs1 and rs2 read, no rd; pc moves to pc + imm when the branch is taken */
+void orc_step_record_b(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rs1, uint8_t rs2, int32_t imm, uint32_t rs1_val,
+                       uint32_t rs2_val, uint64_t prev_cycle) {
+    orc_step_record r;
+    memset(&r, 0, sizeof(r));
+    r.cycle = cycle;
+    r.pc_before = pc;
+    r.pc_after = pc_after;
+    r.kind = kind; r.rs1_idx = rs1; r.rs2_idx = rs2;
+    r.imm = imm;
+    r.has_rs1 = r.has_rs2 = 1;
+    r.rs1.addr = ((uint32_t)rs1 << 8) / 4; r.rs1.value = rs1_val; r.rs1.previous_cycle = prev_cycle;
+    r.rs2.addr = ((uint32_t)rs2 << 8) / 4; r.rs2.value = rs2_val; r.rs2.previous_cycle = prev_cycle;
+    r.syscall_index = 0xFFFFFFFFu;
+    memcpy(out, &r, sizeof(r));
+}
+
+static uint64_t gl_mul_(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % 0xFFFFFFFF00000001ULL); }
+static uint64_t gl_inv_(uint64_t a) { /* a^(p-2) */
+    uint64_t e = 0xFFFFFFFF00000001ULL - 2, r = 1;
+    while (e) { if (e & 1) r = gl_mul_(r, a); a = gl_mul_(a, a); e >>= 1; }
+    return r;
+}
+
+/* BranchCircuit::assign_instance (riscv/branch/branch_circuit_v2.rs:143-209) over BInstructionConfig::assign_instance (b_insn.rs:92-116: pc, next_pc,
+ * ts, rs1, rs2, imm = imm_internal(insn).1 = i64_to_base(insn.imm), fetch).  is_eq = 0: BLT / BGE / BLTU / BGEU, cols[23] in BranchCmpColumnMap order
+ * (chips/branch_cmp.rs:35-54), flag = is_signed.  is_eq = 1: BEQ / BNE, cols[20] in BranchEqColumnMap order (chips/branch_eq.rs:27-43), flag = is_beq. */
+int orc_witgen_branch(const uint32_t* cols, int is_eq, int flag, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                      uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint64_t P = 0xFFFFFFFF00000001ULL;
+    const int nc = is_eq ? 19 : 22, base = is_eq ? 7 : 10; /* first column of the b_insn block: pc */
+    const uint32_t num_cols = cols[nc];
+    for (int c = 0; c < nc; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rs2) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[base]] = st->pc_before;
+        row[cols[base + 1]] = st->pc_after;
+        row[cols[base + 2]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[base + 3]] = register_index(st->rs1.addr);
+        row[cols[base + 4]] = p;
+        assign_lt(row, cols + base + 5, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+        row[cols[base + 7]] = register_index(st->rs2.addr);
+        row[cols[base + 8]] = p;
+        assign_lt(row, cols + base + 9, lk_dynamic, p, ts + 1);
+        row[cols[base + 11]] = st->imm < 0 ? P - (uint64_t)(-(int64_t)st->imm) : (uint64_t)st->imm;
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint16_t a[2] = {(uint16_t)st->rs1.value, (uint16_t)(st->rs1.value >> 16)}, b[2] = {(uint16_t)st->rs2.value, (uint16_t)(st->rs2.value >> 16)};
+        row[cols[0]] = a[0]; row[cols[1]] = a[1]; row[cols[2]] = b[0]; row[cols[3]] = b[1];
+        if (!is_eq) {
+            assign_uint_lt(row, cols + 4, lk_dynamic, a, b, flag);
+        } else { /* run_eq: the first differing limb from the least significant one */
+            int taken = flag, diff_idx = 0;
+            uint64_t inv = 0;
+            for (int k = 0; k < 2; k++)
+                if (a[k] != b[k]) {
+                    taken = !flag;
+                    diff_idx = k;
+                    inv = gl_inv_(a[k] > b[k] ? (uint64_t)(a[k] - b[k]) : P - (uint64_t)(b[k] - a[k]));
+                    break;
+                }
+            row[cols[4]] = (uint64_t)taken;
+            row[cols[5 + diff_idx]] = inv; /* the other marker stays zero */
+        }
+    }
+    return 0;
+}

@@ -138,6 +138,24 @@ impl Witgen {
                                       raw_stream(steps.stream))
         })
     }
+    /// `witgen_branch_cmp`: BLT / BGE (`is_signed`) and BLTU / BGEU
+    pub fn branch_cmp(&self, map: &sys::ceno_hip_branch_cmp_column_map, is_signed: bool, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                      lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_branch_cmp(self.hal.ctx, map, is_signed as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                            steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                            raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_branch_eq`: BEQ (`is_beq`) and BNE
+    pub fn branch_eq(&self, map: &sys::ceno_hip_branch_eq_column_map, is_beq: bool, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                     lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_branch_eq(self.hal.ctx, map, is_beq as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                           steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                           raw_stream(steps.stream))
+        })
+    }
     /// `witgen_lui`
     pub fn lui(&self, map: &sys::ceno_hip_lui_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
         self.hal.check(unsafe {

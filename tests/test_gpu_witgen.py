@@ -413,3 +413,34 @@ def test_slti_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
     mapped = sorted(cols[:22])
     assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
     assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+@pytest.mark.parametrize("kind", ["BEQ", "BNE", "BLT", "BGE", "BLTU", "BGEU"])
+@pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (500, 512)])
+def test_branch_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
+    """the six branches: comparison gadget (BLT / BGE / BLTU / BGEU) or field-inverse equality marker (BEQ / BNE); the branch offset as a field element"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _branch_steps
+
+    is_eq = kind in ("BEQ", "BNE")
+    flag = kind == "BEQ" if is_eq else kind in ("BLT", "BGE")
+    d = _branch_steps(n, kind)
+    recs = po.step_records_b(d["cycles"], d["pcs"], d["pcs_after"], getattr(po, "INSN_" + kind), 2, 3, d["imms"], d["rs1_vals"], d["rs2_vals"], d["prev_cycles"])
+    nc = 19 if is_eq else 22
+    rng = np.random.default_rng(22)
+    cols = list(rng.permutation(nc + 4)[:nc]) + [nc + 4]
+    idx = np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 4) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_branch(dev, cols, is_eq, flag, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x2000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 4, rows)
+    exp, elkd, elkf = po.witgen_branch(cols, is_eq, flag, recs, idx, 0, 0x2000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)

@@ -412,3 +412,58 @@ def test_slti_oracle_agrees_with_slt_on_the_extended_immediate(signed):
     assert np.array_equal(got[:, 4], d["rd_after"])
     assert np.array_equal(got[:, 2], (d["imms"] & 0xFFFF).astype(np.uint64)) and np.array_equal(got[:, 3], (d["imms"] < 0).astype(np.uint64))
     assert int(lkd.sum()) == 7 * n and np.all(lkf == 1)
+
+
+def _branch_steps(n, kind):
+    """chips/branch_cmp.rs:93-118 / branch_eq.rs: rs1 = 137 i - 500, rs2 = 89 i - 300, offset -8 when taken, +4 otherwise; plus edge cases"""
+    d = _slt_steps(n, kind in ("BLT", "BGE"))
+    a, b = d["rs1_vals"].astype(np.int64), d["rs2_vals"].astype(np.int64)
+    if kind in ("BEQ", "BNE"):
+        b[::5] = a[::5]                                  # equal operands
+        b[1::7] = a[1::7] ^ 0x10000                      # differ in the high limb only
+    sa, sb = np.where(a >> 31, a - (1 << 32), a), np.where(b >> 31, b - (1 << 32), b)
+    taken = {"BEQ": a == b, "BNE": a != b, "BLT": sa < sb, "BGE": sa >= sb, "BLTU": a < b, "BGEU": a >= b}[kind]
+    pc = d["pcs"].astype(np.int64) + 0x1000
+    imm = np.full(n, -8, dtype=np.int64)
+    imm[::3] = 2044
+    return dict(cycles=d["cycles"], pcs=pc.astype(np.uint64), pcs_after=np.where(taken, pc + imm, pc + 4).astype(np.uint64), imms=imm,
+                rs1_vals=a.astype(np.uint64), rs2_vals=b.astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64), taken=taken)
+
+
+@pytest.mark.parametrize("kind", ["BLT", "BGE", "BLTU", "BGEU"])
+def test_branch_cmp_oracle_agrees_with_slt_and_the_branch_decision(kind):
+    n = 500
+    signed = kind in ("BLT", "BGE")
+    d = _branch_steps(n, kind)
+    recs = po.step_records_b(d["cycles"], d["pcs"], d["pcs_after"], getattr(po, "INSN_" + kind), 2, 3, d["imms"], d["rs1_vals"], d["rs2_vals"], d["prev_cycles"])
+    got, lkd, lkf = po.witgen_branch(list(range(22)) + [22], False, signed, recs, np.arange(n), 0, 0x2000, n)
+    recs_r = po.step_records_r(d["cycles"], d["pcs"], po.INSN_SLT if signed else po.INSN_SLTU, 2, 3, 4, d["rs1_vals"], d["rs2_vals"], np.zeros(n), np.zeros(n),
+                               d["prev_cycles"])
+    ref, _, _ = po.witgen_slt(list(range(26)) + [26], signed, recs_r, np.arange(n), 0, 0x2000, n)
+    assert np.array_equal(got[:, :10], ref[:, :10])                       # limbs + the shared comparison gadget
+    lt = got[:, 4].astype(bool)
+    assert np.array_equal(lt if kind in ("BLT", "BLTU") else ~lt, d["taken"])
+    m = got.astype(np.int64)
+    assert np.array_equal(m[:, 10], d["pcs"].astype(np.int64)) and np.array_equal(m[:, 11], d["pcs_after"].astype(np.int64))
+    imm_f = np.where(d["imms"] < 0, P_GL + d["imms"].astype(object), d["imms"].astype(object))
+    assert [int(x) for x in got[:, 21]] == [int(x) for x in imm_f]
+    assert int(lkd.sum()) == 7 * n and int(lkf.sum()) == n
+
+
+@pytest.mark.parametrize("kind", ["BEQ", "BNE"])
+def test_branch_eq_oracle_inverse_marker(kind):
+    n = 400
+    d = _branch_steps(n, kind)
+    recs = po.step_records_b(d["cycles"], d["pcs"], d["pcs_after"], getattr(po, "INSN_" + kind), 2, 3, d["imms"], d["rs1_vals"], d["rs2_vals"], d["prev_cycles"])
+    got, lkd, lkf = po.witgen_branch(list(range(19)) + [19], True, kind == "BEQ", recs, np.arange(n), 0, 0x2000, n)
+    for r in range(n):
+        row = [int(v) for v in got[r]]
+        a, b = [row[0], row[1]], [row[2], row[3]]
+        assert row[4] == int(d["taken"][r])
+        # the circuit's equality test: sum_i marker_i (a_i - b_i) = 1 when the operands differ, every marker zero when they are equal
+        acc = sum(row[5 + k] * ((a[k] - b[k]) % P_GL) for k in range(2)) % P_GL
+        assert acc == (0 if a == b else 1)
+        if a != b:
+            k = 0 if a[0] != b[0] else 1
+            assert row[5 + (1 - k)] == 0
+    assert int(lkd.sum()) == 4 * n
