@@ -436,6 +436,21 @@ def witgen_branch(dev: Device, cols, is_eq: bool, flag: bool, records_ptr: int, 
                  fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
 
 
+def witgen_mem(dev: Device, cols, is_store: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_lw / witgen_sw: `cols` = the 23 column ids in LwColumnMap / SwColumnMap field order followed by num_cols"""
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * 23), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(23):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[23])
+    fn = dev.L.ceno_hip_witgen_sw if is_store else dev.L.ceno_hip_witgen_lw
+    dev.check(fn(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
+                 C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 class LuiColumnMap(C.Structure):
     """ceno_hip_lui_column_map: 16 column ids + num_cols"""
     _fields_ = [("cols", C.c_uint32 * 16), ("num_cols", C.c_uint32)]

@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU and the six branches.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, LW and SW.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -760,6 +760,94 @@ __global__ void __launch_bounds__(NT) k_witgen_branch(MapT m, int flag, const un
     }
 }
 
+// ---- word memory access: LW (riscv/memory/load_v2.rs:197-255 over IMInstructionConfig im_insn.rs:71-90: state, rs1, rd, memory read, fetch) and SW
+// (riscv/memory/store_v2.rs:138-177 over SInstructionConfig s_insn.rs:77-96: state, rs1, rs2, memory write, fetch).  The address rs1 +
+// sign_extend(imm) is witnessed as two u16 limbs and range-checked by MemAddr::assign_instance (insn_base.rs:880-905, MEM_BITS = 30, word-aligned:
+// no low-bit columns): the low limb without its two low bits as a 14-bit value, the high limb as a 14-bit value.  23 mapped columns each.
+constexpr int OFF_MEM = 104;  // memory_op: WriteOp {addr u32 (word address), before u32, after u32, pad, previous_cycle u64}
+constexpr uint64_t SUBCYCLE_MEM = 3;
+struct LwMap {  // ceno_hip_lw_column_map = ceno_gpu's LwColumnMap (chips/lw.rs:35-53)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, mem_addr_limbs[2], mem_read_limbs[2];
+    uint32_t num_cols;
+};
+static_assert(sizeof(LwMap) == sizeof(ceno_hip_lw_column_map), "column map layout");
+struct SwMap {  // ceno_hip_sw_column_map = ceno_gpu's SwColumnMap (chips/sw.rs:31-49)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t num_cols;
+};
+static_assert(sizeof(SwMap) == sizeof(ceno_hip_sw_column_map), "column map layout");
+constexpr int MEM_COLS = 23;
+
+// the memory access itself (ReadMEM / WriteMEM::assign_op, insn_base.rs:517-545,650-680) and the address range checks
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void emit_mem(const Row& o, uint32_t prev_col, const uint32_t (&diff_cols)[2], const uint32_t (&addr_cols)[2], uint32_t addr,
+                                         uint64_t prev_cycle, uint64_t offset, uint64_t ts, uint32_t* lk_dyn) {
+    const uint64_t p = aligned_prev_ts(prev_cycle, offset), d = lt_diff(p, ts + SUBCYCLE_MEM);
+    o.put(prev_col, p);
+    o.put(diff_cols[0], d & 0xffff);
+    o.put(diff_cols[1], (d >> 16) & 0xffff);
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(d & 0xffff));
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << (MAX_TS_BITS - 16)) + (uint32_t)((d >> 16) & 0xffff));
+    o.put(addr_cols[0], addr & 0xffff);
+    o.put(addr_cols[1], addr >> 16);
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << 14) + ((addr & 0xffff) >> 2));  // assert_ux::<14>(mid_u14)
+    lk_count<XCD_LOCAL>(lk_dyn, (1u << 14) + (addr >> 16));            // assert_const_range(high_u16, MEM_BITS - 16)
+}
+
+template <bool XCD_LOCAL, bool STORE, class MapT>
+__global__ void __launch_bounds__(NT) k_witgen_mem(MapT m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n, uint64_t offset,
+                                                   uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows, uint32_t* lk_dyn,
+                                                   uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<MEM_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
+        const uint32_t mem_before = (uint32_t)(q[OFF_MEM / 8] >> 32);
+        const uint64_t mem_prev = q[OFF_MEM / 8 + 2];
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        const uint32_t imm16 = st.imm & 0xffff, neg = (imm16 >> 15) & 1u;
+        const uint32_t addr = st.rs1_val + (imm16 | (neg ? 0xffff0000u : 0u));  // rs1.wrapping_add_signed(imm as i16)
+        o.put(m.rs1_limbs[0], st.rs1_val & 0xffff);
+        o.put(m.rs1_limbs[1], st.rs1_val >> 16);
+        o.put(m.imm, imm16);
+        o.put(m.imm_sign, neg);
+        if constexpr (STORE) {
+            emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+            o.put(m.rs2_limbs[0], st.rs2_val & 0xffff);
+            o.put(m.rs2_limbs[1], st.rs2_val >> 16);
+            o.put(m.prev_mem_val[0], mem_before & 0xffff);
+            o.put(m.prev_mem_val[1], mem_before >> 16);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (mem_before & 0xffff));  // Value::new(memory_op.value.before, lkm)
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (mem_before >> 16));
+            emit_mem<XCD_LOCAL>(o, m.mem_prev_ts, m.mem_lt_diff, m.mem_addr, addr, mem_prev, offset, ts, lk_dyn);
+        } else {
+            emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+            o.put(m.mem_read_limbs[0], mem_before & 0xffff);
+            o.put(m.mem_read_limbs[1], mem_before >> 16);
+            emit_mem<XCD_LOCAL>(o, m.mem_prev_ts, m.mem_lt_diff, m.mem_addr_limbs, addr, mem_prev, offset, ts, lk_dyn);
+        }
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -893,6 +981,20 @@ int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, cons
         else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
+template <bool STORE, class MapT>
+int witgen_mem(ceno_hip_ctx* ctx, const MapT* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset, uint32_t fetch_base,
+               uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, MEM_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+        if (xcd) hipLaunchKernelGGL((k_witgen_mem<true, STORE, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else hipLaunchKernelGGL((k_witgen_mem<false, STORE, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+    });
+}
 #undef WITGEN_LAUNCH
 
 }  // namespace
@@ -978,6 +1080,22 @@ int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column
     CHECK_ARG(ctx, is_beq == 0 || is_beq == 1, "witgen_branch_eq: is_beq is 1 (BEQ) or 0 (BNE)");
     return witgen_branch<1>(ctx, reinterpret_cast<const BranchEqMap*>(map), BRANCH_EQ_COLS, is_beq, dev_step_records, num_records, dev_step_indices, n,
                             shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_lw(ceno_hip_ctx* ctx, const ceno_hip_lw_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_mem<false>(ctx, reinterpret_cast<const LwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                             fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_sw(ceno_hip_ctx* ctx, const ceno_hip_sw_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_mem<true>(ctx, reinterpret_cast<const SwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                            fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_lui(ceno_hip_ctx* ctx, const ceno_hip_lui_column_map* map, const void* dev_step_records, size_t num_records,

@@ -490,6 +490,32 @@ int ceno_hip_witgen_branch_cmp(ceno_hip_ctx* ctx, const ceno_hip_branch_cmp_colu
 int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column_map* map, int is_beq, const void* dev_step_records, size_t num_records,
                               const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                               uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* LW / SW: hal.witgen.witgen_lw / witgen_sw (GpuWitgenKind::Lw / Sw; chips/lw.rs:12-54, chips/sw.rs:12-50; CPU assignment
+ * riscv/memory/load_v2.rs:197-255 + im_insn.rs:71-90 and store_v2.rs:138-177 + s_insn.rs:77-96; memory access insn_base.rs:517-545,650-680,
+ * address checks :880-905).  The memory operand is StepRecord.memory_op; the shard RAM records of the access are not produced here.
+ * 23 mapped columns each. */
+typedef struct ceno_hip_lw_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, mem_addr_limbs[2], mem_read_limbs[2];
+    uint32_t num_cols;
+} ceno_hip_lw_column_map;
+typedef struct ceno_hip_sw_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t num_cols;
+} ceno_hip_sw_column_map;
+int ceno_hip_witgen_lw(ceno_hip_ctx* ctx, const ceno_hip_lw_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+int ceno_hip_witgen_sw(ceno_hip_ctx* ctx, const ceno_hip_sw_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 /* LUI: hal.witgen.witgen_lui (GpuWitgenKind::Lui; column map chips/lui.rs:10-42; CPU assignment riscv/lui.rs:100-120): the I-instruction
  * base, bytes 1..3 of rd (each counted as a byte of the dynamic table), imm = insn.imm as u32 >> 12.  16 mapped columns. */
 typedef struct ceno_hip_lui_column_map {

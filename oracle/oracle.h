@@ -260,6 +260,12 @@ void orc_step_record_b(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after
                        uint32_t rs2_val, uint64_t prev_cycle);
 int orc_witgen_branch(const uint32_t* cols, int is_eq, int flag, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
                       uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* LW / SW (load_v2.rs:197-255, store_v2.rs:138-177): cols[24] in LwColumnMap / SwColumnMap order */
+void orc_step_record_mem(void* out, int is_store, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rs2_or_rd, int32_t imm, uint32_t rs1_val,
+                         uint32_t rs2_val, uint32_t rd_before, uint32_t rd_after, uint32_t mem_byte_addr, uint32_t mem_before, uint32_t mem_after,
+                         uint64_t prev_cycle, uint64_t mem_prev_cycle);
+int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
 /* JAL (jal_v2.rs:99-127) and AUIPC (auipc.rs:149-187): cols[14] / cols[22] in JalColumnMap / AuipcColumnMap order; double_u8 key a << 8 | b */
 void orc_step_record_j(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rd, int32_t imm, uint32_t rd_before,
                        uint32_t rd_after, uint64_t prev_cycle);

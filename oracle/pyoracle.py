@@ -829,7 +829,7 @@ def witgen_addi(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch
     return out, lkd, lkf[:fetch_num_slots]
 
 
-INSN_JAL, INSN_AUIPC = 26, 43  # InsnKind::JAL; AUIPC follows LUI (u16limb_circuit feature)
+INSN_JAL, INSN_AUIPC = 26, 42  # InsnKind::JAL; AUIPC follows LUI (u16limb_circuit feature)
 
 
 def step_records_j(cycles, pcs, pcs_after, kind, rd, imms, rd_before, rd_after, prev_cycles) -> np.ndarray:
@@ -873,6 +873,45 @@ def witgen_jal(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_nu
 def witgen_auipc(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_num_slots=0):
     """CPU assignment of the AUIPC chip: (matrix, dynamic counts, fetch counts, double-u8 counts, xor counts)"""
     return _witgen_4tab(lib().orc_witgen_auipc, 21, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
+
+
+INSN_LW, INSN_SW = 38, 45  # InsnKind::LW; SW = after LUI, AUIPC, SB, SH (u16limb_circuit feature)
+
+
+def step_records_mem(is_store, cycles, pcs, kind, rs1, rs2_or_rd, imms, rs1_vals, rs2_vals, rd_before, rd_after, mem_addrs, mem_before, mem_after, prev_cycles,
+                     mem_prev_cycles) -> np.ndarray:
+    """load / store step records -> (n, 136) uint8 array"""
+    n = len(cycles)
+    out = np.zeros((n, lib().orc_step_record_bytes()), dtype=np.uint8)
+    L = lib()
+    L.orc_step_record_mem.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_int32] + [C.c_uint32] * 7 + \
+        [C.c_uint64, C.c_uint64]
+    L.orc_step_record_mem.restype = None
+    for i in range(n):
+        L.orc_step_record_mem(out[i].ctypes.data, int(is_store), int(cycles[i]), int(pcs[i]), kind, rs1, rs2_or_rd, int(imms[i]), int(rs1_vals[i]),
+                              int(rs2_vals[i]), int(rd_before[i]), int(rd_after[i]), int(mem_addrs[i]), int(mem_before[i]), int(mem_after[i]),
+                              int(prev_cycles[i]), int(mem_prev_cycles[i]))
+    return out
+
+
+def witgen_mem(cols, is_store: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the LW / SW chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (24,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[23])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_mem.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]
+    L.orc_witgen_mem.restype = C.c_int
+    rc = L.orc_witgen_mem(cols.ctypes.data, int(is_store), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                          out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_mem rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
 
 
 INSN_BEQ, INSN_BNE, INSN_BLT, INSN_BGE, INSN_BLTU, INSN_BGEU = 20, 21, 22, 23, 24, 25
@@ -959,7 +998,7 @@ def witgen_slt(cols, is_signed: bool, records: np.ndarray, indices, shard_offset
     return out, lkd, lkf[:fetch_num_slots]
 
 
-INSN_LUI = 42  # InsnKind::LUI (u16limb_circuit feature: after LHU = 41)
+INSN_LUI = 41  # InsnKind::LUI (u16limb_circuit feature: after LHU = 40)
 LUI_COLMAP_FIELDS = 17
 
 

@@ -632,3 +632,98 @@ int orc_witgen_branch(const uint32_t* cols, int is_eq, int flag, const void* rec
     }
     return 0;
 }
+
+/* StepRecord::new_im_instruction / new_s_instruction (ceno_emul/src/tracer.rs:1232-1260,1306-1330): a load reads rs1, writes rd and reads memory; a
+ * store reads rs1 and rs2 and writes memory.  memory_op.addr is a WORD address. */
+void orc_step_record_mem(void* out, int is_store, uint64_t cycle, uint32_t pc, uint8_t kind, uint8_t rs1, uint8_t rs2_or_rd, int32_t imm, uint32_t rs1_val,
+                         uint32_t rs2_val, uint32_t rd_before, uint32_t rd_after, uint32_t mem_byte_addr, uint32_t mem_before, uint32_t mem_after,
+                         uint64_t prev_cycle, uint64_t mem_prev_cycle) {
+    orc_step_record r;
+    memset(&r, 0, sizeof(r));
+    r.cycle = cycle;
+    r.pc_before = pc;
+    r.pc_after = pc + 4;
+    r.kind = kind; r.rs1_idx = rs1;
+    r.imm = imm;
+    r.has_rs1 = 1;
+    r.rs1.addr = ((uint32_t)rs1 << 8) / 4; r.rs1.value = rs1_val; r.rs1.previous_cycle = prev_cycle;
+    if (is_store) {
+        r.rs2_idx = rs2_or_rd; r.has_rs2 = 1;
+        r.rs2.addr = ((uint32_t)rs2_or_rd << 8) / 4; r.rs2.value = rs2_val; r.rs2.previous_cycle = prev_cycle;
+    } else {
+        r.rd_idx = rs2_or_rd; r.has_rd = 1;
+        r.rd.addr = ((uint32_t)rs2_or_rd << 8) / 4; r.rd.before = rd_before; r.rd.after = rd_after; r.rd.previous_cycle = prev_cycle;
+    }
+    r.has_memory_op = 1;
+    r.memory_op.addr = mem_byte_addr / 4; r.memory_op.before = mem_before; r.memory_op.after = mem_after; r.memory_op.previous_cycle = mem_prev_cycle;
+    r.syscall_index = 0xFFFFFFFFu;
+    memcpy(out, &r, sizeof(r));
+}
+
+/* MemAddr::assign_instance for a word-aligned address with max_bits = MEM_BITS = 30 (insn_base.rs:880-905) + ReadMEM / WriteMEM::assign_op (:517-545) */
+static void assign_mem(uint64_t* row, uint32_t prev_col, const uint32_t diff_cols[2], const uint32_t addr_cols[2], uint32_t* lkd, uint32_t addr,
+                       uint64_t prev_cycle, uint64_t shard_offset, uint64_t ts) {
+    const uint64_t p = aligned_prev_ts(prev_cycle, shard_offset);
+    row[prev_col] = p;
+    assign_lt(row, diff_cols, lkd, p, ts + 3); /* Tracer::SUBCYCLE_MEM */
+    row[addr_cols[0]] = addr & 0xffff;
+    row[addr_cols[1]] = addr >> 16;
+    lk_dyn(lkd, (addr & 0xffff) >> 2, 14);
+    lk_dyn(lkd, addr >> 16, 14); /* min(30 - 16, 16) */
+}
+
+/* LW: LoadInstruction::assign_instance (riscv/memory/load_v2.rs:197-255) + IMInstructionConfig (im_insn.rs:71-90); cols[24] in LwColumnMap order.
+ * SW: StoreInstruction::assign_instance (riscv/memory/store_v2.rs:138-177) + SInstructionConfig (s_insn.rs:77-96); cols[24] in SwColumnMap order. */
+int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[23];
+    for (int c = 0; c < 23; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_memory_op || (is_store ? !st->has_rs2 : !st->has_rd)) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        const uint16_t imm = (uint16_t)(int16_t)st->imm;
+        const int negative = (int16_t)st->imm < 0;
+        const uint32_t addr = st->rs1.value + (uint32_t)(int32_t)(int16_t)st->imm; /* wrapping_add_signed(imm_internal.0 as i32) */
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        if (!is_store) {
+            p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+            row[cols[6]] = register_index(st->rd.addr);
+            row[cols[7]] = p;
+            row[cols[8]] = st->rd.before & 0xffff;
+            row[cols[9]] = st->rd.before >> 16;
+            assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+            row[cols[15]] = st->rs1.value & 0xffff; row[cols[16]] = st->rs1.value >> 16;
+            row[cols[17]] = imm;
+            row[cols[18]] = negative ? 1 : 0;
+            assign_mem(row, cols[12], cols + 13, cols + 19, lk_dynamic, addr, st->memory_op.previous_cycle, shard_offset, ts);
+            row[cols[21]] = st->memory_op.before & 0xffff; row[cols[22]] = st->memory_op.before >> 16;
+        } else {
+            p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+            row[cols[6]] = register_index(st->rs2.addr);
+            row[cols[7]] = p;
+            assign_lt(row, cols + 8, lk_dynamic, p, ts + 1);
+            row[cols[13]] = st->rs1.value & 0xffff; row[cols[14]] = st->rs1.value >> 16;
+            row[cols[15]] = st->rs2.value & 0xffff; row[cols[16]] = st->rs2.value >> 16;
+            row[cols[17]] = imm;
+            row[cols[18]] = negative ? 1 : 0;
+            row[cols[19]] = st->memory_op.before & 0xffff; row[cols[20]] = st->memory_op.before >> 16;
+            lk_dyn(lk_dynamic, st->memory_op.before & 0xffff, 16); /* Value::new(memory_op.value.before, lkm) */
+            lk_dyn(lk_dynamic, st->memory_op.before >> 16, 16);
+            assign_mem(row, cols[10], cols + 11, cols + 21, lk_dynamic, addr, st->memory_op.previous_cycle, shard_offset, ts);
+        }
+    }
+    return 0;
+}

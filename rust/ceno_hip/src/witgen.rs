@@ -156,6 +156,20 @@ impl Witgen {
                                            raw_stream(steps.stream))
         })
     }
+    /// `witgen_lw`: the word load (register read, register write, memory read, address range checks)
+    pub fn lw(&self, map: &sys::ceno_hip_lw_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_lw(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                    lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_sw`: the word store (two register reads, memory write, address range checks)
+    pub fn sw(&self, map: &sys::ceno_hip_sw_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_sw(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                    lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
     /// `witgen_lui`
     pub fn lui(&self, map: &sys::ceno_hip_lui_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
         self.hal.check(unsafe {

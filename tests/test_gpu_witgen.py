@@ -444,3 +444,52 @@ def test_branch_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     mapped = sorted(cols[:nc])
     assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
     assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+@pytest.mark.parametrize("is_store", [False, True])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (500, 512, 0), (300, 512, 2)])
+def test_lw_sw_witness_and_lookups_match_cpu_assignment(dev, is_store, n, rows, offset):
+    """LW / SW: register reads / write, the memory access with its own timestamp comparison, the address limbs with their 14-bit range lookups"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _mem_records, _mem_steps
+
+    d = _mem_steps(n, is_store)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500                      # earlier in this shard
+        d["prev_cycles"][1::3] = 1                       # before the shard began: aligned to 0
+    recs = _mem_records(d, is_store)
+    nc = 23
+    rng = np.random.default_rng(23 + is_store)
+    cols = list(rng.permutation(nc + 5)[:nc]) + [nc + 5]
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 5) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    off = 996 if offset else 0
+    api.witgen_mem(dev, cols, is_store, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, off, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 5, rows)
+    exp, elkd, elkf = po.witgen_mem(cols, is_store, recs, idx, off, 0x1000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    unmapped = sorted(set(range(nc + 5)) - set(mapped))
+    assert (got[unmapped] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()            # columns the chip does not own stay untouched
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+def test_lw_sw_bad_arguments_fail_loudly(dev):
+    from ceno_amd import CenoHipError, api
+
+    with pytest.raises(CenoHipError):
+        api.witgen_mem(dev, list(range(23)) + [10], False, 8, 1, 8, 1, 8, 2)      # a column id beyond num_cols
+    dup = list(range(23)) + [23]
+    dup[21] = dup[0]
+    with pytest.raises(CenoHipError):
+        api.witgen_mem(dev, dup, True, 8, 1, 8, 1, 8, 2)                          # two fields on one column
+    with pytest.raises(CenoHipError):
+        api.witgen_mem(dev, list(range(23)) + [23], True, 0, 1, 8, 1, 8, 2)       # no step records

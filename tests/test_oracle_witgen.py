@@ -467,3 +467,73 @@ def test_branch_eq_oracle_inverse_marker(kind):
             k = 0 if a[0] != b[0] else 1
             assert row[5 + (1 - k)] == 0
     assert int(lkd.sum()) == 4 * n
+
+
+def _mem_steps(n, is_store):
+    """chips/lw.rs:69-101 / chips/sw.rs:88-117: base 0x1000 + 16 i, offsets 0, 4, -4, -8, memory value 111 i mod 10^6; plus edge cases (a high address,
+    the largest and smallest offsets, a wrapped sum, a previous access in an earlier shard)"""
+    i = np.arange(n, dtype=np.int64)
+    rs1 = 0x1000 + 16 * i
+    imm = np.array([0, 4, -4, -8], dtype=np.int64)[i % 4]
+    mem_val = (i * 111) % 1000000
+    prev_mem = (i * 77) % 500000
+    mem_prev_cycle = np.zeros(n, dtype=np.uint64)
+    if n >= 8:
+        rs1[1], imm[1] = 0x3FFF_F000, 2044        # both address limbs at their 14-bit limit region
+        rs1[2], imm[2] = 0x2000_0800, -2048       # the smallest offset
+        rs1[3], imm[3] = 0xFFFF_FFFC, 8           # the sum wraps: address 4
+        rs1[5], imm[5] = 0x3FFF_FFF8, 4           # the largest address MEM_BITS = 30 admits
+        mem_val[6], prev_mem[6] = 0xFFFF_FFFF, 0xFFFF_0001
+        mem_prev_cycle[7] = 8                     # touched two steps ago
+    addr = (rs1 + imm) & 0xFFFFFFFF
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), imms=imm, rs1_vals=rs1.astype(np.uint64),
+                rs2_vals=mem_val.astype(np.uint64), rd_before=(i % 200).astype(np.uint64), rd_after=mem_val.astype(np.uint64), mem_addrs=addr.astype(np.uint64),
+                mem_before=(prev_mem if is_store else mem_val).astype(np.uint64), mem_after=mem_val.astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64),
+                mem_prev_cycles=mem_prev_cycle)
+
+
+def _mem_records(d, is_store):
+    return po.step_records_mem(is_store, d["cycles"], d["pcs"], po.INSN_SW if is_store else po.INSN_LW, 2, 3 if is_store else 4, d["imms"], d["rs1_vals"],
+                               d["rs2_vals"], d["rd_before"], d["rd_after"], d["mem_addrs"], d["mem_before"], d["mem_after"], d["prev_cycles"],
+                               d["mem_prev_cycles"])
+
+
+@pytest.mark.parametrize("is_store", [False, True])
+def test_lw_sw_oracle_rows_satisfy_the_circuit_relations(is_store):
+    """load_v2.rs:60-135 / store_v2.rs:50-110: address = rs1 + sign-extended offset (mod 2^32) over u16 limbs; the loaded word is the memory word;
+    every timestamp difference re-adds to 2^MAX_TS_BITS + prev - now"""
+    n = 600
+    d = _mem_steps(n, is_store)
+    recs = _mem_records(d, is_store)
+    got, lkd, lkf = po.witgen_mem(list(range(23)) + [23], is_store, recs, np.arange(n), 0, 0x1000, n)
+    g = got.astype(np.int64)
+    assert np.array_equal(g[:, 0], d["pcs"].astype(np.int64)) and np.array_equal(g[:, 1], d["cycles"].astype(np.int64))
+    if is_store:
+        rs1, rs2, imm, sign, prev, addr = g[:, 13] + (g[:, 14] << 16), g[:, 15] + (g[:, 16] << 16), g[:, 17], g[:, 18], g[:, 19] + (g[:, 20] << 16), g[:, 21] + (g[:, 22] << 16)
+        assert np.array_equal(rs2, d["rs2_vals"].astype(np.int64)) and np.array_equal(prev, d["mem_before"].astype(np.int64))
+        assert np.array_equal(g[:, 2], np.full(n, 2)) and np.array_equal(g[:, 6], np.full(n, 3))
+        mem_prev, mem_diff = g[:, 10], g[:, 11] + (g[:, 12] << 16)
+    else:
+        rs1, imm, sign, addr, word = g[:, 15] + (g[:, 16] << 16), g[:, 17], g[:, 18], g[:, 19] + (g[:, 20] << 16), g[:, 21] + (g[:, 22] << 16)
+        assert np.array_equal(word, d["mem_before"].astype(np.int64))
+        assert np.array_equal(g[:, 8] + (g[:, 9] << 16), d["rd_before"].astype(np.int64)) and np.array_equal(g[:, 6], np.full(n, 4))
+        mem_prev, mem_diff = g[:, 12], g[:, 13] + (g[:, 14] << 16)
+    assert np.array_equal(rs1, d["rs1_vals"].astype(np.int64))
+    assert np.array_equal(sign, (d["imms"] < 0).astype(np.int64)) and np.array_equal(imm, d["imms"] & 0xFFFF)
+    assert np.array_equal((rs1 + imm + sign * 0xFFFF0000) & 0xFFFFFFFF, addr) and np.array_equal(addr, d["mem_addrs"].astype(np.int64))
+    assert not (addr & 3).any() and (addr >> 30 == 0).all()
+    assert np.array_equal(mem_prev, d["mem_prev_cycles"].astype(np.int64))
+    assert np.array_equal(mem_diff, (1 << 29) + mem_prev - (g[:, 1] + 3))
+    # 2 lookups per timestamp comparison (3 of them), 2 for the address, 2 more for a store's previous memory word
+    assert int(lkd.sum()) == (10 if is_store else 8) * n and int(lkf.sum()) == n
+    assert int(lkd[(1 << 14):(1 << 15)].sum()) >= 2 * n  # the 14-bit table takes the address checks (and shares no key with the others)
+
+
+def test_lw_sw_oracle_rejects_other_record_shapes():
+    d = _mem_steps(16, False)
+    with pytest.raises(ValueError):
+        po.witgen_mem(list(range(23)) + [23], True, _mem_records(d, False), np.arange(16))     # a load record has no rs2
+    with pytest.raises(ValueError):
+        po.witgen_mem(list(range(23)) + [23], False, _mem_records(d, True), np.arange(16))     # a store record has no rd
+    with pytest.raises(ValueError):
+        po.witgen_mem(list(range(23)) + [22], False, _mem_records(d, False), np.arange(16))    # column id out of range
