@@ -124,6 +124,8 @@ def lib():
         "ceno_hip_witgen_slti": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_branch_cmp": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_branch_eq": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
+        "ceno_hip_sumcheck_fused_eq_rounds": (i, [vp]),
+        "ceno_hip_sumcheck_set_claim": (i, [vp, vp, u64p]),
         "ceno_hip_witgen_lw": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_sw": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_lui": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),

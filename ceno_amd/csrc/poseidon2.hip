@@ -329,8 +329,12 @@ int merkle_build_upper(ceno_hip_ctx* ctx, ceno_hip_merkle* t, hipStream_t st, co
         t->host_top_pending = true;
     }
     int l = 1;
-    // levels with more than 2^14 nodes: one lane per node (throughput bound)
-    for (; l <= top && ((size_t)1 << (log_rows - l)) > ((size_t)1 << 14); l++) {
+    // levels with more than 2^top_from nodes: one lane per node (throughput bound)
+    static const int top_from = [] {
+        const char* e = getenv("CENO_HIP_MERKLE_TOP_FROM_LOG");
+        return e ? std::max(0, std::min(atoi(e), 30)) : 14;
+    }();
+    for (; l <= top && ((size_t)1 << (log_rows - l)) > ((size_t)1 << top_from); l++) {
         size_t np = (size_t)1 << (log_rows - l);
         hipLaunchKernelGGL(k_compress, dim3(grid_for(np, NT, MAXB)), dim3(NT), 0, st, t->levels[l - 1], np, t->levels[l],
                            inject ? inject[l] : (const uint64_t*)nullptr, pp);

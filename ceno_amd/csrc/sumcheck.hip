@@ -20,6 +20,7 @@
 // host spins on (or into a caller device buffer): one launch and no D2H copy per round.
 #include "sumcheck_dev.hpp"
 #include "sumcheck_gen.hpp"
+#include "sumcheck_tower.hpp"
 #include "sumcheck_small.hpp"
 
 #include <algorithm>
@@ -831,6 +832,16 @@ struct ceno_hip_sumcheck {
     MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
     size_t slots_per_round = 0;
     std::vector<void*> dev_allocs; // everything from ctx_alloc, freed on free()
+    // tower layers (sumcheck_tower.hpp): rounds [0, fast_upto) run on k_tower, whose message the host completes (sc_tower_message)
+    struct {
+        bool on = false;
+        int n_prod = 0, n_logup = 0, fast_upto = 0;
+        TowerCoef coef;
+        std::vector<E2> pt, inv1m;  // the eq point rt and 1 / (1 - rt_i) for the rounds that need it
+        E2 q0, c1, c2;              // q_{i-1} of the round answered last
+        bool has_claim = false;     // the caller stated the sum (ceno_hip_sumcheck_set_claim): round 0 needs two values instead of three
+        E2 claim0;
+    } eqf;
     bool owns_tower_eq = false;
     ceno_hip_mle* extra_owned = nullptr;  // eq table built by tower_layer_sumcheck_begin
     // LDS-blocked generic rounds (sumcheck_gen.hip): component tables and the slot schedule of every round, one device blob
@@ -1913,6 +1924,10 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 }
                 continue;
             }
+            if (sc->eqf.on && i < sc->eqf.fast_upto) {  // a tower layer's large rounds: one fused pass, one evaluation point fewer
+                launch_tower_round(sc->eqf.n_prod, sc->eqf.n_logup, i > 0 ? 2 : sc->eqf.has_claim ? 1 : 0, cl.d_slots + (size_t)i * k, sc->eqf.coef, pairs, ep, sc_grid(pairs), sc->st);
+                continue;
+            }
             DevPlan pl;
             pl.slots = cl.d_slots + (size_t)i * k;
             pl.use_out = i > 0 ? 1 : 0;
@@ -2013,6 +2028,35 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     return 0;
 }
 
+// A round of k_tower (sumcheck_tower.hpp) delivers q_i(1), q_i's leading coefficient and, in round 0, q_i(0); `h` leaves as the
+// message p_i(1), p_i(2), p_i(3) with p_i(X) = eq(X, rt_i) q_i(X).  `r` = the challenge of round i - 1.
+static void sc_tower_message(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h) {
+    auto& F = sc->eqf;
+    const E2 rt = F.pt[i];
+    const E2 q1{h[0], h[1]}, c2{h[2], h[3]};
+    E2 q0;
+    if (i == 0 && !F.has_claim) {
+        q0 = E2{h[4], h[5]};
+    } else if (i == 0) {
+        q0 = (F.claim0 - rt * q1) * F.inv1m[0];
+    } else {
+        // the claim this round answers: p_{i-1}(r) = eq(r, rt_{i-1}) q_{i-1}(r) = (1 - rt_i) q_i(0) + rt_i q_i(1)
+        const E2 rp = F.pt[i - 1];
+        const E2 eq_r = e2_one() - rp - r + e2_mul_base(rp * r, 2);
+        const E2 claim = eq_r * (F.q0 + r * (F.c1 + r * F.c2));
+        q0 = (claim - rt * q1) * F.inv1m[i];
+    }
+    const E2 c1 = q1 - q0 - c2;
+    const E2 qa = q0 + e2_mul_base(c1, 2) + e2_mul_base(c2, 4), qb = q0 + e2_mul_base(c1, 3) + e2_mul_base(c2, 9);  // q_i(2), q_i(3)
+    const E2 p1 = rt * q1;
+    const E2 p2 = (e2_mul_base(rt, 3) - e2_one()) * qa;        // eq(2, rt) = 3 rt - 1
+    const E2 p3 = (e2_mul_base(rt, 5) - E2{2, 0}) * qb;        // eq(3, rt) = 5 rt - 2
+    h[0] = p1.c0; h[1] = p1.c1; h[2] = p2.c0; h[3] = p2.c1; h[4] = p3.c0; h[5] = p3.c1;
+    F.q0 = q0;
+    F.c1 = c1;
+    F.c2 = c2;
+}
+
 // one round; out goes to host (h_out != NULL, waits for the message) or to device memory d_out
 static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* h_out, uint64_t* d_out) {
     ceno_hip_ctx* ctx = sc->ctx;
@@ -2046,6 +2090,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         timespec ta, tb;
         if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
         TRY(sc_take_message(sc, h_out));
+        if (sc->eqf.on && i < sc->eqf.fast_upto) sc_tower_message(sc, i, r, h_out);
         if (dbg) {
             clock_gettime(CLOCK_MONOTONIC, &tb);
             static timespec last_ret = {0, 0};
@@ -2425,5 +2470,68 @@ size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const
 }  // extern "C"
 
 // used by tower.hip: attach an MLE whose lifetime is tied to the sumcheck handle
+// Called by ceno_hip_tower_layer_sumcheck_begin on the handle it built (MLE 0 = eq(., rt), one common-factor group over every term):
+// turns the k_tower rounds on when the plan has exactly the shape the kernel is written for.  Anything else keeps the generic rounds.
+void sumcheck_enable_tower_fast(ceno_hip_sumcheck* sc, const uint64_t* rt, int n_prod, int n_logup) {
+    // (read per call, not cached: the test-suite switches it between sumchecks)
+    const char* e = getenv("CENO_HIP_TOWER_FAST_MIN_LOG");  // rounds with at least 2^this pairs run on k_tower
+    const int min_log = e ? std::max(atoi(e), 6) : 16;
+    if (!tower_fast_shape(n_prod, n_logup) || sc->d != 3 || sc->classes.size() != 1) return;
+    const ScClass& cl = sc->classes[0];
+    const int k = 1 + 2 * n_prod + 4 * n_logup;
+    if (cl.nv != sc->n || cl.dense || (int)cl.mles.size() != k || (int)cl.terms.size() != n_prod + 3 * n_logup || sc->n - min_log < 1) return;
+    for (int m = 0; m < k; m++)
+        if (cl.mles[m] != m || !sc->mles[m].cur_ext) return;
+    auto term_is = [&](int t, int a, int b) {
+        const ScTerm& T = sc->terms[cl.terms[t]];
+        return T.idx.size() == 2 && T.idx[0] == a && T.idx[1] == b && T.full.size() == 3;
+    };
+    auto& F = sc->eqf;
+    for (int i = 0; i < n_prod; i++) {
+        if (!term_is(i, 1 + 2 * i, 2 + 2 * i)) return;
+        F.coef.prod[i] = sc->terms[cl.terms[i]].coeff;
+    }
+    for (int j = 0; j < n_logup; j++) {
+        const int t = n_prod + 3 * j, b = 1 + 2 * n_prod + 4 * j;
+        if (!term_is(t, b, b + 3) || !term_is(t + 1, b + 1, b + 2) || !term_is(t + 2, b + 2, b + 3)) return;
+        const E2 an = sc->terms[cl.terms[t]].coeff, an2 = sc->terms[cl.terms[t + 1]].coeff;
+        if (an.c0 != an2.c0 || an.c1 != an2.c1) return;
+        F.coef.logup[j][0] = an;
+        F.coef.logup[j][1] = sc->terms[cl.terms[t + 2]].coeff;
+    }
+    F.fast_upto = sc->n - min_log;  // round i has 2^(n - 1 - i) pairs
+    F.pt.resize((size_t)F.fast_upto);
+    F.inv1m.assign((size_t)F.fast_upto, e2_zero());
+    // 1 / (1 - rt_i) for the rounds 0 .. fast_upto - 1, one inversion (prefix products)
+    std::vector<E2> pre((size_t)F.fast_upto, e2_one());
+    E2 run = e2_one();
+    for (int i = 0; i < F.fast_upto; i++) {
+        F.pt[i] = E2{rt[2 * i], rt[2 * i + 1]};
+        const E2 v = e2_one() - F.pt[i];
+        if (v.c0 == 0 && v.c1 == 0) return;  // rt_i = 1: the claim does not determine q_i(0)
+        pre[i] = run;
+        run = run * v;
+    }
+    E2 inv = e2_inv(run);
+    for (int i = F.fast_upto - 1; i >= 0; i--) {
+        F.inv1m[i] = inv * pre[i];
+        inv = inv * (e2_one() - F.pt[i]);
+    }
+    F.n_prod = n_prod;
+    F.n_logup = n_logup;
+    F.on = true;
+}
+
+extern "C" int ceno_hip_sumcheck_set_claim(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* claim2) {
+    CHECK_ARG(ctx, sc && claim2, "NULL argument");
+    CHECK_ARG(ctx, claim2[0] < gl::P && claim2[1] < gl::P, "sumcheck claim is not canonical");
+    if (sc->round != 0 || sc->enq != 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: the claim must be stated before round 0");
+    sc->eqf.has_claim = true;  // only the fused tower rounds use it; every other handle computes its messages without the sum
+    sc->eqf.claim0 = E2{claim2[0], claim2[1]};
+    return 0;
+}
+
+extern "C" int ceno_hip_sumcheck_fused_eq_rounds(const ceno_hip_sumcheck* sc) { return sc && sc->eqf.on ? sc->eqf.fast_upto : 0; }
+
 void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m) { sc->extra_owned = m; }
 void sumcheck_adopt_alloc(ceno_hip_sumcheck* sc, void* p) { if (p) sc->dev_allocs.push_back(p); }

@@ -352,6 +352,7 @@ int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
 }  // extern "C"
 
 void sumcheck_adopt_mle(ceno_hip_sumcheck* sc, ceno_hip_mle* m);
+void sumcheck_enable_tower_fast(ceno_hip_sumcheck* sc, const uint64_t* rt, int n_prod, int n_logup);
 void sumcheck_adopt_alloc(ceno_hip_sumcheck* sc, void* p);
 
 extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup,
@@ -381,7 +382,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
         gterms.push_back((uint32_t)toff.size() - 1);
         toff.push_back((uint32_t)tidx.size());
     };
-    int rc = 0;
+    int rc = 0, n_prod_live = 0, n_logup_live = 0;  // towers that have this layer
     for (int i = 0; i < n_prod && !rc; i++) {
         if (!prod[i] || prod[i]->n_limbs != 2) { rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "prod tower %d invalid", i); break; }
         if (prod[i]->num_vars <= layer) continue;  // spec has no layer `layer`
@@ -392,6 +393,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
             if (!rc) { views.push_back(v); mles.push_back(v); }
         }
         if (!rc) add_term(alpha_pows + 2 * i, {base, base + 1});
+        n_prod_live++;
     }
     for (int i = 0; i < n_logup && !rc; i++) {
         if (!logup[i] || logup[i]->n_limbs != 4) { rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "logup tower %d invalid", i); break; }
@@ -409,6 +411,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
         add_term(an, {p1, q2});
         add_term(an, {p2, q1});
         add_term(ad, {q1, q2});
+        n_logup_live++;
     }
     if (!rc && toff.size() == 1) rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "no tower has layer %d", layer);
     if (rc) {
@@ -456,6 +459,8 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
         ceno_hip_mle_free(ctx, eq);
         return rc;
     }
+    const bool fast = !(getenv("CENO_HIP_TOWER_FAST") && atoi(getenv("CENO_HIP_TOWER_FAST")) == 0);  // A/B switch (read per call: tests toggle it)
+    if (fast) sumcheck_enable_tower_fast(*out, out_rt, n_prod_live, n_logup_live);
     sumcheck_adopt_mle(*out, eq);      // eq lives as long as the sumcheck
     sumcheck_adopt_alloc(*out, eq_tmp);
     return 0;

@@ -325,6 +325,8 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         for (int i = 0; i < n_logup; i++)
             if (int rc = fetch(logup[i], top_logup[i])) return fail_from_ctx(ctx, rc);
     }
+    E2 claim = gl::e2_zero();  // the sum the next layer's sumcheck proves, known from the layer before it (round 1: from the out-evals, not formed here)
+    bool have_claim = false;
     for (int round = 1; round <= R; round++) {      // cpu/mod.rs:409: skip(1) for the output layer
         bool on_host = round <= host_layers;
         for (int i = 0; i < n_prod && on_host; i++)
@@ -379,6 +381,11 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         chal.assign((size_t)2 * round, 0);
         fin.assign((size_t)2 * n_mles, 0);
         ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // the loop below drives the rounds back to back
+        if (have_claim) {                             // the fused tower rounds then need two values in round 0 instead of three
+            const uint64_t c2[2] = {claim.c0, claim.c1};
+            rc = ceno_hip_sumcheck_set_claim(ctx, sc, c2);
+            if (rc) { ceno_hip_sumcheck_free(ctx, sc); return fail_from_ctx(ctx, rc); }
+        }
         rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + msg_off, chal.data(), fin.data());
         const double t_c = dbg ? now_us() : 0;
         ceno_hip_sumcheck_free(ctx, sc);
@@ -412,6 +419,28 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         out_rt[2 * round] = r_merge.c0;
         out_rt[2 * round + 1] = r_merge.c1;
         tr_challenge_pows(tr, n_alpha, alpha);       // cpu/mod.rs:538-541
+        // What layer round + 1 will prove: the alpha-combination (new powers) of this layer's tables merged at r_merge — a tower's layer as one
+        // vector is [first half | second half], r_merge binds the top variable (the sum TowerVerify forms, scheme/verifier.rs:1587-1680).
+        claim = gl::e2_zero();
+        cursor = 1;
+        for (int i = 0; i < n_prod; i++) {
+            const int nv = ceno_hip_tower_num_vars(prod[i]);
+            if (nv <= round) continue;
+            const E2 a{fin[2 * cursor], fin[2 * cursor + 1]}, b{fin[2 * cursor + 2], fin[2 * cursor + 3]};
+            if (nv > round + 1) claim = claim + E2{alpha[2 * i], alpha[2 * i + 1]} * (a + r_merge * (b - a));
+            cursor += 2;
+        }
+        for (int i = 0; i < n_logup; i++) {
+            const int nv = ceno_hip_tower_num_vars(logup[i]);
+            if (nv <= round) continue;
+            auto f = [&](int k) { return E2{fin[2 * (cursor + k)], fin[2 * (cursor + k) + 1]}; };
+            if (nv > round + 1) {
+                const E2 an{alpha[2 * (n_prod + 2 * i)], alpha[2 * (n_prod + 2 * i) + 1]}, ad{alpha[2 * (n_prod + 2 * i + 1)], alpha[2 * (n_prod + 2 * i + 1) + 1]};
+                claim = claim + an * (f(0) + r_merge * (f(1) - f(0))) + ad * (f(2) + r_merge * (f(3) - f(2)));
+            }
+            cursor += 4;
+        }
+        have_claim = true;
     }
     memcpy(out->point, out_rt.data(), (size_t)16 * max_nv);
     return 0;

@@ -260,6 +260,16 @@ int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t);
 int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
                                         int layer, const uint64_t* out_rt /* `layer` ext */, const uint64_t* alpha_pows,
                                         ceno_hip_stream s, ceno_hip_sumcheck** out);
+/* How many leading rounds of this handle run on the fused tower-layer kernel when it is driven pipelined (one pass per round, the eq
+ * factor taken out of the evaluation points; the messages are the same field elements): 0 for every other handle.  Diagnostics and
+ * tests only; CENO_HIP_TOWER_FAST=0 turns the kernel off, CENO_HIP_TOWER_FAST_MIN_LOG moves the hand-over to the generic rounds. */
+int ceno_hip_sumcheck_fused_eq_rounds(const ceno_hip_sumcheck* sc);
+/* Optional, before round 0: the sum this sumcheck proves (one extension element), when the caller has it — the tower prover does: the
+ * claim of layer l + 1 is the alpha-combination of layer l's evaluations merged at r_merge (scheme/cpu/mod.rs:497-541, as
+ * TowerVerify recomputes it, scheme/verifier.rs:1587-1680).  The fused tower rounds then evaluate two points in round 0 instead of three;
+ * handles without them ignore it.  A WRONG claim yields wrong messages for those rounds — the reference's prover never needs the sum,
+ * so nothing checks it here. */
+int ceno_hip_sumcheck_set_claim(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* claim2);
 
 /* ------------------------------------------------------------------------------------------------
  * Basefold commit path  (cuda_hal.basefold.batch_commit, ceno_zkvm/src/scheme/gpu/mod.rs:1642-1646;

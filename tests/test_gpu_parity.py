@@ -974,6 +974,58 @@ def test_sumcheck_host_finished_tail_every_split(dev, prover, monkeypatch, cap, 
 
 @pytest.mark.parametrize("seed", range(8))
 def test_tower_random_specs_differential(dev, prover, seed):
+    _tower_random_specs_differential(dev, prover, seed)
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("host_layers", [4, 8])
+def test_tower_fused_eq_rounds_random_specs_differential(dev, prover, monkeypatch, seed, host_layers):
+    """the same batches with the fused tower-layer kernel (sumcheck_tower.hip) taking every round of at least 2^6 pairs: the host completes
+    each of its messages from q(1), the leading coefficient and the running claim, and proof and evaluations stay the oracle's bit for bit"""
+    monkeypatch.setenv("CENO_HIP_TOWER_FAST_MIN_LOG", "6")
+    monkeypatch.setenv("CENO_TOWER_HOST_LAYERS", str(host_layers))
+    _tower_random_specs_differential(dev, prover, seed)
+
+
+def test_tower_fused_eq_rounds_engage_only_on_the_tower_shape(dev, prover, monkeypatch):
+    """ceno_hip_sumcheck_fused_eq_rounds: n - min_log leading rounds for a tower layer, none when switched off, none for other handles"""
+    import ctypes as C
+
+    lasts = [[po.rand_ext(1 << 10, 61), po.rand_ext(1 << 10, 62)], [po.rand_ext(1 << 8, 63), po.rand_ext(1 << 8, 64)]]
+    lk = [po.rand_ext(1 << 10, 70 + j) for j in range(4)]
+    pt = [prover.Tower.from_last_layer(dev, [dev.upload(x) for x in l]) for l in lasts]
+    lt = prover.Tower.from_last_layer(dev, [dev.upload(x) for x in lk])
+    rt = po.rand_ext(10, 77)
+    alphas = po.rand_ext(4, 78)
+
+    def fused_rounds(layer):
+        pa = (C.c_void_p * 2)(pt[0].h, pt[1].h)
+        la = (C.c_void_p * 1)(lt.h)
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_tower_layer_sumcheck_begin(dev.h, pa, 2, la, 1, layer, rt.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                            alphas.ctypes.data_as(C.POINTER(C.c_uint64)), None, C.byref(h)))
+        n = dev.L.ceno_hip_sumcheck_fused_eq_rounds(h)
+        dev.check(dev.L.ceno_hip_sumcheck_free(dev.h, h))
+        return n
+
+    monkeypatch.setenv("CENO_HIP_TOWER_FAST_MIN_LOG", "6")
+    assert fused_rounds(10) == 4 and fused_rounds(8) == 2 and fused_rounds(6) == 0   # layer 10: only the first product tower and the LogUp tower have it
+    monkeypatch.setenv("CENO_HIP_TOWER_FAST", "0")
+    assert fused_rounds(10) == 0
+    monkeypatch.delenv("CENO_HIP_TOWER_FAST")
+    monkeypatch.delenv("CENO_HIP_TOWER_FAST_MIN_LOG")
+    assert fused_rounds(10) == 0                                                        # default hand-over: rounds of 2^16 pairs and more
+    from ceno_amd import Sumcheck
+
+    tabs = [dev.upload(po.rand_ext(1 << 9, 80 + j)) for j in range(3)]
+    sc = Sumcheck(dev, tabs, po.ext([(1, 0)]), [[0, 1, 2]], 9, 3)
+    assert dev.L.ceno_hip_sumcheck_fused_eq_rounds(sc.h) == 0
+    sc.free()
+    for t in pt + [lt] + tabs:
+        t.free()
+
+
+def _tower_random_specs_differential(dev, prover, seed):
     """seeded random tower batches (0-3 product specs, 0-2 LogUp specs with or without numerators, heights 2-13 so that
     layers cross the tile / two-kernel thresholds): out-evals, every message, every per-round evaluation and the point
     equal the oracle's; the restated TowerVerify accepts"""
