@@ -80,6 +80,15 @@ impl Sumcheck {
     pub fn set_pipelined(&mut self, on: bool) -> Result<()> {
         self.hal.check(unsafe { sys::ceno_hip_sumcheck_set_pipelined(self.hal.ctx, self.raw, on as i32) })
     }
+    /// optional, before round 0: the sum this sumcheck proves.  Only the fused tower-layer rounds use it (two evaluation points in round 0
+    /// instead of three); a tower prover has it from the layer before (`TowerVerify`'s expected evaluation, `scheme/verifier.rs:1587-1680`)
+    pub fn set_claim(&mut self, claim: ExtWords) -> Result<()> {
+        self.hal.check(unsafe { sys::ceno_hip_sumcheck_set_claim(self.hal.ctx, self.raw, claim.as_ptr()) })
+    }
+    /// how many leading rounds run on the fused tower-layer kernel (0 for every other handle): diagnostics
+    pub fn fused_eq_rounds(&self) -> usize {
+        unsafe { sys::ceno_hip_sumcheck_fused_eq_rounds(self.raw) as usize }
+    }
     /// message of the next round: p(1..d); `challenge` = the previous round's (None for round 0)
     pub fn round(&mut self, challenge: Option<ExtWords>) -> Result<Vec<ExtWords>> {
         let mut out = vec![[0u64; 2]; self.degree];

@@ -91,6 +91,8 @@ pub fn create_proof(hal: &Arc<HipHal>, prod: &[&HipTower], logup: &[&HipTower], 
                                                      out_rt.as_ptr() as *const u64, alpha.as_ptr() as *const u64, raw_stream(stream), &mut sc)
         })?;
         // MLE order of the handle: [eq, active prod (a, b).., active logup (p1, p2, q1, q2)..]
+        // (this crate moves boundary words and has no field arithmetic: the zkvm arm, which has E, states each layer's claim with
+        // Sumcheck::set_claim before running it — INTEGRATION.md, TowerProver row; without it the proof is the same, round 0 a third dearer)
         let n_mles = 1 + 2 * prod.iter().filter(|t| t.num_vars() > round).count() + 4 * logup.iter().filter(|t| t.num_vars() > round).count();
         let (msgs, evals, point) = Sumcheck::from_raw(hal, sc, round, 3, n_mles).run(transcript)?;
         proof.proofs.push(msgs);
