@@ -436,6 +436,41 @@ def witgen_branch(dev: Device, cols, is_eq: bool, flag: bool, records_ptr: int, 
                  fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
 
 
+def witgen_shift(dev: Device, cols, is_imm: bool, kind: int, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+                 shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0,
+                 lk_double_u8_ptr: int = 0, lk_xor_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_shift_r / witgen_shift_i (kind 0 = left, 1 = logical right, 2 = arithmetic right): `cols` = the 47 / 40 column ids in
+    ShiftRColumnMap / ShiftIColumnMap field order followed by num_cols"""
+    nc = 40 if is_imm else 47
+
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(nc):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[nc])
+    fn = dev.L.ceno_hip_witgen_shift_i if is_imm else dev.L.ceno_hip_witgen_shift_r
+    dev.check(fn(dev.h, C.byref(m), int(kind), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
+                 C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
+                 C.c_void_p(lk_double_u8_ptr or None), C.c_void_p(lk_xor_ptr or None), stream))
+
+
+def witgen_jalr(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_jalr (GpuWitgenKind::Jalr): `cols` = the 22 column ids in JalrColumnMap field order followed by num_cols"""
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * 22), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(22):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[22])
+    dev.check(dev.L.ceno_hip_witgen_jalr(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
+                                         fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
+                                         C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 def witgen_mem(dev: Device, cols, is_store: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_lw / witgen_sw: `cols` = the 23 column ids in LwColumnMap / SwColumnMap field order followed by num_cols"""

@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, LW and SW.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, LW and SW.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(NT) k_witgen_lui(LuiMap m, const unsigned char
 // ---- JAL (JalInstruction, ceno_zkvm/src/instructions/riscv/jump/jal_v2.rs:99-127; J-instruction base j_insn.rs:58-73: state with next_pc,
 // rd write, fetch): rd = pc + 4 as four bytes, range-checked pairwise in the double-byte table (key a << 8 | b), the top byte also XORed
 // with 0xC0 in the XOR table (PC_BITS = 30: the two bits above the program counter's range must be clear).  13 mapped columns.
+constexpr uint32_t PC_BITS = 30;  // riscv/constants.rs
 constexpr uint32_t PC_MSB_MASK = 0xC0;  // sum of 2^x for x in PC_BITS - 24 .. 8 (riscv/constants.rs:29, jal_v2.rs:120-124)
 struct JalMap {  // ceno_hip_jal_column_map = ceno_gpu's JalColumnMap (chips/jal.rs:21-31)
     uint32_t pc, next_pc, ts;
@@ -848,6 +849,152 @@ __global__ void __launch_bounds__(NT) k_witgen_mem(MapT m, const unsigned char* 
     }
 }
 
+// ---- JALR (JalrInstruction, riscv/jump/jalr_v2.rs:146-190 over IInstructionConfig with a branching state: pc, next_pc, ts): rs1 as limbs, the
+// offset's low 16 bits and its sign, the jump target rs1 + sign_extend(imm) as a MemAddr with max_bits = PC_BITS = 30 and BOTH low bits
+// witnessed (construct_with_max_bits(cb, 0, PC_BITS); next_pc is the target rounded down to an even address), rd = pc + 4 with its high limb
+// witnessed and both limbs range-checked (16 bits, PC_BITS - 16 bits).  22 mapped columns.
+struct JalrMap {  // ceno_hip_jalr_column_map = ceno_gpu's JalrColumnMap (chips/jalr.rs:31-49)
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, jump_pc_addr[2], jump_pc_addr_bit[2], rd_high;
+    uint32_t num_cols;
+};
+static_assert(sizeof(JalrMap) == sizeof(ceno_hip_jalr_column_map), "column map layout");
+constexpr int JALR_COLS = 22;
+
+template <bool XCD_LOCAL>
+__global__ void __launch_bounds__(NT) k_witgen_jalr(JalrMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                    uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                    uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<JALR_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint32_t pc_after = *reinterpret_cast<const uint32_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES + OFF_PC_AFTER);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.next_pc, pc_after);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t imm16 = st.imm & 0xffff, neg = (imm16 >> 15) & 1u;
+        const uint32_t target = st.rs1_val + (imm16 | (neg ? 0xffff0000u : 0u));  // rs1.overflowing_add_signed(sign-extended imm)
+        o.put(m.rs1_limbs[0], st.rs1_val & 0xffff);
+        o.put(m.rs1_limbs[1], st.rs1_val >> 16);
+        o.put(m.imm, imm16);
+        o.put(m.imm_sign, neg);
+        o.put(m.jump_pc_addr[0], target & 0xffff);
+        o.put(m.jump_pc_addr[1], target >> 16);
+        o.put(m.jump_pc_addr_bit[0], target & 1u);
+        o.put(m.jump_pc_addr_bit[1], (target >> 1) & 1u);
+        o.put(m.rd_high, st.rd_after >> 16);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (st.rd_after & 0xffff));             // assert_const_range(rd_limb[0], 16)
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << (PC_BITS - 16)) + (st.rd_after >> 16));    // assert_const_range(rd_limb[1], PC_BITS - 16)
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 14) + ((target & 0xffff) >> 2));           // MemAddr: assert_ux::<14>(mid_u14)
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << (PC_BITS - 16)) + (target >> 16));         // MemAddr: assert_const_range(high limb, PC_BITS - 16)
+    }
+}
+
+// ---- shifts: SLL / SRL / SRA (ShiftLogicalInstruction, riscv/shift/shift_circuit_v2.rs:359-396 over RInstructionConfig) and SLLI / SRLI / SRAI
+// (ShiftImmInstruction, :485-521 over IInstructionConfig).  Operands and result as BYTES (the result's pairs in the double-byte table), and the
+// ShiftBase gadget (:242-293): the shift amount c[0] mod 32 split into limb_shift (c / 8) and bit_shift (c mod 8) as one-hot markers, the power
+// 2^bit_shift in the left (SLL) or right (SRL / SRA) multiplier column, per operand byte the bits that cross into the neighbour byte (range
+// lookups of bit_shift bits), (c[0] - shift) >> 5 as a 3-bit range lookup, and for SRA the operand's sign with its top byte XORed with 128.
+// 47 (R) / 40 (I) mapped columns.
+struct ShiftRMap {  // ceno_hip_shift_r_column_map = ceno_gpu's ShiftRColumnMap (chips/shift_r.rs:36-59)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_bytes[4], rs2_bytes[4], rd_bytes[4];
+    uint32_t bit_shift_marker[8], limb_shift_marker[4], bit_multiplier_left, bit_multiplier_right, b_sign, bit_shift_carry[4];
+    uint32_t num_cols;
+};
+static_assert(sizeof(ShiftRMap) == sizeof(ceno_hip_shift_r_column_map), "column map layout");
+struct ShiftIMap {  // ceno_hip_shift_i_column_map = ceno_gpu's ShiftIColumnMap (chips/shift_i.rs:33-53)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_bytes[4], rd_bytes[4], imm;
+    uint32_t bit_shift_marker[8], limb_shift_marker[4], bit_multiplier_left, bit_multiplier_right, b_sign, bit_shift_carry[4];
+    uint32_t num_cols;
+};
+static_assert(sizeof(ShiftIMap) == sizeof(ceno_hip_shift_i_column_map), "column map layout");
+constexpr int SHIFT_R_COLS = 47, SHIFT_I_COLS = 40;
+
+// KIND 0: shift left, 1: logical right, 2: arithmetic right (GpuWitgenKind::ShiftR / ShiftI's argument)
+template <bool XCD_LOCAL, bool IMM, class MapT>
+__global__ void __launch_bounds__(NT) k_witgen_shift(MapT m, int kind, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                     uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                     uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    lk_du8 = xcd_copy<XCD_LOCAL>(lk_du8, LOGIC_SLOTS);
+    lk_xor = xcd_copy<XCD_LOCAL>(lk_xor, LOGIC_SLOTS);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<IMM ? SHIFT_I_COLS : SHIFT_R_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        uint32_t c;
+        if constexpr (IMM) {
+            c = st.imm & 0xffff;  // insn.imm as i16 as u16
+            o.put(m.imm, c);
+        } else {
+            c = st.rs2_val;
+            emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+#pragma unroll
+            for (int k = 0; k < 4; k++) o.put(m.rs2_bytes[k], (c >> (8 * k)) & 0xff);
+        }
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t b = st.rs1_val, d = st.rd_after;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o.put(m.rs1_bytes[k], (b >> (8 * k)) & 0xff);
+            o.put(m.rd_bytes[k], (d >> (8 * k)) & 0xff);
+        }
+        lk_count<XCD_LOCAL>(lk_du8, ((d & 0xff) << 8) + ((d >> 8) & 0xff));  // assert_double_u8 per byte pair of the result
+        lk_count<XCD_LOCAL>(lk_du8, (((d >> 16) & 0xff) << 8) + (d >> 24));
+        const uint32_t c0 = c & 0xff, shift = c0 & 31, limb_shift = shift >> 3, bit_shift = shift & 7;
+        o.put(m.bit_multiplier_left, kind == 0 ? (1u << bit_shift) : 0u);
+        o.put(m.bit_multiplier_right, kind == 0 ? 0u : (1u << bit_shift));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t byte = (b >> (8 * k)) & 0xff;
+            const uint32_t carry = kind == 0 ? (byte >> (8 - bit_shift)) : (byte & ((1u << bit_shift) - 1));
+            o.put(m.bit_shift_carry[k], carry);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << bit_shift) + carry);  // assert_dynamic_range(carry, bit_shift)
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) o.put(m.bit_shift_marker[k], k == (int)bit_shift ? 1u : 0u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) o.put(m.limb_shift_marker[k], k == (int)limb_shift ? 1u : 0u);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 3) + ((c0 - shift) >> 5));  // assert_const_range((c[0] - bit_shift - 8 limb_shift) >> 5, 3)
+        uint32_t sign = 0;
+        if (kind == 2) {
+            sign = b >> 31;
+            lk_count<XCD_LOCAL>(lk_xor, (b >> 24) | (128u << 8));  // lookup_xor_byte(top byte, 1 << 7)
+        }
+        o.put(m.b_sign, sign);
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -981,6 +1128,36 @@ int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, cons
         else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
+template <bool IMM, class MapT>
+int witgen_shift(ceno_hip_ctx* ctx, const MapT* map, int kind, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+                 uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor,
+                 ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    CHECK_ARG(ctx, kind >= 0 && kind <= 2, "witgen_shift: kind is 0 (left), 1 (logical right) or 2 (arithmetic right)");
+    TRY(witgen_check(ctx, &map->pc, IMM ? SHIFT_I_COLS : SHIFT_R_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
+        if (xcd) hipLaunchKernelGGL((k_witgen_shift<true, IMM, MapT>), dim3(grid), dim3(NT), 0, st, *map, kind, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+        else hipLaunchKernelGGL((k_witgen_shift<false, IMM, MapT>), dim3(grid), dim3(NT), 0, st, *map, kind, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
+    });
+}
+
+int witgen_jalr(ceno_hip_ctx* ctx, const JalrMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset, uint32_t fetch_base,
+                uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    TRY(witgen_check(ctx, &map->pc, JALR_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+        if (xcd) hipLaunchKernelGGL(k_witgen_jalr<true>, dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else hipLaunchKernelGGL(k_witgen_jalr<false>, dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+    });
+}
 template <bool STORE, class MapT>
 int witgen_mem(ceno_hip_ctx* ctx, const MapT* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset, uint32_t fetch_base,
                uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
@@ -1080,6 +1257,32 @@ int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column
     CHECK_ARG(ctx, is_beq == 0 || is_beq == 1, "witgen_branch_eq: is_beq is 1 (BEQ) or 0 (BNE)");
     return witgen_branch<1>(ctx, reinterpret_cast<const BranchEqMap*>(map), BRANCH_EQ_COLS, is_beq, dev_step_records, num_records, dev_step_indices, n,
                             shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_shift_r(ceno_hip_ctx* ctx, const ceno_hip_shift_r_column_map* map, int kind, const void* dev_step_records, size_t num_records,
+                            const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                            uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                            uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_shift<false>(ctx, reinterpret_cast<const ShiftRMap*>(map), kind, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                               fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_double_u8, dev_lk_xor, s);
+}
+
+int ceno_hip_witgen_shift_i(ceno_hip_ctx* ctx, const ceno_hip_shift_i_column_map* map, int kind, const void* dev_step_records, size_t num_records,
+                            const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                            uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                            uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_shift<true>(ctx, reinterpret_cast<const ShiftIMap*>(map), kind, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                              fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_double_u8, dev_lk_xor, s);
+}
+
+int ceno_hip_witgen_jalr(ceno_hip_ctx* ctx, const ceno_hip_jalr_column_map* map, const void* dev_step_records, size_t num_records,
+                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_jalr(ctx, reinterpret_cast<const JalrMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                       fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_lw(ceno_hip_ctx* ctx, const ceno_hip_lw_column_map* map, const void* dev_step_records, size_t num_records,

@@ -500,6 +500,48 @@ int ceno_hip_witgen_branch_cmp(ceno_hip_ctx* ctx, const ceno_hip_branch_cmp_colu
 int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column_map* map, int is_beq, const void* dev_step_records, size_t num_records,
                               const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                               uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+/* Shifts: hal.witgen.witgen_shift_r / witgen_shift_i (GpuWitgenKind::ShiftR(kind) / ShiftI(kind), kind 0 = SLL / SLLI, 1 = SRL / SRLI, 2 = SRA / SRAI;
+ * chips/shift_r.rs:12-60, chips/shift_i.rs:9-54; CPU assignment riscv/shift/shift_circuit_v2.rs:359-396,485-521 with the ShiftBase gadget :242-293).
+ * The result is StepRecord.rd.value.after; its byte pairs count into the double-byte table, SRA's sign lookup into the XOR table.  47 / 40 mapped columns. */
+typedef struct ceno_hip_shift_r_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_bytes[4], rs2_bytes[4], rd_bytes[4];
+    uint32_t bit_shift_marker[8], limb_shift_marker[4], bit_multiplier_left, bit_multiplier_right, b_sign, bit_shift_carry[4];
+    uint32_t num_cols;
+} ceno_hip_shift_r_column_map;
+typedef struct ceno_hip_shift_i_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_bytes[4], rd_bytes[4], imm;
+    uint32_t bit_shift_marker[8], limb_shift_marker[4], bit_multiplier_left, bit_multiplier_right, b_sign, bit_shift_carry[4];
+    uint32_t num_cols;
+} ceno_hip_shift_i_column_map;
+int ceno_hip_witgen_shift_r(ceno_hip_ctx* ctx, const ceno_hip_shift_r_column_map* map, int kind, const void* dev_step_records, size_t num_records,
+                            const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                            uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                            uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s);
+int ceno_hip_witgen_shift_i(ceno_hip_ctx* ctx, const ceno_hip_shift_i_column_map* map, int kind, const void* dev_step_records, size_t num_records,
+                            const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                            uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                            uint32_t* dev_lk_double_u8, uint32_t* dev_lk_xor, ceno_hip_stream s);
+
+/* JALR: hal.witgen.witgen_jalr (GpuWitgenKind::Jalr; chips/jalr.rs:12-50; CPU assignment riscv/jump/jalr_v2.rs:146-190 + i_insn.rs:66-82; the
+ * jump target's MemAddr insn_base.rs:880-905 with max_bits = PC_BITS and both low bits witnessed).  22 mapped columns. */
+typedef struct ceno_hip_jalr_column_map {
+    uint32_t pc, next_pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, jump_pc_addr[2], jump_pc_addr_bit[2], rd_high;
+    uint32_t num_cols;
+} ceno_hip_jalr_column_map;
+int ceno_hip_witgen_jalr(ceno_hip_ctx* ctx, const ceno_hip_jalr_column_map* map, const void* dev_step_records, size_t num_records,
+                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+
 /* LW / SW: hal.witgen.witgen_lw / witgen_sw (GpuWitgenKind::Lw / Sw; chips/lw.rs:12-54, chips/sw.rs:12-50; CPU assignment
  * riscv/memory/load_v2.rs:197-255 + im_insn.rs:71-90 and store_v2.rs:138-177 + s_insn.rs:77-96; memory access insn_base.rs:517-545,650-680,
  * address checks :880-905).  The memory operand is StepRecord.memory_op; the shard RAM records of the access are not produced here.

@@ -266,6 +266,13 @@ void orc_step_record_mem(void* out, int is_store, uint64_t cycle, uint32_t pc, u
                          uint64_t prev_cycle, uint64_t mem_prev_cycle);
 int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* JALR (jalr_v2.rs:146-190): cols[23] in JalrColumnMap order */
+int orc_witgen_jalr(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* shifts (shift_circuit_v2.rs:242-293,359-396,485-521): cols[48] in ShiftRColumnMap order / cols[41] in ShiftIColumnMap order; kind 0 left, 1 logical right, 2 arithmetic right */
+int orc_witgen_shift(const uint32_t* cols, int is_imm, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                     uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_double_u8,
+                     uint32_t* lk_xor);
 /* JAL (jal_v2.rs:99-127) and AUIPC (auipc.rs:149-187): cols[14] / cols[22] in JalColumnMap / AuipcColumnMap order; double_u8 key a << 8 | b */
 void orc_step_record_j(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rd, int32_t imm, uint32_t rd_before,
                        uint32_t rd_after, uint64_t prev_cycle);

@@ -875,6 +875,60 @@ def witgen_auipc(cols, records, indices, shard_offset=0, fetch_base_pc=0, fetch_
     return _witgen_4tab(lib().orc_witgen_auipc, 21, cols, records, indices, shard_offset, fetch_base_pc, fetch_num_slots)
 
 
+INSN_SLL, INSN_SRL, INSN_SRA, INSN_SLLI, INSN_SRLI, INSN_SRAI = 6, 7, 8, 15, 16, 17  # InsnKind discriminants
+
+
+def witgen_shift(cols, is_imm: bool, kind: int, records, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of a shift chip (kind 0 left, 1 logical right, 2 arithmetic right): (matrix, dynamic, fetch, double-u8, xor counts)"""
+    nc = 40 if is_imm else 47
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (nc + 1,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    lk2 = np.zeros(1 << 16, dtype=np.uint32)
+    lkx = np.zeros(1 << 16, dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 5
+    L.orc_witgen_shift.restype = C.c_int
+    rc = L.orc_witgen_shift(cols.ctypes.data, int(is_imm), int(kind), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots,
+                            out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data, lk2.ctypes.data, lkx.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_shift rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots], lk2, lkx
+
+
+INSN_JALR = 27  # InsnKind::JALR
+
+
+def step_records_jalr(cycles, pcs, pcs_after, rs1, rd, imms, rs1_vals, rd_before, rd_after, prev_cycles) -> np.ndarray:
+    """an I-type record (StepRecord::new_i_instruction) whose pc.after is the jump target"""
+    recs = step_records_i(cycles, pcs, INSN_JALR, rs1, rd, imms, rs1_vals, rd_before, rd_after, prev_cycles)
+    recs[:, 12:16] = np.ascontiguousarray(np.asarray(pcs_after, dtype=np.uint64).astype("<u4")).view(np.uint8).reshape(-1, 4)
+    return recs
+
+
+def witgen_jalr(cols, records, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of the JALR chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (23,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_jalr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_witgen_jalr.restype = C.c_int
+    rc = L.orc_witgen_jalr(cols.ctypes.data, recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots, out.ctypes.data,
+                           lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_jalr rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_LW, INSN_SW = 38, 45  # InsnKind::LW; SW = after LUI, AUIPC, SB, SH (u16limb_circuit feature)
 
 

@@ -727,3 +727,139 @@ int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, cons
     }
     return 0;
 }
+
+
+/* JalrInstruction::assign_instance (riscv/jump/jalr_v2.rs:146-190): imm = insn.imm as i16 as u16 with its sign, rd.after as limbs (low: 16-bit range,
+ * high: PC_BITS - 16 = 14-bit range, witnessed as rd_high), rs1 limbs, the target rs1 + sign-extended imm as a MemAddr with both low bits witnessed and
+ * max_bits = PC_BITS (insn_base.rs:880-905), then the I-instruction base with a branching state (pc, next_pc, ts).  cols[23]: JalrColumnMap order. */
+int orc_witgen_jalr(const uint32_t* cols, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[22];
+    for (int c = 0; c < 22; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = st->pc_after;
+        row[cols[2]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[3]] = register_index(st->rs1.addr);
+        row[cols[4]] = p;
+        assign_lt(row, cols + 5, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[7]] = register_index(st->rd.addr);
+        row[cols[8]] = p;
+        row[cols[9]] = st->rd.before & 0xffff;
+        row[cols[10]] = st->rd.before >> 16;
+        assign_lt(row, cols + 11, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint32_t target = st->rs1.value + (uint32_t)(int32_t)(int16_t)st->imm;
+        row[cols[13]] = st->rs1.value & 0xffff;
+        row[cols[14]] = st->rs1.value >> 16;
+        row[cols[15]] = (uint16_t)(int16_t)st->imm;
+        row[cols[16]] = (int16_t)st->imm < 0 ? 1 : 0;
+        row[cols[17]] = target & 0xffff;
+        row[cols[18]] = target >> 16;
+        row[cols[19]] = target & 1;
+        row[cols[20]] = (target >> 1) & 1;
+        row[cols[21]] = st->rd.after >> 16;
+        lk_dyn(lk_dynamic, st->rd.after & 0xffff, 16);
+        lk_dyn(lk_dynamic, st->rd.after >> 16, 14); /* PC_BITS - 16 */
+        lk_dyn(lk_dynamic, (target & 0xffff) >> 2, 14);
+        lk_dyn(lk_dynamic, target >> 16, 14);
+    }
+    return 0;
+}
+
+
+/* ShiftLogicalInstruction / ShiftImmInstruction::assign_instance (riscv/shift/shift_circuit_v2.rs:359-396,485-521) with ShiftBaseConfig::assign_instances
+ * (:242-293) over byte limbs: kind 0 = SLL / SLLI, 1 = SRL / SRLI, 2 = SRA / SRAI.  cols[48] in ShiftRColumnMap order or cols[41] in ShiftIColumnMap order. */
+int orc_witgen_shift(const uint32_t* cols, int is_imm, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                     uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch, uint32_t* lk_double_u8,
+                     uint32_t* lk_xor) {
+    const int nc = is_imm ? 40 : 47;
+    const uint32_t num_cols = cols[nc];
+    if (kind < 0 || kind > 2) return -3;
+    for (int c = 0; c < nc; c++)
+        if (cols[c] >= num_cols) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd || (!is_imm && !st->has_rs2)) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        const uint32_t* k = cols;
+        row[k[0]] = st->pc_before;
+        row[k[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[k[2]] = register_index(st->rs1.addr);
+        row[k[3]] = p;
+        assign_lt(row, k + 4, lk_dynamic, p, ts + 0);
+        k += 6;
+        uint32_t c;
+        if (!is_imm) {
+            p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+            row[k[0]] = register_index(st->rs2.addr);
+            row[k[1]] = p;
+            assign_lt(row, k + 2, lk_dynamic, p, ts + 1);
+            k += 4;
+            c = st->rs2.value;
+        } else {
+            c = (uint16_t)(int16_t)st->imm;
+        }
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[k[0]] = register_index(st->rd.addr);
+        row[k[1]] = p;
+        row[k[2]] = st->rd.before & 0xffff;
+        row[k[3]] = st->rd.before >> 16;
+        assign_lt(row, k + 4, lk_dynamic, p, ts + 2);
+        k += 6;
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint32_t b = st->rs1.value, d = st->rd.after;
+        for (int j = 0; j < 4; j++) row[k[j]] = (b >> (8 * j)) & 0xff;
+        k += 4;
+        if (!is_imm) {
+            for (int j = 0; j < 4; j++) row[k[j]] = (c >> (8 * j)) & 0xff;
+            k += 4;
+        }
+        for (int j = 0; j < 4; j++) row[k[j]] = (d >> (8 * j)) & 0xff;
+        k += 4;
+        if (lk_double_u8) {
+            lk_double_u8[((d & 0xff) << 8) + ((d >> 8) & 0xff)] += 1;
+            lk_double_u8[(((d >> 16) & 0xff) << 8) + (d >> 24)] += 1;
+        }
+        if (is_imm) { row[k[0]] = c; k += 1; }
+        const uint32_t c0 = c & 0xff, shift = c0 % 32, limb_shift = shift / 8, bit_shift = shift % 8;
+        for (uint32_t j = 0; j < 8; j++) row[k[j]] = j == bit_shift;
+        k += 8;
+        for (uint32_t j = 0; j < 4; j++) row[k[j]] = j == limb_shift;
+        k += 4;
+        row[k[0]] = kind == 0 ? (1u << bit_shift) : 0;  /* bit_multiplier_left: only the shift's own column is set (:254-265) */
+        row[k[1]] = kind == 0 ? 0 : (1u << bit_shift);
+        uint32_t sign = 0;
+        if (kind == 2) {
+            sign = b >> 31;
+            if (lk_xor) lk_xor[(b >> 24) | (128u << 8)] += 1;
+        }
+        row[k[2]] = sign;
+        k += 3;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t byte = (b >> (8 * j)) & 0xff;
+            const uint32_t carry = kind == 0 ? (byte >> (8 - bit_shift)) : (byte % (1u << bit_shift));
+            row[k[j]] = carry;
+            if (lk_dynamic) lk_dynamic[(1u << bit_shift) + carry] += 1; /* assert_dynamic_range(carry, bit_shift): no skip at 0 or 1 bits */
+        }
+        lk_dyn(lk_dynamic, (c0 - bit_shift - limb_shift * 8) >> 5, 3);
+    }
+    return 0;
+}

@@ -156,6 +156,31 @@ impl Witgen {
                                            raw_stream(steps.stream))
         })
     }
+    /// `witgen_jalr`: the indirect jump (target as a MemAddr with both low bits witnessed, rd = pc + 4)
+    pub fn jalr(&self, map: &sys::ceno_hip_jalr_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_jalr(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                      lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_shift_r`: SLL (`kind` 0), SRL (1), SRA (2)
+    pub fn shift_r(&self, map: &sys::ceno_hip_shift_r_column_map, kind: u32, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                   lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_shift_r(self.hal.ctx, map, kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                         steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                         lk.double_u8, lk.xor, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_shift_i`: SLLI (`kind` 0), SRLI (1), SRAI (2)
+    pub fn shift_i(&self, map: &sys::ceno_hip_shift_i_column_map, kind: u32, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+                   lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_shift_i(self.hal.ctx, map, kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                         steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                         lk.double_u8, lk.xor, raw_stream(steps.stream))
+        })
+    }
     /// `witgen_lw`: the word load (register read, register write, memory read, address range checks)
     pub fn lw(&self, map: &sys::ceno_hip_lw_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
         self.hal.check(unsafe {

@@ -493,3 +493,84 @@ def test_lw_sw_bad_arguments_fail_loudly(dev):
         api.witgen_mem(dev, dup, True, 8, 1, 8, 1, 8, 2)                          # two fields on one column
     with pytest.raises(CenoHipError):
         api.witgen_mem(dev, list(range(23)) + [23], True, 0, 1, 8, 1, 8, 2)       # no step records
+
+
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 0), (300, 512, 996)])
+def test_jalr_witness_and_lookups_match_cpu_assignment(dev, n, rows, offset):
+    """JALR: the jump target as a MemAddr with both low bits witnessed, rd = pc + 4 with its high limb, a branching state (pc, next_pc)"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _jalr_steps
+
+    d = _jalr_steps(n)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = po.step_records_jalr(d["cycles"], d["pcs"], d["pcs_after"], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    nc = 22
+    rng = np.random.default_rng(27)
+    cols = list(rng.permutation(nc + 3)[:nc]) + [nc + 3]
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_jalr(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x2000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 3, rows)
+    exp, elkd, elkf = po.witgen_jalr(cols, recs, idx, offset, 0x2000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+@pytest.mark.parametrize("is_imm", [False, True])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
+def test_shift_witness_and_lookups_match_cpu_assignment(dev, kind, is_imm, n, rows, offset):
+    """SLL / SRL / SRA and their immediate forms: byte limbs, the ShiftBase gadget's markers, multiplier, carries and sign, four lookup tables"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _shift_records, _shift_steps
+
+    d = _shift_steps(n, kind, is_imm)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = _shift_records(d, kind, is_imm)
+    nc = 40 if is_imm else 47
+    rng = np.random.default_rng(31 + kind)
+    cols = list(rng.permutation(nc + 3)[:nc]) + [nc + 3]
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    lk2 = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+    lkx = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+    api.witgen_shift(dev, cols, is_imm, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(),
+                     lkf.data_ptr(), lk2.data_ptr(), lkx.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 3, rows)
+    exp, elkd, elkf, elk2, elkx = po.witgen_shift(cols, is_imm, kind, recs, idx, offset, 0x1000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    for g_, e_ in ((lkd, elkd), (lkf, elkf), (lk2, elk2), (lkx, elkx)):
+        assert np.array_equal(g_.cpu().numpy().view(np.uint32), e_)
+
+
+def test_shift_and_jalr_bad_arguments_fail_loudly(dev):
+    from ceno_amd import CenoHipError, api
+
+    with pytest.raises(CenoHipError):
+        api.witgen_shift(dev, list(range(47)) + [47], False, 3, 8, 1, 8, 1, 8, 2)      # kind out of range
+    with pytest.raises(CenoHipError):
+        api.witgen_shift(dev, list(range(40)) + [39], True, 0, 8, 1, 8, 1, 8, 2)       # a column id beyond num_cols
+    with pytest.raises(CenoHipError):
+        api.witgen_jalr(dev, list(range(22)) + [22], 0, 1, 8, 1, 8, 2)                 # no step records

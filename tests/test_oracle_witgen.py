@@ -537,3 +537,133 @@ def test_lw_sw_oracle_rejects_other_record_shapes():
         po.witgen_mem(list(range(23)) + [23], False, _mem_records(d, True), np.arange(16))     # a store record has no rd
     with pytest.raises(ValueError):
         po.witgen_mem(list(range(23)) + [22], False, _mem_records(d, False), np.arange(16))    # column id out of range
+
+
+def _jalr_steps(n):
+    """chips/jalr.rs tests' shape: rs1 = 0x1000 + 8 i, offsets 0, 4, -4, 100 (signed), rd <- pc + 4; plus edge cases (an odd target: bit 0 witnessed
+    and dropped from next_pc, bit 1 set, the smallest and largest offsets, a wrapped sum, a target at the top of the 30-bit range)"""
+    i = np.arange(n, dtype=np.int64)
+    pc = 0x2000 + 4 * i
+    rs1 = 0x1000 + 8 * i
+    imm = np.array([0, 4, -4, 100], dtype=np.int64)[i % 4]
+    if n >= 8:
+        rs1[1], imm[1] = 0x3001, 0                 # odd target
+        rs1[2], imm[2] = 0x4000, 2                 # bit 1 set
+        rs1[3], imm[3] = 0x0001_0800, -2048        # borrow from the high limb
+        rs1[5], imm[5] = 0xFFFF_FFFE, 6            # the sum wraps to 4
+        rs1[6], imm[6] = 0x3FFF_F800, 2047         # 0x3FFFFFFF: every checked bit set
+    target = (rs1 + imm) & 0xFFFFFFFF
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=pc.astype(np.uint64), pcs_after=(target & ~np.int64(1)).astype(np.uint64), imms=imm,
+                rs1_vals=rs1.astype(np.uint64), rd_before=(i % 97).astype(np.uint64), rd_after=(pc + 4).astype(np.uint64),
+                prev_cycles=np.zeros(n, dtype=np.uint64), target=target)
+
+
+def test_jalr_oracle_rows_satisfy_the_circuit_relations():
+    """jalr_v2.rs:60-135: rs1 + sign-extended imm = target over u16 limbs with bit carries; next_pc = target with bit 0 cleared; rd = pc + 4"""
+    n = 300
+    d = _jalr_steps(n)
+    recs = po.step_records_jalr(d["cycles"], d["pcs"], d["pcs_after"], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    got, lkd, lkf = po.witgen_jalr(list(range(22)) + [22], recs, np.arange(n), 0, 0x2000, n)
+    g = got.astype(np.int64)
+    rs1, imm, sign = g[:, 13] + (g[:, 14] << 16), g[:, 15], g[:, 16]
+    target, b0, b1, rd_high = g[:, 17] + (g[:, 18] << 16), g[:, 19], g[:, 20], g[:, 21]
+    assert np.array_equal(rs1, d["rs1_vals"].astype(np.int64)) and np.array_equal(target, d["target"])
+    c0 = g[:, 13] + imm - g[:, 17]
+    assert set(np.unique(c0)) <= {0, 1 << 16}                                           # carry_lo_bit
+    c1 = g[:, 14] + sign * 0xFFFF + (c0 >> 16) - g[:, 18]
+    assert set(np.unique(c1)) <= {0, 1 << 16}                                           # overflow_bit
+    assert np.array_equal(g[:, 1], target - b0) and np.array_equal(b0, target & 1) and np.array_equal(b1, (target >> 1) & 1)
+    assert np.array_equal((rd_high << 16) + ((g[:, 0] + 4) & 0xFFFF), g[:, 0] + 4)      # rd_low = pc + 4 - rd_high 2^16 is a u16
+    assert np.array_equal(g[:, 9] + (g[:, 10] << 16), d["rd_before"].astype(np.int64)) and (g[:, 3] == 2).all() and (g[:, 7] == 4).all()
+    assert int(lkd.sum()) == 8 * n and int(lkf.sum()) == n
+    assert int(lkd[(1 << 14):(1 << 15)].sum()) == 3 * n                                 # rd_high, the target's middle bits and high limb
+
+
+def test_jalr_oracle_rejects_bad_maps_and_records():
+    d = _jalr_steps(8)
+    recs = po.step_records_jalr(d["cycles"], d["pcs"], d["pcs_after"], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    with pytest.raises(ValueError):
+        po.witgen_jalr(list(range(22)) + [21], recs, np.arange(8))
+    jd = _jal_steps(8)
+    jrecs = po.step_records_j(jd["cycles"], jd["pcs"], jd["pcs_after"], po.INSN_JAL, 1, jd["imms"], jd["rd_before"], jd["rd_after"], jd["prev_cycles"])
+    with pytest.raises(ValueError):
+        po.witgen_jalr(list(range(22)) + [22], jrecs, np.arange(8))                     # a J-type record has no rs1
+
+
+def _shift_steps(n, kind, is_imm):
+    """chips/shift_r.rs / shift_i.rs tests' shape: rs1 = 0x12345678-like words, every shift amount 0..31 cycled; plus edge cases (a negative operand
+    under SRA, all ones, zero, and for the register form amounts above 31: only the low five bits of rs2's low byte shift, bits 5..7 are range-checked)"""
+    i = np.arange(n, dtype=np.int64)
+    a = (0x12345678 + 0x01010101 * i * 7) & 0xFFFFFFFF
+    if n >= 8:
+        a[1], a[2], a[3] = 0xFFFFFFFF, 0, 0x80000000
+        a[5] = 0xF00F0FF0
+    amount = i % 32
+    c = amount.copy()
+    if not is_imm:
+        c = (c + 32 * (i % 8)) & 0xFF                  # rs2's low byte above 31
+        c = c + ((i * 0x10100) & 0xFFFFFF00)           # and anything in its upper bytes
+    sa = np.where(a >> 31, a - (1 << 32), a)
+    res = {0: (a << amount) & 0xFFFFFFFF, 1: a >> amount, 2: (sa >> amount) & 0xFFFFFFFF}[kind]
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=a.astype(np.uint64), rs2_vals=c.astype(np.uint64),
+                imms=c, rd_before=(i % 41).astype(np.uint64), rd_after=res.astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64))
+
+
+def _shift_records(d, kind, is_imm):
+    if is_imm:
+        return po.step_records_i(d["cycles"], d["pcs"], [po.INSN_SLLI, po.INSN_SRLI, po.INSN_SRAI][kind], 2, 4, d["imms"], d["rs1_vals"], d["rd_before"],
+                                 d["rd_after"], d["prev_cycles"])
+    return po.step_records_r(d["cycles"], d["pcs"], [po.INSN_SLL, po.INSN_SRL, po.INSN_SRA][kind], 2, 3, 4, d["rs1_vals"], d["rs2_vals"], d["rd_before"],
+                             d["rd_after"], d["prev_cycles"])
+
+
+@pytest.mark.parametrize("is_imm", [False, True])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_shift_oracle_rows_satisfy_the_shift_base_constraints(kind, is_imm):
+    """ShiftBaseConfig::construct_circuit (shift_circuit_v2.rs:71-200): one-hot markers, the multiplier column, and per result byte
+    a[i] = b[i - limb_shift] 2^bit_shift - 256 carry[i - limb_shift] + carry[i - limb_shift - 1]  (left) or
+    a[i] 2^bit_shift = b[i + limb_shift] - carry[i + limb_shift] + 256 carry-or-sign-fill above  (right), under the active limb marker"""
+    n = 512
+    d = _shift_steps(n, kind, is_imm)
+    recs = _shift_records(d, kind, is_imm)
+    nc = 40 if is_imm else 47
+    got, lkd, lkf, lk2, lkx = po.witgen_shift(list(range(nc)) + [nc], is_imm, kind, recs, np.arange(n), 0, 0x1000, n)
+    g = got.astype(np.int64)
+    o = 12 if is_imm else 16                              # first byte column
+    b = g[:, o:o + 4]
+    if is_imm:
+        a, c_low = g[:, o + 4:o + 8], g[:, o + 8] & 0xFF
+        assert np.array_equal(g[:, o + 8], d["imms"] & 0xFFFF)
+        m = o + 9
+    else:
+        cb, a = g[:, o + 4:o + 8], g[:, o + 8:o + 12]
+        assert np.array_equal(sum(cb[:, k] << (8 * k) for k in range(4)), d["rs2_vals"].astype(np.int64))
+        c_low = cb[:, 0]
+        m = o + 12
+    bit_m, limb_m, ml, mr, sign, carry = g[:, m:m + 8], g[:, m + 8:m + 12], g[:, m + 12], g[:, m + 13], g[:, m + 14], g[:, m + 15:m + 19]
+    assert np.array_equal(sum(b[:, k] << (8 * k) for k in range(4)), d["rs1_vals"].astype(np.int64))
+    assert np.array_equal(sum(a[:, k] << (8 * k) for k in range(4)), d["rd_after"].astype(np.int64))
+    assert (bit_m.sum(axis=1) == 1).all() and (limb_m.sum(axis=1) == 1).all()
+    bit_shift, limb_shift = bit_m.argmax(axis=1), limb_m.argmax(axis=1)
+    assert np.array_equal(bit_shift + 8 * limb_shift, c_low % 32)
+    assert np.array_equal(ml, np.where(kind == 0, 1 << bit_shift, 0)) and np.array_equal(mr, np.where(kind == 0, 0, 1 << bit_shift))
+    assert np.array_equal(sign, (b[:, 3] >> 7) if kind == 2 else np.zeros(n, dtype=np.int64))
+    assert (carry < (1 << bit_shift)[:, None]).all()
+    for r in range(n):
+        ls, bs = int(limb_shift[r]), int(bit_shift[r])
+        for i in range(4):
+            if kind == 0:
+                exp = 0 if i < ls else (int(b[r, i - ls]) << bs) - 256 * int(carry[r, i - ls]) + (int(carry[r, i - ls - 1]) if i > ls else 0)
+                assert int(a[r, i]) == exp
+            else:
+                fill = 255 * int(sign[r])
+                if i + ls >= 4:
+                    assert int(a[r, i]) == fill
+                else:
+                    above = int(carry[r, i + ls + 1]) if i + ls + 1 < 4 else fill % (1 << bs) if bs else 0
+                    # a[i] 2^bs + carry[i + ls] = b[i + ls] + 2^8 (bits arriving from above)
+                    assert (int(a[r, i]) << bs) + int(carry[r, i + ls]) == int(b[r, i + ls]) + 256 * above
+    # lookups: 2 per timestamp comparison, 4 carries, the amount's upper bits; the result's two byte pairs; SRA's sign
+    n_ts = 2 if is_imm else 3
+    assert int(lkd.sum()) == (2 * n_ts + 5) * n and int(lkf.sum()) == n and int(lk2.sum()) == 2 * n and int(lkx.sum()) == (n if kind == 2 else 0)
+    assert int(lkd[8:16].sum()) == n + 4 * int((bit_shift == 3).sum())   # the 3-bit range of (c[0] - shift) >> 5, and the carries of 3-bit shifts
