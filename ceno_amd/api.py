@@ -471,17 +471,40 @@ def witgen_jalr(dev: Device, cols, records_ptr: int, num_records: int, indices_p
                                          C.c_void_p(lk_fetch_ptr or None), stream))
 
 
-def witgen_mem(dev: Device, cols, is_store: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
-               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
-    """hal.witgen.witgen_lw / witgen_sw: `cols` = the 23 column ids in LwColumnMap / SwColumnMap field order followed by num_cols"""
+NO_COLUMN = 0xFFFFFFFF
+
+
+def witgen_load_sub(dev: Device, cols, load_width: int, is_signed: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int,
+                    rows_padded: int, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0,
+                    stream=None):
+    """hal.witgen.witgen_load_sub (LH / LHU / LB / LBU): `cols` = the 29 column ids in LoadSubColumnMap field order (NO_COLUMN for the Option fields
+    the variant does not have) followed by num_cols"""
     class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 23), ("num_cols", C.c_uint32)]
+        _fields_ = [("cols", C.c_uint32 * 29), ("num_cols", C.c_uint32)]
 
     m = M()
-    for k in range(23):
+    for k in range(29):
         m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[23])
-    fn = dev.L.ceno_hip_witgen_sw if is_store else dev.L.ceno_hip_witgen_lw
+    m.num_cols = int(cols[29])
+    dev.check(dev.L.ceno_hip_witgen_load_sub(dev.h, C.byref(m), int(load_width), int(is_signed), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n,
+                                             shard_offset, fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded,
+                                             C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
+
+
+def witgen_mem(dev: Device, cols, is_store, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_lw / witgen_sw / witgen_sh / witgen_sb: `cols` = the 23 (LW, SW), 24 (SH) or 29 (SB) column ids in the chip's
+    ColumnMap field order followed by num_cols; `is_store` = 0 / False (LW), 1 / True (SW), 2 (SH) or 3 (SB)"""
+    nc = {0: 23, 1: 23, 2: 24, 3: 29}[int(is_store)]
+
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(nc):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[nc])
+    fn = {0: dev.L.ceno_hip_witgen_lw, 1: dev.L.ceno_hip_witgen_sw, 2: dev.L.ceno_hip_witgen_sh, 3: dev.L.ceno_hip_witgen_sb}[int(is_store)]
     dev.check(fn(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
                  C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
 

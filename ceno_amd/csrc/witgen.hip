@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, LW and SW.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, the five loads and the three stores.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -785,7 +785,30 @@ struct SwMap {  // ceno_hip_sw_column_map = ceno_gpu's SwColumnMap (chips/sw.rs:
     uint32_t num_cols;
 };
 static_assert(sizeof(SwMap) == sizeof(ceno_hip_sw_column_map), "column map layout");
-constexpr int MEM_COLS = 23;
+// SH / SB (StoreConfig<E, 1> / <E, 0>, store_v2.rs:100-177): the SW columns, the address bits the width leaves free (bit 1; bits 0 and 1) and, for SB,
+// MemWordUtil's byte columns (riscv/memory/gadget.rs:134-185): the two bytes of the previous word's addressed limb, the stored byte, the limb after it
+struct ShMap {  // ceno_hip_sh_column_map = ceno_gpu's ShColumnMap (chips/sh.rs:39-58)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t mem_addr_bit_1;
+    uint32_t num_cols;
+};
+static_assert(sizeof(ShMap) == sizeof(ceno_hip_sh_column_map), "column map layout");
+struct SbMap {  // ceno_hip_sb_column_map = ceno_gpu's SbColumnMap (chips/sb.rs:57-81)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t mem_addr_bit_0, mem_addr_bit_1, prev_limb_bytes[2], rs2_limb_byte, expected_limb;
+    uint32_t num_cols;
+};
+static_assert(sizeof(SbMap) == sizeof(ceno_hip_sb_column_map), "column map layout");
+constexpr int MEM_COLS = 23, SH_COLS = 24, SB_COLS = 29;
+constexpr int mem_cols(int kind) { return kind == 2 ? SH_COLS : kind == 3 ? SB_COLS : MEM_COLS; }
 
 // the memory access itself (ReadMEM / WriteMEM::assign_op, insn_base.rs:517-545,650-680) and the address range checks
 template <bool XCD_LOCAL>
@@ -803,7 +826,8 @@ __device__ __forceinline__ void emit_mem(const Row& o, uint32_t prev_col, const 
     lk_count<XCD_LOCAL>(lk_dyn, (1u << 14) + (addr >> 16));            // assert_const_range(high_u16, MEM_BITS - 16)
 }
 
-template <bool XCD_LOCAL, bool STORE, class MapT>
+// KIND 0: LW, 1: SW, 2: SH, 3: SB
+template <bool XCD_LOCAL, int KIND, class MapT>
 __global__ void __launch_bounds__(NT) k_witgen_mem(MapT m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n, uint64_t offset,
                                                    uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows, uint32_t* lk_dyn,
                                                    uint32_t* lk_fetch) {
@@ -812,8 +836,9 @@ __global__ void __launch_bounds__(NT) k_witgen_mem(MapT m, const unsigned char* 
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
         const Row o{w, rows, r};
+        constexpr bool STORE = KIND != 0;
         if (r >= n) {
-            zero_row<MEM_COLS>(o, &m.pc);
+            zero_row<mem_cols(KIND)>(o, &m.pc);
             continue;
         }
         const Step st = load_step(recs, idx[r]);
@@ -839,6 +864,22 @@ __global__ void __launch_bounds__(NT) k_witgen_mem(MapT m, const unsigned char* 
             lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (mem_before & 0xffff));  // Value::new(memory_op.value.before, lkm)
             lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (mem_before >> 16));
             emit_mem<XCD_LOCAL>(o, m.mem_prev_ts, m.mem_lt_diff, m.mem_addr, addr, mem_prev, offset, ts, lk_dyn);
+            if constexpr (KIND == 2) o.put(m.mem_addr_bit_1, (addr >> 1) & 1u);
+            if constexpr (KIND == 3) {
+                const uint32_t bit0 = addr & 1u, bit1 = (addr >> 1) & 1u;
+                const uint32_t prev_limb = (mem_before >> (16 * bit1)) & 0xffff, rs2_limb = st.rs2_val & 0xffff;
+                const uint32_t p_lo = prev_limb & 0xff, p_hi = prev_limb >> 8, s_lo = rs2_limb & 0xff, s_hi = rs2_limb >> 8;
+                o.put(m.mem_addr_bit_0, bit0);
+                o.put(m.mem_addr_bit_1, bit1);
+                o.put(m.prev_limb_bytes[0], p_lo);
+                o.put(m.prev_limb_bytes[1], p_hi);
+                o.put(m.rs2_limb_byte, s_lo);
+                o.put(m.expected_limb, bit0 ? (s_lo << 8) + p_lo : (p_hi << 8) + s_lo);
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + p_lo);  // assert_ux::<8> of both bytes of the previous limb and of rs2's low limb
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + p_hi);
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + s_lo);
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + s_hi);
+            }
         } else {
             emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
             o.put(m.mem_read_limbs[0], mem_before & 0xffff);
@@ -995,6 +1036,83 @@ __global__ void __launch_bounds__(NT) k_witgen_shift(MapT m, int kind, const uns
     }
 }
 
+// ---- sub-word loads LH / LHU / LB / LBU (LoadInstruction, riscv/memory/load_v2.rs:197-255): LW's columns, then the address bit that selects
+// the 16-bit limb of the memory word and that limb; for byte loads the bit that selects the byte, the addressed byte and the other one (both
+// byte-range lookups); for signed loads the sign bit of the loaded value with SignedExtendConfig's range lookup of 2 val - (msb << n_bits)
+// (gadgets/signed_ext.rs:92-103).  Columns a variant does not have carry CENO_HIP_NO_COLUMN in the map.
+struct LoadSubMap {  // ceno_hip_load_sub_column_map = ceno_gpu's LoadSubColumnMap (chips/load_sub.rs:67-91)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, mem_addr[2], mem_read[2];
+    uint32_t addr_bit_1, target_limb, addr_bit_0, target_byte, dummy_byte, msb;
+    uint32_t num_cols;
+};
+static_assert(sizeof(LoadSubMap) == sizeof(ceno_hip_load_sub_column_map), "column map layout");
+constexpr int LOAD_SUB_COMMON = 25;  // the fields every variant has (up to target_limb)
+
+template <bool XCD_LOCAL, bool BYTE, bool SIGNED>
+__global__ void __launch_bounds__(NT) k_witgen_load_sub(LoadSubMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                        uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                        uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<LOAD_SUB_COMMON>(o, &m.pc);
+            if (BYTE) {
+                o.put(m.addr_bit_0, 0);
+                o.put(m.target_byte, 0);
+                o.put(m.dummy_byte, 0);
+            }
+            if (SIGNED) o.put(m.msb, 0);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(recs + (size_t)idx[r] * CENO_HIP_STEP_RECORD_BYTES);
+        const uint32_t word = (uint32_t)(q[OFF_MEM / 8] >> 32);
+        const uint64_t mem_prev = q[OFF_MEM / 8 + 2];
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        const uint32_t imm16 = st.imm & 0xffff, neg = (imm16 >> 15) & 1u;
+        const uint32_t addr = st.rs1_val + (imm16 | (neg ? 0xffff0000u : 0u));
+        o.put(m.rs1_limbs[0], st.rs1_val & 0xffff);
+        o.put(m.rs1_limbs[1], st.rs1_val >> 16);
+        o.put(m.imm, imm16);
+        o.put(m.imm_sign, neg);
+        o.put(m.mem_read[0], word & 0xffff);
+        o.put(m.mem_read[1], word >> 16);
+        emit_mem<XCD_LOCAL>(o, m.mem_prev_ts, m.mem_lt_diff, m.mem_addr, addr, mem_prev, offset, ts, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t bit0 = addr & 1u, bit1 = (addr >> 1) & 1u;
+        const uint32_t limb = (word >> (16 * bit1)) & 0xffff;
+        o.put(m.addr_bit_1, bit1);
+        o.put(m.target_limb, limb);
+        uint32_t val = limb;
+        if (BYTE) {
+            const uint32_t target = (limb >> (8 * bit0)) & 0xff, other = (limb >> (8 * (1 - bit0))) & 0xff;
+            o.put(m.addr_bit_0, bit0);
+            o.put(m.target_byte, target);
+            o.put(m.dummy_byte, other);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + target);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 8) + other);
+            val = target;
+        }
+        if (SIGNED) {
+            constexpr uint32_t BITS = BYTE ? 8 : 16;
+            const uint32_t msb = val >> (BITS - 1);
+            o.put(m.msb, msb);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << BITS) + (2 * val - (msb << BITS)));  // assert_const_range(2 val - (msb << n_bits), n_bits)
+        }
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -1128,6 +1246,39 @@ int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, cons
         else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
+int witgen_load_sub(ceno_hip_ctx* ctx, const LoadSubMap* map, int load_width, int is_signed, const void* recs, size_t num_records, const uint32_t* idx,
+                    size_t n, uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch,
+                    ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    CHECK_ARG(ctx, (load_width == 8 || load_width == 16) && (is_signed == 0 || is_signed == 1), "witgen_load_sub: load_width is 8 or 16, is_signed 0 or 1");
+    const bool byte = load_width == 8;
+    // the columns this variant has, in map order; the others must be marked absent
+    uint32_t cols[LOAD_SUB_COMMON + 4];
+    int nc = LOAD_SUB_COMMON;
+    memcpy(cols, &map->pc, sizeof(uint32_t) * LOAD_SUB_COMMON);
+    if (byte) {
+        cols[nc++] = map->addr_bit_0;
+        cols[nc++] = map->target_byte;
+        cols[nc++] = map->dummy_byte;
+    } else {
+        CHECK_ARG(ctx, map->addr_bit_0 == CENO_HIP_NO_COLUMN && map->target_byte == CENO_HIP_NO_COLUMN && map->dummy_byte == CENO_HIP_NO_COLUMN,
+                  "witgen_load_sub: a halfword load has no byte columns (CENO_HIP_NO_COLUMN)");
+    }
+    if (is_signed) cols[nc++] = map->msb;
+    else CHECK_ARG(ctx, map->msb == CENO_HIP_NO_COLUMN, "witgen_load_sub: an unsigned load has no msb column (CENO_HIP_NO_COLUMN)");
+    TRY(witgen_check(ctx, cols, nc, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+#define LS(X, B, S) hipLaunchKernelGGL((k_witgen_load_sub<X, B, S>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1)
+        if (xcd) { if (byte) { if (is_signed) LS(true, true, true); else LS(true, true, false); } else { if (is_signed) LS(true, false, true); else LS(true, false, false); } }
+        else { if (byte) { if (is_signed) LS(false, true, true); else LS(false, true, false); } else { if (is_signed) LS(false, false, true); else LS(false, false, false); } }
+#undef LS
+    });
+}
+
 template <bool IMM, class MapT>
 int witgen_shift(ceno_hip_ctx* ctx, const MapT* map, int kind, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
                  uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, uint32_t* lk_du8, uint32_t* lk_xor,
@@ -1158,18 +1309,18 @@ int witgen_jalr(ceno_hip_ctx* ctx, const JalrMap* map, const void* recs, size_t 
         else hipLaunchKernelGGL(k_witgen_jalr<false>, dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
-template <bool STORE, class MapT>
+template <int KIND, class MapT>
 int witgen_mem(ceno_hip_ctx* ctx, const MapT* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset, uint32_t fetch_base,
                uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, map, "NULL column map");
-    TRY(witgen_check(ctx, &map->pc, MEM_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    TRY(witgen_check(ctx, &map->pc, mem_cols(KIND), map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
     const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
-        if (xcd) hipLaunchKernelGGL((k_witgen_mem<true, STORE, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
-        else hipLaunchKernelGGL((k_witgen_mem<false, STORE, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        if (xcd) hipLaunchKernelGGL((k_witgen_mem<true, KIND, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
+        else hipLaunchKernelGGL((k_witgen_mem<false, KIND, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
 #undef WITGEN_LAUNCH
@@ -1259,6 +1410,31 @@ int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column
                             shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
+int ceno_hip_witgen_load_sub(ceno_hip_ctx* ctx, const ceno_hip_load_sub_column_map* map, int load_width, int is_signed, const void* dev_step_records,
+                             size_t num_records, const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                             uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                             ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_load_sub(ctx, reinterpret_cast<const LoadSubMap*>(map), load_width, is_signed, dev_step_records, num_records, dev_step_indices, n,
+                           shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_sh(ceno_hip_ctx* ctx, const ceno_hip_sh_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_mem<2>(ctx, reinterpret_cast<const ShMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                         fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_sb(ceno_hip_ctx* ctx, const ceno_hip_sb_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_mem<3>(ctx, reinterpret_cast<const SbMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+                         fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
 int ceno_hip_witgen_shift_r(ceno_hip_ctx* ctx, const ceno_hip_shift_r_column_map* map, int kind, const void* dev_step_records, size_t num_records,
                             const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                             uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
@@ -1289,7 +1465,7 @@ int ceno_hip_witgen_lw(ceno_hip_ctx* ctx, const ceno_hip_lw_column_map* map, con
                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, ctx, "NULL context");
-    return witgen_mem<false>(ctx, reinterpret_cast<const LwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+    return witgen_mem<0>(ctx, reinterpret_cast<const LwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
                              fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
@@ -1297,7 +1473,7 @@ int ceno_hip_witgen_sw(ceno_hip_ctx* ctx, const ceno_hip_sw_column_map* map, con
                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, ctx, "NULL context");
-    return witgen_mem<true>(ctx, reinterpret_cast<const SwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
+    return witgen_mem<1>(ctx, reinterpret_cast<const SwMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle, fetch_base_pc,
                             fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 

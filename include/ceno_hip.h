@@ -562,6 +562,51 @@ typedef struct ceno_hip_sw_column_map {
     uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
     uint32_t num_cols;
 } ceno_hip_sw_column_map;
+/* LH / LHU / LB / LBU: hal.witgen.witgen_load_sub (GpuWitgenKind::LoadSub { load_width: 16 | 8, is_signed }; chips/load_sub.rs:12-92; CPU assignment
+ * riscv/memory/load_v2.rs:197-255, SignedExtendConfig gadgets/signed_ext.rs:92-103).  The reference's map holds Option columns: a halfword load has no
+ * addr_bit_0 / target_byte / dummy_byte, an unsigned load no msb — such fields carry CENO_HIP_NO_COLUMN here and are checked.  25 .. 29 mapped columns. */
+#define CENO_HIP_NO_COLUMN 0xffffffffu
+typedef struct ceno_hip_load_sub_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], imm, imm_sign, mem_addr[2], mem_read[2];
+    uint32_t addr_bit_1, target_limb, addr_bit_0, target_byte, dummy_byte, msb;
+    uint32_t num_cols;
+} ceno_hip_load_sub_column_map;
+int ceno_hip_witgen_load_sub(ceno_hip_ctx* ctx, const ceno_hip_load_sub_column_map* map, int load_width, int is_signed, const void* dev_step_records,
+                             size_t num_records, const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
+                             uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
+                             ceno_hip_stream s);
+
+/* SH / SB: hal.witgen.witgen_sh / witgen_sb (GpuWitgenKind::Sh / Sb; chips/sh.rs:12-59, chips/sb.rs:10-82; StoreConfig<E, 1> / <E, 0>,
+ * store_v2.rs:100-177, MemWordUtil riscv/memory/gadget.rs:134-185): SW's columns, the free address bits, and for SB the byte columns of the
+ * addressed limb.  24 / 29 mapped columns. */
+typedef struct ceno_hip_sh_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t mem_addr_bit_1;
+    uint32_t num_cols;
+} ceno_hip_sh_column_map;
+typedef struct ceno_hip_sb_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t mem_prev_ts, mem_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], imm, imm_sign, prev_mem_val[2], mem_addr[2];
+    uint32_t mem_addr_bit_0, mem_addr_bit_1, prev_limb_bytes[2], rs2_limb_byte, expected_limb;
+    uint32_t num_cols;
+} ceno_hip_sb_column_map;
+int ceno_hip_witgen_sh(ceno_hip_ctx* ctx, const ceno_hip_sh_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+int ceno_hip_witgen_sb(ceno_hip_ctx* ctx, const ceno_hip_sb_column_map* map, const void* dev_step_records, size_t num_records,
+                       const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                       uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 int ceno_hip_witgen_lw(ceno_hip_ctx* ctx, const ceno_hip_lw_column_map* map, const void* dev_step_records, size_t num_records,
                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);

@@ -929,6 +929,40 @@ def witgen_jalr(cols, records, indices, shard_offset: int = 0, fetch_base_pc: in
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_LB, INSN_LH, INSN_LBU, INSN_LHU = 36, 37, 39, 40
+NO_COLUMN = 0xFFFFFFFF
+
+
+def load_sub_cols(ids, load_width: int, is_signed: bool, num_cols: int):
+    """LoadSubColumnMap from a list of distinct ids: the fields the variant has take them in order, the others NO_COLUMN"""
+    ids = list(ids)
+    cols = [ids.pop(0) for _ in range(25)]
+    cols += [ids.pop(0) for _ in range(3)] if load_width == 8 else [NO_COLUMN] * 3
+    cols += [ids.pop(0)] if is_signed else [NO_COLUMN]
+    return cols + [num_cols]
+
+
+def witgen_load_sub(cols, load_width: int, is_signed: bool, records, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of LH / LHU / LB / LBU: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (30,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[29])), dtype=np.uint64)
+    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_load_sub.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+    L.orc_witgen_load_sub.restype = C.c_int
+    rc = L.orc_witgen_load_sub(cols.ctypes.data, int(load_width), int(is_signed), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc,
+                               fetch_num_slots, out.ctypes.data, lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_load_sub rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
+INSN_SB, INSN_SH = 43, 44
 INSN_LW, INSN_SW = 38, 45  # InsnKind::LW; SW = after LUI, AUIPC, SB, SH (u16limb_circuit feature)
 
 
@@ -948,13 +982,14 @@ def step_records_mem(is_store, cycles, pcs, kind, rs1, rs2_or_rd, imms, rs1_vals
     return out
 
 
-def witgen_mem(cols, is_store: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+def witgen_mem(cols, is_store, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
     """CPU assignment of the LW / SW chip: (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
     cols = np.ascontiguousarray(cols, dtype=np.uint32)
-    assert cols.shape == (24,)
+    nc = {0: 23, 1: 23, 2: 24, 3: 29}[int(is_store)]  # 2 = SH, 3 = SB
+    assert cols.shape == (nc + 1,)
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
-    out = np.zeros((len(idx), int(cols[23])), dtype=np.uint64)
+    out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
     lkd = np.zeros(1 << 17, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()

@@ -674,10 +674,13 @@ static void assign_mem(uint64_t* row, uint32_t prev_col, const uint32_t diff_col
 
 /* LW: LoadInstruction::assign_instance (riscv/memory/load_v2.rs:197-255) + IMInstructionConfig (im_insn.rs:71-90); cols[24] in LwColumnMap order.
  * SW: StoreInstruction::assign_instance (riscv/memory/store_v2.rs:138-177) + SInstructionConfig (s_insn.rs:77-96); cols[24] in SwColumnMap order. */
+/* is_store 2 = SH (cols[25]: + mem_addr_bit_1), 3 = SB (cols[30]: + bit_0, bit_1, prev_limb_bytes[2], rs2_limb_byte, expected_limb): StoreConfig<E, 1> / <E, 0>
+ * with MemWordUtil::assign_instance (riscv/memory/gadget.rs:134-185) */
 int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
-    const uint32_t num_cols = cols[23];
-    for (int c = 0; c < 23; c++)
+    const int nc = is_store == 2 ? 24 : is_store == 3 ? 29 : 23;
+    const uint32_t num_cols = cols[nc];
+    for (int c = 0; c < nc; c++)
         if (cols[c] >= num_cols) return -1;
     const orc_step_record* recs = (const orc_step_record*)records;
     for (size_t i = 0; i < n; i++) {
@@ -723,6 +726,21 @@ int orc_witgen_mem(const uint32_t* cols, int is_store, const void* records, cons
             lk_dyn(lk_dynamic, st->memory_op.before & 0xffff, 16); /* Value::new(memory_op.value.before, lkm) */
             lk_dyn(lk_dynamic, st->memory_op.before >> 16, 16);
             assign_mem(row, cols[10], cols + 11, cols + 21, lk_dynamic, addr, st->memory_op.previous_cycle, shard_offset, ts);
+            if (is_store == 2) row[cols[23]] = (addr >> 1) & 1;
+            if (is_store == 3) {
+                const uint32_t bit0 = addr & 1, bit1 = (addr >> 1) & 1;
+                const uint32_t prev_limb = (st->memory_op.before >> (16 * bit1)) & 0xffff, rs2_limb = st->rs2.value & 0xffff;
+                row[cols[23]] = bit0;
+                row[cols[24]] = bit1;
+                row[cols[25]] = prev_limb & 0xff;
+                row[cols[26]] = prev_limb >> 8;
+                row[cols[27]] = rs2_limb & 0xff;
+                row[cols[28]] = bit0 ? ((rs2_limb & 0xff) << 8) + (prev_limb & 0xff) : ((prev_limb >> 8) << 8) + (rs2_limb & 0xff);
+                lk_dyn(lk_dynamic, prev_limb & 0xff, 8);
+                lk_dyn(lk_dynamic, prev_limb >> 8, 8);
+                lk_dyn(lk_dynamic, rs2_limb & 0xff, 8);
+                lk_dyn(lk_dynamic, rs2_limb >> 8, 8);
+            }
         }
     }
     return 0;
@@ -860,6 +878,70 @@ int orc_witgen_shift(const uint32_t* cols, int is_imm, int kind, const void* rec
             if (lk_dynamic) lk_dynamic[(1u << bit_shift) + carry] += 1; /* assert_dynamic_range(carry, bit_shift): no skip at 0 or 1 bits */
         }
         lk_dyn(lk_dynamic, (c0 - bit_shift - limb_shift * 8) >> 5, 3);
+    }
+    return 0;
+}
+
+
+/* LoadInstruction::assign_instance for LH / LHU / LB / LBU (riscv/memory/load_v2.rs:197-255): LW's assignment, the selected limb, (bytes: the addressed and
+ * the other byte of it, byte-range lookups), (signed: SignedExtendConfig::assign_instance, gadgets/signed_ext.rs:92-103).  cols[30]: LoadSubColumnMap field
+ * order, 0xFFFFFFFF in the Option fields the variant lacks, num_cols last. */
+int orc_witgen_load_sub(const uint32_t* cols, int load_width, int is_signed, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
+                        uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[29];
+    const int byte = load_width == 8;
+    if ((load_width != 8 && load_width != 16) || (is_signed != 0 && is_signed != 1)) return -3;
+    for (int c = 0; c < 29; c++) {
+        const int present = c < 25 || (c < 28 ? byte : is_signed);
+        if (present ? cols[c] >= num_cols : cols[c] != 0xFFFFFFFFu) return -1;
+    }
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rd || !st->has_memory_op) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        const uint32_t addr = st->rs1.value + (uint32_t)(int32_t)(int16_t)st->imm, word = st->memory_op.before;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rd.addr);
+        row[cols[7]] = p;
+        row[cols[8]] = st->rd.before & 0xffff;
+        row[cols[9]] = st->rd.before >> 16;
+        assign_lt(row, cols + 10, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        row[cols[15]] = st->rs1.value & 0xffff; row[cols[16]] = st->rs1.value >> 16;
+        row[cols[17]] = (uint16_t)(int16_t)st->imm;
+        row[cols[18]] = (int16_t)st->imm < 0 ? 1 : 0;
+        assign_mem(row, cols[12], cols + 13, cols + 19, lk_dynamic, addr, st->memory_op.previous_cycle, shard_offset, ts);
+        row[cols[21]] = word & 0xffff; row[cols[22]] = word >> 16;
+        const uint32_t bit0 = addr & 1, bit1 = (addr >> 1) & 1, limb = (word >> (16 * bit1)) & 0xffff;
+        row[cols[23]] = bit1;
+        row[cols[24]] = limb;
+        uint32_t val = limb;
+        if (byte) {
+            const uint32_t target = (limb >> (8 * bit0)) & 0xff, other = (limb >> (8 * (1 - bit0))) & 0xff;
+            row[cols[25]] = bit0;
+            row[cols[26]] = target;
+            row[cols[27]] = other;
+            lk_dyn(lk_dynamic, target, 8);
+            lk_dyn(lk_dynamic, other, 8);
+            val = target;
+        }
+        if (is_signed) {
+            const int bits = byte ? 8 : 16;
+            const uint32_t msb = val >> (bits - 1);
+            row[cols[28]] = msb;
+            lk_dyn(lk_dynamic, 2 * val - (msb << bits), bits);
+        }
     }
     return 0;
 }

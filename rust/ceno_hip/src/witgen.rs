@@ -156,6 +156,29 @@ impl Witgen {
                                            raw_stream(steps.stream))
         })
     }
+    /// `witgen_load_sub`: LH / LHU (`load_width` 16) and LB / LBU (8); Option columns the variant lacks hold `sys::CENO_HIP_NO_COLUMN`
+    pub fn load_sub(&self, map: &sys::ceno_hip_load_sub_column_map, load_width: u32, is_signed: bool, steps: &ChipSteps, dev_witness: *mut u64,
+                    rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_load_sub(self.hal.ctx, map, load_width as i32, is_signed as i32, steps.dev_records.cast(), steps.num_records,
+                                          steps.dev_indices, steps.n, steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness,
+                                          rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_sh`: the halfword store
+    pub fn sh(&self, map: &sys::ceno_hip_sh_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_sh(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                    lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_sb`: the byte store
+    pub fn sb(&self, map: &sys::ceno_hip_sb_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_sb(self.hal.ctx, map, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n, steps.shard_offset_cycle,
+                                    lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch, raw_stream(steps.stream))
+        })
+    }
     /// `witgen_jalr`: the indirect jump (target as a MemAddr with both low bits witnessed, rd = pc + 4)
     pub fn jalr(&self, map: &sys::ceno_hip_jalr_column_map, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize, lk: &LkTables) -> Result<()> {
         self.hal.check(unsafe {

@@ -574,3 +574,79 @@ def test_shift_and_jalr_bad_arguments_fail_loudly(dev):
         api.witgen_shift(dev, list(range(40)) + [39], True, 0, 8, 1, 8, 1, 8, 2)       # a column id beyond num_cols
     with pytest.raises(CenoHipError):
         api.witgen_jalr(dev, list(range(22)) + [22], 0, 1, 8, 1, 8, 2)                 # no step records
+
+
+@pytest.mark.parametrize("kind", [2, 3])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
+def test_sh_sb_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
+    """SH / SB: SW's columns, the free address bits, and SB's byte columns of the addressed limb with their byte-range lookups"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _sub_store_records, _sub_store_steps
+
+    d = _sub_store_steps(n, kind)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = _sub_store_records(d, kind)
+    nc = 24 if kind == 2 else 29
+    rng = np.random.default_rng(40 + kind)
+    cols = list(rng.permutation(nc + 4)[:nc]) + [nc + 4]
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 4) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_mem(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 4, rows)
+    exp, elkd, elkf = po.witgen_mem(cols, kind, recs, idx, offset, 0x1000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+
+
+@pytest.mark.parametrize("signed", [False, True])
+@pytest.mark.parametrize("width", [16, 8])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
+def test_load_sub_witness_and_lookups_match_cpu_assignment(dev, width, signed, n, rows, offset):
+    """LH / LHU / LB / LBU: LW's columns, limb and byte selection, the sign bit with its range lookup; absent Option columns are marked, not written"""
+    import torch
+
+    from ceno_amd import CenoHipError, api
+    from tests.test_oracle_witgen import _sub_load_records, _sub_load_steps
+
+    d = _sub_load_steps(n, width, signed)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = _sub_load_records(d, width, signed)
+    nc = 25 + (3 if width == 8 else 0) + int(signed)
+    rng = np.random.default_rng(50 + width + signed)
+    ids = [int(x) for x in rng.permutation(nc + 3)[:nc]]
+    cols = po.load_sub_cols(ids, width, signed, nc + 3)
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_load_sub(dev, cols, width, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(),
+                        lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 3, rows)
+    exp, elkd, elkf = po.witgen_load_sub(cols, width, signed, recs, idx, offset, 0x1000, n)
+    mapped = sorted(ids)
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    unmapped = sorted(set(range(nc + 3)) - set(mapped))
+    assert (got[unmapped] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+    if n == 1 and not signed:
+        bad = list(cols)
+        bad[28] = 0                                                                   # an unsigned load that names an msb column
+        with pytest.raises(CenoHipError):
+            api.witgen_load_sub(dev, bad, width, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows)

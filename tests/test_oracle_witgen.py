@@ -667,3 +667,125 @@ def test_shift_oracle_rows_satisfy_the_shift_base_constraints(kind, is_imm):
     n_ts = 2 if is_imm else 3
     assert int(lkd.sum()) == (2 * n_ts + 5) * n and int(lkf.sum()) == n and int(lk2.sum()) == 2 * n and int(lkx.sum()) == (n if kind == 2 else 0)
     assert int(lkd[8:16].sum()) == n + 4 * int((bit_shift == 3).sum())   # the 3-bit range of (c[0] - shift) >> 5, and the carries of 3-bit shifts
+
+
+def _sub_store_steps(n, kind):
+    """SH (kind 2) / SB (kind 3): base 0x1000 + 16 i, offsets that visit every halfword / byte of a word, the stored value's low limb with both bytes set"""
+    d = _mem_steps(n, True)
+    i = np.arange(n, dtype=np.int64)
+    off = (2 * (i % 2)) if kind == 2 else (i % 4)
+    rs1 = 0x1000 + 16 * i
+    imm = np.array([0, 4, -4, -8], dtype=np.int64)[(i // 4) % 4] + off
+    rs2 = (0xA1B2C3D4 + 0x01030507 * i) & 0xFFFFFFFF
+    before = (0x11223344 + 0x10101010 * i) & 0xFFFFFFFF
+    addr = (rs1 + imm) & 0xFFFFFFFF
+    sh = 8 * (addr & 3)
+    mask = np.where(kind == 2, 0xFFFF, 0xFF) << sh
+    after = (before & ~mask & 0xFFFFFFFF) | ((rs2 << sh) & mask)
+    d.update(rs1_vals=rs1.astype(np.uint64), imms=imm, rs2_vals=rs2.astype(np.uint64), mem_addrs=addr.astype(np.uint64), mem_before=before.astype(np.uint64),
+             mem_after=after.astype(np.uint64))
+    return d
+
+
+def _sub_store_records(d, kind):
+    return po.step_records_mem(True, d["cycles"], d["pcs"], po.INSN_SH if kind == 2 else po.INSN_SB, 2, 3, d["imms"], d["rs1_vals"], d["rs2_vals"],
+                               d["rd_before"], d["rd_after"], d["mem_addrs"], d["mem_before"], d["mem_after"], d["prev_cycles"], d["mem_prev_cycles"])
+
+
+@pytest.mark.parametrize("kind", [2, 3])
+def test_sh_sb_oracle_rows_satisfy_the_circuit_relations(kind):
+    """store_v2.rs:60-135 + MemWordUtil (memory/gadget.rs:30-130): the address bits select the limb (bit 1) and the byte (bit 0); SH replaces the selected
+    limb by rs2's low limb, SB replaces one byte of it (expected_limb); the rest of the row is SW's"""
+    n = 400
+    d = _sub_store_steps(n, kind)
+    recs = _sub_store_records(d, kind)
+    nc = 24 if kind == 2 else 29
+    got, lkd, lkf = po.witgen_mem(list(range(nc)) + [nc], kind, recs, np.arange(n), 0, 0x1000, n)
+    ref, rlkd, _ = po.witgen_mem(list(range(23)) + [23], True, recs, np.arange(n), 0, 0x1000, n)
+    assert np.array_equal(got[:, :23], ref)                                     # SW's columns
+    g = got.astype(np.int64)
+    addr, prev, rs2 = g[:, 21] + (g[:, 22] << 16), g[:, 19] + (g[:, 20] << 16), g[:, 15] + (g[:, 16] << 16)
+    after = d["mem_after"].astype(np.int64)
+    if kind == 2:
+        bit1 = g[:, 23]
+        assert np.array_equal(bit1, (addr >> 1) & 1) and not (addr & 1).any()
+        new_limbs = [np.where(bit1 == k, rs2 & 0xFFFF, (prev >> (16 * k)) & 0xFFFF) for k in range(2)]
+        assert np.array_equal(int(lkd.sum()), int(rlkd.sum()))
+    else:
+        bit0, bit1, pb0, pb1, sb, exp = (g[:, 23 + k] for k in range(6))
+        assert np.array_equal(bit0 + 2 * bit1, addr & 3)
+        limb = np.where(bit1 == 1, prev >> 16, prev & 0xFFFF)
+        assert np.array_equal(pb0 + (pb1 << 8), limb) and np.array_equal(sb, rs2 & 0xFF)
+        assert np.array_equal(exp, np.where(bit0 == 1, (sb << 8) + pb0, (pb1 << 8) + sb))
+        new_limbs = [np.where(bit1 == k, exp, (prev >> (16 * k)) & 0xFFFF) for k in range(2)]
+        assert int(lkd.sum()) == int(rlkd.sum()) + 4 * n and int(lkd[256:512].sum()) == 4 * n
+    assert np.array_equal(new_limbs[0] + (new_limbs[1] << 16), after)           # what the memory write records
+    assert int(lkf.sum()) == n
+
+
+def _sub_load_steps(n, width, signed):
+    """LH / LHU / LB / LBU: offsets that visit every halfword / byte of a word, memory words with set and clear sign bits in every position"""
+    d = _mem_steps(n, False)
+    i = np.arange(n, dtype=np.int64)
+    off = (2 * (i % 2)) if width == 16 else (i % 4)
+    rs1 = 0x1000 + 16 * i
+    imm = np.array([0, 4, -4, -8], dtype=np.int64)[(i // 4) % 4] + off
+    word = (0x7F80FF01 + 0x01810283 * i) & 0xFFFFFFFF
+    addr = (rs1 + imm) & 0xFFFFFFFF
+    mask = 0xFFFF if width == 16 else 0xFF
+    val = (word >> (8 * (addr & 3))) & mask
+    if signed:
+        val = np.where(val >> (width - 1), val | (0xFFFFFFFF ^ mask), val)
+    d.update(rs1_vals=rs1.astype(np.uint64), imms=imm, mem_addrs=addr.astype(np.uint64), mem_before=word.astype(np.uint64), mem_after=word.astype(np.uint64),
+             rd_after=val.astype(np.uint64), loaded=val)
+    return d
+
+
+def _sub_load_records(d, width, signed):
+    kind = {(16, True): po.INSN_LH, (16, False): po.INSN_LHU, (8, True): po.INSN_LB, (8, False): po.INSN_LBU}[(width, signed)]
+    return po.step_records_mem(False, d["cycles"], d["pcs"], kind, 2, 4, d["imms"], d["rs1_vals"], d["rs2_vals"], d["rd_before"], d["rd_after"], d["mem_addrs"],
+                               d["mem_before"], d["mem_after"], d["prev_cycles"], d["mem_prev_cycles"])
+
+
+@pytest.mark.parametrize("signed", [False, True])
+@pytest.mark.parametrize("width", [16, 8])
+def test_load_sub_oracle_rows_satisfy_the_circuit_relations(width, signed):
+    """load_v2.rs:95-170: target_limb = memory limb[bit 1]; byte loads: target_limb = target_byte * 2^(8 bit0) + dummy_byte * 2^(8 (1 - bit0));
+    the value written to rd is the loaded value extended by msb"""
+    n = 400
+    d = _sub_load_steps(n, width, signed)
+    recs = _sub_load_records(d, width, signed)
+    nc = 25 + (3 if width == 8 else 0) + int(signed)
+    cols = po.load_sub_cols(range(nc), width, signed, nc)
+    got, lkd, lkf = po.witgen_load_sub(cols, width, signed, recs, np.arange(n), 0, 0x1000, n)
+    ref, rlkd, _ = po.witgen_mem(list(range(23)) + [23], False, recs, np.arange(n), 0, 0x1000, n)
+    assert np.array_equal(got[:, :23], ref)                                          # LW's columns
+    g = got.astype(np.int64)
+    addr, word = g[:, 19] + (g[:, 20] << 16), g[:, 21] + (g[:, 22] << 16)
+    bit1, limb = g[:, 23], g[:, 24]
+    assert np.array_equal(bit1, (addr >> 1) & 1) and np.array_equal(limb, np.where(bit1 == 1, word >> 16, word & 0xFFFF))
+    val, extra = limb, 0
+    if width == 8:
+        bit0, target, other = g[:, 25], g[:, 26], g[:, 27]
+        assert np.array_equal(bit0, addr & 1)
+        assert np.array_equal(limb, np.where(bit0 == 1, (target << 8) + other, (other << 8) + target))
+        val, extra = target, 2
+    else:
+        assert not (addr & 1).any()
+    if signed:
+        msb = g[:, nc - 1]
+        assert np.array_equal(msb, val >> (width - 1))
+        val = val + msb * ((1 << 32) - (1 << width))
+        extra += 1
+        assert int(lkd[(1 << width):(2 << width)].sum()) >= n
+    assert np.array_equal(val, d["loaded"])                                           # what the register write records
+    assert int(lkd.sum()) == int(rlkd.sum()) + extra * n and int(lkf.sum()) == n
+
+
+def test_load_sub_oracle_rejects_columns_a_variant_does_not_have():
+    d = _sub_load_steps(8, 16, False)
+    recs = _sub_load_records(d, 16, False)
+    with pytest.raises(ValueError):
+        po.witgen_load_sub(list(range(29)) + [29], 16, False, recs, np.arange(8))       # LHU with byte and msb columns
+    with pytest.raises(ValueError):
+        po.witgen_load_sub(po.load_sub_cols(range(25), 16, False, 25), 12, False, recs, np.arange(8))
