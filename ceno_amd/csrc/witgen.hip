@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, the five loads and the three stores.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, the five loads, the three stores and the four multiplications.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -60,9 +60,10 @@ __device__ __forceinline__ void lk_count(uint32_t* table, uint32_t slot) {
     }
 }
 // dst[i] += sum over the 8 per-XCD copies (device-scope atomics: other chips of the shard may be adding to dst concurrently)
-__global__ void __launch_bounds__(NT) k_lk_merge(const uint32_t* __restrict__ copies, size_t slots, uint32_t* dst) {
+// (`used` <= `slots`: the chip only counts into the first `used` entries of each copy)
+__global__ void __launch_bounds__(NT) k_lk_merge(const uint32_t* __restrict__ copies, size_t slots, size_t used, uint32_t* dst) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-    if (i >= slots) return;
+    if (i >= used) return;
     uint32_t s = 0;
 #pragma unroll
     for (int x = 0; x < 8; x++) s += copies[(size_t)x * slots + i];
@@ -241,7 +242,10 @@ int witgen_check(ceno_hip_ctx* ctx, const uint32_t* cols, int n_cols, uint32_t n
 struct LkTab {
     uint32_t* user;
     size_t slots;
+    size_t used = 0;  // entries of each copy that are cleared and merged (0 = all): the dynamic table has 2^19 entries (range checks of up to
+                      // DYNAMIC_RANGE_MAX_BITS = 18 bits), every chip but the multiplications stays below 2^17
 };
+constexpr size_t DYN_USED_16 = (size_t)1 << 17;
 template <class Launch>
 int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[4], Launch&& launch) {
     static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
@@ -258,11 +262,19 @@ int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[
     uint32_t* copy[4];
     copy[0] = (uint32_t*)scratch;
     for (int t = 1; t < 4; t++) copy[t] = copy[t - 1] + 8 * slots[t - 1];
-    hipError_t e = hipMemsetAsync(scratch, 0, 8 * total * sizeof(uint32_t), st);
+    hipError_t e = hipSuccess;
+    size_t used[4];
+    for (int t = 0; t < 4 && e == hipSuccess; t++) {
+        used[t] = tabs[t].used && tabs[t].used < slots[t] ? tabs[t].used : slots[t];
+        if (!tabs[t].user) continue;
+        if (used[t] == slots[t]) e = hipMemsetAsync(copy[t], 0, 8 * slots[t] * sizeof(uint32_t), st);
+        else e = hipMemset2DAsync(copy[t], slots[t] * sizeof(uint32_t), 0, used[t] * sizeof(uint32_t), 8, st);
+    }
     if (e == hipSuccess) {
         launch(true, tabs[0].user ? copy[0] : nullptr, tabs[1].user ? copy[1] : nullptr, tabs[2].user ? copy[2] : nullptr, tabs[3].user ? copy[3] : nullptr);
         for (int t = 0; t < 4; t++)
-            if (tabs[t].user) hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((slots[t] + NT - 1) / NT)), dim3(NT), 0, st, copy[t], slots[t], tabs[t].user);
+            if (tabs[t].user)
+                hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((used[t] + NT - 1) / NT)), dim3(NT), 0, st, copy[t], slots[t], used[t], tabs[t].user);
         e = hipGetLastError();
     }
     const hipError_t e2 = hipStreamSynchronize(st);
@@ -1113,6 +1125,87 @@ __global__ void __launch_bounds__(NT) k_witgen_load_sub(LoadSubMap m, const unsi
     }
 }
 
+// ---- MUL / MULH / MULHU / MULHSU (MulhInstructionBase, riscv/mulh/mulh_circuit_v2.rs:234-333 over RInstructionConfig): operands as u16 limbs, the
+// low product limbs, and for the high forms the high product limbs with the operands' sign extensions; run_mulh (:427-487) is a schoolbook product
+// over 16-bit limbs whose carries (< 2^18) and result limbs are range-checked, plus the operands' sign tests.  The register write is the circuit's
+// own expression of rd_low / rd_high: StepRecord.rd.value.after is not read.  22 (MUL) / 26 mapped columns.
+struct MulMap {  // ceno_hip_mul_column_map = ceno_gpu's MulColumnMap (chips/mul.rs:36-56); rd_high, rs1_ext, rs2_ext = CENO_HIP_NO_COLUMN for MUL
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], rd_low[2], rd_high[2], rs1_ext, rs2_ext;
+    uint32_t num_cols;
+};
+static_assert(sizeof(MulMap) == sizeof(ceno_hip_mul_column_map), "column map layout");
+constexpr int MUL_COMMON = 22;
+
+// kind 0: MUL, 1: MULH, 2: MULHU, 3: MULHSU (GpuWitgenKind::Mul's argument)
+template <bool XCD_LOCAL, bool HIGH>
+__global__ void __launch_bounds__(NT) k_witgen_mul(MulMap m, int kind, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n,
+                                                   uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows,
+                                                   uint32_t* lk_dyn, uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<MUL_COMMON>(o, &m.pc);
+            if (HIGH) {
+                o.put(m.rd_high[0], 0);
+                o.put(m.rd_high[1], 0);
+                o.put(m.rs1_ext, 0);
+                o.put(m.rs2_ext, 0);
+            }
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint64_t x0 = st.rs1_val & 0xffff, x1 = st.rs1_val >> 16, y0 = st.rs2_val & 0xffff, y1 = st.rs2_val >> 16;
+        o.put(m.rs1_limbs[0], x0);
+        o.put(m.rs1_limbs[1], x1);
+        o.put(m.rs2_limbs[0], y0);
+        o.put(m.rs2_limbs[1], y1);
+        // run_mulh: low half
+        const uint64_t m0 = x0 * y0, c0 = m0 >> 16;
+        const uint64_t m1 = c0 + x0 * y1 + x1 * y0, c1 = m1 >> 16;
+        o.put(m.rd_low[0], m0 & 0xffff);
+        o.put(m.rd_low[1], m1 & 0xffff);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(m0 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c0);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(m1 & 0xffff));
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c1);
+        if (HIGH) {
+            const uint64_t x_ext = (x1 >> 15) * (kind == 2 ? 0u : 0xffffu), y_ext = (y1 >> 15) * (kind == 1 ? 0xffffu : 0u);
+            const uint64_t h0 = c1 + x0 * y_ext + y0 * x_ext + x1 * y1, c2 = h0 >> 16;
+            const uint64_t h1 = c2 + (x0 + x1) * y_ext + (y0 + y1) * x_ext, c3 = h1 >> 16;
+            o.put(m.rd_high[0], h0 & 0xffff);
+            o.put(m.rd_high[1], h1 & 0xffff);
+            o.put(m.rs1_ext, x_ext);
+            o.put(m.rs2_ext, y_ext);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(h0 & 0xffff));
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c2);
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)(h1 & 0xffff));
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c3);
+            const uint32_t s1 = (uint32_t)(x_ext / 0xffff), s2 = (uint32_t)(y_ext / 0xffff);
+            if (kind == 1) {  // MULH: both operands' top limbs without their sign bit, doubled
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + 2 * ((uint32_t)x1 - s1 * 0x8000u));
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + 2 * ((uint32_t)y1 - s2 * 0x8000u));
+            } else if (kind == 3) {  // MULHSU: rs1 signed, rs2 unsigned (its extension is zero)
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + 2 * ((uint32_t)x1 - s1 * 0x8000u));
+                lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + ((uint32_t)y1 - s2 * 0x8000u));
+            }
+        }
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -1129,7 +1222,7 @@ int witgen_arith(ceno_hip_ctx* ctx, const Map* map, bool sub, const void* recs, 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);  // unmapped columns (num_cols > 22) are left to the caller; mapped ones are fully written
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
         if (sub && xcd) hipLaunchKernelGGL((k_witgen_arith<true, true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else if (sub) hipLaunchKernelGGL((k_witgen_arith<true, false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
@@ -1146,7 +1239,7 @@ int witgen_logic(ceno_hip_ctx* ctx, const LogicMap* map, const void* recs, size_
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
 }
 
@@ -1158,7 +1251,7 @@ int witgen_logic_i(ceno_hip_ctx* ctx, const LogicIMap* map, const void* recs, si
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {lk_logic, LOGIC_SLOTS}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_logic_i, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2));
 }
 
@@ -1169,7 +1262,7 @@ int witgen_addi(ceno_hip_ctx* ctx, const AddiMap* map, const void* recs, size_t 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_addi, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 
@@ -1180,7 +1273,7 @@ int witgen_lui(ceno_hip_ctx* ctx, const LuiMap* map, const void* recs, size_t nu
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_lui, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 int witgen_jal(ceno_hip_ctx* ctx, const JalMap* map, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
@@ -1191,7 +1284,7 @@ int witgen_jal(ceno_hip_ctx* ctx, const JalMap* map, const void* recs, size_t nu
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
         if (xcd) hipLaunchKernelGGL((k_witgen_jal<true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
         else hipLaunchKernelGGL((k_witgen_jal<false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
@@ -1206,7 +1299,7 @@ int witgen_auipc(ceno_hip_ctx* ctx, const AuipcMap* map, const void* recs, size_
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
         if (xcd) hipLaunchKernelGGL((k_witgen_auipc<true>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
         else hipLaunchKernelGGL((k_witgen_auipc<false>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
@@ -1219,7 +1312,7 @@ int witgen_slt(ceno_hip_ctx* ctx, const SltMap* map, int is_signed, const void* 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slt, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 int witgen_slti(ceno_hip_ctx* ctx, const SltiMap* map, int is_signed, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
@@ -1229,7 +1322,7 @@ int witgen_slti(ceno_hip_ctx* ctx, const SltiMap* map, int is_signed, const void
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, WITGEN_LAUNCH(k_witgen_slti, *map, is_signed, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1));
 }
 template <int MODE, class MapT>
@@ -1240,12 +1333,43 @@ int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, cons
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
         if (xcd) hipLaunchKernelGGL((k_witgen_branch<true, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
+int witgen_mul(ceno_hip_ctx* ctx, const MulMap* map, int kind, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+               uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    CHECK_ARG(ctx, kind >= 0 && kind <= 3, "witgen_mul: kind is 0 (MUL), 1 (MULH), 2 (MULHU) or 3 (MULHSU)");
+    const bool high = kind != 0;
+    uint32_t cols[MUL_COMMON + 4];
+    int nc = MUL_COMMON;
+    memcpy(cols, &map->pc, sizeof(uint32_t) * MUL_COMMON);
+    if (high) {
+        cols[nc++] = map->rd_high[0];
+        cols[nc++] = map->rd_high[1];
+        cols[nc++] = map->rs1_ext;
+        cols[nc++] = map->rs2_ext;
+    } else {
+        CHECK_ARG(ctx, map->rd_high[0] == CENO_HIP_NO_COLUMN && map->rd_high[1] == CENO_HIP_NO_COLUMN && map->rs1_ext == CENO_HIP_NO_COLUMN &&
+                           map->rs2_ext == CENO_HIP_NO_COLUMN,
+                  "witgen_mul: MUL has no rd_high / rs1_ext / rs2_ext columns (CENO_HIP_NO_COLUMN)");
+    }
+    TRY(witgen_check(ctx, cols, nc, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+#define ML(X, H) hipLaunchKernelGGL((k_witgen_mul<X, H>), dim3(grid), dim3(NT), 0, st, *map, kind, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1)
+        if (xcd) { if (high) ML(true, true); else ML(true, false); }
+        else { if (high) ML(false, true); else ML(false, false); }
+#undef ML
+    });
+}
+
 int witgen_load_sub(ceno_hip_ctx* ctx, const LoadSubMap* map, int load_width, int is_signed, const void* recs, size_t num_records, const uint32_t* idx,
                     size_t n, uint64_t offset, uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch,
                     ceno_hip_stream s) {
@@ -1270,7 +1394,7 @@ int witgen_load_sub(ceno_hip_ctx* ctx, const LoadSubMap* map, int load_width, in
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
 #define LS(X, B, S) hipLaunchKernelGGL((k_witgen_load_sub<X, B, S>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1)
         if (xcd) { if (byte) { if (is_signed) LS(true, true, true); else LS(true, true, false); } else { if (is_signed) LS(true, false, true); else LS(true, false, false); } }
@@ -1289,7 +1413,7 @@ int witgen_shift(ceno_hip_ctx* ctx, const MapT* map, int kind, const void* recs,
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {lk_du8, LOGIC_SLOTS}, {lk_xor, LOGIC_SLOTS}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {
         if (xcd) hipLaunchKernelGGL((k_witgen_shift<true, IMM, MapT>), dim3(grid), dim3(NT), 0, st, *map, kind, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
         else hipLaunchKernelGGL((k_witgen_shift<false, IMM, MapT>), dim3(grid), dim3(NT), 0, st, *map, kind, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1, t2, t3);
@@ -1303,7 +1427,7 @@ int witgen_jalr(ceno_hip_ctx* ctx, const JalrMap* map, const void* recs, size_t 
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
         if (xcd) hipLaunchKernelGGL(k_witgen_jalr<true>, dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else hipLaunchKernelGGL(k_witgen_jalr<false>, dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
@@ -1317,7 +1441,7 @@ int witgen_mem(ceno_hip_ctx* ctx, const MapT* map, const void* recs, size_t num_
     hipStream_t st = ctx_stream(ctx, s);
     const unsigned grid = grid_for(rows, NT, MAXB);
     const unsigned char* rp = (const unsigned char*)recs;
-    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS, DYN_USED_16}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
     return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
         if (xcd) hipLaunchKernelGGL((k_witgen_mem<true, KIND, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
         else hipLaunchKernelGGL((k_witgen_mem<false, KIND, MapT>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
@@ -1408,6 +1532,14 @@ int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column
     CHECK_ARG(ctx, is_beq == 0 || is_beq == 1, "witgen_branch_eq: is_beq is 1 (BEQ) or 0 (BNE)");
     return witgen_branch<1>(ctx, reinterpret_cast<const BranchEqMap*>(map), BRANCH_EQ_COLS, is_beq, dev_step_records, num_records, dev_step_indices, n,
                             shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_mul(ceno_hip_ctx* ctx, const ceno_hip_mul_column_map* map, int mul_kind, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_mul(ctx, reinterpret_cast<const MulMap*>(map), mul_kind, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                      fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_load_sub(ceno_hip_ctx* ctx, const ceno_hip_load_sub_column_map* map, int load_width, int is_signed, const void* dev_step_records,

@@ -373,14 +373,14 @@ int ceno_hip_pow_grind_duplex(ceno_hip_ctx* ctx, const uint64_t* state16, int bi
  * ceno_emul/src/tracer.rs:33-60) already on the device, and the indices of the steps that belong to this chip.
  * Output: the witness matrix COLUMN-major, `num_cols` columns of `rows_padded` base-field words (rows >= n are zero =
  * InstancePaddingStrategy::Default), and the lookup multiplicities this chip contributes:
- *   dev_lk_dynamic[(1 << bits) + v]  (LookupTable::Dynamic, gkr_iop/src/utils/lk_multiplicity.rs:181-198; 2^17 counters)
+ *   dev_lk_dynamic[(1 << bits) + v]  (LookupTable::Dynamic, gkr_iop/src/utils/lk_multiplicity.rs:181-198; 2^19 counters: bits <= DYNAMIC_RANGE_MAX_BITS = 18, scheme/constants.rs:11)
  *   dev_lk_fetch[(pc - fetch_base_pc) / 4]  (LookupTable::Instruction, dispatch.rs:438-443)
  * Counters are ADDED to (atomics), so one pair of tables serves all chips of a shard; either pointer may be NULL.
  * With lookup tables the call synchronises the stream (it counts into per-XCD scratch copies and merges them).
  * The shard RAM records of the reference's kernels (F-3) are not produced here.
  * ---------------------------------------------------------------------------------------------- */
 #define CENO_HIP_STEP_RECORD_BYTES 136
-#define CENO_HIP_LK_DYNAMIC_SLOTS (1u << 17)
+#define CENO_HIP_LK_DYNAMIC_SLOTS (1u << 19)
 /* same fields, same order as ceno_gpu's AddColumnMap (chips/add.rs:29-46): every entry is a column id < num_cols */
 typedef struct ceno_hip_add_column_map {
     uint32_t pc, ts;
@@ -579,6 +579,21 @@ int ceno_hip_witgen_load_sub(ceno_hip_ctx* ctx, const ceno_hip_load_sub_column_m
                              size_t num_records, const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
                              uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch,
                              ceno_hip_stream s);
+
+/* MUL / MULH / MULHU / MULHSU: hal.witgen.witgen_mul (GpuWitgenKind::Mul(mul_kind), mul_kind 0 = MUL, 1 = MULH, 2 = MULHU, 3 = MULHSU; chips/mul.rs:11-57;
+ * CPU assignment riscv/mulh/mulh_circuit_v2.rs:234-333 with run_mulh :427-487).  rd_high[2], rs1_ext, rs2_ext are Option columns of the reference's map:
+ * CENO_HIP_NO_COLUMN for MUL.  22 / 26 mapped columns. */
+typedef struct ceno_hip_mul_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t rs1_limbs[2], rs2_limbs[2], rd_low[2], rd_high[2], rs1_ext, rs2_ext;
+    uint32_t num_cols;
+} ceno_hip_mul_column_map;
+int ceno_hip_witgen_mul(ceno_hip_ctx* ctx, const ceno_hip_mul_column_map* map, int mul_kind, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 
 /* SH / SB: hal.witgen.witgen_sh / witgen_sb (GpuWitgenKind::Sh / Sb; chips/sh.rs:12-59, chips/sb.rs:10-82; StoreConfig<E, 1> / <E, 0>,
  * store_v2.rs:100-177, MemWordUtil riscv/memory/gadget.rs:134-185): SW's columns, the free address bits, and for SB the byte columns of the

@@ -773,13 +773,13 @@ def step_records_r(cycles, pcs, kind, rs1, rs2, rd, rs1_vals, rs2_vals, rd_befor
 
 
 def witgen_arith(cols, is_sub: bool, records: np.ndarray, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
-    """CPU assignment of the chip's instances: (row-major n x num_cols matrix, dynamic-table counts (2^17), fetch counts)"""
+    """CPU assignment of the chip's instances: (row-major n x num_cols matrix, dynamic-table counts (2^19), fetch counts)"""
     cols = np.ascontiguousarray(cols, dtype=np.uint32)
     assert cols.shape == (ARITH_COLMAP_FIELDS,)
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_arith.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -817,7 +817,7 @@ def witgen_addi(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[18])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_addi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -851,7 +851,7 @@ def _witgen_4tab(fn, n_cols, cols, records, indices, shard_offset, fetch_base_pc
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[n_cols])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     lk2 = np.zeros(1 << 16, dtype=np.uint32)
     lkx = np.zeros(1 << 16, dtype=np.uint32)
@@ -886,7 +886,7 @@ def witgen_shift(cols, is_imm: bool, kind: int, records, indices, shard_offset: 
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     lk2 = np.zeros(1 << 16, dtype=np.uint32)
     lkx = np.zeros(1 << 16, dtype=np.uint32)
@@ -917,7 +917,7 @@ def witgen_jalr(cols, records, indices, shard_offset: int = 0, fetch_base_pc: in
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_jalr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -926,6 +926,28 @@ def witgen_jalr(cols, records, indices, shard_offset: int = 0, fetch_base_pc: in
                            lkd.ctypes.data, lkf.ctypes.data)
     if rc != 0:
         raise ValueError(f"orc_witgen_jalr rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
+INSN_MUL, INSN_MULH, INSN_MULHSU, INSN_MULHU = 28, 29, 30, 31
+
+
+def witgen_mul(cols, kind: int, records, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of MUL (kind 0) / MULH (1) / MULHU (2) / MULHSU (3): (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (27,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[26])), dtype=np.uint64)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_witgen_mul.restype = C.c_int
+    rc = L.orc_witgen_mul(cols.ctypes.data, int(kind), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots, out.ctypes.data,
+                          lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_mul rc={rc}")
     return out, lkd, lkf[:fetch_num_slots]
 
 
@@ -949,7 +971,7 @@ def witgen_load_sub(cols, load_width: int, is_signed: bool, records, indices, sh
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[29])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_load_sub.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -990,7 +1012,7 @@ def witgen_mem(cols, is_store, records: np.ndarray, indices, shard_offset: int =
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_mem.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -1028,7 +1050,7 @@ def witgen_branch(cols, is_eq: bool, flag: bool, records: np.ndarray, indices, s
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[nc])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_branch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -1051,7 +1073,7 @@ def witgen_slti(cols, is_signed: bool, records: np.ndarray, indices, shard_offse
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[22])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_slti.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -1074,7 +1096,7 @@ def witgen_slt(cols, is_signed: bool, records: np.ndarray, indices, shard_offset
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[26])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_slt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -1098,7 +1120,7 @@ def witgen_lui(cols, records: np.ndarray, indices, shard_offset: int = 0, fetch_
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[16])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     L = lib()
     L.orc_witgen_lui.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -1121,7 +1143,7 @@ def witgen_logic_i(cols, records: np.ndarray, indices, shard_offset: int = 0, fe
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[24])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     lkl = np.zeros(1 << 16, dtype=np.uint32)
     L = lib()
@@ -1146,7 +1168,7 @@ def witgen_logic_r(cols, records: np.ndarray, indices, shard_offset: int = 0, fe
     idx = np.ascontiguousarray(indices, dtype=np.uint32)
     recs = np.ascontiguousarray(records)
     out = np.zeros((len(idx), int(cols[28])), dtype=np.uint64)
-    lkd = np.zeros(1 << 17, dtype=np.uint32)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
     lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
     lkl = np.zeros(1 << 16, dtype=np.uint32)
     L = lib()

@@ -78,7 +78,7 @@ static void assign_lt(uint64_t* row, const uint32_t diff_cols[2], uint32_t* lkd,
 static uint8_t register_index(uint32_t waddr) { return (uint8_t)((waddr * 4u) >> 8); }
 
 /* cols[23]: the column map in AddColumnMap / SubColumnMap field order (num_cols last).  out: ROW-major n x num_cols
- * (as cpu_assign_instances produces it); lk_dynamic: 2^17 counters or NULL; lk_fetch: slots or NULL. */
+ * (as cpu_assign_instances produces it); lk_dynamic: 2^19 counters or NULL; lk_fetch: slots or NULL. */
 int orc_witgen_arith(const uint32_t* cols, int is_sub, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset,
                      uint32_t fetch_base_pc, uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
     const uint32_t num_cols = cols[22];
@@ -941,6 +941,88 @@ int orc_witgen_load_sub(const uint32_t* cols, int load_width, int is_signed, con
             const uint32_t msb = val >> (bits - 1);
             row[cols[28]] = msb;
             lk_dyn(lk_dynamic, 2 * val - (msb << bits), bits);
+        }
+    }
+    return 0;
+}
+
+
+/* MulhInstructionBase::assign_instance (riscv/mulh/mulh_circuit_v2.rs:234-333) with run_mulh (:427-487) for two 16-bit limbs: kind 0 = MUL, 1 = MULH,
+ * 2 = MULHU, 3 = MULHSU.  cols[27]: MulColumnMap field order (0xFFFFFFFF in rd_high[2], rs1_ext, rs2_ext for MUL), num_cols last. */
+int orc_witgen_mul(const uint32_t* cols, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint32_t num_cols = cols[26];
+    if (kind < 0 || kind > 3) return -3;
+    for (int c = 0; c < 26; c++)
+        if ((c < 22 || kind != 0) ? cols[c] >= num_cols : cols[c] != 0xFFFFFFFFu) return -1;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rs2 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rs2.addr);
+        row[cols[7]] = p;
+        assign_lt(row, cols + 8, lk_dynamic, p, ts + 1);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[10]] = register_index(st->rd.addr);
+        row[cols[11]] = p;
+        row[cols[12]] = st->rd.before & 0xffff;
+        row[cols[13]] = st->rd.before >> 16;
+        assign_lt(row, cols + 14, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint32_t x[2] = {st->rs1.value & 0xffff, st->rs1.value >> 16}, y[2] = {st->rs2.value & 0xffff, st->rs2.value >> 16};
+        row[cols[16]] = x[0]; row[cols[17]] = x[1];
+        row[cols[18]] = y[0]; row[cols[19]] = y[1];
+        uint64_t mul[2] = {0, 0}, carry[4] = {0, 0, 0, 0};
+        for (int a = 0; a < 2; a++) {
+            if (a > 0) mul[a] = carry[a - 1];
+            for (int j = 0; j <= a; j++) mul[a] += (uint64_t)(x[j] * y[a - j]);
+            carry[a] = mul[a] >> 16;
+            mul[a] %= 1 << 16;
+        }
+        const uint32_t x_ext = (x[1] >> 15) * (kind == 2 ? 0u : 0xffffu), y_ext = (y[1] >> 15) * (kind == 1 ? 0xffffu : 0u);
+        uint64_t mulh[2] = {0, 0};
+        uint32_t xp = 0, yp = 0;
+        for (int a = 0; a < 2; a++) {
+            xp += x[a];
+            yp += y[a];
+            mulh[a] = carry[2 + a - 1] + (uint64_t)xp * y_ext + (uint64_t)yp * x_ext;
+            for (int j = a + 1; j < 2; j++) mulh[a] += (uint64_t)(x[j] * y[2 + a - j]);
+            carry[2 + a] = mulh[a] >> 16;
+            mulh[a] %= 1 << 16;
+        }
+        for (int a = 0; a < 2; a++) {
+            row[cols[20 + a]] = mul[a];
+            lk_dyn(lk_dynamic, mul[a], 16);
+            lk_dyn(lk_dynamic, carry[a], 18);
+        }
+        if (kind != 0) {
+            for (int a = 0; a < 2; a++) {
+                row[cols[22 + a]] = mulh[a];
+                lk_dyn(lk_dynamic, mulh[a], 16);
+                lk_dyn(lk_dynamic, carry[2 + a], 18);
+            }
+            row[cols[24]] = x_ext;
+            row[cols[25]] = y_ext;
+            const uint32_t s1 = x_ext / 0xffff, s2 = y_ext / 0xffff;
+            if (kind == 1) {
+                lk_dyn(lk_dynamic, 2 * (x[1] - s1 * 0x8000), 16);
+                lk_dyn(lk_dynamic, 2 * (y[1] - s2 * 0x8000), 16);
+            } else if (kind == 3) {
+                lk_dyn(lk_dynamic, 2 * (x[1] - s1 * 0x8000), 16);
+                lk_dyn(lk_dynamic, y[1] - s2 * 0x8000, 16);
+            }
         }
     }
     return 0;

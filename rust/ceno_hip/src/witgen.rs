@@ -21,7 +21,7 @@ use crate::{
 /// pointer skips that table.  `logic` is the 2^16-entry table of the operation being generated (`LookupTable::And` / `Or` / `Xor`).
 #[derive(Clone, Copy)]
 pub struct LkTables {
-    /// `LookupTable::Dynamic`: 2^17 counters, key `(1 << bits) + value`
+    /// `LookupTable::Dynamic`: 2^19 counters (DYNAMIC_RANGE_MAX_BITS = 18), key `(1 << bits) + value`
     pub dynamic: *mut u32,
     /// `LookupTable::Instruction`: one counter per program slot, key `(pc - fetch_base_pc) / 4`
     pub fetch: *mut u32,
@@ -154,6 +154,15 @@ impl Witgen {
             sys::ceno_hip_witgen_branch_eq(self.hal.ctx, map, is_beq as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
                                            steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
                                            raw_stream(steps.stream))
+        })
+    }
+    /// `witgen_mul`: MUL (`mul_kind` 0), MULH (1), MULHU (2), MULHSU (3); `rd_high`, `rs1_ext`, `rs2_ext` hold `sys::CENO_HIP_NO_COLUMN` for MUL
+    pub fn mul(&self, map: &sys::ceno_hip_mul_column_map, mul_kind: u32, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+               lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_mul(self.hal.ctx, map, mul_kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                     steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                     raw_stream(steps.stream))
         })
     }
     /// `witgen_load_sub`: LH / LHU (`load_width` 16) and LB / LBU (8); Option columns the variant lacks hold `sys::CENO_HIP_NO_COLUMN`

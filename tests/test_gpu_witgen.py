@@ -34,7 +34,7 @@ def _run(dev, cols, sub, recs, idx, rows, offset, base_pc, slots, lk=True, poiso
     d_idx = _to_dev(np.asarray(idx, dtype=np.uint32).view(np.int32))
     num_cols = int(cols[22])
     w = torch.full((num_cols * rows,), -1 if poison else 0, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(max(slots, 1), dtype=torch.int32, device="cuda:0")
     api.witgen_arith(dev, cols, sub, d_recs.data_ptr(), recs.shape[0], d_idx.data_ptr(), len(idx), w.data_ptr(), rows, offset, base_pc, slots,
                      lkd.data_ptr() if lk else 0, lkf.data_ptr() if lk else 0)
@@ -141,7 +141,7 @@ def _run_logic(dev, cols, kind, recs, idx, rows, offset, base_pc, slots, lk=True
     d_idx = _to_dev(np.asarray(idx, dtype=np.uint32).view(np.int32))
     num_cols = int(cols[28])
     w = torch.full((num_cols * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(max(slots, 1), dtype=torch.int32, device="cuda:0")
     lkl = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
     api.witgen_logic_r(dev, cols, kind, d_recs.data_ptr(), recs.shape[0], d_idx.data_ptr(), len(idx), w.data_ptr(), rows, offset, base_pc, slots,
@@ -217,7 +217,7 @@ def _run_addi(dev, cols, recs, idx, rows, offset, base_pc, slots, lk=True):
     d_idx = _to_dev(np.asarray(idx, dtype=np.uint32).view(np.int32))
     num_cols = int(cols[18])
     w = torch.full((num_cols * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(max(slots, 1), dtype=torch.int32, device="cuda:0")
     api.witgen_addi(dev, cols, d_recs.data_ptr(), recs.shape[0], d_idx.data_ptr(), len(idx), w.data_ptr(), rows, offset, base_pc, slots,
                     lkd.data_ptr() if lk else 0, lkf.data_ptr() if lk else 0)
@@ -280,7 +280,7 @@ def test_logic_i_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full((30 * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     lkl = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
     api.witgen_logic_i(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr(),
@@ -310,7 +310,7 @@ def test_lui_witness_and_lookups_match_cpu_assignment(dev, n, rows):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full((22 * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_lui(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -346,7 +346,7 @@ def test_jal_and_auipc_witness_and_lookups_match_cpu_assignment(dev, chip, n, ro
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full((total * rows,), -1, dtype=torch.int64, device="cuda:0")
-    tabs = [torch.zeros(sz, dtype=torch.int32, device="cuda:0") for sz in (1 << 17, slots, 1 << 16, 1 << 16)]
+    tabs = [torch.zeros(sz, dtype=torch.int32, device="cuda:0") for sz in (1 << 19, slots, 1 << 16, 1 << 16)]
     fn_gpu(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, slots, *[t.data_ptr() for t in tabs])
     dev.sync()
     got = w.cpu().numpy().view(np.uint64).reshape(total, rows)
@@ -376,7 +376,7 @@ def test_slt_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full((30 * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_slt(dev, cols, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -404,7 +404,7 @@ def test_slti_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full((27 * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_slti(dev, cols, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -435,7 +435,7 @@ def test_branch_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 4) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_branch(dev, cols, is_eq, flag, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, 0, 0x2000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -468,7 +468,7 @@ def test_lw_sw_witness_and_lookups_match_cpu_assignment(dev, is_store, n, rows, 
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 5) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     off = 996 if offset else 0
     api.witgen_mem(dev, cols, is_store, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, off, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
@@ -516,7 +516,7 @@ def test_jalr_witness_and_lookups_match_cpu_assignment(dev, n, rows, offset):
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_jalr(dev, cols, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x2000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -550,7 +550,7 @@ def test_shift_witness_and_lookups_match_cpu_assignment(dev, kind, is_imm, n, ro
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     lk2 = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
     lkx = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
@@ -598,7 +598,7 @@ def test_sh_sb_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offs
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 4) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_mem(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
     dev.sync()
@@ -633,7 +633,7 @@ def test_load_sub_witness_and_lookups_match_cpu_assignment(dev, width, signed, n
     d_recs = _to_dev(recs.reshape(-1))
     d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
     w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
-    lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
     lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     api.witgen_load_sub(dev, cols, width, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(),
                         lkf.data_ptr())
@@ -650,3 +650,41 @@ def test_load_sub_witness_and_lookups_match_cpu_assignment(dev, width, signed, n
         bad[28] = 0                                                                   # an unsigned load that names an msb column
         with pytest.raises(CenoHipError):
             api.witgen_load_sub(dev, bad, width, signed, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
+def test_mul_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
+    """MUL / MULH / MULHU / MULHSU: the schoolbook product over 16-bit limbs, 18-bit carry lookups (the upper part of the 2^19-entry dynamic table)"""
+    import torch
+
+    from ceno_amd import CenoHipError, api
+    from tests.test_oracle_witgen import _mul_cols, _mul_steps
+
+    d = _mul_steps(n, kind)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = po.step_records_r(d["cycles"], d["pcs"], [po.INSN_MUL, po.INSN_MULH, po.INSN_MULHU, po.INSN_MULHSU][kind], 2, 3, 4, d["rs1_vals"], d["rs2_vals"],
+                             d["rd_before"], d["rd_after"], d["prev_cycles"])
+    nc = 26 if kind else 22
+    rng = np.random.default_rng(60 + kind)
+    ids = [int(x) for x in rng.permutation(nc + 3)[:nc]]
+    cols = _mul_cols(ids, kind, nc + 3)
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_mul(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 3, rows)
+    exp, elkd, elkf = po.witgen_mul(cols, kind, recs, idx, offset, 0x1000, n)
+    mapped = sorted(ids)
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)
+    if n == 1 and kind == 0:
+        with pytest.raises(CenoHipError):
+            api.witgen_mul(dev, list(range(26)) + [26], 0, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows)   # MUL naming rd_high columns

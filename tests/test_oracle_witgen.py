@@ -44,7 +44,7 @@ def test_oracle_matches_python_model(sub, offset, prev):
     idx = rng.permutation(n)[:250]
     base_pc, slots = 0x1000, n
     got, lkd, lkf = po.witgen_arith(cols, sub, recs, idx, offset, base_pc, slots)
-    exp_dyn, exp_fetch = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
+    exp_dyn, exp_fetch = np.zeros(1 << 19, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
     for r, i in enumerate(idx):
         row, lk = wc.model_row(cols, sub, int(d["cycles"][i]), int(d["pcs"][i]), 2, 3, 4, int(d["rs1_vals"][i]), int(d["rs2_vals"][i]),
                                int(d["rd_before"][i]), int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
@@ -99,7 +99,7 @@ def test_logic_oracle_matches_python_model(kind, offset, prev):
     idx = rng.permutation(n)[:250]
     base_pc, slots = 0x1000, n
     got, lkd, lkf, lkl = po.witgen_logic_r(cols, recs, idx, offset, base_pc, slots)
-    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
+    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 19, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
     for r, i in enumerate(idx):
         row, lk = wc.model_logic_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 3, 4, int(d["rs1_vals"][i]), int(d["rs2_vals"][i]),
                                      int(d["rd_before"][i]), int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
@@ -151,7 +151,7 @@ def test_addi_oracle_matches_python_model(offset, prev):
     idx = np.concatenate([np.arange(6), 6 + rng.permutation(n - 6)[:400]])
     base_pc, slots = 0x1000, n
     got, lkd, lkf = po.witgen_addi(cols, recs, idx, offset, base_pc, slots)
-    exp_dyn, exp_fetch = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
+    exp_dyn, exp_fetch = np.zeros(1 << 19, dtype=np.uint32), np.zeros(slots, dtype=np.uint32)
     for r, i in enumerate(idx):
         row, lk = wc.model_addi_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 4, int(d["rs1_vals"][i]), int(d["imms"][i]), int(d["rd_before"][i]),
                                     int(d["prev_cycles"][i]), offset)
@@ -192,7 +192,7 @@ def test_logic_i_oracle_matches_python_model(kind, offset, prev):
     idx = rng.permutation(n)[:500]
     base_pc, slots = 0x1000, n
     got, lkd, lkf, lkl = po.witgen_logic_i(cols, recs, idx, offset, base_pc, slots)
-    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 17, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
+    exp_dyn, exp_fetch, exp_logic = np.zeros(1 << 19, dtype=np.uint32), np.zeros(slots, dtype=np.uint32), np.zeros(1 << 16, dtype=np.uint32)
     for r, i in enumerate(idx):
         row, lk = wc.model_logic_i_row(cols, int(d["cycles"][i]), int(d["pcs"][i]), 2, 4, int(d["rs1_vals"][i]), int(d["imms"][i]), int(d["rd_before"][i]),
                                        int(d["rd_after"][i]), int(d["prev_cycles"][i]), offset)
@@ -240,7 +240,7 @@ def test_lui_oracle_rows_and_lookups():
     assert np.all(m[:, cols[2]] == 0) and np.all(m[:, cols[6]] == 4) and np.array_equal(m[:, cols[0]], d["pcs"].astype(np.int64))
     for base, diff0, sub_cycle in ((3, 4, 0), (7, 10, 2)):
         assert np.array_equal(m[:, cols[base]] - (m[:, cols[1]] + sub_cycle), m[:, cols[diff0]] + (m[:, cols[diff0 + 1]] << 16) - (1 << 29))
-    exp = np.zeros(1 << 17, dtype=np.int64)
+    exp = np.zeros(1 << 19, dtype=np.int64)
     for b in (12, 13, 14):
         np.add.at(exp, (1 << 8) + m[:, cols[b]], 1)
     for d0 in (4, 10):
@@ -304,7 +304,7 @@ def test_auipc_oracle_rows_and_lookups():
     assert np.array_equal(sum(m[:, cols[18 + b]] << (8 * b) for b in range(3)), imm24)
     # the circuit's identity: rd = pc + (imm24 << 8) mod 2^32
     assert np.array_equal(d["rd_after"].astype(np.int64), (pc + (imm24 << 8)) & 0xFFFFFFFF)
-    ed = np.zeros(1 << 17, dtype=np.int64)
+    ed = np.zeros(1 << 19, dtype=np.int64)
     for c in (16, 17, 18, 19, 20):
         np.add.at(ed, (1 << 8) + m[:, cols[c]], 1)
     for d0 in (4, 10):
@@ -347,7 +347,7 @@ def test_slt_oracle_satisfies_the_comparison_gadget(signed):
     cols = list(rng.permutation(32)[:26]) + [32]
     got, lkd, lkf = po.witgen_slt(cols, signed, recs, np.arange(n), 0, 0x1000, n)
     g = [[int(v) for v in row] for row in got]
-    exp = np.zeros(1 << 17, dtype=np.int64)
+    exp = np.zeros(1 << 19, dtype=np.int64)
     for r in range(n):
         row = g[r]
         a = [row[cols[0]], row[cols[1]]]
@@ -789,3 +789,62 @@ def test_load_sub_oracle_rejects_columns_a_variant_does_not_have():
         po.witgen_load_sub(list(range(29)) + [29], 16, False, recs, np.arange(8))       # LHU with byte and msb columns
     with pytest.raises(ValueError):
         po.witgen_load_sub(po.load_sub_cols(range(25), 16, False, 25), 12, False, recs, np.arange(8))
+
+
+def _mul_steps(n, kind):
+    """chips/mul.rs tests' shape (rs1 = 3 i + 1-like words) plus operands with set sign bits and limb-boundary values"""
+    i = np.arange(n, dtype=np.int64)
+    a = (0x9E3779B1 * (i + 1)) & 0xFFFFFFFF
+    b = (0x85EBCA77 * (i + 3)) & 0xFFFFFFFF
+    if n >= 10:
+        a[:10] = [0, 1, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0xFFFF0000, 0x0000FFFF, 0x80000000, 0xFFFFFFFF, 0x00010000]
+        b[:10] = [5, 0xFFFFFFFF, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0x0000FFFF, 0xFFFF0000, 1, 1, 0x00010000]
+    sa, sb = np.where(a >> 31, a - (1 << 32), a), np.where(b >> 31, b - (1 << 32), b)
+    full = {0: a.astype(object) * b.astype(object), 1: sa.astype(object) * sb.astype(object), 2: a.astype(object) * b.astype(object),
+            3: sa.astype(object) * b.astype(object)}[kind]
+    prod = np.array([int(v) % (1 << 64) for v in full], dtype=object)
+    rd = np.array([int(v) & 0xFFFFFFFF if kind == 0 else int(v) >> 32 for v in prod], dtype=np.uint64)
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=a.astype(np.uint64), rs2_vals=b.astype(np.uint64),
+                rd_before=(i % 53).astype(np.uint64), rd_after=rd, prev_cycles=np.zeros(n, dtype=np.uint64), prod=prod)
+
+
+def _mul_cols(ids, kind, num_cols):
+    ids = list(ids)
+    return [ids.pop(0) for _ in range(22)] + ([ids.pop(0) for _ in range(4)] if kind else [po.NO_COLUMN] * 4) + [num_cols]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_mul_oracle_rows_hold_the_full_product(kind):
+    """mulh_circuit_v2.rs:60-200: rd_low | rd_high are the limbs of rs1 * rs2 with the signedness of the opcode (MULH: both signed, MULHSU: rs1 signed,
+    MULHU / MUL: unsigned), the extensions are 0 or 0xffff by the operands' signs"""
+    n = 300
+    d = _mul_steps(n, kind)
+    recs = po.step_records_r(d["cycles"], d["pcs"], [po.INSN_MUL, po.INSN_MULH, po.INSN_MULHU, po.INSN_MULHSU][kind], 2, 3, 4, d["rs1_vals"], d["rs2_vals"],
+                             d["rd_before"], d["rd_after"], d["prev_cycles"])
+    nc = 26 if kind else 22
+    got, lkd, lkf = po.witgen_mul(_mul_cols(range(nc), kind, nc), kind, recs, np.arange(n), 0, 0x1000, n)
+    g = got.astype(np.int64)
+    assert np.array_equal(g[:, 16] + (g[:, 17] << 16), d["rs1_vals"].astype(np.int64)) and np.array_equal(g[:, 18] + (g[:, 19] << 16), d["rs2_vals"].astype(np.int64))
+    low = g[:, 20] + (g[:, 21] << 16)
+    assert [int(v) for v in low] == [int(p) & 0xFFFFFFFF for p in d["prod"]]
+    n_lk = 6 + 4
+    if kind:
+        high = g[:, 22] + (g[:, 23] << 16)
+        assert [int(v) for v in high] == [int(p) >> 32 for p in d["prod"]]
+        assert np.array_equal(high, d["rd_after"].astype(np.int64))
+        s1, s2 = d["rs1_vals"].astype(np.int64) >> 31, d["rs2_vals"].astype(np.int64) >> 31
+        assert np.array_equal(g[:, 24], np.where(kind == 2, 0, s1 * 0xFFFF)) and np.array_equal(g[:, 25], np.where(kind == 1, s2 * 0xFFFF, 0))
+        n_lk += 4 + (2 if kind in (1, 3) else 0)
+    else:
+        assert np.array_equal(low, d["rd_after"].astype(np.int64))
+    assert int(lkd.sum()) == n_lk * n and int(lkf.sum()) == n
+    assert int(lkd[(1 << 18):].sum()) == (4 if kind else 2) * n                          # the carries: 18-bit range lookups
+
+
+def test_mul_oracle_rejects_option_columns_on_mul():
+    d = _mul_steps(8, 0)
+    recs = po.step_records_r(d["cycles"], d["pcs"], po.INSN_MUL, 2, 3, 4, d["rs1_vals"], d["rs2_vals"], d["rd_before"], d["rd_after"], d["prev_cycles"])
+    with pytest.raises(ValueError):
+        po.witgen_mul(list(range(26)) + [26], 0, recs, np.arange(8))
+    with pytest.raises(ValueError):
+        po.witgen_mul(_mul_cols(range(22), 0, 22), 4, recs, np.arange(8))

@@ -79,7 +79,7 @@ def main():
         d_rec = torch.from_numpy(rec.view(np.int64)).to("cuda:0")
         d_idx = torch.arange(rows, dtype=torch.int32, device="cuda:0")
         d_w = torch.empty(22 * rows, dtype=torch.int64, device="cuda:0")
-        d_lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+        d_lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
         d_lkf = torch.zeros(4096, dtype=torch.int32, device="cuda:0")
         tw = 1e9
         for _ in range(args.reps):

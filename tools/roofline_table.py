@@ -97,7 +97,7 @@ rec[:, 11] = (v1 + v2) & np.uint64(0xFFFFFFFF)
 d_rec = torch.from_numpy(rec.view(np.int64)).to("cuda:0")
 d_idx = torch.arange(n_w, dtype=torch.int32, device="cuda:0")
 d_w = torch.empty(22 * n_w, dtype=torch.int64, device="cuda:0")
-d_lkd = torch.zeros(1 << 17, dtype=torch.int32, device="cuda:0")
+d_lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
 d_lkf = torch.zeros(4096, dtype=torch.int32, device="cuda:0")
 wcols = list(range(22)) + [22]
 row("witgen_add 2^20 instances (22 columns + lookup counts)",
