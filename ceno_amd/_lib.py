@@ -130,6 +130,7 @@ def lib():
         "ceno_hip_witgen_shift_i": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp, vp, vp]),
         "ceno_hip_witgen_load_sub": (i, [vp, vp, i, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_mul": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
+        "ceno_hip_witgen_div": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_sh": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_sb": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_jalr": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),

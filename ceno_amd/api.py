@@ -474,6 +474,21 @@ def witgen_jalr(dev: Device, cols, records_ptr: int, num_records: int, indices_p
 NO_COLUMN = 0xFFFFFFFF
 
 
+def witgen_div(dev: Device, cols, div_kind: int, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
+               shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
+    """hal.witgen.witgen_div (div_kind 0 DIV, 1 DIVU, 2 REM, 3 REMU): `cols` = the 39 column ids in DivColumnMap field order followed by num_cols"""
+    class M(C.Structure):
+        _fields_ = [("cols", C.c_uint32 * 39), ("num_cols", C.c_uint32)]
+
+    m = M()
+    for k in range(39):
+        m.cols[k] = int(cols[k])
+    m.num_cols = int(cols[39])
+    dev.check(dev.L.ceno_hip_witgen_div(dev.h, C.byref(m), int(div_kind), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
+                                        fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
+                                        C.c_void_p(lk_fetch_ptr or None), stream))
+
+
 def witgen_mul(dev: Device, cols, mul_kind: int, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_mul (mul_kind 0 MUL, 1 MULH, 2 MULHU, 3 MULHSU): `cols` = the 26 column ids in MulColumnMap field order (NO_COLUMN in

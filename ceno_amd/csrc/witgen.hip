@@ -1,4 +1,4 @@
-// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, the five loads, the three stores and the four multiplications.
+// On-device witness generation for the chips ADD / SUB, AND / OR / XOR (R-type) and ADDI, ANDI / ORI / XORI, LUI, AUIPC (I-type base), JAL, SLT / SLTU, SLTI / SLTIU, the six branches, JALR, the six shifts, the five loads, the three stores, the four multiplications and the four divisions.
 //
 // One lane per instance: read the step record, compute the 22 witness words of the row exactly as the reference's
 // CPU assignment does (ceno_zkvm/src/instructions/riscv/arith.rs:101-142, r_insn.rs:67-86, insn_base.rs:61-77,
@@ -1206,6 +1206,128 @@ __global__ void __launch_bounds__(NT) k_witgen_mul(MulMap m, int kind, const uns
     }
 }
 
+// ---- DIV / DIVU / REM / REMU (DivRemInstruction, riscv/div/div_circuit_v2.rs:391-536 over RInstructionConfig): dividend = quotient * divisor + remainder
+// witnessed over u16 limbs (run_divrem :628-697: RISC-V's results for a zero divisor and for the signed overflow), the operands' and the
+// quotient's signs, zero flags with the field inverses that prove them, the carries of divisor * quotient + remainder as 18-bit range lookups
+// (run_mul_carries :711-752), and |remainder| < |divisor| through remainder' (the remainder with the divisor's sign) and an unsigned comparison's
+// marker / difference (run_sltu_diff_idx :699-709).  Field-element columns (the inverses) are canonical Goldilocks values.  39 mapped columns.
+struct DivMap {  // ceno_hip_div_column_map = ceno_gpu's DivColumnMap (chips/div.rs:54-84)
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t dividend[2], divisor[2], quotient[2], remainder[2];
+    uint32_t dividend_sign, divisor_sign, quotient_sign, remainder_zero, divisor_zero;
+    uint32_t divisor_sum_inv, remainder_sum_inv, remainder_inv[2], sign_xor, remainder_prime[2], lt_marker[2], lt_diff;
+    uint32_t num_cols;
+};
+static_assert(sizeof(DivMap) == sizeof(ceno_hip_div_column_map), "column map layout");
+constexpr int DIV_COLS = 39;
+
+// SIGNED: DIV / REM (div_kind 0 / 2), otherwise DIVU / REMU (1 / 3): the quotient and the remainder are both witnessed, the kinds of one signedness
+// write the same row
+template <bool XCD_LOCAL, bool SIGNED>
+__global__ void __launch_bounds__(NT) k_witgen_div(DivMap m, const unsigned char* __restrict__ recs, const uint32_t* __restrict__ idx, size_t n, uint64_t offset,
+                                                   uint32_t fetch_base, uint32_t fetch_slots, uint64_t* __restrict__ w, size_t rows, uint32_t* lk_dyn,
+                                                   uint32_t* lk_fetch) {
+    lk_dyn = xcd_copy<XCD_LOCAL>(lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS);
+    lk_fetch = xcd_copy<XCD_LOCAL>(lk_fetch, fetch_slots);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t r = (size_t)blockIdx.x * NT + threadIdx.x; r < rows; r += stride) {
+        const Row o{w, rows, r};
+        if (r >= n) {
+            zero_row<DIV_COLS>(o, &m.pc);
+            continue;
+        }
+        const Step st = load_step(recs, idx[r]);
+        const uint64_t ts = st.cycle - offset;
+        o.put(m.pc, st.pc);
+        o.put(m.ts, ts);
+        emit_read<XCD_LOCAL>(o, m.rs1_id, m.rs1_prev_ts, m.rs1_lt_diff, st.rs1_addr, st.rs1_prev, offset, ts + SUBCYCLE_RS1, lk_dyn);
+        emit_read<XCD_LOCAL>(o, m.rs2_id, m.rs2_prev_ts, m.rs2_lt_diff, st.rs2_addr, st.rs2_prev, offset, ts + SUBCYCLE_RS2, lk_dyn);
+        emit_write<XCD_LOCAL>(o, m.rd_id, m.rd_prev_ts, m.rd_prev_val, m.rd_lt_diff, st.rd_addr, st.rd_before, st.rd_prev, offset, ts + SUBCYCLE_RD, lk_dyn);
+        emit_fetch<XCD_LOCAL>(lk_fetch, st.pc, fetch_base, fetch_slots);
+        const uint32_t x = st.rs1_val, y = st.rs2_val;
+        // run_divrem
+        const bool x_sign = SIGNED && (x >> 31), y_sign = SIGNED && (y >> 31);
+        const bool zero_divisor = y == 0, overflow = SIGNED && x == 0x80000000u && y == 0xffffffffu;
+        uint32_t q, rem;
+        bool q_sign;
+        if (zero_divisor) {
+            q = 0xffffffffu;
+            rem = x;
+            q_sign = SIGNED;
+        } else if (overflow) {
+            q = x;
+            rem = 0;
+            q_sign = false;
+        } else {
+            const uint32_t xa = x_sign ? 0u - x : x, ya = y_sign ? 0u - y : y;
+            const uint32_t qb = xa / ya, rb = xa % ya;
+            q = (x_sign != y_sign) ? 0u - qb : qb;
+            q_sign = SIGNED && (q >> 31);
+            rem = x_sign ? 0u - rb : rb;
+        }
+        const uint64_t d0 = y & 0xffff, d1 = y >> 16, q0 = q & 0xffff, q1 = q >> 16, r0 = rem & 0xffff, r1 = rem >> 16;
+        o.put(m.dividend[0], x & 0xffff);
+        o.put(m.dividend[1], x >> 16);
+        o.put(m.divisor[0], d0);
+        o.put(m.divisor[1], d1);
+        o.put(m.quotient[0], q0);
+        o.put(m.quotient[1], q1);
+        o.put(m.remainder[0], r0);
+        o.put(m.remainder[1], r1);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)q0);  // Value::new(quotient), Value::new(remainder): every limb a u16
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)q1);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)r0);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (uint32_t)r1);
+        o.put(m.dividend_sign, x_sign);
+        o.put(m.divisor_sign, y_sign);
+        o.put(m.quotient_sign, q_sign);
+        o.put(m.divisor_zero, zero_divisor);
+        // run_mul_carries: d * q + r over 16-bit limbs, sign-extended to four limbs
+        const uint64_t c0 = (r0 + d0 * q0) >> 16;
+        const uint64_t c1 = (r1 + c0 + d0 * q1 + d1 * q0) >> 16;
+        const uint64_t q_ext = (q_sign && SIGNED) ? 0xffffu : 0u, d_ext = (d1 >> 15) * (SIGNED ? 0xffffu : 0u), r_ext = (r1 >> 15) * (SIGNED ? 0xffffu : 0u);
+        const uint64_t c2 = (c1 + d0 * q_ext + q0 * d_ext + r_ext + d1 * q1) >> 16;
+        const uint64_t c3 = (c2 + (d0 + d1) * q_ext + (q0 + q1) * d_ext + r_ext) >> 16;
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c0);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c2);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c1);
+        lk_count<XCD_LOCAL>(lk_dyn, (1u << 18) + (uint32_t)c3);
+        const bool sign_xor = x_sign != y_sign;
+        const uint32_t rp = sign_xor ? 0u - rem : rem;  // remainder_prime
+        const uint32_t rp0 = rp & 0xffff, rp1 = rp >> 16;
+        const bool remainder_zero = rem == 0 && !zero_divisor;
+        o.put(m.remainder_zero, remainder_zero);
+        if (SIGNED) {
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (((x >> 16) - (x_sign ? 0x8000u : 0u)) << 1));
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (((uint32_t)d1 - (y_sign ? 0x8000u : 0u)) << 1));
+        }
+        o.put(m.divisor_sum_inv, gl::inv(d0 + d1));
+        o.put(m.remainder_sum_inv, gl::inv(r0 + r1));
+        o.put(m.remainder_inv[0], gl::inv(GOLDILOCKS_P - (0x10000u - rp0)));
+        o.put(m.remainder_inv[1], gl::inv(GOLDILOCKS_P - (0x10000u - rp1)));
+        int lt_idx = 2;
+        uint32_t lt_val = 0;
+        if (!zero_divisor && !overflow && !remainder_zero) {
+            // run_sltu_diff_idx(divisor, remainder', divisor_sign): the most significant limb in which they differ
+            lt_idx = (uint32_t)d1 != rp1 ? 1 : 0;
+            const uint32_t dl = lt_idx ? (uint32_t)d1 : (uint32_t)d0, rl = lt_idx ? rp1 : rp0;
+            lt_val = y_sign ? rl - dl : dl - rl;
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + (lt_val - 1));
+        } else {
+            lk_count<XCD_LOCAL>(lk_dyn, (1u << 16) + 0u);
+        }
+        o.put(m.lt_marker[0], lt_idx == 0);
+        o.put(m.lt_marker[1], lt_idx == 1);
+        o.put(m.sign_xor, sign_xor);
+        o.put(m.remainder_prime[0], rp0);
+        o.put(m.remainder_prime[1], rp1);
+        o.put(m.lt_diff, lt_val);
+    }
+}
+
 // one launcher for every chip: K<true> counts into per-XCD table copies, K<false> into the caller's tables
 #define WITGEN_LAUNCH(KERNEL, ...)                                                                                        \
     [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t* t2, uint32_t* t3) {                                               \
@@ -1339,6 +1461,24 @@ int witgen_branch(ceno_hip_ctx* ctx, const MapT* map, int n_cols, int flag, cons
         else hipLaunchKernelGGL((k_witgen_branch<false, MODE, MapT>), dim3(grid), dim3(NT), 0, st, *map, flag, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1);
     });
 }
+int witgen_div(ceno_hip_ctx* ctx, const DivMap* map, int kind, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
+               uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, map, "NULL column map");
+    CHECK_ARG(ctx, kind >= 0 && kind <= 3, "witgen_div: kind is 0 (DIV), 1 (DIVU), 2 (REM) or 3 (REMU)");
+    TRY(witgen_check(ctx, &map->pc, DIV_COLS, map->num_cols, recs, num_records, idx, n, w, rows, lk_fetch, fetch_slots));
+    hipStream_t st = ctx_stream(ctx, s);
+    const unsigned grid = grid_for(rows, NT, MAXB);
+    const unsigned char* rp = (const unsigned char*)recs;
+    const bool is_signed = kind == 0 || kind == 2;
+    const LkTab tabs[4] = {{lk_dyn, CENO_HIP_LK_DYNAMIC_SLOTS}, {lk_fetch, fetch_slots}, {nullptr, 0}, {nullptr, 0}};
+    return witgen_run(ctx, st, n, tabs, [&](bool xcd, uint32_t* t0, uint32_t* t1, uint32_t*, uint32_t*) {
+#define DV(X, S) hipLaunchKernelGGL((k_witgen_div<X, S>), dim3(grid), dim3(NT), 0, st, *map, rp, idx, n, offset, fetch_base, fetch_slots, w, rows, t0, t1)
+        if (xcd) { if (is_signed) DV(true, true); else DV(true, false); }
+        else { if (is_signed) DV(false, true); else DV(false, false); }
+#undef DV
+    });
+}
+
 int witgen_mul(ceno_hip_ctx* ctx, const MulMap* map, int kind, const void* recs, size_t num_records, const uint32_t* idx, size_t n, uint64_t offset,
                uint32_t fetch_base, uint32_t fetch_slots, uint64_t* w, size_t rows, uint32_t* lk_dyn, uint32_t* lk_fetch, ceno_hip_stream s) {
     CHECK_ARG(ctx, map, "NULL column map");
@@ -1532,6 +1672,14 @@ int ceno_hip_witgen_branch_eq(ceno_hip_ctx* ctx, const ceno_hip_branch_eq_column
     CHECK_ARG(ctx, is_beq == 0 || is_beq == 1, "witgen_branch_eq: is_beq is 1 (BEQ) or 0 (BNE)");
     return witgen_branch<1>(ctx, reinterpret_cast<const BranchEqMap*>(map), BRANCH_EQ_COLS, is_beq, dev_step_records, num_records, dev_step_indices, n,
                             shard_offset_cycle, fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
+}
+
+int ceno_hip_witgen_div(ceno_hip_ctx* ctx, const ceno_hip_div_column_map* map, int div_kind, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    return witgen_div(ctx, reinterpret_cast<const DivMap*>(map), div_kind, dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
+                      fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, s);
 }
 
 int ceno_hip_witgen_mul(ceno_hip_ctx* ctx, const ceno_hip_mul_column_map* map, int mul_kind, const void* dev_step_records, size_t num_records,

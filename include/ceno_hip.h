@@ -595,6 +595,23 @@ int ceno_hip_witgen_mul(ceno_hip_ctx* ctx, const ceno_hip_mul_column_map* map, i
                         const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
                         uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
 
+/* DIV / DIVU / REM / REMU: hal.witgen.witgen_div (GpuWitgenKind::Div(div_kind), div_kind 0 = DIV, 1 = DIVU, 2 = REM, 3 = REMU; chips/div.rs:11-85; CPU
+ * assignment riscv/div/div_circuit_v2.rs:391-536 with run_divrem :628-697, run_mul_carries :711-752, run_sltu_diff_idx :699-709).  divisor_sum_inv,
+ * remainder_sum_inv and remainder_inv[2] are FIELD elements (inverses; 0 for a zero sum), written as canonical Goldilocks values.  39 mapped columns. */
+typedef struct ceno_hip_div_column_map {
+    uint32_t pc, ts;
+    uint32_t rs1_id, rs1_prev_ts, rs1_lt_diff[2];
+    uint32_t rs2_id, rs2_prev_ts, rs2_lt_diff[2];
+    uint32_t rd_id, rd_prev_ts, rd_prev_val[2], rd_lt_diff[2];
+    uint32_t dividend[2], divisor[2], quotient[2], remainder[2];
+    uint32_t dividend_sign, divisor_sign, quotient_sign, remainder_zero, divisor_zero;
+    uint32_t divisor_sum_inv, remainder_sum_inv, remainder_inv[2], sign_xor, remainder_prime[2], lt_marker[2], lt_diff;
+    uint32_t num_cols;
+} ceno_hip_div_column_map;
+int ceno_hip_witgen_div(ceno_hip_ctx* ctx, const ceno_hip_div_column_map* map, int div_kind, const void* dev_step_records, size_t num_records,
+                        const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc, uint32_t fetch_num_slots,
+                        uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic, uint32_t* dev_lk_fetch, ceno_hip_stream s);
+
 /* SH / SB: hal.witgen.witgen_sh / witgen_sb (GpuWitgenKind::Sh / Sb; chips/sh.rs:12-59, chips/sb.rs:10-82; StoreConfig<E, 1> / <E, 0>,
  * store_v2.rs:100-177, MemWordUtil riscv/memory/gadget.rs:134-185): SW's columns, the free address bits, and for SB the byte columns of the
  * addressed limb.  24 / 29 mapped columns. */

@@ -279,6 +279,9 @@ int orc_witgen_load_sub(const uint32_t* cols, int load_width, int is_signed, con
 /* MUL / MULH / MULHU / MULHSU (mulh_circuit_v2.rs:234-333,427-487): cols[27] in MulColumnMap order, 0xFFFFFFFF in the Option fields for MUL */
 int orc_witgen_mul(const uint32_t* cols, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
                    uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
+/* DIV / DIVU / REM / REMU (div_circuit_v2.rs:391-536): cols[40] in DivColumnMap order */
+int orc_witgen_div(const uint32_t* cols, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch);
 /* JAL (jal_v2.rs:99-127) and AUIPC (auipc.rs:149-187): cols[14] / cols[22] in JalColumnMap / AuipcColumnMap order; double_u8 key a << 8 | b */
 void orc_step_record_j(void* out, uint64_t cycle, uint32_t pc, uint32_t pc_after, uint8_t kind, uint8_t rd, int32_t imm, uint32_t rd_before,
                        uint32_t rd_after, uint64_t prev_cycle);

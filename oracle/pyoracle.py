@@ -929,6 +929,28 @@ def witgen_jalr(cols, records, indices, shard_offset: int = 0, fetch_base_pc: in
     return out, lkd, lkf[:fetch_num_slots]
 
 
+INSN_DIV, INSN_DIVU, INSN_REM, INSN_REMU = 32, 33, 34, 35
+
+
+def witgen_div(cols, kind: int, records, indices, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0):
+    """CPU assignment of DIV (kind 0) / DIVU (1) / REM (2) / REMU (3): (row-major n x num_cols matrix, dynamic-table counts, fetch counts)"""
+    cols = np.ascontiguousarray(cols, dtype=np.uint32)
+    assert cols.shape == (40,)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    recs = np.ascontiguousarray(records)
+    out = np.zeros((len(idx), int(cols[39])), dtype=np.uint64)
+    lkd = np.zeros(1 << 19, dtype=np.uint32)
+    lkf = np.zeros(max(fetch_num_slots, 1), dtype=np.uint32)
+    L = lib()
+    L.orc_witgen_div.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_witgen_div.restype = C.c_int
+    rc = L.orc_witgen_div(cols.ctypes.data, int(kind), recs.ctypes.data, idx.ctypes.data, len(idx), shard_offset, fetch_base_pc, fetch_num_slots, out.ctypes.data,
+                          lkd.ctypes.data, lkf.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"orc_witgen_div rc={rc}")
+    return out, lkd, lkf[:fetch_num_slots]
+
+
 INSN_MUL, INSN_MULH, INSN_MULHSU, INSN_MULHU = 28, 29, 30, 31
 
 

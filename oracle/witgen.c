@@ -1027,3 +1027,135 @@ int orc_witgen_mul(const uint32_t* cols, int kind, const void* records, const ui
     }
     return 0;
 }
+
+
+/* DivRemInstruction::assign_instance (riscv/div/div_circuit_v2.rs:391-536) with run_divrem (:628-697), run_mul_carries (:711-752) and run_sltu_diff_idx
+ * (:699-709) over two 16-bit limbs: kind 0 = DIV, 1 = DIVU, 2 = REM, 3 = REMU.  cols[40]: DivColumnMap field order, num_cols last. */
+static void div_negate(const uint32_t x[2], uint32_t out[2]) { /* negate (:776-783) */
+    uint32_t carry = 1;
+    for (int i = 0; i < 2; i++) {
+        const uint32_t val = (1u << 16) + carry - 1 - x[i];
+        carry = val >> 16;
+        out[i] = val % (1u << 16);
+    }
+}
+int orc_witgen_div(const uint32_t* cols, int kind, const void* records, const uint32_t* indices, size_t n, uint64_t shard_offset, uint32_t fetch_base_pc,
+                   uint32_t fetch_num_slots, uint64_t* out_row_major, uint32_t* lk_dynamic, uint32_t* lk_fetch) {
+    const uint64_t P = 0xFFFFFFFF00000001ULL;
+    const uint32_t num_cols = cols[39];
+    if (kind < 0 || kind > 3) return -3;
+    for (int c = 0; c < 39; c++)
+        if (cols[c] >= num_cols) return -1;
+    const int is_signed = kind == 0 || kind == 2;
+    const orc_step_record* recs = (const orc_step_record*)records;
+    for (size_t i = 0; i < n; i++) {
+        const orc_step_record* st = &recs[indices[i]];
+        uint64_t* row = out_row_major + i * num_cols;
+        if (!st->has_rs1 || !st->has_rs2 || !st->has_rd) return -2;
+        const uint64_t ts = st->cycle - shard_offset;
+        row[cols[0]] = st->pc_before;
+        row[cols[1]] = ts;
+        uint64_t p = aligned_prev_ts(st->rs1.previous_cycle, shard_offset);
+        row[cols[2]] = register_index(st->rs1.addr);
+        row[cols[3]] = p;
+        assign_lt(row, cols + 4, lk_dynamic, p, ts + 0);
+        p = aligned_prev_ts(st->rs2.previous_cycle, shard_offset);
+        row[cols[6]] = register_index(st->rs2.addr);
+        row[cols[7]] = p;
+        assign_lt(row, cols + 8, lk_dynamic, p, ts + 1);
+        p = aligned_prev_ts(st->rd.previous_cycle, shard_offset);
+        row[cols[10]] = register_index(st->rd.addr);
+        row[cols[11]] = p;
+        row[cols[12]] = st->rd.before & 0xffff;
+        row[cols[13]] = st->rd.before >> 16;
+        assign_lt(row, cols + 14, lk_dynamic, p, ts + 2);
+        if (lk_fetch) {
+            const uint32_t slot = (st->pc_before - fetch_base_pc) / 4;
+            if (slot < fetch_num_slots) lk_fetch[slot] += 1;
+        }
+        const uint32_t x[2] = {st->rs1.value & 0xffff, st->rs1.value >> 16}, y[2] = {st->rs2.value & 0xffff, st->rs2.value >> 16};
+        /* run_divrem */
+        const int x_sign = is_signed && (x[1] >> 15) == 1, y_sign = is_signed && (y[1] >> 15) == 1;
+        const int zero_divisor = y[0] == 0 && y[1] == 0;
+        const int overflow = x[1] == 0x8000 && x[0] == 0 && y[0] == 0xffff && y[1] == 0xffff && x_sign && y_sign;
+        uint32_t q[2], r[2];
+        int q_sign, special = zero_divisor ? 1 : overflow ? 2 : 0;
+        if (zero_divisor) {
+            q[0] = q[1] = 0xffff; r[0] = x[0]; r[1] = x[1]; q_sign = is_signed;
+        } else if (overflow) {
+            q[0] = x[0]; q[1] = x[1]; r[0] = r[1] = 0; q_sign = 0;
+        } else {
+            uint32_t xa[2] = {x[0], x[1]}, ya[2] = {y[0], y[1]};
+            if (x_sign) div_negate(x, xa);
+            if (y_sign) div_negate(y, ya);
+            const uint32_t xb = xa[0] + (xa[1] << 16), yb = ya[0] + (ya[1] << 16), qb = xb / yb, rb = xb % yb;
+            const uint32_t ql[2] = {qb & 0xffff, qb >> 16}, rl[2] = {rb & 0xffff, rb >> 16};
+            if (x_sign ^ y_sign) div_negate(ql, q); else { q[0] = ql[0]; q[1] = ql[1]; }
+            q_sign = is_signed && (q[1] >> 15) == 1;
+            if (x_sign) div_negate(rl, r); else { r[0] = rl[0]; r[1] = rl[1]; }
+        }
+        row[cols[16]] = x[0]; row[cols[17]] = x[1];
+        row[cols[18]] = y[0]; row[cols[19]] = y[1];
+        for (int a = 0; a < 2; a++) {
+            row[cols[20 + a]] = q[a];
+            row[cols[22 + a]] = r[a];
+        }
+        lk_dyn(lk_dynamic, q[0], 16); lk_dyn(lk_dynamic, q[1], 16);   /* Value::new(quotient, lkm) */
+        lk_dyn(lk_dynamic, r[0], 16); lk_dyn(lk_dynamic, r[1], 16);   /* Value::new(remainder, lkm) */
+        row[cols[24]] = x_sign;
+        row[cols[25]] = y_sign;
+        row[cols[26]] = q_sign;
+        row[cols[28]] = special == 1;
+        /* run_mul_carries(signed, d = divisor, q, r, q_sign) */
+        uint32_t carry[4] = {0, 0, 0, 0};
+        for (int a = 0; a < 2; a++) {
+            uint64_t val = (uint64_t)r[a] + (a > 0 ? carry[a - 1] : 0);
+            for (int j = 0; j <= a; j++) val += (uint64_t)y[j] * q[a - j];
+            carry[a] = (uint32_t)(val >> 16);
+        }
+        const uint32_t q_ext = (q_sign && is_signed) ? 0xffff : 0, d_ext = (y[1] >> 15) * (is_signed ? 0xffffu : 0u), r_ext = (r[1] >> 15) * (is_signed ? 0xffffu : 0u);
+        uint32_t d_prefix = 0, q_prefix = 0;
+        for (int a = 0; a < 2; a++) {
+            d_prefix += y[a];
+            q_prefix += q[a];
+            uint64_t val = (uint64_t)carry[2 + a - 1] + (uint64_t)d_prefix * q_ext + (uint64_t)q_prefix * d_ext + r_ext;
+            for (int j = a + 1; j < 2; j++) val += (uint64_t)y[j] * q[2 + a - j];
+            carry[2 + a] = (uint32_t)(val >> 16);
+        }
+        for (int a = 0; a < 2; a++) {
+            lk_dyn(lk_dynamic, carry[a], 18);
+            lk_dyn(lk_dynamic, carry[a + 2], 18);
+        }
+        const int sign_xor = x_sign ^ y_sign;
+        uint32_t rp[2] = {r[0], r[1]};
+        if (sign_xor) div_negate(r, rp);
+        const int remainder_zero = r[0] == 0 && r[1] == 0 && special != 1;
+        row[cols[27]] = remainder_zero;
+        if (is_signed) {
+            lk_dyn(lk_dynamic, ((uint64_t)x[1] - (x_sign ? 0x8000 : 0)) << 1, 16);
+            lk_dyn(lk_dynamic, ((uint64_t)y[1] - (y_sign ? 0x8000 : 0)) << 1, 16);
+        }
+        row[cols[29]] = gl_inv_((uint64_t)y[0] + y[1]);
+        row[cols[30]] = gl_inv_((uint64_t)r[0] + r[1]);
+        row[cols[31]] = gl_inv_(P - (0x10000 - (uint64_t)rp[0]));
+        row[cols[32]] = gl_inv_(P - (0x10000 - (uint64_t)rp[1]));
+        int lt_idx = 2;
+        uint32_t lt_val = 0;
+        if (special == 0 && !remainder_zero) {
+            for (int a = 1; a >= 0; a--)
+                if (y[a] != rp[a]) { lt_idx = a; break; }
+            if (lt_idx == 2) return -4; /* |remainder| = |divisor|: the reference panics here */
+            lt_val = y_sign ? rp[lt_idx] - y[lt_idx] : y[lt_idx] - rp[lt_idx];
+            lk_dyn(lk_dynamic, (uint64_t)lt_val - 1, 16);
+        } else {
+            lk_dyn(lk_dynamic, 0, 16);
+        }
+        row[cols[33]] = sign_xor;
+        row[cols[34]] = rp[0];
+        row[cols[35]] = rp[1];
+        row[cols[36]] = lt_idx == 0;
+        row[cols[37]] = lt_idx == 1;
+        row[cols[38]] = lt_val;
+    }
+    return 0;
+}

@@ -156,6 +156,15 @@ impl Witgen {
                                            raw_stream(steps.stream))
         })
     }
+    /// `witgen_div`: DIV (`div_kind` 0), DIVU (1), REM (2), REMU (3)
+    pub fn div(&self, map: &sys::ceno_hip_div_column_map, div_kind: u32, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
+               lk: &LkTables) -> Result<()> {
+        self.hal.check(unsafe {
+            sys::ceno_hip_witgen_div(self.hal.ctx, map, div_kind as i32, steps.dev_records.cast(), steps.num_records, steps.dev_indices, steps.n,
+                                     steps.shard_offset_cycle, lk.fetch_base_pc, lk.fetch_num_slots, dev_witness, rows_padded, lk.dynamic, lk.fetch,
+                                     raw_stream(steps.stream))
+        })
+    }
     /// `witgen_mul`: MUL (`mul_kind` 0), MULH (1), MULHU (2), MULHSU (3); `rd_high`, `rs1_ext`, `rs2_ext` hold `sys::CENO_HIP_NO_COLUMN` for MUL
     pub fn mul(&self, map: &sys::ceno_hip_mul_column_map, mul_kind: u32, steps: &ChipSteps, dev_witness: *mut u64, rows_padded: usize,
                lk: &LkTables) -> Result<()> {

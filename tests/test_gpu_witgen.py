@@ -688,3 +688,37 @@ def test_mul_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset
     if n == 1 and kind == 0:
         with pytest.raises(CenoHipError):
             api.witgen_mul(dev, list(range(26)) + [26], 0, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows)   # MUL naming rd_high columns
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
+def test_div_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
+    """DIV / DIVU / REM / REMU: RISC-V's special cases, sign and zero flags with their field inverses, the 18-bit carries of divisor * quotient + remainder,
+    the |remainder| < |divisor| comparison"""
+    import torch
+
+    from ceno_amd import api
+    from tests.test_oracle_witgen import _div_records, _div_steps
+
+    d = _div_steps(n, kind)
+    if offset:
+        d["cycles"] = d["cycles"] + np.uint64(1000)
+        d["prev_cycles"][::3] = 500
+        d["prev_cycles"][1::3] = 1
+    recs = _div_records(d, kind)
+    nc = 39
+    rng = np.random.default_rng(70 + kind)
+    cols = [int(x) for x in rng.permutation(nc + 3)[:nc]] + [nc + 3]
+    idx = rng.permutation(n) if offset else np.arange(n)
+    d_recs = _to_dev(recs.reshape(-1))
+    d_idx = _to_dev(idx.astype(np.uint32).view(np.int32))
+    w = torch.full(((nc + 3) * rows,), -1, dtype=torch.int64, device="cuda:0")
+    lkd = torch.zeros(1 << 19, dtype=torch.int32, device="cuda:0")
+    lkf = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    api.witgen_div(dev, cols, kind, d_recs.data_ptr(), n, d_idx.data_ptr(), n, w.data_ptr(), rows, offset, 0x1000, n, lkd.data_ptr(), lkf.data_ptr())
+    dev.sync()
+    got = w.cpu().numpy().view(np.uint64).reshape(nc + 3, rows)
+    exp, elkd, elkf = po.witgen_div(cols, kind, recs, idx, offset, 0x1000, n)
+    mapped = sorted(cols[:nc])
+    assert np.array_equal(got[mapped, :n], exp.T[mapped]) and not got[mapped, n:].any()
+    assert np.array_equal(lkd.cpu().numpy().view(np.uint32), elkd) and np.array_equal(lkf.cpu().numpy().view(np.uint32), elkf)

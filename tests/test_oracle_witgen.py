@@ -848,3 +848,78 @@ def test_mul_oracle_rejects_option_columns_on_mul():
         po.witgen_mul(list(range(26)) + [26], 0, recs, np.arange(8))
     with pytest.raises(ValueError):
         po.witgen_mul(_mul_cols(range(22), 0, 22), 4, recs, np.arange(8))
+
+
+def _div_steps(n, kind):
+    """operands that reach every branch of run_divrem: a zero divisor, the signed overflow (INT_MIN / -1), exact divisions (remainder 0), both signs of
+    both operands, |dividend| < |divisor|, divisors of one limb and of two"""
+    i = np.arange(n, dtype=np.int64)
+    a = (0x9E3779B1 * (i + 1)) & 0xFFFFFFFF
+    b = np.where(i % 3 == 0, (0x85EBCA77 * (i + 3)) & 0xFFFF, (0x85EBCA77 * (i + 3)) & 0xFFFFFFFF)
+    b = np.where(i % 5 == 0, (0 - b) & 0xFFFFFFFF, b)
+    b[b == 0] = 7
+    if n >= 12:
+        a[:12] = [100, 0x80000000, 0x80000000, 7, 0xFFFFFFF9, 0xFFFFFFF9, 21, 0, 5, 0xFFFFFFFF, 0x7FFFFFFF, 0x00010000]
+        b[:12] = [0, 0xFFFFFFFF, 1, 0xFFFFFFFE, 2, 0xFFFFFFFE, 7, 9, 0x00020000, 0xFFFFFFFF, 0x80000000, 0x0000FFFF]
+    signed = kind in (0, 2)
+    sa = np.where((a >> 31) & signed, a - (1 << 32), a)
+    sb = np.where((b >> 31) & signed, b - (1 << 32), b)
+    q, r = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    for k in range(n):
+        x, y = int(sa[k]), int(sb[k])
+        if y == 0:
+            qq, rr = -1, x
+        elif signed and x == -(1 << 31) and y == -1:
+            qq, rr = x, 0
+        else:
+            qq = abs(x) // abs(y) * (1 if (x < 0) == (y < 0) else -1)       # C division: truncates toward zero
+            rr = x - qq * y
+        q[k], r[k] = qq & 0xFFFFFFFF, rr & 0xFFFFFFFF
+    rd = q if kind in (0, 1) else r
+    return dict(cycles=(4 + 4 * i).astype(np.uint64), pcs=(0x1000 + 4 * i).astype(np.uint64), rs1_vals=a.astype(np.uint64), rs2_vals=b.astype(np.uint64),
+                rd_before=(i % 59).astype(np.uint64), rd_after=rd.astype(np.uint64), prev_cycles=np.zeros(n, dtype=np.uint64), q=q, r=r)
+
+
+def _div_records(d, kind):
+    return po.step_records_r(d["cycles"], d["pcs"], [po.INSN_DIV, po.INSN_DIVU, po.INSN_REM, po.INSN_REMU][kind], 2, 3, 4, d["rs1_vals"], d["rs2_vals"],
+                             d["rd_before"], d["rd_after"], d["prev_cycles"])
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_div_oracle_rows_satisfy_the_circuit_relations(kind):
+    """div_circuit_v2.rs:60-380: quotient and remainder are RISC-V's; the zero flags are proved by their inverse witnesses (flag = 1 - sum * inv);
+    remainder' carries the divisor's sign and differs from the divisor at the marked limb by lt_diff; (remainder'_i - 2^16) * remainder_inv_i = 1"""
+    n = 400
+    d = _div_steps(n, kind)
+    recs = _div_records(d, kind)
+    got, lkd, lkf = po.witgen_div(list(range(39)) + [39], kind, recs, np.arange(n), 0, 0x1000, n)
+    signed = kind in (0, 2)
+    for r in range(n):
+        row = [int(v) for v in got[r]]
+        x, y, q, rem = (row[16 + 2 * k] + (row[17 + 2 * k] << 16) for k in range(4))
+        assert (x, y, q, rem) == (int(d["rs1_vals"][r]), int(d["rs2_vals"][r]), int(d["q"][r]), int(d["r"][r]))
+        xs, ys, qs, rz, dz = row[24:29]
+        assert xs == (signed and x >> 31) and ys == (signed and y >> 31) and dz == (y == 0)
+        overflow = signed and x == 0x80000000 and y == 0xFFFFFFFF
+        # a zero divisor's quotient -1 counts as negative when signed; the overflow's quotient INT_MIN does not (run_divrem :663-671)
+        assert qs == (signed and not overflow and (q >> 31 or y == 0))
+        assert rz == (rem == 0 and y != 0)
+        dsum, rsum = row[18] + row[19], row[22] + row[23]
+        assert (dsum * row[29]) % P_GL == (0 if dsum == 0 else 1) and (rsum * row[30]) % P_GL == (0 if rsum == 0 else 1)
+        sx, rp = row[33], row[34] + (row[35] << 16)
+        assert sx == (xs ^ ys) and rp == ((-rem) & 0xFFFFFFFF if sx else rem)
+        for k in range(2):
+            assert ((row[34 + k] - (1 << 16)) % P_GL) * row[31 + k] % P_GL == 1
+        m0, m1, lt = row[36], row[37], row[38]
+        special = y == 0 or (signed and x == 0x80000000 and y == 0xFFFFFFFF)
+        if special or rz:
+            assert (m0, m1, lt) == (0, 0, 0)
+        else:
+            assert m0 + m1 == 1
+            k = 1 if m1 else 0
+            assert all(row[18 + j] == row[34 + j] for j in range(k + 1, 2))                  # equal above the marked limb
+            assert lt == (row[34 + k] - row[18 + k] if ys else row[18 + k] - row[34 + k]) and lt >= 1
+    assert int(lkd.sum()) == (6 + 4 + 4 + 1 + (2 if signed else 0)) * n and int(lkf.sum()) == n and int(lkd[(1 << 18):].sum()) == 4 * n
+    # DIV and REM (DIVU and REMU) assign the same row
+    other, _, _ = po.witgen_div(list(range(39)) + [39], {0: 2, 2: 0, 1: 3, 3: 1}[kind], recs, np.arange(n), 0, 0x1000, n)
+    assert np.array_equal(other, got)

@@ -151,7 +151,7 @@ def test_safe_crate_and_arms_reference_only_existing_items_and_cover_every_trait
                  "ceno_hip_witgen_jal", "ceno_hip_witgen_slt", "ceno_hip_witgen_slti", "ceno_hip_witgen_branch_cmp",
                  "ceno_hip_witgen_branch_eq", "ceno_hip_witgen_lw", "ceno_hip_witgen_sw", "ceno_hip_witgen_jalr",
                  "ceno_hip_witgen_shift_r", "ceno_hip_witgen_shift_i", "ceno_hip_sumcheck_set_claim", "ceno_hip_witgen_load_sub",
-                 "ceno_hip_witgen_sh", "ceno_hip_witgen_sb", "ceno_hip_witgen_mul"):
+                 "ceno_hip_witgen_sh", "ceno_hip_witgen_sb", "ceno_hip_witgen_mul", "ceno_hip_witgen_div"):
         assert must in used, must
     zk = open(arms[2]).read()
     for trait in ("TraceCommitter", "TowerProver", "MainSumcheckProver", "BatchedMainConstraintProver", "OpeningProver", "DeviceTransporter",
