@@ -38,8 +38,7 @@ __device__ __forceinline__ uint64_t aligned_prev_ts(uint64_t prev_cycle, uint64_
 // cal_lt_diff (gkr_iop/src/gadgets/is_lt.rs:277-287): lhs - rhs, plus 2^max_bits when lhs < rhs
 __device__ __forceinline__ uint64_t lt_diff(uint64_t lhs, uint64_t rhs) { return (lhs < rhs ? (1ull << MAX_TS_BITS) : 0ull) + lhs - rhs; }
 
-// counter += 1 per lane; lanes of a wave that hit the slot of the first active lane are merged into one atomic
-// (timestamp-difference limbs are nearly constant across a chip, so most of a wave lands on one slot).
+// counter += 1 per lane, merged per wave (lk_count below).
 // XCD_LOCAL: `table` is this XCD's private copy, so the add only has to be atomic inside the XCD's L2 (workgroup-scope
 // read-modify-write, no sc1: it never leaves the L2); a device-scope atomic is executed on the fabric side of the L2 at
 // ~15 G/s chip-wide, which is what bounds this kernel (5 distinct-slot counts per instance).
@@ -48,16 +47,32 @@ __device__ __forceinline__ void lk_add(uint32_t* p, uint32_t v) {
     if (XCD_LOCAL) (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAdd(p, v);
 }
+// One atomic per DISTINCT slot of the wave.  First the common case: every active lane on the slot of the first one (timestamp-difference high
+// limbs are constant across a chip) — one ballot, one atomic.  Otherwise each lane finds the lanes that hold its own slot, bit by bit (a ballot per
+// bit in which the wave's slots differ at all: __match_any over wave64), and the lowest lane of every group adds the group's size.  Few-valued keys
+// (a 3-bit range check, the carries of a shift by few bits, the zero of a special case) put a whole chip on a handful of L2 lines: with only the
+// first lane's group merged, SRA's counts cost 1.74 ms per 2^20 instances (0.11 ms for its witness columns), DIV's 1.9 ms; now 0.80 and 0.58 ms,
+// ADD's spread keys unchanged at 0.20 ms.  (A workgroup-level LDS cache of hot slots in front of the table was measured too: the extra LDS atomics
+// of the spread keys cost more than the hot lines save — ADD 0.29 ms, SRA 0.90 ms — and was dropped.)
 template <bool XCD_LOCAL>
 __device__ __forceinline__ void lk_count(uint32_t* table, uint32_t slot) {
     if (!table) return;
+    const uint64_t active = __ballot(1);
     const uint32_t first = __builtin_amdgcn_readfirstlane(slot);
     const uint64_t same = __ballot(slot == first);
-    if (slot == first) {
-        if ((int)__lane_id() == __ffsll((long long)same) - 1) lk_add<XCD_LOCAL>(table + slot, (uint32_t)__popcll(same));
-    } else {
-        lk_add<XCD_LOCAL>(table + slot, 1u);
+    if (same == active) {  // wave-uniform
+        if ((int)__lane_id() == __ffsll((long long)active) - 1) lk_add<XCD_LOCAL>(table + slot, (uint32_t)__popcll(active));
+        return;
     }
+    uint64_t peers = active;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        const bool bit = (slot >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        if (m == 0 || m == active) continue;  // wave-uniform bit: nothing to separate
+        peers &= bit ? m : ~m;
+    }
+    if ((int)__lane_id() == __ffsll((long long)peers) - 1) lk_add<XCD_LOCAL>(table + slot, (uint32_t)__popcll(peers));
 }
 // dst[i] += sum over the 8 per-XCD copies (device-scope atomics: other chips of the shard may be adding to dst concurrently)
 // (`used` <= `slots`: the chip only counts into the first `used` entries of each copy)

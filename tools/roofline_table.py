@@ -119,4 +119,25 @@ acols = list(range(18)) + [18]
 row("witgen_addi 2^20 instances (18 columns + lookup counts)",
     timed(lambda: api.witgen_addi(dev, acols, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w.data_ptr(), n_w, 0, 0x2000, 4096,
                                   d_lkd.data_ptr(), d_lkf.data_ptr())), (136 + 4 + 8 * 18) * n_w)
+# the widest and the most arithmetic of the later chips on the same records (R-type records serve them: rs1, rs2, rd are all present)
+d_w47 = torch.empty(47 * n_w, dtype=torch.int64, device="cuda:0")
+d_lkx = torch.zeros(1 << 16, dtype=torch.int32, device="cuda:0")
+scols = list(range(47)) + [47]
+row("witgen_shift_r (SRA) 2^20 instances (47 columns + lookup counts: 11 range, fetch, 2 double-byte, 1 xor)",
+    timed(lambda: api.witgen_shift(dev, scols, False, 2, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w47.data_ptr(), n_w, 0, 0x2000, 4096,
+                                   d_lkd.data_ptr(), d_lkf.data_ptr(), d_lkl.data_ptr(), d_lkx.data_ptr())), (136 + 4 + 8 * 47) * n_w)
+row("witgen_shift_r 2^20 instances, witness only",
+    timed(lambda: api.witgen_shift(dev, scols, False, 2, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w47.data_ptr(), n_w, 0, 0x2000, 4096)),
+    (136 + 4 + 8 * 47) * n_w)
+mcols = list(range(26)) + [26]
+row("witgen_mul (MULH) 2^20 instances (26 columns + lookup counts: 16 range of which 4 are 18-bit, fetch)",
+    timed(lambda: api.witgen_mul(dev, mcols, 1, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w47.data_ptr(), n_w, 0, 0x2000, 4096,
+                                 d_lkd.data_ptr(), d_lkf.data_ptr())), (136 + 4 + 8 * 26) * n_w)
+dcols = list(range(39)) + [39]
+row("witgen_div (DIV) 2^20 instances (39 columns, four field inversions per row + lookup counts: 17 range, fetch)",
+    timed(lambda: api.witgen_div(dev, dcols, 0, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w47.data_ptr(), n_w, 0, 0x2000, 4096,
+                                 d_lkd.data_ptr(), d_lkf.data_ptr())), (136 + 4 + 8 * 39) * n_w)
+row("witgen_div 2^20 instances, witness only",
+    timed(lambda: api.witgen_div(dev, dcols, 0, d_rec.data_ptr(), n_w, d_idx.data_ptr(), n_w, d_w47.data_ptr(), n_w, 0, 0x2000, 4096)),
+    (136 + 4 + 8 * 39) * n_w)
 print(json.dumps(out, indent=1))
