@@ -1881,7 +1881,9 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     // (CENO_HIP_DENSE_LADDER=0 keeps one k_dense launch per round: A/B measurements).
     static const size_t dense_small_pairs = [] {
         const char* e = getenv("CENO_HIP_DENSE_LADDER");
-        return (e && atoi(e) == 0) ? (size_t)0 : (size_t)1 << 15;
+        if (e && atoi(e) == 0) return (size_t)0;
+        const char* l = getenv("CENO_HIP_DENSE_LADDER_LOG");  // hand-over point (A/B measurements)
+        return (size_t)1 << (l ? std::max(10, std::min(atoi(l), 20)) : 15);
     }();
     {
         // slot tables of every round are deterministic: stage them all, one upload
