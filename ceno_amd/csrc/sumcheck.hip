@@ -1774,8 +1774,10 @@ static Epilogue pipe_epilogue(ceno_hip_sumcheck* sc, ScClass& cl, int i) {
 // got around to reading its message (measured: 20 us per tiny round instead of 12, 800 us for a 160 us round 0).
 // Rounds at the end of a pipelined sumcheck that the HOST computes.  A device round of the persistent tail costs ~9.6 us whatever
 // its size (publish, PCIe, challenger, poll); a host round costs its arithmetic: pairs x sum_T |T| x d extension multiplications of
-// ~7 ns (measured: 0.31 us per pair for a tower layer's 5 terms of degree 3, 2.5 us per pair for a chip's 33 constraint terms of
-// degree 4).  The host takes over at the first round it computes faster than the device would: 32 pairs for a tower layer, 4 for
+// ~7 ns with every factor of every term multiplied out (measured: 0.31 us per pair for a tower layer's 5 terms of degree 3, 2.5 us per pair for a
+// chip's 33 constraint terms; sc_host_round now walks the plan group by group as the device does — 1.85 us per pair for that chip — and the
+// model below, still counting the old way, hands over a fraction of a round late: a sweep of the budget from 10.5 to 24 us moved nothing).
+// The host takes over at the first round it computes faster than the device would: 32 pairs for a tower layer, 4 for
 // the chip's main sumcheck, 128 for a plain product of three tables.  CENO_HIP_HOST_TAIL caps the number of host rounds (0 = the
 // device runs every round), CENO_HIP_HOST_TAIL_NS is the per-round budget.
 static int host_tail_rounds(const ceno_hip_sumcheck* sc) {
@@ -1826,21 +1828,73 @@ static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out, bool fold
     const int d = sc->d, pairs = sc->host_len / 2;
     E2 acc[MAXD];
     for (int t = 0; t < d; t++) acc[t] = e2_zero();
-    for (int ti : cl.terms) {
-        const ScTerm& T = sc->terms[ti];
+    const E2* tab = sc->host_tab.data();
+    const size_t len0 = (size_t)sc->host_len0;
+    if (cl.h_gto.size() >= 2) {
+        // the class plan as the device kernels walk it: per group  prod(common factors) * sum_terms c_T prod(residual factors); the coefficient
+        // rides on a term's first factor (c f(X) = c f(1) + (X - 1) c delta: two multiplications instead of d), the common factors multiply the
+        // group's sum once — 28 multiplications per pair of a tower layer instead of the 45 of coefficient x every factor of every term
+        const int n_groups = (int)cl.h_gto.size() - 1;
         for (int p = 0; p < pairs; p++) {
-            E2 pr[MAXD];
-            for (int t = 0; t < d; t++) pr[t] = T.coeff;
-            for (int j : T.full) {
-                const E2* q = sc->host_tab.data() + (size_t)sc->mles[j].local * sc->host_len0 + 2 * p;
-                E2 x = q[1];
-                const E2 delta = q[1] - q[0];
-                for (int t = 0; t < d; t++) {
-                    pr[t] = pr[t] * x;
-                    x = x + delta;
+            for (int g = 0; g < n_groups; g++) {
+                E2 inner[MAXD];
+                for (int t = 0; t < d; t++) inner[t] = e2_zero();
+                for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
+                    const uint32_t term = cl.h_gt[ti];
+                    const E2 c = cl.h_coeffs[term];
+                    const uint32_t k0 = cl.h_to[term], k1 = cl.h_to[term + 1];
+                    E2 pr[MAXD];
+                    if (k0 == k1) {
+                        for (int t = 0; t < d; t++) pr[t] = c;
+                    } else {
+                        const E2* q = tab + (size_t)cl.h_ti[k0] * len0 + 2 * p;
+                        E2 x = c * q[1];
+                        const E2 delta = c * (q[1] - q[0]);
+                        for (int t = 0; t < d; t++) {
+                            pr[t] = x;
+                            x = x + delta;
+                        }
+                        for (uint32_t k = k0 + 1; k < k1; k++) {
+                            const E2* f = tab + (size_t)cl.h_ti[k] * len0 + 2 * p;
+                            E2 y = f[1];
+                            const E2 dy = f[1] - f[0];
+                            for (int t = 0; t < d; t++) {
+                                pr[t] = pr[t] * y;
+                                y = y + dy;
+                            }
+                        }
+                    }
+                    for (int t = 0; t < d; t++) inner[t] = inner[t] + pr[t];
                 }
+                for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++) {
+                    const E2* f = tab + (size_t)cl.h_ci[k] * len0 + 2 * p;
+                    E2 y = f[1];
+                    const E2 dy = f[1] - f[0];
+                    for (int t = 0; t < d; t++) {
+                        inner[t] = inner[t] * y;
+                        y = y + dy;
+                    }
+                }
+                for (int t = 0; t < d; t++) acc[t] = acc[t] + inner[t];
             }
-            for (int t = 0; t < d; t++) acc[t] = acc[t] + pr[t];
+        }
+    } else {
+        for (int ti : cl.terms) {
+            const ScTerm& T = sc->terms[ti];
+            for (int p = 0; p < pairs; p++) {
+                E2 pr[MAXD];
+                for (int t = 0; t < d; t++) pr[t] = T.coeff;
+                for (int j : T.full) {
+                    const E2* q = tab + (size_t)sc->mles[j].local * len0 + 2 * p;
+                    E2 x = q[1];
+                    const E2 delta = q[1] - q[0];
+                    for (int t = 0; t < d; t++) {
+                        pr[t] = pr[t] * x;
+                        x = x + delta;
+                    }
+                }
+                for (int t = 0; t < d; t++) acc[t] = acc[t] + pr[t];
+            }
         }
     }
     for (int t = 0; t < d; t++) {
