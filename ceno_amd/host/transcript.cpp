@@ -248,6 +248,11 @@ extern "C" void ceno_prover_test_poseidon2_permute(uint64_t* state8) {
     p2::permute(state8, host_params(false));
 }
 extern "C" void ceno_prover_test_poseidon2_permute_fast(uint64_t* state8) { p2host::permute(state8, host_params(false)); }
+// n independent states through p2host::permute_many (eight at a time on AVX-512 CPUs): returns 1 when the vector path exists on this CPU
+extern "C" int ceno_prover_test_poseidon2_permute_many(uint64_t* states, size_t n) {
+    p2host::permute_many(states, n, host_params(false));
+    return p2host::have_avx512() ? 1 : 0;
+}
 // n chained permutations (timing of the host challenger's critical path without binding overhead)
 extern "C" void ceno_prover_test_poseidon2_chain(uint64_t* state8, int n, int fast) {
     const p2::Params& p = host_params(false);

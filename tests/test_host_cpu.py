@@ -162,6 +162,19 @@ def test_poseidon2_host_source_matches_oracle_and_transcript_is_deterministic(bu
         fast = st.copy()  # the host-only 128-bit form the transcript runs on (host/transcript.cpp p2host)
         L.ceno_prover_test_poseidon2_permute_fast(po._p(fast))
         assert np.array_equal(fast, exp)
+    # eight permutations at once (AVX-512, the host-finished tree tops): every lane position, odd counts, the same edge states in every lane
+    L.ceno_prover_test_poseidon2_permute_many.restype = C.c_int
+    L.ceno_prover_test_poseidon2_permute_many.argtypes = [po.u64p, C.c_size_t]
+    for n in (1, 7, 8, 9, 16, 29, 64):
+        states = np.array([[rng.randrange(1 << 64) if (k + j) % 5 == 0 else rng.randrange(P) for j in range(8)] for k in range(n)], dtype=np.uint64)
+        states[:min(n, len(edge))] = np.array(edge[:min(n, len(edge))], dtype=np.uint64)
+        states %= np.uint64(P)     # inputs are canonical in the product (digests); the non-canonical draws above become other values
+        exp = np.stack([po.poseidon2_permute(states[k].copy()) for k in range(n)])
+        got = states.copy()
+        vec = L.ceno_prover_test_poseidon2_permute_many(po._p(got), n)
+        assert np.array_equal(got, exp), n
+    if "avx512f" in open("/proc/cpuinfo").read():
+        assert vec == 1
     # duplex challenger: same script -> same challenges; one changed element -> different challenges
     def run(x):
         t = prover.Transcript.poseidon2(b"riscv")
