@@ -2,6 +2,9 @@
 // a Merkle tree (poseidon2.hip merkle_finish_host).  Same permutation as p2::permute (csrc/poseidon2.hpp), different arithmetic.
 #pragma once
 #include "poseidon2.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdlib>
 
 // The challenger sits on the critical path of every sumcheck round (two permutations between a message and its challenge) and a
@@ -73,7 +76,6 @@ static inline void permute(uint64_t* s, const p2::Params& p) {
 // an EPYC 9575F), the vector code runs eight in the time of roughly one and a half.  Same arithmetic: residues in [0, 2^64), one reduction
 // per product, canonical at the end — bit-identical to permute() (tests/test_host_cpu.py).  Used only where the CPU has AVX-512F/DQ.
 #if defined(__x86_64__)
-#include <immintrin.h>
 #define P2_AVX512 __attribute__((target("avx512f,avx512dq"), always_inline)) static inline
 static inline bool have_avx512() {
     static const bool v = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") &&

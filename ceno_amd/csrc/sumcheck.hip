@@ -21,6 +21,7 @@
 #include "sumcheck_dev.hpp"
 #include "sumcheck_gen.hpp"
 #include "sumcheck_tower.hpp"
+#include "e2_host_avx512.hpp"
 #include "sumcheck_small.hpp"
 
 #include <algorithm>
@@ -1796,12 +1797,24 @@ static int host_tail_rounds(const ceno_hip_sumcheck* sc) {
 // One host round of a host-finished tail: fold the tables with the challenge of round i - 1, then the message of round i,
 // p(1) .. p(d) of sum_pairs sum_terms c_T prod_{j in T} f_j(X).  Field arithmetic is exact, so the order of the sums is free and the
 // words equal what the device's kernels would have published.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// eight pairs per pass (AVX-512): entries [first, first + 8) of the folded table from the sixteen entries they come from
+__attribute__((target("avx512f,avx512dq"))) static void host_fold8(E2* t, int first, E2 r) {
+    const e2v::VE2 lo = e2v::load(t, 2 * (size_t)first, 2), hi = e2v::load(t, 2 * (size_t)first + 1, 2);
+    e2v::store(t, (size_t)first, e2v::add(lo, e2v::mul(e2v::bcast(r), e2v::sub(hi, lo))));
+}
+#endif
 static void host_fold(ceno_hip_sumcheck* sc, E2 r) {
     const size_t k = sc->classes[0].mles.size();
     const int half = sc->host_len / 2;
     for (size_t m = 0; m < k; m++) {
         E2* t = sc->host_tab.data() + m * (size_t)sc->host_len0;
-        for (int j = 0; j < half; j++) {
+        int j0 = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        if (p2host::have_avx512())
+            for (; j0 + 8 <= half; j0 += 8) host_fold8(t, j0, r);  // in place: pass j0 reads entries [2 j0, 2 j0 + 16), all at or beyond what it writes
+#endif
+        for (int j = j0; j < half; j++) {
             const E2 lo = t[2 * j], hi = t[2 * j + 1];
             t[j] = lo + r * (hi - lo);
         }
@@ -1817,6 +1830,60 @@ static int host_take_over(ceno_hip_sumcheck* sc) {
     sc->host_len = sc->host_len0;
     return 0;
 }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// pairs [p, p + 8) of the grouped plan walk of sc_host_round, one pair per lane: adds the eight pairs' contribution to acc[0 .. d)
+__attribute__((target("avx512f,avx512dq"))) static void host_eval8(const ScClass& cl, const E2* tab, size_t len0, int d, int p, E2* acc) {
+    using namespace e2v;
+    const int n_groups = (int)cl.h_gto.size() - 1;
+    VE2 tot[MAXD];
+    for (int t = 0; t < d; t++) tot[t] = bcast(e2_zero());
+    for (int g = 0; g < n_groups; g++) {
+        VE2 inner[MAXD];
+        for (int t = 0; t < d; t++) inner[t] = bcast(e2_zero());
+        for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
+            const uint32_t term = cl.h_gt[ti];
+            const VE2 c = bcast(cl.h_coeffs[term]);
+            const uint32_t k0 = cl.h_to[term], k1 = cl.h_to[term + 1];
+            VE2 pr[MAXD];
+            if (k0 == k1) {
+                for (int t = 0; t < d; t++) pr[t] = c;
+            } else {
+                const E2* q = tab + (size_t)cl.h_ti[k0] * len0;
+                const VE2 lo = load(q, 2 * (size_t)p, 2), hi = load(q, 2 * (size_t)p + 1, 2);
+                VE2 x = mul(c, hi);
+                const VE2 delta = mul(c, sub(hi, lo));
+                for (int t = 0; t < d; t++) {
+                    pr[t] = x;
+                    x = add(x, delta);
+                }
+                for (uint32_t k = k0 + 1; k < k1; k++) {
+                    const E2* f = tab + (size_t)cl.h_ti[k] * len0;
+                    const VE2 flo = load(f, 2 * (size_t)p, 2), fhi = load(f, 2 * (size_t)p + 1, 2);
+                    VE2 y = fhi;
+                    const VE2 dy = sub(fhi, flo);
+                    for (int t = 0; t < d; t++) {
+                        pr[t] = mul(pr[t], y);
+                        y = add(y, dy);
+                    }
+                }
+            }
+            for (int t = 0; t < d; t++) inner[t] = add(inner[t], pr[t]);
+        }
+        for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++) {
+            const E2* f = tab + (size_t)cl.h_ci[k] * len0;
+            const VE2 flo = load(f, 2 * (size_t)p, 2), fhi = load(f, 2 * (size_t)p + 1, 2);
+            VE2 y = fhi;
+            const VE2 dy = sub(fhi, flo);
+            for (int t = 0; t < d; t++) {
+                inner[t] = mul(inner[t], y);
+                y = add(y, dy);
+            }
+        }
+        for (int t = 0; t < d; t++) tot[t] = add(tot[t], inner[t]);
+    }
+    for (int t = 0; t < d; t++) acc[t] = acc[t] + hsum(tot[t]);
+}
+#endif
 static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out, bool fold = true) {
     static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     timespec ta, tb, tc;
@@ -1835,7 +1902,12 @@ static int sc_host_round(ceno_hip_sumcheck* sc, E2 r, uint64_t* h_out, bool fold
         // rides on a term's first factor (c f(X) = c f(1) + (X - 1) c delta: two multiplications instead of d), the common factors multiply the
         // group's sum once — 28 multiplications per pair of a tower layer instead of the 45 of coefficient x every factor of every term
         const int n_groups = (int)cl.h_gto.size() - 1;
-        for (int p = 0; p < pairs; p++) {
+        int p0 = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        if (p2host::have_avx512())
+            for (; p0 + 8 <= pairs; p0 += 8) host_eval8(cl, tab, len0, d, p0, acc);  // eight pairs per pass; the rest below, one by one
+#endif
+        for (int p = p0; p < pairs; p++) {
             for (int g = 0; g < n_groups; g++) {
                 E2 inner[MAXD];
                 for (int t = 0; t < d; t++) inner[t] = e2_zero();
