@@ -179,7 +179,7 @@ def test_open_of_witness_and_fixed_commitments_at_chip_size_verifies(dev):
 def test_batch_columns_and_fold_commit_primitives(dev):
     """kernel-level parity: column batching with unreduced accumulators, and one fused fold+commit round"""
     import ctypes as C
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import _lib
 

@@ -20,13 +20,13 @@ def dev():
 
 
 def _to_dev(a):
-    import torch
+    from tests import hipbuf as torch
 
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
 def _run(dev, cols, sub, recs, idx, rows, offset, base_pc, slots, lk=True, poison=True):
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
 
@@ -82,7 +82,7 @@ def test_permuted_columns_subset_of_steps_and_shard_offset(dev):
 
 def test_chip_flow_size_properties(dev):
     """2^20 instances (BASELINE config #3 shape): the chip's constraints hold on the device output, lookup totals add up"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
 
@@ -133,7 +133,7 @@ def test_bad_arguments_fail_loudly(dev):
 
 
 def _run_logic(dev, cols, kind, recs, idx, rows, offset, base_pc, slots, lk=True):
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
 
@@ -209,7 +209,7 @@ def test_logic_bad_arguments_fail_loudly(dev):
 
 
 def _run_addi(dev, cols, recs, idx, rows, offset, base_pc, slots, lk=True):
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
 
@@ -265,7 +265,7 @@ def test_addi_permuted_columns_random_operands_and_shard_offset(dev):
 @pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (600, 1024)])
 def test_logic_i_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     """ANDI / ORI / XORI on the reference test's step data (chips/logic_i.rs:79-100) plus sign-extended negative immediates"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
 
@@ -297,7 +297,7 @@ def test_logic_i_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
 @pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (500, 512)])
 def test_lui_witness_and_lookups_match_cpu_assignment(dev, n, rows):
     """LUI on step data shaped like the reference's test (chips/lui.rs:79-97), immediates over the whole 20-bit range"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _lui_steps
@@ -325,7 +325,7 @@ def test_lui_witness_and_lookups_match_cpu_assignment(dev, n, rows):
 @pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (400, 512)])
 def test_jal_and_auipc_witness_and_lookups_match_cpu_assignment(dev, chip, n, rows):
     """JAL (13 columns) and AUIPC (21 columns): dynamic-range, fetch, double-byte and XOR table multiplicities"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _auipc_steps, _jal_steps
@@ -362,7 +362,7 @@ def test_jal_and_auipc_witness_and_lookups_match_cpu_assignment(dev, chip, n, ro
 def test_slt_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
     """SLT / SLTU on the reference test's step data (chips/slt.rs:94-118) plus sign / equality / limb-boundary edge cases; the negative top
     limbs are Goldilocks field elements p - (2^16 - limb)"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _slt_steps
@@ -390,7 +390,7 @@ def test_slt_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
 @pytest.mark.parametrize("signed", [True, False])
 @pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (600, 1024)])
 def test_slti_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _slti_steps
@@ -419,7 +419,7 @@ def test_slti_witness_and_lookups_match_cpu_assignment(dev, signed, n, rows):
 @pytest.mark.parametrize("n,rows", [(1024, 1024), (1, 2), (500, 512)])
 def test_branch_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
     """the six branches: comparison gadget (BLT / BGE / BLTU / BGEU) or field-inverse equality marker (BEQ / BNE); the branch offset as a field element"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _branch_steps
@@ -450,7 +450,7 @@ def test_branch_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows):
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (500, 512, 0), (300, 512, 2)])
 def test_lw_sw_witness_and_lookups_match_cpu_assignment(dev, is_store, n, rows, offset):
     """LW / SW: register reads / write, the memory access with its own timestamp comparison, the address limbs with their 14-bit range lookups"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _mem_records, _mem_steps
@@ -498,7 +498,7 @@ def test_lw_sw_bad_arguments_fail_loudly(dev):
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 0), (300, 512, 996)])
 def test_jalr_witness_and_lookups_match_cpu_assignment(dev, n, rows, offset):
     """JALR: the jump target as a MemAddr with both low bits witnessed, rd = pc + 4 with its high limb, a branching state (pc, next_pc)"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _jalr_steps
@@ -532,7 +532,7 @@ def test_jalr_witness_and_lookups_match_cpu_assignment(dev, n, rows, offset):
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
 def test_shift_witness_and_lookups_match_cpu_assignment(dev, kind, is_imm, n, rows, offset):
     """SLL / SRL / SRA and their immediate forms: byte limbs, the ShiftBase gadget's markers, multiplier, carries and sign, four lookup tables"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _shift_records, _shift_steps
@@ -580,7 +580,7 @@ def test_shift_and_jalr_bad_arguments_fail_loudly(dev):
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
 def test_sh_sb_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
     """SH / SB: SW's columns, the free address bits, and SB's byte columns of the addressed limb with their byte-range lookups"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _sub_store_records, _sub_store_steps
@@ -614,7 +614,7 @@ def test_sh_sb_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offs
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
 def test_load_sub_witness_and_lookups_match_cpu_assignment(dev, width, signed, n, rows, offset):
     """LH / LHU / LB / LBU: LW's columns, limb and byte selection, the sign bit with its range lookup; absent Option columns are marked, not written"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import CenoHipError, api
     from tests.test_oracle_witgen import _sub_load_records, _sub_load_steps
@@ -656,7 +656,7 @@ def test_load_sub_witness_and_lookups_match_cpu_assignment(dev, width, signed, n
 @pytest.mark.parametrize("n,rows,offset", [(1024, 1024, 0), (1, 2, 0), (300, 512, 996)])
 def test_mul_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
     """MUL / MULH / MULHU / MULHSU: the schoolbook product over 16-bit limbs, 18-bit carry lookups (the upper part of the 2^19-entry dynamic table)"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import CenoHipError, api
     from tests.test_oracle_witgen import _mul_cols, _mul_steps
@@ -695,7 +695,7 @@ def test_mul_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset
 def test_div_witness_and_lookups_match_cpu_assignment(dev, kind, n, rows, offset):
     """DIV / DIVU / REM / REMU: RISC-V's special cases, sign and zero flags with their field inverses, the 18-bit carries of divisor * quotient + remainder,
     the |remainder| < |divisor| comparison"""
-    import torch
+    from tests import hipbuf as torch
 
     from ceno_amd import api
     from tests.test_oracle_witgen import _div_records, _div_steps
