@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../csrc/gl64.hpp"
+#include "../csrc/e2_host_avx512.hpp"
 #include "transcript.hpp"
 
 using gl::E2;
@@ -218,6 +219,54 @@ int tower_host_layers() {
     return e ? atoi(e) : 8;
 }
 // one layer sumcheck on the host; tabs[0] = eq, then per active product spec (a, b), per active logup spec (p1, p2, q1, q2)
+#if defined(__x86_64__)
+// eight pairs [p, p + 8) of one round of host_tower_layer, one pair per AVX-512 lane (csrc/e2_host_avx512.hpp); adds to acc[0..3)
+__attribute__((target("avx512f,avx512dq"))) void host_tower_eval8(const std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active,
+                                                                   const std::vector<E2>& alpha_prod, const std::vector<E2>& alpha_num,
+                                                                   const std::vector<E2>& alpha_den, size_t p, E2* acc) {
+    using namespace e2v;
+#define hi_of(t) load(tabs[(t)].data(), 2 * p + 1, 2)
+#define lo_of(t) load(tabs[(t)].data(), 2 * p, 2)
+    VE2 inner[3] = {bcast(gl::e2_zero()), bcast(gl::e2_zero()), bcast(gl::e2_zero())};
+    size_t t = 1;
+    for (int i = 0; i < n_prod_active; i++, t += 2) {
+        const VE2 a1 = hi_of(t), da = sub(a1, lo_of(t)), b1 = hi_of(t + 1), db = sub(b1, lo_of(t + 1));
+        const VE2 al = bcast(alpha_prod[i]);
+        VE2 ca = mul(al, a1);
+        const VE2 cda = mul(al, da);
+        VE2 b = b1;
+        for (int e = 0; e < 3; e++) {
+            inner[e] = add(inner[e], mul(ca, b));
+            ca = add(ca, cda);
+            b = add(b, db);
+        }
+    }
+    for (int k = 0; k < n_logup_active; k++, t += 4) {
+        VE2 p1 = hi_of(t), p2 = hi_of(t + 1), q1 = hi_of(t + 2), q2 = hi_of(t + 3);
+        const VE2 dp1 = sub(p1, lo_of(t)), dp2 = sub(p2, lo_of(t + 1)), dq1 = sub(q1, lo_of(t + 2)), dq2 = sub(q2, lo_of(t + 3));
+        const VE2 an = bcast(alpha_num[k]), ad = bcast(alpha_den[k]);
+        for (int e = 0; e < 3; e++) {
+            inner[e] = add(inner[e], add(mul(an, add(mul(p1, q2), mul(p2, q1))), mul(ad, mul(q1, q2))));
+            p1 = add(p1, dp1);
+            p2 = add(p2, dp2);
+            q1 = add(q1, dq1);
+            q2 = add(q2, dq2);
+        }
+    }
+    VE2 ev = hi_of(0);
+    const VE2 de = sub(ev, lo_of(0));
+    for (int e = 0; e < 3; e++) {
+        acc[e] = acc[e] + hsum(mul(ev, inner[e]));
+        ev = add(ev, de);
+    }
+#undef hi_of
+#undef lo_of
+}
+__attribute__((target("avx512f,avx512dq"))) void host_tower_fold8(E2* t, size_t first, E2 r) {
+    const e2v::VE2 lo = e2v::load(t, 2 * first, 2), hi = e2v::load(t, 2 * first + 1, 2);
+    e2v::store(t, first, e2v::add(lo, e2v::mul(e2v::bcast(r), e2v::sub(hi, lo))));
+}
+#endif
 void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active, const std::vector<E2>& alpha_prod,
                       const std::vector<E2>& alpha_num, const std::vector<E2>& alpha_den, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal,
                       uint64_t* fin) {
@@ -227,7 +276,12 @@ void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_acti
     for (int round = 0; round < n; round++) {
         const size_t pairs = len / 2;
         E2 acc[3] = {gl::e2_zero(), gl::e2_zero(), gl::e2_zero()};
-        for (size_t p = 0; p < pairs; p++) {
+        size_t p0 = 0;
+#if defined(__x86_64__)
+        if (p2host::have_avx512())
+            for (; p0 + 8 <= pairs; p0 += 8) host_tower_eval8(tabs, n_prod_active, n_logup_active, alpha_prod, alpha_num, alpha_den, p0, acc);
+#endif
+        for (size_t p = p0; p < pairs; p++) {
             E2 inner[3] = {gl::e2_zero(), gl::e2_zero(), gl::e2_zero()};
             size_t t = 1;
             for (int i = 0; i < n_prod_active; i++, t += 2) {
@@ -270,8 +324,14 @@ void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_acti
         const E2 r = tr_sample(tr);
         chal[2 * round] = r.c0;
         chal[2 * round + 1] = r.c1;
-        for (auto& T : tabs)
-            for (size_t p = 0; p < pairs; p++) T[p] = T[2 * p] + r * (T[2 * p + 1] - T[2 * p]);
+        for (auto& T : tabs) {
+            size_t q0 = 0;
+#if defined(__x86_64__)
+            if (p2host::have_avx512())
+                for (; q0 + 8 <= pairs; q0 += 8) host_tower_fold8(T.data(), q0, r);  // in place: pass q0 reads [2 q0, 2 q0 + 16), at or beyond what it writes
+#endif
+            for (size_t p = q0; p < pairs; p++) T[p] = T[2 * p] + r * (T[2 * p + 1] - T[2 * p]);
+        }
         len = pairs;
     }
     for (size_t t = 0; t < tabs.size(); t++) {
