@@ -2258,6 +2258,9 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         sc->round++;
         return 0;
     }
+    static const bool phases = getenv("CENO_HIP_ROUND_PHASES") != nullptr;  // where a round of the launch-per-round path spends its time
+    timespec tp0, tp1, tp2, tp3;
+    if (phases) clock_gettime(CLOCK_MONOTONIC, &tp0);
     // ---- 1. classes that are (or just become) scalars: update tails / bind their last variable ----
     ScClass* became_scalar = nullptr;
     for (auto& cl : sc->classes) {
@@ -2289,6 +2292,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             M.cur_ext = 1;
         }
     }
+    if (phases) clock_gettime(CLOCK_MONOTONIC, &tp1);
     // ---- 2. front-loaded contributions: c_t * prod_j (eval_j * tail_j * t)   (scheme/verifier.rs:233-237) ----
     E2 scalars[MAXD];
     for (int x = 0; x < MAXD; x++) scalars[x] = e2_zero();
@@ -2333,6 +2337,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             }
         }
     }
+    if (phases) clock_gettime(CLOCK_MONOTONIC, &tp2);
     // ---- 3. live classes: dense classes launch their fused kernel, all classes with component tables share ONE k_gen
     // launch, the rest take the two-kernel path; the last launch that accumulates finishes the message ----
     std::vector<ScClass*> live;
@@ -2467,7 +2472,15 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             memcpy(h_out, scalars, (size_t)d * sizeof(E2));
         }
     } else if (h_out) {
+        if (phases) clock_gettime(CLOCK_MONOTONIC, &tp3);
         TRY(sc_take_message(sc, h_out));
+        if (phases) {
+            timespec tp4;
+            clock_gettime(CLOCK_MONOTONIC, &tp4);
+            auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) / 1e3; };
+            fprintf(stderr, "[ceno_hip] round %d of %d: retire %.1f us, scalars %.1f us, launch %.1f us, wait %.1f us\n", i, sc->n, us(tp0, tp1), us(tp1, tp2),
+                    us(tp2, tp3), us(tp3, tp4));
+        }
     }
     sc->round++;
     return 0;

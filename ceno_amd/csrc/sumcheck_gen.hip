@@ -59,7 +59,62 @@ __global__ void __launch_bounds__(NT) k_gen(const GenComp* __restrict__ comps, i
         const unsigned tp = 1u << C.tp_log, tpp = tp + GEN_PAD;
         const size_t p0 = (size_t)(tile - C.tile_begin) << C.tp_log;
         const bool staged = C.n_groups != 0;
-        // ---- phase 1: (MLE x pair) items, MLE uniform per wave ----
+        // ---- phase 1: (MLE x pair) items ----
+        auto item = [&](const uint64_t* s_in, uint64_t* s_out, bool in_ext, unsigned row, unsigned q) {
+            const size_t p = p0 + q;
+            if (p >= C.pairs) return;
+            if (BASE0 && !in_ext) {
+                // first round, base-field column: stays in the base field (f(1), f(0) - f(1))
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(s_in + 2 * p);
+                reinterpret_cast<ulonglong2*>(stage)[row + q] = ulonglong2{v.y, sub(v.x, v.y)};
+                return;
+            }
+            E2 lo, hi;
+            if (C.fold) {
+                if (in_ext) {
+                    const uint64_t* qq = s_in + 8 * p;
+                    const E2 a0 = ld_e2(qq), a1 = ld_e2(qq + 2), a2 = ld_e2(qq + 4), a3 = ld_e2(qq + 6);
+                    lo = e2_fma_pre(rp, a1 - a0, a0);
+                    hi = e2_fma_pre(rp, a3 - a2, a2);
+                } else {
+                    const uint64_t* qq = s_in + 4 * p;
+                    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(qq);
+                    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(qq + 2);
+                    const E2 t0 = e2_mul_base(r, sub(v0.y, v0.x)), t1 = e2_mul_base(r, sub(v1.y, v1.x));
+                    lo = E2{add(t0.c0, v0.x), t0.c1};
+                    hi = E2{add(t1.c0, v1.x), t1.c1};
+                }
+                st_e2(s_out + 4 * p, lo);
+                st_e2(s_out + 4 * p + 2, hi);
+            } else if (in_ext) {
+                lo = ld_e2(s_in + 4 * p);
+                hi = ld_e2(s_in + 4 * p + 2);
+            } else {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(s_in + 2 * p);
+                lo = E2{v.x, 0};
+                hi = E2{v.y, 0};
+            }
+            if (staged) {
+                stage[row + q] = hi;             // f(1)
+                stage[row + tpp + q] = lo - hi;  // f(0) - f(1): evaluation points step by subtraction (two instructions shorter)
+            }
+        };
+        const size_t left = C.pairs - p0 < (size_t)tp ? C.pairs - p0 : (size_t)tp;  // pairs of this tile
+        if (left <= 32) {
+            // A SMALL tile (the last rounds of a chip: a handful of pairs) leaves most lanes of a wave idle when every wave takes one MLE at a
+            // time, and the MLEs of a wave then queue behind each other's slot and table loads (~3 dependent round trips each: 44 us for a round
+            // of eight chips with <= 64 pairs).  Here a wave takes 64 / w MLEs at once, w = the tile's pair count rounded up to a power of two.
+            const unsigned w = left <= 1 ? 1u : 1u << (32 - __builtin_clz((unsigned)left - 1));
+            const unsigned sub = 64u / w, ml = lane / w, q = lane % w;
+            for (unsigned m0 = (unsigned)wave * sub; m0 < C.n_mles; m0 += (NT / 64) * sub) {
+                const unsigned m = m0 + ml;
+                if (m < C.n_mles && q < left) {
+                    const MleSlot sl = C.slots[m];
+                    item(sl.in, sl.out, sl.in_ext != 0, (unsigned)C.unit[m] * tpp, q);
+                }
+            }
+        } else {
+        // MLE uniform per wave
         for (unsigned m = (unsigned)wave; m < C.n_mles; m += NT / 64) {
             // MleSlot is 24 bytes: three 8-byte scalar loads
             const GEN_CONST gen_u2* sp = reinterpret_cast<const GEN_CONST gen_u2*>(reinterpret_cast<uintptr_t>(C.slots + m));
@@ -69,44 +124,10 @@ __global__ void __launch_bounds__(NT) k_gen(const GenComp* __restrict__ comps, i
             const bool in_ext = sw2.x != 0;
             const unsigned row = ldc_u16(C.unit + m) * tpp;
             for (unsigned q = lane; q < tp; q += 64) {
-                const size_t p = p0 + q;
-                if (p >= C.pairs) break;
-                if (BASE0 && !in_ext) {
-                    // first round, base-field column: stays in the base field (f(1), f(0) - f(1))
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(s_in + 2 * p);
-                    reinterpret_cast<ulonglong2*>(stage)[row + q] = ulonglong2{v.y, sub(v.x, v.y)};
-                    continue;
-                }
-                E2 lo, hi;
-                if (C.fold) {
-                    if (in_ext) {
-                        const uint64_t* qq = s_in + 8 * p;
-                        const E2 a0 = ld_e2(qq), a1 = ld_e2(qq + 2), a2 = ld_e2(qq + 4), a3 = ld_e2(qq + 6);
-                        lo = e2_fma_pre(rp, a1 - a0, a0);
-                        hi = e2_fma_pre(rp, a3 - a2, a2);
-                    } else {
-                        const uint64_t* qq = s_in + 4 * p;
-                        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(qq);
-                        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(qq + 2);
-                        const E2 t0 = e2_mul_base(r, sub(v0.y, v0.x)), t1 = e2_mul_base(r, sub(v1.y, v1.x));
-                        lo = E2{add(t0.c0, v0.x), t0.c1};
-                        hi = E2{add(t1.c0, v1.x), t1.c1};
-                    }
-                    st_e2(s_out + 4 * p, lo);
-                    st_e2(s_out + 4 * p + 2, hi);
-                } else if (in_ext) {
-                    lo = ld_e2(s_in + 4 * p);
-                    hi = ld_e2(s_in + 4 * p + 2);
-                } else {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(s_in + 2 * p);
-                    lo = E2{v.x, 0};
-                    hi = E2{v.y, 0};
-                }
-                if (staged) {
-                    stage[row + q] = hi;             // f(1)
-                    stage[row + tpp + q] = lo - hi;  // f(0) - f(1): evaluation points step by subtraction (two instructions shorter)
-                }
+                if (p0 + q >= C.pairs) break;
+                item(s_in, s_out, in_ext, row, q);
             }
+        }
         }
         if (!staged) continue;  // fold-only component (tables that no term reads in this class)
         __syncthreads();
