@@ -605,6 +605,30 @@ int ceno_prover_prove_rotation(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, cons
     return 0;
 }
 
+// ---- the eight-lane host arithmetic (csrc/e2_host_avx512.hpp) against the scalar operators: a, b = eight extension elements each (c0, c1
+// interleaved); out = a + b | a - b | a * b | fold(a as four pairs... ) — returns 0 when the CPU has no AVX-512 ----
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512dq"))) static void test_e2v_ops(const E2* a, const E2* b, E2* out) {
+    using namespace e2v;
+    const VE2 va = load(a, 0, 1), vb = load(b, 0, 1);
+    store(out, 0, add(va, vb));
+    store(out, 8, sub(va, vb));
+    store(out, 16, mul(va, vb));
+    out[24] = hsum(va);
+}
+#endif
+extern "C" int ceno_prover_test_e2v(const uint64_t* a16, const uint64_t* b16, uint64_t* out50, uint64_t* fold_io32, const uint64_t* r2) {
+#if defined(__x86_64__)
+    if (!p2host::have_avx512()) return 0;
+    test_e2v_ops(reinterpret_cast<const E2*>(a16), reinterpret_cast<const E2*>(b16), reinterpret_cast<E2*>(out50));
+    host_tower_fold8(reinterpret_cast<E2*>(fold_io32), 0, E2{r2[0], r2[1]});  // sixteen entries in, the eight folded ones in front
+    return 1;
+#else
+    (void)a16; (void)b16; (void)out50; (void)fold_io32; (void)r2;
+    return 0;
+#endif
+}
+
 // ---- host-side field arithmetic exposed for CPU tests of the shared gl64.hpp code ----
 uint64_t ceno_prover_test_gl_mul(uint64_t a, uint64_t b) { return gl::mul(a, b); }
 uint64_t ceno_prover_test_gl_add(uint64_t a, uint64_t b) { return gl::add(a, b); }

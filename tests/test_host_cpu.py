@@ -218,3 +218,40 @@ def test_entry_points_resolve_their_stream_before_they_allocate():
             if allocs and (st < 0 or min(allocs) < st):
                 offenders.append((os.path.basename(f), m.group(1)))
     assert offenders == [], offenders
+
+
+def test_eight_lane_host_arithmetic_matches_the_scalar_operators(built):
+    """csrc/e2_host_avx512.hpp (the host-finished sumcheck tails and tower layers): add / sub / mul / lane sum / fold on eight lanes equal the oracle's
+    extension arithmetic word for word, on canonical inputs including the carry-heavy ones"""
+    _, prover = built
+    import ctypes as C
+
+    L = prover.plib()
+    L.ceno_prover_test_e2v.restype = C.c_int
+    L.ceno_prover_test_e2v.argtypes = [po.u64p] * 5
+    rng = random.Random(11)
+    edge = [P - 1, 0, 1, P - 2, 0xFFFFFFFF, 0xFFFFFFFF00000000, 1 << 63, (1 << 32) + 1]
+    ran = 0
+    for it in range(40):
+        pick = (lambda: rng.choice(edge)) if it < 12 else (lambda: rng.randrange(P))
+        a = np.array([[pick(), pick()] for _ in range(8)], dtype=np.uint64)
+        b = np.array([[pick(), pick()] for _ in range(8)], dtype=np.uint64)
+        tab = np.array([[pick(), pick()] for _ in range(16)], dtype=np.uint64)
+        r = np.array([pick(), pick()], dtype=np.uint64)
+        out = np.zeros((25, 2), dtype=np.uint64)
+        io = tab.copy()
+        if not L.ceno_prover_test_e2v(po._p(a), po._p(b), po._p(out), po._p(io), po._p(r)):
+            pytest.skip("no AVX-512 on this CPU")
+        ran += 1
+        t = lambda x: (int(x[0]), int(x[1]))
+        for k in range(8):
+            assert t(out[k]) == po.e2_add(t(a[k]), t(b[k]))
+            assert t(out[8 + k]) == po.e2_sub(t(a[k]), t(b[k]))
+            assert t(out[16 + k]) == po.e2_mul(t(a[k]), t(b[k]))
+            lo, hi = t(tab[2 * k]), t(tab[2 * k + 1])
+            assert t(io[k]) == po.e2_add(lo, po.e2_mul(t(r), po.e2_sub(hi, lo)))
+        s = (0, 0)
+        for k in range(8):
+            s = po.e2_add(s, t(a[k]))
+        assert t(out[24]) == s
+    assert ran == 40
