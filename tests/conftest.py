@@ -109,3 +109,36 @@ def orc():
 
     pyoracle.build()
     return pyoracle
+
+
+# ---- where a GPU run spends its wall time (a cold box has taken 400-1000 s for a suite that runs in 30 s on a warm one): the five slowest
+# phases and the time before the first test go to the terminal summary and, when the directory exists, to gpurun_out/pytest_gpu_timing.txt ----
+import time as _time
+
+_T0 = _time.time()
+_PHASES = []
+_FIRST_TEST = [None]
+
+
+def pytest_runtest_logreport(report):
+    if _FIRST_TEST[0] is None and report.when == "setup":
+        _FIRST_TEST[0] = _time.time() - _T0
+    if report.duration >= 1.0:
+        _PHASES.append((report.duration, f"{report.nodeid} [{report.when}]"))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    markexpr = getattr(config.option, "markexpr", "") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr:
+        return
+    lines = [f"wall {_time.time() - _T0:.1f} s, first test after {(_FIRST_TEST[0] or 0):.1f} s; phases of 1 s and more:"]
+    lines += [f"  {d:8.1f} s  {name}" for d, name in sorted(_PHASES, reverse=True)[:8]]
+    for ln in lines:
+        terminalreporter.write_line(ln)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        try:
+            with open(os.path.join(out_dir, "pytest_gpu_timing.txt"), "a") as f:
+                f.write("\n".join(lines) + "\n")
+        except OSError:
+            pass
