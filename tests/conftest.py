@@ -38,7 +38,7 @@ if ROOT not in sys.path:
 def _prefetch_torch_libs():
     """On a box whose image is cold the first `import torch` of a GPU run has taken 6-10 minutes here (5.3 GB of shared objects paged in by
     random 4 KB faults; the test bodies themselves take ~15 s).  The first GPU tests do not need torch: meanwhile a background thread reads
-    torch's large libraries front to back, so that the import finds them in the page cache.  Harmless when they are cached already."""
+    torch's core libraries front to back, so that the import finds them in the page cache.  Harmless when they are cached already."""
     import importlib.util
     import threading
 
@@ -49,12 +49,11 @@ def _prefetch_torch_libs():
 
     def work():
         try:
-            files = sorted((f for f in os.listdir(lib) if f.endswith(".so")), key=lambda f: -os.path.getsize(os.path.join(lib, f)))
-            # what `import torch` maps first goes first; the multi-GB solver libraries it merely links against come after
-            first = [f for f in ("libtorch_cpu.so", "libtorch_hip.so", "libtorch_python.so", "libc10.so", "libc10_hip.so", "libamdhip64.so") if f in files]
-            for f in first + [f for f in files if f not in first]:
+            # only what `import torch` really walks through (~1 GB): the multi-GB solver libraries it merely links against (libmagma, MIOpen,
+            # rocsolver, ...) are mapped, hardly read — reading all 5.3 GB on a slow image would compete with the tests for the same storage
+            for f in ("libtorch_cpu.so", "libtorch_hip.so", "libtorch_python.so", "libc10.so", "libc10_hip.so", "libamdhip64.so", "librocblas.so"):
                 path = os.path.join(lib, f)
-                if os.path.getsize(path) < (8 << 20):
+                if not os.path.exists(path):
                     continue
                 fd = os.open(path, os.O_RDONLY)
                 try:
