@@ -174,9 +174,13 @@ def main():
                     help="Fiat-Shamir transcript of the timed steps (the other one is timed too and reported beside it)")
     args = ap.parse_args()
 
-    import torch
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # torch is the multi-rank plumbing (torch.distributed over RCCL, its device tensors for the flags): one rank needs none of it, and on a
+    # box whose image is cold the import alone has cost minutes (tests/conftest.py).  CENO_BENCH_IMPORT_TORCH=1 imports it anyway.
+    torch = None
+    if world > 1 or os.environ.get("CENO_BENCH_IMPORT_TORCH") == "1":
+        import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
@@ -196,7 +200,7 @@ def main():
             torch.cuda.set_device(local_rank)
             dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
         dist = dist_mod
-    else:
+    elif torch is not None:
         torch.cuda.set_device(local_rank)
     # everything imported so far (torch: ~10^6 objects) moves to the collector's permanent generation: a collection that falls into an
     # extra's timing loop or a worker thread later only walks what the benchmark itself allocated
@@ -213,10 +217,30 @@ def main():
     log_w = world.bit_length() - 1
     tdev = (f"cuda:{local_rank}" if dist is not None and dist.get_backend() == "nccl" else "cpu")
 
+    if torch is not None:
+        device_synchronize = torch.cuda.synchronize
+    else:  # the same call underneath: hipDeviceSynchronize on the current device (Device(local_rank) selected it)
+        import ctypes
+
+        _hip = None
+        for _name in ("/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"):
+            try:
+                _hip = ctypes.CDLL(_name)
+                break
+            except OSError:
+                continue
+        if _hip is None:
+            raise RuntimeError("bench.py: libamdhip64.so not found")
+
+        def device_synchronize():
+            rc = _hip.hipDeviceSynchronize()
+            if rc != 0:
+                raise RuntimeError(f"hipDeviceSynchronize failed: {rc}")
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_synchronize()  # torch.cuda.synchronize() with ranks; hipDeviceSynchronize directly with one
         dev.sync()
 
     def max_over_ranks(x):
