@@ -154,6 +154,29 @@ inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
     return (unsigned)g;
 }
 
+// Largest grid (<= max_blocks) of a grid-stride kernel at which EVERY workgroup is resident at once: occupancy (registers, LDS)
+// x compute units.  A kernel bound by VALU issue whose launch exceeds it runs a second, partly filled dispatch wave: k_gen at
+// 168 VGPRs holds 3 workgroups per CU = 768; launched as 1024 the last 256 run alone on their CUs at one wave per SIMD
+// (batched main sumcheck 12.9 -> 11.8 ms, tools/dev/ab_gen_maxb.sh).  Cached per (kernel, LDS size).
+template <typename F>
+inline unsigned resident_grid(ceno_hip_ctx* ctx, F kernel, int block, size_t dyn_lds, unsigned max_blocks) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, unsigned> cache;
+    const std::pair<const void*, size_t> key{reinterpret_cast<const void*>(kernel), dyn_lds >> 10};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return std::min(it->second, max_blocks);
+    }
+    int nb = 0;
+    unsigned g = max_blocks;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) == hipSuccess && nb > 0) g = (unsigned)nb * (unsigned)ctx->num_cus;
+    else (void)hipGetLastError();
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = g;
+    return std::min(g, max_blocks);
+}
+
 // ---- kernels exported across translation units ----
 // fold: out[j] = in[2j] + r (in[2j+1] - in[2j]) for j < half ; `in` base or ext, `out` ext
 int launch_fold(ceno_hip_ctx* ctx, const uint64_t* in, int in_is_ext, uint64_t* out, size_t half, E2 r, hipStream_t st);

@@ -999,26 +999,27 @@ static bool accum_ext() {
     }();
     return v;
 }
+// (grids stay within the workgroups that are resident at once — k_accum<4> holds 3 per CU at 150 VGPRs: resident_grid, common.hpp)
 template <int D>
-static void launch_accum_d(const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0) {
-    if (base0) hipLaunchKernelGGL((k_accum_base0<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
-    else if (accum_lazy()) hipLaunchKernelGGL((k_accum<D, true>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
-    else if (pl.use_out && accum_ext()) hipLaunchKernelGGL((k_accum_ext<D>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
-    else hipLaunchKernelGGL((k_accum<D, false>), dim3(grid), dim3(NT), 0, st, pl, pairs, ep);
+static void launch_accum_d(ceno_hip_ctx* ctx, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0) {
+    if (base0) hipLaunchKernelGGL((k_accum_base0<D>), dim3(resident_grid(ctx, k_accum_base0<D>, NT, 0, grid)), dim3(NT), 0, st, pl, pairs, ep);
+    else if (accum_lazy()) hipLaunchKernelGGL((k_accum<D, true>), dim3(resident_grid(ctx, k_accum<D, true>, NT, 0, grid)), dim3(NT), 0, st, pl, pairs, ep);
+    else if (pl.use_out && accum_ext()) hipLaunchKernelGGL((k_accum_ext<D>), dim3(resident_grid(ctx, k_accum_ext<D>, NT, 0, grid)), dim3(NT), 0, st, pl, pairs, ep);
+    else hipLaunchKernelGGL((k_accum<D, false>), dim3(resident_grid(ctx, k_accum<D, false>, NT, 0, grid)), dim3(NT), 0, st, pl, pairs, ep);
 }
 // base0: round 0 of a class whose every term is a product of base-field tables (k_accum_base0)
-static void launch_accum(int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0 = false) {
+static void launch_accum(ceno_hip_ctx* ctx, int d, const DevPlan& pl, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st, bool base0 = false) {
     static const bool no_base0 = getenv("CENO_HIP_NO_BASE0") != nullptr;  // A/B switch
     if (no_base0) base0 = false;
     switch (d) {
-    case 1: launch_accum_d<1>(pl, pairs, ep, grid, st, base0); break;
-    case 2: launch_accum_d<2>(pl, pairs, ep, grid, st, base0); break;
-    case 3: launch_accum_d<3>(pl, pairs, ep, grid, st, base0); break;
-    case 4: launch_accum_d<4>(pl, pairs, ep, grid, st, base0); break;
-    case 5: launch_accum_d<5>(pl, pairs, ep, grid, st, base0); break;
-    case 6: launch_accum_d<6>(pl, pairs, ep, grid, st, base0); break;
-    case 7: launch_accum_d<7>(pl, pairs, ep, grid, st, base0); break;
-    default: launch_accum_d<8>(pl, pairs, ep, grid, st, base0); break;
+    case 1: launch_accum_d<1>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 2: launch_accum_d<2>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 3: launch_accum_d<3>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 4: launch_accum_d<4>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 5: launch_accum_d<5>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 6: launch_accum_d<6>(ctx, pl, pairs, ep, grid, st, base0); break;
+    case 7: launch_accum_d<7>(ctx, pl, pairs, ep, grid, st, base0); break;
+    default: launch_accum_d<8>(ctx, pl, pairs, ep, grid, st, base0); break;
     }
 }
 
@@ -2057,7 +2058,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 continue;
             }
             if (sc->eqf.on && i < sc->eqf.fast_upto) {  // a tower layer's large rounds: one fused pass, one evaluation point fewer
-                launch_tower_round(sc->eqf.n_prod, sc->eqf.n_logup, i > 0 ? 2 : sc->eqf.has_claim ? 1 : 0, cl.d_slots + (size_t)i * k, sc->eqf.coef, pairs, ep, sc_grid(pairs), sc->st);
+                launch_tower_round(sc->ctx, sc->eqf.n_prod, sc->eqf.n_logup, i > 0 ? 2 : sc->eqf.has_claim ? 1 : 0, cl.d_slots + (size_t)i * k, sc->eqf.coef, pairs, ep, sc_grid(pairs), sc->st);
                 continue;
             }
             DevPlan pl;
@@ -2134,8 +2135,8 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
             }
             if (sc->gen_on && cl.gen && sc->gen_rounds[i].n_comps > 0 && pairs >= gen_pipe_min_pairs()) {
                 const GenRound& R = sc->gen_rounds[i];
-                launch_gen(sc->d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, e2_zero(), ep,
-                           std::min<unsigned>(R.total_tiles, MAXB), R.stage_bytes, sc->st);
+                launch_gen(sc->ctx, sc->d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, e2_zero(), ep,
+                           R.stage_bytes, sc->st);
             } else if (tile_eligible(k, pairs)) {
                 launch_tile(sc->d, pl, (int)k, cl.n_flat, pairs, e2_zero(), ep, sc->st);
             } else if (tnt) {
@@ -2144,7 +2145,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 if (i > 0)
                     hipLaunchKernelGGL(k_fold_batch, dim3(grid_for(2 * pairs, NT, 1024), (unsigned)k), dim3(NT), 0, sc->st, pl.slots, 2 * pairs,
                                        e2_zero(), (const Bcast*)sc->d_bcast, (unsigned long long)i);
-                launch_accum(sc->d, pl, pairs, ep, sc_grid(pairs), sc->st, i == 0 && cl.terms_all_base);
+                launch_accum(sc->ctx, sc->d, pl, pairs, ep, sc_grid(pairs), sc->st, i == 0 && cl.terms_all_base);
             }
         }
     }
@@ -2391,8 +2392,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             const GenRound& R = sc->gen_rounds[i];
             ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);  // the merged launch uses the first class's partial rows
             prof_begin(ctx, sc->st);
-            launch_gen(d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, r, ep,
-                       std::min<unsigned>(R.total_tiles, MAXB), R.stage_bytes, sc->st);
+            launch_gen(ctx, d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps), R.n_comps, R.total_tiles, r, ep, R.stage_bytes, sc->st);
             for (ScClass* cl : live) {
                 if (!(cl->gen && !cl->dense)) continue;
                 const size_t pairs = (size_t)1 << (cl->nv - i - 1);
@@ -2449,7 +2449,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
                 pl.term_idx = cl.d_term_idx;
                 if (tile) launch_tile(d, pl, (int)cl.mles.size(), cl.n_flat, pairs, r, ep, sc->st);
                 else if (tnt) launch_fused(d, tnt, pl, (int)cl.mles.size(), pairs, r, ep, grid_for(pairs, (unsigned)tnt, MAXB), sc->st);
-                else launch_accum(d, pl, pairs, ep, grid, sc->st, i == 0 && cl.terms_all_base);
+                else launch_accum(ctx, d, pl, pairs, ep, grid, sc->st, i == 0 && cl.terms_all_base);
             }
             for (int j : cl.mles) {
                 const double in_el = sc->mles[j].cur_ext ? 16.0 : 8.0;

@@ -21,6 +21,9 @@
 #include "sumcheck_dev.hpp"
 #include "sumcheck_gen.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 static constexpr unsigned GEN_FIXED = 640;  // bytes in front of the stage: block-sum scratch (4 x MAXD E2), challenge words, flag
 
 // Plan records are read through the CONSTANT address space: their addresses are wave-uniform (the wave index comes from
@@ -283,25 +286,32 @@ __global__ void __launch_bounds__(NT) k_gen(const GenComp* __restrict__ comps, i
 
 size_t gen_lds_bytes(int d, size_t stage_bytes) { return GEN_FIXED + ((stage_bytes + 15) & ~(size_t)15) + (size_t)(NT / 64) * d * 64 * sizeof(E2); }
 
+// grid: one workgroup per tile up to the number of workgroups that are resident at once (the kernel is bound by VALU issue: a
+// launch beyond that runs a second, partly filled dispatch wave — 1024 instead of 768 workgroups at degree 4 cost 9 % of the batched
+// main sumcheck, tools/dev/ab_gen_maxb.sh); CENO_HIP_GEN_MAXB overrides the cap
 template <int D>
-static void launch_gen_d(bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, unsigned grid, size_t stage_bytes,
+static void launch_gen_d(ceno_hip_ctx* ctx, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, size_t stage_bytes,
                          hipStream_t st) {
     const size_t lds = gen_lds_bytes(D, stage_bytes);
     const unsigned xch_off = (unsigned)((stage_bytes + 15) & ~(size_t)15);
+    static const unsigned forced = getenv("CENO_HIP_GEN_MAXB") ? (unsigned)std::max(atoi(getenv("CENO_HIP_GEN_MAXB")), 0) : 0u;
+    unsigned cap = base0 ? resident_grid(ctx, k_gen<D, true>, NT, lds, MAXB) : resident_grid(ctx, k_gen<D, false>, NT, lds, MAXB);
+    if (forced) cap = std::min(forced, MAXB);
+    const unsigned grid = std::max(1u, std::min(total_tiles, cap));
     if (base0) hipLaunchKernelGGL((k_gen<D, true>), dim3(grid), dim3(NT), lds, st, comps, n_comps, total_tiles, r, ep, xch_off);
     else hipLaunchKernelGGL((k_gen<D, false>), dim3(grid), dim3(NT), lds, st, comps, n_comps, total_tiles, r, ep, xch_off);
 }
 
-void launch_gen(int d, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, unsigned grid,
-                size_t stage_bytes, hipStream_t st) {
+void launch_gen(ceno_hip_ctx* ctx, int d, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, size_t stage_bytes,
+                hipStream_t st) {
     switch (d) {
-    case 1: launch_gen_d<1>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 2: launch_gen_d<2>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 3: launch_gen_d<3>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 4: launch_gen_d<4>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 5: launch_gen_d<5>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 6: launch_gen_d<6>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    case 7: launch_gen_d<7>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
-    default: launch_gen_d<8>(base0, comps, n_comps, total_tiles, r, ep, grid, stage_bytes, st); break;
+    case 1: launch_gen_d<1>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 2: launch_gen_d<2>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 3: launch_gen_d<3>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 4: launch_gen_d<4>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 5: launch_gen_d<5>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 6: launch_gen_d<6>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    case 7: launch_gen_d<7>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
+    default: launch_gen_d<8>(ctx, base0, comps, n_comps, total_tiles, r, ep, stage_bytes, st); break;
     }
 }

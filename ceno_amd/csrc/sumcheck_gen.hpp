@@ -39,5 +39,5 @@ static_assert(sizeof(GenComp) == 80, "GenComp layout");
 
 // LDS of a launch: fixed block + staged rows + the cross-wave exchange of partial group sums (4 waves x D points x 64 lanes)
 size_t gen_lds_bytes(int d, size_t stage_bytes);
-void launch_gen(int d, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, unsigned grid,
-                size_t stage_bytes, hipStream_t st);
+void launch_gen(ceno_hip_ctx* ctx, int d, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, size_t stage_bytes,
+                hipStream_t st);

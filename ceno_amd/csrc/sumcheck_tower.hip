@@ -87,11 +87,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MODE ==
     epilogue<D, NT>(acc, ep, smem, &s_flag);
 }
 
+// (grids stay within the workgroups that are resident at once: round 0 without a claim holds 3 per CU at 164 VGPRs, see resident_grid)
 template <int NP, int NL>
-void launch_npnl(int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
-    if (mode == 0) hipLaunchKernelGGL((k_tower<NP, NL, 0>), dim3(grid), dim3(NT), 0, st, slots, coef, pairs, ep);
-    else if (mode == 1) hipLaunchKernelGGL((k_tower<NP, NL, 1>), dim3(grid), dim3(NT), 0, st, slots, coef, pairs, ep);
-    else hipLaunchKernelGGL((k_tower<NP, NL, 2>), dim3(grid), dim3(NT), 0, st, slots, coef, pairs, ep);
+void launch_npnl(ceno_hip_ctx* ctx, int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep, unsigned grid, hipStream_t st) {
+    if (mode == 0) hipLaunchKernelGGL((k_tower<NP, NL, 0>), dim3(resident_grid(ctx, k_tower<NP, NL, 0>, NT, 0, grid)), dim3(NT), 0, st, slots, coef, pairs, ep);
+    else if (mode == 1) hipLaunchKernelGGL((k_tower<NP, NL, 1>), dim3(resident_grid(ctx, k_tower<NP, NL, 1>, NT, 0, grid)), dim3(NT), 0, st, slots, coef, pairs, ep);
+    else hipLaunchKernelGGL((k_tower<NP, NL, 2>), dim3(resident_grid(ctx, k_tower<NP, NL, 2>, NT, 0, grid)), dim3(NT), 0, st, slots, coef, pairs, ep);
 }
 
 }  // namespace
@@ -100,10 +101,10 @@ bool tower_fast_shape(int n_prod, int n_logup) {
     return n_prod >= 0 && n_logup >= 0 && n_prod <= TOWER_FAST_MAX_PROD && n_logup <= TOWER_FAST_MAX_LOGUP && n_prod + n_logup >= 1;
 }
 
-void launch_tower_round(int n_prod, int n_logup, int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep, unsigned grid,
-                        hipStream_t st) {
+void launch_tower_round(ceno_hip_ctx* ctx, int n_prod, int n_logup, int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep,
+                        unsigned grid, hipStream_t st) {
 #define CASE(P, L) \
-    case (P) * 4 + (L): launch_npnl<P, L>(mode, slots, coef, pairs, ep, grid, st); break;
+    case (P) * 4 + (L): launch_npnl<P, L>(ctx, mode, slots, coef, pairs, ep, grid, st); break;
     switch (n_prod * 4 + n_logup) {
         CASE(1, 0) CASE(2, 0) CASE(3, 0)
         CASE(0, 1) CASE(1, 1) CASE(2, 1) CASE(3, 1)

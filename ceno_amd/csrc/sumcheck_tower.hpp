@@ -17,5 +17,5 @@ bool tower_fast_shape(int n_prod, int n_logup);
 // slots: eq, then (a, b) per product tower, then (p1, p2, q1, q2) per logup tower — all extension tables; round 0 reads slot.in as
 // pairs, later rounds fold slot.in (four entries per pair) into slot.out.  Message words: q(1), leading coefficient and, in mode 0, q(0).
 // mode 0: round 0 without a claim (three values), 1: round 0 under a claim the caller knows (two values), 2: a later round (fold, two values)
-void launch_tower_round(int n_prod, int n_logup, int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep, unsigned grid,
-                        hipStream_t st);
+void launch_tower_round(ceno_hip_ctx* ctx, int n_prod, int n_logup, int mode, const MleSlot* slots, const TowerCoef& coef, size_t pairs, const Epilogue& ep,
+                        unsigned grid, hipStream_t st);
