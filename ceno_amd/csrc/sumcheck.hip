@@ -781,8 +781,10 @@ struct GenCompHost {
     int tp_log = 8, wt_log = 0;
     bool base0_ok = false;
     size_t units[2] = {0, 0};              // stage rows: [0] all-extension layout, [1] first-round layout (base rows are one unit)
-    size_t off_terms[2] = {0, 0}, off_groups[2] = {0, 0}, off_unit[2] = {0, 0};  // offsets into the gen blob
+    size_t off_terms[3] = {0, 0, 0}, off_groups[3] = {0, 0, 0}, off_unit[3] = {0, 0, 0};  // offsets into the gen blob ([2]: factor bytes = MLE indices, k_eq_base0)
     size_t slot_off = 0;                   // first slot of the component inside a round's slot row
+    int geq = -1;                          // >= 0: the component runs in eq-factored form (index into sumcheck::geq.comps)
+    double pair_cost[2] = {1.0, 1.0};      // relative cost of a pair in phase 1 / phase 2 (workgroup split of the component-aligned launch)
 };
 struct GenRound {
     size_t off_comps = 0;
@@ -790,6 +792,31 @@ struct GenRound {
     unsigned total_tiles = 0;
     size_t stage_bytes = 0;
     bool base0 = false, has_terms = false;
+    // the eq-factored components of the round (k_gen_eq, component-aligned launch): their own list
+    size_t off_comps_eq = 0;
+    int n_comps_eq = 0;
+    unsigned grid_eq = 0;
+    size_t stage_bytes_eq = 0;
+    bool direct0 = false;      // the eq list is laid out for k_eq_base0 (first round, base-field columns, no LDS stage)
+};
+// a table declared as eq(., point) on the rows [lo, hi) (ceno_hip_sumcheck_begin_eq)
+struct EqDecl {
+    bool on = false;
+    std::vector<E2> pt;
+    uint64_t lo = 0, hi = 0;
+};
+// an eq-factored component: host side of the round protocol (sumcheck_gen.hip "EQ-FACTORED FORM")
+struct GeqComp {
+    int comp = -1;                 // index into gen_comps
+    int nv = 0;
+    int slot = 0;                  // index among the eq components
+    std::vector<E2> pt, inv1m;     // the component's eq point and 1 / (1 - pt_i)
+    struct Grp {
+        uint64_t lo, hi;
+        int brow;                  // first of the group's two rows in the boundary block
+    };
+    std::vector<Grp> groups;
+    std::vector<E2> P;             // p_c(0 .. D) of the round answered last
 };
 
 }  // namespace
@@ -855,9 +882,22 @@ struct ceno_hip_sumcheck {
     std::vector<GenRound> gen_rounds;
     char* d_gen = nullptr;
     void* h_gen = nullptr;                // pinned staging of the blob (alive until the handle is freed)
+    // eq-factored main-constraint rounds (ceno_hip_sumcheck_begin_eq; sumcheck_gen.hip "EQ-FACTORED FORM")
+    struct {
+        bool on = false;
+        std::vector<EqDecl> decl;         // per MLE of the plan
+        std::vector<GeqComp> comps;
+        int n_brows = 0;
+        void* h_block = nullptr;          // pinned: [slot][D] quotient sums, then [brow][D] boundary values
+        E2 *h_q = nullptr, *d_q = nullptr, *h_b = nullptr, *d_b = nullptr;
+        unsigned* d_counters = nullptr;   // device: one arrival counter per eq component
+        // interpolation weights (base field), nodes -> target:  A: 1..D-1 -> 0, D   B: 0..D-2 -> D-1, D
+        std::vector<uint64_t> wA0, wAD, wB1, wBD, pow_dm1, lag_den_inv;
+    } geq;
 };
 
 static int host_tail_rounds(const ceno_hip_sumcheck* sc);  // below, next to the host rounds
+static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_words, const char* what);
 
 template <typename T>
 static int upload_vec(ceno_hip_sumcheck* sc, const std::vector<T>& v, T** out) {
@@ -914,6 +954,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
     ctx_free_many_on(sc->ctx, sc->dev_allocs.data(), sc->dev_allocs.size(), sc->st);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
+    ctx_pinned_free(sc->ctx, sc->geq.h_block);
     ctx_vram_slot_free(sc->ctx, sc->vram_slot);
     if (sc->extra_owned) ceno_hip_mle_free(sc->ctx, sc->extra_owned);
     delete sc;
@@ -1094,6 +1135,192 @@ static size_t gen_pipe_min_pairs() {
 }
 static size_t gen_stage_bytes(size_t units, int tp_log) { return units * (((size_t)1 << tp_log) + GEN_PAD) * sizeof(E2); }
 
+// ------------------------------------------------------------------------------------------------
+// eq-factored main-constraint rounds: host side (kernel side and derivation: sumcheck_gen.hip "EQ-FACTORED FORM").
+// Per eq component c and round i the device delivers   Q_c(1 .. D-2), [Q_c(D-1) in the first round], the leading coefficient of Q_c
+// (up to the sign (-1)^(D-1)) and, per boundary pair, the same slots of (c G) at that pair; the host completes
+//     p_c(X) = eq(X, rt_i) Q_c(X) + sum_pairs X (c G)(X)
+// from the component's running claim  p_c^{(i-1)}(r_{i-1}) = p_c(0) + p_c(1)  and adds p_c(1 .. D) to the round's message.
+// ------------------------------------------------------------------------------------------------
+static int geq_prepare(ceno_hip_sumcheck* sc) {
+    auto& Gq = sc->geq;
+    const int D = sc->d;
+    const size_t n_slots = Gq.comps.size();
+    const size_t bytes = (n_slots + (size_t)std::max(Gq.n_brows, 1)) * (size_t)D * sizeof(E2);
+    void *hb = nullptr, *db = nullptr;
+    TRY(ctx_pinned_alloc(sc->ctx, bytes, &hb, &db));
+    Gq.h_block = hb;
+    Gq.h_q = (E2*)hb;
+    Gq.d_q = (E2*)db;
+    Gq.h_b = Gq.h_q + n_slots * D;
+    Gq.d_b = Gq.d_q + n_slots * D;
+    for (size_t k = 0; k < bytes / 8; k++) reinterpret_cast<uint64_t*>(hb)[k] = MSG_INVALID;
+    {
+        void* p = nullptr;
+        TRY(ctx_alloc(sc->ctx, std::max<size_t>(n_slots, 1) * sizeof(unsigned), &p));
+        sc->dev_allocs.push_back(p);
+        Gq.d_counters = (unsigned*)p;
+        HIP_TRY(sc->ctx, hipMemsetAsync(p, 0, std::max<size_t>(n_slots, 1) * sizeof(unsigned), sc->st));
+    }
+    // Lagrange weights over integer nodes: value at `x` of the polynomial of degree < m through (node0 + j, v_j)
+    auto weights = [](int node0, int m, int x) {
+        std::vector<uint64_t> w((size_t)m);
+        for (int j = 0; j < m; j++) {
+            uint64_t num = 1, den = 1;
+            for (int k = 0; k < m; k++) {
+                if (k == j) continue;
+                const int a = x - (node0 + k), b = j - k;
+                num = gl::mul(num, a >= 0 ? (uint64_t)a : gl::neg((uint64_t)(-a)));
+                den = gl::mul(den, b >= 0 ? (uint64_t)b : gl::neg((uint64_t)(-b)));
+            }
+            w[(size_t)j] = gl::mul(num, gl::inv(den));
+        }
+        return w;
+    };
+    Gq.wA0 = weights(1, D - 1, 0);
+    Gq.wAD = weights(1, D - 1, D);
+    Gq.wB1 = weights(0, D - 1, D - 1);
+    Gq.wBD = weights(0, D - 1, D);
+    Gq.pow_dm1.assign((size_t)D + 1, 0);
+    for (int t = 0; t <= D; t++) Gq.pow_dm1[(size_t)t] = gl::pow((uint64_t)t, (uint64_t)(D - 1));
+    // 1 / prod_{j != t} (t - j) over the nodes 0 .. D (Lagrange basis at a field point)
+    Gq.lag_den_inv.assign((size_t)D + 1, 0);
+    for (int t = 0; t <= D; t++) {
+        uint64_t den = 1;
+        for (int j = 0; j <= D; j++)
+            if (j != t) den = gl::mul(den, t > j ? (uint64_t)(t - j) : gl::neg((uint64_t)(j - t)));
+        Gq.lag_den_inv[(size_t)t] = gl::inv(den);
+    }
+    for (auto& Q : Gq.comps) Q.P.assign((size_t)D + 1, e2_zero());
+    Gq.on = true;
+    return 0;
+}
+// boundary pairs of a group in round i: is pair `P` one (the device's predicate, gen_group_eq), and which candidates exist
+static bool geq_pair_irregular(uint64_t lo, uint64_t hi, int i, uint64_t P) {
+    const uint64_t s0 = (2 * P) << i, s1 = (2 * P + 1) << i, s2 = (2 * P + 2) << i;
+    const bool full0 = lo <= s0 && s1 <= hi, full1 = lo <= s1 && s2 <= hi;
+    const bool empty0 = s1 <= lo || s0 >= hi, empty1 = s2 <= lo || s1 >= hi;
+    return !((full0 && full1) || (empty0 && empty1));
+}
+// rows of the boundary block the device will write in round i for group g of a component with `pairs` pairs: out[side] = true
+static void geq_boundary_rows(const GeqComp::Grp& g, int i, uint64_t pairs, bool (&out)[2]) {
+    out[0] = out[1] = false;
+    const uint64_t p_lo = (g.lo >> i) >> 1, p_hi = g.hi > 0 ? ((g.hi - 1) >> i) >> 1 : 0;
+    if (p_lo < pairs && geq_pair_irregular(g.lo, g.hi, i, p_lo)) out[0] = true;
+    if (p_hi != p_lo && p_hi < pairs && geq_pair_irregular(g.lo, g.hi, i, p_hi)) out[1] = true;
+}
+// before the launch of round i: arm the words the device is going to write
+static void geq_arm(ceno_hip_sumcheck* sc, int i) {
+    auto& Gq = sc->geq;
+    const int D = sc->d;
+    for (auto& Q : Gq.comps) {
+        if (Q.nv <= i) continue;
+        uint64_t* w = reinterpret_cast<uint64_t*>(Gq.h_q + (size_t)Q.slot * D);
+        for (int k = 0; k < 2 * D; k++) __atomic_store_n(&w[k], MSG_INVALID, __ATOMIC_RELAXED);
+        const uint64_t pairs = 1ull << (Q.nv - i - 1);
+        for (const auto& g : Q.groups) {
+            bool rows[2];
+            geq_boundary_rows(g, i, pairs, rows);
+            for (int sd = 0; sd < 2; sd++) {
+                if (!rows[sd]) continue;
+                uint64_t* b = reinterpret_cast<uint64_t*>(Gq.h_b + (size_t)(g.brow + sd) * D);
+                for (int k = 0; k < 2 * D; k++) __atomic_store_n(&b[k], MSG_INVALID, __ATOMIC_RELAXED);
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+// after the launch: take the per-component values, complete every p_c and add p_c(1 .. D) to the message `h_out` (D ext); `r` = the
+// challenge of round i - 1 (the running claims are evaluated at it)
+static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
+    auto& Gq = sc->geq;
+    const int D = sc->d;
+    const bool neg_lead = ((D - 1) & 1) != 0;  // the device multiplies the (f(0) - f(1)): the leading coefficient carries (-1)^(D-1)
+    // Lagrange basis over the nodes 0 .. D at r (claims of this round), shared by every component
+    E2 L[MAXD + 1];
+    if (i > 0) {
+        E2 pre[MAXD + 2], suf[MAXD + 2];
+        pre[0] = e2_one();
+        for (int j = 0; j <= D; j++) pre[j + 1] = pre[j] * (r - E2{(uint64_t)j, 0});
+        suf[D + 1] = e2_one();
+        for (int j = D; j >= 0; j--) suf[j] = suf[j + 1] * (r - E2{(uint64_t)j, 0});
+        for (int t = 0; t <= D; t++) L[t] = e2_mul_base(pre[t] * suf[t + 1], Gq.lag_den_inv[(size_t)t]);
+    }
+    E2 msg[MAXD];
+    for (int t = 0; t < D; t++) msg[t] = E2{h_out[2 * t], h_out[2 * t + 1]};
+    auto lead_of = [&](E2 raw) { return neg_lead ? e2_neg(raw) : raw; };
+
+    // value at 0 and at D of the polynomial of degree D - 1 with values v[0 .. D-2] at 1 .. D-1 and leading coefficient a
+    auto ends_from_values = [&](const E2* v, E2 a, E2& at0, E2& atD) {
+        E2 h0 = e2_zero(), hD = e2_zero();
+        for (int j = 0; j < D - 1; j++) {
+            const E2 h = v[j] - e2_mul_base(a, Gq.pow_dm1[(size_t)j + 1]);
+            h0 = h0 + e2_mul_base(h, Gq.wA0[(size_t)j]);
+            hD = hD + e2_mul_base(h, Gq.wAD[(size_t)j]);
+        }
+        at0 = h0;  // a * 0^(D-1) = 0
+        atD = hD + e2_mul_base(a, Gq.pow_dm1[(size_t)D]);
+    };
+    for (auto& Q : Gq.comps) {
+        if (Q.nv <= i) continue;
+        // (all D slots are written every round; slot D - 2 means something in the first round only — later it holds a by-product of the
+        // waves with a boundary pair)
+        const E2* qv = Gq.h_q + (size_t)Q.slot * D;
+        TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(qv), 2 * D, "the quotient sums of an eq-factored component"));
+        const E2 rt = Q.pt[(size_t)i];
+        // ---- boundary part B(t) = t (c G)(t), t = 0 .. D ----
+        E2 B[MAXD + 1];
+        for (int t = 0; t <= D; t++) B[t] = e2_zero();
+        const uint64_t pairs = 1ull << (Q.nv - i - 1);
+        for (const auto& g : Q.groups) {
+            bool rows[2];
+            geq_boundary_rows(g, i, pairs, rows);
+            for (int sd = 0; sd < 2; sd++) {
+                if (!rows[sd]) continue;
+                const E2* bv = Gq.h_b + (size_t)(g.brow + sd) * D;
+                TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(bv), 2 * D, "the boundary values of an eq-factored component"));
+                E2 at0, atD;
+                ends_from_values(bv, lead_of(bv[D - 1]), at0, atD);
+                for (int t = 1; t < D; t++) B[t] = B[t] + e2_mul_base(bv[t - 1], (uint64_t)t);
+                B[D] = B[D] + e2_mul_base(atD, (uint64_t)D);
+            }
+        }
+        // ---- quotient Q(t), t = 0 .. D ----
+        E2 Qt[MAXD + 1];
+        const E2 a = lead_of(qv[D - 1]);
+        if (i == 0) {
+            for (int t = 1; t < D; t++) Qt[t] = qv[t - 1];
+            ends_from_values(qv, a, Qt[0], Qt[D]);
+        } else {
+            E2 claim = e2_zero();
+            for (int t = 0; t <= D; t++) claim = claim + L[t] * Q.P[(size_t)t];
+            for (int t = 1; t <= D - 2; t++) Qt[t] = qv[t - 1];
+            Qt[0] = (claim - rt * Qt[1] - B[1]) * Q.inv1m[(size_t)i];  // claim = (1 - rt) Q(0) + rt Q(1) + B(1)
+            E2 h1 = e2_zero(), hD = e2_zero();
+            for (int j = 0; j < D - 1; j++) {
+                const E2 h = Qt[j] - e2_mul_base(a, Gq.pow_dm1[(size_t)j]);
+                h1 = h1 + e2_mul_base(h, Gq.wB1[(size_t)j]);
+                hD = hD + e2_mul_base(h, Gq.wBD[(size_t)j]);
+            }
+            Qt[D - 1] = h1 + e2_mul_base(a, Gq.pow_dm1[(size_t)D - 1]);
+            Qt[D] = hD + e2_mul_base(a, Gq.pow_dm1[(size_t)D]);
+        }
+        // ---- p_c(t) = eq(t, rt) Q(t) + B(t),  eq(t, rt) = (1 - t) + (2 t - 1) rt ----
+        for (int t = 0; t <= D; t++) {
+            const E2 one_minus_t = t <= 1 ? E2{(uint64_t)(1 - t), 0} : E2{gl::neg((uint64_t)(t - 1)), 0};
+            const E2 two_t_minus_1 = t >= 1 ? E2{(uint64_t)(2 * t - 1), 0} : E2{gl::neg(1), 0};
+            const E2 eq = one_minus_t + e2_mul_base(rt, two_t_minus_1.c0);
+            Q.P[(size_t)t] = eq * Qt[t] + B[t];
+            if (t >= 1) msg[t - 1] = msg[t - 1] + Q.P[(size_t)t];
+        }
+    }
+    for (int t = 0; t < D; t++) {
+        h_out[2 * t] = msg[t].c0;
+        h_out[2 * t + 1] = msg[t].c1;
+    }
+    return 0;
+}
+
 static int sc_build_gen(ceno_hip_sumcheck* sc) {
     ceno_hip_ctx* ctx = sc->ctx;
     if (sc->n < gen_min_log()) return 0;
@@ -1111,6 +1338,14 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         return off;
     };
     std::vector<GenCompHost> comps;
+    bool geq_wanted = false;
+    {
+        const char* e = getenv("CENO_HIP_GEN_EQF");  // 0: declared eq tables are treated like any other common factor (A/B, tests)
+        for (const EqDecl& dcl : sc->geq.decl) geq_wanted = geq_wanted || dcl.on;
+        if (e && atoi(e) == 0) geq_wanted = false;
+    }
+    sc->geq.comps.clear();
+    sc->geq.n_brows = 0;
     for (size_t ci = 0; ci < sc->classes.size(); ci++) {
         ScClass& cl = sc->classes[ci];
         if (cl.dense || cl.nv < gen_min_log()) continue;
@@ -1158,23 +1393,27 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         for (int m = 0; m < km; m++)
             if (!used[m]) fold_only.mles.push_back(m);
         // ---- per component: units, terms, groups in both layouts ----
+        std::vector<GeqComp> geq_new;  // eq-factored components of this class (committed with the class)
+        const int brows_before = sc->geq.n_brows;
         for (auto& C : mine) {
             std::map<int, int> pos;  // class-local id -> component-local id
             for (size_t k = 0; k < C.mles.size(); k++) pos[C.mles[k]] = (int)k;
-            std::vector<uint16_t> unit[2];
+            std::vector<uint16_t> unit[3];
             std::vector<char> is_base(C.mles.size());
             size_t u0 = 0, u1 = 0;
             for (size_t k = 0; k < C.mles.size(); k++) {
                 is_base[k] = !sc->mles[cl.mles[C.mles[k]]].cur_ext;
                 unit[0].push_back((uint16_t)u0);
                 unit[1].push_back((uint16_t)u1);
+                unit[2].push_back((uint16_t)k);
                 u0 += 2;
                 u1 += is_base[k] ? 1 : 2;
             }
             C.units[0] = u0;
             C.units[1] = u1;
-            std::vector<GenTerm> terms[2];
-            std::vector<GenGroup> groups[2];
+            std::vector<GenTerm> terms[3];
+            std::vector<GenGroup> groups[3];
+            std::vector<int> grp_common;  // per emitted group: global id of its ONE common factor, or -1
             C.base0_ok = true;
             size_t max_terms = 0;
             for (int g = 0; g < ng; g++) {
@@ -1191,7 +1430,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                 // widest terms first: the round-robin split over the waves stays balanced
                 std::stable_sort(ts.begin(), ts.end(), [&](uint32_t a, uint32_t b) { return cl.h_to[a + 1] - cl.h_to[a] > cl.h_to[b + 1] - cl.h_to[b]; });
                 max_terms = std::max(max_terms, ts.size());
-                for (int lay = 0; lay < 2; lay++) {
+                for (int lay = 0; lay < 3; lay++) {
                     GenGroup G{};
                     G.term_begin = (uint32_t)terms[lay].size();
                     for (uint32_t t : ts) {
@@ -1208,6 +1447,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     }
                     G.term_end = (uint32_t)terms[lay].size();
                     G.n_common = cl.h_co[g + 1] - cl.h_co[g];
+                    if (lay == 0) grp_common.push_back(G.n_common == 1 ? cl.mles[cl.h_ci[cl.h_co[g]]] : -1);
                     for (uint32_t k = 0; k < G.n_common; k++) {
                         const int cm = pos[(int)cl.h_ci[cl.h_co[g] + k]];
                         G.common8 |= (uint64_t)(unit[lay][cm] & 0xff) << (8 * k);
@@ -1218,22 +1458,78 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             }
             C.n_groups = (int)groups[0].size();
             C.n_terms = (int)terms[0].size();
+            // ---- eq-factored form: every group = ONE common factor, a table declared as eq(., point) on a row range, one point for the
+            // whole component, and no term of the component reads such a table as an ordinary factor ----
+            if (geq_wanted && sc->d >= 3 && C.n_groups > 0) {
+                bool eq_ok = true;
+                const EqDecl* first = nullptr;
+                for (int gid : grp_common) {
+                    if (gid < 0 || !sc->geq.decl[gid].on) { eq_ok = false; break; }
+                    const EqDecl& dcl = sc->geq.decl[gid];
+                    if (!first) first = &dcl;
+                    else if (dcl.pt.size() != first->pt.size() || memcmp(dcl.pt.data(), first->pt.data(), dcl.pt.size() * sizeof(E2)) != 0) eq_ok = false;
+                }
+                for (const GenTerm& T : terms[0]) {
+                    if ((int)T.nf > sc->d - 1) eq_ok = false;
+                    for (uint32_t k = 0; k < T.nf && eq_ok; k++) {
+                        const unsigned u = (unsigned)((T.idx8 >> (8 * k)) & 0xff);
+                        for (size_t m = 0; m < C.mles.size(); m++)
+                            if (unit[0][m] == u && sc->geq.decl[cl.mles[C.mles[m]]].on) eq_ok = false;
+                    }
+                }
+                if (eq_ok && first) {
+                    for (const E2& v : first->pt)
+                        if (v.c0 == 1 && v.c1 == 0) eq_ok = false;  // 1 - rt_i = 0: the running claim does not determine Q(0)
+                }
+                if (eq_ok && first && (int)first->pt.size() == cl.nv) {
+                    GeqComp Q;
+                    Q.nv = cl.nv;
+                    Q.pt = first->pt;
+                    Q.slot = (int)sc->geq.comps.size() + (int)geq_new.size();
+                    for (size_t k = 0; k < grp_common.size(); k++) {
+                        const EqDecl& dcl = sc->geq.decl[grp_common[k]];
+                        const int brow = sc->geq.n_brows;
+                        sc->geq.n_brows += 2;
+                        Q.groups.push_back(GeqComp::Grp{dcl.lo, dcl.hi, brow});
+                        for (int lay = 0; lay < 3; lay++) {
+                            groups[lay][k].eq = 1;
+                            groups[lay][k].brow = (uint32_t)brow;
+                            groups[lay][k].lo = dcl.lo;
+                            groups[lay][k].hi = dcl.hi;
+                        }
+                    }
+                    C.geq = (int)geq_new.size();  // index into geq_new for now; fixed up when the class is accepted
+                    geq_new.push_back(std::move(Q));
+                }
+            }
+            {   // relative cost of a pair (the component-aligned launch splits its workgroups by it)
+                double c2 = 0.0;
+                for (const GenTerm& T : terms[0]) c2 += 2.0 + (T.nf > 1 ? (T.nf - 1) * (double)std::max(sc->d - 2, 1) : 1.0) + ((int)T.nf == sc->d - 1 ? T.nf - 1.0 : 0.0);
+                C.pair_cost[0] = 2.0 * (double)C.mles.size();
+                C.pair_cost[1] = c2 + (double)(sc->d - 1) * C.n_groups;
+            }
             // geometry: waves sharing a group's terms, pairs per tile, shrunk until the staged rows fit the LDS budget
             C.wt_log = max_terms >= 4 ? 2 : (max_terms >= 2 ? 1 : 0);
             C.tp_log = 8 - C.wt_log;
             while (C.tp_log > 4 && gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d)) C.tp_log--;
             if (gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d) || C.units[0] > GEN_MAX_UNITS) { ok = false; break; }
             C.wt_log = std::min(2, 8 - C.tp_log);
-            for (int lay = 0; lay < 2; lay++) {
+            for (int lay = 0; lay < 3; lay++) {
                 C.off_terms[lay] = append(terms[lay].data(), terms[lay].size() * sizeof(GenTerm));
                 C.off_groups[lay] = append(groups[lay].data(), groups[lay].size() * sizeof(GenGroup));
                 C.off_unit[lay] = append(unit[lay].data(), unit[lay].size() * sizeof(uint16_t));
             }
         }
-        if (!ok) continue;
+        if (!ok) {
+            sc->geq.n_brows = brows_before;
+            continue;
+        }
+        for (auto& C : mine)
+            if (C.geq >= 0) C.geq += (int)sc->geq.comps.size();
+        for (auto& Q : geq_new) sc->geq.comps.push_back(std::move(Q));
         if (!fold_only.mles.empty()) {
             std::vector<uint16_t> zeros(fold_only.mles.size(), 0);
-            fold_only.off_unit[0] = fold_only.off_unit[1] = append(zeros.data(), zeros.size() * sizeof(uint16_t));
+            fold_only.off_unit[0] = fold_only.off_unit[1] = fold_only.off_unit[2] = append(zeros.data(), zeros.size() * sizeof(uint16_t));
             fold_only.base0_ok = true;
             mine.push_back(fold_only);
         }
@@ -1273,19 +1569,50 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         }
     }
     // ---- component lists per round ----
+    for (size_t k = 0; k < comps.size(); k++)
+        if (comps[k].geq >= 0) sc->geq.comps[comps[k].geq].comp = (int)k;
+    const bool geq_on = !sc->geq.comps.empty();
+    if (geq_on) {
+        // 1 / (1 - pt_i) for every eq component and round: ONE inversion (prefix products)
+        std::vector<E2*> where;
+        std::vector<E2> vals;
+        for (auto& Q : sc->geq.comps) {
+            Q.inv1m.assign(Q.pt.size(), e2_zero());
+            for (size_t i = 0; i < Q.pt.size(); i++) {
+                where.push_back(&Q.inv1m[i]);
+                vals.push_back(e2_one() - Q.pt[i]);
+            }
+        }
+        std::vector<E2> pre(vals.size());
+        E2 run = e2_one();
+        for (size_t k = 0; k < vals.size(); k++) {
+            pre[k] = run;
+            run = run * vals[k];
+        }
+        E2 inv = e2_inv(run);
+        for (size_t k = vals.size(); k-- > 0;) {
+            *where[k] = inv * pre[k];
+            inv = inv * vals[k];
+        }
+    }
     sc->gen_rounds.assign(n, GenRound{});
     std::vector<size_t> comp_fix;  // offsets of GenComp records whose pointers still hold blob offsets
     for (int i = 0; i < n; i++) {
         GenRound& R = sc->gen_rounds[i];
-        std::vector<GenComp> list;
+        std::vector<GenComp> list, list_eq;
+        std::vector<double> weight_eq;
         bool base0 = i == 0;
         for (auto& C : comps)
             if (sc->classes[C.cls].nv > i && C.n_groups > 0 && !C.base0_ok) base0 = false;
+        // first round of an eq-factored batch over base-field columns: the direct kernel (k_eq_base0, no LDS stage), third record layout
+        static const bool no_direct0 = getenv("CENO_HIP_EQ_DIRECT0") && atoi(getenv("CENO_HIP_EQ_DIRECT0")) == 0;  // A/B: the staged kernel
+        const bool direct0 = geq_on && i == 0 && base0 && !no_direct0;
+        R.direct0 = direct0;
         unsigned tiles = 0;
         for (auto& C : comps) {
             const ScClass& cl = sc->classes[C.cls];
             if (cl.nv <= i) continue;
-            const int lay = base0 ? 1 : 0;
+            const int lay = direct0 && C.geq >= 0 ? 2 : (base0 ? 1 : 0);
             GenComp G{};
             G.slots = reinterpret_cast<const MleSlot*>(off_slots + ((size_t)i * slots_per_round + C.slot_off) * sizeof(MleSlot));
             G.terms = reinterpret_cast<const GenTerm*>(C.off_terms[lay]);
@@ -1300,6 +1627,35 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             G.tile_begin = tiles;
             G.n_tiles = (uint32_t)((G.pairs + ((1ull << C.tp_log) - 1)) >> C.tp_log);
             if (i == 0 && C.n_groups == 0) continue;  // nothing to fold and nothing to evaluate in the first round
+            if (geq_on && (C.geq >= 0 || C.n_groups == 0)) {
+                // the eq-factored launch of the round (fold-only components ride along: no second launch for them)
+                G.tile_begin = 0;
+                double w = (double)G.n_tiles * C.pair_cost[0] * (i > 0 ? 1.0 : 0.1);
+                if (C.geq >= 0) {
+                    const GeqComp& Q = sc->geq.comps[C.geq];
+                    G.eqf = 1u | (i == 0 ? 2u : 0u);
+                    G.eq_slot = (uint32_t)Q.slot;
+                    G.shift = (uint32_t)i;
+                    G.rt = Q.pt[i];
+                    G.inv1m = Q.inv1m[i];
+                    // pairs that meet the row range of some group: [floor(lo / 2^(i+1)), ceil(hi / 2^(i+1)))
+                    uint64_t pb = ~0ull, pe = 0;
+                    for (const auto& g : Q.groups) {
+                        if (g.hi <= g.lo) continue;
+                        pb = std::min(pb, g.lo >> (i + 1));
+                        pe = std::max(pe, ((g.hi - 1) >> (i + 1)) + 1);
+                    }
+                    if (pe > pb) {
+                        G.p2_tile_begin = (uint32_t)(pb >> C.tp_log);
+                        G.p2_tile_end = (uint32_t)std::min<uint64_t>(((pe - 1) >> C.tp_log) + 1, G.n_tiles);
+                    }
+                    w += (double)(G.p2_tile_end - G.p2_tile_begin) * C.pair_cost[1];
+                    R.stage_bytes_eq = std::max(R.stage_bytes_eq, gen_stage_bytes(C.units[lay == 2 ? 1 : lay], C.tp_log));
+                }
+                weight_eq.push_back(w * (double)(1u << C.tp_log));
+                list_eq.push_back(G);
+                continue;
+            }
             tiles += G.n_tiles;
             if (C.n_groups > 0) {
                 R.has_terms = true;
@@ -1312,6 +1668,35 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         R.total_tiles = tiles;
         R.off_comps = append(list.data(), list.size() * sizeof(GenComp));
         for (size_t k = 0; k < list.size(); k++) comp_fix.push_back(R.off_comps + k * sizeof(GenComp));
+        if (!list_eq.empty()) {
+            // component-aligned workgroup split: one workgroup per tile while all of them are resident at once, else every component
+            // gets one workgroup and the rest in proportion to its estimated work
+            uint64_t total = 0;
+            double wsum = 0.0;
+            for (size_t k = 0; k < list_eq.size(); k++) {
+                total += list_eq[k].n_tiles;
+                wsum += weight_eq[k];
+            }
+            const unsigned cap = std::max<unsigned>(direct0 ? eq_base0_resident_cap(ctx, sc->d) : gen_resident_cap(ctx, sc->d, base0, R.stage_bytes_eq),
+                                                    (unsigned)list_eq.size());
+            unsigned wg = 0;
+            for (size_t k = 0; k < list_eq.size(); k++) {
+                GenComp& G = list_eq[k];
+                unsigned cnt = G.n_tiles;
+                if (total > cap) {
+                    const double share = wsum > 0 ? weight_eq[k] / wsum : 0.0;
+                    cnt = 1u + (unsigned)(share * (double)(cap - (unsigned)list_eq.size()));
+                    cnt = std::min(cnt, G.n_tiles);
+                }
+                G.wg_begin = wg;
+                G.wg_count = std::max(cnt, 1u);
+                wg += G.wg_count;
+            }
+            R.grid_eq = wg;
+            R.n_comps_eq = (int)list_eq.size();
+            R.off_comps_eq = append(list_eq.data(), list_eq.size() * sizeof(GenComp));
+            for (size_t k = 0; k < list_eq.size(); k++) comp_fix.push_back(R.off_comps_eq + k * sizeof(GenComp));
+        }
     }
     // ---- one device allocation, pointers fixed up, one copy from pinned staging ----
     void* d = nullptr;
@@ -1332,11 +1717,18 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
     HIP_TRY(ctx, hipMemcpyAsync(d, hb, blob.size(), hipMemcpyHostToDevice, sc->st));
     sc->gen_comps = std::move(comps);
     sc->gen_on = true;
+    if (geq_on) TRY(geq_prepare(sc));
     return 0;
 }
 
+struct EqDeclArgs {
+    int n;
+    const int* mle_idx;
+    const uint64_t* const* points;
+    const size_t *lo, *hi;
+};
 static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, hipStream_t st,
-                    ceno_hip_sumcheck** out, SetupJob* defer_setup = nullptr) {
+                    ceno_hip_sumcheck** out, SetupJob* defer_setup = nullptr, const EqDeclArgs* eqd = nullptr) {
     CHECK_ARG(ctx, mles && plan && out, "NULL argument");
     const int n = plan->max_num_vars, d = plan->max_degree;
     CHECK_ARG(ctx, n >= 0 && n < 40, "max_num_vars %d out of range", n);
@@ -1354,6 +1746,22 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         sc->mles[j].cur = mles[j]->d;
         sc->mles[j].cur_ext = mles[j]->is_ext;
         sc->mles[j].nv = mles[j]->num_vars;
+    }
+    sc->geq.decl.assign((size_t)plan->num_mles, EqDecl{});
+    for (int k = 0; eqd && k < eqd->n; k++) {
+        const int j = eqd->mle_idx[k];
+        if (j < 0 || j >= plan->num_mles || !eqd->points[k]) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "eq declaration %d: bad table index or point", k); }
+        EqDecl& dcl = sc->geq.decl[(size_t)j];
+        const int nv = sc->mles[j].nv;
+        dcl.pt.resize((size_t)nv);
+        for (int i = 0; i < nv; i++) {
+            dcl.pt[(size_t)i] = E2{eqd->points[k][2 * i], eqd->points[k][2 * i + 1]};
+            if (dcl.pt[(size_t)i].c0 >= gl::P || dcl.pt[(size_t)i].c1 >= gl::P) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "eq declaration %d: point is not canonical", k); }
+        }
+        dcl.lo = std::min<uint64_t>(eqd->lo[k], (uint64_t)1 << nv);
+        dcl.hi = std::min<uint64_t>(eqd->hi[k], (uint64_t)1 << nv);
+        if (dcl.hi <= dcl.lo) dcl.lo = dcl.hi = 0;
+        dcl.on = sc->mles[j].cur_ext != 0 && nv >= 1;
     }
     sc->terms.resize(plan->num_terms);
     for (int t = 0; t < plan->num_terms; t++) {
@@ -2344,7 +2752,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     std::vector<ScClass*> live;
     for (auto& cl : sc->classes)
         if (cl.nv > i) live.push_back(&cl);
-    enum { U_DENSE, U_GEN, U_LEGACY };
+    enum { U_DENSE, U_GEN, U_LEGACY, U_GENEQ };
     struct Unit {
         int kind;
         ScClass* cl;
@@ -2356,13 +2764,17 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     // blocked kernel's first-round form (no staging, one reduction per pair): taken when EVERY class of the merged launch
     // qualifies (the component list of a round is all or nothing); CENO_HIP_GEN_ROUND0=1 keeps k_gen
     static const bool gen_round0 = getenv("CENO_HIP_GEN_ROUND0") != nullptr && atoi(getenv("CENO_HIP_GEN_ROUND0")) != 0;
-    bool legacy_round0 = i == 0 && !gen_round0 && sc->gen_on;
+    bool legacy_round0 = i == 0 && !gen_round0 && sc->gen_on && !sc->geq.on;  // (eq-factored components need their per-component sums)
+    if (sc->geq.on && d_out) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: an eq-factored plan (ceno_hip_sumcheck_begin_eq) produces host messages only");
     for (ScClass* cl : live)
         if (cl->gen && !cl->dense && !cl->terms_all_base) legacy_round0 = false;
     for (ScClass* cl : live) {
         if (cl->dense) units.push_back(Unit{U_DENSE, cl, true});
         else if (cl->gen && sc->gen_on && !legacy_round0) {
             if (!gen_added && sc->gen_rounds[i].n_comps > 0) units.push_back(Unit{U_GEN, nullptr, sc->gen_rounds[i].has_terms});
+            // the eq-factored components: their own (component-aligned) launch; it takes no part in the classic message chain — its
+            // per-component sums go to the host, which completes and adds them (geq_collect)
+            if (!gen_added && sc->gen_rounds[i].n_comps_eq > 0) units.push_back(Unit{U_GENEQ, nullptr, false});
             gen_added = true;
         } else units.push_back(Unit{U_LEGACY, cl, !cl->terms.empty()});
     }
@@ -2388,6 +2800,19 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         if (ep.last_class)
             for (int x = 0; x < MAXD; x++) ep.scalars[x] = scalars[x];
         double bytes = 0.0;
+        if (U.kind == U_GENEQ) {
+            const GenRound& R = sc->gen_rounds[i];
+            geq_arm(sc, i);
+            ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);
+            ep.d = 0;
+            GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters};
+            prof_begin(ctx, sc->st);
+            if (R.direct0) launch_eq_base0(ctx, d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, ep, ea, R.grid_eq, sc->st);
+            else launch_gen(ctx, d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, 0, r, ep, R.stage_bytes_eq, sc->st, &ea,
+                            R.grid_eq);
+            prof_end(ctx, sc->st, 0.0);
+            continue;
+        }
         if (U.kind == U_GEN) {
             const GenRound& R = sc->gen_rounds[i];
             ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);  // the merged launch uses the first class's partial rows
@@ -2470,10 +2895,12 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             HIP_TRY(ctx, hipStreamSynchronize(sc->st));
         } else {
             memcpy(h_out, scalars, (size_t)d * sizeof(E2));
+            if (sc->geq.on) TRY(geq_collect(sc, i, r, h_out));
         }
     } else if (h_out) {
         if (phases) clock_gettime(CLOCK_MONOTONIC, &tp3);
         TRY(sc_take_message(sc, h_out));
+        if (sc->geq.on) TRY(geq_collect(sc, i, r, h_out));
         if (phases) {
             timespec tp4;
             clock_gettime(CLOCK_MONOTONIC, &tp4);
@@ -2501,6 +2928,15 @@ int ceno_hip_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const 
                             ceno_hip_sumcheck** out) {
     return sc_build(ctx, mles, plan, ctx_stream(ctx, s), out);
 }
+
+int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, int num_eq, const int* eq_mle_idx,
+                               const uint64_t* const* eq_points, const size_t* eq_lo, const size_t* eq_hi, ceno_hip_stream s, ceno_hip_sumcheck** out) {
+    CHECK_ARG(ctx, num_eq >= 0 && (num_eq == 0 || (eq_mle_idx && eq_points && eq_lo && eq_hi)), "eq declarations: NULL array");
+    const EqDeclArgs ea{num_eq, eq_mle_idx, eq_points, eq_lo, eq_hi};
+    return sc_build(ctx, mles, plan, ctx_stream(ctx, s), out, nullptr, num_eq > 0 ? &ea : nullptr);
+}
+
+int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc) { return sc && sc->geq.on ? (int)sc->geq.comps.size() : 0; }
 
 int ceno_hip_sumcheck_round(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* out_evals) {
     CHECK_ARG(ctx, sc && out_evals, "NULL argument");

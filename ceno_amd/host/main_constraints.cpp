@@ -60,11 +60,13 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     }
     // ---- selector eq tables per chip (cpu/mod.rs:1200-1234): first selector per structural id wins ----
     std::vector<std::vector<ceno_hip_mle*>> sel_by_id(n_jobs);
+    std::vector<std::vector<int>> sel_k_by_id(n_jobs);  // which selector of the job stands for a structural id
     std::vector<ceno_hip_mle*> owned;
     auto cleanup = [&]() { for (auto* m : owned) ceno_hip_mle_free(ctx, m); };
     for (int c = 0; c < n_jobs; c++) {
         const ceno_main_job& J = jobs[c];
         sel_by_id[c].assign(J.n_structural, nullptr);
+        sel_k_by_id[c].assign(J.n_structural, -1);
         for (int k = 0; k < J.n_selectors; k++) {
             const int id = J.sel_structural_id[k];
             if (id < 0 || id >= J.n_structural) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "selector wit id out of range"); }
@@ -76,6 +78,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
             owned.push_back(m);
             sel_by_id[c][id] = m;
+            sel_k_by_id[c][id] = k;
         }
     }
     const double t_sel = dbg ? (ceno_hip_stream_sync(ctx, s), now_us()) : 0;
@@ -94,6 +97,11 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     std::vector<int> mle_start(n_jobs), mle_nv;
     std::vector<uint64_t> coeffs;
     std::vector<uint32_t> toff{0}, tidx;
+    // Whole / Prefix selectors ARE eq(., point) on a row range: declared to the sumcheck (ceno_hip_sumcheck_begin_eq), whose rounds then
+    // evaluate a chip's quotient by eq(X, rt_i) at one point fewer (the k_tower idea applied to the main constraints)
+    std::vector<int> eq_idx;
+    std::vector<const uint64_t*> eq_pts;
+    std::vector<size_t> eq_lo, eq_hi;
     int alpha_start = 0;
     for (int c = 0; c < n_jobs; c++) {
         const ceno_main_job& J = jobs[c];
@@ -101,7 +109,16 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         const int n_m = J.n_witin + J.n_fixed + J.n_structural;
         for (int j = 0; j < n_m; j++) {
             ceno_hip_mle* m = J.mles[j];
-            if (j >= J.n_witin + J.n_fixed && sel_by_id[c][j - J.n_witin - J.n_fixed]) m = sel_by_id[c][j - J.n_witin - J.n_fixed];
+            if (j >= J.n_witin + J.n_fixed && sel_by_id[c][j - J.n_witin - J.n_fixed]) {
+                const int id = j - J.n_witin - J.n_fixed, k = sel_k_by_id[c][id];
+                m = sel_by_id[c][id];
+                if (J.sel_kind[k] == CENO_HIP_SEL_WHOLE || J.sel_kind[k] == CENO_HIP_SEL_PREFIX) {
+                    eq_idx.push_back((int)mles.size());
+                    eq_pts.push_back(J.sel_points[k]);
+                    eq_lo.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? 0 : J.sel_offset[k]);
+                    eq_hi.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? (size_t)1 << J.num_vars : J.sel_offset[k] + J.sel_num_instances[k]);
+                }
+            }
             if (!m) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "structural witness without selector is NULL"); }
             mles.push_back(m);
             mle_nv.push_back(ceno_hip_mle_num_vars(m));
@@ -176,7 +193,8 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     plan.max_degree = max_deg;
     std::vector<uint64_t> evals(2 * mles.size());
     const double t_plan = dbg ? now_us() : 0;
-    int rc = ceno_prover_sumcheck_prove(ctx, mles.data(), &plan, tr, s, out_msgs, out_global_rt, evals.data());   // cpu/mod.rs:1332-1337
+    int rc = ceno_prover_sumcheck_prove_eq(ctx, mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
+                                           out_msgs, out_global_rt, evals.data());   // cpu/mod.rs:1332-1337
     if (dbg) fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan %.0f us, sumcheck %.0f us\n", t_sel - t_start, t_plan - t_sel, now_us() - t_plan);
     if (rc) { cleanup(); return rc; }
     // ---- final claim by the front-load rule and the claimed sum recovered backwards (cpu/mod.rs:1338-1360,1393-1413) ----

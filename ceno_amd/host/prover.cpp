@@ -170,6 +170,12 @@ int ceno_prover_sumcheck_run(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, in
 
 int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, ceno_transcript* tr,
                                ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
+    return ceno_prover_sumcheck_prove_eq(ctx, mles, plan, 0, nullptr, nullptr, nullptr, nullptr, tr, s, out_msgs, out_challenges, out_final_evals);
+}
+
+int ceno_prover_sumcheck_prove_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, int num_eq, const int* eq_mle_idx,
+                                  const uint64_t* const* eq_points, const size_t* eq_lo, const size_t* eq_hi, ceno_transcript* tr, ceno_hip_stream s,
+                                  uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals) {
     if (!ctx || !plan) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
     ceno_hip_sumcheck* sc = nullptr;
     static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
@@ -179,7 +185,7 @@ int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
         return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
     };
     const double t0 = dbg ? now_us() : 0;
-    int rc = ceno_hip_sumcheck_begin(ctx, mles, plan, s, &sc);
+    int rc = ceno_hip_sumcheck_begin_eq(ctx, mles, plan, num_eq, eq_mle_idx, eq_points, eq_lo, eq_hi, s, &sc);
     if (rc) return fail_from_ctx(ctx, rc);
     const double t1 = dbg ? now_us() : 0;
     ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // this loop drives the rounds back to back

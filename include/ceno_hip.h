@@ -198,6 +198,19 @@ typedef struct ceno_hip_sumcheck_plan {
 
 int ceno_hip_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan,
                             ceno_hip_stream s, ceno_hip_sumcheck** out);
+/* ceno_hip_sumcheck_begin for a plan whose common factors are selector tables of a known form — the main-constraint sumchecks
+ * (ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390: every group is selector x sum of column products, the selectors are
+ * SelectorType::Whole / Prefix, gkr_iop/src/selector.rs:131-245).  Table eq_mle_idx[k] of the plan IS eq(., eq_points[k]) on the rows
+ * [eq_lo[k], eq_hi[k]) and 0 elsewhere (what ceno_hip_selector_build produces for WHOLE: [0, 2^n) and PREFIX: [offset, offset +
+ * num_instances)); eq_points[k] holds as many extension elements as the table has variables.  The caller vouches for the declaration.
+ * Where every group of a chip has one such common factor and all of them share the point, the rounds evaluate the chip's quotient by
+ * eq(X, rt_i) at one point fewer and the library completes each message from the chip's running claim: the same words as without the
+ * declaration (an all-zero declaration list is ceno_hip_sumcheck_begin).  Such a handle produces host messages only
+ * (ceno_hip_sumcheck_round_dev fails).  CENO_HIP_GEN_EQF=0 ignores the declarations. */
+int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, int num_eq, const int* eq_mle_idx,
+                               const uint64_t* const* eq_points, const size_t* eq_lo, const size_t* eq_hi, ceno_hip_stream s, ceno_hip_sumcheck** out);
+/* how many components (chips) of the plan run in the eq-factored form (0: none, the declarations did not apply) */
+int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc);
 /* Produce the message of the next round.  `challenge2` is the challenge of the PREVIOUS round
  * (NULL for round 0): the tables are folded with it and the new message accumulated in one pass.
  * out_evals receives max_degree ext elements (host memory). Synchronises the stream. */

@@ -93,6 +93,11 @@ int ceno_prover_transcript_grind(ceno_hip_ctx* ctx, ceno_transcript* t, int bits
 int ceno_prover_sumcheck_prove(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan,
                                ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs, uint64_t* out_challenges,
                                uint64_t* out_final_evals);
+/* the same with selector declarations handed through to ceno_hip_sumcheck_begin_eq (include/ceno_hip.h): table eq_mle_idx[k] is
+ * eq(., eq_points[k]) on the rows [eq_lo[k], eq_hi[k]); the messages are the same words, the rounds of the declared chips cheaper */
+int ceno_prover_sumcheck_prove_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan, int num_eq, const int* eq_mle_idx,
+                                  const uint64_t* const* eq_points, const size_t* eq_lo, const size_t* eq_hi, ceno_transcript* tr, ceno_hip_stream s,
+                                  uint64_t* out_msgs, uint64_t* out_challenges, uint64_t* out_final_evals);
 /* VirtualPolynomialsBuilder (EXT multilinear_extensions; call sites gkr_iop/src/gkr/layer/cpu/mod.rs:80-88,213-226,
  * ceno_zkvm/src/scheme/cpu/mod.rs:98,135-137,413-418,1255-1334): register MLEs — `lift` returns the expression id,
  * the same id for the same handle; take_ownership != 0 is the reference's `Either::Right` (owned, freed with the builder),
