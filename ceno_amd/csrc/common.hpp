@@ -61,6 +61,7 @@ struct ceno_hip_ctx {
     // device, so the pool's soft-cap trim (ctx_alloc) only runs while this is zero — two lanes each inside hipFree, each with
     // kernels that need the other's... host would otherwise wait for each other until the kernels' poll timeout
     std::atomic<int> pipelined_live{0};
+    std::atomic<unsigned long long> eq_launches{0};  // eq-factored round launches so far (ceno_hip_stat_eq_launches: tests, A/B)
     // ... and the other half of that rule: a trim that has STARTED keeps new pipelined sumchecks from starting until it is done
     // (a lane that begins proving while another sits in hipFree has its round kernels waited for by that hipFree, and its own next
     // hipMalloc queues behind the same hipFree inside the runtime: host and kernel then wait for each other until the kernel's

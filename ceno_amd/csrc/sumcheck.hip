@@ -1605,7 +1605,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         for (auto& C : comps)
             if (sc->classes[C.cls].nv > i && C.n_groups > 0 && !C.base0_ok) base0 = false;
         // first round of an eq-factored batch over base-field columns: the direct kernel (k_eq_base0, no LDS stage), third record layout
-        static const bool no_direct0 = getenv("CENO_HIP_EQ_DIRECT0") && atoi(getenv("CENO_HIP_EQ_DIRECT0")) == 0;  // A/B: the staged kernel
+        const bool no_direct0 = getenv("CENO_HIP_EQ_DIRECT0") && atoi(getenv("CENO_HIP_EQ_DIRECT0")) == 0;  // A/B, tests: the staged kernel (read per call)
         const bool direct0 = geq_on && i == 0 && base0 && !no_direct0;
         R.direct0 = direct0;
         unsigned tiles = 0;
@@ -2803,6 +2803,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         if (U.kind == U_GENEQ) {
             const GenRound& R = sc->gen_rounds[i];
             geq_arm(sc, i);
+            ctx->eq_launches.fetch_add(1, std::memory_order_relaxed);
             ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);
             ep.d = 0;
             GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters};
@@ -2935,6 +2936,8 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
     const EqDeclArgs ea{num_eq, eq_mle_idx, eq_points, eq_lo, eq_hi};
     return sc_build(ctx, mles, plan, ctx_stream(ctx, s), out, nullptr, num_eq > 0 ? &ea : nullptr);
 }
+
+unsigned long long ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx) { return ctx ? ctx->eq_launches.load() : 0ull; }
 
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc) { return sc && sc->geq.on ? (int)sc->geq.comps.size() : 0; }
 

@@ -211,6 +211,8 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
                                const uint64_t* const* eq_points, const size_t* eq_lo, const size_t* eq_hi, ceno_hip_stream s, ceno_hip_sumcheck** out);
 /* how many components (chips) of the plan run in the eq-factored form (0: none, the declarations did not apply) */
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc);
+/* eq-factored round launches this context has issued so far (a statistic for tests and A/B runs) */
+unsigned long long ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx);
 /* Produce the message of the next round.  `challenge2` is the challenge of the PREVIOUS round
  * (NULL for round 0): the tables are folded with it and the new message accumulated in one pass.
  * out_evals receives max_degree ext elements (host memory). Synchronises the stream. */

@@ -196,6 +196,87 @@ def test_main_constraints_public_instance_atoms(dev, prover):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# eq-factored main-constraint rounds (ceno_hip_sumcheck_begin_eq, csrc/sumcheck_gen.hip "EQ-FACTORED FORM"): Whole / Prefix selectors are
+# declared as eq(., rt) on a row range; the rounds evaluate each chip's quotient at one point fewer and the host completes the messages
+# from the chips' running claims.  The words must be those of the oracle's prover — for row ranges that start and end anywhere (boundary
+# pairs in every round), several selectors per chip, chips whose selector is not of that form (generic rounds in the same sumcheck),
+# and messages of 3, 4 and 5 points.
+# ------------------------------------------------------------------------------------------------------------------
+def _eq_case_jobs(dev, case, max_degree):
+    w = 4
+    jobs, tabs, terms_all, scal_all, nvs = [], [], [], [], []
+    for c, (nv, sels) in enumerate(case):
+        cols = [po.rand_base(1 << nv, 7000 + 31 * c + j) for j in range(w)]
+        point = po.rand_ext(nv, 500 + c)
+        ns = len(sels)
+        sel_t = [(k, off, n, sid, tuple(sp), snv, point) for sid, (k, off, n, sp, snv) in enumerate(sels)]
+        terms = []
+        for sid in range(ns):  # every selector gates a few products of 1 .. max_degree - 1 columns
+            s = w + sid
+            terms += [[s, (sid + j) % w, (sid + j + 1) % w][: min(3, max_degree)] for j in range(2)]
+            terms += [[s, j % w] for j in range(2)]
+            if max_degree >= 4:
+                terms += [[s, 0, 2, 3], [s, 1, 2, 3]]
+            if max_degree >= 5:
+                terms += [[s, 0, 1, 2, 3]]
+        scalars = [[((5 + 3 * t + c, 1 + t), [2 + (t % 2)])] for t in range(len(terms))]
+        jobs.append(dict(num_vars=nv, mles=[dev.upload(t) for t in cols] + [None] * ns, n_witin=w, n_fixed=0, n_structural=ns, selectors=sel_t,
+                         n_exprs=2, max_degree=max_degree, terms=terms, scalars=scalars))
+        start = len(nvs)
+        nvs += [nv] * (w + ns)
+        tabs += cols + [po.selector_compute(k, point, off, n, tuple(sp), snv) for (k, off, n, sp, snv) in sels]
+        terms_all += [[start + j for j in t] for t in terms]
+        scal_all.append(scalars)
+    return jobs, tabs, terms_all, scal_all, nvs
+
+
+EQ_CASES = {
+    # (num_vars, [(kind, offset, num_instances, sparse indices, sparse num_vars), ...]) per chip
+    "prefix_ends_anywhere": [(15, [(po.SEL_PREFIX, 0, (1 << 15) - 5, (), 0)]), (14, [(po.SEL_PREFIX, 3, 100, (), 0)]),
+                             (14, [(po.SEL_PREFIX, 1, (1 << 14) - 1, (), 0)]), (13, [(po.SEL_PREFIX, 4097, 2047, (), 0)])],
+    "aligned_and_tiny": [(15, [(po.SEL_PREFIX, 1 << 14, 1 << 14, (), 0)]), (14, [(po.SEL_PREFIX, 0, 1, (), 0)]), (14, [(po.SEL_PREFIX, (1 << 14) - 1, 1, (), 0)]),
+                         (13, [(po.SEL_PREFIX, 0, 64, (), 0)]), (13, [(po.SEL_PREFIX, 64, 64, (), 0)]), (13, [(po.SEL_PREFIX, 0, (1 << 12) + 1, (), 0)])],
+    "whole_and_two_selectors": [(14, [(po.SEL_WHOLE, 0, 0, (), 0)]), (15, [(po.SEL_PREFIX, 0, 20000, (), 0), (po.SEL_PREFIX, 7, 12345, (), 0)]),
+                                (13, [(po.SEL_PREFIX, 0, 2, (), 0), (po.SEL_WHOLE, 0, 0, (), 0)])],
+    "generic_chip_in_the_batch": [(14, [(po.SEL_PREFIX, 0, 9999, (), 0)]), (13, [(po.SEL_ORDERED_SPARSE, 0, 200, (0, 2, 5), 3)]),
+                                  (15, [(po.SEL_PREFIX, 5, 30001, (), 0), (po.SEL_ORDERED_SPARSE, 0, 1000, (1, 3), 2)])],
+}
+
+
+@pytest.mark.parametrize("max_degree", [4, 3, 5])
+@pytest.mark.parametrize("name", sorted(EQ_CASES))
+def test_eq_factored_main_constraints_match_the_oracle(dev, prover, monkeypatch, name, max_degree):
+    gch = [(11, 22), (33, 44)]
+    jobs, tabs, terms, scal_all, nvs = _eq_case_jobs(dev, EQ_CASES[name], max_degree)
+    max_nv = max(nvs)
+    L = dev.L
+    before = L.ceno_hip_stat_eq_launches(dev.h)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+    launches = L.ceno_hip_stat_eq_launches(dev.h) - before
+    assert launches >= max_nv - 2, "the eq-factored rounds did not run"
+    t2 = po.StubTranscript(5)
+    t2.append_label(b"combine subset evals")
+    a = t2.sample_ext()
+    pows = [e2_pow(a, i) for i in range(2 * len(jobs))]
+    coeffs = []
+    for c, sc in enumerate(scal_all):
+        coeffs += oracle_scalars(sc, gch + pows[2 * c: 2 * c + 2])
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext(coeffs), terms, max_nv, max_degree, t2)
+    assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals)
+    # the same proof with the declarations ignored
+    monkeypatch.setenv("CENO_HIP_GEN_EQF", "0")
+    before = L.ceno_hip_stat_eq_launches(dev.h)
+    c2, m2, r2, e2 = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+    assert L.ceno_hip_stat_eq_launches(dev.h) == before
+    assert c2 == claimed and np.array_equal(m2, msgs) and np.array_equal(e2, evals)
+    if max_degree == 4:  # ... and through the staged first-round kernel instead of the direct one
+        monkeypatch.delenv("CENO_HIP_GEN_EQF")
+        monkeypatch.setenv("CENO_HIP_EQ_DIRECT0", "0")
+        c3, m3, r3, e3 = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+        assert c3 == claimed and np.array_equal(m3, msgs) and np.array_equal(e3, evals)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # BASELINE config #3 at full size
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("log_rows", [12, 20])
