@@ -2,6 +2,7 @@
 // Reference counterpart: the process-global `CUDA_HAL` with its memory pool and stream binding
 // (gkr_iop/src/gpu/mod.rs:53-154) and the alloc/copy entry points catalogued in SURVEY.md §2.2.
 #include "common.hpp"
+#include <chrono>
 
 #include <algorithm>
 #include <functional>
@@ -65,12 +66,30 @@ static bool stream_drained(hipStream_t s) {
     return true;
 }
 
+// pipelined sumchecks the CALLING thread has begun and not ended yet: a thread that holds none may wait for the trim gate (the lanes'
+// sumchecks end within milliseconds); one that does must not — its own queued kernels are among those a trim would wait for
+static thread_local int tls_pipelined = 0;
 void ctx_pipelined_begin(ceno_hip_ctx* ctx) {
     std::unique_lock<std::mutex> lk(ctx->gate_mu);
     ctx->gate_cv.wait(lk, [&] { return !ctx->trimming; });
     ctx->pipelined_live.fetch_add(1);
+    tls_pipelined++;
 }
-void ctx_pipelined_end(ceno_hip_ctx* ctx) { ctx->pipelined_live.fetch_sub(1); }
+void ctx_pipelined_end(ceno_hip_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> g(ctx->gate_mu);
+        ctx->pipelined_live.fetch_sub(1);
+    }
+    if (tls_pipelined > 0) tls_pipelined--;
+    ctx->gate_cv.notify_all();  // a thread waiting to trim (ctx_trim_begin_wait)
+}
+// take the trim gate as soon as no pipelined sumcheck is alive anywhere; only for threads that hold none themselves.  false: timed out
+static bool ctx_trim_begin_wait(ceno_hip_ctx* ctx, int timeout_ms) {
+    std::unique_lock<std::mutex> lk(ctx->gate_mu);
+    if (!ctx->gate_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !ctx->trimming && ctx->pipelined_live.load() == 0; })) return false;
+    ctx->trimming = true;
+    return true;
+}
 bool ctx_trim_begin(ceno_hip_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->gate_mu);
     if (ctx->trimming || ctx->pipelined_live.load() > 0) return false;
@@ -99,6 +118,10 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
             if (gate) ctx_trim_end(ctx);
         }
     } release{ctx, victims};
+    int attempt = 0;
+    bool need_gate;
+again:
+    need_gate = false;
     {
         std::lock_guard<std::mutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
@@ -147,20 +170,78 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
                 return 0;
             }
         }
-        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit && (release.gate = ctx_trim_begin(ctx))) {
-            // try to make room by dropping cached blocks (only while no pipelined sumcheck is alive: gate)
-            for (auto& kv : ctx->free_lists) {
-                for (auto& p : kv.second) {
-                    victims.push_back(p.first);
-                    ctx->pool_cached -= kv.first;
+        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
+            // over the limit with the cache counted in: blocks of the cache have to go back to the driver — possible only while no
+            // pipelined sumcheck is alive (the trim gate) — or a LARGER idle block of the cache serves the request as it is
+            if (release.gate || (release.gate = ctx_trim_begin(ctx))) {
+                for (auto& kv : ctx->free_lists) {
+                    for (auto& p : kv.second) {
+                        victims.push_back(p.first);
+                        ctx->pool_cached -= kv.first;
+                    }
+                    kv.second.clear();
                 }
-                kv.second.clear();
+            } else {
+                const hipStream_t cur = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
+                size_t best = 0;
+                int best_k = -1;
+                hipStream_t seen[16];
+                bool idle[16];
+                int n_seen = 0;
+                for (auto& kv : ctx->free_lists) {
+                    if (kv.first < b || (best && kv.first >= best)) continue;
+                    for (int k = (int)kv.second.size() - 1; k >= 0; k--) {
+                        const hipStream_t last = kv.second[k].second;
+                        bool ok = !last || last == cur || !stream_alive(ctx, last);
+                        if (!ok) {
+                            int j = 0;
+                            while (j < n_seen && seen[j] != last) j++;
+                            if (j == n_seen && n_seen < 16) {
+                                seen[n_seen] = last;
+                                idle[n_seen] = stream_drained(last);
+                                n_seen++;
+                            }
+                            ok = j < n_seen && idle[j];
+                        }
+                        if (ok) {
+                            best = kv.first;
+                            best_k = k;
+                            break;
+                        }
+                    }
+                }
+                if (best_k >= 0) {
+                    auto& fl = ctx->free_lists[best];
+                    void* p = fl[best_k].first;
+                    fl.erase(fl.begin() + best_k);
+                    ctx->pool_cached -= best;
+                    ctx->pool_used += best;
+                    ctx->live[p] = best;
+                    *out = p;
+                    return 0;
+                }
+                need_gate = true;
             }
         }
-        if (ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
+        if (!need_gate && ctx->pool_limit && ctx->pool_used + ctx->pool_cached + b > ctx->pool_limit) {
             ctx->err = "pool capacity exceeded";
             return CENO_HIP_ERR_OOM;
         }
+    }
+    if (need_gate) {
+        // lanes are proving and no idle block is large enough.  A thread with no pipelined sumcheck of its own waits for them (their
+        // rounds end within milliseconds) and trims then; one that has such a sumcheck alive cannot — a retryable failure
+        if (attempt == 0 && tls_pipelined == 0 && ctx_trim_begin_wait(ctx, 10000)) {
+            release.gate = true;
+            attempt = 1;
+            goto again;
+        }
+        bool hopeless;
+        {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            hopeless = ctx->pool_used + b > ctx->pool_limit;
+        }
+        return ctx_fail(ctx, CENO_HIP_ERR_OOM, hopeless ? "pool capacity exceeded" : "pool capacity exceeded while other lanes are proving (cached blocks cannot be returned now): retry");
     }
     void* p = nullptr;
     ctx_make_current(ctx);
@@ -233,7 +314,9 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     }
     hipError_t e = hipMalloc(&p, b);
     if (e != hipSuccess) {
-        // drop the cache and retry once
+        // drop the cache and retry once (a thread without a pipelined sumcheck of its own waits for the lanes' to end first:
+        // ceno_hip_mem_trim returns at once while any is alive)
+        if (tls_pipelined == 0 && ctx_trim_begin_wait(ctx, 10000)) ctx_trim_end(ctx);
         ceno_hip_mem_trim(ctx);
         e = hipMalloc(&p, b);
         if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));

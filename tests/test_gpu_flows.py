@@ -619,6 +619,61 @@ def test_pool_cache_does_not_grow_over_repeated_flows_with_lanes(prover):
     assert grown <= base // 4 + (8 << 20), (base, grown)
 
 
+def test_pool_limit_with_a_full_cache_does_not_fail_lanes(prover):
+    """pool_bytes set, the cache full of parked blocks (what a large batch leaves behind) and a pipelined sumcheck alive (another
+    lane proving): nothing can go back to the driver then (the trim gate), and `used + cached + request > limit` used to be
+    reported as 'pool capacity exceeded' although the cache held everything that was needed (round-3 advisor finding).  A request
+    now takes a larger idle block of the cache; failing that, a thread with no pipelined sumcheck of its own waits for the gate
+    and trims, and a thread that has one gets a retryable error instead of a deadlock."""
+    import threading
+
+    from ceno_amd import Device, api
+    from ceno_amd.api import CenoHipError
+
+    limit = 1 << 30
+    d = Device(0, pool_bytes=limit)
+    parked = [d.synthetic(24, False, 700 + i) for i in range(6)]     # 6 x 128 MiB of the 1 GiB ...
+    d.sync()
+    for m in parked:
+        m.free()                                                     # ... parked in the cache
+    assert d.mem_info()["pool_cached"] >= 6 << 27
+    nv = 16
+    tabs = [d.synthetic(nv, True, 40 + j) for j in range(3)]
+    sc = api.Sumcheck(d, tabs, po.ext([1]), [[0, 1, 2]], nv, 3)
+    sc.set_pipelined(True)
+    sc.round()                                                        # a pipelined sumcheck is alive from here on
+    # (1) same thread, a larger idle block exists: a 100 MiB request is served by a parked 128 MiB block
+    m1 = d.synthetic(23, True, 1)                                     # 128 MiB exactly: the ordinary reuse
+    m2 = d.alloc(23, False)                                           # 64 MiB: no block of that size; 704 + 64 MiB fits under the limit
+    big = d.mem_info()
+    assert big["pool_used"] + big["pool_cached"] <= limit
+    small = [d.alloc(23, False) for _ in range(3)]                    # 3 x 64 MiB more: over the limit with the cache counted in
+    assert d.mem_info()["pool_used"] + d.mem_info()["pool_cached"] <= limit  # ... served from the parked 128 MiB blocks
+    # (2) same thread, nothing large enough: retryable failure, not a hang
+    with pytest.raises(CenoHipError) as ei:
+        d.alloc(25, False)                                            # 256 MiB: larger than any parked block
+    assert "retry" in str(ei.value)
+    # (3) another thread (no pipelined sumcheck of its own) waits for the gate, trims and gets its block once this one is done
+    got = {}
+
+    def worker():
+        try:
+            got["m"] = d.alloc(25, False)
+        except Exception as e:  # noqa: BLE001
+            got["err"] = e
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join(0.3)
+    assert t.is_alive(), "the other thread should be waiting for the trim gate"
+    sc.free()                                                         # aborts the queued rounds: no pipelined sumcheck is alive any more
+    t.join(20)
+    assert not t.is_alive() and "m" in got, got.get("err")
+    for m in [m1, m2, got["m"]] + small + tabs:
+        m.free()
+    d.close()
+
+
 def test_cache_over_the_soft_cap_does_not_stall_lanes(prover):
     """A phase that leaves many GB in the pool's cache (the 13 GB batch of config #4) followed by concurrent chip proofs: the
     pool's soft cap must not call hipFree — which waits for every stream of the device — while round kernels of the lanes are
