@@ -71,6 +71,7 @@ def lib():
         "ceno_hip_stream_sync": (i, [vp, vp]),
         "ceno_hip_mem_info": (i, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
         "ceno_hip_mem_trim": (i, [vp]),
+        "ceno_hip_mem_peak": (sz, [vp, i]),
         "ceno_hip_mem_book": (i, [vp, sz]),
         "ceno_hip_mem_unbook": (i, [vp, sz]),
         "ceno_hip_mem_booked": (sz, [vp]),

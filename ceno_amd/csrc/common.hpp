@@ -34,6 +34,7 @@ struct ceno_hip_ctx {
     std::mutex mu;
     size_t pool_limit = 0;  // 0 = unlimited
     size_t pool_used = 0;   // bytes handed out
+    size_t pool_peak = 0;   // high-water mark of pool_used since the last ceno_hip_mem_peak(reset)
     size_t pool_cached = 0; // bytes parked in free lists
     size_t pool_booked = 0; // bytes promised to scheduled-but-not-yet-running tasks (ceno_hip_mem_book)
     size_t pool_capacity = 0;  // booking capacity: pool_limit, or the device memory size when unlimited

@@ -165,6 +165,7 @@ again:
                 fl.erase(fl.begin() + pick);
                 ctx->pool_cached -= b;
                 ctx->pool_used += b;
+                    ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_used);
                 ctx->live[p] = b;
                 *out = p;
                 return 0;
@@ -216,6 +217,7 @@ again:
                     fl.erase(fl.begin() + best_k);
                     ctx->pool_cached -= best;
                     ctx->pool_used += best;
+                    ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_used);
                     ctx->live[p] = best;
                     *out = p;
                     return 0;
@@ -323,6 +325,7 @@ again:
     }
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->pool_used += b;
+                    ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_used);
     ctx->live[p] = b;
     *out = p;
     return 0;
@@ -647,6 +650,14 @@ int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_
     if (pipelined_live) *pipelined_live = ctx->pipelined_live.load();
     if (mid_units_in_flight) *mid_units_in_flight = ctx->mid_wgs_in_flight.load();
     return 0;
+}
+
+size_t ceno_hip_mem_peak(ceno_hip_ctx* ctx, int reset) {
+    if (!ctx) return 0;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const size_t v = ctx->pool_peak;
+    if (reset) ctx->pool_peak = ctx->pool_used;
+    return v;
 }
 
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {

@@ -131,6 +131,33 @@ int chip_job_fn(void* arg, int lane, ceno_hip_stream stream) {
 }
 }  // namespace
 
+// Device bytes one chip proof allocates on top of its (borrowed) tables — what the scheduler books before it starts the task (the
+// reference's estimator: ceno_zkvm/src/scheme/gpu/memory.rs:54-145, checked there against real usage; here
+// tests/test_gpu_flows.py::test_chip_proof_booking_estimate_covers_the_pool_high_water_mark holds it between 1x and 2x the pool's
+// high-water mark).  All tables are extension-field tables of `rows` entries: the records; per product tower the interleaved last
+// layer of rows * next_pow2(k) entries and the layers above it (2x); the LogUp tower with numerators and denominators (4 limbs); the
+// ping-pong buffers of the largest layer's sumcheck.
+extern "C" size_t ceno_prover_chip_proof_estimate_bytes(const ceno_chip_task* t) {
+    if (!t) return 0;
+    auto np2 = [](size_t k) {
+        size_t p = 1;
+        while (p < k) p <<= 1;
+        return p;
+    };
+    const double rows = (double)((size_t)1 << (t->log2_num_instances + t->rotation_vars));
+    const size_t n_lk = t->num_lk_tables > 0 ? 2 * (size_t)t->num_lk_tables : (size_t)t->num_lk;
+    const size_t n_rec = (size_t)t->num_reads + t->num_writes + n_lk;
+    double bytes = 16.0 * rows * (double)(n_rec ? n_rec : 1);                      // records
+    double last_layers = 0.0;
+    if (t->num_reads) last_layers += 16.0 * rows * (double)np2(t->num_reads);       // product towers: last layer (2 limbs)
+    if (t->num_writes) last_layers += 16.0 * rows * (double)np2(t->num_writes);
+    if (n_lk) last_layers += 2.0 * 16.0 * rows * (double)np2(n_lk);                 // LogUp tower: 4 limbs
+    bytes += 2.0 * last_layers;                                                     // all layers of the towers
+    bytes += 0.75 * last_layers;                                                    // sumcheck ping (1/2) + pong (1/4) of the largest layer
+    bytes += 32.0 * rows * (double)(t->n_rotation_pairs > 0 ? 2 * t->n_rotation_pairs + 2 : 0);  // rotated copies + selector of the rotation argument
+    return (size_t)(bytes * 1.15) + ((size_t)4 << 20);                              // bucket rounding, small fixed blocks
+}
+
 extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4,
                                               ceno_transcript* const* transcripts, int n_lanes, ceno_chip_proof* out_proofs, int* out_status) {
     if (!ctx || !tasks || !challenges4 || !transcripts || !out_proofs || n_tasks < 0 || n_lanes < 1)
@@ -140,11 +167,7 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
     for (int i = 0; i < n_tasks; i++) {
         if (!transcripts[i]) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proofs: NULL transcript");
         jobs[i] = ChipJob{ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i]};
-        const ceno_chip_task& t = tasks[i];
-        const size_t rows = (size_t)1 << (t.log2_num_instances + t.rotation_vars);
-        const size_t n_rec = (size_t)t.num_reads + t.num_writes + (t.num_lk_tables > 0 ? 2 * (size_t)t.num_lk_tables : (size_t)t.num_lk);
-        // records (16 B x rows each), towers ~ 2 x the interleaved records, sumcheck ping-pong ~ 0.75 x the tower's last layer
-        lt[i] = ceno_lane_task{chip_job_fn, &jobs[i], (size_t)(16.0 * (double)rows * (double)(n_rec ? n_rec : 1) * 4.0)};
+        lt[i] = ceno_lane_task{chip_job_fn, &jobs[i], ceno_prover_chip_proof_estimate_bytes(&tasks[i])};
     }
     return ceno_prover_lanes_run(ctx, std::min(n_lanes, std::max(n_tasks, 1)), lt.data(), n_tasks, out_status, nullptr);
 }

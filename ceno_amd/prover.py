@@ -869,6 +869,15 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
         L.ceno_chip_proof_free(C.byref(out))
 
 
+def chip_proof_estimate_bytes(task: dict) -> int:
+    """ceno_prover_chip_proof_estimate_bytes: what the lane scheduler books for this chip proof"""
+    L = plib()
+    L.ceno_prover_chip_proof_estimate_bytes.restype = C.c_size_t
+    L.ceno_prover_chip_proof_estimate_bytes.argtypes = [C.POINTER(ChipTaskC)]
+    T, keep = _marshal_chip_task(task)
+    return int(L.ceno_prover_chip_proof_estimate_bytes(C.byref(T)))
+
+
 class ChipTasks:
     """the C view of a list of chip tasks, marshalled once (a Rust caller hands the structs over directly)"""
 

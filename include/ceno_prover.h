@@ -206,6 +206,9 @@ typedef struct ceno_chip_proof {
 int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
                                   ceno_hip_stream s, ceno_chip_proof* out);
 void ceno_chip_proof_free(ceno_chip_proof* p);
+/* device bytes a chip proof allocates on top of its borrowed tables: the booking estimate ceno_prover_create_chip_proofs uses (the
+ * reference's estimator, ceno_zkvm/src/scheme/gpu/memory.rs:54-145); held between 1x and 2x the pool's high-water mark by the GPU tests */
+size_t ceno_prover_chip_proof_estimate_bytes(const ceno_chip_task* task);
 
 /* prove_rotation (gkr_iop/src/gkr/layer/cpu/mod.rs:249-389; GPU arm layer/gpu/mod.rs:305-462): for pairs
  * (source_j, target_j) of base-field witness tables prove  0 = sum_b sel(b) sum_j alpha^j (rotated(source_j)(b) - target_j(b))

@@ -619,6 +619,36 @@ def test_pool_cache_does_not_grow_over_repeated_flows_with_lanes(prover):
     assert grown <= base // 4 + (8 << 20), (base, grown)
 
 
+@pytest.mark.parametrize("log_rows,n_reads,n_writes,n_lk", [(12, 4, 4, 8), (16, 1, 1, 1), (18, 4, 4, 8), (17, 2, 3, 5)])
+def test_chip_proof_booking_estimate_covers_the_pool_high_water_mark(prover, log_rows, n_reads, n_writes, n_lk):
+    """what the lane scheduler books for a chip proof (ceno_prover_chip_proof_estimate_bytes) against what the proof really takes from
+    the pool (ceno_hip_mem_peak): the reference asserts its estimator against actual usage (scheme/gpu/memory.rs:54-145); here
+    high-water <= estimate <= 2 x high-water + 8 MiB on chips of different heights and record counts"""
+    from ceno_amd import Device, synthetic
+
+    d = Device(0)
+    w = 12
+    cols = [d.synthetic(log_rows, False, 300 + j) for j in range(w)]
+    alpha, beta = (5, 6), (7, 8)
+    n_rec = n_reads + n_writes + n_lk
+    coeffs, terms, out_terms = synthetic.record_plan(w, n_rec, alpha, beta)
+    task = dict(mles=cols, n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << log_rows) - 3, log2_num_instances=log_rows, num_reads=n_reads,
+                num_writes=n_writes, num_lk_tables=0, num_lk=n_lk, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+    est = prover.chip_proof_estimate_bytes(task)
+    prover.create_chip_proof(d, task, [alpha, beta], prover.Transcript.stub(3))   # warm: code objects, pinned blocks
+    d.sync()
+    base = d.mem_info()["pool_used"]
+    d.L.ceno_hip_mem_peak(d.h, 1)
+    prover.create_chip_proof(d, task, [alpha, beta], prover.Transcript.stub(3))
+    d.sync()
+    peak = int(d.L.ceno_hip_mem_peak(d.h, 0)) - base
+    print(f"chip 2^{log_rows} x ({n_reads},{n_writes},{n_lk}): high-water {peak / 2**20:.1f} MiB, estimate {est / 2**20:.1f} MiB, ratio {est / max(peak, 1):.2f}")
+    assert peak <= est <= 2 * peak + (8 << 20), (peak, est)
+    for m in cols:
+        m.free()
+    d.close()
+
+
 def test_pool_limit_with_a_full_cache_does_not_fail_lanes(prover):
     """pool_bytes set, the cache full of parked blocks (what a large batch leaves behind) and a pipelined sumcheck alive (another
     lane proving): nothing can go back to the driver then (the trim gate), and `used + cached + request > limit` used to be
