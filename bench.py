@@ -388,6 +388,68 @@ def main():
             m.free()
         return out
 
+    def dist_commit_extra() -> dict:
+        """N > 1: the multi-rank commitment (ceno_dist_commit_traces_mmcs: column-sharded RS encoding, ONE grouped ncclSend / ncclRecv
+        re-shard by rows, local sub-tree, replicated top levels — DESIGN.md section 6) on two small synthetic traces of different
+        heights, validated against the single-device root computed by rank 0, then timed.  Guarded exactly like the RCCL sumcheck arm:
+        without a validated RCCL communicator it reports why and the bench goes on; a rank that fails reports it through the
+        all-reduce; a collective that never returns is caught by the caller's watchdog (non-zero exit of the process)."""
+        if "rccl" not in comms:
+            return {"status": "skipped: no RCCL communicator on this launch (the re-shard by rows is a device-to-device exchange)"}
+        import ctypes as C
+
+        from ceno_amd import dist as cdist2
+
+        log_rows, cols_per_rank, blow = [14, 10], [2, 1], 1
+        ok, root, info = 1, None, {}
+        try:
+            mine = [dev.synthetic(lr + (c.bit_length() - 1), False, 0xC0117 + 97 * m + rank) for m, (lr, c) in enumerate(zip(log_rows, cols_per_rank))]
+            dev.sync()
+            widths = [[c] * world for c in cols_per_rank]
+            cst = dev.stream_create()
+
+            def run_once():
+                r_ = cdist2.sharded_commit_mmcs_native(dev, comms["rccl"].h, [m_.device_ptr for m_ in mine], widths, log_rows, blow, rank, cst)
+                dev.sync(cst)
+                for key in ("subtree", "top"):
+                    if r_.get(key):
+                        dev.L.ceno_hip_merkle_free(dev.h, r_[key])
+                return r_["root"]
+
+            root = run_once()
+            if rank == 0:  # the same traces on ONE device: all ranks' columns side by side, row-major on the host -> commit_traces
+                mats = []
+                for m, (lr, c) in enumerate(zip(log_rows, cols_per_rank)):
+                    cols = []
+                    for g in range(world):
+                        t = dev.synthetic(lr + (c.bit_length() - 1), False, 0xC0117 + 97 * m + g)
+                        cols.append(t.download().reshape(c, 1 << lr))
+                        t.free()
+                    mats.append(np.ascontiguousarray(np.concatenate(cols, axis=0).T))
+                pcs = prover.PcsData(dev, mats, blow, stream)
+                want = pcs.root()
+                pcs.free()
+                ok = 1 if np.array_equal(np.asarray(want, dtype=np.uint64).reshape(-1), np.asarray(root, dtype=np.uint64).reshape(-1)) else 0
+                info["root_matches_single_device"] = bool(ok)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: multi-rank commit failed on rank {rank}: {e}", file=sys.stderr)
+            ok, info["error"] = 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            return {"status": "failed validation (reported, bench continues)", **info}
+        reps = 5
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(reps):
+            run_once()
+        barrier()
+        ms = max_over_ranks(time.perf_counter() - t_) / reps * 1e3
+        for m_ in mine:
+            m_.free()
+        return {"status": "ok", "ms": ms, "workload": f"ceno_dist_commit_traces_mmcs: traces of 2^{log_rows[0]} x {cols_per_rank[0] * world} and 2^{log_rows[1]} x "
+                f"{cols_per_rank[1] * world} base elements column-sharded over {world} ranks, blow-up 2, ONE root", **info}
+
     def line(m: dict, scaling: str) -> dict:
         n_local, n_total = m["n_local"], m["n_total"]
         dt, kernel_ms, launches = m["dt"], m["kernel_ms"], m["launches"]
@@ -455,6 +517,29 @@ def main():
         if strong is not None and weak is not None:
             res["weak_scaling"] = {k: weak[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "collective_ms", "roofline")}
     n_local = res["config"]["num_vars_per_gpu"]
+    if world > 1 and not args.no_extra:
+        # the multi-rank commitment as an extra, under a watchdog: a collective that never returns must not take the headline along —
+        # rank 0 prints the line it has, and the process exits non-zero
+        import threading
+
+        box = {}
+
+        def run_extra():
+            try:
+                box["r"] = dist_commit_extra()
+            except Exception as e:  # noqa: BLE001
+                box["r"] = {"status": f"failed: {type(e).__name__}: {e}"}
+
+        th = threading.Thread(target=run_extra, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("CENO_BENCH_DIST_COMMIT_TIMEOUT_S", "120")))
+        if th.is_alive():
+            res.setdefault("extra", {})["dist_commit"] = {"status": "timeout: the multi-rank commit did not return (reported, process exits non-zero)"}
+            if rank == 0:
+                print(json.dumps(res))
+                sys.stdout.flush()
+            os._exit(4)
+        res.setdefault("extra", {})["dist_commit"] = box["r"]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
