@@ -502,6 +502,12 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
                 "schedule_bytes_per_step": m["prof_bytes"] / args.steps if args.steps else None,
                 "schedule_gbps": (m["prof_bytes"] / (kernel_ms * 1e-3) / 1e9) if kernel_ms > 0 else None,
+                # against what THIS schedule can reach on this chip (tools/ubench_bw.hip, profiles/r03_dense_kernel_ab.json): the read-only
+                # round streams at 6.45 TB/s, the fold rounds (read four elements, write two per table) at 5.79 TB/s; the fraction is
+                # (time the schedule's bytes need at those ceilings) / (measured kernel time)
+                "schedule_ceiling_frac": ((K * 16 * (1 << n_local) / 6.45e12 + (m["prof_bytes"] / args.steps - K * 16 * (1 << n_local)) / 5.79e12)
+                                          / (kernel_ms * 1e-3 / args.steps)) if kernel_ms > 0 and args.steps else None,
+                "schedule_ceilings_gbps": {"read_only_round": 6450.0, "fold_rounds": 5790.0},
             },
         }
 
@@ -557,9 +563,9 @@ def main():
                 cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sumcheck_nv26_pmc_traffic.json")))
                 if cands:
                     pm = json.load(open(cands[-1]))
-                    # per launch of the timed pass above (one round kernel per round; the PMC run itself is pipelined and hands its
-                    # small rounds to the persistent ladder, so its own launch count is not the divisor)
-                    res["roofline"]["traffic"] = pm["hbm_bytes_per_sumcheck"] * args.steps / max(int(res["roofline"]["launches"]), 1)
+                    # HBM bytes of ONE sumcheck (= one step) by the PMC counters; `achieved` is that step's algorithmic bytes over its kernel time
+                    res["roofline"]["traffic"] = pm["hbm_bytes_per_sumcheck"]
+                    res["roofline"]["traffic_unit"] = "HBM bytes per sumcheck (one step), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"
                     res["roofline"]["traffic_per_sumcheck"] = pm["hbm_bytes_per_sumcheck"]
                     res["roofline"]["traffic_source"] = os.path.relpath(cands[-1], ROOT)
         except Exception:

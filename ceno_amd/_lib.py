@@ -113,6 +113,7 @@ def lib():
         "ceno_hip_tower_out_evals": (i, [vp, vp, u64p, vp]),
         "ceno_hip_tower_download_top": (i, [vp, vp, i, u64p, vp]),
         "ceno_hip_tower_top_layers": (i, [vp]),
+        "ceno_hip_tower_prefetch_tops": (i, [vp, vpp, i, i, vp]),
         "ceno_hip_tower_num_limbs": (i, [vp]),
         "ceno_hip_tower_free": (i, [vp, vp]),
         "ceno_hip_tower_layer_sumcheck_begin": (i, [vp, vpp, i, vpp, i, i, u64p, u64p, vp, vpp]),

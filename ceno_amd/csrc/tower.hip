@@ -24,6 +24,10 @@ struct ceno_hip_tower {
     // layers 0 .. top_layers-1 live back to back in ONE block (layer l at element offset n_limbs * (2^l - 1)): the host proves
     // the small layers itself from a single copy of that block (ceno_hip_tower_download_top)
     int top_layers = 0;
+    // host copy of the layers 0 .. host_top_layers-1 (ceno_hip_tower_prefetch_tops: ONE synchronisation for all towers of a chip);
+    // ceno_hip_tower_out_evals / ceno_hip_tower_download_top are served from it.  A tower is immutable once built.
+    std::vector<uint64_t> host_top;
+    int host_top_layers = 0;
 };
 static constexpr int TOWER_TOP_LAYERS = 11;  // layers of up to 2^10 entries per limb
 
@@ -327,15 +331,55 @@ int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int li
 
 int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out, ceno_hip_stream s) {
     CHECK_ARG(ctx, t && out, "NULL argument");
+    if (t->host_top_layers >= 1) {  // prefetched (ceno_hip_tower_prefetch_tops): layer 0 heads the block
+        memcpy(out, t->host_top.data(), (size_t)t->n_limbs * sizeof(E2));
+        return 0;
+    }
     hipStream_t st = ctx_stream(ctx, s);
     HIP_TRY(ctx, hipMemcpyAsync(out, t->layers[0], (size_t)t->n_limbs * sizeof(E2), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return 0;
 }
 
+int ceno_hip_tower_prefetch_tops(ceno_hip_ctx* ctx, ceno_hip_tower* const* towers, int n_towers, int n_layers, ceno_hip_stream s) {
+    CHECK_ARG(ctx, towers && n_towers >= 0 && n_layers >= 1, "tower prefetch: bad arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    // every tower's top block into ONE pinned staging block, one wait for all of them (a copy into pageable memory per tower — and per
+    // out-evaluation — cost a staged blit and a synchronisation each: nine per chip proof, ~30 us apiece)
+    std::vector<size_t> off((size_t)n_towers + 1, 0);
+    std::vector<int> nl((size_t)n_towers, 0);
+    for (int i = 0; i < n_towers; i++) {
+        CHECK_ARG(ctx, towers[i], "tower prefetch: tower %d is NULL", i);
+        nl[(size_t)i] = std::min(n_layers, towers[i]->top_layers);
+        off[(size_t)i + 1] = off[(size_t)i] + (size_t)towers[i]->n_limbs * (((size_t)1 << nl[(size_t)i]) - 1) * sizeof(E2);
+    }
+    if (off[(size_t)n_towers] == 0) return 0;
+    void *hb = nullptr, *db = nullptr;
+    TRY(ctx_pinned_alloc(ctx, off[(size_t)n_towers], &hb, &db));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n_towers && e == hipSuccess; i++)
+        if (off[(size_t)i + 1] > off[(size_t)i])
+            e = hipMemcpyAsync((char*)hb + off[(size_t)i], towers[i]->layers[0], off[(size_t)i + 1] - off[(size_t)i], hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) {
+        for (int i = 0; i < n_towers; i++) {
+            const uint64_t* src = reinterpret_cast<const uint64_t*>((char*)hb + off[(size_t)i]);
+            towers[i]->host_top.assign(src, src + (off[(size_t)i + 1] - off[(size_t)i]) / 8);
+            towers[i]->host_top_layers = nl[(size_t)i];
+        }
+    }
+    ctx_pinned_free(ctx, hb);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower prefetch: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int ceno_hip_tower_download_top(ceno_hip_ctx* ctx, ceno_hip_tower* t, int n_layers, uint64_t* host_out, ceno_hip_stream s) {
     CHECK_ARG(ctx, t && host_out, "NULL argument");
     CHECK_ARG(ctx, n_layers >= 1 && n_layers <= t->top_layers, "tower: %d top layers requested, %d are contiguous", n_layers, t->top_layers);
+    if (n_layers <= t->host_top_layers) {  // prefetched (ceno_hip_tower_prefetch_tops)
+        memcpy(host_out, t->host_top.data(), (size_t)t->n_limbs * (((size_t)1 << n_layers) - 1) * sizeof(E2));
+        return 0;
+    }
     hipStream_t st = ctx_stream(ctx, s);
     HIP_TRY(ctx, hipMemcpyAsync(host_out, t->layers[0], (size_t)t->n_limbs * (((size_t)1 << n_layers) - 1) * sizeof(E2), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -17,7 +17,8 @@
 
 #include "../../include/ceno_prover.h"
 
-int prover_set_error(int code, const char* msg);  // prover.cpp
+int prover_set_error(int code, const char* msg);
+int prover_tower_host_layers();  // prover.cpp: tower layers the host proves (CENO_TOWER_HOST_LAYERS)  // prover.cpp
 
 namespace {
 
@@ -74,20 +75,30 @@ int ceno_prover_build_tower_witness(ceno_hip_ctx* ctx, ceno_hip_mle* const* reco
     if (num_reads > 0) {
         rc = ceno_hip_tower_build_prod(ctx, r_set, num_reads, active_rows, one, s, &out->prod[out->n_prod]);
         if (!rc && ceno_hip_tower_num_vars(out->prod[out->n_prod]) != group_num_vars(num_reads)) rc = CENO_HIP_ERR_STATE;
-        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->prod[out->n_prod], out->r_out_evals, s);
         if (!rc) { out->has_r = 1; out->n_prod++; }
     }
     if (!rc && num_writes > 0) {
         rc = ceno_hip_tower_build_prod(ctx, w_set, num_writes, active_rows, one, s, &out->prod[out->n_prod]);
         if (!rc && ceno_hip_tower_num_vars(out->prod[out->n_prod]) != group_num_vars(num_writes)) rc = CENO_HIP_ERR_STATE;
-        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->prod[out->n_prod], out->w_out_evals, s);
         if (!rc) { out->has_w = 1; out->n_prod++; }
     }
     if (!rc && n_lk_den > 0) {
         rc = ceno_hip_tower_build_logup(ctx, n_lk_num > 0 ? lk_n : nullptr, lk_d, n_lk_den, active_rows, alpha, s, &out->logup[0]);
         if (!rc && ceno_hip_tower_num_vars(out->logup[0]) != group_num_vars(n_lk_den)) rc = CENO_HIP_ERR_STATE;
-        if (!rc) rc = ceno_hip_tower_out_evals(ctx, out->logup[0], out->lk_out_evals, s);
         if (!rc) { out->has_lk = 1; out->n_logup = 1; }
+    }
+    if (!rc) {
+        // the three builds are queued back to back; ONE copy + wait brings the top layers of all towers to the host — the out-evaluations
+        // (layer 0) now, the layers the tower prover proves on the host later (ceno_hip_tower_prefetch_tops)
+        ceno_hip_tower* all[3];
+        int n_all = 0;
+        for (int i = 0; i < out->n_prod; i++) all[n_all++] = out->prod[i];
+        if (out->n_logup) all[n_all++] = out->logup[0];
+        rc = ceno_hip_tower_prefetch_tops(ctx, all, n_all, prover_tower_host_layers() + 1, s);
+        int k = 0;
+        if (!rc && out->has_r) rc = ceno_hip_tower_out_evals(ctx, out->prod[k++], out->r_out_evals, s);
+        if (!rc && out->has_w) rc = ceno_hip_tower_out_evals(ctx, out->prod[k++], out->w_out_evals, s);
+        if (!rc && out->has_lk) rc = ceno_hip_tower_out_evals(ctx, out->logup[0], out->lk_out_evals, s);
     }
     if (rc) {
         std::string msg = rc == CENO_HIP_ERR_STATE ? "build_tower_witness: tower height differs from group_num_vars" : ceno_hip_last_error(ctx);

@@ -347,6 +347,9 @@ void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_acti
 }
 }  // namespace
 
+}  // extern "C"
+int prover_tower_host_layers() { return std::max(tower_host_layers(), 0); }
+extern "C" {
 int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
                                    ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out) {
     if (!ctx || !tr || !out) return fail(CENO_HIP_ERR_INVALID, "NULL argument");

@@ -268,6 +268,9 @@ int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out
  * layers needs ONE copy: layers 0 .. n_layers-1 into host_out, layer l limb b at element offset n_limbs * (2^l - 1) + b * 2^l
  * (n_limbs * (2^n_layers - 1) extension elements in all; n_layers <= ceno_hip_tower_top_layers).  Synchronises. */
 int ceno_hip_tower_download_top(ceno_hip_ctx* ctx, ceno_hip_tower* t, int n_layers, uint64_t* host_out, ceno_hip_stream s);
+/* the same copy for SEVERAL towers with one synchronisation (the towers of a chip): layers 0 .. min(n_layers, top layers) - 1 of each go to
+ * a host-side cache inside the handle, from which ceno_hip_tower_out_evals and ceno_hip_tower_download_top are then served */
+int ceno_hip_tower_prefetch_tops(ceno_hip_ctx* ctx, ceno_hip_tower* const* towers, int n_towers, int n_layers, ceno_hip_stream s);
 int ceno_hip_tower_top_layers(const ceno_hip_tower* t);  /* how many layers are contiguous (min(num_vars, 11)) */
 int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t);
 
