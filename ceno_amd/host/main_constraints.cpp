@@ -63,6 +63,10 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     std::vector<std::vector<int>> sel_k_by_id(n_jobs);  // which selector of the job stands for a structural id
     std::vector<ceno_hip_mle*> owned;
     auto cleanup = [&]() { for (auto* m : owned) ceno_hip_mle_free(ctx, m); };
+    // Whole / Prefix selectors (every chip's sel_all: the common case) are built together, two launches for the batch; the other kinds one
+    // at a time.  First selector per structural id wins.
+    struct Pending { int c, id, k; };
+    std::vector<Pending> batch;
     for (int c = 0; c < n_jobs; c++) {
         const ceno_main_job& J = jobs[c];
         sel_by_id[c].assign(J.n_structural, nullptr);
@@ -70,7 +74,12 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         for (int k = 0; k < J.n_selectors; k++) {
             const int id = J.sel_structural_id[k];
             if (id < 0 || id >= J.n_structural) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "selector wit id out of range"); }
-            if (sel_by_id[c][id]) continue;
+            if (sel_k_by_id[c][id] >= 0) continue;
+            sel_k_by_id[c][id] = k;
+            if (J.sel_kind[k] == CENO_HIP_SEL_WHOLE || J.sel_kind[k] == CENO_HIP_SEL_PREFIX) {
+                batch.push_back(Pending{c, id, k});
+                continue;
+            }
             ceno_hip_mle* m = nullptr;
             int rc = ceno_hip_selector_build(ctx, J.sel_kind[k], J.sel_points[k], J.num_vars, J.sel_offset[k], J.sel_num_instances[k],
                                              J.sel_sparse_indices ? J.sel_sparse_indices[k] : nullptr, J.sel_n_sparse ? J.sel_n_sparse[k] : 0,
@@ -78,7 +87,28 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
             owned.push_back(m);
             sel_by_id[c][id] = m;
-            sel_k_by_id[c][id] = k;
+        }
+    }
+    if (!batch.empty()) {
+        const int nb = (int)batch.size();
+        std::vector<int> kinds(nb), nvs(nb);
+        std::vector<const uint64_t*> pts(nb);
+        std::vector<size_t> offs(nb), nins(nb);
+        std::vector<ceno_hip_mle*> outs(nb, nullptr);
+        for (int b = 0; b < nb; b++) {
+            const ceno_main_job& J = jobs[batch[b].c];
+            const int k = batch[b].k;
+            kinds[b] = J.sel_kind[k];
+            nvs[b] = J.num_vars;
+            pts[b] = J.sel_points[k];
+            offs[b] = J.sel_offset[k];
+            nins[b] = J.sel_num_instances[k];
+        }
+        int rc = ceno_hip_selector_build_batch(ctx, nb, kinds.data(), pts.data(), nvs.data(), offs.data(), nins.data(), s, outs.data());
+        if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        for (int b = 0; b < nb; b++) {
+            owned.push_back(outs[b]);
+            sel_by_id[batch[b].c][batch[b].id] = outs[b];
         }
     }
     const double t_sel = dbg ? (ceno_hip_stream_sync(ctx, s), now_us()) : 0;

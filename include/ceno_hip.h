@@ -149,6 +149,11 @@ int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, co
 int ceno_hip_selector_build(ceno_hip_ctx* ctx, int kind, const uint64_t* point, int num_vars, size_t offset, size_t num_instances,
                             const uint32_t* sparse_indices, int n_sparse, int sparse_num_vars, ceno_hip_stream s, ceno_hip_mle** out);
 
+/* all Whole / Prefix selectors of a batch (the chips of prove_batched_main_constraints, ceno_zkvm/src/scheme/cpu/mod.rs:1200-1234) in two
+ * launches; table k = ceno_hip_selector_build(kinds[k], points[k], num_vars[k], offsets[k], num_instances[k]).  Other kinds: one at a time. */
+int ceno_hip_selector_build_batch(ceno_hip_ctx* ctx, int n, const int* kinds, const uint64_t* const* points, const int* num_vars,
+                                  const size_t* offsets, const size_t* num_instances, ceno_hip_stream s, ceno_hip_mle** outs);
+
 /* ------------------------------------------------------------------------------------------------
  * rotation argument of the keccak-style chips  (rotation_next_base_mle_gpu / rotation_selector_gpu,
  * gkr_iop/src/gkr/layer/gpu/utils.rs:231-336; semantics gkr_iop/src/utils.rs:19-76,
