@@ -44,6 +44,8 @@ struct ceno_hip_ctx {
     std::unordered_map<size_t, std::vector<std::pair<void*, hipStream_t>>> free_lists;
     std::unordered_map<void*, size_t> live;  // ptr -> bucket size
     std::vector<hipStream_t> streams;        // streams created through the C ABI that are still alive
+    std::atomic<unsigned> stream_gen{0};     // bumped by ceno_hip_stream_destroy: a thread's "already adopted" shortcut is only valid within one generation
+    bool xcd_private_l2 = true;              // gfx942 / gfx950: workgroup-scope atomics of one XCD meet in that XCD's L2 (witgen.hip lookup counters)
     std::vector<hipStream_t> lane_streams;   // the context's own lane streams (ceno_hip_lane_stream): created once, reused by every scheduler run
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
@@ -115,12 +117,18 @@ void ctx_make_current(ceno_hip_ctx* ctx);
 // every entry point that touches the device resolves its stream through here, which also makes the device current
 extern thread_local hipStream_t ceno_tls_stream;   // the stream the calling thread resolved last (ctx.hip)
 extern thread_local hipStream_t ceno_tls_adopted;  // the last caller-made stream this thread registered with the context
+extern thread_local unsigned ceno_tls_adopted_gen; // ... and the context's stream generation at that moment
 void ctx_adopt_stream(ceno_hip_ctx* ctx, hipStream_t s);
 inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     ctx_make_current(ctx);
-    if (s && (hipStream_t)s != ceno_tls_adopted) {  // streams the library did not create are adopted on first use
+    // streams the library did not create are adopted on first use.  The per-thread shortcut holds only while no stream has been destroyed
+    // since: a handle destroyed on ANOTHER thread can come back at the same address, and a thread that still remembered it would skip the
+    // adoption — the pool would then treat the stream as dead and hand its tagged blocks out while its work is still queued
+    const unsigned gen = ctx->stream_gen.load(std::memory_order_acquire);
+    if (s && ((hipStream_t)s != ceno_tls_adopted || gen != ceno_tls_adopted_gen)) {
         ctx_adopt_stream(ctx, (hipStream_t)s);
         ceno_tls_adopted = (hipStream_t)s;
+        ceno_tls_adopted_gen = gen;
     }
     return ceno_tls_stream = (s ? (hipStream_t)s : ctx->default_stream);
 }

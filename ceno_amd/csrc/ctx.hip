@@ -43,6 +43,7 @@ static size_t bucket_size(size_t bytes) {
 
 thread_local hipStream_t ceno_tls_stream = nullptr;
 thread_local hipStream_t ceno_tls_adopted = nullptr;
+thread_local unsigned ceno_tls_adopted_gen = 0;
 
 static bool stream_alive(ceno_hip_ctx* ctx, hipStream_t s) {
     if (s == ctx->default_stream) return true;
@@ -463,7 +464,12 @@ int ceno_hip_init(int device, size_t pool_bytes, ceno_hip_ctx** out) {
     ctx->device = device;
     ctx->pool_limit = pool_bytes;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cus = prop.multiProcessorCount;
+        // the XCD-private lookup counters of the witness kernels rely on gfx942 / gfx950 behaviour (workgroup-scope atomics of the workgroups
+        // of one XCD meet in that XCD's L2, HW_REG_XCC_ID names the XCD): any other target takes device-scope atomics
+        ctx->xcd_private_l2 = strncmp(prop.gcnArchName, "gfx942", 6) == 0 || strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    }
     e = hipStreamCreateWithFlags(&ctx->default_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
@@ -596,6 +602,7 @@ int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
                 break;
             }
     }
+    ctx->stream_gen.fetch_add(1, std::memory_order_release);  // every thread re-adopts a caller-made stream at this address
     if (ceno_tls_stream == (hipStream_t)s) ceno_tls_stream = nullptr;
     if (ceno_tls_adopted == (hipStream_t)s) ceno_tls_adopted = nullptr;
     HIP_TRY(ctx, hipStreamDestroy((hipStream_t)s));

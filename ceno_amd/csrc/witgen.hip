@@ -263,7 +263,8 @@ struct LkTab {
 constexpr size_t DYN_USED_16 = (size_t)1 << 17;
 template <class Launch>
 int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[4], Launch&& launch) {
-    static const bool xcd_local = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    static const bool xcd_wanted = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    const bool xcd_local = xcd_wanted && ctx->xcd_private_l2;  // (gfx942 / gfx950 only: ctx.hip)
     const bool any = tabs[0].user || tabs[1].user || tabs[2].user || tabs[3].user;
     if (!(xcd_local && any && n > 0)) {
         launch(false, tabs[0].user, tabs[1].user, tabs[2].user, tabs[3].user);

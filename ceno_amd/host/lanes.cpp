@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <map>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -20,8 +22,26 @@
 
 int prover_set_error(int code, const char* msg);  // prover.cpp
 
+// the lane streams belong to the CONTEXT: two runs on one context at the same time would interleave on the same four streams (the pool's
+// tags and drain checks would see one owner, and one run's round kernels would queue behind the other's host-waiting kernels), so runs on
+// one context take turns
+static std::mutex g_runs_mu;
+static std::map<ceno_hip_ctx*, std::shared_ptr<std::mutex>> g_runs;
+extern "C" int ceno_prover_lanes_effective(int n_lanes) {
+    const char* e = getenv("CENO_HIP_MAX_LANES");
+    const int cap = e && atoi(e) > 0 ? atoi(e) : 4;
+    return std::max(1, std::min(n_lanes, cap));
+}
 extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane) {
     if (!ctx || !tasks || n_lanes < 1 || n_lanes > 64 || n_tasks < 0) return prover_set_error(CENO_HIP_ERR_INVALID, "lanes_run: bad arguments");
+    std::shared_ptr<std::mutex> run_mu;
+    {
+        std::lock_guard<std::mutex> g(g_runs_mu);
+        auto& slot = g_runs[ctx];
+        if (!slot) slot = std::make_shared<std::mutex>();
+        run_mu = slot;
+    }
+    std::lock_guard<std::mutex> one_run(*run_mu);
     {
         // The command processor dispatches FOUR queues concurrently; further streams are time-multiplexed onto them, and a lane whose
         // stream shares a queue with another lane's persistent round kernel waits behind it (tools/ubench_lanes.hip,

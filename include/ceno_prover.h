@@ -387,6 +387,9 @@ typedef struct ceno_lane_task {
     size_t estimated_bytes;
 } ceno_lane_task;
 int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane);
+/* lanes a run of `n_lanes` really uses: the device dispatches four queues concurrently, more lanes are run as four (CENO_HIP_MAX_LANES
+ * overrides).  Runs on one context take turns (the lane streams are the context's). */
+int ceno_prover_lanes_effective(int n_lanes);
 /* The chip-proof phase of create_proof on the scheduler (prover.rs:556-570, scheduler.rs:231-336): task i = one
  * ceno_prover_create_chip_proof with its OWN transcript (the caller forks the parent transcript per chip and merges one sample of
  * each fork back afterwards, prover.rs:567-570), run on whichever of the context's lanes picks it, largest estimate first, booked
