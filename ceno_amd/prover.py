@@ -211,13 +211,26 @@ def make_plan(n_mles: int, coeffs: np.ndarray, terms, max_num_vars: int, max_deg
 
 
 def sumcheck_prove(dev: Device, mles: Sequence[Mle], coeffs: np.ndarray, terms, max_num_vars: int, max_degree: int,
-                   tr: Transcript, groups=None, stream=None):
-    """IOPProverState::prove — returns (msgs (n,d,2), challenges (n,2), final_evals (k,2))"""
+                   tr: Transcript, groups=None, stream=None, eq_decls=None):
+    """IOPProverState::prove — returns (msgs (n,d,2), challenges (n,2), final_evals (k,2)).
+    eq_decls: [(mle index, point (nv,2), lo, hi)] — tables that ARE eq(., point) on the rows [lo, hi) (ceno_prover_sumcheck_prove_eq)"""
     plan, keep = make_plan(len(mles), coeffs, terms, max_num_vars, max_degree, groups)
     arr = (C.c_void_p * len(mles))(*[m.h for m in mles])
     msgs = np.zeros((max_num_vars, max_degree, 2), dtype=np.uint64)
     chal = np.zeros((max(max_num_vars, 1), 2), dtype=np.uint64)
     fin = np.zeros((len(mles), 2), dtype=np.uint64)
+    if eq_decls:
+        L = plib()
+        L.ceno_prover_sumcheck_prove_eq.restype = C.c_int
+        n = len(eq_decls)
+        idx = (C.c_int * n)(*[int(d[0]) for d in eq_decls])
+        pts = [np.ascontiguousarray(d[1], dtype=np.uint64) for d in eq_decls]
+        ptp = (u64p * n)(*[_p(p_) for p_ in pts])
+        lo = (C.c_size_t * n)(*[int(d[2]) for d in eq_decls])
+        hi = (C.c_size_t * n)(*[int(d[3]) for d in eq_decls])
+        _check(L.ceno_prover_sumcheck_prove_eq(dev.h, arr, C.byref(plan), n, idx, ptp, lo, hi, tr.h, stream,
+                                               _p(msgs) if max_num_vars else None, _p(chal), _p(fin)))
+        return msgs, chal[:max_num_vars], fin
     _check(plib().ceno_prover_sumcheck_prove(dev.h, arr, C.byref(plan), tr.h, stream,
                                              _p(msgs) if max_num_vars else None, _p(chal), _p(fin)))
     return msgs, chal[:max_num_vars], fin

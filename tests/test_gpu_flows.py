@@ -276,6 +276,48 @@ def test_eq_factored_main_constraints_match_the_oracle(dev, prover, monkeypatch,
         assert c3 == claimed and np.array_equal(m3, msgs) and np.array_equal(e3, evals)
 
 
+@pytest.mark.parametrize("max_degree", [4, 3])
+def test_eq_factored_rounds_over_extension_columns(dev, prover, max_degree):
+    """ceno_hip_sumcheck_begin_eq on a plan whose columns are EXTENSION-field tables from the start (a later GKR layer): the first round
+    then runs on the staged eq kernel in its all-extension form (no base-field products), every slot wanted; two chips of different
+    sizes, Prefix ranges with boundary pairs, one chip with two selectors at one point"""
+    rng_seed = 900
+    chips = [(14, [(5, 9000)]), (13, [(0, 8191), (100, 3000)])]
+    tabs, mles, coeffs, terms, groups, decls, nvs = [], [], [], [], [], [], []
+    for c, (nv, sels) in enumerate(chips):
+        start = len(tabs)
+        cols = [po.rand_ext(1 << nv, rng_seed + 17 * c + j) for j in range(3)]
+        point = po.rand_ext(nv, 70 + c)
+        tabs += cols
+        for k, (off, n) in enumerate(sels):
+            tabs.append(po.selector_compute(po.SEL_PREFIX, point, off, n))
+            s_id = start + 3 + k
+            t0 = len(terms)
+            terms += [[start + (k + j) % 3, start + (k + j + 1) % 3][: max_degree - 1] for j in range(2)] + [[start + k % 3]]
+            if max_degree >= 4:
+                terms += [[start, start + 1, start + 2]]
+            groups.append(([s_id], list(range(t0, len(terms)))))
+            decls.append((s_id, point, off, off + n))
+        nvs += [nv] * (3 + len(sels))
+    coeffs = po.ext([(3 + 5 * t, 1 + t) for t in range(len(terms))])
+    mles = [dev.upload(t) for t in tabs]
+    max_nv = max(nvs)
+    before = dev.L.ceno_hip_stat_eq_launches(dev.h)
+    msgs, chal, fin = prover.sumcheck_prove(dev, mles, coeffs, terms, max_nv, max_degree, prover.Transcript.stub(21), groups=groups, eq_decls=decls)
+    assert dev.L.ceno_hip_stat_eq_launches(dev.h) - before >= max_nv - 2
+    full_terms = []
+    for common, ts in groups:
+        for t in ts:
+            full_terms.append((t, list(common) + terms[t]))
+    full_terms.sort()
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, coeffs, [ft for _, ft in full_terms], max_nv, max_degree, po.StubTranscript(21))
+    assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, chal) and np.array_equal(ofin, fin)
+    m2, c2, f2 = prover.sumcheck_prove(dev, mles, coeffs, terms, max_nv, max_degree, prover.Transcript.stub(21), groups=groups)  # no declarations
+    assert np.array_equal(m2, msgs) and np.array_equal(f2, fin)
+    for m in mles:
+        m.free()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE config #3 at full size
 # ------------------------------------------------------------------------------------------------------------------
