@@ -138,9 +138,15 @@ again:
             int pick = -1;
             // first choice: a block this stream (or nobody alive) used last — no runtime call; concurrent lanes mostly recycle
             // their own blocks, and a hipStreamQuery per candidate under the pool mutex would serialise them
+            // (its OWN blocks before untagged ones: a stream that took the untagged blocks first — the most recently freed ones — left
+            // its own tagged pile idle and grew it by what it absorbed, while the streams those untagged blocks had come from went
+            // back to the driver for new ones: the chip proof on the flow's stream against the opening's two tree streams, +70 MB of
+            // cache and 55 hipMalloc per chip flow, tools/dev/pool_growth_chip.py)
+            for (int k = (int)fl.size() - 1; k >= 0 && pick < 0; k--)
+                if (fl[k].second == cur) pick = k;
             for (int k = (int)fl.size() - 1; k >= 0 && pick < 0; k--) {
                 const hipStream_t last = fl[k].second;
-                if (!last || last == cur || !stream_alive(ctx, last)) pick = k;
+                if (!last || !stream_alive(ctx, last)) pick = k;
             }
             // second choice: any block whose stream has drained — one query per DISTINCT stream (a handful), not per block, so
             // that blocks tagged with a lane that no longer asks for this size do not pile up behind busy ones
@@ -310,7 +316,24 @@ again:
     if (pool_trace && !victims.empty()) fprintf(stderr, "[ceno_hip] pool: hipFree of %zu cached blocks (cached %zu MB, used %zu MB)\n", victims.size(), ctx->pool_cached >> 20, ctx->pool_used >> 20);
     for (void* v : victims) (void)hipFree(v);  // outside the mutex (see above)
     victims.clear();
-    if (pool_trace) fprintf(stderr, "[ceno_hip] pool: hipMalloc %zu KB (cached %zu MB, used %zu MB)\n", b >> 10, ctx->pool_cached >> 20, ctx->pool_used >> 20);
+    if (pool_trace) {
+        size_t n_same = 0, n_busy = 0;
+        {
+            std::lock_guard<std::mutex> g(ctx->mu);
+            auto it = ctx->free_lists.find(b);
+            if (it != ctx->free_lists.end()) {
+                n_same = it->second.size();
+                std::map<hipStream_t, int> tags;
+                for (auto& e : it->second) {
+                    tags[e.second]++;
+                    if (e.second && stream_alive(ctx, e.second) && !stream_drained(e.second)) n_busy++;
+                }
+                for (auto& kv : tags) fprintf(stderr, "[ceno_hip] pool:   tag %p x %d (alive %d)\n", (void*)kv.first, kv.second, kv.first ? (int)stream_alive(ctx, kv.first) : -1);
+            }
+        }
+        fprintf(stderr, "[ceno_hip] pool: hipMalloc %zu KB (cached %zu MB, used %zu MB; %zu cached blocks of this size, %zu of them on a busy stream; stream %p)\n", b >> 10,
+                ctx->pool_cached >> 20, ctx->pool_used >> 20, n_same, n_busy, (void*)(ceno_tls_stream ? ceno_tls_stream : ctx->default_stream));
+    }
     if (release.gate) {
         ctx_trim_end(ctx);
         release.gate = false;

@@ -872,7 +872,10 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
     L.ceno_prover_create_chip_proof.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), u64p, C.c_void_p, C.c_void_p, C.POINTER(ChipProofC)]
     L.ceno_chip_proof_free.restype = None
     L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
-    T, keep = _marshal_chip_task(task)
+    if isinstance(task, ChipTasks):  # marshalled once by the caller (a Rust caller hands the struct over directly): the first task of the list
+        T, keep = task.arr[0], None
+    else:
+        T, keep = _marshal_chip_task(task)
     ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
     out = ChipProofC()
     _check(L.ceno_prover_create_chip_proof(dev.h, C.byref(T), _p(ch), tr.h, stream, C.byref(out)))

