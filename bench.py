@@ -263,9 +263,9 @@ def main():
     comms = {}        # exchange kind -> communicator, created once and shared by the strong and the weak run
     comm_info = {}    # e.g. the rank count RCCL itself reports
 
-    def measure(n_local: int) -> dict:
+    def measure(n_local: int, kinds=None) -> dict:
         """all the timings of one hypercube size: every rank holds shard `rank` (2^n_local elements per table) of a
-        2^(n_local + log2 world) hypercube"""
+        2^(n_local + log2 world) hypercube.  kinds: the exchanges to validate and time (N > 1)"""
         n_total = n_local + log_w
         # shard `rank` of table j: words [rank * 2 * 2^n_local, ...) of the SplitMix stream seeded SEED0 + j
         mles = [dev.synthetic(n_local, True, SEED0 + j, word_offset=rank * 2 * (1 << n_local)) for j in range(K)]
@@ -297,7 +297,7 @@ def main():
             except Exception as e:  # without it a candidate is accepted when it runs on every rank (its proof is replicated by construction)
                 print(f"bench.py: torch.distributed reference path failed on rank {rank}: {e}", file=sys.stderr)
                 reference = None
-            order = [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
+            order = list(kinds) if kinds is not None else [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
             ok_kinds = []
             for kind in order:
                 ok = 1
@@ -511,17 +511,86 @@ def main():
             },
         }
 
+    def run_sizes(kinds):
+        strong = weak = None
+        if args.scaling in ("strong", "both") and args.nv - log_w >= 1:
+            strong = line(measure(args.nv - log_w, kinds), "strong")
+        if args.scaling in ("weak", "both") or strong is None:
+            weak = line(measure(args.nv, kinds), "weak")
+        r_ = strong if strong is not None else weak
+        if strong is not None and weak is not None:
+            r_["weak_scaling"] = {k: weak[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "collective_ms", "roofline")}
+        return r_
+
     if world == 1:
         res = line(measure(args.nv), "weak")  # one GPU: strong and weak coincide; `weak` is what the single-GPU line has always said
     else:
-        strong = weak = None
-        if args.scaling in ("strong", "both") and args.nv - log_w >= 1:
-            strong = line(measure(args.nv - log_w), "strong")
-        if args.scaling in ("weak", "both") or strong is None:
-            weak = line(measure(args.nv), "weak")
-        res = strong if strong is not None else weak
-        if strong is not None and weak is not None:
-            res["weak_scaling"] = {k: weak[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "collective_ms", "roofline")}
+        # N > 1.  FIRST a complete measurement that needs no RCCL call of this library (the shared-memory exchange, validated against the
+        # torch.distributed path): whatever happens to the RCCL arm afterwards, this line exists.  THEN the RCCL communicator is created and
+        # one sharded sumcheck validated under a watchdog; only if every rank reports success is the measurement repeated over RCCL — which
+        # then carries the headline (north_star names the RCCL collective; CENO_BENCH_HEADLINE=fastest picks the faster one).  A collective
+        # that never returns: every rank notices after CENO_BENCH_RCCL_TIMEOUT_S, rank 0 prints the shared-memory line with the reason,
+        # and the processes leave through os._exit (their stream cannot be drained any more) — a reported fallback, not a hang.
+        wanted = [x for x in os.environ.get("CENO_BENCH_EXCHANGE", "shm,rccl").split(",") if x]
+        base = [k for k in wanted if k != "rccl"] or ["shm"]
+        res = run_sizes(base)
+        if "rccl" in wanted:
+            import threading
+
+            probe = {"ok": 0, "why": "timeout: the RCCL communicator or its first all-gather did not return"}
+
+            def rccl_probe():
+                try:
+                    if os.environ.get("CENO_BENCH_FAKE_RCCL_HANG") == "1":  # tests: what a collective that never returns looks like
+                        time.sleep(1e6)
+                    n_probe = 10
+                    pm = [dev.synthetic(n_probe, True, SEED0 + j, word_offset=rank * 2 * (1 << n_probe)) for j in range(K)]
+                    ref = cdist.sharded_sumcheck_prove(cdist.HipShardEngine(dev, pm), n_probe + log_w, K, prover.Transcript.stub(TR_SEED), dist=dist,
+                                                       world=world, rank=rank)
+                    comms["rccl"] = prover.RcclComm(world, rank, dist)
+                    comm_info["rccl_ranks"] = comms["rccl"].nranks()
+                    got = prover.dist_sumcheck_prove(dev, comms["rccl"], pm, ONE, TERMS, n_probe + log_w, K, prover.Transcript.stub(TR_SEED), stream)
+                    dev.sync()
+                    same = all(np.array_equal(x, y) for x, y in zip(got, ref))
+                    probe["ok"], probe["why"] = (1, "ok") if same else (0, "the RCCL path's proof differs from the torch.distributed path's")
+                    for m_ in pm:
+                        m_.free()
+                except Exception as e:  # noqa: BLE001
+                    probe["ok"], probe["why"] = 0, f"{type(e).__name__}: {e}"
+
+            th = threading.Thread(target=rccl_probe, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("CENO_BENCH_RCCL_TIMEOUT_S", "90")))
+            hung = th.is_alive()
+            flag = torch.tensor([0 if hung else probe["ok"]], dtype=torch.int32, device=tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                over_rccl = run_sizes(["rccl"])
+                if "rccl" in over_rccl.get("exchanges_validated", []):
+                    for key in ("collective_ms",):
+                        over_rccl[key] = dict(res.get(key, {}), **over_rccl.get(key, {}))
+                    over_rccl["exchanges_validated"] = sorted(set(res.get("exchanges_validated", [])) | {"rccl"})
+                    if "weak_scaling" in over_rccl and "weak_scaling" in res:
+                        over_rccl["weak_scaling"]["collective_ms"] = dict(res["weak_scaling"].get("collective_ms", {}), **over_rccl["weak_scaling"].get("collective_ms", {}))
+                    fastest = min(over_rccl["collective_ms"], key=lambda k_: over_rccl["collective_ms"][k_])
+                    over_rccl["fastest_exchange"] = fastest
+                    if os.environ.get("CENO_BENCH_HEADLINE", "rccl") == "fastest" and fastest != "rccl":
+                        res["collective_ms"], res["exchanges_validated"], res["fastest_exchange"] = over_rccl["collective_ms"], over_rccl["exchanges_validated"], fastest
+                        res.update(comm_info)
+                    else:
+                        res = over_rccl
+                else:
+                    res["rccl"] = "unavailable: validated in the probe but not at the benchmark size"
+            else:
+                res["rccl"] = "unavailable: " + (probe["why"] if not hung else "timeout after CENO_BENCH_RCCL_TIMEOUT_S: the RCCL communicator or its first all-gather did not return")
+                print(f"bench.py: RCCL arm unavailable on rank {rank}: {res['rccl']}", file=sys.stderr)
+                comms.pop("rccl", None)
+                if hung:  # this process cannot synchronise its device any more: report and leave
+                    res.setdefault("extra", {})["dist_commit"] = {"status": "skipped: the RCCL arm did not return"}
+                    if rank == 0:
+                        print(json.dumps(res))
+                        sys.stdout.flush()
+                    os._exit(0)
     n_local = res["config"]["num_vars_per_gpu"]
     if world > 1 and not args.no_extra:
         # the multi-rank commitment as an extra, under a watchdog: a collective that never returns must not take the headline along —

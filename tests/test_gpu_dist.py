@@ -98,3 +98,23 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     assert r["extra"]["dist_commit"]["status"].startswith("skipped")
     assert "shared-memory exchange" in r["config"]["collective"] and "checked against the torch.distributed path" in r["config"]["collective"]
     assert r["value"] > 0 and abs(r["value"] - 9 * ((1 << r["config"]["global_num_vars"]) - 1) / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+
+
+def test_bench_py_reports_an_rccl_arm_that_never_returns():
+    """a collective that never returns (simulated: CENO_BENCH_FAKE_RCCL_HANG=1) must not take the N > 1 bench line along: the
+    shared-memory measurement was completed before the RCCL arm was touched, every rank notices the timeout, rank 0 prints that line
+    with the reason and the processes leave — a reported fallback, no hang past CENO_BENCH_RCCL_TIMEOUT_S"""
+    import json
+
+    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", CENO_BENCH_FAKE_RCCL_HANG="1", CENO_BENCH_RCCL_TIMEOUT_S="3")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--nv", "12", "--scaling", "strong"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["headline_exchange"] == "shm" and r["value"] > 0
+    assert r["rccl"].startswith("unavailable: timeout") and r["extra"]["dist_commit"]["status"].startswith("skipped")
