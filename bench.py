@@ -126,7 +126,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     # config #3: ADD-shaped chip, 2^20 rows x 22 columns, commit -> chip proof -> main constraints -> open
     flow = synthetic.ChipFlow(dev, prover, 20, 22)
     best = None
-    for _ in range(reps):
+    for _ in range(reps + 2):  # latency-bound flows on a shared host: best of five (a neighbour's burst costs a whole repetition)
         r = flow.run(new_transcript)
         if best is None or r["total_ms"] < best["total_ms"]:
             best = r
@@ -141,7 +141,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     fork = (lambda: prover.Transcript.poseidon2(b"fork")) if transcript_name == "poseidon2" else (lambda: prover.Transcript.stub(0xF0))
     bs, by_lanes = None, {}
     for lanes in (1, 4, 8):  # chip proofs serially, then on 4 and 8 lanes of the C++ scheduler (ceno_prover_create_chip_proofs: context-owned lane streams)
-        for _ in range(reps):
+        for _ in range(reps + 2):
             r = shard.run(new_transcript, fork, lanes=lanes)
             by_lanes[lanes] = min(by_lanes.get(lanes, 1e30), r["total_ms"])
             if bs is None or r["total_ms"] < bs["total_ms"]:
