@@ -728,6 +728,28 @@ __global__ void __launch_bounds__(NT) k_export_tables(const MleSlot* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host-side state
 // ------------------------------------------------------------------------------------------------
+// CENO_HIP_EQ_VERIFY=1: spot check of a declared eq table (ceno_hip_sumcheck_begin_eq) — rows at and around the ends of the declared range and a
+// few inside must hold eq(row, point) resp. zero; *bad counts the rows that do not
+struct EqVerifyArg {
+    E2 pt[40];
+    int nv;
+    unsigned long long rows[8];
+    unsigned long long lo, hi;
+};
+__global__ void k_eq_verify(const E2* __restrict__ table, EqVerifyArg a, unsigned* __restrict__ bad) {
+    const int k = threadIdx.x;
+    if (k >= 8) return;
+    const unsigned long long x = a.rows[k];
+    if (x >= (1ull << a.nv)) return;
+    E2 want = e2_zero();
+    if (x >= a.lo && x < a.hi) {
+        want = e2_one();
+        for (int v = 0; v < a.nv; v++) want = want * (((x >> v) & 1) ? a.pt[v] : (e2_one() - a.pt[v]));
+    }
+    const E2 got = table[x];
+    if (got.c0 != want.c0 || got.c1 != want.c1) atomicAdd(bad, 1u);
+}
+
 namespace {
 
 struct ScMle {
@@ -1762,6 +1784,31 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         dcl.hi = std::min<uint64_t>(eqd->hi[k], (uint64_t)1 << nv);
         if (dcl.hi <= dcl.lo) dcl.lo = dcl.hi = 0;
         dcl.on = sc->mles[j].cur_ext != 0 && nv >= 1;
+        if (dcl.on && getenv("CENO_HIP_EQ_VERIFY") && atoi(getenv("CENO_HIP_EQ_VERIFY")) != 0) {
+            // the caller vouches for a declaration; this switch (tests, bring-up of a new caller) checks it on a handful of rows
+            EqVerifyArg a{};
+            a.nv = nv;
+            a.lo = dcl.lo;
+            a.hi = dcl.hi;
+            for (int i = 0; i < nv; i++) a.pt[i] = dcl.pt[(size_t)i];
+            const unsigned long long len = 1ull << nv, mid = dcl.lo + (dcl.hi - dcl.lo) / 2;
+            const unsigned long long rows[8] = {dcl.lo, dcl.hi ? dcl.hi - 1 : 0, dcl.lo ? dcl.lo - 1 : len, dcl.hi, mid, mid ^ 1, 0, len - 1};
+            for (int i = 0; i < 8; i++) a.rows[i] = rows[i];
+            void* p = nullptr;
+            int rc = ctx_alloc(ctx, 256, &p);
+            unsigned bad = ~0u;
+            if (!rc) {
+                hipError_t e = hipMemsetAsync(p, 0, 4, st);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL(k_eq_verify, dim3(1), dim3(64), 0, st, reinterpret_cast<const E2*>(sc->mles[j].cur), a, (unsigned*)p);
+                    e = hipMemcpyAsync(&bad, p, 4, hipMemcpyDeviceToHost, st);
+                }
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                ctx_free(ctx, p);
+                if (e != hipSuccess) bad = ~0u;
+            }
+            if (bad != 0) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "eq declaration %d: table %d is not eq(., point) on the rows [%llu, %llu) (CENO_HIP_EQ_VERIFY)", k, j, (unsigned long long)dcl.lo, (unsigned long long)dcl.hi); }
+        }
     }
     sc->terms.resize(plan->num_terms);
     for (int t = 0; t < plan->num_terms; t++) {

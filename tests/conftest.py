@@ -29,6 +29,8 @@ def _cpu_budget() -> int:
 # half of the budget for the checker's OpenMP team, the rest stays free for the host threads of the product under test
 os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(8, _cpu_budget() // 2))))
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+# every eq declaration the tests hand to ceno_hip_sumcheck_begin_eq is spot-checked against its table (csrc/sumcheck.hip)
+os.environ.setdefault("CENO_HIP_EQ_VERIFY", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

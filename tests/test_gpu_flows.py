@@ -314,6 +314,12 @@ def test_eq_factored_rounds_over_extension_columns(dev, prover, max_degree):
     assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, chal) and np.array_equal(ofin, fin)
     m2, c2, f2 = prover.sumcheck_prove(dev, mles, coeffs, terms, max_nv, max_degree, prover.Transcript.stub(21), groups=groups)  # no declarations
     assert np.array_equal(m2, msgs) and np.array_equal(f2, fin)
+    if max_degree == 4:  # a declaration that does not describe its table is refused under CENO_HIP_EQ_VERIFY (set by tests/conftest.py)
+        from ceno_amd.api import CenoHipError
+
+        wrong = [(decls[0][0], decls[0][1], decls[0][2], decls[0][3] + 1)] + decls[1:]
+        with pytest.raises(CenoHipError):
+            prover.sumcheck_prove(dev, mles, coeffs, terms, max_nv, max_degree, prover.Transcript.stub(21), groups=groups, eq_decls=wrong)
     for m in mles:
         m.free()
 
