@@ -33,6 +33,9 @@
 // ------------------------------------------------------------------------------------------------
 // dense fused kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef CENO_DENSE_FMA
+#define CENO_DENSE_FMA 0
+#endif
 template <int K>
 struct TabPtrs {
     const uint64_t* in[K];
@@ -91,8 +94,13 @@ __global__ void __launch_bounds__(NT) k_dense(TabPtrs<K> tp, size_t pairs, E2 r,
                 } else if (MODE == 2) {
                     const uint64_t* q = tp.in[m] + 8 * p;
                     E2 a0 = ld_e2(q), a1 = ld_e2(q + 2), a2 = ld_e2(q + 4), a3 = ld_e2(q + 6);
+#if CENO_DENSE_FMA  // the addend inside the 129-bit sum of the product (one reduction, no separate modular add): A/B tools/dev/ab_dense_fma.sh
+                    lo = e2_fma_pre(rp, a1 - a0, a0);
+                    hi = e2_fma_pre(rp, a3 - a2, a2);
+#else
                     lo = a0 + e2_mul_pre(rp, a1 - a0);
                     hi = a2 + e2_mul_pre(rp, a3 - a2);
+#endif
                     st_e2(tp.out[m] + 4 * p, lo);
                     st_e2(tp.out[m] + 4 * p + 2, hi);
                 } else {
