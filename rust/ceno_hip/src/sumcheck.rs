@@ -35,6 +35,16 @@ pub struct CommonTermPlan {
     pub group_common_mles: Vec<Vec<usize>>,
 }
 
+/// A table of the plan that IS `eq(., point)` on the rows `[lo, hi)` and zero elsewhere — a `SelectorType::Whole` / `Prefix` selector
+/// (`gkr_iop/src/selector.rs:131-245`).  Declared to `Sumcheck::begin_eq`, the rounds of the chips whose every group hangs on one such
+/// table evaluate the quotient of the round polynomial by `eq(X, rt_i)` at one point fewer; the messages are the same words.
+pub struct EqDeclaration<'a> {
+    pub mle_index: usize,
+    pub point: &'a [ExtWords],
+    pub lo: usize,
+    pub hi: usize,
+}
+
 /// (round messages `n x d`, final evaluations per MLE, challenges = opening point)
 pub type SumcheckOutput = (Vec<Vec<ExtWords>>, Vec<ExtWords>, Vec<ExtWords>);
 
@@ -71,6 +81,43 @@ impl Sumcheck {
         let mut sc = ptr::null_mut();
         hal.check(unsafe { sys::ceno_hip_sumcheck_begin(hal.ctx, handles.as_ptr(), &c_plan, raw_stream(stream), &mut sc) })?;
         Ok(Self { hal: hal.clone(), raw: sc, num_vars: max_num_var, degree: max_degree, num_mles: handles.len() })
+    }
+    /// `begin` with selector declarations (`ceno_hip_sumcheck_begin_eq`): what `prove_batched_main_constraints` knows about its selectors
+    #[allow(clippy::too_many_arguments)]
+    pub fn begin_eq(hal: &Arc<HipHal>, mles: &[&HipMle], term_coefficients: &[ExtWords], mle_indices_per_term: &[Vec<usize>], max_num_var: usize,
+                    max_degree: usize, plan: Option<&CommonTermPlan>, eq: &[EqDeclaration<'_>], stream: Option<&HipStream>) -> Result<Self> {
+        let handles: Vec<*mut sys::ceno_hip_mle> = mles.iter().map(|m| m.raw()).collect();
+        let (toff, tidx) = csr(mle_indices_per_term);
+        let (goff, gidx) = plan.map_or((vec![0u32], vec![0u32]), |p| csr(&p.group_terms));
+        let (coff, cidx) = plan.map_or((vec![0u32], vec![0u32]), |p| csr(&p.group_common_mles));
+        let c_plan = sys::ceno_hip_sumcheck_plan {
+            num_mles: handles.len() as i32,
+            num_terms: mle_indices_per_term.len() as i32,
+            term_coeffs: term_coefficients.as_ptr() as *const u64,
+            term_offsets: toff.as_ptr(),
+            term_mle_idx: tidx.as_ptr(),
+            num_groups: plan.map_or(0, |p| p.group_terms.len() as i32),
+            group_term_offsets: goff.as_ptr(),
+            group_term_idx: gidx.as_ptr(),
+            common_offsets: coff.as_ptr(),
+            common_mle_idx: cidx.as_ptr(),
+            max_num_vars: max_num_var as i32,
+            max_degree: max_degree as i32,
+        };
+        let idx: Vec<i32> = eq.iter().map(|d| d.mle_index as i32).collect();
+        let pts: Vec<*const u64> = eq.iter().map(|d| d.point.as_ptr() as *const u64).collect();
+        let lo: Vec<usize> = eq.iter().map(|d| d.lo).collect();
+        let hi: Vec<usize> = eq.iter().map(|d| d.hi).collect();
+        let mut sc = ptr::null_mut();
+        hal.check(unsafe {
+            sys::ceno_hip_sumcheck_begin_eq(hal.ctx, handles.as_ptr(), &c_plan, eq.len() as i32, idx.as_ptr(), pts.as_ptr(), lo.as_ptr(), hi.as_ptr(),
+                                            raw_stream(stream), &mut sc)
+        })?;
+        Ok(Self { hal: hal.clone(), raw: sc, num_vars: max_num_var, degree: max_degree, num_mles: handles.len() })
+    }
+    /// how many chips of the plan run in the eq-factored form (diagnostics)
+    pub fn eq_components(&self) -> usize {
+        unsafe { sys::ceno_hip_sumcheck_eq_components(self.raw) as usize }
     }
     /// adopt a handle made by another entry point (tower layers)
     pub(crate) fn from_raw(hal: &Arc<HipHal>, raw: *mut sys::ceno_hip_sumcheck, num_vars: usize, degree: usize, num_mles: usize) -> Self {
