@@ -1,10 +1,12 @@
 // Internal definitions shared by the translation units of libceno_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <atomic>
 #include <condition_variable>
@@ -26,12 +28,37 @@ void ctx_pipelined_end(ceno_hip_ctx* ctx);
 bool ctx_trim_begin(ceno_hip_ctx* ctx);       // false: pipelined sumchecks are alive (or another trim runs) — nothing may be hipFree'd now
 void ctx_trim_end(ceno_hip_ctx* ctx);
 
+// The pool's lock.  Its critical sections are a map lookup and a vector pop — tens of nanoseconds — and a sumcheck takes it ~20 times
+// (begin: a buffer pair per table, partials, counters, plan; free: the same again).  A contended std::mutex parks the thread in the
+// kernel: with four lanes proving small chips side by side that measured ~5 us per acquisition, 110 us per tower layer instead of 10, and
+// the lanes ran at half speed (tools/dev/lanes_sc.cpp, CENO_HIP_HOST_TIMING=1).  The lane threads are busy-polling threads anyway:
+// they spin here too (and yield now and then: the rare holder that calls into the runtime — a stream query — keeps it longer).
+struct PoolMutex {
+    std::atomic<int> held{0};
+    void lock() {
+        for (int spins = 0;;) {
+            if (!held.exchange(1, std::memory_order_acquire)) return;
+            while (held.load(std::memory_order_relaxed)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if (++spins >= 2048) {
+                    spins = 0;
+                    sched_yield();
+                }
+            }
+        }
+    }
+    bool try_lock() { return !held.exchange(1, std::memory_order_acquire); }
+    void unlock() { held.store(0, std::memory_order_release); }
+};
+
 struct ceno_hip_ctx {
     int device = 0;
     hipStream_t default_stream = nullptr;
     int num_cus = 256;
     // ---- pool (size-bucketed caching allocator over hipMalloc) ----
-    std::mutex mu;
+    PoolMutex mu;
     size_t pool_limit = 0;  // 0 = unlimited
     size_t pool_used = 0;   // bytes handed out
     size_t pool_peak = 0;   // high-water mark of pool_used since the last ceno_hip_mem_peak(reset)
@@ -50,6 +77,7 @@ struct ceno_hip_ctx {
     // ---- pinned host memory cache (mailboxes of in-flight sumchecks; hipHostMalloc costs ~100 us) ----
     std::unordered_map<size_t, std::vector<void*>> pinned_free;
     std::unordered_map<void*, size_t> pinned_live;
+    std::unordered_map<void*, void*> pinned_dev;  // device view of every pinned block the pool owns (asked of the runtime once per block)
     // ---- challenge mailboxes in host-writable device memory (large-BAR boxes): the device polls HBM, the host posts one
     // PCIe write per challenge; vram_state: 0 = not probed, 1 = available, -1 = unavailable (mailboxes stay in pinned memory)
     int vram_state = 0;
@@ -101,10 +129,41 @@ struct ceno_hip_mle {
 };
 
 int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
+
+// CENO_HIP_HOST_TIMING=1: where the HOST threads of the library spend their time — calls and total microseconds per labelled scope,
+// printed by ceno_hip_destroy (tools/dev/lanes_sc.cpp: what concurrent lanes contend for).  Off: one predictable branch per scope.
+struct HostTimeSlot {
+    const char* label = nullptr;
+    std::atomic<unsigned long long> ns{0}, n{0}, seen{0};
+};
+unsigned long long host_timing_skip();  // CENO_HIP_HOST_TIMING_SKIP=k: the first k calls of every scope are warm-up and not counted
+HostTimeSlot* host_time_slot(const char* label);
+bool host_timing_on();
+void host_timing_dump();
+struct HostTimed {
+    HostTimeSlot* s;
+    timespec t0;
+    explicit HostTimed(HostTimeSlot* slot) : s(host_timing_on() ? slot : nullptr) {
+        if (s) clock_gettime(CLOCK_MONOTONIC, &t0);
+    }
+    ~HostTimed() {
+        if (!s) return;
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (s->seen.fetch_add(1, std::memory_order_relaxed) < host_timing_skip()) return;
+        s->ns.fetch_add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
+        s->n.fetch_add(1, std::memory_order_relaxed);
+    }
+};
+#define CENO_TIMED_CAT2(a, b) a##b
+#define CENO_TIMED_CAT(a, b) CENO_TIMED_CAT2(a, b)
+#define CENO_TIMED(label)                                                                  \
+    static HostTimeSlot* CENO_TIMED_CAT(_hts_, __LINE__) = host_time_slot(label);          \
+    HostTimed CENO_TIMED_CAT(_ht_, __LINE__)(CENO_TIMED_CAT(_hts_, __LINE__))
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out);
 void ctx_free(ceno_hip_ctx* ctx, void* p);                         // tag = the stream the calling thread resolved last
 void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner);   // tag = the stream that used the block
-void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner);  // the same for all blocks of one handle
+void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner, bool ask_drained = true);  // the same for all blocks of one handle
 // pinned, device-mapped host memory from a per-context cache; *dev_view is the device address of *host
 // 64-byte slot of fine-grained device memory the host can write through the BAR (nullptr when unavailable)
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx);

@@ -16,12 +16,38 @@ int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     if (ctx) {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         ctx->err = buf;
     } else {
         g_init_err = buf;
     }
     return code;
+}
+
+static HostTimeSlot g_host_time_slots[128];
+static std::atomic<int> g_host_time_n{0};
+bool host_timing_on() {
+    static const bool on = getenv("CENO_HIP_HOST_TIMING") && atoi(getenv("CENO_HIP_HOST_TIMING")) != 0;
+    return on;
+}
+unsigned long long host_timing_skip() {
+    static const unsigned long long k = getenv("CENO_HIP_HOST_TIMING_SKIP") ? strtoull(getenv("CENO_HIP_HOST_TIMING_SKIP"), nullptr, 10) : 0;
+    return k;
+}
+HostTimeSlot* host_time_slot(const char* label) {
+    const int k = g_host_time_n.fetch_add(1);
+    HostTimeSlot* s = &g_host_time_slots[k < 128 ? k : 127];
+    s->label = label;
+    return s;
+}
+void host_timing_dump() {
+    if (!host_timing_on()) return;
+    const int n = std::min(g_host_time_n.load(), 128);
+    for (int k = 0; k < n; k++) {
+        HostTimeSlot& s = g_host_time_slots[k];
+        const unsigned long long c = s.n.exchange(0), ns = s.ns.exchange(0);
+        if (c) fprintf(stderr, "[ceno_hip] host timing: %-34s %8llu calls  %10.1f us total  %8.2f us each\n", s.label, c, ns / 1e3, ns / 1e3 / c);
+    }
 }
 
 void ctx_make_current(ceno_hip_ctx* ctx) {
@@ -54,7 +80,7 @@ static bool stream_alive(ceno_hip_ctx* ctx, hipStream_t s) {
 // a stream the library did not create (a torch stream, a Rust-side stream) becomes known the first time a thread resolves it:
 // blocks freed while it still has work queued then wait for it to drain like those of the library's own streams
 void ctx_adopt_stream(ceno_hip_ctx* ctx, hipStream_t s) {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if (!stream_alive(ctx, s)) ctx->streams.push_back(s);
 }
 // has everything queued on `s` finished?  A handle the runtime no longer knows (destroyed behind the library's back) has
@@ -71,12 +97,14 @@ static bool stream_drained(hipStream_t s) {
 // sumchecks end within milliseconds); one that does must not — its own queued kernels are among those a trim would wait for
 static thread_local int tls_pipelined = 0;
 void ctx_pipelined_begin(ceno_hip_ctx* ctx) {
+    CENO_TIMED("ctx_pipelined_begin");
     std::unique_lock<std::mutex> lk(ctx->gate_mu);
     ctx->gate_cv.wait(lk, [&] { return !ctx->trimming; });
     ctx->pipelined_live.fetch_add(1);
     tls_pipelined++;
 }
 void ctx_pipelined_end(ceno_hip_ctx* ctx) {
+    CENO_TIMED("ctx_pipelined_end");
     {
         std::lock_guard<std::mutex> g(ctx->gate_mu);
         ctx->pipelined_live.fetch_sub(1);
@@ -106,6 +134,7 @@ void ctx_trim_end(ceno_hip_ctx* ctx) {
 }
 
 int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
+    CENO_TIMED("ctx_alloc");
     size_t b = bucket_size(bytes);
     // hipFree waits for every stream of the device, and a lane's queued round kernels wait for a host that may be waiting
     // for this mutex: blocks that go back to the driver are only COLLECTED under the mutex and released after it is dropped
@@ -124,7 +153,7 @@ int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
 again:
     need_gate = false;
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         auto it = ctx->free_lists.find(b);
         if (it != ctx->free_lists.end() && !it->second.empty()) {
             // A cached block was last used on the stream in its tag, which may still have that work queued.  Same stream:
@@ -247,7 +276,7 @@ again:
         }
         bool hopeless;
         {
-            std::lock_guard<std::mutex> g(ctx->mu);
+            std::lock_guard<PoolMutex> g(ctx->mu);
             hopeless = ctx->pool_used + b > ctx->pool_limit;
         }
         return ctx_fail(ctx, CENO_HIP_ERR_OOM, hopeless ? "pool capacity exceeded" : "pool capacity exceeded while other lanes are proving (cached blocks cannot be returned now): retry");
@@ -263,11 +292,11 @@ again:
         const size_t floor_ = (size_t)2 << 30;
         bool over = false;
         {
-            std::lock_guard<std::mutex> g(ctx->mu);
+            std::lock_guard<PoolMutex> g(ctx->mu);
             over = ctx->pool_cached > 4 * std::max(ctx->pool_used + b, floor_);
         }
         if (over && !release.gate) release.gate = ctx_trim_begin(ctx);  // (gate before pool mutex, everywhere)
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         if (over && release.gate) {
             // LARGEST blocks first, only blocks of >= 1 MB, only until the cache is back under HALF the cap: what puts a cache over
             // a cap of >= 8 GB are the tables of a big batch, not the working set of the flows that follow it — returning every
@@ -319,7 +348,7 @@ again:
     if (pool_trace) {
         size_t n_same = 0, n_busy = 0;
         {
-            std::lock_guard<std::mutex> g(ctx->mu);
+            std::lock_guard<PoolMutex> g(ctx->mu);
             auto it = ctx->free_lists.find(b);
             if (it != ctx->free_lists.end()) {
                 n_same = it->second.size();
@@ -347,7 +376,7 @@ again:
         e = hipMalloc(&p, b);
         if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
     }
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     ctx->pool_used += b;
                     ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_used);
     ctx->live[p] = b;
@@ -361,28 +390,35 @@ void ctx_free(ceno_hip_ctx* ctx, void* p) { ctx_free_on(ctx, p, ceno_tls_stream 
 // calling thread happened to resolve last)
 void ctx_free_on(ceno_hip_ctx* ctx, void* p, hipStream_t owner) {
     if (!p) return;
-    if (!owner) owner = ctx->default_stream;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    auto it = ctx->live.find(p);
-    if (it == ctx->live.end()) return;
-    size_t b = it->second;
-    ctx->live.erase(it);
-    ctx->pool_used -= b;
-    ctx->pool_cached += b;
-    // Tag = the stream this thread worked on last.  A LARGE block is worth one runtime call: if that stream has already
-    // drained, the block is free for everybody (no tag) — otherwise blocks freed after a synchronisation by a thread that
-    // alternates between streams (commit_traces, the opening) could only ever go back to the stream of the tag, and every run
-    // would allocate the other stream's share afresh (measured: +230 MB of cache per shard flow).
-    hipStream_t tag = owner;
-    if (b >= ((size_t)64 << 10) && stream_alive(ctx, tag) && stream_drained(tag)) tag = nullptr;
-    ctx->free_lists[b].push_back({p, tag});
+    ctx_free_many_on(ctx, &p, 1, owner);
 }
 
+// Tag = the stream that used the block last.  A LARGE block is worth one runtime call: if that stream has already
+// drained, the block is free for everybody (no tag) — otherwise blocks freed after a synchronisation by a thread that
+// alternates between streams (commit_traces, the opening) could only ever go back to the stream of the tag, and every run
+// would allocate the other stream's share afresh (measured: +230 MB of cache per shard flow).
 // all blocks of one handle: one lock, one stream query (a sumcheck handle frees ~a dozen blocks, and the query alone is 1-2 us)
-void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner) {
+void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_t owner, bool ask_drained) {
+    CENO_TIMED("ctx_free_many_on");
     if (!owner) owner = ctx->default_stream;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    int drained = -1;  // not asked yet
+    // the stream query is a call into the runtime (1-6 us, longer when other threads are in there too): it is made with the pool's lock
+    // RELEASED — lanes that free a handle each would otherwise queue up behind each other's queries, and so would every allocation
+    // (ask_drained = false: a sumcheck handle at its release — its stream has just run its last kernel, the blocks go back to the same lane
+    // for the next layer, and a stream that needs them later asks then: ctx_alloc's second choice)
+    int drained = -1;  // not asked
+    if (ask_drained) {
+        bool ask = false;
+        {
+            std::lock_guard<PoolMutex> g(ctx->mu);
+            for (size_t i = 0; i < n && !ask; i++) {
+                auto it = ptrs[i] ? ctx->live.find(ptrs[i]) : ctx->live.end();
+                ask = it != ctx->live.end() && it->second >= ((size_t)64 << 10);
+            }
+            ask = ask && stream_alive(ctx, owner);
+        }
+        if (ask) drained = stream_drained(owner) ? 1 : 0;
+    }
+    std::lock_guard<PoolMutex> g(ctx->mu);
     for (size_t i = 0; i < n; i++) {
         void* p = ptrs[i];
         if (!p) continue;
@@ -393,18 +429,16 @@ void ctx_free_many_on(ceno_hip_ctx* ctx, void* const* ptrs, size_t n, hipStream_
         ctx->pool_used -= b;
         ctx->pool_cached += b;
         hipStream_t tag = owner;
-        if (b >= ((size_t)64 << 10)) {  // (see ctx_free_on)
-            if (drained < 0) drained = stream_alive(ctx, owner) && stream_drained(owner) ? 1 : 0;
-            if (drained) tag = nullptr;
-        }
+        if (b >= ((size_t)64 << 10) && drained == 1) tag = nullptr;
         ctx->free_lists[b].push_back({p, tag});
     }
 }
 
 static constexpr int VRAM_SLOTS = 1024;
 void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx) {
+    CENO_TIMED("ctx_vram_slot_alloc");
     ctx_make_current(ctx);
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if (ctx->vram_state == 0) {
         ctx->vram_state = -1;
         const char* env = getenv("CENO_HIP_VRAM_MAILBOX");  // 0 keeps the mailboxes in pinned host memory (A/B measurements)
@@ -425,36 +459,39 @@ void* ctx_vram_slot_alloc(ceno_hip_ctx* ctx) {
 }
 void ctx_vram_slot_free(ceno_hip_ctx* ctx, void* slot) {
     if (!slot) return;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     ctx->vram_free_slots.push_back((int)(((char*)slot - ctx->vram_arena) / 64));
 }
 
 int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_view) {
+    CENO_TIMED("ctx_pinned_alloc");
     size_t b = 4096;
     while (b < bytes) b <<= 1;
-    void* h = nullptr;
+    void *h = nullptr, *d = nullptr;
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        // a recycled block comes with the device view it was given when it was made: no runtime call (hipSetDevice and
+        // hipHostGetDevicePointer take the runtime's own locks — ~14 us per sumcheck with four lanes asking at once)
+        std::lock_guard<PoolMutex> g(ctx->mu);
         auto it = ctx->pinned_free.find(b);
         if (it != ctx->pinned_free.end() && !it->second.empty()) {
             h = it->second.back();
             it->second.pop_back();
+            d = ctx->pinned_dev[h];
+            ctx->pinned_live[h] = b;
         }
     }
-    ctx_make_current(ctx);
     if (!h) {
+        ctx_make_current(ctx);
         hipError_t e = hipHostMalloc(&h, b, hipHostMallocDefault);
         if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipHostMalloc(%zu): %s", b, hipGetErrorString(e));
-    }
-    void* d = nullptr;
-    hipError_t e = hipHostGetDevicePointer(&d, h, 0);
-    if (e != hipSuccess) {
-        (void)hipHostFree(h);
-        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
-    }
-    {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            (void)hipHostFree(h);
+            return ctx_fail(ctx, CENO_HIP_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+        }
+        std::lock_guard<PoolMutex> g(ctx->mu);
         ctx->pinned_live[h] = b;
+        ctx->pinned_dev[h] = d;
     }
     *host = h;
     *dev_view = d;
@@ -462,8 +499,9 @@ int ctx_pinned_alloc(ceno_hip_ctx* ctx, size_t bytes, void** host, void** dev_vi
 }
 
 void ctx_pinned_free(ceno_hip_ctx* ctx, void* host) {
+    CENO_TIMED("ctx_pinned_free");
     if (!host) return;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     auto it = ctx->pinned_live.find(host);
     if (it == ctx->pinned_live.end()) return;
     ctx->pinned_free[it->second].push_back(host);
@@ -504,6 +542,7 @@ int ceno_hip_init(int device, size_t pool_bytes, ceno_hip_ctx** out) {
 
 void ceno_hip_destroy(ceno_hip_ctx* ctx) {
     if (!ctx) return;
+    host_timing_dump();
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto& kv : ctx->free_lists)
@@ -528,7 +567,7 @@ const char* ceno_hip_last_error(ceno_hip_ctx* ctx) {
     // a copy per calling thread: another lane may be writing its own failure into ctx->err right now
     thread_local std::string mine;
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         mine = ctx->err;
     }
     return mine.c_str();
@@ -547,7 +586,7 @@ int ceno_hip_stream_create(ceno_hip_ctx* ctx, ceno_hip_stream* out) {
     hipStream_t s;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         ctx->streams.push_back(s);
     }
     *out = (ceno_hip_stream)s;
@@ -566,7 +605,7 @@ int ceno_hip_stream_create_lane(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* ou
     hipStream_t s;
     HIP_TRY(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, levels[lane % 3]));
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         ctx->streams.push_back(s);
     }
     *out = (ceno_hip_stream)s;
@@ -578,7 +617,7 @@ int ceno_hip_lane_stream(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out) {
     // handed out again on every later run, destroyed with the context.
     CHECK_ARG(ctx, out && lane >= 0 && lane < 64, "bad lane");
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         if (lane < (int)ctx->lane_streams.size() && ctx->lane_streams[lane]) {
             *out = (ceno_hip_stream)ctx->lane_streams[lane];
             return 0;
@@ -586,7 +625,7 @@ int ceno_hip_lane_stream(ceno_hip_ctx* ctx, int lane, ceno_hip_stream* out) {
     }
     ceno_hip_stream s = nullptr;
     TRY(ceno_hip_stream_create_lane(ctx, lane, &s));
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if ((int)ctx->lane_streams.size() <= lane) ctx->lane_streams.resize(lane + 1, nullptr);
     if (ctx->lane_streams[lane]) {  // another thread was faster: keep its stream (ours is dropped from the bookkeeping below)
         hipStream_t mine = (hipStream_t)s;
@@ -609,7 +648,7 @@ int ceno_hip_stream_bind(ceno_hip_ctx* ctx, ceno_hip_stream s) {
 }
 int ceno_hip_stream_adopt(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     CHECK_ARG(ctx, ctx && s, "bad stream");
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if (!stream_alive(ctx, (hipStream_t)s)) ctx->streams.push_back((hipStream_t)s);
     return 0;
 }
@@ -618,7 +657,7 @@ int ceno_hip_stream_destroy(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     // blocks freed while this stream still had work queued carry its tag in the pool: drain it before the tag goes stale
     (void)hipStreamSynchronize((hipStream_t)s);
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         for (size_t i = 0; i < ctx->streams.size(); i++)
             if (ctx->streams[i] == (hipStream_t)s) {
                 ctx->streams.erase(ctx->streams.begin() + i);
@@ -642,7 +681,7 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
     HIP_TRY(ctx, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if (pool_used) *pool_used = ctx->pool_used;
     if (pool_cached) *pool_cached = ctx->pool_cached;
     return 0;
@@ -653,7 +692,7 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
 // ESTIMATED footprint before it is handed to a lane and unbooks it when done; booking fails — nothing is allocated —
 // when live allocations + bookings would exceed the capacity, which is how the scheduler back-fills smaller tasks.
 int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes) {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     if (ctx->pool_capacity == 0) {
         size_t f = 0, t = 0;
         ctx->pool_capacity = ctx->pool_limit ? ctx->pool_limit : (hipMemGetInfo(&f, &t) == hipSuccess ? t : 0);
@@ -666,12 +705,12 @@ int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes) {
     return 0;
 }
 int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes) {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     ctx->pool_booked = bytes > ctx->pool_booked ? 0 : ctx->pool_booked - bytes;
     return 0;
 }
 size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     return ctx->pool_booked;
 }
 
@@ -684,7 +723,7 @@ int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_
 
 size_t ceno_hip_mem_peak(ceno_hip_ctx* ctx, int reset) {
     if (!ctx) return 0;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    std::lock_guard<PoolMutex> g(ctx->mu);
     const size_t v = ctx->pool_peak;
     if (reset) ctx->pool_peak = ctx->pool_used;
     return v;
@@ -698,7 +737,7 @@ int ceno_hip_mem_trim(ceno_hip_ctx* ctx) {
         ~End() { ctx_trim_end(c); }
     } end{ctx};
     {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        std::lock_guard<PoolMutex> g(ctx->mu);
         for (auto& kv : ctx->free_lists) {
             for (auto& p : kv.second) {
                 victims.push_back(p.first);

@@ -894,6 +894,8 @@ struct ceno_hip_sumcheck {
     MleSlot* h_slots = nullptr;    // pinned staging for slot tables, (n + 2) x total class mles
     size_t slots_per_round = 0;
     std::vector<void*> dev_allocs; // everything from ctx_alloc, freed on free()
+    char* arena = nullptr;         // the current chunk of the handle's small-block arena (sc_dev_alloc; the chunk itself is in dev_allocs)
+    size_t arena_used = 0;
     // tower layers (sumcheck_tower.hpp): rounds [0, fast_upto) run on k_tower, whose message the host completes (sc_tower_message)
     struct {
         bool on = false;
@@ -929,12 +931,36 @@ struct ceno_hip_sumcheck {
 static int host_tail_rounds(const ceno_hip_sumcheck* sc);  // below, next to the host rounds
 static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_words, const char* what);
 
+// Device memory of a handle.  Every block lives until the handle is released, so the SMALL ones (a working buffer pair per table of a
+// small layer, message / evaluation / counter / slot / plan blocks: ~25 of them for a tower layer) are cut from chunks of the handle's own
+// arena: one trip to the pool per chunk instead of one per block — with four lanes beginning and releasing layers side by side the pool's
+// lock was most of a layer's begin (tools/dev/lanes_sc.cpp: 96 us at four lanes against 8 us alone).  Large blocks stay pool blocks of
+// their own (the pool can hand them to the next handle whatever its shape).
+static constexpr size_t SC_ARENA_CHUNK = (size_t)2 << 20, SC_ARENA_ITEM_MAX = (size_t)512 << 10;
+static int sc_dev_alloc(ceno_hip_sumcheck* sc, size_t bytes, void** out) {
+    const size_t b = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    if (b <= SC_ARENA_ITEM_MAX) {
+        if (!sc->arena || sc->arena_used + b > SC_ARENA_CHUNK) {
+            void* c = nullptr;
+            TRY(ctx_alloc(sc->ctx, SC_ARENA_CHUNK, &c));
+            sc->dev_allocs.push_back(c);
+            sc->arena = (char*)c;
+            sc->arena_used = 0;
+        }
+        *out = sc->arena + sc->arena_used;
+        sc->arena_used += b;
+        return 0;
+    }
+    TRY(ctx_alloc(sc->ctx, bytes, out));
+    sc->dev_allocs.push_back(*out);
+    return 0;
+}
+
 template <typename T>
 static int upload_vec(ceno_hip_sumcheck* sc, const std::vector<T>& v, T** out) {
     void* p = nullptr;
     size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-    TRY(ctx_alloc(sc->ctx, bytes, &p));
-    sc->dev_allocs.push_back(p);
+    TRY(sc_dev_alloc(sc, bytes, &p));
     if (!v.empty()) HIP_TRY(sc->ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, sc->st));
     *out = (T*)p;
     return 0;
@@ -959,6 +985,7 @@ static inline void mailbox_clear(Mailbox* m) {
 
 static void sc_release(ceno_hip_sumcheck* sc) {
     if (!sc) return;
+    CENO_TIMED("sc_release");
     if (sc->pipelined && !sc->finished && sc->h_mailbox) {  // also after the last round: the tail may be waiting for the final challenge
         __atomic_store_n(&sc->h_mailbox->abort, 1ull, __ATOMIC_RELEASE);  // queued kernels exit at their wait
         host_store_fence();
@@ -981,7 +1008,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         sc->mid_reserved = 0;
     }
     if (sc->live_counted) ctx_pipelined_end(sc->ctx);
-    ctx_free_many_on(sc->ctx, sc->dev_allocs.data(), sc->dev_allocs.size(), sc->st);
+    ctx_free_many_on(sc->ctx, sc->dev_allocs.data(), sc->dev_allocs.size(), sc->st, false);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
     ctx_pinned_free(sc->ctx, sc->geq.h_block);
@@ -1187,8 +1214,7 @@ static int geq_prepare(ceno_hip_sumcheck* sc) {
     for (size_t k = 0; k < bytes / 8; k++) reinterpret_cast<uint64_t*>(hb)[k] = MSG_INVALID;
     {
         void* p = nullptr;
-        TRY(ctx_alloc(sc->ctx, std::max<size_t>(n_slots, 1) * sizeof(unsigned), &p));
-        sc->dev_allocs.push_back(p);
+        TRY(sc_dev_alloc(sc, std::max<size_t>(n_slots, 1) * sizeof(unsigned), &p));
         Gq.d_counters = (unsigned*)p;
         HIP_TRY(sc->ctx, hipMemsetAsync(p, 0, std::max<size_t>(n_slots, 1) * sizeof(unsigned), sc->st));
     }
@@ -1730,8 +1756,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
     }
     // ---- one device allocation, pointers fixed up, one copy from pinned staging ----
     void* d = nullptr;
-    TRY(ctx_alloc(ctx, blob.size(), &d));
-    sc->dev_allocs.push_back(d);
+    TRY(sc_dev_alloc(sc, blob.size(), &d));
     sc->d_gen = (char*)d;
     for (size_t off : comp_fix) {
         GenComp* G = reinterpret_cast<GenComp*>(blob.data() + off);
@@ -1764,6 +1789,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     CHECK_ARG(ctx, n >= 0 && n < 40, "max_num_vars %d out of range", n);
     CHECK_ARG(ctx, d >= 1 && d <= MAXD, "max_degree %d unsupported (1..%d)", d, MAXD);
     CHECK_ARG(ctx, plan->num_mles >= 1 && plan->num_terms >= 1, "empty plan");
+    CENO_TIMED("sc_build (whole)");
     auto* sc = new ceno_hip_sumcheck();
     sc->ctx = ctx;
     sc->st = st;
@@ -1875,16 +1901,14 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     for (auto& M : sc->mles) {
         if (M.nv >= 1) {
             void* p = nullptr;
-            int rc = ctx_alloc(ctx, ((size_t)1 << (M.nv - 1)) * sizeof(E2), &p);
+            int rc = sc_dev_alloc(sc, ((size_t)1 << (M.nv - 1)) * sizeof(E2), &p);
             if (rc) { sc_release(sc); return rc; }
-            sc->dev_allocs.push_back(p);
             M.buf[0] = (uint64_t*)p;
         }
         if (M.nv >= 2) {
             void* p = nullptr;
-            int rc = ctx_alloc(ctx, ((size_t)1 << (M.nv - 2)) * sizeof(E2), &p);
+            int rc = sc_dev_alloc(sc, ((size_t)1 << (M.nv - 2)) * sizeof(E2), &p);
             if (rc) { sc_release(sc); return rc; }
-            sc->dev_allocs.push_back(p);
             M.buf[1] = (uint64_t*)p;
         }
     }
@@ -1961,20 +1985,20 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
                                     append(coeffs.data(), coeffs.size() * sizeof(E2))});
         if (!rc) {
             void* p = nullptr;
-            rc = ctx_alloc(ctx, std::max<size_t>(cl.mles.size(), 1) * sizeof(MleSlot) * (size_t)(n + 2), &p);
-            if (!rc) { sc->dev_allocs.push_back(p); cl.d_slots = (MleSlot*)p; }
+            rc = sc_dev_alloc(sc, std::max<size_t>(cl.mles.size(), 1) * sizeof(MleSlot) * (size_t)(n + 2), &p);
+            if (!rc) cl.d_slots = (MleSlot*)p;
         }
         if (rc) { sc_release(sc); return rc; }
     }
     sc->slots_per_round = total_slots;
     {
         void* p = nullptr;
-        int rc = ctx_alloc(ctx, (size_t)part_off * sizeof(E2), &p);
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_partials = (E2*)p; rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_msg = (E2*)p; rc = ctx_alloc(ctx, (size_t)plan->num_mles * sizeof(E2), &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_evals = (E2*)p; rc = ctx_alloc(ctx, 4096, &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_counter = (unsigned*)p; sc->d_bcast = (Bcast*)((char*)p + 64); rc = ctx_alloc(ctx, MAXD * sizeof(E2), &p); }
-        if (!rc) { sc->dev_allocs.push_back(p); sc->d_round_acc = (E2*)p; }
+        int rc = sc_dev_alloc(sc, (size_t)part_off * sizeof(E2), &p);
+        if (!rc) { sc->d_partials = (E2*)p; rc = sc_dev_alloc(sc, MAXD * sizeof(E2), &p); }
+        if (!rc) { sc->d_msg = (E2*)p; rc = sc_dev_alloc(sc, (size_t)plan->num_mles * sizeof(E2), &p); }
+        if (!rc) { sc->d_evals = (E2*)p; rc = sc_dev_alloc(sc, 4096, &p); }
+        if (!rc) { sc->d_counter = (unsigned*)p; sc->d_bcast = (Bcast*)((char*)p + 64); rc = sc_dev_alloc(sc, MAXD * sizeof(E2), &p); }
+        if (!rc) sc->d_round_acc = (E2*)p;
         if (rc) { sc_release(sc); return rc; }
         // zeroed together with the plan upload below (k_setup), or by a memset when the plan takes the copy path
     }
@@ -2009,6 +2033,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     }
     hipError_t e = hipSuccess;
     {
+        CENO_TIMED("sc_build: pinned block + plan upload");
         // pinned block: [flag 64 B][mailbox 64 B][message MAXD + evals num_mles (E2)][slot staging]
         const size_t msg_bytes = (MAXD + (size_t)plan->num_mles) * sizeof(E2);
         const size_t slot_bytes = std::max<size_t>(total_slots, 1) * sizeof(MleSlot) * (size_t)(n + 2);
@@ -2047,17 +2072,15 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         char* h_blob = (char*)hb + ((128 + msg_bytes + slot_bytes + 15) & ~(size_t)15);
         memcpy(h_blob, blob.data(), blob.size());
         void* d_blob = nullptr;
-        rc = ctx_alloc(ctx, std::max<size_t>(blob.size(), 16), &d_blob);
+        rc = sc_dev_alloc(sc, std::max<size_t>(blob.size(), 16), &d_blob);
         if (rc) { sc_release(sc); return rc; }
-        sc->dev_allocs.push_back(d_blob);
         // rows of the persistent mid-round kernel (2 sets x 256 workgroups x MAXD ext, then 256 relay lines): armed HERE, by the
         // set-up kernel — a fill queued right in front of k_mid sat on the critical path of its first round (~9 us)
         static constexpr size_t MID_ROWS_BYTES = (size_t)2 * 256 * MAXD * sizeof(E2), MID_BLOCK_BYTES = MID_ROWS_BYTES + 256 * 64;
         if (off_pre_slots != (size_t)-1 && n >= 9) {
             void* p = nullptr;
-            rc = ctx_alloc(ctx, MID_BLOCK_BYTES, &p);
+            rc = sc_dev_alloc(sc, MID_BLOCK_BYTES, &p);
             if (rc) { sc_release(sc); return rc; }
-            sc->dev_allocs.push_back(p);
             sc->d_mid_rows = (uint64_t*)p;
         }
         if (blob.size() <= 16 * 1024 && blob.size() % 8 == 0) {
@@ -2073,6 +2096,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
             if (defer_setup) {
                 *defer_setup = job;  // the caller queues it with a kernel of its own (a tower layer: its eq table)
             } else {
+                CENO_TIMED("sc_build: launch_setup_job");
                 launch_setup_job(job, st);
                 if (hipGetLastError() != hipSuccess) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_HIP, "plan upload failed"); }
             }
@@ -2175,6 +2199,7 @@ static int sc_wait_words(ceno_hip_sumcheck* sc, const uint64_t* words, int n_wor
 // take the round message out of the pinned block and arm the words for the next one (the reset is ordered before whatever
 // releases the next kernel: the mailbox post fences, a launch rings a doorbell)
 static int sc_take_message(ceno_hip_sumcheck* sc, uint64_t* h_out) {
+    CENO_TIMED("sc_take_message (wait)");
     uint64_t* w = reinterpret_cast<uint64_t*>(sc->h_pinned);
     const int n_words = 2 * sc->d;
     TRY(sc_wait_words(sc, w, n_words));
@@ -2457,6 +2482,7 @@ static int pipe_lookahead() {
     return v;
 }
 static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
+    CENO_TIMED("sc_pipeline_enqueue");
     ceno_hip_ctx* ctx = sc->ctx;
     ScClass& cl = sc->classes[0];
     const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
@@ -3008,6 +3034,7 @@ int ceno_hip_sumcheck_round_dev(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const 
 
 int ceno_hip_sumcheck_finish(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* last_challenge2, uint64_t* final_evals) {
     CHECK_ARG(ctx, sc && final_evals, "NULL argument");
+    CENO_TIMED("sumcheck_finish");
     if (sc->finished) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck already finished");
     if (sc->round != sc->n) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck finish after %d of %d rounds", sc->round, sc->n);
     if (sc->n > 0) {
@@ -3122,12 +3149,17 @@ size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const
         return r;
     };
     (void)max_num_vars;
-    size_t total = 0;
+    size_t total = 0, small = 0;  // blocks of at most SC_ARENA_ITEM_MAX come out of the handle's arena chunks (sc_dev_alloc)
+    auto block = [&](size_t b) {
+        if (b <= SC_ARENA_ITEM_MAX) small += (b + 255) & ~(size_t)255;
+        else total += bucket(b);
+    };
     for (int j = 0; j < num_mles; j++) {
         const int nv = mle_num_vars ? mle_num_vars[j] : max_num_vars;
-        if (nv >= 1) total += bucket(((size_t)1 << (nv - 1)) * sizeof(E2));
-        if (nv >= 2) total += bucket(((size_t)1 << (nv - 2)) * sizeof(E2));
+        if (nv >= 1) block(((size_t)1 << (nv - 1)) * sizeof(E2));
+        if (nv >= 2) block(((size_t)1 << (nv - 2)) * sizeof(E2));
     }
+    total += (small / (SC_ARENA_CHUNK - SC_ARENA_ITEM_MAX) + 2) * SC_ARENA_CHUNK;  // (a chunk is left when the next block does not fit)
     total += bucket((size_t)MAXB * MAXD * sizeof(E2) * 4);                       // partials (per size class, a few classes)
     total += 3 * bucket(MAXD * sizeof(E2)) + bucket((size_t)std::max(num_mles, 1) * sizeof(E2)) + bucket(4096);
     total += bucket((size_t)std::max(num_terms, 1) * (sizeof(E2) + 8 * (size_t)std::max(max_degree, 1)) + (size_t)num_mles * 64);  // plan blob

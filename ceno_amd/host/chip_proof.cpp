@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -160,15 +161,25 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
         if ((int)j >= n_mles || remap[j] == UINT32_MAX) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a record expression reads an absent table");
         ridx.push_back(remap[j]);
     }
+    static const bool trace = getenv("CENO_PROVER_CHIP_TRACE") != nullptr;  // where a chip proof's wall time goes (host view, microseconds)
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
+    const double t0 = trace ? now_us() : 0;
     int rc = ceno_hip_wit_infer(ctx, present.data(), (int)present.size(), task->record_coeffs, task->record_term_offsets, ridx.data(),
                                 task->n_record_terms, task->record_out_term_offsets, n_records, num_var_with_rotation, s, records.data());
     if (rc) return fail_ctx(ctx, rc);
+    const double t1 = trace ? now_us() : 0;
     // ---- prove_tower_relation (prover.rs:747-755 -> cpu/mod.rs:765-797) ----
     ceno_tower_witness tw;
     rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk,
                                          task->log2_num_instances, task->rotation_vars, challenges4, s, &tw);
+    const double t2 = trace ? now_us() : 0;
     free_records();  // prover.rs:756 drop(records): the towers own their interleaved copies
     if (rc) return rc;
+    const double t3 = trace ? now_us() : 0;
     int max_nv = 0;
     for (int i = 0; i < tw.n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.prod[i]));
     for (int i = 0; i < tw.n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.logup[i]));
@@ -189,8 +200,13 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
     // out-evals were computed by build_tower_witness; prove_tower_relation binds them into the transcript (r, w, lk) and
     // runs the tower prover
     std::vector<uint64_t> out_evals((size_t)2 * (2 * tw.n_prod + 4 * tw.n_logup));
+    const double t4 = trace ? now_us() : 0;
     rc = ceno_prover_prove_tower_relation(ctx, tw.prod, tw.n_prod, tw.logup, tw.n_logup, tr, s, out_evals.data(), &out->tower);
+    const double t5 = trace ? now_us() : 0;
     ceno_tower_witness_free(ctx, &tw);
+    if (trace)
+        fprintf(stderr, "[ceno_prover] chip 2^%d: wit_infer %.0f us, tower witness (to out-evals) %.0f, free records %.0f, host alloc %.0f, tower proof %.0f, free towers %.0f\n",
+                task->log2_num_instances, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, now_us() - t5);
     if (rc) {
         ceno_chip_proof_free(out);
         return rc;

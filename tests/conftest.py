@@ -119,6 +119,7 @@ import time as _time
 _T0 = _time.time()
 _PHASES = []
 _FIRST_TEST = [None]
+_GUARD_SKIPPED = []
 
 
 def pytest_runtest_setup(item):
@@ -131,8 +132,10 @@ def pytest_runtest_setup(item):
     elapsed = _time.time() - _T0
     if "torch" in sys.modules:
         if elapsed > 900:
+            _GUARD_SKIPPED.append(item.nodeid)
             pytest.skip(f"GPU run at {elapsed:.0f} s: remaining torch.distributed tests skipped to stay inside the step limit")
     elif elapsed > 240:
+        _GUARD_SKIPPED.append(item.nodeid)
         pytest.skip(f"torch-free GPU tests took {elapsed:.0f} s (cold image): torch.distributed tests skipped to stay inside the step limit")
 
 
@@ -149,6 +152,10 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         return
     lines = [f"wall {_time.time() - _T0:.1f} s, first test after {(_FIRST_TEST[0] or 0):.1f} s; phases of 1 s and more:"]
     lines += [f"  {d:8.1f} s  {name}" for d, name in sorted(_PHASES, reverse=True)[:8]]
+    if _GUARD_SKIPPED:
+        # a skip is silent in a -q run: the multi-rank tests that did NOT run on this (cold) box are named in the summary and in the artifact
+        lines.append(f"NOT RUN on this box (cold-image guard, CENO_GPU_TEST_NO_GUARD=1 runs them): {len(_GUARD_SKIPPED)} torch.distributed tests")
+        lines += [f"  not run: {n}" for n in _GUARD_SKIPPED]
     for ln in lines:
         terminalreporter.write_line(ln)
     out_dir = os.path.join(ROOT, "gpurun_out")

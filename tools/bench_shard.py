@@ -16,7 +16,7 @@ def main():
     flow = synthetic.ShardFlow(dev, prover)
     for lanes in [int(x) for x in os.environ.get("LANES", "1,2,4,8").split(",")]:
         best = None
-        for _ in range(3):
+        for _ in range(int(os.environ.get("REPS", "3"))):
             r = flow.run(new_tr, fork, lanes=lanes)
             if best is None or r["total_ms"] < best["total_ms"]:
                 best = r
