@@ -180,6 +180,7 @@ again:
             // second choice: any block whose stream has drained — one query per DISTINCT stream (a handful), not per block, so
             // that blocks tagged with a lane that no longer asks for this size do not pile up behind busy ones
             if (pick < 0) {
+                CENO_TIMED("ctx_alloc: second choice (stream queries under the lock)");
                 hipStream_t seen[16];
                 bool idle[16];
                 int n_seen = 0;
@@ -282,6 +283,7 @@ again:
         return ctx_fail(ctx, CENO_HIP_ERR_OOM, hopeless ? "pool capacity exceeded" : "pool capacity exceeded while other lanes are proving (cached blocks cannot be returned now): retry");
     }
     void* p = nullptr;
+    CENO_TIMED("ctx_alloc: driver path (hipMalloc)");
     ctx_make_current(ctx);
     {   // soft cap on the cache: blocks parked without a tag (their stream had drained) go back to the driver once the cache is
         // several times what is in use — a backstop against slow growth under many lanes, far below any real footprint.
@@ -820,6 +822,7 @@ int ceno_hip_mle_download(ceno_hip_ctx* ctx, const ceno_hip_mle* m, uint64_t* ho
 }
 
 int ceno_hip_mle_free(ceno_hip_ctx* ctx, ceno_hip_mle* m) {
+    CENO_TIMED("mle_free");
     if (!m) return 0;
     if (m->owned) ctx_free(ctx, m->d);
     if (m->aux) ctx_free(ctx, m->aux);

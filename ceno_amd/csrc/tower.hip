@@ -219,6 +219,7 @@ extern "C" {
 
 int ceno_hip_tower_build_prod(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, int k, size_t num_instances, const uint64_t* default2,
                               ceno_hip_stream s, ceno_hip_tower** out) {
+    CENO_TIMED("tower_build_prod");
     CHECK_ARG(ctx, records && default2 && out, "NULL argument");
     hipStream_t st = ctx_stream(ctx, s);
     RecArg ra{};
@@ -240,6 +241,7 @@ int ceno_hip_tower_build_prod(ceno_hip_ctx* ctx, ceno_hip_mle* const* records, i
 
 int ceno_hip_tower_build_logup(ceno_hip_ctx* ctx, ceno_hip_mle* const* p_records, ceno_hip_mle* const* q_records, int k,
                                size_t num_instances, const uint64_t* default2, ceno_hip_stream s, ceno_hip_tower** out) {
+    CENO_TIMED("tower_build_logup");
     CHECK_ARG(ctx, q_records && default2 && out, "NULL argument");
     hipStream_t st = ctx_stream(ctx, s);
     RecArg rq{};
@@ -342,6 +344,7 @@ int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out
 }
 
 int ceno_hip_tower_prefetch_tops(ceno_hip_ctx* ctx, ceno_hip_tower* const* towers, int n_towers, int n_layers, ceno_hip_stream s) {
+    CENO_TIMED("tower_prefetch_tops");
     CHECK_ARG(ctx, towers && n_towers >= 0 && n_layers >= 1, "tower prefetch: bad arguments");
     hipStream_t st = ctx_stream(ctx, s);
     // every tower's top block into ONE pinned staging block, one wait for all of them (a copy into pageable memory per tower — and per
@@ -388,6 +391,7 @@ int ceno_hip_tower_download_top(ceno_hip_ctx* ctx, ceno_hip_tower* t, int n_laye
 int ceno_hip_tower_top_layers(const ceno_hip_tower* t) { return t ? t->top_layers : 0; }
 
 int ceno_hip_tower_free(ceno_hip_ctx* ctx, ceno_hip_tower* t) {
+    CENO_TIMED("tower_free");
     tower_release(ctx, t);
     return 0;
 }
@@ -403,6 +407,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
                                                    int n_logup, int layer, const uint64_t* out_rt, const uint64_t* alpha_pows,
                                                    ceno_hip_stream s, ceno_hip_sumcheck** out) {
     CHECK_ARG(ctx, out && out_rt && alpha_pows && layer >= 1, "tower layer sumcheck: bad arguments");
+    CENO_TIMED("tower_layer_sumcheck_begin");
     CHECK_ARG(ctx, (n_prod == 0 || prod) && (n_logup == 0 || logup), "NULL tower list");
     (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")
     // sum_x eq(x, out_rt) * [ sum_i alpha_i a_i b_i + sum_k (alpha_n (p1 q2 + p2 q1) + alpha_d q1 q2) ]

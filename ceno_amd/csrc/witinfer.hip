@@ -131,6 +131,7 @@ extern "C" {
 int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mles, const uint64_t* term_coeffs,
                        const uint32_t* term_offsets, const uint32_t* term_mle_idx, int num_terms, const uint32_t* out_term_offsets,
                        int num_outs, int num_vars, ceno_hip_stream s, ceno_hip_mle** outs) {
+    CENO_TIMED("wit_infer");
     CHECK_ARG(ctx, mles && term_coeffs && term_offsets && term_mle_idx && out_term_offsets && outs, "NULL argument");
     CHECK_ARG(ctx, num_mles >= 1 && num_terms >= 0 && num_outs >= 1, "empty wit_infer plan");
     CHECK_ARG(ctx, out_term_offsets[0] == 0 && (int)out_term_offsets[num_outs] == num_terms, "out_term_offsets must cover all terms");

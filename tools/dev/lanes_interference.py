@@ -13,7 +13,8 @@ new_tr = lambda: prover.Transcript.stub(0x5A)
 fork = lambda: prover.Transcript.stub(0xF0)
 for lanes in [int(x) for x in os.environ.get("LANES", "1,4").split(",")]:
     best = None
-    for _ in range(4):
+    for rep in range(int(os.environ.get("REPS", "4"))):
+        print(f"=== lanes {lanes} rep {rep}", file=sys.stderr, flush=True)
         r = flow.run(new_tr, fork, lanes=lanes)
         if best is None or r["chip_proofs_ms"] < best["chip_proofs_ms"]:
             best = r
