@@ -638,6 +638,37 @@ def test_shard_flow_end_to_end_verifies(dev, prover, lanes):
     flow.close()
 
 
+@pytest.mark.gpu
+def test_concurrent_lanes_produce_the_single_lane_proofs_every_time(dev, prover):
+    """A soak of the chip scheduler: twelve chips of 2^8 .. 2^13 rows proved on one lane, then eight times over on four lanes (every lane
+    beginning and releasing sumcheck handles, towers and record tables at the same moments: the pool's lock, the handles' arenas, the
+    stream tags of recycled blocks).  Forked transcripts make a proof a function of its task alone: every word must come back
+    identical, whatever the interleaving."""
+    from ceno_amd import synthetic
+
+    w = 22
+    alpha, beta = (5, 6), (7, 8)
+    coeffs, terms, out_terms = synthetic.record_plan(w, 16, alpha, beta)
+    logs = (13, 8, 12, 9, 11, 10, 10, 11, 9, 12, 8, 13)
+    cols = [[dev.synthetic(r, False, 0x700 + 37 * i + j) for j in range(w)] for i, r in enumerate(logs)]
+    tasks = prover.ChipTasks([dict(circuit_idx=i, mles=cols[i], n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3, log2_num_instances=r,
+                                   num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms,
+                                   record_out_terms=out_terms) for i, r in enumerate(logs)])
+
+    def run(lanes):
+        forks = [prover.Transcript.stub(0xF0 + i) for i in range(len(logs))]
+        proofs = prover.create_chip_proofs(dev, tasks, [alpha, beta], forks, lanes)
+        return [(p.tower_msgs, p.tower_prod_evals, p.tower_logup_evals, p.tower_point, p.rt_main, p.r_out_evals, p.w_out_evals, p.lk_out_evals,
+                 np.array(f.sample_ext(), dtype=np.uint64)) for p, f in zip(proofs, forks)]
+
+    want = run(1)
+    for rep in range(8):
+        got = run(4)
+        for i, (a, b) in enumerate(zip(want, got)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (rep, i)
+
+
 def _stub_absorb(t, word):
     """one absorb step of the SplitMix stub transcript (oracle/oracle.c orc_stub_*; host/transcript.cpp Stub::absorb)"""
     M = (1 << 64) - 1
