@@ -229,11 +229,11 @@ inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
 // (batched main sumcheck 12.9 -> 11.8 ms, tools/dev/ab_gen_maxb.sh).  Cached per (kernel, LDS size).
 template <typename F>
 inline unsigned resident_grid(ceno_hip_ctx* ctx, F kernel, int block, size_t dyn_lds, unsigned max_blocks) {
-    static std::mutex mu;
+    static PoolMutex mu;  // (a map lookup per launch, from every lane: a spin lock like the pool's)
     static std::map<std::pair<const void*, size_t>, unsigned> cache;
     const std::pair<const void*, size_t> key{reinterpret_cast<const void*>(kernel), dyn_lds >> 10};
     {
-        std::lock_guard<std::mutex> lk(mu);
+        std::lock_guard<PoolMutex> lk(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return std::min(it->second, max_blocks);
     }
@@ -241,7 +241,7 @@ inline unsigned resident_grid(ceno_hip_ctx* ctx, F kernel, int block, size_t dyn
     unsigned g = max_blocks;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) == hipSuccess && nb > 0) g = (unsigned)nb * (unsigned)ctx->num_cus;
     else (void)hipGetLastError();
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<PoolMutex> lk(mu);
     cache[key] = g;
     return std::min(g, max_blocks);
 }

@@ -581,11 +581,11 @@ static int mid_occupancy_d(size_t lds) {
 int mid_blocks_per_cu(int d, size_t n_mles, size_t S0, size_t n_flat) {
     const size_t lds = mid_lds_bytes(n_mles, S0, std::min(std::max(d, 1), 8), n_flat);
     // cached by (degree, LDS rounded up to 2 KB): the query costs a few microseconds and sits in front of every tower layer
-    static std::mutex mu;
+    static PoolMutex mu;
     static std::map<std::pair<int, size_t>, int> cache;
     const std::pair<int, size_t> key{std::min(std::max(d, 1), 8), (lds + 2047) / 2048};
     {
-        std::lock_guard<std::mutex> g(mu);
+        std::lock_guard<PoolMutex> g(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
     }
@@ -601,7 +601,7 @@ int mid_blocks_per_cu(int d, size_t n_mles, size_t S0, size_t n_flat) {
     case 7: nb = mid_occupancy_d<7>(q); break;
     default: nb = mid_occupancy_d<8>(q); break;
     }
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<PoolMutex> g(mu);
     cache[key] = nb;
     return nb;
 }
