@@ -826,6 +826,7 @@ struct GenRound {
     size_t off_comps_eq = 0;
     int n_comps_eq = 0;
     unsigned grid_eq = 0;
+    size_t off_wg_comp = 0;  // uint16 per workgroup of the component-aligned launch: its component
     size_t stage_bytes_eq = 0;
     bool direct0 = false;      // the eq list is laid out for k_eq_base0 (first round, base-field columns, no LDS stage)
 };
@@ -1378,6 +1379,7 @@ static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
 }
 
 static int sc_build_gen(ceno_hip_sumcheck* sc) {
+    CENO_TIMED("sc_build_gen");
     ceno_hip_ctx* ctx = sc->ctx;
     if (sc->n < gen_min_log()) return 0;
     // a single class covering all variables runs pipelined (tower layers, one chip's main sumcheck), where k_gen is off unless
@@ -1593,6 +1595,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         comps.insert(comps.end(), mine.begin(), mine.end());
     }
     if (comps.empty()) return 0;
+    CENO_TIMED("sc_build_gen: from the slot schedule on");
     // ---- slot schedule of every round (simulation of the buffer ping-pong of sc_round / sc_advance) ----
     size_t slots_per_round = 0;
     for (auto& C : comps) {
@@ -1624,6 +1627,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                         }
         }
     }
+    CENO_TIMED("sc_build_gen: from the component lists on");
     // ---- component lists per round ----
     for (size_t k = 0; k < comps.size(); k++)
         if (comps[k].geq >= 0) sc->geq.comps[comps[k].geq].comp = (int)k;
@@ -1752,8 +1756,15 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             R.n_comps_eq = (int)list_eq.size();
             R.off_comps_eq = append(list_eq.data(), list_eq.size() * sizeof(GenComp));
             for (size_t k = 0; k < list_eq.size(); k++) comp_fix.push_back(R.off_comps_eq + k * sizeof(GenComp));
+            // workgroup -> component, one scalar load (walking the list cost the last of 24 components ~10 us of dependent loads in
+            // every round: CENO_HIP_GEN_PHASE_DBG=1)
+            std::vector<uint16_t> wg_comp(wg);
+            for (size_t k = 0; k < list_eq.size(); k++)
+                for (unsigned x = 0; x < list_eq[k].wg_count; x++) wg_comp[list_eq[k].wg_begin + x] = (uint16_t)k;
+            R.off_wg_comp = append(wg_comp.data(), wg_comp.size() * sizeof(uint16_t));
         }
     }
+    CENO_TIMED("sc_build_gen: allocation + upload");
     // ---- one device allocation, pointers fixed up, one copy from pinned staging ----
     void* d = nullptr;
     TRY(sc_dev_alloc(sc, blob.size(), &d));
@@ -2887,7 +2898,12 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             ctx->eq_launches.fetch_add(1, std::memory_order_relaxed);
             ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);
             ep.d = 0;
-            GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters};
+            GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters, reinterpret_cast<const uint16_t*>(sc->d_gen + R.off_wg_comp)};
+            static const bool phase_dbg = getenv("CENO_HIP_GEN_PHASE_DBG") != nullptr;  // device-side phase stamps of the launch's last workgroup
+            if (phase_dbg) {
+                ep.bcast = sc->d_bcast;
+                ep.dbg = 1;
+            }
             prof_begin(ctx, sc->st);
             if (R.direct0) launch_eq_base0(ctx, d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, ep, ea, R.grid_eq, sc->st);
             else launch_gen(ctx, d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, 0, r, ep, R.stage_bytes_eq, sc->st, &ea,
@@ -2977,7 +2993,26 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             HIP_TRY(ctx, hipStreamSynchronize(sc->st));
         } else {
             memcpy(h_out, scalars, (size_t)d * sizeof(E2));
+            if (phases) clock_gettime(CLOCK_MONOTONIC, &tp3);
             if (sc->geq.on) TRY(geq_collect(sc, i, r, h_out));
+            if (phases) {
+                timespec tp4;
+                clock_gettime(CLOCK_MONOTONIC, &tp4);
+                auto us = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) / 1e3; };
+                static timespec last_ret = tp4;
+                fprintf(stderr, "[ceno_hip] round %d of %d (eq-factored): caller %.1f us, retire %.1f us, scalars %.1f us, arm + launch %.1f us, wait + complete %.1f us\n", i, sc->n,
+                        us(last_ret, tp0), us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
+                last_ret = tp4;
+            }
+            if (sc->geq.on && getenv("CENO_HIP_GEN_PHASE_DBG") && sc->d_bcast) {
+                static Bcast hb;
+                (void)hipStreamSynchronize(sc->st);
+                if (hipMemcpy(&hb, sc->d_bcast, sizeof(Bcast), hipMemcpyDeviceToHost) == hipSuccess) {
+                    const unsigned long long* a = hb.dbg[seq & 31];
+                    fprintf(stderr, "[ceno_hip] eq round %d, last workgroup: find component %.1f us, phase 1 %.1f us, groups %.1f us, epilogue %.1f us\n", i,
+                            (a[1] - a[0]) / 100.0, (a[2] - a[1]) / 100.0, (a[3] - a[2]) / 100.0, (hb.dbg[32 + (seq & 31)][0] - a[3]) / 100.0);
+                }
+            }
         }
     } else if (h_out) {
         if (phases) clock_gettime(CLOCK_MONOTONIC, &tp3);

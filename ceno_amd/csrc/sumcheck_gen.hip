@@ -635,13 +635,19 @@ __global__ void __launch_bounds__(NT, gen_eq_min_waves(D, BASE0)) k_gen_eq(const
     E2 acc[D];
 #pragma unroll
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    // CENO_HIP_GEN_PHASE_DBG=1: the last workgroup of the launch stamps its phases (100 MHz wall clock) into bcast->dbg rows seq and seq + 32
+    const bool stamp = ep.dbg && ep.bcast && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
+    if (stamp) ep.bcast->dbg[ep.seq & 31][0] = wall_clock64();
     // the component this workgroup belongs to (component-aligned launch: comps are sorted by wg_begin, every one owns >= 1 workgroup)
     int c = 0;
-    while (c + 1 < n_comps && comps[c + 1].wg_begin <= blockIdx.x) c++;
+    if (eqa.wg_comp) c = (int)ldc_u16(eqa.wg_comp + blockIdx.x);
+    else
+        while (c + 1 < n_comps && comps[c + 1].wg_begin <= blockIdx.x) c++;
     const GenComp& C = comps[c];
     const unsigned tp = 1u << C.tp_log, tpp = tp + GEN_PAD;
     const unsigned wt = 1u << C.wt_log;
     const unsigned ts = (unsigned)wave & (wt - 1), q = (((unsigned)wave >> C.wt_log) << 6) + lane;
+    if (stamp) ep.bcast->dbg[ep.seq & 31][1] = wall_clock64();
     for (unsigned tile = blockIdx.x - C.wg_begin; tile < C.n_tiles; tile += C.wg_count) {
         const size_t p0 = (size_t)tile << C.tp_log;
         gen_phase1<BASE0>(C, p0, stage, rp, r, wave, lane);
@@ -651,11 +657,14 @@ __global__ void __launch_bounds__(NT, gen_eq_min_waves(D, BASE0)) k_gen_eq(const
             continue;
         }
         __syncthreads();
+        if (stamp) ep.bcast->dbg[ep.seq & 31][2] = wall_clock64();
         const bool valid = q < tp && p0 + q < C.pairs;
         for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq<D, BASE0>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out);
         __syncthreads();  // the stage (and the exchange block) are reused by the next tile
     }
+    if (stamp) ep.bcast->dbg[ep.seq & 31][3] = wall_clock64();
     epilogue_eq<D>(acc, C, ep, eqa, smem, s_flag);
+    if (stamp) ep.bcast->dbg[32 + (ep.seq & 31)][0] = wall_clock64();
 }
 
 // First round of an eq-factored batch whose terms are products of BASE-field columns (the main-constraint sumcheck before any fold):
@@ -672,7 +681,9 @@ __global__ void __launch_bounds__(NT) k_eq_base0(const GenComp* __restrict__ com
 #pragma unroll
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
     int c = 0;
-    while (c + 1 < n_comps && comps[c + 1].wg_begin <= blockIdx.x) c++;
+    if (eqa.wg_comp) c = (int)ldc_u16(eqa.wg_comp + blockIdx.x);
+    else
+        while (c + 1 < n_comps && comps[c + 1].wg_begin <= blockIdx.x) c++;
     const GenComp& C = comps[c];
     const size_t p_begin = (size_t)C.p2_tile_begin << C.tp_log;
     const size_t p_end = std::min<size_t>((size_t)C.p2_tile_end << C.tp_log, (size_t)C.pairs);

@@ -53,6 +53,7 @@ struct GenEqArgs {
     E2* q_out;                 // host-mapped: [eq_slot][D] per-component quotient sums (armed by the host)
     E2* b_out;                 // host-mapped: [brow + side][D] scaled values of a boundary pair (armed by the host where one exists)
     unsigned* counters;        // device: arrival counter per eq_slot (components with several workgroups), zero between launches
+    const uint16_t* wg_comp;   // device: the component of every workgroup of the launch (NULL: walk the list)
 };
 
 // LDS of a launch: fixed block + staged rows + the cross-wave exchange of partial group sums (4 waves x D points x 64 lanes)
