@@ -801,6 +801,12 @@ struct ScClass {
     std::vector<uint32_t> h_gto, h_gt, h_co, h_ci, h_to, h_ti;
     std::vector<E2> h_coeffs;
     bool gen = false;         // rounds of this class run in the merged k_gen launch (sumcheck_gen.hip)
+    // once the class is a scalar: its terms' constant parts c_t prod_j eval_j summed by number of factors (the class's tail and the point
+    // enter as powers: sum_t c_t prod_j (eval_j tail (x + 1)) = sum_k front_sum[k] tail^k (x + 1)^k) and the terms that do not fit the form
+    bool front_grouped = false;
+    E2 front_sum[17];
+    bool front_has[17] = {};
+    std::vector<int> front_slow;
 };
 
 // one connected component of a class's plan (a chip of a batched main sumcheck: its columns, selectors and terms)
@@ -2780,7 +2786,8 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             became_scalar = &cl;  // at most one class reaches its last variable per round
         }
     }
-    if (became_scalar) {
+    auto retire_wait = [&]() -> int {
+        if (!became_scalar) return 0;
         ScClass* cl = became_scalar;
         E2* h_ev = sc->h_pinned + MAXD;
         HIP_TRY(ctx, hipGetLastError());
@@ -2792,52 +2799,74 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             M.cur = M.buf[M.which];
             M.cur_ext = 1;
         }
-    }
+        return 0;
+    };
+    // A round whose only launch is the eq-factored one hands nothing of the retired classes to the device (the host adds their scalars to
+    // the message): the wait for a retiring class's evaluations (~10 us) and the scalars then overlap the round's kernel
+    bool defer_retire = sc->geq.on && h_out && !d_out && sc->gen_on && i > 0 && sc->gen_rounds[i].n_comps == 0;
+    for (auto& cl : sc->classes)
+        if (cl.nv > i && (cl.dense || !cl.gen)) defer_retire = false;
+    if (!defer_retire) TRY(retire_wait());
     if (phases) clock_gettime(CLOCK_MONOTONIC, &tp1);
     // ---- 2. front-loaded contributions: c_t * prod_j (eval_j * tail_j * t)   (scheme/verifier.rs:233-237) ----
     E2 scalars[MAXD];
     for (int x = 0; x < MAXD; x++) scalars[x] = e2_zero();
+    auto compute_scalars = [&]() {
     // c_t prod_j (eval_j tail_j (x + 1)) = (x + 1)^|T| c_t prod_j (eval_j tail_j): the product once per term and round, a small base-field
     // power per point (the retired chips of a mixed-size batch cost 20-40 us of host arithmetic per round with one product per point)
+    // (per retired class ONE product per distinct term size and round — the 16 terms of each of ~20 retired chips cost 4-12 us per round
+    // term by term: CENO_HIP_ROUND_PHASES=1)
+    uint64_t pw[MAXD][17];  // (x + 1)^k
+    for (int x = 0; x < d; x++) {
+        pw[x][0] = 1;
+        for (int k = 1; k < 17; k++) pw[x][k] = gl::mul(pw[x][k - 1], (uint64_t)(x + 1));
+    }
     for (auto& cl : sc->classes) {
         if (cl.nv > i) continue;
-        E2 tail_pow[17];  // powers of the class's tail (one multiplication per term and round where all factors share it)
-        int n_pow = 0;
-        for (int t : cl.terms) {
-            ScTerm& T = sc->terms[t];
-            if (!T.front_ready) {
+        if (!cl.front_grouped) {
+            const int this_cls = (int)(&cl - sc->classes.data());
+            for (int k = 0; k < 17; k++) cl.front_sum[k] = e2_zero();
+            for (int t : cl.terms) {
+                ScTerm& T = sc->terms[t];
                 T.front = T.coeff;
                 T.front_one_class = !T.full.empty() && T.full.size() <= 16;
-                const int this_cls = (int)(&cl - sc->classes.data());
                 for (int j : T.full) {
                     T.front = T.front * sc->mles[j].eval;
                     if (sc->mles[j].cls != this_cls) T.front_one_class = false;  // a factor that retired earlier carries another tail
                 }
                 T.front_ready = true;
-            }
-            E2 pv;
-            if (T.front_one_class) {
-                if (n_pow == 0) {
-                    tail_pow[0] = e2_one();
-                    n_pow = 1;
+                if (T.front_one_class) {
+                    cl.front_sum[T.full.size()] = cl.front_sum[T.full.size()] + T.front;
+                    cl.front_has[T.full.size()] = true;
+                } else {
+                    cl.front_slow.push_back(t);
                 }
-                const E2 tl = sc->mles[T.full[0]].tail;
-                while (n_pow <= (int)T.full.size()) {
-                    tail_pow[n_pow] = tail_pow[n_pow - 1] * tl;
-                    n_pow++;
-                }
-                pv = T.front * tail_pow[T.full.size()];
-            } else {
-                pv = T.coeff;
-                for (int j : T.full) pv = pv * (sc->mles[j].eval * sc->mles[j].tail);
             }
+            cl.front_grouped = true;
+        }
+        if (!cl.mles.empty()) {
+            const E2 tl = sc->mles[cl.mles[0]].tail;  // every table of a class has the class's number of variables, hence its tail
+            E2 tp_ = e2_one();
+            for (int k = 1; k < 17; k++) {
+                tp_ = tp_ * tl;
+                if (!cl.front_has[k]) continue;
+                const E2 pv = cl.front_sum[k] * tp_;
+                for (int x = 0; x < d; x++) scalars[x] = scalars[x] + e2_mul_base(pv, pw[x][k]);
+            }
+        }
+        for (int t : cl.front_slow) {
+            ScTerm& T = sc->terms[t];
+            E2 pv = T.coeff;
+            for (int j : T.full) pv = pv * (sc->mles[j].eval * sc->mles[j].tail);
             for (int x = 0; x < d; x++) {
-                uint64_t pw = 1;  // (x + 1)^|T| < 2^64 for every plan this library accepts (d <= MAXD = 8 points, |T| <= 8 + 8 factors ... reduced below)
-                for (size_t k = 0; k < T.full.size(); k++) pw = gl::mul(pw, (uint64_t)(x + 1));
-                scalars[x] = scalars[x] + e2_mul_base(pv, pw);
+                uint64_t w = 1;
+                for (size_t k = 0; k < T.full.size(); k++) w = gl::mul(w, (uint64_t)(x + 1));
+                scalars[x] = scalars[x] + e2_mul_base(pv, w);
             }
         }
     }
+    };
+    if (!defer_retire) compute_scalars();
     if (phases) clock_gettime(CLOCK_MONOTONIC, &tp2);
     // ---- 3. live classes: dense classes launch their fused kernel, all classes with component tables share ONE k_gen
     // launch, the rest take the two-kernel path; the last launch that accumulates finishes the message ----
@@ -2985,6 +3014,11 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
     if (i > 0)
         for (ScClass* cl : live) sc_advance(sc, *cl);
     HIP_TRY(ctx, hipGetLastError());
+    if (defer_retire) {
+        if (last_acc >= 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: a deferred retirement met a round that accumulates on the device");
+        TRY(retire_wait());
+        compute_scalars();
+    }
     if (last_acc < 0) {
         // no term is live in this round: the message consists of the front-loaded scalars only
         if (d_out) {
