@@ -1897,6 +1897,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     for (int t = 0; t < plan->num_terms; t++)
         if (term_group[t] < 0 && (int)sc->terms[t].idx.size() > d) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d exceeds max_degree %d", t, d); }
 
+    CENO_TIMED("sc_build: from the size classes on");
     // ---- size classes (descending nv); every MLE belongs to the class of its nv ----
     std::vector<int> nvs;
     for (auto& M : sc->mles) nvs.push_back(M.nv);
@@ -1914,6 +1915,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
     }
     for (int t = 0; t < plan->num_terms; t++) sc->classes[class_of(sc->terms[t].nv)].terms.push_back(t);
 
+    CENO_TIMED("sc_build: from the working buffers on");
     // ---- working buffers per MLE ----
     for (auto& M : sc->mles) {
         if (M.nv >= 1) {
@@ -1930,6 +1932,7 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
     }
 
+    CENO_TIMED("sc_build: from the per-class plans on");
     // ---- per-class plans: every array goes into ONE blob, uploaded with a single copy from pinned memory ----
     uint32_t part_off = 0;
     size_t total_slots = 0;
