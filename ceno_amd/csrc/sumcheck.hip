@@ -833,6 +833,7 @@ struct GenRound {
     int n_comps_eq = 0;
     unsigned grid_eq = 0;
     size_t off_wg_comp = 0;  // uint16 per workgroup of the component-aligned launch: its component
+    bool slots = false;      // every component of the eq launch is one tile: one workgroup per component and slot (k_gen_eq_slots)
     size_t stage_bytes_eq = 0;
     bool direct0 = false;      // the eq list is laid out for k_eq_base0 (first round, base-field columns, no LDS stage)
 };
@@ -1745,10 +1746,23 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             }
             const unsigned cap = std::max<unsigned>(direct0 ? eq_base0_resident_cap(ctx, sc->d) : gen_resident_cap(ctx, sc->d, base0, R.stage_bytes_eq),
                                                     (unsigned)list_eq.size());
+            // small rounds: every component a single tile -> one workgroup per component and SLOT (the four waves of a lone workgroup
+            // walking 4-8 terms each were the longest phase of such a round: CENO_HIP_GEN_PHASE_DBG=1).  CENO_HIP_EQ_SLOTS=0: off (A/B, read per build)
+            const bool no_slots = getenv("CENO_HIP_EQ_SLOTS") && atoi(getenv("CENO_HIP_EQ_SLOTS")) == 0;
+            bool slots = !no_slots && i > 0 && !direct0 && sc->d >= 3 && total == list_eq.size() && list_eq.size() * (size_t)sc->d <= cap;
+            R.slots = slots;
             unsigned wg = 0;
             for (size_t k = 0; k < list_eq.size(); k++) {
                 GenComp& G = list_eq[k];
                 unsigned cnt = G.n_tiles;
+                if (slots && G.n_groups > 0) {
+                    cnt = (unsigned)sc->d;
+                    G.eqf |= 4u;
+                    G.wg_begin = wg;
+                    G.wg_count = cnt;
+                    wg += cnt;
+                    continue;
+                }
                 if (total > cap) {
                     const double share = wsum > 0 ? weight_eq[k] / wsum : 0.0;
                     cnt = 1u + (unsigned)(share * (double)(cap - (unsigned)list_eq.size()));
@@ -2938,6 +2952,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             }
             prof_begin(ctx, sc->st);
             if (R.direct0) launch_eq_base0(ctx, d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, ep, ea, R.grid_eq, sc->st);
+            else if (R.slots) launch_gen_eq_slots(d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, r, ep, R.stage_bytes_eq, sc->st, ea, R.grid_eq);
             else launch_gen(ctx, d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, 0, r, ep, R.stage_bytes_eq, sc->st, &ea,
                             R.grid_eq);
             prof_end(ctx, sc->st, 0.0);

@@ -667,6 +667,114 @@ __global__ void __launch_bounds__(NT, gen_eq_min_waves(D, BASE0)) k_gen_eq(const
     if (stamp) ep.bcast->dbg[32 + (ep.seq & 31)][0] = wall_clock64();
 }
 
+// ONE slot of an eq group (small rounds: a component of a single tile is given D workgroups, one per slot — its four waves walking 4-8 terms
+// each, one pair per lane, were the longest phase of a small round, and the slots are independent chains of the same length).  Slot numbering
+// as in gen_group_eq; extension-field tables only.
+template <int D, int S>
+__device__ __forceinline__ E2 gen_eq_slot_terms(const GenComp& C, unsigned term_begin, unsigned term_end, unsigned ts, unsigned wt, const E2* stage, unsigned tpp,
+                                                unsigned q, unsigned slot, bool extra) {
+    if constexpr (S < D - 1) {
+        if (slot == (unsigned)S) {
+            if (S == D - 2 && !extra) return e2_zero();
+            E2 o[1];
+            gen_eq_terms<1, false, S, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, o);  // X = S + 1
+            return o[0];
+        }
+        return gen_eq_slot_terms<D, S + 1>(C, term_begin, term_end, ts, wt, stage, tpp, q, slot, extra);
+    } else {
+        E2 o[1];
+        gen_eq_terms<0, true, 0, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, o);  // the leading coefficient
+        return o[0];
+    }
+}
+template <int D>
+__device__ __forceinline__ void gen_group_eq_slot(const GenComp& C, unsigned g, const E2* stage, E2* xch, unsigned tpp, unsigned q, unsigned ts, unsigned wt,
+                                                  bool valid, size_t pair, int wave, unsigned lane, E2 (&acc)[D], E2* b_out, unsigned slot) {
+    const gen_u4 gw = ldc4(C.groups + g);
+    const gen_u4 gw3 = ldc4(reinterpret_cast<const char*>(C.groups + g) + 16);
+    const gen_u4 gw4 = ldc4(reinterpret_cast<const char*>(C.groups + g) + 32);
+    const unsigned term_begin = gw.x, term_end = gw.y;
+    const unsigned sel_row = (unsigned)(gw3.x & 0xff) * tpp + q, brow = gw3.w;
+    const uint64_t lo = u64_of(gw4.x, gw4.y), hi = u64_of(gw4.z, gw4.w);
+    const unsigned sh = C.shift;
+    const uint64_t s0 = (uint64_t)(2 * pair) << sh, s1 = (uint64_t)(2 * pair + 1) << sh, s2 = (uint64_t)(2 * pair + 2) << sh;
+    const bool full0 = lo <= s0 && s1 <= hi, full1 = lo <= s1 && s2 <= hi;
+    const bool empty0 = s1 <= lo || s0 >= hi, empty1 = s2 <= lo || s1 >= hi;
+    const bool irr = valid && !((full0 && full1) || (empty0 && empty1));
+    const bool extra = (C.eqf & 2) != 0 || __builtin_amdgcn_ballot_w64(irr) != 0;
+    const E2 inner = gen_eq_slot_terms<D, 0>(C, term_begin, term_end, ts, wt, stage, tpp, q, slot, extra);
+    if (wt > 1) {
+        __syncthreads();
+        xch[(unsigned)wave * 64 + lane] = inner;
+        __syncthreads();
+    }
+    if (wt > 1 && ts != 0) return;  // the first wave of every group of wt finishes the slot
+    if (slot == (unsigned)(D - 2) && !extra) return;
+    const E2 e1 = stage[sel_row], e0 = stage[sel_row + tpp] + e1;  // staged: (f(1), f(0) - f(1))
+    E2 w = e0 + e1, cb = e2_zero();
+    if (irr) {
+        w = e0 * C.inv1m;
+        cb = e1 - w * C.rt;
+    }
+    const unsigned side = pair == (size_t)((lo >> sh) >> 1) ? 0u : 1u;
+    E2 v = inner;
+    if (wt > 1)
+        for (unsigned s = 1; s < wt; s++) v = v + xch[((unsigned)wave + s) * 64 + lane];
+    if (irr) {
+        const E2 bv = cb * v;
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+        const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(b_out + (size_t)(brow + side) * D + slot), "v"(ww) : "memory");
+    }
+    if (valid) {
+        const E2 add = w * v;
+#pragma unroll
+        for (int t = 0; t < D; t++)
+            if ((unsigned)t == slot) acc[t] = acc[t] + add;
+    }
+}
+
+// The small rounds of an eq-factored batch: every component is ONE tile, and gets D workgroups — one per slot (gen_group_eq_slot).  A kernel of
+// its own: the slot forms inlined into k_gen_eq cost it its third wave per SIMD at degree 3.  Every workgroup stages the tile and writes the
+// same folded tables (identical words); each writes its own word of the component's row straight into the host's armed words.
+template <int D>
+__global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__ comps, int n_comps, E2 r, Epilogue ep, unsigned xch_off, GenEqArgs eqa) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    E2* smem = reinterpret_cast<E2*>(dyn);
+    E2* stage = reinterpret_cast<E2*>(dyn + GEN_FIXED);
+    E2* xch = reinterpret_cast<E2*>(dyn + GEN_FIXED + xch_off);  // [wave][64]
+    const E2Pre rp = e2_pre(r);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63;
+    E2 acc[D];
+#pragma unroll
+    for (int t = 0; t < D; t++) acc[t] = e2_zero();
+    const int c = (int)ldc_u16(eqa.wg_comp + blockIdx.x);
+    const GenComp& C = comps[c];
+    const unsigned slot = blockIdx.x - C.wg_begin;
+    const unsigned tp = 1u << C.tp_log, tpp = tp + GEN_PAD;
+    const unsigned wt = 1u << C.wt_log;
+    const unsigned ts = (unsigned)wave & (wt - 1), q = (((unsigned)wave >> C.wt_log) << 6) + lane;
+    gen_phase1<false>(C, 0, stage, rp, r, wave, lane);
+    if (C.n_groups == 0) return;  // folded only
+    __syncthreads();
+    if (C.p2_tile_begin == 0 && C.p2_tile_end >= 1) {
+        const bool valid = q < tp && q < C.pairs;
+        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq_slot<D>(C, g, stage, xch, tpp, q, ts, wt, valid, (size_t)q, wave, lane, acc, eqa.b_out, slot);
+        __syncthreads();
+    }
+    red::block_sum<D, NT>(acc, smem);
+    if (threadIdx.x == 0) {
+        typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int t = 0; t < D; t++) {
+            if ((unsigned)t != slot) continue;
+            const u4 ww = {(unsigned)acc[t].c0, (unsigned)(acc[t].c0 >> 32), (unsigned)acc[t].c1, (unsigned)(acc[t].c1 >> 32)};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(eqa.q_out + (size_t)C.eq_slot * D + t), "v"(ww) : "memory");
+        }
+    }
+}
+
 // First round of an eq-factored batch whose terms are products of BASE-field columns (the main-constraint sumcheck before any fold):
 // nothing is folded and nothing is shared through LDS — every lane walks the terms of its pair with the column pairs straight from
 // L1 / L2 (k_accum_base0's form: the staged kernel pays two barriers and an LDS round trip per tile for columns that are read once or
@@ -838,6 +946,20 @@ unsigned gen_resident_cap(ceno_hip_ctx* ctx, int d, bool base0, size_t stage_byt
     case 7: return gen_cap_d<7>(ctx, base0, true, gen_lds_bytes(7, stage_bytes));
     case 8: return gen_cap_d<8>(ctx, base0, true, gen_lds_bytes(8, stage_bytes));
     default: return MAXB;
+    }
+}
+
+void launch_gen_eq_slots(int d, const GenComp* comps, int n_comps, E2 r, const Epilogue& ep, size_t stage_bytes, hipStream_t st, const GenEqArgs& eq,
+                          unsigned grid) {
+    const size_t lds = gen_lds_bytes(d, stage_bytes);
+    const unsigned xch_off = (unsigned)((stage_bytes + 15) & ~(size_t)15);
+    switch (d) {
+    case 3: hipLaunchKernelGGL((k_gen_eq_slots<3>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
+    case 4: hipLaunchKernelGGL((k_gen_eq_slots<4>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
+    case 5: hipLaunchKernelGGL((k_gen_eq_slots<5>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
+    case 6: hipLaunchKernelGGL((k_gen_eq_slots<6>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
+    case 7: hipLaunchKernelGGL((k_gen_eq_slots<7>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
+    default: hipLaunchKernelGGL((k_gen_eq_slots<8>), dim3(grid), dim3(NT), lds, st, comps, n_comps, r, ep, xch_off, eq); break;
     }
 }
 

@@ -65,5 +65,8 @@ unsigned gen_resident_cap(ceno_hip_ctx* ctx, int d, bool base0, size_t stage_byt
 // (factor bytes = MLE indices), component-aligned grid
 unsigned eq_base0_resident_cap(ceno_hip_ctx* ctx, int d);
 void launch_eq_base0(ceno_hip_ctx* ctx, int d, const GenComp* comps, int n_comps, const Epilogue& ep, const GenEqArgs& eq, unsigned grid, hipStream_t st);
+// the small rounds of an eq-factored batch (every component one tile, d >= 3): one workgroup per component and slot (sumcheck_gen.hip k_gen_eq_slots)
+void launch_gen_eq_slots(int d, const GenComp* comps, int n_comps, E2 r, const Epilogue& ep, size_t stage_bytes, hipStream_t st, const GenEqArgs& eq,
+                          unsigned grid);
 void launch_gen(ceno_hip_ctx* ctx, int d, bool base0, const GenComp* comps, int n_comps, unsigned total_tiles, E2 r, const Epilogue& ep, size_t stage_bytes,
                 hipStream_t st, const GenEqArgs* eq = nullptr, unsigned aligned_grid = 0);
