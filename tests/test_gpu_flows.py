@@ -274,6 +274,11 @@ def test_eq_factored_main_constraints_match_the_oracle(dev, prover, monkeypatch,
         monkeypatch.setenv("CENO_HIP_EQ_DIRECT0", "0")
         c3, m3, r3, e3 = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
         assert c3 == claimed and np.array_equal(m3, msgs) and np.array_equal(e3, evals)
+    else:  # ... and with the small rounds on one workgroup per component (k_gen_eq) instead of one per component and slot (k_gen_eq_slots)
+        monkeypatch.delenv("CENO_HIP_GEN_EQF")
+        monkeypatch.setenv("CENO_HIP_EQ_SLOTS", "0")
+        c3, m3, r3, e3 = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+        assert c3 == claimed and np.array_equal(m3, msgs) and np.array_equal(e3, evals)
 
 
 @pytest.mark.parametrize("max_degree", [4, 3])
