@@ -1746,17 +1746,18 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             }
             const unsigned cap = std::max<unsigned>(direct0 ? eq_base0_resident_cap(ctx, sc->d) : gen_resident_cap(ctx, sc->d, base0, R.stage_bytes_eq),
                                                     (unsigned)list_eq.size());
-            // small rounds: every component a single tile -> one workgroup per component and SLOT (the four waves of a lone workgroup
-            // walking 4-8 terms each were the longest phase of such a round: CENO_HIP_GEN_PHASE_DBG=1).  CENO_HIP_EQ_SLOTS=0: off (A/B, read per build)
+            // small rounds -> one workgroup per tile and SLOT (the four waves of a workgroup walking 4-8 terms each, one pair per lane, were
+            // the longest phase of such a round: CENO_HIP_GEN_PHASE_DBG=1).  CENO_HIP_EQ_SLOTS=0: off (A/B, read per build)
             const bool no_slots = getenv("CENO_HIP_EQ_SLOTS") && atoi(getenv("CENO_HIP_EQ_SLOTS")) == 0;
-            bool slots = !no_slots && i > 0 && !direct0 && sc->d >= 3 && total == list_eq.size() && list_eq.size() * (size_t)sc->d <= cap;
+            // (one workgroup per TILE and slot as long as the whole launch is resident at once: a workgroup then has one tile, as before)
+            bool slots = !no_slots && i > 0 && !direct0 && sc->d >= 3 && total * (uint64_t)sc->d <= cap;
             R.slots = slots;
             unsigned wg = 0;
             for (size_t k = 0; k < list_eq.size(); k++) {
                 GenComp& G = list_eq[k];
                 unsigned cnt = G.n_tiles;
                 if (slots && G.n_groups > 0) {
-                    cnt = (unsigned)sc->d;
+                    cnt = G.n_tiles * (unsigned)sc->d;
                     G.eqf |= 4u;
                     G.wg_begin = wg;
                     G.wg_count = cnt;

@@ -734,13 +734,16 @@ __device__ __forceinline__ void gen_group_eq_slot(const GenComp& C, unsigned g, 
     }
 }
 
-// The small rounds of an eq-factored batch: every component is ONE tile, and gets D workgroups — one per slot (gen_group_eq_slot).  A kernel of
-// its own: the slot forms inlined into k_gen_eq cost it its third wave per SIMD at degree 3.  Every workgroup stages the tile and writes the
-// same folded tables (identical words); each writes its own word of the component's row straight into the host's armed words.
+// The small rounds of an eq-factored batch: every tile of every component gets D workgroups — one per slot (gen_group_eq_slot) — where the whole
+// launch still fits the chip at once.  A kernel of its own: the slot forms inlined into k_gen_eq cost it its third wave per SIMD at degree 3.
+// The D workgroups of a tile all stage it and write the same folded tables (identical words).  A component of ONE tile: each workgroup writes
+// its own word of the component's row straight into the host's armed words; more tiles: the rows-and-counter epilogue of k_gen_eq (a row
+// holds one slot, the others are zero).
 template <int D>
 __global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__ comps, int n_comps, E2 r, Epilogue ep, unsigned xch_off, GenEqArgs eqa) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     E2* smem = reinterpret_cast<E2*>(dyn);
+    int* s_flag = reinterpret_cast<int*>(dyn + (NT / 64) * MAXD * sizeof(E2) + 32);
     E2* stage = reinterpret_cast<E2*>(dyn + GEN_FIXED);
     E2* xch = reinterpret_cast<E2*>(dyn + GEN_FIXED + xch_off);  // [wave][64]
     const E2Pre rp = e2_pre(r);
@@ -751,17 +754,24 @@ __global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__
     for (int t = 0; t < D; t++) acc[t] = e2_zero();
     const int c = (int)ldc_u16(eqa.wg_comp + blockIdx.x);
     const GenComp& C = comps[c];
-    const unsigned slot = blockIdx.x - C.wg_begin;
+    const unsigned k = blockIdx.x - C.wg_begin;
+    const bool split = (C.eqf & 4) != 0;            // (a fold-only component rides along with one workgroup per tile)
+    const unsigned tile = split ? k / D : k, slot = split ? k % D : 0;
     const unsigned tp = 1u << C.tp_log, tpp = tp + GEN_PAD;
     const unsigned wt = 1u << C.wt_log;
     const unsigned ts = (unsigned)wave & (wt - 1), q = (((unsigned)wave >> C.wt_log) << 6) + lane;
-    gen_phase1<false>(C, 0, stage, rp, r, wave, lane);
+    const size_t p0 = (size_t)tile << C.tp_log;
+    gen_phase1<false>(C, p0, stage, rp, r, wave, lane);
     if (C.n_groups == 0) return;  // folded only
     __syncthreads();
-    if (C.p2_tile_begin == 0 && C.p2_tile_end >= 1) {
-        const bool valid = q < tp && q < C.pairs;
-        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq_slot<D>(C, g, stage, xch, tpp, q, ts, wt, valid, (size_t)q, wave, lane, acc, eqa.b_out, slot);
+    if (tile >= C.p2_tile_begin && tile < C.p2_tile_end) {
+        const bool valid = q < tp && p0 + q < C.pairs;
+        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq_slot<D>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out, slot);
         __syncthreads();
+    }
+    if (C.n_tiles > 1) {
+        epilogue_eq<D>(acc, C, ep, eqa, smem, s_flag);  // (wg_count = n_tiles x D > 1: rows and the component's counter)
+        return;
     }
     red::block_sum<D, NT>(acc, smem);
     if (threadIdx.x == 0) {
