@@ -12,6 +12,8 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <memory>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -23,8 +25,12 @@ using gl::E2;
 struct PoseidonParams;  // poseidon2.hip
 struct ceno_hip_ctx;
 void merkle_drop_host_params(ceno_hip_ctx* ctx);  // poseidon2.hip: frees the host copy of the Poseidon2 table
-void ctx_pipelined_begin(ceno_hip_ctx* ctx);  // ctx.hip: counts a pipelined sumcheck in (waits for a trim in progress)
-void ctx_pipelined_end(ceno_hip_ctx* ctx);
+// ctx.hip: counts a pipelined sumcheck in (waits for a trim in progress, and — on a thread that holds no other pipelined sumcheck — for a
+// trimmer that is waiting for the gate).  The token is the BEGINNING thread's counter: _end gives it back, on whatever thread it runs
+// (a handle released by a finaliser or handed to another thread must not touch the releaser's own count)
+typedef std::shared_ptr<std::atomic<int>> PipelinedOwner;
+PipelinedOwner ctx_pipelined_begin(ceno_hip_ctx* ctx);
+void ctx_pipelined_end(ceno_hip_ctx* ctx, PipelinedOwner& owner);
 bool ctx_trim_begin(ceno_hip_ctx* ctx);       // false: pipelined sumchecks are alive (or another trim runs) — nothing may be hipFree'd now
 void ctx_trim_end(ceno_hip_ctx* ctx);
 
@@ -100,6 +106,7 @@ struct ceno_hip_ctx {
     std::mutex gate_mu;
     std::condition_variable gate_cv;
     bool trimming = false;
+    int trim_pending = 0;  // threads inside ctx_trim_begin_wait (under gate_mu): new pipelined sumchecks of threads that hold none wait for them
     // ---- errors ----
     std::string err;
     // ---- profiling of the dominant kernel (bench.py roofline) ----
@@ -226,24 +233,30 @@ inline unsigned grid_for(size_t work, unsigned block, unsigned max_blocks) {
 // Largest grid (<= max_blocks) of a grid-stride kernel at which EVERY workgroup is resident at once: occupancy (registers, LDS)
 // x compute units.  A kernel bound by VALU issue whose launch exceeds it runs a second, partly filled dispatch wave: k_gen at
 // 168 VGPRs holds 3 workgroups per CU = 768; launched as 1024 the last 256 run alone on their CUs at one wave per SIMD
-// (batched main sumcheck 12.9 -> 11.8 ms, tools/dev/ab_gen_maxb.sh).  Cached per (kernel, LDS size).
+// (batched main sumcheck 12.9 -> 11.8 ms, tools/dev/ab_gen_maxb.sh).  What is cached is the kernel's workgroups PER CU, keyed by
+// everything the occupancy query depends on — (device, kernel, block size, exact dynamic LDS bytes) — and multiplied by the asking
+// context's CU count at the call: two contexts on different devices, or two LDS sizes inside one KB, never share an entry.
 template <typename F>
 inline unsigned resident_grid(ceno_hip_ctx* ctx, F kernel, int block, size_t dyn_lds, unsigned max_blocks) {
     static PoolMutex mu;  // (a map lookup per launch, from every lane: a spin lock like the pool's)
-    static std::map<std::pair<const void*, size_t>, unsigned> cache;
-    const std::pair<const void*, size_t> key{reinterpret_cast<const void*>(kernel), dyn_lds >> 10};
+    typedef std::tuple<int, const void*, int, size_t> Key;
+    static std::map<Key, unsigned> cache;  // -> workgroups per CU (0: the query failed, no cap)
+    const Key key{ctx->device, reinterpret_cast<const void*>(kernel), block, dyn_lds};
+    unsigned per_cu = 0;
+    bool hit = false;
     {
         std::lock_guard<PoolMutex> lk(mu);
         auto it = cache.find(key);
-        if (it != cache.end()) return std::min(it->second, max_blocks);
+        if (it != cache.end()) per_cu = it->second, hit = true;
     }
-    int nb = 0;
-    unsigned g = max_blocks;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) == hipSuccess && nb > 0) g = (unsigned)nb * (unsigned)ctx->num_cus;
-    else (void)hipGetLastError();
-    std::lock_guard<PoolMutex> lk(mu);
-    cache[key] = g;
-    return std::min(g, max_blocks);
+    if (!hit) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) == hipSuccess && nb > 0) per_cu = (unsigned)nb;
+        else (void)hipGetLastError();
+        std::lock_guard<PoolMutex> lk(mu);
+        cache[key] = per_cu;
+    }
+    return per_cu ? std::min(per_cu * (unsigned)ctx->num_cus, max_blocks) : max_blocks;
 }
 
 // ---- kernels exported across translation units ----

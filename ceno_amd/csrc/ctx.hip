@@ -94,30 +94,56 @@ static bool stream_drained(hipStream_t s) {
 }
 
 // pipelined sumchecks the CALLING thread has begun and not ended yet: a thread that holds none may wait for the trim gate (the lanes'
-// sumchecks end within milliseconds); one that does must not — its own queued kernels are among those a trim would wait for
-static thread_local int tls_pipelined = 0;
-void ctx_pipelined_begin(ceno_hip_ctx* ctx) {
-    CENO_TIMED("ctx_pipelined_begin");
-    std::unique_lock<std::mutex> lk(ctx->gate_mu);
-    ctx->gate_cv.wait(lk, [&] { return !ctx->trimming; });
-    ctx->pipelined_live.fetch_add(1);
-    tls_pipelined++;
+// sumchecks end within milliseconds); one that does must not — its own queued kernels are among those a trim would wait for.  The counter
+// lives on the heap and every handle keeps a reference to the counter of the thread that BEGAN it, so that an end on another thread (a
+// finaliser, a handle handed over) decrements the right one and never the releaser's.
+static PipelinedOwner& tls_owner() {
+    static thread_local PipelinedOwner c = std::make_shared<std::atomic<int>>(0);
+    return c;
 }
-void ctx_pipelined_end(ceno_hip_ctx* ctx) {
+static int tls_pipelined() { return tls_owner()->load(std::memory_order_relaxed); }
+PipelinedOwner ctx_pipelined_begin(ceno_hip_ctx* ctx) {
+    CENO_TIMED("ctx_pipelined_begin");
+    PipelinedOwner me = tls_owner();
+    const bool holds = me->load(std::memory_order_relaxed) > 0;
+    std::unique_lock<std::mutex> lk(ctx->gate_mu);
+    // a trim in progress holds everybody back; a trimmer that is WAITING for the gate holds back the threads that have nothing in flight
+    // (those that do must go on: the trimmer waits for exactly their sumchecks to end) — without this, four lanes proving tower layers back
+    // to back never let pipelined_live reach 0 and the waiter starved until its timeout
+    ctx->gate_cv.wait(lk, [&] { return !ctx->trimming && (holds || ctx->trim_pending == 0); });
+    ctx->pipelined_live.fetch_add(1);
+    me->fetch_add(1, std::memory_order_relaxed);
+    return me;
+}
+void ctx_pipelined_end(ceno_hip_ctx* ctx, PipelinedOwner& owner) {
     CENO_TIMED("ctx_pipelined_end");
     {
         std::lock_guard<std::mutex> g(ctx->gate_mu);
         ctx->pipelined_live.fetch_sub(1);
     }
-    if (tls_pipelined > 0) tls_pipelined--;
+    if (owner) {
+        owner->fetch_sub(1, std::memory_order_relaxed);
+        owner.reset();
+    }
     ctx->gate_cv.notify_all();  // a thread waiting to trim (ctx_trim_begin_wait)
 }
-// take the trim gate as soon as no pipelined sumcheck is alive anywhere; only for threads that hold none themselves.  false: timed out
+// take the trim gate as soon as no pipelined sumcheck is alive anywhere; only for threads that hold none themselves.  While it waits,
+// threads with nothing in flight do not begin new pipelined sumchecks (trim_pending), so the wait is bounded by the sumchecks already
+// alive — milliseconds.  false: timed out
 static bool ctx_trim_begin_wait(ceno_hip_ctx* ctx, int timeout_ms) {
     std::unique_lock<std::mutex> lk(ctx->gate_mu);
-    if (!ctx->gate_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !ctx->trimming && ctx->pipelined_live.load() == 0; })) return false;
-    ctx->trimming = true;
-    return true;
+    ctx->trim_pending++;
+    const bool got = ctx->gate_cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return !ctx->trimming && ctx->pipelined_live.load() == 0; });
+    ctx->trim_pending--;
+    if (got) ctx->trimming = true;
+    lk.unlock();
+    if (!got) ctx->gate_cv.notify_all();  // the beginners this waiter held back
+    return got;
+}
+// how long an over-the-limit request waits for the sumchecks in flight to end (they take milliseconds; CENO_HIP_TRIM_WAIT_MS)
+static int trim_wait_ms() {
+    static const int v = getenv("CENO_HIP_TRIM_WAIT_MS") ? std::max(1, atoi(getenv("CENO_HIP_TRIM_WAIT_MS"))) : 2000;
+    return v;
 }
 bool ctx_trim_begin(ceno_hip_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->gate_mu);
@@ -270,7 +296,7 @@ again:
     if (need_gate) {
         // lanes are proving and no idle block is large enough.  A thread with no pipelined sumcheck of its own waits for them (their
         // rounds end within milliseconds) and trims then; one that has such a sumcheck alive cannot — a retryable failure
-        if (attempt == 0 && tls_pipelined == 0 && ctx_trim_begin_wait(ctx, 10000)) {
+        if (attempt == 0 && tls_pipelined() == 0 && ctx_trim_begin_wait(ctx, trim_wait_ms())) {
             release.gate = true;
             attempt = 1;
             goto again;
@@ -373,7 +399,7 @@ again:
     if (e != hipSuccess) {
         // drop the cache and retry once (a thread without a pipelined sumcheck of its own waits for the lanes' to end first:
         // ceno_hip_mem_trim returns at once while any is alive)
-        if (tls_pipelined == 0 && ctx_trim_begin_wait(ctx, 10000)) ctx_trim_end(ctx);
+        if (tls_pipelined() == 0 && ctx_trim_begin_wait(ctx, trim_wait_ms())) ctx_trim_end(ctx);
         ceno_hip_mem_trim(ctx);
         e = hipMalloc(&p, b);
         if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_OOM, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));

@@ -896,6 +896,7 @@ struct ceno_hip_sumcheck {
     bool allow_pipeline = false;   // caller promised to drive the rounds back to back (ceno_hip_sumcheck_set_pipelined)
     bool pipelined = false;        // round kernels are enqueued ahead of their challenges, which travel through the mailbox
     bool live_counted = false;     // counted in ctx->pipelined_live (ctx_pipelined_begin / _end)
+    PipelinedOwner live_owner;     // the beginning thread's counter (the handle may be released on another thread)
     int enq = 0;                   // pipelined: rounds [0, enq) are in the stream
     E2* d_evals = nullptr;         // gather scratch (device), num_mles
     E2* h_pinned = nullptr;        // pinned host staging: msg (MAXD) + evals (num_mles)
@@ -1015,7 +1016,7 @@ static void sc_release(ceno_hip_sumcheck* sc) {
         sc->ctx->mid_wgs_in_flight.fetch_sub(sc->mid_reserved);
         sc->mid_reserved = 0;
     }
-    if (sc->live_counted) ctx_pipelined_end(sc->ctx);
+    if (sc->live_counted) ctx_pipelined_end(sc->ctx, sc->live_owner);
     ctx_free_many_on(sc->ctx, sc->dev_allocs.data(), sc->dev_allocs.size(), sc->st, false);
     ctx_pinned_free(sc->ctx, sc->h_block);
     ctx_pinned_free(sc->ctx, sc->h_gen);
@@ -2527,7 +2528,7 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
     const int from = sc->enq;
     if (from >= upto) return 0;
     if (!sc->live_counted) {  // (once per handle, BEFORE the first kernel that waits for this host is queued) the pool returns nothing
-        ctx_pipelined_begin(ctx);  // to the driver while such kernels exist, and none is queued while a trim is under way (common.hpp)
+        sc->live_owner = ctx_pipelined_begin(ctx);  // to the driver while such kernels exist, and none is queued while a trim is under way (common.hpp)
         sc->live_counted = true;
     }
     // A dense class (one product of K <= 4 tables) runs its LARGE rounds on the register-resident fused kernel and hands over to
@@ -3106,7 +3107,7 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
     return sc_build(ctx, mles, plan, ctx_stream(ctx, s), out, nullptr, num_eq > 0 ? &ea : nullptr);
 }
 
-unsigned long long ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx) { return ctx ? ctx->eq_launches.load() : 0ull; }
+uint64_t ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx) { return ctx ? (uint64_t)ctx->eq_launches.load() : 0ull; }
 
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc) { return sc && sc->geq.on ? (int)sc->geq.comps.size() : 0; }
 

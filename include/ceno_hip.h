@@ -94,11 +94,12 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
 /* bookkeeping that must return to zero when no sumcheck handle is alive (tests): live pipelined sumchecks (the pool's soft-cap
  * trim waits for zero) and the residency budget booked by persistent mid-round kernels (units of 1/64 compute unit) */
 int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight);
+/* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device; a no-op while pipelined sumchecks are alive on any lane */
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx);
 /* high-water mark of the bytes handed out by the pool since the last reset (reset != 0: restart the mark at the current usage).  What a
  * scheduler's booking estimates are checked against (the reference asserts its estimator against real usage,
  * ceno_zkvm/src/scheme/gpu/memory.rs:54-145). */
-size_t ceno_hip_mem_peak(ceno_hip_ctx* ctx, int reset);             /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device; a no-op while pipelined sumchecks are alive on any lane */
+size_t ceno_hip_mem_peak(ceno_hip_ctx* ctx, int reset);
 /* booking of estimated task footprints by a chip scheduler (mem_pool try_book_capacity / unbook_capacity /
  * get_booked_total, ceno_zkvm/src/scheme/scheduler.rs:342-347,390,622-652): refused (CENO_HIP_ERR_OOM, nothing is
  * allocated) when live allocations + bookings + bytes would exceed pool_bytes (or the device memory when unlimited) */
@@ -221,7 +222,7 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
 /* how many components (chips) of the plan run in the eq-factored form (0: none, the declarations did not apply) */
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc);
 /* eq-factored round launches this context has issued so far (a statistic for tests and A/B runs) */
-unsigned long long ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx);
+uint64_t ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx);
 /* Produce the message of the next round.  `challenge2` is the challenge of the PREVIOUS round
  * (NULL for round 0): the tables are folded with it and the new message accumulated in one pass.
  * out_evals receives max_degree ext elements (host memory). Synchronises the stream. */

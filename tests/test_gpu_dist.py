@@ -118,3 +118,35 @@ def test_bench_py_reports_an_rccl_arm_that_never_returns():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["headline_exchange"] == "shm" and r["value"] > 0
     assert r["rccl"].startswith("unavailable: timeout") and r["extra"]["dist_commit"]["status"].startswith("skipped")
+    assert r["degraded"] == "rccl_timeout"  # visible at the top level of the line, not only in the exit path
+
+
+@pytest.mark.parametrize("world", [4])
+def test_bench_py_plain_invocation_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` invoked exactly as `--gpus 1` is (no launcher, WORLD_SIZE unset): the process must start its N ranks as
+    CHILD processes before anything touches the GPU, relay rank 0's single JSON line and its exit status"""
+    import json
+
+    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--nv", "12"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == world and r["steps"] == 3 and r["scaling"] == "strong" and r["value"] > 0
+    assert "shm" in r["exchanges_validated"]
+
+
+def test_bench_py_plain_invocation_propagates_a_failing_rank():
+    """a rank that dies (simulated: CENO_BENCH_FAIL_RANK) makes the launcher return that rank's exit status and print no JSON line; the
+    surviving rank, stuck in the rendezvous, is ended after the grace period"""
+    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1", CENO_BENCH_PEER_GRACE_S="5", CENO_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nv", "12"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 7, (out.returncode, out.stderr[-1000:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -788,6 +788,91 @@ def test_pool_limit_with_a_full_cache_does_not_fail_lanes(prover):
     d.close()
 
 
+def test_trim_waiter_is_not_starved_by_back_to_back_sumchecks(prover):
+    """(round-4 advisor finding) lanes that prove small pipelined sumchecks back to back rarely leave an instant with NO pipelined sumcheck
+    alive, and nothing held new ones back while a thread waited for the trim gate: an over-the-limit request from a thread with nothing
+    in flight starved until its time-out and reported a spurious OOM.  A waiting trimmer now holds back the threads that have nothing
+    in flight; the request is served while the lanes keep proving."""
+    import threading
+    import time
+
+    from ceno_amd import Device
+
+    limit = 1 << 30
+    d = Device(0, pool_bytes=limit)
+    parked = [d.synthetic(24, False, 700 + i) for i in range(6)]     # 6 x 128 MiB parked in the cache of a 1 GiB pool
+    d.sync()
+    for m in parked:
+        m.free()
+    stop = threading.Event()
+    count = [0, 0, 0, 0]
+    errs = []
+
+    def lane(t):
+        try:
+            st = d.stream_create()
+            tabs = [d.synthetic(10, True, 40 + 7 * t + j) for j in range(3)]
+            while not stop.is_set():
+                prover.sumcheck_prove(d, tabs, po.ext([1]), [[0, 1, 2]], 10, 3, prover.Transcript.stub(t), stream=st)
+                count[t] += 1
+            for m in tabs:
+                m.free()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=lane, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    time.sleep(0.5)
+    before = sum(count)
+    t0 = time.perf_counter()
+    big = d.alloc(25, False)   # 256 MiB: larger than any parked block -> has to trim, i.e. needs the gate
+    waited = time.perf_counter() - t0
+    time.sleep(0.3)
+    stop.set()
+    for th in ths:
+        th.join(60)
+    assert not errs, errs
+    assert waited < 1.0, f"the request waited {waited:.2f} s for the trim gate"
+    assert before > 20 and sum(count) > before, "the lanes must keep proving after the trim"
+    big.free()
+    d.close()
+
+
+def test_pipelined_handle_released_on_another_thread(prover):
+    """(round-4 advisor finding) the count of pipelined sumchecks a thread holds belongs to the thread that BEGAN them: a handle released
+    on another thread must neither leave the beginner unable to wait for the trim gate for ever nor decrement the releaser's count"""
+    import ctypes as C
+    import threading
+
+    from ceno_amd import Device, api
+
+    limit = 1 << 29
+    d = Device(0, pool_bytes=limit)
+    tabs = [d.synthetic(14, True, 40 + j) for j in range(3)]
+    sc = api.Sumcheck(d, tabs, po.ext([1]), [[0, 1, 2]], 14, 3)
+    sc.set_pipelined(True)
+    sc.round()                                   # this thread holds one pipelined sumcheck
+    th = threading.Thread(target=sc.free)        # ... released by another thread
+    th.start()
+    th.join(30)
+    assert not th.is_alive()
+    live, mid = C.c_int(-1), C.c_int(-1)
+    d.check(d.L.ceno_hip_debug_state(d.h, C.byref(live), C.byref(mid)))
+    assert (live.value, mid.value) == (0, 0)
+    # the beginner's count is back at zero: with the cache full, an over-the-limit request of THIS thread waits for the gate (nothing is
+    # alive: immediately) and trims instead of failing with 'retry'
+    parked = [d.synthetic(24, False, 700 + i) for i in range(3)]     # 3 x 128 MiB parked
+    d.sync()
+    for m in parked:
+        m.free()
+    big = d.alloc(25, False)                     # 256 MiB: only possible after a trim
+    big.free()
+    for m in tabs:
+        m.free()
+    d.close()
+
+
 def test_cache_over_the_soft_cap_does_not_stall_lanes(prover):
     """A phase that leaves many GB in the pool's cache (the 13 GB batch of config #4) followed by concurrent chip proofs: the
     pool's soft cap must not call hipFree — which waits for every stream of the device — while round kernels of the lanes are

@@ -29,7 +29,8 @@ class CType:
         if self.is_ptr or self.base in typedef_ptrs:
             return "ptr"
         return {"int": "i32", "unsigned": "u32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "double": "f64",
-                "uint8_t": "u8", "uint16_t": "u16", "void": "void", "char": "i8"}.get(self.base, "struct:" + self.base)
+                "uint8_t": "u8", "uint16_t": "u16", "void": "void", "char": "i8", "int64_t": "i64", "int32_t": "i32",
+                "c_ulong": "usize"}.get(self.base, "struct:" + self.base)
 
 
 @dataclass
@@ -72,6 +73,11 @@ def parse_type(decl: str) -> Tuple[CType, str]:
     if ma:
         arr = int(ma.group(1))
         decl = decl[: ma.start()].strip()
+    # multi-word integer types become one token BEFORE the declarator name is split off (`unsigned long long f(...)` has no name to pop)
+    for spelled, canon in (("unsigned long long int", "uint64_t"), ("unsigned long long", "uint64_t"), ("long long int", "int64_t"),
+                           ("long long", "int64_t"), ("unsigned long", "c_ulong"), ("unsigned int", "unsigned"), ("unsigned char", "uint8_t"),
+                           ("unsigned short", "uint16_t")):
+        decl = re.sub(r"\b" + spelled.replace(" ", r"\s+") + r"\b", canon, decl)
     toks = re.findall(r"\w+|\*", decl)
     name = ""
     if toks and toks[-1] != "*" and toks[-1] != "const" and len([t for t in toks if t not in ("const", "*", "struct", "unsigned")]) > 1:
