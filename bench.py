@@ -52,11 +52,35 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     inputs resident in HBM), each with its algorithmic bytes against the 8 TB/s HBM peak"""
     from ceno_amd import synthetic
 
-    def roof(alg_bytes, ms, note=None):
+    # VALU-bound extras: wave-level VALU instruction counts of ONE run of the workload from the committed --pmc pass (tools/r05_valu_counters.sh ->
+    # profiles/r*_valu_counters.json); valu_frac = SQ_INSTS_VALU x measured cycles per instruction / (SIMDs x clock x time of THIS run)
+    import glob as _glob
+
+    _vc = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_valu_counters.json")))
+    valu_counters = json.load(open(_vc[-1])) if _vc else {}
+
+    def roof(alg_bytes, ms, note=None, valu_key=None):
         gbps = alg_bytes / (ms * 1e-3) / 1e9
         r = {"bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0, "algorithmic_bytes": alg_bytes}
         if note:
             r["note"] = note
+        vc = valu_counters.get(valu_key) if valu_key else None
+        if valu_key:
+            r["bound"] = "valu"  # integer-ALU issue, not HBM: `frac` stays the HBM fraction of the algorithmic bytes (the contract's field)
+            r["hbm_frac"] = r["frac"]
+        if vc:
+            cpi, simds, ghz = valu_counters.get("cycles_per_valu_inst", 4.3), valu_counters.get("simds", 1024), valu_counters.get("clock_ghz", 2.4)
+            insts = vc["SQ_INSTS_VALU"]
+            frac = insts * cpi / (simds * ghz * 1e9 * ms * 1e-3)
+            r["valu"] = {"SQ_INSTS_VALU": insts, "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz, "source": os.path.relpath(_vc[-1], ROOT)}
+            if valu_key == "chip_flow.commit":
+                # Poseidon2's mix holds full-rate 32-bit adds and moves (2.3-2.7 cycles, profiles/r01_valu_issue_rates.txt): the 4.3-cycle
+                # figure of the multiply / carry instructions overstates it — at 4.0 cycles per instruction the count already fills the SIMDs
+                r["valu"]["note"] = ("instruction mix includes full-rate adds / moves: insts x 4.3 cycles exceeds the SIMD time of the phase "
+                                     f"({frac:.2f}); the VALU port is saturated (profiles/r04_merkle_sq_pmc.json)")
+                r["valu_frac"] = None
+            else:
+                r["valu_frac"] = frac
         return r
 
     def best_of(f):
@@ -88,12 +112,27 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
         streams = [dev.stream_create() for _ in range(n_inst)]
         per = 4
 
-        def work(t):
-            for _ in range(per):
-                prover.sumcheck_prove(dev, insts[t], one, [list(range(K))], 26, K, new_transcript(), stream=streams[t])
+        calls = [[] for _ in range(n_inst)]
 
-        work(0)  # warm-up (buffers, streams)
+        def work(t, reps=per):
+            for _ in range(reps):
+                c0 = time.perf_counter()
+                prover.sumcheck_prove(dev, insts[t], one, [list(range(K))], 26, K, new_transcript(), stream=streams[t])
+                calls[t].append((time.perf_counter() - c0) * 1e3)
+
+        # warm-up of EVERY instance on its own stream, concurrently: the first sumcheck on a new stream takes its 2.4 GB of working buffers
+        # from the driver inside what used to be the timed region.  Two boxes (the round-4 driver run and one round-5 run) reported two
+        # instances SLOWER than one (3.3 / 5.5 vs 2.9 ms) — a constant ~20 ms on top of the expected total, whatever the instance count;
+        # the dev boxes never showed it (tools/dev/flight_ab.py: 2.92 / 2.75 / 2.68 ms, hipMalloc 250 us each).  Steady state is what the
+        # extra reports; the slowest and fastest single call are reported so that a one-off stall is visible as such.
+        ths = [threading.Thread(target=work, args=(t, 1)) for t in range(n_inst)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
         dev.sync()
+        for c_ in calls:
+            c_.clear()
         ths = [threading.Thread(target=work, args=(t,)) for t in range(n_inst)]
         t0 = time.perf_counter()
         for th in ths:
@@ -102,7 +141,9 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
             th.join()
         dev.sync()
         dt = time.perf_counter() - t0
-        flight[str(n_inst)] = {"ms_per_sumcheck": dt / (per * n_inst) * 1e3, "ext_mults_per_s": K * K * ((1 << 26) - 1) * per * n_inst / dt}
+        flat = [x for c_ in calls for x in c_]
+        flight[str(n_inst)] = {"ms_per_sumcheck": dt / (per * n_inst) * 1e3, "ext_mults_per_s": K * K * ((1 << 26) - 1) * per * n_inst / dt,
+                               "call_ms_min": min(flat), "call_ms_max": max(flat)}
         for row in insts:
             for m in row:
                 m.free()
@@ -117,12 +158,40 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
         ms = best_of(lambda: prover.prove_batched_main_constraints(dev, mj, [(11, 22), (33, 44)], new_transcript()))
         out[key] = {"workload": f"config #4{' shape' if max_nv != 26 else ''}: prove_batched_main_constraints, 24 chips of {max_nv - 10}..{max_nv} "
                                 "variables, 12 base columns + selector, 16 terms of degree <= 4 each", "ms": ms, "table_elements": elems,
-                    "roofline": roof(synthetic.batched_algorithmic_bytes(max_nv, 12), ms, "integer-ALU bound: DESIGN.md section 3")}
+                    "roofline": roof(synthetic.batched_algorithmic_bytes(max_nv, 12), ms, "integer-ALU bound: DESIGN.md section 3", valu_key=key)}
         for j in jobs:
             for m in j["mles"]:
                 if m is not None:
                     m.free()
         del mj, jobs
+    # config #4 at the REFERENCE's plan statistics (zerocheck_layer.rs:86-207, instructions.rs:48-83): 48 chips of 2^12..2^24 rows, 22..96 base
+    # columns, 1..3 selectors, 42..250 monomials each (selector x column for every column, selector x constant, products of 2..4 columns)
+    os.environ["CENO_HIP_PLAN_REPORT"] = "1"
+    try:
+        jobs, _chips, elems = synthetic.wide_batched_jobs(dev, 24)
+        mj = prover.MainJobs(jobs)
+        before = dev.L.ceno_hip_stat_eq_launches(dev.h)
+        ms = best_of(lambda: prover.prove_batched_main_constraints(dev, mj, [(11, 22), (33, 44)], new_transcript()))
+        launches = int(dev.L.ceno_hip_stat_eq_launches(dev.h) - before) // reps
+        classes = json.loads(dev.L.ceno_hip_plan_report(dev.h).decode() or "[]")
+        deg = max(j["max_degree"] for j in jobs)
+        mult_eq = synthetic.eq_form_mult_equivalents(jobs, deg)
+        out["batched_main_wide"] = {
+            "workload": "config #4 at the reference's plan statistics: prove_batched_main_constraints, 48 chips of 2^12..2^24 rows x 22..96 base columns, "
+                        "1..3 Prefix selectors, 42..250 monomials per chip (selector x column for every column, selector x constant, products of 2..4 columns)",
+            "ms": ms, "chips": len(jobs), "tables": sum(len(j["mles"]) for j in jobs), "monomials": sum(len(j["terms"]) for j in jobs),
+            "max_degree": deg, "table_elements": elems, "eq_launches_per_sumcheck": launches, "ext_mult_equivalents": mult_eq,
+            "mult_equivalents_per_s": mult_eq / (ms * 1e-3),
+            "classes_of_2p16_rows_and_more_on_eq_factored_kernel": all(c["path"] == "eq-factored" for c in classes if c["num_vars"] >= 16),
+            "classes": [{k: c[k] for k in ("num_vars", "tables", "terms", "path", "components", "tables_staged", "pairs_per_tile_log2")} for c in classes],
+            "roofline": roof(synthetic.wide_algorithmic_bytes(24), ms, "integer-ALU bound: DESIGN.md section 3", valu_key="batched_main_wide")}
+        for j in jobs:
+            for m in j["mles"]:
+                if m is not None:
+                    m.free()
+        del mj, jobs, _chips
+    finally:
+        os.environ.pop("CENO_HIP_PLAN_REPORT", None)
     # config #3: ADD-shaped chip, 2^20 rows x 22 columns, commit -> chip proof -> main constraints -> open
     flow = synthetic.ChipFlow(dev, prover, 20, 22)
     best = None
@@ -134,7 +203,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     flow.close()
     best["workload"] = "config #3: ADD-shaped chip, 2^20 rows x 22 base columns, blow-up 2, 100 queries, 16-bit proof of work"
     best["roofline"] = roof(sum(ab.values()), best["total_ms"], "commit is integer-ALU bound (Poseidon2): DESIGN.md section 3")
-    best["roofline_by_phase"] = {k: roof(v, best[f"{k}_ms"]) for k, v in ab.items()}
+    best["roofline_by_phase"] = {k: roof(v, best[f"{k}_ms"], valu_key=("chip_flow.commit" if k == "commit" else None)) for k, v in ab.items()}
     out["chip_flow"] = best
     # metric M2 shape: one synthetic shard of 2^20 cycles through the whole create_proof flow
     shard = synthetic.ShardFlow(dev, prover)
@@ -167,6 +236,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     out["small_shard_e2e"] = bsm
     out["chip_flow_ms"], out["batched_main_ms"], out["nv22_ms"] = best["total_ms"], out["batched_main"]["ms"], out["nv22"]["ms"]
     out["batched_main_nv26_ms"] = out["batched_main_nv26"]["ms"]
+    out["batched_main_wide_ms"] = out["batched_main_wide"]["ms"]
     out["shard_e2e_sec"] = bs["e2e_prover_sec_for_2p20_cycles"]
     return out
 
@@ -410,9 +480,7 @@ def main():
 
         for _ in range(args.warmup):
             step()
-        # timed region: exactly `steps` steps, no profiling hooks active.  The interpreter's cyclic garbage collector stays out of it (as in
-        # `timeit`): with torch imported a full collection walks ~10^6 objects and takes ~35 ms — ten sumchecks — whenever the allocation count
-        # of the process happens to cross its threshold (measured: it fell into the timed region from 24 steps on, 2.8 -> 4.0 ms per step).
+        # an UNINSTRUMENTED pass of the same steps first (reported as ms_per_step_uninstrumented: what the event recording costs) ...
         gc.collect()
         gc.disable()
         barrier()
@@ -420,15 +488,22 @@ def main():
         for _ in range(args.steps):
             step()
         barrier()
-        out["dt"] = max_over_ranks(time.perf_counter() - t0)
-        gc.enable()
-        # second, untimed pass of the same steps with HIP events around every launch of the dominant kernel
-        # (events recorded on the library's launch stream) -> roofline numbers
-        dev.prof_enable(True)
+        out["dt_plain"] = max_over_ranks(time.perf_counter() - t0)
+        # ... then the TIMED REGION: exactly `steps` steps, with HIP events on the launch stream around every launch of the dominant kernel
+        # (prof mode 2: the sumchecks stay pipelined, exactly as in the pass above; a queued round ends when its finishing workgroup has the
+        # next challenge, so the events' sum is part of — never more than — the wall time of this same region: the roofline numbers and
+        # `value` come from ONE pass).  The interpreter's cyclic garbage collector stays out of it (as in `timeit`): with torch imported a
+        # full collection walks ~10^6 objects and takes ~35 ms — ten sumchecks — whenever the allocation count of the process happens to
+        # cross its threshold (measured: it fell into the timed region from 24 steps on, 2.8 -> 4.0 ms per step).
+        dev.prof_enable(2)
         dev.prof_reset()
+        barrier()
+        t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
+        out["dt"] = max_over_ranks(time.perf_counter() - t0)
+        gc.enable()
         out["kernel_ms"], out["launches"], out["prof_bytes"] = dev.prof_get()
         dev.prof_enable(False)
         # the same steps with the other transcript (untimed for `value`; reported as ms_per_step_<name>)
@@ -524,6 +599,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_uninstrumented": m["dt_plain"] / args.steps * 1e3,
             f"ms_per_step_{args.transcript}": dt / args.steps * 1e3,
             f"ms_per_step_{other}": m["dt_other"] / args.steps * 1e3,
             "higher_is_better": True,
@@ -553,10 +629,10 @@ def main():
                 "traffic": None,
                 "launches": int(launches),
                 "avg_launch_ms": kernel_ms / launches if launches else None,
-                # (to compare with `rocprofv3 --kernel-trace --stats` of this command — profiles/r*_sumcheck_nv26_kernel_stats.csv: sum the
-                # TotalDurationNs of the k_dense rows and divide by the calls of the read-only round-0 instantiation k_dense<3, 0, *> =
-                # the number of sumchecks; the timed steps are pipelined and hand rounds of <= 2^15 pairs to k_mid / k_tail, whose
-                # durations include the waits for the host, so the per-LAUNCH averages of the two runs are not the same population)
+                # HIP events around every k_dense launch of the TIMED steps (pipelined: a launch ends when its finishing workgroup has the next
+                # challenge, so kernel_ms_per_sumcheck <= ms_per_step by construction; rounds of <= 2^15 pairs run on k_mid / k_tail and are not
+                # in it).  `rocprofv3 --kernel-trace --stats` of this command (profiles/r*_sumcheck_nv26_kernel_stats.csv): sum the
+                # TotalDurationNs of the k_dense rows and divide by the calls of the read-only round-0 instantiation k_dense<3, 0, *>.
                 "kernel_ms_per_sumcheck": kernel_ms / args.steps if args.steps else None,
                 "algorithmic_bytes_per_launch": alg_bytes_per_step * args.steps / launches if launches else None,
                 "schedule_bytes_per_step": m["prof_bytes"] / args.steps if args.steps else None,

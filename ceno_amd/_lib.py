@@ -98,6 +98,7 @@ def lib():
         "ceno_hip_sumcheck_begin_eq": (i, [vp, vpp, C.POINTER(SumcheckPlan), i, C.POINTER(i), C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), vp, vpp]),
         "ceno_hip_sumcheck_eq_components": (i, [vp]),
         "ceno_hip_stat_eq_launches": (C.c_uint64, [vp]),
+        "ceno_hip_plan_report": (C.c_char_p, [vp]),
         "ceno_hip_sumcheck_round": (i, [vp, vp, u64p, u64p]),
         "ceno_hip_sumcheck_round_dev": (i, [vp, vp, u64p, vp]),
         "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),

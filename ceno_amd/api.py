@@ -165,7 +165,8 @@ class Device:
         return [Mle(self, C.c_void_p(o)) for o in outs]
 
     # ---- profiling hooks ----
-    def prof_enable(self, on: bool = True):
+    def prof_enable(self, on=True):
+        """True / 1: unpipelined, events around the bare kernels; 2: pipelined sumchecks stay pipelined (events around the queued rounds)"""
         self.check(self.L.ceno_hip_prof_enable(self.h, int(on)))
 
     def prof_reset(self):

@@ -109,8 +109,12 @@ struct ceno_hip_ctx {
     int trim_pending = 0;  // threads inside ctx_trim_begin_wait (under gate_mu): new pipelined sumchecks of threads that hold none wait for them
     // ---- errors ----
     std::string err;
+    // CENO_HIP_PLAN_REPORT=1: which round kernels the size classes of the sumcheck built last on this context were given (one JSON object
+    // per class; ceno_hip_plan_report — benches and tests)
+    std::string plan_report;
     // ---- profiling of the dominant kernel (bench.py roofline) ----
     bool prof_on = false;
+    bool prof_pipelined = false;  // ceno_hip_prof_enable(ctx, 2): pipelined sumchecks stay pipelined, events around their large dense rounds
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_event_pool;
     uint64_t prof_launches = 0;
@@ -201,7 +205,8 @@ inline hipStream_t ctx_stream(ceno_hip_ctx* ctx, ceno_hip_stream s) {
 
 // profiling hooks (ctx.hip)
 void prof_begin(ceno_hip_ctx* ctx, hipStream_t st);
-void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes);
+void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes, int launches = 1);
+void prof_count(ceno_hip_ctx* ctx, double algorithmic_bytes);  // a launch inside an open event pair
 
 #define HIP_TRY(ctx, expr)                                                                              \
     do {                                                                                                \

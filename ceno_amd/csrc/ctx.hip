@@ -864,6 +864,7 @@ uint64_t* ceno_hip_mle_device_ptr(const ceno_hip_mle* m) { return m ? m->d : nul
 // ------------------------------------------------------------------------------------------------
 int ceno_hip_prof_enable(ceno_hip_ctx* ctx, int on) {
     ctx->prof_on = on != 0;
+    ctx->prof_pipelined = on == 2;
     return 0;
 }
 int ceno_hip_prof_reset(ceno_hip_ctx* ctx) {
@@ -902,9 +903,15 @@ void prof_begin(ceno_hip_ctx* ctx, hipStream_t st) {
     (void)hipEventRecord(ev.first, st);
     ctx->prof_events.push_back(ev);
 }
-void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes) {
-    if (!ctx->prof_on) return;
+void prof_end(ceno_hip_ctx* ctx, hipStream_t st, double algorithmic_bytes, int launches) {
+    if (!ctx->prof_on || ctx->prof_events.empty()) return;
     (void)hipEventRecord(ctx->prof_events.back().second, st);
+    ctx->prof_launches += launches;
+    ctx->prof_bytes += algorithmic_bytes;
+}
+// a launch inside an open event pair (a span over several back-to-back launches)
+void prof_count(ceno_hip_ctx* ctx, double algorithmic_bytes) {
+    if (!ctx->prof_on) return;
     ctx->prof_launches += 1;
     ctx->prof_bytes += algorithmic_bytes;
 }

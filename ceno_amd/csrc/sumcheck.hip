@@ -813,6 +813,9 @@ struct ScClass {
 struct GenCompHost {
     int cls = 0;
     std::vector<int> mles;                 // class-local MLE ids in component order
+    std::vector<char> writes;              // per MLE: this component writes its folded table (a column staged by several column blocks of a
+                                           // wide chip is written by ONE of them; empty = all)
+    std::vector<std::vector<uint32_t>> gts;  // per group of the class: the class-local terms this component evaluates
     int n_groups = 0, n_terms = 0;
     int tp_log = 8, wt_log = 0;
     bool base0_ok = false;
@@ -932,6 +935,8 @@ struct ceno_hip_sumcheck {
         void* h_block = nullptr;          // pinned: [slot][D] quotient sums, then [brow][D] boundary values
         E2 *h_q = nullptr, *d_q = nullptr, *h_b = nullptr, *d_b = nullptr;
         unsigned* d_counters = nullptr;   // device: one arrival counter per eq component
+        unsigned max_grid = 0;            // largest eq launch of the sumcheck (rows of the components with several workgroups)
+        uint64_t* d_rows = nullptr;       // device: [workgroup][D] partial sums of such components
         // interpolation weights (base field), nodes -> target:  A: 1..D-1 -> 0, D   B: 0..D-2 -> D-1, D
         std::vector<uint64_t> wA0, wAD, wB1, wBD, pow_dm1, lag_den_inv;
     } geq;
@@ -1192,6 +1197,17 @@ static size_t gen_stage_budget(int d) {
     const size_t cap = 63 * 1024 - gen_lds_bytes(d, 0);
     return std::min((size_t)std::max(kb, 1) * 1024, cap);
 }
+// ... and what the staged rows may take when THREE workgroups are to share a CU's 160 KB (the round kernels are bound by VALU issue: at degree 5
+// the 64 KB block held two workgroups per CU = two waves per SIMD, VALU busy 0.72; three: ~0.9).  The column blocks of wide components are cut
+// to this size, and tiles larger than 64 pairs are only taken where they fit it.
+static size_t gen_stage_budget3(ceno_hip_ctx* ctx, int d) {
+    // (only where the REGISTERS allow a third workgroup: the eq-factored kernel of degree 5 takes 205 VGPRs + AGPRs = two waves per SIMD
+    // whatever its LDS, and smaller blocks then only stage the selectors more often — 62.9 vs 61.1 ms for the wide batch)
+    if (gen_resident_cap(ctx, d, false, 0) < 3u * (unsigned)ctx->num_cus) return gen_stage_budget(d);
+    const size_t per_wg = (size_t)52 * 1024;  // 160 KB / 3 rounded down to the allocation granularity
+    const size_t fixed = gen_lds_bytes(d, 0);
+    return std::min(gen_stage_budget(d), per_wg > fixed ? per_wg - fixed : (size_t)0);
+}
 static size_t gen_pipe_min_pairs() {
     // pipelined single-class sumchecks (tower layers, a single chip's main sumcheck): rounds with at least 2^this pairs use
     // k_gen.  Off by default: these plans have few terms per column (memory-bound), where the two-kernel path's streaming
@@ -1242,6 +1258,11 @@ static int geq_prepare(ceno_hip_sumcheck* sc) {
         }
         return w;
     };
+    {
+        void* p = nullptr;
+        TRY(sc_dev_alloc(sc, (size_t)std::max(Gq.max_grid, 1u) * (size_t)D * sizeof(E2), &p));
+        Gq.d_rows = (uint64_t*)p;
+    }
     Gq.wA0 = weights(1, D - 1, 0);
     Gq.wAD = weights(1, D - 1, D);
     Gq.wB1 = weights(0, D - 1, D - 1);
@@ -1386,9 +1407,116 @@ static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
     return 0;
 }
 
+// ---- column blocks of a WIDE component ----
+// A chip of the reference has 22 .. 96 witness columns under one (two, three) selectors and 60 .. 250 monomials, most of them
+// selector x column (ceno_zkvm/src/instructions.rs:48-83, gkr_iop/src/gkr/layer/zerocheck_layer.rs:86-207).  The LDS stage holds 32 bytes per
+// MLE and pair: at 64 pairs per tile — the geometry at which every lane of phase 2 owns a pair — about 21 MLEs fit beside the exchange block
+// with three workgroups per CU; a 26-MLE chip used to drop to 32-pair tiles (half the lanes of phase 2 idle), an 86-MLE chip to the two-kernel
+// path.  A sum of monomials splits freely: the component is cut into BLOCKS of at most `cap` MLEs, every block with the selectors of its
+// groups, a term goes to a block that holds all its columns (columns of the product terms are clustered first, the selector x column terms fill
+// up), and every block is a component of its own from here on — its own tiles, its own eq slot and running claim (the round polynomial of a
+// chip is the sum of its blocks').  A column that two blocks need is staged by both and written by the first.
+static unsigned gen_oversub() {
+    const char* e = getenv("CENO_HIP_GEN_OVERSUB");  // workgroups per resident slot in the large rounds of an eq-factored batch (read per build)
+    return e ? (unsigned)std::min(std::max(atoi(e), 1), 64) : 16u;
+}
+static int gen_split_cap(ceno_hip_ctx* ctx, int d) {
+    const char* off = getenv("CENO_HIP_GEN_SPLIT");  // 0: no column blocks (A/B, tests)
+    if (off && atoi(off) == 0) return 0;
+    const char* e = getenv("CENO_HIP_GEN_SPLIT_MLES");
+    if (e && atoi(e) > 0) return std::max(atoi(e), 3);
+    return std::max(3, (int)(gen_stage_budget3(ctx, d) / gen_stage_bytes(2, 6)));  // MLEs (two units each) whose rows fit at 64 pairs per tile
+}
+static void gen_split_component(const ScClass& cl, const GenCompHost& C, int cap, std::vector<GenCompHost>& out) {
+    const int ng = (int)C.gts.size();
+    struct Blk {
+        std::vector<int> mles;
+        std::vector<char> has;  // by class-local id
+        std::vector<std::vector<uint32_t>> gts;
+    };
+    std::vector<Blk> blocks;
+    const size_t km = cl.mles.size();
+    // terms in clustering order: products first (widest first), then single columns, then constants
+    struct Item { int g; uint32_t t; uint32_t nf; };
+    std::vector<Item> items;
+    size_t max_need = 0;
+    for (int g = 0; g < ng; g++)
+        for (uint32_t t : C.gts[(size_t)g]) {
+            items.push_back(Item{g, t, cl.h_to[t + 1] - cl.h_to[t]});
+            max_need = std::max<size_t>(max_need, (size_t)(cl.h_to[t + 1] - cl.h_to[t]) + (cl.h_co[g + 1] - cl.h_co[g]));
+        }
+    if ((int)max_need > cap) {  // a single term does not fit a block: leave the component as it is
+        out.push_back(C);
+        return;
+    }
+    {   // blocks of EQUAL size rather than full blocks and a remainder (23 tables at 20 per block were 20 + 4: the small block staged the selector
+        // for three columns): with s selectors in every block, n = ceil((M - s) / (cap - s)) blocks of ceil((M - s) / n) + s tables
+        std::vector<char> is_common(km, 0);
+        int n_common = 0;
+        for (int g = 0; g < ng; g++)
+            if (!C.gts[(size_t)g].empty())
+                for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++)
+                    if (!is_common[cl.h_ci[k]]) is_common[cl.h_ci[k]] = 1, n_common++;
+        const int cols = (int)C.mles.size() - n_common;
+        if (cap > n_common + 1 && cols > 0) {
+            const int nb = (cols + (cap - n_common) - 1) / (cap - n_common);
+            cap = std::max((int)max_need, std::min(cap, (cols + nb - 1) / nb + n_common + 1));  // (+1: room for a column two blocks share)
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.nf > b.nf; });
+    auto wanted = [&](const Item& it, std::vector<int>& w) {
+        w.clear();
+        for (uint32_t k = cl.h_co[it.g]; k < cl.h_co[it.g + 1]; k++) w.push_back((int)cl.h_ci[k]);
+        for (uint32_t k = cl.h_to[it.t]; k < cl.h_to[it.t + 1]; k++) w.push_back((int)cl.h_ti[k]);
+        std::sort(w.begin(), w.end());
+        w.erase(std::unique(w.begin(), w.end()), w.end());
+    };
+    std::vector<int> w;
+    for (const Item& it : items) {
+        wanted(it, w);
+        int best = -1, best_need = 1 << 30;
+        for (size_t b = 0; b < blocks.size(); b++) {
+            int need = 0;
+            for (int m : w) need += blocks[b].has[(size_t)m] ? 0 : 1;
+            if ((int)blocks[b].mles.size() + need <= cap && need < best_need) best = (int)b, best_need = need;
+        }
+        if (best < 0) {
+            blocks.emplace_back();
+            blocks.back().has.assign(km, 0);
+            blocks.back().gts.assign((size_t)ng, {});
+            best = (int)blocks.size() - 1;
+        }
+        Blk& B = blocks[(size_t)best];
+        for (int m : w)
+            if (!B.has[(size_t)m]) {
+                B.has[(size_t)m] = 1;
+                B.mles.push_back(m);
+            }
+        B.gts[(size_t)it.g].push_back(it.t);
+    }
+    std::vector<char> owned(km, 0);
+    for (Blk& B : blocks) {
+        GenCompHost S;
+        S.cls = C.cls;
+        S.mles = B.mles;
+        std::sort(S.mles.begin(), S.mles.end());
+        for (int m : S.mles) {
+            S.writes.push_back(owned[(size_t)m] ? 0 : 1);
+            owned[(size_t)m] = 1;
+        }
+        for (auto& ts : B.gts) std::sort(ts.begin(), ts.end());  // (the per-component code orders them widest first)
+        S.gts = std::move(B.gts);
+        out.push_back(std::move(S));
+    }
+}
+
 static int sc_build_gen(ceno_hip_sumcheck* sc) {
     CENO_TIMED("sc_build_gen");
     ceno_hip_ctx* ctx = sc->ctx;
+    if (getenv("CENO_HIP_PLAN_REPORT")) {
+        std::lock_guard<PoolMutex> g(ctx->mu);
+        ctx->plan_report = "[]";
+    }
     if (sc->n < gen_min_log()) return 0;
     // a single class covering all variables runs pipelined (tower layers, one chip's main sumcheck), where k_gen is off unless
     // CENO_HIP_GEN_PIPE_MIN_LOG asks for it: do not build tables nobody reads
@@ -1411,6 +1539,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         if (e && atoi(e) == 0) geq_wanted = false;
     }
     sc->geq.comps.clear();
+    sc->geq.max_grid = 0;
     sc->geq.n_brows = 0;
     for (size_t ci = 0; ci < sc->classes.size(); ci++) {
         ScClass& cl = sc->classes[ci];
@@ -1454,6 +1583,29 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             }
             mine[it->second].mles.push_back(m);
         }
+        // the terms of every component, group by group (a common-factor group lies in one component entirely; the ungrouped terms of the
+        // class are spread over theirs), then the column blocks of the wide ones
+        for (auto& C : mine) {
+            std::vector<char> in_c(km, 0);
+            for (int m : C.mles) in_c[(size_t)m] = 1;
+            C.gts.assign((size_t)ng, {});
+            for (int g = 0; g < ng; g++) {
+                const bool free_group = cl.h_co[g + 1] == cl.h_co[g];
+                for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
+                    const uint32_t t = cl.h_gt[ti];
+                    const uint32_t probe = cl.h_to[t + 1] > cl.h_to[t] ? cl.h_ti[cl.h_to[t]] : (free_group ? UINT32_MAX : cl.h_ci[cl.h_co[g]]);
+                    if (probe != UINT32_MAX && in_c[probe]) C.gts[(size_t)g].push_back(t);
+                }
+            }
+        }
+        if (const int cap = gen_split_cap(ctx, sc->d)) {
+            std::vector<GenCompHost> cut;
+            for (auto& C : mine) {
+                if ((int)C.mles.size() <= cap) cut.push_back(std::move(C));
+                else gen_split_component(cl, C, cap, cut);
+            }
+            mine = std::move(cut);
+        }
         GenCompHost fold_only;  // tables no term reads: folded only
         fold_only.cls = (int)ci;
         for (int m = 0; m < km; m++)
@@ -1483,15 +1635,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             C.base0_ok = true;
             size_t max_terms = 0;
             for (int g = 0; g < ng; g++) {
-                const bool free_group = cl.h_co[g + 1] == cl.h_co[g];
-                // terms of this group that live in this component (a common-factor group lies in one component entirely; the
-                // ungrouped terms of the class are spread over theirs)
-                std::vector<uint32_t> ts;
-                for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
-                    const uint32_t t = cl.h_gt[ti];
-                    const uint32_t probe = cl.h_to[t + 1] > cl.h_to[t] ? cl.h_ti[cl.h_to[t]] : (free_group ? UINT32_MAX : cl.h_ci[cl.h_co[g]]);
-                    if (probe != UINT32_MAX && pos.count((int)probe)) ts.push_back(t);
-                }
+                std::vector<uint32_t> ts = C.gts[(size_t)g];  // the terms of this group that this component evaluates
                 if (ts.empty()) continue;
                 // widest terms first: the round-robin split over the waves stays balanced
                 std::stable_sort(ts.begin(), ts.end(), [&](uint32_t a, uint32_t b) { return cl.h_to[a + 1] - cl.h_to[a] > cl.h_to[b + 1] - cl.h_to[b]; });
@@ -1508,7 +1652,6 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                             T.idx8 |= (uint64_t)(unit[lay][cm] & 0xff) << (8 * k);
                             if (lay == 1 && !is_base[cm]) C.base0_ok = false;  // an extension factor inside a term: no base-field product
                         }
-                        if (lay == 1 && T.nf == 0) C.base0_ok = false;
                         terms[lay].push_back(T);
                     }
                     G.term_end = (uint32_t)terms[lay].size();
@@ -1570,13 +1713,17 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
             }
             {   // relative cost of a pair (the component-aligned launch splits its workgroups by it)
                 double c2 = 0.0;
-                for (const GenTerm& T : terms[0]) c2 += 2.0 + (T.nf > 1 ? (T.nf - 1) * (double)std::max(sc->d - 2, 1) : 1.0) + ((int)T.nf == sc->d - 1 ? T.nf - 1.0 : 0.0);
-                C.pair_cost[0] = 2.0 * (double)C.mles.size();
+                const double w_nl = getenv("CENO_HIP_GEN_W_NL") ? atof(getenv("CENO_HIP_GEN_W_NL")) : 1.0;      // (calibration knobs)
+                const double w_fold = getenv("CENO_HIP_GEN_W_FOLD") ? atof(getenv("CENO_HIP_GEN_W_FOLD")) : 1.0;
+                for (const GenTerm& T : terms[0])
+                    c2 += T.nf > 1 ? w_nl * (2.0 + (T.nf - 1) * (double)std::max(sc->d - 2, 1) + ((int)T.nf == sc->d - 1 ? T.nf - 1.0 : 0.0)) : (double)std::max(sc->d - 2, 1);
+                C.pair_cost[0] = 2.0 * w_fold * (double)C.mles.size();
                 C.pair_cost[1] = c2 + (double)(sc->d - 1) * C.n_groups;
             }
             // geometry: waves sharing a group's terms, pairs per tile, shrunk until the staged rows fit the LDS budget
             C.wt_log = max_terms >= 4 ? 2 : (max_terms >= 2 ? 1 : 0);
             C.tp_log = 8 - C.wt_log;
+            while (C.tp_log > 6 && gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget3(ctx, sc->d)) C.tp_log--;
             while (C.tp_log > 4 && gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d)) C.tp_log--;
             if (gen_stage_bytes(C.units[0], C.tp_log) > gen_stage_budget(sc->d) || C.units[0] > GEN_MAX_UNITS) { ok = false; break; }
             C.wt_log = std::min(2, 8 - C.tp_log);
@@ -1602,6 +1749,32 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         cl.gen = true;
         comps.insert(comps.end(), mine.begin(), mine.end());
     }
+    if (getenv("CENO_HIP_PLAN_REPORT")) {
+        std::string rep = "[";
+        for (size_t ci = 0; ci < sc->classes.size(); ci++) {
+            const ScClass& cl = sc->classes[ci];
+            int n_comp = 0, n_eq = 0, staged = 0, tp_min = 99, tp_max = 0;
+            size_t units_max = 0;
+            for (const auto& C : comps) {
+                if (C.cls != (int)ci || C.n_groups == 0) continue;
+                n_comp++;
+                n_eq += C.geq >= 0 ? 1 : 0;
+                staged += (int)C.mles.size();
+                tp_min = std::min(tp_min, C.tp_log);
+                tp_max = std::max(tp_max, C.tp_log);
+                units_max = std::max(units_max, C.units[0]);
+            }
+            const char* path = cl.dense ? "dense" : (!cl.gen ? "two-kernel" : (n_comp > 0 && n_eq == n_comp ? "eq-factored" : (n_eq > 0 ? "eq-factored+generic" : "generic")));
+            char buf[512];
+            snprintf(buf, sizeof buf, "%s{\"num_vars\": %d, \"tables\": %zu, \"terms\": %zu, \"groups\": %d, \"path\": \"%s\", \"components\": %d, "
+                     "\"eq_components\": %d, \"tables_staged\": %d, \"pairs_per_tile_log2\": [%d, %d], \"max_stage_units\": %zu}",
+                     ci ? ", " : "", cl.nv, cl.mles.size(), cl.terms.size(), cl.n_groups, path, n_comp, n_eq, staged, n_comp ? tp_min : 0, tp_max, units_max);
+            rep += buf;
+        }
+        rep += "]";
+        std::lock_guard<PoolMutex> g(ctx->mu);
+        ctx->plan_report = rep;
+    }
     if (comps.empty()) return 0;
     CENO_TIMED("sc_build_gen: from the slot schedule on");
     // ---- slot schedule of every round (simulation of the buffer ping-pong of sc_round / sc_advance) ----
@@ -1621,7 +1794,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                 if (cl.nv <= i) continue;
                 for (size_t k = 0; k < C.mles.size(); k++) {
                     const ScMle& M = sim[cl.mles[C.mles[k]]];
-                    row[C.slot_off + k] = MleSlot{M.cur, M.buf[M.which], M.cur_ext, 0};
+                    row[C.slot_off + k] = MleSlot{M.cur, C.writes.empty() || C.writes[k] ? M.buf[M.which] : nullptr, M.cur_ext, 0};
                 }
             }
             if (i > 0)
@@ -1766,15 +1939,29 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     continue;
                 }
                 if (total > cap) {
+                    // more workgroups than are resident at once, each with 1 / oversub of a resident slot's share: the dispatcher hands the
+                    // next one to whichever slot frees up, so a component whose cost the estimate got wrong no longer sets the launch's time
+                    // (with one workgroup per slot a 2x error in the weight of the product terms cost the wide batch 106 -> 157 ms,
+                    // tools/dev/wide_sweep.sh) — and the tail of the launch is 1 / oversub of a slot's time
                     const double share = wsum > 0 ? weight_eq[k] / wsum : 0.0;
-                    cnt = 1u + (unsigned)(share * (double)(cap - (unsigned)list_eq.size()));
+                    const unsigned budget = std::max(cap * gen_oversub(), (unsigned)list_eq.size());
+                    cnt = 1u + (unsigned)(share * (double)(budget - (unsigned)list_eq.size()));
                     cnt = std::min(cnt, G.n_tiles);
                 }
                 G.wg_begin = wg;
                 G.wg_count = std::max(cnt, 1u);
                 wg += G.wg_count;
             }
+            if (i == 1 && getenv("CENO_HIP_PLAN_REPORT") && atoi(getenv("CENO_HIP_PLAN_REPORT")) >= 2) {
+                fprintf(stderr, "[ceno_hip] eq launch of round 1: cap %u, %zu components, %u workgroups, stage %zu B, LDS per workgroup %zu B\n", cap, list_eq.size(), wg,
+                        R.stage_bytes_eq, gen_lds_bytes(sc->d, R.stage_bytes_eq));
+                for (size_t k = 0; k < list_eq.size(); k++)
+                    fprintf(stderr, "[ceno_hip]   comp %3zu: pairs 2^%d mles %3u groups %u tp_log %u tiles %7u p2 tiles %7u weight %.3e wgs %4u weight/wg %.3e\n", k,
+                            (int)(63 - __builtin_clzll(list_eq[k].pairs)), list_eq[k].n_mles, list_eq[k].n_groups, list_eq[k].tp_log, list_eq[k].n_tiles,
+                            list_eq[k].p2_tile_end - list_eq[k].p2_tile_begin, weight_eq[k], list_eq[k].wg_count, weight_eq[k] / list_eq[k].wg_count);
+            }
             R.grid_eq = wg;
+            sc->geq.max_grid = std::max(sc->geq.max_grid, wg);
             R.n_comps_eq = (int)list_eq.size();
             R.off_comps_eq = append(list_eq.data(), list_eq.size() * sizeof(GenComp));
             for (size_t k = 0; k < list_eq.size(); k++) comp_fix.push_back(R.off_comps_eq + k * sizeof(GenComp));
@@ -1878,29 +2065,43 @@ static int sc_build(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, const ceno_hip
         }
     }
     sc->terms.resize(plan->num_terms);
+    // the group of every term first: a term of a common-factor group may have NO factor of its own (coefficient x the group's common
+    // factors: the `selector x constant` monomials of a chip's records, zerocheck_layer.rs:118-140) and takes its size from the group
+    std::vector<int> term_group(plan->num_terms, -1);
+    for (int g = 0; g < plan->num_groups; g++)
+        for (uint32_t k = plan->group_term_offsets[g]; k < plan->group_term_offsets[g + 1]; k++) {
+            const uint32_t t = plan->group_term_idx[k];
+            if ((int)t >= plan->num_terms || term_group[t] != -1) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "bad common-term plan (term %u)", t); }
+            term_group[t] = g;
+        }
     for (int t = 0; t < plan->num_terms; t++) {
         uint32_t b = plan->term_offsets[t], e = plan->term_offsets[t + 1];
         ScTerm& T = sc->terms[t];
         T.coeff = E2{plan->term_coeffs[2 * t], plan->term_coeffs[2 * t + 1]};
         // all factors of a term share num_vars (layer/gpu/utils.rs:54-63); empty products are not sumcheck terms
-        if (e <= b) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d has an empty product", t); }
+        const int g = term_group[t];
+        const bool has_common = g >= 0 && plan->common_offsets[g + 1] > plan->common_offsets[g];
+        if (e <= b && !has_common) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d has an empty product", t); }
         for (uint32_t k = b; k < e; k++) {
             uint32_t j = plan->term_mle_idx[k];
             if ((int)j >= plan->num_mles) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d references mle %u", t, j); }
             T.idx.push_back((int)j);
         }
-        T.nv = sc->mles[T.idx[0]].nv;
+        if (T.idx.empty()) {
+            const uint32_t j = plan->common_mle_idx[plan->common_offsets[g]];
+            if ((int)j >= plan->num_mles) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "group %d references mle %u", g, j); }
+            T.nv = sc->mles[j].nv;
+        } else {
+            T.nv = sc->mles[T.idx[0]].nv;
+        }
         for (int j : T.idx)
             if (sc->mles[j].nv != T.nv) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %d mixes MLEs of %d and %d variables", t, T.nv, sc->mles[j].nv); }
     }
     // degree check including common factors
-    std::vector<int> term_group(plan->num_terms, -1);
     for (int g = 0; g < plan->num_groups; g++) {
         int ncommon = (int)(plan->common_offsets[g + 1] - plan->common_offsets[g]);
         for (uint32_t k = plan->group_term_offsets[g]; k < plan->group_term_offsets[g + 1]; k++) {
             uint32_t t = plan->group_term_idx[k];
-            if ((int)t >= plan->num_terms || term_group[t] != -1) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "bad common-term plan (term %u)", t); }
-            term_group[t] = g;
             if ((int)sc->terms[t].idx.size() + ncommon > d) { sc_release(sc); return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "term %u exceeds max_degree %d", t, d); }
             for (uint32_t c = plan->common_offsets[g]; c < plan->common_offsets[g + 1]; c++) {
                 uint32_t j = plan->common_mle_idx[c];
@@ -2257,7 +2458,7 @@ static bool sc_pipeline_eligible(const ceno_hip_sumcheck* sc) {
     if (!sc->allow_pipeline) return false;
     static const bool disabled = getenv("CENO_HIP_NO_PIPELINE") != nullptr;  // A/B switch for measurements
     if (disabled) return false;
-    if (sc->ctx->prof_on) return false;  // per-launch timing wants the kernels free of mailbox waits
+    if (sc->ctx->prof_on && !sc->ctx->prof_pipelined) return false;  // per-launch timing (mode 1) wants the kernels free of mailbox waits
     if (sc->classes.size() != 1) return false;
     const ScClass& cl = sc->classes[0];
     return cl.nv == sc->n && sc->n >= 2 && !cl.terms.empty();
@@ -2574,11 +2775,21 @@ static int sc_pipeline_enqueue(ceno_hip_sumcheck* sc, int upto) {
                 ep.coeff = T.coeff;
                 const int mode = (i == 0 ? 0 : 2) + (row[0].in_ext ? 0 : 1);
                 const unsigned grid = sc_grid(pairs);
+                // ceno_hip_prof_enable(ctx, 2): ONE event pair around the large rounds of a sumcheck as queued — they run back to back on the
+                // stream, so the span is the sum of their durations, the waits for the next challenge included (an event pair per launch
+                // cost the timed steps 2.6 %)
+                const bool last_large = ((size_t)1 << (cl.nv - i - 1)) / 2 <= dense_small_pairs || i + 1 >= sc->n;
+                if (i == 0) prof_begin(ctx, sc->st);
                 switch ((int)T.idx.size()) {
                 case 1: launch_dense_row<1>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
                 case 2: launch_dense_row<2>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
                 case 3: launch_dense_row<3>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
                 default: launch_dense_row<4>(sc, cl, mode, pairs, e2_zero(), grid, ep, row); break;
+                }
+                {
+                    const double in_el = row[0].in_ext ? 16.0 : 8.0, kk = (double)T.idx.size();
+                    prof_count(ctx, i == 0 ? kk * 2.0 * pairs * in_el : kk * (4.0 * pairs * in_el + 2.0 * pairs * 16.0));
+                    if (last_large) prof_end(ctx, sc->st, 0.0, 0);
                 }
                 continue;
             }
@@ -2944,7 +3155,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             const GenRound& R = sc->gen_rounds[i];
             geq_arm(sc, i);
             ctx->eq_launches.fetch_add(1, std::memory_order_relaxed);
-            ep.partials = reinterpret_cast<uint64_t*>(sc->d_partials);
+            ep.partials = sc->geq.d_rows;
             ep.d = 0;
             GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters, reinterpret_cast<const uint16_t*>(sc->d_gen + R.off_wg_comp)};
             static const bool phase_dbg = getenv("CENO_HIP_GEN_PHASE_DBG") != nullptr;  // device-side phase stamps of the launch's last workgroup
@@ -3109,6 +3320,7 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
 
 uint64_t ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx) { return ctx ? (uint64_t)ctx->eq_launches.load() : 0ull; }
 
+const char* ceno_hip_plan_report(const ceno_hip_ctx* ctx) { return ctx ? ctx->plan_report.c_str() : ""; }
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc) { return sc && sc->geq.on ? (int)sc->geq.comps.size() : 0; }
 
 int ceno_hip_sumcheck_round(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t* out_evals) {

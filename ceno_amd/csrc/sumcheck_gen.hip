@@ -77,8 +77,10 @@ __device__ __forceinline__ void gen_phase1(const GenComp& C, size_t p0, E2* stag
                 lo = E2{add(t0.c0, v0.x), t0.c1};
                 hi = E2{add(t1.c0, v1.x), t1.c1};
             }
-            st_e2(s_out + 4 * p, lo);
-            st_e2(s_out + 4 * p + 2, hi);
+            if (s_out) {  // (a column staged by several column blocks of one chip is written by the block that owns it)
+                st_e2(s_out + 4 * p, lo);
+                st_e2(s_out + 4 * p + 2, hi);
+            }
         } else if (in_ext) {
             lo = ld_e2(s_in + 4 * p);
             hi = ld_e2(s_in + 4 * p + 2);
@@ -175,8 +177,10 @@ __global__ void __launch_bounds__(NT) k_gen(const GenComp* __restrict__ comps, i
                     lo = E2{add(t0.c0, v0.x), t0.c1};
                     hi = E2{add(t1.c0, v1.x), t1.c1};
                 }
-                st_e2(s_out + 4 * p, lo);
-                st_e2(s_out + 4 * p + 2, hi);
+                if (s_out) {  // (a column staged by several column blocks of one chip is written by the block that owns it)
+                    st_e2(s_out + 4 * p, lo);
+                    st_e2(s_out + 4 * p + 2, hi);
+                }
             } else if (in_ext) {
                 lo = ld_e2(s_in + 4 * p);
                 hi = ld_e2(s_in + 4 * p + 2);
@@ -244,7 +248,10 @@ __global__ void __launch_bounds__(NT) k_gen(const GenComp* __restrict__ comps, i
                     const unsigned nf = t1.x;
                     uint64_t idx8 = u64_of(t1.z, t1.w);
                     uint64_t pb[D];
-                    {
+                    if (nf == 0) {  // coefficient x the group's common factors only
+#pragma unroll
+                        for (int t = 0; t < D; t++) pb[t] = 1;
+                    } else {
                         const ulonglong2 v = reinterpret_cast<const ulonglong2*>(stage)[(unsigned)(idx8 & 0xff) * tpp + q];
                         uint64_t x = v.x;
 #pragma unroll
@@ -481,7 +488,10 @@ __device__ __forceinline__ void gen_group_eq(const GenComp& C, unsigned g, const
             const bool lead = nf == (unsigned)(D - 1);
             uint64_t idx8 = u64_of(t1.z, t1.w);
             uint64_t pb[D];  // pb[D - 1]: the product of the (f(0) - f(1))
-            {
+            if (nf == 0) {  // a constant under the selector: every value slot, no leading coefficient (D - 1 >= 2 factors make one)
+#pragma unroll
+                for (int t = 0; t < D; t++) pb[t] = 1;
+            } else {
                 const ulonglong2 v = reinterpret_cast<const ulonglong2*>(stage)[(unsigned)(idx8 & 0xff) * tpp + q];
                 uint64_t x = v.x;
 #pragma unroll
@@ -832,7 +842,10 @@ __global__ void __launch_bounds__(NT) k_eq_base0(const GenComp* __restrict__ com
                 const bool lead = nf == (unsigned)(D - 1);
                 uint64_t idx8 = u64_of(t1.z, t1.w);
                 uint64_t pb[D];  // pb[D - 1]: the product of the (f(0) - f(1))
-                {
+                if (nf == 0) {  // a constant under the selector
+#pragma unroll
+                    for (int t = 0; t < D; t++) pb[t] = 1;
+                } else {
                     const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(table((unsigned)(idx8 & 0xff)) + 2 * p);
                     const uint64_t nd = sub(v.x, v.y);
                     uint64_t x = v.y;

@@ -190,7 +190,12 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         for (int t = 0; t < n_terms; t++) {
             std::vector<uint32_t> ext_part;
             for (uint32_t k = toff[t]; k < toff[t + 1]; k++) (ceno_hip_mle_is_ext(mles[tidx[k]]) ? ext_part : base_part[t]).push_back(tidx[k]);
-            if (ext_part.empty() || base_part[t].empty()) {
+            if (ext_part.size() == 1 && base_part[t].empty()) {
+                // selector x constant (the constants of a chip's record RLCs, zerocheck_layer.rs:118-140): a term of the selector's group
+                // with no factor of its own — left ungrouped it would read the selector as an ordinary factor and take the whole chip off
+                // the eq-factored rounds
+                by_ext[ext_part].push_back(t);
+            } else if (ext_part.empty() || base_part[t].empty()) {
                 base_part[t].assign(tidx.begin() + toff[t], tidx.begin() + toff[t + 1]);  // ungrouped: full product
             } else {
                 std::sort(ext_part.begin(), ext_part.end());

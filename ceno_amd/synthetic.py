@@ -60,6 +60,110 @@ def batched_algorithmic_bytes(max_nv: int = 24, w: int = 12) -> float:
     return float(sum((40 * w + 48) << nv for nv in batched_sizes(max_nv)))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# config #4 at the REFERENCE's plan statistics (round-4 verdict, item 1).  What the monomial form of a real chip looks like
+# (gkr_iop/src/gkr/layer/zerocheck_layer.rs:86-207: every out-eval expression is multiplied by its group's selector, the groups are
+# summed with the alpha powers and the sum is monomialised; ceno_zkvm/src/instructions.rs:48-83: the r / w / lk / zero groups of an
+# opcode chip SHARE one Prefix selector, tables/shard_ram.rs:575-578: a few chips have two or three): per chip 22..96 base columns, one
+# (sometimes 2-3) selectors, and 60..250 monomials = selector x column for (nearly) every column — the records are RLCs of columns —
+# plus a `selector x constant` monomial per selector, plus a tail of selector x (2..4 columns) from the zero constraints, whose columns
+# come from a small cluster (the limbs and carries the arithmetic constraints tie together).
+# ------------------------------------------------------------------------------------------------------------------
+WIDE_SPREAD = [0, 1, 2, 2, 3, 3] + [4] * 4 + [5] * 4 + [6] * 6 + [7] * 6 + [8] * 6 + [9] * 4 + [10] * 4 + [11] * 4 + [12] * 4   # 48 chips
+WIDE_WIDTHS = [22, 30, 26, 40, 34, 64, 22, 48, 80, 96, 26, 30, 56, 22, 34, 40, 96, 22, 64, 26, 48, 30, 80, 22,
+               34, 56, 26, 40, 22, 96, 30, 48, 64, 22, 26, 80, 34, 40, 22, 56, 30, 96, 26, 48, 22, 64, 34, 80]
+
+
+def wide_plan(c: int, w: int, n_exprs: int):
+    """the monomial plan of wide chip `c`: (n_sel, terms [[mle ids]], scalars [[(coeff, [challenge ids])]], max_degree).  MLE ids: columns
+    0 .. w - 1, selectors w .. w + n_sel - 1.  Deterministic in (c, w)."""
+    rng = np.random.RandomState(0x51DE + 7919 * c + w)
+    n_sel = 3 if c % 12 == 11 else (2 if c % 6 == 5 else 1)
+    terms, scalars = [], []
+
+    def scalar(t):
+        monos = [((int(rng.randint(1, 1 << 30)), int(rng.randint(0, 1 << 30))), [2 + int(rng.randint(0, n_exprs))])]
+        if t % 3 == 0:  # a column that several records share: its coefficient is a sum of challenge monomials
+            monos.append(((int(rng.randint(1, 1 << 30)), 0), [int(rng.randint(0, 2)), 2 + int(rng.randint(0, n_exprs))]))
+        return monos
+
+    for si in range(n_sel):
+        sel = w + si
+        cols = range(w) if si == 0 else [j for j in range(w) if (j + si) % 3 == 0]
+        for j in cols:                      # selector x column: the record RLCs
+            terms.append([sel, j])
+            scalars.append(scalar(len(terms)))
+        terms.append([sel])                 # selector x constant (the constants of the records)
+        scalars.append(scalar(len(terms)))
+    # the zero constraints: products of 2 .. 4 columns of a cluster of ~ w / 4 columns under the first selector
+    cluster = [int(x) for x in rng.choice(w, size=max(6, w // 4), replace=False)]
+    n_nl = max(8, min(250 - len(terms), int(w * 0.9) + int(rng.randint(0, 12))))
+    max_deg = 3
+    for t in range(n_nl):
+        u = rng.randint(0, 100)
+        k = 2 if u < 70 else (3 if u < 92 else 4)
+        if c % 4 != 0 and k == 4:           # degree 5 (selector x 4 columns) only on every fourth chip
+            k = 3
+        fs = [cluster[int(x)] for x in rng.randint(0, len(cluster), size=k)]  # repeated factors happen (x^2 terms)
+        terms.append([w] + fs)
+        scalars.append(scalar(len(terms)))
+        max_deg = max(max_deg, k + 1)
+    return n_sel, terms, scalars, max_deg
+
+
+def wide_sizes(max_nv: int):
+    return [max(1, max_nv - d) for d in WIDE_SPREAD]
+
+
+def wide_batched_jobs(dev, max_nv: int = 24, n_chips: int = 48, point_of=None):
+    """48 chips of 2^(max_nv - 12) .. 2^max_nv rows and 22 .. 96 columns (>= 2000 monomials over >= 1500 MLEs in ONE sumcheck).
+    Returns (jobs, chips, table_elements): `chips` carries what a checker needs (columns, points, ranges, terms, scalars)."""
+    jobs, chips, elems = [], [], 0
+    n_exprs = 4
+    for c, nv in enumerate(wide_sizes(max_nv)[:n_chips]):
+        w = WIDE_WIDTHS[c % len(WIDE_WIDTHS)]
+        n_sel, terms, scalars, deg = wide_plan(c, w, n_exprs)
+        cols = [dev.synthetic(nv, False, 0x77000 + 131 * c + j) for j in range(w)]
+        point = np.array([[(i * 7919 + 13 + c) % P, (i * 104729 + 17) % P] for i in range(nv)], dtype=np.uint64)
+        sels, ranges = [], []
+        for si in range(n_sel):
+            n_inst = max(1, (1 << nv) - 3 - 5 * c - ((1 << nv) // 3) * si)  # the further selectors cover a shorter prefix
+            sels.append((1, 0, n_inst, si, (), 0, point))
+            ranges.append(n_inst)
+        jobs.append(dict(num_vars=nv, mles=cols + [None] * n_sel, n_witin=w, n_fixed=0, n_structural=n_sel, selectors=sels, n_exprs=n_exprs,
+                         max_degree=deg, terms=terms, scalars=scalars))
+        chips.append(dict(nv=nv, w=w, n_sel=n_sel, cols=cols, point=point, n_inst=ranges, terms=terms, scalars=scalars, n_exprs=n_exprs))
+        elems += (w + n_sel) << nv
+    return jobs, chips, elems
+
+
+def eq_form_mult_equivalents(jobs, degree: int) -> float:
+    """extension-field multiplication equivalents of one batched main sumcheck in the eq-factored form (k_gen_eq row), the
+    yardstick the VALU instruction counts of two plans are compared on: per chip and pair a fold is 2 per table, a monomial of nf column
+    factors under its selector costs D - 2 multiply-accumulates for nf <= 1 and 2 + (nf - 1)(D - 2) (+ nf - 1 when it reaches the leading
+    coefficient, nf = D - 1) otherwise, a selector group D - 1; a chip of 2^nv rows has 2^nv - 1 pairs over its rounds"""
+    tot = 0.0
+    for j in jobs:
+        n_sel = j["n_structural"]
+        first_sel = j["n_witin"] + j["n_fixed"]
+        per_pair = 2.0 * len(j["mles"]) + (degree - 1) * n_sel
+        for t in j["terms"]:
+            nf = sum(1 for m in t if m < first_sel)
+            per_pair += (degree - 2) if nf <= 1 else 2 + (nf - 1) * (degree - 2) + (nf - 1 if nf == degree - 1 else 0)
+        tot += per_pair * ((1 << j["num_vars"]) - 1)
+    return tot
+
+
+def wide_algorithmic_bytes(max_nv: int = 24) -> float:
+    """as batched_algorithmic_bytes: 40 B per base-column element, 48 B per selector element"""
+    tot = 0
+    for c, nv in enumerate(wide_sizes(max_nv)):
+        w = WIDE_WIDTHS[c % len(WIDE_WIDTHS)]
+        n_sel = 3 if c % 12 == 11 else (2 if c % 6 == 5 else 1)
+        tot += (40 * w + 48 * n_sel) << nv
+    return float(tot)
+
+
 class ChipFlow:
     """config #3: device-resident 2^log_rows x w base trace -> commit -> 2 challenges -> create_chip_proof ->
     batched main constraints (one job) -> Basefold open.  `run()` returns per-phase wall times in ms."""

@@ -223,6 +223,10 @@ int ceno_hip_sumcheck_begin_eq(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, con
 int ceno_hip_sumcheck_eq_components(const ceno_hip_sumcheck* sc);
 /* eq-factored round launches this context has issued so far (a statistic for tests and A/B runs) */
 uint64_t ceno_hip_stat_eq_launches(const ceno_hip_ctx* ctx);
+/* With CENO_HIP_PLAN_REPORT=1 in the environment: a JSON array describing the round kernels the size classes of the multi-class sumcheck
+ * built LAST on this context were given — per class its variables, tables, terms, "path" ("eq-factored" | "generic" | "two-kernel" |
+ * "dense"), components, column blocks, tables staged twice, pairs per tile.  "" otherwise.  Valid until the next begin on the context. */
+const char* ceno_hip_plan_report(const ceno_hip_ctx* ctx);
 /* Produce the message of the next round.  `challenge2` is the challenge of the PREVIOUS round
  * (NULL for round 0): the tables are folded with it and the new message accumulated in one pass.
  * out_evals receives max_degree ext elements (host memory). Synchronises the stream. */
@@ -721,6 +725,9 @@ int ceno_hip_witgen_logic_r(ceno_hip_ctx* ctx, const ceno_hip_logic_r_column_map
  * ---------------------------------------------------------------------------------------------- */
 /* accumulated device time (ms) and launch count of the fused sumcheck round kernel since the last reset */
 int ceno_hip_prof_reset(ceno_hip_ctx* ctx);
+/* on = 1: every round is launched when it is asked for (no pipelining), events bracket the bare kernels.  on = 2: pipelined sumchecks STAY
+ * pipelined — what a timed region runs — and the events bracket their large dense rounds as queued (a queued round ends when its finishing
+ * workgroup has the next challenge, so the sum includes those waits and can never exceed the wall time of the same region). */
 int ceno_hip_prof_enable(ceno_hip_ctx* ctx, int on);
 int ceno_hip_prof_get(ceno_hip_ctx* ctx, double* kernel_ms, uint64_t* launches, double* algorithmic_bytes);
 

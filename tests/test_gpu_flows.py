@@ -512,6 +512,89 @@ def test_config4_batched_main_sumcheck_full_size(dev, prover, max_nv):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# config #4 at the reference's plan statistics: 48 chips, 22..96 columns, 60..250 monomials per chip (ceno_amd/synthetic.py
+# wide_batched_jobs; shapes: gkr_iop/src/gkr/layer/zerocheck_layer.rs:86-207, ceno_zkvm/src/instructions.rs:48-83)
+# ------------------------------------------------------------------------------------------------------------------
+def _wide_oracle_plan(chips, gch, pows):
+    coeffs, terms, nvs = [], [], []
+    a0 = 0
+    for ch in chips:
+        start = len(nvs)
+        nvs += [ch["nv"]] * (ch["w"] + ch["n_sel"])
+        coeffs += oracle_scalars(ch["scalars"], gch + pows[a0: a0 + ch["n_exprs"]])
+        terms += [[start + j for j in t] for t in ch["terms"]]
+        a0 += ch["n_exprs"]
+    return po.ext(coeffs), terms, nvs
+
+
+@pytest.mark.parametrize("max_nv,switches", [(13, {}), (13, {"CENO_HIP_GEN_EQF": "0"}), (13, {"CENO_HIP_GEN_SPLIT": "0"}), (14, {"CENO_HIP_GEN_MIN_LOG": "4"}),
+                                             (20, {})])
+def test_wide_batched_main_constraints_match_the_oracle(dev, prover, monkeypatch, max_nv, switches):
+    """the batched main sumcheck over 48 WIDE chips (22..96 base columns, 1..3 Prefix selectors, selector x column monomials for every
+    column, selector x constant, a tail of degree 3..5 products): every message, challenge and final evaluation equals the oracle prover's
+    (max_nv <= 14: from round 0; 20: verifier + independent evaluations + the last 12 rounds), with the eq-factored rounds, with the
+    declarations ignored (generic rounds), without the column-block split of wide components, and with the component tables on from 2^4
+    rows so that the smallest chips take the same path as the largest"""
+    from ceno_amd import synthetic
+
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    gch = [(11, 22), (33, 44)]
+    jobs, chips, _ = synthetic.wide_batched_jobs(dev, max_nv)
+    D = max(j["max_degree"] for j in jobs)
+    claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+    vt = po.StubTranscript(5)
+    vt.append_label(b"combine subset evals")
+    a = vt.sample_ext()
+    pows, acc = [], (1, 0)
+    for _ in range(sum(ch["n_exprs"] for ch in chips)):
+        pows.append(acc)
+        acc = po.e2_mul(acc, a)
+    coeffs, terms, nvs = _wide_oracle_plan(chips, gch, pows)
+    vpoint, expected = po.sumcheck_verify(claimed, msgs, vt)
+    assert np.array_equal(vpoint, rt)
+    off = 0
+    for ch in chips:
+        nv, w = ch["nv"], ch["w"]
+        for j in (0, w // 2, w - 1):
+            assert ch["cols"][j].evaluate(rt[:nv]) == tup(evals[off + j])
+        for si in range(ch["n_sel"]):
+            assert po.selector_evaluate(po.SEL_PREFIX, ch["point"], rt[:nv], 0, ch["n_inst"][si]) == tup(evals[off + w + si])
+        off += w + ch["n_sel"]
+    final_claim = po.sumcheck_expected_from_evals(nvs, coeffs, terms, max_nv, rt, evals)
+    assert expected == final_claim and claimed == po.recover_claim_from_final(final_claim, msgs, rt)
+    if max_nv <= 14:  # the oracle's prover from round 0
+        full = []
+        for ch in chips:
+            full += [m.download() for m in ch["cols"]]
+            full += [po.selector_compute(po.SEL_PREFIX, ch["point"], 0, n) for n in ch["n_inst"]]
+        t2 = po.StubTranscript(5)
+        t2.append_label(b"combine subset evals")
+        t2.sample_ext()
+        omsgs, ochal, ofin = po.sumcheck_prove(full, coeffs, terms, max_nv, D, t2)
+        assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals)
+    else:       # the last 12 rounds on the oracle's prover, from tables folded by the independent fix_variables kernel
+        keep = 12
+        cut = max_nv - keep
+        if all(ch["nv"] > cut for ch in chips):
+            tables = []
+            for ch in chips:
+                sel_tabs = [dev.selector_build(po.SEL_PREFIX, ch["point"], 0, n) for n in ch["n_inst"]]
+                for m in ch["cols"] + sel_tabs:
+                    t = m.fix_variables(rt[:cut]).download()
+                    if t.ndim == 1:
+                        t = np.stack([t, np.zeros_like(t)], axis=1)
+                    tables.append(np.ascontiguousarray(t))
+                for m in sel_tabs:
+                    m.free()
+            omsgs, _, ofin = po.sumcheck_prove(tables, coeffs, terms, keep, D, po.ReplayTranscript(rt[cut:]))
+            assert np.array_equal(omsgs, msgs[cut:]) and np.array_equal(ofin, evals)
+    for ch in chips:
+        for m in ch["cols"]:
+            m.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # multi-layer GKR circuit (a13): rotation argument first, then zerocheck -> linear -> sumcheck layers
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", [0, 1, 2])

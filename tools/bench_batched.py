@@ -42,7 +42,10 @@ def main():
         prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
         dev.sync()
         best = min(best, (time.perf_counter() - t0) * 1e3)
-    print(json.dumps({"chips": len(sizes), "num_vars": sizes, "width": w, "table_elements": total_elems, "batched_main_sumcheck_ms": best}))
+    from ceno_amd import synthetic
+    plain = [dict(num_vars=nv, mles=[None] * (w + 1), n_witin=w, n_fixed=0, n_structural=1,
+                  terms=[[w, j, (j + 1) % w] for j in range(w)] + [[w, j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 3)]) for nv in sizes]
+    print(json.dumps({"ext_mult_equivalents": synthetic.eq_form_mult_equivalents(plain, 4), "chips": len(sizes), "num_vars": sizes, "width": w, "table_elements": total_elems, "batched_main_sumcheck_ms": best}))
 
 
 if __name__ == "__main__":
