@@ -159,7 +159,7 @@ void ctx_trim_end(ceno_hip_ctx* ctx) {
     ctx->gate_cv.notify_all();
 }
 
-int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
+static int ctx_alloc_impl(ceno_hip_ctx* ctx, size_t bytes, void** out) {
     CENO_TIMED("ctx_alloc");
     size_t b = bucket_size(bytes);
     // hipFree waits for every stream of the device, and a lane's queued round kernels wait for a host that may be waiting
@@ -410,6 +410,19 @@ again:
     ctx->live[p] = b;
     *out = p;
     return 0;
+}
+
+// CENO_HIP_POOL_POISON=1 (debugging): every block the pool hands out is filled with a non-canonical pattern on the calling thread's stream — a
+// kernel that reads memory nobody wrote then fails the same way in every run instead of depending on what the block held before
+int ctx_alloc(ceno_hip_ctx* ctx, size_t bytes, void** out) {
+    const int rc = ctx_alloc_impl(ctx, bytes, out);
+    static const bool poison = getenv("CENO_HIP_POOL_POISON") != nullptr;
+    if (rc == 0 && poison) {
+        hipStream_t st = ceno_tls_stream ? ceno_tls_stream : ctx->default_stream;
+        (void)hipMemsetAsync(*out, 0xA5, bucket_size(bytes), st);
+        (void)hipStreamSynchronize(st);
+    }
+    return rc;
 }
 
 void ctx_free(ceno_hip_ctx* ctx, void* p) { ctx_free_on(ctx, p, ceno_tls_stream ? ceno_tls_stream : ctx->default_stream); }

@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(NT) k_eval_dot_host(const uint64_t* __restrict
     if (threadIdx.x == 0) {
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 w = {(unsigned)tot[0].c0, (unsigned)(tot[0].c0 >> 32), (unsigned)tot[0].c1, (unsigned)(tot[0].c1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host), "v"(w) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out_host), "v"(w) : "memory");
     }
 }
 

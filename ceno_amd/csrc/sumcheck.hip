@@ -223,6 +223,96 @@ __global__ void __launch_bounds__(NT) k_dense_pf(TabPtrs<K> tp, size_t pairs, E2
     epilogue<K, NT>(acc, ep, smem, &s_flag);
 }
 
+// LDS-prefetched form of the folding rounds (MODE 2: extension tables in, fold + accumulate).  The plain kernel's waves issue the twelve
+// 16-byte loads of an iteration, wait, multiply, store — the waves of a SIMD run in near lock step (they start together and do identical
+// work), so the memory pipe idles while they multiply and the VALU idles while they wait: the fold rounds of the nv = 26 sumcheck take
+// ~1.94 ms against 1.67 ms of memory time at the ceiling of their access pattern and 1.34 ms of VALU issue time
+// (profiles/r03_dense_kernel_ab.json).  Here every wave keeps the NEXT iteration's 3 x 4 KB in flight through the LDS-DMA path
+// (global_load_lds_dwordx4: no registers, lane l's 16 bytes land at base + 16 l) while it multiplies the current one: per table step
+//     wait for this step's block (counted vmcnt: everything issued after it stays in flight) -> four ds_read_b128 -> re-issue the block's
+//     loads for the next iteration into the same LDS lines -> fold, store, multiply.
+// The compiler does not see the LDS-DMA loads (inline assembly), so it inserts no conservative vmcnt(0) in front of the LDS reads; the
+// waits are written here.  vmcnt counts loads and stores in issue order on gfx9-family parts: between a block's loads and their use lie the
+// 2 stores of its own step and the 6 operations (4 loads + 2 stores) of each of the other K - 1 steps.
+template <int K>
+__global__ void __launch_bounds__(NT) k_dense_lds(TabPtrs<K> tp, size_t pairs, E2 r, Epilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];  // [wave][K][4][64] x 16 B
+    __shared__ E2 smem[(NT / 64) * K];
+    __shared__ unsigned long long s_chal[3];
+    __shared__ int s_flag;
+    E2 acc[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) acc[t] = e2_zero();
+    const size_t stride = (size_t)gridDim.x * NT;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef unsigned int lds_u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const lds_u4 lds_vec;
+    auto e2_of = [](const lds_u4 v) { return E2{((uint64_t)v.y << 32) | v.x, ((uint64_t)v.w << 32) | v.z}; };
+    lds_char* const wbase = (lds_char*)dyn + (size_t)wave * K * 4096;
+    const unsigned lds0 = (unsigned)(uintptr_t)wbase;  // LDS byte address of this wave's region (wave-uniform)
+    size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
+    // four 16-byte LDS-DMA loads of one (table, pair) block: element k of every lane -> line k of the block
+    auto issue = [&](int m, size_t pp) {
+        const uint64_t* q = tp.in[m] + 8 * pp;
+        const unsigned l = lds0 + (unsigned)m * 4096u;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(q), "v"(q + 2), "v"(q + 4), "v"(q + 6), "s"(l), "s"(l + 1024u), "s"(l + 2048u), "s"(l + 3072u)
+            : "memory");
+    };
+    const bool live = p < pairs;  // (pairs is a multiple of 64: a wave is live or idle as a whole)
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < K; m++) issue(m, p);
+    }
+    if (ep.wait_seq != 0) {
+        if (!read_challenge(ep, r, s_chal)) {  // pipeline aborted / timed out: leave everything untouched
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+    }
+    const E2Pre rp = e2_pre(r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first iteration's blocks (the loop's counted waits assume a full pipeline behind them)
+    for (; p < pairs; p += stride) {
+        const size_t pn = p + stride < pairs ? p + stride : p;  // (the last iteration re-reads its own blocks: no branch, uniform counts)
+        E2 pr[K];
+#pragma unroll
+        for (int m = 0; m < K; m++) {
+            constexpr int AFTER = 2 + 6 * (K - 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER) : "memory");
+            lds_vec* blk = (lds_vec*)(wbase + (size_t)m * 4096) + lane;
+            const lds_u4 v0 = blk[0], v1 = blk[64], v2 = blk[128], v3 = blk[192];
+            const E2 a0 = e2_of(v0), a1 = e2_of(v1), a2 = e2_of(v2), a3 = e2_of(v3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the lines are free again
+            issue(m, pn);
+            const E2 lo = a0 + e2_mul_pre(rp, a1 - a0);
+            const E2 hi = a2 + e2_mul_pre(rp, a3 - a2);
+            st_e2(tp.out[m] + 4 * p, lo);
+            st_e2(tp.out[m] + 4 * p + 2, hi);
+            E2 nd = lo - hi, x = hi;
+#pragma unroll
+            for (int t = 0; t < K; t++) {
+                if (m == 0) pr[t] = x;
+                else if (m < K - 1) pr[t] = e2_mul_nc(pr[t], x);
+                else pr[t] = pr[t] * x;
+                if (t + 1 < K) x = x - nd;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < K; t++) acc[t] = acc[t] + pr[t];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last iteration's spare loads must not land in LDS the epilogue reuses
+    epilogue<K, NT>(acc, ep, smem, &s_flag);
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic path
 // ------------------------------------------------------------------------------------------------
@@ -717,7 +807,7 @@ __global__ void k_finish_evals(const MleSlot* __restrict__ slots, int n, E2 r, E
     const E2 v = lo + r * (hi - lo);
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host + i), "v"(w) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out_host + i), "v"(w) : "memory");
 }
 
 // tables of a class as extension elements into pinned host memory (armed with MSG_INVALID): the host takes the sumcheck over from here
@@ -729,7 +819,7 @@ __global__ void __launch_bounds__(NT) k_export_tables(const MleSlot* __restrict_
         const E2 v = sl.in_ext ? ld_e2(sl.in + 2 * (size_t)j) : E2{sl.in[j], 0};
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_host + idx), "v"(w) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out_host + idx), "v"(w) : "memory");
     }
 }
 
@@ -1049,8 +1139,16 @@ static int dense_pf_mode() {  // tuning switch (bit 0: read-only round, bit 1: f
     return m;
 }
 
+static int dense_lds_mode() {  // folding rounds on the LDS-prefetched kernel (k_dense_lds)
+    static int m = [] {
+        const char* e = getenv("CENO_HIP_DENSE_LDS");
+        return e ? atoi(e) : 0;
+    }();
+    return m;
+}
+
 template <int K>
-static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
+static void launch_dense_k(ceno_hip_ctx* ctx, int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, const Epilogue& ep, unsigned grid, hipStream_t st) {
     const int wm = dense_wide_mode(), pf = dense_pf_mode();
     switch (mode) {
     case 0:
@@ -1062,6 +1160,14 @@ static void launch_dense_k(int mode, const TabPtrs<K>& tp, size_t pairs, E2 r, c
         break;
     case 1: hipLaunchKernelGGL((k_dense<K, 1, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep); break;
     case 2:
+        if constexpr (K >= 2 && K <= 3) {
+            if (dense_lds_mode() && pairs >= ((size_t)1 << 16)) {
+                // K x 16 KB of LDS per workgroup: three workgroups per CU, all resident (768 on 256 CUs)
+                const unsigned g = std::min(grid, resident_grid(ctx, k_dense_lds<K>, NT, (size_t)K * 16384, MAXB));
+                hipLaunchKernelGGL((k_dense_lds<K>), dim3(g), dim3(NT), (size_t)K * 16384, st, tp, pairs, r, ep);
+                break;
+            }
+        }
         if (pf & 2) {
             if (wm >= 2) hipLaunchKernelGGL((k_dense_pf<K, 2, true>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
             else hipLaunchKernelGGL((k_dense_pf<K, 2, false>), dim3(grid), dim3(NT), 0, st, tp, pairs, r, ep);
@@ -1081,7 +1187,7 @@ static void launch_dense(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_t pa
         tp.in[m] = M.cur;
         tp.out[m] = M.buf[M.which];
     }
-    launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
+    launch_dense_k<K>(sc->ctx, mode, tp, pairs, r, ep, grid, sc->st);
 }
 
 // the same launch with the tables of one staged slot row (pipelined rounds: the ping-pong walk of every round is staged once)
@@ -1094,7 +1200,7 @@ static void launch_dense_row(ceno_hip_sumcheck* sc, ScClass& cl, int mode, size_
         tp.in[m] = sl.in;
         tp.out[m] = sl.out;
     }
-    launch_dense_k<K>(mode, tp, pairs, r, ep, grid, sc->st);
+    launch_dense_k<K>(sc->ctx, mode, tp, pairs, r, ep, grid, sc->st);
 }
 
 static bool accum_lazy() {

@@ -138,7 +138,7 @@ __device__ __forceinline__ void finish_message(const E2 (&tot)[D], const Epilogu
                 // ONE 16-byte write-through system-scope store per point (each such store is its own fabric transaction)
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                 const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ep.out_msg + 2 * t), "v"(w) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ep.out_msg + 2 * t), "v"(w) : "memory");
             } else {
                 ep.out_msg[2 * t] = v.c0;
                 ep.out_msg[2 * t + 1] = v.c1;

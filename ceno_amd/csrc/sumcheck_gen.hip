@@ -570,7 +570,7 @@ __device__ __forceinline__ void gen_group_eq(const GenComp& C, unsigned g, const
             const E2 bv = cb * v;
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
             const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
         }
         if (valid) acc[t] = acc[t] + w * v;
     }
@@ -589,7 +589,7 @@ __device__ __forceinline__ void epilogue_eq(E2 (&acc)[D], const GenComp& C, cons
 #pragma unroll
         for (int t = 0; t < D; t++) {
             const u4 ww = {(unsigned)v[t].c0, (unsigned)(v[t].c0 >> 32), (unsigned)v[t].c1, (unsigned)(v[t].c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(eqa.q_out + (size_t)slot * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)slot * D + t), "v"(ww) : "memory");
         }
     };
     if (C.n_groups == 0) return;  // folded only: nothing to report
@@ -734,7 +734,7 @@ __device__ __forceinline__ void gen_group_eq_slot(const GenComp& C, unsigned g, 
         const E2 bv = cb * v;
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(b_out + (size_t)(brow + side) * D + slot), "v"(ww) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * D + slot), "v"(ww) : "memory");
     }
     if (valid) {
         const E2 add = w * v;
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__
         for (int t = 0; t < D; t++) {
             if ((unsigned)t != slot) continue;
             const u4 ww = {(unsigned)acc[t].c0, (unsigned)(acc[t].c0 >> 32), (unsigned)acc[t].c1, (unsigned)(acc[t].c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(eqa.q_out + (size_t)C.eq_slot * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)C.eq_slot * D + t), "v"(ww) : "memory");
         }
     }
 }
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(NT) k_eq_base0(const GenComp* __restrict__ com
                     const E2 bv = cb * v;
                     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                     const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(eqa.b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
                 }
                 acc[t] = acc[t] + w * v;
             }

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
             const int m = idx / len, j = idx - m * len;
             const E2 v = cur[(size_t)m * sc_ + j];
             const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(export_host + idx), "v"(w) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(export_host + idx), "v"(w) : "memory");
         }
         return;
     }
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(NT) k_tail(DevPlan pl, const MleSlot* __restri
                 const E2 v = lo + e2_mul_pre(rp, hi - lo);
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                 const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out_evals + m), "v"(w) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(out_evals + m), "v"(w) : "memory");
             }
         }
     }
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(NT) k_mid(DevPlan pl, const MleSlot* __restric
             for (int t = 0; t < D; t++) {
                 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                 const u4 w = {(unsigned)acc[t].c0, (unsigned)(acc[t].c0 >> 32), (unsigned)acc[t].c1, (unsigned)(acc[t].c1 >> 32)};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(row + 2 * t), "v"(w) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(row + 2 * t), "v"(w) : "memory");
             }
         }
         if (i == i1) {  // the tables this round was computed on go back to memory for the tail kernel: `pairs` pairs per workgroup

@@ -594,6 +594,30 @@ def test_wide_batched_main_constraints_match_the_oracle(dev, prover, monkeypatch
             m.free()
 
 
+@pytest.mark.parametrize("max_nv,n_chips,reps", [(18, 2, 60), (14, 48, 40)])
+def test_wide_batched_main_is_the_same_in_every_run(dev, prover, max_nv, n_chips, reps):
+    """Regression (round 5): the 16-byte stores that hand boundary values and component sums to the host are inline assembly, and a VMEM store
+    of more than 64 bits reads its data registers late — without wait states inside the statement the compiler's next instruction could
+    overwrite them (gfx940+: two wait states; the hazard recogniser does not look inside asm).  Under the load of an oversubscribed launch the
+    first words (c0 of the first slots) of a boundary value went out corrupted in up to 87 % of the runs of this two-chip batch.  Every run
+    must produce the words of the first."""
+    from ceno_amd import synthetic
+
+    jobs, chips, _ = synthetic.wide_batched_jobs(dev, max_nv, n_chips)
+    mj = prover.MainJobs(jobs)
+    gch = [(11, 22), (33, 44)]
+    first = None
+    for _ in range(reps):
+        out = prover.prove_batched_main_constraints(dev, mj, gch, prover.Transcript.stub(5))
+        if first is None:
+            first = out
+            continue
+        assert out[0] == first[0] and np.array_equal(out[1], first[1]) and np.array_equal(out[3], first[3])
+    for ch in chips:
+        for m in ch["cols"]:
+            m.free()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # multi-layer GKR circuit (a13): rotation argument first, then zerocheck -> linear -> sumcheck layers
 # ------------------------------------------------------------------------------------------------------------------
