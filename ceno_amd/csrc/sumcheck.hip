@@ -3530,6 +3530,43 @@ int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_in
     return 0;
 }
 
+int ceno_hip_sumcheck_table_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t* out_host, size_t cap_ext, int* num_vars) {
+    CHECK_ARG(ctx, sc && out_host && num_vars, "NULL argument");
+    CHECK_ARG(ctx, mle_index >= 0 && mle_index < (int)sc->mles.size(), "mle index out of range");
+    if (sc->pipelined) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "tables of a pipelined sumcheck are not observable between rounds");
+    if (sc->host_from >= 0) {  // the host has taken the last rounds over: the live tables are in its copy
+        if (!sc->host_len) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "the host copy of the tables is not there yet");
+        const ScMle& M = sc->mles[mle_index];
+        if (M.cls != 0 || M.local < 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "table %d is not part of the host-finished class", mle_index);
+        const size_t len = (size_t)sc->host_len;
+        if (len > cap_ext) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "table_host: buffer of %zu elements for a table of %zu", cap_ext, len);
+        memcpy(out_host, sc->host_tab.data() + (size_t)M.local * (size_t)sc->host_len0, len * sizeof(E2));
+        int nv = 0;
+        while (((size_t)1 << nv) < len) nv++;
+        *num_vars = nv;
+        return 0;
+    }
+    uint64_t* d = nullptr;
+    int is_ext = 0, nv = 0;
+    TRY(ceno_hip_sumcheck_table(ctx, sc, mle_index, &d, &is_ext, &nv));
+    const size_t len = (size_t)1 << nv;
+    if (len > cap_ext) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "table_host: buffer of %zu elements for a table of %zu", cap_ext, len);
+    if (is_ext) {
+        HIP_TRY(ctx, hipMemcpyAsync(out_host, d, len * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+    } else {  // a base-field table (before its first fold): widened on the way out
+        std::vector<uint64_t> b(len);
+        HIP_TRY(ctx, hipMemcpyAsync(b.data(), d, len * 8, hipMemcpyDeviceToHost, sc->st));
+        HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+        for (size_t j = 0; j < len; j++) {
+            out_host[2 * j] = b[j];
+            out_host[2 * j + 1] = 0;
+        }
+    }
+    *num_vars = nv;
+    return 0;
+}
+
 int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on) {
     CHECK_ARG(ctx, sc, "NULL argument");
     if (sc->round != 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: pipelining must be chosen before round 0");

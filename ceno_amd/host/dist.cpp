@@ -987,6 +987,49 @@ int gather_digests(ceno_dist_comm* c, const uint64_t* mine4, uint64_t* out, hipS
 
 }  // namespace
 
+// ---- helpers for the row-sharded GKR half (dist_gkr.cpp) ----
+int dist_comm_world(const ceno_dist_comm* c) { return c ? c->world : 1; }
+int dist_comm_rank(const ceno_dist_comm* c) { return c ? c->rank : 0; }
+// all-gather `n_words` 64-bit words per rank (host memory in, host memory out: out[g * n_words + k]) over the communicator's small-message
+// transport — in-process group, shared segment or RCCL — in chunks of 128 words.  Bulk data (MBs) belongs on exchange_blocks; this carries the
+// per-round partial sums and the folded tables (KBs) of the sharded tower prover.
+int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, hipStream_t st) {
+    if (!c || c->world == 1) {
+        if (n_words) memcpy(out, mine, n_words * 8);
+        return 0;
+    }
+    const int W = c->world;
+    uint64_t buf[128];
+    for (size_t off = 0; off < n_words; off += 128) {
+        const size_t n = std::min<size_t>(128, n_words - off);
+        memset(buf, 0, sizeof buf);
+        memcpy(buf, mine + off, n * 8);
+        if (c->local) {
+            ceno_dist_local_group* G = c->local;
+            {
+                std::lock_guard<std::mutex> g(G->mu);
+                memcpy(&G->small[(size_t)c->rank * 128], buf, sizeof buf);
+            }
+            if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "allgather: a peer of the local group is gone");
+            {
+                std::lock_guard<std::mutex> g(G->mu);
+                for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, &G->small[(size_t)r * 128], n * 8);
+            }
+            if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "allgather: a peer of the local group is gone");
+        } else if (c->shm) {
+            if (int rc = shm_gather_ext(c, buf, 64)) return rc;
+            for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, c->h_recv + (size_t)r * 128, n * 8);
+        } else if (c->comm) {
+            if (hipMemcpyAsync(c->d_send, buf, sizeof buf, hipMemcpyHostToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "allgather: upload failed");
+            if (int rc = gather_ext(c, 64, st)) return rc;
+            for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, c->h_recv + (size_t)r * 128, n * 8);
+        } else {
+            return dist_fail(CENO_HIP_ERR_STATE, "allgather: communicator without a transport");
+        }
+    }
+    return 0;
+}
+
 extern "C" {
 
 ceno_dist_local_group* ceno_dist_local_group_create(int world) {

@@ -275,9 +275,11 @@ __attribute__((target("avx512f,avx512dq"))) void host_tower_fold8(E2* t, size_t 
 #endif
 void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active, const std::vector<E2>& alpha_prod,
                       const std::vector<E2>& alpha_num, const std::vector<E2>& alpha_den, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal,
-                      uint64_t* fin) {
-    tr_usize(tr, (uint64_t)n);
-    tr_usize(tr, 3);
+                      uint64_t* fin, bool prologue = true) {
+    if (prologue) {  // (false: the last n rounds of a layer whose first rounds ran elsewhere — the row-sharded tower prover, dist_gkr.cpp)
+        tr_usize(tr, (uint64_t)n);
+        tr_usize(tr, 3);
+    }
     size_t len = (size_t)1 << n;
     for (int round = 0; round < n; round++) {
         const size_t pairs = len / 2;
@@ -349,10 +351,35 @@ void host_tower_layer(int n, std::vector<std::vector<E2>>& tabs, int n_prod_acti
 
 }  // extern "C"
 int prover_tower_host_layers() { return std::max(tower_host_layers(), 0); }
+// the last `n` rounds of a tower layer's sumcheck on host tables (tabs[0] = eq, then (a, b) per product tower, (p1, p2, q1, q2) per LogUp
+// tower), no prologue: what the row-sharded tower prover runs on the gathered tables after its local rounds (dist_gkr.cpp)
+void prover_host_tower_rounds(int n, std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active, const std::vector<E2>& alpha_prod,
+                              const std::vector<E2>& alpha_num, const std::vector<E2>& alpha_den, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal,
+                              uint64_t* fin) {
+    host_tower_layer(n, tabs, n_prod_active, n_logup_active, alpha_prod, alpha_num, alpha_den, tr, msgs, chal, fin, false);
+}
+#include "tower_hook.hpp"
+int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                     ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out, const TowerDistHook* hook);
 extern "C" {
 int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
                                    ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out) {
+    return prover_tower_create_proof_hooked(ctx, prod, n_prod, logup, n_logup, tr, s, out, nullptr);
+}
+}  // extern "C"
+// CpuTowerProver::create_proof.  hook == NULL: the towers hold every layer.  hook != NULL (row-sharded chip proof): the towers passed in are
+// the REPLICATED tops of towers whose large layers live sharded across ranks — the numbers of variables come from the hook, rounds above
+// hook->r_rep are proved by hook->layer (same outputs: the round's messages, challenges and final evaluations).
+int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                     ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out, const TowerDistHook* hook) {
     if (!ctx || !tr || !out) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
+    auto ceno_hip_tower_num_vars = [&](const ceno_hip_tower* t) {  // (shadows the C entry inside this function: the GLOBAL height of a tower)
+        if (hook) {
+            for (int i = 0; i < n_prod; i++) if (prod[i] == t) return hook->nv_global[i];
+            for (int i = 0; i < n_logup; i++) if (logup[i] == t) return hook->nv_global[n_prod + i];
+        }
+        return ::ceno_hip_tower_num_vars(t);
+    };
     int max_nv = 0;
     for (int i = 0; i < n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(prod[i]));
     for (int i = 0; i < n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(logup[i]));
@@ -384,7 +411,7 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
         auto fetch = [&](ceno_hip_tower* t, HostTowerTop& h) -> int {
             // layers 0 .. min(host_layers, num_vars - 1) of this tower (layer `round` exists when num_vars > round)
             h.n_limbs = ceno_hip_tower_num_limbs(t);
-            h.n_layers = std::min(std::min(host_layers + 1, ceno_hip_tower_num_vars(t)), ceno_hip_tower_top_layers(t));
+            h.n_layers = std::min(std::min(host_layers + 1, ::ceno_hip_tower_num_vars(t)), ceno_hip_tower_top_layers(t));
             if (h.n_layers < 1) return 0;
             h.words.resize((size_t)2 * h.n_limbs * (((size_t)1 << h.n_layers) - 1));
             return ceno_hip_tower_download_top(ctx, t, h.n_layers, h.words.data(), s);
@@ -402,7 +429,14 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
             if (ceno_hip_tower_num_vars(prod[i]) > round && top_prod[i].n_layers <= round) on_host = false;
         for (int i = 0; i < n_logup && on_host; i++)
             if (ceno_hip_tower_num_vars(logup[i]) > round && top_logup[i].n_layers <= round) on_host = false;
-        if (on_host) {
+        if (hook && round > hook->r_rep) {
+            int n_mles = 1;
+            for (int i = 0; i < n_prod; i++) if (ceno_hip_tower_num_vars(prod[i]) > round) n_mles += 2;
+            for (int i = 0; i < n_logup; i++) if (ceno_hip_tower_num_vars(logup[i]) > round) n_mles += 4;
+            chal.assign((size_t)2 * round, 0);
+            fin.assign((size_t)2 * n_mles, 0);
+            if (int rc = hook->layer(hook->self, round, out_rt.data(), alpha.data(), tr, out->msgs + msg_off, chal.data(), fin.data())) return rc;
+        } else if (on_host) {
             std::vector<std::vector<E2>> tabs;
             std::vector<E2> a_prod, a_num, a_den;
             const size_t len = (size_t)1 << round;
@@ -515,6 +549,7 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
     return 0;
 }
 
+extern "C" {
 int ceno_prover_prove_tower_relation(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
                                      ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_evals, ceno_tower_proof* out) {
     if (!ctx || !tr || !out || !out_evals) return fail(CENO_HIP_ERR_INVALID, "NULL argument");

@@ -885,6 +885,64 @@ def create_chip_proof(dev: Device, task: dict, challenges, tr: Transcript, strea
         L.ceno_chip_proof_free(C.byref(out))
 
 
+class LocalGroup:
+    """in-process group of `world` virtual ranks (threads of one process sharing a device): ceno_dist_local_group"""
+
+    def __init__(self, world: int):
+        L = plib()
+        L.ceno_dist_local_group_create.restype = C.c_void_p
+        L.ceno_dist_local_group_create.argtypes = [C.c_int]
+        L.ceno_dist_local_group_destroy.restype = None
+        L.ceno_dist_local_group_destroy.argtypes = [C.c_void_p]
+        L.ceno_dist_comm_init_local.restype = C.c_int
+        L.ceno_dist_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ceno_dist_comm_destroy.restype = None
+        L.ceno_dist_comm_destroy.argtypes = [C.c_void_p]
+        self.world = world
+        self.h = L.ceno_dist_local_group_create(world)
+        if not self.h:
+            raise CenoHipError(-1, "local group: world must be a power of two")
+        self.comms = []
+        for r in range(world):
+            c = C.c_void_p()
+            _check(L.ceno_dist_comm_init_local(self.h, r, C.byref(c)))
+            self.comms.append(c)
+
+    def close(self):
+        L = plib()
+        for c in self.comms:
+            L.ceno_dist_comm_destroy(c)
+        self.comms = []
+        if self.h:
+            L.ceno_dist_local_group_destroy(self.h)
+            self.h = None
+
+
+def shard_rows(full: np.ndarray, world: int, rank: int, q: int) -> np.ndarray:
+    """the rows of a column that rank `rank` holds under ceno_dist_create_chip_proof's layout: index bits [q, q + log2 world) == rank, in order"""
+    k = world.bit_length() - 1
+    idx = np.arange(full.shape[0])
+    return np.ascontiguousarray(full[((idx >> q) & (world - 1)) == rank]) if k else full
+
+
+def dist_create_chip_proof(dev: Device, comm, task_local: dict, log2_num_instances_global: int, q: int, challenges, tr: Transcript, stream=None) -> ChipProof:
+    """ceno_dist_create_chip_proof: the chip proof over row-sharded columns (task_local: this rank's tables, log2_num_instances = the local height).
+    `comm`: a communicator handle (LocalGroup.comms[rank], ShmComm(...).h, RcclComm(...).h)"""
+    L = plib()
+    L.ceno_dist_create_chip_proof.restype = C.c_int
+    L.ceno_dist_create_chip_proof.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ChipTaskC), C.c_int, C.c_int, u64p, C.c_void_p, C.c_void_p, C.POINTER(ChipProofC)]
+    L.ceno_chip_proof_free.restype = None
+    L.ceno_chip_proof_free.argtypes = [C.POINTER(ChipProofC)]
+    T, keep = _marshal_chip_task(task_local)
+    ch = np.array([[int(c[0]), int(c[1])] for c in challenges], dtype=np.uint64)
+    out = ChipProofC()
+    _check(L.ceno_dist_create_chip_proof(dev.h, comm, C.byref(T), log2_num_instances_global, q, _p(ch), tr.h, stream, C.byref(out)))
+    try:
+        return ChipProof(out)
+    finally:
+        L.ceno_chip_proof_free(C.byref(out))
+
+
 def chip_proof_estimate_bytes(task: dict) -> int:
     """ceno_prover_chip_proof_estimate_bytes: what the lane scheduler books for this chip proof"""
     L = plib()

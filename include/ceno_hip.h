@@ -245,6 +245,10 @@ size_t ceno_hip_sumcheck_estimate_memory(int max_num_vars, int max_degree, const
  * read it (i.e. not yet folded with the challenge that call is going to receive).  Valid until the next
  * round/finish call; used by the sharded driver to gather small shards onto every rank. */
 int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t** device_ptr, int* is_ext, int* num_vars);
+/* The same table copied to HOST memory as extension elements (cap_ext = capacity of out_host in elements), wherever it lives: on the device,
+ * or in the host's copy once the host has taken the last rounds of a round-by-round sumcheck over (then ceno_hip_sumcheck_table fails).
+ * Synchronises the handle's stream.  Used by the row-sharded tower prover to gather the folded shards (ceno_amd/host/dist_gkr.cpp). */
+int ceno_hip_sumcheck_table_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t* out_host, size_t cap_ext, int* num_vars);
 /* Opt in (before round 0) to pipelined rounds: all round kernels are enqueued at round 0 and pick their
  * challenges up from a pinned-memory mailbox, which removes the launch latency from every round.  The
  * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after CENO_HIP_PIPE_TIMEOUT_S (60 s) without

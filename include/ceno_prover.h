@@ -465,6 +465,20 @@ typedef struct ceno_dist_local_group ceno_dist_local_group;
 ceno_dist_local_group* ceno_dist_local_group_create(int world);
 void ceno_dist_local_group_destroy(ceno_dist_local_group* g);
 int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_comm** out);
+/* The GKR half of a chip proof over ROW-SHARDED witness columns (ceno_amd/host/dist_gkr.cpp; SURVEY section 8(e): a3, a5-a10): record
+ * inference, tower witness and tower proof, bit for bit the proof ceno_prover_create_chip_proof produces from the whole columns
+ * (single-device flow: ZKVMProver::create_chip_proof, ceno_zkvm/src/scheme/prover.rs:717-833; tower prover scheme/cpu/mod.rs:346-554;
+ * the reference has no distribution, docs/src/optimizations.md:3-5).
+ * Row layout: with k = log2(world) and q = row_block_log (<= 0: ceno_dist_chip_block_log(), 10), rank g holds the rows whose index bits
+ * [q, q + k) equal g — blocks of 2^q rows dealt round-robin — in increasing order; `task->mles` are those local tables and
+ * task->log2_num_instances = log2_num_instances_global - k their height (task->num_instances stays the GLOBAL count; record plans as in
+ * ceno_chip_task).  A layout by the MIDDLE bits keeps both the product layers (which pair the top bit) and the LSB-first layer sumchecks
+ * local; the top of every tower (<= 2^(q + log2 records + k) entries per limb) is gathered and proved replicated.  Needs
+ * log2_num_instances_global >= q + k + 1; the rotation argument is not sharded (CENO_HIP_ERR_UNSUPPORTED).  Every rank passes a transcript
+ * in the same state and ends with the same proof; works over any transport of the communicator (in-process group, shared segment, RCCL). */
+int ceno_dist_chip_block_log(void);
+int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_chip_task* task, int log2_num_instances_global, int row_block_log,
+                                const uint64_t* challenges4, ceno_transcript* tr, ceno_hip_stream s, ceno_chip_proof* out);
 const char* ceno_dist_last_error(void);
 
 #ifdef __cplusplus

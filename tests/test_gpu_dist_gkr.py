@@ -1,0 +1,157 @@
+"""The GKR half of a chip proof over ROW-SHARDED witness columns (ceno_dist_create_chip_proof, ceno_amd/host/dist_gkr.cpp; SURVEY section 8(e):
+a3, a5-a10): record inference, tower witness and tower proof on `world` virtual ranks — threads of one process on their own streams and
+transcripts, exchanging through the in-process group — must produce, on EVERY rank, the proof ceno_prover_create_chip_proof produces from the
+whole columns, bit for bit; and that proof equals the oracle's (tests/test_gpu_flows.py pins the single-device flow to the oracle: one
+representative shape is re-checked here).  Reference: ZKVMProver::create_chip_proof ceno_zkvm/src/scheme/prover.rs:717-833, tower prover
+scheme/cpu/mod.rs:346-554."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+P = po.P
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from ceno_amd import Device
+
+    d = Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def prover():
+    from ceno_amd import prover as p
+
+    return p
+
+
+def record_plan(w, n_records, alpha, beta):
+    b2 = po.e2_mul(beta, beta)
+    terms, coeffs, out_terms = [], [], []
+    for k in range(n_records):
+        base = len(terms)
+        terms += [[(2 * k) % w], [(2 * k + 1) % w], [(3 * k + 5) % w, (k + 7) % w]]
+        coeffs += [beta, b2, alpha]
+        out_terms.append([base, base + 1, base + 2])
+    return po.ext(coeffs), terms, out_terms
+
+
+def proofs_equal(a, b):
+    return (np.array_equal(a.tower_msgs, b.tower_msgs) and np.array_equal(a.tower_point, b.tower_point) and
+            np.array_equal(a.tower_prod_evals, b.tower_prod_evals) and np.array_equal(a.tower_logup_evals, b.tower_logup_evals) and
+            np.array_equal(a.r_out_evals, b.r_out_evals) and np.array_equal(a.w_out_evals, b.w_out_evals) and
+            np.array_equal(a.lk_out_evals, b.lk_out_evals) and np.array_equal(a.rt_main, b.rt_main) and a.tower_num_vars == b.tower_num_vars)
+
+
+def run_sharded(dev, prover, cols, world, q, log2_n, shape, coeffs, terms, out_terms, challenges, seed):
+    num_reads, num_writes, num_lk_tables, num_lk = shape
+    w = len(cols)
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            local = [dev.upload(prover.shard_rows(c, world, g, q)) for c in cols]
+            task = dict(mles=local, n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << log2_n) - 5, log2_num_instances=log2_n - (world.bit_length() - 1),
+                        num_reads=num_reads, num_writes=num_writes, num_lk_tables=num_lk_tables, num_lk=num_lk, record_coeffs=coeffs, record_terms=terms,
+                        record_out_terms=out_terms)
+            results[g] = prover.dist_create_chip_proof(dev, group.comms[g], task, log2_n, q, challenges, prover.Transcript.stub(seed), st)
+            dev.sync(st)
+            for m in local:
+                m.free()
+            dev.stream_destroy(st)
+        except Exception as e:  # noqa: BLE001
+            errors.append((g, e))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world,log2_n,q,shape", [
+    (2, 12, 4, (4, 4, 0, 8)),      # the ADD shape: two product towers of 2 record bits, one LogUp tower of 3 -> two engine groups per layer
+    (4, 12, 3, (4, 4, 0, 8)),
+    (8, 13, 3, (4, 4, 0, 8)),
+    (4, 11, 4, (3, 0, 2, 0)),      # table circuit: numerators, no write set
+    (2, 10, 5, (0, 1, 0, 1)),      # single records (no record bits)
+    (4, 12, 2, (5, 2, 0, 3)),      # three different record counts -> three engine groups
+    (8, 14, 10 - 3, (4, 4, 0, 8)),
+])
+def test_row_sharded_chip_proof_equals_the_single_device_proof(dev, prover, world, log2_n, q, shape):
+    num_reads, num_writes, num_lk_tables, num_lk = shape
+    w = 9
+    rows = 1 << log2_n
+    n_lk_den = num_lk_tables if num_lk_tables else num_lk
+    n_rec = num_reads + num_writes + num_lk_tables + n_lk_den
+    alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+    cols = [po.rand_base(rows, 700 + j) for j in range(w)]
+    coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+    full = [dev.upload(c) for c in cols]
+    task = dict(mles=full, n_witin=w, n_fixed=0, n_structural=0, num_instances=rows - 5, log2_num_instances=log2_n, num_reads=num_reads,
+                num_writes=num_writes, num_lk_tables=num_lk_tables, num_lk=num_lk, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+    want = prover.create_chip_proof(dev, task, [alpha, beta], prover.Transcript.stub(21))
+    got = run_sharded(dev, prover, cols, world, q, log2_n, shape, coeffs, terms, out_terms, [alpha, beta], 21)
+    for g in range(world):
+        assert proofs_equal(got[g], want), f"rank {g} of {world}: the sharded proof differs from the single-device proof"
+    for m in full:
+        m.free()
+
+
+def test_row_sharded_chip_proof_matches_the_oracle(dev, prover):
+    """the same flow against the oracle's restatement directly (one shape; the single-device flow is pinned to the oracle on five)"""
+    world, log2_n, q = 4, 10, 3
+    num_reads, num_writes, num_lk_tables, num_lk = 4, 4, 0, 8
+    w, rows = 9, 1 << log2_n
+    alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+    cols = [po.rand_base(rows, 900 + j) for j in range(w)]
+    coeffs, terms, out_terms = record_plan(w, 16, alpha, beta)
+    got = run_sharded(dev, prover, cols, world, q, log2_n, (num_reads, num_writes, num_lk_tables, num_lk), coeffs, terms, out_terms, [alpha, beta], 33)[0]
+    recs = [po.wit_infer(cols, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], log2_n) for ts in out_terms]
+    prod_specs, out_evals = [], []
+    for group in (recs[:4], recs[4:8]):
+        limbs = po.interleaving_mles_to_mles(group, rows, 2, (1, 0))
+        layers = po.infer_tower_product_witness(int(limbs[0].shape[0]).bit_length(), limbs)
+        prod_specs.append(layers)
+        out_evals += [layers[0][0][0], layers[0][1][0]]
+    ql = po.interleaving_mles_to_mles(recs[8:], rows, 2, alpha)
+    layers = po.infer_tower_logup_witness(None, ql)
+    out_evals += [layers[0][k][0] for k in range(4)]
+    tr = po.StubTranscript(33)
+    for e in out_evals:
+        tr.append_ext((int(e[0]), int(e[1])))
+    oproof = po.tower_prove(prod_specs, [layers], tr)
+    assert np.array_equal(got.tower_msgs, oproof.msgs) and np.array_equal(got.tower_point, oproof.point[: got.tower_num_vars])
+    assert np.array_equal(got.tower_prod_evals, oproof.prod_evals) and np.array_equal(got.tower_logup_evals, oproof.logup_evals)
+
+
+def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
+    from ceno_amd.api import CenoHipError
+
+    world, log2_n, q = 4, 6, 5   # needs log2 rows >= q + log2 world + 1
+    cols = [po.rand_base(1 << log2_n, 5 + j) for j in range(4)]
+    coeffs, terms, out_terms = record_plan(4, 2, (3, 4), (5, 6))
+    group = prover.LocalGroup(world)
+    local = [dev.upload(prover.shard_rows(c, world, 0, 1)) for c in cols]
+    task = dict(mles=local, n_witin=4, n_fixed=0, n_structural=0, num_instances=60, log2_num_instances=log2_n - 2, num_reads=1, num_writes=1,
+                num_lk_tables=0, num_lk=0, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+    with pytest.raises(CenoHipError) as ei:
+        prover.dist_create_chip_proof(dev, group.comms[0], task, log2_n, q, [(3, 4), (5, 6)], prover.Transcript.stub(1))
+    assert "too small" in str(ei.value)
+    for m in local:
+        m.free()
+    group.close()
