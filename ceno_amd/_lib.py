@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libceno_hip.so")
-PROVER_LIB_PATH = os.path.join(HERE, "libceno_prover.so")
+PROVER_LIB_PATH = os.environ.get("CENO_PROVER_LIB") or os.path.join(HERE, "libceno_prover.so")  # (override: the sanitizer build, ceno_amd/build.py --sanitize)
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)

@@ -100,6 +100,60 @@ def build_all(force: bool = False, verbose: bool = False):
     build_prover(force)
 
 
+SAN = os.path.join(HERE, "_san")
+
+
+def build_sanitized(verbose: bool = True) -> dict:
+    """CPU-ONLY sanitizer builds (never the GPU code, never shipped; verdict round 4 item 7):
+      * oracle/_san/libceno_oracle_asan.so     the C restatement under AddressSanitizer + UndefinedBehaviorSanitizer (gcc)
+      * ceno_amd/_san/libceno_prover_asan.so   the C++ host layer (host/*.cpp: transcript, virtual polynomials, host arithmetic, the exchange,
+                                               the proof drivers) under ASan + UBSan (g++), linked against the ordinary libceno_hip.so
+      * ceno_amd/_san/exchange_stress_tsan / _asan   tools/sanitize/exchange_stress.cpp + host/dist.cpp + transcript.cpp under
+                                               ThreadSanitizer / ASan: the shared-memory exchange between `world` threads-as-ranks and the
+                                               pool's spin lock
+    tests/test_sanitizers.py (CENO_RUN_SANITIZERS=1) runs the CPU test-suite subset against the first two (LD_PRELOAD of the ASan runtime,
+    CENO_PROVER_LIB / CENO_ORACLE_LIB) and the drivers; profiles/r05_sanitizers.log is such a run."""
+    build_all()
+    os.makedirs(SAN, exist_ok=True)
+    osan = os.path.join(ROOT, "oracle", "_san")
+    os.makedirs(osan, exist_ok=True)
+    gcc, gxx = shutil.which("gcc") or "gcc", shutil.which("g++") or "g++"
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+    out = {}
+    osrcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "tower.c", "commit.c", "rotation.c", "basefold.c", "witgen.c", "transcript.c")]
+    out["oracle_asan"] = os.path.join(osan, "libceno_oracle_asan.so")
+    _run([gcc] + san + ["-march=x86-64-v3", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", out["oracle_asan"]] + osrcs)
+    hsrcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
+    link = ["-L", HERE, "-lceno_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-ldl"]
+    inc = ["-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"]
+    out["prover_asan"] = os.path.join(SAN, "libceno_prover_asan.so")
+    _run([gxx] + san + inc + ["-shared", "-o", out["prover_asan"]] + hsrcs + link)
+    drv = [os.path.join(ROOT, "tools", "sanitize", "exchange_stress.cpp"), os.path.join(HOST, "dist.cpp"), os.path.join(HOST, "transcript.cpp")]
+    stub = os.path.join(SAN, "stub.cpp")  # dist.cpp's references into the other host units (not on the exchange path)
+    with open(stub, "w") as f:
+        f.write('#include <string>\nstatic thread_local std::string e; int prover_set_error(int c, const char* m) { e = m ? m : ""; return c; }\n'
+                'extern "C" const char* ceno_prover_last_error(void) { return e.c_str(); }\n')
+    out["exchange_tsan"] = os.path.join(SAN, "exchange_stress_tsan")
+    out["exchange_asan"] = os.path.join(SAN, "exchange_stress_asan")
+    for key, flags in (("exchange_tsan", ["-fsanitize=thread", "-g", "-O1"]), ("exchange_asan", san)):
+        try:
+            _run([gxx] + flags + inc + ["-o", out[key]] + drv + [stub] + link + ["-lrt"])
+        except RuntimeError as e:
+            if "undefined reference" not in str(e):
+                raise
+            # dist.cpp calls into more host units than the stub covers: link the whole host layer (same flags)
+            _run([gxx] + flags + inc + ["-o", out[key], drv[0]] + hsrcs + link + ["-lrt"])
+    out["asan_runtime"] = subprocess.run([gcc, "-print-file-name=libasan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    out["ubsan_runtime"] = subprocess.run([gcc, "-print-file-name=libubsan.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if verbose:
+        for k, v in out.items():
+            print("sanitize:", k, v)
+    return out
+
+
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        build_sanitized()
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose=True)
     print("built", LIB_HIP, LIB_PROVER if os.path.exists(LIB_PROVER) else "")

@@ -120,7 +120,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(os.environ.get("CENO_ORACLE_LIB") or _LIB_PATH)  # (override: the sanitizer build of the checker)
         _lib.orc_gl_mul.restype = C.c_uint64
         _lib.orc_gl_mul.argtypes = [C.c_uint64, C.c_uint64]
         _lib.orc_gl_mul_div.restype = C.c_uint64

@@ -221,7 +221,48 @@ def main_shm_gpu_batched(out_dir, n_total):
     dist.destroy_process_group()
 
 
+def chip_case(log2_n, w=9, shape=(4, 4, 0, 8)):
+    """the row-sharded chip proof's test case: columns, record plan, challenges (deterministic; shared by the workers and the test)"""
+    num_reads, num_writes, num_lk_tables, num_lk = shape
+    n_rec = num_reads + num_writes + num_lk_tables + (num_lk_tables if num_lk_tables else num_lk)
+    alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+    cols = [po.rand_base(1 << log2_n, 700 + j) for j in range(w)]
+    b2 = po.e2_mul(beta, beta)
+    terms, coeffs, out_terms = [], [], []
+    for k in range(n_rec):
+        base = len(terms)
+        terms += [[(2 * k) % w], [(2 * k + 1) % w], [(3 * k + 5) % w, (k + 7) % w]]
+        coeffs += [beta, b2, alpha]
+        out_terms.append([base, base + 1, base + 2])
+    return cols, po.ext(coeffs), terms, out_terms, [alpha, beta], shape
+
+
+def main_shm_gpu_chip(out_dir, log2_n):
+    """ceno_dist_create_chip_proof with the shared-memory exchange: `world` PROCESSES sharing GPU 0, every rank its rows of every column"""
+    from ceno_amd import Device
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    q = int(os.environ.get("CENO_TEST_ROW_BLOCK_LOG", "3"))
+    dist = FileRendezvous(out_dir, rank, world)
+    dev = Device(0)
+    cols, coeffs, terms, out_terms, challenges, shape = chip_case(log2_n)
+    local = [dev.upload(prover.shard_rows(c, world, rank, q)) for c in cols]
+    comm = prover.ShmComm(world, rank, dist)
+    stream = dev.stream_create()
+    task = dict(mles=local, n_witin=len(cols), n_fixed=0, n_structural=0, num_instances=(1 << log2_n) - 5, log2_num_instances=log2_n - (world.bit_length() - 1),
+                num_reads=shape[0], num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms,
+                record_out_terms=out_terms)
+    pr = prover.dist_create_chip_proof(dev, comm.h, task, log2_n, q, challenges, prover.Transcript.stub(21), stream)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=pr.tower_msgs, point=pr.tower_point, prod=pr.tower_prod_evals, logup=pr.tower_logup_evals,
+             r_out=pr.r_out_evals, w_out=pr.w_out_evals, lk_out=pr.lk_out_evals, rt_main=pr.rt_main)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_chip":
+        return main_shm_gpu_chip(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":
         return main_shm_gpu(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_batched":

@@ -64,6 +64,39 @@ def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
         assert np.array_equal(res[r]["fin"], ofin)
 
 
+@pytest.mark.parametrize("world,log2_n", [(2, 10), (4, 11)])
+def test_row_sharded_chip_proof_as_processes_on_one_gpu(world, log2_n):
+    """ceno_dist_create_chip_proof (record inference, tower witness, tower proof over row-sharded columns) as `world` PROCESSES sharing GPU 0 with
+    the shared-memory exchange: every rank's proof must equal the single-device proof of the whole columns, computed here"""
+    from ceno_amd import Device, prover
+    from tests.dist_worker import chip_case
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29980 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG="3")
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(log2_n), "shm_gpu_chip"], env=e))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        res = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(world)]
+    dev = Device(0)
+    cols, coeffs, terms, out_terms, challenges, shape = chip_case(log2_n)
+    full = [dev.upload(c) for c in cols]
+    task = dict(mles=full, n_witin=len(cols), n_fixed=0, n_structural=0, num_instances=(1 << log2_n) - 5, log2_num_instances=log2_n, num_reads=shape[0],
+                num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+    want = prover.create_chip_proof(dev, task, challenges, prover.Transcript.stub(21))
+    for r in range(world):
+        got = res[r]
+        assert np.array_equal(got["msgs"], want.tower_msgs) and np.array_equal(got["point"], want.tower_point)
+        assert np.array_equal(got["prod"], want.tower_prod_evals) and np.array_equal(got["logup"], want.tower_logup_evals)
+        assert np.array_equal(got["r_out"], want.r_out_evals) and np.array_equal(got["w_out"], want.w_out_evals)
+        assert np.array_equal(got["lk_out"], want.lk_out_evals) and np.array_equal(got["rt_main"], want.rt_main)
+    for m in full:
+        m.free()
+    dev.close()
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_py_multi_rank_launch_end_to_end(world):
     """`bench.py --gpus N` exactly as the driver launches it (python -m torch.distributed.run, one rank per GPU), on a 1-GPU box:
