@@ -584,6 +584,72 @@ def main():
         return {"status": "ok", "ms": ms, "workload": f"ceno_dist_commit_traces_mmcs: traces of 2^{log_rows[0]} x {cols_per_rank[0] * world} and 2^{log_rows[1]} x "
                 f"{cols_per_rank[1] * world} base elements column-sharded over {world} ranks, blow-up 2, ONE root", **info}
 
+    def dist_chip_proof_extra() -> dict:
+        """N > 1: the GKR half of config #3's chip across the ranks (ceno_dist_create_chip_proof): an ADD-shaped chip of 2^20
+        rows x 22 base columns, rows dealt to the ranks in blocks of 2^10 (block-cyclic), record inference + three towers + tower proof, the
+        per-round partial sums exchanged through the shared segment.  Validated against the single-device proof rank 0 computes from the whole
+        columns, then timed (max over ranks)."""
+        from ceno_amd import synthetic
+
+        if "shm" not in comms:
+            return {"status": "skipped: no shared-memory communicator on this launch"}
+        log_rows, w, q = int(os.environ.get("CENO_BENCH_DIST_CHIP_LOG_ROWS", "20")), 22, 10
+        if log_rows < q + log_w + 1:
+            return {"status": f"skipped: 2^{log_rows} rows are too few for {world} ranks at blocks of 2^{q}"}
+        alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+        coeffs, terms, out_terms = synthetic.record_plan(w, 16, alpha, beta)
+        idx = np.arange(1 << log_rows)
+        mine = ((idx >> q) & (world - 1)) == rank
+        local, full = [], []
+        for j in range(w):
+            c = dev.synthetic(log_rows, False, 0xADD0 + j)
+            local.append(dev.upload(np.ascontiguousarray(c.download()[mine])))
+            if rank == 0:
+                full.append(c)
+            else:
+                c.free()
+        task = dict(mles=local, n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << log_rows) - 3, log2_num_instances=log_rows - log_w, num_reads=4,
+                    num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+        cst = dev.stream_create()
+
+        def run_once():
+            return prover.dist_create_chip_proof(dev, comms["shm"].h, task, log_rows, q, [alpha, beta], factories[args.transcript](), cst)
+
+        got = run_once()
+        ok, single_ms = 1, None
+        if rank == 0:
+            ftask = dict(task, mles=full, log2_num_instances=log_rows)
+            want = prover.create_chip_proof(dev, ftask, [alpha, beta], factories[args.transcript](), cst)
+            ok = 1 if (np.array_equal(want.tower_msgs, got.tower_msgs) and np.array_equal(want.tower_point, got.tower_point) and
+                       np.array_equal(want.tower_prod_evals, got.tower_prod_evals) and np.array_equal(want.tower_logup_evals, got.tower_logup_evals)) else 0
+            best = 1e9
+            for _ in range(3):
+                dev.sync()
+                t_ = time.perf_counter()
+                prover.create_chip_proof(dev, ftask, [alpha, beta], factories[args.transcript](), cst)
+                dev.sync()
+                best = min(best, (time.perf_counter() - t_) * 1e3)
+            single_ms = best
+            for m_ in full:
+                m_.free()
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            return {"status": "failed validation: the sharded proof differs from the single-device proof"}
+        best = 1e9
+        for _ in range(3):
+            barrier()
+            t_ = time.perf_counter()
+            run_once()
+            dev.sync()
+            best = min(best, max_over_ranks(time.perf_counter() - t_) * 1e3)
+        for m_ in local:
+            m_.free()
+        dev.stream_destroy(cst)
+        return {"status": "ok", "ms": best, "single_device_ms_on_rank0": single_ms, "proof_equals_single_device": True,
+                "workload": f"ceno_dist_create_chip_proof: ADD-shaped chip, 2^{log_rows} rows x {w} base columns, 4 + 4 + 8 records, rows dealt to {world} ranks in "
+                            f"blocks of 2^{q}; record inference, tower witness, tower proof; shared-memory exchange"}
+
     def line(m: dict, scaling: str) -> dict:
         n_local, n_total = m["n_local"], m["n_total"]
         dt, kernel_ms, launches = m["dt"], m["kernel_ms"], m["launches"]
@@ -754,6 +820,10 @@ def main():
                 sys.stdout.flush()
             os._exit(4)
         res.setdefault("extra", {})["dist_commit"] = box["r"]
+        try:
+            res["extra"]["dist_chip_proof"] = dist_chip_proof_extra()
+        except Exception as e:  # noqa: BLE001  (an extra must not take the headline down; every rank runs the same code, so all fail alike)
+            res["extra"]["dist_chip_proof"] = {"status": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

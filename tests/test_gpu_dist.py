@@ -106,7 +106,7 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     as unavailable here and validated on the multi-GPU node.)"""
     import json
 
-    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, CENO_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", CENO_BENCH_DIST_CHIP_LOG_ROWS="15")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
@@ -129,6 +129,9 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     # extra says why it did not run instead of hanging or failing the line
     assert r.get("rccl_ranks", world) == world and "rccl" not in r["exchanges_validated"]
     assert r["extra"]["dist_commit"]["status"].startswith("skipped")
+    # the GKR half of a chip across the ranks (row-sharded record inference, towers, tower proof), validated against the single-device proof
+    dcp = r["extra"]["dist_chip_proof"]
+    assert dcp["status"] == "ok" and dcp["proof_equals_single_device"] and dcp["ms"] > 0, dcp
     assert "shared-memory exchange" in r["config"]["collective"] and "checked against the torch.distributed path" in r["config"]["collective"]
     assert r["value"] > 0 and abs(r["value"] - 9 * ((1 << r["config"]["global_num_vars"]) - 1) / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
 
