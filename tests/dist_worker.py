@@ -260,7 +260,207 @@ def main_shm_gpu_chip(out_dir, log2_n):
     dist.destroy_process_group()
 
 
+# ---- the row-sharded tower proof a SECOND time, in Python over the oracle's primitives and torch.distributed (gloo): an independent
+# statement of the algorithm of ceno_amd/host/dist_gkr.cpp (block-cyclic rows, local towers = shards of the large layers, replicated tops,
+# local rounds with exchanged partial sums, interleaved gather, replicated tail).  Test infrastructure: everything arithmetic is the oracle's. ----
+def _usize(tr, v):
+    tr.append_label(int(v).to_bytes(8, "little"))
+
+
+def _pows(tr, n):
+    tr.append_label(b"combine subset evals")
+    a = tr.sample_ext()
+    out, acc = [], (1, 0)
+    for _ in range(n):
+        out.append(acc)
+        acc = po.e2_mul(acc, a)
+    return out
+
+
+def _plan(n_prod_active, n_logup_active, a_prod, a_num, a_den):
+    """tables [eq, (a, b) per product tower, (p1, p2, q1, q2) per LogUp tower] -> monomial plan of the layer sumcheck"""
+    coeffs, terms, t = [], [], 1
+    for i in range(n_prod_active):
+        coeffs.append(a_prod[i]); terms.append([0, t, t + 1]); t += 2
+    for i in range(n_logup_active):
+        coeffs += [a_num[i], a_num[i], a_den[i]]
+        terms += [[0, t, t + 3], [0, t + 1, t + 2], [0, t + 2, t + 3]]
+        t += 4
+    return po.ext(coeffs), terms
+
+
+def _first_msg(tabs, coeffs, terms):
+    nv = int(tabs[0].shape[0]).bit_length() - 1
+    msgs, _, _ = po.sumcheck_prove(tabs, coeffs, terms, nv, 3, po.StubTranscript(1))
+    return msgs[0]
+
+
+def _rounds(tabs, coeffs, terms, n_rounds, tr, msgs_out, chal_out, combine=None):
+    """n_rounds rounds on `tabs` (folded in place); combine: sums a partial message over the ranks"""
+    for _ in range(n_rounds):
+        m = _first_msg(tabs, coeffs, terms)
+        if combine is not None:
+            m = combine(m)
+        for e in range(3):
+            tr.append_ext((int(m[e][0]), int(m[e][1])))
+        tr.append_label(b"Internal round")
+        ch = tr.sample_ext()
+        msgs_out.append(m)
+        chal_out.append(ch)
+        for j in range(len(tabs)):
+            tabs[j] = po.mle_fix_variable(tabs[j], ch)
+
+
+def _interleave(parts, lo_bits, k):
+    """per-rank tables -> the global table: index (hi, rank, lo)"""
+    world, n_loc = len(parts), parts[0].shape[0]
+    out = np.zeros((n_loc * world, 2), dtype=np.uint64)
+    j = np.arange(n_loc)
+    lo, hi = j & ((1 << lo_bits) - 1), j >> lo_bits
+    for g in range(world):
+        out[(hi << (k + lo_bits)) | (g << lo_bits) | lo] = parts[g]
+    return out
+
+
+def main_chip_gloo(out_dir, log2_n):
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    k, q = world.bit_length() - 1, int(os.environ.get("CENO_TEST_ROW_BLOCK_LOG", "2"))
+    cols, coeffs, terms, out_terms, (alpha, beta), shape = chip_case(log2_n, w=6, shape=(2, 3, 0, 4))
+    n_loc, rows_loc = log2_n - k, 1 << (log2_n - k)
+    local = [prover.shard_rows(c, world, rank, q) for c in cols]
+    recs = [po.wit_infer(local, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], n_loc) for ts in out_terms]
+    nr, nw = shape[0], shape[1]
+    groups = [recs[:nr], recs[nr: nr + nw], recs[nr + nw:]]
+
+    def gather(x):
+        got = [None] * world
+        dist.all_gather_object(got, x)
+        return got
+
+    towers = []  # dict(layers (local), limbs, s, nv)
+    for gi, grp in enumerate(groups):
+        c = (max(1, len(grp)) - 1).bit_length()
+        if gi < 2:
+            limbs = po.interleaving_mles_to_mles(grp, rows_loc, 2, (1, 0))
+            layers = po.infer_tower_product_witness(int(limbs[0].shape[0]).bit_length(), limbs)
+            towers.append(dict(layers=layers, limbs=2, s=q + c, nv=len(layers) + k))
+        else:
+            ql = po.interleaving_mles_to_mles(grp, rows_loc, 2, alpha)
+            layers = po.infer_tower_logup_witness(None, ql)
+            towers.append(dict(layers=layers, limbs=4, s=q + c, nv=len(layers) + k))
+    n_prod, n_logup = 2, 1
+    s_min, s_max = min(t["s"] for t in towers), max(t["s"] for t in towers)
+    r_rep = s_max + k
+    for t in towers:  # the replicated top: global layer G, gathered and interleaved, and everything above it
+        G = min(r_rep, t["nv"] - 1)
+        glob = [_interleave(gather(np.ascontiguousarray(t["layers"][G - k][b])), t["s"], k) for b in range(t["limbs"])]
+        t["top"] = po.infer_tower_product_witness(G + 1, glob) if t["limbs"] == 2 else po.infer_tower_logup_witness(glob[:2], glob[2:])
+    tr = po.StubTranscript(21)
+    for t in towers:
+        for b in range(t["limbs"]):
+            tr.append_ext((int(t["top"][0][b][0][0]), int(t["top"][0][b][0][1])))
+    max_nv = max(t["nv"] for t in towers)
+    n_alpha = n_prod + 2 * n_logup
+    alphas = _pows(tr, n_alpha)
+    tr.append_label(b"product_sum")
+    out_rt = [tr.sample_ext()]
+    all_msgs, prod_evals, logup_evals = [], np.zeros((n_prod, max_nv - 1, 2, 2), dtype=np.uint64), np.zeros((n_logup, max_nv - 1, 4, 2), dtype=np.uint64)
+    for rnd in range(1, max_nv):
+        active = [i for i, t in enumerate(towers) if t["nv"] > rnd]
+        a_prod = [alphas[i] for i in active if i < n_prod]
+        a_num = [alphas[n_prod + 2 * (i - n_prod)] for i in active if i >= n_prod]
+        a_den = [alphas[n_prod + 2 * (i - n_prod) + 1] for i in active if i >= n_prod]
+        cf, tm = _plan(len(a_prod), len(a_num), a_prod, a_num, a_den)
+        msgs, chal = [], []
+        _usize(tr, rnd)
+        _usize(tr, 3)
+        if rnd <= r_rep:
+            tabs = [po.build_eq(po.ext(out_rt[:rnd]))]
+            for i in active:
+                tabs += [np.ascontiguousarray(towers[i]["top"][rnd][b]) for b in range(towers[i]["limbs"])]
+            _rounds(tabs, cf, tm, rnd, tr, msgs, chal)
+        else:
+            # one local sumcheck per group of towers with the same shard position
+            by_s = {}
+            for i in active:
+                by_s.setdefault(towers[i]["s"], []).append(i)
+            engines = []
+            for s_t, members in sorted(by_s.items()):
+                rt_loc = [out_rt[j] for j in range(rnd) if j < s_t or j >= s_t + k]
+                eq_g = (1, 0)
+                for j in range(k):
+                    c_ = out_rt[s_t + j]
+                    eq_g = po.e2_mul(eq_g, c_ if (rank >> j) & 1 else po.e2_sub((1, 0), c_))
+                tabs = [po.build_eq(po.ext(rt_loc))]
+                ap, an, ad = [], [], []
+                for i in members:
+                    tabs += [np.ascontiguousarray(towers[i]["layers"][rnd - k][b]) for b in range(towers[i]["limbs"])]
+                    if i < n_prod:
+                        ap.append(po.e2_mul(alphas[i], eq_g))
+                    else:
+                        an.append(po.e2_mul(alphas[n_prod + 2 * (i - n_prod)], eq_g))
+                        ad.append(po.e2_mul(alphas[n_prod + 2 * (i - n_prod) + 1], eq_g))
+                c2, t2 = _plan(len(ap), len(an), ap, an, ad)
+                engines.append(dict(s=s_t, members=members, tabs=tabs, coeffs=c2, terms=t2, eq_g=eq_g))
+            for _ in range(s_min):
+                part = np.zeros((3, 2), dtype=np.uint64)
+                for E in engines:
+                    m = _first_msg(E["tabs"], E["coeffs"], E["terms"])
+                    for e in range(3):
+                        part[e] = po.ext([po.e2_add((int(part[e][0]), int(part[e][1])), (int(m[e][0]), int(m[e][1])))])[0]
+                tot = np.zeros((3, 2), dtype=np.uint64)
+                for p_ in gather(part):
+                    for e in range(3):
+                        tot[e] = po.ext([po.e2_add((int(tot[e][0]), int(tot[e][1])), (int(p_[e][0]), int(p_[e][1])))])[0]
+                for e in range(3):
+                    tr.append_ext((int(tot[e][0]), int(tot[e][1])))
+                tr.append_label(b"Internal round")
+                ch = tr.sample_ext()
+                msgs.append(tot)
+                chal.append(ch)
+                for E in engines:
+                    E["tabs"] = [po.mle_fix_variable(t_, ch) for t_ in E["tabs"]]
+            # gather the folded tables, interleave, finish replicated
+            where = {}
+            for E in engines:
+                cur = 1
+                for i in E["members"]:
+                    where[i] = (E, cur)
+                    cur += towers[i]["limbs"]
+            E0 = engines[0]
+            eq_scaled = np.array([po.e2_mul((int(v[0]), int(v[1])), E0["eq_g"]) for v in E0["tabs"][0]], dtype=np.uint64).reshape(-1, 2)
+            tabs = [_interleave(gather(eq_scaled), E0["s"] - s_min, k)]
+            for i in active:
+                E, cur = where[i]
+                tabs += [_interleave(gather(np.ascontiguousarray(E["tabs"][cur + b])), E["s"] - s_min, k) for b in range(towers[i]["limbs"])]
+            _rounds(tabs, cf, tm, rnd - s_min, tr, msgs, chal)
+        all_msgs += [np.asarray(m, dtype=np.uint64) for m in msgs]
+        fin = [(int(t_[0][0]), int(t_[0][1])) for t_ in tabs]
+        cur = 1
+        for i in active:
+            for b in range(towers[i]["limbs"]):
+                tr.append_ext(fin[cur + b])
+                if i < n_prod:
+                    prod_evals[i, rnd - 1, b] = fin[cur + b]
+                else:
+                    logup_evals[i - n_prod, rnd - 1, b] = fin[cur + b]
+            cur += towers[i]["limbs"]
+        tr.append_label(b"merge")
+        r_merge = tr.sample_ext()
+        out_rt = list(chal) + [r_merge]
+        alphas = _pows(tr, n_alpha)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=np.concatenate([m.reshape(-1) for m in all_msgs]), point=po.ext(out_rt[:max_nv]),
+             prod=prod_evals, logup=logup_evals)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "chip_gloo":
+        return main_chip_gloo(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_chip":
         return main_shm_gpu_chip(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":

@@ -93,3 +93,41 @@ def test_shared_memory_exchange_between_processes(world):
         for r in range(world):
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "0"
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("ceno_dist_")]
+
+
+@pytest.mark.parametrize("world,log2_n", [(2, 7), (4, 8)])
+def test_row_sharded_tower_proof_matches_unsharded(world, log2_n):
+    """the GKR half of a chip over ROW-SHARDED columns (a5-a10) a second time, independent of ceno_amd/host/dist_gkr.cpp: gloo
+    ranks holding block-cyclic row shards run record inference and tower building locally (the oracle's primitives), gather the tower tops,
+    prove the large layers with exchanged partial sums and an interleaved gather — and must end, on every rank, with the tower proof the
+    oracle's prover produces from the whole columns (CpuTowerProver::create_proof, ceno_zkvm/src/scheme/cpu/mod.rs:346-554)"""
+    from tests.dist_worker import chip_case
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29870 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG="2", OMP_NUM_THREADS="2")
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(log2_n), "chip_gloo"], env=e))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
+    cols, coeffs, terms, out_terms, (alpha, beta), shape = chip_case(log2_n, w=6, shape=(2, 3, 0, 4))
+    rows = 1 << log2_n
+    recs = [po.wit_infer(cols, coeffs[ts[0]: ts[-1] + 1], [terms[t] for t in ts], log2_n) for ts in out_terms]
+    prod_specs, out_evals = [], []
+    for group in (recs[:2], recs[2:5]):
+        limbs = po.interleaving_mles_to_mles(group, rows, 2, (1, 0))
+        layers = po.infer_tower_product_witness(int(limbs[0].shape[0]).bit_length(), limbs)
+        prod_specs.append(layers)
+        out_evals += [layers[0][0][0], layers[0][1][0]]
+    layers = po.infer_tower_logup_witness(None, po.interleaving_mles_to_mles(recs[5:], rows, 2, alpha))
+    out_evals += [layers[0][k][0] for k in range(4)]
+    tr = po.StubTranscript(21)
+    for e in out_evals:
+        tr.append_ext((int(e[0]), int(e[1])))
+    oproof = po.tower_prove(prod_specs, [layers], tr)
+    for r in range(world):
+        assert np.array_equal(res[r]["msgs"], oproof.msgs)
+        assert np.array_equal(res[r]["point"], oproof.point[: res[r]["point"].shape[0]])
+        assert np.array_equal(res[r]["prod"], oproof.prod_evals) and np.array_equal(res[r]["logup"], oproof.logup_evals)
