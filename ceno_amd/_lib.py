@@ -99,6 +99,7 @@ def lib():
         "ceno_hip_sumcheck_eq_components": (i, [vp]),
         "ceno_hip_stat_eq_launches": (C.c_uint64, [vp]),
         "ceno_hip_plan_report": (C.c_char_p, [vp]),
+        "ceno_hip_ext_sum_blocks": (i, [vp, vp, i, C.c_size_t, vp, vp]),
         "ceno_hip_sumcheck_round": (i, [vp, vp, u64p, u64p]),
         "ceno_hip_sumcheck_round_dev": (i, [vp, vp, u64p, vp]),
         "ceno_hip_sumcheck_finish": (i, [vp, vp, u64p, u64p]),

@@ -291,6 +291,24 @@ int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t l
     return 0;
 }
 
+// out[i] = sum_b in[b * len + i] (mod p), extension elements: the modular all-reduce of per-rank partial batchings (no collective library
+// has a mod-p reduction; the blocks arrive by an all-gather)
+__global__ void __launch_bounds__(NT) k_ext_sum_blocks(const E2* __restrict__ in, int n_blocks, size_t len, E2* __restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < len; i += stride) {
+        E2 acc = in[i];
+        for (int b = 1; b < n_blocks; b++) acc = acc + in[(size_t)b * len + i];
+        out[i] = acc;
+    }
+}
+int ceno_hip_ext_sum_blocks(ceno_hip_ctx* ctx, const uint64_t* dev_in_ext, int n_blocks, size_t len, uint64_t* dev_out_ext, ceno_hip_stream s) {
+    CHECK_ARG(ctx, dev_in_ext && dev_out_ext && n_blocks >= 1 && len >= 1, "bad ext_sum_blocks arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    hipLaunchKernelGGL(k_ext_sum_blocks, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, (const E2*)dev_in_ext, n_blocks, len, (E2*)dev_out_ext);
+    if (hipGetLastError() != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "ext_sum_blocks: launch failed");
+    return 0;
+}
+
 int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,
                                   const uint64_t* dev_addend_ext, uint64_t* dev_out_ext, ceno_hip_stream s, ceno_hip_merkle** out_tree) {
     CHECK_ARG(ctx, dev_codeword_ext && challenge2 && dev_out_ext && out_tree && log_h >= 1 && log_h <= 32, "bad fold_commit arguments");

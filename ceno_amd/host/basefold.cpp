@@ -31,6 +31,9 @@
 using gl::E2;
 
 int prover_set_error(int code, const char* msg);  // prover.cpp
+#include "open_hook.hpp"
+int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points, const uint64_t* const* evals,
+                         int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof, const BasefoldOpenHook* hook);
 
 namespace {
 
@@ -140,7 +143,26 @@ size_t ceno_prover_basefold_proof_words(ceno_pcs_data* const* commits, int n_com
 int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points,
                               const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s,
                               uint64_t* out_proof) {
-    if (!ctx || !commits_ok(commits, n_commits) || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 || pow_bits > 40)
+    return basefold_open_hooked(ctx, commits, n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, nullptr);
+}
+size_t ceno_prover_basefold_proof_words_meta(int n_mats, int total_width, int max_log_rows, int log_blowup, int n_queries) {
+    const int n = max_log_rows;
+    size_t w = 1 + (size_t)total_width + 4 * (size_t)(n + log_blowup);
+    for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + log_blowup - r - 1);
+    return 8 * (size_t)n + 2 * (size_t)n_mats + 1 + (size_t)n_queries * w;
+}
+}  // extern "C"
+
+// hook == NULL: the commitments hold their traces, codewords and trees on this device.  hook != NULL (ceno_dist_basefold_open, dist_open.cpp):
+// `commits` carry the SHAPES only (mats, classes, log_blowup; no tables, no tree) and the three places that touch the committed data go
+// through the hook: the batched codeword of a height class, the batched trace polynomial of a matrix, the opening of the commitment at the
+// query indices.  Everything else — the sumcheck, the folds, the round trees, proof of work, the round answers — runs here on whatever the
+// hook produced, so a sharded opening ends with the words of the single-device one.
+int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points,
+                         const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof,
+                         const BasefoldOpenHook* hook) {
+    if (!ctx || !(hook ? (commits && n_commits >= 1) : commits_ok(commits, n_commits)) || !points || !evals || !tr || !out_proof || n_queries < 0 || pow_bits < 0 ||
+        pow_bits > 40)
         return prover_set_error(CENO_HIP_ERR_INVALID, "bad basefold_open arguments");
     if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "basefold_open needs an explicit stream (ceno_hip_stream_create)");
     if (!tr->sample_bits || !tr->append_base)
@@ -239,8 +261,9 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
                     rc = alloc_ext(h, &B[h]);
                     fresh = 1;
                 }
-                if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(K.codeword), (size_t)1 << h, (int)K.width, cc.data(),
-                                                     ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
+                if (!rc && hook) rc = hook->batch_codeword(hook->self, c, (int)k, cc.data(), ceno_hip_mle_device_ptr(B[h]), h, fresh ? 0 : 1, s);
+                else if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(K.codeword), (size_t)1 << h, (int)K.width, cc.data(),
+                                                          ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
                 if (rc) return fail(rc);
             }
             m0 += d->mats.size();
@@ -249,8 +272,14 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
             auto& M = flat[m].d->mats[flat[m].m];
             const size_t ci = flat[m].coeff0;
             int rc = alloc_ext(M.log_rows, &F[m]);
-            if (!rc) rc = ceno_hip_batch_columns(ctx, flat[m].d->trace_ptr(flat[m].m), M.rows, (int)M.width, coeff.data() + 2 * ci,
-                                                 ceno_hip_mle_device_ptr(F[m]), 0, s);
+            if (!rc && hook) {
+                int ci_commit = 0;
+                for (int c2 = 0; c2 < n_commits; c2++)
+                    if (commits[c2] == flat[m].d) ci_commit = c2;
+                rc = hook->batch_trace(hook->self, ci_commit, flat[m].m, coeff.data() + 2 * ci, ceno_hip_mle_device_ptr(F[m]), s);
+            } else if (!rc)
+                rc = ceno_hip_batch_columns(ctx, flat[m].d->trace_ptr(flat[m].m), M.rows, (int)M.width, coeff.data() + 2 * ci,
+                                            ceno_hip_mle_device_ptr(F[m]), 0, s);
             if (!rc) {
                 rc = ceno_hip_eq_build(ctx, points[m], M.log_rows, nullptr, s, &Eq[m]);
                 if (!rc) owned.push_back(Eq[m]);
@@ -422,7 +451,10 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
         cleanup();
         return 0;
     }
-    const size_t qw = query_words(commits, n_commits, n), Q = (size_t)n_queries;
+    size_t qw = 1;
+    for (int c = 0; c < n_commits; c++) qw += hook ? hook->opening_words(hook->self, c) : ceno_hip_mmcs_opening_words(commits[c]->tree);
+    for (int r = 0; r < n; r++) qw += 2 + 4 * (size_t)(n + rate_log - r - 1);
+    const size_t Q = (size_t)n_queries;
     std::vector<uint64_t> qidx(Q);
     for (size_t q = 0; q < Q; q++) qidx[q] = ceno_transcript_sample_bits(tr, H);  // ONE base sample per query (pcs/mod.rs:1252-1266)
     // device scratch: [indices Q][piece-major answers]; host buffer mirrors the answers
@@ -449,8 +481,9 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
     for (int c = 0; c < n_commits && !rc; c++) {  // one MMCS opening per commitment at reduced_index = query >> bits_reduced
         ceno_pcs_data* d = commits[c];
         const int hc = d->max_log_rows() + rate_log;
-        const size_t per_q = ceno_hip_mmcs_opening_words(d->tree);
-        rc = ceno_hip_mmcs_open_batch(ctx, d->tree, d_idx, Q, H - hc, d_ans + off, per_q, s);
+        const size_t per_q = hook ? hook->opening_words(hook->self, c) : ceno_hip_mmcs_opening_words(d->tree);
+        if (hook) rc = hook->mmcs_open(hook->self, c, qidx.data(), d_idx, Q, H - hc, d_ans + off, per_q, s);
+        else rc = ceno_hip_mmcs_open_batch(ctx, d->tree, d_idx, Q, H - hc, d_ans + off, per_q, s);
         pieces.push_back({off, per_q});
         off += Q * per_q;
     }
@@ -482,5 +515,3 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
     cleanup();
     return 0;
 }
-
-}  // extern "C"

@@ -1030,6 +1030,19 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
     return 0;
 }
 
+// all-gather of `n_words` words per rank between DEVICE buffers over the communicator's bulk transport (in-process group: device copies; RCCL:
+// grouped send / recv): recv[g * n_words ..] = rank g's block
+int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_words, uint64_t* recv_dev, hipStream_t st) {
+    if (!c || c->world == 1) {
+        if (n_words && hipMemcpyAsync(recv_dev, send_dev, n_words * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "allgather: device copy failed");
+        return 0;
+    }
+    const int W = c->world;
+    std::vector<size_t> soff((size_t)W, 0), scnt((size_t)W, n_words), roff((size_t)W), rcnt((size_t)W, n_words);
+    for (int g = 0; g < W; g++) roff[(size_t)g] = (size_t)g * n_words;
+    return exchange_blocks(c, send_dev, soff.data(), scnt.data(), recv_dev, roff.data(), rcnt.data(), st);
+}
+
 extern "C" {
 
 ceno_dist_local_group* ceno_dist_local_group_create(int world) {

@@ -1,0 +1,205 @@
+// Basefold opening of a commitment whose matrices were committed ACROSS ranks (ceno_dist_commit_traces_mmcs): the proof equals
+// ceno_prover_basefold_open's on the single-device commitment of the same matrices, word for word, on every rank.
+//
+// Reference flow (single device): OpeningProver::open -> PCS::batch_open, ceno_zkvm/src/scheme/cpu/mod.rs:1418-1457; protocol restated in
+// ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781.  The reference has no distribution (docs/src/optimizations.md:3-5).
+//
+// What is sharded and what is not.  Config #3's opening is 3.1 ms of which ~2.7 ms are ~21 DEPENDENT commit rounds (fold, tree, root, transcript)
+// on a running codeword that is 1/width of the committed data: latency, which more GPUs do not shorten.  What scales with the data is the
+// batching — one pass over every codeword and trace column (555 MB for 2^20 x 22) — and the commitment's own rows and paths at the queries.  So:
+//   * batched codeword: every rank batches ITS ROWS of all columns (the row shard the commit left it with), the shards are all-gathered
+//     (bulk transport) into the full batched codeword on every rank;
+//   * batched trace polynomial F = sum_c coeff_c col_c: every rank batches ITS COLUMNS (the column shard it committed), the partial sums are
+//     all-gathered and added mod p (ceno_hip_ext_sum_blocks; no collective library reduces mod p);
+//   * sumcheck, folds, round trees, final message, proof of work, round answers: replicated, the single-device code (basefold.cpp) on the
+//     gathered tables — same transcript on every rank;
+//   * the commitment's opening at a query: the rank that owns the row answers from its rows and its sub-tree (ceno_hip_mmcs_open_batch on
+//     local indices), every rank appends the top log2(world) levels from the replicated top tree; the answers travel by the small-message
+//     transport.
+// v1 limits: ONE commitment whose matrices all have the same height (a chip's trace, config #3); at least `world` codeword rows.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ceno_prover.h"
+#include "open_hook.hpp"
+#include "pcs_data.hpp"
+
+int prover_set_error(int code, const char* msg);  // prover.cpp
+int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n_commits, const uint64_t* const* points, const uint64_t* const* evals,
+                         int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof, const BasefoldOpenHook* hook);
+int dist_comm_world(const ceno_dist_comm* c);  // dist.cpp
+int dist_comm_rank(const ceno_dist_comm* c);
+int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, hipStream_t st);
+int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_words, uint64_t* recv_dev, hipStream_t st);
+
+namespace {
+
+struct DistOpen {
+    ceno_hip_ctx* ctx;
+    ceno_dist_comm* comm;
+    int W, rank, k;
+    int n_mats, log_rows, log_blowup;
+    const int* widths;                         // [m * W + g]
+    const uint64_t* const* local_trace_cols;   // [m]: this rank's columns of matrix m, column-major, 2^log_rows rows
+    const uint64_t* const* local_cw_rows;      // [m]: ALL columns of matrix m x (R / W) rows, column-major (ceno_dist_commit_traces_mmcs out_rows_dev)
+    ceno_hip_merkle* subtree;
+    ceno_hip_merkle* top;
+    std::vector<size_t> width_of;              // per matrix: all ranks' columns
+    size_t total_width = 0;
+};
+
+int fail_ctx(ceno_hip_ctx* ctx, int rc) { return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+
+struct DevBuf {
+    ceno_hip_ctx* ctx;
+    ceno_hip_mle* m = nullptr;
+    ~DevBuf() {
+        if (m) ceno_hip_mle_free(ctx, m);
+    }
+    int alloc_words(size_t words) {  // a base-field table of at least `words` words from the library's pool
+        int nv = 0;
+        while (((size_t)1 << nv) < words) nv++;
+        return ceno_hip_mle_alloc(ctx, nv, 0, &m);
+    }
+    uint64_t* ptr() const { return ceno_hip_mle_device_ptr(m); }
+};
+
+int hook_batch_codeword(void* self, int, int, const uint64_t* coeffs, uint64_t* dev_B, int log_h, int accumulate, ceno_hip_stream s) {
+    DistOpen& D = *static_cast<DistOpen*>(self);
+    if (accumulate) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: one height class only");
+    const size_t R = (size_t)1 << log_h, Rl = R / (size_t)D.W;
+    DevBuf loc{D.ctx};
+    if (int rc = loc.alloc_words(2 * Rl)) return fail_ctx(D.ctx, rc);
+    // this rank's rows of every matrix: the class's columns are the matrices' columns back to back (coeffs in that order)
+    size_t c0 = 0;
+    for (int m = 0; m < D.n_mats; m++) {
+        int rc = ceno_hip_batch_columns(D.ctx, D.local_cw_rows[m], Rl, (int)D.width_of[(size_t)m], coeffs + 2 * c0, loc.ptr(), m > 0 ? 1 : 0, s);
+        if (rc) return fail_ctx(D.ctx, rc);
+        c0 += D.width_of[(size_t)m];
+    }
+    if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, dev_B, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: sync failed");
+    return 0;
+}
+
+int hook_batch_trace(void* self, int, int mat, const uint64_t* coeffs, uint64_t* dev_F, ceno_hip_stream s) {
+    DistOpen& D = *static_cast<DistOpen*>(self);
+    const size_t rows = (size_t)1 << D.log_rows;
+    DevBuf part{D.ctx}, all{D.ctx};
+    if (int rc = part.alloc_words(2 * rows)) return fail_ctx(D.ctx, rc);
+    if (int rc = all.alloc_words(2 * rows * (size_t)D.W)) return fail_ctx(D.ctx, rc);
+    size_t col0 = 0;
+    for (int g = 0; g < D.rank; g++) col0 += (size_t)D.widths[(size_t)mat * D.W + g];
+    const int mine = D.widths[(size_t)mat * D.W + D.rank];
+    if (mine > 0) {
+        int rc = ceno_hip_batch_columns(D.ctx, D.local_trace_cols[mat], rows, mine, coeffs + 2 * col0, part.ptr(), 0, s);
+        if (rc) return fail_ctx(D.ctx, rc);
+    } else if (hipMemsetAsync(part.ptr(), 0, rows * 16, (hipStream_t)s) != hipSuccess) {
+        return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: memset failed");
+    }
+    if (int rc = dist_allgather_device(D.comm, part.ptr(), 2 * rows, all.ptr(), (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+    if (int rc = ceno_hip_ext_sum_blocks(D.ctx, all.ptr(), D.W, rows, dev_F, s)) return fail_ctx(D.ctx, rc);
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: sync failed");
+    return 0;
+}
+
+size_t hook_opening_words(void* self, int) {
+    DistOpen& D = *static_cast<DistOpen*>(self);
+    return D.total_width + 4 * (size_t)(D.log_rows + D.log_blowup);
+}
+
+int hook_mmcs_open(void* self, int, const uint64_t* idx, const uint64_t*, size_t n, int shift, uint64_t* dev_out, size_t per_q, ceno_hip_stream s) {
+    DistOpen& D = *static_cast<DistOpen*>(self);
+    hipStream_t st = (hipStream_t)s;
+    const int H = D.log_rows + D.log_blowup, hl = H - D.k;  // levels of a rank's sub-tree
+    const size_t per_loc = D.total_width + 4 * (size_t)hl, per_top = 4 * (size_t)D.k;
+    if (per_q != per_loc + per_top) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: opening size mismatch");
+    std::vector<uint64_t> loc_idx(n), own(n);
+    for (size_t q = 0; q < n; q++) {
+        const uint64_t row = idx[q] >> shift;
+        own[q] = row >> hl;
+        loc_idx[q] = row & (((uint64_t)1 << hl) - 1);
+    }
+    DevBuf buf{D.ctx};
+    if (int rc = buf.alloc_words(2 * n + n * per_loc + n * per_top)) return fail_ctx(D.ctx, rc);
+    uint64_t *d_loc = buf.ptr(), *d_own = d_loc + n, *d_ans = d_own + n, *d_top = d_ans + n * per_loc;
+    if (hipMemcpyAsync(d_loc, loc_idx.data(), n * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_own, own.data(), n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+        return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: index upload failed");
+    // every rank opens its own sub-tree at the local index of every query (only the owner's answer is used) ...
+    int rc = ceno_hip_mmcs_open_batch(D.ctx, D.subtree, d_loc, n, 0, d_ans, per_loc, s);
+    // ... and the replicated top tree at the owner's leaf
+    if (!rc && D.k > 0) rc = ceno_hip_merkle_open_batch(D.ctx, D.top, d_own, n, 0, d_top, s);
+    if (rc) return fail_ctx(D.ctx, rc);
+    std::vector<uint64_t> mine(n * per_loc), top(n * per_top), all((size_t)D.W * n * per_loc), out(n * per_q);
+    if (hipMemcpyAsync(mine.data(), d_ans, mine.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (per_top && hipMemcpyAsync(top.data(), d_top, top.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess) || hipStreamSynchronize(st) != hipSuccess)
+        return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: answer download failed");
+    if (int rc2 = dist_allgather_words(D.comm, mine.data(), mine.size(), all.data(), st)) return prover_set_error(rc2, ceno_dist_last_error());
+    for (size_t q = 0; q < n; q++) {
+        memcpy(out.data() + q * per_q, all.data() + (size_t)own[q] * n * per_loc + q * per_loc, per_loc * 8);
+        if (per_top) memcpy(out.data() + q * per_q + per_loc, top.data() + q * per_top, per_top * 8);
+    }
+    if (hipMemcpyAsync(dev_out, out.data(), out.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: answer upload failed");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, int log_rows, const int* widths, int log_blowup,
+                            const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                            ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                            ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
+    if (!ctx || !comm || n_mats < 1 || !widths || !local_trace_cols || !local_cw_rows || !subtree || !points || !evals || !tr || !out_proof)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad arguments");
+    DistOpen D;
+    D.ctx = ctx;
+    D.comm = comm;
+    D.W = dist_comm_world(comm);
+    D.rank = dist_comm_rank(comm);
+    D.k = 0;
+    while ((1 << D.k) < D.W) D.k++;
+    if ((1 << D.k) != D.W) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the number of ranks must be a power of two");
+    if (log_rows + log_blowup < D.k) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: fewer codeword rows than ranks");
+    if (D.W > 1 && !top) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the replicated top tree is missing");
+    D.n_mats = n_mats;
+    D.log_rows = log_rows;
+    D.log_blowup = log_blowup;
+    D.widths = widths;
+    D.local_trace_cols = local_trace_cols;
+    D.local_cw_rows = local_cw_rows;
+    D.subtree = subtree;
+    D.top = top;
+    // the SHAPE of the commitment for the single-device code: one height class, no tables, no tree
+    ceno_pcs_data shape;
+    shape.log_blowup = log_blowup;
+    ceno_pcs_data::Class K;
+    K.log_rows = log_rows;
+    for (int m = 0; m < n_mats; m++) {
+        size_t w = 0;
+        for (int g = 0; g < D.W; g++) w += (size_t)widths[(size_t)m * D.W + g];
+        if (w < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: a matrix without columns");
+        ceno_pcs_data::Mat M;
+        M.rows = (size_t)1 << log_rows;
+        M.width = w;
+        M.log_rows = log_rows;
+        M.cls = 0;
+        M.col0 = K.width;
+        K.width += w;
+        shape.mats.push_back(M);
+        D.width_of.push_back(w);
+        D.total_width += w;
+    }
+    shape.classes.push_back(K);
+    BasefoldOpenHook hook{&D, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
+    ceno_pcs_data* commits[1] = {&shape};
+    return basefold_open_hooked(ctx, commits, 1, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
+}
+
+}  // extern "C"

@@ -367,6 +367,9 @@ int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
  * coefficients from the host, ext accumulator of length `len` on the device.  Synchronises the stream. */
 int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t len, int n_cols, const uint64_t* coeffs_ext,
                            uint64_t* dev_acc_ext, int accumulate, ceno_hip_stream s);
+/* out[i] = sum over b < n_blocks of in[b * len + i] (mod p), extension elements: the modular all-reduce of per-rank partial batchings
+ * after an all-gather (the multi-rank opening, ceno_dist_basefold_open).  Asynchronous on `s`. */
+int ceno_hip_ext_sum_blocks(ceno_hip_ctx* ctx, const uint64_t* dev_in_ext, int n_blocks, size_t len, uint64_t* dev_out_ext, ceno_hip_stream s);
 /* One commit-phase round over the running ext codeword of length 2^log_h (bit-reversed order, pairs adjacent):
  * tree over the 2^(log_h-1) pair leaves (returned), and out[j] = fold(cw[2j], cw[2j+1]; challenge) (+ addend[j]). */
 int ceno_hip_basefold_fold_commit(ceno_hip_ctx* ctx, const uint64_t* dev_codeword_ext, int log_h, const uint64_t* challenge2,

@@ -479,6 +479,22 @@ int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_
 int ceno_dist_chip_block_log(void);
 int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_chip_task* task, int log2_num_instances_global, int row_block_log,
                                 const uint64_t* challenges4, ceno_transcript* tr, ceno_hip_stream s, ceno_chip_proof* out);
+/* Basefold opening of a commitment made ACROSS ranks by ceno_dist_commit_traces_mmcs (ceno_amd/host/dist_open.cpp): on every rank the
+ * proof ceno_prover_basefold_open produces for the single-device commitment of the same matrices, word for word (layout and size:
+ * ceno_prover_basefold_proof_words_meta).  The bandwidth-bound part is sharded — the batched codeword from every rank's ROW shard
+ * (local_cw_rows = the commit's out_rows_dev), the batched trace polynomial from every rank's COLUMN shard (local_trace_cols = the commit's
+ * input), the commitment's rows and sub-tree paths at the queries from the rank that owns them — and gathered; the commit phase (~21
+ * dependent rounds on a codeword 1 / width the size of the data: latency) runs replicated.  v1: ONE commitment, all matrices of the same
+ * height 2^log_rows, at least `world` codeword rows; widths[m * world + g] as in the commit; points / evals per matrix as in
+ * ceno_prover_basefold_open (evals: all `sum_g widths` columns, rank-major).  Needs the communicator's bulk transport (in-process group or
+ * RCCL) for the two all-gathers. */
+int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, int log_rows, const int* widths, int log_blowup,
+                            const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                            ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                            ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof);
+/* words of a Basefold opening proof from the shapes alone (n_mats matrices, total_width columns, tallest trace 2^max_log_rows): what
+ * ceno_prover_basefold_proof_words returns for one commitment of such matrices */
+size_t ceno_prover_basefold_proof_words_meta(int n_mats, int total_width, int max_log_rows, int log_blowup, int n_queries);
 const char* ceno_dist_last_error(void);
 
 #ifdef __cplusplus

@@ -155,3 +155,74 @@ def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     for m in local:
         m.free()
     group.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the opening of a commitment made across ranks (ceno_dist_basefold_open, ceno_amd/host/dist_open.cpp)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world,log_rows,col_split,transcript", [
+    (2, 8, [[2, 1], [1, 3]], "stub"),
+    (4, 9, [[2, 1, 0, 3], [1, 1, 2, 1]], "stub"),          # a rank without columns of the first matrix
+    (8, 10, [[1] * 8], "poseidon2"),
+    (4, 7, [[3, 2, 2, 1]], "poseidon2"),
+])
+def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world, log_rows, col_split, transcript):
+    """commit across `world` virtual ranks (column-sharded RS encoding, re-shard by rows, sub-trees + replicated top), then open across them:
+    batched codeword from the row shards, batched polynomial from the column shards (all-gather + modular sum), owner ranks answer the queries
+    of the commitment, the commit phase replicated — every rank must end with the proof the single-device opening of the same matrices gives,
+    word for word, under the stub and under the Poseidon2 duplex transcript (OpeningProver::open, ceno_zkvm/src/scheme/cpu/mod.rs:1418-1457;
+    protocol ceno_recursion_v2/src/pcs/mod.rs:1111-1316)"""
+    import torch
+
+    from ceno_amd import dist as cdist
+
+    blow, n_queries, pow_bits = 1, 12, 4
+    n_mats = len(col_split)
+    fulls = [po.rand_base((1 << log_rows) * sum(ws), 800 + i).reshape(1 << log_rows, sum(ws)) for i, ws in enumerate(col_split)]
+    point = np.array([[(i * 7919 + 13) % P, (i * 104729 + 17) % P] for i in range(log_rows)], dtype=np.uint64)
+    points = [point] * n_mats
+    evals = [np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), point) for c in range(full.shape[1])], dtype=np.uint64) for full in fulls]
+    new_tr = (lambda: prover.Transcript.stub(77)) if transcript == "stub" else (lambda: prover.Transcript.poseidon2(b"open"))
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, fulls, blow, stream)
+    want_root = pcs.root()
+    want = pcs.basefold_open(points, evals, n_queries, pow_bits, new_tr())
+    pcs.free()
+    group = prover.LocalGroup(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            keep, ptrs = [], []
+            for ws, full in zip(col_split, fulls):
+                c0 = sum(ws[:rank])
+                cols = np.ascontiguousarray(full[:, c0:c0 + ws[rank]].T)
+                t = torch.from_numpy(cols.view(np.int64).copy()).to("cuda:0") if cols.size else torch.empty(1, dtype=torch.int64, device="cuda:0")
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+            torch.cuda.synchronize()
+            s_ = dev.stream_create()
+            com = cdist.sharded_commit_mmcs_native(dev, group.comms[rank], ptrs, col_split, [log_rows] * n_mats, blow, rank, s_)
+            dev.sync(s_)
+            proof = prover.dist_basefold_open(dev, group.comms[rank], log_rows, col_split, blow, ptrs, [t.data_ptr() for t in com["codeword_rows"]], com["subtree"],
+                                              com["top"], points, evals, n_queries, pow_bits, new_tr(), s_)
+            res[rank] = (np.asarray(com["root"]), proof)
+            for key in ("subtree", "top"):
+                if com.get(key):
+                    dev.L.ceno_hip_merkle_free(dev.h, com[key])
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for r in range(world):
+        assert np.array_equal(res[r][0].reshape(-1), np.asarray(want_root, dtype=np.uint64).reshape(-1)), f"rank {r}: commitment root"
+        assert res[r][1].shape == want.shape and np.array_equal(res[r][1], want), f"rank {r}: the opening differs from the single-device opening"
