@@ -581,8 +581,57 @@ def main():
         ms = max_over_ranks(time.perf_counter() - t_) / reps * 1e3
         for m_ in mine:
             m_.free()
+        # ... and the OPENING of a commitment made across the ranks (ceno_dist_basefold_open: one matrix of 2^14 rows, 2 columns per rank):
+        # validated word for word against the single-device opening rank 0 computes, then timed
+        try:
+            info["dist_open"] = dist_open_part(cdist2, cst)
+        except Exception as e:  # noqa: BLE001
+            info["dist_open"] = {"status": f"failed: {type(e).__name__}: {e}"}
         return {"status": "ok", "ms": ms, "workload": f"ceno_dist_commit_traces_mmcs: traces of 2^{log_rows[0]} x {cols_per_rank[0] * world} and 2^{log_rows[1]} x "
                 f"{cols_per_rank[1] * world} base elements column-sharded over {world} ranks, blow-up 2, ONE root", **info}
+
+    def dist_open_part(cdist2, cst) -> dict:
+        lr, c, blow, nq, pow_bits = 14, 2, 1, 20, 8
+        mine = dev.synthetic(lr + 1, False, 0x0BE11 + rank)
+        dev.sync()
+        widths = [[c] * world]
+        com = cdist2.sharded_commit_mmcs_native(dev, comms["rccl"].h, [mine.device_ptr], widths, [lr], blow, rank, cst)
+        dev.sync(cst)
+        point = np.array([[i * 7919 + 13, i * 104729 + 17] for i in range(lr)], dtype=np.uint64)
+        evals = [np.zeros((c * world, 2), dtype=np.uint64)]  # (one height class: the claimed evaluations do not enter the proof's words)
+
+        def run_once():
+            return prover.dist_basefold_open(dev, comms["rccl"].h, lr, widths, blow, [mine.device_ptr], [t.data_ptr() for t in com["codeword_rows"]],
+                                             com["subtree"], com["top"], [point], evals, nq, pow_bits, factories[args.transcript](), cst)
+
+        got = run_once()
+        ok = 1
+        if rank == 0:
+            cols = []
+            for g in range(world):
+                t = dev.synthetic(lr + 1, False, 0x0BE11 + g)
+                cols.append(t.download().reshape(c, 1 << lr))
+                t.free()
+            pcs = prover.PcsData(dev, [np.ascontiguousarray(np.concatenate(cols, axis=0).T)], blow, stream)
+            want = pcs.basefold_open([point], evals, nq, pow_bits, factories[args.transcript]())
+            pcs.free()
+            ok = 1 if np.array_equal(want, got) else 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            return {"status": "failed validation: the multi-rank opening differs from the single-device opening"}
+        barrier()
+        t_ = time.perf_counter()
+        for _ in range(3):
+            run_once()
+        barrier()
+        ms = max_over_ranks(time.perf_counter() - t_) / 3 * 1e3
+        for key in ("subtree", "top"):
+            if com.get(key):
+                dev.L.ceno_hip_merkle_free(dev.h, com[key])
+        mine.free()
+        return {"status": "ok", "ms": ms, "proof_equals_single_device": True,
+                "workload": f"ceno_dist_basefold_open: one trace of 2^{lr} x {c * world} base elements committed across {world} ranks, {nq} queries, {pow_bits}-bit proof of work"}
 
     def dist_chip_proof_extra() -> dict:
         """N > 1: the GKR half of config #3's chip across the ranks (ceno_dist_create_chip_proof): an ADD-shaped chip of 2^20
