@@ -1704,7 +1704,10 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                 }
             }
         }
-        if (const int cap = gen_split_cap(ctx, sc->d)) {
+        // (CENO_HIP_GEN_SPLIT_MIN_LOG: smallest class that gets column blocks.  Measured: blocks for every class are best — the wide batch 60.2 ms
+        // against 69.9 with blocks from 2^18 rows up and 96.8 without; the latency-bound batch of the 2^20-cycle shard does not care, 2.03-2.19 ms)
+        static const int split_min_log = getenv("CENO_HIP_GEN_SPLIT_MIN_LOG") ? atoi(getenv("CENO_HIP_GEN_SPLIT_MIN_LOG")) : 0;
+        if (const int cap = cl.nv >= split_min_log ? gen_split_cap(ctx, sc->d) : 0) {
             std::vector<GenCompHost> cut;
             for (auto& C : mine) {
                 if ((int)C.mles.size() <= cap) cut.push_back(std::move(C));
@@ -2050,7 +2053,10 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     // (with one workgroup per slot a 2x error in the weight of the product terms cost the wide batch 106 -> 157 ms,
                     // tools/dev/wide_sweep.sh) — and the tail of the launch is 1 / oversub of a slot's time
                     const double share = wsum > 0 ? weight_eq[k] / wsum : 0.0;
-                    const unsigned budget = std::max(cap * gen_oversub(), (unsigned)list_eq.size());
+                    // ... as long as a workgroup still has ~8 tiles to amortise its epilogue over (a row, an atomic, a share of the last workgroup's
+                    // sum): the medium rounds of a small batch lost 0.13 ms of 1.9 to sixteen workgroups per slot (tools/dev/shard_ab.sh)
+                    const unsigned os = (unsigned)std::min<uint64_t>(gen_oversub(), std::max<uint64_t>(1, total / ((uint64_t)cap * 8)));
+                    const unsigned budget = std::max(cap * os, (unsigned)list_eq.size());
                     cnt = 1u + (unsigned)(share * (double)(budget - (unsigned)list_eq.size()));
                     cnt = std::min(cnt, G.n_tiles);
                 }
