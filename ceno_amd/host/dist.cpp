@@ -235,7 +235,14 @@ void ceno_dist_comm_destroy(ceno_dist_comm* c) {
     delete c;
 }
 
-static size_t shm_size(int world) { return sizeof(ShmSeg) + sizeof(ShmRank) * (size_t)(world > 0 ? world - 1 : 0); }
+// ... followed by a BULK area: per rank two parity-indexed buffers of SHM_BULK_WORDS words, for the KB-sized gathers of the sharded GKR half and
+// opening (tower tops: 64 KB per limb; folded tables; query answers) — the 128-word slots made such a gather hundreds of exchanges
+static constexpr size_t SHM_BULK_WORDS = 16384;  // 128 KB per buffer
+static size_t shm_head_size(int world) { return (sizeof(ShmSeg) + sizeof(ShmRank) * (size_t)(world > 0 ? world - 1 : 0) + 63) & ~(size_t)63; }
+static size_t shm_size(int world) { return shm_head_size(world) + (size_t)world * 2 * SHM_BULK_WORDS * 8; }
+static uint64_t* shm_bulk(ShmSeg* seg, int world, int rank, int parity) {
+    return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(seg) + shm_head_size(world)) + ((size_t)rank * 2 + (size_t)parity) * SHM_BULK_WORDS;
+}
 static const uint64_t SHM_MAGIC = 0x43454e4f53484d31ULL;  // "CENOSHM1"
 
 /* Attach the host shared-memory exchange to a communicator (`c` may come from ceno_dist_comm_init, or be created
@@ -320,6 +327,33 @@ static int shm_gather_ext(ceno_dist_comm* c, const uint64_t* mine, int n_ext) {
     return 0;
 }
 
+// all-gather of up to SHM_BULK_WORDS words per rank through the bulk area: out[g * n_words ..] = rank g's words
+static int shm_gather_bulk(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, size_t out_stride_words) {
+    if (n_words > SHM_BULK_WORDS) {
+        g_dist_err = "shm_gather_bulk: block too large";
+        return CENO_HIP_ERR_INVALID;
+    }
+    const uint64_t seq = ++c->shm_seq;
+    ShmRank& me = c->shm->ranks[c->rank];
+    memcpy(shm_bulk(c->shm, c->world, c->rank, (int)(seq & 1)), mine, n_words * 8);
+    __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    for (int g = 0; g < c->world; g++) {
+        ShmRank& r = c->shm->ranks[g];
+        uint64_t spins = 0;
+        while (__atomic_load_n(&r.seq, __ATOMIC_ACQUIRE) < seq) {
+            if (++spins > ((uint64_t)1 << 34)) {
+                g_dist_err = "shm_gather_bulk: peer never published its block";
+                return CENO_HIP_ERR_STATE;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        memcpy(out + (size_t)g * out_stride_words, shm_bulk(c->shm, c->world, g, (int)(seq & 1)), n_words * 8);
+    }
+    return 0;
+}
+
 /* self-test of the exchange (CPU tests, no GPU involved): `iters` gathers of varying size; every rank checks every
  * payload word.  Returns 0 when all match. */
 int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters) {
@@ -336,6 +370,19 @@ int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters) {
                     g_dist_err = "shm selftest: payload mismatch";
                     return CENO_HIP_ERR_STATE;
                 }
+        if (it % 64 == 0) {  // ... and a bulk gather now and then (same sequence words, the big buffers)
+            const size_t nb = 1 + (size_t)(it * 37) % SHM_BULK_WORDS;
+            std::vector<uint64_t> mine(nb), all(nb * (size_t)c->world);
+            for (size_t k = 0; k < nb; k++) mine[k] = gl::splitmix64_at(2000 + (uint64_t)c->rank, (uint64_t)it * 977 + k);
+            rc = shm_gather_bulk(c, mine.data(), nb, all.data(), nb);
+            if (rc) return rc;
+            for (int g = 0; g < c->world; g++)
+                for (size_t k = 0; k < nb; k += 97)
+                    if (all[(size_t)g * nb + k] != gl::splitmix64_at(2000 + (uint64_t)g, (uint64_t)it * 977 + k)) {
+                        g_dist_err = "shm selftest: bulk payload mismatch";
+                        return CENO_HIP_ERR_STATE;
+                    }
+        }
     }
     return 0;
 }
@@ -999,6 +1046,13 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
         return 0;
     }
     const int W = c->world;
+    if (c->shm && !c->local) {  // the shared segment's bulk area: up to SHM_BULK_WORDS words per exchange
+        for (size_t off = 0; off < n_words; off += SHM_BULK_WORDS) {
+            const size_t nb = std::min<size_t>(SHM_BULK_WORDS, n_words - off);
+            if (int rc = shm_gather_bulk(c, mine + off, nb, out + off, n_words)) return rc;
+        }
+        return 0;
+    }
     uint64_t buf[128];
     for (size_t off = 0; off < n_words; off += 128) {
         const size_t n = std::min<size_t>(128, n_words - off);
@@ -1016,9 +1070,6 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
                 for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, &G->small[(size_t)r * 128], n * 8);
             }
             if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "allgather: a peer of the local group is gone");
-        } else if (c->shm) {
-            if (int rc = shm_gather_ext(c, buf, 64)) return rc;
-            for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, c->h_recv + (size_t)r * 128, n * 8);
         } else if (c->comm) {
             if (hipMemcpyAsync(c->d_send, buf, sizeof buf, hipMemcpyHostToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "allgather: upload failed");
             if (int rc = gather_ext(c, 64, st)) return rc;
