@@ -913,6 +913,7 @@ struct GenCompHost {
     size_t off_terms[3] = {0, 0, 0}, off_groups[3] = {0, 0, 0}, off_unit[3] = {0, 0, 0};  // offsets into the gen blob ([2]: factor bytes = MLE indices, k_eq_base0)
     size_t slot_off = 0;                   // first slot of the component inside a round's slot row
     int geq = -1;                          // >= 0: the component runs in eq-factored form (index into sumcheck::geq.comps)
+    int deg = 0;                           // eq components: 1 + the most column factors of a term, at least 3 (the length of ITS round polynomial)
     double pair_cost[2] = {1.0, 1.0};      // relative cost of a pair in phase 1 / phase 2 (workgroup split of the component-aligned launch)
 };
 struct GenRound {
@@ -921,14 +922,20 @@ struct GenRound {
     unsigned total_tiles = 0;
     size_t stage_bytes = 0;
     bool base0 = false, has_terms = false;
-    // the eq-factored components of the round (k_gen_eq, component-aligned launch): their own list
-    size_t off_comps_eq = 0;
-    int n_comps_eq = 0;
-    unsigned grid_eq = 0;
-    size_t off_wg_comp = 0;  // uint16 per workgroup of the component-aligned launch: its component
-    bool slots = false;      // every component of the eq launch is one tile: one workgroup per component and slot (k_gen_eq_slots)
-    size_t stage_bytes_eq = 0;
-    bool direct0 = false;      // the eq list is laid out for k_eq_base0 (first round, base-field columns, no LDS stage)
+    // the eq-factored components of the round (k_gen_eq, component-aligned launches): ONE launch at the sumcheck's degree, or — in the large
+    // rounds of a batch whose components have polynomials of different lengths (round 5) — one launch per component degree
+    struct EqLaunch {
+        size_t off_comps = 0;
+        int n_comps = 0;
+        unsigned grid = 0;
+        size_t off_wg_comp = 0;  // uint16 per workgroup of the component-aligned launch: its component
+        bool slots = false;      // every component of the launch is one tile: one workgroup per component and slot (k_gen_eq_slots)
+        size_t stage_bytes = 0;
+        int D = 0;               // message length the launch's kernel is instantiated for
+    };
+    std::vector<EqLaunch> eq;
+    bool by_degree = false;    // every eq component delivers the slots of ITS OWN degree this round (geq_collect extends its polynomial)
+    bool direct0 = false;      // the eq lists are laid out for k_eq_base0 (first round, base-field columns, no LDS stage)
 };
 // a table declared as eq(., point) on the rows [lo, hi) (ceno_hip_sumcheck_begin_eq)
 struct EqDecl {
@@ -941,6 +948,7 @@ struct GeqComp {
     int comp = -1;                 // index into gen_comps
     int nv = 0;
     int slot = 0;                  // index among the eq components
+    int deg = 0;                   // the component's own message length (<= the sumcheck's)
     std::vector<E2> pt, inv1m;     // the component's eq point and 1 / (1 - pt_i)
     struct Grp {
         uint64_t lo, hi;
@@ -1027,8 +1035,13 @@ struct ceno_hip_sumcheck {
         unsigned* d_counters = nullptr;   // device: one arrival counter per eq component
         unsigned max_grid = 0;            // largest eq launch of the sumcheck (rows of the components with several workgroups)
         uint64_t* d_rows = nullptr;       // device: [workgroup][D] partial sums of such components
-        // interpolation weights (base field), nodes -> target:  A: 1..D-1 -> 0, D   B: 0..D-2 -> D-1, D
-        std::vector<uint64_t> wA0, wAD, wB1, wBD, pow_dm1, lag_den_inv;
+        // interpolation weights (base field) per message length Dc (index Dc; 3 .. D), nodes -> target:  A: 1..Dc-1 -> 0, Dc   B: 0..Dc-2 -> Dc-1, Dc
+        struct Wts {
+            std::vector<uint64_t> wA0, wAD, wB1, wBD, pow_dm1;
+            std::vector<std::vector<uint64_t>> ext;  // ext[t - Dc - 1][j]: value at t = Dc + 1 .. D of the polynomial through (j, v_j), j = 0 .. Dc
+        };
+        std::vector<Wts> w;
+        std::vector<uint64_t> lag_den_inv;
     } geq;
 };
 
@@ -1369,12 +1382,18 @@ static int geq_prepare(ceno_hip_sumcheck* sc) {
         TRY(sc_dev_alloc(sc, (size_t)std::max(Gq.max_grid, 1u) * (size_t)D * sizeof(E2), &p));
         Gq.d_rows = (uint64_t*)p;
     }
-    Gq.wA0 = weights(1, D - 1, 0);
-    Gq.wAD = weights(1, D - 1, D);
-    Gq.wB1 = weights(0, D - 1, D - 1);
-    Gq.wBD = weights(0, D - 1, D);
-    Gq.pow_dm1.assign((size_t)D + 1, 0);
-    for (int t = 0; t <= D; t++) Gq.pow_dm1[(size_t)t] = gl::pow((uint64_t)t, (uint64_t)(D - 1));
+    // (a component whose own polynomial is shorter than the sumcheck's delivers Dc < D slots in the large rounds: weights for every length)
+    Gq.w.assign((size_t)D + 1, {});
+    for (int Dc = 3; Dc <= D; Dc++) {
+        auto& W = Gq.w[(size_t)Dc];
+        W.wA0 = weights(1, Dc - 1, 0);
+        W.wAD = weights(1, Dc - 1, Dc);
+        W.wB1 = weights(0, Dc - 1, Dc - 1);
+        W.wBD = weights(0, Dc - 1, Dc);
+        W.pow_dm1.assign((size_t)Dc + 1, 0);
+        for (int t = 0; t <= Dc; t++) W.pow_dm1[(size_t)t] = gl::pow((uint64_t)t, (uint64_t)(Dc - 1));
+        for (int t = Dc + 1; t <= D; t++) W.ext.push_back(weights(0, Dc + 1, t));
+    }
     // 1 / prod_{j != t} (t - j) over the nodes 0 .. D (Lagrange basis at a field point)
     Gq.lag_den_inv.assign((size_t)D + 1, 0);
     for (int t = 0; t <= D; t++) {
@@ -1405,10 +1424,12 @@ static void geq_boundary_rows(const GeqComp::Grp& g, int i, uint64_t pairs, bool
 static void geq_arm(ceno_hip_sumcheck* sc, int i) {
     auto& Gq = sc->geq;
     const int D = sc->d;
+    const bool by_degree = sc->gen_rounds[(size_t)i].by_degree;
     for (auto& Q : Gq.comps) {
         if (Q.nv <= i) continue;
+        const int Dc = by_degree ? Q.deg : D;  // (the rows keep their stride D)
         uint64_t* w = reinterpret_cast<uint64_t*>(Gq.h_q + (size_t)Q.slot * D);
-        for (int k = 0; k < 2 * D; k++) __atomic_store_n(&w[k], MSG_INVALID, __ATOMIC_RELAXED);
+        for (int k = 0; k < 2 * Dc; k++) __atomic_store_n(&w[k], MSG_INVALID, __ATOMIC_RELAXED);
         const uint64_t pairs = 1ull << (Q.nv - i - 1);
         for (const auto& g : Q.groups) {
             bool rows[2];
@@ -1416,7 +1437,7 @@ static void geq_arm(ceno_hip_sumcheck* sc, int i) {
             for (int sd = 0; sd < 2; sd++) {
                 if (!rows[sd]) continue;
                 uint64_t* b = reinterpret_cast<uint64_t*>(Gq.h_b + (size_t)(g.brow + sd) * D);
-                for (int k = 0; k < 2 * D; k++) __atomic_store_n(&b[k], MSG_INVALID, __ATOMIC_RELAXED);
+                for (int k = 0; k < 2 * Dc; k++) __atomic_store_n(&b[k], MSG_INVALID, __ATOMIC_RELAXED);
             }
         }
     }
@@ -1427,7 +1448,7 @@ static void geq_arm(ceno_hip_sumcheck* sc, int i) {
 static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
     auto& Gq = sc->geq;
     const int D = sc->d;
-    const bool neg_lead = ((D - 1) & 1) != 0;  // the device multiplies the (f(0) - f(1)): the leading coefficient carries (-1)^(D-1)
+    const bool by_degree = sc->gen_rounds[(size_t)i].by_degree;
     // Lagrange basis over the nodes 0 .. D at r (claims of this round), shared by every component
     E2 L[MAXD + 1];
     if (i > 0) {
@@ -1440,29 +1461,34 @@ static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
     }
     E2 msg[MAXD];
     for (int t = 0; t < D; t++) msg[t] = E2{h_out[2 * t], h_out[2 * t + 1]};
-    auto lead_of = [&](E2 raw) { return neg_lead ? e2_neg(raw) : raw; };
 
-    // value at 0 and at D of the polynomial of degree D - 1 with values v[0 .. D-2] at 1 .. D-1 and leading coefficient a
-    auto ends_from_values = [&](const E2* v, E2 a, E2& at0, E2& atD) {
-        E2 h0 = e2_zero(), hD = e2_zero();
-        for (int j = 0; j < D - 1; j++) {
-            const E2 h = v[j] - e2_mul_base(a, Gq.pow_dm1[(size_t)j + 1]);
-            h0 = h0 + e2_mul_base(h, Gq.wA0[(size_t)j]);
-            hD = hD + e2_mul_base(h, Gq.wAD[(size_t)j]);
-        }
-        at0 = h0;  // a * 0^(D-1) = 0
-        atD = hD + e2_mul_base(a, Gq.pow_dm1[(size_t)D]);
-    };
     for (auto& Q : Gq.comps) {
         if (Q.nv <= i) continue;
-        // (all D slots are written every round; slot D - 2 means something in the first round only — later it holds a by-product of the
+        // Dc: the length of the message this component's workgroups were instantiated for — the sumcheck's, or in a large round of a batch of
+        // mixed degrees the component's own (its polynomial has no higher coefficients: the nodes Dc + 1 .. D follow by extrapolation)
+        const int Dc = by_degree ? Q.deg : D;
+        const auto& W = Gq.w[(size_t)Dc];
+        const bool neg_lead = ((Dc - 1) & 1) != 0;  // the device multiplies the (f(0) - f(1)): the leading coefficient carries (-1)^(Dc-1)
+        auto lead_of = [&](E2 raw) { return neg_lead ? e2_neg(raw) : raw; };
+        // value at 0 and at Dc of the polynomial of degree Dc - 1 with values v[0 .. Dc-2] at 1 .. Dc-1 and leading coefficient a
+        auto ends_from_values = [&](const E2* v, E2 a, E2& at0, E2& atD) {
+            E2 h0 = e2_zero(), hD = e2_zero();
+            for (int j = 0; j < Dc - 1; j++) {
+                const E2 h = v[j] - e2_mul_base(a, W.pow_dm1[(size_t)j + 1]);
+                h0 = h0 + e2_mul_base(h, W.wA0[(size_t)j]);
+                hD = hD + e2_mul_base(h, W.wAD[(size_t)j]);
+            }
+            at0 = h0;  // a * 0^(Dc-1) = 0
+            atD = hD + e2_mul_base(a, W.pow_dm1[(size_t)Dc]);
+        };
+        // (all Dc slots are written every round; slot Dc - 2 means something in the first round only — later it holds a by-product of the
         // waves with a boundary pair)
         const E2* qv = Gq.h_q + (size_t)Q.slot * D;
-        TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(qv), 2 * D, "the quotient sums of an eq-factored component"));
+        TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(qv), 2 * Dc, "the quotient sums of an eq-factored component"));
         const E2 rt = Q.pt[(size_t)i];
-        // ---- boundary part B(t) = t (c G)(t), t = 0 .. D ----
+        // ---- boundary part B(t) = t (c G)(t), t = 0 .. Dc ----
         E2 B[MAXD + 1];
-        for (int t = 0; t <= D; t++) B[t] = e2_zero();
+        for (int t = 0; t <= Dc; t++) B[t] = e2_zero();
         const uint64_t pairs = 1ull << (Q.nv - i - 1);
         for (const auto& g : Q.groups) {
             bool rows[2];
@@ -1470,41 +1496,47 @@ static int geq_collect(ceno_hip_sumcheck* sc, int i, E2 r, uint64_t* h_out) {
             for (int sd = 0; sd < 2; sd++) {
                 if (!rows[sd]) continue;
                 const E2* bv = Gq.h_b + (size_t)(g.brow + sd) * D;
-                TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(bv), 2 * D, "the boundary values of an eq-factored component"));
+                TRY(sc_wait_words(sc, reinterpret_cast<const uint64_t*>(bv), 2 * Dc, "the boundary values of an eq-factored component"));
                 E2 at0, atD;
-                ends_from_values(bv, lead_of(bv[D - 1]), at0, atD);
-                for (int t = 1; t < D; t++) B[t] = B[t] + e2_mul_base(bv[t - 1], (uint64_t)t);
-                B[D] = B[D] + e2_mul_base(atD, (uint64_t)D);
+                ends_from_values(bv, lead_of(bv[Dc - 1]), at0, atD);
+                for (int t = 1; t < Dc; t++) B[t] = B[t] + e2_mul_base(bv[t - 1], (uint64_t)t);
+                B[Dc] = B[Dc] + e2_mul_base(atD, (uint64_t)Dc);
             }
         }
-        // ---- quotient Q(t), t = 0 .. D ----
+        // ---- quotient Q(t), t = 0 .. Dc ----
         E2 Qt[MAXD + 1];
-        const E2 a = lead_of(qv[D - 1]);
+        const E2 a = lead_of(qv[Dc - 1]);
         if (i == 0) {
-            for (int t = 1; t < D; t++) Qt[t] = qv[t - 1];
-            ends_from_values(qv, a, Qt[0], Qt[D]);
+            for (int t = 1; t < Dc; t++) Qt[t] = qv[t - 1];
+            ends_from_values(qv, a, Qt[0], Qt[Dc]);
         } else {
             E2 claim = e2_zero();
             for (int t = 0; t <= D; t++) claim = claim + L[t] * Q.P[(size_t)t];
-            for (int t = 1; t <= D - 2; t++) Qt[t] = qv[t - 1];
+            for (int t = 1; t <= Dc - 2; t++) Qt[t] = qv[t - 1];
             Qt[0] = (claim - rt * Qt[1] - B[1]) * Q.inv1m[(size_t)i];  // claim = (1 - rt) Q(0) + rt Q(1) + B(1)
             E2 h1 = e2_zero(), hD = e2_zero();
-            for (int j = 0; j < D - 1; j++) {
-                const E2 h = Qt[j] - e2_mul_base(a, Gq.pow_dm1[(size_t)j]);
-                h1 = h1 + e2_mul_base(h, Gq.wB1[(size_t)j]);
-                hD = hD + e2_mul_base(h, Gq.wBD[(size_t)j]);
+            for (int j = 0; j < Dc - 1; j++) {
+                const E2 h = Qt[j] - e2_mul_base(a, W.pow_dm1[(size_t)j]);
+                h1 = h1 + e2_mul_base(h, W.wB1[(size_t)j]);
+                hD = hD + e2_mul_base(h, W.wBD[(size_t)j]);
             }
-            Qt[D - 1] = h1 + e2_mul_base(a, Gq.pow_dm1[(size_t)D - 1]);
-            Qt[D] = hD + e2_mul_base(a, Gq.pow_dm1[(size_t)D]);
+            Qt[Dc - 1] = h1 + e2_mul_base(a, W.pow_dm1[(size_t)Dc - 1]);
+            Qt[Dc] = hD + e2_mul_base(a, W.pow_dm1[(size_t)Dc]);
         }
         // ---- p_c(t) = eq(t, rt) Q(t) + B(t),  eq(t, rt) = (1 - t) + (2 t - 1) rt ----
-        for (int t = 0; t <= D; t++) {
+        for (int t = 0; t <= Dc; t++) {
             const E2 one_minus_t = t <= 1 ? E2{(uint64_t)(1 - t), 0} : E2{gl::neg((uint64_t)(t - 1)), 0};
             const E2 two_t_minus_1 = t >= 1 ? E2{(uint64_t)(2 * t - 1), 0} : E2{gl::neg(1), 0};
             const E2 eq = one_minus_t + e2_mul_base(rt, two_t_minus_1.c0);
             Q.P[(size_t)t] = eq * Qt[t] + B[t];
-            if (t >= 1) msg[t - 1] = msg[t - 1] + Q.P[(size_t)t];
         }
+        for (int t = Dc + 1; t <= D; t++) {
+            const auto& we = W.ext[(size_t)(t - Dc - 1)];
+            E2 v = e2_zero();
+            for (int j = 0; j <= Dc; j++) v = v + e2_mul_base(Q.P[(size_t)j], we[(size_t)j]);
+            Q.P[(size_t)t] = v;
+        }
+        for (int t = 1; t <= D; t++) msg[t - 1] = msg[t - 1] + Q.P[(size_t)t];
     }
     for (int t = 0; t < D; t++) {
         h_out[2 * t] = msg[t].c0;
@@ -1526,49 +1558,64 @@ static unsigned gen_oversub() {
     const char* e = getenv("CENO_HIP_GEN_OVERSUB");  // workgroups per resident slot in the large rounds of an eq-factored batch (read per build)
     return e ? (unsigned)std::min(std::max(atoi(e), 1), 64) : 16u;
 }
-static int gen_split_cap(ceno_hip_ctx* ctx, int d) {
+static int gen_by_degree_mode() {
+    // per-degree launches of the large eq-factored rounds (sc_build_gen): 0 off, 1 where a round has more tiles than resident workgroups, 2 in
+    // every round (tests).  Read per build.
+    return getenv("CENO_HIP_GEN_BY_DEGREE") ? atoi(getenv("CENO_HIP_GEN_BY_DEGREE")) : 1;
+}
+// MLEs per column block for a block whose own polynomial has length `deg` in a sumcheck of length d (0: no column blocks)
+static int gen_split_cap(ceno_hip_ctx* ctx, int d, int deg) {
     const char* off = getenv("CENO_HIP_GEN_SPLIT");  // 0: no column blocks (A/B, tests)
     if (off && atoi(off) == 0) return 0;
     const char* e = getenv("CENO_HIP_GEN_SPLIT_MLES");
     if (e && atoi(e) > 0) return std::max(atoi(e), 3);
-    return std::max(3, (int)(gen_stage_budget3(ctx, d) / gen_stage_bytes(2, 6)));  // MLEs (two units each) whose rows fit at 64 pairs per tile
+    // MLEs (two units each) whose rows fit at 64 pairs per tile: beside the exchange block of the block's own kernel with three workgroups per
+    // CU where its registers allow them, and beside the sumcheck's in the one launch of a small round
+    return std::max(3, (int)(std::min(gen_stage_budget3(ctx, deg), gen_stage_budget(d)) / gen_stage_bytes(2, 6)));
 }
-static void gen_split_component(const ScClass& cl, const GenCompHost& C, int cap, std::vector<GenCompHost>& out) {
+// caps[deg]: gen_split_cap per block degree (3 .. d; all equal = the blocks are cut without regard to their degree)
+static void gen_split_component(const ScClass& cl, const GenCompHost& C, const int* caps, int d, bool by_degree, std::vector<GenCompHost>& out) {
     const int ng = (int)C.gts.size();
     struct Blk {
         std::vector<int> mles;
         std::vector<char> has;  // by class-local id
         std::vector<std::vector<uint32_t>> gts;
+        int deg = 3;
     };
     std::vector<Blk> blocks;
     const size_t km = cl.mles.size();
+    auto deg_of = [d](uint32_t nf) { return std::min(d, std::max(3, 1 + (int)nf)); };
     // terms in clustering order: products first (widest first), then single columns, then constants
     struct Item { int g; uint32_t t; uint32_t nf; };
     std::vector<Item> items;
     size_t max_need = 0;
+    int cap_min = 1 << 30;
     for (int g = 0; g < ng; g++)
         for (uint32_t t : C.gts[(size_t)g]) {
-            items.push_back(Item{g, t, cl.h_to[t + 1] - cl.h_to[t]});
-            max_need = std::max<size_t>(max_need, (size_t)(cl.h_to[t + 1] - cl.h_to[t]) + (cl.h_co[g + 1] - cl.h_co[g]));
+            const uint32_t nf = cl.h_to[t + 1] - cl.h_to[t];
+            items.push_back(Item{g, t, nf});
+            max_need = std::max<size_t>(max_need, (size_t)nf + (cl.h_co[g + 1] - cl.h_co[g]));
+            cap_min = std::min(cap_min, caps[by_degree ? deg_of(nf) : d]);
         }
-    if ((int)max_need > cap) {  // a single term does not fit a block: leave the component as it is
+    if (items.empty() || (int)max_need > cap_min) {  // a single term does not fit a block: leave the component as it is
         out.push_back(C);
         return;
     }
-    {   // blocks of EQUAL size rather than full blocks and a remainder (23 tables at 20 per block were 20 + 4: the small block staged the selector
-        // for three columns): with s selectors in every block, n = ceil((M - s) / (cap - s)) blocks of ceil((M - s) / n) + s tables
-        std::vector<char> is_common(km, 0);
-        int n_common = 0;
-        for (int g = 0; g < ng; g++)
-            if (!C.gts[(size_t)g].empty())
-                for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++)
-                    if (!is_common[cl.h_ci[k]]) is_common[cl.h_ci[k]] = 1, n_common++;
-        const int cols = (int)C.mles.size() - n_common;
+    std::vector<char> is_common(km, 0);
+    int n_common = 0;
+    for (int g = 0; g < ng; g++)
+        if (!C.gts[(size_t)g].empty())
+            for (uint32_t k = cl.h_co[g]; k < cl.h_co[g + 1]; k++)
+                if (!is_common[cl.h_ci[k]]) is_common[cl.h_ci[k]] = 1, n_common++;
+    // blocks of EQUAL size rather than full blocks and a remainder (23 tables at 20 per block were 20 + 4: the small block staged the selector
+    // for three columns): `cols` columns with s selectors in every block -> n = ceil(cols / (cap - s)) blocks of ceil(cols / n) + s tables
+    auto balanced = [&](int cap, int cols) {
         if (cap > n_common + 1 && cols > 0) {
             const int nb = (cols + (cap - n_common) - 1) / (cap - n_common);
             cap = std::max((int)max_need, std::min(cap, (cols + nb - 1) / nb + n_common + 1));  // (+1: room for a column two blocks share)
         }
-    }
+        return cap;
+    };
     std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.nf > b.nf; });
     auto wanted = [&](const Item& it, std::vector<int>& w) {
         w.clear();
@@ -1578,18 +1625,21 @@ static void gen_split_component(const ScClass& cl, const GenCompHost& C, int cap
         w.erase(std::unique(w.begin(), w.end()), w.end());
     };
     std::vector<int> w;
-    for (const Item& it : items) {
+    // `cap_of(block)`: what the block may hold; `foreign_ok(block, it)`: may the item bring NEW columns into it
+    auto place = [&](const Item& it, auto&& cap_of, auto&& foreign_ok, int deg_new) {
         wanted(it, w);
         int best = -1, best_need = 1 << 30;
         for (size_t b = 0; b < blocks.size(); b++) {
             int need = 0;
             for (int m : w) need += blocks[b].has[(size_t)m] ? 0 : 1;
-            if ((int)blocks[b].mles.size() + need <= cap && need < best_need) best = (int)b, best_need = need;
+            if (need > 0 && !foreign_ok(blocks[b])) continue;
+            if ((int)blocks[b].mles.size() + need <= cap_of(blocks[b]) && need < best_need) best = (int)b, best_need = need;
         }
         if (best < 0) {
             blocks.emplace_back();
             blocks.back().has.assign(km, 0);
             blocks.back().gts.assign((size_t)ng, {});
+            blocks.back().deg = deg_new;
             best = (int)blocks.size() - 1;
         }
         Blk& B = blocks[(size_t)best];
@@ -1599,6 +1649,31 @@ static void gen_split_component(const ScClass& cl, const GenCompHost& C, int cap
                 B.mles.push_back(m);
             }
         B.gts[(size_t)it.g].push_back(it.t);
+    };
+    if (!by_degree) {
+        const int cap = balanced(caps[d], (int)C.mles.size() - n_common);
+        for (const Item& it : items) place(it, [&](const Blk&) { return cap; }, [](const Blk&) { return true; }, d);
+    } else {
+        // Blocks by DEGREE (the large rounds launch every block on the kernel of its own message length, sc_build_gen): the products cluster
+        // first, every block as large as its kernel allows; a selector x column term joins the block that already stages its column; the columns
+        // that no product reads go to blocks of length 3 only — in a block of length 5 such a term is evaluated at four points instead of two,
+        // by waves that hold five accumulators — of equal size.
+        size_t k = 0;
+        for (; k < items.size() && items[k].nf >= 2; k++)
+            place(items[k], [&](const Blk& B) { return caps[B.deg]; }, [](const Blk&) { return true; }, deg_of(items[k].nf));
+        std::vector<char> covered(km, 0);
+        int cols3 = 0;
+        for (const Blk& B : blocks)
+            for (int m : B.mles)
+                if (!covered[(size_t)m]) {
+                    covered[(size_t)m] = 1;
+                    if (B.deg == 3 && !is_common[(size_t)m]) cols3++;
+                }
+        for (int m : C.mles)
+            if (!covered[(size_t)m] && !is_common[(size_t)m]) cols3++;
+        const int cap3 = balanced(caps[3], cols3);
+        for (; k < items.size(); k++)
+            place(items[k], [&](const Blk& B) { return B.deg == 3 ? std::max(cap3, (int)B.mles.size()) : caps[B.deg]; }, [](const Blk& B) { return B.deg == 3; }, 3);
     }
     std::vector<char> owned(km, 0);
     for (Blk& B : blocks) {
@@ -1707,11 +1782,18 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         // (CENO_HIP_GEN_SPLIT_MIN_LOG: smallest class that gets column blocks.  Measured: blocks for every class are best — the wide batch 60.2 ms
         // against 69.9 with blocks from 2^18 rows up and 96.8 without; the latency-bound batch of the 2^20-cycle shard does not care, 2.03-2.19 ms)
         static const int split_min_log = getenv("CENO_HIP_GEN_SPLIT_MIN_LOG") ? atoi(getenv("CENO_HIP_GEN_SPLIT_MIN_LOG")) : 0;
-        if (const int cap = cl.nv >= split_min_log ? gen_split_cap(ctx, sc->d) : 0) {
+        if (cl.nv >= split_min_log && gen_split_cap(ctx, sc->d, sc->d) > 0) {
+            const bool by_degree = geq_wanted && sc->d >= 3 && gen_by_degree_mode() >= 1;
+            int caps[MAXD + 1] = {};
+            int cap_min = 1 << 30;
+            for (int dg = std::min(3, sc->d); dg <= sc->d; dg++) {
+                caps[dg] = gen_split_cap(ctx, sc->d, by_degree ? dg : sc->d);
+                cap_min = std::min(cap_min, caps[dg]);
+            }
             std::vector<GenCompHost> cut;
             for (auto& C : mine) {
-                if ((int)C.mles.size() <= cap) cut.push_back(std::move(C));
-                else gen_split_component(cl, C, cap, cut);
+                if ((int)C.mles.size() <= cap_min) cut.push_back(std::move(C));
+                else gen_split_component(cl, C, caps, sc->d, by_degree, cut);
             }
             mine = std::move(cut);
         }
@@ -1803,6 +1885,10 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     GeqComp Q;
                     Q.nv = cl.nv;
                     Q.pt = first->pt;
+                    // the length of the component's OWN round polynomial: eq x (products of at most nf columns); the kernels exist from 3 on
+                    uint32_t nf_max = 0;
+                    for (const GenTerm& T : terms[0]) nf_max = std::max(nf_max, T.nf);
+                    Q.deg = C.deg = std::min(sc->d, std::max(3, 1 + (int)nf_max));
                     Q.slot = (int)sc->geq.comps.size() + (int)geq_new.size();
                     for (size_t k = 0; k < grp_common.size(); k++) {
                         const EqDecl& dcl = sc->geq.decl[grp_common[k]];
@@ -1951,6 +2037,8 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         GenRound& R = sc->gen_rounds[i];
         std::vector<GenComp> list, list_eq;
         std::vector<double> weight_eq;
+        std::vector<int> deg_eq;         // per entry of list_eq: the component's own degree (0: folded only)
+        std::vector<size_t> stage_eq;    // ... and the bytes of its LDS stage
         bool base0 = i == 0;
         for (auto& C : comps)
             if (sc->classes[C.cls].nv > i && C.n_groups > 0 && !C.base0_ok) base0 = false;
@@ -2000,9 +2088,10 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                         G.p2_tile_end = (uint32_t)std::min<uint64_t>(((pe - 1) >> C.tp_log) + 1, G.n_tiles);
                     }
                     w += (double)(G.p2_tile_end - G.p2_tile_begin) * C.pair_cost[1];
-                    R.stage_bytes_eq = std::max(R.stage_bytes_eq, gen_stage_bytes(C.units[lay == 2 ? 1 : lay], C.tp_log));
                 }
                 weight_eq.push_back(w * (double)(1u << C.tp_log));
+                deg_eq.push_back(C.geq >= 0 ? C.deg : 0);
+                stage_eq.push_back(C.geq >= 0 ? gen_stage_bytes(C.units[lay == 2 ? 1 : lay], C.tp_log) : 0);
                 list_eq.push_back(G);
                 continue;
             }
@@ -2018,29 +2107,38 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         R.total_tiles = tiles;
         R.off_comps = append(list.data(), list.size() * sizeof(GenComp));
         for (size_t k = 0; k < list.size(); k++) comp_fix.push_back(R.off_comps + k * sizeof(GenComp));
-        if (!list_eq.empty()) {
+        // one component-aligned launch over `sel` (indices into list_eq) with the kernels instantiated for messages of length Dl
+        auto emit_eq_launch = [&](const std::vector<size_t>& sel, int Dl) {
+            GenRound::EqLaunch EL;
+            EL.D = Dl;
+            std::vector<GenComp> lst;
+            std::vector<double> wts;
+            for (size_t k : sel) {
+                lst.push_back(list_eq[k]);
+                wts.push_back(weight_eq[k]);
+                EL.stage_bytes = std::max(EL.stage_bytes, stage_eq[k]);
+            }
             // component-aligned workgroup split: one workgroup per tile while all of them are resident at once, else every component
             // gets one workgroup and the rest in proportion to its estimated work
             uint64_t total = 0;
             double wsum = 0.0;
-            for (size_t k = 0; k < list_eq.size(); k++) {
-                total += list_eq[k].n_tiles;
-                wsum += weight_eq[k];
+            for (size_t k = 0; k < lst.size(); k++) {
+                total += lst[k].n_tiles;
+                wsum += wts[k];
             }
-            const unsigned cap = std::max<unsigned>(direct0 ? eq_base0_resident_cap(ctx, sc->d) : gen_resident_cap(ctx, sc->d, base0, R.stage_bytes_eq),
-                                                    (unsigned)list_eq.size());
+            const unsigned cap = std::max<unsigned>(direct0 ? eq_base0_resident_cap(ctx, Dl) : gen_resident_cap(ctx, Dl, base0, EL.stage_bytes), (unsigned)lst.size());
             // small rounds -> one workgroup per tile and SLOT (the four waves of a workgroup walking 4-8 terms each, one pair per lane, were
             // the longest phase of such a round: CENO_HIP_GEN_PHASE_DBG=1).  CENO_HIP_EQ_SLOTS=0: off (A/B, read per build)
             const bool no_slots = getenv("CENO_HIP_EQ_SLOTS") && atoi(getenv("CENO_HIP_EQ_SLOTS")) == 0;
             // (one workgroup per TILE and slot as long as the whole launch is resident at once: a workgroup then has one tile, as before)
-            bool slots = !no_slots && i > 0 && !direct0 && sc->d >= 3 && total * (uint64_t)sc->d <= cap;
-            R.slots = slots;
+            const bool slots = !no_slots && i > 0 && !direct0 && Dl >= 3 && total * (uint64_t)Dl <= cap;
+            EL.slots = slots;
             unsigned wg = 0;
-            for (size_t k = 0; k < list_eq.size(); k++) {
-                GenComp& G = list_eq[k];
+            for (size_t k = 0; k < lst.size(); k++) {
+                GenComp& G = lst[k];
                 unsigned cnt = G.n_tiles;
                 if (slots && G.n_groups > 0) {
-                    cnt = G.n_tiles * (unsigned)sc->d;
+                    cnt = G.n_tiles * (unsigned)Dl;
                     G.eqf |= 4u;
                     G.wg_begin = wg;
                     G.wg_count = cnt;
@@ -2052,12 +2150,12 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     // next one to whichever slot frees up, so a component whose cost the estimate got wrong no longer sets the launch's time
                     // (with one workgroup per slot a 2x error in the weight of the product terms cost the wide batch 106 -> 157 ms,
                     // tools/dev/wide_sweep.sh) — and the tail of the launch is 1 / oversub of a slot's time
-                    const double share = wsum > 0 ? weight_eq[k] / wsum : 0.0;
+                    const double share = wsum > 0 ? wts[k] / wsum : 0.0;
                     // ... as long as a workgroup still has ~8 tiles to amortise its epilogue over (a row, an atomic, a share of the last workgroup's
                     // sum): the medium rounds of a small batch lost 0.13 ms of 1.9 to sixteen workgroups per slot (tools/dev/shard_ab.sh)
                     const unsigned os = (unsigned)std::min<uint64_t>(gen_oversub(), std::max<uint64_t>(1, total / ((uint64_t)cap * 8)));
-                    const unsigned budget = std::max(cap * os, (unsigned)list_eq.size());
-                    cnt = 1u + (unsigned)(share * (double)(budget - (unsigned)list_eq.size()));
+                    const unsigned budget = std::max(cap * os, (unsigned)lst.size());
+                    cnt = 1u + (unsigned)(share * (double)(budget - (unsigned)lst.size()));
                     cnt = std::min(cnt, G.n_tiles);
                 }
                 G.wg_begin = wg;
@@ -2065,24 +2163,61 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                 wg += G.wg_count;
             }
             if (i == 1 && getenv("CENO_HIP_PLAN_REPORT") && atoi(getenv("CENO_HIP_PLAN_REPORT")) >= 2) {
-                fprintf(stderr, "[ceno_hip] eq launch of round 1: cap %u, %zu components, %u workgroups, stage %zu B, LDS per workgroup %zu B\n", cap, list_eq.size(), wg,
-                        R.stage_bytes_eq, gen_lds_bytes(sc->d, R.stage_bytes_eq));
-                for (size_t k = 0; k < list_eq.size(); k++)
+                fprintf(stderr, "[ceno_hip] eq launch of round 1 at degree %d: cap %u, %zu components, %u workgroups, stage %zu B, LDS per workgroup %zu B\n", Dl, cap,
+                        lst.size(), wg, EL.stage_bytes, gen_lds_bytes(Dl, EL.stage_bytes));
+                for (size_t k = 0; k < lst.size(); k++)
                     fprintf(stderr, "[ceno_hip]   comp %3zu: pairs 2^%d mles %3u groups %u tp_log %u tiles %7u p2 tiles %7u weight %.3e wgs %4u weight/wg %.3e\n", k,
-                            (int)(63 - __builtin_clzll(list_eq[k].pairs)), list_eq[k].n_mles, list_eq[k].n_groups, list_eq[k].tp_log, list_eq[k].n_tiles,
-                            list_eq[k].p2_tile_end - list_eq[k].p2_tile_begin, weight_eq[k], list_eq[k].wg_count, weight_eq[k] / list_eq[k].wg_count);
+                            (int)(63 - __builtin_clzll(lst[k].pairs)), lst[k].n_mles, lst[k].n_groups, lst[k].tp_log, lst[k].n_tiles,
+                            lst[k].p2_tile_end - lst[k].p2_tile_begin, wts[k], lst[k].wg_count, wts[k] / lst[k].wg_count);
             }
-            R.grid_eq = wg;
+            EL.grid = wg;
             sc->geq.max_grid = std::max(sc->geq.max_grid, wg);
-            R.n_comps_eq = (int)list_eq.size();
-            R.off_comps_eq = append(list_eq.data(), list_eq.size() * sizeof(GenComp));
-            for (size_t k = 0; k < list_eq.size(); k++) comp_fix.push_back(R.off_comps_eq + k * sizeof(GenComp));
+            EL.n_comps = (int)lst.size();
+            EL.off_comps = append(lst.data(), lst.size() * sizeof(GenComp));
+            for (size_t k = 0; k < lst.size(); k++) comp_fix.push_back(EL.off_comps + k * sizeof(GenComp));
             // workgroup -> component, one scalar load (walking the list cost the last of 24 components ~10 us of dependent loads in
             // every round: CENO_HIP_GEN_PHASE_DBG=1)
             std::vector<uint16_t> wg_comp(wg);
-            for (size_t k = 0; k < list_eq.size(); k++)
-                for (unsigned x = 0; x < list_eq[k].wg_count; x++) wg_comp[list_eq[k].wg_begin + x] = (uint16_t)k;
-            R.off_wg_comp = append(wg_comp.data(), wg_comp.size() * sizeof(uint16_t));
+            for (size_t k = 0; k < lst.size(); k++)
+                for (unsigned x = 0; x < lst[k].wg_count; x++) wg_comp[lst[k].wg_begin + x] = (uint16_t)k;
+            EL.off_wg_comp = append(wg_comp.data(), wg_comp.size() * sizeof(uint16_t));
+            R.eq.push_back(EL);
+        };
+        if (!list_eq.empty()) {
+            // A batch's sumcheck has the length of its LONGEST polynomial (degree 5 for the wide batch: eq x four columns) while most column
+            // blocks hold selector x column terms only — a polynomial of length 3 (clamped: 2 + 1) that the kernel for length 5 evaluates at
+            // four points instead of two, with the registers of five accumulators (two waves per SIMD).  In the LARGE rounds (more tiles than
+            // resident workgroups: throughput, not latency) the components are launched per degree, each with the kernel of its own length;
+            // the host completes every component's polynomial at ITS length and extends it to the sumcheck's nodes (geq_collect).  The small
+            // rounds keep the one launch.  CENO_HIP_GEN_BY_DEGREE=0: off; =2: in every round (tests).  Read per build.
+            const int by_deg_mode = gen_by_degree_mode();
+            uint64_t total = 0;
+            size_t stage_all = 0;
+            int deg_min = sc->d;
+            for (size_t k = 0; k < list_eq.size(); k++) {
+                total += list_eq[k].n_tiles;
+                stage_all = std::max(stage_all, stage_eq[k]);
+                if (deg_eq[k] > 0) deg_min = std::min(deg_min, deg_eq[k]);
+            }
+            const unsigned cap_all = direct0 ? eq_base0_resident_cap(ctx, sc->d) : gen_resident_cap(ctx, sc->d, base0, stage_all);
+            R.by_degree = deg_min < sc->d && (by_deg_mode >= 2 || (by_deg_mode == 1 && total > cap_all));
+            std::vector<size_t> sel;
+            if (!R.by_degree) {
+                for (size_t k = 0; k < list_eq.size(); k++) sel.push_back(k);
+                emit_eq_launch(sel, sc->d);
+            } else {
+                bool first = true;
+                for (int Dl = sc->d; Dl >= 3; Dl--) {  // (longest first; the folded-only tables ride with the first launch)
+                    sel.clear();
+                    for (size_t k = 0; k < list_eq.size(); k++)
+                        if (deg_eq[k] == Dl || (first && deg_eq[k] == 0)) sel.push_back(k);
+                    bool any = false;
+                    for (size_t k : sel) any = any || deg_eq[k] == Dl;
+                    if (!any) continue;
+                    emit_eq_launch(sel, Dl);
+                    first = false;
+                }
+            }
         }
     }
     CENO_TIMED("sc_build_gen: allocation + upload");
@@ -3237,7 +3372,7 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
             if (!gen_added && sc->gen_rounds[i].n_comps > 0) units.push_back(Unit{U_GEN, nullptr, sc->gen_rounds[i].has_terms});
             // the eq-factored components: their own (component-aligned) launch; it takes no part in the classic message chain — its
             // per-component sums go to the host, which completes and adds them (geq_collect)
-            if (!gen_added && sc->gen_rounds[i].n_comps_eq > 0) units.push_back(Unit{U_GENEQ, nullptr, false});
+            if (!gen_added && !sc->gen_rounds[i].eq.empty()) units.push_back(Unit{U_GENEQ, nullptr, false});
             gen_added = true;
         } else units.push_back(Unit{U_LEGACY, cl, !cl->terms.empty()});
     }
@@ -3266,21 +3401,24 @@ static int sc_round(ceno_hip_sumcheck* sc, const uint64_t* challenge2, uint64_t*
         if (U.kind == U_GENEQ) {
             const GenRound& R = sc->gen_rounds[i];
             geq_arm(sc, i);
-            ctx->eq_launches.fetch_add(1, std::memory_order_relaxed);
             ep.partials = sc->geq.d_rows;
             ep.d = 0;
-            GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters, reinterpret_cast<const uint16_t*>(sc->d_gen + R.off_wg_comp)};
             static const bool phase_dbg = getenv("CENO_HIP_GEN_PHASE_DBG") != nullptr;  // device-side phase stamps of the launch's last workgroup
             if (phase_dbg) {
                 ep.bcast = sc->d_bcast;
                 ep.dbg = 1;
             }
-            prof_begin(ctx, sc->st);
-            if (R.direct0) launch_eq_base0(ctx, d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, ep, ea, R.grid_eq, sc->st);
-            else if (R.slots) launch_gen_eq_slots(d, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, r, ep, R.stage_bytes_eq, sc->st, ea, R.grid_eq);
-            else launch_gen(ctx, d, R.base0, reinterpret_cast<const GenComp*>(sc->d_gen + R.off_comps_eq), R.n_comps_eq, 0, r, ep, R.stage_bytes_eq, sc->st, &ea,
-                            R.grid_eq);
-            prof_end(ctx, sc->st, 0.0);
+            // (launches of one round follow each other on the stream: the rows of the first are summed before the second starts)
+            for (const GenRound::EqLaunch& EL : R.eq) {
+                ctx->eq_launches.fetch_add(1, std::memory_order_relaxed);
+                const GenEqArgs ea{1, sc->geq.d_q, sc->geq.d_b, sc->geq.d_counters, reinterpret_cast<const uint16_t*>(sc->d_gen + EL.off_wg_comp), (unsigned)d};
+                const GenComp* cs = reinterpret_cast<const GenComp*>(sc->d_gen + EL.off_comps);
+                prof_begin(ctx, sc->st);
+                if (R.direct0) launch_eq_base0(ctx, EL.D, cs, EL.n_comps, ep, ea, EL.grid, sc->st);
+                else if (EL.slots) launch_gen_eq_slots(EL.D, cs, EL.n_comps, r, ep, EL.stage_bytes, sc->st, ea, EL.grid);
+                else launch_gen(ctx, EL.D, R.base0, cs, EL.n_comps, 0, r, ep, EL.stage_bytes, sc->st, &ea, EL.grid);
+                prof_end(ctx, sc->st, 0.0);
+            }
             continue;
         }
         if (U.kind == U_GEN) {

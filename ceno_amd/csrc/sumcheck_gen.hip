@@ -461,7 +461,7 @@ __device__ __forceinline__ void gen_eq_terms(const GenComp& C, unsigned term_beg
 //   slot D - 1:     the coefficient of X^(D-1), up to the sign (-1)^(D-1) the host applies: only terms of D - 1 factors have one
 template <int D, bool BASE0>
 __device__ __forceinline__ void gen_group_eq(const GenComp& C, unsigned g, const E2* stage, E2* xch, unsigned tpp, unsigned q, unsigned ts, unsigned wt,
-                                             bool valid, size_t pair, int wave, unsigned lane, E2 (&acc)[D], E2* b_out) {
+                                             bool valid, size_t pair, int wave, unsigned lane, E2 (&acc)[D], E2* b_out, unsigned bstride) {
     static_assert(D >= 3, "eq-factored groups need a message of at least three points");
     const gen_u4 gw = ldc4(C.groups + g);
     const gen_u4 gw3 = ldc4(reinterpret_cast<const char*>(C.groups + g) + 16);
@@ -570,7 +570,7 @@ __device__ __forceinline__ void gen_group_eq(const GenComp& C, unsigned g, const
             const E2 bv = cb * v;
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
             const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * bstride + t), "v"(ww) : "memory");
         }
         if (valid) acc[t] = acc[t] + w * v;
     }
@@ -589,7 +589,7 @@ __device__ __forceinline__ void epilogue_eq(E2 (&acc)[D], const GenComp& C, cons
 #pragma unroll
         for (int t = 0; t < D; t++) {
             const u4 ww = {(unsigned)v[t].c0, (unsigned)(v[t].c0 >> 32), (unsigned)v[t].c1, (unsigned)(v[t].c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)slot * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)slot * eqa.stride + t), "v"(ww) : "memory");
         }
     };
     if (C.n_groups == 0) return;  // folded only: nothing to report
@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(NT, gen_eq_min_waves(D, BASE0)) k_gen_eq(const
         __syncthreads();
         if (stamp) ep.bcast->dbg[ep.seq & 31][2] = wall_clock64();
         const bool valid = q < tp && p0 + q < C.pairs;
-        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq<D, BASE0>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out);
+        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq<D, BASE0>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out, eqa.stride);
         __syncthreads();  // the stage (and the exchange block) are reused by the next tile
     }
     if (stamp) ep.bcast->dbg[ep.seq & 31][3] = wall_clock64();
@@ -699,7 +699,7 @@ __device__ __forceinline__ E2 gen_eq_slot_terms(const GenComp& C, unsigned term_
 }
 template <int D>
 __device__ __forceinline__ void gen_group_eq_slot(const GenComp& C, unsigned g, const E2* stage, E2* xch, unsigned tpp, unsigned q, unsigned ts, unsigned wt,
-                                                  bool valid, size_t pair, int wave, unsigned lane, E2 (&acc)[D], E2* b_out, unsigned slot) {
+                                                  bool valid, size_t pair, int wave, unsigned lane, E2 (&acc)[D], E2* b_out, unsigned bstride, unsigned slot) {
     const gen_u4 gw = ldc4(C.groups + g);
     const gen_u4 gw3 = ldc4(reinterpret_cast<const char*>(C.groups + g) + 16);
     const gen_u4 gw4 = ldc4(reinterpret_cast<const char*>(C.groups + g) + 32);
@@ -734,7 +734,7 @@ __device__ __forceinline__ void gen_group_eq_slot(const GenComp& C, unsigned g, 
         const E2 bv = cb * v;
         typedef unsigned int u4 __attribute__((ext_vector_type(4)));
         const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * D + slot), "v"(ww) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(b_out + (size_t)(brow + side) * bstride + slot), "v"(ww) : "memory");
     }
     if (valid) {
         const E2 add = w * v;
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__
     __syncthreads();
     if (tile >= C.p2_tile_begin && tile < C.p2_tile_end) {
         const bool valid = q < tp && p0 + q < C.pairs;
-        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq_slot<D>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out, slot);
+        for (unsigned g = 0; g < C.n_groups; g++) gen_group_eq_slot<D>(C, g, stage, xch, tpp, q, ts, wt, valid, p0 + q, wave, lane, acc, eqa.b_out, eqa.stride, slot);
         __syncthreads();
     }
     if (C.n_tiles > 1) {
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(NT) k_gen_eq_slots(const GenComp* __restrict__
         for (int t = 0; t < D; t++) {
             if ((unsigned)t != slot) continue;
             const u4 ww = {(unsigned)acc[t].c0, (unsigned)(acc[t].c0 >> 32), (unsigned)acc[t].c1, (unsigned)(acc[t].c1 >> 32)};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)C.eq_slot * D + t), "v"(ww) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.q_out + (size_t)C.eq_slot * eqa.stride + t), "v"(ww) : "memory");
         }
     }
 }
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(NT) k_eq_base0(const GenComp* __restrict__ com
                     const E2 bv = cb * v;
                     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
                     const u4 ww = {(unsigned)bv.c0, (unsigned)(bv.c0 >> 32), (unsigned)bv.c1, (unsigned)(bv.c1 >> 32)};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.b_out + (size_t)(brow + side) * D + t), "v"(ww) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(eqa.b_out + (size_t)(brow + side) * eqa.stride + t), "v"(ww) : "memory");
                 }
                 acc[t] = acc[t] + w * v;
             }

@@ -54,6 +54,8 @@ struct GenEqArgs {
     E2* b_out;                 // host-mapped: [brow + side][D] scaled values of a boundary pair (armed by the host where one exists)
     unsigned* counters;        // device: arrival counter per eq_slot (components with several workgroups), zero between launches
     const uint16_t* wg_comp;   // device: the component of every workgroup of the launch (NULL: walk the list)
+    unsigned stride;           // entries per row of q_out / b_out (the sumcheck's message length: a launch of LOWER degree — the components whose
+                               // own polynomial is shorter, round 5 — fills the first D' entries of the same rows)
 };
 
 // LDS of a launch: fixed block + staged rows + the cross-wave exchange of partial group sums (4 waves x D points x 64 lanes)

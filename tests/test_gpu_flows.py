@@ -202,10 +202,12 @@ def test_main_constraints_public_instance_atoms(dev, prover):
 # pairs in every round), several selectors per chip, chips whose selector is not of that form (generic rounds in the same sumcheck),
 # and messages of 3, 4 and 5 points.
 # ------------------------------------------------------------------------------------------------------------------
-def _eq_case_jobs(dev, case, max_degree):
+def _eq_case_jobs(dev, case, max_degree, degs=None):
     w = 4
     jobs, tabs, terms_all, scal_all, nvs = [], [], [], [], []
+    batch_degree = max_degree
     for c, (nv, sels) in enumerate(case):
+        max_degree = degs[c % len(degs)] if degs else batch_degree  # (chips of different degrees in one batch)
         cols = [po.rand_base(1 << nv, 7000 + 31 * c + j) for j in range(w)]
         point = po.rand_ext(nv, 500 + c)
         ns = len(sels)
@@ -279,6 +281,39 @@ def test_eq_factored_main_constraints_match_the_oracle(dev, prover, monkeypatch,
         monkeypatch.setenv("CENO_HIP_EQ_SLOTS", "0")
         c3, m3, r3, e3 = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
         assert c3 == claimed and np.array_equal(m3, msgs) and np.array_equal(e3, evals)
+
+
+@pytest.mark.parametrize("degs", [(5, 2, 4, 3), (2, 5), (3, 4, 2)])
+@pytest.mark.parametrize("name", sorted(EQ_CASES))
+def test_eq_factored_rounds_per_component_degree(dev, prover, monkeypatch, name, degs):
+    """chips of DIFFERENT degrees in one batch (selector x column only: length 3 after the clamp; products of two, three, four columns): in
+    the large rounds every component runs on the kernel of its own message length and the host extends its polynomial to the sumcheck's
+    nodes (CENO_HIP_GEN_BY_DEGREE=2: in every round; also with the staged first round and with one workgroup per component in the small
+    rounds).  Every variant produces the words of the oracle's prover."""
+    gch = [(11, 22), (33, 44)]
+    D = max(degs)
+    jobs, tabs, terms, scal_all, nvs = _eq_case_jobs(dev, EQ_CASES[name], D, degs)
+    max_nv = max(nvs)
+    t2 = po.StubTranscript(5)
+    t2.append_label(b"combine subset evals")
+    a = t2.sample_ext()
+    pows = [e2_pow(a, i) for i in range(2 * len(jobs))]
+    coeffs = []
+    for c, sc in enumerate(scal_all):
+        coeffs += oracle_scalars(sc, gch + pows[2 * c: 2 * c + 2])
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext(coeffs), terms, max_nv, D, t2)
+    for switches in ({}, {"CENO_HIP_GEN_BY_DEGREE": "2"}, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_EQ_DIRECT0": "0"},
+                     {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_EQ_SLOTS": "0"}, {"CENO_HIP_GEN_BY_DEGREE": "0"}):
+        for k in ("CENO_HIP_GEN_BY_DEGREE", "CENO_HIP_EQ_DIRECT0", "CENO_HIP_EQ_SLOTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in switches.items():
+            monkeypatch.setenv(k, v)
+        before = dev.L.ceno_hip_stat_eq_launches(dev.h)
+        claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+        launches = dev.L.ceno_hip_stat_eq_launches(dev.h) - before
+        assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals), switches
+        if switches.get("CENO_HIP_GEN_BY_DEGREE") == "2" and name != "generic_chip_in_the_batch":
+            assert launches > max_nv, "the per-degree launches did not run"
 
 
 @pytest.mark.parametrize("max_degree", [4, 3])
@@ -528,13 +563,15 @@ def _wide_oracle_plan(chips, gch, pows):
 
 
 @pytest.mark.parametrize("max_nv,switches", [(13, {}), (13, {"CENO_HIP_GEN_EQF": "0"}), (13, {"CENO_HIP_GEN_SPLIT": "0"}), (14, {"CENO_HIP_GEN_MIN_LOG": "4"}),
-                                             (20, {})])
+                                             (13, {"CENO_HIP_GEN_BY_DEGREE": "2"}), (14, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_GEN_MIN_LOG": "4"}),
+                                             (14, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_EQ_DIRECT0": "0"}), (20, {}), (20, {"CENO_HIP_GEN_BY_DEGREE": "0"})])
 def test_wide_batched_main_constraints_match_the_oracle(dev, prover, monkeypatch, max_nv, switches):
     """the batched main sumcheck over 48 WIDE chips (22..96 base columns, 1..3 Prefix selectors, selector x column monomials for every
     column, selector x constant, a tail of degree 3..5 products): every message, challenge and final evaluation equals the oracle prover's
     (max_nv <= 14: from round 0; 20: verifier + independent evaluations + the last 12 rounds), with the eq-factored rounds, with the
-    declarations ignored (generic rounds), without the column-block split of wide components, and with the component tables on from 2^4
-    rows so that the smallest chips take the same path as the largest"""
+    declarations ignored (generic rounds), without the column-block split of wide components, with the component tables on from 2^4
+    rows so that the smallest chips take the same path as the largest, and with the per-degree launches of the large rounds (column blocks of
+    selector x column terms on the kernel of length 3, the products on theirs) in EVERY round, with the direct and the staged first round"""
     from ceno_amd import synthetic
 
     for k, v in switches.items():
