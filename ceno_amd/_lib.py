@@ -90,6 +90,8 @@ def lib():
         "ceno_hip_mle_fix_variables": (i, [vp, vp, u64p, i, vp, vpp]),
         "ceno_hip_eq_build": (i, [vp, u64p, i, u64p, vp, vpp]),
         "ceno_hip_selector_build": (i, [vp, i, u64p, i, sz, sz, u32p, i, i, vp, vpp]),
+        "ceno_hip_mle_evaluate_prefix_batch": (i, [vp, i, vpp, u64p, i, vp, u64p]),
+        "ceno_hip_lincomb_base_batch": (i, [vp, i, u32p, vpp, u64p, vp, vpp, vpp]),
         "ceno_hip_selector_build_batch": (i, [vp, i, C.POINTER(i), C.POINTER(u64p), C.POINTER(i), C.POINTER(sz), C.POINTER(sz), vp, vpp]),
         "ceno_hip_rotation_next_base_mle": (i, [vp, vp, i, vp, vpp]),
         "ceno_hip_rotation_selector_build": (i, [vp, u64p, i, i, i, vp, vpp]),

@@ -111,6 +111,28 @@ class Device:
         self.check(self.L.ceno_hip_mle_wrap(self.h, C.c_void_p(device_ptr), num_vars, int(is_ext), C.byref(h)))
         return Mle(self, h)
 
+    def evaluate_prefix_batch(self, cols: Sequence["Mle"], point: np.ndarray, stream=None) -> np.ndarray:
+        """cols[j](point[:num_vars_j]) for base-field tables, one pass (ceno_hip_mle_evaluate_prefix_batch); returns (n, 2) words"""
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
+        arr = (C.c_void_p * max(len(cols), 1))(*[m.h for m in cols])
+        out = np.zeros((len(cols), 2), dtype=np.uint64)
+        self.check(self.L.ceno_hip_mle_evaluate_prefix_batch(self.h, len(cols), arr, _p(point), point.shape[0], stream, _p(out)))
+        return out
+
+    def lincomb_base_batch(self, groups: Sequence[Sequence["Mle"]], coeffs: Sequence[np.ndarray], stream=None):
+        """per group g: (sum_j c_j.c0 col_j, sum_j c_j.c1 col_j) as two base-field tables (ceno_hip_lincomb_base_batch)"""
+        offs, flat = [0], []
+        for g in groups:
+            flat += list(g)
+            offs.append(len(flat))
+        co = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint64).reshape(-1, 2) for c in coeffs]), dtype=np.uint64)
+        offs = np.asarray(offs, dtype=np.uint32)
+        arr = (C.c_void_p * max(len(flat), 1))(*[m.h for m in flat])
+        o0 = (C.c_void_p * len(groups))()
+        o1 = (C.c_void_p * len(groups))()
+        self.check(self.L.ceno_hip_lincomb_base_batch(self.h, len(groups), offs.ctypes.data_as(C.POINTER(C.c_uint32)), arr, _p(co), stream, o0, o1))
+        return [(Mle(self, C.c_void_p(o0[g])), Mle(self, C.c_void_p(o1[g]))) for g in range(len(groups))]
+
     def synthetic(self, num_vars: int, is_ext: bool, seed: int, word_offset: int = 0, stream=None) -> "Mle":
         self.check(self.L.ceno_hip_stream_bind(self.h, stream))  # the block is for work on `stream` (pool tags)
         m = self.alloc(num_vars, is_ext)

@@ -660,6 +660,290 @@ int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Columns that a constraint system only reads LINEARLY (the record RLCs of a chip: selector x column for three quarters of its columns,
+// gkr_iop/src/gkr/layer/zerocheck_layer.rs:118-140) need not go through the rounds of the main-constraint sumcheck one by one:
+//     sum_j c_j sel(x) col_j(x) = sel(x) (A(x) + X B(x)),   A = sum_j c_j.c0 col_j,  B = sum_j c_j.c1 col_j   (two BASE-field tables)
+// and their evaluations at the sumcheck's point follow from one read-only pass afterwards (host/main_constraints.cpp).  Two kernels:
+// the combinations of many groups in one launch, and the evaluations of many base-field tables at prefixes of one point in one launch.
+// Both stream every column once: HBM-bound (18 VALU instructions per 8 bytes).
+// ------------------------------------------------------------------------------------------------
+struct LinGroup {
+    const uint64_t* const* cols;  // device array of the group's column tables
+    const uint64_t* coeffs;       // two words per column (device)
+    uint64_t *out0, *out1;
+    uint32_t n_cols, log_rows, wg_begin, pad;
+};
+constexpr unsigned LIN_TILE = 2 * NT;  // rows per workgroup: two per lane (16-byte loads)
+__global__ void __launch_bounds__(NT) k_lincomb_base(const LinGroup* __restrict__ groups, int n_groups) {
+    int g = 0;
+    {   // the group of this workgroup (groups are sorted by wg_begin): binary search, wave-uniform
+        int lo = 0, hi = n_groups - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (groups[mid].wg_begin <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        g = lo;
+    }
+    const LinGroup G = groups[g];
+    const size_t rows = (size_t)1 << G.log_rows;
+    const size_t r0 = (size_t)(blockIdx.x - G.wg_begin) * LIN_TILE + 2 * threadIdx.x;
+    if (r0 >= rows) return;
+    Acc5 a00{0, 0, 0, 0, 0}, a01{0, 0, 0, 0, 0}, a10{0, 0, 0, 0, 0}, a11{0, 0, 0, 0, 0};
+    if (rows == 1) {
+        for (uint32_t j = 0; j < G.n_cols; j++) {
+            const uint64_t v = G.cols[j][0];
+            acc5_add(a00, mul_wide(G.coeffs[2 * j], v));
+            acc5_add(a01, mul_wide(G.coeffs[2 * j + 1], v));
+        }
+        G.out0[0] = acc5_reduce(a00);
+        G.out1[0] = acc5_reduce(a01);
+        return;
+    }
+    uint32_t j = 0;
+    for (; j + 4 <= G.n_cols; j += 4) {  // four columns in flight
+        ulonglong2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const ulonglong2*>(G.cols[j + u] + r0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t c0 = G.coeffs[2 * (j + u)], c1 = G.coeffs[2 * (j + u) + 1];
+            acc5_add(a00, mul_wide(c0, v[u].x));
+            acc5_add(a01, mul_wide(c1, v[u].x));
+            acc5_add(a10, mul_wide(c0, v[u].y));
+            acc5_add(a11, mul_wide(c1, v[u].y));
+        }
+    }
+    for (; j < G.n_cols; j++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(G.cols[j] + r0);
+        const uint64_t c0 = G.coeffs[2 * j], c1 = G.coeffs[2 * j + 1];
+        acc5_add(a00, mul_wide(c0, v.x));
+        acc5_add(a01, mul_wide(c1, v.x));
+        acc5_add(a10, mul_wide(c0, v.y));
+        acc5_add(a11, mul_wide(c1, v.y));
+    }
+    *reinterpret_cast<ulonglong2*>(G.out0 + r0) = ulonglong2{acc5_reduce(a00), acc5_reduce(a10)};
+    *reinterpret_cast<ulonglong2*>(G.out1 + r0) = ulonglong2{acc5_reduce(a01), acc5_reduce(a11)};
+}
+
+extern "C" int ceno_hip_lincomb_base_batch(ceno_hip_ctx* ctx, int n_groups, const uint32_t* group_offsets, ceno_hip_mle* const* cols, const uint64_t* coeffs,
+                                           ceno_hip_stream s, ceno_hip_mle** out0, ceno_hip_mle** out1) {
+    CHECK_ARG(ctx, n_groups >= 0 && (n_groups == 0 || (group_offsets && cols && coeffs && out0 && out1)), "lincomb batch: NULL argument");
+    if (n_groups == 0) return 0;
+    hipStream_t st = ctx_stream(ctx, s);
+    const size_t n_cols = group_offsets[n_groups];
+    std::vector<LinGroup> desc((size_t)n_groups);
+    size_t wgs = 0;
+    for (int g = 0; g < n_groups; g++) {
+        out0[g] = out1[g] = nullptr;
+        const uint32_t b = group_offsets[g], e = group_offsets[g + 1];
+        CHECK_ARG(ctx, e > b, "lincomb batch: group %d is empty", g);
+        const int nv = cols[b] ? cols[b]->num_vars : -1;
+        for (uint32_t j = b; j < e; j++)
+            CHECK_ARG(ctx, cols[j] && !cols[j]->is_ext && cols[j]->num_vars == nv, "lincomb batch: the columns of group %d are base-field tables of one size", g);
+        desc[(size_t)g].n_cols = e - b;
+        desc[(size_t)g].log_rows = (uint32_t)nv;
+        desc[(size_t)g].wg_begin = (uint32_t)wgs;
+        wgs += (((size_t)1 << nv) + LIN_TILE - 1) / LIN_TILE;
+    }
+    CHECK_ARG(ctx, wgs < ((size_t)1 << 31), "lincomb batch too large");
+    int rc = 0;
+    for (int g = 0; g < n_groups && !rc; g++) {
+        rc = ceno_hip_mle_alloc(ctx, (int)desc[(size_t)g].log_rows, 0, &out0[g]);
+        if (!rc) rc = ceno_hip_mle_alloc(ctx, (int)desc[(size_t)g].log_rows, 0, &out1[g]);
+    }
+    const size_t bytes = (size_t)n_groups * sizeof(LinGroup) + n_cols * (sizeof(uint64_t*) + 2 * sizeof(uint64_t));
+    void *scratch = nullptr, *hb = nullptr, *db = nullptr;
+    if (!rc) rc = ctx_alloc(ctx, bytes, &scratch);
+    if (!rc) rc = ctx_pinned_alloc(ctx, bytes, &hb, &db);
+    auto fail = [&](int code) {
+        for (int g = 0; g < n_groups; g++) {
+            if (out0[g]) { ceno_hip_mle_free(ctx, out0[g]); out0[g] = nullptr; }
+            if (out1[g]) { ceno_hip_mle_free(ctx, out1[g]); out1[g] = nullptr; }
+        }
+        if (scratch) ctx_free_on(ctx, scratch, st);
+        if (hb) ctx_pinned_free(ctx, hb);
+        return code;
+    };
+    if (rc) return fail(rc);
+    // one block: descriptors | column pointers | coefficients
+    LinGroup* d_desc = (LinGroup*)scratch;
+    const uint64_t** d_cols = reinterpret_cast<const uint64_t**>(d_desc + n_groups);
+    uint64_t* d_coeffs = reinterpret_cast<uint64_t*>(d_cols + n_cols);
+    char* h = (char*)hb;
+    const uint64_t** h_cols = reinterpret_cast<const uint64_t**>(h + (size_t)n_groups * sizeof(LinGroup));
+    for (size_t j = 0; j < n_cols; j++) h_cols[j] = cols[j]->d;
+    memcpy(h_cols + n_cols, coeffs, n_cols * 2 * sizeof(uint64_t));
+    for (int g = 0; g < n_groups; g++) {
+        LinGroup& G = desc[(size_t)g];
+        G.cols = d_cols + group_offsets[g];
+        G.coeffs = d_coeffs + 2 * (size_t)group_offsets[g];
+        G.out0 = out0[g]->d;
+        G.out1 = out1[g]->d;
+    }
+    memcpy(h, desc.data(), (size_t)n_groups * sizeof(LinGroup));
+    hipError_t e = hipMemcpyAsync(scratch, hb, bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (covers the copy only: the staging block goes back to the pool)
+    ctx_pinned_free(ctx, hb);
+    hb = nullptr;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_lincomb_base, dim3((unsigned)wgs), dim3(NT), 0, st, d_desc, n_groups);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        fail(0);
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "lincomb batch: %s", hipGetErrorString(e));
+    }
+    ctx_free_on(ctx, scratch, st);  // read by the queued kernel: stream-ordered reuse
+    return 0;
+}
+
+struct EvalCol {
+    const uint64_t* col;
+    const E2 *lo, *hi;  // eq over the first a variables / over the rest (of THIS table's prefix of the point)
+    uint32_t a, n_hi, wg_begin, n_chunks;
+};
+constexpr unsigned EVAL_A = 10, EVAL_HC = 64;  // entries per row of the split (four per lane), rows per workgroup
+__global__ void __launch_bounds__(NT) k_eval_cols(const EvalCol* __restrict__ cols, int n_cols, E2* __restrict__ partials) {
+    __shared__ E2 smem[NT / 64];
+    int c = 0;
+    {
+        int lo = 0, hi = n_cols - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cols[mid].wg_begin <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        c = lo;
+    }
+    const EvalCol C = cols[c];
+    const unsigned h0 = (blockIdx.x - C.wg_begin) * EVAL_HC, h1 = min(h0 + EVAL_HC, C.n_hi);
+    E2 acc[1] = {e2_zero()};
+    if (C.a == EVAL_A) {
+        // sum_h hi[h] col[h, e] per owned entry e, unreduced (hi[h] is wave-uniform: scalar registers), then once  x lo[e]
+        Acc5 w[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; m++) w[m][0] = w[m][1] = Acc5{0, 0, 0, 0, 0};
+        const uint64_t* base = C.col + 2 * threadIdx.x;
+        unsigned h = h0;
+        for (; h + 2 <= h1; h += 2) {
+            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)h << EVAL_A));
+            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)h << EVAL_A) + 512);
+            const ulonglong2 v2 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)(h + 1) << EVAL_A));
+            const ulonglong2 v3 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)(h + 1) << EVAL_A) + 512);
+            const E2 ha = C.hi[h], hb = C.hi[h + 1];
+            acc5_add(w[0][0], mul_wide(ha.c0, v0.x)); acc5_add(w[0][1], mul_wide(ha.c1, v0.x));
+            acc5_add(w[1][0], mul_wide(ha.c0, v0.y)); acc5_add(w[1][1], mul_wide(ha.c1, v0.y));
+            acc5_add(w[2][0], mul_wide(ha.c0, v1.x)); acc5_add(w[2][1], mul_wide(ha.c1, v1.x));
+            acc5_add(w[3][0], mul_wide(ha.c0, v1.y)); acc5_add(w[3][1], mul_wide(ha.c1, v1.y));
+            acc5_add(w[0][0], mul_wide(hb.c0, v2.x)); acc5_add(w[0][1], mul_wide(hb.c1, v2.x));
+            acc5_add(w[1][0], mul_wide(hb.c0, v2.y)); acc5_add(w[1][1], mul_wide(hb.c1, v2.y));
+            acc5_add(w[2][0], mul_wide(hb.c0, v3.x)); acc5_add(w[2][1], mul_wide(hb.c1, v3.x));
+            acc5_add(w[3][0], mul_wide(hb.c0, v3.y)); acc5_add(w[3][1], mul_wide(hb.c1, v3.y));
+        }
+        for (; h < h1; h++) {
+            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)h << EVAL_A));
+            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(base + ((size_t)h << EVAL_A) + 512);
+            const E2 ha = C.hi[h];
+            acc5_add(w[0][0], mul_wide(ha.c0, v0.x)); acc5_add(w[0][1], mul_wide(ha.c1, v0.x));
+            acc5_add(w[1][0], mul_wide(ha.c0, v0.y)); acc5_add(w[1][1], mul_wide(ha.c1, v0.y));
+            acc5_add(w[2][0], mul_wide(ha.c0, v1.x)); acc5_add(w[2][1], mul_wide(ha.c1, v1.x));
+            acc5_add(w[3][0], mul_wide(ha.c0, v1.y)); acc5_add(w[3][1], mul_wide(ha.c1, v1.y));
+        }
+        const E2* lo = C.lo + 2 * threadIdx.x;
+        acc[0] = E2{acc5_reduce(w[0][0]), acc5_reduce(w[0][1])} * lo[0] + E2{acc5_reduce(w[1][0]), acc5_reduce(w[1][1])} * lo[1] +
+                 E2{acc5_reduce(w[2][0]), acc5_reduce(w[2][1])} * lo[512] + E2{acc5_reduce(w[3][0]), acc5_reduce(w[3][1])} * lo[513];
+    } else {
+        // a table of fewer than 2^10 rows: one row of the split, entry by entry
+        const size_t len = (size_t)1 << C.a;
+        for (size_t e = threadIdx.x; e < len; e += NT) acc[0] = acc[0] + e2_mul_base(C.lo[e] * C.hi[0], C.col[e]);
+    }
+    red::block_sum<1, NT>(acc, smem);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+// one wave per table: the sum of its workgroups' partials
+__global__ void __launch_bounds__(64) k_eval_cols_finish(const EvalCol* __restrict__ cols, const E2* __restrict__ partials, E2* __restrict__ out) {
+    const EvalCol C = cols[blockIdx.x];
+    E2 acc = e2_zero();
+    for (unsigned k = threadIdx.x; k < C.n_chunks; k += 64) acc = acc + partials[C.wg_begin + k];
+    acc = red::wave_sum(acc);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
+extern "C" int ceno_hip_mle_evaluate_prefix_batch(ceno_hip_ctx* ctx, int n, ceno_hip_mle* const* cols, const uint64_t* point, int point_len, ceno_hip_stream s,
+                                                  uint64_t* out) {
+    CHECK_ARG(ctx, n >= 0 && (n == 0 || (cols && out && (point || point_len == 0))), "evaluate batch: NULL argument");
+    CHECK_ARG(ctx, point_len >= 0 && point_len <= 40, "evaluate batch: point of %d elements", point_len);
+    if (n == 0) return 0;
+    hipStream_t st = ctx_stream(ctx, s);
+    // half tables per distinct table size (every table is evaluated at the first num_vars elements of the point)
+    size_t half_off[41];
+    bool have[41] = {};
+    size_t half_total = 0, wgs = 0;
+    std::vector<EvalCol> desc((size_t)n);
+    for (int j = 0; j < n; j++) {
+        CHECK_ARG(ctx, cols[j] && !cols[j]->is_ext && cols[j]->num_vars <= point_len, "evaluate batch: table %d is not a base-field table of at most %d variables", j, point_len);
+        const int nv = cols[j]->num_vars;
+        const int a = std::min(nv, (int)EVAL_A);
+        if (!have[nv]) {
+            have[nv] = true;
+            half_off[nv] = half_total;
+            half_total += ((size_t)1 << a) + ((size_t)1 << (nv - a));
+        }
+        EvalCol& C = desc[(size_t)j];
+        C.col = cols[j]->d;
+        C.a = (uint32_t)a;
+        C.n_hi = 1u << (nv - a);
+        C.wg_begin = (uint32_t)wgs;
+        C.n_chunks = a == (int)EVAL_A ? (C.n_hi + EVAL_HC - 1) / EVAL_HC : 1u;
+        wgs += C.n_chunks;
+    }
+    CHECK_ARG(ctx, wgs < ((size_t)1 << 31), "evaluate batch too large");
+    // one block: half tables | partials | results | descriptors | arrival counter of k_eq_halves
+    const size_t bytes = (half_total + wgs + (size_t)n) * sizeof(E2) + (size_t)n * sizeof(EvalCol) + 64;
+    void *scratch = nullptr, *hb = nullptr, *db = nullptr;
+    TRY(ctx_alloc(ctx, bytes, &scratch));
+    int rc = ctx_pinned_alloc(ctx, (size_t)n * (sizeof(EvalCol) + sizeof(E2)), &hb, &db);  // descriptors out, results back
+    if (rc) {
+        ctx_free_on(ctx, scratch, st);
+        return rc;
+    }
+    E2* halves = (E2*)scratch;
+    E2* partials = halves + half_total;
+    E2* d_out = partials + wgs;
+    EvalCol* d_desc = reinterpret_cast<EvalCol*>(d_out + n);
+    unsigned* counter = reinterpret_cast<unsigned*>(d_desc + n);
+    for (int j = 0; j < n; j++) {
+        EvalCol& C = desc[(size_t)j];
+        C.lo = halves + half_off[cols[j]->num_vars];
+        C.hi = C.lo + ((size_t)1 << C.a);
+    }
+    memcpy(hb, desc.data(), (size_t)n * sizeof(EvalCol));
+    hipError_t e = hipMemcpyAsync(d_desc, hb, (size_t)n * sizeof(EvalCol), hipMemcpyHostToDevice, st);
+    PointArg pt;
+    for (int k = 0; k < point_len; k++) pt.r[k] = E2{point[2 * k], point[2 * k + 1]};
+    for (int nv = 0; nv <= point_len && e == hipSuccess; nv++) {
+        if (!have[nv]) continue;
+        const int a = std::min(nv, (int)EVAL_A), b = nv - a;
+        E2* lo = halves + half_off[nv];
+        hipLaunchKernelGGL(k_eq_halves, dim3(grid_for(((size_t)1 << a) + ((size_t)1 << b), NT, MAXB)), dim3(NT), 0, st, lo, a, lo + ((size_t)1 << a), b, pt, counter);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_eval_cols, dim3((unsigned)wgs), dim3(NT), 0, st, d_desc, n, partials);
+        hipLaunchKernelGGL(k_eval_cols_finish, dim3((unsigned)n), dim3(64), 0, st, d_desc, partials, d_out);
+        e = hipGetLastError();
+    }
+    char* h_res = (char*)hb + (size_t)n * sizeof(EvalCol);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_res, d_out, (size_t)n * sizeof(E2), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) memcpy(out, h_res, (size_t)n * sizeof(E2));
+    ctx_pinned_free(ctx, hb);
+    ctx_free_on(ctx, scratch, st);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "evaluate batch: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, int n_fix, ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, m && out && (point || n_fix == 0), "NULL argument");
     CHECK_ARG(ctx, n_fix >= 0 && n_fix <= m->num_vars, "n_fix %d out of range", n_fix);

@@ -174,8 +174,112 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         }
         alpha_start += J.n_exprs;
     }
-    const int n_terms = (int)toff.size() - 1;
-    if (n_terms == 0) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "all term scalars are zero"); }
+    const int n_terms_all = (int)toff.size() - 1;
+    if (n_terms_all == 0) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "all term scalars are zero"); }
+    // ---- columns the batch reads only LINEARLY.  The monomial form of a chip is dominated by `selector x column` terms — the records are
+    // RLCs of columns (zerocheck_layer.rs:118-140, instructions.rs:48-83) — and most columns occur in nothing else.  For such columns
+    //     sum_j c_j sel(x) col_j(x) = sel(x) A(x) + X sel(x) B(x),   A = sum_j c_j.c0 col_j,  B = sum_j c_j.c1 col_j
+    // with two BASE-field tables per selector built in one streaming pass (ceno_hip_lincomb_base_batch): the sumcheck then folds two tables
+    // where it folded dozens, and the evaluations of the columns themselves at the sumcheck's point — which the proof carries — come from one
+    // read-only pass afterwards (ceno_hip_mle_evaluate_prefix_batch).  Messages and evaluations are the same field elements either way.
+    // CENO_PROVER_MAIN_LINCOMB: smallest group that is combined (default 3; 0: off).  Read per call. ----
+    const int lin_min = getenv("CENO_PROVER_MAIN_LINCOMB") ? atoi(getenv("CENO_PROVER_MAIN_LINCOMB")) : 3;
+    std::vector<int> plan_of(mles.size(), 0);          // index in the sumcheck's table list, -1: a combined column
+    std::vector<ceno_hip_mle*> plan_mles;
+    std::vector<uint64_t> p_coeffs;
+    std::vector<uint32_t> p_toff{0}, p_tidx;
+    std::vector<int> removed;                          // global ids of the combined columns
+    {
+        const size_t nm = mles.size();
+        std::vector<char> is_ext(nm), other(nm, 0);
+        for (size_t j = 0; j < nm; j++) is_ext[j] = (char)ceno_hip_mle_is_ext(mles[j]);
+        std::vector<int> lin_sel(n_terms_all, -1), lin_col(n_terms_all, -1);
+        for (int t = 0; t < n_terms_all; t++) {
+            int n_ext = 0, n_base = 0, sel = -1, col = -1;
+            for (uint32_t k = toff[t]; k < toff[t + 1]; k++) {
+                if (is_ext[tidx[k]]) n_ext++, sel = (int)tidx[k];
+                else n_base++, col = (int)tidx[k];
+            }
+            if (lin_min > 0 && n_ext == 1 && n_base == 1 && mle_nv[sel] == mle_nv[col]) {
+                lin_sel[t] = sel;
+                lin_col[t] = col;
+            } else {
+                for (uint32_t k = toff[t]; k < toff[t + 1]; k++) other[tidx[k]] = 1;
+            }
+        }
+        // groups per selector; a column leaves the plan only if EVERY selector it stands under combines it
+        std::map<int, std::map<int, E2>> by_sel;  // selector -> column -> summed coefficient
+        for (int t = 0; t < n_terms_all; t++) {
+            if (lin_sel[t] < 0 || other[lin_col[t]]) continue;
+            E2& c = by_sel[lin_sel[t]].emplace(lin_col[t], gl::e2_zero()).first->second;
+            c = c + E2{coeffs[2 * t], coeffs[2 * t + 1]};
+        }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (auto it = by_sel.begin(); it != by_sel.end();) {
+                if ((int)it->second.size() >= lin_min) { ++it; continue; }
+                for (auto& kv : it->second) other[kv.first] = 1;  // these columns stay: no other selector may drop them either
+                it = by_sel.erase(it);
+                changed = true;
+            }
+            for (auto& g : by_sel)
+                for (auto it = g.second.begin(); it != g.second.end();)
+                    if (other[it->first]) it = g.second.erase(it), changed = true;
+                    else ++it;
+        }
+        std::vector<char> gone(nm, 0);
+        std::vector<uint32_t> goff{0};
+        std::vector<ceno_hip_mle*> gcols;
+        std::vector<uint64_t> gco;
+        std::vector<int> gsel;
+        for (auto& g : by_sel) {
+            gsel.push_back(g.first);
+            for (auto& kv : g.second) {
+                gone[kv.first] = 1;
+                gcols.push_back(mles[kv.first]);
+                gco.push_back(kv.second.c0);
+                gco.push_back(kv.second.c1);
+            }
+            goff.push_back((uint32_t)gcols.size());
+        }
+        std::vector<ceno_hip_mle*> la(gsel.size(), nullptr), lb(gsel.size(), nullptr);
+        if (!gsel.empty()) {
+            int rc = ceno_hip_lincomb_base_batch(ctx, (int)gsel.size(), goff.data(), gcols.data(), gco.data(), s, la.data(), lb.data());
+            if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+            for (size_t g = 0; g < gsel.size(); g++) {
+                owned.push_back(la[g]);
+                owned.push_back(lb[g]);
+            }
+        }
+        for (size_t j = 0; j < nm; j++) {
+            if (gone[j]) {
+                plan_of[j] = -1;
+                removed.push_back((int)j);
+            } else {
+                plan_of[j] = (int)plan_mles.size();
+                plan_mles.push_back(mles[j]);
+            }
+        }
+        for (int t = 0; t < n_terms_all; t++) {
+            if (lin_col[t] >= 0 && gone[lin_col[t]]) continue;
+            p_coeffs.push_back(coeffs[2 * t]);
+            p_coeffs.push_back(coeffs[2 * t + 1]);
+            for (uint32_t k = toff[t]; k < toff[t + 1]; k++) p_tidx.push_back((uint32_t)plan_of[tidx[k]]);
+            p_toff.push_back((uint32_t)p_tidx.size());
+        }
+        for (size_t g = 0; g < gsel.size(); g++) {
+            for (int half = 0; half < 2; half++) {  // sel x A + X sel x B
+                p_coeffs.push_back(half == 0 ? 1 : 0);
+                p_coeffs.push_back(half == 0 ? 0 : 1);
+                p_tidx.push_back((uint32_t)plan_of[gsel[g]]);
+                p_tidx.push_back((uint32_t)plan_mles.size());
+                p_toff.push_back((uint32_t)p_tidx.size());
+                plan_mles.push_back(half == 0 ? la[g] : lb[g]);
+            }
+        }
+        for (int& e : eq_idx) e = plan_of[e];
+    }
+    const int n_terms = (int)p_toff.size() - 1;
     // ---- common-factor plan (the role of CommonTermPlan in the reference's GPU arm, scheme/gpu/mod.rs:2811-2962, built
     // there from shared witness prefixes, gkr_iop/src/gkr/layer/zerocheck_layer.rs:389-513).  Any factoring gives the same
     // messages; here terms are grouped by their EXTENSION-field factors — the selectors (eq tables) that every constraint of
@@ -189,14 +293,14 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         std::vector<std::vector<uint32_t>> base_part(n_terms);
         for (int t = 0; t < n_terms; t++) {
             std::vector<uint32_t> ext_part;
-            for (uint32_t k = toff[t]; k < toff[t + 1]; k++) (ceno_hip_mle_is_ext(mles[tidx[k]]) ? ext_part : base_part[t]).push_back(tidx[k]);
+            for (uint32_t k = p_toff[t]; k < p_toff[t + 1]; k++) (ceno_hip_mle_is_ext(plan_mles[p_tidx[k]]) ? ext_part : base_part[t]).push_back(p_tidx[k]);
             if (ext_part.size() == 1 && base_part[t].empty()) {
                 // selector x constant (the constants of a chip's record RLCs, zerocheck_layer.rs:118-140): a term of the selector's group
                 // with no factor of its own — left ungrouped it would read the selector as an ordinary factor and take the whole chip off
                 // the eq-factored rounds
                 by_ext[ext_part].push_back(t);
             } else if (ext_part.empty() || base_part[t].empty()) {
-                base_part[t].assign(tidx.begin() + toff[t], tidx.begin() + toff[t + 1]);  // ungrouped: full product
+                base_part[t].assign(p_tidx.begin() + p_toff[t], p_tidx.begin() + p_toff[t + 1]);  // ungrouped: full product
             } else {
                 std::sort(ext_part.begin(), ext_part.end());
                 by_ext[ext_part].push_back(t);
@@ -214,9 +318,9 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         }
     }
     ceno_hip_sumcheck_plan plan{};
-    plan.num_mles = (int)mles.size();
+    plan.num_mles = (int)plan_mles.size();
     plan.num_terms = n_terms;
-    plan.term_coeffs = coeffs.data();
+    plan.term_coeffs = p_coeffs.data();
     plan.term_offsets = r_toff.data();
     plan.term_mle_idx = r_tidx.data();
     plan.num_groups = (int)g_toff.size() - 1;
@@ -226,15 +330,36 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     plan.common_mle_idx = g_cidx.data();
     plan.max_num_vars = max_nv;
     plan.max_degree = max_deg;
-    std::vector<uint64_t> evals(2 * mles.size());
+    std::vector<uint64_t> evals(2 * mles.size()), p_evals(2 * plan_mles.size());
     const double t_plan = dbg ? now_us() : 0;
-    int rc = ceno_prover_sumcheck_prove_eq(ctx, mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
-                                           out_msgs, out_global_rt, evals.data());   // cpu/mod.rs:1332-1337
-    if (dbg) fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan %.0f us, sumcheck %.0f us\n", t_sel - t_start, t_plan - t_sel, now_us() - t_plan);
+    int rc = ceno_prover_sumcheck_prove_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
+                                           out_msgs, out_global_rt, p_evals.data());   // cpu/mod.rs:1332-1337
+    const double t_sc = dbg ? now_us() : 0;
     if (rc) { cleanup(); return rc; }
+    // the evaluations of every table of the batch at (its prefix of) the sumcheck's point: the sumcheck's own for the tables it folded, one
+    // read-only pass for the combined columns
+    for (size_t j = 0; j < mles.size(); j++)
+        if (plan_of[j] >= 0) {
+            evals[2 * j] = p_evals[2 * (size_t)plan_of[j]];
+            evals[2 * j + 1] = p_evals[2 * (size_t)plan_of[j] + 1];
+        }
+    if (!removed.empty()) {
+        std::vector<ceno_hip_mle*> rc_cols(removed.size());
+        std::vector<uint64_t> rc_out(2 * removed.size());
+        for (size_t k = 0; k < removed.size(); k++) rc_cols[k] = mles[(size_t)removed[k]];
+        rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), out_global_rt, max_nv, s, rc_out.data());
+        if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        for (size_t k = 0; k < removed.size(); k++) {
+            evals[2 * (size_t)removed[k]] = rc_out[2 * k];
+            evals[2 * (size_t)removed[k] + 1] = rc_out[2 * k + 1];
+        }
+    }
+    if (dbg)
+        fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan + %zu combined columns %.0f us, sumcheck %.0f us, their evaluations %.0f us\n",
+                t_sel - t_start, removed.size(), t_plan - t_sel, t_sc - t_plan, now_us() - t_sc);
     // ---- final claim by the front-load rule and the claimed sum recovered backwards (cpu/mod.rs:1338-1360,1393-1413) ----
     E2 final_claim = gl::e2_zero();
-    for (int t = 0; t < n_terms; t++) {
+    for (int t = 0; t < n_terms_all; t++) {
         E2 v{coeffs[2 * t], coeffs[2 * t + 1]};
         for (uint32_t k = toff[t]; k < toff[t + 1]; k++) {
             const int j = (int)tidx[k];

@@ -132,6 +132,17 @@ int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed
 int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, uint64_t* out2, ceno_hip_stream s);
 /* fix_variables (low variables first): out has num_vars - n_fix variables, always ext */
 int ceno_hip_mle_fix_variables(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, int n_fix, ceno_hip_stream s, ceno_hip_mle** out);
+/* MultilinearExtension::evaluate for n base-field tables in one pass: out[2 j ..] = cols[j](point[0 .. num_vars_j)), every table at the
+ * prefix of ONE point of point_len >= num_vars_j ext elements (the final evaluations of a batched sumcheck whose smaller tables bind the
+ * first variables, ceno_zkvm/src/scheme/cpu/mod.rs:1338-1361).  `out` is host memory; returns when it is filled. */
+int ceno_hip_mle_evaluate_prefix_batch(ceno_hip_ctx* ctx, int n, ceno_hip_mle* const* cols, const uint64_t* point, int point_len, ceno_hip_stream s,
+                                       uint64_t* out);
+/* linear combinations of base-field columns with ext coefficients, n_groups at once (group g = cols[group_offsets[g] .. group_offsets[g+1]),
+ * one table size per group): out0[g][x] = sum_j coeffs[2j] cols[j][x],  out1[g][x] = sum_j coeffs[2j+1] cols[j][x]  (mod p), i.e.
+ * sum_j c_j col_j = out0 + X out1 as two BASE-field tables.  The monomial form of a chip's record RLCs (selector x column for most
+ * columns, gkr_iop/src/gkr/layer/zerocheck_layer.rs:118-140) enters prove_batched_main_constraints as two tables per selector this way. */
+int ceno_hip_lincomb_base_batch(ceno_hip_ctx* ctx, int n_groups, const uint32_t* group_offsets, ceno_hip_mle* const* cols, const uint64_t* coeffs,
+                                ceno_hip_stream s, ceno_hip_mle** out0, ceno_hip_mle** out1);
 
 /* ------------------------------------------------------------------------------------------------
  * eq tables and selectors  (build_mle_as_ceno / ordered_sparse_selector_gpu,

@@ -564,14 +564,18 @@ def _wide_oracle_plan(chips, gch, pows):
 
 @pytest.mark.parametrize("max_nv,switches", [(13, {}), (13, {"CENO_HIP_GEN_EQF": "0"}), (13, {"CENO_HIP_GEN_SPLIT": "0"}), (14, {"CENO_HIP_GEN_MIN_LOG": "4"}),
                                              (13, {"CENO_HIP_GEN_BY_DEGREE": "2"}), (14, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_GEN_MIN_LOG": "4"}),
-                                             (14, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_EQ_DIRECT0": "0"}), (20, {}), (20, {"CENO_HIP_GEN_BY_DEGREE": "0"})])
+                                             (14, {"CENO_HIP_GEN_BY_DEGREE": "2", "CENO_HIP_EQ_DIRECT0": "0"}), (20, {}), (20, {"CENO_HIP_GEN_BY_DEGREE": "0"}),
+                                             (13, {"CENO_PROVER_MAIN_LINCOMB": "0"}), (14, {"CENO_PROVER_MAIN_LINCOMB": "1", "CENO_HIP_GEN_MIN_LOG": "4"}),
+                                             (20, {"CENO_PROVER_MAIN_LINCOMB": "0"})])
 def test_wide_batched_main_constraints_match_the_oracle(dev, prover, monkeypatch, max_nv, switches):
     """the batched main sumcheck over 48 WIDE chips (22..96 base columns, 1..3 Prefix selectors, selector x column monomials for every
     column, selector x constant, a tail of degree 3..5 products): every message, challenge and final evaluation equals the oracle prover's
     (max_nv <= 14: from round 0; 20: verifier + independent evaluations + the last 12 rounds), with the eq-factored rounds, with the
     declarations ignored (generic rounds), without the column-block split of wide components, with the component tables on from 2^4
     rows so that the smallest chips take the same path as the largest, and with the per-degree launches of the large rounds (column blocks of
-    selector x column terms on the kernel of length 3, the products on theirs) in EVERY round, with the direct and the staged first round"""
+    selector x column terms on the kernel of length 3, the products on theirs) in EVERY round, with the direct and the staged first round;
+    with the columns that are read only linearly combined into two tables per selector and evaluated afterwards (the default), with every
+    such column kept in the sumcheck (CENO_PROVER_MAIN_LINCOMB=0), and with groups of a single column combined as well (=1)"""
     from ceno_amd import synthetic
 
     for k, v in switches.items():
@@ -629,6 +633,67 @@ def test_wide_batched_main_constraints_match_the_oracle(dev, prover, monkeypatch
     for ch in chips:
         for m in ch["cols"]:
             m.free()
+
+
+def test_linear_only_columns_are_combined_and_evaluated_afterwards(dev, prover, monkeypatch):
+    """prove_batched_main_constraints with columns that occur in `selector x column` monomials only (host/main_constraints.cpp): a column
+    under ONE selector, under TWO selectors (it leaves the plan only if both combine it), one that also stands in a product (it stays), a
+    selector with fewer linear columns than the threshold (its columns stay, and so does a column it shares with a larger group), several
+    monomials of one column under one selector (coefficients add), chips of 2^3 .. 2^12 rows, a chip without any.  The proof equals the
+    oracle prover's word for word with the combination on (default threshold 3, threshold 1) and off."""
+    gch = [(11, 22), (33, 44)]
+    w = 9
+    cases = [  # (num_vars, selectors [(kind, offset, n)], terms over columns 0..w-1 and selectors w, w+1, ...)
+        (12, [(po.SEL_PREFIX, 0, 4000), (po.SEL_PREFIX, 5, 3000)],
+         [[w, 0], [w, 1], [w, 2], [w, 3], [w, 3], [w + 1, 2], [w + 1, 4], [w + 1, 5], [w + 1, 6], [w, 7, 8], [w, 7], [w], [w + 1]]),
+        (10, [(po.SEL_PREFIX, 0, 1000), (po.SEL_WHOLE, 0, 0)],
+         [[w, 0], [w, 1], [w, 2], [w, 3], [w + 1, 3], [w + 1, 4], [w, 5, 6], [w, 7, 8, 5]]),   # selector w+1: two linear columns, one shared
+        (3, [(po.SEL_PREFIX, 1, 6)], [[w, j] for j in range(w)] + [[w]]),
+        (11, [(po.SEL_PREFIX, 0, 2047)], [[w, j, (j + 1) % w] for j in range(w)]),              # no linear column at all
+        (9, [(po.SEL_ORDERED_SPARSE, 0, 100, (0, 2), 2)], [[w, j] for j in range(5)] + [[w, 5, 6]]),  # a selector that is no eq table
+    ]
+    jobs, tabs, terms_all, scal_all, nvs = [], [], [], [], []
+    for c, (nv, sels, terms) in enumerate(cases):
+        cols = [po.rand_base(1 << nv, 8100 + 31 * c + j) for j in range(w)]
+        point = po.rand_ext(nv, 600 + c)
+        sel_t = []
+        for sid, sl in enumerate(sels):
+            kind, off, n = sl[0], sl[1], sl[2]
+            sp, snv = (tuple(sl[3]), sl[4]) if len(sl) > 3 else ((), 0)
+            sel_t.append((kind, off, n, sid, sp, snv, point))
+        scalars = [[((7 + 5 * t + c, 2 + t), [2 + (t % 2)])] + ([((3 + t, 0), [t % 2, 2])] if t % 4 == 1 else []) for t in range(len(terms))]
+        jobs.append(dict(num_vars=nv, mles=[dev.upload(t) for t in cols] + [None] * len(sels), n_witin=w, n_fixed=0, n_structural=len(sels),
+                         selectors=sel_t, n_exprs=2, max_degree=max(len(t) for t in terms), terms=terms, scalars=scalars))
+        start = len(nvs)
+        nvs += [nv] * (w + len(sels))
+        tabs += cols + [po.selector_compute(k, point, off, n, sp, snv) for (k, off, n, _sid, sp, snv, _pt) in sel_t]
+        terms_all += [[start + j for j in t] for t in terms]
+        scal_all.append(scalars)
+    max_nv, D = max(nvs), max(j["max_degree"] for j in jobs)
+    t2 = po.StubTranscript(5)
+    t2.append_label(b"combine subset evals")
+    a = t2.sample_ext()
+    pows = [e2_pow(a, i) for i in range(2 * len(jobs))]
+    coeffs = []
+    for c, sc in enumerate(scal_all):
+        coeffs += oracle_scalars(sc, gch + pows[2 * c: 2 * c + 2])
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext(coeffs), terms_all, max_nv, D, t2)
+    for mode in (None, "1", "0", "4"):
+        if mode is None:
+            monkeypatch.delenv("CENO_PROVER_MAIN_LINCOMB", raising=False)
+        else:
+            monkeypatch.setenv("CENO_PROVER_MAIN_LINCOMB", mode)
+        claimed, msgs, rt, evals = prover.prove_batched_main_constraints(dev, jobs, gch, prover.Transcript.stub(5))
+        assert np.array_equal(omsgs, msgs) and np.array_equal(ochal, rt) and np.array_equal(ofin, evals), mode
+        vpoint, expected = po.sumcheck_verify(claimed, msgs, po_stub_after_alpha())
+        assert np.array_equal(vpoint, rt)
+
+
+def po_stub_after_alpha():
+    vt = po.StubTranscript(5)
+    vt.append_label(b"combine subset evals")
+    vt.sample_ext()
+    return vt
 
 
 @pytest.mark.parametrize("max_nv,n_chips,reps", [(18, 2, 60), (14, 48, 40)])

@@ -103,6 +103,48 @@ def test_evaluate_and_fix_variables(dev, nv, is_ext):
         assert np.array_equal(got, exp)
 
 
+def test_evaluate_prefix_batch_matches_single_evaluations(dev):
+    """base-field tables of 2^0 .. 2^17 rows at prefixes of one point, one pass (the final evaluations of the columns a batched main
+    sumcheck read only linearly): every value equals the oracle's MultilinearExtension::evaluate and the single-table kernel's"""
+    nvs = [0, 1, 3, 9, 10, 10, 11, 13, 16, 17, 5]
+    pt = po.rand_ext(17, 4242)
+    tabs = [po.rand_base(1 << nv, 300 + k) for k, nv in enumerate(nvs)]
+    mles = [dev.upload(t) for t in tabs]
+    got = dev.evaluate_prefix_batch(mles, pt)
+    for k, nv in enumerate(nvs):
+        exp = po.mle_evaluate(tabs[k], pt[:nv]) if nv else (int(tabs[k][0]), 0)
+        assert tup(got[k]) == exp, (k, nv)
+        if nv:
+            assert mles[k].evaluate(pt[:nv]) == exp
+    assert dev.evaluate_prefix_batch([], pt).shape == (0, 2)
+    with pytest.raises(Exception):
+        dev.evaluate_prefix_batch([dev.upload(po.rand_base(1 << 18, 1))], pt)  # more variables than the point has
+
+
+def test_lincomb_base_batch_matches_integer_arithmetic(dev):
+    """sum_j c_j col_j over base-field columns with extension-field coefficients = two base-field tables (c0 part, c1 part); groups of
+    1 .. 9 columns and 2^0 .. 2^12 rows in one launch, coefficients at the edges of the field"""
+    shapes = [(0, 1), (0, 5), (1, 3), (5, 4), (9, 7), (10, 9), (12, 2), (11, 8)]
+    groups, coeffs, exp = [], [], []
+    for g, (nv, w) in enumerate(shapes):
+        tabs = [po.rand_base(1 << nv, 900 + 17 * g + j) for j in range(w)]
+        c = po.rand_ext(w, 70 + g)
+        c[0] = (P - 1, P - 1)
+        if w > 1:
+            c[1] = (0, 1)
+        e0 = [sum(int(c[j][0]) * int(tabs[j][x]) for j in range(w)) % P for x in range(1 << nv)]
+        e1 = [sum(int(c[j][1]) * int(tabs[j][x]) for j in range(w)) % P for x in range(1 << nv)]
+        groups.append([dev.upload(t) for t in tabs])
+        coeffs.append(c)
+        exp.append((np.array(e0, dtype=np.uint64), np.array(e1, dtype=np.uint64)))
+    outs = dev.lincomb_base_batch(groups, coeffs)
+    for g, (a, b) in enumerate(outs):
+        assert not a.is_ext and not b.is_ext and a.num_vars == shapes[g][0]
+        assert np.array_equal(a.download(), exp[g][0]) and np.array_equal(b.download(), exp[g][1]), g
+    with pytest.raises(Exception):
+        dev.lincomb_base_batch([[groups[0][0], groups[3][0]]], [po.rand_ext(2, 1)])  # two sizes in one group
+
+
 # ------------------------------------------------------------------------------------------
 # sumcheck: every round message, every challenge, every final evaluation
 # ------------------------------------------------------------------------------------------
