@@ -631,7 +631,10 @@ __device__ __forceinline__ void epilogue_eq(E2 (&acc)[D], const GenComp& C, cons
 }
 
 // (the first-round form at degree 4 sits four registers above the four-waves-per-SIMD line: the allocator is asked for it)
-constexpr int gen_eq_min_waves(int d, bool base0) { return base0 && d == 4 ? 4 : 1; }
+#ifndef GEN_EQ5_WAVES
+#define GEN_EQ5_WAVES 1
+#endif
+constexpr int gen_eq_min_waves(int d, bool base0) { return base0 && d == 4 ? 4 : (!base0 && d == 5 ? GEN_EQ5_WAVES : 1); }
 template <int D, bool BASE0>
 __global__ void __launch_bounds__(NT, gen_eq_min_waves(D, BASE0)) k_gen_eq(const GenComp* __restrict__ comps, int n_comps, E2 r, Epilogue ep, unsigned xch_off, GenEqArgs eqa) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];

@@ -16,9 +16,12 @@
 //   * the commitment's opening at a query: the rank that owns the row answers from its rows and its sub-tree (ceno_hip_mmcs_open_batch on
 //     local indices), every rank appends the top log2(world) levels from the replicated top tree; the answers travel by the small-message
 //     transport.
-// v1 limits: ONE commitment whose matrices all have the same height (a chip's trace, config #3); at least `world` codeword rows.
+// Limits: ONE commitment; matrices of any heights (the traces of a shard's chips: one batched codeword per height class, the sub-trees are
+// mixed-height trees over the row shards) as long as every codeword has at least `world` rows (shorter ones would join the replicated top
+// tree: refused).
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -42,7 +45,9 @@ struct DistOpen {
     ceno_hip_ctx* ctx;
     ceno_dist_comm* comm;
     int W, rank, k;
-    int n_mats, log_rows, log_blowup;
+    int n_mats, log_rows, log_blowup;          // log_rows: of the TALLEST trace
+    std::vector<int> log_rows_of;              // per matrix
+    std::vector<std::vector<int>> class_mats;  // height classes, tallest first; the matrices of a class in the caller's order (commit.cpp)
     const int* widths;                         // [m * W + g]
     const uint64_t* const* local_trace_cols;   // [m]: this rank's columns of matrix m, column-major, 2^log_rows rows
     const uint64_t* const* local_cw_rows;      // [m]: ALL columns of matrix m x (R / W) rows, column-major (ceno_dist_commit_traces_mmcs out_rows_dev)
@@ -68,18 +73,21 @@ struct DevBuf {
     uint64_t* ptr() const { return ceno_hip_mle_device_ptr(m); }
 };
 
-int hook_batch_codeword(void* self, int, int, const uint64_t* coeffs, uint64_t* dev_B, int log_h, int accumulate, ceno_hip_stream s) {
+int hook_batch_codeword(void* self, int, int cls, const uint64_t* coeffs, uint64_t* dev_B, int log_h, int accumulate, ceno_hip_stream s) {
     DistOpen& D = *static_cast<DistOpen*>(self);
-    if (accumulate) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: one height class only");
+    if (accumulate || cls < 0 || cls >= (int)D.class_mats.size())
+        return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: one commitment, one batched codeword per height class");
     const size_t R = (size_t)1 << log_h, Rl = R / (size_t)D.W;
     DevBuf loc{D.ctx};
     if (int rc = loc.alloc_words(2 * Rl)) return fail_ctx(D.ctx, rc);
-    // this rank's rows of every matrix: the class's columns are the matrices' columns back to back (coeffs in that order)
+    // this rank's rows of every matrix of the class: the class's columns are its matrices' columns back to back (coeffs in that order)
     size_t c0 = 0;
-    for (int m = 0; m < D.n_mats; m++) {
-        int rc = ceno_hip_batch_columns(D.ctx, D.local_cw_rows[m], Rl, (int)D.width_of[(size_t)m], coeffs + 2 * c0, loc.ptr(), m > 0 ? 1 : 0, s);
+    bool first = true;
+    for (int m : D.class_mats[(size_t)cls]) {
+        int rc = ceno_hip_batch_columns(D.ctx, D.local_cw_rows[m], Rl, (int)D.width_of[(size_t)m], coeffs + 2 * c0, loc.ptr(), first ? 0 : 1, s);
         if (rc) return fail_ctx(D.ctx, rc);
         c0 += D.width_of[(size_t)m];
+        first = false;
     }
     if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, dev_B, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: sync failed");
@@ -88,7 +96,7 @@ int hook_batch_codeword(void* self, int, int, const uint64_t* coeffs, uint64_t* 
 
 int hook_batch_trace(void* self, int, int mat, const uint64_t* coeffs, uint64_t* dev_F, ceno_hip_stream s) {
     DistOpen& D = *static_cast<DistOpen*>(self);
-    const size_t rows = (size_t)1 << D.log_rows;
+    const size_t rows = (size_t)1 << D.log_rows_of[(size_t)mat];
     DevBuf part{D.ctx}, all{D.ctx};
     if (int rc = part.alloc_words(2 * rows)) return fail_ctx(D.ctx, rc);
     if (int rc = all.alloc_words(2 * rows * (size_t)D.W)) return fail_ctx(D.ctx, rc);
@@ -152,11 +160,11 @@ int hook_mmcs_open(void* self, int, const uint64_t* idx, const uint64_t*, size_t
 
 extern "C" {
 
-int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, int log_rows, const int* widths, int log_blowup,
-                            const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
-                            ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
-                            ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
-    if (!ctx || !comm || n_mats < 1 || !widths || !local_trace_cols || !local_cw_rows || !subtree || !points || !evals || !tr || !out_proof)
+int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, const int* log_rows, const int* widths, int log_blowup,
+                                 const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                                 ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                                 ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
+    if (!ctx || !comm || n_mats < 1 || !log_rows || !widths || !local_trace_cols || !local_cw_rows || !subtree || !points || !evals || !tr || !out_proof)
         return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad arguments");
     DistOpen D;
     D.ctx = ctx;
@@ -166,40 +174,67 @@ int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats,
     D.k = 0;
     while ((1 << D.k) < D.W) D.k++;
     if ((1 << D.k) != D.W) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the number of ranks must be a power of two");
-    if (log_rows + log_blowup < D.k) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: fewer codeword rows than ranks");
+    int max_log = 0;
+    for (int m = 0; m < n_mats; m++) {
+        if (log_rows[m] < 0 || log_rows[m] > 40) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad matrix height");
+        if (log_rows[m] + log_blowup < D.k)
+            return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: a codeword with fewer rows than ranks (it lives in the replicated top tree)");
+        max_log = std::max(max_log, log_rows[m]);
+    }
     if (D.W > 1 && !top) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the replicated top tree is missing");
     D.n_mats = n_mats;
-    D.log_rows = log_rows;
+    D.log_rows = max_log;
+    D.log_rows_of.assign(log_rows, log_rows + n_mats);
     D.log_blowup = log_blowup;
     D.widths = widths;
     D.local_trace_cols = local_trace_cols;
     D.local_cw_rows = local_cw_rows;
     D.subtree = subtree;
     D.top = top;
-    // the SHAPE of the commitment for the single-device code: one height class, no tables, no tree
+    // the SHAPE of the commitment for the single-device code (no tables, no tree): height classes tallest first, the matrices of a class in
+    // the caller's order — what commit_traces builds (commit.cpp)
     ceno_pcs_data shape;
     shape.log_blowup = log_blowup;
-    ceno_pcs_data::Class K;
-    K.log_rows = log_rows;
+    std::vector<int> heights(log_rows, log_rows + n_mats);
+    std::sort(heights.begin(), heights.end(), [](int a, int b) { return a > b; });
+    heights.erase(std::unique(heights.begin(), heights.end()), heights.end());
+    for (int h : heights) {
+        ceno_pcs_data::Class K;
+        K.log_rows = h;
+        shape.classes.push_back(K);
+        D.class_mats.emplace_back();
+    }
     for (int m = 0; m < n_mats; m++) {
         size_t w = 0;
         for (int g = 0; g < D.W; g++) w += (size_t)widths[(size_t)m * D.W + g];
         if (w < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: a matrix without columns");
+        const int cls = (int)(std::find(heights.begin(), heights.end(), log_rows[m]) - heights.begin());
+        ceno_pcs_data::Class& K = shape.classes[(size_t)cls];
         ceno_pcs_data::Mat M;
-        M.rows = (size_t)1 << log_rows;
+        M.rows = (size_t)1 << log_rows[m];
         M.width = w;
-        M.log_rows = log_rows;
-        M.cls = 0;
+        M.log_rows = log_rows[m];
+        M.cls = cls;
         M.col0 = K.width;
         K.width += w;
         shape.mats.push_back(M);
+        D.class_mats[(size_t)cls].push_back(m);
         D.width_of.push_back(w);
         D.total_width += w;
     }
-    shape.classes.push_back(K);
     BasefoldOpenHook hook{&D, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
     ceno_pcs_data* commits[1] = {&shape};
     return basefold_open_hooked(ctx, commits, 1, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
+}
+
+int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, int log_rows, const int* widths, int log_blowup,
+                            const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                            ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                            ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
+    if (n_mats < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad arguments");
+    std::vector<int> lr((size_t)n_mats, log_rows);
+    return ceno_dist_basefold_open_mmcs(ctx, comm, n_mats, lr.data(), widths, log_blowup, local_trace_cols, local_cw_rows, subtree, top, points, evals, n_queries,
+                                        pow_bits, tr, s, out_proof);
 }
 
 }  // extern "C"

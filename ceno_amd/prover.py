@@ -943,9 +943,10 @@ def dist_create_chip_proof(dev: Device, comm, task_local: dict, log2_num_instanc
         L.ceno_chip_proof_free(C.byref(out))
 
 
-def dist_basefold_open(dev: Device, comm, log_rows: int, widths, log_blowup: int, trace_ptrs, cw_row_ptrs, subtree, top, points, evals,
+def dist_basefold_open(dev: Device, comm, log_rows, widths, log_blowup: int, trace_ptrs, cw_row_ptrs, subtree, top, points, evals,
                        n_queries: int, pow_bits: int, tr: Transcript, stream) -> np.ndarray:
-    """ceno_dist_basefold_open: the opening of a commitment made across ranks by ceno_dist_commit_traces_mmcs (all matrices 2^log_rows rows).
+    """ceno_dist_basefold_open[_mmcs]: the opening of a commitment made across ranks by ceno_dist_commit_traces_mmcs (log_rows: one height for
+    all matrices, or a list with one height per matrix).
     widths[m][g]; trace_ptrs[m] = this rank's columns of matrix m (device pointer), cw_row_ptrs[m] = its codeword rows of ALL columns (the
     commit's output); subtree / top = the commit's trees.  Returns the flat proof = ceno_prover_basefold_open's of the single-device commitment."""
     L = plib()
@@ -953,10 +954,14 @@ def dist_basefold_open(dev: Device, comm, log_rows: int, widths, log_blowup: int
     L.ceno_dist_basefold_open.restype = C.c_int
     L.ceno_dist_basefold_open.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.c_void_p, C.c_void_p, C.POINTER(u64p), C.POINTER(u64p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, u64p]
+    L.ceno_dist_basefold_open_mmcs.restype = C.c_int
+    L.ceno_dist_basefold_open_mmcs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)] + L.ceno_dist_basefold_open.argtypes[4:]
     L.ceno_prover_basefold_proof_words_meta.restype = C.c_size_t
     L.ceno_prover_basefold_proof_words_meta.argtypes = [C.c_int] * 5
     total_w = int(sum(sum(row) for row in widths))
-    proof = np.zeros(int(L.ceno_prover_basefold_proof_words_meta(n, total_w, log_rows, log_blowup, n_queries)), dtype=np.uint64)
+    mixed = not isinstance(log_rows, (int, np.integer))
+    max_log = max(int(x) for x in log_rows) if mixed else int(log_rows)
+    proof = np.zeros(int(L.ceno_prover_basefold_proof_words_meta(n, total_w, max_log, log_blowup, n_queries)), dtype=np.uint64)
     wa = (C.c_int * (n * world))(*[int(w) for row in widths for w in row])
     tp = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in trace_ptrs])
     cp = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in cw_row_ptrs])
@@ -964,7 +969,11 @@ def dist_basefold_open(dev: Device, comm, log_rows: int, widths, log_blowup: int
     evs = [np.ascontiguousarray(x, dtype=np.uint64) for x in evals]
     pp = (u64p * n)(*[_p(x) for x in pts])
     ep = (u64p * n)(*[_p(x) for x in evs])
-    rc = L.ceno_dist_basefold_open(dev.h, comm, n, log_rows, wa, log_blowup, tp, cp, subtree, top, pp, ep, n_queries, pow_bits, tr.h, stream, _p(proof))
+    if mixed:
+        lr = (C.c_int * n)(*[int(x) for x in log_rows])
+        rc = L.ceno_dist_basefold_open_mmcs(dev.h, comm, n, lr, wa, log_blowup, tp, cp, subtree, top, pp, ep, n_queries, pow_bits, tr.h, stream, _p(proof))
+    else:
+        rc = L.ceno_dist_basefold_open(dev.h, comm, n, log_rows, wa, log_blowup, tp, cp, subtree, top, pp, ep, n_queries, pow_bits, tr.h, stream, _p(proof))
     _check(rc)
     return proof
 

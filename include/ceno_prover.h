@@ -484,10 +484,15 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno
  * ceno_prover_basefold_proof_words_meta).  The bandwidth-bound part is sharded — the batched codeword from every rank's ROW shard
  * (local_cw_rows = the commit's out_rows_dev), the batched trace polynomial from every rank's COLUMN shard (local_trace_cols = the commit's
  * input), the commitment's rows and sub-tree paths at the queries from the rank that owns them — and gathered; the commit phase (~21
- * dependent rounds on a codeword 1 / width the size of the data: latency) runs replicated.  v1: ONE commitment, all matrices of the same
- * height 2^log_rows, at least `world` codeword rows; widths[m * world + g] as in the commit; points / evals per matrix as in
+ * dependent rounds on a codeword 1 / width the size of the data: latency) runs replicated.  ONE commitment; ceno_dist_basefold_open takes
+ * matrices of one height 2^log_rows, ceno_dist_basefold_open_mmcs matrices of any heights log_rows[m] (a shard's traces; one batched codeword
+ * per height class) — every codeword with at least `world` rows; widths[m * world + g] as in the commit; points / evals per matrix as in
  * ceno_prover_basefold_open (evals: all `sum_g widths` columns, rank-major).  Needs the communicator's bulk transport (in-process group or
- * RCCL) for the two all-gathers. */
+ * RCCL) for the all-gathers. */
+int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, const int* log_rows, const int* widths, int log_blowup,
+                                 const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                                 ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                                 ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof);
 int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, int log_rows, const int* widths, int log_blowup,
                             const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
                             ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,

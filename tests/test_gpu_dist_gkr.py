@@ -157,6 +157,21 @@ def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     group.close()
 
 
+def test_multi_rank_opening_refuses_a_codeword_shorter_than_the_ranks(dev, prover):
+    """a matrix whose codeword has fewer rows than there are ranks lives in the replicated top tree of the sharded commitment: the opening
+    says so (before it touches any table) instead of opening the wrong rows"""
+    from ceno_amd.api import CenoHipError
+
+    group = prover.LocalGroup(8)
+    stream = dev.stream_create()
+    pts = [np.zeros((6, 2), dtype=np.uint64), np.zeros((1, 2), dtype=np.uint64)]
+    evs = [np.zeros((8, 2), dtype=np.uint64)] * 2
+    with pytest.raises(CenoHipError) as ei:
+        prover.dist_basefold_open(dev, group.comms[0], [6, 1], [[1] * 8, [1] * 8], 1, [8, 8], [8, 8], 8, 8, pts, evs, 4, 0, prover.Transcript.stub(1), stream)
+    assert "fewer rows than ranks" in str(ei.value)
+    group.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the opening of a commitment made across ranks (ceno_dist_basefold_open, ceno_amd/host/dist_open.cpp)
 # ------------------------------------------------------------------------------------------------------------------
@@ -165,6 +180,10 @@ def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     (4, 9, [[2, 1, 0, 3], [1, 1, 2, 1]], "stub"),          # a rank without columns of the first matrix
     (8, 10, [[1] * 8], "poseidon2"),
     (4, 7, [[3, 2, 2, 1]], "poseidon2"),
+    # matrices of different heights in one commitment (a shard's traces): one batched codeword per height class, mixed-height sub-trees
+    (2, [8, 6], [[2, 1], [1, 3]], "stub"),
+    (4, [7, 9, 5, 9], [[1, 1, 1, 1], [2, 1, 0, 3], [1, 2, 1, 1], [1, 1, 2, 1]], "poseidon2"),
+    (8, [10, 6, 8], [[1] * 8, [2, 1, 1, 1, 1, 1, 1, 1], [1] * 8], "stub"),
 ])
 def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world, log_rows, col_split, transcript):
     """commit across `world` virtual ranks (column-sharded RS encoding, re-shard by rows, sub-trees + replicated top), then open across them:
@@ -178,10 +197,12 @@ def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world,
 
     blow, n_queries, pow_bits = 1, 12, 4
     n_mats = len(col_split)
-    fulls = [po.rand_base((1 << log_rows) * sum(ws), 800 + i).reshape(1 << log_rows, sum(ws)) for i, ws in enumerate(col_split)]
-    point = np.array([[(i * 7919 + 13) % P, (i * 104729 + 17) % P] for i in range(log_rows)], dtype=np.uint64)
-    points = [point] * n_mats
-    evals = [np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), point) for c in range(full.shape[1])], dtype=np.uint64) for full in fulls]
+    heights = list(log_rows) if isinstance(log_rows, list) else [log_rows] * n_mats
+    fulls = [po.rand_base((1 << heights[i]) * sum(ws), 800 + i).reshape(1 << heights[i], sum(ws)) for i, ws in enumerate(col_split)]
+    point = np.array([[(i * 7919 + 13) % P, (i * 104729 + 17) % P] for i in range(max(heights))], dtype=np.uint64)
+    points = [point[:h] for h in heights]
+    evals = [np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), points[m]) for c in range(full.shape[1])], dtype=np.uint64)
+             for m, full in enumerate(fulls)]
     new_tr = (lambda: prover.Transcript.stub(77)) if transcript == "stub" else (lambda: prover.Transcript.poseidon2(b"open"))
     stream = dev.stream_create()
     pcs = prover.PcsData(dev, fulls, blow, stream)
@@ -202,7 +223,7 @@ def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world,
                 ptrs.append(t.data_ptr())
             torch.cuda.synchronize()
             s_ = dev.stream_create()
-            com = cdist.sharded_commit_mmcs_native(dev, group.comms[rank], ptrs, col_split, [log_rows] * n_mats, blow, rank, s_)
+            com = cdist.sharded_commit_mmcs_native(dev, group.comms[rank], ptrs, col_split, heights, blow, rank, s_)
             dev.sync(s_)
             proof = prover.dist_basefold_open(dev, group.comms[rank], log_rows, col_split, blow, ptrs, [t.data_ptr() for t in com["codeword_rows"]], com["subtree"],
                                               com["top"], points, evals, n_queries, pow_bits, new_tr(), s_)
