@@ -207,25 +207,23 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
                 for (uint32_t k = toff[t]; k < toff[t + 1]; k++) other[tidx[k]] = 1;
             }
         }
-        // groups per selector; a column leaves the plan only if EVERY selector it stands under combines it
+        // groups per selector: EVERY `selector x column` monomial of a selector with at least lin_min of them moves into the selector's two
+        // combined tables — also those of a column that products read as well (its monomial then costs one pass of the combination instead of
+        // D - 2 multiply-accumulates per pair and round); a column leaves the plan when nothing else reads it and all its monomials moved
         std::map<int, std::map<int, E2>> by_sel;  // selector -> column -> summed coefficient
+        for (int t = 0; t < n_terms_all; t++)
+            if (lin_sel[t] >= 0) by_sel[lin_sel[t]].emplace(lin_col[t], gl::e2_zero());
+        for (auto it = by_sel.begin(); it != by_sel.end();) it = (int)it->second.size() >= lin_min ? std::next(it) : by_sel.erase(it);
         for (int t = 0; t < n_terms_all; t++) {
-            if (lin_sel[t] < 0 || other[lin_col[t]]) continue;
-            E2& c = by_sel[lin_sel[t]].emplace(lin_col[t], gl::e2_zero()).first->second;
-            c = c + E2{coeffs[2 * t], coeffs[2 * t + 1]};
-        }
-        for (bool changed = true; changed;) {
-            changed = false;
-            for (auto it = by_sel.begin(); it != by_sel.end();) {
-                if ((int)it->second.size() >= lin_min) { ++it; continue; }
-                for (auto& kv : it->second) other[kv.first] = 1;  // these columns stay: no other selector may drop them either
-                it = by_sel.erase(it);
-                changed = true;
+            if (lin_sel[t] < 0) continue;
+            auto g = by_sel.find(lin_sel[t]);
+            if (g == by_sel.end()) {  // the monomial stays a term of the sumcheck: so does its column
+                other[lin_col[t]] = 1;
+                lin_sel[t] = lin_col[t] = -1;
+                continue;
             }
-            for (auto& g : by_sel)
-                for (auto it = g.second.begin(); it != g.second.end();)
-                    if (other[it->first]) it = g.second.erase(it), changed = true;
-                    else ++it;
+            E2& c = g->second[lin_col[t]];
+            c = c + E2{coeffs[2 * t], coeffs[2 * t + 1]};
         }
         std::vector<char> gone(nm, 0);
         std::vector<uint32_t> goff{0};
@@ -235,7 +233,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         for (auto& g : by_sel) {
             gsel.push_back(g.first);
             for (auto& kv : g.second) {
-                gone[kv.first] = 1;
+                if (!other[kv.first]) gone[kv.first] = 1;
                 gcols.push_back(mles[kv.first]);
                 gco.push_back(kv.second.c0);
                 gco.push_back(kv.second.c1);
@@ -261,7 +259,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             }
         }
         for (int t = 0; t < n_terms_all; t++) {
-            if (lin_col[t] >= 0 && gone[lin_col[t]]) continue;
+            if (lin_col[t] >= 0) continue;  // moved into its selector's combination
             p_coeffs.push_back(coeffs[2 * t]);
             p_coeffs.push_back(coeffs[2 * t + 1]);
             for (uint32_t k = toff[t]; k < toff[t + 1]; k++) p_tidx.push_back((uint32_t)plan_of[tidx[k]]);
@@ -355,7 +353,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         }
     }
     if (dbg)
-        fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan + %zu combined columns %.0f us, sumcheck %.0f us, their evaluations %.0f us\n",
+        fprintf(stderr, "[ceno_prover] batched main: selectors %.0f us, host plan + combination (%zu columns left the plan) %.0f us, sumcheck %.0f us, their evaluations %.0f us\n",
                 t_sel - t_start, removed.size(), t_plan - t_sel, t_sc - t_plan, now_us() - t_sc);
     // ---- final claim by the front-load rule and the claimed sum recovered backwards (cpu/mod.rs:1338-1360,1393-1413) ----
     E2 final_claim = gl::e2_zero();
