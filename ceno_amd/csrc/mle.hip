@@ -674,7 +674,8 @@ struct LinGroup {
     uint64_t *out0, *out1;
     uint32_t n_cols, log_rows, wg_begin, pad;
 };
-constexpr unsigned LIN_TILE = 2 * NT;  // rows per workgroup: two per lane (16-byte loads)
+constexpr int LIN_L = 2;                      // 16-byte loads per lane and column
+constexpr unsigned LIN_TILE = 2 * LIN_L * NT;  // rows per workgroup: load l of lane t = rows 2 NT l + 2 t, + 1
 __global__ void __launch_bounds__(NT) k_lincomb_base(const LinGroup* __restrict__ groups, int n_groups) {
     int g = 0;
     {   // the group of this workgroup (groups are sorted by wg_begin): binary search, wave-uniform
@@ -690,41 +691,57 @@ __global__ void __launch_bounds__(NT) k_lincomb_base(const LinGroup* __restrict_
     const size_t rows = (size_t)1 << G.log_rows;
     const size_t r0 = (size_t)(blockIdx.x - G.wg_begin) * LIN_TILE + 2 * threadIdx.x;
     if (r0 >= rows) return;
-    Acc5 a00{0, 0, 0, 0, 0}, a01{0, 0, 0, 0, 0}, a10{0, 0, 0, 0, 0}, a11{0, 0, 0, 0, 0};
     if (rows == 1) {
+        Acc5 a0{0, 0, 0, 0, 0}, a1{0, 0, 0, 0, 0};
         for (uint32_t j = 0; j < G.n_cols; j++) {
             const uint64_t v = G.cols[j][0];
-            acc5_add(a00, mul_wide(G.coeffs[2 * j], v));
-            acc5_add(a01, mul_wide(G.coeffs[2 * j + 1], v));
+            acc5_add(a0, mul_wide(G.coeffs[2 * j], v));
+            acc5_add(a1, mul_wide(G.coeffs[2 * j + 1], v));
         }
-        G.out0[0] = acc5_reduce(a00);
-        G.out1[0] = acc5_reduce(a01);
+        G.out0[0] = acc5_reduce(a0);
+        G.out1[0] = acc5_reduce(a1);
         return;
     }
+    Acc5 a[LIN_L][4];  // per load: (c0, row 0), (c1, row 0), (c0, row 1), (c1, row 1)
+    bool on[LIN_L];
+#pragma unroll
+    for (int l = 0; l < LIN_L; l++) {
+        on[l] = r0 + (size_t)l * 2 * NT < rows;  // (a table of fewer rows than a tile)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[l][k] = Acc5{0, 0, 0, 0, 0};
+    }
+    auto mac = [&](int l, uint64_t c0, uint64_t c1, const ulonglong2& v) {
+        acc5_add(a[l][0], mul_wide(c0, v.x));
+        acc5_add(a[l][1], mul_wide(c1, v.x));
+        acc5_add(a[l][2], mul_wide(c0, v.y));
+        acc5_add(a[l][3], mul_wide(c1, v.y));
+    };
     uint32_t j = 0;
     for (; j + 4 <= G.n_cols; j += 4) {  // four columns in flight
-        ulonglong2 v[4];
+        ulonglong2 v[4][LIN_L];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const ulonglong2*>(G.cols[j + u] + r0);
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int l = 0; l < LIN_L; l++) v[u][l] = on[l] ? *reinterpret_cast<const ulonglong2*>(G.cols[j + u] + r0 + (size_t)l * 2 * NT) : ulonglong2{0, 0};
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint64_t c0 = G.coeffs[2 * (j + u)], c1 = G.coeffs[2 * (j + u) + 1];
-            acc5_add(a00, mul_wide(c0, v[u].x));
-            acc5_add(a01, mul_wide(c1, v[u].x));
-            acc5_add(a10, mul_wide(c0, v[u].y));
-            acc5_add(a11, mul_wide(c1, v[u].y));
+#pragma unroll
+            for (int l = 0; l < LIN_L; l++) mac(l, c0, c1, v[u][l]);
         }
     }
     for (; j < G.n_cols; j++) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(G.cols[j] + r0);
         const uint64_t c0 = G.coeffs[2 * j], c1 = G.coeffs[2 * j + 1];
-        acc5_add(a00, mul_wide(c0, v.x));
-        acc5_add(a01, mul_wide(c1, v.x));
-        acc5_add(a10, mul_wide(c0, v.y));
-        acc5_add(a11, mul_wide(c1, v.y));
+#pragma unroll
+        for (int l = 0; l < LIN_L; l++)
+            if (on[l]) mac(l, c0, c1, *reinterpret_cast<const ulonglong2*>(G.cols[j] + r0 + (size_t)l * 2 * NT));
     }
-    *reinterpret_cast<ulonglong2*>(G.out0 + r0) = ulonglong2{acc5_reduce(a00), acc5_reduce(a10)};
-    *reinterpret_cast<ulonglong2*>(G.out1 + r0) = ulonglong2{acc5_reduce(a01), acc5_reduce(a11)};
+#pragma unroll
+    for (int l = 0; l < LIN_L; l++) {
+        if (!on[l]) continue;
+        *reinterpret_cast<ulonglong2*>(G.out0 + r0 + (size_t)l * 2 * NT) = ulonglong2{acc5_reduce(a[l][0]), acc5_reduce(a[l][2])};
+        *reinterpret_cast<ulonglong2*>(G.out1 + r0 + (size_t)l * 2 * NT) = ulonglong2{acc5_reduce(a[l][1]), acc5_reduce(a[l][3])};
+    }
 }
 
 extern "C" int ceno_hip_lincomb_base_batch(ceno_hip_ctx* ctx, int n_groups, const uint32_t* group_offsets, ceno_hip_mle* const* cols, const uint64_t* coeffs,
