@@ -145,6 +145,19 @@ int ceno_prover_basefold_open(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, 
                               uint64_t* out_proof) {
     return basefold_open_hooked(ctx, commits, n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, nullptr);
 }
+size_t ceno_prover_basefold_proof_words_commits(int n_commits, const int* n_mats, const int* total_width, const int* max_log_rows, int log_blowup,
+                                                int n_queries) {
+    if (n_commits < 1 || !n_mats || !total_width || !max_log_rows) return 0;
+    int n = 0;
+    size_t mats = 0, w = 1;
+    for (int c = 0; c < n_commits; c++) {
+        n = std::max(n, max_log_rows[c]);
+        mats += (size_t)n_mats[c];
+        w += (size_t)total_width[c] + 4 * (size_t)(max_log_rows[c] + log_blowup);
+    }
+    for (int r = 0; r < n; r++) w += 2 + 4 * (size_t)(n + log_blowup - r - 1);
+    return 8 * (size_t)n + 2 * mats + 1 + (size_t)n_queries * w;
+}
 size_t ceno_prover_basefold_proof_words_meta(int n_mats, int total_width, int max_log_rows, int log_blowup, int n_queries) {
     const int n = max_log_rows;
     size_t w = 1 + (size_t)total_width + 4 * (size_t)(n + log_blowup);

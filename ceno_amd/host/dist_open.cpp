@@ -16,7 +16,7 @@
 //   * the commitment's opening at a query: the rank that owns the row answers from its rows and its sub-tree (ceno_hip_mmcs_open_batch on
 //     local indices), every rank appends the top log2(world) levels from the replicated top tree; the answers travel by the small-message
 //     transport.
-// Limits: ONE commitment; matrices of any heights (the traces of a shard's chips: one batched codeword per height class, the sub-trees are
+// Limits: matrices of any heights (the traces of a shard's chips: one batched codeword per height class, the sub-trees are
 // mixed-height trees over the row shards) as long as every codeword has at least `world` rows (shorter ones would join the replicated top
 // tree: refused).
 #include <hip/hip_runtime_api.h>
@@ -41,20 +41,24 @@ int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_
 
 namespace {
 
+struct DistCommit {                            // one commitment made across the ranks
+    int n_mats = 0, log_rows = 0;              // log_rows: of its TALLEST trace
+    std::vector<int> log_rows_of;              // per matrix
+    std::vector<std::vector<int>> class_mats;  // height classes, tallest first; the matrices of a class in the caller's order (commit.cpp)
+    const int* widths = nullptr;               // [m * W + g]
+    const uint64_t* const* local_trace_cols = nullptr;  // [m]: this rank's columns of matrix m, column-major, 2^log_rows rows
+    const uint64_t* const* local_cw_rows = nullptr;     // [m]: ALL columns of matrix m x (R / W) rows, column-major (ceno_dist_commit_traces_mmcs out_rows_dev)
+    ceno_hip_merkle* subtree = nullptr;
+    ceno_hip_merkle* top = nullptr;
+    std::vector<size_t> width_of;              // per matrix: all ranks' columns
+    size_t total_width = 0;
+};
 struct DistOpen {
     ceno_hip_ctx* ctx;
     ceno_dist_comm* comm;
     int W, rank, k;
-    int n_mats, log_rows, log_blowup;          // log_rows: of the TALLEST trace
-    std::vector<int> log_rows_of;              // per matrix
-    std::vector<std::vector<int>> class_mats;  // height classes, tallest first; the matrices of a class in the caller's order (commit.cpp)
-    const int* widths;                         // [m * W + g]
-    const uint64_t* const* local_trace_cols;   // [m]: this rank's columns of matrix m, column-major, 2^log_rows rows
-    const uint64_t* const* local_cw_rows;      // [m]: ALL columns of matrix m x (R / W) rows, column-major (ceno_dist_commit_traces_mmcs out_rows_dev)
-    ceno_hip_merkle* subtree;
-    ceno_hip_merkle* top;
-    std::vector<size_t> width_of;              // per matrix: all ranks' columns
-    size_t total_width = 0;
+    int log_blowup;
+    std::vector<DistCommit> commits;
 };
 
 int fail_ctx(ceno_hip_ctx* ctx, int rc) { return prover_set_error(rc, ceno_hip_last_error(ctx)); }
@@ -73,38 +77,50 @@ struct DevBuf {
     uint64_t* ptr() const { return ceno_hip_mle_device_ptr(m); }
 };
 
-int hook_batch_codeword(void* self, int, int cls, const uint64_t* coeffs, uint64_t* dev_B, int log_h, int accumulate, ceno_hip_stream s) {
+int hook_batch_codeword(void* self, int commit, int cls, const uint64_t* coeffs, uint64_t* dev_B, int log_h, int accumulate, ceno_hip_stream s) {
     DistOpen& D = *static_cast<DistOpen*>(self);
-    if (accumulate || cls < 0 || cls >= (int)D.class_mats.size())
-        return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: one commitment, one batched codeword per height class");
+    if (commit < 0 || commit >= (int)D.commits.size()) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: commitment index");
+    const DistCommit& K = D.commits[(size_t)commit];
+    if (cls < 0 || cls >= (int)K.class_mats.size()) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: height class index");
     const size_t R = (size_t)1 << log_h, Rl = R / (size_t)D.W;
-    DevBuf loc{D.ctx};
+    DevBuf loc{D.ctx}, both{D.ctx};
     if (int rc = loc.alloc_words(2 * Rl)) return fail_ctx(D.ctx, rc);
     // this rank's rows of every matrix of the class: the class's columns are its matrices' columns back to back (coeffs in that order)
     size_t c0 = 0;
     bool first = true;
-    for (int m : D.class_mats[(size_t)cls]) {
-        int rc = ceno_hip_batch_columns(D.ctx, D.local_cw_rows[m], Rl, (int)D.width_of[(size_t)m], coeffs + 2 * c0, loc.ptr(), first ? 0 : 1, s);
+    for (int m : K.class_mats[(size_t)cls]) {
+        int rc = ceno_hip_batch_columns(D.ctx, K.local_cw_rows[m], Rl, (int)K.width_of[(size_t)m], coeffs + 2 * c0, loc.ptr(), first ? 0 : 1, s);
         if (rc) return fail_ctx(D.ctx, rc);
-        c0 += D.width_of[(size_t)m];
+        c0 += K.width_of[(size_t)m];
         first = false;
     }
-    if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, dev_B, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+    if (!accumulate) {
+        if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, dev_B, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+    } else {
+        // a second commitment with a class of this height (witness + fixed traces of one size): B += the gathered codeword — the running B and the
+        // gathered block side by side, added mod p
+        if (int rc = both.alloc_words(4 * R)) return fail_ctx(D.ctx, rc);
+        if (hipMemcpyAsync(both.ptr(), dev_B, R * 16, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess)
+            return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: copy failed");
+        if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, both.ptr() + 2 * R, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+        if (int rc = ceno_hip_ext_sum_blocks(D.ctx, both.ptr(), 2, R, dev_B, s)) return fail_ctx(D.ctx, rc);
+    }
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: sync failed");
     return 0;
 }
 
-int hook_batch_trace(void* self, int, int mat, const uint64_t* coeffs, uint64_t* dev_F, ceno_hip_stream s) {
+int hook_batch_trace(void* self, int commit, int mat, const uint64_t* coeffs, uint64_t* dev_F, ceno_hip_stream s) {
     DistOpen& D = *static_cast<DistOpen*>(self);
-    const size_t rows = (size_t)1 << D.log_rows_of[(size_t)mat];
+    const DistCommit& K = D.commits[(size_t)commit];
+    const size_t rows = (size_t)1 << K.log_rows_of[(size_t)mat];
     DevBuf part{D.ctx}, all{D.ctx};
     if (int rc = part.alloc_words(2 * rows)) return fail_ctx(D.ctx, rc);
     if (int rc = all.alloc_words(2 * rows * (size_t)D.W)) return fail_ctx(D.ctx, rc);
     size_t col0 = 0;
-    for (int g = 0; g < D.rank; g++) col0 += (size_t)D.widths[(size_t)mat * D.W + g];
-    const int mine = D.widths[(size_t)mat * D.W + D.rank];
+    for (int g = 0; g < D.rank; g++) col0 += (size_t)K.widths[(size_t)mat * D.W + g];
+    const int mine = K.widths[(size_t)mat * D.W + D.rank];
     if (mine > 0) {
-        int rc = ceno_hip_batch_columns(D.ctx, D.local_trace_cols[mat], rows, mine, coeffs + 2 * col0, part.ptr(), 0, s);
+        int rc = ceno_hip_batch_columns(D.ctx, K.local_trace_cols[mat], rows, mine, coeffs + 2 * col0, part.ptr(), 0, s);
         if (rc) return fail_ctx(D.ctx, rc);
     } else if (hipMemsetAsync(part.ptr(), 0, rows * 16, (hipStream_t)s) != hipSuccess) {
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: memset failed");
@@ -115,16 +131,18 @@ int hook_batch_trace(void* self, int, int mat, const uint64_t* coeffs, uint64_t*
     return 0;
 }
 
-size_t hook_opening_words(void* self, int) {
+size_t hook_opening_words(void* self, int commit) {
     DistOpen& D = *static_cast<DistOpen*>(self);
-    return D.total_width + 4 * (size_t)(D.log_rows + D.log_blowup);
+    const DistCommit& K = D.commits[(size_t)commit];
+    return K.total_width + 4 * (size_t)(K.log_rows + D.log_blowup);
 }
 
-int hook_mmcs_open(void* self, int, const uint64_t* idx, const uint64_t*, size_t n, int shift, uint64_t* dev_out, size_t per_q, ceno_hip_stream s) {
+int hook_mmcs_open(void* self, int commit, const uint64_t* idx, const uint64_t*, size_t n, int shift, uint64_t* dev_out, size_t per_q, ceno_hip_stream s) {
     DistOpen& D = *static_cast<DistOpen*>(self);
+    const DistCommit& K = D.commits[(size_t)commit];
     hipStream_t st = (hipStream_t)s;
-    const int H = D.log_rows + D.log_blowup, hl = H - D.k;  // levels of a rank's sub-tree
-    const size_t per_loc = D.total_width + 4 * (size_t)hl, per_top = 4 * (size_t)D.k;
+    const int H = K.log_rows + D.log_blowup, hl = H - D.k;  // levels of a rank's sub-tree
+    const size_t per_loc = K.total_width + 4 * (size_t)hl, per_top = 4 * (size_t)D.k;
     if (per_q != per_loc + per_top) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: opening size mismatch");
     std::vector<uint64_t> loc_idx(n), own(n);
     for (size_t q = 0; q < n; q++) {
@@ -138,9 +156,9 @@ int hook_mmcs_open(void* self, int, const uint64_t* idx, const uint64_t*, size_t
     if (hipMemcpyAsync(d_loc, loc_idx.data(), n * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipMemcpyAsync(d_own, own.data(), n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: index upload failed");
     // every rank opens its own sub-tree at the local index of every query (only the owner's answer is used) ...
-    int rc = ceno_hip_mmcs_open_batch(D.ctx, D.subtree, d_loc, n, 0, d_ans, per_loc, s);
+    int rc = ceno_hip_mmcs_open_batch(D.ctx, K.subtree, d_loc, n, 0, d_ans, per_loc, s);
     // ... and the replicated top tree at the owner's leaf
-    if (!rc && D.k > 0) rc = ceno_hip_merkle_open_batch(D.ctx, D.top, d_own, n, 0, d_top, s);
+    if (!rc && D.k > 0) rc = ceno_hip_merkle_open_batch(D.ctx, K.top, d_own, n, 0, d_top, s);
     if (rc) return fail_ctx(D.ctx, rc);
     std::vector<uint64_t> mine(n * per_loc), top(n * per_top), all((size_t)D.W * n * per_loc), out(n * per_q);
     if (hipMemcpyAsync(mine.data(), d_ans, mine.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -160,12 +178,10 @@ int hook_mmcs_open(void* self, int, const uint64_t* idx, const uint64_t*, size_t
 
 extern "C" {
 
-int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, const int* log_rows, const int* widths, int log_blowup,
-                                 const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
-                                 ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
-                                 ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
-    if (!ctx || !comm || n_mats < 1 || !log_rows || !widths || !local_trace_cols || !local_cw_rows || !subtree || !points || !evals || !tr || !out_proof)
-        return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad arguments");
+int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_commits, const ceno_dist_commit_view* views, int log_blowup,
+                                    const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr,
+                                    ceno_hip_stream s, uint64_t* out_proof) {
+    if (!ctx || !comm || n_commits < 1 || !views || !points || !evals || !tr || !out_proof) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad arguments");
     DistOpen D;
     D.ctx = ctx;
     D.comm = comm;
@@ -174,57 +190,72 @@ int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_
     D.k = 0;
     while ((1 << D.k) < D.W) D.k++;
     if ((1 << D.k) != D.W) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the number of ranks must be a power of two");
-    int max_log = 0;
-    for (int m = 0; m < n_mats; m++) {
-        if (log_rows[m] < 0 || log_rows[m] > 40) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad matrix height");
-        if (log_rows[m] + log_blowup < D.k)
-            return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: a codeword with fewer rows than ranks (it lives in the replicated top tree)");
-        max_log = std::max(max_log, log_rows[m]);
-    }
-    if (D.W > 1 && !top) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the replicated top tree is missing");
-    D.n_mats = n_mats;
-    D.log_rows = max_log;
-    D.log_rows_of.assign(log_rows, log_rows + n_mats);
     D.log_blowup = log_blowup;
-    D.widths = widths;
-    D.local_trace_cols = local_trace_cols;
-    D.local_cw_rows = local_cw_rows;
-    D.subtree = subtree;
-    D.top = top;
-    // the SHAPE of the commitment for the single-device code (no tables, no tree): height classes tallest first, the matrices of a class in
+    D.commits.resize((size_t)n_commits);
+    // the SHAPE of every commitment for the single-device code (no tables, no tree): height classes tallest first, the matrices of a class in
     // the caller's order — what commit_traces builds (commit.cpp)
-    ceno_pcs_data shape;
-    shape.log_blowup = log_blowup;
-    std::vector<int> heights(log_rows, log_rows + n_mats);
-    std::sort(heights.begin(), heights.end(), [](int a, int b) { return a > b; });
-    heights.erase(std::unique(heights.begin(), heights.end()), heights.end());
-    for (int h : heights) {
-        ceno_pcs_data::Class K;
-        K.log_rows = h;
-        shape.classes.push_back(K);
-        D.class_mats.emplace_back();
-    }
-    for (int m = 0; m < n_mats; m++) {
-        size_t w = 0;
-        for (int g = 0; g < D.W; g++) w += (size_t)widths[(size_t)m * D.W + g];
-        if (w < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: a matrix without columns");
-        const int cls = (int)(std::find(heights.begin(), heights.end(), log_rows[m]) - heights.begin());
-        ceno_pcs_data::Class& K = shape.classes[(size_t)cls];
-        ceno_pcs_data::Mat M;
-        M.rows = (size_t)1 << log_rows[m];
-        M.width = w;
-        M.log_rows = log_rows[m];
-        M.cls = cls;
-        M.col0 = K.width;
-        K.width += w;
-        shape.mats.push_back(M);
-        D.class_mats[(size_t)cls].push_back(m);
-        D.width_of.push_back(w);
-        D.total_width += w;
+    std::vector<ceno_pcs_data> shapes((size_t)n_commits);
+    std::vector<ceno_pcs_data*> shape_ptrs;
+    for (int c = 0; c < n_commits; c++) {
+        const ceno_dist_commit_view& V = views[c];
+        if (V.n_mats < 1 || !V.log_rows || !V.widths || !V.local_trace_cols || !V.local_cw_rows || !V.subtree)
+            return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad commitment view");
+        if (D.W > 1 && !V.top) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: the replicated top tree is missing");
+        DistCommit& K = D.commits[(size_t)c];
+        K.n_mats = V.n_mats;
+        for (int m = 0; m < V.n_mats; m++) {
+            if (V.log_rows[m] < 0 || V.log_rows[m] > 40) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad matrix height");
+            if (V.log_rows[m] + log_blowup < D.k)
+                return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: a codeword with fewer rows than ranks (it lives in the replicated top tree)");
+            K.log_rows = std::max(K.log_rows, V.log_rows[m]);
+        }
+        K.log_rows_of.assign(V.log_rows, V.log_rows + V.n_mats);
+        K.widths = V.widths;
+        K.local_trace_cols = V.local_trace_cols;
+        K.local_cw_rows = V.local_cw_rows;
+        K.subtree = V.subtree;
+        K.top = V.top;
+        ceno_pcs_data& shape = shapes[(size_t)c];
+        shape.log_blowup = log_blowup;
+        std::vector<int> heights(V.log_rows, V.log_rows + V.n_mats);
+        std::sort(heights.begin(), heights.end(), [](int a, int b) { return a > b; });
+        heights.erase(std::unique(heights.begin(), heights.end()), heights.end());
+        for (int h : heights) {
+            ceno_pcs_data::Class C;
+            C.log_rows = h;
+            shape.classes.push_back(C);
+            K.class_mats.emplace_back();
+        }
+        for (int m = 0; m < V.n_mats; m++) {
+            size_t w = 0;
+            for (int g = 0; g < D.W; g++) w += (size_t)V.widths[(size_t)m * D.W + g];
+            if (w < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: a matrix without columns");
+            const int cls = (int)(std::find(heights.begin(), heights.end(), V.log_rows[m]) - heights.begin());
+            ceno_pcs_data::Class& C = shape.classes[(size_t)cls];
+            ceno_pcs_data::Mat M;
+            M.rows = (size_t)1 << V.log_rows[m];
+            M.width = w;
+            M.log_rows = V.log_rows[m];
+            M.cls = cls;
+            M.col0 = C.width;
+            C.width += w;
+            shape.mats.push_back(M);
+            K.class_mats[(size_t)cls].push_back(m);
+            K.width_of.push_back(w);
+            K.total_width += w;
+        }
+        shape_ptrs.push_back(&shape);
     }
     BasefoldOpenHook hook{&D, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
-    ceno_pcs_data* commits[1] = {&shape};
-    return basefold_open_hooked(ctx, commits, 1, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
+    return basefold_open_hooked(ctx, shape_ptrs.data(), n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
+}
+
+int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, const int* log_rows, const int* widths, int log_blowup,
+                                 const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
+                                 ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,
+                                 ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof) {
+    ceno_dist_commit_view V{n_mats, log_rows, widths, local_trace_cols, local_cw_rows, subtree, top};
+    return ceno_dist_basefold_open_commits(ctx, comm, 1, &V, log_blowup, points, evals, n_queries, pow_bits, tr, s, out_proof);
 }
 
 int ceno_dist_basefold_open(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int n_mats, int log_rows, const int* widths, int log_blowup,

@@ -978,6 +978,46 @@ def dist_basefold_open(dev: Device, comm, log_rows, widths, log_blowup: int, tra
     return proof
 
 
+class DistCommitViewC(C.Structure):
+    _fields_ = [("n_mats", C.c_int), ("log_rows", C.POINTER(C.c_int)), ("widths", C.POINTER(C.c_int)), ("local_trace_cols", C.POINTER(C.c_void_p)),
+                ("local_cw_rows", C.POINTER(C.c_void_p)), ("subtree", C.c_void_p), ("top", C.c_void_p)]
+
+
+def dist_basefold_open_commits(dev: Device, comm, commits, log_blowup: int, points, evals, n_queries: int, pow_bits: int, tr: Transcript, stream) -> np.ndarray:
+    """ceno_dist_basefold_open_commits: ONE opening of several commitments made across ranks (witness + fixed).  commits: dicts with log_rows
+    [per matrix], widths [m][g], trace_ptrs [m], cw_row_ptrs [m], subtree, top; points / evals over the matrices of all commitments in order."""
+    L = plib()
+    world = len(commits[0]["widths"][0])
+    nc = len(commits)
+    views = (DistCommitViewC * nc)()
+    keep = []
+    for c, cm in enumerate(commits):
+        n = len(cm["log_rows"])
+        lr = (C.c_int * n)(*[int(x) for x in cm["log_rows"]])
+        wa = (C.c_int * (n * world))(*[int(w) for row in cm["widths"] for w in row])
+        tp = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in cm["trace_ptrs"]])
+        cp = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in cm["cw_row_ptrs"]])
+        keep += [lr, wa, tp, cp]
+        views[c] = DistCommitViewC(n, lr, wa, tp, cp, cm["subtree"], cm["top"])
+    L.ceno_prover_basefold_proof_words_commits.restype = C.c_size_t
+    L.ceno_prover_basefold_proof_words_commits.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int]
+    nm = (C.c_int * nc)(*[len(cm["log_rows"]) for cm in commits])
+    tw = (C.c_int * nc)(*[int(sum(sum(row) for row in cm["widths"])) for cm in commits])
+    ml = (C.c_int * nc)(*[max(int(x) for x in cm["log_rows"]) for cm in commits])
+    proof = np.zeros(int(L.ceno_prover_basefold_proof_words_commits(nc, nm, tw, ml, log_blowup, n_queries)), dtype=np.uint64)
+    n_all = sum(len(cm["log_rows"]) for cm in commits)
+    pts = [np.ascontiguousarray(x, dtype=np.uint64) for x in points]
+    evs = [np.ascontiguousarray(x, dtype=np.uint64) for x in evals]
+    assert len(pts) == n_all and len(evs) == n_all
+    pp = (u64p * n_all)(*[_p(x) for x in pts])
+    ep = (u64p * n_all)(*[_p(x) for x in evs])
+    L.ceno_dist_basefold_open_commits.restype = C.c_int
+    L.ceno_dist_basefold_open_commits.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(DistCommitViewC), C.c_int, C.POINTER(u64p), C.POINTER(u64p), C.c_int,
+                                                  C.c_int, C.c_void_p, C.c_void_p, u64p]
+    _check(L.ceno_dist_basefold_open_commits(dev.h, comm, nc, views, log_blowup, pp, ep, n_queries, pow_bits, tr.h, stream, _p(proof)))
+    return proof
+
+
 def chip_proof_estimate_bytes(task: dict) -> int:
     """ceno_prover_chip_proof_estimate_bytes: what the lane scheduler books for this chip proof"""
     L = plib()

@@ -488,7 +488,24 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno
  * matrices of one height 2^log_rows, ceno_dist_basefold_open_mmcs matrices of any heights log_rows[m] (a shard's traces; one batched codeword
  * per height class) — every codeword with at least `world` rows; widths[m * world + g] as in the commit; points / evals per matrix as in
  * ceno_prover_basefold_open (evals: all `sum_g widths` columns, rank-major).  Needs the communicator's bulk transport (in-process group or
- * RCCL) for the all-gathers. */
+ * RCCL) for the all-gathers.  ceno_dist_basefold_open_commits: several such commitments in one opening. */
+/* ... and of SEVERAL commitments in one opening (OpeningProver::open takes the witness and the fixed commitment, scheme/hal.rs:284-294): one view
+ * per commitment, points / evals over the matrices of all of them in order; a height that two commitments share is one batched codeword */
+typedef struct ceno_dist_commit_view {
+    int n_mats;
+    const int* log_rows;                       /* [n_mats] */
+    const int* widths;                         /* [n_mats * world] */
+    const uint64_t* const* local_trace_cols;   /* [n_mats]: this rank's columns (the commit's input) */
+    const uint64_t* const* local_cw_rows;      /* [n_mats]: this rank's codeword rows of all columns (the commit's out_rows_dev) */
+    ceno_hip_merkle* subtree;
+    ceno_hip_merkle* top;
+} ceno_dist_commit_view;
+int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_commits, const ceno_dist_commit_view* commits, int log_blowup,
+                                    const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits, ceno_transcript* tr,
+                                    ceno_hip_stream s, uint64_t* out_proof);
+/* words of that proof from the shapes alone: n_mats / total_width / max_log_rows per commitment */
+size_t ceno_prover_basefold_proof_words_commits(int n_commits, const int* n_mats, const int* total_width, const int* max_log_rows, int log_blowup,
+                                                int n_queries);
 int ceno_dist_basefold_open_mmcs(ceno_hip_ctx* ctx, ceno_dist_comm* c, int n_mats, const int* log_rows, const int* widths, int log_blowup,
                                  const uint64_t* const* local_trace_cols, const uint64_t* const* local_cw_rows, ceno_hip_merkle* subtree,
                                  ceno_hip_merkle* top, const uint64_t* const* points, const uint64_t* const* evals, int n_queries, int pow_bits,

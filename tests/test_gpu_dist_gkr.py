@@ -247,3 +247,79 @@ def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world,
     for r in range(world):
         assert np.array_equal(res[r][0].reshape(-1), np.asarray(want_root, dtype=np.uint64).reshape(-1)), f"rank {r}: commitment root"
         assert res[r][1].shape == want.shape and np.array_equal(res[r][1], want), f"rank {r}: the opening differs from the single-device opening"
+
+
+@pytest.mark.parametrize("world,heights_w,heights_f,transcript", [
+    (2, [8, 6], [8], "stub"),              # witness of two heights + a fixed commitment that shares the taller one (one batched codeword for both)
+    (4, [9], [7, 9], "poseidon2"),
+    (8, [7, 10], [6], "stub"),             # the fixed commitment is shorter than every height of the witness
+])
+def test_multi_rank_opening_of_witness_and_fixed_commitments(dev, prover, world, heights_w, heights_f, transcript):
+    """OpeningProver::open takes the witness AND the fixed commitment (scheme/hal.rs:284-294, cpu/mod.rs:1418-1457): two commitments made across the
+    ranks, opened in one proof — a height both share is ONE batched codeword (the second is added to the gathered first), each commitment answers
+    the queries from its own sub-trees — equal to the single-device opening of the same two commitments word for word"""
+    import torch
+
+    from ceno_amd import dist as cdist
+
+    blow, n_queries, pow_bits = 1, 10, 3
+    sets = []
+    for tag, heights in (("w", heights_w), ("f", heights_f)):
+        col_split = [[1 + ((m + g + len(tag)) % 2) for g in range(world)] for m in range(len(heights))]
+        fulls = [po.rand_base((1 << h) * sum(ws), 1300 + 7 * i + len(heights)).reshape(1 << h, sum(ws)) for i, (h, ws) in enumerate(zip(heights, col_split))]
+        sets.append((heights, col_split, fulls))
+    max_h = max(heights_w + heights_f)
+    point = np.array([[(i * 7919 + 29) % P, (i * 104729 + 31) % P] for i in range(max_h)], dtype=np.uint64)
+    points, evals = [], []
+    for heights, _cs, fulls in sets:
+        for h, full in zip(heights, fulls):
+            points.append(point[:h])
+            evals.append(np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), point[:h]) for c in range(full.shape[1])], dtype=np.uint64))
+    new_tr = (lambda: prover.Transcript.stub(78)) if transcript == "stub" else (lambda: prover.Transcript.poseidon2(b"open2"))
+    stream = dev.stream_create()
+    pcs_w = prover.PcsData(dev, sets[0][2], blow, stream)
+    pcs_f = prover.PcsData(dev, sets[1][2], blow, stream)
+    want = pcs_w.basefold_open(points, evals, n_queries, pow_bits, new_tr(), more_commits=[pcs_f])
+    pcs_w.free()
+    pcs_f.free()
+    group = prover.LocalGroup(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            s_ = dev.stream_create()
+            keep, commits = [], []
+            for heights, col_split, fulls in sets:
+                ptrs = []
+                for ws, full in zip(col_split, fulls):
+                    c0 = sum(ws[:rank])
+                    cols = np.ascontiguousarray(full[:, c0:c0 + ws[rank]].T)
+                    t = torch.from_numpy(cols.view(np.int64).copy()).to("cuda:0")
+                    keep.append(t)
+                    ptrs.append(t.data_ptr())
+                torch.cuda.synchronize()
+                com = cdist.sharded_commit_mmcs_native(dev, group.comms[rank], ptrs, col_split, heights, blow, rank, s_)
+                dev.sync(s_)
+                keep.append(com)
+                commits.append(dict(log_rows=heights, widths=col_split, trace_ptrs=ptrs, cw_row_ptrs=[t.data_ptr() for t in com["codeword_rows"]],
+                                    subtree=com["subtree"], top=com["top"]))
+            res[rank] = prover.dist_basefold_open_commits(dev, group.comms[rank], commits, blow, points, evals, n_queries, pow_bits, new_tr(), s_)
+            for cm in commits:
+                for key in ("subtree", "top"):
+                    if cm.get(key):
+                        dev.L.ceno_hip_merkle_free(dev.h, cm[key])
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for r in range(world):
+        assert res[r].shape == want.shape and np.array_equal(res[r], want), f"rank {r}: the opening differs from the single-device opening"
