@@ -1309,6 +1309,14 @@ static int gen_min_log() {
     const char* e = getenv("CENO_HIP_GEN_MIN_LOG");  // smallest class (variables) that gets component tables
     return e ? atoi(e) : 13;
 }
+// ... and, inside a sumcheck that has them, the smallest CLASS that goes through them.  A batch of many chips has many small classes (48 chips of
+// 2^2 .. 2^14 rows: thirteen), and on the two-kernel path every one of them costs two launches per round: 5.35 ms for that batch against 3.95 with
+// every class from 2^4 rows in the one launch of the round (2^16: 5.8 -> 4.5, 2^20: 7.7 -> 6.6, 2^24: unchanged; tools/dev/min_log_sweep.sh).
+static int gen_class_min_log() {
+    if (const char* e = getenv("CENO_HIP_GEN_CLASS_MIN_LOG")) return atoi(e);
+    if (const char* e = getenv("CENO_HIP_GEN_MIN_LOG")) return atoi(e);
+    return 4;
+}
 static size_t gen_stage_budget(int d) {
     const char* e = getenv("CENO_HIP_GEN_STAGE_KB");  // LDS the staged rows of one tile may take
     const int kb = e ? atoi(e) : 48;
@@ -1698,12 +1706,15 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         std::lock_guard<PoolMutex> g(ctx->mu);
         ctx->plan_report = "[]";
     }
-    if (sc->n < gen_min_log()) return 0;
+    // (a batch of three and more size classes pays for its tables at any size — wide batch of 48 chips at max_nv 8 / 10 / 12 / 13: 3.30 -> 3.05,
+    // 3.98 -> 3.44, 4.70 -> 3.68, 5.06 -> 3.81 ms, tools/dev/min_log_sweep2.sh; with one or two classes the table build is the larger cost)
+    const int sc_min_log = sc->classes.size() >= 3 ? std::min(gen_min_log(), gen_class_min_log()) : gen_min_log();
+    if (sc->n < sc_min_log) return 0;
     // a single class covering all variables runs pipelined (tower layers, one chip's main sumcheck), where k_gen is off unless
     // CENO_HIP_GEN_PIPE_MIN_LOG asks for it: do not build tables nobody reads
     if (sc->classes.size() == 1 && sc->classes[0].nv == sc->n && !getenv("CENO_HIP_GEN_PIPE_MIN_LOG")) return 0;
     bool any = false;
-    for (auto& cl : sc->classes) any = any || (!cl.dense && cl.nv >= gen_min_log());
+    for (auto& cl : sc->classes) any = any || (!cl.dense && cl.nv >= sc_min_log);
     if (!any) return 0;
     std::vector<char> blob;
     auto append = [&blob](const void* data, size_t bytes) {
@@ -1724,7 +1735,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
     sc->geq.n_brows = 0;
     for (size_t ci = 0; ci < sc->classes.size(); ci++) {
         ScClass& cl = sc->classes[ci];
-        if (cl.dense || cl.nv < gen_min_log()) continue;
+        if (cl.dense || cl.nv < gen_class_min_log()) continue;
         const int km = (int)cl.mles.size();
         // ---- connected components over class-local MLE ids (a group ties its common factors and its terms' factors) ----
         std::vector<int> uf(km);
