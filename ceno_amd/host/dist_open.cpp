@@ -16,9 +16,10 @@
 //   * the commitment's opening at a query: the rank that owns the row answers from its rows and its sub-tree (ceno_hip_mmcs_open_batch on
 //     local indices), every rank appends the top log2(world) levels from the replicated top tree; the answers travel by the small-message
 //     transport.
-// Limits: matrices of any heights (the traces of a shard's chips: one batched codeword per height class, the sub-trees are
-// mixed-height trees over the row shards) as long as every codeword has at least `world` rows (shorter ones would join the replicated top
-// tree: refused).
+// Matrices of any heights (the traces of a shard's chips: one batched codeword per height class, the sub-trees are mixed-height trees over the
+// row shards); a matrix whose codeword has fewer rows than there are ranks is held whole by every rank and lives in the replicated top tree
+// (ceno_dist_commit_traces_mmcs): its class is batched locally, its rows at a query come from the top tree's opening.  The tallest codeword of a
+// commitment needs at least `world` rows.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
@@ -51,7 +52,8 @@ struct DistCommit {                            // one commitment made across the
     ceno_hip_merkle* subtree = nullptr;
     ceno_hip_merkle* top = nullptr;
     std::vector<size_t> width_of;              // per matrix: all ranks' columns
-    size_t total_width = 0;
+    std::vector<char> is_short;                // per matrix: fewer codeword rows than ranks — every rank holds ALL its rows, it joins the tree in the replicated top
+    size_t total_width = 0, short_width = 0;
 };
 struct DistOpen {
     ceno_hip_ctx* ctx;
@@ -82,7 +84,9 @@ int hook_batch_codeword(void* self, int commit, int cls, const uint64_t* coeffs,
     if (commit < 0 || commit >= (int)D.commits.size()) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: commitment index");
     const DistCommit& K = D.commits[(size_t)commit];
     if (cls < 0 || cls >= (int)K.class_mats.size()) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: height class index");
-    const size_t R = (size_t)1 << log_h, Rl = R / (size_t)D.W;
+    const size_t R = (size_t)1 << log_h;
+    const bool shorter = log_h < D.k;  // fewer rows than ranks: nothing is sharded, every rank batches the whole codeword itself
+    const size_t Rl = shorter ? R : R / (size_t)D.W;
     DevBuf loc{D.ctx}, both{D.ctx};
     if (int rc = loc.alloc_words(2 * Rl)) return fail_ctx(D.ctx, rc);
     // this rank's rows of every matrix of the class: the class's columns are its matrices' columns back to back (coeffs in that order)
@@ -94,7 +98,17 @@ int hook_batch_codeword(void* self, int commit, int cls, const uint64_t* coeffs,
         c0 += K.width_of[(size_t)m];
         first = false;
     }
-    if (!accumulate) {
+    if (shorter) {
+        if (!accumulate) {
+            if (hipMemcpyAsync(dev_B, loc.ptr(), R * 16, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: copy failed");
+        } else {
+            if (int rc = both.alloc_words(4 * R)) return fail_ctx(D.ctx, rc);
+            if (hipMemcpyAsync(both.ptr(), dev_B, R * 16, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess ||
+                hipMemcpyAsync(both.ptr() + 2 * R, loc.ptr(), R * 16, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess)
+                return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: copy failed");
+            if (int rc = ceno_hip_ext_sum_blocks(D.ctx, both.ptr(), 2, R, dev_B, s)) return fail_ctx(D.ctx, rc);
+        }
+    } else if (!accumulate) {
         if (int rc = dist_allgather_device(D.comm, loc.ptr(), 2 * Rl, dev_B, (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
     } else {
         // a second commitment with a class of this height (witness + fixed traces of one size): B += the gathered codeword — the running B and the
@@ -142,7 +156,9 @@ int hook_mmcs_open(void* self, int commit, const uint64_t* idx, const uint64_t*,
     const DistCommit& K = D.commits[(size_t)commit];
     hipStream_t st = (hipStream_t)s;
     const int H = K.log_rows + D.log_blowup, hl = H - D.k;  // levels of a rank's sub-tree
-    const size_t per_loc = K.total_width + 4 * (size_t)hl, per_top = 4 * (size_t)D.k;
+    // the sub-trees hold the matrices with at least W codeword rows, the replicated top tree the shorter ones (their rows, then its log2 W levels)
+    const size_t tall_width = K.total_width - K.short_width;
+    const size_t per_loc = tall_width + 4 * (size_t)hl, per_top = K.short_width + 4 * (size_t)D.k;
     if (per_q != per_loc + per_top) return prover_set_error(CENO_HIP_ERR_STATE, "dist_basefold_open: opening size mismatch");
     std::vector<uint64_t> loc_idx(n), own(n);
     for (size_t q = 0; q < n; q++) {
@@ -157,8 +173,9 @@ int hook_mmcs_open(void* self, int commit, const uint64_t* idx, const uint64_t*,
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: index upload failed");
     // every rank opens its own sub-tree at the local index of every query (only the owner's answer is used) ...
     int rc = ceno_hip_mmcs_open_batch(D.ctx, K.subtree, d_loc, n, 0, d_ans, per_loc, s);
-    // ... and the replicated top tree at the owner's leaf
-    if (!rc && D.k > 0) rc = ceno_hip_merkle_open_batch(D.ctx, K.top, d_own, n, 0, d_top, s);
+    // ... and the replicated top tree at the owner's leaf: the rows of the short matrices + the top log2 W levels
+    if (!rc && K.short_width > 0) rc = ceno_hip_mmcs_open_batch(D.ctx, K.top, d_own, n, 0, d_top, per_top, s);
+    else if (!rc && D.k > 0) rc = ceno_hip_merkle_open_batch(D.ctx, K.top, d_own, n, 0, d_top, s);
     if (rc) return fail_ctx(D.ctx, rc);
     std::vector<uint64_t> mine(n * per_loc), top(n * per_top), all((size_t)D.W * n * per_loc), out(n * per_q);
     if (hipMemcpyAsync(mine.data(), d_ans, mine.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -166,8 +183,20 @@ int hook_mmcs_open(void* self, int commit, const uint64_t* idx, const uint64_t*,
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: answer download failed");
     if (int rc2 = dist_allgather_words(D.comm, mine.data(), mine.size(), all.data(), st)) return prover_set_error(rc2, ceno_dist_last_error());
     for (size_t q = 0; q < n; q++) {
-        memcpy(out.data() + q * per_q, all.data() + (size_t)own[q] * n * per_loc + q * per_loc, per_loc * 8);
-        if (per_top) memcpy(out.data() + q * per_q + per_loc, top.data() + q * per_top, per_top * 8);
+        // [row of every matrix in the caller's order][path of the sub-tree][path of the top]
+        const uint64_t* tall = all.data() + (size_t)own[q] * n * per_loc + q * per_loc;
+        const uint64_t* shrt = top.data() + q * per_top;
+        uint64_t* o = out.data() + q * per_q;
+        for (int m = 0; m < K.n_mats; m++) {
+            const size_t w = K.width_of[(size_t)m];
+            const uint64_t*& src = K.is_short[(size_t)m] ? shrt : tall;
+            memcpy(o, src, w * 8);
+            o += w;
+            src += w;
+        }
+        memcpy(o, tall, 4 * (size_t)hl * 8);
+        o += 4 * (size_t)hl;
+        memcpy(o, shrt, 4 * (size_t)D.k * 8);
     }
     if (hipMemcpyAsync(dev_out, out.data(), out.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: answer upload failed");
@@ -204,11 +233,12 @@ int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int
         DistCommit& K = D.commits[(size_t)c];
         K.n_mats = V.n_mats;
         for (int m = 0; m < V.n_mats; m++) {
-            if (V.log_rows[m] < 0 || V.log_rows[m] > 40) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad matrix height");
-            if (V.log_rows[m] + log_blowup < D.k)
-                return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: a codeword with fewer rows than ranks (it lives in the replicated top tree)");
+            // (a trace has at least two rows: next_pow2_instance_padding, ceno_zkvm/src/scheme/hal.rs:127-128)
+            if (V.log_rows[m] < 1 || V.log_rows[m] > 40) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_basefold_open: bad matrix height");
             K.log_rows = std::max(K.log_rows, V.log_rows[m]);
         }
+        if (K.log_rows + log_blowup < D.k)
+            return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_basefold_open: a commitment whose tallest codeword has fewer rows than there are ranks");
         K.log_rows_of.assign(V.log_rows, V.log_rows + V.n_mats);
         K.widths = V.widths;
         K.local_trace_cols = V.local_trace_cols;
@@ -243,6 +273,8 @@ int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int
             K.class_mats[(size_t)cls].push_back(m);
             K.width_of.push_back(w);
             K.total_width += w;
+            K.is_short.push_back(V.log_rows[m] + log_blowup < D.k ? 1 : 0);
+            if (K.is_short.back()) K.short_width += w;
         }
         shape_ptrs.push_back(&shape);
     }

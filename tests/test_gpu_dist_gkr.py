@@ -157,18 +157,18 @@ def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     group.close()
 
 
-def test_multi_rank_opening_refuses_a_codeword_shorter_than_the_ranks(dev, prover):
-    """a matrix whose codeword has fewer rows than there are ranks lives in the replicated top tree of the sharded commitment: the opening
-    says so (before it touches any table) instead of opening the wrong rows"""
+def test_multi_rank_opening_refuses_a_commitment_shorter_than_the_ranks(dev, prover):
+    """a commitment whose TALLEST codeword has fewer rows than there are ranks has no row shards at all: the opening says so before it touches
+    any table"""
     from ceno_amd.api import CenoHipError
 
     group = prover.LocalGroup(8)
     stream = dev.stream_create()
-    pts = [np.zeros((6, 2), dtype=np.uint64), np.zeros((1, 2), dtype=np.uint64)]
+    pts = [np.zeros((1, 2), dtype=np.uint64), np.zeros((1, 2), dtype=np.uint64)]
     evs = [np.zeros((8, 2), dtype=np.uint64)] * 2
     with pytest.raises(CenoHipError) as ei:
-        prover.dist_basefold_open(dev, group.comms[0], [6, 1], [[1] * 8, [1] * 8], 1, [8, 8], [8, 8], 8, 8, pts, evs, 4, 0, prover.Transcript.stub(1), stream)
-    assert "fewer rows than ranks" in str(ei.value)
+        prover.dist_basefold_open(dev, group.comms[0], [1, 1], [[1] * 8, [1] * 8], 1, [8, 8], [8, 8], 8, 8, pts, evs, 4, 0, prover.Transcript.stub(1), stream)
+    assert "fewer rows than there are ranks" in str(ei.value)
     group.close()
 
 
@@ -184,6 +184,11 @@ def test_multi_rank_opening_refuses_a_codeword_shorter_than_the_ranks(dev, prove
     (2, [8, 6], [[2, 1], [1, 3]], "stub"),
     (4, [7, 9, 5, 9], [[1, 1, 1, 1], [2, 1, 0, 3], [1, 2, 1, 1], [1, 1, 2, 1]], "poseidon2"),
     (8, [10, 6, 8], [[1] * 8, [2, 1, 1, 1, 1, 1, 1, 1], [1] * 8], "stub"),
+    # chips of one or two rows in a shard (traces are padded to two rows, scheme/hal.rs:127-128): a codeword with exactly as many rows as ranks
+    # joins at the sub-trees' roots; one with FEWER rows than ranks is held whole by every rank and lives in the replicated top tree
+    (4, [6, 1, 5], [[1, 1, 1, 1], [1, 2, 1, 1], [2, 1, 1, 1]], "stub"),
+    (8, [1, 9, 1], [[1] * 8, [1] * 8, [1, 1, 2, 1, 1, 1, 1, 1]], "poseidon2"),
+    (8, [7, 1], [[1] * 8, [2, 1, 1, 1, 1, 1, 1, 3]], "stub"),
 ])
 def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world, log_rows, col_split, transcript):
     """commit across `world` virtual ranks (column-sharded RS encoding, re-shard by rows, sub-trees + replicated top), then open across them:
@@ -232,7 +237,9 @@ def test_multi_rank_opening_equals_the_single_device_opening(dev, prover, world,
                 if com.get(key):
                     dev.L.ceno_hip_merkle_free(dev.h, com[key])
         except Exception as e:  # noqa: BLE001
-            errors.append((rank, repr(e)))
+            import traceback
+
+            errors.append((rank, repr(e), traceback.format_exc(limit=4)))
 
     ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in ths:
@@ -309,7 +316,9 @@ def test_multi_rank_opening_of_witness_and_fixed_commitments(dev, prover, world,
                     if cm.get(key):
                         dev.L.ceno_hip_merkle_free(dev.h, cm[key])
         except Exception as e:  # noqa: BLE001
-            errors.append((rank, repr(e)))
+            import traceback
+
+            errors.append((rank, repr(e), traceback.format_exc(limit=4)))
 
     ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
     for t in ths:
