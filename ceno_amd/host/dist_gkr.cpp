@@ -20,6 +20,8 @@
 //     eq(g, rt[s_t .. s_t + k)) (folded into the alpha powers) — the 3 partial evaluations per round are summed across ranks (one small
 //     all-gather per round, as ceno_dist_sumcheck_prove); then the folded tables (2^(r - k - s_min) entries per rank) are gathered,
 //     interleaved into the global tables of 2^(r - s_min) entries and the remaining rounds run replicated on the host;
+//   * the rotation argument of a keccak-style chip (prover_prove_rotation_sharded, prover.cpp): the rotation pairs rows inside blocks of 32 / 64,
+//     which a row block (2^q >= 64 rows) keeps on one rank; its sumcheck runs q local rounds, then the gathered tail replicated;
 //   * the transcript is replicated: every rank appends the same words and draws the same challenges.
 // Per-rank work is 1 / world of the large layers; what is replicated is the tower top (<= 2^(s_max + k) entries) and the tails.
 #include <hip/hip_runtime_api.h>
@@ -282,12 +284,15 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* comm, const c
     const int W = dist_comm_world(comm), rank = dist_comm_rank(comm), k = ceil_log2((size_t)W);
     if (W == 1) return ceno_prover_create_chip_proof(ctx, task, challenges4, tr, s, out);
     if (((size_t)1 << k) != (size_t)W) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_create_chip_proof: the number of ranks must be a power of two");
-    if (task->n_rotation_pairs > 0 || task->rotation_vars > 0)
-        return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "dist_create_chip_proof: the rotation argument is not sharded (prove such chips on one rank)");
     const int q = row_block_log > 0 ? row_block_log : ceno_dist_chip_block_log();
-    const int n = log2_num_instances_global, n_loc = n - k;
+    // a keccak-style chip has 2^rotation_vars rows per instance (prover.rs:728-729): the ROWS are what is sharded
+    const int rot_vars = std::max(task->rotation_vars, 0);
+    const int n = log2_num_instances_global + rot_vars, n_loc = n - k;
     if (n_loc < q + 1) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_create_chip_proof: the chip is too small for this block size (needs log2 rows >= q + log2 world + 1)");
-    if (task->log2_num_instances != n_loc) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_create_chip_proof: task->log2_num_instances must be the LOCAL height");
+    if (task->log2_num_instances + rot_vars != n_loc)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "dist_create_chip_proof: task->log2_num_instances (+ rotation_vars) must be the LOCAL height");
+    if (task->n_rotation_pairs > 0 && (q < task->cyclic_group_log2 || !task->rotation_source_idx || !task->rotation_target_idx))
+        return prover_set_error(CENO_HIP_ERR_INVALID, "dist_create_chip_proof: the row blocks must hold whole cyclic groups of the rotation (q >= cyclic_group_log2)");
     memset(out, 0, sizeof(*out));
     hipStream_t st = (hipStream_t)s;
     const int n_mles = task->n_witin + task->n_fixed + task->n_structural;
@@ -316,8 +321,8 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* comm, const c
     if (rc) return fail_ctx(ctx, rc);
     // ---- local towers = the shards of the global towers' large layers ----
     ceno_tower_witness tw_loc;
-    rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk, n_loc, 0, challenges4, s,
-                                         &tw_loc);
+    rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk, n_loc - rot_vars, rot_vars,
+                                         challenges4, s, &tw_loc);
     for (auto* m : records)
         if (m) ceno_hip_mle_free(ctx, m);
     if (rc) return rc;
@@ -457,6 +462,36 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* comm, const c
         return prover_set_error(CENO_HIP_ERR_STATE, "tower challenge point is shorter than the main point");
     }
     memcpy(out->rt_main, out->tower.point + (size_t)2 * (max_nv - n), (size_t)16 * n);
+    // ---- prove_rotation (prover.rs:771-776; keccak-style chips): local rotations and local rounds, the tail replicated ----
+    if (task->n_rotation_pairs > 0) {
+        const int np = task->n_rotation_pairs;
+        out->n_rotation_pairs = np;
+        out->rotation_msgs = (uint64_t*)calloc((size_t)n * 2 * 2, 8);
+        out->rotation_evals = (uint64_t*)calloc((size_t)3 * np * 2, 8);
+        out->rotation_points = (uint64_t*)calloc((size_t)3 * n * 2, 8);  // origin | left | right
+        if (!out->rotation_msgs || !out->rotation_evals || !out->rotation_points) {
+            ceno_chip_proof_free(out);
+            return prover_set_error(CENO_HIP_ERR_OOM, "dist_create_chip_proof: out of host memory");
+        }
+        struct Gather {
+            ceno_dist_comm* comm;
+            hipStream_t st;
+        } gth{comm, st};
+        RotationShard sh{W, rank, k, q,
+                         [](void* self, const uint64_t* mine, size_t n_words, uint64_t* all) -> int {
+                             auto* G = static_cast<Gather*>(self);
+                             if (int rc2 = dist_allgather_words(G->comm, mine, n_words, all, G->st)) return prover_set_error(rc2, ceno_dist_last_error());
+                             return 0;
+                         },
+                         &gth};
+        rc = prover_prove_rotation_sharded(ctx, task->mles, task->rotation_source_idx, task->rotation_target_idx, np, task->cyclic_subgroup_size,
+                                           task->cyclic_group_log2, out->rt_main, n, tr, s, out->rotation_msgs, out->rotation_evals, out->rotation_points,
+                                           out->rotation_points + (size_t)2 * n, out->rotation_points + (size_t)4 * n, &sh);
+        if (rc) {
+            ceno_chip_proof_free(out);
+            return rc;
+        }
+    }
     return 0;
 }
 

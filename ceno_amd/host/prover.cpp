@@ -649,6 +649,190 @@ int ceno_prover_prove_rotation(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, cons
     return 0;
 }
 
+}  // extern "C"
+
+// The same argument over row-sharded columns (ceno_dist_create_chip_proof; layout: tower_hook.hpp RotationShard, dist_gkr.cpp).  The rotation
+// pairs rows inside blocks of 2^log2 <= 2^q rows, which the block layout keeps on one rank: every rank rotates its own tables.  The selector is
+// eq(x, rt) masked on the low log2 bits of x, so a rank's selector is the same construction at the point without the rank coordinates, times
+// the scalar eq(rank, rt[q .. q + k)) — carried by the coefficients.  The first q rounds run on the local tables (two partial evaluations per
+// round, summed over the ranks), then the folded tables — 2^(n - k - q) entries per rank — are gathered into the global tables (rank bits
+// lowest) and the remaining n - q rounds run replicated; the left evaluations are sums of per-rank evaluations weighted by eq over the rank
+// coordinates of the left point.  Messages, challenges, points and evaluations are those of ceno_prover_prove_rotation on the whole columns.
+int prover_prove_rotation_sharded(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit, const int* source_idx, const int* target_idx, int n_pairs,
+                                  int cyclic_subgroup_size, int cyclic_group_log2, const uint64_t* rt, int n, ceno_transcript* tr, ceno_hip_stream s,
+                                  uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin, uint64_t* out_left, uint64_t* out_right,
+                                  const RotationShard* sh) {
+    if (!ctx || !wit || !source_idx || !target_idx || !rt || !tr || n_pairs < 1 || !sh || !sh->allgather) return fail(CENO_HIP_ERR_INVALID, "bad rotation arguments");
+    if (cyclic_group_log2 != 5 && cyclic_group_log2 != 6) return fail(CENO_HIP_ERR_INVALID, "cyclic group log2 must be 5 or 6");
+    const int W = sh->world, k = sh->k, q = sh->q, n_loc = n - k;
+    if (q < cyclic_group_log2 || n_loc < q + 1) return fail(CENO_HIP_ERR_INVALID, "sharded rotation: the row blocks must hold whole cyclic groups and every rank at least two blocks");
+    auto point = [&](const uint64_t* p, int j) { return E2{p[2 * j], p[2 * j + 1]}; };
+    auto eq_rank = [&](const uint64_t* p) {  // eq(rank, p[q .. q + k))
+        E2 v = gl::e2_one();
+        for (int j = 0; j < k; j++) v = v * (((sh->rank >> j) & 1) ? point(p, q + j) : gl::e2_one() - point(p, q + j));
+        return v;
+    };
+    auto local_point = [&](const uint64_t* p, std::vector<uint64_t>& out) {
+        out.clear();
+        for (int j = 0; j < n; j++)
+            if (j < q || j >= q + k) {
+                out.push_back(p[2 * j]);
+                out.push_back(p[2 * j + 1]);
+            }
+    };
+    std::vector<ceno_hip_mle*> rotated(n_pairs, nullptr), glob;
+    ceno_hip_mle* sel = nullptr;
+    ceno_hip_sumcheck *sc = nullptr, *sc2 = nullptr;
+    auto cleanup = [&]() {
+        if (sc) ceno_hip_sumcheck_free(ctx, sc);
+        if (sc2) ceno_hip_sumcheck_free(ctx, sc2);
+        for (auto* m : rotated) if (m) ceno_hip_mle_free(ctx, m);
+        for (auto* m : glob) if (m) ceno_hip_mle_free(ctx, m);
+        if (sel) ceno_hip_mle_free(ctx, sel);
+    };
+    std::vector<uint64_t> rt_loc;
+    local_point(rt, rt_loc);
+    const E2 eq_g = eq_rank(rt);
+    int rc = ceno_hip_rotation_selector_build(ctx, rt_loc.data(), n_loc, cyclic_subgroup_size, cyclic_group_log2, s, &sel);
+    for (int j = 0; j < n_pairs && !rc; j++) rc = ceno_hip_rotation_next_base_mle(ctx, wit[source_idx[j]], cyclic_group_log2, s, &rotated[j]);
+    if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    std::vector<uint64_t> alpha;
+    tr_challenge_pows(tr, n_pairs, alpha);
+    // mles [rot_0, tgt_0, ..., selector]; sel * sum_j alpha^j (rot_j - tgt_j); the LOCAL plan carries the rank's eq factor in its coefficients
+    const int n_mles = 2 * n_pairs + 1;
+    std::vector<ceno_hip_mle*> mles;
+    std::vector<uint64_t> coeffs, coeffs_loc;
+    std::vector<uint32_t> toff{0}, tidx, gterms;
+    for (int j = 0; j < n_pairs; j++) {
+        mles.push_back(rotated[j]);
+        mles.push_back(wit[target_idx[j]]);
+        const E2 a{alpha[2 * j], alpha[2 * j + 1]}, na = gl::e2_neg(a), al = a * eq_g, nal = gl::e2_neg(al);
+        coeffs.insert(coeffs.end(), {a.c0, a.c1, na.c0, na.c1});
+        coeffs_loc.insert(coeffs_loc.end(), {al.c0, al.c1, nal.c0, nal.c1});
+        tidx.push_back(2 * j);     toff.push_back((uint32_t)tidx.size()); gterms.push_back(2 * j);
+        tidx.push_back(2 * j + 1); toff.push_back((uint32_t)tidx.size()); gterms.push_back(2 * j + 1);
+    }
+    mles.push_back(sel);
+    std::vector<uint32_t> goff{0, (uint32_t)gterms.size()}, coff{0, 1}, cidx{(uint32_t)(2 * n_pairs)};
+    ceno_hip_sumcheck_plan plan{};
+    plan.num_mles = n_mles;
+    plan.num_terms = 2 * n_pairs;
+    plan.term_coeffs = coeffs_loc.data();
+    plan.term_offsets = toff.data();
+    plan.term_mle_idx = tidx.data();
+    plan.num_groups = 1;
+    plan.group_term_offsets = goff.data();
+    plan.group_term_idx = gterms.data();
+    plan.common_offsets = coff.data();
+    plan.common_mle_idx = cidx.data();
+    plan.max_num_vars = n_loc;
+    plan.max_degree = 2;
+    rc = ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, &sc);
+    if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    tr_usize(tr, (uint64_t)n);
+    tr_usize(tr, 2);
+    uint64_t ch[2] = {0, 0};
+    std::vector<uint64_t> all((size_t)W * 4);
+    auto publish = [&](int round, const E2* p) {  // the round's message into the proof and the transcript, its challenge out
+        uint64_t* msg = out_msgs + (size_t)4 * round;
+        for (int e = 0; e < 2; e++) {
+            msg[2 * e] = p[e].c0;
+            msg[2 * e + 1] = p[e].c1;
+            tr_ext(tr, msg + 2 * e);
+        }
+        tr_label(tr, "Internal round");
+        const E2 r = tr_sample(tr);
+        ch[0] = r.c0;
+        ch[1] = r.c1;
+        out_origin[2 * round] = r.c0;
+        out_origin[2 * round + 1] = r.c1;
+    };
+    for (int i = 0; i < q; i++) {  // local rounds: the partial evaluations of every rank, summed
+        uint64_t m[4];
+        rc = ceno_hip_sumcheck_round(ctx, sc, i == 0 ? nullptr : ch, m);
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+        if (int rc2 = sh->allgather(sh->self, m, 4, all.data())) { cleanup(); return rc2; }
+        E2 p[2] = {gl::e2_zero(), gl::e2_zero()};
+        for (int g = 0; g < W; g++)
+            for (int e = 0; e < 2; e++) p[e] = p[e] + E2{all[(size_t)g * 4 + 2 * e], all[(size_t)g * 4 + 2 * e + 1]};
+        publish(i, p);
+    }
+    // the folded tables (as the next round would read them: folded q - 1 times; once more here), gathered with the rank bits lowest
+    const size_t len_loc = (size_t)1 << (n_loc - q);
+    const int nv_rem = n - q;
+    const E2 r_last{ch[0], ch[1]};
+    std::vector<E2> t(2 * len_loc), g_tab(len_loc * (size_t)W);
+    std::vector<uint64_t> mine(2 * len_loc), gathered((size_t)W * 2 * len_loc);
+    glob.assign((size_t)n_mles, nullptr);
+    for (int mi = 0; mi < n_mles; mi++) {
+        int nv = 0;
+        rc = ceno_hip_sumcheck_table_host(ctx, sc, mi, reinterpret_cast<uint64_t*>(t.data()), t.size(), &nv);
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+        if (nv != n_loc - q + 1) { cleanup(); return fail(CENO_HIP_ERR_STATE, "sharded rotation: unexpected table shape after the local rounds"); }
+        const bool is_sel = mi == n_mles - 1;  // (its rank factor went into the coefficients: the global selector carries it)
+        for (size_t j = 0; j < len_loc; j++) {
+            E2 v = t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j]);
+            if (is_sel) v = v * eq_g;
+            mine[2 * j] = v.c0;
+            mine[2 * j + 1] = v.c1;
+        }
+        if (int rc2 = sh->allgather(sh->self, mine.data(), 2 * len_loc, gathered.data())) { cleanup(); return rc2; }
+        for (int g = 0; g < W; g++) {
+            const E2* src = reinterpret_cast<const E2*>(gathered.data()) + (size_t)g * len_loc;
+            for (size_t j = 0; j < len_loc; j++) g_tab[(j << k) | (size_t)g] = src[j];
+        }
+        rc = ceno_hip_mle_upload(ctx, reinterpret_cast<const uint64_t*>(g_tab.data()), nv_rem, 1, s, &glob[(size_t)mi]);
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    }
+    ceno_hip_sumcheck_free(ctx, sc);
+    sc = nullptr;
+    // the remaining rounds, replicated
+    plan.term_coeffs = coeffs.data();
+    plan.max_num_vars = nv_rem;
+    rc = ceno_hip_sumcheck_begin(ctx, glob.data(), &plan, s, &sc2);
+    if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    for (int i = 0; i < nv_rem; i++) {
+        uint64_t m[4];
+        rc = ceno_hip_sumcheck_round(ctx, sc2, i == 0 ? nullptr : ch, m);
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+        const E2 p[2] = {E2{m[0], m[1]}, E2{m[2], m[3]}};
+        publish(q + i, p);
+    }
+    std::vector<uint64_t> fin(2 * (size_t)n_mles);
+    rc = ceno_hip_sumcheck_finish(ctx, sc2, nv_rem > 0 ? ch : nullptr, fin.data());
+    if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+    rotation_points(out_origin, n, cyclic_group_log2, out_left, out_right);
+    const int kk = cyclic_group_log2 - 1;
+    const E2 rk{out_origin[2 * kk], out_origin[2 * kk + 1]};
+    const E2 rk_inv = gl::e2_inv(rk);
+    // left evaluations: every rank evaluates its rows at the left point without the rank coordinates, weighted by eq over them
+    std::vector<uint64_t> left_loc;
+    local_point(out_left, left_loc);
+    const E2 eq_left = eq_rank(out_left);
+    std::vector<uint64_t> part(2 * (size_t)n_pairs), parts((size_t)W * 2 * n_pairs);
+    for (int j = 0; j < n_pairs; j++) {
+        uint64_t le[2];
+        rc = ceno_hip_mle_evaluate(ctx, wit[source_idx[j]], left_loc.data(), le, s);
+        if (rc) { cleanup(); return fail_from_ctx(ctx, rc); }
+        const E2 v = E2{le[0], le[1]} * eq_left;
+        part[2 * j] = v.c0;
+        part[2 * j + 1] = v.c1;
+    }
+    if (int rc2 = sh->allgather(sh->self, part.data(), part.size(), parts.data())) { cleanup(); return rc2; }
+    for (int j = 0; j < n_pairs; j++) {
+        E2 left = gl::e2_zero();
+        for (int g = 0; g < W; g++) left = left + E2{parts[(size_t)g * 2 * n_pairs + 2 * j], parts[(size_t)g * 2 * n_pairs + 2 * j + 1]};
+        const E2 rot{fin[4 * j], fin[4 * j + 1]}, target{fin[4 * j + 2], fin[4 * j + 3]};
+        const E2 right = (rot - (gl::e2_one() - rk) * left) * rk_inv;
+        uint64_t* e = out_evals + 6 * j;
+        e[0] = left.c0; e[1] = left.c1; e[2] = right.c0; e[3] = right.c1; e[4] = target.c0; e[5] = target.c1;
+    }
+    for (int j = 0; j < 3 * n_pairs; j++) tr_ext(tr, out_evals + 2 * j);
+    cleanup();
+    return 0;
+}
+
+extern "C" {
 // ---- the eight-lane host arithmetic (csrc/e2_host_avx512.hpp) against the scalar operators: a, b = eight extension elements each (c0, c1
 // interleaved); out = a + b | a - b | a * b | fold(a as four pairs... ) — returns 0 when the CPU has no AVX-512 ----
 #if defined(__x86_64__)

@@ -12,3 +12,15 @@ struct TowerDistHook {
     int (*layer)(void* self, int round, const uint64_t* out_rt, const uint64_t* alpha, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal, uint64_t* fin);
     void* self;
 };
+
+// The rotation argument over ROW-SHARDED witness columns (prover.cpp prover_prove_rotation_sharded <-> dist_gkr.cpp): rank `rank` of `world` = 2^k
+// holds the rows whose index bits [q, q + k) equal its number; `allgather` collects n_words words of every rank, rank-major.
+struct RotationShard {
+    int world, rank, k, q;
+    int (*allgather)(void* self, const uint64_t* mine, size_t n_words, uint64_t* all);
+    void* self;
+};
+int prover_prove_rotation_sharded(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit_local, const int* source_idx, const int* target_idx, int n_pairs,
+                                  int cyclic_subgroup_size, int cyclic_group_log2, const uint64_t* rt, int n, ceno_transcript* tr, ceno_hip_stream s,
+                                  uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin, uint64_t* out_left, uint64_t* out_right,
+                                  const RotationShard* sh);

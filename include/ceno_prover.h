@@ -474,7 +474,9 @@ int ceno_dist_comm_init_local(ceno_dist_local_group* group, int rank, ceno_dist_
  * task->log2_num_instances = log2_num_instances_global - k their height (task->num_instances stays the GLOBAL count; record plans as in
  * ceno_chip_task).  A layout by the MIDDLE bits keeps both the product layers (which pair the top bit) and the LSB-first layer sumchecks
  * local; the top of every tower (<= 2^(q + log2 records + k) entries per limb) is gathered and proved replicated.  Needs
- * log2_num_instances_global >= q + k + 1; the rotation argument is not sharded (CENO_HIP_ERR_UNSUPPORTED).  Every rank passes a transcript
+ * log2_num_instances_global (+ rotation_vars) >= q + k + 1.  A keccak-style chip (task->rotation_vars, rotation pairs) shards its ROWS the same way
+ * (task->log2_num_instances + rotation_vars = the local height; q >= cyclic_group_log2): rotations are local, the rotation sumcheck runs q local
+ * rounds and its gathered tail replicated.  Every rank passes a transcript
  * in the same state and ends with the same proof; works over any transport of the communicator (in-process group, shared segment, RCCL). */
 int ceno_dist_chip_block_log(void);
 int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_chip_task* task, int log2_num_instances_global, int row_block_log,

@@ -139,6 +139,61 @@ def test_row_sharded_chip_proof_matches_the_oracle(dev, prover):
     assert np.array_equal(got.tower_prod_evals, oproof.prod_evals) and np.array_equal(got.tower_logup_evals, oproof.logup_evals)
 
 
+@pytest.mark.parametrize("world,log2_inst,rot_log,q", [(2, 3, 5, 5), (4, 4, 5, 6), (2, 2, 6, 6), (8, 5, 5, 5), (4, 4, 6, 7)])
+def test_row_sharded_chip_proof_with_rotation_equals_the_single_device_proof(dev, prover, world, log2_inst, rot_log, q):
+    """a keccak-style chip (2^log2_inst instances x 2^rot_log rotation rows; rotation pairs inside cyclic groups of 32 / 64 rows) with its ROWS
+    sharded: tower proof as before, then the rotation argument — local rotations, q local sumcheck rounds, the gathered tail replicated, left
+    evaluations summed over the ranks — must give the single-device proof's messages, points and evaluations word for word on every rank
+    (prove_rotation, gkr_iop/src/gkr/layer/cpu/mod.rs:249-389)"""
+    w = 4
+    nv = log2_inst + rot_log
+    k = world.bit_length() - 1
+    alpha, beta = (5, 6), (7, 8)
+    src = po.rand_base(1 << nv, 31 + world)
+    cols = [src, po.rotation_next_base_mle(src, rot_log), po.rand_base(1 << nv, 32), po.rand_base(1 << nv, 33)]
+    coeffs, terms, out_terms = record_plan(w, 3, alpha, beta)
+    rotation = dict(pairs=[(0, 1), (2, 3)], cyclic_subgroup_size=23 if rot_log == 5 else 45, cyclic_group_log2=rot_log)
+    base = dict(n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << log2_inst) - 1, rotation_vars=rot_log, num_reads=1, num_writes=1,
+                num_lk_tables=0, num_lk=1, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms, rotation=rotation)
+    mles = [dev.upload(c) for c in cols]
+    want = prover.create_chip_proof(dev, dict(base, mles=mles, log2_num_instances=log2_inst), [alpha, beta], prover.Transcript.stub(8))
+    for m in mles:
+        m.free()
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            local = [dev.upload(prover.shard_rows(c, world, g, q)) for c in cols]
+            task = dict(base, mles=local, log2_num_instances=log2_inst - k)
+            results[g] = prover.dist_create_chip_proof(dev, group.comms[g], task, log2_inst, q, [alpha, beta], prover.Transcript.stub(8), st)
+            dev.sync(st)
+            for m in local:
+                m.free()
+            dev.stream_destroy(st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((g, repr(e), traceback.format_exc(limit=3)))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for g in range(world):
+        got = results[g]
+        assert proofs_equal(got, want), f"rank {g}: tower part"
+        assert np.array_equal(got.rotation_msgs, want.rotation_msgs), f"rank {g}: rotation messages"
+        assert np.array_equal(got.rotation_points, want.rotation_points) and np.array_equal(got.rotation_evals, want.rotation_evals), f"rank {g}"
+
+
 def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     from ceno_amd.api import CenoHipError
 
