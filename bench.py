@@ -540,8 +540,11 @@ def main():
         heights, validated against the single-device root computed by rank 0, then timed.  Guarded exactly like the RCCL sumcheck arm:
         without a validated RCCL communicator it reports why and the bench goes on; a rank that fails reports it through the
         all-reduce; a collective that never returns is caught by the caller's watchdog (non-zero exit of the process)."""
-        if "rccl" not in comms:
-            return {"status": "skipped: no RCCL communicator on this launch (the re-shard by rows is a device-to-device exchange)"}
+        # RCCL where this launch has a validated communicator; otherwise the shared segment's host-staged bulk exchange (ranks sharing one GPU, a
+        # node whose RCCL is unusable): the same entry points, validated the same way — its times say nothing about xGMI and are labelled
+        bulk = "rccl" if "rccl" in comms else ("shm" if "shm" in comms else None)
+        if bulk is None:
+            return {"status": "skipped: no communicator with a bulk exchange on this launch"}
         import ctypes as C
 
         from ceno_amd import dist as cdist2
@@ -555,7 +558,7 @@ def main():
             cst = dev.stream_create()
 
             def run_once():
-                r_ = cdist2.sharded_commit_mmcs_native(dev, comms["rccl"].h, [m_.device_ptr for m_ in mine], widths, log_rows, blow, rank, cst)
+                r_ = cdist2.sharded_commit_mmcs_native(dev, comms[bulk].h, [m_.device_ptr for m_ in mine], widths, log_rows, blow, rank, cst)
                 dev.sync(cst)
                 for key in ("subtree", "top"):
                     if r_.get(key):
@@ -596,24 +599,25 @@ def main():
         # ... and the OPENING of a commitment made across the ranks (ceno_dist_basefold_open: one matrix of 2^14 rows, 2 columns per rank):
         # validated word for word against the single-device opening rank 0 computes, then timed
         try:
-            info["dist_open"] = dist_open_part(cdist2, cst)
+            info["dist_open"] = dist_open_part(cdist2, cst, bulk)
         except Exception as e:  # noqa: BLE001
             info["dist_open"] = {"status": f"failed: {type(e).__name__}: {e}"}
-        return {"status": "ok", "ms": ms, "workload": f"ceno_dist_commit_traces_mmcs: traces of 2^{log_rows[0]} x {cols_per_rank[0] * world} and 2^{log_rows[1]} x "
+        return {"status": "ok", "ms": ms, "bulk_exchange": "RCCL (grouped ncclSend / ncclRecv)" if bulk == "rccl" else "shared segment, host-staged (no RCCL communicator)",
+                "workload": f"ceno_dist_commit_traces_mmcs: traces of 2^{log_rows[0]} x {cols_per_rank[0] * world} and 2^{log_rows[1]} x "
                 f"{cols_per_rank[1] * world} base elements column-sharded over {world} ranks, blow-up 2, ONE root", **info}
 
-    def dist_open_part(cdist2, cst) -> dict:
+    def dist_open_part(cdist2, cst, bulk) -> dict:
         lr, c, blow, nq, pow_bits = 14, 2, 1, 20, 8
         mine = dev.synthetic(lr + 1, False, 0x0BE11 + rank)
         dev.sync()
         widths = [[c] * world]
-        com = cdist2.sharded_commit_mmcs_native(dev, comms["rccl"].h, [mine.device_ptr], widths, [lr], blow, rank, cst)
+        com = cdist2.sharded_commit_mmcs_native(dev, comms[bulk].h, [mine.device_ptr], widths, [lr], blow, rank, cst)
         dev.sync(cst)
         point = np.array([[i * 7919 + 13, i * 104729 + 17] for i in range(lr)], dtype=np.uint64)
         evals = [np.zeros((c * world, 2), dtype=np.uint64)]  # (one height class: the claimed evaluations do not enter the proof's words)
 
         def run_once():
-            return prover.dist_basefold_open(dev, comms["rccl"].h, lr, widths, blow, [mine.device_ptr], [t.data_ptr() for t in com["codeword_rows"]],
+            return prover.dist_basefold_open(dev, comms[bulk].h, lr, widths, blow, [mine.device_ptr], [t.data_ptr() for t in com["codeword_rows"]],
                                              com["subtree"], com["top"], [point], evals, nq, pow_bits, factories[args.transcript](), cst)
 
         got = run_once()

@@ -955,6 +955,58 @@ int dist_fail(int code, const std::string& msg) {
 
 // all-to-all of unequal blocks of 64-bit words.  send block for destination g: send + soff[g], scnt[g] words;
 // block from source g lands at recv + roff[g], rcnt[g] words.  The own block is copied on the device.
+// The same exchange between PROCESSES without RCCL (several ranks on one GPU, or a node whose RCCL is unusable): through the shared segment's bulk
+// area, staged on the host.  Step k = 1 .. W - 1 moves the block for rank me + k and takes the one from rank me - k, 128 KB per publication; every
+// rank makes the same number of publications per step (the largest block of anyone sets it), so the sequence words stay in lock step and a buffer is
+// rewritten only after every rank has passed the publication that read it.  A correctness path (~10 GB/s of host copies), not a fast one.
+static int shm_exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const size_t* soff, const size_t* scnt, uint64_t* recv, const size_t* roff,
+                               const size_t* rcnt, hipStream_t st) {
+    const int W = c->world, me = c->rank;
+    if (scnt[me] && hipMemcpyAsync(recv + roff[me], send + soff[me], scnt[me] * 8, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: device copy failed");
+    uint64_t mx = 0;
+    for (int g = 0; g < W; g++) mx = std::max<uint64_t>(mx, g == me ? 0 : scnt[g]);
+    std::vector<uint64_t> all_mx((size_t)W);
+    if (int rc = shm_gather_bulk(c, &mx, 1, all_mx.data(), 1)) return dist_fail(rc, g_dist_err.c_str());
+    for (uint64_t v : all_mx) mx = std::max(mx, v);
+    const size_t n_chunks = (size_t)((mx + SHM_BULK_WORDS - 1) / SHM_BULK_WORDS);
+    std::vector<std::vector<uint64_t>> hs((size_t)W), hr((size_t)W);
+    for (int g = 0; g < W; g++) {
+        if (g == me) continue;
+        hs[(size_t)g].resize(scnt[g]);
+        hr[(size_t)g].resize(rcnt[g]);
+        if (scnt[g] && hipMemcpyAsync(hs[(size_t)g].data(), send + soff[g], scnt[g] * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+            return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: download failed");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: sync failed");
+    for (int k = 1; k < W; k++) {
+        const int to = (me + k) % W, from = (me - k + W) % W;
+        for (size_t ch = 0; ch < n_chunks; ch++) {
+            const size_t o = ch * SHM_BULK_WORDS;
+            const size_t ns = scnt[to] > o ? std::min<size_t>(SHM_BULK_WORDS, scnt[to] - o) : 0;
+            const size_t nr = rcnt[from] > o ? std::min<size_t>(SHM_BULK_WORDS, rcnt[from] - o) : 0;
+            const uint64_t seq = ++c->shm_seq;
+            if (ns) memcpy(shm_bulk(c->shm, W, me, (int)(seq & 1)), hs[(size_t)to].data() + o, ns * 8);
+            __atomic_store_n(&c->shm->ranks[me].seq, seq, __ATOMIC_RELEASE);
+            for (int g = 0; g < W; g++) {
+                uint64_t spins = 0;
+                while (__atomic_load_n(&c->shm->ranks[g].seq, __ATOMIC_ACQUIRE) < seq) {
+                    if (++spins > ((uint64_t)1 << 34)) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: a peer never published its block");
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            }
+            if (nr) memcpy(hr[(size_t)from].data() + o, shm_bulk(c->shm, W, from, (int)(seq & 1)), nr * 8);
+        }
+    }
+    for (int g = 0; g < W; g++)
+        if (g != me && rcnt[g] && hipMemcpyAsync(recv + roff[g], hr[(size_t)g].data(), rcnt[g] * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+            return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: upload failed");
+    if (hipStreamSynchronize(st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "exchange_blocks: sync failed");  // (the staging vectors go out of scope)
+    return 0;
+}
+
 int exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const size_t* soff, const size_t* scnt, uint64_t* recv, const size_t* roff,
                     const size_t* rcnt, hipStream_t st) {
     const int W = c->world, me = c->rank;
@@ -981,7 +1033,8 @@ int exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const size_t* soff,
         if (!G->barrier()) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: a peer of the local group is gone");  // send buffers may be reused now
         return 0;
     }
-    if (!c->comm) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: the communicator has no bulk transport (RCCL or local group)");
+    if (!c->comm && c->shm) return shm_exchange_blocks(c, send, soff, scnt, recv, roff, rcnt, st);
+    if (!c->comm) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: the communicator has no transport");
     if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
         return dist_fail(CENO_HIP_ERR_UNSUPPORTED, "this RCCL has no ncclSend / ncclRecv");
     const bool self_p2p = getenv("CENO_DIST_SELF_P2P") && atoi(getenv("CENO_DIST_SELF_P2P")) != 0;  // tests: own block through RCCL too

@@ -490,8 +490,8 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno
  * matrices of one height 2^log_rows, ceno_dist_basefold_open_mmcs matrices of any heights log_rows[m] (a shard's traces; one batched codeword
  * per height class; a matrix whose codeword has fewer rows than ranks is opened from the replicated top tree; only the TALLEST codeword of the
  * commitment needs at least `world` rows); widths[m * world + g] as in the commit; points / evals per matrix as in
- * ceno_prover_basefold_open (evals: all `sum_g widths` columns, rank-major).  Needs the communicator's bulk transport (in-process group or
- * RCCL) for the all-gathers.  ceno_dist_basefold_open_commits: several such commitments in one opening. */
+ * ceno_prover_basefold_open (evals: all `sum_g widths` columns, rank-major).  The bulk all-gathers use RCCL, the in-process group's device copies, or — between
+ * processes without RCCL — the shared segment (host-staged: a correctness path).  ceno_dist_basefold_open_commits: several such commitments in one opening. */
 /* ... and of SEVERAL commitments in one opening (OpeningProver::open takes the witness and the fixed commitment, scheme/hal.rs:284-294): one view
  * per commitment, points / evals over the matrices of all of them in order; a height that two commitments share is one batched codeword */
 typedef struct ceno_dist_commit_view {

@@ -260,6 +260,50 @@ def main_shm_gpu_chip(out_dir, log2_n):
     dist.destroy_process_group()
 
 
+def open_case(world):
+    """matrices of a commitment for the process test of the multi-rank opening: (heights, column split per matrix and rank, full matrices)"""
+    heights = [9, 7, 9] if world <= 2 else [10, 8, 10]
+    col_split = [[1 + ((m + g) % 2) for g in range(world)] for m in range(len(heights))]
+    fulls = [po.rand_base((1 << h) * sum(ws), 2100 + 5 * i).reshape(1 << h, sum(ws)) for i, (h, ws) in enumerate(zip(heights, col_split))]
+    return heights, col_split, fulls
+
+
+def main_shm_gpu_open(out_dir, _n):
+    """commit across `world` PROCESSES sharing GPU 0 (ceno_dist_commit_traces_mmcs) and open across them (ceno_dist_basefold_open_mmcs), every
+    exchange through the shared segment (no RCCL between ranks of one device): root and proof written per rank"""
+    import torch
+
+    from ceno_amd import Device
+    from ceno_amd import dist as cdist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist = FileRendezvous(out_dir, rank, world)
+    dev = Device(0)
+    heights, col_split, fulls = open_case(world)
+    comm = prover.ShmComm(world, rank, dist)
+    stream = dev.stream_create()
+    keep, ptrs = [], []
+    for ws, full in zip(col_split, fulls):
+        c0 = sum(ws[:rank])
+        cols = np.ascontiguousarray(full[:, c0:c0 + ws[rank]].T)
+        t = torch.from_numpy(cols.view(np.int64).copy()).to("cuda:0")
+        keep.append(t)
+        ptrs.append(t.data_ptr())
+    torch.cuda.synchronize()
+    com = cdist.sharded_commit_mmcs_native(dev, comm.h, ptrs, col_split, heights, 1, rank, stream)
+    dev.sync(stream)
+    point = np.array([[(i * 7919 + 13) % po.P, (i * 104729 + 17) % po.P] for i in range(max(heights))], dtype=np.uint64)
+    points = [point[:h] for h in heights]
+    evals = [np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), points[m]) for c in range(full.shape[1])], dtype=np.uint64)
+             for m, full in enumerate(fulls)]
+    proof = prover.dist_basefold_open(dev, comm.h, heights, col_split, 1, ptrs, [t.data_ptr() for t in com["codeword_rows"]], com["subtree"], com["top"],
+                                      points, evals, 10, 3, prover.Transcript.poseidon2(b"open"), stream)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), root=np.asarray(com["root"]), proof=proof)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
 # ---- the row-sharded tower proof a SECOND time, in Python over the oracle's primitives and torch.distributed (gloo): an independent
 # statement of the algorithm of ceno_amd/host/dist_gkr.cpp (block-cyclic rows, local towers = shards of the large layers, replicated tops,
 # local rounds with exchanged partial sums, interleaved gather, replicated tail).  Test infrastructure: everything arithmetic is the oracle's. ----
@@ -461,6 +505,8 @@ def main_chip_gloo(out_dir, log2_n):
 def main():
     if len(sys.argv) > 3 and sys.argv[3] == "chip_gloo":
         return main_chip_gloo(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_open":
+        return main_shm_gpu_open(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_chip":
         return main_shm_gpu_chip(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu":

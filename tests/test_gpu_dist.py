@@ -64,6 +64,41 @@ def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
         assert np.array_equal(res[r]["fin"], ofin)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_commitment_and_opening_as_processes_on_one_gpu(world):
+    """ceno_dist_commit_traces_mmcs + ceno_dist_basefold_open_mmcs as `world` PROCESSES sharing GPU 0: the re-shard of the codewords, the gathered
+    batched codeword / polynomial and the query answers all travel through the shared segment's bulk area (RCCL does not run between ranks of one
+    device); every rank's root and opening must equal the single-device commitment's, computed here, word for word"""
+    from ceno_amd import Device, prover
+    from oracle import pyoracle as po
+    from tests.dist_worker import open_case
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29970 + world), WORLD_SIZE=str(world))
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "0", "shm_gpu_open"], env=e))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        res = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(world)]
+    dev = Device(0)
+    heights, col_split, fulls = open_case(world)
+    stream = dev.stream_create()
+    pcs = prover.PcsData(dev, fulls, 1, stream)
+    point = np.array([[(i * 7919 + 13) % po.P, (i * 104729 + 17) % po.P] for i in range(max(heights))], dtype=np.uint64)
+    points = [point[:h] for h in heights]
+    evals = [np.array([po.mle_evaluate(np.ascontiguousarray(full[:, c]), points[m]) for c in range(full.shape[1])], dtype=np.uint64)
+             for m, full in enumerate(fulls)]
+    want_root = np.asarray(pcs.root(), dtype=np.uint64).reshape(-1)
+    want = pcs.basefold_open(points, evals, 10, 3, prover.Transcript.poseidon2(b"open"))
+    pcs.free()
+    for r in range(world):
+        assert np.array_equal(res[r]["root"].reshape(-1), want_root), f"rank {r}: root"
+        assert res[r]["proof"].shape == want.shape and np.array_equal(res[r]["proof"], want), f"rank {r}: opening"
+    dev.close()
+
+
 @pytest.mark.parametrize("world,log2_n", [(2, 10), (4, 11)])
 def test_row_sharded_chip_proof_as_processes_on_one_gpu(world, log2_n):
     """ceno_dist_create_chip_proof (record inference, tower witness, tower proof over row-sharded columns) as `world` PROCESSES sharing GPU 0 with
@@ -125,10 +160,12 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     assert w["scaling"] == "weak" and w["config"]["global_num_vars"] == 12 + log_w and w["config"]["num_vars_per_gpu"] == 12
     assert w["value"] > 0 and abs(w["value"] - 9 * ((1 << (12 + log_w)) - 1) / (w["ms_per_step"] * 1e-3)) / w["value"] < 1e-6
     assert "shm" in r["exchanges_validated"] and r["collective_ms"]["shm"] > 0 and r["headline_exchange"] == "shm"  # (no RCCL with two ranks on one device)
-    # RCCL either counted its ranks or fell back cleanly (here: several ranks on one device, so the fallback), and the multi-rank commit
-    # extra says why it did not run instead of hanging or failing the line
+    # RCCL either counted its ranks or fell back cleanly (here: several ranks on one device, so the fallback); the multi-rank commitment and
+    # opening then run through the shared segment's host-staged bulk exchange, validated against the single-device root and opening
     assert r.get("rccl_ranks", world) == world and "rccl" not in r["exchanges_validated"]
-    assert r["extra"]["dist_commit"]["status"].startswith("skipped")
+    dc = r["extra"]["dist_commit"]
+    assert dc["status"] == "ok" and dc["root_matches_single_device"] and dc["bulk_exchange"].startswith("shared segment"), dc
+    assert dc["dist_open"]["status"] == "ok" and dc["dist_open"]["proof_equals_single_device"], dc["dist_open"]
     # the GKR half of a chip across the ranks (row-sharded record inference, towers, tower proof), validated against the single-device proof
     dcp = r["extra"]["dist_chip_proof"]
     assert dcp["status"] == "ok" and dcp["proof_equals_single_device"] and dcp["ms"] > 0, dcp
