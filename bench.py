@@ -511,10 +511,16 @@ def main():
         dev.prof_reset()
         barrier()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(args.steps):
             step()
+            marks.append(time.perf_counter())  # (a step returns with its final evaluations on the host: the stamps cost ~0.1 us each)
         barrier()
         out["dt"] = max_over_ranks(time.perf_counter() - t0)
+        # the single steps of THIS rank, so that a one-off pause of the device inside the region (profiles/r05_in_flight_stall_trace.txt: ~10 ms, some
+        # boxes) is visible as such next to the mean that `value` is made of
+        per = sorted((b_ - a_) * 1e3 for a_, b_ in zip(marks, marks[1:]))
+        out["step_ms"] = {"min": per[0], "median": per[len(per) // 2], "max": per[-1]} if per else {}
         gc.enable()
         out["kernel_ms"], out["launches"], out["prof_bytes"] = dev.prof_get()
         dev.prof_enable(False)
@@ -731,6 +737,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_uninstrumented": m["dt_plain"] / args.steps * 1e3,
+            "step_ms": m.get("step_ms", {}),
             f"ms_per_step_{args.transcript}": dt / args.steps * 1e3,
             f"ms_per_step_{other}": m["dt_other"] / args.steps * 1e3,
             "higher_is_better": True,
