@@ -366,6 +366,106 @@ def _interleave(parts, lo_bits, k):
     return out
 
 
+def rotation_case(n, log2):
+    """full columns, rotation pairs, subgroup size and the point of the rotation argument for the CPU second implementation"""
+    src = po.rand_base(1 << n, 41)
+    cols = [src, po.rotation_next_base_mle(src, log2), po.rand_base(1 << n, 42), po.rand_base(1 << n, 43)]
+    return cols, [(0, 1), (2, 3)], 23 if log2 == 5 else 45, po.rand_ext(n, 44)
+
+
+def main_rotation_gloo(out_dir, n):
+    """the rotation argument over ROW-SHARDED columns a second time (independent of prover.cpp prover_prove_rotation_sharded), in Python over the
+    oracle's primitives and gloo: local rotations, the local selector at the point without the rank coordinates, q local rounds with the two
+    partial evaluations summed over the ranks, the folded tables gathered with the rank bits lowest, the tail replicated, the left evaluations
+    as eq-weighted sums of per-rank evaluations.  Test infrastructure: every piece of arithmetic is the oracle's."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    k, q, log2 = world.bit_length() - 1, int(os.environ.get("CENO_TEST_ROW_BLOCK_LOG", "5")), int(os.environ.get("CENO_TEST_ROT_LOG", "5"))
+    cols, pairs, subgroup, rt = rotation_case(n, log2)
+    rt = [(int(x[0]), int(x[1])) for x in rt]
+    local = [prover.shard_rows(c, world, rank, q) for c in cols]
+    one = (1, 0)
+
+    def gather(x):
+        got = [None] * world
+        dist.all_gather_object(got, x)
+        return got
+
+    def eq_rank(pt):
+        v = one
+        for j in range(k):
+            c_ = pt[q + j]
+            v = po.e2_mul(v, c_ if (rank >> j) & 1 else po.e2_sub(one, c_))
+        return v
+
+    def without_rank(pt):
+        return [pt[j] for j in range(len(pt)) if j < q or j >= q + k]
+
+    tr = po.StubTranscript(8)
+    alphas = _pows(tr, len(pairs))
+    eq_g = eq_rank(rt)
+    sel = po.rotation_selector(po.build_eq(po.ext(without_rank(rt))), subgroup, log2)
+    tabs, cf_loc, cf_glob, terms = [], [], [], []
+    for j, (s_, t_) in enumerate(pairs):
+        tabs += [po.rotation_next_base_mle(local[s_], log2), local[t_]]
+        na = po.e2_sub((0, 0), alphas[j])
+        cf_glob += [alphas[j], na]
+        cf_loc += [po.e2_mul(alphas[j], eq_g), po.e2_mul(na, eq_g)]
+        terms += [[2 * j, 2 * len(pairs)], [2 * j + 1, 2 * len(pairs)]]
+    tabs.append(sel)
+    _usize(tr, n)
+    _usize(tr, 2)
+    msgs, origin = [], []
+
+    def first(tabs_, cf_):
+        nv = int(tabs_[0].shape[0]).bit_length() - 1
+        m, _, _ = po.sumcheck_prove(tabs_, po.ext(cf_), terms, nv, 2, po.StubTranscript(1))
+        return [(int(m[0][e][0]), int(m[0][e][1])) for e in range(2)]
+
+    def publish(m):
+        for e in range(2):
+            tr.append_ext(m[e])
+        tr.append_label(b"Internal round")
+        ch = tr.sample_ext()
+        msgs.append(m)
+        origin.append(ch)
+        return ch
+
+    for _ in range(q):
+        tot = [(0, 0), (0, 0)]
+        for part in gather(first(tabs, cf_loc)):
+            tot = [po.e2_add(tot[e], part[e]) for e in range(2)]
+        ch = publish(tot)
+        tabs = [po.mle_fix_variable(t_, ch) for t_ in tabs]
+    # the selector's rank factor went into the coefficients: the global selector carries it
+    tabs[-1] = po.ext([po.e2_mul((int(v[0]), int(v[1])), eq_g) for v in tabs[-1]])
+    tabs = [_interleave(gather(np.ascontiguousarray(t_)), 0, k) for t_ in tabs]
+    for _ in range(n - q):
+        ch = publish(first(tabs, cf_glob))
+        tabs = [po.mle_fix_variable(t_, ch) for t_ in tabs]
+    fin = [(int(t_[0][0]), int(t_[0][1])) for t_ in tabs]
+    left, right = po.rotation_points(po.ext(origin), log2)
+    left_l = [(int(x[0]), int(x[1])) for x in left]
+    eq_left = eq_rank(left_l)
+    rk = origin[log2 - 1]
+    rk_inv = po.e2_inv(rk)
+    evals = []
+    parts = gather([po.e2_mul(po.mle_evaluate(local[s_], po.ext(without_rank(left_l))), eq_left) for (s_, _t) in pairs])
+    for j in range(len(pairs)):
+        lv = (0, 0)
+        for g in range(world):
+            lv = po.e2_add(lv, parts[g][j])
+        rot, target = fin[2 * j], fin[2 * j + 1]
+        rv = po.e2_mul(po.e2_sub(rot, po.e2_mul(po.e2_sub(one, rk), lv)), rk_inv)
+        evals += [lv, rv, target]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=po.ext([m[e] for m in msgs for e in range(2)]).reshape(n, 2, 2), evals=po.ext(evals),
+             origin=po.ext(origin), left=left, right=right)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main_chip_gloo(out_dir, log2_n):
     import torch.distributed as dist
 
@@ -503,6 +603,8 @@ def main_chip_gloo(out_dir, log2_n):
 
 
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "rotation_gloo":
+        return main_rotation_gloo(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "chip_gloo":
         return main_chip_gloo(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "shm_gpu_open":

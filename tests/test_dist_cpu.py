@@ -131,3 +131,30 @@ def test_row_sharded_tower_proof_matches_unsharded(world, log2_n):
         assert np.array_equal(res[r]["msgs"], oproof.msgs)
         assert np.array_equal(res[r]["point"], oproof.point[: res[r]["point"].shape[0]])
         assert np.array_equal(res[r]["prod"], oproof.prod_evals) and np.array_equal(res[r]["logup"], oproof.logup_evals)
+
+
+@pytest.mark.parametrize("world,n,q,log2", [(2, 8, 5, 5), (4, 9, 6, 5), (2, 8, 6, 6)])
+def test_row_sharded_rotation_argument_matches_unsharded(world, n, q, log2):
+    """the rotation argument of a keccak-style chip over ROW-SHARDED columns a second time, independent of ceno_amd/host/prover.cpp
+    prover_prove_rotation_sharded: gloo ranks with block-cyclic row shards rotate locally, run q local rounds with exchanged partial sums, gather
+    the folded tables and finish replicated — and must end, on every rank, with the messages, points and evaluations the oracle's prove_rotation
+    produces from the whole columns (gkr_iop/src/gkr/layer/cpu/mod.rs:249-389)"""
+    from tests.dist_worker import rotation_case
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29850 + world + log2), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG=str(q),
+                   CENO_TEST_ROT_LOG=str(log2), OMP_NUM_THREADS="2")
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n), "rotation_gloo"], env=e))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
+    cols, pairs, subgroup, rt = rotation_case(n, log2)
+    tr = po.StubTranscript(8)
+    msgs, evals, origin, left, right = po.prove_rotation(cols, pairs, subgroup, log2, np.ascontiguousarray(rt), tr)
+    for r in range(world):
+        assert np.array_equal(res[r]["msgs"], msgs), f"rank {r}: messages"
+        assert np.array_equal(res[r]["origin"], origin) and np.array_equal(res[r]["left"], left) and np.array_equal(res[r]["right"], right), f"rank {r}: points"
+        assert np.array_equal(res[r]["evals"], evals), f"rank {r}: evaluations"
