@@ -382,7 +382,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                 // group's kernels behind them on the same stream would never produce the message this thread waits for.
                 // CENO_BASEFOLD_PIPELINE=0: one launch + synchronisation per round (A/B measurements)
                 static const bool pipe = !(getenv("CENO_BASEFOLD_PIPELINE") && atoi(getenv("CENO_BASEFOLD_PIPELINE")) == 0);
-                if (!rc && pipe && groups.size() == 1) (void)ceno_hip_sumcheck_set_pipelined(ctx, g.sc, 1);
+                if (!rc && pipe && groups.size() == 1 && !(hook && hook->serial_rounds)) (void)ceno_hip_sumcheck_set_pipelined(ctx, g.sc, 1);
                 g.started = true;
             }
             uint64_t ev[4];

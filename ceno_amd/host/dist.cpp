@@ -1090,6 +1090,7 @@ int gather_digests(ceno_dist_comm* c, const uint64_t* mine4, uint64_t* out, hipS
 // ---- helpers for the row-sharded GKR half (dist_gkr.cpp) ----
 int dist_comm_world(const ceno_dist_comm* c) { return c ? c->world : 1; }
 int dist_comm_rank(const ceno_dist_comm* c) { return c ? c->rank : 0; }
+bool dist_comm_has_rccl(const ceno_dist_comm* c) { return c && c->comm != nullptr; }
 // all-gather `n_words` 64-bit words per rank (host memory in, host memory out: out[g * n_words + k]) over the communicator's small-message
 // transport — in-process group, shared segment or RCCL — in chunks of 128 words.  Bulk data (MBs) belongs on exchange_blocks; this carries the
 // per-round partial sums and the folded tables (KBs) of the sharded tower prover.

@@ -495,4 +495,31 @@ int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* comm, const c
     return 0;
 }
 
+// prove_batched_main_constraints over tables in the block layout of ceno_dist_create_chip_proof (main_constraints.cpp
+// prover_main_constraints_sharded): every job's tables hold this rank's rows, J.num_vars stays the global number of variables
+int ceno_dist_prove_batched_main_constraints(ceno_hip_ctx* ctx, ceno_dist_comm* comm, const ceno_main_job* jobs_local, int n_jobs, int row_block_log,
+                                             const uint64_t* global_challenges4, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum,
+                                             uint64_t* out_msgs, uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree) {
+    if (!ctx || !jobs_local || n_jobs < 1 || !tr) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_prove_batched_main_constraints: NULL argument");
+    const int W = dist_comm_world(comm), rank = dist_comm_rank(comm), k = ceil_log2((size_t)W);
+    if (W == 1)
+        return ceno_prover_prove_batched_main_constraints(ctx, jobs_local, n_jobs, global_challenges4, tr, s, out_claimed_sum, out_msgs, out_global_rt, out_evals,
+                                                          out_num_vars, out_degree);
+    if (((size_t)1 << k) != (size_t)W) return prover_set_error(CENO_HIP_ERR_INVALID, "dist_prove_batched_main_constraints: the number of ranks must be a power of two");
+    const int q = row_block_log > 0 ? row_block_log : ceno_dist_chip_block_log();
+    struct Gather {
+        ceno_dist_comm* comm;
+        hipStream_t st;
+    } gth{comm, (hipStream_t)s};
+    RotationShard sh{W, rank, k, q,
+                     [](void* self, const uint64_t* mine, size_t n_words, uint64_t* all) -> int {
+                         auto* G = static_cast<Gather*>(self);
+                         if (int rc2 = dist_allgather_words(G->comm, mine, n_words, all, G->st)) return prover_set_error(rc2, ceno_dist_last_error());
+                         return 0;
+                     },
+                     &gth};
+    return prover_main_constraints_sharded(ctx, jobs_local, n_jobs, global_challenges4, tr, s, out_claimed_sum, out_msgs, out_global_rt, out_evals, out_num_vars,
+                                           out_degree, &sh);
+}
+
 }  // extern "C"

@@ -37,6 +37,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                          int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof, const BasefoldOpenHook* hook);
 int dist_comm_world(const ceno_dist_comm* c);  // dist.cpp
 int dist_comm_rank(const ceno_dist_comm* c);
+bool dist_comm_has_rccl(const ceno_dist_comm* c);  // one rank per GPU by construction (RCCL does not place two ranks on a device)
 int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, hipStream_t st);
 int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_words, uint64_t* recv_dev, hipStream_t st);
 
@@ -278,7 +279,7 @@ int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int
         }
         shape_ptrs.push_back(&shape);
     }
-    BasefoldOpenHook hook{&D, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
+    BasefoldOpenHook hook{&D, !dist_comm_has_rccl(comm), hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
     return basefold_open_hooked(ctx, shape_ptrs.data(), n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
 }
 

@@ -12,6 +12,7 @@
 
 #include "../../include/ceno_prover.h"
 #include "../csrc/gl64.hpp"
+#include "tower_hook.hpp"
 
 using gl::E2;
 
@@ -44,7 +45,47 @@ E2 extrapolate(E2 p0, const std::vector<E2>& ev, E2 x) {
 extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, const ceno_main_job* jobs, int n_jobs, const uint64_t* gc4,
                                                           ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum, uint64_t* out_msgs,
                                                           uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree) {
+    return prover_main_constraints_sharded(ctx, jobs, n_jobs, gc4, tr, s, out_claimed_sum, out_msgs, out_global_rt, out_evals, out_num_vars, out_degree, nullptr);
+}
+
+// sh == NULL: the tables of the jobs are whole.  sh != NULL (ceno_dist_prove_batched_main_constraints, dist_gkr.cpp): every table holds THIS rank's
+// rows in the block layout of the row-sharded chip proof (rows whose index bits [q, q + k) equal the rank; J.num_vars stays the GLOBAL number
+// of variables, the tables have num_vars - k).  A Whole / Prefix selector is eq(x, point) on a row range: on a rank it is the same construction
+// at the point without the rank coordinates, on the rank's part of the range (a prefix of its own rows), times the scalar
+// eq(rank, point[q .. q + k)), which rides on the coefficients of the selector's terms.  The first q rounds run on the local tables (the d
+// partial evaluations of a round are summed over the ranks), then every table — 2^(n_c - k - q) entries per rank — is gathered with the
+// rank bits lowest and the remaining rounds run replicated; the evaluations of the columns that left the plan (below) are per-rank
+// evaluations at the local point, weighted by eq over the rank coordinates and summed.  Every rank ends with the single-device outputs.
+int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs, int n_jobs, const uint64_t* gc4, ceno_transcript* tr, ceno_hip_stream s,
+                                    uint64_t* out_claimed_sum, uint64_t* out_msgs, uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars,
+                                    int* out_degree, const RotationShard* sh) {
     if (!ctx || !jobs || n_jobs < 1 || !gc4 || !tr) return prover_set_error(CENO_HIP_ERR_INVALID, "bad arguments");
+    const int shk = sh ? sh->k : 0, shq = sh ? sh->q : 0;
+    auto eq_rank = [&](const uint64_t* p) {  // eq(rank, p[q .. q + k))
+        E2 v = gl::e2_one();
+        for (int j = 0; j < shk; j++) {
+            const E2 c{p[2 * (shq + j)], p[2 * (shq + j) + 1]};
+            v = v * (((sh->rank >> j) & 1) ? c : gl::e2_one() - c);
+        }
+        return v;
+    };
+    auto local_point = [&](const uint64_t* p, int n_glob) {  // the point without its rank coordinates
+        std::vector<uint64_t> out;
+        for (int j = 0; j < n_glob; j++)
+            if (j < shq || j >= shq + shk) {
+                out.push_back(p[2 * j]);
+                out.push_back(p[2 * j + 1]);
+            }
+        return out;
+    };
+    auto local_rows = [&](size_t t) -> size_t {  // how many of this rank's rows have a global index below t
+        const size_t lo = t & (((size_t)1 << shq) - 1), g = (t >> shq) & (((size_t)1 << shk) - 1), hi = t >> (shq + shk);
+        return (hi << shq) + ((size_t)sh->rank < g ? (size_t)1 << shq : ((size_t)sh->rank == g ? lo : 0));
+    };
+    if (sh)
+        for (int c = 0; c < n_jobs; c++)
+            if (jobs[c].num_vars - shk < shq + 1)
+                return prover_set_error(CENO_HIP_ERR_INVALID, "sharded main constraints: a chip is too small for this block size (needs log2 rows >= q + log2 world + 1)");
     static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     auto now_us = []() {
         timespec ts;
@@ -80,6 +121,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
                 batch.push_back(Pending{c, id, k});
                 continue;
             }
+            if (sh) { cleanup(); return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "sharded main constraints: Whole and Prefix selectors only"); }
             ceno_hip_mle* m = nullptr;
             int rc = ceno_hip_selector_build(ctx, J.sel_kind[k], J.sel_points[k], J.num_vars, J.sel_offset[k], J.sel_num_instances[k],
                                              J.sel_sparse_indices ? J.sel_sparse_indices[k] : nullptr, J.sel_n_sparse ? J.sel_n_sparse[k] : 0,
@@ -89,12 +131,20 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             sel_by_id[c][id] = m;
         }
     }
+    std::vector<std::vector<uint64_t>> sel_loc_pt;        // sharded: per batched selector its point without the rank coordinates ...
+    std::vector<std::vector<size_t>> sel_loc_pt_of(n_jobs);  // ... indexed [job][selector k] -> sel_loc_pt (SIZE_MAX: none)
+    std::vector<std::vector<E2>> sel_eqg(n_jobs);         // ... and per structural id the rank's eq factor (1 when the tables are whole)
+    for (int c = 0; c < n_jobs; c++) {
+        sel_eqg[c].assign(jobs[c].n_structural, gl::e2_one());
+        sel_loc_pt_of[c].assign(jobs[c].n_selectors, (size_t)-1);
+    }
     if (!batch.empty()) {
         const int nb = (int)batch.size();
         std::vector<int> kinds(nb), nvs(nb);
         std::vector<const uint64_t*> pts(nb);
         std::vector<size_t> offs(nb), nins(nb);
         std::vector<ceno_hip_mle*> outs(nb, nullptr);
+        sel_loc_pt.reserve((size_t)nb);
         for (int b = 0; b < nb; b++) {
             const ceno_main_job& J = jobs[batch[b].c];
             const int k = batch[b].k;
@@ -103,6 +153,18 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             pts[b] = J.sel_points[k];
             offs[b] = J.sel_offset[k];
             nins[b] = J.sel_num_instances[k];
+            if (sh) {
+                sel_loc_pt.push_back(local_point(J.sel_points[k], J.num_vars));
+                sel_loc_pt_of[batch[b].c][k] = sel_loc_pt.size() - 1;
+                pts[b] = sel_loc_pt.back().data();
+                nvs[b] = J.num_vars - shk;
+                sel_eqg[batch[b].c][batch[b].id] = eq_rank(J.sel_points[k]);
+                if (kinds[b] == CENO_HIP_SEL_PREFIX) {
+                    const size_t lo = local_rows(J.sel_offset[k]), hi = local_rows(J.sel_offset[k] + J.sel_num_instances[k]);
+                    offs[b] = lo;
+                    nins[b] = hi - lo;
+                }
+            }
         }
         int rc = ceno_hip_selector_build_batch(ctx, nb, kinds.data(), pts.data(), nvs.data(), offs.data(), nins.data(), s, outs.data());
         if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
@@ -124,6 +186,7 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     }
     // ---- global MLE list and monomial terms (cpu/mod.rs:1255-1329) ----
     std::vector<ceno_hip_mle*> mles;
+    std::vector<E2> mle_eqg;  // per table: the rank's eq factor of a sharded selector (1 otherwise)
     std::vector<int> mle_start(n_jobs), mle_nv;
     std::vector<uint64_t> coeffs;
     std::vector<uint32_t> toff{0}, tidx;
@@ -144,14 +207,22 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
                 m = sel_by_id[c][id];
                 if (J.sel_kind[k] == CENO_HIP_SEL_WHOLE || J.sel_kind[k] == CENO_HIP_SEL_PREFIX) {
                     eq_idx.push_back((int)mles.size());
-                    eq_pts.push_back(J.sel_points[k]);
-                    eq_lo.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? 0 : J.sel_offset[k]);
-                    eq_hi.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? (size_t)1 << J.num_vars : J.sel_offset[k] + J.sel_num_instances[k]);
+                    if (!sh) {
+                        eq_pts.push_back(J.sel_points[k]);
+                        eq_lo.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? 0 : J.sel_offset[k]);
+                        eq_hi.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? (size_t)1 << J.num_vars : J.sel_offset[k] + J.sel_num_instances[k]);
+                    } else {  // this rank's rows of the table: eq at the local point on the rank's part of the range
+                        eq_pts.push_back(sel_loc_pt[sel_loc_pt_of[c][k]].data());
+                        eq_lo.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? 0 : local_rows(J.sel_offset[k]));
+                        eq_hi.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? (size_t)1 << (J.num_vars - shk) : local_rows(J.sel_offset[k] + J.sel_num_instances[k]));
+                    }
                 }
             }
             if (!m) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "structural witness without selector is NULL"); }
+            if (sh && ceno_hip_mle_num_vars(m) != J.num_vars - shk) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "sharded main constraints: a local table has the wrong height"); }
             mles.push_back(m);
-            mle_nv.push_back(ceno_hip_mle_num_vars(m));
+            mle_nv.push_back(ceno_hip_mle_num_vars(m) + shk);  // (the GLOBAL number of variables)
+            mle_eqg.push_back(j >= J.n_witin + J.n_fixed && sel_by_id[c][j - J.n_witin - J.n_fixed] ? sel_eqg[c][j - J.n_witin - J.n_fixed] : gl::e2_one());
         }
         std::vector<E2> ch{E2{gc4[0], gc4[1]}, E2{gc4[2], gc4[3]}};
         for (int i = 0; i < J.n_exprs; i++) ch.push_back(alpha_pows[alpha_start + i]);
@@ -186,9 +257,10 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     const int lin_min = getenv("CENO_PROVER_MAIN_LINCOMB") ? atoi(getenv("CENO_PROVER_MAIN_LINCOMB")) : 3;
     std::vector<int> plan_of(mles.size(), 0);          // index in the sumcheck's table list, -1: a combined column
     std::vector<ceno_hip_mle*> plan_mles;
-    std::vector<uint64_t> p_coeffs;
+    std::vector<uint64_t> p_coeffs, p_coeffs_loc;
     std::vector<uint32_t> p_toff{0}, p_tidx;
     std::vector<int> removed;                          // global ids of the combined columns
+    std::vector<E2> plan_eqg;                          // per table of the plan: the rank's eq factor of a sharded selector (1 otherwise)
     {
         const size_t nm = mles.size();
         std::vector<char> is_ext(nm), other(nm, 0);
@@ -258,17 +330,24 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
                 plan_mles.push_back(mles[j]);
             }
         }
+        auto push_coeff = [&](E2 c, E2 rank_factor) {  // the term's coefficient; the LOCAL plan of a sharded run carries its selectors' eq factors
+            p_coeffs.push_back(c.c0);
+            p_coeffs.push_back(c.c1);
+            const E2 cl = c * rank_factor;
+            p_coeffs_loc.push_back(cl.c0);
+            p_coeffs_loc.push_back(cl.c1);
+        };
         for (int t = 0; t < n_terms_all; t++) {
             if (lin_col[t] >= 0) continue;  // moved into its selector's combination
-            p_coeffs.push_back(coeffs[2 * t]);
-            p_coeffs.push_back(coeffs[2 * t + 1]);
+            E2 f = gl::e2_one();
+            for (uint32_t k = toff[t]; k < toff[t + 1]; k++) f = f * mle_eqg[tidx[k]];
+            push_coeff(E2{coeffs[2 * t], coeffs[2 * t + 1]}, f);
             for (uint32_t k = toff[t]; k < toff[t + 1]; k++) p_tidx.push_back((uint32_t)plan_of[tidx[k]]);
             p_toff.push_back((uint32_t)p_tidx.size());
         }
         for (size_t g = 0; g < gsel.size(); g++) {
             for (int half = 0; half < 2; half++) {  // sel x A + X sel x B
-                p_coeffs.push_back(half == 0 ? 1 : 0);
-                p_coeffs.push_back(half == 0 ? 0 : 1);
+                push_coeff(half == 0 ? E2{1, 0} : E2{0, 1}, mle_eqg[(size_t)gsel[g]]);
                 p_tidx.push_back((uint32_t)plan_of[gsel[g]]);
                 p_tidx.push_back((uint32_t)plan_mles.size());
                 p_toff.push_back((uint32_t)p_tidx.size());
@@ -276,6 +355,9 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
             }
         }
         for (int& e : eq_idx) e = plan_of[e];
+        plan_eqg.assign(plan_mles.size(), gl::e2_one());
+        for (size_t j = 0; j < nm; j++)
+            if (plan_of[j] >= 0) plan_eqg[(size_t)plan_of[j]] = mle_eqg[j];
     }
     const int n_terms = (int)p_toff.size() - 1;
     // ---- common-factor plan (the role of CommonTermPlan in the reference's GPU arm, scheme/gpu/mod.rs:2811-2962, built
@@ -330,8 +412,107 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
     plan.max_degree = max_deg;
     std::vector<uint64_t> evals(2 * mles.size()), p_evals(2 * plan_mles.size());
     const double t_plan = dbg ? now_us() : 0;
-    int rc = ceno_prover_sumcheck_prove_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
+    int rc = 0;
+    if (!sh) {
+        rc = ceno_prover_sumcheck_prove_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
                                            out_msgs, out_global_rt, p_evals.data());   // cpu/mod.rs:1332-1337
+    } else {
+        // ---- the same sumcheck over row-sharded tables: q local rounds, the gathered tail replicated ----
+        const int D = max_deg, W = sh->world;
+        auto tr_usize = [&](uint64_t v) {
+            uint8_t b[8];
+            for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
+            tr->append_label(tr->self, b, 8);
+        };
+        ceno_hip_sumcheck *sc = nullptr, *sc2 = nullptr;
+        auto drop = [&]() {
+            if (sc) ceno_hip_sumcheck_free(ctx, sc);
+            if (sc2) ceno_hip_sumcheck_free(ctx, sc2);
+            sc = sc2 = nullptr;
+        };
+        plan.term_coeffs = p_coeffs_loc.data();
+        plan.max_num_vars = max_nv - shk;
+        rc = ceno_hip_sumcheck_begin_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), s, &sc);
+        if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        tr_usize((uint64_t)max_nv);
+        tr_usize((uint64_t)D);
+        uint64_t ch[2] = {0, 0};
+        std::vector<uint64_t> m((size_t)2 * D), all((size_t)W * 2 * D);
+        auto publish = [&](int round, const E2* pv) {
+            uint64_t* msg = out_msgs + (size_t)2 * D * round;
+            for (int e = 0; e < D; e++) {
+                msg[2 * e] = pv[e].c0;
+                msg[2 * e + 1] = pv[e].c1;
+                tr->append_ext(tr->self, msg + 2 * e);
+            }
+            static const char lbl_r[] = "Internal round";
+            tr->append_label(tr->self, (const uint8_t*)lbl_r, sizeof(lbl_r) - 1);
+            tr->sample_ext(tr->self, ch);
+            out_global_rt[2 * round] = ch[0];
+            out_global_rt[2 * round + 1] = ch[1];
+        };
+        std::vector<E2> pv((size_t)D);
+        for (int i = 0; i < shq && !rc; i++) {
+            rc = ceno_hip_sumcheck_round(ctx, sc, i == 0 ? nullptr : ch, m.data());
+            if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
+            rc = sh->allgather(sh->self, m.data(), m.size(), all.data());
+            if (rc) break;
+            for (int e = 0; e < D; e++) {
+                pv[(size_t)e] = gl::e2_zero();
+                for (int g = 0; g < W; g++) pv[(size_t)e] = pv[(size_t)e] + E2{all[(size_t)g * 2 * D + 2 * e], all[(size_t)g * 2 * D + 2 * e + 1]};
+            }
+            publish(i, pv.data());
+        }
+        if (rc) { drop(); cleanup(); return rc; }
+        // every table as the next round would read it (folded q - 1 times; once more here), gathered with the rank bits lowest
+        const E2 r_last{ch[0], ch[1]};
+        std::vector<ceno_hip_mle*> glob(plan_mles.size(), nullptr);
+        std::vector<E2> t, g_tab;
+        std::vector<uint64_t> mine, gathered;
+        for (size_t mi = 0; mi < plan_mles.size() && !rc; mi++) {
+            const int nv_loc = ceno_hip_mle_num_vars(plan_mles[mi]);
+            const size_t len_loc = (size_t)1 << (nv_loc - shq);
+            int nv = 0;
+            t.resize(2 * len_loc);
+            rc = ceno_hip_sumcheck_table_host(ctx, sc, (int)mi, reinterpret_cast<uint64_t*>(t.data()), t.size(), &nv);
+            if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
+            if (nv != nv_loc - shq + 1) { rc = prover_set_error(CENO_HIP_ERR_STATE, "sharded main constraints: unexpected table shape after the local rounds"); break; }
+            mine.resize(2 * len_loc);
+            for (size_t j = 0; j < len_loc; j++) {
+                const E2 v = (t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j])) * plan_eqg[mi];  // (a selector's rank factor went into the coefficients)
+                mine[2 * j] = v.c0;
+                mine[2 * j + 1] = v.c1;
+            }
+            gathered.resize((size_t)W * 2 * len_loc);
+            rc = sh->allgather(sh->self, mine.data(), mine.size(), gathered.data());
+            if (rc) break;
+            g_tab.resize(len_loc * (size_t)W);
+            for (int g = 0; g < W; g++) {
+                const E2* src = reinterpret_cast<const E2*>(gathered.data()) + (size_t)g * len_loc;
+                for (size_t j = 0; j < len_loc; j++) g_tab[(j << shk) | (size_t)g] = src[j];
+            }
+            rc = ceno_hip_mle_upload(ctx, reinterpret_cast<const uint64_t*>(g_tab.data()), nv_loc - shq + shk, 1, s, &glob[mi]);
+            if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
+            owned.push_back(glob[mi]);
+        }
+        if (rc) { drop(); cleanup(); return rc; }
+        ceno_hip_sumcheck_free(ctx, sc);
+        sc = nullptr;
+        plan.term_coeffs = p_coeffs.data();
+        plan.max_num_vars = max_nv - shq;
+        rc = ceno_hip_sumcheck_begin(ctx, glob.data(), &plan, s, &sc2);
+        if (rc) { drop(); cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        for (int i = shq; i < max_nv; i++) {
+            rc = ceno_hip_sumcheck_round(ctx, sc2, i == shq ? nullptr : ch, m.data());
+            if (rc) { drop(); cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+            for (int e = 0; e < D; e++) pv[(size_t)e] = E2{m[2 * e], m[2 * e + 1]};
+            publish(i, pv.data());
+        }
+        rc = ceno_hip_sumcheck_finish(ctx, sc2, max_nv > shq ? ch : nullptr, p_evals.data());
+        if (rc) rc = prover_set_error(rc, ceno_hip_last_error(ctx));
+        drop();
+        plan.max_num_vars = max_nv;
+    }
     const double t_sc = dbg ? now_us() : 0;
     if (rc) { cleanup(); return rc; }
     // the evaluations of every table of the batch at (its prefix of) the sumcheck's point: the sumcheck's own for the tables it folded, one
@@ -345,8 +526,29 @@ extern "C" int ceno_prover_prove_batched_main_constraints(ceno_hip_ctx* ctx, con
         std::vector<ceno_hip_mle*> rc_cols(removed.size());
         std::vector<uint64_t> rc_out(2 * removed.size());
         for (size_t k = 0; k < removed.size(); k++) rc_cols[k] = mles[(size_t)removed[k]];
-        rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), out_global_rt, max_nv, s, rc_out.data());
-        if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        if (!sh) {
+            rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), out_global_rt, max_nv, s, rc_out.data());
+            if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        } else {  // per-rank evaluations at the point without the rank coordinates, weighted by eq over them, summed over the ranks
+            const std::vector<uint64_t> rt_loc = local_point(out_global_rt, max_nv);
+            rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), rt_loc.data(), max_nv - shk, s, rc_out.data());
+            if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+            const E2 w = eq_rank(out_global_rt);
+            for (size_t k = 0; k < removed.size(); k++) {
+                const E2 v = E2{rc_out[2 * k], rc_out[2 * k + 1]} * w;
+                rc_out[2 * k] = v.c0;
+                rc_out[2 * k + 1] = v.c1;
+            }
+            std::vector<uint64_t> parts((size_t)sh->world * rc_out.size());
+            rc = sh->allgather(sh->self, rc_out.data(), rc_out.size(), parts.data());
+            if (rc) { cleanup(); return rc; }
+            for (size_t k = 0; k < removed.size(); k++) {
+                E2 v = gl::e2_zero();
+                for (int g = 0; g < sh->world; g++) v = v + E2{parts[(size_t)g * rc_out.size() + 2 * k], parts[(size_t)g * rc_out.size() + 2 * k + 1]};
+                rc_out[2 * k] = v.c0;
+                rc_out[2 * k + 1] = v.c1;
+            }
+        }
         for (size_t k = 0; k < removed.size(); k++) {
             evals[2 * (size_t)removed[k]] = rc_out[2 * k];
             evals[2 * (size_t)removed[k] + 1] = rc_out[2 * k + 1];

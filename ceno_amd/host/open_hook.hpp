@@ -7,6 +7,10 @@
 
 struct BasefoldOpenHook {
     void* self;
+    // the ranks may share ONE device (virtual ranks of an in-process group, processes over the shared segment): the opening's sumcheck then runs
+    // round by round instead of pipelined — queued round kernels that wait for their host occupy hardware queues the other ranks' streams share,
+    // and the ranks wait for each other in the gathers (a multi-rank opening on 8 virtual ranks once lost three rounds to the 60 s give-up)
+    bool serial_rounds;
     // B (+)= sum_c coeffs[c] * codeword column c of height class `cls` of commitment `commit`: the FULL batched codeword of 2^log_h extension
     // elements on this device (coeffs: 2 words per column of the class, in the class's column order)
     int (*batch_codeword)(void* self, int commit, int cls, const uint64_t* coeffs, uint64_t* dev_B_ext, int log_h, int accumulate, ceno_hip_stream s);

@@ -24,3 +24,8 @@ int prover_prove_rotation_sharded(ceno_hip_ctx* ctx, ceno_hip_mle* const* wit_lo
                                   int cyclic_subgroup_size, int cyclic_group_log2, const uint64_t* rt, int n, ceno_transcript* tr, ceno_hip_stream s,
                                   uint64_t* out_msgs, uint64_t* out_evals, uint64_t* out_origin, uint64_t* out_left, uint64_t* out_right,
                                   const RotationShard* sh);
+
+// prove_batched_main_constraints over row-sharded tables in the same layout (main_constraints.cpp; sh == NULL: whole tables)
+int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs, int n_jobs, const uint64_t* gc4, ceno_transcript* tr, ceno_hip_stream s,
+                                    uint64_t* out_claimed_sum, uint64_t* out_msgs, uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars,
+                                    int* out_degree, const RotationShard* sh);

@@ -661,6 +661,27 @@ def prove_batched_main_constraints(dev: Device, jobs, global_challenges, tr: Tra
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
 
 
+def dist_prove_batched_main_constraints(dev: Device, comm, jobs_local, global_challenges, tr: Transcript, q: int = 0, stream=None):
+    """ceno_dist_prove_batched_main_constraints: prove_batched_main_constraints over row-sharded tables (the block layout of
+    dist_create_chip_proof: shard_rows(column, world, rank, q)).  jobs_local: as for prove_batched_main_constraints with THIS rank's tables and the
+    GLOBAL num_vars / selector ranges / points.  Returns what prove_batched_main_constraints returns for the whole tables."""
+    L = plib()
+    L.ceno_dist_prove_batched_main_constraints.restype = C.c_int
+    mj = jobs_local if isinstance(jobs_local, MainJobs) else MainJobs(jobs_local)
+    gc = np.array([[int(global_challenges[0][0]), int(global_challenges[0][1])],
+                   [int(global_challenges[1][0]), int(global_challenges[1][1])]], dtype=np.uint64)
+    claimed = np.zeros(2, dtype=np.uint64)
+    msgs = np.zeros((mj.max_nv, mj.max_deg, 2), dtype=np.uint64)
+    rt = np.zeros((mj.max_nv, 2), dtype=np.uint64)
+    evals = np.zeros((mj.total_mles, 2), dtype=np.uint64)
+    nv_o, d_o = C.c_int(), C.c_int()
+    L.ceno_dist_prove_batched_main_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_void_p, u64p, u64p, u64p, u64p,
+                                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _check(L.ceno_dist_prove_batched_main_constraints(dev.h, comm, C.cast(mj.arr, C.c_void_p), mj.n, q, _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
+                                                      _p(evals), C.byref(nv_o), C.byref(d_o)))
+    return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
+
+
 class EvalExprC(C.Structure):
     _fields_ = [("kind", C.c_int), ("idx", C.c_int), ("c0", C.c_uint64 * 2), ("c1", C.c_uint64 * 2)]
 

@@ -387,3 +387,130 @@ def test_multi_rank_opening_of_witness_and_fixed_commitments(dev, prover, world,
     assert not errors, errors
     for r in range(world):
         assert res[r].shape == want.shape and np.array_equal(res[r], want), f"rank {r}: the opening differs from the single-device opening"
+
+
+@pytest.mark.parametrize("world,q,nvs,lincomb", [
+    (2, 4, (9, 7, 8), None),
+    (4, 3, (10, 8, 6), None),
+    (8, 3, (11, 9, 7), None),
+    (4, 4, (9, 9, 7), "0"),        # every column a table of the sumcheck (no combination)
+    (2, 5, (10, 7), "1"),
+])
+def test_row_sharded_main_constraints_equal_the_single_device_proof(dev, prover, monkeypatch, world, q, nvs, lincomb):
+    """prove_batched_main_constraints over ROW-SHARDED tables in the block layout of the sharded chip proof: chips of different sizes, Prefix
+    selectors that start and end anywhere (a rank's part of the range is a prefix of its own rows) and a Whole selector, products of two and
+    three columns and columns that are read only linearly (combined per rank, their evaluations summed over the ranks) — q local rounds, the
+    gathered tail replicated — must give, on every rank, the messages, point, evaluations and claimed sum of the single-device proof
+    (BatchedMainConstraintProver::prove_batched_main_constraints, ceno_zkvm/src/scheme/cpu/mod.rs:1052-1390)"""
+    if lincomb is not None:
+        monkeypatch.setenv("CENO_PROVER_MAIN_LINCOMB", lincomb)
+    gch, w = [(11, 22), (33, 44)], 7
+    k = world.bit_length() - 1
+    cases = []
+    for c, nv in enumerate(nvs):
+        cols = [po.rand_base(1 << nv, 3100 + 13 * c + j) for j in range(w)]
+        point = po.rand_ext(nv, 3200 + c)
+        sels = [(po.SEL_PREFIX, 5 * c, (1 << nv) - 9 - 7 * c, 0, (), 0, point)]
+        terms = [[w, 0, 1], [w, 1, 2, 3], [w, 2, 0], [w, 3], [w, 4], [w, 5], [w, 6], [w, 1], [w]]
+        if c == 1:  # a second selector (Whole) over some of the columns
+            sels.append((po.SEL_WHOLE, 0, 0, 1, (), 0, point))
+            terms += [[w + 1, 4], [w + 1, 5, 6], [w + 1, 2]]
+        scalars = [[((9 + 3 * t + c, 2 + t), [2 + (t % 2)])] + ([((5 + t, 0), [t % 2, 3])] if t % 3 == 0 else []) for t in range(len(terms))]
+        cases.append((nv, cols, sels, terms, scalars))
+
+    def jobs_for(tables_of):
+        return [dict(num_vars=nv, mles=tables_of(cols) + [None] * len(sels), n_witin=w, n_fixed=0, n_structural=len(sels), selectors=sels, n_exprs=2,
+                     max_degree=4, terms=terms, scalars=scalars) for (nv, cols, sels, terms, scalars) in cases]
+
+    full = jobs_for(lambda cols: [dev.upload(c_) for c_ in cols])
+    want = prover.prove_batched_main_constraints(dev, full, gch, prover.Transcript.stub(5))
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            local = jobs_for(lambda cols: [dev.upload(prover.shard_rows(c_, world, g, q)) for c_ in cols])
+            results[g] = prover.dist_prove_batched_main_constraints(dev, group.comms[g], local, gch, prover.Transcript.stub(5), q, st)
+            dev.sync(st)
+            dev.stream_destroy(st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((g, repr(e), traceback.format_exc(limit=3)))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for g in range(world):
+        got = results[g]
+        assert np.array_equal(got[1], want[1]), f"rank {g}: messages"
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), f"rank {g}: point / evaluations"
+        assert got[0] == want[0], f"rank {g}: claimed sum"
+
+
+@pytest.mark.parametrize("world,log2_n,q", [(2, 10, 4), (4, 11, 3)])
+def test_gkr_half_and_main_constraints_of_one_chip_on_one_row_layout(dev, prover, world, log2_n, q):
+    """the phases of a chip between commitment and opening on ONE layout of its rows (blocks of 2^q rows dealt round-robin): the row-sharded chip
+    proof, then — selectors at the rt_main it returns, the same transcript — the row-sharded main-constraint sumcheck; every rank ends with the
+    single-device flow's chip proof, messages, point and evaluations"""
+    shape, w = (4, 4, 0, 8), 9
+    rows = 1 << log2_n
+    n_rec = shape[0] + shape[1] + shape[2] + (shape[2] if shape[2] else shape[3])
+    alpha, beta = (0x1234567, 0x89ABCDE), (0x13579B, 0x2468AC)
+    cols = [po.rand_base(rows, 700 + j) for j in range(w)]
+    coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+    mterms = [[w, j, (j + 1) % w] for j in range(w)] + [[w, j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 3)] + [[w, j] for j in range(w)]
+    mscal = [[((3 + 5 * t, 11 * t + 1), [2 + (t % 2)])] for t in range(len(mterms))]
+
+    def flow(dev_cols, log2_local, chip_fn, main_fn):
+        task = dict(mles=dev_cols, n_witin=w, n_fixed=0, n_structural=0, num_instances=rows - 5, log2_num_instances=log2_local, num_reads=shape[0],
+                    num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+        tr = prover.Transcript.stub(21)
+        proof = chip_fn(task, tr)
+        sel = (po.SEL_PREFIX, 0, rows - 5, 0, (), 0, np.ascontiguousarray(proof.rt_main))
+        job = dict(num_vars=log2_n, mles=dev_cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4, terms=mterms,
+                   scalars=mscal)
+        return proof, main_fn([job], tr)
+
+    full = [dev.upload(c) for c in cols]
+    want_proof, want_main = flow(full, log2_n, lambda task, tr: prover.create_chip_proof(dev, task, [alpha, beta], tr),
+                                 lambda jobs, tr: prover.prove_batched_main_constraints(dev, jobs, [alpha, beta], tr))
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            local = [dev.upload(prover.shard_rows(c, world, g, q)) for c in cols]
+            results[g] = flow(local, log2_n - (world.bit_length() - 1),
+                              lambda task, tr: prover.dist_create_chip_proof(dev, group.comms[g], task, log2_n, q, [alpha, beta], tr, st),
+                              lambda jobs, tr: prover.dist_prove_batched_main_constraints(dev, group.comms[g], jobs, [alpha, beta], tr, q, st))
+            dev.sync(st)
+            dev.stream_destroy(st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((g, repr(e), traceback.format_exc(limit=3)))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    alive = any(t.is_alive() for t in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for g in range(world):
+        proof, main = results[g]
+        assert proofs_equal(proof, want_proof), f"rank {g}: chip proof"
+        assert main[0] == want_main[0] and all(np.array_equal(a, b) for a, b in zip(main[1:], want_main[1:])), f"rank {g}: main constraints"
