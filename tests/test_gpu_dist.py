@@ -169,6 +169,7 @@ def test_bench_py_multi_rank_launch_end_to_end(world):
     # the GKR half of a chip across the ranks (row-sharded record inference, towers, tower proof), validated against the single-device proof
     dcp = r["extra"]["dist_chip_proof"]
     assert dcp["status"] == "ok" and dcp["proof_equals_single_device"] and dcp["ms"] > 0, dcp
+    assert dcp["main_constraints"]["equals_single_device"] and dcp["main_constraints"]["ms"] > 0, dcp  # ... and its main constraints on the same layout
     assert "shared-memory exchange" in r["config"]["collective"] and "checked against the torch.distributed path" in r["config"]["collective"]
     assert r["value"] > 0 and abs(r["value"] - 9 * ((1 << r["config"]["global_num_vars"]) - 1) / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
 
