@@ -466,6 +466,104 @@ def main_rotation_gloo(out_dir, n):
     dist.destroy_process_group()
 
 
+def main_case(world):
+    """chips of a batched main-constraint sumcheck for the CPU second implementation of its row-sharded form: per chip (num_vars, columns, Prefix
+    range, terms over the columns 0 .. w - 1 and the selector w, coefficients), and the selector points"""
+    w, nvs = 4, ((8, 6) if world <= 2 else (9, 7))
+    chips = []
+    for c, nv in enumerate(nvs):
+        cols = [po.rand_base(1 << nv, 5100 + 11 * c + j) for j in range(w)]
+        terms = [[w, 0, 1], [w, 1, 2, 3], [w, 2], [w, 3], [w, 0]]
+        coeffs = [(7 + 3 * t + c, 2 + t) for t in range(len(terms))]
+        chips.append(dict(nv=nv, cols=cols, off=3 * c, n=(1 << nv) - 7 - 5 * c, terms=terms, coeffs=coeffs, point=po.rand_ext(nv, 5200 + c)))
+    return chips
+
+
+def main_sharded_gloo(out_dir, _n):
+    """prove_batched_main_constraints' sumcheck over ROW-SHARDED tables a second time (independent of main_constraints.cpp
+    prover_main_constraints_sharded), in Python over the oracle's primitives and gloo: a rank's Prefix selector is eq at the point without the rank
+    coordinates on the rank's part of the range, its eq factor rides on the coefficients; q local rounds with the partial evaluations summed over
+    the ranks; every table gathered with the rank bits lowest; the tail replicated (a table that has run out of variables is multiplied by
+    every further challenge: the front-load rule).  Test infrastructure: every piece of arithmetic is the oracle's."""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    k, q, D = world.bit_length() - 1, int(os.environ.get("CENO_TEST_ROW_BLOCK_LOG", "3")), 4
+    chips = main_case(world)
+    one = (1, 0)
+
+    def gather(x):
+        got = [None] * world
+        dist.all_gather_object(got, x)
+        return got
+
+    def local_rows(t):
+        lo, g, hi = t & ((1 << q) - 1), (t >> q) & (world - 1), t >> (q + k)
+        return (hi << q) + ((1 << q) if rank < g else (lo if rank == g else 0))
+
+    tabs, nv_of, cf_loc, cf_glob, terms, sel_scale = [], [], [], [], [], []
+    for ch in chips:
+        pt = [(int(x[0]), int(x[1])) for x in ch["point"]]
+        eq_g = one
+        for j in range(k):
+            eq_g = po.e2_mul(eq_g, pt[q + j] if (rank >> j) & 1 else po.e2_sub(one, pt[q + j]))
+        pt_loc = po.ext([pt[j] for j in range(ch["nv"]) if j < q or j >= q + k])
+        lo, hi = local_rows(ch["off"]), local_rows(ch["off"] + ch["n"])
+        start = len(tabs)
+        tabs += [prover.shard_rows(c_, world, rank, q) for c_ in ch["cols"]] + [po.selector_compute(po.SEL_PREFIX, pt_loc, lo, hi - lo)]
+        sel_scale += [one] * len(ch["cols"]) + [eq_g]
+        nv_of += [ch["nv"]] * (len(ch["cols"]) + 1)
+        for t_, c_ in zip(ch["terms"], ch["coeffs"]):
+            terms.append([start + j for j in t_])
+            cf_glob.append(c_)
+            cf_loc.append(po.e2_mul(c_, eq_g))
+    max_nv = max(c_["nv"] for c_ in chips)
+    tr = po.StubTranscript(5)
+    _usize(tr, max_nv)
+    _usize(tr, D)
+    msgs, rt = [], []
+
+    def first(tabs_, cf_, remaining):
+        m, _, _ = po.sumcheck_prove(tabs_, po.ext(cf_), terms, remaining, D, po.StubTranscript(1))
+        return [(int(m[0][e][0]), int(m[0][e][1])) for e in range(D)]
+
+    def publish(m):
+        for e in range(D):
+            tr.append_ext(m[e])
+        tr.append_label(b"Internal round")
+        ch_ = tr.sample_ext()
+        msgs.append(m)
+        rt.append(ch_)
+        return ch_
+
+    for i in range(q):  # every chip still has local variables: plain folds
+        tot = [(0, 0)] * D
+        for part in gather(first(tabs, cf_loc, max_nv - k - i)):
+            tot = [po.e2_add(tot[e], part[e]) for e in range(D)]
+        ch_ = publish(tot)
+        tabs = [po.mle_fix_variable(t_, ch_) for t_ in tabs]
+    tabs = [po.ext([po.e2_mul((int(v[0]), int(v[1])), sc) for v in t_]) if sc != one else t_ for t_, sc in zip(tabs, sel_scale)]
+    tabs = [_interleave(gather(np.ascontiguousarray(t_)), 0, k) for t_ in tabs]
+    evals = [None] * len(tabs)
+    for i in range(q, max_nv):
+        ch_ = publish(first(tabs, cf_glob, max_nv - i))
+        nxt = []
+        for j, t_ in enumerate(tabs):
+            if t_.shape[0] > 1:
+                t_ = po.mle_fix_variable(t_, ch_)
+                if t_.shape[0] == 1:
+                    evals[j] = (int(t_[0][0]), int(t_[0][1]))  # the table's evaluation at its prefix of the point
+            else:  # out of variables: f * x_i at x_i = r (the front-load rule)
+                t_ = po.ext([po.e2_mul((int(t_[0][0]), int(t_[0][1])), ch_)])
+            nxt.append(t_)
+        tabs = nxt
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=po.ext([m[e] for m in msgs for e in range(D)]).reshape(max_nv, D, 2), rt=po.ext(rt),
+             evals=po.ext(evals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main_chip_gloo(out_dir, log2_n):
     import torch.distributed as dist
 
@@ -603,6 +701,8 @@ def main_chip_gloo(out_dir, log2_n):
 
 
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "main_gloo":
+        return main_sharded_gloo(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "rotation_gloo":
         return main_rotation_gloo(sys.argv[1], int(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "chip_gloo":

@@ -158,3 +158,35 @@ def test_row_sharded_rotation_argument_matches_unsharded(world, n, q, log2):
         assert np.array_equal(res[r]["msgs"], msgs), f"rank {r}: messages"
         assert np.array_equal(res[r]["origin"], origin) and np.array_equal(res[r]["left"], left) and np.array_equal(res[r]["right"], right), f"rank {r}: points"
         assert np.array_equal(res[r]["evals"], evals), f"rank {r}: evaluations"
+
+
+@pytest.mark.parametrize("world,q", [(2, 3), (4, 3)])
+def test_row_sharded_main_constraint_sumcheck_matches_unsharded(world, q):
+    """the batched main-constraint sumcheck over ROW-SHARDED tables a second time, independent of ceno_amd/host/main_constraints.cpp
+    prover_main_constraints_sharded: gloo ranks with block-cyclic row shards of two chips of different sizes (Prefix selectors that start and end
+    anywhere) run q local rounds with exchanged partial sums, gather every table and finish replicated — and must end, on every rank, with the
+    messages, point and evaluations of the oracle's sumcheck prover on the whole tables (the sumcheck of prove_batched_main_constraints,
+    ceno_zkvm/src/scheme/cpu/mod.rs:1255-1337)"""
+    from tests.dist_worker import main_case
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29830 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG=str(q), OMP_NUM_THREADS="2")
+        procs = []
+        for rank in range(world):
+            e = dict(env, RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "0", "main_gloo"], env=e))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
+    chips = main_case(world)
+    tabs, terms, coeffs = [], [], []
+    for ch in chips:
+        start = len(tabs)
+        tabs += ch["cols"] + [po.selector_compute(po.SEL_PREFIX, ch["point"], ch["off"], ch["n"])]
+        terms += [[start + j for j in t] for t in ch["terms"]]
+        coeffs += ch["coeffs"]
+    max_nv = max(ch["nv"] for ch in chips)
+    omsgs, ochal, ofin = po.sumcheck_prove(tabs, po.ext(coeffs), terms, max_nv, 4, po.StubTranscript(5))
+    for r in range(world):
+        assert np.array_equal(res[r]["msgs"], omsgs), f"rank {r}: messages"
+        assert np.array_equal(res[r]["rt"], ochal) and np.array_equal(res[r]["evals"], ofin), f"rank {r}: point / evaluations"
