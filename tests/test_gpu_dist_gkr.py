@@ -4,6 +4,7 @@ transcripts, exchanging through the in-process group — must produce, on EVERY 
 whole columns, bit for bit; and that proof equals the oracle's (tests/test_gpu_flows.py pins the single-device flow to the oracle: one
 representative shape is re-checked here).  Reference: ZKVMProver::create_chip_proof ceno_zkvm/src/scheme/prover.rs:717-833, tower prover
 scheme/cpu/mod.rs:346-554."""
+import os
 import threading
 
 import numpy as np
@@ -514,3 +515,109 @@ def test_gkr_half_and_main_constraints_of_one_chip_on_one_row_layout(dev, prover
         proof, main = results[g]
         assert proofs_equal(proof, want_proof), f"rank {g}: chip proof"
         assert main[0] == want_main[0] and all(np.array_equal(a, b) for a, b in zip(main[1:], want_main[1:])), f"rank {g}: main constraints"
+
+
+@pytest.mark.parametrize("world,log2_n,q,transcript", [(2, 10, 4, "stub"), (4, 11, 3, "poseidon2")])
+def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover, world, log2_n, q, transcript):
+    """config #3's flow with every phase across the ranks on ONE transcript: the commitment (column shards; ceno_dist_commit_traces_mmcs), its root
+    into the transcript, two challenges out, the chip proof (row shards, block layout; ceno_dist_create_chip_proof), the main-constraint sumcheck
+    at its rt_main (same row shards; ceno_dist_prove_batched_main_constraints), the opening of the commitment at the sumcheck's point with the
+    sumcheck's evaluations (ceno_dist_basefold_open) — every rank must end with the root, the chip proof, the sumcheck's messages / point /
+    evaluations and the opening proof of the single-device flow, word for word (ZKVMProver::create_proof's per-chip phases,
+    ceno_zkvm/src/scheme/prover.rs:324-586)"""
+    import torch
+
+    from ceno_amd import dist as cdist
+
+    shape, w, blow, nq, pow_bits = (4, 4, 0, 8), 9, 1, 8, 3
+    rows, k = 1 << log2_n, world.bit_length() - 1
+    n_rec = shape[0] + shape[1] + shape[3]
+    cols = [po.rand_base(rows, 900 + j) for j in range(w)]
+    col_split = [[w // world + (1 if g < w % world else 0) for g in range(world)]]
+    mterms = [[w, j, (j + 1) % w] for j in range(w)] + [[w, j, (j + 3) % w, (j + 5) % w] for j in range(0, w, 3)] + [[w, j] for j in range(w)]
+    mscal = [[((3 + 5 * t, 11 * t + 1), [2 + (t % 2)])] for t in range(len(mterms))]
+    new_tr = (lambda: prover.Transcript.stub(31)) if transcript == "stub" else (lambda: prover.Transcript.poseidon2(b"flow"))
+
+    def flow(tables, log2_local, commit_fn, chip_fn, main_fn, open_fn):
+        import time as _t
+        _t0 = _t.time()
+        def lap(what):
+            if os.environ.get("CENO_TEST_TIMING"):
+                print(f"[flow {log2_local}] {what}: {_t.time() - _t0:.2f} s", flush=True)
+        tr = new_tr()
+        root, commit_state = commit_fn()
+        lap("commit")
+        root = np.asarray(root, dtype=np.uint64).reshape(-1)
+        for v in root:
+            tr.append_base(int(v))
+        alpha, beta = tr.sample_ext(), tr.sample_ext()
+        coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+        task = dict(mles=tables, n_witin=w, n_fixed=0, n_structural=0, num_instances=rows - 5, log2_num_instances=log2_local, num_reads=shape[0],
+                    num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+        proof = chip_fn(task, [alpha, beta], tr)
+        lap("chip proof")
+        sel = (po.SEL_PREFIX, 0, rows - 5, 0, (), 0, np.ascontiguousarray(proof.rt_main))
+        job = dict(num_vars=log2_n, mles=tables + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4, terms=mterms,
+                   scalars=mscal)
+        main = main_fn([job], [alpha, beta], tr)
+        lap("main")
+        opening = open_fn(commit_state, [np.ascontiguousarray(main[2][:log2_n])], [np.ascontiguousarray(main[3][:w])], tr)
+        lap("open")
+        return root, proof, main, opening
+
+    stream = dev.stream_create()
+    full = [dev.upload(c) for c in cols]
+    matrix = np.ascontiguousarray(np.stack(cols, axis=1))
+
+    def commit_single():
+        pcs = prover.PcsData(dev, [matrix], blow, stream)
+        return pcs.root(), pcs
+
+    want = flow(full, log2_n, commit_single, lambda task, ch, tr: prover.create_chip_proof(dev, task, ch, tr),
+                lambda jobs, ch, tr: prover.prove_batched_main_constraints(dev, jobs, ch, tr),
+                lambda pcs, pts, evs, tr: pcs.basefold_open(pts, evs, nq, pow_bits, tr))
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            c0 = sum(col_split[0][:g])
+            mine = np.ascontiguousarray(matrix[:, c0:c0 + col_split[0][g]].T)
+            t = torch.from_numpy(mine.view(np.int64).copy()).to("cuda:0")
+            torch.cuda.synchronize()
+            local = [dev.upload(prover.shard_rows(c, world, g, q)) for c in cols]
+
+            def commit_dist():
+                com = cdist.sharded_commit_mmcs_native(dev, group.comms[g], [t.data_ptr()], col_split, [log2_n], blow, g, st)
+                dev.sync(st)
+                return com["root"], com
+
+            results[g] = flow(local, log2_n - k, commit_dist,
+                              lambda task, ch, tr: prover.dist_create_chip_proof(dev, group.comms[g], task, log2_n, q, ch, tr, st),
+                              lambda jobs, ch, tr: prover.dist_prove_batched_main_constraints(dev, group.comms[g], jobs, ch, tr, q, st),
+                              lambda com, pts, evs, tr: prover.dist_basefold_open(dev, group.comms[g], log2_n, col_split, blow, [t.data_ptr()],
+                                                                                  [x.data_ptr() for x in com["codeword_rows"]], com["subtree"], com["top"], pts,
+                                                                                  evs, nq, pow_bits, tr, st))
+            dev.sync(st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((g, repr(e), traceback.format_exc(limit=3)))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t_ in ths:
+        t_.start()
+    for t_ in ths:
+        t_.join(300)
+    alive = any(t_.is_alive() for t_ in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for g in range(world):
+        root, proof, main, opening = results[g]
+        assert np.array_equal(root, want[0]), f"rank {g}: commitment root"
+        assert proofs_equal(proof, want[1]), f"rank {g}: chip proof"
+        assert main[0] == want[2][0] and all(np.array_equal(a, b) for a, b in zip(main[1:], want[2][1:])), f"rank {g}: main constraints"
+        assert opening.shape == want[3].shape and np.array_equal(opening, want[3]), f"rank {g}: opening"
