@@ -279,7 +279,10 @@ int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int
         }
         shape_ptrs.push_back(&shape);
     }
-    BasefoldOpenHook hook{&D, !dist_comm_has_rccl(comm), hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
+    // (CENO_DIST_OPEN_PIPELINE=1 / 0 overrides the choice: A/B and the stress run that shows what the serial rounds are for, tools/dev/open_ranks_stress.sh)
+    const char* pe = getenv("CENO_DIST_OPEN_PIPELINE");
+    const bool serial = pe ? atoi(pe) == 0 : !dist_comm_has_rccl(comm);
+    BasefoldOpenHook hook{&D, serial, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
     return basefold_open_hooked(ctx, shape_ptrs.data(), n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
 }
 
