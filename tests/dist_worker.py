@@ -237,6 +237,16 @@ def chip_case(log2_n, w=9, shape=(4, 4, 0, 8)):
     return cols, po.ext(coeffs), terms, out_terms, [alpha, beta], shape
 
 
+def chip_main_job(tables, log2_n, w, rt_main):
+    """the main-constraint job of the process test's chip: products of two and three columns and every column alone under one Prefix selector at
+    the chip proof's rt_main (`tables`: the device tables — whole, or one rank's rows)"""
+    terms = [[w, j, (j + 1) % w] for j in range(w)] + [[w, j, (j + 2) % w, (j + 4) % w] for j in range(0, w, 2)] + [[w, j] for j in range(w)]
+    scalars = [[((3 + 5 * t, 11 * t + 1), [2 + (t % 2)])] for t in range(len(terms))]
+    sel = (po.SEL_PREFIX, 0, (1 << log2_n) - 5, 0, (), 0, np.ascontiguousarray(rt_main))
+    return dict(num_vars=log2_n, mles=list(tables) + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4, terms=terms,
+                scalars=scalars)
+
+
 def main_shm_gpu_chip(out_dir, log2_n):
     """ceno_dist_create_chip_proof with the shared-memory exchange: `world` PROCESSES sharing GPU 0, every rank its rows of every column"""
     from ceno_amd import Device
@@ -252,9 +262,14 @@ def main_shm_gpu_chip(out_dir, log2_n):
     task = dict(mles=local, n_witin=len(cols), n_fixed=0, n_structural=0, num_instances=(1 << log2_n) - 5, log2_num_instances=log2_n - (world.bit_length() - 1),
                 num_reads=shape[0], num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms,
                 record_out_terms=out_terms)
-    pr = prover.dist_create_chip_proof(dev, comm.h, task, log2_n, q, challenges, prover.Transcript.stub(21), stream)
+    tr = prover.Transcript.stub(21)
+    pr = prover.dist_create_chip_proof(dev, comm.h, task, log2_n, q, challenges, tr, stream)
+    # ... and the chip's main-constraint sumcheck on the same row shards, the same transcript (ceno_dist_prove_batched_main_constraints)
+    mjob = chip_main_job(local, log2_n, len(cols), pr.rt_main)
+    mc, mm, mrt, mev = prover.dist_prove_batched_main_constraints(dev, comm.h, [mjob], challenges, tr, q, stream)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=pr.tower_msgs, point=pr.tower_point, prod=pr.tower_prod_evals, logup=pr.tower_logup_evals,
-             r_out=pr.r_out_evals, w_out=pr.w_out_evals, lk_out=pr.lk_out_evals, rt_main=pr.rt_main)
+             r_out=pr.r_out_evals, w_out=pr.w_out_evals, lk_out=pr.lk_out_evals, rt_main=pr.rt_main, main_claim=np.array(mc, dtype=np.uint64), main_msgs=mm,
+             main_rt=mrt, main_evals=mev)
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

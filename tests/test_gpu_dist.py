@@ -101,8 +101,9 @@ def test_sharded_commitment_and_opening_as_processes_on_one_gpu(world):
 
 @pytest.mark.parametrize("world,log2_n", [(2, 10), (4, 11)])
 def test_row_sharded_chip_proof_as_processes_on_one_gpu(world, log2_n):
-    """ceno_dist_create_chip_proof (record inference, tower witness, tower proof over row-sharded columns) as `world` PROCESSES sharing GPU 0 with
-    the shared-memory exchange: every rank's proof must equal the single-device proof of the whole columns, computed here"""
+    """ceno_dist_create_chip_proof (record inference, tower witness, tower proof over row-sharded columns) and, on the same row shards and
+    transcript, ceno_dist_prove_batched_main_constraints, as `world` PROCESSES sharing GPU 0 with the shared-memory exchange: every rank's proof
+    and sumcheck must equal the single-device ones of the whole columns, computed here"""
     from ceno_amd import Device, prover
     from tests.dist_worker import chip_case
 
@@ -120,13 +121,20 @@ def test_row_sharded_chip_proof_as_processes_on_one_gpu(world, log2_n):
     full = [dev.upload(c) for c in cols]
     task = dict(mles=full, n_witin=len(cols), n_fixed=0, n_structural=0, num_instances=(1 << log2_n) - 5, log2_num_instances=log2_n, num_reads=shape[0],
                 num_writes=shape[1], num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
-    want = prover.create_chip_proof(dev, task, challenges, prover.Transcript.stub(21))
+    from tests.dist_worker import chip_main_job
+
+    tr = prover.Transcript.stub(21)
+    want = prover.create_chip_proof(dev, task, challenges, tr)
+    wc, wm, wrt, wev = prover.prove_batched_main_constraints(dev, [chip_main_job(full, log2_n, len(cols), want.rt_main)], challenges, tr)
     for r in range(world):
         got = res[r]
         assert np.array_equal(got["msgs"], want.tower_msgs) and np.array_equal(got["point"], want.tower_point)
         assert np.array_equal(got["prod"], want.tower_prod_evals) and np.array_equal(got["logup"], want.tower_logup_evals)
         assert np.array_equal(got["r_out"], want.r_out_evals) and np.array_equal(got["w_out"], want.w_out_evals)
         assert np.array_equal(got["lk_out"], want.lk_out_evals) and np.array_equal(got["rt_main"], want.rt_main)
+        # ... and the main-constraint sumcheck on the same row shards and transcript
+        assert tuple(int(x) for x in got["main_claim"]) == wc and np.array_equal(got["main_msgs"], wm), f"rank {r}: main constraints"
+        assert np.array_equal(got["main_rt"], wrt) and np.array_equal(got["main_evals"], wev), f"rank {r}: main constraints"
     for m in full:
         m.free()
     dev.close()

@@ -195,6 +195,30 @@ def test_row_sharded_chip_proof_with_rotation_equals_the_single_device_proof(dev
         assert np.array_equal(got.rotation_points, want.rotation_points) and np.array_equal(got.rotation_evals, want.rotation_evals), f"rank {g}"
 
 
+def test_row_sharded_main_constraints_refuse_what_they_cannot_shard(dev, prover):
+    """a chip with too few rows for the block size, and a selector that is no eq table on a row range (OrderedSparse): refused with a message
+    instead of a wrong proof"""
+    from ceno_amd.api import CenoHipError
+
+    world, q, w = 4, 4, 3
+    group = prover.LocalGroup(world)
+
+    def job(nv, sel):
+        cols = [dev.upload(prover.shard_rows(po.rand_base(1 << nv, 60 + j), world, 0, q)) for j in range(w)]
+        return dict(num_vars=nv, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=3,
+                    terms=[[w, 0, 1], [w, 2]], scalars=[[((3, 1), [2])], [((5, 0), [3])]])
+
+    with pytest.raises(CenoHipError) as ei:  # 2^6 rows: 6 - 2 < q + 1
+        prover.dist_prove_batched_main_constraints(dev, group.comms[0], [job(6, (po.SEL_PREFIX, 0, 60, 0, (), 0, po.rand_ext(6, 1)))], [(1, 2), (3, 4)],
+                                                   prover.Transcript.stub(1), q)
+    assert "too small" in str(ei.value)
+    with pytest.raises(CenoHipError) as ei:
+        prover.dist_prove_batched_main_constraints(dev, group.comms[0], [job(8, (po.SEL_ORDERED_SPARSE, 0, 10, 0, (0, 2), 2, po.rand_ext(8, 2)))],
+                                                   [(1, 2), (3, 4)], prover.Transcript.stub(1), q)
+    assert "Whole and Prefix" in str(ei.value)
+    group.close()
+
+
 def test_row_sharded_chip_proof_refuses_what_it_cannot_shard(dev, prover):
     from ceno_amd.api import CenoHipError
 
