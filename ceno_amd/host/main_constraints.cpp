@@ -60,7 +60,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                                     uint64_t* out_claimed_sum, uint64_t* out_msgs, uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars,
                                     int* out_degree, const RotationShard* sh) {
     if (!ctx || !jobs || n_jobs < 1 || !gc4 || !tr) return prover_set_error(CENO_HIP_ERR_INVALID, "bad arguments");
-    const int shk = sh ? sh->k : 0, shq = sh ? sh->q : 0;
+    const int shk = sh ? sh->k : 0, shq = sh ? sh->q : 0;  // (constants of the layout; `sh` itself is dropped below when no chip is large enough to be sharded)
     auto eq_rank = [&](const uint64_t* p) {  // eq(rank, p[q .. q + k))
         E2 v = gl::e2_one();
         for (int j = 0; j < shk; j++) {
@@ -82,10 +82,16 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         const size_t lo = t & (((size_t)1 << shq) - 1), g = (t >> shq) & (((size_t)1 << shk) - 1), hi = t >> (shq + shk);
         return (hi << shq) + ((size_t)sh->rank < g ? (size_t)1 << shq : ((size_t)sh->rank == g ? lo : 0));
     };
-    if (sh)
-        for (int c = 0; c < n_jobs; c++)
-            if (jobs[c].num_vars - shk < shq + 1)
-                return prover_set_error(CENO_HIP_ERR_INVALID, "sharded main constraints: a chip is too small for this block size (needs log2 rows >= q + log2 world + 1)");
+    // a chip with fewer than 2^(q + k + 1) rows is not sharded: every rank holds its WHOLE tables (`big[c]` = 0) and proves it replicated — its part
+    // of every round's message is the same on every rank and is added once
+    std::vector<char> big((size_t)n_jobs, 0);
+    bool any_big = false, any_small = false;
+    for (int c = 0; c < n_jobs; c++) {
+        big[(size_t)c] = sh && jobs[c].num_vars - shk >= shq + 1;
+        any_big = any_big || big[(size_t)c];
+        any_small = any_small || !big[(size_t)c];
+    }
+    if (sh && !any_big) sh = nullptr;  // nothing is sharded: every rank runs the whole batch (same transcript, same outputs)
     static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr;
     auto now_us = []() {
         timespec ts;
@@ -121,7 +127,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                 batch.push_back(Pending{c, id, k});
                 continue;
             }
-            if (sh) { cleanup(); return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "sharded main constraints: Whole and Prefix selectors only"); }
+            if (sh && big[(size_t)c]) { cleanup(); return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "sharded main constraints: Whole and Prefix selectors only"); }
             ceno_hip_mle* m = nullptr;
             int rc = ceno_hip_selector_build(ctx, J.sel_kind[k], J.sel_points[k], J.num_vars, J.sel_offset[k], J.sel_num_instances[k],
                                              J.sel_sparse_indices ? J.sel_sparse_indices[k] : nullptr, J.sel_n_sparse ? J.sel_n_sparse[k] : 0,
@@ -153,7 +159,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
             pts[b] = J.sel_points[k];
             offs[b] = J.sel_offset[k];
             nins[b] = J.sel_num_instances[k];
-            if (sh) {
+            if (sh && big[(size_t)batch[b].c]) {
                 sel_loc_pt.push_back(local_point(J.sel_points[k], J.num_vars));
                 sel_loc_pt_of[batch[b].c][k] = sel_loc_pt.size() - 1;
                 pts[b] = sel_loc_pt.back().data();
@@ -187,6 +193,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
     // ---- global MLE list and monomial terms (cpu/mod.rs:1255-1329) ----
     std::vector<ceno_hip_mle*> mles;
     std::vector<E2> mle_eqg;  // per table: the rank's eq factor of a sharded selector (1 otherwise)
+    std::vector<int> mle_job;  // per table: its chip
     std::vector<int> mle_start(n_jobs), mle_nv;
     std::vector<uint64_t> coeffs;
     std::vector<uint32_t> toff{0}, tidx;
@@ -207,7 +214,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                 m = sel_by_id[c][id];
                 if (J.sel_kind[k] == CENO_HIP_SEL_WHOLE || J.sel_kind[k] == CENO_HIP_SEL_PREFIX) {
                     eq_idx.push_back((int)mles.size());
-                    if (!sh) {
+                    if (!sh || !big[(size_t)c]) {
                         eq_pts.push_back(J.sel_points[k]);
                         eq_lo.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? 0 : J.sel_offset[k]);
                         eq_hi.push_back(J.sel_kind[k] == CENO_HIP_SEL_WHOLE ? (size_t)1 << J.num_vars : J.sel_offset[k] + J.sel_num_instances[k]);
@@ -219,9 +226,11 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                 }
             }
             if (!m) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "structural witness without selector is NULL"); }
-            if (sh && ceno_hip_mle_num_vars(m) != J.num_vars - shk) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "sharded main constraints: a local table has the wrong height"); }
+            const int shift = sh && big[(size_t)c] ? shk : 0;
+            if (sh && ceno_hip_mle_num_vars(m) != J.num_vars - shift) { cleanup(); return prover_set_error(CENO_HIP_ERR_INVALID, "sharded main constraints: a table has the wrong height (rows of this rank for a sharded chip, all rows for a small one)"); }
             mles.push_back(m);
-            mle_nv.push_back(ceno_hip_mle_num_vars(m) + shk);  // (the GLOBAL number of variables)
+            mle_job.push_back(c);
+            mle_nv.push_back(ceno_hip_mle_num_vars(m) + shift);  // (the GLOBAL number of variables)
             mle_eqg.push_back(j >= J.n_witin + J.n_fixed && sel_by_id[c][j - J.n_witin - J.n_fixed] ? sel_eqg[c][j - J.n_witin - J.n_fixed] : gl::e2_one());
         }
         std::vector<E2> ch{E2{gc4[0], gc4[1]}, E2{gc4[2], gc4[3]}};
@@ -261,6 +270,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
     std::vector<uint32_t> p_toff{0}, p_tidx;
     std::vector<int> removed;                          // global ids of the combined columns
     std::vector<E2> plan_eqg;                          // per table of the plan: the rank's eq factor of a sharded selector (1 otherwise)
+    std::vector<int> plan_job;                         // per table of the plan: its chip
     {
         const size_t nm = mles.size();
         std::vector<char> is_ext(nm), other(nm, 0);
@@ -356,8 +366,14 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         }
         for (int& e : eq_idx) e = plan_of[e];
         plan_eqg.assign(plan_mles.size(), gl::e2_one());
+        plan_job.assign(plan_mles.size(), 0);
         for (size_t j = 0; j < nm; j++)
-            if (plan_of[j] >= 0) plan_eqg[(size_t)plan_of[j]] = mle_eqg[j];
+            if (plan_of[j] >= 0) {
+                plan_eqg[(size_t)plan_of[j]] = mle_eqg[j];
+                plan_job[(size_t)plan_of[j]] = mle_job[j];
+            }
+        for (size_t g = 0; g < gsel.size(); g++)  // the combined tables belong to their selector's chip
+            for (int half = 0; half < 2; half++) plan_job[plan_mles.size() - 2 * (gsel.size() - g) + (size_t)half] = mle_job[(size_t)gsel[g]];
     }
     const int n_terms = (int)p_toff.size() - 1;
     // ---- common-factor plan (the role of CommonTermPlan in the reference's GPU arm, scheme/gpu/mod.rs:2811-2962, built
@@ -417,27 +433,99 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         rc = ceno_prover_sumcheck_prove_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), tr, s,
                                            out_msgs, out_global_rt, p_evals.data());   // cpu/mod.rs:1332-1337
     } else {
-        // ---- the same sumcheck over row-sharded tables: q local rounds, the gathered tail replicated ----
+        // ---- the same sumcheck over row-sharded tables: q local rounds, the gathered tail replicated; the chips that are too small to be
+        // sharded run beside it in a sumcheck of their own, the same on every rank, whose messages are added once ----
         const int D = max_deg, W = sh->world;
         auto tr_usize = [&](uint64_t v) {
             uint8_t b[8];
             for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i));
             tr->append_label(tr->self, b, 8);
         };
-        ceno_hip_sumcheck *sc = nullptr, *sc2 = nullptr;
+        // the plan of a subset of the chips: its tables, terms and groups renumbered (a term, a group and an eq declaration belong to one chip)
+        struct Pack {
+            std::vector<ceno_hip_mle*> mles;
+            std::vector<int> orig;  // index in the whole plan
+            std::vector<uint64_t> coeffs, coeffs_loc;
+            std::vector<uint32_t> toff{0}, tidx, gtoff{0}, gtidx, gcoff{0}, gcidx;
+            std::vector<int> eq_i;
+            std::vector<const uint64_t*> eq_p;
+            std::vector<size_t> eq_l, eq_h;
+            ceno_hip_sumcheck_plan plan{};
+        };
+        auto make_pack = [&](bool want_big, Pack& P) {
+            std::vector<int> remap(plan_mles.size(), -1), tmap((size_t)n_terms, -1);
+            for (size_t i = 0; i < plan_mles.size(); i++)
+                if ((bool)big[(size_t)plan_job[i]] == want_big) {
+                    remap[i] = (int)P.mles.size();
+                    P.mles.push_back(plan_mles[i]);
+                    P.orig.push_back((int)i);
+                }
+            auto job_of_term = [&](int t) {  // (a term without residual factors sits in a group: its common factor names the chip)
+                if (p_toff[t + 1] > p_toff[t]) return plan_job[p_tidx[p_toff[t]]];
+                return -1;
+            };
+            std::vector<int> tjob((size_t)n_terms, -1);
+            for (int t = 0; t < n_terms; t++) tjob[(size_t)t] = job_of_term(t);
+            for (size_t g = 0; g + 1 < g_toff.size(); g++) {
+                const int j = plan_job[g_cidx[g_coff[g]]];
+                for (uint32_t x = g_toff[g]; x < g_toff[g + 1]; x++) tjob[g_tidx[x]] = j;
+            }
+            for (int t = 0; t < n_terms; t++) {
+                if ((bool)big[(size_t)tjob[(size_t)t]] != want_big) continue;
+                tmap[(size_t)t] = (int)P.toff.size() - 1;
+                P.coeffs.insert(P.coeffs.end(), {p_coeffs[2 * t], p_coeffs[2 * t + 1]});
+                P.coeffs_loc.insert(P.coeffs_loc.end(), {p_coeffs_loc[2 * t], p_coeffs_loc[2 * t + 1]});
+                for (uint32_t x = r_toff[t]; x < r_toff[t + 1]; x++) P.tidx.push_back((uint32_t)remap[r_tidx[x]]);
+                P.toff.push_back((uint32_t)P.tidx.size());
+            }
+            for (size_t g = 0; g + 1 < g_toff.size(); g++) {
+                if ((bool)big[(size_t)plan_job[g_cidx[g_coff[g]]]] != want_big) continue;
+                for (uint32_t x = g_toff[g]; x < g_toff[g + 1]; x++) P.gtidx.push_back((uint32_t)tmap[g_tidx[x]]);
+                P.gtoff.push_back((uint32_t)P.gtidx.size());
+                for (uint32_t x = g_coff[g]; x < g_coff[g + 1]; x++) P.gcidx.push_back((uint32_t)remap[g_cidx[x]]);
+                P.gcoff.push_back((uint32_t)P.gcidx.size());
+            }
+            for (size_t e = 0; e < eq_idx.size(); e++)
+                if (remap[(size_t)eq_idx[e]] >= 0) {
+                    P.eq_i.push_back(remap[(size_t)eq_idx[e]]);
+                    P.eq_p.push_back(eq_pts[e]);
+                    P.eq_l.push_back(eq_lo[e]);
+                    P.eq_h.push_back(eq_hi[e]);
+                }
+            P.plan.num_mles = (int)P.mles.size();
+            P.plan.num_terms = (int)P.toff.size() - 1;
+            P.plan.term_coeffs = P.coeffs.data();
+            P.plan.term_offsets = P.toff.data();
+            P.plan.term_mle_idx = P.tidx.data();
+            P.plan.num_groups = (int)P.gtoff.size() - 1;
+            P.plan.group_term_offsets = P.gtoff.data();
+            P.plan.group_term_idx = P.gtidx.data();
+            P.plan.common_offsets = P.gcoff.data();
+            P.plan.common_mle_idx = P.gcidx.data();
+            P.plan.max_degree = D;
+        };
+        Pack PB, PS;
+        make_pack(true, PB);
+        if (any_small) make_pack(false, PS);
+        ceno_hip_sumcheck *sc = nullptr, *sc2 = nullptr, *scs = nullptr;
         auto drop = [&]() {
             if (sc) ceno_hip_sumcheck_free(ctx, sc);
             if (sc2) ceno_hip_sumcheck_free(ctx, sc2);
-            sc = sc2 = nullptr;
+            if (scs) ceno_hip_sumcheck_free(ctx, scs);
+            sc = sc2 = scs = nullptr;
         };
-        plan.term_coeffs = p_coeffs_loc.data();
-        plan.max_num_vars = max_nv - shk;
-        rc = ceno_hip_sumcheck_begin_eq(ctx, plan_mles.data(), &plan, (int)eq_idx.size(), eq_idx.data(), eq_pts.data(), eq_lo.data(), eq_hi.data(), s, &sc);
-        if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+        PB.plan.term_coeffs = PB.coeffs_loc.data();
+        PB.plan.max_num_vars = max_nv - shk;
+        rc = ceno_hip_sumcheck_begin_eq(ctx, PB.mles.data(), &PB.plan, (int)PB.eq_i.size(), PB.eq_i.data(), PB.eq_p.data(), PB.eq_l.data(), PB.eq_h.data(), s, &sc);
+        if (!rc && any_small && PS.plan.num_terms > 0) {  // the small chips: whole tables, all max_nv rounds in one handle (its own front-load rule)
+            PS.plan.max_num_vars = max_nv;
+            rc = ceno_hip_sumcheck_begin_eq(ctx, PS.mles.data(), &PS.plan, (int)PS.eq_i.size(), PS.eq_i.data(), PS.eq_p.data(), PS.eq_l.data(), PS.eq_h.data(), s, &scs);
+        }
+        if (rc) { drop(); cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
         tr_usize((uint64_t)max_nv);
         tr_usize((uint64_t)D);
         uint64_t ch[2] = {0, 0};
-        std::vector<uint64_t> m((size_t)2 * D), all((size_t)W * 2 * D);
+        std::vector<uint64_t> m((size_t)2 * D), ms((size_t)2 * D), all((size_t)W * 2 * D);
         auto publish = [&](int round, const E2* pv) {
             uint64_t* msg = out_msgs + (size_t)2 * D * round;
             for (int e = 0; e < D; e++) {
@@ -452,6 +540,13 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
             out_global_rt[2 * round + 1] = ch[1];
         };
         std::vector<E2> pv((size_t)D);
+        auto add_small = [&](int i) -> int {  // the small chips' part of round i, once
+            if (!scs) return 0;
+            int r2 = ceno_hip_sumcheck_round(ctx, scs, i == 0 ? nullptr : ch, ms.data());
+            if (r2) return prover_set_error(r2, ceno_hip_last_error(ctx));
+            for (int e = 0; e < D; e++) pv[(size_t)e] = pv[(size_t)e] + E2{ms[2 * e], ms[2 * e + 1]};
+            return 0;
+        };
         for (int i = 0; i < shq && !rc; i++) {
             rc = ceno_hip_sumcheck_round(ctx, sc, i == 0 ? nullptr : ch, m.data());
             if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
@@ -461,16 +556,18 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                 pv[(size_t)e] = gl::e2_zero();
                 for (int g = 0; g < W; g++) pv[(size_t)e] = pv[(size_t)e] + E2{all[(size_t)g * 2 * D + 2 * e], all[(size_t)g * 2 * D + 2 * e + 1]};
             }
+            rc = add_small(i);
+            if (rc) break;
             publish(i, pv.data());
         }
         if (rc) { drop(); cleanup(); return rc; }
-        // every table as the next round would read it (folded q - 1 times; once more here), gathered with the rank bits lowest
+        // every sharded table as the next round would read it (folded q - 1 times; once more here), gathered with the rank bits lowest
         const E2 r_last{ch[0], ch[1]};
-        std::vector<ceno_hip_mle*> glob(plan_mles.size(), nullptr);
+        std::vector<ceno_hip_mle*> glob(PB.mles.size(), nullptr);
         std::vector<E2> t, g_tab;
         std::vector<uint64_t> mine, gathered;
-        for (size_t mi = 0; mi < plan_mles.size() && !rc; mi++) {
-            const int nv_loc = ceno_hip_mle_num_vars(plan_mles[mi]);
+        for (size_t mi = 0; mi < PB.mles.size() && !rc; mi++) {
+            const int nv_loc = ceno_hip_mle_num_vars(PB.mles[mi]);
             const size_t len_loc = (size_t)1 << (nv_loc - shq);
             int nv = 0;
             t.resize(2 * len_loc);
@@ -478,8 +575,9 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
             if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
             if (nv != nv_loc - shq + 1) { rc = prover_set_error(CENO_HIP_ERR_STATE, "sharded main constraints: unexpected table shape after the local rounds"); break; }
             mine.resize(2 * len_loc);
+            const E2 scale = plan_eqg[(size_t)PB.orig[mi]];  // (a selector's rank factor went into the coefficients)
             for (size_t j = 0; j < len_loc; j++) {
-                const E2 v = (t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j])) * plan_eqg[mi];  // (a selector's rank factor went into the coefficients)
+                const E2 v = (t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j])) * scale;
                 mine[2 * j] = v.c0;
                 mine[2 * j + 1] = v.c1;
             }
@@ -498,20 +596,31 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         if (rc) { drop(); cleanup(); return rc; }
         ceno_hip_sumcheck_free(ctx, sc);
         sc = nullptr;
-        plan.term_coeffs = p_coeffs.data();
-        plan.max_num_vars = max_nv - shq;
-        rc = ceno_hip_sumcheck_begin(ctx, glob.data(), &plan, s, &sc2);
+        PB.plan.term_coeffs = PB.coeffs.data();
+        PB.plan.max_num_vars = max_nv - shq;
+        rc = ceno_hip_sumcheck_begin(ctx, glob.data(), &PB.plan, s, &sc2);
         if (rc) { drop(); cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
         for (int i = shq; i < max_nv; i++) {
             rc = ceno_hip_sumcheck_round(ctx, sc2, i == shq ? nullptr : ch, m.data());
             if (rc) { drop(); cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
             for (int e = 0; e < D; e++) pv[(size_t)e] = E2{m[2 * e], m[2 * e + 1]};
+            rc = add_small(i);
+            if (rc) { drop(); cleanup(); return rc; }
             publish(i, pv.data());
         }
-        rc = ceno_hip_sumcheck_finish(ctx, sc2, max_nv > shq ? ch : nullptr, p_evals.data());
+        std::vector<uint64_t> eb(2 * PB.mles.size()), es(2 * std::max<size_t>(PS.mles.size(), 1));
+        rc = ceno_hip_sumcheck_finish(ctx, sc2, max_nv > shq ? ch : nullptr, eb.data());
+        if (!rc && scs) rc = ceno_hip_sumcheck_finish(ctx, scs, ch, es.data());
         if (rc) rc = prover_set_error(rc, ceno_hip_last_error(ctx));
+        for (size_t mi = 0; mi < PB.mles.size(); mi++) {
+            p_evals[2 * (size_t)PB.orig[mi]] = eb[2 * mi];
+            p_evals[2 * (size_t)PB.orig[mi] + 1] = eb[2 * mi + 1];
+        }
+        for (size_t mi = 0; scs && mi < PS.mles.size(); mi++) {
+            p_evals[2 * (size_t)PS.orig[mi]] = es[2 * mi];
+            p_evals[2 * (size_t)PS.orig[mi] + 1] = es[2 * mi + 1];
+        }
         drop();
-        plan.max_num_vars = max_nv;
     }
     const double t_sc = dbg ? now_us() : 0;
     if (rc) { cleanup(); return rc; }
@@ -529,24 +638,42 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         if (!sh) {
             rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), out_global_rt, max_nv, s, rc_out.data());
             if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
-        } else {  // per-rank evaluations at the point without the rank coordinates, weighted by eq over them, summed over the ranks
-            const std::vector<uint64_t> rt_loc = local_point(out_global_rt, max_nv);
-            rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)removed.size(), rc_cols.data(), rt_loc.data(), max_nv - shk, s, rc_out.data());
-            if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
-            const E2 w = eq_rank(out_global_rt);
-            for (size_t k = 0; k < removed.size(); k++) {
-                const E2 v = E2{rc_out[2 * k], rc_out[2 * k + 1]} * w;
-                rc_out[2 * k] = v.c0;
-                rc_out[2 * k + 1] = v.c1;
+        } else {
+            // a sharded chip's column: per-rank evaluations at the point without the rank coordinates, weighted by eq over them, summed over the
+            // ranks; a small chip's column is whole on every rank: evaluated at the point itself
+            std::vector<size_t> kb, ks;
+            for (size_t k = 0; k < removed.size(); k++) (big[(size_t)mle_job[(size_t)removed[k]]] ? kb : ks).push_back(k);
+            std::vector<ceno_hip_mle*> cb(kb.size()), cs(ks.size());
+            std::vector<uint64_t> ob(2 * kb.size()), os(2 * ks.size());
+            for (size_t x = 0; x < kb.size(); x++) cb[x] = rc_cols[kb[x]];
+            for (size_t x = 0; x < ks.size(); x++) cs[x] = rc_cols[ks[x]];
+            if (!ks.empty()) {
+                rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)ks.size(), cs.data(), out_global_rt, max_nv, s, os.data());
+                if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+                for (size_t x = 0; x < ks.size(); x++) {
+                    rc_out[2 * ks[x]] = os[2 * x];
+                    rc_out[2 * ks[x] + 1] = os[2 * x + 1];
+                }
             }
-            std::vector<uint64_t> parts((size_t)sh->world * rc_out.size());
-            rc = sh->allgather(sh->self, rc_out.data(), rc_out.size(), parts.data());
-            if (rc) { cleanup(); return rc; }
-            for (size_t k = 0; k < removed.size(); k++) {
-                E2 v = gl::e2_zero();
-                for (int g = 0; g < sh->world; g++) v = v + E2{parts[(size_t)g * rc_out.size() + 2 * k], parts[(size_t)g * rc_out.size() + 2 * k + 1]};
-                rc_out[2 * k] = v.c0;
-                rc_out[2 * k + 1] = v.c1;
+            if (!kb.empty()) {
+                const std::vector<uint64_t> rt_loc = local_point(out_global_rt, max_nv);
+                rc = ceno_hip_mle_evaluate_prefix_batch(ctx, (int)kb.size(), cb.data(), rt_loc.data(), max_nv - shk, s, ob.data());
+                if (rc) { cleanup(); return prover_set_error(rc, ceno_hip_last_error(ctx)); }
+                const E2 w = eq_rank(out_global_rt);
+                for (size_t x = 0; x < kb.size(); x++) {
+                    const E2 v = E2{ob[2 * x], ob[2 * x + 1]} * w;
+                    ob[2 * x] = v.c0;
+                    ob[2 * x + 1] = v.c1;
+                }
+                std::vector<uint64_t> parts((size_t)sh->world * ob.size());
+                rc = sh->allgather(sh->self, ob.data(), ob.size(), parts.data());
+                if (rc) { cleanup(); return rc; }
+                for (size_t x = 0; x < kb.size(); x++) {
+                    E2 v = gl::e2_zero();
+                    for (int g = 0; g < sh->world; g++) v = v + E2{parts[(size_t)g * ob.size() + 2 * x], parts[(size_t)g * ob.size() + 2 * x + 1]};
+                    rc_out[2 * kb[x]] = v.c0;
+                    rc_out[2 * kb[x] + 1] = v.c1;
+                }
             }
         }
         for (size_t k = 0; k < removed.size(); k++) {

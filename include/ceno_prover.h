@@ -482,9 +482,11 @@ int ceno_dist_chip_block_log(void);
 int ceno_dist_create_chip_proof(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_chip_task* task, int log2_num_instances_global, int row_block_log,
                                 const uint64_t* challenges4, ceno_transcript* tr, ceno_hip_stream s, ceno_chip_proof* out);
 /* prove_batched_main_constraints over the same block layout (ceno_amd/host/main_constraints.cpp prover_main_constraints_sharded): the tables of every
- * job hold THIS rank's rows (num_vars - log2 world variables; job.num_vars, the selectors' offsets / counts and points stay GLOBAL); Whole and
- * Prefix selectors only; every chip needs num_vars >= q + log2 world + 1.  q local rounds (the partial evaluations of a round summed over the
- * ranks), the gathered tail replicated; outputs as ceno_prover_prove_batched_main_constraints on the whole tables, word for word, on every rank. */
+ * job hold THIS rank's rows (num_vars - log2 world variables; job.num_vars, the selectors' offsets / counts and points stay GLOBAL; Whole and
+ * Prefix selectors only).  A chip with num_vars < q + log2 world + 1 is too small to be sharded: every rank passes its WHOLE tables and it is
+ * proved replicated beside the sharded ones (any selector kind; its part of a round's message is added once).  q local rounds (the partial
+ * evaluations of a round summed over the ranks), the gathered tail replicated; outputs as ceno_prover_prove_batched_main_constraints on the whole
+ * tables, word for word, on every rank. */
 int ceno_dist_prove_batched_main_constraints(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_main_job* jobs_local, int n_jobs, int row_block_log,
                                              const uint64_t* global_challenges4, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_claimed_sum,
                                              uint64_t* out_msgs, uint64_t* out_global_rt, uint64_t* out_evals, int* out_num_vars, int* out_degree);

@@ -196,8 +196,8 @@ def test_row_sharded_chip_proof_with_rotation_equals_the_single_device_proof(dev
 
 
 def test_row_sharded_main_constraints_refuse_what_they_cannot_shard(dev, prover):
-    """a chip with too few rows for the block size, and a selector that is no eq table on a row range (OrderedSparse): refused with a message
-    instead of a wrong proof"""
+    """a SHARDED chip with a selector that is no eq table on a row range (OrderedSparse): refused with a message instead of a wrong proof (a chip
+    too small to be sharded is proved replicated, whatever its selectors)"""
     from ceno_amd.api import CenoHipError
 
     world, q, w = 4, 4, 3
@@ -208,10 +208,6 @@ def test_row_sharded_main_constraints_refuse_what_they_cannot_shard(dev, prover)
         return dict(num_vars=nv, mles=cols + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=3,
                     terms=[[w, 0, 1], [w, 2]], scalars=[[((3, 1), [2])], [((5, 0), [3])]])
 
-    with pytest.raises(CenoHipError) as ei:  # 2^6 rows: 6 - 2 < q + 1
-        prover.dist_prove_batched_main_constraints(dev, group.comms[0], [job(6, (po.SEL_PREFIX, 0, 60, 0, (), 0, po.rand_ext(6, 1)))], [(1, 2), (3, 4)],
-                                                   prover.Transcript.stub(1), q)
-    assert "too small" in str(ei.value)
     with pytest.raises(CenoHipError) as ei:
         prover.dist_prove_batched_main_constraints(dev, group.comms[0], [job(8, (po.SEL_ORDERED_SPARSE, 0, 10, 0, (0, 2), 2, po.rand_ext(8, 2)))],
                                                    [(1, 2), (3, 4)], prover.Transcript.stub(1), q)
@@ -420,6 +416,10 @@ def test_multi_rank_opening_of_witness_and_fixed_commitments(dev, prover, world,
     (8, 3, (11, 9, 7), None),
     (4, 4, (9, 9, 7), "0"),        # every column a table of the sumcheck (no combination)
     (2, 5, (10, 7), "1"),
+    # chips too small to be sharded ride along replicated (whole tables on every rank, their part of a message added once)
+    (4, 3, (10, 8, 5, 2), None),
+    (8, 4, (12, 6, 3), "0"),
+    (2, 6, (9, 7, 6, 1), None),
 ])
 def test_row_sharded_main_constraints_equal_the_single_device_proof(dev, prover, monkeypatch, world, q, nvs, lincomb):
     """prove_batched_main_constraints over ROW-SHARDED tables in the block layout of the sharded chip proof: chips of different sizes, Prefix
@@ -435,7 +435,7 @@ def test_row_sharded_main_constraints_equal_the_single_device_proof(dev, prover,
     for c, nv in enumerate(nvs):
         cols = [po.rand_base(1 << nv, 3100 + 13 * c + j) for j in range(w)]
         point = po.rand_ext(nv, 3200 + c)
-        sels = [(po.SEL_PREFIX, 5 * c, (1 << nv) - 9 - 7 * c, 0, (), 0, point)]
+        sels = [(po.SEL_PREFIX, min(5 * c, (1 << nv) // 4), max(1, (1 << nv) - 9 - 7 * c) if nv >= 5 else max(1, (1 << nv) - 1 - min(5 * c, (1 << nv) // 4)), 0, (), 0, point)]
         terms = [[w, 0, 1], [w, 1, 2, 3], [w, 2, 0], [w, 3], [w, 4], [w, 5], [w, 6], [w, 1], [w]]
         if c == 1:  # a second selector (Whole) over some of the columns
             sels.append((po.SEL_WHOLE, 0, 0, 1, (), 0, point))
@@ -444,10 +444,10 @@ def test_row_sharded_main_constraints_equal_the_single_device_proof(dev, prover,
         cases.append((nv, cols, sels, terms, scalars))
 
     def jobs_for(tables_of):
-        return [dict(num_vars=nv, mles=tables_of(cols) + [None] * len(sels), n_witin=w, n_fixed=0, n_structural=len(sels), selectors=sels, n_exprs=2,
+        return [dict(num_vars=nv, mles=tables_of(cols, nv) + [None] * len(sels), n_witin=w, n_fixed=0, n_structural=len(sels), selectors=sels, n_exprs=2,
                      max_degree=4, terms=terms, scalars=scalars) for (nv, cols, sels, terms, scalars) in cases]
 
-    full = jobs_for(lambda cols: [dev.upload(c_) for c_ in cols])
+    full = jobs_for(lambda cols, nv: [dev.upload(c_) for c_ in cols])
     want = prover.prove_batched_main_constraints(dev, full, gch, prover.Transcript.stub(5))
     group = prover.LocalGroup(world)
     results, errors = [None] * world, []
@@ -455,7 +455,8 @@ def test_row_sharded_main_constraints_equal_the_single_device_proof(dev, prover,
     def rank_main(g):
         try:
             st = dev.stream_create()
-            local = jobs_for(lambda cols: [dev.upload(prover.shard_rows(c_, world, g, q)) for c_ in cols])
+            # (a chip of fewer than 2^(q + k + 1) rows is not sharded: every rank passes its whole tables)
+            local = jobs_for(lambda cols, nv: [dev.upload(prover.shard_rows(c_, world, g, q) if nv - k >= q + 1 else c_) for c_ in cols])
             results[g] = prover.dist_prove_batched_main_constraints(dev, group.comms[g], local, gch, prover.Transcript.stub(5), q, st)
             dev.sync(st)
             dev.stream_destroy(st)
@@ -643,5 +644,116 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
         root, proof, main, opening = results[g]
         assert np.array_equal(root, want[0]), f"rank {g}: commitment root"
         assert proofs_equal(proof, want[1]), f"rank {g}: chip proof"
+        assert main[0] == want[2][0] and all(np.array_equal(a, b) for a, b in zip(main[1:], want[2][1:])), f"rank {g}: main constraints"
+        assert opening.shape == want[3].shape and np.array_equal(opening, want[3]), f"rank {g}: opening"
+
+
+@pytest.mark.parametrize("world,q,transcript", [(2, 3, "stub"), (4, 3, "poseidon2")])
+def test_whole_shard_flow_across_ranks_equals_the_single_device_flow(dev, prover, world, q, transcript):
+    """a SHARD — chips of 2^11, 2^9, 2^6 and 2^2 rows — through every phase across the ranks on one transcript: ONE commitment of the four traces
+    (column shards, mixed heights), its root in, two challenges out, a chip proof per chip (row-sharded where the chip is large enough, the
+    single-device proof on every rank where it is not), ONE batched main-constraint sumcheck over all chips (sharded and replicated chips side by
+    side), ONE opening of the commitment at every chip's prefix of the sumcheck's point.  Every rank ends with what the single-device flow
+    produces, word for word (ZKVMProver::create_proof, ceno_zkvm/src/scheme/prover.rs:324-586)"""
+    import torch
+
+    from ceno_amd import dist as cdist
+
+    shape, w, blow, nq, pow_bits = (2, 2, 0, 4), 6, 1, 8, 3
+    k = world.bit_length() - 1
+    log_rows = [11, 9, 6, 2]
+    n_rec = shape[0] + shape[1] + shape[3]
+    cols = [[po.rand_base(1 << lr, 1500 + 20 * c + j) for j in range(w)] for c, lr in enumerate(log_rows)]
+    col_split = [[w // world + (1 if g < w % world else 0) for g in range(world)] for _ in log_rows]
+    mterms = [[w, j, (j + 1) % w] for j in range(w)] + [[w, 0, 2, 4]] + [[w, j] for j in range(w)]
+    mscal = [[((3 + 5 * t, 11 * t + 1), [2 + (t % 2)])] for t in range(len(mterms))]
+    new_tr = (lambda: prover.Transcript.stub(41)) if transcript == "stub" else (lambda: prover.Transcript.poseidon2(b"shard"))
+    sharded = [lr - k >= q + 1 for lr in log_rows]
+
+    def flow(tables, commit_fn, chip_fn, main_fn, open_fn):
+        tr = new_tr()
+        root, commit_state = commit_fn()
+        for v in np.asarray(root, dtype=np.uint64).reshape(-1):
+            tr.append_base(int(v))
+        alpha, beta = tr.sample_ext(), tr.sample_ext()
+        coeffs, terms, out_terms = record_plan(w, n_rec, alpha, beta)
+        proofs, jobs = [], []
+        for c, lr in enumerate(log_rows):
+            task = dict(mles=tables[c], n_witin=w, n_fixed=0, n_structural=0, num_instances=max(1, (1 << lr) - 1 - c), num_reads=shape[0], num_writes=shape[1],
+                        num_lk_tables=shape[2], num_lk=shape[3], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+            proofs.append(chip_fn(c, task, [alpha, beta], tr))
+            sel = (po.SEL_PREFIX, 0, max(1, (1 << lr) - 1 - c), 0, (), 0, np.ascontiguousarray(proofs[-1].rt_main))
+            jobs.append(dict(num_vars=lr, mles=tables[c] + [None], n_witin=w, n_fixed=0, n_structural=1, selectors=[sel], n_exprs=2, max_degree=4,
+                             terms=mterms, scalars=mscal))
+        main = main_fn(jobs, [alpha, beta], tr)
+        pts, evs, off = [], [], 0
+        for c, lr in enumerate(log_rows):
+            pts.append(np.ascontiguousarray(main[2][:lr]))
+            evs.append(np.ascontiguousarray(main[3][off:off + w]))
+            off += w + 1
+        opening = open_fn(commit_state, pts, evs, tr)
+        return np.asarray(root, dtype=np.uint64).reshape(-1), proofs, main, opening
+
+    stream = dev.stream_create()
+    full = [[dev.upload(c_) for c_ in cc] for cc in cols]
+    mats = [np.ascontiguousarray(np.stack(cc, axis=1)) for cc in cols]
+
+    def commit_single():
+        pcs = prover.PcsData(dev, mats, blow, stream)
+        return pcs.root(), pcs
+
+    want = flow(full, commit_single, lambda c, task, ch, tr: prover.create_chip_proof(dev, dict(task, log2_num_instances=log_rows[c]), ch, tr),
+                lambda jobs, ch, tr: prover.prove_batched_main_constraints(dev, jobs, ch, tr),
+                lambda pcs, pts, evs, tr: pcs.basefold_open(pts, evs, nq, pow_bits, tr))
+    group = prover.LocalGroup(world)
+    results, errors = [None] * world, []
+
+    def rank_main(g):
+        try:
+            st = dev.stream_create()
+            keep, ptrs = [], []
+            for m_, ws in zip(mats, col_split):
+                c0 = sum(ws[:g])
+                t = torch.from_numpy(np.ascontiguousarray(m_[:, c0:c0 + ws[g]].T).view(np.int64).copy()).to("cuda:0")
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+            torch.cuda.synchronize()
+            local = [[dev.upload(prover.shard_rows(c_, world, g, q) if sharded[c] else c_) for c_ in cc] for c, cc in enumerate(cols)]
+
+            def commit_dist():
+                com = cdist.sharded_commit_mmcs_native(dev, group.comms[g], ptrs, col_split, log_rows, blow, g, st)
+                dev.sync(st)
+                return com["root"], com
+
+            def chip(c, task, ch, tr):
+                if sharded[c]:
+                    return prover.dist_create_chip_proof(dev, group.comms[g], dict(task, log2_num_instances=log_rows[c] - k), log_rows[c], q, ch, tr, st)
+                return prover.create_chip_proof(dev, dict(task, log2_num_instances=log_rows[c]), ch, tr, st)  # replicated: the same proof on every rank
+
+            results[g] = flow(local, commit_dist, chip, lambda jobs, ch, tr: prover.dist_prove_batched_main_constraints(dev, group.comms[g], jobs, ch, tr, q, st),
+                              lambda com, pts, evs, tr: prover.dist_basefold_open(dev, group.comms[g], log_rows, col_split, blow, ptrs,
+                                                                                  [x.data_ptr() for x in com["codeword_rows"]], com["subtree"], com["top"], pts,
+                                                                                  evs, nq, pow_bits, tr, st))
+            dev.sync(st)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((g, repr(e), traceback.format_exc(limit=3)))
+
+    ths = [threading.Thread(target=rank_main, args=(g,)) for g in range(world)]
+    for t_ in ths:
+        t_.start()
+    for t_ in ths:
+        t_.join(300)
+    alive = any(t_.is_alive() for t_ in ths)
+    if not alive:
+        group.close()
+    assert not alive, "a virtual rank hangs"
+    assert not errors, errors
+    for g in range(world):
+        root, proofs, main, opening = results[g]
+        assert np.array_equal(root, want[0]), f"rank {g}: commitment root"
+        for c in range(len(log_rows)):
+            assert proofs_equal(proofs[c], want[1][c]), f"rank {g}: chip proof {c}"
         assert main[0] == want[2][0] and all(np.array_equal(a, b) for a, b in zip(main[1:], want[2][1:])), f"rank {g}: main constraints"
         assert opening.shape == want[3].shape and np.array_equal(opening, want[3]), f"rank {g}: opening"
