@@ -484,13 +484,15 @@ def main_rotation_gloo(out_dir, n):
 def main_case(world):
     """chips of a batched main-constraint sumcheck for the CPU second implementation of its row-sharded form: per chip (num_vars, columns, Prefix
     range, terms over the columns 0 .. w - 1 and the selector w, coefficients), and the selector points"""
-    w, nvs = 4, ((8, 6) if world <= 2 else (9, 7))
+    w, nvs = 4, ((8, 6, 3) if world <= 2 else (9, 7, 4))  # (the last chip is too small to be sharded at q = 3: it rides along replicated)
     chips = []
     for c, nv in enumerate(nvs):
         cols = [po.rand_base(1 << nv, 5100 + 11 * c + j) for j in range(w)]
         terms = [[w, 0, 1], [w, 1, 2, 3], [w, 2], [w, 3], [w, 0]]
         coeffs = [(7 + 3 * t + c, 2 + t) for t in range(len(terms))]
-        chips.append(dict(nv=nv, cols=cols, off=3 * c, n=(1 << nv) - 7 - 5 * c, terms=terms, coeffs=coeffs, point=po.rand_ext(nv, 5200 + c)))
+        off = min(3 * c, (1 << nv) // 4)
+        chips.append(dict(nv=nv, cols=cols, off=off, n=max(1, (1 << nv) - 7 - 5 * c) if nv >= 6 else (1 << nv) - 1 - off, terms=terms, coeffs=coeffs,
+                          point=po.rand_ext(nv, 5200 + c)))
     return chips
 
 
@@ -518,7 +520,14 @@ def main_sharded_gloo(out_dir, _n):
         return (hi << q) + ((1 << q) if rank < g else (lo if rank == g else 0))
 
     tabs, nv_of, cf_loc, cf_glob, terms, sel_scale = [], [], [], [], [], []
+    s_tabs, s_cf, s_terms = [], [], []  # the chips that are too small to be sharded: whole tables, the same on every rank
     for ch in chips:
+        if ch["nv"] - k < q + 1:
+            start = len(s_tabs)
+            s_tabs += list(ch["cols"]) + [po.selector_compute(po.SEL_PREFIX, ch["point"], ch["off"], ch["n"])]
+            s_terms += [[start + j for j in t_] for t_ in ch["terms"]]
+            s_cf += list(ch["coeffs"])
+            continue
         pt = [(int(x[0]), int(x[1])) for x in ch["point"]]
         eq_g = one
         for j in range(k):
@@ -539,9 +548,26 @@ def main_sharded_gloo(out_dir, _n):
     _usize(tr, D)
     msgs, rt = [], []
 
-    def first(tabs_, cf_, remaining):
-        m, _, _ = po.sumcheck_prove(tabs_, po.ext(cf_), terms, remaining, D, po.StubTranscript(1))
+    def first(tabs_, cf_, remaining, terms_=None):
+        m, _, _ = po.sumcheck_prove(tabs_, po.ext(cf_), terms if terms_ is None else terms_, remaining, D, po.StubTranscript(1))
         return [(int(m[0][e][0]), int(m[0][e][1])) for e in range(D)]
+
+    s_evals = [None] * len(s_tabs)
+
+    def small_part(i):  # the replicated chips' part of round i (added once) ...
+        return first(s_tabs, s_cf, max_nv - i, s_terms) if s_tabs else [(0, 0)] * D
+
+    def small_fold(ch_):  # ... and their tables after it: a fold, or — out of variables — the front-load rule
+        for j, t_ in enumerate(s_tabs):
+            if t_.shape[0] > 1:
+                t_ = po.mle_fix_variable(t_, ch_)
+                if t_.shape[0] == 1:
+                    s_evals[j] = (int(t_[0][0]), int(t_[0][1]))
+            else:
+                if t_.ndim == 1:
+                    t_ = po.ext([(int(t_[0]), 0)])
+                t_ = po.ext([po.e2_mul((int(t_[0][0]), int(t_[0][1])), ch_)])
+            s_tabs[j] = t_
 
     def publish(m):
         for e in range(D):
@@ -553,16 +579,19 @@ def main_sharded_gloo(out_dir, _n):
         return ch_
 
     for i in range(q):  # every chip still has local variables: plain folds
-        tot = [(0, 0)] * D
+        tot = small_part(i)
         for part in gather(first(tabs, cf_loc, max_nv - k - i)):
             tot = [po.e2_add(tot[e], part[e]) for e in range(D)]
         ch_ = publish(tot)
         tabs = [po.mle_fix_variable(t_, ch_) for t_ in tabs]
+        small_fold(ch_)
     tabs = [po.ext([po.e2_mul((int(v[0]), int(v[1])), sc) for v in t_]) if sc != one else t_ for t_, sc in zip(tabs, sel_scale)]
     tabs = [_interleave(gather(np.ascontiguousarray(t_)), 0, k) for t_ in tabs]
     evals = [None] * len(tabs)
     for i in range(q, max_nv):
-        ch_ = publish(first(tabs, cf_glob, max_nv - i))
+        sm = small_part(i)
+        ch_ = publish([po.e2_add(a_, b_) for a_, b_ in zip(first(tabs, cf_glob, max_nv - i), sm)])
+        small_fold(ch_)
         nxt = []
         for j, t_ in enumerate(tabs):
             if t_.shape[0] > 1:
@@ -574,7 +603,7 @@ def main_sharded_gloo(out_dir, _n):
             nxt.append(t_)
         tabs = nxt
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=po.ext([m[e] for m in msgs for e in range(D)]).reshape(max_nv, D, 2), rt=po.ext(rt),
-             evals=po.ext(evals))
+             evals=po.ext(evals + s_evals))  # (the sharded chips come first in main_case)
     dist.barrier()
     dist.destroy_process_group()
 

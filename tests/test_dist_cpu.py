@@ -164,7 +164,8 @@ def test_row_sharded_rotation_argument_matches_unsharded(world, n, q, log2):
 def test_row_sharded_main_constraint_sumcheck_matches_unsharded(world, q):
     """the batched main-constraint sumcheck over ROW-SHARDED tables a second time, independent of ceno_amd/host/main_constraints.cpp
     prover_main_constraints_sharded: gloo ranks with block-cyclic row shards of two chips of different sizes (Prefix selectors that start and end
-    anywhere) run q local rounds with exchanged partial sums, gather every table and finish replicated — and must end, on every rank, with the
+    anywhere) and the whole tables of a third that is too small to shard (its part of a message added once) run q local rounds with exchanged
+    partial sums, gather every sharded table and finish replicated — and must end, on every rank, with the
     messages, point and evaluations of the oracle's sumcheck prover on the whole tables (the sumcheck of prove_batched_main_constraints,
     ceno_zkvm/src/scheme/cpu/mod.rs:1255-1337)"""
     from tests.dist_worker import main_case
