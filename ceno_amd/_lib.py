@@ -75,6 +75,7 @@ def lib():
         "ceno_hip_mem_book": (i, [vp, sz]),
         "ceno_hip_mem_unbook": (i, [vp, sz]),
         "ceno_hip_mem_booked": (sz, [vp]),
+        "ceno_hip_mem_booked_peak": (sz, [vp, i]),
         "ceno_hip_mle_alloc": (i, [vp, i, i, vpp]),
         "ceno_hip_mle_upload": (i, [vp, u64p, i, i, vp, vpp]),
         "ceno_hip_mle_wrap": (i, [vp, vp, i, i, vpp]),
@@ -86,6 +87,7 @@ def lib():
         "ceno_hip_mle_is_ext": (i, [vp]),
         "ceno_hip_mle_device_ptr": (vp, [vp]),
         "ceno_hip_mle_fill_splitmix": (i, [vp, vp, C.c_uint64, C.c_uint64, vp]),
+        "ceno_hip_mle_fill_zero": (i, [vp, vp, vp]),
         "ceno_hip_mle_evaluate": (i, [vp, vp, u64p, u64p, vp]),
         "ceno_hip_mle_fix_variables": (i, [vp, vp, u64p, i, vp, vpp]),
         "ceno_hip_eq_build": (i, [vp, u64p, i, u64p, vp, vpp]),
@@ -150,6 +152,9 @@ def lib():
         "ceno_hip_witgen_lui": (i, [vp, vp, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp]),
         "ceno_hip_witgen_logic_i": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp, vp]),
         "ceno_hip_witgen_logic_r": (i, [vp, vp, i, vp, sz, vp, sz, C.c_uint64, C.c_uint32, C.c_uint32, vp, sz, vp, vp, vp, vp]),
+        "ceno_hip_witgen_session_begin": (i, [vp, vpp, C.POINTER(sz), i, vp]),
+        "ceno_hip_witgen_session_end": (i, [vp, vp]),
+        "ceno_hip_lk_to_mlt_column": (i, [vp, vp, sz, vp, sz, vp]),
         "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),
         "ceno_hip_poseidon2_is_pinned": (i, [vp]),
         "ceno_hip_poseidon2_permute": (i, [vp, vp, sz, vp]),

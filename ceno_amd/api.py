@@ -139,6 +139,28 @@ class Device:
         self.check(self.L.ceno_hip_mle_fill_splitmix(self.h, m.h, C.c_uint64(seed), C.c_uint64(word_offset), stream))
         return m
 
+    def zeros(self, num_vars: int, is_ext: bool = False, stream=None) -> "Mle":
+        """a table of zeros (ceno_hip_mle_fill_zero); its words double as raw device storage for lookup counters (two u32 counters per word)"""
+        self.check(self.L.ceno_hip_stream_bind(self.h, stream))
+        m = self.alloc(num_vars, is_ext)
+        self.check(self.L.ceno_hip_mle_fill_zero(self.h, m.h, stream))
+        return m
+
+    # ---- a shard's witness generation as one session (ceno_hip_witgen_session_begin / _end) ----
+    def witgen_session_begin(self, tables: Sequence[Tuple[int, int]], stream=None):
+        """tables: [(device pointer of the u32 counters, slots)] — every lookup table the shard's chips count into"""
+        n = len(tables)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p_)) for p_, _ in tables])
+        slots = (C.c_size_t * n)(*[int(s_) for _, s_ in tables])
+        self.check(self.L.ceno_hip_witgen_session_begin(self.h, ptrs, slots, n, stream))
+
+    def witgen_session_end(self, stream=None):
+        self.check(self.L.ceno_hip_witgen_session_end(self.h, stream))
+
+    def lk_to_mlt_column(self, counters_ptr: int, n: int, column_ptr: int, rows_padded: int, stream=None):
+        """a table circuit's `mlt` witness column from the device counters (ceno_hip_lk_to_mlt_column)"""
+        self.check(self.L.ceno_hip_lk_to_mlt_column(self.h, C.c_void_p(int(counters_ptr)), n, C.c_void_p(int(column_ptr)), rows_padded, stream))
+
     def eq_build(self, point: np.ndarray, scalar=None, stream=None) -> "Mle":
         point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 2)
         h = C.c_void_p()
@@ -253,6 +275,9 @@ class Mle:
         m = Mle(self.dev, h)
         m._parent = self  # keep the parent alive (gkr_iop/src/gpu/mod.rs:244-253)
         return m
+
+    def fill_zero(self, stream=None):
+        self.dev.check(self.dev.L.ceno_hip_mle_fill_zero(self.dev.h, self.h, stream))
 
     def free(self):
         if self.h and not self.borrowed and self.dev.h:

@@ -47,6 +47,7 @@ struct ceno_hip_ctx {
     size_t pool_peak = 0;   // high-water mark of pool_used since the last ceno_hip_mem_peak(reset)
     size_t pool_cached = 0; // bytes parked in free lists
     size_t pool_booked = 0; // bytes promised to scheduled-but-not-yet-running tasks (ceno_hip_mem_book)
+    size_t pool_booked_peak = 0; // high-water mark of pool_booked (ceno_hip_mem_booked_peak)
     size_t pool_capacity = 0;  // booking capacity: pool_limit, or the device memory size when unlimited
     // a cached block remembers the stream its last user was working on (the freeing thread's current stream): it is handed to
     // a DIFFERENT stream only once that stream has drained (ctx_alloc), so a block freed with kernels still queued is never

@@ -743,6 +743,7 @@ int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes) {
         return CENO_HIP_ERR_OOM;
     }
     ctx->pool_booked += bytes;
+    if (ctx->pool_booked > ctx->pool_booked_peak) ctx->pool_booked_peak = ctx->pool_booked;
     return 0;
 }
 int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes) {
@@ -753,6 +754,13 @@ int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes) {
 size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx) {
     std::lock_guard<PoolMutex> g(ctx->mu);
     return ctx->pool_booked;
+}
+size_t ceno_hip_mem_booked_peak(ceno_hip_ctx* ctx, int reset) {
+    if (!ctx) return 0;
+    std::lock_guard<PoolMutex> g(ctx->mu);
+    const size_t v = ctx->pool_booked_peak;
+    if (reset) ctx->pool_booked_peak = ctx->pool_booked;
+    return v;
 }
 
 int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight) {

@@ -417,6 +417,12 @@ int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed
     return 0;
 }
 
+int ceno_hip_mle_fill_zero(ceno_hip_ctx* ctx, ceno_hip_mle* m, ceno_hip_stream s) {
+    CHECK_ARG(ctx, m, "NULL mle");
+    HIP_TRY(ctx, hipMemsetAsync(m->d, 0, m->len() * (m->is_ext ? 16 : 8), ctx_stream(ctx, s)));
+    return 0;
+}
+
 int ceno_hip_eq_build(ceno_hip_ctx* ctx, const uint64_t* point, int num_vars, const uint64_t* scalar2, ceno_hip_stream s, ceno_hip_mle** out) {
     CHECK_ARG(ctx, out && (point || num_vars == 0), "NULL argument");
     (void)ctx_stream(ctx, s);  // allocations below belong to work on `s`: bind the thread first (pool tags, include/ceno_hip.h "Memory")

@@ -6,6 +6,10 @@
 // column-major matrix through the caller's column map, and count the lookups of the row.
 // HBM-bound integer work: 136 B read + 8 * num_cols B written per row; consecutive lanes write consecutive rows of a
 // column (coalesced), the 136-byte records are fetched with 8-byte loads that the L2 merges.
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -83,6 +87,13 @@ __global__ void __launch_bounds__(NT) k_lk_merge(const uint32_t* __restrict__ co
 #pragma unroll
     for (int x = 0; x < 8; x++) s += copies[(size_t)x * slots + i];
     if (s) atomicAdd(dst + i, s);
+}
+
+// the `mlt` witness column of a table circuit from its counters: column[i] = counters[i] as a field element (a count is < 2^32 < p), zero
+// beyond the table (InstancePaddingStrategy::Default); ceno_zkvm/src/tables/ops/ops_impl.rs:85-100, tables/range/range_impl.rs:60-96
+__global__ void __launch_bounds__(NT) k_lk_to_mlt(const uint32_t* __restrict__ counters, size_t n, uint64_t* __restrict__ column, size_t rows) {
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < rows; i += stride) column[i] = i < n ? (uint64_t)counters[i] : 0ull;
 }
 
 // XCD_LOCAL: lk_dyn / lk_fetch point at 8 consecutive copies of the tables, one per XCD (HW_REG_XCC_ID picks this wave's)
@@ -261,11 +272,49 @@ struct LkTab {
                       // DYNAMIC_RANGE_MAX_BITS = 18 bits), every chip but the multiplications stays below 2^17
 };
 constexpr size_t DYN_USED_16 = (size_t)1 << 17;
+// ---- a SHARD's witness generation as one session (ceno_hip_witgen_session_begin / _end, include/ceno_hip.h) ----
+// A shard runs ~45 chips against the same handful of lookup tables.  Chip by chip, every call clears, merges and waits for its own eight
+// per-XCD copies (16 MB of memset, four merge launches and a stream synchronisation per chip).  Inside a session the copies of the
+// registered tables live as long as the session: cleared once, counted into by every chip's kernel back to back on the stream (no wait,
+// no merge), merged once at the end.  The per-chip entry points are unchanged: witgen_run recognises a registered table by its pointer.
+struct WitgenSession {
+    struct Tab {
+        uint32_t* user;
+        size_t slots;
+        uint32_t* copies;  // 8 x slots
+    };
+    std::vector<Tab> tabs;
+    void* scratch = nullptr;
+    hipStream_t stream = nullptr;
+};
+std::mutex g_sessions_mu;
+std::map<ceno_hip_ctx*, WitgenSession> g_sessions;
+
 template <class Launch>
 int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[4], Launch&& launch) {
     static const bool xcd_wanted = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
     const bool xcd_local = xcd_wanted && ctx->xcd_private_l2;  // (gfx942 / gfx950 only: ctx.hip)
     const bool any = tabs[0].user || tabs[1].user || tabs[2].user || tabs[3].user;
+    if (xcd_local && any && n > 0) {
+        std::lock_guard<std::mutex> g(g_sessions_mu);
+        auto it = g_sessions.find(ctx);
+        if (it != g_sessions.end()) {
+            const WitgenSession& S = it->second;
+            uint32_t* copy[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int t = 0; t < 4; t++) {
+                if (!tabs[t].user) continue;
+                for (const auto& T : S.tabs)
+                    if (T.user == tabs[t].user) copy[t] = T.copies;
+                CHECK_ARG(ctx, copy[t] != nullptr, "witgen: a lookup table that is not registered with the open witgen session");
+                for (const auto& T : S.tabs)
+                    if (T.user == tabs[t].user) CHECK_ARG(ctx, T.slots == tabs[t].slots, "witgen: a session table registered with another slot count");
+            }
+            CHECK_ARG(ctx, st == S.stream, "witgen: inside a session every chip runs on the session's stream");
+            launch(true, copy[0], copy[1], copy[2], copy[3]);
+            HIP_TRY(ctx, hipGetLastError());
+            return 0;
+        }
+    }
     if (!(xcd_local && any && n > 0)) {
         launch(false, tabs[0].user, tabs[1].user, tabs[2].user, tabs[3].user);
         HIP_TRY(ctx, hipGetLastError());
@@ -1800,6 +1849,72 @@ int ceno_hip_witgen_logic_r(ceno_hip_ctx* ctx, const ceno_hip_logic_r_column_map
     CHECK_ARG(ctx, logic_kind >= 0 && logic_kind <= 2, "witgen_logic_r: kind %d is not AND (0) / OR (1) / XOR (2)", logic_kind);
     return witgen_logic(ctx, reinterpret_cast<const LogicMap*>(map), dev_step_records, num_records, dev_step_indices, n, shard_offset_cycle,
                         fetch_base_pc, fetch_num_slots, dev_witness_col_major, rows_padded, dev_lk_dynamic, dev_lk_fetch, dev_lk_logic, s);
+}
+
+
+int ceno_hip_witgen_session_begin(ceno_hip_ctx* ctx, uint32_t* const* dev_tables, const size_t* slots, int n_tables, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, dev_tables && slots && n_tables >= 1 && n_tables <= 16, "witgen_session_begin: 1 .. 16 tables");
+    size_t total = 0;
+    for (int t = 0; t < n_tables; t++) {
+        CHECK_ARG(ctx, dev_tables[t] && slots[t] > 0, "witgen_session_begin: NULL table / no slots");
+        for (int u = 0; u < t; u++) CHECK_ARG(ctx, dev_tables[u] != dev_tables[t], "witgen_session_begin: a table registered twice");
+        total += slots[t];
+    }
+    static const bool xcd_wanted = [] { const char* e = getenv("CENO_HIP_WITGEN_XCD"); return !(e && atoi(e) == 0); }();
+    if (!(xcd_wanted && ctx->xcd_private_l2)) return 0;  // the chips count into the caller's tables directly: nothing to hold
+    std::lock_guard<std::mutex> g(g_sessions_mu);
+    CHECK_ARG(ctx, g_sessions.find(ctx) == g_sessions.end(), "witgen_session_begin: this context has an open session");
+    hipStream_t st = ctx_stream(ctx, s);
+    WitgenSession S;
+    S.stream = st;
+    TRY(ctx_alloc(ctx, 8 * total * sizeof(uint32_t), &S.scratch));
+    const hipError_t e = hipMemsetAsync(S.scratch, 0, 8 * total * sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        ctx_free(ctx, S.scratch);
+        HIP_TRY(ctx, e);
+    }
+    uint32_t* p = (uint32_t*)S.scratch;
+    for (int t = 0; t < n_tables; t++) {
+        S.tabs.push_back({dev_tables[t], slots[t], p});
+        p += 8 * slots[t];
+    }
+    g_sessions[ctx] = std::move(S);
+    return 0;
+}
+
+int ceno_hip_witgen_session_end(ceno_hip_ctx* ctx, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    WitgenSession S;
+    {
+        std::lock_guard<std::mutex> g(g_sessions_mu);
+        auto it = g_sessions.find(ctx);
+        if (it == g_sessions.end()) return 0;  // (no per-XCD copies on this device: begin held nothing)
+        S = std::move(it->second);
+        g_sessions.erase(it);
+    }
+    hipStream_t st = ctx_stream(ctx, s);
+    hipError_t e = st == S.stream ? hipSuccess : hipErrorInvalidValue;
+    if (e == hipSuccess) {
+        for (const auto& T : S.tabs)
+            hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((T.slots + NT - 1) / NT)), dim3(NT), 0, st, T.copies, T.slots, T.slots, T.user);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipStreamSynchronize(S.stream);  // the copies go back to the pool only after the stream has consumed them
+    ctx_free(ctx, S.scratch);
+    HIP_TRY(ctx, e);
+    HIP_TRY(ctx, e2);
+    return 0;
+}
+
+int ceno_hip_lk_to_mlt_column(ceno_hip_ctx* ctx, const uint32_t* dev_counters, size_t n, uint64_t* dev_column, size_t rows_padded, ceno_hip_stream s) {
+    CHECK_ARG(ctx, ctx, "NULL context");
+    CHECK_ARG(ctx, dev_counters && dev_column && n <= rows_padded && rows_padded > 0, "lk_to_mlt_column: bad arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    hipLaunchKernelGGL(k_lk_to_mlt, dim3(grid_for(rows_padded, NT, MAXB)), dim3(NT), 0, st, dev_counters, n, dev_column, rows_padded);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/ceno_prover.h"
@@ -12,6 +13,9 @@
 int prover_set_error(int code, const char* msg);  // prover.cpp
 
 #include "pcs_data.hpp"
+
+// (a negative count that crossed the ABI as size_t must not reach the padding loop)
+static constexpr size_t MAX_ROWS = (size_t)1 << 40, MAX_WIDTH = (size_t)1 << 20;
 
 static int ceil_log2_sz(size_t x) {
     int l = 0;
@@ -43,32 +47,11 @@ int ceno_prover_commit_traces_dev(ceno_hip_ctx* ctx, const uint64_t* const* dev_
     return commit_impl(ctx, dev_row_major, num_instances, widths, n_matrices, log_blowup, s, out, true);
 }
 
-static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
-                       int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out, bool on_device) {
-    if (!ctx || !host_row_major || !num_instances || !widths || !out || n_matrices < 1 || log_blowup < 0)
-        return prover_set_error(CENO_HIP_ERR_INVALID, "bad commit_traces arguments");
-    if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces needs an explicit stream (ceno_hip_stream_create)");
-    for (int i = 0; i < n_matrices; i++)
-        if (!host_row_major[i] || widths[i] < 1 || num_instances[i] < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces: empty matrix");
-    auto* d = new ceno_pcs_data();
+// the height classes of a commitment and their storage (trace + codeword per class): what commit_traces computes before it touches a
+// matrix, and ALL that ceno_prover_commit_reserve does
+static int commit_layout(ceno_hip_ctx* ctx, const size_t* num_instances, const size_t* widths, int n_matrices, int log_blowup, ceno_pcs_data* d) {
     d->log_blowup = log_blowup;
     d->mats.resize(n_matrices);
-    // Everything is queued on the caller's stream, in order behind whatever produced a device-resident input, and nothing
-    // waits until the end: per matrix pad / copy + transpose into its height class, per CLASS one Reed-Solomon encoding of all
-    // its columns, then ONE launch that hashes the rows of every class and one tree (ceno_hip_mmcs_commit).
-    (void)ceno_hip_stream_bind(ctx, s);
-    std::vector<ceno_hip_mle*> stagings;
-    auto drain = [&]() {
-        int rc = ceno_hip_stream_sync(ctx, s);
-        for (auto* m : stagings) ceno_hip_mle_free(ctx, m);
-        stagings.clear();
-        return rc;
-    };
-    auto bail = [&](int rc, const char* msg) {
-        (void)drain();
-        ceno_pcs_data_free(ctx, d);
-        return prover_set_error(rc, msg);
-    };
     // height classes, tallest first; inside a class the matrices keep the caller's order (what the tree's stable sort does)
     std::map<int, size_t, std::greater<int>> class_width;
     for (int i = 0; i < n_matrices; i++) {
@@ -92,12 +75,59 @@ static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major,
         if (!rc) rc = ceno_hip_mle_alloc(ctx, ceil_log2_sz(words << log_blowup), 0, &c.codeword);
         class_of[kv.first] = (int)d->classes.size();
         d->classes.push_back(c);
-        if (rc) return bail(rc, ceno_hip_last_error(ctx));
+        if (rc) return rc;
     }
+    for (int i = 0; i < n_matrices; i++) d->mats[i].cls = class_of[d->mats[i].log_rows];
+    return 0;
+}
+
+// per CLASS one Reed-Solomon encoding of all its columns, then ONE launch that hashes the rows of every class and one tree
+static int commit_encode_and_hash(ceno_hip_ctx* ctx, ceno_pcs_data* d, ceno_hip_stream s) {
+    const int n_matrices = (int)d->mats.size();
+    for (auto& c : d->classes) {
+        int rc = ceno_hip_rs_encode(ctx, ceno_hip_mle_device_ptr(c.trace), c.log_rows, (int)c.width, d->log_blowup, ceno_hip_mle_device_ptr(c.codeword), s);
+        if (rc) return rc;
+    }
+    std::vector<const uint64_t*> ptrs(n_matrices);
+    std::vector<int> lr(n_matrices), w(n_matrices);
+    for (int i = 0; i < n_matrices; i++) {
+        ptrs[i] = d->codeword_ptr(i);
+        lr[i] = d->mats[i].log_rows + d->log_blowup;
+        w[i] = (int)d->mats[i].width;
+    }
+    return ceno_hip_mmcs_commit(ctx, ptrs.data(), lr.data(), w.data(), n_matrices, s, &d->tree);
+}
+
+static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major, const size_t* num_instances, const size_t* widths,
+                       int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out, bool on_device) {
+    if (!ctx || !host_row_major || !num_instances || !widths || !out || n_matrices < 1 || log_blowup < 0)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "bad commit_traces arguments");
+    if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces needs an explicit stream (ceno_hip_stream_create)");
+    for (int i = 0; i < n_matrices; i++)
+        if (!host_row_major[i] || widths[i] < 1 || num_instances[i] < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces: empty matrix");
+    for (int i = 0; i < n_matrices; i++)
+        if (num_instances[i] > MAX_ROWS || widths[i] > MAX_WIDTH) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_traces: matrix larger than 2^40 rows / 2^20 columns");
+    auto* d = new ceno_pcs_data();
+    // Everything is queued on the caller's stream, in order behind whatever produced a device-resident input, and nothing
+    // waits until the end: per matrix pad / copy + transpose into its height class, per CLASS one Reed-Solomon encoding of all
+    // its columns, then ONE launch that hashes the rows of every class and one tree (ceno_hip_mmcs_commit).
+    (void)ceno_hip_stream_bind(ctx, s);
+    std::vector<ceno_hip_mle*> stagings;
+    auto drain = [&]() {
+        int rc = ceno_hip_stream_sync(ctx, s);
+        for (auto* m : stagings) ceno_hip_mle_free(ctx, m);
+        stagings.clear();
+        return rc;
+    };
+    auto bail = [&](int rc, const char* msg) {
+        (void)drain();
+        ceno_pcs_data_free(ctx, d);
+        return prover_set_error(rc, msg);
+    };
+    if (int rc = commit_layout(ctx, num_instances, widths, n_matrices, log_blowup, d)) return bail(rc, ceno_hip_last_error(ctx));
     hipStream_t st = (hipStream_t)s;
     for (int i = 0; i < n_matrices; i++) {
         auto& M = d->mats[i];
-        M.cls = class_of[M.log_rows];
         const size_t words = M.rows * M.width;
         // a device-resident matrix that already has all `rows` rows is transposed straight out of the caller's buffer
         const bool direct = on_device && num_instances[i] == M.rows;
@@ -119,27 +149,53 @@ static int commit_impl(ceno_hip_ctx* ctx, const uint64_t* const* host_row_major,
         int rc = ceno_hip_transpose(ctx, d_stage, M.rows, M.width, const_cast<uint64_t*>(d->trace_ptr(i)), s);
         if (rc) return bail(rc, ceno_hip_last_error(ctx));
     }
-    for (auto& c : d->classes) {
-        int rc = ceno_hip_rs_encode(ctx, ceno_hip_mle_device_ptr(c.trace), c.log_rows, (int)c.width, log_blowup, ceno_hip_mle_device_ptr(c.codeword), s);
-        if (rc) return bail(rc, ceno_hip_last_error(ctx));
-    }
-    {
-        std::vector<const uint64_t*> ptrs(n_matrices);
-        std::vector<int> lr(n_matrices), w(n_matrices);
-        for (int i = 0; i < n_matrices; i++) {
-            ptrs[i] = d->codeword_ptr(i);
-            lr[i] = d->mats[i].log_rows + log_blowup;
-            w[i] = (int)d->mats[i].width;
-        }
-        int rc = ceno_hip_mmcs_commit(ctx, ptrs.data(), lr.data(), w.data(), n_matrices, s, &d->tree);
-        if (rc) return bail(rc, ceno_hip_last_error(ctx));
-    }
+    if (int rc = commit_encode_and_hash(ctx, d, s)) return bail(rc, ceno_hip_last_error(ctx));
     if (int rc = drain()) {
         ceno_pcs_data_free(ctx, d);
         return prover_set_error(rc, ceno_hip_last_error(ctx));
     }
     *out = d;
     return 0;
+}
+
+// ---- commit_traces for traces that are PRODUCED on the device, in two steps (include/ceno_prover.h) ----
+int ceno_prover_commit_reserve(ceno_hip_ctx* ctx, const size_t* num_instances, const size_t* widths, int n_matrices, int log_blowup,
+                               ceno_hip_stream s, ceno_pcs_data** out) {
+    if (!ctx || !num_instances || !widths || !out || n_matrices < 1 || log_blowup < 0)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "bad commit_reserve arguments");
+    if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_reserve needs an explicit stream (ceno_hip_stream_create)");
+    for (int i = 0; i < n_matrices; i++)
+        if (widths[i] < 1 || num_instances[i] < 1 || num_instances[i] > MAX_ROWS || widths[i] > MAX_WIDTH)
+            return prover_set_error(CENO_HIP_ERR_INVALID, "commit_reserve: empty matrix, or larger than 2^40 rows / 2^20 columns");
+    auto* d = new ceno_pcs_data();
+    (void)ceno_hip_stream_bind(ctx, s);
+    if (int rc = commit_layout(ctx, num_instances, widths, n_matrices, log_blowup, d)) {
+        std::string msg = ceno_hip_last_error(ctx);
+        ceno_pcs_data_free(ctx, d);
+        return prover_set_error(rc, msg.c_str());
+    }
+    *out = d;
+    return 0;
+}
+
+uint64_t* ceno_pcs_data_trace_ptr(ceno_pcs_data* d, int matrix) {
+    if (!d || matrix < 0 || matrix >= (int)d->mats.size()) return nullptr;
+    return const_cast<uint64_t*>(d->trace_ptr(matrix));
+}
+
+size_t ceno_pcs_data_rows(const ceno_pcs_data* d, int matrix) {
+    if (!d || matrix < 0 || matrix >= (int)d->mats.size()) return 0;
+    return d->mats[matrix].rows;
+}
+
+int ceno_prover_commit_finish(ceno_hip_ctx* ctx, ceno_pcs_data* d, ceno_hip_stream s) {
+    if (!ctx || !d || d->mats.empty()) return prover_set_error(CENO_HIP_ERR_INVALID, "bad commit_finish arguments");
+    if (!s) return prover_set_error(CENO_HIP_ERR_INVALID, "commit_finish needs an explicit stream (ceno_hip_stream_create)");
+    if (d->tree) return prover_set_error(CENO_HIP_ERR_STATE, "commit_finish: this commitment is already finished");
+    (void)ceno_hip_stream_bind(ctx, s);
+    int rc = commit_encode_and_hash(ctx, d, s);
+    if (!rc) rc = ceno_hip_stream_sync(ctx, s);
+    return rc ? prover_set_error(rc, ceno_hip_last_error(ctx)) : 0;
 }
 
 int ceno_pcs_data_num_matrices(const ceno_pcs_data* d) { return d ? (int)d->mats.size() : -1; }

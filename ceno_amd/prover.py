@@ -1094,6 +1094,30 @@ class PcsData:
         row-major matrices (ceno_prover_commit_traces_dev)"""
         L = plib()
         vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        self._declare(L)
+        self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
+        if device_ptrs is not None:
+            n = len(device_ptrs)
+            self.shapes = [(int(r), int(w)) for _, r, w in device_ptrs]
+            ptrs = (u64p * n)(*[C.cast(C.c_void_p(int(p_)), u64p) for p_, _, _ in device_ptrs])
+            rows = (sz * n)(*[r for _, r, _ in device_ptrs])
+            widths = (sz * n)(*[w for _, _, w in device_ptrs])
+            h = vp()
+            _check(L.ceno_prover_commit_traces_dev(dev.h, ptrs, rows, widths, n, log_blowup, stream, C.byref(h)))
+            self.h = h
+            return
+        mats = [np.ascontiguousarray(m, dtype=np.uint64) for m in matrices]
+        self.shapes = [m.shape for m in mats]
+        ptrs = (u64p * len(mats))(*[_p(m) for m in mats])
+        rows = (sz * len(mats))(*[m.shape[0] for m in mats])
+        widths = (sz * len(mats))(*[m.shape[1] for m in mats])
+        h = vp()
+        _check(L.ceno_prover_commit_traces(dev.h, ptrs, rows, widths, len(mats), log_blowup, stream, C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def _declare(L):
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
         L.ceno_prover_commit_traces.restype = i
         L.ceno_prover_commit_traces.argtypes = [vp, C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
         L.ceno_pcs_data_num_vars.restype = i
@@ -1114,25 +1138,42 @@ class PcsData:
         L.ceno_prover_basefold_open.argtypes = [vp, C.POINTER(vp), i, C.POINTER(u64p), C.POINTER(u64p), i, i, vp, vp, u64p]
         L.ceno_prover_commit_traces_dev.restype = i
         L.ceno_prover_commit_traces_dev.argtypes = [vp, C.POINTER(u64p), C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
+
+    @classmethod
+    def reserve(cls, dev: Device, shapes: Sequence[Tuple[int, int]], log_blowup: int, stream) -> "PcsData":
+        """ceno_prover_commit_reserve: the commitment's storage for matrices of (num_instances, width) that are PRODUCED on the device;
+        write matrix m COLUMN-major at trace_ptr(m) (rows(m) words per column), then finish()"""
+        L = plib()
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.ceno_prover_commit_reserve.restype = i
+        L.ceno_prover_commit_reserve.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), i, i, vp, C.POINTER(vp)]
+        L.ceno_prover_commit_finish.restype = i
+        L.ceno_prover_commit_finish.argtypes = [vp, vp, vp]
+        L.ceno_pcs_data_trace_ptr.restype = vp
+        L.ceno_pcs_data_trace_ptr.argtypes = [vp, i]
+        L.ceno_pcs_data_rows.restype = sz
+        L.ceno_pcs_data_rows.argtypes = [vp, i]
+        self = cls.__new__(cls)
+        cls._declare(L)
         self.dev, self.stream, self.log_blowup = dev, stream, log_blowup
-        if device_ptrs is not None:
-            n = len(device_ptrs)
-            self.shapes = [(int(r), int(w)) for _, r, w in device_ptrs]
-            ptrs = (u64p * n)(*[C.cast(C.c_void_p(int(p_)), u64p) for p_, _, _ in device_ptrs])
-            rows = (sz * n)(*[r for _, r, _ in device_ptrs])
-            widths = (sz * n)(*[w for _, _, w in device_ptrs])
-            h = vp()
-            _check(L.ceno_prover_commit_traces_dev(dev.h, ptrs, rows, widths, n, log_blowup, stream, C.byref(h)))
-            self.h = h
-            return
-        mats = [np.ascontiguousarray(m, dtype=np.uint64) for m in matrices]
-        self.shapes = [m.shape for m in mats]
-        ptrs = (u64p * len(mats))(*[_p(m) for m in mats])
-        rows = (sz * len(mats))(*[m.shape[0] for m in mats])
-        widths = (sz * len(mats))(*[m.shape[1] for m in mats])
+        n = len(shapes)
+        rows = (sz * n)(*[int(r) for r, _ in shapes])
+        widths = (sz * n)(*[int(w) for _, w in shapes])
         h = vp()
-        _check(L.ceno_prover_commit_traces(dev.h, ptrs, rows, widths, len(mats), log_blowup, stream, C.byref(h)))
+        _check(L.ceno_prover_commit_reserve(dev.h, rows, widths, n, log_blowup, stream, C.byref(h)))
         self.h = h
+        self.shapes = [(int(L.ceno_pcs_data_rows(h, m)), int(w)) for m, (_, w) in enumerate(shapes)]
+        return self
+
+    def trace_ptr(self, matrix: int) -> int:
+        return int(plib().ceno_pcs_data_trace_ptr(self.h, matrix) or 0)
+
+    def rows(self, matrix: int) -> int:
+        return int(plib().ceno_pcs_data_rows(self.h, matrix))
+
+    def finish(self):
+        """ceno_prover_commit_finish: encode + hash what the producers wrote (queued on the commitment's stream behind them)"""
+        _check(plib().ceno_prover_commit_finish(self.dev.h, self.h, self.stream))
 
     def num_vars(self, matrix: int) -> int:
         return plib().ceno_pcs_data_num_vars(self.h, matrix)

@@ -332,3 +332,409 @@ class ShardFlow:
         for t in self.traces:
             t.free()
         self.dev.stream_destroy(self.stream)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# metric M2 on a shard with the REFERENCE's population (round-5 verdict, item 1): the 45 RV32IM opcode circuits that have on-device
+# witness generation (every opcode circuit but ECALL, ceno_zkvm/src/instructions/riscv/rv32im.rs:124-204), their row counts following an
+# instruction mix (a few hot opcodes, a long tail: ~2^18 .. ~2^10 instances, NOT powers of two), the table circuits of rv32im.rs:223-230,
+# 580-587 — dynamic range (2^19 rows, two structural columns: tables/range/range_impl.rs:15-52), double-u8 (2^16), AND / OR / XOR / LTU
+# (2^16 rows, three FIXED columns a, b, c: tables/ops/ops_impl.rs:17-50), the program table (fixed pc + instruction fields,
+# tables/program.rs) — each with ONE witness column `mlt` and one LogUp table record, and two wide circuits standing for the ECALL /
+# precompile class whose witness comes from the host side.  Record and constraint EXPRESSIONS are synthetic of the right shape (the real
+# ComposedConstrainSystem needs the Rust front end): r / w / lk record counts per opcode class, main constraints from `wide_plan`.
+# ------------------------------------------------------------------------------------------------------------------
+NO_COLUMN = 0xFFFFFFFF
+# (name, call kind, mapped columns, call arguments, (reads, writes, lookups), weight in the instruction mix)
+OPCODE_KINDS = [
+    ("ADDI", "addi", 18, (), (3, 3, 7), 170), ("LW", "mem", 23, (0,), (4, 4, 9), 140), ("ADD", "arith", 22, (False,), (4, 4, 9), 90),
+    ("SW", "mem", 23, (1,), (4, 4, 9), 80), ("BNE", "branch", 19, (True, False), (3, 3, 7), 60), ("BEQ", "branch", 19, (True, True), (3, 3, 7), 50),
+    ("SLLI", "shift", 40, (True, 0), (3, 3, 16), 40), ("JAL", "jal", 13, (), (2, 2, 5), 30), ("LUI", "lui", 16, (), (2, 2, 6), 30),
+    ("ANDI", "logic_i", 24, (0,), (3, 3, 9), 30), ("LBU", "load_sub", 28, (8, False), (4, 4, 12), 25), ("JALR", "jalr", 22, (), (3, 3, 9), 20),
+    ("AND", "logic_r", 28, (0,), (4, 4, 11), 20), ("OR", "logic_r", 28, (1,), (4, 4, 11), 20), ("SUB", "arith", 22, (True,), (4, 4, 11), 20),
+    ("BLT", "branch", 22, (False, True), (3, 3, 9), 20), ("SRLI", "shift", 40, (True, 1), (3, 3, 16), 20), ("XOR", "logic_r", 28, (2,), (4, 4, 11), 15),
+    ("SLTU", "slt", 26, (False,), (4, 4, 11), 15), ("BGE", "branch", 22, (False, True), (3, 3, 9), 15), ("BLTU", "branch", 22, (False, False), (3, 3, 9), 15),
+    ("BGEU", "branch", 22, (False, False), (3, 3, 9), 15), ("SB", "mem", 29, (3,), (4, 4, 12), 15), ("MUL", "mul", 22, (0,), (4, 4, 11), 15),
+    ("AUIPC", "auipc", 21, (), (2, 2, 8), 10), ("LHU", "load_sub", 25, (16, False), (4, 4, 11), 10), ("SH", "mem", 24, (2,), (4, 4, 10), 10),
+    ("SRAI", "shift", 40, (True, 2), (3, 3, 16), 10), ("ORI", "logic_i", 24, (1,), (3, 3, 9), 8), ("XORI", "logic_i", 24, (2,), (3, 3, 9), 6),
+    ("SLTIU", "slti", 22, (False,), (3, 3, 9), 6), ("LB", "load_sub", 29, (8, True), (4, 4, 12), 5), ("LH", "load_sub", 26, (16, True), (4, 4, 11), 5),
+    ("SLL", "shift", 47, (False, 0), (4, 4, 18), 5), ("SRL", "shift", 47, (False, 1), (4, 4, 18), 5), ("SLT", "slt", 26, (True,), (4, 4, 11), 4),
+    ("SLTI", "slti", 22, (True,), (3, 3, 9), 4), ("MULHU", "mul", 26, (2,), (4, 4, 13), 4), ("SRA", "shift", 47, (False, 2), (4, 4, 18), 3),
+    ("DIVU", "div", 39, (1,), (4, 4, 20), 3), ("REMU", "div", 39, (3,), (4, 4, 20), 3), ("MULH", "mul", 26, (1,), (4, 4, 13), 2),
+    ("DIV", "div", 39, (0,), (4, 4, 20), 2), ("REM", "div", 39, (2,), (4, 4, 20), 2), ("MULHSU", "mul", 26, (3,), (4, 4, 13), 1),
+]
+assert len(OPCODE_KINDS) == 45
+# wide circuits without device witness generation (ECALL / precompile class): (name, width, log2 rows at 2^20 cycles, (r, w, lk))
+WIDE_KINDS = [("ECALL_A", 64, 12, (4, 4, 12)), ("ECALL_B", 96, 10, (6, 6, 16))]
+# table circuits: (name, counters it is fed from, log2 rows, fixed columns, structural columns)
+TABLE_KINDS = [("DynamicRange", "dyn", 19, 0, 2), ("DoubleU8", "du8", 16, 0, 2), ("AndTable", "and", 16, 3, 0), ("OrTable", "or", 16, 3, 0),
+               ("XorTable", "xor", 16, 3, 0), ("LtuTable", "ltu", 16, 3, 0), ("Program", "fetch", None, 7, 0)]
+
+
+def opcode_counts(log_cycles: int):
+    """instances per opcode circuit: the mix's weights scaled to 2^log_cycles cycles in all, at least one each"""
+    total = 1 << log_cycles
+    wsum = sum(k[5] for k in OPCODE_KINDS)
+    counts = [max(1, (total * k[5]) // wsum) for k in OPCODE_KINDS]
+    counts[0] += total - sum(counts)   # the remainder goes to the hottest opcode
+    assert sum(counts) == total and min(counts) >= 1
+    return counts
+
+
+def synthetic_step_records(n: int, fetch_base_pc: int, fetch_slots: int, offset: int = 0, seed: int = 0x57E9):
+    """n StepRecords in the emulator's #[repr(C)] layout (136 bytes = 17 words each; ceno_emul/src/tracer.rs:33-60; the offsets the
+    witgen kernels read: ceno_amd/csrc/witgen.hip): plausible values in every field a chip reads — cycles 4 apart, earlier previous
+    cycles, pcs inside the program, register word addresses, a memory operation."""
+    rng = np.random.RandomState(seed)
+    i = np.arange(n, dtype=np.uint64)
+    u = np.uint64
+    rec = np.zeros((n, 17), dtype=np.uint64)
+    cyc = u(offset) + u(4) + u(4) * i
+    pc = u(fetch_base_pc) + u(4) * (rng.randint(0, fetch_slots, n).astype(np.uint64))
+    nxt = pc + u(4)
+    jump = rng.randint(0, 8, n) == 0
+    nxt[jump] = u(fetch_base_pc) + u(4) * rng.randint(0, fetch_slots, int(jump.sum())).astype(np.uint64)
+
+    def r32(k):
+        # a mix of small and full-width operands (edge cases included)
+        v = rng.randint(0, 1 << 32, k, dtype=np.uint64)
+        small = rng.randint(0, 4, k) == 0
+        v[small] = rng.randint(0, 1 << 12, int(small.sum())).astype(np.uint64)
+        return v
+
+    def prev(k):
+        p = (rng.randint(0, 1 << 30, k).astype(np.uint64) % (cyc - u(offset))) + u(offset)
+        p[rng.randint(0, 5, k) == 0] = 0  # first access of the shard
+        return p
+
+    regs = rng.randint(1, 32, (n, 3)).astype(np.uint64)
+    imm = (rng.randint(-2048, 2048, n).astype(np.int64) & 0xFFFFFFFF).astype(np.uint64)
+    rec[:, 0] = cyc
+    rec[:, 1] = pc | (nxt << u(32))
+    rec[:, 4] = u(1) | (regs[:, 0] << u(8)) | (regs[:, 1] << u(16)) | (regs[:, 2] << u(24)) | (imm << u(32))
+    rec[:, 5] = u(0x01010101) << u(32)   # has_rs1, has_rs2, has_rd, has_memory_op (the Option discriminants: every chip finds its operands)
+    rec[:, 16] = u(0xFFFFFFFF)           # syscall_index: none
+    rec[:, 6] = ((regs[:, 0] << u(8)) >> u(2)) | (r32(n) << u(32))
+    rec[:, 7] = prev(n)
+    rec[:, 8] = ((regs[:, 1] << u(8)) >> u(2)) | (r32(n) << u(32))
+    rec[:, 9] = prev(n)
+    rec[:, 10] = ((regs[:, 2] << u(8)) >> u(2)) | (r32(n) << u(32))
+    rec[:, 11] = r32(n)
+    rec[:, 12] = prev(n)
+    rec[:, 13] = (u(0x20000000) >> u(2)) + rng.randint(0, 1 << 20, n).astype(np.uint64) | (r32(n) << u(32))
+    rec[:, 14] = r32(n)
+    rec[:, 15] = prev(n)
+    return rec
+
+
+def _table_plan(n_cols: int, n_exprs: int, c: int):
+    """main constraints of a table circuit: selector x every column (the LogUp record is an RLC of them) + selector x constant; degree 2"""
+    rng = np.random.RandomState(0x7AB1E + c)
+    sel = n_cols
+    terms = [[sel, j] for j in range(n_cols)] + [[sel]]
+    scalars = [[((int(rng.randint(1, 1 << 30)), int(rng.randint(0, 1 << 30))), [2 + int(rng.randint(0, n_exprs))])] for _ in terms]
+    return terms, scalars
+
+
+class ShardFlowWide:
+    """BASELINE.json metric M2 ("e2e prover sec for 2^20 cycles") on a synthetic shard with the reference's population, proved the way
+    ZKVMProver::create_proof does it (ceno_zkvm/src/scheme/prover.rs:319-611) with the witness PRODUCED on the device:
+
+      step records resident in HBM (the emulator's output, upstream) ->
+      witness generation, every opcode circuit's kernel writing column-major INTO the commitment's storage (ceno_prover_commit_reserve),
+        all chips counting into one set of per-XCD lookup counters (ceno_hip_witgen_session_*), the table circuits' `mlt` columns built from the
+        counters on the device (ceno_hip_lk_to_mlt_column) — no PCIe transfer anywhere ->
+      commit_traces (witness; the FIXED commitment of the op tables and the program table is set-up, outside the time: keygen) ->
+      bind the roots, two challenges -> one chip proof per circuit (~54) on forked transcripts over the lane scheduler with VRAM booking
+        (scheme/scheduler.rs:231-470) -> ONE batched main-constraint sumcheck on the wide plans ->
+      ONE opening of witness + fixed commitment (OpeningProver::open, scheme/hal.rs:284-294)."""
+
+    FETCH_BASE_PC = 0x20000000
+
+    def __init__(self, dev, prover, log_cycles: int = 20, log_blowup: int = 1, n_queries: int = 100, pow_bits: int = 16, log_program: int = None,
+                 include_wide: bool = True):
+        from . import api
+
+        self.dev, self.prover, self.api = dev, prover, api
+        self.log_cycles, self.log_blowup, self.n_queries, self.pow_bits = log_cycles, log_blowup, n_queries, pow_bits
+        self.log_program = log_program if log_program is not None else max(4, min(17, log_cycles - 3))
+        self.fetch_slots = 1 << self.log_program
+        self.stream = dev.stream_create()
+        self.n_exprs = 4
+        # ---- the emulator's output: step records + per-circuit step indices, resident on the device ----
+        n = 1 << log_cycles
+        recs = synthetic_step_records(n, self.FETCH_BASE_PC, self.fetch_slots)
+        words = recs.reshape(-1)
+        pad = 1 << (words.size - 1).bit_length()
+        self.records = dev.upload(np.concatenate([words, np.zeros(pad - words.size, dtype=np.uint64)]))
+        self.n_records = n
+        counts = opcode_counts(log_cycles)
+        perm = np.random.RandomState(0x1D5).permutation(n).astype(np.uint32)
+        self.chips = []     # dicts: name, kind, w, n_inst, nv, rows, (r, w, lk), witgen call, index buffer
+        off = 0
+        for k, (name, call, ncols, args, rec_shape, _wt) in enumerate(OPCODE_KINDS):
+            cnt = counts[k]
+            idx = np.sort(perm[off: off + cnt])   # a circuit sees its steps in execution order
+            off += cnt
+            iw = np.zeros(1 << max(1, ((cnt + 1) // 2 - 1).bit_length()), dtype=np.uint64)
+            iw.view(np.uint32)[:cnt] = idx
+            self.chips.append(dict(name=name, cls="opcode", call=call, args=args, w=ncols, n_inst=cnt, rec_shape=rec_shape, idx=dev.upload(iw)))
+        if include_wide:
+            for name, w, lr, rec_shape in WIDE_KINDS:
+                lr_ = max(2, lr - (20 - log_cycles))
+                self.chips.append(dict(name=name, cls="wide", w=w, n_inst=(1 << lr_) - (5 if lr_ >= 4 else 1), rec_shape=rec_shape))
+        for name, src, lr, n_fixed, n_struct in TABLE_KINDS:
+            lr_ = self.log_program if lr is None else lr
+            self.chips.append(dict(name=name, cls="table", src=src, w=1, n_inst=1 << lr_, n_fixed=n_fixed, n_struct=n_struct))
+        for c, ch in enumerate(self.chips):
+            ch["circuit_idx"] = c
+            ch["rows"] = max(2, 1 << (ch["n_inst"] - 1).bit_length())
+            ch["nv"] = ch["rows"].bit_length() - 1
+        # ---- lookup counters (u32, two per word of a zeroed table) ----
+        self.counter_slots = {"dyn": 1 << 19, "fetch": self.fetch_slots, "du8": 1 << 16, "and": 1 << 16, "or": 1 << 16, "xor": 1 << 16, "ltu": 1 << 16}
+        self.counters = {k: dev.zeros(max(1, (v // 2 - 1).bit_length()), False) for k, v in self.counter_slots.items()}
+        # ---- set-up (keygen): the fixed commitment and the structural columns of the table circuits ----
+        fixed_ptrs, self.fixed_src = [], []
+        self.structural = {}
+        for ch in self.chips:
+            if ch["cls"] != "table":
+                continue
+            if ch["n_fixed"]:
+                t = dev.synthetic((ch["rows"] * ch["n_fixed"] - 1).bit_length(), False, 0xF1D0 + ch["circuit_idx"])
+                self.fixed_src.append(t)
+                ch["fixed_matrix"] = len(fixed_ptrs)
+                fixed_ptrs.append((t.device_ptr, ch["rows"], ch["n_fixed"]))
+            if ch["n_struct"]:
+                self.structural[ch["circuit_idx"]] = [dev.synthetic(ch["nv"], False, 0x57C0 + 16 * ch["circuit_idx"] + j) for j in range(ch["n_struct"])]
+        self.fixed_pcs = prover.PcsData(dev, None, log_blowup, self.stream, device_ptrs=fixed_ptrs)
+        dev.sync()
+
+    # -- one opcode circuit's witness generation, writing at `wptr` (column-major, `rows` words per column) --
+    def _witgen(self, ch, wptr: int, rows: int):
+        api, dev, st = self.api, self.dev, self.stream
+        T = {k: m.device_ptr for k, m in self.counters.items()}
+        w, call, a = ch["w"], ch["call"], ch["args"]
+        common = (self.records.device_ptr, self.n_records, ch["idx"].device_ptr, ch["n_inst"], wptr, rows, 0, self.FETCH_BASE_PC, self.fetch_slots)
+        nat = list(range(w))
+        if call == "arith":
+            api.witgen_arith(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "addi":
+            api.witgen_addi(dev, nat + [w], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "logic_r":
+            api.witgen_logic_r(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], T[("and", "or", "xor")[a[0]]], stream=st)
+        elif call == "logic_i":
+            api.witgen_logic_i(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], T[("and", "or", "xor")[a[0]]], stream=st)
+        elif call == "lui":
+            api.witgen_lui(dev, nat + [w], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "jal":
+            api.witgen_jal(dev, nat + [w], *common, T["dyn"], T["fetch"], T["du8"], T["xor"], stream=st)
+        elif call == "auipc":
+            api.witgen_auipc(dev, nat + [w], *common, T["dyn"], T["fetch"], T["du8"], T["xor"], stream=st)
+        elif call == "jalr":
+            api.witgen_jalr(dev, nat + [w], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "slt":
+            api.witgen_slt(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "slti":
+            api.witgen_slti(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "branch":
+            api.witgen_branch(dev, nat + [w], a[0], a[1], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "shift":
+            api.witgen_shift(dev, nat + [w], a[0], a[1], *common, T["dyn"], T["fetch"], T["du8"], T["xor"], stream=st)
+        elif call == "mul":
+            cols = nat[:22] + (nat[22:26] if a[0] else [NO_COLUMN] * 4) + [w]
+            api.witgen_mul(dev, cols, a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "div":
+            api.witgen_div(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "mem":
+            api.witgen_mem(dev, nat + [w], a[0], *common, T["dyn"], T["fetch"], stream=st)
+        elif call == "load_sub":
+            ids = list(nat)
+            cols = [ids.pop(0) for _ in range(25)]
+            cols += [ids.pop(0) for _ in range(3)] if a[0] == 8 else [NO_COLUMN] * 3
+            cols += [ids.pop(0)] if a[1] else [NO_COLUMN]
+            api.witgen_load_sub(dev, cols + [w], a[0], a[1], *common, T["dyn"], T["fetch"], stream=st)
+        else:
+            raise ValueError(call)
+
+    def generate_witness(self):
+        """the witness of the whole shard, on the device, inside the commitment's storage; returns the reserved PcsData (finish() commits)"""
+        dev, st = self.dev, self.stream
+        pcs = self.prover.PcsData.reserve(dev, [(ch["n_inst"], ch["w"]) for ch in self.chips], self.log_blowup, st)
+        for m in self.counters.values():
+            m.fill_zero(st)
+        dev.witgen_session_begin([(self.counters[k].device_ptr, v) for k, v in self.counter_slots.items()], st)
+        try:
+            for c, ch in enumerate(self.chips):
+                assert pcs.rows(c) == ch["rows"]
+                if ch["cls"] == "opcode":
+                    self._witgen(ch, pcs.trace_ptr(c), ch["rows"])
+                elif ch["cls"] == "wide":
+                    # the host side's witness arriving in place: whole power-of-two blocks of columns of the column-major matrix
+                    ptr, left, blk = pcs.trace_ptr(c), ch["w"], 0
+                    while left:
+                        p2 = 1 << (left.bit_length() - 1)
+                        m = dev.wrap(ptr, ch["nv"] + p2.bit_length() - 1, False)
+                        dev.check(dev.L.ceno_hip_mle_fill_splitmix(dev.h, m.h, 0xECA11 + 97 * c + blk, 0, st))
+                        m.free()
+                        ptr += 8 * p2 * ch["rows"]
+                        left -= p2
+                        blk += 1
+        finally:
+            dev.witgen_session_end(st)
+        for c, ch in enumerate(self.chips):
+            if ch["cls"] == "table":
+                dev.lk_to_mlt_column(self.counters[ch["src"]].device_ptr, min(ch["n_inst"], self.counter_slots[ch["src"]]), pcs.trace_ptr(c), ch["rows"], st)
+        return pcs
+
+    def _chip_mles(self, pcs, c):
+        """(witness ++ fixed ++ structural tables of circuit c, n_witin, n_fixed, n_structural without selectors)"""
+        ch = self.chips[c]
+        cols = [pcs.witness_mle(c, j) for j in range(ch["w"])]
+        if ch["cls"] != "table":
+            return cols, ch["w"], 0, 0
+        fixed = [self.fixed_pcs.witness_mle(ch["fixed_matrix"], j) for j in range(ch["n_fixed"])] if ch["n_fixed"] else []
+        struct = self.structural.get(c, [])
+        return cols + fixed + list(struct), 1, len(fixed), len(struct)
+
+    def run(self, transcript_factory, fork_factory, lanes: int = 4) -> dict:
+        dev, prover = self.dev, self.prover
+
+        def timed(f):
+            dev.sync()
+            t0 = time.perf_counter()
+            r = f()
+            dev.sync()
+            return r, (time.perf_counter() - t0) * 1e3
+
+        self.free_last()
+        res = {}
+        pcs, res["witgen_ms"] = timed(self.generate_witness)
+        _, res["commit_ms"] = timed(pcs.finish)
+        tr = transcript_factory()
+        for root in (self.fixed_pcs.root(), pcs.root()):            # fixed commitment (vk), then the witness commitment (prover.rs:343-368)
+            tr.append_ext((int(root[0]), int(root[1])))
+            tr.append_ext((int(root[2]), int(root[3])))
+        alpha, beta = tr.sample_ext(), tr.sample_ext()
+        n_chips = len(self.chips)
+        mles_all, tasks = [], []
+        for c, ch in enumerate(self.chips):
+            mles, n_wit, n_fix, n_str = self._chip_mles(pcs, c)
+            mles_all.append((mles, n_wit, n_fix, n_str))
+            n_all = len(mles)
+            if ch["cls"] == "table":
+                # one LogUp TABLE record: numerator = mlt, denominator = an RLC of the table's fixed / structural columns
+                b2 = _e2_mul(beta, beta)
+                terms = [[0], [1], [2 % n_all if n_all > 2 else 1], [1, (n_all - 1)]]
+                coeffs = np.array([(1, 0), beta, b2, alpha], dtype=np.uint64)
+                out_terms = [[0], [1, 2, 3]]
+                shape = dict(num_reads=0, num_writes=0, num_lk_tables=1, num_lk=0)
+            else:
+                nr, nw, nl = ch["rec_shape"]
+                coeffs, terms, out_terms = record_plan(ch["w"], nr + nw + nl, alpha, beta)
+                shape = dict(num_reads=nr, num_writes=nw, num_lk_tables=0, num_lk=nl)
+            tasks.append(dict(circuit_idx=c, mles=mles, n_witin=n_wit, n_fixed=n_fix, n_structural=n_str, num_instances=ch["n_inst"],
+                              log2_num_instances=ch["nv"], record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms, **shape))
+        ct = prover.ChipTasks(tasks)
+        res["chip_proof_booking_estimates_bytes_sum"] = int(sum(prover.chip_proof_estimate_bytes(t) for t in tasks))
+        proofs, samples = [], []
+
+        def chip_proofs():
+            forks = []
+            for c, ch in enumerate(self.chips):
+                fork = fork_factory()
+                fork.append_ext(alpha)
+                fork.append_ext(beta)
+                for v in (c, c, ch["n_inst"], 0):
+                    fork.append_base(v)
+                forks.append(fork)
+            proofs.extend(prover.create_chip_proofs(dev, ct, [alpha, beta], forks, max(1, lanes)))
+            for f in forks:
+                samples.append(f.sample_ext())
+            for s_ in samples:
+                tr.append_ext(s_)
+
+        base_used = dev.mem_info()["pool_used"]
+        dev.L.ceno_hip_mem_peak(dev.h, 1)
+        dev.L.ceno_hip_mem_booked_peak(dev.h, 1)
+        _, res["chip_proofs_ms"] = timed(chip_proofs)
+        res["chip_proofs_pool_high_water_bytes"] = int(dev.L.ceno_hip_mem_peak(dev.h, 0)) - int(base_used)
+        res["chip_proofs_booked_high_water_bytes"] = int(dev.L.ceno_hip_mem_booked_peak(dev.h, 0))
+        jobs, plans = [], []
+        for c, ch in enumerate(self.chips):
+            mles, n_wit, n_fix, n_str = mles_all[c]
+            n_cols = len(mles)
+            if ch["cls"] == "table":
+                n_sel, deg = 1, 2
+                terms, scalars = _table_plan(n_cols, self.n_exprs, c)
+            else:
+                n_sel, terms, scalars, deg = wide_plan(c, n_cols, self.n_exprs)
+            sels = []
+            for si in range(n_sel):
+                n_inst = max(1, ch["n_inst"] - (ch["n_inst"] // 3) * si)   # the further selectors cover a shorter prefix
+                sels.append((1, 0, n_inst, n_str + si, (), 0, proofs[c].rt_main))
+            jobs.append(dict(circuit_idx=c, num_vars=ch["nv"], mles=mles + [None] * n_sel, n_witin=n_wit, n_fixed=n_fix, n_structural=n_str + n_sel,
+                             selectors=sels, n_exprs=self.n_exprs, max_degree=deg, terms=terms, scalars=scalars))
+            plans.append(dict(terms=terms, scalars=scalars, n_sel=n_sel, sel_n_inst=[s[2] for s in sels], n_cols=n_cols))
+        mj = prover.MainJobs(jobs)
+        (claimed, msgs, rt, evals), res["batched_main_ms"] = timed(lambda: prover.prove_batched_main_constraints(dev, mj, [alpha, beta], tr, self.stream))
+        # ---- the opening: every witness matrix, then every fixed matrix, at its circuit's prefix of the sumcheck point ----
+        points, ev, off, fixed_pts, fixed_ev = [], [], 0, [], []
+        for c, ch in enumerate(self.chips):
+            mles, n_wit, n_fix, n_str = mles_all[c]
+            points.append(rt[: ch["nv"]])
+            ev.append(evals[off: off + n_wit])
+            if n_fix:
+                fixed_pts.append(rt[: ch["nv"]])
+                fixed_ev.append(evals[off + n_wit: off + n_wit + n_fix])
+            off += len(jobs[c]["mles"])
+        oproof, res["open_ms"] = timed(lambda: pcs.basefold_open(points + fixed_pts, ev + fixed_ev, self.n_queries, self.pow_bits, tr, more_commits=[self.fixed_pcs]))
+        res["total_ms"] = res["witgen_ms"] + res["commit_ms"] + res["chip_proofs_ms"] + res["batched_main_ms"] + res["open_ms"]
+        res["e2e_prover_sec_for_2p20_cycles"] = res["total_ms"] / 1e3
+        res["open_proof_bytes"] = int(oproof.size * 8)
+        res["n_chips"], res["lanes"] = n_chips, lanes
+        self.artifacts = dict(roots=[self.fixed_pcs.root(), pcs.root()], alpha=alpha, beta=beta, chip_proofs=proofs, fork_samples=samples, claimed=claimed,
+                              msgs=msgs, rt=rt, evals=evals, points=points + fixed_pts, open_evals=ev + fixed_ev, open_proof=oproof, plans=plans,
+                              tasks=tasks, jobs=jobs)
+        self.last_pcs = pcs   # (tests read the generated witness before free_last())
+        return res
+
+    def free_last(self):
+        a = getattr(self, "artifacts", None)
+        if a:
+            for j in a["jobs"]:
+                for m in j["mles"]:
+                    if m is not None and getattr(m, "_parent", None) is not None:
+                        m.free()
+        if getattr(self, "last_pcs", None) is not None:
+            self.last_pcs.free()
+            self.last_pcs = None
+
+    def population(self) -> dict:
+        """what the shard holds (for the bench line)"""
+        by = {}
+        for ch in self.chips:
+            d = by.setdefault(ch["cls"], dict(chips=0, instances=0, padded_rows=0, cells=0, widths=set()))
+            d["chips"] += 1
+            d["instances"] += ch["n_inst"]
+            d["padded_rows"] += ch["rows"]
+            d["cells"] += ch["rows"] * ch["w"]
+            d["widths"].add(ch["w"])
+        for d in by.values():
+            d["widths"] = [min(d["widths"]), max(d["widths"])]
+        return by
+
+    def close(self):
+        self.free_last()
+        self.fixed_pcs.free()
+        for t in self.fixed_src:
+            t.free()
+        for ms in self.structural.values():
+            for m in ms:
+                m.free()
+        for m in self.counters.values():
+            m.free()
+        for ch in self.chips:
+            if "idx" in ch:
+                ch["idx"].free()
+        self.records.free()
+        self.dev.stream_destroy(self.stream)

@@ -106,6 +106,9 @@ size_t ceno_hip_mem_peak(ceno_hip_ctx* ctx, int reset);
 int ceno_hip_mem_book(ceno_hip_ctx* ctx, size_t bytes);
 int ceno_hip_mem_unbook(ceno_hip_ctx* ctx, size_t bytes);
 size_t ceno_hip_mem_booked(ceno_hip_ctx* ctx);
+/* high-water mark of the booked total since the last reset: what the scheduler promised at its busiest moment, to hold against
+ * ceno_hip_mem_peak (what the booked tasks really took) */
+size_t ceno_hip_mem_booked_peak(ceno_hip_ctx* ctx, int reset);
 
 /* ------------------------------------------------------------------------------------------------
  * MLE handles  (alloc_elems_on_device / alloc_ext_elems_from_host / Buffer::to_cpu_vec)
@@ -127,6 +130,9 @@ int ceno_hip_mle_is_ext(const ceno_hip_mle* m);
 uint64_t* ceno_hip_mle_device_ptr(const ceno_hip_mle* m);
 /* word i of the table = SplitMix64(seed, word_offset + i) reduced mod p (BASELINE.md synthetic inputs) */
 int ceno_hip_mle_fill_splitmix(ceno_hip_ctx* ctx, ceno_hip_mle* m, uint64_t seed, uint64_t word_offset, ceno_hip_stream s);
+/* every word zero, queued on `s` (a fresh table is NOT zero: pool blocks are recycled).  MultilinearExtension of zeros /
+ * RowMajorMatrix::new(.., InstancePaddingStrategy::Default) (witness crate); also how a caller clears lookup counters kept in a table's words */
+int ceno_hip_mle_fill_zero(ceno_hip_ctx* ctx, ceno_hip_mle* m, ceno_hip_stream s);
 
 /* MultilinearExtension::evaluate(point) — out2 = f(point), point has num_vars ext elements */
 int ceno_hip_mle_evaluate(ceno_hip_ctx* ctx, const ceno_hip_mle* m, const uint64_t* point, uint64_t* out2, ceno_hip_stream s);
@@ -737,6 +743,23 @@ int ceno_hip_witgen_logic_r(ceno_hip_ctx* ctx, const ceno_hip_logic_r_column_map
                             size_t num_records, const uint32_t* dev_step_indices, size_t n, uint64_t shard_offset_cycle, uint32_t fetch_base_pc,
                             uint32_t fetch_num_slots, uint64_t* dev_witness_col_major, size_t rows_padded, uint32_t* dev_lk_dynamic,
                             uint32_t* dev_lk_fetch, uint32_t* dev_lk_logic, ceno_hip_stream s);
+
+/* A SHARD's witness generation as one session: the ~45 opcode chips of a shard count into the same few lookup tables (the reference
+ * accumulates them in one LkMultiplicity per shard, gkr_iop/src/utils/lk_multiplicity.rs:181-198, and its GPU path fetches the device
+ * counters back chip by chip, instructions/gpu/dispatch.rs:234-236 `gpu_lk_d2h`).  Between begin and end the ceno_hip_witgen_* calls on
+ * `s` that name a registered table neither clear, merge nor wait: the per-XCD copies of the registered tables are cleared once at
+ * begin, every chip's kernel is queued behind the previous one, and `end` adds the totals to the registered tables with one merge per
+ * table and synchronises.  dev_tables[t]: slots[t] counters, e.g. the dynamic-range table (CENO_HIP_LK_DYNAMIC_SLOTS), the fetch table
+ * (fetch_num_slots), the double-u8 and the AND / OR / XOR tables (2^16 each).  A table used inside the session must be registered.
+ * One open session per context. */
+int ceno_hip_witgen_session_begin(ceno_hip_ctx* ctx, uint32_t* const* dev_tables, const size_t* slots, int n_tables, ceno_hip_stream s);
+int ceno_hip_witgen_session_end(ceno_hip_ctx* ctx, ceno_hip_stream s);
+/* The `mlt` witness column of a table circuit straight from the device counters (no trip through the host): dev_column[i] = dev_counters[i]
+ * for i < n, zero up to rows_padded (TableConfig::assign_instances: ceno_zkvm/src/tables/ops/ops_impl.rs:85-100,
+ * tables/range/range_impl.rs:60-96 set `mlt` from the shard's multiplicity map; InstancePaddingStrategy::Default beyond the table).
+ * dev_column is typically ceno_pcs_data_trace_ptr of the table's one-column witness matrix (include/ceno_prover.h). */
+int ceno_hip_lk_to_mlt_column(ceno_hip_ctx* ctx, const uint32_t* dev_counters, size_t n, uint64_t* dev_column, size_t rows_padded,
+                              ceno_hip_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * diagnostics used by bench.py (HIP-event timing of the dominant kernel on the launch stream)

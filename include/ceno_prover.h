@@ -343,6 +343,20 @@ int ceno_prover_commit_traces(ceno_hip_ctx* ctx, const uint64_t* const* host_row
  * is queued on `s`, behind whatever the caller queued there to produce the matrices. */
 int ceno_prover_commit_traces_dev(ceno_hip_ctx* ctx, const uint64_t* const* dev_row_major, const size_t* num_instances, const size_t* widths,
                                   int n_matrices, int log_blowup, ceno_hip_stream s, ceno_pcs_data** out);
+/* commit_traces for traces PRODUCED on the device (on-device witness generation: the reference keeps the GPU witgen's output as the
+ * device backing of the RowMajorMatrix, column-major, and hands it to batch_commit without a copy —
+ * `should_materialize_witness_on_gpu`, `normalize_traces_to_device_col_major`, scheme/gpu/mod.rs:1565-1592), in two steps so that the
+ * producer writes INSIDE the commitment's own storage: `reserve` lays the matrices out in their height classes and allocates trace +
+ * codeword storage; ceno_pcs_data_trace_ptr(d, m) is matrix m's destination — COLUMN-major, widths[m] columns of
+ * ceno_pcs_data_rows(d, m) = next_pow2_instance_padding(num_instances[m]) words, the layout the ceno_hip_witgen_* kernels write
+ * (rows >= num_instances must be written as zero: they do); `finish` RS-encodes every class and builds the tree, queued on `s`
+ * behind the producers (which must have been queued on `s` or be complete).  Between the two calls the handle supports
+ * ceno_pcs_data_num_vars / _width / _rows / _trace_ptr / _witness_mle only. */
+int ceno_prover_commit_reserve(ceno_hip_ctx* ctx, const size_t* num_instances, const size_t* widths, int n_matrices, int log_blowup,
+                               ceno_hip_stream s, ceno_pcs_data** out);
+uint64_t* ceno_pcs_data_trace_ptr(ceno_pcs_data* d, int matrix);
+size_t ceno_pcs_data_rows(const ceno_pcs_data* d, int matrix);
+int ceno_prover_commit_finish(ceno_hip_ctx* ctx, ceno_pcs_data* d, ceno_hip_stream s);
 int ceno_pcs_data_num_matrices(const ceno_pcs_data* d);
 int ceno_pcs_data_num_vars(const ceno_pcs_data* d, int matrix);
 int ceno_pcs_data_width(const ceno_pcs_data* d, int matrix);

@@ -255,3 +255,17 @@ def test_eight_lane_host_arithmetic_matches_the_scalar_operators(built):
             s = po.e2_add(s, t(a[k]))
         assert t(out[24]) == s
     assert ran == 40
+
+
+def test_shard_population_is_the_references():
+    """45 opcode circuits (every RV32IM opcode circuit but ECALL), instance counts that add up to the cycle count, seven table circuits"""
+    from ceno_amd import synthetic
+
+    names = [k[0] for k in synthetic.OPCODE_KINDS]
+    assert len(set(names)) == 45
+    for lc in (10, 12, 20):
+        c = synthetic.opcode_counts(lc)
+        assert sum(c) == 1 << lc and min(c) >= 1
+    c = synthetic.opcode_counts(20)
+    assert max(c) > 100 * min(c) and sum(1 for x in c if x & (x - 1)) > 40   # a few hot opcodes, a long tail, not powers of two
+    assert [t[0] for t in synthetic.TABLE_KINDS] == ["DynamicRange", "DoubleU8", "AndTable", "OrTable", "XorTable", "LtuTable", "Program"]
