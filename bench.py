@@ -33,6 +33,50 @@ SEED0 = 0xCE10
 TR_SEED = 0xF5
 
 
+def csrc_sha16() -> str:
+    """what a committed counters file is valid for: the kernel sources (ceno_amd/csrc/*, file names and contents)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "ceno_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_valu_counters():
+    """(counters, source path, stale): the committed --pmc pass (tools/r06_valu_counters.sh -> profiles/r*_valu_counters.json).  The file is stamped
+    with the hash of the kernel sources it was measured on; when the tree's kernels differ, the instruction counts are NOT used (valu_frac null,
+    "stale_counters": true) — a count from another build times this run's milliseconds would be a wrong fraction beside live numbers."""
+    import glob
+
+    vc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_counters.json")))
+    if not vc:
+        return {}, None, False
+    d = json.load(open(vc[-1]))
+    stale = d.get("csrc_sha16") != csrc_sha16()
+    return d, os.path.relpath(vc[-1], ROOT), stale
+
+
+def valu_headline(kernel_ms_per_sumcheck: float, n_local: int) -> dict:
+    """VALU-issue fraction of the dense kernel on THIS run's kernel time: wave-level SQ_INSTS_VALU of one nv = 26 sumcheck from the committed
+    --pmc pass x 4.3 cycles per instruction / (1024 SIMDs x 2.4 GHz x time); null when the counters are stale or for another size"""
+    d, src, stale = load_valu_counters()
+    vc = d.get("sumcheck_nv26")
+    if not vc or n_local != 26 or kernel_ms_per_sumcheck <= 0:
+        return {"valu_frac": None}
+    if stale:
+        return {"valu_frac": None, "stale_counters": True, "valu": {"source": src}}
+    cpi, simds, ghz = d.get("cycles_per_valu_inst", 4.3), d.get("simds", 1024), d.get("clock_ghz", 2.4)
+    frac = vc["SQ_INSTS_VALU"] * cpi / (simds * ghz * 1e9 * kernel_ms_per_sumcheck * 1e-3)
+    out = {"valu_frac": frac, "valu": {"SQ_INSTS_VALU_per_sumcheck": vc["SQ_INSTS_VALU"], "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz, "source": src}}
+    if "fold_rounds_valu_issue_frac" in vc:
+        out["valu"]["fold_rounds_valu_issue_frac"] = vc["fold_rounds_valu_issue_frac"]
+    return out
+
+
 def cpu_baseline(nv: int = 26):
     """the oracle's OpenMP fused sumcheck (a port, not the Rust/rayon reference binary) on the host cores,
     in a child process with a clean OpenMP environment"""
@@ -54,10 +98,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
 
     # VALU-bound extras: wave-level VALU instruction counts of ONE run of the workload from the committed --pmc pass (tools/r05_valu_counters.sh ->
     # profiles/r*_valu_counters.json); valu_frac = SQ_INSTS_VALU x measured cycles per instruction / (SIMDs x clock x time of THIS run)
-    import glob as _glob
-
-    _vc = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_valu_counters.json")))
-    valu_counters = json.load(open(_vc[-1])) if _vc else {}
+    valu_counters, valu_source, valu_stale = load_valu_counters()
 
     def roof(alg_bytes, ms, note=None, valu_key=None):
         gbps = alg_bytes / (ms * 1e-3) / 1e9
@@ -68,11 +109,15 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
         if valu_key:
             r["bound"] = "valu"  # integer-ALU issue, not HBM: `frac` stays the HBM fraction of the algorithmic bytes (the contract's field)
             r["hbm_frac"] = r["frac"]
-        if vc:
+        if vc and valu_stale:
+            r["valu_frac"] = None
+            r["stale_counters"] = True
+            r["valu"] = {"source": valu_source, "note": "measured on other kernel sources than this tree's (csrc_sha16 differs): re-run tools/r06_valu_counters.sh"}
+        elif vc:
             cpi, simds, ghz = valu_counters.get("cycles_per_valu_inst", 4.3), valu_counters.get("simds", 1024), valu_counters.get("clock_ghz", 2.4)
             insts = vc["SQ_INSTS_VALU"]
             frac = insts * cpi / (simds * ghz * 1e9 * ms * 1e-3)
-            r["valu"] = {"SQ_INSTS_VALU": insts, "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz, "source": os.path.relpath(_vc[-1], ROOT)}
+            r["valu"] = {"SQ_INSTS_VALU": insts, "cycles_per_inst": cpi, "simds": simds, "clock_ghz": ghz, "source": valu_source}
             if valu_key == "chip_flow.commit":
                 # Poseidon2's mix holds full-rate 32-bit adds and moves (2.3-2.7 cycles, profiles/r01_valu_issue_rates.txt): the 4.3-cycle
                 # figure of the multiply / carry instructions overstates it — at 4.0 cycles per instruction the count already fills the SIMDs
@@ -233,6 +278,33 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
                       "8 chip proofs (tower relation) on forked transcripts, one batched main sumcheck, one Basefold opening; witness generation "
                       "and the emulator are upstream and excluded")
     out["shard_e2e"] = bs
+    # metric M2 on a shard with the REFERENCE's population (rv32im.rs:124-230,580-587): 45 opcode circuits with on-device witness generation
+    # writing into the commitment's storage, 2 wide circuits, 7 table circuits (mlt from the device lookup counters), a fixed commitment
+    # opened beside the witness commitment; chip proofs on 1 / 4 / 8 / 16 requested lanes (the scheduler runs at most 8 at once for such a batch)
+    wide = synthetic.ShardFlowWide(dev, prover)
+    bw, w_lanes = None, {}
+    for lanes in (1, 4, 8, 16):
+        bl = None
+        for _ in range(reps if lanes > 1 else 2):
+            r = wide.run(new_transcript, fork, lanes=lanes)
+            if bl is None or r["total_ms"] < bl["total_ms"]:
+                bl = r
+        w_lanes[str(lanes)] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in bl.items()
+                               if k.endswith("_ms") or k.endswith("_bytes") or k.endswith("_bytes_sum")}
+        if bw is None or bl["total_ms"] < bw["total_ms"]:
+            bw = dict(bl, chip_proof_lanes=lanes)
+    wide.free_last()
+    pop = wide.population()
+    wide.close()
+    bw["by_chip_proof_lanes"] = w_lanes
+    bw["population"] = pop
+    bw["workload"] = ("metric M2 on a shard with the reference's population: 2^20 cycles over 45 opcode circuits (13..47 columns, ~2^10..~2^18 instances "
+                      "following an instruction mix, witness generated ON THE DEVICE from resident step records straight into the commitment's storage), "
+                      "2 wide circuits (64 / 96 columns), 7 table circuits of 2^16..2^19 rows (mlt from the device lookup counters; 3-7 fixed columns in a "
+                      "FIXED commitment, or 2 structural columns): witgen -> commit -> 54 chip proofs on the lane scheduler with VRAM booking -> one "
+                      "batched main sumcheck on the wide plans (degree <= 5) -> one opening of witness + fixed commitment; the emulator is upstream "
+                      "and excluded, the fixed commitment is set-up (keygen)")
+    out["shard_e2e_wide"] = bw
     # config #1 SHAPE (the reference's own CPU-runnable case is the fibonacci program at 2^10 steps; its emulator and opcode circuits are upstream
     # of the path and not here): the same create_proof flow on 2^10 synthetic cycles — what a proof costs when nothing but latency is left
     small = synthetic.ShardFlow(dev, prover, log_rows=(9, 8, 7, 7))
@@ -249,7 +321,9 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
     out["chip_flow_ms"], out["batched_main_ms"], out["nv22_ms"] = best["total_ms"], out["batched_main"]["ms"], out["nv22"]["ms"]
     out["batched_main_nv26_ms"] = out["batched_main_nv26"]["ms"]
     out["batched_main_wide_ms"] = out["batched_main_wide"]["ms"]
-    out["shard_e2e_sec"] = bs["e2e_prover_sec_for_2p20_cycles"]
+    # metric M2: from the shard with the reference's population; the eight-chip shard of rounds 3-5 beside it
+    out["shard_e2e_sec"] = bw["e2e_prover_sec_for_2p20_cycles"]
+    out["shard_e2e_8chips_sec"] = bs["e2e_prover_sec_for_2p20_cycles"]
     return out
 
 
@@ -792,7 +866,13 @@ def main():
             **({"collective_ms": m["collective_ms"], "exchanges_validated": m["validated"], "headline_exchange": m.get("headline_exchange"),
                 "fastest_exchange": m.get("fastest_exchange"), **comm_info} if world > 1 else {}),
             "roofline": {
+                # the contract's field: HBM is the roof `frac` is taken against.  The kernel is CO-LIMITED (profiles/r05_dense_overlap.json,
+                # r04_dense_kernel_floor.json): its fold rounds issue VALU instructions at ~0.86 of capacity while its schedule moves its bytes at
+                # ~0.84 of what that access pattern can reach — `valu_frac` / `schedule_ceiling_frac` below say so on this run's time
                 "bound": "hbm",
+                "co_limited_by": "valu",
+                **valu_headline(kernel_ms / args.steps if args.steps else 0.0, n_local),
+                "schedule_min_bytes": 4 * K * 16 * (1 << n_local),   # 192 * 2^n: one round per pass (Fiat-Shamir) reads T0 twice; 144 * 2^n is the yardstick
                 "kernel": "k_dense<3,*> (fused fold + round-polynomial accumulate)",
                 "achieved": achieved,
                 "peak": peak,

@@ -17,7 +17,9 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <rccl/rccl.h>
 
@@ -124,7 +126,9 @@ struct ShmRank {
 struct ShmSeg {
     uint64_t magic;
     uint64_t world;
-    uint64_t pad[6];
+    uint64_t bytes;                    // size of the whole segment as its creator laid it out (checked on attach, before anything past the header is touched)
+    volatile uint64_t abort;           // != 0: a rank gave up (its own error, a time-out): every waiting peer returns at once
+    uint64_t pad[4];
     ShmRank ranks[1];                  // `world` entries
 };
 
@@ -169,6 +173,7 @@ struct ceno_dist_comm {
     uint64_t shm_seq = 0;        // exchanges done so far (identical on every rank)
     bool h_recv_plain = false;
     struct ceno_dist_local_group* local = nullptr;  // in-process group of virtual ranks (threads sharing one device)
+    int shares_device = -1;      // -1: not asked yet; 1: at least two ranks sit on one device (dist_comm_ranks_share_device)
 };
 
 int ceno_dist_unique_id(uint8_t* out128) {
@@ -243,7 +248,46 @@ static size_t shm_size(int world) { return shm_head_size(world) + (size_t)world 
 static uint64_t* shm_bulk(ShmSeg* seg, int world, int rank, int parity) {
     return reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(seg) + shm_head_size(world)) + ((size_t)rank * 2 + (size_t)parity) * SHM_BULK_WORDS;
 }
-static const uint64_t SHM_MAGIC = 0x43454e4f53484d31ULL;  // "CENOSHM1"
+static const uint64_t SHM_MAGIC = 0x43454e4f53484d32ULL;  // "CENOSHM2" (2: size and abort word in the header, bulk area behind the ranks)
+
+// Waiting for a peer: pause-spin, the clock every 1024 spins, the CPU given up every 4096 (more ranks than cores must not starve the rank that is
+// waited for).  Bounded by WALL CLOCK (CENO_DIST_SHM_TIMEOUT_S, default 60 s), not by an iteration count; a rank that gives up — here or through
+// dist_fail / ceno_dist_comm_abort — raises the segment's abort word, and every peer that waits returns at once instead of after its own time-out.
+static double shm_timeout_s() {
+    static const double v = [] {
+        const char* e = getenv("CENO_DIST_SHM_TIMEOUT_S");
+        const double x = e ? atof(e) : 60.0;
+        return x > 0 ? x : 60.0;
+    }();
+    return v;
+}
+static thread_local ceno_dist_comm* tls_shm_comm = nullptr;  // the communicator this thread exchanged through last (dist_fail raises its abort word)
+static int shm_wait(ceno_dist_comm* c, int g, uint64_t seq, const char* what) {
+    volatile uint64_t* flag = &c->shm->ranks[g].seq;
+    uint64_t spins = 0;
+    timespec t0{0, 0};
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) {
+        if ((++spins & 1023) == 0) {
+            if (c->shm->abort) {
+                g_dist_err = std::string(what) + ": another rank gave up (abort word raised)";
+                return CENO_HIP_ERR_STATE;
+            }
+            timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if (t0.tv_sec == 0 && t0.tv_nsec == 0) t0 = now;
+            if ((double)(now.tv_sec - t0.tv_sec) + 1e-9 * (double)(now.tv_nsec - t0.tv_nsec) > shm_timeout_s()) {
+                c->shm->abort = 1;
+                g_dist_err = std::string(what) + ": rank " + std::to_string(g) + " never published (timed out, CENO_DIST_SHM_TIMEOUT_S)";
+                return CENO_HIP_ERR_STATE;
+            }
+            if ((spins & 4095) == 0) sched_yield();
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return 0;
+}
 
 /* Attach the host shared-memory exchange to a communicator (`c` may come from ceno_dist_comm_init, or be created
  * here without RCCL when *c is NULL).  Rank 0 passes create != 0 and must attach BEFORE the name is given to the
@@ -269,6 +313,14 @@ int ceno_dist_comm_attach_shm(ceno_dist_comm** pc, int world, int rank, const ch
         g_dist_err = "ftruncate on the shared segment failed";
         return CENO_HIP_ERR_STATE;
     }
+    if (!create) {  // a segment of another layout (an older library) is shorter: check the file's size before mapping `bytes` of it (SIGBUS otherwise)
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || (size_t)sb.st_size != bytes) {
+            close(fd);
+            g_dist_err = "shared segment has another size than this library lays out for this world size (mixed versions?)";
+            return CENO_HIP_ERR_STATE;
+        }
+    }
     void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) {
@@ -279,8 +331,9 @@ int ceno_dist_comm_attach_shm(ceno_dist_comm** pc, int world, int rank, const ch
     if (create) {
         memset(m, 0, bytes);
         seg->world = (uint64_t)world;
+        seg->bytes = (uint64_t)bytes;
         __atomic_store_n(&seg->magic, SHM_MAGIC, __ATOMIC_RELEASE);
-    } else if (__atomic_load_n(&seg->magic, __ATOMIC_ACQUIRE) != SHM_MAGIC || seg->world != (uint64_t)world) {
+    } else if (__atomic_load_n(&seg->magic, __ATOMIC_ACQUIRE) != SHM_MAGIC || seg->world != (uint64_t)world || seg->bytes != (uint64_t)bytes) {
         munmap(m, bytes);
         g_dist_err = "shared segment is not initialised for this world size";
         return CENO_HIP_ERR_STATE;
@@ -298,6 +351,11 @@ int ceno_dist_comm_attach_shm(ceno_dist_comm** pc, int world, int rank, const ch
     c->shm_seq = 0;
     return 0;
 }
+int ceno_dist_comm_abort(ceno_dist_comm* c) {
+    if (!c) return CENO_HIP_ERR_INVALID;
+    if (c->shm) c->shm->abort = 1;
+    return 0;
+}
 int ceno_dist_shm_unlink(const char* name) { return name && shm_unlink(name) == 0 ? 0 : CENO_HIP_ERR_STATE; }
 
 // all-gather `n_ext` extension elements per rank through the shared segment; result (world x n_ext) in c->h_recv
@@ -310,18 +368,10 @@ static int shm_gather_ext(ceno_dist_comm* c, const uint64_t* mine, int n_ext) {
     ShmRank& me = c->shm->ranks[c->rank];
     memcpy((void*)me.slot[seq & 1], mine, (size_t)n_ext * 16);
     __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    tls_shm_comm = c;
     for (int g = 0; g < c->world; g++) {
         ShmRank& r = c->shm->ranks[g];
-        uint64_t spins = 0;
-        while (__atomic_load_n(&r.seq, __ATOMIC_ACQUIRE) < seq) {
-            if (++spins > ((uint64_t)1 << 34)) {  // a peer died: minutes of spinning
-                g_dist_err = "shm_gather_ext: peer never published its message";
-                return CENO_HIP_ERR_STATE;
-            }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
+        if (int rc = shm_wait(c, g, seq, "shm_gather_ext")) return rc;
         memcpy(c->h_recv + (size_t)g * n_ext * 2, (const void*)r.slot[seq & 1], (size_t)n_ext * 16);
     }
     return 0;
@@ -337,18 +387,9 @@ static int shm_gather_bulk(ceno_dist_comm* c, const uint64_t* mine, size_t n_wor
     ShmRank& me = c->shm->ranks[c->rank];
     memcpy(shm_bulk(c->shm, c->world, c->rank, (int)(seq & 1)), mine, n_words * 8);
     __atomic_store_n(&me.seq, seq, __ATOMIC_RELEASE);
+    tls_shm_comm = c;
     for (int g = 0; g < c->world; g++) {
-        ShmRank& r = c->shm->ranks[g];
-        uint64_t spins = 0;
-        while (__atomic_load_n(&r.seq, __ATOMIC_ACQUIRE) < seq) {
-            if (++spins > ((uint64_t)1 << 34)) {
-                g_dist_err = "shm_gather_bulk: peer never published its block";
-                return CENO_HIP_ERR_STATE;
-            }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
+        if (int rc = shm_wait(c, g, seq, "shm_gather_bulk")) return rc;
         memcpy(out + (size_t)g * out_stride_words, shm_bulk(c->shm, c->world, g, (int)(seq & 1)), n_words * 8);
     }
     return 0;
@@ -950,6 +991,8 @@ namespace {
 
 int dist_fail(int code, const std::string& msg) {
     g_dist_err = msg;
+    // a rank that fails on its own (a copy, a validation) will not publish what its peers wait for: let them return now
+    if (tls_shm_comm && tls_shm_comm->shm) tls_shm_comm->shm->abort = 1;
     return code;
 }
 
@@ -988,15 +1031,9 @@ static int shm_exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const si
             const uint64_t seq = ++c->shm_seq;
             if (ns) memcpy(shm_bulk(c->shm, W, me, (int)(seq & 1)), hs[(size_t)to].data() + o, ns * 8);
             __atomic_store_n(&c->shm->ranks[me].seq, seq, __ATOMIC_RELEASE);
-            for (int g = 0; g < W; g++) {
-                uint64_t spins = 0;
-                while (__atomic_load_n(&c->shm->ranks[g].seq, __ATOMIC_ACQUIRE) < seq) {
-                    if (++spins > ((uint64_t)1 << 34)) return dist_fail(CENO_HIP_ERR_STATE, "exchange_blocks: a peer never published its block");
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                }
-            }
+            tls_shm_comm = c;
+            for (int g = 0; g < W; g++)
+                if (int rc = shm_wait(c, g, seq, "exchange_blocks")) return rc;
             if (nr) memcpy(hr[(size_t)from].data() + o, shm_bulk(c->shm, W, from, (int)(seq & 1)), nr * 8);
         }
     }
@@ -1091,6 +1128,39 @@ int gather_digests(ceno_dist_comm* c, const uint64_t* mine4, uint64_t* out, hipS
 int dist_comm_world(const ceno_dist_comm* c) { return c ? c->world : 1; }
 int dist_comm_rank(const ceno_dist_comm* c) { return c ? c->rank : 0; }
 bool dist_comm_has_rccl(const ceno_dist_comm* c) { return c && c->comm != nullptr; }
+int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, hipStream_t st);
+// Do two ranks of the communicator sit on ONE device?  Decided from the placement itself — every rank's host name and the PCI bus id of its
+// current device, gathered once per communicator — not from which transports happen to be attached: ranks that share a device share its
+// hardware queues (a queued round kernel of one can hold up the tree kernels another waits for: docs/rounds/r05.md "A hazard found late"), whatever
+// carries their messages.  COLLECTIVE on first use (every rank must ask).  An in-process group is one device by construction.
+bool dist_comm_ranks_share_device(ceno_dist_comm* c, hipStream_t st) {
+    if (!c || c->world == 1) return false;
+    if (c->local) return true;
+    if (c->shares_device >= 0) return c->shares_device == 1;
+    uint64_t mine[2] = {0, 0};  // FNV-1a of "<host name>/<pci bus id>", twice with different seeds
+    {
+        char host[256] = {0}, bus[64] = {0};
+        (void)gethostname(host, sizeof host - 1);
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+        const std::string key = std::string(host) + "/" + bus;
+        uint64_t h0 = 0xcbf29ce484222325ULL, h1 = 0x84222325cbf29ce4ULL;
+        for (unsigned char ch : key) {
+            h0 = (h0 ^ ch) * 0x100000001b3ULL;
+            h1 = (h1 ^ (ch + 0x9e)) * 0x100000001b3ULL;
+        }
+        mine[0] = h0 >> 1;  // (the small-message transports carry field words: keep them below 2^63)
+        mine[1] = h1 >> 1;
+    }
+    std::vector<uint64_t> all((size_t)2 * c->world);
+    if (dist_allgather_words(c, mine, 2, all.data(), st) != 0) return true;  // cannot tell: take the safe (serial) side
+    int shared = 0;
+    for (int a = 0; a < c->world && !shared; a++)
+        for (int b = a + 1; b < c->world; b++)
+            if (all[2 * a] == all[2 * b] && all[2 * a + 1] == all[2 * b + 1]) shared = 1;
+    c->shares_device = shared;
+    return shared == 1;
+}
 // all-gather `n_words` 64-bit words per rank (host memory in, host memory out: out[g * n_words + k]) over the communicator's small-message
 // transport — in-process group, shared segment or RCCL — in chunks of 128 words.  Bulk data (MBs) belongs on exchange_blocks; this carries the
 // per-round partial sums and the folded tables (KBs) of the sharded tower prover.

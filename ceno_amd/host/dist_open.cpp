@@ -37,6 +37,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                          int n_queries, int pow_bits, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_proof, const BasefoldOpenHook* hook);
 int dist_comm_world(const ceno_dist_comm* c);  // dist.cpp
 int dist_comm_rank(const ceno_dist_comm* c);
+bool dist_comm_ranks_share_device(ceno_dist_comm* c, hipStream_t st);  // dist.cpp: from the ranks' host names + PCI bus ids, gathered once
 bool dist_comm_has_rccl(const ceno_dist_comm* c);  // one rank per GPU by construction (RCCL does not place two ranks on a device)
 int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words, uint64_t* out, hipStream_t st);
 int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_words, uint64_t* recv_dev, hipStream_t st);
@@ -129,8 +130,11 @@ int hook_batch_trace(void* self, int commit, int mat, const uint64_t* coeffs, ui
     const DistCommit& K = D.commits[(size_t)commit];
     const size_t rows = (size_t)1 << K.log_rows_of[(size_t)mat];
     DevBuf part{D.ctx}, all{D.ctx};
+    // the ranks' partial sums are gathered and added in CHUNKS of at most 2^20 rows: the gather scratch stays at W x 16 MB whatever the height of the
+    // matrix (whole: 2 x rows x W extension words rounded up to a power of two — ~2 GB at 2^24 rows and 8 ranks, which no booking estimate knew of)
+    const size_t chunk = std::min<size_t>(rows, (size_t)1 << 20);
     if (int rc = part.alloc_words(2 * rows)) return fail_ctx(D.ctx, rc);
-    if (int rc = all.alloc_words(2 * rows * (size_t)D.W)) return fail_ctx(D.ctx, rc);
+    if (int rc = all.alloc_words(2 * chunk * (size_t)D.W)) return fail_ctx(D.ctx, rc);
     size_t col0 = 0;
     for (int g = 0; g < D.rank; g++) col0 += (size_t)K.widths[(size_t)mat * D.W + g];
     const int mine = K.widths[(size_t)mat * D.W + D.rank];
@@ -140,8 +144,10 @@ int hook_batch_trace(void* self, int commit, int mat, const uint64_t* coeffs, ui
     } else if (hipMemsetAsync(part.ptr(), 0, rows * 16, (hipStream_t)s) != hipSuccess) {
         return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: memset failed");
     }
-    if (int rc = dist_allgather_device(D.comm, part.ptr(), 2 * rows, all.ptr(), (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
-    if (int rc = ceno_hip_ext_sum_blocks(D.ctx, all.ptr(), D.W, rows, dev_F, s)) return fail_ctx(D.ctx, rc);
+    for (size_t off = 0; off < rows; off += chunk) {
+        if (int rc = dist_allgather_device(D.comm, part.ptr() + 2 * off, 2 * chunk, all.ptr(), (hipStream_t)s)) return prover_set_error(rc, ceno_dist_last_error());
+        if (int rc = ceno_hip_ext_sum_blocks(D.ctx, all.ptr(), D.W, chunk, dev_F + 2 * off, s)) return fail_ctx(D.ctx, rc);
+    }
     if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return prover_set_error(CENO_HIP_ERR_HIP, "dist_basefold_open: sync failed");
     return 0;
 }
@@ -281,7 +287,10 @@ int ceno_dist_basefold_open_commits(ceno_hip_ctx* ctx, ceno_dist_comm* comm, int
     }
     // (CENO_DIST_OPEN_PIPELINE=1 / 0 overrides the choice: A/B and the stress run that shows what the serial rounds are for, tools/dev/open_ranks_stress.sh)
     const char* pe = getenv("CENO_DIST_OPEN_PIPELINE");
-    const bool serial = pe ? atoi(pe) == 0 : !dist_comm_has_rccl(comm);
+    // pipelined rounds only when no two ranks share a device — asked of the placement (host name + PCI bus id of every rank), not of the transports:
+    // a communicator that has RCCL AND a shared segment, or a one-device RCCL set-up, must not get the pipelined path by accident
+    const bool shared = dist_comm_ranks_share_device(comm, (hipStream_t)s);   // (collective: asked on every rank, whatever the override says)
+    const bool serial = pe ? atoi(pe) == 0 : shared;
     BasefoldOpenHook hook{&D, serial, hook_batch_codeword, hook_batch_trace, hook_opening_words, hook_mmcs_open};
     return basefold_open_hooked(ctx, shape_ptrs.data(), n_commits, points, evals, n_queries, pow_bits, tr, s, out_proof, &hook);
 }

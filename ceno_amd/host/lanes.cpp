@@ -46,9 +46,12 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
         // The command processor dispatches FOUR queues concurrently; further streams are time-multiplexed onto them, and a lane whose
         // stream shares a queue with another lane's persistent round kernel waits behind it (tools/ubench_lanes.hip,
         // profiles/r03_lane_launch_latency.json: launch + wait 116 us for 16 launches on 4 streams, 219 us on 8; eight chip-proof
-        // lanes measured 10-20 % slower than four).  More lanes than that are therefore run as four; CENO_HIP_MAX_LANES overrides.
+        // lanes measured 10-20 % slower than four on a shard of eight chips).  More lanes than that are therefore run as four —
+        // unless the batch is MANY tasks (a shard with the reference's ~54 circuits): then the gaps one lane leaves on its queue
+        // (host layers, set-up between launches) are worth a second lane per queue — 54 chip proofs: 29.4 ms on 4 lanes, 26.5 on 6,
+        // 24.7-25.9 on 8-10, 25.5 on 12 (profiles/r06_shard_wide_lanes.jsonl).  CENO_HIP_MAX_LANES overrides.
         const char* e = getenv("CENO_HIP_MAX_LANES");
-        const int cap = e && atoi(e) > 0 ? atoi(e) : 4;
+        const int cap = e && atoi(e) > 0 ? atoi(e) : (n_tasks >= 24 ? 8 : 4);
         n_lanes = std::min(n_lanes, cap);
     }
     std::vector<int> order(n_tasks);

@@ -452,7 +452,7 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
             std::vector<size_t> eq_l, eq_h;
             ceno_hip_sumcheck_plan plan{};
         };
-        auto make_pack = [&](bool want_big, Pack& P) {
+        auto make_pack = [&](bool want_big, Pack& P) -> int {
             std::vector<int> remap(plan_mles.size(), -1), tmap((size_t)n_terms, -1);
             for (size_t i = 0; i < plan_mles.size(); i++)
                 if ((bool)big[(size_t)plan_job[i]] == want_big) {
@@ -471,6 +471,9 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
                 for (uint32_t x = g_toff[g]; x < g_toff[g + 1]; x++) tjob[g_tidx[x]] = j;
             }
             for (int t = 0; t < n_terms; t++) {
+                // a monomial with no factor at all, in no group: nothing names its chip (the engine refuses such a plan as an "empty product",
+                // but only at begin — this index comes first)
+                if (tjob[(size_t)t] < 0) return CENO_HIP_ERR_INVALID;
                 if ((bool)big[(size_t)tjob[(size_t)t]] != want_big) continue;
                 tmap[(size_t)t] = (int)P.toff.size() - 1;
                 P.coeffs.insert(P.coeffs.end(), {p_coeffs[2 * t], p_coeffs[2 * t + 1]});
@@ -503,10 +506,13 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
             P.plan.common_offsets = P.gcoff.data();
             P.plan.common_mle_idx = P.gcidx.data();
             P.plan.max_degree = D;
+            return 0;
         };
         Pack PB, PS;
-        make_pack(true, PB);
-        if (any_small) make_pack(false, PS);
+        if (make_pack(true, PB) || (any_small && make_pack(false, PS))) {
+            cleanup();
+            return prover_set_error(CENO_HIP_ERR_INVALID, "main constraints: a monomial without factors belongs to no chip (empty product)");
+        }
         ceno_hip_sumcheck *sc = nullptr, *sc2 = nullptr, *scs = nullptr;
         auto drop = [&]() {
             if (sc) ceno_hip_sumcheck_free(ctx, sc);

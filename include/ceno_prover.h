@@ -433,6 +433,10 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
  * attach, and may unlink the name once all have (the mappings stay valid). */
 int ceno_dist_comm_attach_shm(ceno_dist_comm** c, int world, int rank, const char* name, int create);
 int ceno_dist_shm_unlink(const char* name);
+/* Raise the segment's abort word: every rank that waits for a peer in a shared-memory exchange returns an error at once (instead of after
+ * CENO_DIST_SHM_TIMEOUT_S, default 60 s of wall clock).  What a rank calls when ITS part of a collective entry failed before it published —
+ * the library does it itself on the errors it raises inside an exchange and on a time-out.  The communicator is unusable afterwards. */
+int ceno_dist_comm_abort(ceno_dist_comm* c);
 int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters);
 /* Mixed-size (front-loaded) batched sumcheck across ranks (BASELINE config #4): every size class is
  * split along the top bits of ITS OWN hypercube or replicated; needs the shared-memory exchange.  Term MLE ids are

@@ -8,6 +8,8 @@ import tempfile
 import numpy as np
 import pytest
 
+from tests.ranks import run_ranks
+
 from oracle import pyoracle as po
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,13 +30,7 @@ def test_sharded_sumcheck_matches_unsharded(world, n_local):
 
     build.build_all()
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world * 7 + n_local), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n_local)], env=e))
-        for p in procs:
-            assert p.wait(timeout=300) == 0
+        run_ranks(world, [tmp, str(n_local)], deadline_s=300)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     k = 3
     n_total = n_local + world.bit_length() - 1
@@ -54,13 +50,7 @@ def test_sharded_batched_mixed_size_sumcheck_matches_unsharded(world, n_total):
 
     build.build_all()
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29650 + world * 7 + n_total), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n_total), "batched"], env=e))
-        for p in procs:
-            assert p.wait(timeout=300) == 0
+        run_ranks(world, [tmp, str(n_total), "batched"], deadline_s=300)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     tables, coeffs, terms, off = [], [], [], 0
     for c in batched_case(n_total):
@@ -83,13 +73,7 @@ def test_shared_memory_exchange_between_processes(world):
 
     build.build_all()
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + world), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "20000", "shm"], env=e))
-        for p in procs:
-            assert p.wait(timeout=300) == 0
+        run_ranks(world, [tmp, "20000", "shm"], deadline_s=300)
         for r in range(world):
             assert open(os.path.join(tmp, f"rank{r}.txt")).read() == "0"
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("ceno_dist_")]
@@ -104,13 +88,7 @@ def test_row_sharded_tower_proof_matches_unsharded(world, log2_n):
     from tests.dist_worker import chip_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29870 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG="2", OMP_NUM_THREADS="2")
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(log2_n), "chip_gloo"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, str(log2_n), "chip_gloo"], extra_env={"CENO_TEST_ROW_BLOCK_LOG": "2", "OMP_NUM_THREADS": "2"}, deadline_s=600)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     cols, coeffs, terms, out_terms, (alpha, beta), shape = chip_case(log2_n, w=6, shape=(2, 3, 0, 4))
     rows = 1 << log2_n
@@ -142,14 +120,8 @@ def test_row_sharded_rotation_argument_matches_unsharded(world, n, q, log2):
     from tests.dist_worker import rotation_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29850 + world + log2), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG=str(q),
-                   CENO_TEST_ROT_LOG=str(log2), OMP_NUM_THREADS="2")
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n), "rotation_gloo"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, str(n), "rotation_gloo"],
+                  extra_env={"CENO_TEST_ROW_BLOCK_LOG": str(q), "CENO_TEST_ROT_LOG": str(log2), "OMP_NUM_THREADS": "2"}, deadline_s=600)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     cols, pairs, subgroup, rt = rotation_case(n, log2)
     tr = po.StubTranscript(8)
@@ -171,13 +143,7 @@ def test_row_sharded_main_constraint_sumcheck_matches_unsharded(world, q):
     from tests.dist_worker import main_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29830 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG=str(q), OMP_NUM_THREADS="2")
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "0", "main_gloo"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, "0", "main_gloo"], extra_env={"CENO_TEST_ROW_BLOCK_LOG": str(q), "OMP_NUM_THREADS": "2"}, deadline_s=600)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     chips = main_case(world)
     tabs, terms, coeffs = [], [], []

@@ -9,6 +9,8 @@ import tempfile
 import numpy as np
 import pytest
 
+from tests.ranks import run_ranks
+
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -18,13 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("world,n_local", [(2, 9), (4, 7), (8, 5)])
 def test_cpp_sharded_driver_shared_memory_exchange(world, n_local):
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + world), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n_local), "shm_gpu"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, str(n_local), "shm_gpu"], deadline_s=600)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     k = 3
     n_total = n_local + world.bit_length() - 1
@@ -43,13 +39,7 @@ def test_cpp_batched_mixed_size_sharded_driver(world, n_total):
     from tests.dist_worker import batched_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + world), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(n_total), "shm_gpu_batched"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, str(n_total), "shm_gpu_batched"], deadline_s=600)
         res = [np.load(os.path.join(tmp, f"rank{r}.npz")) for r in range(world)]
     tables, coeffs, terms, off = [], [], [], 0
     for c in batched_case(n_total):
@@ -74,13 +64,7 @@ def test_sharded_commitment_and_opening_as_processes_on_one_gpu(world):
     from tests.dist_worker import open_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29970 + world), WORLD_SIZE=str(world))
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, "0", "shm_gpu_open"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, "0", "shm_gpu_open"], deadline_s=600)
         res = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(world)]
     dev = Device(0)
     heights, col_split, fulls = open_case(world)
@@ -108,13 +92,7 @@ def test_row_sharded_chip_proof_as_processes_on_one_gpu(world, log2_n):
     from tests.dist_worker import chip_case
 
     with tempfile.TemporaryDirectory() as tmp:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29980 + world), WORLD_SIZE=str(world), CENO_TEST_ROW_BLOCK_LOG="3")
-        procs = []
-        for rank in range(world):
-            e = dict(env, RANK=str(rank))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), tmp, str(log2_n), "shm_gpu_chip"], env=e))
-        for p in procs:
-            assert p.wait(timeout=600) == 0
+        run_ranks(world, [tmp, str(log2_n), "shm_gpu_chip"], extra_env={"CENO_TEST_ROW_BLOCK_LOG": "3"}, deadline_s=600)
         res = [dict(np.load(os.path.join(tmp, f"rank{r}.npz"))) for r in range(world)]
     dev = Device(0)
     cols, coeffs, terms, out_terms, challenges, shape = chip_case(log2_n)
