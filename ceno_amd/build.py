@@ -120,7 +120,7 @@ def build_sanitized(verbose: bool = True) -> dict:
     gcc, gxx = shutil.which("gcc") or "gcc", shutil.which("g++") or "g++"
     san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
     out = {}
-    osrcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "tower.c", "commit.c", "rotation.c", "basefold.c", "witgen.c", "transcript.c")]
+    osrcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "tower.c", "commit.c", "rotation.c", "basefold.c", "witgen.c", "transcript.c", "dense_avx512.c")]
     out["oracle_asan"] = os.path.join(osan, "libceno_oracle_asan.so")
     _run([gcc] + san + ["-march=x86-64-v3", "-fopenmp", "-fPIC", "-std=c11", "-shared", "-o", out["oracle_asan"]] + osrcs)
     hsrcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))

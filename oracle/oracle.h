@@ -145,6 +145,10 @@ void orc_recover_claim_from_final(const uint64_t* final_claim, const uint64_t* m
  * tables are consumed (folded in place). */
 int orc_sumcheck_dense_mt(uint64_t** tables, int k, int num_vars, const uint64_t* challenges, int threads,
                           uint64_t* out_msgs, uint64_t* out_final_evals);
+/* the same, eight pairs per AVX-512 vector (oracle/dense_avx512.c): identical outputs; -2 when the CPU lacks AVX-512 F + DQ */
+int orc_sumcheck_dense_mt_avx512(uint64_t** tables, int k, int num_vars, const uint64_t* challenges, int threads,
+                                 uint64_t* out_msgs, uint64_t* out_final_evals);
+int orc_have_avx512(void);
 
 /* ---- element-wise witness inference (a5, EXT wit_infer_by_monomial_expr;
  * gkr_iop/src/cpu/mod.rs:119-176) ---- */

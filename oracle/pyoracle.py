@@ -390,8 +390,12 @@ def dense_mt_workspace(k: int, n: int):
     return ping, pong
 
 
-def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, threads: int = 0, workspace=None):
-    """tables: k ext arrays (2^n,2). Inputs are not modified."""
+def have_avx512() -> bool:
+    return bool(lib().orc_have_avx512())
+
+
+def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, threads: int = 0, workspace=None, avx512: bool = False):
+    """tables: k ext arrays (2^n,2). Inputs are not modified.  avx512: the vector form (oracle/dense_avx512.c), same outputs"""
     k = len(tables)
     n = int(tables[0].shape[0]).bit_length() - 1
     bufs = [np.ascontiguousarray(t) for t in tables]
@@ -399,9 +403,10 @@ def sumcheck_dense_mt(tables: Sequence[np.ndarray], challenges: np.ndarray, thre
     ptrs = (u64p * (3 * k))(*[_p(b) for b in bufs + ping + pong])
     msgs = np.zeros((n, k, 2), dtype=np.uint64)
     fin = np.zeros((k, 2), dtype=np.uint64)
-    rc = lib().orc_sumcheck_dense_mt(ptrs, k, n, _p(np.ascontiguousarray(challenges)), threads, _p(msgs), _p(fin))
+    fn = lib().orc_sumcheck_dense_mt_avx512 if avx512 else lib().orc_sumcheck_dense_mt
+    rc = fn(ptrs, k, n, _p(np.ascontiguousarray(challenges)), threads, _p(msgs), _p(fin))
     if rc != 0:
-        raise ValueError(f"orc_sumcheck_dense_mt rc={rc}")
+        raise ValueError(f"orc_sumcheck_dense_mt{'_avx512' if avx512 else ''} rc={rc}")
     return msgs, fin
 
 

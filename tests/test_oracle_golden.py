@@ -414,3 +414,23 @@ def test_prove_rotation_messages_verify():
     rk = tuple(map(int, origin[log2 - 1]))
     rot = po.e2_add(po.e2_mul(po.e2_sub((1, 0), rk), tuple(map(int, evals[0]))), po.e2_mul(rk, tuple(map(int, evals[1]))))
     assert po.e2_mul(po.mle_evaluate(sel, origin), po.e2_sub(rot, tuple(map(int, evals[2])))) == expected
+
+
+@pytest.mark.parametrize("n,k", [(1, 3), (2, 1), (3, 3), (4, 2), (6, 3), (11, 3), (13, 4)])
+def test_dense_avx512_equals_scalar(n, k):
+    """bench.py's cpu_baseline times the AVX-512 form of the fused dense sumcheck (oracle/dense_avx512.c): its messages, folded tables' effect and
+    final evaluations must equal the scalar restatement's word for word (rounds of fewer than eight pairs run its scalar remainder)"""
+    if not po.have_avx512():
+        pytest.skip("this CPU has no AVX-512 F + DQ")
+    tabs = [po.rand_ext(1 << n, 900 + 7 * n + j) for j in range(k)]
+    ch = po.rand_ext(n, 31 + n)
+    for threads in (1, 3):
+        a = po.sumcheck_dense_mt(tabs, ch, threads=threads)
+        b = po.sumcheck_dense_mt(tabs, ch, threads=threads, avx512=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # edge values: all zero, all p - 1 (the largest canonical residue in both limbs)
+    for fill in (0, po.P - 1):
+        tabs = [np.full((1 << n, 2), fill, dtype=np.uint64) for _ in range(k)]
+        a = po.sumcheck_dense_mt(tabs, ch, threads=2)
+        b = po.sumcheck_dense_mt(tabs, ch, threads=2, avx512=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
