@@ -59,6 +59,32 @@ def _flags_changed() -> bool:
     return False
 
 
+def device_asm_path(src: str) -> str:
+    """gfx950 assembly of one .hip translation unit, as assembled into its object (kept by build_hip)"""
+    return os.path.join(OBJ, os.path.basename(src) + ".gfx950.s")
+
+
+def _keep_device_asm(src: str):
+    """after a -save-temps=obj compile: keep `<stem>-hip-amdgcn-amd-amdhsa-gfx950.s` as `<name>.hip.gfx950.s`, drop the other temporaries"""
+    stem = os.path.splitext(os.path.basename(src))[0]
+    dev = os.path.join(OBJ, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if os.path.exists(dev):
+        os.replace(dev, device_asm_path(src))
+    for f in glob.glob(os.path.join(OBJ, stem + "-hip-amdgcn-amd-amdhsa-gfx950.*")) + glob.glob(os.path.join(OBJ, stem + "-host-x86_64-unknown-linux-gnu.*")) + \
+            glob.glob(os.path.join(OBJ, os.path.basename(src) + "-hip-amdgcn-amd-amdhsa.hipfb")):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+
+
+def device_asm_files(build: bool = True):
+    """[(source, path of its gfx950 assembly)] for every .hip unit; builds what is missing or stale first"""
+    if build:
+        build_hip()
+    return [(s, device_asm_path(s)) for s in sorted(glob.glob(os.path.join(CSRC, "*.hip")))]
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     force = force or _flags_changed()
@@ -70,11 +96,19 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s) + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + HIP_FLAGS + ["-c", s, "-o", o])
+        if force or _stale(o, [s] + hdrs) or not os.path.exists(device_asm_path(s)):
+            # -save-temps=obj: the device assembly that is ASSEMBLED INTO this object is kept beside it (no second compile) — what
+            # tests/test_isa_lint.py reads: hand-written wait states inside `asm` statements are invisible to the compiler's hazard recogniser
+            jobs.append(([HIPCC] + HIP_FLAGS + ["-save-temps=obj", "-c", s, "-o", o], s))
     if jobs:
+        def compile_one(job):
+            cmd, src = job
+            out = _run(cmd)
+            _keep_device_asm(src)
+            return out
+
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
-            for out in ex.map(_run, jobs):
+            for out in ex.map(compile_one, jobs):
                 if verbose and out.strip():
                     print(out)
     if force or jobs or _stale(LIB_HIP, objs):
