@@ -174,6 +174,10 @@ struct ceno_dist_comm {
     bool h_recv_plain = false;
     struct ceno_dist_local_group* local = nullptr;  // in-process group of virtual ranks (threads sharing one device)
     int shares_device = -1;      // -1: not asked yet; 1: at least two ranks sit on one device (dist_comm_ranks_share_device)
+    // what this rank put on the wire since the last reset (ceno_dist_comm_stats): [0] message exchanges (per-round partial sums, gathered
+    // evaluations, digests: host words), [1] their bytes sent by this rank, [2] bulk exchanges (device buffers: codeword re-shard, gathered
+    // tables), [3] their bytes sent by this rank
+    uint64_t stats[4] = {0, 0, 0, 0};
 };
 
 int ceno_dist_unique_id(uint8_t* out128) {
@@ -351,6 +355,12 @@ int ceno_dist_comm_attach_shm(ceno_dist_comm** pc, int world, int rank, const ch
     c->shm_seq = 0;
     return 0;
 }
+int ceno_dist_comm_stats(ceno_dist_comm* c, uint64_t* out4, int reset) {
+    if (!c || !out4) return CENO_HIP_ERR_INVALID;
+    memcpy(out4, c->stats, sizeof c->stats);
+    if (reset) memset(c->stats, 0, sizeof c->stats);
+    return 0;
+}
 int ceno_dist_comm_abort(ceno_dist_comm* c) {
     if (!c) return CENO_HIP_ERR_INVALID;
     if (c->shm) c->shm->abort = 1;
@@ -360,6 +370,8 @@ int ceno_dist_shm_unlink(const char* name) { return name && shm_unlink(name) == 
 
 // all-gather `n_ext` extension elements per rank through the shared segment; result (world x n_ext) in c->h_recv
 static int shm_gather_ext(ceno_dist_comm* c, const uint64_t* mine, int n_ext) {
+    c->stats[0]++;
+    c->stats[1] += (uint64_t)n_ext * 16;
     if (n_ext > 64) {
         g_dist_err = "shm_gather_ext: more than 64 elements per rank";
         return CENO_HIP_ERR_INVALID;
@@ -430,6 +442,8 @@ int ceno_dist_shm_selftest(ceno_dist_comm* c, int iters) {
 
 // all-gather `n_ext` extension elements per rank from device buffer c->d_send; result (world x n_ext) in c->h_recv
 static int gather_ext(ceno_dist_comm* c, int n_ext, hipStream_t st) {
+    c->stats[0]++;
+    c->stats[1] += (uint64_t)n_ext * 16;
     if (n_ext > 64) {
         g_dist_err = "gather_ext: more than 64 elements per rank";
         return CENO_HIP_ERR_INVALID;
@@ -554,6 +568,19 @@ static int dist_tail(ceno_hip_ctx* ctx, ceno_dist_comm* c, const ceno_hip_sumche
 // Sharded rounds with the host shared-memory exchange: every rank runs the ordinary PIPELINED single-device round
 // loop over its shard (message to pinned host memory, challenge through the mailbox) and the only addition per round
 // is the ~1-2 us exchange of d ext partials between the host processes.  No device collective on the round path.
+extern "C++" bool dist_comm_ranks_share_device(ceno_dist_comm* c, hipStream_t st);  // below: from the ranks' host names + PCI bus ids
+// Rounds queued ahead of their challenges (pipelined) only where every rank has a device of its own.  Ranks that SHARE a device (several
+// processes on one GPU: tests, a dry run of the multi-rank flow) launch every round when its challenge is known: a queued round kernel spins
+// on the device until its challenge arrives, the challenge needs EVERY rank's message of the round before, and eight ranks' spinning kernels
+// leave no room for the one kernel all of them wait for — found the first time the nv = 26 hypercube was split over 8 processes on one device
+// (tests/test_gpu_dist_at_size.py): "sumcheck round finished without publishing its message (round 8 of 23)" after the 60 s pipe time-out;
+// the toy sizes of the earlier tests ran those rounds on the host tail and never met it.  CENO_DIST_PIPELINE=1 / 0 overrides.
+static bool dist_rounds_pipelined(ceno_dist_comm* c, hipStream_t st) {
+    const bool shared = dist_comm_ranks_share_device(c, st);  // (collective: asked on every rank whatever the override says)
+    const char* e = getenv("CENO_DIST_PIPELINE");
+    return e ? atoi(e) != 0 : !shared;
+}
+
 static int dist_prove_shm(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* const* mles, const ceno_hip_sumcheck_plan* plan_local,
                           int n_total, int n_local, int log_w, ceno_transcript* tr, ceno_hip_stream s, uint64_t* out_msgs,
                           uint64_t* out_challenges, uint64_t* out_final_evals) {
@@ -568,7 +595,7 @@ static int dist_prove_shm(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle* co
         g_dist_err = ceno_hip_last_error(ctx);
         return rc;
     }
-    ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);
+    if (dist_rounds_pipelined(c, (hipStream_t)s)) ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);
     uint64_t ch[2] = {0, 0};
     std::vector<uint64_t> part(2 * (size_t)d), msg(2 * (size_t)d);
     for (int r = 0; r < n_local && !rc; r++) {
@@ -1047,6 +1074,9 @@ static int shm_exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const si
 int exchange_blocks(ceno_dist_comm* c, const uint64_t* send, const size_t* soff, const size_t* scnt, uint64_t* recv, const size_t* roff,
                     const size_t* rcnt, hipStream_t st) {
     const int W = c->world, me = c->rank;
+    c->stats[2]++;
+    for (int g = 0; g < W; g++)
+        if (g != me) c->stats[3] += (uint64_t)scnt[g] * 8;
     if (scnt[me] != rcnt[me]) return dist_fail(CENO_HIP_ERR_INVALID, "exchange_blocks: own block size mismatch");
     if (c->local) {
         ceno_dist_local_group* G = c->local;
@@ -1170,6 +1200,8 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
         return 0;
     }
     const int W = c->world;
+    c->stats[0]++;   // one message exchange, whatever it is chunked into underneath
+    c->stats[1] += (uint64_t)n_words * 8;
     if (c->shm && !c->local) {  // the shared segment's bulk area: up to SHM_BULK_WORDS words per exchange
         for (size_t off = 0; off < n_words; off += SHM_BULK_WORDS) {
             const size_t nb = std::min<size_t>(SHM_BULK_WORDS, n_words - off);
@@ -1197,6 +1229,8 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
         } else if (c->comm) {
             if (hipMemcpyAsync(c->d_send, buf, sizeof buf, hipMemcpyHostToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "allgather: upload failed");
             if (int rc = gather_ext(c, 64, st)) return rc;
+            c->stats[0]--;   // (gather_ext counted the chunk: the exchange was counted once above)
+            c->stats[1] -= 64 * 16;
             for (int r = 0; r < W; r++) memcpy(out + (size_t)r * n_words + off, c->h_recv + (size_t)r * 128, n * 8);
         } else {
             return dist_fail(CENO_HIP_ERR_STATE, "allgather: communicator without a transport");
@@ -1208,6 +1242,10 @@ int dist_allgather_words(ceno_dist_comm* c, const uint64_t* mine, size_t n_words
 // all-gather of `n_words` words per rank between DEVICE buffers over the communicator's bulk transport (in-process group: device copies; RCCL:
 // grouped send / recv): recv[g * n_words ..] = rank g's block
 int dist_allgather_device(ceno_dist_comm* c, const uint64_t* send_dev, size_t n_words, uint64_t* recv_dev, hipStream_t st) {
+    if (c) {
+        c->stats[2]++;
+        c->stats[3] += (uint64_t)n_words * 8;
+    }
     if (!c || c->world == 1) {
         if (n_words && hipMemcpyAsync(recv_dev, send_dev, n_words * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) return dist_fail(CENO_HIP_ERR_HIP, "allgather: device copy failed");
         return 0;

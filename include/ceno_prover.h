@@ -433,6 +433,10 @@ int ceno_dist_sumcheck_prove(ceno_hip_ctx* ctx, ceno_dist_comm* c, ceno_hip_mle*
  * attach, and may unlink the name once all have (the mappings stay valid). */
 int ceno_dist_comm_attach_shm(ceno_dist_comm** c, int world, int rank, const char* name, int create);
 int ceno_dist_shm_unlink(const char* name);
+/* What THIS rank put on the wire through the communicator since the last reset: out4 = [message exchanges (per-round partial sums, gathered
+ * evaluations / tables, digests: host words over the small-message transport), bytes this rank sent in them, bulk exchanges (device buffers: the
+ * codeword re-shard, gathered blocks), bytes this rank sent in them].  The per-rank critical path of DESIGN.md section 6 is read from these. */
+int ceno_dist_comm_stats(ceno_dist_comm* c, uint64_t* out4, int reset);
 /* Raise the segment's abort word: every rank that waits for a peer in a shared-memory exchange returns an error at once (instead of after
  * CENO_DIST_SHM_TIMEOUT_S, default 60 s of wall clock).  What a rank calls when ITS part of a collective entry failed before it published —
  * the library does it itself on the errors it raises inside an exchange and on a time-out.  The communicator is unusable afterwards. */

@@ -3,6 +3,7 @@
 the product engine is HipShardEngine)."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -183,13 +184,30 @@ def main_shm_gpu(out_dir, n_local):
     dist = FileRendezvous(out_dir, rank, world)
     dev = Device(0)
     k = 3
-    tables = [po.fill_splitmix(2 << n_local, 0xCE10 + j, rank * 2 * (1 << n_local)).reshape(-1, 2) for j in range(k)]
-    mles = [dev.upload(t) for t in tables]
+    if n_local >= 16:  # at size: shard `rank` of the SplitMix stream generated on the device (the same words as fill_splitmix at this offset)
+        mles = [dev.synthetic(n_local, True, 0xCE10 + j, word_offset=rank * 2 * (1 << n_local)) for j in range(k)]
+        dev.sync()
+    else:
+        tables = [po.fill_splitmix(2 << n_local, 0xCE10 + j, rank * 2 * (1 << n_local)).reshape(-1, 2) for j in range(k)]
+        mles = [dev.upload(t) for t in tables]
     comm = prover.ShmComm(world, rank, dist)
     stream = dev.stream_create()
     n_total = n_local + world.bit_length() - 1
-    msgs, chal, fin = prover.dist_sumcheck_prove(dev, comm, mles, po.ext([1]), [list(range(k))], n_total, k, prover.Transcript.stub(0xF5), stream)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=msgs, chal=chal, fin=fin)
+    reps = int(os.environ.get("CENO_TEST_DIST_REPS", "1"))
+    walls = []
+    for _ in range(reps):
+        dist.barrier()
+        t0 = time.time()
+        msgs, chal, fin = prover.dist_sumcheck_prove(dev, comm, mles, po.ext([1]), [list(range(k))], n_total, k, prover.Transcript.stub(0xF5), stream)
+        walls.append(time.time() - t0)
+    import ctypes as C
+
+    L = prover.plib()
+    L.ceno_dist_comm_stats.restype = C.c_int
+    L.ceno_dist_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    st4 = (C.c_uint64 * 4)()
+    L.ceno_dist_comm_stats(comm.h, st4, 0)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), msgs=msgs, chal=chal, fin=fin, wall_s=np.array(walls), wire=np.array(list(st4), dtype=np.uint64) // reps)
     dist.barrier()
     comm.close()
     dist.destroy_process_group()

@@ -43,6 +43,18 @@ def record_plan(w, n_records, alpha, beta):
     return po.ext(coeffs), terms, out_terms
 
 
+def comm_stats(prover, comm, reset=False):
+    """ceno_dist_comm_stats of a communicator handle: what this rank put on the wire"""
+    import ctypes as C
+
+    L = prover.plib()
+    L.ceno_dist_comm_stats.restype = C.c_int
+    L.ceno_dist_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+    out = (C.c_uint64 * 4)()
+    assert L.ceno_dist_comm_stats(comm, out, int(reset)) == 0
+    return dict(message_exchanges=int(out[0]), message_bytes_sent=int(out[1]), bulk_exchanges=int(out[2]), bulk_bytes_sent=int(out[3]))
+
+
 def proofs_equal(a, b):
     return (np.array_equal(a.tower_msgs, b.tower_msgs) and np.array_equal(a.tower_point, b.tower_point) and
             np.array_equal(a.tower_prod_evals, b.tower_prod_evals) and np.array_equal(a.tower_logup_evals, b.tower_logup_evals) and
@@ -544,6 +556,10 @@ def test_gkr_half_and_main_constraints_of_one_chip_on_one_row_layout(dev, prover
 
 @pytest.mark.parametrize("world,log2_n,q,transcript", [(2, 10, 4, "stub"), (4, 11, 3, "poseidon2")])
 def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover, world, log2_n, q, transcript):
+    whole_chip_flow(dev, prover, world, log2_n, q, transcript)
+
+
+def whole_chip_flow(dev, prover, world, log2_n, q, transcript, w=9, shape=(4, 4, 0, 8), stats=None):
     """config #3's flow with every phase across the ranks on ONE transcript: the commitment (column shards; ceno_dist_commit_traces_mmcs), its root
     into the transcript, two challenges out, the chip proof (row shards, block layout; ceno_dist_create_chip_proof), the main-constraint sumcheck
     at its rt_main (same row shards; ceno_dist_prove_batched_main_constraints), the opening of the commitment at the sumcheck's point with the
@@ -554,7 +570,7 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
 
     from ceno_amd import dist as cdist
 
-    shape, w, blow, nq, pow_bits = (4, 4, 0, 8), 9, 1, 8, 3
+    blow, nq, pow_bits = 1, 8, 3
     rows, k = 1 << log2_n, world.bit_length() - 1
     n_rec = shape[0] + shape[1] + shape[3]
     cols = [po.rand_base(rows, 900 + j) for j in range(w)]
@@ -569,6 +585,12 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
         def lap(what):
             if os.environ.get("CENO_TEST_TIMING"):
                 print(f"[flow {log2_local}] {what}: {_t.time() - _t0:.2f} s", flush=True)
+        laps = {}
+        _lap = lap
+
+        def lap(what):  # noqa: F811
+            laps[what] = _t.time() - _t0
+            _lap(what)
         tr = new_tr()
         root, commit_state = commit_fn()
         lap("commit")
@@ -588,6 +610,7 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
         lap("main")
         opening = open_fn(commit_state, [np.ascontiguousarray(main[2][:log2_n])], [np.ascontiguousarray(main[3][:w])], tr)
         lap("open")
+        flow.laps = laps
         return root, proof, main, opening
 
     stream = dev.stream_create()
@@ -601,7 +624,9 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
     want = flow(full, log2_n, commit_single, lambda task, ch, tr: prover.create_chip_proof(dev, task, ch, tr),
                 lambda jobs, ch, tr: prover.prove_batched_main_constraints(dev, jobs, ch, tr),
                 lambda pcs, pts, evs, tr: pcs.basefold_open(pts, evs, nq, pow_bits, tr))
+    single_laps = dict(flow.laps)
     group = prover.LocalGroup(world)
+    rank_stats = [None] * world
     results, errors = [None] * world, []
 
     def rank_main(g):
@@ -625,6 +650,7 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
                                                                                   [x.data_ptr() for x in com["codeword_rows"]], com["subtree"], com["top"], pts,
                                                                                   evs, nq, pow_bits, tr, st))
             dev.sync(st)
+            rank_stats[g] = comm_stats(prover, group.comms[g])
         except Exception as e:  # noqa: BLE001
             import traceback
 
@@ -634,12 +660,14 @@ def test_whole_chip_flow_across_ranks_equals_the_single_device_flow(dev, prover,
     for t_ in ths:
         t_.start()
     for t_ in ths:
-        t_.join(300)
+        t_.join(600)
     alive = any(t_.is_alive() for t_ in ths)
     if not alive:
         group.close()
     assert not alive, "a virtual rank hangs"
     assert not errors, errors
+    if stats is not None:
+        stats.update(single_device_s=single_laps, rank0_wire=rank_stats[0], world=world, log2_n=log2_n, q=q, w=w)
     for g in range(world):
         root, proof, main, opening = results[g]
         assert np.array_equal(root, want[0]), f"rank {g}: commitment root"
