@@ -163,6 +163,7 @@ def lib():
         "ceno_hip_merkle_open": (i, [vp, vp, sz, u64p, vp]),
         "ceno_hip_merkle_free": (i, [vp, vp]),
         "ceno_hip_batch_columns": (i, [vp, vp, sz, i, u64p, vp, i, vp]),
+        "ceno_hip_batch_columns_multi": (i, [vp, i, vpp, C.POINTER(sz), C.POINTER(i), u64p, vpp, C.POINTER(i), vp]),
         "ceno_hip_basefold_fold_commit": (i, [vp, vp, i, u64p, vp, vp, vp, C.POINTER(vp)]),
         "ceno_hip_basefold_commit_codeword": (i, [vp, vp, i, vp, C.POINTER(vp)]),
         "ceno_hip_basefold_fold": (i, [vp, vp, i, u64p, vp, vp, vp]),

@@ -11,6 +11,10 @@
 //                   this round), fold it with the round challenge, add the codeword that joins at the next height
 //   k_gather        query answers: rows / siblings / authentication paths gathered on device, one D2H copy
 //   k_pow_grind     proof-of-work search, one Poseidon2 permutation per candidate
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
 #include "merkle.hpp"
 
 using namespace gl;
@@ -78,6 +82,48 @@ __global__ void __launch_bounds__(NT) k_batch_cols(const uint64_t* __restrict__ 
             E2 r{acc5_reduce(a0), acc5_reduce(a1)};
             if (accumulate) r = r + acc[i];
             acc[i] = r;
+        }
+    }
+}
+
+// the same for MANY (columns, accumulator) jobs of different lengths in ONE launch (the opening batches ~60 trace matrices and ~12 codeword classes:
+// one launch + one synchronisation each was 3 of its 8 ms): block b works on job blk[b].job as its blk[b].idx-th of jobs[job].n_blocks blocks
+struct BatchJob {
+    const uint64_t* cols;
+    E2* acc;
+    size_t len;
+    uint32_t n_cols, coeff0, n_blocks, accumulate;
+};
+struct BatchBlk {
+    uint32_t job, idx;
+};
+__global__ void __launch_bounds__(NT) k_batch_cols_multi(const BatchJob* __restrict__ jobs, const BatchBlk* __restrict__ blk, const E2* __restrict__ coeffs) {
+    __shared__ E2 sc[COEFF_CHUNK];
+    const BatchBlk B = blk[blockIdx.x];
+    const BatchJob J = jobs[B.job];
+    const uint64_t* __restrict__ cols = J.cols;
+    const size_t len = J.len, stride = (size_t)J.n_blocks * NT;
+    const size_t rounds = (len + stride - 1) / stride;
+    for (size_t it = 0; it < rounds; it++) {
+        const size_t i = it * stride + (size_t)B.idx * NT + threadIdx.x;
+        Acc5 a0{0, 0, 0, 0, 0}, a1{0, 0, 0, 0, 0};
+        for (uint32_t c0 = 0; c0 < J.n_cols; c0 += COEFF_CHUNK) {
+            const int nc = (int)min((uint32_t)COEFF_CHUNK, J.n_cols - c0);
+            __syncthreads();
+            for (int k = threadIdx.x; k < nc; k += NT) sc[k] = coeffs[J.coeff0 + c0 + k];
+            __syncthreads();
+            if (i < len) {
+                for (int k = 0; k < nc; k++) {
+                    const uint64_t v = cols[(size_t)(c0 + k) * len + i];
+                    acc5_add(a0, mul_wide(sc[k].c0, v));
+                    acc5_add(a1, mul_wide(sc[k].c1, v));
+                }
+            }
+        }
+        if (i < len) {
+            E2 r{acc5_reduce(a0), acc5_reduce(a1)};
+            if (J.accumulate) r = r + J.acc[i];
+            J.acc[i] = r;
         }
     }
 }
@@ -288,6 +334,67 @@ int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t l
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // the coefficient buffer goes back to the pool
     ctx_free(ctx, d_coeff);
     if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "batch_columns: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int ceno_hip_batch_columns_multi(ceno_hip_ctx* ctx, int n_jobs, const uint64_t* const* dev_cols, const size_t* lens, const int* n_cols,
+                                 const uint64_t* coeffs_ext, uint64_t* const* dev_acc_ext, const int* accumulate, ceno_hip_stream s) {
+    CHECK_ARG(ctx, n_jobs >= 1 && dev_cols && lens && n_cols && coeffs_ext && dev_acc_ext, "bad batch_columns_multi arguments");
+    size_t total_cols = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        CHECK_ARG(ctx, dev_cols[j] && dev_acc_ext[j] && lens[j] >= 1 && n_cols[j] >= 1, "batch_columns_multi: empty job %d", j);
+        total_cols += (size_t)n_cols[j];
+    }
+    for (size_t i = 0; i < 2 * total_cols; i++) CHECK_ARG(ctx, coeffs_ext[i] < gl::P, "batch coefficient word %zu is not canonical", i);
+    // jobs that ADD to an accumulator run after the job that wrote it: wave w = how many earlier jobs name the same accumulator
+    std::vector<int> wave((size_t)n_jobs, 0);
+    int n_waves = 1;
+    for (int j = 0; j < n_jobs; j++) {
+        for (int i = 0; i < j; i++)
+            if (dev_acc_ext[i] == dev_acc_ext[j]) wave[(size_t)j]++;
+        CHECK_ARG(ctx, (wave[(size_t)j] == 0) == !(accumulate && accumulate[j]), "batch_columns_multi: job %d: the first job of an accumulator writes it, later ones add", j);
+        n_waves = std::max(n_waves, wave[(size_t)j] + 1);
+    }
+    std::vector<BatchJob> jobs((size_t)n_jobs);
+    std::vector<std::vector<BatchBlk>> blks((size_t)n_waves);
+    size_t c0 = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const uint32_t nb = (uint32_t)std::min<size_t>((lens[j] + NT - 1) / NT, MAXB);
+        jobs[(size_t)j] = BatchJob{dev_cols[j], (E2*)dev_acc_ext[j], lens[j], (uint32_t)n_cols[j], (uint32_t)c0, nb, (uint32_t)(wave[(size_t)j] > 0)};
+        for (uint32_t b = 0; b < nb; b++) blks[(size_t)wave[(size_t)j]].push_back(BatchBlk{(uint32_t)j, b});
+        c0 += (size_t)n_cols[j];
+    }
+    size_t n_blk = 0;
+    for (auto& w : blks) n_blk += w.size();
+    // one upload: [jobs][blocks of every wave][coefficients]
+    const size_t off_blk = (sizeof(BatchJob) * (size_t)n_jobs + 15) & ~(size_t)15, off_co = (off_blk + sizeof(BatchBlk) * n_blk + 15) & ~(size_t)15;
+    const size_t bytes = off_co + total_cols * 16;
+    std::vector<unsigned char> host(bytes);
+    memcpy(host.data(), jobs.data(), sizeof(BatchJob) * (size_t)n_jobs);
+    {
+        size_t o = off_blk;
+        for (auto& w : blks) {
+            memcpy(host.data() + o, w.data(), sizeof(BatchBlk) * w.size());
+            o += sizeof(BatchBlk) * w.size();
+        }
+    }
+    memcpy(host.data() + off_co, coeffs_ext, total_cols * 16);
+    hipStream_t st = ctx_stream(ctx, s);
+    void* d = nullptr;
+    TRY(ctx_alloc(ctx, bytes, &d));
+    hipError_t e = hipMemcpyAsync(d, host.data(), bytes, hipMemcpyHostToDevice, st);  // (pageable source: the copy is staged before the call returns)
+    size_t o = off_blk;
+    for (auto& w : blks) {
+        if (e == hipSuccess && !w.empty()) {
+            hipLaunchKernelGGL(k_batch_cols_multi, dim3((unsigned)w.size()), dim3(NT), 0, st, (const BatchJob*)d, (const BatchBlk*)((const char*)d + o),
+                               (const E2*)((const char*)d + off_co));
+            e = hipGetLastError();
+        }
+        o += sizeof(BatchBlk) * w.size();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // the job table goes back to the pool (ONE synchronisation for all the jobs)
+    ctx_free(ctx, d);
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "batch_columns_multi: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -256,7 +256,16 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
     std::vector<E2> S(n_mats);
     {
         // codewords: one pass per height CLASS of every commitment (its matrices are stored back to back, so the class is one
-        // wide column-major matrix); the class's coefficients are gathered from the flat order
+        // wide column-major matrix); the class's coefficients are gathered from the flat order.
+        // Single device: every class codeword and every F_m is a JOB of one batched launch (ceno_hip_batch_columns_multi) and the eq tables of all
+        // opening points come from one batched build (ceno_hip_selector_build_batch, Whole = eq(., point)) — a shard of the reference's population
+        // has ~60 matrices in ~12 height classes, and a launch + a synchronisation per matrix was 3 of the opening's 8 ms.  With a hook
+        // (multi-rank opening) the pieces are gathered across ranks one by one as before.
+        std::vector<const uint64_t*> j_cols;
+        std::vector<size_t> j_len;
+        std::vector<int> j_ncols, j_acc;
+        std::vector<uint64_t> j_coeffs;
+        std::vector<uint64_t*> j_dst;
         size_t m0 = 0;
         for (int c = 0; c < n_commits; c++) {
             ceno_pcs_data* d = commits[c];
@@ -275,8 +284,14 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                     fresh = 1;
                 }
                 if (!rc && hook) rc = hook->batch_codeword(hook->self, c, (int)k, cc.data(), ceno_hip_mle_device_ptr(B[h]), h, fresh ? 0 : 1, s);
-                else if (!rc) rc = ceno_hip_batch_columns(ctx, ceno_hip_mle_device_ptr(K.codeword), (size_t)1 << h, (int)K.width, cc.data(),
-                                                          ceno_hip_mle_device_ptr(B[h]), fresh ? 0 : 1, s);
+                else if (!rc) {
+                    j_cols.push_back(ceno_hip_mle_device_ptr(K.codeword));
+                    j_len.push_back((size_t)1 << h);
+                    j_ncols.push_back((int)K.width);
+                    j_acc.push_back(fresh ? 0 : 1);
+                    j_dst.push_back(ceno_hip_mle_device_ptr(B[h]));
+                    j_coeffs.insert(j_coeffs.end(), cc.begin(), cc.end());
+                }
                 if (rc) return fail(rc);
             }
             m0 += d->mats.size();
@@ -290,10 +305,15 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                 for (int c2 = 0; c2 < n_commits; c2++)
                     if (commits[c2] == flat[m].d) ci_commit = c2;
                 rc = hook->batch_trace(hook->self, ci_commit, flat[m].m, coeff.data() + 2 * ci, ceno_hip_mle_device_ptr(F[m]), s);
-            } else if (!rc)
-                rc = ceno_hip_batch_columns(ctx, flat[m].d->trace_ptr(flat[m].m), M.rows, (int)M.width, coeff.data() + 2 * ci,
-                                            ceno_hip_mle_device_ptr(F[m]), 0, s);
-            if (!rc) {
+            } else if (!rc) {
+                j_cols.push_back(flat[m].d->trace_ptr(flat[m].m));
+                j_len.push_back(M.rows);
+                j_ncols.push_back((int)M.width);
+                j_acc.push_back(0);
+                j_dst.push_back(ceno_hip_mle_device_ptr(F[m]));
+                j_coeffs.insert(j_coeffs.end(), coeff.begin() + 2 * ci, coeff.begin() + 2 * (ci + M.width));
+            }
+            if (!rc && hook) {
                 rc = ceno_hip_eq_build(ctx, points[m], M.log_rows, nullptr, s, &Eq[m]);
                 if (!rc) owned.push_back(Eq[m]);
             }
@@ -303,6 +323,18 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                 acc = acc + E2{coeff[2 * (ci + c)], coeff[2 * (ci + c) + 1]} * E2{evals[m][2 * c], evals[m][2 * c + 1]};
             S[m] = acc;
             groups[M.log_rows].mats.push_back(m);
+        }
+        if (!hook) {
+            (void)ceno_hip_stream_bind(ctx, s);
+            int rc = ceno_hip_batch_columns_multi(ctx, (int)j_cols.size(), j_cols.data(), j_len.data(), j_ncols.data(), j_coeffs.data(), j_dst.data(),
+                                                  j_acc.data(), s);
+            if (rc) return fail(rc);
+            std::vector<int> kinds((size_t)n_mats, CENO_HIP_SEL_WHOLE), nvs((size_t)n_mats);
+            std::vector<size_t> zero((size_t)n_mats, 0);
+            for (int m = 0; m < n_mats; m++) nvs[(size_t)m] = flat[m].d->mats[flat[m].m].log_rows;
+            rc = ceno_hip_selector_build_batch(ctx, n_mats, kinds.data(), points, nvs.data(), zero.data(), zero.data(), s, Eq.data());
+            if (rc) return fail(rc);
+            for (int m = 0; m < n_mats; m++) owned.push_back(Eq[m]);
         }
     }
     lap("batching");
@@ -338,9 +370,27 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
         if (rc) return fail(rc);
     }
     auto t_round = std::chrono::steady_clock::now();
+    // Several height groups (a shard's commitment: ~10): every live group's handle has tables of the SAME current size in round r (suffix
+    // alignment: n - r variables left), and their round kernels do not depend on each other — while the tables are large the rounds of all live
+    // groups are queued back to back with their messages left on the device (ceno_hip_sumcheck_round_dev) and fetched by ONE copy + wait, instead of
+    // a launch and a wait per group; from 2^8 entries down the handles finish on the host as before (no device trip at all).
+    // CENO_BASEFOLD_GROUP_ASYNC=0: the old one-by-one rounds (A/B)
+    static const bool group_async_on = !(getenv("CENO_BASEFOLD_GROUP_ASYNC") && atoi(getenv("CENO_BASEFOLD_GROUP_ASYNC")) == 0);
+    const bool group_async = group_async_on && !hook && groups.size() > 1;
+    ceno_hip_mle* round_buf = nullptr;
+    std::vector<uint64_t> round_host;
+    if (group_async) {
+        (void)ceno_hip_stream_bind(ctx, s);
+        int nvb = 1;
+        while (((size_t)1 << nvb) < 2 * groups.size() + 2) nvb++;
+        if (int rc = alloc_ext(nvb, &round_buf)) return fail(rc);
+        round_host.resize(4 * groups.size());
+    }
     for (int r = 0; r < n; r++) {
         const int h = H - r;
         E2 p1 = gl::e2_zero(), p2 = gl::e2_zero();
+        const bool async_round = group_async && (n - r) > 8;
+        int n_async = 0;
         for (auto& kv : groups) {
             Group& g = kv.second;
             const int s_m = n - kv.first;
@@ -386,10 +436,25 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                 g.started = true;
             }
             uint64_t ev[4];
+            if (!rc && async_round) {
+                rc = ceno_hip_sumcheck_round_dev(ctx, g.sc, (r - s_m) == 0 ? nullptr : &ch[2 * (r - 1)], ceno_hip_mle_device_ptr(round_buf) + 4 * n_async);
+                n_async++;
+                if (rc) return fail(rc);
+                continue;
+            }
             if (!rc) rc = ceno_hip_sumcheck_round(ctx, g.sc, (r - s_m) == 0 ? nullptr : &ch[2 * (r - 1)], ev);
             if (rc) return fail(rc);
             p1 = p1 + E2{ev[0], ev[1]};
             p2 = p2 + E2{ev[2], ev[3]};
+        }
+        if (n_async) {
+            if (hipMemcpyAsync(round_host.data(), ceno_hip_mle_device_ptr(round_buf), (size_t)32 * n_async, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return fail(CENO_HIP_ERR_HIP, "download of the round messages failed");
+            for (int a = 0; a < n_async; a++) {
+                p1 = p1 + E2{round_host[4 * a], round_host[4 * a + 1]};
+                p2 = p2 + E2{round_host[4 * a + 2], round_host[4 * a + 3]};
+            }
         }
         msgs[4 * r] = p1.c0; msgs[4 * r + 1] = p1.c1; msgs[4 * r + 2] = p2.c0; msgs[4 * r + 3] = p2.c1;
         tr_ext(tr, p1);

@@ -384,6 +384,13 @@ int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
  * coefficients from the host, ext accumulator of length `len` on the device.  Synchronises the stream. */
 int ceno_hip_batch_columns(ceno_hip_ctx* ctx, const uint64_t* dev_cols, size_t len, int n_cols, const uint64_t* coeffs_ext,
                            uint64_t* dev_acc_ext, int accumulate, ceno_hip_stream s);
+/* n_jobs such batchings of different lengths in ONE launch (per wave of accumulation) and one synchronisation: job j reads n_cols[j] columns of
+ * length lens[j] at dev_cols[j] with the next n_cols[j] coefficients of coeffs_ext (jobs' coefficients back to back, 2 words each) into
+ * dev_acc_ext[j].  The first job that names an accumulator writes it (accumulate[j] = 0), later ones add to it (accumulate[j] = 1) and run in a
+ * launch of their own after it.  What the opening's batching phase is: the batched codeword per height class and F_m per matrix
+ * (ceno_recursion_v2/src/pcs/mod.rs:1130-1180).  Synchronises the stream once. */
+int ceno_hip_batch_columns_multi(ceno_hip_ctx* ctx, int n_jobs, const uint64_t* const* dev_cols, const size_t* lens, const int* n_cols,
+                                 const uint64_t* coeffs_ext, uint64_t* const* dev_acc_ext, const int* accumulate, ceno_hip_stream s);
 /* out[i] = sum over b < n_blocks of in[b * len + i] (mod p), extension elements: the modular all-reduce of per-rank partial batchings
  * after an all-gather (the multi-rank opening, ceno_dist_basefold_open).  Asynchronous on `s`. */
 int ceno_hip_ext_sum_blocks(ceno_hip_ctx* ctx, const uint64_t* dev_in_ext, int n_blocks, size_t len, uint64_t* dev_out_ext, ceno_hip_stream s);
