@@ -163,6 +163,74 @@ def check_sumcheck_on_oracle(g):
     assert chal.tolist() == s["challenges"] and fin.tolist() == s["final_evals"]
 
 
+def _flat_numbers(x):
+    """every integer of a JSON value, in document order (the reference's serde layouts are not known here: proofs are compared as word sequences)"""
+    if isinstance(x, bool):
+        return []
+    if isinstance(x, int):
+        return [x]
+    if isinstance(x, (list, tuple)):
+        return [v for e in x for v in _flat_numbers(e)]
+    if isinstance(x, dict):
+        return [v for e in x.values() for v in _flat_numbers(e)]
+    return []
+
+
+def _contains_run(hay, needle):
+    n = len(needle)
+    if n == 0:
+        return True
+    first = needle[0]
+    return any(hay[i] == first and hay[i: i + n] == needle for i in range(len(hay) - n + 1))
+
+
+def _section(g, key):
+    if key not in g:
+        pytest.xfail(f"PARITY UNPINNED: the goldens file has no '{key}' section (dumped with an older tools/goldens/dump_goldens.rs)")
+    return g[key]
+
+
+def check_tower_on_oracle(g):
+    """CpuTowerProver::create_proof (scheme/cpu/mod.rs:346-554) on one product and one LogUp spec: the point, every round message and every
+    per-layer evaluation of the oracle's tower prover under the real transcript"""
+    t = _section(g, "tower")
+    prod_last = [np.array(l, dtype=np.uint64) for l in t["prod_last_layer"]]
+    p_last = [np.array(l, dtype=np.uint64) for l in t["logup_p_last_layer"]]
+    q_last = [np.array(l, dtype=np.uint64) for l in t["logup_q_last_layer"]]
+    prod = po.infer_tower_product_witness(int(prod_last[0].shape[0]).bit_length(), prod_last)
+    logup = po.infer_tower_logup_witness(p_last, q_last)
+    proof = po.tower_prove([prod], [logup], _HostTranscriptForOracle(t["label"].encode()))
+    nv = max(len(prod), len(logup))
+    assert proof.point[:nv].tolist() == t["point"], "tower point differs from CpuTowerProver::create_proof"
+    ref = _flat_numbers(t["proof"])
+    if ref:
+        off = 0
+        for r in range(1, nv):  # the messages of every layer's sumcheck appear in the reference proof as one run of words
+            words = proof.msgs[off: off + 6 * r].tolist()
+            assert _contains_run(ref, words), f"tower layer {r}: round messages not found in the reference's TowerProofs"
+            off += 6 * r
+
+
+def check_rotation_on_oracle(g):
+    r = _section(g, "rotation")
+    table = np.array(r["table"], dtype=np.uint64)
+    assert po.rotation_next_base_mle(table, r["cyclic_group_log2"]).tolist() == r["rotated"], "rotation_next_base_mle"
+    eq = po.build_eq(np.array(r["point"], dtype=np.uint64))
+    assert po.rotation_selector(eq, r["cyclic_subgroup_size"], r["cyclic_group_log2"]).tolist() == r["selector"], "rotation_selector"
+
+
+def check_mixed_size_sumcheck_on_oracle(g):
+    """IOPProverState::prove on a front-loaded plan: base columns of two chips of different sizes, each under its eq table, in monomial form"""
+    m = _section(g, "mixed_size_sumcheck")
+    a_cols = [np.array(c, dtype=np.uint64) for c in m["a_cols"]]
+    b_cols = [np.array(c, dtype=np.uint64) for c in m["b_cols"]]
+    tables = a_cols + [po.build_eq(np.array(m["a_point"], dtype=np.uint64))] + b_cols + [po.build_eq(np.array(m["b_point"], dtype=np.uint64))]
+    msgs, chal, fin = po.sumcheck_prove(tables, po.ext([tuple(x) for x in m["scalars"]]), m["terms"], m["max_num_vars"], m["degree"],
+                                        _HostTranscriptForOracle(m["label"].encode()))
+    assert msgs.tolist() == m["messages"], "mixed-size sumcheck messages differ from IOPProverState::prove"
+    assert chal.tolist() == m["challenges"] and fin.tolist() == m["final_evals"]
+
+
 def test_extension_field_w(plib):
     check_ext_mul(plib, _load())
 
@@ -186,6 +254,53 @@ def test_sumcheck_proof_on_the_oracle_under_the_real_transcript(plib):
     g = _load()
     _install(plib, g)
     check_sumcheck_on_oracle(g)
+
+
+def test_tower_proof_on_the_oracle_under_the_real_transcript(plib):
+    g = _load()
+    _install(plib, g)
+    check_tower_on_oracle(g)
+
+
+def test_rotation_helpers_against_the_reference(plib):
+    check_rotation_on_oracle(_load())
+
+
+def test_mixed_size_sumcheck_on_the_oracle_under_the_real_transcript(plib):
+    g = _load()
+    _install(plib, g)
+    check_mixed_size_sumcheck_on_oracle(g)
+
+
+@pytest.mark.gpu
+def test_opening_of_witness_and_fixed_commitments_against_the_reference(plib):
+    """OpeningProver::open over two commitments: says whether our proof's words already coincide with the reference's batch_open, and xfails with
+    the first difference when they do not (the layout of the commit path is unpinned like the root's)"""
+    g = _load()
+    b = _section(g, "basefold_two_commitments")
+    ext, internal, diag = _constants(g)
+    _install(plib, g)
+    from ceno_amd import Device, api, prover
+
+    dev = Device(0)
+    api.poseidon2_set_constants(dev, ext.reshape(-1), internal, diag)
+    stream = dev.stream_create()
+    mats = lambda key: [np.array(m["values_row_major"], dtype=np.uint64).reshape(m["rows"], m["width"]) for m in b[key]]  # noqa: E731
+    ref = _flat_numbers(b["proof"])
+    hits = {}
+    for log_blowup in (1, 2, 3):
+        pw, pf = prover.PcsData(dev, mats("witness"), log_blowup, stream), prover.PcsData(dev, mats("fixed"), log_blowup, stream)
+        tr = prover.Transcript.poseidon2(b["label"].encode())
+        proof = pw.basefold_open([np.array(p_, dtype=np.uint64) for p_ in b["points"]], [np.array(e_, dtype=np.uint64) for e_ in b["evals"]], 100, 16, tr,
+                                 more_commits=[pf])
+        n = 4
+        hits[log_blowup] = _contains_run(ref, proof[: 4 * n].tolist())   # the sumcheck messages of the opening: the first words of our flat proof
+        pw.free()
+        pf.free()
+    api.poseidon2_set_constants(dev)
+    dev.close()
+    if not any(hits.values()):
+        pytest.xfail(f"PARITY UNPINNED (Basefold opening): our opening's first round messages are not in the reference proof at any blow-up {hits}")
 
 
 @pytest.mark.gpu
@@ -262,6 +377,24 @@ def _self_goldens():
     msgs, chal, fin = po.sumcheck_prove(tables, po.ext([1]), [[0, 1, 2]], 4, 3, _HostTranscriptForOracle(b"sumcheck"))
     g["sumcheck"] = {"label": "sumcheck", "num_vars": 4, "degree": 3, "tables": [t.tolist() for t in tables], "messages": msgs.tolist(),
                      "challenges": chal.tolist(), "final_evals": fin.tolist()}
+    # rounds 4 - 6: tower proof, rotation helpers, mixed-size sumcheck (the sections tools/goldens/dump_goldens.rs 7 - 9 write)
+    prod_last = [po.rand_ext(16, 0x70 + l) for l in range(2)]
+    p_last, q_last = [po.rand_ext(8, 0x7C + l) for l in range(2)], [po.rand_ext(8, 0x7A + l) for l in range(2)]
+    proof = po.tower_prove([po.infer_tower_product_witness(5, prod_last)], [po.infer_tower_logup_witness(p_last, q_last)], _HostTranscriptForOracle(b"tower"))
+    g["tower"] = {"label": "tower", "prod_last_layer": [x.tolist() for x in prod_last], "logup_p_last_layer": [x.tolist() for x in p_last],
+                  "logup_q_last_layer": [x.tolist() for x in q_last], "point": proof.point[:5].tolist(),
+                  "proof": {"proofs": proof.msgs.tolist(), "prod_specs_eval": proof.prod_evals.tolist(), "logup_specs_eval": proof.logup_evals.tolist()}}
+    table, point = po.rand_base(128, 0x707), po.rand_ext(7, 0x708)
+    g["rotation"] = {"cyclic_group_log2": 5, "cyclic_subgroup_size": 23, "table": table.tolist(), "rotated": po.rotation_next_base_mle(table, 5).tolist(),
+                     "point": point.tolist(), "selector": po.rotation_selector(po.build_eq(point), 23, 5).tolist()}
+    a_cols, b_cols = [po.rand_base(16, 0x910 + j) for j in range(3)], [po.rand_base(4, 0x920 + j) for j in range(2)]
+    pa, pb, scal = po.rand_ext(4, 0x9A), po.rand_ext(2, 0x9B), po.rand_ext(4, 0x930)
+    terms = [[3, 0, 1], [3, 2], [6, 4, 5], [6, 5]]
+    tabs = a_cols + [po.build_eq(pa)] + b_cols + [po.build_eq(pb)]
+    msgs, chal, fin = po.sumcheck_prove(tabs, scal, terms, 4, 3, _HostTranscriptForOracle(b"batched_main"))
+    g["mixed_size_sumcheck"] = {"label": "batched_main", "max_num_vars": 4, "degree": 3, "a_cols": [c.tolist() for c in a_cols], "a_point": pa.tolist(),
+                                "b_cols": [c.tolist() for c in b_cols], "b_point": pb.tolist(), "scalars": scal.tolist(), "terms": terms,
+                                "messages": msgs.tolist(), "challenges": chal.tolist(), "final_evals": fin.tolist()}
     return g
 
 
@@ -276,6 +409,9 @@ def test_kit_plumbing_on_self_generated_file(plib, tmp_path):
     check_labels(plib, g)
     check_transcript(plib, g)
     check_sumcheck_on_oracle(g)
+    check_tower_on_oracle(g)
+    check_rotation_on_oracle(g)
+    check_mixed_size_sumcheck_on_oracle(g)
     # a wrong table must be noticed
     g["poseidon2"]["kats"][0]["out"][0] ^= 1
     with pytest.raises(AssertionError):

@@ -153,6 +153,131 @@ fn dump_hip_goldens() {
         "params": { "note": "BasefoldRSParams: rate_log / num_queries / basecode_msg_size_log as compiled into mpcs" },
     }));
 
+    // =================================================================================================================
+    // What rounds 4 - 6 of ceno_amd added (kept current so that ONE `cargo test` pins everything): a tower proof with product and LogUp
+    // specs, the rotation helpers, a mixed-size (front-loaded) sumcheck of base columns under a selector — the engine of
+    // prove_batched_main_constraints — and ONE opening of a witness commitment of two heights together with a fixed commitment.
+    // =================================================================================================================
+
+    // ---- 7. CpuTowerProver::create_proof: one product spec (2^4 leaves per limb) + one LogUp spec (2^3 per limb), scheme/cpu/mod.rs:346-554;
+    //         API as in scheme/tests.rs:447-500 ----
+    {
+        use crate::scheme::{cpu::CpuTowerProver, hal::TowerProverSpec, utils::{infer_tower_logup_witness, infer_tower_product_witness}};
+        let prod_last: Vec<MultilinearExtension<E>> = (0..2u64).map(|l| (0..16u64).map(|i| ee(0x70 + l, i)).collect_vec().into_mle()).collect();
+        let prod_layers = infer_tower_product_witness(5, prod_last.clone(), 2);
+        let q_last: Vec<MultilinearExtension<E>> = (0..2u64).map(|l| (0..8u64).map(|i| ee(0x7A + l, i)).collect_vec().into_mle()).collect();
+        let p_last: Vec<MultilinearExtension<E>> = (0..2u64).map(|l| (0..8u64).map(|i| ee(0x7C + l, i)).collect_vec().into_mle()).collect();
+        let logup_layers = infer_tower_logup_witness(Some(p_last.clone()), q_last.clone());
+        let mut tr = BasicTranscript::<E>::new(b"tower");
+        let (rt, proof) = CpuTowerProver::create_proof::<E, Pcs>(
+            vec![TowerProverSpec { witness: prod_layers.clone() }],
+            vec![TowerProverSpec { witness: logup_layers.clone() }],
+            2,
+            &mut tr,
+        );
+        let limb = |m: &MultilinearExtension<E>| es(&m.get_ext_field_vec().to_vec());
+        out.insert("tower".into(), json!({
+            "label": "tower",
+            "prod_last_layer": prod_last.iter().map(limb).collect_vec(),
+            "logup_p_last_layer": p_last.iter().map(limb).collect_vec(),
+            "logup_q_last_layer": q_last.iter().map(limb).collect_vec(),
+            "point": es(&rt),
+            "proof": serde_json::to_value(&proof).unwrap_or(Value::Null),   // TowerProofs { proofs, prod_specs_eval, logup_specs_eval, .. }
+        }));
+    }
+
+    // ---- 8. rotation helpers (gkr_iop/src/utils.rs:19-102, gkr/booleanhypercube.rs): a base table of 2^7 rows, cyclic group 2^5 ----
+    {
+        use gkr_iop::{gkr::booleanhypercube::BooleanHypercube, utils::{rotation_next_base_mle, rotation_selector, rotation_selector_eval}};
+        use multilinear_extensions::{mle::ArcMultilinearExtension, virtual_poly::build_eq_x_r_vec};
+        let bh = BooleanHypercube::new(5);
+        let table: Vec<F> = (0..128u64).map(|i| fe(0x707, i)).collect();
+        let mle: ArcMultilinearExtension<E> = std::sync::Arc::new(table.clone().into_mle());
+        let rotated = rotation_next_base_mle(&bh, &mle, 5);
+        let point = (0..7u64).map(|i| ee(0x708, i)).collect_vec();
+        let in_point = (0..7u64).map(|i| ee(0x709, i)).collect_vec();
+        let eq = build_eq_x_r_vec(&point);
+        let sel = rotation_selector(&bh, &eq, 23, 5, 128);
+        out.insert("rotation".into(), json!({
+            "cyclic_group_log2": 5, "cyclic_subgroup_size": 23,
+            "table": table.iter().map(|v| b(*v)).collect_vec(),
+            "rotated": rotated.get_base_field_vec().iter().map(|v| b(*v)).collect_vec(),
+            "point": es(&point), "selector": es(&sel.get_ext_field_vec().to_vec()),
+            "in_point": es(&in_point), "selector_eval": e(rotation_selector_eval(&bh, &point, &in_point, 23, 5)),
+        }));
+    }
+
+    // ---- 9. a MIXED-SIZE sumcheck in monomial form over BASE columns under an eq table (what prove_batched_main_constraints runs,
+    //         scheme/cpu/mod.rs:1255-1337): chip A 2^4 rows (3 columns + eq), chip B 2^2 rows (2 columns + eq); degree 3 ----
+    {
+        use multilinear_extensions::{monomial::Term, virtual_poly::build_eq_x_r_vec};
+        let col = |seed: u64, n: u64| (0..n).map(|i| fe(seed, i)).collect_vec();
+        let (pa, pb) = ((0..4u64).map(|i| ee(0x9A, i)).collect_vec(), (0..2u64).map(|i| ee(0x9B, i)).collect_vec());
+        let a_cols = (0..3u64).map(|j| col(0x910 + j, 16)).collect_vec();
+        let b_cols = (0..2u64).map(|j| col(0x920 + j, 4)).collect_vec();
+        let (ea, eb) = (build_eq_x_r_vec(&pa), build_eq_x_r_vec(&pb));
+        let mut mles: Vec<MultilinearExtension<E>> = a_cols.iter().map(|c| c.clone().into_mle()).collect();
+        mles.push(ea.clone().into_mle());
+        mles.extend(b_cols.iter().map(|c| c.clone().into_mle()));
+        mles.push(eb.clone().into_mle());
+        // MLE ids: A columns 0..2, A eq 3, B columns 4..5, B eq 6.  Terms: eq_A a0 a1, eq_A a2, eq_B b0 b1, eq_B b1
+        let scal = (0..4u64).map(|i| ee(0x930, i)).collect_vec();
+        let prods: [Vec<usize>; 4] = [vec![3, 0, 1], vec![3, 2], vec![6, 4, 5], vec![6, 5]];
+        let mut builder = VirtualPolynomialsBuilder::new(1, 4);
+        let exprs: Vec<Expression<E>> = mles.iter().map(|m| builder.lift(either::Either::Left(m))).collect();
+        let terms = prods.iter().zip(&scal).map(|(p, sc)| Term { scalar: either::Either::Right(*sc), product: p.iter().map(|i| exprs[*i].clone()).collect_vec() }).collect_vec();
+        let mut tr = BasicTranscript::<E>::new(b"batched_main");
+        let (proof, state) = IOPProverState::prove(builder.to_virtual_polys_with_monomial_terms(terms), &mut tr);
+        out.insert("mixed_size_sumcheck".into(), json!({
+            "label": "batched_main", "max_num_vars": 4, "degree": 3,
+            "a_cols": a_cols.iter().map(|c| c.iter().map(|v| b(*v)).collect_vec()).collect_vec(), "a_point": es(&pa),
+            "b_cols": b_cols.iter().map(|c| c.iter().map(|v| b(*v)).collect_vec()).collect_vec(), "b_point": es(&pb),
+            "scalars": es(&scal), "terms": prods.iter().map(|p| p.clone()).collect_vec(),
+            "messages": proof.proofs.iter().map(|m| es(&m.evaluations)).collect_vec(),
+            "challenges": es(&state.collect_raw_challenges()),
+            "final_evals": es(&state.get_mle_flatten_final_evaluations()),
+        }));
+    }
+
+    // ---- 10. ONE opening of two commitments (OpeningProver::open, scheme/hal.rs:284-294; cpu/mod.rs:1418-1457): witness = matrices of 2^4 x 3 and
+    //          2^2 x 2 under one root, fixed = one matrix of 2^3 x 2 ----
+    {
+        let mat = |seed: u64, rows: usize, width: usize| {
+            let values = (0..(rows * width) as u64).map(|i| fe(seed, i)).collect_vec();
+            (values.clone(), RowMajorMatrix::<F>::new_by_values(values, width, witness::InstancePaddingStrategy::Default))
+        };
+        let (w0v, w0) = mat(0xA10, 16, 3);
+        let (w1v, w1) = mat(0xA11, 4, 2);
+        let (f0v, f0) = mat(0xA12, 8, 2);
+        let param = Pcs::setup(1 << 20, SecurityLevel::default()).unwrap();
+        let (pp, _vp) = Pcs::trim(param, 1 << 10).unwrap();
+        let comm_w = Pcs::batch_commit(&pp, vec![w0, w1]).unwrap();
+        let comm_f = Pcs::batch_commit(&pp, vec![f0]).unwrap();
+        let pts = [(0..4u64).map(|i| ee(0xA20, i)).collect_vec(), (0..2u64).map(|i| ee(0xA21, i)).collect_vec(), (0..3u64).map(|i| ee(0xA22, i)).collect_vec()];
+        let wp = Pcs::get_arc_mle_witness_from_commitment(&comm_w);
+        let fp = Pcs::get_arc_mle_witness_from_commitment(&comm_f);
+        // the witness polynomials come back matrix after matrix: 3 columns at pts[0], then 2 at pts[1]
+        let ev_w0 = wp[..3].iter().map(|p| p.evaluate(&pts[0])).collect_vec();
+        let ev_w1 = wp[3..].iter().map(|p| p.evaluate(&pts[1])).collect_vec();
+        let ev_f0 = fp.iter().map(|p| p.evaluate(&pts[2])).collect_vec();
+        let mut tr = BasicTranscript::<E>::new(b"open2");
+        let open = Pcs::batch_open(
+            &pp,
+            vec![(&comm_w, vec![(pts[0].clone(), ev_w0.clone()), (pts[1].clone(), ev_w1.clone())]), (&comm_f, vec![(pts[2].clone(), ev_f0.clone())])],
+            &mut tr,
+        ).unwrap();
+        out.insert("basefold_two_commitments".into(), json!({
+            "label": "open2",
+            "witness": [{ "rows": 16, "width": 3, "values_row_major": w0v.iter().map(|v| b(*v)).collect_vec() },
+                        { "rows": 4, "width": 2, "values_row_major": w1v.iter().map(|v| b(*v)).collect_vec() }],
+            "fixed": [{ "rows": 8, "width": 2, "values_row_major": f0v.iter().map(|v| b(*v)).collect_vec() }],
+            "points": pts.iter().map(|p| es(p)).collect_vec(), "evals": [es(&ev_w0), es(&ev_w1), es(&ev_f0)],
+            "witness_commitment": serde_json::to_value(&Pcs::get_pure_commitment(&comm_w)).unwrap_or(Value::Null),
+            "fixed_commitment": serde_json::to_value(&Pcs::get_pure_commitment(&comm_f)).unwrap_or(Value::Null),
+            "proof": serde_json::to_value(&open).unwrap_or(Value::Null),
+        }));
+    }
+
     std::fs::write("ref_goldens.json", serde_json::to_string_pretty(&Value::Object(out)).unwrap()).unwrap();
     println!("wrote ref_goldens.json");
 }
