@@ -112,6 +112,7 @@ def lib():
         "ceno_hip_sumcheck_set_pipelined": (i, [vp, vp, i]),
         "ceno_hip_sumcheck_table": (i, [vp, vp, i, C.POINTER(u64p), C.POINTER(i), C.POINTER(i)]),
         "ceno_hip_sumcheck_table_host": (i, [vp, vp, i, u64p, C.c_size_t, C.POINTER(i)]),
+        "ceno_hip_sumcheck_tables_host": (i, [vp, vp, i, C.POINTER(i), C.POINTER(u64p), C.POINTER(sz), C.POINTER(i)]),
         "ceno_hip_sumcheck_free": (i, [vp, vp]),
         "ceno_hip_tower_build_prod": (i, [vp, vpp, i, sz, u64p, vp, vpp]),
         "ceno_hip_tower_build_logup": (i, [vp, vpp, vpp, i, sz, u64p, vp, vpp]),

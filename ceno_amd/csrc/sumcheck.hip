@@ -3722,6 +3722,41 @@ int ceno_hip_sumcheck_table_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int m
     return 0;
 }
 
+// every listed table in one go: all device-to-host copies queued, ONE synchronisation (a wide chip's handle has hundreds of tables; the sharded main
+// constraints fetch all of them before their gathered tail: a copy + wait per table was most of that phase)
+int ceno_hip_sumcheck_tables_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, const int* mle_indices, uint64_t* const* outs_host, const size_t* caps_ext,
+                                  int* num_vars) {
+    CHECK_ARG(ctx, sc && n >= 0 && (n == 0 || (mle_indices && outs_host && caps_ext && num_vars)), "NULL argument");
+    if (sc->pipelined) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "tables of a pipelined sumcheck are not observable between rounds");
+    if (sc->host_from >= 0) {  // the host's copy: nothing to wait for
+        for (int k = 0; k < n; k++) TRY(ceno_hip_sumcheck_table_host(ctx, sc, mle_indices[k], outs_host[k], caps_ext[k], &num_vars[k]));
+        return 0;
+    }
+    std::vector<std::pair<int, std::vector<uint64_t>>> base;  // (position, staging) of base-field tables: widened after the wait
+    for (int k = 0; k < n; k++) {
+        CHECK_ARG(ctx, mle_indices[k] >= 0 && mle_indices[k] < (int)sc->mles.size() && outs_host[k], "mle index out of range");
+        uint64_t* d = nullptr;
+        int is_ext = 0, nv = 0;
+        TRY(ceno_hip_sumcheck_table(ctx, sc, mle_indices[k], &d, &is_ext, &nv));
+        const size_t len = (size_t)1 << nv;
+        if (len > caps_ext[k]) return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tables_host: buffer of %zu elements for a table of %zu", caps_ext[k], len);
+        num_vars[k] = nv;
+        if (is_ext) {
+            HIP_TRY(ctx, hipMemcpyAsync(outs_host[k], d, len * sizeof(E2), hipMemcpyDeviceToHost, sc->st));
+        } else {
+            base.emplace_back(k, std::vector<uint64_t>(len));
+            HIP_TRY(ctx, hipMemcpyAsync(base.back().second.data(), d, len * 8, hipMemcpyDeviceToHost, sc->st));
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(sc->st));
+    for (auto& b : base)
+        for (size_t j = 0; j < b.second.size(); j++) {
+            outs_host[b.first][2 * j] = b.second[j];
+            outs_host[b.first][2 * j + 1] = 0;
+        }
+    return 0;
+}
+
 int ceno_hip_sumcheck_set_pipelined(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int on) {
     CHECK_ARG(ctx, sc, "NULL argument");
     if (sc->round != 0) return ctx_fail(ctx, CENO_HIP_ERR_STATE, "sumcheck: pipelining must be chosen before round 0");

@@ -570,34 +570,79 @@ int prover_main_constraints_sharded(ceno_hip_ctx* ctx, const ceno_main_job* jobs
         // every sharded table as the next round would read it (folded q - 1 times; once more here), gathered with the rank bits lowest
         const E2 r_last{ch[0], ch[1]};
         std::vector<ceno_hip_mle*> glob(PB.mles.size(), nullptr);
-        std::vector<E2> t, g_tab;
-        std::vector<uint64_t> mine, gathered;
-        for (size_t mi = 0; mi < PB.mles.size() && !rc; mi++) {
-            const int nv_loc = ceno_hip_mle_num_vars(PB.mles[mi]);
-            const size_t len_loc = (size_t)1 << (nv_loc - shq);
-            int nv = 0;
-            t.resize(2 * len_loc);
-            rc = ceno_hip_sumcheck_table_host(ctx, sc, (int)mi, reinterpret_cast<uint64_t*>(t.data()), t.size(), &nv);
-            if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
-            if (nv != nv_loc - shq + 1) { rc = prover_set_error(CENO_HIP_ERR_STATE, "sharded main constraints: unexpected table shape after the local rounds"); break; }
-            mine.resize(2 * len_loc);
-            const E2 scale = plan_eqg[(size_t)PB.orig[mi]];  // (a selector's rank factor went into the coefficients)
-            for (size_t j = 0; j < len_loc; j++) {
-                const E2 v = (t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j])) * scale;
-                mine[2 * j] = v.c0;
-                mine[2 * j + 1] = v.c1;
+        {
+            // ALL tables in three steps — one fetch (every copy queued, one wait), ONE exchange of the concatenated folded tables, one upload into one
+            // device block that the gathered tables are views of — instead of a copy + wait, an exchange and an upload PER TABLE: a wide plan has
+            // hundreds of tables in the sumcheck, and on eight ranks that was hundreds of exchanges in front of the tail (config #4's wide plan at
+            // max_nv = 20 on 8 virtual ranks: 301 message exchanges per rank before, ~30 now; tests/test_gpu_dist_at_size.py)
+            const size_t n_t = PB.mles.size();
+            std::vector<size_t> len_loc(n_t), off_loc(n_t + 1, 0);
+            for (size_t mi = 0; mi < n_t; mi++) {
+                len_loc[mi] = (size_t)1 << (ceno_hip_mle_num_vars(PB.mles[mi]) - shq);
+                off_loc[mi + 1] = off_loc[mi] + len_loc[mi];
             }
-            gathered.resize((size_t)W * 2 * len_loc);
-            rc = sh->allgather(sh->self, mine.data(), mine.size(), gathered.data());
-            if (rc) break;
-            g_tab.resize(len_loc * (size_t)W);
-            for (int g = 0; g < W; g++) {
-                const E2* src = reinterpret_cast<const E2*>(gathered.data()) + (size_t)g * len_loc;
-                for (size_t j = 0; j < len_loc; j++) g_tab[(j << shk) | (size_t)g] = src[j];
+            const size_t total = off_loc[n_t];
+            std::vector<E2> raw(2 * total);  // table mi: 2 len_loc entries (one fold still to do) at 2 off_loc[mi]
+            std::vector<int> idx(n_t), nvs(n_t);
+            std::vector<uint64_t*> outs(n_t);
+            std::vector<size_t> caps(n_t);
+            for (size_t mi = 0; mi < n_t; mi++) {
+                idx[mi] = (int)mi;
+                outs[mi] = reinterpret_cast<uint64_t*>(raw.data() + 2 * off_loc[mi]);
+                caps[mi] = 2 * len_loc[mi];
             }
-            rc = ceno_hip_mle_upload(ctx, reinterpret_cast<const uint64_t*>(g_tab.data()), nv_loc - shq + shk, 1, s, &glob[mi]);
-            if (rc) { rc = prover_set_error(rc, ceno_hip_last_error(ctx)); break; }
-            owned.push_back(glob[mi]);
+            rc = ceno_hip_sumcheck_tables_host(ctx, sc, (int)n_t, idx.data(), outs.data(), caps.data(), nvs.data());
+            if (rc) rc = prover_set_error(rc, ceno_hip_last_error(ctx));
+            for (size_t mi = 0; mi < n_t && !rc; mi++)
+                if (nvs[mi] != ceno_hip_mle_num_vars(PB.mles[mi]) - shq + 1)
+                    rc = prover_set_error(CENO_HIP_ERR_STATE, "sharded main constraints: unexpected table shape after the local rounds");
+            std::vector<uint64_t> mine(2 * total), gathered;
+            if (!rc) {
+                for (size_t mi = 0; mi < n_t; mi++) {
+                    const E2 scale = plan_eqg[(size_t)PB.orig[mi]];  // (a selector's rank factor went into the coefficients)
+                    const E2* t = raw.data() + 2 * off_loc[mi];
+                    uint64_t* dst = mine.data() + 2 * off_loc[mi];
+                    for (size_t j = 0; j < len_loc[mi]; j++) {
+                        const E2 v = (t[2 * j] + r_last * (t[2 * j + 1] - t[2 * j])) * scale;
+                        dst[2 * j] = v.c0;
+                        dst[2 * j + 1] = v.c1;
+                    }
+                }
+                gathered.resize((size_t)W * 2 * total);
+                rc = sh->allgather(sh->self, mine.data(), mine.size(), gathered.data());
+            }
+            if (!rc) {
+                // one device block for all gathered tables (each a power of two long, tallest first is not needed: offsets are multiples of the
+                // smallest table only when sorted — so every table is placed at a multiple of its own length)
+                std::vector<size_t> order(n_t), off_g(n_t);
+                for (size_t mi = 0; mi < n_t; mi++) order[mi] = mi;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return len_loc[a] > len_loc[b]; });
+                size_t tot_g = 0;
+                for (size_t mi : order) {
+                    off_g[mi] = tot_g;
+                    tot_g += len_loc[mi] * (size_t)W;
+                }
+                int nv_all = 0;
+                while (((size_t)1 << nv_all) < tot_g) nv_all++;
+                std::vector<E2> g_all((size_t)1 << nv_all, gl::e2_zero());
+                for (size_t mi = 0; mi < n_t; mi++)
+                    for (int g = 0; g < W; g++) {
+                        const E2* src = reinterpret_cast<const E2*>(gathered.data()) + (size_t)g * total + off_loc[mi];
+                        E2* dst = g_all.data() + off_g[mi];
+                        for (size_t j = 0; j < len_loc[mi]; j++) dst[(j << shk) | (size_t)g] = src[j];
+                    }
+                ceno_hip_mle* block = nullptr;
+                rc = ceno_hip_mle_upload(ctx, reinterpret_cast<const uint64_t*>(g_all.data()), nv_all, 1, s, &block);
+                if (rc) rc = prover_set_error(rc, ceno_hip_last_error(ctx));
+                else {
+                    owned.push_back(block);
+                    for (size_t mi = 0; mi < n_t && !rc; mi++) {
+                        rc = ceno_hip_mle_wrap(ctx, ceno_hip_mle_device_ptr(block) + 2 * off_g[mi], ceno_hip_mle_num_vars(PB.mles[mi]) - shq + shk, 1, &glob[mi]);
+                        if (rc) rc = prover_set_error(rc, ceno_hip_last_error(ctx));
+                        else owned.push_back(glob[mi]);
+                    }
+                }
+            }
         }
         if (rc) { drop(); cleanup(); return rc; }
         ceno_hip_sumcheck_free(ctx, sc);

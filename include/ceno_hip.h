@@ -266,6 +266,9 @@ int ceno_hip_sumcheck_table(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_in
  * or in the host's copy once the host has taken the last rounds of a round-by-round sumcheck over (then ceno_hip_sumcheck_table fails).
  * Synchronises the handle's stream.  Used by the row-sharded tower prover to gather the folded shards (ceno_amd/host/dist_gkr.cpp). */
 int ceno_hip_sumcheck_table_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int mle_index, uint64_t* out_host, size_t cap_ext, int* num_vars);
+/* n tables at once: every copy queued, ONE wait (the sharded main constraints fetch hundreds of folded tables before their gathered tail) */
+int ceno_hip_sumcheck_tables_host(ceno_hip_ctx* ctx, ceno_hip_sumcheck* sc, int n, const int* mle_indices, uint64_t* const* outs_host,
+                                  const size_t* caps_ext, int* num_vars);
 /* Opt in (before round 0) to pipelined rounds: all round kernels are enqueued at round 0 and pick their
  * challenges up from a pinned-memory mailbox, which removes the launch latency from every round.  The
  * caller promises to call ceno_hip_sumcheck_round back to back (a queued kernel gives up after CENO_HIP_PIPE_TIMEOUT_S (60 s) without

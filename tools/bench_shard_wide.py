@@ -23,7 +23,7 @@ def main():
             if best is None or r["total_ms"] < best["total_ms"]:
                 best = r
         flow.free_last()
-        print(json.dumps({"lanes": lanes, "max_lanes": os.environ.get("CENO_HIP_MAX_LANES", "4 (default)"), "transcript": tname,
+        print(json.dumps({"lanes": lanes, "max_lanes": os.environ.get("CENO_HIP_MAX_LANES", "adaptive: 8 for >= 24 tasks, else 4"), "transcript": tname,
                           **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in best.items()}}), flush=True)
     flow.close()
 
