@@ -156,6 +156,13 @@ def lib():
         "ceno_hip_witgen_session_begin": (i, [vp, vpp, C.POINTER(sz), i, vp]),
         "ceno_hip_witgen_session_end": (i, [vp, vp]),
         "ceno_hip_lk_to_mlt_column": (i, [vp, vp, sz, vp, sz, vp]),
+        "ceno_hip_tower_cohort_max_vars": (i, []),
+        "ceno_hip_tower_cohort_begin": (i, [vp, vp, i, vp, vpp]),
+        "ceno_hip_tower_cohort_try_message": (i, [vp, i, i, u64p]),
+        "ceno_hip_tower_cohort_send_challenge": (i, [vp, i, i, u64p]),
+        "ceno_hip_tower_cohort_try_final": (i, [vp, i, u64p]),
+        "ceno_hip_tower_cohort_abort": (i, [vp]),
+        "ceno_hip_tower_cohort_end": (i, [vp, vp]),
         "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),
         "ceno_hip_poseidon2_is_pinned": (i, [vp]),
         "ceno_hip_poseidon2_permute": (i, [vp, vp, sz, vp]),

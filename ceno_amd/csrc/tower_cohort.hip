@@ -1,0 +1,396 @@
+// A COHORT of tower-layer sumchecks in ONE launch (round 6).
+//
+// A shard's chip-proof phase is ~54 independent chains of dependent device <-> host round trips (one per sumcheck round of every tower
+// layer of every chip: CpuTowerProver::create_proof, ceno_zkvm/src/scheme/cpu/mod.rs:346-554).  The command processor runs FOUR queues at
+// a time (profiles/r03_lane_launch_latency.json) and a persistent round kernel that waits for its host holds its queue: more lanes than
+// queues gain little (profiles/r06_shard_wide_lane_cap_sweep.jsonl: 28 ms on 4 lanes, 25 ms on 8 - 12).  What scales instead is one launch
+// in which MANY chains wait side by side: layer r of a tower is 2^r entries per limb whatever the chip's size, so all chips that have a
+// layer r run it in lock-step — one workgroup per chain (or per SUB-CUBE of a chain, below), each with its own pair of mailboxes, all of
+// them resident at once, the host serving them round-robin with each chain's own transcript.
+//
+// One workgroup = one sumcheck of  sum_x eq(x, rt) [ sum_i alpha_i a_i(x) b_i(x) + sum_k (an_k (p1 q2 + p2 q1) + ad_k q1 q2) ]  over n <= 13
+// variables, LSB first: messages p(1), p(2), p(3) per round, the fold of round i fused with the evaluation of round i + 1 (the schedule of
+// every other kernel of this library), final evaluations of all tables at the end.  The eq table is built by the workgroup itself.
+// Layers of MORE than 2^13 entries are split by their TOP index bits into sub-cubes of 2^13 — the trick the multi-rank sumcheck uses
+// between GPUs, here between workgroups: the first 13 rounds fold low variables, which never cross a sub-cube;
+// the host adds the sub-cubes' partial messages (scaled by eq over the high variables) and finishes the remaining <= 4 rounds on the
+// gathered 2^(r-13)-entry tables itself (prover_host_tower_rounds).  No workgroup ever waits for another one.
+//
+// Field arithmetic is exact: messages, challenges and evaluations equal the per-chip path's (and the oracle's) bit for bit.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "sumcheck_dev.hpp"
+
+namespace {
+
+constexpr int CNT = 512;            // lanes per workgroup: 8 waves; 432 workgroups (54 chains x 8 sub-cubes) are resident at once
+constexpr int COHORT_MAX_TABS = 14; // tables besides eq: 2 per product tower (<= 3), 4 per LogUp tower (<= 2)
+constexpr int COHORT_SUB = 13;      // variables of a sub-cube
+
+struct CohortJob {
+    const E2* in[COHORT_MAX_TABS];  // this sub-cube's slice of every table: 2^n entries each
+    E2* eq;                         // scratch: 2^n
+    E2* ping;                       // scratch: K x 2^(n-1)
+    E2* pong;                       // scratch: K x 2^(n-2)
+    uint64_t* h_msg;                // pinned host memory: n rounds x 8 words (6 used), MSG_INVALID until written
+    uint64_t* h_fin;                // pinned host memory: K x 2 words
+    const Mailbox* box;             // device-memory mailbox the host writes the challenges into (large BAR)
+    E2 rt[COHORT_SUB];              // the low n coordinates of the layer's point
+    E2 a_prod[3], a_num[2], a_den[2];
+    int n, np, nl, pad_;
+    unsigned long long poll_ticks;
+};
+
+__device__ __forceinline__ void put16(uint64_t* dst, E2 v) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+}
+
+__global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restrict__ jobs) {
+    __shared__ E2 smem[(CNT / 64) * 3];
+    __shared__ unsigned long long s_c[3];
+    __shared__ CohortJob J;
+    {   // the job record: one cooperative copy into LDS (its pointer arrays are indexed at run time)
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(jobs + blockIdx.x);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(&J);
+        for (int i = threadIdx.x; i < (int)(sizeof(CohortJob) / 8); i += CNT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int n = J.n, np = J.np, nl = J.nl, K = 1 + 2 * np + 4 * nl;
+    // ---- eq(x, rt) over the n low variables, variable j = bit j of the index ----
+    E2* eq = J.eq;
+    if (threadIdx.x == 0) eq[0] = e2_one();
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        const E2 rj = J.rt[j];
+        const size_t half = (size_t)1 << j;
+        for (size_t x = threadIdx.x; x < half; x += CNT) {
+            const E2 lo = eq[x], hi = lo * rj;
+            eq[x + half] = hi;
+            eq[x] = lo - hi;
+        }
+        __syncthreads();
+    }
+    E2 r = e2_zero();
+    E2* cur = J.ping;   // tables of the round being evaluated (rounds >= 1): K x len, table m at cur + m * len
+    E2* prev = nullptr; // tables of the round before
+    size_t prev_len = 0;
+    for (int i = 0; i < n; i++) {
+        const size_t pairs = (size_t)1 << (n - 1 - i), len = 2 * pairs;
+        const E2Pre rp = e2_pre(r);
+        E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
+        for (size_t p = threadIdx.x; p < pairs; p += CNT) {
+            // (lo, hi) of table m at this pair: round 0 reads the inputs, later rounds fold the previous round's tables and keep the result
+            auto load = [&](int m, E2& lo, E2& hi) {
+                if (i == 0) {
+                    const E2* t = m == 0 ? eq : J.in[m - 1];
+                    lo = t[2 * p];
+                    hi = t[2 * p + 1];
+                } else {
+                    const E2* q = (i == 1 ? (m == 0 ? eq : J.in[m - 1]) : prev + (size_t)m * prev_len) + 4 * p;
+                    const E2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+                    lo = a0 + e2_mul_pre(rp, a1 - a0);
+                    hi = a2 + e2_mul_pre(rp, a3 - a2);
+                    E2* o = cur + (size_t)m * len + 2 * p;
+                    o[0] = lo;
+                    o[1] = hi;
+                }
+            };
+            E2 inner[3] = {e2_zero(), e2_zero(), e2_zero()};
+            int m = 1;
+            for (int t = 0; t < np; t++, m += 2) {
+                E2 alo, ahi, blo, bhi;
+                load(m, alo, ahi);
+                load(m + 1, blo, bhi);
+                const E2 da = ahi - alo, db = bhi - blo;
+                E2 ca = J.a_prod[t] * ahi;           // the coefficient rides on the first factor
+                const E2 cda = J.a_prod[t] * da;
+                E2 b = bhi;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    inner[e] = inner[e] + ca * b;
+                    ca = ca + cda;
+                    b = b + db;
+                }
+            }
+            for (int k = 0; k < nl; k++, m += 4) {
+                E2 p1l, p1, p2l, p2, q1l, q1, q2l, q2;
+                load(m, p1l, p1);
+                load(m + 1, p2l, p2);
+                load(m + 2, q1l, q1);
+                load(m + 3, q2l, q2);
+                const E2 dp1 = p1 - p1l, dp2 = p2 - p2l, dq1 = q1 - q1l, dq2 = q2 - q2l;
+                const E2 an = J.a_num[k], ad = J.a_den[k];
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    inner[e] = inner[e] + an * (p1 * q2 + p2 * q1) + ad * (q1 * q2);
+                    p1 = p1 + dp1;
+                    p2 = p2 + dp2;
+                    q1 = q1 + dq1;
+                    q2 = q2 + dq2;
+                }
+            }
+            E2 elo, ev;
+            load(0, elo, ev);
+            const E2 de = ev - elo;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                acc[e] = acc[e] + ev * inner[e];
+                ev = ev + de;
+            }
+        }
+        red::block_sum<3, CNT>(acc, smem);
+        if (threadIdx.x == 0) {
+            uint64_t* msg = J.h_msg + 8 * (size_t)i;
+            put16(msg, acc[0]);
+            put16(msg + 2, acc[1]);
+            put16(msg + 4, acc[2]);
+            unsigned long long c0 = 0, c1 = 0;
+            const bool ok = poll_challenge(J.box, (unsigned long long)(i + 1), c0, c1, J.poll_ticks);
+            s_c[0] = c0;
+            s_c[1] = c1;
+            s_c[2] = ok ? 1ull : 0ull;
+        }
+        __syncthreads();  // (also: every lane's stores into `cur` are done before the next round reads them as `prev`)
+        if (s_c[2] == 0) return;  // aborted / timed out: leave the evaluations unwritten
+        r = E2{s_c[0], s_c[1]};
+        if (i >= 1) {
+            prev = cur;
+            prev_len = len;
+            cur = (cur == J.ping) ? J.pong : J.ping;
+        }
+        __syncthreads();  // s_c is rewritten by the next round
+    }
+    // ---- final evaluations: the last round's tables have two entries each ----
+    if ((int)threadIdx.x < K) {
+        const int m = threadIdx.x;
+        const E2* t = n == 1 ? (m == 0 ? eq : J.in[m - 1]) : prev + (size_t)m * prev_len;
+        put16(J.h_fin + 2 * (size_t)m, t[0] + r * (t[1] - t[0]));
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+struct ceno_hip_cohort {
+    ceno_hip_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;
+    int n_jobs = 0;
+    std::vector<int> n, K;
+    void* d_jobs = nullptr;          // pool block: CohortJob x n_jobs
+    void* d_scratch = nullptr;       // pool block: eq + ping + pong of every job
+    uint64_t* h_area = nullptr;      // pinned: per job [COHORT_SUB rounds x 8 words][16 x 2 words of evaluations]
+    uint64_t* d_area = nullptr;      // its device view
+    Mailbox* boxes = nullptr;        // device memory the host writes (large BAR): one 64-byte line per job
+    bool own_boxes = false;
+};
+namespace {
+constexpr size_t COHORT_H_WORDS = 8 * COHORT_SUB + 2 * 16;
+// host-writable device memory for the challenge mailboxes: one arena per context, grown on demand, kept for the context's life
+struct BoxArena {
+    void* p = nullptr;
+    size_t lines = 0, next = 0;  // bump allocation: lines [0, next) belong to live cohorts
+    int live = 0;                // cohorts holding lines; the bump pointer goes back to 0 when the last one ends
+};
+std::mutex g_box_mu;
+std::map<ceno_hip_ctx*, BoxArena> g_box;
+inline void host_fence() {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
+}  // namespace
+
+extern "C" {
+
+int ceno_hip_tower_cohort_max_vars(void) { return COHORT_SUB; }
+
+int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
+    CHECK_ARG(ctx, ctx && jobs && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_begin: bad arguments");
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar)
+        return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "tower cohort: the challenge mailboxes need host-writable device memory (large BAR)");
+    hipStream_t st = ctx_stream(ctx, s);
+    auto* c = new ceno_hip_cohort();
+    c->ctx = ctx;
+    c->st = st;
+    c->n_jobs = n_jobs;
+    size_t scratch_e2 = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const ceno_hip_cohort_job& G = jobs[j];
+        const int K = 1 + 2 * G.n_prod + 4 * G.n_logup;
+        if (G.n < 1 || G.n > COHORT_SUB || G.n_prod < 0 || G.n_prod > 3 || G.n_logup < 0 || G.n_logup > 2 || K < 3 || !G.rt || !G.tables) {
+            delete c;
+            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: 1 .. %d variables, <= 3 product and <= 2 LogUp towers, at least one", j, COHORT_SUB);
+        }
+        c->n.push_back(G.n);
+        c->K.push_back(K);
+        const size_t len = (size_t)1 << G.n;
+        scratch_e2 += len + (size_t)K * (len / 2) + (size_t)K * std::max<size_t>(len / 4, 1);
+    }
+    int rc = ctx_alloc(ctx, sizeof(CohortJob) * (size_t)n_jobs, &c->d_jobs);
+    if (!rc) rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
+    void *hb = nullptr, *db = nullptr;
+    if (!rc) rc = ctx_pinned_alloc(ctx, COHORT_H_WORDS * 8 * (size_t)n_jobs, &hb, &db);
+    if (!rc) {
+        std::lock_guard<std::mutex> g(g_box_mu);
+        BoxArena& A = g_box[ctx];
+        if (!A.p) {
+            void* p = nullptr;
+            const size_t lines = 8192;  // 512 KB of host-writable device memory per context, allocated once
+            if (hipExtMallocWithFlags(&p, lines * 64, hipDeviceMallocFinegrained) != hipSuccess || !p) rc = ctx_fail(ctx, CENO_HIP_ERR_OOM, "tower cohort: mailbox arena");
+            else {
+                A.p = p;
+                A.lines = lines;
+            }
+        }
+        if (!rc && A.next + (size_t)n_jobs > A.lines) rc = ctx_fail(ctx, CENO_HIP_ERR_OOM, "tower cohort: more than %zu mailboxes in flight on one context", A.lines);
+        if (!rc) {
+            c->boxes = reinterpret_cast<Mailbox*>((char*)A.p + 64 * A.next);
+            A.next += (size_t)n_jobs;
+            A.live++;
+            c->own_boxes = true;
+        }
+    }
+    auto release_boxes = [&]() {
+        if (!c->own_boxes) return;
+        std::lock_guard<std::mutex> g(g_box_mu);
+        BoxArena& A = g_box[ctx];
+        if (--A.live == 0) A.next = 0;
+        c->own_boxes = false;
+    };
+    if (rc) {
+        release_boxes();
+        if (hb) ctx_pinned_free(ctx, hb);
+        if (c->d_scratch) ctx_free(ctx, c->d_scratch);
+        if (c->d_jobs) ctx_free(ctx, c->d_jobs);
+        delete c;
+        return rc;
+    }
+    c->h_area = (uint64_t*)hb;
+    c->d_area = (uint64_t*)db;
+    for (size_t i = 0; i < COHORT_H_WORDS * (size_t)n_jobs; i++) c->h_area[i] = MSG_INVALID;
+    static const unsigned long long ticks = [] {
+        const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
+        const double sec = e && atof(e) > 0 ? atof(e) : 60.0;
+        return (unsigned long long)(sec * 1e8);
+    }();
+    std::vector<CohortJob> hj((size_t)n_jobs);
+    E2* sp = (E2*)c->d_scratch;
+    for (int j = 0; j < n_jobs; j++) {
+        const ceno_hip_cohort_job& G = jobs[j];
+        CohortJob& J = hj[(size_t)j];
+        memset(&J, 0, sizeof(J));
+        const int K = c->K[(size_t)j];
+        const size_t len = (size_t)1 << G.n;
+        for (int m = 0; m < K - 1; m++) J.in[m] = reinterpret_cast<const E2*>(G.tables[m]);
+        J.eq = sp;
+        sp += len;
+        J.ping = sp;
+        sp += (size_t)K * (len / 2);
+        J.pong = sp;
+        sp += (size_t)K * std::max<size_t>(len / 4, 1);
+        J.h_msg = c->d_area + COHORT_H_WORDS * (size_t)j;
+        J.h_fin = J.h_msg + 8 * COHORT_SUB;
+        J.box = c->boxes + 2 * (size_t)j;  // (Mailbox is 32 bytes: every job gets a 64-byte line of its own)
+        for (int v = 0; v < G.n; v++) J.rt[v] = E2{G.rt[2 * v], G.rt[2 * v + 1]};
+        for (int t = 0; t < G.n_prod; t++) J.a_prod[t] = E2{G.alpha_prod[2 * t], G.alpha_prod[2 * t + 1]};
+        for (int t = 0; t < G.n_logup; t++) {
+            J.a_num[t] = E2{G.alpha_num[2 * t], G.alpha_num[2 * t + 1]};
+            J.a_den[t] = E2{G.alpha_den[2 * t], G.alpha_den[2 * t + 1]};
+        }
+        J.n = G.n;
+        J.np = G.n_prod;
+        J.nl = G.n_logup;
+        J.poll_ticks = ticks;
+        // the mailbox line: no challenge yet
+        volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
+        mb->chal_seq = 0;
+        mb->abort = 0;
+    }
+    host_fence();
+    hipError_t e = hipMemcpyAsync(c->d_jobs, hj.data(), sizeof(CohortJob) * (size_t)n_jobs, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the host vector goes away; the launch below is asynchronous)
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)n_jobs), dim3(CNT), 0, st, (const CohortJob*)c->d_jobs);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        release_boxes();
+        ctx_pinned_free(ctx, hb);
+        ctx_free(ctx, c->d_scratch);
+        ctx_free(ctx, c->d_jobs);
+        delete c;
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6) {
+    if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !out6) return CENO_HIP_ERR_INVALID;
+    const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * (size_t)round;
+    uint64_t v[6];
+    for (int i = 0; i < 6; i++) {
+        v[i] = w[i];
+        if (v[i] >= gl::P) return 0;  // a word the device has not written yet (MSG_INVALID is no field element)
+    }
+    memcpy(out6, v, sizeof v);
+    return 1;
+}
+
+int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2) {
+    if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !chal2) return CENO_HIP_ERR_INVALID;
+    volatile Mailbox* mb = c->boxes + 2 * (size_t)job;
+    mb->chal[0] = chal2[0];
+    mb->chal[1] = chal2[1];
+    host_fence();
+    __atomic_store_n(&mb->chal_seq, (unsigned long long)(round + 1), __ATOMIC_RELEASE);
+    host_fence();
+    return 0;
+}
+
+int ceno_hip_tower_cohort_try_final(ceno_hip_cohort* c, int job, uint64_t* out_evals) {
+    if (!c || job < 0 || job >= c->n_jobs || !out_evals) return CENO_HIP_ERR_INVALID;
+    const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * COHORT_SUB;
+    const int K = c->K[(size_t)job];
+    for (int i = 0; i < 2 * K; i++)
+        if (w[i] >= gl::P) return 0;
+    for (int i = 0; i < 2 * K; i++) out_evals[i] = w[i];
+    return 1;
+}
+
+int ceno_hip_tower_cohort_abort(ceno_hip_cohort* c) {
+    if (!c) return CENO_HIP_ERR_INVALID;
+    for (int j = 0; j < c->n_jobs; j++) {
+        volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
+        mb->abort = 1;
+    }
+    host_fence();
+    return 0;
+}
+
+int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
+    if (!c) return 0;
+    const hipError_t e = hipStreamSynchronize(c->st);  // every workgroup has left (all challenges answered, or aborted)
+    if (c->own_boxes) {
+        std::lock_guard<std::mutex> g(g_box_mu);
+        BoxArena& A = g_box[ctx];
+        if (--A.live == 0) A.next = 0;
+    }
+    ctx_pinned_free(ctx, c->h_area);
+    ctx_free_on(ctx, c->d_scratch, c->st);
+    ctx_free_on(ctx, c->d_jobs, c->st);
+    delete c;
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

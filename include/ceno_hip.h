@@ -379,6 +379,34 @@ int ceno_hip_merkle_open(ceno_hip_ctx* ctx, ceno_hip_merkle* t, size_t index, ui
 int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
 
 /* ------------------------------------------------------------------------------------------------
+ * A COHORT of tower-layer sumchecks in one launch (round 6; ceno_amd/csrc/tower_cohort.hip): the layer sumcheck of
+ * CpuTowerProver::create_proof (ceno_zkvm/src/scheme/cpu/mod.rs:417-494;  sum_x eq(x, rt) [ sum_i alpha_i a_i b_i + sum_k (an_k (p1 q2 + p2 q1) +
+ * ad_k q1 q2) ], degree 3, LSB first) for MANY independent chains side by side — one workgroup per job, each waiting for its own host.
+ * The reference proves its chips' towers one `tower.create_proof` call at a time (scheme/gpu/mod.rs:343-353) and overlaps them with
+ * scheduler lanes; on this hardware four queues run at a time, so the chains are put into ONE launch instead.
+ * A job: n <= ceno_hip_tower_cohort_max_vars() (13) variables; tables = 2 n_prod + 4 n_logup device pointers, each 2^n extension elements
+ * ([a, b] per product tower, [p1, p2, q1, q2] per LogUp tower); rt: n ext; alpha_*: one ext per tower.  A layer of more than 2^13 entries
+ * is split by its TOP index bits into 2^13-entry jobs whose partial messages the caller adds (scaled by eq over the high variables).
+ * Protocol per job and round i = 0 .. n - 1: try_message(job, i) until it returns 1 (out6 = p(1), p(2), p(3)), send_challenge(job, i, r_i);
+ * after the last challenge try_final(job) yields the 1 + 2 n_prod + 4 n_logup evaluations [eq, a, b, .., p1, p2, q1, q2, ..] at the point.
+ * begin launches and returns; end waits for the launch and frees.  abort releases every waiting workgroup (then call end).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ceno_hip_cohort ceno_hip_cohort;
+typedef struct ceno_hip_cohort_job {
+    const uint64_t* const* tables;
+    int n_prod, n_logup, n;
+    const uint64_t* rt;
+    const uint64_t *alpha_prod, *alpha_num, *alpha_den;
+} ceno_hip_cohort_job;
+int ceno_hip_tower_cohort_max_vars(void);
+int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
+int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6);
+int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2);
+int ceno_hip_tower_cohort_try_final(ceno_hip_cohort* c, int job, uint64_t* out_evals);
+int ceno_hip_tower_cohort_abort(ceno_hip_cohort* c);
+int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c);
+
+/* ------------------------------------------------------------------------------------------------
  * Basefold batch open  (OpeningProver::open -> PCS::batch_open, ceno_zkvm/src/scheme/hal.rs:284-294,
  * cpu/mod.rs:1418-1457; protocol restated in ceno_recursion_v2/src/pcs/mod.rs:1111-1316,7494-7781).
  * PARITY UNPINNED like the commit path.  The round loop lives in the host layer (ceno_prover_basefold_open).
