@@ -119,6 +119,7 @@ def lib():
         "ceno_hip_tower_from_last_layer": (i, [vp, vpp, i, vp, vpp]),
         "ceno_hip_tower_num_vars": (i, [vp]),
         "ceno_hip_tower_layer": (i, [vp, vp, i, i, vpp]),
+        "ceno_hip_tower_layer_ptr": (vp, [vp, i, i]),
         "ceno_hip_tower_out_evals": (i, [vp, vp, u64p, vp]),
         "ceno_hip_tower_download_top": (i, [vp, vp, i, u64p, vp]),
         "ceno_hip_tower_top_layers": (i, [vp]),
@@ -157,6 +158,7 @@ def lib():
         "ceno_hip_witgen_session_end": (i, [vp, vp]),
         "ceno_hip_lk_to_mlt_column": (i, [vp, vp, sz, vp, sz, vp]),
         "ceno_hip_tower_cohort_max_vars": (i, []),
+        "ceno_hip_tower_cohort_capacity": (i, [vp]),
         "ceno_hip_tower_cohort_begin": (i, [vp, vp, i, vp, vpp]),
         "ceno_hip_tower_cohort_try_message": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_send_challenge": (i, [vp, i, i, u64p]),

@@ -331,6 +331,11 @@ int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int li
     return ceno_hip_mle_wrap(ctx, reinterpret_cast<uint64_t*>(t->layers[layer] + ((size_t)limb << layer)), layer, 1, out);
 }
 
+const uint64_t* ceno_hip_tower_layer_ptr(const ceno_hip_tower* t, int layer, int limb) {
+    if (!t || layer < 0 || layer >= t->num_vars || limb < 0 || limb >= t->n_limbs) return nullptr;
+    return reinterpret_cast<const uint64_t*>(t->layers[layer] + ((size_t)limb << layer));
+}
+
 int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out, ceno_hip_stream s) {
     CHECK_ARG(ctx, t && out, "NULL argument");
     if (t->host_top_layers >= 1) {  // prefetched (ceno_hip_tower_prefetch_tops): layer 0 heads the block

@@ -212,6 +212,21 @@ extern "C" {
 
 int ceno_hip_tower_cohort_max_vars(void) { return COHORT_SUB; }
 
+int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx) {
+    if (!ctx) return 0;
+    static std::mutex mu;
+    static std::map<int, int> cap;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cap.find(ctx->device);
+    if (it != cap.end()) return it->second;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tower_cohort, CNT, 0) != hipSuccess) per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 0;
+    // every workgroup of a launch waits for its host: a launch of more workgroups than the device holds at once would leave some undispatched
+    // behind workgroups that wait for THEIR messages (a layer split into sub-cubes needs all of them) — callers keep a launch below this
+    return cap[ctx->device] = std::max(0, per_cu) * std::max(0, cus);
+}
+
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
     CHECK_ARG(ctx, ctx && jobs && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_begin: bad arguments");
     int large_bar = 0;

@@ -19,6 +19,7 @@
 #include "../../include/ceno_prover.h"
 
 int prover_set_error(int code, const char* msg);
+#include "chip_run.hpp"
 int prover_tower_host_layers();  // prover.cpp: tower layers the host proves (CENO_TOWER_HOST_LAYERS)  // prover.cpp
 
 namespace {
@@ -124,10 +125,26 @@ void ceno_chip_proof_free(ceno_chip_proof* p) {
 
 int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
                                   ceno_hip_stream s, ceno_chip_proof* out) {
+    ChipProofRun run;
+    if (int rc = chip_run_begin(run, ctx, task, challenges4, tr, s, out)) return rc;
+    return chip_run_finish(run, s);
+}
+
+}  // extern "C"
+
+// ---- ZKVMProver::create_chip_proof in two halves (chip_run.hpp) ----------------------------------------------------------------------------
+int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                   ceno_hip_stream s, ceno_chip_proof* out) {
     if (!ctx || !task || !challenges4 || !tr || !out) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: NULL argument");
     memset(out, 0, sizeof(*out));
+    run.ctx = ctx;
+    run.task = task;
+    run.tr = tr;
+    run.out = out;
+    run.live = false;
     const int n_mles = task->n_witin + task->n_fixed + task->n_structural;
     const int num_var_with_rotation = task->log2_num_instances + task->rotation_vars;   // prover.rs:728-729
+    run.num_var_with_rotation = num_var_with_rotation;
     const int n_lk_num = task->num_lk_tables, n_lk_den = task->num_lk_tables > 0 ? task->num_lk_tables : task->num_lk;
     const int n_records = task->num_reads + task->num_writes + n_lk_num + n_lk_den;
     if (n_records < 1) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a circuit needs at least one read / write / lookup");  // utils.rs:701-710
@@ -173,13 +190,13 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
     if (rc) return fail_ctx(ctx, rc);
     const double t1 = trace ? now_us() : 0;
     // ---- prove_tower_relation (prover.rs:747-755 -> cpu/mod.rs:765-797) ----
-    ceno_tower_witness tw;
+    ceno_tower_witness& tw = run.tw;
     rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk,
                                          task->log2_num_instances, task->rotation_vars, challenges4, s, &tw);
     const double t2 = trace ? now_us() : 0;
     free_records();  // prover.rs:756 drop(records): the towers own their interleaved copies
     if (rc) return rc;
-    const double t3 = trace ? now_us() : 0;
+    run.live = true;
     int max_nv = 0;
     for (int i = 0; i < tw.n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.prod[i]));
     for (int i = 0; i < tw.n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.logup[i]));
@@ -193,30 +210,52 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
     out->tower.point = (uint64_t*)calloc((size_t)2 * (max_nv + 1), 8);
     out->rt_main = (uint64_t*)calloc((size_t)2 * std::max(1, num_var_with_rotation), 8);
     if (!out->tower.msgs || !out->tower.prod_evals || !out->tower.logup_evals || !out->tower.point || !out->rt_main) {
-        ceno_tower_witness_free(ctx, &tw);
-        ceno_chip_proof_free(out);
+        chip_run_abandon(run);
         return prover_set_error(CENO_HIP_ERR_OOM, "create_chip_proof: out of host memory");
     }
-    // out-evals were computed by build_tower_witness; prove_tower_relation binds them into the transcript (r, w, lk) and
-    // runs the tower prover
-    std::vector<uint64_t> out_evals((size_t)2 * (2 * tw.n_prod + 4 * tw.n_logup));
-    const double t4 = trace ? now_us() : 0;
-    rc = ceno_prover_prove_tower_relation(ctx, tw.prod, tw.n_prod, tw.logup, tw.n_logup, tr, s, out_evals.data(), &out->tower);
-    const double t5 = trace ? now_us() : 0;
-    ceno_tower_witness_free(ctx, &tw);
-    if (trace)
-        fprintf(stderr, "[ceno_prover] chip 2^%d: wit_infer %.0f us, tower witness (to out-evals) %.0f, free records %.0f, host alloc %.0f, tower proof %.0f, free towers %.0f\n",
-                task->log2_num_instances, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, now_us() - t5);
-    if (rc) {
-        ceno_chip_proof_free(out);
-        return rc;
-    }
+    // out-evals were computed by build_tower_witness; prove_tower_relation binds them into the transcript (r, w, lk: cpu/mod.rs:783-786), the
+    // tower prover follows
     out->n_r_out = tw.has_r ? 2 : 0;
     out->n_w_out = tw.has_w ? 2 : 0;
     out->n_lk_out = tw.has_lk ? 4 : 0;
     memcpy(out->r_out_evals, tw.r_out_evals, sizeof(out->r_out_evals));
     memcpy(out->w_out_evals, tw.w_out_evals, sizeof(out->w_out_evals));
     memcpy(out->lk_out_evals, tw.lk_out_evals, sizeof(out->lk_out_evals));
+    if (tw.has_r) prover_tr_ext_words(tr, tw.r_out_evals, 2);
+    if (tw.has_w) prover_tr_ext_words(tr, tw.w_out_evals, 2);
+    if (tw.has_lk) prover_tr_ext_words(tr, tw.lk_out_evals, 4);
+    rc = tower_state_init(run.st, ctx, tw.prod, tw.n_prod, tw.logup, tw.n_logup, tr, s, &out->tower, nullptr);
+    if (trace)
+        fprintf(stderr, "[ceno_prover] chip 2^%d: wit_infer %.0f us, tower witness (to out-evals) %.0f, to the first layer %.0f\n", task->log2_num_instances,
+                t1 - t0, t2 - t1, now_us() - t2);
+    if (rc) {
+        chip_run_abandon(run);
+        return rc;
+    }
+    return 0;
+}
+
+void chip_run_abandon(ChipProofRun& run) {
+    if (run.live) ceno_tower_witness_free(run.ctx, &run.tw);
+    run.live = false;
+    if (run.out) ceno_chip_proof_free(run.out);
+}
+
+int chip_run_finish(ChipProofRun& run, ceno_hip_stream s) {
+    ceno_hip_ctx* ctx = run.ctx;
+    const ceno_chip_task* task = run.task;
+    ceno_chip_proof* out = run.out;
+    ceno_transcript* tr = run.tr;
+    run.st.s = s;
+    while (!run.st.done())
+        if (int rc = tower_state_step(run.st)) {
+            chip_run_abandon(run);
+            return rc;
+        }
+    tower_state_finish(run.st);
+    ceno_tower_witness_free(ctx, &run.tw);
+    run.live = false;
+    const int max_nv = out->tower_num_vars, num_var_with_rotation = run.num_var_with_rotation;
     // rt_main = the LAST num_var_with_rotation coordinates of the tower point (prover.rs:758-764): the record selector
     // occupies the low variables of the interleaved layout (utils.rs:402-462)
     if (max_nv < num_var_with_rotation) {
@@ -236,9 +275,9 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
             ceno_chip_proof_free(out);
             return prover_set_error(CENO_HIP_ERR_OOM, "create_chip_proof: out of host memory");
         }
-        rc = ceno_prover_prove_rotation(ctx, task->mles, task->rotation_source_idx, task->rotation_target_idx, np, task->cyclic_subgroup_size,
-                                        task->cyclic_group_log2, out->rt_main, n, tr, s, out->rotation_msgs, out->rotation_evals,
-                                        out->rotation_points, out->rotation_points + (size_t)2 * n, out->rotation_points + (size_t)4 * n);
+        int rc = ceno_prover_prove_rotation(ctx, task->mles, task->rotation_source_idx, task->rotation_target_idx, np, task->cyclic_subgroup_size,
+                                            task->cyclic_group_log2, out->rt_main, n, tr, s, out->rotation_msgs, out->rotation_evals,
+                                            out->rotation_points, out->rotation_points + (size_t)2 * n, out->rotation_points + (size_t)4 * n);
         if (rc) {
             ceno_chip_proof_free(out);
             return rc;
@@ -246,5 +285,3 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
     }
     return 0;
 }
-
-}  // extern "C"

@@ -1,0 +1,22 @@
+// ZKVMProver::create_chip_proof (ceno_zkvm/src/scheme/prover.rs:717-833) in two halves around the tower prover's layers, so that the layers of
+// MANY chips can be proved together (cohort.cpp): begin = records, towers, out-evaluations into the transcript, the tower prover's state before
+// layer 1; finish = the layers still open, the main point, the rotation argument, the towers released.
+#pragma once
+#include "../../include/ceno_prover.h"
+#include "tower_state.hpp"
+
+struct ChipProofRun {
+    ceno_hip_ctx* ctx = nullptr;
+    const ceno_chip_task* task = nullptr;
+    ceno_transcript* tr = nullptr;
+    ceno_chip_proof* out = nullptr;
+    ceno_tower_witness tw{};
+    TowerProveState st;
+    int num_var_with_rotation = 0;
+    bool live = false;  // the towers exist
+};
+int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                   ceno_hip_stream s, ceno_chip_proof* out);
+int chip_run_finish(ChipProofRun& run, ceno_hip_stream s);  // on failure the proof and the towers are released
+void chip_run_abandon(ChipProofRun& run);
+void prover_tr_ext_words(ceno_transcript* t, const uint64_t* ext, int n_ext);  // prover.cpp

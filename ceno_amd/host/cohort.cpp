@@ -1,0 +1,341 @@
+// The chip-proof phase with the MIDDLE tower layers of all chips proved together.
+//
+// A shard with the reference's population has ~54 circuits, and each of their tower proofs (CpuTowerProver::create_proof,
+// ceno_zkvm/src/scheme/cpu/mod.rs:346-554) is a chain of ~20 layer sumchecks whose rounds each wait for a transcript challenge from the host.
+// On scheduler lanes (lanes.cpp; the reference's ChipScheduler, scheme/scheduler.rs:231-336) every chip's chain occupies a stream, the device
+// runs four queues at a time, and the layers of 2^9 .. 2^16 entries — too large for the host, far too small to fill the device — make up most
+// of a chip's time: the phase plateaus at ~25 ms however many lanes there are (profiles/r06_shard_wide_lanes.jsonl).  Here those layers run as
+// ONE launch per layer for ALL chips (csrc/tower_cohort.hip: a workgroup per chip, or per 2^13-entry sub-cube of a larger layer, each with its
+// own mailboxes), served by the lane threads:
+//   phase A (lanes)   per chip: records, towers, out-evaluations into its transcript, the layers the host proves (1 .. CENO_TOWER_HOST_LAYERS)
+//   phase B (cohort)  layer by layer for all chips in lock-step: one launch, every chip's rounds answered as its messages arrive; a layer of
+//                     more than 2^13 entries is split by its top index bits, the partial messages are added (scaled by eq over the top
+//                     variables) and the last rounds run on the host over the sub-cubes' final evaluations
+//   phase C (lanes)   per chip: the larger layers on the device-wide kernels, the main point, the rotation argument
+// Every chip keeps its own forked transcript (prover.rs:556-570), so the proofs are the words the per-chip path writes
+// (tests/test_gpu_shard_wide.py::test_cohort_layers_write_the_same_proofs).
+#include <sched.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ceno_prover.h"
+#include "../csrc/gl64.hpp"
+#include "chip_run.hpp"
+
+using gl::E2;
+
+int prover_set_error(int code, const char* msg);  // prover.cpp
+int prover_tower_host_layers();                   // prover.cpp
+void prover_host_tower_rounds(int n, std::vector<std::vector<E2>>& tabs, int n_prod_active, int n_logup_active, const std::vector<E2>& alpha_prod,
+                              const std::vector<E2>& alpha_num, const std::vector<E2>& alpha_den, ceno_transcript* tr, uint64_t* msgs, uint64_t* chal,
+                              uint64_t* fin);  // prover.cpp
+
+namespace {
+
+struct SpinBarrier {
+    std::atomic<int> arrived{0}, gen{0};
+    int n = 1;
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            arrived.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+            return;
+        }
+        int spins = 0;
+        while (gen.load(std::memory_order_acquire) == g)
+            if (++spins > 2000) sched_yield();
+    }
+};
+
+// one chip's share of one cohort launch
+struct LayerChip {
+    ChipProofRun* run = nullptr;
+    int L = 0, n_lo = 0, G = 1, first_job = 0, np_act = 0, nl_act = 0, K = 0;
+    std::vector<uint64_t> a_prod, a_num, a_den;           // the active towers' alpha powers (words)
+    std::vector<std::vector<const uint64_t*>> tables;     // [job][K - 1]
+    std::vector<E2> eq_hi;                                // eq(g; rt[n_lo ..]) over the sub-cubes (G > 1)
+    // serving state
+    bool started = false, done = false;
+    int round = 0, n_got = 0;
+    std::vector<char> got;
+    std::vector<uint64_t> part, chal, fin, finbuf;
+};
+
+void prepare(LayerChip& c, ChipProofRun* run, int L, int sub) {
+    c.run = run;
+    c.L = L;
+    c.n_lo = std::min(L, sub);
+    c.G = 1 << (L - c.n_lo);
+    TowerProveState& st = run->st;
+    c.a_prod.clear();
+    c.a_num.clear();
+    c.a_den.clear();
+    std::vector<const ceno_hip_tower*> act_p, act_l;
+    for (int i = 0; i < st.n_prod; i++)
+        if (st.nv_of(st.prod[i]) > L) {
+            act_p.push_back(st.prod[i]);
+            c.a_prod.insert(c.a_prod.end(), {st.alpha[2 * i], st.alpha[2 * i + 1]});
+        }
+    for (int i = 0; i < st.n_logup; i++)
+        if (st.nv_of(st.logup[i]) > L) {
+            act_l.push_back(st.logup[i]);
+            const size_t k = (size_t)st.n_prod + 2 * i;
+            c.a_num.insert(c.a_num.end(), {st.alpha[2 * k], st.alpha[2 * k + 1]});
+            c.a_den.insert(c.a_den.end(), {st.alpha[2 * k + 2], st.alpha[2 * k + 3]});
+        }
+    c.np_act = (int)act_p.size();
+    c.nl_act = (int)act_l.size();
+    c.K = 1 + 2 * c.np_act + 4 * c.nl_act;
+    c.tables.assign((size_t)c.G, {});
+    for (int g = 0; g < c.G; g++) {
+        auto& tb = c.tables[(size_t)g];
+        const size_t off = (size_t)2 * ((size_t)g << c.n_lo);  // words: sub-cube g = the entries whose top index bits are g
+        for (auto* t : act_p)
+            for (int b = 0; b < 2; b++) tb.push_back(ceno_hip_tower_layer_ptr(t, L, b) + off);
+        for (auto* t : act_l)
+            for (int b = 0; b < 4; b++) tb.push_back(ceno_hip_tower_layer_ptr(t, L, b) + off);
+    }
+    c.eq_hi.assign((size_t)c.G, gl::e2_one());
+    for (int j = 0; j < L - c.n_lo; j++) {  // variable n_lo + j of the layer is bit j of g
+        const E2 rj{st.out_rt[2 * (size_t)(c.n_lo + j)], st.out_rt[2 * (size_t)(c.n_lo + j) + 1]};
+        for (size_t x = 0; x < ((size_t)1 << j); x++) {
+            const E2 hi = c.eq_hi[x] * rj;
+            c.eq_hi[x + ((size_t)1 << j)] = hi;
+            c.eq_hi[x] = c.eq_hi[x] - hi;
+        }
+    }
+    c.started = c.done = false;
+    c.round = c.n_got = 0;
+    c.got.assign((size_t)c.G, 0);
+    c.part.assign((size_t)6 * c.G, 0);
+    c.chal.assign((size_t)2 * L, 0);
+    c.fin.assign((size_t)2 * c.K, 0);
+    c.finbuf.assign((size_t)2 * c.K * c.G, 0);
+}
+
+// answer what has arrived for this chip; 0 = nothing new or progress, < 0 = error.  Never blocks.
+int serve(ceno_hip_cohort* co, LayerChip& c) {
+    TowerProveState& st = c.run->st;
+    if (!c.started) {  // IOPProverState::prove's header: the number of variables and the degree
+        prover_tr_usize(st.tr, (uint64_t)c.L);
+        prover_tr_usize(st.tr, 3);
+        c.started = true;
+    }
+    if (c.round < c.n_lo) {
+        for (int g = 0; g < c.G; g++) {
+            if (c.got[(size_t)g]) continue;
+            const int r = ceno_hip_tower_cohort_try_message(co, c.first_job + g, c.round, c.part.data() + 6 * (size_t)g);
+            if (r < 0) return r;
+            if (r == 1) {
+                c.got[(size_t)g] = 1;
+                c.n_got++;
+            }
+        }
+        if (c.n_got < c.G) return 0;
+        uint64_t* msg = st.out->msgs + st.msg_off + 6 * (size_t)c.round;
+        if (c.G == 1) memcpy(msg, c.part.data(), 48);
+        else
+            for (int e = 0; e < 3; e++) {
+                E2 acc = gl::e2_zero();
+                for (int g = 0; g < c.G; g++) acc = acc + c.eq_hi[(size_t)g] * E2{c.part[6 * (size_t)g + 2 * e], c.part[6 * (size_t)g + 2 * e + 1]};
+                msg[2 * e] = acc.c0;
+                msg[2 * e + 1] = acc.c1;
+            }
+        const E2 ch = prover_tr_round(st.tr, msg);
+        const uint64_t w[2] = {ch.c0, ch.c1};
+        c.chal[2 * (size_t)c.round] = w[0];
+        c.chal[2 * (size_t)c.round + 1] = w[1];
+        for (int g = 0; g < c.G; g++)
+            if (int r = ceno_hip_tower_cohort_send_challenge(co, c.first_job + g, c.round, w)) return r;
+        c.round++;
+        c.n_got = 0;
+        std::fill(c.got.begin(), c.got.end(), 0);
+        return 0;
+    }
+    // every challenge of the launch is out: the sub-cubes' evaluations at the point
+    for (int g = 0; g < c.G; g++) {
+        if (c.got[(size_t)g]) continue;
+        const int r = ceno_hip_tower_cohort_try_final(co, c.first_job + g, c.finbuf.data() + (size_t)2 * c.K * g);
+        if (r < 0) return r;
+        if (r == 1) {
+            c.got[(size_t)g] = 1;
+            c.n_got++;
+        }
+    }
+    if (c.n_got < c.G) return 0;
+    if (c.G == 1) c.fin = c.finbuf;
+    else {
+        // the tables over the top variables: entry g = sub-cube g's evaluation (eq: times eq over the top variables); the last L - n_lo
+        // rounds on the host, as the row-sharded tower prover finishes its layers (dist_gkr.cpp)
+        std::vector<std::vector<E2>> tabs((size_t)c.K, std::vector<E2>((size_t)c.G));
+        for (int g = 0; g < c.G; g++)
+            for (int m = 0; m < c.K; m++) {
+                const uint64_t* w = c.finbuf.data() + (size_t)2 * c.K * g + 2 * (size_t)m;
+                tabs[(size_t)m][(size_t)g] = m == 0 ? c.eq_hi[(size_t)g] * E2{w[0], w[1]} : E2{w[0], w[1]};
+            }
+        auto as_e2 = [](const std::vector<uint64_t>& v) {
+            std::vector<E2> o(v.size() / 2);
+            for (size_t i = 0; i < o.size(); i++) o[i] = E2{v[2 * i], v[2 * i + 1]};
+            return o;
+        };
+        prover_host_tower_rounds(c.L - c.n_lo, tabs, c.np_act, c.nl_act, as_e2(c.a_prod), as_e2(c.a_num), as_e2(c.a_den), st.tr,
+                                 st.out->msgs + st.msg_off + 6 * (size_t)c.n_lo, c.chal.data() + 2 * (size_t)c.n_lo, c.fin.data());
+    }
+    c.done = true;
+    return tower_state_layer_epilogue(st, c.chal.data(), c.fin.data());
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// layers first .. last of every run in `runs` that stands before such a layer, on `n_threads` serving threads.  A run whose status is set is
+// skipped; a failure sets the status of the runs it touches.  Returns the first error.
+int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int last_layer, int n_threads) {
+    const int sub = ceno_hip_tower_cohort_max_vars();
+    int capacity = ceno_hip_tower_cohort_capacity(ctx);
+    if (const char* e = getenv("CENO_TOWER_COHORT_CAPACITY"))  // (tests: several launches per layer)
+        if (atoi(e) > 0) capacity = std::min(capacity, atoi(e));
+    if (capacity < 1) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "cohort: the device holds no cohort workgroup");
+    ceno_hip_stream stream = nullptr;
+    if (int rc = ceno_hip_lane_stream(ctx, 0, &stream)) return prover_set_error(rc, ceno_hip_last_error(ctx));
+    static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
+    static const double timeout_ms = [] {
+        const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
+        return 1e3 * (e && atof(e) > 0 ? atof(e) : 60.0);
+    }();
+    n_threads = std::max(1, std::min<int>(n_threads, (int)runs.size()));
+    SpinBarrier bar;
+    bar.n = n_threads;
+    std::atomic<int> err{0};
+    std::vector<LayerChip> chips;      // this launch's chips
+    ceno_hip_cohort* co = nullptr;
+    std::atomic<bool> more{true};
+    std::string err_msg;
+    // thread 0 between the barriers: the next launch (the chips standing before the lowest open layer <= last_layer, as many as the device
+    // holds at once), or the end
+    int first_pending = 0;  // (within one layer: chips from this index on have not been launched yet)
+    int layer_now = 0;
+    auto next_launch = [&]() -> bool {
+        for (;;) {
+            if (layer_now == 0) {
+                int L = 0;
+                for (size_t i = 0; i < runs.size(); i++)
+                    if (!status[i] && !runs[i]->st.done() && runs[i]->st.round <= last_layer) L = L ? std::min(L, runs[i]->st.round) : runs[i]->st.round;
+                if (!L) return false;
+                layer_now = L;
+                first_pending = 0;
+            }
+            chips.clear();
+            int jobs = 0;
+            size_t i = (size_t)first_pending;
+            for (; i < runs.size(); i++) {
+                if (status[i] || runs[i]->st.done() || runs[i]->st.round != layer_now) continue;
+                const int G = 1 << std::max(0, layer_now - sub);
+                if (G > capacity) {  // (a layer no launch can hold: left to the per-chip prover)
+                    return false;
+                }
+                if (jobs + G > capacity) break;
+                chips.emplace_back();
+                prepare(chips.back(), runs[i], layer_now, sub);
+                chips.back().first_job = jobs;
+                jobs += G;
+            }
+            first_pending = (int)i;
+            if (chips.empty()) {
+                layer_now = 0;
+                continue;
+            }
+            if (i >= runs.size()) layer_now = 0;  // the layer is complete with this launch
+            std::vector<ceno_hip_cohort_job> hj((size_t)jobs);
+            for (auto& c : chips)
+                for (int g = 0; g < c.G; g++) {
+                    ceno_hip_cohort_job& J = hj[(size_t)(c.first_job + g)];
+                    J.tables = c.tables[(size_t)g].data();
+                    J.n_prod = c.np_act;
+                    J.n_logup = c.nl_act;
+                    J.n = c.n_lo;
+                    J.rt = c.run->st.out_rt.data();
+                    J.alpha_prod = c.a_prod.data();
+                    J.alpha_num = c.a_num.data();
+                    J.alpha_den = c.a_den.data();
+                }
+            const double t0 = trace ? now_ms() : 0;
+            const int rc = ceno_hip_tower_cohort_begin(ctx, hj.data(), jobs, stream, &co);
+            if (rc) {
+                err_msg = ceno_hip_last_error(ctx);
+                err.store(rc);
+                return false;
+            }
+            if (trace) fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs, launch %.3f ms\n", chips[0].L, chips.size(), jobs, now_ms() - t0);
+            return true;
+        }
+    };
+    auto worker = [&](int t) {
+        if (t == 0) (void)ceno_hip_make_current(ctx);
+        for (;;) {
+            if (t == 0) more.store(next_launch());
+            bar.wait();
+            if (!more.load()) return;
+            const double t_begin = now_ms();
+            size_t open = 0;
+            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) open++;
+            unsigned spins = 0;
+            while (open && !err.load(std::memory_order_relaxed)) {
+                for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) {
+                    LayerChip& c = chips[i];
+                    if (c.done) continue;
+                    const int r = serve(co, c);
+                    if (r) {
+                        int zero = 0;
+                        if (err.compare_exchange_strong(zero, r)) err_msg = r == CENO_HIP_ERR_INVALID ? "cohort: a mailbox call was refused" : ceno_prover_last_error();
+                        break;
+                    }
+                    if (c.done) open--;
+                }
+                if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms) {
+                    int zero = 0;
+                    if (err.compare_exchange_strong(zero, CENO_HIP_ERR_STATE)) err_msg = "cohort: a tower layer's rounds did not arrive in time (CENO_HIP_PIPE_TIMEOUT_S)";
+                }
+            }
+            bar.wait();
+            if (t == 0) {
+                if (err.load()) (void)ceno_hip_tower_cohort_abort(co);
+                const int rc = ceno_hip_tower_cohort_end(ctx, co);
+                co = nullptr;
+                if (rc && !err.load()) {
+                    err_msg = ceno_hip_last_error(ctx);
+                    err.store(rc);
+                }
+                if (trace) fprintf(stderr, "[ceno_prover] cohort: layer served in %.3f ms\n", now_ms() - t_begin);
+                if (err.load()) {
+                    more.store(false);
+                }
+            }
+            bar.wait();
+            if (err.load()) return;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+    if (const int rc = err.load()) {
+        for (size_t i = 0; i < runs.size(); i++)
+            if (!status[i] && !runs[i]->st.done()) status[i] = rc;  // (their transcripts may be mid-layer: these proofs are lost)
+        return prover_set_error(rc, err_msg.c_str());
+    }
+    return 0;
+}

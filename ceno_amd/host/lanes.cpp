@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -30,6 +31,12 @@ static std::map<ceno_hip_ctx*, std::shared_ptr<std::mutex>> g_runs;
 extern "C" int ceno_prover_lanes_effective(int n_lanes) {
     const char* e = getenv("CENO_HIP_MAX_LANES");
     const int cap = e && atoi(e) > 0 ? atoi(e) : 4;
+    return std::max(1, std::min(n_lanes, cap));
+}
+// the lanes a run of n_tasks tasks really gets (see the comment in ceno_prover_lanes_run)
+int ceno_prover_lanes_effective_for(int n_lanes, int n_tasks) {
+    const char* e = getenv("CENO_HIP_MAX_LANES");
+    const int cap = e && atoi(e) > 0 ? atoi(e) : (n_tasks >= 24 ? 8 : 4);
     return std::max(1, std::min(n_lanes, cap));
 }
 extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane) {
@@ -50,9 +57,7 @@ extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_
         // unless the batch is MANY tasks (a shard with the reference's ~54 circuits): then the gaps one lane leaves on its queue
         // (host layers, set-up between launches) are worth a second lane per queue — 54 chip proofs: 29.4 ms on 4 lanes, 26.5 on 6,
         // 24.7-25.9 on 8-10, 25.5 on 12 (profiles/r06_shard_wide_lanes.jsonl).  CENO_HIP_MAX_LANES overrides.
-        const char* e = getenv("CENO_HIP_MAX_LANES");
-        const int cap = e && atoi(e) > 0 ? atoi(e) : (n_tasks >= 24 ? 8 : 4);
-        n_lanes = std::min(n_lanes, cap);
+        n_lanes = ceno_prover_lanes_effective_for(n_lanes, n_tasks);
     }
     std::vector<int> order(n_tasks);
     for (int i = 0; i < n_tasks; i++) order[i] = i;
@@ -181,16 +186,97 @@ extern "C" size_t ceno_prover_chip_proof_estimate_bytes(const ceno_chip_task* t)
     return (size_t)(bytes * 1.15) + ((size_t)4 << 20);                              // bucket rounding, small fixed blocks
 }
 
+// ---- the same phase with the middle tower layers of all chips proved together (cohort.cpp) ----
+#include "chip_run.hpp"
+int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int last_layer, int n_threads);  // cohort.cpp
+int prover_tower_host_layers();                                                                                                       // prover.cpp
+namespace {
+struct PhaseJob {
+    ChipProofRun* run;
+    ceno_hip_ctx* ctx;
+    const ceno_chip_task* task;
+    const uint64_t* challenges4;
+    ceno_transcript* tr;
+    ceno_chip_proof* out;
+    int* status;
+    int host_layers;
+};
+int phase_a_fn(void* arg, int, ceno_hip_stream stream) {
+    auto* j = (PhaseJob*)arg;
+    int rc = chip_run_begin(*j->run, j->ctx, j->task, j->challenges4, j->tr, stream, j->out);
+    while (!rc && !j->run->st.done() && j->run->st.round <= j->host_layers) {
+        rc = tower_state_step(j->run->st);
+        if (rc) chip_run_abandon(*j->run);
+    }
+    return *j->status = rc;
+}
+int phase_c_fn(void* arg, int, ceno_hip_stream stream) {
+    auto* j = (PhaseJob*)arg;
+    if (*j->status) {  // lost in an earlier phase
+        chip_run_abandon(*j->run);
+        return *j->status;
+    }
+    return *j->status = chip_run_finish(*j->run, stream);
+}
+// the highest tower layer proved in cohorts: CENO_TOWER_COHORT_LAYERS (0 = the per-chip prover alone; default 16: 2^16 entries = eight
+// sub-cubes per chip)
+int cohort_last_layer() {
+    const char* e = getenv("CENO_TOWER_COHORT_LAYERS");
+    const int v = e ? atoi(e) : 16;
+    return std::max(0, std::min(v, 24));
+}
+}  // namespace
+
 extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4,
                                               ceno_transcript* const* transcripts, int n_lanes, ceno_chip_proof* out_proofs, int* out_status) {
     if (!ctx || !tasks || !challenges4 || !transcripts || !out_proofs || n_tasks < 0 || n_lanes < 1)
         return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proofs: bad arguments");
-    std::vector<ChipJob> jobs(n_tasks);
-    std::vector<ceno_lane_task> lt(n_tasks);
-    for (int i = 0; i < n_tasks; i++) {
+    for (int i = 0; i < n_tasks; i++)
         if (!transcripts[i]) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proofs: NULL transcript");
-        jobs[i] = ChipJob{ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i]};
-        lt[i] = ceno_lane_task{chip_job_fn, &jobs[i], ceno_prover_chip_proof_estimate_bytes(&tasks[i])};
+    const int lanes = std::min(n_lanes, std::max(n_tasks, 1));
+    // Cohorts pay when there are many chips (fewer than the lanes: every chip has a stream to itself anyway), need every chip's towers
+    // resident at once — booked here as one block, the per-chip path when that is refused — and a device whose memory the host can write.
+    const int last_layer = cohort_last_layer(), host_layers = prover_tower_host_layers();
+    size_t total = 0;
+    for (int i = 0; i < n_tasks; i++) total += ceno_prover_chip_proof_estimate_bytes(&tasks[i]);
+    const bool cohort = last_layer > host_layers && n_tasks >= 8 && ceno_hip_tower_cohort_capacity(ctx) >= 8 && ceno_hip_mem_book(ctx, total + ((size_t)1 << 30)) == 0;
+    if (!cohort) {
+        std::vector<ChipJob> jobs(n_tasks);
+        std::vector<ceno_lane_task> lt(n_tasks);
+        for (int i = 0; i < n_tasks; i++) {
+            jobs[i] = ChipJob{ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i]};
+            lt[i] = ceno_lane_task{chip_job_fn, &jobs[i], ceno_prover_chip_proof_estimate_bytes(&tasks[i])};
+        }
+        return ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, out_status, nullptr);
     }
-    return ceno_prover_lanes_run(ctx, std::min(n_lanes, std::max(n_tasks, 1)), lt.data(), n_tasks, out_status, nullptr);
+    std::vector<ChipProofRun> runs((size_t)n_tasks);
+    std::vector<ChipProofRun*> run_ptrs((size_t)n_tasks);
+    std::vector<int> status((size_t)n_tasks, 0);
+    std::vector<PhaseJob> jobs((size_t)n_tasks);
+    std::vector<ceno_lane_task> lt((size_t)n_tasks);
+    for (int i = 0; i < n_tasks; i++) {
+        run_ptrs[(size_t)i] = &runs[(size_t)i];
+        jobs[(size_t)i] = PhaseJob{&runs[(size_t)i], ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i], &status[(size_t)i], host_layers};
+        // (the block above is the booking; what a task "books" here only orders the tasks, largest first)
+        lt[(size_t)i] = ceno_lane_task{phase_a_fn, &jobs[(size_t)i], ceno_prover_chip_proof_estimate_bytes(&tasks[i]) >> 20};
+    }
+    static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    (void)ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
+    const double t_a = ms();
+    const int rc_b = cohort_prove_layers(ctx, run_ptrs, status, last_layer, ceno_prover_lanes_effective_for(lanes, n_tasks));
+    const std::string msg_b = rc_b ? ceno_prover_last_error() : "";
+    const double t_b = ms();
+    for (int i = 0; i < n_tasks; i++) lt[(size_t)i].fn = phase_c_fn;
+    (void)ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
+    if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: to layer %d on lanes %.3f ms, cohort layers to %d %.3f ms, the rest on lanes %.3f ms\n", host_layers, t_a, last_layer, t_b - t_a, ms() - t_b);
+    ceno_hip_mem_unbook(ctx, total + ((size_t)1 << 30));
+    int first_err = 0;
+    for (int i = 0; i < n_tasks; i++) {
+        if (out_status) out_status[i] = status[(size_t)i];
+        if (status[(size_t)i] && !first_err) first_err = status[(size_t)i];
+    }
+    if (rc_b) return prover_set_error(rc_b, msg_b.c_str());
+    return first_err ? prover_set_error(first_err, "create_chip_proofs: a task failed (see the per-task status)") : 0;
 }

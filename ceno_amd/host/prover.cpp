@@ -19,6 +19,7 @@
 #include "../csrc/gl64.hpp"
 #include "../csrc/e2_host_avx512.hpp"
 #include "transcript.hpp"
+#include "tower_state.hpp"
 
 using gl::E2;
 
@@ -213,13 +214,6 @@ size_t ceno_tower_msgs_words(int max_nv) {
 // Field arithmetic is exact, so the messages, challenges and evaluations equal the device path's bit for bit.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
-struct HostTowerTop {
-    std::vector<uint64_t> words;  // ceno_hip_tower_download_top layout
-    int n_limbs = 0, n_layers = 0;
-    const E2* limb(int layer, int b) const {
-        return reinterpret_cast<const E2*>(words.data()) + (size_t)n_limbs * (((size_t)1 << layer) - 1) + ((size_t)b << layer);
-    }
-};
 int tower_host_layers() {
     const char* e = getenv("CENO_TOWER_HOST_LAYERS");  // layers 1 .. this are proved on the host (0: none)
     return e ? atoi(e) : 8;
@@ -370,72 +364,101 @@ int ceno_prover_tower_create_proof(ceno_hip_ctx* ctx, ceno_hip_tower* const* pro
 // CpuTowerProver::create_proof.  hook == NULL: the towers hold every layer.  hook != NULL (row-sharded chip proof): the towers passed in are
 // the REPLICATED tops of towers whose large layers live sharded across ranks — the numbers of variables come from the hook, rounds above
 // hook->r_rep are proved by hook->layer (same outputs: the round's messages, challenges and final evaluations).
-int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
-                                     ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out, const TowerDistHook* hook) {
+// Written as a resumable state (tower_state.hpp): init, one step per layer, finish — the cohort driver interleaves the steps of many chips.
+int TowerProveState::nv_of(const ceno_hip_tower* t) const {
+    if (hook) {
+        for (int i = 0; i < n_prod; i++) if (prod[i] == t) return hook->nv_global[i];
+        for (int i = 0; i < n_logup; i++) if (logup[i] == t) return hook->nv_global[n_prod + i];
+    }
+    return ::ceno_hip_tower_num_vars(t);
+}
+void prover_tr_usize(ceno_transcript* t, uint64_t v) { tr_usize(t, v); }
+void prover_tr_ext_words(ceno_transcript* t, const uint64_t* ext, int n_ext) {
+    for (int i = 0; i < n_ext; i++) tr_ext(t, ext + 2 * i);
+}
+E2 prover_tr_round(ceno_transcript* t, const uint64_t* msg6) {
+    for (int e = 0; e < 3; e++) tr_ext(t, msg6 + 2 * e);
+    tr_label(t, "Internal round");
+    return tr_sample(t);
+}
+
+int tower_state_init(TowerProveState& st, ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                     ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out, const TowerDistHook* hook) {
     if (!ctx || !tr || !out) return fail(CENO_HIP_ERR_INVALID, "NULL argument");
-    auto ceno_hip_tower_num_vars = [&](const ceno_hip_tower* t) {  // (shadows the C entry inside this function: the GLOBAL height of a tower)
-        if (hook) {
-            for (int i = 0; i < n_prod; i++) if (prod[i] == t) return hook->nv_global[i];
-            for (int i = 0; i < n_logup; i++) if (logup[i] == t) return hook->nv_global[n_prod + i];
-        }
-        return ::ceno_hip_tower_num_vars(t);
-    };
-    int max_nv = 0;
-    for (int i = 0; i < n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(prod[i]));
-    for (int i = 0; i < n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(logup[i]));
-    if (max_nv < 1) return fail(CENO_HIP_ERR_INVALID, "tower: no specs");
-    const int n_alpha = n_prod + 2 * n_logup;
-    std::vector<uint64_t> alpha;
-    tr_challenge_pows(tr, n_alpha, alpha);          // cpu/mod.rs:375-380
+    st.ctx = ctx; st.prod = prod; st.n_prod = n_prod; st.logup = logup; st.n_logup = n_logup; st.tr = tr; st.s = s; st.out = out; st.hook = hook;
+    st.max_nv = 0;
+    for (int i = 0; i < n_prod; i++) st.max_nv = std::max(st.max_nv, st.nv_of(prod[i]));
+    for (int i = 0; i < n_logup; i++) st.max_nv = std::max(st.max_nv, st.nv_of(logup[i]));
+    if (st.max_nv < 1) return fail(CENO_HIP_ERR_INVALID, "tower: no specs");
+    st.n_alpha = n_prod + 2 * n_logup;
+    tr_challenge_pows(tr, st.n_alpha, st.alpha);    // cpu/mod.rs:375-380
     tr_label(tr, "product_sum");                    // cpu/mod.rs:381  (sample_and_append_vec, log2(fanin) = 1)
-    std::vector<uint64_t> out_rt(2 * (size_t)(max_nv + 1));
+    st.out_rt.assign(2 * (size_t)(st.max_nv + 1), 0);
     {
         E2 r0 = tr_sample(tr);
-        out_rt[0] = r0.c0;
-        out_rt[1] = r0.c1;
+        st.out_rt[0] = r0.c0;
+        st.out_rt[1] = r0.c1;
     }
-    const int R = max_nv - 1;
-    out->num_rounds = R;
-    size_t msg_off = 0;
-    std::vector<uint64_t> chal, fin;
-    const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr || getenv("CENO_PROVER_LAYER_TRACE") != nullptr;
-    auto now_us = []() {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
-    };
+    st.R = st.max_nv - 1;
+    out->num_rounds = st.R;
+    st.msg_off = 0;
+    st.round = 1;
+    st.claim = gl::e2_zero();  // round 1: from the out-evals, not formed here
+    st.have_claim = false;
     // the small layers of every tower, one copy per tower
-    const int host_layers = std::min(tower_host_layers(), R);
-    std::vector<HostTowerTop> top_prod((size_t)n_prod), top_logup((size_t)n_logup);
-    if (host_layers >= 1) {
+    st.host_layers = std::min(tower_host_layers(), st.R);
+    st.top_prod.assign((size_t)n_prod, HostTowerTop());
+    st.top_logup.assign((size_t)n_logup, HostTowerTop());
+    if (st.host_layers >= 1) {
         auto fetch = [&](ceno_hip_tower* t, HostTowerTop& h) -> int {
             // layers 0 .. min(host_layers, num_vars - 1) of this tower (layer `round` exists when num_vars > round)
             h.n_limbs = ceno_hip_tower_num_limbs(t);
-            h.n_layers = std::min(std::min(host_layers + 1, ::ceno_hip_tower_num_vars(t)), ceno_hip_tower_top_layers(t));
+            h.n_layers = std::min(std::min(st.host_layers + 1, ::ceno_hip_tower_num_vars(t)), ceno_hip_tower_top_layers(t));
             if (h.n_layers < 1) return 0;
             h.words.resize((size_t)2 * h.n_limbs * (((size_t)1 << h.n_layers) - 1));
             return ceno_hip_tower_download_top(ctx, t, h.n_layers, h.words.data(), s);
         };
         for (int i = 0; i < n_prod; i++)
-            if (int rc = fetch(prod[i], top_prod[i])) return fail_from_ctx(ctx, rc);
+            if (int rc = fetch(prod[i], st.top_prod[i])) return fail_from_ctx(ctx, rc);
         for (int i = 0; i < n_logup; i++)
-            if (int rc = fetch(logup[i], top_logup[i])) return fail_from_ctx(ctx, rc);
+            if (int rc = fetch(logup[i], st.top_logup[i])) return fail_from_ctx(ctx, rc);
     }
-    E2 claim = gl::e2_zero();  // the sum the next layer's sumcheck proves, known from the layer before it (round 1: from the out-evals, not formed here)
-    bool have_claim = false;
-    for (int round = 1; round <= R; round++) {      // cpu/mod.rs:409: skip(1) for the output layer
-        bool on_host = round <= host_layers;
+    return 0;
+}
+
+int tower_state_step(TowerProveState& st) {
+    if (st.done()) return 0;
+    ceno_hip_ctx* ctx = st.ctx;
+    ceno_transcript* tr = st.tr;
+    ceno_hip_stream s = st.s;
+    ceno_tower_proof* out = st.out;
+    const TowerDistHook* hook = st.hook;
+    ceno_hip_tower* const* prod = st.prod;
+    ceno_hip_tower* const* logup = st.logup;
+    const int n_prod = st.n_prod, n_logup = st.n_logup, round = st.round;
+    std::vector<uint64_t>& alpha = st.alpha;
+    std::vector<uint64_t>& out_rt = st.out_rt;
+    auto ceno_hip_tower_num_vars = [&](const ceno_hip_tower* t) { return st.nv_of(t); };  // (shadows the C entry: the GLOBAL height of a tower)
+    std::vector<uint64_t> chal, fin;
+    static const bool dbg = getenv("CENO_HIP_DEBUG") != nullptr || getenv("CENO_PROVER_LAYER_TRACE") != nullptr;
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
+    {                                               // cpu/mod.rs:409: skip(1) for the output layer
+        bool on_host = round <= st.host_layers;
         for (int i = 0; i < n_prod && on_host; i++)
-            if (ceno_hip_tower_num_vars(prod[i]) > round && top_prod[i].n_layers <= round) on_host = false;
+            if (ceno_hip_tower_num_vars(prod[i]) > round && st.top_prod[i].n_layers <= round) on_host = false;
         for (int i = 0; i < n_logup && on_host; i++)
-            if (ceno_hip_tower_num_vars(logup[i]) > round && top_logup[i].n_layers <= round) on_host = false;
+            if (ceno_hip_tower_num_vars(logup[i]) > round && st.top_logup[i].n_layers <= round) on_host = false;
         if (hook && round > hook->r_rep) {
             int n_mles = 1;
             for (int i = 0; i < n_prod; i++) if (ceno_hip_tower_num_vars(prod[i]) > round) n_mles += 2;
             for (int i = 0; i < n_logup; i++) if (ceno_hip_tower_num_vars(logup[i]) > round) n_mles += 4;
             chal.assign((size_t)2 * round, 0);
             fin.assign((size_t)2 * n_mles, 0);
-            if (int rc = hook->layer(hook->self, round, out_rt.data(), alpha.data(), tr, out->msgs + msg_off, chal.data(), fin.data())) return rc;
+            if (int rc = hook->layer(hook->self, round, out_rt.data(), alpha.data(), tr, out->msgs + st.msg_off, chal.data(), fin.data())) return rc;
         } else if (on_host) {
             std::vector<std::vector<E2>> tabs;
             std::vector<E2> a_prod, a_num, a_den;
@@ -456,13 +479,13 @@ int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
             int np_act = 0, nl_act = 0;
             for (int i = 0; i < n_prod; i++) {
                 if (ceno_hip_tower_num_vars(prod[i]) <= round) continue;
-                for (int b = 0; b < 2; b++) tabs.emplace_back(top_prod[i].limb(round, b), top_prod[i].limb(round, b) + len);
+                for (int b = 0; b < 2; b++) tabs.emplace_back(st.top_prod[i].limb(round, b), st.top_prod[i].limb(round, b) + len);
                 a_prod.push_back(E2{alpha[2 * i], alpha[2 * i + 1]});
                 np_act++;
             }
             for (int i = 0; i < n_logup; i++) {
                 if (ceno_hip_tower_num_vars(logup[i]) <= round) continue;
-                for (int b = 0; b < 4; b++) tabs.emplace_back(top_logup[i].limb(round, b), top_logup[i].limb(round, b) + len);
+                for (int b = 0; b < 4; b++) tabs.emplace_back(st.top_logup[i].limb(round, b), st.top_logup[i].limb(round, b) + len);
                 a_num.push_back(E2{alpha[2 * (n_prod + 2 * i)], alpha[2 * (n_prod + 2 * i) + 1]});
                 a_den.push_back(E2{alpha[2 * (n_prod + 2 * i + 1)], alpha[2 * (n_prod + 2 * i + 1) + 1]});
                 nl_act++;
@@ -470,7 +493,7 @@ int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
             if (np_act + nl_act == 0) return fail(CENO_HIP_ERR_INVALID, "tower: no spec has this layer");
             chal.assign((size_t)2 * round, 0);
             fin.assign((size_t)2 * tabs.size(), 0);
-            host_tower_layer(round, tabs, np_act, nl_act, a_prod, a_num, a_den, tr, out->msgs + msg_off, chal.data(), fin.data());
+            host_tower_layer(round, tabs, np_act, nl_act, a_prod, a_num, a_den, tr, out->msgs + st.msg_off, chal.data(), fin.data());
         } else {
         ceno_hip_sumcheck* sc = nullptr;
         const double t_a = dbg ? now_us() : 0;
@@ -484,25 +507,39 @@ int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
         chal.assign((size_t)2 * round, 0);
         fin.assign((size_t)2 * n_mles, 0);
         ceno_hip_sumcheck_set_pipelined(ctx, sc, 1);  // the loop below drives the rounds back to back
-        if (have_claim) {                             // the fused tower rounds then need two values in round 0 instead of three
-            const uint64_t c2[2] = {claim.c0, claim.c1};
+        if (st.have_claim) {                          // the fused tower rounds then need two values in round 0 instead of three
+            const uint64_t c2[2] = {st.claim.c0, st.claim.c1};
             rc = ceno_hip_sumcheck_set_claim(ctx, sc, c2);
             if (rc) { ceno_hip_sumcheck_free(ctx, sc); return fail_from_ctx(ctx, rc); }
         }
-        rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + msg_off, chal.data(), fin.data());
+        rc = ceno_prover_sumcheck_run(ctx, sc, round, 3, n_mles, tr, out->msgs + st.msg_off, chal.data(), fin.data());
         const double t_c = dbg ? now_us() : 0;
         ceno_hip_sumcheck_free(ctx, sc);
         if (dbg) fprintf(stderr, "[ceno_prover] tower layer %d: begin %.0f us, rounds %.0f us, free %.0f us\n", round, t_b - t_a, t_c - t_b, now_us() - t_c);
         if (rc) return rc;
         }
-        msg_off += (size_t)round * 3 * 2;
+    }
+    return tower_state_layer_epilogue(st, chal.data(), fin.data());
+}
+
+int tower_state_layer_epilogue(TowerProveState& st, const uint64_t* chal, const uint64_t* fin) {
+    ceno_transcript* tr = st.tr;
+    ceno_tower_proof* out = st.out;
+    ceno_hip_tower* const* prod = st.prod;
+    ceno_hip_tower* const* logup = st.logup;
+    const int n_prod = st.n_prod, n_logup = st.n_logup, round = st.round, R = st.R;
+    std::vector<uint64_t>& alpha = st.alpha;
+    std::vector<uint64_t>& out_rt = st.out_rt;
+    auto ceno_hip_tower_num_vars = [&](const ceno_hip_tower* t) { return st.nv_of(t); };
+    {
+        st.msg_off += (size_t)round * 3 * 2;
         // evaluations are bound into the transcript before r_merge is sampled (cpu/mod.rs:498-531)
         int cursor = 1;
         for (int i = 0; i < n_prod; i++) {
             uint64_t* dst = out->prod_evals + 2 * ((size_t)(i * R + (round - 1)) * 2);
             if (ceno_hip_tower_num_vars(prod[i]) <= round) { memset(dst, 0, 32); continue; }
             for (int k = 0; k < 2; k++) {
-                memcpy(dst + 2 * k, fin.data() + 2 * (cursor + k), 16);
+                memcpy(dst + 2 * k, fin + 2 * (cursor + k), 16);
                 tr_ext(tr, dst + 2 * k);
             }
             cursor += 2;
@@ -511,20 +548,20 @@ int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
             uint64_t* dst = out->logup_evals + 2 * ((size_t)(i * R + (round - 1)) * 4);
             if (ceno_hip_tower_num_vars(logup[i]) <= round) { memset(dst, 0, 64); continue; }
             for (int k = 0; k < 4; k++) {
-                memcpy(dst + 2 * k, fin.data() + 2 * (cursor + k), 16);
+                memcpy(dst + 2 * k, fin + 2 * (cursor + k), 16);
                 tr_ext(tr, dst + 2 * k);
             }
             cursor += 4;
         }
         tr_label(tr, "merge");                       // cpu/mod.rs:534
         E2 r_merge = tr_sample(tr);
-        memcpy(out_rt.data(), chal.data(), (size_t)16 * round);   // rt' = challenges || r_merge (cpu/mod.rs:535)
+        memcpy(out_rt.data(), chal, (size_t)16 * round);          // rt' = challenges || r_merge (cpu/mod.rs:535)
         out_rt[2 * round] = r_merge.c0;
         out_rt[2 * round + 1] = r_merge.c1;
-        tr_challenge_pows(tr, n_alpha, alpha);       // cpu/mod.rs:538-541
+        tr_challenge_pows(tr, st.n_alpha, alpha);    // cpu/mod.rs:538-541
         // What layer round + 1 will prove: the alpha-combination (new powers) of this layer's tables merged at r_merge — a tower's layer as one
         // vector is [first half | second half], r_merge binds the top variable (the sum TowerVerify forms, scheme/verifier.rs:1587-1680).
-        claim = gl::e2_zero();
+        E2 claim = gl::e2_zero();
         cursor = 1;
         for (int i = 0; i < n_prod; i++) {
             const int nv = ceno_hip_tower_num_vars(prod[i]);
@@ -543,9 +580,22 @@ int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* p
             }
             cursor += 4;
         }
-        have_claim = true;
+        st.claim = claim;
+        st.have_claim = true;
     }
-    memcpy(out->point, out_rt.data(), (size_t)16 * max_nv);
+    st.round++;
+    return 0;
+}
+
+void tower_state_finish(TowerProveState& st) { memcpy(st.out->point, st.out_rt.data(), (size_t)16 * st.max_nv); }
+
+int prover_tower_create_proof_hooked(ceno_hip_ctx* ctx, ceno_hip_tower* const* prod, int n_prod, ceno_hip_tower* const* logup, int n_logup,
+                                     ceno_transcript* tr, ceno_hip_stream s, ceno_tower_proof* out, const TowerDistHook* hook) {
+    TowerProveState st;
+    if (int rc = tower_state_init(st, ctx, prod, n_prod, logup, n_logup, tr, s, out, hook)) return rc;
+    while (!st.done())
+        if (int rc = tower_state_step(st)) return rc;
+    tower_state_finish(st);
     return 0;
 }
 

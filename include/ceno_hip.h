@@ -297,6 +297,8 @@ int ceno_hip_tower_num_vars(const ceno_hip_tower* t);   /* number of layers */
 int ceno_hip_tower_num_limbs(const ceno_hip_tower* t);  /* 2 or 4 */
 /* borrowed handle of limb `limb` of layer `layer` (valid while the tower lives) */
 int ceno_hip_tower_layer(ceno_hip_ctx* ctx, ceno_hip_tower* t, int layer, int limb, ceno_hip_mle** out);
+/* the same table as a bare device pointer (2^layer extension elements; NULL when out of range) */
+const uint64_t* ceno_hip_tower_layer_ptr(const ceno_hip_tower* t, int layer, int limb);
 int ceno_hip_tower_out_evals(ceno_hip_ctx* ctx, ceno_hip_tower* t, uint64_t* out /* n_limbs ext */, ceno_hip_stream s);
 /* The top layers of a tower (layer l has n_limbs * 2^l elements) are stored back to back so that a host-side prover of the small
  * layers needs ONE copy: layers 0 .. n_layers-1 into host_out, layer l limb b at element offset n_limbs * (2^l - 1) + b * 2^l
@@ -399,6 +401,8 @@ typedef struct ceno_hip_cohort_job {
     const uint64_t *alpha_prod, *alpha_num, *alpha_den;
 } ceno_hip_cohort_job;
 int ceno_hip_tower_cohort_max_vars(void);
+/* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host */
+int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx);
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
 int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6);
 int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2);

@@ -294,6 +294,43 @@ def test_wide_shard_proof_does_not_depend_on_the_lanes(dev, prover):
     flow.close()
 
 
+def _proof_words(a):
+    per_chip = []
+    for p in a["chip_proofs"]:
+        per_chip.append((p.tower_num_vars, p.tower_msgs.tolist(), p.tower_point.tolist(), p.tower_logup_evals.tolist(),
+                         p.tower_prod_evals.tolist() if p.n_prod else None, [tup(x) for x in p.r_out_evals], [tup(x) for x in p.w_out_evals],
+                         [tup(x) for x in p.lk_out_evals], np.asarray(p.rt_main).tolist()))
+    return (per_chip, a["fork_samples"], a["msgs"].tolist(), a["evals"].tolist(), a["open_proof"].tolist())
+
+
+def test_cohort_layers_write_the_same_proofs(dev, prover, monkeypatch):
+    """the middle tower layers of all chips proved together (host/cohort.cpp, csrc/tower_cohort.hip) against the per-chip prover
+    (CENO_TOWER_COHORT_LAYERS=0), word for word over every chip proof and everything derived from them: cohorts up to 2^13 entries (one workgroup
+    per chip), up to 2^16 (the default: eight sub-cubes + three host rounds) and 2^18, several launches per layer (a device that holds 24
+    workgroups), and with the host layers moved so that the cohorts start at layer 5"""
+    from ceno_amd import synthetic
+
+    flow = synthetic.ShardFlowWide(dev, prover, log_cycles=12, n_queries=8, pow_bits=4)
+
+    def run(env):
+        for k in ("CENO_TOWER_COHORT_LAYERS", "CENO_TOWER_COHORT_CAPACITY", "CENO_TOWER_HOST_LAYERS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        flow.run(lambda: prover.Transcript.stub(0x5A), lambda: prover.Transcript.stub(0xF0), lanes=8)
+        return _proof_words(flow.artifacts)
+
+    ref = run({"CENO_TOWER_COHORT_LAYERS": "0"})
+    assert max(p[0] for p in ref[0]) >= 18      # the tables' towers reach past every cohort layer tried here
+    for env in ({}, {"CENO_TOWER_COHORT_LAYERS": "13"}, {"CENO_TOWER_COHORT_LAYERS": "18"}, {"CENO_TOWER_COHORT_CAPACITY": "24"},
+                {"CENO_TOWER_HOST_LAYERS": "4"}):
+        got = run(env)
+        for c, (w, g) in enumerate(zip(ref[0], got[0])):
+            assert w == g, (env, flow.chips[c]["name"])
+        assert got[1:] == ref[1:], env
+    flow.close()
+
+
 def test_witgen_session_rejects_unregistered_tables_and_nests_cleanly(dev, prover):
     """a table named inside a session must have been registered; a second begin on the same context is refused; without a session the per-chip
     calls behave as before (they clear, merge and wait on their own)"""
