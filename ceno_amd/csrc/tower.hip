@@ -157,6 +157,101 @@ __global__ void __launch_bounds__(1024) k_tower_top(E2* __restrict__ block, int 
     }
 }
 
+// ---- MANY towers per launch (ceno_hip_tower_build_many): the towers of all chips of a shard, level by level ---------------------------------
+// A shard's ~54 chips have ~160 towers of ~11 dependent launches each; chip by chip on scheduler lanes that is ~1800 dependent launches over
+// four hardware queues (~1.7 us apiece however many lanes there are).  Level-synchronous over ALL towers it is one interleave launch, one
+// launch per layer size and one for the contiguous tops: ~15 launches, each wide enough to fill the device.
+struct BlkRef {
+    uint32_t job, blk, nblk;  // workgroup b of the launch is block `blk` of `nblk` of job `job`
+};
+struct IlvJob {
+    RecArg ra;
+    E2 *out0, *out1;
+    size_t out_len;
+};
+struct LayerJob {
+    const E2* below;
+    E2* out;
+    size_t len_below;
+    int limbs, pad_;
+};
+struct TopJob {
+    E2* block;
+    int from, limbs;
+};
+struct CopyJob {
+    const E2* src;
+    E2* dst;
+    size_t n;
+};
+__global__ void __launch_bounds__(NT) k_interleave_many(const IlvJob* __restrict__ jobs, const BlkRef* __restrict__ blks) {
+    const BlkRef b = blks[blockIdx.x];
+    const IlvJob& J = jobs[b.job];
+    const RecArg& ra = J.ra;
+    const size_t out_len = J.out_len, stride = (size_t)b.nblk * NT;
+    const int log_s = ra.log_s, k = ra.k, ones = ra.ones;
+    const size_t smask = ((size_t)1 << log_s) - 1, start1 = ra.start1;
+    const E2 dflt = ra.dflt;
+    E2 *out0 = J.out0, *out1 = J.out1;
+    for (size_t o = (size_t)b.blk * NT + threadIdx.x; o < 2 * out_len; o += stride) {
+        const int limb = o >= out_len;
+        const size_t x = limb ? o - out_len : o;
+        const size_t i = x >> log_s;
+        const int j = (int)(x & smask);
+        E2 v = dflt;
+        if (!ones && j < k) {
+            const uint32_t cnt = limb ? ra.cnt1[j] : ra.cnt0[j];
+            if (i < cnt) {
+                const size_t src = (limb ? start1 : 0) + i;
+                if (ra.is_ext[j]) v = reinterpret_cast<const E2*>(ra.ptr[j])[src];
+                else v = E2{ra.ptr[j][src], 0};
+            }
+        }
+        (limb ? out1 : out0)[x] = v;
+    }
+}
+__global__ void __launch_bounds__(NT) k_layer_many(const LayerJob* __restrict__ jobs, const BlkRef* __restrict__ blks) {
+    const BlkRef b = blks[blockIdx.x];
+    const LayerJob J = jobs[b.job];
+    const size_t stride = (size_t)b.nblk * NT, len_below = J.len_below;
+    const E2* below = J.below;
+    E2* out = J.out;
+    if (J.limbs == 2) {
+        for (size_t x = (size_t)b.blk * NT + threadIdx.x; x < len_below; x += stride) out[x] = below[x] * below[len_below + x];
+    } else {
+        for (size_t x = (size_t)b.blk * NT + threadIdx.x; x < len_below; x += stride) {
+            const E2 a = below[2 * len_below + x], c = below[3 * len_below + x];
+            out[x] = a * below[len_below + x] + c * below[x];
+            out[len_below + x] = a * c;
+        }
+    }
+}
+__global__ void __launch_bounds__(1024) k_tower_top_many(const TopJob* __restrict__ jobs) {
+    const TopJob J = jobs[blockIdx.x];
+    E2* block = J.block;
+    const size_t limbs = (size_t)J.limbs;
+    for (int l = J.from - 1; l >= 0; l--) {
+        const E2* below = block + limbs * (((size_t)1 << (l + 1)) - 1);
+        E2* out = block + limbs * (((size_t)1 << l) - 1);
+        const size_t len_below = (size_t)1 << (l + 1);
+        for (size_t x = threadIdx.x; x < len_below; x += 1024) {
+            if (J.limbs == 2) {
+                out[x] = below[x] * below[len_below + x];
+            } else {
+                const E2 a = below[2 * len_below + x], b = below[3 * len_below + x];
+                out[x] = a * below[len_below + x] + b * below[x];
+                out[len_below + x] = a * b;
+            }
+        }
+        __syncthreads();
+    }
+}
+// the top blocks of many towers into one staging block (pinned host memory: the device writes it through PCIe), one workgroup per tower
+__global__ void __launch_bounds__(256) k_copy_many(const CopyJob* __restrict__ jobs) {
+    const CopyJob J = jobs[blockIdx.x];
+    for (size_t i = threadIdx.x; i < J.n; i += 256) J.dst[i] = J.src[i];
+}
+
 static int tower_build_upper(ceno_hip_ctx* ctx, ceno_hip_tower* t, hipStream_t st) {
     static const bool fuse = !(getenv("CENO_HIP_TOWER_TOP_FUSED") && atoi(getenv("CENO_HIP_TOWER_TOP_FUSED")) == 0);  // A/B switch
     const int from = fuse ? std::min(t->num_vars - 1, t->top_layers - 1) : 0;  // layers below `from` come from the fused kernel
@@ -322,6 +417,140 @@ int ceno_hip_tower_from_last_layer(ceno_hip_ctx* ctx, ceno_hip_mle* const* limbs
     return 0;
 }
 
+int ceno_hip_tower_build_many(ceno_hip_ctx* ctx, const ceno_hip_tower_spec* specs, int n, ceno_hip_stream s, ceno_hip_tower** out) {
+    CENO_TIMED("tower_build_many");
+    CHECK_ARG(ctx, specs && out && n >= 1 && n <= 4096, "tower_build_many: bad arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    std::vector<ceno_hip_tower*> towers((size_t)n, nullptr);
+    auto release_all = [&]() {
+        for (auto* t : towers) tower_release(ctx, t);
+    };
+    std::vector<IlvJob> ilv;
+    std::vector<BlkRef> ilv_blk;
+    auto add_blocks = [](std::vector<BlkRef>& v, uint32_t job, size_t work) {
+        // a few elements per lane, at most 1024 workgroups per job: the launch as a whole is what fills the device
+        const uint32_t nblk = (uint32_t)std::min<size_t>(std::max<size_t>((work + (size_t)NT * 4 - 1) / ((size_t)NT * 4), 1), 1024);
+        for (uint32_t b = 0; b < nblk; b++) v.push_back(BlkRef{job, b, nblk});
+    };
+    int max_nv = 0;
+    for (int i = 0; i < n; i++) {
+        const ceno_hip_tower_spec& S = specs[i];
+        int rc = 0;
+        if (!S.records || S.k < 1) rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower_build_many: tower %d has no records", i);
+        const E2 dflt{S.default2[0], S.default2[1]};
+        IlvJob q{};
+        size_t out_len = 0;
+        if (!rc) rc = make_rec_arg(ctx, S.records, S.k, S.num_instances, dflt, q.ra, out_len);
+        const int num_vars = ceil_log2_sz(out_len) + 1;
+        if (!rc) rc = tower_alloc(ctx, num_vars, S.logup ? 4 : 2, &towers[(size_t)i]);
+        if (!rc) {
+            E2* last = towers[(size_t)i]->layers[num_vars - 1];
+            if (S.logup) {
+                IlvJob pj{};
+                if (S.numerators) {
+                    size_t pl = 0;
+                    rc = make_rec_arg(ctx, S.numerators, S.k, S.num_instances, dflt, pj.ra, pl);
+                    if (!rc && pl != out_len) rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "logup numerator / denominator shapes differ");
+                } else {  // numerators absent: the input layer's p limbs are all ONE (utils.rs:558-579)
+                    pj.ra.ones = 1;
+                    pj.ra.dflt = e2_one();
+                    pj.ra.log_s = 0;
+                }
+                pj.out0 = last;
+                pj.out1 = last + out_len;
+                pj.out_len = out_len;
+                q.out0 = last + 2 * out_len;
+                q.out1 = last + 3 * out_len;
+                q.out_len = out_len;
+                if (!rc) {
+                    add_blocks(ilv_blk, (uint32_t)ilv.size(), 2 * out_len);
+                    ilv.push_back(pj);
+                }
+            } else {
+                q.out0 = last;
+                q.out1 = last + out_len;
+                q.out_len = out_len;
+            }
+            if (!rc) {
+                add_blocks(ilv_blk, (uint32_t)ilv.size(), 2 * out_len);
+                ilv.push_back(q);
+            }
+            max_nv = std::max(max_nv, num_vars);
+        }
+        if (rc) {
+            release_all();
+            return rc;
+        }
+    }
+    // levels: layer l of tower t comes from a layer kernel for from_t <= l <= nv_t - 2, the layers below from_t from the top kernel
+    struct Level {
+        std::vector<LayerJob> jobs;
+        std::vector<BlkRef> blks;
+    };
+    std::vector<Level> levels((size_t)std::max(max_nv, 1));
+    std::vector<TopJob> tops;
+    for (int i = 0; i < n; i++) {
+        ceno_hip_tower* t = towers[(size_t)i];
+        const int from = std::min(t->num_vars - 1, t->top_layers - 1);
+        for (int l = t->num_vars - 2; l >= from; l--) {
+            Level& L = levels[(size_t)l];
+            const size_t len_below = (size_t)1 << (l + 1);
+            add_blocks(L.blks, (uint32_t)L.jobs.size(), len_below);
+            L.jobs.push_back(LayerJob{t->layers[l + 1], t->layers[l], len_below, t->n_limbs, 0});
+        }
+        if (from >= 1) tops.push_back(TopJob{t->layers[0], from, t->n_limbs});
+    }
+    // one blob, one copy
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    size_t total = 0;
+    const size_t o_ilv = total;
+    total = al(total + ilv.size() * sizeof(IlvJob));
+    const size_t o_ilv_blk = total;
+    total = al(total + ilv_blk.size() * sizeof(BlkRef));
+    std::vector<size_t> o_jobs(levels.size(), 0), o_blks(levels.size(), 0);
+    for (size_t l = 0; l < levels.size(); l++) {
+        o_jobs[l] = total;
+        total = al(total + levels[l].jobs.size() * sizeof(LayerJob));
+        o_blks[l] = total;
+        total = al(total + levels[l].blks.size() * sizeof(BlkRef));
+    }
+    const size_t o_tops = total;
+    total = al(total + tops.size() * sizeof(TopJob));
+    std::vector<char> blob(total, 0);
+    memcpy(blob.data() + o_ilv, ilv.data(), ilv.size() * sizeof(IlvJob));
+    memcpy(blob.data() + o_ilv_blk, ilv_blk.data(), ilv_blk.size() * sizeof(BlkRef));
+    for (size_t l = 0; l < levels.size(); l++) {
+        if (!levels[l].jobs.empty()) memcpy(blob.data() + o_jobs[l], levels[l].jobs.data(), levels[l].jobs.size() * sizeof(LayerJob));
+        if (!levels[l].blks.empty()) memcpy(blob.data() + o_blks[l], levels[l].blks.data(), levels[l].blks.size() * sizeof(BlkRef));
+    }
+    if (!tops.empty()) memcpy(blob.data() + o_tops, tops.data(), tops.size() * sizeof(TopJob));
+    void* d_blob = nullptr;
+    int rc = ctx_alloc(ctx, std::max<size_t>(total, 16), &d_blob);
+    if (rc) {
+        release_all();
+        return rc;
+    }
+    // (pageable source: the runtime has captured it when hipMemcpyAsync returns)
+    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), total, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        char* d = (char*)d_blob;
+        hipLaunchKernelGGL(k_interleave_many, dim3((unsigned)ilv_blk.size()), dim3(NT), 0, st, (const IlvJob*)(d + o_ilv), (const BlkRef*)(d + o_ilv_blk));
+        for (int l = (int)levels.size() - 1; l >= 0; l--)
+            if (!levels[(size_t)l].blks.empty())
+                hipLaunchKernelGGL(k_layer_many, dim3((unsigned)levels[(size_t)l].blks.size()), dim3(NT), 0, st, (const LayerJob*)(d + o_jobs[(size_t)l]),
+                                   (const BlkRef*)(d + o_blks[(size_t)l]));
+        if (!tops.empty()) hipLaunchKernelGGL(k_tower_top_many, dim3((unsigned)tops.size()), dim3(1024), 0, st, (const TopJob*)(d + o_tops));
+        e = hipGetLastError();
+    }
+    ctx_free(ctx, d_blob);  // (tagged with this stream: handed to another one only after the launches above have drained)
+    if (e != hipSuccess) {
+        release_all();
+        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower_build_many: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < n; i++) out[i] = towers[(size_t)i];
+    return 0;
+}
+
 int ceno_hip_tower_num_vars(const ceno_hip_tower* t) { return t ? t->num_vars : -1; }
 int ceno_hip_tower_num_limbs(const ceno_hip_tower* t) { return t ? t->n_limbs : -1; }
 
@@ -365,10 +594,29 @@ int ceno_hip_tower_prefetch_tops(ceno_hip_ctx* ctx, ceno_hip_tower* const* tower
     void *hb = nullptr, *db = nullptr;
     TRY(ctx_pinned_alloc(ctx, off[(size_t)n_towers], &hb, &db));
     hipError_t e = hipSuccess;
-    for (int i = 0; i < n_towers && e == hipSuccess; i++)
-        if (off[(size_t)i + 1] > off[(size_t)i])
-            e = hipMemcpyAsync((char*)hb + off[(size_t)i], towers[i]->layers[0], off[(size_t)i + 1] - off[(size_t)i], hipMemcpyDeviceToHost, st);
+    void* d_jobs = nullptr;
+    if (n_towers > 6) {
+        // many towers (a whole shard's): one kernel writes every top block into the staging block — a copy command per tower costs ~5 us
+        std::vector<CopyJob> cj((size_t)n_towers);
+        for (int i = 0; i < n_towers; i++)
+            cj[(size_t)i] = CopyJob{towers[i]->layers[0], reinterpret_cast<E2*>((char*)db + off[(size_t)i]), (off[(size_t)i + 1] - off[(size_t)i]) / sizeof(E2)};
+        int rc = ctx_alloc(ctx, cj.size() * sizeof(CopyJob), &d_jobs);
+        if (rc) {
+            ctx_pinned_free(ctx, hb);
+            return rc;
+        }
+        e = hipMemcpyAsync(d_jobs, cj.data(), cj.size() * sizeof(CopyJob), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_copy_many, dim3((unsigned)n_towers), dim3(256), 0, st, (const CopyJob*)d_jobs);
+            e = hipGetLastError();
+        }
+    } else {
+        for (int i = 0; i < n_towers && e == hipSuccess; i++)
+            if (off[(size_t)i + 1] > off[(size_t)i])
+                e = hipMemcpyAsync((char*)hb + off[(size_t)i], towers[i]->layers[0], off[(size_t)i + 1] - off[(size_t)i], hipMemcpyDeviceToHost, st);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_jobs) ctx_free(ctx, d_jobs);
     if (e == hipSuccess) {
         for (int i = 0; i < n_towers; i++) {
             const uint64_t* src = reinterpret_cast<const uint64_t*>((char*)hb + off[(size_t)i]);

@@ -133,14 +133,15 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
 }  // extern "C"
 
 // ---- ZKVMProver::create_chip_proof in two halves (chip_run.hpp) ----------------------------------------------------------------------------
-int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
-                   ceno_hip_stream s, ceno_chip_proof* out) {
+int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                     ceno_hip_stream s, ceno_chip_proof* out) {
     if (!ctx || !task || !challenges4 || !tr || !out) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: NULL argument");
     memset(out, 0, sizeof(*out));
     run.ctx = ctx;
     run.task = task;
     run.tr = tr;
     run.out = out;
+    run.challenges4 = challenges4;
     run.live = false;
     const int n_mles = task->n_witin + task->n_fixed + task->n_structural;
     const int num_var_with_rotation = task->log2_num_instances + task->rotation_vars;   // prover.rs:728-729
@@ -155,13 +156,7 @@ int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* t
             return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: witness sizes differ from log2_num_instances + rotation_vars");
     out->num_instances = task->num_instances;
     // ---- build_main_witness, tower stage (prover.rs:735-745): only the tower-facing records are materialised ----
-    std::vector<ceno_hip_mle*> records(n_records, nullptr);
-    auto free_records = [&]() {
-        for (auto*& m : records) {
-            if (m) ceno_hip_mle_free(ctx, m);
-            m = nullptr;
-        }
-    };
+    run.records.assign((size_t)n_records, nullptr);
     // structural witnesses may be absent at this stage ("they are `eq`, and will be filled later", utils.rs:690-695): the
     // record expressions never read them, so the inference runs on the tables that exist
     std::vector<ceno_hip_mle*> present;
@@ -178,25 +173,86 @@ int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* t
         if ((int)j >= n_mles || remap[j] == UINT32_MAX) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a record expression reads an absent table");
         ridx.push_back(remap[j]);
     }
-    static const bool trace = getenv("CENO_PROVER_CHIP_TRACE") != nullptr;  // where a chip proof's wall time goes (host view, microseconds)
-    auto now_us = []() {
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
-    };
-    const double t0 = trace ? now_us() : 0;
     int rc = ceno_hip_wit_infer(ctx, present.data(), (int)present.size(), task->record_coeffs, task->record_term_offsets, ridx.data(),
-                                task->n_record_terms, task->record_out_term_offsets, n_records, num_var_with_rotation, s, records.data());
+                                task->n_record_terms, task->record_out_term_offsets, n_records, num_var_with_rotation, s, run.records.data());
     if (rc) return fail_ctx(ctx, rc);
-    const double t1 = trace ? now_us() : 0;
-    // ---- prove_tower_relation (prover.rs:747-755 -> cpu/mod.rs:765-797) ----
+    return 0;
+}
+
+void chip_run_free_records(ChipProofRun& run) {  // prover.rs:756 drop(records): the towers own their interleaved copies
+    for (auto*& m : run.records) {
+        if (m) ceno_hip_mle_free(run.ctx, m);
+        m = nullptr;
+    }
+    run.records.clear();
+}
+
+// the record slicing of build_tower_witness (cpu/mod.rs:626-677) as tower specs: [reads], [writes], [lookups]
+int chip_run_tower_specs(ChipProofRun& run, ceno_hip_tower_spec* specs3) {
+    const ceno_chip_task* t = run.task;
+    const int n_lk_num = t->num_lk_tables, n_lk_den = t->num_lk_tables > 0 ? t->num_lk_tables : t->num_lk;
+    ceno_hip_mle* const* rec = run.records.data();
+    const size_t active_rows = (size_t)1 << (t->log2_num_instances + t->rotation_vars);
+    int n = 0;
+    auto put = [&](ceno_hip_mle* const* r, ceno_hip_mle* const* num, int k, int logup, uint64_t d0, uint64_t d1) {
+        specs3[n++] = ceno_hip_tower_spec{r, num, k, logup, active_rows, {d0, d1}};
+    };
+    if (t->num_reads > 0) put(rec, nullptr, t->num_reads, 0, 1, 0);
+    if (t->num_writes > 0) put(rec + t->num_reads, nullptr, t->num_writes, 0, 1, 0);
+    if (n_lk_den > 0) {
+        ceno_hip_mle* const* lk_n = rec + t->num_reads + t->num_writes;
+        put(lk_n + n_lk_num, n_lk_num > 0 ? lk_n : nullptr, n_lk_den, 1, run.challenges4[0], run.challenges4[1]);  // challenges[0]: cpu/mod.rs:658-661
+    }
+    return n;
+}
+
+int chip_run_adopt_towers(ChipProofRun& run, ceno_hip_tower* const* towers, int n) {
+    const ceno_chip_task* t = run.task;
     ceno_tower_witness& tw = run.tw;
-    rc = ceno_prover_build_tower_witness(ctx, records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk,
-                                         task->log2_num_instances, task->rotation_vars, challenges4, s, &tw);
-    const double t2 = trace ? now_us() : 0;
-    free_records();  // prover.rs:756 drop(records): the towers own their interleaved copies
-    if (rc) return rc;
+    memset(&tw, 0, sizeof(tw));
+    const int n_lk_den = t->num_lk_tables > 0 ? t->num_lk_tables : t->num_lk;
+    const int active_row_vars = t->log2_num_instances + t->rotation_vars;
+    auto group_num_vars = [&](int num_ops) { return active_row_vars + ceil_log2(next_pow2((size_t)num_ops)); };  // cpu/mod.rs:647-648
+    int k = 0;
+    bool ok = true;
+    if (t->num_reads > 0) {
+        tw.prod[tw.n_prod++] = towers[k];
+        tw.has_r = 1;
+        ok = ok && ceno_hip_tower_num_vars(towers[k++]) == group_num_vars(t->num_reads);
+    }
+    if (t->num_writes > 0) {
+        tw.prod[tw.n_prod++] = towers[k];
+        tw.has_w = 1;
+        ok = ok && ceno_hip_tower_num_vars(towers[k++]) == group_num_vars(t->num_writes);
+    }
+    if (n_lk_den > 0) {
+        tw.logup[0] = towers[k];
+        tw.n_logup = 1;
+        tw.has_lk = 1;
+        ok = ok && ceno_hip_tower_num_vars(towers[k++]) == group_num_vars(n_lk_den);
+    }
     run.live = true;
+    if (k != n || !ok) {
+        chip_run_abandon(run);
+        return prover_set_error(CENO_HIP_ERR_STATE, "build_tower_witness: tower height differs from group_num_vars");
+    }
+    return 0;
+}
+
+// the towers stand (their tops prefetched): out-evaluations, the proof's buffers, the transcript up to the first layer
+int chip_run_after_towers(ChipProofRun& run, ceno_hip_stream s) {
+    ceno_hip_ctx* ctx = run.ctx;
+    ceno_chip_proof* out = run.out;
+    ceno_transcript* tr = run.tr;
+    ceno_tower_witness& tw = run.tw;
+    int rc = 0, k = 0;
+    if (tw.has_r) rc = ceno_hip_tower_out_evals(ctx, tw.prod[k++], tw.r_out_evals, s);
+    if (!rc && tw.has_w) rc = ceno_hip_tower_out_evals(ctx, tw.prod[k++], tw.w_out_evals, s);
+    if (!rc && tw.has_lk) rc = ceno_hip_tower_out_evals(ctx, tw.logup[0], tw.lk_out_evals, s);
+    if (rc) {
+        chip_run_abandon(run);
+        return fail_ctx(ctx, rc);
+    }
     int max_nv = 0;
     for (int i = 0; i < tw.n_prod; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.prod[i]));
     for (int i = 0; i < tw.n_logup; i++) max_nv = std::max(max_nv, ceno_hip_tower_num_vars(tw.logup[i]));
@@ -208,13 +264,12 @@ int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* t
     out->tower.prod_evals = (uint64_t*)calloc((size_t)std::max(1, tw.n_prod) * std::max(1, R) * 4, 8);
     out->tower.logup_evals = (uint64_t*)calloc((size_t)std::max(1, tw.n_logup) * std::max(1, R) * 8, 8);
     out->tower.point = (uint64_t*)calloc((size_t)2 * (max_nv + 1), 8);
-    out->rt_main = (uint64_t*)calloc((size_t)2 * std::max(1, num_var_with_rotation), 8);
+    out->rt_main = (uint64_t*)calloc((size_t)2 * std::max(1, run.num_var_with_rotation), 8);
     if (!out->tower.msgs || !out->tower.prod_evals || !out->tower.logup_evals || !out->tower.point || !out->rt_main) {
         chip_run_abandon(run);
         return prover_set_error(CENO_HIP_ERR_OOM, "create_chip_proof: out of host memory");
     }
-    // out-evals were computed by build_tower_witness; prove_tower_relation binds them into the transcript (r, w, lk: cpu/mod.rs:783-786), the
-    // tower prover follows
+    // prove_tower_relation binds the out-evaluations into the transcript (r, w, lk: cpu/mod.rs:783-786), the tower prover follows
     out->n_r_out = tw.has_r ? 2 : 0;
     out->n_w_out = tw.has_w ? 2 : 0;
     out->n_lk_out = tw.has_lk ? 4 : 0;
@@ -225,9 +280,6 @@ int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* t
     if (tw.has_w) prover_tr_ext_words(tr, tw.w_out_evals, 2);
     if (tw.has_lk) prover_tr_ext_words(tr, tw.lk_out_evals, 4);
     rc = tower_state_init(run.st, ctx, tw.prod, tw.n_prod, tw.logup, tw.n_logup, tr, s, &out->tower, nullptr);
-    if (trace)
-        fprintf(stderr, "[ceno_prover] chip 2^%d: wit_infer %.0f us, tower witness (to out-evals) %.0f, to the first layer %.0f\n", task->log2_num_instances,
-                t1 - t0, t2 - t1, now_us() - t2);
     if (rc) {
         chip_run_abandon(run);
         return rc;
@@ -235,7 +287,33 @@ int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* t
     return 0;
 }
 
+int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                   ceno_hip_stream s, ceno_chip_proof* out) {
+    static const bool trace = getenv("CENO_PROVER_CHIP_TRACE") != nullptr;  // where a chip proof's wall time goes (host view, microseconds)
+    auto now_us = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec / 1e3;
+    };
+    const double t0 = trace ? now_us() : 0;
+    if (int rc = chip_run_records(run, ctx, task, challenges4, tr, s, out)) return rc;
+    const double t1 = trace ? now_us() : 0;
+    // ---- prove_tower_relation (prover.rs:747-755 -> cpu/mod.rs:765-797) ----
+    int rc = ceno_prover_build_tower_witness(ctx, run.records.data(), task->num_reads, task->num_writes, task->num_lk_tables, task->num_lk,
+                                             task->log2_num_instances, task->rotation_vars, challenges4, s, &run.tw);
+    const double t2 = trace ? now_us() : 0;
+    chip_run_free_records(run);
+    if (rc) return rc;
+    run.live = true;
+    rc = chip_run_after_towers(run, s);
+    if (trace)
+        fprintf(stderr, "[ceno_prover] chip 2^%d: wit_infer %.0f us, tower witness (to out-evals) %.0f, to the first layer %.0f\n", task->log2_num_instances,
+                t1 - t0, t2 - t1, now_us() - t2);
+    return rc;
+}
+
 void chip_run_abandon(ChipProofRun& run) {
+    chip_run_free_records(run);
     if (run.live) ceno_tower_witness_free(run.ctx, &run.tw);
     run.live = false;
     if (run.out) ceno_chip_proof_free(run.out);

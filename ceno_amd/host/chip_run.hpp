@@ -14,7 +14,17 @@ struct ChipProofRun {
     TowerProveState st;
     int num_var_with_rotation = 0;
     bool live = false;  // the towers exist
+    const uint64_t* challenges4 = nullptr;
+    std::vector<ceno_hip_mle*> records;  // between chip_run_records and chip_run_free_records
 };
+// begin in pieces, for callers that build the towers of MANY chips in one go (cohort.cpp): records -> tower specs -> [ceno_hip_tower_build_many,
+// ceno_hip_tower_prefetch_tops] -> adopt -> free records -> after_towers
+int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                     ceno_hip_stream s, ceno_chip_proof* out);
+int chip_run_tower_specs(ChipProofRun& run, ceno_hip_tower_spec* specs3);  // returns how many (<= 3)
+int chip_run_adopt_towers(ChipProofRun& run, ceno_hip_tower* const* towers, int n);
+void chip_run_free_records(ChipProofRun& run);
+int chip_run_after_towers(ChipProofRun& run, ceno_hip_stream s);
 int chip_run_begin(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
                    ceno_hip_stream s, ceno_chip_proof* out);
 int chip_run_finish(ChipProofRun& run, ceno_hip_stream s);  // on failure the proof and the towers are released

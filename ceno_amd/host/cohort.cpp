@@ -201,28 +201,38 @@ double now_ms() {
 
 }  // namespace
 
-// layers first .. last of every run in `runs` that stands before such a layer, on `n_threads` serving threads.  A run whose status is set is
-// skipped; a failure sets the status of the runs it touches.  Returns the first error.
-int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int last_layer, int n_threads) {
+// Phases A and B for all chips on one pool of `n_threads` threads (thread t drives lane stream t mod 8):
+//   A1  every chip's records (wit_infer), queued without waiting                               all threads, chips dealt round-robin
+//   A2  the towers of ALL chips in level-synchronous launches, their tops to the host in one copy      thread 0
+//   A3  per chip: out-evaluations into its transcript, the tower prover's state, the layers the host proves    all threads
+//   B   layers host_layers + 1 .. last_layer in cohorts                                                  all threads serve
+// A chip whose status is set is skipped from then on; a failure sets the status of the chips it touches.  Returns the first error of
+// a step that concerns all chips (0 when only single chips failed).
+int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uint64_t* challenges4, ceno_transcript* const* transcripts,
+                       ceno_chip_proof* out_proofs, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int host_layers, int last_layer,
+                       int n_threads) {
     const int sub = ceno_hip_tower_cohort_max_vars();
     int capacity = ceno_hip_tower_cohort_capacity(ctx);
     if (const char* e = getenv("CENO_TOWER_COHORT_CAPACITY"))  // (tests: several launches per layer)
         if (atoi(e) > 0) capacity = std::min(capacity, atoi(e));
     if (capacity < 1) return prover_set_error(CENO_HIP_ERR_UNSUPPORTED, "cohort: the device holds no cohort workgroup");
-    ceno_hip_stream stream = nullptr;
-    if (int rc = ceno_hip_lane_stream(ctx, 0, &stream)) return prover_set_error(rc, ceno_hip_last_error(ctx));
+    n_threads = std::max(1, std::min<int>(n_threads, (int)runs.size()));
+    std::vector<ceno_hip_stream> streams((size_t)std::min(n_threads, 8), nullptr);
+    for (size_t l = 0; l < streams.size(); l++)
+        if (int rc = ceno_hip_lane_stream(ctx, (int)l, &streams[l])) return prover_set_error(rc, ceno_hip_last_error(ctx));
+    ceno_hip_stream stream = streams[0];
     static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
     static const double timeout_ms = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         return 1e3 * (e && atof(e) > 0 ? atof(e) : 60.0);
     }();
-    n_threads = std::max(1, std::min<int>(n_threads, (int)runs.size()));
     SpinBarrier bar;
     bar.n = n_threads;
     std::atomic<int> err{0};
     std::vector<LayerChip> chips;      // this launch's chips
     ceno_hip_cohort* co = nullptr;
     std::atomic<bool> more{true};
+    std::vector<double> busy((size_t)n_threads, 0.0);  // (trace: time spent answering, per thread)
     std::string err_msg;
     // thread 0 between the barriers: the next launch (the chips standing before the lowest open layer <= last_layer, as many as the device
     // holds at once), or the end
@@ -283,8 +293,69 @@ int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std
             return true;
         }
     };
+    double t_a1 = 0, t_a2 = 0, t_a3 = 0;
+    const double t_start = now_ms();
     auto worker = [&](int t) {
-        if (t == 0) (void)ceno_hip_make_current(ctx);
+        (void)ceno_hip_make_current(ctx);
+        ceno_hip_stream mine = streams[(size_t)t % streams.size()];
+        // ---- A1 ----
+        for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads)
+            status[i] = chip_run_records(*runs[i], ctx, &tasks[i], challenges4, transcripts[i], mine, &out_proofs[i]);
+        (void)ceno_hip_stream_sync(ctx, mine);
+        bar.wait();
+        // ---- A2 ----
+        if (t == 0) {
+            t_a1 = now_ms() - t_start;
+            std::vector<ceno_hip_tower_spec> specs;
+            std::vector<int> first((size_t)runs.size() + 1, 0);
+            for (size_t i = 0; i < runs.size(); i++) {
+                first[i] = (int)specs.size();
+                if (!status[i]) {
+                    ceno_hip_tower_spec s3[3];
+                    const int k = chip_run_tower_specs(*runs[i], s3);
+                    specs.insert(specs.end(), s3, s3 + k);
+                }
+            }
+            first[runs.size()] = (int)specs.size();
+            if (!specs.empty()) {
+                std::vector<ceno_hip_tower*> towers(specs.size(), nullptr);
+                int rc = ceno_hip_tower_build_many(ctx, specs.data(), (int)specs.size(), stream, towers.data());
+                if (!rc) {
+                    rc = ceno_hip_tower_prefetch_tops(ctx, towers.data(), (int)towers.size(), host_layers + 1, stream);
+                    if (rc)
+                        for (auto* tw : towers) ceno_hip_tower_free(ctx, tw);
+                }
+                if (rc) {
+                    err_msg = ceno_hip_last_error(ctx);
+                    err.store(rc);
+                }
+                for (size_t i = 0; i < runs.size(); i++) {
+                    if (status[i]) continue;
+                    if (rc) status[i] = rc;
+                    else status[i] = chip_run_adopt_towers(*runs[i], towers.data() + first[i], first[i + 1] - first[i]);
+                    chip_run_free_records(*runs[i]);
+                }
+            }
+            t_a2 = now_ms() - t_start;
+        }
+        bar.wait();
+        if (err.load()) return;
+        // ---- A3 ----
+        for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads) {
+            if (status[i]) {
+                chip_run_abandon(*runs[i]);
+                continue;
+            }
+            int rc = chip_run_after_towers(*runs[i], mine);
+            while (!rc && !runs[i]->st.done() && runs[i]->st.round <= host_layers) {
+                rc = tower_state_step(runs[i]->st);
+                if (rc) chip_run_abandon(*runs[i]);
+            }
+            status[i] = rc;
+        }
+        bar.wait();
+        if (t == 0) t_a3 = now_ms() - t_start;
+        // ---- B ----
         for (;;) {
             if (t == 0) more.store(next_launch());
             bar.wait();
@@ -297,7 +368,10 @@ int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std
                 for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) {
                     LayerChip& c = chips[i];
                     if (c.done) continue;
+                    const int round_before = c.round;
+                    const double t_s = trace ? now_ms() : 0;
                     const int r = serve(co, c);
+                    if (trace && (c.round != round_before || c.done)) busy[(size_t)t] += now_ms() - t_s;
                     if (r) {
                         int zero = 0;
                         if (err.compare_exchange_strong(zero, r)) err_msg = r == CENO_HIP_ERR_INVALID ? "cohort: a mailbox call was refused" : ceno_prover_last_error();
@@ -319,7 +393,15 @@ int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std
                     err_msg = ceno_hip_last_error(ctx);
                     err.store(rc);
                 }
-                if (trace) fprintf(stderr, "[ceno_prover] cohort: layer served in %.3f ms\n", now_ms() - t_begin);
+                if (trace) {
+                    double mx = 0, sum = 0;
+                    for (double& b : busy) {
+                        mx = std::max(mx, b);
+                        sum += b;
+                        b = 0;
+                    }
+                    fprintf(stderr, "[ceno_prover] cohort: layer served in %.3f ms (threads answering: busiest %.3f ms, all %.3f ms)\n", now_ms() - t_begin, mx, sum);
+                }
                 if (err.load()) {
                     more.store(false);
                 }
@@ -332,6 +414,8 @@ int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std
     for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
     worker(0);
     for (auto& x : th) x.join();
+    if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: records %.3f ms, towers of all chips %.3f, to the cohort layers %.3f, cohort layers to %d %.3f\n", t_a1,
+                       t_a2 - t_a1, t_a3 - t_a2, last_layer, now_ms() - t_start - t_a3);
     if (const int rc = err.load()) {
         for (size_t i = 0; i < runs.size(); i++)
             if (!status[i] && !runs[i]->st.done()) status[i] = rc;  // (their transcripts may be mid-layer: these proofs are lost)

@@ -39,16 +39,20 @@ int ceno_prover_lanes_effective_for(int n_lanes, int n_tasks) {
     const int cap = e && atoi(e) > 0 ? atoi(e) : (n_tasks >= 24 ? 8 : 4);
     return std::max(1, std::min(n_lanes, cap));
 }
+static std::shared_ptr<std::mutex> run_mutex_of(ceno_hip_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_runs_mu);
+    auto& slot = g_runs[ctx];
+    if (!slot) slot = std::make_shared<std::mutex>();
+    return slot;
+}
+static int lanes_run_locked(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane);
 extern "C" int ceno_prover_lanes_run(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane) {
     if (!ctx || !tasks || n_lanes < 1 || n_lanes > 64 || n_tasks < 0) return prover_set_error(CENO_HIP_ERR_INVALID, "lanes_run: bad arguments");
-    std::shared_ptr<std::mutex> run_mu;
-    {
-        std::lock_guard<std::mutex> g(g_runs_mu);
-        auto& slot = g_runs[ctx];
-        if (!slot) slot = std::make_shared<std::mutex>();
-        run_mu = slot;
-    }
+    std::shared_ptr<std::mutex> run_mu = run_mutex_of(ctx);
     std::lock_guard<std::mutex> one_run(*run_mu);
+    return lanes_run_locked(ctx, n_lanes, tasks, n_tasks, out_status, out_lane);
+}
+static int lanes_run_locked(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task* tasks, int n_tasks, int* out_status, int* out_lane) {
     {
         // The command processor dispatches FOUR queues concurrently; further streams are time-multiplexed onto them, and a lane whose
         // stream shares a queue with another lane's persistent round kernel waits behind it (tools/ubench_lanes.hip,
@@ -188,7 +192,9 @@ extern "C" size_t ceno_prover_chip_proof_estimate_bytes(const ceno_chip_task* t)
 
 // ---- the same phase with the middle tower layers of all chips proved together (cohort.cpp) ----
 #include "chip_run.hpp"
-int cohort_prove_layers(ceno_hip_ctx* ctx, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int last_layer, int n_threads);  // cohort.cpp
+int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uint64_t* challenges4, ceno_transcript* const* transcripts,
+                       ceno_chip_proof* out_proofs, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int host_layers, int last_layer,
+                       int n_threads);  // cohort.cpp
 int prover_tower_host_layers();                                                                                                       // prover.cpp
 namespace {
 struct PhaseJob {
@@ -201,15 +207,6 @@ struct PhaseJob {
     int* status;
     int host_layers;
 };
-int phase_a_fn(void* arg, int, ceno_hip_stream stream) {
-    auto* j = (PhaseJob*)arg;
-    int rc = chip_run_begin(*j->run, j->ctx, j->task, j->challenges4, j->tr, stream, j->out);
-    while (!rc && !j->run->st.done() && j->run->st.round <= j->host_layers) {
-        rc = tower_state_step(j->run->st);
-        if (rc) chip_run_abandon(*j->run);
-    }
-    return *j->status = rc;
-}
 int phase_c_fn(void* arg, int, ceno_hip_stream stream) {
     auto* j = (PhaseJob*)arg;
     if (*j->status) {  // lost in an earlier phase
@@ -249,6 +246,9 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
         }
         return ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, out_status, nullptr);
     }
+    // (the lane streams are the context's: the whole phase is one run on it)
+    std::shared_ptr<std::mutex> run_mu = run_mutex_of(ctx);
+    std::lock_guard<std::mutex> one_run(*run_mu);
     std::vector<ChipProofRun> runs((size_t)n_tasks);
     std::vector<ChipProofRun*> run_ptrs((size_t)n_tasks);
     std::vector<int> status((size_t)n_tasks, 0);
@@ -258,19 +258,19 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
         run_ptrs[(size_t)i] = &runs[(size_t)i];
         jobs[(size_t)i] = PhaseJob{&runs[(size_t)i], ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i], &status[(size_t)i], host_layers};
         // (the block above is the booking; what a task "books" here only orders the tasks, largest first)
-        lt[(size_t)i] = ceno_lane_task{phase_a_fn, &jobs[(size_t)i], ceno_prover_chip_proof_estimate_bytes(&tasks[i]) >> 20};
+        lt[(size_t)i] = ceno_lane_task{phase_c_fn, &jobs[(size_t)i], ceno_prover_chip_proof_estimate_bytes(&tasks[i]) >> 20};
     }
     static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    (void)ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
-    const double t_a = ms();
-    const int rc_b = cohort_prove_layers(ctx, run_ptrs, status, last_layer, ceno_prover_lanes_effective_for(lanes, n_tasks));
+    // (the serving threads wait for messages and hash transcripts — host work, not bounded by the device's four queues)
+    const char* e_thr = getenv("CENO_COHORT_THREADS");
+    const int n_threads = e_thr && atoi(e_thr) > 0 ? atoi(e_thr) : ceno_prover_lanes_effective_for(lanes, n_tasks);
+    const int rc_b = cohort_chip_proofs(ctx, tasks, challenges4, transcripts, out_proofs, run_ptrs, status, host_layers, last_layer, n_threads);
     const std::string msg_b = rc_b ? ceno_prover_last_error() : "";
     const double t_b = ms();
-    for (int i = 0; i < n_tasks; i++) lt[(size_t)i].fn = phase_c_fn;
-    (void)ceno_prover_lanes_run(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
-    if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: to layer %d on lanes %.3f ms, cohort layers to %d %.3f ms, the rest on lanes %.3f ms\n", host_layers, t_a, last_layer, t_b - t_a, ms() - t_b);
+    (void)lanes_run_locked(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
+    if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: to layer %d %.3f ms, the rest on lanes %.3f ms\n", last_layer, t_b, ms() - t_b);
     ceno_hip_mem_unbook(ctx, total + ((size_t)1 << 30));
     int first_err = 0;
     for (int i = 0; i < n_tasks; i++) {

@@ -297,6 +297,11 @@ class VirtualPolynomialsBuilder:
             pass
 
 
+class TowerSpecC(C.Structure):
+    _fields_ = [("records", C.c_void_p), ("numerators", C.c_void_p), ("k", C.c_int), ("logup", C.c_int), ("num_instances", C.c_size_t),
+                ("default2", C.c_uint64 * 2)]
+
+
 class Tower:
     """built tower witness (reference: TowerProverSpec / GpuProverSpec)"""
 
@@ -318,6 +323,29 @@ class Tower:
         h = C.c_void_p()
         dev.check(dev.L.ceno_hip_tower_build_logup(dev.h, p, q, len(q_records), num_instances, _p(_ext1(default)), stream, C.byref(h)))
         return cls(dev, h)
+
+    @classmethod
+    def build_many(cls, dev: Device, specs: Sequence[tuple], stream=None) -> list:
+        """specs: ("prod", records, num_instances, default) or ("logup", p_records | None, q_records, num_instances, default): all towers in
+        level-synchronous launches (ceno_hip_tower_build_many) — the same layers as build_prod / build_logup one by one"""
+        arr = (TowerSpecC * len(specs))()
+        keep = []
+        for a, sp in zip(arr, specs):
+            if sp[0] == "prod":
+                _, recs, n_inst, dflt = sp
+                nums = None
+            else:
+                _, nums, recs, n_inst, dflt = sp
+            r = (C.c_void_p * len(recs))(*[m.h for m in recs])
+            nm = (C.c_void_p * len(nums))(*[m.h for m in nums]) if nums is not None else None
+            keep += [r, nm]
+            a.records, a.numerators = C.cast(r, C.c_void_p), (C.cast(nm, C.c_void_p) if nm is not None else None)
+            a.k, a.logup, a.num_instances = len(recs), int(sp[0] == "logup"), n_inst
+            d = _ext1(dflt)
+            a.default2[0], a.default2[1] = int(d[0]), int(d[1])
+        hs = (C.c_void_p * len(specs))()
+        dev.check(dev.L.ceno_hip_tower_build_many(dev.h, C.cast(arr, C.c_void_p), len(specs), stream, hs))
+        return [cls(dev, C.c_void_p(h)) for h in hs]
 
     @classmethod
     def from_last_layer(cls, dev: Device, limbs: Sequence[Optional[Mle]], stream=None):

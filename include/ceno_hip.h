@@ -293,6 +293,18 @@ int ceno_hip_tower_build_logup(ceno_hip_ctx* ctx, ceno_hip_mle* const* p_records
 /* build directly from already interleaved last-layer limbs (infer_tower_product_witness / _logup_witness) */
 int ceno_hip_tower_from_last_layer(ceno_hip_ctx* ctx, ceno_hip_mle* const* limbs, int n_limbs /* 2 = prod; 4 = logup p1,p2,q1,q2; */,
                                    ceno_hip_stream s, ceno_hip_tower** out);
+/* MANY towers in level-synchronous launches (one interleave launch, one launch per layer size, one for the contiguous tops) instead of ~11
+ * dependent launches per tower: the towers of all chips of a shard (ceno_prover_create_chip_proofs).  Tower i: logup == 0 — a product tower
+ * over records[0 .. k) as ceno_hip_tower_build_prod; logup != 0 — a LogUp tower with denominators records[0 .. k) and numerators[0 .. k)
+ * (NULL: all one) as ceno_hip_tower_build_logup.  Same layers, bit for bit.  On failure nothing is built. */
+typedef struct ceno_hip_tower_spec {
+    ceno_hip_mle* const* records;
+    ceno_hip_mle* const* numerators;
+    int k, logup;
+    size_t num_instances;
+    uint64_t default2[2];
+} ceno_hip_tower_spec;
+int ceno_hip_tower_build_many(ceno_hip_ctx* ctx, const ceno_hip_tower_spec* specs, int n, ceno_hip_stream s, ceno_hip_tower** out /* n */);
 int ceno_hip_tower_num_vars(const ceno_hip_tower* t);   /* number of layers */
 int ceno_hip_tower_num_limbs(const ceno_hip_tower* t);  /* 2 or 4 */
 /* borrowed handle of limb `limb` of layer `layer` (valid while the tower lives) */

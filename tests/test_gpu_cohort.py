@@ -148,3 +148,39 @@ def test_sub_cubes_of_a_large_layer_add_up(dev, r):
         if m == 0:
             tab = np.array([po.e2_mul(tuple(int(x) for x in tab[g]), tuple(int(x) for x in eq_hi[g])) for g in range(G)], dtype=np.uint64)
         assert po.mle_evaluate(tab, ochal[sub:]) == tuple(int(x) for x in ofin[m]), m
+
+
+def test_towers_built_many_at_a_time_equal_towers_built_one_by_one(dev):
+    """ceno_hip_tower_build_many (level-synchronous launches over all towers: csrc/tower.hip) against ceno_hip_tower_build_prod / _logup tower
+    by tower, every layer and limb: product towers of 1 .. 9 records, LogUp towers with and without numerators, base and extension records,
+    instance counts that are no power of two, towers too small for a layer kernel and towers of 2^17 entries, all in one call"""
+    from ceno_amd import prover
+
+    shapes = [("prod", 5, 12, 4096), ("prod", 1, 3, 5), ("logup", 3, 10, 1000, True), ("logup", 20, 12, 4096, False), ("prod", 9, 13, 8191),
+              ("logup", 1, 2, 3, False), ("prod", 2, 16, 65536), ("logup", 4, 9, 512, True), ("prod", 3, 1, 2), ("logup", 7, 14, 16000, False)]
+    specs, keep = [], []
+    for j, sh in enumerate(shapes):
+        kind, k, nv, n_inst = sh[:4]
+        recs = [dev.synthetic(nv, (j + r) % 3 != 0, 0xB00 + 37 * j + r) for r in range(k)]
+        keep += recs
+        if kind == "prod":
+            specs.append(("prod", recs, n_inst, (1, 0)))
+        else:
+            nums = None
+            if sh[4]:
+                nums = [dev.synthetic(nv, True, 0xD00 + 41 * j + r) for r in range(k)]
+                keep += nums
+            specs.append(("logup", nums, recs, n_inst, (77 + j, 5)))
+    st = dev.stream_create()
+    many = prover.Tower.build_many(dev, specs, stream=st)
+    for sp, got in zip(specs, many):
+        want = prover.Tower.build_prod(dev, sp[1], sp[2], sp[3], stream=st) if sp[0] == "prod" else prover.Tower.build_logup(dev, sp[1], sp[2], sp[3], sp[4], stream=st)
+        assert (got.num_vars, got.num_limbs) == (want.num_vars, want.num_limbs)
+        for layer in range(want.num_vars):
+            for limb in range(want.num_limbs):
+                assert np.array_equal(got.layer(layer, limb), want.layer(layer, limb)), (sp[0], layer, limb)
+        want.free()
+        got.free()
+    dev.stream_destroy(st)
+    for m in keep:
+        m.free()
