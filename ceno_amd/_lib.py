@@ -164,6 +164,7 @@ def lib():
         "ceno_hip_tower_cohort_try_message": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_send_challenge": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_try_final": (i, [vp, i, u64p]),
+        "ceno_hip_tower_cohort_round_times": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_abort": (i, [vp]),
         "ceno_hip_tower_cohort_end": (i, [vp, vp]),
         "ceno_hip_poseidon2_set_constants": (i, [vp, u64p, u64p, u64p]),

@@ -27,7 +27,10 @@
 
 namespace {
 
-constexpr int CNT = 512;            // lanes per workgroup: 8 waves; 432 workgroups (54 chains x 8 sub-cubes) are resident at once
+// lanes per workgroup: 4 waves, one per SIMD.  A sub-cube's rounds are VALU work on ONE compute unit (a 2^13-entry sub-cube: ~350 us), so
+// the callers cut a layer into as many sub-cubes as the device holds at once (four workgroups per compute unit: ~1000) — small workgroups
+// make that many, and a sub-cube of <= 2^9 entries has at most one pair per lane in every round (the rest is round-trip latency).
+constexpr int CNT = 256;
 constexpr int COHORT_MAX_TABS = 14; // tables besides eq: 2 per product tower (<= 3), 4 per LogUp tower (<= 2)
 constexpr int COHORT_SUB = 13;      // variables of a sub-cube
 
@@ -43,6 +46,11 @@ struct CohortJob {
     E2 a_prod[3], a_num[2], a_den[2];
     int n, np, nl, pad_;
     unsigned long long poll_ticks;
+    // a GROUP of jobs (the sub-cubes of one layer) publishes ONE message per round: the sum of the jobs' messages, each scaled by its `scale`
+    E2 scale;
+    uint64_t* part;     // the group's partial messages: 8 words per job
+    unsigned* counter;  // the group's arrival counter (monotonic: G arrivals per round)
+    int G, g;           // jobs in the group (1: no group), this job's place in it
 };
 
 __device__ __forceinline__ void put16(uint64_t* dst, E2 v) {
@@ -51,9 +59,28 @@ __device__ __forceinline__ void put16(uint64_t* dst, E2 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 }
 
+// poll_challenge (sumcheck_dev.hpp) with a pause between polls: hundreds of workgroups poll at once here (`gap` units of ~0.2 us)
+__device__ __forceinline__ bool poll_challenge_paced(const Mailbox* mb, unsigned long long want_seq, unsigned long long& c0, unsigned long long& c1,
+                                                     unsigned long long poll_ticks, int gap) {
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    unsigned spins = 0;
+    for (;;) {
+        if (__hip_atomic_load(&mb->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == want_seq) break;
+        for (int k = 0; k < gap; k++) __builtin_amdgcn_s_sleep(8);
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || wall_clock64() - t0 > poll_ticks) return false;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c0 = __hip_atomic_load(&mb->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    c1 = __hip_atomic_load(&mb->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+}
+
 __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restrict__ jobs) {
     __shared__ E2 smem[(CNT / 64) * 3];
     __shared__ unsigned long long s_c[3];
+    __shared__ int s_last;
     __shared__ CohortJob J;
     {   // the job record: one cooperative copy into LDS (its pointer arrays are indexed at run time)
         const uint64_t* src = reinterpret_cast<const uint64_t*>(jobs + blockIdx.x);
@@ -77,6 +104,7 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
         __syncthreads();
     }
     E2 r = e2_zero();
+    unsigned long long t_chal = wall_clock64();  // (lane 0: the start of round 0 = the launch)
     E2* cur = J.ping;   // tables of the round being evaluated (rounds >= 1): K x len, table m at cur + m * len
     E2* prev = nullptr; // tables of the round before
     size_t prev_len = 0;
@@ -145,16 +173,58 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
             }
         }
         red::block_sum<3, CNT>(acc, smem);
+        // Every store into host memory is a PCIe write, and the device gets ~10 M of them through per second: a layer cut into hundreds of
+        // sub-cubes that each sent their own message spent its rounds queueing there (measured: 320 jobs x 4 stores = ~125 us per round).
+        // A group therefore adds its messages up on the device — every job stores its scaled share write-through, the job that arrives
+        // last sums them (the pattern of `epilogue`, sumcheck_dev.hpp) — and the message leaves as ONE 64-byte write.
+        bool publish = true;
+        if (J.G > 1) {
+            if (threadIdx.x == 0) {
+                uint64_t* row = J.part + 8 * (size_t)J.g;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const E2 v = J.scale * acc[e];
+                    st_agent(row + 2 * e, v.c0);
+                    st_agent(row + 2 * e + 1, v.c1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (write-through stores: draining them is enough, see `epilogue`)
+                const unsigned prev = __hip_atomic_fetch_add(J.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = prev == (unsigned)(J.G * (i + 1) - 1) ? 1 : 0;
+            }
+            __syncthreads();
+            publish = s_last != 0;
+            if (publish) {
+                if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __syncthreads();
+                E2 tot[3] = {e2_zero(), e2_zero(), e2_zero()};
+                for (int b = threadIdx.x; b < J.G; b += CNT) {
+                    const uint64_t* row = J.part + 8 * (size_t)b;
+#pragma unroll
+                    for (int e = 0; e < 3; e++) tot[e] = tot[e] + E2{ld_agent(row + 2 * e), ld_agent(row + 2 * e + 1)};
+                }
+                __syncthreads();  // smem is reused
+                red::block_sum<3, CNT>(tot, smem);
+#pragma unroll
+                for (int e = 0; e < 3; e++) acc[e] = tot[e];
+            }
+        }
+        if (publish && threadIdx.x < 4) {  // lanes 0 .. 3 of wave 0: one coalesced 64-byte store [p(1), p(2), p(3), clocks]
+            E2 v[4] = {acc[0], acc[1], acc[2], E2{(uint64_t)t_chal, (uint64_t)wall_clock64()}};  // (clocks: diagnostics, 100 MHz)
+            E2 mine = v[0];
+#pragma unroll
+            for (int e = 1; e < 4; e++) {
+                const E2 from0 = E2{(uint64_t)__shfl((unsigned long long)v[e].c0, 0), (uint64_t)__shfl((unsigned long long)v[e].c1, 0)};
+                if ((int)threadIdx.x == e) mine = from0;
+            }
+            put16(J.h_msg + 8 * (size_t)i + 2 * threadIdx.x, mine);
+        }
         if (threadIdx.x == 0) {
-            uint64_t* msg = J.h_msg + 8 * (size_t)i;
-            put16(msg, acc[0]);
-            put16(msg + 2, acc[1]);
-            put16(msg + 4, acc[2]);
             unsigned long long c0 = 0, c1 = 0;
-            const bool ok = poll_challenge(J.box, (unsigned long long)(i + 1), c0, c1, J.poll_ticks);
+            const bool ok = poll_challenge_paced(J.box, (unsigned long long)(i + 1), c0, c1, J.poll_ticks, J.pad_);
             s_c[0] = c0;
             s_c[1] = c1;
             s_c[2] = ok ? 1ull : 0ull;
+            t_chal = wall_clock64();
         }
         __syncthreads();  // (also: every lane's stores into `cur` are done before the next round reads them as `prev`)
         if (s_c[2] == 0) return;  // aborted / timed out: leave the evaluations unwritten
@@ -184,6 +254,8 @@ struct ceno_hip_cohort {
     std::vector<int> n, K;
     void* d_jobs = nullptr;          // pool block: CohortJob x n_jobs
     void* d_scratch = nullptr;       // pool block: eq + ping + pong of every job
+    void* d_group = nullptr;         // pool block: the groups' partial messages and arrival counters
+    std::vector<int> leader;         // the job whose try_message yields the group's message
     uint64_t* h_area = nullptr;      // pinned: per job [COHORT_SUB rounds x 8 words][16 x 2 words of evaluations]
     uint64_t* d_area = nullptr;      // its device view
     Mailbox* boxes = nullptr;        // device memory the host writes (large BAR): one 64-byte line per job
@@ -241,17 +313,30 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     for (int j = 0; j < n_jobs; j++) {
         const ceno_hip_cohort_job& G = jobs[j];
         const int K = 1 + 2 * G.n_prod + 4 * G.n_logup;
-        if (G.n < 1 || G.n > COHORT_SUB || G.n_prod < 0 || G.n_prod > 3 || G.n_logup < 0 || G.n_logup > 2 || K < 3 || !G.rt || !G.tables) {
+        if (G.share_mailbox_of < 0 || G.share_mailbox_of > n_jobs || G.n < 1 || G.n > COHORT_SUB || G.n_prod < 0 || G.n_prod > 3 || G.n_logup < 0 || G.n_logup > 2 || K < 3 || !G.rt || !G.tables) {
             delete c;
             return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: 1 .. %d variables, <= 3 product and <= 2 LogUp towers, at least one", j, COHORT_SUB);
         }
         c->n.push_back(G.n);
         c->K.push_back(K);
+        c->leader.push_back(G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j);
         const size_t len = (size_t)1 << G.n;
         scratch_e2 += len + (size_t)K * (len / 2) + (size_t)K * std::max<size_t>(len / 4, 1);
     }
+    // groups: consecutive jobs naming the same leader, the leader first
+    std::vector<int> group_size((size_t)n_jobs, 1);
+    for (int j = 0; j < n_jobs; j++) {
+        const int l = jobs[j].share_mailbox_of > 0 ? jobs[j].share_mailbox_of - 1 : j;
+        const bool ok = l <= j && (l == j || (jobs[l].share_mailbox_of == l + 1 && jobs[j - 1].share_mailbox_of == l + 1 && jobs[j].n == jobs[l].n));
+        if (!ok) {
+            delete c;
+            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: a group is consecutive jobs of one size naming their first job", j);
+        }
+        if (l != j) group_size[(size_t)l]++;
+    }
     int rc = ctx_alloc(ctx, sizeof(CohortJob) * (size_t)n_jobs, &c->d_jobs);
     if (!rc) rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
+    if (!rc) rc = ctx_alloc(ctx, (size_t)128 * n_jobs, &c->d_group);  // per job: 8 words of partial message, 8 words holding the group counter
     void *hb = nullptr, *db = nullptr;
     if (!rc) rc = ctx_pinned_alloc(ctx, COHORT_H_WORDS * 8 * (size_t)n_jobs, &hb, &db);
     if (!rc) {
@@ -284,6 +369,7 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     if (rc) {
         release_boxes();
         if (hb) ctx_pinned_free(ctx, hb);
+        if (c->d_group) ctx_free(ctx, c->d_group);
         if (c->d_scratch) ctx_free(ctx, c->d_scratch);
         if (c->d_jobs) ctx_free(ctx, c->d_jobs);
         delete c;
@@ -291,12 +377,19 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     }
     c->h_area = (uint64_t*)hb;
     c->d_area = (uint64_t*)db;
-    for (size_t i = 0; i < COHORT_H_WORDS * (size_t)n_jobs; i++) c->h_area[i] = MSG_INVALID;
+    for (int j = 0; j < n_jobs; j++) {  // (only the words a job's device side writes: a leader's messages, every job's evaluations)
+        uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)j;
+        if (c->leader[(size_t)j] == j)
+            for (int i = 0; i < 8 * c->n[(size_t)j]; i++) w[i] = MSG_INVALID;
+        for (int i = 0; i < 2 * c->K[(size_t)j]; i++) w[8 * COHORT_SUB + i] = MSG_INVALID;
+    }
     static const unsigned long long ticks = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         const double sec = e && atof(e) > 0 ? atof(e) : 60.0;
         return (unsigned long long)(sec * 1e8);
     }();
+    const char* e_gap = getenv("CENO_HIP_COHORT_POLL_GAP");
+    const int poll_gap = e_gap ? atoi(e_gap) : 0;
     std::vector<CohortJob> hj((size_t)n_jobs);
     E2* sp = (E2*)c->d_scratch;
     for (int j = 0; j < n_jobs; j++) {
@@ -312,9 +405,16 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         sp += (size_t)K * (len / 2);
         J.pong = sp;
         sp += (size_t)K * std::max<size_t>(len / 4, 1);
-        J.h_msg = c->d_area + COHORT_H_WORDS * (size_t)j;
-        J.h_fin = J.h_msg + 8 * COHORT_SUB;
-        J.box = c->boxes + 2 * (size_t)j;  // (Mailbox is 32 bytes: every job gets a 64-byte line of its own)
+        // a group (share_mailbox_of = leader + 1 on every member, the leader first): one mailbox, one message slot, one counter
+        const int leader = G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j;
+        J.h_msg = c->d_area + COHORT_H_WORDS * (size_t)leader;
+        J.h_fin = c->d_area + COHORT_H_WORDS * (size_t)j + 8 * COHORT_SUB;
+        J.box = c->boxes + 2 * (size_t)leader;  // (Mailbox is 32 bytes: every job gets a 64-byte line of its own)
+        J.G = group_size[(size_t)leader];
+        J.g = j - leader;
+        J.scale = G.scale ? E2{G.scale[0], G.scale[1]} : e2_one();
+        J.part = (uint64_t*)c->d_group + 8 * (size_t)leader;
+        J.counter = (unsigned*)((uint64_t*)c->d_group + 8 * (size_t)n_jobs + 8 * (size_t)leader);
         for (int v = 0; v < G.n; v++) J.rt[v] = E2{G.rt[2 * v], G.rt[2 * v + 1]};
         for (int t = 0; t < G.n_prod; t++) J.a_prod[t] = E2{G.alpha_prod[2 * t], G.alpha_prod[2 * t + 1]};
         for (int t = 0; t < G.n_logup; t++) {
@@ -325,13 +425,15 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         J.np = G.n_prod;
         J.nl = G.n_logup;
         J.poll_ticks = ticks;
+        J.pad_ = poll_gap;
         // the mailbox line: no challenge yet
         volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
         mb->chal_seq = 0;
         mb->abort = 0;
     }
     host_fence();
-    hipError_t e = hipMemcpyAsync(c->d_jobs, hj.data(), sizeof(CohortJob) * (size_t)n_jobs, hipMemcpyHostToDevice, st);
+    hipError_t e = hipMemsetAsync(c->d_group, 0, (size_t)128 * n_jobs, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_jobs, hj.data(), sizeof(CohortJob) * (size_t)n_jobs, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the host vector goes away; the launch below is asynchronous)
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)n_jobs), dim3(CNT), 0, st, (const CohortJob*)c->d_jobs);
@@ -340,6 +442,7 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     if (e != hipSuccess) {
         release_boxes();
         ctx_pinned_free(ctx, hb);
+        ctx_free(ctx, c->d_group);
         ctx_free(ctx, c->d_scratch);
         ctx_free(ctx, c->d_jobs);
         delete c;
@@ -351,6 +454,7 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
 
 int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6) {
     if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !out6) return CENO_HIP_ERR_INVALID;
+    if (c->leader[(size_t)job] != job) return CENO_HIP_ERR_INVALID;  // a group's message is its leader's
     const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * (size_t)round;
     uint64_t v[6];
     for (int i = 0; i < 6; i++) {
@@ -361,8 +465,16 @@ int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, ui
     return 1;
 }
 
+int ceno_hip_tower_cohort_round_times(ceno_hip_cohort* c, int job, int round, uint64_t* out2) {
+    if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !out2) return CENO_HIP_ERR_INVALID;
+    const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * (size_t)round + 6;
+    out2[0] = w[0];
+    out2[1] = w[1];
+    return 0;
+}
+
 int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2) {
-    if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !chal2) return CENO_HIP_ERR_INVALID;
+    if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !chal2 || c->leader[(size_t)job] != job) return CENO_HIP_ERR_INVALID;
     volatile Mailbox* mb = c->boxes + 2 * (size_t)job;
     mb->chal[0] = chal2[0];
     mb->chal[1] = chal2[1];
@@ -401,6 +513,7 @@ int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
         if (--A.live == 0) A.next = 0;
     }
     ctx_pinned_free(ctx, c->h_area);
+    ctx_free_on(ctx, c->d_group, c->st);
     ctx_free_on(ctx, c->d_scratch, c->st);
     ctx_free_on(ctx, c->d_jobs, c->st);
     delete c;

@@ -61,7 +61,7 @@ struct LayerChip {
     ChipProofRun* run = nullptr;
     int L = 0, n_lo = 0, G = 1, first_job = 0, np_act = 0, nl_act = 0, K = 0;
     std::vector<uint64_t> a_prod, a_num, a_den;           // the active towers' alpha powers (words)
-    std::vector<std::vector<const uint64_t*>> tables;     // [job][K - 1]
+    std::vector<const uint64_t*> tables;                  // [job][K - 1]
     std::vector<E2> eq_hi;                                // eq(g; rt[n_lo ..]) over the sub-cubes (G > 1)
     // serving state
     bool started = false, done = false;
@@ -70,10 +70,23 @@ struct LayerChip {
     std::vector<uint64_t> part, chal, fin, finbuf;
 };
 
-void prepare(LayerChip& c, ChipProofRun* run, int L, int sub) {
+// How a layer of 2^L entries is cut for n_chips chips: a sub-cube's rounds are VALU work on one compute unit, so the cut is as fine as the
+// device can hold at once (every sub-cube of a layer must be resident: the chip's next challenge waits for all of them) — but not below
+// 2^9 entries (a workgroup of 256 lanes has at most one pair per lane there: what remains is round-trip latency, which finer cuts only
+// lengthen by host rounds), nor into more than 32 sub-cubes (the host adds their partial messages every round).
+int sub_cube_vars(int L, int n_chips, int capacity, int sub_max) {
+    const char* e = getenv("CENO_TOWER_COHORT_SUB");  // (A/B and tests: a fixed sub-cube size)
+    const int fixed = e ? atoi(e) : 0;
+    if (fixed > 0) return std::min(L, std::min(fixed, sub_max));
+    int n = std::min(L, 9);
+    while (n < std::min(L, sub_max) && ((L - n) > 5 || (long)n_chips << (L - n) > capacity)) n++;
+    return n;
+}
+
+void prepare(LayerChip& c, ChipProofRun* run, int L, int n_lo) {
     c.run = run;
     c.L = L;
-    c.n_lo = std::min(L, sub);
+    c.n_lo = std::min(L, n_lo);
     c.G = 1 << (L - c.n_lo);
     TowerProveState& st = run->st;
     c.a_prod.clear();
@@ -95,14 +108,15 @@ void prepare(LayerChip& c, ChipProofRun* run, int L, int sub) {
     c.np_act = (int)act_p.size();
     c.nl_act = (int)act_l.size();
     c.K = 1 + 2 * c.np_act + 4 * c.nl_act;
-    c.tables.assign((size_t)c.G, {});
+    std::vector<const uint64_t*> base;
+    for (auto* t : act_p)
+        for (int b = 0; b < 2; b++) base.push_back(ceno_hip_tower_layer_ptr(t, L, b));
+    for (auto* t : act_l)
+        for (int b = 0; b < 4; b++) base.push_back(ceno_hip_tower_layer_ptr(t, L, b));
+    c.tables.resize((size_t)c.G * base.size());
     for (int g = 0; g < c.G; g++) {
-        auto& tb = c.tables[(size_t)g];
         const size_t off = (size_t)2 * ((size_t)g << c.n_lo);  // words: sub-cube g = the entries whose top index bits are g
-        for (auto* t : act_p)
-            for (int b = 0; b < 2; b++) tb.push_back(ceno_hip_tower_layer_ptr(t, L, b) + off);
-        for (auto* t : act_l)
-            for (int b = 0; b < 4; b++) tb.push_back(ceno_hip_tower_layer_ptr(t, L, b) + off);
+        for (size_t m = 0; m < base.size(); m++) c.tables[(size_t)g * base.size() + m] = base[m] + off;
     }
     c.eq_hi.assign((size_t)c.G, gl::e2_one());
     for (int j = 0; j < L - c.n_lo; j++) {  // variable n_lo + j of the layer is bit j of g
@@ -131,34 +145,16 @@ int serve(ceno_hip_cohort* co, LayerChip& c) {
         c.started = true;
     }
     if (c.round < c.n_lo) {
-        for (int g = 0; g < c.G; g++) {
-            if (c.got[(size_t)g]) continue;
-            const int r = ceno_hip_tower_cohort_try_message(co, c.first_job + g, c.round, c.part.data() + 6 * (size_t)g);
-            if (r < 0) return r;
-            if (r == 1) {
-                c.got[(size_t)g] = 1;
-                c.n_got++;
-            }
-        }
-        if (c.n_got < c.G) return 0;
         uint64_t* msg = st.out->msgs + st.msg_off + 6 * (size_t)c.round;
-        if (c.G == 1) memcpy(msg, c.part.data(), 48);
-        else
-            for (int e = 0; e < 3; e++) {
-                E2 acc = gl::e2_zero();
-                for (int g = 0; g < c.G; g++) acc = acc + c.eq_hi[(size_t)g] * E2{c.part[6 * (size_t)g + 2 * e], c.part[6 * (size_t)g + 2 * e + 1]};
-                msg[2 * e] = acc.c0;
-                msg[2 * e + 1] = acc.c1;
-            }
+        const int got = ceno_hip_tower_cohort_try_message(co, c.first_job, c.round, msg);  // (the group's message: the sub-cubes' sum)
+        if (got < 0) return got;
+        if (got == 0) return 0;
         const E2 ch = prover_tr_round(st.tr, msg);
         const uint64_t w[2] = {ch.c0, ch.c1};
         c.chal[2 * (size_t)c.round] = w[0];
         c.chal[2 * (size_t)c.round + 1] = w[1];
-        for (int g = 0; g < c.G; g++)
-            if (int r = ceno_hip_tower_cohort_send_challenge(co, c.first_job + g, c.round, w)) return r;
+        if (int r = ceno_hip_tower_cohort_send_challenge(co, c.first_job, c.round, w)) return r;
         c.round++;
-        c.n_got = 0;
-        std::fill(c.got.begin(), c.got.end(), 0);
         return 0;
     }
     // every challenge of the launch is out: the sub-cubes' evaluations at the point
@@ -222,6 +218,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         if (int rc = ceno_hip_lane_stream(ctx, (int)l, &streams[l])) return prover_set_error(rc, ceno_hip_last_error(ctx));
     ceno_hip_stream stream = streams[0];
     static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
+    static const bool times = getenv("CENO_COHORT_TIMES") != nullptr;
     static const double timeout_ms = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         return 1e3 * (e && atof(e) > 0 ? atof(e) : 60.0);
@@ -238,7 +235,18 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     // holds at once), or the end
     int first_pending = 0;  // (within one layer: chips from this index on have not been launched yet)
     int layer_now = 0;
+    double t_prep = 0, t_end = 0;  // (trace: thread 0's time building launches / closing them)
+    int n_jobs_planned = 0;
     auto next_launch = [&]() -> bool {
+        const double t_in = trace ? now_ms() : 0;
+        struct Acc {
+            double& a;
+            double t;
+            bool on;
+            ~Acc() {
+                if (on) a += now_ms() - t;
+            }
+        } acc_{t_prep, t_in, trace};
         for (;;) {
             if (layer_now == 0) {
                 int L = 0;
@@ -249,17 +257,22 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 first_pending = 0;
             }
             chips.clear();
-            int jobs = 0;
+            int jobs = 0, at_layer = 0;
+            for (size_t k = 0; k < runs.size(); k++)
+                if (!status[k] && !runs[k]->st.done() && runs[k]->st.round == layer_now) at_layer++;
+            const int n_lo = sub_cube_vars(layer_now, at_layer, capacity, sub);
             size_t i = (size_t)first_pending;
             for (; i < runs.size(); i++) {
                 if (status[i] || runs[i]->st.done() || runs[i]->st.round != layer_now) continue;
-                const int G = 1 << std::max(0, layer_now - sub);
+                const int G = 1 << (layer_now - n_lo);
                 if (G > capacity) {  // (a layer no launch can hold: left to the per-chip prover)
                     return false;
                 }
                 if (jobs + G > capacity) break;
                 chips.emplace_back();
-                prepare(chips.back(), runs[i], layer_now, sub);
+                chips.back().run = runs[i];  // (prepared by its serving thread)
+                chips.back().L = layer_now;
+                chips.back().n_lo = n_lo;
                 chips.back().first_job = jobs;
                 jobs += G;
             }
@@ -269,11 +282,19 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 continue;
             }
             if (i >= runs.size()) layer_now = 0;  // the layer is complete with this launch
+            n_jobs_planned = jobs;
+            return true;
+        }
+    };
+    auto begin_launch = [&]() {
+        const double t_in = trace ? now_ms() : 0;
+        {
+            const int jobs = n_jobs_planned;
             std::vector<ceno_hip_cohort_job> hj((size_t)jobs);
             for (auto& c : chips)
                 for (int g = 0; g < c.G; g++) {
                     ceno_hip_cohort_job& J = hj[(size_t)(c.first_job + g)];
-                    J.tables = c.tables[(size_t)g].data();
+                    J.tables = c.tables.data() + (size_t)g * (size_t)(c.K - 1);
                     J.n_prod = c.np_act;
                     J.n_logup = c.nl_act;
                     J.n = c.n_lo;
@@ -281,17 +302,22 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                     J.alpha_prod = c.a_prod.data();
                     J.alpha_num = c.a_num.data();
                     J.alpha_den = c.a_den.data();
+                    // the sub-cubes of a layer are a group: one mailbox, one message per round (added up on the device, scaled by eq_hi)
+                    J.share_mailbox_of = c.G > 1 ? c.first_job + 1 : 0;
+                    J.scale = reinterpret_cast<const uint64_t*>(&c.eq_hi[(size_t)g]);
                 }
             const double t0 = trace ? now_ms() : 0;
             const int rc = ceno_hip_tower_cohort_begin(ctx, hj.data(), jobs, stream, &co);
             if (rc) {
                 err_msg = ceno_hip_last_error(ctx);
                 err.store(rc);
-                return false;
+                co = nullptr;
             }
-            if (trace) fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs, launch %.3f ms\n", chips[0].L, chips.size(), jobs, now_ms() - t0);
-            return true;
+            if (trace)
+                fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs of 2^%d (the device holds %d), launch %.3f ms\n", chips[0].L, chips.size(), jobs,
+                        chips[0].n_lo, capacity, now_ms() - t0);
         }
+        if (trace) t_prep += now_ms() - t_in;
     };
     double t_a1 = 0, t_a2 = 0, t_a3 = 0;
     const double t_start = now_ms();
@@ -360,6 +386,11 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             if (t == 0) more.store(next_launch());
             bar.wait();
             if (!more.load()) return;
+            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) prepare(chips[i], chips[i].run, chips[i].L, chips[i].n_lo);
+            bar.wait();
+            if (t == 0) begin_launch();
+            bar.wait();
+            if (err.load()) return;
             const double t_begin = now_ms();
             size_t open = 0;
             for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) open++;
@@ -385,9 +416,29 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 }
             }
             bar.wait();
+            if (t == 0 && times && !err.load() && !chips.empty()) {
+                // (CENO_COHORT_TIMES: the first and the last chip's first sub-cube, round by round: device time from challenge to message,
+                // then how long the message waited for its answer)
+                for (const LayerChip* c : {&chips.front(), &chips.back()}) {
+                    std::string line;
+                    uint64_t prev_sent = 0, first = 0;
+                    for (int i = 0; i < c->n_lo; i++) {
+                        uint64_t w[2] = {0, 0};
+                        (void)ceno_hip_tower_cohort_round_times(co, c->first_job, i, w);
+                        if (i == 0) first = w[0];
+                        char buf[96];
+                        snprintf(buf, sizeof buf, " [%d: wait %.1f, compute %.1f]", i, i ? (double)(w[0] - prev_sent) / 100.0 : 0.0, (double)(w[1] - w[0]) / 100.0);
+                        line += buf;
+                        prev_sent = w[1];
+                    }
+                    fprintf(stderr, "[ceno_prover] cohort times (us), layer %d job %d, %.1f us in all:%s\n", c->L, c->first_job, (double)(prev_sent - first) / 100.0, line.c_str());
+                }
+            }
             if (t == 0) {
+                const double t_e = trace ? now_ms() : 0;
                 if (err.load()) (void)ceno_hip_tower_cohort_abort(co);
                 const int rc = ceno_hip_tower_cohort_end(ctx, co);
+                if (trace) t_end += now_ms() - t_e;
                 co = nullptr;
                 if (rc && !err.load()) {
                     err_msg = ceno_hip_last_error(ctx);
@@ -414,6 +465,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
     worker(0);
     for (auto& x : th) x.join();
+    if (trace) fprintf(stderr, "[ceno_prover] cohort: thread 0 spent %.3f ms building launches, %.3f ms closing them\n", t_prep, t_end);
     if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: records %.3f ms, towers of all chips %.3f, to the cohort layers %.3f, cohort layers to %d %.3f\n", t_a1,
                        t_a2 - t_a1, t_a3 - t_a2, last_layer, now_ms() - t_start - t_a3);
     if (const int rc = err.load()) {

@@ -197,6 +197,22 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                        int n_threads);  // cohort.cpp
 int prover_tower_host_layers();                                                                                                       // prover.cpp
 namespace {
+// CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread host with a quota of 16)
+int cpu_budget() {
+    static const int budget = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && q[0] != 'm') n = std::min<long>(n, std::max<long>(1, atol(q) / period));
+            fclose(f);
+        }
+        return std::max(1, n);
+    }();
+    return budget;
+}
 struct PhaseJob {
     ChipProofRun* run;
     ceno_hip_ctx* ctx;
@@ -265,7 +281,7 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
     auto ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     // (the serving threads wait for messages and hash transcripts — host work, not bounded by the device's four queues)
     const char* e_thr = getenv("CENO_COHORT_THREADS");
-    const int n_threads = e_thr && atoi(e_thr) > 0 ? atoi(e_thr) : ceno_prover_lanes_effective_for(lanes, n_tasks);
+    const int n_threads = e_thr && atoi(e_thr) > 0 ? atoi(e_thr) : std::max(ceno_prover_lanes_effective_for(lanes, n_tasks), std::min(16, cpu_budget()));
     const int rc_b = cohort_chip_proofs(ctx, tasks, challenges4, transcripts, out_proofs, run_ptrs, status, host_layers, last_layer, n_threads);
     const std::string msg_b = rc_b ? ceno_prover_last_error() : "";
     const double t_b = ms();

@@ -400,8 +400,9 @@ int ceno_hip_merkle_free(ceno_hip_ctx* ctx, ceno_hip_merkle* t);
  * scheduler lanes; on this hardware four queues run at a time, so the chains are put into ONE launch instead.
  * A job: n <= ceno_hip_tower_cohort_max_vars() (13) variables; tables = 2 n_prod + 4 n_logup device pointers, each 2^n extension elements
  * ([a, b] per product tower, [p1, p2, q1, q2] per LogUp tower); rt: n ext; alpha_*: one ext per tower.  A layer of more than 2^13 entries
- * is split by its TOP index bits into 2^13-entry jobs whose partial messages the caller adds (scaled by eq over the high variables).
- * Protocol per job and round i = 0 .. n - 1: try_message(job, i) until it returns 1 (out6 = p(1), p(2), p(3)), send_challenge(job, i, r_i);
+ * is split by its TOP index bits into smaller jobs forming a group (below) whose messages the device adds, scaled by eq over the high variables.
+ * Protocol per job and round i = 0 .. n - 1: try_message(job, i) until it returns 1 (out6 = p(1), p(2), p(3)), send_challenge(job, i, r_i)
+ * (to the mailbox's owner alone when jobs share one);
  * after the last challenge try_final(job) yields the 1 + 2 n_prod + 4 n_logup evaluations [eq, a, b, .., p1, p2, q1, q2, ..] at the point.
  * begin launches and returns; end waits for the launch and frees.  abort releases every waiting workgroup (then call end).
  * ---------------------------------------------------------------------------------------------- */
@@ -411,6 +412,12 @@ typedef struct ceno_hip_cohort_job {
     int n_prod, n_logup, n;
     const uint64_t* rt;
     const uint64_t *alpha_prod, *alpha_num, *alpha_den;
+    int share_mailbox_of; /* 0: the job stands alone.  j + 1: it belongs to the GROUP led by job j (consecutive jobs of one size, j first, j names
+                           * itself): the sub-cubes of one layer.  A group takes its challenges from ONE mailbox (send_challenge to j alone)
+                           * and publishes ONE message per round — the sum of its jobs' messages, each times its `scale` — through
+                           * try_message(j): the device adds them up, so that a round costs one write to the host however fine the cut.
+                           * Final evaluations stay per job. */
+    const uint64_t* scale; /* one ext (NULL: one): eq of the sub-cube's index at the layer's high coordinates */
 } ceno_hip_cohort_job;
 int ceno_hip_tower_cohort_max_vars(void);
 /* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host */
@@ -418,6 +425,9 @@ int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx);
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
 int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6);
 int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2);
+/* diagnostics, valid once try_message(job, round) returned 1: out2 = the device's 100 MHz clock when the job saw the challenge that opened
+ * this round (round 0: when it started) and when it sent the round's message */
+int ceno_hip_tower_cohort_round_times(ceno_hip_cohort* c, int job, int round, uint64_t* out2);
 int ceno_hip_tower_cohort_try_final(ceno_hip_cohort* c, int job, uint64_t* out_evals);
 int ceno_hip_tower_cohort_abort(ceno_hip_cohort* c);
 int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c);

@@ -25,7 +25,7 @@ def dev():
 
 class JobC(C.Structure):
     _fields_ = [("tables", C.POINTER(C.c_void_p)), ("n_prod", C.c_int), ("n_logup", C.c_int), ("n", C.c_int), ("rt", po.u64p),
-                ("alpha_prod", po.u64p), ("alpha_num", po.u64p), ("alpha_den", po.u64p)]
+                ("alpha_prod", po.u64p), ("alpha_num", po.u64p), ("alpha_den", po.u64p), ("share_mailbox_of", C.c_int), ("scale", po.u64p)]
 
 
 def _oracle_layer(tabs, n, np_, nl, rt, a_prod, a_num, a_den, seed):
@@ -45,8 +45,11 @@ def _oracle_layer(tabs, n, np_, nl, rt, a_prod, a_num, a_den, seed):
     return po.sumcheck_prove(tables, po.ext(coeffs), terms, n, 3, po.StubTranscript(seed))
 
 
-def _run_cohort(dev, cases):
-    """cases: [(n, np, nl, host tables [2^n x 2], rt (n, 2), a_prod, a_num, a_den, challenges (n, 2))] -> [(msgs, fin)] served round-robin"""
+def _run_cohort(dev, cases, group_scales=None):
+    """cases: [(n, np, nl, host tables [2^n x 2], rt (n, 2), a_prod, a_num, a_den, challenges (n, 2))] -> [(msgs, fin)] served round-robin.
+    group_scales (one ext per case): the cases are ONE group led by case 0 — one mailbox, one message per round (the device's sum of the
+    cases' messages times their scales), returned as case 0's; the final evaluations stay per case"""
+    share_first_mailbox = group_scales is not None
     L = dev.L
     keep, jobs = [], (JobC * len(cases))()
     for j, (n, np_, nl, tabs, rt, a_prod, a_num, a_den, _) in enumerate(cases):
@@ -57,6 +60,10 @@ def _run_cohort(dev, cases):
         J = jobs[j]
         J.tables, J.n_prod, J.n_logup, J.n = ptrs, np_, nl, n
         J.rt, J.alpha_prod, J.alpha_num, J.alpha_den = (x.ctypes.data_as(po.u64p) for x in (rt_c, ap, an, ad))
+        if share_first_mailbox:
+            sc = np.ascontiguousarray(group_scales[j], dtype=np.uint64)
+            keep.append(sc)
+            J.share_mailbox_of, J.scale = 1, sc.ctypes.data_as(po.u64p)
     st = dev.stream_create()
     h = C.c_void_p()
     dev.check(L.ceno_hip_tower_cohort_begin(dev.h, C.cast(jobs, C.c_void_p), len(cases), st, C.byref(h)))
@@ -70,7 +77,11 @@ def _run_cohort(dev, cases):
         for j, c in enumerate(cases):
             if done[j]:
                 continue
+            if share_first_mailbox and j > 0:
+                rnd[j] = rnd[0]      # (a member follows its leader: only the leader has messages and a mailbox)
             if rnd[j] < c[0]:
+                if share_first_mailbox and j > 0:
+                    continue
                 out = np.zeros(6, dtype=np.uint64)
                 got = L.ceno_hip_tower_cohort_try_message(h, j, rnd[j], out.ctypes.data_as(po.u64p))
                 assert got >= 0
@@ -120,25 +131,29 @@ def test_many_jobs_at_once_are_all_resident(dev):
         assert np.array_equal(msgs, want[0]) and np.array_equal(fin, want[1])
 
 
-@pytest.mark.parametrize("r", [14, 16])
-def test_sub_cubes_of_a_large_layer_add_up(dev, r):
-    """a layer of 2^r > 2^13 entries as 2^(r - 13) jobs over its top-bit sub-cubes: with every job fed the WHOLE layer's challenges, the sum of the
-    jobs' messages scaled by eq(g; rt_high) equals the layer's message in each of the first 13 rounds, and the jobs' final evaluations are the
-    tables the host finishes the last r - 13 rounds on"""
-    np_, nl, sub = 2, 1, 13
+@pytest.mark.parametrize("r,sub,grouped", [(14, 13, False), (16, 13, False), (16, 13, True), (15, 9, True), (12, 11, True)])
+def test_sub_cubes_of_a_large_layer_add_up(dev, r, sub, grouped):
+    """a layer of 2^r entries as 2^(r - sub) jobs over its top-bit sub-cubes: with every job fed the WHOLE layer's challenges, the sum of the
+    jobs' messages scaled by eq(g; rt_high) equals the layer's message in each of the first `sub` rounds — added by this test, or by the device
+    when the jobs form a group — and the jobs' final evaluations are the tables the host finishes the last r - sub rounds on"""
+    np_, nl = 2, 1
     tabs = [po.rand_ext(1 << r, 9000 + j) for j in range(2 * np_ + 4 * nl)]
     rt = po.rand_ext(r, 9100)
     a_prod, a_num, a_den = po.rand_ext(np_, 9200), po.rand_ext(nl, 9300), po.rand_ext(nl, 9400)
     omsgs, ochal, ofin = _oracle_layer(tabs, r, np_, nl, rt, a_prod, a_num, a_den, 0xE0)
     G = 1 << (r - sub)
     cases = [(sub, np_, nl, [np.ascontiguousarray(t[g << sub: (g + 1) << sub]) for t in tabs], rt[:sub], a_prod, a_num, a_den, ochal[:sub]) for g in range(G)]
-    got = _run_cohort(dev, cases)
     eq_hi = po.build_eq(rt[sub:])
+    # grouped: one mailbox and one message per round for all sub-cubes, added up on the device (what host/cohort.cpp launches)
+    got = _run_cohort(dev, cases, group_scales=[eq_hi[g] for g in range(G)] if grouped else None)
     for i in range(sub):
         for e in range(3):
-            acc = (0, 0)
-            for g in range(G):
-                acc = po.e2_add(acc, po.e2_mul(tuple(int(x) for x in eq_hi[g]), tuple(int(x) for x in got[g][0][i][e])))
+            if grouped:
+                acc = tuple(int(x) for x in got[0][0][i][e])
+            else:
+                acc = (0, 0)
+                for g in range(G):
+                    acc = po.e2_add(acc, po.e2_mul(tuple(int(x) for x in eq_hi[g]), tuple(int(x) for x in got[g][0][i][e])))
             assert acc == tuple(int(x) for x in omsgs[i][e]), (i, e)
     # the gathered tables: table m over the high variables = the jobs' final evaluations (eq: times eq_hi); folding them with the remaining
     # challenges gives the layer's final evaluations

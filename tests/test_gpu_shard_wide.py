@@ -306,14 +306,15 @@ def _proof_words(a):
 def test_cohort_layers_write_the_same_proofs(dev, prover, monkeypatch):
     """the middle tower layers of all chips proved together (host/cohort.cpp, csrc/tower_cohort.hip) against the per-chip prover
     (CENO_TOWER_COHORT_LAYERS=0), word for word over every chip proof and everything derived from them: cohorts up to 2^13 entries (one workgroup
-    per chip), up to 2^16 (the default: eight sub-cubes + three host rounds) and 2^18, several launches per layer (a device that holds 24
-    workgroups), and with the host layers moved so that the cohorts start at layer 5"""
+    per chip), up to 2^16 (the default; a layer is cut into as many sub-cubes as the device holds at once, the host adds their partial messages
+    and proves the last rounds) and 2^18, several launches per layer (a device that holds 24 workgroups), with the host layers moved so that
+    the cohorts start at layer 5, and with fixed sub-cube sizes (2^13: at most eight per layer; 2^6: thirty-two and five host rounds)"""
     from ceno_amd import synthetic
 
     flow = synthetic.ShardFlowWide(dev, prover, log_cycles=12, n_queries=8, pow_bits=4)
 
     def run(env):
-        for k in ("CENO_TOWER_COHORT_LAYERS", "CENO_TOWER_COHORT_CAPACITY", "CENO_TOWER_HOST_LAYERS"):
+        for k in ("CENO_TOWER_COHORT_LAYERS", "CENO_TOWER_COHORT_CAPACITY", "CENO_TOWER_HOST_LAYERS", "CENO_TOWER_COHORT_SUB"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -323,7 +324,7 @@ def test_cohort_layers_write_the_same_proofs(dev, prover, monkeypatch):
     ref = run({"CENO_TOWER_COHORT_LAYERS": "0"})
     assert max(p[0] for p in ref[0]) >= 18      # the tables' towers reach past every cohort layer tried here
     for env in ({}, {"CENO_TOWER_COHORT_LAYERS": "13"}, {"CENO_TOWER_COHORT_LAYERS": "18"}, {"CENO_TOWER_COHORT_CAPACITY": "24"},
-                {"CENO_TOWER_HOST_LAYERS": "4"}):
+                {"CENO_TOWER_HOST_LAYERS": "4"}, {"CENO_TOWER_COHORT_SUB": "13"}, {"CENO_TOWER_COHORT_SUB": "6", "CENO_TOWER_COHORT_LAYERS": "11"}):
         got = run(env)
         for c, (w, g) in enumerate(zip(ref[0], got[0])):
             assert w == g, (env, flow.chips[c]["name"])
