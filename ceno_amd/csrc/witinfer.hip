@@ -9,6 +9,8 @@
 // row-major RowMajorMatrix values[row*width+col] -> column-major device layout.
 #include "common.hpp"
 
+#include <algorithm>
+
 using namespace gl;
 
 static constexpr int NT = 256;
@@ -48,29 +50,88 @@ __global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len, int num
     for (int i = threadIdx.x; i < num_factors; i += NT) s_tidx[i] = pl.term_idx[i];
     for (int i = threadIdx.x; i <= pl.num_outs; i += NT) s_ooff[i] = pl.out_term_off[i];
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * NT;
-    for (size_t x = (size_t)blockIdx.x * NT + threadIdx.x; x < len; x += stride) {
-        for (int o = 0; o < pl.num_outs; o++) {
-            E2 acc = e2_zero();
-            for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
-                E2 v = s_coeffs[t];
-                uint64_t pb = 1;
-                bool any_base = false;
-                for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
-                    const WiSlot sl = s_slots[s_tidx[k]];
-                    if (sl.is_ext) {
-                        v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
-                    } else {
-                        const uint64_t f = sl.ptr[x];
-                        pb = any_base ? mul(pb, f) : f;
-                        any_base = true;
-                    }
+    // one work item = one (record, row): a chip of 2^12 rows and 30 records is 120 k items, not 4 k lanes walking 30 records each — the
+    // walk is a chain of dependent loads (plan word -> column pointer -> value), and what hides it is lanes, not loop iterations.  Items
+    // of one record are consecutive rows (coalesced); the columns the records share come back from L2.  (len is a power of two.)
+    const size_t stride = (size_t)gridDim.x * NT, items = (size_t)pl.num_outs * len, mask = len - 1;
+    const int shift = __builtin_ctzll((unsigned long long)len);
+    for (size_t it = (size_t)blockIdx.x * NT + threadIdx.x; it < items; it += stride) {
+        const int o = (int)(it >> shift);
+        const size_t x = it & mask;
+        E2 acc = e2_zero();
+        for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
+            E2 v = s_coeffs[t];
+            uint64_t pb = 1;
+            bool any_base = false;
+            for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
+                const WiSlot sl = s_slots[s_tidx[k]];
+                if (sl.is_ext) {
+                    v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
+                } else {
+                    const uint64_t f = sl.ptr[x];
+                    pb = any_base ? mul(pb, f) : f;
+                    any_base = true;
                 }
-                if (any_base) v = e2_mul_base(v, pb);
-                acc = acc + v;
             }
-            s_outs[o][x] = acc;
+            if (any_base) v = e2_mul_base(v, pb);
+            acc = acc + v;
         }
+        s_outs[o][x] = acc;
+    }
+}
+// MANY plans in one launch (ceno_hip_wit_infer_many): the records of all chips of a shard.  A workgroup belongs to one plan (BlkRef), stages
+// that plan in LDS and walks its (record, row) items as k_wit_infer does.
+struct WiJob {
+    WiPlan pl;
+    size_t len;
+    int num_mles, num_terms, num_factors, pad_;
+};
+struct WiBlk {
+    uint32_t job, blk, nblk;
+};
+__global__ void __launch_bounds__(NT) k_wit_infer_many(const WiJob* __restrict__ jobs, const WiBlk* __restrict__ blks) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const WiBlk b = blks[blockIdx.x];
+    const WiJob J = jobs[b.job];
+    const WiPlan& pl = J.pl;
+    const int num_mles = J.num_mles, num_terms = J.num_terms, num_factors = J.num_factors;
+    WiSlot* s_slots = reinterpret_cast<WiSlot*>(dyn);
+    E2* s_coeffs = reinterpret_cast<E2*>(s_slots + num_mles);
+    E2** s_outs = reinterpret_cast<E2**>(s_coeffs + num_terms);
+    uint32_t* s_toff = reinterpret_cast<uint32_t*>(s_outs + pl.num_outs);
+    uint32_t* s_tidx = s_toff + num_terms + 1;
+    uint32_t* s_ooff = s_tidx + num_factors;
+    for (int i = threadIdx.x; i < num_mles; i += NT) s_slots[i] = pl.mles[i];
+    for (int i = threadIdx.x; i < num_terms; i += NT) s_coeffs[i] = pl.coeffs[i];
+    for (int i = threadIdx.x; i < pl.num_outs; i += NT) s_outs[i] = pl.outs[i];
+    for (int i = threadIdx.x; i <= num_terms; i += NT) s_toff[i] = pl.term_off[i];
+    for (int i = threadIdx.x; i < num_factors; i += NT) s_tidx[i] = pl.term_idx[i];
+    for (int i = threadIdx.x; i <= pl.num_outs; i += NT) s_ooff[i] = pl.out_term_off[i];
+    __syncthreads();
+    const size_t len = J.len, stride = (size_t)b.nblk * NT, items = (size_t)pl.num_outs * len, mask = len - 1;
+    const int shift = __builtin_ctzll((unsigned long long)len);
+    for (size_t it = (size_t)b.blk * NT + threadIdx.x; it < items; it += stride) {
+        const int o = (int)(it >> shift);
+        const size_t x = it & mask;
+        E2 acc = e2_zero();
+        for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
+            E2 v = s_coeffs[t];
+            uint64_t pb = 1;
+            bool any_base = false;
+            for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
+                const WiSlot sl = s_slots[s_tidx[k]];
+                if (sl.is_ext) {
+                    v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
+                } else {
+                    const uint64_t f = sl.ptr[x];
+                    pb = any_base ? mul(pb, f) : f;
+                    any_base = true;
+                }
+            }
+            if (any_base) v = e2_mul_base(v, pb);
+            acc = acc + v;
+        }
+        s_outs[o][x] = acc;
     }
 }
 // plans too large for the LDS stage (thousands of terms) walk the records in global memory
@@ -169,7 +230,7 @@ int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mle
         pl.outs = reinterpret_cast<E2* const*>(d_blob + o_outs);
         pl.num_outs = num_outs;
         size_t len = (size_t)1 << num_vars;
-        if (lds <= 60 * 1024) hipLaunchKernelGGL(k_wit_infer, dim3(grid_for(len, NT, MAXB)), dim3(NT), lds, st, pl, len, num_mles, num_terms, (int)n_fac);
+        if (lds <= 60 * 1024) hipLaunchKernelGGL(k_wit_infer, dim3(grid_for(len * (size_t)num_outs, NT, 4 * MAXB)), dim3(NT), lds, st, pl, len, num_mles, num_terms, (int)n_fac);
         else hipLaunchKernelGGL(k_wit_infer_big, dim3(grid_for(len, NT, MAXB)), dim3(NT), 0, st, pl, len);
         // no wait: the outputs are ordered on `st` like every other result, and the plan blob returns to the pool tagged with
         // this stream (another stream gets it only after this one has drained)
@@ -182,6 +243,144 @@ int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mle
         return rc;
     }
     for (int o = 0; o < num_outs; o++) outs[o] = res[o];
+    return 0;
+}
+
+int ceno_hip_wit_infer_many(ceno_hip_ctx* ctx, const ceno_hip_wit_plan* plans, int n, ceno_hip_stream s) {
+    CENO_TIMED("wit_infer_many");
+    CHECK_ARG(ctx, plans && n >= 1 && n <= 4096, "wit_infer_many: bad arguments");
+    hipStream_t st = ctx_stream(ctx, s);
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    // pass 1: checks and the blob's layout; a plan too large for the LDS stage goes through the single-plan call
+    struct Lay {
+        size_t o_slots, o_coeffs, o_outs, o_toff, o_tidx, o_ooff;
+        size_t n_fac, lds;
+        bool many;
+    };
+    std::vector<Lay> lay((size_t)n);
+    size_t total = al((size_t)n * sizeof(WiJob)), max_lds = 0;
+    int n_many = 0;
+    for (int i = 0; i < n; i++) {
+        const ceno_hip_wit_plan& P = plans[i];
+        CHECK_ARG(ctx, P.mles && P.term_coeffs && P.term_offsets && P.term_mle_idx && P.out_term_offsets && P.outs, "wit_infer_many: plan %d: NULL argument", i);
+        CHECK_ARG(ctx, P.num_mles >= 1 && P.num_terms >= 0 && P.num_outs >= 1 && P.num_vars >= 0 && P.num_vars < 40, "wit_infer_many: plan %d is empty", i);
+        CHECK_ARG(ctx, P.out_term_offsets[0] == 0 && (int)P.out_term_offsets[P.num_outs] == P.num_terms, "wit_infer_many: plan %d: out_term_offsets must cover all terms", i);
+        for (int j = 0; j < P.num_mles; j++)
+            CHECK_ARG(ctx, P.mles[j] && P.mles[j]->num_vars == P.num_vars, "wit_infer_many: plan %d: mle %d must have %d variables", i, j, P.num_vars);
+        Lay& L = lay[(size_t)i];
+        L.n_fac = P.term_offsets[P.num_terms];
+        for (uint32_t k = 0; k < L.n_fac; k++) CHECK_ARG(ctx, (int)P.term_mle_idx[k] < P.num_mles, "wit_infer_many: plan %d: term factor %u out of range", i, P.term_mle_idx[k]);
+        L.lds = wit_infer_lds(P.num_mles, P.num_terms, (int)L.n_fac, P.num_outs);
+        L.many = L.lds <= 60 * 1024;
+        if (!L.many) continue;
+        n_many++;
+        max_lds = std::max(max_lds, L.lds);
+        L.o_slots = total;
+        total = al(total + (size_t)P.num_mles * sizeof(WiSlot));
+        L.o_coeffs = total;
+        total = al(total + (size_t)P.num_terms * sizeof(E2));
+        L.o_outs = total;
+        total = al(total + (size_t)P.num_outs * sizeof(E2*));
+        L.o_toff = total;
+        total = al(total + ((size_t)P.num_terms + 1) * 4);
+        L.o_tidx = total;
+        total = al(total + L.n_fac * 4);
+        L.o_ooff = total;
+        total = al(total + ((size_t)P.num_outs + 1) * 4);
+    }
+    // outputs
+    std::vector<ceno_hip_mle*> made;
+    auto undo = [&]() {
+        for (auto* m : made) ceno_hip_mle_free(ctx, m);
+        for (int i = 0; i < n; i++)
+            for (int o = 0; o < plans[i].num_outs; o++) plans[i].outs[o] = nullptr;
+    };
+    for (int i = 0; i < n; i++)
+        for (int o = 0; o < plans[i].num_outs; o++) plans[i].outs[o] = nullptr;
+    for (int i = 0; i < n; i++) {
+        if (!lay[(size_t)i].many) continue;
+        for (int o = 0; o < plans[i].num_outs; o++) {
+            ceno_hip_mle* m = nullptr;
+            const int rc = ceno_hip_mle_alloc(ctx, plans[i].num_vars, 1, &m);
+            if (rc) {
+                undo();
+                return rc;
+            }
+            made.push_back(m);
+            plans[i].outs[o] = m;
+        }
+    }
+    if (n_many) {
+        std::vector<WiBlk> blks;
+        void* d_blob = nullptr;
+        const size_t o_blks_guess = total;  // (block table follows the plans)
+        // block table
+        int job = 0;
+        std::vector<int> job_of((size_t)n, -1);
+        for (int i = 0; i < n; i++) {
+            if (!lay[(size_t)i].many) continue;
+            job_of[(size_t)i] = job;
+            const size_t items = ((size_t)1 << plans[i].num_vars) * (size_t)plans[i].num_outs;
+            const uint32_t nblk = (uint32_t)std::min<size_t>(std::max<size_t>((items + (size_t)NT * 2 - 1) / ((size_t)NT * 2), 1), 2048);
+            for (uint32_t b = 0; b < nblk; b++) blks.push_back(WiBlk{(uint32_t)job, b, nblk});
+            job++;
+        }
+        total = al(o_blks_guess + blks.size() * sizeof(WiBlk));
+        int rc = ctx_alloc(ctx, total, &d_blob);
+        if (rc) {
+            undo();
+            return rc;
+        }
+        std::vector<char> blob(total, 0);
+        char* d = (char*)d_blob;
+        for (int i = 0; i < n; i++) {
+            const Lay& L = lay[(size_t)i];
+            if (!L.many) continue;
+            const ceno_hip_wit_plan& P = plans[i];
+            for (int j = 0; j < P.num_mles; j++) reinterpret_cast<WiSlot*>(blob.data() + L.o_slots)[j] = WiSlot{P.mles[j]->d, P.mles[j]->is_ext, 0};
+            for (int t = 0; t < P.num_terms; t++) reinterpret_cast<E2*>(blob.data() + L.o_coeffs)[t] = E2{P.term_coeffs[2 * t], P.term_coeffs[2 * t + 1]};
+            for (int o = 0; o < P.num_outs; o++) reinterpret_cast<E2**>(blob.data() + L.o_outs)[o] = reinterpret_cast<E2*>(P.outs[o]->d);
+            memcpy(blob.data() + L.o_toff, P.term_offsets, ((size_t)P.num_terms + 1) * 4);
+            if (L.n_fac) memcpy(blob.data() + L.o_tidx, P.term_mle_idx, L.n_fac * 4);
+            memcpy(blob.data() + L.o_ooff, P.out_term_offsets, ((size_t)P.num_outs + 1) * 4);
+            WiJob& J = reinterpret_cast<WiJob*>(blob.data())[job_of[(size_t)i]];
+            J.pl.mles = reinterpret_cast<const WiSlot*>(d + L.o_slots);
+            J.pl.coeffs = reinterpret_cast<const E2*>(d + L.o_coeffs);
+            J.pl.term_off = reinterpret_cast<const uint32_t*>(d + L.o_toff);
+            J.pl.term_idx = reinterpret_cast<const uint32_t*>(d + L.o_tidx);
+            J.pl.out_term_off = reinterpret_cast<const uint32_t*>(d + L.o_ooff);
+            J.pl.outs = reinterpret_cast<E2* const*>(d + L.o_outs);
+            J.pl.num_outs = P.num_outs;
+            J.len = (size_t)1 << P.num_vars;
+            J.num_mles = P.num_mles;
+            J.num_terms = P.num_terms;
+            J.num_factors = (int)L.n_fac;
+        }
+        memcpy(blob.data() + o_blks_guess, blks.data(), blks.size() * sizeof(WiBlk));
+        // (pageable source: the runtime has captured it when hipMemcpyAsync returns)
+        hipError_t e = hipMemcpyAsync(d_blob, blob.data(), total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_wit_infer_many, dim3((unsigned)blks.size()), dim3(NT), max_lds, st, (const WiJob*)d, (const WiBlk*)(d + o_blks_guess));
+            e = hipGetLastError();
+        }
+        ctx_free(ctx, d_blob);
+        if (e != hipSuccess) {
+            undo();
+            return ctx_fail(ctx, CENO_HIP_ERR_HIP, "wit_infer_many: %s", hipGetErrorString(e));
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (lay[(size_t)i].many) continue;
+        const ceno_hip_wit_plan& P = plans[i];
+        const int rc = ceno_hip_wit_infer(ctx, P.mles, P.num_mles, P.term_coeffs, P.term_offsets, P.term_mle_idx, P.num_terms, P.out_term_offsets, P.num_outs, P.num_vars,
+                                          s, P.outs);
+        if (rc) {
+            for (int o = 0; o < P.num_outs; o++) P.outs[o] = nullptr;
+            undo();
+            return rc;
+        }
+        for (int o = 0; o < P.num_outs; o++) made.push_back(P.outs[o]);
+    }
     return 0;
 }
 

@@ -133,8 +133,8 @@ int ceno_prover_create_chip_proof(ceno_hip_ctx* ctx, const ceno_chip_task* task,
 }  // extern "C"
 
 // ---- ZKVMProver::create_chip_proof in two halves (chip_run.hpp) ----------------------------------------------------------------------------
-int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
-                     ceno_hip_stream s, ceno_chip_proof* out) {
+int chip_run_records_plan(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                          ceno_chip_proof* out, ceno_hip_wit_plan* plan) {
     if (!ctx || !task || !challenges4 || !tr || !out) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: NULL argument");
     memset(out, 0, sizeof(*out));
     run.ctx = ctx;
@@ -159,8 +159,11 @@ int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task*
     run.records.assign((size_t)n_records, nullptr);
     // structural witnesses may be absent at this stage ("they are `eq`, and will be filled later", utils.rs:690-695): the
     // record expressions never read them, so the inference runs on the tables that exist
-    std::vector<ceno_hip_mle*> present;
-    std::vector<uint32_t> remap(n_mles, UINT32_MAX), ridx;
+    std::vector<ceno_hip_mle*>& present = run.present;
+    std::vector<uint32_t>& ridx = run.ridx;
+    present.clear();
+    ridx.clear();
+    std::vector<uint32_t> remap(n_mles, UINT32_MAX);
     for (int j = 0; j < n_mles; j++)
         if (task->mles[j]) {
             remap[j] = (uint32_t)present.size();
@@ -173,8 +176,17 @@ int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task*
         if ((int)j >= n_mles || remap[j] == UINT32_MAX) return prover_set_error(CENO_HIP_ERR_INVALID, "create_chip_proof: a record expression reads an absent table");
         ridx.push_back(remap[j]);
     }
-    int rc = ceno_hip_wit_infer(ctx, present.data(), (int)present.size(), task->record_coeffs, task->record_term_offsets, ridx.data(),
-                                task->n_record_terms, task->record_out_term_offsets, n_records, num_var_with_rotation, s, run.records.data());
+    *plan = ceno_hip_wit_plan{present.data(), (int)present.size(), task->record_coeffs, task->record_term_offsets, ridx.data(), task->n_record_terms,
+                              task->record_out_term_offsets, n_records, num_var_with_rotation, run.records.data()};
+    return 0;
+}
+
+int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
+                     ceno_hip_stream s, ceno_chip_proof* out) {
+    ceno_hip_wit_plan p{};
+    if (int rc = chip_run_records_plan(run, ctx, task, challenges4, tr, out, &p)) return rc;
+    const int rc = ceno_hip_wit_infer(ctx, p.mles, p.num_mles, p.term_coeffs, p.term_offsets, p.term_mle_idx, p.num_terms, p.out_term_offsets, p.num_outs, p.num_vars,
+                                      s, p.outs);
     if (rc) return fail_ctx(ctx, rc);
     return 0;
 }

@@ -198,8 +198,8 @@ double now_ms() {
 }  // namespace
 
 // Phases A and B for all chips on one pool of `n_threads` threads (thread t drives lane stream t mod 8):
-//   A1  every chip's records (wit_infer), queued without waiting                               all threads, chips dealt round-robin
-//   A2  the towers of ALL chips in level-synchronous launches, their tops to the host in one copy      thread 0
+//   A1  every chip's checks and record plan (host work)                                         all threads, chips dealt round-robin
+//   A2  the records of ALL chips in one launch, their towers in level-synchronous launches, the tops to the host in one copy    thread 0
 //   A3  per chip: out-evaluations into its transcript, the tower prover's state, the layers the host proves    all threads
 //   B   layers host_layers + 1 .. last_layer in cohorts                                                  all threads serve
 // A chip whose status is set is skipped from then on; a failure sets the status of the chips it touches.  Returns the first error of
@@ -320,17 +320,29 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         if (trace) t_prep += now_ms() - t_in;
     };
     double t_a1 = 0, t_a2 = 0, t_a3 = 0;
+    std::vector<ceno_hip_wit_plan> plans(runs.size());
     const double t_start = now_ms();
     auto worker = [&](int t) {
         (void)ceno_hip_make_current(ctx);
         ceno_hip_stream mine = streams[(size_t)t % streams.size()];
-        // ---- A1 ----
+        // ---- A1: the checks and the record plans (host work), then ONE launch for the records of all chips ----
         for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads)
-            status[i] = chip_run_records(*runs[i], ctx, &tasks[i], challenges4, transcripts[i], mine, &out_proofs[i]);
-        (void)ceno_hip_stream_sync(ctx, mine);
+            status[i] = chip_run_records_plan(*runs[i], ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i], &plans[i]);
         bar.wait();
         // ---- A2 ----
         if (t == 0) {
+            {
+                std::vector<ceno_hip_wit_plan> live;
+                for (size_t i = 0; i < runs.size(); i++)
+                    if (!status[i]) live.push_back(plans[i]);
+                if (!live.empty())
+                    if (const int rc = ceno_hip_wit_infer_many(ctx, live.data(), (int)live.size(), stream)) {
+                        for (size_t i = 0; i < runs.size(); i++)
+                            if (!status[i]) status[i] = rc;  // (nothing is left allocated)
+                        err_msg = ceno_hip_last_error(ctx);
+                        err.store(rc);
+                    }
+            }
             t_a1 = now_ms() - t_start;
             std::vector<ceno_hip_tower_spec> specs;
             std::vector<int> first((size_t)runs.size() + 1, 0);

@@ -193,6 +193,20 @@ int ceno_hip_rotation_selector_build(ceno_hip_ctx* ctx, const uint64_t* point, i
 int ceno_hip_wit_infer(ceno_hip_ctx* ctx, ceno_hip_mle* const* mles, int num_mles, const uint64_t* term_coeffs,
                        const uint32_t* term_offsets, const uint32_t* term_mle_idx, int num_terms,
                        const uint32_t* out_term_offsets, int num_outs, int num_vars, ceno_hip_stream s, ceno_hip_mle** outs);
+/* MANY plans in one launch and one upload (the records of all chips of a shard: ceno_prover_create_chip_proofs); plan i as the arguments
+ * of ceno_hip_wit_infer, its outputs into plan i's outs[0 .. num_outs).  On failure no output is left allocated. */
+typedef struct ceno_hip_wit_plan {
+    ceno_hip_mle* const* mles;
+    int num_mles;
+    const uint64_t* term_coeffs;
+    const uint32_t* term_offsets;
+    const uint32_t* term_mle_idx;
+    int num_terms;
+    const uint32_t* out_term_offsets;
+    int num_outs, num_vars;
+    ceno_hip_mle** outs;
+} ceno_hip_wit_plan;
+int ceno_hip_wit_infer_many(ceno_hip_ctx* ctx, const ceno_hip_wit_plan* plans, int n, ceno_hip_stream s);
 
 /* ------------------------------------------------------------------------------------------------
  * generic sumcheck  (prove_generic_sumcheck_gpu / _v2, gkr_iop/src/gkr/layer/gpu/mod.rs:259-271,

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/r06
 out=gpurun_out/r06/cohort_sweep.log
 : > $out
-for L in 0 13 16 17 18; do
+for L in ${LAYER_LIST:-0 13 16 17 18}; do
   echo "== CENO_TOWER_COHORT_LAYERS=$L" >> $out
   CENO_TOWER_COHORT_LAYERS=$L LANES=8 REPS=4 timeout 300 python tools/bench_shard_wide.py 2>&1 | grep -v population | python -c "
 import sys, json
