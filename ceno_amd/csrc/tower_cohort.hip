@@ -252,7 +252,6 @@ struct ceno_hip_cohort {
     hipStream_t st = nullptr;
     int n_jobs = 0;
     std::vector<int> n, K;
-    void* d_jobs = nullptr;          // pool block: CohortJob x n_jobs
     void* d_scratch = nullptr;       // pool block: eq + ping + pong of every job
     void* d_group = nullptr;         // pool block: the groups' partial messages and arrival counters
     std::vector<int> leader;         // the job whose try_message yields the group's message
@@ -300,6 +299,7 @@ int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx) {
 }
 
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
+    CENO_TIMED("tower_cohort_begin");
     CHECK_ARG(ctx, ctx && jobs && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_begin: bad arguments");
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar)
@@ -334,11 +334,17 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         }
         if (l != j) group_size[(size_t)l]++;
     }
-    int rc = ctx_alloc(ctx, sizeof(CohortJob) * (size_t)n_jobs, &c->d_jobs);
-    if (!rc) rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
+    int rc = 0;
+    {
+        CENO_TIMED("tower_cohort_begin: scratch");
+        rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
+    }
     if (!rc) rc = ctx_alloc(ctx, (size_t)128 * n_jobs, &c->d_group);  // per job: 8 words of partial message, 8 words holding the group counter
     void *hb = nullptr, *db = nullptr;
-    if (!rc) rc = ctx_pinned_alloc(ctx, COHORT_H_WORDS * 8 * (size_t)n_jobs, &hb, &db);
+    // pinned host memory: the message / evaluation slots of every job, then the job records — the workgroups read their record straight
+    // from there (one 432-byte read each at their start: no upload, no wait before the launch)
+    const size_t jobs_off = COHORT_H_WORDS * 8 * (size_t)n_jobs;
+    if (!rc) rc = ctx_pinned_alloc(ctx, jobs_off + sizeof(CohortJob) * (size_t)n_jobs, &hb, &db);
     if (!rc) {
         std::lock_guard<std::mutex> g(g_box_mu);
         BoxArena& A = g_box[ctx];
@@ -371,7 +377,6 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         if (hb) ctx_pinned_free(ctx, hb);
         if (c->d_group) ctx_free(ctx, c->d_group);
         if (c->d_scratch) ctx_free(ctx, c->d_scratch);
-        if (c->d_jobs) ctx_free(ctx, c->d_jobs);
         delete c;
         return rc;
     }
@@ -390,11 +395,12 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     }();
     const char* e_gap = getenv("CENO_HIP_COHORT_POLL_GAP");
     const int poll_gap = e_gap ? atoi(e_gap) : 0;
-    std::vector<CohortJob> hj((size_t)n_jobs);
+    CENO_TIMED("tower_cohort_begin: job records");
+    CohortJob* hj = reinterpret_cast<CohortJob*>((char*)hb + jobs_off);
     E2* sp = (E2*)c->d_scratch;
     for (int j = 0; j < n_jobs; j++) {
         const ceno_hip_cohort_job& G = jobs[j];
-        CohortJob& J = hj[(size_t)j];
+        CohortJob& J = hj[j];
         memset(&J, 0, sizeof(J));
         const int K = c->K[(size_t)j];
         const size_t len = (size_t)1 << G.n;
@@ -426,17 +432,18 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         J.nl = G.n_logup;
         J.poll_ticks = ticks;
         J.pad_ = poll_gap;
-        // the mailbox line: no challenge yet
-        volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
-        mb->chal_seq = 0;
-        mb->abort = 0;
+        // the mailbox line: no challenge yet (a write through the BAR each: only the lines that are read — the leaders')
+        if (leader == j) {
+            volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
+            mb->chal_seq = 0;
+            mb->abort = 0;
+        }
     }
     host_fence();
+    CENO_TIMED("tower_cohort_begin: launch");
     hipError_t e = hipMemsetAsync(c->d_group, 0, (size_t)128 * n_jobs, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(c->d_jobs, hj.data(), sizeof(CohortJob) * (size_t)n_jobs, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the host vector goes away; the launch below is asynchronous)
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)n_jobs), dim3(CNT), 0, st, (const CohortJob*)c->d_jobs);
+        hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)n_jobs), dim3(CNT), 0, st, reinterpret_cast<const CohortJob*>((char*)db + jobs_off));
         e = hipGetLastError();
     }
     if (e != hipSuccess) {
@@ -444,7 +451,6 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
         ctx_pinned_free(ctx, hb);
         ctx_free(ctx, c->d_group);
         ctx_free(ctx, c->d_scratch);
-        ctx_free(ctx, c->d_jobs);
         delete c;
         return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
     }
@@ -515,7 +521,6 @@ int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
     ctx_pinned_free(ctx, c->h_area);
     ctx_free_on(ctx, c->d_group, c->st);
     ctx_free_on(ctx, c->d_scratch, c->st);
-    ctx_free_on(ctx, c->d_jobs, c->st);
     delete c;
     if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
     return 0;

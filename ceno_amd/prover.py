@@ -6,6 +6,7 @@ CpuTowerProver::create_proof, `prove_tower_relation` = TowerProver::prove_tower_
 from __future__ import annotations
 
 import ctypes as C
+import time
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -1105,7 +1106,9 @@ def create_chip_proofs(dev: Device, tasks, challenges, transcripts: Sequence[Tra
     trs = (C.c_void_p * ct.n)(*[t.h for t in transcripts])
     outs = (ChipProofC * ct.n)()
     status = (C.c_int * ct.n)()
+    t0 = time.perf_counter()
     rc = L.ceno_prover_create_chip_proofs(dev.h, ct.arr, ct.n, _p(ch), trs, lanes, outs, status)
+    create_chip_proofs.last_native_ms = (time.perf_counter() - t0) * 1e3   # (the C call alone: what remains is this wrapper's marshalling)
     try:
         _check(rc)
         return [ChipProof(outs[i]) for i in range(ct.n)]

@@ -657,6 +657,7 @@ class ShardFlowWide:
         dev.L.ceno_hip_mem_peak(dev.h, 1)
         dev.L.ceno_hip_mem_booked_peak(dev.h, 1)
         _, res["chip_proofs_ms"] = timed(chip_proofs)
+        res["chip_proofs_native_ms"] = float(getattr(prover.create_chip_proofs, "last_native_ms", 0.0))   # the C++ call inside it
         res["chip_proofs_pool_high_water_bytes"] = int(dev.L.ceno_hip_mem_peak(dev.h, 0)) - int(base_used)
         res["chip_proofs_booked_high_water_bytes"] = int(dev.L.ceno_hip_mem_booked_peak(dev.h, 0))
         jobs, plans = [], []

@@ -6,7 +6,7 @@ most of the time and wrong under load.  tests/test_isa_lint.py guards the cause;
 (commit_traces), the Basefold fold / commit rounds + query gathers (batch open), on-device witness generation with the per-XCD lookup counters —
 each repeated while a second host thread keeps the device busy with large sumchecks on another stream.  Every repetition must produce the words of
 the first (and the first is checked against the oracle elsewhere: tests/test_gpu_parity.py, test_gpu_flows.py, test_gpu_commit.py,
-test_gpu_basefold.py, test_gpu_shard_wide.py)."""
+test_gpu_basefold.py, test_gpu_shard_wide.py).  The last test repeats the wide shard's whole flow with the chip proofs in cohorts."""
 import threading
 
 import numpy as np
@@ -184,4 +184,25 @@ def test_shard_witness_generation_is_the_same_in_every_run(dev, prover):
 
     with Load(dev, prover):
         _repeat(60, once)
+    flow.close()
+
+
+def test_chip_proofs_in_cohorts_are_the_same_in_every_run(dev, prover):
+    """the whole wide-shard flow with the middle tower layers of all 54 chips proved in cohorts (host/cohort.cpp: records and towers of all chips
+    in shared launches, one cohort launch per layer with the sub-cubes' messages added up by whichever workgroup arrives last, sixteen host
+    threads answering) — every chip proof, fork sample, main-constraint message and opening word, every time"""
+    from ceno_amd import synthetic
+
+    flow = synthetic.ShardFlowWide(dev, prover, log_cycles=13, n_queries=8, pow_bits=4)
+
+    def once():
+        flow.run(lambda: prover.Transcript.stub(0x5A), lambda: prover.Transcript.stub(0xF0), lanes=8)
+        a = flow.artifacts
+        out = ([(p.tower_msgs.copy(), p.tower_point.copy(), p.tower_logup_evals.copy()) for p in a["chip_proofs"]], a["fork_samples"], a["msgs"].copy(),
+               a["evals"].copy(), a["open_proof"].copy())
+        flow.free_last()
+        return out
+
+    with Load(dev, prover):
+        _repeat(40, once)
     flow.close()
