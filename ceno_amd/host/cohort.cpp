@@ -29,6 +29,7 @@
 #include "../../include/ceno_prover.h"
 #include "../csrc/gl64.hpp"
 #include "chip_run.hpp"
+#include "worker_pool.hpp"
 
 using gl::E2;
 
@@ -322,9 +323,12 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     double t_a1 = 0, t_a2 = 0, t_a3 = 0;
     std::vector<ceno_hip_wit_plan> plans(runs.size());
     const double t_start = now_ms();
+    std::vector<double> t_started((size_t)n_threads, 0.0);
     auto worker = [&](int t) {
+        if (trace) t_started[(size_t)t] = now_ms() - t_start;
         (void)ceno_hip_make_current(ctx);
         ceno_hip_stream mine = streams[(size_t)t % streams.size()];
+        (void)ceno_hip_stream_bind(ctx, mine);  // (a pool thread may remember a stream of an earlier run)
         // ---- A1: the checks and the record plans (host work), then ONE launch for the records of all chips ----
         for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads)
             status[i] = chip_run_records_plan(*runs[i], ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i], &plans[i]);
@@ -473,10 +477,8 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             if (err.load()) return;
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; t++) th.emplace_back(worker, t);
-    worker(0);
-    for (auto& x : th) x.join();
+    WorkerPool::instance().run(n_threads, worker);
+    if (trace) fprintf(stderr, "[ceno_prover] cohort: the last of %d threads started %.3f ms in\n", n_threads, *std::max_element(t_started.begin(), t_started.end()));
     if (trace) fprintf(stderr, "[ceno_prover] cohort: thread 0 spent %.3f ms building launches, %.3f ms closing them\n", t_prep, t_end);
     if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: records %.3f ms, towers of all chips %.3f, to the cohort layers %.3f, cohort layers to %d %.3f\n", t_a1,
                        t_a2 - t_a1, t_a3 - t_a2, last_layer, now_ms() - t_start - t_a3);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/ceno_prover.h"
+#include "worker_pool.hpp"
 
 int prover_set_error(int code, const char* msg);  // prover.cpp
 
@@ -136,9 +137,7 @@ static int lanes_run_locked(ceno_hip_ctx* ctx, int n_lanes, const ceno_lane_task
             cv.notify_all();
         }
     };
-    std::vector<std::thread> th;
-    for (int l = 0; l < n_lanes; l++) th.emplace_back(worker, l);
-    for (auto& t : th) t.join();
+    WorkerPool::instance().run(n_lanes, worker);  // (threads kept between runs: starting eight costs ~0.2 ms)
     return first_err ? prover_set_error(first_err, "lanes_run: a task failed (see the per-task status)") : 0;
 }
 
