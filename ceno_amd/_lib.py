@@ -162,6 +162,9 @@ def lib():
         "ceno_hip_tower_cohort_max_vars": (i, []),
         "ceno_hip_tower_cohort_capacity": (i, [vp]),
         "ceno_hip_tower_cohort_begin": (i, [vp, vp, i, vp, vpp]),
+        "ceno_hip_tower_cohort_open": (i, [vp, vp, i, vp, vpp]),
+        "ceno_hip_tower_cohort_set_job": (i, [vp, i, vp]),
+        "ceno_hip_tower_cohort_launch": (i, [vp, vp]),
         "ceno_hip_tower_cohort_try_message": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_send_challenge": (i, [vp, i, i, u64p]),
         "ceno_hip_tower_cohort_try_final": (i, [vp, i, u64p]),

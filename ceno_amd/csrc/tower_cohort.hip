@@ -255,6 +255,10 @@ struct ceno_hip_cohort {
     void* d_scratch = nullptr;       // pool block: eq + ping + pong of every job
     void* d_group = nullptr;         // pool block: the groups' partial messages and arrival counters
     std::vector<int> leader;         // the job whose try_message yields the group's message
+    std::vector<int> np, nl, group_size;
+    std::vector<size_t> scratch_off; // a job's scratch inside d_scratch (extension elements)
+    size_t jobs_off = 0;             // the job records inside the pinned block (bytes)
+    bool launched = false;
     uint64_t* h_area = nullptr;      // pinned: per job [COHORT_SUB rounds x 8 words][16 x 2 words of evaluations]
     uint64_t* d_area = nullptr;      // its device view
     Mailbox* boxes = nullptr;        // device memory the host writes (large BAR): one 64-byte line per job
@@ -298,9 +302,11 @@ int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx) {
     return cap[ctx->device] = std::max(0, per_cu) * std::max(0, cus);
 }
 
-int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
-    CENO_TIMED("tower_cohort_begin");
-    CHECK_ARG(ctx, ctx && jobs && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_begin: bad arguments");
+// begin in three steps, so that the job records — the bulk of the work for a launch of ~1000 jobs — can be written by several host threads:
+// open (shapes and groups: allocations, the scratch layout), set_job (one job's record; any thread, distinct jobs concurrently), launch
+int ceno_hip_tower_cohort_open(ceno_hip_ctx* ctx, const ceno_hip_cohort_shape* shapes, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
+    CENO_TIMED("tower_cohort_open");
+    CHECK_ARG(ctx, ctx && shapes && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_open: bad arguments");
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar)
         return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "tower cohort: the challenge mailboxes need host-writable device memory (large BAR)");
@@ -309,42 +315,45 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     c->ctx = ctx;
     c->st = st;
     c->n_jobs = n_jobs;
+    c->n.resize((size_t)n_jobs);
+    c->K.resize((size_t)n_jobs);
+    c->leader.resize((size_t)n_jobs);
+    c->np.resize((size_t)n_jobs);
+    c->nl.resize((size_t)n_jobs);
+    c->scratch_off.resize((size_t)n_jobs);
+    c->group_size.assign((size_t)n_jobs, 1);
     size_t scratch_e2 = 0;
     for (int j = 0; j < n_jobs; j++) {
-        const ceno_hip_cohort_job& G = jobs[j];
+        const ceno_hip_cohort_shape& G = shapes[j];
         const int K = 1 + 2 * G.n_prod + 4 * G.n_logup;
-        if (G.share_mailbox_of < 0 || G.share_mailbox_of > n_jobs || G.n < 1 || G.n > COHORT_SUB || G.n_prod < 0 || G.n_prod > 3 || G.n_logup < 0 || G.n_logup > 2 || K < 3 || !G.rt || !G.tables) {
+        if (G.share_mailbox_of < 0 || G.share_mailbox_of > n_jobs || G.n < 1 || G.n > COHORT_SUB || G.n_prod < 0 || G.n_prod > 3 || G.n_logup < 0 || G.n_logup > 2 || K < 3) {
             delete c;
             return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: 1 .. %d variables, <= 3 product and <= 2 LogUp towers, at least one", j, COHORT_SUB);
         }
-        c->n.push_back(G.n);
-        c->K.push_back(K);
-        c->leader.push_back(G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j);
-        const size_t len = (size_t)1 << G.n;
-        scratch_e2 += len + (size_t)K * (len / 2) + (size_t)K * std::max<size_t>(len / 4, 1);
-    }
-    // groups: consecutive jobs naming the same leader, the leader first
-    std::vector<int> group_size((size_t)n_jobs, 1);
-    for (int j = 0; j < n_jobs; j++) {
-        const int l = jobs[j].share_mailbox_of > 0 ? jobs[j].share_mailbox_of - 1 : j;
-        const bool ok = l <= j && (l == j || (jobs[l].share_mailbox_of == l + 1 && jobs[j - 1].share_mailbox_of == l + 1 && jobs[j].n == jobs[l].n));
+        // groups: consecutive jobs naming the same leader, the leader first
+        const int l = G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j;
+        const bool ok = l <= j && (l == j || (shapes[l].share_mailbox_of == l + 1 && shapes[j - 1].share_mailbox_of == l + 1 && G.n == shapes[l].n));
         if (!ok) {
             delete c;
             return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: a group is consecutive jobs of one size naming their first job", j);
         }
-        if (l != j) group_size[(size_t)l]++;
+        if (l != j) c->group_size[(size_t)l]++;
+        c->n[(size_t)j] = G.n;
+        c->K[(size_t)j] = K;
+        c->np[(size_t)j] = G.n_prod;
+        c->nl[(size_t)j] = G.n_logup;
+        c->leader[(size_t)j] = l;
+        c->scratch_off[(size_t)j] = scratch_e2;
+        const size_t len = (size_t)1 << G.n;
+        scratch_e2 += len + (size_t)K * (len / 2) + (size_t)K * std::max<size_t>(len / 4, 1);
     }
-    int rc = 0;
-    {
-        CENO_TIMED("tower_cohort_begin: scratch");
-        rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
-    }
+    int rc = ctx_alloc(ctx, scratch_e2 * sizeof(E2), &c->d_scratch);
     if (!rc) rc = ctx_alloc(ctx, (size_t)128 * n_jobs, &c->d_group);  // per job: 8 words of partial message, 8 words holding the group counter
     void *hb = nullptr, *db = nullptr;
     // pinned host memory: the message / evaluation slots of every job, then the job records — the workgroups read their record straight
     // from there (one 432-byte read each at their start: no upload, no wait before the launch)
-    const size_t jobs_off = COHORT_H_WORDS * 8 * (size_t)n_jobs;
-    if (!rc) rc = ctx_pinned_alloc(ctx, jobs_off + sizeof(CohortJob) * (size_t)n_jobs, &hb, &db);
+    c->jobs_off = COHORT_H_WORDS * 8 * (size_t)n_jobs;
+    if (!rc) rc = ctx_pinned_alloc(ctx, c->jobs_off + sizeof(CohortJob) * (size_t)n_jobs, &hb, &db);
     if (!rc) {
         std::lock_guard<std::mutex> g(g_box_mu);
         BoxArena& A = g_box[ctx];
@@ -365,15 +374,7 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
             c->own_boxes = true;
         }
     }
-    auto release_boxes = [&]() {
-        if (!c->own_boxes) return;
-        std::lock_guard<std::mutex> g(g_box_mu);
-        BoxArena& A = g_box[ctx];
-        if (--A.live == 0) A.next = 0;
-        c->own_boxes = false;
-    };
     if (rc) {
-        release_boxes();
         if (hb) ctx_pinned_free(ctx, hb);
         if (c->d_group) ctx_free(ctx, c->d_group);
         if (c->d_scratch) ctx_free(ctx, c->d_scratch);
@@ -382,77 +383,114 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     }
     c->h_area = (uint64_t*)hb;
     c->d_area = (uint64_t*)db;
-    for (int j = 0; j < n_jobs; j++) {  // (only the words a job's device side writes: a leader's messages, every job's evaluations)
-        uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)j;
-        if (c->leader[(size_t)j] == j)
-            for (int i = 0; i < 8 * c->n[(size_t)j]; i++) w[i] = MSG_INVALID;
-        for (int i = 0; i < 2 * c->K[(size_t)j]; i++) w[8 * COHORT_SUB + i] = MSG_INVALID;
-    }
+    *out = c;
+    return 0;
+}
+
+int ceno_hip_tower_cohort_set_job(ceno_hip_cohort* c, int j, const ceno_hip_cohort_job* job) {
+    if (!c || !job || j < 0 || j >= c->n_jobs || c->launched) return CENO_HIP_ERR_INVALID;
+    const ceno_hip_cohort_job& G = *job;
+    const int K = c->K[(size_t)j], leader = c->leader[(size_t)j];
+    if (G.n != c->n[(size_t)j] || G.n_prod != c->np[(size_t)j] || G.n_logup != c->nl[(size_t)j] || !G.rt || !G.tables ||
+        (G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j) != leader || (G.n_prod && !G.alpha_prod) || (G.n_logup && (!G.alpha_num || !G.alpha_den)))
+        return CENO_HIP_ERR_INVALID;
     static const unsigned long long ticks = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         const double sec = e && atof(e) > 0 ? atof(e) : 60.0;
         return (unsigned long long)(sec * 1e8);
     }();
-    const char* e_gap = getenv("CENO_HIP_COHORT_POLL_GAP");
-    const int poll_gap = e_gap ? atoi(e_gap) : 0;
-    CENO_TIMED("tower_cohort_begin: job records");
-    CohortJob* hj = reinterpret_cast<CohortJob*>((char*)hb + jobs_off);
-    E2* sp = (E2*)c->d_scratch;
-    for (int j = 0; j < n_jobs; j++) {
-        const ceno_hip_cohort_job& G = jobs[j];
-        CohortJob& J = hj[j];
-        memset(&J, 0, sizeof(J));
-        const int K = c->K[(size_t)j];
-        const size_t len = (size_t)1 << G.n;
-        for (int m = 0; m < K - 1; m++) J.in[m] = reinterpret_cast<const E2*>(G.tables[m]);
-        J.eq = sp;
-        sp += len;
-        J.ping = sp;
-        sp += (size_t)K * (len / 2);
-        J.pong = sp;
-        sp += (size_t)K * std::max<size_t>(len / 4, 1);
-        // a group (share_mailbox_of = leader + 1 on every member, the leader first): one mailbox, one message slot, one counter
-        const int leader = G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j;
-        J.h_msg = c->d_area + COHORT_H_WORDS * (size_t)leader;
-        J.h_fin = c->d_area + COHORT_H_WORDS * (size_t)j + 8 * COHORT_SUB;
-        J.box = c->boxes + 2 * (size_t)leader;  // (Mailbox is 32 bytes: every job gets a 64-byte line of its own)
-        J.G = group_size[(size_t)leader];
-        J.g = j - leader;
-        J.scale = G.scale ? E2{G.scale[0], G.scale[1]} : e2_one();
-        J.part = (uint64_t*)c->d_group + 8 * (size_t)leader;
-        J.counter = (unsigned*)((uint64_t*)c->d_group + 8 * (size_t)n_jobs + 8 * (size_t)leader);
-        for (int v = 0; v < G.n; v++) J.rt[v] = E2{G.rt[2 * v], G.rt[2 * v + 1]};
-        for (int t = 0; t < G.n_prod; t++) J.a_prod[t] = E2{G.alpha_prod[2 * t], G.alpha_prod[2 * t + 1]};
-        for (int t = 0; t < G.n_logup; t++) {
-            J.a_num[t] = E2{G.alpha_num[2 * t], G.alpha_num[2 * t + 1]};
-            J.a_den[t] = E2{G.alpha_den[2 * t], G.alpha_den[2 * t + 1]};
-        }
-        J.n = G.n;
-        J.np = G.n_prod;
-        J.nl = G.n_logup;
-        J.poll_ticks = ticks;
-        J.pad_ = poll_gap;
-        // the mailbox line: no challenge yet (a write through the BAR each: only the lines that are read — the leaders')
-        if (leader == j) {
-            volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
-            mb->chal_seq = 0;
-            mb->abort = 0;
-        }
+    static const int poll_gap = [] {
+        const char* e = getenv("CENO_HIP_COHORT_POLL_GAP");
+        return e ? atoi(e) : 0;
+    }();
+    {   // the words the device side writes: a leader's messages, every job's evaluations
+        uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)j;
+        if (leader == j)
+            for (int i = 0; i < 8 * G.n; i++) w[i] = MSG_INVALID;
+        for (int i = 0; i < 2 * K; i++) w[8 * COHORT_SUB + i] = MSG_INVALID;
     }
+    CohortJob& J = reinterpret_cast<CohortJob*>((char*)c->h_area + c->jobs_off)[j];
+    memset(&J, 0, sizeof(J));
+    const size_t len = (size_t)1 << G.n;
+    for (int m = 0; m < K - 1; m++) J.in[m] = reinterpret_cast<const E2*>(G.tables[m]);
+    E2* sp = (E2*)c->d_scratch + c->scratch_off[(size_t)j];
+    J.eq = sp;
+    sp += len;
+    J.ping = sp;
+    sp += (size_t)K * (len / 2);
+    J.pong = sp;
+    // a group (share_mailbox_of = leader + 1 on every member, the leader first): one mailbox, one message slot, one counter
+    J.h_msg = c->d_area + COHORT_H_WORDS * (size_t)leader;
+    J.h_fin = c->d_area + COHORT_H_WORDS * (size_t)j + 8 * COHORT_SUB;
+    J.box = c->boxes + 2 * (size_t)leader;  // (Mailbox is 32 bytes: every job gets a 64-byte line of its own)
+    J.G = c->group_size[(size_t)leader];
+    J.g = j - leader;
+    J.scale = G.scale ? E2{G.scale[0], G.scale[1]} : e2_one();
+    J.part = (uint64_t*)c->d_group + 8 * (size_t)leader;
+    J.counter = (unsigned*)((uint64_t*)c->d_group + 8 * (size_t)c->n_jobs + 8 * (size_t)leader);
+    for (int v = 0; v < G.n; v++) J.rt[v] = E2{G.rt[2 * v], G.rt[2 * v + 1]};
+    for (int t = 0; t < G.n_prod; t++) J.a_prod[t] = E2{G.alpha_prod[2 * t], G.alpha_prod[2 * t + 1]};
+    for (int t = 0; t < G.n_logup; t++) {
+        J.a_num[t] = E2{G.alpha_num[2 * t], G.alpha_num[2 * t + 1]};
+        J.a_den[t] = E2{G.alpha_den[2 * t], G.alpha_den[2 * t + 1]};
+    }
+    J.n = G.n;
+    J.np = G.n_prod;
+    J.nl = G.n_logup;
+    J.poll_ticks = ticks;
+    J.pad_ = poll_gap;
+    // the mailbox line: no challenge yet (a write through the BAR each: only the lines that are read — the leaders')
+    if (leader == j) {
+        volatile Mailbox* mb = c->boxes + 2 * (size_t)j;
+        mb->chal_seq = 0;
+        mb->abort = 0;
+    }
+    return 0;
+}
+
+static void cohort_release(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
+    if (c->own_boxes) {
+        std::lock_guard<std::mutex> g(g_box_mu);
+        BoxArena& A = g_box[ctx];
+        if (--A.live == 0) A.next = 0;
+        c->own_boxes = false;
+    }
+    ctx_pinned_free(ctx, c->h_area);
+    ctx_free_on(ctx, c->d_group, c->st);
+    ctx_free_on(ctx, c->d_scratch, c->st);
+    delete c;
+}
+
+int ceno_hip_tower_cohort_launch(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
+    CENO_TIMED("tower_cohort_launch");
+    CHECK_ARG(ctx, ctx && c && !c->launched, "tower_cohort_launch: bad arguments");
     host_fence();
-    CENO_TIMED("tower_cohort_begin: launch");
-    hipError_t e = hipMemsetAsync(c->d_group, 0, (size_t)128 * n_jobs, st);
+    hipError_t e = hipMemsetAsync(c->d_group, 0, (size_t)128 * c->n_jobs, c->st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)n_jobs), dim3(CNT), 0, st, reinterpret_cast<const CohortJob*>((char*)db + jobs_off));
+        hipLaunchKernelGGL(k_tower_cohort, dim3((unsigned)c->n_jobs), dim3(CNT), 0, c->st, reinterpret_cast<const CohortJob*>((char*)c->d_area + c->jobs_off));
         e = hipGetLastError();
     }
-    if (e != hipSuccess) {
-        release_boxes();
-        ctx_pinned_free(ctx, hb);
-        ctx_free(ctx, c->d_group);
-        ctx_free(ctx, c->d_scratch);
-        delete c;
-        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
+    c->launched = true;
+    return 0;
+}
+
+int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out) {
+    CENO_TIMED("tower_cohort_begin");
+    CHECK_ARG(ctx, ctx && jobs && out && n_jobs >= 1 && n_jobs <= 4096, "tower_cohort_begin: bad arguments");
+    std::vector<ceno_hip_cohort_shape> shapes((size_t)n_jobs);
+    for (int j = 0; j < n_jobs; j++) shapes[(size_t)j] = ceno_hip_cohort_shape{jobs[j].n_prod, jobs[j].n_logup, jobs[j].n, jobs[j].share_mailbox_of};
+    ceno_hip_cohort* c = nullptr;
+    TRY(ceno_hip_tower_cohort_open(ctx, shapes.data(), n_jobs, s, &c));
+    for (int j = 0; j < n_jobs; j++)
+        if (ceno_hip_tower_cohort_set_job(c, j, &jobs[j])) {
+            cohort_release(ctx, c);
+            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: NULL tables / point / alpha powers", j);
+        }
+    const int rc = ceno_hip_tower_cohort_launch(ctx, c);
+    if (rc) {
+        cohort_release(ctx, c);
+        return rc;
     }
     *out = c;
     return 0;
@@ -512,16 +550,8 @@ int ceno_hip_tower_cohort_abort(ceno_hip_cohort* c) {
 
 int ceno_hip_tower_cohort_end(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
     if (!c) return 0;
-    const hipError_t e = hipStreamSynchronize(c->st);  // every workgroup has left (all challenges answered, or aborted)
-    if (c->own_boxes) {
-        std::lock_guard<std::mutex> g(g_box_mu);
-        BoxArena& A = g_box[ctx];
-        if (--A.live == 0) A.next = 0;
-    }
-    ctx_pinned_free(ctx, c->h_area);
-    ctx_free_on(ctx, c->d_group, c->st);
-    ctx_free_on(ctx, c->d_scratch, c->st);
-    delete c;
+    const hipError_t e = c->launched ? hipStreamSynchronize(c->st) : hipSuccess;  // every workgroup has left (all challenges answered, or aborted)
+    cohort_release(ctx, c);
     if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower cohort: %s", hipGetErrorString(e));
     return 0;
 }

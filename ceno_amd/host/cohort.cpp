@@ -284,41 +284,55 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             }
             if (i >= runs.size()) layer_now = 0;  // the layer is complete with this launch
             n_jobs_planned = jobs;
-            return true;
-        }
-    };
-    auto begin_launch = [&]() {
-        const double t_in = trace ? now_ms() : 0;
-        {
-            const int jobs = n_jobs_planned;
-            std::vector<ceno_hip_cohort_job> hj((size_t)jobs);
-            for (auto& c : chips)
-                for (int g = 0; g < c.G; g++) {
-                    ceno_hip_cohort_job& J = hj[(size_t)(c.first_job + g)];
-                    J.tables = c.tables.data() + (size_t)g * (size_t)(c.K - 1);
-                    J.n_prod = c.np_act;
-                    J.n_logup = c.nl_act;
-                    J.n = c.n_lo;
-                    J.rt = c.run->st.out_rt.data();
-                    J.alpha_prod = c.a_prod.data();
-                    J.alpha_num = c.a_num.data();
-                    J.alpha_den = c.a_den.data();
-                    // the sub-cubes of a layer are a group: one mailbox, one message per round (added up on the device, scaled by eq_hi)
-                    J.share_mailbox_of = c.G > 1 ? c.first_job + 1 : 0;
-                    J.scale = reinterpret_cast<const uint64_t*>(&c.eq_hi[(size_t)g]);
-                }
-            const double t0 = trace ? now_ms() : 0;
-            const int rc = ceno_hip_tower_cohort_begin(ctx, hj.data(), jobs, stream, &co);
-            if (rc) {
+            // the shapes (which towers still have this layer) and the allocations; the job records are written by the serving threads
+            std::vector<ceno_hip_cohort_shape> shapes((size_t)jobs);
+            for (auto& c : chips) {
+                const TowerProveState& st = c.run->st;
+                int np = 0, nl = 0;
+                for (int k = 0; k < st.n_prod; k++) np += st.nv_of(st.prod[k]) > c.L;
+                for (int k = 0; k < st.n_logup; k++) nl += st.nv_of(st.logup[k]) > c.L;
+                const int G = 1 << (c.L - c.n_lo);
+                for (int g = 0; g < G; g++) shapes[(size_t)(c.first_job + g)] = ceno_hip_cohort_shape{np, nl, c.n_lo, G > 1 ? c.first_job + 1 : 0};
+            }
+            if (const int rc = ceno_hip_tower_cohort_open(ctx, shapes.data(), jobs, stream, &co)) {
                 err_msg = ceno_hip_last_error(ctx);
                 err.store(rc);
                 co = nullptr;
+                return false;
             }
-            if (trace)
-                fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs of 2^%d (the device holds %d), launch %.3f ms\n", chips[0].L, chips.size(), jobs,
-                        chips[0].n_lo, capacity, now_ms() - t0);
+            return true;
         }
-        if (trace) t_prep += now_ms() - t_in;
+    };
+    // a chip's job records (its serving thread: the bulk of a launch's set-up, in parallel)
+    auto set_jobs = [&](LayerChip& c) -> int {
+        for (int g = 0; g < c.G; g++) {
+            ceno_hip_cohort_job J{};
+            J.tables = c.tables.data() + (size_t)g * (size_t)(c.K - 1);
+            J.n_prod = c.np_act;
+            J.n_logup = c.nl_act;
+            J.n = c.n_lo;
+            J.rt = c.run->st.out_rt.data();
+            J.alpha_prod = c.a_prod.data();
+            J.alpha_num = c.a_num.data();
+            J.alpha_den = c.a_den.data();
+            // the sub-cubes of a layer are a group: one mailbox, one message per round (added up on the device, scaled by eq_hi)
+            J.share_mailbox_of = c.G > 1 ? c.first_job + 1 : 0;
+            J.scale = reinterpret_cast<const uint64_t*>(&c.eq_hi[(size_t)g]);
+            if (const int rc = ceno_hip_tower_cohort_set_job(co, c.first_job + g, &J)) return rc;
+        }
+        return 0;
+    };
+    auto begin_launch = [&]() {
+        const double t_in = trace ? now_ms() : 0;
+        if (const int rc = ceno_hip_tower_cohort_launch(ctx, co)) {
+            err_msg = ceno_hip_last_error(ctx);
+            err.store(rc);
+        }
+        if (trace) {
+            fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs of 2^%d (the device holds %d), launch %.3f ms\n", chips[0].L, chips.size(), n_jobs_planned,
+                    chips[0].n_lo, capacity, now_ms() - t_in);
+            t_prep += now_ms() - t_in;
+        }
     };
     double t_a1 = 0, t_a2 = 0, t_a3 = 0;
     std::vector<ceno_hip_wit_plan> plans(runs.size());
@@ -402,11 +416,24 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             if (t == 0) more.store(next_launch());
             bar.wait();
             if (!more.load()) return;
-            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) prepare(chips[i], chips[i].run, chips[i].L, chips[i].n_lo);
+            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) {
+                prepare(chips[i], chips[i].run, chips[i].L, chips[i].n_lo);
+                if (const int rc = set_jobs(chips[i])) {
+                    int zero = 0;
+                    if (err.compare_exchange_strong(zero, rc)) err_msg = "cohort: a job record was refused";
+                }
+            }
             bar.wait();
-            if (t == 0) begin_launch();
+            if (t == 0 && !err.load()) begin_launch();
             bar.wait();
-            if (err.load()) return;
+            if (err.load()) {
+                if (t == 0 && co) {  // (opened, perhaps launched: release every waiting workgroup, then the cohort)
+                    (void)ceno_hip_tower_cohort_abort(co);
+                    (void)ceno_hip_tower_cohort_end(ctx, co);
+                    co = nullptr;
+                }
+                return;
+            }
             const double t_begin = now_ms();
             size_t open = 0;
             for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) open++;

@@ -437,6 +437,15 @@ int ceno_hip_tower_cohort_max_vars(void);
 /* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host */
 int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx);
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
+/* begin in three steps, for callers with several host threads (a launch of ~1000 jobs: the job records are most of begin's time):
+ * open — the jobs' shapes and groups (allocations, layout); set_job — one job's record, callable from any thread, distinct jobs
+ * concurrently (the shape must be the one given to open); launch.  end releases a cohort whether it was launched or not. */
+typedef struct ceno_hip_cohort_shape {
+    int n_prod, n_logup, n, share_mailbox_of;
+} ceno_hip_cohort_shape;
+int ceno_hip_tower_cohort_open(ceno_hip_ctx* ctx, const ceno_hip_cohort_shape* shapes, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
+int ceno_hip_tower_cohort_set_job(ceno_hip_cohort* c, int job, const ceno_hip_cohort_job* record);
+int ceno_hip_tower_cohort_launch(ceno_hip_ctx* ctx, ceno_hip_cohort* c);
 int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6);
 int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2);
 /* diagnostics, valid once try_message(job, round) returned 1: out2 = the device's 100 MHz clock when the job saw the challenge that opened
