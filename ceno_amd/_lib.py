@@ -122,6 +122,7 @@ def lib():
         "ceno_hip_tower_layer_ptr": (vp, [vp, i, i]),
         "ceno_hip_tower_build_many": (i, [vp, vp, i, vp, vpp]),
         "ceno_hip_wit_infer_many": (i, [vp, vp, i, vp]),
+        "ceno_hip_tower_build_many_virtual": (i, [vp, vp, i, vp, i, vp, vpp]),
         "ceno_hip_tower_out_evals": (i, [vp, vp, u64p, vp]),
         "ceno_hip_tower_download_top": (i, [vp, vp, i, u64p, vp]),
         "ceno_hip_tower_top_layers": (i, [vp]),

@@ -8,8 +8,10 @@
 // layer l is computed from the s-th half of the limbs of layer l+1.  All kernels are element-wise
 // streams: 48 B of traffic per product -> HBM bound.
 #include "common.hpp"
+#include "witinfer_dev.hpp"
 
 #include <algorithm>
+#include <functional>
 
 using namespace gl;
 
@@ -213,6 +215,36 @@ __global__ void __launch_bounds__(NT) k_interleave_many(const IlvJob* __restrict
         (limb ? out1 : out0)[x] = v;
     }
 }
+// the last layer of a tower straight from the record EXPRESSIONS (the reference's build_prod_tower_from_virtual_ext_batch /
+// build_logup_tower_from_virtual_ext_batch, ceno_zkvm/src/scheme/gpu/mod.rs:2365-2402): out[limb][i * S + j] = record (rec0 + j) of the plan at
+// row limb * half + i — what k_wit_infer writes into a record table and k_interleave copies from it, without the table.  Records of a chip
+// proof have one row per slot of the padded trace (num_instances = 2^num_vars: every limb is full, no default inside a record's range).
+struct VtJob {
+    WiPlan pl;
+    int num_mles, num_terms, num_factors;
+    int log_s, k, rec0, ones;
+    int pad_plan, pad_;  // (host: which plan the job's pointers go to)
+    size_t half, out_len;
+    E2 dflt;
+    E2 *out0, *out1;
+};
+__global__ void __launch_bounds__(NT) k_virtual_last_layer(const VtJob* __restrict__ jobs, const BlkRef* __restrict__ blks) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const BlkRef b = blks[blockIdx.x];
+    const VtJob J = jobs[b.job];
+    WiLds L{};
+    if (!J.ones) L = wi_stage<NT>(dyn, J.pl, J.num_mles, J.num_terms, J.num_factors, false);
+    const size_t out_len = J.out_len, stride = (size_t)b.nblk * NT, smask = ((size_t)1 << J.log_s) - 1;
+    for (size_t o = (size_t)b.blk * NT + threadIdx.x; o < 2 * out_len; o += stride) {
+        const int limb = o >= out_len;
+        const size_t x = limb ? o - out_len : o;
+        const size_t i = x >> J.log_s;
+        const int j = (int)(x & smask);
+        E2 v = J.dflt;
+        if (!J.ones && j < J.k) v = wi_eval(L, J.rec0 + j, (limb ? J.half : 0) + i);
+        (limb ? J.out1 : J.out0)[x] = v;
+    }
+}
 __global__ void __launch_bounds__(NT) k_layer_many(const LayerJob* __restrict__ jobs, const BlkRef* __restrict__ blks) {
     const BlkRef b = blks[blockIdx.x];
     const LayerJob J = jobs[b.job];
@@ -310,6 +342,80 @@ static int make_rec_arg(ceno_hip_ctx* ctx, ceno_hip_mle* const* recs, int k, siz
         ra.ptr[j] = recs[j]->d;
         ra.is_ext[j] = (uint8_t)recs[j]->is_ext;
     }
+    return 0;
+}
+
+// the rest of a many-tower build once the jobs of the LAST layers are known: one blob [head: the first kernel's jobs (and plans) | its block
+// table | per layer size: jobs, blocks | the tops], one copy, then the first kernel (k_interleave_many over records that exist, or
+// k_virtual_last_layer over record expressions), one k_layer_many per layer size and k_tower_top_many
+static int towers_build_upper_many(ceno_hip_ctx* ctx, const std::vector<ceno_hip_tower*>& towers, hipStream_t st, const void* head, size_t head_bytes,
+                                   const std::vector<BlkRef>& first_blks, size_t first_lds, bool virtual_first, size_t jobs_off = 0,
+                                   const std::function<void(char*, const char*)>& fixup = {}) {
+    auto add_blocks = [](std::vector<BlkRef>& v, uint32_t job, size_t work) {
+        // a few elements per lane, at most 1024 workgroups per job: the launch as a whole is what fills the device
+        const uint32_t nblk = (uint32_t)std::min<size_t>(std::max<size_t>((work + (size_t)NT * 4 - 1) / ((size_t)NT * 4), 1), 1024);
+        for (uint32_t b = 0; b < nblk; b++) v.push_back(BlkRef{job, b, nblk});
+    };
+    int max_nv = 0;
+    for (auto* t : towers) max_nv = std::max(max_nv, t->num_vars);
+    // levels: layer l of tower t comes from a layer kernel for from_t <= l <= nv_t - 2, the layers below from_t from the top kernel
+    struct Level {
+        std::vector<LayerJob> jobs;
+        std::vector<BlkRef> blks;
+    };
+    std::vector<Level> levels((size_t)std::max(max_nv, 1));
+    std::vector<TopJob> tops;
+    for (auto* t : towers) {
+        const int from = std::min(t->num_vars - 1, t->top_layers - 1);
+        for (int l = t->num_vars - 2; l >= from; l--) {
+            Level& L = levels[(size_t)l];
+            const size_t len_below = (size_t)1 << (l + 1);
+            add_blocks(L.blks, (uint32_t)L.jobs.size(), len_below);
+            L.jobs.push_back(LayerJob{t->layers[l + 1], t->layers[l], len_below, t->n_limbs, 0});
+        }
+        if (from >= 1) tops.push_back(TopJob{t->layers[0], from, t->n_limbs});
+    }
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    size_t total = al(head_bytes);
+    const size_t o_first_blk = total;
+    total = al(total + first_blks.size() * sizeof(BlkRef));
+    std::vector<size_t> o_jobs(levels.size(), 0), o_blks(levels.size(), 0);
+    for (size_t l = 0; l < levels.size(); l++) {
+        o_jobs[l] = total;
+        total = al(total + levels[l].jobs.size() * sizeof(LayerJob));
+        o_blks[l] = total;
+        total = al(total + levels[l].blks.size() * sizeof(BlkRef));
+    }
+    const size_t o_tops = total;
+    total = al(total + tops.size() * sizeof(TopJob));
+    void* d_blob = nullptr;
+    TRY(ctx_alloc(ctx, std::max<size_t>(total, 16), &d_blob));
+    std::vector<char> blob(total, 0);
+    memcpy(blob.data(), head, head_bytes);
+    if (fixup) fixup(blob.data(), (const char*)d_blob);
+    if (!first_blks.empty()) memcpy(blob.data() + o_first_blk, first_blks.data(), first_blks.size() * sizeof(BlkRef));
+    for (size_t l = 0; l < levels.size(); l++) {
+        if (!levels[l].jobs.empty()) memcpy(blob.data() + o_jobs[l], levels[l].jobs.data(), levels[l].jobs.size() * sizeof(LayerJob));
+        if (!levels[l].blks.empty()) memcpy(blob.data() + o_blks[l], levels[l].blks.data(), levels[l].blks.size() * sizeof(BlkRef));
+    }
+    if (!tops.empty()) memcpy(blob.data() + o_tops, tops.data(), tops.size() * sizeof(TopJob));
+    // (pageable source: the runtime has captured it when hipMemcpyAsync returns)
+    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), total, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        char* d = (char*)d_blob;
+        if (virtual_first)
+            hipLaunchKernelGGL(k_virtual_last_layer, dim3((unsigned)first_blks.size()), dim3(NT), first_lds, st, (const VtJob*)(d + jobs_off), (const BlkRef*)(d + o_first_blk));
+        else
+            hipLaunchKernelGGL(k_interleave_many, dim3((unsigned)first_blks.size()), dim3(NT), 0, st, (const IlvJob*)d, (const BlkRef*)(d + o_first_blk));
+        for (int l = (int)levels.size() - 1; l >= 0; l--)
+            if (!levels[(size_t)l].blks.empty())
+                hipLaunchKernelGGL(k_layer_many, dim3((unsigned)levels[(size_t)l].blks.size()), dim3(NT), 0, st, (const LayerJob*)(d + o_jobs[(size_t)l]),
+                                   (const BlkRef*)(d + o_blks[(size_t)l]));
+        if (!tops.empty()) hipLaunchKernelGGL(k_tower_top_many, dim3((unsigned)tops.size()), dim3(1024), 0, st, (const TopJob*)(d + o_tops));
+        e = hipGetLastError();
+    }
+    ctx_free(ctx, d_blob);  // (tagged with this stream: handed to another one only after the launches above have drained)
+    if (e != hipSuccess) return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower_build_many: %s", hipGetErrorString(e));
     return 0;
 }
 
@@ -485,70 +591,148 @@ int ceno_hip_tower_build_many(ceno_hip_ctx* ctx, const ceno_hip_tower_spec* spec
             return rc;
         }
     }
-    // levels: layer l of tower t comes from a layer kernel for from_t <= l <= nv_t - 2, the layers below from_t from the top kernel
-    struct Level {
-        std::vector<LayerJob> jobs;
-        std::vector<BlkRef> blks;
-    };
-    std::vector<Level> levels((size_t)std::max(max_nv, 1));
-    std::vector<TopJob> tops;
-    for (int i = 0; i < n; i++) {
-        ceno_hip_tower* t = towers[(size_t)i];
-        const int from = std::min(t->num_vars - 1, t->top_layers - 1);
-        for (int l = t->num_vars - 2; l >= from; l--) {
-            Level& L = levels[(size_t)l];
-            const size_t len_below = (size_t)1 << (l + 1);
-            add_blocks(L.blks, (uint32_t)L.jobs.size(), len_below);
-            L.jobs.push_back(LayerJob{t->layers[l + 1], t->layers[l], len_below, t->n_limbs, 0});
-        }
-        if (from >= 1) tops.push_back(TopJob{t->layers[0], from, t->n_limbs});
+    const int rc_up = towers_build_upper_many(ctx, towers, st, ilv.data(), ilv.size() * sizeof(IlvJob), ilv_blk, 0, false);
+    if (rc_up) {
+        release_all();
+        return rc_up;
     }
-    // one blob, one copy
+    for (int i = 0; i < n; i++) out[i] = towers[(size_t)i];
+    return 0;
+}
+
+int ceno_hip_tower_build_many_virtual(ceno_hip_ctx* ctx, const ceno_hip_wit_plan* plans, int n_plans, const ceno_hip_virtual_tower_spec* specs, int n,
+                                      ceno_hip_stream s, ceno_hip_tower** out) {
+    CENO_TIMED("tower_build_many_virtual");
+    CHECK_ARG(ctx, plans && specs && out && n_plans >= 1 && n >= 1 && n <= 4096, "tower_build_many_virtual: bad arguments");
+    hipStream_t st = ctx_stream(ctx, s);
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    size_t total = 0;
-    const size_t o_ilv = total;
-    total = al(total + ilv.size() * sizeof(IlvJob));
-    const size_t o_ilv_blk = total;
-    total = al(total + ilv_blk.size() * sizeof(BlkRef));
-    std::vector<size_t> o_jobs(levels.size(), 0), o_blks(levels.size(), 0);
-    for (size_t l = 0; l < levels.size(); l++) {
-        o_jobs[l] = total;
-        total = al(total + levels[l].jobs.size() * sizeof(LayerJob));
-        o_blks[l] = total;
-        total = al(total + levels[l].blks.size() * sizeof(BlkRef));
+    // the plans, each once, in the head of the blob (the jobs point into it); a plan too large for the LDS stage: not this path
+    struct Lay {
+        size_t o_slots, o_coeffs, o_toff, o_tidx, o_ooff, n_fac;
+    };
+    std::vector<Lay> lay((size_t)n_plans);
+    size_t plan_bytes = 0, max_lds = 0;
+    for (int i = 0; i < n_plans; i++) {
+        const ceno_hip_wit_plan& P = plans[i];
+        CHECK_ARG(ctx, P.mles && P.term_coeffs && P.term_offsets && P.term_mle_idx && P.out_term_offsets, "tower_build_many_virtual: plan %d: NULL argument", i);
+        CHECK_ARG(ctx, P.num_mles >= 1 && P.num_terms >= 0 && P.num_outs >= 1 && P.num_vars >= 1 && P.num_vars < 40, "tower_build_many_virtual: plan %d is empty", i);
+        CHECK_ARG(ctx, P.out_term_offsets[0] == 0 && (int)P.out_term_offsets[P.num_outs] == P.num_terms, "tower_build_many_virtual: plan %d: out_term_offsets must cover all terms", i);
+        for (int j = 0; j < P.num_mles; j++)
+            CHECK_ARG(ctx, P.mles[j] && P.mles[j]->num_vars == P.num_vars, "tower_build_many_virtual: plan %d: mle %d must have %d variables", i, j, P.num_vars);
+        Lay& L = lay[(size_t)i];
+        L.n_fac = P.term_offsets[P.num_terms];
+        for (uint32_t k = 0; k < L.n_fac; k++) CHECK_ARG(ctx, (int)P.term_mle_idx[k] < P.num_mles, "tower_build_many_virtual: plan %d: term factor %u out of range", i, P.term_mle_idx[k]);
+        const size_t lds = wit_infer_lds(P.num_mles, P.num_terms, (int)L.n_fac, P.num_outs);
+        if (lds > 60 * 1024) return ctx_fail(ctx, CENO_HIP_ERR_UNSUPPORTED, "tower_build_many_virtual: plan %d does not fit the LDS stage", i);
+        max_lds = std::max(max_lds, lds);
+        L.o_slots = plan_bytes;
+        plan_bytes = al(plan_bytes + (size_t)P.num_mles * sizeof(WiSlot));
+        L.o_coeffs = plan_bytes;
+        plan_bytes = al(plan_bytes + (size_t)P.num_terms * sizeof(E2));
+        L.o_toff = plan_bytes;
+        plan_bytes = al(plan_bytes + ((size_t)P.num_terms + 1) * 4);
+        L.o_tidx = plan_bytes;
+        plan_bytes = al(plan_bytes + L.n_fac * 4);
+        L.o_ooff = plan_bytes;
+        plan_bytes = al(plan_bytes + ((size_t)P.num_outs + 1) * 4);
     }
-    const size_t o_tops = total;
-    total = al(total + tops.size() * sizeof(TopJob));
-    std::vector<char> blob(total, 0);
-    memcpy(blob.data() + o_ilv, ilv.data(), ilv.size() * sizeof(IlvJob));
-    memcpy(blob.data() + o_ilv_blk, ilv_blk.data(), ilv_blk.size() * sizeof(BlkRef));
-    for (size_t l = 0; l < levels.size(); l++) {
-        if (!levels[l].jobs.empty()) memcpy(blob.data() + o_jobs[l], levels[l].jobs.data(), levels[l].jobs.size() * sizeof(LayerJob));
-        if (!levels[l].blks.empty()) memcpy(blob.data() + o_blks[l], levels[l].blks.data(), levels[l].blks.size() * sizeof(BlkRef));
+    std::vector<ceno_hip_tower*> towers((size_t)n, nullptr);
+    auto release_all = [&]() {
+        for (auto* t : towers) tower_release(ctx, t);
+    };
+    std::vector<VtJob> jobs;
+    std::vector<BlkRef> blks;
+    auto add_blocks = [](std::vector<BlkRef>& v, uint32_t job, size_t work) {
+        const uint32_t nblk = (uint32_t)std::min<size_t>(std::max<size_t>((work + (size_t)NT * 2 - 1) / ((size_t)NT * 2), 1), 2048);
+        for (uint32_t b = 0; b < nblk; b++) v.push_back(BlkRef{job, b, nblk});
+    };
+    for (int i = 0; i < n; i++) {
+        const ceno_hip_virtual_tower_spec& S = specs[i];
+        int rc = 0;
+        if (S.plan < 0 || S.plan >= n_plans || S.k < 1 || S.k > MAX_REC || S.first_record < 0 || S.first_record + S.k > plans[S.plan].num_outs ||
+            (S.first_numerator >= 0 && (!S.logup || S.first_numerator + S.k > plans[S.plan].num_outs)))
+            rc = ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower_build_many_virtual: tower %d names records its plan does not have", i);
+        if (rc) {
+            release_all();
+            return rc;
+        }
+        const ceno_hip_wit_plan& P = plans[S.plan];
+        const size_t len = (size_t)1 << P.num_vars, half = len / 2;
+        const int log_s = ceil_log2_sz((size_t)S.k);
+        const size_t out_len = half << log_s;
+        const int num_vars = ceil_log2_sz(out_len) + 1;
+        rc = tower_alloc(ctx, num_vars, S.logup ? 4 : 2, &towers[(size_t)i]);
+        if (rc) {
+            release_all();
+            return rc;
+        }
+        E2* last = towers[(size_t)i]->layers[num_vars - 1];
+        VtJob q{};
+        q.pl.num_outs = P.num_outs;  // (the pointers are set once the blob has its address)
+        q.num_mles = P.num_mles;
+        q.num_terms = P.num_terms;
+        q.num_factors = (int)lay[(size_t)S.plan].n_fac;
+        q.log_s = log_s;
+        q.k = S.k;
+        q.rec0 = S.first_record;
+        q.half = half;
+        q.out_len = out_len;
+        q.dflt = E2{S.default2[0], S.default2[1]};
+        q.pad_plan = S.plan;
+        if (S.logup) {
+            VtJob pj = q;
+            if (S.first_numerator >= 0) pj.rec0 = S.first_numerator;
+            else {  // numerators absent: the input layer's p limbs are all ONE (utils.rs:558-579)
+                pj.ones = 1;
+                pj.dflt = e2_one();
+            }
+            pj.out0 = last;
+            pj.out1 = last + out_len;
+            q.out0 = last + 2 * out_len;
+            q.out1 = last + 3 * out_len;
+            add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len);
+            jobs.push_back(pj);
+        } else {
+            q.out0 = last;
+            q.out1 = last + out_len;
+        }
+        add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len);
+        jobs.push_back(q);
     }
-    if (!tops.empty()) memcpy(blob.data() + o_tops, tops.data(), tops.size() * sizeof(TopJob));
-    void* d_blob = nullptr;
-    int rc = ctx_alloc(ctx, std::max<size_t>(total, 16), &d_blob);
-    if (rc) {
+    // the head of the blob: plans, then the jobs; towers_build_upper_many appends the levels and launches everything
+    std::vector<char> head(al(plan_bytes) + jobs.size() * sizeof(VtJob), 0);
+    for (int i = 0; i < n_plans; i++) {
+        const Lay& L = lay[(size_t)i];
+        const ceno_hip_wit_plan& P = plans[i];
+        for (int j = 0; j < P.num_mles; j++) reinterpret_cast<WiSlot*>(head.data() + L.o_slots)[j] = WiSlot{P.mles[j]->d, P.mles[j]->is_ext, 0};
+        for (int t = 0; t < P.num_terms; t++) reinterpret_cast<E2*>(head.data() + L.o_coeffs)[t] = E2{P.term_coeffs[2 * t], P.term_coeffs[2 * t + 1]};
+        memcpy(head.data() + L.o_toff, P.term_offsets, ((size_t)P.num_terms + 1) * 4);
+        if (L.n_fac) memcpy(head.data() + L.o_tidx, P.term_mle_idx, L.n_fac * 4);
+        memcpy(head.data() + L.o_ooff, P.out_term_offsets, ((size_t)P.num_outs + 1) * 4);
+    }
+    // (the jobs' plan pointers are offsets into the blob until it has an address: fixed up by the helper through `fix`)
+    struct Fix {
+        const std::vector<Lay>* lay;
+        std::vector<VtJob>* jobs;
+        size_t jobs_off;
+    } fix{&lay, &jobs, al(plan_bytes)};
+    auto fixup = [&](char* host, const char* dev) {
+        for (size_t j = 0; j < jobs.size(); j++) {
+            VtJob& J = reinterpret_cast<VtJob*>(host + fix.jobs_off)[j];
+            J = jobs[j];
+            const Lay& L = lay[(size_t)jobs[j].pad_plan];
+            J.pl.mles = reinterpret_cast<const WiSlot*>(dev + L.o_slots);
+            J.pl.coeffs = reinterpret_cast<const E2*>(dev + L.o_coeffs);
+            J.pl.term_off = reinterpret_cast<const uint32_t*>(dev + L.o_toff);
+            J.pl.term_idx = reinterpret_cast<const uint32_t*>(dev + L.o_tidx);
+            J.pl.out_term_off = reinterpret_cast<const uint32_t*>(dev + L.o_ooff);
+            J.pl.outs = nullptr;
+        }
+    };
+    const int rc_up = towers_build_upper_many(ctx, towers, st, head.data(), head.size(), blks, max_lds, true, fix.jobs_off, fixup);
+    if (rc_up) {
         release_all();
-        return rc;
-    }
-    // (pageable source: the runtime has captured it when hipMemcpyAsync returns)
-    hipError_t e = hipMemcpyAsync(d_blob, blob.data(), total, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) {
-        char* d = (char*)d_blob;
-        hipLaunchKernelGGL(k_interleave_many, dim3((unsigned)ilv_blk.size()), dim3(NT), 0, st, (const IlvJob*)(d + o_ilv), (const BlkRef*)(d + o_ilv_blk));
-        for (int l = (int)levels.size() - 1; l >= 0; l--)
-            if (!levels[(size_t)l].blks.empty())
-                hipLaunchKernelGGL(k_layer_many, dim3((unsigned)levels[(size_t)l].blks.size()), dim3(NT), 0, st, (const LayerJob*)(d + o_jobs[(size_t)l]),
-                                   (const BlkRef*)(d + o_blks[(size_t)l]));
-        if (!tops.empty()) hipLaunchKernelGGL(k_tower_top_many, dim3((unsigned)tops.size()), dim3(1024), 0, st, (const TopJob*)(d + o_tops));
-        e = hipGetLastError();
-    }
-    ctx_free(ctx, d_blob);  // (tagged with this stream: handed to another one only after the launches above have drained)
-    if (e != hipSuccess) {
-        release_all();
-        return ctx_fail(ctx, CENO_HIP_ERR_HIP, "tower_build_many: %s", hipGetErrorString(e));
+        return rc_up;
     }
     for (int i = 0; i < n; i++) out[i] = towers[(size_t)i];
     return 0;

@@ -8,6 +8,7 @@
 // transpose: reference `common::transpose::matrix_transpose` (ceno_zkvm/src/scheme/gpu/mod.rs:84,963-968):
 // row-major RowMajorMatrix values[row*width+col] -> column-major device layout.
 #include "common.hpp"
+#include "witinfer_dev.hpp"
 
 #include <algorithm>
 
@@ -16,40 +17,12 @@ using namespace gl;
 static constexpr int NT = 256;
 static constexpr unsigned MAXB = 2048;
 
-struct WiSlot {
-    const uint64_t* ptr;
-    int is_ext;
-    int pad;
-};
-
-struct WiPlan {
-    const WiSlot* mles;
-    const E2* coeffs;
-    const uint32_t* term_off;
-    const uint32_t* term_idx;
-    const uint32_t* out_term_off;
-    E2* const* outs;
-    int num_outs;
-};
-
 // The plan (slots, coefficients, CSR offsets) is pulled into LDS once per workgroup: every lane walks the same records, and
 // from global memory that walk is a chain of four dependent loads per factor.  Base-field factors of a term are multiplied
 // together first (one 64-bit product each) and meet the extension-field coefficient once at the end.
 __global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len, int num_mles, int num_terms, int num_factors) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    WiSlot* s_slots = reinterpret_cast<WiSlot*>(dyn);
-    E2* s_coeffs = reinterpret_cast<E2*>(s_slots + num_mles);
-    E2** s_outs = reinterpret_cast<E2**>(s_coeffs + num_terms);
-    uint32_t* s_toff = reinterpret_cast<uint32_t*>(s_outs + pl.num_outs);
-    uint32_t* s_tidx = s_toff + num_terms + 1;
-    uint32_t* s_ooff = s_tidx + num_factors;
-    for (int i = threadIdx.x; i < num_mles; i += NT) s_slots[i] = pl.mles[i];
-    for (int i = threadIdx.x; i < num_terms; i += NT) s_coeffs[i] = pl.coeffs[i];
-    for (int i = threadIdx.x; i < pl.num_outs; i += NT) s_outs[i] = pl.outs[i];
-    for (int i = threadIdx.x; i <= num_terms; i += NT) s_toff[i] = pl.term_off[i];
-    for (int i = threadIdx.x; i < num_factors; i += NT) s_tidx[i] = pl.term_idx[i];
-    for (int i = threadIdx.x; i <= pl.num_outs; i += NT) s_ooff[i] = pl.out_term_off[i];
-    __syncthreads();
+    const WiLds L = wi_stage<NT>(dyn, pl, num_mles, num_terms, num_factors, true);
     // one work item = one (record, row): a chip of 2^12 rows and 30 records is 120 k items, not 4 k lanes walking 30 records each — the
     // walk is a chain of dependent loads (plan word -> column pointer -> value), and what hides it is lanes, not loop iterations.  Items
     // of one record are consecutive rows (coalesced); the columns the records share come back from L2.  (len is a power of two.)
@@ -58,25 +31,7 @@ __global__ void __launch_bounds__(NT) k_wit_infer(WiPlan pl, size_t len, int num
     for (size_t it = (size_t)blockIdx.x * NT + threadIdx.x; it < items; it += stride) {
         const int o = (int)(it >> shift);
         const size_t x = it & mask;
-        E2 acc = e2_zero();
-        for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
-            E2 v = s_coeffs[t];
-            uint64_t pb = 1;
-            bool any_base = false;
-            for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
-                const WiSlot sl = s_slots[s_tidx[k]];
-                if (sl.is_ext) {
-                    v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
-                } else {
-                    const uint64_t f = sl.ptr[x];
-                    pb = any_base ? mul(pb, f) : f;
-                    any_base = true;
-                }
-            }
-            if (any_base) v = e2_mul_base(v, pb);
-            acc = acc + v;
-        }
-        s_outs[o][x] = acc;
+        L.outs[o][x] = wi_eval(L, o, x);
     }
 }
 // MANY plans in one launch (ceno_hip_wit_infer_many): the records of all chips of a shard.  A workgroup belongs to one plan (BlkRef), stages
@@ -93,45 +48,13 @@ __global__ void __launch_bounds__(NT) k_wit_infer_many(const WiJob* __restrict__
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     const WiBlk b = blks[blockIdx.x];
     const WiJob J = jobs[b.job];
-    const WiPlan& pl = J.pl;
-    const int num_mles = J.num_mles, num_terms = J.num_terms, num_factors = J.num_factors;
-    WiSlot* s_slots = reinterpret_cast<WiSlot*>(dyn);
-    E2* s_coeffs = reinterpret_cast<E2*>(s_slots + num_mles);
-    E2** s_outs = reinterpret_cast<E2**>(s_coeffs + num_terms);
-    uint32_t* s_toff = reinterpret_cast<uint32_t*>(s_outs + pl.num_outs);
-    uint32_t* s_tidx = s_toff + num_terms + 1;
-    uint32_t* s_ooff = s_tidx + num_factors;
-    for (int i = threadIdx.x; i < num_mles; i += NT) s_slots[i] = pl.mles[i];
-    for (int i = threadIdx.x; i < num_terms; i += NT) s_coeffs[i] = pl.coeffs[i];
-    for (int i = threadIdx.x; i < pl.num_outs; i += NT) s_outs[i] = pl.outs[i];
-    for (int i = threadIdx.x; i <= num_terms; i += NT) s_toff[i] = pl.term_off[i];
-    for (int i = threadIdx.x; i < num_factors; i += NT) s_tidx[i] = pl.term_idx[i];
-    for (int i = threadIdx.x; i <= pl.num_outs; i += NT) s_ooff[i] = pl.out_term_off[i];
-    __syncthreads();
-    const size_t len = J.len, stride = (size_t)b.nblk * NT, items = (size_t)pl.num_outs * len, mask = len - 1;
+    const WiLds L = wi_stage<NT>(dyn, J.pl, J.num_mles, J.num_terms, J.num_factors, true);
+    const size_t len = J.len, stride = (size_t)b.nblk * NT, items = (size_t)J.pl.num_outs * len, mask = len - 1;
     const int shift = __builtin_ctzll((unsigned long long)len);
     for (size_t it = (size_t)b.blk * NT + threadIdx.x; it < items; it += stride) {
         const int o = (int)(it >> shift);
         const size_t x = it & mask;
-        E2 acc = e2_zero();
-        for (uint32_t t = s_ooff[o]; t < s_ooff[o + 1]; t++) {
-            E2 v = s_coeffs[t];
-            uint64_t pb = 1;
-            bool any_base = false;
-            for (uint32_t k = s_toff[t]; k < s_toff[t + 1]; k++) {
-                const WiSlot sl = s_slots[s_tidx[k]];
-                if (sl.is_ext) {
-                    v = v * reinterpret_cast<const E2*>(sl.ptr)[x];
-                } else {
-                    const uint64_t f = sl.ptr[x];
-                    pb = any_base ? mul(pb, f) : f;
-                    any_base = true;
-                }
-            }
-            if (any_base) v = e2_mul_base(v, pb);
-            acc = acc + v;
-        }
-        s_outs[o][x] = acc;
+        L.outs[o][x] = wi_eval(L, o, x);
     }
 }
 // plans too large for the LDS stage (thousands of terms) walk the records in global memory
@@ -152,10 +75,6 @@ __global__ void __launch_bounds__(NT) k_wit_infer_big(WiPlan pl, size_t len) {
             pl.outs[o][x] = acc;
         }
     }
-}
-static size_t wit_infer_lds(int num_mles, int num_terms, int num_factors, int num_outs) {
-    return (size_t)num_mles * sizeof(WiSlot) + (size_t)num_terms * sizeof(E2) + (size_t)num_outs * sizeof(E2*) +
-           ((size_t)num_terms + 1 + (size_t)num_factors + (size_t)num_outs + 1) * 4 + 16;
 }
 
 // 32x32 tile transpose of 64-bit words through LDS (+1 padding: conflict-free column reads)

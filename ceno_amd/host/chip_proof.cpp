@@ -218,6 +218,20 @@ int chip_run_tower_specs(ChipProofRun& run, ceno_hip_tower_spec* specs3) {
     return n;
 }
 
+// the same towers named by their records' places in the chip's record plan (ceno_hip_tower_build_many_virtual: no record tables)
+int chip_run_virtual_tower_specs(ChipProofRun& run, int plan_index, ceno_hip_virtual_tower_spec* specs3) {
+    const ceno_chip_task* t = run.task;
+    const int n_lk_num = t->num_lk_tables, n_lk_den = t->num_lk_tables > 0 ? t->num_lk_tables : t->num_lk;
+    int n = 0;
+    if (t->num_reads > 0) specs3[n++] = ceno_hip_virtual_tower_spec{plan_index, 0, t->num_reads, -1, 0, {1, 0}};
+    if (t->num_writes > 0) specs3[n++] = ceno_hip_virtual_tower_spec{plan_index, t->num_reads, t->num_writes, -1, 0, {1, 0}};
+    if (n_lk_den > 0) {
+        const int lk0 = t->num_reads + t->num_writes;
+        specs3[n++] = ceno_hip_virtual_tower_spec{plan_index, lk0 + n_lk_num, n_lk_den, n_lk_num > 0 ? lk0 : -1, 1, {run.challenges4[0], run.challenges4[1]}};  // cpu/mod.rs:658-661
+    }
+    return n;
+}
+
 int chip_run_adopt_towers(ChipProofRun& run, ceno_hip_tower* const* towers, int n) {
     const ceno_chip_task* t = run.task;
     ceno_tower_witness& tw = run.tw;

@@ -27,6 +27,7 @@ int chip_run_records(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task*
 int chip_run_records_plan(ChipProofRun& run, ceno_hip_ctx* ctx, const ceno_chip_task* task, const uint64_t* challenges4, ceno_transcript* tr,
                           ceno_chip_proof* out, ceno_hip_wit_plan* plan);
 int chip_run_tower_specs(ChipProofRun& run, ceno_hip_tower_spec* specs3);  // returns how many (<= 3)
+int chip_run_virtual_tower_specs(ChipProofRun& run, int plan_index, ceno_hip_virtual_tower_spec* specs3);
 int chip_run_adopt_towers(ChipProofRun& run, ceno_hip_tower* const* towers, int n);
 void chip_run_free_records(ChipProofRun& run);
 int chip_run_after_towers(ChipProofRun& run, ceno_hip_stream s);

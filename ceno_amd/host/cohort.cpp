@@ -349,33 +349,39 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         bar.wait();
         // ---- A2 ----
         if (t == 0) {
-            {
-                std::vector<ceno_hip_wit_plan> live;
-                for (size_t i = 0; i < runs.size(); i++)
-                    if (!status[i]) live.push_back(plans[i]);
-                if (!live.empty())
-                    if (const int rc = ceno_hip_wit_infer_many(ctx, live.data(), (int)live.size(), stream)) {
-                        for (size_t i = 0; i < runs.size(); i++)
-                            if (!status[i]) status[i] = rc;  // (nothing is left allocated)
-                        err_msg = ceno_hip_last_error(ctx);
-                        err.store(rc);
-                    }
-            }
-            t_a1 = now_ms() - t_start;
-            std::vector<ceno_hip_tower_spec> specs;
+            // the towers of all chips: straight from the record expressions (no record tables: the reference's ..._from_virtual_ext_batch), or —
+            // a plan too large for that kernel's LDS stage, CENO_TOWER_VIRTUAL_RECORDS=0 — records first, then towers from them
+            std::vector<ceno_hip_wit_plan> live;
             std::vector<int> first((size_t)runs.size() + 1, 0);
+            std::vector<ceno_hip_virtual_tower_spec> vspecs;
             for (size_t i = 0; i < runs.size(); i++) {
-                first[i] = (int)specs.size();
-                if (!status[i]) {
-                    ceno_hip_tower_spec s3[3];
-                    const int k = chip_run_tower_specs(*runs[i], s3);
-                    specs.insert(specs.end(), s3, s3 + k);
-                }
+                first[i] = (int)vspecs.size();
+                if (status[i]) continue;
+                ceno_hip_virtual_tower_spec s3[3];
+                const int k = chip_run_virtual_tower_specs(*runs[i], (int)live.size(), s3);
+                vspecs.insert(vspecs.end(), s3, s3 + k);
+                live.push_back(plans[i]);
             }
-            first[runs.size()] = (int)specs.size();
-            if (!specs.empty()) {
-                std::vector<ceno_hip_tower*> towers(specs.size(), nullptr);
-                int rc = ceno_hip_tower_build_many(ctx, specs.data(), (int)specs.size(), stream, towers.data());
+            first[runs.size()] = (int)vspecs.size();
+            std::vector<ceno_hip_tower*> towers(vspecs.size(), nullptr);
+            int rc = 0;
+            if (!vspecs.empty()) {
+                const char* e_v = getenv("CENO_TOWER_VIRTUAL_RECORDS");
+                rc = e_v && atoi(e_v) == 0 ? CENO_HIP_ERR_UNSUPPORTED : ceno_hip_tower_build_many_virtual(ctx, live.data(), (int)live.size(), vspecs.data(), (int)vspecs.size(), stream, towers.data());
+                if (rc == CENO_HIP_ERR_UNSUPPORTED) {
+                    rc = ceno_hip_wit_infer_many(ctx, live.data(), (int)live.size(), stream);
+                    t_a1 = now_ms() - t_start;
+                    std::vector<ceno_hip_tower_spec> specs;
+                    if (!rc)
+                        for (size_t i = 0; i < runs.size(); i++)
+                            if (!status[i]) {
+                                ceno_hip_tower_spec s3[3];
+                                const int k = chip_run_tower_specs(*runs[i], s3);
+                                specs.insert(specs.end(), s3, s3 + k);
+                            }
+                    if (!rc) rc = ceno_hip_tower_build_many(ctx, specs.data(), (int)specs.size(), stream, towers.data());
+                } else
+                    t_a1 = now_ms() - t_start;
                 if (!rc) {
                     rc = ceno_hip_tower_prefetch_tops(ctx, towers.data(), (int)towers.size(), host_layers + 1, stream);
                     if (rc)

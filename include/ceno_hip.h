@@ -319,6 +319,19 @@ typedef struct ceno_hip_tower_spec {
     uint64_t default2[2];
 } ceno_hip_tower_spec;
 int ceno_hip_tower_build_many(ceno_hip_ctx* ctx, const ceno_hip_tower_spec* specs, int n, ceno_hip_stream s, ceno_hip_tower** out /* n */);
+/* The same towers straight from the record EXPRESSIONS (the reference's build_prod_tower_from_virtual_ext_batch /
+ * build_logup_tower_from_virtual_ext_batch, ceno_zkvm/src/scheme/gpu/mod.rs:2365-2402): tower i reads records first_record .. + k (and, a LogUp
+ * tower with numerators, first_numerator .. + k) of plans[plan] — what ceno_hip_wit_infer would write into record tables of 2^num_vars rows
+ * (one row per slot of the padded trace: num_instances = 2^num_vars) — without the tables ever existing (plans[..].outs is not used).
+ * CENO_HIP_ERR_UNSUPPORTED when a plan is too large for the kernel's LDS stage: the caller materialises the records then. */
+typedef struct ceno_hip_virtual_tower_spec {
+    int plan, first_record, k;
+    int first_numerator; /* < 0: none (a product tower, or a LogUp tower whose numerators are all one) */
+    int logup;
+    uint64_t default2[2];
+} ceno_hip_virtual_tower_spec;
+int ceno_hip_tower_build_many_virtual(ceno_hip_ctx* ctx, const ceno_hip_wit_plan* plans, int n_plans, const ceno_hip_virtual_tower_spec* specs, int n,
+                                      ceno_hip_stream s, ceno_hip_tower** out /* n */);
 int ceno_hip_tower_num_vars(const ceno_hip_tower* t);   /* number of layers */
 int ceno_hip_tower_num_limbs(const ceno_hip_tower* t);  /* 2 or 4 */
 /* borrowed handle of limb `limb` of layer `layer` (valid while the tower lives) */
