@@ -227,84 +227,83 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     SpinBarrier bar;
     bar.n = n_threads;
     std::atomic<int> err{0};
-    std::vector<LayerChip> chips;      // this launch's chips
-    ceno_hip_cohort* co = nullptr;
-    std::atomic<bool> more{true};
     std::vector<double> busy((size_t)n_threads, 0.0);  // (trace: time spent answering, per thread)
     std::string err_msg;
-    // thread 0 between the barriers: the next launch (the chips standing before the lowest open layer <= last_layer, as many as the device
-    // holds at once), or the end
-    int first_pending = 0;  // (within one layer: chips from this index on have not been launched yet)
-    int layer_now = 0;
-    double t_prep = 0, t_end = 0;  // (trace: thread 0's time building launches / closing them)
-    int n_jobs_planned = 0;
-    auto next_launch = [&]() -> bool {
-        const double t_in = trace ? now_ms() : 0;
-        struct Acc {
-            double& a;
-            double t;
-            bool on;
-            ~Acc() {
-                if (on) a += now_ms() - t;
-            }
-        } acc_{t_prep, t_in, trace};
-        for (;;) {
-            if (layer_now == 0) {
-                int L = 0;
-                for (size_t i = 0; i < runs.size(); i++)
-                    if (!status[i] && !runs[i]->st.done() && runs[i]->st.round <= last_layer) L = L ? std::min(L, runs[i]->st.round) : runs[i]->st.round;
-                if (!L) return false;
-                layer_now = L;
-                first_pending = 0;
-            }
-            chips.clear();
-            int jobs = 0, at_layer = 0;
-            for (size_t k = 0; k < runs.size(); k++)
-                if (!status[k] && !runs[k]->st.done() && runs[k]->st.round == layer_now) at_layer++;
-            const int n_lo = sub_cube_vars(layer_now, at_layer, capacity, sub);
-            size_t i = (size_t)first_pending;
-            for (; i < runs.size(); i++) {
-                if (status[i] || runs[i]->st.done() || runs[i]->st.round != layer_now) continue;
-                const int G = 1 << (layer_now - n_lo);
-                if (G > capacity) {  // (a layer no launch can hold: left to the per-chip prover)
-                    return false;
+    double t_prep = 0, t_end = 0;  // (trace: the coordinator's time opening launches / closing them)
+    // The schedule of phase B is known before it starts — which chips have a layer L is a matter of their towers' heights — so everything a launch
+    // needs that does not depend on the transcript (allocations, shapes: `open`) is done by a COORDINATOR (thread 0, which serves no chips)
+    // while the launch before it is being served, and so is the closing of the launch before that: between two launches the device waits for
+    // the epilogues, the job records (written by the serving threads, in parallel) and the launch itself.
+    struct Launch {
+        int L = 0, n_lo = 0, jobs = 0;
+        std::vector<LayerChip> chips;
+        ceno_hip_cohort* co = nullptr;
+    };
+    std::vector<Launch> launches;
+    std::atomic<bool> go{true};
+    auto build_schedule = [&]() {
+        int L0 = 0;
+        for (size_t i = 0; i < runs.size(); i++)
+            if (!status[i] && !runs[i]->st.done() && runs[i]->st.round <= last_layer) L0 = L0 ? std::min(L0, runs[i]->st.round) : runs[i]->st.round;
+        if (!L0) return;
+        for (int L = L0; L <= last_layer; L++) {
+            std::vector<size_t> at;
+            for (size_t i = 0; i < runs.size(); i++)
+                if (!status[i] && !runs[i]->st.done() && runs[i]->st.round <= L && L <= runs[i]->st.R) at.push_back(i);
+            size_t next = 0;
+            while (next < at.size()) {
+                const int n_lo = sub_cube_vars(L, (int)(at.size() - next), capacity, sub);
+                const int G = 1 << (L - n_lo);
+                if (G > capacity) return;  // (a layer no launch can hold: this one and the ones above are left to the per-chip prover)
+                Launch la;
+                la.L = L;
+                la.n_lo = n_lo;
+                while (next < at.size() && la.jobs + G <= capacity) {
+                    la.chips.emplace_back();
+                    LayerChip& c = la.chips.back();
+                    c.run = runs[at[next++]];
+                    c.L = L;
+                    c.n_lo = n_lo;
+                    c.first_job = la.jobs;
+                    la.jobs += G;
                 }
-                if (jobs + G > capacity) break;
-                chips.emplace_back();
-                chips.back().run = runs[i];  // (prepared by its serving thread)
-                chips.back().L = layer_now;
-                chips.back().n_lo = n_lo;
-                chips.back().first_job = jobs;
-                jobs += G;
+                launches.push_back(std::move(la));
             }
-            first_pending = (int)i;
-            if (chips.empty()) {
-                layer_now = 0;
-                continue;
-            }
-            if (i >= runs.size()) layer_now = 0;  // the layer is complete with this launch
-            n_jobs_planned = jobs;
-            // the shapes (which towers still have this layer) and the allocations; the job records are written by the serving threads
-            std::vector<ceno_hip_cohort_shape> shapes((size_t)jobs);
-            for (auto& c : chips) {
-                const TowerProveState& st = c.run->st;
-                int np = 0, nl = 0;
-                for (int k = 0; k < st.n_prod; k++) np += st.nv_of(st.prod[k]) > c.L;
-                for (int k = 0; k < st.n_logup; k++) nl += st.nv_of(st.logup[k]) > c.L;
-                const int G = 1 << (c.L - c.n_lo);
-                for (int g = 0; g < G; g++) shapes[(size_t)(c.first_job + g)] = ceno_hip_cohort_shape{np, nl, c.n_lo, G > 1 ? c.first_job + 1 : 0};
-            }
-            if (const int rc = ceno_hip_tower_cohort_open(ctx, shapes.data(), jobs, stream, &co)) {
-                err_msg = ceno_hip_last_error(ctx);
-                err.store(rc);
-                co = nullptr;
-                return false;
-            }
-            return true;
         }
     };
+    auto open_launch = [&](Launch& la) {
+        const double t_in = trace ? now_ms() : 0;
+        // the shapes (which towers still have this layer) and the allocations
+        std::vector<ceno_hip_cohort_shape> shapes((size_t)la.jobs);
+        for (auto& c : la.chips) {
+            const TowerProveState& st = c.run->st;
+            int np = 0, nl = 0;
+            for (int k = 0; k < st.n_prod; k++) np += st.nv_of(st.prod[k]) > c.L;
+            for (int k = 0; k < st.n_logup; k++) nl += st.nv_of(st.logup[k]) > c.L;
+            const int G = 1 << (c.L - c.n_lo);
+            for (int g = 0; g < G; g++) shapes[(size_t)(c.first_job + g)] = ceno_hip_cohort_shape{np, nl, c.n_lo, G > 1 ? c.first_job + 1 : 0};
+        }
+        if (const int rc = ceno_hip_tower_cohort_open(ctx, shapes.data(), la.jobs, stream, &la.co)) {
+            int zero = 0;
+            if (err.compare_exchange_strong(zero, rc)) err_msg = ceno_hip_last_error(ctx);
+            la.co = nullptr;
+        }
+        if (trace) t_prep += now_ms() - t_in;
+    };
+    auto close_launch = [&](Launch& la, bool aborted) {
+        if (!la.co) return;
+        const double t_in = trace ? now_ms() : 0;
+        if (aborted) (void)ceno_hip_tower_cohort_abort(la.co);
+        const int rc = ceno_hip_tower_cohort_end(ctx, la.co);
+        la.co = nullptr;
+        if (rc && !aborted) {
+            int zero = 0;
+            if (err.compare_exchange_strong(zero, rc)) err_msg = ceno_hip_last_error(ctx);
+        }
+        if (trace) t_end += now_ms() - t_in;
+    };
     // a chip's job records (its serving thread: the bulk of a launch's set-up, in parallel)
-    auto set_jobs = [&](LayerChip& c) -> int {
+    auto set_jobs = [&](ceno_hip_cohort* co, LayerChip& c) -> int {
         for (int g = 0; g < c.G; g++) {
             ceno_hip_cohort_job J{};
             J.tables = c.tables.data() + (size_t)g * (size_t)(c.K - 1);
@@ -321,18 +320,6 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             if (const int rc = ceno_hip_tower_cohort_set_job(co, c.first_job + g, &J)) return rc;
         }
         return 0;
-    };
-    auto begin_launch = [&]() {
-        const double t_in = trace ? now_ms() : 0;
-        if (const int rc = ceno_hip_tower_cohort_launch(ctx, co)) {
-            err_msg = ceno_hip_last_error(ctx);
-            err.store(rc);
-        }
-        if (trace) {
-            fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs of 2^%d (the device holds %d), launch %.3f ms\n", chips[0].L, chips.size(), n_jobs_planned,
-                    chips[0].n_lo, capacity, now_ms() - t_in);
-            t_prep += now_ms() - t_in;
-        }
     };
     double t_a1 = 0, t_a2 = 0, t_a3 = 0;
     std::vector<ceno_hip_wit_plan> plans(runs.size());
@@ -418,62 +405,86 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         bar.wait();
         if (t == 0) t_a3 = now_ms() - t_start;
         // ---- B ----
-        for (;;) {
-            if (t == 0) more.store(next_launch());
-            bar.wait();
-            if (!more.load()) return;
-            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) {
-                prepare(chips[i], chips[i].run, chips[i].L, chips[i].n_lo);
-                if (const int rc = set_jobs(chips[i])) {
-                    int zero = 0;
-                    if (err.compare_exchange_strong(zero, rc)) err_msg = "cohort: a job record was refused";
+        if (t == 0) {
+            build_schedule();
+            if (!launches.empty()) open_launch(launches[0]);
+        }
+        bar.wait();
+        const bool serves = n_threads == 1 || t > 0;
+        const size_t n_serving = (size_t)std::max(1, n_threads - 1), me = n_threads == 1 ? 0 : (size_t)t - 1;
+        auto fail_with = [&](int rc, const char* msg) {
+            int zero = 0;
+            if (err.compare_exchange_strong(zero, rc)) err_msg = msg;
+        };
+        for (size_t k = 0; k < launches.size(); k++) {
+            Launch& la = launches[k];
+            if (serves && !err.load())
+                for (size_t i = me; i < la.chips.size(); i += n_serving) {
+                    prepare(la.chips[i], la.chips[i].run, la.L, la.n_lo);
+                    if (const int rc = set_jobs(la.co, la.chips[i])) fail_with(rc, "cohort: a job record was refused");
                 }
-            }
             bar.wait();
-            if (t == 0 && !err.load()) begin_launch();
-            bar.wait();
-            if (err.load()) {
-                if (t == 0 && co) {  // (opened, perhaps launched: release every waiting workgroup, then the cohort)
-                    (void)ceno_hip_tower_cohort_abort(co);
-                    (void)ceno_hip_tower_cohort_end(ctx, co);
-                    co = nullptr;
-                }
-                return;
-            }
             const double t_begin = now_ms();
-            size_t open = 0;
-            for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) open++;
-            unsigned spins = 0;
-            while (open && !err.load(std::memory_order_relaxed)) {
-                for (size_t i = (size_t)t; i < chips.size(); i += (size_t)n_threads) {
-                    LayerChip& c = chips[i];
-                    if (c.done) continue;
-                    const int round_before = c.round;
-                    const double t_s = trace ? now_ms() : 0;
-                    const int r = serve(co, c);
-                    if (trace && (c.round != round_before || c.done)) busy[(size_t)t] += now_ms() - t_s;
-                    if (r) {
-                        int zero = 0;
-                        if (err.compare_exchange_strong(zero, r)) err_msg = r == CENO_HIP_ERR_INVALID ? "cohort: a mailbox call was refused" : ceno_prover_last_error();
-                        break;
-                    }
-                    if (c.done) open--;
-                }
-                if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms) {
-                    int zero = 0;
-                    if (err.compare_exchange_strong(zero, CENO_HIP_ERR_STATE)) err_msg = "cohort: a tower layer's rounds did not arrive in time (CENO_HIP_PIPE_TIMEOUT_S)";
-                }
+            if (t == 0) {
+                if (!err.load())
+                    if (const int rc = ceno_hip_tower_cohort_launch(ctx, la.co)) fail_with(rc, ceno_hip_last_error(ctx));
+                go.store(err.load() == 0);  // (ONE decision per launch, taken between two barriers: every thread leaves the loop at the same place)
             }
             bar.wait();
-            if (t == 0 && times && !err.load() && !chips.empty()) {
+            if (!go.load()) break;
+            auto serve_mine = [&]() {
+                size_t open = 0;
+                for (size_t i = me; i < la.chips.size(); i += n_serving) open++;
+                unsigned spins = 0;
+                while (open && !err.load(std::memory_order_relaxed)) {
+                    for (size_t i = me; i < la.chips.size(); i += n_serving) {
+                        LayerChip& c = la.chips[i];
+                        if (c.done) continue;
+                        const int round_before = c.round;
+                        const double t_s = trace ? now_ms() : 0;
+                        const int r = serve(la.co, c);
+                        if (trace && (c.round != round_before || c.done)) busy[(size_t)t] += now_ms() - t_s;
+                        if (r) {
+                            fail_with(r, r == CENO_HIP_ERR_INVALID ? "cohort: a mailbox call was refused" : ceno_prover_last_error());
+                            break;
+                        }
+                        if (c.done) open--;
+                    }
+                    if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms)
+                        fail_with(CENO_HIP_ERR_STATE, "cohort: a tower layer's rounds did not arrive in time (CENO_HIP_PIPE_TIMEOUT_S)");
+                }
+            };
+            auto coordinate = [&]() {  // while launch k is served: open the next, close the one before (its wait covers launch k: same stream)
+                if (k + 1 < launches.size() && !err.load()) open_launch(launches[k + 1]);
+                if (k > 0) close_launch(launches[k - 1], false);
+            };
+            if (n_threads == 1) {
+                serve_mine();
+                coordinate();
+            } else if (t == 0)
+                coordinate();
+            else
+                serve_mine();
+            bar.wait();
+            if (t == 0 && trace) {
+                double mx = 0, sum = 0;
+                for (double& b : busy) {
+                    mx = std::max(mx, b);
+                    sum += b;
+                    b = 0;
+                }
+                fprintf(stderr, "[ceno_prover] cohort: layer %d, %zu chips, %d jobs of 2^%d (the device holds %d): %.3f ms from launch to the last epilogue (threads answering: busiest %.3f ms, all %.3f ms)\n",
+                        la.L, la.chips.size(), la.jobs, la.n_lo, capacity, now_ms() - t_begin, mx, sum);
+            }
+            if (t == 0 && times && !err.load() && !la.chips.empty()) {
                 // (CENO_COHORT_TIMES: the first and the last chip's first sub-cube, round by round: device time from challenge to message,
                 // then how long the message waited for its answer)
-                for (const LayerChip* c : {&chips.front(), &chips.back()}) {
+                for (const LayerChip* c : {&la.chips.front(), &la.chips.back()}) {
                     std::string line;
                     uint64_t prev_sent = 0, first = 0;
                     for (int i = 0; i < c->n_lo; i++) {
                         uint64_t w[2] = {0, 0};
-                        (void)ceno_hip_tower_cohort_round_times(co, c->first_job, i, w);
+                        (void)ceno_hip_tower_cohort_round_times(la.co, c->first_job, i, w);
                         if (i == 0) first = w[0];
                         char buf[96];
                         snprintf(buf, sizeof buf, " [%d: wait %.1f, compute %.1f]", i, i ? (double)(w[0] - prev_sent) / 100.0 : 0.0, (double)(w[1] - w[0]) / 100.0);
@@ -483,36 +494,14 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                     fprintf(stderr, "[ceno_prover] cohort times (us), layer %d job %d, %.1f us in all:%s\n", c->L, c->first_job, (double)(prev_sent - first) / 100.0, line.c_str());
                 }
             }
-            if (t == 0) {
-                const double t_e = trace ? now_ms() : 0;
-                if (err.load()) (void)ceno_hip_tower_cohort_abort(co);
-                const int rc = ceno_hip_tower_cohort_end(ctx, co);
-                if (trace) t_end += now_ms() - t_e;
-                co = nullptr;
-                if (rc && !err.load()) {
-                    err_msg = ceno_hip_last_error(ctx);
-                    err.store(rc);
-                }
-                if (trace) {
-                    double mx = 0, sum = 0;
-                    for (double& b : busy) {
-                        mx = std::max(mx, b);
-                        sum += b;
-                        b = 0;
-                    }
-                    fprintf(stderr, "[ceno_prover] cohort: layer served in %.3f ms (threads answering: busiest %.3f ms, all %.3f ms)\n", now_ms() - t_begin, mx, sum);
-                }
-                if (err.load()) {
-                    more.store(false);
-                }
-            }
-            bar.wait();
-            if (err.load()) return;
         }
+        bar.wait();  // (every thread has left the loop: nobody reads a cohort any more)
+        if (t == 0)
+            for (auto& la : launches) close_launch(la, err.load() != 0);  // (the last one; after an error: whatever is open, its workgroups released)
     };
     WorkerPool::instance().run(n_threads, worker);
     if (trace) fprintf(stderr, "[ceno_prover] cohort: the last of %d threads started %.3f ms in\n", n_threads, *std::max_element(t_started.begin(), t_started.end()));
-    if (trace) fprintf(stderr, "[ceno_prover] cohort: thread 0 spent %.3f ms building launches, %.3f ms closing them\n", t_prep, t_end);
+    if (trace) fprintf(stderr, "[ceno_prover] cohort: the coordinator spent %.3f ms opening launches, %.3f ms closing them (beside the serving threads)\n", t_prep, t_end);
     if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: records %.3f ms, towers of all chips %.3f, to the cohort layers %.3f, cohort layers to %d %.3f\n", t_a1,
                        t_a2 - t_a1, t_a3 - t_a2, last_layer, now_ms() - t_start - t_a3);
     if (const int rc = err.load()) {
