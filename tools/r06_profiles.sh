@@ -25,9 +25,18 @@ cp $(ls $o/wide_kt/*/*kernel_stats.csv | head -1) $o/out/r06_shard_wide_kernel_s
 cp $(ls $o/bmw_kt/*/*kernel_stats.csv | head -1) $o/out/r06_batched_main_wide_kernel_stats.csv
 LANES=1,2,4,8 python3 tools/bench_shard.py poseidon2 2>/dev/null | grep lanes > $o/out/r06_shard_lanes.jsonl
 LANES=1,4,8,16 REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null > $o/out/r06_shard_wide_lanes.jsonl
-for L in 4 6 8 10 12; do CENO_HIP_MAX_LANES=$L LANES=$L REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null | tail -1 >> $o/out/r06_shard_wide_lane_cap_sweep.jsonl; done
-CENO_LANES_TRACE=1 CENO_PROVER_CHIP_TRACE=1 LANES=1 REPS=2 python3 tools/bench_shard_wide.py poseidon2 2>&1 >/dev/null | grep "lanes trace\|chip 2" | tail -108 > $o/out/r06_shard_wide_chip_trace_1lane.txt
-CENO_LANES_TRACE=1 LANES=8 REPS=2 python3 tools/bench_shard_wide.py poseidon2 2>&1 >/dev/null | grep "lanes trace" | tail -54 > $o/out/r06_shard_wide_chip_trace_8lanes.txt
+# the per-chip tower prover (round 5's path, CENO_TOWER_COHORT_LAYERS=0): lanes, the lane cap, where a chip's time goes
+rm -f $o/out/r06_shard_wide_lane_cap_sweep.jsonl $o/out/r06_cohort_last_layer.txt
+CENO_TOWER_COHORT_LAYERS=0 LANES=1,4,8,16 REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null > $o/out/r06_shard_wide_lanes_per_chip_prover.jsonl
+for L in 4 6 8 10 12; do CENO_TOWER_COHORT_LAYERS=0 CENO_HIP_MAX_LANES=$L LANES=$L REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null | tail -1 >> $o/out/r06_shard_wide_lane_cap_sweep.jsonl; done
+CENO_TOWER_COHORT_LAYERS=0 CENO_LANES_TRACE=1 CENO_PROVER_CHIP_TRACE=1 LANES=1 REPS=2 python3 tools/bench_shard_wide.py poseidon2 2>&1 >/dev/null | grep "lanes trace\|chip 2" | tail -108 > $o/out/r06_shard_wide_chip_trace_1lane.txt
+CENO_TOWER_COHORT_LAYERS=0 CENO_LANES_TRACE=1 LANES=8 REPS=2 python3 tools/bench_shard_wide.py poseidon2 2>&1 >/dev/null | grep "lanes trace" | tail -54 > $o/out/r06_shard_wide_chip_trace_8lanes.txt
+# the cohort layers: the phase's own account (records / towers / host layers / cohort layers / the rest), device-side round times of the first
+# and the last chip of every layer, the last cohort layer swept, the sub-cube cut fixed at 2^13 against the adaptive one
+CENO_COHORT_TRACE=1 CENO_COHORT_TIMES=1 LANES=8 REPS=3 python3 tools/bench_shard_wide.py poseidon2 2>&1 >/dev/null | grep "cohort" | tail -34 | cut -c1-1200 > $o/out/r06_cohort_trace.txt
+for L in 0 13 16 17 18 19 20 22; do echo "CENO_TOWER_COHORT_LAYERS=$L $(CENO_TOWER_COHORT_LAYERS=$L LANES=8 REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null | tail -1)" >> $o/out/r06_cohort_last_layer.txt; done
+echo "CENO_TOWER_COHORT_SUB=13 $(CENO_TOWER_COHORT_SUB=13 LANES=8 REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null | tail -1)" >> $o/out/r06_cohort_last_layer.txt
+echo "CENO_TOWER_VIRTUAL_RECORDS=0 $(CENO_TOWER_VIRTUAL_RECORDS=0 LANES=8 REPS=5 python3 tools/bench_shard_wide.py poseidon2 2>/dev/null | tail -1)" >> $o/out/r06_cohort_last_layer.txt
 python3 tools/bench_chip.py 2>/dev/null | tail -1 > $o/out/r06_chip_flow.json
 python3 tools/bench_batched_wide.py --reps 4 2>/dev/null | tail -1 > $o/out/r06_batched_main_wide.json
 ls -la $o/out/

@@ -55,5 +55,5 @@ for fn in sorted(glob.glob(root + "/ceno_amd/csrc/*")):
         h.update(os.path.basename(fn).encode()); h.update(open(fn, "rb").read())
 res["csrc_sha16"] = h.hexdigest()[:16]   # bench.py uses the counts only while the tree's kernel sources hash to this
 json.dump(res, open(o + "/r06_valu_counters.json", "w"), indent=1)
-print(json.dumps({k: (v["SQ_INSTS_VALU"], v["VALUBusy_over_kernel_time"]) for k, v in res.items() if isinstance(v, dict)}))
+print(json.dumps({k: (v["SQ_INSTS_VALU"], v.get("VALUBusy_over_kernel_time")) for k, v in res.items() if isinstance(v, dict)}))
 PY
