@@ -1090,10 +1090,10 @@ class ChipTasks:
             self.keep.append(keep)
 
 
-def create_chip_proofs(dev: Device, tasks, challenges, transcripts: Sequence[Transcript], lanes: int) -> List[ChipProof]:
+def create_chip_proofs(dev: Device, tasks, challenges, transcripts: Sequence[Transcript], lanes: int, statuses: Optional[list] = None) -> List[ChipProof]:
     """the chip-proof phase of create_proof on the C++ scheduler (ceno_prover_create_chip_proofs; prover.rs:556-570,
     scheduler.rs:231-336): one forked transcript per task, `lanes` concurrent lanes on the context's own lane streams, results in
-    task order"""
+    task order.  `statuses` (a list): receives every task's return code; a failed task then yields None instead of raising"""
     L = plib()
     L.ceno_prover_create_chip_proofs.restype = C.c_int
     L.ceno_prover_create_chip_proofs.argtypes = [C.c_void_p, C.POINTER(ChipTaskC), C.c_int, u64p, C.POINTER(C.c_void_p), C.c_int,
@@ -1110,6 +1110,11 @@ def create_chip_proofs(dev: Device, tasks, challenges, transcripts: Sequence[Tra
     rc = L.ceno_prover_create_chip_proofs(dev.h, ct.arr, ct.n, _p(ch), trs, lanes, outs, status)
     create_chip_proofs.last_native_ms = (time.perf_counter() - t0) * 1e3   # (the C call alone: what remains is this wrapper's marshalling)
     try:
+        if statuses is not None:
+            statuses[:] = [int(status[i]) for i in range(ct.n)]
+            if rc != 0 and all(x == 0 for x in statuses):
+                _check(rc)   # (a failure that is nobody's in particular)
+            return [ChipProof(outs[i]) if status[i] == 0 else None for i in range(ct.n)]
         _check(rc)
         return [ChipProof(outs[i]) for i in range(ct.n)]
     finally:

@@ -883,6 +883,88 @@ def test_concurrent_lanes_produce_the_single_lane_proofs_every_time(dev, prover)
                 assert np.array_equal(x, y), (rep, i)
 
 
+def _twelve_chips(d, prover, bad=None):
+    from ceno_amd import synthetic
+
+    w = 22
+    alpha, beta = (5, 6), (7, 8)
+    coeffs, terms, out_terms = synthetic.record_plan(w, 16, alpha, beta)
+    logs = (13, 8, 12, 9, 11, 10, 10, 11, 9, 12, 8, 13)
+    cols = [[d.synthetic(r, False, 0x700 + 37 * i + j) for j in range(w)] for i, r in enumerate(logs)]
+    tasks = [dict(circuit_idx=i, mles=cols[i], n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3, log2_num_instances=r,
+                  num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms, record_out_terms=out_terms)
+             for i, r in enumerate(logs)]
+    if bad is not None:
+        tasks[bad]["log2_num_instances"] += 1   # (the witness tables are shorter than the task says: utils.rs:713-723 refuses it)
+    return prover.ChipTasks(tasks), cols, (alpha, beta), len(logs)
+
+
+def _proofs_words(proofs, forks):
+    return [None if p is None else (p.tower_msgs.tolist(), p.tower_prod_evals.tolist(), p.tower_logup_evals.tolist(), p.tower_point.tolist(),
+                                    np.asarray(p.rt_main).tolist(), list(f.sample_ext())) for p, f in zip(proofs, forks)]
+
+
+@pytest.mark.gpu
+def test_one_bad_task_fails_alone_in_the_cohort_phase(dev, prover):
+    """twelve chips through ceno_prover_create_chip_proofs (the cohort path: records, towers and tower layers of all chips in shared launches), one of
+    them with a task its tables do not fit: that task's status says so, the other eleven proofs are the words of a run without it, nothing stays
+    allocated, and the next run on the context is unharmed"""
+    good, cols_g, (alpha, beta), n = _twelve_chips(dev, prover)
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n)]
+    want = _proofs_words(prover.create_chip_proofs(dev, good, [alpha, beta], forks, 4), forks)
+    dev.sync()
+    base = dev.mem_info()["pool_used"]
+    bad_tasks, cols_b, _, _ = _twelve_chips(dev, prover, bad=5)
+    base_b = dev.mem_info()["pool_used"]
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n)]
+    st = []
+    got = _proofs_words(prover.create_chip_proofs(dev, bad_tasks, [alpha, beta], forks, 4, statuses=st), forks)
+    assert st[5] != 0 and all(x == 0 for i, x in enumerate(st) if i != 5), st
+    assert got[5] is None
+    for i in range(n):
+        if i != 5:
+            assert got[i] == want[i], i
+    dev.sync()
+    assert dev.mem_info()["pool_used"] == base_b, "the failed run left device memory allocated"
+    with pytest.raises(Exception):
+        prover.create_chip_proofs(dev, bad_tasks, [alpha, beta], [prover.Transcript.stub(0xF0 + i) for i in range(n)], 4)   # (without statuses: raises)
+    for c in cols_b:
+        for m in c:
+            m.free()
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n)]
+    assert _proofs_words(prover.create_chip_proofs(dev, good, [alpha, beta], forks, 4), forks) == want
+    for c in cols_g:
+        for m in c:
+            m.free()
+    dev.sync()
+    assert dev.mem_info()["pool_used"] <= base
+
+
+@pytest.mark.gpu
+def test_chip_proofs_fall_back_to_lanes_when_the_phase_cannot_be_booked(dev, prover):
+    """the cohort path keeps every chip's towers resident and books the whole phase at once; on a context whose pool cannot promise that (pool_bytes)
+    the phase runs chip by chip on the lanes, each task booked by itself (scheduler.rs:342-347,622-652) — same proofs"""
+    from ceno_amd import Device
+
+    tasks, cols, (alpha, beta), n = _twelve_chips(dev, prover)
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n)]
+    want = _proofs_words(prover.create_chip_proofs(dev, tasks, [alpha, beta], forks, 4), forks)
+    for c in cols:
+        for m in c:
+            m.free()
+    d = Device(0, pool_bytes=1 << 30)   # the phase's booking is the sum of the estimates plus 1 GiB of cohort scratch: refused
+    tasks, cols, _, _ = _twelve_chips(d, prover)
+    d.L.ceno_hip_mem_booked_peak(d.h, 1)
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n)]
+    got = _proofs_words(prover.create_chip_proofs(d, tasks, [alpha, beta], forks, 4), forks)
+    assert got == want
+    assert 0 < int(d.L.ceno_hip_mem_booked_peak(d.h, 0)) < (1 << 30)   # per-task bookings, never the whole phase
+    for c in cols:
+        for m in c:
+            m.free()
+    d.close()
+
+
 def _stub_absorb(t, word):
     """one absorb step of the SplitMix stub transcript (oracle/oracle.c orc_stub_*; host/transcript.cpp Stub::absorb)"""
     M = (1 << 64) - 1
