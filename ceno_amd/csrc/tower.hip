@@ -234,20 +234,18 @@ __global__ void __launch_bounds__(NT) k_virtual_last_layer(const VtJob* __restri
     const VtJob J = jobs[b.job];
     WiLds L{};
     if (!J.ones) L = wi_stage<NT>(dyn, J.pl, J.num_mles, J.num_terms, J.num_factors, false);
-    // one work item = (limb, a chunk of <= 4 consecutive records, one row), rows fastest: a wave walks the SAME records over 64 consecutive rows —
-    // one control flow, coalesced column reads — and every lane writes its 1 .. 4 values side by side (one 64-byte line for a full chunk)
-    const int S = 1 << J.log_s, CH = S < 4 ? S : 4, n_chunks = S / CH;
-    const size_t half = J.half, stride = (size_t)b.nblk * NT, items = 2 * half * (size_t)n_chunks;
-    for (size_t it = (size_t)b.blk * NT + threadIdx.x; it < items; it += stride) {
-        const size_t i = it % half, rest = it / half;  // (half is a power of two)
-        const int c = (int)(rest % (size_t)n_chunks), limb = (int)(rest / (size_t)n_chunks);
-        E2* dst = (limb ? J.out1 : J.out0) + (i << J.log_s) + (size_t)c * CH;
-        for (int jj = 0; jj < CH; jj++) {
-            const int j = c * CH + jj;
-            E2 v = J.dflt;
-            if (!J.ones && j < J.k) v = wi_eval(L, J.rec0 + j, (limb ? half : 0) + i);
-            dst[jj] = v;
-        }
+    // one work item = one element of the last layer, consecutive lanes = consecutive slots of a row (coalesced writes; the lanes of a row read the
+    // same witness words).  Measured against a wave walking the same records over 64 consecutive rows (coalesced reads, one control flow, a
+    // 64-byte line written per lane): 0.49 against 0.62 ms per shard — the writes are what matters (profiles/r06_shard_wide_kernel_stats.csv)
+    const size_t out_len = J.out_len, stride = (size_t)b.nblk * NT, smask = ((size_t)1 << J.log_s) - 1;
+    for (size_t o = (size_t)b.blk * NT + threadIdx.x; o < 2 * out_len; o += stride) {
+        const int limb = o >= out_len;
+        const size_t x = limb ? o - out_len : o;
+        const size_t i = x >> J.log_s;
+        const int j = (int)(x & smask);
+        E2 v = J.dflt;
+        if (!J.ones && j < J.k) v = wi_eval(L, J.rec0 + j, (limb ? J.half : 0) + i);
+        (limb ? J.out1 : J.out0)[x] = v;
     }
 }
 __global__ void __launch_bounds__(NT) k_layer_many(const LayerJob* __restrict__ jobs, const BlkRef* __restrict__ blks) {
@@ -695,13 +693,13 @@ int ceno_hip_tower_build_many_virtual(ceno_hip_ctx* ctx, const ceno_hip_wit_plan
             pj.out1 = last + out_len;
             q.out0 = last + 2 * out_len;
             q.out1 = last + 3 * out_len;
-            add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len / (size_t)std::min(4, 1 << log_s));
+            add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len);
             jobs.push_back(pj);
         } else {
             q.out0 = last;
             q.out1 = last + out_len;
         }
-        add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len / (size_t)std::min(4, 1 << log_s));
+        add_blocks(blks, (uint32_t)jobs.size(), 2 * out_len);
         jobs.push_back(q);
     }
     // the head of the blob: plans, then the jobs; towers_build_upper_many appends the levels and launches everything

@@ -263,14 +263,26 @@ struct ceno_hip_cohort {
     uint64_t* d_area = nullptr;      // its device view
     Mailbox* boxes = nullptr;        // device memory the host writes (large BAR): one 64-byte line per job
     bool own_boxes = false;
+    size_t box_first = 0;            // its first line in the arena
 };
 namespace {
 constexpr size_t COHORT_H_WORDS = 8 * COHORT_SUB + 2 * 16;
 // host-writable device memory for the challenge mailboxes: one arena per context, grown on demand, kept for the context's life
 struct BoxArena {
     void* p = nullptr;
-    size_t lines = 0, next = 0;  // bump allocation: lines [0, next) belong to live cohorts
-    int live = 0;                // cohorts holding lines; the bump pointer goes back to 0 when the last one ends
+    size_t lines = 0;
+    std::map<size_t, size_t> live;  // first line -> lines of every cohort that holds some (a handful: first fit over the gaps)
+    bool take(size_t n, size_t* first) {
+        size_t at = 0;
+        for (const auto& r : live) {
+            if (r.first - at >= n) break;
+            at = r.first + r.second;
+        }
+        if (at + n > lines) return false;
+        live[at] = n;
+        *first = at;
+        return true;
+    }
 };
 std::mutex g_box_mu;
 std::map<ceno_hip_ctx*, BoxArena> g_box;
@@ -366,11 +378,11 @@ int ceno_hip_tower_cohort_open(ceno_hip_ctx* ctx, const ceno_hip_cohort_shape* s
                 A.lines = lines;
             }
         }
-        if (!rc && A.next + (size_t)n_jobs > A.lines) rc = ctx_fail(ctx, CENO_HIP_ERR_OOM, "tower cohort: more than %zu mailboxes in flight on one context", A.lines);
+        size_t first = 0;
+        if (!rc && !A.take((size_t)n_jobs, &first)) rc = ctx_fail(ctx, CENO_HIP_ERR_OOM, "tower cohort: more than %zu mailboxes in flight on one context", A.lines);
         if (!rc) {
-            c->boxes = reinterpret_cast<Mailbox*>((char*)A.p + 64 * A.next);
-            A.next += (size_t)n_jobs;
-            A.live++;
+            c->boxes = reinterpret_cast<Mailbox*>((char*)A.p + 64 * first);
+            c->box_first = first;
             c->own_boxes = true;
         }
     }
@@ -451,8 +463,7 @@ int ceno_hip_tower_cohort_set_job(ceno_hip_cohort* c, int j, const ceno_hip_coho
 static void cohort_release(ceno_hip_ctx* ctx, ceno_hip_cohort* c) {
     if (c->own_boxes) {
         std::lock_guard<std::mutex> g(g_box_mu);
-        BoxArena& A = g_box[ctx];
-        if (--A.live == 0) A.next = 0;
+        g_box[ctx].live.erase(c->box_first);
         c->own_boxes = false;
     }
     ctx_pinned_free(ctx, c->h_area);

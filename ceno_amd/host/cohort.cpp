@@ -41,10 +41,11 @@ void prover_host_tower_rounds(int n, std::vector<std::vector<E2>>& tabs, int n_p
 
 namespace {
 
+double now_ms();
 struct SpinBarrier {
     std::atomic<int> arrived{0}, gen{0};
     int n = 1;
-    void wait() {
+    void wait(int who = -1, int site = 0) {
         const int g = gen.load(std::memory_order_acquire);
         if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
             arrived.store(0, std::memory_order_relaxed);
@@ -52,8 +53,20 @@ struct SpinBarrier {
             return;
         }
         int spins = 0;
+        double t0 = 0;
+        bool said = false;
         while (gen.load(std::memory_order_acquire) == g)
-            if (++spins > 2000) sched_yield();
+            if (++spins > 2000) {
+                sched_yield();
+                if ((spins & 0xFFFF) == 0) {  // (a thread that never arrives is a bug of this file: say where the others stand)
+                    if (t0 == 0) t0 = now_ms();
+                    else if (!said && now_ms() - t0 > 20000.0) {
+                        fprintf(stderr, "[ceno_prover] cohort: thread %d has waited 20 s at barrier site %d (generation %d, %d of %d arrived)\n", who, site, g,
+                                arrived.load(), n);
+                        said = true;
+                    }
+                }
+            }
     }
 };
 
@@ -333,7 +346,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         // ---- A1: the checks and the record plans (host work), then ONE launch for the records of all chips ----
         for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads)
             status[i] = chip_run_records_plan(*runs[i], ctx, &tasks[i], challenges4, transcripts[i], &out_proofs[i], &plans[i]);
-        bar.wait();
+        bar.wait(t, 1);
         // ---- A2 ----
         if (t == 0) {
             // the towers of all chips: straight from the record expressions (no record tables: the reference's ..._from_virtual_ext_batch), or —
@@ -387,7 +400,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             }
             t_a2 = now_ms() - t_start;
         }
-        bar.wait();
+        bar.wait(t, 2);
         if (err.load()) return;
         // ---- A3 ----
         for (size_t i = (size_t)t; i < runs.size(); i += (size_t)n_threads) {
@@ -402,14 +415,14 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             }
             status[i] = rc;
         }
-        bar.wait();
+        bar.wait(t, 3);
         if (t == 0) t_a3 = now_ms() - t_start;
         // ---- B ----
         if (t == 0) {
             build_schedule();
             if (!launches.empty()) open_launch(launches[0]);
         }
-        bar.wait();
+        bar.wait(t, 4);
         const bool serves = n_threads == 1 || t > 0;
         const size_t n_serving = (size_t)std::max(1, n_threads - 1), me = n_threads == 1 ? 0 : (size_t)t - 1;
         auto fail_with = [&](int rc, const char* msg) {
@@ -423,14 +436,14 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                     prepare(la.chips[i], la.chips[i].run, la.L, la.n_lo);
                     if (const int rc = set_jobs(la.co, la.chips[i])) fail_with(rc, "cohort: a job record was refused");
                 }
-            bar.wait();
+            bar.wait(t, 5);
             const double t_begin = now_ms();
             if (t == 0) {
                 if (!err.load())
                     if (const int rc = ceno_hip_tower_cohort_launch(ctx, la.co)) fail_with(rc, ceno_hip_last_error(ctx));
                 go.store(err.load() == 0);  // (ONE decision per launch, taken between two barriers: every thread leaves the loop at the same place)
             }
-            bar.wait();
+            bar.wait(t, 6);
             if (!go.load()) break;
             auto serve_mine = [&]() {
                 size_t open = 0;
@@ -465,7 +478,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 coordinate();
             else
                 serve_mine();
-            bar.wait();
+            bar.wait(t, 7);
             if (t == 0 && trace) {
                 double mx = 0, sum = 0;
                 for (double& b : busy) {
@@ -495,7 +508,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 }
             }
         }
-        bar.wait();  // (every thread has left the loop: nobody reads a cohort any more)
+        bar.wait(t, 8);  // (every thread has left the loop: nobody reads a cohort any more)
         if (t == 0)
             for (auto& la : launches) close_launch(la, err.load() != 0);  // (the last one; after an error: whatever is open, its workgroups released)
     };

@@ -295,3 +295,34 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
     if (rc_b) return prover_set_error(rc_b, msg_b.c_str());
     return first_err ? prover_set_error(first_err, "create_chip_proofs: a task failed (see the per-task status)") : 0;
 }
+
+// ZKVMProver::run_chip_proofs (ceno_zkvm/src/scheme/prover.rs:618-710) with the scheduler's forking (`ChipScheduler::execute`,
+// scheduler.rs:231-336: one clone of the fork transcript per task): every task's transcript is a clone of `fork_parent` bound to the two
+// global challenges and the task's words (task id, circuit index, instance counts: prover.rs:646-654) "in the same order as verifier";
+// after the proofs one sample of every fork goes back to the caller, who merges them into the main transcript (prover.rs:567-570).
+extern "C" int ceno_prover_run_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4, const ceno_transcript* fork_parent,
+                                           const uint64_t* bind_words, const uint32_t* bind_offsets, int n_lanes, ceno_chip_proof* out_proofs,
+                                           uint64_t* out_samples, int* out_status) {
+    if (!ctx || !tasks || !challenges4 || !fork_parent || !bind_offsets || !out_proofs || !out_samples || n_tasks < 0 || n_lanes < 1)
+        return prover_set_error(CENO_HIP_ERR_INVALID, "run_chip_proofs: bad arguments");
+    std::vector<ceno_transcript*> forks((size_t)n_tasks, nullptr);
+    auto free_forks = [&]() {
+        for (auto* f : forks)
+            if (f) ceno_transcript_free(f);
+    };
+    for (int i = 0; i < n_tasks; i++) {
+        ceno_transcript* f = ceno_transcript_clone(fork_parent);
+        if (!f) {
+            free_forks();
+            return prover_set_error(CENO_HIP_ERR_INVALID, "run_chip_proofs: the fork transcript cannot be cloned");
+        }
+        forks[(size_t)i] = f;
+        f->append_ext(f->self, challenges4);
+        f->append_ext(f->self, challenges4 + 2);
+        for (uint32_t k = bind_offsets[i]; k < bind_offsets[i + 1]; k++) f->append_base(f->self, bind_words[k]);
+    }
+    const int rc = ceno_prover_create_chip_proofs(ctx, tasks, n_tasks, challenges4, forks.data(), n_lanes, out_proofs, out_status);
+    for (int i = 0; i < n_tasks; i++) forks[(size_t)i]->sample_ext(forks[(size_t)i]->self, out_samples + 2 * (size_t)i);
+    free_forks();
+    return rc;
+}

@@ -3,7 +3,9 @@
 // hands run(n, fn) the caller's thread as worker 0 and n - 1 parked ones as workers 1 .. n - 1; a run that finds the pool busy starts its own threads.
 // The threads are detached and the pool is never destroyed: nothing to join at process exit.
 #pragma once
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -45,7 +47,8 @@ public:
         cv_.notify_all();
         fn(0);
         std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [&] { return left_ == 0; });
+        while (!done_cv_.wait_for(lk, std::chrono::seconds(30), [&] { return left_ == 0; }))
+            fprintf(stderr, "[ceno_prover] worker pool: a run of %d has waited 30 s for %d of its workers\n", n, left_);
         fn_ = nullptr;
     }
 

@@ -638,18 +638,14 @@ class ShardFlowWide:
         res["chip_proof_booking_estimates_bytes_sum"] = int(sum(prover.chip_proof_estimate_bytes(t) for t in tasks))
         proofs, samples = [], []
 
+        # every task's transcript is forked INSIDE the library from one parent and bound to the challenges and the task's words (task id, circuit
+        # index, instance counts: ZKVMProver::run_chip_proofs, prover.rs:618-710); one sample per fork comes back for the main transcript
+        bind_words = [(c, c, ch["n_inst"], 0) for c, ch in enumerate(self.chips)]
+
         def chip_proofs():
-            forks = []
-            for c, ch in enumerate(self.chips):
-                fork = fork_factory()
-                fork.append_ext(alpha)
-                fork.append_ext(beta)
-                for v in (c, c, ch["n_inst"], 0):
-                    fork.append_base(v)
-                forks.append(fork)
-            proofs.extend(prover.create_chip_proofs(dev, ct, [alpha, beta], forks, max(1, lanes)))
-            for f in forks:
-                samples.append(f.sample_ext())
+            pr, sm = prover.run_chip_proofs(dev, ct, [alpha, beta], fork_factory(), bind_words, max(1, lanes))
+            proofs.extend(pr)
+            samples.extend(sm)
             for s_ in samples:
                 tr.append_ext(s_)
 

@@ -410,6 +410,13 @@ int ceno_prover_lanes_effective(int n_lanes);
  * against the pool.  out_proofs[i] are released with ceno_chip_proof_free; out_status (may be NULL) receives every task's code. */
 int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4,
                                    ceno_transcript* const* transcripts, int n_lanes, ceno_chip_proof* out_proofs, int* out_status);
+/* ZKVMProver::run_chip_proofs (prover.rs:618-710) with the scheduler's forking (scheduler.rs:231-336): task i's transcript is a clone of
+ * `fork_parent` bound to the two global challenges and then to bind_words[bind_offsets[i] .. bind_offsets[i + 1]) as base-field elements (task id,
+ * circuit index, instance counts: prover.rs:646-654, the verifier's order); after the proofs ONE extension sample of every fork is returned in
+ * out_samples (n_tasks x 2 words) for the caller to merge into the main transcript (prover.rs:567-570). */
+int ceno_prover_run_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, int n_tasks, const uint64_t* challenges4, const ceno_transcript* fork_parent,
+                                const uint64_t* bind_words, const uint32_t* bind_offsets, int n_lanes, ceno_chip_proof* out_proofs,
+                                uint64_t* out_samples, int* out_status);
 
 const char* ceno_prover_last_error(void);
 
