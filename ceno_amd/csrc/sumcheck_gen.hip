@@ -456,6 +456,11 @@ __device__ __forceinline__ void gen_eq_terms(const GenComp& C, unsigned term_beg
     for (int t = 0; t < NS; t++) out[t] = e2acc_reduce(wacc[t]);
 }
 
+// (A/B, tools/dev/ab_eq5.sh: -DGEN_EQ5_SPLIT=1 -DGEN_EQ5_WAVES=3 = two passes at 168 registers, 7 spilled, three waves per SIMD: 31.7-32.6 ms for the
+// wide batch against 32.2 in one pass at two waves — the second walk over the terms costs what the third wave returns; two passes at two waves: 33.8)
+#ifndef GEN_EQ5_SPLIT
+#define GEN_EQ5_SPLIT 0
+#endif
 // Evaluation SLOTS of an eq group (D = the message length, G has degree <= D - 1):
 //   slot s < D - 1: X = s + 1  (slot D - 2, X = D - 1, only where it is wanted: the first round, and the waves that hold a boundary pair)
 //   slot D - 1:     the coefficient of X^(D-1), up to the sign (-1)^(D-1) the host applies: only terms of D - 1 factors have one
@@ -529,12 +534,37 @@ __device__ __forceinline__ void gen_group_eq(const GenComp& C, unsigned g, const
     } else {
         // two passes keep the registers of the common case at those of a message one point shorter (three waves per SIMD at degree 4):
         // the slots every wave needs — X = 1 .. D - 2 and the leading coefficient — and, where it is wanted, X = D - 1 on its own
+        if constexpr (D == 5 && GEN_EQ5_SPLIT) {
+            // degree 5: the one-pass form holds four product chains and four wide accumulators — 205 registers, two waves per SIMD.  Walking the
+            // terms GEN_EQ5_SPLIT + 1 times with fewer chains each (the staged values are re-read from LDS, the term words from the scalar cache)
+            // keeps every pass at the registers of a shorter message
+            if constexpr (GEN_EQ5_SPLIT == 1) {
+                E2 in_a[3], in_b[1];
+                gen_eq_terms<2, true, 0, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_a);   // X = 1, 2 and the leading coefficient
+                inner[0] = in_a[0];
+                inner[1] = in_a[1];
+                inner[4] = in_a[2];
+                gen_eq_terms<1, false, 2, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_b);  // X = 3
+                inner[2] = in_b[0];
+            } else {
+                E2 in_a[2], in_b[1], in_c[1];
+                gen_eq_terms<1, true, 0, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_a);   // X = 1 and the leading coefficient
+                inner[0] = in_a[0];
+                inner[4] = in_a[1];
+                gen_eq_terms<1, false, 1, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_b);  // X = 2
+                inner[1] = in_b[0];
+                gen_eq_terms<1, false, 2, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_c);  // X = 3
+                inner[2] = in_c[0];
+            }
+            inner[D - 2] = e2_zero();
+        } else {
         E2 in_a[D - 1];
         gen_eq_terms<D - 2, true, 0, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_a);
 #pragma unroll
         for (int t = 0; t < D - 2; t++) inner[t] = in_a[t];
         inner[D - 1] = in_a[D - 2];
         inner[D - 2] = e2_zero();
+        }
         if (extra) {
             E2 in_b[1];
             gen_eq_terms<1, false, D - 2, D>(C, term_begin, term_end, ts, wt, stage, tpp, q, in_b);
