@@ -306,7 +306,9 @@ int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx) {
     std::lock_guard<std::mutex> g(mu);
     auto it = cap.find(ctx->device);
     if (it != cap.end()) return it->second;
-    int per_cu = 0, cus = 0;
+    int per_cu = 0, cus = 0, large_bar = 0;
+    // (no host-writable device memory for the challenge mailboxes: no cohorts on this device — callers take the per-chip path)
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->device) != hipSuccess || !large_bar) return cap[ctx->device] = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tower_cohort, CNT, 0) != hipSuccess) per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) cus = 0;
     // every workgroup of a launch waits for its host: a launch of more workgroups than the device holds at once would leave some undispatched

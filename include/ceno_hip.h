@@ -447,7 +447,8 @@ typedef struct ceno_hip_cohort_job {
     const uint64_t* scale; /* one ext (NULL: one): eq of the sub-cube's index at the layer's high coordinates */
 } ceno_hip_cohort_job;
 int ceno_hip_tower_cohort_max_vars(void);
-/* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host */
+/* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host.
+ * 0 on a device without host-writable device memory (large BAR): no cohorts there */
 int ceno_hip_tower_cohort_capacity(ceno_hip_ctx* ctx);
 int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jobs, int n_jobs, ceno_hip_stream s, ceno_hip_cohort** out);
 /* begin in three steps, for callers with several host threads (a launch of ~1000 jobs: the job records are most of begin's time):
