@@ -233,6 +233,8 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     ceno_hip_stream stream = streams[0];
     static const bool trace = getenv("CENO_COHORT_TRACE") != nullptr;
     static const bool times = getenv("CENO_COHORT_TIMES") != nullptr;
+    const char* e_fail = getenv("CENO_TOWER_COHORT_FAIL_AT");  // (tests: the cohort phase fails while launch k is served)
+    const int fail_at = e_fail ? atoi(e_fail) : -1;
     static const double timeout_ms = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         return 1e3 * (e && atof(e) > 0 ? atof(e) : 60.0);
@@ -254,6 +256,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     };
     std::vector<Launch> launches;
     std::atomic<bool> go{true};
+    bool phase_b_reached = false;  // (an error before the cohort layers — records, towers — is not the cohorts')
     auto build_schedule = [&]() {
         int L0 = 0;
         for (size_t i = 0; i < runs.size(); i++)
@@ -283,6 +286,48 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 launches.push_back(std::move(la));
             }
         }
+    };
+    // Where every chip stands before the first cohort layer — its tower prover's state and a copy of its transcript: if the cohort phase fails
+    // (a launch that cannot be opened, rounds that do not arrive in time on a device somebody else is using, ...) the chips go back there and
+    // their remaining layers are proved chip by chip on the lanes, as if the cohorts had not been tried.  Only for transcripts that can be
+    // cloned and whose clones are released like the original (the library's own; a foreign transcript without `fork`: the failure stands).
+    struct Snap {
+        bool have = false;
+        int round = 0;
+        size_t msg_off = 0;
+        E2 claim{0, 0};
+        bool have_claim = false;
+        std::vector<uint64_t> alpha, out_rt;
+        ceno_transcript* tr = nullptr;
+    };
+    std::vector<Snap> snaps(runs.size());
+    bool can_restore = true;
+    auto take_snapshots = [&]() {
+        for (size_t i = 0; i < runs.size(); i++) {
+            if (status[i] || runs[i]->st.done()) continue;
+            TowerProveState& st = runs[i]->st;
+            Snap& sn = snaps[i];
+            ceno_transcript* t = st.tr;
+            sn.tr = (t && t->fork && t->fork_free && t->destroy == t->fork_free) ? ceno_transcript_clone(t) : nullptr;
+            if (!sn.tr) {
+                can_restore = false;
+                continue;
+            }
+            sn.have = true;
+            sn.round = st.round;
+            sn.msg_off = st.msg_off;
+            sn.claim = st.claim;
+            sn.have_claim = st.have_claim;
+            sn.alpha = st.alpha;
+            sn.out_rt = st.out_rt;
+        }
+    };
+    auto drop_snapshots = [&]() {
+        for (auto& sn : snaps)
+            if (sn.tr) {
+                ceno_transcript_free(sn.tr);
+                sn.tr = nullptr;
+            }
     };
     auto open_launch = [&](Launch& la) {
         const double t_in = trace ? now_ms() : 0;
@@ -420,7 +465,11 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
         // ---- B ----
         if (t == 0) {
             build_schedule();
-            if (!launches.empty()) open_launch(launches[0]);
+            phase_b_reached = true;
+            if (!launches.empty()) {
+                take_snapshots();
+                open_launch(launches[0]);
+            }
         }
         bar.wait(t, 4);
         const bool serves = n_threads == 1 || t > 0;
@@ -446,6 +495,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             bar.wait(t, 6);
             if (!go.load()) break;
             auto serve_mine = [&]() {
+                if (fail_at >= 0 && (size_t)fail_at == k && me == 0) fail_with(CENO_HIP_ERR_STATE, "CENO_TOWER_COHORT_FAIL_AT (a test's failure)");
                 size_t open = 0;
                 for (size_t i = me; i < la.chips.size(); i += n_serving) open++;
                 unsigned spins = 0;
@@ -466,6 +516,8 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                     if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms)
                         fail_with(CENO_HIP_ERR_STATE, "cohort: a tower layer's rounds did not arrive in time (CENO_HIP_PIPE_TIMEOUT_S)");
                 }
+                // nobody answers this launch any more: release its workgroups now (the coordinator may be waiting for its stream)
+                if (err.load()) (void)ceno_hip_tower_cohort_abort(la.co);
             };
             auto coordinate = [&]() {  // while launch k is served: open the next, close the one before (its wait covers launch k: same stream)
                 if (k + 1 < launches.size() && !err.load()) open_launch(launches[k + 1]);
@@ -518,9 +570,29 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     if (trace) fprintf(stderr, "[ceno_prover] chip proofs in cohorts: records %.3f ms, towers of all chips %.3f, to the cohort layers %.3f, cohort layers to %d %.3f\n", t_a1,
                        t_a2 - t_a1, t_a3 - t_a2, last_layer, now_ms() - t_start - t_a3);
     if (const int rc = err.load()) {
+        if (phase_b_reached && can_restore) {
+            // the cohort phase failed: every chip back to where it stood before it (state + transcript), the lanes prove the rest
+            for (size_t i = 0; i < runs.size(); i++) {
+                Snap& sn = snaps[i];
+                if (!sn.have || status[i]) continue;
+                TowerProveState& st = runs[i]->st;
+                st.round = sn.round;
+                st.msg_off = sn.msg_off;
+                st.claim = sn.claim;
+                st.have_claim = sn.have_claim;
+                st.alpha = sn.alpha;
+                st.out_rt = sn.out_rt;
+                std::swap(st.tr->self, sn.tr->self);  // (the clone now holds the used-up state and is released with it)
+            }
+            drop_snapshots();
+            fprintf(stderr, "[ceno_prover] WARNING: the cohort layers of the chip-proof phase failed (%s); the chips' tower proofs restart on the lanes\n", err_msg.c_str());
+            return 0;
+        }
+        drop_snapshots();
         for (size_t i = 0; i < runs.size(); i++)
             if (!status[i] && !runs[i]->st.done()) status[i] = rc;  // (their transcripts may be mid-layer: these proofs are lost)
         return prover_set_error(rc, err_msg.c_str());
     }
+    drop_snapshots();
     return 0;
 }

@@ -8,14 +8,20 @@
 #include <cstdio>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
 class WorkerPool {
 public:
     static WorkerPool& instance() {
-        static WorkerPool* p = new WorkerPool();  // (leaked on purpose)
-        return *p;
+        static WorkerPool* p = [] {
+            // a forked child inherits the pool's bookkeeping but none of its threads: it starts over with an empty pool
+            pthread_atfork(nullptr, nullptr, [] { slot() = new WorkerPool(); });
+            return slot() = new WorkerPool();  // (leaked on purpose)
+        }();
+        (void)p;
+        return *slot();
     }
     // fn(0) on the calling thread, fn(1) .. fn(n - 1) on pool threads; returns when all have returned
     void run(int n, const std::function<void(int)>& fn) {
@@ -53,6 +59,10 @@ public:
     }
 
 private:
+    static WorkerPool*& slot() {
+        static WorkerPool* s = nullptr;
+        return s;
+    }
     void loop(int id) {
         unsigned long long seen = 0;
         for (;;) {

@@ -309,13 +309,15 @@ def test_cohort_layers_write_the_same_proofs(dev, prover, monkeypatch):
     per chip), up to 2^16 (the default; a layer is cut into as many sub-cubes as the device holds at once, the host adds their partial messages
     and proves the last rounds) and 2^18, several launches per layer (a device that holds 24 workgroups), with the host layers moved so that
     the cohorts start at layer 5, with fixed sub-cube sizes (2^13: at most eight per layer; 2^6: thirty-two and five host rounds), and with the
-    towers built from record tables instead of straight from the record expressions (CENO_TOWER_VIRTUAL_RECORDS=0)"""
+    towers built from record tables instead of straight from the record expressions (CENO_TOWER_VIRTUAL_RECORDS=0) — and with the cohort phase
+    FAILING while its first / fifth launch is served (CENO_TOWER_COHORT_FAIL_AT): every chip goes back to where it stood before the cohorts (state
+    and transcript) and the lanes prove the rest: the same proofs again"""
     from ceno_amd import synthetic
 
     flow = synthetic.ShardFlowWide(dev, prover, log_cycles=12, n_queries=8, pow_bits=4)
 
     def run(env):
-        for k in ("CENO_TOWER_COHORT_LAYERS", "CENO_TOWER_COHORT_CAPACITY", "CENO_TOWER_HOST_LAYERS", "CENO_TOWER_COHORT_SUB", "CENO_TOWER_VIRTUAL_RECORDS"):
+        for k in ("CENO_TOWER_COHORT_LAYERS", "CENO_TOWER_COHORT_CAPACITY", "CENO_TOWER_HOST_LAYERS", "CENO_TOWER_COHORT_SUB", "CENO_TOWER_VIRTUAL_RECORDS", "CENO_TOWER_COHORT_FAIL_AT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -325,7 +327,7 @@ def test_cohort_layers_write_the_same_proofs(dev, prover, monkeypatch):
     ref = run({"CENO_TOWER_COHORT_LAYERS": "0"})
     assert max(p[0] for p in ref[0]) >= 18      # the tables' towers reach past every cohort layer tried here
     for env in ({}, {"CENO_TOWER_COHORT_LAYERS": "13"}, {"CENO_TOWER_COHORT_LAYERS": "18"}, {"CENO_TOWER_COHORT_CAPACITY": "24"},
-                {"CENO_TOWER_HOST_LAYERS": "4"}, {"CENO_TOWER_COHORT_SUB": "13"}, {"CENO_TOWER_COHORT_SUB": "6", "CENO_TOWER_COHORT_LAYERS": "11"}, {"CENO_TOWER_VIRTUAL_RECORDS": "0"}):
+                {"CENO_TOWER_HOST_LAYERS": "4"}, {"CENO_TOWER_COHORT_SUB": "13"}, {"CENO_TOWER_COHORT_SUB": "6", "CENO_TOWER_COHORT_LAYERS": "11"}, {"CENO_TOWER_VIRTUAL_RECORDS": "0"}, {"CENO_TOWER_COHORT_FAIL_AT": "0"}, {"CENO_TOWER_COHORT_FAIL_AT": "4"}):
         got = run(env)
         for c, (w, g) in enumerate(zip(ref[0], got[0])):
             assert w == g, (env, flow.chips[c]["name"])
