@@ -235,9 +235,12 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
     static const bool times = getenv("CENO_COHORT_TIMES") != nullptr;
     const char* e_fail = getenv("CENO_TOWER_COHORT_FAIL_AT");  // (tests: the cohort phase fails while launch k is served)
     const int fail_at = e_fail ? atoi(e_fail) : -1;
+    // how long a launch may take before the phase gives up on cohorts (a healthy one takes under a millisecond; after a failure the lanes take
+    // over): CENO_TOWER_COHORT_TIMEOUT_S, 15 s, never more than the device side's own bound CENO_HIP_PIPE_TIMEOUT_S
     static const double timeout_ms = [] {
-        const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
-        return 1e3 * (e && atof(e) > 0 ? atof(e) : 60.0);
+        const char *e = getenv("CENO_HIP_PIPE_TIMEOUT_S"), *c = getenv("CENO_TOWER_COHORT_TIMEOUT_S");
+        const double pipe = e && atof(e) > 0 ? atof(e) : 60.0, mine = c && atof(c) > 0 ? atof(c) : 15.0;
+        return 1e3 * std::min(pipe, mine);
     }();
     SpinBarrier bar;
     bar.n = n_threads;
@@ -514,7 +517,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                         if (c.done) open--;
                     }
                     if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms)
-                        fail_with(CENO_HIP_ERR_STATE, "cohort: a tower layer's rounds did not arrive in time (CENO_HIP_PIPE_TIMEOUT_S)");
+                        fail_with(CENO_HIP_ERR_STATE, "cohort: a tower layer's rounds did not arrive in time (CENO_TOWER_COHORT_TIMEOUT_S)");
                 }
                 // nobody answers this launch any more: release its workgroups now (the coordinator may be waiting for its stream)
                 if (err.load()) (void)ceno_hip_tower_cohort_abort(la.co);
