@@ -78,7 +78,7 @@ __device__ __forceinline__ bool poll_challenge_paced(const Mailbox* mb, unsigned
 }
 
 __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restrict__ jobs) {
-    __shared__ E2 smem[(CNT / 64) * 3];
+    __shared__ E2 smem[(CNT / 64) * 3];  // (two sums per wave; sized for three)
     __shared__ unsigned long long s_c[3];
     __shared__ int s_last;
     __shared__ CohortJob J;
@@ -89,38 +89,45 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
     }
     __syncthreads();
     const int n = J.n, np = J.np, nl = J.nl, K = 1 + 2 * np + 4 * nl;
-    // ---- eq(x, rt) over the n low variables, variable j = bit j of the index ----
+    // ---- the eq factor, taken out of the tables (as in k_tower, sumcheck_tower.hpp): the round polynomial is
+    //   p_i(X) = e_i * eq(X, rt_i) * q_i(X),   q_i(X) = sum_{x'} E_i[x'] F(r_0 .. r_{i-1}, X, x'),   E_i[x'] = eq(x', rt_{i+1 ..}),
+    // q_i of degree 2: the workgroup reports q_i(1) and q_i's leading coefficient (two values, not three evaluations of a cubic; no eq table to
+    // fold); the host knows e_i and the running claim p_i(0) + p_i(1) and makes p_i(1), p_i(2), p_i(3) of them (cohort_message below).
+    // E_{n-1} = [1]; E_{i-1}[2 x + b] = eq(b, rt_i) E_i[x]; E_i lives at eq + 2^(n-1-i) - 1.
     E2* eq = J.eq;
     if (threadIdx.x == 0) eq[0] = e2_one();
     __syncthreads();
-    for (int j = 0; j < n; j++) {
-        const E2 rj = J.rt[j];
-        const size_t half = (size_t)1 << j;
+    for (int lvl = n - 1; lvl >= 1; lvl--) {
+        const E2 rj = J.rt[lvl];
+        const size_t half = (size_t)1 << (n - 1 - lvl);
+        const E2* src = eq + (half - 1);
+        E2* dst = eq + (2 * half - 1);
         for (size_t x = threadIdx.x; x < half; x += CNT) {
-            const E2 lo = eq[x], hi = lo * rj;
-            eq[x + half] = hi;
-            eq[x] = lo - hi;
+            const E2 v = src[x], hi = v * rj;
+            dst[2 * x + 1] = hi;
+            dst[2 * x] = v - hi;
         }
         __syncthreads();
     }
     E2 r = e2_zero();
     unsigned long long t_chal = wall_clock64();  // (lane 0: the start of round 0 = the launch)
-    E2* cur = J.ping;   // tables of the round being evaluated (rounds >= 1): K x len, table m at cur + m * len
+    E2* cur = J.ping;   // tables of the round being evaluated (rounds >= 1): K x len, table m at cur + m * len (slot 0 unused)
     E2* prev = nullptr; // tables of the round before
     size_t prev_len = 0;
     for (int i = 0; i < n; i++) {
         const size_t pairs = (size_t)1 << (n - 1 - i), len = 2 * pairs;
         const E2Pre rp = e2_pre(r);
-        E2 acc[3] = {e2_zero(), e2_zero(), e2_zero()};
+        const E2* W = eq + (pairs - 1);  // E_i
+        E2 acc[2] = {e2_zero(), e2_zero()};
         for (size_t p = threadIdx.x; p < pairs; p += CNT) {
             // (lo, hi) of table m at this pair: round 0 reads the inputs, later rounds fold the previous round's tables and keep the result
             auto load = [&](int m, E2& lo, E2& hi) {
                 if (i == 0) {
-                    const E2* t = m == 0 ? eq : J.in[m - 1];
+                    const E2* t = J.in[m - 1];
                     lo = t[2 * p];
                     hi = t[2 * p + 1];
                 } else {
-                    const E2* q = (i == 1 ? (m == 0 ? eq : J.in[m - 1]) : prev + (size_t)m * prev_len) + 4 * p;
+                    const E2* q = (i == 1 ? J.in[m - 1] : prev + (size_t)m * prev_len) + 4 * p;
                     const E2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
                     lo = a0 + e2_mul_pre(rp, a1 - a0);
                     hi = a2 + e2_mul_pre(rp, a3 - a2);
@@ -129,22 +136,15 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
                     o[1] = hi;
                 }
             };
-            E2 inner[3] = {e2_zero(), e2_zero(), e2_zero()};
+            E2 s1 = e2_zero(), c2 = e2_zero();  // this pair's F at X = 1 and the coefficient of X^2 of F (products of the slopes)
             int m = 1;
             for (int t = 0; t < np; t++, m += 2) {
                 E2 alo, ahi, blo, bhi;
                 load(m, alo, ahi);
                 load(m + 1, blo, bhi);
-                const E2 da = ahi - alo, db = bhi - blo;
-                E2 ca = J.a_prod[t] * ahi;           // the coefficient rides on the first factor
-                const E2 cda = J.a_prod[t] * da;
-                E2 b = bhi;
-#pragma unroll
-                for (int e = 0; e < 3; e++) {
-                    inner[e] = inner[e] + ca * b;
-                    ca = ca + cda;
-                    b = b + db;
-                }
+                const E2 al = J.a_prod[t];
+                s1 = s1 + (al * ahi) * bhi;
+                c2 = c2 + (al * (ahi - alo)) * (bhi - blo);
             }
             for (int k = 0; k < nl; k++, m += 4) {
                 E2 p1l, p1, p2l, p2, q1l, q1, q2l, q2;
@@ -154,25 +154,14 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
                 load(m + 3, q2l, q2);
                 const E2 dp1 = p1 - p1l, dp2 = p2 - p2l, dq1 = q1 - q1l, dq2 = q2 - q2l;
                 const E2 an = J.a_num[k], ad = J.a_den[k];
-#pragma unroll
-                for (int e = 0; e < 3; e++) {
-                    inner[e] = inner[e] + an * (p1 * q2 + p2 * q1) + ad * (q1 * q2);
-                    p1 = p1 + dp1;
-                    p2 = p2 + dp2;
-                    q1 = q1 + dq1;
-                    q2 = q2 + dq2;
-                }
+                s1 = s1 + an * (p1 * q2 + p2 * q1) + ad * (q1 * q2);
+                c2 = c2 + an * (dp1 * dq2 + dp2 * dq1) + ad * (dq1 * dq2);
             }
-            E2 elo, ev;
-            load(0, elo, ev);
-            const E2 de = ev - elo;
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                acc[e] = acc[e] + ev * inner[e];
-                ev = ev + de;
-            }
+            const E2 w = W[p];
+            acc[0] = acc[0] + w * s1;
+            acc[1] = acc[1] + w * c2;
         }
-        red::block_sum<3, CNT>(acc, smem);
+        red::block_sum<2, CNT>(acc, smem);
         // Every store into host memory is a PCIe write, and the device gets ~10 M of them through per second: a layer cut into hundreds of
         // sub-cubes that each sent their own message spent its rounds queueing there (measured: 320 jobs x 4 stores = ~125 us per round).
         // A group therefore adds its messages up on the device — every job stores its scaled share write-through, the job that arrives
@@ -182,7 +171,7 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
             if (threadIdx.x == 0) {
                 uint64_t* row = J.part + 8 * (size_t)J.g;
 #pragma unroll
-                for (int e = 0; e < 3; e++) {
+                for (int e = 0; e < 2; e++) {
                     const E2 v = J.scale * acc[e];
                     st_agent(row + 2 * e, v.c0);
                     st_agent(row + 2 * e + 1, v.c1);
@@ -196,20 +185,20 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
             if (publish) {
                 if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __syncthreads();
-                E2 tot[3] = {e2_zero(), e2_zero(), e2_zero()};
+                E2 tot[2] = {e2_zero(), e2_zero()};
                 for (int b = threadIdx.x; b < J.G; b += CNT) {
                     const uint64_t* row = J.part + 8 * (size_t)b;
 #pragma unroll
-                    for (int e = 0; e < 3; e++) tot[e] = tot[e] + E2{ld_agent(row + 2 * e), ld_agent(row + 2 * e + 1)};
+                    for (int e = 0; e < 2; e++) tot[e] = tot[e] + E2{ld_agent(row + 2 * e), ld_agent(row + 2 * e + 1)};
                 }
                 __syncthreads();  // smem is reused
-                red::block_sum<3, CNT>(tot, smem);
+                red::block_sum<2, CNT>(tot, smem);
 #pragma unroll
-                for (int e = 0; e < 3; e++) acc[e] = tot[e];
+                for (int e = 0; e < 2; e++) acc[e] = tot[e];
             }
         }
-        if (publish && threadIdx.x < 4) {  // lanes 0 .. 3 of wave 0: one coalesced 64-byte store [p(1), p(2), p(3), clocks]
-            E2 v[4] = {acc[0], acc[1], acc[2], E2{(uint64_t)t_chal, (uint64_t)wall_clock64()}};  // (clocks: diagnostics, 100 MHz)
+        if (publish && threadIdx.x < 4) {  // lanes 0 .. 3 of wave 0: one coalesced 64-byte store [q(1), leading coefficient, -, clocks]
+            E2 v[4] = {acc[0], acc[1], e2_zero(), E2{(uint64_t)t_chal, (uint64_t)wall_clock64()}};  // (clocks: diagnostics, 100 MHz)
             E2 mine = v[0];
 #pragma unroll
             for (int e = 1; e < 4; e++) {
@@ -237,9 +226,9 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
         __syncthreads();  // s_c is rewritten by the next round
     }
     // ---- final evaluations: the last round's tables have two entries each ----
-    if ((int)threadIdx.x < K) {
+    if ((int)threadIdx.x >= 1 && (int)threadIdx.x < K) {  // (slot 0, the eq factor's value, is the host's: a product of n numbers it knows)
         const int m = threadIdx.x;
-        const E2* t = n == 1 ? (m == 0 ? eq : J.in[m - 1]) : prev + (size_t)m * prev_len;
+        const E2* t = n == 1 ? J.in[m - 1] : prev + (size_t)m * prev_len;
         put16(J.h_fin + 2 * (size_t)m, t[0] + r * (t[1] - t[0]));
     }
 }
@@ -256,6 +245,16 @@ struct ceno_hip_cohort {
     void* d_group = nullptr;         // pool block: the groups' partial messages and arrival counters
     std::vector<int> leader;         // the job whose try_message yields the group's message
     std::vector<int> np, nl, group_size;
+    // what the host keeps per leader to turn the device's (q_i(1), leading coefficient) into the round message p_i(1), p_i(2), p_i(3)
+    struct Lead {
+        int n = 0;
+        E2 claim{0, 0};
+        std::vector<E2> rt, inv1m, chal, e;  // e[i] = prod_{j < i} eq(r_j, rt_j)
+        E2 q0{0, 0}, c1{0, 0}, c2{0, 0};     // q_{i-1}'s coefficients (with e_{i-1})
+        std::vector<uint64_t> msgs;          // 6 words per finished round
+        std::vector<char> have, have_chal;
+    };
+    std::vector<Lead> lead;                  // indexed by job; only leaders' entries are used
     std::vector<size_t> scratch_off; // a job's scratch inside d_scratch (extension elements)
     size_t jobs_off = 0;             // the job records inside the pinned block (bytes)
     bool launched = false;
@@ -336,6 +335,7 @@ int ceno_hip_tower_cohort_open(ceno_hip_ctx* ctx, const ceno_hip_cohort_shape* s
     c->nl.resize((size_t)n_jobs);
     c->scratch_off.resize((size_t)n_jobs);
     c->group_size.assign((size_t)n_jobs, 1);
+    c->lead.resize((size_t)n_jobs);
     size_t scratch_e2 = 0;
     for (int j = 0; j < n_jobs; j++) {
         const ceno_hip_cohort_shape& G = shapes[j];
@@ -408,6 +408,34 @@ int ceno_hip_tower_cohort_set_job(ceno_hip_cohort* c, int j, const ceno_hip_coho
     if (G.n != c->n[(size_t)j] || G.n_prod != c->np[(size_t)j] || G.n_logup != c->nl[(size_t)j] || !G.rt || !G.tables ||
         (G.share_mailbox_of > 0 ? G.share_mailbox_of - 1 : j) != leader || (G.n_prod && !G.alpha_prod) || (G.n_logup && (!G.alpha_num || !G.alpha_den)))
         return CENO_HIP_ERR_INVALID;
+    if (leader == j) {
+        if (!G.claim) return CENO_HIP_ERR_INVALID;
+        ceno_hip_cohort::Lead& S = c->lead[(size_t)j];
+        S.n = G.n;
+        S.claim = E2{G.claim[0], G.claim[1]};
+        S.rt.resize((size_t)G.n);
+        S.inv1m.assign((size_t)G.n, e2_zero());
+        S.chal.assign((size_t)G.n, e2_zero());
+        S.e.assign((size_t)G.n + 1, e2_one());
+        S.msgs.assign((size_t)6 * G.n, 0);
+        S.have.assign((size_t)G.n, 0);
+        S.have_chal.assign((size_t)G.n, 0);
+        // 1 / (1 - rt_i) for every round, one inversion (prefix products); rt_i = 1 leaves q_i(0) undetermined by the claim
+        std::vector<E2> pre((size_t)G.n, e2_one());
+        E2 run = e2_one();
+        for (int i = 0; i < G.n; i++) {
+            S.rt[(size_t)i] = E2{G.rt[2 * i], G.rt[2 * i + 1]};
+            const E2 v = e2_one() - S.rt[(size_t)i];
+            if (v.c0 == 0 && v.c1 == 0) return CENO_HIP_ERR_UNSUPPORTED;
+            pre[(size_t)i] = run;
+            run = run * v;
+        }
+        E2 inv = e2_inv(run);
+        for (int i = G.n - 1; i >= 0; i--) {
+            S.inv1m[(size_t)i] = inv * pre[(size_t)i];
+            inv = inv * (e2_one() - S.rt[(size_t)i]);
+        }
+    }
     static const unsigned long long ticks = [] {
         const char* e = getenv("CENO_HIP_PIPE_TIMEOUT_S");
         const double sec = e && atof(e) > 0 ? atof(e) : 60.0;
@@ -421,7 +449,8 @@ int ceno_hip_tower_cohort_set_job(ceno_hip_cohort* c, int j, const ceno_hip_coho
         uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)j;
         if (leader == j)
             for (int i = 0; i < 8 * G.n; i++) w[i] = MSG_INVALID;
-        for (int i = 0; i < 2 * K; i++) w[8 * COHORT_SUB + i] = MSG_INVALID;
+        w[8 * COHORT_SUB] = w[8 * COHORT_SUB + 1] = 0;  // (the eq factor's slot: filled by try_final)
+        for (int i = 2; i < 2 * K; i++) w[8 * COHORT_SUB + i] = MSG_INVALID;
     }
     CohortJob& J = reinterpret_cast<CohortJob*>((char*)c->h_area + c->jobs_off)[j];
     memset(&J, 0, sizeof(J));
@@ -496,9 +525,10 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     ceno_hip_cohort* c = nullptr;
     TRY(ceno_hip_tower_cohort_open(ctx, shapes.data(), n_jobs, s, &c));
     for (int j = 0; j < n_jobs; j++)
-        if (ceno_hip_tower_cohort_set_job(c, j, &jobs[j])) {
+        if (const int rj = ceno_hip_tower_cohort_set_job(c, j, &jobs[j])) {
             cohort_release(ctx, c);
-            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: NULL tables / point / alpha powers", j);
+            if (rj == CENO_HIP_ERR_UNSUPPORTED) return ctx_fail(ctx, rj, "tower cohort: job %d: a coordinate of its point is 1 (the claim does not determine the round polynomials)", j);
+            return ctx_fail(ctx, CENO_HIP_ERR_INVALID, "tower cohort: job %d: NULL tables / point / alpha powers / claim", j);
         }
     const int rc = ceno_hip_tower_cohort_launch(ctx, c);
     if (rc) {
@@ -509,16 +539,47 @@ int ceno_hip_tower_cohort_begin(ceno_hip_ctx* ctx, const ceno_hip_cohort_job* jo
     return 0;
 }
 
+// the device's (q_i(1), leading coefficient of q_i) of round i -> p_i(1), p_i(2), p_i(3) with p_i(X) = e_i eq(X, rt_i) q_i(X): q_i(0) from the
+// running claim p_i(0) + p_i(1) = (1 - rt_i) q_i(0) + rt_i q_i(1) (round 0: the layer's claim; later: p_{i-1}(r_{i-1})), as sc_tower_message
+// (sumcheck.hip) does for the fused tower kernel
+static void cohort_message(ceno_hip_cohort::Lead& S, int i, E2 dq1, E2 dc2, uint64_t* h) {
+    const E2 rt = S.rt[(size_t)i];
+    E2 claim = S.claim;
+    if (i > 0) {
+        const E2 rp = S.rt[(size_t)i - 1], r = S.chal[(size_t)i - 1];
+        const E2 eq_r = e2_one() - rp - r + e2_mul_base(rp * r, 2);
+        S.e[(size_t)i] = S.e[(size_t)i - 1] * eq_r;
+        claim = eq_r * (S.q0 + r * (S.c1 + r * S.c2));
+    }
+    const E2 q1 = S.e[(size_t)i] * dq1, c2 = S.e[(size_t)i] * dc2;
+    const E2 q0 = (claim - rt * q1) * S.inv1m[(size_t)i];
+    const E2 c1 = q1 - q0 - c2;
+    const E2 qa = q0 + e2_mul_base(c1, 2) + e2_mul_base(c2, 4), qb = q0 + e2_mul_base(c1, 3) + e2_mul_base(c2, 9);  // q_i(2), q_i(3)
+    const E2 p1 = rt * q1;
+    const E2 p2 = (e2_mul_base(rt, 3) - e2_one()) * qa;  // eq(2, rt) = 3 rt - 1
+    const E2 p3 = (e2_mul_base(rt, 5) - E2{2, 0}) * qb;  // eq(3, rt) = 5 rt - 2
+    h[0] = p1.c0; h[1] = p1.c1; h[2] = p2.c0; h[3] = p2.c1; h[4] = p3.c0; h[5] = p3.c1;
+    S.q0 = q0;
+    S.c1 = c1;
+    S.c2 = c2;
+}
+
 int ceno_hip_tower_cohort_try_message(ceno_hip_cohort* c, int job, int round, uint64_t* out6) {
     if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !out6) return CENO_HIP_ERR_INVALID;
     if (c->leader[(size_t)job] != job) return CENO_HIP_ERR_INVALID;  // a group's message is its leader's
-    const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * (size_t)round;
-    uint64_t v[6];
-    for (int i = 0; i < 6; i++) {
-        v[i] = w[i];
-        if (v[i] >= gl::P) return 0;  // a word the device has not written yet (MSG_INVALID is no field element)
+    ceno_hip_cohort::Lead& S = c->lead[(size_t)job];
+    if (!S.have[(size_t)round]) {
+        if (round > 0 && (!S.have[(size_t)round - 1] || !S.have_chal[(size_t)round - 1])) return CENO_HIP_ERR_STATE;  // rounds are taken in order
+        const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * (size_t)round;
+        uint64_t v[4];
+        for (int i = 0; i < 4; i++) {
+            v[i] = w[i];
+            if (v[i] >= gl::P) return 0;  // a word the device has not written yet (MSG_INVALID is no field element)
+        }
+        cohort_message(S, round, E2{v[0], v[1]}, E2{v[2], v[3]}, S.msgs.data() + 6 * (size_t)round);
+        S.have[(size_t)round] = 1;
     }
-    memcpy(out6, v, sizeof v);
+    memcpy(out6, S.msgs.data() + 6 * (size_t)round, 48);
     return 1;
 }
 
@@ -532,6 +593,8 @@ int ceno_hip_tower_cohort_round_times(ceno_hip_cohort* c, int job, int round, ui
 
 int ceno_hip_tower_cohort_send_challenge(ceno_hip_cohort* c, int job, int round, const uint64_t* chal2) {
     if (!c || job < 0 || job >= c->n_jobs || round < 0 || round >= c->n[(size_t)job] || !chal2 || c->leader[(size_t)job] != job) return CENO_HIP_ERR_INVALID;
+    c->lead[(size_t)job].chal[(size_t)round] = E2{chal2[0], chal2[1]};
+    c->lead[(size_t)job].have_chal[(size_t)round] = 1;
     volatile Mailbox* mb = c->boxes + 2 * (size_t)job;
     mb->chal[0] = chal2[0];
     mb->chal[1] = chal2[1];
@@ -545,9 +608,18 @@ int ceno_hip_tower_cohort_try_final(ceno_hip_cohort* c, int job, uint64_t* out_e
     if (!c || job < 0 || job >= c->n_jobs || !out_evals) return CENO_HIP_ERR_INVALID;
     const volatile uint64_t* w = c->h_area + COHORT_H_WORDS * (size_t)job + 8 * COHORT_SUB;
     const int K = c->K[(size_t)job];
-    for (int i = 0; i < 2 * K; i++)
+    for (int i = 2; i < 2 * K; i++)
         if (w[i] >= gl::P) return 0;
-    for (int i = 0; i < 2 * K; i++) out_evals[i] = w[i];
+    // the eq factor at the point: e_n = prod_j eq(r_j, rt_j), the group's (every member folds the same low variables)
+    ceno_hip_cohort::Lead& S = c->lead[(size_t)c->leader[(size_t)job]];
+    const int n = S.n;
+    if (n < 1 || !S.have_chal[(size_t)n - 1] || !S.have[(size_t)n - 1]) return CENO_HIP_ERR_STATE;
+    const E2 rp = S.rt[(size_t)n - 1], r = S.chal[(size_t)n - 1];
+    const E2 en = S.e[(size_t)n - 1] * (e2_one() - rp - r + e2_mul_base(rp * r, 2));
+    S.e[(size_t)n] = en;
+    out_evals[0] = en.c0;
+    out_evals[1] = en.c1;
+    for (int i = 2; i < 2 * K; i++) out_evals[i] = w[i];
     return 1;
 }
 

@@ -378,6 +378,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             // the sub-cubes of a layer are a group: one mailbox, one message per round (added up on the device, scaled by eq_hi)
             J.share_mailbox_of = c.G > 1 ? c.first_job + 1 : 0;
             J.scale = reinterpret_cast<const uint64_t*>(&c.eq_hi[(size_t)g]);
+            J.claim = reinterpret_cast<const uint64_t*>(&c.run->st.claim);  // (the whole layer's: what its sumcheck proves)
             if (const int rc = ceno_hip_tower_cohort_set_job(co, c.first_job + g, &J)) return rc;
         }
         return 0;
@@ -457,7 +458,9 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 continue;
             }
             int rc = chip_run_after_towers(*runs[i], mine);
-            while (!rc && !runs[i]->st.done() && runs[i]->st.round <= host_layers) {
+            // (the cohort kernel needs the claim of the layer it proves: known from the layer before — layer 1's is never formed, so with
+            // CENO_TOWER_HOST_LAYERS=0 the first layer still goes the per-chip way)
+            while (!rc && !runs[i]->st.done() && (runs[i]->st.round <= host_layers || !runs[i]->st.have_claim)) {
                 rc = tower_state_step(runs[i]->st);
                 if (rc) chip_run_abandon(*runs[i]);
             }
@@ -486,7 +489,8 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             if (serves && !err.load())
                 for (size_t i = me; i < la.chips.size(); i += n_serving) {
                     prepare(la.chips[i], la.chips[i].run, la.L, la.n_lo);
-                    if (const int rc = set_jobs(la.co, la.chips[i])) fail_with(rc, "cohort: a job record was refused");
+                    if (const int rc = set_jobs(la.co, la.chips[i]))
+                        fail_with(rc, rc == CENO_HIP_ERR_UNSUPPORTED ? "cohort: a coordinate of a layer's point is 1" : "cohort: a job record was refused");
                 }
             bar.wait(t, 5);
             const double t_begin = now_ms();

@@ -445,6 +445,10 @@ typedef struct ceno_hip_cohort_job {
                            * try_message(j): the device adds them up, so that a round costs one write to the host however fine the cut.
                            * Final evaluations stay per job. */
     const uint64_t* scale; /* one ext (NULL: one): eq of the sub-cube's index at the layer's high coordinates */
+    const uint64_t* claim; /* one ext, a job that stands alone or leads a group: the sum its (group's) sumcheck proves — the device reports two
+                            * values per round (the eq factor is taken out of the tables and of the evaluation points), the third comes from
+                            * the running claim.  CENO_HIP_ERR_UNSUPPORTED from set_job / begin when a coordinate of rt is 1 (the claim does not
+                            * determine the round polynomial then): prove that layer another way */
 } ceno_hip_cohort_job;
 int ceno_hip_tower_cohort_max_vars(void);
 /* workgroups (= jobs) the device holds at once; a launch of more would leave jobs undispatched behind jobs that wait for their host.

@@ -25,7 +25,7 @@ def dev():
 
 class JobC(C.Structure):
     _fields_ = [("tables", C.POINTER(C.c_void_p)), ("n_prod", C.c_int), ("n_logup", C.c_int), ("n", C.c_int), ("rt", po.u64p),
-                ("alpha_prod", po.u64p), ("alpha_num", po.u64p), ("alpha_den", po.u64p), ("share_mailbox_of", C.c_int), ("scale", po.u64p)]
+                ("alpha_prod", po.u64p), ("alpha_num", po.u64p), ("alpha_den", po.u64p), ("share_mailbox_of", C.c_int), ("scale", po.u64p), ("claim", po.u64p)]
 
 
 def _oracle_layer(tabs, n, np_, nl, rt, a_prod, a_num, a_den, seed):
@@ -42,7 +42,11 @@ def _oracle_layer(tabs, n, np_, nl, rt, a_prod, a_num, a_den, seed):
         coeffs += [an, an, ad]
         terms += [[0, m, m + 3], [0, m + 1, m + 2], [0, m + 2, m + 3]]
         m += 4
-    return po.sumcheck_prove(tables, po.ext(coeffs), terms, n, 3, po.StubTranscript(seed))
+    msgs, chal, fin = po.sumcheck_prove(tables, po.ext(coeffs), terms, n, 3, po.StubTranscript(seed))
+    # the sum the sumcheck proves (the cohort kernel takes it: it reports two values per round, the third comes from the running claim)
+    final = po.sumcheck_expected_from_evals([n] * len(tables), po.ext(coeffs), terms, n, chal, fin)
+    _oracle_layer.claim = po.recover_claim_from_final(final, msgs, chal)
+    return msgs, chal, fin
 
 
 def _run_cohort(dev, cases, group_scales=None):
@@ -52,7 +56,7 @@ def _run_cohort(dev, cases, group_scales=None):
     share_first_mailbox = group_scales is not None
     L = dev.L
     keep, jobs = [], (JobC * len(cases))()
-    for j, (n, np_, nl, tabs, rt, a_prod, a_num, a_den, _) in enumerate(cases):
+    for j, (n, np_, nl, tabs, rt, a_prod, a_num, a_den, _, claim) in enumerate(cases):
         mles = [dev.upload(t) for t in tabs]
         ptrs = (C.c_void_p * len(mles))(*[m.device_ptr for m in mles])
         rt_c, ap, an, ad = (np.ascontiguousarray(x, dtype=np.uint64) for x in (rt, a_prod, a_num, a_den))
@@ -60,6 +64,9 @@ def _run_cohort(dev, cases, group_scales=None):
         J = jobs[j]
         J.tables, J.n_prod, J.n_logup, J.n = ptrs, np_, nl, n
         J.rt, J.alpha_prod, J.alpha_num, J.alpha_den = (x.ctypes.data_as(po.u64p) for x in (rt_c, ap, an, ad))
+        cl = np.array([int(claim[0]), int(claim[1])], dtype=np.uint64)
+        keep.append(cl)
+        J.claim = cl.ctypes.data_as(po.u64p)
         if share_first_mailbox:
             sc = np.ascontiguousarray(group_scales[j], dtype=np.uint64)
             keep.append(sc)
@@ -108,7 +115,7 @@ def _case(n, np_, nl, seed):
     rt = po.rand_ext(n, 7100 + seed)
     a_prod, a_num, a_den = po.rand_ext(max(np_, 1), 7200 + seed), po.rand_ext(max(nl, 1), 7300 + seed), po.rand_ext(max(nl, 1), 7400 + seed)
     omsgs, ochal, ofin = _oracle_layer(tabs, n, np_, nl, rt, a_prod, a_num, a_den, 0xC0 + seed)
-    return (n, np_, nl, tabs, rt, a_prod, a_num, a_den, ochal), (omsgs, ofin)
+    return (n, np_, nl, tabs, rt, a_prod, a_num, a_den, ochal, _oracle_layer.claim), (omsgs, ofin)
 
 
 def test_cohort_jobs_of_every_shape_match_the_oracle(dev):
@@ -142,7 +149,13 @@ def test_sub_cubes_of_a_large_layer_add_up(dev, r, sub, grouped):
     a_prod, a_num, a_den = po.rand_ext(np_, 9200), po.rand_ext(nl, 9300), po.rand_ext(nl, 9400)
     omsgs, ochal, ofin = _oracle_layer(tabs, r, np_, nl, rt, a_prod, a_num, a_den, 0xE0)
     G = 1 << (r - sub)
-    cases = [(sub, np_, nl, [np.ascontiguousarray(t[g << sub: (g + 1) << sub]) for t in tabs], rt[:sub], a_prod, a_num, a_den, ochal[:sub]) for g in range(G)]
+    claim = _oracle_layer.claim   # (the whole layer's: what a GROUP's leader is given)
+    cases = []
+    for g in range(G):
+        sub_tabs = [np.ascontiguousarray(t[g << sub: (g + 1) << sub]) for t in tabs]
+        if not grouped:   # a job that stands alone proves its own sub-cube's sum
+            _oracle_layer(sub_tabs, sub, np_, nl, rt[:sub], a_prod, a_num, a_den, 0xE1)
+        cases.append((sub, np_, nl, sub_tabs, rt[:sub], a_prod, a_num, a_den, ochal[:sub], claim if grouped else _oracle_layer.claim))
     eq_hi = po.build_eq(rt[sub:])
     # grouped: one mailbox and one message per round for all sub-cubes, added up on the device (what host/cohort.cpp launches)
     got = _run_cohort(dev, cases, group_scales=[eq_hi[g] for g in range(G)] if grouped else None)
