@@ -53,6 +53,12 @@ struct CohortJob {
     int G, g;           // jobs in the group (1: no group), this job's place in it
 };
 
+struct CTerm {
+    E2 coef;
+    int a, b;            // table numbers (1 ..: J.in[m - 1])
+    int keep_a, keep_b;  // this term stores the folded table (each table has exactly one keeper)
+};
+
 __device__ __forceinline__ void put16(uint64_t* dst, E2 v) {
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     const u4 w = {(unsigned)v.c0, (unsigned)(v.c0 >> 32), (unsigned)v.c1, (unsigned)(v.c1 >> 32)};
@@ -82,6 +88,8 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
     __shared__ unsigned long long s_c[3];
     __shared__ int s_last;
     __shared__ CohortJob J;
+    __shared__ CTerm s_terms[3 + 3 * 2];
+    __shared__ int s_nterms;
     {   // the job record: one cooperative copy into LDS (its pointer arrays are indexed at run time)
         const uint64_t* src = reinterpret_cast<const uint64_t*>(jobs + blockIdx.x);
         uint64_t* dst = reinterpret_cast<uint64_t*>(&J);
@@ -89,6 +97,17 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
     }
     __syncthreads();
     const int n = J.n, np = J.np, nl = J.nl, K = 1 + 2 * np + 4 * nl;
+    if (threadIdx.x == 0) {  // F's bilinear terms (the small rounds walk them lane-parallel); every table is kept by exactly one of them
+        int u = 0, m = 1;
+        for (int t = 0; t < np; t++, m += 2) s_terms[u++] = CTerm{J.a_prod[t], m, m + 1, 1, 1};
+        for (int k = 0; k < nl; k++, m += 4) {
+            s_terms[u++] = CTerm{J.a_num[k], m, m + 3, 1, 1};      // an p1 q2
+            s_terms[u++] = CTerm{J.a_num[k], m + 1, m + 2, 1, 1};  // an p2 q1
+            s_terms[u++] = CTerm{J.a_den[k], m + 2, m + 3, 0, 0};  // ad q1 q2
+        }
+        s_nterms = u;
+    }
+    __syncthreads();
     // ---- the eq factor, taken out of the tables (as in k_tower, sumcheck_tower.hpp): the round polynomial is
     //   p_i(X) = e_i * eq(X, rt_i) * q_i(X),   q_i(X) = sum_{x'} E_i[x'] F(r_0 .. r_{i-1}, X, x'),   E_i[x'] = eq(x', rt_{i+1 ..}),
     // q_i of degree 2: the workgroup reports q_i(1) and q_i's leading coefficient (two values, not three evaluations of a cubic; no eq table to
@@ -119,6 +138,46 @@ __global__ void __launch_bounds__(CNT) k_tower_cohort(const CohortJob* __restric
         const E2Pre rp = e2_pre(r);
         const E2* W = eq + (pairs - 1);  // E_i
         E2 acc[2] = {e2_zero(), e2_zero()};
+        // SMALL rounds (<= CNT / 4 pairs): one pair per lane would be a chain of ~36 dependent extension multiplications (~10 us) on a few
+        // lanes while the rest of the workgroup idles.  F is a sum of BILINEAR terms coef * A(X) * B(X) (a product tower: alpha a b; a LogUp
+        // tower: an p1 q2, an p2 q1, ad q1 q2): R = 4 or 8 lanes share a pair, lane `role` takes the terms role, role + R, ... — the same
+        // instructions on different tables (no divergence), 8 multiplications per term; a table two terms read is folded twice and stored once.
+        const int R = pairs * 8 <= (size_t)CNT ? 8 : (pairs * 4 <= (size_t)CNT ? 4 : 1);
+        if (R > 1) {
+            const size_t p = threadIdx.x / (unsigned)R;
+            const int role = (int)(threadIdx.x % (unsigned)R);
+            if (p < pairs) {
+                E2 s1 = e2_zero(), c2 = e2_zero();
+                for (int u = role; u < s_nterms; u += R) {
+                    const CTerm T = s_terms[u];
+                    auto fold = [&](int m, bool keep, E2& lo, E2& hi) {
+                        if (i == 0) {
+                            const E2* t = J.in[m - 1];
+                            lo = t[2 * p];
+                            hi = t[2 * p + 1];
+                        } else {
+                            const E2* q = (i == 1 ? J.in[m - 1] : prev + (size_t)m * prev_len) + 4 * p;
+                            const E2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+                            lo = a0 + e2_mul_pre(rp, a1 - a0);
+                            hi = a2 + e2_mul_pre(rp, a3 - a2);
+                            if (keep) {
+                                E2* o = cur + (size_t)m * len + 2 * p;
+                                o[0] = lo;
+                                o[1] = hi;
+                            }
+                        }
+                    };
+                    E2 alo, ahi, blo, bhi;
+                    fold(T.a, T.keep_a != 0, alo, ahi);
+                    fold(T.b, T.keep_b != 0, blo, bhi);
+                    s1 = s1 + (T.coef * ahi) * bhi;
+                    c2 = c2 + (T.coef * (ahi - alo)) * (bhi - blo);
+                }
+                const E2 w = W[p];
+                acc[0] = w * s1;
+                acc[1] = w * c2;
+            }
+        } else
         for (size_t p = threadIdx.x; p < pairs; p += CNT) {
             // (lo, hi) of table m at this pair: round 0 reads the inputs, later rounds fold the previous round's tables and keep the result
             auto load = [&](int m, E2& lo, E2& hi) {
