@@ -220,7 +220,10 @@ double now_ms() {
 // a step that concerns all chips (0 when only single chips failed).
 int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uint64_t* challenges4, ceno_transcript* const* transcripts,
                        ceno_chip_proof* out_proofs, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int host_layers, int last_layer,
-                       int n_threads) {
+                       int n_threads, int host_layers_here) {
+    // host_layers: what the tower prover's state fetches of every tower (CENO_TOWER_HOST_LAYERS: the tops' one copy covers it);
+    // host_layers_here <= host_layers: the layers this phase really leaves to the host — a cohort layer of 2^6 .. 2^8 entries costs ~0.15 ms for
+    // all chips, the host ~0.1 ms of every serving thread's time per such layer
     const int sub = ceno_hip_tower_cohort_max_vars();
     int capacity = ceno_hip_tower_cohort_capacity(ctx);
     if (const char* e = getenv("CENO_TOWER_COHORT_CAPACITY"))  // (tests: several launches per layer)
@@ -460,7 +463,7 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
             int rc = chip_run_after_towers(*runs[i], mine);
             // (the cohort kernel needs the claim of the layer it proves: known from the layer before — layer 1's is never formed, so with
             // CENO_TOWER_HOST_LAYERS=0 the first layer still goes the per-chip way)
-            while (!rc && !runs[i]->st.done() && (runs[i]->st.round <= host_layers || !runs[i]->st.have_claim)) {
+            while (!rc && !runs[i]->st.done() && (runs[i]->st.round <= host_layers_here || !runs[i]->st.have_claim)) {
                 rc = tower_state_step(runs[i]->st);
                 if (rc) chip_run_abandon(*runs[i]);
             }
