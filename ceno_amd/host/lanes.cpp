@@ -230,11 +230,11 @@ int phase_c_fn(void* arg, int, ceno_hip_stream stream) {
     }
     return *j->status = chip_run_finish(*j->run, stream);
 }
-// the highest tower layer proved in cohorts: CENO_TOWER_COHORT_LAYERS (0 = the per-chip prover alone; default 18: past that the device-wide kernels of the per-chip prover do better,
+// the highest tower layer proved in cohorts: CENO_TOWER_COHORT_LAYERS (0 = the per-chip prover alone; default 19: past that the device-wide kernels of the per-chip prover do as well or better,
 // profiles/r06_cohort_last_layer.txt)
 int cohort_last_layer() {
     const char* e = getenv("CENO_TOWER_COHORT_LAYERS");
-    const int v = e ? atoi(e) : 18;
+    const int v = e ? atoi(e) : 19;
     return std::max(0, std::min(v, 24));
 }
 }  // namespace
