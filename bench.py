@@ -296,7 +296,7 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
             if bw is None or bl["total_ms"] < bw["total_ms"]:
                 bw = dict(bl, chip_proof_lanes=lanes)
         # the same shard with every chip's tower proof on its own lane (round 5's path: CENO_TOWER_COHORT_LAYERS=0) — what the cohort layers
-        # (host/cohort.cpp: records, towers and tower layers 9..18 of all 54 chips in shared launches) are measured against
+        # (host/cohort.cpp: records, towers and tower layers 6..19 of all 54 chips in shared launches) are measured against
         prev = os.environ.get("CENO_TOWER_COHORT_LAYERS")
         os.environ["CENO_TOWER_COHORT_LAYERS"] = "0"
         try:
@@ -319,8 +319,8 @@ def extra_measurements(dev, prover, new_transcript, transcript_name, reps: int =
         bw["workload"] = ("metric M2 on a shard with the reference's population: 2^20 cycles over 45 opcode circuits (13..47 columns, ~2^10..~2^18 instances "
                           "following an instruction mix, witness generated ON THE DEVICE from resident step records straight into the commitment's storage), "
                           "2 wide circuits (64 / 96 columns), 7 table circuits of 2^16..2^19 rows (mlt from the device lookup counters; 3-7 fixed columns in a "
-                          "FIXED commitment, or 2 structural columns): witgen -> commit -> 54 chip proofs (records, towers and tower layers 9..18 of all chips in "
-                          "shared launches — cohorts —, the larger layers on the lane scheduler; VRAM booked for the phase) -> one "
+                          "FIXED commitment, or 2 structural columns): witgen -> commit -> 54 chip proofs (records, towers and the middle tower layers of all chips in "
+                          "shared launches — cohorts: layers 6..19 —, the larger layers on the lane scheduler; VRAM booked for the phase) -> one "
                           "batched main sumcheck on the wide plans (degree <= 5) -> one opening of witness + fixed commitment; the emulator is upstream "
                           "and excluded, the fixed commitment is set-up (keygen)")
         out["shard_e2e_wide"] = bw
