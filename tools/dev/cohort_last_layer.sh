@@ -1,7 +1,7 @@
 #!/bin/bash
 # the chip-proof phase of the wide shard with the cohort layers off / to 13 / 16 / 18, and the phase trace of one run
 mkdir -p gpurun_out/r06
-out=gpurun_out/r06/cohort_sweep.log
+out=gpurun_out/r06/cohort_last_layer.log
 : > $out
 for L in ${LAYER_LIST:-0 13 16 17 18}; do
   echo "== CENO_TOWER_COHORT_LAYERS=$L" >> $out

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r06
-out=gpurun_out/r06/cohort_sweep5.log
+out=gpurun_out/r06/cohort_trace.log
 : > $out
 for SUB in 0; do
 echo "== CENO_TOWER_COHORT_SUB=$SUB" >> $out
