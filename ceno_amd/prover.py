@@ -855,32 +855,75 @@ class ChipProofC(C.Structure):
                 ("rotation_evals", u64p), ("rotation_points", u64p)]
 
 
+class _ProofBlock:
+    """the C proofs of one phase: released together when the last Python proof that reads them is gone (a Rust caller owns the C buffers the same
+    way; copying 54 proofs out eagerly cost the harness ~0.9 ms per shard)"""
+
+    def __init__(self, outs, n):
+        self.outs, self.n = outs, n
+
+    def __del__(self):
+        try:
+            L = plib()
+            for i in range(self.n):
+                L.ceno_chip_proof_free(C.byref(self.outs[i]))
+        except Exception:  # noqa: BLE001 (interpreter shutdown)
+            pass
+
+
 class ChipProof:
-    """ZKVMChipProof (ceno_zkvm/src/scheme.rs:59-76) copied out of the C structure"""
+    """ZKVMChipProof (ceno_zkvm/src/scheme.rs:59-76): copied out of the C structure at once, or — given the block that owns the C buffers — array by
+    array when first read"""
 
-    def __init__(self, c: ChipProofC):
-        def arr(ptr, n):   # (np.ctypeslib.as_array builds an array interface per call: ~30 us; a buffer view of the same words: ~2 us)
-            if not n:
-                return np.zeros(0, dtype=np.uint64)
-            return np.frombuffer((C.c_uint64 * n).from_address(C.addressof(ptr.contents)), dtype=np.uint64).copy()
+    _LAZY = ("tower_msgs", "tower_prod_evals", "tower_logup_evals", "tower_point", "rt_main", "rotation_msgs", "rotation_evals", "rotation_points")
 
-        nv, R = c.tower_num_vars, c.tower_num_vars - 1
+    def __init__(self, c: ChipProofC, owner: Optional[_ProofBlock] = None):
+        nv = c.tower_num_vars
+        self._c, self._owner = c, owner
         self.num_instances = c.num_instances
         self.r_out_evals = np.array(c.r_out_evals, dtype=np.uint64).reshape(2, 2)[: c.n_r_out]
         self.w_out_evals = np.array(c.w_out_evals, dtype=np.uint64).reshape(2, 2)[: c.n_w_out]
         self.lk_out_evals = np.array(c.lk_out_evals, dtype=np.uint64).reshape(4, 2)[: c.n_lk_out]
         self.tower_num_vars, self.n_prod, self.n_logup = nv, c.n_prod, c.n_logup
-        self.tower_msgs = arr(c.tower.msgs, int(plib().ceno_tower_msgs_words(nv)))
-        self.tower_prod_evals = arr(c.tower.prod_evals, c.n_prod * R * 4).reshape(c.n_prod, R, 2, 2)
-        self.tower_logup_evals = arr(c.tower.logup_evals, c.n_logup * R * 8).reshape(c.n_logup, R, 4, 2)
-        self.tower_point = arr(c.tower.point, 2 * nv).reshape(nv, 2)
-        n = c.num_var_with_rotation
-        self.rt_main = arr(c.rt_main, 2 * n).reshape(n, 2)
         self.n_rotation_pairs = c.n_rotation_pairs
-        if c.n_rotation_pairs:
-            self.rotation_msgs = arr(c.rotation_msgs, n * 4).reshape(n, 2, 2)
-            self.rotation_evals = arr(c.rotation_evals, 6 * c.n_rotation_pairs).reshape(-1, 2)
-            self.rotation_points = arr(c.rotation_points, 6 * n).reshape(3, n, 2)
+        if owner is None:  # (the C buffers go away with the caller: everything now)
+            for k in self._LAZY:
+                if k.startswith("rotation") and not c.n_rotation_pairs:
+                    continue
+                getattr(self, k)
+            self._c = None
+
+    def __getattr__(self, name):  # (only reached for attributes not set yet: the lazy arrays)
+        if name not in ChipProof._LAZY or self.__dict__.get("_c") is None:
+            raise AttributeError(name)
+        c = self._c
+
+        def arr(ptr, n):   # (np.ctypeslib.as_array builds an array interface per call: ~30 us; a buffer view of the same words: ~2 us)
+            if not n:
+                return np.zeros(0, dtype=np.uint64)
+            return np.frombuffer((C.c_uint64 * n).from_address(C.addressof(ptr.contents)), dtype=np.uint64).copy()
+
+        nv, R, n = c.tower_num_vars, c.tower_num_vars - 1, c.num_var_with_rotation
+        if name == "tower_msgs":
+            v = arr(c.tower.msgs, int(plib().ceno_tower_msgs_words(nv)))
+        elif name == "tower_prod_evals":
+            v = arr(c.tower.prod_evals, c.n_prod * R * 4).reshape(c.n_prod, R, 2, 2)
+        elif name == "tower_logup_evals":
+            v = arr(c.tower.logup_evals, c.n_logup * R * 8).reshape(c.n_logup, R, 4, 2)
+        elif name == "tower_point":
+            v = arr(c.tower.point, 2 * nv).reshape(nv, 2)
+        elif name == "rt_main":
+            v = arr(c.rt_main, 2 * n).reshape(n, 2)
+        elif not c.n_rotation_pairs:
+            raise AttributeError(name)
+        elif name == "rotation_msgs":
+            v = arr(c.rotation_msgs, n * 4).reshape(n, 2, 2)
+        elif name == "rotation_evals":
+            v = arr(c.rotation_evals, 6 * c.n_rotation_pairs).reshape(-1, 2)
+        else:
+            v = arr(c.rotation_points, 6 * n).reshape(3, n, 2)
+        self.__dict__[name] = v
+        return v
 
     def tower_round_msgs(self, rnd: int) -> np.ndarray:
         off = sum(r * 6 for r in range(1, rnd))
@@ -1145,12 +1188,9 @@ def run_chip_proofs(dev: Device, tasks, challenges, fork_parent: Transcript, bin
     t0 = time.perf_counter()
     rc = L.ceno_prover_run_chip_proofs(dev.h, ct.arr, ct.n, _p(ch), fork_parent.h, _p(words), _p32(offs), lanes, outs, _p(samples), status)
     create_chip_proofs.last_native_ms = (time.perf_counter() - t0) * 1e3
-    try:
-        _check(rc)
-        return [ChipProof(outs[i]) for i in range(ct.n)], [(int(a), int(b)) for a, b in samples]
-    finally:
-        for i in range(ct.n):
-            L.ceno_chip_proof_free(C.byref(outs[i]))
+    block = _ProofBlock(outs, ct.n)   # (frees the C proofs — also when the check below raises)
+    _check(rc)
+    return [ChipProof(outs[i], block) for i in range(ct.n)], [(int(a), int(b)) for a, b in samples]
 
 
 class PcsData:
