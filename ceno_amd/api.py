@@ -39,6 +39,29 @@ def _ext1(e) -> np.ndarray:
     return a
 
 
+_COLMAP_TYPES: dict = {}
+_COLMAPS: dict = {}
+
+
+def _colmap(n_cols: int, cols, cls=None):
+    """the column map of a witness kernel ({cols[n_cols], num_cols}: the reference's `extract_*_column_map`, made once per circuit) as a ctypes
+    structure — cached: building a Structure class and filling it cost ~40 us per call, 45 calls per shard"""
+    key = (n_cols, cls, tuple(int(c) for c in cols[: n_cols + 1]))
+    m = _COLMAPS.get(key)
+    if m is None:
+        if cls is None:
+            cls = _COLMAP_TYPES.get(n_cols)
+            if cls is None:
+                cls = _COLMAP_TYPES[n_cols] = type(f"ColumnMap{n_cols}", (C.Structure,), {"_fields_": [("cols", C.c_uint32 * n_cols), ("num_cols", C.c_uint32)]})
+        m = cls()
+        for k in range(n_cols):
+            m.cols[k] = key[2][k]
+        m.num_cols = key[2][n_cols]
+        if len(_COLMAPS) < 4096:
+            _COLMAPS[key] = m
+    return m
+
+
 class Device:
     """ceno_hip_ctx: one per process/GPU (reference: process-global CUDA_HAL, gkr_iop/src/gpu/mod.rs:53-66)."""
 
@@ -379,10 +402,7 @@ def witgen_arith(dev: Device, cols, is_sub: bool, records_ptr: int, num_records:
                  lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_add / witgen_sub (ceno_zkvm/src/instructions/gpu/dispatch.rs:509-571): `cols` = the 22 column ids in
     AddColumnMap / SubColumnMap field order followed by num_cols; all pointers are device pointers"""
-    m = ArithColumnMap()
-    for k in range(22):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[22])
+    m = _colmap(22, cols, ArithColumnMap)
     f = dev.L.ceno_hip_witgen_sub if is_sub else dev.L.ceno_hip_witgen_add
     dev.check(f(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
                 fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
@@ -397,10 +417,7 @@ class AddiColumnMap(C.Structure):
 def witgen_addi(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                 shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_addi (GpuWitgenKind::Addi): `cols` = the 18 column ids in AddiColumnMap field order followed by num_cols"""
-    m = AddiColumnMap()
-    for k in range(18):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[18])
+    m = _colmap(18, cols, AddiColumnMap)
     dev.check(dev.L.ceno_hip_witgen_addi(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                          fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                          C.c_void_p(lk_fetch_ptr or None), stream))
@@ -408,13 +425,7 @@ def witgen_addi(dev: Device, cols, records_ptr: int, num_records: int, indices_p
 
 def _witgen_4tab(dev: Device, fn, n_cols: int, cols, records_ptr, num_records, indices_ptr, n, witness_ptr, rows_padded, shard_offset, fetch_base_pc,
                  fetch_num_slots, lk_dynamic_ptr, lk_fetch_ptr, lk_double_u8_ptr, lk_xor_ptr, stream):
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * n_cols), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(n_cols):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[n_cols])
+    m = _colmap(n_cols, cols)
     dev.check(fn(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
                  C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
                  C.c_void_p(lk_double_u8_ptr or None), C.c_void_p(lk_xor_ptr or None), stream))
@@ -439,13 +450,7 @@ def witgen_auipc(dev: Device, cols, records_ptr: int, num_records: int, indices_
 def witgen_slt(dev: Device, cols, is_signed: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_slt (GpuWitgenKind::Slt): `cols` = the 26 column ids in SltColumnMap field order followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 26), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(26):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[26])
+    m = _colmap(26, cols)
     dev.check(dev.L.ceno_hip_witgen_slt(dev.h, C.byref(m), int(is_signed), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                         fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                         C.c_void_p(lk_fetch_ptr or None), stream))
@@ -454,13 +459,7 @@ def witgen_slt(dev: Device, cols, is_signed: bool, records_ptr: int, num_records
 def witgen_slti(dev: Device, cols, is_signed: bool, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                 shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_slti (GpuWitgenKind::Slti): `cols` = the 22 column ids in SltiColumnMap field order followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 22), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(22):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[22])
+    m = _colmap(22, cols)
     dev.check(dev.L.ceno_hip_witgen_slti(dev.h, C.byref(m), int(is_signed), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                          fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                          C.c_void_p(lk_fetch_ptr or None), stream))
@@ -472,13 +471,7 @@ def witgen_branch(dev: Device, cols, is_eq: bool, flag: bool, records_ptr: int, 
     """hal.witgen.witgen_branch_cmp (is_eq False; flag = is_signed, 22 column ids) / witgen_branch_eq (is_eq True; flag = is_beq, 19 column ids)"""
     nc = 19 if is_eq else 22
 
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(nc):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[nc])
+    m = _colmap(nc, cols)
     fn = dev.L.ceno_hip_witgen_branch_eq if is_eq else dev.L.ceno_hip_witgen_branch_cmp
     dev.check(fn(dev.h, C.byref(m), int(flag), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
                  fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
@@ -491,13 +484,7 @@ def witgen_shift(dev: Device, cols, is_imm: bool, kind: int, records_ptr: int, n
     ShiftRColumnMap / ShiftIColumnMap field order followed by num_cols"""
     nc = 40 if is_imm else 47
 
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(nc):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[nc])
+    m = _colmap(nc, cols)
     fn = dev.L.ceno_hip_witgen_shift_i if is_imm else dev.L.ceno_hip_witgen_shift_r
     dev.check(fn(dev.h, C.byref(m), int(kind), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
                  C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None),
@@ -507,13 +494,7 @@ def witgen_shift(dev: Device, cols, is_imm: bool, kind: int, records_ptr: int, n
 def witgen_jalr(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                 shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_jalr (GpuWitgenKind::Jalr): `cols` = the 22 column ids in JalrColumnMap field order followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 22), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(22):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[22])
+    m = _colmap(22, cols)
     dev.check(dev.L.ceno_hip_witgen_jalr(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc,
                                          fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                          C.c_void_p(lk_fetch_ptr or None), stream))
@@ -525,13 +506,7 @@ NO_COLUMN = 0xFFFFFFFF
 def witgen_div(dev: Device, cols, div_kind: int, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_div (div_kind 0 DIV, 1 DIVU, 2 REM, 3 REMU): `cols` = the 39 column ids in DivColumnMap field order followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 39), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(39):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[39])
+    m = _colmap(39, cols)
     dev.check(dev.L.ceno_hip_witgen_div(dev.h, C.byref(m), int(div_kind), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                         fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                         C.c_void_p(lk_fetch_ptr or None), stream))
@@ -541,13 +516,7 @@ def witgen_mul(dev: Device, cols, mul_kind: int, records_ptr: int, num_records: 
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_mul (mul_kind 0 MUL, 1 MULH, 2 MULHU, 3 MULHSU): `cols` = the 26 column ids in MulColumnMap field order (NO_COLUMN in
     rd_high / rs1_ext / rs2_ext for MUL) followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 26), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(26):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[26])
+    m = _colmap(26, cols)
     dev.check(dev.L.ceno_hip_witgen_mul(dev.h, C.byref(m), int(mul_kind), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                         fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                         C.c_void_p(lk_fetch_ptr or None), stream))
@@ -558,13 +527,7 @@ def witgen_load_sub(dev: Device, cols, load_width: int, is_signed: bool, records
                     stream=None):
     """hal.witgen.witgen_load_sub (LH / LHU / LB / LBU): `cols` = the 29 column ids in LoadSubColumnMap field order (NO_COLUMN for the Option fields
     the variant does not have) followed by num_cols"""
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * 29), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(29):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[29])
+    m = _colmap(29, cols)
     dev.check(dev.L.ceno_hip_witgen_load_sub(dev.h, C.byref(m), int(load_width), int(is_signed), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n,
                                              shard_offset, fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded,
                                              C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
@@ -576,13 +539,7 @@ def witgen_mem(dev: Device, cols, is_store, records_ptr: int, num_records: int, 
     ColumnMap field order followed by num_cols; `is_store` = 0 / False (LW), 1 / True (SW), 2 (SH) or 3 (SB)"""
     nc = {0: 23, 1: 23, 2: 24, 3: 29}[int(is_store)]
 
-    class M(C.Structure):
-        _fields_ = [("cols", C.c_uint32 * nc), ("num_cols", C.c_uint32)]
-
-    m = M()
-    for k in range(nc):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[nc])
+    m = _colmap(nc, cols)
     fn = {0: dev.L.ceno_hip_witgen_lw, 1: dev.L.ceno_hip_witgen_sw, 2: dev.L.ceno_hip_witgen_sh, 3: dev.L.ceno_hip_witgen_sb}[int(is_store)]
     dev.check(fn(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset, fetch_base_pc, fetch_num_slots,
                  C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), stream))
@@ -596,10 +553,7 @@ class LuiColumnMap(C.Structure):
 def witgen_lui(dev: Device, cols, records_ptr: int, num_records: int, indices_ptr: int, n: int, witness_ptr: int, rows_padded: int,
                shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0, lk_fetch_ptr: int = 0, stream=None):
     """hal.witgen.witgen_lui (GpuWitgenKind::Lui): `cols` = the 16 column ids in LuiColumnMap field order followed by num_cols"""
-    m = LuiColumnMap()
-    for k in range(16):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[16])
+    m = _colmap(16, cols, LuiColumnMap)
     dev.check(dev.L.ceno_hip_witgen_lui(dev.h, C.byref(m), C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n, shard_offset,
                                         fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded, C.c_void_p(lk_dynamic_ptr or None),
                                         C.c_void_p(lk_fetch_ptr or None), stream))
@@ -614,10 +568,7 @@ def witgen_logic_i(dev: Device, cols, logic_kind: int, records_ptr: int, num_rec
                    rows_padded: int, shard_offset: int = 0, fetch_base_pc: int = 0, fetch_num_slots: int = 0, lk_dynamic_ptr: int = 0,
                    lk_fetch_ptr: int = 0, lk_logic_ptr: int = 0, stream=None):
     """hal.witgen.witgen_logic_i (GpuWitgenKind::LogicI): `cols` = the 24 column ids in LogicIColumnMap field order followed by num_cols"""
-    m = LogicIColumnMap()
-    for k in range(24):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[24])
+    m = _colmap(24, cols, LogicIColumnMap)
     dev.check(dev.L.ceno_hip_witgen_logic_i(dev.h, C.byref(m), logic_kind, C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n,
                                             shard_offset, fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded,
                                             C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), C.c_void_p(lk_logic_ptr or None),
@@ -634,10 +585,7 @@ def witgen_logic_r(dev: Device, cols, logic_kind: int, records_ptr: int, num_rec
                    lk_fetch_ptr: int = 0, lk_logic_ptr: int = 0, stream=None):
     """hal.witgen.witgen_logic_r (ceno_zkvm/src/instructions/gpu/dispatch.rs:574-611): `cols` = the 28 column ids in LogicRColumnMap
     field order followed by num_cols; logic_kind 0 AND / 1 OR / 2 XOR; all pointers are device pointers"""
-    m = LogicRColumnMap()
-    for k in range(28):
-        m.cols[k] = int(cols[k])
-    m.num_cols = int(cols[28])
+    m = _colmap(28, cols, LogicRColumnMap)
     dev.check(dev.L.ceno_hip_witgen_logic_r(dev.h, C.byref(m), logic_kind, C.c_void_p(records_ptr), num_records, C.c_void_p(indices_ptr), n,
                                             shard_offset, fetch_base_pc, fetch_num_slots, C.c_void_p(witness_ptr), rows_padded,
                                             C.c_void_p(lk_dynamic_ptr or None), C.c_void_p(lk_fetch_ptr or None), C.c_void_p(lk_logic_ptr or None),

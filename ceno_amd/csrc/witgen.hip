@@ -12,6 +12,8 @@
 
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int NT = 256;
@@ -286,6 +288,10 @@ struct WitgenSession {
     std::vector<Tab> tabs;
     void* scratch = nullptr;
     hipStream_t stream = nullptr;
+    // chips may run on OTHER streams too (a shard's ~45 witness kernels are small: one after the other they are ~1.3 ms of device time, over four
+    // streams a third of that): a stream seen for the first time waits for the session's set-up (`begun`), the session's end waits for all of them
+    hipEvent_t begun = nullptr;
+    std::vector<hipStream_t> others;
 };
 std::mutex g_sessions_mu;
 std::map<ceno_hip_ctx*, WitgenSession> g_sessions;
@@ -299,7 +305,7 @@ int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[
         std::lock_guard<std::mutex> g(g_sessions_mu);
         auto it = g_sessions.find(ctx);
         if (it != g_sessions.end()) {
-            const WitgenSession& S = it->second;
+            WitgenSession& S = it->second;
             uint32_t* copy[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int t = 0; t < 4; t++) {
                 if (!tabs[t].user) continue;
@@ -309,7 +315,10 @@ int witgen_run(ceno_hip_ctx* ctx, hipStream_t st, size_t n, const LkTab (&tabs)[
                 for (const auto& T : S.tabs)
                     if (T.user == tabs[t].user) CHECK_ARG(ctx, T.slots == tabs[t].slots, "witgen: a session table registered with another slot count");
             }
-            CHECK_ARG(ctx, st == S.stream, "witgen: inside a session every chip runs on the session's stream");
+            if (st != S.stream && std::find(S.others.begin(), S.others.end(), st) == S.others.end()) {
+                HIP_TRY(ctx, hipStreamWaitEvent(st, S.begun, 0));  // (the copies' zero fill, and whatever the caller queued on the session's stream before)
+                S.others.push_back(st);
+            }
             launch(true, copy[0], copy[1], copy[2], copy[3]);
             HIP_TRY(ctx, hipGetLastError());
             return 0;
@@ -1875,6 +1884,14 @@ int ceno_hip_witgen_session_begin(ceno_hip_ctx* ctx, uint32_t* const* dev_tables
         ctx_free(ctx, S.scratch);
         HIP_TRY(ctx, e);
     }
+    hipError_t e_ev = hipEventCreateWithFlags(&S.begun, hipEventDisableTiming);
+    if (e_ev == hipSuccess) e_ev = hipEventRecord(S.begun, st);
+    if (e_ev != hipSuccess) {
+        (void)hipStreamSynchronize(st);
+        if (S.begun) (void)hipEventDestroy(S.begun);
+        ctx_free(ctx, S.scratch);
+        HIP_TRY(ctx, e_ev);
+    }
     uint32_t* p = (uint32_t*)S.scratch;
     for (int t = 0; t < n_tables; t++) {
         S.tabs.push_back({dev_tables[t], slots[t], p});
@@ -1896,12 +1913,24 @@ int ceno_hip_witgen_session_end(ceno_hip_ctx* ctx, ceno_hip_stream s) {
     }
     hipStream_t st = ctx_stream(ctx, s);
     hipError_t e = st == S.stream ? hipSuccess : hipErrorInvalidValue;
+    // the merge follows every chip: the session's stream waits for the other streams the chips ran on (the event is reused: a wait captures the
+    // record before it)
+    for (hipStream_t o : S.others) {
+        if (e != hipSuccess) break;
+        e = hipEventRecord(S.begun, o);
+        if (e == hipSuccess) e = hipStreamWaitEvent(S.stream, S.begun, 0);
+    }
     if (e == hipSuccess) {
         for (const auto& T : S.tabs)
             hipLaunchKernelGGL(k_lk_merge, dim3((unsigned)((T.slots + NT - 1) / NT)), dim3(NT), 0, st, T.copies, T.slots, T.slots, T.user);
         e = hipGetLastError();
     }
-    const hipError_t e2 = hipStreamSynchronize(S.stream);  // the copies go back to the pool only after the stream has consumed them
+    hipError_t e2 = hipStreamSynchronize(S.stream);  // the copies go back to the pool only after the stream has consumed them
+    for (hipStream_t o : S.others) {  // (after an error above the other streams may still be writing the copies)
+        const hipError_t eo = e == hipSuccess ? hipSuccess : hipStreamSynchronize(o);
+        if (e2 == hipSuccess) e2 = eo;
+    }
+    if (S.begun) (void)hipEventDestroy(S.begun);
     ctx_free(ctx, S.scratch);
     HIP_TRY(ctx, e);
     HIP_TRY(ctx, e2);

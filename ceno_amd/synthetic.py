@@ -510,8 +510,9 @@ class ShardFlowWide:
         dev.sync()
 
     # -- one opcode circuit's witness generation, writing at `wptr` (column-major, `rows` words per column) --
-    def _witgen(self, ch, wptr: int, rows: int):
-        api, dev, st = self.api, self.dev, self.stream
+    def _witgen(self, ch, wptr: int, rows: int, st=None):
+        api, dev = self.api, self.dev
+        st = self.stream if st is None else st
         T = {k: m.device_ptr for k, m in self.counters.items()}
         w, call, a = ch["w"], ch["call"], ch["args"]
         common = (self.records.device_ptr, self.n_records, ch["idx"].device_ptr, ch["n_inst"], wptr, rows, 0, self.FETCH_BASE_PC, self.fetch_slots)
@@ -563,11 +564,15 @@ class ShardFlowWide:
         for m in self.counters.values():
             m.fill_zero(st)
         dev.witgen_session_begin([(self.counters[k].device_ptr, v) for k, v in self.counter_slots.items()], st)
+        # the 45 witness kernels are small (2^10 .. 2^18 rows, ~1.3 ms of device time one after the other): they go round-robin over four streams
+        # (the session's per-XCD counter copies take their atomics from any stream); the tables' mlt columns wait for all of them
+        if not hasattr(self, "_wit_streams"):
+            self._wit_streams = [st] + [dev.stream_create() for _ in range(3)]
         try:
             for c, ch in enumerate(self.chips):
                 assert pcs.rows(c) == ch["rows"]
                 if ch["cls"] == "opcode":
-                    self._witgen(ch, pcs.trace_ptr(c), ch["rows"])
+                    self._witgen(ch, pcs.trace_ptr(c), ch["rows"], self._wit_streams[c % len(self._wit_streams)])
                 elif ch["cls"] == "wide":
                     # the host side's witness arriving in place: whole power-of-two blocks of columns of the column-major matrix
                     ptr, left, blk = pcs.trace_ptr(c), ch["w"], 0
@@ -580,7 +585,7 @@ class ShardFlowWide:
                         left -= p2
                         blk += 1
         finally:
-            dev.witgen_session_end(st)
+            dev.witgen_session_end(st)   # (waits for the other streams by itself)
         for c, ch in enumerate(self.chips):
             if ch["cls"] == "table":
                 dev.lk_to_mlt_column(self.counters[ch["src"]].device_ptr, min(ch["n_inst"], self.counter_slots[ch["src"]]), pcs.trace_ptr(c), ch["rows"], st)
@@ -734,4 +739,6 @@ class ShardFlowWide:
             if "idx" in ch:
                 ch["idx"].free()
         self.records.free()
+        for s_ in getattr(self, "_wit_streams", [])[1:]:
+            self.dev.stream_destroy(s_)
         self.dev.stream_destroy(self.stream)

@@ -856,7 +856,8 @@ int ceno_hip_witgen_logic_r(ceno_hip_ctx* ctx, const ceno_hip_logic_r_column_map
  * begin, every chip's kernel is queued behind the previous one, and `end` adds the totals to the registered tables with one merge per
  * table and synchronises.  dev_tables[t]: slots[t] counters, e.g. the dynamic-range table (CENO_HIP_LK_DYNAMIC_SLOTS), the fetch table
  * (fetch_num_slots), the double-u8 and the AND / OR / XOR tables (2^16 each).  A table used inside the session must be registered.
- * One open session per context. */
+ * One open session per context.  Chips inside a session may run on ANY stream of the context: a stream's first chip waits for the session's set-up, and
+ * ceno_hip_witgen_session_end (on the session's stream) waits for every stream the chips ran on before it merges. */
 int ceno_hip_witgen_session_begin(ceno_hip_ctx* ctx, uint32_t* const* dev_tables, const size_t* slots, int n_tables, ceno_hip_stream s);
 int ceno_hip_witgen_session_end(ceno_hip_ctx* ctx, ceno_hip_stream s);
 /* The `mlt` witness column of a table circuit straight from the device counters (no trip through the host): dev_column[i] = dev_counters[i]
