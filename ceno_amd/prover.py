@@ -685,8 +685,11 @@ def prove_batched_main_constraints(dev: Device, jobs, global_challenges, tr: Tra
     rt = np.zeros((mj.max_nv, 2), dtype=np.uint64)
     evals = np.zeros((mj.total_mles, 2), dtype=np.uint64)
     nv_o, d_o = C.c_int(), C.c_int()
-    _check(L.ceno_prover_prove_batched_main_constraints(dev.h, mj.arr, mj.n, _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
-                                                        _p(evals), C.byref(nv_o), C.byref(d_o)))
+    t0 = time.perf_counter()
+    rc = L.ceno_prover_prove_batched_main_constraints(dev.h, mj.arr, mj.n, _p(gc), tr.h, stream, _p(claimed), _p(msgs), _p(rt),
+                                                      _p(evals), C.byref(nv_o), C.byref(d_o))
+    prove_batched_main_constraints.last_native_ms = (time.perf_counter() - t0) * 1e3
+    _check(rc)
     return (int(claimed[0]), int(claimed[1])), msgs, rt, evals
 
 
@@ -1331,7 +1334,10 @@ class PcsData:
         proof = np.zeros(int(L.ceno_prover_basefold_proof_words(ch, len(commits), n_queries)), dtype=np.uint64)
         pp = (u64p * n)(*[_p(x) for x in pts])
         ep = (u64p * n)(*[_p(x) for x in evs])
-        _check(L.ceno_prover_basefold_open(self.dev.h, ch, len(commits), pp, ep, n_queries, pow_bits, transcript.h, self.stream, _p(proof)))
+        t0 = time.perf_counter()
+        rc = L.ceno_prover_basefold_open(self.dev.h, ch, len(commits), pp, ep, n_queries, pow_bits, transcript.h, self.stream, _p(proof))
+        PcsData.last_open_native_ms = (time.perf_counter() - t0) * 1e3
+        _check(rc)
         return proof
 
     def free(self):

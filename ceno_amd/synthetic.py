@@ -691,6 +691,8 @@ class ShardFlowWide:
             off += len(jobs[c]["mles"])
         oproof, res["open_ms"] = timed(lambda: pcs.basefold_open(points + fixed_pts, ev + fixed_ev, self.n_queries, self.pow_bits, tr, more_commits=[self.fixed_pcs]))
         res["total_ms"] = res["witgen_ms"] + res["commit_ms"] + res["chip_proofs_ms"] + res["batched_main_ms"] + res["open_ms"]
+        res["batched_main_native_ms"] = float(getattr(prover.prove_batched_main_constraints, "last_native_ms", 0.0))   # (the C++ calls inside the phases)
+        res["open_native_ms"] = float(getattr(prover.PcsData, "last_open_native_ms", 0.0))
         res["e2e_prover_sec_for_2p20_cycles"] = res["total_ms"] / 1e3
         res["open_proof_bytes"] = int(oproof.size * 8)
         res["n_chips"], res["lanes"] = n_chips, lanes
