@@ -220,7 +220,7 @@ double now_ms() {
 // a step that concerns all chips (0 when only single chips failed).
 int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uint64_t* challenges4, ceno_transcript* const* transcripts,
                        ceno_chip_proof* out_proofs, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int host_layers, int last_layer,
-                       int n_threads, int host_layers_here) {
+                       int n_threads, int host_layers_here, bool more_threads_than_cpus) {
     // host_layers: what the tower prover's state fetches of every tower (CENO_TOWER_HOST_LAYERS: the tops' one copy covers it);
     // host_layers_here <= host_layers: the layers this phase really leaves to the host — a cohort layer of 2^6 .. 2^8 entries costs ~0.15 ms for
     // all chips, the host ~0.1 ms of every serving thread's time per such layer
@@ -508,8 +508,9 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                 if (fail_at >= 0 && (size_t)fail_at == k && me == 0) fail_with(CENO_HIP_ERR_STATE, "CENO_TOWER_COHORT_FAIL_AT (a test's failure)");
                 size_t open = 0;
                 for (size_t i = me; i < la.chips.size(); i += n_serving) open++;
-                unsigned spins = 0;
+                unsigned spins = 0, idle = 0;
                 while (open && !err.load(std::memory_order_relaxed)) {
+                    bool moved = false;
                     for (size_t i = me; i < la.chips.size(); i += n_serving) {
                         LayerChip& c = la.chips[i];
                         if (c.done) continue;
@@ -522,6 +523,13 @@ int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uin
                             break;
                         }
                         if (c.done) open--;
+                        moved = moved || c.done || c.round != round_before;
+                    }
+                    // (threads that poll without yielding starve each other where there are fewer CPUs than threads: a small box, a tight quota)
+                    if (moved) idle = 0;
+                    else if (more_threads_than_cpus && ++idle >= 64) {
+                        sched_yield();
+                        idle = 0;
                     }
                     if ((++spins & 1023) == 0 && now_ms() - t_begin > timeout_ms)
                         fail_with(CENO_HIP_ERR_STATE, "cohort: a tower layer's rounds did not arrive in time (CENO_TOWER_COHORT_TIMEOUT_S)");

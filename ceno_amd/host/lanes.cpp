@@ -193,7 +193,7 @@ extern "C" size_t ceno_prover_chip_proof_estimate_bytes(const ceno_chip_task* t)
 #include "chip_run.hpp"
 int cohort_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip_task* tasks, const uint64_t* challenges4, ceno_transcript* const* transcripts,
                        ceno_chip_proof* out_proofs, std::vector<ChipProofRun*>& runs, std::vector<int>& status, int host_layers, int last_layer,
-                       int n_threads, int host_layers_here);  // cohort.cpp
+                       int n_threads, int host_layers_here, bool more_threads_than_cpus);  // cohort.cpp
 int prover_tower_host_layers();                                                                                                       // prover.cpp
 namespace {
 // CPUs this process may really use: the affinity mask, capped by the cgroup's CPU quota (a container on a 256-thread host with a quota of 16)
@@ -284,7 +284,8 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
     // (the layers the host proves inside the cohort phase: CENO_TOWER_COHORT_HOST_LAYERS, 5, at most the tower prover's own CENO_TOWER_HOST_LAYERS)
     const char* e_hl = getenv("CENO_TOWER_COHORT_HOST_LAYERS");
     const int host_layers_here = std::max(0, std::min(host_layers, e_hl ? atoi(e_hl) : 5));
-    const int rc_b = cohort_chip_proofs(ctx, tasks, challenges4, transcripts, out_proofs, run_ptrs, status, host_layers, last_layer, n_threads, host_layers_here);
+    const int rc_b = cohort_chip_proofs(ctx, tasks, challenges4, transcripts, out_proofs, run_ptrs, status, host_layers, last_layer, n_threads, host_layers_here,
+                                        n_threads > cpu_budget());
     const std::string msg_b = rc_b ? ceno_prover_last_error() : "";
     const double t_b = ms();
     (void)lanes_run_locked(ctx, lanes, lt.data(), n_tasks, nullptr, nullptr);
