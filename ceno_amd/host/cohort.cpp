@@ -1,19 +1,22 @@
-// The chip-proof phase with the MIDDLE tower layers of all chips proved together.
+// The chip-proof phase with the records, the towers and the MIDDLE tower layers of all chips proved together.
 //
 // A shard with the reference's population has ~54 circuits, and each of their tower proofs (CpuTowerProver::create_proof,
 // ceno_zkvm/src/scheme/cpu/mod.rs:346-554) is a chain of ~20 layer sumchecks whose rounds each wait for a transcript challenge from the host.
 // On scheduler lanes (lanes.cpp; the reference's ChipScheduler, scheme/scheduler.rs:231-336) every chip's chain occupies a stream, the device
-// runs four queues at a time, and the layers of 2^9 .. 2^16 entries — too large for the host, far too small to fill the device — make up most
-// of a chip's time: the phase plateaus at ~25 ms however many lanes there are (profiles/r06_shard_wide_lanes.jsonl).  Here those layers run as
-// ONE launch per layer for ALL chips (csrc/tower_cohort.hip: a workgroup per chip, or per 2^13-entry sub-cube of a larger layer, each with its
-// own mailboxes), served by the lane threads:
-//   phase A (lanes)   per chip: records, towers, out-evaluations into its transcript, the layers the host proves (1 .. CENO_TOWER_HOST_LAYERS)
-//   phase B (cohort)  layer by layer for all chips in lock-step: one launch, every chip's rounds answered as its messages arrive; a layer of
-//                     more than 2^13 entries is split by its top index bits, the partial messages are added (scaled by eq over the top
-//                     variables) and the last rounds run on the host over the sub-cubes' final evaluations
-//   phase C (lanes)   per chip: the larger layers on the device-wide kernels, the main point, the rotation argument
+// runs four queues at a time, and the layers of 2^6 .. 2^18 entries — too large for the host, far too small to fill the device — make up most
+// of a chip's time: the phase plateaus at ~25 ms however many lanes there are (profiles/r06_shard_wide_lane_cap_sweep.jsonl).  Here, on ONE
+// pool of host threads (worker_pool.hpp):
+//   A1  every chip's checks and record plan                                                                     all threads
+//   A2  the towers of all chips straight from their record expressions, level-synchronous launches, tops in one copy      thread 0
+//   A3  per chip: out-evaluations into its transcript, the tower prover's state, the layers the host proves (1 .. 5)       all threads
+//   B   layers 6 .. 19 in COHORTS (csrc/tower_cohort.hip): one launch per layer for all chips — a workgroup per chip, or per sub-cube of a
+//       layer cut as finely as the device holds at once, the sub-cubes' messages added up on the device — on a schedule known up front:
+//       thread 0 coordinates (opens launch k + 1 and closes k - 1 while k is served), the others each answer their chips' rounds as the
+//       messages arrive, with the chip's own transcript; the last rounds of a cut layer run on the host over the sub-cubes' evaluations
+//   (then, lanes.cpp)  per chip on the lanes: the larger layers on the device-wide kernels, the main point, the rotation argument
 // Every chip keeps its own forked transcript (prover.rs:556-570), so the proofs are the words the per-chip path writes
-// (tests/test_gpu_shard_wide.py::test_cohort_layers_write_the_same_proofs).
+// (tests/test_gpu_shard_wide.py::test_cohort_layers_write_the_same_proofs).  If phase B fails — a launch that cannot be opened, rounds that do
+// not arrive in time — every chip goes back to where it stood before it (state and transcript) and the lanes prove the rest.
 #include <sched.h>
 
 #include <algorithm>
@@ -81,7 +84,7 @@ struct LayerChip {
     bool started = false, done = false;
     int round = 0, n_got = 0;
     std::vector<char> got;
-    std::vector<uint64_t> part, chal, fin, finbuf;
+    std::vector<uint64_t> chal, fin, finbuf;
 };
 
 // How a layer of 2^L entries is cut for n_chips chips: a sub-cube's rounds are VALU work on one compute unit, so the cut is as fine as the
@@ -144,7 +147,6 @@ void prepare(LayerChip& c, ChipProofRun* run, int L, int n_lo) {
     c.started = c.done = false;
     c.round = c.n_got = 0;
     c.got.assign((size_t)c.G, 0);
-    c.part.assign((size_t)6 * c.G, 0);
     c.chal.assign((size_t)2 * L, 0);
     c.fin.assign((size_t)2 * c.K, 0);
     c.finbuf.assign((size_t)2 * c.K * c.G, 0);
