@@ -9,12 +9,15 @@
 // them resident at once, the host serving them round-robin with each chain's own transcript.
 //
 // One workgroup = one sumcheck of  sum_x eq(x, rt) [ sum_i alpha_i a_i(x) b_i(x) + sum_k (an_k (p1 q2 + p2 q1) + ad_k q1 q2) ]  over n <= 13
-// variables, LSB first: messages p(1), p(2), p(3) per round, the fold of round i fused with the evaluation of round i + 1 (the schedule of
-// every other kernel of this library), final evaluations of all tables at the end.  The eq table is built by the workgroup itself.
-// Layers of MORE than 2^13 entries are split by their TOP index bits into sub-cubes of 2^13 — the trick the multi-rank sumcheck uses
-// between GPUs, here between workgroups: the first 13 rounds fold low variables, which never cross a sub-cube;
-// the host adds the sub-cubes' partial messages (scaled by eq over the high variables) and finishes the remaining <= 4 rounds on the
-// gathered 2^(r-13)-entry tables itself (prover_host_tower_rounds).  No workgroup ever waits for another one.
+// variables, LSB first, the fold of round i fused with the evaluation of round i + 1 (the schedule of every other kernel of this library),
+// final evaluations of all tables at the end.  The eq factor is out of the tables and of the evaluation points: the device reports q_i(1) and
+// q_i's leading coefficient, the library's host side makes the round message p_i(1), p_i(2), p_i(3) of them from the running claim
+// (cohort_message).  Small rounds (<= 64 pairs) walk the polynomial's bilinear terms lane-parallel, 4 or 8 lanes per pair.
+// Layers of more entries than one workgroup should fold are split by their TOP index bits into sub-cubes — the trick the multi-rank sumcheck
+// uses between GPUs, here between workgroups: the first rounds fold low variables, which never cross a sub-cube.  The
+// sub-cubes of a layer are a GROUP: every member stores its message scaled by eq over the top variables, the member that arrives last adds
+// them up and publishes ONE line to the host (a store into host memory is a PCIe write: ~10 M per second get through), all members poll
+// ONE mailbox; the caller finishes the remaining rounds on the sub-cubes' final evaluations itself (prover_host_tower_rounds).
 //
 // Field arithmetic is exact: messages, challenges and evaluations equal the per-chip path's (and the oracle's) bit for bit.
 #include <algorithm>
