@@ -3,6 +3,7 @@
 // hands run(n, fn) the caller's thread as worker 0 and n - 1 parked ones as workers 1 .. n - 1; a run that finds the pool busy starts its own threads.
 // The threads are detached and the pool is never destroyed: nothing to join at process exit.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -15,13 +16,17 @@
 class WorkerPool {
 public:
     static WorkerPool& instance() {
-        static WorkerPool* p = [] {
-            // a forked child inherits the pool's bookkeeping but none of its threads: it starts over with an empty pool
-            pthread_atfork(nullptr, nullptr, [] { slot() = new WorkerPool(); });
-            return slot() = new WorkerPool();  // (leaked on purpose)
-        }();
-        (void)p;
-        return *slot();
+        // a forked child inherits the pool's bookkeeping but none of its threads: its handler only forgets the pool (no allocation, no lock between
+        // fork and exec), the child's first run makes a new one
+        static const int registered = pthread_atfork(nullptr, nullptr, [] { slot().store(nullptr, std::memory_order_relaxed); });
+        (void)registered;
+        WorkerPool* p = slot().load(std::memory_order_acquire);
+        if (!p) {
+            WorkerPool* fresh = new WorkerPool();  // (leaked on purpose; has no threads until its first run)
+            if (slot().compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;
+            else delete fresh;
+        }
+        return *p;
     }
     // fn(0) on the calling thread, fn(1) .. fn(n - 1) on pool threads; returns when all have returned
     void run(int n, const std::function<void(int)>& fn) {
@@ -59,8 +64,8 @@ public:
     }
 
 private:
-    static WorkerPool*& slot() {
-        static WorkerPool* s = nullptr;
+    static std::atomic<WorkerPool*>& slot() {
+        static std::atomic<WorkerPool*> s{nullptr};
         return s;
     }
     void loop(int id) {
