@@ -186,6 +186,11 @@ def lib():
         "ceno_hip_basefold_fold": (i, [vp, vp, i, u64p, vp, vp, vp]),
         "ceno_hip_gather": (i, [vp, vp, sz, i, i, vp, sz, i, i, vp, vp]),
         "ceno_hip_basefold_query_rounds": (i, [vp, C.POINTER(vp), C.POINTER(vp), i, vp, sz, vp, vp]),
+        "ceno_hip_open_rounds_begin": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), vp, C.POINTER(vp)]),
+        "ceno_hip_open_rounds_round": (i, [vp, vp, u64p, u64p]),
+        "ceno_hip_open_rounds_finish": (i, [vp, vp, u64p, u64p]),
+        "ceno_hip_open_rounds_done": (i, [vp]),
+        "ceno_hip_open_rounds_free": (None, [vp, vp]),
         "ceno_hip_merkle_open_batch": (i, [vp, vp, vp, sz, i, vp, vp]),
         "ceno_hip_pow_grind_duplex": (i, [vp, u64p, i, u64p, vp]),
         "ceno_hip_lane_stream": (i, [vp, i, vpp]),

@@ -379,6 +379,44 @@ class Sumcheck:
             pass
 
 
+class OpenRounds:
+    """the commit phase's sumcheck of a batch opening over matrices of mixed heights, one launch per round for all of them
+    (ceno_hip_open_rounds_*, include/ceno_hip.h; protocol: ceno_recursion_v2/src/pcs/mod.rs:1111-1316).  eq / f: extension tables (Mle) per matrix."""
+
+    def __init__(self, dev: Device, eq: Sequence[Mle], f: Sequence[Mle], num_vars: Sequence[int], stream=None):
+        assert len(eq) == len(f) == len(num_vars)
+        self.dev, self.keep, self.n_mats, self.n = dev, (list(eq), list(f)), len(eq), max(num_vars)
+        pe = (C.c_void_p * len(eq))(*[m.device_ptr for m in eq])
+        pf = (C.c_void_p * len(f))(*[m.device_ptr for m in f])
+        nv = (C.c_int * len(num_vars))(*num_vars)
+        h = C.c_void_p()
+        dev.check(dev.L.ceno_hip_open_rounds_begin(dev.h, len(eq), pe, pf, nv, stream, C.byref(h)))
+        self.h = h
+
+    def round(self, challenge_prev=None) -> np.ndarray:
+        out = np.zeros((2, 2), dtype=np.uint64)
+        ch = _p(_ext1(challenge_prev)) if challenge_prev is not None else None
+        self.dev.check(self.dev.L.ceno_hip_open_rounds_round(self.dev.h, self.h, ch, _p(out)))
+        return out
+
+    def finish(self, challenge_last=None) -> np.ndarray:
+        out = np.zeros((self.n_mats, 2), dtype=np.uint64)
+        ch = _p(_ext1(challenge_last)) if challenge_last is not None else None
+        self.dev.check(self.dev.L.ceno_hip_open_rounds_finish(self.dev.h, self.h, ch, _p(out)))
+        return out
+
+    def free(self):
+        if getattr(self, "h", None) and self.dev.h:
+            self.dev.L.ceno_hip_open_rounds_free(self.dev.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---- Basefold commit path over raw device memory (torch tensors or Mle.device_ptr) -----------------
 def ntt_batch(dev: Device, dev_ptr: int, log_n: int, n_cols: int, inverse: bool = False, stream=None):
     dev.check(dev.L.ceno_hip_ntt_batch(dev.h, C.c_void_p(dev_ptr), log_n, n_cols, int(inverse), stream))

@@ -206,6 +206,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
     ceno_hip_stream sx[2] = {nullptr, nullptr};  // tree building runs one round ahead on two alternating streams
     hipEvent_t ev[2] = {nullptr, nullptr};
     int ts_device = 0;
+    ceno_hip_open_rounds* all_rounds = nullptr;  // several height groups: the sumcheck of all matrices behind one handle (one launch per round)
     auto cleanup = [&]() {
         for (int i = 0; i < 2; i++) {
             if (sx[i]) (void)hipStreamSynchronize((hipStream_t)sx[i]);
@@ -215,6 +216,8 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
         sx[0] = sx[1] = nullptr;
         for (auto& g : groups)
             if (g.second.sc) ceno_hip_sumcheck_free(ctx, g.second.sc);
+        if (all_rounds) ceno_hip_open_rounds_free(ctx, all_rounds);
+        all_rounds = nullptr;
         for (auto* t : trees)
             if (t) ceno_hip_merkle_free(ctx, t);
         for (auto* m : owned) ceno_hip_mle_free(ctx, m);
@@ -376,7 +379,11 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
     // a launch and a wait per group; from 2^8 entries down the handles finish on the host as before (no device trip at all).
     // CENO_BASEFOLD_GROUP_ASYNC=0: the old one-by-one rounds (A/B)
     static const bool group_async_on = !(getenv("CENO_BASEFOLD_GROUP_ASYNC") && atoi(getenv("CENO_BASEFOLD_GROUP_ASYNC")) == 0);
-    const bool group_async = group_async_on && !hook && groups.size() > 1;
+    // ... and since round 6 in ONE launch per round for all of them (ceno_hip_open_rounds: the ~8 live groups of a shard's round were 8 slot-table
+    // blits + 8 launches, ~135 us of a 265 us round, queued by this one thread).  CENO_BASEFOLD_OPEN_ROUNDS=0: the handles per group (A/B; read
+    // per call).  With a hook too (the tables are whole on this device either way, and every launch ends without waiting for the host).
+    const bool open_rounds_on = !(getenv("CENO_BASEFOLD_OPEN_ROUNDS") && atoi(getenv("CENO_BASEFOLD_OPEN_ROUNDS")) == 0) && groups.size() > 1 && n > 0;
+    const bool group_async = group_async_on && !hook && groups.size() > 1 && !open_rounds_on;
     ceno_hip_mle* round_buf = nullptr;
     std::vector<uint64_t> round_host;
     if (group_async) {
@@ -386,11 +393,28 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
         if (int rc = alloc_ext(nvb, &round_buf)) return fail(rc);
         round_host.resize(4 * groups.size());
     }
+    if (open_rounds_on) {
+        std::vector<const uint64_t*> pe((size_t)n_mats), pf((size_t)n_mats);
+        std::vector<int> nvs((size_t)n_mats);
+        for (int m = 0; m < n_mats; m++) {
+            pe[(size_t)m] = ceno_hip_mle_device_ptr(Eq[m]);
+            pf[(size_t)m] = ceno_hip_mle_device_ptr(F[m]);
+            nvs[(size_t)m] = flat[m].d->mats[flat[m].m].log_rows;
+        }
+        (void)ceno_hip_stream_bind(ctx, s);
+        if (int rc = ceno_hip_open_rounds_begin(ctx, n_mats, pe.data(), pf.data(), nvs.data(), s, &all_rounds)) return fail(rc);
+    }
     for (int r = 0; r < n; r++) {
         const int h = H - r;
         E2 p1 = gl::e2_zero(), p2 = gl::e2_zero();
         const bool async_round = group_async && (n - r) > 8;
         int n_async = 0;
+        if (all_rounds) {
+            uint64_t ev[4];
+            if (int rc = ceno_hip_open_rounds_round(ctx, all_rounds, r == 0 ? nullptr : &ch[2 * (r - 1)], ev)) return fail(rc);
+            p1 = E2{ev[0], ev[1]};
+            p2 = E2{ev[2], ev[3]};
+        }
         for (auto& kv : groups) {
             Group& g = kv.second;
             const int s_m = n - kv.first;
@@ -403,6 +427,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
                 }
                 continue;
             }
+            if (all_rounds) continue;  // live: in the one launch above
             int rc = 0;
             if (!g.started) {  // becomes live now: terms E_m * F_m over kv.first variables
                 std::vector<ceno_hip_mle*> mles;
@@ -487,7 +512,11 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
     lap("commit phase");
     // ---- final message: F_m at the challenges, one row per opening point ----
     E2 total = gl::e2_zero();
+    if (all_rounds) {
+        if (int rc = ceno_hip_open_rounds_finish(ctx, all_rounds, &ch[2 * (n - 1)], finalm)) return fail(rc);
+    }
     for (auto& kv : groups) {
+        if (all_rounds) break;
         Group& g = kv.second;
         std::vector<uint64_t> fin(4 * g.mats.size());
         int rc = ceno_hip_sumcheck_finish(ctx, g.sc, n ? &ch[2 * (n - 1)] : nullptr, fin.data());

@@ -517,6 +517,23 @@ int ceno_hip_merkle_open_batch(ceno_hip_ctx* ctx, ceno_hip_merkle* t, const uint
  * ceno_hip_gather + ceno_hip_merkle_open_batch).  Query phase of ceno_recursion_v2/src/pcs/mod.rs:7611-7690.  Synchronises. */
 int ceno_hip_basefold_query_rounds(ceno_hip_ctx* ctx, const uint64_t* const* dev_codewords_ext, ceno_hip_merkle* const* trees, int n_rounds,
                                    const uint64_t* dev_indices, size_t n_q, uint64_t* dev_out, ceno_hip_stream s);
+/* The commit phase's sumcheck of a batch opening over matrices of MIXED heights, every live matrix of a round in one launch: the claim is
+ * sum_m sum_x Eq_m(x) * F_m(x) (degree 2; Eq_m = eq(., point_m), F_m = the matrix's columns batched with the batch coefficients — both extension
+ * tables of 2^num_vars[m] entries in device memory, borrowed until _free and left untouched); with n = the most variables of any matrix, matrix m
+ * joins in round n - num_vars[m] (suffix alignment, ceno_recursion_v2/src/pcs/mod.rs:1111-1316).  Replaces one ceno_hip_sumcheck handle per
+ * height group (what PCS::batch_open's prover does per matrix through the EXT crate mpcs; ceno_zkvm/src/scheme/cpu/mod.rs:1418-1457).
+ *   _round:  round r = 0 .. n-1 in order; challenge_prev2 = round r-1's challenge (NULL for round 0).  out_evals4 = (p(1), p(2)) of the LIVE
+ *            matrices' part of the round polynomial — a matrix that joins in a later round j is a constant in this variable (its claimed sum
+ *            times 2^(j - r - 1) at both points): the caller adds those.  Returns when the message is in host memory (the stream is not drained).
+ *   _finish: after round n-1, with its challenge: out_finals[2m .. 2m+1] = F_m(r_{n - nv_m} .. r_{n-1}), the caller's matrix order.
+ * Device memory on top of the inputs: 1.5 x the inputs' bytes (two fold buffers per table) + 40 KB. */
+typedef struct ceno_hip_open_rounds ceno_hip_open_rounds;
+int ceno_hip_open_rounds_begin(ceno_hip_ctx* ctx, int n_mats, const uint64_t* const* dev_eq_ext, const uint64_t* const* dev_f_ext, const int* num_vars,
+                               ceno_hip_stream s, ceno_hip_open_rounds** out);
+int ceno_hip_open_rounds_round(ceno_hip_ctx* ctx, ceno_hip_open_rounds* h, const uint64_t* challenge_prev2, uint64_t* out_evals4);
+int ceno_hip_open_rounds_finish(ceno_hip_ctx* ctx, ceno_hip_open_rounds* h, const uint64_t* challenge_last2, uint64_t* out_finals);
+int ceno_hip_open_rounds_done(const ceno_hip_open_rounds* h); /* rounds produced so far (n + 1 after _finish) */
+void ceno_hip_open_rounds_free(ceno_hip_ctx* ctx, ceno_hip_open_rounds* h);
 /* Proof-of-work search of p3's grinding challenger (GrindingChallenger::grind; the verifier side is check_witness,
  * ceno_recursion_v2/src/pcs/mod.rs:8125-8155): the least w for which a CLONE of the Poseidon2 duplex challenger (width 8, rate 4)
  * that observes w samples a base element whose low `bits` bits are zero.  state16 = the challenger state as exported by

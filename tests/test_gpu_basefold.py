@@ -291,3 +291,72 @@ def test_host_finished_tree_tops_change_nothing(dev, levels):
         pcs.free()
     dev.stream_destroy(stream)
     assert got == " | ".join(want)
+
+
+def _fold(t, r):
+    return [po.e2_add(t[2 * j], po.e2_mul(r, po.e2_sub(t[2 * j + 1], t[2 * j]))) for j in range(len(t) // 2)]
+
+
+@pytest.mark.parametrize("nvs", [[11, 9, 11, 6, 3, 1, 0, 9], [4], [1, 0, 1], [14, 14, 12, 13]])
+def test_open_rounds_all_matrices_in_one_launch(dev, nvs):
+    """ceno_hip_open_rounds_*: the opening's degree-2 sumcheck over matrices of mixed heights (suffix alignment: a matrix of v variables joins in
+    round n - v), one launch per round — every message and the final evaluations against a pure-python restatement of the rounds
+    (ceno_recursion_v2/src/pcs/mod.rs:1111-1316): fold the live tables with the previous challenge, p(1) = sum eq(1) f(1), p(2) = sum eq(2) f(2)."""
+    from ceno_amd import api
+
+    stream = dev.stream_create()
+    n = max(nvs)
+    eq = [po.rand_ext(1 << nv, 500 + i) for i, nv in enumerate(nvs)]
+    f = [po.rand_ext(1 << nv, 900 + i) for i, nv in enumerate(nvs)]
+    d_eq, d_f = [dev.upload(t) for t in eq], [dev.upload(t) for t in f]
+    h = api.OpenRounds(dev, d_eq, d_f, nvs, stream)
+    cur = [([(int(a), int(b)) for a, b in e], [(int(a), int(b)) for a, b in t]) for e, t in zip(eq, f)]
+    ch = None
+    for r in range(n):
+        p1, p2 = (0, 0), (0, 0)
+        for m, nv in enumerate(nvs):
+            if nv == 0 or nv < n - r:
+                continue  # not live yet (or never: a single entry has no variable)
+            if nv > n - r:  # was live in the round before: bind that round's variable
+                cur[m] = (_fold(cur[m][0], ch), _fold(cur[m][1], ch))
+            e, t = cur[m]
+            assert len(e) == 1 << (n - r)
+            for j in range(len(e) // 2):
+                p1 = po.e2_add(p1, po.e2_mul(e[2 * j + 1], t[2 * j + 1]))
+                e2 = po.e2_sub(po.e2_add(e[2 * j + 1], e[2 * j + 1]), e[2 * j])
+                t2 = po.e2_sub(po.e2_add(t[2 * j + 1], t[2 * j + 1]), t[2 * j])
+                p2 = po.e2_add(p2, po.e2_mul(e2, t2))
+        got = h.round(ch)
+        assert (int(got[0, 0]), int(got[0, 1])) == p1 and (int(got[1, 0]), int(got[1, 1])) == p2, f"round {r}"
+        c = po.rand_ext(1, 7000 + r)[0]
+        ch = (int(c[0]) % P, int(c[1]) % P)
+    fin = h.finish(ch if n else None)
+    for m, nv in enumerate(nvs):
+        want = _fold(cur[m][1], ch)[0] if nv >= 1 else cur[m][1][0]
+        assert (int(fin[m, 0]), int(fin[m, 1])) == want, f"final evaluation of matrix {m}"
+    # the inputs are left as they were
+    for m in range(len(nvs)):
+        assert np.array_equal(d_eq[m].download(stream), eq[m]) and np.array_equal(d_f[m].download(stream), f[m])
+    with pytest.raises(Exception):
+        h.round(ch)  # all rounds are done
+    h.free()
+    dev.stream_destroy(stream)
+
+
+def test_one_launch_per_round_writes_the_proof_of_the_handles_per_height_group(dev, monkeypatch):
+    """CENO_BASEFOLD_OPEN_ROUNDS=0 (one generic sumcheck handle per height group, the path before round 6) and the default (all matrices in one
+    launch per round): the same proof, which is the oracle's"""
+    from ceno_amd import prover
+
+    shapes = [(10, 3), (4, 5), (10, 1), (1, 2), (3, 7), (9, 2), (7, 1)]
+    stream = dev.stream_create()
+    traces, points, evals = make_case(11, shapes)
+    pcs = prover.PcsData(dev, traces, 1, stream)
+    proof = pcs.basefold_open(points, evals, 8, 3, prover.Transcript.stub(0xBF))
+    monkeypatch.setenv("CENO_BASEFOLD_OPEN_ROUNDS", "0")
+    proof_handles = pcs.basefold_open(points, evals, 8, 3, prover.Transcript.stub(0xBF))
+    monkeypatch.delenv("CENO_BASEFOLD_OPEN_ROUNDS")
+    assert np.array_equal(proof, proof_handles)
+    assert np.array_equal(proof, po.basefold_open(traces, points, evals, 1, 8, 3, po.StubTranscript(0xBF)))
+    pcs.free()
+    dev.stream_destroy(stream)
