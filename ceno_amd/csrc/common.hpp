@@ -144,6 +144,22 @@ struct HostTimed {
         s->n.fetch_add(1, std::memory_order_relaxed);
     }
 };
+// a region that is not a scope: t0 = host_time_mark() in front of it, host_time_add(slot, t0) behind it (returns the new mark)
+inline timespec host_time_mark() {
+    timespec t{};
+    if (host_timing_on()) clock_gettime(CLOCK_MONOTONIC, &t);
+    return t;
+}
+inline timespec host_time_add(HostTimeSlot* s, const timespec& t0) {
+    timespec t1{};
+    if (!host_timing_on()) return t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (s->seen.fetch_add(1, std::memory_order_relaxed) >= host_timing_skip()) {
+        s->ns.fetch_add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
+        s->n.fetch_add(1, std::memory_order_relaxed);
+    }
+    return t1;
+}
 #define CENO_TIMED_CAT2(a, b) a##b
 #define CENO_TIMED_CAT(a, b) CENO_TIMED_CAT2(a, b)
 #define CENO_TIMED(label)                                                                  \

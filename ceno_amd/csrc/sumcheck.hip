@@ -1398,6 +1398,10 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         ScClass& cl = sc->classes[ci];
         if (cl.dense || cl.nv < gen_class_min_log()) continue;
         const int km = (int)cl.mles.size();
+        static HostTimeSlot* const hs_comp = host_time_slot("sc_build_gen: components of the classes");
+        static HostTimeSlot* const hs_split = host_time_slot("sc_build_gen: column blocks of the classes");
+        static HostTimeSlot* const hs_rec = host_time_slot("sc_build_gen: component records of the classes");
+        timespec ht = host_time_mark();
         // ---- connected components over class-local MLE ids (a group ties its common factors and its terms' factors) ----
         std::vector<int> uf(km);
         std::iota(uf.begin(), uf.end(), 0);
@@ -1438,22 +1442,26 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         }
         // the terms of every component, group by group (a common-factor group lies in one component entirely; the ungrouped terms of the
         // class are spread over theirs), then the column blocks of the wide ones
-        for (auto& C : mine) {
-            std::vector<char> in_c(km, 0);
-            for (int m : C.mles) in_c[(size_t)m] = 1;
-            C.gts.assign((size_t)ng, {});
+        // (one pass over the terms: a batch of ~50 chips is ~50 components per class, and a pass per component made this quadratic)
+        {
+            std::vector<int> comp_of((size_t)km, -1);
+            for (size_t c = 0; c < mine.size(); c++) {
+                for (int m : mine[c].mles) comp_of[(size_t)m] = (int)c;
+                mine[c].gts.assign((size_t)ng, {});
+            }
             for (int g = 0; g < ng; g++) {
                 const bool free_group = cl.h_co[g + 1] == cl.h_co[g];
                 for (uint32_t ti = cl.h_gto[g]; ti < cl.h_gto[g + 1]; ti++) {
                     const uint32_t t = cl.h_gt[ti];
                     const uint32_t probe = cl.h_to[t + 1] > cl.h_to[t] ? cl.h_ti[cl.h_to[t]] : (free_group ? UINT32_MAX : cl.h_ci[cl.h_co[g]]);
-                    if (probe != UINT32_MAX && in_c[probe]) C.gts[(size_t)g].push_back(t);
+                    if (probe != UINT32_MAX && comp_of[probe] >= 0) mine[(size_t)comp_of[probe]].gts[(size_t)g].push_back(t);
                 }
             }
         }
         // (CENO_HIP_GEN_SPLIT_MIN_LOG: smallest class that gets column blocks.  Measured: blocks for every class are best — the wide batch 60.2 ms
         // against 69.9 with blocks from 2^18 rows up and 96.8 without; the latency-bound batch of the 2^20-cycle shard does not care, 2.03-2.19 ms)
         static const int split_min_log = getenv("CENO_HIP_GEN_SPLIT_MIN_LOG") ? atoi(getenv("CENO_HIP_GEN_SPLIT_MIN_LOG")) : 0;
+        ht = host_time_add(hs_comp, ht);
         if (cl.nv >= split_min_log && gen_split_cap(ctx, sc->d, sc->d) > 0) {
             const bool by_degree = geq_wanted && sc->d >= 3 && gen_by_degree_mode() >= 1;
             int caps[MAXD + 1] = {};
@@ -1474,6 +1482,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
         for (int m = 0; m < km; m++)
             if (!used[m]) fold_only.mles.push_back(m);
         // ---- per component: units, terms, groups in both layouts ----
+        ht = host_time_add(hs_split, ht);
         std::vector<GeqComp> geq_new;  // eq-factored components of this class (committed with the class)
         const int brows_before = sc->geq.n_brows;
         for (auto& C : mine) {
@@ -1545,8 +1554,8 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                     if ((int)T.nf > sc->d - 1) eq_ok = false;
                     for (uint32_t k = 0; k < T.nf && eq_ok; k++) {
                         const unsigned u = (unsigned)((T.idx8 >> (8 * k)) & 0xff);
-                        for (size_t m = 0; m < C.mles.size(); m++)
-                            if (unit[0][m] == u && sc->geq.decl[cl.mles[C.mles[m]]].on) eq_ok = false;
+                        const size_t m = u / 2;  // layout 0 gives table m the unit 2m (a walk over the component's tables per factor was its largest loop)
+                        if (m < C.mles.size() && unit[0][m] == u && sc->geq.decl[cl.mles[C.mles[m]]].on) eq_ok = false;
                     }
                 }
                 if (eq_ok && first) {
@@ -1600,6 +1609,7 @@ static int sc_build_gen(ceno_hip_sumcheck* sc) {
                 C.off_unit[lay] = append(unit[lay].data(), unit[lay].size() * sizeof(uint16_t));
             }
         }
+        (void)host_time_add(hs_rec, ht);
         if (!ok) {
             sc->geq.n_brows = brows_before;
             continue;

@@ -200,6 +200,7 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
 
     // everything allocated here is released by `cleanup`
     std::vector<ceno_hip_mle*> owned;
+    std::vector<std::pair<ceno_hip_mle*, ceno_hip_stream>> owned_on;  // tables made (and used) on a tree stream
     std::vector<ceno_hip_merkle*> trees;
     std::map<int, Group> groups;  // key: nv
     void* d_scratch = nullptr;
@@ -212,6 +213,15 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
             if (sx[i]) (void)hipStreamSynchronize((hipStream_t)sx[i]);
             if (ev[i]) (void)hipEventDestroy(ev[i]);
         }
+        // the running codewords go back to the pool from the stream they were made on: a block freed under another stream's tag is out of reach
+        // of that stream's next request while the tag's stream has work queued — every opening then took its ~16 small codewords from the driver
+        // (hipMalloc, ~8 us each) and left the last opening's in the cache for good (CENO_HIP_POOL_TRACE)
+        for (auto& po : owned_on) {
+            (void)ceno_hip_stream_bind(ctx, po.second);
+            ceno_hip_mle_free(ctx, po.first);
+        }
+        owned_on.clear();
+        (void)ceno_hip_stream_bind(ctx, s);
         if (sx[0]) tree_streams_release(TreeStreams{{(hipStream_t)sx[0], (hipStream_t)sx[1]}, ts_device});
         sx[0] = sx[1] = nullptr;
         for (auto& g : groups)
@@ -491,7 +501,8 @@ int basefold_open_hooked(ceno_hip_ctx* ctx, ceno_pcs_data* const* commits, int n
         // fold with c_r (the codeword of the next height joins) and start the NEXT round's tree right away
         ceno_hip_stream fs = sx[(r + 1) & 1];  // C[r] was produced on sx[r & 1] (event ev[r & 1]); C[0] by the batching on `s` (synchronised)
         (void)ceno_hip_stream_bind(ctx, fs);  // C[r + 1] is produced and consumed on `fs`
-        int rc = alloc_ext(h - 1, &C[r + 1]);
+        int rc = ceno_hip_mle_alloc(ctx, h - 1, 1, &C[r + 1]);
+        if (!rc) owned_on.push_back({C[r + 1], fs});
         if (!rc && r > 0 && hipStreamWaitEvent((hipStream_t)fs, ev[r & 1], 0) != hipSuccess) rc = CENO_HIP_ERR_HIP;
         if (!rc) rc = ceno_hip_basefold_fold(ctx, ceno_hip_mle_device_ptr(C[r]), h, &ch[2 * r], B[h - 1] ? ceno_hip_mle_device_ptr(B[h - 1]) : nullptr,
                                              ceno_hip_mle_device_ptr(C[r + 1]), fs);
