@@ -195,6 +195,7 @@ def lib():
         "ceno_hip_pow_grind_duplex": (i, [vp, u64p, i, u64p, vp]),
         "ceno_hip_lane_stream": (i, [vp, i, vpp]),
         "ceno_hip_debug_state": (i, [vp, C.POINTER(i), C.POINTER(i)]),
+        "ceno_hip_host_timing_dump": (None, [C.c_char_p]),
         "ceno_hip_mmcs_commit": (i, [vp, C.POINTER(vp), C.POINTER(i), C.POINTER(i), i, vp, vpp]),
         "ceno_hip_mmcs_commit_over": (i, [vp, vp, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), i, vp, vpp]),
         "ceno_hip_mmcs_opening_words": (sz, [vp]),

@@ -123,7 +123,13 @@ int ctx_fail(ceno_hip_ctx* ctx, int code, const char* fmt, ...);
 // printed by ceno_hip_destroy (tools/dev/lanes_sc.cpp: what concurrent lanes contend for).  Off: one predictable branch per scope.
 struct HostTimeSlot {
     const char* label = nullptr;
-    std::atomic<unsigned long long> ns{0}, n{0}, seen{0};
+    std::atomic<unsigned long long> ns{0}, n{0}, seen{0}, max_ns{0};
+    void add(unsigned long long d) {
+        ns.fetch_add(d, std::memory_order_relaxed);
+        n.fetch_add(1, std::memory_order_relaxed);
+        unsigned long long m = max_ns.load(std::memory_order_relaxed);
+        while (d > m && !max_ns.compare_exchange_weak(m, d, std::memory_order_relaxed)) {}
+    }
 };
 unsigned long long host_timing_skip();  // CENO_HIP_HOST_TIMING_SKIP=k: the first k calls of every scope are warm-up and not counted
 HostTimeSlot* host_time_slot(const char* label);
@@ -140,8 +146,7 @@ struct HostTimed {
         timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if (s->seen.fetch_add(1, std::memory_order_relaxed) < host_timing_skip()) return;
-        s->ns.fetch_add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
-        s->n.fetch_add(1, std::memory_order_relaxed);
+        s->add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)));
     }
 };
 // a region that is not a scope: t0 = host_time_mark() in front of it, host_time_add(slot, t0) behind it (returns the new mark)
@@ -155,8 +160,7 @@ inline timespec host_time_add(HostTimeSlot* s, const timespec& t0) {
     if (!host_timing_on()) return t1;
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (s->seen.fetch_add(1, std::memory_order_relaxed) >= host_timing_skip()) {
-        s->ns.fetch_add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)), std::memory_order_relaxed);
-        s->n.fetch_add(1, std::memory_order_relaxed);
+        s->add((unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec)));
     }
     return t1;
 }

@@ -40,13 +40,18 @@ HostTimeSlot* host_time_slot(const char* label) {
     s->label = label;
     return s;
 }
+extern "C" void ceno_hip_host_timing_dump(const char* what) {
+    if (!host_timing_on()) return;
+    if (what) fprintf(stderr, "[ceno_hip] host timing: ---- %s\n", what);
+    host_timing_dump();
+}
 void host_timing_dump() {
     if (!host_timing_on()) return;
     const int n = std::min(g_host_time_n.load(), 128);
     for (int k = 0; k < n; k++) {
         HostTimeSlot& s = g_host_time_slots[k];
-        const unsigned long long c = s.n.exchange(0), ns = s.ns.exchange(0);
-        if (c) fprintf(stderr, "[ceno_hip] host timing: %-34s %8llu calls  %10.1f us total  %8.2f us each\n", s.label, c, ns / 1e3, ns / 1e3 / c);
+        const unsigned long long c = s.n.exchange(0), ns = s.ns.exchange(0), mx = s.max_ns.exchange(0);
+        if (c) fprintf(stderr, "[ceno_hip] host timing: %-34s %8llu calls  %10.1f us total  %8.2f us each  %9.1f us the longest\n", s.label, c, ns / 1e3, ns / 1e3 / c, mx / 1e3);
     }
 }
 

@@ -857,7 +857,13 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     // -> one common-factor group (eq) over all residual terms  (scheme/cpu/mod.rs:417-494)
     ceno_hip_mle* eq = nullptr;
     void* eq_tmp = nullptr;  // scratch of the eq build; lives (like eq) until the sumcheck handle is freed
+    static HostTimeSlot* const hs_eq = host_time_slot("tower_layer_sumcheck_begin: eq table allocation");
+    static HostTimeSlot* const hs_views = host_time_slot("tower_layer_sumcheck_begin: views + terms");
+    static HostTimeSlot* const hs_build = host_time_slot("tower_layer_sumcheck_begin: sumcheck handle");
+    static HostTimeSlot* const hs_launch = host_time_slot("tower_layer_sumcheck_begin: eq build + set-up launch");
+    timespec ht = host_time_mark();
     TRY(ceno_hip_mle_alloc(ctx, layer, 1, &eq));
+    ht = host_time_add(hs_eq, ht);
     // The eq table is built AFTER the handle below exists: a small table's kernel then also does the handle's set-up work
     // (launch_eq_build_with_setup), one dependent launch instead of two in front of every layer.  CENO_HIP_TOWER_EQ_SETUP=0 keeps them apart.
     std::vector<ceno_hip_mle*> mles{eq};
@@ -913,6 +919,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
         ceno_hip_mle_free(ctx, eq);
         return rc;
     }
+    ht = host_time_add(hs_views, ht);
     std::vector<uint32_t> goff{0, (uint32_t)gterms.size()}, coff{0, 1}, cidx{0};
     ceno_hip_sumcheck_plan plan{};
     plan.num_mles = (int)mles.size();
@@ -932,6 +939,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
     hipStream_t st = ctx_stream(ctx, s);
     rc = fuse ? sumcheck_begin_deferred(ctx, mles.data(), &plan, st, out, &job) : ceno_hip_sumcheck_begin(ctx, mles.data(), &plan, s, out);
     cleanup();  // views are borrowed wrappers; the sumcheck copied the pointers
+    ht = host_time_add(hs_build, ht);
     if (!rc) {
         int fused = 1;
         if (job.dst) fused = launch_eq_build_with_setup(ctx, out_rt, layer, gl::e2_one(), eq->d, st, job);
@@ -951,6 +959,7 @@ extern "C" int ceno_hip_tower_layer_sumcheck_begin(ceno_hip_ctx* ctx, ceno_hip_t
         ceno_hip_mle_free(ctx, eq);
         return rc;
     }
+    ht = host_time_add(hs_launch, ht);
     const bool fast = !(getenv("CENO_HIP_TOWER_FAST") && atoi(getenv("CENO_HIP_TOWER_FAST")) == 0);  // A/B switch (read per call: tests toggle it)
     if (fast) sumcheck_enable_tower_fast(*out, out_rt, n_prod_live, n_logup_live);
     sumcheck_adopt_mle(*out, eq);      // eq lives as long as the sumcheck

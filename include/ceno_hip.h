@@ -94,6 +94,10 @@ int ceno_hip_mem_info(ceno_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes
 /* bookkeeping that must return to zero when no sumcheck handle is alive (tests): live pipelined sumchecks (the pool's soft-cap
  * trim waits for zero) and the residency budget booked by persistent mid-round kernels (units of 1/64 compute unit) */
 int ceno_hip_debug_state(ceno_hip_ctx* ctx, int* pipelined_live, int* mid_units_in_flight);
+/* CENO_HIP_HOST_TIMING=1: print where the library's HOST threads spent their time since the last dump (calls, total, mean and longest per labelled
+ * scope; process-wide) to stderr and start counting afresh — ceno_hip_destroy does the same.  Nothing without the switch.  `what` (may be NULL)
+ * heads the lines.  A measurement aid: call it between the repetitions of a benchmark to see the steady state apart from the first run. */
+void ceno_hip_host_timing_dump(const char* what);
 /* release cached blocks (trim_mem_pool, e2e.rs:3331-3334); waits for the device; a no-op while pipelined sumchecks are alive on any lane */
 int ceno_hip_mem_trim(ceno_hip_ctx* ctx);
 /* high-water mark of the bytes handed out by the pool since the last reset (reset != 0: restart the mark at the current usage).  What a

@@ -20,6 +20,7 @@ def main():
         best = None
         for _ in range(int(os.environ.get("REPS", "3"))):
             r = flow.run(new_tr, fork, lanes=lanes)
+            dev.L.ceno_hip_host_timing_dump(b"one run of the wide shard")  # (prints only under CENO_HIP_HOST_TIMING=1)
             if best is None or r["total_ms"] < best["total_ms"]:
                 best = r
         flow.free_last()
