@@ -251,7 +251,10 @@ extern "C" int ceno_prover_create_chip_proofs(ceno_hip_ctx* ctx, const ceno_chip
     const int last_layer = cohort_last_layer(), host_layers = prover_tower_host_layers();
     size_t total = 0;
     for (int i = 0; i < n_tasks; i++) total += ceno_prover_chip_proof_estimate_bytes(&tasks[i]);
-    const bool cohort = last_layer > host_layers && n_tasks >= 8 && ceno_hip_tower_cohort_capacity(ctx) >= 8 && ceno_hip_mem_book(ctx, total + ((size_t)1 << 30)) == 0;
+    // (CENO_TOWER_COHORT_MIN_TASKS: the fewest chips that go through cohorts — 8; a single chip measured in tools/dev/cohort_one_chip.py)
+    const char* e_min = getenv("CENO_TOWER_COHORT_MIN_TASKS");
+    const int min_tasks = e_min && atoi(e_min) > 0 ? atoi(e_min) : 8;
+    const bool cohort = last_layer > host_layers && n_tasks >= min_tasks && ceno_hip_tower_cohort_capacity(ctx) >= 8 && ceno_hip_mem_book(ctx, total + ((size_t)1 << 30)) == 0;
     if (!cohort) {
         std::vector<ChipJob> jobs(n_tasks);
         std::vector<ceno_lane_task> lt(n_tasks);
