@@ -965,6 +965,35 @@ def test_chip_proofs_fall_back_to_lanes_when_the_phase_cannot_be_booked(dev, pro
     d.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_chips", [1, 3])
+def test_fewer_chips_than_the_threshold_forced_through_cohorts_write_the_same_proofs(dev, prover, monkeypatch, n_chips):
+    """CENO_TOWER_COHORT_MIN_TASKS (default 8: a few chips have a lane each anyway, tools/dev/cohort_one_chip.py) = 1: one chip, and three, through
+    the cohort launches — a chip per serving thread, a launch of one or a few jobs, groups of sub-cubes of a single chip — write the words the
+    per-chip tower prover writes (which test_create_chip_proof_matches_oracle holds against the oracle)"""
+    from ceno_amd import synthetic
+
+    w = 22
+    alpha, beta = (5, 6), (7, 8)
+    coeffs, terms, out_terms = synthetic.record_plan(w, 16, alpha, beta)
+    logs = (13, 9, 11)[:n_chips]
+    cols = [[dev.synthetic(r, False, 0x900 + 41 * i + j) for j in range(w)] for i, r in enumerate(logs)]
+    tasks = prover.ChipTasks([dict(circuit_idx=i, mles=cols[i], n_witin=w, n_fixed=0, n_structural=0, num_instances=(1 << r) - 3, log2_num_instances=r,
+                                   num_reads=4, num_writes=4, num_lk_tables=0, num_lk=8, record_coeffs=coeffs, record_terms=terms,
+                                   record_out_terms=out_terms) for i, r in enumerate(logs)])
+    forks = [prover.Transcript.stub(0xF0 + i) for i in range(n_chips)]
+    want = _proofs_words(prover.create_chip_proofs(dev, tasks, [alpha, beta], forks, 2), forks)
+    monkeypatch.setenv("CENO_TOWER_COHORT_MIN_TASKS", "1")
+    for last in ("19", "9"):
+        monkeypatch.setenv("CENO_TOWER_COHORT_LAYERS", last)
+        forks = [prover.Transcript.stub(0xF0 + i) for i in range(n_chips)]
+        got = _proofs_words(prover.create_chip_proofs(dev, tasks, [alpha, beta], forks, 2), forks)
+        assert got == want, f"cohort layers to {last}"
+    for c in cols:
+        for m in c:
+            m.free()
+
+
 def _stub_absorb(t, word):
     """one absorb step of the SplitMix stub transcript (oracle/oracle.c orc_stub_*; host/transcript.cpp Stub::absorb)"""
     M = (1 << 64) - 1
